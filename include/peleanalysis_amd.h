@@ -1,0 +1,179 @@
+/*
+ * peleanalysis_amd.h -- C ABI of the MI355X-native PeleAnalysis stencil path.
+ *
+ * The reference (AMReX-Combustion/PeleAnalysis) has no plugin/FFI interface:
+ * its boundary is (i) each tool's key=value command line + plotfile formats and
+ * (ii) the per-FArrayBox call shape inside the MFIter loops of the tool mains.
+ * This header is the C ABI at (ii); tools/ keeps (i).  Every entry point cites
+ * the reference call site it replaces.  Plain pointers and sizes only; all
+ * `double*` named dev* / stored in pa_mf are DEVICE pointers (HBM).
+ *
+ * Conventions: return 0 = OK, non-zero = error (text via pa_last_error); the
+ * library never aborts.  All work is enqueued on the pa_ctx's HIP stream and is
+ * asynchronous unless stated; pa_sync() waits.  A pa_ctx is not thread-safe;
+ * use one per host thread (the reference's per-FAB loops are serial per rank).
+ *
+ * Array layout: AMReX FArrayBox layout -- [comp][k][j][i], i fastest, over the
+ * valid box grown by ng ghost cells.  Boxes are inclusive cell-index boxes
+ * {lo0,lo1,lo2,hi0,hi1,hi2}.
+ */
+#ifndef PELEANALYSIS_AMD_H
+#define PELEANALYSIS_AMD_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pa_ctx pa_ctx;     /* device, stream, error text, scratch */
+typedef struct pa_level pa_level; /* BoxArray + Geometry of one AMR level (host + device copies) */
+typedef struct pa_mf pa_mf;       /* MultiFab: ncomp x (boxes grown by ng) doubles in HBM */
+
+/* mirrors amrex::Array4 / FArrayBox: p = device pointer, lo/hi incl. ghosts */
+typedef struct { double* p; int32_t lo[3]; int32_t hi[3]; int32_t ncomp; } pa_fab;
+typedef struct { int32_t lo[3]; int32_t hi[3]; } pa_box;
+
+/* LinOpBCType subset used by grad.cpp:180-193 / curvature.cpp:428-441 */
+enum { PA_BC_PERIODIC = 0, PA_BC_NEUMANN = 1, PA_BC_REFLECT_ODD = 2 };
+
+/* ------------------------------------------------------------------ context */
+int         pa_version(void);
+pa_ctx*     pa_ctx_create(int device, void* hip_stream /* NULL: library-owned stream */);
+void        pa_ctx_destroy(pa_ctx*);
+const char* pa_last_error(const pa_ctx*);
+int         pa_sync(pa_ctx*);
+void*       pa_ctx_stream(pa_ctx*);
+
+/* ---------------------------------------------------- level = BoxArray+Geometry
+ * replaces: amrData.boxArray(lev) / Geometry(ProbDomain, rb, coord, is_per)
+ * (grad.cpp:160-163, curvature.cpp:287-291).  dx = (prob_hi-prob_lo)/ncells. */
+pa_level* pa_level_create(pa_ctx*, int nboxes, const int32_t* boxes6, const int32_t domlo[3],
+                          const int32_t domhi[3], const int32_t is_per[3], const double prob_lo[3],
+                          const double prob_hi[3]);
+void      pa_level_destroy(pa_level*);
+int       pa_level_nboxes(const pa_level*);
+
+/* -------------------------------------------------------------- MultiFab
+ * pa_mf_layout is pure host arithmetic (no GPU): offsets (in doubles) of each
+ * box in the flat buffer, returns the total size in doubles.
+ * replaces: MultiFab(ba, dm, ncomp, ngrow) (grad.cpp:164, curvature.cpp:294). */
+int64_t pa_mf_layout(int nboxes, const int32_t* boxes6, int ncomp, int ng, int64_t* off);
+pa_mf*  pa_mf_create(pa_ctx*, const pa_level*, int ncomp, int ng, double* devptr /* NULL: library allocates */);
+void    pa_mf_destroy(pa_mf*);
+double* pa_mf_data(pa_mf*);
+int64_t pa_mf_size(const pa_mf*);
+int     pa_mf_upload(pa_ctx*, pa_mf*, const double* host);  /* synchronous */
+int     pa_mf_download(pa_ctx*, const pa_mf*, double* host); /* synchronous */
+int     pa_mf_setval(pa_ctx*, pa_mf*, int comp, int ncomp, double v); /* whole fabs incl. ghosts */
+/* MultiFab::Copy(dst, src, scomp, dcomp, ncomp, ng) -- same BoxArray */
+int     pa_mf_copy(pa_ctx*, const pa_mf* src, int scomp, pa_mf* dst, int dcomp, int ncomp, int ng);
+
+/* ------------------------------------------------------------ ghost cells
+ * FabArray::FillBoundary(comp, ncomp, periodicity): grad.cpp:169,
+ * curvature.cpp:322,484,488,502; isosurface.cpp:1468. */
+int pa_fill_boundary(pa_ctx*, pa_mf*, int comp, int ncomp, int ng);
+/* MLCellLinOp::applyBC on the ring-1 face ghosts (inside MLMG::getFluxes,
+ * grad.cpp:212-213, curvature.cpp:445-457,518-531): covered cells untouched,
+ * physical walls Neumann / reflect_odd, coarse-fine cells = InterpBndryData
+ * (order 3, tangential) + cubic in the normal direction (setMaxOrder(4)).
+ * crse may be NULL on level 0.  only_dir = -1 for all three directions. */
+int pa_apply_bc(pa_ctx*, pa_mf* fine, int comp, const pa_mf* crse, int ccomp, const int32_t bc[3],
+                int ratio, int only_dir);
+/* coarse-fine ghost cells (since the last call) whose coarse data was missing: improper
+ * nesting.  Synchronous; resets the counter.  0 = all ghost fills were well defined. */
+int pa_bc_errors(pa_ctx*);
+
+/* --------------------------------------------------- level-batched kernels
+ * One launch covers every box of the level (many small FABs per launch). */
+/* grad.cpp:211-236: gx,gy,gz,|g| of phi[comp] into out[ocomp..ocomp+3] */
+int pa_grad_level(pa_ctx*, const pa_mf* phi, int comp, pa_mf* out, int ocomp);
+/* curvature.cpp:139-149 (AmrData::MinMax of one level; valid cells) */
+int pa_minmax_level(pa_ctx*, const pa_mf* s, int comp, double* mn, double* mx); /* synchronous */
+/* curvature.cpp:310-321: c = (s - pmin) * (1/(pmax-pmin)), ng ghost layers too */
+int pa_progress_level(pa_ctx*, const pa_mf* s, int comp, double pmin, double pmax, pa_mf* c, int ccomp, int ng);
+/* curvature.cpp:451-502: G = grad c, normgrad = -max(1e-14,|G|), n = G/normgrad
+ * (valid cells).  G, normgrad may be NULL (not stored). */
+int pa_normal_level(pa_ctx*, const pa_mf* c, int comp, pa_mf* G, int gcomp, pa_mf* normgrad, int ngcomp,
+                    pa_mf* n, int ncomp0);
+/* curvature.cpp:508-546: K = scale * sum_d d n_d/dx_d  (n: 3 comps with
+ * resolved face ghosts), + threshold clip :549-567 if thr >= 0 (c needed) */
+int pa_div_level(pa_ctx*, pa_mf* n, int ncomp0, double scale, const pa_mf* c, int ccomp, double thr,
+                 pa_mf* K, int kcomp);
+/* fused grad->curvature (headline kernel).  phi (ng>=1, resolved face ghosts)
+ * -> out[ocomp..+3] = gx,gy,gz,|g| ; c (ng>=2: FillBoundary(2) + resolved
+ * face ghosts) -> out[ocomp+4..+6] = FlameNormal, out[ocomp+7] = MeanCurvature.
+ * Cells next to a coarse-fine or physical face get their curvature from
+ * pa_gradcurv_faces_level (the ghost normals there come from applyBC on n). */
+int pa_gradcurv_level(pa_ctx*, const pa_mf* phi, int pcomp, const pa_mf* c, int ccomp, double thr,
+                      pa_mf* out, int ocomp);
+int pa_gradcurv_faces_level(pa_ctx*, const pa_mf* c, int ccomp, const pa_mf* crse_n /* NULL on level 0 */,
+                            int cncomp0, const int32_t bc[3], int ratio, double thr, pa_mf* out, int kcomp);
+
+/* -------------------------------------------------------- per-FAB entry points
+ * (the body of one MFIter iteration; device pointers in pa_fab) */
+/* grad.cpp:211-236 for one FAB; phi has >=1 resolved ghost layer */
+int pa_grad_fab(pa_ctx*, pa_box valid, const pa_fab* phi, int comp, const double dxinv[3], pa_fab* out, int ocomp);
+/* curvature.cpp:316-320 */
+int pa_progress_fab(pa_ctx*, pa_box bx, const pa_fab* s, int comp, double pmin, double pmax, pa_fab* c, int ccomp);
+/* curvature.cpp:451-502 */
+int pa_normal_fab(pa_ctx*, pa_box valid, const pa_fab* c, int comp, const double dxinv[3], pa_fab* G, int gcomp,
+                  pa_fab* normgrad, int ngcomp, pa_fab* n, int ncomp0);
+/* curvature.cpp:508-546 */
+int pa_div_fab(pa_ctx*, pa_box valid, const pa_fab* n, int ncomp0, const double dxinv[3], double scale,
+               pa_fab* K, int kcomp);
+/* fused interior variant for one FAB (c with 2 ghost layers, all same-level) */
+int pa_gradcurv_fab(pa_ctx*, pa_box valid, const pa_fab* phi, int pcomp, const pa_fab* c, int ccomp,
+                    const double dxinv[3], double thr, pa_fab* out, int ocomp);
+/* filterPlt.cpp:217 Filter::apply_filter(box, in, out) */
+int pa_boxfilter_fab(pa_ctx*, pa_box valid, const pa_fab* in, pa_fab* out, int scomp, int ncomp, int ng,
+                     const double* w /* host, 2ng+1 */);
+
+/* ----------------------------------------------------------------- filterPlt
+ * Filter(type=box, fgr) weights (filterPlt.cpp:136-137); returns ngrow */
+int pa_box_filter_weights(int fgr, double* w);
+/* filterPlt.cpp:206-219, all boxes of a level */
+int pa_boxfilter_level(pa_ctx*, const pa_mf* in, pa_mf* out, int scomp, int ncomp, int ng, const double* w);
+/* filterPlt.cpp:174-203 ghost fill pieces */
+int pa_foextrap(pa_ctx*, pa_mf*, int comp, int ncomp, int ng);
+int pa_fillpatch_two_levels(pa_ctx*, pa_mf* fine, const pa_mf* crse, int comp, int ncomp, int ng, int ratio,
+                            int interp_type);
+
+/* ---------------------------------------------------------------- isosurface
+ * isosurface.cpp:1531-1592 for one FAB: state = 3 coordinate comps + fields,
+ * mask (<0 = covered by a finer level), loop = box of cube base points.
+ * pa_mc_count_fab classifies and counts (wave ballot + popcount); pa_mc_emit_fab
+ * writes vertices in the reference's vertCache (std::map<Edge>) order and
+ * triangles in cube traversal order; both deterministic.  Synchronous. */
+int pa_mc_count_fab(pa_ctx*, pa_box loop, const pa_fab* state, const pa_fab* mask, int isocomp, double isoval,
+                    int64_t* nvert, int64_t* ntri);
+int pa_mc_emit_fab(pa_ctx*, pa_box loop, const pa_fab* state, const pa_fab* mask, int isocomp, double isoval,
+                   double* dev_verts /* [nvert][ncomp] */, int32_t* dev_vkeys /* [nvert][6] */,
+                   int32_t* dev_tris /* [ntri][3] */, int64_t nvert, int64_t ntri);
+const uint16_t* pa_mc_edge_table(void); /* [256] host */
+const int8_t*   pa_mc_tri_table(void);  /* [256][16] host */
+
+/* ------------------------------------------------------------ tool pipelines
+ * The level loops of the tool mains, operating on device-resident MultiFabs.
+ * levels/state/out are arrays of nlev pointers, coarse first. */
+/* grad.cpp:158-236.  state[lev]: comp = gradVar, ng >= 1.  out[lev][ocomp..+3]. */
+int pa_grad_run(pa_ctx*, int nlev, pa_mf* const* state, int comp, const int32_t bc[3], pa_mf* const* out, int ocomp);
+
+typedef struct {
+  double  prog_min, prog_max; /* if prog_min > prog_max: use file min/max over the levels */
+  int32_t do_threshold;       /* threshold_prog */
+  double  threshold;          /* threshold_value */
+  int32_t fused;              /* 1: fused grad->curvature kernels, 0: pass-by-pass */
+} pa_curv_params;
+/* curvature.cpp:283-326 + 408-570 (core).  state[lev][comp] = progress source (ng>=2).
+ * out[lev] comps: ocomp+0 Progress, +1 MeanCurvature, +2..4 FlameNormal. */
+int pa_curvature_run(pa_ctx*, int nlev, pa_mf* const* state, int comp, const int32_t bc[3],
+                     const pa_curv_params*, pa_mf* const* out, int ocomp);
+/* fused grad+curvature of one variable: out[lev] comps ocomp+0..3 = gx,gy,gz,|g|,
+ * +4..6 FlameNormal, +7 MeanCurvature.  work[lev]: scratch mf, 1 comp, ng=2. */
+int pa_gradcurv_run(pa_ctx*, int nlev, pa_mf* const* state, int comp, const int32_t bc[3],
+                    const pa_curv_params*, pa_mf* const* work, pa_mf* const* out, int ocomp);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

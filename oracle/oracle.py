@@ -1,0 +1,260 @@
+"""CPU ORACLE python wrapper -- test infrastructure, NOT product code.
+
+ctypes binding of oracle/_build/libpa_oracle*.so (plain-C restatement of the
+reference arithmetic, see pa_oracle.h; PARITY UNPINNED) plus the level loops of
+the tool mains restated in python on top of it:
+  grad_pipeline       grad.cpp:158-236
+  curvature_pipeline  curvature.cpp:283-326, 408-570 (+ options 575-789)
+  filter_pipeline     filterPlt.cpp:120-219
+  isosurface_pipeline isosurface.cpp:1434-1728, 1750-1890
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
+Works on duck-typed "level" objects (boxes, domlo, domhi, is_per, prob_lo, prob_hi)
+and "multifab" objects (level, ncomp, ng, data, off).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class _Level(C.Structure):
+    _fields_ = [("nboxes", C.c_int32), ("boxes", C.POINTER(C.c_int32)), ("domlo", C.c_int32 * 3), ("domhi", C.c_int32 * 3),
+                ("is_per", C.c_int32 * 3), ("prob_lo", C.c_double * 3), ("prob_hi", C.c_double * 3)]
+
+
+class _MF(C.Structure):
+    _fields_ = [("lev", C.POINTER(_Level)), ("ncomp", C.c_int32), ("ng", C.c_int32), ("data", C.POINTER(C.c_double)),
+                ("off", C.POINTER(C.c_int64))]
+
+
+def build(force: bool = False) -> None:
+    """Compile the oracle with gcc (also done by __graft_entry__.build())."""
+    if force or not os.path.exists(os.path.join(_HERE, "_build", "libpa_oracle.so")):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+
+
+_LIBS = {}
+
+
+def lib(omp: bool = False):
+    name = "libpa_oracle_omp.so" if omp else "libpa_oracle.so"
+    if name not in _LIBS:
+        path = os.path.join(_HERE, "_build", name)
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        L.orc_mc_edge_table.restype = C.POINTER(C.c_int32)
+        L.orc_mc_tri_table.restype = C.POINTER(C.c_int32)
+        _LIBS[name] = L
+    return _LIBS[name]
+
+
+def _lv(level):
+    s = _Level()
+    boxes = np.ascontiguousarray(level.boxes, dtype=np.int32)
+    s._keep = boxes
+    s.nboxes = boxes.shape[0]
+    s.boxes = boxes.ctypes.data_as(C.POINTER(C.c_int32))
+    for d in range(3):
+        s.domlo[d] = int(level.domlo[d]); s.domhi[d] = int(level.domhi[d]); s.is_per[d] = int(level.is_per[d])
+        s.prob_lo[d] = float(level.prob_lo[d]); s.prob_hi[d] = float(level.prob_hi[d])
+    return s
+
+
+def _mf(mf):
+    if mf is None:
+        return None
+    lv = _lv(mf.level)
+    s = _MF()
+    s._keep = (lv, mf.data, mf.off)
+    s.lev = C.pointer(lv)
+    s.ncomp = mf.ncomp; s.ng = mf.ng
+    s.data = mf.data.ctypes.data_as(C.POINTER(C.c_double))
+    s.off = np.ascontiguousarray(mf.off, dtype=np.int64).ctypes.data_as(C.POINTER(C.c_int64))
+    return s
+
+
+def _p(s):
+    return C.byref(s) if s is not None else None
+
+
+def _bc(bc):
+    return (C.c_int32 * 3)(*[int(b) for b in bc])
+
+
+BC_PERIODIC, BC_NEUMANN, BC_REFLECT_ODD = 0, 1, 2
+
+
+def bc_from_flags(is_per, sym_dir=(0, 0, 0)):
+    """grad.cpp:180-193 / curvature.cpp:428-441"""
+    return [BC_PERIODIC if p else (BC_REFLECT_ODD if s else BC_NEUMANN) for p, s in zip(is_per, sym_dir)]
+
+
+# ---------------------------------------------------------------- thin wrappers
+def fill_boundary(mf, comp, ncomp, ng, omp=False):
+    lib(omp).orc_fill_boundary(_p(_mf(mf)), comp, ncomp, ng)
+
+
+def apply_bc(fine, comp, crse, ccomp, bc, ratio=2, only_dir=-1, omp=False):
+    nbad = lib(omp).orc_apply_bc(_p(_mf(fine)), comp, _p(_mf(crse)), ccomp, _bc(bc), ratio, only_dir)
+    if nbad:
+        raise RuntimeError(f"orc_apply_bc: {nbad} coarse-fine ghost cells without coarse data")
+
+
+def grad_multipass(phi, comp, out, ocomp):
+    lib().orc_grad_multipass(_p(_mf(phi)), comp, _p(_mf(out)), ocomp)
+
+
+def grad_fused(phi, comp, out, ocomp, with_mag=True, omp=False):
+    lib(omp).orc_grad_fused(_p(_mf(phi)), comp, _p(_mf(out)), ocomp, int(with_mag))
+
+
+def minmax(s, comp):
+    a, b = C.c_double(), C.c_double()
+    lib().orc_minmax(_p(_mf(s)), comp, C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+def box_filter_weights(fgr):
+    w = (C.c_double * (fgr + 2))()
+    ng = lib().orc_box_filter_weights(int(fgr), w)
+    return ng, np.array(w[:2 * ng + 1])
+
+
+# ---------------------------------------------------------------- pipelines
+def grad_pipeline(levels, states, comp, bc, outs, ocomp, multipass=True, omp=False):
+    """grad.cpp:158-236.  states[l]: multifab with ng>=1; outs[l][ocomp..ocomp+3]."""
+    for l in range(len(levels)):
+        fill_boundary(states[l], comp, 1, 1, omp)
+    for l in range(len(levels)):
+        apply_bc(states[l], comp, states[l - 1] if l > 0 else None, comp, bc, omp=omp)
+        if multipass:
+            grad_multipass(states[l], comp, outs[l], ocomp)
+        else:
+            grad_fused(states[l], comp, outs[l], ocomp, True, omp)
+
+
+def curvature_pipeline(levels, states, comp, bc, outs, ocomp, MF, prog_min=None, prog_max=None, threshold=None,
+                       do_gauss=False, vel_comp=None, do_strain=False, do_velnormal=False, omp=False):
+    """curvature.cpp:283-326 + 408-570 (core), 575-789 (options).
+    out comps: ocomp+0 Progress, +1 MeanCurvature, +2..4 FlameNormal, +5 GaussianCurvature
+    (0.0 when not requested: quirk Q1), +6 StrainRate, +7 VelFlameNormal (when requested).
+    MF = host multifab class (level, ncomp, ng) used for scratch."""
+    L = lib(omp)
+    nlev = len(levels)
+    if prog_min is None or prog_max is None:
+        mm = [minmax(states[l], comp) for l in range(nlev)]
+        prog_min, prog_max = min(m[0] for m in mm), max(m[1] for m in mm)
+    thr = -1.0 if threshold is None else float(threshold)
+    cmf, nmf, gmf = [], [], []
+    for l in range(nlev):
+        c = MF(levels[l], 1, 2)
+        L.orc_progress(_p(_mf(states[l])), comp, C.c_double(prog_min), C.c_double(prog_max), _p(_mf(c)), 0)
+        fill_boundary(c, 0, 1, 2, omp)
+        cmf.append(c)
+    for l in range(nlev):
+        c = cmf[l]
+        apply_bc(c, 0, cmf[l - 1] if l > 0 else None, 0, bc, omp=omp)
+        G = MF(levels[l], 3, 1)  # cell_normal (with ghosts, :487-488)
+        grad_fused(c, 0, G, 0, False, omp)
+        normgrad = MF(levels[l], 1, 1)
+        n = MF(levels[l], 3, 1)
+        L.orc_normal(_p(_mf(G)), 0, _p(_mf(normgrad)), 0, _p(_mf(n)), 0)
+        fill_boundary(G, 0, 3, 1, omp)
+        fill_boundary(n, 0, 3, 1, omp)
+        K = MF(levels[l], 1, 0)
+        for d in range(3):
+            apply_bc(n, d, outs[l - 1] if l > 0 else None, ocomp + 2 + d, bc, only_dir=d, omp=omp)
+            L.orc_div_accum(_p(_mf(n)), d, d, _p(_mf(K)), 0)
+        L.orc_mult(_p(_mf(K)), 0, C.c_double(0.5))
+        if thr >= 0:
+            L.orc_threshold(_p(_mf(c)), 0, C.c_double(thr), _p(_mf(K)), 0, _p(_mf(n)), 0)
+        L.orc_copy(_p(_mf(c)), 0, _p(_mf(outs[l])), ocomp, 1, 0)
+        L.orc_copy(_p(_mf(K)), 0, _p(_mf(outs[l])), ocomp + 1, 1, 0)
+        L.orc_copy(_p(_mf(n)), 0, _p(_mf(outs[l])), ocomp + 2, 3, 0)
+        gmf.append(G)
+        nmf.append(n)
+        if outs[l].ncomp > ocomp + 5:
+            L.orc_setval(_p(_mf(outs[l])), ocomp + 5, C.c_double(0.0))
+        if do_gauss:
+            H = MF(levels[l], 9, 0)
+            for d in range(3):
+                # Hessian row d = grad(G_d); c/f BC from cell_normal[lev-1] (valid cells)
+                apply_bc(G, d, gmf[l - 1] if l > 0 else None, d, bc, omp=omp)
+                grad_fused(G, d, H, 3 * d, False, omp)
+            Kg = MF(levels[l], 1, 0)
+            L.orc_gauss_curv(_p(_mf(H)), _p(_mf(G)), _p(_mf(normgrad)), _p(_mf(c)), 0, C.c_double(thr), _p(_mf(Kg)), 0)
+            L.orc_copy(_p(_mf(Kg)), 0, _p(_mf(outs[l])), ocomp + 5, 1, 0)
+        if do_strain and vel_comp is not None:
+            gu = MF(levels[l], 9, 0)
+            for d in range(3):
+                u = MF(levels[l], 1, 1)
+                L.orc_copy(_p(_mf(states[l])), vel_comp + d, _p(_mf(u)), 0, 1, 0)
+                fill_boundary(u, 0, 1, 1, omp)  # MLMG applyBC starts with FillBoundary
+                crse = None
+                if l > 0:
+                    crse = MF(levels[l - 1], 1, 0)
+                    L.orc_copy(_p(_mf(states[l - 1])), vel_comp + d, _p(_mf(crse)), 0, 1, 0)
+                apply_bc(u, 0, crse, 0, bc, omp=omp)
+                grad_fused(u, 0, gu, 3 * d, False, omp)
+            sr = MF(levels[l], 1, 0)
+            L.orc_strain_rate(_p(_mf(gu)), _p(_mf(n)), _p(_mf(sr)), 0)
+            L.orc_copy(_p(_mf(sr)), 0, _p(_mf(outs[l])), ocomp + 6, 1, 0)
+        if do_velnormal and vel_comp is not None:
+            L.orc_vel_normal(_p(_mf(states[l])), vel_comp, _p(_mf(n)), _p(_mf(c)), 0, C.c_double(thr), _p(_mf(outs[l])), ocomp + 7)
+    return prog_min, prog_max
+
+
+def filter_pipeline(levels, ins, outs, ncomp, base_fgr=2, same_fgr_all_levels=False, ratio=2, interp_type=1, omp=False):
+    """filterPlt.cpp:126-219.  ins[l] must have ng >= fgr_l/2 ghost layers, valid cells filled."""
+    L = lib(omp)
+    fgr = base_fgr
+    info = []
+    for l in range(len(levels)):
+        if l > 0 and not same_fgr_all_levels:
+            fgr *= ratio
+        ngf, w = box_filter_weights(fgr)
+        assert ins[l].ng >= ngf
+        fill_boundary(ins[l], 0, ncomp, ngf, omp)
+        if l > 0:
+            nbad = L.orc_fillpatch_two_levels(_p(_mf(ins[l])), _p(_mf(ins[l - 1])), 0, ncomp, ngf, ratio, interp_type)
+            if nbad:
+                raise RuntimeError(f"fillpatch: {nbad} cells without coarse data")
+        L.orc_foextrap(_p(_mf(ins[l])), 0, ncomp, ngf)
+        wc = (C.c_double * len(w))(*w)
+        L.orc_apply_filter(_p(_mf(ins[l])), _p(_mf(outs[l])), 0, ncomp, ngf, wc)
+        info.append((fgr, ngf))
+    return info
+
+
+# ---------------------------------------------------------------- marching cubes
+def mc_tables():
+    e = np.ctypeslib.as_array(lib().orc_mc_edge_table(), shape=(256,)).copy()
+    t = np.ctypeslib.as_array(lib().orc_mc_tri_table(), shape=(256, 16)).copy()
+    return e, t
+
+
+def mc_fab(state, mask, slo, shi, isocomp, isoval, llo, lhi):
+    """Polygonise over one FAB.  state: (ncomp,nz,ny,nx) float64; mask: (nz,ny,nx) float64."""
+    state = np.ascontiguousarray(state, dtype=np.float64)
+    mask = np.ascontiguousarray(mask, dtype=np.float64)
+    ncomp = state.shape[0]
+    nv, nt = C.c_int64(0), C.c_int64(0)
+    i3 = lambda v: (C.c_int32 * 3)(*[int(x) for x in v])
+    args = (state.ctypes.data_as(C.POINTER(C.c_double)), mask.ctypes.data_as(C.POINTER(C.c_double)), i3(slo), i3(shi), ncomp,
+            int(isocomp), C.c_double(isoval), i3(llo), i3(lhi))
+    L = lib()
+    L.orc_mc_fab(*args, None, None, C.c_int64(0), None, C.c_int64(0), C.byref(nv), C.byref(nt))
+    verts = np.zeros((max(nv.value, 1), ncomp))
+    vkeys = np.zeros((max(nv.value, 1), 6), dtype=np.int32)
+    tris = np.zeros((max(nt.value, 1), 3), dtype=np.int32)
+    rc = L.orc_mc_fab(*args, verts.ctypes.data_as(C.POINTER(C.c_double)), vkeys.ctypes.data_as(C.POINTER(C.c_int32)),
+                      C.c_int64(nv.value), tris.ctypes.data_as(C.POINTER(C.c_int32)), C.c_int64(nt.value), C.byref(nv), C.byref(nt))
+    assert rc == 0
+    return verts[:nv.value], vkeys[:nv.value], tris[:nt.value]

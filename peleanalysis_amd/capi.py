@@ -1,0 +1,248 @@
+"""ctypes binding of libpeleanalysis_amd.so (the C ABI in include/peleanalysis_amd.h).
+
+This is the host-side mirror used by tests/ and bench.py; the C++ tool drivers in
+tools/ call the same C ABI directly.  There is NO CPU fallback: if the HIP library is
+missing or no GPU is present, constructing a Context raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from .hierarchy import Hierarchy, Level, MultiFab, mf_layout
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpeleanalysis_amd.so")
+
+BC_PERIODIC, BC_NEUMANN, BC_REFLECT_ODD = 0, 1, 2
+
+
+class PaFab(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("lo", C.c_int32 * 3), ("hi", C.c_int32 * 3), ("ncomp", C.c_int32)]
+
+
+class PaBox(C.Structure):
+    _fields_ = [("lo", C.c_int32 * 3), ("hi", C.c_int32 * 3)]
+
+
+class PaCurvParams(C.Structure):
+    _fields_ = [("prog_min", C.c_double), ("prog_max", C.c_double), ("do_threshold", C.c_int32), ("threshold", C.c_double),
+                ("fused", C.c_int32)]
+
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """dlopen the HIP library; fails loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+    pi32, pdbl = C.POINTER(C.c_int32), C.POINTER(C.c_double)
+    sig = {
+        "pa_version": (C.c_int, []),
+        "pa_ctx_create": (vp, [C.c_int, vp]),
+        "pa_ctx_destroy": (None, [vp]),
+        "pa_last_error": (C.c_char_p, [vp]),
+        "pa_sync": (C.c_int, [vp]),
+        "pa_ctx_stream": (vp, [vp]),
+        "pa_level_create": (vp, [vp, C.c_int, pi32, pi32, pi32, pi32, pdbl, pdbl]),
+        "pa_level_destroy": (None, [vp]),
+        "pa_level_nboxes": (C.c_int, [vp]),
+        "pa_mf_layout": (i64, [C.c_int, pi32, C.c_int, C.c_int, C.POINTER(i64)]),
+        "pa_mf_create": (vp, [vp, vp, C.c_int, C.c_int, vp]),
+        "pa_mf_destroy": (None, [vp]),
+        "pa_mf_data": (vp, [vp]),
+        "pa_mf_size": (i64, [vp]),
+        "pa_mf_upload": (C.c_int, [vp, vp, vp]),
+        "pa_mf_download": (C.c_int, [vp, vp, vp]),
+        "pa_mf_setval": (C.c_int, [vp, vp, C.c_int, C.c_int, dbl]),
+        "pa_mf_copy": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int]),
+        "pa_fill_boundary": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int]),
+        "pa_apply_bc": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, pi32, C.c_int, C.c_int]),
+        "pa_bc_errors": (C.c_int, [vp]),
+        "pa_grad_level": (C.c_int, [vp, vp, C.c_int, vp, C.c_int]),
+        "pa_minmax_level": (C.c_int, [vp, vp, C.c_int, pdbl, pdbl]),
+        "pa_progress_level": (C.c_int, [vp, vp, C.c_int, dbl, dbl, vp, C.c_int, C.c_int]),
+        "pa_normal_level": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int]),
+        "pa_div_level": (C.c_int, [vp, vp, C.c_int, dbl, vp, C.c_int, dbl, vp, C.c_int]),
+        "pa_gradcurv_level": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, dbl, vp, C.c_int]),
+        "pa_gradcurv_faces_level": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, pi32, C.c_int, dbl, vp, C.c_int]),
+        "pa_grad_fab": (C.c_int, [vp, PaBox, C.POINTER(PaFab), C.c_int, pdbl, C.POINTER(PaFab), C.c_int]),
+        "pa_progress_fab": (C.c_int, [vp, PaBox, C.POINTER(PaFab), C.c_int, dbl, dbl, C.POINTER(PaFab), C.c_int]),
+        "pa_normal_fab": (C.c_int, [vp, PaBox, C.POINTER(PaFab), C.c_int, pdbl, C.POINTER(PaFab), C.c_int, C.POINTER(PaFab), C.c_int,
+                                    C.POINTER(PaFab), C.c_int]),
+        "pa_div_fab": (C.c_int, [vp, PaBox, C.POINTER(PaFab), C.c_int, pdbl, dbl, C.POINTER(PaFab), C.c_int]),
+        "pa_gradcurv_fab": (C.c_int, [vp, PaBox, C.POINTER(PaFab), C.c_int, C.POINTER(PaFab), C.c_int, pdbl, dbl, C.POINTER(PaFab), C.c_int]),
+        "pa_boxfilter_fab": (C.c_int, [vp, PaBox, C.POINTER(PaFab), C.POINTER(PaFab), C.c_int, C.c_int, C.c_int, pdbl]),
+        "pa_box_filter_weights": (C.c_int, [C.c_int, pdbl]),
+        "pa_boxfilter_level": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, pdbl]),
+        "pa_foextrap": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int]),
+        "pa_fillpatch_two_levels": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+        "pa_mc_count_fab": (C.c_int, [vp, PaBox, C.POINTER(PaFab), C.POINTER(PaFab), C.c_int, dbl, C.POINTER(i64), C.POINTER(i64)]),
+        "pa_mc_emit_fab": (C.c_int, [vp, PaBox, C.POINTER(PaFab), C.POINTER(PaFab), C.c_int, dbl, vp, vp, vp, i64, i64]),
+        "pa_mc_edge_table": (C.POINTER(C.c_uint16), []),
+        "pa_mc_tri_table": (C.POINTER(C.c_int8), []),
+        "pa_grad_run": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.c_int, pi32, C.POINTER(vp), C.c_int]),
+        "pa_curvature_run": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.c_int, pi32, C.POINTER(PaCurvParams), C.POINTER(vp), C.c_int]),
+        "pa_gradcurv_run": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.c_int, pi32, C.POINTER(PaCurvParams), C.POINTER(vp), C.POINTER(vp),
+                                      C.c_int]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)  # AttributeError = symbol missing from the .so
+        fn.restype = res
+        fn.argtypes = args
+    L._pa_signatures = sig
+    _lib = L
+    return L
+
+
+def declared_symbols(header: Optional[str] = None) -> List[str]:
+    """Names of every function declared in include/peleanalysis_amd.h."""
+    import re
+    header = header or os.path.join(os.path.dirname(_HERE), "include", "peleanalysis_amd.h")
+    txt = re.sub(r"/\*.*?\*/", "", open(header).read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(pa_[a-z0-9_]+)\s*\(", txt)))
+
+
+class PaError(RuntimeError):
+    pass
+
+
+def _i3(v):
+    return (C.c_int32 * 3)(*[int(x) for x in v])
+
+
+def _d3(v):
+    return (C.c_double * 3)(*[float(x) for x in v])
+
+
+class Context:
+    def __init__(self, device: int = 0, stream: Optional[int] = None):
+        self.lib = load_library()
+        self.h = self.lib.pa_ctx_create(int(device), C.c_void_p(stream) if stream else None)
+        if not self.h:
+            raise PaError("pa_ctx_create failed: no MI355X/HIP device visible (no CPU fallback)")
+
+    def check(self, rc: int):
+        if rc != 0:
+            raise PaError(self.lib.pa_last_error(self.h).decode())
+
+    def sync(self):
+        self.check(self.lib.pa_sync(self.h))
+
+    def bc_errors(self) -> int:
+        return int(self.lib.pa_bc_errors(self.h))
+
+    def close(self):
+        if self.h:
+            self.lib.pa_ctx_destroy(self.h)
+            self.h = None
+
+
+class DevLevel:
+    def __init__(self, ctx: Context, level: Level):
+        self.ctx, self.level = ctx, level
+        b = np.ascontiguousarray(level.boxes, dtype=np.int32)
+        self.h = ctx.lib.pa_level_create(ctx.h, level.nboxes, b.ctypes.data_as(C.POINTER(C.c_int32)), _i3(level.domlo), _i3(level.domhi),
+                                         _i3(level.is_per), _d3(level.prob_lo), _d3(level.prob_hi))
+        if not self.h:
+            raise PaError(ctx.lib.pa_last_error(ctx.h).decode())
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.pa_level_destroy(self.h)
+            self.h = None
+
+
+class DevMF:
+    """MultiFab in HBM.  devptr: optional externally owned device pointer (e.g. torch tensor)."""
+
+    def __init__(self, ctx: Context, dlev: DevLevel, ncomp: int, ng: int, devptr: Optional[int] = None):
+        self.ctx, self.dlev, self.ncomp, self.ng = ctx, dlev, int(ncomp), int(ng)
+        self.h = ctx.lib.pa_mf_create(ctx.h, dlev.h, ncomp, ng, C.c_void_p(devptr) if devptr else None)
+        if not self.h:
+            raise PaError(ctx.lib.pa_last_error(ctx.h).decode())
+        self.size = int(ctx.lib.pa_mf_size(self.h))
+        self.ptr = int(ctx.lib.pa_mf_data(self.h))
+
+    @classmethod
+    def from_host(cls, ctx, dlev, mf: MultiFab) -> "DevMF":
+        d = cls(ctx, dlev, mf.ncomp, mf.ng)
+        d.upload(mf)
+        return d
+
+    def upload(self, mf: MultiFab):
+        assert mf.total == self.size, (mf.total, self.size)
+        self.ctx.check(self.ctx.lib.pa_mf_upload(self.ctx.h, self.h, mf.data.ctypes.data_as(C.c_void_p)))
+
+    def download(self) -> MultiFab:
+        mf = MultiFab(self.dlev.level, self.ncomp, self.ng)
+        assert mf.total == self.size
+        self.ctx.check(self.ctx.lib.pa_mf_download(self.ctx.h, self.h, mf.data.ctypes.data_as(C.c_void_p)))
+        return mf
+
+    def fab(self, b: int) -> PaFab:
+        """pa_fab for box b (device pointer into this multifab)."""
+        lv = self.dlev.level
+        off, _ = mf_layout(lv.boxes, self.ncomp, self.ng)
+        f = PaFab()
+        f.p = self.ptr + 8 * int(off[b])
+        for d in range(3):
+            f.lo[d] = int(lv.boxes[b, d]) - self.ng
+            f.hi[d] = int(lv.boxes[b, 3 + d]) + self.ng
+        f.ncomp = self.ncomp
+        return f
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.pa_mf_destroy(self.h)
+            self.h = None
+
+
+def box_of(level: Level, b: int, grow: int = 0) -> PaBox:
+    bx = PaBox()
+    for d in range(3):
+        bx.lo[d] = int(level.boxes[b, d]) - grow
+        bx.hi[d] = int(level.boxes[b, 3 + d]) + grow
+    return bx
+
+
+def _handles(mfs: Sequence[Optional[DevMF]]):
+    return (C.c_void_p * len(mfs))(*[m.h if m is not None else None for m in mfs])
+
+
+def bc_from_flags(is_per, sym_dir=(0, 0, 0)):
+    """grad.cpp:180-193 / curvature.cpp:428-441"""
+    return [BC_PERIODIC if p else (BC_REFLECT_ODD if s else BC_NEUMANN) for p, s in zip(is_per, sym_dir)]
+
+
+def grad_run(ctx: Context, states: Sequence[DevMF], comp: int, bc, outs: Sequence[DevMF], ocomp: int):
+    ctx.check(ctx.lib.pa_grad_run(ctx.h, len(states), _handles(states), comp, _i3(bc), _handles(outs), ocomp))
+
+
+def curv_params(prog_min=None, prog_max=None, threshold=None, fused=True) -> PaCurvParams:
+    p = PaCurvParams()
+    p.prog_min = 1e20 if prog_min is None else prog_min
+    p.prog_max = -1e20 if prog_max is None else prog_max
+    p.do_threshold = 0 if threshold is None else 1
+    p.threshold = 0.0 if threshold is None else float(threshold)
+    p.fused = 1 if fused else 0
+    return p
+
+
+def curvature_run(ctx, states, comp, bc, params: PaCurvParams, outs, ocomp):
+    ctx.check(ctx.lib.pa_curvature_run(ctx.h, len(states), _handles(states), comp, _i3(bc), C.byref(params), _handles(outs), ocomp))
+
+
+def gradcurv_run(ctx, states, comp, bc, params: PaCurvParams, works, outs, ocomp):
+    ctx.check(ctx.lib.pa_gradcurv_run(ctx.h, len(states), _handles(states), comp, _i3(bc), C.byref(params), _handles(works),
+                                      _handles(outs), ocomp))

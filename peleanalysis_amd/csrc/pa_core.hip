@@ -1,0 +1,560 @@
+// pa_core.hip -- context, level (BoxArray + owner map), MultiFab, ghost-cell kernels.
+// gfx950 only.  Replaces the AMReX pieces the reference tools lean on for this path:
+// MultiFab storage, FabArray::FillBoundary and MLCellLinOp::applyBC.
+#include "pa_internal.h"
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+
+int pa_fail(pa_ctx* ctx, const std::string& msg) {
+  if (ctx) ctx->err = msg;
+  return 1;
+}
+
+extern "C" int pa_version(void) { return 100; }
+
+extern "C" pa_ctx* pa_ctx_create(int device, void* hip_stream) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device >= ndev) return nullptr;
+  if (hipSetDevice(device) != hipSuccess) return nullptr;
+  pa_ctx* ctx = new pa_ctx();
+  ctx->device = device;
+  if (hip_stream) {
+    ctx->stream = (hipStream_t)hip_stream;
+  } else {
+    if (hipStreamCreate(&ctx->stream) != hipSuccess) { delete ctx; return nullptr; }
+    ctx->own_stream = true;
+  }
+  if (hipMalloc(&ctx->d_flags, 16 * sizeof(int)) != hipSuccess || hipMemset(ctx->d_flags, 0, 16 * sizeof(int)) != hipSuccess) {
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return nullptr;
+  }
+  return ctx;
+}
+
+extern "C" void pa_ctx_destroy(pa_ctx* ctx) {
+  if (!ctx) return;
+  if (ctx->d_red) (void)hipFree(ctx->d_red);
+  if (ctx->d_flags) (void)hipFree(ctx->d_flags);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+extern "C" const char* pa_last_error(const pa_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+extern "C" void* pa_ctx_stream(pa_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+extern "C" int pa_sync(pa_ctx* ctx) {
+  if (!ctx) return 1;
+  PA_HIP(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+// ------------------------------------------------------------------------ level
+static int host_classify(const pa_level* L, int i, int j, int k) {
+  int p[3] = {i, j, k};
+  for (int d = 0; d < 3; ++d) {
+    const int len = L->domhi[d] - L->domlo[d] + 1;
+    if (p[d] < L->domlo[d] || p[d] > L->domhi[d]) {
+      if (!L->is_per[d]) return 2;
+      while (p[d] < L->domlo[d]) p[d] += len;
+      while (p[d] > L->domhi[d]) p[d] -= len;
+    }
+  }
+  int m[3];
+  for (int d = 0; d < 3; ++d) {
+    const int r = p[d] - L->mlo[d];
+    if (r < 0) return 1;
+    m[d] = r / L->g;
+    if (m[d] >= L->mn[d]) return 1;
+  }
+  return L->owner[((size_t)m[2] * L->mn[1] + m[1]) * L->mn[0] + m[0]] >= 0 ? 0 : 1;
+}
+
+extern "C" pa_level* pa_level_create(pa_ctx* ctx, int nboxes, const int32_t* b6, const int32_t domlo[3],
+                                     const int32_t domhi[3], const int32_t is_per[3], const double prob_lo[3],
+                                     const double prob_hi[3]) {
+  if (!ctx) return nullptr;
+  if (nboxes <= 0 || !b6) { pa_fail(ctx, "pa_level_create: empty BoxArray"); return nullptr; }
+  pa_level* L = new pa_level();
+  L->ctx = ctx;
+  L->boxes.resize(nboxes);
+  for (int d = 0; d < 3; ++d) {
+    L->domlo[d] = domlo[d]; L->domhi[d] = domhi[d]; L->is_per[d] = is_per[d] ? 1 : 0;
+    L->prob_lo[d] = prob_lo[d]; L->prob_hi[d] = prob_hi[d];
+    // Geometry: dx = length / ncells ; inv_dx = 1/dx
+    L->dx[d] = (prob_hi[d] - prob_lo[d]) / (double)(domhi[d] - domlo[d] + 1);
+    L->dxinv[d] = 1.0 / L->dx[d];
+    L->mlo[d] = INT32_MAX;
+  }
+  int mhi[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+  for (int b = 0; b < nboxes; ++b) {
+    for (int d = 0; d < 3; ++d) {
+      L->boxes[b].lo[d] = b6[6 * b + d];
+      L->boxes[b].hi[d] = b6[6 * b + 3 + d];
+      if (L->boxes[b].hi[d] < L->boxes[b].lo[d] || L->boxes[b].lo[d] < domlo[d] || L->boxes[b].hi[d] > domhi[d]) {
+        pa_fail(ctx, "pa_level_create: box " + std::to_string(b) + " is empty or outside the domain");
+        delete L;
+        return nullptr;
+      }
+      L->mlo[d] = std::min(L->mlo[d], L->boxes[b].lo[d]);
+      mhi[d] = std::max(mhi[d], L->boxes[b].hi[d]);
+      L->maxn[d] = std::max(L->maxn[d], L->boxes[b].hi[d] - L->boxes[b].lo[d] + 1);
+    }
+    L->ncells += (long long)(L->boxes[b].hi[0] - L->boxes[b].lo[0] + 1) * (L->boxes[b].hi[1] - L->boxes[b].lo[1] + 1) *
+                 (L->boxes[b].hi[2] - L->boxes[b].lo[2] + 1);
+  }
+  // owner-map granularity
+  int g = 0;
+  for (int b = 0; b < nboxes; ++b)
+    for (int d = 0; d < 3; ++d) {
+      g = std::gcd(g, L->boxes[b].lo[d] - L->mlo[d]);
+      g = std::gcd(g, L->boxes[b].hi[d] - L->boxes[b].lo[d] + 1);
+    }
+  if (g <= 0) g = 1;
+  L->g = g;
+  size_t msz = 1;
+  for (int d = 0; d < 3; ++d) {
+    L->mn[d] = (mhi[d] - L->mlo[d] + 1) / g;
+    msz *= (size_t)L->mn[d];
+  }
+  if (msz > ((size_t)1 << 28)) {
+    pa_fail(ctx, "pa_level_create: owner map too large (boxes not aligned to a common blocking factor)");
+    delete L;
+    return nullptr;
+  }
+  L->owner.assign(msz, -1);
+  for (int b = 0; b < nboxes; ++b) {
+    const DBox& B = L->boxes[b];
+    for (int kz = (B.lo[2] - L->mlo[2]) / g; kz <= (B.hi[2] - L->mlo[2]) / g; ++kz)
+      for (int ky = (B.lo[1] - L->mlo[1]) / g; ky <= (B.hi[1] - L->mlo[1]) / g; ++ky)
+        for (int kx = (B.lo[0] - L->mlo[0]) / g; kx <= (B.hi[0] - L->mlo[0]) / g; ++kx) {
+          int& o = L->owner[((size_t)kz * L->mn[1] + ky) * L->mn[0] + kx];
+          if (o >= 0) {
+            pa_fail(ctx, "pa_level_create: boxes " + std::to_string(o) + " and " + std::to_string(b) + " overlap");
+            delete L;
+            return nullptr;
+          }
+          o = b;
+        }
+  }
+  // Fused grad->curvature legality: an edge ghost cell that is NOT a valid cell while both
+  // of its face-ring neighbours towards the box ARE valid cells (concave coarse-fine corner)
+  // would need two different boundary values in one FAB slot.
+  L->fusable = true;
+  for (int b = 0; b < nboxes && L->fusable; ++b) {
+    const DBox& B = L->boxes[b];
+    for (int a = 0; a < 3 && L->fusable; ++a)
+      for (int c = a + 1; c < 3 && L->fusable; ++c) {
+        const int e = 3 - a - c;
+        for (int sa = 0; sa < 2 && L->fusable; ++sa)
+          for (int sc = 0; sc < 2 && L->fusable; ++sc)
+            for (int t = B.lo[e]; t <= B.hi[e]; ++t) {
+              int q[3];
+              q[e] = t;
+              q[a] = sa ? B.hi[a] + 1 : B.lo[a] - 1;
+              q[c] = sc ? B.hi[c] + 1 : B.lo[c] - 1;
+              if (host_classify(L, q[0], q[1], q[2]) == 0) continue;
+              int qa[3] = {q[0], q[1], q[2]}, qc[3] = {q[0], q[1], q[2]};
+              qa[a] += sa ? -1 : 1;
+              qc[c] += sc ? -1 : 1;
+              if (host_classify(L, qa[0], qa[1], qa[2]) == 0 && host_classify(L, qc[0], qc[1], qc[2]) == 0) {
+                L->fusable = false;
+                break;
+              }
+            }
+      }
+  }
+  if (hipMalloc(&L->d_boxes, sizeof(DBox) * nboxes) != hipSuccess ||
+      hipMalloc(&L->d_owner, sizeof(int) * msz) != hipSuccess ||
+      hipMemcpy(L->d_boxes, L->boxes.data(), sizeof(DBox) * nboxes, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(L->d_owner, L->owner.data(), sizeof(int) * msz, hipMemcpyHostToDevice) != hipSuccess) {
+    pa_fail(ctx, "pa_level_create: device allocation failed");
+    if (L->d_boxes) (void)hipFree(L->d_boxes);
+    if (L->d_owner) (void)hipFree(L->d_owner);
+    delete L;
+    return nullptr;
+  }
+  DLevelView& V = L->view;
+  V.nboxes = nboxes;
+  V.boxes = L->d_boxes;
+  V.owner = L->d_owner;
+  V.g = g;
+  for (int d = 0; d < 3; ++d) {
+    V.domlo[d] = L->domlo[d]; V.domhi[d] = L->domhi[d]; V.is_per[d] = L->is_per[d];
+    V.mlo[d] = L->mlo[d]; V.mn[d] = L->mn[d]; V.dxinv[d] = L->dxinv[d];
+  }
+  return L;
+}
+
+extern "C" void pa_level_destroy(pa_level* L) {
+  if (!L) return;
+  if (L->d_boxes) (void)hipFree(L->d_boxes);
+  if (L->d_owner) (void)hipFree(L->d_owner);
+  delete L;
+}
+extern "C" int pa_level_nboxes(const pa_level* L) { return L ? (int)L->boxes.size() : 0; }
+
+// --------------------------------------------------------------------- MultiFab
+extern "C" int64_t pa_mf_layout(int nboxes, const int32_t* b6, int ncomp, int ng, int64_t* off) {
+  int64_t t = 0;
+  for (int b = 0; b < nboxes; ++b) {
+    if (off) off[b] = t;
+    int64_t n = ncomp;
+    for (int d = 0; d < 3; ++d) n *= (int64_t)(b6[6 * b + 3 + d] - b6[6 * b + d] + 1 + 2 * ng);
+    t += (n + 63) / 64 * 64;  // every FAB starts on a 512-byte boundary
+  }
+  return t;
+}
+
+extern "C" pa_mf* pa_mf_create(pa_ctx* ctx, const pa_level* L, int ncomp, int ng, double* devptr) {
+  if (!ctx || !L) return nullptr;
+  if (ncomp <= 0 || ng < 0) { pa_fail(ctx, "pa_mf_create: bad ncomp/ng"); return nullptr; }
+  pa_mf* M = new pa_mf();
+  M->lev = L; M->ncomp = ncomp; M->ng = ng;
+  const int nb = (int)L->boxes.size();
+  std::vector<int32_t> b6(6 * (size_t)nb);
+  for (int b = 0; b < nb; ++b)
+    for (int d = 0; d < 3; ++d) { b6[6 * b + d] = L->boxes[b].lo[d]; b6[6 * b + 3 + d] = L->boxes[b].hi[d]; }
+  std::vector<int64_t> off(nb);
+  M->total = pa_mf_layout(nb, b6.data(), ncomp, ng, off.data());
+  M->off.assign(off.begin(), off.end());
+  if (hipMalloc(&M->d_off, sizeof(long long) * nb) != hipSuccess ||
+      hipMemcpy(M->d_off, M->off.data(), sizeof(long long) * nb, hipMemcpyHostToDevice) != hipSuccess) {
+    pa_fail(ctx, "pa_mf_create: device allocation failed");
+    delete M;
+    return nullptr;
+  }
+  if (devptr) {
+    M->data = devptr;
+  } else {
+    if (hipMalloc(&M->data, sizeof(double) * (size_t)M->total) != hipSuccess ||
+        hipMemsetAsync(M->data, 0, sizeof(double) * (size_t)M->total, ctx->stream) != hipSuccess) {
+      pa_fail(ctx, "pa_mf_create: out of device memory (" + std::to_string(M->total * 8) + " bytes)");
+      (void)hipFree(M->d_off);
+      delete M;
+      return nullptr;
+    }
+    M->owned = true;
+  }
+  M->view.data = M->data; M->view.off = M->d_off; M->view.ncomp = ncomp; M->view.ng = ng;
+  return M;
+}
+
+extern "C" void pa_mf_destroy(pa_mf* M) {
+  if (!M) return;
+  if (M->owned && M->data) (void)hipFree(M->data);
+  if (M->d_off) (void)hipFree(M->d_off);
+  delete M;
+}
+extern "C" double* pa_mf_data(pa_mf* M) { return M ? M->data : nullptr; }
+extern "C" int64_t pa_mf_size(const pa_mf* M) { return M ? M->total : 0; }
+
+extern "C" int pa_mf_upload(pa_ctx* ctx, pa_mf* M, const double* host) {
+  if (!ctx || !M || !host) return pa_fail(ctx, "pa_mf_upload: null argument");
+  PA_HIP(hipMemcpyAsync(M->data, host, sizeof(double) * (size_t)M->total, hipMemcpyHostToDevice, ctx->stream));
+  PA_HIP(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+extern "C" int pa_mf_download(pa_ctx* ctx, const pa_mf* M, double* host) {
+  if (!ctx || !M || !host) return pa_fail(ctx, "pa_mf_download: null argument");
+  PA_HIP(hipMemcpyAsync(host, M->data, sizeof(double) * (size_t)M->total, hipMemcpyDeviceToHost, ctx->stream));
+  PA_HIP(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+__global__ void k_setval(double* p, long long n, double v) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = v;
+}
+
+// per-box component ranges are contiguous: [comp][k][j][i]
+__global__ void k_setval_comp(DLevelView L, DMFView M, int comp, int ncomp, double v) {
+  const int b = blockIdx.y;
+  const DBox B = L.boxes[b];
+  const long long per = (long long)(B.hi[0] - B.lo[0] + 1 + 2 * M.ng) * (B.hi[1] - B.lo[1] + 1 + 2 * M.ng) *
+                        (B.hi[2] - B.lo[2] + 1 + 2 * M.ng);
+  double* p = M.data + M.off[b] + per * comp;
+  const long long n = per * ncomp;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = v;
+}
+
+extern "C" int pa_mf_setval(pa_ctx* ctx, pa_mf* M, int comp, int ncomp, double v) {
+  if (!ctx || !M) return pa_fail(ctx, "pa_mf_setval: null argument");
+  if (comp < 0 || comp + ncomp > M->ncomp) return pa_fail(ctx, "pa_mf_setval: component range");
+  dim3 grid(64, (unsigned)M->lev->boxes.size());
+  hipLaunchKernelGGL(k_setval_comp, grid, dim3(256), 0, ctx->stream, M->lev->view, M->view, comp, ncomp, v);
+  PA_HIP(hipGetLastError());
+  return 0;
+}
+
+__global__ void k_copy(DLevelView L, DMFView S, int scomp, DMFView D, int dcomp, int ncomp, int ng) {
+  const int b = blockIdx.y;
+  const DBox B = L.boxes[b];
+  const int nx = B.hi[0] - B.lo[0] + 1 + 2 * ng, ny = B.hi[1] - B.lo[1] + 1 + 2 * ng, nz = B.hi[2] - B.lo[2] + 1 + 2 * ng;
+  const long long n = (long long)nx * ny * nz * ncomp;
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+    const int i = (int)(t % nx);
+    const int j = (int)((t / nx) % ny);
+    const int k = (int)((t / ((long long)nx * ny)) % nz);
+    const int c = (int)(t / ((long long)nx * ny * nz));
+    const int I = B.lo[0] - ng + i, J = B.lo[1] - ng + j, K = B.lo[2] - ng + k;
+    D.data[D.off[b] + fab_index(B, D.ng, dcomp + c, I, J, K)] = S.data[S.off[b] + fab_index(B, S.ng, scomp + c, I, J, K)];
+  }
+}
+
+extern "C" int pa_mf_copy(pa_ctx* ctx, const pa_mf* S, int scomp, pa_mf* D, int dcomp, int ncomp, int ng) {
+  if (!ctx || !S || !D) return pa_fail(ctx, "pa_mf_copy: null argument");
+  if (S->lev != D->lev) return pa_fail(ctx, "pa_mf_copy: different levels");
+  if (ng > S->ng || ng > D->ng || scomp + ncomp > S->ncomp || dcomp + ncomp > D->ncomp)
+    return pa_fail(ctx, "pa_mf_copy: ng/component range");
+  dim3 grid(128, (unsigned)S->lev->boxes.size());
+  hipLaunchKernelGGL(k_copy, grid, dim3(256), 0, ctx->stream, S->lev->view, S->view, scomp, D->view, dcomp, ncomp, ng);
+  PA_HIP(hipGetLastError());
+  return 0;
+}
+
+// ----------------------------------------------------------------- FillBoundary
+// Thread per ghost-shell cell.  The shell of depth ng is enumerated as 2 z-slabs (full grown
+// xy extent), 2 y-slabs (valid z, full grown x) and 2 x-slabs (valid y,z): x-contiguous runs.
+__device__ __forceinline__ bool shell_cell(const DBox& B, int ng, long long t, int& i, int& j, int& k) {
+  const int nx = B.hi[0] - B.lo[0] + 1, ny = B.hi[1] - B.lo[1] + 1, nz = B.hi[2] - B.lo[2] + 1;
+  const int gx = nx + 2 * ng, gy = ny + 2 * ng;
+  const long long nzs = (long long)ng * gy * gx;  // one z slab
+  const long long nys = (long long)nz * ng * gx;  // one y slab
+  const long long nxs = (long long)nz * ny * ng;  // one x slab
+  if (t < 2 * nzs) {
+    const int s = t >= nzs;
+    if (s) t -= nzs;
+    i = B.lo[0] - ng + (int)(t % gx);
+    j = B.lo[1] - ng + (int)((t / gx) % gy);
+    k = (int)(t / ((long long)gx * gy));
+    k = s ? B.hi[2] + 1 + k : B.lo[2] - ng + k;
+    return true;
+  }
+  t -= 2 * nzs;
+  if (t < 2 * nys) {
+    const int s = t >= nys;
+    if (s) t -= nys;
+    i = B.lo[0] - ng + (int)(t % gx);
+    j = (int)((t / gx) % ng);
+    k = B.lo[2] + (int)(t / ((long long)gx * ng));
+    j = s ? B.hi[1] + 1 + j : B.lo[1] - ng + j;
+    return true;
+  }
+  t -= 2 * nys;
+  if (t < 2 * nxs) {
+    const int s = t >= nxs;
+    if (s) t -= nxs;
+    i = (int)(t % ng);
+    j = B.lo[1] + (int)((t / ng) % ny);
+    k = B.lo[2] + (int)(t / ((long long)ng * ny));
+    i = s ? B.hi[0] + 1 + i : B.lo[0] - ng + i;
+    return true;
+  }
+  return false;
+}
+
+__global__ void k_fill_boundary(DLevelView L, DMFView M, int comp, int ncomp, int ngf) {
+  const int b = blockIdx.y;
+  const DBox B = L.boxes[b];
+  const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  int i, j, k;
+  if (!shell_cell(B, ngf, t, i, j, k)) return;
+  int s, p[3];
+  if (classify(L, i, j, k, s, p) != 0) return;
+  const DBox S = L.boxes[s];
+  for (int c = comp; c < comp + ncomp; ++c)
+    M.data[M.off[b] + fab_index(B, M.ng, c, i, j, k)] = M.data[M.off[s] + fab_index(S, M.ng, c, p[0], p[1], p[2])];
+}
+
+static long long max_shell(const pa_level* L, int ng) {
+  long long m = 0;
+  for (const DBox& B : L->boxes) {
+    const long long nx = B.hi[0] - B.lo[0] + 1, ny = B.hi[1] - B.lo[1] + 1, nz = B.hi[2] - B.lo[2] + 1;
+    m = std::max(m, (nx + 2 * ng) * (ny + 2 * ng) * (nz + 2 * ng) - nx * ny * nz);
+  }
+  return m;
+}
+
+extern "C" int pa_fill_boundary(pa_ctx* ctx, pa_mf* M, int comp, int ncomp, int ng) {
+  if (!ctx || !M) return pa_fail(ctx, "pa_fill_boundary: null argument");
+  if (ng > M->ng || ng < 0 || comp < 0 || comp + ncomp > M->ncomp) return pa_fail(ctx, "pa_fill_boundary: ng/component range");
+  if (ng == 0) return 0;
+  for (int d = 0; d < 3; ++d)
+    if (M->lev->is_per[d] && ng > M->lev->domhi[d] - M->lev->domlo[d] + 1)
+      return pa_fail(ctx, "pa_fill_boundary: ng larger than the periodic domain");
+  const long long ms = max_shell(M->lev, ng);
+  dim3 grid((unsigned)((ms + 255) / 256), (unsigned)M->lev->boxes.size());
+  hipLaunchKernelGGL(k_fill_boundary, grid, dim3(256), 0, ctx->stream, M->lev->view, M->view, comp, ncomp, ng);
+  PA_HIP(hipGetLastError());
+  return 0;
+}
+
+// --------------------------------------------------------------------- applyBC
+struct BCArgs {
+  int bc[3];
+  int ratio;
+  int only_dir;
+  int has_crse;
+  int edges;  // 0: face ghosts (AMReX applyBC); 1: the 12 edge-ghost lines (fused path extension)
+};
+
+// resolved boundary value of ghost cell q of box B (fab pointer f) whose interior neighbour
+// in direction dir is q + s*e_dir.  cls: 1 coarse-fine, 2 physical wall.
+__device__ __forceinline__ double bc_ghost_value(const DLevelView& L, const DMFView& M, const DBox& B, int b, int comp,
+                                                 const DLevelView& LC, const DMFView& MC, int ccomp, const BCArgs& A,
+                                                 const int q[3], int dir, int s, int cls, bool& ok) {
+  int in[3] = {q[0], q[1], q[2]};
+  in[dir] += s;
+  const double* f = M.data + M.off[b];
+  if (cls == 2) {
+    const double v = f[fab_index(B, M.ng, comp, in[0], in[1], in[2])];
+    return (A.bc[dir] == PA_BC_REFLECT_ODD) ? -v : v;
+  }
+  double coef[4];
+  const int NX = cf_normal_coef(B.hi[dir] - B.lo[dir] + 1, A.ratio, coef);
+  const double bv = cf_bndry_value(L, LC, MC, ccomp, q, dir, A.ratio, ok);
+  double tmp = 0.0;
+  for (int m = 1; m < NX; ++m) {
+    int pc[3] = {q[0], q[1], q[2]};
+    pc[dir] += s * m;
+    tmp += f[fab_index(B, M.ng, comp, pc[0], pc[1], pc[2])] * coef[m];
+  }
+  double g = tmp;
+  g += bv * coef[0];
+  return g;
+}
+
+__global__ void k_apply_bc_faces(DLevelView L, DMFView M, int comp, DLevelView LC, DMFView MC, int ccomp, BCArgs A,
+                                 int* nbad) {
+  const int b = blockIdx.y;
+  const DBox B = L.boxes[b];
+  const int n[3] = {B.hi[0] - B.lo[0] + 1, B.hi[1] - B.lo[1] + 1, B.hi[2] - B.lo[2] + 1};
+  long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  int dir = -1, side = 0, a0 = 0, b1 = 0;
+  for (int d = 0; d < 3; ++d) {
+    const int t0 = (d == 0) ? 1 : 0, t1 = (d == 2) ? 1 : 2;
+    const long long fs = (long long)n[t0] * n[t1];
+    if (t < 2 * fs) {
+      dir = d;
+      side = t >= fs;
+      if (side) t -= fs;
+      a0 = (int)(t % n[t0]);
+      b1 = (int)(t / n[t0]);
+      break;
+    }
+    t -= 2 * fs;
+  }
+  if (dir < 0) return;
+  if (A.only_dir >= 0 && dir != A.only_dir) return;
+  const int t0 = (dir == 0) ? 1 : 0, t1 = (dir == 2) ? 1 : 2;
+  int q[3];
+  q[dir] = side ? B.hi[dir] + 1 : B.lo[dir] - 1;
+  q[t0] = B.lo[t0] + a0;
+  q[t1] = B.lo[t1] + b1;
+  const int cls = classify(L, q[0], q[1], q[2]);
+  if (cls == 0) return;
+  if (cls == 1 && !A.has_crse) { atomicAdd(nbad, 1); return; }
+  bool ok = true;
+  const double v = bc_ghost_value(L, M, B, b, comp, LC, MC, ccomp, A, q, dir, side ? -1 : 1, cls, ok);
+  if (!ok) atomicAdd(nbad, 1);
+  M.data[M.off[b] + fab_index(B, M.ng, comp, q[0], q[1], q[2])] = v;
+}
+
+// Fused-path extension: edge ghost cells (outside the box in two directions a<c).  Such a cell
+// is needed as the boundary ghost of a valid cell of a NEIGHBOURING box (role = the direction
+// towards that valid cell); see DESIGN.md "resolved ghost ring".
+__global__ void k_apply_bc_edges(DLevelView L, DMFView M, int comp, DLevelView LC, DMFView MC, int ccomp, BCArgs A,
+                                 int* nbad) {
+  const int b = blockIdx.y;
+  const DBox B = L.boxes[b];
+  const int n[3] = {B.hi[0] - B.lo[0] + 1, B.hi[1] - B.lo[1] + 1, B.hi[2] - B.lo[2] + 1};
+  long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  // 3 edge orientations e (the free direction), 4 edges each
+  int e = -1, which = 0, pos = 0;
+  for (int d = 0; d < 3; ++d) {
+    if (t < 4LL * n[d]) { e = d; which = (int)(t / n[d]); pos = (int)(t % n[d]); break; }
+    t -= 4LL * n[d];
+  }
+  if (e < 0) return;
+  const int a = (e == 0) ? 1 : 0, c = (e == 2) ? 1 : 2;
+  const int sa = which & 1, sc = which >> 1;
+  int q[3];
+  q[e] = B.lo[e] + pos;
+  q[a] = sa ? B.hi[a] + 1 : B.lo[a] - 1;
+  q[c] = sc ? B.hi[c] + 1 : B.lo[c] - 1;
+  const int cls = classify(L, q[0], q[1], q[2]);
+  if (cls == 0) return;
+  int qa[3] = {q[0], q[1], q[2]}, qc[3] = {q[0], q[1], q[2]};
+  qa[a] += sa ? -1 : 1;
+  qc[c] += sc ? -1 : 1;
+  const bool va = classify(L, qa[0], qa[1], qa[2]) == 0;
+  const bool vc = classify(L, qc[0], qc[1], qc[2]) == 0;
+  if (va == vc) return;  // neither: unused; both: non-fusable level (checked on the host)
+  const int dir = va ? a : c;
+  const int s = va ? (sa ? -1 : 1) : (sc ? -1 : 1);
+  // class of q as a ghost in direction dir: outside the domain along dir -> wall
+  int cl = cls;
+  if (cls == 2) {
+    const bool out_dir = (q[dir] < L.domlo[dir] || q[dir] > L.domhi[dir]) && !L.is_per[dir];
+    if (!out_dir) return;  // outside along the other direction only: the neighbour is not valid either
+  }
+  if (cl == 1 && !A.has_crse) { atomicAdd(nbad, 1); return; }
+  bool ok = true;
+  const double v = bc_ghost_value(L, M, B, b, comp, LC, MC, ccomp, A, q, dir, s, cl, ok);
+  if (!ok) atomicAdd(nbad, 1);
+  M.data[M.off[b] + fab_index(B, M.ng, comp, q[0], q[1], q[2])] = v;
+}
+
+int pa_ensure_red(pa_ctx* ctx, size_t n) {
+  if (ctx->red_cap >= n) return 0;
+  if (ctx->d_red) (void)hipFree(ctx->d_red);
+  ctx->d_red = nullptr;
+  ctx->red_cap = 0;
+  PA_HIP(hipMalloc(&ctx->d_red, n * sizeof(double)));
+  ctx->red_cap = n;
+  return 0;
+}
+
+// number of coarse-fine ghost cells, since the last call, whose coarse data was missing
+// (improper nesting or a level-0 box not covering the domain).  Synchronous; resets the count.
+extern "C" int pa_bc_errors(pa_ctx* ctx) {
+  if (!ctx) return -1;
+  int n = 0;
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipMemcpy(&n, ctx->d_flags, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemset(ctx->d_flags, 0, sizeof(int)) != hipSuccess)
+    return -1;
+  return n;
+}
+
+int pa_apply_bc_impl(pa_ctx* ctx, pa_mf* F, int comp, const pa_mf* C, int ccomp, const int32_t bc[3], int ratio,
+                     int only_dir, int edges) {
+  if (!ctx || !F) return pa_fail(ctx, "pa_apply_bc: null argument");
+  if (F->ng < 1) return pa_fail(ctx, "pa_apply_bc: multifab has no ghost cells");
+  if (comp < 0 || comp >= F->ncomp || (C && (ccomp < 0 || ccomp >= C->ncomp))) return pa_fail(ctx, "pa_apply_bc: component range");
+  if (ratio != 2 && C) return pa_fail(ctx, "pa_apply_bc: only refinement ratio 2 is supported (quirk Q11)");
+  int* nbad = ctx->d_flags;
+  BCArgs A;
+  for (int d = 0; d < 3; ++d) A.bc[d] = bc[d];
+  A.ratio = ratio; A.only_dir = only_dir; A.has_crse = C ? 1 : 0; A.edges = edges;
+  const pa_level* L = F->lev;
+  DLevelView LC = C ? C->lev->view : L->view;
+  DMFView MC = C ? C->view : F->view;
+  const long long n0 = L->maxn[0], n1 = L->maxn[1], n2 = L->maxn[2];
+  if (!edges) {
+    const long long nt = 2 * (n1 * n2 + n0 * n2 + n0 * n1);
+    dim3 grid((unsigned)((nt + 255) / 256), (unsigned)L->boxes.size());
+    hipLaunchKernelGGL(k_apply_bc_faces, grid, dim3(256), 0, ctx->stream, L->view, F->view, comp, LC, MC, ccomp, A, nbad);
+  } else {
+    const long long nt = 4 * (n0 + n1 + n2);
+    dim3 grid((unsigned)((nt + 255) / 256), (unsigned)L->boxes.size());
+    hipLaunchKernelGGL(k_apply_bc_edges, grid, dim3(256), 0, ctx->stream, L->view, F->view, comp, LC, MC, ccomp, A, nbad);
+  }
+  PA_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int pa_apply_bc(pa_ctx* ctx, pa_mf* F, int comp, const pa_mf* C, int ccomp, const int32_t bc[3], int ratio,
+                           int only_dir) {
+  return pa_apply_bc_impl(ctx, F, comp, C, ccomp, bc, ratio, only_dir, 0);
+}

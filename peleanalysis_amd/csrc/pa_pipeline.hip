@@ -1,0 +1,137 @@
+// pa_pipeline.hip -- the level loops of the tool mains (grad.cpp:158-236,
+// curvature.cpp:283-326 + 408-570) on device-resident MultiFabs.  Host orchestration only;
+// every numeric step is a kernel launch through the level-batched entry points.
+#include "pa_internal.h"
+#include <memory>
+
+int pa_apply_bc_impl(pa_ctx* ctx, pa_mf* F, int comp, const pa_mf* C, int ccomp, const int32_t bc[3], int ratio, int only_dir,
+                     int edges);
+
+#define PA_TRY(x)        \
+  do {                   \
+    if ((x) != 0) return 1; \
+  } while (0)
+
+static int check_levels(pa_ctx* ctx, int nlev, pa_mf* const* a, const char* who) {
+  if (!ctx) return 1;
+  if (nlev <= 0 || !a) return pa_fail(ctx, std::string(who) + ": no levels");
+  for (int l = 0; l < nlev; ++l)
+    if (!a[l]) return pa_fail(ctx, std::string(who) + ": null multifab at level " + std::to_string(l));
+  return 0;
+}
+
+extern "C" int pa_grad_run(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, const int32_t bc[3], pa_mf* const* out, int ocomp) {
+  PA_TRY(check_levels(ctx, nlev, state, "pa_grad_run"));
+  PA_TRY(check_levels(ctx, nlev, out, "pa_grad_run"));
+  // grad.cpp:169 FillBoundary on every level, then MLMG getFluxes level by level (applyBC + flux)
+  for (int l = 0; l < nlev; ++l) PA_TRY(pa_fill_boundary(ctx, state[l], comp, 1, 1));
+  for (int l = 0; l < nlev; ++l) {
+    PA_TRY(pa_apply_bc(ctx, state[l], comp, l > 0 ? state[l - 1] : nullptr, comp, bc, 2, -1));
+    PA_TRY(pa_grad_level(ctx, state[l], comp, out[l], ocomp));
+  }
+  return 0;
+}
+
+struct MFDel { void operator()(pa_mf* m) const { pa_mf_destroy(m); } };
+using MFPtr = std::unique_ptr<pa_mf, MFDel>;
+
+static int prog_minmax(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, const pa_curv_params* P, double& pmin, double& pmax) {
+  pmin = P->prog_min;
+  pmax = P->prog_max;
+  if (pmin > pmax) {  // useFileMinMax (curvature.cpp:139-149): min/max over the levels used
+    pmin = 1e300; pmax = -1e300;
+    for (int l = 0; l < nlev; ++l) {
+      double a, b;
+      PA_TRY(pa_minmax_level(ctx, state[l], comp, &a, &b));
+      pmin = a < pmin ? a : pmin;
+      pmax = b > pmax ? b : pmax;
+    }
+  }
+  if (!(pmax > pmin)) return pa_fail(ctx, "progress variable has no range (progMax <= progMin)");
+  return 0;
+}
+
+// pass-by-pass curvature core; out comps: pc (Progress, -1 = skip), kc (MeanCurvature), nc (FlameNormal x3)
+static int curvature_passes(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, const int32_t bc[3], double pmin, double pmax,
+                            double thr, pa_mf* const* out, int pc, int kc, int nc) {
+  std::vector<MFPtr> cmf(nlev), nmf(nlev);
+  for (int l = 0; l < nlev; ++l) {
+    cmf[l].reset(pa_mf_create(ctx, state[l]->lev, 1, 1, nullptr));
+    nmf[l].reset(pa_mf_create(ctx, state[l]->lev, 3, 1, nullptr));
+    if (!cmf[l] || !nmf[l]) return 1;
+    PA_TRY(pa_progress_level(ctx, state[l], comp, pmin, pmax, cmf[l].get(), 0, 0));  // curvature.cpp:316-320
+    PA_TRY(pa_fill_boundary(ctx, cmf[l].get(), 0, 1, 1));                            // :322
+  }
+  for (int l = 0; l < nlev; ++l) {
+    pa_mf* c = cmf[l].get();
+    pa_mf* n = nmf[l].get();
+    PA_TRY(pa_apply_bc(ctx, c, 0, l > 0 ? cmf[l - 1].get() : nullptr, 0, bc, 2, -1));  // :426-457 (inside getFluxes)
+    PA_TRY(pa_normal_level(ctx, c, 0, nullptr, 0, nullptr, 0, n, 0));                   // :457-500
+    PA_TRY(pa_fill_boundary(ctx, n, 0, 3, 1));                                          // :502
+    for (int d = 0; d < 3; ++d)                                                         // :508-531
+      PA_TRY(pa_apply_bc(ctx, n, d, l > 0 ? out[l - 1] : nullptr, nc + d, bc, 2, d));
+    PA_TRY(pa_div_level(ctx, n, 0, 0.5, c, 0, thr, out[l], kc));                        // :533-567
+    if (pc >= 0) PA_TRY(pa_mf_copy(ctx, c, 0, out[l], pc, 1, 0));
+    PA_TRY(pa_mf_copy(ctx, n, 0, out[l], nc, 3, 0));                                    // :569-570
+  }
+  PA_TRY(pa_sync(ctx));  // scratch multifabs are freed on return
+  return 0;
+}
+
+static int fused_passes(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, const int32_t bc[3], double pmin, double pmax, double thr,
+                        pa_mf* const* work, pa_mf* const* out, int ocomp) {
+  for (int l = 0; l < nlev; ++l) {
+    if (state[l]->ng < 2 || work[l]->ng < 2) return pa_fail(ctx, "fused grad->curvature needs 2 ghost layers on state and work");
+    PA_TRY(pa_fill_boundary(ctx, state[l], comp, 1, 2));
+    PA_TRY(pa_progress_level(ctx, state[l], comp, pmin, pmax, work[l], 0, 2));
+  }
+  for (int l = 0; l < nlev; ++l) {
+    const pa_mf* cs = l > 0 ? state[l - 1] : nullptr;
+    const pa_mf* cw = l > 0 ? work[l - 1] : nullptr;
+    PA_TRY(pa_apply_bc(ctx, state[l], comp, cs, comp, bc, 2, -1));
+    PA_TRY(pa_apply_bc_impl(ctx, work[l], 0, cw, 0, bc, 2, -1, 0));
+    PA_TRY(pa_apply_bc_impl(ctx, work[l], 0, cw, 0, bc, 2, -1, 1));
+    PA_TRY(pa_gradcurv_level(ctx, state[l], comp, work[l], 0, thr, out[l], ocomp));
+    PA_TRY(pa_gradcurv_faces_level(ctx, work[l], 0, l > 0 ? out[l - 1] : nullptr, ocomp + 4, bc, 2, thr, out[l], ocomp + 7));
+  }
+  return 0;
+}
+
+static bool all_fusable(int nlev, pa_mf* const* state) {
+  for (int l = 0; l < nlev; ++l) {
+    if (!state[l]->lev->fusable) return false;
+    if (l > 0)
+      for (const DBox& B : state[l]->lev->boxes)
+        for (int d = 0; d < 3; ++d)
+          if (B.hi[d] - B.lo[d] + 1 < 3) return false;
+  }
+  return true;
+}
+
+extern "C" int pa_curvature_run(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, const int32_t bc[3], const pa_curv_params* P,
+                                pa_mf* const* out, int ocomp) {
+  PA_TRY(check_levels(ctx, nlev, state, "pa_curvature_run"));
+  PA_TRY(check_levels(ctx, nlev, out, "pa_curvature_run"));
+  if (!P) return pa_fail(ctx, "pa_curvature_run: null params");
+  double pmin, pmax;
+  PA_TRY(prog_minmax(ctx, nlev, state, comp, P, pmin, pmax));
+  const double thr = P->do_threshold ? P->threshold : -1.0;
+  return curvature_passes(ctx, nlev, state, comp, bc, pmin, pmax, thr, out, ocomp, ocomp + 1, ocomp + 2);
+}
+
+extern "C" int pa_gradcurv_run(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, const int32_t bc[3], const pa_curv_params* P,
+                               pa_mf* const* work, pa_mf* const* out, int ocomp) {
+  PA_TRY(check_levels(ctx, nlev, state, "pa_gradcurv_run"));
+  PA_TRY(check_levels(ctx, nlev, out, "pa_gradcurv_run"));
+  if (!P) return pa_fail(ctx, "pa_gradcurv_run: null params");
+  double pmin, pmax;
+  PA_TRY(prog_minmax(ctx, nlev, state, comp, P, pmin, pmax));
+  const double thr = P->do_threshold ? P->threshold : -1.0;
+  if (P->fused && all_fusable(nlev, state)) {
+    PA_TRY(check_levels(ctx, nlev, work, "pa_gradcurv_run"));
+    return fused_passes(ctx, nlev, state, comp, bc, pmin, pmax, thr, work, out, ocomp);
+  }
+  // general AMR (concave coarse-fine corners, very thin boxes) or fused=0: pass by pass
+  PA_TRY(pa_grad_run(ctx, nlev, state, comp, bc, out, ocomp));
+  return curvature_passes(ctx, nlev, state, comp, bc, pmin, pmax, thr, out, -1, ocomp + 7, ocomp + 4);
+}
