@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: fused grad->curvature over a 512^3-base 3-level AMR hierarchy.
+
+Contract (driver): python bench.py --gpus N --steps K --warmup W ; N>1 is launched by
+torch.distributed.run (one rank per GPU, RCCL).  One "step" = one pass of the hot path
+(ghost fills + fused grad->curvature + coarse-fine/wall face fix-up, every level, every
+component) over synthetic input already resident in HBM.  Prints ONE JSON line on rank 0.
+
+metric  : Mcells/s  = sum over levels of valid cells * ncomp / t   (BASELINE.json)
+roofline: dominant kernel = the fused grad->curvature kernel; achieved = 72 B (read phi once,
+          write gx,gy,gz,|g|,Nx,Ny,Nz,K) * cells per launch / average launch duration, measured
+          with HIP events recorded by the library on its own stream inside the timed region.
+cpu_baseline: the CPU oracle (oracle/, OpenMP over boxes) on a bounded sample of the same
+          workload (a smaller hierarchy of the same shape), timed on this node's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+BYTES_PER_CELL = 72.0  # fused grad->curvature algorithmic bytes per cell per component
+
+
+def torch_field_flame(torch, x, y, z, m):
+    xc, yc, zc = x - 0.5, y - 0.5, z - 0.5
+    r = torch.sqrt((xc / 0.30) ** 2 + (yc / 0.15) ** 2 + (zc / 0.18) ** 2)
+    theta = torch.atan2(yc + 0 * xc, xc + 0 * yc)
+    rho = torch.sqrt(xc * xc + yc * yc + zc * zc) + 1e-30
+    phi = torch.acos(torch.clamp(zc / rho, -1.0, 1.0))
+    s = r - 0.03 * torch.sin(6 * theta) * torch.sin(5 * phi)
+    return (1.0 + 0.1 * m) * (300.0 + 850.0 * (1.0 + torch.tanh((s - 1.0) / 0.08))) + 3.0 * m * torch.sin(2 * np.pi * (x + 0.37 * m))
+
+
+def fill_level_on_device(torch, level, buf, ncomp, ng, off, dev, seed):
+    """synthetic flame field + hash-like noise, written straight into HBM"""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    dx = level.dx
+    for b in range(level.nboxes):
+        lo = level.boxes[b, :3]
+        nz, ny, nx = level.box_shape(b, ng)
+        x = (torch.arange(lo[0] - ng, lo[0] - ng + nx, device=dev, dtype=torch.float64) + 0.5) * dx[0] + level.prob_lo[0]
+        y = (torch.arange(lo[1] - ng, lo[1] - ng + ny, device=dev, dtype=torch.float64) + 0.5) * dx[1] + level.prob_lo[1]
+        z = (torch.arange(lo[2] - ng, lo[2] - ng + nz, device=dev, dtype=torch.float64) + 0.5) * dx[2] + level.prob_lo[2]
+        X, Y, Z = x[None, None, :], y[None, :, None], z[:, None, None]
+        n = nz * ny * nx
+        for c in range(ncomp):
+            v = torch_field_flame(torch, X, Y, Z, c).expand(nz, ny, nx)
+            v = v + 1e-3 * (2.0 * torch.rand((nz, ny, nx), generator=g, device=dev, dtype=torch.float64) - 1.0)
+            buf[off[b] + c * n: off[b] + (c + 1) * n] = v.reshape(-1)
+
+
+def cpu_baseline(base, nlev, box, ncomp_unused):
+    """Oracle (kind 'port') timed on the host cores: same pipeline, smaller hierarchy of the same shape."""
+    from oracle import oracle as O
+    from peleanalysis_amd.hierarchy import MultiFab, fill_analytic, nested_hierarchy, field_flame
+    O.build()
+    H = nested_hierarchy(base, nlev, box, is_per=(1, 1, 0))
+    bc = O.bc_from_flags((1, 1, 0))
+    states = []
+    for lv in H.levels:
+        s = MultiFab(lv, 1, 2)
+        fill_analytic(s, 0, lambda x, y, z: field_flame(x, y, z, 0), valid_only=False)
+        states.append(s)
+    og = [MultiFab(lv, 4, 0) for lv in H.levels]
+    oc = [MultiFab(lv, 5, 0) for lv in H.levels]
+    cells = sum(lv.ncells for lv in H.levels)
+    t0 = time.perf_counter()
+    O.grad_pipeline(H.levels, states, 0, bc, og, 0, multipass=False, omp=True)
+    O.curvature_pipeline(H.levels, states, 0, bc, oc, 0, MultiFab, prog_min=300.0, prog_max=2000.0, omp=True)
+    dt = time.perf_counter() - t0
+    return {"value": cells / dt / 1e6, "unit": "Mcells/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"oracle grad+curvature pipelines (OpenMP over boxes), {nlev}-level base {base}^3, {box}^3 boxes, "
+                      f"{cells} cells, 1 comp, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--base", type=int, default=512, help="base-level cells per direction (headline: 512)")
+    ap.add_argument("--nlev", type=int, default=3)
+    ap.add_argument("--box", type=int, default=128)
+    ap.add_argument("--ncomp", type=int, default=1, help="components pushed through grad->curvature per step")
+    ap.add_argument("--fused", type=int, default=1)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-base", type=int, default=128)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from peleanalysis_amd import capi
+    from peleanalysis_amd.hierarchy import mf_layout, nested_hierarchy
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (the product path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    stream = torch.cuda.Stream(device=dev)
+    ctx = capi.Context(local, stream.cuda_stream)
+
+    # weak scaling: every rank owns one full copy of the headline hierarchy (fixed work per GPU)
+    H = nested_hierarchy(args.base, args.nlev, args.box, is_per=(1, 1, 0))
+    bc = capi.bc_from_flags((1, 1, 0))
+    dls = [capi.DevLevel(ctx, lv) for lv in H.levels]
+    cells = sum(lv.ncells for lv in H.levels)
+    hold = []
+    states, works, outs = [], [], []
+    with torch.cuda.stream(stream):
+        for li, (lv, dl) in enumerate(zip(H.levels, dls)):
+            off, tot = mf_layout(lv.boxes, args.ncomp, 2)
+            tin = torch.empty(tot, dtype=torch.float64, device=dev)
+            fill_level_on_device(torch, lv, tin, args.ncomp, 2, off, dev, 1234 + 100 * rank + li)
+            _, tw = mf_layout(lv.boxes, 1, 2)
+            _, to = mf_layout(lv.boxes, 8, 0)
+            twk = torch.zeros(tw, dtype=torch.float64, device=dev)
+            tout = torch.zeros(to, dtype=torch.float64, device=dev)
+            hold += [tin, twk, tout]
+            states.append(capi.DevMF(ctx, dl, args.ncomp, 2, tin.data_ptr()))
+            works.append(capi.DevMF(ctx, dl, 1, 2, twk.data_ptr()))
+            outs.append(capi.DevMF(ctx, dl, 8, 0, tout.data_ptr()))
+    stream.synchronize()
+    params = capi.curv_params(prog_min=300.0, prog_max=2000.0, threshold=None, fused=bool(args.fused))
+
+    def step():
+        for c in range(args.ncomp):  # output buffers are recycled per component (SURVEY 8d memory budget)
+            capi.gradcurv_run(ctx, states, c, bc, params, works, outs, 0)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ctx.profile_read(1, reset=True)
+    ctx.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    ctx.profile_enable(False)
+    nk, ms_k = ctx.profile_read(1)
+    nf, ms_f = ctx.profile_read(2)
+    nfill, ms_fill = ctx.profile_read(3)
+    nbc, ms_bc = ctx.profile_read(4)
+    nprog, ms_prog = ctx.profile_read(6, reset=True)
+    assert ctx.bc_errors() == 0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    total_cells = cells * args.ncomp * world
+    value = total_cells * args.steps / dt / 1e6
+    res = {
+        "metric": "Mcells/s for grad+curvature on 512^3-base 3-level AMR; % HBM roofline",
+        "value": value, "unit": "Mcells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"fused grad->curvature, {args.nlev}-level AMR, base {args.base}^3, ref_ratio 2, {args.box}^3 boxes "
+                               f"({H.levels[0].nboxes} per level), {args.ncomp} comp(s), periodic x/y + wall z, {cells} cells per GPU",
+                   "cells_per_gpu": cells, "ncomp": args.ncomp, "fused": bool(args.fused),
+                   "parallelism": "1 hierarchy per GPU" if world > 1 else "single GPU"},
+    }
+    if nk:
+        # one launch of the fused kernel = one level = cells/nlev cells (all levels have base^3 cells here)
+        avg_ms = ms_k / nk
+        cells_per_launch = cells / args.nlev
+        ach = cells_per_launch * BYTES_PER_CELL / (avg_ms * 1e-3) / 1e9
+        res["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                           "traffic": None, "kernel": "k_gradcurv (fused grad->curvature)", "avg_launch_ms": avg_ms,
+                           "launches": nk, "bytes_per_cell": BYTES_PER_CELL}
+        res["breakdown_ms_per_step"] = {"gradcurv": ms_k / args.steps, "faces": ms_f / args.steps, "fill_boundary": ms_fill / args.steps,
+                                        "apply_bc": ms_bc / args.steps, "progress": ms_prog / args.steps}
+        res["step_frac_of_hbm_roofline"] = (cells * args.ncomp * BYTES_PER_CELL / (dt / args.steps) / 1e9) / HBM_PEAK_GBS
+    if rank == 0 and world == 1 and not args.no_cpu:
+        try:
+            res["cpu_baseline"] = cpu_baseline(args.cpu_base, args.nlev, max(args.cpu_base // 4, 8), args.ncomp)
+        except Exception as e:  # the baseline is reported, never required for the GPU number
+            res["cpu_baseline"] = {"error": repr(e)}
+    if rank == 0:
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -44,6 +44,13 @@ const char* pa_last_error(const pa_ctx*);
 int         pa_sync(pa_ctx*);
 void*       pa_ctx_stream(pa_ctx*);
 
+/* Per-launch timing of the library's own kernels with HIP events recorded on the
+ * context's stream (what bench.py's roofline object reports).  Tags: 1 fused
+ * grad->curvature, 2 its face fix-up, 3 FillBoundary, 4 applyBC, 5 grad,
+ * 6 progress, 7 box filter, 8 marching cubes.  pa_profile_read is synchronous. */
+int pa_profile_enable(pa_ctx*, int on);
+int pa_profile_read(pa_ctx*, int tag, int64_t* nlaunch, double* total_ms, int reset);
+
 /* ---------------------------------------------------- level = BoxArray+Geometry
  * replaces: amrData.boxArray(lev) / Geometry(ProbDomain, rb, coord, is_per)
  * (grad.cpp:160-163, curvature.cpp:287-291).  dx = (prob_hi-prob_lo)/ncells. */

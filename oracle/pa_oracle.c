@@ -80,6 +80,7 @@ void orc_dxinv(const orc_level* L, double dxinv[3]) {
 /* ------------------------------------------------------------ FillBoundary */
 void orc_fill_boundary(orc_mf* mf, int comp, int ncomp, int ngf) {
   const orc_level* L = mf->lev;
+#pragma omp parallel for schedule(dynamic)
   for (int b = 0; b < L->nboxes; ++b) {
     bx_t B = get_box(L, b);
     int hint = -1;
@@ -192,6 +193,7 @@ int orc_apply_bc(orc_mf* fine, int comp, const orc_mf* crse, int ccomp, const in
                  int only_dir) {
   const orc_level* L = fine->lev;
   int nbad = 0;
+#pragma omp parallel for schedule(dynamic) reduction(+ : nbad)
   for (int b = 0; b < L->nboxes; ++b) {
     bx_t B = get_box(L, b);
     int fhint = b, chint = -1;
@@ -386,6 +388,7 @@ void orc_div_accum(const orc_mf* nd, int comp, int dir, orc_mf* curv, int kcomp)
 
 void orc_setval(orc_mf* mf, int comp, double v) {
   const orc_level* L = mf->lev;
+#pragma omp parallel for schedule(dynamic)
   for (int b = 0; b < L->nboxes; ++b) {
     bx_t B = get_box(L, b);
     for (int k = B.lo[2]; k <= B.hi[2]; ++k)
@@ -396,6 +399,7 @@ void orc_setval(orc_mf* mf, int comp, double v) {
 
 void orc_mult(orc_mf* mf, int comp, double v) {
   const orc_level* L = mf->lev;
+#pragma omp parallel for schedule(dynamic)
   for (int b = 0; b < L->nboxes; ++b) {
     bx_t B = get_box(L, b);
     for (int k = B.lo[2]; k <= B.hi[2]; ++k)
@@ -424,6 +428,7 @@ void orc_threshold(const orc_mf* c, int ccomp, double thr, orc_mf* K, int kcomp,
 
 void orc_copy(const orc_mf* src, int scomp, orc_mf* dst, int dcomp, int ncomp, int ng) {
   const orc_level* L = src->lev;
+#pragma omp parallel for schedule(dynamic)
   for (int b = 0; b < L->nboxes; ++b) {
     bx_t B = get_box(L, b);
     for (int c = 0; c < ncomp; ++c)

@@ -54,6 +54,8 @@ def load_library() -> C.CDLL:
         "pa_last_error": (C.c_char_p, [vp]),
         "pa_sync": (C.c_int, [vp]),
         "pa_ctx_stream": (vp, [vp]),
+        "pa_profile_enable": (C.c_int, [vp, C.c_int]),
+        "pa_profile_read": (C.c_int, [vp, C.c_int, C.POINTER(i64), pdbl, C.c_int]),
         "pa_level_create": (vp, [vp, C.c_int, pi32, pi32, pi32, pi32, pdbl, pdbl]),
         "pa_level_destroy": (None, [vp]),
         "pa_level_nboxes": (C.c_int, [vp]),
@@ -96,11 +98,17 @@ def load_library() -> C.CDLL:
         "pa_gradcurv_run": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.c_int, pi32, C.POINTER(PaCurvParams), C.POINTER(vp), C.POINTER(vp),
                                       C.c_int]),
     }
+    missing = []
     for name, (res, args) in sig.items():
-        fn = getattr(L, name)  # AttributeError = symbol missing from the .so
+        try:
+            fn = getattr(L, name)
+        except AttributeError:  # symbol missing from the .so: calling it later raises AttributeError
+            missing.append(name)
+            continue
         fn.restype = res
         fn.argtypes = args
     L._pa_signatures = sig
+    L._pa_missing = missing  # tests/test_abi.py asserts this is empty
     _lib = L
     return L
 
@@ -138,6 +146,14 @@ class Context:
 
     def sync(self):
         self.check(self.lib.pa_sync(self.h))
+
+    def profile_enable(self, on: bool = True):
+        self.check(self.lib.pa_profile_enable(self.h, int(on)))
+
+    def profile_read(self, tag: int, reset: bool = False):
+        n, ms = C.c_int64(0), C.c_double(0.0)
+        self.check(self.lib.pa_profile_read(self.h, tag, C.byref(n), C.byref(ms), int(reset)))
+        return n.value, ms.value
 
     def bc_errors(self) -> int:
         return int(self.lib.pa_bc_errors(self.h))

@@ -37,8 +37,35 @@ extern "C" void pa_ctx_destroy(pa_ctx* ctx) {
   if (!ctx) return;
   if (ctx->d_red) (void)hipFree(ctx->d_red);
   if (ctx->d_flags) (void)hipFree(ctx->d_flags);
+  for (auto& e : ctx->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
+}
+
+extern "C" int pa_profile_enable(pa_ctx* ctx, int on) {
+  if (!ctx) return 1;
+  ctx->profile = on != 0;
+  return 0;
+}
+
+// sum of the durations (ms) of all launches recorded under `tag` since the last reset; synchronous
+extern "C" int pa_profile_read(pa_ctx* ctx, int tag, int64_t* nlaunch, double* total_ms, int reset) {
+  if (!ctx || !nlaunch || !total_ms) return 1;
+  PA_HIP(hipStreamSynchronize(ctx->stream));
+  *nlaunch = 0;
+  *total_ms = 0.0;
+  for (auto& e : ctx->evs) {
+    if (e.tag != tag) continue;
+    float ms = 0.f;
+    PA_HIP(hipEventElapsedTime(&ms, e.a, e.b));
+    *total_ms += ms;
+    ++*nlaunch;
+  }
+  if (reset) {
+    for (auto& e : ctx->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    ctx->evs.clear();
+  }
+  return 0;
 }
 
 extern "C" const char* pa_last_error(const pa_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
@@ -385,6 +412,7 @@ extern "C" int pa_fill_boundary(pa_ctx* ctx, pa_mf* M, int comp, int ncomp, int 
       return pa_fail(ctx, "pa_fill_boundary: ng larger than the periodic domain");
   const long long ms = max_shell(M->lev, ng);
   dim3 grid((unsigned)((ms + 255) / 256), (unsigned)M->lev->boxes.size());
+  ProfScope prof(ctx, PA_TAG_FILL);
   hipLaunchKernelGGL(k_fill_boundary, grid, dim3(256), 0, ctx->stream, M->lev->view, M->view, comp, ncomp, ng);
   PA_HIP(hipGetLastError());
   return 0;
@@ -541,6 +569,7 @@ int pa_apply_bc_impl(pa_ctx* ctx, pa_mf* F, int comp, const pa_mf* C, int ccomp,
   DLevelView LC = C ? C->lev->view : L->view;
   DMFView MC = C ? C->view : F->view;
   const long long n0 = L->maxn[0], n1 = L->maxn[1], n2 = L->maxn[2];
+  ProfScope prof(ctx, PA_TAG_BC);
   if (!edges) {
     const long long nt = 2 * (n1 * n2 + n0 * n2 + n0 * n1);
     dim3 grid((unsigned)((nt + 255) / 256), (unsigned)L->boxes.size());

@@ -187,6 +187,7 @@ extern "C" int pa_gradcurv_faces_level(pa_ctx* ctx, const pa_mf* c, int ccomp, c
   const long long n0 = L->maxn[0], n1 = L->maxn[1], n2 = L->maxn[2];
   const long long nt = 2 * (n1 * n2 + n0 * n2 + n0 * n1);
   dim3 grid((unsigned)((nt + 255) / 256), (unsigned)L->boxes.size());
+  ProfScope prof(ctx, PA_TAG_GRADCURV_FACES);
   hipLaunchKernelGGL(k_gradcurv_faces, grid, dim3(256), 0, ctx->stream, L->view, c->view, ccomp, crse_n ? crse_n->lev->view : L->view,
                      crse_n ? crse_n->view : c->view, cncomp0, out->view, kcomp, A, ctx->d_flags);
   PA_HIP(hipGetLastError());
@@ -195,6 +196,7 @@ extern "C" int pa_gradcurv_faces_level(pa_ctx* ctx, const pa_mf* c, int ccomp, c
 
 int pa_gradcurv_launch(pa_ctx* ctx, const pa_mf* phi, int pcomp, const pa_mf* c, int ccomp, double thr, pa_mf* out, int ocomp) {
   LevelBP4 bp{phi->lev->view, phi->view, c->view, out->view, out->view};
+  ProfScope prof(ctx, PA_TAG_GRADCURV);
   hipLaunchKernelGGL(k_gradcurv_naive<LevelBP4>, tile_grid(phi->lev), dim3(256), 0, ctx->stream, bp, pcomp, ccomp, ocomp, thr);
   PA_HIP(hipGetLastError());
   return 0;

@@ -34,7 +34,31 @@ struct pa_ctx {
   double* d_red = nullptr;  // reduction scratch
   size_t red_cap = 0;
   int* d_flags = nullptr;   // [0] = coarse-fine ghost cells whose coarse data was missing
+  // optional per-launch timing of tagged kernels with HIP events on ctx->stream (bench.py roofline)
+  bool profile = false;
+  struct Ev { hipEvent_t a, b; int tag; };
+  std::vector<Ev> evs;
 };
+
+// RAII: records an event pair around a tagged kernel launch when profiling is enabled
+struct ProfScope {
+  pa_ctx* ctx;
+  pa_ctx::Ev e;
+  bool on;
+  ProfScope(pa_ctx* c, int tag) : ctx(c), on(c->profile) {
+    if (!on) return;
+    e.tag = tag;
+    if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) { on = false; return; }
+    (void)hipEventRecord(e.a, ctx->stream);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(e.b, ctx->stream);
+    ctx->evs.push_back(e);
+  }
+};
+enum { PA_TAG_GRADCURV = 1, PA_TAG_GRADCURV_FACES = 2, PA_TAG_FILL = 3, PA_TAG_BC = 4, PA_TAG_GRAD = 5, PA_TAG_PROGRESS = 6,
+       PA_TAG_FILTER = 7, PA_TAG_MC = 8 };
 
 struct pa_level {
   pa_ctx* ctx = nullptr;

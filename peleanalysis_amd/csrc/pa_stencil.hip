@@ -37,6 +37,7 @@ extern "C" int pa_grad_level(pa_ctx* ctx, const pa_mf* phi, int comp, pa_mf* out
   if (phi->ng < 1) return pa_fail(ctx, "pa_grad_level: phi needs >= 1 ghost layer");
   if (comp < 0 || comp >= phi->ncomp || ocomp < 0 || ocomp + 4 > out->ncomp) return pa_fail(ctx, "pa_grad_level: component range");
   LevelBP2 bp{phi->lev->view, phi->view, out->view};
+  ProfScope prof(ctx, PA_TAG_GRAD);
   hipLaunchKernelGGL(k_grad<LevelBP2>, tile_grid(phi->lev), dim3(256), 0, ctx->stream, bp, comp, ocomp);
   PA_HIP(hipGetLastError());
   return 0;
@@ -121,6 +122,7 @@ extern "C" int pa_progress_level(pa_ctx* ctx, const pa_mf* s, int comp, double p
   if (ng > s->ng || ng > c->ng || comp >= s->ncomp || ccomp >= c->ncomp) return pa_fail(ctx, "pa_progress_level: ng/component range");
   const double invdenom = 1.0 / (pmax - pmin);  // curvature.cpp:315 (quirk Q13: multiply, not divide)
   LevelBP2 bp{s->lev->view, s->view, c->view, ng};
+  ProfScope prof(ctx, PA_TAG_PROGRESS);
   hipLaunchKernelGGL(k_progress<LevelBP2>, tile_grid(s->lev, ng), dim3(256), 0, ctx->stream, bp, comp, ccomp, pmin, invdenom);
   PA_HIP(hipGetLastError());
   return 0;
