@@ -11,6 +11,8 @@
 // K for those cells only.
 #include "pa_internal.h"
 #include "pa_fabview.h"
+#include "pa_fused_march.h"
+#include <cstdlib>
 
 struct Vec3 { double x, y, z; };
 
@@ -194,10 +196,40 @@ extern "C" int pa_gradcurv_faces_level(pa_ctx* ctx, const pa_mf* c, int ccomp, c
   return 0;
 }
 
+// tuning knobs (environment, read once): PA_FUSED_VARIANT=naive|march, PA_KSEG=<planes per workgroup>
+static int fused_variant() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("PA_FUSED_VARIANT");
+    v = (e && std::string(e) == "naive") ? 0 : 1;
+  }
+  return v;
+}
+static int fused_kseg() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("PA_KSEG");
+    v = e ? atoi(e) : 64;
+    if (v < 4) v = 4;
+  }
+  return v;
+}
+static dim3 march_grid(int nx, int ny, int nz, int kseg, unsigned nboxes) {
+  const unsigned tx = (nx + 63) / 64, ty = (ny + PA_MTY - 1) / PA_MTY, tz = (nz + kseg - 1) / kseg;
+  return dim3(tx * ty * tz, nboxes);
+}
+
 int pa_gradcurv_launch(pa_ctx* ctx, const pa_mf* phi, int pcomp, const pa_mf* c, int ccomp, double thr, pa_mf* out, int ocomp) {
   LevelBP4 bp{phi->lev->view, phi->view, c->view, out->view, out->view};
   ProfScope prof(ctx, PA_TAG_GRADCURV);
-  hipLaunchKernelGGL(k_gradcurv_naive<LevelBP4>, tile_grid(phi->lev), dim3(256), 0, ctx->stream, bp, pcomp, ccomp, ocomp, thr);
+  const pa_level* L = phi->lev;
+  if (fused_variant() == 0) {
+    hipLaunchKernelGGL(k_gradcurv_naive<LevelBP4>, tile_grid(L), dim3(256), 0, ctx->stream, bp, pcomp, ccomp, ocomp, thr);
+  } else {
+    const int kseg = fused_kseg();
+    hipLaunchKernelGGL(k_gradcurv_march<LevelBP4>, march_grid(L->maxn[0], L->maxn[1], L->maxn[2], kseg, (unsigned)L->boxes.size()),
+                       dim3(64 * PA_MNW), 0, ctx->stream, bp, pcomp, ccomp, ocomp, thr, kseg);
+  }
   PA_HIP(hipGetLastError());
   return 0;
 }
@@ -209,7 +241,14 @@ extern "C" int pa_gradcurv_fab(pa_ctx* ctx, pa_box valid, const pa_fab* phi, int
   if (!fab_covers(*phi, valid, 1, pcomp, 1, why) || !fab_covers(*c, valid, 2, ccomp, 1, why) || !fab_covers(*out, valid, 0, ocomp, 8, why))
     return pa_fail(ctx, "pa_gradcurv_fab: " + why);
   FabBP4 bp{fab_view(*phi), fab_view(*c), fab_view(*out), fab_view(*out), to_dbox(valid), {dxinv[0], dxinv[1], dxinv[2]}};
-  hipLaunchKernelGGL(k_gradcurv_naive<FabBP4>, tile_grid(valid), dim3(256), 0, ctx->stream, bp, pcomp, ccomp, ocomp, thr);
+  if (fused_variant() == 0) {
+    hipLaunchKernelGGL(k_gradcurv_naive<FabBP4>, tile_grid(valid), dim3(256), 0, ctx->stream, bp, pcomp, ccomp, ocomp, thr);
+  } else {
+    const int kseg = fused_kseg();
+    hipLaunchKernelGGL(k_gradcurv_march<FabBP4>,
+                       march_grid(valid.hi[0] - valid.lo[0] + 1, valid.hi[1] - valid.lo[1] + 1, valid.hi[2] - valid.lo[2] + 1, kseg, 1),
+                       dim3(64 * PA_MNW), 0, ctx->stream, bp, pcomp, ccomp, ocomp, thr, kseg);
+  }
   PA_HIP(hipGetLastError());
   return 0;
 }

@@ -1,0 +1,211 @@
+// pa_fused_march.h -- fused grad->curvature, "k-marching" kernel for gfx950.
+//
+// Workgroup = MTY+3 wavefronts over a tile of 64 (x) x MTY (y) columns that marches through
+// kseg z-planes:
+//   waves 0..MTY+1  one row each: rows j0-1 .. j0+MTY.  Output rows produce the 8 results; the two
+//                   outer ("halo") rows only supply c / phi / n_y to their neighbours,
+//   wave  MTY+2     the "edge" wave: the columns left/right of the tile (c, phi, n_x only).
+// Each thread owns one (i,j) column.  z-neighbours of c, phi and n_z live in registers (rolling
+// queues fed by ONE coalesced global load per array and plane, issued one plane ahead);
+// x/y-neighbours of c, phi, n_x, n_y go through a 3-slot LDS ring with ONE barrier per plane.
+// The flame normal is therefore evaluated ~1.4x per cell instead of 7x (direct form), never
+// touches HBM, and every input cell is read from global memory once per tile (+ halo).
+//
+// The per-role loops are branch-free around global memory operations (lanes past the box edge
+// mirror the last valid lane instead of being masked) so that hipcc can count the outstanding
+// loads/stores and keep the prefetched plane in flight across the barrier (s_waitcnt vmcnt(N)
+// instead of vmcnt(0)).
+//
+// Arithmetic order is the reference's (cdiff, normal_from): results are bit-identical to the
+// pass-by-pass path and to the CPU oracle.
+#pragma once
+#include "pa_fabview.h"
+
+#define PA_MTY 8
+#define PA_MROWS (PA_MTY + 2)
+#define PA_MNW (PA_MTY + 3)
+#define PA_MLW 66
+
+__device__ __forceinline__ void normal_from(double cl, double cr, double cs, double cn, double cm, double cc, double cp,
+                                            const double dxinv[3], double& nx, double& ny, double& nz) {
+  const double gx = cdiff(dxinv[0], cl, cc, cr);
+  const double gy = cdiff(dxinv[1], cs, cc, cn);
+  const double gz = cdiff(dxinv[2], cm, cc, cp);
+  const double sn = sqrt(gx * gx + gy * gy + gz * gz);
+  const double ng = -((1e-14 < sn) ? sn : 1e-14);
+  nx = gx / ng;
+  ny = gy / ng;
+  nz = gz / ng;
+}
+
+struct MarchLds {
+  double c[3][PA_MROWS][PA_MLW];   // c: x index 0 = left edge column, 1..64 = lanes, llast+2 = right edge column
+  double p[3][PA_MROWS][PA_MLW];   // phi
+  double nx[3][PA_MTY][PA_MLW];    // n_x of rows 1..MTY (+ edge columns)
+  double ny[3][PA_MROWS][64];      // n_y
+};
+
+template <typename BP>
+__global__ __launch_bounds__(64 * PA_MNW) void k_gradcurv_march(BP bp, int pcomp, int ccomp, int ocomp, double thr, int kseg) {
+  FabView P, C, O, unused;
+  DBox V;
+  double dxinv[3];
+  if (!bp.get(blockIdx.y, P, C, O, unused, V, dxinv)) return;
+  const int nx = V.hi[0] - V.lo[0] + 1, ny = V.hi[1] - V.lo[1] + 1, nz = V.hi[2] - V.lo[2] + 1;
+  const int tx = (nx + 63) / 64, ty = (ny + PA_MTY - 1) / PA_MTY, tz = (nz + kseg - 1) / kseg;
+  const unsigned bid = blockIdx.x;
+  if (bid >= (unsigned)tx * ty * tz) return;  // uniform for the whole workgroup
+  const int bx = bid % tx, by = (bid / tx) % ty, bz = bid / (tx * ty);
+  const int i0 = V.lo[0] + bx * 64, j0 = V.lo[1] + by * PA_MTY;
+  const int k0 = V.lo[2] + bz * kseg, k1 = min(k0 + kseg - 1, V.hi[2]);
+  const int iR = min(i0 + 64, V.hi[0] + 1);  // column right of the tile's last valid column
+  const int llast = iR - 1 - i0;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int rtop = min(PA_MROWS - 1, V.hi[1] + 1 - j0 + 1);  // row slot of the last live row (j = min(j0+MTY, hi_y+1))
+
+  __shared__ MarchLds S;
+  const long long cps = (long long)C.nx * C.ny, pps = (long long)P.nx * P.ny;  // plane strides
+  const int niter = k1 - k0 + 3;                                               // planes k0-1 .. k1+1
+
+  if (w < PA_MROWS && w > rtop) {
+    // ---------------------------------------------------------------- dead row (partial tile)
+    for (int it = 0; it <= niter; ++it) __syncthreads();
+    return;
+  }
+
+  if (w < PA_MROWS) {
+    // ------------------------------------------------------------------------- row waves
+    const int rr = w;
+    const int j = j0 + rr - 1;
+    const int le = min(lane, llast);  // lanes past the box edge mirror the last valid lane
+    const int i = i0 + le;
+    const int xs = le + 1;
+    const bool halo = (rr == 0) || (rr == rtop);  // supplies neighbours only; one y-neighbour comes from global
+    const double* gc = C.p + C.idx(i, j, k0 - 2, ccomp);
+    const double* gp = P.p + P.idx(i, j, k0 - 1, pcomp);
+    double cm = gc[0], cc = gc[cps], cp = gc[2 * cps], cn2;
+    gc += 2 * cps;  // -> c(k0)
+    double pm = 0, pc = 0, pnew = gp[0], pn;
+    S.c[0][rr][xs] = cc;
+    if (halo) {
+      const int jout = (rr == 0) ? j - 1 : j + 1;
+      const double* go = C.p + C.idx(i, jout, k0 - 1, ccomp);
+      double co = go[0], con;
+      __syncthreads();
+      int sp = 0;
+      for (int p = k0 - 1; p <= k1 + 1; ++p) {
+        const int sp1 = (sp == 2) ? 0 : sp + 1;
+        const long long ci = (p <= k1) ? cps : 0, pi = (p <= k1) ? pps : 0;  // clamp the prefetch on the last plane
+        gc += ci; go += ci; gp += pi;
+        cn2 = gc[0]; con = go[0]; pn = gp[0];
+        const double cl = S.c[sp][rr][xs - 1], cr = S.c[sp][rr][xs + 1];
+        const double cin = S.c[sp][(rr == 0) ? 1 : rr - 1][xs];
+        const double cs = (rr == 0) ? co : cin, cn = (rr == 0) ? cin : co;
+        double nxp, nyp, nzp;
+        normal_from(cl, cr, cs, cn, cm, cc, cp, dxinv, nxp, nyp, nzp);
+        S.ny[sp][rr][lane] = nyp;
+        S.c[sp1][rr][xs] = cp;
+        S.p[sp][rr][xs] = pnew;
+        __syncthreads();
+        cm = cc; cc = cp; cp = cn2; co = con; pnew = pn;
+        sp = sp1;
+      }
+      return;
+    }
+    // output rows
+    __syncthreads();
+    double nxq = 0, nyq = 0, nzq = 0, nzqm = 0;
+    double* op = O.p + O.idx(i, j, k0, ocomp);
+    const long long ops = (long long)O.nx * O.ny, osc = O.sc;
+    int sp = 0;
+    // normal at plane p, outputs at plane q = p-1.  The first two planes (p = k0-1, k0) have no
+    // output yet: their (meaningless) results are stored to plane k0 and overwritten, in program
+    // order by the same thread, when p = k0+1.  This keeps the loop free of branches around
+    // global memory operations so that the prefetched plane stays in flight (vmcnt(N), N > 0).
+#pragma unroll 1
+    for (int p = k0 - 1; p <= k1 + 1; ++p) {
+      const int sp1 = (sp == 2) ? 0 : sp + 1;
+      const int sq = (sp == 0) ? 2 : sp - 1;
+      const long long ci = (p <= k1) ? cps : 0, pi = (p <= k1) ? pps : 0;
+      gc += ci; gp += pi;
+      cn2 = gc[0]; pn = gp[0];
+      const double cl = S.c[sp][rr][xs - 1], cr = S.c[sp][rr][xs + 1];
+      const double cs = S.c[sp][rr - 1][xs], cn = S.c[sp][rr + 1][xs];
+      double nxp, nyp, nzp;
+      normal_from(cl, cr, cs, cn, cm, cc, cp, dxinv, nxp, nyp, nzp);
+      S.ny[sp][rr][lane] = nyp;
+      S.nx[sp][rr - 1][xs] = nxp;
+      S.c[sp1][rr][xs] = cp;
+      S.p[sp][rr][xs] = pnew;
+      __syncthreads();
+      const double nxl = S.nx[sq][rr - 1][xs - 1], nxr = S.nx[sq][rr - 1][xs + 1];
+      const double nys = S.ny[sq][rr - 1][lane], nyn = S.ny[sq][rr + 1][lane];
+      double curv = 0.0;
+      curv += cdiff(dxinv[0], nxl, nxq, nxr);
+      curv += cdiff(dxinv[1], nys, nyq, nyn);
+      curv += cdiff(dxinv[2], nzqm, nzq, nzp);
+      curv = curv * 0.5;
+      // phi gradient at plane q (pc = phi(q), pm = phi(q-1), pnew = phi(q+1))
+      const double pl = S.p[sq][rr][xs - 1], pr = S.p[sq][rr][xs + 1];
+      const double ps = S.p[sq][rr - 1][xs], pnn = S.p[sq][rr + 1][xs];
+      const double gx = cdiff(dxinv[0], pl, pc, pr);
+      const double gy = cdiff(dxinv[1], ps, pc, pnn);
+      const double gz = cdiff(dxinv[2], pm, pc, pnew);
+      // threshold clip (curvature.cpp:557-566); cm = c at plane q.  thr < 0 never clips.
+      const bool clip = (thr >= 0.0) && ((cm < thr) || (cm > 1.0 - thr));
+      op[0] = gx;
+      op[osc] = gy;
+      op[2 * osc] = gz;
+      op[3 * osc] = sqrt(gx * gx + gy * gy + gz * gz);
+      op[4 * osc] = clip ? 0.0 : nxq;
+      op[5 * osc] = clip ? 0.0 : nyq;
+      op[6 * osc] = clip ? 0.0 : nzq;
+      op[7 * osc] = clip ? 0.0 : curv;
+      op += (p > k0) ? ops : 0;
+      cm = cc; cc = cp; cp = cn2;
+      pm = pc; pc = pnew; pnew = pn;
+      nzqm = nzq; nxq = nxp; nyq = nyp; nzq = nzp;
+      sp = sp1;
+    }
+    return;
+  }
+
+  // ----------------------------------------------------------------------------- edge wave
+  {
+    const int l20 = lane % (2 * PA_MROWS);  // idle lanes mirror the active ones
+    const int rr = min(l20 >> 1, rtop);
+    const int side = l20 & 1;
+    const int j = j0 + rr - 1;
+    const int i = side ? iR : i0 - 1;
+    const int xs = side ? llast + 2 : 0;
+    const int xin = side ? llast + 1 : 1;  // the tile column next to this edge column
+    const int rlo = max(rr - 1, 0), rhi = min(rr + 1, PA_MROWS - 1);
+    const bool has_n = (rr >= 1 && rr <= PA_MTY);
+    const double* gc = C.p + C.idx(i, j, k0 - 2, ccomp);
+    const double* go = C.p + C.idx(side ? i + 1 : i - 1, j, k0 - 1, ccomp);
+    const double* gp = P.p + P.idx(i, j, k0 - 1, pcomp);
+    double cm = gc[0], cc = gc[cps], cp = gc[2 * cps], cn2;
+    gc += 2 * cps;
+    double co = go[0], con, pnew = gp[0], pn;
+    S.c[0][rr][xs] = cc;
+    __syncthreads();
+    int sp = 0;
+    for (int p = k0 - 1; p <= k1 + 1; ++p) {
+      const int sp1 = (sp == 2) ? 0 : sp + 1;
+      const long long ci = (p <= k1) ? cps : 0, pi = (p <= k1) ? pps : 0;
+      gc += ci; go += ci; gp += pi;
+      cn2 = gc[0]; con = go[0]; pn = gp[0];
+      const double inner = S.c[sp][rr][xin];
+      const double cl = side ? inner : co, cr = side ? co : inner;
+      const double cs = S.c[sp][rlo][xs], cn = S.c[sp][rhi][xs];
+      double nxp, nyp, nzp;
+      normal_from(cl, cr, cs, cn, cm, cc, cp, dxinv, nxp, nyp, nzp);
+      if (has_n) S.nx[sp][rr - 1][xs] = nxp;
+      S.c[sp1][rr][xs] = cp;
+      S.p[sp][rr][xs] = pnew;
+      __syncthreads();
+      cm = cc; cc = cp; cp = cn2; co = con; pnew = pn;
+      sp = sp1;
+    }
+  }
+}
