@@ -38,7 +38,7 @@ def torch_field_flame(torch, x, y, z, m):
     return (1.0 + 0.1 * m) * (300.0 + 850.0 * (1.0 + torch.tanh((s - 1.0) / 0.08))) + 3.0 * m * torch.sin(2 * np.pi * (x + 0.37 * m))
 
 
-def fill_level_on_device(torch, level, buf, ncomp, ng, off, dev, seed):
+def fill_level_on_device(torch, level, buf, ncomp, ng, off, cs, dev, seed):
     """synthetic flame field + hash-like noise, written straight into HBM"""
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
@@ -54,7 +54,7 @@ def fill_level_on_device(torch, level, buf, ncomp, ng, off, dev, seed):
         for c in range(ncomp):
             v = torch_field_flame(torch, X, Y, Z, c).expand(nz, ny, nx)
             v = v + 1e-3 * (2.0 * torch.rand((nz, ny, nx), generator=g, device=dev, dtype=torch.float64) - 1.0)
-            buf[off[b] + c * n: off[b] + (c + 1) * n] = v.reshape(-1)
+            buf[off[b] + c * cs[b]: off[b] + c * cs[b] + n] = v.reshape(-1)
 
 
 def cpu_baseline(base, nlev, box, ncomp_unused):
@@ -123,11 +123,11 @@ def main():
     states, works, outs = [], [], []
     with torch.cuda.stream(stream):
         for li, (lv, dl) in enumerate(zip(H.levels, dls)):
-            off, tot = mf_layout(lv.boxes, args.ncomp, 2)
-            tin = torch.empty(tot, dtype=torch.float64, device=dev)
-            fill_level_on_device(torch, lv, tin, args.ncomp, 2, off, dev, 1234 + 100 * rank + li)
-            _, tw = mf_layout(lv.boxes, 1, 2)
-            _, to = mf_layout(lv.boxes, 8, 0)
+            off, cs, tot = mf_layout(lv.boxes, args.ncomp, 2)
+            tin = torch.zeros(tot, dtype=torch.float64, device=dev)
+            fill_level_on_device(torch, lv, tin, args.ncomp, 2, off, cs, dev, 1234 + 100 * rank + li)
+            _, _, tw = mf_layout(lv.boxes, 1, 2)
+            _, _, to = mf_layout(lv.boxes, 8, 0)
             twk = torch.zeros(tw, dtype=torch.float64, device=dev)
             tout = torch.zeros(to, dtype=torch.float64, device=dev)
             hold += [tin, twk, tout]

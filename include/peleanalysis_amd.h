@@ -29,8 +29,9 @@ typedef struct pa_ctx pa_ctx;     /* device, stream, error text, scratch */
 typedef struct pa_level pa_level; /* BoxArray + Geometry of one AMR level (host + device copies) */
 typedef struct pa_mf pa_mf;       /* MultiFab: ncomp x (boxes grown by ng) doubles in HBM */
 
-/* mirrors amrex::Array4 / FArrayBox: p = device pointer, lo/hi incl. ghosts */
-typedef struct { double* p; int32_t lo[3]; int32_t hi[3]; int32_t ncomp; } pa_fab;
+/* mirrors amrex::Array4 / FArrayBox: p = device pointer, lo/hi incl. ghosts, nstride = component
+ * stride in doubles (Array4::nstride; 0 = contiguous nx*ny*nz like a plain FArrayBox) */
+typedef struct { double* p; int32_t lo[3]; int32_t hi[3]; int32_t ncomp; int64_t nstride; } pa_fab;
 typedef struct { int32_t lo[3]; int32_t hi[3]; } pa_box;
 
 /* LinOpBCType subset used by grad.cpp:180-193 / curvature.cpp:428-441 */
@@ -61,10 +62,12 @@ void      pa_level_destroy(pa_level*);
 int       pa_level_nboxes(const pa_level*);
 
 /* -------------------------------------------------------------- MultiFab
- * pa_mf_layout is pure host arithmetic (no GPU): offsets (in doubles) of each
- * box in the flat buffer, returns the total size in doubles.
+ * pa_mf_layout is pure host arithmetic (no GPU): offset (in doubles) of each box in the flat
+ * buffer and its component stride (>= nx*ny*nz incl. ghosts: rounded up to 512 B and kept off
+ * multiples of 16 KiB so that the components of one cell do not share an HBM channel); returns
+ * the total size in doubles.  Inside a component the layout is the FArrayBox one ([k][j][i]).
  * replaces: MultiFab(ba, dm, ncomp, ngrow) (grad.cpp:164, curvature.cpp:294). */
-int64_t pa_mf_layout(int nboxes, const int32_t* boxes6, int ncomp, int ng, int64_t* off);
+int64_t pa_mf_layout(int nboxes, const int32_t* boxes6, int ncomp, int ng, int64_t* off, int64_t* cstride);
 pa_mf*  pa_mf_create(pa_ctx*, const pa_level*, int ncomp, int ng, double* devptr /* NULL: library allocates */);
 void    pa_mf_destroy(pa_mf*);
 double* pa_mf_data(pa_mf*);

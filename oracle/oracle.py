@@ -30,7 +30,7 @@ class _Level(C.Structure):
 
 class _MF(C.Structure):
     _fields_ = [("lev", C.POINTER(_Level)), ("ncomp", C.c_int32), ("ng", C.c_int32), ("data", C.POINTER(C.c_double)),
-                ("off", C.POINTER(C.c_int64))]
+                ("off", C.POINTER(C.c_int64)), ("cstride", C.POINTER(C.c_int64))]
 
 
 def build(force: bool = False) -> None:
@@ -72,11 +72,14 @@ def _mf(mf):
         return None
     lv = _lv(mf.level)
     s = _MF()
-    s._keep = (lv, mf.data, mf.off)
+    off = np.ascontiguousarray(mf.off, dtype=np.int64)
+    cs = np.ascontiguousarray(mf.cstride, dtype=np.int64)
+    s._keep = (lv, mf.data, off, cs)
     s.lev = C.pointer(lv)
     s.ncomp = mf.ncomp; s.ng = mf.ng
     s.data = mf.data.ctypes.data_as(C.POINTER(C.c_double))
-    s.off = np.ascontiguousarray(mf.off, dtype=np.int64).ctypes.data_as(C.POINTER(C.c_int64))
+    s.off = off.ctypes.data_as(C.POINTER(C.c_int64))
+    s.cstride = cs.ctypes.data_as(C.POINTER(C.c_int64))
     return s
 
 

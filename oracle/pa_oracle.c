@@ -26,8 +26,8 @@ static inline bx_t get_box(const orc_level* L, int b) {
 
 static inline int64_t mf_index(const orc_mf* m, const bx_t* B, int b, int c, int i, int j, int k) {
   const int ng = m->ng;
-  const int64_t nx = B->n[0] + 2 * ng, ny = B->n[1] + 2 * ng, nz = B->n[2] + 2 * ng;
-  return m->off[b] + ((c * nz + (k - B->lo[2] + ng)) * ny + (j - B->lo[1] + ng)) * nx + (i - B->lo[0] + ng);
+  const int64_t nx = B->n[0] + 2 * ng, ny = B->n[1] + 2 * ng;
+  return m->off[b] + (int64_t)c * m->cstride[b] + ((int64_t)(k - B->lo[2] + ng) * ny + (j - B->lo[1] + ng)) * nx + (i - B->lo[0] + ng);
 }
 #define AT(m, B, b, c, i, j, k) ((m)->data[mf_index((m), (B), (b), (c), (i), (j), (k))])
 

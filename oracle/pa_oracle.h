@@ -42,6 +42,7 @@ typedef struct {
   int32_t ncomp, ng;
   double* data;
   const int64_t* off; /* [nboxes] offset of box b in doubles */
+  const int64_t* cstride; /* [nboxes] component stride in doubles (>= cells incl. ghosts) */
 } orc_mf;
 
 /* boundary-condition types per dimension (lo == hi in the reference tools) */

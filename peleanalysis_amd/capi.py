@@ -21,7 +21,7 @@ BC_PERIODIC, BC_NEUMANN, BC_REFLECT_ODD = 0, 1, 2
 
 
 class PaFab(C.Structure):
-    _fields_ = [("p", C.c_void_p), ("lo", C.c_int32 * 3), ("hi", C.c_int32 * 3), ("ncomp", C.c_int32)]
+    _fields_ = [("p", C.c_void_p), ("lo", C.c_int32 * 3), ("hi", C.c_int32 * 3), ("ncomp", C.c_int32), ("nstride", C.c_int64)]
 
 
 class PaBox(C.Structure):
@@ -59,7 +59,7 @@ def load_library() -> C.CDLL:
         "pa_level_create": (vp, [vp, C.c_int, pi32, pi32, pi32, pi32, pdbl, pdbl]),
         "pa_level_destroy": (None, [vp]),
         "pa_level_nboxes": (C.c_int, [vp]),
-        "pa_mf_layout": (i64, [C.c_int, pi32, C.c_int, C.c_int, C.POINTER(i64)]),
+        "pa_mf_layout": (i64, [C.c_int, pi32, C.c_int, C.c_int, C.POINTER(i64), C.POINTER(i64)]),
         "pa_mf_create": (vp, [vp, vp, C.c_int, C.c_int, vp]),
         "pa_mf_destroy": (None, [vp]),
         "pa_mf_data": (vp, [vp]),
@@ -209,8 +209,9 @@ class DevMF:
     def fab(self, b: int) -> PaFab:
         """pa_fab for box b (device pointer into this multifab)."""
         lv = self.dlev.level
-        off, _ = mf_layout(lv.boxes, self.ncomp, self.ng)
+        off, cs, _ = mf_layout(lv.boxes, self.ncomp, self.ng)
         f = PaFab()
+        f.nstride = int(cs[b])
         f.p = self.ptr + 8 * int(off[b])
         for d in range(3):
             f.lo[d] = int(lv.boxes[b, d]) - self.ng

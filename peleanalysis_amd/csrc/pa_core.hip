@@ -223,13 +223,15 @@ extern "C" void pa_level_destroy(pa_level* L) {
 extern "C" int pa_level_nboxes(const pa_level* L) { return L ? (int)L->boxes.size() : 0; }
 
 // --------------------------------------------------------------------- MultiFab
-extern "C" int64_t pa_mf_layout(int nboxes, const int32_t* b6, int ncomp, int ng, int64_t* off) {
+extern "C" int64_t pa_mf_layout(int nboxes, const int32_t* b6, int ncomp, int ng, int64_t* off, int64_t* cstride) {
   int64_t t = 0;
   for (int b = 0; b < nboxes; ++b) {
     if (off) off[b] = t;
-    int64_t n = ncomp;
+    int64_t n = 1;
     for (int d = 0; d < 3; ++d) n *= (int64_t)(b6[6 * b + 3 + d] - b6[6 * b + d] + 1 + 2 * ng);
-    t += (n + 63) / 64 * 64;  // every FAB starts on a 512-byte boundary
+    const int64_t cs = pa_cstride(n, ncomp);  // component stride (>= n, see pa_internal.h)
+    if (cstride) cstride[b] = cs;
+    t += cs * ncomp;  // every FAB (and every component) starts on a 512-byte boundary
   }
   return t;
 }
@@ -244,7 +246,7 @@ extern "C" pa_mf* pa_mf_create(pa_ctx* ctx, const pa_level* L, int ncomp, int ng
   for (int b = 0; b < nb; ++b)
     for (int d = 0; d < 3; ++d) { b6[6 * b + d] = L->boxes[b].lo[d]; b6[6 * b + 3 + d] = L->boxes[b].hi[d]; }
   std::vector<int64_t> off(nb);
-  M->total = pa_mf_layout(nb, b6.data(), ncomp, ng, off.data());
+  M->total = pa_mf_layout(nb, b6.data(), ncomp, ng, off.data(), nullptr);
   M->off.assign(off.begin(), off.end());
   if (hipMalloc(&M->d_off, sizeof(long long) * nb) != hipSuccess ||
       hipMemcpy(M->d_off, M->off.data(), sizeof(long long) * nb, hipMemcpyHostToDevice) != hipSuccess) {
@@ -298,8 +300,8 @@ __global__ void k_setval(double* p, long long n, double v) {
 __global__ void k_setval_comp(DLevelView L, DMFView M, int comp, int ncomp, double v) {
   const int b = blockIdx.y;
   const DBox B = L.boxes[b];
-  const long long per = (long long)(B.hi[0] - B.lo[0] + 1 + 2 * M.ng) * (B.hi[1] - B.lo[1] + 1 + 2 * M.ng) *
-                        (B.hi[2] - B.lo[2] + 1 + 2 * M.ng);
+  const long long per = pa_cstride((long long)(B.hi[0] - B.lo[0] + 1 + 2 * M.ng) * (B.hi[1] - B.lo[1] + 1 + 2 * M.ng) *
+                                       (B.hi[2] - B.lo[2] + 1 + 2 * M.ng), M.ncomp);
   double* p = M.data + M.off[b] + per * comp;
   const long long n = per * ncomp;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = v;
@@ -325,7 +327,7 @@ __global__ void k_copy(DLevelView L, DMFView S, int scomp, DMFView D, int dcomp,
     const int k = (int)((t / ((long long)nx * ny)) % nz);
     const int c = (int)(t / ((long long)nx * ny * nz));
     const int I = B.lo[0] - ng + i, J = B.lo[1] - ng + j, K = B.lo[2] - ng + k;
-    D.data[D.off[b] + fab_index(B, D.ng, dcomp + c, I, J, K)] = S.data[S.off[b] + fab_index(B, S.ng, scomp + c, I, J, K)];
+    D.data[D.off[b] + fab_index(B, D.ng, D.ncomp, dcomp + c, I, J, K)] = S.data[S.off[b] + fab_index(B, S.ng, S.ncomp, scomp + c, I, J, K)];
   }
 }
 
@@ -391,7 +393,7 @@ __global__ void k_fill_boundary(DLevelView L, DMFView M, int comp, int ncomp, in
   if (classify(L, i, j, k, s, p) != 0) return;
   const DBox S = L.boxes[s];
   for (int c = comp; c < comp + ncomp; ++c)
-    M.data[M.off[b] + fab_index(B, M.ng, c, i, j, k)] = M.data[M.off[s] + fab_index(S, M.ng, c, p[0], p[1], p[2])];
+    M.data[M.off[b] + fab_index(B, M.ng, M.ncomp, c, i, j, k)] = M.data[M.off[s] + fab_index(S, M.ng, M.ncomp, c, p[0], p[1], p[2])];
 }
 
 static long long max_shell(const pa_level* L, int ng) {
@@ -436,7 +438,7 @@ __device__ __forceinline__ double bc_ghost_value(const DLevelView& L, const DMFV
   in[dir] += s;
   const double* f = M.data + M.off[b];
   if (cls == 2) {
-    const double v = f[fab_index(B, M.ng, comp, in[0], in[1], in[2])];
+    const double v = f[fab_index(B, M.ng, M.ncomp, comp, in[0], in[1], in[2])];
     return (A.bc[dir] == PA_BC_REFLECT_ODD) ? -v : v;
   }
   double coef[4];
@@ -446,7 +448,7 @@ __device__ __forceinline__ double bc_ghost_value(const DLevelView& L, const DMFV
   for (int m = 1; m < NX; ++m) {
     int pc[3] = {q[0], q[1], q[2]};
     pc[dir] += s * m;
-    tmp += f[fab_index(B, M.ng, comp, pc[0], pc[1], pc[2])] * coef[m];
+    tmp += f[fab_index(B, M.ng, M.ncomp, comp, pc[0], pc[1], pc[2])] * coef[m];
   }
   double g = tmp;
   g += bv * coef[0];
@@ -486,7 +488,7 @@ __global__ void k_apply_bc_faces(DLevelView L, DMFView M, int comp, DLevelView L
   bool ok = true;
   const double v = bc_ghost_value(L, M, B, b, comp, LC, MC, ccomp, A, q, dir, side ? -1 : 1, cls, ok);
   if (!ok) atomicAdd(nbad, 1);
-  M.data[M.off[b] + fab_index(B, M.ng, comp, q[0], q[1], q[2])] = v;
+  M.data[M.off[b] + fab_index(B, M.ng, M.ncomp, comp, q[0], q[1], q[2])] = v;
 }
 
 // Fused-path extension: edge ghost cells (outside the box in two directions a<c).  Such a cell
@@ -531,7 +533,7 @@ __global__ void k_apply_bc_edges(DLevelView L, DMFView M, int comp, DLevelView L
   bool ok = true;
   const double v = bc_ghost_value(L, M, B, b, comp, LC, MC, ccomp, A, q, dir, s, cl, ok);
   if (!ok) atomicAdd(nbad, 1);
-  M.data[M.off[b] + fab_index(B, M.ng, comp, q[0], q[1], q[2])] = v;
+  M.data[M.off[b] + fab_index(B, M.ng, M.ncomp, comp, q[0], q[1], q[2])] = v;
 }
 
 int pa_ensure_red(pa_ctx* ctx, size_t n) {

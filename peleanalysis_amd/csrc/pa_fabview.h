@@ -22,7 +22,7 @@ __device__ __forceinline__ FabView mf_view(const DMFView& M, const DBox& B, int 
   const int nz = B.hi[2] - B.lo[2] + 1 + 2 * M.ng;
   f.nx = B.hi[0] - B.lo[0] + 1 + 2 * M.ng;
   f.ny = B.hi[1] - B.lo[1] + 1 + 2 * M.ng;
-  f.sc = (long long)f.nx * f.ny * nz;
+  f.sc = pa_cstride((long long)f.nx * f.ny * nz, M.ncomp);
   for (int d = 0; d < 3; ++d) f.lo[d] = B.lo[d] - M.ng;
   return f;
 }
@@ -32,7 +32,7 @@ inline FabView fab_view(const pa_fab& f) {
   v.p = f.p;
   v.nx = f.hi[0] - f.lo[0] + 1;
   v.ny = f.hi[1] - f.lo[1] + 1;
-  v.sc = (long long)v.nx * v.ny * (f.hi[2] - f.lo[2] + 1);
+  v.sc = f.nstride > 0 ? (long long)f.nstride : (long long)v.nx * v.ny * (f.hi[2] - f.lo[2] + 1);
   for (int d = 0; d < 3; ++d) v.lo[d] = f.lo[d];
   return v;
 }

@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void k_gradcurv_faces(DLevelView L, DMFView MC
     if (c0 < A.thr || c0 > 1.0 - A.thr) curv = 0.0;
   }
   if (!ok) atomicAdd(nbad, 1);
-  MO.data[MO.off[b] + fab_index(B, MO.ng, kcomp, X[0], X[1], X[2])] = curv;
+  MO.data[MO.off[b] + fab_index(B, MO.ng, MO.ncomp, kcomp, X[0], X[1], X[2])] = curv;
 }
 
 int pa_gradcurv_launch(pa_ctx* ctx, const pa_mf* phi, int pcomp, const pa_mf* c, int ccomp, double thr, pa_mf* out, int ocomp);
@@ -214,9 +214,33 @@ static int fused_kseg() {
   }
   return v;
 }
-static dim3 march_grid(int nx, int ny, int nz, int kseg, unsigned nboxes) {
-  const unsigned tx = (nx + 63) / 64, ty = (ny + PA_MTY - 1) / PA_MTY, tz = (nz + kseg - 1) / kseg;
+static int fused_mty() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("PA_MTY");
+    v = e ? atoi(e) : 81;  // MTY*10 + min waves per SIMD
+  }
+  return v;
+}
+static dim3 march_grid(int nx, int ny, int nz, int kseg, int mty, unsigned nboxes) {
+  const unsigned tx = (nx + 63) / 64, ty = (ny + mty - 1) / mty, tz = (nz + kseg - 1) / kseg;
   return dim3(tx * ty * tz, nboxes);
+}
+template <typename BP>
+static void march_launch(hipStream_t st, const BP& bp, int nx, int ny, int nz, unsigned nboxes, int pcomp, int ccomp, int ocomp, double thr) {
+  const int kseg = fused_kseg();
+  switch (fused_mty()) {
+#define PA_CASE(M, W)                                                                                                         \
+  case M * 10 + W:                                                                                                            \
+    hipLaunchKernelGGL((k_gradcurv_march<BP, M, W>), march_grid(nx, ny, nz, kseg, M, nboxes), dim3(64 * (M + 3)), 0, st, bp, \
+                       pcomp, ccomp, ocomp, thr, kseg);                                                                       \
+    break;
+    PA_CASE(4, 1) PA_CASE(4, 6) PA_CASE(4, 7) PA_CASE(8, 1) PA_CASE(8, 6) PA_CASE(12, 1) PA_CASE(13, 1)
+#undef PA_CASE
+    default:
+      hipLaunchKernelGGL((k_gradcurv_march<BP, 8, 1>), march_grid(nx, ny, nz, kseg, 8, nboxes), dim3(64 * 11), 0, st, bp, pcomp, ccomp,
+                         ocomp, thr, kseg);
+  }
 }
 
 int pa_gradcurv_launch(pa_ctx* ctx, const pa_mf* phi, int pcomp, const pa_mf* c, int ccomp, double thr, pa_mf* out, int ocomp) {
@@ -226,9 +250,7 @@ int pa_gradcurv_launch(pa_ctx* ctx, const pa_mf* phi, int pcomp, const pa_mf* c,
   if (fused_variant() == 0) {
     hipLaunchKernelGGL(k_gradcurv_naive<LevelBP4>, tile_grid(L), dim3(256), 0, ctx->stream, bp, pcomp, ccomp, ocomp, thr);
   } else {
-    const int kseg = fused_kseg();
-    hipLaunchKernelGGL(k_gradcurv_march<LevelBP4>, march_grid(L->maxn[0], L->maxn[1], L->maxn[2], kseg, (unsigned)L->boxes.size()),
-                       dim3(64 * PA_MNW), 0, ctx->stream, bp, pcomp, ccomp, ocomp, thr, kseg);
+    march_launch(ctx->stream, bp, L->maxn[0], L->maxn[1], L->maxn[2], (unsigned)L->boxes.size(), pcomp, ccomp, ocomp, thr);
   }
   PA_HIP(hipGetLastError());
   return 0;
@@ -244,10 +266,8 @@ extern "C" int pa_gradcurv_fab(pa_ctx* ctx, pa_box valid, const pa_fab* phi, int
   if (fused_variant() == 0) {
     hipLaunchKernelGGL(k_gradcurv_naive<FabBP4>, tile_grid(valid), dim3(256), 0, ctx->stream, bp, pcomp, ccomp, ocomp, thr);
   } else {
-    const int kseg = fused_kseg();
-    hipLaunchKernelGGL(k_gradcurv_march<FabBP4>,
-                       march_grid(valid.hi[0] - valid.lo[0] + 1, valid.hi[1] - valid.lo[1] + 1, valid.hi[2] - valid.lo[2] + 1, kseg, 1),
-                       dim3(64 * PA_MNW), 0, ctx->stream, bp, pcomp, ccomp, ocomp, thr, kseg);
+    march_launch(ctx->stream, bp, valid.hi[0] - valid.lo[0] + 1, valid.hi[1] - valid.lo[1] + 1, valid.hi[2] - valid.lo[2] + 1, 1, pcomp,
+                 ccomp, ocomp, thr);
   }
   PA_HIP(hipGetLastError());
   return 0;

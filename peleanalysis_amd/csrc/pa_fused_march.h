@@ -21,9 +21,6 @@
 #pragma once
 #include "pa_fabview.h"
 
-#define PA_MTY 8
-#define PA_MROWS (PA_MTY + 2)
-#define PA_MNW (PA_MTY + 3)
 #define PA_MLW 66
 
 __device__ __forceinline__ void normal_from(double cl, double cr, double cs, double cn, double cm, double cc, double cp,
@@ -38,18 +35,20 @@ __device__ __forceinline__ void normal_from(double cl, double cr, double cs, dou
   nz = gz / ng;
 }
 
+template <int MTY>
 struct MarchLds {
-  double c[3][PA_MROWS][PA_MLW];   // c: x index 0 = left edge column, 1..64 = lanes, llast+2 = right edge column
-  double p[3][PA_MROWS][PA_MLW];   // phi
-  double nx[3][PA_MTY][PA_MLW];    // n_x of rows 1..MTY (+ edge columns)
-  double ny[3][PA_MROWS][64];      // n_y
+  double c[3][MTY + 2][PA_MLW];   // c: x index 0 = left edge column, 1..64 = lanes, llast+2 = right edge column
+  double p[3][MTY + 2][PA_MLW];   // phi
+  double nx[3][MTY][PA_MLW];      // n_x of rows 1..MTY (+ edge columns)
+  double ny[3][MTY + 2][64];      // n_y
 };
 
-template <typename BP>
-__global__ __launch_bounds__(64 * PA_MNW) void k_gradcurv_march(BP bp, int pcomp, int ccomp, int ocomp, double thr, int kseg) {
+template <typename BP, int PA_MTY, int MINW>
+__global__ __launch_bounds__(64 * (PA_MTY + 3), MINW) void k_gradcurv_march(BP bp, int pcomp, int ccomp, int ocomp, double thr, int kseg) {
   FabView P, C, O, unused;
   DBox V;
   double dxinv[3];
+  constexpr int PA_MROWS = PA_MTY + 2;
   if (!bp.get(blockIdx.y, P, C, O, unused, V, dxinv)) return;
   const int nx = V.hi[0] - V.lo[0] + 1, ny = V.hi[1] - V.lo[1] + 1, nz = V.hi[2] - V.lo[2] + 1;
   const int tx = (nx + 63) / 64, ty = (ny + PA_MTY - 1) / PA_MTY, tz = (nz + kseg - 1) / kseg;
@@ -63,7 +62,7 @@ __global__ __launch_bounds__(64 * PA_MNW) void k_gradcurv_march(BP bp, int pcomp
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int rtop = min(PA_MROWS - 1, V.hi[1] + 1 - j0 + 1);  // row slot of the last live row (j = min(j0+MTY, hi_y+1))
 
-  __shared__ MarchLds S;
+  __shared__ MarchLds<PA_MTY> S;
   const long long cps = (long long)C.nx * C.ny, pps = (long long)P.nx * P.ny;  // plane strides
   const int niter = k1 - k0 + 3;                                               // planes k0-1 .. k1+1
 

@@ -98,10 +98,21 @@ struct pa_mf {
 int pa_fail(pa_ctx* ctx, const std::string& msg);
 
 // ---------------------------------------------------------------- device helpers
-__device__ __forceinline__ long long fab_index(const DBox& B, int ng, int c, int i, int j, int k) {
+// Component stride of a FAB inside a pa_mf (in doubles): the cell count rounded up to 512 B and
+// kept off multiples of 16 KiB.  With the plain AMReX stride (nx*ny*nz) a 128^3 box puts all
+// components of one cell 16 MiB apart = on the same HBM channel, which costs ~20 % of the write
+// bandwidth of an 8-output kernel (tools/bench/membench2.hip); amrex::Array4 carries an explicit
+// nstride too, so this stays within the reference's data model.
+__host__ __device__ __forceinline__ long long pa_cstride(long long ncells, int ncomp) {
+  long long cs = (ncells + 63) / 64 * 64;
+  if (ncomp > 1 && (cs % 2048) == 0) cs += 64;
+  return cs;
+}
+
+__device__ __forceinline__ long long fab_index(const DBox& B, int ng, int ncomp, int c, int i, int j, int k) {
   const long long nx = B.hi[0] - B.lo[0] + 1 + 2 * ng, ny = B.hi[1] - B.lo[1] + 1 + 2 * ng,
                   nz = B.hi[2] - B.lo[2] + 1 + 2 * ng;
-  return (((long long)c * nz + (k - B.lo[2] + ng)) * ny + (j - B.lo[1] + ng)) * nx + (i - B.lo[0] + ng);
+  return (long long)c * pa_cstride(nx * ny * nz, ncomp) + ((long long)(k - B.lo[2] + ng) * ny + (j - B.lo[1] + ng)) * nx + (i - B.lo[0] + ng);
 }
 
 // wrap into the domain along periodic directions; false if outside a wall
@@ -174,7 +185,7 @@ __device__ __forceinline__ double crse_val(const DLevelView& LC, const DMFView& 
   if (!wrap_cell(LC, p)) { ok = false; return 0.0; }
   const int b = owner_of(LC, p);
   if (b < 0) { ok = false; return 0.0; }
-  return MC.data[MC.off[b] + fab_index(LC.boxes[b], MC.ng, comp, p[0], p[1], p[2])];
+  return MC.data[MC.off[b] + fab_index(LC.boxes[b], MC.ng, MC.ncomp, comp, p[0], p[1], p[2])];
 }
 
 // InterpBndryData (order 3) restated -- see oracle/pa_oracle.c cf_bndry_value

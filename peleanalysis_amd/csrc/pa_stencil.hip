@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void k_minmax(DLevelView L, DMFView M, int com
   const double* f = M.data + M.off[b];
   for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
     const int i = (int)(t % nx), j = (int)((t / nx) % ny), k = (int)(t / ((long long)nx * ny));
-    const double v = f[fab_index(B, M.ng, comp, B.lo[0] + i, B.lo[1] + j, B.lo[2] + k)];
+    const double v = f[fab_index(B, M.ng, M.ncomp, comp, B.lo[0] + i, B.lo[1] + j, B.lo[2] + k)];
     lo = v < lo ? v : lo;
     hi = v > hi ? v : hi;
   }

@@ -49,14 +49,23 @@ class Level:
         return int(np.prod(n, axis=1).sum())
 
 
+def comp_stride(ncells, ncomp: int):
+    """Same rule as pa_cstride: cells rounded up to 64 doubles (512 B), never a multiple of 16 KiB
+    when there is more than one component (HBM channel conflicts, see csrc/pa_internal.h)."""
+    cs = (np.asarray(ncells, dtype=np.int64) + 63) // 64 * 64
+    if ncomp > 1:
+        cs = np.where(cs % 2048 == 0, cs + 64, cs)
+    return cs
+
+
 def mf_layout(boxes: np.ndarray, ncomp: int, ng: int):
-    """Same rule as pa_mf_layout: every FAB starts on a 64-double (512 B) boundary."""
+    """Same rule as pa_mf_layout: returns (box offsets, component strides, total) in doubles."""
     n = boxes[:, 3:].astype(np.int64) - boxes[:, :3] + 1 + 2 * ng
-    size = ncomp * np.prod(n, axis=1)
-    size = (size + 63) // 64 * 64
+    cs = comp_stride(np.prod(n, axis=1), ncomp)
+    size = ncomp * cs
     off = np.zeros(len(boxes), dtype=np.int64)
     off[1:] = np.cumsum(size)[:-1]
-    return off, int(size.sum())
+    return off, cs.astype(np.int64), int(size.sum())
 
 
 class MultiFab:
@@ -66,7 +75,7 @@ class MultiFab:
         self.level = level
         self.ncomp = int(ncomp)
         self.ng = int(ng)
-        self.off, self.total = mf_layout(level.boxes, ncomp, ng)
+        self.off, self.cstride, self.total = mf_layout(level.boxes, ncomp, ng)
         if data is None:
             data = np.full(self.total, fill, dtype=np.float64)
         assert data.dtype == np.float64 and data.size == self.total
@@ -74,8 +83,9 @@ class MultiFab:
 
     def fab(self, b: int) -> np.ndarray:
         nz, ny, nx = self.level.box_shape(b, self.ng)
-        n = self.ncomp * nz * ny * nx
-        return self.data[self.off[b]:self.off[b] + n].reshape(self.ncomp, nz, ny, nx)
+        cs = int(self.cstride[b])
+        base = self.data[self.off[b]:self.off[b] + self.ncomp * cs]
+        return np.lib.stride_tricks.as_strided(base, shape=(self.ncomp, nz, ny, nx), strides=(8 * cs, 8 * ny * nx, 8 * nx, 8))
 
     def valid(self, b: int) -> np.ndarray:
         g = self.ng
