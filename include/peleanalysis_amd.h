@@ -109,15 +109,22 @@ int pa_normal_level(pa_ctx*, const pa_mf* c, int comp, pa_mf* G, int gcomp, pa_m
  * resolved face ghosts), + threshold clip :549-567 if thr >= 0 (c needed) */
 int pa_div_level(pa_ctx*, pa_mf* n, int ncomp0, double scale, const pa_mf* c, int ccomp, double thr,
                  pa_mf* K, int kcomp);
-/* fused grad->curvature (headline kernel).  phi (ng>=1, resolved face ghosts)
- * -> out[ocomp..+3] = gx,gy,gz,|g| ; c (ng>=2: FillBoundary(2) + resolved
- * face ghosts) -> out[ocomp+4..+6] = FlameNormal, out[ocomp+7] = MeanCurvature.
- * Cells next to a coarse-fine or physical face get their curvature from
- * pa_gradcurv_faces_level (the ghost normals there come from applyBC on n). */
-int pa_gradcurv_level(pa_ctx*, const pa_mf* phi, int pcomp, const pa_mf* c, int ccomp, double thr,
+/* same, only on the cells (of the box grown by ng) within `depth` cells of a box face: the
+ * shell in which the fused path needs a stored progress variable */
+int pa_progress_shell_level(pa_ctx*, const pa_mf* s, int comp, double pmin, double pmax, pa_mf* c, int ccomp, int ng,
+                            int depth);
+/* fused grad->curvature (headline kernel; grad.cpp:211-236 + curvature.cpp:316-320,451-567 in
+ * one sweep).  Reads phi only (ng>=2: FillBoundary(2) + applyBC'd face ghosts; 8 B/cell) and
+ * writes out[ocomp..+3] = gx,gy,gz,|g|, out[ocomp+4..+6] = FlameNormal, out[ocomp+7] =
+ * MeanCurvature (64 B/cell); the progress variable (phi-pmin)/(pmax-pmin) is formed on chip.
+ * Cells within two layers of a coarse-fine or physical face of their box then get N and K from
+ * pa_gradcurv_faces_level, which applies the reference's boundary conditions on c and n there
+ * (c: ng>=2, FillBoundary(2) + applyBC on face and edge ghosts, valid within 4 cells of the faces). */
+int pa_gradcurv_level(pa_ctx*, const pa_mf* phi, int pcomp, double prog_min, double prog_max, double thr,
                       pa_mf* out, int ocomp);
 int pa_gradcurv_faces_level(pa_ctx*, const pa_mf* c, int ccomp, const pa_mf* crse_n /* NULL on level 0 */,
-                            int cncomp0, const int32_t bc[3], int ratio, double thr, pa_mf* out, int kcomp);
+                            int cncomp0, const int32_t bc[3], int ratio, double thr, pa_mf* out, int ncomp0,
+                            int kcomp);
 
 /* -------------------------------------------------------- per-FAB entry points
  * (the body of one MFIter iteration; device pointers in pa_fab) */
@@ -131,8 +138,8 @@ int pa_normal_fab(pa_ctx*, pa_box valid, const pa_fab* c, int comp, const double
 /* curvature.cpp:508-546 */
 int pa_div_fab(pa_ctx*, pa_box valid, const pa_fab* n, int ncomp0, const double dxinv[3], double scale,
                pa_fab* K, int kcomp);
-/* fused interior variant for one FAB (c with 2 ghost layers, all same-level) */
-int pa_gradcurv_fab(pa_ctx*, pa_box valid, const pa_fab* phi, int pcomp, const pa_fab* c, int ccomp,
+/* fused sweep for one FAB (phi with 2 ghost layers; exact where they hold same-level data) */
+int pa_gradcurv_fab(pa_ctx*, pa_box valid, const pa_fab* phi, int pcomp, double prog_min, double prog_max,
                     const double dxinv[3], double thr, pa_fab* out, int ocomp);
 /* filterPlt.cpp:217 Filter::apply_filter(box, in, out) */
 int pa_boxfilter_fab(pa_ctx*, pa_box valid, const pa_fab* in, pa_fab* out, int scomp, int ncomp, int ng,

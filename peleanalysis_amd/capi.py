@@ -76,14 +76,15 @@ def load_library() -> C.CDLL:
         "pa_progress_level": (C.c_int, [vp, vp, C.c_int, dbl, dbl, vp, C.c_int, C.c_int]),
         "pa_normal_level": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int]),
         "pa_div_level": (C.c_int, [vp, vp, C.c_int, dbl, vp, C.c_int, dbl, vp, C.c_int]),
-        "pa_gradcurv_level": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, dbl, vp, C.c_int]),
-        "pa_gradcurv_faces_level": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, pi32, C.c_int, dbl, vp, C.c_int]),
+        "pa_progress_shell_level": (C.c_int, [vp, vp, C.c_int, dbl, dbl, vp, C.c_int, C.c_int, C.c_int]),
+        "pa_gradcurv_level": (C.c_int, [vp, vp, C.c_int, dbl, dbl, dbl, vp, C.c_int]),
+        "pa_gradcurv_faces_level": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, pi32, C.c_int, dbl, vp, C.c_int, C.c_int]),
         "pa_grad_fab": (C.c_int, [vp, PaBox, C.POINTER(PaFab), C.c_int, pdbl, C.POINTER(PaFab), C.c_int]),
         "pa_progress_fab": (C.c_int, [vp, PaBox, C.POINTER(PaFab), C.c_int, dbl, dbl, C.POINTER(PaFab), C.c_int]),
         "pa_normal_fab": (C.c_int, [vp, PaBox, C.POINTER(PaFab), C.c_int, pdbl, C.POINTER(PaFab), C.c_int, C.POINTER(PaFab), C.c_int,
                                     C.POINTER(PaFab), C.c_int]),
         "pa_div_fab": (C.c_int, [vp, PaBox, C.POINTER(PaFab), C.c_int, pdbl, dbl, C.POINTER(PaFab), C.c_int]),
-        "pa_gradcurv_fab": (C.c_int, [vp, PaBox, C.POINTER(PaFab), C.c_int, C.POINTER(PaFab), C.c_int, pdbl, dbl, C.POINTER(PaFab), C.c_int]),
+        "pa_gradcurv_fab": (C.c_int, [vp, PaBox, C.POINTER(PaFab), C.c_int, dbl, dbl, pdbl, dbl, C.POINTER(PaFab), C.c_int]),
         "pa_boxfilter_fab": (C.c_int, [vp, PaBox, C.POINTER(PaFab), C.POINTER(PaFab), C.c_int, C.c_int, C.c_int, pdbl]),
         "pa_box_filter_weights": (C.c_int, [C.c_int, pdbl]),
         "pa_boxfilter_level": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, pdbl]),

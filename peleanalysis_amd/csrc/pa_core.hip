@@ -266,7 +266,7 @@ extern "C" pa_mf* pa_mf_create(pa_ctx* ctx, const pa_level* L, int ncomp, int ng
     }
     M->owned = true;
   }
-  M->view.data = M->data; M->view.off = M->d_off; M->view.ncomp = ncomp; M->view.ng = ng;
+  M->view.data = M->data; M->view.off = M->d_off; M->view.ncomp = ncomp; M->view.ng = ng; M->view.xform = 0; M->view.xa = 0; M->view.xb = 1;
   return M;
 }
 
@@ -558,7 +558,7 @@ extern "C" int pa_bc_errors(pa_ctx* ctx) {
 }
 
 int pa_apply_bc_impl(pa_ctx* ctx, pa_mf* F, int comp, const pa_mf* C, int ccomp, const int32_t bc[3], int ratio,
-                     int only_dir, int edges) {
+                     int only_dir, int edges, const double* crse_xform) {
   if (!ctx || !F) return pa_fail(ctx, "pa_apply_bc: null argument");
   if (F->ng < 1) return pa_fail(ctx, "pa_apply_bc: multifab has no ghost cells");
   if (comp < 0 || comp >= F->ncomp || (C && (ccomp < 0 || ccomp >= C->ncomp))) return pa_fail(ctx, "pa_apply_bc: component range");
@@ -570,6 +570,8 @@ int pa_apply_bc_impl(pa_ctx* ctx, pa_mf* F, int comp, const pa_mf* C, int ccomp,
   const pa_level* L = F->lev;
   DLevelView LC = C ? C->lev->view : L->view;
   DMFView MC = C ? C->view : F->view;
+  MC.xform = 0;
+  if (crse_xform) { MC.xform = 1; MC.xa = crse_xform[0]; MC.xb = crse_xform[1]; }  // coarse value = (v - xa) * xb
   const long long n0 = L->maxn[0], n1 = L->maxn[1], n2 = L->maxn[2];
   ProfScope prof(ctx, PA_TAG_BC);
   if (!edges) {
@@ -587,5 +589,40 @@ int pa_apply_bc_impl(pa_ctx* ctx, pa_mf* F, int comp, const pa_mf* C, int ccomp,
 
 extern "C" int pa_apply_bc(pa_ctx* ctx, pa_mf* F, int comp, const pa_mf* C, int ccomp, const int32_t bc[3], int ratio,
                            int only_dir) {
-  return pa_apply_bc_impl(ctx, F, comp, C, ccomp, bc, ratio, only_dir, 0);
+  return pa_apply_bc_impl(ctx, F, comp, C, ccomp, bc, ratio, only_dir, 0, nullptr);
+}
+
+// ------------------------------------------------------------ progress variable, shell only
+// c = (s - pmin) * invdenom (curvature.cpp:316-320) on the cells of the box grown by ng that lie
+// within `depth` cells of a box face (the only place the fused path needs a stored c).
+__global__ void k_progress_shell(DLevelView L, DMFView S, int comp, DMFView Cm, int ccomp, int ng, int depth, double pmin, double invdenom) {
+  const int b = blockIdx.y;
+  DBox B = L.boxes[b];
+  DBox core = B;
+  for (int d = 0; d < 3; ++d) { core.lo[d] += depth; core.hi[d] -= depth; }
+  const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  int i, j, k;
+  if (!shell_cell(core, depth + ng, t, i, j, k)) return;
+  Cm.data[Cm.off[b] + fab_index(B, Cm.ng, Cm.ncomp, ccomp, i, j, k)] = (S.data[S.off[b] + fab_index(B, S.ng, S.ncomp, comp, i, j, k)] - pmin) * invdenom;
+}
+
+extern "C" int pa_progress_shell_level(pa_ctx* ctx, const pa_mf* s, int comp, double pmin, double pmax, pa_mf* c, int ccomp, int ng, int depth) {
+  if (!ctx || !s || !c) return pa_fail(ctx, "pa_progress_shell_level: null argument");
+  if (s->lev != c->lev) return pa_fail(ctx, "pa_progress_shell_level: different levels");
+  if (ng > s->ng || ng > c->ng || comp >= s->ncomp || ccomp >= c->ncomp || depth < 1) return pa_fail(ctx, "pa_progress_shell_level: ng/component range");
+  const pa_level* L = s->lev;
+  for (const DBox& B : L->boxes)
+    for (int d = 0; d < 3; ++d)
+      if (B.hi[d] - B.lo[d] + 1 <= 2 * depth)  // no interior core left: the shell is the whole box
+        return pa_progress_level(ctx, s, comp, pmin, pmax, c, ccomp, ng);
+  long long ms = 0;
+  for (const DBox& B : L->boxes) {
+    const long long nx = B.hi[0] - B.lo[0] + 1, ny = B.hi[1] - B.lo[1] + 1, nz = B.hi[2] - B.lo[2] + 1;
+    ms = std::max(ms, (nx + 2 * ng) * (ny + 2 * ng) * (nz + 2 * ng) - (nx - 2 * depth) * (ny - 2 * depth) * (nz - 2 * depth));
+  }
+  dim3 grid((unsigned)((ms + 255) / 256), (unsigned)L->boxes.size());
+  ProfScope prof(ctx, PA_TAG_PROGRESS);
+  hipLaunchKernelGGL(k_progress_shell, grid, dim3(256), 0, ctx->stream, L->view, s->view, comp, c->view, ccomp, ng, depth, pmin, 1.0 / (pmax - pmin));
+  PA_HIP(hipGetLastError());
+  return 0;
 }

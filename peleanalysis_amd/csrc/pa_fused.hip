@@ -1,14 +1,17 @@
-// pa_fused.hip -- fused grad -> curvature kernels (headline path), gfx950.
+// pa_fused.hip -- fused grad -> curvature (headline path), gfx950.
 //
-// One sweep reads phi (resolved ring-1 face ghosts) and the progress variable c (ring-2
-// same-level ghosts + resolved ring-1 faces/edges) and writes gx,gy,gz,|g|,Nx,Ny,Nz,K.
-// The flame normal at the six neighbours is recomputed from c instead of being stored,
-// ghost-exchanged and re-read (curvature.cpp:451-546 does ~10 passes over memory).
-// Arithmetic order is that of the reference call sites (see pa_internal.h cdiff).
+// k_gradcurv_march (pa_fused_march.h) sweeps every box once: reads phi, writes
+// gx,gy,gz,|g|,Nx,Ny,Nz,K.  The flame normal at the neighbours is recomputed on chip instead of
+// being stored, ghost-exchanged and re-read (curvature.cpp:451-546 makes ~10 passes over memory).
 //
-// Cells adjacent to a coarse-fine or physical face need the ghost NORMAL, which the
-// reference obtains from applyBC on n itself: k_gradcurv_faces recomputes
-// K for those cells only.
+// k_gradcurv_faces then recomputes, for the cells within two layers of a coarse-fine or physical
+// face of their box, what depends on boundary conditions the sweep cannot know:
+//   * the ghost NORMAL beyond such a face comes from MLMG applyBC on n_d itself
+//     (curvature.cpp:510-531), not from c;
+//   * the ghost PROGRESS VARIABLE there comes from applyBC on c (curvature.cpp:443-457), which is
+//     not (phi_ghost - pmin)*invdenom at coarse-fine and reflect_odd faces.
+// It works from a resolved copy of c (FillBoundary(2) + applyBC on faces and edge ghosts) that only
+// needs to be valid in a shell around the box faces.
 #include "pa_internal.h"
 #include "pa_fabview.h"
 #include "pa_fused_march.h"
@@ -18,77 +21,32 @@ struct Vec3 { double x, y, z; };
 
 // flame normal n = G/normgrad at cell (i,j,k), from c
 __device__ __forceinline__ Vec3 normal_at(const FabView& C, int cc, int i, int j, int k, const double dxinv[3]) {
-  const double c0 = C(i, j, k, cc);
-  const double gx = cdiff(dxinv[0], C(i - 1, j, k, cc), c0, C(i + 1, j, k, cc));
-  const double gy = cdiff(dxinv[1], C(i, j - 1, k, cc), c0, C(i, j + 1, k, cc));
-  const double gz = cdiff(dxinv[2], C(i, j, k - 1, cc), c0, C(i, j, k + 1, cc));
-  const double sn = sqrt(gx * gx + gy * gy + gz * gz);
-  const double ng = -((1e-14 < sn) ? sn : 1e-14);
   Vec3 n;
-  n.x = gx / ng;
-  n.y = gy / ng;
-  n.z = gz / ng;
+  normal_from(C(i - 1, j, k, cc), C(i + 1, j, k, cc), C(i, j - 1, k, cc), C(i, j + 1, k, cc), C(i, j, k - 1, cc), C(i, j, k, cc),
+              C(i, j, k + 1, cc), dxinv, n.x, n.y, n.z);
   return n;
 }
 
-// ---------------------------------------------------------------- v1: direct loads
-template <typename BP>
-__global__ __launch_bounds__(256) void k_gradcurv_naive(BP bp, int pcomp, int ccomp, int ocomp, double thr) {
-  FabView P, C, O, unused;
-  DBox V;
-  double dxinv[3];
-  if (!bp.get(blockIdx.y, P, C, O, unused, V, dxinv)) return;
-  int i, j, k0, k1;
-  if (!tile_cell(V, i, j, k0, k1)) return;
-  for (int k = k0; k <= k1; ++k) {
-    const double p0 = P(i, j, k, pcomp);
-    const double gx = cdiff(dxinv[0], P(i - 1, j, k, pcomp), p0, P(i + 1, j, k, pcomp));
-    const double gy = cdiff(dxinv[1], P(i, j - 1, k, pcomp), p0, P(i, j + 1, k, pcomp));
-    const double gz = cdiff(dxinv[2], P(i, j, k - 1, pcomp), p0, P(i, j, k + 1, pcomp));
-    O(i, j, k, ocomp) = gx;
-    O(i, j, k, ocomp + 1) = gy;
-    O(i, j, k, ocomp + 2) = gz;
-    O(i, j, k, ocomp + 3) = sqrt(gx * gx + gy * gy + gz * gz);
-    const Vec3 n0 = normal_at(C, ccomp, i, j, k, dxinv);
-    double curv = 0.0;
-    curv += cdiff(dxinv[0], normal_at(C, ccomp, i - 1, j, k, dxinv).x, n0.x, normal_at(C, ccomp, i + 1, j, k, dxinv).x);
-    curv += cdiff(dxinv[1], normal_at(C, ccomp, i, j - 1, k, dxinv).y, n0.y, normal_at(C, ccomp, i, j + 1, k, dxinv).y);
-    curv += cdiff(dxinv[2], normal_at(C, ccomp, i, j, k - 1, dxinv).z, n0.z, normal_at(C, ccomp, i, j, k + 1, dxinv).z);
-    curv = curv * 0.5;
-    Vec3 n = n0;
-    if (thr >= 0.0) {
-      const double c0 = C(i, j, k, ccomp);
-      if (c0 < thr || c0 > 1.0 - thr) { curv = 0.0; n.x = 0.0; n.y = 0.0; n.z = 0.0; }
-    }
-    O(i, j, k, ocomp + 4) = n.x;
-    O(i, j, k, ocomp + 5) = n.y;
-    O(i, j, k, ocomp + 6) = n.z;
-    O(i, j, k, ocomp + 7) = curv;
-  }
-}
-
-// ---------------------------------------------------------------- face fix-up
-// Thread per (box face cell X).  If the ghost cell beyond the face is not a valid cell of this
-// level, K(X) is recomputed with the ghost normal given by MLMG applyBC on n_d
-// (curvature.cpp:510-531): wall -> +-n_d(X); coarse-fine -> cubic through the coarse
-// boundary value (InterpBndryData of the coarse, already thresholded, normal: quirk Q2) and
-// n_d at X, X-+1, X-+2.  All other normals are recomputed from c.
 struct FaceArgs {
   int bc[3];
   int ratio;
   int has_crse;
+  int layers;  // cells per face normal that are recomputed (2)
   double thr;
 };
 
 __device__ __forceinline__ double comp_of(const Vec3& v, int d) { return d == 0 ? v.x : (d == 1 ? v.y : v.z); }
 
+// Thread per (box face cell, layer).  Skips faces whose ghost cell is a valid cell of the level.
 __global__ __launch_bounds__(256) void k_gradcurv_faces(DLevelView L, DMFView MC_, int ccomp, DLevelView LCr, DMFView MN, int cncomp0,
-                                                        DMFView MO, int kcomp, FaceArgs A, int* nbad) {
+                                                        DMFView MO, int ncomp0, int kcomp, FaceArgs A, int* nbad) {
   const int b = blockIdx.y;
   if (b >= L.nboxes) return;
   const DBox B = L.boxes[b];
   const int n[3] = {B.hi[0] - B.lo[0] + 1, B.hi[1] - B.lo[1] + 1, B.hi[2] - B.lo[2] + 1};
   long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  const int layer = (int)(t % A.layers);
+  t /= A.layers;
   int fdir = -1, side = 0, a0 = 0, b1 = 0;
   for (int d = 0; d < 3; ++d) {
     const int t0 = (d == 0) ? 1 : 0, t1 = (d == 2) ? 1 : 2;
@@ -103,18 +61,17 @@ __global__ __launch_bounds__(256) void k_gradcurv_faces(DLevelView L, DMFView MC
     }
     t -= 2 * fs;
   }
-  if (fdir < 0) return;
+  if (fdir < 0 || layer >= n[fdir]) return;
   int X[3];
   {
     const int t0 = (fdir == 0) ? 1 : 0, t1 = (fdir == 2) ? 1 : 2;
-    X[fdir] = side ? B.hi[fdir] : B.lo[fdir];
-    X[t0] = B.lo[t0] + a0;
-    X[t1] = B.lo[t1] + b1;
-  }
-  {
-    int q[3] = {X[0], X[1], X[2]};
-    q[fdir] += side ? 1 : -1;
-    if (classify(L, q[0], q[1], q[2]) == 0) return;  // ordinary same-level face: the fused kernel was exact
+    int q[3];
+    q[fdir] = side ? B.hi[fdir] + 1 : B.lo[fdir] - 1;
+    q[t0] = B.lo[t0] + a0;
+    q[t1] = B.lo[t1] + b1;
+    if (classify(L, q[0], q[1], q[2]) == 0) return;  // ordinary same-level face: the sweep was exact
+    X[0] = q[0]; X[1] = q[1]; X[2] = q[2];
+    X[fdir] += side ? -(1 + layer) : (1 + layer);
   }
   const FabView C = mf_view(MC_, B, b);
   const double dxinv[3] = {L.dxinv[0], L.dxinv[1], L.dxinv[2]};
@@ -153,72 +110,34 @@ __global__ __launch_bounds__(256) void k_gradcurv_faces(DLevelView L, DMFView MC
     curv += cdiff(dxinv[d], nb[0], comp_of(n0, d), nb[1]);
   }
   curv = curv * 0.5;
+  Vec3 no = n0;
   if (A.thr >= 0.0) {
     const double c0 = C(X[0], X[1], X[2], ccomp);
-    if (c0 < A.thr || c0 > 1.0 - A.thr) curv = 0.0;
+    if (c0 < A.thr || c0 > 1.0 - A.thr) { curv = 0.0; no.x = 0.0; no.y = 0.0; no.z = 0.0; }
   }
   if (!ok) atomicAdd(nbad, 1);
-  MO.data[MO.off[b] + fab_index(B, MO.ng, MO.ncomp, kcomp, X[0], X[1], X[2])] = curv;
+  double* o = MO.data + MO.off[b];
+  o[fab_index(B, MO.ng, MO.ncomp, kcomp, X[0], X[1], X[2])] = curv;
+  o[fab_index(B, MO.ng, MO.ncomp, ncomp0, X[0], X[1], X[2])] = no.x;
+  o[fab_index(B, MO.ng, MO.ncomp, ncomp0 + 1, X[0], X[1], X[2])] = no.y;
+  o[fab_index(B, MO.ng, MO.ncomp, ncomp0 + 2, X[0], X[1], X[2])] = no.z;
 }
 
-int pa_gradcurv_launch(pa_ctx* ctx, const pa_mf* phi, int pcomp, const pa_mf* c, int ccomp, double thr, pa_mf* out, int ocomp);
-
-extern "C" int pa_gradcurv_level(pa_ctx* ctx, const pa_mf* phi, int pcomp, const pa_mf* c, int ccomp, double thr, pa_mf* out, int ocomp) {
-  if (!ctx || !phi || !c || !out) return pa_fail(ctx, "pa_gradcurv_level: null argument");
-  if (phi->lev != c->lev || phi->lev != out->lev) return pa_fail(ctx, "pa_gradcurv_level: different levels");
-  if (phi->ng < 1 || c->ng < 2) return pa_fail(ctx, "pa_gradcurv_level: phi needs >= 1 and c >= 2 ghost layers");
-  if (pcomp < 0 || pcomp >= phi->ncomp || ccomp < 0 || ccomp >= c->ncomp || ocomp < 0 || ocomp + 8 > out->ncomp)
-    return pa_fail(ctx, "pa_gradcurv_level: component range");
-  return pa_gradcurv_launch(ctx, phi, pcomp, c, ccomp, thr, out, ocomp);
-}
-
-extern "C" int pa_gradcurv_faces_level(pa_ctx* ctx, const pa_mf* c, int ccomp, const pa_mf* crse_n, int cncomp0, const int32_t bc[3],
-                                       int ratio, double thr, pa_mf* out, int kcomp) {
-  if (!ctx || !c || !out) return pa_fail(ctx, "pa_gradcurv_faces_level: null argument");
-  if (c->lev != out->lev) return pa_fail(ctx, "pa_gradcurv_faces_level: different levels");
-  if (c->ng < 2) return pa_fail(ctx, "pa_gradcurv_faces_level: c needs >= 2 ghost layers");
-  if (ccomp >= c->ncomp || kcomp >= out->ncomp || (crse_n && cncomp0 + 3 > crse_n->ncomp)) return pa_fail(ctx, "pa_gradcurv_faces_level: component range");
-  if (crse_n && ratio != 2) return pa_fail(ctx, "pa_gradcurv_faces_level: only refinement ratio 2 is supported");
-  const pa_level* L = c->lev;
-  for (const DBox& B : L->boxes)
-    for (int d = 0; d < 3; ++d)
-      if (crse_n && B.hi[d] - B.lo[d] + 1 < 3) return pa_fail(ctx, "pa_gradcurv_faces_level: boxes thinner than 3 cells need the pass-by-pass path");
-  FaceArgs A;
-  for (int d = 0; d < 3; ++d) A.bc[d] = bc[d];
-  A.ratio = ratio; A.has_crse = crse_n ? 1 : 0; A.thr = thr;
-  const long long n0 = L->maxn[0], n1 = L->maxn[1], n2 = L->maxn[2];
-  const long long nt = 2 * (n1 * n2 + n0 * n2 + n0 * n1);
-  dim3 grid((unsigned)((nt + 255) / 256), (unsigned)L->boxes.size());
-  ProfScope prof(ctx, PA_TAG_GRADCURV_FACES);
-  hipLaunchKernelGGL(k_gradcurv_faces, grid, dim3(256), 0, ctx->stream, L->view, c->view, ccomp, crse_n ? crse_n->lev->view : L->view,
-                     crse_n ? crse_n->view : c->view, cncomp0, out->view, kcomp, A, ctx->d_flags);
-  PA_HIP(hipGetLastError());
-  return 0;
-}
-
-// tuning knobs (environment, read once): PA_FUSED_VARIANT=naive|march, PA_KSEG=<planes per workgroup>
-static int fused_variant() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("PA_FUSED_VARIANT");
-    v = (e && std::string(e) == "naive") ? 0 : 1;
-  }
-  return v;
-}
+// tuning knobs (environment, read once): PA_KSEG=<planes per workgroup>, PA_MTY=<rows*10 + min waves/SIMD>
 static int fused_kseg() {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("PA_KSEG");
-    v = e ? atoi(e) : 64;
+    v = e ? atoi(e) : 128;
     if (v < 4) v = 4;
   }
   return v;
 }
 static int fused_mty() {
-  static int v = -1;
-  if (v < 0) {
+  static int v = -2;
+  if (v == -2) {
     const char* e = getenv("PA_MTY");
-    v = e ? atoi(e) : 81;  // MTY*10 + min waves per SIMD
+    v = e ? atoi(e) : -1;
   }
   return v;
 }
@@ -227,48 +146,70 @@ static dim3 march_grid(int nx, int ny, int nz, int kseg, int mty, unsigned nboxe
   return dim3(tx * ty * tz, nboxes);
 }
 template <typename BP>
-static void march_launch(hipStream_t st, const BP& bp, int nx, int ny, int nz, unsigned nboxes, int pcomp, int ccomp, int ocomp, double thr) {
-  const int kseg = fused_kseg();
-  switch (fused_mty()) {
-#define PA_CASE(M, W)                                                                                                         \
-  case M * 10 + W:                                                                                                            \
-    hipLaunchKernelGGL((k_gradcurv_march<BP, M, W>), march_grid(nx, ny, nz, kseg, M, nboxes), dim3(64 * (M + 3)), 0, st, bp, \
-                       pcomp, ccomp, ocomp, thr, kseg);                                                                       \
+static void march_launch(hipStream_t st, const BP& bp, int nx, int ny, int nz, unsigned nboxes, const MarchArgs& A) {
+  int sel = fused_mty();
+  if (sel < 0) sel = (ny >= 52) ? 131 : (ny >= 16 ? 81 : 41);  // short boxes do not fill a 13-row tile
+  switch (sel) {
+#define PA_CASE(M, W)                                                                                                              \
+  case M * 10 + W:                                                                                                                 \
+    hipLaunchKernelGGL((k_gradcurv_march<BP, M, W>), march_grid(nx, ny, nz, A.kseg, M, nboxes), dim3(64 * (M + 3)), 0, st, bp, A); \
     break;
-    PA_CASE(4, 1) PA_CASE(4, 6) PA_CASE(4, 7) PA_CASE(8, 1) PA_CASE(8, 6) PA_CASE(12, 1) PA_CASE(13, 1)
+    PA_CASE(4, 1) PA_CASE(8, 1) PA_CASE(8, 6) PA_CASE(12, 1) PA_CASE(13, 1)
 #undef PA_CASE
     default:
-      hipLaunchKernelGGL((k_gradcurv_march<BP, 8, 1>), march_grid(nx, ny, nz, kseg, 8, nboxes), dim3(64 * 11), 0, st, bp, pcomp, ccomp,
-                         ocomp, thr, kseg);
+      hipLaunchKernelGGL((k_gradcurv_march<BP, 8, 1>), march_grid(nx, ny, nz, A.kseg, 8, nboxes), dim3(64 * 11), 0, st, bp, A);
   }
 }
 
-int pa_gradcurv_launch(pa_ctx* ctx, const pa_mf* phi, int pcomp, const pa_mf* c, int ccomp, double thr, pa_mf* out, int ocomp) {
-  LevelBP4 bp{phi->lev->view, phi->view, c->view, out->view, out->view};
-  ProfScope prof(ctx, PA_TAG_GRADCURV);
+extern "C" int pa_gradcurv_level(pa_ctx* ctx, const pa_mf* phi, int pcomp, double pmin, double pmax, double thr, pa_mf* out, int ocomp) {
+  if (!ctx || !phi || !out) return pa_fail(ctx, "pa_gradcurv_level: null argument");
+  if (phi->lev != out->lev) return pa_fail(ctx, "pa_gradcurv_level: different levels");
+  if (phi->ng < 2) return pa_fail(ctx, "pa_gradcurv_level: phi needs >= 2 ghost layers");
+  if (pcomp < 0 || pcomp >= phi->ncomp || ocomp < 0 || ocomp + 8 > out->ncomp) return pa_fail(ctx, "pa_gradcurv_level: component range");
+  if (!(pmax > pmin)) return pa_fail(ctx, "pa_gradcurv_level: progress variable has no range");
   const pa_level* L = phi->lev;
-  if (fused_variant() == 0) {
-    hipLaunchKernelGGL(k_gradcurv_naive<LevelBP4>, tile_grid(L), dim3(256), 0, ctx->stream, bp, pcomp, ccomp, ocomp, thr);
-  } else {
-    march_launch(ctx->stream, bp, L->maxn[0], L->maxn[1], L->maxn[2], (unsigned)L->boxes.size(), pcomp, ccomp, ocomp, thr);
-  }
+  LevelBP2 bp{L->view, phi->view, out->view};
+  MarchArgs A{pcomp, ocomp, fused_kseg(), pmin, 1.0 / (pmax - pmin), thr};
+  ProfScope prof(ctx, PA_TAG_GRADCURV);
+  march_launch(ctx->stream, bp, L->maxn[0], L->maxn[1], L->maxn[2], (unsigned)L->boxes.size(), A);
   PA_HIP(hipGetLastError());
   return 0;
 }
 
-extern "C" int pa_gradcurv_fab(pa_ctx* ctx, pa_box valid, const pa_fab* phi, int pcomp, const pa_fab* c, int ccomp, const double dxinv[3],
+extern "C" int pa_gradcurv_faces_level(pa_ctx* ctx, const pa_mf* c, int ccomp, const pa_mf* crse_n, int cncomp0, const int32_t bc[3],
+                                       int ratio, double thr, pa_mf* out, int ncomp0, int kcomp) {
+  if (!ctx || !c || !out) return pa_fail(ctx, "pa_gradcurv_faces_level: null argument");
+  if (c->lev != out->lev) return pa_fail(ctx, "pa_gradcurv_faces_level: different levels");
+  if (c->ng < 2) return pa_fail(ctx, "pa_gradcurv_faces_level: c needs >= 2 ghost layers");
+  if (ccomp >= c->ncomp || kcomp >= out->ncomp || ncomp0 + 3 > out->ncomp || (crse_n && cncomp0 + 3 > crse_n->ncomp))
+    return pa_fail(ctx, "pa_gradcurv_faces_level: component range");
+  if (crse_n && ratio != 2) return pa_fail(ctx, "pa_gradcurv_faces_level: only refinement ratio 2 is supported");
+  const pa_level* L = c->lev;
+  for (const DBox& B : L->boxes)
+    for (int d = 0; d < 3; ++d)
+      if (crse_n && B.hi[d] - B.lo[d] + 1 < 3) return pa_fail(ctx, "pa_gradcurv_faces_level: boxes thinner than 3 cells need the pass-by-pass path");
+  FaceArgs A;
+  for (int d = 0; d < 3; ++d) A.bc[d] = bc[d];
+  A.ratio = ratio; A.has_crse = crse_n ? 1 : 0; A.thr = thr; A.layers = 2;
+  const long long n0 = L->maxn[0], n1 = L->maxn[1], n2 = L->maxn[2];
+  const long long nt = 2 * (n1 * n2 + n0 * n2 + n0 * n1) * A.layers;
+  dim3 grid((unsigned)((nt + 255) / 256), (unsigned)L->boxes.size());
+  ProfScope prof(ctx, PA_TAG_GRADCURV_FACES);
+  hipLaunchKernelGGL(k_gradcurv_faces, grid, dim3(256), 0, ctx->stream, L->view, c->view, ccomp, crse_n ? crse_n->lev->view : L->view,
+                     crse_n ? crse_n->view : c->view, cncomp0, out->view, ncomp0, kcomp, A, ctx->d_flags);
+  PA_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int pa_gradcurv_fab(pa_ctx* ctx, pa_box valid, const pa_fab* phi, int pcomp, double pmin, double pmax, const double dxinv[3],
                                double thr, pa_fab* out, int ocomp) {
-  if (!ctx || !phi || !c || !out || !dxinv) return pa_fail(ctx, "pa_gradcurv_fab: null argument");
+  if (!ctx || !phi || !out || !dxinv) return pa_fail(ctx, "pa_gradcurv_fab: null argument");
   std::string why;
-  if (!fab_covers(*phi, valid, 1, pcomp, 1, why) || !fab_covers(*c, valid, 2, ccomp, 1, why) || !fab_covers(*out, valid, 0, ocomp, 8, why))
-    return pa_fail(ctx, "pa_gradcurv_fab: " + why);
-  FabBP4 bp{fab_view(*phi), fab_view(*c), fab_view(*out), fab_view(*out), to_dbox(valid), {dxinv[0], dxinv[1], dxinv[2]}};
-  if (fused_variant() == 0) {
-    hipLaunchKernelGGL(k_gradcurv_naive<FabBP4>, tile_grid(valid), dim3(256), 0, ctx->stream, bp, pcomp, ccomp, ocomp, thr);
-  } else {
-    march_launch(ctx->stream, bp, valid.hi[0] - valid.lo[0] + 1, valid.hi[1] - valid.lo[1] + 1, valid.hi[2] - valid.lo[2] + 1, 1, pcomp,
-                 ccomp, ocomp, thr);
-  }
+  if (!fab_covers(*phi, valid, 2, pcomp, 1, why) || !fab_covers(*out, valid, 0, ocomp, 8, why)) return pa_fail(ctx, "pa_gradcurv_fab: " + why);
+  if (!(pmax > pmin)) return pa_fail(ctx, "pa_gradcurv_fab: progress variable has no range");
+  FabBP2 bp{fab_view(*phi), fab_view(*out), to_dbox(valid), {dxinv[0], dxinv[1], dxinv[2]}};
+  MarchArgs A{pcomp, ocomp, fused_kseg(), pmin, 1.0 / (pmax - pmin), thr};
+  march_launch(ctx->stream, bp, valid.hi[0] - valid.lo[0] + 1, valid.hi[1] - valid.lo[1] + 1, valid.hi[2] - valid.lo[2] + 1, 1, A);
   PA_HIP(hipGetLastError());
   return 0;
 }

@@ -1,23 +1,30 @@
 // pa_fused_march.h -- fused grad->curvature, "k-marching" kernel for gfx950.
 //
+// Reads ONLY phi (8 B/cell) and writes gx,gy,gz,|g|,Nx,Ny,Nz,K (64 B/cell): the 72 B/cell
+// algorithmic traffic of SURVEY 8(d).  The progress variable c = (phi-pmin)*invdenom
+// (curvature.cpp:316-320) is formed on the fly from the same loads.
+//
 // Workgroup = MTY+3 wavefronts over a tile of 64 (x) x MTY (y) columns that marches through
 // kseg z-planes:
 //   waves 0..MTY+1  one row each: rows j0-1 .. j0+MTY.  Output rows produce the 8 results; the two
 //                   outer ("halo") rows only supply c / phi / n_y to their neighbours,
 //   wave  MTY+2     the "edge" wave: the columns left/right of the tile (c, phi, n_x only).
-// Each thread owns one (i,j) column.  z-neighbours of c, phi and n_z live in registers (rolling
-// queues fed by ONE coalesced global load per array and plane, issued one plane ahead);
-// x/y-neighbours of c, phi, n_x, n_y go through a 3-slot LDS ring with ONE barrier per plane.
-// The flame normal is therefore evaluated ~1.4x per cell instead of 7x (direct form), never
-// touches HBM, and every input cell is read from global memory once per tile (+ halo).
+// Each thread owns one (i,j) column.  z-neighbours of phi, c and n_z live in registers (rolling
+// queues fed by ONE coalesced global load per plane, issued two planes ahead); x/y-neighbours of
+// c, phi, n_x, n_y go through a 3-slot LDS ring with ONE barrier per plane.  The flame normal is
+// therefore evaluated ~1.2-1.4x per cell instead of 7x (direct form) and never touches HBM.
 //
 // The per-role loops are branch-free around global memory operations (lanes past the box edge
-// mirror the last valid lane instead of being masked) so that hipcc can count the outstanding
+// mirror the last valid lane instead of being masked; the two warm-up planes store to the first
+// output plane and are overwritten in program order) so that hipcc can count the outstanding
 // loads/stores and keep the prefetched plane in flight across the barrier (s_waitcnt vmcnt(N)
 // instead of vmcnt(0)).
 //
-// Arithmetic order is the reference's (cdiff, normal_from): results are bit-identical to the
-// pass-by-pass path and to the CPU oracle.
+// Ghost cells of phi that are NOT valid cells of the level (coarse-fine / physical walls) give a
+// c that differs from the reference's (which applies the boundary condition to c itself); every
+// result that depends on such a cell lies within two cells of a coarse-fine or wall face and is
+// recomputed by k_gradcurv_faces (pa_fused.hip).  Everywhere else results are bit-identical to
+// the pass-by-pass path and to the CPU oracle (same operation order: cdiff, normal_from).
 #pragma once
 #include "pa_fabview.h"
 
@@ -43,13 +50,20 @@ struct MarchLds {
   double ny[3][MTY + 2][64];      // n_y
 };
 
+struct MarchArgs {
+  int pcomp, ocomp, kseg;
+  double pmin, invdenom, thr;
+};
+
 template <typename BP, int PA_MTY, int MINW>
-__global__ __launch_bounds__(64 * (PA_MTY + 3), MINW) void k_gradcurv_march(BP bp, int pcomp, int ccomp, int ocomp, double thr, int kseg) {
-  FabView P, C, O, unused;
+__global__ __launch_bounds__(64 * (PA_MTY + 3), MINW) void k_gradcurv_march(BP bp, MarchArgs A) {
+  FabView P, O;
   DBox V;
   double dxinv[3];
   constexpr int PA_MROWS = PA_MTY + 2;
-  if (!bp.get(blockIdx.y, P, C, O, unused, V, dxinv)) return;
+  if (!bp.get(blockIdx.y, P, O, V, dxinv)) return;
+  const int pcomp = A.pcomp, kseg = A.kseg;
+  const double pmin = A.pmin, invd = A.invdenom, thr = A.thr;
   const int nx = V.hi[0] - V.lo[0] + 1, ny = V.hi[1] - V.lo[1] + 1, nz = V.hi[2] - V.lo[2] + 1;
   const int tx = (nx + 63) / 64, ty = (ny + PA_MTY - 1) / PA_MTY, tz = (nz + kseg - 1) / kseg;
   const unsigned bid = blockIdx.x;
@@ -63,8 +77,9 @@ __global__ __launch_bounds__(64 * (PA_MTY + 3), MINW) void k_gradcurv_march(BP b
   const int rtop = min(PA_MROWS - 1, V.hi[1] + 1 - j0 + 1);  // row slot of the last live row (j = min(j0+MTY, hi_y+1))
 
   __shared__ MarchLds<PA_MTY> S;
-  const long long cps = (long long)C.nx * C.ny, pps = (long long)P.nx * P.ny;  // plane strides
-  const int niter = k1 - k0 + 3;                                               // planes k0-1 .. k1+1
+  const long long pps = (long long)P.nx * P.ny;  // plane stride
+  const int niter = k1 - k0 + 3;                 // planes k0-1 .. k1+1
+#define PA_PROG(x) (((x) - pmin) * invd)         /* curvature.cpp:319 */
 
   if (w < PA_MROWS && w > rtop) {
     // ---------------------------------------------------------------- dead row (partial tile)
@@ -80,23 +95,23 @@ __global__ __launch_bounds__(64 * (PA_MTY + 3), MINW) void k_gradcurv_march(BP b
     const int i = i0 + le;
     const int xs = le + 1;
     const bool halo = (rr == 0) || (rr == rtop);  // supplies neighbours only; one y-neighbour comes from global
-    const double* gc = C.p + C.idx(i, j, k0 - 2, ccomp);
-    const double* gp = P.p + P.idx(i, j, k0 - 1, pcomp);
-    double cm = gc[0], cc = gc[cps], cp = gc[2 * cps], cn2;
-    gc += 2 * cps;  // -> c(k0)
-    double pm = 0, pc = 0, pnew = gp[0], pn;
+    const double* gp = P.p + P.idx(i, j, k0 - 2, pcomp);
+    // phi queue: pm = phi(p-2), pc = phi(p-1), p0 = phi(p), p1 = phi(p+1), p2 = (prefetched) phi(p+2)
+    double pm = 0, pc = gp[0], p0 = gp[pps], p1 = gp[2 * pps], p2;
+    gp += 2 * pps;  // -> phi(k0)
+    double cm = PA_PROG(pc), cc = PA_PROG(p0), cp = PA_PROG(p1);  // c at planes p-1, p, p+1  (p = k0-1)
     S.c[0][rr][xs] = cc;
     if (halo) {
       const int jout = (rr == 0) ? j - 1 : j + 1;
-      const double* go = C.p + C.idx(i, jout, k0 - 1, ccomp);
-      double co = go[0], con;
+      const double* go = P.p + P.idx(i, jout, k0 - 1, pcomp);
+      double co = PA_PROG(go[0]), con;
       __syncthreads();
       int sp = 0;
       for (int p = k0 - 1; p <= k1 + 1; ++p) {
         const int sp1 = (sp == 2) ? 0 : sp + 1;
-        const long long ci = (p <= k1) ? cps : 0, pi = (p <= k1) ? pps : 0;  // clamp the prefetch on the last plane
-        gc += ci; go += ci; gp += pi;
-        cn2 = gc[0]; con = go[0]; pn = gp[0];
+        const long long pi = (p <= k1) ? pps : 0;  // clamp the prefetch on the last plane
+        gp += pi; go += pi;
+        p2 = gp[0]; con = go[0];
         const double cl = S.c[sp][rr][xs - 1], cr = S.c[sp][rr][xs + 1];
         const double cin = S.c[sp][(rr == 0) ? 1 : rr - 1][xs];
         const double cs = (rr == 0) ? co : cin, cn = (rr == 0) ? cin : co;
@@ -104,9 +119,10 @@ __global__ __launch_bounds__(64 * (PA_MTY + 3), MINW) void k_gradcurv_march(BP b
         normal_from(cl, cr, cs, cn, cm, cc, cp, dxinv, nxp, nyp, nzp);
         S.ny[sp][rr][lane] = nyp;
         S.c[sp1][rr][xs] = cp;
-        S.p[sp][rr][xs] = pnew;
+        S.p[sp][rr][xs] = p0;
         __syncthreads();
-        cm = cc; cc = cp; cp = cn2; co = con; pnew = pn;
+        cm = cc; cc = cp; cp = PA_PROG(p2); co = PA_PROG(con);
+        p0 = p1; p1 = p2;
         sp = sp1;
       }
       return;
@@ -114,28 +130,49 @@ __global__ __launch_bounds__(64 * (PA_MTY + 3), MINW) void k_gradcurv_march(BP b
     // output rows
     __syncthreads();
     double nxq = 0, nyq = 0, nzq = 0, nzqm = 0;
-    double* op = O.p + O.idx(i, j, k0, ocomp);
+    double* op = O.p + O.idx(i, j, k0, A.ocomp);
     const long long ops = (long long)O.nx * O.ny, osc = O.sc;
     int sp = 0;
-    // normal at plane p, outputs at plane q = p-1.  The first two planes (p = k0-1, k0) have no
-    // output yet: their (meaningless) results are stored to plane k0 and overwritten, in program
-    // order by the same thread, when p = k0+1.  This keeps the loop free of branches around
-    // global memory operations so that the prefetched plane stays in flight (vmcnt(N), N > 0).
+    // normal at plane p, outputs at plane q = p-1.  The 8 results of a plane are kept in registers
+    // and stored DURING the next plane's normal computation, two at a time between its stages:
+    // a burst of 8 stores per wave right after the barrier fills the CU's memory pipe and blocks
+    // every wave (and the prefetch loads queued behind them) until it drains.  The first three
+    // iterations have nothing valid to store yet: they write to plane k0, which the same thread
+    // overwrites in program order at p = k0+2.  Keeps the loop free of branches around global
+    // memory operations (vmcnt(N) instead of vmcnt(0)).
+    double o0 = 0, o1 = 0, o2 = 0, o3 = 0, o4 = 0, o5 = 0, o6 = 0, o7 = 0;
 #pragma unroll 1
     for (int p = k0 - 1; p <= k1 + 1; ++p) {
       const int sp1 = (sp == 2) ? 0 : sp + 1;
       const int sq = (sp == 0) ? 2 : sp - 1;
-      const long long ci = (p <= k1) ? cps : 0, pi = (p <= k1) ? pps : 0;
-      gc += ci; gp += pi;
-      cn2 = gc[0]; pn = gp[0];
+      gp += (p <= k1) ? pps : 0;
+      p2 = gp[0];
       const double cl = S.c[sp][rr][xs - 1], cr = S.c[sp][rr][xs + 1];
       const double cs = S.c[sp][rr - 1][xs], cn = S.c[sp][rr + 1][xs];
-      double nxp, nyp, nzp;
-      normal_from(cl, cr, cs, cn, cm, cc, cp, dxinv, nxp, nyp, nzp);
+      op[0] = o0;
+      __builtin_amdgcn_sched_barrier(0);
+      const double ggx = cdiff(dxinv[0], cl, cc, cr);
+      const double ggy = cdiff(dxinv[1], cs, cc, cn);
+      const double ggz = cdiff(dxinv[2], cm, cc, cp);
+      __builtin_amdgcn_sched_barrier(0);
+      op[osc] = o1;
+      __builtin_amdgcn_sched_barrier(0);
+      const double sn = sqrt(ggx * ggx + ggy * ggy + ggz * ggz);
+      const double ng = -((1e-14 < sn) ? sn : 1e-14);
+      __builtin_amdgcn_sched_barrier(0);
+      op[2 * osc] = o2;
+      __builtin_amdgcn_sched_barrier(0);
+      const double nxp = ggx / ng, nyp = ggy / ng;
+      __builtin_amdgcn_sched_barrier(0);
+      op[3 * osc] = o3;
+      __builtin_amdgcn_sched_barrier(0);
+      const double nzp = ggz / ng;
       S.ny[sp][rr][lane] = nyp;
       S.nx[sp][rr - 1][xs] = nxp;
       S.c[sp1][rr][xs] = cp;
-      S.p[sp][rr][xs] = pnew;
+      S.p[sp][rr][xs] = p0;
+      __builtin_amdgcn_sched_barrier(0);
+      op[4 * osc] = o4;
       __syncthreads();
       const double nxl = S.nx[sq][rr - 1][xs - 1], nxr = S.nx[sq][rr - 1][xs + 1];
       const double nys = S.ny[sq][rr - 1][lane], nyn = S.ny[sq][rr + 1][lane];
@@ -144,28 +181,37 @@ __global__ __launch_bounds__(64 * (PA_MTY + 3), MINW) void k_gradcurv_march(BP b
       curv += cdiff(dxinv[1], nys, nyq, nyn);
       curv += cdiff(dxinv[2], nzqm, nzq, nzp);
       curv = curv * 0.5;
-      // phi gradient at plane q (pc = phi(q), pm = phi(q-1), pnew = phi(q+1))
+      __builtin_amdgcn_sched_barrier(0);
+      op[5 * osc] = o5;
+      __builtin_amdgcn_sched_barrier(0);
+      // phi gradient at plane q (pc = phi(q), pm = phi(q-1), p0 = phi(q+1))
       const double pl = S.p[sq][rr][xs - 1], pr = S.p[sq][rr][xs + 1];
       const double ps = S.p[sq][rr - 1][xs], pnn = S.p[sq][rr + 1][xs];
       const double gx = cdiff(dxinv[0], pl, pc, pr);
       const double gy = cdiff(dxinv[1], ps, pc, pnn);
-      const double gz = cdiff(dxinv[2], pm, pc, pnew);
+      const double gz = cdiff(dxinv[2], pm, pc, p0);
+      __builtin_amdgcn_sched_barrier(0);
+      op[6 * osc] = o6;
+      __builtin_amdgcn_sched_barrier(0);
+      const double gm = sqrt(gx * gx + gy * gy + gz * gz);
       // threshold clip (curvature.cpp:557-566); cm = c at plane q.  thr < 0 never clips.
       const bool clip = (thr >= 0.0) && ((cm < thr) || (cm > 1.0 - thr));
-      op[0] = gx;
-      op[osc] = gy;
-      op[2 * osc] = gz;
-      op[3 * osc] = sqrt(gx * gx + gy * gy + gz * gz);
-      op[4 * osc] = clip ? 0.0 : nxq;
-      op[5 * osc] = clip ? 0.0 : nyq;
-      op[6 * osc] = clip ? 0.0 : nzq;
-      op[7 * osc] = clip ? 0.0 : curv;
-      op += (p > k0) ? ops : 0;
-      cm = cc; cc = cp; cp = cn2;
-      pm = pc; pc = pnew; pnew = pn;
+      __builtin_amdgcn_sched_barrier(0);
+      op[7 * osc] = o7;
+      op += (p >= k0 + 2) ? ops : 0;
+      o0 = gx; o1 = gy; o2 = gz; o3 = gm;
+      o4 = clip ? 0.0 : nxq;
+      o5 = clip ? 0.0 : nyq;
+      o6 = clip ? 0.0 : nzq;
+      o7 = clip ? 0.0 : curv;
+      cm = cc; cc = cp; cp = PA_PROG(p2);
+      pm = pc; pc = p0; p0 = p1; p1 = p2;
       nzqm = nzq; nxq = nxp; nyq = nyp; nzq = nzp;
       sp = sp1;
     }
+    // results of the last plane (k1)
+    op[0] = o0; op[osc] = o1; op[2 * osc] = o2; op[3 * osc] = o3;
+    op[4 * osc] = o4; op[5 * osc] = o5; op[6 * osc] = o6; op[7 * osc] = o7;
     return;
   }
 
@@ -180,20 +226,20 @@ __global__ __launch_bounds__(64 * (PA_MTY + 3), MINW) void k_gradcurv_march(BP b
     const int xin = side ? llast + 1 : 1;  // the tile column next to this edge column
     const int rlo = max(rr - 1, 0), rhi = min(rr + 1, PA_MROWS - 1);
     const bool has_n = (rr >= 1 && rr <= PA_MTY);
-    const double* gc = C.p + C.idx(i, j, k0 - 2, ccomp);
-    const double* go = C.p + C.idx(side ? i + 1 : i - 1, j, k0 - 1, ccomp);
-    const double* gp = P.p + P.idx(i, j, k0 - 1, pcomp);
-    double cm = gc[0], cc = gc[cps], cp = gc[2 * cps], cn2;
-    gc += 2 * cps;
-    double co = go[0], con, pnew = gp[0], pn;
+    const double* gp = P.p + P.idx(i, j, k0 - 2, pcomp);
+    const double* go = P.p + P.idx(side ? i + 1 : i - 1, j, k0 - 1, pcomp);
+    double pc = gp[0], p0 = gp[pps], p1 = gp[2 * pps], p2;
+    gp += 2 * pps;
+    double cm = PA_PROG(pc), cc = PA_PROG(p0), cp = PA_PROG(p1);
+    double co = PA_PROG(go[0]), con;
     S.c[0][rr][xs] = cc;
     __syncthreads();
     int sp = 0;
     for (int p = k0 - 1; p <= k1 + 1; ++p) {
       const int sp1 = (sp == 2) ? 0 : sp + 1;
-      const long long ci = (p <= k1) ? cps : 0, pi = (p <= k1) ? pps : 0;
-      gc += ci; go += ci; gp += pi;
-      cn2 = gc[0]; con = go[0]; pn = gp[0];
+      const long long pi = (p <= k1) ? pps : 0;
+      gp += pi; go += pi;
+      p2 = gp[0]; con = go[0];
       const double inner = S.c[sp][rr][xin];
       const double cl = side ? inner : co, cr = side ? co : inner;
       const double cs = S.c[sp][rlo][xs], cn = S.c[sp][rhi][xs];
@@ -201,10 +247,12 @@ __global__ __launch_bounds__(64 * (PA_MTY + 3), MINW) void k_gradcurv_march(BP b
       normal_from(cl, cr, cs, cn, cm, cc, cp, dxinv, nxp, nyp, nzp);
       if (has_n) S.nx[sp][rr - 1][xs] = nxp;
       S.c[sp1][rr][xs] = cp;
-      S.p[sp][rr][xs] = pnew;
+      S.p[sp][rr][xs] = p0;
       __syncthreads();
-      cm = cc; cc = cp; cp = cn2; co = con; pnew = pn;
+      cm = cc; cc = cp; cp = PA_PROG(p2); co = PA_PROG(con);
+      p0 = p1; p1 = p2;
       sp = sp1;
     }
   }
+#undef PA_PROG
 }

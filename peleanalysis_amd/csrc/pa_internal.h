@@ -24,6 +24,10 @@ struct DMFView {
   double* data;
   const long long* off;  // per box, in doubles
   int ncomp, ng;
+  // optional affine view used when this multifab is read as COARSE data: value = (v - xa) * xb.
+  // Lets applyBC on the progress variable interpolate from the coarse phi without a stored coarse c.
+  int xform;
+  double xa, xb;
 };
 
 struct pa_ctx {
@@ -185,7 +189,8 @@ __device__ __forceinline__ double crse_val(const DLevelView& LC, const DMFView& 
   if (!wrap_cell(LC, p)) { ok = false; return 0.0; }
   const int b = owner_of(LC, p);
   if (b < 0) { ok = false; return 0.0; }
-  return MC.data[MC.off[b] + fab_index(LC.boxes[b], MC.ng, MC.ncomp, comp, p[0], p[1], p[2])];
+  const double v = MC.data[MC.off[b] + fab_index(LC.boxes[b], MC.ng, MC.ncomp, comp, p[0], p[1], p[2])];
+  return MC.xform ? (v - MC.xa) * MC.xb : v;
 }
 
 // InterpBndryData (order 3) restated -- see oracle/pa_oracle.c cf_bndry_value

@@ -36,7 +36,37 @@ __global__ void k_march(const double* __restrict__ in, double* __restrict__ out,
   }
 }
 
-template <int CPL, int TY, int NIN>
+template <int CPL, int TZ, int NIN>
+__global__ void k_march_y(const double* __restrict__ in, double* __restrict__ out, int nb, int jseg, int order, long long pad) {
+  constexpr int N = 128;
+  const int tx = N / (64 * CPL), tz = N / TZ, ty = N / jseg;
+  int bid = blockIdx.x;
+  const int per_box = tx * ty * tz;
+  int b, t;
+  if (order == 0) { b = bid / per_box; t = bid % per_box; }
+  else { b = bid % nb; t = bid / nb; }
+  const int bx = t % tx, bz = (t / tx) % tz, by = t / (tx * tz);
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long long cell0 = (((long long)(bz * TZ + w) * N + by * jseg) * N) + bx * 64 * CPL + lane * CPL;
+  const long long boxsz = (long long)N * N * N + pad;
+  const double* pi = in + (long long)b * NIN * boxsz + cell0;
+  double* po = out + (long long)b * 8 * boxsz + cell0;
+  for (int j = 0; j < jseg; ++j) {
+    double v[CPL];
+    for (int q = 0; q < CPL; ++q) v[q] = 0;
+    for (int s = 0; s < NIN; ++s) {
+      if (CPL == 2) { double2 a = *(const double2*)(pi + s * boxsz); v[0] += a.x; v[1] += a.y; }
+      else v[0] += pi[s * boxsz];
+    }
+    for (int s = 0; s < 8; ++s) {
+      if (CPL == 2) *(double2*)(po + s * boxsz) = make_double2(v[0] + s, v[1] + s);
+      else po[s * boxsz] = v[0] + s;
+    }
+    pi += N; po += N;
+  }
+}
+
+template <int CPL, int TY, int NIN, bool MY = false>
 int run(const char* name, int nb, int kseg, int order, long long pad = 0) {
   const long long boxsz = 128LL * 128 * 128 + pad;
   double *in, *out;
@@ -49,7 +79,8 @@ int run(const char* name, int nb, int kseg, int order, long long pad = 0) {
   float best = 1e9;
   for (int it = 0; it < 8; ++it) {
     CK(hipEventRecord(a));
-    hipLaunchKernelGGL((k_march<CPL, TY, NIN>), dim3(grid), dim3(64 * TY), 0, 0, in, out, nb, kseg, order, pad);
+    if (MY) hipLaunchKernelGGL((k_march_y<CPL, TY, NIN>), dim3(grid), dim3(64 * TY), 0, 0, in, out, nb, kseg, order, pad);
+    else hipLaunchKernelGGL((k_march<CPL, TY, NIN>), dim3(grid), dim3(64 * TY), 0, 0, in, out, nb, kseg, order, pad);
     CK(hipEventRecord(b));
     CK(hipEventSynchronize(b));
     float ms; CK(hipEventElapsedTime(&ms, a, b));
@@ -63,11 +94,15 @@ int run(const char* name, int nb, int kseg, int order, long long pad = 0) {
 
 int main() {
   const int nb = 64;
-  for (long long pad : {0LL, 64LL, 512LL, 4096LL + 64, 65536LL + 512 + 64})
-    for (int kseg : {128, 32}) {
-      run<1, 8, 2>("64x8 tile", nb, kseg, 0, pad);
-      run<2, 8, 2>("128x8 tile", nb, kseg, 0, pad);
-      run<2, 8, 1>("128x8 tile 1in", nb, kseg, 0, pad);
+  for (int rep = 0; rep < 2; ++rep)
+  for (long long pad : {64LL})
+    for (int kseg : {128, 64}) {
+      run<1, 8, 2>("z-march 64x8", nb, kseg, 0, pad);
+      run<1, 8, 2, true>("y-march 64x8planes", nb, kseg, 0, pad);
+      run<1, 13, 1>("z-march 64x13 1in", nb, kseg, 0, pad);
+      run<1, 8, 1, true>("y-march 64x8pl 1in", nb, kseg, 0, pad);
+      run<1, 16, 1, true>("y-march 64x16pl 1in", nb, kseg, 0, pad);
+      run<2, 8, 1, true>("y-march 128x8pl 1in", nb, kseg, 0, pad);
     }
   return 0;
 }
