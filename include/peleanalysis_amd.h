@@ -45,6 +45,13 @@ const char* pa_last_error(const pa_ctx*);
 int         pa_sync(pa_ctx*);
 void*       pa_ctx_stream(pa_ctx*);
 
+/* raw HBM buffers for callers without their own device allocator (vertex / triangle buffers of
+ * the marching-cubes entry points, caller-owned FABs).  Copies are synchronous. */
+void* pa_device_malloc(pa_ctx*, int64_t bytes);
+void  pa_device_free(pa_ctx*, void* devptr);
+int   pa_memcpy_h2d(pa_ctx*, void* devdst, const void* hostsrc, int64_t bytes);
+int   pa_memcpy_d2h(pa_ctx*, void* hostdst, const void* devsrc, int64_t bytes);
+
 /* Per-launch timing of the library's own kernels with HIP events recorded on the
  * context's stream (what bench.py's roofline object reports).  Tags: 1 fused
  * grad->curvature, 2 its face fix-up, 3 FillBoundary, 4 applyBC, 5 grad,

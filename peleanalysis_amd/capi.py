@@ -54,6 +54,10 @@ def load_library() -> C.CDLL:
         "pa_last_error": (C.c_char_p, [vp]),
         "pa_sync": (C.c_int, [vp]),
         "pa_ctx_stream": (vp, [vp]),
+        "pa_device_malloc": (vp, [vp, i64]),
+        "pa_device_free": (None, [vp, vp]),
+        "pa_memcpy_h2d": (C.c_int, [vp, vp, vp, i64]),
+        "pa_memcpy_d2h": (C.c_int, [vp, vp, vp, i64]),
         "pa_profile_enable": (C.c_int, [vp, C.c_int]),
         "pa_profile_read": (C.c_int, [vp, C.c_int, C.POINTER(i64), pdbl, C.c_int]),
         "pa_level_create": (vp, [vp, C.c_int, pi32, pi32, pi32, pi32, pdbl, pdbl]),
@@ -163,6 +167,36 @@ class Context:
         if self.h:
             self.lib.pa_ctx_destroy(self.h)
             self.h = None
+
+
+class DevBuf:
+    """raw HBM buffer from pa_device_malloc (freed with the object)"""
+
+    def __init__(self, ctx: Context, nbytes: int):
+        self.ctx, self.nbytes = ctx, int(nbytes)
+        self.ptr = ctx.lib.pa_device_malloc(ctx.h, self.nbytes)
+        if not self.ptr:
+            raise PaError(ctx.lib.pa_last_error(ctx.h).decode())
+
+    @classmethod
+    def from_numpy(cls, ctx: Context, a: np.ndarray) -> "DevBuf":
+        a = np.ascontiguousarray(a)
+        b = cls(ctx, a.nbytes)
+        ctx.check(ctx.lib.pa_memcpy_h2d(ctx.h, b.ptr, a.ctypes.data_as(C.c_void_p), a.nbytes))
+        return b
+
+    def to_numpy(self, dtype, shape) -> np.ndarray:
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        self.ctx.check(self.ctx.lib.pa_memcpy_d2h(self.ctx.h, out.ctypes.data_as(C.c_void_p), self.ptr, out.nbytes))
+        return out
+
+    def __del__(self):
+        try:
+            if self.ptr and self.ctx.h:
+                self.ctx.lib.pa_device_free(self.ctx.h, self.ptr)
+        except Exception:
+            pass
 
 
 class DevLevel:

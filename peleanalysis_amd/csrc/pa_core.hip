@@ -37,6 +37,7 @@ extern "C" void pa_ctx_destroy(pa_ctx* ctx) {
   if (!ctx) return;
   if (ctx->d_red) (void)hipFree(ctx->d_red);
   if (ctx->d_flags) (void)hipFree(ctx->d_flags);
+  if (ctx->d_scr) (void)hipFree(ctx->d_scr);
   for (auto& e : ctx->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -624,5 +625,29 @@ extern "C" int pa_progress_shell_level(pa_ctx* ctx, const pa_mf* s, int comp, do
   ProfScope prof(ctx, PA_TAG_PROGRESS);
   hipLaunchKernelGGL(k_progress_shell, grid, dim3(256), 0, ctx->stream, L->view, s->view, comp, c->view, ccomp, ng, depth, pmin, 1.0 / (pmax - pmin));
   PA_HIP(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------ raw device buffers
+extern "C" void* pa_device_malloc(pa_ctx* ctx, int64_t bytes) {
+  if (!ctx || bytes < 0) return nullptr;
+  void* p = nullptr;
+  if (hipMalloc(&p, (size_t)(bytes > 0 ? bytes : 8)) != hipSuccess) { pa_fail(ctx, "pa_device_malloc: out of device memory"); return nullptr; }
+  return p;
+}
+extern "C" void pa_device_free(pa_ctx* ctx, void* p) {
+  (void)ctx;
+  if (p) (void)hipFree(p);
+}
+extern "C" int pa_memcpy_h2d(pa_ctx* ctx, void* dst, const void* src, int64_t bytes) {
+  if (!ctx || (bytes > 0 && (!dst || !src))) return pa_fail(ctx, "pa_memcpy_h2d: null argument");
+  PA_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyHostToDevice, ctx->stream));
+  PA_HIP(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+extern "C" int pa_memcpy_d2h(pa_ctx* ctx, void* dst, const void* src, int64_t bytes) {
+  if (!ctx || (bytes > 0 && (!dst || !src))) return pa_fail(ctx, "pa_memcpy_d2h: null argument");
+  PA_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream));
+  PA_HIP(hipStreamSynchronize(ctx->stream));
   return 0;
 }

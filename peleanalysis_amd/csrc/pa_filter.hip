@@ -1,0 +1,276 @@
+// pa_filter.hip -- filterPlt hot path on gfx950: PelePhysics Filter (box) applied per FAB
+// (filterPlt.cpp:206-219) and the ghost-cell fill around it (filterPlt.cpp:174-203:
+// FillPatchSingleLevel / FillPatchTwoLevels + first-order extrapolation at walls).
+//
+// apply_filter keeps the reference's summation order (n = z outermost, l = x innermost,
+// ((w_l*w_m)*w_n)*q added term by term) so results are bit-identical to the oracle; the
+// (2ng+1)^3 taps are served from an LDS tile with an ng-deep halo.
+#include "pa_internal.h"
+#include "pa_fabview.h"
+#include <algorithm>
+
+extern "C" int pa_box_filter_weights(int fgr, double* w) {
+  // PelePhysics Filter::set_box_weights restated
+  if (fgr < 1 || !w) return -1;
+  const int ng = fgr / 2, nw = 2 * ng + 1;
+  for (int i = 0; i < nw; ++i) w[i] = 1.0 / (double)fgr;
+  if (nw > 1) { w[0] = 0.5 * w[0]; w[nw - 1] = w[0]; }
+  return ng;
+}
+
+struct FilterW { double w[33]; };  // up to ng = 16
+
+// tile of TX x TY x TZ outputs per 256-thread workgroup; thread = (x, y) column, loops over z
+template <typename BP, int NG, int TX, int TY, int TZ>
+__global__ __launch_bounds__(256) void k_boxfilter(BP bp, int scomp, int ncomp, FilterW W) {
+  constexpr int LX = TX + 2 * NG, LY = TY + 2 * NG, LZ = TZ + 2 * NG, NW = 2 * NG + 1;
+  static_assert(TX * TY == 256, "one thread per (x,y) column");
+  __shared__ double s_in[LZ][LY][LX];
+  __shared__ double s_wlm[NW][NW];  // w[l]*w[m], index [m][l]
+  FabView I, O;
+  DBox V;
+  double dxinv[3];
+  if (!bp.get(blockIdx.y, I, O, V, dxinv)) return;
+  const int nx = V.hi[0] - V.lo[0] + 1, ny = V.hi[1] - V.lo[1] + 1, nz = V.hi[2] - V.lo[2] + 1;
+  const int tx = (nx + TX - 1) / TX, ty = (ny + TY - 1) / TY, tz = (nz + TZ - 1) / TZ;
+  const unsigned bid = blockIdx.x;
+  if (bid >= (unsigned)tx * ty * tz) return;
+  const int i0 = V.lo[0] + (bid % tx) * TX, j0 = V.lo[1] + ((bid / tx) % ty) * TY, k0 = V.lo[2] + (bid / (tx * ty)) * TZ;
+  const int t = threadIdx.x;
+  if (t < NW * NW) s_wlm[t / NW][t % NW] = W.w[t % NW] * W.w[t / NW];
+  const int li = t % TX, lj = t / TX;
+  for (int c = scomp; c < scomp + ncomp; ++c) {
+    __syncthreads();
+    // stage the tile + halo; positions past the box + ng are clamped (their values are never used)
+    for (int q = t; q < LZ * LY * LX; q += 256) {
+      const int x = q % LX, y = (q / LX) % LY, z = q / (LX * LY);
+      const int gi = min(i0 - NG + x, V.hi[0] + NG), gj = min(j0 - NG + y, V.hi[1] + NG), gk = min(k0 - NG + z, V.hi[2] + NG);
+      s_in[z][y][x] = I(gi, gj, gk, c);
+    }
+    __syncthreads();
+    const int i = i0 + li, j = j0 + lj;
+    if (i <= V.hi[0] && j <= V.hi[1]) {
+      for (int kk = 0; kk < TZ && k0 + kk <= V.hi[2]; ++kk) {
+        double acc = 0.0;
+        for (int n = 0; n < NW; ++n) {
+          const double wn = W.w[n];
+          for (int m = 0; m < NW; ++m)
+#pragma unroll
+            for (int l = 0; l < NW; ++l) acc += (s_wlm[m][l] * wn) * s_in[kk + n][lj + m][li + l];
+        }
+        O(i, j, k0 + kk, c) = acc;
+      }
+    }
+  }
+}
+
+// any filter width: taps straight from global memory (L1/L2), same summation order
+template <typename BP>
+__global__ __launch_bounds__(256) void k_boxfilter_generic(BP bp, int scomp, int ncomp, int ng, FilterW W) {
+  FabView I, O;
+  DBox V;
+  double dxinv[3];
+  if (!bp.get(blockIdx.y, I, O, V, dxinv)) return;
+  int i, j, k0, k1;
+  if (!tile_cell(V, i, j, k0, k1)) return;
+  const int nw = 2 * ng + 1;
+  for (int c = scomp; c < scomp + ncomp; ++c)
+    for (int k = k0; k <= k1; ++k) {
+      double acc = 0.0;
+      for (int n = 0; n < nw; ++n)
+        for (int m = 0; m < nw; ++m)
+          for (int l = 0; l < nw; ++l) acc += ((W.w[l] * W.w[m]) * W.w[n]) * I(i + l - ng, j + m - ng, k + n - ng, c);
+      O(i, j, k, c) = acc;
+    }
+}
+
+template <typename BP>
+static void filter_launch(hipStream_t st, const BP& bp, int nx, int ny, int nz, unsigned nboxes, int scomp, int ncomp, int ng, const FilterW& W) {
+  auto grid = [&](int TX, int TY, int TZ) { return dim3(((nx + TX - 1) / TX) * ((ny + TY - 1) / TY) * ((nz + TZ - 1) / TZ), nboxes); };
+  if (ng == 1) hipLaunchKernelGGL((k_boxfilter<BP, 1, 32, 8, 8>), grid(32, 8, 8), dim3(256), 0, st, bp, scomp, ncomp, W);
+  else if (ng == 2) hipLaunchKernelGGL((k_boxfilter<BP, 2, 32, 8, 8>), grid(32, 8, 8), dim3(256), 0, st, bp, scomp, ncomp, W);
+  else if (ng == 4) hipLaunchKernelGGL((k_boxfilter<BP, 4, 32, 8, 4>), grid(32, 8, 4), dim3(256), 0, st, bp, scomp, ncomp, W);
+  else hipLaunchKernelGGL(k_boxfilter_generic<BP>, tile_grid_dims(nx, ny, nz, nboxes), dim3(256), 0, st, bp, scomp, ncomp, ng, W);
+}
+
+extern "C" int pa_boxfilter_level(pa_ctx* ctx, const pa_mf* in, pa_mf* out, int scomp, int ncomp, int ng, const double* w) {
+  if (!ctx || !in || !out || !w) return pa_fail(ctx, "pa_boxfilter_level: null argument");
+  if (in->lev != out->lev) return pa_fail(ctx, "pa_boxfilter_level: different levels");
+  if (ng < 0 || ng > 16 || ng > in->ng) return pa_fail(ctx, "pa_boxfilter_level: input has fewer ghost cells than the filter half-width");
+  if (scomp < 0 || ncomp < 1 || scomp + ncomp > in->ncomp || scomp + ncomp > out->ncomp) return pa_fail(ctx, "pa_boxfilter_level: component range");
+  FilterW W;
+  for (int q = 0; q < 2 * ng + 1; ++q) W.w[q] = w[q];
+  const pa_level* L = in->lev;
+  LevelBP2 bp{L->view, in->view, out->view};
+  ProfScope prof(ctx, PA_TAG_FILTER);
+  filter_launch(ctx->stream, bp, L->maxn[0], L->maxn[1], L->maxn[2], (unsigned)L->boxes.size(), scomp, ncomp, ng, W);
+  PA_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int pa_boxfilter_fab(pa_ctx* ctx, pa_box valid, const pa_fab* in, pa_fab* out, int scomp, int ncomp, int ng, const double* w) {
+  if (!ctx || !in || !out || !w) return pa_fail(ctx, "pa_boxfilter_fab: null argument");
+  if (ng < 0 || ng > 16) return pa_fail(ctx, "pa_boxfilter_fab: filter half-width out of range");
+  std::string why;
+  if (!fab_covers(*in, valid, ng, scomp, ncomp, why) || !fab_covers(*out, valid, 0, scomp, ncomp, why)) return pa_fail(ctx, "pa_boxfilter_fab: " + why);
+  FilterW W;
+  for (int q = 0; q < 2 * ng + 1; ++q) W.w[q] = w[q];
+  FabBP2 bp{fab_view(*in), fab_view(*out), to_dbox(valid), {1, 1, 1}};
+  filter_launch(ctx->stream, bp, valid.hi[0] - valid.lo[0] + 1, valid.hi[1] - valid.lo[1] + 1, valid.hi[2] - valid.lo[2] + 1, 1, scomp, ncomp, ng, W);
+  PA_HIP(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------ ghost cells for filterPlt
+// shell enumeration shared with FillBoundary (pa_core.hip)
+__device__ __forceinline__ bool shell_cell2(const DBox& B, int ng, long long t, int& i, int& j, int& k) {
+  const int nx = B.hi[0] - B.lo[0] + 1, ny = B.hi[1] - B.lo[1] + 1, nz = B.hi[2] - B.lo[2] + 1;
+  const int gx = nx + 2 * ng, gy = ny + 2 * ng;
+  const long long nzs = (long long)ng * gy * gx, nys = (long long)nz * ng * gx, nxs = (long long)nz * ny * ng;
+  if (t < 2 * nzs) {
+    const int s = t >= nzs;
+    if (s) t -= nzs;
+    i = B.lo[0] - ng + (int)(t % gx);
+    j = B.lo[1] - ng + (int)((t / gx) % gy);
+    k = (int)(t / ((long long)gx * gy));
+    k = s ? B.hi[2] + 1 + k : B.lo[2] - ng + k;
+    return true;
+  }
+  t -= 2 * nzs;
+  if (t < 2 * nys) {
+    const int s = t >= nys;
+    if (s) t -= nys;
+    i = B.lo[0] - ng + (int)(t % gx);
+    j = (int)((t / gx) % ng);
+    k = B.lo[2] + (int)(t / ((long long)gx * ng));
+    j = s ? B.hi[1] + 1 + j : B.lo[1] - ng + j;
+    return true;
+  }
+  t -= 2 * nys;
+  if (t < 2 * nxs) {
+    const int s = t >= nxs;
+    if (s) t -= nxs;
+    i = (int)(t % ng);
+    j = B.lo[1] + (int)((t / ng) % ny);
+    k = B.lo[2] + (int)(t / ((long long)ng * ny));
+    i = s ? B.hi[0] + 1 + i : B.lo[0] - ng + i;
+    return true;
+  }
+  return false;
+}
+
+static long long max_shell2(const pa_level* L, int ng) {
+  long long m = 0;
+  for (const DBox& B : L->boxes) {
+    const long long nx = B.hi[0] - B.lo[0] + 1, ny = B.hi[1] - B.lo[1] + 1, nz = B.hi[2] - B.lo[2] + 1;
+    m = std::max(m, (nx + 2 * ng) * (ny + 2 * ng) * (nz + 2 * ng) - nx * ny * nz);
+  }
+  return m;
+}
+
+// first-order extrapolation: a ghost cell outside a non-periodic wall takes the value of the
+// nearest cell inside the domain (which lies in the same grown FAB and is already filled)
+__global__ void k_foextrap(DLevelView L, DMFView M, int comp, int ncomp, int ngf) {
+  const int b = blockIdx.y;
+  const DBox B = L.boxes[b];
+  const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  int q[3];
+  if (!shell_cell2(B, ngf, t, q[0], q[1], q[2])) return;
+  int p[3] = {q[0], q[1], q[2]};
+  bool out = false;
+  for (int d = 0; d < 3; ++d)
+    if (!L.is_per[d]) {
+      if (p[d] < L.domlo[d]) { p[d] = L.domlo[d]; out = true; }
+      if (p[d] > L.domhi[d]) { p[d] = L.domhi[d]; out = true; }
+    }
+  if (!out) return;
+  double* f = M.data + M.off[b];
+  for (int c = comp; c < comp + ncomp; ++c) f[fab_index(B, M.ng, M.ncomp, c, q[0], q[1], q[2])] = f[fab_index(B, M.ng, M.ncomp, c, p[0], p[1], p[2])];
+}
+
+extern "C" int pa_foextrap(pa_ctx* ctx, pa_mf* M, int comp, int ncomp, int ng) {
+  if (!ctx || !M) return pa_fail(ctx, "pa_foextrap: null argument");
+  if (ng > M->ng || ng < 0 || comp < 0 || comp + ncomp > M->ncomp) return pa_fail(ctx, "pa_foextrap: ng/component range");
+  if (ng == 0) return 0;
+  dim3 grid((unsigned)((max_shell2(M->lev, ng) + 255) / 256), (unsigned)M->lev->boxes.size());
+  hipLaunchKernelGGL(k_foextrap, grid, dim3(256), 0, ctx->stream, M->lev->view, M->view, comp, ncomp, ng);
+  PA_HIP(hipGetLastError());
+  return 0;
+}
+
+// FillPatchTwoLevels for the ghost cells that no fine box covers: piecewise constant or
+// cell-conservative linear interpolation of the coarse level (see oracle/pa_oracle.c
+// orc_fillpatch_two_levels for the restated limiter)
+__global__ void k_fillpatch2(DLevelView L, DMFView M, DLevelView LC, DMFView MC, int comp, int ncomp, int ngf, int r, int interp, int* nbad) {
+  const int b = blockIdx.y;
+  const DBox B = L.boxes[b];
+  const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  int q[3];
+  if (!shell_cell2(B, ngf, t, q[0], q[1], q[2])) return;
+  if (classify(L, q[0], q[1], q[2]) != 1) return;  // covered: FillBoundary; outside a wall: foextrap afterwards
+  const int qc[3] = {coarsen_idx(q[0], r), coarsen_idx(q[1], r), coarsen_idx(q[2], r)};
+  double* f = M.data + M.off[b];
+  for (int c = comp; c < comp + ncomp; ++c) {
+    bool ok = true;
+    const double u0 = crse_val(LC, MC, c, qc[0], qc[1], qc[2], ok);
+    double val = u0;
+    if (interp == 1) {
+      double umin = u0, umax = u0, sl[3];
+      for (int dz = -1; dz <= 1; ++dz)
+        for (int dy = -1; dy <= 1; ++dy)
+          for (int dx = -1; dx <= 1; ++dx) {
+            int p[3] = {qc[0] + dx, qc[1] + dy, qc[2] + dz};
+            for (int d = 0; d < 3; ++d)
+              if (!LC.is_per[d]) { p[d] = max(p[d], LC.domlo[d]); p[d] = min(p[d], LC.domhi[d]); }
+            const double v = crse_val(LC, MC, c, p[0], p[1], p[2], ok);
+            umin = v < umin ? v : umin;
+            umax = v > umax ? v : umax;
+          }
+      for (int d = 0; d < 3; ++d) {
+        int pm[3] = {qc[0], qc[1], qc[2]}, pp[3] = {qc[0], qc[1], qc[2]};
+        pm[d] -= 1; pp[d] += 1;
+        bool has_m = true, has_p = true;
+        if (!LC.is_per[d]) { has_m = pm[d] >= LC.domlo[d]; has_p = pp[d] <= LC.domhi[d]; }
+        const double um = has_m ? crse_val(LC, MC, c, pm[0], pm[1], pm[2], ok) : u0;
+        const double up = has_p ? crse_val(LC, MC, c, pp[0], pp[1], pp[2], ok) : u0;
+        double dc;
+        if (has_m && has_p) dc = 0.5 * (up - um);
+        else if (has_p) dc = up - u0;
+        else if (has_m) dc = u0 - um;
+        else dc = 0.0;
+        const double df = 2.0 * (up - u0), db = 2.0 * (u0 - um);
+        double lim = (df * db >= 0.0) ? fmin(fabs(df), fabs(db)) : 0.0;
+        if (!(has_m && has_p)) lim = fabs(dc);
+        const double sgn = (dc > 0.0) ? 1.0 : ((dc < 0.0) ? -1.0 : 0.0);
+        sl[d] = sgn * fmin(lim, fabs(dc));
+      }
+      double alpha = 1.0;
+      const double dmax = 0.5 * (fabs(sl[0]) + fabs(sl[1]) + fabs(sl[2]));
+      if (dmax != 0.0) {
+        const double a1 = (umax - u0) / dmax, a2 = (u0 - umin) / dmax;
+        alpha = fmin(1.0, fmin(a1, a2));
+      }
+      double acc = u0;
+      for (int d = 0; d < 3; ++d) {
+        const double xoff = ((double)(q[d] - qc[d] * r) + 0.5) / (double)r - 0.5;
+        acc += xoff * (alpha * sl[d]);
+      }
+      val = acc;
+    }
+    if (!ok) atomicAdd(nbad, 1);
+    f[fab_index(B, M.ng, M.ncomp, c, q[0], q[1], q[2])] = val;
+  }
+}
+
+extern "C" int pa_fillpatch_two_levels(pa_ctx* ctx, pa_mf* fine, const pa_mf* crse, int comp, int ncomp, int ng, int ratio, int interp_type) {
+  if (!ctx || !fine || !crse) return pa_fail(ctx, "pa_fillpatch_two_levels: null argument");
+  if (ng > fine->ng || ng < 0 || comp < 0 || comp + ncomp > fine->ncomp || comp + ncomp > crse->ncomp) return pa_fail(ctx, "pa_fillpatch_two_levels: ng/component range");
+  if (ratio != 2) return pa_fail(ctx, "pa_fillpatch_two_levels: only refinement ratio 2 is supported (quirk Q11)");
+  if (interp_type != 0 && interp_type != 1) return pa_fail(ctx, "pa_fillpatch_two_levels: interp_type must be 0 (pc) or 1 (cell-conservative linear)");
+  if (ng == 0) return 0;
+  dim3 grid((unsigned)((max_shell2(fine->lev, ng) + 255) / 256), (unsigned)fine->lev->boxes.size());
+  hipLaunchKernelGGL(k_fillpatch2, grid, dim3(256), 0, ctx->stream, fine->lev->view, fine->view, crse->lev->view, crse->view, comp, ncomp, ng, ratio,
+                     interp_type, ctx->d_flags);
+  PA_HIP(hipGetLastError());
+  return 0;
+}

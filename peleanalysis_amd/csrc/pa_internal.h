@@ -38,6 +38,8 @@ struct pa_ctx {
   double* d_red = nullptr;  // reduction scratch
   size_t red_cap = 0;
   int* d_flags = nullptr;   // [0] = coarse-fine ghost cells whose coarse data was missing
+  void* d_scr = nullptr;    // grow-only scratch (marching cubes)
+  size_t scr_cap = 0;
   // optional per-launch timing of tagged kernels with HIP events on ctx->stream (bench.py roofline)
   bool profile = false;
   struct Ev { hipEvent_t a, b; int tag; };
