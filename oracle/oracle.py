@@ -261,3 +261,96 @@ def mc_fab(state, mask, slo, shi, isocomp, isoval, llo, lhi):
                       C.c_int64(nv.value), tris.ctypes.data_as(C.POINTER(C.c_int32)), C.c_int64(nt.value), C.byref(nv), C.byref(nt))
     assert rc == 0
     return verts[:nv.value], vkeys[:nv.value], tris[:nt.value]
+
+
+# ---------------------------------------------------------------- isosurface pipeline
+def iso_merge(fragments, ncomp):
+    """isosurface.cpp:1687-1726 + 1751-1812 restated: merge per-FAB (verts, tris) fragments in order.
+    Nodes are unique by position up to the reference's tolerance (Node::operator<, :834-873: two
+    nodes closer than 1e-15 in Euclidean distance are the same node -- this is what merges the
+    copies of a vertex that two FABs interpolated from opposite ends of the same edge; quirk Q10: a
+    spatial hash replaces the not-quite-strict-weak std::set ordering, the FIRST inserted copy is
+    kept); ids = order of first insertion; elements are rotated so the smallest id comes first,
+    degenerate ones dropped, then sorted (std::set<Element>)."""
+    EPS, H = 1.0e-15, 1.0e-14
+    grid = {}
+    nodes = []
+    elts = set()
+    for verts, tris in fragments:
+        ids = np.empty(len(verts), dtype=np.int64)
+        for q in range(len(verts)):
+            p = verts[q, :3]
+            g = (int(np.floor(p[0] / H)), int(np.floor(p[1] / H)), int(np.floor(p[2] / H)))
+            i = None
+            for dz in (-1, 0, 1):
+                for dy in (-1, 0, 1):
+                    for dx in (-1, 0, 1):
+                        for cand in grid.get((g[0] + dx, g[1] + dy, g[2] + dz), ()):
+                            d = nodes[cand][:3] - p
+                            if np.sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]) < EPS:
+                                i = cand if i is None else min(i, cand)
+            if i is None:
+                i = len(nodes)
+                grid.setdefault(g, []).append(i)
+                nodes.append(verts[q].copy())
+            ids[q] = i
+        for t in tris:
+            v = [int(ids[t[0]]), int(ids[t[1]]), int(ids[t[2]])]
+            if v[0] == v[1] or v[1] == v[2] or v[0] == v[2]:
+                continue
+            s = v.index(min(v))
+            elts.add(tuple(v[s:] + v[:s]))
+    nodes = np.array(nodes).reshape(-1, ncomp) if nodes else np.zeros((0, ncomp))
+    elts = np.array(sorted(elts), dtype=np.int32).reshape(-1, 3)
+    return nodes, elts
+
+
+def iso_fab_inputs(levels, states, lev, b, ng=1):
+    """mask (isosurface.cpp:1540-1563) and loop box (:1566-1569) of box b; state fab as a contiguous array"""
+    L = levels[lev]
+    lo, hi = L.boxes[b, :3] - ng, L.boxes[b, 3:] + ng
+    shape = tuple(int(x) for x in (hi - lo + 1)[::-1])
+    mask = np.ones(shape)
+    if lev + 1 < len(levels):
+        for fb in levels[lev + 1].boxes:
+            clo, chi = fb[:3] // 2, fb[3:] // 2  # coarsen (non-negative indices)
+            ilo, ihi = np.maximum(lo, clo), np.minimum(hi, chi)
+            if np.all(ilo <= ihi):
+                mask[ilo[2] - lo[2]:ihi[2] - lo[2] + 1, ilo[1] - lo[1]:ihi[1] - lo[1] + 1, ilo[0] - lo[0]:ihi[0] - lo[0] + 1] = -1.0
+    llo = np.maximum(lo, L.domlo)
+    lhi = np.minimum(hi, L.domhi) - 1
+    return lo, hi, mask, llo, lhi
+
+
+def isosurface_pipeline(levels, fields, comps, isocomp_index, isoval, MF):
+    """isosurface.cpp:1434-1728 (non-periodic, nGrow = 1, rm_external_elements is a no-op then).
+    fields[l]: multifab holding the plotfile components; comps: which of them to map; the iso
+    component is comps[isocomp_index].  Returns (nodes [N][3+len(comps)], elements [M][3] 0-based)."""
+    L = lib()
+    nc = 3 + len(comps)
+    states, frags = [], []
+    for l, lv in enumerate(levels):
+        st = MF(lv, nc, 1, fill=-666.0)
+        dx = lv.dx
+        for b in range(lv.nboxes):
+            f = st.fab(b)
+            lo = lv.boxes[b, :3] - 1
+            nz, ny, nx = f.shape[1:]
+            f[0] = ((np.arange(lo[0], lo[0] + nx) + 0.5) * dx[0] + lv.prob_lo[0])[None, None, :]
+            f[1] = ((np.arange(lo[1], lo[1] + ny) + 0.5) * dx[1] + lv.prob_lo[1])[None, :, None]
+            f[2] = ((np.arange(lo[2], lo[2] + nz) + 0.5) * dx[2] + lv.prob_lo[2])[:, None, None]
+            for n, c in enumerate(comps):
+                st.valid(b)[3 + n] = fields[l].valid(b)[c]
+        fill_boundary(st, 0, nc, 1)
+        if l > 0:
+            nbad = L.orc_fillpatch_two_levels(_p(_mf(st)), _p(_mf(states[l - 1])), 0, nc, 1, 2, 0)
+            assert nbad == 0
+        states.append(st)
+    for l, lv in enumerate(levels):
+        for b in range(lv.nboxes):
+            lo, hi, mask, llo, lhi = iso_fab_inputs(levels, states, l, b)
+            if np.any(llo > lhi):
+                continue
+            verts, _, tris = mc_fab(np.ascontiguousarray(states[l].fab(b)), mask, lo, hi, 3 + isocomp_index, isoval, llo, lhi)
+            frags.append((verts, tris))
+    return iso_merge(frags, nc)

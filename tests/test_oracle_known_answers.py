@@ -1,0 +1,192 @@
+"""The oracle is pinned by analytic known-answer tests (the reference ships no golden vectors and
+cannot be built here: PARITY UNPINNED).  CPU only."""
+import numpy as np
+import pytest
+
+from peleanalysis_amd.hierarchy import MultiFab, cell_centers, fill_analytic, field_trig, nested_hierarchy
+
+
+def test_grad_multipass_equals_fused_bitwise(oracle):
+    """reference-shaped pass-by-pass form (face fluxes, 1/bscalar, average, mult(-1)) == one sweep"""
+    H = nested_hierarchy(32, 1, 16, is_per=(1, 1, 1))
+    lv = H.levels[0]
+    s = MultiFab(lv, 1, 1)
+    fill_analytic(s, 0, field_trig)
+    a, b = MultiFab(lv, 4, 0), MultiFab(lv, 4, 0)
+    bc = oracle.bc_from_flags(lv.is_per)
+    oracle.grad_pipeline([lv], [s.copy()], 0, bc, [a], 0, multipass=True)
+    oracle.grad_pipeline([lv], [s.copy()], 0, bc, [b], 0, multipass=False)
+    assert np.array_equal(a.data.view(np.int64), b.data.view(np.int64))
+
+
+def test_grad_trig_central_difference_factor(oracle):
+    """C1 config: d/dx of sin(kx) by central differences = k cos(kx) * sin(k h)/(k h), exactly"""
+    H = nested_hierarchy(64, 1, 32, is_per=(1, 1, 1))
+    lv = H.levels[0]
+    s = MultiFab(lv, 1, 1)
+    fill_analytic(s, 0, field_trig)
+    o = MultiFab(lv, 4, 0)
+    oracle.grad_pipeline([lv], [s], 0, oracle.bc_from_flags(lv.is_per), [o], 0)
+    h, k = lv.dx[0], 2 * np.pi
+    for b in range(lv.nboxes):
+        x, y, z = cell_centers(lv, b, 0)
+        gx = 600 * k * np.cos(k * x) * np.cos(2 * k * y) * np.sin(k * z + 0.3) * np.sin(k * h) / (k * h)
+        gy = -600 * 2 * k * np.sin(k * x) * np.sin(2 * k * y) * np.sin(k * z + 0.3) * np.sin(2 * k * h) / (2 * k * h)
+        v = o.valid(b)
+        assert np.abs(v[0] - gx).max() < 1e-9 * 600 * k
+        assert np.abs(v[1] - gy).max() < 1e-9 * 1200 * k
+        assert np.allclose(v[3], np.sqrt(v[0] ** 2 + v[1] ** 2 + v[2] ** 2), rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("fn,exact", [
+    (lambda x, y, z: 3.0 * x - 2.0 * y + 0.5 * z + 1.0 + 0 * x * y * z, lambda x, y, z: (3.0 + 0 * x * y * z, -2.0 + 0 * x * y * z, 0.5 + 0 * x * y * z)),
+    (lambda x, y, z: x * x + 2 * y * y - z * z + x * y + y * z - 0.5 * x * z + x,
+     lambda x, y, z: (2 * x + y - 0.5 * z + 1 + 0 * y * z, 4 * y + x + z + 0 * x * z, -2 * z + y - 0.5 * x + 0 * y)),
+])
+def test_grad_exact_for_quadratics_across_coarse_fine(oracle, fn, exact):
+    """central differences + the coarse-fine boundary interpolation (tangential order 3 with cross
+    term, normal cubic) are exact for quadratics: fine levels must reproduce the analytic gradient"""
+    H = nested_hierarchy(32, 3, 16, is_per=(0, 0, 0))
+    sts, outs = [], []
+    for lv in H.levels:
+        s = MultiFab(lv, 1, 1)
+        fill_analytic(s, 0, fn)
+        sts.append(s)
+        outs.append(MultiFab(lv, 4, 0))
+    oracle.grad_pipeline(H.levels, sts, 0, oracle.bc_from_flags((0, 0, 0)), outs, 0)
+    for l in (1, 2):  # fine levels do not touch the physical walls
+        lv = H.levels[l]
+        for b in range(lv.nboxes):
+            x, y, z = cell_centers(lv, b, 0)
+            ex = exact(x, y, z)
+            for d in range(3):
+                assert np.abs(outs[l].valid(b)[d] - ex[d]).max() < 2e-13, (l, b, d)
+
+
+def test_neumann_and_reflect_odd_walls(oracle):
+    """wall cell gradient: Neumann ghost = interior -> half a one-sided difference; reflect_odd ghost = -interior"""
+    H = nested_hierarchy(16, 1, 8, is_per=(1, 1, 0))
+    lv = H.levels[0]
+    f = lambda x, y, z: 2.0 + z + 0 * x * y
+    for sym, expect in ((0, 0.5), (1, None)):
+        s = MultiFab(lv, 1, 1)
+        fill_analytic(s, 0, f)
+        o = MultiFab(lv, 4, 0)
+        oracle.grad_pipeline([lv], [s], 0, oracle.bc_from_flags((1, 1, 0), (0, 0, sym)), [o], 0)
+        for b in range(lv.nboxes):
+            if lv.boxes[b, 2] == 0:
+                gz = o.valid(b)[2][0]
+                z0 = 0.5 * lv.dx[2]
+                want = 0.5 if sym == 0 else (2.0 + 1.5 * lv.dx[2] + (2.0 + z0)) / (2 * lv.dx[2])
+                assert np.allclose(gz, want, rtol=1e-13)
+
+
+def test_curvature_of_sphere(oracle):
+    """c = distance from a point: n = -r_hat, mean curvature 0.5 div n = -1/r, Gaussian = 1/r^2, O(h^2)"""
+    H = nested_hierarchy(32, 3, 16, is_per=(1, 1, 0))
+    f = lambda x, y, z: np.sqrt((x - 0.5) ** 2 + (y - 0.5) ** 2 + (z - 0.5) ** 2) + 0 * x * y * z
+    sts, outs = [], []
+    for lv in H.levels:
+        s = MultiFab(lv, 1, 2)
+        fill_analytic(s, 0, f)
+        sts.append(s)
+        outs.append(MultiFab(lv, 8, 0))
+    oracle.curvature_pipeline(H.levels, sts, 0, oracle.bc_from_flags((1, 1, 0)), outs, 0, MultiFab, do_gauss=True)
+    errs = []
+    for l, lv in enumerate(H.levels):
+        e = eg = 0.0
+        for b in range(lv.nboxes):
+            x, y, z = cell_centers(lv, b, 0)
+            r = f(x, y, z)
+            m = (r > 0.1) & (r < 0.22)
+            if m.any():
+                e = max(e, np.abs(outs[l].valid(b)[1][m] * r[m] + 1).max())
+                eg = max(eg, np.abs(outs[l].valid(b)[5][m] * r[m] ** 2 - 1).max())
+                nn = np.sqrt(sum(outs[l].valid(b)[2 + d][m] ** 2 for d in range(3)))
+                assert np.abs(nn - 1).max() < 1e-12  # unit normal
+        errs.append((e, eg))
+    assert errs[0][0] < 0.08 and errs[1][0] < 0.03 and errs[2][0] < 0.008  # second order
+    assert errs[2][1] < 0.02
+
+
+def test_threshold_clips_curvature_and_normal(oracle):
+    H = nested_hierarchy(16, 2, 8, is_per=(1, 1, 1))
+    f = lambda x, y, z: np.tanh((np.sqrt((x - 0.5) ** 2 + (y - 0.5) ** 2 + (z - 0.5) ** 2) - 0.25) / 0.1) + 0 * x * y * z
+    sts = []
+    outs = [MultiFab(lv, 5, 0) for lv in H.levels]
+    for lv in H.levels:
+        s = MultiFab(lv, 1, 2)
+        fill_analytic(s, 0, f)
+        sts.append(s)
+    oracle.curvature_pipeline(H.levels, sts, 0, [0, 0, 0], outs, 0, MultiFab, threshold=0.2)
+    for l, lv in enumerate(H.levels):
+        for b in range(lv.nboxes):
+            v = outs[l].valid(b)
+            clipped = (v[0] < 0.2) | (v[0] > 0.8)
+            assert clipped.any() and (~clipped).any()
+            for c in (1, 2, 3, 4):
+                assert np.all(v[c][clipped] == 0.0)
+            assert np.all(np.abs(v[2][~clipped]) + np.abs(v[3][~clipped]) + np.abs(v[4][~clipped]) > 0)
+
+
+def test_box_filter_weights_and_identity(oracle):
+    for fgr, ng in ((2, 1), (4, 2), (8, 4), (6, 3)):
+        n, w = oracle.box_filter_weights(fgr)
+        assert n == ng and len(w) == 2 * ng + 1
+        assert abs(w.sum() - 1.0) < 1e-15 and w[0] == w[-1] == 0.5 / fgr and np.all(w[1:-1] == 1.0 / fgr)
+    # constants and linear fields are reproduced in the interior (symmetric weights, sum 1)
+    H = nested_hierarchy(16, 1, 8, is_per=(1, 1, 1))
+    lv = H.levels[0]
+    s = MultiFab(lv, 2, 2)
+    fill_analytic(s, 0, lambda x, y, z: 7.5 + 0 * x * y * z)
+    fill_analytic(s, 1, lambda x, y, z: 1.0 + 2 * x - 3 * y + 0.25 * z + 0 * x * y * z)
+    o = [MultiFab(lv, 2, 0)]
+    oracle.filter_pipeline([lv], [s], o, 2, base_fgr=4)
+    for b in range(lv.nboxes):
+        x, y, z = cell_centers(lv, b, 0)
+        assert np.abs(o[0].valid(b)[0] - 7.5).max() < 1e-13
+        interior = (x > 0.2) & (x < 0.8) & (y > 0.2) & (y < 0.8) & (z > 0.2) & (z < 0.8)  # away from the periodic jump
+        lin = 1.0 + 2 * x - 3 * y + 0.25 * z + 0 * x * y * z
+        if interior.any():
+            assert np.abs(o[0].valid(b)[1] - lin)[interior].max() < 1e-13
+
+
+def _manifold_checks(nodes, elts):
+    """checkIso.cpp:127-149: every edge is used by exactly two triangles, in opposite directions"""
+    edges = {}
+    for t in elts:
+        for a, b in ((t[0], t[1]), (t[1], t[2]), (t[2], t[0])):
+            edges[(a, b)] = edges.get((a, b), 0) + 1
+    for (a, b), n in edges.items():
+        assert n == 1, "directed edge used twice (orientation flip)"
+        assert (b, a) in edges, "open edge: surface not closed"
+    V, E, F = len(nodes), len(edges) // 2, len(elts)
+    return V - E + F
+
+
+def test_isosurface_sphere_closed_manifold_amr(oracle):
+    """sphere crossing both coarse-fine interfaces of a 3-level hierarchy: closed, orientable
+    (checkIso invariant), Euler characteristic 2, area -> 4 pi R^2, mapped component interpolated"""
+    H = nested_hierarchy(32, 3, 16, is_per=(0, 0, 0))
+    R = 0.3
+    fields = []
+    for lv in H.levels:
+        s = MultiFab(lv, 2, 0)
+        fill_analytic(s, 0, lambda x, y, z: 1000.0 + 400.0 * (np.sqrt((x - 0.5) ** 2 + (y - 0.5) ** 2 + (z - 0.5) ** 2) - R) + 0 * x * y * z)
+        fill_analytic(s, 1, lambda x, y, z: x + 2 * y + 3 * z + 0 * x * y * z)
+        fields.append(s)
+    nodes, elts = oracle.isosurface_pipeline(H.levels, fields, [0, 1], 0, 1000.0, MultiFab)
+    assert len(elts) > 2000
+    assert _manifold_checks(nodes, elts) == 2
+    p = nodes[:, :3]
+    r = np.sqrt(((p - 0.5) ** 2).sum(1))
+    assert np.abs(r - R).max() < 2e-3                      # vertices on the sphere (linear interpolation of a distance)
+    assert np.abs(nodes[:, 3] - 1000.0).max() < 1e-9       # iso component equals isoVal at every vertex
+    assert np.abs(nodes[:, 4] - (p[:, 0] + 2 * p[:, 1] + 3 * p[:, 2])).max() < 1e-12  # linear field mapped exactly
+    a, b, c = p[elts[:, 0]], p[elts[:, 1]], p[elts[:, 2]]
+    area = 0.5 * np.sqrt((np.cross(b - a, c - a) ** 2).sum(1)).sum()
+    assert abs(area / (4 * np.pi * R * R) - 1) < 0.01
+    # consistent orientation: normals all point the same way relative to the centre
+    nrm = np.cross(b - a, c - a)
+    s = np.sign((nrm * ((a + b + c) / 3 - 0.5)).sum(1))
+    assert np.all(s == s[0])

@@ -40,11 +40,10 @@ def make_states(H, ncomp, ng, fn, seed=None):
                 v = s.valid(b)
                 v += 1e-3 * rng.uniform(-1, 1, size=v.shape)
         # poison ghosts so an unfilled ghost cell cannot go unnoticed
-        for b in range(lev.nboxes):
+        for b in range(lev.nboxes if ng else 0):
             f = s.fab(b)
             m = np.ones(f.shape[1:], bool)
-            if ng:
-                m[ng:-ng, ng:-ng, ng:-ng] = False
+            m[ng:-ng, ng:-ng, ng:-ng] = False
             f[:, m] = np.nan
         out.append(s)
     return out
