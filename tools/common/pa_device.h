@@ -1,0 +1,50 @@
+// pa_device.h -- glue between the host plotfile containers and the C ABI (device levels / multifabs)
+#pragma once
+#include <memory>
+
+#include "pa_plotfile.h"
+
+namespace pa {
+
+struct Ctx {
+  pa_ctx* h = nullptr;
+  Ctx() {
+    h = pa_ctx_create(0, nullptr);
+    if (!h) Abort("no MI355X / HIP device available (this build has no CPU fallback)");
+  }
+  ~Ctx() { pa_ctx_destroy(h); }
+  void check(int rc) const {
+    if (rc != 0) Abort(pa_last_error(h));
+  }
+};
+
+struct DevLevel {
+  pa_level* h = nullptr;
+  DevLevel(const Ctx& c, const std::vector<Box3>& boxes, const Box3& dom, const int is_per[3], const double plo[3], const double phi[3]) {
+    std::vector<int32_t> b6(6 * boxes.size());
+    for (size_t i = 0; i < boxes.size(); ++i)
+      for (int d = 0; d < 3; ++d) { b6[6 * i + d] = boxes[i].lo[d]; b6[6 * i + 3 + d] = boxes[i].hi[d]; }
+    int32_t per[3] = {is_per[0], is_per[1], is_per[2]};
+    h = pa_level_create(c.h, (int)boxes.size(), b6.data(), dom.lo, dom.hi, per, plo, phi);
+    if (!h) Abort(pa_last_error(c.h));
+  }
+  ~DevLevel() { pa_level_destroy(h); }
+  DevLevel(const DevLevel&) = delete;
+};
+
+struct DevMF {
+  pa_mf* h = nullptr;
+  DevMF(const Ctx& c, const DevLevel& L, int ncomp, int ng) {
+    h = pa_mf_create(c.h, L.h, ncomp, ng, nullptr);
+    if (!h) Abort(pa_last_error(c.h));
+  }
+  ~DevMF() { pa_mf_destroy(h); }
+  DevMF(const DevMF&) = delete;
+};
+
+inline void bc_from_flags(const std::vector<int>& is_per, const std::vector<int>& sym_dir, int32_t bc[3]) {
+  // grad.cpp:180-193 / curvature.cpp:428-441
+  for (int d = 0; d < 3; ++d) bc[d] = is_per[d] == 1 ? PA_BC_PERIODIC : (sym_dir[d] == 1 ? PA_BC_REFLECT_ODD : PA_BC_NEUMANN);
+}
+
+}  // namespace pa

@@ -1,0 +1,338 @@
+// pa_plotfile.h -- AMReX plotfile (HyperCLaw-V1.1) reader / writer and MEF writer for the tool
+// drivers (Docs/source/data.rst:19-32, isosurface.cpp:2097-2134 of the
+// reference).  Host-only C++17, no AMReX.
+//
+// HostMF keeps a level's data in the flat layout of pa_mf_layout (include/peleanalysis_amd.h), so
+// a whole level goes to / from HBM with one pa_mf_upload / pa_mf_download.
+#pragma once
+#include <sys/stat.h>
+
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <regex>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/peleanalysis_amd.h"
+#include "pa_parmparse.h"
+
+namespace pa {
+
+struct Box3 {
+  int lo[3], hi[3];
+  long long numPts() const { return (long long)(hi[0] - lo[0] + 1) * (hi[1] - lo[1] + 1) * (hi[2] - lo[2] + 1); }
+};
+
+struct LevelMeta {
+  Box3 domain;
+  std::vector<Box3> boxes;
+  int level_step = 0;
+  // where each FAB lives on disk
+  std::vector<std::string> fab_file;
+  std::vector<long long> fab_off;
+};
+
+struct PlotfileHeader {
+  std::vector<std::string> names;
+  double time = 0.0;
+  int nlev = 0;
+  double prob_lo[3], prob_hi[3];
+  std::vector<int> ref_ratio;
+  std::vector<LevelMeta> lev;
+  std::string path;
+  int comp(const std::string& n) const {
+    for (size_t i = 0; i < names.size(); ++i)
+      if (names[i] == n) return (int)i;
+    return -1;
+  }
+};
+
+// level data in pa_mf_layout order
+struct HostMF {
+  std::vector<Box3> boxes;
+  int ncomp = 0, ng = 0;
+  std::vector<int64_t> off, cs;
+  std::vector<double> data;
+  void define(const std::vector<Box3>& b, int nc, int g) {
+    boxes = b; ncomp = nc; ng = g;
+    std::vector<int32_t> b6(6 * b.size());
+    for (size_t i = 0; i < b.size(); ++i)
+      for (int d = 0; d < 3; ++d) { b6[6 * i + d] = b[i].lo[d]; b6[6 * i + 3 + d] = b[i].hi[d]; }
+    off.resize(b.size()); cs.resize(b.size());
+    const int64_t tot = pa_mf_layout((int)b.size(), b6.data(), nc, g, off.data(), cs.data());
+    data.assign((size_t)tot, 0.0);
+  }
+  double* ptr(int b, int c, int i, int j, int k) {
+    const Box3& B = boxes[b];
+    const long long nx = B.hi[0] - B.lo[0] + 1 + 2 * ng, ny = B.hi[1] - B.lo[1] + 1 + 2 * ng;
+    return data.data() + off[b] + (long long)c * cs[b] + ((long long)(k - B.lo[2] + ng) * ny + (j - B.lo[1] + ng)) * nx + (i - B.lo[0] + ng);
+  }
+  std::vector<int32_t> boxes6() const {
+    std::vector<int32_t> b6(6 * boxes.size());
+    for (size_t i = 0; i < boxes.size(); ++i)
+      for (int d = 0; d < 3; ++d) { b6[6 * i + d] = boxes[i].lo[d]; b6[6 * i + 3 + d] = boxes[i].hi[d]; }
+    return b6;
+  }
+};
+
+inline bool parse_box(const std::string& s, size_t& pos, Box3& b) {
+  static const std::regex re(R"(\(\((-?\d+),(-?\d+),(-?\d+)\)\s*\((-?\d+),(-?\d+),(-?\d+)\)\s*\((-?\d+),(-?\d+),(-?\d+)\)\))");
+  std::smatch m;
+  std::string::const_iterator st = s.begin() + pos;
+  if (!std::regex_search(st, s.end(), m, re)) return false;
+  for (int d = 0; d < 3; ++d) { b.lo[d] = std::stoi(m[1 + d]); b.hi[d] = std::stoi(m[4 + d]); }
+  pos += m.position(0) + m.length(0);
+  return true;
+}
+
+inline PlotfileHeader read_header(const std::string& path) {
+  PlotfileHeader H;
+  H.path = path;
+  std::ifstream f(path + "/Header");
+  if (!f) Abort("Unable to open plotfile Header: " + path + "/Header");
+  std::string line;
+  std::getline(f, line);  // version
+  int ncomp;
+  f >> ncomp;
+  std::getline(f, line);
+  H.names.resize(ncomp);
+  for (int i = 0; i < ncomp; ++i) {
+    std::getline(f, H.names[i]);
+    while (!H.names[i].empty() && (H.names[i].back() == ' ' || H.names[i].back() == '\r')) H.names[i].pop_back();
+  }
+  int dim, finest;
+  f >> dim >> H.time >> finest;
+  if (dim != 3) Abort("only 3-D plotfiles are supported by this build");
+  H.nlev = finest + 1;
+  for (int d = 0; d < 3; ++d) f >> H.prob_lo[d];
+  for (int d = 0; d < 3; ++d) f >> H.prob_hi[d];
+  std::getline(f, line);
+  std::getline(f, line);  // ref ratios (possibly empty)
+  {
+    std::stringstream ss(line);
+    int r;
+    while (ss >> r) H.ref_ratio.push_back(r);
+  }
+  std::getline(f, line);  // domains
+  H.lev.resize(H.nlev);
+  {
+    size_t pos = 0;
+    for (int l = 0; l < H.nlev; ++l)
+      if (!parse_box(line, pos, H.lev[l].domain)) Abort("bad domain line in plotfile Header");
+  }
+  for (int l = 0; l < H.nlev; ++l) f >> H.lev[l].level_step;
+  std::getline(f, line);
+  for (int l = 0; l < H.nlev; ++l) std::getline(f, line);  // dx (recomputed like amrex::Geometry)
+  std::getline(f, line);                                   // coord sys
+  std::getline(f, line);                                   // boundary width
+  for (int l = 0; l < H.nlev; ++l) {
+    int lev, ngrids, step;
+    double t;
+    f >> lev >> ngrids >> t >> step;
+    double a, b;
+    for (int g = 0; g < 3 * ngrids; ++g) f >> a >> b;
+    std::string rel;
+    f >> rel;  // Level_n/Cell
+    std::ifstream h(path + "/" + rel + "_H");
+    if (!h) Abort("Unable to open " + path + "/" + rel + "_H");
+    std::stringstream ss;
+    ss << h.rdbuf();
+    const std::string txt = ss.str();
+    const size_t fod = txt.find("FabOnDisk");
+    const std::string blk = txt.substr(0, fod == std::string::npos ? txt.size() : fod);
+    size_t pos = blk.find('(');
+    Box3 bx;
+    while (parse_box(blk, pos, bx)) H.lev[l].boxes.push_back(bx);
+    if ((int)H.lev[l].boxes.size() != ngrids) Abort("Cell_H box count does not match the Header");
+    const std::string dir = rel.substr(0, rel.rfind('/') + 1);
+    size_t p = fod;
+    while (p != std::string::npos) {
+      std::stringstream ls(txt.substr(p + 10, 256));
+      std::string fn;
+      long long off;
+      ls >> fn >> off;
+      H.lev[l].fab_file.push_back(path + "/" + dir + fn);
+      H.lev[l].fab_off.push_back(off);
+      p = txt.find("FabOnDisk", p + 9);
+    }
+    if ((int)H.lev[l].fab_file.size() != ngrids) Abort("Cell_H FabOnDisk count does not match the Header");
+  }
+  for (int r : H.ref_ratio)
+    if (r != 2 && H.nlev > 1) Abort("only refinement ratio 2 is supported (the reference tools write ratio 2 as well)");
+  return H;
+}
+
+// read component `comp` of the plotfile on level lev into component `dcomp` of dst (valid cells of
+// every dst box that lies inside a file box: dst boxes are the file's or a re-chop of them)
+inline void read_comp(const PlotfileHeader& H, int lev, int comp, HostMF& dst, int dcomp) {
+  const LevelMeta& L = H.lev[lev];
+  for (size_t fb = 0; fb < L.boxes.size(); ++fb) {
+    // does any dst box intersect this file box?
+    std::vector<int> hits;
+    for (size_t b = 0; b < dst.boxes.size(); ++b) {
+      bool in = true;
+      for (int d = 0; d < 3; ++d) in = in && dst.boxes[b].lo[d] <= L.boxes[fb].hi[d] && dst.boxes[b].hi[d] >= L.boxes[fb].lo[d];
+      if (in) hits.push_back((int)b);
+    }
+    if (hits.empty()) continue;
+    std::ifstream f(L.fab_file[fb], std::ios::binary);
+    if (!f) Abort("Unable to open " + L.fab_file[fb]);
+    f.seekg(L.fab_off[fb]);
+    std::string hdr;
+    std::getline(f, hdr);
+    size_t pos = hdr.find(")))");  // end of the real descriptor
+    Box3 fbx;
+    if (pos == std::string::npos || !parse_box(hdr, pos, fbx)) Abort("bad FAB header in " + L.fab_file[fb]);
+    const long long n = fbx.numPts();
+    std::vector<double> buf((size_t)n);
+    f.seekg((long long)f.tellg() + (long long)comp * n * 8);
+    f.read((char*)buf.data(), n * 8);
+    if (!f) Abort("short read in " + L.fab_file[fb]);
+    const long long fx = fbx.hi[0] - fbx.lo[0] + 1, fy = fbx.hi[1] - fbx.lo[1] + 1;
+    for (int b : hits) {
+      const Box3& B = dst.boxes[b];
+      for (int k = std::max(B.lo[2], L.boxes[fb].lo[2]); k <= std::min(B.hi[2], L.boxes[fb].hi[2]); ++k)
+        for (int j = std::max(B.lo[1], L.boxes[fb].lo[1]); j <= std::min(B.hi[1], L.boxes[fb].hi[1]); ++j) {
+          const int i0 = std::max(B.lo[0], L.boxes[fb].lo[0]), i1 = std::min(B.hi[0], L.boxes[fb].hi[0]);
+          std::memcpy(dst.ptr(b, dcomp, i0, j, k), &buf[((long long)(k - fbx.lo[2]) * fy + (j - fbx.lo[1])) * fx + (i0 - fbx.lo[0])],
+                      sizeof(double) * (size_t)(i1 - i0 + 1));
+        }
+    }
+  }
+}
+
+inline std::string box_str(const Box3& b) {
+  char s[160];
+  std::snprintf(s, sizeof s, "((%d,%d,%d) (%d,%d,%d) (0,0,0))", b.lo[0], b.lo[1], b.lo[2], b.hi[0], b.hi[1], b.hi[2]);
+  return s;
+}
+inline std::string g17(double v) {
+  char s[64];
+  std::snprintf(s, sizeof s, "%.17g", v);
+  return s;
+}
+
+// WriteMultiLevelPlotfile restated: valid cells of comps [0, names.size()) of each level's HostMF
+inline void write_plotfile(const std::string& path, const std::vector<std::string>& names, const std::vector<Box3>& domains,
+                           const double prob_lo[3], const double prob_hi[3], std::vector<HostMF>& mf, double time,
+                           const std::vector<int>& level_steps, int ref_ratio = 2) {
+  const int nlev = (int)mf.size(), ncomp = (int)names.size();
+  ::mkdir(path.c_str(), 0755);
+  {
+    std::ofstream f(path + "/Header");
+    if (!f) Abort("Unable to create " + path + "/Header");
+    f << "HyperCLaw-V1.1\n" << ncomp << "\n";
+    for (auto& n : names) f << n << "\n";
+    f << "3\n" << g17(time) << "\n" << nlev - 1 << "\n";
+    for (int d = 0; d < 3; ++d) f << g17(prob_lo[d]) << ' ';
+    f << "\n";
+    for (int d = 0; d < 3; ++d) f << g17(prob_hi[d]) << ' ';
+    f << "\n";
+    for (int l = 0; l < nlev - 1; ++l) f << ref_ratio << ' ';
+    f << "\n";
+    for (int l = 0; l < nlev; ++l) f << box_str(domains[l]) << ' ';
+    f << "\n";
+    for (int l = 0; l < nlev; ++l) f << level_steps[l] << ' ';
+    f << "\n";
+    for (int l = 0; l < nlev; ++l) {
+      for (int d = 0; d < 3; ++d) f << g17((prob_hi[d] - prob_lo[d]) / (double)(domains[l].hi[d] - domains[l].lo[d] + 1)) << ' ';
+      f << "\n";
+    }
+    f << "0\n0\n";
+    for (int l = 0; l < nlev; ++l) {
+      f << l << ' ' << mf[l].boxes.size() << ' ' << g17(time) << "\n" << level_steps[l] << "\n";
+      for (auto& B : mf[l].boxes)
+        for (int d = 0; d < 3; ++d) {
+          const double dx = (prob_hi[d] - prob_lo[d]) / (double)(domains[l].hi[d] - domains[l].lo[d] + 1);
+          f << g17(prob_lo[d] + B.lo[d] * dx) << ' ' << g17(prob_lo[d] + (B.hi[d] + 1) * dx) << "\n";
+        }
+      f << "Level_" << l << "/Cell\n";
+    }
+  }
+  for (int l = 0; l < nlev; ++l) {
+    const std::string dir = path + "/Level_" + std::to_string(l);
+    ::mkdir(dir.c_str(), 0755);
+    HostMF& M = mf[l];
+    std::vector<long long> offs;
+    std::vector<std::vector<double>> mins, maxs;
+    {
+      std::ofstream f(dir + "/Cell_D_00000", std::ios::binary);
+      if (!f) Abort("Unable to create " + dir + "/Cell_D_00000");
+      std::vector<double> row;
+      for (size_t b = 0; b < M.boxes.size(); ++b) {
+        offs.push_back((long long)f.tellp());
+        const Box3& B = M.boxes[b];
+        f << "FAB ((8, (64 11 52 0 1 12 0 1023)),(8, (8 7 6 5 4 3 2 1)))" << box_str(B) << ' ' << ncomp << "\n";
+        std::vector<double> mn(ncomp, 1e300), mx(ncomp, -1e300);
+        const int nx = B.hi[0] - B.lo[0] + 1;
+        for (int c = 0; c < ncomp; ++c)
+          for (int k = B.lo[2]; k <= B.hi[2]; ++k)
+            for (int j = B.lo[1]; j <= B.hi[1]; ++j) {
+              const double* p = M.ptr((int)b, c, B.lo[0], j, k);
+              f.write((const char*)p, sizeof(double) * (size_t)nx);
+              for (int i = 0; i < nx; ++i) { mn[c] = std::min(mn[c], p[i]); mx[c] = std::max(mx[c], p[i]); }
+            }
+        mins.push_back(mn); maxs.push_back(mx);
+      }
+    }
+    std::ofstream h(dir + "/Cell_H");
+    h << "1\n1\n" << ncomp << "\n0\n(" << M.boxes.size() << " 0\n";
+    for (auto& B : M.boxes) h << box_str(B) << "\n";
+    h << ")\n" << M.boxes.size() << "\n";
+    for (size_t b = 0; b < M.boxes.size(); ++b) h << "FabOnDisk: Cell_D_00000 " << offs[b] << "\n";
+    h << "\n" << M.boxes.size() << "," << ncomp << "\n";
+    for (auto& m : mins) { for (double v : m) h << g17(v) << ","; h << "\n"; }
+    h << "\n" << M.boxes.size() << "," << ncomp << "\n";
+    for (auto& m : maxs) { for (double v : m) h << g17(v) << ","; h << "\n"; }
+  }
+}
+
+// MEF surface file (isosurface.cpp:2097-2134): label, names, "nElts nodesPerElt", FAB of Box
+// (0..N-1,0,0) x ncomp written node-major, then raw 1-based int32 connectivity, no trailing newline
+inline void write_mef(const std::string& file, double time, const std::vector<std::string>& names, const std::vector<double>& nodes /* [N][ncomp] */,
+                      const std::vector<int32_t>& elts0 /* [M][3], 0-based */) {
+  const int ncomp = (int)names.size();
+  const long long N = ncomp ? (long long)nodes.size() / ncomp : 0, M = (long long)elts0.size() / 3;
+  std::ofstream f(file, std::ios::binary);
+  if (!f) Abort("Unable to create " + file);
+  char lab[64];
+  std::snprintf(lab, sizeof lab, "%g", time);
+  f << lab << "\n";
+  for (int c = 0; c < ncomp; ++c) f << names[c] << (c + 1 < ncomp ? " " : "");
+  f << "\n" << M << " 3\n";
+  Box3 b{{0, 0, 0}, {(int)N - 1, 0, 0}};
+  f << "FAB ((8, (64 11 52 0 1 12 0 1023)),(8, (8 7 6 5 4 3 2 1)))" << box_str(b) << ' ' << ncomp << "\n";
+  f.write((const char*)nodes.data(), sizeof(double) * nodes.size());
+  std::vector<int32_t> e1(elts0.size());
+  for (size_t q = 0; q < elts0.size(); ++q) e1[q] = elts0[q] + 1;
+  f.write((const char*)e1.data(), sizeof(int32_t) * e1.size());
+}
+
+// BoxArray::maxSize: chop every box into pieces <= n per direction (even split)
+inline std::vector<Box3> max_size(const std::vector<Box3>& in, int n) {
+  std::vector<Box3> out;
+  for (const Box3& B : in) {
+    std::vector<std::pair<int, int>> cut[3];
+    for (int d = 0; d < 3; ++d) {
+      const int len = B.hi[d] - B.lo[d] + 1, parts = (len + n - 1) / n, base = len / parts, rem = len % parts;
+      int s = B.lo[d];
+      for (int p = 0; p < parts; ++p) {
+        const int sz = base + (p < rem ? 1 : 0);
+        cut[d].push_back({s, s + sz - 1});
+        s += sz;
+      }
+    }
+    for (auto& z : cut[2])
+      for (auto& y : cut[1])
+        for (auto& x : cut[0]) out.push_back(Box3{{x.first, y.first, z.first}, {x.second, y.second, z.second}});
+  }
+  return out;
+}
+
+}  // namespace pa

@@ -1,0 +1,135 @@
+// curvature3d -- drop-in for PeleAnalysis Src/curvature.cpp (core path) on MI355X.
+//   curvature3d.ex infile=<plt> [outfile=<root>_K] [finestLevel=<n>] [progressName=temp] [progMin=..] [progMax=..]
+//       [useFileMinMax=1] [threshold_prog=0] [threshold_value=1e-4] [Aux_Variables="a b"] [sym_dir="0 0 0"]
+//       [is_per="1 1 1"] [verbose=0] [fused=1]
+// Output components (curvature.cpp:165-236, 796-844): [progressName, aux..., Progress, SmoothedProgress,
+// MeanCurvature_<v>, FlameNormalX/Y/Z_<v>, GaussianCurvature_<v>]; SmoothedProgress and
+// GaussianCurvature are written as 0.0 (the reference leaves them uninitialised when the options are
+// off: quirk Q1).  do_gaussCurv / do_strain / do_velnormal / do_smooth are not ported yet.
+#include "../common/pa_device.h"
+
+int main(int argc, char** argv) {
+  if (argc < 2) {
+    std::cerr << "usage:\n" << argv[0] << " infile=<plotfilename> \n\tOptions:\n\tis_per=<L M N> progressName=<name>\n";
+    return 1;
+  }
+  pa::ParmParse pp(argc, argv);
+  int verbose = 0, finestLevel = 1000;
+  int do_gaussCurv = 0, floorIt = 0, useFileMinMax = 1, do_threshold = 0, do_smooth = 0, do_strain = 0, do_velnormal = 0, fused = 1;
+  std::string progressName = "temp", infile;
+  double progMin = 1.0e20, progMax = -1.0e20, threshold = 0.0001;
+  pp.query("verbose", verbose);
+  pp.get("infile", infile);
+  std::string outfile = pa::getFileRoot(infile) + "_K";
+  pp.query("outfile", outfile);
+  pp.query("finestLevel", finestLevel);
+  pp.query("do_gaussCurv", do_gaussCurv);
+  pp.query("progressName", progressName);
+  pp.query("progMin", progMin);
+  pp.query("progMax", progMax);
+  pp.query("floorIt", floorIt);
+  pp.query("useFileMinMax", useFileMinMax);
+  pp.query("threshold_prog", do_threshold);
+  pp.query("threshold_value", threshold);
+  pp.query("do_smooth", do_smooth);
+  pp.query("do_strain", do_strain);
+  pp.query("do_velnormal", do_velnormal);
+  pp.query("fused", fused);
+  if (do_gaussCurv || do_strain || do_velnormal || do_smooth)
+    pa::Abort("do_gaussCurv / do_strain / do_velnormal / do_smooth are not available in this build (core mean-curvature path only)");
+  const int nAux = pp.countval("Aux_Variables");
+  std::cout << "infile = " << infile << "\n" << "reading plt file = " << infile << "\n";
+  pa::PlotfileHeader H = pa::read_header(infile);
+  finestLevel = std::min(finestLevel, H.nlev - 1);
+  const int Nlev = finestLevel + 1;
+  const int idC = H.comp(progressName);
+  if (idC < 0) pa::Abort("Wrong progress variable name: " + progressName);
+  std::vector<std::string> inNames{progressName};
+  std::vector<int> inComps{idC};
+  for (int i = 0; i < nAux; ++i) {
+    std::string a;
+    pp.get("Aux_Variables", a, i);
+    if (H.comp(a) < 0) pa::Abort("Unknown auxiliary variable name: " + a);
+    inNames.push_back(a);
+    inComps.push_back(H.comp(a));
+  }
+  const int nCompIn = (int)inNames.size();
+  const int idProg = nCompIn, idSmProg = idProg + 1, idKm = idSmProg + 1, idN = idKm + 1, idKg = idN + 3, nCompOut = idKg + 1;
+  std::vector<int> sym_dir(3, 0), is_per(3, 1);
+  pp.queryarr("sym_dir", sym_dir, 0, 3);
+  pp.queryarr("is_per", is_per, 0, 3);
+  int32_t bc[3];
+  pa::bc_from_flags(is_per, sym_dir, bc);
+
+  pa::Ctx ctx;
+  std::vector<std::unique_ptr<pa::DevLevel>> dl;
+  std::vector<std::unique_ptr<pa::DevMF>> dst, dwork, dout;
+  std::vector<pa::HostMF> in(Nlev), res(Nlev), ostate(Nlev);
+  std::vector<pa::Box3> doms;
+  for (int lev = 0; lev < Nlev; ++lev) {
+    if (verbose) std::cout << "Reading data for level " << lev << "\n";
+    in[lev].define(H.lev[lev].boxes, nCompIn, 2);
+    for (int c = 0; c < nCompIn; ++c) pa::read_comp(H, lev, inComps[c], in[lev], c);
+    dl.emplace_back(new pa::DevLevel(ctx, H.lev[lev].boxes, H.lev[lev].domain, is_per.data(), H.prob_lo, H.prob_hi));
+    dst.emplace_back(new pa::DevMF(ctx, *dl.back(), nCompIn, 2));
+    dwork.emplace_back(new pa::DevMF(ctx, *dl.back(), 1, 2));
+    dout.emplace_back(new pa::DevMF(ctx, *dl.back(), 8, 0));
+    ctx.check(pa_mf_upload(ctx.h, dst.back()->h, in[lev].data.data()));
+    doms.push_back(H.lev[lev].domain);
+  }
+  std::vector<pa_mf*> s, w, o;
+  for (int l = 0; l < Nlev; ++l) { s.push_back(dst[l]->h); w.push_back(dwork[l]->h); o.push_back(dout[l]->h); }
+  // progress-variable range (curvature.cpp:139-160): the file min/max over the levels in use
+  if (useFileMinMax) {
+    for (int l = 0; l < Nlev; ++l) {
+      double a, b;
+      ctx.check(pa_minmax_level(ctx.h, s[l], 0, &a, &b));
+      progMin = std::min(progMin, a);
+      progMax = std::max(progMax, b);
+    }
+  }
+  if (useFileMinMax || floorIt) {
+    std::cout << "progressName = " << progressName << " at index: " << idC << "\n";
+    std::cout << "useFileMinMax = " << useFileMinMax << "\n";
+    std::cout << "Min/Max = " << progMin << " / " << progMax << "\n";
+    if (progMin >= progMax) pa::Abort("progMin must be less than progMax");
+  }
+  pa_curv_params P;
+  P.prog_min = progMin; P.prog_max = progMax; P.do_threshold = do_threshold; P.threshold = threshold; P.fused = fused;
+  ctx.check(pa_gradcurv_run(ctx.h, Nlev, s.data(), 0, bc, &P, w.data(), o.data(), 0));
+  ctx.check(pa_sync(ctx.h));
+  if (pa_bc_errors(ctx.h) != 0) pa::Abort("coarse-fine boundary: fine grids are not properly nested in the coarse level");
+  const double invdenom = 1.0 / (progMax - progMin);
+  for (int lev = 0; lev < Nlev; ++lev) {
+    res[lev].define(H.lev[lev].boxes, 8, 0);
+    ctx.check(pa_mf_download(ctx.h, dout[lev]->h, res[lev].data.data()));
+    ostate[lev].define(H.lev[lev].boxes, nCompOut, 0);  // ghost-free output state (curvature.cpp:833-839)
+    for (size_t b = 0; b < H.lev[lev].boxes.size(); ++b) {
+      const pa::Box3& B = H.lev[lev].boxes[b];
+      const size_t nx = (size_t)(B.hi[0] - B.lo[0] + 1);
+      for (int k = B.lo[2]; k <= B.hi[2]; ++k)
+        for (int j = B.lo[1]; j <= B.hi[1]; ++j) {
+          for (int c = 0; c < nCompIn; ++c) std::memcpy(ostate[lev].ptr((int)b, c, B.lo[0], j, k), in[lev].ptr((int)b, c, B.lo[0], j, k), 8 * nx);
+          const double* sv = in[lev].ptr((int)b, 0, B.lo[0], j, k);
+          double* pr = ostate[lev].ptr((int)b, idProg, B.lo[0], j, k);
+          for (size_t i = 0; i < nx; ++i) pr[i] = (sv[i] - progMin) * invdenom;  // curvature.cpp:319 (same fp order as the device)
+          std::memcpy(ostate[lev].ptr((int)b, idKm, B.lo[0], j, k), res[lev].ptr((int)b, 7, B.lo[0], j, k), 8 * nx);
+          for (int d = 0; d < 3; ++d) std::memcpy(ostate[lev].ptr((int)b, idN + d, B.lo[0], j, k), res[lev].ptr((int)b, 4 + d, B.lo[0], j, k), 8 * nx);
+        }
+    }
+    if (verbose) std::cout << "Mean curvature has been computed on level " << lev << "\n";
+  }
+  std::vector<std::string> nnames(inNames);
+  nnames.resize(nCompOut);
+  nnames[idProg] = "Progress";
+  nnames[idSmProg] = "SmoothedProgress";
+  nnames[idKm] = "MeanCurvature_" + progressName;
+  nnames[idN] = "FlameNormalX_" + progressName;
+  nnames[idN + 1] = "FlameNormalY_" + progressName;
+  nnames[idN + 2] = "FlameNormalZ_" + progressName;
+  nnames[idKg] = "GaussianCurvature_" + progressName;
+  std::cout << "Writing new data to " << outfile << "\n";
+  std::vector<int> isteps(Nlev, 0);
+  pa::write_plotfile(outfile, nnames, doms, H.prob_lo, H.prob_hi, ostate, 0.0, isteps);
+  return 0;
+}

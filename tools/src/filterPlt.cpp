@@ -1,0 +1,92 @@
+// filterPlt3d -- drop-in for PeleAnalysis Src/filterPlt.cpp (box filter) on MI355X.
+//   filterPlt3d.ex infile=<plt> [max_filter_level=<n>] [filter_type=1] [base_fgr=2] [same_fgr_all_levels=false]
+//       [max_grid_size=32] [interp_type=1] [variables="a b"] [is_per="0 0 0"]
+// Output: <root>_filtered, same variable names, plotfile time (filterPlt.cpp:222-225).
+// The plotfile Header stores no periodicity; like PltFileManager's Geometry it defaults to
+// non-periodic unless is_per / geometry.is_periodic is given.
+#include "../common/pa_device.h"
+
+int main(int argc, char** argv) {
+  pa::ParmParse pp(argc, argv);
+  if (argc < 2 || pp.contains("help")) {
+    std::cerr << "usage:\n" << argv[0] << " infile=<plotfilename> \n\tOptions:\n\tmax_filter_level=<n> filter_type=1 base_fgr=<even n> variables=<names>\n";
+    return 1;
+  }
+  std::string infile;
+  int finestLevel = 1000, filter_type = 1, fgr = 2, max_grid_size = 32, interp_type = 1;
+  bool same_fgr = false;
+  pp.get("infile", infile);
+  pp.query("max_filter_level", finestLevel);
+  pp.query("filter_type", filter_type);
+  pp.query("base_fgr", fgr);
+  pp.query("same_fgr_all_levels", same_fgr);
+  pp.query("max_grid_size", max_grid_size);
+  pp.query("interp_type", interp_type);
+  if (filter_type != 1) pa::Abort("only filter_type=1 (box) is available in this build");
+  if (fgr != 1 && fgr % 2 != 0) pa::Abort("Box filter requires an even filter-to-grid ratio");
+  std::vector<int> is_per(3, 0);
+  if (!pp.queryarr("is_per", is_per, 0, 3)) pp.queryarr("geometry.is_periodic", is_per, 0, 3);
+  pa::PlotfileHeader H = pa::read_header(infile);
+  const int Nlev = std::min(finestLevel + 1, H.nlev);
+  std::vector<std::string> names;
+  std::vector<int> comps;
+  if (pp.countval("variables") > 0) {
+    pp.getarr("variables", names);
+    for (auto& n : names) {
+      if (H.comp(n) < 0) pa::Abort("Variable '" + n + "' not found in file");
+      comps.push_back(H.comp(n));
+    }
+  } else {
+    names = H.names;
+    for (int c = 0; c < (int)names.size(); ++c) comps.push_back(c);
+  }
+  const int ncomp = (int)names.size();
+  pa::Ctx ctx;
+  std::vector<std::unique_ptr<pa::DevLevel>> dl;
+  std::vector<std::unique_ptr<pa::DevMF>> din, dout;
+  std::vector<pa::HostMF> host(Nlev), out(Nlev);
+  std::vector<pa::Box3> doms;
+  std::vector<int> ngs;
+  std::vector<std::vector<double>> ws;
+  std::cout << "Reading data..." << std::endl;
+  int fgr_lev = fgr;
+  for (int lev = 0; lev < Nlev; ++lev) {
+    std::cout << "on level " << lev << std::endl;
+    if (!same_fgr && lev > 0) fgr_lev *= 2;
+    std::vector<double> w(fgr_lev + 2);
+    const int ng = pa_box_filter_weights(fgr_lev, w.data());
+    ngs.push_back(ng);
+    ws.push_back(w);
+    const std::vector<pa::Box3> ba = pa::max_size(H.lev[lev].boxes, max_grid_size);
+    host[lev].define(ba, ncomp, ng);
+    for (int c = 0; c < ncomp; ++c) pa::read_comp(H, lev, comps[c], host[lev], c);
+    dl.emplace_back(new pa::DevLevel(ctx, ba, H.lev[lev].domain, is_per.data(), H.prob_lo, H.prob_hi));
+    din.emplace_back(new pa::DevMF(ctx, *dl.back(), ncomp, ng));
+    dout.emplace_back(new pa::DevMF(ctx, *dl.back(), ncomp, 0));
+    ctx.check(pa_mf_upload(ctx.h, din.back()->h, host[lev].data.data()));
+    doms.push_back(H.lev[lev].domain);
+  }
+  std::cout << "Done!" << std::endl << "FillPatching data..." << std::endl;
+  for (int lev = 0; lev < Nlev; ++lev) {
+    std::cout << "on level " << lev << std::endl;
+    ctx.check(pa_fill_boundary(ctx.h, din[lev]->h, 0, ncomp, ngs[lev]));
+    if (lev > 0) ctx.check(pa_fillpatch_two_levels(ctx.h, din[lev]->h, din[lev - 1]->h, 0, ncomp, ngs[lev], 2, interp_type == 1 ? 1 : 0));
+    ctx.check(pa_foextrap(ctx.h, din[lev]->h, 0, ncomp, ngs[lev]));
+  }
+  std::cout << "Done!" << std::endl << "Filtering data..." << std::endl;
+  for (int lev = 0; lev < Nlev; ++lev) {
+    std::cout << "on level " << lev << std::endl;
+    ctx.check(pa_boxfilter_level(ctx.h, din[lev]->h, dout[lev]->h, 0, ncomp, ngs[lev], ws[lev].data()));
+  }
+  ctx.check(pa_sync(ctx.h));
+  if (pa_bc_errors(ctx.h) != 0) pa::Abort("FillPatchTwoLevels: fine grids are not properly nested in the coarse level");
+  std::cout << "Done!" << std::endl << "Saving filtered data..." << std::endl;
+  for (int lev = 0; lev < Nlev; ++lev) {
+    out[lev].define(host[lev].boxes, ncomp, 0);
+    ctx.check(pa_mf_download(ctx.h, dout[lev]->h, out[lev].data.data()));
+  }
+  std::vector<int> steps(Nlev, 0);
+  pa::write_plotfile(pa::getFileRoot(infile) + "_filtered", names, doms, H.prob_lo, H.prob_hi, out, H.time, steps);
+  std::cout << "Done!" << std::endl;
+  return 0;
+}

@@ -1,0 +1,77 @@
+// grad3d -- drop-in for PeleAnalysis Src/grad.cpp on MI355X.
+//   grad3d.ex infile=<plt> [gradVar=temp] [finestLevel=<n>] [Aux_Variables="a b"] [sym_dir="0 0 0"]
+//             [is_per="1 1 1"] [outfile=<root>_gt]
+// Output plotfile components: [gradVar, aux..., <v>_gx, <v>_gy, <v>_gz, ||grad<v>||], time 0, steps 0,
+// ref ratio 2 (grad.cpp:241-257).  All arithmetic runs in libpeleanalysis_amd (HIP, gfx950).
+#include "../common/pa_device.h"
+
+static void print_usage(char** argv) {
+  std::cerr << "usage:\n" << argv[0] << " infile=<plotfilename> \n\tOptions:\n\tis_per=<L M N> gradVar=<name>\n";
+  std::exit(1);
+}
+
+int main(int argc, char** argv) {
+  if (argc < 2) print_usage(argv);
+  pa::ParmParse pp(argc, argv);
+  if (pp.contains("help")) print_usage(argv);
+  std::string gradVar = "temp", infile;
+  int finestLevel = 1000;
+  pp.get("infile", infile);
+  pp.query("gradVar", gradVar);
+  pp.query("finestLevel", finestLevel);
+  pa::PlotfileHeader H = pa::read_header(infile);
+  finestLevel = std::min(finestLevel, H.nlev - 1);
+  const int Nlev = finestLevel + 1;
+  const int idC = H.comp(gradVar);
+  if (idC < 0) pa::Abort("Cannot find " + gradVar + " data in pltfile");  // quirk Q9: the reference only prints, then indexes [-1]
+  const int nAux = pp.countval("Aux_Variables");
+  std::vector<std::string> inNames{gradVar};
+  std::vector<int> inComps{idC};
+  for (int i = 0; i < nAux; ++i) {
+    std::string a;
+    pp.get("Aux_Variables", a, i);
+    if (H.comp(a) < 0) pa::Abort("Unknown auxiliary variable name: " + a);
+    inNames.push_back(a);
+    inComps.push_back(H.comp(a));
+  }
+  const int nCompIn = (int)inNames.size(), idGr = nCompIn, nCompOut = idGr + 4;
+  std::vector<int> sym_dir(3, 0), is_per(3, 1);
+  pp.queryarr("sym_dir", sym_dir, 0, 3);
+  pp.queryarr("is_per", is_per, 0, 3);
+  std::cout << "Periodicity assumed for this case: " << is_per[0] << " " << is_per[1] << " " << is_per[2] << " \n";
+  int32_t bc[3];
+  pa::bc_from_flags(is_per, sym_dir, bc);
+
+  pa::Ctx ctx;
+  std::vector<std::unique_ptr<pa::DevLevel>> dl;
+  std::vector<std::unique_ptr<pa::DevMF>> dmf;
+  std::vector<pa::HostMF> state(Nlev);
+  std::vector<pa::Box3> doms;
+  for (int lev = 0; lev < Nlev; ++lev) {
+    std::cout << "Reading data for level: " << lev << std::endl;
+    state[lev].define(H.lev[lev].boxes, nCompOut, 1);
+    for (int c = 0; c < nCompIn; ++c) pa::read_comp(H, lev, inComps[c], state[lev], c);
+    dl.emplace_back(new pa::DevLevel(ctx, H.lev[lev].boxes, H.lev[lev].domain, is_per.data(), H.prob_lo, H.prob_hi));
+    dmf.emplace_back(new pa::DevMF(ctx, *dl.back(), nCompOut, 1));
+    ctx.check(pa_mf_upload(ctx.h, dmf.back()->h, state[lev].data.data()));
+    doms.push_back(H.lev[lev].domain);
+  }
+  std::vector<pa_mf*> mfs;
+  for (auto& m : dmf) mfs.push_back(m->h);
+  ctx.check(pa_grad_run(ctx.h, Nlev, mfs.data(), 0, bc, mfs.data(), idGr));  // outputs into the same MultiFab, like grad.cpp
+  ctx.check(pa_sync(ctx.h));
+  if (pa_bc_errors(ctx.h) != 0) pa::Abort("coarse-fine boundary: fine grids are not properly nested in the coarse level");
+  for (int lev = 0; lev < Nlev; ++lev) ctx.check(pa_mf_download(ctx.h, dmf[lev]->h, state[lev].data.data()));
+
+  std::vector<std::string> nnames(inNames);
+  nnames.push_back(gradVar + "_gx");
+  nnames.push_back(gradVar + "_gy");
+  nnames.push_back(gradVar + "_gz");
+  nnames.push_back("||grad" + gradVar + "||");
+  std::string outfile = pa::getFileRoot(infile) + "_gt";
+  pp.query("outfile", outfile);
+  std::cout << "Writing new data to " << outfile << std::endl;
+  std::vector<int> isteps(Nlev, 0);
+  pa::write_plotfile(outfile, nnames, doms, H.prob_lo, H.prob_hi, state, 0.0, isteps);
+  return 0;
+}

@@ -1,0 +1,180 @@
+// isosurface3d -- drop-in for PeleAnalysis Src/isosurface.cpp (3-D marching cubes on the AMR dual
+// grid, MEF output) on MI355X.
+//   isosurface3d.ex infile=<plt> [isoVal=1090] [isoCompName=temp] [comps="i j" | sComp=0 nComp=1] [finestLevel=<n>]
+//       [is_per="0 0 0"] [outfile_base=<infile>_<comp>_<isoVal>] [writeSurf=1] [computeArea=0] [verbose=0]
+// Per FAB the cube classification, ballot/prefix-sum compaction, edge interpolation and triangle
+// emission run on the GPU (libpeleanalysis_amd); the global node/element sets are merged on the
+// host in FAB order, which reproduces the reference's node numbering on one rank.
+// Not ported yet: build_distance_function, nGrow != 1, periodic directions (quirk Q5), XDMF.
+#include "../common/pa_device.h"
+#include "../common/pa_isomerge.h"
+
+int main(int argc, char** argv) {
+  pa::ParmParse pp(argc, argv);
+  if (argc < 2 || pp.contains("help")) {
+    std::cerr << "usage:\n" << argv[0] << " infile=<plotfilename> isoCompName=<name> isoVal=<v> [comps=<list>] [finestLevel=<n>]\n";
+    return 1;
+  }
+  int verbose = 0;
+  pp.query("verbose", verbose);
+  std::string infile;
+  pp.get("infile", infile);
+  if (infile.empty()) pa::Abort("Plotfile not specified, Use infile=");
+  pa::PlotfileHeader H = pa::read_header(infile);
+  double isoVal = 1090;
+  pp.query("isoVal", isoVal);
+  std::string isoCompName = "temp";
+  pp.query("isoCompName", isoCompName);
+  std::vector<int> pltComps;
+  if (int nc = pp.countval("comps")) {
+    pp.queryarr("comps", pltComps, 0, nc);
+  } else {
+    int sComp = 0, nComp = 1;
+    pp.query("sComp", sComp);
+    pp.query("nComp", nComp);
+    for (int i = 0; i < nComp; ++i) pltComps.push_back(sComp + i);
+  }
+  int isoComp = -1;
+  for (size_t i = 0; i < pltComps.size(); ++i) {
+    if (pltComps[i] < 0 || pltComps[i] >= (int)H.names.size()) pa::Abort("At least one of the components requested is not in pltfile");
+    if (H.names[pltComps[i]] == isoCompName) isoComp = (int)i;
+  }
+  if (isoComp < 0) pa::Abort("isoCompName not in list of variables to read in");
+  const int nComp = (int)pltComps.size(), nc = 3 + nComp;
+  int finestLevel = H.nlev - 1;
+  pp.query("finestLevel", finestLevel);
+  finestLevel = std::min(finestLevel, H.nlev - 1);
+  const int Nlev = finestLevel + 1;
+  int build_distance_function = 0, nGrow = 1;
+  pp.query("build_distance_function", build_distance_function);
+  pp.query("nGrow", nGrow);
+  if (build_distance_function) pa::Abort("build_distance_function is not available in this build");
+  if (nGrow != 1) pa::Abort("only nGrow=1 is available in this build");
+  std::vector<int> is_per(3, 0);
+  pp.queryarr("is_per", is_per, 0, 3);
+  if (is_per[0] || is_per[1] || is_per[2]) pa::Abort("periodic directions are not available in this build (the reference leaves bad data there too)");
+
+  pa::Ctx ctx;
+  std::vector<std::unique_ptr<pa::DevLevel>> dl;
+  std::vector<std::unique_ptr<pa::DevMF>> dst;
+  std::vector<pa::HostMF> host(Nlev);
+  for (int lev = 0; lev < Nlev; ++lev) {
+    const auto& L = H.lev[lev];
+    host[lev].define(L.boxes, nc, 1);
+    std::fill(host[lev].data.begin(), host[lev].data.end(), -666.0);  // gstate.setVal(-666) (isosurface.cpp:1512)
+    double dx[3];
+    for (int d = 0; d < 3; ++d) dx[d] = (H.prob_hi[d] - H.prob_lo[d]) / (double)(L.domain.hi[d] - L.domain.lo[d] + 1);
+    for (size_t b = 0; b < L.boxes.size(); ++b) {  // cell-centre coordinates incl. ghosts (isosurface.cpp:1458-1465)
+      const pa::Box3& B = L.boxes[b];
+      for (int k = B.lo[2] - 1; k <= B.hi[2] + 1; ++k)
+        for (int j = B.lo[1] - 1; j <= B.hi[1] + 1; ++j)
+          for (int i = B.lo[0] - 1; i <= B.hi[0] + 1; ++i) {
+            *host[lev].ptr((int)b, 0, i, j, k) = (i + 0.5) * dx[0] + H.prob_lo[0];
+            *host[lev].ptr((int)b, 1, i, j, k) = (j + 0.5) * dx[1] + H.prob_lo[1];
+            *host[lev].ptr((int)b, 2, i, j, k) = (k + 0.5) * dx[2] + H.prob_lo[2];
+          }
+    }
+    for (int n = 0; n < nComp; ++n) pa::read_comp(H, lev, pltComps[n], host[lev], 3 + n);
+    dl.emplace_back(new pa::DevLevel(ctx, L.boxes, L.domain, is_per.data(), H.prob_lo, H.prob_hi));
+    dst.emplace_back(new pa::DevMF(ctx, *dl.back(), nc, 1));
+    ctx.check(pa_mf_upload(ctx.h, dst.back()->h, host[lev].data.data()));
+    std::cout << "FillPatching the grown structures at level " << lev << "..." << std::endl;
+    ctx.check(pa_fill_boundary(ctx.h, dst[lev]->h, 0, nc, 1));
+    if (lev > 0) ctx.check(pa_fillpatch_two_levels(ctx.h, dst[lev]->h, dst[lev - 1]->h, 0, nc, 1, 2, 0));  // PCInterp
+    std::cout << "...done FillPatching the grown structures at level " << lev << "..." << std::endl;
+  }
+  ctx.check(pa_sync(ctx.h));
+  if (pa_bc_errors(ctx.h) != 0) pa::Abort("FillPatchTwoLevels: fine grids are not properly nested in the coarse level");
+
+  pa::IsoMerger merger(nc);
+  std::vector<double> mask, hv;
+  std::vector<int32_t> ht;
+  for (int lev = 0; lev < Nlev; ++lev) {
+    const auto& L = H.lev[lev];
+    double* base = pa_mf_data(dst[lev]->h);
+    for (size_t b = 0; b < L.boxes.size(); ++b) {
+      const pa::Box3& B = L.boxes[b];
+      pa::Box3 g{{B.lo[0] - 1, B.lo[1] - 1, B.lo[2] - 1}, {B.hi[0] + 1, B.hi[1] + 1, B.hi[2] + 1}};
+      const long long nx = g.hi[0] - g.lo[0] + 1, ny = g.hi[1] - g.lo[1] + 1;
+      mask.assign((size_t)g.numPts(), 1.0);
+      if (lev < finestLevel)  // fine-covered mask (isosurface.cpp:1540-1563)
+        for (const pa::Box3& F : H.lev[lev + 1].boxes) {
+          int lo[3], hi[3];
+          bool ok = true;
+          for (int d = 0; d < 3; ++d) {
+            lo[d] = std::max(g.lo[d], F.lo[d] >= 0 ? F.lo[d] / 2 : -((-F.lo[d] + 1) / 2));
+            hi[d] = std::min(g.hi[d], F.hi[d] >= 0 ? F.hi[d] / 2 : -((-F.hi[d] + 1) / 2));
+            ok = ok && lo[d] <= hi[d];
+          }
+          if (!ok) continue;
+          for (int k = lo[2]; k <= hi[2]; ++k)
+            for (int j = lo[1]; j <= hi[1]; ++j)
+              for (int i = lo[0]; i <= hi[0]; ++i) mask[((long long)(k - g.lo[2]) * ny + (j - g.lo[1])) * nx + (i - g.lo[0])] = -1.0;
+        }
+      pa_box loop;  // base points: (grown box & domain), high side - 1 (isosurface.cpp:1566-1569)
+      bool empty = false;
+      for (int d = 0; d < 3; ++d) {
+        loop.lo[d] = std::max(g.lo[d], L.domain.lo[d]);
+        loop.hi[d] = std::min(g.hi[d], L.domain.hi[d]) - 1;
+        empty = empty || loop.lo[d] > loop.hi[d];
+      }
+      if (empty) continue;
+      void* dmask = pa_device_malloc(ctx.h, (int64_t)mask.size() * 8);
+      if (!dmask) pa::Abort(pa_last_error(ctx.h));
+      ctx.check(pa_memcpy_h2d(ctx.h, dmask, mask.data(), (int64_t)mask.size() * 8));
+      pa_fab fs, fm;
+      fs.p = base + host[lev].off[b]; fs.ncomp = nc; fs.nstride = host[lev].cs[b];
+      fm.p = (double*)dmask; fm.ncomp = 1; fm.nstride = 0;
+      for (int d = 0; d < 3; ++d) { fs.lo[d] = fm.lo[d] = g.lo[d]; fs.hi[d] = fm.hi[d] = g.hi[d]; }
+      int64_t nv = 0, nt = 0;
+      ctx.check(pa_mc_count_fab(ctx.h, loop, &fs, &fm, 3 + isoComp, isoVal, &nv, &nt));
+      if (nt > 0) {
+        void* dv = pa_device_malloc(ctx.h, nv * nc * 8);
+        void* dk = pa_device_malloc(ctx.h, nv * 6 * 4);
+        void* dt = pa_device_malloc(ctx.h, nt * 3 * 4);
+        if (!dv || !dk || !dt) pa::Abort(pa_last_error(ctx.h));
+        ctx.check(pa_mc_emit_fab(ctx.h, loop, &fs, &fm, 3 + isoComp, isoVal, (double*)dv, (int32_t*)dk, (int32_t*)dt, nv, nt));
+        hv.resize((size_t)(nv * nc));
+        ht.resize((size_t)(nt * 3));
+        ctx.check(pa_memcpy_d2h(ctx.h, hv.data(), dv, nv * nc * 8));
+        ctx.check(pa_memcpy_d2h(ctx.h, ht.data(), dt, nt * 3 * 4));
+        merger.add(hv.data(), nv, ht.data(), nt);  // with nGrow = 1 rm_external_elements removes nothing
+        pa_device_free(ctx.h, dv); pa_device_free(ctx.h, dk); pa_device_free(ctx.h, dt);
+      }
+      pa_device_free(ctx.h, dmask);
+    }
+  }
+  merger.finish();
+  const std::vector<int32_t> elts = merger.elements();
+  int writeSurf = 1, computeArea = 0;
+  pp.query("writeSurf", writeSurf);
+  pp.query("computeArea", computeArea);
+  std::string surfFormat = "MEF";
+  pp.query("surfFormat", surfFormat);
+  if (surfFormat != "MEF") pa::Abort("only surfFormat=MEF is available in this build");
+  if (computeArea) {  // computed before the element list is released (the reference prints 0 here: quirk Q7)
+    const auto& nd = merger.nodes();
+    double area = 0;
+    for (size_t e = 0; e + 2 < elts.size(); e += 3) {
+      const double *a = &nd[(size_t)elts[e] * nc], *b = &nd[(size_t)elts[e + 1] * nc], *c = &nd[(size_t)elts[e + 2] * nc];
+      const double ux = b[0] - a[0], uy = b[1] - a[1], uz = b[2] - a[2], vx = c[0] - a[0], vy = c[1] - a[1], vz = c[2] - a[2];
+      const double cx = uy * vz - uz * vy, cy = uz * vx - ux * vz, cz = ux * vy - uy * vx;
+      area += 0.5 * std::sqrt(cx * cx + cy * cy + cz * cz);
+    }
+    std::cout << "Total area = " << area << std::endl;
+  }
+  if (writeSurf) {
+    std::cout << "...write surface in mef format (mef = Marcs element format)" << std::endl;
+    std::cout << "      (Nelts,Nnodes):(" << elts.size() / 3 << ", " << merger.num_nodes() << ")" << std::endl;
+    std::vector<std::string> vars{"X", "Y", "Z"};
+    for (int n = 0; n < nComp; ++n) vars.push_back(H.names[pltComps[n]]);
+    char buf[72];
+    std::snprintf(buf, sizeof buf, "%g", isoVal);
+    std::string outfile_base = infile + "_" + isoCompName + "_" + std::string(buf);
+    pp.query("outfile_base", outfile_base);
+    std::cout << "  Writing the file..." << std::endl;
+    pa::write_mef(outfile_base + ".mef", H.time, vars, merger.nodes(), elts);
+    std::cout << "            ...done" << std::endl;
+  }
+  return 0;
+}
