@@ -2,16 +2,18 @@
 """bench.py -- headline benchmark: fused grad->curvature over a 512^3-base 3-level AMR hierarchy.
 
 Contract (driver): python bench.py --gpus N --steps K --warmup W ; N>1 is launched by
-torch.distributed.run (one rank per GPU, RCCL).  One "step" = one pass of the hot path
-(ghost fills + fused grad->curvature + coarse-fine/wall face fix-up, every level, every
-component) over synthetic input already resident in HBM.  Prints ONE JSON line on rank 0.
+torch.distributed.run (one rank per GPU, RCCL).  One "step" = one pass of the hot path (cross-rank
+ghost exchange when N>1, ghost fills, fused grad->curvature sweep, coarse-fine/wall face fix-up;
+every level, every component) over synthetic input already resident in HBM.  ONE JSON line on rank 0.
 
-metric  : Mcells/s  = sum over levels of valid cells * ncomp / t   (BASELINE.json)
-roofline: dominant kernel = the fused grad->curvature kernel; achieved = 72 B (read phi once,
-          write gx,gy,gz,|g|,Nx,Ny,Nz,K) * cells per launch / average launch duration, measured
-          with HIP events recorded by the library on its own stream inside the timed region.
-cpu_baseline: the CPU oracle (oracle/, OpenMP over boxes) on a bounded sample of the same
-          workload (a smaller hierarchy of the same shape), timed on this node's host cores.
+metric  : Mcells/s = sum over levels of valid cells * ncomp / t   (BASELINE.json)
+roofline: dominant kernel = the fused grad->curvature sweep; achieved = 72 B (read phi once, write
+          gx,gy,gz,|g|,Nx,Ny,Nz,K) * cells per launch / average launch duration, measured with HIP
+          events recorded by the library on its own stream inside the timed region.
+cpu_baseline: the CPU oracle (oracle/, OpenMP over boxes, kind "port") on a bounded sample of the
+          same workload (a smaller hierarchy of the same shape) on this node's host cores.
+N > 1   : weak scaling -- N copies of the hierarchy side by side in x (periodic), rank r owns slab r;
+          the level-0 slab faces exchange 2 ghost layers per step over RCCL point-to-point.
 """
 import argparse
 import json
@@ -29,7 +31,8 @@ BYTES_PER_CELL = 72.0  # fused grad->curvature algorithmic bytes pe
 
 
 def torch_field_flame(torch, x, y, z, m):
-    xc, yc, zc = x - 0.5, y - 0.5, z - 0.5
+    # periodic images of the flame kernel in x so that every slab of a multi-rank run holds a front
+    xc, yc, zc = (x - torch.floor(x)) - 0.5, y - 0.5, z - 0.5
     r = torch.sqrt((xc / 0.30) ** 2 + (yc / 0.15) ** 2 + (zc / 0.18) ** 2)
     theta = torch.atan2(yc + 0 * xc, xc + 0 * yc)
     rho = torch.sqrt(xc * xc + yc * yc + zc * zc) + 1e-30
@@ -39,7 +42,7 @@ def torch_field_flame(torch, x, y, z, m):
 
 
 def fill_level_on_device(torch, level, buf, ncomp, ng, off, cs, dev, seed):
-    """synthetic flame field + hash-like noise, written straight into HBM"""
+    """synthetic flame field + noise, written straight into HBM"""
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
     dx = level.dx
@@ -57,7 +60,7 @@ def fill_level_on_device(torch, level, buf, ncomp, ng, off, cs, dev, seed):
             buf[off[b] + c * cs[b]: off[b] + c * cs[b] + n] = v.reshape(-1)
 
 
-def cpu_baseline(base, nlev, box, ncomp_unused):
+def cpu_baseline(base, nlev, box):
     """Oracle (kind 'port') timed on the host cores: same pipeline, smaller hierarchy of the same shape."""
     from oracle import oracle as O
     from peleanalysis_amd.hierarchy import MultiFab, fill_analytic, nested_hierarchy, field_flame
@@ -77,7 +80,7 @@ def cpu_baseline(base, nlev, box, ncomp_unused):
     O.curvature_pipeline(H.levels, states, 0, bc, oc, 0, MultiFab, prog_min=300.0, prog_max=2000.0, omp=True)
     dt = time.perf_counter() - t0
     return {"value": cells / dt / 1e6, "unit": "Mcells/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": f"oracle grad+curvature pipelines (OpenMP over boxes), {nlev}-level base {base}^3, {box}^3 boxes, "
+            "sample": f"oracle grad+curvature pipelines (C restatement, OpenMP over boxes), {nlev}-level base {base}^3, {box}^3 boxes, "
                       f"{cells} cells, 1 comp, {dt:.1f} s"}
 
 
@@ -92,35 +95,41 @@ def main():
     ap.add_argument("--ncomp", type=int, default=1, help="components pushed through grad->curvature per step")
     ap.add_argument("--fused", type=int, default=1)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--cpu-base", type=int, default=128)
+    ap.add_argument("--cpu-base", type=int, default=0, help="base size of the cpu_baseline sample (0: from the core count)")
     args = ap.parse_args()
 
-    import torch
+    import torch  # torch first: one HIP runtime in the process
     import torch.distributed as dist
     from peleanalysis_amd import capi
+    from peleanalysis_amd import dist as padist
     from peleanalysis_amd.hierarchy import mf_layout, nested_hierarchy
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the product path has no CPU fallback)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    gloo = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
     stream = torch.cuda.Stream(device=dev)
     ctx = capi.Context(local, stream.cuda_stream)
 
     # weak scaling: every rank owns one full copy of the headline hierarchy (fixed work per GPU)
-    H = nested_hierarchy(args.base, args.nlev, args.box, is_per=(1, 1, 0))
+    if world == 1:
+        H = nested_hierarchy(args.base, args.nlev, args.box, is_per=(1, 1, 0))
+        remotes, plans = [None] * args.nlev, None
+    else:
+        R = padist.slab_hierarchy(args.base, args.nlev, args.box, world, rank, 2)
+        H, remotes, plans = R.local, R.remote, R.plans
     bc = capi.bc_from_flags((1, 1, 0))
-    dls = [capi.DevLevel(ctx, lv) for lv in H.levels]
+    dls = [capi.DevLevel(ctx, lv, remotes[l]) for l, lv in enumerate(H.levels)]
     cells = sum(lv.ncells for lv in H.levels)
-    hold = []
-    states, works, outs = [], [], []
+    hold, states, works, outs = [], [], [], []
     with torch.cuda.stream(stream):
         for li, (lv, dl) in enumerate(zip(H.levels, dls)):
             off, cs, tot = mf_layout(lv.boxes, args.ncomp, 2)
@@ -136,9 +145,42 @@ def main():
             outs.append(capi.DevMF(ctx, dl, 8, 0, tout.data_ptr()))
     stream.synchronize()
     params = capi.curv_params(prog_min=300.0, prog_max=2000.0, threshold=None, fused=bool(args.fused))
+    xch = {"mode": "none", "bytes_per_step": 0}
+
+    def exchange_rccl(c):
+        for l in range(args.nlev):
+            if plans[l].send or plans[l].recv:
+                padist.exchange_device(plans[l], ctx, states[l], c, 1, dev)
+
+    def exchange_gloo(c):  # host-staged fallback: same region lists and HIP pack/unpack, gloo transport
+        for l in range(args.nlev):
+            if plans[l].send or plans[l].recv:
+                padist.exchange_device_staged(plans[l], ctx, states[l], c, 1, dev, group=gloo)
+
+    do_exchange = None
+    if world > 1:
+        xch["bytes_per_step"] = int(sum(8 * pl.size(v, 1) for pl in plans for v in pl.send.values()) * args.ncomp)
+        try:
+            exchange_rccl(0)
+            ok = torch.tensor([1], device=dev)
+        except Exception as e:  # keep the measurement valid (all work done) if RCCL p2p is unavailable
+            xch["rccl_error"] = repr(e)[:300]
+            ok = torch.tensor([0], device=dev)
+        try:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            use_rccl = bool(ok.item())
+        except Exception:
+            use_rccl = False
+        if use_rccl:
+            do_exchange, xch["mode"] = exchange_rccl, "RCCL point-to-point (batch_isend_irecv), one packed buffer per peer"
+        else:
+            gloo = dist.new_group(backend="gloo")
+            do_exchange, xch["mode"] = exchange_gloo, "host-staged gloo point-to-point (RCCL p2p failed)"
 
     def step():
         for c in range(args.ncomp):  # output buffers are recycled per component (SURVEY 8d memory budget)
+            if do_exchange is not None:
+                do_exchange(c)
             capi.gradcurv_run(ctx, states, c, bc, params, works, outs, 0)
 
     def barrier():
@@ -178,7 +220,9 @@ def main():
         "config": {"workload": f"fused grad->curvature, {args.nlev}-level AMR, base {args.base}^3, ref_ratio 2, {args.box}^3 boxes "
                                f"({H.levels[0].nboxes} per level), {args.ncomp} comp(s), periodic x/y + wall z, {cells} cells per GPU",
                    "cells_per_gpu": cells, "ncomp": args.ncomp, "fused": bool(args.fused),
-                   "parallelism": "1 hierarchy per GPU" if world > 1 else "single GPU"},
+                   "parallelism": (f"{world} x-slabs (one hierarchy per GPU), level-0 slab faces exchanged per step"
+                                   if world > 1 else "single GPU"),
+                   "exchange": xch},
     }
     if nk:
         # one launch of the fused kernel = one level = cells/nlev cells (all levels have base^3 cells here)
@@ -186,19 +230,23 @@ def main():
         cells_per_launch = cells / args.nlev
         ach = cells_per_launch * BYTES_PER_CELL / (avg_ms * 1e-3) / 1e9
         res["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                           "traffic": None, "kernel": "k_gradcurv (fused grad->curvature)", "avg_launch_ms": avg_ms,
+                           "traffic": None, "kernel": "k_gradcurv_march (fused grad->curvature sweep)", "avg_launch_ms": avg_ms,
                            "launches": nk, "bytes_per_cell": BYTES_PER_CELL}
         res["breakdown_ms_per_step"] = {"gradcurv": ms_k / args.steps, "faces": ms_f / args.steps, "fill_boundary": ms_fill / args.steps,
                                         "apply_bc": ms_bc / args.steps, "progress": ms_prog / args.steps}
         res["step_frac_of_hbm_roofline"] = (cells * args.ncomp * BYTES_PER_CELL / (dt / args.steps) / 1e9) / HBM_PEAK_GBS
     if rank == 0 and world == 1 and not args.no_cpu:
         try:
-            res["cpu_baseline"] = cpu_baseline(args.cpu_base, args.nlev, max(args.cpu_base // 4, 8), args.ncomp)
+            # bounded sample (~10-30 s of CPU work): a 3-level hierarchy sized from the host core count
+            cores = os.cpu_count() or 1
+            base = args.cpu_base or (256 if cores >= 64 else (128 if cores >= 8 else 64))
+            res["cpu_baseline"] = cpu_baseline(base, args.nlev, max(base // 4, 8))
         except Exception as e:  # the baseline is reported, never required for the GPU number
             res["cpu_baseline"] = {"error": repr(e)}
     if rank == 0:
         print(json.dumps(res))
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -65,6 +65,20 @@ int pa_profile_read(pa_ctx*, int tag, int64_t* nlaunch, double* total_ms, int re
 pa_level* pa_level_create(pa_ctx*, int nboxes, const int32_t* boxes6, const int32_t domlo[3],
                           const int32_t domhi[3], const int32_t is_per[3], const double prob_lo[3],
                           const double prob_hi[3]);
+/* One rank's share of a level (replaces DistributionMapping(ba): grad.cpp:162, curvature.cpp:289):
+ * `boxes6` are the FABs this rank owns, `remote6` the boxes of the same level owned by other
+ * ranks.  Cells of remote boxes count as valid cells of the level (never coarse-fine, never
+ * filled locally); their data arrive through pa_pack_regions / pa_unpack_regions + the caller's
+ * exchange (RCCL send/recv of one packed buffer per peer). */
+pa_level* pa_level_create_dist(pa_ctx*, int nboxes, const int32_t* boxes6, int nremote, const int32_t* remote6,
+                               const int32_t domlo[3], const int32_t domhi[3], const int32_t is_per[3],
+                               const double prob_lo[3], const double prob_hi[3]);
+/* cross-rank halves of FillBoundary: gather / scatter lists of regions {local box, lo[3], hi[3]}
+ * (box index space, ghost cells allowed) to / from one contiguous device buffer, regions in list
+ * order, each [comp][k][j][i].  Synchronous (the buffer goes to the network next). */
+int64_t pa_regions_size(int ncomp, int nreg, const int32_t* regs7);
+int pa_pack_regions(pa_ctx*, const pa_mf*, int comp, int ncomp, int nreg, const int32_t* regs7, double* devbuf);
+int pa_unpack_regions(pa_ctx*, pa_mf*, int comp, int ncomp, int nreg, const int32_t* regs7, const double* devbuf);
 void      pa_level_destroy(pa_level*);
 int       pa_level_nboxes(const pa_level*);
 

@@ -61,6 +61,10 @@ def load_library() -> C.CDLL:
         "pa_profile_enable": (C.c_int, [vp, C.c_int]),
         "pa_profile_read": (C.c_int, [vp, C.c_int, C.POINTER(i64), pdbl, C.c_int]),
         "pa_level_create": (vp, [vp, C.c_int, pi32, pi32, pi32, pi32, pdbl, pdbl]),
+        "pa_level_create_dist": (vp, [vp, C.c_int, pi32, C.c_int, pi32, pi32, pi32, pi32, pdbl, pdbl]),
+        "pa_regions_size": (i64, [C.c_int, C.c_int, pi32]),
+        "pa_pack_regions": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, pi32, vp]),
+        "pa_unpack_regions": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, pi32, vp]),
         "pa_level_destroy": (None, [vp]),
         "pa_level_nboxes": (C.c_int, [vp]),
         "pa_mf_layout": (i64, [C.c_int, pi32, C.c_int, C.c_int, C.POINTER(i64), C.POINTER(i64)]),
@@ -200,11 +204,18 @@ class DevBuf:
 
 
 class DevLevel:
-    def __init__(self, ctx: Context, level: Level):
+    def __init__(self, ctx: Context, level: Level, remote_boxes: Optional[np.ndarray] = None):
+        """level: the boxes this rank owns; remote_boxes: (m,6) boxes of the same level owned by other ranks"""
         self.ctx, self.level = ctx, level
         b = np.ascontiguousarray(level.boxes, dtype=np.int32)
-        self.h = ctx.lib.pa_level_create(ctx.h, level.nboxes, b.ctypes.data_as(C.POINTER(C.c_int32)), _i3(level.domlo), _i3(level.domhi),
-                                         _i3(level.is_per), _d3(level.prob_lo), _d3(level.prob_hi))
+        if remote_boxes is None or len(remote_boxes) == 0:
+            self.h = ctx.lib.pa_level_create(ctx.h, level.nboxes, b.ctypes.data_as(C.POINTER(C.c_int32)), _i3(level.domlo), _i3(level.domhi),
+                                             _i3(level.is_per), _d3(level.prob_lo), _d3(level.prob_hi))
+        else:
+            r = np.ascontiguousarray(remote_boxes, dtype=np.int32)
+            self.h = ctx.lib.pa_level_create_dist(ctx.h, level.nboxes, b.ctypes.data_as(C.POINTER(C.c_int32)), len(r),
+                                                  r.ctypes.data_as(C.POINTER(C.c_int32)), _i3(level.domlo), _i3(level.domhi), _i3(level.is_per),
+                                                  _d3(level.prob_lo), _d3(level.prob_hi))
         if not self.h:
             raise PaError(ctx.lib.pa_last_error(ctx.h).decode())
 

@@ -96,12 +96,32 @@ static int host_classify(const pa_level* L, int i, int j, int k) {
     m[d] = r / L->g;
     if (m[d] >= L->mn[d]) return 1;
   }
-  return L->owner[((size_t)m[2] * L->mn[1] + m[1]) * L->mn[0] + m[0]] >= 0 ? 0 : 1;
+  const int o = L->owner[((size_t)m[2] * L->mn[1] + m[1]) * L->mn[0] + m[0]];
+  return (o >= 0 || o == -2) ? 0 : 1;  // -2: valid cell of a box owned by another rank
 }
+
+static pa_level* level_create_impl(pa_ctx* ctx, int nboxes, const int32_t* b6, int nremote, const int32_t* r6, const int32_t domlo[3],
+                                   const int32_t domhi[3], const int32_t is_per[3], const double prob_lo[3], const double prob_hi[3]);
 
 extern "C" pa_level* pa_level_create(pa_ctx* ctx, int nboxes, const int32_t* b6, const int32_t domlo[3],
                                      const int32_t domhi[3], const int32_t is_per[3], const double prob_lo[3],
                                      const double prob_hi[3]) {
+  return level_create_impl(ctx, nboxes, b6, 0, nullptr, domlo, domhi, is_per, prob_lo, prob_hi);
+}
+
+// One rank's share of a level: `boxes` are the FABs this rank owns, `remote` the boxes of the same
+// level owned by other ranks.  Remote boxes only mark their cells as valid cells of the level (so
+// that ghost cells they cover are neither treated as coarse-fine nor filled locally): their data
+// arrive through pa_pack_regions / pa_unpack_regions and the caller's exchange (RCCL).
+extern "C" pa_level* pa_level_create_dist(pa_ctx* ctx, int nboxes, const int32_t* b6, int nremote, const int32_t* r6, const int32_t domlo[3],
+                                          const int32_t domhi[3], const int32_t is_per[3], const double prob_lo[3],
+                                          const double prob_hi[3]) {
+  if (nremote < 0 || (nremote > 0 && !r6)) { pa_fail(ctx, "pa_level_create_dist: bad remote box list"); return nullptr; }
+  return level_create_impl(ctx, nboxes, b6, nremote, r6, domlo, domhi, is_per, prob_lo, prob_hi);
+}
+
+static pa_level* level_create_impl(pa_ctx* ctx, int nboxes, const int32_t* b6, int nremote, const int32_t* r6, const int32_t domlo[3],
+                                   const int32_t domhi[3], const int32_t is_per[3], const double prob_lo[3], const double prob_hi[3]) {
   if (!ctx) return nullptr;
   if (nboxes <= 0 || !b6) { pa_fail(ctx, "pa_level_create: empty BoxArray"); return nullptr; }
   pa_level* L = new pa_level();
@@ -132,13 +152,28 @@ extern "C" pa_level* pa_level_create(pa_ctx* ctx, int nboxes, const int32_t* b6,
     L->ncells += (long long)(L->boxes[b].hi[0] - L->boxes[b].lo[0] + 1) * (L->boxes[b].hi[1] - L->boxes[b].lo[1] + 1) *
                  (L->boxes[b].hi[2] - L->boxes[b].lo[2] + 1);
   }
+  std::vector<DBox> remote(nremote);
+  for (int b = 0; b < nremote; ++b)
+    for (int d = 0; d < 3; ++d) {
+      remote[b].lo[d] = r6[6 * b + d];
+      remote[b].hi[d] = r6[6 * b + 3 + d];
+      if (remote[b].hi[d] < remote[b].lo[d] || remote[b].lo[d] < domlo[d] || remote[b].hi[d] > domhi[d]) {
+        pa_fail(ctx, "pa_level_create_dist: remote box " + std::to_string(b) + " is empty or outside the domain");
+        delete L;
+        return nullptr;
+      }
+      L->mlo[d] = std::min(L->mlo[d], remote[b].lo[d]);
+      mhi[d] = std::max(mhi[d], remote[b].hi[d]);
+    }
   // owner-map granularity
   int g = 0;
-  for (int b = 0; b < nboxes; ++b)
+  for (int b = 0; b < nboxes + nremote; ++b) {
+    const DBox& B = b < nboxes ? L->boxes[b] : remote[b - nboxes];
     for (int d = 0; d < 3; ++d) {
-      g = std::gcd(g, L->boxes[b].lo[d] - L->mlo[d]);
-      g = std::gcd(g, L->boxes[b].hi[d] - L->boxes[b].lo[d] + 1);
+      g = std::gcd(g, B.lo[d] - L->mlo[d]);
+      g = std::gcd(g, B.hi[d] - B.lo[d] + 1);
     }
+  }
   if (g <= 0) g = 1;
   L->g = g;
   size_t msz = 1;
@@ -152,18 +187,18 @@ extern "C" pa_level* pa_level_create(pa_ctx* ctx, int nboxes, const int32_t* b6,
     return nullptr;
   }
   L->owner.assign(msz, -1);
-  for (int b = 0; b < nboxes; ++b) {
-    const DBox& B = L->boxes[b];
+  for (int b = 0; b < nboxes + nremote; ++b) {
+    const DBox& B = b < nboxes ? L->boxes[b] : remote[b - nboxes];
     for (int kz = (B.lo[2] - L->mlo[2]) / g; kz <= (B.hi[2] - L->mlo[2]) / g; ++kz)
       for (int ky = (B.lo[1] - L->mlo[1]) / g; ky <= (B.hi[1] - L->mlo[1]) / g; ++ky)
         for (int kx = (B.lo[0] - L->mlo[0]) / g; kx <= (B.hi[0] - L->mlo[0]) / g; ++kx) {
           int& o = L->owner[((size_t)kz * L->mn[1] + ky) * L->mn[0] + kx];
-          if (o >= 0) {
+          if (o != -1) {
             pa_fail(ctx, "pa_level_create: boxes " + std::to_string(o) + " and " + std::to_string(b) + " overlap");
             delete L;
             return nullptr;
           }
-          o = b;
+          o = b < nboxes ? b : -2;
         }
   }
   // Fused grad->curvature legality: an edge ghost cell that is NOT a valid cell while both
@@ -391,7 +426,7 @@ __global__ void k_fill_boundary(DLevelView L, DMFView M, int comp, int ncomp, in
   int i, j, k;
   if (!shell_cell(B, ngf, t, i, j, k)) return;
   int s, p[3];
-  if (classify(L, i, j, k, s, p) != 0) return;
+  if (classify(L, i, j, k, s, p) != 0 || s < 0) return;  // s < 0: covered by another rank's box (filled by the exchange)
   const DBox S = L.boxes[s];
   for (int c = comp; c < comp + ncomp; ++c)
     M.data[M.off[b] + fab_index(B, M.ng, M.ncomp, c, i, j, k)] = M.data[M.off[s] + fab_index(S, M.ng, M.ncomp, c, p[0], p[1], p[2])];
@@ -650,4 +685,78 @@ extern "C" int pa_memcpy_d2h(pa_ctx* ctx, void* dst, const void* src, int64_t by
   PA_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream));
   PA_HIP(hipStreamSynchronize(ctx->stream));
   return 0;
+}
+
+// ------------------------------------------------------------------ ghost exchange between ranks
+// Regions are [local box, lo0,lo1,lo2, hi0,hi1,hi2] in that box's index space (ghost cells allowed).
+// The buffer is the concatenation of the regions in list order, each laid out [comp][k][j][i].
+__global__ void k_regions(DLevelView L, DMFView M, int comp, int ncomp, int nreg, const int* regs, const long long* roff, double* buf, int unpack) {
+  const int r = blockIdx.y;
+  if (r >= nreg) return;
+  const int* R = regs + 7 * r;
+  const int b = R[0];
+  const int nx = R[4] - R[1] + 1, ny = R[5] - R[2] + 1, nz = R[6] - R[3] + 1;
+  const long long n = (long long)nx * ny * nz * ncomp;
+  const DBox B = L.boxes[b];
+  double* f = M.data + M.off[b];
+  double* q = buf + roff[r];
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+    const int i = (int)(t % nx), j = (int)((t / nx) % ny), k = (int)((t / ((long long)nx * ny)) % nz), c = (int)(t / ((long long)nx * ny * nz));
+    const long long idx = fab_index(B, M.ng, M.ncomp, comp + c, R[1] + i, R[2] + j, R[3] + k);
+    if (unpack) f[idx] = q[t];
+    else q[t] = f[idx];
+  }
+}
+
+static int regions_impl(pa_ctx* ctx, pa_mf* M, int comp, int ncomp, int nreg, const int32_t* regs, double* devbuf, int unpack) {
+  if (!ctx || !M) return pa_fail(ctx, "pa_pack_regions: null argument");
+  if (nreg == 0) return 0;
+  if (!regs || !devbuf) return pa_fail(ctx, "pa_pack_regions: null region list / buffer");
+  if (comp < 0 || ncomp < 1 || comp + ncomp > M->ncomp) return pa_fail(ctx, "pa_pack_regions: component range");
+  const pa_level* L = M->lev;
+  std::vector<long long> roff(nreg);
+  long long tot = 0, maxn = 0;
+  for (int r = 0; r < nreg; ++r) {
+    const int32_t* R = regs + 7 * r;
+    if (R[0] < 0 || R[0] >= (int)L->boxes.size()) return pa_fail(ctx, "pa_pack_regions: region " + std::to_string(r) + ": bad box index");
+    long long n = ncomp;
+    for (int d = 0; d < 3; ++d) {
+      const DBox& B = L->boxes[R[0]];
+      if (R[1 + d] > R[4 + d] || R[1 + d] < B.lo[d] - M->ng || R[4 + d] > B.hi[d] + M->ng)
+        return pa_fail(ctx, "pa_pack_regions: region " + std::to_string(r) + " lies outside its (grown) box");
+      n *= R[4 + d] - R[1 + d] + 1;
+    }
+    roff[r] = tot;
+    tot += n;
+    maxn = std::max(maxn, n);
+  }
+  // region table to the device (small; lives until the stream has consumed it)
+  const size_t bytes = sizeof(int) * 7 * (size_t)nreg + sizeof(long long) * (size_t)nreg;
+  if (pa_ensure_red(ctx, (bytes + 7) / 8 + 8)) return 1;
+  PA_HIP(hipStreamSynchronize(ctx->stream));  // the scratch may still be in use by an earlier call
+  long long* d_off = (long long*)ctx->d_red;
+  int* d_regs = (int*)(d_off + nreg);
+  PA_HIP(hipMemcpyAsync(d_off, roff.data(), sizeof(long long) * nreg, hipMemcpyHostToDevice, ctx->stream));
+  PA_HIP(hipMemcpyAsync(d_regs, regs, sizeof(int) * 7 * nreg, hipMemcpyHostToDevice, ctx->stream));
+  dim3 grid((unsigned)std::min<long long>((maxn + 255) / 256, 1024), (unsigned)nreg);
+  hipLaunchKernelGGL(k_regions, grid, dim3(256), 0, ctx->stream, L->view, M->view, comp, ncomp, nreg, d_regs, d_off, devbuf, unpack);
+  PA_HIP(hipGetLastError());
+  PA_HIP(hipStreamSynchronize(ctx->stream));  // the caller hands the buffer to RCCL next
+  return 0;
+}
+
+extern "C" int64_t pa_regions_size(int ncomp, int nreg, const int32_t* regs) {
+  int64_t tot = 0;
+  for (int r = 0; r < nreg; ++r) {
+    int64_t n = ncomp;
+    for (int d = 0; d < 3; ++d) n *= regs[7 * r + 4 + d] - regs[7 * r + 1 + d] + 1;
+    tot += n;
+  }
+  return tot;
+}
+extern "C" int pa_pack_regions(pa_ctx* ctx, const pa_mf* M, int comp, int ncomp, int nreg, const int32_t* regs, double* devbuf) {
+  return regions_impl(ctx, const_cast<pa_mf*>(M), comp, ncomp, nreg, regs, devbuf, 0);
+}
+extern "C" int pa_unpack_regions(pa_ctx* ctx, pa_mf* M, int comp, int ncomp, int nreg, const int32_t* regs, const double* devbuf) {
+  return regions_impl(ctx, M, comp, ncomp, nreg, regs, const_cast<double*>(devbuf), 1);
 }

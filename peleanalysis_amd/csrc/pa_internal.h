@@ -152,8 +152,8 @@ __device__ __forceinline__ int owner_of(const DLevelView& L, const int p[3]) {
 __device__ __forceinline__ int classify(const DLevelView& L, int i, int j, int k, int& box, int p[3]) {
   p[0] = i; p[1] = j; p[2] = k;
   if (!wrap_cell(L, p)) return 2;
-  box = owner_of(L, p);
-  return box >= 0 ? 0 : 1;
+  box = owner_of(L, p);  // >= 0: box of this rank; -2: valid cell of a box owned by another rank; -1: none
+  return (box >= 0 || box == -2) ? 0 : 1;
 }
 __device__ __forceinline__ int classify(const DLevelView& L, int i, int j, int k) {
   int b, p[3];
