@@ -229,8 +229,12 @@ def main():
         avg_ms = ms_k / nk
         cells_per_launch = cells / args.nlev
         ach = cells_per_launch * BYTES_PER_CELL / (avg_ms * 1e-3) / 1e9
+        traffic = None  # HBM bytes per launch from the committed rocprofv3 PMC pass of the same workload (profiles/)
+        tj = os.path.join(ROOT, "profiles", "r01_headline_traffic.json")
+        if os.path.exists(tj) and (args.base, args.nlev, args.box, args.ncomp) == (512, 3, 128, 1):
+            traffic = json.load(open(tj)).get("traffic_bytes_per_launch")
         res["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                           "traffic": None, "kernel": "k_gradcurv_march (fused grad->curvature sweep)", "avg_launch_ms": avg_ms,
+                           "traffic": traffic, "kernel": "k_gradcurv_march (fused grad->curvature sweep)", "avg_launch_ms": avg_ms,
                            "launches": nk, "bytes_per_cell": BYTES_PER_CELL}
         res["breakdown_ms_per_step"] = {"gradcurv": ms_k / args.steps, "faces": ms_f / args.steps, "fill_boundary": ms_fill / args.steps,
                                         "apply_bc": ms_bc / args.steps, "progress": ms_prog / args.steps}
