@@ -201,9 +201,17 @@ typedef struct {
   int32_t do_threshold;       /* threshold_prog */
   double  threshold;          /* threshold_value */
   int32_t fused;              /* 1: fused grad->curvature kernels, 0: pass-by-pass */
+  /* options of curvature.cpp:575-789 (pa_curvature_run only) */
+  int32_t do_gauss_curv;      /* do_gaussCurv  (:575-677) */
+  int32_t do_strain;          /* do_strain     (:679-749), keeps the reference's result = div u (quirk Q3) */
+  int32_t get_strain_tensor;  /* getStrainTensor (:755-757): the 9 components of grad u */
+  int32_t do_velnormal;       /* do_velnormal  (:765-787) */
+  int32_t vel_comp;           /* first of the 3 consecutive velocity components in state */
 } pa_curv_params;
-/* curvature.cpp:283-326 + 408-570 (core).  state[lev][comp] = progress source (ng>=2).
- * out[lev] comps: ocomp+0 Progress, +1 MeanCurvature, +2..4 FlameNormal. */
+/* curvature.cpp:283-326 + 408-570 (core) + 575-789 (options).  state[lev][comp] = progress source
+ * (ng>=2; with do_strain the velocity components get their ghost cells filled in place).
+ * out[lev] comps: ocomp+0 Progress, +1 MeanCurvature, +2..4 FlameNormal, and when requested
+ * +5 GaussianCurvature, +6 StrainRate, +7 VelFlameNormal, +8..16 ROST_dU?d? (row-major grad u). */
 int pa_curvature_run(pa_ctx*, int nlev, pa_mf* const* state, int comp, const int32_t bc[3],
                      const pa_curv_params*, pa_mf* const* out, int ocomp);
 /* fused grad+curvature of one variable: out[lev] comps ocomp+0..3 = gx,gy,gz,|g|,

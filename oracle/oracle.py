@@ -144,7 +144,7 @@ def grad_pipeline(levels, states, comp, bc, outs, ocomp, multipass=True, omp=Fal
 
 
 def curvature_pipeline(levels, states, comp, bc, outs, ocomp, MF, prog_min=None, prog_max=None, threshold=None,
-                       do_gauss=False, vel_comp=None, do_strain=False, do_velnormal=False, omp=False):
+                       do_gauss=False, vel_comp=None, do_strain=False, do_velnormal=False, strain_tensor=False, omp=False):
     """curvature.cpp:283-326 + 408-570 (core), 575-789 (options).
     out comps: ocomp+0 Progress, +1 MeanCurvature, +2..4 FlameNormal, +5 GaussianCurvature
     (0.0 when not requested: quirk Q1), +6 StrainRate, +7 VelFlameNormal (when requested).
@@ -209,6 +209,8 @@ def curvature_pipeline(levels, states, comp, bc, outs, ocomp, MF, prog_min=None,
             sr = MF(levels[l], 1, 0)
             L.orc_strain_rate(_p(_mf(gu)), _p(_mf(n)), _p(_mf(sr)), 0)
             L.orc_copy(_p(_mf(sr)), 0, _p(_mf(outs[l])), ocomp + 6, 1, 0)
+            if strain_tensor:  # getStrainTensor (curvature.cpp:755-757)
+                L.orc_copy(_p(_mf(gu)), 0, _p(_mf(outs[l])), ocomp + 8, 9, 0)
         if do_velnormal and vel_comp is not None:
             L.orc_vel_normal(_p(_mf(states[l])), vel_comp, _p(_mf(n)), _p(_mf(c)), 0, C.c_double(thr), _p(_mf(outs[l])), ocomp + 7)
     return prog_min, prog_max

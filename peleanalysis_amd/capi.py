@@ -30,7 +30,8 @@ class PaBox(C.Structure):
 
 class PaCurvParams(C.Structure):
     _fields_ = [("prog_min", C.c_double), ("prog_max", C.c_double), ("do_threshold", C.c_int32), ("threshold", C.c_double),
-                ("fused", C.c_int32)]
+                ("fused", C.c_int32), ("do_gauss_curv", C.c_int32), ("do_strain", C.c_int32), ("get_strain_tensor", C.c_int32),
+                ("do_velnormal", C.c_int32), ("vel_comp", C.c_int32)]
 
 
 _lib = None
@@ -292,8 +293,10 @@ def grad_run(ctx: Context, states: Sequence[DevMF], comp: int, bc, outs: Sequenc
     ctx.check(ctx.lib.pa_grad_run(ctx.h, len(states), _handles(states), comp, _i3(bc), _handles(outs), ocomp))
 
 
-def curv_params(prog_min=None, prog_max=None, threshold=None, fused=True) -> PaCurvParams:
+def curv_params(prog_min=None, prog_max=None, threshold=None, fused=True, do_gauss=False, do_strain=False, strain_tensor=False,
+                do_velnormal=False, vel_comp=0) -> PaCurvParams:
     p = PaCurvParams()
+    p.do_gauss_curv, p.do_strain, p.get_strain_tensor, p.do_velnormal, p.vel_comp = int(do_gauss), int(do_strain), int(strain_tensor), int(do_velnormal), int(vel_comp)
     p.prog_min = 1e20 if prog_min is None else prog_min
     p.prog_max = -1e20 if prog_max is None else prog_max
     p.do_threshold = 0 if threshold is None else 1

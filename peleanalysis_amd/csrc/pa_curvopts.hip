@@ -1,0 +1,142 @@
+// pa_curvopts.hip -- optional outputs of curvature.cpp on gfx950:
+//   Gaussian curvature (curvature.cpp:575-677), strain rate / rate-of-strain tensor (:679-757),
+//   flame-normal velocity (:765-787).
+// The reference builds three more MLPoisson operators per option just to differentiate three fields;
+// here each option is ONE sweep that differentiates from ghost-resolved inputs (FillBoundary +
+// applyBC done by the caller, pa_pipeline.hip) in the reference's operation order (cdiff).
+#include "pa_internal.h"
+#include "pa_fabview.h"
+
+struct BP3 {
+  DLevelView L;
+  DMFView A, B, C;
+  __device__ __forceinline__ bool get(int b, FabView& a, FabView& o, FabView& c, DBox& V, double dxinv[3]) const {
+    if (b >= L.nboxes) return false;
+    const DBox X = L.boxes[b];
+    a = mf_view(A, X, b);
+    o = mf_view(B, X, b);
+    c = mf_view(C, X, b);
+    V = X;
+    for (int d = 0; d < 3; ++d) dxinv[d] = L.dxinv[d];
+    return true;
+  }
+};
+
+// Hessian rows = grad(G_d) (:582-613), adjugate (:630-638), Kg = G^T adj(H) G / normgrad^4 (:659-668)
+__global__ __launch_bounds__(256) void k_gauss_curv(BP3 bp, int gcomp, DMFView MNG, int ngcomp, int ccomp, double thr, int kcomp) {
+  FabView G, K, C;
+  DBox V;
+  double dxinv[3];
+  if (!bp.get(blockIdx.y, G, K, C, V, dxinv)) return;
+  int i, j, k0, k1;
+  if (!tile_cell(V, i, j, k0, k1)) return;
+  const FabView NG = mf_view(MNG, V, blockIdx.y);
+  for (int k = k0; k <= k1; ++k) {
+    double H[3][3], g[3];
+    for (int d = 0; d < 3; ++d) {
+      const double c0 = G(i, j, k, gcomp + d);
+      g[d] = c0;
+      H[d][0] = cdiff(dxinv[0], G(i - 1, j, k, gcomp + d), c0, G(i + 1, j, k, gcomp + d));
+      H[d][1] = cdiff(dxinv[1], G(i, j - 1, k, gcomp + d), c0, G(i, j + 1, k, gcomp + d));
+      H[d][2] = cdiff(dxinv[2], G(i, j, k - 1, gcomp + d), c0, G(i, j, k + 1, gcomp + d));
+    }
+#define HX(n) H[0][n]
+#define HY(n) H[1][n]
+#define HZ(n) H[2][n]
+    const double ax0 = HY(1) * HZ(2) - HZ(1) * HY(2);
+    const double ay0 = HY(2) * HZ(0) - HZ(2) * HY(0);
+    const double az0 = HY(0) * HZ(1) - HZ(0) * HY(1);
+    const double ax1 = HX(2) * HZ(1) - HZ(2) * HX(1);
+    const double ay1 = HX(0) * HZ(2) - HZ(0) * HX(2);
+    const double az1 = HX(1) * HZ(0) - HZ(1) * HX(0);
+    const double ax2 = HX(1) * HY(2) - HY(1) * HX(2);
+    const double ay2 = HX(2) * HY(0) - HY(2) * HX(0);
+    const double az2 = HX(0) * HY(1) - HY(0) * HX(1);
+#undef HX
+#undef HY
+#undef HZ
+    const double cx = g[0], cy = g[1], cz = g[2];
+    const double gn = NG(i, j, k, ngcomp);
+    // pow(x,4.0) == (x*x)*(x*x) (quirk Q12)
+    double kg = (cx * (ax0 * cx + ax1 * cy + ax2 * cz) + cy * (ay0 * cx + ay1 * cy + ay2 * cz) + cz * (az0 * cx + az1 * cy + az2 * cz)) /
+                ((gn * gn) * (gn * gn));
+    if (thr >= 0.0) {
+      const double p = C(i, j, k, ccomp);
+      if (p < thr || p > 1.0 - thr) kg = 0.0;
+    }
+    K(i, j, k, kcomp) = kg;
+  }
+}
+
+// grad u (9 components, row = velocity component) and the "strain rate" the reference stores:
+// its first assignment (-nn:grad u) is overwritten by div u (curvature.cpp:736-747, quirk Q3)
+__global__ __launch_bounds__(256) void k_strain(LevelBP2 bp, int ucomp, int srcomp, int rostcomp) {
+  FabView U, O;
+  DBox V;
+  double dxinv[3];
+  if (!bp.get(blockIdx.y, U, O, V, dxinv)) return;
+  int i, j, k0, k1;
+  if (!tile_cell(V, i, j, k0, k1)) return;
+  for (int k = k0; k <= k1; ++k) {
+    double gu[9];
+    for (int d = 0; d < 3; ++d) {
+      const double c0 = U(i, j, k, ucomp + d);
+      gu[3 * d + 0] = cdiff(dxinv[0], U(i - 1, j, k, ucomp + d), c0, U(i + 1, j, k, ucomp + d));
+      gu[3 * d + 1] = cdiff(dxinv[1], U(i, j - 1, k, ucomp + d), c0, U(i, j + 1, k, ucomp + d));
+      gu[3 * d + 2] = cdiff(dxinv[2], U(i, j, k - 1, ucomp + d), c0, U(i, j, k + 1, ucomp + d));
+    }
+    O(i, j, k, srcomp) = +gu[0] + gu[4] + gu[8];
+    if (rostcomp >= 0)
+      for (int q = 0; q < 9; ++q) O(i, j, k, rostcomp + q) = gu[q];
+  }
+}
+
+// u . n with the (already thresholded) flame normal, clipped like the curvature (curvature.cpp:776-785)
+__global__ __launch_bounds__(256) void k_velnormal(BP3 bp, int ucomp, int ncomp0, int ocomp, DMFView MC, int ccomp, double thr) {
+  FabView U, O, N;
+  DBox V;
+  double dxinv[3];
+  if (!bp.get(blockIdx.y, U, O, N, V, dxinv)) return;
+  int i, j, k0, k1;
+  if (!tile_cell(V, i, j, k0, k1)) return;
+  const FabView C = mf_view(MC, V, blockIdx.y);
+  for (int k = k0; k <= k1; ++k) {
+    double v = +U(i, j, k, ucomp) * N(i, j, k, ncomp0) + U(i, j, k, ucomp + 1) * N(i, j, k, ncomp0 + 1) + U(i, j, k, ucomp + 2) * N(i, j, k, ncomp0 + 2);
+    if (thr >= 0.0) {
+      const double p = C(i, j, k, ccomp);
+      if (p < thr || p > 1.0 - thr) v = 0.0;
+    }
+    O(i, j, k, ocomp) = v;
+  }
+}
+
+int pa_gauss_curv_level(pa_ctx* ctx, const pa_mf* G, int gcomp, const pa_mf* normgrad, int ngcomp, const pa_mf* c, int ccomp, double thr, pa_mf* out,
+                        int kcomp) {
+  if (!ctx || !G || !normgrad || !out || (thr >= 0.0 && !c)) return pa_fail(ctx, "pa_gauss_curv_level: null argument");
+  if (G->ng < 1) return pa_fail(ctx, "pa_gauss_curv_level: G needs >= 1 ghost layer");
+  if (G->lev != out->lev || G->lev != normgrad->lev) return pa_fail(ctx, "pa_gauss_curv_level: different levels");
+  BP3 bp{G->lev->view, G->view, out->view, c ? c->view : G->view};
+  hipLaunchKernelGGL(k_gauss_curv, tile_grid(G->lev), dim3(256), 0, ctx->stream, bp, gcomp, normgrad->view, ngcomp, ccomp, thr, kcomp);
+  PA_HIP(hipGetLastError());
+  return 0;
+}
+
+int pa_strain_level(pa_ctx* ctx, const pa_mf* u, int ucomp, pa_mf* out, int srcomp, int rostcomp) {
+  if (!ctx || !u || !out) return pa_fail(ctx, "pa_strain_level: null argument");
+  if (u->ng < 1 || u->lev != out->lev) return pa_fail(ctx, "pa_strain_level: velocity needs >= 1 ghost layer on the same level");
+  if (ucomp < 0 || ucomp + 3 > u->ncomp || srcomp >= out->ncomp || (rostcomp >= 0 && rostcomp + 9 > out->ncomp)) return pa_fail(ctx, "pa_strain_level: component range");
+  LevelBP2 bp{u->lev->view, u->view, out->view};
+  hipLaunchKernelGGL(k_strain, tile_grid(u->lev), dim3(256), 0, ctx->stream, bp, ucomp, srcomp, rostcomp);
+  PA_HIP(hipGetLastError());
+  return 0;
+}
+
+int pa_velnormal_level(pa_ctx* ctx, const pa_mf* u, int ucomp, const pa_mf* n, int ncomp0, const pa_mf* c, int ccomp, double thr, pa_mf* out, int ocomp) {
+  if (!ctx || !u || !n || !out || (thr >= 0.0 && !c)) return pa_fail(ctx, "pa_velnormal_level: null argument");
+  if (u->lev != out->lev || n->lev != out->lev) return pa_fail(ctx, "pa_velnormal_level: different levels");
+  if (ucomp < 0 || ucomp + 3 > u->ncomp || ncomp0 + 3 > n->ncomp || ocomp >= out->ncomp) return pa_fail(ctx, "pa_velnormal_level: component range");
+  BP3 bp{u->lev->view, u->view, out->view, n->view};
+  hipLaunchKernelGGL(k_velnormal, tile_grid(u->lev), dim3(256), 0, ctx->stream, bp, ucomp, ncomp0, ocomp, c ? c->view : u->view, ccomp, thr);
+  PA_HIP(hipGetLastError());
+  return 0;
+}

@@ -154,7 +154,7 @@ static void march_launch(hipStream_t st, const BP& bp, int nx, int ny, int nz, u
   case M * 10 + W:                                                                                                                 \
     hipLaunchKernelGGL((k_gradcurv_march<BP, M, W>), march_grid(nx, ny, nz, A.kseg, M, nboxes), dim3(64 * (M + 3)), 0, st, bp, A); \
     break;
-    PA_CASE(4, 1) PA_CASE(8, 1) PA_CASE(8, 6) PA_CASE(12, 1) PA_CASE(13, 1)
+    PA_CASE(4, 1) PA_CASE(5, 1) PA_CASE(5, 4) PA_CASE(8, 1) PA_CASE(8, 6) PA_CASE(12, 1) PA_CASE(13, 1)
 #undef PA_CASE
     default:
       hipLaunchKernelGGL((k_gradcurv_march<BP, 8, 1>), march_grid(nx, ny, nz, A.kseg, 8, nboxes), dim3(64 * 11), 0, st, bp, A);

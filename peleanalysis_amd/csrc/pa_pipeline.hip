@@ -6,6 +6,10 @@
 
 int pa_apply_bc_impl(pa_ctx* ctx, pa_mf* F, int comp, const pa_mf* C, int ccomp, const int32_t bc[3], int ratio, int only_dir,
                      int edges, const double* crse_xform);
+int pa_gauss_curv_level(pa_ctx* ctx, const pa_mf* G, int gcomp, const pa_mf* normgrad, int ngcomp, const pa_mf* c, int ccomp, double thr, pa_mf* out,
+                        int kcomp);
+int pa_strain_level(pa_ctx* ctx, const pa_mf* u, int ucomp, pa_mf* out, int srcomp, int rostcomp);
+int pa_velnormal_level(pa_ctx* ctx, const pa_mf* u, int ucomp, const pa_mf* n, int ncomp0, const pa_mf* c, int ccomp, double thr, pa_mf* out, int ocomp);
 
 #define PA_TRY(x)        \
   do {                   \
@@ -52,9 +56,18 @@ static int prog_minmax(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, con
 }
 
 // pass-by-pass curvature core; out comps: pc (Progress, -1 = skip), kc (MeanCurvature), nc (FlameNormal x3)
+// opt >= 0: also the options of curvature.cpp:575-789 selected in P, written at out comps opt+5.. (see the header)
 static int curvature_passes(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, const int32_t bc[3], double pmin, double pmax,
-                            double thr, pa_mf* const* out, int pc, int kc, int nc) {
-  std::vector<MFPtr> cmf(nlev), nmf(nlev);
+                            double thr, pa_mf* const* out, int pc, int kc, int nc, const pa_curv_params* P = nullptr, int opt = -1) {
+  std::vector<MFPtr> cmf(nlev), nmf(nlev), gmf(nlev), ngmf(nlev);
+  const bool gauss = opt >= 0 && P && P->do_gauss_curv;
+  const bool strain = opt >= 0 && P && P->do_strain;
+  const bool veln = opt >= 0 && P && P->do_velnormal;
+  for (int l = 0; l < nlev && opt >= 0; ++l) {
+    const int need = opt + (strain && P->get_strain_tensor ? 17 : (veln ? 8 : (strain ? 7 : (gauss ? 6 : 5))));
+    if (out[l]->ncomp < need) return pa_fail(ctx, "pa_curvature_run: out needs " + std::to_string(need) + " components for the requested options");
+    if ((strain || veln) && (P->vel_comp < 0 || P->vel_comp + 3 > state[l]->ncomp)) return pa_fail(ctx, "pa_curvature_run: vel_comp out of range");
+  }
   for (int l = 0; l < nlev; ++l) {
     cmf[l].reset(pa_mf_create(ctx, state[l]->lev, 1, 1, nullptr));
     nmf[l].reset(pa_mf_create(ctx, state[l]->lev, 3, 1, nullptr));
@@ -66,13 +79,30 @@ static int curvature_passes(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp
     pa_mf* c = cmf[l].get();
     pa_mf* n = nmf[l].get();
     PA_TRY(pa_apply_bc(ctx, c, 0, l > 0 ? cmf[l - 1].get() : nullptr, 0, bc, 2, -1));  // :426-457 (inside getFluxes)
-    PA_TRY(pa_normal_level(ctx, c, 0, nullptr, 0, nullptr, 0, n, 0));                   // :457-500
+    if (gauss) {
+      gmf[l].reset(pa_mf_create(ctx, state[l]->lev, 3, 1, nullptr));
+      ngmf[l].reset(pa_mf_create(ctx, state[l]->lev, 1, 0, nullptr));
+      if (!gmf[l] || !ngmf[l]) return 1;
+    }
+    PA_TRY(pa_normal_level(ctx, c, 0, gmf[l].get(), 0, ngmf[l].get(), 0, n, 0));         // :457-500
     PA_TRY(pa_fill_boundary(ctx, n, 0, 3, 1));                                          // :502
     for (int d = 0; d < 3; ++d)                                                         // :508-531
       PA_TRY(pa_apply_bc(ctx, n, d, l > 0 ? out[l - 1] : nullptr, nc + d, bc, 2, d));
     PA_TRY(pa_div_level(ctx, n, 0, 0.5, c, 0, thr, out[l], kc));                        // :533-567
     if (pc >= 0) PA_TRY(pa_mf_copy(ctx, c, 0, out[l], pc, 1, 0));
     PA_TRY(pa_mf_copy(ctx, n, 0, out[l], nc, 3, 0));                                    // :569-570
+    if (gauss) {  // :575-677: Hessian of c from cell_normal (= G), coarse-fine BC from cell_normal[lev-1]
+      pa_mf* G = gmf[l].get();
+      PA_TRY(pa_fill_boundary(ctx, G, 0, 3, 1));                                        // :488
+      for (int d = 0; d < 3; ++d) PA_TRY(pa_apply_bc(ctx, G, d, l > 0 ? gmf[l - 1].get() : nullptr, d, bc, 2, -1));
+      PA_TRY(pa_gauss_curv_level(ctx, G, 0, ngmf[l].get(), 0, c, 0, thr, out[l], opt + 5));
+    }
+    if (strain) {  // :679-757: grad u through the same ghost-resolved central differences
+      PA_TRY(pa_fill_boundary(ctx, state[l], P->vel_comp, 3, 1));
+      for (int d = 0; d < 3; ++d) PA_TRY(pa_apply_bc(ctx, state[l], P->vel_comp + d, l > 0 ? state[l - 1] : nullptr, P->vel_comp + d, bc, 2, -1));
+      PA_TRY(pa_strain_level(ctx, state[l], P->vel_comp, out[l], opt + 6, P->get_strain_tensor ? opt + 8 : -1));
+    }
+    if (veln) PA_TRY(pa_velnormal_level(ctx, state[l], P->vel_comp, n, 0, c, 0, thr, out[l], opt + 7));  // :765-787
   }
   PA_TRY(pa_sync(ctx));  // scratch multifabs are freed on return
   return 0;
@@ -121,7 +151,7 @@ extern "C" int pa_curvature_run(pa_ctx* ctx, int nlev, pa_mf* const* state, int 
   double pmin, pmax;
   PA_TRY(prog_minmax(ctx, nlev, state, comp, P, pmin, pmax));
   const double thr = P->do_threshold ? P->threshold : -1.0;
-  return curvature_passes(ctx, nlev, state, comp, bc, pmin, pmax, thr, out, ocomp, ocomp + 1, ocomp + 2);
+  return curvature_passes(ctx, nlev, state, comp, bc, pmin, pmax, thr, out, ocomp, ocomp + 1, ocomp + 2, P, ocomp);
 }
 
 extern "C" int pa_gradcurv_run(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, const int32_t bc[3], const pa_curv_params* P,

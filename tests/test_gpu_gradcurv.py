@@ -126,3 +126,60 @@ def test_per_fab_entry_points(ctx, oracle):
     bad = capi.box_of(lv, 0, grow=2)
     assert ctx.lib.pa_grad_fab(ctx.h, bad, dphi.fab(0), 0, dxinv, dout.fab(0), 0) != 0
     assert b"cover" in ctx.lib.pa_last_error(ctx.h)
+
+
+def _lshape_hierarchy():
+    """level 1 = three 8^3-coarse-cell blocks in an L (concave coarse-fine corner): not fusable"""
+    from peleanalysis_amd.hierarchy import Hierarchy, Level, chop_box
+    l0 = Level(chop_box((0, 0, 0), (31, 31, 31), 16), (0, 0, 0), (31, 31, 31), (1, 0, 1), (0, 0, 0), (1, 1, 1))
+    fine = np.array([[16, 16, 16, 31, 31, 47], [32, 16, 16, 47, 31, 47], [16, 32, 16, 31, 47, 47]], dtype=np.int32)
+    l1 = Level(fine, (0, 0, 0), (63, 63, 63), (1, 0, 1), (0, 0, 0), (1, 1, 1))
+    return Hierarchy([l0, l1], 2)
+
+
+def test_concave_coarse_fine_corner_falls_back_to_passes(ctx, oracle):
+    """general AMR: a level with an L-shaped refined region cannot use the fused sweep (one edge ghost
+    cell would need two boundary values); pa_gradcurv_run must take the pass-by-pass kernels and
+    still match the oracle (one-sided tangential interpolation stencils are exercised here too)"""
+    from util import field_flame
+    H = _lshape_hierarchy()
+    per, sym = (1, 0, 1), (0, 1, 0)
+    states = make_states(H, 1, 2, field_flame, seed=17)
+    bc = capi.bc_from_flags(per, sym)
+    og = [MultiFab(lv, 4, 0) for lv in H.levels]
+    oc = [MultiFab(lv, 5, 0) for lv in H.levels]
+    oracle.grad_pipeline(H.levels, [s.copy() for s in states], 0, bc, og, 0)
+    oracle.curvature_pipeline(H.levels, [s.copy() for s in states], 0, bc, oc, 0, MultiFab, threshold=0.03)
+    dls, dst = _dev(ctx, H, states)
+    work = [capi.DevMF(ctx, dl, 1, 2) for dl in dls]
+    dout = [capi.DevMF(ctx, dl, 8, 0) for dl in dls]
+    capi.gradcurv_run(ctx, dst, 0, bc, capi.curv_params(threshold=0.03, fused=True), work, dout, 0)
+    ctx.sync()
+    assert ctx.bc_errors() == 0
+    for l in range(H.nlev):
+        got = dout[l].download()
+        assert_valid_bits_equal(got, og[l], [(c, c) for c in range(4)], f"L-shape grad level {l}")
+        assert_valid_bits_equal(got, oc[l], [(4, 2), (5, 3), (6, 4), (7, 1)], f"L-shape curv level {l}")
+
+
+@pytest.mark.parametrize("name", ["amr3_wall_z", "amr3_sym_x"])
+def test_curvature_options_match_oracle(ctx, oracle, name):
+    """do_gaussCurv, do_strain (+getStrainTensor), do_velnormal (curvature.cpp:575-789) vs the oracle"""
+    H, per, sym, fn = build_config(name)
+    states = make_states(H, 4, 2, fn, seed=23)  # comp 0 = progress source, 1..3 = velocity
+    bc = capi.bc_from_flags(per, sym)
+    oout = [MultiFab(lv, 17, 0) for lv in H.levels]
+    oracle.curvature_pipeline(H.levels, [s.copy() for s in states], 0, bc, oout, 0, MultiFab, threshold=0.05, do_gauss=True, vel_comp=1,
+                              do_strain=True, do_velnormal=True, strain_tensor=True)
+    dls, dst = _dev(ctx, H, states)
+    dout = [capi.DevMF(ctx, dl, 17, 0) for dl in dls]
+    P = capi.curv_params(threshold=0.05, fused=False, do_gauss=True, do_strain=True, strain_tensor=True, do_velnormal=True, vel_comp=1)
+    capi.curvature_run(ctx, dst, 0, bc, P, dout, 0)
+    ctx.sync()
+    assert ctx.bc_errors() == 0
+    for l in range(H.nlev):
+        assert_valid_bits_equal(dout[l].download(), oout[l], [(c, c) for c in range(17)], f"{name} options level {l}")
+    # too few output components are rejected before any launch
+    small = [capi.DevMF(ctx, dl, 6, 0) for dl in dls]
+    with pytest.raises(capi.PaError):
+        capi.curvature_run(ctx, dst, 0, bc, P, small, 0)

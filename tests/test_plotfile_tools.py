@@ -164,3 +164,30 @@ def test_isosurface_tool_end_to_end(tmp_path, oracle):
     assert len(oelts) > 200
     assert np.array_equal(faces, oelts + 1), "connectivity (1-based) differs"
     assert np.array_equal(nodes.view(np.int64), onodes.view(np.int64)), "node data not bit-identical"
+
+
+@pytest.mark.gpu
+def test_curvature_tool_options(tmp_path, oracle):
+    """do_gaussCurv=1 do_strain=1 getStrainTensor=1 do_velnormal=1: names (curvature.cpp:796-831) and values"""
+    p, H, mfs = _synth(tmp_path, nlev=2, ncomp=4, names=("temp", "x_velocity", "y_velocity", "z_velocity"))
+    _run("curvature3d.ex", ["infile=" + p, "is_per=1 1 0", "do_gaussCurv=1", "do_strain=1", "getStrainTensor=1", "do_velnormal=1"], tmp_path)
+    r = read_plotfile(str(tmp_path / "plt00005_K"))
+    assert r.names[:4] == ["temp", "x_velocity", "y_velocity", "z_velocity"]
+    assert r.names[4:12] == ["Progress", "SmoothedProgress", "MeanCurvature_temp", "FlameNormalX_temp", "FlameNormalY_temp", "FlameNormalZ_temp",
+                             "GaussianCurvature_temp", "StrainRate_temp"]
+    assert r.names[12:21] == ["ROST_dUxdx", "ROST_dUxdy", "ROST_dUxdz", "ROST_dUydx", "ROST_dUydy", "ROST_dUydz", "ROST_dUzdx", "ROST_dUzdy", "ROST_dUzdz"]
+    assert r.names[21] == "VelFlameNormal" and len(r.names) == 22
+    st = [MultiFab(lv, 4, 2) for lv in H.levels]
+    for l, lv in enumerate(H.levels):
+        for b in range(lv.nboxes):
+            st[l].valid(b)[:] = mfs[l].valid(b)
+    oc = [MultiFab(lv, 17, 0) for lv in H.levels]
+    oracle.curvature_pipeline(H.levels, st, 0, oracle.bc_from_flags((1, 1, 0)), oc, 0, MultiFab, do_gauss=True, vel_comp=1, do_strain=True,
+                              do_velnormal=True, strain_tensor=True)
+    same = lambda a, c: np.array_equal(np.ascontiguousarray(a).view(np.int64), np.ascontiguousarray(c).view(np.int64))
+    for l, lv in enumerate(H.levels):
+        for b in range(lv.nboxes):
+            v, w = r.mfs[l].valid(b), oc[l].valid(b)
+            assert same(v[6], w[1]) and same(v[7:10], w[2:5]) and same(v[10], w[5]) and same(v[11], w[6]) and same(v[12:21], w[8:17]) and same(v[21], w[7])
+    bad = subprocess.run([os.path.join(BIN, "curvature3d.ex"), "infile=" + p, "do_smooth=1"], cwd=tmp_path, capture_output=True, text=True)
+    assert bad.returncode != 0 and "do_smooth" in bad.stderr

@@ -1,11 +1,16 @@
-// curvature3d -- drop-in for PeleAnalysis Src/curvature.cpp (core path) on MI355X.
+// curvature3d -- drop-in for PeleAnalysis Src/curvature.cpp on MI355X.
 //   curvature3d.ex infile=<plt> [outfile=<root>_K] [finestLevel=<n>] [progressName=temp] [progMin=..] [progMax=..]
-//       [useFileMinMax=1] [threshold_prog=0] [threshold_value=1e-4] [Aux_Variables="a b"] [sym_dir="0 0 0"]
-//       [is_per="1 1 1"] [verbose=0] [fused=1]
-// Output components (curvature.cpp:165-236, 796-844): [progressName, aux..., Progress, SmoothedProgress,
-// MeanCurvature_<v>, FlameNormalX/Y/Z_<v>, GaussianCurvature_<v>]; SmoothedProgress and
-// GaussianCurvature are written as 0.0 (the reference leaves them uninitialised when the options are
-// off: quirk Q1).  do_gaussCurv / do_strain / do_velnormal / do_smooth are not ported yet.
+//       [useFileMinMax=1] [threshold_prog=0] [threshold_value=1e-4] [do_gaussCurv=0] [do_strain=0]
+//       [getStrainTensor=0] [do_velnormal=0] [Aux_Variables="a b"] [sym_dir="0 0 0"] [is_per="1 1 1"]
+//       [verbose=0] [fused=1]
+// Output components (curvature.cpp:165-236, 796-844): [progressName, (x/y/z_velocity), aux..., Progress,
+// SmoothedProgress, MeanCurvature_<v>, FlameNormalX/Y/Z_<v>, GaussianCurvature_<v>, (StrainRate_<v>),
+// (ROST_dU?d? x9), (VelFlameNormal)].
+// Deviations, all stated: SmoothedProgress / GaussianCurvature are 0.0 when their option is off (the
+// reference leaves them uninitialised: quirk Q1); StrainRate keeps the reference's value = div u
+// (quirk Q3); the velocities are also read when only do_velnormal is set (the reference reads them
+// only under do_strain and then indexes whatever sits at idVst); do_smooth (implicit multigrid
+// smoothing) is not ported and aborts.
 #include "../common/pa_device.h"
 
 int main(int argc, char** argv) {
@@ -15,7 +20,8 @@ int main(int argc, char** argv) {
   }
   pa::ParmParse pp(argc, argv);
   int verbose = 0, finestLevel = 1000;
-  int do_gaussCurv = 0, floorIt = 0, useFileMinMax = 1, do_threshold = 0, do_smooth = 0, do_strain = 0, do_velnormal = 0, fused = 1;
+  int do_gaussCurv = 0, floorIt = 0, useFileMinMax = 1, do_threshold = 0, do_smooth = 0, do_strain = 0, getStrainTensor = 0, do_velnormal = 0,
+      fused = 1;
   std::string progressName = "temp", infile;
   double progMin = 1.0e20, progMax = -1.0e20, threshold = 0.0001;
   pp.query("verbose", verbose);
@@ -33,10 +39,10 @@ int main(int argc, char** argv) {
   pp.query("threshold_value", threshold);
   pp.query("do_smooth", do_smooth);
   pp.query("do_strain", do_strain);
+  if (do_strain) pp.query("getStrainTensor", getStrainTensor);
   pp.query("do_velnormal", do_velnormal);
   pp.query("fused", fused);
-  if (do_gaussCurv || do_strain || do_velnormal || do_smooth)
-    pa::Abort("do_gaussCurv / do_strain / do_velnormal / do_smooth are not available in this build (core mean-curvature path only)");
+  if (do_smooth) pa::Abort("do_smooth (implicit smoothing of the progress variable) is not available in this build");
   const int nAux = pp.countval("Aux_Variables");
   std::cout << "infile = " << infile << "\n" << "reading plt file = " << infile << "\n";
   pa::PlotfileHeader H = pa::read_header(infile);
@@ -46,6 +52,14 @@ int main(int argc, char** argv) {
   if (idC < 0) pa::Abort("Wrong progress variable name: " + progressName);
   std::vector<std::string> inNames{progressName};
   std::vector<int> inComps{idC};
+  const bool need_vel = do_strain || do_velnormal;
+  const int idVst = 1;
+  if (need_vel)
+    for (const char* v : {"x_velocity", "y_velocity", "z_velocity"}) {
+      if (H.comp(v) < 0) pa::Abort(std::string("Unknown velocity variable name: ") + v);
+      inNames.push_back(v);
+      inComps.push_back(H.comp(v));
+    }
   for (int i = 0; i < nAux; ++i) {
     std::string a;
     pp.get("Aux_Variables", a, i);
@@ -54,12 +68,18 @@ int main(int argc, char** argv) {
     inComps.push_back(H.comp(a));
   }
   const int nCompIn = (int)inNames.size();
-  const int idProg = nCompIn, idSmProg = idProg + 1, idKm = idSmProg + 1, idN = idKm + 1, idKg = idN + 3, nCompOut = idKg + 1;
+  const int idProg = nCompIn, idSmProg = idProg + 1, idKm = idSmProg + 1, idN = idKm + 1, idKg = idN + 3;
+  int idSR = -1, idROST = -1, idVelNormal = -1, nCompOut = idKg + 1;
+  if (do_strain) { idSR = idKg + 1; nCompOut = idSR + 1; }
+  if (getStrainTensor) { idROST = nCompOut; nCompOut = idROST + 9; }
+  if (do_velnormal) { idVelNormal = nCompOut; nCompOut += 1; }
   std::vector<int> sym_dir(3, 0), is_per(3, 1);
   pp.queryarr("sym_dir", sym_dir, 0, 3);
   pp.queryarr("is_per", is_per, 0, 3);
   int32_t bc[3];
   pa::bc_from_flags(is_per, sym_dir, bc);
+  const bool options = do_gaussCurv || do_strain || do_velnormal;
+  const int nres = options ? 17 : 8;
 
   pa::Ctx ctx;
   std::vector<std::unique_ptr<pa::DevLevel>> dl;
@@ -73,7 +93,7 @@ int main(int argc, char** argv) {
     dl.emplace_back(new pa::DevLevel(ctx, H.lev[lev].boxes, H.lev[lev].domain, is_per.data(), H.prob_lo, H.prob_hi));
     dst.emplace_back(new pa::DevMF(ctx, *dl.back(), nCompIn, 2));
     dwork.emplace_back(new pa::DevMF(ctx, *dl.back(), 1, 2));
-    dout.emplace_back(new pa::DevMF(ctx, *dl.back(), 8, 0));
+    dout.emplace_back(new pa::DevMF(ctx, *dl.back(), nres, 0));
     ctx.check(pa_mf_upload(ctx.h, dst.back()->h, in[lev].data.data()));
     doms.push_back(H.lev[lev].domain);
   }
@@ -96,25 +116,39 @@ int main(int argc, char** argv) {
   }
   pa_curv_params P;
   P.prog_min = progMin; P.prog_max = progMax; P.do_threshold = do_threshold; P.threshold = threshold; P.fused = fused;
-  ctx.check(pa_gradcurv_run(ctx.h, Nlev, s.data(), 0, bc, &P, w.data(), o.data(), 0));
+  P.do_gauss_curv = do_gaussCurv; P.do_strain = do_strain; P.get_strain_tensor = getStrainTensor; P.do_velnormal = do_velnormal; P.vel_comp = idVst;
+  // result layout: fused sweep -> [gx gy gz |g| Nx Ny Nz K]; pass-by-pass with options -> [Progress K Nx Ny Nz Kg SR Vn ROSTx9]
+  int rK, rN, rKg = -1, rSR = -1, rVn = -1, rROST = -1;
+  if (options) {
+    ctx.check(pa_curvature_run(ctx.h, Nlev, s.data(), 0, bc, &P, o.data(), 0));
+    rK = 1; rN = 2; rKg = 5; rSR = 6; rVn = 7; rROST = 8;
+  } else {
+    ctx.check(pa_gradcurv_run(ctx.h, Nlev, s.data(), 0, bc, &P, w.data(), o.data(), 0));
+    rK = 7; rN = 4;
+  }
   ctx.check(pa_sync(ctx.h));
   if (pa_bc_errors(ctx.h) != 0) pa::Abort("coarse-fine boundary: fine grids are not properly nested in the coarse level");
   const double invdenom = 1.0 / (progMax - progMin);
   for (int lev = 0; lev < Nlev; ++lev) {
-    res[lev].define(H.lev[lev].boxes, 8, 0);
+    res[lev].define(H.lev[lev].boxes, nres, 0);
     ctx.check(pa_mf_download(ctx.h, dout[lev]->h, res[lev].data.data()));
     ostate[lev].define(H.lev[lev].boxes, nCompOut, 0);  // ghost-free output state (curvature.cpp:833-839)
     for (size_t b = 0; b < H.lev[lev].boxes.size(); ++b) {
       const pa::Box3& B = H.lev[lev].boxes[b];
       const size_t nx = (size_t)(B.hi[0] - B.lo[0] + 1);
+      auto cp = [&](int dstc, int srcc, int k, int j) { std::memcpy(ostate[lev].ptr((int)b, dstc, B.lo[0], j, k), res[lev].ptr((int)b, srcc, B.lo[0], j, k), 8 * nx); };
       for (int k = B.lo[2]; k <= B.hi[2]; ++k)
         for (int j = B.lo[1]; j <= B.hi[1]; ++j) {
           for (int c = 0; c < nCompIn; ++c) std::memcpy(ostate[lev].ptr((int)b, c, B.lo[0], j, k), in[lev].ptr((int)b, c, B.lo[0], j, k), 8 * nx);
           const double* sv = in[lev].ptr((int)b, 0, B.lo[0], j, k);
           double* pr = ostate[lev].ptr((int)b, idProg, B.lo[0], j, k);
           for (size_t i = 0; i < nx; ++i) pr[i] = (sv[i] - progMin) * invdenom;  // curvature.cpp:319 (same fp order as the device)
-          std::memcpy(ostate[lev].ptr((int)b, idKm, B.lo[0], j, k), res[lev].ptr((int)b, 7, B.lo[0], j, k), 8 * nx);
-          for (int d = 0; d < 3; ++d) std::memcpy(ostate[lev].ptr((int)b, idN + d, B.lo[0], j, k), res[lev].ptr((int)b, 4 + d, B.lo[0], j, k), 8 * nx);
+          cp(idKm, rK, k, j);
+          for (int d = 0; d < 3; ++d) cp(idN + d, rN + d, k, j);
+          if (do_gaussCurv) cp(idKg, rKg, k, j);
+          if (do_strain) cp(idSR, rSR, k, j);
+          if (getStrainTensor) for (int q = 0; q < 9; ++q) cp(idROST + q, rROST + q, k, j);
+          if (do_velnormal) cp(idVelNormal, rVn, k, j);
         }
     }
     if (verbose) std::cout << "Mean curvature has been computed on level " << lev << "\n";
@@ -128,6 +162,12 @@ int main(int argc, char** argv) {
   nnames[idN + 1] = "FlameNormalY_" + progressName;
   nnames[idN + 2] = "FlameNormalZ_" + progressName;
   nnames[idKg] = "GaussianCurvature_" + progressName;
+  if (do_strain) nnames[idSR] = "StrainRate_" + progressName;
+  if (getStrainTensor) {
+    const std::string dirChar[3] = {"x", "y", "z"};
+    for (int i = 0; i < 9; ++i) nnames[idROST + i] = "ROST_dU" + dirChar[i / 3] + "d" + dirChar[i % 3];  // curvature.cpp:815-823
+  }
+  if (do_velnormal) nnames[idVelNormal] = "VelFlameNormal";
   std::cout << "Writing new data to " << outfile << "\n";
   std::vector<int> isteps(Nlev, 0);
   pa::write_plotfile(outfile, nnames, doms, H.prob_lo, H.prob_hi, ostate, 0.0, isteps);
