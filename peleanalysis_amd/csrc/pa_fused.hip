@@ -145,18 +145,33 @@ static dim3 march_grid(int nx, int ny, int nz, int kseg, int mty, unsigned nboxe
   const unsigned tx = (nx + 63) / 64, ty = (ny + mty - 1) / mty, tz = (nz + kseg - 1) / kseg;
   return dim3(tx * ty * tz, nboxes);
 }
+static int fused_order() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("PA_ORDER");
+    v = e ? atoi(e) : 0;
+  }
+  return v;
+}
 template <typename BP>
-static void march_launch(hipStream_t st, const BP& bp, int nx, int ny, int nz, unsigned nboxes, const MarchArgs& A) {
+static void march_launch(hipStream_t st, const BP& bp, int nx, int ny, int nz, unsigned nboxes, const MarchArgs& A0) {
+  MarchArgs A = A0;
+  A.order = fused_order();
+  A.nboxes = (int)nboxes;
   int sel = fused_mty();
   if (sel < 0) sel = (ny >= 52) ? 131 : (ny >= 16 ? 81 : 41);  // short boxes do not fill a 13-row tile
   switch (sel) {
-#define PA_CASE(M, W)                                                                                                              \
-  case M * 10 + W:                                                                                                                 \
-    hipLaunchKernelGGL((k_gradcurv_march<BP, M, W>), march_grid(nx, ny, nz, A.kseg, M, nboxes), dim3(64 * (M + 3)), 0, st, bp, A); \
-    break;
+#define PA_CASE(M, W)                                                                                                  \
+  case M * 10 + W: {                                                                                                   \
+    dim3 g = march_grid(nx, ny, nz, A.kseg, M, nboxes);                                                                \
+    A.txy_max = ((nx + 63) / 64) * ((ny + M - 1) / M);                                                                 \
+    if (A.order) g = dim3(g.x * g.y, 1);                                                                               \
+    hipLaunchKernelGGL((k_gradcurv_march<BP, M, W>), g, dim3(64 * (M + 3)), 0, st, bp, A);                             \
+  } break;
     PA_CASE(4, 1) PA_CASE(5, 1) PA_CASE(5, 4) PA_CASE(8, 1) PA_CASE(8, 6) PA_CASE(12, 1) PA_CASE(13, 1)
 #undef PA_CASE
     default:
+      A.order = 0;
       hipLaunchKernelGGL((k_gradcurv_march<BP, 8, 1>), march_grid(nx, ny, nz, A.kseg, 8, nboxes), dim3(64 * 11), 0, st, bp, A);
   }
 }
@@ -169,7 +184,7 @@ extern "C" int pa_gradcurv_level(pa_ctx* ctx, const pa_mf* phi, int pcomp, doubl
   if (!(pmax > pmin)) return pa_fail(ctx, "pa_gradcurv_level: progress variable has no range");
   const pa_level* L = phi->lev;
   LevelBP2 bp{L->view, phi->view, out->view};
-  MarchArgs A{pcomp, ocomp, fused_kseg(), pmin, 1.0 / (pmax - pmin), thr};
+  MarchArgs A{pcomp, ocomp, fused_kseg(), pmin, 1.0 / (pmax - pmin), thr, 0, 1, 1};
   ProfScope prof(ctx, PA_TAG_GRADCURV);
   march_launch(ctx->stream, bp, L->maxn[0], L->maxn[1], L->maxn[2], (unsigned)L->boxes.size(), A);
   PA_HIP(hipGetLastError());
@@ -208,7 +223,7 @@ extern "C" int pa_gradcurv_fab(pa_ctx* ctx, pa_box valid, const pa_fab* phi, int
   if (!fab_covers(*phi, valid, 2, pcomp, 1, why) || !fab_covers(*out, valid, 0, ocomp, 8, why)) return pa_fail(ctx, "pa_gradcurv_fab: " + why);
   if (!(pmax > pmin)) return pa_fail(ctx, "pa_gradcurv_fab: progress variable has no range");
   FabBP2 bp{fab_view(*phi), fab_view(*out), to_dbox(valid), {dxinv[0], dxinv[1], dxinv[2]}};
-  MarchArgs A{pcomp, ocomp, fused_kseg(), pmin, 1.0 / (pmax - pmin), thr};
+  MarchArgs A{pcomp, ocomp, fused_kseg(), pmin, 1.0 / (pmax - pmin), thr, 0, 1, 1};
   march_launch(ctx->stream, bp, valid.hi[0] - valid.lo[0] + 1, valid.hi[1] - valid.lo[1] + 1, valid.hi[2] - valid.lo[2] + 1, 1, A);
   PA_HIP(hipGetLastError());
   return 0;

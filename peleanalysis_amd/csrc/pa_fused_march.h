@@ -53,6 +53,9 @@ struct MarchLds {
 struct MarchArgs {
   int pcomp, ocomp, kseg;
   double pmin, invdenom, thr;
+  // order = 1: 1-D grid, z-segment slowest across ALL boxes (the chip works on the same few planes of
+  // every box at a time); order = 0: grid.y = box, all tiles of a box are consecutive
+  int order, nboxes, txy_max;
 };
 
 template <typename BP, int PA_MTY, int MINW>
@@ -61,12 +64,18 @@ __global__ __launch_bounds__(64 * (PA_MTY + 3), MINW) void k_gradcurv_march(BP b
   DBox V;
   double dxinv[3];
   constexpr int PA_MROWS = PA_MTY + 2;
-  if (!bp.get(blockIdx.y, P, O, V, dxinv)) return;
+  const int box = A.order ? (int)((blockIdx.x / (unsigned)A.txy_max) % (unsigned)A.nboxes) : (int)blockIdx.y;
+  if (!bp.get(box, P, O, V, dxinv)) return;
   const int pcomp = A.pcomp, kseg = A.kseg;
   const double pmin = A.pmin, invd = A.invdenom, thr = A.thr;
   const int nx = V.hi[0] - V.lo[0] + 1, ny = V.hi[1] - V.lo[1] + 1, nz = V.hi[2] - V.lo[2] + 1;
   const int tx = (nx + 63) / 64, ty = (ny + PA_MTY - 1) / PA_MTY, tz = (nz + kseg - 1) / kseg;
-  const unsigned bid = blockIdx.x;
+  unsigned bid = blockIdx.x;
+  if (A.order) {
+    const unsigned t = bid % (unsigned)A.txy_max, z = bid / ((unsigned)A.txy_max * (unsigned)A.nboxes);
+    if (t >= (unsigned)tx * ty || z >= (unsigned)tz) return;
+    bid = z * (unsigned)(tx * ty) + t;
+  }
   if (bid >= (unsigned)tx * ty * tz) return;  // uniform for the whole workgroup
   const int bx = bid % tx, by = (bid / tx) % ty, bz = bid / (tx * ty);
   const int i0 = V.lo[0] + bx * 64, j0 = V.lo[1] + by * PA_MTY;
