@@ -130,8 +130,10 @@ int pa_normal_level(pa_ctx*, const pa_mf* c, int comp, pa_mf* G, int gcomp, pa_m
  * resolved face ghosts), + threshold clip :549-567 if thr >= 0 (c needed) */
 int pa_div_level(pa_ctx*, pa_mf* n, int ncomp0, double scale, const pa_mf* c, int ccomp, double thr,
                  pa_mf* K, int kcomp);
-/* same, only on the cells (of the box grown by ng) within `depth` cells of a box face: the
- * shell in which the fused path needs a stored progress variable */
+/* same, only where the fused path reads a stored progress variable: for every box face that has
+ * a ghost cell which is not a valid cell of the level (coarse-fine or wall), the `depth` valid
+ * layers + ng ghost layers behind/beyond that face over the grown tangential extent.  Other cells
+ * of c are left untouched. */
 int pa_progress_shell_level(pa_ctx*, const pa_mf* s, int comp, double pmin, double pmax, pa_mf* c, int ccomp, int ng,
                             int depth);
 /* fused grad->curvature (headline kernel; grad.cpp:211-236 + curvature.cpp:316-320,451-567 in

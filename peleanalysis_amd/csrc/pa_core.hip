@@ -100,6 +100,15 @@ static int host_classify(const pa_level* L, int i, int j, int k) {
   return (o >= 0 || o == -2) ? 0 : 1;  // -2: valid cell of a box owned by another rank
 }
 
+// cf_masks of every ghost cell of every special face (once per level; ratio 2)
+__global__ __launch_bounds__(256) void k_build_sfcode(DLevelView L, unsigned short* code) {
+  int b, dir, side, layer, q[3];
+  DBox B;
+  const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (!sface_decode(L, blockIdx.y, t, 1, b, B, dir, side, q, layer)) return;
+  code[L.sfoff[blockIdx.y] + t] = (unsigned short)cf_masks(L, q, dir, 2);
+}
+
 static pa_level* level_create_impl(pa_ctx* ctx, int nboxes, const int32_t* b6, int nremote, const int32_t* r6, const int32_t domlo[3],
                                    const int32_t domhi[3], const int32_t is_per[3], const double prob_lo[3], const double prob_hi[3]);
 
@@ -228,17 +237,66 @@ static pa_level* level_create_impl(pa_ctx* ctx, int nboxes, const int32_t* b6, i
             }
       }
   }
+  // Special faces: box faces with at least one adjacent ghost cell that is not a valid cell of the
+  // level (coarse-fine or wall).  The class of a ghost cell is constant over a g-block of the owner
+  // map in the tangential directions, so one probe per block is enough.
+  for (int b = 0; b < nboxes; ++b) {
+    const DBox& B = L->boxes[b];
+    for (int d = 0; d < 3; ++d) {
+      const int t0 = (d == 0) ? 1 : 0, t1 = (d == 2) ? 1 : 2;
+      for (int side = 0; side < 2; ++side) {
+        bool special = false;
+        int q[3];
+        q[d] = side ? B.hi[d] + 1 : B.lo[d] - 1;
+        for (int v = B.lo[t1]; v <= B.hi[t1] && !special; v += g)
+          for (int u = B.lo[t0]; u <= B.hi[t0]; u += g) {
+            q[t0] = u; q[t1] = v;
+            if (host_classify(L, q[0], q[1], q[2]) != 0) { special = true; break; }
+          }
+        if (special) L->sfaces.push_back(b * 6 + d * 2 + side);
+      }
+    }
+  }
+  const size_t nsf_alloc = std::max<size_t>(L->sfaces.size(), 1);
+  std::vector<int> sfindex((size_t)nboxes * 6, -1);
+  std::vector<long long> sfoff(nsf_alloc, 0);
+  long long ncode = 0;
+  for (size_t e = 0; e < L->sfaces.size(); ++e) {
+    const int f = L->sfaces[e];
+    const DBox& B = L->boxes[f / 6];
+    const int d = (f % 6) >> 1, t0 = (d == 0) ? 1 : 0, t1 = (d == 2) ? 1 : 2;
+    sfindex[f] = (int)e;
+    sfoff[e] = ncode;
+    ncode += (long long)(B.hi[t0] - B.lo[t0] + 1) * (B.hi[t1] - B.lo[t1] + 1);
+  }
   if (hipMalloc(&L->d_boxes, sizeof(DBox) * nboxes) != hipSuccess ||
+      hipMalloc(&L->d_sfaces, sizeof(int) * nsf_alloc) != hipSuccess ||
+      (!L->sfaces.empty() && hipMemcpy(L->d_sfaces, L->sfaces.data(), sizeof(int) * L->sfaces.size(), hipMemcpyHostToDevice) != hipSuccess) ||
+      hipMalloc(&L->d_sfindex, sizeof(int) * sfindex.size()) != hipSuccess ||
+      hipMemcpy(L->d_sfindex, sfindex.data(), sizeof(int) * sfindex.size(), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMalloc(&L->d_sfoff, sizeof(long long) * nsf_alloc) != hipSuccess ||
+      hipMemcpy(L->d_sfoff, sfoff.data(), sizeof(long long) * nsf_alloc, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMalloc(&L->d_sfcode, sizeof(unsigned short) * std::max<long long>(ncode, 1)) != hipSuccess ||
       hipMalloc(&L->d_owner, sizeof(int) * msz) != hipSuccess ||
       hipMemcpy(L->d_boxes, L->boxes.data(), sizeof(DBox) * nboxes, hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(L->d_owner, L->owner.data(), sizeof(int) * msz, hipMemcpyHostToDevice) != hipSuccess) {
     pa_fail(ctx, "pa_level_create: device allocation failed");
     if (L->d_boxes) (void)hipFree(L->d_boxes);
     if (L->d_owner) (void)hipFree(L->d_owner);
+    if (L->d_sfaces) (void)hipFree(L->d_sfaces);
+    if (L->d_sfindex) (void)hipFree(L->d_sfindex);
+    if (L->d_sfoff) (void)hipFree(L->d_sfoff);
+    if (L->d_sfcode) (void)hipFree(L->d_sfcode);
     delete L;
     return nullptr;
   }
   DLevelView& V = L->view;
+  V.sfindex = L->d_sfindex;
+  V.sfoff = L->d_sfoff;
+  V.sfcode = L->d_sfcode;
+  V.gshift = (g & (g - 1)) == 0 ? __builtin_ctz((unsigned)g) : -1;
+  V.nsf = (int)L->sfaces.size();
+  V.sfaces = L->d_sfaces;
   V.nboxes = nboxes;
   V.boxes = L->d_boxes;
   V.owner = L->d_owner;
@@ -247,11 +305,25 @@ static pa_level* level_create_impl(pa_ctx* ctx, int nboxes, const int32_t* b6, i
     V.domlo[d] = L->domlo[d]; V.domhi[d] = L->domhi[d]; V.is_per[d] = L->is_per[d];
     V.mlo[d] = L->mlo[d]; V.mn[d] = L->mn[d]; V.dxinv[d] = L->dxinv[d];
   }
+  if (!L->sfaces.empty()) {
+    const long long n0 = L->maxn[0], n1 = L->maxn[1], n2 = L->maxn[2];
+    const long long nt = std::max(n1 * n2, std::max(n0 * n2, n0 * n1));
+    hipLaunchKernelGGL(k_build_sfcode, dim3((unsigned)((nt + 255) / 256), (unsigned)L->sfaces.size()), dim3(256), 0, ctx->stream, V, L->d_sfcode);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
+      pa_fail(ctx, "pa_level_create: building the boundary masks failed");
+      pa_level_destroy(L);
+      return nullptr;
+    }
+  }
   return L;
 }
 
 extern "C" void pa_level_destroy(pa_level* L) {
   if (!L) return;
+  if (L->d_sfaces) (void)hipFree(L->d_sfaces);
+  if (L->d_sfindex) (void)hipFree(L->d_sfindex);
+  if (L->d_sfoff) (void)hipFree(L->d_sfoff);
+  if (L->d_sfcode) (void)hipFree(L->d_sfcode);
   if (L->d_boxes) (void)hipFree(L->d_boxes);
   if (L->d_owner) (void)hipFree(L->d_owner);
   delete L;
@@ -381,42 +453,50 @@ extern "C" int pa_mf_copy(pa_ctx* ctx, const pa_mf* S, int scomp, pa_mf* D, int 
 // ----------------------------------------------------------------- FillBoundary
 // Thread per ghost-shell cell.  The shell of depth ng is enumerated as 2 z-slabs (full grown
 // xy extent), 2 y-slabs (valid z, full grown x) and 2 x-slabs (valid y,z): x-contiguous runs.
-__device__ __forceinline__ bool shell_cell(const DBox& B, int ng, long long t, int& i, int& j, int& k) {
-  const int nx = B.hi[0] - B.lo[0] + 1, ny = B.hi[1] - B.lo[1] + 1, nz = B.hi[2] - B.lo[2] + 1;
-  const int gx = nx + 2 * ng, gy = ny + 2 * ng;
-  const long long nzs = (long long)ng * gy * gx;  // one z slab
-  const long long nys = (long long)nz * ng * gx;  // one y slab
-  const long long nxs = (long long)nz * ny * ng;  // one x slab
+// (32-bit unsigned index arithmetic: a 64-bit division costs hundreds of instructions on the GPU;
+// the shell of one box is far below 2^32 cells)
+__device__ __forceinline__ bool shell_cell(const DBox& B, int ng, long long tt, int& i, int& j, int& k) {
+  const unsigned nx = B.hi[0] - B.lo[0] + 1, ny = B.hi[1] - B.lo[1] + 1, nz = B.hi[2] - B.lo[2] + 1;
+  const unsigned g = (unsigned)ng, gx = nx + 2 * g, gy = ny + 2 * g;
+  const unsigned nzs = g * gy * gx;  // one z slab
+  const unsigned nys = nz * g * gx;  // one y slab
+  const unsigned nxs = nz * ny * g;  // one x slab
+  if (tt >= 2LL * nzs + 2LL * nys + 2LL * nxs) return false;
+  unsigned t = (unsigned)tt;
   if (t < 2 * nzs) {
     const int s = t >= nzs;
     if (s) t -= nzs;
-    i = B.lo[0] - ng + (int)(t % gx);
-    j = B.lo[1] - ng + (int)((t / gx) % gy);
-    k = (int)(t / ((long long)gx * gy));
-    k = s ? B.hi[2] + 1 + k : B.lo[2] - ng + k;
+    const unsigned r = t / gx;
+    i = B.lo[0] - ng + (int)(t - r * gx);
+    const unsigned kk = r / gy;
+    j = B.lo[1] - ng + (int)(r - kk * gy);
+    k = s ? B.hi[2] + 1 + (int)kk : B.lo[2] - ng + (int)kk;
     return true;
   }
   t -= 2 * nzs;
   if (t < 2 * nys) {
     const int s = t >= nys;
     if (s) t -= nys;
-    i = B.lo[0] - ng + (int)(t % gx);
-    j = (int)((t / gx) % ng);
-    k = B.lo[2] + (int)(t / ((long long)gx * ng));
-    j = s ? B.hi[1] + 1 + j : B.lo[1] - ng + j;
+    const unsigned r = t / gx;
+    i = B.lo[0] - ng + (int)(t - r * gx);
+    const unsigned kk = r / g;
+    const int jj = (int)(r - kk * g);
+    k = B.lo[2] + (int)kk;
+    j = s ? B.hi[1] + 1 + jj : B.lo[1] - ng + jj;
     return true;
   }
   t -= 2 * nys;
-  if (t < 2 * nxs) {
+  {
     const int s = t >= nxs;
     if (s) t -= nxs;
-    i = (int)(t % ng);
-    j = B.lo[1] + (int)((t / ng) % ny);
-    k = B.lo[2] + (int)(t / ((long long)ng * ny));
-    i = s ? B.hi[0] + 1 + i : B.lo[0] - ng + i;
+    const unsigned r = t / g;
+    const int ii = (int)(t - r * g);
+    const unsigned kk = r / ny;
+    j = B.lo[1] + (int)(r - kk * ny);
+    k = B.lo[2] + (int)kk;
+    i = s ? B.hi[0] + 1 + ii : B.lo[0] - ng + ii;
     return true;
   }
-  return false;
 }
 
 __global__ void k_fill_boundary(DLevelView L, DMFView M, int comp, int ncomp, int ngf) {
@@ -491,40 +571,56 @@ __device__ __forceinline__ double bc_ghost_value(const DLevelView& L, const DMFV
   return g;
 }
 
-__global__ void k_apply_bc_faces(DLevelView L, DMFView M, int comp, DLevelView LC, DMFView MC, int ccomp, BCArgs A,
-                                 int* nbad) {
-  const int b = blockIdx.y;
-  const DBox B = L.boxes[b];
-  const int n[3] = {B.hi[0] - B.lo[0] + 1, B.hi[1] - B.lo[1] + 1, B.hi[2] - B.lo[2] + 1};
-  long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  int dir = -1, side = 0, a0 = 0, b1 = 0;
-  for (int d = 0; d < 3; ++d) {
-    const int t0 = (d == 0) ? 1 : 0, t1 = (d == 2) ? 1 : 2;
-    const long long fs = (long long)n[t0] * n[t1];
-    if (t < 2 * fs) {
-      dir = d;
-      side = t >= fs;
-      if (side) t -= fs;
-      a0 = (int)(t % n[t0]);
-      b1 = (int)(t / n[t0]);
-      break;
-    }
-    t -= 2 * fs;
-  }
-  if (dir < 0) return;
+// MLMG applyBC on the face ghost cells of NF fields of one level at once (same ghost cells, same
+// masks and weights; the coarse-fine boundary values of all fields come from ONE coarse component,
+// see cf_bndry_values).  Thread per ghost cell of a special face.
+template <int NF>
+struct BCFields {
+  DMFView M[NF];
+  int comp[NF];
+  int xf[NF];
+};
+template <int NF>
+__global__ __launch_bounds__(256) void k_apply_bc_sfaces(DLevelView L, BCFields<NF> F, DLevelView LC, DMFView MC, int ccomp, BCArgs A, int* nbad) {
+  int b, dir, side, layer, q[3];
+  DBox B;
+  const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (!sface_decode(L, blockIdx.y, t, 1, b, B, dir, side, q, layer)) return;
   if (A.only_dir >= 0 && dir != A.only_dir) return;
-  const int t0 = (dir == 0) ? 1 : 0, t1 = (dir == 2) ? 1 : 2;
-  int q[3];
-  q[dir] = side ? B.hi[dir] + 1 : B.lo[dir] - 1;
-  q[t0] = B.lo[t0] + a0;
-  q[t1] = B.lo[t1] + b1;
-  const int cls = classify(L, q[0], q[1], q[2]);
+  const unsigned code = L.sfcode[L.sfoff[blockIdx.y] + t];
+  const int cls = (int)(code & 3u);
   if (cls == 0) return;
   if (cls == 1 && !A.has_crse) { atomicAdd(nbad, 1); return; }
+  const int s = side ? -1 : 1;
+  if (cls == 2) {
+    int in[3] = {q[0], q[1], q[2]};
+    in[dir] += s;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      double* p = F.M[f].data + F.M[f].off[b];
+      const double v = p[fab_index(B, F.M[f].ng, F.M[f].ncomp, F.comp[f], in[0], in[1], in[2])];
+      p[fab_index(B, F.M[f].ng, F.M[f].ncomp, F.comp[f], q[0], q[1], q[2])] = (A.bc[dir] == PA_BC_REFLECT_ODD) ? -v : v;
+    }
+    return;
+  }
   bool ok = true;
-  const double v = bc_ghost_value(L, M, B, b, comp, LC, MC, ccomp, A, q, dir, side ? -1 : 1, cls, ok);
+  double coef[4], bv[NF];
+  const int NX = cf_normal_coef(B.hi[dir] - B.lo[dir] + 1, A.ratio, coef);
+  cf_interp<NF>(code, LC, MC, ccomp, q, dir, A.ratio, F.xf, ok, bv);
   if (!ok) atomicAdd(nbad, 1);
-  M.data[M.off[b] + fab_index(B, M.ng, M.ncomp, comp, q[0], q[1], q[2])] = v;
+#pragma unroll
+  for (int f = 0; f < NF; ++f) {
+    double* p = F.M[f].data + F.M[f].off[b];
+    double tmp = 0.0;
+    for (int m = 1; m < NX; ++m) {
+      int pc[3] = {q[0], q[1], q[2]};
+      pc[dir] += s * m;
+      tmp += p[fab_index(B, F.M[f].ng, F.M[f].ncomp, F.comp[f], pc[0], pc[1], pc[2])] * coef[m];
+    }
+    double g = tmp;
+    g += bv[f] * coef[0];
+    p[fab_index(B, F.M[f].ng, F.M[f].ncomp, F.comp[f], q[0], q[1], q[2])] = g;
+  }
 }
 
 // Fused-path extension: edge ghost cells (outside the box in two directions a<c).  Such a cell
@@ -539,7 +635,7 @@ __global__ void k_apply_bc_edges(DLevelView L, DMFView M, int comp, DLevelView L
   // 3 edge orientations e (the free direction), 4 edges each
   int e = -1, which = 0, pos = 0;
   for (int d = 0; d < 3; ++d) {
-    if (t < 4LL * n[d]) { e = d; which = (int)(t / n[d]); pos = (int)(t % n[d]); break; }
+    if (t < 4LL * n[d]) { e = d; which = (int)((unsigned)t / (unsigned)n[d]); pos = (int)((unsigned)t % (unsigned)n[d]); break; }
     t -= 4LL * n[d];
   }
   if (e < 0) return;
@@ -611,14 +707,47 @@ int pa_apply_bc_impl(pa_ctx* ctx, pa_mf* F, int comp, const pa_mf* C, int ccomp,
   const long long n0 = L->maxn[0], n1 = L->maxn[1], n2 = L->maxn[2];
   ProfScope prof(ctx, PA_TAG_BC);
   if (!edges) {
-    const long long nt = 2 * (n1 * n2 + n0 * n2 + n0 * n1);
-    dim3 grid((unsigned)((nt + 255) / 256), (unsigned)L->boxes.size());
-    hipLaunchKernelGGL(k_apply_bc_faces, grid, dim3(256), 0, ctx->stream, L->view, F->view, comp, LC, MC, ccomp, A, nbad);
+    if (L->sfaces.empty()) return 0;  // every ghost cell is a valid cell of the level
+    const long long nt = std::max(n1 * n2, std::max(n0 * n2, n0 * n1));
+    dim3 grid((unsigned)((nt + 255) / 256), (unsigned)L->sfaces.size());
+    BCFields<1> Fs;
+    Fs.M[0] = F->view; Fs.comp[0] = comp; Fs.xf[0] = MC.xform;
+    hipLaunchKernelGGL(k_apply_bc_sfaces<1>, grid, dim3(256), 0, ctx->stream, L->view, Fs, LC, MC, ccomp, A, nbad);
   } else {
     const long long nt = 4 * (n0 + n1 + n2);
     dim3 grid((unsigned)((nt + 255) / 256), (unsigned)L->boxes.size());
     hipLaunchKernelGGL(k_apply_bc_edges, grid, dim3(256), 0, ctx->stream, L->view, F->view, comp, LC, MC, ccomp, A, nbad);
   }
+  PA_HIP(hipGetLastError());
+  return 0;
+}
+
+// applyBC on the face ghosts of two fields of one level in one launch: F0/comp0 takes the coarse
+// component as it is, F1/comp1 sees it through the affine view (v - xform[0]) * xform[1].
+int pa_apply_bc_dual(pa_ctx* ctx, pa_mf* F0, int comp0, pa_mf* F1, int comp1, const pa_mf* C, int ccomp, const int32_t bc[3], int ratio,
+                     const double* xform) {
+  if (!ctx || !F0 || !F1 || !xform) return pa_fail(ctx, "pa_apply_bc_dual: null argument");
+  if (F0->lev != F1->lev) return pa_fail(ctx, "pa_apply_bc_dual: different levels");
+  if (F0->ng < 1 || F1->ng < 1) return pa_fail(ctx, "pa_apply_bc: multifab has no ghost cells");
+  if (comp0 < 0 || comp0 >= F0->ncomp || comp1 < 0 || comp1 >= F1->ncomp || (C && (ccomp < 0 || ccomp >= C->ncomp)))
+    return pa_fail(ctx, "pa_apply_bc: component range");
+  if (ratio != 2 && C) return pa_fail(ctx, "pa_apply_bc: only refinement ratio 2 is supported (quirk Q11)");
+  const pa_level* L = F0->lev;
+  if (L->sfaces.empty()) return 0;
+  BCArgs A;
+  for (int d = 0; d < 3; ++d) A.bc[d] = bc[d];
+  A.ratio = ratio; A.only_dir = -1; A.has_crse = C ? 1 : 0; A.edges = 0;
+  DLevelView LC = C ? C->lev->view : L->view;
+  DMFView MC = C ? C->view : F0->view;
+  MC.xform = 1; MC.xa = xform[0]; MC.xb = xform[1];
+  BCFields<2> Fs;
+  Fs.M[0] = F0->view; Fs.comp[0] = comp0; Fs.xf[0] = 0;
+  Fs.M[1] = F1->view; Fs.comp[1] = comp1; Fs.xf[1] = 1;
+  const long long n0 = L->maxn[0], n1 = L->maxn[1], n2 = L->maxn[2];
+  const long long nt = std::max(n1 * n2, std::max(n0 * n2, n0 * n1));
+  dim3 grid((unsigned)((nt + 255) / 256), (unsigned)L->sfaces.size());
+  ProfScope prof(ctx, PA_TAG_BC);
+  hipLaunchKernelGGL(k_apply_bc_sfaces<2>, grid, dim3(256), 0, ctx->stream, L->view, Fs, LC, MC, ccomp, A, ctx->d_flags);
   PA_HIP(hipGetLastError());
   return 0;
 }
@@ -629,16 +758,21 @@ extern "C" int pa_apply_bc(pa_ctx* ctx, pa_mf* F, int comp, const pa_mf* C, int 
 }
 
 // ------------------------------------------------------------ progress variable, shell only
-// c = (s - pmin) * invdenom (curvature.cpp:316-320) on the cells of the box grown by ng that lie
-// within `depth` cells of a box face (the only place the fused path needs a stored c).
-__global__ void k_progress_shell(DLevelView L, DMFView S, int comp, DMFView Cm, int ccomp, int ng, int depth, double pmin, double invdenom) {
-  const int b = blockIdx.y;
-  DBox B = L.boxes[b];
-  DBox core = B;
-  for (int d = 0; d < 3; ++d) { core.lo[d] += depth; core.hi[d] -= depth; }
-  const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  int i, j, k;
-  if (!shell_cell(core, depth + ng, t, i, j, k)) return;
+// c = (s - pmin) * invdenom (curvature.cpp:316-320) stored only where the fused path reads it: for
+// every special face of a box, the slab of `depth` valid layers + ng ghost layers along the face
+// normal, over the full grown tangential extent.  Slabs of one box overlap at its edges (same value).
+__global__ __launch_bounds__(256) void k_progress_shell(DLevelView L, DMFView S, int comp, DMFView Cm, int ccomp, int ng, int depth, double pmin, double invdenom) {
+  const int e = L.sfaces[blockIdx.y];
+  const int b = e / 6, dir = (e % 6) >> 1, side = e & 1;
+  const DBox B = L.boxes[b];
+  int o[3], n[3];
+  for (int d = 0; d < 3; ++d) { o[d] = B.lo[d] - ng; n[d] = B.hi[d] - B.lo[d] + 1 + 2 * ng; }
+  n[dir] = ng + depth;
+  if (side) o[dir] = B.hi[dir] - depth + 1;
+  const long long tt = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (tt >= (long long)n[0] * n[1] * n[2]) return;
+  const unsigned t = (unsigned)tt, r = t / (unsigned)n[0], kk = r / (unsigned)n[1];  // 32-bit: see shell_cell
+  const int i = o[0] + (int)(t - r * (unsigned)n[0]), j = o[1] + (int)(r - kk * (unsigned)n[1]), k = o[2] + (int)kk;
   Cm.data[Cm.off[b] + fab_index(B, Cm.ng, Cm.ncomp, ccomp, i, j, k)] = (S.data[S.off[b] + fab_index(B, S.ng, S.ncomp, comp, i, j, k)] - pmin) * invdenom;
 }
 
@@ -651,19 +785,16 @@ extern "C" int pa_progress_shell_level(pa_ctx* ctx, const pa_mf* s, int comp, do
     for (int d = 0; d < 3; ++d)
       if (B.hi[d] - B.lo[d] + 1 <= 2 * depth)  // no interior core left: the shell is the whole box
         return pa_progress_level(ctx, s, comp, pmin, pmax, c, ccomp, ng);
-  long long ms = 0;
-  for (const DBox& B : L->boxes) {
-    const long long nx = B.hi[0] - B.lo[0] + 1, ny = B.hi[1] - B.lo[1] + 1, nz = B.hi[2] - B.lo[2] + 1;
-    ms = std::max(ms, (nx + 2 * ng) * (ny + 2 * ng) * (nz + 2 * ng) - (nx - 2 * depth) * (ny - 2 * depth) * (nz - 2 * depth));
-  }
-  dim3 grid((unsigned)((ms + 255) / 256), (unsigned)L->boxes.size());
+  if (L->sfaces.empty()) return 0;
+  const long long g0 = L->maxn[0] + 2 * ng, g1 = L->maxn[1] + 2 * ng, g2 = L->maxn[2] + 2 * ng;
+  const long long ms = (long long)(ng + depth) * std::max(g1 * g2, std::max(g0 * g2, g0 * g1));
+  dim3 grid((unsigned)((ms + 255) / 256), (unsigned)L->sfaces.size());
   ProfScope prof(ctx, PA_TAG_PROGRESS);
   hipLaunchKernelGGL(k_progress_shell, grid, dim3(256), 0, ctx->stream, L->view, s->view, comp, c->view, ccomp, ng, depth, pmin, 1.0 / (pmax - pmin));
   PA_HIP(hipGetLastError());
   return 0;
 }
 
-// ------------------------------------------------------------------ raw device buffers
 extern "C" void* pa_device_malloc(pa_ctx* ctx, int64_t bytes) {
   if (!ctx || bytes < 0) return nullptr;
   void* p = nullptr;

@@ -37,69 +37,97 @@ struct FaceArgs {
 
 __device__ __forceinline__ double comp_of(const Vec3& v, int d) { return d == 0 ? v.x : (d == 1 ? v.y : v.z); }
 
-// Thread per (box face cell, layer).  Skips faces whose ghost cell is a valid cell of the level.
-__global__ __launch_bounds__(256) void k_gradcurv_faces(DLevelView L, DMFView MC_, int ccomp, DLevelView LCr, DMFView MN, int cncomp0,
-                                                        DMFView MO, int ncomp0, int kcomp, FaceArgs A, int* nbad) {
-  const int b = blockIdx.y;
-  if (b >= L.nboxes) return;
-  const DBox B = L.boxes[b];
-  const int n[3] = {B.hi[0] - B.lo[0] + 1, B.hi[1] - B.lo[1] + 1, B.hi[2] - B.lo[2] + 1};
-  long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  const int layer = (int)(t % A.layers);
-  t /= A.layers;
-  int fdir = -1, side = 0, a0 = 0, b1 = 0;
-  for (int d = 0; d < 3; ++d) {
-    const int t0 = (d == 0) ? 1 : 0, t1 = (d == 2) ? 1 : 2;
-    const long long fs = (long long)n[t0] * n[t1];
-    if (t < 2 * fs) {
-      fdir = d;
-      side = t >= fs;
-      if (side) t -= fs;
-      a0 = (int)(t % n[t0]);
-      b1 = (int)(t / n[t0]);
-      break;
-    }
-    t -= 2 * fs;
-  }
-  if (fdir < 0 || layer >= n[fdir]) return;
-  int X[3];
-  {
-    const int t0 = (fdir == 0) ? 1 : 0, t1 = (fdir == 2) ? 1 : 2;
-    int q[3];
-    q[fdir] = side ? B.hi[fdir] + 1 : B.lo[fdir] - 1;
-    q[t0] = B.lo[t0] + a0;
-    q[t1] = B.lo[t1] + b1;
-    if (classify(L, q[0], q[1], q[2]) == 0) return;  // ordinary same-level face: the sweep was exact
-    X[0] = q[0]; X[1] = q[1]; X[2] = q[2];
-    X[fdir] += side ? -(1 + layer) : (1 + layer);
-  }
+__device__ __forceinline__ bool in_box(const DBox& B, const int q[3]) {
+  return q[0] >= B.lo[0] && q[0] <= B.hi[0] && q[1] >= B.lo[1] && q[1] <= B.hi[1] && q[2] >= B.lo[2] && q[2] <= B.hi[2];
+}
+
+// Phase A: thread per layer-1 cell of a special face whose ghost cell is not a valid cell.  Its
+// normal depends on the resolved ghost c (applyBC on c), which the sweep did not have: recompute.
+__global__ __launch_bounds__(256) void k_faces_normal(DLevelView L, DMFView MC_, int ccomp, DMFView MO, int ncomp0, FaceArgs A) {
+  int b, dir, side, layer, q[3];
+  DBox B;
+  const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (!sface_decode(L, blockIdx.y, t, 1, b, B, dir, side, q, layer)) return;
+  if ((L.sfcode[L.sfoff[blockIdx.y] + t] & 3u) == 0) return;  // ordinary same-level ghost: the sweep was exact
+  int X[3] = {q[0], q[1], q[2]};
+  X[dir] += side ? -1 : 1;
   const FabView C = mf_view(MC_, B, b);
   const double dxinv[3] = {L.dxinv[0], L.dxinv[1], L.dxinv[2]};
-  const Vec3 n0 = normal_at(C, ccomp, X[0], X[1], X[2], dxinv);
+  Vec3 no = normal_at(C, ccomp, X[0], X[1], X[2], dxinv);
+  if (A.thr >= 0.0) {
+    const double c0 = C(X[0], X[1], X[2], ccomp);
+    if (c0 < A.thr || c0 > 1.0 - A.thr) { no.x = 0.0; no.y = 0.0; no.z = 0.0; }
+  }
+  double* o = MO.data + MO.off[b];
+  o[fab_index(B, MO.ng, MO.ncomp, ncomp0, X[0], X[1], X[2])] = no.x;
+  o[fab_index(B, MO.ng, MO.ncomp, ncomp0 + 1, X[0], X[1], X[2])] = no.y;
+  o[fab_index(B, MO.ng, MO.ncomp, ncomp0 + 2, X[0], X[1], X[2])] = no.z;
+}
+
+// Phase B: thread per (cell, layer 1..2) behind such a ghost cell: K = 0.5 * div n with the ghost
+// normals of MLMG applyBC on n_d (curvature.cpp:510-546).  Normals of cells of this box are read
+// back from the output (exact after phase A) unless the threshold clip zeroed them there; normals
+// of valid cells of neighbouring boxes are recomputed from the local ghost c.
+__global__ __launch_bounds__(256) void k_faces_curv(DLevelView L, DMFView MC_, int ccomp, DLevelView LCr, DMFView MN, int cncomp0, DMFView MO,
+                                                    int ncomp0, int kcomp, FaceArgs A, int* nbad) {
+  int b, fdir, side, layer, q0[3];
+  DBox B;
+  const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (!sface_decode(L, blockIdx.y, t, A.layers, b, B, fdir, side, q0, layer)) return;
+  const int n[3] = {B.hi[0] - B.lo[0] + 1, B.hi[1] - B.lo[1] + 1, B.hi[2] - B.lo[2] + 1};
+  if (layer >= n[fdir]) return;
+  {
+    const int t0 = (fdir == 0) ? 1 : 0, t1 = (fdir == 2) ? 1 : 2;
+    if ((L.sfcode[L.sfoff[blockIdx.y] + (t - (long long)layer * n[t0] * n[t1])] & 3u) == 0) return;
+  }
+  int X[3] = {q0[0], q0[1], q0[2]};
+  X[fdir] += side ? -(1 + layer) : (1 + layer);
+  const FabView C = mf_view(MC_, B, b);
+  const double dxinv[3] = {L.dxinv[0], L.dxinv[1], L.dxinv[2]};
+  const double* o = MO.data + MO.off[b];
+  // component d of the (unclipped) normal at a valid cell p of this box
+  auto nrm = [&](const int p[3], int d) -> double {
+    if (A.thr >= 0.0) {
+      const double cp = C(p[0], p[1], p[2], ccomp);
+      if (cp < A.thr || cp > 1.0 - A.thr) return comp_of(normal_at(C, ccomp, p[0], p[1], p[2], dxinv), d);
+    }
+    return o[fab_index(B, MO.ng, MO.ncomp, ncomp0 + d, p[0], p[1], p[2])];
+  };
   double curv = 0.0;
   bool ok = true;
   for (int d = 0; d < 3; ++d) {
+    const double n0d = nrm(X, d);
     double nb[2];
     for (int s2 = 0; s2 < 2; ++s2) {
       const int sg = s2 ? 1 : -1;
       int q[3] = {X[0], X[1], X[2]};
       q[d] += sg;
-      const int cls = classify(L, q[0], q[1], q[2]);
+      if (in_box(B, q)) { nb[s2] = nrm(q, d); continue; }
+      // q is a ghost cell of face (d, s2) of this box: its masks are stored unless the face is ordinary
+      unsigned code = 0;
+      {
+        const int e2 = L.sfindex[b * 6 + d * 2 + s2];
+        const int u0 = (d == 0) ? 1 : 0, u1 = (d == 2) ? 1 : 2;
+        if (e2 >= 0) code = L.sfcode[L.sfoff[e2] + (q[u0] - B.lo[u0]) + (long long)n[u0] * (q[u1] - B.lo[u1])];
+      }
+      const int cls = (int)(code & 3u);
       if (cls == 0) {
         nb[s2] = comp_of(normal_at(C, ccomp, q[0], q[1], q[2], dxinv), d);
       } else if (cls == 2) {
-        const double v = comp_of(n0, d);
-        nb[s2] = (A.bc[d] == PA_BC_REFLECT_ODD) ? -v : v;
+        nb[s2] = (A.bc[d] == PA_BC_REFLECT_ODD) ? -n0d : n0d;
       } else {
         if (!A.has_crse) { ok = false; nb[s2] = 0.0; continue; }
         double coef[4];
         const int NX = cf_normal_coef(n[d], A.ratio, coef);
-        const double bv = cf_bndry_value(L, LCr, MN, cncomp0 + d, q, d, A.ratio, ok);
+        const int xf[1] = {0};
+        double bv1[1];
+        cf_interp<1>(code, LCr, MN, cncomp0 + d, q, d, A.ratio, xf, ok, bv1);
+        const double bv = bv1[0];
         double tmp = 0.0;
         for (int m = 1; m < NX; ++m) {
           int pc[3] = {q[0], q[1], q[2]};
           pc[d] -= sg * m;  // into the box
-          const double v = (m == 1) ? comp_of(n0, d) : comp_of(normal_at(C, ccomp, pc[0], pc[1], pc[2], dxinv), d);
+          const double v = (m == 1) ? n0d : nrm(pc, d);
           tmp += v * coef[m];
         }
         double g = tmp;
@@ -107,20 +135,15 @@ __global__ __launch_bounds__(256) void k_gradcurv_faces(DLevelView L, DMFView MC
         nb[s2] = g;
       }
     }
-    curv += cdiff(dxinv[d], nb[0], comp_of(n0, d), nb[1]);
+    curv += cdiff(dxinv[d], nb[0], n0d, nb[1]);
   }
   curv = curv * 0.5;
-  Vec3 no = n0;
   if (A.thr >= 0.0) {
     const double c0 = C(X[0], X[1], X[2], ccomp);
-    if (c0 < A.thr || c0 > 1.0 - A.thr) { curv = 0.0; no.x = 0.0; no.y = 0.0; no.z = 0.0; }
+    if (c0 < A.thr || c0 > 1.0 - A.thr) curv = 0.0;
   }
   if (!ok) atomicAdd(nbad, 1);
-  double* o = MO.data + MO.off[b];
-  o[fab_index(B, MO.ng, MO.ncomp, kcomp, X[0], X[1], X[2])] = curv;
-  o[fab_index(B, MO.ng, MO.ncomp, ncomp0, X[0], X[1], X[2])] = no.x;
-  o[fab_index(B, MO.ng, MO.ncomp, ncomp0 + 1, X[0], X[1], X[2])] = no.y;
-  o[fab_index(B, MO.ng, MO.ncomp, ncomp0 + 2, X[0], X[1], X[2])] = no.z;
+  MO.data[MO.off[b] + fab_index(B, MO.ng, MO.ncomp, kcomp, X[0], X[1], X[2])] = curv;
 }
 
 // tuning knobs (environment, read once): PA_KSEG=<planes per workgroup>, PA_MTY=<rows*10 + min waves/SIMD>
@@ -206,12 +229,14 @@ extern "C" int pa_gradcurv_faces_level(pa_ctx* ctx, const pa_mf* c, int ccomp, c
   FaceArgs A;
   for (int d = 0; d < 3; ++d) A.bc[d] = bc[d];
   A.ratio = ratio; A.has_crse = crse_n ? 1 : 0; A.thr = thr; A.layers = 2;
+  if (L->sfaces.empty()) return 0;
   const long long n0 = L->maxn[0], n1 = L->maxn[1], n2 = L->maxn[2];
-  const long long nt = 2 * (n1 * n2 + n0 * n2 + n0 * n1) * A.layers;
-  dim3 grid((unsigned)((nt + 255) / 256), (unsigned)L->boxes.size());
+  const long long nf = std::max(n1 * n2, std::max(n0 * n2, n0 * n1));
+  const unsigned nsf = (unsigned)L->sfaces.size();
   ProfScope prof(ctx, PA_TAG_GRADCURV_FACES);
-  hipLaunchKernelGGL(k_gradcurv_faces, grid, dim3(256), 0, ctx->stream, L->view, c->view, ccomp, crse_n ? crse_n->lev->view : L->view,
-                     crse_n ? crse_n->view : c->view, cncomp0, out->view, ncomp0, kcomp, A, ctx->d_flags);
+  hipLaunchKernelGGL(k_faces_normal, dim3((unsigned)((nf + 255) / 256), nsf), dim3(256), 0, ctx->stream, L->view, c->view, ccomp, out->view, ncomp0, A);
+  hipLaunchKernelGGL(k_faces_curv, dim3((unsigned)((nf * A.layers + 255) / 256), nsf), dim3(256), 0, ctx->stream, L->view, c->view, ccomp,
+                     crse_n ? crse_n->lev->view : L->view, crse_n ? crse_n->view : c->view, cncomp0, out->view, ncomp0, kcomp, A, ctx->d_flags);
   PA_HIP(hipGetLastError());
   return 0;
 }

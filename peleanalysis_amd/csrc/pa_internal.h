@@ -18,6 +18,12 @@ struct DLevelView {
   int g, mlo[3], mn[3];
   const int* owner;
   double dxinv[3];
+  int gshift;        // log2(g) when g is a power of two (owner_of shifts instead of dividing), else -1
+  int nsf;           // number of "special" box faces: faces with at least one ghost cell that is not a valid cell
+  const int* sfaces; // nsf entries box*6 + dir*2 + side; the boundary kernels launch over these only
+  const int* sfindex;           // [nboxes*6] entry of a box face in sfaces, or -1 (ordinary face: every ghost cell is a valid cell)
+  const long long* sfoff;       // [nsf] start of the face's ghost-cell codes in sfcode
+  const unsigned short* sfcode; // cf_masks of every ghost cell of every special face, (t0 fastest, t1) per face
 };
 
 struct DMFView {
@@ -75,6 +81,11 @@ struct pa_level {
   std::vector<int> owner;  // host copy
   DBox* d_boxes = nullptr;
   int* d_owner = nullptr;
+  std::vector<int> sfaces;  // special faces (see DLevelView)
+  int* d_sfaces = nullptr;
+  int* d_sfindex = nullptr;
+  long long* d_sfoff = nullptr;
+  unsigned short* d_sfcode = nullptr;
   int maxn[3] = {0, 0, 0};  // max box extent per dim
   long long ncells = 0;
   bool fusable = true;      // no concave coarse-fine corner (see pa_level_create)
@@ -141,7 +152,7 @@ __device__ __forceinline__ int owner_of(const DLevelView& L, const int p[3]) {
   for (int d = 0; d < 3; ++d) {
     const int r = p[d] - L.mlo[d];
     if (r < 0) return -1;
-    m[d] = r / L.g;
+    m[d] = L.gshift >= 0 ? (r >> L.gshift) : (r / L.g);
     if (m[d] >= L.mn[d]) return -1;
   }
   return L.owner[((long long)m[2] * L.mn[1] + m[1]) * L.mn[0] + m[0]];
@@ -160,7 +171,7 @@ __device__ __forceinline__ int classify(const DLevelView& L, int i, int j, int k
   return classify(L, i, j, k, b, p);
 }
 
-__device__ __forceinline__ int coarsen_idx(int i, int r) { return (i < 0) ? -((-i + r - 1) / r) : i / r; }
+__device__ __forceinline__ int coarsen_idx(int i, int r) { return r == 2 ? (i >> 1) : ((i < 0) ? -((-i + r - 1) / r) : i / r); }  // floor
 
 // amrex::poly_interp_coeff restated (Lagrange weights evaluated in fp64)
 __device__ __forceinline__ void poly_interp_coeff(double xInt, const double* x, int N, double* c) {
@@ -184,24 +195,75 @@ __device__ __forceinline__ double cdiff(double dxinv, double m, double c, double
   return -(0.5 * (fl + fh));
 }
 
-// coarse value with periodic wrap; ok cleared if the cell has no owner
-__device__ __forceinline__ double crse_val(const DLevelView& LC, const DMFView& MC, int comp, int ic, int jc,
-                                           int kc, bool& ok) {
+// raw coarse value with periodic wrap; ok cleared if the cell has no owner
+__device__ __forceinline__ double crse_raw(const DLevelView& LC, const DMFView& MC, int comp, int ic, int jc, int kc, bool& ok) {
   int p[3] = {ic, jc, kc};
   if (!wrap_cell(LC, p)) { ok = false; return 0.0; }
   const int b = owner_of(LC, p);
   if (b < 0) { ok = false; return 0.0; }
-  const double v = MC.data[MC.off[b] + fab_index(LC.boxes[b], MC.ng, MC.ncomp, comp, p[0], p[1], p[2])];
+  return MC.data[MC.off[b] + fab_index(LC.boxes[b], MC.ng, MC.ncomp, comp, p[0], p[1], p[2])];
+}
+__device__ __forceinline__ double crse_val(const DLevelView& LC, const DMFView& MC, int comp, int ic, int jc,
+                                           int kc, bool& ok) {
+  const double v = crse_raw(LC, MC, comp, ic, jc, kc, ok);
   return MC.xform ? (v - MC.xa) * MC.xb : v;
 }
 
-// InterpBndryData (order 3) restated -- see oracle/pa_oracle.c cf_bndry_value
-__device__ inline double cf_bndry_value(const DLevelView& LF, const DLevelView& LC, const DMFView& MC, int ccomp,
-                                        const int q[3], int dir, int r, bool& ok) {
-  const int qc[3] = {coarsen_idx(q[0], r), coarsen_idx(q[1], r), coarsen_idx(q[2], r)};
-  const int tdir[2] = {dir == 0 ? 1 : 0, dir == 2 ? 1 : 2};
-  double b = 0.0;
-  double xi[2];
+// amrex::poly_interp_coeff at compile time (same IEEE operations, correctly rounded) for the
+// stencils of refinement ratio 2: tangential points lo..hi (lo in {-2,-1,0}, hi in {0,1,2}) seen
+// from xInt = -0.25 (even fine cell) or +0.25 (odd), and the normal-direction points
+// {-1, 0.5, 1.5, 2.5} seen from -0.5.
+struct CfCoefTab {
+  double tan[2][3][3][3];  // [odd][lo+2][hi][m]
+  double nrm[5][4];        // [NX][m]
+};
+constexpr CfCoefTab make_cf_coef_tab() {
+  CfCoefTab T{};
+  for (int odd = 0; odd < 2; ++odd)
+    for (int lo = -2; lo <= 0; ++lo)
+      for (int hi = 0; hi <= 2; ++hi) {
+        const int N = hi - lo + 1;
+        if (N > 3) continue;
+        const double xInt = -0.5 + ((double)odd + 0.5) / 2.0;
+        double x[3] = {0.0, 0.0, 0.0};
+        for (int m = 0; m < N; ++m) x[m] = (double)(lo + m);
+        for (int jj = 0; jj < N; ++jj) {
+          double num = 1.0, den = 1.0;
+          for (int ii = 0; ii < N; ++ii) {
+            if (ii == jj) continue;
+            num *= xInt - x[ii];
+            den *= x[jj] - x[ii];
+          }
+          T.tan[odd][lo + 2][hi][jj] = num / den;
+        }
+      }
+  for (int NX = 1; NX <= 4; ++NX) {
+    const double x[4] = {-1.0, 0.5, 1.5, 2.5};
+    for (int jj = 0; jj < NX; ++jj) {
+      double num = 1.0, den = 1.0;
+      for (int ii = 0; ii < NX; ++ii) {
+        if (ii == jj) continue;
+        num *= -0.5 - x[ii];
+        den *= x[jj] - x[ii];
+      }
+      T.nrm[NX][jj] = num / den;
+    }
+  }
+  return T;
+}
+static __device__ __constant__ const CfCoefTab g_cf_coef = make_cf_coef_tab();
+
+// Masks of InterpBndryData for ghost cell q of a face normal to `dir` (ratio r), packed:
+//   bits 0-1 class of q (0 valid cell, 1 coarse-fine, 2 outside a wall); for class 1 also
+//   bits 2-3 lo0+2, 4-5 hi0, 6-7 lo1+2, 8-9 hi1 (tangential stencil extents in coarse cells),
+//   bit 10: all four diagonal neighbours are coarse-fine cells too (cross term on).
+// Depends on the fine level only; stored per special-face ghost cell at level creation (sfcode).
+__device__ inline unsigned cf_masks(const DLevelView& LF, const int q[3], int dir, int r) {
+  const unsigned cls = (unsigned)classify(LF, q[0], q[1], q[2]);
+  if (cls != 1u) return cls;
+  const int t0 = dir == 0 ? 1 : 0, t1 = dir == 2 ? 1 : 2;
+  const int tdir[2] = {t0, t1};
+  unsigned code = cls;
   for (int t = 0; t < 2; ++t) {
     const int td = tdir[t];
     int m1[3] = {q[0], q[1], q[2]}, p1[3] = {q[0], q[1], q[2]}, m2[3] = {q[0], q[1], q[2]}, p2[3] = {q[0], q[1], q[2]};
@@ -211,50 +273,137 @@ __device__ inline double cf_bndry_value(const DLevelView& LF, const DLevelView& 
     int lo = okm1 ? -1 : 0, hi = okp1 ? 1 : 0;
     if (lo == -1 && hi == 0 && classify(LF, m2[0], m2[1], m2[2]) == 1) lo = -2;
     else if (hi == 1 && lo == 0 && classify(LF, p2[0], p2[1], p2[2]) == 1) hi = 2;
+    code |= (unsigned)(lo + 2) << (2 + 4 * t);
+    code |= (unsigned)hi << (4 + 4 * t);
+  }
+  bool all = true;
+  for (int s1 = -1; s1 <= 1 && all; s1 += 2)
+    for (int s0 = -1; s0 <= 1; s0 += 2) {
+      int p[3] = {q[0], q[1], q[2]};
+      p[t0] += s0 * r; p[t1] += s1 * r;
+      if (classify(LF, p[0], p[1], p[2]) != 1) { all = false; break; }
+    }
+  if (all) code |= 1u << 10;
+  return code;
+}
+
+// InterpBndryData (order 3) restated -- see oracle/pa_oracle.c cf_bndry_value -- for a ghost cell
+// whose masks are `code` (cf_masks).  NF fields are interpolated from the SAME coarse component with
+// shared weights and loads: field f sees the coarse value v when xf[f] == 0 and
+// (v - MC.xa) * MC.xb when xf[f] != 0 (the progress variable as an affine view of the coarse phi).
+// Per field the operation order is the reference's.  Coarse neighbours inside the FAB that holds
+// the coarse cell of q are addressed relative to it (one owner-map lookup instead of eleven).
+template <int NF>
+__device__ inline void cf_interp(unsigned code, const DLevelView& LC, const DMFView& MC, int ccomp, const int q[3], int dir, int r,
+                                 const int xf[NF], bool& ok, double b[NF]) {
+  const int qc[3] = {coarsen_idx(q[0], r), coarsen_idx(q[1], r), coarsen_idx(q[2], r)};
+  const int t0 = dir == 0 ? 1 : 0, t1 = dir == 2 ? 1 : 2;
+  int pq[3] = {qc[0], qc[1], qc[2]};
+  const int cb = wrap_cell(LC, pq) ? owner_of(LC, pq) : -1;
+  DBox Bc = {{0, 0, 0}, {-1, -1, -1}};
+  const double* base = MC.data;
+  long long st0 = 0, st1 = 0;
+  if (cb >= 0) {
+    Bc = LC.boxes[cb];
+    const long long nxg = Bc.hi[0] - Bc.lo[0] + 1 + 2 * MC.ng, nyg = Bc.hi[1] - Bc.lo[1] + 1 + 2 * MC.ng;
+    base = MC.data + MC.off[cb] + fab_index(Bc, MC.ng, MC.ncomp, ccomp, pq[0], pq[1], pq[2]);
+    st0 = t0 == 0 ? 1 : nxg;          // t0 is x or y
+    st1 = t1 == 1 ? nxg : nxg * nyg;  // t1 is y or z
+  }
+  // raw coarse value at qc + a0 e_t0 + a1 e_t1
+  auto craw = [&](int a0, int a1) -> double {
+    const int u = pq[t0] + a0, v = pq[t1] + a1;
+    if (u >= Bc.lo[t0] && u <= Bc.hi[t0] && v >= Bc.lo[t1] && v <= Bc.hi[t1]) return base[a0 * st0 + a1 * st1];
+    int cc[3] = {qc[0], qc[1], qc[2]};
+    cc[t0] += a0; cc[t1] += a1;
+    return crse_raw(LC, MC, ccomp, cc[0], cc[1], cc[2], ok);
+  };
+#pragma unroll
+  for (int f = 0; f < NF; ++f) b[f] = 0.0;
+  double xi[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int td = t == 0 ? t0 : t1;
+    const int lo = (int)((code >> (2 + 4 * t)) & 3u) - 2, hi = (int)((code >> (4 + 4 * t)) & 3u);
     const int N = hi - lo + 1;
-    double x[3], c[3];
-    for (int m = 0; m < N; ++m) x[m] = (double)(lo + m);
-    const double xInt = -0.5 + ((double)(q[td] - qc[td] * r) + 0.5) / (double)r;
-    xi[t] = xInt;
-    poly_interp_coeff(xInt, x, N, c);
+    const int rem = q[td] - qc[td] * r;
+    double c[3];
+    if (r == 2) {
+      xi[t] = rem ? 0.25 : -0.25;
+      for (int m = 0; m < N; ++m) c[m] = g_cf_coef.tan[rem][lo + 2][hi][m];
+    } else {
+      double x[3];
+      for (int m = 0; m < N; ++m) x[m] = (double)(lo + m);
+      const double xInt = -0.5 + ((double)rem + 0.5) / (double)r;
+      xi[t] = xInt;
+      poly_interp_coeff(xInt, x, N, c);
+    }
     for (int m = 0; m < N; ++m) {
-      int cc[3] = {qc[0], qc[1], qc[2]};
-      cc[td] += lo + m;
-      b += c[m] * crse_val(LC, MC, ccomp, cc[0], cc[1], cc[2], ok);
+      const double v = t == 0 ? craw(lo + m, 0) : craw(0, lo + m);
+#pragma unroll
+      for (int f = 0; f < NF; ++f) b[f] += c[m] * (xf[f] ? (v - MC.xa) * MC.xb : v);
     }
   }
-  b -= crse_val(LC, MC, ccomp, qc[0], qc[1], qc[2], ok);
   {
-    const int t0 = tdir[0], t1 = tdir[1];
-    bool all = true;
-    for (int s1 = -1; s1 <= 1 && all; s1 += 2)
-      for (int s0 = -1; s0 <= 1; s0 += 2) {
-        int p[3] = {q[0], q[1], q[2]};
-        p[t0] += s0 * r; p[t1] += s1 * r;
-        if (classify(LF, p[0], p[1], p[2]) != 1) { all = false; break; }
-      }
-    if (all) {
-      int cpp[3] = {qc[0], qc[1], qc[2]}, cmp[3] = {qc[0], qc[1], qc[2]}, cmm[3] = {qc[0], qc[1], qc[2]},
-          cpm[3] = {qc[0], qc[1], qc[2]};
-      cpp[t0] += 1; cpp[t1] += 1;
-      cmp[t0] -= 1; cmp[t1] += 1;
-      cmm[t0] -= 1; cmm[t1] -= 1;
-      cpm[t0] += 1; cpm[t1] -= 1;
-      const double vpp = crse_val(LC, MC, ccomp, cpp[0], cpp[1], cpp[2], ok);
-      const double vmp = crse_val(LC, MC, ccomp, cmp[0], cmp[1], cmp[2], ok);
-      const double vmm = crse_val(LC, MC, ccomp, cmm[0], cmm[1], cmm[2], ok);
-      const double vpm = crse_val(LC, MC, ccomp, cpm[0], cpm[1], cpm[2], ok);
-      b += ((xi[0] * xi[1]) * 0.25) * (((vpp - vmp) + vmm) - vpm);
+    const double v = craw(0, 0);
+#pragma unroll
+    for (int f = 0; f < NF; ++f) b[f] -= xf[f] ? (v - MC.xa) * MC.xb : v;
+  }
+  if (code & (1u << 10)) {
+    const double rpp = craw(1, 1), rmp = craw(-1, 1), rmm = craw(-1, -1), rpm = craw(1, -1);
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      const double vpp = xf[f] ? (rpp - MC.xa) * MC.xb : rpp, vmp = xf[f] ? (rmp - MC.xa) * MC.xb : rmp;
+      const double vmm = xf[f] ? (rmm - MC.xa) * MC.xb : rmm, vpm = xf[f] ? (rpm - MC.xa) * MC.xb : rpm;
+      b[f] += ((xi[0] * xi[1]) * 0.25) * (((vpp - vmp) + vmm) - vpm);
     }
   }
-  return b;
+}
+template <int NF>
+__device__ inline void cf_bndry_values(const DLevelView& LF, const DLevelView& LC, const DMFView& MC, int ccomp,
+                                       const int q[3], int dir, int r, const int xf[NF], bool& ok, double b[NF]) {
+  cf_interp<NF>(cf_masks(LF, q, dir, r) | 1u, LC, MC, ccomp, q, dir, r, xf, ok, b);
+}
+__device__ inline double cf_bndry_value(const DLevelView& LF, const DLevelView& LC, const DMFView& MC, int ccomp,
+                                        const int q[3], int dir, int r, bool& ok) {
+  const int xf[1] = {MC.xform};
+  double b[1];
+  cf_bndry_values<1>(LF, LC, MC, ccomp, q, dir, r, xf, ok, b);
+  return b[0];
 }
 
 // normal-direction Lagrange weights of MLMG applyBC at a coarse-fine face:
 // points {-ratio/2 (bc), 0.5, 1.5, 2.5}, evaluated at -0.5, NX = min(len+1, 4)
 __device__ __forceinline__ int cf_normal_coef(int blen, int ratio, double coef[4]) {
   const int NX = (blen + 1 < 4) ? blen + 1 : 4;
+  if (ratio == 2) {
+    for (int m = 0; m < NX; ++m) coef[m] = g_cf_coef.nrm[NX][m];
+    return NX;
+  }
   const double x[4] = {-0.5 * (double)ratio, 0.5, 1.5, 2.5};
   poly_interp_coeff(-0.5, x, NX, coef);
   return NX;
+}
+
+// Decode thread t of special face `entry` (DLevelView::sfaces): box, direction, side and the ghost
+// cell q adjacent to the face; nlayer > 1 enumerates layers slowest (waves do not mix layers).
+__device__ __forceinline__ bool sface_decode(const DLevelView& L, int entry, long long tt, int nlayer, int& b, DBox& B, int& dir, int& side,
+                                             int q[3], int& layer) {
+  const int e = L.sfaces[entry];
+  b = e / 6;
+  dir = (e % 6) >> 1;
+  side = e & 1;
+  B = L.boxes[b];
+  const int t0 = (dir == 0) ? 1 : 0, t1 = (dir == 2) ? 1 : 2;
+  const unsigned n0 = B.hi[t0] - B.lo[t0] + 1, n1 = B.hi[t1] - B.lo[t1] + 1;
+  const unsigned fs = n0 * n1;
+  if (tt >= (long long)fs * nlayer) return false;
+  unsigned t = (unsigned)tt;  // 32-bit index arithmetic (a 64-bit division costs hundreds of instructions)
+  layer = 0;
+  while (t >= fs) { t -= fs; ++layer; }
+  const unsigned r = t / n0;
+  q[dir] = side ? B.hi[dir] + 1 : B.lo[dir] - 1;
+  q[t0] = B.lo[t0] + (int)(t - r * n0);
+  q[t1] = B.lo[t1] + (int)r;
+  return true;
 }

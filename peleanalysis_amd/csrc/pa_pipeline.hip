@@ -6,6 +6,8 @@
 
 int pa_apply_bc_impl(pa_ctx* ctx, pa_mf* F, int comp, const pa_mf* C, int ccomp, const int32_t bc[3], int ratio, int only_dir,
                      int edges, const double* crse_xform);
+int pa_apply_bc_dual(pa_ctx* ctx, pa_mf* F0, int comp0, pa_mf* F1, int comp1, const pa_mf* C, int ccomp, const int32_t bc[3], int ratio,
+                     const double* xform);
 int pa_gauss_curv_level(pa_ctx* ctx, const pa_mf* G, int gcomp, const pa_mf* normgrad, int ngcomp, const pa_mf* c, int ccomp, double thr, pa_mf* out,
                         int kcomp);
 int pa_strain_level(pa_ctx* ctx, const pa_mf* u, int ucomp, pa_mf* out, int srcomp, int rostcomp);
@@ -123,9 +125,8 @@ static int fused_passes(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, co
     const pa_mf* cs = l > 0 ? state[l - 1] : nullptr;
     // order matters: c's coarse-fine values read the coarse phi's VALID cells only, so they may be
     // taken before or after applyBC on the coarse phi; the fine phi ghosts are written here
-    PA_TRY(pa_apply_bc_impl(ctx, work[l], 0, cs, comp, bc, 2, -1, 0, xf));
-    PA_TRY(pa_apply_bc_impl(ctx, work[l], 0, cs, comp, bc, 2, -1, 1, xf));
-    PA_TRY(pa_apply_bc(ctx, state[l], comp, cs, comp, bc, 2, -1));
+    PA_TRY(pa_apply_bc_dual(ctx, state[l], comp, work[l], 0, cs, comp, bc, 2, xf));  // face ghosts of phi and of c, one launch
+    PA_TRY(pa_apply_bc_impl(ctx, work[l], 0, cs, comp, bc, 2, -1, 1, xf));           // edge ghosts of c
     PA_TRY(pa_gradcurv_level(ctx, state[l], comp, pmin, pmax, thr, out[l], ocomp));
     PA_TRY(pa_gradcurv_faces_level(ctx, work[l], 0, l > 0 ? out[l - 1] : nullptr, ocomp + 4, bc, 2, thr, out[l], ocomp + 4, ocomp + 7));
   }
