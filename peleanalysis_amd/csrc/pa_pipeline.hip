@@ -2,6 +2,7 @@
 // curvature.cpp:283-326 + 408-570) on device-resident MultiFabs.  Host orchestration only;
 // every numeric step is a kernel launch through the level-batched entry points.
 #include "pa_internal.h"
+#include <cstdlib>
 #include <memory>
 
 int pa_apply_bc_impl(pa_ctx* ctx, pa_mf* F, int comp, const pa_mf* C, int ccomp, const int32_t bc[3], int ratio, int only_dir,
@@ -110,23 +111,28 @@ static int curvature_passes(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp
   return 0;
 }
 
+static int fused_pre(pa_ctx* ctx, int l, pa_mf* const* state, int comp, const int32_t bc[3], double pmin, double pmax, pa_mf* const* work) {
+  // The stored progress variable (work) is only needed near the special faces (face fix-up).  The
+  // coarse-fine boundary values of c are interpolated from the coarse PHI through the affine view
+  // (v - pmin) * invdenom, which is bit-identical to a stored coarse c; they read the coarse phi's
+  // VALID cells only, so the order relative to applyBC on the coarse phi does not matter.
+  const double xf[2] = {pmin, 1.0 / (pmax - pmin)};
+  const pa_mf* cs = l > 0 ? state[l - 1] : nullptr;
+  PA_TRY(pa_fill_boundary(ctx, state[l], comp, 1, 2));
+  PA_TRY(pa_progress_shell_level(ctx, state[l], comp, pmin, pmax, work[l], 0, 2, 4));
+  PA_TRY(pa_apply_bc_dual(ctx, state[l], comp, work[l], 0, cs, comp, bc, 2, xf));  // face ghosts of phi and of c, one launch
+  PA_TRY(pa_apply_bc_impl(ctx, work[l], 0, cs, comp, bc, 2, -1, 1, xf));           // edge ghosts of c
+  return 0;
+}
+
 static int fused_passes(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, const int32_t bc[3], double pmin, double pmax, double thr,
                         pa_mf* const* work, pa_mf* const* out, int ocomp) {
-  // The stored progress variable (work) is only needed within 4 cells of the box faces (face
-  // fix-up).  The coarse-fine boundary values of c are interpolated from the coarse PHI through the
-  // affine view (v - pmin) * invdenom, which is bit-identical to a stored coarse c.
-  const double xf[2] = {pmin, 1.0 / (pmax - pmin)};
-  for (int l = 0; l < nlev; ++l) {
+  for (int l = 0; l < nlev; ++l)
     if (state[l]->ng < 2 || work[l]->ng < 2) return pa_fail(ctx, "fused grad->curvature needs 2 ghost layers on state and work");
-    PA_TRY(pa_fill_boundary(ctx, state[l], comp, 1, 2));
-    PA_TRY(pa_progress_shell_level(ctx, state[l], comp, pmin, pmax, work[l], 0, 2, 4));
-  }
+  // One stream: running the boundary kernels of one level on a second stream next to the sweep of
+  // another was measured (MI355X, headline workload) to give no gain -- both compete for HBM.
+  for (int l = 0; l < nlev; ++l) PA_TRY(fused_pre(ctx, l, state, comp, bc, pmin, pmax, work));
   for (int l = 0; l < nlev; ++l) {
-    const pa_mf* cs = l > 0 ? state[l - 1] : nullptr;
-    // order matters: c's coarse-fine values read the coarse phi's VALID cells only, so they may be
-    // taken before or after applyBC on the coarse phi; the fine phi ghosts are written here
-    PA_TRY(pa_apply_bc_dual(ctx, state[l], comp, work[l], 0, cs, comp, bc, 2, xf));  // face ghosts of phi and of c, one launch
-    PA_TRY(pa_apply_bc_impl(ctx, work[l], 0, cs, comp, bc, 2, -1, 1, xf));           // edge ghosts of c
     PA_TRY(pa_gradcurv_level(ctx, state[l], comp, pmin, pmax, thr, out[l], ocomp));
     PA_TRY(pa_gradcurv_faces_level(ctx, work[l], 0, l > 0 ? out[l - 1] : nullptr, ocomp + 4, bc, 2, thr, out[l], ocomp + 4, ocomp + 7));
   }
