@@ -265,6 +265,52 @@ def mc_fab(state, mask, slo, shi, isocomp, isoval, llo, lhi):
     return verts[:nv.value], vkeys[:nv.value], tris[:nt.value]
 
 
+# ---------------------------------------------------------------- distance function (SDFGen)
+def _sdf_args(tris, verts, origin, dx, n):
+    tris = np.ascontiguousarray(tris, dtype=np.uint32).reshape(-1, 3)
+    verts = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 3)
+    org = (C.c_float * 3)(*[float(np.float32(v)) for v in origin])
+    ni, nj, nk = (int(v) for v in n)
+    phi = np.empty((nk, nj, ni), dtype=np.float32)
+    return tris, verts, org, C.c_float(float(np.float32(dx))), ni, nj, nk, phi
+
+
+def sdf_level_set(tris, verts, origin, dx, n, exact_band=1, want_closest=False):
+    """orc_make_level_set3 (restatement of Tools/SDFGen/makelevelset3.cpp:118-185).  tris (nt,3) uint32,
+    verts (nv,3) float32, origin 3 floats, dx float, n = (ni,nj,nk) -> phi[nk][nj][ni] float32."""
+    L = lib()
+    tris, verts, org, fdx, ni, nj, nk, phi = _sdf_args(tris, verts, origin, dx, n)
+    ct = np.empty((nk, nj, ni), dtype=np.int32) if want_closest else None
+    rc = L.orc_make_level_set3(C.c_int64(len(tris)), tris.ctypes.data_as(C.c_void_p), C.c_int64(len(verts)), verts.ctypes.data_as(C.c_void_p), org,
+                               fdx, ni, nj, nk, phi.ctypes.data_as(C.c_void_p), int(exact_band), ct.ctypes.data_as(C.c_void_p) if want_closest else None)
+    assert rc == 0
+    return (phi, ct) if want_closest else phi
+
+
+_REF = {}
+
+
+def sdf_ref_lib():
+    """The reference's own make_level_set3 compiled from /root/reference (oracle/_ref), or None."""
+    if "sdf" not in _REF:
+        path = os.path.join(_HERE, "_ref", "libsdfgen_ref.so")
+        if not os.path.exists(path) and os.path.isdir("/root/reference/Tools/SDFGen"):
+            subprocess.call(["make", "-C", _HERE, "-s", "ref"])
+        _REF["sdf"] = C.CDLL(path) if os.path.exists(path) else None
+    return _REF["sdf"]
+
+
+def sdf_level_set_ref(tris, verts, origin, dx, n, exact_band=1):
+    R = sdf_ref_lib()
+    if R is None:
+        return None
+    tris, verts, org, fdx, ni, nj, nk, phi = _sdf_args(tris, verts, origin, dx, n)
+    rc = R.ref_make_level_set3(C.c_int64(len(tris)), tris.ctypes.data_as(C.c_void_p), C.c_int64(len(verts)), verts.ctypes.data_as(C.c_void_p), org,
+                               fdx, ni, nj, nk, phi.ctypes.data_as(C.c_void_p), int(exact_band))
+    assert rc == 0
+    return phi
+
+
 # ---------------------------------------------------------------- isosurface pipeline
 def iso_merge(fragments, ncomp):
     """isosurface.cpp:1687-1726 + 1751-1812 restated: merge per-FAB (verts, tris) fragments in order.
