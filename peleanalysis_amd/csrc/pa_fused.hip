@@ -15,6 +15,7 @@
 #include "pa_internal.h"
 #include "pa_fabview.h"
 #include "pa_fused_march.h"
+#include "pa_fused_march3.h"
 #include <cstdlib>
 
 struct Vec3 { double x, y, z; };
@@ -172,17 +173,56 @@ static int fused_order() {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("PA_ORDER");
-    v = e ? atoi(e) : 0;
+    v = e ? atoi(e) : 2;
   }
   return v;
 }
+// pair_ok: every tile of every box is 64 columns wide and starts on an even column of an even-length
+// output row (16-byte stores, see PAIR in pa_fused_march3.h)
 template <typename BP>
-static void march_launch(hipStream_t st, const BP& bp, int nx, int ny, int nz, unsigned nboxes, const MarchArgs& A0) {
+static void march_launch(hipStream_t st, const BP& bp, int nx, int ny, int nz, unsigned nboxes, const MarchArgs& A0, bool pair_ok = false) {
   MarchArgs A = A0;
+  static const int pair_env = [] { const char* e = getenv("PA_PAIR"); return e ? atoi(e) : 0; }();  // measured: no gain (2.36 vs 2.31 ms), see DESIGN.md 3.1
+  const bool pair = pair_ok && pair_env;
   A.order = fused_order();
   A.nboxes = (int)nboxes;
   int sel = fused_mty();
   if (sel < 0) sel = (ny >= 52) ? 131 : (ny >= 16 ? 81 : 41);  // short boxes do not fill a 13-row tile
+  static const int march_ver = [] { const char* e = getenv("PA_MARCH"); return e ? atoi(e) : 3; }();  // 1: k_gradcurv_march (A/B)
+  if (march_ver == 3) {
+    const bool clip = A.thr >= 0.0;
+    static const int dbg = [] { const char* e = getenv("PA_DBG"); return e ? atoi(e) : 0; }();  // diagnostic variants (wrong results)
+    if (dbg && !clip && sel / 10 == 13) {
+      dim3 g = march_grid(nx, ny, nz, A.kseg, 13, nboxes);
+      A.txy_max = ((nx + 63) / 64) * ((ny + 12) / 13);
+      A.tiles_max = (int)g.x;
+      if (A.order == 2) g = dim3(g.x * 8u * ((nboxes + 7u) / 8u), 1);
+      else if (A.order) g = dim3(g.x * g.y, 1);
+      switch (dbg) {
+#define PA_DBGCASE(D) case D: hipLaunchKernelGGL((k_gradcurv_march3<BP, 13, false, false, D>), g, dim3(64 * 16), 0, st, bp, A); return;
+        PA_DBGCASE(1) PA_DBGCASE(7) PA_DBGCASE(16)
+#undef PA_DBGCASE
+        default: break;
+      }
+    }
+    switch (sel / 10) {
+#define PA_CASE3(M)                                                                                                    \
+  case M: {                                                                                                            \
+    dim3 g = march_grid(nx, ny, nz, A.kseg, M, nboxes);                                                                \
+    A.txy_max = ((nx + 63) / 64) * ((ny + M - 1) / M);                                                                 \
+    A.tiles_max = (int)g.x;                                                                                            \
+    if (A.order == 2) g = dim3(g.x * 8u * ((nboxes + 7u) / 8u), 1);                                                    \
+    else if (A.order) g = dim3(g.x * g.y, 1);                                                                          \
+    if (pair && clip) hipLaunchKernelGGL((k_gradcurv_march3<BP, M, true, true>), g, dim3(64 * (M + 3)), 0, st, bp, A); \
+    else if (pair) hipLaunchKernelGGL((k_gradcurv_march3<BP, M, false, true>), g, dim3(64 * (M + 3)), 0, st, bp, A);   \
+    else if (clip) hipLaunchKernelGGL((k_gradcurv_march3<BP, M, true>), g, dim3(64 * (M + 3)), 0, st, bp, A);          \
+    else hipLaunchKernelGGL((k_gradcurv_march3<BP, M, false>), g, dim3(64 * (M + 3)), 0, st, bp, A);                   \
+  } return;
+      PA_CASE3(4) PA_CASE3(8) PA_CASE3(12) PA_CASE3(13)
+#undef PA_CASE3
+      default: break;
+    }
+  }
   switch (sel) {
 #define PA_CASE(M, W)                                                                                                  \
   case M * 10 + W: {                                                                                                   \
@@ -207,9 +247,14 @@ extern "C" int pa_gradcurv_level(pa_ctx* ctx, const pa_mf* phi, int pcomp, doubl
   if (!(pmax > pmin)) return pa_fail(ctx, "pa_gradcurv_level: progress variable has no range");
   const pa_level* L = phi->lev;
   LevelBP2 bp{L->view, phi->view, out->view};
-  MarchArgs A{pcomp, ocomp, fused_kseg(), pmin, 1.0 / (pmax - pmin), thr, 0, 1, 1};
+  MarchArgs A{pcomp, ocomp, fused_kseg(), pmin, 1.0 / (pmax - pmin), thr, 0, 1, 1, 1};
+  bool pair_ok = (out->ng % 2 == 0);
+  for (const DBox& B : L->boxes) {
+    const long long nxb = B.hi[0] - B.lo[0] + 1, nyb = B.hi[1] - B.lo[1] + 1 + 2 * out->ng, nzb = B.hi[2] - B.lo[2] + 1 + 2 * out->ng;
+    pair_ok = pair_ok && (nxb % 64 == 0) && pa_cstride((nxb + 2 * out->ng) * nyb * nzb, out->ncomp) * 8 < (1ll << 31);
+  }
   ProfScope prof(ctx, PA_TAG_GRADCURV);
-  march_launch(ctx->stream, bp, L->maxn[0], L->maxn[1], L->maxn[2], (unsigned)L->boxes.size(), A);
+  march_launch(ctx->stream, bp, L->maxn[0], L->maxn[1], L->maxn[2], (unsigned)L->boxes.size(), A, pair_ok);
   PA_HIP(hipGetLastError());
   return 0;
 }
@@ -248,7 +293,7 @@ extern "C" int pa_gradcurv_fab(pa_ctx* ctx, pa_box valid, const pa_fab* phi, int
   if (!fab_covers(*phi, valid, 2, pcomp, 1, why) || !fab_covers(*out, valid, 0, ocomp, 8, why)) return pa_fail(ctx, "pa_gradcurv_fab: " + why);
   if (!(pmax > pmin)) return pa_fail(ctx, "pa_gradcurv_fab: progress variable has no range");
   FabBP2 bp{fab_view(*phi), fab_view(*out), to_dbox(valid), {dxinv[0], dxinv[1], dxinv[2]}};
-  MarchArgs A{pcomp, ocomp, fused_kseg(), pmin, 1.0 / (pmax - pmin), thr, 0, 1, 1};
+  MarchArgs A{pcomp, ocomp, fused_kseg(), pmin, 1.0 / (pmax - pmin), thr, 0, 1, 1, 1};
   march_launch(ctx->stream, bp, valid.hi[0] - valid.lo[0] + 1, valid.hi[1] - valid.lo[1] + 1, valid.hi[2] - valid.lo[2] + 1, 1, A);
   PA_HIP(hipGetLastError());
   return 0;

@@ -55,7 +55,11 @@ struct MarchArgs {
   double pmin, invdenom, thr;
   // order = 1: 1-D grid, z-segment slowest across ALL boxes (the chip works on the same few planes of
   // every box at a time); order = 0: grid.y = box, all tiles of a box are consecutive
-  int order, nboxes, txy_max;
+  // order = 2 (k_gradcurv_march3): 1-D grid, XCD-aware.  Workgroups are dealt round-robin over the 8
+  // XCDs (blocks b and b+8 share one), so block L = 8*T*g + 8*t + q works on tile t of box 8*g + q:
+  // all tiles of a box run on ONE XCD at about the same time and the halo rows / partial lines that
+  // neighbouring tiles both read are served by that XCD's L2 instead of being fetched once per XCD.
+  int order, nboxes, txy_max, tiles_max;
 };
 
 template <typename BP, int PA_MTY, int MINW>

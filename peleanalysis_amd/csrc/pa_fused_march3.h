@@ -1,0 +1,433 @@
+// pa_fused_march3.h -- fused grad->curvature, k-marching kernel with a 3-plane-deep prefetch.
+//
+// Same tiling, roles, LDS ring and arithmetic as k_gradcurv_march (pa_fused_march.h; read that
+// header first), restructured around what its ISA showed: there every wave consumed, at the end of
+// a plane, the load it had issued at the top of the SAME plane (`s_waitcnt vmcnt(8)`), and because
+// vmcnt retires in issue order that wait also covered the previous plane's 8 stores.  One memory
+// round trip (and one store acknowledge) therefore sat on the barrier-to-barrier critical path of
+// every plane, in all three wave roles.  Here
+//   * every role keeps THREE planes in flight (f0,f1,f2): the plane consumed in a step was
+//     requested three steps earlier, so a step waits only for stores that are >= 4 planes old
+//     (`vmcnt(26)`); the loop is unrolled by 3 = the LDS ring period, which also makes every ring
+//     slot a compile-time LDS offset and keeps the in-flight registers free of moves;
+//   * global addresses are a wave-uniform base (SGPR pair, advanced with scalar adds) plus one
+//     loop-invariant 32-bit lane offset: no per-store 64-bit vector address arithmetic;
+//   * the z-direction face fluxes of c, phi and n_z are carried from plane to plane (the high face
+//     of plane k is the low face of plane k+1: same operation on the same operands);
+//   * the three components of the flame normal share one reciprocal (div3_shared): the exact
+//     instruction sequence hipcc emits for an IEEE fp64 division (v_rcp_f64, two Newton steps,
+//     quotient, remainder, correction) with its v_div_scale / v_div_fixup steps dropped under a
+//     wave-uniform guard that proves them to be no-ops; otherwise the plain `/` is taken.  Results
+//     are bit-identical to `/` for every input;
+//   * the threshold clip is a template parameter.
+// Results are bit-identical to k_gradcurv_march and to the CPU oracle.
+#pragma once
+#include <type_traits>
+#include "pa_fused_march.h"
+
+// a/d, b/d, c/d, each bit-identical to the IEEE-correct `/` of hipcc.
+// hipcc lowers x/y (fp64) to: ys = div_scale(y), xs = div_scale(x), r0 = rcp(ys), two Newton
+// steps r <- fma(r, fma(-ys, r, 1), r), q = xs*r, rem = fma(-ys, q, xs), div_fmas(rem, r, q),
+// div_fixup.  V_DIV_SCALE_F64 returns its operand unchanged (and VCC = 0, so div_fmas is a plain
+// fma) unless: x or y is zero, y is denormal, 1/y is denormal, x/y is denormal or near overflow
+// (exponent difference >= 768), or the biased exponent of x is <= 53; V_DIV_FIXUP_F64 passes the
+// quotient through unless an operand is zero/inf/nan or the quotient over/underflows.  The guard
+// below (2^-100 <= |d| <= 2^100, each numerator zero or of binary exponent >= -900; |numerator|
+// <= |d|(1+eps) by construction of d = -max(1e-14, |G|)) excludes all of those, and a zero
+// numerator goes through the unscaled sequence to the correctly signed zero.
+__device__ __forceinline__ void div3_shared(double a, double b, double c, double d, double& qa, double& qb, double& qc) {
+  const double ad = __builtin_fabs(d);
+  const int ea = __builtin_amdgcn_frexp_exp(a), eb = __builtin_amdgcn_frexp_exp(b), ec = __builtin_amdgcn_frexp_exp(c);
+  const int emin = min(ea, min(eb, ec));
+  const bool plain = (ad <= 0x1p100) && (ad >= 0x1p-100) && (emin >= -900);
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64(!plain) == 0ull, 1)) {
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    const double ma = a * r, mb = b * r, mc = c * r;
+    const double ra = __builtin_fma(-d, ma, a), rb = __builtin_fma(-d, mb, b), rc = __builtin_fma(-d, mc, c);
+    qa = __builtin_fma(ra, r, ma);
+    qb = __builtin_fma(rb, r, mb);
+    qc = __builtin_fma(rc, r, mc);
+  } else {
+    qa = a / d;
+    qb = b / d;
+    qc = c / d;
+  }
+}
+
+// central difference with the low-face flux carried in (cdiff of pa_internal.h split in two)
+__device__ __forceinline__ double zflux(double dxinv, double lo, double hi) { return -(dxinv * (hi - lo)); }
+__device__ __forceinline__ double favg(double fl, double fh) { return -(0.5 * (fl + fh)); }
+
+// PA_TAKE: move a value that was in flight into a fresh register HERE (the wait for it lands on this
+// instruction), so that the register it arrived in can take the next request: the in-flight
+// registers then never rotate, and no move of a still-in-flight value ends up at the loop's back edge.
+// PA_OPAQUE: keeps the zero-extension of a lane offset inside the loop body, where instruction
+// selection can fold it into the `global_* v_off, v_data, s[base]` addressing form.
+#define PA_TAKE(dst, src) asm volatile("v_mov_b64 %0, %1" : "=v"(dst) : "v"(src))
+#define PA_OPAQUE(x) asm volatile("" : "+v"(x))
+#define PA_LDG(base, off) (*(const double*)((const char*)(base) + (off)))
+#define PA_STG(base, off, v) (*(double*)((char*)(base) + (off)) = (v))
+#define PA_STL(base, off, v) do { if (!(DBG & 8) && (!(DBG & 1) || (v) == 1.2345e-300)) PA_STG(base, off, v); } while (0)
+
+// DBG (diagnostic builds only, selected with PA_DBG; results are wrong except 8 and 16: store
+// timing only): 8 = the 8 stores of a plane in one burst at the top of the next step, 16 = at most one
+// plane of stores outstanding per wave (vmcnt(8) at the top of a step); 1 = no global stores in the
+// loop (a never-true data-dependent condition keeps the arithmetic alive), 2 = sqrt and divisions
+// replaced by additions, 4 = no x/y-neighbour reads from LDS (own values instead).
+// PAIR: 16-byte stores.  A CU issues `global_store_dwordx2` at only ~7 B/cycle (measured: with 8-B
+// stores the sweep left the L2->HBM write interface idle -- TCC_EA0_WRREQ_STALL 0.5 M cycles against
+// 41 M for a no-arithmetic emulation of the same pattern -- while its time did not move with the
+// arithmetic, the LDS traffic or the prefetch depth).  Lanes 2m and 2m+1 therefore swap one value
+// (DPP quad_perm [1,0,3,2]) so that the even lane holds component A of cells 2m, 2m+1 and the odd
+// lane component B of the same two cells: one `global_store_dwordx4` writes 512 B of A and 512 B
+// of B, four store instructions per plane instead of eight.  Needs full 64-wide tiles, an even row
+// length and an even first column in the output FAB (checked on the host, else PAIR = false).
+__device__ __forceinline__ double swap_lane_pair(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+typedef double pa_d2 __attribute__((ext_vector_type(2)));
+// lane parity `odd`; `off` = even lane: 8*lane, odd lane: 8*(lane-1) + component stride
+__device__ __forceinline__ void store_pair(char* base, unsigned off, bool odd, double A, double B) {
+  const double recv = swap_lane_pair(odd ? A : B);
+  pa_d2 v;
+  v.x = odd ? recv : A;
+  v.y = odd ? B : recv;
+  *(pa_d2*)(base + off) = v;
+}
+
+template <typename BP, int PA_MTY, bool CLIP, bool PAIR = false, int DBG = 0>
+__global__ __launch_bounds__(64 * (PA_MTY + 3), 1) void k_gradcurv_march3(BP bp, MarchArgs A) {
+  FabView P, O;
+  DBox V;
+  double dxinv[3];
+  constexpr int PA_MROWS = PA_MTY + 2;
+  unsigned bid = blockIdx.x;
+  int box;
+  if (A.order == 2) {
+    const unsigned per8 = 8u * (unsigned)A.tiles_max, g = bid / per8, r = bid % per8;
+    box = (int)(g * 8u + (r & 7u));
+    bid = r >> 3;
+    if (box >= A.nboxes) return;
+  } else {
+    box = A.order ? (int)((blockIdx.x / (unsigned)A.txy_max) % (unsigned)A.nboxes) : (int)blockIdx.y;
+  }
+  if (!bp.get(box, P, O, V, dxinv)) return;
+  const int pcomp = A.pcomp, kseg = A.kseg;
+  const double pmin = A.pmin, invd = A.invdenom;
+  const int nx = V.hi[0] - V.lo[0] + 1, ny = V.hi[1] - V.lo[1] + 1, nz = V.hi[2] - V.lo[2] + 1;
+  const int tx = (nx + 63) / 64, ty = (ny + PA_MTY - 1) / PA_MTY, tz = (nz + kseg - 1) / kseg;
+  if (A.order == 1) {
+    const unsigned t = bid % (unsigned)A.txy_max, z = bid / ((unsigned)A.txy_max * (unsigned)A.nboxes);
+    if (t >= (unsigned)tx * ty || z >= (unsigned)tz) return;
+    bid = z * (unsigned)(tx * ty) + t;
+  }
+  if (bid >= (unsigned)tx * ty * tz) return;  // uniform for the whole workgroup
+  const int bx = bid % tx, by = (bid / tx) % ty, bz = bid / (tx * ty);
+  const int i0 = V.lo[0] + bx * 64, j0 = V.lo[1] + by * PA_MTY;
+  const int k0 = V.lo[2] + bz * kseg, k1 = min(k0 + kseg - 1, V.hi[2]);
+  const int iR = min(i0 + 64, V.hi[0] + 1);  // column right of the tile's last valid column
+  const int llast = iR - 1 - i0;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int rtop = min(PA_MROWS - 1, V.hi[1] + 1 - j0 + 1);  // row slot of the last live row
+
+  __shared__ MarchLds<PA_MTY> S;
+  const long long pps = (long long)P.nx * P.ny * 8;  // plane stride of phi, bytes
+  const int pend = k1 + 1;                            // normals are formed on planes k0-1 .. k1+1
+  const int kfmax = k1 + 2;                           // last plane of phi that exists for this segment
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+#define PA_PROG(x) (((x) - pmin) * invd) /* curvature.cpp:319 */
+#define PA_RUN3(step)                                                                                                  \
+  {                                                                                                                    \
+    int p = k0 - 1;                                                                                                    \
+    _Pragma("unroll 1") for (; p + 2 <= pend; p += 3) {                                                                \
+      step(I0{}, p);                                                                                                   \
+      step(I1{}, p + 1);                                                                                               \
+      step(I2{}, p + 2);                                                                                               \
+    }                                                                                                                  \
+    if (p <= pend) {                                                                                                   \
+      step(I0{}, p);                                                                                                   \
+      if (p + 1 <= pend) step(I1{}, p + 1);                                                                            \
+    }                                                                                                                  \
+  }
+
+  if (w < PA_MROWS && w > rtop) {
+    // ---------------------------------------------------------------- dead row (partial tile)
+    for (int it = 0; it <= pend - (k0 - 1) + 1; ++it) __syncthreads();
+    return;
+  }
+
+  if (w < PA_MROWS) {
+    // ------------------------------------------------------------------------- row waves
+    const int rr = w;
+    const int j = j0 + rr - 1;
+    const int le = min(lane, llast);  // lanes past the box edge mirror the last valid lane
+    const int xs = le + 1;
+    unsigned lo8 = (unsigned)le * 8u;
+    const char* gp = (const char*)(P.p + P.idx(i0, j, k0 - 2, pcomp));  // wave-uniform
+    double pc = PA_LDG(gp, lo8), p0 = PA_LDG(gp + pps, lo8), p1 = PA_LDG(gp + 2 * pps, lo8);
+    const bool halo = (rr == 0) || (rr == rtop);  // supplies neighbours only; one y-neighbour comes from global
+    double cm = PA_PROG(pc), cc = PA_PROG(p0), cp = PA_PROG(p1);  // c at planes p-1, p, p+1  (p = k0-1)
+    double fzc = zflux(dxinv[2], cm, cc);                         // low z-face flux of c at plane p
+    double f[3];
+    if (halo) {
+      // requests in the order of the steady state (f, fo per plane): the wait counts the compiler
+      // derives for the loop are the minimum over the entry edge and the back edge
+      const int jout = (rr == 0) ? j - 1 : j + 1;
+      const char* go = (const char*)(P.p + P.idx(i0, jout, k0 - 1, pcomp));
+      double co = PA_PROG(PA_LDG(go, lo8));
+      double fo[3];
+      __builtin_amdgcn_sched_barrier(0);
+      f[0] = PA_LDG(gp + 3 * pps, lo8);
+      fo[0] = PA_LDG(go + pps, lo8);
+      __builtin_amdgcn_sched_barrier(0);
+      f[1] = PA_LDG(gp + 4 * pps, lo8);
+      fo[1] = PA_LDG(go + 2 * pps, lo8);
+      __builtin_amdgcn_sched_barrier(0);
+      gp += 4 * pps;
+      gp += (k0 + 3 <= kfmax) ? pps : 0;
+      go += 2 * pps;
+      go += (k0 + 2 <= pend) ? pps : 0;
+      f[2] = PA_LDG(gp, lo8);   // gp -> plane min(k0+3, k1+2), the youngest plane requested
+      fo[2] = PA_LDG(go, lo8);  // go -> plane min(k0+2, k1+1)
+      __builtin_amdgcn_sched_barrier(0);
+      S.c[0][rr][xs] = cc;
+      __syncthreads();
+      auto step = [&](auto spc, int p) __attribute__((always_inline)) {
+        constexpr int SP = decltype(spc)::value, SP1 = (SP + 1) % 3;
+        double x, xo;  // phi(min(p+2, k1+2)), phi_out(min(p+1, k1+1))
+        PA_TAKE(x, f[SP]);
+        PA_TAKE(xo, fo[SP]);
+        PA_OPAQUE(lo8);
+        __builtin_amdgcn_sched_barrier(0);
+        gp += (p + 5 <= kfmax) ? pps : 0;
+        go += (p + 4 <= pend) ? pps : 0;
+        f[SP] = PA_LDG(gp, lo8);
+        fo[SP] = PA_LDG(go, lo8);
+        const double cl = S.c[SP][rr][xs - 1], cr = S.c[SP][rr][xs + 1];
+        const double cin = S.c[SP][(rr == 0) ? 1 : rr - 1][xs];
+        const double cs = (rr == 0) ? co : cin, cn = (rr == 0) ? cin : co;
+        const double ggx = cdiff(dxinv[0], cl, cc, cr);
+        const double ggy = cdiff(dxinv[1], cs, cc, cn);
+        const double fzh = zflux(dxinv[2], cc, cp);
+        const double ggz = favg(fzc, fzh);
+        const double sn = sqrt(ggx * ggx + ggy * ggy + ggz * ggz);
+        const double ng = -((1e-14 < sn) ? sn : 1e-14);
+        S.ny[SP][rr][lane] = ggy / ng;
+        S.c[SP1][rr][xs] = cp;
+        S.p[SP][rr][xs] = p0;
+        __syncthreads();
+        cm = cc; cc = cp; cp = PA_PROG(x); co = PA_PROG(xo);
+        fzc = fzh;
+        p0 = p1; p1 = x;
+      };
+      PA_RUN3(step)
+      return;
+    }
+    // output rows
+    f[0] = PA_LDG(gp + 3 * pps, lo8);
+    f[1] = PA_LDG(gp + 4 * pps, lo8);
+    gp += 4 * pps;
+    gp += (k0 + 3 <= kfmax) ? pps : 0;
+    f[2] = PA_LDG(gp, lo8);  // gp -> plane min(k0+3, k1+2), the youngest plane requested
+    // Enter the loop with nothing in flight: one `s_waitcnt vmcnt(N)` must hold for the first trip and
+    // for the steady state, so requests still pending on entry (no stores behind them yet) would pull
+    // N down from 26 to 2 and drain the stores every third plane.  Costs one round trip per segment.
+    asm volatile("" ::"v"(f[0]), "v"(f[1]), "v"(f[2]));
+    S.c[0][rr][xs] = cc;
+    __syncthreads();
+    double nxq = 0, nyq = 0, nzq = 0, fzn = 0, fzp = 0;
+    char* ob = (char*)(O.p + O.idx(i0, j, k0, A.ocomp));  // wave-uniform
+    const long long ops = (long long)O.nx * O.ny * 8, osc = O.sc * 8;
+    const double thr = A.thr;
+    const bool odd = lane & 1;
+    unsigned lo16 = odd ? (unsigned)(le - 1) * 8u + (unsigned)osc : (unsigned)le * 8u;
+    // normal at plane p, outputs at plane q = p-1.  The 8 results of a plane are kept in registers
+    // and stored DURING the next plane's normal computation (see pa_fused_march.h); the first three
+    // steps have nothing valid to store yet and write to plane k0, which the same thread
+    // overwrites in program order.
+    double o0 = 0, o1 = 0, o2 = 0, o3 = 0, o4 = 0, o5 = 0, o6 = 0, o7 = 0;
+    auto step = [&](auto spc, int p) __attribute__((always_inline)) {
+      constexpr int SP = decltype(spc)::value, SP1 = (SP + 1) % 3, SQ = (SP + 2) % 3;
+      double x;  // phi(min(p+2, k1+2)), requested three steps ago
+      PA_TAKE(x, f[SP]);
+      PA_OPAQUE(lo8);
+      __builtin_amdgcn_sched_barrier(0);
+      gp += (p + 5 <= kfmax) ? pps : 0;
+      if (DBG & 16) __builtin_amdgcn_s_waitcnt(0x0F70 | 8);  // vmcnt(8): at most one plane of stores outstanding
+      f[SP] = PA_LDG(gp, lo8);
+      if (DBG & 8) {  // all 8 stores of the previous plane in one burst
+        PA_STG(ob, lo8, o0); PA_STG(ob + osc, lo8, o1); PA_STG(ob + 2 * osc, lo8, o2); PA_STG(ob + 3 * osc, lo8, o3);
+        PA_STG(ob + 4 * osc, lo8, o4); PA_STG(ob + 5 * osc, lo8, o5); PA_STG(ob + 6 * osc, lo8, o6); PA_STG(ob + 7 * osc, lo8, o7);
+      }
+      const double cl = (DBG & 4) ? cm : S.c[SP][rr][xs - 1], cr = (DBG & 4) ? cp : S.c[SP][rr][xs + 1];
+      const double cs = (DBG & 4) ? cm : S.c[SP][rr - 1][xs], cn = (DBG & 4) ? cp : S.c[SP][rr + 1][xs];
+      if (PAIR) { PA_OPAQUE(lo16); store_pair(ob, lo16, odd, o0, o1); } else PA_STL(ob, lo8, o0);
+      __builtin_amdgcn_sched_barrier(0);
+      const double ggx = cdiff(dxinv[0], cl, cc, cr);
+      const double ggy = cdiff(dxinv[1], cs, cc, cn);
+      const double fzh = zflux(dxinv[2], cc, cp);
+      const double ggz = favg(fzc, fzh);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!PAIR) PA_STL(ob + osc, lo8, o1);
+      __builtin_amdgcn_sched_barrier(0);
+      const double sn = (DBG & 2) ? (ggx * ggx + ggy * ggy + ggz * ggz) : sqrt(ggx * ggx + ggy * ggy + ggz * ggz);
+      const double ng = -((1e-14 < sn) ? sn : 1e-14);
+      __builtin_amdgcn_sched_barrier(0);
+      if (PAIR) { PA_OPAQUE(lo16); store_pair(ob + 2 * osc, lo16, odd, o2, o3); } else PA_STL(ob + 2 * osc, lo8, o2);
+      __builtin_amdgcn_sched_barrier(0);
+      double nxp, nyp, nzp;
+      if (DBG & 2) { nxp = ggx + ng; nyp = ggy + ng; nzp = ggz + ng; }
+      else div3_shared(ggx, ggy, ggz, ng, nxp, nyp, nzp);
+      PA_OPAQUE(lo8);  // new basic block after the guard's branch: see PA_OPAQUE
+      __builtin_amdgcn_sched_barrier(0);
+      if (!PAIR) PA_STL(ob + 3 * osc, lo8, o3);
+      __builtin_amdgcn_sched_barrier(0);
+      S.ny[SP][rr][lane] = nyp;
+      S.nx[SP][rr - 1][xs] = nxp;
+      S.c[SP1][rr][xs] = cp;
+      S.p[SP][rr][xs] = p0;
+      __builtin_amdgcn_sched_barrier(0);
+      if (!PAIR) PA_STL(ob + 4 * osc, lo8, o4);
+      __syncthreads();
+      const double nxl = (DBG & 4) ? nzq : S.nx[SQ][rr - 1][xs - 1], nxr = (DBG & 4) ? nzp : S.nx[SQ][rr - 1][xs + 1];
+      const double nys = (DBG & 4) ? nzq : S.ny[SQ][rr - 1][lane], nyn = (DBG & 4) ? nzp : S.ny[SQ][rr + 1][lane];
+      const double fznh = zflux(dxinv[2], nzq, nzp);
+      double curv = 0.0;
+      curv += cdiff(dxinv[0], nxl, nxq, nxr);
+      curv += cdiff(dxinv[1], nys, nyq, nyn);
+      curv += favg(fzn, fznh);
+      curv = curv * 0.5;
+      __builtin_amdgcn_sched_barrier(0);
+      if (PAIR) { PA_OPAQUE(lo16); store_pair(ob + 4 * osc, lo16, odd, o4, o5); } else PA_STL(ob + 5 * osc, lo8, o5);
+      __builtin_amdgcn_sched_barrier(0);
+      // phi gradient at plane q (pc = phi(q), p0 = phi(q+1); fzp = low z-face flux at plane q)
+      const double pl = (DBG & 4) ? p1 : S.p[SQ][rr][xs - 1], pr = (DBG & 4) ? p0 : S.p[SQ][rr][xs + 1];
+      const double ps = (DBG & 4) ? p1 : S.p[SQ][rr - 1][xs], pnn = (DBG & 4) ? p0 : S.p[SQ][rr + 1][xs];
+      const double gx = cdiff(dxinv[0], pl, pc, pr);
+      const double gy = cdiff(dxinv[1], ps, pc, pnn);
+      const double fzph = zflux(dxinv[2], pc, p0);
+      const double gz = favg(fzp, fzph);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!PAIR) PA_STL(ob + 6 * osc, lo8, o6);
+      __builtin_amdgcn_sched_barrier(0);
+      const double gm = (DBG & 2) ? (gx * gx + gy * gy + gz * gz) : sqrt(gx * gx + gy * gy + gz * gz);
+      __builtin_amdgcn_sched_barrier(0);
+      if (PAIR) { PA_OPAQUE(lo16); store_pair(ob + 6 * osc, lo16, odd, o6, o7); } else PA_STL(ob + 7 * osc, lo8, o7);
+      ob += (p >= k0 + 2) ? ops : 0;
+      o0 = gx; o1 = gy; o2 = gz; o3 = gm;
+      if (CLIP) {  // threshold clip (curvature.cpp:557-566); cm = c at plane q
+        const bool clip = (cm < thr) || (cm > 1.0 - thr);
+        o4 = clip ? 0.0 : nxq;
+        o5 = clip ? 0.0 : nyq;
+        o6 = clip ? 0.0 : nzq;
+        o7 = clip ? 0.0 : curv;
+      } else {
+        o4 = nxq; o5 = nyq; o6 = nzq; o7 = curv;
+      }
+      cm = cc; cc = cp; cp = PA_PROG(x);
+      fzc = fzh; fzn = fznh; fzp = fzph;
+      pc = p0; p0 = p1; p1 = x;
+      nxq = nxp; nyq = nyp; nzq = nzp;
+    };
+    PA_RUN3(step)
+    // results of the last plane (k1)
+    if (PAIR) {
+      store_pair(ob, lo16, odd, o0, o1);
+      store_pair(ob + 2 * osc, lo16, odd, o2, o3);
+      store_pair(ob + 4 * osc, lo16, odd, o4, o5);
+      store_pair(ob + 6 * osc, lo16, odd, o6, o7);
+    } else {
+      PA_STG(ob, lo8, o0);
+      PA_STG(ob + osc, lo8, o1);
+      PA_STG(ob + 2 * osc, lo8, o2);
+      PA_STG(ob + 3 * osc, lo8, o3);
+      PA_STG(ob + 4 * osc, lo8, o4);
+      PA_STG(ob + 5 * osc, lo8, o5);
+      PA_STG(ob + 6 * osc, lo8, o6);
+      PA_STG(ob + 7 * osc, lo8, o7);
+    }
+    return;
+  }
+
+  // ----------------------------------------------------------------------------- edge wave
+  {
+    const int l20 = lane % (2 * PA_MROWS);  // idle lanes mirror the active ones
+    const int rr = min(l20 >> 1, rtop);
+    const int side = l20 & 1;
+    const int j = j0 + rr - 1;
+    const int i = side ? iR : i0 - 1;
+    const int xs = side ? llast + 2 : 0;
+    const int xin = side ? llast + 1 : 1;  // the tile column next to this edge column
+    const int rlo = max(rr - 1, 0), rhi = min(rr + 1, PA_MROWS - 1);
+    const bool has_n = (rr >= 1 && rr <= PA_MTY);
+    // uniform base (plane k0-2 of the component) + per-lane in-plane byte offsets (< 4 GiB)
+    const char* gb = (const char*)(P.p + P.idx(P.lo[0], P.lo[1], k0 - 2, pcomp));
+    unsigned og = (unsigned)((j - P.lo[1]) * P.nx + (i - P.lo[0])) * 8u;
+    unsigned oo = (unsigned)((j - P.lo[1]) * P.nx + ((side ? i + 1 : i - 1) - P.lo[0])) * 8u;
+    const char* gp = gb;
+    const char* go = gb + pps;  // the column beyond the edge column starts at plane k0-1
+    double p0 = PA_LDG(gp + pps, og), p1 = PA_LDG(gp + 2 * pps, og);
+    double cm = PA_PROG(PA_LDG(gp, og)), cc = PA_PROG(p0), cp = PA_PROG(p1);
+    double co = PA_PROG(PA_LDG(go, oo));
+    double f[3], fo[3];
+    __builtin_amdgcn_sched_barrier(0);
+    f[0] = PA_LDG(gp + 3 * pps, og);
+    fo[0] = PA_LDG(go + pps, oo);
+    __builtin_amdgcn_sched_barrier(0);
+    f[1] = PA_LDG(gp + 4 * pps, og);
+    fo[1] = PA_LDG(go + 2 * pps, oo);
+    __builtin_amdgcn_sched_barrier(0);
+    gp += 4 * pps;
+    gp += (k0 + 3 <= kfmax) ? pps : 0;
+    go += 2 * pps;
+    go += (k0 + 2 <= pend) ? pps : 0;
+    f[2] = PA_LDG(gp, og);
+    fo[2] = PA_LDG(go, oo);
+    __builtin_amdgcn_sched_barrier(0);
+    double fzc = zflux(dxinv[2], cm, cc);
+    S.c[0][rr][xs] = cc;
+    __syncthreads();
+    auto step = [&](auto spc, int p) __attribute__((always_inline)) {
+      constexpr int SP = decltype(spc)::value, SP1 = (SP + 1) % 3;
+      double x, xo;
+      PA_TAKE(x, f[SP]);
+      PA_TAKE(xo, fo[SP]);
+      PA_OPAQUE(og);
+      PA_OPAQUE(oo);
+      __builtin_amdgcn_sched_barrier(0);
+      gp += (p + 5 <= kfmax) ? pps : 0;
+      go += (p + 4 <= pend) ? pps : 0;
+      f[SP] = PA_LDG(gp, og);
+      fo[SP] = PA_LDG(go, oo);
+      const double inner = S.c[SP][rr][xin];
+      const double cl = side ? inner : co, cr = side ? co : inner;
+      const double cs = S.c[SP][rlo][xs], cn = S.c[SP][rhi][xs];
+      const double ggx = cdiff(dxinv[0], cl, cc, cr);
+      const double ggy = cdiff(dxinv[1], cs, cc, cn);
+      const double fzh = zflux(dxinv[2], cc, cp);
+      const double ggz = favg(fzc, fzh);
+      const double sn = sqrt(ggx * ggx + ggy * ggy + ggz * ggz);
+      const double ng = -((1e-14 < sn) ? sn : 1e-14);
+      const double nxp = ggx / ng;
+      if (has_n) S.nx[SP][rr - 1][xs] = nxp;
+      S.c[SP1][rr][xs] = cp;
+      S.p[SP][rr][xs] = p0;
+      __syncthreads();
+      cm = cc; cc = cp; cp = PA_PROG(x); co = PA_PROG(xo);
+      fzc = fzh;
+      p0 = p1; p1 = x;
+    };
+    PA_RUN3(step)
+  }
+#undef PA_PROG
+#undef PA_RUN3
+}

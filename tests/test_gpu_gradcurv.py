@@ -84,6 +84,33 @@ def test_gradcurv_fused_matches_oracle(ctx, oracle, name, threshold):
         assert_valid_bits_equal(got, oc[l], [(4, 2), (5, 3), (6, 4), (7, 1)], f"{name} curv level {l}")
 
 
+@pytest.mark.parametrize("threshold", [None, 0.05])
+def test_gradcurv_fused_wide_boxes(ctx, oracle, threshold):
+    """boxes 64 cells wide (the 16-byte paired-store variant of the sweep, pa_fused_march3.h PAIR) with a
+    partial last row tile (48 = 3*13 + 9 rows), anisotropic dx, 2 levels, periodic x/y + wall z"""
+    from peleanalysis_amd.hierarchy import Hierarchy, Level, chop_box, field_flame
+    l0 = Level(chop_box((0, 0, 0), (127, 47, 19), 64), (0, 0, 0), (127, 47, 19), (1, 1, 0), (0, 0, 0), (1, 1, 1))
+    l1 = Level(chop_box((64, 24, 10), (191, 71, 29), 64), (0, 0, 0), (255, 95, 39), (1, 1, 0), (0, 0, 0), (1, 1, 1))
+    H = Hierarchy([l0, l1], 2)
+    assert all(lv.boxes[:, 3].max() - lv.boxes[:, 0].min() + 1 == 128 and ((lv.boxes[:, 3] - lv.boxes[:, 0] + 1) == 64).all() for lv in H.levels)
+    states = make_states(H, 1, 2, field_flame, seed=23)
+    bc = capi.bc_from_flags((1, 1, 0), (0, 0, 0))
+    og = [MultiFab(lv, 4, 0) for lv in H.levels]
+    oracle.grad_pipeline(H.levels, [s.copy() for s in states], 0, bc, og, 0, multipass=True)
+    oc = [MultiFab(lv, 5, 0) for lv in H.levels]
+    oracle.curvature_pipeline(H.levels, [s.copy() for s in states], 0, bc, oc, 0, MultiFab, threshold=threshold)
+    dls, dst = _dev(ctx, H, states)
+    work = [capi.DevMF(ctx, dl, 1, 2) for dl in dls]
+    dout = [capi.DevMF(ctx, dl, 8, 0) for dl in dls]
+    capi.gradcurv_run(ctx, dst, 0, bc, capi.curv_params(threshold=threshold, fused=True), work, dout, 0)
+    ctx.sync()
+    assert ctx.bc_errors() == 0
+    for l in range(H.nlev):
+        got = dout[l].download()
+        assert_valid_bits_equal(got, og[l], [(c, c) for c in range(4)], f"wide grad level {l}")
+        assert_valid_bits_equal(got, oc[l], [(4, 2), (5, 3), (6, 4), (7, 1)], f"wide curv level {l}")
+
+
 def test_ghost_fill_matches_oracle(ctx, oracle):
     """FillBoundary (ng=2, edges+corners) and applyBC individually, all ghost cells compared"""
     H, per, sym, fn = build_config("amr3_wall_z")
