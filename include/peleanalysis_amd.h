@@ -192,6 +192,27 @@ int pa_mc_emit_fab(pa_ctx*, pa_box loop, const pa_fab* state, const pa_fab* mask
 const uint16_t* pa_mc_edge_table(void); /* [256] host */
 const int8_t*   pa_mc_tri_table(void);  /* [256][16] host */
 
+/* ----------------------------------------------- isosurface: distance function
+ * isosurface.cpp:1595-1655 (build_distance_function).  One pa_sdf_grid = one call of
+ * make_level_set3(faceList, vertList, local_origin, dx, ni, nj, nk, phi_grid) (isosurface.cpp:1625,
+ * Tools/SDFGen/makelevelset3.cpp:118-185): unsigned distance, in the reference's float arithmetic and
+ * visiting order, from grid point (i,j,k) = origin + (i,j,k)*dx to the triangle mesh; phi is
+ * [k][j][i] with i fastest (Array3f order), ni*nj*nk floats.  All pointers are DEVICE pointers; tri
+ * holds 3 vertex indices per triangle, x 3 floats per vertex.  A batch of grids runs concurrently
+ * (one workgroup per grid for the sweeps).  Asynchronous on the context's stream. */
+typedef struct {
+  int64_t ntri;  const uint32_t* tri;
+  int64_t nvert; const float* x;
+  float origin[3]; float dx;
+  int32_t n[3];
+  float* phi;
+} pa_sdf_grid;
+int pa_sdf_level_set3(pa_ctx*, int ngrids, const pa_sdf_grid* grids /* host array */, int exact_band /* reference default 1 */);
+/* isosurface.cpp:1637-1650: dist(i,j,k,dcomp) = sgn * min(dmax, phi(i-lo,j-lo,k-lo)) over vbox (the
+ * distance FAB's box incl. ghosts), sgn = state(i,j,k,isocomp) < isoval ? -1 : +1 */
+int pa_sdf_signed_fab(pa_ctx*, pa_box vbox, const float* dev_phi, const pa_fab* state, int isocomp, double isoval,
+                      double dmax, pa_fab* dist, int dcomp);
+
 /* ------------------------------------------------------------ tool pipelines
  * The level loops of the tool mains, operating on device-resident MultiFabs.
  * levels/state/out are arrays of nlev pointers, coarse first. */

@@ -34,6 +34,11 @@ class PaCurvParams(C.Structure):
                 ("do_velnormal", C.c_int32), ("vel_comp", C.c_int32)]
 
 
+class PaSdfGrid(C.Structure):
+    _fields_ = [("ntri", C.c_int64), ("tri", C.c_void_p), ("nvert", C.c_int64), ("x", C.c_void_p), ("origin", C.c_float * 3), ("dx", C.c_float),
+                ("n", C.c_int32 * 3), ("phi", C.c_void_p)]
+
+
 _lib = None
 
 
@@ -103,6 +108,8 @@ def load_library() -> C.CDLL:
         "pa_mc_emit_fab": (C.c_int, [vp, PaBox, C.POINTER(PaFab), C.POINTER(PaFab), C.c_int, dbl, vp, vp, vp, i64, i64]),
         "pa_mc_edge_table": (C.POINTER(C.c_uint16), []),
         "pa_mc_tri_table": (C.POINTER(C.c_int8), []),
+        "pa_sdf_level_set3": (C.c_int, [vp, C.c_int, C.POINTER(PaSdfGrid), C.c_int]),
+        "pa_sdf_signed_fab": (C.c_int, [vp, PaBox, vp, C.POINTER(PaFab), C.c_int, dbl, dbl, C.POINTER(PaFab), C.c_int]),
         "pa_grad_run": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.c_int, pi32, C.POINTER(vp), C.c_int]),
         "pa_curvature_run": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.c_int, pi32, C.POINTER(PaCurvParams), C.POINTER(vp), C.c_int]),
         "pa_gradcurv_run": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.c_int, pi32, C.POINTER(PaCurvParams), C.POINTER(vp), C.POINTER(vp),
@@ -312,3 +319,28 @@ def curvature_run(ctx, states, comp, bc, params: PaCurvParams, outs, ocomp):
 def gradcurv_run(ctx, states, comp, bc, params: PaCurvParams, works, outs, ocomp):
     ctx.check(ctx.lib.pa_gradcurv_run(ctx.h, len(states), _handles(states), comp, _i3(bc), C.byref(params), _handles(works),
                                       _handles(outs), ocomp))
+
+
+def sdf_level_set(ctx: Context, meshes, exact_band: int = 1):
+    """pa_sdf_level_set3 on a batch: meshes = list of (tris (nt,3) uint32, verts (nv,3) float32, origin, dx, (ni,nj,nk));
+    returns the list of phi arrays, float32 (nk, nj, ni)."""
+    grids = (PaSdfGrid * len(meshes))()
+    keep, outs = [], []
+    for g, (tris, verts, origin, dx, n) in zip(grids, meshes):
+        tris = np.ascontiguousarray(tris, dtype=np.uint32).reshape(-1, 3)
+        verts = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 3)
+        dt = DevBuf.from_numpy(ctx, tris) if len(tris) else None
+        dv = DevBuf.from_numpy(ctx, verts) if len(verts) else None
+        ni, nj, nk = (int(v) for v in n)
+        dp = DevBuf(ctx, 4 * ni * nj * nk)
+        keep += [dt, dv]
+        outs.append((dp, (nk, nj, ni)))
+        g.ntri, g.tri, g.nvert, g.x = len(tris), (dt.ptr if dt else None), len(verts), (dv.ptr if dv else None)
+        for d in range(3):
+            g.origin[d] = np.float32(origin[d])
+            g.n[d] = (ni, nj, nk)[d]
+        g.dx = np.float32(dx)
+        g.phi = dp.ptr
+    ctx.check(ctx.lib.pa_sdf_level_set3(ctx.h, len(meshes), grids, int(exact_band)))
+    ctx.sync()
+    return [dp.to_numpy(np.float32, shape) for dp, shape in outs]

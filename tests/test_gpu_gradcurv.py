@@ -84,11 +84,13 @@ def test_gradcurv_fused_matches_oracle(ctx, oracle, name, threshold):
         assert_valid_bits_equal(got, oc[l], [(4, 2), (5, 3), (6, 4), (7, 1)], f"{name} curv level {l}")
 
 
+@pytest.mark.parametrize("pair", [0, 1])
 @pytest.mark.parametrize("threshold", [None, 0.05])
-def test_gradcurv_fused_wide_boxes(ctx, oracle, threshold):
+def test_gradcurv_fused_wide_boxes(ctx, oracle, threshold, pair, monkeypatch):
     """boxes 64 cells wide (the 16-byte paired-store variant of the sweep, pa_fused_march3.h PAIR) with a
     partial last row tile (48 = 3*13 + 9 rows), anisotropic dx, 2 levels, periodic x/y + wall z"""
     from peleanalysis_amd.hierarchy import Hierarchy, Level, chop_box, field_flame
+    monkeypatch.setenv("PA_PAIR", str(pair))  # read by the library at every launch
     l0 = Level(chop_box((0, 0, 0), (127, 47, 19), 64), (0, 0, 0), (127, 47, 19), (1, 1, 0), (0, 0, 0), (1, 1, 1))
     l1 = Level(chop_box((64, 24, 10), (191, 71, 29), 64), (0, 0, 0), (255, 95, 39), (1, 1, 0), (0, 0, 0), (1, 1, 1))
     H = Hierarchy([l0, l1], 2)

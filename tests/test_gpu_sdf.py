@@ -1,0 +1,85 @@
+"""GPU parity: distance function (pa_sdf_level_set3 / pa_sdf_signed_fab, isosurface.cpp:1595-1655) vs
+(i) the golden vectors produced by the REFERENCE's own make_level_set3 (tests/golden/sdf_ref.npz),
+(ii) the oracle restatement (itself pinned to the reference build), bit for bit (float32)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from peleanalysis_amd import capi
+from sdf_cases import cases
+from test_sdf_oracle import bits, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _mesh(c):
+    return (c["tris"], c["verts"], c["origin"], c["dx"], c["n"])
+
+
+def test_sdf_matches_reference_golden(ctx):
+    gold = load_golden()
+    for c in gold:  # one grid per call: the reference's call shape
+        phi = capi.sdf_level_set(ctx, [_mesh(c)], c["band"])[0]
+        assert phi.shape == c["phi_ref"].shape
+        assert np.array_equal(bits(phi), bits(c["phi_ref"])), c["name"]
+
+
+def test_sdf_batch_matches_oracle(ctx, oracle):
+    """all cases of one band in ONE batched call (grids run concurrently) + random triangle soups"""
+    rng = np.random.default_rng(11)
+    cs = [c for c in cases(oracle) if c["band"] == 1]
+    for q in range(8):
+        nt, nv = int(rng.integers(1, 60)), int(rng.integers(3, 40))
+        verts = rng.random((nv, 3)).astype(np.float32)
+        tris = rng.integers(0, nv, size=(nt, 3)).astype(np.uint32)
+        n = tuple(int(v) for v in rng.integers(1, 18, size=3))
+        cs.append(dict(name=f"soup{q}", tris=tris, verts=verts, origin=tuple(rng.random(3) * 0.3 - 0.15), dx=float(rng.random() * 0.1 + 0.05), n=n, band=1))
+    got = capi.sdf_level_set(ctx, [_mesh(c) for c in cs], 1)
+    for c, phi in zip(cs, got):
+        want = oracle.sdf_level_set(c["tris"], c["verts"], c["origin"], c["dx"], c["n"], 1)
+        assert np.array_equal(bits(phi), bits(want)), c["name"]
+    for band in (2, 3):
+        c = cs[-1]
+        phi = capi.sdf_level_set(ctx, [_mesh(c)], band)[0]
+        assert np.array_equal(bits(phi), bits(oracle.sdf_level_set(c["tris"], c["verts"], c["origin"], c["dx"], c["n"], band))), band
+
+
+def test_sdf_fab_sized_grid(ctx, oracle):
+    """a FAB-sized call: 40^3 marching-cubes sphere on a 44 x 44 x 44 grid (box + 2 ghost layers), node-
+    aligned origin as in isosurface.cpp:1619-1623; ~3000 hyperplane steps"""
+    from sdf_cases import _mc_mesh
+    sph = lambda X, Y, Z: np.sqrt((X - 0.47) ** 2 + (Y - 0.52) ** 2 + (Z - 0.5) ** 2)
+    t, v = _mc_mesh(oracle, 40, sph, 0.33)
+    dx = 1.0 / 40
+    c = dict(tris=t, verts=v, origin=(-2 * dx, -2 * dx, -2 * dx), dx=dx, n=(44, 44, 44))
+    phi = capi.sdf_level_set(ctx, [_mesh(c)], 1)[0]
+    want = oracle.sdf_level_set(c["tris"], c["verts"], c["origin"], c["dx"], c["n"], 1)
+    assert np.array_equal(bits(phi), bits(want))
+    # away from the surface the distance is |r - 0.33| to O(dx^2) (faceted sphere)
+    k, j, i = np.meshgrid(np.arange(44), np.arange(44), np.arange(44), indexing="ij")
+    r = np.sqrt((-2 * dx + i * dx - 0.47) ** 2 + (-2 * dx + j * dx - 0.52) ** 2 + (-2 * dx + k * dx - 0.5) ** 2)
+    assert np.abs(phi - np.abs(r - 0.33)).max() < 1.5 * dx
+
+
+def test_sdf_signed_fab(ctx):
+    """isosurface.cpp:1637-1650: sign from the iso component, magnitude clipped at dmax"""
+    rng = np.random.default_rng(5)
+    lo, hi = (3, -2, 7), (10, 6, 12)
+    n = tuple(h - l + 1 for l, h in zip(lo, hi))
+    phi = rng.random(n[::-1]).astype(np.float32)
+    state = rng.random((2,) + n[::-1]) * 2000.0
+    dmax, iso = 0.6, 1000.0
+    dphi, dst = capi.DevBuf.from_numpy(ctx, phi), capi.DevBuf.from_numpy(ctx, state)
+    ddist = capi.DevBuf(ctx, 8 * phi.size)
+    fs, fd, bx = capi.PaFab(), capi.PaFab(), capi.PaBox()
+    for d in range(3):
+        fs.lo[d] = fd.lo[d] = bx.lo[d] = lo[d]
+        fs.hi[d] = fd.hi[d] = bx.hi[d] = hi[d]
+    fs.p, fs.ncomp, fs.nstride = dst.ptr, 2, 0
+    fd.p, fd.ncomp, fd.nstride = ddist.ptr, 1, 0
+    ctx.check(ctx.lib.pa_sdf_signed_fab(ctx.h, bx, C.c_void_p(dphi.ptr), C.byref(fs), 1, iso, dmax, C.byref(fd), 0))
+    ctx.sync()
+    got = ddist.to_numpy(np.float64, n[::-1])
+    want = np.where(state[1] < iso, -1.0, 1.0) * np.minimum(dmax, phi.astype(np.float64))
+    assert np.array_equal(got.view(np.int64), want.view(np.int64))
