@@ -353,13 +353,14 @@ def iso_merge(fragments, ncomp):
     return nodes, elts
 
 
-def iso_fab_inputs(levels, states, lev, b, ng=1):
-    """mask (isosurface.cpp:1540-1563) and loop box (:1566-1569) of box b; state fab as a contiguous array"""
+def iso_fab_inputs(levels, states, lev, b, ng=1, fine_mask=True):
+    """mask (isosurface.cpp:1540-1563; all 1 when building the distance function, :1542) and loop box
+    (:1566-1569) of box b grown by ng"""
     L = levels[lev]
     lo, hi = L.boxes[b, :3] - ng, L.boxes[b, 3:] + ng
     shape = tuple(int(x) for x in (hi - lo + 1)[::-1])
     mask = np.ones(shape)
-    if lev + 1 < len(levels):
+    if fine_mask and lev + 1 < len(levels):
         for fb in levels[lev + 1].boxes:
             clo, chi = fb[:3] // 2, fb[3:] // 2  # coarsen (non-negative indices)
             ilo, ihi = np.maximum(lo, clo), np.minimum(hi, chi)
@@ -370,35 +371,82 @@ def iso_fab_inputs(levels, states, lev, b, ng=1):
     return lo, hi, mask, llo, lhi
 
 
-def isosurface_pipeline(levels, fields, comps, isocomp_index, isoval, MF):
-    """isosurface.cpp:1434-1728 (non-periodic, nGrow = 1, rm_external_elements is a no-op then).
-    fields[l]: multifab holding the plotfile components; comps: which of them to map; the iso
-    component is comps[isocomp_index].  Returns (nodes [N][3+len(comps)], elements [M][3] 0-based)."""
+def iso_ngrow(levels, build_distance, dmax=None, ngrow=1):
+    """isosurface.cpp:1368-1382.  Quirk kept: with build_distance_function the level's cell size is taken
+    from probSize()[lev] (the domain length of DIRECTION lev) over the level's x extent.  Returns (nGrow
+    per level, dmax)."""
+    l0 = levels[0]
+    if dmax is None:
+        dmax = float(l0.prob_hi[0] - l0.prob_lo[0]) / float(l0.domhi[0] - l0.domlo[0] + 1)
+    if not build_distance:
+        return [int(ngrow)] * len(levels), dmax
+    out = []
+    for lev, lv in enumerate(levels):
+        d = min(lev, 2)
+        dxl = float(lv.prob_hi[d] - lv.prob_lo[d]) / float(lv.domhi[0] - lv.domlo[0] + 1)
+        out.append(int(dmax * (1.0000001) / dxl))
+    return out, dmax
+
+
+def isosurface_pipeline(levels, fields, comps, isocomp_index, isoval, MF, ngrow=1, rm_external=True, build_distance=False, dmax=None):
+    """isosurface.cpp:1434-1728 (non-periodic).  fields[l]: multifab holding the plotfile components;
+    comps: which of them to map; the iso component is comps[isocomp_index].  Returns (nodes
+    [N][3+len(comps)], elements [M][3] 0-based) and, with build_distance, also the list of distance
+    multifabs (1 comp, nGrow[lev] ghosts; :1595-1655) -- the reference writes their valid cells."""
     L = lib()
     nc = 3 + len(comps)
-    states, frags = [], []
+    ngs, dmax = iso_ngrow(levels, build_distance, dmax, ngrow)
+    states, frags, dists = [], [], []
     for l, lv in enumerate(levels):
-        st = MF(lv, nc, 1, fill=-666.0)
+        ng = ngs[l]
+        st = MF(lv, nc, ng, fill=-666.0)
         dx = lv.dx
         for b in range(lv.nboxes):
             f = st.fab(b)
-            lo = lv.boxes[b, :3] - 1
+            lo = lv.boxes[b, :3] - ng
             nz, ny, nx = f.shape[1:]
             f[0] = ((np.arange(lo[0], lo[0] + nx) + 0.5) * dx[0] + lv.prob_lo[0])[None, None, :]
             f[1] = ((np.arange(lo[1], lo[1] + ny) + 0.5) * dx[1] + lv.prob_lo[1])[None, :, None]
             f[2] = ((np.arange(lo[2], lo[2] + nz) + 0.5) * dx[2] + lv.prob_lo[2])[:, None, None]
             for n, c in enumerate(comps):
                 st.valid(b)[3 + n] = fields[l].valid(b)[c]
-        fill_boundary(st, 0, nc, 1)
+        fill_boundary(st, 0, nc, ng)
         if l > 0:
-            nbad = L.orc_fillpatch_two_levels(_p(_mf(st)), _p(_mf(states[l - 1])), 0, nc, 1, 2, 0)
+            nbad = L.orc_fillpatch_two_levels(_p(_mf(st)), _p(_mf(states[l - 1])), 0, nc, ng, 2, 0)
             assert nbad == 0
         states.append(st)
     for l, lv in enumerate(levels):
+        ng = ngs[l]
+        dist = MF(lv, 1, ng) if build_distance else None
         for b in range(lv.nboxes):
-            lo, hi, mask, llo, lhi = iso_fab_inputs(levels, states, l, b)
-            if np.any(llo > lhi):
-                continue
-            verts, _, tris = mc_fab(np.ascontiguousarray(states[l].fab(b)), mask, lo, hi, 3 + isocomp_index, isoval, llo, lhi)
-            frags.append((verts, tris))
-    return iso_merge(frags, nc)
+            lo, hi, mask, llo, lhi = iso_fab_inputs(levels, states, l, b, ng, fine_mask=not build_distance)
+            sfab = np.ascontiguousarray(states[l].fab(b))
+            verts = np.zeros((0, nc))
+            vkeys = np.zeros((0, 6), np.int32)
+            tris = np.zeros((0, 3), np.int32)
+            if not np.any(llo > lhi):
+                verts, vkeys, tris = mc_fab(sfab, mask, lo, hi, 3 + isocomp_index, isoval, llo, lhi)
+            if build_distance:
+                if len(tris) > 0:  # :1596-1650
+                    dxf = lv.dx
+                    origin = np.array([lv.prob_lo[d] + float(lo[d]) * dxf[d] for d in range(3)]).astype(np.float32)  # Vec3f(local_origin)
+                    n = tuple(int(x) for x in (hi - lo + 1))
+                    phi = sdf_level_set(tris.astype(np.uint32), verts[:, :3].astype(np.float32), origin, np.float32(dxf[0]), n, 1)
+                    abs_d = np.minimum(dmax, phi.astype(np.float64))
+                    sgn = np.where(sfab[3 + isocomp_index] < isoval, -1.0, 1.0)
+                    dist.fab(b)[0] = sgn * abs_d
+                else:  # :1651-1654
+                    dist.fab(b)[0] = -dmax if states[l].valid(b)[3 + isocomp_index][0, 0, 0] < isoval else dmax
+            if rm_external and len(verts):  # :1657-1682: vertices whose edge leaves the valid box grown by 1, and their elements
+                glo, ghi = lv.boxes[b, :3] - 1, lv.boxes[b, 3:] + 1
+                inside = np.all((vkeys[:, :3] >= glo) & (vkeys[:, :3] <= ghi) & (vkeys[:, 3:] >= glo) & (vkeys[:, 3:] <= ghi), axis=1)
+                if not inside.all():
+                    remap = np.cumsum(inside) - 1
+                    keep_t = inside[tris].all(axis=1) if len(tris) else np.zeros(0, bool)
+                    tris = remap[tris[keep_t]].astype(np.int32).reshape(-1, 3)
+                    verts = verts[inside]
+            if len(verts):
+                frags.append((verts, tris))
+        dists.append(dist)
+    nodes, elts = iso_merge(frags, nc)
+    return (nodes, elts, dists) if build_distance else (nodes, elts)

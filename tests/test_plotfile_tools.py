@@ -167,6 +167,35 @@ def test_isosurface_tool_end_to_end(tmp_path, oracle):
 
 
 @pytest.mark.gpu
+def test_isosurface_tool_distance_function(tmp_path, oracle):
+    """build_distance_function=1 (isosurface.cpp:1361-1381, 1595-1655, 1731-1748): the "distance" plotfile
+    and the (unmasked) surface identical to the oracle's -- whose make_level_set3 is pinned to the reference
+    build; nGrow = 1, 2, 4 on the three levels, so the element trimming of :1657-1682 is exercised too"""
+    p, H, mfs = _synth(tmp_path, nlev=3, base=16, box=8, per=(0, 0, 0))
+    out = _run("isosurface3d.ex", ["infile=" + p, "isoCompName=temp", "isoVal=1150", "comps=0 2", "build_distance_function=1", "outfile=" + str(tmp_path / "dist")],
+               tmp_path)
+    assert "dmax: 0.0625" in out.stdout
+    fields = [MultiFab(lv, 3, 0, mfs[l].data.copy()) for l, lv in enumerate(H.levels)]
+    onodes, oelts, odist = oracle.isosurface_pipeline(H.levels, fields, [0, 2], 0, 1150.0, MultiFab, build_distance=True)
+    assert [d.ng for d in odist] == [1, 2, 4]
+    r = read_plotfile(str(tmp_path / "dist"))
+    assert r.names == ["distance"] and r.time == 0.125 and r.level_steps == [5, 5, 5]
+    for l, lv in enumerate(H.levels):
+        for b in range(lv.nboxes):
+            got, want = np.ascontiguousarray(r.mfs[l].valid(b)[0]), np.ascontiguousarray(odist[l].valid(b)[0])
+            assert np.array_equal(got.view(np.int64), want.view(np.int64)), (l, b)
+        v = r.mfs[l].valid_concat(0)
+        assert np.abs(v).max() == 0.0625 and (np.abs(v) < 0.0625).any()
+    label, names, nodes, faces = read_mef(p + "_temp_1150.mef")
+    assert np.array_equal(faces, oelts + 1) and np.array_equal(nodes.view(np.int64), onodes.view(np.int64))
+    # plain surface with two ghost layers: trimming leaves the one-ghost-layer surface
+    _run("isosurface3d.ex", ["infile=" + p, "isoCompName=temp", "isoVal=1150", "comps=0 2", "nGrow=2", "outfile_base=" + str(tmp_path / "g2")], tmp_path)
+    _, _, nodes2, faces2 = read_mef(str(tmp_path / "g2.mef"))
+    on2, oe2 = oracle.isosurface_pipeline(H.levels, fields, [0, 2], 0, 1150.0, MultiFab, ngrow=2)
+    assert np.array_equal(faces2, oe2 + 1) and np.array_equal(nodes2.view(np.int64), on2.view(np.int64))
+
+
+@pytest.mark.gpu
 def test_curvature_tool_options(tmp_path, oracle):
     """do_gaussCurv=1 do_strain=1 getStrainTensor=1 do_velnormal=1: names (curvature.cpp:796-831) and values"""
     p, H, mfs = _synth(tmp_path, nlev=2, ncomp=4, names=("temp", "x_velocity", "y_velocity", "z_velocity"))

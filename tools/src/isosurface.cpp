@@ -5,7 +5,12 @@
 // Per FAB the cube classification, ballot/prefix-sum compaction, edge interpolation and triangle
 // emission run on the GPU (libpeleanalysis_amd); the global node/element sets are merged on the
 // host in FAB order, which reproduces the reference's node numbering on one rank.
-// Not ported yet: build_distance_function, nGrow != 1, periodic directions (quirk Q5), XDMF.
+//       [nGrow=1] [rm_external_elements=1] [build_distance_function=0 [dmax=<dx0>] [outfile=distance]]
+// build_distance_function (isosurface.cpp:1361-1381, 1595-1655, 1731-1748): per FAB the marching-cubes
+// triangles of the box grown by nGrow[lev] = int(dmax*1.0000001/dx_lev) feed the GPU distance function
+// (pa_sdf_level_set3 = Tools/SDFGen make_level_set3, batched over all FABs of a level), signed with
+// the iso component and clipped at dmax; written as a one-component plotfile "distance".
+// Not ported yet: periodic directions (quirk Q5), XDMF.
 #include "../common/pa_device.h"
 #include "../common/pa_isomerge.h"
 
@@ -45,11 +50,27 @@ int main(int argc, char** argv) {
   pp.query("finestLevel", finestLevel);
   finestLevel = std::min(finestLevel, H.nlev - 1);
   const int Nlev = finestLevel + 1;
-  int build_distance_function = 0, nGrow = 1;
+  int build_distance_function = 0, rm_external_elements = 1;
+  pp.query("rm_external_elements", rm_external_elements);
   pp.query("build_distance_function", build_distance_function);
-  pp.query("nGrow", nGrow);
-  if (build_distance_function) pa::Abort("build_distance_function is not available in this build");
-  if (nGrow != 1) pa::Abort("only nGrow=1 is available in this build");
+  // ghost layers per level (isosurface.cpp:1368-1382).  Quirk kept: the reference computes the level's
+  // cell size from probSize()[lev] -- the domain length of DIRECTION lev -- over the level's x extent.
+  std::vector<int> nGrow(Nlev, 1);
+  double dmax = (H.prob_hi[0] - H.prob_lo[0]) / (double)(H.lev[0].domain.hi[0] - H.lev[0].domain.lo[0] + 1);
+  if (build_distance_function) {
+    pp.query("dmax", dmax);
+    std::cout << "dmax: " << dmax << std::endl;
+    for (int lev = 0; lev < Nlev; ++lev) {
+      const int dl = std::min(lev, 2);
+      const double dxL = (H.prob_hi[dl] - H.prob_lo[dl]) / (double)(H.lev[lev].domain.hi[0] - H.lev[lev].domain.lo[0] + 1);
+      nGrow[lev] = (int)(dmax * (1.0000001) / dxL);
+      if (nGrow[lev] < 1) pa::Abort("dmax is smaller than a cell of level " + std::to_string(lev) + ": no ghost layer to polygonise");
+    }
+  } else {
+    pp.query("nGrow", nGrow[0]);
+    if (nGrow[0] < 1) pa::Abort("nGrow must be at least 1");
+    for (int lev = 1; lev < Nlev; ++lev) nGrow[lev] = nGrow[0];
+  }
   std::vector<int> is_per(3, 0);
   pp.queryarr("is_per", is_per, 0, 3);
   if (is_per[0] || is_per[1] || is_per[2]) pa::Abort("periodic directions are not available in this build (the reference leaves bad data there too)");
@@ -60,15 +81,16 @@ int main(int argc, char** argv) {
   std::vector<pa::HostMF> host(Nlev);
   for (int lev = 0; lev < Nlev; ++lev) {
     const auto& L = H.lev[lev];
-    host[lev].define(L.boxes, nc, 1);
+    const int ng = nGrow[lev];
+    host[lev].define(L.boxes, nc, ng);
     std::fill(host[lev].data.begin(), host[lev].data.end(), -666.0);  // gstate.setVal(-666) (isosurface.cpp:1512)
     double dx[3];
     for (int d = 0; d < 3; ++d) dx[d] = (H.prob_hi[d] - H.prob_lo[d]) / (double)(L.domain.hi[d] - L.domain.lo[d] + 1);
     for (size_t b = 0; b < L.boxes.size(); ++b) {  // cell-centre coordinates incl. ghosts (isosurface.cpp:1458-1465)
       const pa::Box3& B = L.boxes[b];
-      for (int k = B.lo[2] - 1; k <= B.hi[2] + 1; ++k)
-        for (int j = B.lo[1] - 1; j <= B.hi[1] + 1; ++j)
-          for (int i = B.lo[0] - 1; i <= B.hi[0] + 1; ++i) {
+      for (int k = B.lo[2] - ng; k <= B.hi[2] + ng; ++k)
+        for (int j = B.lo[1] - ng; j <= B.hi[1] + ng; ++j)
+          for (int i = B.lo[0] - ng; i <= B.hi[0] + ng; ++i) {
             *host[lev].ptr((int)b, 0, i, j, k) = (i + 0.5) * dx[0] + H.prob_lo[0];
             *host[lev].ptr((int)b, 1, i, j, k) = (j + 0.5) * dx[1] + H.prob_lo[1];
             *host[lev].ptr((int)b, 2, i, j, k) = (k + 0.5) * dx[2] + H.prob_lo[2];
@@ -76,11 +98,11 @@ int main(int argc, char** argv) {
     }
     for (int n = 0; n < nComp; ++n) pa::read_comp(H, lev, pltComps[n], host[lev], 3 + n);
     dl.emplace_back(new pa::DevLevel(ctx, L.boxes, L.domain, is_per.data(), H.prob_lo, H.prob_hi));
-    dst.emplace_back(new pa::DevMF(ctx, *dl.back(), nc, 1));
+    dst.emplace_back(new pa::DevMF(ctx, *dl.back(), nc, ng));
     ctx.check(pa_mf_upload(ctx.h, dst.back()->h, host[lev].data.data()));
     std::cout << "FillPatching the grown structures at level " << lev << "..." << std::endl;
-    ctx.check(pa_fill_boundary(ctx.h, dst[lev]->h, 0, nc, 1));
-    if (lev > 0) ctx.check(pa_fillpatch_two_levels(ctx.h, dst[lev]->h, dst[lev - 1]->h, 0, nc, 1, 2, 0));  // PCInterp
+    ctx.check(pa_fill_boundary(ctx.h, dst[lev]->h, 0, nc, ng));
+    if (lev > 0) ctx.check(pa_fillpatch_two_levels(ctx.h, dst[lev]->h, dst[lev - 1]->h, 0, nc, ng, 2, 0));  // PCInterp
     std::cout << "...done FillPatching the grown structures at level " << lev << "..." << std::endl;
   }
   ctx.check(pa_sync(ctx.h));
@@ -88,16 +110,30 @@ int main(int argc, char** argv) {
 
   pa::IsoMerger merger(nc);
   std::vector<double> mask, hv;
-  std::vector<int32_t> ht;
+  std::vector<int32_t> ht, hk;
+  std::vector<pa::HostMF> hdist(build_distance_function ? Nlev : 0);
   for (int lev = 0; lev < Nlev; ++lev) {
     const auto& L = H.lev[lev];
+    const int ng = nGrow[lev];
     double* base = pa_mf_data(dst[lev]->h);
+    // distance function: one grid per FAB that holds triangles, run as one batch per level
+    std::unique_ptr<pa::DevMF> ddist;
+    std::vector<pa_sdf_grid> grids;
+    std::vector<size_t> grid_box;
+    std::vector<void*> grid_bufs;
+    std::vector<char> has_elts(L.boxes.size(), 0);
+    double dxf[3];
+    for (int d = 0; d < 3; ++d) dxf[d] = (H.prob_hi[d] - H.prob_lo[d]) / (double)(L.domain.hi[d] - L.domain.lo[d] + 1);
+    if (build_distance_function) {
+      hdist[lev].define(L.boxes, 1, ng);
+      ddist.reset(new pa::DevMF(ctx, *dl[lev], 1, ng));
+    }
     for (size_t b = 0; b < L.boxes.size(); ++b) {
       const pa::Box3& B = L.boxes[b];
-      pa::Box3 g{{B.lo[0] - 1, B.lo[1] - 1, B.lo[2] - 1}, {B.hi[0] + 1, B.hi[1] + 1, B.hi[2] + 1}};
+      pa::Box3 g{{B.lo[0] - ng, B.lo[1] - ng, B.lo[2] - ng}, {B.hi[0] + ng, B.hi[1] + ng, B.hi[2] + ng}};
       const long long nx = g.hi[0] - g.lo[0] + 1, ny = g.hi[1] - g.lo[1] + 1;
       mask.assign((size_t)g.numPts(), 1.0);
-      if (lev < finestLevel)  // fine-covered mask (isosurface.cpp:1540-1563)
+      if (lev < finestLevel && !build_distance_function)  // fine-covered mask (isosurface.cpp:1540-1563)
         for (const pa::Box3& F : H.lev[lev + 1].boxes) {
           int lo[3], hi[3];
           bool ok = true;
@@ -129,6 +165,7 @@ int main(int argc, char** argv) {
       int64_t nv = 0, nt = 0;
       ctx.check(pa_mc_count_fab(ctx.h, loop, &fs, &fm, 3 + isoComp, isoVal, &nv, &nt));
       if (nt > 0) {
+        has_elts[b] = 1;
         void* dv = pa_device_malloc(ctx.h, nv * nc * 8);
         void* dk = pa_device_malloc(ctx.h, nv * 6 * 4);
         void* dt = pa_device_malloc(ctx.h, nt * 3 * 4);
@@ -136,13 +173,98 @@ int main(int argc, char** argv) {
         ctx.check(pa_mc_emit_fab(ctx.h, loop, &fs, &fm, 3 + isoComp, isoVal, (double*)dv, (int32_t*)dk, (int32_t*)dt, nv, nt));
         hv.resize((size_t)(nv * nc));
         ht.resize((size_t)(nt * 3));
+        hk.resize((size_t)(nv * 6));
         ctx.check(pa_memcpy_d2h(ctx.h, hv.data(), dv, nv * nc * 8));
         ctx.check(pa_memcpy_d2h(ctx.h, ht.data(), dt, nt * 3 * 4));
-        merger.add(hv.data(), nv, ht.data(), nt);  // with nGrow = 1 rm_external_elements removes nothing
-        pa_device_free(ctx.h, dv); pa_device_free(ctx.h, dk); pa_device_free(ctx.h, dt);
+        ctx.check(pa_memcpy_d2h(ctx.h, hk.data(), dk, nv * 6 * 4));
+        if (build_distance_function) {
+          // vertList / faceList of this FAB BEFORE trimming (isosurface.cpp:1598-1626); Vec3f(loc) rounds to float
+          std::vector<float> xf((size_t)nv * 3);
+          for (int64_t q = 0; q < nv; ++q)
+            for (int d = 0; d < 3; ++d) xf[(size_t)q * 3 + d] = (float)hv[(size_t)q * nc + d];
+          pa_sdf_grid G;
+          G.ntri = nt; G.nvert = nv;
+          void* dx3 = pa_device_malloc(ctx.h, nv * 3 * 4);
+          void* dphi = pa_device_malloc(ctx.h, g.numPts() * 4);
+          if (!dx3 || !dphi) pa::Abort(pa_last_error(ctx.h));
+          ctx.check(pa_memcpy_h2d(ctx.h, dx3, xf.data(), nv * 3 * 4));
+          G.tri = (const uint32_t*)dt;  // local vertex ids in vertCache order = ptID (isosurface.cpp:1602-1611)
+          G.x = (const float*)dx3;
+          for (int d = 0; d < 3; ++d) {
+            G.origin[d] = (float)(H.prob_lo[d] + g.lo[d] * dxf[d]);  // local_origin: the box's low NODE (quirk: not the cell centre)
+            G.n[d] = g.hi[d] - g.lo[d] + 1;
+          }
+          G.dx = (float)dxf[0];
+          G.phi = (float*)dphi;
+          grids.push_back(G);
+          grid_box.push_back(b);
+          grid_bufs.push_back(dt); grid_bufs.push_back(dx3); grid_bufs.push_back(dphi);
+        } else {
+          pa_device_free(ctx.h, dt);
+        }
+        // elements with a vertex whose edge is not inside the valid box grown by 1 are dropped, with those
+        // vertices (isosurface.cpp:1657-1682); a no-op when nGrow = 1
+        long long nvk = nv, ntk = nt;
+        if (rm_external_elements && ng > 1) {
+          std::vector<int32_t> remap((size_t)nv);
+          nvk = 0;
+          for (int64_t q = 0; q < nv; ++q) {
+            bool in = true;
+            for (int d = 0; d < 3; ++d) {
+              const int a = hk[(size_t)q * 6 + d], c = hk[(size_t)q * 6 + 3 + d];
+              in = in && a >= B.lo[d] - 1 && a <= B.hi[d] + 1 && c >= B.lo[d] - 1 && c <= B.hi[d] + 1;
+            }
+            remap[(size_t)q] = in ? (int32_t)nvk : -1;
+            if (in) {
+              if (nvk != q) std::copy(hv.begin() + q * nc, hv.begin() + (q + 1) * nc, hv.begin() + nvk * nc);
+              ++nvk;
+            }
+          }
+          ntk = 0;
+          for (int64_t t = 0; t < nt; ++t) {
+            const int32_t a = remap[(size_t)ht[(size_t)t * 3]], c = remap[(size_t)ht[(size_t)t * 3 + 1]], e = remap[(size_t)ht[(size_t)t * 3 + 2]];
+            if (a < 0 || c < 0 || e < 0) continue;
+            ht[(size_t)ntk * 3] = a; ht[(size_t)ntk * 3 + 1] = c; ht[(size_t)ntk * 3 + 2] = e;
+            ++ntk;
+          }
+        }
+        merger.add(hv.data(), nvk, ht.data(), ntk);
+        pa_device_free(ctx.h, dv); pa_device_free(ctx.h, dk);
       }
       pa_device_free(ctx.h, dmask);
     }
+    if (build_distance_function) {
+      ctx.check(pa_sdf_level_set3(ctx.h, (int)grids.size(), grids.data(), 1));
+      double* dbase = pa_mf_data(ddist->h);
+      for (size_t q = 0; q < grids.size(); ++q) {  // isosurface.cpp:1632-1650
+        const size_t b = grid_box[q];
+        const pa::Box3& B = L.boxes[b];
+        pa_box vb;
+        pa_fab fs, fd;
+        fs.p = base + host[lev].off[b]; fs.ncomp = nc; fs.nstride = host[lev].cs[b];
+        fd.p = dbase + hdist[lev].off[b]; fd.ncomp = 1; fd.nstride = hdist[lev].cs[b];
+        for (int d = 0; d < 3; ++d) { vb.lo[d] = fs.lo[d] = fd.lo[d] = B.lo[d] - ng; vb.hi[d] = fs.hi[d] = fd.hi[d] = B.hi[d] + ng; }
+        ctx.check(pa_sdf_signed_fab(ctx.h, vb, grids[q].phi, &fs, 3 + isoComp, isoVal, dmax, &fd, 0));
+      }
+      ctx.check(pa_mf_download(ctx.h, ddist->h, hdist[lev].data.data()));
+      for (void* p : grid_bufs) pa_device_free(ctx.h, p);
+      for (size_t b = 0; b < L.boxes.size(); ++b) {  // FABs without triangles: +-dmax from the first valid cell (isosurface.cpp:1651-1654)
+        if (has_elts[b]) continue;
+        const pa::Box3& B = L.boxes[b];
+        const double v = *host[lev].ptr((int)b, 3 + isoComp, B.lo[0], B.lo[1], B.lo[2]) < isoVal ? -dmax : dmax;
+        for (int k = B.lo[2] - ng; k <= B.hi[2] + ng; ++k)
+          for (int j = B.lo[1] - ng; j <= B.hi[1] + ng; ++j)
+            for (int i = B.lo[0] - ng; i <= B.hi[0] + ng; ++i) *hdist[lev].ptr((int)b, 0, i, j, k) = v;
+      }
+    }
+  }
+  if (build_distance_function) {  // isosurface.cpp:1731-1748
+    std::string outfile("distance");
+    pp.query("outfile", outfile);
+    std::vector<pa::Box3> doms;
+    std::vector<int> steps;
+    for (int lev = 0; lev < Nlev; ++lev) { doms.push_back(H.lev[lev].domain); steps.push_back(H.lev[lev].level_step); }
+    pa::write_plotfile(outfile, {"distance"}, doms, H.prob_lo, H.prob_hi, hdist, H.time, steps);
   }
   merger.finish();
   const std::vector<int32_t> elts = merger.elements();
