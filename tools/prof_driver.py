@@ -22,7 +22,8 @@ rng = np.random.default_rng(1)
 states, works, outs = [], [], []
 for lv, dl in zip(H.levels, dls):
     s = MultiFab(lv, 1, 2)
-    s.data[:] = 300.0 + 1700.0 * rng.random(s.total)
+    blk = 300.0 + 1700.0 * rng.random(1 << 22)  # incompressible block, tiled (a full-size draw costs seconds per pass)
+    s.data[:] = np.resize(blk, s.total)
     states.append(capi.DevMF.from_host(ctx, dl, s))
     works.append(capi.DevMF(ctx, dl, 1, 2))
     outs.append(capi.DevMF(ctx, dl, 8, 0))
