@@ -18,6 +18,9 @@
 #include "pa_fused_march3.h"
 #include <cstdlib>
 
+#ifndef PA_FC_WAVES
+#define PA_FC_WAVES 3  /* measured: 1 -> 1.30, 2 -> 1.34, 3 -> 1.21, 4 (spills) -> 2.28 ms of face fix-up per step */
+#endif
 struct Vec3 { double x, y, z; };
 
 // flame normal n = G/normgrad at cell (i,j,k), from c
@@ -69,7 +72,7 @@ __global__ __launch_bounds__(256) void k_faces_normal(DLevelView L, DMFView MC_,
 // normals of MLMG applyBC on n_d (curvature.cpp:510-546).  Normals of cells of this box are read
 // back from the output (exact after phase A) unless the threshold clip zeroed them there; normals
 // of valid cells of neighbouring boxes are recomputed from the local ghost c.
-__global__ __launch_bounds__(256) void k_faces_curv(DLevelView L, DMFView MC_, int ccomp, DLevelView LCr, DMFView MN, int cncomp0, DMFView MO,
+__global__ __launch_bounds__(256, PA_FC_WAVES) void k_faces_curv(DLevelView L, DMFView MC_, int ccomp, DLevelView LCr, DMFView MN, int cncomp0, DMFView MO,
                                                     int ncomp0, int kcomp, FaceArgs A, int* nbad) {
   int b, fdir, side, layer, q0[3];
   DBox B;
@@ -221,7 +224,7 @@ static void march_launch(hipStream_t st, const BP& bp, int nx, int ny, int nz, u
     else if (clip) hipLaunchKernelGGL((k_gradcurv_march3<BP, M, true>), g, dim3(64 * (M + 3)), 0, st, bp, A);          \
     else hipLaunchKernelGGL((k_gradcurv_march3<BP, M, false>), g, dim3(64 * (M + 3)), 0, st, bp, A);                   \
   } return;
-      PA_CASE3(4) PA_CASE3(8) PA_CASE3(12) PA_CASE3(13)
+      PA_CASE3(4) PA_CASE3(8) PA_CASE3(9) PA_CASE3(10) PA_CASE3(11) PA_CASE3(12) PA_CASE3(13)
 #undef PA_CASE3
       default: break;
     }
