@@ -148,16 +148,30 @@ __device__ __forceinline__ void relax_point(const SdfGrid& G, int i, int j, int 
   float phi = G.phi[q];
   int ct = G.ct[q];
   const long long nb[7] = {q - di, q - dj * sj, q - di - dj * sj, q - dk * sk, q - di - dk * sk, q - dj * sj - dk * sk, q - di - dj * sj - dk * sk};
+  // A triangle whose distance to this point is already known to be >= phi cannot pass the strict
+  // `d < phi` test: the point's own closest triangle (d == phi when phi came from it -- phi always is
+  // the distance to triangle ct once ct >= 0) and a triangle already tried in this call.  Skipping
+  // those evaluations changes nothing in the result; after the first sweeps most neighbours share
+  // the point's triangle.
+  int tried[7];
+  const int ct0 = ct;
+  bool changed = false;
 #pragma unroll
   for (int m = 0; m < 7; ++m) {
     const int t = G.ct[nb[m]];
-    if (t >= 0) {
+    tried[m] = t;
+    bool skip = (t < 0) || (t == ct0);
+#pragma unroll
+    for (int r = 0; r < m; ++r) skip = skip || (tried[r] == t);
+    if (!skip) {
       const float d = dist_to_tri(G, gx, t);
-      if (d < phi) { phi = d; ct = t; }
+      if (d < phi) { phi = d; ct = t; changed = true; }
     }
   }
-  G.phi[q] = phi;
-  G.ct[q] = ct;
+  if (changed) {
+    G.phi[q] = phi;
+    G.ct[q] = ct;
+  }
 }
 
 // :60-85 + :169-178: one workgroup per grid, hyperplane by hyperplane

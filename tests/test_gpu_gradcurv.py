@@ -113,6 +113,32 @@ def test_gradcurv_fused_wide_boxes(ctx, oracle, threshold, pair, monkeypatch):
         assert_valid_bits_equal(got, oc[l], [(4, 2), (5, 3), (6, 4), (7, 1)], f"wide curv level {l}")
 
 
+def test_gradcurv_four_levels_many_components(ctx, oracle):
+    """BASELINE config 5 in small: 4 levels (PeleLMeX-style nesting), several components (species-like
+    fields with different phases/amplitudes) pushed through the fused grad->curvature pipeline one after
+    the other into recycled output buffers, each compared with the oracle's grad + curvature tools"""
+    from peleanalysis_amd.hierarchy import nested_hierarchy, field_flame
+    H = nested_hierarchy(16, 4, 8, is_per=(1, 1, 0))
+    ncomp = 5
+    states = make_states(H, ncomp, 2, field_flame, seed=31)
+    bc = capi.bc_from_flags((1, 1, 0), (0, 0, 0))
+    dls, dst = _dev(ctx, H, states)
+    work = [capi.DevMF(ctx, dl, 1, 2) for dl in dls]
+    dout = [capi.DevMF(ctx, dl, 8, 0) for dl in dls]
+    for c in range(ncomp):
+        og = [MultiFab(lv, 4, 0) for lv in H.levels]
+        oracle.grad_pipeline(H.levels, [s.copy() for s in states], c, bc, og, 0, multipass=True)
+        oc = [MultiFab(lv, 5, 0) for lv in H.levels]
+        oracle.curvature_pipeline(H.levels, [s.copy() for s in states], c, bc, oc, 0, MultiFab)
+        capi.gradcurv_run(ctx, dst, c, bc, capi.curv_params(fused=True), work, dout, 0)
+        ctx.sync()
+        assert ctx.bc_errors() == 0
+        for l in range(H.nlev):
+            got = dout[l].download()
+            assert_valid_bits_equal(got, og[l], [(k, k) for k in range(4)], f"comp {c} grad level {l}")
+            assert_valid_bits_equal(got, oc[l], [(4, 2), (5, 3), (6, 4), (7, 1)], f"comp {c} curv level {l}")
+
+
 def test_ghost_fill_matches_oracle(ctx, oracle):
     """FillBoundary (ng=2, edges+corners) and applyBC individually, all ghost cells compared"""
     H, per, sym, fn = build_config("amr3_wall_z")

@@ -1,0 +1,121 @@
+#!/usr/bin/env python3
+"""Per-kernel measurements of the non-headline kernels of the path: grad,
+box filter, marching cubes, distance function, on one 512^3 level of 128^3 boxes (SURVEY 8d sizes),
+timed with the library's own HIP events on its stream (pa_profile_*).  Algorithmic bytes per cell as in
+SURVEY 8(d).  usage: python tools/kernel_bench.py [n=512] [box=128]   (prints one JSON object)"""
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402  (torch first: one HIP runtime; used for device-side synthetic data)
+
+from peleanalysis_amd import capi  # noqa: E402
+from peleanalysis_amd.hierarchy import Level, chop_box, mf_layout  # noqa: E402
+
+HBM = 8000.0
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+box = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+dev = torch.device("cuda", 0)
+stream = torch.cuda.Stream(device=dev)
+ctx = capi.Context(0, stream.cuda_stream)
+lv = Level(chop_box((0, 0, 0), (n - 1,) * 3, box), (0, 0, 0), (n - 1,) * 3, (1, 1, 1), (0, 0, 0), (1, 1, 1))
+dl = capi.DevLevel(ctx, lv)
+cells = lv.ncells
+out = {"level": f"{n}^3, {lv.nboxes} boxes of {box}^3, periodic", "cells": cells, "hbm_peak_GBs": HBM, "kernels": {}}
+
+
+def dev_mf(ncomp, ng, fill_random=True):
+    _, _, tot = mf_layout(lv.boxes, ncomp, ng)
+    with torch.cuda.stream(stream):
+        t = (300.0 + 1700.0 * torch.rand(tot, dtype=torch.float64, device=dev)) if fill_random else torch.zeros(tot, dtype=torch.float64, device=dev)
+    stream.synchronize()
+    return t, capi.DevMF(ctx, dl, ncomp, ng, t.data_ptr())
+
+
+def timed(tag, fn, reps=5):
+    fn()
+    ctx.sync()
+    ctx.profile_read(tag, reset=True)
+    ctx.profile_enable(True)
+    for _ in range(reps):
+        fn()
+    ctx.sync()
+    ctx.profile_enable(False)
+    nl, ms = ctx.profile_read(tag, reset=True)
+    return ms / reps
+
+
+# ---- grad (grad.cpp:211-236): read phi, write gx,gy,gz,|g| = 40 B/cell
+tphi, phi = dev_mf(1, 1)
+tout, gout = dev_mf(4, 0, False)
+ctx.check(ctx.lib.pa_fill_boundary(ctx.h, phi.h, 0, 1, 1))
+ms = timed(5, lambda: ctx.check(ctx.lib.pa_grad_level(ctx.h, phi.h, 0, gout.h, 0)))
+out["kernels"]["k_grad"] = {"ms": ms, "bytes_per_cell": 40, "GBs": cells * 40 / ms / 1e6, "frac_hbm": cells * 40 / ms / 1e6 / HBM, "Mcells_s": cells / ms / 1e3}
+del gout, tout
+
+# ---- box filter (filterPlt.cpp:217): 16 B/cell, fgr 2 / 4 / 8 -> 27 / 125 / 729 taps
+for fgr in (2, 4, 8):
+    w = (C.c_double * (fgr + 2))()
+    ng = ctx.lib.pa_box_filter_weights(fgr, w)
+    tin, fin = dev_mf(1, ng)
+    tfo, fo = dev_mf(1, 0, False)
+    ctx.check(ctx.lib.pa_fill_boundary(ctx.h, fin.h, 0, 1, ng))
+    ms = timed(7, lambda: ctx.check(ctx.lib.pa_boxfilter_level(ctx.h, fin.h, fo.h, 0, 1, ng, w)))
+    taps = (2 * ng + 1) ** 3
+    out["kernels"][f"k_boxfilter fgr={fgr} ({taps} taps)"] = {"ms": ms, "bytes_per_cell": 16, "GBs": cells * 16 / ms / 1e6, "frac_hbm": cells * 16 / ms / 1e6 / HBM,
+                                                             "Mcells_s": cells / ms / 1e3, "Gflop_s": cells * 2 * taps / ms / 1e6}
+    del fin, fo, tin, tfo
+
+# ---- marching cubes on one FAB (isosurface.cpp:1566-1592): scan 8 B/cell (+ mask 8 B/cell as the reference stores it)
+g = box + 2
+x = (torch.arange(g, device=dev, dtype=torch.float64) - 0.5) / box
+X, Y, Z = x[None, None, :].expand(g, g, g), x[None, :, None].expand(g, g, g), x[:, None, None].expand(g, g, g)
+r = torch.sqrt((X - 0.5) ** 2 + (Y - 0.5) ** 2 + (Z - 0.5) ** 2)
+with torch.cuda.stream(stream):
+    st = torch.stack([X, Y, Z, 300.0 + 1700.0 * 0.5 * (1 + torch.tanh((r - 0.3) / 0.05)), r]).contiguous()
+    mk = torch.ones((g, g, g), dtype=torch.float64, device=dev)
+stream.synchronize()
+fs, fm, bx = capi.PaFab(), capi.PaFab(), capi.PaBox()
+fs.p, fs.ncomp, fs.nstride = st.data_ptr(), 5, 0
+fm.p, fm.ncomp, fm.nstride = mk.data_ptr(), 1, 0
+for d in range(3):
+    fs.lo[d] = fm.lo[d] = -1
+    fs.hi[d] = fm.hi[d] = box
+    bx.lo[d], bx.hi[d] = -1, box - 1
+nv, nt = C.c_int64(0), C.c_int64(0)
+ms_count = timed(8, lambda: ctx.check(ctx.lib.pa_mc_count_fab(ctx.h, bx, fs, fm, 3, 1150.0, C.byref(nv), C.byref(nt))))
+tv = torch.empty(max(nv.value, 1) * 5, dtype=torch.float64, device=dev)
+tk = torch.empty(max(nv.value, 1) * 6, dtype=torch.int32, device=dev)
+tt = torch.empty(max(nt.value, 1) * 3, dtype=torch.int32, device=dev)
+ms_emit = timed(8, lambda: ctx.check(ctx.lib.pa_mc_emit_fab(ctx.h, bx, fs, fm, 3, 1150.0, tv.data_ptr(), tk.data_ptr(), tt.data_ptr(), nv.value, nt.value)))
+fc = g ** 3
+out["kernels"]["k_mc count (classify+count+scan, 1 FAB)"] = {"ms": ms_count, "cells": fc, "Mcells_s": fc / ms_count / 1e3, "bytes_per_cell": 16,
+                                                            "GBs": fc * 16 / ms_count / 1e6, "note": "includes the synchronous 16-byte D2H of the totals"}
+out["kernels"]["k_mc emit (count again + vertices + triangles, 1 FAB)"] = {"ms": ms_emit, "vertices": nv.value, "triangles": nt.value,
+                                                                         "Mtriangles_s": nt.value / ms_emit / 1e3, "Mcells_s": fc / ms_emit / 1e3}
+
+# ---- distance function (make_level_set3) on that FAB's mesh: one grid, and a batch of 64 grids
+xf = tv.view(-1, 5)[:, :3].to(torch.float32).contiguous()
+phis = [torch.empty(g ** 3, dtype=torch.float32, device=dev) for _ in range(64)]
+grids = (capi.PaSdfGrid * 64)()
+for q, gr in enumerate(grids):
+    gr.ntri, gr.tri, gr.nvert, gr.x = nt.value, tt.data_ptr(), nv.value, xf.data_ptr()
+    for d in range(3):
+        gr.origin[d] = np.float32(-1.0 / box)
+        gr.n[d] = g
+    gr.dx = np.float32(1.0 / box)
+    gr.phi = phis[q].data_ptr()
+for nb in (1, 64):
+    ctx.check(ctx.lib.pa_sdf_level_set3(ctx.h, nb, grids, 1))
+    ctx.sync()
+    t0 = time.perf_counter()
+    ctx.check(ctx.lib.pa_sdf_level_set3(ctx.h, nb, grids, 1))
+    ctx.sync()
+    dt = (time.perf_counter() - t0) * 1e3
+    out["kernels"][f"sdf make_level_set3, {nb} grid(s) of {g}^3, {nt.value} triangles each"] = {"ms": dt, "Mpoints_s": nb * g ** 3 / dt / 1e3}
+print(json.dumps(out, indent=1))
