@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--box", type=int, default=128)
     ap.add_argument("--ncomp", type=int, default=1, help="components pushed through grad->curvature per step")
     ap.add_argument("--fused", type=int, default=1)
+    ap.add_argument("--per", type=str, default="1 1 0", help="periodicity flags x y z (headline: periodic x/y, wall z); single GPU only")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-base", type=int, default=0, help="base size of the cpu_baseline sample (0: from the core count)")
     args = ap.parse_args()
@@ -124,13 +125,16 @@ def main():
     ctx = capi.Context(local, stream.cuda_stream)
 
     # weak scaling: every rank owns one full copy of the headline hierarchy (fixed work per GPU)
+    per = tuple(int(v) for v in args.per.split())
+    if world > 1 and per != (1, 1, 0):
+        raise SystemExit("--per is a single-GPU diagnostic option")
     if world == 1:
-        H = nested_hierarchy(args.base, args.nlev, args.box, is_per=(1, 1, 0))
+        H = nested_hierarchy(args.base, args.nlev, args.box, is_per=per)
         remotes, plans = [None] * args.nlev, None
     else:
         R = padist.slab_hierarchy(args.base, args.nlev, args.box, world, rank, 2)
         H, remotes, plans = R.local, R.remote, R.plans
-    bc = capi.bc_from_flags((1, 1, 0))
+    bc = capi.bc_from_flags(per)
     dls = [capi.DevLevel(ctx, lv, remotes[l]) for l, lv in enumerate(H.levels)]
     cells = sum(lv.ncells for lv in H.levels)
     hold, states, works, outs = [], [], [], []

@@ -37,6 +37,7 @@ struct FaceArgs {
   int has_crse;
   int layers;  // cells per face normal that are recomputed (2)
   double thr;
+  int perim_only;  // k_faces_curv: only the cells on the perimeter of each face (k_faces_curv_fast does the interior)
 };
 
 __device__ __forceinline__ double comp_of(const Vec3& v, int d) { return d == 0 ? v.x : (d == 1 ? v.y : v.z); }
@@ -77,13 +78,36 @@ __global__ __launch_bounds__(256, PA_FC_WAVES) void k_faces_curv(DLevelView L, D
   int b, fdir, side, layer, q0[3];
   DBox B;
   const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  if (!sface_decode(L, blockIdx.y, t, A.layers, b, B, fdir, side, q0, layer)) return;
-  const int n[3] = {B.hi[0] - B.lo[0] + 1, B.hi[1] - B.lo[1] + 1, B.hi[2] - B.lo[2] + 1};
-  if (layer >= n[fdir]) return;
-  {
+  if (A.perim_only) {
+    // compact enumeration of the perimeter cells of the face (the interior belongs to k_faces_curv_fast):
+    // two full rows in t0, then the two end columns of the rows in between; layers slowest
+    const int e = L.sfaces[blockIdx.y];
+    b = e / 6; fdir = (e % 6) >> 1; side = e & 1;
+    B = L.boxes[b];
     const int t0 = (fdir == 0) ? 1 : 0, t1 = (fdir == 2) ? 1 : 2;
-    if ((L.sfcode[L.sfoff[blockIdx.y] + (t - (long long)layer * n[t0] * n[t1])] & 3u) == 0) return;
+    const unsigned n0 = B.hi[t0] - B.lo[t0] + 1, n1 = B.hi[t1] - B.lo[t1] + 1;
+    const unsigned P = (n1 >= 2) ? 2 * n0 + 2 * (n1 - 2) : n0;
+    if (t >= (long long)P * A.layers) return;
+    unsigned r = (unsigned)t;
+    layer = 0;
+    while (r >= P) { r -= P; ++layer; }
+    unsigned a0, a1;
+    if (r < n0) { a0 = r; a1 = 0; }
+    else if (r < 2 * n0) { a0 = r - n0; a1 = n1 - 1; }
+    else { r -= 2 * n0; a0 = (r & 1u) ? n0 - 1 : 0; a1 = 1 + (r >> 1); }
+    if (n0 == 1 && (r & 1u) && t >= 2 * (long long)n0) return;  // a single column: do not visit it twice
+    q0[fdir] = side ? B.hi[fdir] + 1 : B.lo[fdir] - 1;
+    q0[t0] = B.lo[t0] + (int)a0;
+    q0[t1] = B.lo[t1] + (int)a1;
+    if (layer >= B.hi[fdir] - B.lo[fdir] + 1) return;
+    if ((L.sfcode[L.sfoff[blockIdx.y] + a0 + (long long)n0 * a1] & 3u) == 0) return;
+  } else {
+    if (!sface_decode(L, blockIdx.y, t, A.layers, b, B, fdir, side, q0, layer)) return;
+    const int t0 = (fdir == 0) ? 1 : 0, t1 = (fdir == 2) ? 1 : 2;
+    if (layer >= B.hi[fdir] - B.lo[fdir] + 1) return;
+    if ((L.sfcode[L.sfoff[blockIdx.y] + (t - (long long)layer * (B.hi[t0] - B.lo[t0] + 1) * (B.hi[t1] - B.lo[t1] + 1))] & 3u) == 0) return;
   }
+  const int n[3] = {B.hi[0] - B.lo[0] + 1, B.hi[1] - B.lo[1] + 1, B.hi[2] - B.lo[2] + 1};
   int X[3] = {q0[0], q0[1], q0[2]};
   X[fdir] += side ? -(1 + layer) : (1 + layer);
   const FabView C = mf_view(MC_, B, b);
@@ -148,6 +172,97 @@ __global__ __launch_bounds__(256, PA_FC_WAVES) void k_faces_curv(DLevelView L, D
   }
   if (!ok) atomicAdd(nbad, 1);
   MO.data[MO.off[b] + fab_index(B, MO.ng, MO.ncomp, kcomp, X[0], X[1], X[2])] = curv;
+}
+
+// Phase B, fast path: the interior cells of a special face (all four tangential neighbours inside the
+// box), no threshold clip, boxes >= 3 cells thick.  One thread per face cell does BOTH layers: the
+// normals it needs are plain loads from the output (exact after phase A), shared between the two
+// layers, and only the ghost normal beyond the face needs the boundary condition.  Same operations in
+// the same order as k_faces_curv (d = 0,1,2; cdiff; *0.5), which still handles the perimeter cells.
+template <int FD>
+__device__ __forceinline__ void faces_curv_fast_body(const DLevelView& L, const DLevelView& LCr, const DMFView& MN, int cncomp0, const DMFView& MO,
+                                                     int ncomp0, int kcomp, const FaceArgs& A, int* nbad, int b, const DBox& B, int side,
+                                                     const int q0[3], unsigned code) {
+  constexpr int T0 = (FD == 0) ? 1 : 0, T1 = (FD == 2) ? 1 : 2;
+  const int cls = (int)(code & 3u);
+  if (cls == 0) return;
+  const int n[3] = {B.hi[0] - B.lo[0] + 1, B.hi[1] - B.lo[1] + 1, B.hi[2] - B.lo[2] + 1};
+  const int sg = side ? 1 : -1;  // the ghost cell sits at X1 + sg e_FD
+  int X1[3] = {q0[0], q0[1], q0[2]};
+  X1[FD] -= sg;
+  const long long nxo = n[0] + 2 * MO.ng, nyo = n[1] + 2 * MO.ng, nzo = n[2] + 2 * MO.ng;
+  const long long cso = pa_cstride(nxo * nyo * nzo, MO.ncomp);
+  const long long st[3] = {1, nxo, nxo * nyo};
+  const long long idx1 = ((long long)(X1[2] - B.lo[2] + MO.ng) * nyo + (X1[1] - B.lo[1] + MO.ng)) * nxo + (X1[0] - B.lo[0] + MO.ng);
+  const long long in = -sg * st[FD];
+  double* o = MO.data + MO.off[b];
+  const double* nf = o + (long long)(ncomp0 + FD) * cso + idx1;
+  const double* n0p = o + (long long)(ncomp0 + T0) * cso + idx1;
+  const double* n1p = o + (long long)(ncomp0 + T1) * cso + idx1;
+  const double nfd1 = nf[0], nfd2 = nf[in], nfd3 = nf[2 * in];
+  const double a0m = n0p[-st[T0]], a0c = n0p[0], a0p = n0p[st[T0]];
+  const double a1m = n1p[-st[T1]], a1c = n1p[0], a1p = n1p[st[T1]];
+  const double b0m = n0p[in - st[T0]], b0c = n0p[in], b0p = n0p[in + st[T0]];
+  const double b1m = n1p[in - st[T1]], b1c = n1p[in], b1p = n1p[in + st[T1]];
+  // ghost normal: MLMG applyBC on n_FD (curvature.cpp:510-531)
+  double g;
+  bool ok = true;
+  if (cls == 2) {
+    g = (A.bc[FD] == PA_BC_REFLECT_ODD) ? -nfd1 : nfd1;
+  } else {
+    if (!A.has_crse) { ok = false; g = 0.0; }
+    else {
+      double coef[4];
+      const int NX = cf_normal_coef(n[FD], A.ratio, coef);
+      const int xf[1] = {0};
+      double bv1[1];
+      cf_interp<1>(code, LCr, MN, cncomp0 + FD, q0, FD, A.ratio, xf, ok, bv1);
+      double tmp = 0.0;
+      for (int m = 1; m < NX; ++m) {
+        const double v = (m == 1) ? nfd1 : (m == 2 ? nfd2 : nfd3);
+        tmp += v * coef[m];
+      }
+      g = tmp;
+      g += bv1[0] * coef[0];
+    }
+  }
+  const double dx0 = L.dxinv[0], dx1 = L.dxinv[1], dx2 = L.dxinv[2];
+  // face-normal terms: (minus neighbour, centre, plus neighbour)
+  const double f1 = side ? cdiff(L.dxinv[FD], nfd2, nfd1, g) : cdiff(L.dxinv[FD], g, nfd1, nfd2);
+  const double f2 = side ? cdiff(L.dxinv[FD], nfd3, nfd2, nfd1) : cdiff(L.dxinv[FD], nfd1, nfd2, nfd3);
+  const double t01 = cdiff(L.dxinv[T0], a0m, a0c, a0p), t11 = cdiff(L.dxinv[T1], a1m, a1c, a1p);
+  const double t02 = cdiff(L.dxinv[T0], b0m, b0c, b0p), t12 = cdiff(L.dxinv[T1], b1m, b1c, b1p);
+  (void)dx0; (void)dx1; (void)dx2;
+  double k1 = 0.0, k2 = 0.0;
+  // d = 0, 1, 2 in order: the term of direction d is the face-normal one when d == FD, else T0's or T1's
+  k1 += (FD == 0) ? f1 : t01;
+  k1 += (FD == 1) ? f1 : (FD == 0 ? t01 : t11);
+  k1 += (FD == 2) ? f1 : t11;
+  k2 += (FD == 0) ? f2 : t02;
+  k2 += (FD == 1) ? f2 : (FD == 0 ? t02 : t12);
+  k2 += (FD == 2) ? f2 : t12;
+  k1 = k1 * 0.5;
+  k2 = k2 * 0.5;
+  if (!ok) atomicAdd(nbad, 1);
+  double* ko = o + (long long)kcomp * cso + idx1;
+  ko[0] = k1;
+  ko[in] = k2;
+}
+
+__global__ __launch_bounds__(256) void k_faces_curv_fast(DLevelView L, DLevelView LCr, DMFView MN, int cncomp0, DMFView MO, int ncomp0, int kcomp,
+                                                         FaceArgs A, int* nbad) {
+  int b, fdir, side, layer, q0[3];
+  DBox B;
+  const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (!sface_decode(L, blockIdx.y, t, 1, b, B, fdir, side, q0, layer)) return;
+  const int t0 = (fdir == 0) ? 1 : 0, t1 = (fdir == 2) ? 1 : 2;
+  if (!(q0[t0] > B.lo[t0] && q0[t0] < B.hi[t0] && q0[t1] > B.lo[t1] && q0[t1] < B.hi[t1])) return;  // perimeter: k_faces_curv
+  const unsigned code = L.sfcode[L.sfoff[blockIdx.y] + t];
+  switch (fdir) {  // uniform per workgroup
+    case 0: faces_curv_fast_body<0>(L, LCr, MN, cncomp0, MO, ncomp0, kcomp, A, nbad, b, B, side, q0, code); break;
+    case 1: faces_curv_fast_body<1>(L, LCr, MN, cncomp0, MO, ncomp0, kcomp, A, nbad, b, B, side, q0, code); break;
+    default: faces_curv_fast_body<2>(L, LCr, MN, cncomp0, MO, ncomp0, kcomp, A, nbad, b, B, side, q0, code); break;
+  }
 }
 
 // tuning knobs (environment, read once): PA_KSEG=<planes per workgroup>, PA_MTY=<rows*10 + min waves/SIMD>
@@ -279,14 +394,26 @@ extern "C" int pa_gradcurv_faces_level(pa_ctx* ctx, const pa_mf* c, int ccomp, c
       if (crse_n && B.hi[d] - B.lo[d] + 1 < 3) return pa_fail(ctx, "pa_gradcurv_faces_level: boxes thinner than 3 cells need the pass-by-pass path");
   FaceArgs A;
   for (int d = 0; d < 3; ++d) A.bc[d] = bc[d];
-  A.ratio = ratio; A.has_crse = crse_n ? 1 : 0; A.thr = thr; A.layers = 2;
+  A.ratio = ratio; A.has_crse = crse_n ? 1 : 0; A.thr = thr; A.layers = 2; A.perim_only = 0;
+  // fast path for the interior of the faces: no threshold clip, every box >= 3 cells thick
+  bool fast = !(thr >= 0.0);
+  for (const DBox& B : c->lev->boxes)
+    for (int d = 0; d < 3; ++d) fast = fast && (B.hi[d] - B.lo[d] + 1 >= 3);
+  static const int fast_env = [] { const char* e = getenv("PA_FACES_FAST"); return e ? atoi(e) : 1; }();
+  fast = fast && fast_env;
   if (L->sfaces.empty()) return 0;
   const long long n0 = L->maxn[0], n1 = L->maxn[1], n2 = L->maxn[2];
   const long long nf = std::max(n1 * n2, std::max(n0 * n2, n0 * n1));
   const unsigned nsf = (unsigned)L->sfaces.size();
   ProfScope prof(ctx, PA_TAG_GRADCURV_FACES);
   hipLaunchKernelGGL(k_faces_normal, dim3((unsigned)((nf + 255) / 256), nsf), dim3(256), 0, ctx->stream, L->view, c->view, ccomp, out->view, ncomp0, A);
-  hipLaunchKernelGGL(k_faces_curv, dim3((unsigned)((nf * A.layers + 255) / 256), nsf), dim3(256), 0, ctx->stream, L->view, c->view, ccomp,
+  if (fast) {
+    hipLaunchKernelGGL(k_faces_curv_fast, dim3((unsigned)((nf + 255) / 256), nsf), dim3(256), 0, ctx->stream, L->view,
+                       crse_n ? crse_n->lev->view : L->view, crse_n ? crse_n->view : c->view, cncomp0, out->view, ncomp0, kcomp, A, ctx->d_flags);
+    A.perim_only = 1;
+  }
+  const long long ncell = fast ? 2 * (std::max(n0, std::max(n1, n2)) + std::max(n0, std::max(n1, n2))) : nf;  // perimeter <= 4 * longest edge
+  hipLaunchKernelGGL(k_faces_curv, dim3((unsigned)((ncell * A.layers + 255) / 256), nsf), dim3(256), 0, ctx->stream, L->view, c->view, ccomp,
                      crse_n ? crse_n->lev->view : L->view, crse_n ? crse_n->view : c->view, cncomp0, out->view, ncomp0, kcomp, A, ctx->d_flags);
   PA_HIP(hipGetLastError());
   return 0;
