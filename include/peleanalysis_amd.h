@@ -230,13 +230,24 @@ typedef struct {
   int32_t get_strain_tensor;  /* getStrainTensor (:755-757): the 9 components of grad u */
   int32_t do_velnormal;       /* do_velnormal  (:765-787) */
   int32_t vel_comp;           /* first of the 3 consecutive velocity components in state */
+  /* do_smooth (:328-406, pa_curvature_run only): one implicit diffusion step of the progress variable,
+   * composite over the levels; everything downstream (curvature, threshold) then uses the smoothed field */
+  int32_t do_smooth;
+  double  smoothing_time;     /* smoothing_time (reference default 1e-7) */
 } pa_curv_params;
 /* curvature.cpp:283-326 + 408-570 (core) + 575-789 (options).  state[lev][comp] = progress source
  * (ng>=2; with do_strain the velocity components get their ghost cells filled in place).
  * out[lev] comps: ocomp+0 Progress, +1 MeanCurvature, +2..4 FlameNormal, and when requested
- * +5 GaussianCurvature, +6 StrainRate, +7 VelFlameNormal, +8..16 ROST_dU?d? (row-major grad u). */
+ * +5 GaussianCurvature, +6 StrainRate, +7 VelFlameNormal, +8..16 ROST_dU?d? (row-major grad u), and with
+ * do_smooth +17 SmoothedProgress. */
 int pa_curvature_run(pa_ctx*, int nlev, pa_mf* const* state, int comp, const int32_t bc[3],
                      const pa_curv_params*, pa_mf* const* out, int ocomp);
+/* curvature.cpp:328-406: (I - dt Lap) sol = rhs[rcomp] as a composite solve over the levels (periodic /
+ * homogeneous Neumann walls from bc, fine ghosts by applyBC, refluxed coarse-fine fluxes, covered coarse
+ * cells = child averages), BiCGStab to ||b - A x||_inf <= tol ||b||_inf (the reference: 1e-12).  sol[lev]
+ * comp scomp receives the solution on valid cells.  Refinement ratio 2, single rank.  Synchronous. */
+int pa_smooth_solve(pa_ctx*, int nlev, pa_mf* const* rhs, int rcomp, pa_mf* const* sol, int scomp, double dt,
+                    const int32_t bc[3], double tol, int maxiter, int* iters, double* rel_residual);
 /* fused grad+curvature of one variable: out[lev] comps ocomp+0..3 = gx,gy,gz,|g|,
  * +4..6 FlameNormal, +7 MeanCurvature.  work[lev]: scratch mf, 1 comp, ng=2. */
 int pa_gradcurv_run(pa_ctx*, int nlev, pa_mf* const* state, int comp, const int32_t bc[3],

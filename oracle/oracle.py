@@ -144,7 +144,8 @@ def grad_pipeline(levels, states, comp, bc, outs, ocomp, multipass=True, omp=Fal
 
 
 def curvature_pipeline(levels, states, comp, bc, outs, ocomp, MF, prog_min=None, prog_max=None, threshold=None,
-                       do_gauss=False, vel_comp=None, do_strain=False, do_velnormal=False, strain_tensor=False, omp=False):
+                       do_gauss=False, vel_comp=None, do_strain=False, do_velnormal=False, strain_tensor=False, omp=False,
+                       do_smooth=False, smoothing_time=1e-7, smooth_tol=1e-12):
     """curvature.cpp:283-326 + 408-570 (core), 575-789 (options).
     out comps: ocomp+0 Progress, +1 MeanCurvature, +2..4 FlameNormal, +5 GaussianCurvature
     (0.0 when not requested: quirk Q1), +6 StrainRate, +7 VelFlameNormal (when requested).
@@ -161,6 +162,15 @@ def curvature_pipeline(levels, states, comp, bc, outs, ocomp, MF, prog_min=None,
         L.orc_progress(_p(_mf(states[l])), comp, C.c_double(prog_min), C.c_double(prog_max), _p(_mf(c)), 0)
         fill_boundary(c, 0, 1, 2, omp)
         cmf.append(c)
+    progress = [c.copy() for c in cmf] if do_smooth else None
+    if do_smooth:  # :328-406; everything below uses the smoothed field (idprogvar = idSmProg, :408)
+        sol, it, res = smooth_solve(levels, cmf, 0, smoothing_time, bc, MF, tol=smooth_tol, maxiter=100, omp=omp)
+        assert it > 0, f"composite smoothing solve failed ({it}, residual {res})"
+        for l in range(nlev):
+            L.orc_copy(_p(_mf(sol[l])), 0, _p(_mf(cmf[l])), 0, 1, 0)
+            if outs[l].ncomp > ocomp + 17:
+                L.orc_copy(_p(_mf(sol[l])), 0, _p(_mf(outs[l])), ocomp + 17, 1, 0)
+            fill_boundary(cmf[l], 0, 1, 2, omp)
     for l in range(nlev):
         c = cmf[l]
         apply_bc(c, 0, cmf[l - 1] if l > 0 else None, 0, bc, omp=omp)
@@ -178,7 +188,7 @@ def curvature_pipeline(levels, states, comp, bc, outs, ocomp, MF, prog_min=None,
         L.orc_mult(_p(_mf(K)), 0, C.c_double(0.5))
         if thr >= 0:
             L.orc_threshold(_p(_mf(c)), 0, C.c_double(thr), _p(_mf(K)), 0, _p(_mf(n)), 0)
-        L.orc_copy(_p(_mf(c)), 0, _p(_mf(outs[l])), ocomp, 1, 0)
+        L.orc_copy(_p(_mf(progress[l] if do_smooth else c)), 0, _p(_mf(outs[l])), ocomp, 1, 0)
         L.orc_copy(_p(_mf(K)), 0, _p(_mf(outs[l])), ocomp + 1, 1, 0)
         L.orc_copy(_p(_mf(n)), 0, _p(_mf(outs[l])), ocomp + 2, 3, 0)
         gmf.append(G)
@@ -309,6 +319,45 @@ def sdf_level_set_ref(tris, verts, origin, dx, n, exact_band=1):
                                fdx, ni, nj, nk, phi.ctypes.data_as(C.c_void_p), int(exact_band))
     assert rc == 0
     return phi
+
+
+# ---------------------------------------------------------------- do_smooth (curvature.cpp:328-406)
+def _mfptrs(mfs):
+    """array of orc_mf* for a list of multifabs (+ the objects that keep them alive)"""
+    keep = [_mf(m) for m in mfs]
+    arr = (C.c_void_p * len(mfs))(*[C.cast(C.pointer(k), C.c_void_p) for k in keep])
+    return arr, keep
+
+
+def smooth_solve(levels, rhs, rcomp, dt, bc, MF, tol=1e-13, maxiter=200, omp=False):
+    """orc_smooth_solve: composite (I - dt Lap) x = rhs[rcomp].  Returns (list of solution multifabs
+    (1 comp, ng 1), iterations, relative residual)."""
+    L = lib(omp)
+    nlev = len(levels)
+    sol = [MF(lv, 1, 1) for lv in levels]
+    work = [MF(lv, 1, 1) for _ in range(7) for lv in levels]
+    ra, k1 = _mfptrs(rhs)
+    sa, k2 = _mfptrs(sol)
+    wa, k3 = _mfptrs(work)
+    res = C.c_double(0.0)
+    L.orc_smooth_solve.restype = C.c_int
+    it = L.orc_smooth_solve(nlev, ra, int(rcomp), sa, wa, C.c_double(dt), _bc(bc), 2, C.c_double(tol), int(maxiter), C.byref(res))
+    return sol, it, res.value
+
+
+def smooth_apply(levels, x, dt, bc, MF):
+    """y = A x with the composite operator (for tests); x: list of 1-comp ng-1 multifabs (modified)"""
+    L = lib()
+    nlev = len(levels)
+    y = [MF(lv, 1, 1) for lv in levels]
+    mask = [MF(lv, 1, 1) for lv in levels]
+    for l in range(nlev):
+        L.orc_smooth_mask(_p(_mf(mask[l])), _p(_lv(levels[l + 1])) if l + 1 < nlev else None, 2)
+    xa, k1 = _mfptrs(x)
+    ya, k2 = _mfptrs(y)
+    ma, k3 = _mfptrs(mask)
+    L.orc_smooth_apply(nlev, xa, ya, ma, C.c_double(dt), _bc(bc), 2)
+    return y, mask
 
 
 # ---------------------------------------------------------------- isosurface pipeline

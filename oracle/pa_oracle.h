@@ -112,6 +112,19 @@ void orc_foextrap(orc_mf* mf, int comp, int ncomp, int ng_fill);
 int orc_fillpatch_two_levels(orc_mf* fine, const orc_mf* crse, int comp, int ncomp, int ng_fill,
                              int ratio, int interp_type);
 
+/* ---- curvature.cpp:328-406 (do_smooth), pa_oracle_smooth.c ------------- */
+void orc_smooth_mask(const orc_mf* mask, const orc_level* fine, int ratio);
+void orc_smooth_avgdown(const orc_mf* fine, int fcomp, orc_mf* crse, int ccomp, int ratio);
+void orc_smooth_apply_level(const orc_mf* x, int xc, orc_mf* y, int yc, double dt);
+void orc_smooth_reflux(const orc_mf* xf, int xfc, const orc_mf* xc, int xcc, orc_mf* yc, int ycc, double dt, int ratio);
+void orc_smooth_dot(const orc_mf* a, const orc_mf* b, const orc_mf* mask, double* dot, double* amax);
+/* y = A x, the composite operator (x: covered cells and ghost cells are overwritten) */
+void orc_smooth_apply(int nlev, orc_mf* const* x, orc_mf* const* y, const orc_mf* const* mask, double dt, const int32_t bc[3], int ratio);
+/* (I - dt Lap) sol = rhs, composite, BiCGStab to ||b - A x||_inf <= tol ||b||_inf; work = 7 vectors per
+ * level (1 comp, ng 1), the last one receives the covered-cell mask.  Returns iterations (< 0: failed). */
+int orc_smooth_solve(int nlev, orc_mf* const* rhs, int rcomp, orc_mf* const* sol, orc_mf* const* work, double dt,
+                     const int32_t bc[3], int ratio, double tol, int maxiter, double* res);
+
 /* ---- isosurface -------------------------------------------------------- */
 const int32_t* orc_mc_edge_table(void); /* [256] */
 const int32_t* orc_mc_tri_table(void);  /* [256][16] */

@@ -31,7 +31,7 @@ class PaBox(C.Structure):
 class PaCurvParams(C.Structure):
     _fields_ = [("prog_min", C.c_double), ("prog_max", C.c_double), ("do_threshold", C.c_int32), ("threshold", C.c_double),
                 ("fused", C.c_int32), ("do_gauss_curv", C.c_int32), ("do_strain", C.c_int32), ("get_strain_tensor", C.c_int32),
-                ("do_velnormal", C.c_int32), ("vel_comp", C.c_int32)]
+                ("do_velnormal", C.c_int32), ("vel_comp", C.c_int32), ("do_smooth", C.c_int32), ("smoothing_time", C.c_double)]
 
 
 class PaSdfGrid(C.Structure):
@@ -110,6 +110,7 @@ def load_library() -> C.CDLL:
         "pa_mc_tri_table": (C.POINTER(C.c_int8), []),
         "pa_sdf_level_set3": (C.c_int, [vp, C.c_int, C.POINTER(PaSdfGrid), C.c_int]),
         "pa_sdf_signed_fab": (C.c_int, [vp, PaBox, vp, C.POINTER(PaFab), C.c_int, dbl, dbl, C.POINTER(PaFab), C.c_int]),
+        "pa_smooth_solve": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.c_int, C.POINTER(vp), C.c_int, dbl, pi32, dbl, C.c_int, C.POINTER(C.c_int), pdbl]),
         "pa_grad_run": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.c_int, pi32, C.POINTER(vp), C.c_int]),
         "pa_curvature_run": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.c_int, pi32, C.POINTER(PaCurvParams), C.POINTER(vp), C.c_int]),
         "pa_gradcurv_run": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.c_int, pi32, C.POINTER(PaCurvParams), C.POINTER(vp), C.POINTER(vp),
@@ -301,8 +302,9 @@ def grad_run(ctx: Context, states: Sequence[DevMF], comp: int, bc, outs: Sequenc
 
 
 def curv_params(prog_min=None, prog_max=None, threshold=None, fused=True, do_gauss=False, do_strain=False, strain_tensor=False,
-                do_velnormal=False, vel_comp=0) -> PaCurvParams:
+                do_velnormal=False, vel_comp=0, do_smooth=False, smoothing_time=1e-7) -> PaCurvParams:
     p = PaCurvParams()
+    p.do_smooth, p.smoothing_time = int(do_smooth), float(smoothing_time)
     p.do_gauss_curv, p.do_strain, p.get_strain_tensor, p.do_velnormal, p.vel_comp = int(do_gauss), int(do_strain), int(strain_tensor), int(do_velnormal), int(vel_comp)
     p.prog_min = 1e20 if prog_min is None else prog_min
     p.prog_max = -1e20 if prog_max is None else prog_max
@@ -344,3 +346,11 @@ def sdf_level_set(ctx: Context, meshes, exact_band: int = 1):
     ctx.check(ctx.lib.pa_sdf_level_set3(ctx.h, len(meshes), grids, int(exact_band)))
     ctx.sync()
     return [dp.to_numpy(np.float32, shape) for dp, shape in outs]
+
+
+def smooth_solve(ctx, rhs, rcomp, sol, scomp, dt, bc, tol=1e-12, maxiter=100):
+    """pa_smooth_solve; returns (iterations, relative residual)"""
+    it, res = C.c_int(0), C.c_double(0.0)
+    ctx.check(ctx.lib.pa_smooth_solve(ctx.h, len(rhs), _handles(rhs), rcomp, _handles(sol), scomp, float(dt), _i3(bc), float(tol), int(maxiter),
+                                      C.byref(it), C.byref(res)))
+    return it.value, res.value

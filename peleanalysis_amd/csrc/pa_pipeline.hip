@@ -76,7 +76,22 @@ static int curvature_passes(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp
     nmf[l].reset(pa_mf_create(ctx, state[l]->lev, 3, 1, nullptr));
     if (!cmf[l] || !nmf[l]) return 1;
     PA_TRY(pa_progress_level(ctx, state[l], comp, pmin, pmax, cmf[l].get(), 0, 0));  // curvature.cpp:316-320
+    if (pc >= 0) PA_TRY(pa_mf_copy(ctx, cmf[l].get(), 0, out[l], pc, 1, 0));         // Progress is the unsmoothed field
     PA_TRY(pa_fill_boundary(ctx, cmf[l].get(), 0, 1, 1));                            // :322
+  }
+  if (opt >= 0 && P && P->do_smooth) {  // :328-406; idprogvar = idSmProg from here on (:408)
+    std::vector<pa_mf*> cs(nlev);
+    for (int l = 0; l < nlev; ++l) {
+      cs[l] = cmf[l].get();
+      if (out[l]->ncomp < opt + 18) return pa_fail(ctx, "pa_curvature_run: out needs " + std::to_string(opt + 18) + " components with do_smooth");
+    }
+    int iters = 0;
+    double res = 0.0;
+    PA_TRY(pa_smooth_solve(ctx, nlev, cs.data(), 0, cs.data(), 0, P->smoothing_time, bc, 1e-12, 100, &iters, &res));  // setMaxIter(100)
+    for (int l = 0; l < nlev; ++l) {
+      PA_TRY(pa_mf_copy(ctx, cmf[l].get(), 0, out[l], opt + 17, 1, 0));
+      PA_TRY(pa_fill_boundary(ctx, cmf[l].get(), 0, 1, 1));  // :403
+    }
   }
   for (int l = 0; l < nlev; ++l) {
     pa_mf* c = cmf[l].get();
@@ -92,7 +107,6 @@ static int curvature_passes(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp
     for (int d = 0; d < 3; ++d)                                                         // :508-531
       PA_TRY(pa_apply_bc(ctx, n, d, l > 0 ? out[l - 1] : nullptr, nc + d, bc, 2, d));
     PA_TRY(pa_div_level(ctx, n, 0, 0.5, c, 0, thr, out[l], kc));                        // :533-567
-    if (pc >= 0) PA_TRY(pa_mf_copy(ctx, c, 0, out[l], pc, 1, 0));
     PA_TRY(pa_mf_copy(ctx, n, 0, out[l], nc, 3, 0));                                    // :569-570
     if (gauss) {  // :575-677: Hessian of c from cell_normal (= G), coarse-fine BC from cell_normal[lev-1]
       pa_mf* G = gmf[l].get();

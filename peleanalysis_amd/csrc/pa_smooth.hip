@@ -1,0 +1,352 @@
+// pa_smooth.hip -- do_smooth of curvature.cpp:328-406 on gfx950: one implicit diffusion step of the
+// progress variable, (I - dt Lap) x = c, as a COMPOSITE solve over the AMR hierarchy (MLABecLaplacian
+// alpha = 1, A = 1, beta = smoothing_time, B = 1; periodic / homogeneous Neumann domain boundaries;
+// fine ghosts from MLCellLinOp::applyBC; coarse flux at a coarse-fine face = average of the fine fluxes;
+// covered coarse cells = child averages; tol_rel = tol_abs = 1e-12).
+// The reference solves with AMReX's MLMG (absent); any solver that reaches the
+// tolerance gives the same field to ~tol*cond, so this is BiCGStab on the composite operator -- the same
+// algorithm as oracle/pa_oracle_smooth.c, compared with it to a tolerance.  Every building block is a
+// bandwidth-bound stencil / vector kernel over the level's boxes; the 7-point apply reads x once and
+// writes y once (16 B/cell), reductions are two-stage with a fixed summation order per launch shape.
+#include "pa_internal.h"
+#include "pa_fabview.h"
+#include <cmath>
+#include <memory>
+#include <vector>
+
+int pa_ensure_red(pa_ctx* ctx, size_t n);
+
+struct BoxIt {  // thread -> cell of box blockIdx.y (grid-stride over the box's valid cells)
+  DBox B;
+  int nx, ny, nz;
+  long long n;
+  __device__ __forceinline__ BoxIt(const DLevelView& L, int b) {
+    B = L.boxes[b];
+    nx = B.hi[0] - B.lo[0] + 1; ny = B.hi[1] - B.lo[1] + 1; nz = B.hi[2] - B.lo[2] + 1;
+    n = (long long)nx * ny * nz;
+  }
+  __device__ __forceinline__ void cell(long long t, int& i, int& j, int& k) const {
+    const unsigned u = (unsigned)t, r = u / (unsigned)nx;
+    i = B.lo[0] + (int)(u - r * (unsigned)nx);
+    j = B.lo[1] + (int)(r % (unsigned)ny);
+    k = B.lo[2] + (int)(r / (unsigned)ny);
+  }
+};
+#define PA_BOX_LOOP(L)                                                                                                \
+  const int b = blockIdx.y;                                                                                            \
+  const BoxIt it(L, b);                                                                                                \
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < it.n; t += (long long)gridDim.x * blockDim.x)
+
+// mask = 1 on valid cells not covered by the next finer level, else 0
+__global__ __launch_bounds__(256) void k_smooth_mask(DLevelView L, DMFView M, DLevelView LF, int has_fine, int ratio) {
+  PA_BOX_LOOP(L) {
+    int i, j, k;
+    it.cell(t, i, j, k);
+    double m = 1.0;
+    if (has_fine) {
+      int p[3] = {i * ratio, j * ratio, k * ratio};
+      if (owner_of(LF, p) != -1) m = 0.0;
+    }
+    M.data[M.off[b] + fab_index(it.B, M.ng, M.ncomp, 0, i, j, k)] = m;
+  }
+}
+
+// average_down: thread per coarse cell under fine box b (sum of the children in k,j,i order, * 1/r^3)
+__global__ __launch_bounds__(256) void k_smooth_avgdown(DLevelView LF, DMFView F, DLevelView LC, DMFView Cm, int ratio) {
+  const int b = blockIdx.y;
+  const DBox B = LF.boxes[b];
+  const int cx = (B.hi[0] - B.lo[0] + 1) / ratio, cy = (B.hi[1] - B.lo[1] + 1) / ratio, cz = (B.hi[2] - B.lo[2] + 1) / ratio;
+  const long long n = (long long)cx * cy * cz;
+  const double fac = 1.0 / (double)(ratio * ratio * ratio);
+  const double* f = F.data + F.off[b];
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+    const unsigned u = (unsigned)t, r = u / (unsigned)cx;
+    const int ic = coarsen_idx(B.lo[0], ratio) + (int)(u - r * cx), jc = coarsen_idx(B.lo[1], ratio) + (int)(r % cy), kc = coarsen_idx(B.lo[2], ratio) + (int)(r / cy);
+    double c = 0.0;
+    for (int kk = 0; kk < ratio; ++kk)
+      for (int jj = 0; jj < ratio; ++jj)
+        for (int ii = 0; ii < ratio; ++ii) c += f[fab_index(B, F.ng, F.ncomp, 0, ic * ratio + ii, jc * ratio + jj, kc * ratio + kk)];
+    c *= fac;
+    const int p[3] = {ic, jc, kc};
+    const int cb = owner_of(LC, p);
+    if (cb >= 0) Cm.data[Cm.off[cb] + fab_index(LC.boxes[cb], Cm.ng, Cm.ncomp, 0, ic, jc, kc)] = c;
+  }
+}
+
+// y = x - dt * div(grad x), flux form (same association as the oracle); x has resolved ring-1 face ghosts
+__global__ __launch_bounds__(256) void k_smooth_apply(DLevelView L, DMFView X, DMFView Y, double dt) {
+  PA_BOX_LOOP(L) {
+    int i, j, k;
+    it.cell(t, i, j, k);
+    const double* x = X.data + X.off[b];
+    const long long nxg = it.nx + 2 * X.ng, nyg = it.ny + 2 * X.ng;
+    const long long q = fab_index(it.B, X.ng, X.ncomp, 0, i, j, k);
+    const double c = x[q];
+    const double d0 = L.dxinv[0], d1 = L.dxinv[1], d2 = L.dxinv[2];
+    double div = 0.0;
+    div += d0 * (d0 * (x[q + 1] - c) - d0 * (c - x[q - 1]));
+    div += d1 * (d1 * (x[q + nxg] - c) - d1 * (c - x[q - nxg]));
+    div += d2 * (d2 * (x[q + nxg * nyg] - c) - d2 * (c - x[q - nxg * nyg]));
+    Y.data[Y.off[b] + fab_index(it.B, Y.ng, Y.ncomp, 0, i, j, k)] = c - dt * div;
+  }
+}
+
+// reflux from the fine side: thread per coarse face of a special fine face (coarse-fine cells only)
+__global__ __launch_bounds__(256) void k_smooth_reflux(DLevelView LF, DMFView XF, DLevelView LC, DMFView XC, DMFView YC, double dt, int ratio) {
+  const int e = LF.sfaces[blockIdx.y];
+  const int b = e / 6, dir = (e % 6) >> 1, side = e & 1;
+  const DBox B = LF.boxes[b];
+  const int t0 = (dir == 0) ? 1 : 0, t1 = (dir == 2) ? 1 : 2;
+  const int n0 = B.hi[t0] - B.lo[t0] + 1, n1 = B.hi[t1] - B.lo[t1] + 1;
+  const unsigned c0 = n0 / ratio, c1 = n1 / ratio;
+  const long long tt = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (tt >= (long long)c0 * c1) return;
+  const unsigned u = (unsigned)tt, r = u / c0;
+  const int a0 = (int)(u - r * c0), b1 = (int)r;  // coarse offsets inside the face
+  // class of the first child ghost cell: 1 = coarse-fine (a coarse cell is covered entirely or not at all)
+  if ((LF.sfcode[LF.sfoff[blockIdx.y] + (long long)(a0 * ratio) + (long long)n0 * (b1 * ratio)] & 3u) != 1u) return;
+  const int gq = side ? B.hi[dir] + 1 : B.lo[dir] - 1, inq = side ? B.hi[dir] : B.lo[dir];
+  int oc[3], ic[3];
+  oc[dir] = coarsen_idx(gq, ratio); ic[dir] = coarsen_idx(inq, ratio);
+  oc[t0] = ic[t0] = coarsen_idx(B.lo[t0], ratio) + a0;
+  oc[t1] = ic[t1] = coarsen_idx(B.lo[t1], ratio) + b1;
+  int ow[3] = {oc[0], oc[1], oc[2]}, iw[3] = {ic[0], ic[1], ic[2]};
+  if (!wrap_cell(LC, ow) || !wrap_cell(LC, iw)) return;
+  const int ob = owner_of(LC, ow), ib = owner_of(LC, iw);
+  if (ob < 0 || ib < 0) return;
+  const double* xf = XF.data + XF.off[b];
+  const double dxf = LF.dxinv[dir], dxc = LC.dxinv[dir];
+  double favg = 0.0;
+  for (int v = 0; v < ratio; ++v)
+    for (int uu = 0; uu < ratio; ++uu) {
+      int g[3], in[3];
+      g[dir] = gq; in[dir] = inq;
+      g[t0] = in[t0] = B.lo[t0] + a0 * ratio + uu;
+      g[t1] = in[t1] = B.lo[t1] + b1 * ratio + v;
+      const double xg = xf[fab_index(B, XF.ng, XF.ncomp, 0, g[0], g[1], g[2])], xi = xf[fab_index(B, XF.ng, XF.ncomp, 0, in[0], in[1], in[2])];
+      favg += side ? dxf * (xg - xi) : dxf * (xi - xg);
+    }
+  favg *= 1.0 / (double)(ratio * ratio);
+  const double xo = XC.data[XC.off[ob] + fab_index(LC.boxes[ob], XC.ng, XC.ncomp, 0, ow[0], ow[1], ow[2])];
+  const double xin = XC.data[XC.off[ib] + fab_index(LC.boxes[ib], XC.ng, XC.ncomp, 0, iw[0], iw[1], iw[2])];
+  const double fc = side ? dxc * (xo - xin) : dxc * (xin - xo);
+  const double corr = dt * (dxc * (favg - fc));
+  atomicAdd(&YC.data[YC.off[ob] + fab_index(LC.boxes[ob], YC.ng, YC.ncomp, 0, ow[0], ow[1], ow[2])], side ? corr : -corr);
+}
+
+__global__ __launch_bounds__(256) void k_smooth_zero_covered(DLevelView L, DMFView Y, DMFView M) {
+  PA_BOX_LOOP(L) {
+    int i, j, k;
+    it.cell(t, i, j, k);
+    const long long q = fab_index(it.B, Y.ng, Y.ncomp, 0, i, j, k);
+    if (M.data[M.off[b] + q] == 0.0) Y.data[Y.off[b] + q] = 0.0;
+  }
+}
+
+// z = a x + bc y + c z on valid cells (x, y may be null)
+__global__ __launch_bounds__(256) void k_smooth_axpbypcz(DLevelView L, double a, DMFView X, int hx, double bc, DMFView Y, int hy, double c, DMFView Z) {
+  PA_BOX_LOOP(L) {
+    int i, j, k;
+    it.cell(t, i, j, k);
+    const long long q = fab_index(it.B, Z.ng, Z.ncomp, 0, i, j, k);
+    double v = c * Z.data[Z.off[b] + q];
+    if (hx) v += a * X.data[X.off[b] + q];
+    if (hy) v += bc * Y.data[Y.off[b] + q];
+    Z.data[Z.off[b] + q] = v;
+  }
+}
+
+// copy comp sc of S (any ng) into the 1-comp vector D / back
+__global__ __launch_bounds__(256) void k_smooth_copy(DLevelView L, DMFView S, int sc, DMFView D, int dc) {
+  PA_BOX_LOOP(L) {
+    int i, j, k;
+    it.cell(t, i, j, k);
+    D.data[D.off[b] + fab_index(it.B, D.ng, D.ncomp, dc, i, j, k)] = S.data[S.off[b] + fab_index(it.B, S.ng, S.ncomp, sc, i, j, k)];
+  }
+}
+
+// per-block partial sums of a*b and max|a| over uncovered cells
+__global__ __launch_bounds__(256) void k_smooth_dot(DLevelView L, DMFView A, DMFView Bv, DMFView M, double* part) {
+  double s = 0.0, m = 0.0;
+  {
+    PA_BOX_LOOP(L) {
+      int i, j, k;
+      it.cell(t, i, j, k);
+      const long long q = fab_index(it.B, A.ng, A.ncomp, 0, i, j, k);
+      if (M.data[M.off[b] + q] != 0.0) {
+        const double va = A.data[A.off[b] + q];
+        s += va * Bv.data[Bv.off[b] + q];
+        m = fabs(va) > m ? fabs(va) : m;
+      }
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o);
+    const double m2 = __shfl_xor(m, o);
+    m = m2 > m ? m2 : m;
+  }
+  __shared__ double ss[4], sm[4];
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { ss[w] = s; sm[w] = m; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int q = 1; q < 4; ++q) { s += ss[q]; m = sm[q] > m ? sm[q] : m; }
+    const long long slot = (long long)blockIdx.y * gridDim.x + blockIdx.x;
+    part[2 * slot] = s;
+    part[2 * slot + 1] = m;
+  }
+}
+
+namespace {
+struct Vecs {  // one 1-comp ng-1 vector per level, owned
+  std::vector<pa_mf*> v;
+  ~Vecs() { for (pa_mf* m : v) pa_mf_destroy(m); }
+};
+dim3 box_grid(const pa_level* L, unsigned gx = 0) {
+  if (!gx) gx = (unsigned)std::min<long long>(((long long)L->maxn[0] * L->maxn[1] * L->maxn[2] + 255) / 256, 1024);
+  return dim3(gx, (unsigned)L->boxes.size());
+}
+}  // namespace
+
+struct SmoothSolver {
+  pa_ctx* ctx;
+  int nlev, ratio;
+  double dt;
+  int32_t bc[3];
+  std::vector<const pa_level*> lev;
+  Vecs r, rh, p, v, s, t, mask;
+
+  int alloc(Vecs& V) {
+    for (int l = 0; l < nlev; ++l) {
+      pa_mf* m = pa_mf_create(ctx, lev[l], 1, 1, nullptr);
+      if (!m) return 1;
+      V.v.push_back(m);
+    }
+    return 0;
+  }
+  int apply(Vecs& X, Vecs& Y) {  // y = A x (x: covered cells and ghosts are overwritten)
+    for (int l = nlev - 1; l > 0; --l)
+      hipLaunchKernelGGL(k_smooth_avgdown, box_grid(lev[l]), dim3(256), 0, ctx->stream, lev[l]->view, X.v[l]->view, lev[l - 1]->view, X.v[l - 1]->view, ratio);
+    for (int l = 0; l < nlev; ++l) {
+      if (pa_fill_boundary(ctx, X.v[l], 0, 1, 1)) return 1;
+      if (pa_apply_bc(ctx, X.v[l], 0, l ? X.v[l - 1] : nullptr, 0, bc, ratio, -1)) return 1;
+      hipLaunchKernelGGL(k_smooth_apply, box_grid(lev[l]), dim3(256), 0, ctx->stream, lev[l]->view, X.v[l]->view, Y.v[l]->view, dt);
+    }
+    for (int l = nlev - 1; l > 0; --l) {
+      const pa_level* LF = lev[l];
+      if (LF->sfaces.empty()) continue;
+      const long long nf = std::max((long long)LF->maxn[1] * LF->maxn[2], std::max((long long)LF->maxn[0] * LF->maxn[2], (long long)LF->maxn[0] * LF->maxn[1])) / (ratio * ratio);
+      hipLaunchKernelGGL(k_smooth_reflux, dim3((unsigned)((nf + 255) / 256), (unsigned)LF->sfaces.size()), dim3(256), 0, ctx->stream, LF->view, X.v[l]->view,
+                         lev[l - 1]->view, X.v[l - 1]->view, Y.v[l - 1]->view, dt, ratio);
+    }
+    for (int l = 0; l + 1 < nlev; ++l)
+      hipLaunchKernelGGL(k_smooth_zero_covered, box_grid(lev[l]), dim3(256), 0, ctx->stream, lev[l]->view, Y.v[l]->view, mask.v[l]->view);
+    PA_HIP(hipGetLastError());
+    return 0;
+  }
+  int dot(Vecs& A, Vecs& B, double* d, double* amax) {
+    double sd = 0.0, sm = 0.0;
+    for (int l = 0; l < nlev; ++l) {
+      const dim3 g = box_grid(lev[l], 64);
+      const size_t np = (size_t)g.x * g.y;
+      if (pa_ensure_red(ctx, 2 * np)) return 1;
+      hipLaunchKernelGGL(k_smooth_dot, g, dim3(256), 0, ctx->stream, lev[l]->view, A.v[l]->view, B.v[l]->view, mask.v[l]->view, ctx->d_red);
+      PA_HIP(hipGetLastError());
+      std::vector<double> h(2 * np);
+      PA_HIP(hipMemcpyAsync(h.data(), ctx->d_red, h.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+      PA_HIP(hipStreamSynchronize(ctx->stream));
+      for (size_t q = 0; q < np; ++q) { sd += h[2 * q]; sm = std::max(sm, h[2 * q + 1]); }  // fixed order
+    }
+    *d = sd;
+    *amax = sm;
+    return 0;
+  }
+  void axpbypcz(double a, Vecs* X, double b, Vecs* Y, double c, Vecs& Z) {
+    for (int l = 0; l < nlev; ++l)
+      hipLaunchKernelGGL(k_smooth_axpbypcz, box_grid(lev[l]), dim3(256), 0, ctx->stream, lev[l]->view, a, X ? X->v[l]->view : Z.v[l]->view, X ? 1 : 0, b,
+                         Y ? Y->v[l]->view : Z.v[l]->view, Y ? 1 : 0, c, Z.v[l]->view);
+  }
+  void copy(Vecs& S, Vecs& D) {
+    for (int l = 0; l < nlev; ++l)
+      hipLaunchKernelGGL(k_smooth_copy, box_grid(lev[l]), dim3(256), 0, ctx->stream, lev[l]->view, S.v[l]->view, 0, D.v[l]->view, 0);
+  }
+};
+
+extern "C" int pa_smooth_solve(pa_ctx* ctx, int nlev, pa_mf* const* rhs, int rcomp, pa_mf* const* sol, int scomp, double dt, const int32_t bc[3], double tol,
+                               int maxiter, int* iters, double* res) {
+  if (!ctx || nlev <= 0 || !rhs || !sol || !bc) return pa_fail(ctx, "pa_smooth_solve: null argument");
+  SmoothSolver S;
+  S.ctx = ctx; S.nlev = nlev; S.ratio = 2; S.dt = dt;
+  for (int d = 0; d < 3; ++d) S.bc[d] = bc[d];
+  for (int l = 0; l < nlev; ++l) {
+    if (!rhs[l] || !sol[l] || rhs[l]->lev != sol[l]->lev) return pa_fail(ctx, "pa_smooth_solve: rhs/sol on different levels");
+    if (rcomp < 0 || rcomp >= rhs[l]->ncomp || scomp < 0 || scomp >= sol[l]->ncomp) return pa_fail(ctx, "pa_smooth_solve: component range");
+    S.lev.push_back(rhs[l]->lev);
+    if (l > 0)
+      for (const DBox& B : S.lev[l]->boxes)
+        for (int d = 0; d < 3; ++d)
+          if ((B.lo[d] & 1) || !((B.hi[d] - B.lo[d]) & 1)) return pa_fail(ctx, "pa_smooth_solve: fine boxes must be aligned to the refinement ratio 2");
+  }
+  if (S.alloc(S.r) || S.alloc(S.rh) || S.alloc(S.p) || S.alloc(S.v) || S.alloc(S.s) || S.alloc(S.t) || S.alloc(S.mask)) return 1;
+  Vecs x;  // the solution as a 1-comp vector (sol may have other components / ghost widths)
+  if (S.alloc(x)) return 1;
+  for (int l = 0; l < nlev; ++l) {
+    const pa_level* L = S.lev[l];
+    hipLaunchKernelGGL(k_smooth_mask, box_grid(L), dim3(256), 0, ctx->stream, L->view, S.mask.v[l]->view, l + 1 < nlev ? S.lev[l + 1]->view : L->view, l + 1 < nlev ? 1 : 0, 2);
+    hipLaunchKernelGGL(k_smooth_copy, box_grid(L), dim3(256), 0, ctx->stream, L->view, rhs[l]->view, rcomp, S.r.v[l]->view, 0);
+    hipLaunchKernelGGL(k_smooth_copy, box_grid(L), dim3(256), 0, ctx->stream, L->view, rhs[l]->view, rcomp, S.rh.v[l]->view, 0);
+  }
+  PA_HIP(hipGetLastError());
+  double bnorm, dummy, rho = 1.0, alpha = 1.0, omega = 1.0;
+  if (S.dot(S.r, S.r, &dummy, &bnorm)) return 1;
+  int it = 0, status = -1;
+  double rnorm = bnorm;
+  if (bnorm == 0.0) status = 0;
+  while (status != 0 && it < maxiter) {
+    ++it;
+    double rho1;
+    if (S.dot(S.rh, S.r, &rho1, &dummy)) return 1;
+    if (rho1 == 0.0) { status = -2; break; }
+    const double beta = (rho1 / rho) * (alpha / omega);
+    S.axpbypcz(-omega * beta, &S.v, 0.0, nullptr, beta, S.p);  // p = r + beta (p - omega v)
+    S.axpbypcz(1.0, &S.r, 0.0, nullptr, 1.0, S.p);
+    if (S.apply(S.p, S.v)) return 1;
+    double rhv;
+    if (S.dot(S.rh, S.v, &rhv, &dummy)) return 1;
+    if (rhv == 0.0) { status = -3; break; }
+    alpha = rho1 / rhv;
+    S.copy(S.r, S.s);  // s = r - alpha v
+    S.axpbypcz(-alpha, &S.v, 0.0, nullptr, 1.0, S.s);
+    double snorm;
+    if (S.dot(S.s, S.s, &dummy, &snorm)) return 1;
+    if (snorm <= tol * bnorm) {
+      S.axpbypcz(alpha, &S.p, 0.0, nullptr, 1.0, x);
+      rnorm = snorm;
+      status = 0;
+      break;
+    }
+    if (S.apply(S.s, S.t)) return 1;
+    double ts, tt;
+    if (S.dot(S.t, S.s, &ts, &dummy)) return 1;
+    if (S.dot(S.t, S.t, &tt, &dummy)) return 1;
+    if (tt == 0.0) { status = -4; break; }
+    omega = ts / tt;
+    S.axpbypcz(alpha, &S.p, omega, &S.s, 1.0, x);  // x += alpha p + omega s
+    S.copy(S.s, S.r);                               // r = s - omega t
+    S.axpbypcz(-omega, &S.t, 0.0, nullptr, 1.0, S.r);
+    if (S.dot(S.r, S.r, &dummy, &rnorm)) return 1;
+    rho = rho1;
+    if (rnorm <= tol * bnorm) { status = 0; break; }
+    if (omega == 0.0) { status = -5; break; }
+  }
+  for (int l = nlev - 1; l > 0; --l)
+    hipLaunchKernelGGL(k_smooth_avgdown, box_grid(S.lev[l]), dim3(256), 0, ctx->stream, S.lev[l]->view, x.v[l]->view, S.lev[l - 1]->view, x.v[l - 1]->view, 2);
+  for (int l = 0; l < nlev; ++l)
+    hipLaunchKernelGGL(k_smooth_copy, box_grid(S.lev[l]), dim3(256), 0, ctx->stream, S.lev[l]->view, x.v[l]->view, 0, sol[l]->view, scomp);
+  PA_HIP(hipGetLastError());
+  PA_HIP(hipStreamSynchronize(ctx->stream));  // the work vectors are freed on return
+  if (iters) *iters = it;
+  if (res) *res = bnorm > 0.0 ? rnorm / bnorm : 0.0;
+  if (status != 0) return pa_fail(ctx, "pa_smooth_solve: BiCGStab did not reach the tolerance (status " + std::to_string(status) + " after " + std::to_string(it) + " iterations)");
+  return 0;
+}

@@ -218,5 +218,27 @@ def test_curvature_tool_options(tmp_path, oracle):
         for b in range(lv.nboxes):
             v, w = r.mfs[l].valid(b), oc[l].valid(b)
             assert same(v[6], w[1]) and same(v[7:10], w[2:5]) and same(v[10], w[5]) and same(v[11], w[6]) and same(v[12:21], w[8:17]) and same(v[21], w[7])
-    bad = subprocess.run([os.path.join(BIN, "curvature3d.ex"), "infile=" + p, "do_smooth=1"], cwd=tmp_path, capture_output=True, text=True)
-    assert bad.returncode != 0 and "do_smooth" in bad.stderr
+
+
+@pytest.mark.gpu
+def test_curvature_tool_do_smooth(tmp_path, oracle):
+    """do_smooth=1 smoothing_time=<dt> (curvature.cpp:328-406): SmoothedProgress from the composite implicit solve
+    (to the oracle's solve within 1e-10), Progress untouched, curvature computed from the smoothed field"""
+    p, H, mfs = _synth(tmp_path, nlev=3, ncomp=1, names=("temp",))
+    _run("curvature3d.ex", ["infile=" + p, "is_per=1 1 0", "do_smooth=1", "smoothing_time=1e-3"], tmp_path)
+    r = read_plotfile(str(tmp_path / "plt00005_K"))
+    assert r.names == ["temp", "Progress", "SmoothedProgress", "MeanCurvature_temp", "FlameNormalX_temp", "FlameNormalY_temp", "FlameNormalZ_temp",
+                       "GaussianCurvature_temp"]
+    st = [MultiFab(lv, 1, 2) for lv in H.levels]
+    for l, lv in enumerate(H.levels):
+        for b in range(lv.nboxes):
+            st[l].valid(b)[:] = mfs[l].valid(b)
+    oc = [MultiFab(lv, 18, 0) for lv in H.levels]
+    oracle.curvature_pipeline(H.levels, st, 0, oracle.bc_from_flags((1, 1, 0)), oc, 0, MultiFab, do_smooth=True, smoothing_time=1e-3, smooth_tol=1e-13)
+    for l, lv in enumerate(H.levels):
+        for b in range(lv.nboxes):
+            v, w = r.mfs[l].valid(b), oc[l].valid(b)
+            assert np.array_equal(np.ascontiguousarray(v[1]).view(np.int64), np.ascontiguousarray(w[0]).view(np.int64))
+            assert np.abs(v[2] - w[17]).max() <= 1e-10 and np.abs(v[2] - v[1]).max() > 1e-4
+            strong = np.abs(w[17] - 0.5) < 0.45
+            assert np.abs((v[3] - w[1]) * strong).max() <= 1e-5 * max(np.abs(w[1]).max(), 1.0)

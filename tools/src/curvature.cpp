@@ -9,8 +9,9 @@
 // Deviations, all stated: SmoothedProgress / GaussianCurvature are 0.0 when their option is off (the
 // reference leaves them uninitialised: quirk Q1); StrainRate keeps the reference's value = div u
 // (quirk Q3); the velocities are also read when only do_velnormal is set (the reference reads them
-// only under do_strain and then indexes whatever sits at idVst); do_smooth (implicit multigrid
-// smoothing) is not ported and aborts.
+// only under do_strain and then indexes whatever sits at idVst); do_smooth=1 [smoothing_time=1e-7] solves
+// the reference's composite implicit diffusion problem to its tolerance (1e-12) with BiCGStab instead of
+// AMReX's MLMG (pa_smooth_solve): same field to ~1e-12, not the same iteration history.
 #include "../common/pa_device.h"
 
 int main(int argc, char** argv) {
@@ -42,7 +43,8 @@ int main(int argc, char** argv) {
   if (do_strain) pp.query("getStrainTensor", getStrainTensor);
   pp.query("do_velnormal", do_velnormal);
   pp.query("fused", fused);
-  if (do_smooth) pa::Abort("do_smooth (implicit smoothing of the progress variable) is not available in this build");
+  double smoothing_time = 1.e-7;  // curvature.cpp:93-94
+  pp.query("smoothing_time", smoothing_time);
   const int nAux = pp.countval("Aux_Variables");
   std::cout << "infile = " << infile << "\n" << "reading plt file = " << infile << "\n";
   pa::PlotfileHeader H = pa::read_header(infile);
@@ -78,8 +80,8 @@ int main(int argc, char** argv) {
   pp.queryarr("is_per", is_per, 0, 3);
   int32_t bc[3];
   pa::bc_from_flags(is_per, sym_dir, bc);
-  const bool options = do_gaussCurv || do_strain || do_velnormal;
-  const int nres = options ? 17 : 8;
+  const bool options = do_gaussCurv || do_strain || do_velnormal || do_smooth;
+  const int nres = options ? 18 : 8;
 
   pa::Ctx ctx;
   std::vector<std::unique_ptr<pa::DevLevel>> dl;
@@ -117,10 +119,12 @@ int main(int argc, char** argv) {
   pa_curv_params P;
   P.prog_min = progMin; P.prog_max = progMax; P.do_threshold = do_threshold; P.threshold = threshold; P.fused = fused;
   P.do_gauss_curv = do_gaussCurv; P.do_strain = do_strain; P.get_strain_tensor = getStrainTensor; P.do_velnormal = do_velnormal; P.vel_comp = idVst;
+  P.do_smooth = do_smooth; P.smoothing_time = smoothing_time;
   // result layout: fused sweep -> [gx gy gz |g| Nx Ny Nz K]; pass-by-pass with options -> [Progress K Nx Ny Nz Kg SR Vn ROSTx9]
   int rK, rN, rKg = -1, rSR = -1, rVn = -1, rROST = -1;
   if (options) {
     ctx.check(pa_curvature_run(ctx.h, Nlev, s.data(), 0, bc, &P, o.data(), 0));
+    if (do_smooth && verbose) std::cout << "Progress variable smoothed successfully \n";
     rK = 1; rN = 2; rKg = 5; rSR = 6; rVn = 7; rROST = 8;
   } else {
     ctx.check(pa_gradcurv_run(ctx.h, Nlev, s.data(), 0, bc, &P, w.data(), o.data(), 0));
@@ -145,6 +149,7 @@ int main(int argc, char** argv) {
           for (size_t i = 0; i < nx; ++i) pr[i] = (sv[i] - progMin) * invdenom;  // curvature.cpp:319 (same fp order as the device)
           cp(idKm, rK, k, j);
           for (int d = 0; d < 3; ++d) cp(idN + d, rN + d, k, j);
+          if (do_smooth) cp(idSmProg, 17, k, j);
           if (do_gaussCurv) cp(idKg, rKg, k, j);
           if (do_strain) cp(idSR, rSR, k, j);
           if (getStrainTensor) for (int q = 0; q < 9; ++q) cp(idROST + q, rROST + q, k, j);
