@@ -5,16 +5,26 @@
 #include "pa_fabview.h"
 #include <algorithm>
 #include <cfloat>
+#include <cstdlib>
 
 // ============================================================ grad.cpp:211-236
-template <typename BP>
-__global__ __launch_bounds__(256) void k_grad(BP bp, int comp, int ocomp) {
+// Block = 64 (x) x TY (y) columns marching tz planes in z with the z-column in registers (one wavefront per
+// row: 512 contiguous bytes); x/y neighbours come through L1/L2.  Tile shape tuned on MI355X (512^3 level of
+// 128^3 boxes): see the table in DESIGN.md section 3.
+template <typename BP, int TY>
+__global__ __launch_bounds__(64 * TY) void k_grad(BP bp, int comp, int ocomp, int tz) {
   FabView P, O;
   DBox V;
   double dxinv[3];
   if (!bp.get(blockIdx.y, P, O, V, dxinv)) return;
-  int i, j, k0, k1;
-  if (!tile_cell(V, i, j, k0, k1)) return;
+  const int nx = V.hi[0] - V.lo[0] + 1, ny = V.hi[1] - V.lo[1] + 1, nz = V.hi[2] - V.lo[2] + 1;
+  const int tx = (nx + 63) / 64, ty = (ny + TY - 1) / TY, ntz = (nz + tz - 1) / tz;
+  const unsigned bid = blockIdx.x;
+  if (bid >= (unsigned)tx * ty * ntz) return;
+  const int bx = bid % tx, by = (bid / tx) % ty, bz = bid / (tx * ty);
+  const int i = V.lo[0] + bx * 64 + (threadIdx.x & 63), j = V.lo[1] + by * TY + (threadIdx.x >> 6);
+  const int k0 = V.lo[2] + bz * tz, k1 = min(k0 + tz - 1, V.hi[2]);
+  if (i > V.hi[0] || j > V.hi[1]) return;
   // march in k keeping the z-column in registers
   double zm = P(i, j, k0 - 1, comp), zc = P(i, j, k0, comp);
   for (int k = k0; k <= k1; ++k) {
@@ -31,14 +41,28 @@ __global__ __launch_bounds__(256) void k_grad(BP bp, int comp, int ocomp) {
   }
 }
 
+template <typename BP>
+static void grad_launch(hipStream_t st, const BP& bp, int nx, int ny, int nz, unsigned nboxes, int comp, int ocomp) {
+  static const int ty_env = [] { const char* e = getenv("PA_GRAD_TY"); return e ? atoi(e) : 4; }();  // sweep (tools/grad_sweep.py): 1.34-1.51 ms, best 4 x 32
+  static const int tz_env = [] { const char* e = getenv("PA_GRAD_TZ"); return e ? atoi(e) : 32; }();
+  const int tz = std::max(1, std::min(tz_env, nz));
+  auto grid = [&](int TY) { return dim3((unsigned)(((nx + 63) / 64) * ((ny + TY - 1) / TY) * ((nz + tz - 1) / tz)), nboxes); };
+  switch (ny >= 16 ? ty_env : 4) {
+    case 16: hipLaunchKernelGGL((k_grad<BP, 16>), grid(16), dim3(1024), 0, st, bp, comp, ocomp, tz); break;
+    case 8: hipLaunchKernelGGL((k_grad<BP, 8>), grid(8), dim3(512), 0, st, bp, comp, ocomp, tz); break;
+    default: hipLaunchKernelGGL((k_grad<BP, 4>), grid(4), dim3(256), 0, st, bp, comp, ocomp, tz); break;
+  }
+}
+
 extern "C" int pa_grad_level(pa_ctx* ctx, const pa_mf* phi, int comp, pa_mf* out, int ocomp) {
   if (!ctx || !phi || !out) return pa_fail(ctx, "pa_grad_level: null argument");
   if (phi->lev != out->lev) return pa_fail(ctx, "pa_grad_level: phi and out live on different levels");
   if (phi->ng < 1) return pa_fail(ctx, "pa_grad_level: phi needs >= 1 ghost layer");
   if (comp < 0 || comp >= phi->ncomp || ocomp < 0 || ocomp + 4 > out->ncomp) return pa_fail(ctx, "pa_grad_level: component range");
   LevelBP2 bp{phi->lev->view, phi->view, out->view};
+  const pa_level* L = phi->lev;
   ProfScope prof(ctx, PA_TAG_GRAD);
-  hipLaunchKernelGGL(k_grad<LevelBP2>, tile_grid(phi->lev), dim3(256), 0, ctx->stream, bp, comp, ocomp);
+  grad_launch(ctx->stream, bp, L->maxn[0], L->maxn[1], L->maxn[2], (unsigned)L->boxes.size(), comp, ocomp);
   PA_HIP(hipGetLastError());
   return 0;
 }
@@ -48,7 +72,7 @@ extern "C" int pa_grad_fab(pa_ctx* ctx, pa_box valid, const pa_fab* phi, int com
   std::string why;
   if (!fab_covers(*phi, valid, 1, comp, 1, why) || !fab_covers(*out, valid, 0, ocomp, 4, why)) return pa_fail(ctx, "pa_grad_fab: " + why);
   FabBP2 bp{fab_view(*phi), fab_view(*out), to_dbox(valid), {dxinv[0], dxinv[1], dxinv[2]}};
-  hipLaunchKernelGGL(k_grad<FabBP2>, tile_grid(valid), dim3(256), 0, ctx->stream, bp, comp, ocomp);
+  grad_launch(ctx->stream, bp, valid.hi[0] - valid.lo[0] + 1, valid.hi[1] - valid.lo[1] + 1, valid.hi[2] - valid.lo[2] + 1, 1, comp, ocomp);
   PA_HIP(hipGetLastError());
   return 0;
 }

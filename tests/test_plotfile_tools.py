@@ -188,6 +188,20 @@ def test_isosurface_tool_distance_function(tmp_path, oracle):
         assert np.abs(v).max() == 0.0625 and (np.abs(v) < 0.0625).any()
     label, names, nodes, faces = read_mef(p + "_temp_1150.mef")
     assert np.array_equal(faces, oelts + 1) and np.array_equal(nodes.view(np.int64), onodes.view(np.int64))
+    # XDMF output (isosurface.cpp:2135-2229): same surface, 0-based connectivity, xyz then one array per component
+    _run("isosurface3d.ex", ["infile=" + p, "isoCompName=temp", "isoVal=1150", "comps=0 2", "build_distance_function=1", "outfile=" + str(tmp_path / "d2"),
+                            "surfFormat=XDMF", "outfile_base=" + str(tmp_path / "xs")], tmp_path)
+    xmf = open(str(tmp_path / "xs.xmf")).read()
+    raw = open(str(tmp_path / "xs.mesh"), "rb").read()
+    nn, ne = len(onodes), len(oelts)
+    assert f'NumberOfElements="{ne}"' in xmf and f'Seek="{12 * ne}" Dimensions="{3 * nn}"' in xmf and 'Value="1150"' in xmf and 'Attribute Name="density"' in xmf
+    assert len(raw) == 12 * ne + 8 * nn * 5
+    assert np.array_equal(np.frombuffer(raw[:12 * ne], "<i4").reshape(ne, 3), oelts)
+    xyz = np.frombuffer(raw[12 * ne:12 * ne + 24 * nn], "<f8").reshape(nn, 3)
+    assert np.array_equal(xyz.view(np.int64), np.ascontiguousarray(onodes[:, :3]).view(np.int64))
+    for c in range(2):
+        a = np.frombuffer(raw[12 * ne + 24 * nn + 8 * nn * c:12 * ne + 24 * nn + 8 * nn * (c + 1)], "<f8")
+        assert np.array_equal(a.view(np.int64), np.ascontiguousarray(onodes[:, 3 + c]).view(np.int64))
     # plain surface with two ghost layers: trimming leaves the one-ghost-layer surface
     _run("isosurface3d.ex", ["infile=" + p, "isoCompName=temp", "isoVal=1150", "comps=0 2", "nGrow=2", "outfile_base=" + str(tmp_path / "g2")], tmp_path)
     _, _, nodes2, faces2 = read_mef(str(tmp_path / "g2.mef"))

@@ -314,6 +314,42 @@ inline void write_mef(const std::string& file, double time, const std::vector<st
   f.write((const char*)e1.data(), sizeof(int32_t) * e1.size());
 }
 
+// XDMF surface (isosurface.cpp:2135-2229): <base>.xmf (XML, precision 8) + <base>.mesh = raw int32 0-based
+// connectivity, then xyz per node, then each mapped component as one array of doubles
+inline void write_xdmf(const std::string& base, double time, const std::string& isoCompName, double isoVal, const std::vector<std::string>& varnames,
+                       const std::vector<double>& nodes /* [N][3+nvar] */, const std::vector<int32_t>& elts0 /* [M][3], 0-based */) {
+  const int nvar = (int)varnames.size(), nc = 3 + nvar;
+  const size_t N = nodes.size() / (size_t)nc, M = elts0.size() / 3;
+  const std::string mesh = base + ".mesh";
+  std::ofstream x(base + ".xmf");
+  if (!x) Abort("Unable to create " + base + ".xmf");
+  x.precision(8);
+  size_t seek = sizeof(int32_t) * elts0.size();
+  x << "<?xml version=\"1.0\"?>\n<Xdmf Version=\"3.0\" xmlns:xi=\"http://www.w3.org/2001/XInclude\">\n   <Domain>\n      <Grid Name=\"isoSurface\">\n";
+  x << "      <Information Name=\"Variable\" Value=\"" << isoCompName << "\"/>\n";
+  x << "      <Information Name=\"IsoValue\" Value=\"" << isoVal << "\"/>\n";
+  x << "      <Time Value=\"" << time << "\"/>\n";
+  x << "         <Topology TopologyType=\"Triangle\" NumberOfElements=\"" << M << "\">\n";
+  x << "            <DataItem Name=\"Conn\" Format=\"Binary\" DataType=\"Int\" Dimensions=\"" << 3 * M << "\">\n               " << mesh << "\n            </DataItem>\n";
+  x << "         </Topology>\n         <Geometry GeometryType=\"XYZ\">\n";
+  x << "            <DataItem Name=\"Coord\" Format=\"Binary\" Precision=\"8\" DataType=\"Float\" Seek=\"" << seek << "\" Dimensions=\"" << 3 * N << "\">\n               " << mesh
+    << "\n            </DataItem>\n         </Geometry>\n";
+  seek += 3 * N * sizeof(double);
+  for (int c = 0; c < nvar; ++c) {
+    x << "         <Attribute Name=\"" << varnames[c] << "\" AttributeType=\"Scalar\" Center=\"Node\">\n";
+    x << "            <DataItem Format=\"Binary\" Precision=\"8\" DataType=\"Float\" Seek=\"" << seek << "\" Dimensions=\"" << N << "\">\n               " << mesh
+      << "\n            </DataItem>\n         </Attribute>\n";
+    seek += N * sizeof(double);
+  }
+  x << "      </Grid>\n   </Domain>\n</Xdmf>\n";
+  std::ofstream f(mesh, std::ios::binary | std::ios::trunc);
+  if (!f) Abort("Unable to create " + mesh);
+  f.write((const char*)elts0.data(), sizeof(int32_t) * elts0.size());
+  for (size_t q = 0; q < N; ++q) f.write((const char*)&nodes[q * nc], sizeof(double) * 3);
+  for (int c = 0; c < nvar; ++c)
+    for (size_t q = 0; q < N; ++q) f.write((const char*)&nodes[q * nc + 3 + c], sizeof(double));
+}
+
 // BoxArray::maxSize: chop every box into pieces <= n per direction (even split)
 inline std::vector<Box3> max_size(const std::vector<Box3>& in, int n) {
   std::vector<Box3> out;

@@ -57,6 +57,9 @@ ctx.check(ctx.lib.pa_fill_boundary(ctx.h, phi.h, 0, 1, 1))
 ms = timed(5, lambda: ctx.check(ctx.lib.pa_grad_level(ctx.h, phi.h, 0, gout.h, 0)))
 out["kernels"]["k_grad"] = {"ms": ms, "bytes_per_cell": 40, "GBs": cells * 40 / ms / 1e6, "frac_hbm": cells * 40 / ms / 1e6 / HBM, "Mcells_s": cells / ms / 1e3}
 del gout, tout
+if len(sys.argv) > 3 and sys.argv[3] == "gradonly":
+    print(json.dumps(out))
+    sys.exit(0)
 
 # ---- box filter (filterPlt.cpp:217): 16 B/cell, fgr 2 / 4 / 8 -> 27 / 125 / 729 taps
 for fgr in (2, 4, 8):

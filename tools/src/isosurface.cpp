@@ -10,7 +10,8 @@
 // triangles of the box grown by nGrow[lev] = int(dmax*1.0000001/dx_lev) feed the GPU distance function
 // (pa_sdf_level_set3 = Tools/SDFGen make_level_set3, batched over all FABs of a level), signed with
 // the iso component and clipped at dmax; written as a one-component plotfile "distance".
-// Not ported yet: periodic directions (quirk Q5), XDMF.
+//       [surfFormat=MEF|XDMF]
+// Not ported yet: periodic directions (quirk Q5).
 #include "../common/pa_device.h"
 #include "../common/pa_isomerge.h"
 
@@ -273,7 +274,7 @@ int main(int argc, char** argv) {
   pp.query("computeArea", computeArea);
   std::string surfFormat = "MEF";
   pp.query("surfFormat", surfFormat);
-  if (surfFormat != "MEF") pa::Abort("only surfFormat=MEF is available in this build");
+  if (surfFormat != "MEF" && surfFormat != "XDMF") pa::Abort("surfFormat must be MEF or XDMF");
   if (computeArea) {  // computed before the element list is released (the reference prints 0 here: quirk Q7)
     const auto& nd = merger.nodes();
     double area = 0;
@@ -285,7 +286,15 @@ int main(int argc, char** argv) {
     }
     std::cout << "Total area = " << area << std::endl;
   }
-  if (writeSurf) {
+  if (writeSurf && surfFormat == "XDMF") {  // isosurface.cpp:2135-2229; quirk kept: the default name carries the plotfile TIME, not isoVal
+    char buf[72];
+    std::snprintf(buf, sizeof buf, "%g", H.time);
+    std::string outfile_base = infile + "_" + isoCompName + "_" + std::string(buf);
+    pp.query("outfile_base", outfile_base);
+    std::vector<std::string> vn;
+    for (int n = 0; n < nComp; ++n) vn.push_back(H.names[pltComps[n]]);
+    pa::write_xdmf(outfile_base, H.time, isoCompName, isoVal, vn, merger.nodes(), elts);
+  } else if (writeSurf) {
     std::cout << "...write surface in mef format (mef = Marcs element format)" << std::endl;
     std::cout << "      (Nelts,Nnodes):(" << elts.size() / 3 << ", " << merger.num_nodes() << ")" << std::endl;
     std::vector<std::string> vars{"X", "Y", "Z"};
