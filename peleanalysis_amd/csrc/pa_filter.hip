@@ -8,6 +8,8 @@
 #include "pa_internal.h"
 #include "pa_fabview.h"
 #include <algorithm>
+#include <cstdlib>
+#include <type_traits>
 
 extern "C" int pa_box_filter_weights(int fgr, double* w) {
   // PelePhysics Filter::set_box_weights restated
@@ -64,6 +66,104 @@ __global__ __launch_bounds__(256) void k_boxfilter(BP bp, int scomp, int ncomp, 
   }
 }
 
+// Box weights, streaming form.  PelePhysics' box filter has w = (f/2, f, ..., f, f/2) with f = 1/fgr, so every
+// tap weight ((w_l*w_m)*w_n) is c3 = (f*f)*f times an exact power of two 2^-e (e = how many of l, m, n are end
+// indices), and the tap ((w_l*w_m)*w_n)*q = 2^-e * RN(c3*q) exactly: scaling by a power of two commutes with
+// rounding.  The reference's accumulation order of ONE output is n (z) outermost, then m (y), then l (x); an
+// output therefore consumes the input planes in ascending order, and the outputs k-NG..k+NG that share input
+// plane k can be advanced together without changing any output's own order.  Thread = (x,y) column with a
+// window of 2NG+1 running sums (output planes in flight, slot = plane mod (2NG+1), compile-time after unrolling
+// the plane loop by the window length); each input plane is staged ONCE in LDS (double-buffered, prefetched
+// through registers) and each staged value is read once per row and reused for the 2NG+1 outputs of the
+// window: 1/(2NG+1) LDS reads and 1 + 3/(2NG+1) fp64 instructions per tap instead of 2 and 2.  Bit-identical
+// to k_boxfilter / the oracle (except where c3*q is denormal, < 1e-307).
+template <typename BP, int NG>
+__global__ __launch_bounds__(256) void k_boxfilter_stream(BP bp, int scomp, int ncomp, double f, int kseg) {
+  constexpr int TX = 32, TY = 8, LX = TX + 2 * NG, LY = TY + 2 * NG, NW = 2 * NG + 1, NLD = (LX * LY + 255) / 256;
+  __shared__ double s_in[2][LY][LX];
+  FabView I, O;
+  DBox V;
+  double dxinv[3];
+  if (!bp.get(blockIdx.y, I, O, V, dxinv)) return;
+  const int nx = V.hi[0] - V.lo[0] + 1, ny = V.hi[1] - V.lo[1] + 1, nz = V.hi[2] - V.lo[2] + 1;
+  const int tx = (nx + TX - 1) / TX, ty = (ny + TY - 1) / TY, tz = (nz + kseg - 1) / kseg;
+  const unsigned bid = blockIdx.x;
+  if (bid >= (unsigned)tx * ty * tz) return;
+  const int i0 = V.lo[0] + (bid % tx) * TX, j0 = V.lo[1] + ((bid / tx) % ty) * TY, k0 = V.lo[2] + (bid / (tx * ty)) * kseg;
+  const int k1 = min(k0 + kseg - 1, V.hi[2]);
+  const int t = threadIdx.x, li = t % TX, lj = t / TX;
+  const int i = i0 + li, j = j0 + lj;
+  const bool live = i <= V.hi[0] && j <= V.hi[1];
+  const double c3 = (f * f) * f;
+  const int nq = k1 - k0 + 1 + 2 * NG;  // input planes k0-NG .. k1+NG
+  for (int c = scomp; c < scomp + ncomp; ++c) {
+    double acc[NW], pre[NLD];
+#pragma unroll
+    for (int q = 0; q < NW; ++q) acc[q] = 0.0;
+    auto fetch = [&](int q) {  // plane q of the segment into registers (positions past the box + NG are clamped, never used)
+      const int gk = k0 - NG + q;
+#pragma unroll
+      for (int r = 0; r < NLD; ++r) {
+        const int e = min(t + 256 * r, LX * LY - 1);
+        const int x = e % LX, y = e / LX;
+        pre[r] = I(min(i0 - NG + x, V.hi[0] + NG), min(j0 - NG + y, V.hi[1] + NG), gk, c);
+      }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+      for (int r = 0; r < NLD; ++r) {
+        const int e = t + 256 * r;
+        if (e < LX * LY) s_in[buf][e / LX][e % LX] = pre[r];
+      }
+    };
+    __syncthreads();  // the previous component's readers are done with both buffers
+    fetch(0);
+    stage(0);
+    __syncthreads();
+    auto step = [&](auto zzc, int q) __attribute__((always_inline)) {
+      constexpr int ZZ = decltype(zzc)::value;
+      const int buf = q & 1;
+      if (q + 1 < nq) fetch(q + 1);
+#pragma unroll 1
+      for (int m = 0; m < NW; ++m) {
+        const double c3m = (m == 0 || m == NW - 1) ? c3 * 0.5 : c3;  // exact scaling
+        double p[NW], h[NW];
+#pragma unroll
+        for (int l = 0; l < NW; ++l) {
+          p[l] = c3m * s_in[buf][lj + m][li + l];
+          if (l == 0 || l == NW - 1) p[l] = p[l] * 0.5;
+          h[l] = p[l] * 0.5;
+        }
+#pragma unroll
+        for (int d = 0; d < NW; ++d) {  // output a = q - d sees this plane as its n = d
+          constexpr int dummy = 0;
+          (void)dummy;
+          const int slot = ((ZZ - d) % NW + NW) % NW;
+#pragma unroll
+          for (int l = 0; l < NW; ++l) acc[slot] += (d == 0 || d == NW - 1) ? h[l] : p[l];
+        }
+      }
+      {  // the output whose last plane (n = 2NG) this was
+        constexpr int slot = ((ZZ - 2 * NG) % NW + NW) % NW;
+        const int a = q - 2 * NG;
+        if (a >= 0 && live) O(i, j, k0 + a, c) = acc[slot];
+        acc[slot] = 0.0;
+      }
+      if (q + 1 < nq) stage(buf ^ 1);
+      __syncthreads();
+    };
+    int q = 0;
+    // unrolled by the window length so that the slots are compile-time registers
+#define PA_FS(z) if (q < nq) { step(std::integral_constant<int, (z)>{}, q); ++q; }
+    while (q < nq) {
+      PA_FS(0) PA_FS(1) PA_FS(2)
+      if (NW > 3) { PA_FS(3 % NW) PA_FS(4 % NW) }
+      if (NW > 5) { PA_FS(5 % NW) PA_FS(6 % NW) PA_FS(7 % NW) PA_FS(8 % NW) }
+    }
+#undef PA_FS
+  }
+}
+
 // any filter width: taps straight from global memory (L1/L2), same summation order
 template <typename BP>
 __global__ __launch_bounds__(256) void k_boxfilter_generic(BP bp, int scomp, int ncomp, int ng, FilterW W) {
@@ -87,6 +187,20 @@ __global__ __launch_bounds__(256) void k_boxfilter_generic(BP bp, int scomp, int
 template <typename BP>
 static void filter_launch(hipStream_t st, const BP& bp, int nx, int ny, int nz, unsigned nboxes, int scomp, int ncomp, int ng, const FilterW& W) {
   auto grid = [&](int TX, int TY, int TZ) { return dim3(((nx + TX - 1) / TX) * ((ny + TY - 1) / TY) * ((nz + TZ - 1) / TZ), nboxes); };
+  // box weights (w0/2, w0, ..., w0, w0/2): the streaming kernel (PA_FILTER_STREAM=0 forces the tile kernel)
+  static const int stream_env = [] { const char* e = getenv("PA_FILTER_STREAM"); return e ? atoi(e) : 1; }();
+  const int nw = 2 * ng + 1;
+  bool box = stream_env && ng >= 1 && W.w[0] == 0.5 * W.w[1] && W.w[nw - 1] == W.w[0];
+  for (int q = 2; q < nw - 1 && box; ++q) box = W.w[q] == W.w[1];
+  if (box && (ng == 1 || ng == 2 || ng == 4)) {
+    static const int kseg_env = [] { const char* e = getenv("PA_FILTER_KSEG"); return e ? atoi(e) : 32; }();
+    const int kseg = std::max(1, std::min(kseg_env, nz));
+    const dim3 g = grid(32, 8, kseg);
+    if (ng == 1) hipLaunchKernelGGL((k_boxfilter_stream<BP, 1>), g, dim3(256), 0, st, bp, scomp, ncomp, W.w[1], kseg);
+    else if (ng == 2) hipLaunchKernelGGL((k_boxfilter_stream<BP, 2>), g, dim3(256), 0, st, bp, scomp, ncomp, W.w[1], kseg);
+    else hipLaunchKernelGGL((k_boxfilter_stream<BP, 4>), g, dim3(256), 0, st, bp, scomp, ncomp, W.w[1], kseg);
+    return;
+  }
   if (ng == 1) hipLaunchKernelGGL((k_boxfilter<BP, 1, 32, 8, 8>), grid(32, 8, 8), dim3(256), 0, st, bp, scomp, ncomp, W);
   else if (ng == 2) hipLaunchKernelGGL((k_boxfilter<BP, 2, 32, 8, 8>), grid(32, 8, 8), dim3(256), 0, st, bp, scomp, ncomp, W);
   else if (ng == 4) hipLaunchKernelGGL((k_boxfilter<BP, 4, 32, 8, 4>), grid(32, 8, 4), dim3(256), 0, st, bp, scomp, ncomp, W);
