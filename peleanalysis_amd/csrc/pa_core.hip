@@ -39,6 +39,8 @@ extern "C" void pa_ctx_destroy(pa_ctx* ctx) {
   if (ctx->d_flags) (void)hipFree(ctx->d_flags);
   if (ctx->d_scr) (void)hipFree(ctx->d_scr);
   for (auto& e : ctx->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  for (auto& e : ctx->sync_evs) (void)hipEventDestroy(e);
+  if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }

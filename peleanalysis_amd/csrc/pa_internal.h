@@ -50,6 +50,10 @@ struct pa_ctx {
   bool profile = false;
   struct Ev { hipEvent_t a, b; int tag; };
   std::vector<Ev> evs;
+  // second stream + ordering events of the fused pipeline (boundary kernels of one level next to the sweep of
+  // another; pa_pipeline.hip); created on first use
+  hipStream_t stream2 = nullptr;
+  std::vector<hipEvent_t> sync_evs;
 };
 
 // RAII: records an event pair around a tagged kernel launch when profiling is enabled

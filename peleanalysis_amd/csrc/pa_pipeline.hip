@@ -139,17 +139,75 @@ static int fused_pre(pa_ctx* ctx, int l, pa_mf* const* state, int comp, const in
   return 0;
 }
 
+// Two-stream schedule of the fused pipeline.  The sweep leaves the CU's vector units, a third of its registers
+// and 69 KB of LDS idle (it is bound by the store path), and the boundary kernels are latency-
+// bound on little data, so the ghost-cell preparation of the NEXT levels and the face fix-up of the PREVIOUS
+// level run on a second stream next to the sweep:
+//   stream A: prep(0) sweep(0)          sweep(1)            sweep(2)        [wait faces(2)]
+//   stream B: prep(1) prep(2) .. faces(0)  ..     faces(1)   ..       faces(2)
+// prep(l) writes only ghost cells of phi_l and the shell copy of c_l and reads VALID cells of phi_{l-1};
+// sweep(l) needs prep(l); faces(l) needs sweep(l), the shell of c_l and the final normals of level l-1.
+// MEASURED (MI355X, headline workload, twice): 8.53 / 8.61 ms per step with the overlap against 8.43 / 8.69 ms
+// without -- the sweep slows from 2.23-2.31 to 2.57-2.60 ms per launch and gives back everything the second
+// stream hides: both sides wait on the same memory path.  Kept for A/B (PA_OVERLAP=1), OFF by default.
+static int overlap_on() {
+  static const int v = [] { const char* e = getenv("PA_OVERLAP"); return e ? atoi(e) : 0; }();
+  return v;
+}
+struct StreamSwap {  // the level entry points launch on ctx->stream
+  pa_ctx* c;
+  hipStream_t keep;
+  StreamSwap(pa_ctx* ctx, hipStream_t s) : c(ctx), keep(ctx->stream) { ctx->stream = s; }
+  ~StreamSwap() { c->stream = keep; }
+};
+
+static int fused_faces(pa_ctx* ctx, int l, const int32_t bc[3], double thr, pa_mf* const* work, pa_mf* const* out, int ocomp) {
+  return pa_gradcurv_faces_level(ctx, work[l], 0, l > 0 ? out[l - 1] : nullptr, ocomp + 4, bc, 2, thr, out[l], ocomp + 4, ocomp + 7);
+}
+
 static int fused_passes(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, const int32_t bc[3], double pmin, double pmax, double thr,
                         pa_mf* const* work, pa_mf* const* out, int ocomp) {
   for (int l = 0; l < nlev; ++l)
     if (state[l]->ng < 2 || work[l]->ng < 2) return pa_fail(ctx, "fused grad->curvature needs 2 ghost layers on state and work");
-  // One stream: running the boundary kernels of one level on a second stream next to the sweep of
-  // another was measured (MI355X, headline workload) to give no gain -- both compete for HBM.
-  for (int l = 0; l < nlev; ++l) PA_TRY(fused_pre(ctx, l, state, comp, bc, pmin, pmax, work));
-  for (int l = 0; l < nlev; ++l) {
-    PA_TRY(pa_gradcurv_level(ctx, state[l], comp, pmin, pmax, thr, out[l], ocomp));
-    PA_TRY(pa_gradcurv_faces_level(ctx, work[l], 0, l > 0 ? out[l - 1] : nullptr, ocomp + 4, bc, 2, thr, out[l], ocomp + 4, ocomp + 7));
+  if (!overlap_on() || nlev < 2) {
+    for (int l = 0; l < nlev; ++l) PA_TRY(fused_pre(ctx, l, state, comp, bc, pmin, pmax, work));
+    for (int l = 0; l < nlev; ++l) {
+      PA_TRY(pa_gradcurv_level(ctx, state[l], comp, pmin, pmax, thr, out[l], ocomp));
+      PA_TRY(fused_faces(ctx, l, bc, thr, work, out, ocomp));
+    }
+    return 0;
   }
+  if (!ctx->stream2) PA_HIP(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+  const size_t nev = 2 + 3 * (size_t)nlev;
+  while (ctx->sync_evs.size() < nev) {
+    hipEvent_t e;
+    PA_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    ctx->sync_evs.push_back(e);
+  }
+  hipStream_t A = ctx->stream, B = ctx->stream2;
+  hipEvent_t e_start = ctx->sync_evs[0], e_end = ctx->sync_evs[1];
+  auto e_prep = [&](int l) { return ctx->sync_evs[2 + l]; };
+  auto e_sweep = [&](int l) { return ctx->sync_evs[2 + nlev + l]; };
+  PA_HIP(hipEventRecord(e_start, A));  // B starts after everything already queued on A (inputs, the previous component)
+  PA_HIP(hipStreamWaitEvent(B, e_start, 0));
+  {
+    StreamSwap sw(ctx, B);
+    for (int l = 1; l < nlev; ++l) {
+      PA_TRY(fused_pre(ctx, l, state, comp, bc, pmin, pmax, work));
+      PA_HIP(hipEventRecord(e_prep(l), B));
+    }
+  }
+  PA_TRY(fused_pre(ctx, 0, state, comp, bc, pmin, pmax, work));
+  for (int l = 0; l < nlev; ++l) {
+    if (l > 0) PA_HIP(hipStreamWaitEvent(A, e_prep(l), 0));
+    PA_TRY(pa_gradcurv_level(ctx, state[l], comp, pmin, pmax, thr, out[l], ocomp));
+    PA_HIP(hipEventRecord(e_sweep(l), A));
+    PA_HIP(hipStreamWaitEvent(B, e_sweep(l), 0));
+    StreamSwap sw(ctx, B);
+    PA_TRY(fused_faces(ctx, l, bc, thr, work, out, ocomp));
+  }
+  PA_HIP(hipEventRecord(e_end, B));
+  PA_HIP(hipStreamWaitEvent(A, e_end, 0));  // later work on the caller's stream sees the finished level data
   return 0;
 }
 
