@@ -136,6 +136,7 @@ static pa_level* level_create_impl(pa_ctx* ctx, int nboxes, const int32_t* b6, i
   if (!ctx) return nullptr;
   if (nboxes <= 0 || !b6) { pa_fail(ctx, "pa_level_create: empty BoxArray"); return nullptr; }
   pa_level* L = new pa_level();
+  L->nremote = nremote;
   L->ctx = ctx;
   L->boxes.resize(nboxes);
   for (int d = 0; d < 3; ++d) {

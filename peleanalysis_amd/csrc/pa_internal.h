@@ -93,6 +93,7 @@ struct pa_level {
   int maxn[3] = {0, 0, 0};  // max box extent per dim
   long long ncells = 0;
   bool fusable = true;      // no concave coarse-fine corner (see pa_level_create)
+  int nremote = 0;          // boxes of this level owned by other ranks (pa_level_create_dist)
   DLevelView view;
 };
 

@@ -131,6 +131,15 @@ __global__ __launch_bounds__(256) void k_sdf_band(const SdfGrid* grids, int band
   }
 }
 
+// every triangle must refer to existing vertices (a bad index would be an out-of-bounds read): counts offenders
+__global__ __launch_bounds__(256) void k_sdf_check(const SdfGrid* grids, const long long* nvert, int* nbad) {
+  const SdfGrid G = grids[blockIdx.y];
+  const unsigned nv = (unsigned)min(nvert[blockIdx.y], 0xFFFFFFFFll);
+  int bad = 0;
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < 3 * G.ntri; t += (long long)gridDim.x * blockDim.x) bad += G.tri[t] >= nv;
+  if (bad) atomicAdd(nbad, bad);
+}
+
 __global__ __launch_bounds__(256) void k_sdf_unpack(const SdfGrid* grids) {
   const SdfGrid G = grids[blockIdx.y];
   const long long n = (long long)G.ni * G.nj * G.nk;
@@ -227,8 +236,8 @@ extern "C" int pa_sdf_level_set3(pa_ctx* ctx, int ngrids, const pa_sdf_grid* gri
     max_cells = std::max(max_cells, n);
     max_tri = std::max(max_tri, (long long)S.ntri);
   }
-  // scratch: descriptors | keys (8 B per point) | closest triangle (4 B per point)
-  const size_t desc_bytes = ((size_t)ngrids * sizeof(SdfGrid) + 255) / 256 * 256;
+  // scratch: descriptors + vertex counts | keys (8 B per point) | closest triangle (4 B per point)
+  const size_t desc_bytes = ((size_t)ngrids * (sizeof(SdfGrid) + sizeof(long long)) + 255) / 256 * 256;
   if (ensure_scr_sdf(ctx, desc_bytes + cells * 12 + 256)) return 1;
   unsigned char* base = (unsigned char*)ctx->d_scr;
   unsigned long long* keys = (unsigned long long*)(base + desc_bytes);
@@ -244,12 +253,24 @@ extern "C" int pa_sdf_level_set3(pa_ctx* ctx, int ngrids, const pa_sdf_grid* gri
     D.phi = S.phi; D.key = keys + at; D.ct = cts + at;
     at += (size_t)S.n[0] * S.n[1] * S.n[2];
   }
-  // the index check the kernels rely on: every triangle refers to an existing vertex (host-visible
-  // meshes only: device meshes are the caller's marching-cubes output, valid by construction)
+  std::vector<long long> hnv((size_t)ngrids);
+  for (int g = 0; g < ngrids; ++g) hnv[(size_t)g] = grids[g].nvert;
+  long long* dnv = (long long*)(base + (size_t)ngrids * sizeof(SdfGrid));
   PA_HIP(hipMemcpyAsync(base, h.data(), (size_t)ngrids * sizeof(SdfGrid), hipMemcpyHostToDevice, ctx->stream));
-  PA_HIP(hipStreamSynchronize(ctx->stream));  // h goes out of scope
+  PA_HIP(hipMemcpyAsync(dnv, hnv.data(), (size_t)ngrids * sizeof(long long), hipMemcpyHostToDevice, ctx->stream));
   const SdfGrid* dg = (const SdfGrid*)base;
   const unsigned gx_cells = (unsigned)std::min<long long>((max_cells + 255) / 256, 4096);
+  if (max_tri > 0) {  // shape check on the device data before a kernel dereferences an index
+    int* dbad = ctx->d_flags + 8;
+    int hbad = 0;
+    PA_HIP(hipMemsetAsync(dbad, 0, sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(k_sdf_check, dim3((unsigned)std::min<long long>((3 * max_tri + 255) / 256, 4096), (unsigned)ngrids), dim3(256), 0, ctx->stream, dg, dnv, dbad);
+    PA_HIP(hipMemcpyAsync(&hbad, dbad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    PA_HIP(hipStreamSynchronize(ctx->stream));
+    if (hbad) return pa_fail(ctx, "pa_sdf_level_set3: " + std::to_string(hbad) + " triangle vertex indices are out of range");
+  } else {
+    PA_HIP(hipStreamSynchronize(ctx->stream));  // h goes out of scope
+  }
   hipLaunchKernelGGL(k_sdf_init, dim3(gx_cells, (unsigned)ngrids), dim3(256), 0, ctx->stream, dg);
   if (max_tri > 0) {
     const unsigned gx_tri = (unsigned)std::min<long long>((max_tri + 255) / 256, 4096);

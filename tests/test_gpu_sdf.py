@@ -83,3 +83,11 @@ def test_sdf_signed_fab(ctx):
     got = ddist.to_numpy(np.float64, n[::-1])
     want = np.where(state[1] < iso, -1.0, 1.0) * np.minimum(dmax, phi.astype(np.float64))
     assert np.array_equal(got.view(np.int64), want.view(np.int64))
+
+
+def test_sdf_rejects_bad_triangle_indices(ctx):
+    """host-side shape check before a hand-written kernel touches caller memory: an index >= nvert is an error, not a fault"""
+    verts = np.array([[0.1, 0.1, 0.1], [0.9, 0.1, 0.1], [0.1, 0.9, 0.1]], dtype=np.float32)
+    tris = np.array([[0, 1, 2], [0, 1, 7]], dtype=np.uint32)
+    with pytest.raises(capi.PaError, match="out of range"):
+        capi.sdf_level_set(ctx, [(tris, verts, (0.0, 0.0, 0.0), 0.1, (5, 5, 5))], 1)
