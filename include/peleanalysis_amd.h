@@ -213,6 +213,17 @@ int pa_sdf_level_set3(pa_ctx*, int ngrids, const pa_sdf_grid* grids /* host arra
 int pa_sdf_signed_fab(pa_ctx*, pa_box vbox, const float* dev_phi, const pa_fab* state, int isocomp, double isoval,
                       double dmax, pa_fab* dist, int dcomp);
 
+/* ------------------------------------------------------------- streamlines
+ * partStream.cpp:121-207 / StreamPC.cpp: two lines per seed (line 2s forward, 2s+1 backward) of nsteps
+ * points each, RK4 with step dt (= hRK * finest dx in the tool) through the trilinear interpolant of
+ * vfield[lev] comps vcomp..vcomp+2, whose nGrow ghost layers the caller has filled (FillPatch with
+ * piecewise-constant interpolation + FillBoundary, partStream.cpp:160-177).  A line interpolates from the
+ * grid it was last assigned to; all lines are re-assigned to the finest level containing them whenever one
+ * leaves its grid grown by nGrow-1 (StreamPC.cpp:88-141).  seeds: host [nseed][3]; dev_pos: device
+ * [2*nseed][nsteps][3].  Returns non-zero where the reference aborts with "bad RK".  Synchronous. */
+int pa_stream_trace(pa_ctx*, int nlev, pa_mf* const* vfield, int vcomp, int64_t nseed, const double* seeds, int nsteps,
+                    double dt, double* dev_pos, int32_t* nredist /* may be NULL */);
+
 /* ------------------------------------------------------------ tool pipelines
  * The level loops of the tool mains, operating on device-resident MultiFabs.
  * levels/state/out are arrays of nlev pointers, coarse first. */

@@ -360,6 +360,41 @@ def smooth_apply(levels, x, dt, bc, MF):
     return y, mask
 
 
+# ---------------------------------------------------------------- streamlines (partStream.cpp / StreamPC.cpp)
+def stream_field(levels, fields, comps, MF, ngrow=3):
+    """partStream.cpp:160-177: vector field with nGrow ghost layers, FillPatch with piecewise-constant
+    interpolation from the coarser level, then FillBoundary.  Ghost cells outside a non-periodic domain
+    are left at 0.0 (the reference leaves them uninitialised)."""
+    L = lib()
+    out = []
+    for l, lv in enumerate(levels):
+        v = MF(lv, 3, ngrow)
+        for b in range(lv.nboxes):
+            for d, c in enumerate(comps):
+                v.valid(b)[d] = fields[l].valid(b)[c]
+        fill_boundary(v, 0, 3, ngrow)
+        if l > 0:
+            nbad = L.orc_fillpatch_two_levels(_p(_mf(v)), _p(_mf(out[l - 1])), 0, 3, ngrow, 2, 0)
+            assert nbad == 0
+        out.append(v)
+    return out
+
+
+def stream_trace(levels, vfield, seeds, nsteps, dt):
+    """orc_stream_trace -> (pos [2*nseed][nsteps][3], number of redistributions)"""
+    L = lib()
+    seeds = np.ascontiguousarray(seeds, dtype=np.float64).reshape(-1, 3)
+    pos = np.zeros((2 * len(seeds), nsteps, 3))
+    va, keep = _mfptrs(vfield)
+    nred = C.c_int32(0)
+    L.orc_stream_trace.restype = C.c_int
+    rc = L.orc_stream_trace(len(levels), va, 0, C.c_int64(len(seeds)), seeds.ctypes.data_as(C.c_void_p), int(nsteps), C.c_double(dt),
+                            pos.ctypes.data_as(C.c_void_p), C.byref(nred))
+    if rc != 0:
+        raise RuntimeError(f"bad RK (line {rc})")
+    return pos, nred.value
+
+
 # ---------------------------------------------------------------- isosurface pipeline
 def iso_merge(fragments, ncomp):
     """isosurface.cpp:1687-1726 + 1751-1812 restated: merge per-FAB (verts, tris) fragments in order.

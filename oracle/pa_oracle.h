@@ -125,6 +125,10 @@ void orc_smooth_apply(int nlev, orc_mf* const* x, orc_mf* const* y, const orc_mf
 int orc_smooth_solve(int nlev, orc_mf* const* rhs, int rcomp, orc_mf* const* sol, orc_mf* const* work, double dt,
                      const int32_t bc[3], int ratio, double tol, int maxiter, double* res);
 
+/* ---- partStream.cpp / StreamPC.cpp, pa_oracle_stream.c ----------------- */
+int orc_stream_trace(int nlev, const orc_mf* const* v, int vcomp, int64_t nseed, const double* seeds, int nsteps, double dt, double* pos,
+                     int32_t* nredist);
+
 /* ---- isosurface -------------------------------------------------------- */
 const int32_t* orc_mc_edge_table(void); /* [256] */
 const int32_t* orc_mc_tri_table(void);  /* [256][16] */

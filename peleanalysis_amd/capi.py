@@ -111,6 +111,7 @@ def load_library() -> C.CDLL:
         "pa_sdf_level_set3": (C.c_int, [vp, C.c_int, C.POINTER(PaSdfGrid), C.c_int]),
         "pa_sdf_signed_fab": (C.c_int, [vp, PaBox, vp, C.POINTER(PaFab), C.c_int, dbl, dbl, C.POINTER(PaFab), C.c_int]),
         "pa_smooth_solve": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.c_int, C.POINTER(vp), C.c_int, dbl, pi32, dbl, C.c_int, C.POINTER(C.c_int), pdbl]),
+        "pa_stream_trace": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.c_int, i64, pdbl, C.c_int, dbl, vp, pi32]),
         "pa_grad_run": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.c_int, pi32, C.POINTER(vp), C.c_int]),
         "pa_curvature_run": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.c_int, pi32, C.POINTER(PaCurvParams), C.POINTER(vp), C.c_int]),
         "pa_gradcurv_run": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.c_int, pi32, C.POINTER(PaCurvParams), C.POINTER(vp), C.POINTER(vp),
@@ -354,3 +355,14 @@ def smooth_solve(ctx, rhs, rcomp, sol, scomp, dt, bc, tol=1e-12, maxiter=100):
     ctx.check(ctx.lib.pa_smooth_solve(ctx.h, len(rhs), _handles(rhs), rcomp, _handles(sol), scomp, float(dt), _i3(bc), float(tol), int(maxiter),
                                       C.byref(it), C.byref(res)))
     return it.value, res.value
+
+
+def stream_trace(ctx, vfield, vcomp, seeds, nsteps, dt):
+    """pa_stream_trace -> (pos float64 [2*nseed][nsteps][3], number of redistributions)"""
+    seeds = np.ascontiguousarray(seeds, dtype=np.float64).reshape(-1, 3)
+    n = len(seeds)
+    buf = DevBuf(ctx, max(8 * 2 * n * nsteps * 3, 8))
+    nred = C.c_int32(0)
+    ctx.check(ctx.lib.pa_stream_trace(ctx.h, len(vfield), _handles(vfield), int(vcomp), n, seeds.ctypes.data_as(C.POINTER(C.c_double)), int(nsteps),
+                                      float(dt), C.c_void_p(buf.ptr), C.byref(nred)))
+    return buf.to_numpy(np.float64, (2 * n, nsteps, 3)), nred.value

@@ -256,3 +256,38 @@ def test_curvature_tool_do_smooth(tmp_path, oracle):
             assert np.abs(v[2] - w[17]).max() <= 1e-10 and np.abs(v[2] - v[1]).max() > 1e-4
             strong = np.abs(w[17] - 0.5) < 0.45
             assert np.abs((v[3] - w[1]) * strong).max() <= 1e-5 * max(np.abs(w[1]).max(), 1.0)
+
+
+@pytest.mark.gpu
+def test_partstream_tool_end_to_end(tmp_path, oracle):
+    """partStream3d.ex (partStream.cpp / StreamPC.cpp): seeds from the isosurface tool's MEF nodes and from a rake;
+    the Tecplot zones (seed order, forward then backward line) equal the oracle's lines to the 6 digits written"""
+    p, H, mfs = _synth(tmp_path, nlev=3, ncomp=4, names=("temp", "x_velocity", "y_velocity", "z_velocity"), per=(0, 0, 0))
+    _run("isosurface3d.ex", ["infile=" + p, "isoCompName=temp", "isoVal=1150", "comps=0", "outfile_base=" + str(tmp_path / "surf")], tmp_path)
+    _, _, nodes, _ = read_mef(str(tmp_path / "surf.mef"))
+    fields = [MultiFab(lv, 4, 0, mfs[l].data.copy()) for l, lv in enumerate(H.levels)]
+    v = oracle.stream_field(H.levels, fields, (1, 2, 3), MultiFab, ngrow=3)
+    dt = 0.2 * float(H.levels[-1].dx[0])
+
+    def zones(path):
+        txt = open(path).read().split("\n")
+        assert txt[0].strip() == "VARIABLES = X Y Z"
+        out, cur = [], None
+        for ln in txt[1:]:
+            if ln.startswith("ZONE"):
+                cur = []
+                out.append(cur)
+            elif ln.strip():
+                cur.append([float(t) for t in ln.split()])
+        return np.array(out)
+
+    for args, seeds in ((["isoFile=" + str(tmp_path / "surf.mef")], nodes[:, :3]),
+                        (["seedRakeNum=5", "seedRakeL=0.3 0.4 0.45", "seedRakeR=0.7 0.6 0.55"],
+                         np.array([[0.3 + (i / 4.0) * (0.7 - 0.3), 0.4 + (i / 4.0) * (0.6 - 0.4), 0.45 + (i / 4.0) * (0.55 - 0.45)] for i in range(5)]))):
+        _run("partStream3d.ex", ["infile=" + p, "Nsteps=30", "hRK=0.2"] + args, tmp_path)
+        z = zones(str(tmp_path / "tec.dat" / "str_00000.dat"))
+        want, _ = oracle.stream_trace(H.levels, v, seeds, 30, dt)
+        assert z.shape == want.shape and len(seeds) >= 5
+        assert np.abs(z - want).max() <= 5e-6 * max(1.0, np.abs(want).max())  # ostream default precision: 6 significant digits
+    bad = subprocess.run([os.path.join(BIN, "partStream3d.ex"), "infile=" + p], cwd=tmp_path, capture_output=True, text=True)
+    assert bad.returncode != 0 and "Assertion" in bad.stderr
