@@ -321,7 +321,7 @@ static void march_launch(hipStream_t st, const BP& bp, int nx, int ny, int nz, u
       else if (A.order) g = dim3(g.x * g.y, 1);
       switch (dbg) {
 #define PA_DBGCASE(D) case D: hipLaunchKernelGGL((k_gradcurv_march3<BP, 13, false, false, D>), g, dim3(64 * 16), 0, st, bp, A); return;
-        PA_DBGCASE(1) PA_DBGCASE(7) PA_DBGCASE(16)
+        PA_DBGCASE(1) PA_DBGCASE(7) PA_DBGCASE(256)
 #undef PA_DBGCASE
         default: break;
       }

@@ -6,6 +6,12 @@
 // vmcnt retires in issue order that wait also covered the previous plane's 8 stores.  One memory
 // round trip (and one store acknowledge) therefore sat on the barrier-to-barrier critical path of
 // every plane, in all three wave roles.  Here
+//   * SCHEDULE OF A STEP (the largest single effect, measured 2.27 -> 1.92 ms per launch): all 8 stores of the
+//     previous plane go out in ONE burst at the top of the step, and every role issues its request for the
+//     plane three steps ahead right AFTER the plane's barrier -- loads and stores never sit next to each other
+//     in a wave's instruction stream.  With the requests at the top of the step, directly in front of the
+//     stores (the first v3 schedule, kept as DBG 256 for A/B), the same kernel takes 2.27 ms; moving only the
+//     output rows' request behind the barrier gives 2.02-2.10, all roles 1.97, plus the burst 1.92.
 //   * every role keeps THREE planes in flight (f0,f1,f2): the plane consumed in a step was
 //     requested three steps earlier, so a step waits only for stores that are >= 4 planes old
 //     (`vmcnt(26)`); the loop is unrolled by 3 = the LDS ring period, which also makes every ring
@@ -71,11 +77,10 @@ __device__ __forceinline__ double favg(double fl, double fh) { return -(0.5 * (f
 #define PA_OPAQUE(x) asm volatile("" : "+v"(x))
 #define PA_LDG(base, off) (*(const double*)((const char*)(base) + (off)))
 #define PA_STG(base, off, v) (*(double*)((char*)(base) + (off)) = (v))
-#define PA_STL(base, off, v) do { if (!(DBG & 8) && (!(DBG & 1) || (v) == 1.2345e-300)) PA_STG(base, off, v); } while (0)
+#define PA_STL(base, off, v) do { if (!(DBG & 1) || (v) == 1.2345e-300) PA_STG(base, off, v); } while (0)
 
-// DBG (diagnostic builds only, selected with PA_DBG; results are wrong except 8 and 16: store
-// timing only): 8 = the 8 stores of a plane in one burst at the top of the next step, 16 = at most one
-// plane of stores outstanding per wave (vmcnt(8) at the top of a step); 1 = no global stores in the
+// DBG (diagnostic builds only, selected with PA_DBG): 256 = the first v3 schedule (requests at the top of a
+// step, stores spread over it; results correct); wrong results on purpose: 1 = no global stores in the
 // loop (a never-true data-dependent condition keeps the arithmetic alive), 2 = sqrt and divisions
 // replaced by additions, 4 = no x/y-neighbour reads from LDS (own values instead).
 // PAIR: 16-byte stores.  A CU issues `global_store_dwordx2` at only ~7 B/cycle (measured: with 8-B
@@ -108,6 +113,7 @@ __global__ __launch_bounds__(64 * (PA_MTY + 3), 1) void k_gradcurv_march3(BP bp,
   DBox V;
   double dxinv[3];
   constexpr int PA_MROWS = PA_MTY + 2;
+  constexpr bool OLD_SCHED = (DBG & 256) != 0;  // requests at the top of a step + stores spread over it (first v3 schedule)
   unsigned bid = blockIdx.x;
   int box;
   if (A.order == 2) {
@@ -210,8 +216,10 @@ __global__ __launch_bounds__(64 * (PA_MTY + 3), 1) void k_gradcurv_march3(BP bp,
         __builtin_amdgcn_sched_barrier(0);
         gp += (p + 5 <= kfmax) ? pps : 0;
         go += (p + 4 <= pend) ? pps : 0;
-        f[SP] = PA_LDG(gp, lo8);
-        fo[SP] = PA_LDG(go, lo8);
+        if (OLD_SCHED) {
+          f[SP] = PA_LDG(gp, lo8);
+          fo[SP] = PA_LDG(go, lo8);
+        }
         const double cl = S.c[SP][rr][xs - 1], cr = S.c[SP][rr][xs + 1];
         const double cin = S.c[SP][(rr == 0) ? 1 : rr - 1][xs];
         const double cs = (rr == 0) ? co : cin, cn = (rr == 0) ? cin : co;
@@ -225,6 +233,11 @@ __global__ __launch_bounds__(64 * (PA_MTY + 3), 1) void k_gradcurv_march3(BP bp,
         S.c[SP1][rr][xs] = cp;
         S.p[SP][rr][xs] = p0;
         __syncthreads();
+        if (!OLD_SCHED) {
+          PA_OPAQUE(lo8);
+          f[SP] = PA_LDG(gp, lo8);
+          fo[SP] = PA_LDG(go, lo8);
+        }
         cm = cc; cc = cp; cp = PA_PROG(x); co = PA_PROG(xo);
         fzc = fzh;
         p0 = p1; p1 = x;
@@ -251,9 +264,8 @@ __global__ __launch_bounds__(64 * (PA_MTY + 3), 1) void k_gradcurv_march3(BP bp,
     const bool odd = lane & 1;
     unsigned lo16 = odd ? (unsigned)(le - 1) * 8u + (unsigned)osc : (unsigned)le * 8u;
     // normal at plane p, outputs at plane q = p-1.  The 8 results of a plane are kept in registers
-    // and stored DURING the next plane's normal computation (see pa_fused_march.h); the first three
-    // steps have nothing valid to store yet and write to plane k0, which the same thread
-    // overwrites in program order.
+    // and stored at the top of the next step; the first three steps have nothing valid to store yet
+    // and write to plane k0, which the same thread overwrites in program order.
     double o0 = 0, o1 = 0, o2 = 0, o3 = 0, o4 = 0, o5 = 0, o6 = 0, o7 = 0;
     auto step = [&](auto spc, int p) __attribute__((always_inline)) {
       constexpr int SP = decltype(spc)::value, SP1 = (SP + 1) % 3, SQ = (SP + 2) % 3;
@@ -262,42 +274,49 @@ __global__ __launch_bounds__(64 * (PA_MTY + 3), 1) void k_gradcurv_march3(BP bp,
       PA_OPAQUE(lo8);
       __builtin_amdgcn_sched_barrier(0);
       gp += (p + 5 <= kfmax) ? pps : 0;
-      if (DBG & 16) __builtin_amdgcn_s_waitcnt(0x0F70 | 8);  // vmcnt(8): at most one plane of stores outstanding
-      f[SP] = PA_LDG(gp, lo8);
-      if (DBG & 8) {  // all 8 stores of the previous plane in one burst
-        PA_STG(ob, lo8, o0); PA_STG(ob + osc, lo8, o1); PA_STG(ob + 2 * osc, lo8, o2); PA_STG(ob + 3 * osc, lo8, o3);
-        PA_STG(ob + 4 * osc, lo8, o4); PA_STG(ob + 5 * osc, lo8, o5); PA_STG(ob + 6 * osc, lo8, o6); PA_STG(ob + 7 * osc, lo8, o7);
+      if (OLD_SCHED) f[SP] = PA_LDG(gp, lo8);
+      if (!OLD_SCHED) {  // the 8 results of the previous plane, one burst; the request for plane p+5 follows the barrier
+        if (PAIR) {
+          PA_OPAQUE(lo16);
+          store_pair(ob, lo16, odd, o0, o1); store_pair(ob + 2 * osc, lo16, odd, o2, o3);
+          store_pair(ob + 4 * osc, lo16, odd, o4, o5); store_pair(ob + 6 * osc, lo16, odd, o6, o7);
+        } else {
+          PA_STL(ob, lo8, o0); PA_STL(ob + osc, lo8, o1); PA_STL(ob + 2 * osc, lo8, o2); PA_STL(ob + 3 * osc, lo8, o3);
+          PA_STL(ob + 4 * osc, lo8, o4); PA_STL(ob + 5 * osc, lo8, o5); PA_STL(ob + 6 * osc, lo8, o6); PA_STL(ob + 7 * osc, lo8, o7);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // the burst stays ahead of the plane's arithmetic
       }
       const double cl = (DBG & 4) ? cm : S.c[SP][rr][xs - 1], cr = (DBG & 4) ? cp : S.c[SP][rr][xs + 1];
       const double cs = (DBG & 4) ? cm : S.c[SP][rr - 1][xs], cn = (DBG & 4) ? cp : S.c[SP][rr + 1][xs];
-      if (PAIR) { PA_OPAQUE(lo16); store_pair(ob, lo16, odd, o0, o1); } else PA_STL(ob, lo8, o0);
-      __builtin_amdgcn_sched_barrier(0);
+      if (OLD_SCHED) { if (PAIR) { PA_OPAQUE(lo16); store_pair(ob, lo16, odd, o0, o1); } else PA_STL(ob, lo8, o0); }
+      if (OLD_SCHED) __builtin_amdgcn_sched_barrier(0);
       const double ggx = cdiff(dxinv[0], cl, cc, cr);
       const double ggy = cdiff(dxinv[1], cs, cc, cn);
       const double fzh = zflux(dxinv[2], cc, cp);
       const double ggz = favg(fzc, fzh);
-      __builtin_amdgcn_sched_barrier(0);
-      if (!PAIR) PA_STL(ob + osc, lo8, o1);
-      __builtin_amdgcn_sched_barrier(0);
+      if (OLD_SCHED) __builtin_amdgcn_sched_barrier(0);
+      if (OLD_SCHED && !PAIR) PA_STL(ob + osc, lo8, o1);
+      if (OLD_SCHED) __builtin_amdgcn_sched_barrier(0);
       const double sn = (DBG & 2) ? (ggx * ggx + ggy * ggy + ggz * ggz) : sqrt(ggx * ggx + ggy * ggy + ggz * ggz);
       const double ng = -((1e-14 < sn) ? sn : 1e-14);
-      __builtin_amdgcn_sched_barrier(0);
-      if (PAIR) { PA_OPAQUE(lo16); store_pair(ob + 2 * osc, lo16, odd, o2, o3); } else PA_STL(ob + 2 * osc, lo8, o2);
-      __builtin_amdgcn_sched_barrier(0);
+      if (OLD_SCHED) __builtin_amdgcn_sched_barrier(0);
+      if (OLD_SCHED) { if (PAIR) { PA_OPAQUE(lo16); store_pair(ob + 2 * osc, lo16, odd, o2, o3); } else PA_STL(ob + 2 * osc, lo8, o2); }
+      if (OLD_SCHED) __builtin_amdgcn_sched_barrier(0);
       double nxp, nyp, nzp;
       if (DBG & 2) { nxp = ggx + ng; nyp = ggy + ng; nzp = ggz + ng; }
       else div3_shared(ggx, ggy, ggz, ng, nxp, nyp, nzp);
       PA_OPAQUE(lo8);  // new basic block after the guard's branch: see PA_OPAQUE
-      __builtin_amdgcn_sched_barrier(0);
-      if (!PAIR) PA_STL(ob + 3 * osc, lo8, o3);
-      __builtin_amdgcn_sched_barrier(0);
+      if (OLD_SCHED) __builtin_amdgcn_sched_barrier(0);
+      if (OLD_SCHED && !PAIR) PA_STL(ob + 3 * osc, lo8, o3);
+      if (OLD_SCHED) __builtin_amdgcn_sched_barrier(0);
       S.ny[SP][rr][lane] = nyp;
       S.nx[SP][rr - 1][xs] = nxp;
       S.c[SP1][rr][xs] = cp;
       S.p[SP][rr][xs] = p0;
-      __builtin_amdgcn_sched_barrier(0);
-      if (!PAIR) PA_STL(ob + 4 * osc, lo8, o4);
+      if (OLD_SCHED) __builtin_amdgcn_sched_barrier(0);
+      if (OLD_SCHED && !PAIR) PA_STL(ob + 4 * osc, lo8, o4);
       __syncthreads();
+      if (!OLD_SCHED) { PA_OPAQUE(lo8); f[SP] = PA_LDG(gp, lo8); }  // request for plane p+5, after the barrier (see the header)
       const double nxl = (DBG & 4) ? nzq : S.nx[SQ][rr - 1][xs - 1], nxr = (DBG & 4) ? nzp : S.nx[SQ][rr - 1][xs + 1];
       const double nys = (DBG & 4) ? nzq : S.ny[SQ][rr - 1][lane], nyn = (DBG & 4) ? nzp : S.ny[SQ][rr + 1][lane];
       const double fznh = zflux(dxinv[2], nzq, nzp);
@@ -306,9 +325,9 @@ __global__ __launch_bounds__(64 * (PA_MTY + 3), 1) void k_gradcurv_march3(BP bp,
       curv += cdiff(dxinv[1], nys, nyq, nyn);
       curv += favg(fzn, fznh);
       curv = curv * 0.5;
-      __builtin_amdgcn_sched_barrier(0);
-      if (PAIR) { PA_OPAQUE(lo16); store_pair(ob + 4 * osc, lo16, odd, o4, o5); } else PA_STL(ob + 5 * osc, lo8, o5);
-      __builtin_amdgcn_sched_barrier(0);
+      if (OLD_SCHED) __builtin_amdgcn_sched_barrier(0);
+      if (OLD_SCHED) { if (PAIR) { PA_OPAQUE(lo16); store_pair(ob + 4 * osc, lo16, odd, o4, o5); } else PA_STL(ob + 5 * osc, lo8, o5); }
+      if (OLD_SCHED) __builtin_amdgcn_sched_barrier(0);
       // phi gradient at plane q (pc = phi(q), p0 = phi(q+1); fzp = low z-face flux at plane q)
       const double pl = (DBG & 4) ? p1 : S.p[SQ][rr][xs - 1], pr = (DBG & 4) ? p0 : S.p[SQ][rr][xs + 1];
       const double ps = (DBG & 4) ? p1 : S.p[SQ][rr - 1][xs], pnn = (DBG & 4) ? p0 : S.p[SQ][rr + 1][xs];
@@ -316,12 +335,12 @@ __global__ __launch_bounds__(64 * (PA_MTY + 3), 1) void k_gradcurv_march3(BP bp,
       const double gy = cdiff(dxinv[1], ps, pc, pnn);
       const double fzph = zflux(dxinv[2], pc, p0);
       const double gz = favg(fzp, fzph);
-      __builtin_amdgcn_sched_barrier(0);
-      if (!PAIR) PA_STL(ob + 6 * osc, lo8, o6);
-      __builtin_amdgcn_sched_barrier(0);
+      if (OLD_SCHED) __builtin_amdgcn_sched_barrier(0);
+      if (OLD_SCHED && !PAIR) PA_STL(ob + 6 * osc, lo8, o6);
+      if (OLD_SCHED) __builtin_amdgcn_sched_barrier(0);
       const double gm = (DBG & 2) ? (gx * gx + gy * gy + gz * gz) : sqrt(gx * gx + gy * gy + gz * gz);
-      __builtin_amdgcn_sched_barrier(0);
-      if (PAIR) { PA_OPAQUE(lo16); store_pair(ob + 6 * osc, lo16, odd, o6, o7); } else PA_STL(ob + 7 * osc, lo8, o7);
+      if (OLD_SCHED) __builtin_amdgcn_sched_barrier(0);
+      if (OLD_SCHED) { if (PAIR) { PA_OPAQUE(lo16); store_pair(ob + 6 * osc, lo16, odd, o6, o7); } else PA_STL(ob + 7 * osc, lo8, o7); }
       ob += (p >= k0 + 2) ? ops : 0;
       o0 = gx; o1 = gy; o2 = gz; o3 = gm;
       if (CLIP) {  // threshold clip (curvature.cpp:557-566); cm = c at plane q
@@ -406,8 +425,10 @@ __global__ __launch_bounds__(64 * (PA_MTY + 3), 1) void k_gradcurv_march3(BP bp,
       __builtin_amdgcn_sched_barrier(0);
       gp += (p + 5 <= kfmax) ? pps : 0;
       go += (p + 4 <= pend) ? pps : 0;
-      f[SP] = PA_LDG(gp, og);
-      fo[SP] = PA_LDG(go, oo);
+      if (OLD_SCHED) {
+        f[SP] = PA_LDG(gp, og);
+        fo[SP] = PA_LDG(go, oo);
+      }
       const double inner = S.c[SP][rr][xin];
       const double cl = side ? inner : co, cr = side ? co : inner;
       const double cs = S.c[SP][rlo][xs], cn = S.c[SP][rhi][xs];
@@ -422,6 +443,12 @@ __global__ __launch_bounds__(64 * (PA_MTY + 3), 1) void k_gradcurv_march3(BP bp,
       S.c[SP1][rr][xs] = cp;
       S.p[SP][rr][xs] = p0;
       __syncthreads();
+      if (!OLD_SCHED) {
+        PA_OPAQUE(og);
+        PA_OPAQUE(oo);
+        f[SP] = PA_LDG(gp, og);
+        fo[SP] = PA_LDG(go, oo);
+      }
       cm = cc; cc = cp; cp = PA_PROG(x); co = PA_PROG(xo);
       fzc = fzh;
       p0 = p1; p1 = x;
