@@ -270,7 +270,7 @@ static int fused_kseg() {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("PA_KSEG");
-    v = e ? atoi(e) : 128;
+    v = e ? atoi(e) : 64;  // planes per workgroup: 64 vs 128 measured 1.91 vs 1.94 ms with the burst schedule (within noise; more, shorter workgroups)
     if (v < 4) v = 4;
   }
   return v;
@@ -321,7 +321,7 @@ static void march_launch(hipStream_t st, const BP& bp, int nx, int ny, int nz, u
       else if (A.order) g = dim3(g.x * g.y, 1);
       switch (dbg) {
 #define PA_DBGCASE(D) case D: hipLaunchKernelGGL((k_gradcurv_march3<BP, 13, false, false, D>), g, dim3(64 * 16), 0, st, bp, A); return;
-        PA_DBGCASE(1) PA_DBGCASE(7) PA_DBGCASE(256)
+        PA_DBGCASE(1) PA_DBGCASE(7) PA_DBGCASE(256) PA_DBGCASE(512) PA_DBGCASE(1024)
 #undef PA_DBGCASE
         default: break;
       }

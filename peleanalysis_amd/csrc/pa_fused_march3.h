@@ -275,7 +275,7 @@ __global__ __launch_bounds__(64 * (PA_MTY + 3), 1) void k_gradcurv_march3(BP bp,
       __builtin_amdgcn_sched_barrier(0);
       gp += (p + 5 <= kfmax) ? pps : 0;
       if (OLD_SCHED) f[SP] = PA_LDG(gp, lo8);
-      if (!OLD_SCHED) {  // the 8 results of the previous plane, one burst; the request for plane p+5 follows the barrier
+      if (!OLD_SCHED && !(DBG & 512)) {  // the 8 results of the previous plane, one burst; the request for plane p+5 follows the barrier
         if (PAIR) {
           PA_OPAQUE(lo16);
           store_pair(ob, lo16, odd, o0, o1); store_pair(ob + 2 * osc, lo16, odd, o2, o3);
@@ -315,8 +315,13 @@ __global__ __launch_bounds__(64 * (PA_MTY + 3), 1) void k_gradcurv_march3(BP bp,
       S.p[SP][rr][xs] = p0;
       if (OLD_SCHED) __builtin_amdgcn_sched_barrier(0);
       if (OLD_SCHED && !PAIR) PA_STL(ob + 4 * osc, lo8, o4);
+      if (DBG & 512) {  // experiment: the burst just before the barrier
+        PA_OPAQUE(lo8);
+        PA_STL(ob, lo8, o0); PA_STL(ob + osc, lo8, o1); PA_STL(ob + 2 * osc, lo8, o2); PA_STL(ob + 3 * osc, lo8, o3);
+        PA_STL(ob + 4 * osc, lo8, o4); PA_STL(ob + 5 * osc, lo8, o5); PA_STL(ob + 6 * osc, lo8, o6); PA_STL(ob + 7 * osc, lo8, o7);
+      }
       __syncthreads();
-      if (!OLD_SCHED) { PA_OPAQUE(lo8); f[SP] = PA_LDG(gp, lo8); }  // request for plane p+5, after the barrier (see the header)
+      if (!OLD_SCHED && !(DBG & 1024)) { PA_OPAQUE(lo8); f[SP] = PA_LDG(gp, lo8); }  // request for plane p+5, after the barrier (see the header)
       const double nxl = (DBG & 4) ? nzq : S.nx[SQ][rr - 1][xs - 1], nxr = (DBG & 4) ? nzp : S.nx[SQ][rr - 1][xs + 1];
       const double nys = (DBG & 4) ? nzq : S.ny[SQ][rr - 1][lane], nyn = (DBG & 4) ? nzp : S.ny[SQ][rr + 1][lane];
       const double fznh = zflux(dxinv[2], nzq, nzp);
@@ -341,6 +346,7 @@ __global__ __launch_bounds__(64 * (PA_MTY + 3), 1) void k_gradcurv_march3(BP bp,
       const double gm = (DBG & 2) ? (gx * gx + gy * gy + gz * gz) : sqrt(gx * gx + gy * gy + gz * gz);
       if (OLD_SCHED) __builtin_amdgcn_sched_barrier(0);
       if (OLD_SCHED) { if (PAIR) { PA_OPAQUE(lo16); store_pair(ob + 6 * osc, lo16, odd, o6, o7); } else PA_STL(ob + 7 * osc, lo8, o7); }
+      if (DBG & 1024) { PA_OPAQUE(lo8); f[SP] = PA_LDG(gp, lo8); }  // experiment: the request at the end of the step
       ob += (p >= k0 + 2) ? ops : 0;
       o0 = gx; o1 = gy; o2 = gz; o3 = gm;
       if (CLIP) {  // threshold clip (curvature.cpp:557-566); cm = c at plane q
