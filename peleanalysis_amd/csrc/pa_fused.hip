@@ -16,6 +16,7 @@
 #include "pa_fabview.h"
 #include "pa_fused_march.h"
 #include "pa_fused_march3.h"
+#include "pa_fused_march3n.h"
 #include <cstdlib>
 
 #ifndef PA_FC_WAVES
@@ -310,6 +311,17 @@ static void march_launch(hipStream_t st, const BP& bp, int nx, int ny, int nz, u
   int sel = fused_mty();
   if (sel < 0) sel = (ny >= 52) ? 131 : (ny >= 16 ? 81 : 41);  // short boxes do not fill a 13-row tile
   static const int march_ver = [] { const char* e = getenv("PA_MARCH"); return e ? atoi(e) : 3; }();  // 1: k_gradcurv_march (A/B)
+  static const int narrow_env = [] { const char* e = getenv("PA_NARROW"); return e ? atoi(e) : 1; }();
+  if (march_ver == 3 && narrow_env && nx <= 32) {  // boxes at most 32 cells wide: two rows per wavefront (pa_fused_march3n.h)
+    constexpr int NRW = 8;
+    const unsigned tiles = (unsigned)(((nx + 31) / 32) * ((ny + 2 * NRW - 1) / (2 * NRW)) * ((nz + A.kseg - 1) / A.kseg));
+    A.tiles_max = (int)tiles;
+    if (A.order == 1) A.order = 0;
+    const dim3 g = A.order == 2 ? dim3(tiles * 8u * ((nboxes + 7u) / 8u), 1) : dim3(tiles, nboxes);
+    if (A.thr >= 0.0) hipLaunchKernelGGL((k_gradcurv_march3n<BP, NRW, true>), g, dim3(64 * (NRW + 2)), 0, st, bp, A);
+    else hipLaunchKernelGGL((k_gradcurv_march3n<BP, NRW, false>), g, dim3(64 * (NRW + 2)), 0, st, bp, A);
+    return;
+  }
   if (march_ver == 3) {
     const bool clip = A.thr >= 0.0;
     static const int dbg = [] { const char* e = getenv("PA_DBG"); return e ? atoi(e) : 0; }();  // diagnostic variants (wrong results)

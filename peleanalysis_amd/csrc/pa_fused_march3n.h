@@ -1,0 +1,308 @@
+// pa_fused_march3n.h -- fused grad->curvature sweep for NARROW boxes (at most 32 cells in x, AMReX's default
+// max_grid_size in 3-D): k_gradcurv_march3's algorithm, arithmetic and step schedule with TWO rows of 32
+// columns per wavefront, so that a wave's loads and stores stay 512 contiguous bytes (two adjacent 256-byte rows
+// of a 32-wide output FAB) instead of half-empty 64-lane rows (measured with the wide kernel on 32^3 boxes:
+// 2.72 ms per 512^3 level against 1.93 ms on 128^3 boxes).
+//   waves 0..NRW-1   two output rows each: lanes 0-31 row 2w, lanes 32-63 row 2w+1 of the tile (NRW*2 rows),
+//   wave  NRW        the two halo rows: lanes 0-31 the row below the tile, lanes 32-63 the row above,
+//   wave  NRW+1      the edge wave: the columns left/right of the tile (c, phi, n_x only).
+// Rows past the end of a partial tile are clamped onto the last valid row: such lanes repeat that row's
+// computation exactly (same LDS slots, same global addresses) and store the same values again.
+// Everything else -- the 3-slot LDS ring, three planes in flight per role, the burst of 8 stores at the top of
+// a step and the requests after the barrier, scalar base + lane offset addressing, carried z-fluxes,
+// div3_shared -- is as in pa_fused_march3.h (read that header first).  Bit-identical to it and to the oracle.
+#pragma once
+#include "pa_fused_march3.h"
+
+template <int NRW>
+struct MarchLdsN {
+  static constexpr int ROWS = 2 * NRW + 2, LW = 34;
+  double c[3][ROWS][LW];       // x index 0 = left edge column, 1..32 = columns, llast+2 = right edge column
+  double p[3][ROWS][LW];
+  double nx[3][2 * NRW][LW];   // n_x of the output rows (+ edge columns)
+  double ny[3][ROWS][32];
+};
+
+template <typename BP, int NRW, bool CLIP>
+__global__ __launch_bounds__(64 * (NRW + 2), 1) void k_gradcurv_march3n(BP bp, MarchArgs A) {
+  FabView P, O;
+  DBox V;
+  double dxinv[3];
+  constexpr int MTY2 = 2 * NRW, MROWS = MTY2 + 2;
+  unsigned bid = blockIdx.x;
+  int box;
+  if (A.order == 2) {
+    const unsigned per8 = 8u * (unsigned)A.tiles_max, g = bid / per8, r = bid % per8;
+    box = (int)(g * 8u + (r & 7u));
+    bid = r >> 3;
+    if (box >= A.nboxes) return;
+  } else {
+    box = (int)blockIdx.y;
+  }
+  if (!bp.get(box, P, O, V, dxinv)) return;
+  const int pcomp = A.pcomp, kseg = A.kseg;
+  const double pmin = A.pmin, invd = A.invdenom;
+  const int nx = V.hi[0] - V.lo[0] + 1, ny = V.hi[1] - V.lo[1] + 1, nz = V.hi[2] - V.lo[2] + 1;
+  const int tx = (nx + 31) / 32, ty = (ny + MTY2 - 1) / MTY2, tz = (nz + kseg - 1) / kseg;
+  if (bid >= (unsigned)tx * ty * tz) return;  // uniform for the whole workgroup
+  const int bx = bid % tx, by = (bid / tx) % ty, bz = bid / (tx * ty);
+  const int i0 = V.lo[0] + bx * 32, j0 = V.lo[1] + by * MTY2;
+  const int k0 = V.lo[2] + bz * kseg, k1 = min(k0 + kseg - 1, V.hi[2]);
+  const int iR = min(i0 + 32, V.hi[0] + 1);  // column right of the tile's last valid column
+  const int llast = iR - 1 - i0;
+  const int nrows = min(MTY2, V.hi[1] - j0 + 1);  // valid output rows of this tile
+  const int rtop = nrows + 1;                     // row slot of the upper halo row
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int rsub = lane >> 5, col = lane & 31;
+
+  __shared__ MarchLdsN<NRW> S;
+  const long long pps = (long long)P.nx * P.ny * 8;  // plane stride of phi, bytes
+  const int pend = k1 + 1;
+  const int kfmax = k1 + 2;
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+#define PA_PROG(x) (((x) - pmin) * invd) /* curvature.cpp:319 */
+#define PA_RUN3(step)                                                                                                  \
+  {                                                                                                                    \
+    int p = k0 - 1;                                                                                                    \
+    _Pragma("unroll 1") for (; p + 2 <= pend; p += 3) {                                                                \
+      step(I0{}, p);                                                                                                   \
+      step(I1{}, p + 1);                                                                                               \
+      step(I2{}, p + 2);                                                                                               \
+    }                                                                                                                  \
+    if (p <= pend) {                                                                                                   \
+      step(I0{}, p);                                                                                                   \
+      if (p + 1 <= pend) step(I1{}, p + 1);                                                                            \
+    }                                                                                                                  \
+  }
+
+  if (w < NRW) {
+    // ------------------------------------------------------------------------- output rows
+    const int rr = min(1 + 2 * w + rsub, nrows);  // row slot 1..nrows; rows past the tile repeat the last one
+    const int le = min(col, llast);
+    const int xs = le + 1;
+    // wave-uniform bases at the tile's first row, per-lane byte offsets (row inside the tile, column)
+    unsigned lo8 = (unsigned)((rr - 1) * P.nx + le) * 8u;
+    unsigned so8 = (unsigned)((rr - 1) * O.nx + le) * 8u;
+    const char* gp = (const char*)(P.p + P.idx(i0, j0, k0 - 2, pcomp));
+    double pc = PA_LDG(gp, lo8), p0 = PA_LDG(gp + pps, lo8), p1 = PA_LDG(gp + 2 * pps, lo8);
+    double cm = PA_PROG(pc), cc = PA_PROG(p0), cp = PA_PROG(p1);
+    double fzc = zflux(dxinv[2], cm, cc);
+    double f[3];
+    f[0] = PA_LDG(gp + 3 * pps, lo8);
+    f[1] = PA_LDG(gp + 4 * pps, lo8);
+    gp += 4 * pps;
+    gp += (k0 + 3 <= kfmax) ? pps : 0;
+    f[2] = PA_LDG(gp, lo8);
+    asm volatile("" ::"v"(f[0]), "v"(f[1]), "v"(f[2]));  // enter the loop with nothing in flight (see pa_fused_march3.h)
+    S.c[0][rr][xs] = cc;
+    __syncthreads();
+    double nxq = 0, nyq = 0, nzq = 0, fzn = 0, fzp = 0;
+    char* ob = (char*)(O.p + O.idx(i0, j0, k0, A.ocomp));
+    const long long ops = (long long)O.nx * O.ny * 8, osc = O.sc * 8;
+    const double thr = A.thr;
+    double o0 = 0, o1 = 0, o2 = 0, o3 = 0, o4 = 0, o5 = 0, o6 = 0, o7 = 0;
+    auto step = [&](auto spc, int p) __attribute__((always_inline)) {
+      constexpr int SP = decltype(spc)::value, SP1 = (SP + 1) % 3, SQ = (SP + 2) % 3;
+      double x;
+      PA_TAKE(x, f[SP]);
+      PA_OPAQUE(so8);
+      __builtin_amdgcn_sched_barrier(0);
+      gp += (p + 5 <= kfmax) ? pps : 0;
+      PA_STG(ob, so8, o0); PA_STG(ob + osc, so8, o1); PA_STG(ob + 2 * osc, so8, o2); PA_STG(ob + 3 * osc, so8, o3);
+      PA_STG(ob + 4 * osc, so8, o4); PA_STG(ob + 5 * osc, so8, o5); PA_STG(ob + 6 * osc, so8, o6); PA_STG(ob + 7 * osc, so8, o7);
+      __builtin_amdgcn_sched_barrier(0);
+      const double cl = S.c[SP][rr][xs - 1], cr = S.c[SP][rr][xs + 1];
+      const double cs = S.c[SP][rr - 1][xs], cn = S.c[SP][rr + 1][xs];
+      const double ggx = cdiff(dxinv[0], cl, cc, cr);
+      const double ggy = cdiff(dxinv[1], cs, cc, cn);
+      const double fzh = zflux(dxinv[2], cc, cp);
+      const double ggz = favg(fzc, fzh);
+      const double sn = sqrt(ggx * ggx + ggy * ggy + ggz * ggz);
+      const double ng = -((1e-14 < sn) ? sn : 1e-14);
+      double nxp, nyp, nzp;
+      div3_shared(ggx, ggy, ggz, ng, nxp, nyp, nzp);
+      S.ny[SP][rr][col] = nyp;
+      S.nx[SP][rr - 1][xs] = nxp;
+      S.c[SP1][rr][xs] = cp;
+      S.p[SP][rr][xs] = p0;
+      __syncthreads();
+      PA_OPAQUE(lo8);
+      f[SP] = PA_LDG(gp, lo8);  // request for plane p+5, after the barrier
+      const double nxl = S.nx[SQ][rr - 1][xs - 1], nxr = S.nx[SQ][rr - 1][xs + 1];
+      const double nys = S.ny[SQ][rr - 1][col], nyn = S.ny[SQ][rr + 1][col];
+      const double fznh = zflux(dxinv[2], nzq, nzp);
+      double curv = 0.0;
+      curv += cdiff(dxinv[0], nxl, nxq, nxr);
+      curv += cdiff(dxinv[1], nys, nyq, nyn);
+      curv += favg(fzn, fznh);
+      curv = curv * 0.5;
+      const double pl = S.p[SQ][rr][xs - 1], pr = S.p[SQ][rr][xs + 1];
+      const double ps = S.p[SQ][rr - 1][xs], pnn = S.p[SQ][rr + 1][xs];
+      const double gx = cdiff(dxinv[0], pl, pc, pr);
+      const double gy = cdiff(dxinv[1], ps, pc, pnn);
+      const double fzph = zflux(dxinv[2], pc, p0);
+      const double gz = favg(fzp, fzph);
+      const double gm = sqrt(gx * gx + gy * gy + gz * gz);
+      ob += (p >= k0 + 2) ? ops : 0;
+      o0 = gx; o1 = gy; o2 = gz; o3 = gm;
+      if (CLIP) {  // threshold clip (curvature.cpp:557-566); cm = c at plane q
+        const bool clip = (cm < thr) || (cm > 1.0 - thr);
+        o4 = clip ? 0.0 : nxq;
+        o5 = clip ? 0.0 : nyq;
+        o6 = clip ? 0.0 : nzq;
+        o7 = clip ? 0.0 : curv;
+      } else {
+        o4 = nxq; o5 = nyq; o6 = nzq; o7 = curv;
+      }
+      cm = cc; cc = cp; cp = PA_PROG(x);
+      fzc = fzh; fzn = fznh; fzp = fzph;
+      pc = p0; p0 = p1; p1 = x;
+      nxq = nxp; nyq = nyp; nzq = nzp;
+    };
+    PA_RUN3(step)
+    PA_STG(ob, so8, o0); PA_STG(ob + osc, so8, o1); PA_STG(ob + 2 * osc, so8, o2); PA_STG(ob + 3 * osc, so8, o3);
+    PA_STG(ob + 4 * osc, so8, o4); PA_STG(ob + 5 * osc, so8, o5); PA_STG(ob + 6 * osc, so8, o6); PA_STG(ob + 7 * osc, so8, o7);
+    return;
+  }
+
+  if (w == NRW) {
+    // ------------------------------------------------------------------------- the two halo rows
+    const int rr = rsub ? rtop : 0;                 // row slot
+    const int j = rsub ? j0 + nrows : j0 - 1;       // its row, and the row beyond it (one y-neighbour comes from global)
+    const int jout = rsub ? j + 1 : j - 1;
+    const int rin = rsub ? rtop - 1 : 1;            // the tile row next to it
+    const int le = min(col, llast);
+    const int xs = le + 1;
+    const char* gb = (const char*)(P.p + P.idx(i0, P.lo[1], k0 - 2, pcomp));  // wave-uniform: first row of the FAB
+    unsigned lo8 = (unsigned)((j - P.lo[1]) * P.nx + le) * 8u;
+    unsigned oo8 = (unsigned)((jout - P.lo[1]) * P.nx + le) * 8u;
+    const char* gp = gb;
+    const char* go = gb + pps;
+    double p0 = PA_LDG(gp + pps, lo8), p1 = PA_LDG(gp + 2 * pps, lo8);
+    double cm = PA_PROG(PA_LDG(gp, lo8)), cc = PA_PROG(p0), cp = PA_PROG(p1);
+    double co = PA_PROG(PA_LDG(go, oo8));
+    double fzc = zflux(dxinv[2], cm, cc);
+    double f[3], fo[3];
+    __builtin_amdgcn_sched_barrier(0);
+    f[0] = PA_LDG(gp + 3 * pps, lo8);
+    fo[0] = PA_LDG(go + pps, oo8);
+    __builtin_amdgcn_sched_barrier(0);
+    f[1] = PA_LDG(gp + 4 * pps, lo8);
+    fo[1] = PA_LDG(go + 2 * pps, oo8);
+    __builtin_amdgcn_sched_barrier(0);
+    gp += 4 * pps;
+    gp += (k0 + 3 <= kfmax) ? pps : 0;
+    go += 2 * pps;
+    go += (k0 + 2 <= pend) ? pps : 0;
+    f[2] = PA_LDG(gp, lo8);
+    fo[2] = PA_LDG(go, oo8);
+    __builtin_amdgcn_sched_barrier(0);
+    S.c[0][rr][xs] = cc;
+    __syncthreads();
+    auto step = [&](auto spc, int p) __attribute__((always_inline)) {
+      constexpr int SP = decltype(spc)::value, SP1 = (SP + 1) % 3;
+      double x, xo;
+      PA_TAKE(x, f[SP]);
+      PA_TAKE(xo, fo[SP]);
+      __builtin_amdgcn_sched_barrier(0);
+      gp += (p + 5 <= kfmax) ? pps : 0;
+      go += (p + 4 <= pend) ? pps : 0;
+      const double cl = S.c[SP][rr][xs - 1], cr = S.c[SP][rr][xs + 1];
+      const double cin = S.c[SP][rin][xs];
+      const double cs = rsub ? cin : co, cn = rsub ? co : cin;
+      const double ggx = cdiff(dxinv[0], cl, cc, cr);
+      const double ggy = cdiff(dxinv[1], cs, cc, cn);
+      const double fzh = zflux(dxinv[2], cc, cp);
+      const double ggz = favg(fzc, fzh);
+      const double sn = sqrt(ggx * ggx + ggy * ggy + ggz * ggz);
+      const double ng = -((1e-14 < sn) ? sn : 1e-14);
+      S.ny[SP][rr][col] = ggy / ng;
+      S.c[SP1][rr][xs] = cp;
+      S.p[SP][rr][xs] = p0;
+      __syncthreads();
+      PA_OPAQUE(lo8);
+      PA_OPAQUE(oo8);
+      f[SP] = PA_LDG(gp, lo8);
+      fo[SP] = PA_LDG(go, oo8);
+      cm = cc; cc = cp; cp = PA_PROG(x); co = PA_PROG(xo);
+      fzc = fzh;
+      p0 = p1; p1 = x;
+    };
+    PA_RUN3(step)
+    return;
+  }
+
+  // ----------------------------------------------------------------------------- edge wave
+  {
+    const int l20 = lane % (2 * MROWS);  // idle lanes mirror the active ones
+    const int rr = min(l20 >> 1, rtop);
+    const int side = l20 & 1;
+    const int j = j0 + rr - 1;
+    const int i = side ? iR : i0 - 1;
+    const int xs = side ? llast + 2 : 0;
+    const int xin = side ? llast + 1 : 1;
+    const int rlo = max(rr - 1, 0), rhi = min(rr + 1, rtop);
+    const bool has_n = (rr >= 1 && rr <= nrows);
+    const char* gb = (const char*)(P.p + P.idx(P.lo[0], P.lo[1], k0 - 2, pcomp));
+    unsigned og = (unsigned)((j - P.lo[1]) * P.nx + (i - P.lo[0])) * 8u;
+    unsigned oo = (unsigned)((j - P.lo[1]) * P.nx + ((side ? i + 1 : i - 1) - P.lo[0])) * 8u;
+    const char* gp = gb;
+    const char* go = gb + pps;
+    double p0 = PA_LDG(gp + pps, og), p1 = PA_LDG(gp + 2 * pps, og);
+    double cm = PA_PROG(PA_LDG(gp, og)), cc = PA_PROG(p0), cp = PA_PROG(p1);
+    double co = PA_PROG(PA_LDG(go, oo));
+    double f[3], fo[3];
+    __builtin_amdgcn_sched_barrier(0);
+    f[0] = PA_LDG(gp + 3 * pps, og);
+    fo[0] = PA_LDG(go + pps, oo);
+    __builtin_amdgcn_sched_barrier(0);
+    f[1] = PA_LDG(gp + 4 * pps, og);
+    fo[1] = PA_LDG(go + 2 * pps, oo);
+    __builtin_amdgcn_sched_barrier(0);
+    gp += 4 * pps;
+    gp += (k0 + 3 <= kfmax) ? pps : 0;
+    go += 2 * pps;
+    go += (k0 + 2 <= pend) ? pps : 0;
+    f[2] = PA_LDG(gp, og);
+    fo[2] = PA_LDG(go, oo);
+    __builtin_amdgcn_sched_barrier(0);
+    double fzc = zflux(dxinv[2], cm, cc);
+    S.c[0][rr][xs] = cc;
+    __syncthreads();
+    auto step = [&](auto spc, int p) __attribute__((always_inline)) {
+      constexpr int SP = decltype(spc)::value, SP1 = (SP + 1) % 3;
+      double x, xo;
+      PA_TAKE(x, f[SP]);
+      PA_TAKE(xo, fo[SP]);
+      __builtin_amdgcn_sched_barrier(0);
+      gp += (p + 5 <= kfmax) ? pps : 0;
+      go += (p + 4 <= pend) ? pps : 0;
+      const double inner = S.c[SP][rr][xin];
+      const double cl = side ? inner : co, cr = side ? co : inner;
+      const double cs = S.c[SP][rlo][xs], cn = S.c[SP][rhi][xs];
+      const double ggx = cdiff(dxinv[0], cl, cc, cr);
+      const double ggy = cdiff(dxinv[1], cs, cc, cn);
+      const double fzh = zflux(dxinv[2], cc, cp);
+      const double ggz = favg(fzc, fzh);
+      const double sn = sqrt(ggx * ggx + ggy * ggy + ggz * ggz);
+      const double ng = -((1e-14 < sn) ? sn : 1e-14);
+      const double nxp = ggx / ng;
+      if (has_n) S.nx[SP][rr - 1][xs] = nxp;
+      S.c[SP1][rr][xs] = cp;
+      S.p[SP][rr][xs] = p0;
+      __syncthreads();
+      PA_OPAQUE(og);
+      PA_OPAQUE(oo);
+      f[SP] = PA_LDG(gp, og);
+      fo[SP] = PA_LDG(go, oo);
+      cm = cc; cc = cp; cp = PA_PROG(x); co = PA_PROG(xo);
+      fzc = fzh;
+      p0 = p1; p1 = x;
+    };
+    PA_RUN3(step)
+  }
+#undef PA_PROG
+#undef PA_RUN3
+}
