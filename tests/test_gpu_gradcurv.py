@@ -139,6 +139,39 @@ def test_gradcurv_four_levels_many_components(ctx, oracle):
             assert_valid_bits_equal(got, oc[l], [(4, 2), (5, 3), (6, 4), (7, 1)], f"comp {c} curv level {l}")
 
 
+@pytest.mark.parametrize("dom,maxbox,per", [
+    ((47, 39, 9), (47, 13, 3), (1, 1, 1)),     # 47-wide boxes (64-lane rows with mirrored lanes), 3-cell-thin boxes in z
+    ((40, 33, 14), (20, 33, 14), (1, 0, 1)),   # 20-wide boxes (narrow kernel, mirrored columns), 33 rows = 2 full tiles + 1 row
+    ((96, 18, 5), (96, 18, 5), (0, 1, 0)),     # one 96-wide box: a full and a half-filled x tile
+    ((31, 7, 40), (31, 7, 40), (1, 1, 0)),     # odd extents, fewer rows than a tile, many planes (several z segments at kseg 16)
+])
+def test_gradcurv_fused_ragged_shapes(ctx, oracle, dom, maxbox, per, monkeypatch):
+    """single-level boxes of awkward extents through both sweep kernels (partial tiles in x and y, thin boxes,
+    several z segments), periodic and wall boundaries"""
+    from peleanalysis_amd.hierarchy import Hierarchy, Level, field_trig
+    lo, hi = (0, 0, 0), tuple(d - 1 for d in dom)
+    boxes = []
+    for z0 in range(0, dom[2], maxbox[2]):
+        for y0 in range(0, dom[1], maxbox[1]):
+            for x0 in range(0, dom[0], maxbox[0]):
+                boxes.append([x0, y0, z0, min(x0 + maxbox[0], dom[0]) - 1, min(y0 + maxbox[1], dom[1]) - 1, min(z0 + maxbox[2], dom[2]) - 1])
+    H = Hierarchy([Level(np.array(boxes, dtype=np.int32), lo, hi, per, (0, 0, 0), (1, 1, 1))], 2)
+    states = make_states(H, 1, 2, field_trig, seed=5)
+    bc = capi.bc_from_flags(per, (0, 0, 0))
+    og = [MultiFab(lv, 4, 0) for lv in H.levels]
+    oracle.grad_pipeline(H.levels, [s.copy() for s in states], 0, bc, og, 0, multipass=True)
+    oc = [MultiFab(lv, 5, 0) for lv in H.levels]
+    oracle.curvature_pipeline(H.levels, [s.copy() for s in states], 0, bc, oc, 0, MultiFab, threshold=0.02)
+    dls, dst = _dev(ctx, H, states)
+    work = [capi.DevMF(ctx, dl, 1, 2) for dl in dls]
+    dout = [capi.DevMF(ctx, dl, 8, 0) for dl in dls]
+    capi.gradcurv_run(ctx, dst, 0, bc, capi.curv_params(threshold=0.02, fused=True), work, dout, 0)
+    ctx.sync()
+    got = dout[0].download()
+    assert_valid_bits_equal(got, og[0], [(c, c) for c in range(4)], f"ragged {dom} grad")
+    assert_valid_bits_equal(got, oc[0], [(4, 2), (5, 3), (6, 4), (7, 1)], f"ragged {dom} curv")
+
+
 def test_ghost_fill_matches_oracle(ctx, oracle):
     """FillBoundary (ng=2, edges+corners) and applyBC individually, all ghost cells compared"""
     H, per, sym, fn = build_config("amr3_wall_z")
