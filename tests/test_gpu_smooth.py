@@ -86,3 +86,26 @@ def test_curvature_run_with_smoothing(ctx, oracle):
                 scale = max(np.abs(wv[c]).max(), 1.0)
                 strong = np.abs(wv[17] - 0.5) < 0.45  # away from the flat ends of the profile, where n = G/|G| is ill-conditioned
                 assert np.abs((gv[c] - wv[c]) * strong).max() <= 1e-5 * scale, (l, b, c)
+
+
+def test_smooth_and_stream_reject_bad_input(ctx):
+    """host-side shape checks before any kernel runs: misaligned fine boxes, component ranges, ghost widths"""
+    import ctypes as C
+    from peleanalysis_amd.hierarchy import Hierarchy
+    l0 = Level(chop_box((0, 0, 0), (15, 15, 15), 8), (0, 0, 0), (15, 15, 15), (1, 1, 1), (0, 0, 0), (1, 1, 1))
+    l1 = Level(np.array([[9, 8, 8, 18, 23, 23]], dtype=np.int32), (0, 0, 0), (31, 31, 31), (1, 1, 1), (0, 0, 0), (1, 1, 1))  # odd lo: not ratio-aligned
+    dls = [capi.DevLevel(ctx, l0), capi.DevLevel(ctx, l1)]
+    rhs = [capi.DevMF(ctx, dl, 1, 0) for dl in dls]
+    sol = [capi.DevMF(ctx, dl, 1, 0) for dl in dls]
+    with pytest.raises(capi.PaError, match="aligned"):
+        capi.smooth_solve(ctx, rhs, 0, sol, 0, 1e-3, (0, 0, 0))
+    with pytest.raises(capi.PaError, match="component"):
+        capi.smooth_solve(ctx, rhs[:1], 3, sol[:1], 0, 1e-3, (0, 0, 0))
+    v = [capi.DevMF(ctx, dls[0], 3, 0)]  # no ghost layers
+    with pytest.raises(capi.PaError, match="nGrow"):
+        capi.stream_trace(ctx, v, 0, np.array([[0.5, 0.5, 0.5]]), 5, 0.01)
+    v = [capi.DevMF(ctx, dls[0], 2, 2)]  # too few components
+    with pytest.raises(capi.PaError, match="component"):
+        capi.stream_trace(ctx, v, 0, np.array([[0.5, 0.5, 0.5]]), 5, 0.01)
+    pos, nred = capi.stream_trace(ctx, [capi.DevMF(ctx, dls[0], 3, 2)], 0, np.zeros((0, 3)), 5, 0.01)  # no seeds: nothing to do
+    assert pos.shape == (0, 5, 3) and nred == 0
