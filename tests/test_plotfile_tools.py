@@ -59,6 +59,28 @@ def test_cpp_template_tool_roundtrip(tmp_path):
     assert out.returncode != 0 and "infile" in out.stderr
 
 
+def test_cpp_mef_to_dat_tool(tmp_path):
+    """surfMEFtoDAT3d.ex (host only): the MEF layout written by the python writer is what the consumer parses"""
+    _build_tools()
+    rng = np.random.default_rng(2)
+    nodes = rng.random((7, 5))
+    faces = np.array([[1, 2, 3], [3, 4, 5], [5, 6, 7]], dtype=np.int32)
+    f = str(tmp_path / "s.mef")
+    with open(f, "wb") as fh:  # isosurface.cpp:2097-2134
+        fh.write(b"0.25\nX Y Z temp rho\n3 3\n")
+        fh.write(b"FAB ((8, (64 11 52 0 1 12 0 1023)),(8, (8 7 6 5 4 3 2 1)))((0,0,0) (6,0,0) (0,0,0)) 5\n")
+        fh.write(nodes.astype("<f8").tobytes())
+        fh.write(faces.astype("<i4").tobytes())
+    assert read_mef(f)[2].shape == (7, 5)
+    out = subprocess.run([os.path.join(BIN, "surfMEFtoDAT3d.ex"), "infile=" + f], cwd=tmp_path, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    txt = open(str(tmp_path / "s.dat")).read().split("\n")
+    assert txt[0] == "VARIABLES = X Y Z temp rho" and txt[1] == 'ZONE T="0.25" N=7 E=3 F=FEPOINT ET=TRIANGLE'
+    got = np.array([[float(t) for t in ln.split()] for ln in txt[2:9]])
+    assert np.abs(got - nodes).max() < 1e-5
+    assert [[int(t) for t in ln.split()] for ln in txt[9:12]] == faces.tolist()
+
+
 # ------------------------------------------------------------------------------------ GPU tier
 @pytest.mark.gpu
 def test_grad_tool_end_to_end(tmp_path, oracle):
