@@ -41,6 +41,7 @@ extern "C" void pa_ctx_destroy(pa_ctx* ctx) {
   for (auto& e : ctx->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (auto& e : ctx->sync_evs) (void)hipEventDestroy(e);
   if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+  for (auto& st : ctx->lev_streams) (void)hipStreamDestroy(st);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }

@@ -392,8 +392,16 @@ extern "C" int pa_gradcurv_level(pa_ctx* ctx, const pa_mf* phi, int pcomp, doubl
   return 0;
 }
 
+// phase: 1 = recompute the layer-1 normals (k_faces_normal), 2 = curvature of layers 1-2 (needs phase 1 of this
+// level AND of the coarser level), 3 = both
+int pa_gradcurv_faces_phase(pa_ctx* ctx, const pa_mf* c, int ccomp, const pa_mf* crse_n, int cncomp0, const int32_t bc[3], int ratio, double thr,
+                            pa_mf* out, int ncomp0, int kcomp, int phase);
 extern "C" int pa_gradcurv_faces_level(pa_ctx* ctx, const pa_mf* c, int ccomp, const pa_mf* crse_n, int cncomp0, const int32_t bc[3],
                                        int ratio, double thr, pa_mf* out, int ncomp0, int kcomp) {
+  return pa_gradcurv_faces_phase(ctx, c, ccomp, crse_n, cncomp0, bc, ratio, thr, out, ncomp0, kcomp, 3);
+}
+int pa_gradcurv_faces_phase(pa_ctx* ctx, const pa_mf* c, int ccomp, const pa_mf* crse_n, int cncomp0, const int32_t bc[3], int ratio, double thr,
+                            pa_mf* out, int ncomp0, int kcomp, int phase) {
   if (!ctx || !c || !out) return pa_fail(ctx, "pa_gradcurv_faces_level: null argument");
   if (c->lev != out->lev) return pa_fail(ctx, "pa_gradcurv_faces_level: different levels");
   if (c->ng < 2) return pa_fail(ctx, "pa_gradcurv_faces_level: c needs >= 2 ghost layers");
@@ -418,7 +426,11 @@ extern "C" int pa_gradcurv_faces_level(pa_ctx* ctx, const pa_mf* c, int ccomp, c
   const long long nf = std::max(n1 * n2, std::max(n0 * n2, n0 * n1));
   const unsigned nsf = (unsigned)L->sfaces.size();
   ProfScope prof(ctx, PA_TAG_GRADCURV_FACES);
-  hipLaunchKernelGGL(k_faces_normal, dim3((unsigned)((nf + 255) / 256), nsf), dim3(256), 0, ctx->stream, L->view, c->view, ccomp, out->view, ncomp0, A);
+  if (phase & 1) hipLaunchKernelGGL(k_faces_normal, dim3((unsigned)((nf + 255) / 256), nsf), dim3(256), 0, ctx->stream, L->view, c->view, ccomp, out->view, ncomp0, A);
+  if (!(phase & 2)) {
+    PA_HIP(hipGetLastError());
+    return 0;
+  }
   if (fast) {
     hipLaunchKernelGGL(k_faces_curv_fast, dim3((unsigned)((nf + 255) / 256), nsf), dim3(256), 0, ctx->stream, L->view,
                        crse_n ? crse_n->lev->view : L->view, crse_n ? crse_n->view : c->view, cncomp0, out->view, ncomp0, kcomp, A, ctx->d_flags);

@@ -53,6 +53,7 @@ struct pa_ctx {
   // second stream + ordering events of the fused pipeline (boundary kernels of one level next to the sweep of
   // another; pa_pipeline.hip); created on first use
   hipStream_t stream2 = nullptr;
+  std::vector<hipStream_t> lev_streams;  // one per level: level-concurrent boundary kernels (pa_pipeline.hip)
   std::vector<hipEvent_t> sync_evs;
 };
 

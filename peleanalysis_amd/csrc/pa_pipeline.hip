@@ -161,14 +161,79 @@ struct StreamSwap {  // the level entry points launch on ctx->stream
   ~StreamSwap() { c->stream = keep; }
 };
 
-static int fused_faces(pa_ctx* ctx, int l, const int32_t bc[3], double thr, pa_mf* const* work, pa_mf* const* out, int ocomp) {
-  return pa_gradcurv_faces_level(ctx, work[l], 0, l > 0 ? out[l - 1] : nullptr, ocomp + 4, bc, 2, thr, out[l], ocomp + 4, ocomp + 7);
+int pa_gradcurv_faces_phase(pa_ctx* ctx, const pa_mf* c, int ccomp, const pa_mf* crse_n, int cncomp0, const int32_t bc[3], int ratio, double thr,
+                            pa_mf* out, int ncomp0, int kcomp, int phase);
+static int fused_faces(pa_ctx* ctx, int l, const int32_t bc[3], double thr, pa_mf* const* work, pa_mf* const* out, int ocomp, int phase = 3) {
+  return pa_gradcurv_faces_phase(ctx, work[l], 0, l > 0 ? out[l - 1] : nullptr, ocomp + 4, bc, 2, thr, out[l], ocomp + 4, ocomp + 7, phase);
+}
+
+// Level-concurrent boundary schedule (PA_CONC=1; OFF by default).  Between levels almost nothing depends on
+// anything: prep(l) writes ghost cells of phi_l / the shell of c_l and reads VALID cells of phi_{l-1}; the layer-1
+// normals of level l need only sweep(l) and that shell; the face curvature of level l needs the layer-1 normals of
+// levels l and l-1.  So the three groups can run with one stream per level and only the sweeps -- which want the
+// memory path for themselves (PA_OVERLAP above) -- one after the other with nothing beside:
+//   [prep(0) | prep(1) | prep(2)]  sweep(0) sweep(1) sweep(2)  [normal(0) | normal(1) | normal(2)]  [curv(0) | curv(1) | curv(2)]
+// MEASURED (MI355X, headline workload, twice): 7.87 / 7.92 ms per step against 7.81 / 7.88 ms sequential.  The
+// kernel trace shows the kernels DO overlap (two hardware queues) and every kernel that runs beside another takes
+// about twice as long (k_fill_boundary 188 + 192 us side by side against 89 us alone): the boundary kernels are
+// not waiting on latency, they are bound by the memory system's rate for short scattered segments (2-cell-wide
+// ghost strips), which two streams share.  Concurrency buys nothing; kept for A/B only.
+static int conc_on() {
+  static const int v = [] { const char* e = getenv("PA_CONC"); return e ? atoi(e) : 0; }();
+  return v;
+}
+static int fused_passes_conc(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, const int32_t bc[3], double pmin, double pmax, double thr,
+                             pa_mf* const* work, pa_mf* const* out, int ocomp) {
+  while ((int)ctx->lev_streams.size() < nlev) {
+    hipStream_t s;
+    PA_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    ctx->lev_streams.push_back(s);
+  }
+  const size_t nev = 2 + 3 * (size_t)nlev;
+  while (ctx->sync_evs.size() < nev) {
+    hipEvent_t e;
+    PA_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    ctx->sync_evs.push_back(e);
+  }
+  hipStream_t A = ctx->stream;
+  hipEvent_t e_start = ctx->sync_evs[0], e_sweeps = ctx->sync_evs[1];
+  auto e_prep = [&](int l) { return ctx->sync_evs[2 + l]; };
+  auto e_norm = [&](int l) { return ctx->sync_evs[2 + nlev + l]; };
+  auto e_curv = [&](int l) { return ctx->sync_evs[2 + 2 * nlev + l]; };
+  PA_HIP(hipEventRecord(e_start, A));
+  for (int l = 0; l < nlev; ++l) {  // ghost-cell preparation, one stream per level
+    hipStream_t T = ctx->lev_streams[l];
+    PA_HIP(hipStreamWaitEvent(T, e_start, 0));
+    StreamSwap sw(ctx, T);
+    PA_TRY(fused_pre(ctx, l, state, comp, bc, pmin, pmax, work));
+    PA_HIP(hipEventRecord(e_prep(l), T));
+  }
+  for (int l = 0; l < nlev; ++l) PA_HIP(hipStreamWaitEvent(A, e_prep(l), 0));  // nothing runs beside a sweep
+  for (int l = 0; l < nlev; ++l) PA_TRY(pa_gradcurv_level(ctx, state[l], comp, pmin, pmax, thr, out[l], ocomp));
+  PA_HIP(hipEventRecord(e_sweeps, A));
+  for (int l = 0; l < nlev; ++l) {  // layer-1 normals
+    hipStream_t T = ctx->lev_streams[l];
+    PA_HIP(hipStreamWaitEvent(T, e_sweeps, 0));
+    StreamSwap sw(ctx, T);
+    PA_TRY(fused_faces(ctx, l, bc, thr, work, out, ocomp, 1));
+    PA_HIP(hipEventRecord(e_norm(l), T));
+  }
+  for (int l = 0; l < nlev; ++l) {  // face curvature: normals of this level (same stream) and of the coarser one
+    hipStream_t T = ctx->lev_streams[l];
+    if (l > 0) PA_HIP(hipStreamWaitEvent(T, e_norm(l - 1), 0));
+    StreamSwap sw(ctx, T);
+    PA_TRY(fused_faces(ctx, l, bc, thr, work, out, ocomp, 2));
+    PA_HIP(hipEventRecord(e_curv(l), T));
+  }
+  for (int l = 0; l < nlev; ++l) PA_HIP(hipStreamWaitEvent(A, e_curv(l), 0));  // later work on the caller's stream sees the results
+  return 0;
 }
 
 static int fused_passes(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, const int32_t bc[3], double pmin, double pmax, double thr,
                         pa_mf* const* work, pa_mf* const* out, int ocomp) {
   for (int l = 0; l < nlev; ++l)
     if (state[l]->ng < 2 || work[l]->ng < 2) return pa_fail(ctx, "fused grad->curvature needs 2 ghost layers on state and work");
+  if (conc_on() && nlev >= 2 && !overlap_on()) return fused_passes_conc(ctx, nlev, state, comp, bc, pmin, pmax, thr, work, out, ocomp);
   if (!overlap_on() || nlev < 2) {
     for (int l = 0; l < nlev; ++l) PA_TRY(fused_pre(ctx, l, state, comp, bc, pmin, pmax, work));
     for (int l = 0; l < nlev; ++l) {
