@@ -3,6 +3,7 @@
 // grad->curvature kernel lives in pa_fused.hip.
 #include "pa_internal.h"
 #include "pa_fabview.h"
+#include "pa_grad_march.h"
 #include <algorithm>
 #include <cfloat>
 #include <cstdlib>
@@ -45,6 +46,30 @@ template <typename BP>
 static void grad_launch(hipStream_t st, const BP& bp, int nx, int ny, int nz, unsigned nboxes, int comp, int ocomp) {
   static const int ty_env = [] { const char* e = getenv("PA_GRAD_TY"); return e ? atoi(e) : 4; }();  // sweep (tools/grad_sweep.py): 1.34-1.51 ms, best 4 x 32
   static const int tz_env = [] { const char* e = getenv("PA_GRAD_TZ"); return e ? atoi(e) : 32; }();
+  // PA_GRAD_MARCH (default 1): the k-marching kernel of pa_grad_march.h for boxes wider than half a wavefront.
+  // tools/grad_sweep.py, 512^3 level of 128^3 boxes: tiled k_grad 1.45 ms; march 13 rows x 8/16/32/64 planes
+  // 1.037/1.039/1.081/1.088 ms, 8 rows 1.13-1.17 ms (64^3 boxes: 1.42 -> 1.08 ms)
+  static const int march_env = [] { const char* e = getenv("PA_GRAD_MARCH"); return e ? atoi(e) : 1; }();
+  const char* ke = getenv("PA_GRAD_KSEG");  // read per launch: the tests switch them
+  const char* me = getenv("PA_GRAD_MTY");
+  const int kseg_env = ke ? atoi(ke) : 16, mty_env = me ? atoi(me) : 0;
+  if (march_env && nx > 32) {
+    GradMarchArgs A{comp, ocomp, std::max(1, std::min(kseg_env, nz)), (int)nboxes, 0};
+    const int mty = mty_env ? mty_env : (ny >= 52 ? 13 : (ny >= 16 ? 8 : 4));
+    auto go = [&](auto tyc) {
+      constexpr int M = decltype(tyc)::value;
+      A.tiles_max = ((nx + 63) / 64) * ((ny + M - 1) / M) * ((nz + A.kseg - 1) / A.kseg);
+      const dim3 g((unsigned)A.tiles_max * 8u * ((nboxes + 7u) / 8u));
+      hipLaunchKernelGGL((k_grad_march<BP, M>), g, dim3(64 * (M + 3)), 0, st, bp, A);
+    };
+    switch (mty) {
+      case 13: go(std::integral_constant<int, 13>{}); break;
+      case 8: go(std::integral_constant<int, 8>{}); break;
+      case 5: go(std::integral_constant<int, 5>{}); break;
+      default: go(std::integral_constant<int, 4>{}); break;
+    }
+    return;
+  }
   const int tz = std::max(1, std::min(tz_env, nz));
   auto grid = [&](int TY) { return dim3((unsigned)(((nx + 63) / 64) * ((ny + TY - 1) / TY) * ((nz + tz - 1) / tz)), nboxes); };
   switch (ny >= 16 ? ty_env : 4) {

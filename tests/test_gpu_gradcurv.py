@@ -170,6 +170,15 @@ def test_gradcurv_fused_ragged_shapes(ctx, oracle, dom, maxbox, per, monkeypatch
     got = dout[0].download()
     assert_valid_bits_equal(got, og[0], [(c, c) for c in range(4)], f"ragged {dom} grad")
     assert_valid_bits_equal(got, oc[0], [(4, 2), (5, 3), (6, 4), (7, 1)], f"ragged {dom} curv")
+    # the gradient tool's own kernel (k_grad_march above 32 columns, k_grad below), short z segments, every tile height
+    for kseg, mty in (("64", "0"), ("7", "13"), ("16", "8"), ("5", "5"), ("3", "4")):
+        monkeypatch.setenv("PA_GRAD_KSEG", kseg)
+        monkeypatch.setenv("PA_GRAD_MTY", mty)
+        dls2, dst2 = _dev(ctx, H, states)
+        dgr = [capi.DevMF(ctx, dl, 4, 0) for dl in dls2]
+        capi.grad_run(ctx, dst2, 0, bc, dgr, 0)
+        ctx.sync()
+        assert_valid_bits_equal(dgr[0].download(), og[0], [(c, c) for c in range(4)], f"ragged {dom} grad_run kseg {kseg} rows {mty}")
 
 
 def test_ghost_fill_matches_oracle(ctx, oracle):
