@@ -189,6 +189,19 @@ int pa_mc_count_fab(pa_ctx*, pa_box loop, const pa_fab* state, const pa_fab* mas
 int pa_mc_emit_fab(pa_ctx*, pa_box loop, const pa_fab* state, const pa_fab* mask, int isocomp, double isoval,
                    double* dev_verts /* [nvert][ncomp] */, int32_t* dev_vkeys /* [nvert][6] */,
                    int32_t* dev_tris /* [ntri][3] */, int64_t nvert, int64_t ntri);
+/* The same for every FAB of a level in one pass (the whole MFIter loop of isosurface.cpp:1531-1592).
+ * pa_iso_mask_level: mask = 1, and -1 on every cell (ghost cells included) covered by the next finer level
+ * (isosurface.cpp:1540-1563; fine = NULL: nothing covered).  pa_mc_level: state and mask are multifabs of one
+ * level with the same ghost width; loops[b] = cube base points of FAB b (lo > hi: FAB skipped).  Per-FAB results
+ * are identical to pa_mc_count_fab / pa_mc_emit_fab and are concatenated in box order: FAB b owns vertices
+ * [sum_{b'<b} nvert[b'], +nvert[b]) and its triangles hold FAB-local vertex ids.  The three output arrays are
+ * parts of ONE device allocation made by the library whose base is *dev_verts (all NULL when the level has no
+ * surface): release it with pa_device_free(*dev_verts) only.  Synchronous. */
+int pa_iso_mask_level(pa_ctx*, pa_mf* mask, int comp, const pa_level* fine, int ratio);
+int pa_mc_level(pa_ctx*, const pa_mf* state, const pa_mf* mask, int mcomp, const pa_box* loops /* host [nboxes] */,
+                int isocomp, double isoval, int64_t* nvert /* host [nboxes] */, int64_t* ntri /* host [nboxes] */,
+                double** dev_verts /* [sum nvert][ncomp] */, int32_t** dev_vkeys /* [sum nvert][6] */,
+                int32_t** dev_tris /* [sum ntri][3] */);
 const uint16_t* pa_mc_edge_table(void); /* [256] host */
 const int8_t*   pa_mc_tri_table(void);  /* [256][16] host */
 

@@ -438,20 +438,26 @@ def iso_merge(fragments, ncomp):
 
 
 def iso_fab_inputs(levels, states, lev, b, ng=1, fine_mask=True):
-    """mask (isosurface.cpp:1540-1563; all 1 when building the distance function, :1542) and loop box
-    (:1566-1569) of box b grown by ng"""
+    """mask (isosurface.cpp:1540-1563, with the periodic images of the coarsened fine boxes, :1550-1560; all 1 when
+    building the distance function, :1542) and loop box (:1566-1569: grown box & domain grown by ng in the periodic
+    directions, high side - 1) of box b grown by ng"""
     L = levels[lev]
     lo, hi = L.boxes[b, :3] - ng, L.boxes[b, 3:] + ng
     shape = tuple(int(x) for x in (hi - lo + 1)[::-1])
     mask = np.ones(shape)
+    per = np.asarray(L.is_per, dtype=np.int64)
+    dlen = np.asarray(L.domhi, dtype=np.int64) - np.asarray(L.domlo, dtype=np.int64) + 1
     if fine_mask and lev + 1 < len(levels):
+        shifts = [np.array([sx, sy, sz]) * dlen for sx in ((-1, 0, 1) if per[0] else (0,)) for sy in ((-1, 0, 1) if per[1] else (0,))
+                  for sz in ((-1, 0, 1) if per[2] else (0,))]
         for fb in levels[lev + 1].boxes:
-            clo, chi = fb[:3] // 2, fb[3:] // 2  # coarsen (non-negative indices)
-            ilo, ihi = np.maximum(lo, clo), np.minimum(hi, chi)
-            if np.all(ilo <= ihi):
-                mask[ilo[2] - lo[2]:ihi[2] - lo[2] + 1, ilo[1] - lo[1]:ihi[1] - lo[1] + 1, ilo[0] - lo[0]:ihi[0] - lo[0] + 1] = -1.0
-    llo = np.maximum(lo, L.domlo)
-    lhi = np.minimum(hi, L.domhi) - 1
+            for sh in shifts:
+                clo, chi = fb[:3] // 2 + sh, fb[3:] // 2 + sh  # coarsen (floor), periodic image
+                ilo, ihi = np.maximum(lo, clo), np.minimum(hi, chi)
+                if np.all(ilo <= ihi):
+                    mask[ilo[2] - lo[2]:ihi[2] - lo[2] + 1, ilo[1] - lo[1]:ihi[1] - lo[1] + 1, ilo[0] - lo[0]:ihi[0] - lo[0] + 1] = -1.0
+    llo = np.maximum(lo, np.asarray(L.domlo) - ng * per)
+    lhi = np.minimum(hi, np.asarray(L.domhi) + ng * per) - 1
     return lo, hi, mask, llo, lhi
 
 
@@ -473,7 +479,9 @@ def iso_ngrow(levels, build_distance, dmax=None, ngrow=1):
 
 
 def isosurface_pipeline(levels, fields, comps, isocomp_index, isoval, MF, ngrow=1, rm_external=True, build_distance=False, dmax=None):
-    """isosurface.cpp:1434-1728 (non-periodic).  fields[l]: multifab holding the plotfile components;
+    """isosurface.cpp:1434-1728.  Periodic directions as the reference leaves them (:1469 "bad data in periodic
+    directions": the ghost cells behind a periodic face carry the coordinates of the cells they image -- the shift back
+    at :1483-1507 intersects VALID boxes with the domain shifted by a period and so never fires).  fields[l]: multifab holding the plotfile components;
     comps: which of them to map; the iso component is comps[isocomp_index].  Returns (nodes
     [N][3+len(comps)], elements [M][3] 0-based) and, with build_distance, also the list of distance
     multifabs (1 comp, nGrow[lev] ghosts; :1595-1655) -- the reference writes their valid cells."""

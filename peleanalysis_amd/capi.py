@@ -106,6 +106,9 @@ def load_library() -> C.CDLL:
         "pa_fillpatch_two_levels": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
         "pa_mc_count_fab": (C.c_int, [vp, PaBox, C.POINTER(PaFab), C.POINTER(PaFab), C.c_int, dbl, C.POINTER(i64), C.POINTER(i64)]),
         "pa_mc_emit_fab": (C.c_int, [vp, PaBox, C.POINTER(PaFab), C.POINTER(PaFab), C.c_int, dbl, vp, vp, vp, i64, i64]),
+        "pa_iso_mask_level": (C.c_int, [vp, vp, C.c_int, vp, C.c_int]),
+        "pa_mc_level": (C.c_int, [vp, vp, vp, C.c_int, C.POINTER(PaBox), C.c_int, dbl, C.POINTER(i64), C.POINTER(i64), C.POINTER(vp), C.POINTER(vp),
+                                  C.POINTER(vp)]),
         "pa_mc_edge_table": (C.POINTER(C.c_uint16), []),
         "pa_mc_tri_table": (C.POINTER(C.c_int8), []),
         "pa_sdf_level_set3": (C.c_int, [vp, C.c_int, C.POINTER(PaSdfGrid), C.c_int]),
@@ -366,3 +369,34 @@ def stream_trace(ctx, vfield, vcomp, seeds, nsteps, dt):
     ctx.check(ctx.lib.pa_stream_trace(ctx.h, len(vfield), _handles(vfield), int(vcomp), n, seeds.ctypes.data_as(C.POINTER(C.c_double)), int(nsteps),
                                       float(dt), C.c_void_p(buf.ptr), C.byref(nred)))
     return buf.to_numpy(np.float64, (2 * n, nsteps, 3)), nred.value
+
+
+def mc_level(ctx: Context, state: "DevMF", mask: "DevMF", loops, isocomp: int, isoval: float, mcomp: int = 0):
+    """Level-batched marching cubes (pa_mc_level).  loops: (nboxes, 6) cube base-point boxes (lo > hi: skipped).
+    Returns per-box lists [(verts [nv][ncomp], vkeys [nv][6], tris [nt][3] FAB-local ids)]."""
+    loops = np.asarray(loops, dtype=np.int64).reshape(-1, 6)
+    nb = len(loops)
+    arr = (PaBox * max(nb, 1))()
+    for b in range(nb):
+        for d in range(3):
+            arr[b].lo[d], arr[b].hi[d] = int(loops[b, d]), int(loops[b, 3 + d])
+    nv, nt = (C.c_int64 * max(nb, 1))(), (C.c_int64 * max(nb, 1))()
+    pv, pk, pt = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    ctx.check(ctx.lib.pa_mc_level(ctx.h, state.h, mask.h, mcomp, arr, isocomp, isoval, nv, nt, C.byref(pv), C.byref(pk), C.byref(pt)))
+    nc = state.ncomp
+    tv, tt = int(sum(nv[:nb])), int(sum(nt[:nb]))
+    try:
+        V = np.empty((tv, nc)); K = np.empty((tv, 6), np.int32); T = np.empty((tt, 3), np.int32)
+        if tv:
+            ctx.check(ctx.lib.pa_memcpy_d2h(ctx.h, V.ctypes.data_as(C.c_void_p), pv, V.nbytes))
+            ctx.check(ctx.lib.pa_memcpy_d2h(ctx.h, K.ctypes.data_as(C.c_void_p), pk, K.nbytes))
+        if tt:
+            ctx.check(ctx.lib.pa_memcpy_d2h(ctx.h, T.ctypes.data_as(C.c_void_p), pt, T.nbytes))
+    finally:
+        if pv.value:  # one allocation, base = the vertex array
+            ctx.lib.pa_device_free(ctx.h, pv)
+    out, ov, ot = [], 0, 0
+    for b in range(nb):
+        out.append((V[ov:ov + nv[b]], K[ov:ov + nv[b]], T[ot:ot + nt[b]]))
+        ov += nv[b]; ot += nt[b]
+    return out

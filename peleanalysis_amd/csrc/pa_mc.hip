@@ -15,6 +15,7 @@
 #include "pa_internal.h"
 #include "pa_fabview.h"
 #include "mc_tables.h"
+#include <cstdlib>
 #include <vector>
 #define PA_TRY_RET(x) do { if ((x) != 0) return 1; } while (0)
 
@@ -61,7 +62,8 @@ __device__ __forceinline__ void cell_of(const McGeom& G, long long lin, int& i, 
   j = (int)((lin / G.n[0]) % G.n[1]) + G.slo[1];
   k = (int)(lin / ((long long)G.n[0] * G.n[1])) + G.slo[2];
 }
-__device__ __forceinline__ long long lin_of(const McGeom& G, int i, int j, int k) {
+template <typename GEO>
+__device__ __forceinline__ long long lin_of(const GEO& G, int i, int j, int k) {
   return ((long long)(k - G.slo[2]) * G.n[1] + (j - G.slo[1])) * G.n[0] + (i - G.slo[0]);
 }
 
@@ -85,7 +87,8 @@ __global__ __launch_bounds__(256) void k_mc_classify(McGeom G, unsigned char* li
 
 // which of the (up to 4) cubes around the edge (cell l, direction dir) is the first live one in
 // traversal order; returns -1 if none.  Order and orientation: SURVEY A.7.
-__device__ __forceinline__ int first_toucher(const McGeom& G, const unsigned char* live, int i, int j, int k, int dir, bool& reversed) {
+template <typename GEO>
+__device__ __forceinline__ int first_toucher(const GEO& G, const unsigned char* live, int i, int j, int k, int dir, bool& reversed) {
   // bases of the cubes sharing the edge, in traversal (z-major) order, and whether the cube's own
   // edge runs high -> low along dir
   int bi[4], bj[4], bk[4];
@@ -108,7 +111,7 @@ __device__ __forceinline__ int first_toucher(const McGeom& G, const unsigned cha
   }
   for (int q = 0; q < 4; ++q) {
     if (bi[q] < G.slo[0] || bj[q] < G.slo[1] || bk[q] < G.slo[2]) continue;
-    if (live[lin_of(G, bi[q], bj[q], bk[q])]) { reversed = rev[q]; return q; }
+    if (live[lin_of(G, bi[q], bj[q], bk[q])] & 1) { reversed = rev[q]; return q; }  // bit 0 (k_mcl_cells packs more into the byte)
   }
   return -1;
 }
@@ -348,5 +351,444 @@ extern "C" int pa_mc_emit_fab(pa_ctx* ctx, pa_box loop, const pa_fab* state, con
   hipLaunchKernelGGL(k_mc_tris, dim3(W.nblocks), dim3(256), 0, ctx->stream, G, W.live, W.cidx, W.vflag, W.bsum, W.voff, dev_tris);
   PA_HIP(hipGetLastError());
   PA_HIP(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+
+// =============================================================================================
+// Level-batched marching cubes: every FAB of a level in one pass (isosurface.cpp:1531-1592 for the
+// whole MFIter loop).  Same logic as the per-FAB kernels above, launched over (tiles of a FAB) x (FABs);
+// the per-FAB outputs are identical to pa_mc_count_fab / pa_mc_emit_fab and are concatenated in box order.
+// The state and the mask are level multifabs with the same ghost width, so a cell's index in its
+// grown FAB addresses both, and the per-cell scratch (2 B from the cell pass, 1 B edge bits, 4 B vertex
+// offset) is laid out FAB after FAB, each FAB padded to a whole 256-cell block.
+//   k_mcl_cells     ONE streaming pass over the iso component and the mask (16 B per cell): per cell the byte
+//                   lc = cube is live | own x/y/z edge crosses the iso value << 1, and the cube index; marks
+//                   the 256-cell blocks that contain anything (most of a level does not touch the surface)
+//   k_mcl_count     marked blocks only: edge bits (first live cube that touches the edge) + triangle counts
+//   k_mcl_scan      one workgroup per FAB: exclusive scan of its block sums, FAB totals
+//   k_mcl_verts / k_mcl_tris  marked blocks only; as k_mc_verts / k_mc_tris, writing behind the FAB's base
+struct MclGeo {
+  int slo[3], n[3];
+  int llo[3], lhi[3];
+  unsigned ncell;
+};
+struct MclArgs {
+  DLevelView L;
+  DMFView S, M;
+  int mcomp, isocomp, ncomp, kseg;
+  double iso;
+  const DBox* loops;       // [nboxes] cube base points, lo > hi: FAB skipped
+  const long long* coff;   // [nboxes + 1] first scratch cell of a FAB (multiples of 256)
+  unsigned char *lc, *cidx, *vflag, *bact;
+  int* alist;              // marked (block, FAB) pairs in any order, *nact of them
+  int* nact;
+  int* voff;
+  int* bsum;               // [coff[nboxes] / 256][2]
+  long long* tot;          // [nboxes][2]
+  const long long* base;   // [nboxes][2] first vertex / triangle of a FAB in the output
+};
+
+__device__ __forceinline__ bool mcl_geo(const MclArgs& A, int b, MclGeo& G) {
+  const DBox B = A.L.boxes[b], Lp = A.loops[b];
+  unsigned nc = 1;
+  bool live = true;
+  for (int d = 0; d < 3; ++d) {
+    G.slo[d] = B.lo[d] - A.S.ng;
+    G.n[d] = B.hi[d] - B.lo[d] + 1 + 2 * A.S.ng;
+    G.llo[d] = Lp.lo[d];
+    G.lhi[d] = Lp.hi[d];
+    live = live && Lp.lo[d] <= Lp.hi[d];
+    nc *= (unsigned)G.n[d];
+  }
+  G.ncell = nc;
+  return live;
+}
+__device__ __forceinline__ void mcl_cell(const MclGeo& G, unsigned lin, int& i, int& j, int& k) {
+  const unsigned r = lin / (unsigned)G.n[0], kk = r / (unsigned)G.n[1];
+  i = (int)(lin - r * (unsigned)G.n[0]) + G.slo[0];
+  j = (int)(r - kk * (unsigned)G.n[1]) + G.slo[1];
+  k = (int)kk + G.slo[2];
+}
+
+// Cell pass (MEASURED, 64 FABs of 130^3 = 1.4e8 cells: 0.76 ms = 2.9 TB/s of the 16 B/cell; without its byte stores
+// 0.60 ms, without the LDS exchange 0.74 ms, tile rows 4/8/16 and 16..130 planes per workgroup all within 3 %: the
+// two strided read streams are the cost).  Workgroup = 64 x TY cells of a plane marching a z-segment; a cell's cube needs the flags
+// (inside: value < iso; masked) of the 2 x 2 cells at i..i+1, j..j+1 of two consecutive planes: the in-plane
+// neighbours come through LDS (tiles overlap by one column and one row, the re-read lines are L2 hits), the
+// lower plane is carried in registers.  Output cells of a tile: all but its last column / row, plus the FAB's
+// last column / row (no cube there, but the cell still owns the edges along the FAB's high faces).
+template <int TY>
+__global__ __launch_bounds__(64 * TY) void k_mcl_cells(MclArgs A) {
+  const int b = blockIdx.y;
+  MclGeo G;
+  if (!mcl_geo(A, b, G)) return;
+  const int nx = G.n[0], ny = G.n[1], nz = G.n[2];
+  const int ntx = max(1, (nx - 1 + 62) / 63), nty = max(1, (ny - 1 + TY - 2) / (TY - 1)), ntz = (nz + A.kseg - 1) / A.kseg;
+  const unsigned bid = blockIdx.x;
+  if (bid >= (unsigned)(ntx * nty * ntz)) return;  // uniform
+  const int tx = bid % ntx, ty = (bid / ntx) % nty, tz = bid / (ntx * nty);
+  const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+  const int i = tx * 63 + lx, j = ty * (TY - 1) + ly;  // FAB-local
+  const int ic = min(i, nx - 1), jc = min(j, ny - 1);  // threads past the FAB re-read its last column / row
+  const bool own = i < nx && j < ny && (lx < 63 || i == nx - 1) && (ly < TY - 1 || j == ny - 1);
+  const int k0 = tz * A.kseg, k1 = min(k0 + A.kseg, nz) - 1;
+  const long long nxy = (long long)nx * ny;
+  const long long cs = pa_cstride((long long)G.ncell, A.S.ncomp), cm = pa_cstride((long long)G.ncell, A.M.ncomp);
+  const double* sp = A.S.data + A.S.off[b] + (long long)A.isocomp * cs + ((long long)jc * nx + ic);
+  const double* mp = A.M.data + A.M.off[b] + (long long)A.mcomp * cm + ((long long)jc * nx + ic);
+  const double iso = A.iso;
+  __shared__ unsigned char sf[2][TY][64];
+  const int lx1 = min(lx + 1, 63), ly1 = min(ly + 1, TY - 1);
+  // flags of the 2 x 2 cells of one plane in cube-corner order (p0, p1, p2, p3): bits 0-3 inside, bits 4-7 masked
+  auto quad = [&](double s, double m, int par) {
+    const int f = (s < iso ? 1 : 0) | (m < 0.0 ? 2 : 0);
+    sf[par][ly][lx] = (unsigned char)f;
+    __syncthreads();
+    const int f1 = sf[par][ly][lx1], f2 = sf[par][ly1][lx1], f3 = sf[par][ly1][lx];
+    return (f & 1) | ((f1 & 1) << 1) | ((f2 & 1) << 2) | ((f3 & 1) << 3) | ((f & 2) << 3) | ((f1 & 2) << 4) | ((f2 & 2) << 5) | ((f3 & 2) << 6);
+  };
+  const bool xin = i + 1 < nx, yin = j + 1 < ny;
+  const bool okxy = i + G.slo[0] >= G.llo[0] && i + G.slo[0] <= G.lhi[0] && j + G.slo[1] >= G.llo[1] && j + G.slo[1] <= G.lhi[1];
+  const long long g0 = A.coff[b];
+  const unsigned lin0 = (unsigned)((long long)jc * nx + ic);
+  // plane k's results need the flags of plane k+1; planes are requested P at a time, one chunk ahead of the chunk
+  // being consumed (each plane costs a barrier, so without the distance every plane waits out a memory round trip)
+  constexpr int P = 4;
+  const int klast = min(k1 + 1, nz - 1);  // last plane read
+  auto load_chunk = [&](int kb, double (&sv)[P], double (&mv)[P]) {
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+      const long long o = (long long)min(kb + q, nz - 1) * nxy;
+      sv[q] = sp[o];
+      mv[q] = mp[o];
+    }
+  };
+  int cur = 0, par = 0;
+  auto emit = [&](int k, int up, bool up_in) {  // cell (i, j, k): cur = its plane, up = the plane above
+    const int in0 = cur & 1;
+    const int cand = ((xin && in0 != ((cur >> 1) & 1)) ? 1 : 0) | ((yin && in0 != ((cur >> 3) & 1)) ? 2 : 0) | ((up_in && in0 != (up & 1)) ? 4 : 0);
+    const int kk = k + G.slo[2];
+    const bool ok = okxy && kk >= G.llo[2] && kk <= G.lhi[2] && ((cur | up) & 0xF0) == 0;  // Polygonise bails if any corner is masked (:436-438)
+    const int ci = ok ? ((cur & 0xF) | ((up & 0xF) << 4)) : 0;
+    if (own) {
+      const long long g = g0 + lin0 + (unsigned long long)k * (unsigned long long)nxy;
+      A.lc[g] = (unsigned char)((ok ? 1 : 0) | (cand << 1));
+      A.cidx[g] = (unsigned char)ci;
+      if (cand || (ci != 0 && ci != 255)) A.bact[g >> 8] = 1;  // same value from every writer
+    }
+  };
+  auto consume = [&](int kb, const double (&sv)[P], const double (&mv)[P]) {
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+      const int kp = kb + q;
+      if (kp > klast) break;  // uniform
+      const int nib = quad(sv[q], mv[q], par);
+      par ^= 1;
+      if (kp > k0) emit(kp - 1, nib, true);
+      cur = nib;
+    }
+  };
+  double sa[P], ma[P], sb[P], mb[P];
+  load_chunk(k0, sa, ma);
+  for (int kb = k0; kb <= klast; kb += 2 * P) {
+    load_chunk(kb + P, sb, mb);
+    consume(kb, sa, ma);
+    load_chunk(kb + 2 * P, sa, ma);
+    consume(kb + P, sb, mb);
+  }
+  if (k1 + 1 >= nz) emit(k1, 0, false);  // top plane of the FAB: no cube, no z edge
+}
+
+// FAB of a scratch block: last b with coff[b] <= first cell of the block
+__device__ __forceinline__ int mcl_box_of(const MclArgs& A, long long cell0) {
+  int lo = 0, hi = A.L.nboxes - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (A.coff[mid] <= cell0) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+// list of the marked blocks as (block, FAB) pairs (order irrelevant: every block is processed on its own)
+__global__ __launch_bounds__(256) void k_mcl_active(MclArgs A, int nblk) {
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q < nblk && A.bact[q]) {
+    const int slot = atomicAdd(A.nact, 1);
+    A.alist[2 * slot] = q;
+    A.alist[2 * slot + 1] = mcl_box_of(A, 256LL * q);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_mcl_count(MclArgs A) {
+  const int nact = *A.nact;
+  for (int q = blockIdx.x; q < nact; q += gridDim.x) {  // marked blocks only (bsum of the others was zeroed)
+    const long long blk = A.alist[2 * q];
+    const int b = A.alist[2 * q + 1];
+    MclGeo G;
+    mcl_geo(A, b, G);
+    const long long g0 = A.coff[b];
+    const unsigned lin = (unsigned)(blk * 256 - g0) + threadIdx.x;
+    const long long g = g0 + lin;
+    int bits = 0, nt = 0;
+    if (lin < G.ncell) {
+      const int lcv = A.lc[g], cand = lcv >> 1;
+      if (cand) {
+        int i, j, k;
+        mcl_cell(G, lin, i, j, k);
+        for (int d = 0; d < 3; ++d) {
+          if (!((cand >> d) & 1)) continue;  // edgeTable flags an edge iff its endpoints are on different sides
+          bool rev;
+          if (first_toucher(G, A.lc + g0, i, j, k, d, rev) >= 0) bits |= (1 << d);
+        }
+      }
+      nt = (lcv & 1) ? c_ntri[A.cidx[g]] : 0;
+      A.vflag[g] = (unsigned char)bits;
+    }
+    int pv, pt, tv, tt;
+    block_prefix(__popc(bits), nt, pv, pt, tv, tt);
+    if (threadIdx.x == 0) {
+      A.bsum[2 * blk] = tv;
+      A.bsum[2 * blk + 1] = tt;
+    }
+  }
+}
+
+// one workgroup per FAB: exclusive scan of the FAB's block sums in place (FAB-local offsets), totals to tot[b]
+__global__ __launch_bounds__(1024) void k_mcl_scan(MclArgs A) {
+  __shared__ long long s_a[1024], s_b[1024];
+  const int b = blockIdx.x, t = threadIdx.x;
+  MclGeo G;
+  const bool on = mcl_geo(A, b, G);
+  const int nblocks = on ? (int)((G.ncell + 255u) / 256u) : 0;
+  int* bsum = A.bsum + 2 * (A.coff[b] / 256);
+  const int per = (nblocks + 1023) / 1024;
+  const int lo = min(t * per, nblocks), hi = min(lo + per, nblocks);
+  long long a = 0, c = 0;
+  for (int q = lo; q < hi; ++q) { a += bsum[2 * q]; c += bsum[2 * q + 1]; }
+  s_a[t] = a; s_b[t] = c;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const long long xa = t >= o ? s_a[t - o] : 0, xb = t >= o ? s_b[t - o] : 0;
+    __syncthreads();
+    s_a[t] += xa; s_b[t] += xb;
+    __syncthreads();
+  }
+  long long ea = s_a[t] - a, eb = s_b[t] - c;
+  for (int q = lo; q < hi; ++q) {
+    const int va = bsum[2 * q], vb = bsum[2 * q + 1];
+    bsum[2 * q] = (int)ea; bsum[2 * q + 1] = (int)eb;
+    ea += va; eb += vb;
+  }
+  if (t == 1023) { A.tot[2 * b] = s_a[1023]; A.tot[2 * b + 1] = s_b[1023]; }
+}
+
+__global__ __launch_bounds__(256) void k_mcl_verts(MclArgs A, double* verts, int* vkeys) {
+  const int nact = *A.nact;
+  for (int q = blockIdx.x; q < nact; q += gridDim.x) {  // the voff / vflag of unmarked blocks are never read
+    const long long blk = A.alist[2 * q];
+    const int b = A.alist[2 * q + 1];
+    MclGeo G;
+    mcl_geo(A, b, G);
+    const long long g0 = A.coff[b];
+    const unsigned lin = (unsigned)(blk * 256 - g0) + threadIdx.x;
+    const long long g = g0 + lin;
+    const int bits = lin < G.ncell ? A.vflag[g] : 0;
+    int pv, pt, tv, tt;
+    block_prefix(__popc(bits), 0, pv, pt, tv, tt);
+    if (lin >= G.ncell) continue;
+    int vid = A.bsum[2 * blk] + pv;
+    A.voff[g] = vid;
+    if (!bits) continue;
+    int i, j, k;
+    mcl_cell(G, lin, i, j, k);
+    const FabView S = mf_view(A.S, A.L.boxes[b], b);
+    for (int d = 0; d < 3; ++d) {
+      if (!(bits & (1 << d))) continue;
+      bool rev = false;
+      first_toucher(G, A.lc + g0, i, j, k, d, rev);
+      const int hi_i = i + (d == 0), hi_j = j + (d == 1), hi_k = k + (d == 2);
+      const int a[3] = {rev ? hi_i : i, rev ? hi_j : j, rev ? hi_k : k};
+      const int e[3] = {rev ? i : hi_i, rev ? j : hi_j, rev ? k : hi_k};
+      const double v1 = S(a[0], a[1], a[2], A.isocomp), v2 = S(e[0], e[1], e[2], A.isocomp);
+      const long long vo = A.base[2 * b] + vid;
+      double* o = verts + vo * A.ncomp;
+      int mode;  // 0 copy p1, 1 copy p2, 2 interpolate (VI_doIt, isosurface.cpp:257-301)
+      if (fabs(A.iso - v1) < PA_EPS_DEF) mode = 0;
+      else if (fabs(A.iso - v2) < PA_EPS_DEF) mode = 1;
+      else if (fabs(v1 - v2) < PA_EPS_DEF) mode = 0;
+      else mode = 2;
+      const double mu = mode == 2 ? (A.iso - v1) / (v2 - v1) : 0.0;
+      for (int c = 0; c < A.ncomp; ++c) {
+        const double a1 = S(a[0], a[1], a[2], c), a2 = S(e[0], e[1], e[2], c);
+        o[c] = mode == 0 ? a1 : (mode == 1 ? a2 : a1 + mu * (a2 - a1));
+      }
+      int* key = vkeys + 6LL * vo;
+      key[0] = i; key[1] = j; key[2] = k; key[3] = hi_i; key[4] = hi_j; key[5] = hi_k;
+      ++vid;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_mcl_tris(MclArgs A, int* tris) {
+  const int nact = *A.nact;
+  for (int q = blockIdx.x; q < nact; q += gridDim.x) {
+    const long long blk = A.alist[2 * q];
+    const int b = A.alist[2 * q + 1];
+    MclGeo G;
+    mcl_geo(A, b, G);
+    const long long g0 = A.coff[b];
+    const unsigned lin = (unsigned)(blk * 256 - g0) + threadIdx.x;
+    const long long g = g0 + lin;
+    const int ci = (lin < G.ncell && (A.lc[g] & 1)) ? A.cidx[g] : 0;
+    const int nt = c_ntri[ci];
+    int pv, pt, tv, tt;
+    block_prefix(0, nt, pv, pt, tv, tt);
+    if (nt == 0) continue;
+    int i, j, k;
+    mcl_cell(G, lin, i, j, k);
+    int* o = tris + 3LL * (A.base[2 * b + 1] + A.bsum[2 * blk + 1] + pt);
+    for (int t = 0; t < 3 * nt; ++t) {
+      const int e = c_tri[ci][t];
+      const long long le = g0 + lin_of(G, i + d_elo[e][0], j + d_elo[e][1], k + d_elo[e][2]);
+      const int dir = d_edir[e];
+      o[t] = A.voff[le] + __popc(A.vflag[le] & ((1 << dir) - 1));
+    }
+  }
+}
+
+// mask of isosurface.cpp:1540-1563: 1, and -1 on cells (ghost cells included) covered by the next finer level
+__global__ __launch_bounds__(256) void k_iso_mask(DLevelView L, DMFView M, int comp, DLevelView LF, int has_fine, int ratio) {
+  const int b = blockIdx.y;
+  const DBox B = L.boxes[b];
+  const unsigned nx = B.hi[0] - B.lo[0] + 1 + 2 * M.ng, ny = B.hi[1] - B.lo[1] + 1 + 2 * M.ng, nz = B.hi[2] - B.lo[2] + 1 + 2 * M.ng;
+  const unsigned lin = blockIdx.x * 256u + threadIdx.x;
+  if (lin >= nx * ny * nz) return;
+  const unsigned r = lin / nx, kk = r / ny;
+  double v = 1.0;
+  if (has_fine) {
+    int p[3] = {(B.lo[0] - M.ng + (int)(lin - r * nx)) * ratio, (B.lo[1] - M.ng + (int)(r - kk * ny)) * ratio, (B.lo[2] - M.ng + (int)kk) * ratio};
+    if (wrap_cell(LF, p)) {  // periodic images of the coarsened fine boxes mask too (isosurface.cpp:1550-1560)
+      const int o = owner_of(LF, p);
+      if (o >= 0 || o == -2) v = -1.0;
+    }
+  }
+  M.data[M.off[b] + (long long)comp * pa_cstride((long long)nx * ny * nz, M.ncomp) + lin] = v;
+}
+
+extern "C" int pa_iso_mask_level(pa_ctx* ctx, pa_mf* mask, int comp, const pa_level* fine, int ratio) {
+  if (!ctx || !mask) return pa_fail(ctx, "pa_iso_mask_level: null argument");
+  if (comp < 0 || comp >= mask->ncomp) return pa_fail(ctx, "pa_iso_mask_level: component range");
+  if (fine && ratio < 1) return pa_fail(ctx, "pa_iso_mask_level: bad refinement ratio");
+  const pa_level* L = mask->lev;
+  const long long nmax = (long long)(L->maxn[0] + 2 * mask->ng) * (L->maxn[1] + 2 * mask->ng) * (L->maxn[2] + 2 * mask->ng);
+  if (nmax >= (1LL << 31)) return pa_fail(ctx, "pa_iso_mask_level: FAB too large");
+  hipLaunchKernelGGL(k_iso_mask, dim3((unsigned)((nmax + 255) / 256), (unsigned)L->boxes.size()), dim3(256), 0, ctx->stream, L->view, mask->view, comp,
+                     fine ? fine->view : L->view, fine ? 1 : 0, ratio);
+  PA_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int pa_mc_level(pa_ctx* ctx, const pa_mf* state, const pa_mf* mask, int mcomp, const pa_box* loops, int isocomp, double isoval,
+                           int64_t* nvert, int64_t* ntri, double** dev_verts, int32_t** dev_vkeys, int32_t** dev_tris) {
+  if (!ctx || !state || !mask || !loops || !nvert || !ntri || !dev_verts || !dev_vkeys || !dev_tris) return pa_fail(ctx, "pa_mc_level: null argument");
+  *dev_verts = nullptr; *dev_vkeys = nullptr; *dev_tris = nullptr;
+  if (state->lev != mask->lev || state->ng != mask->ng) return pa_fail(ctx, "pa_mc_level: state and mask must share the level and the ghost width");
+  if (state->ncomp < 4) return pa_fail(ctx, "pa_mc_level: state needs 3 coordinate components + at least one field");
+  if (isocomp < 0 || isocomp >= state->ncomp || mcomp < 0 || mcomp >= mask->ncomp) return pa_fail(ctx, "pa_mc_level: component range");
+  const pa_level* L = state->lev;
+  const int nb = (int)L->boxes.size(), ng = state->ng;
+  std::vector<long long> coff((size_t)nb + 1, 0);
+  std::vector<DBox> dl((size_t)nb);
+  long long maxcell = 0;
+  for (int b = 0; b < nb; ++b) {
+    const DBox& B = L->boxes[b];
+    long long nc = 1;
+    bool on = true;
+    for (int d = 0; d < 3; ++d) {
+      nc *= B.hi[d] - B.lo[d] + 1 + 2 * ng;
+      dl[b].lo[d] = loops[b].lo[d];
+      dl[b].hi[d] = loops[b].hi[d];
+      on = on && loops[b].lo[d] <= loops[b].hi[d];
+    }
+    if (on)
+      for (int d = 0; d < 3; ++d)
+        if (loops[b].lo[d] < B.lo[d] - ng || loops[b].hi[d] + 1 > B.hi[d] + ng) return pa_fail(ctx, "pa_mc_level: loop box + 1 must lie inside the grown FAB");
+    if (nc >= (1LL << 31)) return pa_fail(ctx, "pa_mc_level: FAB too large");
+    maxcell = std::max(maxcell, on ? nc : 0);
+    coff[b + 1] = coff[b] + (on ? (nc + 255) / 256 * 256 : 0);
+    nvert[b] = ntri[b] = 0;
+  }
+  if (nb == 0 || maxcell == 0) return 0;
+  PA_TRY_RET(upload_tables(ctx));
+  const size_t ncell = (size_t)coff[nb], nblk = ncell / 256;
+  if (nblk > 0x7fffffffull) return pa_fail(ctx, "pa_mc_level: level too large for one pass");
+  const size_t hdr = ((size_t)nb * (16 + 16 + 24) + ((size_t)nb + 1) * 8 + 255) / 256 * 256;
+  if (ensure_scr(ctx, hdr + 7 * ncell + 17 * nblk + 512)) return 1;
+  unsigned char* p = (unsigned char*)ctx->d_scr;
+  MclArgs A;
+  A.L = L->view; A.S = state->view; A.M = mask->view;
+  A.mcomp = mcomp; A.isocomp = isocomp; A.ncomp = state->ncomp; A.iso = isoval;
+  A.kseg = 32;
+  A.tot = (long long*)p; p += 16 * (size_t)nb;
+  long long* d_base = (long long*)p; p += 16 * (size_t)nb;
+  long long* d_coff = (long long*)p; p += 8 * ((size_t)nb + 1);
+  DBox* d_loops = (DBox*)p;
+  p = (unsigned char*)ctx->d_scr + hdr;
+  A.voff = (int*)p; p += 4 * ncell;
+  A.bsum = (int*)p; p += 8 * nblk;
+  A.lc = p; p += ncell;
+  A.cidx = p; p += ncell;
+  A.vflag = p; p += ncell;
+  A.bact = p; p += (nblk + 255) / 256 * 256;
+  A.alist = (int*)p; p += 8 * nblk;
+  A.nact = (int*)p;
+  A.base = d_base; A.coff = d_coff; A.loops = d_loops;
+  ProfScope prof(ctx, PA_TAG_MC);
+  PA_HIP(hipMemcpyAsync(d_coff, coff.data(), 8 * ((size_t)nb + 1), hipMemcpyHostToDevice, ctx->stream));
+  PA_HIP(hipMemcpyAsync(d_loops, dl.data(), sizeof(DBox) * (size_t)nb, hipMemcpyHostToDevice, ctx->stream));
+  {
+    const char* te = getenv("PA_MC_TY");  // tile rows / planes per workgroup of the cell pass (tuning, read per call)
+    const char* ke = getenv("PA_MC_KSEG");
+    const int TY = te ? atoi(te) : 8;
+    if (ke && atoi(ke) > 0) A.kseg = atoi(ke);
+    const int mx = L->maxn[0] + 2 * ng, my = L->maxn[1] + 2 * ng, mz = L->maxn[2] + 2 * ng;
+    auto tiles = [&](int ty) { return (unsigned)(std::max(1, (mx - 1 + 62) / 63) * std::max(1, (my - 1 + ty - 2) / (ty - 1)) * ((mz + A.kseg - 1) / A.kseg)); };
+    PA_HIP(hipMemsetAsync(A.bact, 0, nblk, ctx->stream));
+    PA_HIP(hipMemsetAsync(A.bsum, 0, 8 * nblk, ctx->stream));
+    PA_HIP(hipMemsetAsync(A.nact, 0, 4, ctx->stream));
+    if (TY == 16) hipLaunchKernelGGL((k_mcl_cells<16>), dim3(tiles(16), (unsigned)nb), dim3(64 * 16), 0, ctx->stream, A);
+    else if (TY == 4) hipLaunchKernelGGL((k_mcl_cells<4>), dim3(tiles(4), (unsigned)nb), dim3(64 * 4), 0, ctx->stream, A);
+    else hipLaunchKernelGGL((k_mcl_cells<8>), dim3(tiles(8), (unsigned)nb), dim3(64 * 8), 0, ctx->stream, A);
+    hipLaunchKernelGGL(k_mcl_active, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, ctx->stream, A, (int)nblk);
+  }
+  const dim3 grid(4096);  // persistent over the marked blocks
+  hipLaunchKernelGGL(k_mcl_count, grid, dim3(256), 0, ctx->stream, A);
+  hipLaunchKernelGGL(k_mcl_scan, dim3((unsigned)nb), dim3(1024), 0, ctx->stream, A);
+  PA_HIP(hipGetLastError());
+  std::vector<long long> tot(2 * (size_t)nb), base(2 * (size_t)nb);
+  PA_HIP(hipMemcpyAsync(tot.data(), A.tot, 16 * (size_t)nb, hipMemcpyDeviceToHost, ctx->stream));
+  PA_HIP(hipStreamSynchronize(ctx->stream));  // coff / dl / tot are host vectors of this call
+  long long nv = 0, nt = 0;
+  for (int b = 0; b < nb; ++b) {
+    const bool on = coff[b + 1] > coff[b];
+    nvert[b] = on ? tot[2 * b] : 0;
+    ntri[b] = on ? tot[2 * b + 1] : 0;
+    if (nvert[b] > 0x7fffffffLL || ntri[b] > 0x7fffffffLL / 3) return pa_fail(ctx, "pa_mc_level: surface of one FAB too large for 32-bit ids");
+    base[2 * b] = nv; base[2 * b + 1] = nt;
+    nv += nvert[b]; nt += ntri[b];
+  }
+  if (nv == 0 && nt == 0) return 0;
+  // one allocation: vertices | keys | triangles (each part 256-byte aligned)
+  const size_t bv = ((size_t)nv * state->ncomp * 8 + 255) / 256 * 256, bk = ((size_t)nv * 24 + 255) / 256 * 256, bt = std::max<size_t>(8, (size_t)nt * 12);
+  unsigned char* blockp = nullptr;
+  auto bail = [&](const std::string& m) { if (blockp) (void)hipFree(blockp); return pa_fail(ctx, m); };
+  if (hipMalloc(&blockp, bv + bk + bt) != hipSuccess) return bail("pa_mc_level: out of device memory for the surface");
+  double* dv = (double*)blockp;
+  int32_t *dk = (int32_t*)(blockp + bv), *dt = (int32_t*)(blockp + bv + bk);
+  if (hipMemcpyAsync(d_base, base.data(), 16 * (size_t)nb, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return bail("pa_mc_level: upload failed");
+  hipLaunchKernelGGL(k_mcl_verts, grid, dim3(256), 0, ctx->stream, A, dv, dk);
+  hipLaunchKernelGGL(k_mcl_tris, grid, dim3(256), 0, ctx->stream, A, dt);
+  if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return bail("pa_mc_level: emit kernels failed");
+  *dev_verts = dv; *dev_vkeys = dk; *dev_tris = dt;
   return 0;
 }

@@ -189,6 +189,31 @@ def test_isosurface_tool_end_to_end(tmp_path, oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("per", [(1, 1, 0), (1, 1, 1)])
+def test_isosurface_tool_periodic(tmp_path, oracle, per):
+    """is_per != 0 (isosurface.cpp:1395, 1437, 1469, 1550-1560): periodic ghost fill of coordinates and fields, periodic
+    images of the fine-covered mask, loop box over the periodically grown domain -- MEF identical to the oracle's.  The
+    fine level touches the low x and the high z face of the domain and the surface crosses every face."""
+    from peleanalysis_amd.hierarchy import Hierarchy, Level, chop_box, field_trig
+    zero, one = np.zeros(3), np.ones(3)
+    l0 = Level(chop_box((0, 0, 0), (15, 15, 15), 8), (0, 0, 0), (15, 15, 15), np.asarray(per), zero, one)
+    l1 = Level(chop_box((0, 8, 16), (15, 23, 31), 8), (0, 0, 0), (31, 31, 31), np.asarray(per), zero, one)
+    H = Hierarchy([l0, l1], 2)
+    mfs = make_states(H, 3, 0, field_trig, seed=5)
+    p = str(tmp_path / "plt00007")
+    write_plotfile(p, H, mfs, ["temp", "x_velocity", "density"], time=0.5, level_steps=[7, 7])
+    _run("isosurface3d.ex", ["infile=" + p, "isoCompName=temp", "isoVal=1050", "comps=0 2", "is_per=" + " ".join(str(x) for x in per)], tmp_path)
+    _, _, nodes, faces = read_mef(p + "_temp_1050.mef")
+    fields = [MultiFab(lv, 3, 0, mfs[l].data.copy()) for l, lv in enumerate(H.levels)]
+    onodes, oelts = oracle.isosurface_pipeline(H.levels, fields, [0, 2], 0, 1050.0, MultiFab)
+    assert len(oelts) > 500
+    span = onodes[oelts][:, :, 0].max(axis=1) - onodes[oelts][:, :, 0].min(axis=1)
+    assert (span > 2.0 / 32).any(), "no stretched element behind the periodic x face: the quirk is not exercised"
+    assert np.array_equal(faces, oelts + 1), "connectivity (1-based) differs"
+    assert np.array_equal(nodes.view(np.int64), onodes.view(np.int64)), "node data not bit-identical"
+
+
+@pytest.mark.gpu
 def test_isosurface_tool_distance_function(tmp_path, oracle):
     """build_distance_function=1 (isosurface.cpp:1361-1381, 1595-1655, 1731-1748): the "distance" plotfile
     and the (unmasked) surface identical to the oracle's -- whose make_level_set3 is pinned to the reference

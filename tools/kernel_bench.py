@@ -61,8 +61,9 @@ if len(sys.argv) > 3 and sys.argv[3] == "gradonly":
     print(json.dumps(out))
     sys.exit(0)
 
+MCONLY = len(sys.argv) > 3 and sys.argv[3] == "mconly"
 # ---- box filter (filterPlt.cpp:217): 16 B/cell, fgr 2 / 4 / 8 -> 27 / 125 / 729 taps
-for fgr in (2, 4, 8):
+for fgr in (() if MCONLY else (2, 4, 8)):
     w = (C.c_double * (fgr + 2))()
     ng = ctx.lib.pa_box_filter_weights(fgr, w)
     tin, fin = dev_mf(1, ng)
@@ -101,6 +102,52 @@ out["kernels"]["k_mc count (classify+count+scan, 1 FAB)"] = {"ms": ms_count, "ce
                                                             "GBs": fc * 16 / ms_count / 1e6, "note": "includes the synchronous 16-byte D2H of the totals"}
 out["kernels"]["k_mc emit (count again + vertices + triangles, 1 FAB)"] = {"ms": ms_emit, "vertices": nv.value, "triangles": nt.value,
                                                                          "Mtriangles_s": nt.value / ms_emit / 1e3, "Mcells_s": fc / ms_emit / 1e3}
+
+# ---- marching cubes, level-batched (pa_iso_mask_level + pa_mc_level): every FAB of the level in one pass
+off5, cs5, tot5 = mf_layout(lv.boxes, 5, 1)
+with torch.cuda.stream(stream):
+    t5 = torch.empty(tot5, dtype=torch.float64, device=dev)
+    for b in range(lv.nboxes):
+        lo = lv.boxes[b, :3] - 1
+        xs = [(torch.arange(int(lo[d]), int(lo[d]) + g, device=dev, dtype=torch.float64) + 0.5) / n for d in range(3)]
+        Xb, Yb, Zb = xs[0][None, None, :].expand(g, g, g), xs[1][None, :, None].expand(g, g, g), xs[2][:, None, None].expand(g, g, g)
+        rb = torch.sqrt((Xb - 0.5) ** 2 + (Yb - 0.5) ** 2 + (Zb - 0.5) ** 2)
+        for c, v in enumerate((Xb, Yb, Zb, 300.0 + 1700.0 * 0.5 * (1 + torch.tanh((rb - 0.3) / 0.05)), rb)):
+            t5[off5[b] + c * cs5[b]: off5[b] + c * cs5[b] + g ** 3] = v.reshape(-1)
+stream.synchronize()
+st5 = capi.DevMF(ctx, dl, 5, 1, t5.data_ptr())
+tmk, mk5 = dev_mf(1, 1, False)
+ctx.check(ctx.lib.pa_iso_mask_level(ctx.h, mk5.h, 0, None, 2))
+loops = (capi.PaBox * lv.nboxes)()
+for b in range(lv.nboxes):
+    for d in range(3):
+        loops[b].lo[d] = max(int(lv.boxes[b, d]) - 1, 0)
+        loops[b].hi[d] = min(int(lv.boxes[b, 3 + d]) + 1, n - 1) - 1
+nvb, ntb = (C.c_int64 * lv.nboxes)(), (C.c_int64 * lv.nboxes)()
+pv, pk, pt = C.c_void_p(), C.c_void_p(), C.c_void_p()
+
+
+def mc_level_once():
+    ctx.check(ctx.lib.pa_mc_level(ctx.h, st5.h, mk5.h, 0, loops, 3, 1150.0, nvb, ntb, C.byref(pv), C.byref(pk), C.byref(pt)))
+    ctx.lib.pa_device_free(ctx.h, pv)  # one allocation
+
+
+mc_level_once()
+ctx.sync()
+t0 = time.perf_counter()
+for _ in range(3):
+    mc_level_once()
+ctx.sync()
+ms_lvl = (time.perf_counter() - t0) * 1e3 / 3
+lc = lv.nboxes * g ** 3
+out["kernels"][f"pa_mc_level ({lv.nboxes} FABs of {g}^3 in one pass: flags, classify, count, scan, vertices, triangles; wall clock incl. allocation)"] = {
+    "ms": ms_lvl, "cells": lc, "Mcells_s": lc / ms_lvl / 1e3, "bytes_per_cell": 16, "GBs": lc * 16 / ms_lvl / 1e6, "frac_hbm": lc * 16 / ms_lvl / 1e6 / HBM,
+    "triangles": int(sum(ntb)), "Mtriangles_s": sum(ntb) / ms_lvl / 1e3}
+ms_mask = timed(8, lambda: ctx.check(ctx.lib.pa_iso_mask_level(ctx.h, mk5.h, 0, None, 2)))
+del st5, mk5, t5, tmk
+if MCONLY:
+    print(json.dumps(out))
+    sys.exit(0)
 
 # ---- distance function (make_level_set3) on that FAB's mesh: one grid, and a batch of 64 grids
 xf = tv.view(-1, 5)[:, :3].to(torch.float32).contiguous()

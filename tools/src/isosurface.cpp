@@ -11,7 +11,8 @@
 // (pa_sdf_level_set3 = Tools/SDFGen make_level_set3, batched over all FABs of a level), signed with
 // the iso component and clipped at dmax; written as a one-component plotfile "distance".
 //       [surfFormat=MEF|XDMF]
-// Not ported yet: periodic directions (quirk Q5).
+// Periodic directions behave as in the reference: ghost cells behind a periodic face keep the coordinates of the
+// cells they image (isosurface.cpp:1469 "bad data in periodic directions"; the shift back at :1483-1507 never fires).
 #include "../common/pa_device.h"
 #include "../common/pa_isomerge.h"
 
@@ -74,7 +75,6 @@ int main(int argc, char** argv) {
   }
   std::vector<int> is_per(3, 0);
   pp.queryarr("is_per", is_per, 0, 3);
-  if (is_per[0] || is_per[1] || is_per[2]) pa::Abort("periodic directions are not available in this build (the reference leaves bad data there too)");
 
   pa::Ctx ctx;
   std::vector<std::unique_ptr<pa::DevLevel>> dl;
@@ -110,7 +110,7 @@ int main(int argc, char** argv) {
   if (pa_bc_errors(ctx.h) != 0) pa::Abort("FillPatchTwoLevels: fine grids are not properly nested in the coarse level");
 
   pa::IsoMerger merger(nc);
-  std::vector<double> mask, hv;
+  std::vector<double> hv;
   std::vector<int32_t> ht, hk;
   std::vector<pa::HostMF> hdist(build_distance_function ? Nlev : 0);
   for (int lev = 0; lev < Nlev; ++lev) {
@@ -129,111 +129,102 @@ int main(int argc, char** argv) {
       hdist[lev].define(L.boxes, 1, ng);
       ddist.reset(new pa::DevMF(ctx, *dl[lev], 1, ng));
     }
-    for (size_t b = 0; b < L.boxes.size(); ++b) {
+    // fine-covered mask (isosurface.cpp:1540-1563; all 1 when building the distance function, :1542) and the whole
+    // MFIter loop of :1531-1592 as one batch per level
+    pa::DevMF dmask(ctx, *dl[lev], 1, ng);
+    const bool fine_mask = lev < finestLevel && !build_distance_function;
+    ctx.check(pa_iso_mask_level(ctx.h, dmask.h, 0, fine_mask ? dl[lev + 1]->h : nullptr, 2));
+    const size_t nb = L.boxes.size();
+    std::vector<pa_box> loops(nb);
+    for (size_t b = 0; b < nb; ++b) {  // base points: (grown box & domain grown in the periodic directions), high side - 1 (isosurface.cpp:1566-1569)
       const pa::Box3& B = L.boxes[b];
-      pa::Box3 g{{B.lo[0] - ng, B.lo[1] - ng, B.lo[2] - ng}, {B.hi[0] + ng, B.hi[1] + ng, B.hi[2] + ng}};
-      const long long nx = g.hi[0] - g.lo[0] + 1, ny = g.hi[1] - g.lo[1] + 1;
-      mask.assign((size_t)g.numPts(), 1.0);
-      if (lev < finestLevel && !build_distance_function)  // fine-covered mask (isosurface.cpp:1540-1563)
-        for (const pa::Box3& F : H.lev[lev + 1].boxes) {
-          int lo[3], hi[3];
-          bool ok = true;
-          for (int d = 0; d < 3; ++d) {
-            lo[d] = std::max(g.lo[d], F.lo[d] >= 0 ? F.lo[d] / 2 : -((-F.lo[d] + 1) / 2));
-            hi[d] = std::min(g.hi[d], F.hi[d] >= 0 ? F.hi[d] / 2 : -((-F.hi[d] + 1) / 2));
-            ok = ok && lo[d] <= hi[d];
-          }
-          if (!ok) continue;
-          for (int k = lo[2]; k <= hi[2]; ++k)
-            for (int j = lo[1]; j <= hi[1]; ++j)
-              for (int i = lo[0]; i <= hi[0]; ++i) mask[((long long)(k - g.lo[2]) * ny + (j - g.lo[1])) * nx + (i - g.lo[0])] = -1.0;
-        }
-      pa_box loop;  // base points: (grown box & domain), high side - 1 (isosurface.cpp:1566-1569)
-      bool empty = false;
       for (int d = 0; d < 3; ++d) {
-        loop.lo[d] = std::max(g.lo[d], L.domain.lo[d]);
-        loop.hi[d] = std::min(g.hi[d], L.domain.hi[d]) - 1;
-        empty = empty || loop.lo[d] > loop.hi[d];
+        const int pg = is_per[d] ? ng : 0;  // growPeriodicDomain (isosurface.cpp:1437)
+        loops[b].lo[d] = std::max(B.lo[d] - ng, L.domain.lo[d] - pg);
+        loops[b].hi[d] = std::min(B.hi[d] + ng, L.domain.hi[d] + pg) - 1;
       }
-      if (empty) continue;
-      void* dmask = pa_device_malloc(ctx.h, (int64_t)mask.size() * 8);
-      if (!dmask) pa::Abort(pa_last_error(ctx.h));
-      ctx.check(pa_memcpy_h2d(ctx.h, dmask, mask.data(), (int64_t)mask.size() * 8));
-      pa_fab fs, fm;
-      fs.p = base + host[lev].off[b]; fs.ncomp = nc; fs.nstride = host[lev].cs[b];
-      fm.p = (double*)dmask; fm.ncomp = 1; fm.nstride = 0;
-      for (int d = 0; d < 3; ++d) { fs.lo[d] = fm.lo[d] = g.lo[d]; fs.hi[d] = fm.hi[d] = g.hi[d]; }
-      int64_t nv = 0, nt = 0;
-      ctx.check(pa_mc_count_fab(ctx.h, loop, &fs, &fm, 3 + isoComp, isoVal, &nv, &nt));
-      if (nt > 0) {
-        has_elts[b] = 1;
-        void* dv = pa_device_malloc(ctx.h, nv * nc * 8);
-        void* dk = pa_device_malloc(ctx.h, nv * 6 * 4);
-        void* dt = pa_device_malloc(ctx.h, nt * 3 * 4);
-        if (!dv || !dk || !dt) pa::Abort(pa_last_error(ctx.h));
-        ctx.check(pa_mc_emit_fab(ctx.h, loop, &fs, &fm, 3 + isoComp, isoVal, (double*)dv, (int32_t*)dk, (int32_t*)dt, nv, nt));
-        hv.resize((size_t)(nv * nc));
-        ht.resize((size_t)(nt * 3));
-        hk.resize((size_t)(nv * 6));
-        ctx.check(pa_memcpy_d2h(ctx.h, hv.data(), dv, nv * nc * 8));
-        ctx.check(pa_memcpy_d2h(ctx.h, ht.data(), dt, nt * 3 * 4));
-        ctx.check(pa_memcpy_d2h(ctx.h, hk.data(), dk, nv * 6 * 4));
-        if (build_distance_function) {
-          // vertList / faceList of this FAB BEFORE trimming (isosurface.cpp:1598-1626); Vec3f(loc) rounds to float
-          std::vector<float> xf((size_t)nv * 3);
-          for (int64_t q = 0; q < nv; ++q)
-            for (int d = 0; d < 3; ++d) xf[(size_t)q * 3 + d] = (float)hv[(size_t)q * nc + d];
-          pa_sdf_grid G;
-          G.ntri = nt; G.nvert = nv;
-          void* dx3 = pa_device_malloc(ctx.h, nv * 3 * 4);
-          void* dphi = pa_device_malloc(ctx.h, g.numPts() * 4);
-          if (!dx3 || !dphi) pa::Abort(pa_last_error(ctx.h));
-          ctx.check(pa_memcpy_h2d(ctx.h, dx3, xf.data(), nv * 3 * 4));
-          G.tri = (const uint32_t*)dt;  // local vertex ids in vertCache order = ptID (isosurface.cpp:1602-1611)
-          G.x = (const float*)dx3;
-          for (int d = 0; d < 3; ++d) {
-            G.origin[d] = (float)(H.prob_lo[d] + g.lo[d] * dxf[d]);  // local_origin: the box's low NODE (quirk: not the cell centre)
-            G.n[d] = g.hi[d] - g.lo[d] + 1;
-          }
-          G.dx = (float)dxf[0];
-          G.phi = (float*)dphi;
-          grids.push_back(G);
-          grid_box.push_back(b);
-          grid_bufs.push_back(dt); grid_bufs.push_back(dx3); grid_bufs.push_back(dphi);
-        } else {
-          pa_device_free(ctx.h, dt);
-        }
-        // elements with a vertex whose edge is not inside the valid box grown by 1 are dropped, with those
-        // vertices (isosurface.cpp:1657-1682); a no-op when nGrow = 1
-        long long nvk = nv, ntk = nt;
-        if (rm_external_elements && ng > 1) {
-          std::vector<int32_t> remap((size_t)nv);
-          nvk = 0;
-          for (int64_t q = 0; q < nv; ++q) {
-            bool in = true;
-            for (int d = 0; d < 3; ++d) {
-              const int a = hk[(size_t)q * 6 + d], c = hk[(size_t)q * 6 + 3 + d];
-              in = in && a >= B.lo[d] - 1 && a <= B.hi[d] + 1 && c >= B.lo[d] - 1 && c <= B.hi[d] + 1;
-            }
-            remap[(size_t)q] = in ? (int32_t)nvk : -1;
-            if (in) {
-              if (nvk != q) std::copy(hv.begin() + q * nc, hv.begin() + (q + 1) * nc, hv.begin() + nvk * nc);
-              ++nvk;
-            }
-          }
-          ntk = 0;
-          for (int64_t t = 0; t < nt; ++t) {
-            const int32_t a = remap[(size_t)ht[(size_t)t * 3]], c = remap[(size_t)ht[(size_t)t * 3 + 1]], e = remap[(size_t)ht[(size_t)t * 3 + 2]];
-            if (a < 0 || c < 0 || e < 0) continue;
-            ht[(size_t)ntk * 3] = a; ht[(size_t)ntk * 3 + 1] = c; ht[(size_t)ntk * 3 + 2] = e;
-            ++ntk;
-          }
-        }
-        merger.add(hv.data(), nvk, ht.data(), ntk);
-        pa_device_free(ctx.h, dv); pa_device_free(ctx.h, dk);
-      }
-      pa_device_free(ctx.h, dmask);
     }
+    std::vector<int64_t> nvb(nb, 0), ntb(nb, 0);
+    double* dv = nullptr;
+    int32_t *dk = nullptr, *dt = nullptr;
+    ctx.check(pa_mc_level(ctx.h, dst[lev]->h, dmask.h, 0, loops.data(), 3 + isoComp, isoVal, nvb.data(), ntb.data(), &dv, &dk, &dt));
+    int64_t nvt = 0, ntt = 0;
+    for (size_t b = 0; b < nb; ++b) { nvt += nvb[b]; ntt += ntb[b]; }
+    std::vector<double> hva((size_t)(nvt * nc));
+    std::vector<int32_t> hta((size_t)(ntt * 3)), hka((size_t)(nvt * 6));
+    if (nvt > 0) {
+      ctx.check(pa_memcpy_d2h(ctx.h, hva.data(), dv, nvt * nc * 8));
+      ctx.check(pa_memcpy_d2h(ctx.h, hka.data(), dk, nvt * 6 * 4));
+    }
+    if (ntt > 0) ctx.check(pa_memcpy_d2h(ctx.h, hta.data(), dt, ntt * 3 * 4));
+    void* dx3 = nullptr;
+    if (build_distance_function && nvt > 0) {  // vertList: Vec3f(loc) rounds to float (isosurface.cpp:1598-1611)
+      std::vector<float> xf((size_t)nvt * 3);
+      for (int64_t q = 0; q < nvt; ++q)
+        for (int d = 0; d < 3; ++d) xf[(size_t)q * 3 + d] = (float)hva[(size_t)q * nc + d];
+      dx3 = pa_device_malloc(ctx.h, nvt * 3 * 4);
+      if (!dx3) pa::Abort(pa_last_error(ctx.h));
+      ctx.check(pa_memcpy_h2d(ctx.h, dx3, xf.data(), nvt * 3 * 4));
+      grid_bufs.push_back(dx3);
+    }
+    int64_t vo = 0, to = 0;
+    for (size_t b = 0; b < nb; vo += nvb[b], to += ntb[b], ++b) {
+      const pa::Box3& B = L.boxes[b];
+      const int64_t nv = nvb[b], nt = ntb[b];
+      if (nt <= 0) continue;
+      has_elts[b] = 1;
+      hv.assign(hva.begin() + vo * nc, hva.begin() + (vo + nv) * nc);
+      ht.assign(hta.begin() + to * 3, hta.begin() + (to + nt) * 3);
+      hk.assign(hka.begin() + vo * 6, hka.begin() + (vo + nv) * 6);
+      if (build_distance_function) {
+        // vertList / faceList of this FAB BEFORE trimming (isosurface.cpp:1598-1626)
+        pa::Box3 g{{B.lo[0] - ng, B.lo[1] - ng, B.lo[2] - ng}, {B.hi[0] + ng, B.hi[1] + ng, B.hi[2] + ng}};
+        pa_sdf_grid G;
+        G.ntri = nt; G.nvert = nv;
+        void* dphi = pa_device_malloc(ctx.h, g.numPts() * 4);
+        if (!dphi) pa::Abort(pa_last_error(ctx.h));
+        G.tri = (const uint32_t*)(dt + 3 * to);  // local vertex ids in vertCache order = ptID (isosurface.cpp:1602-1611)
+        G.x = (const float*)dx3 + 3 * vo;
+        for (int d = 0; d < 3; ++d) {
+          G.origin[d] = (float)(H.prob_lo[d] + g.lo[d] * dxf[d]);  // local_origin: the box's low NODE (quirk: not the cell centre)
+          G.n[d] = g.hi[d] - g.lo[d] + 1;
+        }
+        G.dx = (float)dxf[0];
+        G.phi = (float*)dphi;
+        grids.push_back(G);
+        grid_box.push_back(b);
+        grid_bufs.push_back(dphi);
+      }
+      // elements with a vertex whose edge is not inside the valid box grown by 1 are dropped, with those
+      // vertices (isosurface.cpp:1657-1682); a no-op when nGrow = 1
+      long long nvk = nv, ntk = nt;
+      if (rm_external_elements && ng > 1) {
+        std::vector<int32_t> remap((size_t)nv);
+        nvk = 0;
+        for (int64_t q = 0; q < nv; ++q) {
+          bool in = true;
+          for (int d = 0; d < 3; ++d) {
+            const int a = hk[(size_t)q * 6 + d], c = hk[(size_t)q * 6 + 3 + d];
+            in = in && a >= B.lo[d] - 1 && a <= B.hi[d] + 1 && c >= B.lo[d] - 1 && c <= B.hi[d] + 1;
+          }
+          remap[(size_t)q] = in ? (int32_t)nvk : -1;
+          if (in) {
+            if (nvk != q) std::copy(hv.begin() + q * nc, hv.begin() + (q + 1) * nc, hv.begin() + nvk * nc);
+            ++nvk;
+          }
+        }
+        ntk = 0;
+        for (int64_t t = 0; t < nt; ++t) {
+          const int32_t a = remap[(size_t)ht[(size_t)t * 3]], c = remap[(size_t)ht[(size_t)t * 3 + 1]], e = remap[(size_t)ht[(size_t)t * 3 + 2]];
+          if (a < 0 || c < 0 || e < 0) continue;
+          ht[(size_t)ntk * 3] = a; ht[(size_t)ntk * 3 + 1] = c; ht[(size_t)ntk * 3 + 2] = e;
+          ++ntk;
+        }
+      }
+      merger.add(hv.data(), nvk, ht.data(), ntk);
+    }
+    // dv, dk, dt are one allocation (base dv); the distance function still reads the triangles
+    if (build_distance_function) grid_bufs.push_back(dv); else pa_device_free(ctx.h, dv);
     if (build_distance_function) {
       ctx.check(pa_sdf_level_set3(ctx.h, (int)grids.size(), grids.data(), 1));
       double* dbase = pa_mf_data(ddist->h);
