@@ -188,7 +188,8 @@ template <typename BP>
 static void filter_launch(hipStream_t st, const BP& bp, int nx, int ny, int nz, unsigned nboxes, int scomp, int ncomp, int ng, const FilterW& W) {
   auto grid = [&](int TX, int TY, int TZ) { return dim3(((nx + TX - 1) / TX) * ((ny + TY - 1) / TY) * ((nz + TZ - 1) / TZ), nboxes); };
   // box weights (w0/2, w0, ..., w0, w0/2): the streaming kernel (PA_FILTER_STREAM=0 forces the tile kernel)
-  static const int stream_env = [] { const char* e = getenv("PA_FILTER_STREAM"); return e ? atoi(e) : 1; }();
+  const char* se = getenv("PA_FILTER_STREAM");  // read per launch: the full-size test runs both kernels
+  const int stream_env = se ? atoi(se) : 1;
   const int nw = 2 * ng + 1;
   bool box = stream_env && ng >= 1 && W.w[0] == 0.5 * W.w[1] && W.w[nw - 1] == W.w[0];
   for (int q = 2; q < nw - 1 && box; ++q) box = W.w[q] == W.w[1];

@@ -1,0 +1,211 @@
+"""(run as a child process by tests/test_gpu_fullsize.py -- torch has to initialise HIP before the library does)
+GPU parity at BASELINE.json's FULL size (3-level AMR, base 512^3, 128^3 boxes, 4.0e8 cells), where the CPU oracle
+would take minutes: size-independent properties of the path instead, every comparison bit for bit on the device.
+
+  1. two independent kernel sets agree: the fused sweep + face fix-up (the headline path) against the pass-by-pass
+     kernels (k_progress / k_normal / k_div / applyBC per pass; each parity-tested against the oracle at small sizes),
+     and its gradient components against the gradient tool's own kernel (k_grad_march);
+  2. exact homogeneity: phi -> 2 phi (a power of two: every operation of the path commutes with it exactly) doubles
+     the gradient and its magnitude bit for bit and leaves Progress' normalisation, hence N and K, unchanged;
+  3. determinism: a second run reproduces every output bit (no atomics / order dependence on the path);
+  4. |N| = 1 wherever the gradient is not floored, K finite (catches a wrong-but-consistent pipeline);
+  5. box filter on a 512^3 level (fgr = 4, 125 taps): the streaming kernel and the LDS-tile kernel (two independent
+     implementations of the reference tap order) agree bit for bit on random data, and a constant field is
+     reproduced exactly (the box weights are dyadic and sum to one without rounding);
+  6. marching cubes on a 512^3 level (64 FABs of 130^3): the level-batched pass reproduces the per-FAB entry points
+     bit for bit on FABs that hold surface, per-FAB counts add up, connectivity stays inside each FAB's vertex range.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch  # torch first: one HIP runtime in the process
+    import bench
+    from peleanalysis_amd import capi
+    from peleanalysis_amd.hierarchy import mf_layout, nested_hierarchy
+
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    ctx = capi.Context(0)
+    base, nlev, box = 512, 3, 128
+    H = nested_hierarchy(base, nlev, box, is_per=(1, 1, 0))
+    assert sum(lv.ncells for lv in H.levels) == 3 * 512 ** 3
+    bc = capi.bc_from_flags((1, 1, 0))
+    dls = [capi.DevLevel(ctx, lv) for lv in H.levels]
+    def mfs(ncomp, ng):
+        """(torch tensors, DevMF views of them) of one multifab per level; the tensors must outlive the views"""
+        ts, ms = [], []
+        for lv, dl in zip(H.levels, dls):
+            _, _, tot = mf_layout(lv.boxes, ncomp, ng)
+            t = torch.zeros(tot, dtype=torch.float64, device=dev)
+            ts.append(t)
+            ms.append(capi.DevMF(ctx, dl, ncomp, ng, t.data_ptr()))
+        return ts, ms
+
+    tins, states = mfs(1, 2)
+    for li, lv in enumerate(H.levels):
+        off, cs, _ = mf_layout(lv.boxes, 1, 2)
+        bench.fill_level_on_device(torch, lv, tins[li], 1, 2, off, cs, dev, 4321 + li)
+    pristine = [t.clone() for t in tins]
+    twork, works = mfs(1, 2)
+
+    def run(fused, thr, scale=1.0):
+        for t, p in zip(tins, pristine):
+            t.copy_(p * scale)
+        touts, outs = mfs(8, 0)
+        torch.cuda.synchronize()  # torch's stream -> the library's stream
+        capi.gradcurv_run(ctx, states, 0, bc, capi.curv_params(prog_min=300.0 * scale, prog_max=2000.0 * scale, threshold=thr, fused=fused), works, outs, 0)
+        ctx.sync()
+        assert ctx.bc_errors() == 0
+        return touts, outs
+
+    def same_bits(a, b):
+        return bool(torch.equal(a.view(torch.int64), b.view(torch.int64)))
+
+    keep = None
+    for thr in (None, 0.02):
+        fused, _f = run(True, thr)
+        again, _a = run(True, thr)
+        for l in range(nlev):
+            assert same_bits(fused[l], again[l]), f"level {l}: the fused path is not deterministic"
+        del again, _a
+        passes, _p = run(False, thr)
+        for l in range(nlev):
+            assert same_bits(fused[l], passes[l]), f"level {l} (threshold {thr}): fused sweep + face fix-up differs from the pass-by-pass kernels"
+        del passes, _p
+        if thr is None:
+            keep = fused
+        del fused, _f
+    # gradient tool's kernel against the fused sweep's gradient components
+    for t, p in zip(tins, pristine):
+        t.copy_(p)
+    tg, gouts = mfs(4, 0)
+    torch.cuda.synchronize()
+    capi.grad_run(ctx, states, 0, bc, gouts, 0)
+    ctx.sync()
+    for l, lv in enumerate(H.levels):
+        off8, cs8, _ = mf_layout(lv.boxes, 8, 0)
+        off4, cs4, _ = mf_layout(lv.boxes, 4, 0)
+        for b in (0, lv.nboxes // 2, lv.nboxes - 1):
+            n = int(np.prod(lv.box_shape(b, 0)))
+            for c in range(4):
+                assert same_bits(keep[l][off8[b] + c * cs8[b]: off8[b] + c * cs8[b] + n], tg[l][off4[b] + c * cs4[b]: off4[b] + c * cs4[b] + n]), (l, b, c)
+    # homogeneity: 2 phi
+    t2, _o2 = run(True, None, scale=2.0)
+    for l, lv in enumerate(H.levels):
+        off8, cs8, _ = mf_layout(lv.boxes, 8, 0)
+        for b in (0, lv.nboxes // 3, lv.nboxes - 1):
+            n = int(np.prod(lv.box_shape(b, 0)))
+            for c in range(8):
+                a = keep[l][off8[b] + c * cs8[b]: off8[b] + c * cs8[b] + n]
+                d = t2[l][off8[b] + c * cs8[b]: off8[b] + c * cs8[b] + n]
+                assert same_bits(a * 2.0 if c < 4 else a, d), f"level {l} box {b} comp {c}: not exactly homogeneous"
+    # analytic sanity on the finest level: |N| = 1 wherever the gradient is not floored; K finite
+    lv = H.levels[-1]
+    off8, cs8, _ = mf_layout(lv.boxes, 8, 0)
+    b = lv.nboxes // 2
+    n = int(np.prod(lv.box_shape(b, 0)))
+    N = [keep[-1][off8[b] + c * cs8[b]: off8[b] + c * cs8[b] + n] for c in (4, 5, 6)]
+    gm = keep[-1][off8[b] + 3 * cs8[b]: off8[b] + 3 * cs8[b] + n]
+    nn = torch.sqrt(N[0] ** 2 + N[1] ** 2 + N[2] ** 2)
+    sel = gm > 1e-6
+    assert bool(sel.any()) and float((nn[sel] - 1.0).abs().max()) < 1e-12
+    K = keep[-1][off8[b] + 7 * cs8[b]: off8[b] + 7 * cs8[b] + n]
+    assert bool(torch.isfinite(K).all())
+    del keep, t2, _o2, tg, gouts, pristine
+    torch.cuda.empty_cache()
+
+    # ---- 5. box filter, 512^3 level of 128^3 boxes, fgr = 4
+    import ctypes as C
+    from peleanalysis_amd.hierarchy import Level, chop_box
+    n = 512
+    lv = Level(chop_box((0, 0, 0), (n - 1,) * 3, 128), (0, 0, 0), (n - 1,) * 3, (1, 1, 1), (0, 0, 0), (1, 1, 1))
+    dl = capi.DevLevel(ctx, lv)
+    w = (C.c_double * 6)()
+    ng = ctx.lib.pa_box_filter_weights(4, w)
+    assert ng == 2
+
+    def one(ncomp, g, fill):
+        _, _, tot = mf_layout(lv.boxes, ncomp, g)
+        t = fill(tot)
+        return t, capi.DevMF(ctx, dl, ncomp, g, t.data_ptr())
+
+    tin, fin = one(1, ng, lambda tot: 300.0 + 1700.0 * torch.rand(tot, dtype=torch.float64, device=dev))
+    outs_f = []
+    for env in ("1", "0"):
+        os.environ["PA_FILTER_STREAM"] = env
+        to, fo = one(1, 0, lambda tot: torch.zeros(tot, dtype=torch.float64, device=dev))
+        torch.cuda.synchronize()
+        ctx.check(ctx.lib.pa_fill_boundary(ctx.h, fin.h, 0, 1, ng))
+        ctx.check(ctx.lib.pa_boxfilter_level(ctx.h, fin.h, fo.h, 0, 1, ng, w))
+        ctx.sync()
+        outs_f.append((to, fo))
+    os.environ.pop("PA_FILTER_STREAM")
+    assert same_bits(outs_f[0][0], outs_f[1][0]), "box filter: streaming kernel and tile kernel differ"
+    tin.fill_(1.0)
+    to, fo = outs_f[0]
+    torch.cuda.synchronize()
+    ctx.check(ctx.lib.pa_boxfilter_level(ctx.h, fin.h, fo.h, 0, 1, ng, w))
+    ctx.sync()
+    off1, cs1, _ = mf_layout(lv.boxes, 1, 0)
+    for b in range(lv.nboxes):
+        assert bool((to[off1[b]: off1[b] + 128 ** 3] == 1.0).all()), "box filter does not reproduce a constant exactly"
+    del outs_f, tin, fin, to, fo
+
+    # ---- 6. marching cubes, the same level: sphere of radius 0.3, 3 coordinate comps + 2 fields, one ghost layer
+    g = 130
+    off5, cs5, tot5 = mf_layout(lv.boxes, 5, 1)
+    t5 = torch.empty(tot5, dtype=torch.float64, device=dev)
+    for b in range(lv.nboxes):
+        lo = lv.boxes[b, :3] - 1
+        xs = [(torch.arange(int(lo[d]), int(lo[d]) + g, device=dev, dtype=torch.float64) + 0.5) / n for d in range(3)]
+        Xb, Yb, Zb = xs[0][None, None, :].expand(g, g, g), xs[1][None, :, None].expand(g, g, g), xs[2][:, None, None].expand(g, g, g)
+        rb = torch.sqrt((Xb - 0.5) ** 2 + (Yb - 0.5) ** 2 + (Zb - 0.5) ** 2)
+        for c, v in enumerate((Xb, Yb, Zb, 300.0 + 1700.0 * 0.5 * (1 + torch.tanh((rb - 0.3) / 0.05)), rb)):
+            t5[off5[b] + c * cs5[b]: off5[b] + c * cs5[b] + g ** 3] = v.reshape(-1)
+    st5 = capi.DevMF(ctx, dl, 5, 1, t5.data_ptr())
+    tmk, mk5 = one(1, 1, lambda tot: torch.zeros(tot, dtype=torch.float64, device=dev))
+    torch.cuda.synchronize()
+    ctx.check(ctx.lib.pa_iso_mask_level(ctx.h, mk5.h, 0, None, 2))
+    ctx.sync()
+    assert bool((tmk[: g ** 3] == 1.0).all())
+    loops = np.zeros((lv.nboxes, 6), np.int64)
+    for b in range(lv.nboxes):
+        loops[b, :3] = np.maximum(lv.boxes[b, :3] - 1, 0)
+        loops[b, 3:] = np.minimum(lv.boxes[b, 3:] + 1, n - 1) - 1
+    frags = capi.mc_level(ctx, st5, mk5, loops, 3, 1150.0)
+    ntot = sum(len(f[2]) for f in frags)
+    assert ntot > 800000, ntot  # 4 pi (0.3 * 512)^2 cells cut, about 2 triangles each, + the FAB overlaps
+    checked = 0
+    offm, csm, _ = mf_layout(lv.boxes, 1, 1)
+    for b, (v, k, t) in enumerate(frags):
+        if len(t):
+            assert t.min() >= 0 and t.max() < len(v), f"FAB {b}: connectivity leaves the FAB's vertex range"
+        if len(t) and checked < 3:
+            fs, fm, bx = capi.PaFab(), capi.PaFab(), capi.PaBox()
+            fs.p, fs.ncomp, fs.nstride = t5.data_ptr() + 8 * int(off5[b]), 5, int(cs5[b])
+            fm.p, fm.ncomp, fm.nstride = tmk.data_ptr() + 8 * int(offm[b]), 1, int(csm[b])
+            for d in range(3):
+                fs.lo[d] = fm.lo[d] = int(lv.boxes[b, d]) - 1
+                fs.hi[d] = fm.hi[d] = int(lv.boxes[b, 3 + d]) + 1
+                bx.lo[d], bx.hi[d] = int(loops[b, d]), int(loops[b, 3 + d])
+            nv, nt = C.c_int64(0), C.c_int64(0)
+            ctx.check(ctx.lib.pa_mc_count_fab(ctx.h, bx, fs, fm, 3, 1150.0, C.byref(nv), C.byref(nt)))
+            assert (nv.value, nt.value) == (len(v), len(t)), f"FAB {b}: counts differ from the per-FAB entry point"
+            dv, dk, dt = capi.DevBuf(ctx, nv.value * 40), capi.DevBuf(ctx, nv.value * 24), capi.DevBuf(ctx, nt.value * 12)
+            ctx.check(ctx.lib.pa_mc_emit_fab(ctx.h, bx, fs, fm, 3, 1150.0, dv.ptr, dk.ptr, dt.ptr, nv.value, nt.value))
+            assert np.array_equal(dv.to_numpy(np.float64, (nv.value, 5)).view(np.int64), np.ascontiguousarray(v).view(np.int64))
+            assert np.array_equal(dk.to_numpy(np.int32, (nv.value, 6)), k) and np.array_equal(dt.to_numpy(np.int32, (nt.value, 3)), t)
+            checked += 1
+    assert checked == 3
+    print("fullsize properties OK")
+
+
+if __name__ == "__main__":
+    main()
