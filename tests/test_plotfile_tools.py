@@ -81,6 +81,37 @@ def test_cpp_mef_to_dat_tool(tmp_path):
     assert [[int(t) for t in ln.split()] for ln in txt[9:12]] == faces.tolist()
 
 
+def _write_mef(path, nodes, faces1, names=b"X Y Z"):
+    with open(path, "wb") as fh:  # isosurface.cpp:2097-2134
+        fh.write(b"0.5\n" + names + b"\n%d 3\n" % len(faces1))
+        fh.write(b"FAB ((8, (64 11 52 0 1 12 0 1023)),(8, (8 7 6 5 4 3 2 1)))((0,0,0) (%d,0,0) (0,0,0)) %d\n" % (len(nodes) - 1, nodes.shape[1]))
+        fh.write(np.ascontiguousarray(nodes, "<f8").tobytes())
+        fh.write(np.ascontiguousarray(faces1, "<i4").tobytes())
+
+
+def test_cpp_check_iso_tool(tmp_path):
+    """checkIso3d.ex (host only; checkIso.cpp:127-149): a consistently oriented tetrahedron passes; with one face
+    flipped the reference's assertion still cannot fire (direction-blind comparator: quirk kept), strict=1 reports it"""
+    _build_tools()
+    nodes = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]], float)
+    good = np.array([[1, 3, 2], [1, 2, 4], [2, 3, 4], [3, 1, 4]], np.int32)  # outward normals
+    f = str(tmp_path / "tet.mef")
+    _write_mef(f, nodes, good)
+    for extra in ([], ["strict=1"]):
+        out = subprocess.run([os.path.join(BIN, "checkIso3d.ex"), "isoFile=" + f] + extra, cwd=tmp_path, capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr
+        assert "Found 6 edges (nElts * 3 = 12)" in out.stdout and "All shared edges are consistently numbered." in out.stdout
+    bad = good.copy()
+    bad[2] = bad[2][::-1]
+    _write_mef(f, nodes, bad)
+    out = subprocess.run([os.path.join(BIN, "checkIso3d.ex"), "isoFile=" + f], cwd=tmp_path, capture_output=True, text=True)
+    assert out.returncode == 0 and "Found 6 edges" in out.stdout
+    out = subprocess.run([os.path.join(BIN, "checkIso3d.ex"), "isoFile=" + f, "strict=1"], cwd=tmp_path, capture_output=True, text=True)
+    assert out.returncode == 2 and "traversed twice in the same direction" in out.stderr
+    out = subprocess.run([os.path.join(BIN, "checkIso3d.ex")], cwd=tmp_path, capture_output=True, text=True)
+    assert out.returncode != 0 and "isoFile" in out.stderr
+
+
 # ------------------------------------------------------------------------------------ GPU tier
 @pytest.mark.gpu
 def test_grad_tool_end_to_end(tmp_path, oracle):
@@ -186,6 +217,12 @@ def test_isosurface_tool_end_to_end(tmp_path, oracle):
     assert len(oelts) > 200
     assert np.array_equal(faces, oelts + 1), "connectivity (1-based) differs"
     assert np.array_equal(nodes.view(np.int64), onodes.view(np.int64)), "node data not bit-identical"
+    # single-level surface: closed and consistently oriented (the invariant checkIso.cpp is after, checked for real)
+    (tmp_path / "one").mkdir()
+    p1, H1, _ = _synth(tmp_path / "one", nlev=1, base=32, box=16, per=(0, 0, 0))
+    _run("isosurface3d.ex", ["infile=" + p1, "isoCompName=temp", "isoVal=1150", "comps=0"], tmp_path)
+    out = _run("checkIso3d.ex", ["isoFile=" + p1 + "_temp_1150.mef", "strict=1"], tmp_path)
+    assert "All shared edges are consistently numbered." in out.stdout
 
 
 @pytest.mark.gpu

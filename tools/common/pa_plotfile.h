@@ -314,6 +314,43 @@ inline void write_mef(const std::string& file, double time, const std::vector<st
   f.write((const char*)e1.data(), sizeof(int32_t) * e1.size());
 }
 
+// reader of the same file, as the MEF consumers parse it (surfMEFtoDAT.cpp:46-72, checkIso.cpp:84-120)
+struct MefSurface {
+  std::string title;
+  std::vector<std::string> names;
+  long long nElts = 0, nodesPerElt = 0, nNodes = 0;
+  std::vector<double> nodes;   // [nNodes][names.size()], node-major as stored
+  std::vector<int32_t> conn;   // [nElts][nodesPerElt], 1-based as stored
+};
+inline MefSurface read_mef(const std::string& file) {
+  MefSurface S;
+  std::ifstream is(file, std::ios::in | std::ios::binary);
+  if (!is) Abort("Unable to open file : " + file);
+  std::string line;
+  std::getline(is, S.title);  // parseTitle
+  std::getline(is, line);     // parseVarNames: tokens separated by ", "
+  {
+    std::string t;
+    for (char ch : line) {
+      if (ch == ' ' || ch == ',') { if (!t.empty()) S.names.push_back(t); t.clear(); }
+      else t.push_back(ch);
+    }
+    if (!t.empty()) S.names.push_back(t);
+  }
+  is >> S.nElts >> S.nodesPerElt;
+  std::getline(is, line);
+  std::getline(is, line);  // FAB header: "... ((0,0,0) (N-1,0,0) (0,0,0)) ncomp"
+  const size_t p0 = line.rfind("((0,0,0) (");
+  if (p0 == std::string::npos || S.nElts < 0 || S.nodesPerElt < 0) Abort("cannot parse the node FAB header of " + file);
+  S.nNodes = std::atoll(line.c_str() + p0 + 10) + 1;
+  S.nodes.resize((size_t)S.nNodes * S.names.size());
+  is.read((char*)S.nodes.data(), sizeof(double) * S.nodes.size());
+  S.conn.assign((size_t)S.nElts * S.nodesPerElt, 0);
+  is.read((char*)S.conn.data(), sizeof(int32_t) * S.conn.size());
+  if (!is) Abort("truncated MEF file " + file);
+  return S;
+}
+
 // XDMF surface (isosurface.cpp:2135-2229): <base>.xmf (XML, precision 8) + <base>.mesh = raw int32 0-based
 // connectivity, then xyz per node, then each mapped component as one array of doubles
 inline void write_xdmf(const std::string& base, double time, const std::string& isoCompName, double isoVal, const std::vector<std::string>& varnames,
