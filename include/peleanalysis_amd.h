@@ -198,6 +198,9 @@ int pa_mc_emit_fab(pa_ctx*, pa_box loop, const pa_fab* state, const pa_fab* mask
  * parts of ONE device allocation made by the library whose base is *dev_verts (all NULL when the level has no
  * surface): release it with pa_device_free(*dev_verts) only.  Synchronous. */
 int pa_iso_mask_level(pa_ctx*, pa_mf* mask, int comp, const pa_level* fine, int ratio);
+/* isosurface.cpp:1458-1465: comps comp0..comp0+2 of every cell of every grown FAB = its cell-centre coordinates,
+ * (index + 0.5) * dx + prob_lo in that operation order (what FillBoundary / FillPatch then overwrite in ghost cells) */
+int pa_iso_coords_level(pa_ctx*, pa_mf* state, int comp0);
 int pa_mc_level(pa_ctx*, const pa_mf* state, const pa_mf* mask, int mcomp, const pa_box* loops /* host [nboxes] */,
                 int isocomp, double isoval, int64_t* nvert /* host [nboxes] */, int64_t* ntri /* host [nboxes] */,
                 double** dev_verts /* [sum nvert][ncomp] */, int32_t** dev_vkeys /* [sum nvert][6] */,

@@ -107,6 +107,7 @@ def load_library() -> C.CDLL:
         "pa_mc_count_fab": (C.c_int, [vp, PaBox, C.POINTER(PaFab), C.POINTER(PaFab), C.c_int, dbl, C.POINTER(i64), C.POINTER(i64)]),
         "pa_mc_emit_fab": (C.c_int, [vp, PaBox, C.POINTER(PaFab), C.POINTER(PaFab), C.c_int, dbl, vp, vp, vp, i64, i64]),
         "pa_iso_mask_level": (C.c_int, [vp, vp, C.c_int, vp, C.c_int]),
+        "pa_iso_coords_level": (C.c_int, [vp, vp, C.c_int]),
         "pa_mc_level": (C.c_int, [vp, vp, vp, C.c_int, C.POINTER(PaBox), C.c_int, dbl, C.POINTER(i64), C.POINTER(i64), C.POINTER(vp), C.POINTER(vp),
                                   C.POINTER(vp)]),
         "pa_mc_edge_table": (C.POINTER(C.c_uint16), []),

@@ -675,6 +675,36 @@ __global__ __launch_bounds__(256) void k_iso_mask(DLevelView L, DMFView M, int c
   M.data[M.off[b] + (long long)comp * pa_cstride((long long)nx * ny * nz, M.ncomp) + lin] = v;
 }
 
+// cell-centre coordinates of every cell of every grown FAB (isosurface.cpp:1458-1465): (i + 0.5) * dx + plo
+struct IsoGeom { double dx[3], plo[3]; };
+__global__ __launch_bounds__(256) void k_iso_coords(DLevelView L, DMFView M, int comp0, IsoGeom Q) {
+  const int b = blockIdx.y;
+  const DBox B = L.boxes[b];
+  const unsigned nx = B.hi[0] - B.lo[0] + 1 + 2 * M.ng, ny = B.hi[1] - B.lo[1] + 1 + 2 * M.ng, nz = B.hi[2] - B.lo[2] + 1 + 2 * M.ng;
+  const unsigned lin = blockIdx.x * 256u + threadIdx.x;
+  if (lin >= nx * ny * nz) return;
+  const unsigned r = lin / nx, kk = r / ny;
+  const int p[3] = {B.lo[0] - M.ng + (int)(lin - r * nx), B.lo[1] - M.ng + (int)(r - kk * ny), B.lo[2] - M.ng + (int)kk};
+  const long long cs = pa_cstride((long long)nx * ny * nz, M.ncomp);
+  double* o = M.data + M.off[b] + (long long)comp0 * cs + lin;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) o[d * cs] = (p[d] + 0.5) * Q.dx[d] + Q.plo[d];
+}
+
+extern "C" int pa_iso_coords_level(pa_ctx* ctx, pa_mf* state, int comp0) {
+  if (!ctx || !state) return pa_fail(ctx, "pa_iso_coords_level: null argument");
+  if (comp0 < 0 || comp0 + 3 > state->ncomp) return pa_fail(ctx, "pa_iso_coords_level: component range");
+  const pa_level* L = state->lev;
+  const long long nmax = (long long)(L->maxn[0] + 2 * state->ng) * (L->maxn[1] + 2 * state->ng) * (L->maxn[2] + 2 * state->ng);
+  if (nmax >= (1LL << 31)) return pa_fail(ctx, "pa_iso_coords_level: FAB too large");
+  if (L->boxes.empty()) return 0;
+  IsoGeom Q;
+  for (int d = 0; d < 3; ++d) { Q.dx[d] = L->dx[d]; Q.plo[d] = L->prob_lo[d]; }
+  hipLaunchKernelGGL(k_iso_coords, dim3((unsigned)((nmax + 255) / 256), (unsigned)L->boxes.size()), dim3(256), 0, ctx->stream, L->view, state->view, comp0, Q);
+  PA_HIP(hipGetLastError());
+  return 0;
+}
+
 extern "C" int pa_iso_mask_level(pa_ctx* ctx, pa_mf* mask, int comp, const pa_level* fine, int ratio) {
   if (!ctx || !mask) return pa_fail(ctx, "pa_iso_mask_level: null argument");
   if (comp < 0 || comp >= mask->ncomp) return pa_fail(ctx, "pa_iso_mask_level: component range");

@@ -173,6 +173,17 @@ def test_marching_cubes_level_batched_matches_oracle(ctx, oracle, name, ng):
     ntri_total = 0
     for l, lv in enumerate(H.levels):
         dst = capi.DevMF.from_host(ctx, dls[l], states[l])
+        dco = capi.DevMF(ctx, dls[l], 4, ng)  # pa_iso_coords_level: the analytic coordinates of every grown FAB, bit for bit
+        ctx.check(ctx.lib.pa_iso_coords_level(ctx.h, dco.h, 1))
+        ctx.sync()
+        gco = dco.download()
+        for b in range(lv.nboxes):
+            lo = lv.boxes[b, :3] - ng
+            nz, ny, nx = gco.fab(b).shape[1:]
+            for d, (n_, sh) in enumerate(((nx, (1, 1, -1)), (ny, (1, -1, 1)), (nz, (-1, 1, 1)))):
+                want = np.broadcast_to(((np.arange(lo[d], lo[d] + n_) + 0.5) * lv.dx[d] + lv.prob_lo[d]).reshape(sh), (nz, ny, nx))
+                assert np.array_equal(gco.fab(b)[1 + d].view(np.int64), np.ascontiguousarray(want).view(np.int64)), (l, b, d)
+        assert ctx.lib.pa_iso_coords_level(ctx.h, dco.h, 2) != 0  # 3 components do not fit behind comp 2
         dmask = capi.DevMF(ctx, dls[l], 1, ng)
         fine = dls[l + 1].h if l + 1 < H.nlev else None
         ctx.check(ctx.lib.pa_iso_mask_level(ctx.h, dmask.h, 0, fine, 2))

@@ -15,6 +15,7 @@
 // cells they image (isosurface.cpp:1469 "bad data in periodic directions"; the shift back at :1483-1507 never fires).
 #include "../common/pa_device.h"
 #include "../common/pa_isomerge.h"
+#include <chrono>
 
 int main(int argc, char** argv) {
   pa::ParmParse pp(argc, argv);
@@ -76,31 +77,39 @@ int main(int argc, char** argv) {
   std::vector<int> is_per(3, 0);
   pp.queryarr("is_per", is_per, 0, 3);
 
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double strt_time_surf = now();
+  double io_time = 0.0;  // plotfile reads (isosurface.cpp:1388-1415); everything else up to the merge is "Compute Surface"
   pa::Ctx ctx;
   std::vector<std::unique_ptr<pa::DevLevel>> dl;
   std::vector<std::unique_ptr<pa::DevMF>> dst;
   std::vector<pa::HostMF> host(Nlev);
+  std::vector<std::vector<int64_t>> soff(Nlev), scs(Nlev);
   for (int lev = 0; lev < Nlev; ++lev) {
     const auto& L = H.lev[lev];
     const int ng = nGrow[lev];
-    host[lev].define(L.boxes, nc, ng);
-    std::fill(host[lev].data.begin(), host[lev].data.end(), -666.0);  // gstate.setVal(-666) (isosurface.cpp:1512)
-    double dx[3];
-    for (int d = 0; d < 3; ++d) dx[d] = (H.prob_hi[d] - H.prob_lo[d]) / (double)(L.domain.hi[d] - L.domain.lo[d] + 1);
-    for (size_t b = 0; b < L.boxes.size(); ++b) {  // cell-centre coordinates incl. ghosts (isosurface.cpp:1458-1465)
-      const pa::Box3& B = L.boxes[b];
-      for (int k = B.lo[2] - ng; k <= B.hi[2] + ng; ++k)
-        for (int j = B.lo[1] - ng; j <= B.hi[1] + ng; ++j)
-          for (int i = B.lo[0] - ng; i <= B.hi[0] + ng; ++i) {
-            *host[lev].ptr((int)b, 0, i, j, k) = (i + 0.5) * dx[0] + H.prob_lo[0];
-            *host[lev].ptr((int)b, 1, i, j, k) = (j + 0.5) * dx[1] + H.prob_lo[1];
-            *host[lev].ptr((int)b, 2, i, j, k) = (k + 0.5) * dx[2] + H.prob_lo[2];
-          }
-    }
-    for (int n = 0; n < nComp; ++n) pa::read_comp(H, lev, pltComps[n], host[lev], 3 + n);
+    // host side: the mapped plotfile components only (ghost cells -666: gstate.setVal(-666), isosurface.cpp:1512);
+    // the three coordinate components are written on the device (isosurface.cpp:1458-1465)
+    host[lev].define(L.boxes, nComp, ng);
+    std::fill(host[lev].data.begin(), host[lev].data.end(), -666.0);
+    const double t_io = now();
+    for (int n = 0; n < nComp; ++n) pa::read_comp(H, lev, pltComps[n], host[lev], n);
+    io_time += now() - t_io;
     dl.emplace_back(new pa::DevLevel(ctx, L.boxes, L.domain, is_per.data(), H.prob_lo, H.prob_hi));
     dst.emplace_back(new pa::DevMF(ctx, *dl.back(), nc, ng));
-    ctx.check(pa_mf_upload(ctx.h, dst.back()->h, host[lev].data.data()));
+    {
+      pa::DevMF dfield(ctx, *dl.back(), nComp, ng);
+      ctx.check(pa_mf_upload(ctx.h, dfield.h, host[lev].data.data()));
+      ctx.check(pa_iso_coords_level(ctx.h, dst.back()->h, 0));
+      ctx.check(pa_mf_copy(ctx.h, dfield.h, 0, dst.back()->h, 3, nComp, ng));
+      ctx.check(pa_sync(ctx.h));
+    }
+    {  // offsets of the nc-component device multifab
+      const std::vector<int32_t> b6 = host[lev].boxes6();
+      soff[lev].resize(L.boxes.size());
+      scs[lev].resize(L.boxes.size());
+      pa_mf_layout((int)L.boxes.size(), b6.data(), nc, ng, soff[lev].data(), scs[lev].data());
+    }
     std::cout << "FillPatching the grown structures at level " << lev << "..." << std::endl;
     ctx.check(pa_fill_boundary(ctx.h, dst[lev]->h, 0, nc, ng));
     if (lev > 0) ctx.check(pa_fillpatch_two_levels(ctx.h, dst[lev]->h, dst[lev - 1]->h, 0, nc, ng, 2, 0));  // PCInterp
@@ -233,7 +242,7 @@ int main(int argc, char** argv) {
         const pa::Box3& B = L.boxes[b];
         pa_box vb;
         pa_fab fs, fd;
-        fs.p = base + host[lev].off[b]; fs.ncomp = nc; fs.nstride = host[lev].cs[b];
+        fs.p = base + soff[lev][b]; fs.ncomp = nc; fs.nstride = scs[lev][b];
         fd.p = dbase + hdist[lev].off[b]; fd.ncomp = 1; fd.nstride = hdist[lev].cs[b];
         for (int d = 0; d < 3; ++d) { vb.lo[d] = fs.lo[d] = fd.lo[d] = B.lo[d] - ng; vb.hi[d] = fs.hi[d] = fd.hi[d] = B.hi[d] + ng; }
         ctx.check(pa_sdf_signed_fab(ctx.h, vb, grids[q].phi, &fs, 3 + isoComp, isoVal, dmax, &fd, 0));
@@ -243,7 +252,7 @@ int main(int argc, char** argv) {
       for (size_t b = 0; b < L.boxes.size(); ++b) {  // FABs without triangles: +-dmax from the first valid cell (isosurface.cpp:1651-1654)
         if (has_elts[b]) continue;
         const pa::Box3& B = L.boxes[b];
-        const double v = *host[lev].ptr((int)b, 3 + isoComp, B.lo[0], B.lo[1], B.lo[2]) < isoVal ? -dmax : dmax;
+        const double v = *host[lev].ptr((int)b, isoComp, B.lo[0], B.lo[1], B.lo[2]) < isoVal ? -dmax : dmax;
         for (int k = B.lo[2] - ng; k <= B.hi[2] + ng; ++k)
           for (int j = B.lo[1] - ng; j <= B.hi[1] + ng; ++j)
             for (int i = B.lo[0] - ng; i <= B.hi[0] + ng; ++i) *hdist[lev].ptr((int)b, 0, i, j, k) = v;
@@ -258,8 +267,16 @@ int main(int argc, char** argv) {
     for (int lev = 0; lev < Nlev; ++lev) { doms.push_back(H.lev[lev].domain); steps.push_back(H.lev[lev].level_step); }
     pa::write_plotfile(outfile, {"distance"}, doms, H.prob_lo, H.prob_hi, hdist, H.time, steps);
   }
+  {  // isosurface.cpp:1756-1771 (one rank: max = min)
+    const double surf_time = now() - strt_time_surf - io_time;
+    std::cout << "Max Compute Surface time: " << surf_time << '\n' << "Min Compute Surface time: " << surf_time << '\n';
+    std::cout << "Max I/O time: " << io_time << '\n' << "Min I/O time: " << io_time << '\n';
+  }
+  const double strt_time_uniq = now();
   merger.finish();
   const std::vector<int32_t> elts = merger.elements();
+  std::cout << "Uniquify time: " << now() - strt_time_uniq << '\n';  // :1888-1890
+  const double strt_time_sout = now();
   int writeSurf = 1, computeArea = 0;
   pp.query("writeSurf", writeSurf);
   pp.query("computeArea", computeArea);
@@ -298,5 +315,6 @@ int main(int argc, char** argv) {
     pa::write_mef(outfile_base + ".mef", H.time, vars, merger.nodes(), elts);
     std::cout << "            ...done" << std::endl;
   }
+  std::cout << "Surface output time: " << now() - strt_time_sout << '\n';  // :2232-2234
   return 0;
 }
