@@ -205,6 +205,15 @@ int pa_mc_level(pa_ctx*, const pa_mf* state, const pa_mf* mask, int mcomp, const
                 int isocomp, double isoval, int64_t* nvert /* host [nboxes] */, int64_t* ntri /* host [nboxes] */,
                 double** dev_verts /* [sum nvert][ncomp] */, int32_t** dev_vkeys /* [sum nvert][6] */,
                 int32_t** dev_tris /* [sum ntri][3] */);
+/* AMREX_SPACEDIM == 2 builds of the reference (Segmentise, isosurface.cpp:303-406; the loop :1574-1582): a 2-D level
+ * is stored as ONE plane of cells, k = 0 (boxes lo[2] = hi[2] = 0; ghost planes in z are ignored); state = 2
+ * coordinate components + fields; loops[b] = square base points, lo[2] = hi[2] = 0.  Vertices in vertCache order
+ * ((j, i) of the edge's lower endpoint, x before y), segments in traversal order, as rows of THREE int32
+ * (id0, id1, -1) with FAB-local vertex ids; everything else as pa_mc_level (one allocation, base *dev_verts). */
+int pa_msq_level(pa_ctx*, const pa_mf* state, const pa_mf* mask, int mcomp, const pa_box* loops /* host [nboxes] */,
+                 int isocomp, double isoval, int64_t* nvert /* host [nboxes] */, int64_t* nseg /* host [nboxes] */,
+                 double** dev_verts /* [sum nvert][ncomp] */, int32_t** dev_vkeys /* [sum nvert][6] */,
+                 int32_t** dev_segs /* [sum nseg][3] */);
 const uint16_t* pa_mc_edge_table(void); /* [256] host */
 const int8_t*   pa_mc_tri_table(void);  /* [256][16] host */
 

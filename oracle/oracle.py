@@ -542,3 +542,122 @@ def isosurface_pipeline(levels, fields, comps, isocomp_index, isoval, MF, ngrow=
         dists.append(dist)
     nodes, elts = iso_merge(frags, nc)
     return (nodes, elts, dists) if build_distance else (nodes, elts)
+
+
+# --------------------------------------------------------------------------------- 2-D isosurface (AMREX_SPACEDIM == 2)
+# Pure-Python restatement (small cases only) of Segmentise (isosurface.cpp:303-406), VertexInterp / VI_doIt (:257-301),
+# the per-FAB loop (:1574-1582), the node / element sets (:1687-1716, Element :886-927) and MakeCLines (:1159-1265).
+# PARITY UNPINNED: no 2-D golden data exists in the reference tree.
+_SEG_CASES = {1: (0, 3), 14: (0, 3), 2: (0, 1), 13: (0, 1), 3: (1, 3), 12: (1, 3), 4: (1, 2), 11: (1, 2), 6: (0, 2), 9: (0, 2), 7: (2, 3), 8: (2, 3),
+              5: (0, 1, 2, 3), 10: (0, 1, 2, 3)}
+
+
+def msq_fab(state, mask, lo, hi, isocomp, isoval, llo, lhi, eps=1.0e-15):
+    """state [nc][ny][nx] over the 2-D box lo..hi (2 coordinate comps + fields), mask [ny][nx], loop box llo..lhi of
+    square base points.  Returns (verts [nv][nc] in vertCache order, vkeys [nv][4] = (i, j, i2, j2) of the edge's
+    sorted endpoints, segs [ns][2] local vertex ids in traversal order)."""
+    def val(p):
+        return state[:, p[1] - lo[1], p[0] - lo[0]]
+
+    cache = {}  # sorted edge -> point, in first-call orientation
+
+    def vertex(pa, pb):  # VertexInterp(isoVal, isoComp, pa, pa_d, pb, pb_d, vertCache)
+        key = (pa, pb) if (pa[1], pa[0]) < (pb[1], pb[0]) else (pb, pa)  # IntVect operator<: last dimension most significant
+        if key not in cache:
+            a, b = val(pa), val(pb)
+            v1, v2 = a[isocomp], b[isocomp]
+            if abs(isoval - v1) < eps:
+                pt = a.copy()
+            elif abs(isoval - v2) < eps:
+                pt = b.copy()
+            elif abs(v1 - v2) < eps:
+                pt = a.copy()
+            else:
+                mu = (isoval - v1) / (v2 - v1)
+                pt = a + mu * (b - a)
+            cache[key] = pt
+        return key
+
+    segs = []
+    for j in range(llo[1], lhi[1] + 1):
+        for i in range(llo[0], lhi[0] + 1):
+            p = [(i, j), (i + 1, j), (i + 1, j + 1), (i, j + 1)]
+            if any(mask[q[1] - lo[1], q[0] - lo[0]] < 0 for q in p):
+                continue
+            case = sum((1 << m) for m in range(4) if val(p[m])[isocomp] < isoval)
+            if case in (0, 15):
+                continue
+            edges = [(p[0], p[1]), (p[1], p[2]), (p[2], p[3]), (p[3], p[0])]
+            ks = [vertex(*edges[e]) for e in _SEG_CASES[case]]
+            segs.append((ks[0], ks[1]))
+            if len(ks) == 4:
+                segs.append((ks[2], ks[3]))
+    order = sorted(cache, key=lambda e: ((e[0][1], e[0][0]), (e[1][1], e[1][0])))  # Edge::operator<
+    vid = {e: n for n, e in enumerate(order)}
+    nc = state.shape[0]
+    verts = np.array([cache[e] for e in order]).reshape(-1, nc)
+    vkeys = np.array([[e[0][0], e[0][1], e[1][0], e[1][1]] for e in order], dtype=np.int32).reshape(-1, 4)
+    return verts, vkeys, np.array([[vid[a], vid[b]] for a, b in segs], dtype=np.int32).reshape(-1, 2)
+
+
+def iso2d_merge(frags, nc, eps=1.0e-15):
+    """global node / element sets for segments: nodes unique by (x, y) position within eps (first copy kept, id =
+    insertion order); Element(v): the smaller id first (std::rotate on two entries), v0 == v1 dropped, std::set order"""
+    nodes, elts = [], set()
+    for verts, segs in frags:
+        ids = []
+        for v in verts:
+            hit = -1
+            for n, q in enumerate(nodes):  # small cases only
+                if np.sqrt((q[0] - v[0]) ** 2 + (q[1] - v[1]) ** 2) < eps:
+                    hit = n
+                    break
+            if hit < 0:
+                hit = len(nodes)
+                nodes.append(np.array(v))
+            ids.append(hit)
+        for a, b in segs:
+            a, b = ids[a], ids[b]
+            if a != b:
+                elts.add((min(a, b), max(a, b)))
+    return np.array(nodes).reshape(-1, nc), np.array(sorted(elts), dtype=np.int32).reshape(-1, 2)
+
+
+def make_clines(elts0):
+    """MakeCLines (isosurface.cpp:1159-1265) on 0-based segments: list of polylines, each a list of (l, r) segments"""
+    segs = [list(e) for e in elts0]
+    if not segs:
+        return []
+    idx = segs[0][1]
+    segs.pop(0)  # quirk kept: the first segment is consumed as a seed and never stored in a line
+    lines = [[]]
+    while segs:
+        hit = next((n for n, s in enumerate(segs) if s[0] == idx or s[1] == idx), None)
+        if hit is not None:
+            l, r = segs.pop(hit)
+            if l == idx:
+                idx = r
+                lines[-1].append((l, r))
+            else:
+                idx = l
+                lines[-1].append((r, l))
+        else:
+            lines.append([])
+            idx = segs[0][1]
+            segs.pop(0)
+    changed = True
+    while changed:
+        changed = False
+        for a in range(len(lines)):
+            if not lines[a]:
+                continue
+            idx_l, idx_r = lines[a][0][0], lines[a][-1][1]  # read once per outer line, before the inner loop (:1217-1218)
+            for b in range(len(lines)):
+                if lines[b] and lines[a] and lines[a][0] != lines[b][0]:
+                    if idx_r == lines[b][0][0]:
+                        lines[a] += lines[b]; lines[b] = []; changed = True
+                    elif idx_r == lines[b][-1][1]:
+                        lines[a] += [(r, l) for l, r in reversed(lines[b])]; lines[b] = []; changed = True
+                    elif idx_l == lines[b][0][0]:
+                        lines[a] = [(r, l) for l, r in reversed(lines[b])] + lines[a]; lines[b] = []; changed = True
+    return [ln for ln in lines if ln]

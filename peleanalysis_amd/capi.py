@@ -108,6 +108,8 @@ def load_library() -> C.CDLL:
         "pa_mc_emit_fab": (C.c_int, [vp, PaBox, C.POINTER(PaFab), C.POINTER(PaFab), C.c_int, dbl, vp, vp, vp, i64, i64]),
         "pa_iso_mask_level": (C.c_int, [vp, vp, C.c_int, vp, C.c_int]),
         "pa_iso_coords_level": (C.c_int, [vp, vp, C.c_int]),
+        "pa_msq_level": (C.c_int, [vp, vp, vp, C.c_int, C.POINTER(PaBox), C.c_int, dbl, C.POINTER(i64), C.POINTER(i64), C.POINTER(vp), C.POINTER(vp),
+                                   C.POINTER(vp)]),
         "pa_mc_level": (C.c_int, [vp, vp, vp, C.c_int, C.POINTER(PaBox), C.c_int, dbl, C.POINTER(i64), C.POINTER(i64), C.POINTER(vp), C.POINTER(vp),
                                   C.POINTER(vp)]),
         "pa_mc_edge_table": (C.POINTER(C.c_uint16), []),
@@ -372,8 +374,9 @@ def stream_trace(ctx, vfield, vcomp, seeds, nsteps, dt):
     return buf.to_numpy(np.float64, (2 * n, nsteps, 3)), nred.value
 
 
-def mc_level(ctx: Context, state: "DevMF", mask: "DevMF", loops, isocomp: int, isoval: float, mcomp: int = 0):
-    """Level-batched marching cubes (pa_mc_level).  loops: (nboxes, 6) cube base-point boxes (lo > hi: skipped).
+def mc_level(ctx: Context, state: "DevMF", mask: "DevMF", loops, isocomp: int, isoval: float, mcomp: int = 0, squares: bool = False):
+    """Level-batched marching cubes (pa_mc_level) or, with squares=True, marching squares on the plane k = 0
+    (pa_msq_level; segments come back as rows (id0, id1, -1)).  loops: (nboxes, 6) base-point boxes (lo > hi: skipped).
     Returns per-box lists [(verts [nv][ncomp], vkeys [nv][6], tris [nt][3] FAB-local ids)]."""
     loops = np.asarray(loops, dtype=np.int64).reshape(-1, 6)
     nb = len(loops)
@@ -383,7 +386,8 @@ def mc_level(ctx: Context, state: "DevMF", mask: "DevMF", loops, isocomp: int, i
             arr[b].lo[d], arr[b].hi[d] = int(loops[b, d]), int(loops[b, 3 + d])
     nv, nt = (C.c_int64 * max(nb, 1))(), (C.c_int64 * max(nb, 1))()
     pv, pk, pt = C.c_void_p(), C.c_void_p(), C.c_void_p()
-    ctx.check(ctx.lib.pa_mc_level(ctx.h, state.h, mask.h, mcomp, arr, isocomp, isoval, nv, nt, C.byref(pv), C.byref(pk), C.byref(pt)))
+    fn = ctx.lib.pa_msq_level if squares else ctx.lib.pa_mc_level
+    ctx.check(fn(ctx.h, state.h, mask.h, mcomp, arr, isocomp, isoval, nv, nt, C.byref(pv), C.byref(pk), C.byref(pt)))
     nc = state.ncomp
     tv, tt = int(sum(nv[:nb])), int(sum(nt[:nb]))
     try:

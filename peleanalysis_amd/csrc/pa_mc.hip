@@ -378,6 +378,7 @@ struct MclArgs {
   DLevelView L;
   DMFView S, M;
   int mcomp, isocomp, ncomp, kseg;
+  int dim2;                // marching squares on the plane k = loops[b].lo[2] (isosurface.cpp:303-406), see below
   double iso;
   const DBox* loops;       // [nboxes] cube base points, lo > hi: FAB skipped
   const long long* coff;   // [nboxes + 1] first scratch cell of a FAB (multiples of 256)
@@ -410,6 +411,36 @@ __device__ __forceinline__ void mcl_cell(const MclGeo& G, unsigned lin, int& i, 
   i = (int)(lin - r * (unsigned)G.n[0]) + G.slo[0];
   j = (int)(r - kk * (unsigned)G.n[1]) + G.slo[1];
   k = (int)kk + G.slo[2];
+}
+
+// ---- 2-D (AMREX_SPACEDIM == 2 builds of the reference: Segmentise, isosurface.cpp:303-406) in the same pipeline.
+// A 2-D level is stored as one plane of cells (k = 0); the "cube" of a cell is its square p0 = (i,j), p1 = (i+1,j),
+// p2 = (i+1,j+1), p3 = (i,j+1), whose case index is the low nibble of the cube index; square edges e0 = p0p1,
+// e1 = p1p2, e2 = p2p3, e3 = p3p0; the segments of a case in Segmentise's order (:352-406):
+__device__ __constant__ signed char d_seg[16][4] = {{-1, -1, -1, -1}, {0, 3, -1, -1}, {0, 1, -1, -1}, {1, 3, -1, -1}, {1, 2, -1, -1}, {0, 1, 2, 3},
+                                                    {0, 2, -1, -1},   {2, 3, -1, -1}, {2, 3, -1, -1}, {0, 2, -1, -1}, {0, 1, 2, 3},   {1, 2, -1, -1},
+                                                    {1, 3, -1, -1},   {0, 1, -1, -1}, {0, 3, -1, -1}, {-1, -1, -1, -1}};
+__device__ __constant__ unsigned char d_nseg[16] = {0, 1, 1, 1, 1, 2, 1, 1, 1, 1, 2, 1, 1, 1, 1, 0};
+__device__ __constant__ int d_sq_elo[4][2] = {{0, 0}, {1, 0}, {0, 1}, {0, 0}};  // lower endpoint of a square edge
+__device__ __constant__ int d_sq_edir[4] = {0, 1, 0, 1};
+// first live square, in traversal order (x fastest), that touches the edge (cell, dir), and whether its own
+// VertexInterp call runs high -> low along dir: e2 = (p2 -> p3) and e3 = (p3 -> p0) do
+template <typename GEO>
+__device__ __forceinline__ int first_toucher2(const GEO& G, const unsigned char* live, int i, int j, int k, int dir, bool& reversed) {
+  int bi[2], bj[2];
+  bool rev[2];
+  if (dir == 0) {
+    bi[0] = i; bj[0] = j - 1; rev[0] = true;    // e2 of the square below: p2 -> p3
+    bi[1] = i; bj[1] = j;     rev[1] = false;   // e0: p0 -> p1
+  } else {
+    bi[0] = i - 1; bj[0] = j; rev[0] = false;   // e1 of the square to the left: p1 -> p2
+    bi[1] = i;     bj[1] = j; rev[1] = true;    // e3: p3 -> p0
+  }
+  for (int q = 0; q < 2; ++q) {
+    if (bi[q] < G.slo[0] || bj[q] < G.slo[1]) continue;
+    if (live[lin_of(G, bi[q], bj[q], k)] & 1) { reversed = rev[q]; return q; }
+  }
+  return -1;
 }
 
 // Cell pass (MEASURED, 64 FABs of 130^3 = 1.4e8 cells: 0.76 ms = 2.9 TB/s of the 16 B/cell; without its byte stores
@@ -468,15 +499,24 @@ __global__ __launch_bounds__(64 * TY) void k_mcl_cells(MclArgs A) {
   int cur = 0, par = 0;
   auto emit = [&](int k, int up, bool up_in) {  // cell (i, j, k): cur = its plane, up = the plane above
     const int in0 = cur & 1;
-    const int cand = ((xin && in0 != ((cur >> 1) & 1)) ? 1 : 0) | ((yin && in0 != ((cur >> 3) & 1)) ? 2 : 0) | ((up_in && in0 != (up & 1)) ? 4 : 0);
     const int kk = k + G.slo[2];
-    const bool ok = okxy && kk >= G.llo[2] && kk <= G.lhi[2] && ((cur | up) & 0xF0) == 0;  // Polygonise bails if any corner is masked (:436-438)
-    const int ci = ok ? ((cur & 0xF) | ((up & 0xF) << 4)) : 0;
+    int cand = ((xin && in0 != ((cur >> 1) & 1)) ? 1 : 0) | ((yin && in0 != ((cur >> 3) & 1)) ? 2 : 0);
+    bool ok = okxy && kk >= G.llo[2] && kk <= G.lhi[2];
+    int ci;
+    if (A.dim2) {  // squares of the plane k = llo[2] only; no z edges, no upper corners
+      if (kk != G.llo[2]) cand = 0;
+      ok = ok && (cur & 0xF0) == 0;  // Segmentise bails if any corner is masked (:326-327)
+      ci = ok ? (cur & 0xF) : 0;
+    } else {
+      cand |= (up_in && in0 != (up & 1)) ? 4 : 0;
+      ok = ok && ((cur | up) & 0xF0) == 0;  // Polygonise bails if any corner is masked (:436-438)
+      ci = ok ? ((cur & 0xF) | ((up & 0xF) << 4)) : 0;
+    }
     if (own) {
       const long long g = g0 + lin0 + (unsigned long long)k * (unsigned long long)nxy;
       A.lc[g] = (unsigned char)((ok ? 1 : 0) | (cand << 1));
       A.cidx[g] = (unsigned char)ci;
-      if (cand || (ci != 0 && ci != 255)) A.bact[g >> 8] = 1;  // same value from every writer
+      if (cand || (ci != 0 && ci != (A.dim2 ? 15 : 255))) A.bact[g >> 8] = 1;  // same value from every writer
     }
   };
   auto consume = [&](int kb, const double (&sv)[P], const double (&mv)[P]) {
@@ -539,10 +579,10 @@ __global__ __launch_bounds__(256) void k_mcl_count(MclArgs A) {
         for (int d = 0; d < 3; ++d) {
           if (!((cand >> d) & 1)) continue;  // edgeTable flags an edge iff its endpoints are on different sides
           bool rev;
-          if (first_toucher(G, A.lc + g0, i, j, k, d, rev) >= 0) bits |= (1 << d);
+          if ((A.dim2 ? first_toucher2(G, A.lc + g0, i, j, k, d, rev) : first_toucher(G, A.lc + g0, i, j, k, d, rev)) >= 0) bits |= (1 << d);
         }
       }
-      nt = (lcv & 1) ? c_ntri[A.cidx[g]] : 0;
+      nt = (lcv & 1) ? (A.dim2 ? d_nseg[A.cidx[g]] : c_ntri[A.cidx[g]]) : 0;
       A.vflag[g] = (unsigned char)bits;
     }
     int pv, pt, tv, tt;
@@ -598,7 +638,7 @@ __global__ __launch_bounds__(256) void k_mcl_lists(MclArgs A, int* vkeys, int* t
     mcl_geo(A, b, G);
     const bool cell = (unsigned long long)(g - A.coff[b]) < G.ncell;  // the FAB's last block is padded
     const int bits = cell ? A.vflag[g] : 0;
-    const int nt = (cell && (A.lc[g] & 1)) ? c_ntri[A.cidx[g]] : 0;
+    const int nt = (cell && (A.lc[g] & 1)) ? (A.dim2 ? d_nseg[A.cidx[g]] : c_ntri[A.cidx[g]]) : 0;
     int pv, pt, tv, tt;
     block_prefix(__popc(bits), nt, pv, pt, tv, tt);
     if (!cell) continue;
@@ -629,7 +669,8 @@ __global__ __launch_bounds__(256) void k_mcl_verts(MclArgs A, double* verts, int
   mcl_cell(G, (unsigned)(g - g0), i, j, k);
   const FabView S = mf_view(A.S, A.L.boxes[b], b);
   bool rev = false;
-  first_toucher(G, A.lc + g0, i, j, k, d, rev);
+  if (A.dim2) first_toucher2(G, A.lc + g0, i, j, k, d, rev);
+  else first_toucher(G, A.lc + g0, i, j, k, d, rev);
   const int hi_i = i + (d == 0), hi_j = j + (d == 1), hi_k = k + (d == 2);
   const int a[3] = {rev ? hi_i : i, rev ? hi_j : j, rev ? hi_k : k};
   const int e[3] = {rev ? i : hi_i, rev ? j : hi_j, rev ? k : hi_k};
@@ -661,11 +702,21 @@ __global__ __launch_bounds__(256) void k_mcl_tris(MclArgs A, int* tris, long lon
   mcl_cell(G, (unsigned)(g - g0), i, j, k);
   const int ci = A.cidx[g];
   int out[3];
-  for (int q = 0; q < 3; ++q) {
-    const int e = c_tri[ci][3 * r + q];
-    const long long le = g0 + lin_of(G, i + d_elo[e][0], j + d_elo[e][1], k + d_elo[e][2]);
-    const int dir = d_edir[e];
-    out[q] = A.voff[le] + __popc(A.vflag[le] & ((1 << dir) - 1));
+  if (A.dim2) {  // segment r of the square: two vertex ids, third entry -1
+    for (int q = 0; q < 2; ++q) {
+      const int e = d_seg[ci][2 * r + q];
+      const long long le = g0 + lin_of(G, i + d_sq_elo[e][0], j + d_sq_elo[e][1], k);
+      const int dir = d_sq_edir[e];
+      out[q] = A.voff[le] + __popc(A.vflag[le] & ((1 << dir) - 1));
+    }
+    out[2] = -1;
+  } else {
+    for (int q = 0; q < 3; ++q) {
+      const int e = c_tri[ci][3 * r + q];
+      const long long le = g0 + lin_of(G, i + d_elo[e][0], j + d_elo[e][1], k + d_elo[e][2]);
+      const int dir = d_edir[e];
+      out[q] = A.voff[le] + __popc(A.vflag[le] & ((1 << dir) - 1));
+    }
   }
   o[0] = out[0]; o[1] = out[1]; o[2] = out[2];
 }
@@ -732,12 +783,22 @@ extern "C" int pa_iso_mask_level(pa_ctx* ctx, pa_mf* mask, int comp, const pa_le
   return 0;
 }
 
+static int mc_level_impl(pa_ctx* ctx, const pa_mf* state, const pa_mf* mask, int mcomp, const pa_box* loops, int isocomp, double isoval, int64_t* nvert,
+                         int64_t* ntri, double** dev_verts, int32_t** dev_vkeys, int32_t** dev_tris, int dim2);
 extern "C" int pa_mc_level(pa_ctx* ctx, const pa_mf* state, const pa_mf* mask, int mcomp, const pa_box* loops, int isocomp, double isoval,
                            int64_t* nvert, int64_t* ntri, double** dev_verts, int32_t** dev_vkeys, int32_t** dev_tris) {
+  return mc_level_impl(ctx, state, mask, mcomp, loops, isocomp, isoval, nvert, ntri, dev_verts, dev_vkeys, dev_tris, 0);
+}
+extern "C" int pa_msq_level(pa_ctx* ctx, const pa_mf* state, const pa_mf* mask, int mcomp, const pa_box* loops, int isocomp, double isoval,
+                            int64_t* nvert, int64_t* nseg, double** dev_verts, int32_t** dev_vkeys, int32_t** dev_segs) {
+  return mc_level_impl(ctx, state, mask, mcomp, loops, isocomp, isoval, nvert, nseg, dev_verts, dev_vkeys, dev_segs, 1);
+}
+static int mc_level_impl(pa_ctx* ctx, const pa_mf* state, const pa_mf* mask, int mcomp, const pa_box* loops, int isocomp, double isoval, int64_t* nvert,
+                         int64_t* ntri, double** dev_verts, int32_t** dev_vkeys, int32_t** dev_tris, int dim2) {
   if (!ctx || !state || !mask || !loops || !nvert || !ntri || !dev_verts || !dev_vkeys || !dev_tris) return pa_fail(ctx, "pa_mc_level: null argument");
   *dev_verts = nullptr; *dev_vkeys = nullptr; *dev_tris = nullptr;
   if (state->lev != mask->lev || state->ng != mask->ng) return pa_fail(ctx, "pa_mc_level: state and mask must share the level and the ghost width");
-  if (state->ncomp < 4) return pa_fail(ctx, "pa_mc_level: state needs 3 coordinate components + at least one field");
+  if (state->ncomp < (dim2 ? 3 : 4)) return pa_fail(ctx, "pa_mc_level: state needs the coordinate components + at least one field");
   if (isocomp < 0 || isocomp >= state->ncomp || mcomp < 0 || mcomp >= mask->ncomp) return pa_fail(ctx, "pa_mc_level: component range");
   const pa_level* L = state->lev;
   const int nb = (int)L->boxes.size(), ng = state->ng;
@@ -755,8 +816,11 @@ extern "C" int pa_mc_level(pa_ctx* ctx, const pa_mf* state, const pa_mf* mask, i
       on = on && loops[b].lo[d] <= loops[b].hi[d];
     }
     if (on)
-      for (int d = 0; d < 3; ++d)
-        if (loops[b].lo[d] < B.lo[d] - ng || loops[b].hi[d] + 1 > B.hi[d] + ng) return pa_fail(ctx, "pa_mc_level: loop box + 1 must lie inside the grown FAB");
+      for (int d = 0; d < 3; ++d) {
+        const int up = (dim2 && d == 2) ? 0 : 1;  // squares have no upper plane
+        if (loops[b].lo[d] < B.lo[d] - ng || loops[b].hi[d] + up > B.hi[d] + ng) return pa_fail(ctx, "pa_mc_level: loop box + 1 must lie inside the grown FAB");
+        if (dim2 && d == 2 && loops[b].lo[d] != loops[b].hi[d]) return pa_fail(ctx, "pa_msq_level: the loop box must be one plane of cells");
+      }
     if (nc >= (1LL << 31)) return pa_fail(ctx, "pa_mc_level: FAB too large");
     maxcell = std::max(maxcell, on ? nc : 0);
     coff[b + 1] = coff[b] + (on ? (nc + 255) / 256 * 256 : 0);
@@ -773,6 +837,7 @@ extern "C" int pa_mc_level(pa_ctx* ctx, const pa_mf* state, const pa_mf* mask, i
   A.L = L->view; A.S = state->view; A.M = mask->view;
   A.mcomp = mcomp; A.isocomp = isocomp; A.ncomp = state->ncomp; A.iso = isoval;
   A.kseg = 32;
+  A.dim2 = dim2;
   A.tot = (long long*)p; p += 16 * (size_t)nb;
   long long* d_base = (long long*)p; p += 16 * (size_t)nb;
   long long* d_coff = (long long*)p; p += 8 * ((size_t)nb + 1);

@@ -208,3 +208,65 @@ def test_marching_cubes_level_batched_matches_oracle(ctx, oracle, name, ng):
             assert np.array_equal(gv.view(np.int64), np.ascontiguousarray(v).view(np.int64)), f"{name} level {l} box {b}: vertex data not bit-identical"
             ntri_total += len(t)
     assert ntri_total > 100
+
+
+@pytest.mark.parametrize("per", [(0, 0, 0), (1, 0, 0)])
+def test_marching_squares_level_matches_oracle(ctx, oracle, per):
+    """pa_msq_level (AMREX_SPACEDIM == 2: Segmentise, isosurface.cpp:303-406) on a 2-level 2-D hierarchy stored as one
+    plane of cells: per FAB the vertices (bit for bit, vertCache order), edge keys and segments of the Python restatement"""
+    from peleanalysis_amd.hierarchy import Hierarchy, Level, chop_box
+    ng, nc = 1, 4
+    l0 = Level(chop_box((0, 0, 0), (15, 15, 0), 8), (0, 0, 0), (15, 15, 0), np.asarray(per), np.zeros(3), np.ones(3))
+    l1 = Level(chop_box((8, 8, 0), (23, 23, 0), 8), (0, 0, 0), (31, 31, 0), np.asarray(per), np.zeros(3), np.ones(3))
+    H = Hierarchy([l0, l1], 2)
+    rng = np.random.default_rng(8)
+    states = []
+    for l, lv in enumerate(H.levels):
+        st = MultiFab(lv, nc, ng, fill=-666.0)
+        for b in range(lv.nboxes):
+            f = st.fab(b)
+            lo = lv.boxes[b, :3] - ng
+            nz, ny, nx = f.shape[1:]
+            x = ((np.arange(lo[0], lo[0] + nx) + 0.5) * lv.dx[0] + lv.prob_lo[0])[None, None, :]
+            y = ((np.arange(lo[1], lo[1] + ny) + 0.5) * lv.dx[1] + lv.prob_lo[1])[None, :, None]
+            f[0], f[1] = x, y
+            v = st.valid(b)
+            xv, yv = x[:, :, ng:-ng], y[:, ng:-ng, :]
+            v[2] = 1000.0 + 500.0 * np.sin(2 * np.pi * xv) * np.cos(2 * np.pi * yv) + 200.0 * (yv - 0.5) + 1e-3 * rng.standard_normal(v[2].shape)
+            v[3] = xv * yv
+        oracle.fill_boundary(st, 0, nc, ng)
+        if l > 0:
+            assert oracle.lib().orc_fillpatch_two_levels(C.byref(oracle._mf(st)), C.byref(oracle._mf(states[l - 1])), 0, nc, ng, 2, 0) == 0
+        states.append(st)
+    iso = 1040.0
+    dls = [capi.DevLevel(ctx, lv) for lv in H.levels]
+    nseg_total = 0
+    for l, lv in enumerate(H.levels):
+        dst = capi.DevMF.from_host(ctx, dls[l], states[l])
+        dmask = capi.DevMF(ctx, dls[l], 1, ng)
+        ctx.check(ctx.lib.pa_iso_mask_level(ctx.h, dmask.h, 0, dls[l + 1].h if l + 1 < H.nlev else None, 2))
+        ctx.sync()
+        gmask = dmask.download()
+        loops = np.zeros((lv.nboxes, 6), np.int64)
+        want = []
+        pg = ng * np.asarray(per)
+        for b in range(lv.nboxes):
+            lo, hi = lv.boxes[b, :3] - ng, lv.boxes[b, 3:] + ng
+            llo = np.maximum(lo, np.asarray(lv.domlo) - pg)
+            lhi = np.minimum(hi, np.asarray(lv.domhi) + pg) - 1
+            llo[2] = lhi[2] = 0
+            loops[b, :3], loops[b, 3:] = llo, lhi
+            s2 = np.ascontiguousarray(states[l].fab(b)[:, ng])   # the plane k = 0
+            m2 = np.ascontiguousarray(gmask.fab(b)[0, ng])
+            want.append(oracle.msq_fab(s2, m2, lo[:2], hi[:2], 2, iso, llo[:2], lhi[:2]))
+        if l == 0:
+            assert sum((w[1].size > 0) for w in want) > 0 and any((gmask.fab(b)[0, ng] < 0).any() for b in range(lv.nboxes))
+        got = capi.mc_level(ctx, dst, dmask, loops, 2, iso, squares=True)
+        for b in range(lv.nboxes):
+            (v, k, sg), (gv, gk, gt) = want[b], got[b]
+            assert (len(gv), len(gt)) == (len(v), len(sg)), f"level {l} box {b}: counts differ"
+            assert np.array_equal(gk[:, [0, 1, 3, 4]], k) and (gk[:, [2, 5]] == 0).all(), f"level {l} box {b}: edge keys / vertex order differ"
+            assert np.array_equal(gt[:, :2], sg) and (gt[:, 2] == -1).all(), f"level {l} box {b}: segments differ"
+            assert np.array_equal(gv.view(np.int64), np.ascontiguousarray(v).view(np.int64)), f"level {l} box {b}: vertex data not bit-identical"
+            nseg_total += len(sg)
+    assert nseg_total > 60
