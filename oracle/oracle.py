@@ -661,3 +661,47 @@ def make_clines(elts0):
                     elif idx_l == lines[b][0][0]:
                         lines[a] = [(r, l) for l, r in reversed(lines[b])] + lines[a]; lines[b] = []; changed = True
     return [ln for ln in lines if ln]
+
+
+def isosurface2d_pipeline(levels, fields, comps, isocomp_index, isoval, MF, ngrow=1, rm_external=True):
+    """the AMREX_SPACEDIM == 2 build of isosurface.cpp:1434-1728 on a hierarchy stored as one plane of cells (k = 0):
+    state = (x, y, mapped comps), FillBoundary + piecewise-constant FillPatchTwoLevels ghost fill (the 3-D C pieces on the
+    slab; z is a wall direction so nothing crosses planes), fine-covered mask, Segmentise per FAB, node / element sets.
+    Returns (nodes [N][2 + len(comps)], elements [M][2] 0-based, sorted as std::set<Element>)."""
+    L = lib()
+    nc = 2 + len(comps)
+    ng = int(ngrow)
+    states, frags = [], []
+    for l, lv in enumerate(levels):
+        st = MF(lv, nc, ng, fill=-666.0)
+        dx = lv.dx
+        for b in range(lv.nboxes):
+            f = st.fab(b)
+            lo = lv.boxes[b, :3] - ng
+            nz, ny, nx = f.shape[1:]
+            f[0] = ((np.arange(lo[0], lo[0] + nx) + 0.5) * dx[0] + lv.prob_lo[0])[None, None, :]
+            f[1] = ((np.arange(lo[1], lo[1] + ny) + 0.5) * dx[1] + lv.prob_lo[1])[None, :, None]
+            for n, c in enumerate(comps):
+                st.valid(b)[2 + n] = fields[l].valid(b)[c]
+        fill_boundary(st, 0, nc, ng)
+        if l > 0:
+            assert L.orc_fillpatch_two_levels(_p(_mf(st)), _p(_mf(states[l - 1])), 0, nc, ng, 2, 0) == 0
+        states.append(st)
+    for l, lv in enumerate(levels):
+        for b in range(lv.nboxes):
+            lo, hi, mask, llo, lhi = iso_fab_inputs(levels, states, l, b, ng)
+            if np.any(llo[:2] > lhi[:2]):
+                continue
+            s2 = np.ascontiguousarray(states[l].fab(b)[:, ng])
+            verts, vkeys, segs = msq_fab(s2, np.ascontiguousarray(mask[ng]), lo[:2], hi[:2], 2 + isocomp_index, isoval, llo[:2], lhi[:2])
+            if rm_external and len(verts):
+                glo, ghi = lv.boxes[b, :2] - 1, lv.boxes[b, 3:5] + 1
+                inside = np.all((vkeys[:, :2] >= glo) & (vkeys[:, :2] <= ghi) & (vkeys[:, 2:] >= glo) & (vkeys[:, 2:] <= ghi), axis=1)
+                if not inside.all():
+                    remap = np.cumsum(inside) - 1
+                    keep = inside[segs].all(axis=1) if len(segs) else np.zeros(0, bool)
+                    segs = remap[segs[keep]].astype(np.int32).reshape(-1, 2)
+                    verts = verts[inside]
+            if len(verts):
+                frags.append((verts, segs))
+    return iso2d_merge(frags, nc)

@@ -18,13 +18,19 @@ from .hierarchy import Hierarchy, Level, MultiFab
 FAB_DESC = "FAB ((8, (64 11 52 0 1 12 0 1023)),(8, (8 7 6 5 4 3 2 1)))"
 
 
-def _box_str(lo, hi):
+def _box_str(lo, hi, dim=3):
+    if dim == 2:
+        return "((%d,%d) (%d,%d) (0,0))" % (lo[0], lo[1], hi[0], hi[1])
     return "((%d,%d,%d) (%d,%d,%d) (0,0,0))" % (lo[0], lo[1], lo[2], hi[0], hi[1], hi[2])
 
 
 def write_plotfile(path: str, H: Hierarchy, mfs: Sequence[MultiFab], names: Sequence[str], time: float = 0.0,
-                   level_steps: Sequence[int] | None = None) -> None:
-    """WriteMultiLevelPlotfile restated (valid cells only, one Cell_D file per level)."""
+                   level_steps: Sequence[int] | None = None, dim: int = 3) -> None:
+    """WriteMultiLevelPlotfile restated (valid cells only, one Cell_D file per level).  dim = 2: the hierarchy is one
+    plane of cells (k = 0) and the file is what a 2-D AMReX code writes (2 entries per index / coordinate tuple)."""
+    if dim == 2:
+        assert all((lv.boxes[:, 2] == 0).all() and (lv.boxes[:, 5] == 0).all() for lv in H.levels)
+
     nlev = H.nlev
     ncomp = len(names)
     level_steps = list(level_steps) if level_steps is not None else [0] * nlev
@@ -34,20 +40,20 @@ def write_plotfile(path: str, H: Hierarchy, mfs: Sequence[MultiFab], names: Sequ
         f.write("HyperCLaw-V1.1\n%d\n" % ncomp)
         for n in names:
             f.write(n + "\n")
-        f.write("3\n%.17g\n%d\n" % (time, nlev - 1))
-        f.write(" ".join("%.17g" % v for v in L0.prob_lo) + " \n")
-        f.write(" ".join("%.17g" % v for v in L0.prob_hi) + " \n")
+        f.write("%d\n%.17g\n%d\n" % (dim, time, nlev - 1))
+        f.write(" ".join("%.17g" % v for v in L0.prob_lo[:dim]) + " \n")
+        f.write(" ".join("%.17g" % v for v in L0.prob_hi[:dim]) + " \n")
         f.write(" ".join(str(H.ref_ratio) for _ in range(nlev - 1)) + " \n")
-        f.write(" ".join(_box_str(lv.domlo, lv.domhi) for lv in H.levels) + " \n")
+        f.write(" ".join(_box_str(lv.domlo, lv.domhi, dim) for lv in H.levels) + " \n")
         f.write(" ".join(str(s) for s in level_steps) + " \n")
         for lv in H.levels:
-            f.write(" ".join("%.17g" % v for v in lv.dx) + " \n")
+            f.write(" ".join("%.17g" % v for v in lv.dx[:dim]) + " \n")
         f.write("0\n0\n")
         for l, lv in enumerate(H.levels):
             f.write("%d %d %.17g\n%d\n" % (l, lv.nboxes, time, level_steps[l]))
             dx = lv.dx
             for b in range(lv.nboxes):
-                for d in range(3):
+                for d in range(dim):
                     f.write("%.17g %.17g\n" % (lv.prob_lo[d] + lv.boxes[b, d] * dx[d], lv.prob_lo[d] + (lv.boxes[b, 3 + d] + 1) * dx[d]))
             f.write("Level_%d/Cell\n" % l)
     for l, lv in enumerate(H.levels):
@@ -58,14 +64,14 @@ def write_plotfile(path: str, H: Hierarchy, mfs: Sequence[MultiFab], names: Sequ
             for b in range(lv.nboxes):
                 offs.append(f.tell())
                 v = np.ascontiguousarray(mfs[l].valid(b)[:ncomp], dtype="<f8")
-                f.write((FAB_DESC + _box_str(lv.boxes[b, :3], lv.boxes[b, 3:]) + " %d\n" % ncomp).encode())
+                f.write((FAB_DESC + _box_str(lv.boxes[b, :3], lv.boxes[b, 3:], dim) + " %d\n" % ncomp).encode())
                 f.write(v.tobytes())
                 mins.append(v.reshape(ncomp, -1).min(axis=1))
                 maxs.append(v.reshape(ncomp, -1).max(axis=1))
         with open(os.path.join(d, "Cell_H"), "w") as f:
             f.write("1\n1\n%d\n0\n(%d 0\n" % (ncomp, lv.nboxes))
             for b in range(lv.nboxes):
-                f.write(_box_str(lv.boxes[b, :3], lv.boxes[b, 3:]) + "\n")
+                f.write(_box_str(lv.boxes[b, :3], lv.boxes[b, 3:], dim) + "\n")
             f.write(")\n%d\n" % lv.nboxes)
             for b in range(lv.nboxes):
                 f.write("FabOnDisk: Cell_D_00000 %d\n" % offs[b])
@@ -159,8 +165,12 @@ def read_mef(path: str):
         names = f.readline().decode().split()
         nelts, npe = [int(x) for x in f.readline().decode().split()]
         line = f.readline().decode()
-        m = _BOX_RE.findall(line)[-1]
-        nnodes = int(m[3]) - int(m[0]) + 1
+        m3 = _BOX_RE.findall(line)
+        if m3:
+            nnodes = int(m3[-1][3]) - int(m3[-1][0]) + 1
+        else:  # 2-D build: Box (0..N-1, 0)
+            m2 = re.findall(r"\(\((-?\d+),(-?\d+)\)\s*\((-?\d+),(-?\d+)\)\s*\((-?\d+),(-?\d+)\)\)", line)[-1]
+            nnodes = int(m2[2]) - int(m2[0]) + 1
         nc = int(line.strip().split()[-1])
         nodes = np.frombuffer(f.read(8 * nnodes * nc), dtype="<f8").reshape(nnodes, nc)
         faces = np.frombuffer(f.read(4 * nelts * npe), dtype="<i4").reshape(nelts, npe)

@@ -190,3 +190,40 @@ def test_isosurface_sphere_closed_manifold_amr(oracle):
     nrm = np.cross(b - a, c - a)
     s = np.sign((nrm * ((a + b + c) / 3 - 0.5)).sum(1))
     assert np.all(s == s[0])
+
+
+def test_marching_squares_circle_known_answer(oracle):
+    """2-D restatement (Segmentise + node/element sets + MakeCLines): the contour of r = 0.3 on a 64^2 grid is ONE closed
+    line whose length is 2 pi r to second order; every node lies on the circle to second order; the seed segment of the
+    line search is consumed (reference quirk), so the line holds one segment fewer than the element set"""
+    n = 64
+    x = (np.arange(-1, n + 1) + 0.5) / n
+    X, Y = np.meshgrid(x, x)  # [j][i]
+    r = np.sqrt((X - 0.5) ** 2 + (Y - 0.5) ** 2)
+    state = np.stack([X, Y, r])
+    mask = np.ones_like(r)
+    lo, hi = np.array([-1, -1]), np.array([n, n])
+    verts, vkeys, segs = oracle.msq_fab(state, mask, lo, hi, 2, 0.3, np.array([0, 0]), np.array([n - 2, n - 2]))
+    assert len(segs) == len(verts) > 100  # closed curve: as many segments as vertices
+    assert np.abs(np.sqrt((verts[:, 0] - 0.5) ** 2 + (verts[:, 1] - 0.5) ** 2) - 0.3).max() < 1.0 / n ** 2
+    assert np.abs(verts[:, 2] - 0.3).max() < 1e-12  # the iso component is interpolated to the iso value
+    order = np.lexsort((vkeys[:, 2], vkeys[:, 3], vkeys[:, 0], vkeys[:, 1]))
+    assert np.array_equal(order, np.arange(len(vkeys)))  # vertCache order: (j, i) of the lower endpoint, then of the upper
+    nodes, elts = oracle.iso2d_merge([(verts, segs)], 3)
+    assert len(nodes) == len(verts) and len(elts) == len(segs) and (elts[:, 0] < elts[:, 1]).all()
+    length = np.sqrt(((nodes[elts[:, 0], :2] - nodes[elts[:, 1], :2]) ** 2).sum(axis=1)).sum()
+    assert abs(length - 2 * np.pi * 0.3) < 2e-3
+    lines = oracle.make_clines(elts)
+    assert len(lines) == 1 and len(lines[0]) == len(elts) - 1
+    for (a, b), (c, d) in zip(lines[0][:-1], lines[0][1:]):
+        assert b == c  # consecutive segments share a node
+    # a masked corner removes its four squares; the exact-hit branches of VI_doIt copy an endpoint
+    i5, j5 = int(vkeys[5][0]), int(vkeys[5][1])  # a grid point next to the contour
+    mask2 = mask.copy()
+    mask2[j5 + 1, i5 + 1] = -1.0
+    v2, _, s2 = oracle.msq_fab(state, mask2, lo, hi, 2, 0.3, np.array([0, 0]), np.array([n - 2, n - 2]))
+    assert len(s2) < len(segs)
+    st3 = state.copy()
+    st3[2, j5 + 1, i5 + 1] = 0.3
+    v3, _, _ = oracle.msq_fab(st3, mask, lo, hi, 2, 0.3, np.array([0, 0]), np.array([n - 2, n - 2]))
+    assert ((v3[:, 0] == X[j5 + 1, i5 + 1]) & (v3[:, 1] == Y[j5 + 1, i5 + 1])).any()

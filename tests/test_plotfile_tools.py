@@ -375,3 +375,52 @@ def test_partstream_tool_end_to_end(tmp_path, oracle):
         assert np.abs(z - want).max() <= 5e-6 * max(1.0, np.abs(want).max())  # ostream default precision: 6 significant digits
     bad = subprocess.run([os.path.join(BIN, "partStream3d.ex"), "infile=" + p], cwd=tmp_path, capture_output=True, text=True)
     assert bad.returncode != 0 and "Assertion" in bad.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("per", [(0, 0), (1, 0)])
+def test_isosurface2d_tool_end_to_end(tmp_path, oracle, per):
+    """isosurface2d.ex (the AMREX_SPACEDIM == 2 build: Segmentise, two nodes per element, MakeCLines + "Integral:"):
+    2-D plotfile -> MEF identical to the Python restatement (node ids, node data bit for bit, sorted segments), the same
+    number of contour lines and the same line integrals"""
+    from peleanalysis_amd.hierarchy import Hierarchy, Level, chop_box
+    per3 = np.array([per[0], per[1], 0])
+    l0 = Level(chop_box((0, 0, 0), (31, 31, 0), 8), (0, 0, 0), (31, 31, 0), per3, np.zeros(3), np.ones(3))
+    l1 = Level(chop_box((16, 16, 0), (47, 47, 0), 8), (0, 0, 0), (63, 63, 0), per3, np.zeros(3), np.ones(3))
+    H = Hierarchy([l0, l1], 2)
+
+    def fn(x, y, z, c):
+        r = np.sqrt((x - 0.5) ** 2 + ((y - 0.5) / 0.8) ** 2) + 0 * z
+        base = 300.0 + 850.0 * (1.0 + np.tanh((r - 0.27 - 0.03 * np.sin(5 * np.arctan2(y - 0.5, x - 0.5))) / 0.06))
+        return base + 400.0 * np.sin(2 * np.pi * x) * (c == 0) if per[0] else (1.0 + 0.2 * c) * base
+
+    mfs = make_states(H, 2, 0, fn, seed=9)
+    p = str(tmp_path / "plt2d")
+    write_plotfile(p, H, mfs, ["temp", "density"], time=0.25, level_steps=[3, 3], dim=2)
+    assert open(os.path.join(p, "Header")).read().split("\n")[4] == "2"
+    out = _run("isosurface2d.ex", ["infile=" + p, "isoCompName=temp", "isoVal=1150", "comps=0 1", "is_per=%d %d" % per], tmp_path)
+    label, names, nodes, faces = read_mef(p + "_temp_1150.mef")
+    assert label == "0.25" and names == ["X", "Y", "temp", "density"] and faces.shape[1] == 2
+    fields = [MultiFab(lv, 2, 0, mfs[l].data.copy()) for l, lv in enumerate(H.levels)]
+    onodes, oelts = oracle.isosurface2d_pipeline(H.levels, fields, [0, 1], 0, 1150.0, MultiFab)
+    assert len(oelts) > 100
+    assert np.array_equal(faces, oelts + 1), "segments (1-based) differ"
+    assert np.array_equal(nodes.view(np.int64), onodes.view(np.int64)), "node data not bit-identical"
+    lines = oracle.make_clines(oelts)
+    assert "number of contour lines: %d" % len(lines) in out.stderr
+    got = [[float(t) for t in ln.split()[1:]] for ln in out.stdout.splitlines() if ln.startswith("Integral:")]
+    assert len(got) == len(lines)
+    for g, ln in zip(got, lines):
+        integ = np.zeros(2)
+        for a, b in ln:
+            p0, p1 = onodes[a], onodes[b]
+            length = np.sqrt((p1[0] - p0[0]) ** 2 + (p1[1] - p0[1]) ** 2)
+            nrm = np.array([(p0[1] - p1[1]) / length, (p1[0] - p0[0]) / length]) if length > 0 else np.zeros(2)
+            integ += nrm * 0.5 * (p0[2] + p1[2]) * length
+        assert np.allclose(g, integ, rtol=2e-5, atol=1e-9), (g, integ)
+    # a 3-D tool refuses the 2-D plotfile, the 2-D tool a 3-D one; the distance function aborts as in the reference
+    bad = subprocess.run([os.path.join(BIN, "isosurface3d.ex"), "infile=" + p, "isoCompName=temp"], cwd=tmp_path, capture_output=True, text=True)
+    assert bad.returncode != 0 and "3-D" in bad.stderr
+    bad = subprocess.run([os.path.join(BIN, "isosurface2d.ex"), "infile=" + p, "isoCompName=temp", "build_distance_function=1"], cwd=tmp_path,
+                         capture_output=True, text=True)
+    assert bad.returncode != 0 and "not worked out for 2D" in bad.stderr

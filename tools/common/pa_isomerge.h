@@ -16,12 +16,18 @@ namespace pa {
 
 class IsoMerger {
  public:
-  explicit IsoMerger(int ncomp) : nc_(ncomp) {}
+  // dim = 2: the 2-D build (positions are (x, y); elements are segments, passed as rows (id0, id1, -1))
+  explicit IsoMerger(int ncomp, int dim = 3) : nc_(ncomp), dim_(dim) {}
   // one FAB's fragment: verts [nv][ncomp] in vertCache order, tris [nt][3] local ids
   void add(const double* verts, long long nv, const int32_t* tris, long long nt) {
     std::vector<int32_t> ids((size_t)nv);
     for (long long q = 0; q < nv; ++q) ids[q] = node_id(verts + q * nc_);
     for (long long t = 0; t < nt; ++t) {
+      if (dim_ == 2) {  // Element of two ids: the smaller first (std::rotate on two entries), v0 == v1 dropped (:1707-1715)
+        const int32_t a = ids[tris[3 * t]], b = ids[tris[3 * t + 1]];
+        if (a != b) elts_.push_back({std::min(a, b), std::max(a, b), 0});
+        continue;
+      }
       std::array<int32_t, 3> v{ids[tris[3 * t]], ids[tris[3 * t + 1]], ids[tris[3 * t + 2]]};
       if (v[0] == v[1] || v[1] == v[2] || v[0] == v[2]) continue;  // degenerate (isosurface.cpp:1723-1724)
       const int s = (int)(std::min_element(v.begin(), v.end()) - v.begin());
@@ -38,12 +44,12 @@ class IsoMerger {
   std::vector<int32_t> elements() const {
     std::vector<int32_t> e;
     e.reserve(3 * elts_.size());
-    for (auto& v : elts_) { e.push_back(v[0]); e.push_back(v[1]); e.push_back(v[2]); }
+    for (auto& v : elts_) { e.push_back(v[0]); e.push_back(v[1]); if (dim_ == 3) e.push_back(v[2]); }
     return e;
   }
 
  private:
-  int nc_;
+  int nc_, dim_;
   std::vector<double> nodes_;
   std::vector<std::array<int32_t, 3>> elts_;
   struct Key { long long x, y, z; bool operator==(const Key& o) const { return x == o.x && y == o.y && z == o.z; } };
@@ -52,16 +58,18 @@ class IsoMerger {
 
   int32_t node_id(const double* p) {
     constexpr double EPS = 1.0e-15, H = 1.0e-14;
-    const Key g{(long long)std::floor(p[0] / H), (long long)std::floor(p[1] / H), (long long)std::floor(p[2] / H)};
+    const double pz = dim_ == 3 ? p[2] : 0.0;
+    const Key g{(long long)std::floor(p[0] / H), (long long)std::floor(p[1] / H), (long long)std::floor(pz / H)};
     int32_t best = -1;
     for (int dz = -1; dz <= 1; ++dz)
       for (int dy = -1; dy <= 1; ++dy)
         for (int dx = -1; dx <= 1; ++dx) {
+          if (dim_ == 2 && dz != 0) continue;
           auto it = grid_.find(Key{g.x + dx, g.y + dy, g.z + dz});
           if (it == grid_.end()) continue;
           for (int32_t c : it->second) {
             const double* q = &nodes_[(size_t)c * nc_];
-            const double a = q[0] - p[0], b = q[1] - p[1], d = q[2] - p[2];
+            const double a = q[0] - p[0], b = q[1] - p[1], d = dim_ == 3 ? q[2] - p[2] : 0.0;
             if (std::sqrt(a * a + b * b + d * d) < EPS && (best < 0 || c < best)) best = c;
           }
         }

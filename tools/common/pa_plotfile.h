@@ -41,7 +41,7 @@ struct LevelMeta {
 struct PlotfileHeader {
   std::vector<std::string> names;
   double time = 0.0;
-  int nlev = 0;
+  int nlev = 0, dim = 3;
   double prob_lo[3], prob_hi[3];
   std::vector<int> ref_ratio;
   std::vector<LevelMeta> lev;
@@ -81,17 +81,24 @@ struct HostMF {
   }
 };
 
-inline bool parse_box(const std::string& s, size_t& pos, Box3& b) {
-  static const std::regex re(R"(\(\((-?\d+),(-?\d+),(-?\d+)\)\s*\((-?\d+),(-?\d+),(-?\d+)\)\s*\((-?\d+),(-?\d+),(-?\d+)\)\))");
+inline bool parse_box(const std::string& s, size_t& pos, Box3& b, int dim = 3) {
+  static const std::regex re3(R"(\(\((-?\d+),(-?\d+),(-?\d+)\)\s*\((-?\d+),(-?\d+),(-?\d+)\)\s*\((-?\d+),(-?\d+),(-?\d+)\)\))");
+  static const std::regex re2(R"(\(\((-?\d+),(-?\d+)\)\s*\((-?\d+),(-?\d+)\)\s*\((-?\d+),(-?\d+)\)\))");
   std::smatch m;
   std::string::const_iterator st = s.begin() + pos;
-  if (!std::regex_search(st, s.end(), m, re)) return false;
-  for (int d = 0; d < 3; ++d) { b.lo[d] = std::stoi(m[1 + d]); b.hi[d] = std::stoi(m[4 + d]); }
+  if (!std::regex_search(st, s.end(), m, dim == 2 ? re2 : re3)) return false;
+  if (dim == 2) {  // a 2-D box is the plane k = 0
+    for (int d = 0; d < 2; ++d) { b.lo[d] = std::stoi(m[1 + d]); b.hi[d] = std::stoi(m[3 + d]); }
+    b.lo[2] = b.hi[2] = 0;
+  } else {
+    for (int d = 0; d < 3; ++d) { b.lo[d] = std::stoi(m[1 + d]); b.hi[d] = std::stoi(m[4 + d]); }
+  }
   pos += m.position(0) + m.length(0);
   return true;
 }
 
-inline PlotfileHeader read_header(const std::string& path) {
+// dim_wanted = 3: the 3-D tools (a 2-D plotfile aborts); 2: the 2-D build of isosurface (boxes become the plane k = 0)
+inline PlotfileHeader read_header(const std::string& path, int dim_wanted = 3) {
   PlotfileHeader H;
   H.path = path;
   std::ifstream f(path + "/Header");
@@ -108,10 +115,13 @@ inline PlotfileHeader read_header(const std::string& path) {
   }
   int dim, finest;
   f >> dim >> H.time >> finest;
-  if (dim != 3) Abort("only 3-D plotfiles are supported by this build");
+  if (dim != dim_wanted) Abort(dim_wanted == 3 ? "only 3-D plotfiles are supported by this build" : "this is the 2-D build: the plotfile is not 2-D");
+  H.dim = dim;
   H.nlev = finest + 1;
-  for (int d = 0; d < 3; ++d) f >> H.prob_lo[d];
-  for (int d = 0; d < 3; ++d) f >> H.prob_hi[d];
+  H.prob_lo[2] = 0.0;
+  H.prob_hi[2] = 1.0;
+  for (int d = 0; d < dim; ++d) f >> H.prob_lo[d];
+  for (int d = 0; d < dim; ++d) f >> H.prob_hi[d];
   std::getline(f, line);
   std::getline(f, line);  // ref ratios (possibly empty)
   {
@@ -124,7 +134,7 @@ inline PlotfileHeader read_header(const std::string& path) {
   {
     size_t pos = 0;
     for (int l = 0; l < H.nlev; ++l)
-      if (!parse_box(line, pos, H.lev[l].domain)) Abort("bad domain line in plotfile Header");
+      if (!parse_box(line, pos, H.lev[l].domain, dim)) Abort("bad domain line in plotfile Header");
   }
   for (int l = 0; l < H.nlev; ++l) f >> H.lev[l].level_step;
   std::getline(f, line);
@@ -136,7 +146,7 @@ inline PlotfileHeader read_header(const std::string& path) {
     double t;
     f >> lev >> ngrids >> t >> step;
     double a, b;
-    for (int g = 0; g < 3 * ngrids; ++g) f >> a >> b;
+    for (int g = 0; g < dim * ngrids; ++g) f >> a >> b;
     std::string rel;
     f >> rel;  // Level_n/Cell
     std::ifstream h(path + "/" + rel + "_H");
@@ -148,7 +158,7 @@ inline PlotfileHeader read_header(const std::string& path) {
     const std::string blk = txt.substr(0, fod == std::string::npos ? txt.size() : fod);
     size_t pos = blk.find('(');
     Box3 bx;
-    while (parse_box(blk, pos, bx)) H.lev[l].boxes.push_back(bx);
+    while (parse_box(blk, pos, bx, dim)) H.lev[l].boxes.push_back(bx);
     if ((int)H.lev[l].boxes.size() != ngrids) Abort("Cell_H box count does not match the Header");
     const std::string dir = rel.substr(0, rel.rfind('/') + 1);
     size_t p = fod;
@@ -188,7 +198,7 @@ inline void read_comp(const PlotfileHeader& H, int lev, int comp, HostMF& dst, i
     std::getline(f, hdr);
     size_t pos = hdr.find(")))");  // end of the real descriptor
     Box3 fbx;
-    if (pos == std::string::npos || !parse_box(hdr, pos, fbx)) Abort("bad FAB header in " + L.fab_file[fb]);
+    if (pos == std::string::npos || !parse_box(hdr, pos, fbx, H.dim)) Abort("bad FAB header in " + L.fab_file[fb]);
     const long long n = fbx.numPts();
     std::vector<double> buf((size_t)n);
     f.seekg((long long)f.tellg() + (long long)comp * n * 8);
