@@ -145,8 +145,11 @@ def grad_pipeline(levels, states, comp, bc, outs, ocomp, multipass=True, omp=Fal
 
 def curvature_pipeline(levels, states, comp, bc, outs, ocomp, MF, prog_min=None, prog_max=None, threshold=None,
                        do_gauss=False, vel_comp=None, do_strain=False, do_velnormal=False, strain_tensor=False, omp=False,
-                       do_smooth=False, smoothing_time=1e-7, smooth_tol=1e-12):
+                       do_smooth=False, smoothing_time=1e-7, smooth_tol=1e-12, spacedim=3):
     """curvature.cpp:283-326 + 408-570 (core), 575-789 (options).
+    spacedim = 2: the AMREX_SPACEDIM == 2 build on a hierarchy stored as one plane of cells (k = 0, z a wall): the
+    divergence runs over x and y only and is NOT halved (:542-546 multiplies by 0.5 in 3-D only); the gradient pieces
+    are the 3-D ones, whose z terms are exact zeros on such a hierarchy.
     out comps: ocomp+0 Progress, +1 MeanCurvature, +2..4 FlameNormal, +5 GaussianCurvature
     (0.0 when not requested: quirk Q1), +6 StrainRate, +7 VelFlameNormal (when requested).
     MF = host multifab class (level, ncomp, ng) used for scratch."""
@@ -182,10 +185,11 @@ def curvature_pipeline(levels, states, comp, bc, outs, ocomp, MF, prog_min=None,
         fill_boundary(G, 0, 3, 1, omp)
         fill_boundary(n, 0, 3, 1, omp)
         K = MF(levels[l], 1, 0)
-        for d in range(3):
+        for d in range(3 if spacedim == 3 else 2):
             apply_bc(n, d, outs[l - 1] if l > 0 else None, ocomp + 2 + d, bc, only_dir=d, omp=omp)
             L.orc_div_accum(_p(_mf(n)), d, d, _p(_mf(K)), 0)
-        L.orc_mult(_p(_mf(K)), 0, C.c_double(0.5))
+        if spacedim == 3:
+            L.orc_mult(_p(_mf(K)), 0, C.c_double(0.5))
         if thr >= 0:
             L.orc_threshold(_p(_mf(c)), 0, C.c_double(thr), _p(_mf(K)), 0, _p(_mf(n)), 0)
         L.orc_copy(_p(_mf(progress[l] if do_smooth else c)), 0, _p(_mf(outs[l])), ocomp, 1, 0)

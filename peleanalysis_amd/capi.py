@@ -31,7 +31,8 @@ class PaBox(C.Structure):
 class PaCurvParams(C.Structure):
     _fields_ = [("prog_min", C.c_double), ("prog_max", C.c_double), ("do_threshold", C.c_int32), ("threshold", C.c_double),
                 ("fused", C.c_int32), ("do_gauss_curv", C.c_int32), ("do_strain", C.c_int32), ("get_strain_tensor", C.c_int32),
-                ("do_velnormal", C.c_int32), ("vel_comp", C.c_int32), ("do_smooth", C.c_int32), ("smoothing_time", C.c_double)]
+                ("do_velnormal", C.c_int32), ("vel_comp", C.c_int32), ("do_smooth", C.c_int32), ("smoothing_time", C.c_double),
+                ("spacedim", C.c_int32)]
 
 
 class PaSdfGrid(C.Structure):
@@ -309,8 +310,9 @@ def grad_run(ctx: Context, states: Sequence[DevMF], comp: int, bc, outs: Sequenc
 
 
 def curv_params(prog_min=None, prog_max=None, threshold=None, fused=True, do_gauss=False, do_strain=False, strain_tensor=False,
-                do_velnormal=False, vel_comp=0, do_smooth=False, smoothing_time=1e-7) -> PaCurvParams:
+                do_velnormal=False, vel_comp=0, do_smooth=False, smoothing_time=1e-7, spacedim=3) -> PaCurvParams:
     p = PaCurvParams()
+    p.spacedim = int(spacedim)
     p.do_smooth, p.smoothing_time = int(do_smooth), float(smoothing_time)
     p.do_gauss_curv, p.do_strain, p.get_strain_tensor, p.do_velnormal, p.vel_comp = int(do_gauss), int(do_strain), int(strain_tensor), int(do_velnormal), int(vel_comp)
     p.prog_min = 1e20 if prog_min is None else prog_min

@@ -61,7 +61,8 @@ static int prog_minmax(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, con
 // pass-by-pass curvature core; out comps: pc (Progress, -1 = skip), kc (MeanCurvature), nc (FlameNormal x3)
 // opt >= 0: also the options of curvature.cpp:575-789 selected in P, written at out comps opt+5.. (see the header)
 static int curvature_passes(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, const int32_t bc[3], double pmin, double pmax,
-                            double thr, pa_mf* const* out, int pc, int kc, int nc, const pa_curv_params* P = nullptr, int opt = -1) {
+                            double thr, pa_mf* const* out, int pc, int kc, int nc, const pa_curv_params* P = nullptr, int opt = -1,
+                            double kscale = 0.5 /* curvature.cpp:542-546: 0.5 in the 3-D build, none (1.0, exact) in the 2-D build */) {
   std::vector<MFPtr> cmf(nlev), nmf(nlev), gmf(nlev), ngmf(nlev);
   const bool gauss = opt >= 0 && P && P->do_gauss_curv;
   const bool strain = opt >= 0 && P && P->do_strain;
@@ -106,7 +107,7 @@ static int curvature_passes(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp
     PA_TRY(pa_fill_boundary(ctx, n, 0, 3, 1));                                          // :502
     for (int d = 0; d < 3; ++d)                                                         // :508-531
       PA_TRY(pa_apply_bc(ctx, n, d, l > 0 ? out[l - 1] : nullptr, nc + d, bc, 2, d));
-    PA_TRY(pa_div_level(ctx, n, 0, 0.5, c, 0, thr, out[l], kc));                        // :533-567
+    PA_TRY(pa_div_level(ctx, n, 0, kscale, c, 0, thr, out[l], kc));                        // :533-567
     PA_TRY(pa_mf_copy(ctx, n, 0, out[l], nc, 3, 0));                                    // :569-570
     if (gauss) {  // :575-677: Hessian of c from cell_normal (= G), coarse-fine BC from cell_normal[lev-1]
       pa_mf* G = gmf[l].get();
@@ -295,7 +296,9 @@ extern "C" int pa_curvature_run(pa_ctx* ctx, int nlev, pa_mf* const* state, int 
   double pmin, pmax;
   PA_TRY(prog_minmax(ctx, nlev, state, comp, P, pmin, pmax));
   const double thr = P->do_threshold ? P->threshold : -1.0;
-  return curvature_passes(ctx, nlev, state, comp, bc, pmin, pmax, thr, out, ocomp, ocomp + 1, ocomp + 2, P, ocomp);
+  if (P->spacedim == 2 && (P->do_gauss_curv || P->do_strain || P->do_velnormal || P->do_smooth))
+    return pa_fail(ctx, "pa_curvature_run: the curvature options are not available for 2-D levels (spacedim = 2)");
+  return curvature_passes(ctx, nlev, state, comp, bc, pmin, pmax, thr, out, ocomp, ocomp + 1, ocomp + 2, P, ocomp, P->spacedim == 2 ? 1.0 : 0.5);
 }
 
 extern "C" int pa_gradcurv_run(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, const int32_t bc[3], const pa_curv_params* P,
@@ -306,11 +309,11 @@ extern "C" int pa_gradcurv_run(pa_ctx* ctx, int nlev, pa_mf* const* state, int c
   double pmin, pmax;
   PA_TRY(prog_minmax(ctx, nlev, state, comp, P, pmin, pmax));
   const double thr = P->do_threshold ? P->threshold : -1.0;
-  if (P->fused && all_fusable(nlev, state)) {
+  if (P->fused && P->spacedim != 2 && all_fusable(nlev, state)) {
     PA_TRY(check_levels(ctx, nlev, work, "pa_gradcurv_run"));
     return fused_passes(ctx, nlev, state, comp, bc, pmin, pmax, thr, work, out, ocomp);
   }
   // general AMR (concave coarse-fine corners, very thin boxes) or fused=0: pass by pass
   PA_TRY(pa_grad_run(ctx, nlev, state, comp, bc, out, ocomp));
-  return curvature_passes(ctx, nlev, state, comp, bc, pmin, pmax, thr, out, -1, ocomp + 7, ocomp + 4);
+  return curvature_passes(ctx, nlev, state, comp, bc, pmin, pmax, thr, out, -1, ocomp + 7, ocomp + 4, nullptr, -1, P->spacedim == 2 ? 1.0 : 0.5);
 }

@@ -84,6 +84,7 @@ def write_plotfile(path: str, H: Hierarchy, mfs: Sequence[MultiFab], names: Sequ
 
 
 _BOX_RE = re.compile(r"\(\((-?\d+),(-?\d+),(-?\d+)\)\s*\((-?\d+),(-?\d+),(-?\d+)\)\s*\((-?\d+),(-?\d+),(-?\d+)\)\)")
+_BOX2_RE = re.compile(r"\(\((-?\d+),(-?\d+)\)\s*\((-?\d+),(-?\d+)\)\s*\((-?\d+),(-?\d+)\)\)")
 
 
 class PlotfileData:
@@ -103,17 +104,22 @@ def read_plotfile(path: str, is_per=(0, 0, 0)) -> PlotfileData:
     ncomp = int(next(it))
     names = [next(it).strip() for _ in range(ncomp)]
     dim = int(next(it))
-    if dim != 3:
-        raise ValueError("only 3-D plotfiles are supported")
+    if dim not in (2, 3):
+        raise ValueError("only 2-D and 3-D plotfiles are supported")
+    box_re = _BOX_RE if dim == 3 else _BOX2_RE
+
+    def box6(m):  # a 2-D box is the plane k = 0
+        v = [int(x) for x in m]
+        return v[:6] if dim == 3 else [v[0], v[1], 0, v[2], v[3], 0]
     time = float(next(it))
     finest = int(next(it))
     nlev = finest + 1
-    prob_lo = np.array([float(x) for x in next(it).split()])
-    prob_hi = np.array([float(x) for x in next(it).split()])
+    prob_lo = np.array([float(x) for x in next(it).split()] + ([0.0] if dim == 2 else []))
+    prob_hi = np.array([float(x) for x in next(it).split()] + ([1.0] if dim == 2 else []))
     rr = [int(x) for x in re.findall(r"-?\d+", next(it))]
     if any(r != 2 for r in rr[:nlev - 1]):
         raise ValueError("only refinement ratio 2 is supported (quirk Q11)")
-    doms = _BOX_RE.findall(next(it))
+    doms = box_re.findall(next(it))
     steps = [int(x) for x in next(it).split()]
     for _ in range(nlev):
         next(it)  # dx lines (recomputed from prob size / cells like amrex::Geometry)
@@ -124,10 +130,10 @@ def read_plotfile(path: str, is_per=(0, 0, 0)) -> PlotfileData:
         hdr = next(it).split()
         ngrids = int(hdr[1])
         next(it)
-        for _ in range(3 * ngrids):
+        for _ in range(dim * ngrids):
             next(it)
         rel = next(it).strip()
-        d = [int(x) for x in doms[l]]
+        d = box6(doms[l])
         cell_h = os.path.join(path, rel + "_H")
         with open(cell_h) as f:
             txt = f.read()
@@ -135,7 +141,7 @@ def read_plotfile(path: str, is_per=(0, 0, 0)) -> PlotfileData:
         hl = head.split()
         nc_file = int(hl[2])
         blk = rest[: rest.index("FabOnDisk")]  # the BoxArray: "(n 0\n((lo) (hi) (0,0,0))\n...)\n n"
-        boxes = np.array([[int(x) for x in m[:6]] for m in _BOX_RE.findall(blk)], dtype=np.int32)
+        boxes = np.array([box6(m) for m in box_re.findall(blk)], dtype=np.int32)
         assert len(boxes) == ngrids and nc_file == ncomp
         fods = re.findall(r"FabOnDisk:\s*(\S+)\s+(\d+)", rest)
         lv = Level(boxes, d[0:3], d[3:6], is_per, prob_lo, prob_hi)
@@ -144,8 +150,8 @@ def read_plotfile(path: str, is_per=(0, 0, 0)) -> PlotfileData:
             with open(os.path.join(os.path.dirname(cell_h), fn), "rb") as f:
                 f.seek(int(off))
                 line = f.readline().decode()
-                m = _BOX_RE.findall(line)[-1]
-                flo, fhi = np.array([int(x) for x in m[0:3]]), np.array([int(x) for x in m[3:6]])
+                m = box6(box_re.findall(line)[-1])
+                flo, fhi = np.array(m[0:3]), np.array(m[3:6])
                 nc = int(line.strip().split()[-1])
                 n = fhi - flo + 1
                 data = np.frombuffer(f.read(8 * nc * int(n.prod())), dtype="<f8").reshape(nc, n[2], n[1], n[0])

@@ -231,34 +231,43 @@ inline std::string g17(double v) {
 // WriteMultiLevelPlotfile restated: valid cells of comps [0, names.size()) of each level's HostMF
 inline void write_plotfile(const std::string& path, const std::vector<std::string>& names, const std::vector<Box3>& domains,
                            const double prob_lo[3], const double prob_hi[3], std::vector<HostMF>& mf, double time,
-                           const std::vector<int>& level_steps, int ref_ratio = 2) {
+                           const std::vector<int>& level_steps, int ref_ratio = 2, int dim = 3, const std::vector<int>* comps = nullptr) {
+  // dim = 2: the levels are one plane of cells (k = 0) and the file is what a 2-D AMReX code writes; comps: the HostMF
+  // component behind each name (default: 0, 1, 2, ...)
   const int nlev = (int)mf.size(), ncomp = (int)names.size();
+  auto bstr = [dim](const Box3& b) {
+    if (dim == 3) return box_str(b);
+    char s[160];
+    std::snprintf(s, sizeof s, "((%d,%d) (%d,%d) (0,0))", b.lo[0], b.lo[1], b.hi[0], b.hi[1]);
+    return std::string(s);
+  };
+  auto src = [comps](int c) { return comps ? (*comps)[c] : c; };
   ::mkdir(path.c_str(), 0755);
   {
     std::ofstream f(path + "/Header");
     if (!f) Abort("Unable to create " + path + "/Header");
     f << "HyperCLaw-V1.1\n" << ncomp << "\n";
     for (auto& n : names) f << n << "\n";
-    f << "3\n" << g17(time) << "\n" << nlev - 1 << "\n";
-    for (int d = 0; d < 3; ++d) f << g17(prob_lo[d]) << ' ';
+    f << dim << "\n" << g17(time) << "\n" << nlev - 1 << "\n";
+    for (int d = 0; d < dim; ++d) f << g17(prob_lo[d]) << ' ';
     f << "\n";
-    for (int d = 0; d < 3; ++d) f << g17(prob_hi[d]) << ' ';
+    for (int d = 0; d < dim; ++d) f << g17(prob_hi[d]) << ' ';
     f << "\n";
     for (int l = 0; l < nlev - 1; ++l) f << ref_ratio << ' ';
     f << "\n";
-    for (int l = 0; l < nlev; ++l) f << box_str(domains[l]) << ' ';
+    for (int l = 0; l < nlev; ++l) f << bstr(domains[l]) << ' ';
     f << "\n";
     for (int l = 0; l < nlev; ++l) f << level_steps[l] << ' ';
     f << "\n";
     for (int l = 0; l < nlev; ++l) {
-      for (int d = 0; d < 3; ++d) f << g17((prob_hi[d] - prob_lo[d]) / (double)(domains[l].hi[d] - domains[l].lo[d] + 1)) << ' ';
+      for (int d = 0; d < dim; ++d) f << g17((prob_hi[d] - prob_lo[d]) / (double)(domains[l].hi[d] - domains[l].lo[d] + 1)) << ' ';
       f << "\n";
     }
     f << "0\n0\n";
     for (int l = 0; l < nlev; ++l) {
       f << l << ' ' << mf[l].boxes.size() << ' ' << g17(time) << "\n" << level_steps[l] << "\n";
       for (auto& B : mf[l].boxes)
-        for (int d = 0; d < 3; ++d) {
+        for (int d = 0; d < dim; ++d) {
           const double dx = (prob_hi[d] - prob_lo[d]) / (double)(domains[l].hi[d] - domains[l].lo[d] + 1);
           f << g17(prob_lo[d] + B.lo[d] * dx) << ' ' << g17(prob_lo[d] + (B.hi[d] + 1) * dx) << "\n";
         }
@@ -278,13 +287,13 @@ inline void write_plotfile(const std::string& path, const std::vector<std::strin
       for (size_t b = 0; b < M.boxes.size(); ++b) {
         offs.push_back((long long)f.tellp());
         const Box3& B = M.boxes[b];
-        f << "FAB ((8, (64 11 52 0 1 12 0 1023)),(8, (8 7 6 5 4 3 2 1)))" << box_str(B) << ' ' << ncomp << "\n";
+        f << "FAB ((8, (64 11 52 0 1 12 0 1023)),(8, (8 7 6 5 4 3 2 1)))" << bstr(B) << ' ' << ncomp << "\n";
         std::vector<double> mn(ncomp, 1e300), mx(ncomp, -1e300);
         const int nx = B.hi[0] - B.lo[0] + 1;
         for (int c = 0; c < ncomp; ++c)
           for (int k = B.lo[2]; k <= B.hi[2]; ++k)
             for (int j = B.lo[1]; j <= B.hi[1]; ++j) {
-              const double* p = M.ptr((int)b, c, B.lo[0], j, k);
+              const double* p = M.ptr((int)b, src(c), B.lo[0], j, k);
               f.write((const char*)p, sizeof(double) * (size_t)nx);
               for (int i = 0; i < nx; ++i) { mn[c] = std::min(mn[c], p[i]); mx[c] = std::max(mx[c], p[i]); }
             }
@@ -293,7 +302,7 @@ inline void write_plotfile(const std::string& path, const std::vector<std::strin
     }
     std::ofstream h(dir + "/Cell_H");
     h << "1\n1\n" << ncomp << "\n0\n(" << M.boxes.size() << " 0\n";
-    for (auto& B : M.boxes) h << box_str(B) << "\n";
+    for (auto& B : M.boxes) h << bstr(B) << "\n";
     h << ")\n" << M.boxes.size() << "\n";
     for (size_t b = 0; b < M.boxes.size(); ++b) h << "FabOnDisk: Cell_D_00000 " << offs[b] << "\n";
     h << "\n" << M.boxes.size() << "," << ncomp << "\n";

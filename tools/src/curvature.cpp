@@ -12,7 +12,15 @@
 // only under do_strain and then indexes whatever sits at idVst); do_smooth=1 [smoothing_time=1e-7] solves
 // the reference's composite implicit diffusion problem to its tolerance (1e-12) with BiCGStab instead of
 // AMReX's MLMG (pa_smooth_solve): same field to ~1e-12, not the same iteration history.
+// Built twice: curvature3d.ex, and with -DPA_SPACEDIM=2 curvature2d.ex = the AMREX_SPACEDIM == 2 build: 2-D plotfile in and
+// out, sym_dir / is_per of two entries, components [progressName, aux..., Progress, SmoothedProgress, MeanCurvature_<v>,
+// FlameNormalX/Y_<v>] (no Gaussian curvature in 2-D, curvature.cpp:208-226), MeanCurvature = d(nx)/dx + d(ny)/dy without
+// the 0.5 of the 3-D build (:542-546).  The level is one plane of cells with z a homogeneous-Neumann wall
+// (pa_curv_params.spacedim = 2); the options (do_strain, do_velnormal, do_smooth) are not available in this build.
 #include "../common/pa_device.h"
+#ifndef PA_SPACEDIM
+#define PA_SPACEDIM 3
+#endif
 
 int main(int argc, char** argv) {
   if (argc < 2) {
@@ -47,7 +55,10 @@ int main(int argc, char** argv) {
   pp.query("smoothing_time", smoothing_time);
   const int nAux = pp.countval("Aux_Variables");
   std::cout << "infile = " << infile << "\n" << "reading plt file = " << infile << "\n";
-  pa::PlotfileHeader H = pa::read_header(infile);
+  pa::PlotfileHeader H = pa::read_header(infile, PA_SPACEDIM);
+#if PA_SPACEDIM == 2
+  if (do_gaussCurv || do_strain || do_velnormal || do_smooth) pa::Abort("do_gaussCurv / do_strain / do_velnormal / do_smooth are not available in the 2-D build");
+#endif
   finestLevel = std::min(finestLevel, H.nlev - 1);
   const int Nlev = finestLevel + 1;
   const int idC = H.comp(progressName);
@@ -71,13 +82,30 @@ int main(int argc, char** argv) {
   }
   const int nCompIn = (int)inNames.size();
   const int idProg = nCompIn, idSmProg = idProg + 1, idKm = idSmProg + 1, idN = idKm + 1, idKg = idN + 3;
+#if PA_SPACEDIM == 2
+  int idSR = -1, idROST = -1, idVelNormal = -1, nCompOut = idN + 2;  // no GaussianCurvature slot (curvature.cpp:218-226)
+#else
   int idSR = -1, idROST = -1, idVelNormal = -1, nCompOut = idKg + 1;
+#endif
   if (do_strain) { idSR = idKg + 1; nCompOut = idSR + 1; }
   if (getStrainTensor) { idROST = nCompOut; nCompOut = idROST + 9; }
   if (do_velnormal) { idVelNormal = nCompOut; nCompOut += 1; }
   std::vector<int> sym_dir(3, 0), is_per(3, 1);
+#if PA_SPACEDIM == 2
+  is_per[2] = 0;  // the plane's normal: a wall with the default Neumann condition
+  for (const char* key : {"sym_dir", "is_per"}) {
+    std::vector<int> v2;
+    if (pp.countval(key)) {
+      pp.queryarr(key, v2, 0, 2);
+      std::vector<int>& dst = std::string(key) == "sym_dir" ? sym_dir : is_per;
+      dst[0] = v2[0];
+      dst[1] = v2[1];
+    }
+  }
+#else
   pp.queryarr("sym_dir", sym_dir, 0, 3);
   pp.queryarr("is_per", is_per, 0, 3);
+#endif
   int32_t bc[3];
   pa::bc_from_flags(is_per, sym_dir, bc);
   const bool options = do_gaussCurv || do_strain || do_velnormal || do_smooth;
@@ -120,6 +148,7 @@ int main(int argc, char** argv) {
   P.prog_min = progMin; P.prog_max = progMax; P.do_threshold = do_threshold; P.threshold = threshold; P.fused = fused;
   P.do_gauss_curv = do_gaussCurv; P.do_strain = do_strain; P.get_strain_tensor = getStrainTensor; P.do_velnormal = do_velnormal; P.vel_comp = idVst;
   P.do_smooth = do_smooth; P.smoothing_time = smoothing_time;
+  P.spacedim = PA_SPACEDIM;
   // result layout: fused sweep -> [gx gy gz |g| Nx Ny Nz K]; pass-by-pass with options -> [Progress K Nx Ny Nz Kg SR Vn ROSTx9]
   int rK, rN, rKg = -1, rSR = -1, rVn = -1, rROST = -1;
   if (options) {
@@ -148,7 +177,7 @@ int main(int argc, char** argv) {
           double* pr = ostate[lev].ptr((int)b, idProg, B.lo[0], j, k);
           for (size_t i = 0; i < nx; ++i) pr[i] = (sv[i] - progMin) * invdenom;  // curvature.cpp:319 (same fp order as the device)
           cp(idKm, rK, k, j);
-          for (int d = 0; d < 3; ++d) cp(idN + d, rN + d, k, j);
+          for (int d = 0; d < PA_SPACEDIM; ++d) cp(idN + d, rN + d, k, j);
           if (do_smooth) cp(idSmProg, 17, k, j);
           if (do_gaussCurv) cp(idKg, rKg, k, j);
           if (do_strain) cp(idSR, rSR, k, j);
@@ -165,8 +194,10 @@ int main(int argc, char** argv) {
   nnames[idKm] = "MeanCurvature_" + progressName;
   nnames[idN] = "FlameNormalX_" + progressName;
   nnames[idN + 1] = "FlameNormalY_" + progressName;
+#if PA_SPACEDIM == 3
   nnames[idN + 2] = "FlameNormalZ_" + progressName;
   nnames[idKg] = "GaussianCurvature_" + progressName;
+#endif
   if (do_strain) nnames[idSR] = "StrainRate_" + progressName;
   if (getStrainTensor) {
     const std::string dirChar[3] = {"x", "y", "z"};
@@ -175,6 +206,6 @@ int main(int argc, char** argv) {
   if (do_velnormal) nnames[idVelNormal] = "VelFlameNormal";
   std::cout << "Writing new data to " << outfile << "\n";
   std::vector<int> isteps(Nlev, 0);
-  pa::write_plotfile(outfile, nnames, doms, H.prob_lo, H.prob_hi, ostate, 0.0, isteps);
+  pa::write_plotfile(outfile, nnames, doms, H.prob_lo, H.prob_hi, ostate, 0.0, isteps, 2, PA_SPACEDIM);
   return 0;
 }

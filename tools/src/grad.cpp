@@ -3,7 +3,14 @@
 //             [is_per="1 1 1"] [outfile=<root>_gt]
 // Output plotfile components: [gradVar, aux..., <v>_gx, <v>_gy, <v>_gz, ||grad<v>||], time 0, steps 0,
 // ref ratio 2 (grad.cpp:241-257).  All arithmetic runs in libpeleanalysis_amd (HIP, gfx950).
+// Built twice: grad3d.ex, and with -DPA_SPACEDIM=2 grad2d.ex = the AMREX_SPACEDIM == 2 build: 2-D plotfile in and out,
+// sym_dir / is_per of two entries, components [gradVar, aux..., <v>_gx, <v>_gy, ||grad<v>||].  The 2-D level is handed
+// to the library as one plane of cells with z a homogeneous-Neumann wall: every z difference is an exact zero, so gx,
+// gy and sqrt(gx*gx + gy*gy + 0) are the 2-D values bit for bit.
 #include "../common/pa_device.h"
+#ifndef PA_SPACEDIM
+#define PA_SPACEDIM 3
+#endif
 
 static void print_usage(char** argv) {
   std::cerr << "usage:\n" << argv[0] << " infile=<plotfilename> \n\tOptions:\n\tis_per=<L M N> gradVar=<name>\n";
@@ -19,7 +26,7 @@ int main(int argc, char** argv) {
   pp.get("infile", infile);
   pp.query("gradVar", gradVar);
   pp.query("finestLevel", finestLevel);
-  pa::PlotfileHeader H = pa::read_header(infile);
+  pa::PlotfileHeader H = pa::read_header(infile, PA_SPACEDIM);
   finestLevel = std::min(finestLevel, H.nlev - 1);
   const int Nlev = finestLevel + 1;
   const int idC = H.comp(gradVar);
@@ -36,9 +43,23 @@ int main(int argc, char** argv) {
   }
   const int nCompIn = (int)inNames.size(), idGr = nCompIn, nCompOut = idGr + 4;
   std::vector<int> sym_dir(3, 0), is_per(3, 1);
+#if PA_SPACEDIM == 2
+  is_per[2] = 0;  // the plane's normal: a wall with the default Neumann condition
+  for (const char* key : {"sym_dir", "is_per"}) {
+    std::vector<int> v2;
+    if (pp.countval(key)) {
+      pp.queryarr(key, v2, 0, 2);
+      std::vector<int>& dst = std::string(key) == "sym_dir" ? sym_dir : is_per;
+      dst[0] = v2[0];
+      dst[1] = v2[1];
+    }
+  }
+  std::cout << "Periodicity assumed for this case: " << is_per[0] << " " << is_per[1] << " \n";
+#else
   pp.queryarr("sym_dir", sym_dir, 0, 3);
   pp.queryarr("is_per", is_per, 0, 3);
   std::cout << "Periodicity assumed for this case: " << is_per[0] << " " << is_per[1] << " " << is_per[2] << " \n";
+#endif
   int32_t bc[3];
   pa::bc_from_flags(is_per, sym_dir, bc);
 
@@ -66,12 +87,18 @@ int main(int argc, char** argv) {
   std::vector<std::string> nnames(inNames);
   nnames.push_back(gradVar + "_gx");
   nnames.push_back(gradVar + "_gy");
+  std::vector<int> ocomps;
+  for (int c = 0; c < nCompIn + 2; ++c) ocomps.push_back(c);
+#if PA_SPACEDIM == 3
   nnames.push_back(gradVar + "_gz");
+  ocomps.push_back(idGr + 2);
+#endif
   nnames.push_back("||grad" + gradVar + "||");
+  ocomps.push_back(idGr + 3);
   std::string outfile = pa::getFileRoot(infile) + "_gt";
   pp.query("outfile", outfile);
   std::cout << "Writing new data to " << outfile << std::endl;
   std::vector<int> isteps(Nlev, 0);
-  pa::write_plotfile(outfile, nnames, doms, H.prob_lo, H.prob_hi, state, 0.0, isteps);
+  pa::write_plotfile(outfile, nnames, doms, H.prob_lo, H.prob_hi, state, 0.0, isteps, 2, PA_SPACEDIM, &ocomps);
   return 0;
 }
