@@ -173,6 +173,9 @@ int pa_boxfilter_fab(pa_ctx*, pa_box valid, const pa_fab* in, pa_fab* out, int s
 int pa_box_filter_weights(int fgr, double* w);
 /* filterPlt.cpp:206-219, all boxes of a level */
 int pa_boxfilter_level(pa_ctx*, const pa_mf* in, pa_mf* out, int scomp, int ncomp, int ng, const double* w);
+/* the AMREX_SPACEDIM == 2 build of the same call on a level stored as one plane of cells (k = 0):
+ * out(i,j,c) = sum_m sum_l (w_l w_m) in(i+l, j+m, c) */
+int pa_boxfilter_level2d(pa_ctx*, const pa_mf* in, pa_mf* out, int scomp, int ncomp, int ng, const double* w);
 /* filterPlt.cpp:174-203 ghost fill pieces */
 int pa_foextrap(pa_ctx*, pa_mf*, int comp, int ncomp, int ng);
 int pa_fillpatch_two_levels(pa_ctx*, pa_mf* fine, const pa_mf* crse, int comp, int ncomp, int ng, int ratio,

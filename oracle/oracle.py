@@ -230,8 +230,10 @@ def curvature_pipeline(levels, states, comp, bc, outs, ocomp, MF, prog_min=None,
     return prog_min, prog_max
 
 
-def filter_pipeline(levels, ins, outs, ncomp, base_fgr=2, same_fgr_all_levels=False, ratio=2, interp_type=1, omp=False):
-    """filterPlt.cpp:126-219.  ins[l] must have ng >= fgr_l/2 ghost layers, valid cells filled."""
+def filter_pipeline(levels, ins, outs, ncomp, base_fgr=2, same_fgr_all_levels=False, ratio=2, interp_type=1, omp=False, spacedim=3):
+    """filterPlt.cpp:126-219.  ins[l] must have ng >= fgr_l/2 ghost layers, valid cells filled.
+    spacedim = 2: the 2-D build on a hierarchy stored as one plane of cells (ghost fill by the 3-D C pieces, whose z
+    terms vanish on such a hierarchy; the filter itself restated here in numpy over the plane)."""
     L = lib(omp)
     fgr = base_fgr
     info = []
@@ -246,6 +248,18 @@ def filter_pipeline(levels, ins, outs, ncomp, base_fgr=2, same_fgr_all_levels=Fa
             if nbad:
                 raise RuntimeError(f"fillpatch: {nbad} cells without coarse data")
         L.orc_foextrap(_p(_mf(ins[l])), 0, ncomp, ngf)
+        if spacedim == 2:  # (2 ng + 1)^2 taps in the plane: out += (w_l w_m) in(i+l, j+m), m outer, l inner
+            for b in range(levels[l].nboxes):
+                fi, fo = ins[l].fab(b), outs[l].valid(b)
+                g = ins[l].ng
+                nz, ny, nx = fo.shape[1:]
+                acc = np.zeros((ncomp, nz, ny, nx))
+                for m in range(2 * ngf + 1):
+                    for q in range(2 * ngf + 1):
+                        acc = acc + (w[q] * w[m]) * fi[:ncomp, g:g + nz, g + m - ngf:g + m - ngf + ny, g + q - ngf:g + q - ngf + nx]
+                fo[:ncomp] = acc
+            info.append((fgr, ngf))
+            continue
         wc = (C.c_double * len(w))(*w)
         L.orc_apply_filter(_p(_mf(ins[l])), _p(_mf(outs[l])), 0, ncomp, ngf, wc)
         info.append((fgr, ngf))

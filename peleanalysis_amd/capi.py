@@ -103,6 +103,7 @@ def load_library() -> C.CDLL:
         "pa_boxfilter_fab": (C.c_int, [vp, PaBox, C.POINTER(PaFab), C.POINTER(PaFab), C.c_int, C.c_int, C.c_int, pdbl]),
         "pa_box_filter_weights": (C.c_int, [C.c_int, pdbl]),
         "pa_boxfilter_level": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, pdbl]),
+        "pa_boxfilter_level2d": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, pdbl]),
         "pa_foextrap": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int]),
         "pa_fillpatch_two_levels": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
         "pa_mc_count_fab": (C.c_int, [vp, PaBox, C.POINTER(PaFab), C.POINTER(PaFab), C.c_int, dbl, C.POINTER(i64), C.POINTER(i64)]),

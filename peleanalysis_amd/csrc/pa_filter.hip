@@ -223,6 +223,42 @@ extern "C" int pa_boxfilter_level(pa_ctx* ctx, const pa_mf* in, pa_mf* out, int 
   return 0;
 }
 
+// 2-D build of Filter::apply_filter: out(i,j,c) = sum_m sum_l (w_l w_m) in(i+l, j+m, c) on a level stored as one plane
+// of cells (the z index is carried along untouched); thread per cell -- 2-D data is small next to the 3-D levels
+template <typename BP>
+__global__ __launch_bounds__(256) void k_boxfilter2d(BP bp, int scomp, int ncomp, int ng, FilterW W) {
+  FabView I, O;
+  DBox V;
+  double dxinv[3];
+  if (!bp.get(blockIdx.y, I, O, V, dxinv)) return;
+  int i, j, k0, k1;
+  if (!tile_cell(V, i, j, k0, k1)) return;
+  const int nw = 2 * ng + 1;
+  for (int c = scomp; c < scomp + ncomp; ++c)
+    for (int k = k0; k <= k1; ++k) {
+      double acc = 0.0;
+      for (int m = 0; m < nw; ++m)
+        for (int l = 0; l < nw; ++l) acc += (W.w[l] * W.w[m]) * I(i + l - ng, j + m - ng, k, c);
+      O(i, j, k, c) = acc;
+    }
+}
+
+extern "C" int pa_boxfilter_level2d(pa_ctx* ctx, const pa_mf* in, pa_mf* out, int scomp, int ncomp, int ng, const double* w) {
+  if (!ctx || !in || !out || !w) return pa_fail(ctx, "pa_boxfilter_level2d: null argument");
+  if (in->lev != out->lev) return pa_fail(ctx, "pa_boxfilter_level2d: different levels");
+  if (ng < 0 || ng > 16 || ng > in->ng) return pa_fail(ctx, "pa_boxfilter_level2d: input has fewer ghost cells than the filter half-width");
+  if (scomp < 0 || ncomp < 1 || scomp + ncomp > in->ncomp || scomp + ncomp > out->ncomp) return pa_fail(ctx, "pa_boxfilter_level2d: component range");
+  FilterW W;
+  for (int q = 0; q < 2 * ng + 1; ++q) W.w[q] = w[q];
+  const pa_level* L = in->lev;
+  LevelBP2 bp{L->view, in->view, out->view};
+  ProfScope prof(ctx, PA_TAG_FILTER);
+  hipLaunchKernelGGL(k_boxfilter2d<LevelBP2>, tile_grid_dims(L->maxn[0], L->maxn[1], L->maxn[2], (unsigned)L->boxes.size()), dim3(256), 0, ctx->stream, bp, scomp,
+                     ncomp, ng, W);
+  PA_HIP(hipGetLastError());
+  return 0;
+}
+
 extern "C" int pa_boxfilter_fab(pa_ctx* ctx, pa_box valid, const pa_fab* in, pa_fab* out, int scomp, int ncomp, int ng, const double* w) {
   if (!ctx || !in || !out || !w) return pa_fail(ctx, "pa_boxfilter_fab: null argument");
   if (ng < 0 || ng > 16) return pa_fail(ctx, "pa_boxfilter_fab: filter half-width out of range");

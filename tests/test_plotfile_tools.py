@@ -517,3 +517,35 @@ def test_grad2d_and_curvature2d_tools(tmp_path, oracle, per):
     assert nz > 200
     bad = subprocess.run([os.path.join(BIN, "curvature2d.ex"), "infile=" + p, "progressName=temp", "do_strain=1"], cwd=tmp_path, capture_output=True, text=True)
     assert bad.returncode != 0 and "2-D build" in bad.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("per,interp", [((1, 0), 1), ((0, 0), 0)])
+def test_filterplt2d_tool(tmp_path, oracle, per, interp):
+    """filterPlt2d.ex (the AMREX_SPACEDIM == 2 build): 9 taps on level 0, 25 on level 1; identical to the oracle's ghost
+    fill on the one-plane hierarchy followed by a numpy restatement of the 2-D tap loop"""
+    H = _hier2d(per)
+    mfs = make_states(H, 2, 0, _flame2d, seed=6)
+    p = str(tmp_path / "pf2")
+    write_plotfile(p, H, mfs, ["temp", "density"], time=0.75, level_steps=[2, 2], dim=2)
+    _run("filterPlt2d.ex", ["infile=" + p, "base_fgr=2", "max_grid_size=16", "interp_type=%d" % interp, "is_per=%d %d" % per], tmp_path)
+    r = read_plotfile(str(tmp_path / "pf2_filtered"))
+    assert r.names == ["temp", "density"] and r.time == 0.75
+    ins = [MultiFab(lv, 2, 2, fill=0.0) for lv in H.levels]
+    for l, lv in enumerate(H.levels):
+        for b in range(lv.nboxes):
+            ins[l].valid(b)[:] = mfs[l].valid(b)
+    outs = [MultiFab(lv, 2, 0) for lv in H.levels]
+    info = oracle.filter_pipeline(H.levels, ins, outs, 2, base_fgr=2, interp_type=interp, spacedim=2)
+    assert info == [(2, 1), (4, 2)]
+    for l, lv in enumerate(H.levels):
+        assert np.array_equal(r.hier.levels[l].boxes, lv.boxes)
+        for b in range(lv.nboxes):
+            assert np.array_equal(np.ascontiguousarray(r.mfs[l].valid(b)).view(np.int64), np.ascontiguousarray(outs[l].valid(b)).view(np.int64)), (l, b)
+    # a constant stays a constant exactly (dyadic box weights)
+    cm = make_states(H, 1, 0, lambda x, y, z, c: 7.0 + 0 * x + 0 * y + 0 * z)
+    pc = str(tmp_path / "pc2")
+    write_plotfile(pc, H, cm, ["c"], dim=2)
+    _run("filterPlt2d.ex", ["infile=" + pc, "is_per=%d %d" % per], tmp_path)
+    rc = read_plotfile(str(tmp_path / "pc2_filtered"))
+    assert all((rc.mfs[l].data == 7.0).all() for l in range(2))

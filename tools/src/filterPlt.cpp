@@ -4,7 +4,12 @@
 // Output: <root>_filtered, same variable names, plotfile time (filterPlt.cpp:222-225).
 // The plotfile Header stores no periodicity; like PltFileManager's Geometry it defaults to
 // non-periodic unless is_per / geometry.is_periodic is given.
+// Built twice: filterPlt3d.ex, and with -DPA_SPACEDIM=2 filterPlt2d.ex = the AMREX_SPACEDIM == 2 build (2-D plotfile in and
+// out, is_per of two entries, (2 ng + 1)^2 taps; the level is one plane of cells with z a wall direction).
 #include "../common/pa_device.h"
+#ifndef PA_SPACEDIM
+#define PA_SPACEDIM 3
+#endif
 
 int main(int argc, char** argv) {
   pa::ParmParse pp(argc, argv);
@@ -25,8 +30,17 @@ int main(int argc, char** argv) {
   if (filter_type != 1) pa::Abort("only filter_type=1 (box) is available in this build");
   if (fgr != 1 && fgr % 2 != 0) pa::Abort("Box filter requires an even filter-to-grid ratio");
   std::vector<int> is_per(3, 0);
+#if PA_SPACEDIM == 2
+  {
+    std::vector<int> p2(2, 0);
+    if (!pp.queryarr("is_per", p2, 0, 2)) pp.queryarr("geometry.is_periodic", p2, 0, 2);
+    is_per[0] = p2[0];
+    is_per[1] = p2[1];
+  }
+#else
   if (!pp.queryarr("is_per", is_per, 0, 3)) pp.queryarr("geometry.is_periodic", is_per, 0, 3);
-  pa::PlotfileHeader H = pa::read_header(infile);
+#endif
+  pa::PlotfileHeader H = pa::read_header(infile, PA_SPACEDIM);
   const int Nlev = std::min(finestLevel + 1, H.nlev);
   std::vector<std::string> names;
   std::vector<int> comps;
@@ -76,7 +90,11 @@ int main(int argc, char** argv) {
   std::cout << "Done!" << std::endl << "Filtering data..." << std::endl;
   for (int lev = 0; lev < Nlev; ++lev) {
     std::cout << "on level " << lev << std::endl;
+#if PA_SPACEDIM == 2
+    ctx.check(pa_boxfilter_level2d(ctx.h, din[lev]->h, dout[lev]->h, 0, ncomp, ngs[lev], ws[lev].data()));
+#else
     ctx.check(pa_boxfilter_level(ctx.h, din[lev]->h, dout[lev]->h, 0, ncomp, ngs[lev], ws[lev].data()));
+#endif
   }
   ctx.check(pa_sync(ctx.h));
   if (pa_bc_errors(ctx.h) != 0) pa::Abort("FillPatchTwoLevels: fine grids are not properly nested in the coarse level");
@@ -86,7 +104,7 @@ int main(int argc, char** argv) {
     ctx.check(pa_mf_download(ctx.h, dout[lev]->h, out[lev].data.data()));
   }
   std::vector<int> steps(Nlev, 0);
-  pa::write_plotfile(pa::getFileRoot(infile) + "_filtered", names, doms, H.prob_lo, H.prob_hi, out, H.time, steps);
+  pa::write_plotfile(pa::getFileRoot(infile) + "_filtered", names, doms, H.prob_lo, H.prob_hi, out, H.time, steps, 2, PA_SPACEDIM);
   std::cout << "Done!" << std::endl;
   return 0;
 }
