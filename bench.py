@@ -60,8 +60,23 @@ def fill_level_on_device(torch, level, buf, ncomp, ng, off, cs, dev, seed):
             buf[off[b] + c * cs[b]: off[b] + c * cs[b] + n] = v.reshape(-1)
 
 
+def usable_cpus():
+    """CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota (a GPU box hands a 16-CPU share
+    of a 256-thread host to a 1-GPU job; OpenMP would otherwise start 256 threads on 16 CPUs' worth of time)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(base, nlev, box):
     """Oracle (kind 'port') timed on the host cores: same pipeline, smaller hierarchy of the same shape."""
+    cores = usable_cpus()
+    os.environ["OMP_NUM_THREADS"] = str(cores)  # before the OpenMP build of the oracle is loaded
     from oracle import oracle as O
     from peleanalysis_amd.hierarchy import MultiFab, fill_analytic, nested_hierarchy, field_flame
     O.build()
@@ -83,7 +98,7 @@ def cpu_baseline(base, nlev, box):
         dt = time.perf_counter() - t0
         if dt >= 12.0 or reps >= 16:
             break
-    return {"value": cells * reps / dt / 1e6, "unit": "Mcells/s", "cores": os.cpu_count(), "kind": "port",
+    return {"value": cells * reps / dt / 1e6, "unit": "Mcells/s", "cores": cores, "kind": "port",
             "sample": f"oracle grad+curvature pipelines (C restatement, OpenMP over boxes), {nlev}-level base {base}^3, {box}^3 boxes, "
                       f"{cells} cells, 1 comp, {reps} passes, {dt:.1f} s"}
 
@@ -250,8 +265,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu:
         try:
             # bounded sample (~10-30 s of CPU work): a 3-level hierarchy sized from the host core count
-            cores = os.cpu_count() or 1
-            base = args.cpu_base or (256 if cores >= 64 else (128 if cores >= 8 else 64))
+            cores = usable_cpus()
+            base = args.cpu_base or (256 if cores >= 16 else (128 if cores >= 8 else 64))
             res["cpu_baseline"] = cpu_baseline(base, args.nlev, max(base // 4, 8))
         except Exception as e:  # the baseline is reported, never required for the GPU number
             res["cpu_baseline"] = {"error": repr(e)}
