@@ -217,6 +217,15 @@ int pa_msq_level(pa_ctx*, const pa_mf* state, const pa_mf* mask, int mcomp, cons
                  int isocomp, double isoval, int64_t* nvert /* host [nboxes] */, int64_t* nseg /* host [nboxes] */,
                  double** dev_verts /* [sum nvert][ncomp] */, int32_t** dev_vkeys /* [sum nvert][6] */,
                  int32_t** dev_segs /* [sum nseg][3] */);
+/* The same two calls with the mask of isosurface.cpp:1540-1563 evaluated inside the cell pass instead of read from a
+ * multifab: a cell is masked iff its refined image has an owner on `fine` (periodic images included; fine = NULL:
+ * nothing is masked, as when the distance function is built).  Halves the bytes the pass reads. */
+int pa_mc_level_fine(pa_ctx*, const pa_mf* state, const pa_level* fine, int ratio, const pa_box* loops, int isocomp,
+                     double isoval, int64_t* nvert, int64_t* ntri, double** dev_verts, int32_t** dev_vkeys,
+                     int32_t** dev_tris);
+int pa_msq_level_fine(pa_ctx*, const pa_mf* state, const pa_level* fine, int ratio, const pa_box* loops, int isocomp,
+                      double isoval, int64_t* nvert, int64_t* nseg, double** dev_verts, int32_t** dev_vkeys,
+                      int32_t** dev_segs);
 const uint16_t* pa_mc_edge_table(void); /* [256] host */
 const int8_t*   pa_mc_tri_table(void);  /* [256][16] host */
 

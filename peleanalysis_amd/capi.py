@@ -110,6 +110,10 @@ def load_library() -> C.CDLL:
         "pa_mc_emit_fab": (C.c_int, [vp, PaBox, C.POINTER(PaFab), C.POINTER(PaFab), C.c_int, dbl, vp, vp, vp, i64, i64]),
         "pa_iso_mask_level": (C.c_int, [vp, vp, C.c_int, vp, C.c_int]),
         "pa_iso_coords_level": (C.c_int, [vp, vp, C.c_int]),
+        "pa_mc_level_fine": (C.c_int, [vp, vp, vp, C.c_int, C.POINTER(PaBox), C.c_int, dbl, C.POINTER(i64), C.POINTER(i64), C.POINTER(vp), C.POINTER(vp),
+                                       C.POINTER(vp)]),
+        "pa_msq_level_fine": (C.c_int, [vp, vp, vp, C.c_int, C.POINTER(PaBox), C.c_int, dbl, C.POINTER(i64), C.POINTER(i64), C.POINTER(vp), C.POINTER(vp),
+                                        C.POINTER(vp)]),
         "pa_msq_level": (C.c_int, [vp, vp, vp, C.c_int, C.POINTER(PaBox), C.c_int, dbl, C.POINTER(i64), C.POINTER(i64), C.POINTER(vp), C.POINTER(vp),
                                    C.POINTER(vp)]),
         "pa_mc_level": (C.c_int, [vp, vp, vp, C.c_int, C.POINTER(PaBox), C.c_int, dbl, C.POINTER(i64), C.POINTER(i64), C.POINTER(vp), C.POINTER(vp),
@@ -389,8 +393,12 @@ def mc_level(ctx: Context, state: "DevMF", mask: "DevMF", loops, isocomp: int, i
             arr[b].lo[d], arr[b].hi[d] = int(loops[b, d]), int(loops[b, 3 + d])
     nv, nt = (C.c_int64 * max(nb, 1))(), (C.c_int64 * max(nb, 1))()
     pv, pk, pt = C.c_void_p(), C.c_void_p(), C.c_void_p()
-    fn = ctx.lib.pa_msq_level if squares else ctx.lib.pa_mc_level
-    ctx.check(fn(ctx.h, state.h, mask.h, mcomp, arr, isocomp, isoval, nv, nt, C.byref(pv), C.byref(pk), C.byref(pt)))
+    if mask is None or isinstance(mask, DevLevel):  # mask evaluated in the cell pass from the finer level (or nothing masked)
+        fn = ctx.lib.pa_msq_level_fine if squares else ctx.lib.pa_mc_level_fine
+        ctx.check(fn(ctx.h, state.h, mask.h if mask is not None else None, 2, arr, isocomp, isoval, nv, nt, C.byref(pv), C.byref(pk), C.byref(pt)))
+    else:
+        fn = ctx.lib.pa_msq_level if squares else ctx.lib.pa_mc_level
+        ctx.check(fn(ctx.h, state.h, mask.h, mcomp, arr, isocomp, isoval, nv, nt, C.byref(pv), C.byref(pk), C.byref(pt)))
     nc = state.ncomp
     tv, tt = int(sum(nv[:nb])), int(sum(nt[:nb]))
     try:

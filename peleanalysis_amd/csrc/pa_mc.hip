@@ -378,6 +378,8 @@ struct MclArgs {
   DLevelView L;
   DMFView S, M;
   int mcomp, isocomp, ncomp, kseg;
+  int nomask, has_fine, ratio;  // nomask: no mask multifab -- a cell is masked iff the next finer level LF covers it
+  DLevelView LF;
   int dim2;                // marching squares on the plane k = loops[b].lo[2] (isosurface.cpp:303-406), see below
   double iso;
   const DBox* loops;       // [nboxes] cube base points, lo > hi: FAB skipped
@@ -466,9 +468,9 @@ __global__ __launch_bounds__(64 * TY) void k_mcl_cells(MclArgs A) {
   const bool own = i < nx && j < ny && (lx < 63 || i == nx - 1) && (ly < TY - 1 || j == ny - 1);
   const int k0 = tz * A.kseg, k1 = min(k0 + A.kseg, nz) - 1;
   const long long nxy = (long long)nx * ny;
-  const long long cs = pa_cstride((long long)G.ncell, A.S.ncomp), cm = pa_cstride((long long)G.ncell, A.M.ncomp);
+  const long long cs = pa_cstride((long long)G.ncell, A.S.ncomp), cm = A.nomask ? 0 : pa_cstride((long long)G.ncell, A.M.ncomp);
   const double* sp = A.S.data + A.S.off[b] + (long long)A.isocomp * cs + ((long long)jc * nx + ic);
-  const double* mp = A.M.data + A.M.off[b] + (long long)A.mcomp * cm + ((long long)jc * nx + ic);
+  const double* mp = A.nomask ? sp : A.M.data + A.M.off[b] + (long long)A.mcomp * cm + ((long long)jc * nx + ic);
   const double iso = A.iso;
   __shared__ unsigned char sf[2][TY][64];
   const int lx1 = min(lx + 1, 63), ly1 = min(ly + 1, TY - 1);
@@ -493,7 +495,19 @@ __global__ __launch_bounds__(64 * TY) void k_mcl_cells(MclArgs A) {
     for (int q = 0; q < P; ++q) {
       const long long o = (long long)min(kb + q, nz - 1) * nxy;
       sv[q] = sp[o];
-      mv[q] = mp[o];
+      if (A.nomask) {  // isosurface.cpp:1540-1563 evaluated in place: -1 where the refined cell has an owner on the finer level
+        double m = 1.0;
+        if (A.has_fine) {
+          int p[3] = {(G.slo[0] + ic) * A.ratio, (G.slo[1] + jc) * A.ratio, (G.slo[2] + min(kb + q, nz - 1)) * A.ratio};
+          if (wrap_cell(A.LF, p)) {
+            const int ow = owner_of(A.LF, p);
+            if (ow >= 0 || ow == -2) m = -1.0;
+          }
+        }
+        mv[q] = m;
+      } else {
+        mv[q] = mp[o];
+      }
     }
   };
   int cur = 0, par = 0;
@@ -784,7 +798,19 @@ extern "C" int pa_iso_mask_level(pa_ctx* ctx, pa_mf* mask, int comp, const pa_le
 }
 
 static int mc_level_impl(pa_ctx* ctx, const pa_mf* state, const pa_mf* mask, int mcomp, const pa_box* loops, int isocomp, double isoval, int64_t* nvert,
-                         int64_t* ntri, double** dev_verts, int32_t** dev_vkeys, int32_t** dev_tris, int dim2);
+                         int64_t* ntri, double** dev_verts, int32_t** dev_vkeys, int32_t** dev_tris, int dim2, int nomask = 0, const pa_level* fine = nullptr,
+                         int ratio = 2);
+// mask of isosurface.cpp:1540-1563 evaluated inside the cell pass (no mask multifab: half the bytes of the pass)
+extern "C" int pa_mc_level_fine(pa_ctx* ctx, const pa_mf* state, const pa_level* fine, int ratio, const pa_box* loops, int isocomp, double isoval,
+                                int64_t* nvert, int64_t* ntri, double** dev_verts, int32_t** dev_vkeys, int32_t** dev_tris) {
+  if (fine && ratio < 1) return pa_fail(ctx, "pa_mc_level_fine: bad refinement ratio");
+  return mc_level_impl(ctx, state, state, 0, loops, isocomp, isoval, nvert, ntri, dev_verts, dev_vkeys, dev_tris, 0, 1, fine, ratio);
+}
+extern "C" int pa_msq_level_fine(pa_ctx* ctx, const pa_mf* state, const pa_level* fine, int ratio, const pa_box* loops, int isocomp, double isoval,
+                                 int64_t* nvert, int64_t* nseg, double** dev_verts, int32_t** dev_vkeys, int32_t** dev_segs) {
+  if (fine && ratio < 1) return pa_fail(ctx, "pa_msq_level_fine: bad refinement ratio");
+  return mc_level_impl(ctx, state, state, 0, loops, isocomp, isoval, nvert, nseg, dev_verts, dev_vkeys, dev_segs, 1, 1, fine, ratio);
+}
 extern "C" int pa_mc_level(pa_ctx* ctx, const pa_mf* state, const pa_mf* mask, int mcomp, const pa_box* loops, int isocomp, double isoval,
                            int64_t* nvert, int64_t* ntri, double** dev_verts, int32_t** dev_vkeys, int32_t** dev_tris) {
   return mc_level_impl(ctx, state, mask, mcomp, loops, isocomp, isoval, nvert, ntri, dev_verts, dev_vkeys, dev_tris, 0);
@@ -794,7 +820,7 @@ extern "C" int pa_msq_level(pa_ctx* ctx, const pa_mf* state, const pa_mf* mask, 
   return mc_level_impl(ctx, state, mask, mcomp, loops, isocomp, isoval, nvert, nseg, dev_verts, dev_vkeys, dev_segs, 1);
 }
 static int mc_level_impl(pa_ctx* ctx, const pa_mf* state, const pa_mf* mask, int mcomp, const pa_box* loops, int isocomp, double isoval, int64_t* nvert,
-                         int64_t* ntri, double** dev_verts, int32_t** dev_vkeys, int32_t** dev_tris, int dim2) {
+                         int64_t* ntri, double** dev_verts, int32_t** dev_vkeys, int32_t** dev_tris, int dim2, int nomask, const pa_level* fine, int ratio) {
   if (!ctx || !state || !mask || !loops || !nvert || !ntri || !dev_verts || !dev_vkeys || !dev_tris) return pa_fail(ctx, "pa_mc_level: null argument");
   *dev_verts = nullptr; *dev_vkeys = nullptr; *dev_tris = nullptr;
   if (state->lev != mask->lev || state->ng != mask->ng) return pa_fail(ctx, "pa_mc_level: state and mask must share the level and the ghost width");
@@ -838,6 +864,10 @@ static int mc_level_impl(pa_ctx* ctx, const pa_mf* state, const pa_mf* mask, int
   A.mcomp = mcomp; A.isocomp = isocomp; A.ncomp = state->ncomp; A.iso = isoval;
   A.kseg = 32;
   A.dim2 = dim2;
+  A.nomask = nomask;
+  A.has_fine = (nomask && fine) ? 1 : 0;
+  A.ratio = ratio;
+  A.LF = fine ? fine->view : L->view;
   A.tot = (long long*)p; p += 16 * (size_t)nb;
   long long* d_base = (long long*)p; p += 16 * (size_t)nb;
   long long* d_coff = (long long*)p; p += 8 * ((size_t)nb + 1);

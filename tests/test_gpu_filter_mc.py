@@ -201,6 +201,9 @@ def test_marching_cubes_level_batched_matches_oracle(ctx, oracle, name, ng):
                 continue
             want.append(oracle.mc_fab(np.ascontiguousarray(states[l].fab(b)), mask, lo, hi, 3, iso, llo, lhi))
         got = capi.mc_level(ctx, dst, dmask, loops, 3, iso)
+        got_fine = capi.mc_level(ctx, dst, dls[l + 1] if l + 1 < H.nlev else None, loops, 3, iso)  # mask evaluated in the cell pass
+        for (a1, a2, a3), (b1, b2, b3) in zip(got, got_fine):
+            assert np.array_equal(a1.view(np.int64), b1.view(np.int64)) and np.array_equal(a2, b2) and np.array_equal(a3, b3), "pa_mc_level_fine differs"
         for b in range(lv.nboxes):
             (v, k, t), (gv, gk, gt) = want[b], got[b]
             assert (len(gv), len(gt)) == (len(v), len(t)), f"{name} level {l} box {b}: counts differ"
@@ -262,6 +265,9 @@ def test_marching_squares_level_matches_oracle(ctx, oracle, per):
         if l == 0:
             assert sum((w[1].size > 0) for w in want) > 0 and any((gmask.fab(b)[0, ng] < 0).any() for b in range(lv.nboxes))
         got = capi.mc_level(ctx, dst, dmask, loops, 2, iso, squares=True)
+        got_fine = capi.mc_level(ctx, dst, dls[l + 1] if l + 1 < H.nlev else None, loops, 2, iso, squares=True)
+        for (a1, a2, a3), (b1, b2, b3) in zip(got, got_fine):
+            assert np.array_equal(a1.view(np.int64), b1.view(np.int64)) and np.array_equal(a2, b2) and np.array_equal(a3, b3), "pa_msq_level_fine differs"
         for b in range(lv.nboxes):
             (v, k, sg), (gv, gk, gt) = want[b], got[b]
             assert (len(gv), len(gt)) == (len(v), len(sg)), f"level {l} box {b}: counts differ"

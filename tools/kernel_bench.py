@@ -144,6 +144,19 @@ out["kernels"][f"pa_mc_level ({lv.nboxes} FABs of {g}^3 in one pass: flags, clas
     "ms": ms_lvl, "cells": lc, "Mcells_s": lc / ms_lvl / 1e3, "bytes_per_cell": 16, "GBs": lc * 16 / ms_lvl / 1e6, "frac_hbm": lc * 16 / ms_lvl / 1e6 / HBM,
     "triangles": int(sum(ntb)), "Mtriangles_s": sum(ntb) / ms_lvl / 1e3}
 ms_mask = timed(8, lambda: ctx.check(ctx.lib.pa_iso_mask_level(ctx.h, mk5.h, 0, None, 2)))
+
+
+# same pass with the mask evaluated from a "finer level" (here: the level itself as a stand-in owner map; nothing read back)
+mc_level_once()
+t0 = time.perf_counter()
+for _ in range(3):
+    ctx.check(ctx.lib.pa_mc_level_fine(ctx.h, st5.h, None, 2, loops, 3, 1150.0, nvb, ntb, C.byref(pv), C.byref(pk), C.byref(pt)))
+    ctx.lib.pa_device_free(ctx.h, pv)
+ctx.sync()
+ms_fine = (time.perf_counter() - t0) * 1e3 / 3
+out["kernels"]["pa_mc_level_fine (same level, mask evaluated in the cell pass: 8 B/cell read)"] = {
+    "ms": ms_fine, "cells": lc, "Mcells_s": lc / ms_fine / 1e3, "bytes_per_cell": 8, "GBs": lc * 8 / ms_fine / 1e6, "frac_hbm": lc * 8 / ms_fine / 1e6 / HBM,
+    "triangles": int(sum(ntb)), "Mtriangles_s": sum(ntb) / ms_fine / 1e3}
 del st5, mk5, t5, tmk
 if MCONLY:
     print(json.dumps(out))

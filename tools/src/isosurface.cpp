@@ -140,9 +140,7 @@ int main(int argc, char** argv) {
     }
     // fine-covered mask (isosurface.cpp:1540-1563; all 1 when building the distance function, :1542) and the whole
     // MFIter loop of :1531-1592 as one batch per level
-    pa::DevMF dmask(ctx, *dl[lev], 1, ng);
     const bool fine_mask = lev < finestLevel && !build_distance_function;
-    ctx.check(pa_iso_mask_level(ctx.h, dmask.h, 0, fine_mask ? dl[lev + 1]->h : nullptr, 2));
     const size_t nb = L.boxes.size();
     std::vector<pa_box> loops(nb);
     for (size_t b = 0; b < nb; ++b) {  // base points: (grown box & domain grown in the periodic directions), high side - 1 (isosurface.cpp:1566-1569)
@@ -156,7 +154,8 @@ int main(int argc, char** argv) {
     std::vector<int64_t> nvb(nb, 0), ntb(nb, 0);
     double* dv = nullptr;
     int32_t *dk = nullptr, *dt = nullptr;
-    ctx.check(pa_mc_level(ctx.h, dst[lev]->h, dmask.h, 0, loops.data(), 3 + isoComp, isoVal, nvb.data(), ntb.data(), &dv, &dk, &dt));
+    ctx.check(pa_mc_level_fine(ctx.h, dst[lev]->h, fine_mask ? dl[lev + 1]->h : nullptr, 2, loops.data(), 3 + isoComp, isoVal, nvb.data(), ntb.data(), &dv, &dk,
+                               &dt));
     int64_t nvt = 0, ntt = 0;
     for (size_t b = 0; b < nb; ++b) { nvt += nvb[b]; ntt += ntb[b]; }
     std::vector<double> hva((size_t)(nvt * nc));

@@ -5,7 +5,7 @@
 //       [rm_external_elements=1] [nGrow=1] [is_per="0 0"] [writeSurf=1] [outfile_base=<infile>_<comp>_<isoVal>] [verbose=0]
 // The plotfile's plane of cells is handed to the library as boxes with k = 0; the state holds 2 coordinate components
 // + the mapped ones; ghost fill, fine-covered mask and the per-FAB loop are the 3-D tool's (tools/src/isosurface.cpp)
-// with pa_msq_level in place of pa_mc_level.  build_distance_function aborts as in the reference (:1364-1366);
+// with pa_msq_level_fine in place of pa_mc_level_fine.  build_distance_function aborts as in the reference (:1364-1366);
 // surfFormat=XDMF is not available in this build.
 #include "../common/pa_device.h"
 #include "../common/pa_isomerge.h"
@@ -162,8 +162,6 @@ int main(int argc, char** argv) {
   pa::IsoMerger merger(nc, 2);
   for (int lev = 0; lev < Nlev; ++lev) {
     const auto& L = H.lev[lev];
-    pa::DevMF dmask(ctx, *dl[lev], 1, ng);
-    ctx.check(pa_iso_mask_level(ctx.h, dmask.h, 0, lev < finestLevel ? dl[lev + 1]->h : nullptr, 2));
     const size_t nb = L.boxes.size();
     std::vector<pa_box> loops(nb);
     for (size_t b = 0; b < nb; ++b) {  // (grown box & domain grown in the periodic directions), high side - 1 (:1566-1569)
@@ -178,7 +176,8 @@ int main(int argc, char** argv) {
     std::vector<int64_t> nvb(nb, 0), nsb(nb, 0);
     double* dv = nullptr;
     int32_t *dk = nullptr, *ds = nullptr;
-    ctx.check(pa_msq_level(ctx.h, dst[lev]->h, dmask.h, 0, loops.data(), 2 + isoComp, isoVal, nvb.data(), nsb.data(), &dv, &dk, &ds));
+    ctx.check(pa_msq_level_fine(ctx.h, dst[lev]->h, lev < finestLevel ? dl[lev + 1]->h : nullptr, 2, loops.data(), 2 + isoComp, isoVal, nvb.data(), nsb.data(), &dv,
+                                &dk, &ds));
     int64_t nvt = 0, nst = 0;
     for (size_t b = 0; b < nb; ++b) { nvt += nvb[b]; nst += nsb[b]; }
     std::vector<double> hva((size_t)(nvt * nc));
