@@ -61,9 +61,19 @@ class IsoMerger {
     const double pz = dim_ == 3 ? p[2] : 0.0;
     const Key g{(long long)std::floor(p[0] / H), (long long)std::floor(p[1] / H), (long long)std::floor(pz / H)};
     int32_t best = -1;
-    for (int dz = -1; dz <= 1; ++dz)
-      for (int dy = -1; dy <= 1; ++dy)
-        for (int dx = -1; dx <= 1; ++dx) {
+    // a node within EPS of p sits in p's hash cell, or in the neighbour across a face p is within EPS of (H = 10 EPS):
+    // the other neighbours cannot hold one, so they are not looked up (27 lookups -> 1 for almost every node)
+    const double pp[3] = {p[0], p[1], pz};
+    const long long gg[3] = {g.x, g.y, g.z};
+    int lo[3], hi[3];
+    for (int d = 0; d < 3; ++d) {
+      const double r = pp[d] - (double)gg[d] * H;  // position inside the cell, up to rounding of the product
+      lo[d] = (r < 2 * EPS) ? -1 : 0;
+      hi[d] = (r > H - 2 * EPS) ? 1 : 0;
+    }
+    for (int dz = lo[2]; dz <= hi[2]; ++dz)
+      for (int dy = lo[1]; dy <= hi[1]; ++dy)
+        for (int dx = lo[0]; dx <= hi[0]; ++dx) {
           if (dim_ == 2 && dz != 0) continue;
           auto it = grid_.find(Key{g.x + dx, g.y + dy, g.z + dz});
           if (it == grid_.end()) continue;

@@ -59,14 +59,14 @@ struct HostMF {
   int ncomp = 0, ng = 0;
   std::vector<int64_t> off, cs;
   std::vector<double> data;
-  void define(const std::vector<Box3>& b, int nc, int g) {
+  void define(const std::vector<Box3>& b, int nc, int g, double fill = 0.0) {
     boxes = b; ncomp = nc; ng = g;
     std::vector<int32_t> b6(6 * b.size());
     for (size_t i = 0; i < b.size(); ++i)
       for (int d = 0; d < 3; ++d) { b6[6 * i + d] = b[i].lo[d]; b6[6 * i + 3 + d] = b[i].hi[d]; }
     off.resize(b.size()); cs.resize(b.size());
     const int64_t tot = pa_mf_layout((int)b.size(), b6.data(), nc, g, off.data(), cs.data());
-    data.assign((size_t)tot, 0.0);
+    data.assign((size_t)tot, fill);
   }
   double* ptr(int b, int c, int i, int j, int k) {
     const Box3& B = boxes[b];

@@ -22,10 +22,10 @@ print(f"synthetic plotfile: base {base}^3, 3 levels, {box}^3 boxes, {sum(l.ncell
 exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "bin", "isosurface3d.ex")
 for rep in range(2):
     t0 = time.perf_counter()
-    out = subprocess.run([exe, "infile=" + p, "isoCompName=temp", "isoVal=1150", "comps=0 1 2"], capture_output=True, text=True)
+    out = subprocess.run([exe, "infile=" + p, "isoCompName=temp", "isoVal=1150", "comps=0 1 2", "verbose=1"], capture_output=True, text=True)
     dt = time.perf_counter() - t0
     assert out.returncode == 0, out.stderr
     print(f"run {rep}: wall {dt:.2f} s")
     for ln in out.stdout.splitlines():
-        if "time" in ln or "Nelts" in ln:
+        if "time" in ln or "Nelts" in ln or "of which" in ln:
             print("   ", ln.strip())

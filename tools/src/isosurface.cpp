@@ -16,6 +16,7 @@
 #include "../common/pa_device.h"
 #include "../common/pa_isomerge.h"
 #include <chrono>
+#include <future>
 
 int main(int argc, char** argv) {
   pa::ParmParse pp(argc, argv);
@@ -79,22 +80,33 @@ int main(int argc, char** argv) {
 
   auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double strt_time_surf = now();
+  double t_ctx = 0, t_host = 0, t_up = 0, t_fill = 0, t_mc = 0, t_d2h = 0, t_merge = 0;  // verbose: where "Compute Surface" goes
   double io_time = 0.0;  // plotfile reads (isosurface.cpp:1388-1415); everything else up to the merge is "Compute Surface"
-  pa::Ctx ctx;
-  std::vector<std::unique_ptr<pa::DevLevel>> dl;
-  std::vector<std::unique_ptr<pa::DevMF>> dst;
+  // the HIP context comes up on a second thread (~0.25 s) while this one reads the plotfile
+  double tq = now();
+  auto ctx_ready = std::async(std::launch::async, [] { return std::unique_ptr<pa::Ctx>(new pa::Ctx()); });
   std::vector<pa::HostMF> host(Nlev);
   std::vector<std::vector<int64_t>> soff(Nlev), scs(Nlev);
   for (int lev = 0; lev < Nlev; ++lev) {
-    const auto& L = H.lev[lev];
-    const int ng = nGrow[lev];
     // host side: the mapped plotfile components only (ghost cells -666: gstate.setVal(-666), isosurface.cpp:1512);
     // the three coordinate components are written on the device (isosurface.cpp:1458-1465)
-    host[lev].define(L.boxes, nComp, ng);
-    std::fill(host[lev].data.begin(), host[lev].data.end(), -666.0);
+    tq = now();
+    host[lev].define(H.lev[lev].boxes, nComp, nGrow[lev], -666.0);
+    t_host += now() - tq;
     const double t_io = now();
     for (int n = 0; n < nComp; ++n) pa::read_comp(H, lev, pltComps[n], host[lev], n);
     io_time += now() - t_io;
+  }
+  tq = now();
+  std::unique_ptr<pa::Ctx> ctx_holder = ctx_ready.get();
+  pa::Ctx& ctx = *ctx_holder;
+  t_ctx = now() - tq;  // what was not hidden behind the reads
+  std::vector<std::unique_ptr<pa::DevLevel>> dl;
+  std::vector<std::unique_ptr<pa::DevMF>> dst;
+  for (int lev = 0; lev < Nlev; ++lev) {
+    const auto& L = H.lev[lev];
+    const int ng = nGrow[lev];
+    tq = now();
     dl.emplace_back(new pa::DevLevel(ctx, L.boxes, L.domain, is_per.data(), H.prob_lo, H.prob_hi));
     dst.emplace_back(new pa::DevMF(ctx, *dl.back(), nc, ng));
     {
@@ -110,10 +122,14 @@ int main(int argc, char** argv) {
       scs[lev].resize(L.boxes.size());
       pa_mf_layout((int)L.boxes.size(), b6.data(), nc, ng, soff[lev].data(), scs[lev].data());
     }
+    t_up += now() - tq;
+    tq = now();
     std::cout << "FillPatching the grown structures at level " << lev << "..." << std::endl;
     ctx.check(pa_fill_boundary(ctx.h, dst[lev]->h, 0, nc, ng));
     if (lev > 0) ctx.check(pa_fillpatch_two_levels(ctx.h, dst[lev]->h, dst[lev - 1]->h, 0, nc, ng, 2, 0));  // PCInterp
     std::cout << "...done FillPatching the grown structures at level " << lev << "..." << std::endl;
+    ctx.check(pa_sync(ctx.h));
+    t_fill += now() - tq;
   }
   ctx.check(pa_sync(ctx.h));
   if (pa_bc_errors(ctx.h) != 0) pa::Abort("FillPatchTwoLevels: fine grids are not properly nested in the coarse level");
@@ -154,8 +170,11 @@ int main(int argc, char** argv) {
     std::vector<int64_t> nvb(nb, 0), ntb(nb, 0);
     double* dv = nullptr;
     int32_t *dk = nullptr, *dt = nullptr;
+    tq = now();
     ctx.check(pa_mc_level_fine(ctx.h, dst[lev]->h, fine_mask ? dl[lev + 1]->h : nullptr, 2, loops.data(), 3 + isoComp, isoVal, nvb.data(), ntb.data(), &dv, &dk,
                                &dt));
+    t_mc += now() - tq;
+    tq = now();
     int64_t nvt = 0, ntt = 0;
     for (size_t b = 0; b < nb; ++b) { nvt += nvb[b]; ntt += ntb[b]; }
     std::vector<double> hva((size_t)(nvt * nc));
@@ -165,6 +184,8 @@ int main(int argc, char** argv) {
       ctx.check(pa_memcpy_d2h(ctx.h, hka.data(), dk, nvt * 6 * 4));
     }
     if (ntt > 0) ctx.check(pa_memcpy_d2h(ctx.h, hta.data(), dt, ntt * 3 * 4));
+    t_d2h += now() - tq;
+    tq = now();
     void* dx3 = nullptr;
     if (build_distance_function && nvt > 0) {  // vertList: Vec3f(loc) rounds to float (isosurface.cpp:1598-1611)
       std::vector<float> xf((size_t)nvt * 3);
@@ -231,6 +252,7 @@ int main(int argc, char** argv) {
       }
       merger.add(hv.data(), nvk, ht.data(), ntk);
     }
+    t_merge += now() - tq;
     // dv, dk, dt are one allocation (base dv); the distance function still reads the triangles
     if (build_distance_function) grid_bufs.push_back(dv); else pa_device_free(ctx.h, dv);
     if (build_distance_function) {
@@ -270,6 +292,9 @@ int main(int argc, char** argv) {
     const double surf_time = now() - strt_time_surf - io_time;
     std::cout << "Max Compute Surface time: " << surf_time << '\n' << "Min Compute Surface time: " << surf_time << '\n';
     std::cout << "Max I/O time: " << io_time << '\n' << "Min I/O time: " << io_time << '\n';
+    if (verbose)
+      std::cout << "  of which: HIP context (not hidden behind the reads) " << t_ctx << ", host buffers " << t_host << ", level tables + upload + coordinates " << t_up << ", ghost fill " << t_fill
+                << ", marching cubes " << t_mc << ", download " << t_d2h << ", per-FAB trimming + node/element insertion " << t_merge << '\n';
   }
   const double strt_time_uniq = now();
   merger.finish();
