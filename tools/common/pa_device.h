@@ -1,6 +1,8 @@
 // pa_device.h -- glue between the host plotfile containers and the C ABI (device levels / multifabs)
 #pragma once
 #include <memory>
+#include <future>
+#include <memory>
 
 #include "pa_plotfile.h"
 
@@ -15,6 +17,17 @@ struct Ctx {
   ~Ctx() { pa_ctx_destroy(h); }
   void check(int rc) const {
     if (rc != 0) Abort(pa_last_error(h));
+  }
+};
+
+// HIP context brought up on a second thread (~0.25 s of runtime start-up) while the caller reads the plotfile
+struct AsyncCtx {
+  std::future<std::unique_ptr<Ctx>> fut;
+  std::unique_ptr<Ctx> ctx;
+  AsyncCtx() : fut(std::async(std::launch::async, [] { return std::unique_ptr<Ctx>(new Ctx()); })) {}
+  Ctx& get() {
+    if (!ctx) ctx = fut.get();
+    return *ctx;
   }
 };
 

@@ -111,7 +111,7 @@ int main(int argc, char** argv) {
   const bool options = do_gaussCurv || do_strain || do_velnormal || do_smooth;
   const int nres = options ? 18 : 8;
 
-  pa::Ctx ctx;
+  pa::AsyncCtx actx;  // the HIP context comes up behind the reads
   std::vector<std::unique_ptr<pa::DevLevel>> dl;
   std::vector<std::unique_ptr<pa::DevMF>> dst, dwork, dout;
   std::vector<pa::HostMF> in(Nlev), res(Nlev), ostate(Nlev);
@@ -120,6 +120,9 @@ int main(int argc, char** argv) {
     if (verbose) std::cout << "Reading data for level " << lev << "\n";
     in[lev].define(H.lev[lev].boxes, nCompIn, 2);
     for (int c = 0; c < nCompIn; ++c) pa::read_comp(H, lev, inComps[c], in[lev], c);
+  }
+  pa::Ctx& ctx = actx.get();
+  for (int lev = 0; lev < Nlev; ++lev) {
     dl.emplace_back(new pa::DevLevel(ctx, H.lev[lev].boxes, H.lev[lev].domain, is_per.data(), H.prob_lo, H.prob_hi));
     dst.emplace_back(new pa::DevMF(ctx, *dl.back(), nCompIn, 2));
     dwork.emplace_back(new pa::DevMF(ctx, *dl.back(), 1, 2));

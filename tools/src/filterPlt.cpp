@@ -55,7 +55,7 @@ int main(int argc, char** argv) {
     for (int c = 0; c < (int)names.size(); ++c) comps.push_back(c);
   }
   const int ncomp = (int)names.size();
-  pa::Ctx ctx;
+  pa::AsyncCtx actx;  // the HIP context comes up behind the reads
   std::vector<std::unique_ptr<pa::DevLevel>> dl;
   std::vector<std::unique_ptr<pa::DevMF>> din, dout;
   std::vector<pa::HostMF> host(Nlev), out(Nlev);
@@ -74,6 +74,11 @@ int main(int argc, char** argv) {
     const std::vector<pa::Box3> ba = pa::max_size(H.lev[lev].boxes, max_grid_size);
     host[lev].define(ba, ncomp, ng);
     for (int c = 0; c < ncomp; ++c) pa::read_comp(H, lev, comps[c], host[lev], c);
+  }
+  pa::Ctx& ctx = actx.get();
+  for (int lev = 0; lev < Nlev; ++lev) {
+    const std::vector<pa::Box3>& ba = host[lev].boxes;
+    const int ng = ngs[lev];
     dl.emplace_back(new pa::DevLevel(ctx, ba, H.lev[lev].domain, is_per.data(), H.prob_lo, H.prob_hi));
     din.emplace_back(new pa::DevMF(ctx, *dl.back(), ncomp, ng));
     dout.emplace_back(new pa::DevMF(ctx, *dl.back(), ncomp, 0));

@@ -63,7 +63,7 @@ int main(int argc, char** argv) {
   int32_t bc[3];
   pa::bc_from_flags(is_per, sym_dir, bc);
 
-  pa::Ctx ctx;
+  pa::AsyncCtx actx;  // the HIP context comes up behind the reads
   std::vector<std::unique_ptr<pa::DevLevel>> dl;
   std::vector<std::unique_ptr<pa::DevMF>> dmf;
   std::vector<pa::HostMF> state(Nlev);
@@ -72,6 +72,9 @@ int main(int argc, char** argv) {
     std::cout << "Reading data for level: " << lev << std::endl;
     state[lev].define(H.lev[lev].boxes, nCompOut, 1);
     for (int c = 0; c < nCompIn; ++c) pa::read_comp(H, lev, inComps[c], state[lev], c);
+  }
+  pa::Ctx& ctx = actx.get();
+  for (int lev = 0; lev < Nlev; ++lev) {
     dl.emplace_back(new pa::DevLevel(ctx, H.lev[lev].boxes, H.lev[lev].domain, is_per.data(), H.prob_lo, H.prob_hi));
     dmf.emplace_back(new pa::DevMF(ctx, *dl.back(), nCompOut, 1));
     ctx.check(pa_mf_upload(ctx.h, dmf.back()->h, state[lev].data.data()));

@@ -84,7 +84,7 @@ int main(int argc, char** argv) {
   double io_time = 0.0;  // plotfile reads (isosurface.cpp:1388-1415); everything else up to the merge is "Compute Surface"
   // the HIP context comes up on a second thread (~0.25 s) while this one reads the plotfile
   double tq = now();
-  auto ctx_ready = std::async(std::launch::async, [] { return std::unique_ptr<pa::Ctx>(new pa::Ctx()); });
+  pa::AsyncCtx actx;
   std::vector<pa::HostMF> host(Nlev);
   std::vector<std::vector<int64_t>> soff(Nlev), scs(Nlev);
   for (int lev = 0; lev < Nlev; ++lev) {
@@ -98,8 +98,7 @@ int main(int argc, char** argv) {
     io_time += now() - t_io;
   }
   tq = now();
-  std::unique_ptr<pa::Ctx> ctx_holder = ctx_ready.get();
-  pa::Ctx& ctx = *ctx_holder;
+  pa::Ctx& ctx = actx.get();
   t_ctx = now() - tq;  // what was not hidden behind the reads
   std::vector<std::unique_ptr<pa::DevLevel>> dl;
   std::vector<std::unique_ptr<pa::DevMF>> dst;

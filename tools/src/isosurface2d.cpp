@@ -132,17 +132,20 @@ int main(int argc, char** argv) {
 
   const double strt_time_surf = now();
   double io_time = 0.0;
-  pa::Ctx ctx;
+  pa::AsyncCtx actx;  // the HIP context comes up behind the reads
   std::vector<std::unique_ptr<pa::DevLevel>> dl;
   std::vector<std::unique_ptr<pa::DevMF>> dst;
+  std::vector<pa::HostMF> hosts(Nlev);  // the mapped components; ghost cells -666 (gstate.setVal(-666), isosurface.cpp:1512)
+  for (int lev = 0; lev < Nlev; ++lev) {
+    hosts[lev].define(H.lev[lev].boxes, nComp, ng, -666.0);
+    const double t_io = now();
+    for (int n = 0; n < nComp; ++n) pa::read_comp(H, lev, pltComps[n], hosts[lev], n);
+    io_time += now() - t_io;
+  }
+  pa::Ctx& ctx = actx.get();
   for (int lev = 0; lev < Nlev; ++lev) {
     const auto& L = H.lev[lev];
-    pa::HostMF host;  // the mapped components; ghost cells -666 (gstate.setVal(-666), isosurface.cpp:1512)
-    host.define(L.boxes, nComp, ng);
-    std::fill(host.data.begin(), host.data.end(), -666.0);
-    const double t_io = now();
-    for (int n = 0; n < nComp; ++n) pa::read_comp(H, lev, pltComps[n], host, n);
-    io_time += now() - t_io;
+    pa::HostMF& host = hosts[lev];
     dl.emplace_back(new pa::DevLevel(ctx, L.boxes, L.domain, is_per.data(), H.prob_lo, H.prob_hi));
     dst.emplace_back(new pa::DevMF(ctx, *dl.back(), nc, ng));
     pa::DevMF dfield(ctx, *dl.back(), nComp, ng);
