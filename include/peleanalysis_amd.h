@@ -285,8 +285,8 @@ typedef struct {
   /* 0 or 3: the 3-D build.  2: the AMREX_SPACEDIM == 2 build on a level stored as ONE plane of cells (boxes with
    * lo[2] = hi[2] = 0, z a non-periodic direction: the homogeneous-Neumann wall makes every z difference an exact
    * zero, and adding exact zeros changes no sum of the path): MeanCurvature = sum_d d(n_d)/dx_d WITHOUT the 0.5 of
-   * the 3-D build (curvature.cpp:542-546); pass-by-pass kernels (the fused sweep has the 0.5 built in); the options
-   * above are refused. */
+   * the 3-D build (curvature.cpp:542-546); pass-by-pass kernels (the fused sweep has the 0.5 built in); do_strain /
+   * do_velnormal need a zero third velocity component at vel_comp + 2; do_gauss_curv and do_smooth are refused. */
   int32_t spacedim;
 } pa_curv_params;
 /* curvature.cpp:283-326 + 408-570 (core) + 575-789 (options).  state[lev][comp] = progress source

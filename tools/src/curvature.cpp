@@ -16,7 +16,8 @@
 // out, sym_dir / is_per of two entries, components [progressName, aux..., Progress, SmoothedProgress, MeanCurvature_<v>,
 // FlameNormalX/Y_<v>] (no Gaussian curvature in 2-D, curvature.cpp:208-226), MeanCurvature = d(nx)/dx + d(ny)/dy without
 // the 0.5 of the 3-D build (:542-546).  The level is one plane of cells with z a homogeneous-Neumann wall
-// (pa_curv_params.spacedim = 2); the options (do_strain, do_velnormal, do_smooth) are not available in this build.
+// (pa_curv_params.spacedim = 2); do_strain / getStrainTensor (2 x 2) / do_velnormal work through a zero third velocity
+// component on the device; do_gaussCurv (3-D only in the reference) and do_smooth are not available in this build.
 #include "../common/pa_device.h"
 #ifndef PA_SPACEDIM
 #define PA_SPACEDIM 3
@@ -57,7 +58,7 @@ int main(int argc, char** argv) {
   std::cout << "infile = " << infile << "\n" << "reading plt file = " << infile << "\n";
   pa::PlotfileHeader H = pa::read_header(infile, PA_SPACEDIM);
 #if PA_SPACEDIM == 2
-  if (do_gaussCurv || do_strain || do_velnormal || do_smooth) pa::Abort("do_gaussCurv / do_strain / do_velnormal / do_smooth are not available in the 2-D build");
+  if (do_gaussCurv || do_smooth) pa::Abort("do_gaussCurv / do_smooth are not available in the 2-D build");
 #endif
   finestLevel = std::min(finestLevel, H.nlev - 1);
   const int Nlev = finestLevel + 1;
@@ -68,7 +69,11 @@ int main(int argc, char** argv) {
   const bool need_vel = do_strain || do_velnormal;
   const int idVst = 1;
   if (need_vel)
+#if PA_SPACEDIM == 2
+    for (const char* v : {"x_velocity", "y_velocity"}) {
+#else
     for (const char* v : {"x_velocity", "y_velocity", "z_velocity"}) {
+#endif
       if (H.comp(v) < 0) pa::Abort(std::string("Unknown velocity variable name: ") + v);
       inNames.push_back(v);
       inComps.push_back(H.comp(v));
@@ -81,14 +86,24 @@ int main(int argc, char** argv) {
     inComps.push_back(H.comp(a));
   }
   const int nCompIn = (int)inNames.size();
+#if PA_SPACEDIM == 2
+  // the library wants three consecutive velocity components: a zero one is slipped in behind y_velocity on the device
+  // (every term it enters is an exact zero); devOf() maps a tool component to its device component
+  const int hidden = need_vel ? idVst + 2 : -1;
+#else
+  const int hidden = -1;
+#endif
+  auto devOf = [hidden](int c) { return (hidden >= 0 && c >= hidden) ? c + 1 : c; };
+  const int nCompDev = nCompIn + (hidden >= 0 ? 1 : 0);
   const int idProg = nCompIn, idSmProg = idProg + 1, idKm = idSmProg + 1, idN = idKm + 1, idKg = idN + 3;
 #if PA_SPACEDIM == 2
   int idSR = -1, idROST = -1, idVelNormal = -1, nCompOut = idN + 2;  // no GaussianCurvature slot (curvature.cpp:218-226)
+  if (do_strain) { idSR = idN + 2; nCompOut = idSR + 1; }
 #else
   int idSR = -1, idROST = -1, idVelNormal = -1, nCompOut = idKg + 1;
-#endif
   if (do_strain) { idSR = idKg + 1; nCompOut = idSR + 1; }
-  if (getStrainTensor) { idROST = nCompOut; nCompOut = idROST + 9; }
+#endif
+  if (getStrainTensor) { idROST = nCompOut; nCompOut = idROST + PA_SPACEDIM * PA_SPACEDIM; }
   if (do_velnormal) { idVelNormal = nCompOut; nCompOut += 1; }
   std::vector<int> sym_dir(3, 0), is_per(3, 1);
 #if PA_SPACEDIM == 2
@@ -118,13 +133,13 @@ int main(int argc, char** argv) {
   std::vector<pa::Box3> doms;
   for (int lev = 0; lev < Nlev; ++lev) {
     if (verbose) std::cout << "Reading data for level " << lev << "\n";
-    in[lev].define(H.lev[lev].boxes, nCompIn, 2);
-    for (int c = 0; c < nCompIn; ++c) pa::read_comp(H, lev, inComps[c], in[lev], c);
+    in[lev].define(H.lev[lev].boxes, nCompDev, 2);
+    for (int c = 0; c < nCompIn; ++c) pa::read_comp(H, lev, inComps[c], in[lev], devOf(c));
   }
   pa::Ctx& ctx = actx.get();
   for (int lev = 0; lev < Nlev; ++lev) {
     dl.emplace_back(new pa::DevLevel(ctx, H.lev[lev].boxes, H.lev[lev].domain, is_per.data(), H.prob_lo, H.prob_hi));
-    dst.emplace_back(new pa::DevMF(ctx, *dl.back(), nCompIn, 2));
+    dst.emplace_back(new pa::DevMF(ctx, *dl.back(), nCompDev, 2));
     dwork.emplace_back(new pa::DevMF(ctx, *dl.back(), 1, 2));
     dout.emplace_back(new pa::DevMF(ctx, *dl.back(), nres, 0));
     ctx.check(pa_mf_upload(ctx.h, dst.back()->h, in[lev].data.data()));
@@ -175,7 +190,7 @@ int main(int argc, char** argv) {
       auto cp = [&](int dstc, int srcc, int k, int j) { std::memcpy(ostate[lev].ptr((int)b, dstc, B.lo[0], j, k), res[lev].ptr((int)b, srcc, B.lo[0], j, k), 8 * nx); };
       for (int k = B.lo[2]; k <= B.hi[2]; ++k)
         for (int j = B.lo[1]; j <= B.hi[1]; ++j) {
-          for (int c = 0; c < nCompIn; ++c) std::memcpy(ostate[lev].ptr((int)b, c, B.lo[0], j, k), in[lev].ptr((int)b, c, B.lo[0], j, k), 8 * nx);
+          for (int c = 0; c < nCompIn; ++c) std::memcpy(ostate[lev].ptr((int)b, c, B.lo[0], j, k), in[lev].ptr((int)b, devOf(c), B.lo[0], j, k), 8 * nx);
           const double* sv = in[lev].ptr((int)b, 0, B.lo[0], j, k);
           double* pr = ostate[lev].ptr((int)b, idProg, B.lo[0], j, k);
           for (size_t i = 0; i < nx; ++i) pr[i] = (sv[i] - progMin) * invdenom;  // curvature.cpp:319 (same fp order as the device)
@@ -184,7 +199,9 @@ int main(int argc, char** argv) {
           if (do_smooth) cp(idSmProg, 17, k, j);
           if (do_gaussCurv) cp(idKg, rKg, k, j);
           if (do_strain) cp(idSR, rSR, k, j);
-          if (getStrainTensor) for (int q = 0; q < 9; ++q) cp(idROST + q, rROST + q, k, j);
+          if (getStrainTensor)
+            for (int a = 0; a < PA_SPACEDIM; ++a)
+              for (int e = 0; e < PA_SPACEDIM; ++e) cp(idROST + a * PA_SPACEDIM + e, rROST + a * 3 + e, k, j);  // the library's tensor is 3 x 3 row-major
           if (do_velnormal) cp(idVelNormal, rVn, k, j);
         }
     }
@@ -204,7 +221,8 @@ int main(int argc, char** argv) {
   if (do_strain) nnames[idSR] = "StrainRate_" + progressName;
   if (getStrainTensor) {
     const std::string dirChar[3] = {"x", "y", "z"};
-    for (int i = 0; i < 9; ++i) nnames[idROST + i] = "ROST_dU" + dirChar[i / 3] + "d" + dirChar[i % 3];  // curvature.cpp:815-823
+    for (int i = 0; i < PA_SPACEDIM * PA_SPACEDIM; ++i)
+      nnames[idROST + i] = "ROST_dU" + dirChar[i / PA_SPACEDIM] + "d" + dirChar[i % PA_SPACEDIM];  // curvature.cpp:815-823
   }
   if (do_velnormal) nnames[idVelNormal] = "VelFlameNormal";
   std::cout << "Writing new data to " << outfile << "\n";
