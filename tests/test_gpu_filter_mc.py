@@ -276,3 +276,52 @@ def test_marching_squares_level_matches_oracle(ctx, oracle, per):
             assert np.array_equal(gv.view(np.int64), np.ascontiguousarray(v).view(np.int64)), f"level {l} box {b}: vertex data not bit-identical"
             nseg_total += len(sg)
     assert nseg_total > 60
+
+
+def test_level_entry_points_reject_bad_arguments(ctx):
+    """shape / range checks happen on the host before any launch touches memory: every call returns non-zero with a
+    message and leaves the output pointers NULL"""
+    from peleanalysis_amd.hierarchy import Level, chop_box
+    lv = Level(chop_box((0, 0, 0), (15, 15, 15), 8), (0, 0, 0), (15, 15, 15), (0, 0, 0), (0, 0, 0), (1, 1, 1))
+    dl = capi.DevLevel(ctx, lv)
+    st, m1, m2 = capi.DevMF(ctx, dl, 5, 1), capi.DevMF(ctx, dl, 1, 1), capi.DevMF(ctx, dl, 1, 2)
+    loops = (capi.PaBox * lv.nboxes)()
+    for b in range(lv.nboxes):
+        for d in range(3):
+            loops[b].lo[d], loops[b].hi[d] = int(lv.boxes[b, d]), int(lv.boxes[b, 3 + d]) - 1
+    nv, nt = (C.c_int64 * lv.nboxes)(), (C.c_int64 * lv.nboxes)()
+    pv, pk, pt = C.c_void_p(123), C.c_void_p(123), C.c_void_p(123)
+
+    def call(fn, *a):
+        pv.value = pk.value = pt.value = 123
+        rc = fn(ctx.h, *a, nv, nt, C.byref(pv), C.byref(pk), C.byref(pt))
+        return rc, ctx.lib.pa_last_error(ctx.h).decode()
+
+    rc, msg = call(ctx.lib.pa_mc_level, st.h, m2.h, 0, loops, 3, 1.0)  # ghost widths differ
+    assert rc != 0 and "ghost width" in msg and pv.value is None
+    rc, msg = call(ctx.lib.pa_mc_level, st.h, m1.h, 1, loops, 3, 1.0)  # mask component
+    assert rc != 0 and "component" in msg
+    rc, msg = call(ctx.lib.pa_mc_level, st.h, m1.h, 0, loops, 7, 1.0)  # iso component
+    assert rc != 0 and "component" in msg
+    loops[2].hi[1] = int(lv.boxes[2, 4]) + 1  # base points whose cube leaves the grown FAB
+    rc, msg = call(ctx.lib.pa_mc_level, st.h, m1.h, 0, loops, 3, 1.0)
+    assert rc != 0 and "loop box" in msg and pv.value is None
+    rc, msg = call(ctx.lib.pa_mc_level_fine, st.h, dl.h, 0, loops, 3, 1.0)  # ratio
+    assert rc != 0 and "ratio" in msg
+    loops[2].hi[1] = int(lv.boxes[2, 4]) - 1
+    rc, msg = call(ctx.lib.pa_msq_level, st.h, m1.h, 0, loops, 3, 1.0)  # squares want one plane of base points
+    assert rc != 0 and "one plane" in msg
+    assert ctx.lib.pa_iso_mask_level(ctx.h, m1.h, 1, None, 2) != 0
+    assert ctx.lib.pa_iso_coords_level(ctx.h, m1.h, 0) != 0  # 3 components do not fit
+    w = (C.c_double * 5)(0.125, 0.25, 0.25, 0.25, 0.125)
+    assert ctx.lib.pa_boxfilter_level2d(ctx.h, m1.h, m1.h, 0, 1, 2, w) != 0 and "ghost" in ctx.lib.pa_last_error(ctx.h).decode()
+    # 2-D levels refuse the options the 2-D build of the reference does not have
+    out = capi.DevMF(ctx, dl, 18, 0)
+    s2 = capi.DevMF(ctx, dl, 4, 2)
+    with pytest.raises(capi.PaError, match="2-D"):
+        capi.curvature_run(ctx, [s2], 0, capi.bc_from_flags((0, 0, 0)), capi.curv_params(prog_min=0.0, prog_max=1.0, do_gauss=True, spacedim=2), [out], 0)
+    # and a well-formed call still works afterwards
+    rc, _ = call(ctx.lib.pa_mc_level_fine, st.h, None, 2, loops, 3, 1.0e30)
+    assert rc == 0
+    if pv.value:
+        ctx.lib.pa_device_free(ctx.h, pv)
