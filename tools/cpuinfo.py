@@ -3,3 +3,6 @@ print("cpu_count", os.cpu_count(), "affinity", len(os.sched_getaffinity(0)))
 for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us"):
     try: print(f, open(f).read().strip())
     except Exception as e: print(f, "n/a")
+for f in ("/sys/kernel/mm/transparent_hugepage/enabled", "/sys/kernel/mm/transparent_hugepage/defrag"):
+    try: print(f, open(f).read().strip())
+    except Exception as e: print(f, "n/a")
