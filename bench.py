@@ -115,6 +115,7 @@ def main():
     ap.add_argument("--fused", type=int, default=1)
     ap.add_argument("--per", type=str, default="1 1 0", help="periodicity flags x y z (headline: periodic x/y, wall z); single GPU only")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-profile", action="store_true", help="diagnostic: no HIP events in the timed region (no roofline object)")
     ap.add_argument("--cpu-base", type=int, default=0, help="base size of the cpu_baseline sample (0: from the core count)")
     args = ap.parse_args()
 
@@ -215,19 +216,24 @@ def main():
         step()
     barrier()
     ctx.profile_read(1, reset=True)
-    ctx.profile_enable(True)
+    ctx.profile_enable(0 if args.no_profile else (1 << 1))  # timed region: HIP events around the dominant kernel only
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     dt = time.perf_counter() - t0
     ctx.profile_enable(False)
-    nk, ms_k = ctx.profile_read(1)
-    nf, ms_f = ctx.profile_read(2)
-    nfill, ms_fill = ctx.profile_read(3)
-    nbc, ms_bc = ctx.profile_read(4)
-    nprog, ms_prog = ctx.profile_read(6, reset=True)
+    nk, ms_k = ctx.profile_read(1, reset=True)
     assert ctx.bc_errors() == 0
+    # per-stage breakdown from two further, untimed steps with every stage's launches timed
+    nbd = 2
+    ctx.profile_enable(True)
+    for _ in range(nbd):
+        step()
+    barrier()
+    ctx.profile_enable(False)
+    bd = {name: ctx.profile_read(tag)[1] / nbd for name, tag in (("gradcurv", 1), ("faces", 2), ("fill_boundary", 3), ("apply_bc", 4), ("progress", 6))}
+    ctx.profile_read(1, reset=True)  # a reset drops every tag's records
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -259,8 +265,7 @@ def main():
         res["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                            "traffic": traffic, "kernel": "k_gradcurv_march3 (fused grad->curvature sweep)", "avg_launch_ms": avg_ms,
                            "launches": nk, "bytes_per_cell": BYTES_PER_CELL}
-        res["breakdown_ms_per_step"] = {"gradcurv": ms_k / args.steps, "faces": ms_f / args.steps, "fill_boundary": ms_fill / args.steps,
-                                        "apply_bc": ms_bc / args.steps, "progress": ms_prog / args.steps}
+        res["breakdown_ms_per_step"] = bd  # from the untimed steps after the timed region
         res["step_frac_of_hbm_roofline"] = (cells * args.ncomp * BYTES_PER_CELL / (dt / args.steps) / 1e9) / HBM_PEAK_GBS
     if rank == 0 and world == 1 and not args.no_cpu:
         try:

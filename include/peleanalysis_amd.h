@@ -55,7 +55,8 @@ int   pa_memcpy_d2h(pa_ctx*, void* hostdst, const void* devsrc, int64_t bytes);
 /* Per-launch timing of the library's own kernels with HIP events recorded on the
  * context's stream (what bench.py's roofline object reports).  Tags: 1 fused
  * grad->curvature, 2 its face fix-up, 3 FillBoundary, 4 applyBC, 5 grad,
- * 6 progress, 7 box filter, 8 marching cubes.  pa_profile_read is synchronous. */
+ * 6 progress, 7 box filter, 8 marching cubes.  on: 0 off, 1 every tag, otherwise a bit mask (1 << tag) of the
+ * tags to time.  pa_profile_read is synchronous. */
 int pa_profile_enable(pa_ctx*, int on);
 int pa_profile_read(pa_ctx*, int tag, int64_t* nlaunch, double* total_ms, int reset);
 

@@ -178,7 +178,8 @@ class Context:
     def sync(self):
         self.check(self.lib.pa_sync(self.h))
 
-    def profile_enable(self, on: bool = True):
+    def profile_enable(self, on=True):
+        """False / True: no / every tag; an int > 1: bit mask (1 << tag) of the tags to time"""
         self.check(self.lib.pa_profile_enable(self.h, int(on)))
 
     def profile_read(self, tag: int, reset: bool = False):

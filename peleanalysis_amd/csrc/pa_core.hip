@@ -48,7 +48,9 @@ extern "C" void pa_ctx_destroy(pa_ctx* ctx) {
 
 extern "C" int pa_profile_enable(pa_ctx* ctx, int on) {
   if (!ctx) return 1;
-  ctx->profile = on != 0;
+  // 0: off, 1: every tag, otherwise a bit mask (1 << tag): e.g. 2 = the fused sweep only, so that a timed region pays for
+  // two events per sweep launch and nothing else (the events of ~20 small boundary launches per step cost ~2 % of it)
+  ctx->profile = on == 0 ? 0u : (on == 1 ? 0xffffffffu : (unsigned)on);
   return 0;
 }
 

@@ -47,7 +47,7 @@ struct pa_ctx {
   void* d_scr = nullptr;    // grow-only scratch (marching cubes)
   size_t scr_cap = 0;
   // optional per-launch timing of tagged kernels with HIP events on ctx->stream (bench.py roofline)
-  bool profile = false;
+  unsigned profile = 0;  // bit t set: launches under tag t are timed (pa_profile_enable)
   struct Ev { hipEvent_t a, b; int tag; };
   std::vector<Ev> evs;
   // second stream + ordering events of the fused pipeline (boundary kernels of one level next to the sweep of
@@ -62,7 +62,7 @@ struct ProfScope {
   pa_ctx* ctx;
   pa_ctx::Ev e;
   bool on;
-  ProfScope(pa_ctx* c, int tag) : ctx(c), on(c->profile) {
+  ProfScope(pa_ctx* c, int tag) : ctx(c), on(((c->profile >> tag) & 1u) != 0) {
     if (!on) return;
     e.tag = tag;
     if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) { on = false; return; }
