@@ -301,6 +301,14 @@ static int fused_order() {
 template <typename BP>
 static void march_launch(hipStream_t st, const BP& bp, int nx, int ny, int nz, unsigned nboxes, const MarchArgs& A0, bool pair_ok = false) {
   MarchArgs A = A0;
+  // Small levels: a 256^3 level of 64^3 boxes is 320 workgroups at 64 planes each -- 1.25 rounds on 256 CUs -- and
+  // ran at 50 % of the HBM figure; shorter z segments give the chip enough workgroups to balance (PA_KSEG 64 / 32 /
+  // 16 / 8 on that level: 0.305 / 0.280 / 0.267 / 0.269 ms per launch; on the 512^3 headline level 64 stays best).
+  // An explicit PA_KSEG is taken as given.
+  if (!getenv("PA_KSEG")) {
+    const long long per_seg = (long long)((nx + 63) / 64) * ((ny + 12) / 13) * nboxes;
+    while (A.kseg > 16 && per_seg * ((nz + A.kseg - 1) / A.kseg) < 2048) A.kseg /= 2;
+  }
   // PA_PAIR=1 selects the 16-byte paired stores (read per launch so that a test can switch it).
   // Off by default: measured 2.36 vs 2.31 ms per launch on the headline level.
   const char* pe = getenv("PA_PAIR");
