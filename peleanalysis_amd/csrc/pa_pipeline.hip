@@ -168,7 +168,7 @@ static int fused_faces(pa_ctx* ctx, int l, const int32_t bc[3], double thr, pa_m
   return pa_gradcurv_faces_phase(ctx, work[l], 0, l > 0 ? out[l - 1] : nullptr, ocomp + 4, bc, 2, thr, out[l], ocomp + 4, ocomp + 7, phase);
 }
 
-// Level-concurrent boundary schedule (PA_CONC=1; OFF by default).  Between levels almost nothing depends on
+// Level-concurrent boundary schedule (PA_CONC=1 / 0; by default on for small levels only, see conc_on).  Between levels almost nothing depends on
 // anything: prep(l) writes ghost cells of phi_l / the shell of c_l and reads VALID cells of phi_{l-1}; the layer-1
 // normals of level l need only sweep(l) and that shell; the face curvature of level l needs the layer-1 normals of
 // levels l and l-1.  So the three groups can run with one stream per level and only the sweeps -- which want the
@@ -179,9 +179,19 @@ static int fused_faces(pa_ctx* ctx, int l, const int32_t bc[3], double thr, pa_m
 // about twice as long (k_fill_boundary 188 + 192 us side by side against 89 us alone): the boundary kernels are
 // not waiting on latency, they are bound by the memory system's rate for short scattered segments (2-cell-wide
 // ghost strips), which two streams share.  Concurrency buys nothing; kept for A/B only.
-static int conc_on() {
-  static const int v = [] { const char* e = getenv("PA_CONC"); return e ? atoi(e) : 0; }();
-  return v;
+// PA_CONC unset: on for hierarchies of SMALL levels only.  There the boundary launches are short enough not to saturate
+// the memory system and running the levels side by side does pay: 4 levels of 256^3 in 64^3 boxes 16.6-17.0 -> 16.2 ms
+// per 8-component step; on the 512^3 headline levels it costs 1 % (above).
+static int conc_on(int nlev, pa_mf* const* state) {
+  static const int v = [] { const char* e = getenv("PA_CONC"); return e ? atoi(e) : -1; }();
+  if (v >= 0) return v;
+  long long big = 0;
+  for (int l = 0; l < nlev; ++l) {
+    long long n = 0;
+    for (const DBox& B : state[l]->lev->boxes) n += (long long)(B.hi[0] - B.lo[0] + 1) * (B.hi[1] - B.lo[1] + 1) * (B.hi[2] - B.lo[2] + 1);
+    big = std::max(big, n);
+  }
+  return big <= 40000000LL;
 }
 static int fused_passes_conc(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, const int32_t bc[3], double pmin, double pmax, double thr,
                              pa_mf* const* work, pa_mf* const* out, int ocomp) {
@@ -234,7 +244,7 @@ static int fused_passes(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, co
                         pa_mf* const* work, pa_mf* const* out, int ocomp) {
   for (int l = 0; l < nlev; ++l)
     if (state[l]->ng < 2 || work[l]->ng < 2) return pa_fail(ctx, "fused grad->curvature needs 2 ghost layers on state and work");
-  if (conc_on() && nlev >= 2 && !overlap_on()) return fused_passes_conc(ctx, nlev, state, comp, bc, pmin, pmax, thr, work, out, ocomp);
+  if (nlev >= 2 && !overlap_on() && conc_on(nlev, state)) return fused_passes_conc(ctx, nlev, state, comp, bc, pmin, pmax, thr, work, out, ocomp);
   if (!overlap_on() || nlev < 2) {
     for (int l = 0; l < nlev; ++l) PA_TRY(fused_pre(ctx, l, state, comp, bc, pmin, pmax, work));
     for (int l = 0; l < nlev; ++l) {
