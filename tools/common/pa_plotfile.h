@@ -5,7 +5,9 @@
 // HostMF keeps a level's data in the flat layout of pa_mf_layout (include/peleanalysis_amd.h), so
 // a whole level goes to / from HBM with one pa_mf_upload / pa_mf_download.
 #pragma once
+#include <fcntl.h>
 #include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <array>
@@ -17,12 +19,44 @@
 #include <regex>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/peleanalysis_amd.h"
 #include "pa_parmparse.h"
 
 namespace pa {
+
+// The plotfile side of a tool is host work over independent FABs (reads, the per-FAB min / max, writes): spread over the
+// CPUs the process may use (affinity mask capped by the cgroup quota, at most 16)
+inline int io_threads() {
+  static const int n = [] {
+    int v = (int)std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) v = std::min(v, CPU_COUNT(&set));
+    if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+      char q[32];
+      long long per = 0;
+      if (std::fscanf(f, "%31s %lld", q, &per) == 2 && std::strcmp(q, "max") != 0 && per > 0) v = std::min<long long>(v, std::max<long long>(1, (std::atoll(q) + per / 2) / per));
+      std::fclose(f);
+    }
+    if (const char* e = std::getenv("PA_IO_THREADS")) v = std::atoi(e);
+    return std::max(1, std::min(v, 16));
+  }();
+  return n;
+}
+template <typename F>
+inline void parallel_for(size_t n, F fn) {
+  const size_t nt = std::min<size_t>((size_t)io_threads(), n);
+  if (nt <= 1) {
+    for (size_t i = 0; i < n; ++i) fn(i);
+    return;
+  }
+  std::vector<std::thread> th;
+  for (size_t t = 0; t < nt; ++t)
+    th.emplace_back([=] { for (size_t i = t; i < n; i += nt) fn(i); });
+  for (auto& x : th) x.join();
+}
 
 struct Box3 {
   int lo[3], hi[3];
@@ -182,7 +216,7 @@ inline PlotfileHeader read_header(const std::string& path, int dim_wanted = 3) {
 // every dst box that lies inside a file box: dst boxes are the file's or a re-chop of them)
 inline void read_comp(const PlotfileHeader& H, int lev, int comp, HostMF& dst, int dcomp) {
   const LevelMeta& L = H.lev[lev];
-  for (size_t fb = 0; fb < L.boxes.size(); ++fb) {
+  parallel_for(L.boxes.size(), [&](size_t fb) {  // file FABs are independent; destinations are disjoint valid regions
     // does any dst box intersect this file box?
     std::vector<int> hits;
     for (size_t b = 0; b < dst.boxes.size(); ++b) {
@@ -190,7 +224,7 @@ inline void read_comp(const PlotfileHeader& H, int lev, int comp, HostMF& dst, i
       for (int d = 0; d < 3; ++d) in = in && dst.boxes[b].lo[d] <= L.boxes[fb].hi[d] && dst.boxes[b].hi[d] >= L.boxes[fb].lo[d];
       if (in) hits.push_back((int)b);
     }
-    if (hits.empty()) continue;
+    if (hits.empty()) return;
     std::ifstream f(L.fab_file[fb], std::ios::binary);
     if (!f) Abort("Unable to open " + L.fab_file[fb]);
     f.seekg(L.fab_off[fb]);
@@ -214,7 +248,7 @@ inline void read_comp(const PlotfileHeader& H, int lev, int comp, HostMF& dst, i
                       sizeof(double) * (size_t)(i1 - i0 + 1));
         }
     }
-  }
+  });
 }
 
 inline std::string box_str(const Box3& b) {
@@ -278,27 +312,50 @@ inline void write_plotfile(const std::string& path, const std::vector<std::strin
     const std::string dir = path + "/Level_" + std::to_string(l);
     ::mkdir(dir.c_str(), 0755);
     HostMF& M = mf[l];
-    std::vector<long long> offs;
-    std::vector<std::vector<double>> mins, maxs;
+    const size_t nb = M.boxes.size();
+    std::vector<long long> offs(nb);
+    std::vector<std::vector<double>> mins(nb), maxs(nb);
     {
-      std::ofstream f(dir + "/Cell_D_00000", std::ios::binary);
-      if (!f) Abort("Unable to create " + dir + "/Cell_D_00000");
-      std::vector<double> row;
-      for (size_t b = 0; b < M.boxes.size(); ++b) {
-        offs.push_back((long long)f.tellp());
+      // FAB b = header line + ncomp * npts doubles at a known offset: the FABs are gathered, reduced (min / max) and
+      // written by several threads (pwrite)
+      std::vector<std::string> hdr(nb);
+      long long pos = 0;
+      for (size_t b = 0; b < nb; ++b) {
+        hdr[b] = "FAB ((8, (64 11 52 0 1 12 0 1023)),(8, (8 7 6 5 4 3 2 1)))" + bstr(M.boxes[b]) + ' ' + std::to_string(ncomp) + "\n";
+        offs[b] = pos;
+        pos += (long long)hdr[b].size() + (long long)ncomp * M.boxes[b].numPts() * 8;
+      }
+      const std::string fname = dir + "/Cell_D_00000";
+      const int fd = ::open(fname.c_str(), O_CREAT | O_TRUNC | O_WRONLY, 0644);
+      if (fd < 0) Abort("Unable to create " + fname);
+      std::vector<int> bad(nb, 0);
+      parallel_for(nb, [&](size_t b) {
         const Box3& B = M.boxes[b];
-        f << "FAB ((8, (64 11 52 0 1 12 0 1023)),(8, (8 7 6 5 4 3 2 1)))" << bstr(B) << ' ' << ncomp << "\n";
-        std::vector<double> mn(ncomp, 1e300), mx(ncomp, -1e300);
         const int nx = B.hi[0] - B.lo[0] + 1;
+        const long long npts = B.numPts();
+        std::vector<char> buf(hdr[b].size() + (size_t)ncomp * (size_t)npts * 8);
+        std::memcpy(buf.data(), hdr[b].data(), hdr[b].size());
+        double* out = (double*)(buf.data() + hdr[b].size());  // may be unaligned: filled with memcpy
+        char* w = (char*)out;
+        std::vector<double> mn(ncomp, 1e300), mx(ncomp, -1e300);
         for (int c = 0; c < ncomp; ++c)
           for (int k = B.lo[2]; k <= B.hi[2]; ++k)
             for (int j = B.lo[1]; j <= B.hi[1]; ++j) {
               const double* p = M.ptr((int)b, src(c), B.lo[0], j, k);
-              f.write((const char*)p, sizeof(double) * (size_t)nx);
+              std::memcpy(w, p, sizeof(double) * (size_t)nx);
+              w += sizeof(double) * (size_t)nx;
               for (int i = 0; i < nx; ++i) { mn[c] = std::min(mn[c], p[i]); mx[c] = std::max(mx[c], p[i]); }
             }
-        mins.push_back(mn); maxs.push_back(mx);
-      }
+        mins[b] = mn; maxs[b] = mx;
+        size_t done = 0;
+        while (done < buf.size()) {
+          const ssize_t r = ::pwrite(fd, buf.data() + done, buf.size() - done, (off_t)(offs[b] + (long long)done));
+          if (r <= 0) { bad[b] = 1; break; }
+          done += (size_t)r;
+        }
+      });
+      ::close(fd);
+      for (int x : bad) if (x) Abort("short write to " + fname);
     }
     std::ofstream h(dir + "/Cell_H");
     h << "1\n1\n" << ncomp << "\n0\n(" << M.boxes.size() << " 0\n";
