@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <memory>
 #include <regex>
 #include <sstream>
 #include <string>
@@ -88,11 +89,20 @@ struct PlotfileHeader {
 };
 
 // level data in pa_mf_layout order
+// std::vector that leaves new doubles uninitialised: the multi-GB host multifabs are then first touched (page-faulted)
+// by the filling threads instead of by one thread inside resize()
+template <typename T>
+struct DefaultInitAlloc : std::allocator<T> {
+  template <typename U> struct rebind { using other = DefaultInitAlloc<U>; };
+  template <typename U> void construct(U* p) noexcept { ::new ((void*)p) U; }
+  template <typename U, typename... A> void construct(U* p, A&&... a) { ::new ((void*)p) U(std::forward<A>(a)...); }
+};
+
 struct HostMF {
   std::vector<Box3> boxes;
   int ncomp = 0, ng = 0;
   std::vector<int64_t> off, cs;
-  std::vector<double> data;
+  std::vector<double, DefaultInitAlloc<double>> data;
   void define(const std::vector<Box3>& b, int nc, int g, double fill = 0.0) {
     boxes = b; ncomp = nc; ng = g;
     std::vector<int32_t> b6(6 * b.size());
@@ -100,7 +110,11 @@ struct HostMF {
       for (int d = 0; d < 3; ++d) { b6[6 * i + d] = b[i].lo[d]; b6[6 * i + 3 + d] = b[i].hi[d]; }
     off.resize(b.size()); cs.resize(b.size());
     const int64_t tot = pa_mf_layout((int)b.size(), b6.data(), nc, g, off.data(), cs.data());
-    data.assign((size_t)tot, fill);
+    data.clear();
+    data.resize((size_t)tot);  // no value-initialisation (DefaultInitAlloc)
+    const size_t chunk = (size_t)1 << 22, nch = ((size_t)tot + chunk - 1) / chunk;
+    double* d = data.data();
+    parallel_for(nch, [=](size_t q) { std::fill(d + q * chunk, d + std::min((size_t)tot, (q + 1) * chunk), fill); });
   }
   double* ptr(int b, int c, int i, int j, int k) {
     const Box3& B = boxes[b];

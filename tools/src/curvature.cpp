@@ -129,7 +129,7 @@ int main(int argc, char** argv) {
   pa::AsyncCtx actx;  // the HIP context comes up behind the reads
   std::vector<std::unique_ptr<pa::DevLevel>> dl;
   std::vector<std::unique_ptr<pa::DevMF>> dst, dwork, dout;
-  std::vector<pa::HostMF> in(Nlev), res(Nlev), ostate(Nlev);
+  std::vector<pa::HostMF> in(Nlev), ostate(Nlev);
   std::vector<pa::Box3> doms;
   for (int lev = 0; lev < Nlev; ++lev) {
     if (verbose) std::cout << "Reading data for level " << lev << "\n";
@@ -179,32 +179,26 @@ int main(int argc, char** argv) {
   }
   ctx.check(pa_sync(ctx.h));
   if (pa_bc_errors(ctx.h) != 0) pa::Abort("coarse-fine boundary: fine grids are not properly nested in the coarse level");
-  const double invdenom = 1.0 / (progMax - progMin);
+  // the ghost-free output state (curvature.cpp:833-839) is put together on the device and comes down in one piece:
+  // input components (valid cells of the state: the passes only write ghost cells), Progress (curvature.cpp:319, the
+  // same two operations as everywhere else), then the results; slots whose option is off stay 0.0
   for (int lev = 0; lev < Nlev; ++lev) {
-    res[lev].define(H.lev[lev].boxes, nres, 0);
-    ctx.check(pa_mf_download(ctx.h, dout[lev]->h, res[lev].data.data()));
-    ostate[lev].define(H.lev[lev].boxes, nCompOut, 0);  // ghost-free output state (curvature.cpp:833-839)
-    for (size_t b = 0; b < H.lev[lev].boxes.size(); ++b) {
-      const pa::Box3& B = H.lev[lev].boxes[b];
-      const size_t nx = (size_t)(B.hi[0] - B.lo[0] + 1);
-      auto cp = [&](int dstc, int srcc, int k, int j) { std::memcpy(ostate[lev].ptr((int)b, dstc, B.lo[0], j, k), res[lev].ptr((int)b, srcc, B.lo[0], j, k), 8 * nx); };
-      for (int k = B.lo[2]; k <= B.hi[2]; ++k)
-        for (int j = B.lo[1]; j <= B.hi[1]; ++j) {
-          for (int c = 0; c < nCompIn; ++c) std::memcpy(ostate[lev].ptr((int)b, c, B.lo[0], j, k), in[lev].ptr((int)b, devOf(c), B.lo[0], j, k), 8 * nx);
-          const double* sv = in[lev].ptr((int)b, 0, B.lo[0], j, k);
-          double* pr = ostate[lev].ptr((int)b, idProg, B.lo[0], j, k);
-          for (size_t i = 0; i < nx; ++i) pr[i] = (sv[i] - progMin) * invdenom;  // curvature.cpp:319 (same fp order as the device)
-          cp(idKm, rK, k, j);
-          for (int d = 0; d < PA_SPACEDIM; ++d) cp(idN + d, rN + d, k, j);
-          if (do_smooth) cp(idSmProg, 17, k, j);
-          if (do_gaussCurv) cp(idKg, rKg, k, j);
-          if (do_strain) cp(idSR, rSR, k, j);
-          if (getStrainTensor)
-            for (int a = 0; a < PA_SPACEDIM; ++a)
-              for (int e = 0; e < PA_SPACEDIM; ++e) cp(idROST + a * PA_SPACEDIM + e, rROST + a * 3 + e, k, j);  // the library's tensor is 3 x 3 row-major
-          if (do_velnormal) cp(idVelNormal, rVn, k, j);
-        }
-    }
+    pa::DevMF dfin(ctx, *dl[lev], nCompOut, 0);
+    ctx.check(pa_mf_setval(ctx.h, dfin.h, 0, nCompOut, 0.0));
+    for (int c = 0; c < nCompIn; ++c) ctx.check(pa_mf_copy(ctx.h, dst[lev]->h, devOf(c), dfin.h, c, 1, 0));
+    ctx.check(pa_progress_level(ctx.h, dst[lev]->h, 0, progMin, progMax, dfin.h, idProg, 0));
+    auto cp = [&](int dstc, int srcc) { ctx.check(pa_mf_copy(ctx.h, dout[lev]->h, srcc, dfin.h, dstc, 1, 0)); };
+    cp(idKm, rK);
+    for (int d = 0; d < PA_SPACEDIM; ++d) cp(idN + d, rN + d);
+    if (do_smooth) cp(idSmProg, 17);
+    if (do_gaussCurv) cp(idKg, rKg);
+    if (do_strain) cp(idSR, rSR);
+    if (getStrainTensor)
+      for (int a = 0; a < PA_SPACEDIM; ++a)
+        for (int e = 0; e < PA_SPACEDIM; ++e) cp(idROST + a * PA_SPACEDIM + e, rROST + a * 3 + e);  // the library's tensor is 3 x 3 row-major
+    if (do_velnormal) cp(idVelNormal, rVn);
+    ostate[lev].define(H.lev[lev].boxes, nCompOut, 0);
+    ctx.check(pa_mf_download(ctx.h, dfin.h, ostate[lev].data.data()));
     if (verbose) std::cout << "Mean curvature has been computed on level " << lev << "\n";
   }
   std::vector<std::string> nnames(inNames);
