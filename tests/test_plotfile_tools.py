@@ -418,6 +418,16 @@ def test_isosurface2d_tool_end_to_end(tmp_path, oracle, per):
             nrm = np.array([(p0[1] - p1[1]) / length, (p1[0] - p0[0]) / length]) if length > 0 else np.zeros(2)
             integ += nrm * 0.5 * (p0[2] + p1[2]) * length
         assert np.allclose(g, integ, rtol=2e-5, atol=1e-9), (g, integ)
+    # XDMF (Polyline / XY): 0-based segments, then (x, y) per node, then one array per component
+    _run("isosurface2d.ex", ["infile=" + p, "isoCompName=temp", "isoVal=1150", "comps=0 1", "is_per=%d %d" % per, "surfFormat=XDMF",
+                             "outfile_base=" + str(tmp_path / "x2")], tmp_path)
+    xmf, raw = open(str(tmp_path / "x2.xmf")).read(), open(str(tmp_path / "x2.mesh"), "rb").read()
+    nn, ne = len(onodes), len(oelts)
+    assert f'TopologyType="Polyline" NodesPerElement="2" NumberOfElements="{ne}"' in xmf and 'GeometryType="XY"' in xmf and f'Seek="{8 * ne}" Dimensions="{2 * nn}"' in xmf
+    assert len(raw) == 8 * ne + 8 * nn * 4
+    assert np.array_equal(np.frombuffer(raw[:8 * ne], "<i4").reshape(ne, 2), oelts)
+    xy = np.frombuffer(raw[8 * ne:8 * ne + 16 * nn], "<f8").reshape(nn, 2)
+    assert np.array_equal(xy.view(np.int64), np.ascontiguousarray(onodes[:, :2]).view(np.int64))
     # a 3-D tool refuses the 2-D plotfile, the 2-D tool a 3-D one; the distance function aborts as in the reference
     bad = subprocess.run([os.path.join(BIN, "isosurface3d.ex"), "infile=" + p, "isoCompName=temp"], cwd=tmp_path, capture_output=True, text=True)
     assert bad.returncode != 0 and "3-D" in bad.stderr

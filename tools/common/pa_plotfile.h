@@ -444,9 +444,10 @@ inline MefSurface read_mef(const std::string& file) {
 // XDMF surface (isosurface.cpp:2135-2229): <base>.xmf (XML, precision 8) + <base>.mesh = raw int32 0-based
 // connectivity, then xyz per node, then each mapped component as one array of doubles
 inline void write_xdmf(const std::string& base, double time, const std::string& isoCompName, double isoVal, const std::vector<std::string>& varnames,
-                       const std::vector<double>& nodes /* [N][3+nvar] */, const std::vector<int32_t>& elts0 /* [M][3], 0-based */) {
-  const int nvar = (int)varnames.size(), nc = 3 + nvar;
-  const size_t N = nodes.size() / (size_t)nc, M = elts0.size() / 3;
+                       const std::vector<double>& nodes /* [N][dim+nvar] */, const std::vector<int32_t>& elts0 /* [M][dim], 0-based */, int dim = 3) {
+  // dim = 2: the 2-D build -- Polyline topology with two nodes per element, XY geometry (isosurface.cpp:2168-2183)
+  const int nvar = (int)varnames.size(), nc = dim + nvar;
+  const size_t N = nodes.size() / (size_t)nc, M = elts0.size() / (size_t)dim;
   const std::string mesh = base + ".mesh";
   std::ofstream x(base + ".xmf");
   if (!x) Abort("Unable to create " + base + ".xmf");
@@ -456,12 +457,13 @@ inline void write_xdmf(const std::string& base, double time, const std::string& 
   x << "      <Information Name=\"Variable\" Value=\"" << isoCompName << "\"/>\n";
   x << "      <Information Name=\"IsoValue\" Value=\"" << isoVal << "\"/>\n";
   x << "      <Time Value=\"" << time << "\"/>\n";
-  x << "         <Topology TopologyType=\"Triangle\" NumberOfElements=\"" << M << "\">\n";
-  x << "            <DataItem Name=\"Conn\" Format=\"Binary\" DataType=\"Int\" Dimensions=\"" << 3 * M << "\">\n               " << mesh << "\n            </DataItem>\n";
-  x << "         </Topology>\n         <Geometry GeometryType=\"XYZ\">\n";
-  x << "            <DataItem Name=\"Coord\" Format=\"Binary\" Precision=\"8\" DataType=\"Float\" Seek=\"" << seek << "\" Dimensions=\"" << 3 * N << "\">\n               " << mesh
+  if (dim == 2) x << "         <Topology TopologyType=\"Polyline\" NodesPerElement=\"2\" NumberOfElements=\"" << M << "\">\n";
+  else x << "         <Topology TopologyType=\"Triangle\" NumberOfElements=\"" << M << "\">\n";
+  x << "            <DataItem Name=\"Conn\" Format=\"Binary\" DataType=\"Int\" Dimensions=\"" << dim * M << "\">\n               " << mesh << "\n            </DataItem>\n";
+  x << "         </Topology>\n         <Geometry GeometryType=\"" << (dim == 2 ? "XY" : "XYZ") << "\">\n";
+  x << "            <DataItem Name=\"Coord\" Format=\"Binary\" Precision=\"8\" DataType=\"Float\" Seek=\"" << seek << "\" Dimensions=\"" << dim * N << "\">\n               " << mesh
     << "\n            </DataItem>\n         </Geometry>\n";
-  seek += 3 * N * sizeof(double);
+  seek += dim * N * sizeof(double);
   for (int c = 0; c < nvar; ++c) {
     x << "         <Attribute Name=\"" << varnames[c] << "\" AttributeType=\"Scalar\" Center=\"Node\">\n";
     x << "            <DataItem Format=\"Binary\" Precision=\"8\" DataType=\"Float\" Seek=\"" << seek << "\" Dimensions=\"" << N << "\">\n               " << mesh
@@ -472,9 +474,9 @@ inline void write_xdmf(const std::string& base, double time, const std::string& 
   std::ofstream f(mesh, std::ios::binary | std::ios::trunc);
   if (!f) Abort("Unable to create " + mesh);
   f.write((const char*)elts0.data(), sizeof(int32_t) * elts0.size());
-  for (size_t q = 0; q < N; ++q) f.write((const char*)&nodes[q * nc], sizeof(double) * 3);
+  for (size_t q = 0; q < N; ++q) f.write((const char*)&nodes[q * nc], sizeof(double) * dim);
   for (int c = 0; c < nvar; ++c)
-    for (size_t q = 0; q < N; ++q) f.write((const char*)&nodes[q * nc + 3 + c], sizeof(double));
+    for (size_t q = 0; q < N; ++q) f.write((const char*)&nodes[q * nc + dim + c], sizeof(double));
 }
 
 // BoxArray::maxSize: chop every box into pieces <= n per direction (even split)

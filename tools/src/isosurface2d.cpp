@@ -2,11 +2,11 @@
 // contour of a 2-D AMR plotfile as line segments (Segmentise, :303-406), merged over levels, written as an MEF file
 // with two nodes per element, plus the contour-line assembly (MakeCLines, :1159-1265) and its "Integral:" lines.
 //   isosurface2d.ex infile=<plt> isoCompName=<name> isoVal=<v> [comps=<list> | sComp=0 nComp=1] [finestLevel=<n>]
-//       [rm_external_elements=1] [nGrow=1] [is_per="0 0"] [writeSurf=1] [outfile_base=<infile>_<comp>_<isoVal>] [verbose=0]
+//       [rm_external_elements=1] [nGrow=1] [is_per="0 0"] [writeSurf=1] [surfFormat=MEF|XDMF] [outfile_base=<infile>_<comp>_<isoVal>] [verbose=0]
 // The plotfile's plane of cells is handed to the library as boxes with k = 0; the state holds 2 coordinate components
 // + the mapped ones; ghost fill, fine-covered mask and the per-FAB loop are the 3-D tool's (tools/src/isosurface.cpp)
 // with pa_msq_level_fine in place of pa_mc_level_fine.  build_distance_function aborts as in the reference (:1364-1366);
-// surfFormat=XDMF is not available in this build.
+// surfFormat=XDMF writes the Polyline / XY variant of the 3-D tool's file.
 #include "../common/pa_device.h"
 #include "../common/pa_isomerge.h"
 #include <chrono>
@@ -241,8 +241,16 @@ int main(int argc, char** argv) {
   pp.query("writeSurf", writeSurf);
   std::string surfFormat = "MEF";
   pp.query("surfFormat", surfFormat);
-  if (surfFormat != "MEF") pa::Abort("surfFormat must be MEF in the 2-D build");
-  if (writeSurf) {
+  if (surfFormat != "MEF" && surfFormat != "XDMF") pa::Abort("surfFormat must be MEF or XDMF");
+  if (writeSurf && surfFormat == "XDMF") {  // isosurface.cpp:2135-2229 (Polyline / XY); quirk kept: the default name carries the plotfile TIME
+    char buf[72];
+    std::snprintf(buf, sizeof buf, "%g", H.time);
+    std::string outfile_base = infile + "_" + isoCompName + "_" + std::string(buf);
+    pp.query("outfile_base", outfile_base);
+    std::vector<std::string> vn;
+    for (int n = 0; n < nComp; ++n) vn.push_back(H.names[pltComps[n]]);
+    pa::write_xdmf(outfile_base, H.time, isoCompName, isoVal, vn, merger.nodes(), elts, 2);
+  } else if (writeSurf) {
     std::cout << "...write surface in mef format (mef = Marcs element format)" << std::endl;
     std::cout << "      (Nelts,Nnodes):(" << elts.size() / 2 << ", " << merger.num_nodes() << ")" << std::endl;
     // isosurface.cpp:2021-2063: connect the segments into contour lines and integrate the first mapped component times
