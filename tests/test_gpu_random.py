@@ -1,0 +1,156 @@
+"""GPU parity on randomly drawn hierarchies (fixed seeds): odd domain extents, uneven box chops, fine regions touching or
+crossing periodic faces and walls, two or three levels, every boundary-condition mix, with and without the threshold.
+The gradient tool's kernels, the fused sweep + face fix-up and the pass-by-pass kernels against the CPU oracle, bit for
+bit -- the point is shapes nobody wrote a dedicated case for."""
+import numpy as np
+import pytest
+
+from peleanalysis_amd import capi
+from peleanalysis_amd.hierarchy import Hierarchy, Level, MultiFab, chop_box, field_flame, field_trig
+from util import assert_valid_bits_equal, make_states
+
+pytestmark = pytest.mark.gpu
+
+
+def _draw(seed):
+    rng = np.random.default_rng(1000 + seed)
+    n = rng.integers(10, 36, size=3)
+    per = rng.integers(0, 2, size=3)
+    sym = np.where(per == 1, 0, rng.integers(0, 2, size=3))
+    dom_hi = n - 1
+    levels = [Level(chop_box((0, 0, 0), dom_hi, int(rng.integers(5, 20))), (0, 0, 0), dom_hi, per, np.zeros(3), np.ones(3))]
+    lo, hi = np.zeros(3, dtype=np.int64), dom_hi.astype(np.int64)  # region of the current level in ITS index space
+    nlev = int(rng.integers(2, 4))
+    for l in range(1, nlev):
+        ext = hi - lo + 1
+        if np.any(ext < 10):
+            break
+        # refined region in the coarse index space: at least 2 coarse cells inside the coarse region on every side, so
+        # that the fine ghost cells (2 layers = 1 coarse cell) find coarse data; sometimes flush with a periodic face
+        clo = lo + rng.integers(2, np.maximum(3, ext // 3))
+        chi = hi - rng.integers(2, np.maximum(3, ext // 3))
+        if l == 1:
+            for d in range(3):
+                if per[d] and rng.random() < 0.4:
+                    clo[d] = lo[d]  # touches the periodic face: its ghost cells wrap to coarse cells on the far side
+        if np.any(chi - clo < 2):
+            break
+        flo, fhi = 2 * clo, 2 * chi + 1
+        size = int(rng.choice([4, 6, 8, 10, 14, 16]))
+        domhi_f = 2 * (np.asarray(levels[-1].domhi) + 1) - 1
+        levels.append(Level(chop_box(flo, fhi, size), (0, 0, 0), domhi_f, per, np.zeros(3), np.ones(3)))
+        lo, hi = flo, fhi
+    return Hierarchy(levels, 2), tuple(int(x) for x in per), tuple(int(x) for x in sym), (field_flame if seed % 2 else field_trig)
+
+
+import os
+
+NSEEDS = int(os.environ.get("PA_RANDOM_SEEDS", "16"))  # PA_RANDOM_SEEDS=200 for a longer hunt
+
+
+@pytest.mark.parametrize("seed", range(NSEEDS))
+def test_random_hierarchy_matches_oracle(ctx, oracle, seed):
+    H, per, sym, fn = _draw(seed)
+    thr = None if seed % 3 else 0.03
+    states = make_states(H, 1, 2, fn, seed=seed)
+    bc = capi.bc_from_flags(per, sym)
+    og = [MultiFab(lv, 4, 0) for lv in H.levels]
+    oracle.grad_pipeline(H.levels, [s.copy() for s in states], 0, bc, og, 0, multipass=True)
+    oc = [MultiFab(lv, 5, 0) for lv in H.levels]
+    oracle.curvature_pipeline(H.levels, [s.copy() for s in states], 0, bc, oc, 0, MultiFab, threshold=thr)
+    tag = f"seed {seed}: {[tuple(lv.domhi + 1) for lv in H.levels]} per {per} sym {sym} boxes {[lv.nboxes for lv in H.levels]}"
+    for fused in (True, False):
+        dls = [capi.DevLevel(ctx, lv) for lv in H.levels]
+        dst = [capi.DevMF.from_host(ctx, dl, s) for dl, s in zip(dls, states)]
+        work = [capi.DevMF(ctx, dl, 1, 2) for dl in dls]
+        dout = [capi.DevMF(ctx, dl, 8, 0) for dl in dls]
+        capi.gradcurv_run(ctx, dst, 0, bc, capi.curv_params(threshold=thr, fused=fused), work, dout, 0)
+        ctx.sync()
+        assert ctx.bc_errors() == 0, tag
+        for l in range(H.nlev):
+            got = dout[l].download()
+            assert_valid_bits_equal(got, og[l], [(c, c) for c in range(4)], f"{tag} fused {fused} grad level {l}")
+            assert_valid_bits_equal(got, oc[l], [(4, 2), (5, 3), (6, 4), (7, 1)], f"{tag} fused {fused} curv level {l}")
+    # the gradient tool's own pipeline (1 ghost layer is enough for it)
+    dls = [capi.DevLevel(ctx, lv) for lv in H.levels]
+    dst = [capi.DevMF.from_host(ctx, dl, s) for dl, s in zip(dls, states)]
+    dgr = [capi.DevMF(ctx, dl, 4, 0) for dl in dls]
+    capi.grad_run(ctx, dst, 0, bc, dgr, 0)
+    ctx.sync()
+    for l in range(H.nlev):
+        assert_valid_bits_equal(dgr[l].download(), og[l], [(c, c) for c in range(4)], f"{tag} grad_run level {l}")
+
+
+@pytest.mark.parametrize("seed", range(NSEEDS))
+def test_random_hierarchy_isosurface_and_filter(ctx, oracle, seed):
+    """the same random hierarchies through the level-batched marching cubes (mask evaluated from the finer level, periodic
+    images included; 1 or 2 ghost layers) and through the box filter with its ghost fill (conservative-linear or
+    piecewise-constant; 27 or 125 taps), against the oracle per FAB"""
+    import ctypes as C
+    H, per, sym, fn = _draw(seed)
+    rng = np.random.default_rng(77 + seed)
+    ng, nc = int(rng.integers(1, 3)), 5
+    fields = make_states(H, 2, 0, fn, seed=seed + 1)
+    states = []
+    for l, lv in enumerate(H.levels):
+        st = MultiFab(lv, nc, ng, fill=-666.0)
+        for b in range(lv.nboxes):
+            f = st.fab(b)
+            lo = lv.boxes[b, :3] - ng
+            nz, ny, nx = f.shape[1:]
+            f[0] = ((np.arange(lo[0], lo[0] + nx) + 0.5) * lv.dx[0] + lv.prob_lo[0])[None, None, :]
+            f[1] = ((np.arange(lo[1], lo[1] + ny) + 0.5) * lv.dx[1] + lv.prob_lo[1])[None, :, None]
+            f[2] = ((np.arange(lo[2], lo[2] + nz) + 0.5) * lv.dx[2] + lv.prob_lo[2])[:, None, None]
+            st.valid(b)[3:5] = fields[l].valid(b)[0:2]
+        oracle.fill_boundary(st, 0, nc, ng)
+        if l > 0:
+            assert oracle.lib().orc_fillpatch_two_levels(C.byref(oracle._mf(st)), C.byref(oracle._mf(states[l - 1])), 0, nc, ng, 2, 0) == 0
+        states.append(st)
+    allv = np.concatenate([s.valid(b)[3].ravel() for s in states for b in range(s.level.nboxes)])
+    iso = float(np.quantile(allv, 0.4))
+    dls = [capi.DevLevel(ctx, lv) for lv in H.levels]
+    ntri = 0
+    for l, lv in enumerate(H.levels):
+        dst = capi.DevMF.from_host(ctx, dls[l], states[l])
+        loops, want = np.zeros((lv.nboxes, 6), np.int64), []
+        for b in range(lv.nboxes):
+            lo, hi, mask, llo, lhi = oracle.iso_fab_inputs(H.levels, states, l, b, ng)
+            loops[b, :3], loops[b, 3:] = llo, lhi
+            want.append(oracle.mc_fab(np.ascontiguousarray(states[l].fab(b)), mask, lo, hi, 3, iso, llo, lhi))
+        got = capi.mc_level(ctx, dst, dls[l + 1] if l + 1 < H.nlev else None, loops, 3, iso)
+        for b in range(lv.nboxes):
+            (v, k, t), (gv, gk, gt) = want[b], got[b]
+            assert (len(gv), len(gt)) == (len(v), len(t)), f"seed {seed} level {l} box {b}: counts differ"
+            assert np.array_equal(gk, k) and np.array_equal(gt, t), f"seed {seed} level {l} box {b}: keys / connectivity differ"
+            assert np.array_equal(gv.view(np.int64), np.ascontiguousarray(v).view(np.int64)), f"seed {seed} level {l} box {b}: vertex data differ"
+            ntri += len(t)
+    assert ntri > 0
+    # box filter, the same width on every level (fgr 2 or 4: 1 or 2 ghost layers -- the random fine regions keep 2 coarse
+    # cells to their level's edge, which is what 2 fine ghost layers + the interpolation stencil need)
+    interp = int(rng.integers(0, 2))
+    base_fgr = int(rng.choice([2, 4]))
+    ngl = [base_fgr // 2] * H.nlev
+    ins = [MultiFab(lv, 2, g, fill=0.0) for lv, g in zip(H.levels, ngl)]
+    for l, lv in enumerate(H.levels):
+        for b in range(lv.nboxes):
+            ins[l].valid(b)[:] = fields[l].valid(b)
+    oin = [m.copy() for m in ins]
+    oouts = [MultiFab(lv, 2, 0) for lv in H.levels]
+    info = oracle.filter_pipeline(H.levels, oin, oouts, 2, base_fgr=base_fgr, same_fgr_all_levels=True, interp_type=interp)
+    for l, lv in enumerate(H.levels):
+        din = capi.DevMF.from_host(ctx, dls[l], ins[l])
+        if l == 0:
+            dprev = None
+        ctx.check(ctx.lib.pa_fill_boundary(ctx.h, din.h, 0, 2, ngl[l]))
+        if l > 0:
+            ctx.check(ctx.lib.pa_fillpatch_two_levels(ctx.h, din.h, dprev.h, 0, 2, ngl[l], 2, interp))
+        ctx.check(ctx.lib.pa_foextrap(ctx.h, din.h, 0, 2, ngl[l]))
+        dout = capi.DevMF(ctx, dls[l], 2, 0)
+        fgr, ngf = info[l]
+        w = (C.c_double * (2 * ngf + 1))()
+        assert ctx.lib.pa_box_filter_weights(fgr, w) == ngf == ngl[l]
+        ctx.check(ctx.lib.pa_boxfilter_level(ctx.h, din.h, dout.h, 0, 2, ngf, w))
+        ctx.sync()
+        assert ctx.bc_errors() == 0
+        assert_valid_bits_equal(dout.download(), oouts[l], [(0, 0), (1, 1)], f"seed {seed} filter level {l} interp {interp}")
+        dprev = din
