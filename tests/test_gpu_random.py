@@ -154,3 +154,25 @@ def test_random_hierarchy_isosurface_and_filter(ctx, oracle, seed):
         assert ctx.bc_errors() == 0
         assert_valid_bits_equal(dout.download(), oouts[l], [(0, 0), (1, 1)], f"seed {seed} filter level {l} interp {interp}")
         dprev = din
+
+
+@pytest.mark.parametrize("seed", range(NSEEDS))
+def test_random_hierarchy_curvature_options(ctx, oracle, seed):
+    """the same hierarchies through pa_curvature_run with every option on (Gaussian curvature, strain rate + tensor,
+    flame-normal velocity; curvature.cpp:575-789) against the oracle, all 17 output components bit for bit"""
+    H, per, sym, fn = _draw(seed)
+    thr = None if seed % 2 else 0.04
+    states = make_states(H, 4, 2, fn, seed=seed + 5)  # comp 0 = progress source, 1..3 = velocity
+    bc = capi.bc_from_flags(per, sym)
+    oout = [MultiFab(lv, 17, 0) for lv in H.levels]
+    oracle.curvature_pipeline(H.levels, [s.copy() for s in states], 0, bc, oout, 0, MultiFab, threshold=thr, do_gauss=True, vel_comp=1, do_strain=True,
+                              do_velnormal=True, strain_tensor=True)
+    dls = [capi.DevLevel(ctx, lv) for lv in H.levels]
+    dst = [capi.DevMF.from_host(ctx, dl, s) for dl, s in zip(dls, states)]
+    dout = [capi.DevMF(ctx, dl, 17, 0) for dl in dls]
+    P = capi.curv_params(threshold=thr, fused=False, do_gauss=True, do_strain=True, strain_tensor=True, do_velnormal=True, vel_comp=1)
+    capi.curvature_run(ctx, dst, 0, bc, P, dout, 0)
+    ctx.sync()
+    assert ctx.bc_errors() == 0
+    for l in range(H.nlev):
+        assert_valid_bits_equal(dout[l].download(), oout[l], [(c, c) for c in range(17)], f"seed {seed} options level {l}")
