@@ -130,13 +130,23 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the product path has no CPU fallback)")
+    # PA_BENCH_REHEARSE=1: rehearsal of the N > 1 code path on a box with FEWER GPUs than ranks -- ranks share the cards,
+    # transport is gloo through host memory (RCCL wants one GPU per rank).  Same hierarchy split, same region lists,
+    # same pack / unpack kernels, same reductions; the number it prints is not a scaling measurement.
+    rehearse = os.environ.get("PA_BENCH_REHEARSE", "0") == "1"
+    if rehearse:
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    rdev = torch.device("cpu") if rehearse else dev  # where the tiny reduction tensors live
     gloo = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     stream = torch.cuda.Stream(device=dev)
     ctx = capi.Context(local, stream.cuda_stream)
 
@@ -185,11 +195,13 @@ def main():
     if world > 1:
         xch["bytes_per_step"] = int(sum(8 * pl.size(v, 1) for pl in plans for v in pl.send.values()) * args.ncomp)
         try:
+            if rehearse:
+                raise RuntimeError("PA_BENCH_REHEARSE=1: gloo transport")
             exchange_rccl(0)
-            ok = torch.tensor([1], device=dev)
+            ok = torch.tensor([1], device=rdev)
         except Exception as e:  # keep the measurement valid (all work done) if RCCL p2p is unavailable
             xch["rccl_error"] = repr(e)[:300]
-            ok = torch.tensor([0], device=dev)
+            ok = torch.tensor([0], device=rdev)
         try:
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             use_rccl = bool(ok.item())
@@ -198,7 +210,7 @@ def main():
         if use_rccl:
             do_exchange, xch["mode"] = exchange_rccl, "RCCL point-to-point (batch_isend_irecv), one packed buffer per peer"
         else:
-            gloo = dist.new_group(backend="gloo")
+            gloo = None if rehearse else dist.new_group(backend="gloo")  # rehearsal: the default group is gloo already
             do_exchange, xch["mode"] = exchange_gloo, "host-staged gloo point-to-point (RCCL p2p failed)"
 
     def step():
@@ -235,7 +247,7 @@ def main():
     bd = {name: ctx.profile_read(tag)[1] / nbd for name, tag in (("gradcurv", 1), ("faces", 2), ("fill_boundary", 3), ("apply_bc", 4), ("progress", 6))}
     ctx.profile_read(1, reset=True)  # a reset drops every tag's records
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=rdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
