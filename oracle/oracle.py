@@ -44,6 +44,8 @@ _LIBS = {}
 
 def lib(omp: bool = False):
     name = "libpa_oracle_omp.so" if omp else "libpa_oracle.so"
+    if os.environ.get("PA_ORACLE_VARIANT") == "asan":  # tests/test_sanitizers.py: `make -C oracle asan`, libasan preloaded
+        name = "libpa_oracle_asan.so"
     if name not in _LIBS:
         path = os.path.join(_HERE, "_build", name)
         if not os.path.exists(path):

@@ -1,0 +1,96 @@
+"""AddressSanitizer + UndefinedBehaviorSanitizer on the CPU side (GPU sanitizers are not available on the pool):
+the C oracle's pipelines on small hierarchies, and the tools' host-only paths (threaded plotfile reader / writer, MEF
+consumers), each in a child process with the sanitizer runtime active.  Any report aborts the child."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ASAN_ENV = {"ASAN_OPTIONS": "detect_leaks=0:abort_on_error=1:halt_on_error=1", "UBSAN_OPTIONS": "halt_on_error=1:print_stacktrace=1"}
+
+CHILD = r'''
+import sys
+sys.path.insert(0, "%(root)s"); sys.path.insert(0, "%(root)s/tests")
+import numpy as np
+from oracle import oracle
+from peleanalysis_amd.hierarchy import MultiFab
+from util import CONFIGS, build_config, make_states
+for name in ("amr3_wall_z", "amr2_allwalls_ragged", "amr3_sym_x"):
+    H, per, sym, fn = build_config(name)
+    bc = oracle.bc_from_flags(per, sym)
+    states = make_states(H, 4, 2, fn, seed=3)
+    og = [MultiFab(lv, 4, 0) for lv in H.levels]
+    oracle.grad_pipeline(H.levels, [s.copy() for s in states], 0, bc, og, 0, multipass=True)
+    oracle.grad_pipeline(H.levels, [s.copy() for s in states], 0, bc, og, 0, multipass=False)
+    oc = [MultiFab(lv, 18, 0) for lv in H.levels]
+    oracle.curvature_pipeline(H.levels, [s.copy() for s in states], 0, bc, oc, 0, MultiFab, threshold=0.05, do_gauss=True, vel_comp=1, do_strain=True,
+                              do_velnormal=True, strain_tensor=True)
+    ins = [MultiFab(lv, 2, 4, fill=0.0) for lv in H.levels]
+    for l, lv in enumerate(H.levels):
+        for b in range(lv.nboxes):
+            ins[l].valid(b)[:] = states[l].valid(b)[:2]
+    oracle.filter_pipeline(H.levels, ins, [MultiFab(lv, 2, 0) for lv in H.levels], 2, base_fgr=2, same_fgr_all_levels=True)
+    fields = [MultiFab(lv, 4, 0) for lv in H.levels]
+    for l, lv in enumerate(H.levels):
+        for b in range(lv.nboxes):
+            fields[l].valid(b)[:] = states[l].valid(b)
+    iso = float(np.median(np.concatenate([fields[0].valid(b)[0].ravel() for b in range(H.levels[0].nboxes)])))
+    nodes, elts = oracle.isosurface_pipeline(H.levels, fields, [0, 1], 0, iso, MultiFab)
+    assert len(elts) > 0
+    nodes, elts, dist = oracle.isosurface_pipeline(H.levels, fields, [0], 0, iso, MultiFab, build_distance=True)
+H, per, sym, fn = build_config("c1_periodic_1lev")
+states = make_states(H, 1, 2, fn, seed=1)
+oc = [MultiFab(lv, 18, 0) for lv in H.levels]
+oracle.curvature_pipeline(H.levels, states, 0, oracle.bc_from_flags(per, sym), oc, 0, MultiFab, do_smooth=True, smoothing_time=1e-3)
+print("oracle under ASan/UBSan OK")
+'''
+
+
+def _asan_lib():
+    p = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    return p if os.path.isabs(p) and os.path.exists(p) else None
+
+
+def test_oracle_under_address_and_ub_sanitizers():
+    lib = _asan_lib()
+    if lib is None:
+        import pytest
+        pytest.skip("libasan not available")
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "asan"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    env = dict(os.environ, LD_PRELOAD=lib, PA_ORACLE_VARIANT="asan", **ASAN_ENV)
+    r = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0 and "oracle under ASan/UBSan OK" in r.stdout, r.stdout[-1500:] + r.stderr[-4000:]
+
+
+def test_tool_host_paths_under_sanitizers(tmp_path):
+    """C++ plotfile reader -> copy -> threaded writer (template3d), MEF reader + consumers, under ASan/UBSan"""
+    from peleanalysis_amd.hierarchy import field_flame, nested_hierarchy
+    from peleanalysis_amd.plotfile import read_plotfile, write_plotfile
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util import make_states
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "tools"), "asan"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    H = nested_hierarchy(16, 3, 8, is_per=(1, 1, 0))
+    mfs = make_states(H, 3, 0, field_flame, seed=2)
+    p = str(tmp_path / "plt00001")
+    write_plotfile(p, H, mfs, ["temp", "x_velocity", "density"], time=0.5, level_steps=[1, 1, 1])
+    env = dict(os.environ, PA_IO_THREADS="4", **ASAN_ENV)
+    bin_asan = os.path.join(ROOT, "tools", "bin_asan")
+    out = subprocess.run([os.path.join(bin_asan, "template3d.ex"), "infile=" + p, "is_per=1 1 0"], cwd=tmp_path, capture_output=True, text=True, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    back = read_plotfile(str(tmp_path / "plt00001_temp"))
+    for l in range(3):
+        assert np.array_equal(back.mfs[l].data.view(np.int64), mfs[l].data.view(np.int64))
+    nodes = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]], float)
+    faces = np.array([[1, 3, 2], [1, 2, 4], [2, 3, 4], [3, 1, 4]], np.int32)
+    f = str(tmp_path / "tet.mef")
+    with open(f, "wb") as fh:
+        fh.write(b"0.5\nX Y Z\n4 3\nFAB ((8, (64 11 52 0 1 12 0 1023)),(8, (8 7 6 5 4 3 2 1)))((0,0,0) (3,0,0) (0,0,0)) 3\n")
+        fh.write(nodes.astype("<f8").tobytes())
+        fh.write(faces.astype("<i4").tobytes())
+    for tool, args in (("checkIso3d.ex", ["isoFile=" + f, "strict=1"]), ("surfMEFtoDAT3d.ex", ["infile=" + f])):
+        out = subprocess.run([os.path.join(bin_asan, tool)] + args, cwd=tmp_path, capture_output=True, text=True, env=env)
+        assert out.returncode == 0, out.stderr[-3000:]
