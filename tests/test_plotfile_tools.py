@@ -599,3 +599,74 @@ def test_curvature2d_tool_options(tmp_path, oracle):
                 assert np.array_equal(np.ascontiguousarray(got[gc]).view(np.int64), np.ascontiguousarray(want[wc]).view(np.int64)), (l, b, gc, wc)
             assert (want[10] == 0.0).all() and (want[13] == 0.0).all() and (want[14] == 0.0).all()  # d/dz and dw/d. vanish exactly
     assert any((k.mfs[1].valid(b)[8] != 0).any() for b in range(H.levels[1].nboxes))
+
+
+@pytest.mark.gpu
+def test_tool_options_level_limits_ranges_inputs_file(tmp_path, oracle):
+    """keys the other tests leave at their defaults: finestLevel / max_filter_level (fewer levels than the file holds),
+    useFileMinMax=0 with progMin / progMax, same_fgr_all_levels + interp_type=0 + base_fgr=4, sComp / nComp, and the
+    `exe inputs_file key=value` form (later definitions win)"""
+    from peleanalysis_amd import capi
+    p, H, mfs = _synth(tmp_path, nlev=3, base=16, box=8, per=(1, 1, 0))
+    H2 = type(H)(H.levels[:2], 2)
+    bc = capi.bc_from_flags((1, 1, 0), (0, 0, 0))
+    # grad: finestLevel=1 from an inputs file, overridden outfile on the command line
+    inp = tmp_path / "inputs.grad"
+    inp.write_text("# sample inputs (Src/InputsSamples/inputs.grad)\ninfile = %s\ngradVar = temp\nfinestLevel = 1\nis_per = 1 1 0\noutfile = ignored\n" % p)
+    _run("grad3d.ex", [str(inp), "outfile=" + str(tmp_path / "g1")], tmp_path)
+    r = read_plotfile(str(tmp_path / "g1"))
+    assert r.hier.nlev == 2 and r.names == ["temp", "temp_gx", "temp_gy", "temp_gz", "||gradtemp||"]
+    ost = [MultiFab(lv, 1, 1) for lv in H2.levels]
+    for l, lv in enumerate(H2.levels):
+        for b in range(lv.nboxes):
+            ost[l].valid(b)[0] = mfs[l].valid(b)[0]
+    og = [MultiFab(lv, 4, 0) for lv in H2.levels]
+    oracle.grad_pipeline(H2.levels, ost, 0, bc, og, 0, multipass=True)
+    for l, lv in enumerate(H2.levels):
+        for b in range(lv.nboxes):
+            assert np.array_equal(np.ascontiguousarray(r.mfs[l].valid(b)[1:5]).view(np.int64), np.ascontiguousarray(og[l].valid(b)[0:4]).view(np.int64))
+    # curvature: explicit progress range, two levels
+    _run("curvature3d.ex", ["infile=" + p, "progressName=temp", "is_per=1 1 0", "finestLevel=1", "useFileMinMax=0", "progMin=250", "progMax=2100",
+                            "outfile=" + str(tmp_path / "k1")], tmp_path)
+    k = read_plotfile(str(tmp_path / "k1"))
+    assert k.hier.nlev == 2
+    ost = [MultiFab(lv, 1, 2) for lv in H2.levels]
+    for l, lv in enumerate(H2.levels):
+        for b in range(lv.nboxes):
+            ost[l].valid(b)[0] = mfs[l].valid(b)[0]
+    oc = [MultiFab(lv, 5, 0) for lv in H2.levels]
+    oracle.curvature_pipeline(H2.levels, ost, 0, bc, oc, 0, MultiFab, prog_min=250.0, prog_max=2100.0)
+    for l, lv in enumerate(H2.levels):
+        for b in range(lv.nboxes):
+            got, want = k.mfs[l].valid(b), oc[l].valid(b)
+            for gc, wc in ((1, 0), (3, 1), (4, 2), (5, 3), (6, 4)):
+                assert np.array_equal(np.ascontiguousarray(got[gc]).view(np.int64), np.ascontiguousarray(want[wc]).view(np.int64)), (l, b, gc)
+    # filterPlt: two of three levels, the same 125-tap filter on both, piecewise-constant interpolation
+    _run("filterPlt3d.ex", ["infile=" + p, "max_filter_level=1", "same_fgr_all_levels=1", "base_fgr=4", "interp_type=0", "max_grid_size=8", "is_per=1 1 0",
+                            "variables=temp"], tmp_path)
+    f = read_plotfile(str(tmp_path / "plt00005_filtered"))
+    assert f.hier.nlev == 2 and f.names == ["temp"]
+    ins = [MultiFab(lv, 1, 2, fill=0.0) for lv in H2.levels]
+    for l, lv in enumerate(H2.levels):
+        for b in range(lv.nboxes):
+            ins[l].valid(b)[0] = mfs[l].valid(b)[0]
+    outs = [MultiFab(lv, 1, 0) for lv in H2.levels]
+    assert oracle.filter_pipeline(H2.levels, ins, outs, 1, base_fgr=4, same_fgr_all_levels=True, interp_type=0) == [(4, 2), (4, 2)]
+    for l, lv in enumerate(H2.levels):
+        for b in range(lv.nboxes):
+            assert np.array_equal(np.ascontiguousarray(f.mfs[l].valid(b)).view(np.int64), np.ascontiguousarray(outs[l].valid(b)).view(np.int64)), (l, b)
+    # isosurface: sComp / nComp instead of comps, two levels
+    _run("isosurface3d.ex", ["infile=" + p, "isoCompName=temp", "isoVal=1150", "sComp=0", "nComp=2", "finestLevel=1", "outfile_base=" + str(tmp_path / "s1")],
+         tmp_path)
+    _, names, nodes, faces = read_mef(str(tmp_path / "s1.mef"))
+    assert names == ["X", "Y", "Z", "temp", "x_velocity"]
+    fields = [MultiFab(lv, 3, 0, mfs[l].data.copy()) for l, lv in enumerate(H2.levels)]
+    lv_np = [Level_np for Level_np in H2.levels]
+    import copy
+    nonper = []
+    for lv in lv_np:  # the isosurface tool defaults to is_per = 0 0 0
+        q = copy.copy(lv)
+        q.is_per = np.zeros(3, dtype=lv.is_per.dtype if hasattr(lv.is_per, "dtype") else int)
+        nonper.append(q)
+    onodes, oelts = oracle.isosurface_pipeline(nonper, [MultiFab(q, 3, 0, fields[l].data.copy()) for l, q in enumerate(nonper)], [0, 1], 0, 1150.0, MultiFab)
+    assert np.array_equal(faces, oelts + 1) and np.array_equal(nodes.view(np.int64), onodes.view(np.int64))
