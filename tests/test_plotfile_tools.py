@@ -625,9 +625,12 @@ def test_tool_options_level_limits_ranges_inputs_file(tmp_path, oracle):
     for l, lv in enumerate(H2.levels):
         for b in range(lv.nboxes):
             assert np.array_equal(np.ascontiguousarray(r.mfs[l].valid(b)[1:5]).view(np.int64), np.ascontiguousarray(og[l].valid(b)[0:4]).view(np.int64))
-    # curvature: explicit progress range, two levels
-    _run("curvature3d.ex", ["infile=" + p, "progressName=temp", "is_per=1 1 0", "finestLevel=1", "useFileMinMax=0", "progMin=250", "progMax=2100",
-                            "outfile=" + str(tmp_path / "k1")], tmp_path)
+    # curvature: explicit progress range, two levels; bench_json=1 adds one machine-readable line
+    import json
+    out = _run("curvature3d.ex", ["infile=" + p, "progressName=temp", "is_per=1 1 0", "finestLevel=1", "useFileMinMax=0", "progMin=250", "progMax=2100",
+                                  "outfile=" + str(tmp_path / "k1"), "bench_json=1"], tmp_path)
+    js = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{"tool"')][-1])
+    assert js["tool"] == "curvature3d" and js["cells"] == 2 * 16 ** 3 and set(js["phases_s"]) >= {"read", "upload", "compute", "write"}
     k = read_plotfile(str(tmp_path / "k1"))
     assert k.hier.nlev == 2
     ost = [MultiFab(lv, 1, 2) for lv in H2.levels]

@@ -1,6 +1,6 @@
 // pa_device.h -- glue between the host plotfile containers and the C ABI (device levels / multifabs)
 #pragma once
-#include <memory>
+#include <chrono>
 #include <future>
 #include <memory>
 
@@ -28,6 +28,35 @@ struct AsyncCtx {
   Ctx& get() {
     if (!ctx) ctx = fut.get();
     return *ctx;
+  }
+};
+
+// bench_json=1 on any tool's command line: one machine-readable line at exit with the wall time of each phase (the
+// reference only has isosurface's wall-clock prints; SURVEY 5, metrics row).  {"tool": .., "cells": .., "phases_s": {..}}
+struct PhaseTimer {
+  std::string tool;
+  bool on = false;
+  long long cells = 0;
+  std::vector<std::pair<std::string, double>> ph;
+  double t0, tl;
+  static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+  PhaseTimer(const ParmParse& pp, const std::string& name) : tool(name), t0(now()), tl(t0) {
+    int v = 0;
+    pp.query("bench_json", v);
+    on = v != 0;
+  }
+  void mark(const std::string& phase) {  // everything since the previous mark belongs to `phase`
+    const double t = now();
+    for (auto& p : ph)
+      if (p.first == phase) { p.second += t - tl; tl = t; return; }
+    ph.emplace_back(phase, t - tl);
+    tl = t;
+  }
+  ~PhaseTimer() {
+    if (!on) return;
+    std::cout << "{\"tool\": \"" << tool << "\", \"cells\": " << cells << ", \"total_s\": " << now() - t0 << ", \"phases_s\": {";
+    for (size_t i = 0; i < ph.size(); ++i) std::cout << (i ? ", " : "") << "\"" << ph[i].first << "\": " << ph[i].second;
+    std::cout << "}}" << std::endl;
   }
 };
 

@@ -343,10 +343,29 @@ inline void write_plotfile(const std::string& path, const std::vector<std::strin
       const int fd = ::open(fname.c_str(), O_CREAT | O_TRUNC | O_WRONLY, 0644);
       if (fd < 0) Abort("Unable to create " + fname);
       std::vector<int> bad(nb, 0);
+      auto put = [&](size_t b, const char* p, size_t n, long long at) {
+        size_t done = 0;
+        while (done < n) {
+          const ssize_t r = ::pwrite(fd, p + done, n - done, (off_t)(at + (long long)done));
+          if (r <= 0) { bad[b] = 1; return; }
+          done += (size_t)r;
+        }
+      };
       parallel_for(nb, [&](size_t b) {
         const Box3& B = M.boxes[b];
         const int nx = B.hi[0] - B.lo[0] + 1;
         const long long npts = B.numPts();
+        if (M.ng == 0) {  // a component of a ghost-free FAB is one contiguous run: written straight from the multifab
+          std::vector<double> mn(ncomp, 1e300), mx(ncomp, -1e300);
+          put(b, hdr[b].data(), hdr[b].size(), offs[b]);
+          for (int c = 0; c < ncomp; ++c) {
+            const double* p = M.ptr((int)b, src(c), B.lo[0], B.lo[1], B.lo[2]);
+            for (long long i = 0; i < npts; ++i) { mn[c] = std::min(mn[c], p[i]); mx[c] = std::max(mx[c], p[i]); }
+            put(b, (const char*)p, (size_t)npts * 8, offs[b] + (long long)hdr[b].size() + (long long)c * npts * 8);
+          }
+          mins[b] = mn; maxs[b] = mx;
+          return;
+        }
         std::vector<char> buf(hdr[b].size() + (size_t)ncomp * (size_t)npts * 8);
         std::memcpy(buf.data(), hdr[b].data(), hdr[b].size());
         double* out = (double*)(buf.data() + hdr[b].size());  // may be unaligned: filled with memcpy
@@ -361,12 +380,7 @@ inline void write_plotfile(const std::string& path, const std::vector<std::strin
               for (int i = 0; i < nx; ++i) { mn[c] = std::min(mn[c], p[i]); mx[c] = std::max(mx[c], p[i]); }
             }
         mins[b] = mn; maxs[b] = mx;
-        size_t done = 0;
-        while (done < buf.size()) {
-          const ssize_t r = ::pwrite(fd, buf.data() + done, buf.size() - done, (off_t)(offs[b] + (long long)done));
-          if (r <= 0) { bad[b] = 1; break; }
-          done += (size_t)r;
-        }
+        put(b, buf.data(), buf.size(), offs[b]);
       });
       ::close(fd);
       for (int x : bad) if (x) Abort("short write to " + fname);

@@ -56,6 +56,7 @@ int main(int argc, char** argv) {
   pp.query("smoothing_time", smoothing_time);
   const int nAux = pp.countval("Aux_Variables");
   std::cout << "infile = " << infile << "\n" << "reading plt file = " << infile << "\n";
+  pa::PhaseTimer tm(pp, PA_SPACEDIM == 2 ? "curvature2d" : "curvature3d");
   pa::PlotfileHeader H = pa::read_header(infile, PA_SPACEDIM);
 #if PA_SPACEDIM == 2
   if (do_gaussCurv || do_smooth) pa::Abort("do_gaussCurv / do_smooth are not available in the 2-D build");
@@ -136,8 +137,11 @@ int main(int argc, char** argv) {
     in[lev].define(H.lev[lev].boxes, nCompDev, 2);
     for (int c = 0; c < nCompIn; ++c) pa::read_comp(H, lev, inComps[c], in[lev], devOf(c));
   }
+  tm.mark("read");
   pa::Ctx& ctx = actx.get();
+  tm.mark("hip_context_wait");
   for (int lev = 0; lev < Nlev; ++lev) {
+    for (auto& B : H.lev[lev].boxes) tm.cells += B.numPts();
     dl.emplace_back(new pa::DevLevel(ctx, H.lev[lev].boxes, H.lev[lev].domain, is_per.data(), H.prob_lo, H.prob_hi));
     dst.emplace_back(new pa::DevMF(ctx, *dl.back(), nCompDev, 2));
     dwork.emplace_back(new pa::DevMF(ctx, *dl.back(), 1, 2));
@@ -145,6 +149,7 @@ int main(int argc, char** argv) {
     ctx.check(pa_mf_upload(ctx.h, dst.back()->h, in[lev].data.data()));
     doms.push_back(H.lev[lev].domain);
   }
+  tm.mark("upload");
   std::vector<pa_mf*> s, w, o;
   for (int l = 0; l < Nlev; ++l) { s.push_back(dst[l]->h); w.push_back(dwork[l]->h); o.push_back(dout[l]->h); }
   // progress-variable range (curvature.cpp:139-160): the file min/max over the levels in use
@@ -179,6 +184,7 @@ int main(int argc, char** argv) {
   }
   ctx.check(pa_sync(ctx.h));
   if (pa_bc_errors(ctx.h) != 0) pa::Abort("coarse-fine boundary: fine grids are not properly nested in the coarse level");
+  tm.mark("compute");
   // the ghost-free output state (curvature.cpp:833-839) is put together on the device and comes down in one piece:
   // input components (valid cells of the state: the passes only write ghost cells), Progress (curvature.cpp:319, the
   // same two operations as everywhere else), then the results; slots whose option is off stay 0.0
@@ -201,6 +207,7 @@ int main(int argc, char** argv) {
     ctx.check(pa_mf_download(ctx.h, dfin.h, ostate[lev].data.data()));
     if (verbose) std::cout << "Mean curvature has been computed on level " << lev << "\n";
   }
+  tm.mark("assemble_download");
   std::vector<std::string> nnames(inNames);
   nnames.resize(nCompOut);
   nnames[idProg] = "Progress";
@@ -222,5 +229,6 @@ int main(int argc, char** argv) {
   std::cout << "Writing new data to " << outfile << "\n";
   std::vector<int> isteps(Nlev, 0);
   pa::write_plotfile(outfile, nnames, doms, H.prob_lo, H.prob_hi, ostate, 0.0, isteps, 2, PA_SPACEDIM);
+  tm.mark("write");
   return 0;
 }

@@ -40,6 +40,7 @@ int main(int argc, char** argv) {
 #else
   if (!pp.queryarr("is_per", is_per, 0, 3)) pp.queryarr("geometry.is_periodic", is_per, 0, 3);
 #endif
+  pa::PhaseTimer tm(pp, PA_SPACEDIM == 2 ? "filterPlt2d" : "filterPlt3d");
   pa::PlotfileHeader H = pa::read_header(infile, PA_SPACEDIM);
   const int Nlev = std::min(finestLevel + 1, H.nlev);
   std::vector<std::string> names;
@@ -75,9 +76,12 @@ int main(int argc, char** argv) {
     host[lev].define(ba, ncomp, ng);
     for (int c = 0; c < ncomp; ++c) pa::read_comp(H, lev, comps[c], host[lev], c);
   }
+  tm.mark("read");
   pa::Ctx& ctx = actx.get();
+  tm.mark("hip_context_wait");
   for (int lev = 0; lev < Nlev; ++lev) {
     const std::vector<pa::Box3>& ba = host[lev].boxes;
+    for (auto& B : ba) tm.cells += B.numPts();
     const int ng = ngs[lev];
     dl.emplace_back(new pa::DevLevel(ctx, ba, H.lev[lev].domain, is_per.data(), H.prob_lo, H.prob_hi));
     din.emplace_back(new pa::DevMF(ctx, *dl.back(), ncomp, ng));
@@ -85,6 +89,7 @@ int main(int argc, char** argv) {
     ctx.check(pa_mf_upload(ctx.h, din.back()->h, host[lev].data.data()));
     doms.push_back(H.lev[lev].domain);
   }
+  tm.mark("upload");
   std::cout << "Done!" << std::endl << "FillPatching data..." << std::endl;
   for (int lev = 0; lev < Nlev; ++lev) {
     std::cout << "on level " << lev << std::endl;
@@ -103,13 +108,16 @@ int main(int argc, char** argv) {
   }
   ctx.check(pa_sync(ctx.h));
   if (pa_bc_errors(ctx.h) != 0) pa::Abort("FillPatchTwoLevels: fine grids are not properly nested in the coarse level");
+  tm.mark("compute");
   std::cout << "Done!" << std::endl << "Saving filtered data..." << std::endl;
   for (int lev = 0; lev < Nlev; ++lev) {
     out[lev].define(host[lev].boxes, ncomp, 0);
     ctx.check(pa_mf_download(ctx.h, dout[lev]->h, out[lev].data.data()));
   }
+  tm.mark("download");
   std::vector<int> steps(Nlev, 0);
   pa::write_plotfile(pa::getFileRoot(infile) + "_filtered", names, doms, H.prob_lo, H.prob_hi, out, H.time, steps, 2, PA_SPACEDIM);
+  tm.mark("write");
   std::cout << "Done!" << std::endl;
   return 0;
 }

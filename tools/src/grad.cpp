@@ -26,6 +26,7 @@ int main(int argc, char** argv) {
   pp.get("infile", infile);
   pp.query("gradVar", gradVar);
   pp.query("finestLevel", finestLevel);
+  pa::PhaseTimer tm(pp, PA_SPACEDIM == 2 ? "grad2d" : "grad3d");
   pa::PlotfileHeader H = pa::read_header(infile, PA_SPACEDIM);
   finestLevel = std::min(finestLevel, H.nlev - 1);
   const int Nlev = finestLevel + 1;
@@ -73,19 +74,25 @@ int main(int argc, char** argv) {
     state[lev].define(H.lev[lev].boxes, nCompOut, 1);
     for (int c = 0; c < nCompIn; ++c) pa::read_comp(H, lev, inComps[c], state[lev], c);
   }
+  tm.mark("read");
   pa::Ctx& ctx = actx.get();
+  tm.mark("hip_context_wait");
   for (int lev = 0; lev < Nlev; ++lev) {
+    for (auto& B : H.lev[lev].boxes) tm.cells += B.numPts();
     dl.emplace_back(new pa::DevLevel(ctx, H.lev[lev].boxes, H.lev[lev].domain, is_per.data(), H.prob_lo, H.prob_hi));
     dmf.emplace_back(new pa::DevMF(ctx, *dl.back(), nCompOut, 1));
     ctx.check(pa_mf_upload(ctx.h, dmf.back()->h, state[lev].data.data()));
     doms.push_back(H.lev[lev].domain);
   }
+  tm.mark("upload");
   std::vector<pa_mf*> mfs;
   for (auto& m : dmf) mfs.push_back(m->h);
   ctx.check(pa_grad_run(ctx.h, Nlev, mfs.data(), 0, bc, mfs.data(), idGr));  // outputs into the same MultiFab, like grad.cpp
   ctx.check(pa_sync(ctx.h));
   if (pa_bc_errors(ctx.h) != 0) pa::Abort("coarse-fine boundary: fine grids are not properly nested in the coarse level");
+  tm.mark("compute");
   for (int lev = 0; lev < Nlev; ++lev) ctx.check(pa_mf_download(ctx.h, dmf[lev]->h, state[lev].data.data()));
+  tm.mark("download");
 
   std::vector<std::string> nnames(inNames);
   nnames.push_back(gradVar + "_gx");
@@ -103,5 +110,6 @@ int main(int argc, char** argv) {
   std::cout << "Writing new data to " << outfile << std::endl;
   std::vector<int> isteps(Nlev, 0);
   pa::write_plotfile(outfile, nnames, doms, H.prob_lo, H.prob_hi, state, 0.0, isteps, 2, PA_SPACEDIM, &ocomps);
+  tm.mark("write");
   return 0;
 }

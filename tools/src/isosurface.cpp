@@ -291,6 +291,16 @@ int main(int argc, char** argv) {
     const double surf_time = now() - strt_time_surf - io_time;
     std::cout << "Max Compute Surface time: " << surf_time << '\n' << "Min Compute Surface time: " << surf_time << '\n';
     std::cout << "Max I/O time: " << io_time << '\n' << "Min I/O time: " << io_time << '\n';
+    int bench_json = 0;
+    pp.query("bench_json", bench_json);
+    if (bench_json) {
+      long long cells = 0;
+      for (int lev = 0; lev < Nlev; ++lev)
+        for (auto& B : H.lev[lev].boxes) cells += B.numPts();
+      std::cout << "{\"tool\": \"isosurface3d\", \"cells\": " << cells << ", \"phases_s\": {\"read\": " << io_time << ", \"hip_context_wait\": " << t_ctx
+                << ", \"host_buffers\": " << t_host << ", \"upload_coords\": " << t_up << ", \"ghost_fill\": " << t_fill << ", \"marching_cubes\": " << t_mc
+                << ", \"download\": " << t_d2h << ", \"merge\": " << t_merge << "}}" << std::endl;
+    }
     if (verbose)
       std::cout << "  of which: HIP context (not hidden behind the reads) " << t_ctx << ", host buffers " << t_host << ", level tables + upload + coordinates " << t_up << ", ghost fill " << t_fill
                 << ", marching cubes " << t_mc << ", download " << t_d2h << ", per-FAB trimming + node/element insertion " << t_merge << '\n';

@@ -23,7 +23,8 @@ for tool, args in (("grad3d.ex", ["gradVar=temp", "is_per=1 1 0"]), ("curvature3
                    ("filterPlt3d.ex", ["is_per=1 1 0"]), ("isosurface3d.ex", ["isoCompName=temp", "isoVal=1150", "comps=0 1 2"])):
     for rep in range(2):
         t0 = time.perf_counter()
-        out = subprocess.run([os.path.join(bindir, tool), "infile=" + p] + args, cwd=d, capture_output=True, text=True)
+        out = subprocess.run([os.path.join(bindir, tool), "infile=" + p, "bench_json=1"] + args, cwd=d, capture_output=True, text=True)
         dt = time.perf_counter() - t0
         assert out.returncode == 0, out.stderr[-500:]
-    print(f"{tool:18s} wall {dt:.2f} s (second run)", flush=True)
+    js = [ln for ln in out.stdout.splitlines() if ln.startswith('{"tool"')]
+    print(f"{tool:18s} wall {dt:.2f} s (second run)  {js[-1] if js else ''}", flush=True)
