@@ -25,11 +25,13 @@ def _box_str(lo, hi, dim=3):
 
 
 def write_plotfile(path: str, H: Hierarchy, mfs: Sequence[MultiFab], names: Sequence[str], time: float = 0.0,
-                   level_steps: Sequence[int] | None = None, dim: int = 3) -> None:
+                   level_steps: Sequence[int] | None = None, dim: int = 3, precision: int = 64) -> None:
     """WriteMultiLevelPlotfile restated (valid cells only, one Cell_D file per level).  dim = 2: the hierarchy is one
     plane of cells (k = 0) and the file is what a 2-D AMReX code writes (2 entries per index / coordinate tuple)."""
     if dim == 2:
         assert all((lv.boxes[:, 2] == 0).all() and (lv.boxes[:, 5] == 0).all() for lv in H.levels)
+    # precision = 32: FABio::FAB_NATIVE_32 (what AmrLevel-based codes write by default): IEEE floats, little endian
+    desc, dt = (FAB_DESC, "<f8") if precision == 64 else ("FAB ((8, (32 8 23 0 1 9 0 127)),(4, (4 3 2 1)))", "<f4")
 
     nlev = H.nlev
     ncomp = len(names)
@@ -63,8 +65,8 @@ def write_plotfile(path: str, H: Hierarchy, mfs: Sequence[MultiFab], names: Sequ
         with open(os.path.join(d, "Cell_D_00000"), "wb") as f:
             for b in range(lv.nboxes):
                 offs.append(f.tell())
-                v = np.ascontiguousarray(mfs[l].valid(b)[:ncomp], dtype="<f8")
-                f.write((FAB_DESC + _box_str(lv.boxes[b, :3], lv.boxes[b, 3:], dim) + " %d\n" % ncomp).encode())
+                v = np.ascontiguousarray(mfs[l].valid(b)[:ncomp], dtype=dt)
+                f.write((desc + _box_str(lv.boxes[b, :3], lv.boxes[b, 3:], dim) + " %d\n" % ncomp).encode())
                 f.write(v.tobytes())
                 mins.append(v.reshape(ncomp, -1).min(axis=1))
                 maxs.append(v.reshape(ncomp, -1).max(axis=1))
@@ -154,7 +156,12 @@ def read_plotfile(path: str, is_per=(0, 0, 0)) -> PlotfileData:
                 flo, fhi = np.array(m[0:3]), np.array(m[3:6])
                 nc = int(line.strip().split()[-1])
                 n = fhi - flo + 1
-                data = np.frombuffer(f.read(8 * nc * int(n.prod())), dtype="<f8").reshape(nc, n[2], n[1], n[0])
+                if "(8, (8 7 6 5 4 3 2 1))" in line:
+                    data = np.frombuffer(f.read(8 * nc * int(n.prod())), dtype="<f8").reshape(nc, n[2], n[1], n[0])
+                elif "(4, (4 3 2 1))" in line:  # FAB_NATIVE_32: converted to double like AmrData does
+                    data = np.frombuffer(f.read(4 * nc * int(n.prod())), dtype="<f4").astype(np.float64).reshape(nc, n[2], n[1], n[0])
+                else:
+                    raise ValueError("unsupported FAB RealDescriptor: " + line[:80])
             g = boxes[b, :3] - flo  # file fabs may carry ghost cells
             nz, ny, nx = lv.box_shape(b)
             mf.valid(b)[:] = data[:ncomp, g[2]:g[2] + nz, g[1]:g[1] + ny, g[0]:g[0] + nx]

@@ -112,6 +112,31 @@ def test_cpp_check_iso_tool(tmp_path):
     assert out.returncode != 0 and "isoFile" in out.stderr
 
 
+def test_single_precision_plotfile_is_read_like_amrdata(tmp_path):
+    """FABio::FAB_NATIVE_32 plotfiles (IEEE floats; what AmrLevel-based codes such as PeleC write by default): both readers
+    widen to double on read, as AmrData does; the C++ one through template3d.ex, which writes doubles back"""
+    _build_tools()
+    p, H, mfs = _synth(tmp_path)
+    p32 = str(tmp_path / "plt32")
+    write_plotfile(p32, H, mfs, ["temp", "x_velocity", "density"], time=0.125, level_steps=[5, 5, 5], precision=32)
+    assert b"(4, (4 3 2 1))" in open(os.path.join(p32, "Level_0", "Cell_D_00000"), "rb").read(200)
+    r = read_plotfile(p32)
+    for l in range(3):
+        want = mfs[l].data.astype(np.float32).astype(np.float64)
+        assert np.array_equal(r.mfs[l].data.view(np.int64), want.view(np.int64))
+    out = subprocess.run([os.path.join(BIN, "template3d.ex"), "infile=" + p32, "is_per=1 1 0"], cwd=tmp_path, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    back = read_plotfile(str(tmp_path / "plt32_temp"))
+    for l in range(3):
+        want = mfs[l].data.astype(np.float32).astype(np.float64)
+        assert np.array_equal(back.mfs[l].data.view(np.int64), want.view(np.int64))
+    # an unknown RealDescriptor is refused, not misread
+    raw = open(os.path.join(p32, "Level_0", "Cell_D_00000"), "rb").read().replace(b"(4, (4 3 2 1))", b"(4, (1 2 3 4))")
+    open(os.path.join(p32, "Level_0", "Cell_D_00000"), "wb").write(raw)
+    out = subprocess.run([os.path.join(BIN, "template3d.ex"), "infile=" + p32], cwd=tmp_path, capture_output=True, text=True)
+    assert out.returncode != 0 and "RealDescriptor" in out.stderr
+
+
 # ------------------------------------------------------------------------------------ GPU tier
 @pytest.mark.gpu
 def test_grad_tool_end_to_end(tmp_path, oracle):

@@ -248,9 +248,25 @@ inline void read_comp(const PlotfileHeader& H, int lev, int comp, HostMF& dst, i
     Box3 fbx;
     if (pos == std::string::npos || !parse_box(hdr, pos, fbx, H.dim)) Abort("bad FAB header in " + L.fab_file[fb]);
     const long long n = fbx.numPts();
+    // RealDescriptor of the FAB: "((8, (64 11 52 0 1 12 0 1023)),(8, (8 7 6 5 4 3 2 1)))" = little-endian IEEE doubles,
+    // "((8, (32 8 23 0 1 9 0 127)),(4, (4 3 2 1)))" = little-endian IEEE floats (FABio::FAB_NATIVE_32, what AmrLevel-based
+    // codes write by default); AmrData converts to Real on read, and so does this
+    int nbytes = 0;
+    {
+      const size_t q = hdr.find("),(");
+      if (q != std::string::npos) nbytes = std::atoi(hdr.c_str() + q + 3);
+      const bool le8 = hdr.find("(8, (8 7 6 5 4 3 2 1))") != std::string::npos, le4 = hdr.find("(4, (4 3 2 1))") != std::string::npos;
+      if (!((nbytes == 8 && le8) || (nbytes == 4 && le4))) Abort("unsupported FAB RealDescriptor in " + L.fab_file[fb] + ": " + hdr.substr(0, 80));
+    }
     std::vector<double> buf((size_t)n);
-    f.seekg((long long)f.tellg() + (long long)comp * n * 8);
-    f.read((char*)buf.data(), n * 8);
+    f.seekg((long long)f.tellg() + (long long)comp * n * nbytes);
+    if (nbytes == 8) {
+      f.read((char*)buf.data(), n * 8);
+    } else {
+      std::vector<float> b4((size_t)n);
+      f.read((char*)b4.data(), n * 4);
+      for (long long i = 0; i < n; ++i) buf[(size_t)i] = (double)b4[(size_t)i];
+    }
     if (!f) Abort("short read in " + L.fab_file[fb]);
     const long long fx = fbx.hi[0] - fbx.lo[0] + 1, fy = fbx.hi[1] - fbx.lo[1] + 1;
     for (int b : hits) {
