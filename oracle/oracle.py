@@ -112,6 +112,16 @@ def apply_bc(fine, comp, crse, ccomp, bc, ratio=2, only_dir=-1, omp=False):
         raise RuntimeError(f"orc_apply_bc: {nbad} coarse-fine ghost cells without coarse data")
 
 
+def fillpatch_two_levels(fine, crse, comp, ncomp, ng, ratio=2, interp_type=1):
+    """FillPatchTwoLevels for the ghost cells no fine box covers (filterPlt.cpp:193); returns the number of cells
+    whose coarse data was missing"""
+    return lib().orc_fillpatch_two_levels(_p(_mf(fine)), _p(_mf(crse)), comp, ncomp, ng, ratio, interp_type)
+
+
+def foextrap(mf, comp, ncomp, ng):
+    lib().orc_foextrap(_p(_mf(mf)), comp, ncomp, ng)
+
+
 def grad_multipass(phi, comp, out, ocomp):
     lib().orc_grad_multipass(_p(_mf(phi)), comp, _p(_mf(out)), ocomp)
 
@@ -169,7 +179,8 @@ def curvature_pipeline(levels, states, comp, bc, outs, ocomp, MF, prog_min=None,
         cmf.append(c)
     progress = [c.copy() for c in cmf] if do_smooth else None
     if do_smooth:  # :328-406; everything below uses the smoothed field (idprogvar = idSmProg, :408)
-        sol, it, res = smooth_solve(levels, cmf, 0, smoothing_time, bc, MF, tol=smooth_tol, maxiter=100, omp=omp)
+        bc_s = [BC_PERIODIC if v == BC_PERIODIC else BC_NEUMANN for v in bc]  # curvature.cpp:348-357: Periodic / Neumann only, sym_dir ignored
+        sol, it, res = smooth_solve(levels, cmf, 0, smoothing_time, bc_s, MF, tol=smooth_tol, maxiter=100, omp=omp)
         assert it > 0, f"composite smoothing solve failed ({it}, residual {res})"
         for l in range(nlev):
             L.orc_copy(_p(_mf(sol[l])), 0, _p(_mf(cmf[l])), 0, 1, 0)

@@ -593,6 +593,18 @@ static double crse_val_g(const orc_mf* crse, int comp, const int p0[3], int* ok)
   return 0.0;
 }
 
+/* coarse value seen by the interpolater: the cell clamped into the domain along non-periodic
+ * directions (= the foextrap-filled coarse ghost cell), then the valid coarse cell (periodic wrap) */
+static double cu_clamped(const orc_mf* crse, const orc_level* LC, int comp, int i, int j, int k, int* ok) {
+  int p[3] = {i, j, k};
+  for (int d = 0; d < 3; ++d)
+    if (!LC->is_per[d]) {
+      if (p[d] < LC->domlo[d]) p[d] = LC->domlo[d];
+      if (p[d] > LC->domhi[d]) p[d] = LC->domhi[d];
+    }
+  return crse_val_g(crse, comp, p, ok);
+}
+
 int orc_fillpatch_two_levels(orc_mf* fine, const orc_mf* crse, int comp, int ncomp, int ngf, int r,
                              int interp_type) {
   const orc_level* L = fine->lev;
@@ -614,57 +626,44 @@ int orc_fillpatch_two_levels(orc_mf* fine, const orc_mf* crse, int comp, int nco
             const double u0 = crse_val_g(crse, c, qc, &ok);
             double val = u0;
             if (interp_type == 1) {
-              /* mf_cell_cons_interp restated: limited central slopes,
-               * then a common factor so the corner values stay within the
-               * min/max of the 27 coarse neighbours */
+              /* mf_cell_cons_lin_interp_mcslope + mf_cell_cons_lin_interp restated (AMReX
+               * AMReX_MFInterp_3D_C.H, [RECALLED]).  The coarse data FillPatchTwoLevels
+               * interpolates from is the coarse level's valid cells + periodic images + the coarse
+               * physical BC, which filterPlt sets to foextrap (filterPlt.cpp:164-173): a coarse
+               * neighbour outside a non-periodic wall holds the value of the nearest cell inside
+               * the domain, dimension by dimension.  mf_compute_slopes only departs from the
+               * plain central difference for ext_dir / hoextrap, never for foextrap. */
+#define CU(dx_, dy_, dz_) cu_clamped(crse, LC, c, qc[0] + (dx_), qc[1] + (dy_), qc[2] + (dz_), &ok)
               double sl[3];
-              double umin = u0, umax = u0;
-              for (int dz = -1; dz <= 1; ++dz)
-                for (int dy = -1; dy <= 1; ++dy)
-                  for (int dx = -1; dx <= 1; ++dx) {
-                    int p[3] = {qc[0] + dx, qc[1] + dy, qc[2] + dz};
-                    /* one-sided at non-periodic walls: clamp */
-                    for (int d = 0; d < 3; ++d)
-                      if (!LC->is_per[d]) {
-                        if (p[d] < LC->domlo[d]) p[d] = LC->domlo[d];
-                        if (p[d] > LC->domhi[d]) p[d] = LC->domhi[d];
-                      }
-                    const double v = crse_val_g(crse, c, p, &ok);
-                    if (v < umin) umin = v;
-                    if (v > umax) umax = v;
-                  }
               for (int d = 0; d < 3; ++d) {
-                int pm[3] = {qc[0], qc[1], qc[2]}, pp[3] = {qc[0], qc[1], qc[2]};
-                pm[d] -= 1; pp[d] += 1;
-                int has_m = 1, has_p = 1;
-                if (!LC->is_per[d]) {
-                  if (pm[d] < LC->domlo[d]) has_m = 0;
-                  if (pp[d] > LC->domhi[d]) has_p = 0;
-                }
-                const double um = has_m ? crse_val_g(crse, c, pm, &ok) : u0;
-                const double up = has_p ? crse_val_g(crse, c, pp, &ok) : u0;
-                double dc;
-                if (has_m && has_p) dc = 0.5 * (up - um);
-                else if (has_p) dc = up - u0;
-                else if (has_m) dc = u0 - um;
-                else dc = 0.0;
+                const double um = CU(-(d == 0), -(d == 1), -(d == 2)), up = CU(d == 0, d == 1, d == 2);
+                const double dc = 0.5 * (up - um);
                 const double df = 2.0 * (up - u0), db = 2.0 * (u0 - um);
-                double lim = (df * db >= 0.0) ? fmin(fabs(df), fabs(db)) : 0.0;
-                if (!(has_m && has_p)) lim = fabs(dc);
-                const double sgn = (dc > 0.0) ? 1.0 : ((dc < 0.0) ? -1.0 : 0.0);
-                sl[d] = sgn * fmin(lim, fabs(dc));
+                double sx = (df * db >= 0.0) ? fmin(fabs(df), fabs(db)) : 0.0;
+                sx = copysign(1.0, dc) * fmin(sx, fabs(dc));
+                sl[d] = sx;
               }
-              /* common scaling alpha */
               double alpha = 1.0;
-              const double dmax = 0.5 * (fabs(sl[0]) + fabs(sl[1]) + fabs(sl[2]));
-              if (dmax != 0.0) {
-                const double a1 = (umax - u0) / dmax, a2 = (u0 - umin) / dmax;
-                alpha = fmin(1.0, fmin(a1, a2));
+              if (sl[0] != 0.0 || sl[1] != 0.0 || sl[2] != 0.0) {
+                const double dumax = fabs(sl[0]) * (double)(r - 1) / (double)(2 * r) + fabs(sl[1]) * (double)(r - 1) / (double)(2 * r) +
+                                     fabs(sl[2]) * (double)(r - 1) / (double)(2 * r);
+                double umax = u0, umin = u0;
+                for (int dz = -1; dz <= 1; ++dz)
+                  for (int dy = -1; dy <= 1; ++dy)
+                    for (int dx = -1; dx <= 1; ++dx) {
+                      const double v = CU(dx, dy, dz);
+                      umin = (v < umin) ? v : umin;
+                      umax = (v > umax) ? v : umax;
+                    }
+                if (dumax * alpha > (umax - u0)) alpha = (umax - u0) / dumax;
+                if (dumax * alpha > (u0 - umin)) alpha = (u0 - umin) / dumax;
               }
+#undef CU
+              /* slope(ns) = sx*alpha etc.; fine = crse + xoff*slope_x + yoff*slope_y + zoff*slope_z */
               double acc = u0;
               for (int d = 0; d < 3; ++d) {
                 const double xoff = ((double)(q[d] - qc[d] * r) + 0.5) / (double)r - 0.5;
-                acc += xoff * (alpha * sl[d]);
+                acc += xoff * (sl[d] * alpha);
               }
               val = acc;
             }

@@ -34,6 +34,7 @@ extern "C" pa_ctx* pa_ctx_create(int device, void* hip_stream) {
 }
 
 extern "C" void pa_ctx_destroy(pa_ctx* ctx) {
+  PaBind bind_(ctx);
   if (!ctx) return;
   if (ctx->d_red) (void)hipFree(ctx->d_red);
   if (ctx->d_flags) (void)hipFree(ctx->d_flags);
@@ -47,6 +48,7 @@ extern "C" void pa_ctx_destroy(pa_ctx* ctx) {
 }
 
 extern "C" int pa_profile_enable(pa_ctx* ctx, int on) {
+  PaBind bind_(ctx);
   if (!ctx) return 1;
   // 0: off, 1: every tag, otherwise a bit mask (1 << tag): e.g. 2 = the fused sweep only, so that a timed region pays for
   // two events per sweep launch and nothing else (the events of ~20 small boundary launches per step cost ~2 % of it)
@@ -56,6 +58,7 @@ extern "C" int pa_profile_enable(pa_ctx* ctx, int on) {
 
 // sum of the durations (ms) of all launches recorded under `tag` since the last reset; synchronous
 extern "C" int pa_profile_read(pa_ctx* ctx, int tag, int64_t* nlaunch, double* total_ms, int reset) {
+  PaBind bind_(ctx);
   if (!ctx || !nlaunch || !total_ms) return 1;
   PA_HIP(hipStreamSynchronize(ctx->stream));
   *nlaunch = 0;
@@ -78,6 +81,7 @@ extern "C" const char* pa_last_error(const pa_ctx* ctx) { return ctx ? ctx->err.
 extern "C" void* pa_ctx_stream(pa_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
 extern "C" int pa_sync(pa_ctx* ctx) {
+  PaBind bind_(ctx);
   if (!ctx) return 1;
   PA_HIP(hipStreamSynchronize(ctx->stream));
   return 0;
@@ -120,6 +124,7 @@ static pa_level* level_create_impl(pa_ctx* ctx, int nboxes, const int32_t* b6, i
 extern "C" pa_level* pa_level_create(pa_ctx* ctx, int nboxes, const int32_t* b6, const int32_t domlo[3],
                                      const int32_t domhi[3], const int32_t is_per[3], const double prob_lo[3],
                                      const double prob_hi[3]) {
+  PaBind bind_(ctx);
   return level_create_impl(ctx, nboxes, b6, 0, nullptr, domlo, domhi, is_per, prob_lo, prob_hi);
 }
 
@@ -130,6 +135,7 @@ extern "C" pa_level* pa_level_create(pa_ctx* ctx, int nboxes, const int32_t* b6,
 extern "C" pa_level* pa_level_create_dist(pa_ctx* ctx, int nboxes, const int32_t* b6, int nremote, const int32_t* r6, const int32_t domlo[3],
                                           const int32_t domhi[3], const int32_t is_per[3], const double prob_lo[3],
                                           const double prob_hi[3]) {
+  PaBind bind_(ctx);
   if (nremote < 0 || (nremote > 0 && !r6)) { pa_fail(ctx, "pa_level_create_dist: bad remote box list"); return nullptr; }
   return level_create_impl(ctx, nboxes, b6, nremote, r6, domlo, domhi, is_per, prob_lo, prob_hi);
 }
@@ -351,6 +357,7 @@ extern "C" int64_t pa_mf_layout(int nboxes, const int32_t* b6, int ncomp, int ng
 }
 
 extern "C" pa_mf* pa_mf_create(pa_ctx* ctx, const pa_level* L, int ncomp, int ng, double* devptr) {
+  PaBind bind_(ctx);
   if (!ctx || !L) return nullptr;
   if (ncomp <= 0 || ng < 0) { pa_fail(ctx, "pa_mf_create: bad ncomp/ng"); return nullptr; }
   pa_mf* M = new pa_mf();
@@ -394,12 +401,14 @@ extern "C" double* pa_mf_data(pa_mf* M) { return M ? M->data : nullptr; }
 extern "C" int64_t pa_mf_size(const pa_mf* M) { return M ? M->total : 0; }
 
 extern "C" int pa_mf_upload(pa_ctx* ctx, pa_mf* M, const double* host) {
+  PaBind bind_(ctx);
   if (!ctx || !M || !host) return pa_fail(ctx, "pa_mf_upload: null argument");
   PA_HIP(hipMemcpyAsync(M->data, host, sizeof(double) * (size_t)M->total, hipMemcpyHostToDevice, ctx->stream));
   PA_HIP(hipStreamSynchronize(ctx->stream));
   return 0;
 }
 extern "C" int pa_mf_download(pa_ctx* ctx, const pa_mf* M, double* host) {
+  PaBind bind_(ctx);
   if (!ctx || !M || !host) return pa_fail(ctx, "pa_mf_download: null argument");
   PA_HIP(hipMemcpyAsync(host, M->data, sizeof(double) * (size_t)M->total, hipMemcpyDeviceToHost, ctx->stream));
   PA_HIP(hipStreamSynchronize(ctx->stream));
@@ -422,6 +431,7 @@ __global__ void k_setval_comp(DLevelView L, DMFView M, int comp, int ncomp, doub
 }
 
 extern "C" int pa_mf_setval(pa_ctx* ctx, pa_mf* M, int comp, int ncomp, double v) {
+  PaBind bind_(ctx);
   if (!ctx || !M) return pa_fail(ctx, "pa_mf_setval: null argument");
   if (comp < 0 || comp + ncomp > M->ncomp) return pa_fail(ctx, "pa_mf_setval: component range");
   dim3 grid(64, (unsigned)M->lev->boxes.size());
@@ -446,6 +456,7 @@ __global__ void k_copy(DLevelView L, DMFView S, int scomp, DMFView D, int dcomp,
 }
 
 extern "C" int pa_mf_copy(pa_ctx* ctx, const pa_mf* S, int scomp, pa_mf* D, int dcomp, int ncomp, int ng) {
+  PaBind bind_(ctx);
   if (!ctx || !S || !D) return pa_fail(ctx, "pa_mf_copy: null argument");
   if (S->lev != D->lev) return pa_fail(ctx, "pa_mf_copy: different levels");
   if (ng > S->ng || ng > D->ng || scomp + ncomp > S->ncomp || dcomp + ncomp > D->ncomp)
@@ -528,6 +539,7 @@ static long long max_shell(const pa_level* L, int ng) {
 }
 
 extern "C" int pa_fill_boundary(pa_ctx* ctx, pa_mf* M, int comp, int ncomp, int ng) {
+  PaBind bind_(ctx);
   if (!ctx || !M) return pa_fail(ctx, "pa_fill_boundary: null argument");
   if (ng > M->ng || ng < 0 || comp < 0 || comp + ncomp > M->ncomp) return pa_fail(ctx, "pa_fill_boundary: ng/component range");
   if (ng == 0) return 0;
@@ -687,6 +699,7 @@ int pa_ensure_red(pa_ctx* ctx, size_t n) {
 // number of coarse-fine ghost cells, since the last call, whose coarse data was missing
 // (improper nesting or a level-0 box not covering the domain).  Synchronous; resets the count.
 extern "C" int pa_bc_errors(pa_ctx* ctx) {
+  PaBind bind_(ctx);
   if (!ctx) return -1;
   int n = 0;
   if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipMemcpy(&n, ctx->d_flags, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess ||
@@ -760,6 +773,7 @@ int pa_apply_bc_dual(pa_ctx* ctx, pa_mf* F0, int comp0, pa_mf* F1, int comp1, co
 
 extern "C" int pa_apply_bc(pa_ctx* ctx, pa_mf* F, int comp, const pa_mf* C, int ccomp, const int32_t bc[3], int ratio,
                            int only_dir) {
+  PaBind bind_(ctx);
   return pa_apply_bc_impl(ctx, F, comp, C, ccomp, bc, ratio, only_dir, 0, nullptr);
 }
 
@@ -783,6 +797,7 @@ __global__ __launch_bounds__(256) void k_progress_shell(DLevelView L, DMFView S,
 }
 
 extern "C" int pa_progress_shell_level(pa_ctx* ctx, const pa_mf* s, int comp, double pmin, double pmax, pa_mf* c, int ccomp, int ng, int depth) {
+  PaBind bind_(ctx);
   if (!ctx || !s || !c) return pa_fail(ctx, "pa_progress_shell_level: null argument");
   if (s->lev != c->lev) return pa_fail(ctx, "pa_progress_shell_level: different levels");
   if (ng > s->ng || ng > c->ng || comp >= s->ncomp || ccomp >= c->ncomp || depth < 1) return pa_fail(ctx, "pa_progress_shell_level: ng/component range");
@@ -802,22 +817,26 @@ extern "C" int pa_progress_shell_level(pa_ctx* ctx, const pa_mf* s, int comp, do
 }
 
 extern "C" void* pa_device_malloc(pa_ctx* ctx, int64_t bytes) {
+  PaBind bind_(ctx);
   if (!ctx || bytes < 0) return nullptr;
   void* p = nullptr;
   if (hipMalloc(&p, (size_t)(bytes > 0 ? bytes : 8)) != hipSuccess) { pa_fail(ctx, "pa_device_malloc: out of device memory"); return nullptr; }
   return p;
 }
 extern "C" void pa_device_free(pa_ctx* ctx, void* p) {
+  PaBind bind_(ctx);
   (void)ctx;
   if (p) (void)hipFree(p);
 }
 extern "C" int pa_memcpy_h2d(pa_ctx* ctx, void* dst, const void* src, int64_t bytes) {
+  PaBind bind_(ctx);
   if (!ctx || (bytes > 0 && (!dst || !src))) return pa_fail(ctx, "pa_memcpy_h2d: null argument");
   PA_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyHostToDevice, ctx->stream));
   PA_HIP(hipStreamSynchronize(ctx->stream));
   return 0;
 }
 extern "C" int pa_memcpy_d2h(pa_ctx* ctx, void* dst, const void* src, int64_t bytes) {
+  PaBind bind_(ctx);
   if (!ctx || (bytes > 0 && (!dst || !src))) return pa_fail(ctx, "pa_memcpy_d2h: null argument");
   PA_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream));
   PA_HIP(hipStreamSynchronize(ctx->stream));
@@ -892,8 +911,10 @@ extern "C" int64_t pa_regions_size(int ncomp, int nreg, const int32_t* regs) {
   return tot;
 }
 extern "C" int pa_pack_regions(pa_ctx* ctx, const pa_mf* M, int comp, int ncomp, int nreg, const int32_t* regs, double* devbuf) {
+  PaBind bind_(ctx);
   return regions_impl(ctx, const_cast<pa_mf*>(M), comp, ncomp, nreg, regs, devbuf, 0);
 }
 extern "C" int pa_unpack_regions(pa_ctx* ctx, pa_mf* M, int comp, int ncomp, int nreg, const int32_t* regs, const double* devbuf) {
+  PaBind bind_(ctx);
   return regions_impl(ctx, M, comp, ncomp, nreg, regs, const_cast<double*>(devbuf), 1);
 }

@@ -209,6 +209,7 @@ static void filter_launch(hipStream_t st, const BP& bp, int nx, int ny, int nz, 
 }
 
 extern "C" int pa_boxfilter_level(pa_ctx* ctx, const pa_mf* in, pa_mf* out, int scomp, int ncomp, int ng, const double* w) {
+  PaBind bind_(ctx);
   if (!ctx || !in || !out || !w) return pa_fail(ctx, "pa_boxfilter_level: null argument");
   if (in->lev != out->lev) return pa_fail(ctx, "pa_boxfilter_level: different levels");
   if (ng < 0 || ng > 16 || ng > in->ng) return pa_fail(ctx, "pa_boxfilter_level: input has fewer ghost cells than the filter half-width");
@@ -244,6 +245,7 @@ __global__ __launch_bounds__(256) void k_boxfilter2d(BP bp, int scomp, int ncomp
 }
 
 extern "C" int pa_boxfilter_level2d(pa_ctx* ctx, const pa_mf* in, pa_mf* out, int scomp, int ncomp, int ng, const double* w) {
+  PaBind bind_(ctx);
   if (!ctx || !in || !out || !w) return pa_fail(ctx, "pa_boxfilter_level2d: null argument");
   if (in->lev != out->lev) return pa_fail(ctx, "pa_boxfilter_level2d: different levels");
   if (ng < 0 || ng > 16 || ng > in->ng) return pa_fail(ctx, "pa_boxfilter_level2d: input has fewer ghost cells than the filter half-width");
@@ -260,6 +262,7 @@ extern "C" int pa_boxfilter_level2d(pa_ctx* ctx, const pa_mf* in, pa_mf* out, in
 }
 
 extern "C" int pa_boxfilter_fab(pa_ctx* ctx, pa_box valid, const pa_fab* in, pa_fab* out, int scomp, int ncomp, int ng, const double* w) {
+  PaBind bind_(ctx);
   if (!ctx || !in || !out || !w) return pa_fail(ctx, "pa_boxfilter_fab: null argument");
   if (ng < 0 || ng > 16) return pa_fail(ctx, "pa_boxfilter_fab: filter half-width out of range");
   std::string why;
@@ -340,6 +343,7 @@ __global__ void k_foextrap(DLevelView L, DMFView M, int comp, int ncomp, int ngf
 }
 
 extern "C" int pa_foextrap(pa_ctx* ctx, pa_mf* M, int comp, int ncomp, int ng) {
+  PaBind bind_(ctx);
   if (!ctx || !M) return pa_fail(ctx, "pa_foextrap: null argument");
   if (ng > M->ng || ng < 0 || comp < 0 || comp + ncomp > M->ncomp) return pa_fail(ctx, "pa_foextrap: ng/component range");
   if (ng == 0) return 0;
@@ -366,45 +370,44 @@ __global__ void k_fillpatch2(DLevelView L, DMFView M, DLevelView LC, DMFView MC,
     const double u0 = crse_val(LC, MC, c, qc[0], qc[1], qc[2], ok);
     double val = u0;
     if (interp == 1) {
-      double umin = u0, umax = u0, sl[3];
-      for (int dz = -1; dz <= 1; ++dz)
-        for (int dy = -1; dy <= 1; ++dy)
-          for (int dx = -1; dx <= 1; ++dx) {
-            int p[3] = {qc[0] + dx, qc[1] + dy, qc[2] + dz};
-            for (int d = 0; d < 3; ++d)
-              if (!LC.is_per[d]) { p[d] = max(p[d], LC.domlo[d]); p[d] = min(p[d], LC.domhi[d]); }
-            const double v = crse_val(LC, MC, c, p[0], p[1], p[2], ok);
-            umin = v < umin ? v : umin;
-            umax = v > umax ? v : umax;
-          }
+      // mf_cell_cons_lin_interp_mcslope + mf_cell_cons_lin_interp (AMReX, recalled; oracle/pa_oracle.c
+      // orc_fillpatch_two_levels): central slopes limited by df/db, one common factor alpha with
+      // dumax = sum |s_d| (r-1)/(2r); coarse neighbours beyond a non-periodic wall are the foextrap-filled
+      // coarse ghost cells = the nearest cell inside the domain (filterPlt.cpp:164-173)
+      auto cu = [&](int dx, int dy, int dz) -> double {
+        int p[3] = {qc[0] + dx, qc[1] + dy, qc[2] + dz};
+        for (int d = 0; d < 3; ++d)
+          if (!LC.is_per[d]) { p[d] = max(p[d], LC.domlo[d]); p[d] = min(p[d], LC.domhi[d]); }
+        return crse_val(LC, MC, c, p[0], p[1], p[2], ok);
+      };
+      double sl[3];
       for (int d = 0; d < 3; ++d) {
-        int pm[3] = {qc[0], qc[1], qc[2]}, pp[3] = {qc[0], qc[1], qc[2]};
-        pm[d] -= 1; pp[d] += 1;
-        bool has_m = true, has_p = true;
-        if (!LC.is_per[d]) { has_m = pm[d] >= LC.domlo[d]; has_p = pp[d] <= LC.domhi[d]; }
-        const double um = has_m ? crse_val(LC, MC, c, pm[0], pm[1], pm[2], ok) : u0;
-        const double up = has_p ? crse_val(LC, MC, c, pp[0], pp[1], pp[2], ok) : u0;
-        double dc;
-        if (has_m && has_p) dc = 0.5 * (up - um);
-        else if (has_p) dc = up - u0;
-        else if (has_m) dc = u0 - um;
-        else dc = 0.0;
+        const double um = cu(-(d == 0), -(d == 1), -(d == 2)), up = cu(d == 0, d == 1, d == 2);
+        const double dc = 0.5 * (up - um);
         const double df = 2.0 * (up - u0), db = 2.0 * (u0 - um);
-        double lim = (df * db >= 0.0) ? fmin(fabs(df), fabs(db)) : 0.0;
-        if (!(has_m && has_p)) lim = fabs(dc);
-        const double sgn = (dc > 0.0) ? 1.0 : ((dc < 0.0) ? -1.0 : 0.0);
-        sl[d] = sgn * fmin(lim, fabs(dc));
+        double sx = (df * db >= 0.0) ? fmin(fabs(df), fabs(db)) : 0.0;
+        sx = copysign(1.0, dc) * fmin(sx, fabs(dc));
+        sl[d] = sx;
       }
       double alpha = 1.0;
-      const double dmax = 0.5 * (fabs(sl[0]) + fabs(sl[1]) + fabs(sl[2]));
-      if (dmax != 0.0) {
-        const double a1 = (umax - u0) / dmax, a2 = (u0 - umin) / dmax;
-        alpha = fmin(1.0, fmin(a1, a2));
+      if (sl[0] != 0.0 || sl[1] != 0.0 || sl[2] != 0.0) {
+        const double dumax = fabs(sl[0]) * (double)(r - 1) / (double)(2 * r) + fabs(sl[1]) * (double)(r - 1) / (double)(2 * r) +
+                             fabs(sl[2]) * (double)(r - 1) / (double)(2 * r);
+        double umax = u0, umin = u0;
+        for (int dz = -1; dz <= 1; ++dz)
+          for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+              const double v = cu(dx, dy, dz);
+              umin = v < umin ? v : umin;
+              umax = v > umax ? v : umax;
+            }
+        if (dumax * alpha > (umax - u0)) alpha = (umax - u0) / dumax;
+        if (dumax * alpha > (u0 - umin)) alpha = (u0 - umin) / dumax;
       }
       double acc = u0;
       for (int d = 0; d < 3; ++d) {
         const double xoff = ((double)(q[d] - qc[d] * r) + 0.5) / (double)r - 0.5;
-        acc += xoff * (alpha * sl[d]);
+        acc += xoff * (sl[d] * alpha);
       }
       val = acc;
     }
@@ -414,6 +417,7 @@ __global__ void k_fillpatch2(DLevelView L, DMFView M, DLevelView LC, DMFView MC,
 }
 
 extern "C" int pa_fillpatch_two_levels(pa_ctx* ctx, pa_mf* fine, const pa_mf* crse, int comp, int ncomp, int ng, int ratio, int interp_type) {
+  PaBind bind_(ctx);
   if (!ctx || !fine || !crse) return pa_fail(ctx, "pa_fillpatch_two_levels: null argument");
   if (ng > fine->ng || ng < 0 || comp < 0 || comp + ncomp > fine->ncomp || comp + ncomp > crse->ncomp) return pa_fail(ctx, "pa_fillpatch_two_levels: ng/component range");
   if (ratio != 2) return pa_fail(ctx, "pa_fillpatch_two_levels: only refinement ratio 2 is supported (quirk Q11)");

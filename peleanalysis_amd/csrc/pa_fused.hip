@@ -381,6 +381,7 @@ static void march_launch(hipStream_t st, const BP& bp, int nx, int ny, int nz, u
 }
 
 extern "C" int pa_gradcurv_level(pa_ctx* ctx, const pa_mf* phi, int pcomp, double pmin, double pmax, double thr, pa_mf* out, int ocomp) {
+  PaBind bind_(ctx);
   if (!ctx || !phi || !out) return pa_fail(ctx, "pa_gradcurv_level: null argument");
   if (phi->lev != out->lev) return pa_fail(ctx, "pa_gradcurv_level: different levels");
   if (phi->ng < 2) return pa_fail(ctx, "pa_gradcurv_level: phi needs >= 2 ghost layers");
@@ -406,6 +407,7 @@ int pa_gradcurv_faces_phase(pa_ctx* ctx, const pa_mf* c, int ccomp, const pa_mf*
                             pa_mf* out, int ncomp0, int kcomp, int phase);
 extern "C" int pa_gradcurv_faces_level(pa_ctx* ctx, const pa_mf* c, int ccomp, const pa_mf* crse_n, int cncomp0, const int32_t bc[3],
                                        int ratio, double thr, pa_mf* out, int ncomp0, int kcomp) {
+  PaBind bind_(ctx);
   return pa_gradcurv_faces_phase(ctx, c, ccomp, crse_n, cncomp0, bc, ratio, thr, out, ncomp0, kcomp, 3);
 }
 int pa_gradcurv_faces_phase(pa_ctx* ctx, const pa_mf* c, int ccomp, const pa_mf* crse_n, int cncomp0, const int32_t bc[3], int ratio, double thr,
@@ -453,6 +455,7 @@ int pa_gradcurv_faces_phase(pa_ctx* ctx, const pa_mf* c, int ccomp, const pa_mf*
 
 extern "C" int pa_gradcurv_fab(pa_ctx* ctx, pa_box valid, const pa_fab* phi, int pcomp, double pmin, double pmax, const double dxinv[3],
                                double thr, pa_fab* out, int ocomp) {
+  PaBind bind_(ctx);
   if (!ctx || !phi || !out || !dxinv) return pa_fail(ctx, "pa_gradcurv_fab: null argument");
   std::string why;
   if (!fab_covers(*phi, valid, 2, pcomp, 1, why) || !fab_covers(*out, valid, 0, ocomp, 8, why)) return pa_fail(ctx, "pa_gradcurv_fab: " + why);

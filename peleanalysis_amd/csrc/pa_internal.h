@@ -120,6 +120,13 @@ struct pa_mf {
 
 int pa_fail(pa_ctx* ctx, const std::string& msg);
 
+// The current HIP device is per host thread, and a pa_ctx may be used from a thread other than the one that created it
+// (tools bring the context up on a worker thread) or next to contexts of other devices (ngpus > 1 in one process):
+// every entry point that allocates or launches binds the context's device first.
+struct PaBind {
+  explicit PaBind(const pa_ctx* c) { if (c) (void)hipSetDevice(c->device); }
+};
+
 // ---------------------------------------------------------------- device helpers
 // Component stride of a FAB inside a pa_mf (in doubles): the cell count rounded up to 512 B and
 // kept off multiples of 16 KiB.  With the plain AMReX stride (nx*ny*nz) a 128^3 box puts all

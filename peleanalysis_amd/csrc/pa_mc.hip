@@ -321,6 +321,7 @@ static int mc_count(pa_ctx* ctx, const McGeom& G, const McScratch& W, long long 
 
 extern "C" int pa_mc_count_fab(pa_ctx* ctx, pa_box loop, const pa_fab* state, const pa_fab* mask, int isocomp, double isoval, int64_t* nvert,
                                int64_t* ntri) {
+  PaBind bind_(ctx);
   if (!nvert || !ntri) return pa_fail(ctx, "pa_mc_count_fab: null argument");
   McGeom G;
   McScratch W;
@@ -335,6 +336,7 @@ extern "C" int pa_mc_count_fab(pa_ctx* ctx, pa_box loop, const pa_fab* state, co
 
 extern "C" int pa_mc_emit_fab(pa_ctx* ctx, pa_box loop, const pa_fab* state, const pa_fab* mask, int isocomp, double isoval, double* dev_verts,
                               int32_t* dev_vkeys, int32_t* dev_tris, int64_t nvert, int64_t ntri) {
+  PaBind bind_(ctx);
   McGeom G;
   McScratch W;
   if (mc_setup(ctx, loop, state, mask, isocomp, isoval, G, W)) return 1;
@@ -771,6 +773,7 @@ __global__ __launch_bounds__(256) void k_iso_coords(DLevelView L, DMFView M, int
 }
 
 extern "C" int pa_iso_coords_level(pa_ctx* ctx, pa_mf* state, int comp0) {
+  PaBind bind_(ctx);
   if (!ctx || !state) return pa_fail(ctx, "pa_iso_coords_level: null argument");
   if (comp0 < 0 || comp0 + 3 > state->ncomp) return pa_fail(ctx, "pa_iso_coords_level: component range");
   const pa_level* L = state->lev;
@@ -785,6 +788,7 @@ extern "C" int pa_iso_coords_level(pa_ctx* ctx, pa_mf* state, int comp0) {
 }
 
 extern "C" int pa_iso_mask_level(pa_ctx* ctx, pa_mf* mask, int comp, const pa_level* fine, int ratio) {
+  PaBind bind_(ctx);
   if (!ctx || !mask) return pa_fail(ctx, "pa_iso_mask_level: null argument");
   if (comp < 0 || comp >= mask->ncomp) return pa_fail(ctx, "pa_iso_mask_level: component range");
   if (fine && ratio < 1) return pa_fail(ctx, "pa_iso_mask_level: bad refinement ratio");
@@ -803,20 +807,24 @@ static int mc_level_impl(pa_ctx* ctx, const pa_mf* state, const pa_mf* mask, int
 // mask of isosurface.cpp:1540-1563 evaluated inside the cell pass (no mask multifab: half the bytes of the pass)
 extern "C" int pa_mc_level_fine(pa_ctx* ctx, const pa_mf* state, const pa_level* fine, int ratio, const pa_box* loops, int isocomp, double isoval,
                                 int64_t* nvert, int64_t* ntri, double** dev_verts, int32_t** dev_vkeys, int32_t** dev_tris) {
+  PaBind bind_(ctx);
   if (fine && ratio < 1) return pa_fail(ctx, "pa_mc_level_fine: bad refinement ratio");
   return mc_level_impl(ctx, state, state, 0, loops, isocomp, isoval, nvert, ntri, dev_verts, dev_vkeys, dev_tris, 0, 1, fine, ratio);
 }
 extern "C" int pa_msq_level_fine(pa_ctx* ctx, const pa_mf* state, const pa_level* fine, int ratio, const pa_box* loops, int isocomp, double isoval,
                                  int64_t* nvert, int64_t* nseg, double** dev_verts, int32_t** dev_vkeys, int32_t** dev_segs) {
+  PaBind bind_(ctx);
   if (fine && ratio < 1) return pa_fail(ctx, "pa_msq_level_fine: bad refinement ratio");
   return mc_level_impl(ctx, state, state, 0, loops, isocomp, isoval, nvert, nseg, dev_verts, dev_vkeys, dev_segs, 1, 1, fine, ratio);
 }
 extern "C" int pa_mc_level(pa_ctx* ctx, const pa_mf* state, const pa_mf* mask, int mcomp, const pa_box* loops, int isocomp, double isoval,
                            int64_t* nvert, int64_t* ntri, double** dev_verts, int32_t** dev_vkeys, int32_t** dev_tris) {
+  PaBind bind_(ctx);
   return mc_level_impl(ctx, state, mask, mcomp, loops, isocomp, isoval, nvert, ntri, dev_verts, dev_vkeys, dev_tris, 0);
 }
 extern "C" int pa_msq_level(pa_ctx* ctx, const pa_mf* state, const pa_mf* mask, int mcomp, const pa_box* loops, int isocomp, double isoval,
                             int64_t* nvert, int64_t* nseg, double** dev_verts, int32_t** dev_vkeys, int32_t** dev_segs) {
+  PaBind bind_(ctx);
   return mc_level_impl(ctx, state, mask, mcomp, loops, isocomp, isoval, nvert, nseg, dev_verts, dev_vkeys, dev_segs, 1);
 }
 static int mc_level_impl(pa_ctx* ctx, const pa_mf* state, const pa_mf* mask, int mcomp, const pa_box* loops, int isocomp, double isoval, int64_t* nvert,

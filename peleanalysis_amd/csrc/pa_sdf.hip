@@ -219,6 +219,7 @@ static int ensure_scr_sdf(pa_ctx* ctx, size_t bytes) {
 }
 
 extern "C" int pa_sdf_level_set3(pa_ctx* ctx, int ngrids, const pa_sdf_grid* grids, int exact_band) {
+  PaBind bind_(ctx);
   if (!ctx || ngrids < 0 || (ngrids > 0 && !grids)) return pa_fail(ctx, "pa_sdf_level_set3: null argument");
   if (exact_band < 0) return pa_fail(ctx, "pa_sdf_level_set3: negative exact_band");
   if (ngrids == 0) return 0;
@@ -299,6 +300,7 @@ __global__ __launch_bounds__(256) void k_sdf_signed(FabView S, int isocomp, doub
 
 extern "C" int pa_sdf_signed_fab(pa_ctx* ctx, pa_box vbox, const float* dev_phi, const pa_fab* state, int isocomp, double isoval, double dmax,
                                  pa_fab* dist, int dcomp) {
+  PaBind bind_(ctx);
   if (!ctx || !dev_phi || !state || !dist) return pa_fail(ctx, "pa_sdf_signed_fab: null argument");
   std::string why;
   if (!fab_covers(*state, vbox, 0, isocomp, 1, why) || !fab_covers(*dist, vbox, 0, dcomp, 1, why)) return pa_fail(ctx, "pa_sdf_signed_fab: " + why);

@@ -274,6 +274,7 @@ struct SmoothSolver {
 
 extern "C" int pa_smooth_solve(pa_ctx* ctx, int nlev, pa_mf* const* rhs, int rcomp, pa_mf* const* sol, int scomp, double dt, const int32_t bc[3], double tol,
                                int maxiter, int* iters, double* res) {
+  PaBind bind_(ctx);
   if (!ctx || nlev <= 0 || !rhs || !sol || !bc) return pa_fail(ctx, "pa_smooth_solve: null argument");
   SmoothSolver S;
   S.ctx = ctx; S.nlev = nlev; S.ratio = 2; S.dt = dt;

@@ -80,6 +80,7 @@ static void grad_launch(hipStream_t st, const BP& bp, int nx, int ny, int nz, un
 }
 
 extern "C" int pa_grad_level(pa_ctx* ctx, const pa_mf* phi, int comp, pa_mf* out, int ocomp) {
+  PaBind bind_(ctx);
   if (!ctx || !phi || !out) return pa_fail(ctx, "pa_grad_level: null argument");
   if (phi->lev != out->lev) return pa_fail(ctx, "pa_grad_level: phi and out live on different levels");
   if (phi->ng < 1) return pa_fail(ctx, "pa_grad_level: phi needs >= 1 ghost layer");
@@ -93,6 +94,7 @@ extern "C" int pa_grad_level(pa_ctx* ctx, const pa_mf* phi, int comp, pa_mf* out
 }
 
 extern "C" int pa_grad_fab(pa_ctx* ctx, pa_box valid, const pa_fab* phi, int comp, const double dxinv[3], pa_fab* out, int ocomp) {
+  PaBind bind_(ctx);
   if (!ctx || !phi || !out || !dxinv) return pa_fail(ctx, "pa_grad_fab: null argument");
   std::string why;
   if (!fab_covers(*phi, valid, 1, comp, 1, why) || !fab_covers(*out, valid, 0, ocomp, 4, why)) return pa_fail(ctx, "pa_grad_fab: " + why);
@@ -136,6 +138,7 @@ __global__ __launch_bounds__(256) void k_minmax(DLevelView L, DMFView M, int com
 int pa_ensure_red(pa_ctx* ctx, size_t n);
 
 extern "C" int pa_minmax_level(pa_ctx* ctx, const pa_mf* s, int comp, double* mn, double* mx) {
+  PaBind bind_(ctx);
   if (!ctx || !s || !mn || !mx) return pa_fail(ctx, "pa_minmax_level: null argument");
   if (comp < 0 || comp >= s->ncomp) return pa_fail(ctx, "pa_minmax_level: component range");
   const unsigned nb = (unsigned)s->lev->boxes.size();
@@ -166,6 +169,7 @@ __global__ __launch_bounds__(256) void k_progress(BP bp, int comp, int ccomp, do
 }
 
 extern "C" int pa_progress_level(pa_ctx* ctx, const pa_mf* s, int comp, double pmin, double pmax, pa_mf* c, int ccomp, int ng) {
+  PaBind bind_(ctx);
   if (!ctx || !s || !c) return pa_fail(ctx, "pa_progress_level: null argument");
   if (s->lev != c->lev) return pa_fail(ctx, "pa_progress_level: different levels");
   if (ng > s->ng || ng > c->ng || comp >= s->ncomp || ccomp >= c->ncomp) return pa_fail(ctx, "pa_progress_level: ng/component range");
@@ -178,6 +182,7 @@ extern "C" int pa_progress_level(pa_ctx* ctx, const pa_mf* s, int comp, double p
 }
 
 extern "C" int pa_progress_fab(pa_ctx* ctx, pa_box bx, const pa_fab* s, int comp, double pmin, double pmax, pa_fab* c, int ccomp) {
+  PaBind bind_(ctx);
   if (!ctx || !s || !c) return pa_fail(ctx, "pa_progress_fab: null argument");
   std::string why;
   if (!fab_covers(*s, bx, 0, comp, 1, why) || !fab_covers(*c, bx, 0, ccomp, 1, why)) return pa_fail(ctx, "pa_progress_fab: " + why);
@@ -218,6 +223,7 @@ __global__ __launch_bounds__(256) void k_normal(BP bp, int comp, int gcomp, int 
 
 extern "C" int pa_normal_level(pa_ctx* ctx, const pa_mf* c, int comp, pa_mf* G, int gcomp, pa_mf* normgrad, int ngcomp,
                                pa_mf* n, int ncomp0) {
+  PaBind bind_(ctx);
   if (!ctx || !c || !n) return pa_fail(ctx, "pa_normal_level: null argument");
   if (c->ng < 1) return pa_fail(ctx, "pa_normal_level: c needs >= 1 ghost layer");
   if (c->lev != n->lev || (G && G->lev != c->lev) || (normgrad && normgrad->lev != c->lev)) return pa_fail(ctx, "pa_normal_level: different levels");
@@ -232,6 +238,7 @@ extern "C" int pa_normal_level(pa_ctx* ctx, const pa_mf* c, int comp, pa_mf* G, 
 
 extern "C" int pa_normal_fab(pa_ctx* ctx, pa_box valid, const pa_fab* c, int comp, const double dxinv[3], pa_fab* G, int gcomp,
                              pa_fab* normgrad, int ngcomp, pa_fab* n, int ncomp0) {
+  PaBind bind_(ctx);
   if (!ctx || !c || !n || !dxinv) return pa_fail(ctx, "pa_normal_fab: null argument");
   std::string why;
   if (!fab_covers(*c, valid, 1, comp, 1, why) || !fab_covers(*n, valid, 0, ncomp0, 3, why) ||
@@ -284,6 +291,7 @@ __global__ __launch_bounds__(256) void k_threshold(LevelBP4 bp, int ccomp, doubl
 }
 
 extern "C" int pa_div_level(pa_ctx* ctx, pa_mf* n, int ncomp0, double scale, const pa_mf* c, int ccomp, double thr, pa_mf* K, int kcomp) {
+  PaBind bind_(ctx);
   if (!ctx || !n || !K) return pa_fail(ctx, "pa_div_level: null argument");
   if (n->ng < 1) return pa_fail(ctx, "pa_div_level: n needs >= 1 ghost layer");
   if (n->lev != K->lev || (c && c->lev != n->lev)) return pa_fail(ctx, "pa_div_level: different levels");
@@ -301,6 +309,7 @@ extern "C" int pa_div_level(pa_ctx* ctx, pa_mf* n, int ncomp0, double scale, con
 }
 
 extern "C" int pa_div_fab(pa_ctx* ctx, pa_box valid, const pa_fab* n, int ncomp0, const double dxinv[3], double scale, pa_fab* K, int kcomp) {
+  PaBind bind_(ctx);
   if (!ctx || !n || !K || !dxinv) return pa_fail(ctx, "pa_div_fab: null argument");
   std::string why;
   if (!fab_covers(*n, valid, 1, ncomp0, 3, why) || !fab_covers(*K, valid, 0, kcomp, 1, why)) return pa_fail(ctx, "pa_div_fab: " + why);

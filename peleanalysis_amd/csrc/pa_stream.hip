@@ -150,6 +150,7 @@ __global__ __launch_bounds__(256) void k_stream_step(StreamLevels S, long long n
 
 extern "C" int pa_stream_trace(pa_ctx* ctx, int nlev, pa_mf* const* vfield, int vcomp, int64_t nseed, const double* seeds, int nsteps, double dt,
                                double* dev_pos, int32_t* nredist) {
+  PaBind bind_(ctx);
   if (!ctx || !vfield || nlev <= 0 || nlev > PA_STREAM_MAXLEV || (nseed > 0 && (!seeds || !dev_pos))) return pa_fail(ctx, "pa_stream_trace: bad argument");
   if (nsteps < 1) return pa_fail(ctx, "pa_stream_trace: Nsteps must be at least 1");
   if (nredist) *nredist = 0;

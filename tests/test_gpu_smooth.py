@@ -1,7 +1,8 @@
 """GPU parity: do_smooth (curvature.cpp:328-406) -- pa_smooth_solve vs the oracle's composite solve.
 An iterative solve to a tolerance: GPU and oracle run the same algorithm with different summation
-orders, so the comparison is to a stated tolerance (1e-10 absolute on a field in [0,1]; both solve to a
-residual of 1e-13), plus the solver-independent checks (exact discrete eigenmode, residual of the GPU
+orders, so the comparison is to a stated tolerance: 1e-12 absolute on a field in [0,1] (= north_star's 1e-12 relative
+to the field's scale) with both sides iterated to a residual of 1e-14 (cond(I - dt Lap) ~ 25 here), plus the
+solver-independent checks (exact discrete eigenmode, residual of the GPU
 solution under the ORACLE's operator)."""
 import numpy as np
 import pytest
@@ -44,12 +45,12 @@ def test_smooth_composite_matches_oracle(ctx, oracle, per):
         rhs.append(m)
     bc = capi.bc_from_flags(per)
     dt = 5e-4
-    want, oit, ores = oracle.smooth_solve(H.levels, rhs, 0, dt, bc, MultiFab, tol=1e-13)
-    got, it, res = _solve_gpu(ctx, H.levels, rhs, dt, bc, 1e-13)
-    assert 0 < it < 100 and res <= 1e-13 and abs(it - oit) <= 3
+    want, oit, ores = oracle.smooth_solve(H.levels, rhs, 0, dt, bc, MultiFab, tol=1e-14)
+    got, it, res = _solve_gpu(ctx, H.levels, rhs, dt, bc, 1e-14)
+    assert 0 < it < 100 and res <= 1e-14 and abs(it - oit) <= 3
     for l, lv in enumerate(H.levels):
         for b in range(lv.nboxes):
-            assert np.abs(got[l].valid(b)[0] - want[l].valid(b)[0]).max() <= 1e-10, (l, b)
+            assert np.abs(got[l].valid(b)[0] - want[l].valid(b)[0]).max() <= 1e-12, (l, b)
     # the GPU solution under the oracle's composite operator
     x = [MultiFab(lv, 1, 1) for lv in H.levels]
     for l, lv in enumerate(H.levels):
@@ -60,15 +61,17 @@ def test_smooth_composite_matches_oracle(ctx, oracle, per):
     assert r <= 1e-12
 
 
-def test_curvature_run_with_smoothing(ctx, oracle):
-    """the tool path: Progress stays unsmoothed, SmoothedProgress feeds the curvature (idprogvar, :408)"""
+@pytest.mark.parametrize("per,sym", [((1, 1, 0), (0, 0, 0)), ((0, 1, 0), (1, 0, 1))])
+def test_curvature_run_with_smoothing(ctx, oracle, per, sym):
+    """the tool path: Progress stays unsmoothed, SmoothedProgress feeds the curvature (idprogvar, :408).  With sym_dir set
+    the gradient operators see reflect_odd walls but the smoothing operator stays Neumann (curvature.cpp:348-357)."""
     from util import make_states
-    H = nested_hierarchy(16, 3, 8, is_per=(1, 1, 0))
+    H = nested_hierarchy(16, 3, 8, is_per=per)
     states = make_states(H, 1, 2, field_flame, seed=41)
-    bc = capi.bc_from_flags((1, 1, 0))
+    bc = capi.bc_from_flags(per, sym)
     dt = 1e-3
     oout = [MultiFab(lv, 18, 0) for lv in H.levels]
-    oracle.curvature_pipeline(H.levels, [s.copy() for s in states], 0, bc, oout, 0, MultiFab, do_smooth=True, smoothing_time=dt, smooth_tol=1e-13)
+    oracle.curvature_pipeline(H.levels, [s.copy() for s in states], 0, bc, oout, 0, MultiFab, do_smooth=True, smoothing_time=dt, smooth_tol=1e-14)
     dls = [capi.DevLevel(ctx, lv) for lv in H.levels]
     dst = [capi.DevMF.from_host(ctx, dl, s) for dl, s in zip(dls, states)]
     dout = [capi.DevMF(ctx, dl, 18, 0) for dl in dls]
@@ -79,7 +82,7 @@ def test_curvature_run_with_smoothing(ctx, oracle):
         for b in range(lv.nboxes):
             gv, wv = g.valid(b), oout[l].valid(b)
             assert np.array_equal(gv[0].view(np.int64), wv[0].view(np.int64)), "Progress (unsmoothed) must stay bit-identical"
-            assert np.abs(gv[17] - wv[17]).max() <= 1e-10, "SmoothedProgress"
+            assert np.abs(gv[17] - wv[17]).max() <= 1e-12, "SmoothedProgress"
             assert not np.array_equal(gv[17], gv[0])
             # curvature and normals are differentiated from a field that agrees to 1e-10: loose, scaled tolerance
             for c in (1, 2, 3, 4):

@@ -227,3 +227,205 @@ def test_marching_squares_circle_known_answer(oracle):
     st3[2, j5 + 1, i5 + 1] = 0.3
     v3, _, _ = oracle.msq_fab(st3, mask, lo, hi, 2, 0.3, np.array([0, 0]), np.array([n - 2, n - 2]))
     assert ((v3[:, 0] == X[j5 + 1, i5 + 1]) & (v3[:, 1] == Y[j5 + 1, i5 + 1])).any()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Known answers for the RECALLED AMReX pieces of the oracle.  Which lines each test constrains is
+# listed in DESIGN.md section 1.
+def _two_level(ncrse, clo, chi, is_per, box=None):
+    """coarse level ncrse^3 on [0,1]^3 + one fine level over the coarse cells clo..chi (inclusive, per direction)"""
+    from peleanalysis_amd.hierarchy import Level, chop_box
+    clo, chi = np.asarray(clo), np.asarray(chi)
+    L0 = Level(chop_box((0, 0, 0), (ncrse - 1,) * 3, box or ncrse), (0, 0, 0), (ncrse - 1,) * 3, is_per, (0., 0., 0.), (1., 1., 1.))
+    flo, fhi = 2 * clo, 2 * chi + 1
+    L1 = Level(chop_box(flo, fhi, box or 2 * ncrse), (0, 0, 0), (2 * ncrse - 1,) * 3, is_per, (0., 0., 0.), (1., 1., 1.))
+    return L0, L1
+
+
+def _cf_face_ghosts(lv, b, d, side):
+    """index arrays (into fab(b) with ng ghost layers) of the ring-1 ghost cells behind face (d, side) of box b"""
+    lo, hi = lv.boxes[b, :3], lv.boxes[b, 3:]
+    return lo, hi
+
+
+@pytest.mark.parametrize("d", [0, 1, 2])
+def test_cf_ghost_exact_for_normal_cubic_plus_tangential_quadratic(oracle, d):
+    """applyBC at a coarse-fine face (pa_oracle.c orc_apply_bc + cf_bndry_value): the ghost value is the cubic through
+    {boundary value at the coarse cell centre, 3 interior cells} evaluated at the ghost centre, and the boundary value
+    is the order-3 tangential interpolant WITH the cross term.  Both are exact for f = cubic(normal) + quadratic
+    (tangential, incl. the mixed term), so every coarse-fine ghost cell must hold f(ghost centre)."""
+    L0, L1 = _two_level(16, (4, 4, 4), (11, 11, 11), (0, 0, 0), box=8)
+    t0, t1 = [a for a in range(3) if a != d]
+
+    def f(x, y, z):
+        X = (x, y, z)
+        n, a, b = X[d], X[t0], X[t1]
+        return 1.0 + 0.7 * n - 1.3 * n * n + 2.1 * n ** 3 + 0.4 * a - 0.9 * b + 1.7 * a * a - 0.6 * b * b + 2.3 * a * b + 0 * x * y * z
+    c, s = MultiFab(L0, 1, 1), MultiFab(L1, 1, 1)
+    fill_analytic(c, 0, f)
+    fill_analytic(s, 0, f)
+    oracle.fill_boundary(s, 0, 1, 1)
+    oracle.apply_bc(s, 0, c, 0, oracle.bc_from_flags((0, 0, 0)))
+    nchecked = 0
+    for b in range(L1.nboxes):
+        x, y, z = cell_centers(L1, b, 1)
+        want = f(x, y, z)
+        lo, hi = L1.boxes[b, :3], L1.boxes[b, 3:]
+        for side in (0, 1):
+            on_cf = (lo[d] == 8) if side == 0 else (hi[d] == 23)  # faces of the fine REGION: every ghost cell is coarse-fine
+            if not on_cf:
+                continue
+            sl = [slice(1, -1)] * 3
+            sl[2 - d] = slice(0, 1) if side == 0 else slice(-1, None)
+            got = s.fab(b)[0][tuple(sl)]
+            assert np.abs(got - want[tuple(sl)]).max() < 5e-14, (d, b, side)
+            nchecked += got.size
+    assert nchecked == 2 * 16 * 16
+
+
+def test_cf_cross_term_only_when_all_four_diagonals_are_coarse_fine(oracle):
+    """InterpBndryData drops the mixed term (and shifts the tangential stencil one-sided) where a tangential neighbour
+    of the ghost cell is not itself a coarse-fine ghost position.  Fine region flush with the z wall, f = y z on an
+    x-face: the boundary value of ghost cells in the first fine z-pair (coarse k = 0) misses exactly the term
+    yy * zz * Dyz = (+-1/4)(+-1/4) H^2, which reaches the ghost value through the cubic's weight 16/35;
+    all other ghost cells of the face are exact."""
+    L0, L1 = _two_level(16, (4, 4, 0), (11, 11, 7), (0, 0, 0))
+    f = lambda x, y, z: y * z + 0 * x
+    c, s = MultiFab(L0, 1, 1), MultiFab(L1, 1, 1)
+    fill_analytic(c, 0, f)
+    fill_analytic(s, 0, f)
+    oracle.apply_bc(s, 0, c, 0, oracle.bc_from_flags((0, 0, 0)), only_dir=0)
+    x, y, z = cell_centers(L1, 0, 1)
+    want = f(x, y, z)
+    H = 1.0 / 16
+    for xs in (0, -1):
+        got = s.fab(0)[0][1:-1, 1:-1, xs]
+        err = got - want[1:-1, 1:-1, xs]
+        assert np.abs(err[2:, :]).max() < 1e-15  # coarse k >= 1: centred z stencil, cross term on -> exact
+        # coarse k = 0 (fine k = 0, 1): the quadratic one-sided z stencil is exact for a field linear in z, the cross term is missing
+        jj = np.arange(8, 24)
+        yy = np.where(jj % 2 == 0, -0.25, 0.25)[None, :]
+        zz = np.array([-0.25, 0.25])[:, None]
+        # the boundary value enters the normal cubic with the Lagrange weight 16/35 (SURVEY A.2)
+        assert np.abs(err[:2, :] + (16.0 / 35.0) * yy * zz * H * H).max() < 1e-15
+
+
+def _cons_interp_numpy(cr, parent, child_off):
+    """independent restatement of mf_cell_cons_lin_interp_mcslope + mf_cell_cons_lin_interp for ratio 2 on a periodic
+    coarse array cr[k][j][i] (numpy, written from the formulas in SURVEY A.6 / DESIGN 1, not from the C oracle)"""
+    k, j, i = parent
+    n = cr.shape[0]
+    u = lambda di, dj, dk: cr[(k + dk) % n, (j + dj) % n, (i + di) % n]
+    u0 = u(0, 0, 0)
+    s = []
+    for e in ((1, 0, 0), (0, 1, 0), (0, 0, 1)):
+        up, um = u(*e), u(-e[0], -e[1], -e[2])
+        dc, df, db = 0.5 * (up - um), 2.0 * (up - u0), 2.0 * (u0 - um)
+        sl = min(abs(df), abs(db)) if df * db >= 0.0 else 0.0
+        s.append(np.copysign(1.0, dc) * min(sl, abs(dc)))
+    alpha = 1.0
+    if any(v != 0.0 for v in s):
+        dumax = abs(s[0]) * 1.0 / 4.0 + abs(s[1]) * 1.0 / 4.0 + abs(s[2]) * 1.0 / 4.0
+        nb = [u(a, b, c) for c in (-1, 0, 1) for b in (-1, 0, 1) for a in (-1, 0, 1)]
+        umax, umin = max(nb), min(nb)
+        if dumax * alpha > umax - u0:
+            alpha = (umax - u0) / dumax
+        if dumax * alpha > u0 - umin:
+            alpha = (u0 - umin) / dumax
+    return u0 + child_off[0] * (s[0] * alpha) + child_off[1] * (s[1] * alpha) + child_off[2] * (s[2] * alpha)
+
+
+def _ghost_children(L1, s, ng=2):
+    """(parent (ic,jc,kc), child offset (+-1/4)^3, value) of every ghost cell of the one-box fine level that no fine box covers"""
+    lo, hi = L1.boxes[0, :3], L1.boxes[0, 3:]
+    f = s.fab(0)[0]
+    out = []
+    for k in range(lo[2] - ng, hi[2] + ng + 1):
+        for j in range(lo[1] - ng, hi[1] + ng + 1):
+            for i in range(lo[0] - ng, hi[0] + ng + 1):
+                if lo[0] <= i <= hi[0] and lo[1] <= j <= hi[1] and lo[2] <= k <= hi[2]:
+                    continue
+                p = (i // 2, j // 2, k // 2)
+                off = tuple(0.25 if q % 2 else -0.25 for q in (i, j, k))
+                out.append((p, off, f[k - lo[2] + ng, j - lo[1] + ng, i - lo[0] + ng]))
+    return out
+
+
+def test_cell_conservative_interp_conserves_and_stays_in_bounds(oracle):
+    """FillPatchTwoLevels / mf_cell_cons_interp (pa_oracle.c orc_fillpatch_two_levels) on random coarse data: the 8 children
+    of a coarse cell average to the parent (offsets +-1/4 cancel), every child lies within the min / max of the parent's
+    27 neighbours, and every child equals the independent numpy restatement bit for bit."""
+    L0, L1 = _two_level(8, (2, 2, 2), (5, 5, 5), (1, 1, 1))
+    rng = np.random.default_rng(7)
+    cr = rng.uniform(-1, 1, size=(8, 8, 8))
+    c, s = MultiFab(L0, 1, 0), MultiFab(L1, 1, 2)
+    c.valid(0)[0] = cr
+    assert oracle.fillpatch_two_levels(s, c, 0, 1, 2) == 0
+    groups = {}
+    for p, off, v in _ghost_children(L1, s):
+        assert v == _cons_interp_numpy(cr, (p[2], p[1], p[0]), off), (p, off)
+        groups.setdefault(p, []).append(v)
+        nb = [cr[(p[2] + a) % 8, (p[1] + b) % 8, (p[0] + d) % 8] for a in (-1, 0, 1) for b in (-1, 0, 1) for d in (-1, 0, 1)]
+        assert min(nb) - 1e-15 <= v <= max(nb) + 1e-15
+    full = [p for p, vs in groups.items() if len(vs) == 8]
+    assert len(full) == 6 ** 3 - 4 ** 3  # the ring of coarse cells around the fine region is covered by whole children sets
+    for p in full:
+        assert abs(np.mean(groups[p]) - cr[p[2], p[1], p[0]]) < 2e-16 * 8
+
+
+def test_cell_conservative_interp_known_answers(oracle):
+    """(i) a linear field is reproduced exactly away from extrema; (ii) at a local extremum all slopes vanish (children ==
+    parent); (iii) the common factor uses dumax = sum |s_d| (r-1)/(2r), the excursion of the fine CELL CENTRES: with
+    u(-1) = -2, u(0) = 0, u(+1) = 1/2 in every direction and all other neighbours <= 1/2 the limited slopes are 1, 1, 1,
+    dumax = 3/4 > umax - u0 = 1/2, alpha = 2/3, and the (+,+,+) child lands exactly ON the bound 1/2 (the cell-corner
+    form 1/2 sum |s_d| would give alpha = 1/3 and 1/4)."""
+    L0, L1 = _two_level(8, (2, 2, 2), (5, 5, 5), (1, 1, 1))
+    c, s = MultiFab(L0, 1, 0), MultiFab(L1, 1, 2)
+    # (i) linear in the interior of the periodic box (the wrap-around jump is 3 cells away from every parent used)
+    x, y, z = cell_centers(L0, 0, 0)
+    lin = lambda x, y, z: 2.0 * x - 3.0 * y + 0.5 * z + 0 * x * y * z
+    c.valid(0)[0] = lin(x, y, z)
+    assert oracle.fillpatch_two_levels(s, c, 0, 1, 2) == 0
+    xf, yf, zf = cell_centers(L1, 0, 2)
+    m = np.ones(s.fab(0)[0].shape, bool)
+    m[2:-2, 2:-2, 2:-2] = False
+    assert np.abs(s.fab(0)[0] - lin(xf, yf, zf))[m].max() < 1e-15
+    # (ii) + (iii): hand-made 3 x 3 x 3 neighbourhood around the parent (1, 3, 3) (a ghost parent on the low-x side)
+    cr = np.full((8, 8, 8), -5.0)
+    P = (3, 3, 1)  # [k][j][i]
+    cr[P] = 0.0
+    for ax in range(3):
+        lo, hi = list(P), list(P)
+        lo[ax] -= 1
+        hi[ax] += 1
+        cr[tuple(lo)], cr[tuple(hi)] = -2.0, 0.5
+    c.valid(0)[0] = cr
+    assert oracle.fillpatch_two_levels(s, c, 0, 1, 2) == 0
+    kids = {off: v for p, off, v in _ghost_children(L1, s) if p == (1, 3, 3)}
+    assert len(kids) == 8
+    assert kids[(0.25, 0.25, 0.25)] == 0.5 and kids[(-0.25, -0.25, -0.25)] == -0.5
+    assert abs(kids[(0.25, -0.25, 0.25)] - (0.25 * 2.0 / 3.0)) < 1e-16
+    cr2 = np.full((8, 8, 8), -5.0)
+    cr2[P] = 1.0  # strict local maximum: df * db < 0 in every direction
+    c.valid(0)[0] = cr2
+    assert oracle.fillpatch_two_levels(s, c, 0, 1, 2) == 0
+    assert all(v == 1.0 for p, off, v in _ghost_children(L1, s) if p == (1, 3, 3))
+
+
+def test_cell_conservative_interp_next_to_a_wall(oracle):
+    """filterPlt fills the coarse ghost cells beyond a non-periodic wall with foextrap (filterPlt.cpp:164-173) and
+    mf_compute_slopes keeps the central form for foextrap: at a wall-adjacent coarse parent u(-1) == u(0), so db = 0 and the
+    wall-normal slope is 0 -- the two children across that direction are equal -- while the tangential slopes are untouched."""
+    L0, L1 = _two_level(8, (2, 2, 0), (5, 5, 3), (0, 0, 0))
+    c, s = MultiFab(L0, 1, 0), MultiFab(L1, 1, 2)
+    x, y, z = cell_centers(L0, 0, 0)
+    c.valid(0)[0] = 1.0 + 2.0 * x + 3.0 * z + 0 * y
+    assert oracle.fillpatch_two_levels(s, c, 0, 1, 2) == 0
+    f = s.fab(0)[0]  # box lo = (4, 4, 0), ng = 2: fab index = cell - lo + 2
+    xf, yf, zf = cell_centers(L1, 0, 2)
+    # ghost cells at fine i = 2, 3 (parent ic = 1), fine k = 0, 1 (parent kc = 0, on the wall), any j inside
+    g = f[2:4, 4:-4, 0:2]
+    assert np.all(g[0] == g[1])                                    # no z slope at the wall parent
+    assert np.abs(g[0] - (1.0 + 2.0 * xf[0, 0, 0:2] + 3.0 * (0.5 / 8))).max() < 1e-15  # x slope exact, z frozen at the parent centre
+    g2 = f[4:6, 4:-4, 0:2]                                         # parent kc = 1: centred, linear field exact
+    assert np.abs(g2 - (1.0 + 2.0 * xf[:, :, 0:2] + 3.0 * zf[4:6] + 0 * yf[:, 4:-4])).max() < 1e-15

@@ -18,7 +18,10 @@ namespace pa {
   // same text as amrex::Abort
   std::cerr << "amrex::Abort::0::" << msg << " !!!" << std::endl;
   std::fflush(nullptr);
-  std::exit(134);
+  // _Exit, not exit: Abort is also reached from plotfile worker threads while other workers (and the thread that
+  // brings up the HIP runtime) are still running; exit() would run static destructors under live threads.
+  // amrex::Abort itself ends in std::abort() -- no destructors either.
+  std::_Exit(134);
 }
 
 class ParmParse {

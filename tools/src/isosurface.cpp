@@ -285,7 +285,7 @@ int main(int argc, char** argv) {
     std::vector<pa::Box3> doms;
     std::vector<int> steps;
     for (int lev = 0; lev < Nlev; ++lev) { doms.push_back(H.lev[lev].domain); steps.push_back(H.lev[lev].level_step); }
-    pa::write_plotfile(outfile, {"distance"}, doms, H.prob_lo, H.prob_hi, hdist, H.time, steps);
+    pa::write_plotfile(outfile, {"distance"}, doms, H.prob_lo, H.prob_hi, hdist, 0.0 /* isosurface.cpp:1417,1747: the local `Real time = 0` */, steps);
   }
   {  // isosurface.cpp:1756-1771 (one rank: max = min)
     const double surf_time = now() - strt_time_surf - io_time;
