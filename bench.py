@@ -12,12 +12,17 @@ roofline: dominant kernel = the fused grad->curvature sweep; achieved = 72 B (re
           events recorded by the library on its own stream inside the timed region.
 cpu_baseline: the CPU oracle (oracle/, OpenMP over boxes, kind "port") on a bounded sample of the
           same workload (a smaller hierarchy of the same shape) on this node's host cores.
-N > 1   : weak scaling -- N copies of the hierarchy side by side in x (periodic), rank r owns slab r;
-          the level-0 slab faces exchange 2 ghost layers per step over RCCL point-to-point.
+N > 1   : STRONG scaling by default -- the ONE headline hierarchy is sharded over the N ranks (Morton order + equal-volume
+          cuts per level, pa_distribution_map); per step and component the library batches every cross-rank ghost fill
+          (same-level ghost cells, coarse phi and coarse flame normal under the coarse-fine faces) into two grouped
+          RCCL point-to-point exchanges on its own stream.  --scaling weak: N copies of the hierarchy side by side in x.
+          `python bench.py --gpus N` without a launcher starts its own N ranks (torch.distributed.run).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -117,13 +122,26 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-profile", action="store_true", help="diagnostic: no HIP events in the timed region (no roofline object)")
     ap.add_argument("--cpu-base", type=int, default=0, help="base size of the cpu_baseline sample (0: from the core count)")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong", help="N > 1: shard ONE hierarchy (strong) or one hierarchy per GPU (weak)")
+    ap.add_argument("--sim-of", type=int, default=0, help="diagnostic, 1 GPU: time rank 0's share of an N-rank strong-scaling run with no-op exchanges")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.sim_of:
+        # No launcher: this process becomes one and never touches the GPU (a process that has initialised HIP must not be
+        # replaced or forked into ranks).  One rank per GPU, exactly as the driver's torch.distributed.run line does.
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
 
     import torch  # torch first: one HIP runtime in the process
     import torch.distributed as dist
     from peleanalysis_amd import capi
     from peleanalysis_amd import dist as padist
-    from peleanalysis_amd.hierarchy import mf_layout, nested_hierarchy
+    from peleanalysis_amd.hierarchy import Hierarchy, Level, chop_box, mf_layout, nested_hierarchy
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -131,93 +149,89 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the product path has no CPU fallback)")
     # PA_BENCH_REHEARSE=1: rehearsal of the N > 1 code path on a box with FEWER GPUs than ranks -- ranks share the cards,
-    # transport is gloo through host memory (RCCL wants one GPU per rank).  Same hierarchy split, same region lists,
-    # same pack / unpack kernels, same reductions; the number it prints is not a scaling measurement.
+    # transport is the pa_comm callback over gloo through host memory (RCCL wants one GPU per rank).  Same sharding, same
+    # region plans, same pack / unpack kernels, same reductions; the number it prints is not a scaling measurement.
     rehearse = os.environ.get("PA_BENCH_REHEARSE", "0") == "1"
     if rehearse:
         local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    rdev = torch.device("cpu") if rehearse else dev  # where the tiny reduction tensors live
-    gloo = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if rehearse:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)
+        # torch.distributed (gloo) is the control plane only: rendezvous, the 128-byte RCCL id, barriers, the max over
+        # ranks of the elapsed time.  The data plane is the library's own RCCL communicator.
+        dist.init_process_group("gloo")
     stream = torch.cuda.Stream(device=dev)
     ctx = capi.Context(local, stream.cuda_stream)
 
-    # weak scaling: every rank owns one full copy of the headline hierarchy (fixed work per GPU)
     per = tuple(int(v) for v in args.per.split())
     if world > 1 and per != (1, 1, 0):
         raise SystemExit("--per is a single-GPU diagnostic option")
-    if world == 1:
-        H = nested_hierarchy(args.base, args.nlev, args.box, is_per=per)
-        remotes, plans = [None] * args.nlev, None
+    nshard, myrank = (args.sim_of, 0) if args.sim_of else (world, rank)
+    if args.scaling == "weak" and nshard > 1:
+        # N copies of the headline hierarchy side by side in x (global level 0 is N*base x base x base, periodic in x);
+        # rank r owns copy r on every level
+        H1 = nested_hierarchy(args.base, args.nlev, args.box, is_per=per)
+        levels, owners = [], []
+        for l, lv in enumerate(H1.levels):
+            n0 = int(lv.domhi[0] - lv.domlo[0] + 1)
+            bx = np.vstack([lv.boxes + np.array([r * n0, 0, 0, r * n0, 0, 0], dtype=np.int32) for r in range(nshard)])
+            levels.append(Level(bx, lv.domlo, lv.domhi + np.array([(nshard - 1) * n0, 0, 0]), lv.is_per, lv.prob_lo, lv.prob_hi * np.array([nshard, 1, 1])))
+            owners.append(np.repeat(np.arange(nshard, dtype=np.int32), lv.nboxes))
+        H = Hierarchy(levels, 2)
     else:
-        R = padist.slab_hierarchy(args.base, args.nlev, args.box, world, rank, 2)
-        H, remotes, plans = R.local, R.remote, R.plans
+        H = nested_hierarchy(args.base, args.nlev, args.box, is_per=per)
+        owners = padist.shard(H, nshard) if nshard > 1 else [None] * args.nlev
     bc = capi.bc_from_flags(per)
-    dls = [capi.DevLevel(ctx, lv, remotes[l]) for l, lv in enumerate(H.levels)]
-    cells = sum(lv.ncells for lv in H.levels)
+    xch = {"mode": "none"}
+    gcomm = None
+    if args.sim_of:  # one rank's share of an N-rank run on this GPU, exchanges replaced by no-ops: compute time per rank
+        nullx = capi.EXCHANGE_FN(lambda user, st, n, x: 0)
+        nullr = capi.ALLREDUCE_FN(lambda user, v, n, op: 0)
+        simc = capi.PaComm(None, 0, nshard, nullx, nullr)
+        ctx.set_comm(simc)
+        xch["mode"] = f"SIMULATION of rank 0 of {nshard}: exchanges are no-ops (results wrong in ghost cells, timing = compute only)"
+    elif world > 1:
+        err = ""
+        if not rehearse:
+            try:
+                padist.init_rccl(ctx)       # built-in transport: grouped ncclSend / ncclRecv on the library's stream
+                ctx.comm_selftest(1 << 16)  # ring exchange + reduction with known answers before it is trusted
+            except Exception as e:
+                err = repr(e)[:300]
+        ok = [None] * world
+        dist.all_gather_object(ok, err)
+        if rehearse or any(ok):
+            gcomm = padist.GlooComm(ctx)    # pa_comm callbacks: packed buffers staged through host memory + gloo
+            ctx.comm_selftest(1 << 12)
+            xch["mode"] = "host-staged gloo point-to-point (pa_comm callbacks)" + ("" if rehearse else " -- RCCL transport failed: " + next(e for e in ok if e))
+        else:
+            xch["mode"] = "RCCL point-to-point (grouped ncclSend/ncclRecv issued by the library on its stream), 2 exchanges per component per step"
+    dls = [capi.DevLevel(ctx, lv, owners[l], myrank, nshard) if nshard > 1 else capi.DevLevel(ctx, lv) for l, lv in enumerate(H.levels)]
+    cells = sum(lv.ncells for lv in H.levels)                # the whole job
+    cells_local = sum(dl.level.ncells for dl in dls)         # this rank's share
     hold, states, works, outs = [], [], [], []
     with torch.cuda.stream(stream):
-        for li, (lv, dl) in enumerate(zip(H.levels, dls)):
+        for li, dl in enumerate(dls):
+            lv = dl.level
             off, cs, tot = mf_layout(lv.boxes, args.ncomp, 2)
-            tin = torch.zeros(tot, dtype=torch.float64, device=dev)
+            tin = torch.zeros(max(tot, 1), dtype=torch.float64, device=dev)
             fill_level_on_device(torch, lv, tin, args.ncomp, 2, off, cs, dev, 1234 + 100 * rank + li)
             _, _, tw = mf_layout(lv.boxes, 1, 2)
             _, _, to = mf_layout(lv.boxes, 8, 0)
-            twk = torch.zeros(tw, dtype=torch.float64, device=dev)
-            tout = torch.zeros(to, dtype=torch.float64, device=dev)
+            twk = torch.zeros(max(tw, 1), dtype=torch.float64, device=dev)
+            tout = torch.zeros(max(to, 1), dtype=torch.float64, device=dev)
             hold += [tin, twk, tout]
             states.append(capi.DevMF(ctx, dl, args.ncomp, 2, tin.data_ptr()))
             works.append(capi.DevMF(ctx, dl, 1, 2, twk.data_ptr()))
             outs.append(capi.DevMF(ctx, dl, 8, 0, tout.data_ptr()))
     stream.synchronize()
     params = capi.curv_params(prog_min=300.0, prog_max=2000.0, threshold=None, fused=bool(args.fused))
-    xch = {"mode": "none", "bytes_per_step": 0}
-
-    def exchange_rccl(c):
-        for l in range(args.nlev):
-            if plans[l].send or plans[l].recv:
-                padist.exchange_device(plans[l], ctx, states[l], c, 1, dev)
-
-    def exchange_gloo(c):  # host-staged fallback: same region lists and HIP pack/unpack, gloo transport
-        for l in range(args.nlev):
-            if plans[l].send or plans[l].recv:
-                padist.exchange_device_staged(plans[l], ctx, states[l], c, 1, dev, group=gloo)
-
-    do_exchange = None
-    if world > 1:
-        xch["bytes_per_step"] = int(sum(8 * pl.size(v, 1) for pl in plans for v in pl.send.values()) * args.ncomp)
-        try:
-            if rehearse:
-                raise RuntimeError("PA_BENCH_REHEARSE=1: gloo transport")
-            exchange_rccl(0)
-            ok = torch.tensor([1], device=rdev)
-        except Exception as e:  # keep the measurement valid (all work done) if RCCL p2p is unavailable
-            xch["rccl_error"] = repr(e)[:300]
-            ok = torch.tensor([0], device=rdev)
-        try:
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            use_rccl = bool(ok.item())
-        except Exception:
-            use_rccl = False
-        if use_rccl:
-            do_exchange, xch["mode"] = exchange_rccl, "RCCL point-to-point (batch_isend_irecv), one packed buffer per peer"
-        else:
-            gloo = None if rehearse else dist.new_group(backend="gloo")  # rehearsal: the default group is gloo already
-            do_exchange, xch["mode"] = exchange_gloo, "host-staged gloo point-to-point (RCCL p2p failed)"
 
     def step():
         for c in range(args.ncomp):  # output buffers are recycled per component (SURVEY 8d memory budget)
-            if do_exchange is not None:
-                do_exchange(c)
-            capi.gradcurv_run(ctx, states, c, bc, params, works, outs, 0)
+            capi.gradcurv_run(ctx, states, c, bc, params, works, outs, 0)  # cross-rank ghost fills happen inside
 
     def barrier():
         if world > 1:
@@ -244,42 +258,49 @@ def main():
         step()
     barrier()
     ctx.profile_enable(False)
-    bd = {name: ctx.profile_read(tag)[1] / nbd for name, tag in (("gradcurv", 1), ("faces", 2), ("fill_boundary", 3), ("apply_bc", 4), ("progress", 6))}
+    bd = {name: ctx.profile_read(tag)[1] / nbd for name, tag in (("gradcurv", 1), ("faces", 2), ("fill_boundary", 3), ("apply_bc", 4), ("progress", 6),
+                                                                  ("exchange", 9))}
     ctx.profile_read(1, reset=True)  # a reset drops every tag's records
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=rdev)
+        t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    total_cells = cells * args.ncomp * world
-    value = total_cells * args.steps / dt / 1e6
+    weak = args.scaling == "weak" and nshard > 1
+    nb0 = H.levels[0].nboxes
+    value = cells * args.ncomp * args.steps / dt / 1e6  # whole job: every cell of every level and rank
+    per_txt = {(1, 1, 0): "periodic x/y + wall z"}.get(per, f"is_per {per}")
+    if world == 1 and not args.sim_of:
+        par = "single GPU"
+    elif weak:
+        par = f"{nshard} hierarchies side by side in x (weak scaling), rank r owns copy r"
+    else:
+        par = (f"ONE hierarchy sharded over {nshard} ranks (Morton order + equal-volume cuts per level): "
+               f"{', '.join(str(dl.level.nboxes) for dl in dls)} boxes per level on rank {myrank}")
     res = {
         "metric": "Mcells/s for grad+curvature on 512^3-base 3-level AMR; % HBM roofline",
         "value": value, "unit": "Mcells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"fused grad->curvature, {args.nlev}-level AMR, base {args.base}^3, ref_ratio 2, {args.box}^3 boxes "
-                               f"({H.levels[0].nboxes} per level), {args.ncomp} comp(s), periodic x/y + wall z, {cells} cells per GPU",
-                   "cells_per_gpu": cells, "ncomp": args.ncomp, "fused": bool(args.fused),
-                   "parallelism": (f"{world} x-slabs (one hierarchy per GPU), level-0 slab faces exchanged per step"
-                                   if world > 1 else "single GPU"),
-                   "exchange": xch},
+        "config": {"workload": f"fused grad->curvature, {args.nlev}-level AMR, base {args.base}^3{' per GPU' if weak else ''}, ref_ratio 2, {args.box}^3 boxes "
+                               f"({nb0} per level), {args.ncomp} comp(s), {per_txt}, {cells} cells in the job",
+                   "cells": cells, "cells_this_rank": cells_local, "ncomp": args.ncomp, "fused": bool(args.fused),
+                   "parallelism": par, "exchange": xch},
     }
     if nk:
-        # one launch of the fused kernel = one level = cells/nlev cells (all levels have base^3 cells here)
+        # one launch of the fused kernel = this rank's boxes of one level; achieved = algorithmic bytes of all timed launches / their time
         avg_ms = ms_k / nk
-        cells_per_launch = cells / args.nlev
-        ach = cells_per_launch * BYTES_PER_CELL / (avg_ms * 1e-3) / 1e9
+        ach = cells_local * args.ncomp * args.steps * BYTES_PER_CELL / (ms_k * 1e-3) / 1e9
         traffic = None  # HBM bytes per launch from the committed rocprofv3 PMC pass of the same workload (profiles/)
         tj = os.path.join(ROOT, "profiles", "r01_headline_traffic.json")  # refreshed by tools/prof.sh + tools/prof_traffic.py
-        if os.path.exists(tj) and (args.base, args.nlev, args.box, args.ncomp) == (512, 3, 128, 1):
+        if os.path.exists(tj) and (args.base, args.nlev, args.box, args.ncomp, world, args.sim_of) == (512, 3, 128, 1, 1, 0):
             traffic = json.load(open(tj)).get("traffic_bytes_per_launch")
         res["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                            "traffic": traffic, "kernel": "k_gradcurv_march3 (fused grad->curvature sweep)", "avg_launch_ms": avg_ms,
-                           "launches": nk, "bytes_per_cell": BYTES_PER_CELL}
-        res["breakdown_ms_per_step"] = bd  # from the untimed steps after the timed region
-        res["step_frac_of_hbm_roofline"] = (cells * args.ncomp * BYTES_PER_CELL / (dt / args.steps) / 1e9) / HBM_PEAK_GBS
-    if rank == 0 and world == 1 and not args.no_cpu:
+                           "launches": nk, "bytes_per_cell": BYTES_PER_CELL, "cells_per_launch": cells_local / args.nlev}
+        res["breakdown_ms_per_step"] = bd  # from the untimed steps after the timed region (rank 0)
+        res["step_frac_of_hbm_roofline"] = (cells_local * args.ncomp * BYTES_PER_CELL / (dt / args.steps) / 1e9) / HBM_PEAK_GBS
+    if rank == 0 and world == 1 and not args.no_cpu and not args.sim_of:
         try:
             # bounded sample (~10-30 s of CPU work): a 3-level hierarchy sized from the host core count
             cores = usable_cpus()

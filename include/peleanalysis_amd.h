@@ -66,20 +66,62 @@ int pa_profile_read(pa_ctx*, int tag, int64_t* nlaunch, double* total_ms, int re
 pa_level* pa_level_create(pa_ctx*, int nboxes, const int32_t* boxes6, const int32_t domlo[3],
                           const int32_t domhi[3], const int32_t is_per[3], const double prob_lo[3],
                           const double prob_hi[3]);
-/* One rank's share of a level (replaces DistributionMapping(ba): grad.cpp:162, curvature.cpp:289):
- * `boxes6` are the FABs this rank owns, `remote6` the boxes of the same level owned by other
- * ranks.  Cells of remote boxes count as valid cells of the level (never coarse-fine, never
- * filled locally); their data arrive through pa_pack_regions / pa_unpack_regions + the caller's
- * exchange (RCCL send/recv of one packed buffer per peer). */
-pa_level* pa_level_create_dist(pa_ctx*, int nboxes, const int32_t* boxes6, int nremote, const int32_t* remote6,
-                               const int32_t domlo[3], const int32_t domhi[3], const int32_t is_per[3],
-                               const double prob_lo[3], const double prob_hi[3]);
-/* cross-rank halves of FillBoundary: gather / scatter lists of regions {local box, lo[3], hi[3]}
- * (box index space, ghost cells allowed) to / from one contiguous device buffer, regions in list
- * order, each [comp][k][j][i].  Synchronous (the buffer goes to the network next). */
-int64_t pa_regions_size(int ncomp, int nreg, const int32_t* regs7);
-int pa_pack_regions(pa_ctx*, const pa_mf*, int comp, int ncomp, int nreg, const int32_t* regs7, double* devbuf);
-int pa_unpack_regions(pa_ctx*, pa_mf*, int comp, int ncomp, int nreg, const int32_t* regs7, const double* devbuf);
+/* ------------------------------------------------------- multi-GPU: one rank per GPU
+ * The reference distributes the boxes of every level over MPI ranks with DistributionMapping(ba)
+ * (grad.cpp:162, curvature.cpp:289, filterPlt.cpp:142, isosurface.cpp:1441) and moves ghost data with
+ * point-to-point messages inside FillBoundary / FillPatch / the MLMG boundary registers.  Here a rank is one
+ * pa_ctx (one process per GPU, or one host thread per GPU inside a tool).  A level created with
+ * pa_level_create_sharded knows the whole BoxArray and its owner map; every entry point that fills ghost cells
+ * (pa_fill_boundary, pa_apply_bc, pa_fillpatch_two_levels, the pa_*_run pipelines) then also performs the
+ * cross-rank half -- pack kernels -> one grouped point-to-point exchange -> unpack kernels -- through the
+ * context's transport, and pa_*_run reduces the progress-variable range over the ranks (curvature.cpp:147-148).
+ * All ranks must make the same sequence of calls (as MPI ranks of the reference do). */
+typedef struct { int32_t peer; double* sendbuf; int64_t nsend; double* recvbuf; int64_t nrecv; } pa_xfer;
+typedef struct {
+  void*   user;
+  int32_t rank, nranks;
+  /* One grouped exchange: for every i send nsend doubles from sendbuf to rank peer and receive nrecv doubles from it
+   * into recvbuf (device pointers; either count may be 0).  Several entries may name the same peer: they are matched
+   * in list order on both sides.  Stream-ordered: the call consumes data produced by work already enqueued on
+   * hip_stream, and work enqueued on it afterwards sees the received data. */
+  int (*exchange)(void* user, void* hip_stream, int32_t n, const pa_xfer* x);
+  /* vals[i] = reduction over the ranks of vals[i] (host memory); op: 0 min, 1 max, 2 sum */
+  int (*allreduce)(void* user, double* vals, int32_t n, int32_t op);
+} pa_comm;
+/* caller-supplied transport (tests: gloo through host memory; tools: peer copies between host threads) */
+int pa_ctx_set_comm(pa_ctx*, const pa_comm*);
+/* built-in transport: RCCL over xGMI (grouped ncclSend / ncclRecv on the context's stream, ncclAllReduce).
+ * pa_rccl_unique_id fills 128 bytes on one rank; the caller broadcasts them; every rank then calls pa_ctx_init_rccl. */
+int pa_rccl_unique_id(pa_ctx*, void* id128);
+int pa_ctx_init_rccl(pa_ctx*, int nranks, int rank, const void* id128);
+int pa_ctx_nranks(const pa_ctx*);
+/* transport check: a ring exchange of n doubles with known contents + a max-reduction with a known answer; synchronous */
+int pa_comm_selftest(pa_ctx*, int64_t n);
+/* the transport's reduction over the ranks (no-op on one rank): op 0 min, 1 max, 2 sum */
+int pa_allreduce(pa_ctx*, double* vals, int n, int op);
+/* DistributionMapping(ba) restated: boxes in Morton order of their low corners, cut into nranks contiguous pieces of
+ * (nearly) equal cell count.  Host arithmetic only.  owner[b] in [0, nranks). */
+int pa_distribution_map(int nboxes, const int32_t* boxes6, int nranks, int32_t* owner);
+/* This rank's share of a level: the whole BoxArray + the owner rank of every box.  The level's boxes are the ones with
+ * owner == rank, in BoxArray order (pa_level_global_ids gives their indices in the BoxArray). */
+pa_level* pa_level_create_sharded(pa_ctx*, int nboxes, const int32_t* boxes6, const int32_t* owner, int rank, int nranks,
+                                  const int32_t domlo[3], const int32_t domhi[3], const int32_t is_per[3],
+                                  const double prob_lo[3], const double prob_hi[3]);
+int pa_level_global_ids(const pa_level*, int32_t* gids /* [pa_level_nboxes] */);
+/* The region lists behind those exchanges, as plain host arithmetic (no GPU; what the CPU-tier tests check against the
+ * undistributed answer).  Rows of 9 int32: {kind, peer, box, lo0, lo1, lo2, hi0, hi1, hi2}; returns the number of rows
+ * (writes at most cap).  kind 0 = send (box = global index of a box this rank owns, region in its index space),
+ * kind 1 = receive (FillBoundary: box = global index of the destination box, ghost region).
+ * pa_plan_coarse_source: the coarse data rank `rank` needs under the coarse-fine faces of its fine boxes (mode 0: the
+ * stencils of pa_apply_bc) or under the ng ghost layers of its fine boxes grown by `halo` coarse cells (mode 1:
+ * pa_fillpatch_two_levels); kind 2 = piece (box = global coarse box it is cut from, peer = its owner; pieces are
+ * disjoint and listed in the order of the rank's coarse-source BoxArray), kind 0 = what this rank sends to `peer`. */
+int64_t pa_plan_fill_boundary(int nboxes, const int32_t* boxes6, const int32_t* owner, int rank, const int32_t domlo[3],
+                              const int32_t domhi[3], const int32_t is_per[3], int ng, int32_t* rows9, int64_t cap);
+int64_t pa_plan_coarse_source(int nfine, const int32_t* fboxes6, const int32_t* fowner, const int32_t fdomlo[3],
+                              const int32_t fdomhi[3], int ncrse, const int32_t* cboxes6, const int32_t* cowner,
+                              const int32_t cdomlo[3], const int32_t cdomhi[3], const int32_t is_per[3], int rank,
+                              int mode, int ng, int halo, int32_t* rows9, int64_t cap);
 void      pa_level_destroy(pa_level*);
 int       pa_level_nboxes(const pa_level*);
 

@@ -35,6 +35,18 @@ class PaCurvParams(C.Structure):
                 ("spacedim", C.c_int32)]
 
 
+class PaXfer(C.Structure):
+    _fields_ = [("peer", C.c_int32), ("sendbuf", C.c_void_p), ("nsend", C.c_int64), ("recvbuf", C.c_void_p), ("nrecv", C.c_int64)]
+
+
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(PaXfer))
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int32, C.c_int32)
+
+
+class PaComm(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("rank", C.c_int32), ("nranks", C.c_int32), ("exchange", EXCHANGE_FN), ("allreduce", ALLREDUCE_FN)]
+
+
 class PaSdfGrid(C.Structure):
     _fields_ = [("ntri", C.c_int64), ("tri", C.c_void_p), ("nvert", C.c_int64), ("x", C.c_void_p), ("origin", C.c_float * 3), ("dx", C.c_float),
                 ("n", C.c_int32 * 3), ("phi", C.c_void_p)]
@@ -68,10 +80,18 @@ def load_library() -> C.CDLL:
         "pa_profile_enable": (C.c_int, [vp, C.c_int]),
         "pa_profile_read": (C.c_int, [vp, C.c_int, C.POINTER(i64), pdbl, C.c_int]),
         "pa_level_create": (vp, [vp, C.c_int, pi32, pi32, pi32, pi32, pdbl, pdbl]),
-        "pa_level_create_dist": (vp, [vp, C.c_int, pi32, C.c_int, pi32, pi32, pi32, pi32, pdbl, pdbl]),
-        "pa_regions_size": (i64, [C.c_int, C.c_int, pi32]),
-        "pa_pack_regions": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, pi32, vp]),
-        "pa_unpack_regions": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, pi32, vp]),
+        "pa_level_create_sharded": (vp, [vp, C.c_int, pi32, pi32, C.c_int, C.c_int, pi32, pi32, pi32, pdbl, pdbl]),
+        "pa_level_global_ids": (C.c_int, [vp, pi32]),
+        "pa_ctx_set_comm": (C.c_int, [vp, C.POINTER(PaComm)]),
+        "pa_rccl_unique_id": (C.c_int, [vp, vp]),
+        "pa_ctx_init_rccl": (C.c_int, [vp, C.c_int, C.c_int, vp]),
+        "pa_ctx_nranks": (C.c_int, [vp]),
+        "pa_comm_selftest": (C.c_int, [vp, i64]),
+        "pa_allreduce": (C.c_int, [vp, pdbl, C.c_int, C.c_int]),
+        "pa_distribution_map": (C.c_int, [C.c_int, pi32, C.c_int, pi32]),
+        "pa_plan_fill_boundary": (i64, [C.c_int, pi32, pi32, C.c_int, pi32, pi32, pi32, C.c_int, pi32, i64]),
+        "pa_plan_coarse_source": (i64, [C.c_int, pi32, pi32, pi32, pi32, C.c_int, pi32, pi32, pi32, pi32, pi32, C.c_int, C.c_int, C.c_int, C.c_int, pi32,
+                                        i64]),
         "pa_level_destroy": (None, [vp]),
         "pa_level_nboxes": (C.c_int, [vp]),
         "pa_mf_layout": (i64, [C.c_int, pi32, C.c_int, C.c_int, C.POINTER(i64), C.POINTER(i64)]),
@@ -190,6 +210,30 @@ class Context:
     def bc_errors(self) -> int:
         return int(self.lib.pa_bc_errors(self.h))
 
+    # ---- multi-GPU transports (include/peleanalysis_amd.h: pa_comm)
+    def set_comm(self, comm: "PaComm"):
+        """caller-supplied transport; the structure (and its callbacks) must outlive the context"""
+        self._comm = comm
+        self.check(self.lib.pa_ctx_set_comm(self.h, C.byref(comm) if comm is not None else None))
+
+    def rccl_unique_id(self) -> bytes:
+        buf = C.create_string_buffer(128)
+        self.check(self.lib.pa_rccl_unique_id(self.h, buf))
+        return buf.raw
+
+    def init_rccl(self, nranks: int, rank: int, unique_id: bytes):
+        """built-in transport: grouped ncclSend / ncclRecv on the context's stream (RCCL over xGMI)"""
+        assert len(unique_id) == 128
+        self.check(self.lib.pa_ctx_init_rccl(self.h, int(nranks), int(rank), C.create_string_buffer(unique_id, 128)))
+
+    def comm_selftest(self, n: int = 4096):
+        self.check(self.lib.pa_comm_selftest(self.h, int(n)))
+
+    def allreduce(self, vals, op: int):
+        a = np.ascontiguousarray(vals, dtype=np.float64).copy()
+        self.check(self.lib.pa_allreduce(self.h, a.ctypes.data_as(C.POINTER(C.c_double)), a.size, int(op)))
+        return a
+
     def close(self):
         if self.h:
             self.lib.pa_ctx_destroy(self.h)
@@ -227,18 +271,24 @@ class DevBuf:
 
 
 class DevLevel:
-    def __init__(self, ctx: Context, level: Level, remote_boxes: Optional[np.ndarray] = None):
-        """level: the boxes this rank owns; remote_boxes: (m,6) boxes of the same level owned by other ranks"""
-        self.ctx, self.level = ctx, level
+    def __init__(self, ctx: Context, level: Level, owner: Optional[Sequence[int]] = None, rank: int = 0, nranks: int = 1):
+        """level: the whole BoxArray of the AMR level.  owner (one rank per box) + rank + nranks: this context holds only the
+        boxes with owner == rank (pa_level_create_sharded); self.level then describes those boxes, self.gids their indices
+        in the BoxArray, self.glob the whole level."""
+        self.ctx, self.glob = ctx, level
         b = np.ascontiguousarray(level.boxes, dtype=np.int32)
-        if remote_boxes is None or len(remote_boxes) == 0:
+        if owner is None:
+            self.level, self.gids = level, np.arange(level.nboxes)
             self.h = ctx.lib.pa_level_create(ctx.h, level.nboxes, b.ctypes.data_as(C.POINTER(C.c_int32)), _i3(level.domlo), _i3(level.domhi),
                                              _i3(level.is_per), _d3(level.prob_lo), _d3(level.prob_hi))
         else:
-            r = np.ascontiguousarray(remote_boxes, dtype=np.int32)
-            self.h = ctx.lib.pa_level_create_dist(ctx.h, level.nboxes, b.ctypes.data_as(C.POINTER(C.c_int32)), len(r),
-                                                  r.ctypes.data_as(C.POINTER(C.c_int32)), _i3(level.domlo), _i3(level.domhi), _i3(level.is_per),
-                                                  _d3(level.prob_lo), _d3(level.prob_hi))
+            o = np.ascontiguousarray(owner, dtype=np.int32)
+            assert len(o) == level.nboxes
+            self.gids = np.nonzero(o == rank)[0]
+            self.level = Level(level.boxes[self.gids], level.domlo, level.domhi, level.is_per, level.prob_lo, level.prob_hi)
+            self.h = ctx.lib.pa_level_create_sharded(ctx.h, level.nboxes, b.ctypes.data_as(C.POINTER(C.c_int32)), o.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                     int(rank), int(nranks), _i3(level.domlo), _i3(level.domhi), _i3(level.is_per),
+                                                     _d3(level.prob_lo), _d3(level.prob_hi))
         if not self.h:
             raise PaError(ctx.lib.pa_last_error(ctx.h).decode())
 

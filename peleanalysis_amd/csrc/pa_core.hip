@@ -2,7 +2,9 @@
 // gfx950 only.  Replaces the AMReX pieces the reference tools lean on for this path:
 // MultiFab storage, FabArray::FillBoundary and MLCellLinOp::applyBC.
 #include "pa_internal.h"
+#include "pa_dist.h"
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <numeric>
 
@@ -36,6 +38,7 @@ extern "C" pa_ctx* pa_ctx_create(int device, void* hip_stream) {
 extern "C" void pa_ctx_destroy(pa_ctx* ctx) {
   PaBind bind_(ctx);
   if (!ctx) return;
+  pa_rccl_destroy(ctx);
   if (ctx->d_red) (void)hipFree(ctx->d_red);
   if (ctx->d_flags) (void)hipFree(ctx->d_flags);
   if (ctx->d_scr) (void)hipFree(ctx->d_scr);
@@ -106,8 +109,24 @@ static int host_classify(const pa_level* L, int i, int j, int k) {
     if (m[d] >= L->mn[d]) return 1;
   }
   const int o = L->owner[((size_t)m[2] * L->mn[1] + m[1]) * L->mn[0] + m[0]];
-  return (o >= 0 || o == -2) ? 0 : 1;  // -2: valid cell of a box owned by another rank
+  return (o != -1) ? 0 : 1;  // <= -2: valid cell of a box owned by another rank
 }
+
+// true if face (d, side) of box B (any box of the level, local or not) has a ghost cell that is not a valid cell of the
+// level.  The class of a ghost cell is constant over a g-block of the owner map in the tangential directions, so one
+// probe per block is enough.
+bool pa_face_is_special(const pa_level* L, const DBox& B, int d, int side) {
+  const int t0 = (d == 0) ? 1 : 0, t1 = (d == 2) ? 1 : 2;
+  int q[3];
+  q[d] = side ? B.hi[d] + 1 : B.lo[d] - 1;
+  for (int v = B.lo[t1]; v <= B.hi[t1]; v += L->g)
+    for (int u = B.lo[t0]; u <= B.hi[t0]; u += L->g) {
+      q[t0] = u; q[t1] = v;
+      if (host_classify(L, q[0], q[1], q[2]) != 0) return true;
+    }
+  return false;
+}
+int pa_host_classify(const pa_level* L, int i, int j, int k) { return host_classify(L, i, j, k); }
 
 // cf_masks of every ghost cell of every special face (once per level; ratio 2)
 __global__ __launch_bounds__(256) void k_build_sfcode(DLevelView L, unsigned short* code) {
@@ -118,36 +137,79 @@ __global__ __launch_bounds__(256) void k_build_sfcode(DLevelView L, unsigned sho
   code[L.sfoff[blockIdx.y] + t] = (unsigned short)cf_masks(L, q, dir, 2);
 }
 
-static pa_level* level_create_impl(pa_ctx* ctx, int nboxes, const int32_t* b6, int nremote, const int32_t* r6, const int32_t domlo[3],
-                                   const int32_t domhi[3], const int32_t is_per[3], const double prob_lo[3], const double prob_hi[3]);
+// Everything a level is made from.  Unsharded: gboxes empty, every box local.  Sharded: `local` are the global boxes
+// owned by `rank` (global order, gid = their global indices), the other global boxes only mark their cells as valid
+// cells of the level (owner-map entry -2 - g).
+pa_level* pa_level_create_spec(pa_ctx* ctx, const LevelSpec& S, const int32_t domlo[3], const int32_t domhi[3], const int32_t is_per[3],
+                               const double prob_lo[3], const double prob_hi[3]);
+
+static bool read_boxes(pa_ctx* ctx, int n, const int32_t* b6, const int32_t domlo[3], const int32_t domhi[3], std::vector<DBox>& out, const char* who) {
+  out.resize(n);
+  for (int b = 0; b < n; ++b)
+    for (int d = 0; d < 3; ++d) {
+      out[b].lo[d] = b6[6 * b + d];
+      out[b].hi[d] = b6[6 * b + 3 + d];
+      if (out[b].hi[d] < out[b].lo[d] || out[b].lo[d] < domlo[d] || out[b].hi[d] > domhi[d]) {
+        pa_fail(ctx, std::string(who) + ": box " + std::to_string(b) + " is empty or outside the domain");
+        return false;
+      }
+    }
+  return true;
+}
 
 extern "C" pa_level* pa_level_create(pa_ctx* ctx, int nboxes, const int32_t* b6, const int32_t domlo[3],
                                      const int32_t domhi[3], const int32_t is_per[3], const double prob_lo[3],
                                      const double prob_hi[3]) {
   PaBind bind_(ctx);
-  return level_create_impl(ctx, nboxes, b6, 0, nullptr, domlo, domhi, is_per, prob_lo, prob_hi);
-}
-
-// One rank's share of a level: `boxes` are the FABs this rank owns, `remote` the boxes of the same
-// level owned by other ranks.  Remote boxes only mark their cells as valid cells of the level (so
-// that ghost cells they cover are neither treated as coarse-fine nor filled locally): their data
-// arrive through pa_pack_regions / pa_unpack_regions and the caller's exchange (RCCL).
-extern "C" pa_level* pa_level_create_dist(pa_ctx* ctx, int nboxes, const int32_t* b6, int nremote, const int32_t* r6, const int32_t domlo[3],
-                                          const int32_t domhi[3], const int32_t is_per[3], const double prob_lo[3],
-                                          const double prob_hi[3]) {
-  PaBind bind_(ctx);
-  if (nremote < 0 || (nremote > 0 && !r6)) { pa_fail(ctx, "pa_level_create_dist: bad remote box list"); return nullptr; }
-  return level_create_impl(ctx, nboxes, b6, nremote, r6, domlo, domhi, is_per, prob_lo, prob_hi);
-}
-
-static pa_level* level_create_impl(pa_ctx* ctx, int nboxes, const int32_t* b6, int nremote, const int32_t* r6, const int32_t domlo[3],
-                                   const int32_t domhi[3], const int32_t is_per[3], const double prob_lo[3], const double prob_hi[3]) {
   if (!ctx) return nullptr;
   if (nboxes <= 0 || !b6) { pa_fail(ctx, "pa_level_create: empty BoxArray"); return nullptr; }
+  LevelSpec S;
+  if (!read_boxes(ctx, nboxes, b6, domlo, domhi, S.local, "pa_level_create")) return nullptr;
+  return pa_level_create_spec(ctx, S, domlo, domhi, is_per, prob_lo, prob_hi);
+}
+
+// One rank's share of a level (replaces DistributionMapping(ba), grad.cpp:162 / curvature.cpp:289): the whole BoxArray,
+// the owner rank of every box, and which rank this context is.  A rank may own no box of a level.
+extern "C" pa_level* pa_level_create_sharded(pa_ctx* ctx, int nboxes, const int32_t* b6, const int32_t* owner, int rank, int nranks,
+                                             const int32_t domlo[3], const int32_t domhi[3], const int32_t is_per[3], const double prob_lo[3],
+                                             const double prob_hi[3]) {
+  PaBind bind_(ctx);
+  if (!ctx) return nullptr;
+  if (nboxes <= 0 || !b6 || !owner) { pa_fail(ctx, "pa_level_create_sharded: empty BoxArray"); return nullptr; }
+  if (nranks < 1 || rank < 0 || rank >= nranks) { pa_fail(ctx, "pa_level_create_sharded: bad rank / nranks"); return nullptr; }
+  LevelSpec S;
+  S.rank = rank; S.nranks = nranks;
+  if (!read_boxes(ctx, nboxes, b6, domlo, domhi, S.gboxes, "pa_level_create_sharded")) return nullptr;
+  S.gowner.assign(owner, owner + nboxes);
+  for (int g = 0; g < nboxes; ++g) {
+    if (owner[g] < 0 || owner[g] >= nranks) { pa_fail(ctx, "pa_level_create_sharded: owner of box " + std::to_string(g) + " out of range"); return nullptr; }
+    if (owner[g] == rank) { S.local.push_back(S.gboxes[g]); S.gid.push_back(g); }
+  }
+  return pa_level_create_spec(ctx, S, domlo, domhi, is_per, prob_lo, prob_hi);
+}
+
+static std::atomic<long long> g_level_serial{0};
+
+pa_level* pa_level_create_spec(pa_ctx* ctx, const LevelSpec& S, const int32_t domlo[3], const int32_t domhi[3], const int32_t is_per[3],
+                               const double prob_lo[3], const double prob_hi[3]) {
+  if (!ctx) return nullptr;
+  const int nboxes = (int)S.local.size();
   pa_level* L = new pa_level();
-  L->nremote = nremote;
+  L->serial = ++g_level_serial;
   L->ctx = ctx;
-  L->boxes.resize(nboxes);
+  L->boxes = S.local;
+  L->rank = S.rank; L->nranks = S.nranks;
+  L->gboxes = S.gboxes; L->gowner = S.gowner; L->gid = S.gid;
+  L->source_only = S.source_only;
+  L->glocal.assign(S.gboxes.size(), -1);
+  for (size_t b = 0; b < S.gid.size(); ++b) L->glocal[S.gid[b]] = (int)b;
+  // boxes of the level owned by other ranks
+  std::vector<DBox> remote;
+  std::vector<int> remote_gid;
+  for (size_t g = 0; g < S.gboxes.size(); ++g)
+    if (S.gowner[g] != S.rank) { remote.push_back(S.gboxes[g]); remote_gid.push_back((int)g); }
+  const int nremote = (int)remote.size();
+  L->nremote = nremote;
   for (int d = 0; d < 3; ++d) {
     L->domlo[d] = domlo[d]; L->domhi[d] = domhi[d]; L->is_per[d] = is_per[d] ? 1 : 0;
     L->prob_lo[d] = prob_lo[d]; L->prob_hi[d] = prob_hi[d];
@@ -157,35 +219,15 @@ static pa_level* level_create_impl(pa_ctx* ctx, int nboxes, const int32_t* b6, i
     L->mlo[d] = INT32_MAX;
   }
   int mhi[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
-  for (int b = 0; b < nboxes; ++b) {
+  for (int b = 0; b < nboxes + nremote; ++b) {
+    const DBox& B = b < nboxes ? L->boxes[b] : remote[b - nboxes];
     for (int d = 0; d < 3; ++d) {
-      L->boxes[b].lo[d] = b6[6 * b + d];
-      L->boxes[b].hi[d] = b6[6 * b + 3 + d];
-      if (L->boxes[b].hi[d] < L->boxes[b].lo[d] || L->boxes[b].lo[d] < domlo[d] || L->boxes[b].hi[d] > domhi[d]) {
-        pa_fail(ctx, "pa_level_create: box " + std::to_string(b) + " is empty or outside the domain");
-        delete L;
-        return nullptr;
-      }
-      L->mlo[d] = std::min(L->mlo[d], L->boxes[b].lo[d]);
-      mhi[d] = std::max(mhi[d], L->boxes[b].hi[d]);
-      L->maxn[d] = std::max(L->maxn[d], L->boxes[b].hi[d] - L->boxes[b].lo[d] + 1);
+      L->mlo[d] = std::min(L->mlo[d], B.lo[d]);
+      mhi[d] = std::max(mhi[d], B.hi[d]);
+      if (b < nboxes) L->maxn[d] = std::max(L->maxn[d], B.hi[d] - B.lo[d] + 1);
     }
-    L->ncells += (long long)(L->boxes[b].hi[0] - L->boxes[b].lo[0] + 1) * (L->boxes[b].hi[1] - L->boxes[b].lo[1] + 1) *
-                 (L->boxes[b].hi[2] - L->boxes[b].lo[2] + 1);
+    if (b < nboxes) L->ncells += (long long)(B.hi[0] - B.lo[0] + 1) * (B.hi[1] - B.lo[1] + 1) * (B.hi[2] - B.lo[2] + 1);
   }
-  std::vector<DBox> remote(nremote);
-  for (int b = 0; b < nremote; ++b)
-    for (int d = 0; d < 3; ++d) {
-      remote[b].lo[d] = r6[6 * b + d];
-      remote[b].hi[d] = r6[6 * b + 3 + d];
-      if (remote[b].hi[d] < remote[b].lo[d] || remote[b].lo[d] < domlo[d] || remote[b].hi[d] > domhi[d]) {
-        pa_fail(ctx, "pa_level_create_dist: remote box " + std::to_string(b) + " is empty or outside the domain");
-        delete L;
-        return nullptr;
-      }
-      L->mlo[d] = std::min(L->mlo[d], remote[b].lo[d]);
-      mhi[d] = std::max(mhi[d], remote[b].hi[d]);
-    }
   // owner-map granularity
   int g = 0;
   for (int b = 0; b < nboxes + nremote; ++b) {
@@ -219,15 +261,17 @@ static pa_level* level_create_impl(pa_ctx* ctx, int nboxes, const int32_t* b6, i
             delete L;
             return nullptr;
           }
-          o = b < nboxes ? b : -2;
+          o = b < nboxes ? b : -2 - remote_gid[b - nboxes];
         }
   }
   // Fused grad->curvature legality: an edge ghost cell that is NOT a valid cell while both
   // of its face-ring neighbours towards the box ARE valid cells (concave coarse-fine corner)
-  // would need two different boundary values in one FAB slot.
+  // would need two different boundary values in one FAB slot.  A property of the whole BoxArray:
+  // every rank of a sharded level must take the same path (the paths exchange different data).
   L->fusable = true;
-  for (int b = 0; b < nboxes && L->fusable; ++b) {
-    const DBox& B = L->boxes[b];
+  const int nfus = S.source_only ? 0 : (S.gboxes.empty() ? nboxes : (int)S.gboxes.size());
+  for (int b = 0; b < nfus && L->fusable; ++b) {
+    const DBox& B = S.gboxes.empty() ? L->boxes[b] : S.gboxes[b];
     for (int a = 0; a < 3 && L->fusable; ++a)
       for (int c = a + 1; c < 3 && L->fusable; ++c) {
         const int e = 3 - a - c;
@@ -250,25 +294,11 @@ static pa_level* level_create_impl(pa_ctx* ctx, int nboxes, const int32_t* b6, i
       }
   }
   // Special faces: box faces with at least one adjacent ghost cell that is not a valid cell of the
-  // level (coarse-fine or wall).  The class of a ghost cell is constant over a g-block of the owner
-  // map in the tangential directions, so one probe per block is enough.
-  for (int b = 0; b < nboxes; ++b) {
-    const DBox& B = L->boxes[b];
-    for (int d = 0; d < 3; ++d) {
-      const int t0 = (d == 0) ? 1 : 0, t1 = (d == 2) ? 1 : 2;
-      for (int side = 0; side < 2; ++side) {
-        bool special = false;
-        int q[3];
-        q[d] = side ? B.hi[d] + 1 : B.lo[d] - 1;
-        for (int v = B.lo[t1]; v <= B.hi[t1] && !special; v += g)
-          for (int u = B.lo[t0]; u <= B.hi[t0]; u += g) {
-            q[t0] = u; q[t1] = v;
-            if (host_classify(L, q[0], q[1], q[2]) != 0) { special = true; break; }
-          }
-        if (special) L->sfaces.push_back(b * 6 + d * 2 + side);
-      }
-    }
-  }
+  // level (coarse-fine or wall).
+  for (int b = 0; b < nboxes && !S.source_only; ++b)
+    for (int d = 0; d < 3; ++d)
+      for (int side = 0; side < 2; ++side)
+        if (pa_face_is_special(L, L->boxes[b], d, side)) L->sfaces.push_back(b * 6 + d * 2 + side);
   const size_t nsf_alloc = std::max<size_t>(L->sfaces.size(), 1);
   std::vector<int> sfindex((size_t)nboxes * 6, -1);
   std::vector<long long> sfoff(nsf_alloc, 0);
@@ -281,16 +311,16 @@ static pa_level* level_create_impl(pa_ctx* ctx, int nboxes, const int32_t* b6, i
     sfoff[e] = ncode;
     ncode += (long long)(B.hi[t0] - B.lo[t0] + 1) * (B.hi[t1] - B.lo[t1] + 1);
   }
-  if (hipMalloc(&L->d_boxes, sizeof(DBox) * nboxes) != hipSuccess ||
+  if (hipMalloc(&L->d_boxes, sizeof(DBox) * std::max(nboxes, 1)) != hipSuccess ||
       hipMalloc(&L->d_sfaces, sizeof(int) * nsf_alloc) != hipSuccess ||
       (!L->sfaces.empty() && hipMemcpy(L->d_sfaces, L->sfaces.data(), sizeof(int) * L->sfaces.size(), hipMemcpyHostToDevice) != hipSuccess) ||
-      hipMalloc(&L->d_sfindex, sizeof(int) * sfindex.size()) != hipSuccess ||
-      hipMemcpy(L->d_sfindex, sfindex.data(), sizeof(int) * sfindex.size(), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMalloc(&L->d_sfindex, sizeof(int) * std::max<size_t>(sfindex.size(), 1)) != hipSuccess ||
+      (!sfindex.empty() && hipMemcpy(L->d_sfindex, sfindex.data(), sizeof(int) * sfindex.size(), hipMemcpyHostToDevice) != hipSuccess) ||
       hipMalloc(&L->d_sfoff, sizeof(long long) * nsf_alloc) != hipSuccess ||
       hipMemcpy(L->d_sfoff, sfoff.data(), sizeof(long long) * nsf_alloc, hipMemcpyHostToDevice) != hipSuccess ||
       hipMalloc(&L->d_sfcode, sizeof(unsigned short) * std::max<long long>(ncode, 1)) != hipSuccess ||
       hipMalloc(&L->d_owner, sizeof(int) * msz) != hipSuccess ||
-      hipMemcpy(L->d_boxes, L->boxes.data(), sizeof(DBox) * nboxes, hipMemcpyHostToDevice) != hipSuccess ||
+      (nboxes > 0 && hipMemcpy(L->d_boxes, L->boxes.data(), sizeof(DBox) * nboxes, hipMemcpyHostToDevice) != hipSuccess) ||
       hipMemcpy(L->d_owner, L->owner.data(), sizeof(int) * msz, hipMemcpyHostToDevice) != hipSuccess) {
     pa_fail(ctx, "pa_level_create: device allocation failed");
     if (L->d_boxes) (void)hipFree(L->d_boxes);
@@ -369,8 +399,8 @@ extern "C" pa_mf* pa_mf_create(pa_ctx* ctx, const pa_level* L, int ncomp, int ng
   std::vector<int64_t> off(nb);
   M->total = pa_mf_layout(nb, b6.data(), ncomp, ng, off.data(), nullptr);
   M->off.assign(off.begin(), off.end());
-  if (hipMalloc(&M->d_off, sizeof(long long) * nb) != hipSuccess ||
-      hipMemcpy(M->d_off, M->off.data(), sizeof(long long) * nb, hipMemcpyHostToDevice) != hipSuccess) {
+  if (hipMalloc(&M->d_off, sizeof(long long) * std::max(nb, 1)) != hipSuccess ||
+      (nb > 0 && hipMemcpy(M->d_off, M->off.data(), sizeof(long long) * nb, hipMemcpyHostToDevice) != hipSuccess)) {
     pa_fail(ctx, "pa_mf_create: device allocation failed");
     delete M;
     return nullptr;
@@ -378,7 +408,7 @@ extern "C" pa_mf* pa_mf_create(pa_ctx* ctx, const pa_level* L, int ncomp, int ng
   if (devptr) {
     M->data = devptr;
   } else {
-    if (hipMalloc(&M->data, sizeof(double) * (size_t)M->total) != hipSuccess ||
+    if (hipMalloc(&M->data, sizeof(double) * (size_t)std::max<long long>(M->total, 1)) != hipSuccess ||
         hipMemsetAsync(M->data, 0, sizeof(double) * (size_t)M->total, ctx->stream) != hipSuccess) {
       pa_fail(ctx, "pa_mf_create: out of device memory (" + std::to_string(M->total * 8) + " bytes)");
       (void)hipFree(M->d_off);
@@ -434,6 +464,7 @@ extern "C" int pa_mf_setval(pa_ctx* ctx, pa_mf* M, int comp, int ncomp, double v
   PaBind bind_(ctx);
   if (!ctx || !M) return pa_fail(ctx, "pa_mf_setval: null argument");
   if (comp < 0 || comp + ncomp > M->ncomp) return pa_fail(ctx, "pa_mf_setval: component range");
+  if (M->lev->boxes.empty()) return 0;  // a rank that owns no box of this level
   dim3 grid(64, (unsigned)M->lev->boxes.size());
   hipLaunchKernelGGL(k_setval_comp, grid, dim3(256), 0, ctx->stream, M->lev->view, M->view, comp, ncomp, v);
   PA_HIP(hipGetLastError());
@@ -461,6 +492,7 @@ extern "C" int pa_mf_copy(pa_ctx* ctx, const pa_mf* S, int scomp, pa_mf* D, int 
   if (S->lev != D->lev) return pa_fail(ctx, "pa_mf_copy: different levels");
   if (ng > S->ng || ng > D->ng || scomp + ncomp > S->ncomp || dcomp + ncomp > D->ncomp)
     return pa_fail(ctx, "pa_mf_copy: ng/component range");
+  if (S->lev->boxes.empty()) return 0;  // a rank that owns no box of this level
   dim3 grid(128, (unsigned)S->lev->boxes.size());
   hipLaunchKernelGGL(k_copy, grid, dim3(256), 0, ctx->stream, S->lev->view, S->view, scomp, D->view, dcomp, ncomp, ng);
   PA_HIP(hipGetLastError());
@@ -538,20 +570,33 @@ static long long max_shell(const pa_level* L, int ng) {
   return m;
 }
 
-extern "C" int pa_fill_boundary(pa_ctx* ctx, pa_mf* M, int comp, int ncomp, int ng) {
-  PaBind bind_(ctx);
+// no_exchange: only the local half (the caller batches the cross-rank half of several levels into one exchange)
+int pa_fill_boundary_impl(pa_ctx* ctx, pa_mf* M, int comp, int ncomp, int ng, int no_exchange) {
   if (!ctx || !M) return pa_fail(ctx, "pa_fill_boundary: null argument");
   if (ng > M->ng || ng < 0 || comp < 0 || comp + ncomp > M->ncomp) return pa_fail(ctx, "pa_fill_boundary: ng/component range");
   if (ng == 0) return 0;
   for (int d = 0; d < 3; ++d)
     if (M->lev->is_per[d] && ng > M->lev->domhi[d] - M->lev->domlo[d] + 1)
       return pa_fail(ctx, "pa_fill_boundary: ng larger than the periodic domain");
-  const long long ms = max_shell(M->lev, ng);
-  dim3 grid((unsigned)((ms + 255) / 256), (unsigned)M->lev->boxes.size());
   ProfScope prof(ctx, PA_TAG_FILL);
-  hipLaunchKernelGGL(k_fill_boundary, grid, dim3(256), 0, ctx->stream, M->lev->view, M->view, comp, ncomp, ng);
-  PA_HIP(hipGetLastError());
+  if (!M->lev->boxes.empty()) {
+    const long long ms = max_shell(M->lev, ng);
+    dim3 grid((unsigned)((ms + 255) / 256), (unsigned)M->lev->boxes.size());
+    hipLaunchKernelGGL(k_fill_boundary, grid, dim3(256), 0, ctx->stream, M->lev->view, M->view, comp, ncomp, ng);
+    PA_HIP(hipGetLastError());
+  }
+  // ghost cells covered by boxes of other ranks: the cross-rank half (pack -> grouped send/recv -> unpack)
+  if (M->lev->nranks > 1 && !no_exchange) {
+    XPlan* P = pa_fb_plan(ctx, M->lev, ng);
+    if (!P) return 1;
+    XJob J = {P, M, comp, M, comp, ncomp};
+    if (pa_xexchange(ctx, 1, &J)) return 1;
+  }
   return 0;
+}
+extern "C" int pa_fill_boundary(pa_ctx* ctx, pa_mf* M, int comp, int ncomp, int ng) {
+  PaBind bind_(ctx);
+  return pa_fill_boundary_impl(ctx, M, comp, ncomp, ng, 0);
 }
 
 // --------------------------------------------------------------------- applyBC
@@ -715,10 +760,14 @@ int pa_apply_bc_impl(pa_ctx* ctx, pa_mf* F, int comp, const pa_mf* C, int ccomp,
   if (comp < 0 || comp >= F->ncomp || (C && (ccomp < 0 || ccomp >= C->ncomp))) return pa_fail(ctx, "pa_apply_bc: component range");
   if (ratio != 2 && C) return pa_fail(ctx, "pa_apply_bc: only refinement ratio 2 is supported (quirk Q11)");
   int* nbad = ctx->d_flags;
+  const pa_level* L = F->lev;
+  // sharded coarse level: this rank's coarse-source copy, refilled here (callers that batch the refill of several
+  // levels pass the coarse-source multifab itself).  Null afterwards: no coarse-fine ghost cell on this rank.
+  if (C && pa_coarse_source(ctx, L, C, ccomp, 1, 0, 0, 0, &C, &ccomp)) return 1;
   BCArgs A;
   for (int d = 0; d < 3; ++d) A.bc[d] = bc[d];
   A.ratio = ratio; A.only_dir = only_dir; A.has_crse = C ? 1 : 0; A.edges = edges;
-  const pa_level* L = F->lev;
+  if (L->boxes.empty()) return 0;
   DLevelView LC = C ? C->lev->view : L->view;
   DMFView MC = C ? C->view : F->view;
   MC.xform = 0;
@@ -752,6 +801,7 @@ int pa_apply_bc_dual(pa_ctx* ctx, pa_mf* F0, int comp0, pa_mf* F1, int comp1, co
     return pa_fail(ctx, "pa_apply_bc: component range");
   if (ratio != 2 && C) return pa_fail(ctx, "pa_apply_bc: only refinement ratio 2 is supported (quirk Q11)");
   const pa_level* L = F0->lev;
+  if (C && pa_coarse_source(ctx, L, C, ccomp, 1, 0, 0, 0, &C, &ccomp)) return 1;
   if (L->sfaces.empty()) return 0;
   BCArgs A;
   for (int d = 0; d < 3; ++d) A.bc[d] = bc[d];
@@ -807,6 +857,7 @@ extern "C" int pa_progress_shell_level(pa_ctx* ctx, const pa_mf* s, int comp, do
       if (B.hi[d] - B.lo[d] + 1 <= 2 * depth)  // no interior core left: the shell is the whole box
         return pa_progress_level(ctx, s, comp, pmin, pmax, c, ccomp, ng);
   if (L->sfaces.empty()) return 0;
+  if (s->lev->boxes.empty()) return 0;  // a rank that owns no box of this level
   const long long g0 = L->maxn[0] + 2 * ng, g1 = L->maxn[1] + 2 * ng, g2 = L->maxn[2] + 2 * ng;
   const long long ms = (long long)(ng + depth) * std::max(g1 * g2, std::max(g0 * g2, g0 * g1));
   dim3 grid((unsigned)((ms + 255) / 256), (unsigned)L->sfaces.size());
@@ -843,78 +894,3 @@ extern "C" int pa_memcpy_d2h(pa_ctx* ctx, void* dst, const void* src, int64_t by
   return 0;
 }
 
-// ------------------------------------------------------------------ ghost exchange between ranks
-// Regions are [local box, lo0,lo1,lo2, hi0,hi1,hi2] in that box's index space (ghost cells allowed).
-// The buffer is the concatenation of the regions in list order, each laid out [comp][k][j][i].
-__global__ void k_regions(DLevelView L, DMFView M, int comp, int ncomp, int nreg, const int* regs, const long long* roff, double* buf, int unpack) {
-  const int r = blockIdx.y;
-  if (r >= nreg) return;
-  const int* R = regs + 7 * r;
-  const int b = R[0];
-  const int nx = R[4] - R[1] + 1, ny = R[5] - R[2] + 1, nz = R[6] - R[3] + 1;
-  const long long n = (long long)nx * ny * nz * ncomp;
-  const DBox B = L.boxes[b];
-  double* f = M.data + M.off[b];
-  double* q = buf + roff[r];
-  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
-    const int i = (int)(t % nx), j = (int)((t / nx) % ny), k = (int)((t / ((long long)nx * ny)) % nz), c = (int)(t / ((long long)nx * ny * nz));
-    const long long idx = fab_index(B, M.ng, M.ncomp, comp + c, R[1] + i, R[2] + j, R[3] + k);
-    if (unpack) f[idx] = q[t];
-    else q[t] = f[idx];
-  }
-}
-
-static int regions_impl(pa_ctx* ctx, pa_mf* M, int comp, int ncomp, int nreg, const int32_t* regs, double* devbuf, int unpack) {
-  if (!ctx || !M) return pa_fail(ctx, "pa_pack_regions: null argument");
-  if (nreg == 0) return 0;
-  if (!regs || !devbuf) return pa_fail(ctx, "pa_pack_regions: null region list / buffer");
-  if (comp < 0 || ncomp < 1 || comp + ncomp > M->ncomp) return pa_fail(ctx, "pa_pack_regions: component range");
-  const pa_level* L = M->lev;
-  std::vector<long long> roff(nreg);
-  long long tot = 0, maxn = 0;
-  for (int r = 0; r < nreg; ++r) {
-    const int32_t* R = regs + 7 * r;
-    if (R[0] < 0 || R[0] >= (int)L->boxes.size()) return pa_fail(ctx, "pa_pack_regions: region " + std::to_string(r) + ": bad box index");
-    long long n = ncomp;
-    for (int d = 0; d < 3; ++d) {
-      const DBox& B = L->boxes[R[0]];
-      if (R[1 + d] > R[4 + d] || R[1 + d] < B.lo[d] - M->ng || R[4 + d] > B.hi[d] + M->ng)
-        return pa_fail(ctx, "pa_pack_regions: region " + std::to_string(r) + " lies outside its (grown) box");
-      n *= R[4 + d] - R[1 + d] + 1;
-    }
-    roff[r] = tot;
-    tot += n;
-    maxn = std::max(maxn, n);
-  }
-  // region table to the device (small; lives until the stream has consumed it)
-  const size_t bytes = sizeof(int) * 7 * (size_t)nreg + sizeof(long long) * (size_t)nreg;
-  if (pa_ensure_red(ctx, (bytes + 7) / 8 + 8)) return 1;
-  PA_HIP(hipStreamSynchronize(ctx->stream));  // the scratch may still be in use by an earlier call
-  long long* d_off = (long long*)ctx->d_red;
-  int* d_regs = (int*)(d_off + nreg);
-  PA_HIP(hipMemcpyAsync(d_off, roff.data(), sizeof(long long) * nreg, hipMemcpyHostToDevice, ctx->stream));
-  PA_HIP(hipMemcpyAsync(d_regs, regs, sizeof(int) * 7 * nreg, hipMemcpyHostToDevice, ctx->stream));
-  dim3 grid((unsigned)std::min<long long>((maxn + 255) / 256, 1024), (unsigned)nreg);
-  hipLaunchKernelGGL(k_regions, grid, dim3(256), 0, ctx->stream, L->view, M->view, comp, ncomp, nreg, d_regs, d_off, devbuf, unpack);
-  PA_HIP(hipGetLastError());
-  PA_HIP(hipStreamSynchronize(ctx->stream));  // the caller hands the buffer to RCCL next
-  return 0;
-}
-
-extern "C" int64_t pa_regions_size(int ncomp, int nreg, const int32_t* regs) {
-  int64_t tot = 0;
-  for (int r = 0; r < nreg; ++r) {
-    int64_t n = ncomp;
-    for (int d = 0; d < 3; ++d) n *= regs[7 * r + 4 + d] - regs[7 * r + 1 + d] + 1;
-    tot += n;
-  }
-  return tot;
-}
-extern "C" int pa_pack_regions(pa_ctx* ctx, const pa_mf* M, int comp, int ncomp, int nreg, const int32_t* regs, double* devbuf) {
-  PaBind bind_(ctx);
-  return regions_impl(ctx, const_cast<pa_mf*>(M), comp, ncomp, nreg, regs, devbuf, 0);
-}
-extern "C" int pa_unpack_regions(pa_ctx* ctx, pa_mf* M, int comp, int ncomp, int nreg, const int32_t* regs, const double* devbuf) {
-  PaBind bind_(ctx);
-  return regions_impl(ctx, M, comp, ncomp, nreg, regs, const_cast<double*>(devbuf), 1);
-}

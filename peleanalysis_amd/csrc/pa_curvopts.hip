@@ -115,6 +115,7 @@ int pa_gauss_curv_level(pa_ctx* ctx, const pa_mf* G, int gcomp, const pa_mf* nor
   if (!ctx || !G || !normgrad || !out || (thr >= 0.0 && !c)) return pa_fail(ctx, "pa_gauss_curv_level: null argument");
   if (G->ng < 1) return pa_fail(ctx, "pa_gauss_curv_level: G needs >= 1 ghost layer");
   if (G->lev != out->lev || G->lev != normgrad->lev) return pa_fail(ctx, "pa_gauss_curv_level: different levels");
+  if (G->lev->boxes.empty()) return 0;  // a rank that owns no box of this level
   BP3 bp{G->lev->view, G->view, out->view, c ? c->view : G->view};
   hipLaunchKernelGGL(k_gauss_curv, tile_grid(G->lev), dim3(256), 0, ctx->stream, bp, gcomp, normgrad->view, ngcomp, ccomp, thr, kcomp);
   PA_HIP(hipGetLastError());
@@ -125,6 +126,7 @@ int pa_strain_level(pa_ctx* ctx, const pa_mf* u, int ucomp, pa_mf* out, int srco
   if (!ctx || !u || !out) return pa_fail(ctx, "pa_strain_level: null argument");
   if (u->ng < 1 || u->lev != out->lev) return pa_fail(ctx, "pa_strain_level: velocity needs >= 1 ghost layer on the same level");
   if (ucomp < 0 || ucomp + 3 > u->ncomp || srcomp >= out->ncomp || (rostcomp >= 0 && rostcomp + 9 > out->ncomp)) return pa_fail(ctx, "pa_strain_level: component range");
+  if (u->lev->boxes.empty()) return 0;  // a rank that owns no box of this level
   LevelBP2 bp{u->lev->view, u->view, out->view};
   hipLaunchKernelGGL(k_strain, tile_grid(u->lev), dim3(256), 0, ctx->stream, bp, ucomp, srcomp, rostcomp);
   PA_HIP(hipGetLastError());
@@ -135,6 +137,7 @@ int pa_velnormal_level(pa_ctx* ctx, const pa_mf* u, int ucomp, const pa_mf* n, i
   if (!ctx || !u || !n || !out || (thr >= 0.0 && !c)) return pa_fail(ctx, "pa_velnormal_level: null argument");
   if (u->lev != out->lev || n->lev != out->lev) return pa_fail(ctx, "pa_velnormal_level: different levels");
   if (ucomp < 0 || ucomp + 3 > u->ncomp || ncomp0 + 3 > n->ncomp || ocomp >= out->ncomp) return pa_fail(ctx, "pa_velnormal_level: component range");
+  if (u->lev->boxes.empty()) return 0;  // a rank that owns no box of this level
   BP3 bp{u->lev->view, u->view, out->view, n->view};
   hipLaunchKernelGGL(k_velnormal, tile_grid(u->lev), dim3(256), 0, ctx->stream, bp, ucomp, ncomp0, ocomp, c ? c->view : u->view, ccomp, thr);
   PA_HIP(hipGetLastError());

@@ -1,0 +1,737 @@
+// pa_dist.hip -- one hierarchy sharded over ranks (one rank per GPU), gfx950.
+//
+// The reference distributes the boxes of every level with DistributionMapping(ba) (grad.cpp:162,
+// curvature.cpp:289, filterPlt.cpp:142, isosurface.cpp:1441) and lets AMReX move ghost data between MPI
+// ranks: FabArray::FillBoundary for same-level ghost cells, and a ParallelCopy of coarse data under the
+// fine level's boundary for every coarse->fine fill (MLMG boundary registers behind grad.cpp:212-213 and
+// curvature.cpp:443-445,514-518; FillPatchTwoLevels at filterPlt.cpp:193).  This file is the MI355X form
+// of both:
+//   * pa_distribution_map: Morton order + equal-volume cuts (what DistributionMapping's SFC strategy does);
+//   * FillBoundary plan: for every (destination box, source box, periodic shift) whose two boxes live on
+//     different ranks, both sides derive the same region, in the same order;
+//   * coarse-source plan: each rank keeps, per fine level, a small BoxArray of disjoint pieces of the coarse
+//     level -- exactly the coarse cells the stencils of its fine boxes touch -- and a multifab on it that is
+//     refilled from the coarse level's owners; the coarse-fine kernels read that multifab through the same
+//     owner-map lookup they use for a local coarse level (AMReX keeps a coarse BndryRegister the same way);
+//   * one exchange = one pack launch, ONE grouped point-to-point call for all plans and peers in it, one
+//     unpack launch per plan; nothing synchronises the host;
+//   * transports: RCCL over xGMI (grouped ncclSend/ncclRecv on the context's stream, loaded with dlopen so
+//     that the library also loads where RCCL is absent), or a caller-supplied pa_comm.
+#include "pa_internal.h"
+#include "pa_dist.h"
+#include <algorithm>
+#include <array>
+#include <cstring>
+#include <dlfcn.h>
+#include <numeric>
+
+#define PA_TRY(x)           \
+  do {                      \
+    if ((x) != 0) return 1; \
+  } while (0)
+
+// ------------------------------------------------------------------------------------ host geometry
+static inline bool bx_isect(const DBox& a, const DBox& b, DBox& r) {
+  for (int d = 0; d < 3; ++d) {
+    r.lo[d] = std::max(a.lo[d], b.lo[d]);
+    r.hi[d] = std::min(a.hi[d], b.hi[d]);
+    if (r.lo[d] > r.hi[d]) return false;
+  }
+  return true;
+}
+static inline long long bx_cells(const DBox& b) { return (long long)(b.hi[0] - b.lo[0] + 1) * (b.hi[1] - b.lo[1] + 1) * (b.hi[2] - b.lo[2] + 1); }
+static inline DBox bx_grow(DBox b, int n) {
+  for (int d = 0; d < 3; ++d) { b.lo[d] -= n; b.hi[d] += n; }
+  return b;
+}
+static inline DBox bx_shift(DBox b, const int s[3]) {
+  for (int d = 0; d < 3; ++d) { b.lo[d] += s[d]; b.hi[d] += s[d]; }
+  return b;
+}
+static inline int fl2(int i) { return i >> 1; }  // floor(i / 2)
+// a \ b appended to out as up to six disjoint boxes (z slabs, then y slabs of the middle, then x pieces)
+static void bx_diff(const DBox& a, const DBox& b, std::vector<DBox>& out) {
+  DBox I;
+  if (!bx_isect(a, b, I)) { out.push_back(a); return; }
+  DBox rest = a;
+  for (int d = 2; d >= 0; --d) {
+    if (rest.lo[d] < I.lo[d]) { DBox p = rest; p.hi[d] = I.lo[d] - 1; out.push_back(p); rest.lo[d] = I.lo[d]; }
+    if (rest.hi[d] > I.hi[d]) { DBox p = rest; p.lo[d] = I.hi[d] + 1; out.push_back(p); rest.hi[d] = I.hi[d]; }
+  }
+}
+
+// periodic shifts (in cells) of a domain, in one fixed order on every rank
+static std::vector<std::array<int, 3>> domain_shifts(const int domlo[3], const int domhi[3], const int is_per[3]) {
+  std::vector<std::array<int, 3>> sh;
+  const int n[3] = {is_per[0] ? 1 : 0, is_per[1] ? 1 : 0, is_per[2] ? 1 : 0};
+  for (int a = -n[0]; a <= n[0]; ++a)
+    for (int b = -n[1]; b <= n[1]; ++b)
+      for (int c = -n[2]; c <= n[2]; ++c)
+        sh.push_back({a * (domhi[0] - domlo[0] + 1), b * (domhi[1] - domlo[1] + 1), c * (domhi[2] - domlo[2] + 1)});
+  return sh;
+}
+
+// "is cell (i,j,k) a valid cell of the level" for a whole BoxArray (host; the owner map of pa_level_create restated
+// without a device): 0 valid (maybe through a periodic image), 1 inside the domain and not covered, 2 outside a wall
+struct HostGeom {
+  int domlo[3], domhi[3], is_per[3];
+  int g = 1, mlo[3], mn[3];
+  std::vector<int> owner;  // global box index or -1
+  HostGeom(const std::vector<DBox>& boxes, const int dl[3], const int dh[3], const int per[3]) {
+    int mhi[3];
+    for (int d = 0; d < 3; ++d) { domlo[d] = dl[d]; domhi[d] = dh[d]; is_per[d] = per[d] ? 1 : 0; mlo[d] = INT32_MAX; mhi[d] = INT32_MIN; }
+    for (const DBox& B : boxes)
+      for (int d = 0; d < 3; ++d) { mlo[d] = std::min(mlo[d], B.lo[d]); mhi[d] = std::max(mhi[d], B.hi[d]); }
+    int gg = 0;
+    for (const DBox& B : boxes)
+      for (int d = 0; d < 3; ++d) { gg = std::gcd(gg, B.lo[d] - mlo[d]); gg = std::gcd(gg, B.hi[d] - B.lo[d] + 1); }
+    g = gg > 0 ? gg : 1;
+    size_t msz = 1;
+    for (int d = 0; d < 3; ++d) { mn[d] = (mhi[d] - mlo[d] + 1) / g; msz *= (size_t)mn[d]; }
+    owner.assign(msz, -1);
+    for (size_t b = 0; b < boxes.size(); ++b) {
+      const DBox& B = boxes[b];
+      for (int kz = (B.lo[2] - mlo[2]) / g; kz <= (B.hi[2] - mlo[2]) / g; ++kz)
+        for (int ky = (B.lo[1] - mlo[1]) / g; ky <= (B.hi[1] - mlo[1]) / g; ++ky)
+          for (int kx = (B.lo[0] - mlo[0]) / g; kx <= (B.hi[0] - mlo[0]) / g; ++kx) owner[((size_t)kz * mn[1] + ky) * mn[0] + kx] = (int)b;
+    }
+  }
+  int classify(int i, int j, int k) const {
+    int p[3] = {i, j, k};
+    for (int d = 0; d < 3; ++d) {
+      const int len = domhi[d] - domlo[d] + 1;
+      if (p[d] < domlo[d] || p[d] > domhi[d]) {
+        if (!is_per[d]) return 2;
+        while (p[d] < domlo[d]) p[d] += len;
+        while (p[d] > domhi[d]) p[d] -= len;
+      }
+    }
+    int m[3];
+    for (int d = 0; d < 3; ++d) {
+      const int r = p[d] - mlo[d];
+      if (r < 0) return 1;
+      m[d] = r / g;
+      if (m[d] >= mn[d]) return 1;
+    }
+    return owner[((size_t)m[2] * mn[1] + m[1]) * mn[0] + m[0]] >= 0 ? 0 : 1;
+  }
+  bool face_is_special(const DBox& B, int d, int side) const {
+    const int t0 = (d == 0) ? 1 : 0, t1 = (d == 2) ? 1 : 2;
+    int q[3];
+    q[d] = side ? B.hi[d] + 1 : B.lo[d] - 1;
+    for (int v = B.lo[t1]; v <= B.hi[t1]; v += g)
+      for (int u = B.lo[t0]; u <= B.hi[t0]; u += g) {
+        q[t0] = u; q[t1] = v;
+        if (classify(q[0], q[1], q[2]) != 0) return true;
+      }
+    return false;
+  }
+};
+
+// --------------------------------------------------------------------------------- distribution map
+static inline unsigned long long spread3(unsigned long long v) {  // 21 bits -> every third bit
+  v &= 0x1fffffull;
+  v = (v | v << 32) & 0x1f00000000ffffull;
+  v = (v | v << 16) & 0x1f0000ff0000ffull;
+  v = (v | v << 8) & 0x100f00f00f00f00full;
+  v = (v | v << 4) & 0x10c30c30c30c30c3ull;
+  v = (v | v << 2) & 0x1249249249249249ull;
+  return v;
+}
+
+extern "C" int pa_distribution_map(int nboxes, const int32_t* b6, int nranks, int32_t* owner) {
+  if (nboxes <= 0 || !b6 || !owner || nranks < 1) return 1;
+  int mlo[3] = {INT32_MAX, INT32_MAX, INT32_MAX};
+  for (int b = 0; b < nboxes; ++b)
+    for (int d = 0; d < 3; ++d) mlo[d] = std::min(mlo[d], b6[6 * b + d]);
+  std::vector<unsigned long long> key(nboxes);
+  std::vector<long long> vol(nboxes);
+  long long total = 0;
+  for (int b = 0; b < nboxes; ++b) {
+    key[b] = spread3((unsigned)(b6[6 * b] - mlo[0])) | spread3((unsigned)(b6[6 * b + 1] - mlo[1])) << 1 | spread3((unsigned)(b6[6 * b + 2] - mlo[2])) << 2;
+    vol[b] = 1;
+    for (int d = 0; d < 3; ++d) vol[b] *= b6[6 * b + 3 + d] - b6[6 * b + d] + 1;
+    total += vol[b];
+  }
+  std::vector<int> ord(nboxes);
+  std::iota(ord.begin(), ord.end(), 0);
+  std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return key[a] < key[b]; });
+  // a box goes to the rank whose share of the curve holds the box's midpoint (in cells along the curve): contiguous
+  // pieces of the curve, cell counts equal to within one box
+  long long cum = 0;
+  for (int i = 0; i < nboxes; ++i) {
+    const int b = ord[i];
+    const __int128 mid2 = (__int128)2 * cum + vol[b];  // twice the midpoint
+    int r = (int)((mid2 * nranks) / ((__int128)2 * total));
+    owner[b] = std::min(std::max(r, 0), nranks - 1);
+    cum += vol[b];
+  }
+  return 0;
+}
+
+// --------------------------------------------------------------------------------------- host plans
+struct HRegion { int peer; int gbox; DBox r; };  // gbox: global box whose index space the region lives in
+
+// FillBoundary: what `rank` sends and receives for ghost width ng.  Enumeration order (dst box, src box, shift) on all ranks.
+static void plan_fill_boundary(const std::vector<DBox>& boxes, const std::vector<int>& owner, int rank, const int domlo[3], const int domhi[3],
+                               const int is_per[3], int ng, std::vector<HRegion>& send, std::vector<HRegion>& recv) {
+  const auto shifts = domain_shifts(domlo, domhi, is_per);
+  const int n = (int)boxes.size();
+  for (int d = 0; d < n; ++d) {
+    const DBox G = bx_grow(boxes[d], ng);
+    for (int s = 0; s < n; ++s) {
+      if (owner[d] == owner[s] || (owner[d] != rank && owner[s] != rank)) continue;
+      // quick reject: the source box must come within ng cells of the destination box, modulo a period
+      for (const auto& sh : shifts) {
+        DBox I;
+        if (!bx_isect(G, bx_shift(boxes[s], sh.data()), I)) continue;
+        if (owner[d] == rank) {
+          recv.push_back({owner[s], d, I});
+        } else {
+          const int neg[3] = {-sh[0], -sh[1], -sh[2]};
+          send.push_back({owner[d], s, bx_shift(I, neg)});
+        }
+      }
+    }
+  }
+}
+
+struct CsPiece { int cbox; DBox box; };
+
+// coarse cells the coarse-fine stencils of fine box B touch (coarse index space, may reach outside the domain)
+static void cs_rects_of_box(const HostGeom& FG, const DBox& B, int mode, int ng, int halo, std::vector<DBox>& rects) {
+  if (mode == 0) {
+    // pa_apply_bc family (InterpBndryData order 3 behind MLMG applyBC): for a ghost cell q behind face
+    // (d, side) the stencil sits in the coarse plane coarsen(q[d]) and spans +-2 coarse cells tangentially around
+    // coarsen(q); the edge ghost cells the fused path resolves lie one fine cell beyond the face's tangential extent.
+    for (int d = 0; d < 3; ++d)
+      for (int side = 0; side < 2; ++side) {
+        if (!FG.face_is_special(B, d, side)) continue;
+        DBox r;
+        for (int t = 0; t < 3; ++t) {
+          if (t == d) { r.lo[t] = r.hi[t] = fl2(side ? B.hi[d] + 1 : B.lo[d] - 1); }
+          else { r.lo[t] = fl2(B.lo[t] - 1) - 2; r.hi[t] = fl2(B.hi[t] + 1) + 2; }
+        }
+        rects.push_back(r);
+      }
+  } else {
+    // pa_fillpatch_two_levels: parents of the ng ghost layers, grown by `halo` coarse cells (slopes / min-max of
+    // mf_cell_cons_interp: 1), minus the coarse cells well inside the box
+    DBox outer, inner;
+    for (int t = 0; t < 3; ++t) {
+      outer.lo[t] = fl2(B.lo[t] - ng) - halo;
+      outer.hi[t] = fl2(B.hi[t] + ng) + halo;
+      inner.lo[t] = fl2(B.lo[t] + 1) + halo;       // first coarse cell with all children inside, moved in by halo
+      inner.hi[t] = fl2(B.hi[t] + 1) - 1 - halo;
+    }
+    bool has_inner = true;
+    for (int t = 0; t < 3; ++t) has_inner = has_inner && inner.lo[t] <= inner.hi[t];
+    if (has_inner) bx_diff(outer, inner, rects);
+    else rects.push_back(outer);
+  }
+}
+
+// the disjoint pieces of the coarse level that rank r keeps a copy of, in the order of r's coarse-source BoxArray
+static std::vector<CsPiece> cs_pieces(const HostGeom& FG, const std::vector<DBox>& fboxes, const std::vector<int>& fowner, const std::vector<DBox>& cboxes,
+                                      const int cdomlo[3], const int cdomhi[3], const int is_per[3], int r, int mode, int ng, int halo) {
+  std::vector<DBox> rects;
+  for (size_t b = 0; b < fboxes.size(); ++b)
+    if (fowner[b] == r) cs_rects_of_box(FG, fboxes[b], mode, ng, halo, rects);
+  std::vector<CsPiece> out;
+  if (rects.empty()) return out;
+  DBox hull = rects[0];
+  for (const DBox& q : rects)
+    for (int d = 0; d < 3; ++d) { hull.lo[d] = std::min(hull.lo[d], q.lo[d]); hull.hi[d] = std::max(hull.hi[d], q.hi[d]); }
+  const auto shifts = domain_shifts(cdomlo, cdomhi, is_per);
+  std::vector<DBox> mine, tmp, tmp2;
+  for (size_t j = 0; j < cboxes.size(); ++j) {
+    mine.clear();
+    for (const auto& sh : shifts) {
+      const DBox Cs = bx_shift(cboxes[j], sh.data());
+      DBox I;
+      if (!bx_isect(hull, Cs, I)) continue;
+      const int neg[3] = {-sh[0], -sh[1], -sh[2]};
+      for (const DBox& q : rects) {
+        if (!bx_isect(q, Cs, I)) continue;
+        tmp.assign(1, bx_shift(I, neg));  // in the coarse box's own coordinates
+        for (const DBox& have : mine) {
+          tmp2.clear();
+          for (const DBox& t : tmp) bx_diff(t, have, tmp2);
+          tmp.swap(tmp2);
+          if (tmp.empty()) break;
+        }
+        for (const DBox& t : tmp) mine.push_back(t);
+      }
+    }
+    for (const DBox& t : mine) out.push_back({(int)j, t});
+  }
+  return out;
+}
+
+static std::vector<DBox> boxes_from6(int n, const int32_t* b6) {
+  std::vector<DBox> v(n);
+  for (int b = 0; b < n; ++b)
+    for (int d = 0; d < 3; ++d) { v[b].lo[d] = b6[6 * b + d]; v[b].hi[d] = b6[6 * b + 3 + d]; }
+  return v;
+}
+static inline void put_row(int32_t* rows, int64_t cap, int64_t& n, int kind, int peer, int box, const DBox& r) {
+  if (n < cap && rows) {
+    int32_t* p = rows + 9 * n;
+    p[0] = kind; p[1] = peer; p[2] = box;
+    for (int d = 0; d < 3; ++d) { p[3 + d] = r.lo[d]; p[6 + d] = r.hi[d]; }
+  }
+  ++n;
+}
+
+extern "C" int64_t pa_plan_fill_boundary(int nboxes, const int32_t* b6, const int32_t* owner, int rank, const int32_t domlo[3], const int32_t domhi[3],
+                                         const int32_t is_per[3], int ng, int32_t* rows9, int64_t cap) {
+  if (nboxes <= 0 || !b6 || !owner) return -1;
+  std::vector<HRegion> send, recv;
+  plan_fill_boundary(boxes_from6(nboxes, b6), std::vector<int>(owner, owner + nboxes), rank, domlo, domhi, is_per, ng, send, recv);
+  int64_t n = 0;
+  for (const HRegion& h : send) put_row(rows9, cap, n, 0, h.peer, h.gbox, h.r);
+  for (const HRegion& h : recv) put_row(rows9, cap, n, 1, h.peer, h.gbox, h.r);
+  return n;
+}
+
+extern "C" int64_t pa_plan_coarse_source(int nfine, const int32_t* fb6, const int32_t* fowner, const int32_t fdomlo[3], const int32_t fdomhi[3], int ncrse,
+                                         const int32_t* cb6, const int32_t* cowner, const int32_t cdomlo[3], const int32_t cdomhi[3],
+                                         const int32_t is_per[3], int rank, int mode, int ng, int halo, int32_t* rows9, int64_t cap) {
+  if (nfine <= 0 || ncrse <= 0 || !fb6 || !fowner || !cb6 || !cowner) return -1;
+  const std::vector<DBox> fb = boxes_from6(nfine, fb6), cb = boxes_from6(ncrse, cb6);
+  const std::vector<int> fo(fowner, fowner + nfine);
+  const HostGeom FG(fb, fdomlo, fdomhi, is_per);
+  int nranks = 0;
+  for (int v : fo) nranks = std::max(nranks, v + 1);
+  for (int j = 0; j < ncrse; ++j) nranks = std::max(nranks, cowner[j] + 1);
+  int64_t n = 0;
+  for (const CsPiece& p : cs_pieces(FG, fb, fo, cb, cdomlo, cdomhi, is_per, rank, mode, ng, halo)) put_row(rows9, cap, n, 2, cowner[p.cbox], p.cbox, p.box);
+  for (int r = 0; r < nranks; ++r) {
+    if (r == rank) continue;
+    for (const CsPiece& p : cs_pieces(FG, fb, fo, cb, cdomlo, cdomhi, is_per, r, mode, ng, halo))
+      if (cowner[p.cbox] == rank) put_row(rows9, cap, n, 0, r, p.cbox, p.box);
+  }
+  return n;
+}
+
+// ------------------------------------------------------------------------------------- device plans
+XSide::~XSide() {
+  if (d_regs) (void)hipFree(d_regs);
+  if (d_coff) (void)hipFree(d_coff);
+}
+XPlan::~XPlan() {
+  if (sbuf) (void)hipFree(sbuf);
+  if (rbuf) (void)hipFree(rbuf);
+  if (d_lsrc) (void)hipFree(d_lsrc);
+  if (d_ldst) (void)hipFree(d_ldst);
+}
+CsPlan::~CsPlan() {
+  for (auto& kv : mfs) pa_mf_destroy(kv.second);
+  if (cs) pa_level_destroy(cs);
+}
+pa_level::~pa_level() {}
+
+// regions (already sorted by peer, stable) -> host + device tables
+static int side_finish(pa_ctx* ctx, XSide& S, std::vector<std::pair<int, std::array<int32_t, 7>>>& regs) {
+  std::stable_sort(regs.begin(), regs.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+  S.regs7.clear(); S.coff.assign(1, 0); S.peers.clear(); S.first.clear();
+  for (size_t i = 0; i < regs.size(); ++i) {
+    if (S.peers.empty() || S.peers.back() != regs[i].first) { S.peers.push_back(regs[i].first); S.first.push_back((int)i); }
+    const auto& R = regs[i].second;
+    S.regs7.insert(S.regs7.end(), R.begin(), R.end());
+    const long long n = (long long)(R[4] - R[1] + 1) * (R[5] - R[2] + 1) * (R[6] - R[3] + 1);
+    S.maxcells = std::max(S.maxcells, n);
+    S.coff.push_back(S.coff.back() + n);
+  }
+  S.first.push_back((int)regs.size());
+  if (!regs.empty()) {
+    PA_HIP(hipMalloc(&S.d_regs, sizeof(int) * S.regs7.size()));
+    PA_HIP(hipMalloc(&S.d_coff, sizeof(long long) * S.coff.size()));
+    PA_HIP(hipMemcpy(S.d_regs, S.regs7.data(), sizeof(int) * S.regs7.size(), hipMemcpyHostToDevice));
+    PA_HIP(hipMemcpy(S.d_coff, S.coff.data(), sizeof(long long) * S.coff.size(), hipMemcpyHostToDevice));
+  }
+  return 0;
+}
+static std::array<int32_t, 7> reg7(int box, const DBox& r) { return {box, r.lo[0], r.lo[1], r.lo[2], r.hi[0], r.hi[1], r.hi[2]}; }
+
+XPlan* pa_fb_plan(pa_ctx* ctx, const pa_level* L, int ng) {
+  auto it = L->fb_plans.find(ng);
+  if (it != L->fb_plans.end()) return it->second.get();
+  std::vector<HRegion> send, recv;
+  plan_fill_boundary(L->gboxes, L->gowner, L->rank, L->domlo, L->domhi, L->is_per, ng, send, recv);
+  std::unique_ptr<XPlan> P(new XPlan());
+  std::vector<std::pair<int, std::array<int32_t, 7>>> s, r;
+  for (const HRegion& h : send) s.push_back({h.peer, reg7(L->glocal[h.gbox], h.r)});
+  for (const HRegion& h : recv) r.push_back({h.peer, reg7(L->glocal[h.gbox], h.r)});
+  if (side_finish(ctx, P->send, s) || side_finish(ctx, P->recv, r)) return nullptr;
+  XPlan* raw = P.get();
+  L->fb_plans[ng] = std::move(P);
+  return raw;
+}
+
+CsPlan* pa_cs_plan(pa_ctx* ctx, const pa_level* F, const pa_level* C, int mode, int ng, int halo) {
+  const auto key = std::make_pair(C->serial, mode == 0 ? 0 : 1 + ng * 16 + halo);
+  auto it = F->cs_plans.find(key);
+  if (it != F->cs_plans.end()) return it->second.get();
+  if (F->nranks != C->nranks || F->rank != C->rank) { pa_fail(ctx, "coarse and fine level are sharded over different rank sets"); return nullptr; }
+  const HostGeom FG(F->gboxes, F->domlo, F->domhi, F->is_per);
+  std::unique_ptr<CsPlan> P(new CsPlan());
+  const std::vector<CsPiece> mine = cs_pieces(FG, F->gboxes, F->gowner, C->gboxes, C->domlo, C->domhi, C->is_per, F->rank, mode, ng, halo);
+  LevelSpec S;
+  S.source_only = true;
+  std::vector<std::pair<int, std::array<int32_t, 7>>> s, r;
+  std::vector<int32_t> lsrc, ldst;
+  for (size_t i = 0; i < mine.size(); ++i) {
+    S.local.push_back(mine[i].box);
+    const int o = C->gowner[mine[i].cbox];
+    if (o == C->rank) {
+      const auto a = reg7(C->glocal[mine[i].cbox], mine[i].box), b = reg7((int)i, mine[i].box);
+      lsrc.insert(lsrc.end(), a.begin(), a.end());
+      ldst.insert(ldst.end(), b.begin(), b.end());
+      P->x.lmax = std::max(P->x.lmax, bx_cells(mine[i].box));
+    } else {
+      r.push_back({o, reg7((int)i, mine[i].box)});
+    }
+  }
+  for (int q = 0; q < F->nranks; ++q) {
+    if (q == F->rank) continue;
+    for (const CsPiece& p : cs_pieces(FG, F->gboxes, F->gowner, C->gboxes, C->domlo, C->domhi, C->is_per, q, mode, ng, halo))
+      if (C->gowner[p.cbox] == C->rank) s.push_back({q, reg7(C->glocal[p.cbox], p.box)});
+  }
+  if (side_finish(ctx, P->x.send, s) || side_finish(ctx, P->x.recv, r)) return nullptr;
+  P->x.nlocal = (int)(lsrc.size() / 7);
+  if (P->x.nlocal) {
+    if (hipMalloc(&P->x.d_lsrc, sizeof(int) * lsrc.size()) != hipSuccess || hipMalloc(&P->x.d_ldst, sizeof(int) * ldst.size()) != hipSuccess ||
+        hipMemcpy(P->x.d_lsrc, lsrc.data(), sizeof(int) * lsrc.size(), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(P->x.d_ldst, ldst.data(), sizeof(int) * ldst.size(), hipMemcpyHostToDevice) != hipSuccess) {
+      pa_fail(ctx, "coarse-source plan: device allocation failed");
+      return nullptr;
+    }
+  }
+  if (!S.local.empty()) {
+    P->cs = pa_level_create_spec(ctx, S, C->domlo, C->domhi, C->is_per, C->prob_lo, C->prob_hi);
+    if (!P->cs) return nullptr;
+  }
+  CsPlan* raw = P.get();
+  F->cs_plans[key] = std::move(P);
+  return raw;
+}
+
+pa_mf* CsPlan::mf(pa_ctx* ctx, int ncomp) {
+  if (!cs) return nullptr;
+  auto it = mfs.find(ncomp);
+  if (it != mfs.end()) return it->second;
+  pa_mf* m = pa_mf_create(ctx, cs, ncomp, 0, nullptr);
+  if (m) mfs[ncomp] = m;
+  return m;
+}
+
+// ---------------------------------------------------------------------------------- pack / unpack
+// Thread t of block row r handles cell t of region r for all components.  Regions are thin (1-2 cells along one
+// direction); 32-bit index arithmetic.
+__global__ __launch_bounds__(256) void k_xregions(DLevelView L, DMFView M, int comp, int ncomp, const int* regs, const long long* coff, double* buf, int unpack) {
+  const int* R = regs + 7 * blockIdx.y;
+  const int b = R[0];
+  const unsigned nx = R[4] - R[1] + 1, ny = R[5] - R[2] + 1, nz = R[6] - R[3] + 1, n = nx * ny * nz;
+  const DBox B = L.boxes[b];
+  const long long gnx = B.hi[0] - B.lo[0] + 1 + 2 * M.ng, gny = B.hi[1] - B.lo[1] + 1 + 2 * M.ng, gnz = B.hi[2] - B.lo[2] + 1 + 2 * M.ng;
+  const long long cs = pa_cstride(gnx * gny * gnz, M.ncomp);
+  double* f = M.data + M.off[b] + (long long)comp * cs;
+  double* q = buf + coff[blockIdx.y] * ncomp;
+  const int oi = R[1] - B.lo[0] + M.ng, oj = R[2] - B.lo[1] + M.ng, ok = R[3] - B.lo[2] + M.ng;
+  for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
+    const unsigned r = t / nx, i = t - r * nx, k = r / ny, j = r - k * ny;
+    const long long idx = ((long long)(k + ok) * gny + (j + oj)) * gnx + (i + oi);
+    for (int c = 0; c < ncomp; ++c) {
+      if (unpack) f[c * cs + idx] = q[(long long)c * n + t];
+      else q[(long long)c * n + t] = f[c * cs + idx];
+    }
+  }
+}
+
+// same-rank part of a coarse-source refill: region pairs of equal shape, coarse level -> coarse-source level
+__global__ __launch_bounds__(256) void k_xcopy(DLevelView LS, DMFView MS, int scomp, DLevelView LD, DMFView MD, int dcomp, int ncomp, const int* sregs, const int* dregs) {
+  const int* R = sregs + 7 * blockIdx.y;
+  const int* D = dregs + 7 * blockIdx.y;
+  const unsigned nx = R[4] - R[1] + 1, ny = R[5] - R[2] + 1, nz = R[6] - R[3] + 1, n = nx * ny * nz;
+  const DBox BS = LS.boxes[R[0]], BD = LD.boxes[D[0]];
+  for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
+    const unsigned r = t / nx, i = t - r * nx, k = r / ny, j = r - k * ny;
+    for (int c = 0; c < ncomp; ++c)
+      MD.data[MD.off[D[0]] + fab_index(BD, MD.ng, MD.ncomp, dcomp + c, D[1] + (int)i, D[2] + (int)j, D[3] + (int)k)] =
+          MS.data[MS.off[R[0]] + fab_index(BS, MS.ng, MS.ncomp, scomp + c, R[1] + (int)i, R[2] + (int)j, R[3] + (int)k)];
+  }
+}
+
+static int ensure_buf(pa_ctx* ctx, double*& buf, long long& cap, long long need) {
+  if (need <= cap) return 0;
+  if (buf) {
+    PA_HIP(hipStreamSynchronize(ctx->stream));  // an earlier exchange may still read it
+    (void)hipFree(buf);
+    buf = nullptr; cap = 0;
+  }
+  PA_HIP(hipMalloc(&buf, sizeof(double) * (size_t)need));
+  cap = need;
+  return 0;
+}
+
+static void launch_regions(pa_ctx* ctx, const XSide& S, const pa_mf* M, int comp, int ncomp, double* buf, int unpack) {
+  const int nreg = (int)(S.regs7.size() / 7);
+  if (!nreg) return;
+  const unsigned gx = (unsigned)std::min<long long>((S.maxcells + 255) / 256, 64);
+  hipLaunchKernelGGL(k_xregions, dim3(gx, (unsigned)nreg), dim3(256), 0, ctx->stream, M->lev->view, M->view, comp, ncomp, S.d_regs, S.d_coff, buf, unpack);
+}
+
+int pa_xexchange(pa_ctx* ctx, int njobs, const XJob* jobs) {
+  std::vector<pa_xfer> xf;
+  for (int q = 0; q < njobs; ++q) {
+    const XJob& J = jobs[q];
+    XPlan& P = *J.plan;
+    if (J.ncomp < 1 || J.scomp < 0 || J.scomp + J.ncomp > J.src->ncomp || J.dcomp < 0 || (J.dst && J.dcomp + J.ncomp > J.dst->ncomp))
+      return pa_fail(ctx, "ghost exchange: component range");
+    PA_TRY(ensure_buf(ctx, P.sbuf, P.scap, P.send.coff.back() * J.ncomp));
+    PA_TRY(ensure_buf(ctx, P.rbuf, P.rcap, P.recv.coff.back() * J.ncomp));
+    launch_regions(ctx, P.send, J.src, J.scomp, J.ncomp, P.sbuf, 0);
+    if (P.nlocal)
+      hipLaunchKernelGGL(k_xcopy, dim3((unsigned)std::min<long long>((P.lmax + 255) / 256, 64), (unsigned)P.nlocal), dim3(256), 0, ctx->stream, J.src->lev->view,
+                         J.src->view, J.scomp, J.dst->lev->view, J.dst->view, J.dcomp, J.ncomp, P.d_lsrc, P.d_ldst);
+    // one entry per peer of this plan, peers ascending: both sides walk jobs and peers in the same order
+    size_t a = 0, b = 0;
+    while (a < P.send.peers.size() || b < P.recv.peers.size()) {
+      const int ps = a < P.send.peers.size() ? P.send.peers[a] : INT32_MAX, pr = b < P.recv.peers.size() ? P.recv.peers[b] : INT32_MAX;
+      const int p = std::min(ps, pr);
+      pa_xfer x = {p, nullptr, 0, nullptr, 0};
+      if (ps == p) {
+        x.sendbuf = P.sbuf + P.send.coff[P.send.first[a]] * J.ncomp;
+        x.nsend = (P.send.coff[P.send.first[a + 1]] - P.send.coff[P.send.first[a]]) * J.ncomp;
+        ++a;
+      }
+      if (pr == p) {
+        x.recvbuf = P.rbuf + P.recv.coff[P.recv.first[b]] * J.ncomp;
+        x.nrecv = (P.recv.coff[P.recv.first[b + 1]] - P.recv.coff[P.recv.first[b]]) * J.ncomp;
+        ++b;
+      }
+      xf.push_back(x);
+    }
+  }
+  PA_HIP(hipGetLastError());
+  if (!xf.empty()) {
+    if (!ctx->comm.exchange) return pa_fail(ctx, "sharded level without a transport: call pa_ctx_init_rccl or pa_ctx_set_comm first");
+    if (ctx->comm.exchange(ctx->comm.user, (void*)ctx->stream, (int32_t)xf.size(), xf.data()) != 0)
+      return pa_fail(ctx, ctx->rccl ? "RCCL point-to-point exchange failed: " + ctx->err : std::string("the transport's exchange failed"));
+  }
+  for (int q = 0; q < njobs; ++q) launch_regions(ctx, jobs[q].plan->recv, jobs[q].dst, jobs[q].dcomp, jobs[q].ncomp, jobs[q].plan->rbuf, 1);
+  PA_HIP(hipGetLastError());
+  return 0;
+}
+
+// The multifab to read coarse data from when filling ghost cells of `fine` from crse[ccomp .. ccomp+ncomp): crse itself
+// on one rank, else this rank's freshly refilled coarse-source copy (component 0 = ccomp).  *src = nullptr when this
+// rank has nothing to fill (no box, or no coarse-fine face) -- the exchange still runs: other ranks may need our data.
+int pa_coarse_source(pa_ctx* ctx, const pa_level* fine, const pa_mf* crse, int ccomp, int ncomp, int mode, int ng, int halo, const pa_mf** src, int* scomp) {
+  *src = crse;
+  *scomp = ccomp;
+  if (!crse || crse->lev->nranks <= 1) return 0;
+  if (fine->nranks != crse->lev->nranks) return pa_fail(ctx, "coarse and fine level are sharded over different rank sets");
+  CsPlan* P = pa_cs_plan(ctx, fine, crse->lev, mode, ng, halo);
+  if (!P) return 1;
+  pa_mf* m = P->mf(ctx, ncomp);
+  if (P->cs && !m) return 1;
+  XJob J = {&P->x, crse, ccomp, m, 0, ncomp};
+  PA_TRY(pa_xexchange(ctx, 1, &J));
+  *src = m;
+  *scomp = 0;
+  return 0;
+}
+
+// --------------------------------------------------------------------------------------- transports
+extern "C" int pa_ctx_set_comm(pa_ctx* ctx, const pa_comm* c) {
+  if (!ctx) return 1;
+  if (!c) { ctx->comm = pa_comm{nullptr, 0, 1, nullptr, nullptr}; return 0; }
+  if (c->nranks < 1 || c->rank < 0 || c->rank >= c->nranks) return pa_fail(ctx, "pa_ctx_set_comm: bad rank / nranks");
+  if (c->nranks > 1 && (!c->exchange || !c->allreduce)) return pa_fail(ctx, "pa_ctx_set_comm: exchange and allreduce are required");
+  ctx->comm = *c;
+  return 0;
+}
+extern "C" int pa_ctx_nranks(const pa_ctx* ctx) { return ctx ? ctx->comm.nranks : 0; }
+
+extern "C" int pa_allreduce(pa_ctx* ctx, double* vals, int n, int op) {
+  if (!ctx || !vals || n < 0 || op < 0 || op > 2) return pa_fail(ctx, "pa_allreduce: bad argument");
+  if (ctx->comm.nranks <= 1 || n == 0) return 0;
+  if (!ctx->comm.allreduce) return pa_fail(ctx, "pa_allreduce: no transport");
+  if (ctx->comm.allreduce(ctx->comm.user, vals, n, op) != 0) return pa_fail(ctx, "the transport's allreduce failed");
+  return 0;
+}
+
+// RCCL, bound at run time: the library must load (and every single-rank path must work) where librccl is absent,
+// and inside a process that already carries a RCCL (PyTorch bundles one under the same soname) we use that copy.
+typedef struct ncclComm* pa_ncclComm_t;
+struct pa_ncclUniqueId { char internal[128]; };
+enum { PA_NCCL_FLOAT64 = 8, PA_NCCL_SUM = 0, PA_NCCL_MAX = 2, PA_NCCL_MIN = 3 };
+struct RcclApi {
+  void* h = nullptr;
+  int (*GetUniqueId)(pa_ncclUniqueId*) = nullptr;
+  int (*CommInitRank)(pa_ncclComm_t*, int, pa_ncclUniqueId, int) = nullptr;
+  int (*CommDestroy)(pa_ncclComm_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  int (*Send)(const void*, size_t, int, int, pa_ncclComm_t, hipStream_t) = nullptr;
+  int (*Recv)(void*, size_t, int, int, pa_ncclComm_t, hipStream_t) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, pa_ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+static RcclApi* rccl_api(std::string& why) {
+  static RcclApi api;
+  static bool tried = false, ok = false;
+  static std::string err;
+  if (!tried) {
+    tried = true;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      api.h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+      if (api.h) break;
+    }
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      if (api.h) break;
+      api.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    }
+    if (!api.h) {
+      err = std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "?");
+    } else {
+#define PA_SYM(f, n) *(void**)(&api.f) = dlsym(api.h, n)
+      PA_SYM(GetUniqueId, "ncclGetUniqueId"); PA_SYM(CommInitRank, "ncclCommInitRank"); PA_SYM(CommDestroy, "ncclCommDestroy");
+      PA_SYM(GroupStart, "ncclGroupStart"); PA_SYM(GroupEnd, "ncclGroupEnd"); PA_SYM(Send, "ncclSend"); PA_SYM(Recv, "ncclRecv");
+      PA_SYM(AllReduce, "ncclAllReduce"); PA_SYM(GetErrorString, "ncclGetErrorString");
+#undef PA_SYM
+      ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.GroupStart && api.GroupEnd && api.Send && api.Recv && api.AllReduce;
+      if (!ok) err = "librccl lacks a required symbol";
+    }
+  }
+  why = err;
+  return ok ? &api : nullptr;
+}
+
+struct RcclState {
+  RcclApi* api = nullptr;
+  pa_ncclComm_t comm = nullptr;
+  pa_ctx* ctx = nullptr;
+  double* d_red = nullptr;
+};
+static int rccl_fail(RcclState* S, const char* what, int rc) {
+  S->ctx->err = std::string(what) + ": " + (S->api->GetErrorString ? S->api->GetErrorString(rc) : "error " + std::to_string(rc));
+  return 1;
+}
+static int rccl_exchange(void* user, void* stream, int32_t n, const pa_xfer* x) {
+  RcclState* S = (RcclState*)user;
+  int rc = S->api->GroupStart();
+  if (rc) return rccl_fail(S, "ncclGroupStart", rc);
+  for (int i = 0; i < n; ++i) {
+    if (x[i].nsend > 0 && (rc = S->api->Send(x[i].sendbuf, (size_t)x[i].nsend, PA_NCCL_FLOAT64, x[i].peer, S->comm, (hipStream_t)stream))) break;
+    if (x[i].nrecv > 0 && (rc = S->api->Recv(x[i].recvbuf, (size_t)x[i].nrecv, PA_NCCL_FLOAT64, x[i].peer, S->comm, (hipStream_t)stream))) break;
+  }
+  const int rc2 = S->api->GroupEnd();
+  if (rc) return rccl_fail(S, "ncclSend/ncclRecv", rc);
+  if (rc2) return rccl_fail(S, "ncclGroupEnd", rc2);
+  return 0;
+}
+static int rccl_allreduce(void* user, double* vals, int32_t n, int32_t op) {
+  RcclState* S = (RcclState*)user;
+  pa_ctx* ctx = S->ctx;
+  if (n > 64) return 1;
+  PA_HIP(hipMemcpyAsync(S->d_red, vals, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+  const int rc = S->api->AllReduce(S->d_red, S->d_red, (size_t)n, PA_NCCL_FLOAT64, op == 0 ? PA_NCCL_MIN : (op == 1 ? PA_NCCL_MAX : PA_NCCL_SUM), S->comm, ctx->stream);
+  if (rc) return rccl_fail(S, "ncclAllReduce", rc);
+  PA_HIP(hipMemcpyAsync(vals, S->d_red, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+  PA_HIP(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+extern "C" int pa_rccl_unique_id(pa_ctx* ctx, void* id128) {
+  PaBind bind_(ctx);
+  if (!ctx || !id128) return pa_fail(ctx, "pa_rccl_unique_id: null argument");
+  std::string why;
+  RcclApi* api = rccl_api(why);
+  if (!api) return pa_fail(ctx, "pa_rccl_unique_id: " + why);
+  pa_ncclUniqueId id;
+  const int rc = api->GetUniqueId(&id);
+  if (rc) return pa_fail(ctx, std::string("ncclGetUniqueId: ") + (api->GetErrorString ? api->GetErrorString(rc) : "error"));
+  memcpy(id128, &id, 128);
+  return 0;
+}
+
+void pa_rccl_destroy(pa_ctx* ctx) {
+  if (!ctx || !ctx->rccl) return;
+  if (ctx->rccl->comm) (void)ctx->rccl->api->CommDestroy(ctx->rccl->comm);
+  if (ctx->rccl->d_red) (void)hipFree(ctx->rccl->d_red);
+  delete ctx->rccl;
+  ctx->rccl = nullptr;
+}
+
+extern "C" int pa_ctx_init_rccl(pa_ctx* ctx, int nranks, int rank, const void* id128) {
+  PaBind bind_(ctx);
+  if (!ctx || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return pa_fail(ctx, "pa_ctx_init_rccl: bad argument");
+  std::string why;
+  RcclApi* api = rccl_api(why);
+  if (!api) return pa_fail(ctx, "pa_ctx_init_rccl: " + why);
+  pa_rccl_destroy(ctx);
+  RcclState* S = new RcclState();
+  S->api = api; S->ctx = ctx;
+  pa_ncclUniqueId id;
+  memcpy(&id, id128, 128);
+  const int rc = api->CommInitRank(&S->comm, nranks, id, rank);
+  if (rc) {
+    pa_fail(ctx, std::string("ncclCommInitRank: ") + (api->GetErrorString ? api->GetErrorString(rc) : "error"));
+    delete S;
+    return 1;
+  }
+  if (hipMalloc(&S->d_red, 64 * sizeof(double)) != hipSuccess) { (void)api->CommDestroy(S->comm); delete S; return pa_fail(ctx, "pa_ctx_init_rccl: device allocation failed"); }
+  ctx->rccl = S;
+  ctx->comm = pa_comm{S, rank, nranks, rccl_exchange, rccl_allreduce};
+  return 0;
+}
+
+extern "C" int pa_level_global_ids(const pa_level* L, int32_t* gids) {
+  if (!L || !gids) return 1;
+  for (size_t b = 0; b < L->boxes.size(); ++b) gids[b] = L->gid.empty() ? (int32_t)b : L->gid[b];
+  return 0;
+}
+
+// Transport check (what bench.py and the tools run once before trusting a transport): every rank sends n doubles of a
+// rank-specific pattern to rank+1 and receives from rank-1 (itself on one rank) through the context's transport, and a
+// max-reduction over the ranks is compared with its known answer.  Synchronous.  0 = the transport works.
+__global__ void k_selftest_fill(double* p, long long n, int rank) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = 1000.0 * rank + (double)(i % 977);
+}
+extern "C" int pa_comm_selftest(pa_ctx* ctx, int64_t n) {
+  PaBind bind_(ctx);
+  if (!ctx || n < 1) return pa_fail(ctx, "pa_comm_selftest: bad argument");
+  if (!ctx->comm.exchange || !ctx->comm.allreduce) return pa_fail(ctx, "pa_comm_selftest: the context has no transport");
+  const int N = ctx->comm.nranks, r = ctx->comm.rank, to = (r + 1) % N, from = (r + N - 1) % N;
+  double *s = nullptr, *d = nullptr;
+  PA_HIP(hipMalloc(&s, sizeof(double) * n));
+  PA_HIP(hipMalloc(&d, sizeof(double) * n));
+  hipLaunchKernelGGL(k_selftest_fill, dim3(64), dim3(256), 0, ctx->stream, s, (long long)n, r);
+  PA_HIP(hipMemsetAsync(d, 0, sizeof(double) * n, ctx->stream));
+  int rc = 0;
+  if (to == from) {
+    pa_xfer x = {to, s, n, d, n};
+    rc = ctx->comm.exchange(ctx->comm.user, (void*)ctx->stream, 1, &x);
+  } else {
+    pa_xfer x[2] = {{std::min(to, from), nullptr, 0, nullptr, 0}, {std::max(to, from), nullptr, 0, nullptr, 0}};
+    for (auto& e : x) {
+      if (e.peer == to) { e.sendbuf = s; e.nsend = n; }
+      if (e.peer == from) { e.recvbuf = d; e.nrecv = n; }
+    }
+    rc = ctx->comm.exchange(ctx->comm.user, (void*)ctx->stream, 2, x);
+  }
+  std::vector<double> h((size_t)n);
+  if (!rc && (hipMemcpyAsync(h.data(), d, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)) rc = 2;
+  (void)hipFree(s);
+  (void)hipFree(d);
+  if (rc) return pa_fail(ctx, "pa_comm_selftest: exchange failed" + (ctx->err.empty() ? std::string() : " (" + ctx->err + ")"));
+  for (int64_t i = 0; i < n; ++i)
+    if (h[(size_t)i] != 1000.0 * from + (double)(i % 977)) return pa_fail(ctx, "pa_comm_selftest: received data differ from what rank " + std::to_string(from) + " sent");
+  double v[2] = {(double)r, -(double)r};
+  if (ctx->comm.allreduce(ctx->comm.user, v, 2, 1) != 0) return pa_fail(ctx, "pa_comm_selftest: allreduce failed");
+  if (v[0] != (double)(N - 1) || v[1] != 0.0) return pa_fail(ctx, "pa_comm_selftest: allreduce(max) gave a wrong answer");
+  return 0;
+}

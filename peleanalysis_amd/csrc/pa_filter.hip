@@ -6,6 +6,7 @@
 // ((w_l*w_m)*w_n)*q added term by term) so results are bit-identical to the oracle; the
 // (2ng+1)^3 taps are served from an LDS tile with an ng-deep halo.
 #include "pa_internal.h"
+#include "pa_dist.h"
 #include "pa_fabview.h"
 #include <algorithm>
 #include <cstdlib>
@@ -217,6 +218,7 @@ extern "C" int pa_boxfilter_level(pa_ctx* ctx, const pa_mf* in, pa_mf* out, int 
   FilterW W;
   for (int q = 0; q < 2 * ng + 1; ++q) W.w[q] = w[q];
   const pa_level* L = in->lev;
+  if (in->lev->boxes.empty()) return 0;  // a rank that owns no box of this level
   LevelBP2 bp{L->view, in->view, out->view};
   ProfScope prof(ctx, PA_TAG_FILTER);
   filter_launch(ctx->stream, bp, L->maxn[0], L->maxn[1], L->maxn[2], (unsigned)L->boxes.size(), scomp, ncomp, ng, W);
@@ -253,6 +255,7 @@ extern "C" int pa_boxfilter_level2d(pa_ctx* ctx, const pa_mf* in, pa_mf* out, in
   FilterW W;
   for (int q = 0; q < 2 * ng + 1; ++q) W.w[q] = w[q];
   const pa_level* L = in->lev;
+  if (in->lev->boxes.empty()) return 0;  // a rank that owns no box of this level
   LevelBP2 bp{L->view, in->view, out->view};
   ProfScope prof(ctx, PA_TAG_FILTER);
   hipLaunchKernelGGL(k_boxfilter2d<LevelBP2>, tile_grid_dims(L->maxn[0], L->maxn[1], L->maxn[2], (unsigned)L->boxes.size()), dim3(256), 0, ctx->stream, bp, scomp,
@@ -347,6 +350,7 @@ extern "C" int pa_foextrap(pa_ctx* ctx, pa_mf* M, int comp, int ncomp, int ng) {
   if (!ctx || !M) return pa_fail(ctx, "pa_foextrap: null argument");
   if (ng > M->ng || ng < 0 || comp < 0 || comp + ncomp > M->ncomp) return pa_fail(ctx, "pa_foextrap: ng/component range");
   if (ng == 0) return 0;
+  if (M->lev->boxes.empty()) return 0;  // a rank that owns no box of this level
   dim3 grid((unsigned)((max_shell2(M->lev, ng) + 255) / 256), (unsigned)M->lev->boxes.size());
   hipLaunchKernelGGL(k_foextrap, grid, dim3(256), 0, ctx->stream, M->lev->view, M->view, comp, ncomp, ng);
   PA_HIP(hipGetLastError());
@@ -356,7 +360,8 @@ extern "C" int pa_foextrap(pa_ctx* ctx, pa_mf* M, int comp, int ncomp, int ng) {
 // FillPatchTwoLevels for the ghost cells that no fine box covers: piecewise constant or
 // cell-conservative linear interpolation of the coarse level (see oracle/pa_oracle.c
 // orc_fillpatch_two_levels for the restated limiter)
-__global__ void k_fillpatch2(DLevelView L, DMFView M, DLevelView LC, DMFView MC, int comp, int ncomp, int ngf, int r, int interp, int* nbad) {
+__global__ void k_fillpatch2(DLevelView L, DMFView M, DLevelView LC, DMFView MC, int comp, int cshift /* coarse component = fine component + cshift */, int ncomp, int ngf, int r,
+                             int interp, int* nbad) {
   const int b = blockIdx.y;
   const DBox B = L.boxes[b];
   const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
@@ -367,7 +372,7 @@ __global__ void k_fillpatch2(DLevelView L, DMFView M, DLevelView LC, DMFView MC,
   double* f = M.data + M.off[b];
   for (int c = comp; c < comp + ncomp; ++c) {
     bool ok = true;
-    const double u0 = crse_val(LC, MC, c, qc[0], qc[1], qc[2], ok);
+    const double u0 = crse_val(LC, MC, c + cshift, qc[0], qc[1], qc[2], ok);
     double val = u0;
     if (interp == 1) {
       // mf_cell_cons_lin_interp_mcslope + mf_cell_cons_lin_interp (AMReX, recalled; oracle/pa_oracle.c
@@ -378,7 +383,7 @@ __global__ void k_fillpatch2(DLevelView L, DMFView M, DLevelView LC, DMFView MC,
         int p[3] = {qc[0] + dx, qc[1] + dy, qc[2] + dz};
         for (int d = 0; d < 3; ++d)
           if (!LC.is_per[d]) { p[d] = max(p[d], LC.domlo[d]); p[d] = min(p[d], LC.domhi[d]); }
-        return crse_val(LC, MC, c, p[0], p[1], p[2], ok);
+        return crse_val(LC, MC, c + cshift, p[0], p[1], p[2], ok);
       };
       double sl[3];
       for (int d = 0; d < 3; ++d) {
@@ -423,8 +428,12 @@ extern "C" int pa_fillpatch_two_levels(pa_ctx* ctx, pa_mf* fine, const pa_mf* cr
   if (ratio != 2) return pa_fail(ctx, "pa_fillpatch_two_levels: only refinement ratio 2 is supported (quirk Q11)");
   if (interp_type != 0 && interp_type != 1) return pa_fail(ctx, "pa_fillpatch_two_levels: interp_type must be 0 (pc) or 1 (cell-conservative linear)");
   if (ng == 0) return 0;
+  // sharded coarse level: the parents of the ghost layers (+ 1 coarse cell for slopes / min-max) from this rank's coarse-source copy
+  int ccomp = comp;
+  if (pa_coarse_source(ctx, fine->lev, crse, comp, ncomp, 1, ng, 1, &crse, &ccomp)) return 1;
+  if (fine->lev->boxes.empty() || !crse) return 0;
   dim3 grid((unsigned)((max_shell2(fine->lev, ng) + 255) / 256), (unsigned)fine->lev->boxes.size());
-  hipLaunchKernelGGL(k_fillpatch2, grid, dim3(256), 0, ctx->stream, fine->lev->view, fine->view, crse->lev->view, crse->view, comp, ncomp, ng, ratio,
+  hipLaunchKernelGGL(k_fillpatch2, grid, dim3(256), 0, ctx->stream, fine->lev->view, fine->view, crse->lev->view, crse->view, comp, ccomp - comp, ncomp, ng, ratio,
                      interp_type, ctx->d_flags);
   PA_HIP(hipGetLastError());
   return 0;

@@ -13,6 +13,7 @@
 // It works from a resolved copy of c (FillBoundary(2) + applyBC on faces and edge ghosts) that only
 // needs to be valid in a shell around the box faces.
 #include "pa_internal.h"
+#include "pa_dist.h"
 #include "pa_fabview.h"
 #include "pa_fused_march.h"
 #include "pa_fused_march3.h"
@@ -388,6 +389,7 @@ extern "C" int pa_gradcurv_level(pa_ctx* ctx, const pa_mf* phi, int pcomp, doubl
   if (pcomp < 0 || pcomp >= phi->ncomp || ocomp < 0 || ocomp + 8 > out->ncomp) return pa_fail(ctx, "pa_gradcurv_level: component range");
   if (!(pmax > pmin)) return pa_fail(ctx, "pa_gradcurv_level: progress variable has no range");
   const pa_level* L = phi->lev;
+  if (phi->lev->boxes.empty()) return 0;  // a rank that owns no box of this level
   LevelBP2 bp{L->view, phi->view, out->view};
   MarchArgs A{pcomp, ocomp, fused_kseg(), pmin, 1.0 / (pmax - pmin), thr, 0, 1, 1, 1};
   bool pair_ok = (out->ng % 2 == 0);
@@ -422,6 +424,8 @@ int pa_gradcurv_faces_phase(pa_ctx* ctx, const pa_mf* c, int ccomp, const pa_mf*
   for (const DBox& B : L->boxes)
     for (int d = 0; d < 3; ++d)
       if (crse_n && B.hi[d] - B.lo[d] + 1 < 3) return pa_fail(ctx, "pa_gradcurv_faces_level: boxes thinner than 3 cells need the pass-by-pass path");
+  // sharded coarse level: the three components of the coarse normal from this rank's coarse-source copy
+  if (crse_n && (phase & 2) && pa_coarse_source(ctx, L, crse_n, cncomp0, 3, 0, 0, 0, &crse_n, &cncomp0)) return 1;
   FaceArgs A;
   for (int d = 0; d < 3; ++d) A.bc[d] = bc[d];
   A.ratio = ratio; A.has_crse = crse_n ? 1 : 0; A.thr = thr; A.layers = 2; A.perim_only = 0;

@@ -2,7 +2,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <map>
+#include <memory>
 #include <string>
+#include <utility>
 #include <vector>
 #include "../../include/peleanalysis_amd.h"
 
@@ -55,6 +58,10 @@ struct pa_ctx {
   hipStream_t stream2 = nullptr;
   std::vector<hipStream_t> lev_streams;  // one per level: level-concurrent boundary kernels (pa_pipeline.hip)
   std::vector<hipEvent_t> sync_evs;
+  // transport between the ranks that share a sharded hierarchy (pa_dist.hip): caller-supplied (pa_ctx_set_comm)
+  // or the built-in RCCL one (pa_ctx_init_rccl)
+  pa_comm comm = {nullptr, 0, 1, nullptr, nullptr};
+  struct RcclState* rccl = nullptr;
 };
 
 // RAII: records an event pair around a tagged kernel launch when profiling is enabled
@@ -75,7 +82,7 @@ struct ProfScope {
   }
 };
 enum { PA_TAG_GRADCURV = 1, PA_TAG_GRADCURV_FACES = 2, PA_TAG_FILL = 3, PA_TAG_BC = 4, PA_TAG_GRAD = 5, PA_TAG_PROGRESS = 6,
-       PA_TAG_FILTER = 7, PA_TAG_MC = 8 };
+       PA_TAG_FILTER = 7, PA_TAG_MC = 8, PA_TAG_XCHG = 9 };
 
 struct pa_level {
   pa_ctx* ctx = nullptr;
@@ -94,9 +101,34 @@ struct pa_level {
   int maxn[3] = {0, 0, 0};  // max box extent per dim
   long long ncells = 0;
   bool fusable = true;      // no concave coarse-fine corner (see pa_level_create)
-  int nremote = 0;          // boxes of this level owned by other ranks (pa_level_create_dist)
+  int nremote = 0;          // boxes of this level owned by other ranks (pa_level_create_sharded)
   DLevelView view;
+  // ---- sharding (pa_level_create_sharded): the level's whole BoxArray and its DistributionMapping; `boxes` are the
+  // ones this rank owns, in global order.  Owner-map entries: >= 0 local box, -1 none, -2 - g = global box g of another rank.
+  int rank = 0, nranks = 1;
+  long long serial = 0;            // unique per level object (keys of the plan caches)
+  std::vector<DBox> gboxes;        // global BoxArray (empty for an unsharded level)
+  std::vector<int> gowner;         // owner rank of every global box
+  std::vector<int> gid;            // global index of local box b
+  std::vector<int> glocal;         // local index of global box g, or -1
+  bool source_only = false;        // coarse-source level (pa_dist.hip): no special faces, never swept
+  mutable std::map<int, std::unique_ptr<struct XPlan>> fb_plans;                       // FillBoundary plans by ghost width
+  mutable std::map<std::pair<long long, int>, std::unique_ptr<struct CsPlan>> cs_plans; // coarse-source plans by (coarse level serial, mode)
+  ~pa_level();
 };
+
+struct LevelSpec {
+  std::vector<DBox> local;   // boxes this rank owns
+  std::vector<int> gid;      // their global indices (sharded levels)
+  std::vector<DBox> gboxes;  // the whole BoxArray (sharded levels; empty otherwise)
+  std::vector<int> gowner;
+  int rank = 0, nranks = 1;
+  bool source_only = false;
+};
+pa_level* pa_level_create_spec(pa_ctx* ctx, const LevelSpec& S, const int32_t domlo[3], const int32_t domhi[3], const int32_t is_per[3],
+                               const double prob_lo[3], const double prob_hi[3]);
+bool pa_face_is_special(const pa_level* L, const DBox& B, int d, int side);
+int pa_host_classify(const pa_level* L, int i, int j, int k);
 
 struct pa_mf {
   const pa_level* lev = nullptr;
@@ -176,8 +208,8 @@ __device__ __forceinline__ int owner_of(const DLevelView& L, const int p[3]) {
 __device__ __forceinline__ int classify(const DLevelView& L, int i, int j, int k, int& box, int p[3]) {
   p[0] = i; p[1] = j; p[2] = k;
   if (!wrap_cell(L, p)) return 2;
-  box = owner_of(L, p);  // >= 0: box of this rank; -2: valid cell of a box owned by another rank; -1: none
-  return (box >= 0 || box == -2) ? 0 : 1;
+  box = owner_of(L, p);  // >= 0: box of this rank; <= -2: valid cell of a box owned by another rank; -1: none
+  return (box != -1) ? 0 : 1;
 }
 __device__ __forceinline__ int classify(const DLevelView& L, int i, int j, int k) {
   int b, p[3];

@@ -503,7 +503,7 @@ __global__ __launch_bounds__(64 * TY) void k_mcl_cells(MclArgs A) {
           int p[3] = {(G.slo[0] + ic) * A.ratio, (G.slo[1] + jc) * A.ratio, (G.slo[2] + min(kb + q, nz - 1)) * A.ratio};
           if (wrap_cell(A.LF, p)) {
             const int ow = owner_of(A.LF, p);
-            if (ow >= 0 || ow == -2) m = -1.0;
+            if (ow != -1) m = -1.0;
           }
         }
         mv[q] = m;
@@ -750,7 +750,7 @@ __global__ __launch_bounds__(256) void k_iso_mask(DLevelView L, DMFView M, int c
     int p[3] = {(B.lo[0] - M.ng + (int)(lin - r * nx)) * ratio, (B.lo[1] - M.ng + (int)(r - kk * ny)) * ratio, (B.lo[2] - M.ng + (int)kk) * ratio};
     if (wrap_cell(LF, p)) {  // periodic images of the coarsened fine boxes mask too (isosurface.cpp:1550-1560)
       const int o = owner_of(LF, p);
-      if (o >= 0 || o == -2) v = -1.0;
+      if (o != -1) v = -1.0;
     }
   }
   M.data[M.off[b] + (long long)comp * pa_cstride((long long)nx * ny * nz, M.ncomp) + lin] = v;

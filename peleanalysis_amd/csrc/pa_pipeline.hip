@@ -2,6 +2,7 @@
 // curvature.cpp:283-326 + 408-570) on device-resident MultiFabs.  Host orchestration only;
 // every numeric step is a kernel launch through the level-batched entry points.
 #include "pa_internal.h"
+#include "pa_dist.h"
 #include <cstdlib>
 #include <memory>
 
@@ -9,10 +10,14 @@ int pa_apply_bc_impl(pa_ctx* ctx, pa_mf* F, int comp, const pa_mf* C, int ccomp,
                      int edges, const double* crse_xform);
 int pa_apply_bc_dual(pa_ctx* ctx, pa_mf* F0, int comp0, pa_mf* F1, int comp1, const pa_mf* C, int ccomp, const int32_t bc[3], int ratio,
                      const double* xform);
+int pa_fill_boundary_impl(pa_ctx* ctx, pa_mf* M, int comp, int ncomp, int ng, int no_exchange);
 int pa_gauss_curv_level(pa_ctx* ctx, const pa_mf* G, int gcomp, const pa_mf* normgrad, int ngcomp, const pa_mf* c, int ccomp, double thr, pa_mf* out,
                         int kcomp);
 int pa_strain_level(pa_ctx* ctx, const pa_mf* u, int ucomp, pa_mf* out, int srcomp, int rostcomp);
 int pa_velnormal_level(pa_ctx* ctx, const pa_mf* u, int ucomp, const pa_mf* n, int ncomp0, const pa_mf* c, int ccomp, double thr, pa_mf* out, int ocomp);
+
+int pa_gradcurv_faces_phase(pa_ctx* ctx, const pa_mf* c, int ccomp, const pa_mf* crse_n, int cncomp0, const int32_t bc[3], int ratio, double thr,
+                            pa_mf* out, int ncomp0, int kcomp, int phase);
 
 #define PA_TRY(x)        \
   do {                   \
@@ -22,8 +27,11 @@ int pa_velnormal_level(pa_ctx* ctx, const pa_mf* u, int ucomp, const pa_mf* n, i
 static int check_levels(pa_ctx* ctx, int nlev, pa_mf* const* a, const char* who) {
   if (!ctx) return 1;
   if (nlev <= 0 || !a) return pa_fail(ctx, std::string(who) + ": no levels");
-  for (int l = 0; l < nlev; ++l)
+  for (int l = 0; l < nlev; ++l) {
     if (!a[l]) return pa_fail(ctx, std::string(who) + ": null multifab at level " + std::to_string(l));
+    if (a[l]->lev->nranks != a[0]->lev->nranks) return pa_fail(ctx, std::string(who) + ": levels sharded over different numbers of ranks");
+    if (a[l]->lev->nranks > 1 && a[l]->lev->nranks != ctx->comm.nranks) return pa_fail(ctx, std::string(who) + ": the context's transport has a different number of ranks than the levels");
+  }
   return 0;
 }
 
@@ -54,6 +62,9 @@ static int prog_minmax(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, con
       pmin = a < pmin ? a : pmin;
       pmax = b > pmax ? b : pmax;
     }
+    // ParallelDescriptor::ReduceRealMin / ReduceRealMax (curvature.cpp:147-148)
+    PA_TRY(pa_allreduce(ctx, &pmin, 1, 0));
+    PA_TRY(pa_allreduce(ctx, &pmax, 1, 1));
   }
   if (!(pmax > pmin)) return pa_fail(ctx, "progress variable has no range (progMax <= progMin)");
   return 0;
@@ -133,17 +144,69 @@ static int curvature_passes(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp
   return 0;
 }
 
-static int fused_pre(pa_ctx* ctx, int l, pa_mf* const* state, int comp, const int32_t bc[3], double pmin, double pmax, pa_mf* const* work) {
+// cs: coarse data for the coarse-fine ghost cells of level l -- the coarser level's state, or (sharded hierarchy) this
+// rank's coarse-source copy of its component `comp` with the cross-rank half of FillBoundary already done by the caller
+static int fused_pre(pa_ctx* ctx, int l, pa_mf* const* state, int comp, const int32_t bc[3], double pmin, double pmax, pa_mf* const* work,
+                     const pa_mf* cs_dist = nullptr, bool dist = false) {
   // The stored progress variable (work) is only needed near the special faces (face fix-up).  The
   // coarse-fine boundary values of c are interpolated from the coarse PHI through the affine view
   // (v - pmin) * invdenom, which is bit-identical to a stored coarse c; they read the coarse phi's
   // VALID cells only, so the order relative to applyBC on the coarse phi does not matter.
   const double xf[2] = {pmin, 1.0 / (pmax - pmin)};
-  const pa_mf* cs = l > 0 ? state[l - 1] : nullptr;
-  PA_TRY(pa_fill_boundary(ctx, state[l], comp, 1, 2));
+  const pa_mf* cs = dist ? cs_dist : (l > 0 ? state[l - 1] : nullptr);
+  const int ccomp = dist ? 0 : comp;
+  PA_TRY(pa_fill_boundary_impl(ctx, state[l], comp, 1, 2, dist ? 1 : 0));
+  if (state[l]->lev->boxes.empty()) return 0;
   PA_TRY(pa_progress_shell_level(ctx, state[l], comp, pmin, pmax, work[l], 0, 2, 4));
-  PA_TRY(pa_apply_bc_dual(ctx, state[l], comp, work[l], 0, cs, comp, bc, 2, xf));  // face ghosts of phi and of c, one launch
-  PA_TRY(pa_apply_bc_impl(ctx, work[l], 0, cs, comp, bc, 2, -1, 1, xf));           // edge ghosts of c
+  PA_TRY(pa_apply_bc_dual(ctx, state[l], comp, work[l], 0, cs, ccomp, bc, 2, xf));  // face ghosts of phi and of c, one launch
+  PA_TRY(pa_apply_bc_impl(ctx, work[l], 0, cs, ccomp, bc, 2, -1, 1, xf));           // edge ghosts of c
+  return 0;
+}
+
+// The fused pipeline on a hierarchy sharded over ranks.  Everything a level needs from other ranks depends on VALID cells
+// only, so the cross-rank traffic of a whole pass collapses into TWO grouped exchanges:
+//   A  ghost cells of phi on every level (FillBoundary, 2 layers) + the coarse phi under every fine level's coarse-fine
+//      faces (what setCoarseFineBC / the MLMG boundary registers copy, curvature.cpp:443-445, grad.cpp:212)
+//   B  the coarse flame normal under those faces, once the layer-1 normals of every level are final (curvature.cpp:514-518)
+// with the ghost preparation + sweeps + layer-1 normals of all levels between them and the face curvature after B.
+static int fused_passes_dist(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, const int32_t bc[3], double pmin, double pmax, double thr,
+                             pa_mf* const* work, pa_mf* const* out, int ocomp) {
+  std::vector<XJob> jobs;
+  std::vector<CsPlan*> cs(nlev, nullptr);
+  std::vector<pa_mf*> csphi(nlev, nullptr), csn(nlev, nullptr);
+  for (int l = 0; l < nlev; ++l) {
+    XPlan* P = pa_fb_plan(ctx, state[l]->lev, 2);
+    if (!P) return 1;
+    jobs.push_back({P, state[l], comp, state[l], comp, 1});
+  }
+  for (int l = 1; l < nlev; ++l) {
+    cs[l] = pa_cs_plan(ctx, state[l]->lev, state[l - 1]->lev, 0, 0, 0);
+    if (!cs[l]) return 1;
+    csphi[l] = cs[l]->mf(ctx, 1);
+    csn[l] = cs[l]->mf(ctx, 3);
+    if (cs[l]->cs && (!csphi[l] || !csn[l])) return 1;
+    jobs.push_back({&cs[l]->x, state[l - 1], comp, csphi[l], 0, 1});
+  }
+  {
+    ProfScope prof(ctx, PA_TAG_XCHG);
+    PA_TRY(pa_xexchange(ctx, (int)jobs.size(), jobs.data()));
+  }
+  for (int l = 0; l < nlev; ++l) PA_TRY(fused_pre(ctx, l, state, comp, bc, pmin, pmax, work, csphi[l], true));
+  for (int l = 0; l < nlev; ++l) {
+    if (state[l]->lev->boxes.empty()) continue;
+    PA_TRY(pa_gradcurv_level(ctx, state[l], comp, pmin, pmax, thr, out[l], ocomp));
+    PA_TRY(pa_gradcurv_faces_phase(ctx, work[l], 0, nullptr, 0, bc, 2, thr, out[l], ocomp + 4, ocomp + 7, 1));
+  }
+  jobs.clear();
+  for (int l = 1; l < nlev; ++l) jobs.push_back({&cs[l]->x, out[l - 1], ocomp + 4, csn[l], 0, 3});
+  {
+    ProfScope prof(ctx, PA_TAG_XCHG);
+    PA_TRY(pa_xexchange(ctx, (int)jobs.size(), jobs.data()));
+  }
+  for (int l = 0; l < nlev; ++l) {
+    if (state[l]->lev->boxes.empty()) continue;
+    PA_TRY(pa_gradcurv_faces_phase(ctx, work[l], 0, l > 0 ? csn[l] : nullptr, 0, bc, 2, thr, out[l], ocomp + 4, ocomp + 7, 2));
+  }
   return 0;
 }
 
@@ -169,8 +232,6 @@ struct StreamSwap {  // the level entry points launch on ctx->stream
   ~StreamSwap() { c->stream = keep; }
 };
 
-int pa_gradcurv_faces_phase(pa_ctx* ctx, const pa_mf* c, int ccomp, const pa_mf* crse_n, int cncomp0, const int32_t bc[3], int ratio, double thr,
-                            pa_mf* out, int ncomp0, int kcomp, int phase);
 static int fused_faces(pa_ctx* ctx, int l, const int32_t bc[3], double thr, pa_mf* const* work, pa_mf* const* out, int ocomp, int phase = 3) {
   return pa_gradcurv_faces_phase(ctx, work[l], 0, l > 0 ? out[l - 1] : nullptr, ocomp + 4, bc, 2, thr, out[l], ocomp + 4, ocomp + 7, phase);
 }
@@ -251,6 +312,7 @@ static int fused_passes(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, co
                         pa_mf* const* work, pa_mf* const* out, int ocomp) {
   for (int l = 0; l < nlev; ++l)
     if (state[l]->ng < 2 || work[l]->ng < 2) return pa_fail(ctx, "fused grad->curvature needs 2 ghost layers on state and work");
+  if (state[0]->lev->nranks > 1) return fused_passes_dist(ctx, nlev, state, comp, bc, pmin, pmax, thr, work, out, ocomp);
   if (nlev >= 2 && !overlap_on() && conc_on(nlev, state)) return fused_passes_conc(ctx, nlev, state, comp, bc, pmin, pmax, thr, work, out, ocomp);
   if (!overlap_on() || nlev < 2) {
     for (int l = 0; l < nlev; ++l) PA_TRY(fused_pre(ctx, l, state, comp, bc, pmin, pmax, work));
@@ -297,8 +359,8 @@ static int fused_passes(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, co
 static bool all_fusable(int nlev, pa_mf* const* state) {
   for (int l = 0; l < nlev; ++l) {
     if (!state[l]->lev->fusable) return false;
-    if (l > 0)
-      for (const DBox& B : state[l]->lev->boxes)
+    if (l > 0)  // the whole BoxArray of a sharded level: every rank must take the same path
+      for (const DBox& B : (state[l]->lev->gboxes.empty() ? state[l]->lev->boxes : state[l]->lev->gboxes))
         for (int d = 0; d < 3; ++d)
           if (B.hi[d] - B.lo[d] + 1 < 3) return false;
   }

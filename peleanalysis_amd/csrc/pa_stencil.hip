@@ -87,6 +87,7 @@ extern "C" int pa_grad_level(pa_ctx* ctx, const pa_mf* phi, int comp, pa_mf* out
   if (comp < 0 || comp >= phi->ncomp || ocomp < 0 || ocomp + 4 > out->ncomp) return pa_fail(ctx, "pa_grad_level: component range");
   LevelBP2 bp{phi->lev->view, phi->view, out->view};
   const pa_level* L = phi->lev;
+  if (phi->lev->boxes.empty()) return 0;  // a rank that owns no box of this level
   ProfScope prof(ctx, PA_TAG_GRAD);
   grad_launch(ctx->stream, bp, L->maxn[0], L->maxn[1], L->maxn[2], (unsigned)L->boxes.size(), comp, ocomp);
   PA_HIP(hipGetLastError());
@@ -143,6 +144,7 @@ extern "C" int pa_minmax_level(pa_ctx* ctx, const pa_mf* s, int comp, double* mn
   if (comp < 0 || comp >= s->ncomp) return pa_fail(ctx, "pa_minmax_level: component range");
   const unsigned nb = (unsigned)s->lev->boxes.size();
   const unsigned gx = 32;
+  if (nb == 0) { *mn = DBL_MAX; *mx = -DBL_MAX; return 0; }  // a rank that owns no box of this level (the caller reduces over the ranks)
   if (pa_ensure_red(ctx, 2 * (size_t)gx * nb)) return 1;
   hipLaunchKernelGGL(k_minmax, dim3(gx, nb), dim3(256), 0, ctx->stream, s->lev->view, s->view, comp, ctx->d_red);
   PA_HIP(hipGetLastError());
@@ -174,6 +176,7 @@ extern "C" int pa_progress_level(pa_ctx* ctx, const pa_mf* s, int comp, double p
   if (s->lev != c->lev) return pa_fail(ctx, "pa_progress_level: different levels");
   if (ng > s->ng || ng > c->ng || comp >= s->ncomp || ccomp >= c->ncomp) return pa_fail(ctx, "pa_progress_level: ng/component range");
   const double invdenom = 1.0 / (pmax - pmin);  // curvature.cpp:315 (quirk Q13: multiply, not divide)
+  if (s->lev->boxes.empty()) return 0;  // a rank that owns no box of this level
   LevelBP2 bp{s->lev->view, s->view, c->view, ng};
   ProfScope prof(ctx, PA_TAG_PROGRESS);
   hipLaunchKernelGGL(k_progress<LevelBP2>, tile_grid(s->lev, ng), dim3(256), 0, ctx->stream, bp, comp, ccomp, pmin, invdenom);
@@ -230,6 +233,7 @@ extern "C" int pa_normal_level(pa_ctx* ctx, const pa_mf* c, int comp, pa_mf* G, 
   if (comp >= c->ncomp || ncomp0 + 3 > n->ncomp || (G && gcomp + 3 > G->ncomp) || (normgrad && ngcomp >= normgrad->ncomp))
     return pa_fail(ctx, "pa_normal_level: component range");
   DMFView none{nullptr, nullptr, 0, 0};
+  if (c->lev->boxes.empty()) return 0;  // a rank that owns no box of this level
   LevelBP4 bp{c->lev->view, c->view, G ? G->view : none, normgrad ? normgrad->view : none, n->view};
   hipLaunchKernelGGL(k_normal<LevelBP4>, tile_grid(c->lev), dim3(256), 0, ctx->stream, bp, comp, gcomp, ngcomp, ncomp0);
   PA_HIP(hipGetLastError());
@@ -296,6 +300,7 @@ extern "C" int pa_div_level(pa_ctx* ctx, pa_mf* n, int ncomp0, double scale, con
   if (n->ng < 1) return pa_fail(ctx, "pa_div_level: n needs >= 1 ghost layer");
   if (n->lev != K->lev || (c && c->lev != n->lev)) return pa_fail(ctx, "pa_div_level: different levels");
   if (ncomp0 + 3 > n->ncomp || kcomp >= K->ncomp) return pa_fail(ctx, "pa_div_level: component range");
+  if (n->lev->boxes.empty()) return 0;  // a rank that owns no box of this level
   LevelBP2 bp{n->lev->view, n->view, K->view};
   hipLaunchKernelGGL(k_div<LevelBP2>, tile_grid(n->lev), dim3(256), 0, ctx->stream, bp, ncomp0, kcomp, scale);
   PA_HIP(hipGetLastError());

@@ -1,206 +1,192 @@
-"""Multi-GPU sharding of a level's BoxArray (one process per GPU) and the cross-rank half of
-FillBoundary.
+"""One AMR hierarchy sharded over ranks (one process per GPU): the host-side mirror of the multi-GPU part of the C ABI.
 
-The reference distributes boxes with AMReX `DistributionMapping(ba)` over MPI ranks and exchanges
-ghost cells with point-to-point messages inside `FabArray::FillBoundary` (grad.cpp:162,169;
-SURVEY 2.1).  Here each rank owns a subset of the boxes; for every (destination box, source box,
-periodic shift) pair that lives on two different ranks both sides derive the same region list in
-the same order, the sender packs its regions into ONE buffer per peer
-(`pa_pack_regions`), the buffers travel with `torch.distributed` point-to-point ops (backend
-"nccl" = RCCL over xGMI on the GPU box; "gloo" in the CPU tests) and the receiver scatters them
-into its ghost cells (`pa_unpack_regions`).  No other collective is on the data path.
+The reference distributes the boxes of every level with AMReX `DistributionMapping(ba)` over MPI ranks and moves
+ghost data with point-to-point messages inside `FabArray::FillBoundary`, `FillPatchTwoLevels` and the MLMG boundary
+registers (grad.cpp:162,169,212; curvature.cpp:289,443-445,514-518).  The library does all of that
+itself once a level is created with its whole BoxArray + owner map (`capi.DevLevel(ctx, level, owner, rank, nranks)`)
+and the context has a transport:
+
+* `init_rccl(ctx)`: the built-in one -- RCCL over xGMI, grouped ncclSend/ncclRecv issued by the library on its own
+  stream; torch.distributed is only used here to broadcast the 128-byte communicator id;
+* `GlooComm`: a `pa_comm` whose callbacks stage the packed buffers through host memory and a gloo group -- what the
+  tests use when several ranks share one GPU (RCCL wants one GPU per rank), and bench.py's fallback.
+
+Everything else in this file is host arithmetic for tests: the owner map (`pa_distribution_map`), the region lists
+behind the exchanges (`pa_plan_*`), and numpy pack / unpack.
 """
 from __future__ import annotations
 
-import dataclasses
-import itertools
-from typing import Dict, List, Optional, Sequence
+import ctypes as C
+import traceback
+from typing import Dict, List, Sequence
 
 import numpy as np
 
-from .hierarchy import Hierarchy, Level, MultiFab, chop_box
+from . import capi
+from .hierarchy import Hierarchy, Level, MultiFab
 
 
-@dataclasses.dataclass
-class ExchangePlan:
-    """regions7 rows = [local box index, lo0, lo1, lo2, hi0, hi1, hi2] in that box's index space"""
-    send: Dict[int, np.ndarray]  # peer -> (n,7) int32: what to pack for that peer (source regions)
-    recv: Dict[int, np.ndarray]  # peer -> (n,7) int32: where that peer's buffer goes (ghost regions)
-
-    def size(self, regs: np.ndarray, ncomp: int) -> int:
-        if len(regs) == 0:
-            return 0
-        n = regs[:, 4:7].astype(np.int64) - regs[:, 1:4] + 1
-        return int(ncomp * np.prod(n, axis=1).sum())
+def _pi32(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
 
 
-def build_plan(boxes: np.ndarray, owner: Sequence[int], domlo, domhi, is_per, rank: int, ng: int) -> ExchangePlan:
-    """Region lists for `rank`.  Pairs are enumerated in (dst box, src box, shift) order on every rank,
-    so the sender's pack order equals the receiver's unpack order."""
-    boxes = np.asarray(boxes, dtype=np.int64).reshape(-1, 6)
-    owner = np.asarray(owner)
-    domlo, domhi = np.asarray(domlo, dtype=np.int64), np.asarray(domhi, dtype=np.int64)
-    length = domhi - domlo + 1
-    local_index = {int(g): i for i, g in enumerate(np.nonzero(owner == rank)[0])}
-    shifts = [np.array(s) * length for s in itertools.product(*[((-1, 0, 1) if is_per[d] else (0,)) for d in range(3)])]
-    send: Dict[int, List[List[int]]] = {}
-    recv: Dict[int, List[List[int]]] = {}
-    for d in range(len(boxes)):
-        glo, ghi = boxes[d, :3] - ng, boxes[d, 3:] + ng
-        for s in range(len(boxes)):
-            if owner[d] == owner[s] or (owner[d] != rank and owner[s] != rank):
-                continue
-            for sh in shifts:
-                lo = np.maximum(glo, boxes[s, :3] + sh)
-                hi = np.minimum(ghi, boxes[s, 3:] + sh)
-                if np.any(lo > hi):
-                    continue
-                if owner[d] == rank:  # I receive ghost cells of my box d from owner[s]
-                    recv.setdefault(int(owner[s]), []).append([local_index[d], *lo, *hi])
-                else:                 # I send valid cells of my box s (un-shifted) to owner[d]
-                    send.setdefault(int(owner[d]), []).append([local_index[s], *(lo - sh), *(hi - sh)])
-    to_arr = lambda d: {p: np.asarray(v, dtype=np.int32).reshape(-1, 7) for p, v in d.items()}
-    return ExchangePlan(to_arr(send), to_arr(recv))
+def _i3(v):
+    return (C.c_int32 * 3)(*[int(x) for x in v])
 
 
-# ------------------------------------------------------------------------------- host backend
-def host_pack(mf: MultiFab, comp: int, ncomp: int, regs: np.ndarray) -> np.ndarray:
-    out = []
-    for r in regs:
-        b = int(r[0])
-        f = mf.fab(b)
-        o = mf.level.boxes[b, :3] - mf.ng
-        out.append(f[comp:comp + ncomp, r[3] - o[2]:r[6] - o[2] + 1, r[2] - o[1]:r[5] - o[1] + 1, r[1] - o[0]:r[4] - o[0] + 1].ravel())
-    return np.concatenate(out) if out else np.zeros(0)
+def distribution_map(boxes: np.ndarray, nranks: int) -> np.ndarray:
+    """DistributionMapping(ba) restated (pa_distribution_map): Morton order of the boxes' low corners cut into nranks
+    contiguous pieces of equal cell count.  Host arithmetic (no GPU needed)."""
+    lib = capi.load_library()
+    b = np.ascontiguousarray(boxes, dtype=np.int32).reshape(-1, 6)
+    owner = np.zeros(len(b), dtype=np.int32)
+    if lib.pa_distribution_map(len(b), _pi32(b), int(nranks), _pi32(owner)) != 0:
+        raise ValueError("pa_distribution_map: bad arguments")
+    return owner
 
 
-def host_unpack(mf: MultiFab, comp: int, ncomp: int, regs: np.ndarray, buf: np.ndarray) -> None:
-    p = 0
-    for r in regs:
-        b = int(r[0])
-        f = mf.fab(b)
-        o = mf.level.boxes[b, :3] - mf.ng
-        shp = (ncomp, r[6] - r[3] + 1, r[5] - r[2] + 1, r[4] - r[1] + 1)
-        n = int(np.prod(shp))
-        f[comp:comp + ncomp, r[3] - o[2]:r[6] - o[2] + 1, r[2] - o[1]:r[5] - o[1] + 1, r[1] - o[0]:r[4] - o[0] + 1] = buf[p:p + n].reshape(shp)
-        p += n
+def shard(H: Hierarchy, nranks: int) -> List[np.ndarray]:
+    """owner map of every level of a hierarchy"""
+    return [distribution_map(lv.boxes, nranks) for lv in H.levels]
 
 
-def exchange(plan: ExchangePlan, ncomp: int, pack, unpack, make_buffer, device=None) -> None:
-    """One ghost exchange: pack(regs) -> 1-D float64 torch tensor, unpack(regs, tensor).  Point-to-point
-    sends/recvs batched per peer (`batch_isend_irecv`: grouped ncclSend/ncclRecv on RCCL)."""
-    import torch.distributed as dist
-    peers = sorted(set(plan.send) | set(plan.recv))
-    if not peers:
-        return
-    ops, rbufs = [], {}
-    for p in peers:
-        if p in plan.send:
-            ops.append(dist.P2POp(dist.isend, pack(plan.send[p]), p))
-        if p in plan.recv:
-            rbufs[p] = make_buffer(plan.size(plan.recv[p], ncomp))
-            ops.append(dist.P2POp(dist.irecv, rbufs[p], p))
-    for req in dist.batch_isend_irecv(ops):
-        req.wait()
-    if device is not None:
-        import torch
-        torch.cuda.synchronize(device)
-    for p, t in rbufs.items():
-        unpack(plan.recv[p], t)
+def _rows(fn, *args) -> np.ndarray:
+    n = fn(*args, None, 0)
+    if n < 0:
+        raise ValueError("plan: bad arguments")
+    rows = np.zeros((max(n, 1), 9), dtype=np.int32)
+    fn(*args, _pi32(rows), n)
+    return rows[:n]
 
 
-def exchange_host(plan: ExchangePlan, mf: MultiFab, comp: int, ncomp: int) -> None:
-    import torch
-    exchange(plan, ncomp,
-             pack=lambda regs: torch.from_numpy(host_pack(mf, comp, ncomp, regs).copy()),
-             unpack=lambda regs, t: host_unpack(mf, comp, ncomp, regs, t.numpy()),
-             make_buffer=lambda n: torch.empty(n, dtype=torch.float64))
+def plan_fill_boundary(level: Level, owner: Sequence[int], rank: int, ng: int) -> np.ndarray:
+    """rows {kind (0 send, 1 recv), peer, global box, lo[3], hi[3]} of the cross-rank half of FillBoundary(ng) for `rank`"""
+    lib = capi.load_library()
+    b = np.ascontiguousarray(level.boxes, dtype=np.int32)
+    o = np.ascontiguousarray(owner, dtype=np.int32)
+    return _rows(lib.pa_plan_fill_boundary, level.nboxes, _pi32(b), _pi32(o), int(rank), _i3(level.domlo), _i3(level.domhi), _i3(level.is_per), int(ng))
 
 
-def exchange_device(plan: ExchangePlan, ctx, dmf, comp: int, ncomp: int, device) -> None:
-    """device path: HIP pack/unpack kernels around RCCL point-to-point"""
-    import ctypes as C
-
-    import torch
-
-    def pack(regs):
-        t = torch.empty(plan.size(regs, ncomp), dtype=torch.float64, device=device)
-        r = np.ascontiguousarray(regs, dtype=np.int32)
-        ctx.check(ctx.lib.pa_pack_regions(ctx.h, dmf.h, comp, ncomp, len(r), r.ctypes.data_as(C.POINTER(C.c_int32)), t.data_ptr()))
-        return t
-
-    def unpack(regs, t):
-        r = np.ascontiguousarray(regs, dtype=np.int32)
-        ctx.check(ctx.lib.pa_unpack_regions(ctx.h, dmf.h, comp, ncomp, len(r), r.ctypes.data_as(C.POINTER(C.c_int32)), t.data_ptr()))
-
-    exchange(plan, ncomp, pack, unpack, lambda n: torch.empty(n, dtype=torch.float64, device=device), device=device)
+def plan_coarse_source(fine: Level, fowner, crse: Level, cowner, rank: int, mode: int = 0, ng: int = 0, halo: int = 0) -> np.ndarray:
+    """rows {kind, peer, global coarse box, lo[3], hi[3]}: kind 2 = a piece of the coarse level `rank` keeps a copy of (peer =
+    owner of the coarse box), in the order of the rank's coarse-source BoxArray; kind 0 = what `rank` sends to `peer`"""
+    lib = capi.load_library()
+    fb, cb = np.ascontiguousarray(fine.boxes, dtype=np.int32), np.ascontiguousarray(crse.boxes, dtype=np.int32)
+    fo, co = np.ascontiguousarray(fowner, dtype=np.int32), np.ascontiguousarray(cowner, dtype=np.int32)
+    return _rows(lib.pa_plan_coarse_source, fine.nboxes, _pi32(fb), _pi32(fo), _i3(fine.domlo), _i3(fine.domhi), crse.nboxes, _pi32(cb), _pi32(co),
+                 _i3(crse.domlo), _i3(crse.domhi), _i3(fine.is_per), int(rank), int(mode), int(ng), int(halo))
 
 
-def exchange_device_staged(plan: ExchangePlan, ctx, dmf, comp: int, ncomp: int, device, group=None) -> None:
-    """same region lists and HIP pack/unpack kernels, but the packed buffers travel through host
-    memory and a gloo group (fallback when RCCL point-to-point is unavailable; single-GPU tests)"""
-    import ctypes as C
+# ------------------------------------------------------------------------------- numpy pack / unpack (CPU-tier tests)
+def host_region(mf: MultiFab, b: int, lo, hi, comp: int, ncomp: int) -> np.ndarray:
+    """view of components comp..comp+ncomp of box b (local index) over the index-space region lo..hi (ghost cells allowed)"""
+    o = mf.level.boxes[b, :3] - mf.ng
+    return mf.fab(b)[comp:comp + ncomp, lo[2] - o[2]:hi[2] - o[2] + 1, lo[1] - o[1]:hi[1] - o[1] + 1, lo[0] - o[0]:hi[0] - o[0] + 1]
 
+
+def host_exchange(rows: np.ndarray, glocal: Dict[int, int], src: MultiFab, dst: MultiFab, comp: int, ncomp: int, recv_kind: int = 1, recv_box=None) -> None:
+    """the exchange a plan describes, through torch.distributed point-to-point ops on host tensors: one message per peer,
+    regions in row order on both sides.  glocal: global box index -> local index in src (send rows); recv rows address dst
+    through glocal too (FillBoundary) or through recv_box(row index among the rank's kind-2 rows) (coarse source)."""
     import torch
     import torch.distributed as dist
-
-    peers = sorted(set(plan.send) | set(plan.recv))
-    if not peers:
-        return
+    me = dist.get_rank()
+    send: Dict[int, list] = {}
+    recv: Dict[int, list] = {}
+    npiece = 0
+    for r in rows:
+        kind, peer, box = int(r[0]), int(r[1]), int(r[2])
+        if kind == 0:
+            send.setdefault(peer, []).append(host_region(src, glocal[box], r[3:6], r[6:9], comp, ncomp).ravel().copy())
+        elif kind == recv_kind:
+            b = glocal[box] if recv_box is None else recv_box(npiece)
+            npiece += 1
+            if peer == me:  # a piece cut from a coarse box this rank owns itself: local copy
+                host_region(dst, b, r[3:6], r[6:9], 0 if recv_box else comp, ncomp)[...] = host_region(src, glocal[box], r[3:6], r[6:9], comp, ncomp)
+            else:
+                recv.setdefault(peer, []).append((b, r[3:6].copy(), r[6:9].copy()))
     ops, rb = [], {}
-    for p in peers:
-        if p in plan.send:
-            regs = np.ascontiguousarray(plan.send[p], dtype=np.int32)
-            t = torch.empty(plan.size(regs, ncomp), dtype=torch.float64, device=device)
-            ctx.check(ctx.lib.pa_pack_regions(ctx.h, dmf.h, comp, ncomp, len(regs), regs.ctypes.data_as(C.POINTER(C.c_int32)), t.data_ptr()))
-            ops.append(dist.P2POp(dist.isend, t.cpu(), p, group=group))
-        if p in plan.recv:
-            rb[p] = torch.empty(plan.size(plan.recv[p], ncomp), dtype=torch.float64)
-            ops.append(dist.P2POp(dist.irecv, rb[p], p, group=group))
-    for q in dist.batch_isend_irecv(ops):
-        q.wait()
+    for p in sorted(set(send) | set(recv)):
+        if p in send:
+            ops.append(dist.P2POp(dist.isend, torch.from_numpy(np.concatenate(send[p])), p))
+        if p in recv:
+            n = sum(int(np.prod(hi - lo + 1)) * ncomp for _, lo, hi in recv[p])
+            rb[p] = torch.empty(n, dtype=torch.float64)
+            ops.append(dist.P2POp(dist.irecv, rb[p], p))
+    if ops:
+        for q in dist.batch_isend_irecv(ops):
+            q.wait()
     for p, t in rb.items():
-        d = t.to(device)
-        torch.cuda.synchronize(device)
-        regs = np.ascontiguousarray(plan.recv[p], dtype=np.int32)
-        ctx.check(ctx.lib.pa_unpack_regions(ctx.h, dmf.h, comp, ncomp, len(regs), regs.ctypes.data_as(C.POINTER(C.c_int32)), d.data_ptr()))
+        a, at = t.numpy(), 0
+        for b, lo, hi in recv[p]:
+            v = host_region(dst, b, lo, hi, 0 if recv_box else comp, ncomp)
+            v[...] = a[at:at + v.size].reshape(v.shape)
+            at += v.size
 
 
-# ------------------------------------------------------------------------------- slab decomposition
-@dataclasses.dataclass
-class RankLevels:
-    glob: Hierarchy                 # the global hierarchy (all boxes of all ranks)
-    owner: List[np.ndarray]         # per level: owner rank of every global box
-    local: Hierarchy                # this rank's boxes
-    remote: List[np.ndarray]        # per level: boxes owned by other ranks
-    plans: List[ExchangePlan]
+# ------------------------------------------------------------------------------- transports
+def init_rccl(ctx: "capi.Context", group=None) -> None:
+    """built-in RCCL transport: rank 0 creates the communicator id, torch.distributed (any backend) broadcasts it"""
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    ids = [ctx.rccl_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(ids, src=0, group=group)
+    ctx.init_rccl(world, rank, ids[0])
 
 
-def slab_hierarchy(base_n: int, nlev: int, box: int, nranks: int, rank: int, ng: int, is_per=(1, 1, 0)) -> RankLevels:
-    """Weak-scaling workload: `nranks` copies of the nested 3-level hierarchy side by side in x
-    (global base level (nranks*base_n) x base_n x base_n, periodic in x); rank r owns slab r on every level.
-    The only cross-rank ghost cells are on the level-0 slab faces."""
-    glob_levels, owners, loc_levels, remotes, plans = [], [], [], [], []
-    lo = np.zeros(3, dtype=np.int64)
-    hi = np.full(3, base_n - 1, dtype=np.int64)
-    n0 = base_n
-    for l in range(nlev):
-        boxes, own = [], []
-        for r in range(nranks):
-            off = np.array([r * n0, 0, 0])
-            boxes.append(chop_box(lo + off, hi + off, box))
-            own.append(np.full(len(boxes[-1]), r))
-        boxes, own = np.vstack(boxes), np.concatenate(own)
-        domlo, domhi = np.zeros(3, dtype=np.int64), np.array([nranks * n0 - 1, n0 - 1, n0 - 1])
-        prob_hi = (float(nranks), 1.0, 1.0)
-        glob_levels.append(Level(boxes, domlo, domhi, is_per, (0.0, 0.0, 0.0), prob_hi))
-        owners.append(own)
-        loc_levels.append(Level(boxes[own == rank], domlo, domhi, is_per, (0.0, 0.0, 0.0), prob_hi))
-        remotes.append(boxes[own != rank])
-        plans.append(build_plan(boxes, own, domlo, domhi, is_per, rank, ng))
-        n = hi - lo + 1
-        clo = lo + n // 4
-        chi = clo + n // 2 - 1
-        lo, hi = 2 * clo, 2 * chi + 1
-        n0 *= 2
-    return RankLevels(Hierarchy(glob_levels, 2), owners, Hierarchy(loc_levels, 2), remotes, plans)
+class GlooComm:
+    """pa_comm over a torch.distributed group with host tensors (gloo): packed device buffers are staged through host
+    memory.  For ranks that share a GPU (tests, rehearsals) and as the fallback when RCCL point-to-point is unavailable."""
+
+    def __init__(self, ctx: "capi.Context", group=None):
+        import torch
+        import torch.distributed as dist
+        self.ctx, self.group, self.torch, self.dist = ctx, group, torch, dist
+        self.rank, self.nranks = dist.get_rank(group), dist.get_world_size(group)
+        self.nexchange = 0
+        self.bytes_sent = 0
+        self._ex = capi.EXCHANGE_FN(self._exchange)
+        self._ar = capi.ALLREDUCE_FN(self._allreduce)
+        self.comm = capi.PaComm(None, self.rank, self.nranks, self._ex, self._ar)
+        ctx.set_comm(self.comm)
+
+    def _exchange(self, user, stream, n, x):
+        try:
+            torch, dist, lib, h = self.torch, self.dist, self.ctx.lib, self.ctx.h
+            ops, recvs, keep = [], [], []
+            for i in range(n):
+                xi = x[i]
+                if xi.nsend > 0:
+                    a = np.empty(xi.nsend, dtype=np.float64)
+                    if lib.pa_memcpy_d2h(h, a.ctypes.data_as(C.c_void_p), C.c_void_p(xi.sendbuf), 8 * xi.nsend) != 0:  # synchronises the stream
+                        return 1
+                    keep.append(a)
+                    ops.append(dist.P2POp(dist.isend, torch.from_numpy(a), xi.peer, group=self.group))
+                    self.bytes_sent += 8 * xi.nsend
+                if xi.nrecv > 0:
+                    t = torch.empty(xi.nrecv, dtype=torch.float64)
+                    recvs.append((xi.recvbuf, t))
+                    ops.append(dist.P2POp(dist.irecv, t, xi.peer, group=self.group))
+            if ops:
+                for q in dist.batch_isend_irecv(ops):
+                    q.wait()
+            for ptr, t in recvs:
+                a = t.numpy()
+                if lib.pa_memcpy_h2d(h, C.c_void_p(ptr), a.ctypes.data_as(C.c_void_p), a.nbytes) != 0:
+                    return 1
+            self.nexchange += 1
+            return 0
+        except Exception:  # never let an exception cross the C boundary
+            traceback.print_exc()
+            return 1
+
+    def _allreduce(self, user, vals, n, op):
+        try:
+            t = self.torch.tensor([vals[i] for i in range(n)], dtype=self.torch.float64)
+            self.dist.all_reduce(t, op=(self.dist.ReduceOp.MIN, self.dist.ReduceOp.MAX, self.dist.ReduceOp.SUM)[op], group=self.group)
+            for i in range(n):
+                vals[i] = float(t[i])
+            return 0
+        except Exception:
+            traceback.print_exc()
+            return 1

@@ -1,14 +1,17 @@
-"""N > 1 path on CPU: two ranks (gloo) each own one slab of the level BoxArray; after the local
-FillBoundary + the cross-rank exchange (same region lists the HIP pack/unpack kernels consume) every
-ghost cell equals what FillBoundary on the undistributed level gives."""
+"""N > 1 path on the CPU tier: the owner map, the region lists behind the cross-rank exchanges (host arithmetic of the
+C ABI, no GPU) and -- with 2 and 4 gloo ranks -- the data movement itself on a hierarchy whose owner map is SCATTERED
+(neighbouring boxes and the coarse parents of most fine boxes live on other ranks): after the local FillBoundary + the
+exchange every ghost cell equals what FillBoundary on the undistributed level gives, every cell of a rank's coarse-source
+copy equals the undistributed coarse level, and the min / max reduction equals the global one."""
 import os
 import socket
+import sys
 
 import numpy as np
 import pytest
 
 from peleanalysis_amd import dist as padist
-from peleanalysis_amd.hierarchy import MultiFab, cell_centers
+from peleanalysis_amd.hierarchy import Level, MultiFab, cell_centers, nested_hierarchy
 
 
 def _free_port():
@@ -20,7 +23,7 @@ def _free_port():
 
 
 def _field(x, y, z, c):
-    return (1 + c) * (np.sin(2 * np.pi * x / 2.0) + 0.3 * np.cos(2 * np.pi * y) + z * z) + 0 * x * y * z
+    return (1 + c) * (np.sin(2 * np.pi * x) + 0.3 * np.cos(2 * np.pi * y) + z * z) + 0 * x * y * z
 
 
 def _fill(mf):
@@ -30,57 +33,182 @@ def _fill(mf):
             mf.valid(b)[c] = _field(x, y, z, c)
 
 
+def scattered_owner(n, nranks, seed):
+    """every rank owns boxes all over the level (the opposite of a space-filling-curve map)"""
+    rng = np.random.default_rng(seed)
+    o = np.arange(n) % nranks
+    rng.shuffle(o)
+    return o.astype(np.int32)
+
+
+def _sub_level(lv, idx):
+    return Level(lv.boxes[idx], lv.domlo, lv.domhi, lv.is_per, lv.prob_lo, lv.prob_hi)
+
+
+def test_distribution_map_is_balanced_and_follows_the_morton_curve():
+    H = nested_hierarchy(64, 2, 16)  # 64 boxes per level
+    for lv in H.levels:
+        for n in (1, 2, 3, 4, 8):
+            o = padist.distribution_map(lv.boxes, n)
+            cnt = np.bincount(o, minlength=n)
+            assert cnt.sum() == lv.nboxes and cnt.max() - cnt.min() <= 1
+        # 8 ranks on a 4 x 4 x 4 arrangement of equal boxes: every rank gets one 2 x 2 x 2 block (a Morton octant)
+        o = padist.distribution_map(lv.boxes, 8)
+        for r in range(8):
+            bx = lv.boxes[o == r]
+            assert np.all(bx[:, 3:].max(0) - bx[:, :3].min(0) + 1 == 32)
+    # unequal boxes: cell counts, not box counts, are balanced
+    boxes = np.array([[0, 0, 0, 31, 31, 31], [32, 0, 0, 47, 15, 15], [32, 16, 0, 47, 31, 15], [32, 0, 16, 47, 15, 31], [32, 16, 16, 47, 31, 31],
+                      [48, 0, 0, 63, 31, 31]], dtype=np.int32)
+    o = padist.distribution_map(boxes, 2)
+    vol = np.prod(boxes[:, 3:] - boxes[:, :3] + 1, axis=1)
+    assert abs(vol[o == 0].sum() - vol[o == 1].sum()) <= vol.max()
+
+
+@pytest.mark.parametrize("nranks", [2, 3, 4])
+@pytest.mark.parametrize("ng", [1, 2])
+def test_fill_boundary_plans_are_symmetric_and_ordered(nranks, ng):
+    """rank a's send list for b holds the same shapes, in the same order, as b's receive list from a (both sides enumerate
+    (destination box, source box, periodic shift) identically), and a sent region is the received one minus a period"""
+    H = nested_hierarchy(16, 2, 8, is_per=(1, 1, 0))
+    for li, lv in enumerate(H.levels):
+        own = scattered_owner(lv.nboxes, nranks, 5 + li)
+        rows = [padist.plan_fill_boundary(lv, own, r, ng) for r in range(nranks)]
+        for a in range(nranks):
+            for b in range(nranks):
+                if a == b:
+                    continue
+                s = rows[a][(rows[a][:, 0] == 0) & (rows[a][:, 1] == b)]
+                r = rows[b][(rows[b][:, 0] == 1) & (rows[b][:, 1] == a)]
+                assert len(s) == len(r) and len(s) > 0
+                assert np.array_equal(s[:, 6:9] - s[:, 3:6], r[:, 6:9] - r[:, 3:6])
+                n = lv.domhi - lv.domlo + 1
+                assert np.all((r[:, 3:6] - s[:, 3:6]) % n == 0)
+                assert np.all(own[s[:, 2]] == a) and np.all(own[r[:, 2]] == b)
+
+
+def _cf_ghost_cells(lv, gbox):
+    """ring-1 face ghost cells of a box that are inside the domain (periodic wrap applied) and covered by no box of the level"""
+    covered = np.zeros(tuple(lv.domhi - lv.domlo + 1)[::-1], bool)
+    for b in lv.boxes:
+        covered[b[2]:b[5] + 1, b[1]:b[4] + 1, b[0]:b[3] + 1] = True
+    lo, hi = lv.boxes[gbox, :3], lv.boxes[gbox, 3:]
+    n = lv.domhi - lv.domlo + 1
+    out = []
+    for d in range(3):
+        for side in (0, 1):
+            for v in range(lo[(d + 2) % 3], hi[(d + 2) % 3] + 1):
+                for u in range(lo[(d + 1) % 3], hi[(d + 1) % 3] + 1):
+                    q = [0, 0, 0]
+                    q[d] = hi[d] + 1 if side else lo[d] - 1
+                    q[(d + 1) % 3], q[(d + 2) % 3] = u, v
+                    p = list(q)
+                    ok = True
+                    for t in range(3):
+                        if p[t] < lv.domlo[t] or p[t] > lv.domhi[t]:
+                            if not lv.is_per[t]:
+                                ok = False
+                            p[t] = (p[t] - lv.domlo[t]) % n[t] + lv.domlo[t]
+                    if ok and not covered[p[2], p[1], p[0]]:
+                        out.append((d, tuple(q)))
+    return out
+
+
+@pytest.mark.parametrize("nranks", [2, 4])
+def test_coarse_source_pieces_are_disjoint_cover_the_stencils_and_match_the_senders(nranks):
+    H = nested_hierarchy(16, 3, 8, is_per=(1, 1, 0))
+    for l in (1, 2):
+        fine, crse = H.levels[l], H.levels[l - 1]
+        fown, cown = scattered_owner(fine.nboxes, nranks, 11 + l), scattered_owner(crse.nboxes, nranks, 23 + l)
+        rows = [padist.plan_coarse_source(fine, fown, crse, cown, r) for r in range(nranks)]
+        ncr = crse.domhi - crse.domlo + 1
+        for r in range(nranks):
+            pieces = rows[r][rows[r][:, 0] == 2]
+            have = np.zeros(tuple(ncr)[::-1], np.int32)
+            for p in pieces:
+                cb = crse.boxes[p[2]]
+                assert np.all(p[3:6] >= cb[:3]) and np.all(p[6:9] <= cb[3:]) and p[1] == cown[p[2]]  # inside the coarse box it is cut from
+                have[p[5]:p[8] + 1, p[4]:p[7] + 1, p[3]:p[6] + 1] += 1
+            assert have.max() == 1, "pieces overlap"
+            # every coarse cell the order-3 boundary interpolation can touch for a coarse-fine ghost cell of this rank's boxes
+            for g in np.nonzero(fown == r)[0]:
+                for d, q in _cf_ghost_cells(fine, g):
+                    qc = [v // 2 for v in q]
+                    t0, t1 = [a for a in range(3) if a != d]
+                    for a0 in range(-2, 3):
+                        for a1 in range(-2, 3):
+                            c = list(qc)
+                            c[t0] += a0
+                            c[t1] += a1
+                            inside = True
+                            for t in range(3):
+                                if c[t] < crse.domlo[t] or c[t] > crse.domhi[t]:
+                                    if not crse.is_per[t]:
+                                        inside = False
+                                    c[t] = (c[t] - crse.domlo[t]) % ncr[t] + crse.domlo[t]
+                            if inside:
+                                assert have[c[2], c[1], c[0]] == 1, (r, g, q, c)
+            # what the other ranks send to r is exactly r's remote pieces, in order
+            for a in range(nranks):
+                if a == r:
+                    continue
+                s = rows[a][(rows[a][:, 0] == 0) & (rows[a][:, 1] == r)]
+                want = pieces[pieces[:, 1] == a]
+                assert np.array_equal(s[:, 2:], want[:, 2:])
+
+
 def _worker(rank, world, port, ng):
     import torch.distributed as dist
-    import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from oracle import oracle as O
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        R = padist.slab_hierarchy(16, 2, 8, world, rank, ng)
-        for l in range(2):
-            glob = MultiFab(R.glob.levels[l], 2, ng, fill=np.nan)
+        H = nested_hierarchy(16, 3, 8, is_per=(1, 1, 0))
+        owners = [scattered_owner(lv.nboxes, world, 31 + l) for l, lv in enumerate(H.levels)]
+        globs, locs = [], []
+        for l, lv in enumerate(H.levels):
+            glob = MultiFab(lv, 2, ng, fill=np.nan)
             _fill(glob)
             O.fill_boundary(glob, 0, 2, ng)  # the undistributed answer
-            loc = MultiFab(R.local.levels[l], 2, ng, fill=np.nan)
+            mine = np.nonzero(owners[l] == rank)[0]
+            glocal = {int(g): i for i, g in enumerate(mine)}
+            loc = MultiFab(_sub_level(lv, mine), 2, ng, fill=np.nan)
             _fill(loc)
-            O.fill_boundary(loc, 0, 2, ng)   # local half (what pa_fill_boundary does on a rank)
-            padist.exchange_host(R.plans[l], loc, 0, 2)
-            mine = np.nonzero(R.owner[l] == rank)[0]
+            O.fill_boundary(loc, 0, 2, ng)   # the local half (what pa_fill_boundary's kernel does on a rank)
+            rows = padist.plan_fill_boundary(lv, owners[l], rank, ng)
+            assert len(rows) > 0
+            padist.host_exchange(rows, glocal, loc, loc, 0, 2)
             for i, g in enumerate(mine):
                 a, b = loc.fab(i), glob.fab(int(g))
                 same = (a.view(np.int64) == b.view(np.int64)) | (np.isnan(a) & np.isnan(b))
                 assert same.all(), f"rank {rank} level {l} box {g}: {np.count_nonzero(~same)} ghost cells differ"
-            if l == 0:
-                assert len(R.plans[l].recv) >= 1 and all(len(v) > 0 for v in R.plans[l].recv.values())
-                # sender and receiver agree on the buffer sizes
-                sz = {p: R.plans[l].size(v, 2) for p, v in R.plans[l].send.items()}
-                got = [None] * world
-                dist.all_gather_object(got, (rank, sz, {p: R.plans[l].size(v, 2) for p, v in R.plans[l].recv.items()}))
-                for (r, s_, _), in [(g,) for g in got]:
-                    for p, n in s_.items():
-                        assert got[p][2][r] == n
-            else:
-                assert not R.plans[l].send and not R.plans[l].recv  # fine levels sit inside their slab
+            globs.append(glob)
+            locs.append((loc, glocal))
+        # coarse-source copies: every piece equals the undistributed coarse level there
+        for l in (1, 2):
+            rows = padist.plan_coarse_source(H.levels[l], owners[l], H.levels[l - 1], owners[l - 1], rank)
+            pieces = rows[rows[:, 0] == 2]
+            assert len(pieces) > 0 and (pieces[:, 1] != rank).any(), "the scattered owner map must put coarse parents on other ranks"
+            cs_lev = Level(pieces[:, 3:9], H.levels[l - 1].domlo, H.levels[l - 1].domhi, H.levels[l - 1].is_per, H.levels[l - 1].prob_lo, H.levels[l - 1].prob_hi)
+            cs = MultiFab(cs_lev, 2, 0, fill=np.nan)
+            loc, glocal = locs[l - 1]
+            padist.host_exchange(rows, glocal, loc, cs, 0, 2, recv_kind=2, recv_box=lambda i: i)
+            for i, p in enumerate(pieces):
+                want = padist.host_region(globs[l - 1], int(p[2]), p[3:6], p[6:9], 0, 2)
+                assert np.array_equal(cs.fab(i).view(np.int64), np.ascontiguousarray(want).view(np.int64)), (rank, l, i)
+        # curvature.cpp:147-148: the progress range is reduced over the ranks
+        import torch
+        lo = min(float(np.nanmin(locs[l][0].valid_concat(0))) for l in range(3) if locs[l][0].level.nboxes)
+        t = torch.tensor([lo], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        assert float(t) == min(float(g.valid_concat(0).min()) for g in globs)
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("ng", [1, 2])
-def test_two_rank_ghost_exchange_matches_undistributed_fillboundary(ng):
+@pytest.mark.parametrize("world,ng", [(2, 1), (2, 2), (4, 2)])
+def test_ranks_exchange_ghost_cells_and_coarse_data_like_the_undistributed_level(world, ng):
     import torch.multiprocessing as mp
-    mp.spawn(_worker, args=(2, _free_port(), ng), nprocs=2, join=True)
-
-
-def test_plan_is_symmetric_and_ordered():
-    """both sides enumerate (dst box, src box, shift) identically: rank a's send list for b has the same
-    shapes, in the same order, as b's recv list from a"""
-    world = 3
-    Rs = [padist.slab_hierarchy(16, 1, 8, world, r, 2) for r in range(world)]
-    for a in range(world):
-        for b, regs in Rs[a].plans[0].send.items():
-            peer = Rs[b].plans[0].recv[a]
-            assert len(peer) == len(regs)
-            assert np.array_equal(regs[:, 4:7] - regs[:, 1:4], peer[:, 4:7] - peer[:, 1:4])
+    mp.spawn(_worker, args=(world, _free_port(), ng), nprocs=world, join=True)

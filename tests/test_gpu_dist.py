@@ -1,7 +1,9 @@
-"""GPU tier, N > 1 path on ONE device: two processes share cuda:0, each owns one x-slab of every
-level (pa_level_create_dist); ghost cells of the slab faces travel through the HIP pack/unpack
-kernels (transport: gloo, because RCCL needs one GPU per rank).  The fused grad->curvature result of
-both ranks together must equal the oracle on the undistributed hierarchy, bit for bit."""
+"""GPU tier, N > 1 path on ONE device: 2 and 4 processes share cuda:0; ONE 3-level hierarchy is sharded over them with a
+SCATTERED owner map (neighbouring boxes, and the coarse parents of most fine boxes, live on other ranks), so every ghost
+fill crosses ranks: same-level ghost cells, the coarse data under coarse-fine faces (phi, the flame normal, the Hessian
+rows, the velocity) and the progress-range reduction.  Transport: the library's pa_comm callbacks over gloo (RCCL needs
+one GPU per rank); the pack / unpack kernels, region plans and pipelines are the ones an 8-GPU run uses.  The union of
+the ranks' results must equal the oracle on the UNDISTRIBUTED hierarchy bit for bit -- fused and pass by pass."""
 import os
 import socket
 import sys
@@ -20,7 +22,11 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port):
+def _same(a, b):
+    return np.array_equal(np.ascontiguousarray(a).view(np.int64), np.ascontiguousarray(b).view(np.int64))
+
+
+def _worker(rank, world, port, case):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import torch
@@ -29,59 +35,99 @@ def _worker(rank, world, port):
     from oracle import oracle as O
     from peleanalysis_amd import capi
     from peleanalysis_amd import dist as padist
-    from peleanalysis_amd.hierarchy import MultiFab, cell_centers
+    from peleanalysis_amd.hierarchy import MultiFab, cell_centers, nested_hierarchy
+    from test_dist_gloo import scattered_owner
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        dev = torch.device("cuda", 0)
-        R = padist.slab_hierarchy(16, 2, 8, world, rank, 2)
-        f = lambda x, y, z: 1000.0 + 500.0 * np.tanh((np.sqrt(((x % 1.0) - 0.5) ** 2 + (y - 0.5) ** 2 + (z - 0.5) ** 2) - 0.3) / 0.1) \
-            + 20.0 * np.sin(2 * np.pi * x / world) + 0 * x * y * z
-        bc = capi.bc_from_flags((1, 1, 0))
-        # oracle on the global (undistributed) hierarchy
+        per, sym = ((1, 1, 0), (0, 0, 0)) if case != "sym" else ((0, 1, 1), (1, 0, 0))
+        H = nested_hierarchy(16, 3, 8, is_per=per)
+        owners = [scattered_owner(lv.nboxes, world, 31 + l) if case != "sfc" else padist.distribution_map(lv.boxes, world) for l, lv in enumerate(H.levels)]
+        rng = np.random.default_rng(99)
+        ncomp = 4
+        f = lambda x, y, z, c: (1 + 0.2 * c) * (1000.0 + 500.0 * np.tanh((np.sqrt((x - 0.5) ** 2 + (y - 0.45) ** 2 + (z - 0.5) ** 2) - 0.3) / 0.1)) \
+            + 20.0 * np.sin(2 * np.pi * (x + 0.1 * c)) * np.cos(2 * np.pi * y) + 0 * x * y * z
+        bc = capi.bc_from_flags(per, sym)
         gst = []
-        for lv in R.glob.levels:
-            s = MultiFab(lv, 1, 2)
+        for lv in H.levels:
+            s = MultiFab(lv, ncomp, 2)
             for b in range(lv.nboxes):
-                s.valid(b)[0] = f(*cell_centers(lv, b, 0))
+                for c in range(ncomp):
+                    s.valid(b)[c] = f(*cell_centers(lv, b, 0), c) + 1e-3 * rng.uniform(-1, 1, size=s.valid(b)[c].shape)
             gst.append(s)
-        og = [MultiFab(lv, 4, 0) for lv in R.glob.levels]
-        oc = [MultiFab(lv, 5, 0) for lv in R.glob.levels]
-        O.grad_pipeline(R.glob.levels, [s.copy() for s in gst], 0, bc, og, 0)
-        pm = O.curvature_pipeline(R.glob.levels, [s.copy() for s in gst], 0, bc, oc, 0, MultiFab)
-        # this rank's share on the GPU
+        thr = 0.03 if case == "thr" else None
+        og = [MultiFab(lv, 4, 0) for lv in H.levels]
+        oc = [MultiFab(lv, 17, 0) for lv in H.levels]
+        O.grad_pipeline(H.levels, [s.copy() for s in gst], 0, bc, og, 0)
+        pm = O.curvature_pipeline(H.levels, [s.copy() for s in gst], 0, bc, oc, 0, MultiFab, threshold=thr, do_gauss=True, do_strain=True, strain_tensor=True,
+                                  do_velnormal=True, vel_comp=1)
+
         ctx = capi.Context(0)
-        dls = [capi.DevLevel(ctx, lv, R.remote[l]) for l, lv in enumerate(R.local.levels)]
+        comm = padist.GlooComm(ctx)
+        ctx.comm_selftest(1000)  # the transport itself: ring exchange + reduction with known answers
+        dls = [capi.DevLevel(ctx, lv, owners[l], rank, world) for l, lv in enumerate(H.levels)]
         lst = []
-        for l, lv in enumerate(R.local.levels):
-            s = MultiFab(lv, 1, 2)
-            for b in range(lv.nboxes):
-                s.valid(b)[0] = f(*cell_centers(lv, b, 0))
-            lst.append(capi.DevMF.from_host(ctx, dls[l], s))
+        for l, dl in enumerate(dls):
+            s = MultiFab(dl.level, ncomp, 2, fill=np.nan)  # ghost cells poisoned: every one the kernels read must have been filled
+            for i, g in enumerate(dl.gids):
+                s.valid(i)[...] = gst[l].valid(int(g))
+            lst.append(capi.DevMF.from_host(ctx, dl, s))
         work = [capi.DevMF(ctx, dl, 1, 2) for dl in dls]
-        out = [capi.DevMF(ctx, dl, 8, 0) for dl in dls]
-        # (the pass-by-pass path would also need the ghost cells of c and n exchanged: not wired for N > 1)
-        for fused in (True,):
-            for l in range(2):
-                padist.exchange_device_staged(R.plans[l], ctx, lst[l], 0, 1, dev)
-            capi.gradcurv_run(ctx, lst, 0, bc, capi.curv_params(prog_min=pm[0], prog_max=pm[1], fused=fused), work, out, 0)
+
+        def check(out, pairs, what):
+            for l, dl in enumerate(dls):
+                got = out[l].download()
+                for i, g in enumerate(dl.gids):
+                    for gc, (ref, rc) in pairs.items():
+                        assert _same(got.valid(i)[gc], ref[l].valid(int(g))[rc]), f"rank {rank}/{world} {what}: level {l} box {g} comp {gc} differs from the undistributed oracle"
+
+        # fused and pass-by-pass grad -> curvature; the progress range comes from the min / max reduction over the ranks
+        for fused in (True, False):
+            out = [capi.DevMF(ctx, dl, 8, 0) for dl in dls]
+            n0 = comm.nexchange
+            capi.gradcurv_run(ctx, lst, 0, bc, capi.curv_params(threshold=thr, fused=fused), work, out, 0)
             ctx.sync()
             assert ctx.bc_errors() == 0
-            for l in range(2):
-                got = out[l].download()
-                mine = np.nonzero(R.owner[l] == rank)[0]
-                for i, g in enumerate(mine):
-                    v = got.valid(i)
-                    same = lambda a, b: np.array_equal(np.ascontiguousarray(a).view(np.int64), np.ascontiguousarray(b).view(np.int64))
-                    assert same(v[0:4], og[l].valid(int(g))), f"rank {rank} fused={fused} level {l} box {g}: grad differs"
-                    assert same(v[4:7], oc[l].valid(int(g))[2:5]) and same(v[7], oc[l].valid(int(g))[1]), \
-                        f"rank {rank} fused={fused} level {l} box {g}: curvature differs"
+            if fused:
+                assert comm.nexchange - n0 == 2, "the fused pipeline batches its cross-rank traffic into two exchanges"
+            check(out, {0: (og, 0), 1: (og, 1), 2: (og, 2), 3: (og, 3), 4: (oc, 2), 5: (oc, 3), 6: (oc, 4), 7: (oc, 1)}, f"gradcurv fused={fused}")
+        # the curvature tool's pipeline with every option (Hessian rows and velocity need their own coarse data)
+        out = [capi.DevMF(ctx, dl, 17, 0) for dl in dls]
+        capi.curvature_run(ctx, lst, 0, bc, capi.curv_params(threshold=thr, fused=False, do_gauss=True, do_strain=True, strain_tensor=True, do_velnormal=True,
+                                                            vel_comp=1), out, 0)
+        ctx.sync()
+        assert ctx.bc_errors() == 0
+        check(out, {c: (oc, c) for c in range(17)}, "curvature_run with options")
+        # the gradient tool's pipeline
+        out = [capi.DevMF(ctx, dl, 4, 0) for dl in dls]
+        capi.grad_run(ctx, lst, 0, bc, out, 0)
+        ctx.sync()
+        check(out, {c: (og, c) for c in range(4)}, "grad_run")
+        assert comm.bytes_sent > 0
+        dist.barrier()
         ctx.close()
     finally:
         dist.destroy_process_group()
 
 
-def test_two_ranks_one_gpu_fused_gradcurv_matches_undistributed_oracle():
+@pytest.mark.parametrize("world,case", [(2, "scatter"), (4, "scatter"), (4, "thr"), (2, "sym"), (4, "sfc")])
+def test_sharded_hierarchy_on_shared_gpu_matches_undistributed_oracle(world, case):
     import torch.multiprocessing as mp
-    mp.spawn(_worker, args=(2, _free_port()), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), case), nprocs=world, join=True)
+
+
+def test_rccl_transport_single_rank():
+    """the built-in RCCL transport on the one GPU of the box: communicator of one rank, grouped ncclSend / ncclRecv to itself
+    and ncclAllReduce, all issued by the library on its own stream (the multi-rank form of exactly these calls is what a
+    multi-GPU run uses; the box has one GPU and RCCL refuses two ranks on one device)"""
+    from peleanalysis_amd import capi
+    c = capi.Context(0)
+    try:
+        uid = c.rccl_unique_id()
+        assert len(uid) == 128 and any(uid)
+        c.init_rccl(1, 0, uid)
+        assert c.lib.pa_ctx_nranks(c.h) == 1
+        c.comm_selftest(1 << 16)
+    finally:
+        c.close()
