@@ -117,17 +117,31 @@ def test_sharded_hierarchy_on_shared_gpu_matches_undistributed_oracle(world, cas
     mp.spawn(_worker, args=(world, _free_port(), case), nprocs=world, join=True)
 
 
-def test_rccl_transport_single_rank():
+_RCCL_SELF = """
+import sys
+sys.path.insert(0, {root!r})
+{torch_first}
+from peleanalysis_amd import capi
+c = capi.Context(0)
+uid = c.rccl_unique_id()
+assert len(uid) == 128 and any(uid)
+c.init_rccl(1, 0, uid)
+assert c.lib.pa_ctx_nranks(c.h) == 1
+c.comm_selftest(1 << 16)
+c.close()
+print("RCCL_SELF_OK")
+"""
+
+
+@pytest.mark.parametrize("torch_first", [False, True])
+def test_rccl_transport_single_rank(torch_first):
     """the built-in RCCL transport on the one GPU of the box: communicator of one rank, grouped ncclSend / ncclRecv to itself
     and ncclAllReduce, all issued by the library on its own stream (the multi-rank form of exactly these calls is what a
-    multi-GPU run uses; the box has one GPU and RCCL refuses two ranks on one device)"""
-    from peleanalysis_amd import capi
-    c = capi.Context(0)
-    try:
-        uid = c.rccl_unique_id()
-        assert len(uid) == 128 and any(uid)
-        c.init_rccl(1, 0, uid)
-        assert c.lib.pa_ctx_nranks(c.h) == 1
-        c.comm_selftest(1 << 16)
-    finally:
-        c.close()
+    multi-GPU run uses; the box has one GPU and RCCL refuses two ranks on one device).  In a fresh process, in the two
+    library constellations that occur: a C++ tool (system HIP runtime + system RCCL) and bench.py (torch imported first:
+    the HIP runtime and the RCCL that PyTorch bundles).  Mixing the two in one process is what INTEGRATION.md warns about."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = _RCCL_SELF.format(root=root, torch_first="import torch; torch.cuda.init()" if torch_first else "")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "RCCL_SELF_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
