@@ -299,10 +299,30 @@ pa_level* pa_level_create_spec(pa_ctx* ctx, const LevelSpec& S, const int32_t do
     for (int d = 0; d < 3; ++d)
       for (int side = 0; side < 2; ++side)
         if (pa_face_is_special(L, L->boxes[b], d, side)) L->sfaces.push_back(b * 6 + d * 2 + side);
+  // Pure special faces (the exact-normal sweep of pa_fused2.hip wants them): a face with a ghost cell that is not a valid
+  // cell has NO ghost cell that is one.  Again a property of the whole BoxArray (all ranks take the same path).
+  L->pure_faces = true;
+  for (int b = 0; b < nfus && L->pure_faces; ++b) {
+    const DBox& B = S.gboxes.empty() ? L->boxes[b] : S.gboxes[b];
+    for (int d = 0; d < 3 && L->pure_faces; ++d)
+      for (int side = 0; side < 2 && L->pure_faces; ++side) {
+        const int t0 = (d == 0) ? 1 : 0, t1 = (d == 2) ? 1 : 2;
+        int q[3], nval = 0, nnot = 0;
+        q[d] = side ? B.hi[d] + 1 : B.lo[d] - 1;
+        for (int v = B.lo[t1]; v <= B.hi[t1]; v += g)
+          for (int u = B.lo[t0]; u <= B.hi[t0]; u += g) {
+            q[t0] = u; q[t1] = v;
+            (host_classify(L, q[0], q[1], q[2]) == 0 ? nval : nnot)++;
+          }
+        if (nval && nnot) L->pure_faces = false;
+      }
+  }
   const size_t nsf_alloc = std::max<size_t>(L->sfaces.size(), 1);
   std::vector<int> sfindex((size_t)nboxes * 6, -1);
   std::vector<long long> sfoff(nsf_alloc, 0);
   long long ncode = 0;
+  L->cgoff.assign(nsf_alloc, 0);
+  L->cg_total = 0;
   for (size_t e = 0; e < L->sfaces.size(); ++e) {
     const int f = L->sfaces[e];
     const DBox& B = L->boxes[f / 6];
@@ -310,12 +330,16 @@ pa_level* pa_level_create_spec(pa_ctx* ctx, const LevelSpec& S, const int32_t do
     sfindex[f] = (int)e;
     sfoff[e] = ncode;
     ncode += (long long)(B.hi[t0] - B.lo[t0] + 1) * (B.hi[t1] - B.lo[t1] + 1);
+    L->cgoff[e] = L->cg_total;  // (n0+2) x (n1+2) + two rows of slack, starts on a 64-byte boundary
+    L->cg_total += ((long long)(B.hi[t0] - B.lo[t0] + 3) * (B.hi[t1] - B.lo[t1] + 5) + 7) / 8 * 8;
   }
   if (hipMalloc(&L->d_boxes, sizeof(DBox) * std::max(nboxes, 1)) != hipSuccess ||
       hipMalloc(&L->d_sfaces, sizeof(int) * nsf_alloc) != hipSuccess ||
       (!L->sfaces.empty() && hipMemcpy(L->d_sfaces, L->sfaces.data(), sizeof(int) * L->sfaces.size(), hipMemcpyHostToDevice) != hipSuccess) ||
       hipMalloc(&L->d_sfindex, sizeof(int) * std::max<size_t>(sfindex.size(), 1)) != hipSuccess ||
       (!sfindex.empty() && hipMemcpy(L->d_sfindex, sfindex.data(), sizeof(int) * sfindex.size(), hipMemcpyHostToDevice) != hipSuccess) ||
+      hipMalloc(&L->d_cgoff, sizeof(long long) * nsf_alloc) != hipSuccess ||
+      hipMemcpy(L->d_cgoff, L->cgoff.data(), sizeof(long long) * nsf_alloc, hipMemcpyHostToDevice) != hipSuccess ||
       hipMalloc(&L->d_sfoff, sizeof(long long) * nsf_alloc) != hipSuccess ||
       hipMemcpy(L->d_sfoff, sfoff.data(), sizeof(long long) * nsf_alloc, hipMemcpyHostToDevice) != hipSuccess ||
       hipMalloc(&L->d_sfcode, sizeof(unsigned short) * std::max<long long>(ncode, 1)) != hipSuccess ||
@@ -328,11 +352,14 @@ pa_level* pa_level_create_spec(pa_ctx* ctx, const LevelSpec& S, const int32_t do
     if (L->d_sfaces) (void)hipFree(L->d_sfaces);
     if (L->d_sfindex) (void)hipFree(L->d_sfindex);
     if (L->d_sfoff) (void)hipFree(L->d_sfoff);
+    if (L->d_cgoff) (void)hipFree(L->d_cgoff);
     if (L->d_sfcode) (void)hipFree(L->d_sfcode);
     delete L;
     return nullptr;
   }
   DLevelView& V = L->view;
+  V.cgoff = L->d_cgoff;
+  V.cg = nullptr;
   V.sfindex = L->d_sfindex;
   V.sfoff = L->d_sfoff;
   V.sfcode = L->d_sfcode;
@@ -365,6 +392,8 @@ extern "C" void pa_level_destroy(pa_level* L) {
   if (L->d_sfaces) (void)hipFree(L->d_sfaces);
   if (L->d_sfindex) (void)hipFree(L->d_sfindex);
   if (L->d_sfoff) (void)hipFree(L->d_sfoff);
+  if (L->d_cgoff) (void)hipFree(L->d_cgoff);
+  if (L->d_cg) (void)hipFree(L->d_cg);
   if (L->d_sfcode) (void)hipFree(L->d_sfcode);
   if (L->d_boxes) (void)hipFree(L->d_boxes);
   if (L->d_owner) (void)hipFree(L->d_owner);
@@ -548,8 +577,14 @@ __device__ __forceinline__ bool shell_cell(const DBox& B, int ng, long long tt, 
   }
 }
 
-__global__ void k_fill_boundary(DLevelView L, DMFView M, int comp, int ncomp, int ngf) {
-  const int b = blockIdx.y;
+struct FillArgs { DLevelView L; DMFView M; int comp, ncomp, ngf; };
+__global__ void k_fill_boundary(LevBatch<FillArgs> Bt) {
+  unsigned yb;
+  const FillArgs& Fa = Bt.a[Bt.find(blockIdx.y, yb)];
+  const DLevelView& L = Fa.L;
+  const DMFView& M = Fa.M;
+  const int comp = Fa.comp, ncomp = Fa.ncomp, ngf = Fa.ngf;
+  const int b = (int)yb;
   const DBox B = L.boxes[b];
   const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   int i, j, k;
@@ -561,6 +596,7 @@ __global__ void k_fill_boundary(DLevelView L, DMFView M, int comp, int ncomp, in
     M.data[M.off[b] + fab_index(B, M.ng, M.ncomp, c, i, j, k)] = M.data[M.off[s] + fab_index(S, M.ng, M.ncomp, c, p[0], p[1], p[2])];
 }
 
+int pa_fill_boundary_local_batch(pa_ctx* ctx, int n, pa_mf* const* Ms, int comp, int ncomp, int ng);
 static long long max_shell(const pa_level* L, int ng) {
   long long m = 0;
   for (const DBox& B : L->boxes) {
@@ -568,6 +604,25 @@ static long long max_shell(const pa_level* L, int ng) {
     m = std::max(m, (nx + 2 * ng) * (ny + 2 * ng) * (nz + 2 * ng) - nx * ny * nz);
   }
   return m;
+}
+
+// the local half of FillBoundary on several levels (same component range and ghost width) in as few launches as possible
+int pa_fill_boundary_local_batch(pa_ctx* ctx, int n, pa_mf* const* Ms, int comp, int ncomp, int ng) {
+  for (int i0 = 0; i0 < n; i0 += PA_MAXB) {
+    LevBatch<FillArgs> Bt;
+    long long ms = 0;
+    for (int i = i0; i < n && i < i0 + PA_MAXB; ++i) {
+      if (Ms[i]->lev->boxes.empty()) continue;
+      Bt.a[Bt.n] = FillArgs{Ms[i]->lev->view, Ms[i]->view, comp, ncomp, ng};
+      Bt.ycum[Bt.n + 1] = Bt.ycum[Bt.n] + (int)Ms[i]->lev->boxes.size();
+      ++Bt.n;
+      ms = std::max(ms, max_shell(Ms[i]->lev, ng));
+    }
+    if (!Bt.n) continue;
+    hipLaunchKernelGGL(k_fill_boundary, dim3((unsigned)((ms + 255) / 256), (unsigned)Bt.ycum[Bt.n]), dim3(256), 0, ctx->stream, Bt);
+  }
+  PA_HIP(hipGetLastError());
+  return 0;
 }
 
 // no_exchange: only the local half (the caller batches the cross-rank half of several levels into one exchange)
@@ -580,10 +635,8 @@ int pa_fill_boundary_impl(pa_ctx* ctx, pa_mf* M, int comp, int ncomp, int ng, in
       return pa_fail(ctx, "pa_fill_boundary: ng larger than the periodic domain");
   ProfScope prof(ctx, PA_TAG_FILL);
   if (!M->lev->boxes.empty()) {
-    const long long ms = max_shell(M->lev, ng);
-    dim3 grid((unsigned)((ms + 255) / 256), (unsigned)M->lev->boxes.size());
-    hipLaunchKernelGGL(k_fill_boundary, grid, dim3(256), 0, ctx->stream, M->lev->view, M->view, comp, ncomp, ng);
-    PA_HIP(hipGetLastError());
+    pa_mf* one[1] = {M};
+    if (pa_fill_boundary_local_batch(ctx, 1, one, comp, ncomp, ng)) return 1;
   }
   // ghost cells covered by boxes of other ranks: the cross-rank half (pack -> grouped send/recv -> unpack)
   if (M->lev->nranks > 1 && !no_exchange) {

@@ -428,16 +428,23 @@ pa_mf* CsPlan::mf(pa_ctx* ctx, int ncomp) {
 
 // ---------------------------------------------------------------------------------- pack / unpack
 // Thread t of block row r handles cell t of region r for all components.  Regions are thin (1-2 cells along one
-// direction); 32-bit index arithmetic.
-__global__ __launch_bounds__(256) void k_xregions(DLevelView L, DMFView M, int comp, int ncomp, const int* regs, const long long* coff, double* buf, int unpack) {
-  const int* R = regs + 7 * blockIdx.y;
+// direction); 32-bit index arithmetic.  One launch covers the region lists of several plans (LevBatch rows = regions).
+#define PA_XB 8
+struct XRegArgs { DLevelView L; DMFView M; int comp, ncomp; const int* regs; const long long* coff; double* buf; };
+__global__ __launch_bounds__(256) void k_xregions(LevBatch<XRegArgs, PA_XB> Bt, int unpack) {
+  unsigned ry;
+  const XRegArgs& X = Bt.a[Bt.find(blockIdx.y, ry)];
+  const DLevelView& L = X.L;
+  const DMFView& M = X.M;
+  const int comp = X.comp, ncomp = X.ncomp;
+  const int* R = X.regs + 7 * ry;
   const int b = R[0];
   const unsigned nx = R[4] - R[1] + 1, ny = R[5] - R[2] + 1, nz = R[6] - R[3] + 1, n = nx * ny * nz;
   const DBox B = L.boxes[b];
   const long long gnx = B.hi[0] - B.lo[0] + 1 + 2 * M.ng, gny = B.hi[1] - B.lo[1] + 1 + 2 * M.ng, gnz = B.hi[2] - B.lo[2] + 1 + 2 * M.ng;
   const long long cs = pa_cstride(gnx * gny * gnz, M.ncomp);
   double* f = M.data + M.off[b] + (long long)comp * cs;
-  double* q = buf + coff[blockIdx.y] * ncomp;
+  double* q = X.buf + X.coff[ry] * ncomp;
   const int oi = R[1] - B.lo[0] + M.ng, oj = R[2] - B.lo[1] + M.ng, ok = R[3] - B.lo[2] + M.ng;
   for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
     const unsigned r = t / nx, i = t - r * nx, k = r / ny, j = r - k * ny;
@@ -450,16 +457,19 @@ __global__ __launch_bounds__(256) void k_xregions(DLevelView L, DMFView M, int c
 }
 
 // same-rank part of a coarse-source refill: region pairs of equal shape, coarse level -> coarse-source level
-__global__ __launch_bounds__(256) void k_xcopy(DLevelView LS, DMFView MS, int scomp, DLevelView LD, DMFView MD, int dcomp, int ncomp, const int* sregs, const int* dregs) {
-  const int* R = sregs + 7 * blockIdx.y;
-  const int* D = dregs + 7 * blockIdx.y;
+struct XCopyArgs { DLevelView LS; DMFView MS; int scomp; DLevelView LD; DMFView MD; int dcomp, ncomp; const int* sregs; const int* dregs; };
+__global__ __launch_bounds__(256) void k_xcopy(LevBatch<XCopyArgs, PA_XB> Bt) {
+  unsigned ry;
+  const XCopyArgs& X = Bt.a[Bt.find(blockIdx.y, ry)];
+  const int* R = X.sregs + 7 * ry;
+  const int* D = X.dregs + 7 * ry;
   const unsigned nx = R[4] - R[1] + 1, ny = R[5] - R[2] + 1, nz = R[6] - R[3] + 1, n = nx * ny * nz;
-  const DBox BS = LS.boxes[R[0]], BD = LD.boxes[D[0]];
+  const DBox BS = X.LS.boxes[R[0]], BD = X.LD.boxes[D[0]];
   for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
     const unsigned r = t / nx, i = t - r * nx, k = r / ny, j = r - k * ny;
-    for (int c = 0; c < ncomp; ++c)
-      MD.data[MD.off[D[0]] + fab_index(BD, MD.ng, MD.ncomp, dcomp + c, D[1] + (int)i, D[2] + (int)j, D[3] + (int)k)] =
-          MS.data[MS.off[R[0]] + fab_index(BS, MS.ng, MS.ncomp, scomp + c, R[1] + (int)i, R[2] + (int)j, R[3] + (int)k)];
+    for (int c = 0; c < X.ncomp; ++c)
+      X.MD.data[X.MD.off[D[0]] + fab_index(BD, X.MD.ng, X.MD.ncomp, X.dcomp + c, D[1] + (int)i, D[2] + (int)j, D[3] + (int)k)] =
+          X.MS.data[X.MS.off[R[0]] + fab_index(BS, X.MS.ng, X.MS.ncomp, X.scomp + c, R[1] + (int)i, R[2] + (int)j, R[3] + (int)k)];
   }
 }
 
@@ -475,11 +485,25 @@ static int ensure_buf(pa_ctx* ctx, double*& buf, long long& cap, long long need)
   return 0;
 }
 
-static void launch_regions(pa_ctx* ctx, const XSide& S, const pa_mf* M, int comp, int ncomp, double* buf, int unpack) {
-  const int nreg = (int)(S.regs7.size() / 7);
-  if (!nreg) return;
-  const unsigned gx = (unsigned)std::min<long long>((S.maxcells + 255) / 256, 64);
-  hipLaunchKernelGGL(k_xregions, dim3(gx, (unsigned)nreg), dim3(256), 0, ctx->stream, M->lev->view, M->view, comp, ncomp, S.d_regs, S.d_coff, buf, unpack);
+// pack (unpack = 0: the send lists) or unpack (1: the receive lists) of all jobs, PA_XB plans per launch
+static void launch_regions(pa_ctx* ctx, int njobs, const XJob* jobs, int unpack) {
+  for (int q0 = 0; q0 < njobs; q0 += PA_XB) {
+    LevBatch<XRegArgs, PA_XB> Bt;
+    long long maxcells = 0;
+    for (int q = q0; q < njobs && q < q0 + PA_XB; ++q) {
+      const XJob& J = jobs[q];
+      const XSide& S = unpack ? J.plan->recv : J.plan->send;
+      const int nreg = (int)(S.regs7.size() / 7);
+      if (!nreg) continue;
+      const pa_mf* M = unpack ? J.dst : J.src;
+      Bt.a[Bt.n] = XRegArgs{M->lev->view, M->view, unpack ? J.dcomp : J.scomp, J.ncomp, S.d_regs, S.d_coff, unpack ? J.plan->rbuf : J.plan->sbuf};
+      Bt.ycum[Bt.n + 1] = Bt.ycum[Bt.n] + nreg;
+      ++Bt.n;
+      maxcells = std::max(maxcells, S.maxcells);
+    }
+    if (!Bt.n) continue;
+    hipLaunchKernelGGL(k_xregions, dim3((unsigned)std::min<long long>((maxcells + 255) / 256, 64), (unsigned)Bt.ycum[Bt.n]), dim3(256), 0, ctx->stream, Bt, unpack);
+  }
 }
 
 int pa_xexchange(pa_ctx* ctx, int njobs, const XJob* jobs) {
@@ -491,10 +515,6 @@ int pa_xexchange(pa_ctx* ctx, int njobs, const XJob* jobs) {
       return pa_fail(ctx, "ghost exchange: component range");
     PA_TRY(ensure_buf(ctx, P.sbuf, P.scap, P.send.coff.back() * J.ncomp));
     PA_TRY(ensure_buf(ctx, P.rbuf, P.rcap, P.recv.coff.back() * J.ncomp));
-    launch_regions(ctx, P.send, J.src, J.scomp, J.ncomp, P.sbuf, 0);
-    if (P.nlocal)
-      hipLaunchKernelGGL(k_xcopy, dim3((unsigned)std::min<long long>((P.lmax + 255) / 256, 64), (unsigned)P.nlocal), dim3(256), 0, ctx->stream, J.src->lev->view,
-                         J.src->view, J.scomp, J.dst->lev->view, J.dst->view, J.dcomp, J.ncomp, P.d_lsrc, P.d_ldst);
     // one entry per peer of this plan, peers ascending: both sides walk jobs and peers in the same order
     size_t a = 0, b = 0;
     while (a < P.send.peers.size() || b < P.recv.peers.size()) {
@@ -514,13 +534,27 @@ int pa_xexchange(pa_ctx* ctx, int njobs, const XJob* jobs) {
       xf.push_back(x);
     }
   }
+  launch_regions(ctx, njobs, jobs, 0);
+  for (int q0 = 0; q0 < njobs; q0 += PA_XB) {  // same-rank pieces of coarse-source refills
+    LevBatch<XCopyArgs, PA_XB> Bt;
+    long long lmax = 0;
+    for (int q = q0; q < njobs && q < q0 + PA_XB; ++q) {
+      const XJob& J = jobs[q];
+      if (!J.plan->nlocal) continue;
+      Bt.a[Bt.n] = XCopyArgs{J.src->lev->view, J.src->view, J.scomp, J.dst->lev->view, J.dst->view, J.dcomp, J.ncomp, J.plan->d_lsrc, J.plan->d_ldst};
+      Bt.ycum[Bt.n + 1] = Bt.ycum[Bt.n] + J.plan->nlocal;
+      ++Bt.n;
+      lmax = std::max(lmax, J.plan->lmax);
+    }
+    if (Bt.n) hipLaunchKernelGGL(k_xcopy, dim3((unsigned)std::min<long long>((lmax + 255) / 256, 64), (unsigned)Bt.ycum[Bt.n]), dim3(256), 0, ctx->stream, Bt);
+  }
   PA_HIP(hipGetLastError());
   if (!xf.empty()) {
     if (!ctx->comm.exchange) return pa_fail(ctx, "sharded level without a transport: call pa_ctx_init_rccl or pa_ctx_set_comm first");
     if (ctx->comm.exchange(ctx->comm.user, (void*)ctx->stream, (int32_t)xf.size(), xf.data()) != 0)
       return pa_fail(ctx, ctx->rccl ? "RCCL point-to-point exchange failed: " + ctx->err : std::string("the transport's exchange failed"));
   }
-  for (int q = 0; q < njobs; ++q) launch_regions(ctx, jobs[q].plan->recv, jobs[q].dst, jobs[q].dcomp, jobs[q].ncomp, jobs[q].plan->rbuf, 1);
+  launch_regions(ctx, njobs, jobs, 1);
   PA_HIP(hipGetLastError());
   return 0;
 }

@@ -71,6 +71,12 @@ struct LevelBP2 {
     for (int d = 0; d < 3; ++d) { V.lo[d] -= grow; V.hi[d] += grow; dxinv[d] = L.dxinv[d]; }
     return true;
   }
+  // compact resolved-ghost array of face f = dir * 2 + side of box b (DLevelView::cg), null if the face is ordinary
+  __device__ __forceinline__ const double* cg_face(int b, int f) const {
+    if (!L.cg) return nullptr;
+    const int e = L.sfindex[b * 6 + f];
+    return e < 0 ? nullptr : L.cg + L.cgoff[e];
+  }
 };
 struct LevelBP4 {
   DLevelView L;
@@ -96,6 +102,7 @@ struct FabBP2 {
     for (int d = 0; d < 3; ++d) dx[d] = dxinv[d];
     return true;
   }
+  __device__ __forceinline__ const double* cg_face(int, int) const { return nullptr; }
 };
 struct FabBP4 {
   FabView A, B, C, D;

@@ -25,11 +25,54 @@
 #endif
 struct Vec3 { double x, y, z; };
 
+// Where the face fix-up reads the progress variable from.
+// ShellAcc: the stored copy with resolved ghost cells (`work`, filled in a shell around the special faces).
+struct ShellAcc {
+  FabView C;
+  int cc;
+  __device__ __forceinline__ double operator()(int i, int j, int k) const { return C(i, j, k, cc); }
+};
+// CgAcc (exact-normal pipeline, below): nothing is stored but the ghost values behind special faces.  A cell of the box
+// or a ghost cell that is a valid cell of the level: (phi - pmin) * invdenom; the ghost cell behind a special face: that
+// face's compact array; an edge ghost (outside in two directions): the ring of the special one of the two faces.
+struct CgAcc {
+  const DLevelView* L;
+  FabView P;
+  DBox B;
+  int b, pcomp;
+  double pmin, invd;
+  __device__ __forceinline__ double operator()(int i, int j, int k) const {
+    const int p[3] = {i, j, k};
+    int nout = 0, fd[2] = {0, 0}, fs[2] = {0, 0};
+    bool near = true;  // within one cell of the box in every direction
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const int o = p[d] < B.lo[d] ? B.lo[d] - p[d] : (p[d] > B.hi[d] ? p[d] - B.hi[d] : 0);
+      if (o) {
+        if (nout < 2) { fd[nout] = d; fs[nout] = p[d] > B.hi[d]; }
+        ++nout;
+        near = near && o == 1;
+      }
+    }
+    int e = -1, d = 0;
+    if (near && nout == 1) { d = fd[0]; e = L->sfindex[b * 6 + d * 2 + fs[0]]; }
+    if (near && nout == 2) {
+      const int ea = L->sfindex[b * 6 + fd[0] * 2 + fs[0]], ec = L->sfindex[b * 6 + fd[1] * 2 + fs[1]];
+      if (ea >= 0 && ec >= 0) return 0.0;  // needed by nobody (its face-ring neighbours are not valid cells either)
+      if (ea >= 0) { e = ea; d = fd[0]; }
+      if (ec >= 0) { e = ec; d = fd[1]; }
+    }
+    if (e < 0) return (P(i, j, k, pcomp) - pmin) * invd;
+    const int t0 = (d == 0) ? 1 : 0, t1 = (d == 2) ? 1 : 2;
+    return L->cg[L->cgoff[e] + (long long)(p[t1] - B.lo[t1] + 1) * (B.hi[t0] - B.lo[t0] + 3) + (p[t0] - B.lo[t0] + 1)];
+  }
+};
+
 // flame normal n = G/normgrad at cell (i,j,k), from c
-__device__ __forceinline__ Vec3 normal_at(const FabView& C, int cc, int i, int j, int k, const double dxinv[3]) {
+template <typename Acc>
+__device__ __forceinline__ Vec3 normal_at(const Acc& C, int i, int j, int k, const double dxinv[3]) {
   Vec3 n;
-  normal_from(C(i - 1, j, k, cc), C(i + 1, j, k, cc), C(i, j - 1, k, cc), C(i, j + 1, k, cc), C(i, j, k - 1, cc), C(i, j, k, cc),
-              C(i, j, k + 1, cc), dxinv, n.x, n.y, n.z);
+  normal_from(C(i - 1, j, k), C(i + 1, j, k), C(i, j - 1, k), C(i, j + 1, k), C(i, j, k - 1), C(i, j, k), C(i, j, k + 1), dxinv, n.x, n.y, n.z);
   return n;
 }
 
@@ -40,6 +83,20 @@ struct FaceArgs {
   int layers;  // cells per face normal that are recomputed (2)
   double thr;
   int perim_only;  // k_faces_curv: only the cells on the perimeter of each face (k_faces_curv_fast does the interior)
+  double pmin, invd;  // CgAcc: progress variable from phi
+};
+
+// one level's arguments of the curvature fix-up kernels (several levels per launch: LevBatch)
+struct FixArgs {
+  DLevelView L;
+  DMFView MC_;
+  int ccomp;
+  DLevelView LCr;
+  DMFView MN;
+  int cncomp0;
+  DMFView MO;
+  int ncomp0, kcomp;
+  FaceArgs A;
 };
 
 __device__ __forceinline__ double comp_of(const Vec3& v, int d) { return d == 0 ? v.x : (d == 1 ? v.y : v.z); }
@@ -58,11 +115,11 @@ __global__ __launch_bounds__(256) void k_faces_normal(DLevelView L, DMFView MC_,
   if ((L.sfcode[L.sfoff[blockIdx.y] + t] & 3u) == 0) return;  // ordinary same-level ghost: the sweep was exact
   int X[3] = {q[0], q[1], q[2]};
   X[dir] += side ? -1 : 1;
-  const FabView C = mf_view(MC_, B, b);
+  const ShellAcc C = {mf_view(MC_, B, b), ccomp};
   const double dxinv[3] = {L.dxinv[0], L.dxinv[1], L.dxinv[2]};
-  Vec3 no = normal_at(C, ccomp, X[0], X[1], X[2], dxinv);
+  Vec3 no = normal_at(C, X[0], X[1], X[2], dxinv);
   if (A.thr >= 0.0) {
-    const double c0 = C(X[0], X[1], X[2], ccomp);
+    const double c0 = C(X[0], X[1], X[2]);
     if (c0 < A.thr || c0 > 1.0 - A.thr) { no.x = 0.0; no.y = 0.0; no.z = 0.0; }
   }
   double* o = MO.data + MO.off[b];
@@ -75,15 +132,25 @@ __global__ __launch_bounds__(256) void k_faces_normal(DLevelView L, DMFView MC_,
 // normals of MLMG applyBC on n_d (curvature.cpp:510-546).  Normals of cells of this box are read
 // back from the output (exact after phase A) unless the threshold clip zeroed them there; normals
 // of valid cells of neighbouring boxes are recomputed from the local ghost c.
-__global__ __launch_bounds__(256, PA_FC_WAVES) void k_faces_curv(DLevelView L, DMFView MC_, int ccomp, DLevelView LCr, DMFView MN, int cncomp0, DMFView MO,
-                                                    int ncomp0, int kcomp, FaceArgs A, int* nbad) {
+// CG = false: c from the stored shell copy MC_[ccomp]; CG = true: MC_[ccomp] is PHI and c comes through CgAcc.
+template <bool CG>
+__global__ __launch_bounds__(256, PA_FC_WAVES) void k_faces_curv(LevBatch<FixArgs> Bt, int* nbad) {
+  unsigned fy;
+  const FixArgs& Fx = Bt.a[Bt.find(blockIdx.y, fy)];
+  const DLevelView& L = Fx.L;
+  const DMFView& MC_ = Fx.MC_;
+  const DLevelView& LCr = Fx.LCr;
+  const DMFView& MN = Fx.MN;
+  const DMFView& MO = Fx.MO;
+  const FaceArgs& A = Fx.A;
+  const int ccomp = Fx.ccomp, cncomp0 = Fx.cncomp0, ncomp0 = Fx.ncomp0, kcomp = Fx.kcomp;
   int b, fdir, side, layer, q0[3];
   DBox B;
   const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (A.perim_only) {
     // compact enumeration of the perimeter cells of the face (the interior belongs to k_faces_curv_fast):
     // two full rows in t0, then the two end columns of the rows in between; layers slowest
-    const int e = L.sfaces[blockIdx.y];
+    const int e = L.sfaces[fy];
     b = e / 6; fdir = (e % 6) >> 1; side = e & 1;
     B = L.boxes[b];
     const int t0 = (fdir == 0) ? 1 : 0, t1 = (fdir == 2) ? 1 : 2;
@@ -102,24 +169,26 @@ __global__ __launch_bounds__(256, PA_FC_WAVES) void k_faces_curv(DLevelView L, D
     q0[t0] = B.lo[t0] + (int)a0;
     q0[t1] = B.lo[t1] + (int)a1;
     if (layer >= B.hi[fdir] - B.lo[fdir] + 1) return;
-    if ((L.sfcode[L.sfoff[blockIdx.y] + a0 + (long long)n0 * a1] & 3u) == 0) return;
+    if ((L.sfcode[L.sfoff[fy] + a0 + (long long)n0 * a1] & 3u) == 0) return;
   } else {
-    if (!sface_decode(L, blockIdx.y, t, A.layers, b, B, fdir, side, q0, layer)) return;
+    if (!sface_decode(L, fy, t, A.layers, b, B, fdir, side, q0, layer)) return;
     const int t0 = (fdir == 0) ? 1 : 0, t1 = (fdir == 2) ? 1 : 2;
     if (layer >= B.hi[fdir] - B.lo[fdir] + 1) return;
-    if ((L.sfcode[L.sfoff[blockIdx.y] + (t - (long long)layer * (B.hi[t0] - B.lo[t0] + 1) * (B.hi[t1] - B.lo[t1] + 1))] & 3u) == 0) return;
+    if ((L.sfcode[L.sfoff[fy] + (t - (long long)layer * (B.hi[t0] - B.lo[t0] + 1) * (B.hi[t1] - B.lo[t1] + 1))] & 3u) == 0) return;
   }
   const int n[3] = {B.hi[0] - B.lo[0] + 1, B.hi[1] - B.lo[1] + 1, B.hi[2] - B.lo[2] + 1};
   int X[3] = {q0[0], q0[1], q0[2]};
   X[fdir] += side ? -(1 + layer) : (1 + layer);
-  const FabView C = mf_view(MC_, B, b);
+  const ShellAcc Cs = {mf_view(MC_, B, b), ccomp};
+  const CgAcc Cg = {&L, mf_view(MC_, B, b), B, b, ccomp, A.pmin, A.invd};
   const double dxinv[3] = {L.dxinv[0], L.dxinv[1], L.dxinv[2]};
   const double* o = MO.data + MO.off[b];
+  auto C = [&](int i, int j, int k) -> double { return CG ? Cg(i, j, k) : Cs(i, j, k); };
   // component d of the (unclipped) normal at a valid cell p of this box
   auto nrm = [&](const int p[3], int d) -> double {
-    if (A.thr >= 0.0) {
-      const double cp = C(p[0], p[1], p[2], ccomp);
-      if (cp < A.thr || cp > 1.0 - A.thr) return comp_of(normal_at(C, ccomp, p[0], p[1], p[2], dxinv), d);
+    if (!CG && A.thr >= 0.0) {
+      const double cp = C(p[0], p[1], p[2]);
+      if (cp < A.thr || cp > 1.0 - A.thr) return comp_of(normal_at(C, p[0], p[1], p[2], dxinv), d);
     }
     return o[fab_index(B, MO.ng, MO.ncomp, ncomp0 + d, p[0], p[1], p[2])];
   };
@@ -142,7 +211,7 @@ __global__ __launch_bounds__(256, PA_FC_WAVES) void k_faces_curv(DLevelView L, D
       }
       const int cls = (int)(code & 3u);
       if (cls == 0) {
-        nb[s2] = comp_of(normal_at(C, ccomp, q[0], q[1], q[2], dxinv), d);
+        nb[s2] = comp_of(normal_at(C, q[0], q[1], q[2], dxinv), d);
       } else if (cls == 2) {
         nb[s2] = (A.bc[d] == PA_BC_REFLECT_ODD) ? -n0d : n0d;
       } else {
@@ -168,8 +237,8 @@ __global__ __launch_bounds__(256, PA_FC_WAVES) void k_faces_curv(DLevelView L, D
     curv += cdiff(dxinv[d], nb[0], n0d, nb[1]);
   }
   curv = curv * 0.5;
-  if (A.thr >= 0.0) {
-    const double c0 = C(X[0], X[1], X[2], ccomp);
+  if (!CG && A.thr >= 0.0) {
+    const double c0 = C(X[0], X[1], X[2]);
     if (c0 < A.thr || c0 > 1.0 - A.thr) curv = 0.0;
   }
   if (!ok) atomicAdd(nbad, 1);
@@ -181,7 +250,7 @@ __global__ __launch_bounds__(256, PA_FC_WAVES) void k_faces_curv(DLevelView L, D
 // normals it needs are plain loads from the output (exact after phase A), shared between the two
 // layers, and only the ghost normal beyond the face needs the boundary condition.  Same operations in
 // the same order as k_faces_curv (d = 0,1,2; cdiff; *0.5), which still handles the perimeter cells.
-template <int FD>
+template <int FD, int NL>
 __device__ __forceinline__ void faces_curv_fast_body(const DLevelView& L, const DLevelView& LCr, const DMFView& MN, int cncomp0, const DMFView& MO,
                                                      int ncomp0, int kcomp, const FaceArgs& A, int* nbad, int b, const DBox& B, int side,
                                                      const int q0[3], unsigned code) {
@@ -204,8 +273,11 @@ __device__ __forceinline__ void faces_curv_fast_body(const DLevelView& L, const 
   const double nfd1 = nf[0], nfd2 = nf[in], nfd3 = nf[2 * in];
   const double a0m = n0p[-st[T0]], a0c = n0p[0], a0p = n0p[st[T0]];
   const double a1m = n1p[-st[T1]], a1c = n1p[0], a1p = n1p[st[T1]];
-  const double b0m = n0p[in - st[T0]], b0c = n0p[in], b0p = n0p[in + st[T0]];
-  const double b1m = n1p[in - st[T1]], b1c = n1p[in], b1p = n1p[in + st[T1]];
+  double b0m = 0, b0c = 0, b0p = 0, b1m = 0, b1c = 0, b1p = 0;
+  if (NL > 1) {
+    b0m = n0p[in - st[T0]]; b0c = n0p[in]; b0p = n0p[in + st[T0]];
+    b1m = n1p[in - st[T1]]; b1c = n1p[in]; b1p = n1p[in + st[T1]];
+  }
   // ghost normal: MLMG applyBC on n_FD (curvature.cpp:510-531)
   double g;
   bool ok = true;
@@ -248,22 +320,30 @@ __device__ __forceinline__ void faces_curv_fast_body(const DLevelView& L, const 
   if (!ok) atomicAdd(nbad, 1);
   double* ko = o + (long long)kcomp * cso + idx1;
   ko[0] = k1;
-  ko[in] = k2;
+  if (NL > 1) ko[in] = k2;
 }
 
-__global__ __launch_bounds__(256) void k_faces_curv_fast(DLevelView L, DLevelView LCr, DMFView MN, int cncomp0, DMFView MO, int ncomp0, int kcomp,
-                                                         FaceArgs A, int* nbad) {
+template <int NL>
+__global__ __launch_bounds__(256) void k_faces_curv_fast(LevBatch<FixArgs> Bt, int* nbad) {
+  unsigned fy;
+  const FixArgs& Fx = Bt.a[Bt.find(blockIdx.y, fy)];
+  const DLevelView& L = Fx.L;
+  const DLevelView& LCr = Fx.LCr;
+  const DMFView& MN = Fx.MN;
+  const DMFView& MO = Fx.MO;
+  const FaceArgs& A = Fx.A;
+  const int cncomp0 = Fx.cncomp0, ncomp0 = Fx.ncomp0, kcomp = Fx.kcomp;
   int b, fdir, side, layer, q0[3];
   DBox B;
   const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  if (!sface_decode(L, blockIdx.y, t, 1, b, B, fdir, side, q0, layer)) return;
+  if (!sface_decode(L, fy, t, 1, b, B, fdir, side, q0, layer)) return;
   const int t0 = (fdir == 0) ? 1 : 0, t1 = (fdir == 2) ? 1 : 2;
   if (!(q0[t0] > B.lo[t0] && q0[t0] < B.hi[t0] && q0[t1] > B.lo[t1] && q0[t1] < B.hi[t1])) return;  // perimeter: k_faces_curv
-  const unsigned code = L.sfcode[L.sfoff[blockIdx.y] + t];
+  const unsigned code = L.sfcode[L.sfoff[fy] + t];
   switch (fdir) {  // uniform per workgroup
-    case 0: faces_curv_fast_body<0>(L, LCr, MN, cncomp0, MO, ncomp0, kcomp, A, nbad, b, B, side, q0, code); break;
-    case 1: faces_curv_fast_body<1>(L, LCr, MN, cncomp0, MO, ncomp0, kcomp, A, nbad, b, B, side, q0, code); break;
-    default: faces_curv_fast_body<2>(L, LCr, MN, cncomp0, MO, ncomp0, kcomp, A, nbad, b, B, side, q0, code); break;
+    case 0: faces_curv_fast_body<0, NL>(L, LCr, MN, cncomp0, MO, ncomp0, kcomp, A, nbad, b, B, side, q0, code); break;
+    case 1: faces_curv_fast_body<1, NL>(L, LCr, MN, cncomp0, MO, ncomp0, kcomp, A, nbad, b, B, side, q0, code); break;
+    default: faces_curv_fast_body<2, NL>(L, LCr, MN, cncomp0, MO, ncomp0, kcomp, A, nbad, b, B, side, q0, code); break;
   }
 }
 
@@ -355,7 +435,8 @@ static void march_launch(hipStream_t st, const BP& bp, int nx, int ny, int nz, u
     A.tiles_max = (int)g.x;                                                                                            \
     if (A.order == 2) g = dim3(g.x * 8u * ((nboxes + 7u) / 8u), 1);                                                    \
     else if (A.order) g = dim3(g.x * g.y, 1);                                                                          \
-    if (pair && clip) hipLaunchKernelGGL((k_gradcurv_march3<BP, M, true, true>), g, dim3(64 * (M + 3)), 0, st, bp, A); \
+    if (A.cg && !clip) hipLaunchKernelGGL((k_gradcurv_march3<BP, M, false, false, 0, true>), g, dim3(64 * (M + 3)), 0, st, bp, A); \
+    else if (pair && clip) hipLaunchKernelGGL((k_gradcurv_march3<BP, M, true, true>), g, dim3(64 * (M + 3)), 0, st, bp, A); \
     else if (pair) hipLaunchKernelGGL((k_gradcurv_march3<BP, M, false, true>), g, dim3(64 * (M + 3)), 0, st, bp, A);   \
     else if (clip) hipLaunchKernelGGL((k_gradcurv_march3<BP, M, true>), g, dim3(64 * (M + 3)), 0, st, bp, A);          \
     else hipLaunchKernelGGL((k_gradcurv_march3<BP, M, false>), g, dim3(64 * (M + 3)), 0, st, bp, A);                   \
@@ -428,7 +509,7 @@ int pa_gradcurv_faces_phase(pa_ctx* ctx, const pa_mf* c, int ccomp, const pa_mf*
   if (crse_n && (phase & 2) && pa_coarse_source(ctx, L, crse_n, cncomp0, 3, 0, 0, 0, &crse_n, &cncomp0)) return 1;
   FaceArgs A;
   for (int d = 0; d < 3; ++d) A.bc[d] = bc[d];
-  A.ratio = ratio; A.has_crse = crse_n ? 1 : 0; A.thr = thr; A.layers = 2; A.perim_only = 0;
+  A.ratio = ratio; A.has_crse = crse_n ? 1 : 0; A.thr = thr; A.layers = 2; A.perim_only = 0; A.pmin = 0.0; A.invd = 1.0;
   // fast path for the interior of the faces: no threshold clip, every box >= 3 cells thick
   bool fast = !(thr >= 0.0);
   for (const DBox& B : c->lev->boxes)
@@ -445,14 +526,16 @@ int pa_gradcurv_faces_phase(pa_ctx* ctx, const pa_mf* c, int ccomp, const pa_mf*
     PA_HIP(hipGetLastError());
     return 0;
   }
+  LevBatch<FixArgs> Bt;
+  Bt.n = 1;
+  Bt.ycum[1] = (int)nsf;
+  Bt.a[0] = FixArgs{L->view, c->view, ccomp, crse_n ? crse_n->lev->view : L->view, crse_n ? crse_n->view : c->view, cncomp0, out->view, ncomp0, kcomp, A};
   if (fast) {
-    hipLaunchKernelGGL(k_faces_curv_fast, dim3((unsigned)((nf + 255) / 256), nsf), dim3(256), 0, ctx->stream, L->view,
-                       crse_n ? crse_n->lev->view : L->view, crse_n ? crse_n->view : c->view, cncomp0, out->view, ncomp0, kcomp, A, ctx->d_flags);
-    A.perim_only = 1;
+    hipLaunchKernelGGL(k_faces_curv_fast<2>, dim3((unsigned)((nf + 255) / 256), nsf), dim3(256), 0, ctx->stream, Bt, ctx->d_flags);
+    Bt.a[0].A.perim_only = 1;
   }
   const long long ncell = fast ? 2 * (std::max(n0, std::max(n1, n2)) + std::max(n0, std::max(n1, n2))) : nf;  // perimeter <= 4 * longest edge
-  hipLaunchKernelGGL(k_faces_curv, dim3((unsigned)((ncell * A.layers + 255) / 256), nsf), dim3(256), 0, ctx->stream, L->view, c->view, ccomp,
-                     crse_n ? crse_n->lev->view : L->view, crse_n ? crse_n->view : c->view, cncomp0, out->view, ncomp0, kcomp, A, ctx->d_flags);
+  hipLaunchKernelGGL(k_faces_curv<false>, dim3((unsigned)((ncell * A.layers + 255) / 256), nsf), dim3(256), 0, ctx->stream, Bt, ctx->d_flags);
   PA_HIP(hipGetLastError());
   return 0;
 }
@@ -467,6 +550,251 @@ extern "C" int pa_gradcurv_fab(pa_ctx* ctx, pa_box valid, const pa_fab* phi, int
   FabBP2 bp{fab_view(*phi), fab_view(*out), to_dbox(valid), {dxinv[0], dxinv[1], dxinv[2]}};
   MarchArgs A{pcomp, ocomp, fused_kseg(), pmin, 1.0 / (pmax - pmin), thr, 0, 1, 1, 1};
   march_launch(ctx->stream, bp, valid.hi[0] - valid.lo[0] + 1, valid.hi[1] - valid.lo[1] + 1, valid.hi[2] - valid.lo[2] + 1, 1, A);
+  PA_HIP(hipGetLastError());
+  return 0;
+}
+
+// ===================================================================================== exact-normal pipeline
+// The sweep with CG (pa_fused_march3.h) takes the progress variable behind special faces from the level's compact
+// face-major arrays, so N is final after the sweep and only the curvature of the FIRST layer behind a special face is
+// left (its ghost normal is MLMG applyBC on n_d, curvature.cpp:510-531).  Per level: k_prep_faces (+ k_prep_ring) before
+// the sweep, k_faces_curv_fast<1> + k_faces_curv<true> after it -- against progress shell + two applyBC launches before
+// and three fix-up launches over two layers after it in the first pipeline (kept for the threshold clip, mixed faces and
+// narrow boxes).
+struct PrepArgs {
+  int bc[3];
+  int ratio, has_crse;
+  double pmin, invd;
+};
+
+// Thread per ghost cell of a special face: the face ghost of phi (MLMG applyBC, as k_apply_bc_sfaces) and the resolved
+// ghost value of c = the same boundary condition applied to c, whose interior values are (phi - pmin) * invd formed on the
+// fly and whose coarse values are the affine view of the coarse phi -- the operations of k_apply_bc_sfaces<2> on a stored c.
+struct PrepLev { DLevelView L; DMFView M; int comp; DLevelView LC; DMFView MC; int ccomp; PrepArgs A; };
+__global__ __launch_bounds__(256) void k_prep_faces(LevBatch<PrepLev> Bt, int* nbad) {
+  unsigned fy;
+  const PrepLev& Pl = Bt.a[Bt.find(blockIdx.y, fy)];
+  const DLevelView& L = Pl.L;
+  const DMFView& M = Pl.M;
+  const DLevelView& LC = Pl.LC;
+  const DMFView& MC = Pl.MC;
+  const PrepArgs& A = Pl.A;
+  const int comp = Pl.comp, ccomp = Pl.ccomp;
+  int b, dir, side, layer, q[3];
+  DBox B;
+  const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (!sface_decode(L, fy, t, 1, b, B, dir, side, q, layer)) return;
+  const unsigned code = L.sfcode[L.sfoff[fy] + t];
+  const int cls = (int)(code & 3u);
+  const int t0 = (dir == 0) ? 1 : 0, t1 = (dir == 2) ? 1 : 2;
+  double* cgp = L.cg + L.cgoff[fy] + (long long)(q[t1] - B.lo[t1] + 1) * (B.hi[t0] - B.lo[t0] + 3) + (q[t0] - B.lo[t0] + 1);
+  double* p = M.data + M.off[b];
+  if (cls == 0) {  // a valid cell of the level (mixed face): FillBoundary has filled phi there
+    *cgp = (p[fab_index(B, M.ng, M.ncomp, comp, q[0], q[1], q[2])] - A.pmin) * A.invd;
+    return;
+  }
+  const int s = side ? -1 : 1;
+  if (cls == 2) {
+    int in[3] = {q[0], q[1], q[2]};
+    in[dir] += s;
+    const double v = p[fab_index(B, M.ng, M.ncomp, comp, in[0], in[1], in[2])];
+    const double vc = (v - A.pmin) * A.invd;
+    const bool odd = A.bc[dir] == PA_BC_REFLECT_ODD;
+    p[fab_index(B, M.ng, M.ncomp, comp, q[0], q[1], q[2])] = odd ? -v : v;
+    *cgp = odd ? -vc : vc;
+    return;
+  }
+  if (!A.has_crse) { atomicAdd(nbad, 1); return; }
+  bool ok = true;
+  double coef[4], bv[2];
+  const int NX = cf_normal_coef(B.hi[dir] - B.lo[dir] + 1, A.ratio, coef);
+  const int xf[2] = {0, 1};
+  cf_interp<2>(code, LC, MC, ccomp, q, dir, A.ratio, xf, ok, bv);
+  if (!ok) atomicAdd(nbad, 1);
+  double tp = 0.0, tc = 0.0;
+  for (int m = 1; m < NX; ++m) {
+    int pc[3] = {q[0], q[1], q[2]};
+    pc[dir] += s * m;
+    const double v = p[fab_index(B, M.ng, M.ncomp, comp, pc[0], pc[1], pc[2])];
+    tp += v * coef[m];
+    tc += ((v - A.pmin) * A.invd) * coef[m];
+  }
+  double gp = tp, gc = tc;
+  gp += bv[0] * coef[0];
+  gc += bv[1] * coef[0];
+  p[fab_index(B, M.ng, M.ncomp, comp, q[0], q[1], q[2])] = gp;
+  *cgp = gc;
+}
+
+// The edge ghost cells of c (outside the box in two directions a < c) that are the boundary ghost of a valid cell of a
+// NEIGHBOURING box (k_apply_bc_edges): stored in the ring of the special face they continue.  Needs the ghost cells of phi
+// that are valid cells of the level (FillBoundary) filled.
+__global__ void k_prep_ring(LevBatch<PrepLev> Bt, int* nbad) {
+  unsigned fy;
+  const PrepLev& Pl = Bt.a[Bt.find(blockIdx.y, fy)];
+  const DLevelView& L = Pl.L;
+  const DMFView& M = Pl.M;
+  const DLevelView& LC = Pl.LC;
+  const DMFView& MC = Pl.MC;
+  const PrepArgs& A = Pl.A;
+  const int comp = Pl.comp, ccomp = Pl.ccomp;
+  const int b = (int)fy;
+  const DBox B = L.boxes[b];
+  const int n[3] = {B.hi[0] - B.lo[0] + 1, B.hi[1] - B.lo[1] + 1, B.hi[2] - B.lo[2] + 1};
+  long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  int e = -1, which = 0, pos = 0;
+  for (int d = 0; d < 3; ++d) {
+    if (t < 4LL * n[d]) { e = d; which = (int)((unsigned)t / (unsigned)n[d]); pos = (int)((unsigned)t % (unsigned)n[d]); break; }
+    t -= 4LL * n[d];
+  }
+  if (e < 0) return;
+  const int a = (e == 0) ? 1 : 0, c = (e == 2) ? 1 : 2;
+  const int sa = which & 1, sc = which >> 1;
+  int q[3];
+  q[e] = B.lo[e] + pos;
+  q[a] = sa ? B.hi[a] + 1 : B.lo[a] - 1;
+  q[c] = sc ? B.hi[c] + 1 : B.lo[c] - 1;
+  const int cls = classify(L, q[0], q[1], q[2]);
+  if (cls == 0) return;
+  int qa[3] = {q[0], q[1], q[2]}, qc[3] = {q[0], q[1], q[2]};
+  qa[a] += sa ? -1 : 1;
+  qc[c] += sc ? -1 : 1;
+  const bool va = classify(L, qa[0], qa[1], qa[2]) == 0;
+  const bool vc = classify(L, qc[0], qc[1], qc[2]) == 0;
+  if (va == vc) return;
+  const int dir = va ? a : c, sd = va ? sa : sc;
+  const int s = sd ? -1 : 1;
+  if (cls == 2 && !((q[dir] < L.domlo[dir] || q[dir] > L.domhi[dir]) && !L.is_per[dir])) return;
+  const int ef = L.sfindex[b * 6 + dir * 2 + sd];
+  if (ef < 0) return;
+  if (cls == 1 && !A.has_crse) { atomicAdd(nbad, 1); return; }
+  const double* p = M.data + M.off[b];
+  double g;
+  if (cls == 2) {
+    int in[3] = {q[0], q[1], q[2]};
+    in[dir] += s;
+    const double v = (p[fab_index(B, M.ng, M.ncomp, comp, in[0], in[1], in[2])] - A.pmin) * A.invd;
+    g = (A.bc[dir] == PA_BC_REFLECT_ODD) ? -v : v;
+  } else {
+    bool ok = true;
+    double coef[4];
+    const int NX = cf_normal_coef(n[dir], A.ratio, coef);
+    const double bv = cf_bndry_value(L, LC, MC, ccomp, q, dir, A.ratio, ok);  // MC carries the affine view
+    if (!ok) atomicAdd(nbad, 1);
+    double tmp = 0.0;
+    for (int m = 1; m < NX; ++m) {
+      int pc[3] = {q[0], q[1], q[2]};
+      pc[dir] += s * m;
+      tmp += ((p[fab_index(B, M.ng, M.ncomp, comp, pc[0], pc[1], pc[2])] - A.pmin) * A.invd) * coef[m];
+    }
+    g = tmp;
+    g += bv * coef[0];
+  }
+  const int t0 = (dir == 0) ? 1 : 0, t1 = (dir == 2) ? 1 : 2;
+  L.cg[L.cgoff[ef] + (long long)(q[t1] - B.lo[t1] + 1) * (B.hi[t0] - B.lo[t0] + 3) + (q[t0] - B.lo[t0] + 1)] = g;
+}
+
+// the level's compact ghost arrays, allocated on first use (a cache of the level object)
+static int level_cg(pa_ctx* ctx, const pa_level* Lc) {
+  pa_level* L = const_cast<pa_level*>(Lc);
+  if (L->d_cg) return 0;
+  PA_HIP(hipMalloc(&L->d_cg, sizeof(double) * (size_t)std::max<long long>(L->cg_total, 8)));
+  PA_HIP(hipMemsetAsync(L->d_cg, 0, sizeof(double) * (size_t)std::max<long long>(L->cg_total, 8), ctx->stream));
+  L->view.cg = L->d_cg;
+  return 0;
+}
+
+// can the exact-normal pipeline run on this level (same answer on every rank of a sharded level)?
+bool pa_fused2_level_ok(const pa_level* L) {
+  static const int env = [] { const char* e = getenv("PA_FUSED2"); return e ? atoi(e) : 1; }();
+  static const int march = [] { const char* e = getenv("PA_MARCH"); return e ? atoi(e) : 3; }();
+  if (!env || march != 3 || getenv("PA_DBG") || getenv("PA_MTY")) return false;
+  if (!L->fusable || !L->pure_faces) return false;
+  const std::vector<DBox>& all = L->gboxes.empty() ? L->boxes : L->gboxes;
+  int maxnx = 0;
+  for (const DBox& B : all) {
+    maxnx = std::max(maxnx, B.hi[0] - B.lo[0] + 1);
+    for (int d = 0; d < 3; ++d)
+      if (B.hi[d] - B.lo[d] + 1 < 3) return false;
+  }
+  return maxnx > 32;  // narrower boxes run k_gradcurv_march3n, which has no CG variant
+}
+
+// before the sweeps: face ghosts of phi + resolved ghost c (faces and ring) of several levels, one launch pair for up to
+// PA_MAXB levels.  crse[l]: the coarser level's phi (component ccomp) or this rank's coarse-source copy of it, null on
+// level 0 / where this rank has no coarse-fine face; the local half of FillBoundary(2) must have run.
+int pa_gradcurv_prep_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int comp, const pa_mf* const* crse, int ccomp, const int32_t bc[3], double pmin, double pmax) {
+  for (int l0 = 0; l0 < nlev; l0 += PA_MAXB) {
+    LevBatch<PrepLev> Bf, Br;
+    long long ntf = 0, ntr = 0;
+    for (int l = l0; l < nlev && l < l0 + PA_MAXB; ++l) {
+      const pa_level* L = phi[l]->lev;
+      if (L->boxes.empty()) continue;
+      if (level_cg(ctx, L)) return 1;
+      if (L->sfaces.empty()) continue;
+      PrepLev P;
+      for (int d = 0; d < 3; ++d) P.A.bc[d] = bc[d];
+      P.A.ratio = 2; P.A.has_crse = crse[l] ? 1 : 0; P.A.pmin = pmin; P.A.invd = 1.0 / (pmax - pmin);
+      P.L = L->view; P.M = phi[l]->view; P.comp = comp;
+      P.LC = crse[l] ? crse[l]->lev->view : L->view;
+      P.MC = crse[l] ? crse[l]->view : phi[l]->view;
+      P.MC.xform = 1; P.MC.xa = pmin; P.MC.xb = P.A.invd;
+      P.ccomp = ccomp;
+      const long long n0 = L->maxn[0], n1 = L->maxn[1], n2 = L->maxn[2];
+      ntf = std::max(ntf, std::max(n1 * n2, std::max(n0 * n2, n0 * n1)));
+      ntr = std::max(ntr, 4 * (n0 + n1 + n2));
+      Bf.a[Bf.n] = P; Bf.ycum[Bf.n + 1] = Bf.ycum[Bf.n] + (int)L->sfaces.size(); ++Bf.n;
+      Br.a[Br.n] = P; Br.ycum[Br.n + 1] = Br.ycum[Br.n] + (int)L->boxes.size(); ++Br.n;
+    }
+    if (!Bf.n) continue;
+    ProfScope prof(ctx, PA_TAG_BC);
+    hipLaunchKernelGGL(k_prep_faces, dim3((unsigned)((ntf + 255) / 256), (unsigned)Bf.ycum[Bf.n]), dim3(256), 0, ctx->stream, Bf, ctx->d_flags);
+    hipLaunchKernelGGL(k_prep_ring, dim3((unsigned)((ntr + 255) / 256), (unsigned)Br.ycum[Br.n]), dim3(256), 0, ctx->stream, Br, ctx->d_flags);
+  }
+  PA_HIP(hipGetLastError());
+  return 0;
+}
+
+// the sweep with exact normals (the level's compact ghost arrays must be current: pa_gradcurv_prep_level)
+int pa_gradcurv_level_cg(pa_ctx* ctx, const pa_mf* phi, int pcomp, double pmin, double pmax, pa_mf* out, int ocomp) {
+  const pa_level* L = phi->lev;
+  if (L->boxes.empty()) return 0;
+  if (level_cg(ctx, L)) return 1;
+  LevelBP2 bp{L->view, phi->view, out->view};
+  MarchArgs A{pcomp, ocomp, fused_kseg(), pmin, 1.0 / (pmax - pmin), -1.0, 0, 1, 1, 1};
+  A.cg = 1;
+  ProfScope prof(ctx, PA_TAG_GRADCURV);
+  march_launch(ctx->stream, bp, L->maxn[0], L->maxn[1], L->maxn[2], (unsigned)L->boxes.size(), A, false);
+  PA_HIP(hipGetLastError());
+  return 0;
+}
+
+// after the sweeps of ALL levels: curvature of the first layer behind every special face, several levels per launch pair.
+// crse_n[l]: the coarser level's output (normal components from cncomp0) or this rank's coarse-source copy of them.
+int pa_gradcurv_fix_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, const pa_mf* const* crse_n, int cncomp0, const int32_t bc[3], double pmin, double pmax,
+                           pa_mf* const* out, int ncomp0, int kcomp) {
+  for (int l0 = 0; l0 < nlev; l0 += PA_MAXB) {
+    LevBatch<FixArgs> Bt;
+    long long nf = 0, nper = 0;
+    for (int l = l0; l < nlev && l < l0 + PA_MAXB; ++l) {
+      const pa_level* L = phi[l]->lev;
+      if (L->boxes.empty() || L->sfaces.empty()) continue;
+      FaceArgs A;
+      for (int d = 0; d < 3; ++d) A.bc[d] = bc[d];
+      A.ratio = 2; A.has_crse = crse_n[l] ? 1 : 0; A.thr = -1.0; A.layers = 1; A.perim_only = 1; A.pmin = pmin; A.invd = 1.0 / (pmax - pmin);
+      Bt.a[Bt.n] = FixArgs{L->view, phi[l]->view, pcomp, crse_n[l] ? crse_n[l]->lev->view : L->view, crse_n[l] ? crse_n[l]->view : phi[l]->view, cncomp0,
+                           out[l]->view, ncomp0, kcomp, A};
+      Bt.ycum[Bt.n + 1] = Bt.ycum[Bt.n] + (int)L->sfaces.size();
+      ++Bt.n;
+      const long long n0 = L->maxn[0], n1 = L->maxn[1], n2 = L->maxn[2];
+      nf = std::max(nf, std::max(n1 * n2, std::max(n0 * n2, n0 * n1)));
+      nper = std::max(nper, 4 * std::max(n0, std::max(n1, n2)));  // perimeter of a face <= 4 * the longest edge
+    }
+    if (!Bt.n) continue;
+    ProfScope prof(ctx, PA_TAG_GRADCURV_FACES);
+    hipLaunchKernelGGL(k_faces_curv_fast<1>, dim3((unsigned)((nf + 255) / 256), (unsigned)Bt.ycum[Bt.n]), dim3(256), 0, ctx->stream, Bt, ctx->d_flags);
+    hipLaunchKernelGGL(k_faces_curv<true>, dim3((unsigned)((nper + 255) / 256), (unsigned)Bt.ycum[Bt.n]), dim3(256), 0, ctx->stream, Bt, ctx->d_flags);
+  }
   PA_HIP(hipGetLastError());
   return 0;
 }

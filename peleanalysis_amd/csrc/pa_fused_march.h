@@ -60,6 +60,7 @@ struct MarchArgs {
   // all tiles of a box run on ONE XCD at about the same time and the halo rows / partial lines that
   // neighbouring tiles both read are served by that XCD's L2 instead of being fetched once per XCD.
   int order, nboxes, txy_max, tiles_max;
+  int cg = 0;  // host side: launch the CG variant of k_gradcurv_march3 (pa_fused_march3.h)
 };
 
 template <typename BP, int PA_MTY, int MINW>

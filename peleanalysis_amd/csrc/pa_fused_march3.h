@@ -109,7 +109,17 @@ __device__ __forceinline__ void store_pair(char* base, unsigned off, bool odd, d
   *(pa_d2*)(base + off) = v;
 }
 
-template <typename BP, int PA_MTY, bool CLIP, bool PAIR = false, int DBG = 0>
+// CG: the progress variable in the ghost cells behind SPECIAL box faces (coarse-fine / wall) is not (phi_ghost - pmin) *
+// invdenom but the reference's boundary condition applied to c itself; with CG the kernel takes those values from the
+// level's compact face-major arrays (DLevelView::cg, filled by k_prep_faces in pa_fused2.hip), so the flame normal is
+// exact in EVERY valid cell and the curvature everywhere except in the first layer behind such a face (whose ghost
+// normal comes from the boundary condition on n: pa_fused2.hip).  Where the arrays are read:
+//   z faces  output rows: c of plane lo_z - 1 (prologue) / hi_z + 1 (one select per step);
+//   y faces  the halo row wave IS the ghost row: its second stream (the row beyond, only needed for the ghost normal,
+//            which is irrelevant there) is re-aimed at the array, one plane ahead;
+//   x faces  the edge wave's lanes of that side: likewise its stream of the column beyond.
+// Values that only feed ghost normals behind special faces (edge ghosts, second ghost layer) may be anything.
+template <typename BP, int PA_MTY, bool CLIP, bool PAIR = false, int DBG = 0, bool CG = false>
 __global__ __launch_bounds__(64 * (PA_MTY + 3), 1) void k_gradcurv_march3(BP bp, MarchArgs A) {
   FabView P, O;
   DBox V;
@@ -144,6 +154,16 @@ __global__ __launch_bounds__(64 * (PA_MTY + 3), 1) void k_gradcurv_march3(BP bp,
   const int llast = iR - 1 - i0;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int rtop = min(PA_MROWS - 1, V.hi[1] + 1 - j0 + 1);  // row slot of the last live row
+  // compact resolved-ghost arrays of the special faces this tile touches (null: ordinary face / tile not at that face)
+  const double *cgxl = nullptr, *cgxh = nullptr, *cgyl = nullptr, *cgyh = nullptr, *cgzl = nullptr, *cgzh = nullptr;
+  if (CG) {
+    if (bx == 0) cgxl = bp.cg_face(box, 0);
+    if (iR == V.hi[0] + 1) cgxh = bp.cg_face(box, 1);
+    if (by == 0) cgyl = bp.cg_face(box, 2);
+    if (j0 + rtop - 1 == V.hi[1] + 1) cgyh = bp.cg_face(box, 3);
+    if (k0 == V.lo[2]) cgzl = bp.cg_face(box, 4);
+    if (k1 == V.hi[2]) cgzh = bp.cg_face(box, 5);
+  }
 
   __shared__ MarchLds<PA_MTY> S;
   const long long pps = (long long)P.nx * P.ny * 8;  // plane stride of phi, bytes
@@ -191,19 +211,32 @@ __global__ __launch_bounds__(64 * (PA_MTY + 3), 1) void k_gradcurv_march3(BP bp,
       // derives for the loop are the minimum over the entry edge and the back edge
       const int jout = (rr == 0) ? j - 1 : j + 1;
       const char* go = (const char*)(P.p + P.idx(i0, jout, k0 - 1, pcomp));
-      double co = PA_PROG(PA_LDG(go, lo8));
+      // CG: this row is the ghost row behind a special y face: the second stream reads the face's compact array
+      // [plane][x], one plane AHEAD (it supplies c of plane p+2 at step p instead of c_out of plane p+1)
+      const double* cgy = CG ? ((rr == 0) ? cgyl : cgyh) : nullptr;
+      const bool ysp = CG && cgy != nullptr;
+      const long long pso = ysp ? (long long)(nx + 2) * 8 : pps;  // plane stride of the second stream
+      const int sh = ysp ? 1 : 0;
+      if (ysp) {
+        const char* cb = (const char*)(cgy + (long long)(k0 - 1 - V.lo[2] + 1) * (nx + 2) + (i0 - V.lo[0] + 1));
+        cc = PA_LDG(cb, lo8);  // c of plane k0-1
+        go = cb + pso;         // plane k0
+      }
+      double co = PA_LDG(go, lo8);
+      if (ysp) cp = co;        // c of plane k0
+      else co = PA_PROG(co);
       double fo[3];
       __builtin_amdgcn_sched_barrier(0);
       f[0] = PA_LDG(gp + 3 * pps, lo8);
-      fo[0] = PA_LDG(go + pps, lo8);
+      fo[0] = PA_LDG(go + pso, lo8);
       __builtin_amdgcn_sched_barrier(0);
       f[1] = PA_LDG(gp + 4 * pps, lo8);
-      fo[1] = PA_LDG(go + 2 * pps, lo8);
+      fo[1] = PA_LDG(go + 2 * pso, lo8);
       __builtin_amdgcn_sched_barrier(0);
       gp += 4 * pps;
       gp += (k0 + 3 <= kfmax) ? pps : 0;
-      go += 2 * pps;
-      go += (k0 + 2 <= pend) ? pps : 0;
+      go += 2 * pso;
+      go += (k0 + 2 + sh <= pend) ? pso : 0;
       f[2] = PA_LDG(gp, lo8);   // gp -> plane min(k0+3, k1+2), the youngest plane requested
       fo[2] = PA_LDG(go, lo8);  // go -> plane min(k0+2, k1+1)
       __builtin_amdgcn_sched_barrier(0);
@@ -217,7 +250,7 @@ __global__ __launch_bounds__(64 * (PA_MTY + 3), 1) void k_gradcurv_march3(BP bp,
         PA_OPAQUE(lo8);
         __builtin_amdgcn_sched_barrier(0);
         gp += (p + 5 <= kfmax) ? pps : 0;
-        go += (p + 4 <= pend) ? pps : 0;
+        go += (p + 4 + sh <= pend) ? pso : 0;
         if (OLD_SCHED) {
           f[SP] = PA_LDG(gp, lo8);
           fo[SP] = PA_LDG(go, lo8);
@@ -240,7 +273,7 @@ __global__ __launch_bounds__(64 * (PA_MTY + 3), 1) void k_gradcurv_march3(BP bp,
           f[SP] = PA_LDG(gp, lo8);
           fo[SP] = PA_LDG(go, lo8);
         }
-        cm = cc; cc = cp; cp = PA_PROG(x); co = PA_PROG(xo);
+        cm = cc; cc = cp; cp = ysp ? xo : PA_PROG(x); co = PA_PROG(xo);
         fzc = fzh;
         p0 = p1; p1 = x;
       };
@@ -257,6 +290,17 @@ __global__ __launch_bounds__(64 * (PA_MTY + 3), 1) void k_gradcurv_march3(BP bp,
     // for the steady state, so requests still pending on entry (no stores behind them yet) would pull
     // N down from 26 to 2 and drain the stores every third plane.  Costs one round trip per segment.
     asm volatile("" ::"v"(f[0]), "v"(f[1]), "v"(f[2]));
+    // CG: c of the ghost plane behind a special z face from the face's compact array [y][x]
+    double cgzv = 0.0;
+    int pzh = -0x40000000;  // the step whose request becomes c of plane hi_z + 1
+    if (CG && cgzl) {
+      cc = PA_LDG((const char*)(cgzl + (long long)(j - V.lo[1] + 1) * (nx + 2) + (i0 - V.lo[0] + 1)), lo8);
+      fzc = zflux(dxinv[2], cm, cc);
+    }
+    if (CG && cgzh) {
+      cgzv = PA_LDG((const char*)(cgzh + (long long)(j - V.lo[1] + 1) * (nx + 2) + (i0 - V.lo[0] + 1)), lo8);
+      pzh = k1 - 1;
+    }
     S.c[0][rr][xs] = cc;
     __syncthreads();
     double nxq = 0, nyq = 0, nzq = 0, fzn = 0, fzp = 0;
@@ -361,6 +405,7 @@ __global__ __launch_bounds__(64 * (PA_MTY + 3), 1) void k_gradcurv_march3(BP bp,
         o4 = nxq; o5 = nyq; o6 = nzq; o7 = curv;
       }
       cm = cc; cc = cp; cp = PA_PROG(x);
+      if (CG) cp = (p == pzh) ? cgzv : cp;  // x was phi of plane hi_z + 1
       fzc = fzh; fzn = fznh; fzp = fzph;
       pc = p0; p0 = p1; p1 = x;
       nxq = nxp; nyq = nyp; nzq = nzp;
@@ -401,24 +446,44 @@ __global__ __launch_bounds__(64 * (PA_MTY + 3), 1) void k_gradcurv_march3(BP bp,
     unsigned og = (unsigned)((j - P.lo[1]) * P.nx + (i - P.lo[0])) * 8u;
     unsigned oo = (unsigned)((j - P.lo[1]) * P.nx + ((side ? i + 1 : i - 1) - P.lo[0])) * 8u;
     const char* gp = gb;
-    const char* go = gb + pps;  // the column beyond the edge column starts at plane k0-1
+    // the column beyond the edge column starts at plane k0-1: wave-uniform base + lane offset `oo`.  With CG the stream
+    // is addressed through a per-lane pointer instead (gol): the lanes of a side that is a special x face read that
+    // face's compact array [plane][y], one plane ahead (see the halo rows)
+    const char* go = gb + pps;
+    const char* gol = gb + pps + oo;
+    long long pso = pps;
+    int sh = 0;
+#define PA_LDO(d) (CG ? PA_LDG(gol + (d) * pso, 0) : PA_LDG(go + (d) * pps, oo))
     double p0 = PA_LDG(gp + pps, og), p1 = PA_LDG(gp + 2 * pps, og);
     double cm = PA_PROG(PA_LDG(gp, og)), cc = PA_PROG(p0), cp = PA_PROG(p1);
-    double co = PA_PROG(PA_LDG(go, oo));
+    const double* cgx = CG ? (side ? cgxh : cgxl) : nullptr;
+    const bool xsp = CG && cgx != nullptr;
+    if (xsp) {
+      const char* cb = (const char*)(cgx + (long long)(k0 - 1 - V.lo[2] + 1) * (ny + 2) + (j - V.lo[1] + 1));
+      pso = (long long)(ny + 2) * 8;
+      sh = 1;
+      cc = PA_LDG(cb, 0);  // c of plane k0-1
+      gol = cb + pso;      // plane k0
+    }
+    double co = PA_LDO(0);
+    if (xsp) cp = co;
+    else co = PA_PROG(co);
     double f[3], fo[3];
     __builtin_amdgcn_sched_barrier(0);
     f[0] = PA_LDG(gp + 3 * pps, og);
-    fo[0] = PA_LDG(go + pps, oo);
+    fo[0] = PA_LDO(1);
     __builtin_amdgcn_sched_barrier(0);
     f[1] = PA_LDG(gp + 4 * pps, og);
-    fo[1] = PA_LDG(go + 2 * pps, oo);
+    fo[1] = PA_LDO(2);
     __builtin_amdgcn_sched_barrier(0);
     gp += 4 * pps;
     gp += (k0 + 3 <= kfmax) ? pps : 0;
     go += 2 * pps;
     go += (k0 + 2 <= pend) ? pps : 0;
+    gol += 2 * pso;
+    gol += (k0 + 2 + sh <= pend) ? pso : 0;
     f[2] = PA_LDG(gp, og);
-    fo[2] = PA_LDG(go, oo);
+    fo[2] = PA_LDO(0);
     __builtin_amdgcn_sched_barrier(0);
     double fzc = zflux(dxinv[2], cm, cc);
     S.c[0][rr][xs] = cc;
@@ -429,13 +494,14 @@ __global__ __launch_bounds__(64 * (PA_MTY + 3), 1) void k_gradcurv_march3(BP bp,
       PA_TAKE(x, f[SP]);
       PA_TAKE(xo, fo[SP]);
       PA_OPAQUE(og);
-      PA_OPAQUE(oo);
+      if (!CG) PA_OPAQUE(oo);
       __builtin_amdgcn_sched_barrier(0);
       gp += (p + 5 <= kfmax) ? pps : 0;
       go += (p + 4 <= pend) ? pps : 0;
+      if (CG) gol += (p + 4 + sh <= pend) ? pso : 0;
       if (OLD_SCHED) {
         f[SP] = PA_LDG(gp, og);
-        fo[SP] = PA_LDG(go, oo);
+        fo[SP] = PA_LDO(0);
       }
       const double inner = S.c[SP][rr][xin];
       const double cl = side ? inner : co, cr = side ? co : inner;
@@ -453,16 +519,17 @@ __global__ __launch_bounds__(64 * (PA_MTY + 3), 1) void k_gradcurv_march3(BP bp,
       __syncthreads();
       if (!OLD_SCHED) {
         PA_OPAQUE(og);
-        PA_OPAQUE(oo);
+        if (!CG) PA_OPAQUE(oo);
         f[SP] = PA_LDG(gp, og);
-        fo[SP] = PA_LDG(go, oo);
+        fo[SP] = PA_LDO(0);
       }
-      cm = cc; cc = cp; cp = PA_PROG(x); co = PA_PROG(xo);
+      cm = cc; cc = cp; cp = xsp ? xo : PA_PROG(x); co = PA_PROG(xo);
       fzc = fzh;
       p0 = p1; p1 = x;
     };
     PA_RUN3(step)
   }
+#undef PA_LDO
 #undef PA_PROG
 #undef PA_RUN3
 }

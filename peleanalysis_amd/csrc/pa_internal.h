@@ -27,6 +27,11 @@ struct DLevelView {
   const int* sfindex;           // [nboxes*6] entry of a box face in sfaces, or -1 (ordinary face: every ghost cell is a valid cell)
   const long long* sfoff;       // [nsf] start of the face's ghost-cell codes in sfcode
   const unsigned short* sfcode; // cf_masks of every ghost cell of every special face, (t0 fastest, t1) per face
+  // Resolved ghost values of the progress variable behind every special face, compact and FACE-MAJOR (pa_fused2.hip):
+  // face e holds (n0+2) x (n1+2) doubles at cg + cgoff[e], element (a0, a1) = a1 * (n0+2) + a0 with a0 / a1 = tangential
+  // coordinate - box lo + 1 (a ring of one cell for the edge ghosts), + 2 rows of slack.  Null: not allocated.
+  const long long* cgoff;
+  double* cg;
 };
 
 struct DMFView {
@@ -37,6 +42,23 @@ struct DMFView {
   // Lets applyBC on the progress variable interpolate from the coarse phi without a stored coarse c.
   int xform;
   double xa, xb;
+};
+
+// Several levels in ONE launch (the boundary kernels of small or sharded levels are launch / latency bound: a launch per
+// level and kernel costs more than the work): blockIdx.y runs over the concatenated rows (boxes / special faces) of up to
+// PA_MAXB levels; level l owns rows ycum[l] .. ycum[l+1]-1.  Passed by value (kernel arguments, < 4 KB).
+#define PA_MAXB 4
+template <typename A, int CAP = PA_MAXB>
+struct LevBatch {
+  int n = 0;
+  int ycum[CAP + 1] = {};
+  A a[CAP];
+  __device__ __forceinline__ int find(unsigned y, unsigned& local) const {
+    int l = 0;
+    while (l + 1 < n && y >= (unsigned)ycum[l + 1]) ++l;
+    local = y - (unsigned)ycum[l];
+    return l;
+  }
 };
 
 struct pa_ctx {
@@ -101,6 +123,11 @@ struct pa_level {
   int maxn[3] = {0, 0, 0};  // max box extent per dim
   long long ncells = 0;
   bool fusable = true;      // no concave coarse-fine corner (see pa_level_create)
+  bool pure_faces = true;   // every special face of the WHOLE BoxArray has no ghost cell that is a valid cell (pa_fused2.hip)
+  long long* d_cgoff = nullptr;
+  double* d_cg = nullptr;   // allocated on first use (pa_level_cg)
+  long long cg_total = 0;
+  std::vector<long long> cgoff;
   int nremote = 0;          // boxes of this level owned by other ranks (pa_level_create_sharded)
   DLevelView view;
   // ---- sharding (pa_level_create_sharded): the level's whole BoxArray and its DistributionMapping; `boxes` are the

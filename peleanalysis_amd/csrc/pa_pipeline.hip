@@ -11,6 +11,13 @@ int pa_apply_bc_impl(pa_ctx* ctx, pa_mf* F, int comp, const pa_mf* C, int ccomp,
 int pa_apply_bc_dual(pa_ctx* ctx, pa_mf* F0, int comp0, pa_mf* F1, int comp1, const pa_mf* C, int ccomp, const int32_t bc[3], int ratio,
                      const double* xform);
 int pa_fill_boundary_impl(pa_ctx* ctx, pa_mf* M, int comp, int ncomp, int ng, int no_exchange);
+// exact-normal pipeline (pa_fused.hip)
+bool pa_fused2_level_ok(const pa_level* L);
+int pa_fill_boundary_local_batch(pa_ctx* ctx, int n, pa_mf* const* Ms, int comp, int ncomp, int ng);
+int pa_gradcurv_prep_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int comp, const pa_mf* const* crse, int ccomp, const int32_t bc[3], double pmin, double pmax);
+int pa_gradcurv_level_cg(pa_ctx* ctx, const pa_mf* phi, int pcomp, double pmin, double pmax, pa_mf* out, int ocomp);
+int pa_gradcurv_fix_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, const pa_mf* const* crse_n, int cncomp0, const int32_t bc[3], double pmin, double pmax,
+                           pa_mf* const* out, int ncomp0, int kcomp);
 int pa_gauss_curv_level(pa_ctx* ctx, const pa_mf* G, int gcomp, const pa_mf* normgrad, int ngcomp, const pa_mf* c, int ccomp, double thr, pa_mf* out,
                         int kcomp);
 int pa_strain_level(pa_ctx* ctx, const pa_mf* u, int ucomp, pa_mf* out, int srcomp, int rostcomp);
@@ -47,6 +54,13 @@ extern "C" int pa_grad_run(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp,
   }
   return 0;
 }
+
+struct StreamSwap {  // the level entry points launch on ctx->stream
+  pa_ctx* c;
+  hipStream_t keep;
+  StreamSwap(pa_ctx* ctx, hipStream_t s) : c(ctx), keep(ctx->stream) { ctx->stream = s; }
+  ~StreamSwap() { c->stream = keep; }
+};
 
 struct MFDel { void operator()(pa_mf* m) const { pa_mf_destroy(m); } };
 using MFPtr = std::unique_ptr<pa_mf, MFDel>;
@@ -170,7 +184,7 @@ static int fused_pre(pa_ctx* ctx, int l, pa_mf* const* state, int comp, const in
 //   B  the coarse flame normal under those faces, once the layer-1 normals of every level are final (curvature.cpp:514-518)
 // with the ghost preparation + sweeps + layer-1 normals of all levels between them and the face curvature after B.
 static int fused_passes_dist(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, const int32_t bc[3], double pmin, double pmax, double thr,
-                             pa_mf* const* work, pa_mf* const* out, int ocomp) {
+                             pa_mf* const* work, pa_mf* const* out, int ocomp, bool exact) {
   std::vector<XJob> jobs;
   std::vector<CsPlan*> cs(nlev, nullptr);
   std::vector<pa_mf*> csphi(nlev, nullptr), csn(nlev, nullptr);
@@ -190,6 +204,23 @@ static int fused_passes_dist(pa_ctx* ctx, int nlev, pa_mf* const* state, int com
   {
     ProfScope prof(ctx, PA_TAG_XCHG);
     PA_TRY(pa_xexchange(ctx, (int)jobs.size(), jobs.data()));
+  }
+  if (exact) {  // exact-normal pipeline: normals are final after the sweeps, one fix-up launch pair for all levels after exchange B
+    std::vector<const pa_mf*> crse(csphi.begin(), csphi.end()), crse_n(csn.begin(), csn.end());
+    {
+      ProfScope prof(ctx, PA_TAG_FILL);
+      PA_TRY(pa_fill_boundary_local_batch(ctx, nlev, state, comp, 1, 2));
+    }
+    PA_TRY(pa_gradcurv_prep_levels(ctx, nlev, state, comp, crse.data(), 0, bc, pmin, pmax));
+    for (int l = 0; l < nlev; ++l) PA_TRY(pa_gradcurv_level_cg(ctx, state[l], comp, pmin, pmax, out[l], ocomp));
+    jobs.clear();
+    for (int l = 1; l < nlev; ++l) jobs.push_back({&cs[l]->x, out[l - 1], ocomp + 4, csn[l], 0, 3});
+    {
+      ProfScope prof(ctx, PA_TAG_XCHG);
+      PA_TRY(pa_xexchange(ctx, (int)jobs.size(), jobs.data()));
+    }
+    PA_TRY(pa_gradcurv_fix_levels(ctx, nlev, state, comp, crse_n.data(), 0, bc, pmin, pmax, out, ocomp + 4, ocomp + 7));
+    return 0;
   }
   for (int l = 0; l < nlev; ++l) PA_TRY(fused_pre(ctx, l, state, comp, bc, pmin, pmax, work, csphi[l], true));
   for (int l = 0; l < nlev; ++l) {
@@ -225,12 +256,6 @@ static int overlap_on() {
   static const int v = [] { const char* e = getenv("PA_OVERLAP"); return e ? atoi(e) : 0; }();
   return v;
 }
-struct StreamSwap {  // the level entry points launch on ctx->stream
-  pa_ctx* c;
-  hipStream_t keep;
-  StreamSwap(pa_ctx* ctx, hipStream_t s) : c(ctx), keep(ctx->stream) { ctx->stream = s; }
-  ~StreamSwap() { c->stream = keep; }
-};
 
 static int fused_faces(pa_ctx* ctx, int l, const int32_t bc[3], double thr, pa_mf* const* work, pa_mf* const* out, int ocomp, int phase = 3) {
   return pa_gradcurv_faces_phase(ctx, work[l], 0, l > 0 ? out[l - 1] : nullptr, ocomp + 4, bc, 2, thr, out[l], ocomp + 4, ocomp + 7, phase);
@@ -312,7 +337,26 @@ static int fused_passes(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, co
                         pa_mf* const* work, pa_mf* const* out, int ocomp) {
   for (int l = 0; l < nlev; ++l)
     if (state[l]->ng < 2 || work[l]->ng < 2) return pa_fail(ctx, "fused grad->curvature needs 2 ghost layers on state and work");
-  if (state[0]->lev->nranks > 1) return fused_passes_dist(ctx, nlev, state, comp, bc, pmin, pmax, thr, work, out, ocomp);
+  // exact-normal pipeline (pa_fused.hip): no threshold clip, pure special faces, boxes wider than 32 cells
+  bool exact = !(thr >= 0.0);
+  for (int l = 0; l < nlev; ++l) exact = exact && pa_fused2_level_ok(state[l]->lev);
+  if (state[0]->lev->nranks > 1) return fused_passes_dist(ctx, nlev, state, comp, bc, pmin, pmax, thr, work, out, ocomp, exact);
+  if (exact) {
+    // 3 + nlev launches per pass: ghost cells of every level (one launch), resolved ghost c (two), the sweeps, the curvature
+    // of the first layer behind the special faces of every level (two).  (Running the boundary launches on a side stream
+    // next to the sweeps was measured again with this lighter pipeline: 7.04-7.09 against 6.93-7.03 ms per step, the
+    // sweeps slowing from 1.94 to 2.15 ms -- they share the memory path -- so everything stays on one stream.)
+    std::vector<const pa_mf*> crse(nlev, nullptr), crse_n(nlev, nullptr);
+    for (int l = 1; l < nlev; ++l) { crse[l] = state[l - 1]; crse_n[l] = out[l - 1]; }
+    {
+      ProfScope prof(ctx, PA_TAG_FILL);
+      PA_TRY(pa_fill_boundary_local_batch(ctx, nlev, state, comp, 1, 2));
+    }
+    PA_TRY(pa_gradcurv_prep_levels(ctx, nlev, state, comp, crse.data(), comp, bc, pmin, pmax));
+    for (int l = 0; l < nlev; ++l) PA_TRY(pa_gradcurv_level_cg(ctx, state[l], comp, pmin, pmax, out[l], ocomp));
+    PA_TRY(pa_gradcurv_fix_levels(ctx, nlev, state, comp, crse_n.data(), ocomp + 4, bc, pmin, pmax, out, ocomp + 4, ocomp + 7));
+    return 0;
+  }
   if (nlev >= 2 && !overlap_on() && conc_on(nlev, state)) return fused_passes_conc(ctx, nlev, state, comp, bc, pmin, pmax, thr, work, out, ocomp);
   if (!overlap_on() || nlev < 2) {
     for (int l = 0; l < nlev; ++l) PA_TRY(fused_pre(ctx, l, state, comp, bc, pmin, pmax, work));

@@ -42,7 +42,7 @@ def _worker(rank, world, port, case):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         per, sym = ((1, 1, 0), (0, 0, 0)) if case != "sym" else ((0, 1, 1), (1, 0, 0))
-        H = nested_hierarchy(16, 3, 8, is_per=per)
+        H = nested_hierarchy(16, 3, 8, is_per=per) if case != "wide" else nested_hierarchy(80, 3, 40, is_per=per)  # wide: the exact-normal pipeline
         owners = [scattered_owner(lv.nboxes, world, 31 + l) if case != "sfc" else padist.distribution_map(lv.boxes, world) for l, lv in enumerate(H.levels)]
         rng = np.random.default_rng(99)
         ncomp = 4
@@ -111,7 +111,7 @@ def _worker(rank, world, port, case):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,case", [(2, "scatter"), (4, "scatter"), (4, "thr"), (2, "sym"), (4, "sfc")])
+@pytest.mark.parametrize("world,case", [(2, "scatter"), (4, "scatter"), (4, "thr"), (2, "sym"), (4, "sfc"), (4, "wide"), (2, "wide")])
 def test_sharded_hierarchy_on_shared_gpu_matches_undistributed_oracle(world, case):
     import torch.multiprocessing as mp
     mp.spawn(_worker, args=(world, _free_port(), case), nprocs=world, join=True)

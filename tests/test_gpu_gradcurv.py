@@ -113,6 +113,33 @@ def test_gradcurv_fused_wide_boxes(ctx, oracle, threshold, pair, monkeypatch):
         assert_valid_bits_equal(got, oc[l], [(4, 2), (5, 3), (6, 4), (7, 1)], f"wide curv level {l}")
 
 
+@pytest.mark.parametrize("per,sym", [((1, 1, 0), (0, 0, 0)), ((0, 0, 0), (1, 0, 1)), ((0, 1, 1), (0, 0, 0))])
+def test_gradcurv_exact_normal_pipeline(ctx, oracle, per, sym):
+    """boxes wider than 32 cells, no threshold, pure special faces: the exact-normal pipeline (pa_fused.hip: the sweep reads
+    the resolved ghost c behind coarse-fine / wall faces from compact face-major arrays; only the curvature of the first
+    layer behind such a face is fixed up).  3 levels of 48^3 boxes: 4 row tiles per box (3 x 13 + 9 rows), 3 z segments of
+    16 planes (interior and end segments), coarse-fine faces in all three directions, every wall type."""
+    from peleanalysis_amd.hierarchy import nested_hierarchy, field_flame
+    H = nested_hierarchy(96, 3, 48, is_per=per)
+    states = make_states(H, 1, 2, field_flame, seed=29)
+    bc = capi.bc_from_flags(per, sym)
+    og = [MultiFab(lv, 4, 0) for lv in H.levels]
+    oracle.grad_pipeline(H.levels, [s.copy() for s in states], 0, bc, og, 0, multipass=False)
+    oc = [MultiFab(lv, 5, 0) for lv in H.levels]
+    oracle.curvature_pipeline(H.levels, [s.copy() for s in states], 0, bc, oc, 0, MultiFab)
+    dls, dst = _dev(ctx, H, states)
+    work = [capi.DevMF(ctx, dl, 1, 2) for dl in dls]
+    dout = [capi.DevMF(ctx, dl, 8, 0) for dl in dls]
+    for rep in range(2):  # the second pass reuses the level's compact arrays
+        capi.gradcurv_run(ctx, dst, 0, bc, capi.curv_params(fused=True), work, dout, 0)
+        ctx.sync()
+        assert ctx.bc_errors() == 0
+        for l in range(H.nlev):
+            got = dout[l].download()
+            assert_valid_bits_equal(got, og[l], [(c, c) for c in range(4)], f"exact grad level {l}")
+            assert_valid_bits_equal(got, oc[l], [(4, 2), (5, 3), (6, 4), (7, 1)], f"exact curv level {l}")
+
+
 def test_gradcurv_four_levels_many_components(ctx, oracle):
     """BASELINE config 5 in small: 4 levels (PeleLMeX-style nesting), several components (species-like
     fields with different phases/amplitudes) pushed through the fused grad->curvature pipeline one after
