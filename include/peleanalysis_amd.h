@@ -51,6 +51,10 @@ void* pa_device_malloc(pa_ctx*, int64_t bytes);
 void  pa_device_free(pa_ctx*, void* devptr);
 int   pa_memcpy_h2d(pa_ctx*, void* devdst, const void* hostsrc, int64_t bytes);
 int   pa_memcpy_d2h(pa_ctx*, void* hostdst, const void* devsrc, int64_t bytes);
+/* device to device, also between the devices of two contexts of one process (peer copy over xGMI); synchronous */
+int   pa_memcpy_d2d(pa_ctx*, void* devdst, const void* devsrc, int64_t bytes);
+/* number of HIP devices visible to the process (0: none / no runtime) */
+int   pa_device_count(void);
 
 /* Per-launch timing of the library's own kernels with HIP events recorded on the
  * context's stream (what bench.py's roofline object reports).  Tags: 1 fused

@@ -939,6 +939,17 @@ extern "C" int pa_memcpy_h2d(pa_ctx* ctx, void* dst, const void* src, int64_t by
   PA_HIP(hipStreamSynchronize(ctx->stream));
   return 0;
 }
+extern "C" int pa_device_count(void) {
+  int n = 0;
+  return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+extern "C" int pa_memcpy_d2d(pa_ctx* ctx, void* dst, const void* src, int64_t bytes) {
+  PaBind bind_(ctx);
+  if (!ctx || (bytes > 0 && (!dst || !src))) return pa_fail(ctx, "pa_memcpy_d2d: null argument");
+  PA_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDefault, ctx->stream));  // unified addressing: either device
+  PA_HIP(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
 extern "C" int pa_memcpy_d2h(pa_ctx* ctx, void* dst, const void* src, int64_t bytes) {
   PaBind bind_(ctx);
   if (!ctx || (bytes > 0 && (!dst || !src))) return pa_fail(ctx, "pa_memcpy_d2h: null argument");

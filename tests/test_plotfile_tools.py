@@ -288,7 +288,7 @@ def test_isosurface_tool_distance_function(tmp_path, oracle):
     onodes, oelts, odist = oracle.isosurface_pipeline(H.levels, fields, [0, 2], 0, 1150.0, MultiFab, build_distance=True)
     assert [d.ng for d in odist] == [1, 2, 4]
     r = read_plotfile(str(tmp_path / "dist"))
-    assert r.names == ["distance"] and r.time == 0.125 and r.level_steps == [5, 5, 5]
+    assert r.names == ["distance"] and r.time == 0.0 and r.level_steps == [5, 5, 5]  # isosurface.cpp:1417,1747: the local `Real time = 0`
     for l, lv in enumerate(H.levels):
         for b in range(lv.nboxes):
             got, want = np.ascontiguousarray(r.mfs[l].valid(b)[0]), np.ascontiguousarray(odist[l].valid(b)[0])
@@ -698,3 +698,44 @@ def test_tool_options_level_limits_ranges_inputs_file(tmp_path, oracle):
         nonper.append(q)
     onodes, oelts = oracle.isosurface_pipeline(nonper, [MultiFab(q, 3, 0, fields[l].data.copy()) for l, q in enumerate(nonper)], [0, 1], 0, 1150.0, MultiFab)
     assert np.array_equal(faces, oelts + 1) and np.array_equal(nodes.view(np.int64), onodes.view(np.int64))
+
+
+def _tree_bytes(path):
+    """every file of a plotfile directory, by relative name"""
+    out = {}
+    for root, _, files in os.walk(path):
+        for f in files:
+            p = os.path.join(root, f)
+            out[os.path.relpath(p, path)] = open(p, "rb").read()
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tool,args,suffix", [
+    ("grad3d.ex", ["gradVar=temp", "is_per=1 1 0", "Aux_Variables=density"], "_gt"),
+    ("curvature3d.ex", ["progressName=temp", "is_per=1 1 0", "Aux_Variables=density"], "_K"),
+    ("curvature3d.ex", ["progressName=temp", "is_per=0 1 1", "sym_dir=1 0 0", "fused=0", "threshold_prog=1", "threshold_value=0.02", "do_gaussCurv=1",
+                        "do_strain=1", "do_velnormal=1"], "_K"),
+    ("filterPlt3d.ex", ["max_grid_size=8", "is_per=1 1 0"], "_filtered"),
+    ("filterPlt3d.ex", ["max_grid_size=8", "interp_type=0", "base_fgr=4", "same_fgr_all_levels=1"], "_filtered"),
+])
+def test_tools_multi_gpu_outputs_are_byte_identical(tmp_path, tool, args, suffix):
+    """ngpus=<n>: the boxes of every level dealt to n ranks (host threads, one HIP context each; here they share the one GPU
+    and exchange through the in-process transport).  Same pipelines, cross-rank ghost fills inside the library: every
+    output file must be byte-identical to the single-GPU run."""
+    p, H, mfs = _synth(tmp_path, nlev=3, base=16, box=8, ncomp=5, names=("temp", "x_velocity", "y_velocity", "z_velocity", "density"))
+    ref = None
+    for n in (1, 2, 4):
+        d = tmp_path / f"n{n}"
+        d.mkdir()
+        out = _run(tool, ["infile=" + p] + args + [f"ngpus={n}", "gpu_share=1"], d)
+        if n > 1:
+            assert f"distributed over {n} GPUs" in out.stdout
+        got = _tree_bytes(str(d / ("plt00005" + suffix)))
+        assert len(got) >= 5
+        if ref is None:
+            ref = got
+        else:
+            assert got.keys() == ref.keys()
+            for k in ref:
+                assert got[k] == ref[k], f"{tool} ngpus={n}: {k} differs from the single-GPU output"

@@ -10,8 +10,8 @@ namespace pa {
 
 struct Ctx {
   pa_ctx* h = nullptr;
-  Ctx() {
-    h = pa_ctx_create(0, nullptr);
+  explicit Ctx(int device = 0) {
+    h = pa_ctx_create(device, nullptr);
     if (!h) Abort("no MI355X / HIP device available (this build has no CPU fallback)");
   }
   ~Ctx() { pa_ctx_destroy(h); }
@@ -62,12 +62,15 @@ struct PhaseTimer {
 
 struct DevLevel {
   pa_level* h = nullptr;
-  DevLevel(const Ctx& c, const std::vector<Box3>& boxes, const Box3& dom, const int is_per[3], const double plo[3], const double phi[3]) {
+  // owner (one rank per box) + rank + nranks: this context holds only the boxes with owner == rank (pa_level_create_sharded)
+  DevLevel(const Ctx& c, const std::vector<Box3>& boxes, const Box3& dom, const int is_per[3], const double plo[3], const double phi[3],
+           const std::vector<int32_t>* owner = nullptr, int rank = 0, int nranks = 1) {
     std::vector<int32_t> b6(6 * boxes.size());
     for (size_t i = 0; i < boxes.size(); ++i)
       for (int d = 0; d < 3; ++d) { b6[6 * i + d] = boxes[i].lo[d]; b6[6 * i + 3 + d] = boxes[i].hi[d]; }
     int32_t per[3] = {is_per[0], is_per[1], is_per[2]};
-    h = pa_level_create(c.h, (int)boxes.size(), b6.data(), dom.lo, dom.hi, per, plo, phi);
+    if (owner && nranks > 1) h = pa_level_create_sharded(c.h, (int)boxes.size(), b6.data(), owner->data(), rank, nranks, dom.lo, dom.hi, per, plo, phi);
+    else h = pa_level_create(c.h, (int)boxes.size(), b6.data(), dom.lo, dom.hi, per, plo, phi);
     if (!h) Abort(pa_last_error(c.h));
   }
   ~DevLevel() { pa_level_destroy(h); }

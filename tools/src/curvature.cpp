@@ -18,7 +18,7 @@
 // the 0.5 of the 3-D build (:542-546).  The level is one plane of cells with z a homogeneous-Neumann wall
 // (pa_curv_params.spacedim = 2); do_strain / getStrainTensor (2 x 2) / do_velnormal work through a zero third velocity
 // component on the device; do_gaussCurv (3-D only in the reference) and do_smooth are not available in this build.
-#include "../common/pa_device.h"
+#include "../common/pa_team.h"
 #ifndef PA_SPACEDIM
 #define PA_SPACEDIM 3
 #endif
@@ -127,86 +127,108 @@ int main(int argc, char** argv) {
   const bool options = do_gaussCurv || do_strain || do_velnormal || do_smooth;
   const int nres = options ? 18 : 8;
 
-  pa::AsyncCtx actx;  // the HIP context comes up behind the reads
-  std::vector<std::unique_ptr<pa::DevLevel>> dl;
-  std::vector<std::unique_ptr<pa::DevMF>> dst, dwork, dout;
+  pa::AsyncTeam ateam(pp);  // the HIP contexts (ngpus of them, pa_team.h) come up behind the reads
   std::vector<pa::HostMF> in(Nlev), ostate(Nlev);
   std::vector<pa::Box3> doms;
   for (int lev = 0; lev < Nlev; ++lev) {
     if (verbose) std::cout << "Reading data for level " << lev << "\n";
     in[lev].define(H.lev[lev].boxes, nCompDev, 2);
     for (int c = 0; c < nCompIn; ++c) pa::read_comp(H, lev, inComps[c], in[lev], devOf(c));
+    for (auto& B : H.lev[lev].boxes) tm.cells += B.numPts();
+    doms.push_back(H.lev[lev].domain);
+    ostate[lev].define(H.lev[lev].boxes, nCompOut, 0);
   }
   tm.mark("read");
-  pa::Ctx& ctx = actx.get();
+  pa::Team& team = ateam.get();
   tm.mark("hip_context_wait");
-  for (int lev = 0; lev < Nlev; ++lev) {
-    for (auto& B : H.lev[lev].boxes) tm.cells += B.numPts();
-    dl.emplace_back(new pa::DevLevel(ctx, H.lev[lev].boxes, H.lev[lev].domain, is_per.data(), H.prob_lo, H.prob_hi));
-    dst.emplace_back(new pa::DevMF(ctx, *dl.back(), nCompDev, 2));
-    dwork.emplace_back(new pa::DevMF(ctx, *dl.back(), 1, 2));
-    dout.emplace_back(new pa::DevMF(ctx, *dl.back(), nres, 0));
-    ctx.check(pa_mf_upload(ctx.h, dst.back()->h, in[lev].data.data()));
-    doms.push_back(H.lev[lev].domain);
-  }
-  tm.mark("upload");
-  std::vector<pa_mf*> s, w, o;
-  for (int l = 0; l < Nlev; ++l) { s.push_back(dst[l]->h); w.push_back(dwork[l]->h); o.push_back(dout[l]->h); }
-  // progress-variable range (curvature.cpp:139-160): the file min/max over the levels in use
-  if (useFileMinMax) {
-    for (int l = 0; l < Nlev; ++l) {
-      double a, b;
-      ctx.check(pa_minmax_level(ctx.h, s[l], 0, &a, &b));
-      progMin = std::min(progMin, a);
-      progMax = std::max(progMax, b);
+  if (team.n > 1) std::cout << "Boxes distributed over " << team.n << " GPUs, transport: " << team.transport << std::endl;
+  if (team.n > 1 && do_smooth) pa::Abort("do_smooth runs its composite solve on one GPU: use ngpus=1");
+  const std::vector<std::vector<int32_t>> owner = pa::shard_levels(H, Nlev, team.n);
+  // ngpus > 1: the reference's MPI ranks own the FABs DistributionMapping gives them (curvature.cpp:289); here every rank
+  // (host thread + GPU) runs the same pipeline on its share and the library fills ghost cells across ranks
+  team.run([&](int r) {
+    pa::Ctx& ctx = *team.ctx[r];
+    std::vector<std::unique_ptr<pa::DevLevel>> dl;
+    std::vector<std::unique_ptr<pa::DevMF>> dst, dwork, dout;
+    std::vector<pa::Share> sh;
+    std::vector<pa::HostMF> loc(Nlev);
+    for (int lev = 0; lev < Nlev; ++lev) {
+      sh.emplace_back(H.lev[lev].boxes, owner[lev], r);
+      dl.emplace_back(new pa::DevLevel(ctx, H.lev[lev].boxes, H.lev[lev].domain, is_per.data(), H.prob_lo, H.prob_hi, &owner[lev], r, team.n));
+      dst.emplace_back(new pa::DevMF(ctx, *dl.back(), nCompDev, 2));
+      dwork.emplace_back(new pa::DevMF(ctx, *dl.back(), 1, 2));
+      dout.emplace_back(new pa::DevMF(ctx, *dl.back(), nres, 0));
+      if (team.n > 1) sh.back().gather(in[lev], loc[lev]);
+      ctx.check(pa_mf_upload(ctx.h, dst.back()->h, (team.n > 1 ? loc[lev] : in[lev]).data.data()));
     }
-  }
-  if (useFileMinMax || floorIt) {
-    std::cout << "progressName = " << progressName << " at index: " << idC << "\n";
-    std::cout << "useFileMinMax = " << useFileMinMax << "\n";
-    std::cout << "Min/Max = " << progMin << " / " << progMax << "\n";
-    if (progMin >= progMax) pa::Abort("progMin must be less than progMax");
-  }
-  pa_curv_params P;
-  P.prog_min = progMin; P.prog_max = progMax; P.do_threshold = do_threshold; P.threshold = threshold; P.fused = fused;
-  P.do_gauss_curv = do_gaussCurv; P.do_strain = do_strain; P.get_strain_tensor = getStrainTensor; P.do_velnormal = do_velnormal; P.vel_comp = idVst;
-  P.do_smooth = do_smooth; P.smoothing_time = smoothing_time;
-  P.spacedim = PA_SPACEDIM;
-  // result layout: fused sweep -> [gx gy gz |g| Nx Ny Nz K]; pass-by-pass with options -> [Progress K Nx Ny Nz Kg SR Vn ROSTx9]
-  int rK, rN, rKg = -1, rSR = -1, rVn = -1, rROST = -1;
-  if (options) {
-    ctx.check(pa_curvature_run(ctx.h, Nlev, s.data(), 0, bc, &P, o.data(), 0));
-    if (do_smooth && verbose) std::cout << "Progress variable smoothed successfully \n";
-    rK = 1; rN = 2; rKg = 5; rSR = 6; rVn = 7; rROST = 8;
-  } else {
-    ctx.check(pa_gradcurv_run(ctx.h, Nlev, s.data(), 0, bc, &P, w.data(), o.data(), 0));
-    rK = 7; rN = 4;
-  }
-  ctx.check(pa_sync(ctx.h));
-  if (pa_bc_errors(ctx.h) != 0) pa::Abort("coarse-fine boundary: fine grids are not properly nested in the coarse level");
-  tm.mark("compute");
-  // the ghost-free output state (curvature.cpp:833-839) is put together on the device and comes down in one piece:
-  // input components (valid cells of the state: the passes only write ghost cells), Progress (curvature.cpp:319, the
-  // same two operations as everywhere else), then the results; slots whose option is off stay 0.0
-  for (int lev = 0; lev < Nlev; ++lev) {
-    pa::DevMF dfin(ctx, *dl[lev], nCompOut, 0);
-    ctx.check(pa_mf_setval(ctx.h, dfin.h, 0, nCompOut, 0.0));
-    for (int c = 0; c < nCompIn; ++c) ctx.check(pa_mf_copy(ctx.h, dst[lev]->h, devOf(c), dfin.h, c, 1, 0));
-    ctx.check(pa_progress_level(ctx.h, dst[lev]->h, 0, progMin, progMax, dfin.h, idProg, 0));
-    auto cp = [&](int dstc, int srcc) { ctx.check(pa_mf_copy(ctx.h, dout[lev]->h, srcc, dfin.h, dstc, 1, 0)); };
-    cp(idKm, rK);
-    for (int d = 0; d < PA_SPACEDIM; ++d) cp(idN + d, rN + d);
-    if (do_smooth) cp(idSmProg, 17);
-    if (do_gaussCurv) cp(idKg, rKg);
-    if (do_strain) cp(idSR, rSR);
-    if (getStrainTensor)
-      for (int a = 0; a < PA_SPACEDIM; ++a)
-        for (int e = 0; e < PA_SPACEDIM; ++e) cp(idROST + a * PA_SPACEDIM + e, rROST + a * 3 + e);  // the library's tensor is 3 x 3 row-major
-    if (do_velnormal) cp(idVelNormal, rVn);
-    ostate[lev].define(H.lev[lev].boxes, nCompOut, 0);
-    ctx.check(pa_mf_download(ctx.h, dfin.h, ostate[lev].data.data()));
-    if (verbose) std::cout << "Mean curvature has been computed on level " << lev << "\n";
-  }
+    if (r == 0) tm.mark("upload");
+    std::vector<pa_mf*> s, w, o;
+    for (int l = 0; l < Nlev; ++l) { s.push_back(dst[l]->h); w.push_back(dwork[l]->h); o.push_back(dout[l]->h); }
+    // progress-variable range (curvature.cpp:139-160): the file min/max over the levels in use, reduced over the ranks
+    double pMin = progMin, pMax = progMax;
+    if (useFileMinMax) {
+      for (int l = 0; l < Nlev; ++l) {
+        double a, b;
+        ctx.check(pa_minmax_level(ctx.h, s[l], 0, &a, &b));
+        pMin = std::min(pMin, a);
+        pMax = std::max(pMax, b);
+      }
+      ctx.check(pa_allreduce(ctx.h, &pMin, 1, 0));  // ParallelDescriptor::ReduceRealMin / Max (curvature.cpp:147-148)
+      ctx.check(pa_allreduce(ctx.h, &pMax, 1, 1));
+    }
+    if (r == 0 && (useFileMinMax || floorIt)) {
+      std::cout << "progressName = " << progressName << " at index: " << idC << "\n";
+      std::cout << "useFileMinMax = " << useFileMinMax << "\n";
+      std::cout << "Min/Max = " << pMin << " / " << pMax << "\n";
+    }
+    if ((useFileMinMax || floorIt) && pMin >= pMax) pa::Abort("progMin must be less than progMax");
+    pa_curv_params P;
+    P.prog_min = pMin; P.prog_max = pMax; P.do_threshold = do_threshold; P.threshold = threshold; P.fused = fused;
+    P.do_gauss_curv = do_gaussCurv; P.do_strain = do_strain; P.get_strain_tensor = getStrainTensor; P.do_velnormal = do_velnormal; P.vel_comp = idVst;
+    P.do_smooth = do_smooth; P.smoothing_time = smoothing_time;
+    P.spacedim = PA_SPACEDIM;
+    // result layout: fused sweep -> [gx gy gz |g| Nx Ny Nz K]; pass-by-pass with options -> [Progress K Nx Ny Nz Kg SR Vn ROSTx9]
+    int rK, rN, rKg = -1, rSR = -1, rVn = -1, rROST = -1;
+    if (options) {
+      ctx.check(pa_curvature_run(ctx.h, Nlev, s.data(), 0, bc, &P, o.data(), 0));
+      if (r == 0 && do_smooth && verbose) std::cout << "Progress variable smoothed successfully \n";
+      rK = 1; rN = 2; rKg = 5; rSR = 6; rVn = 7; rROST = 8;
+    } else {
+      ctx.check(pa_gradcurv_run(ctx.h, Nlev, s.data(), 0, bc, &P, w.data(), o.data(), 0));
+      rK = 7; rN = 4;
+    }
+    ctx.check(pa_sync(ctx.h));
+    if (pa_bc_errors(ctx.h) != 0) pa::Abort("coarse-fine boundary: fine grids are not properly nested in the coarse level");
+    if (r == 0) tm.mark("compute");
+    // the ghost-free output state (curvature.cpp:833-839) is put together on the device and comes down in one piece:
+    // input components (valid cells of the state: the passes only write ghost cells), Progress (curvature.cpp:319, the
+    // same two operations as everywhere else), then the results; slots whose option is off stay 0.0
+    for (int lev = 0; lev < Nlev; ++lev) {
+      pa::DevMF dfin(ctx, *dl[lev], nCompOut, 0);
+      ctx.check(pa_mf_setval(ctx.h, dfin.h, 0, nCompOut, 0.0));
+      for (int c = 0; c < nCompIn; ++c) ctx.check(pa_mf_copy(ctx.h, dst[lev]->h, devOf(c), dfin.h, c, 1, 0));
+      ctx.check(pa_progress_level(ctx.h, dst[lev]->h, 0, pMin, pMax, dfin.h, idProg, 0));
+      auto cp = [&](int dstc, int srcc) { ctx.check(pa_mf_copy(ctx.h, dout[lev]->h, srcc, dfin.h, dstc, 1, 0)); };
+      cp(idKm, rK);
+      for (int d = 0; d < PA_SPACEDIM; ++d) cp(idN + d, rN + d);
+      if (do_smooth) cp(idSmProg, 17);
+      if (do_gaussCurv) cp(idKg, rKg);
+      if (do_strain) cp(idSR, rSR);
+      if (getStrainTensor)
+        for (int a = 0; a < PA_SPACEDIM; ++a)
+          for (int e = 0; e < PA_SPACEDIM; ++e) cp(idROST + a * PA_SPACEDIM + e, rROST + a * 3 + e);  // the library's tensor is 3 x 3 row-major
+      if (do_velnormal) cp(idVelNormal, rVn);
+      if (team.n > 1) {
+        pa::HostMF lo;
+        lo.define(sh[lev].boxes, nCompOut, 0);
+        ctx.check(pa_mf_download(ctx.h, dfin.h, lo.data.data()));
+        sh[lev].scatter(lo, ostate[lev]);
+      } else {
+        ctx.check(pa_mf_download(ctx.h, dfin.h, ostate[lev].data.data()));
+      }
+      if (r == 0 && verbose) std::cout << "Mean curvature has been computed on level " << lev << "\n";
+    }
+  });
   tm.mark("assemble_download");
   std::vector<std::string> nnames(inNames);
   nnames.resize(nCompOut);

@@ -6,7 +6,7 @@
 // non-periodic unless is_per / geometry.is_periodic is given.
 // Built twice: filterPlt3d.ex, and with -DPA_SPACEDIM=2 filterPlt2d.ex = the AMREX_SPACEDIM == 2 build (2-D plotfile in and
 // out, is_per of two entries, (2 ng + 1)^2 taps; the level is one plane of cells with z a wall direction).
-#include "../common/pa_device.h"
+#include "../common/pa_team.h"
 #ifndef PA_SPACEDIM
 #define PA_SPACEDIM 3
 #endif
@@ -56,9 +56,7 @@ int main(int argc, char** argv) {
     for (int c = 0; c < (int)names.size(); ++c) comps.push_back(c);
   }
   const int ncomp = (int)names.size();
-  pa::AsyncCtx actx;  // the HIP context comes up behind the reads
-  std::vector<std::unique_ptr<pa::DevLevel>> dl;
-  std::vector<std::unique_ptr<pa::DevMF>> din, dout;
+  pa::AsyncTeam ateam(pp);  // the HIP contexts (ngpus of them, pa_team.h) come up behind the reads
   std::vector<pa::HostMF> host(Nlev), out(Nlev);
   std::vector<pa::Box3> doms;
   std::vector<int> ngs;
@@ -75,45 +73,67 @@ int main(int argc, char** argv) {
     const std::vector<pa::Box3> ba = pa::max_size(H.lev[lev].boxes, max_grid_size);
     host[lev].define(ba, ncomp, ng);
     for (int c = 0; c < ncomp; ++c) pa::read_comp(H, lev, comps[c], host[lev], c);
-  }
-  tm.mark("read");
-  pa::Ctx& ctx = actx.get();
-  tm.mark("hip_context_wait");
-  for (int lev = 0; lev < Nlev; ++lev) {
-    const std::vector<pa::Box3>& ba = host[lev].boxes;
     for (auto& B : ba) tm.cells += B.numPts();
-    const int ng = ngs[lev];
-    dl.emplace_back(new pa::DevLevel(ctx, ba, H.lev[lev].domain, is_per.data(), H.prob_lo, H.prob_hi));
-    din.emplace_back(new pa::DevMF(ctx, *dl.back(), ncomp, ng));
-    dout.emplace_back(new pa::DevMF(ctx, *dl.back(), ncomp, 0));
-    ctx.check(pa_mf_upload(ctx.h, din.back()->h, host[lev].data.data()));
+    out[lev].define(ba, ncomp, 0);
     doms.push_back(H.lev[lev].domain);
   }
-  tm.mark("upload");
+  tm.mark("read");
+  pa::Team& team = ateam.get();
+  tm.mark("hip_context_wait");
+  if (team.n > 1) std::cout << "Boxes distributed over " << team.n << " GPUs, transport: " << team.transport << std::endl;
+  std::vector<std::vector<int32_t>> owner(Nlev);
+  for (int lev = 0; lev < Nlev; ++lev) owner[lev] = pa::shard_boxes(host[lev].boxes, team.n);  // DistributionMapping(ba), filterPlt.cpp:142
   std::cout << "Done!" << std::endl << "FillPatching data..." << std::endl;
-  for (int lev = 0; lev < Nlev; ++lev) {
-    std::cout << "on level " << lev << std::endl;
-    ctx.check(pa_fill_boundary(ctx.h, din[lev]->h, 0, ncomp, ngs[lev]));
-    if (lev > 0) ctx.check(pa_fillpatch_two_levels(ctx.h, din[lev]->h, din[lev - 1]->h, 0, ncomp, ngs[lev], 2, interp_type == 1 ? 1 : 0));
-    ctx.check(pa_foextrap(ctx.h, din[lev]->h, 0, ncomp, ngs[lev]));
-  }
-  std::cout << "Done!" << std::endl << "Filtering data..." << std::endl;
-  for (int lev = 0; lev < Nlev; ++lev) {
-    std::cout << "on level " << lev << std::endl;
+  team.run([&](int r) {
+    pa::Ctx& ctx = *team.ctx[r];
+    std::vector<std::unique_ptr<pa::DevLevel>> dl;
+    std::vector<std::unique_ptr<pa::DevMF>> din, dout;
+    std::vector<pa::Share> sh;
+    for (int lev = 0; lev < Nlev; ++lev) {
+      const int ng = ngs[lev];
+      sh.emplace_back(host[lev].boxes, owner[lev], r);
+      dl.emplace_back(new pa::DevLevel(ctx, host[lev].boxes, H.lev[lev].domain, is_per.data(), H.prob_lo, H.prob_hi, &owner[lev], r, team.n));
+      din.emplace_back(new pa::DevMF(ctx, *dl.back(), ncomp, ng));
+      dout.emplace_back(new pa::DevMF(ctx, *dl.back(), ncomp, 0));
+      if (team.n > 1) {
+        pa::HostMF loc;
+        sh.back().gather(host[lev], loc);
+        ctx.check(pa_mf_upload(ctx.h, din.back()->h, loc.data.data()));
+      } else {
+        ctx.check(pa_mf_upload(ctx.h, din.back()->h, host[lev].data.data()));
+      }
+    }
+    if (r == 0) tm.mark("upload");
+    for (int lev = 0; lev < Nlev; ++lev) {
+      if (r == 0) std::cout << "on level " << lev << std::endl;
+      ctx.check(pa_fill_boundary(ctx.h, din[lev]->h, 0, ncomp, ngs[lev]));
+      if (lev > 0) ctx.check(pa_fillpatch_two_levels(ctx.h, din[lev]->h, din[lev - 1]->h, 0, ncomp, ngs[lev], 2, interp_type == 1 ? 1 : 0));
+      ctx.check(pa_foextrap(ctx.h, din[lev]->h, 0, ncomp, ngs[lev]));
+    }
+    if (r == 0) std::cout << "Done!" << std::endl << "Filtering data..." << std::endl;
+    for (int lev = 0; lev < Nlev; ++lev) {
+      if (r == 0) std::cout << "on level " << lev << std::endl;
 #if PA_SPACEDIM == 2
-    ctx.check(pa_boxfilter_level2d(ctx.h, din[lev]->h, dout[lev]->h, 0, ncomp, ngs[lev], ws[lev].data()));
+      ctx.check(pa_boxfilter_level2d(ctx.h, din[lev]->h, dout[lev]->h, 0, ncomp, ngs[lev], ws[lev].data()));
 #else
-    ctx.check(pa_boxfilter_level(ctx.h, din[lev]->h, dout[lev]->h, 0, ncomp, ngs[lev], ws[lev].data()));
+      ctx.check(pa_boxfilter_level(ctx.h, din[lev]->h, dout[lev]->h, 0, ncomp, ngs[lev], ws[lev].data()));
 #endif
-  }
-  ctx.check(pa_sync(ctx.h));
-  if (pa_bc_errors(ctx.h) != 0) pa::Abort("FillPatchTwoLevels: fine grids are not properly nested in the coarse level");
-  tm.mark("compute");
+    }
+    ctx.check(pa_sync(ctx.h));
+    if (pa_bc_errors(ctx.h) != 0) pa::Abort("FillPatchTwoLevels: fine grids are not properly nested in the coarse level");
+    if (r == 0) tm.mark("compute");
+    for (int lev = 0; lev < Nlev; ++lev) {
+      if (team.n > 1) {
+        pa::HostMF lo;
+        lo.define(sh[lev].boxes, ncomp, 0);
+        ctx.check(pa_mf_download(ctx.h, dout[lev]->h, lo.data.data()));
+        sh[lev].scatter(lo, out[lev]);
+      } else {
+        ctx.check(pa_mf_download(ctx.h, dout[lev]->h, out[lev].data.data()));
+      }
+    }
+  });
   std::cout << "Done!" << std::endl << "Saving filtered data..." << std::endl;
-  for (int lev = 0; lev < Nlev; ++lev) {
-    out[lev].define(host[lev].boxes, ncomp, 0);
-    ctx.check(pa_mf_download(ctx.h, dout[lev]->h, out[lev].data.data()));
-  }
   tm.mark("download");
   std::vector<int> steps(Nlev, 0);
   pa::write_plotfile(pa::getFileRoot(infile) + "_filtered", names, doms, H.prob_lo, H.prob_hi, out, H.time, steps, 2, PA_SPACEDIM);

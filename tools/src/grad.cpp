@@ -1,13 +1,15 @@
 // grad3d -- drop-in for PeleAnalysis Src/grad.cpp on MI355X.
 //   grad3d.ex infile=<plt> [gradVar=temp] [finestLevel=<n>] [Aux_Variables="a b"] [sym_dir="0 0 0"]
-//             [is_per="1 1 1"] [outfile=<root>_gt]
+//             [is_per="1 1 1"] [outfile=<root>_gt] [ngpus=<n>] [gpu_share=0|1]
+// ngpus=<n>: the boxes of every level are dealt to n GPUs (one host thread each, pa_team.h) the way the reference's MPI ranks
+// own them (DistributionMapping, grad.cpp:162); the output is byte-identical for every n.
 // Output plotfile components: [gradVar, aux..., <v>_gx, <v>_gy, <v>_gz, ||grad<v>||], time 0, steps 0,
 // ref ratio 2 (grad.cpp:241-257).  All arithmetic runs in libpeleanalysis_amd (HIP, gfx950).
 // Built twice: grad3d.ex, and with -DPA_SPACEDIM=2 grad2d.ex = the AMREX_SPACEDIM == 2 build: 2-D plotfile in and out,
 // sym_dir / is_per of two entries, components [gradVar, aux..., <v>_gx, <v>_gy, ||grad<v>||].  The 2-D level is handed
 // to the library as one plane of cells with z a homogeneous-Neumann wall: every z difference is an exact zero, so gx,
 // gy and sqrt(gx*gx + gy*gy + 0) are the 2-D values bit for bit.
-#include "../common/pa_device.h"
+#include "../common/pa_team.h"
 #ifndef PA_SPACEDIM
 #define PA_SPACEDIM 3
 #endif
@@ -64,34 +66,48 @@ int main(int argc, char** argv) {
   int32_t bc[3];
   pa::bc_from_flags(is_per, sym_dir, bc);
 
-  pa::AsyncCtx actx;  // the HIP context comes up behind the reads
-  std::vector<std::unique_ptr<pa::DevLevel>> dl;
-  std::vector<std::unique_ptr<pa::DevMF>> dmf;
+  pa::AsyncTeam ateam(pp);  // the HIP contexts (ngpus of them) come up behind the reads
   std::vector<pa::HostMF> state(Nlev);
   std::vector<pa::Box3> doms;
   for (int lev = 0; lev < Nlev; ++lev) {
     std::cout << "Reading data for level: " << lev << std::endl;
     state[lev].define(H.lev[lev].boxes, nCompOut, 1);
     for (int c = 0; c < nCompIn; ++c) pa::read_comp(H, lev, inComps[c], state[lev], c);
-  }
-  tm.mark("read");
-  pa::Ctx& ctx = actx.get();
-  tm.mark("hip_context_wait");
-  for (int lev = 0; lev < Nlev; ++lev) {
     for (auto& B : H.lev[lev].boxes) tm.cells += B.numPts();
-    dl.emplace_back(new pa::DevLevel(ctx, H.lev[lev].boxes, H.lev[lev].domain, is_per.data(), H.prob_lo, H.prob_hi));
-    dmf.emplace_back(new pa::DevMF(ctx, *dl.back(), nCompOut, 1));
-    ctx.check(pa_mf_upload(ctx.h, dmf.back()->h, state[lev].data.data()));
     doms.push_back(H.lev[lev].domain);
   }
-  tm.mark("upload");
-  std::vector<pa_mf*> mfs;
-  for (auto& m : dmf) mfs.push_back(m->h);
-  ctx.check(pa_grad_run(ctx.h, Nlev, mfs.data(), 0, bc, mfs.data(), idGr));  // outputs into the same MultiFab, like grad.cpp
-  ctx.check(pa_sync(ctx.h));
-  if (pa_bc_errors(ctx.h) != 0) pa::Abort("coarse-fine boundary: fine grids are not properly nested in the coarse level");
-  tm.mark("compute");
-  for (int lev = 0; lev < Nlev; ++lev) ctx.check(pa_mf_download(ctx.h, dmf[lev]->h, state[lev].data.data()));
+  tm.mark("read");
+  pa::Team& team = ateam.get();
+  tm.mark("hip_context_wait");
+  if (team.n > 1) std::cout << "Boxes distributed over " << team.n << " GPUs, transport: " << team.transport << std::endl;
+  const std::vector<std::vector<int32_t>> owner = pa::shard_levels(H, Nlev, team.n);
+  team.run([&](int r) {  // one rank: its boxes of every level through the library's pipeline (cross-rank ghost fills inside)
+    pa::Ctx& ctx = *team.ctx[r];
+    std::vector<std::unique_ptr<pa::DevLevel>> dl;
+    std::vector<std::unique_ptr<pa::DevMF>> dmf;
+    std::vector<pa::Share> sh;
+    std::vector<pa::HostMF> loc(Nlev);
+    for (int lev = 0; lev < Nlev; ++lev) {
+      sh.emplace_back(H.lev[lev].boxes, owner[lev], r);
+      dl.emplace_back(new pa::DevLevel(ctx, H.lev[lev].boxes, H.lev[lev].domain, is_per.data(), H.prob_lo, H.prob_hi, &owner[lev], r, team.n));
+      dmf.emplace_back(new pa::DevMF(ctx, *dl.back(), nCompOut, 1));
+      pa::HostMF& src = team.n > 1 ? loc[lev] : state[lev];
+      if (team.n > 1) sh.back().gather(state[lev], loc[lev]);
+      ctx.check(pa_mf_upload(ctx.h, dmf.back()->h, src.data.data()));
+    }
+    if (r == 0) tm.mark("upload");
+    std::vector<pa_mf*> mfs;
+    for (auto& m : dmf) mfs.push_back(m->h);
+    ctx.check(pa_grad_run(ctx.h, Nlev, mfs.data(), 0, bc, mfs.data(), idGr));  // outputs into the same MultiFab, like grad.cpp
+    ctx.check(pa_sync(ctx.h));
+    if (pa_bc_errors(ctx.h) != 0) pa::Abort("coarse-fine boundary: fine grids are not properly nested in the coarse level");
+    if (r == 0) tm.mark("compute");
+    for (int lev = 0; lev < Nlev; ++lev) {
+      pa::HostMF& dst = team.n > 1 ? loc[lev] : state[lev];
+      ctx.check(pa_mf_download(ctx.h, dmf[lev]->h, dst.data.data()));
+      if (team.n > 1) sh[lev].scatter(loc[lev], state[lev]);
+    }
+  });
   tm.mark("download");
 
   std::vector<std::string> nnames(inNames);
