@@ -62,6 +62,9 @@ int   pa_device_count(void);
  * 6 progress, 7 box filter, 8 marching cubes.  on: 0 off, 1 every tag, otherwise a bit mask (1 << tag) of the
  * tags to time.  pa_profile_read is synchronous. */
 int pa_profile_enable(pa_ctx*, int on);
+/* which variant of the fused grad->curvature sweep the last pa_gradcurv_* call launched, e.g.
+ * "k_gradcurv_march3<MTY=13,CLIP=0,PAIR=0,CG=1>" (bench.py keys the committed PMC traffic figure on it) */
+const char* pa_sweep_kernel_name(const pa_ctx*);
 int pa_profile_read(pa_ctx*, int tag, int64_t* nlaunch, double* total_ms, int reset);
 
 /* ---------------------------------------------------- level = BoxArray+Geometry

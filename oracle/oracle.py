@@ -122,8 +122,29 @@ def foextrap(mf, comp, ncomp, ng):
     lib().orc_foextrap(_p(_mf(mf)), comp, ncomp, ng)
 
 
-def grad_multipass(phi, comp, out, ocomp):
-    lib().orc_grad_multipass(_p(_mf(phi)), comp, _p(_mf(out)), ocomp)
+def grad_multipass(phi, comp, out, ocomp, omp=False):
+    lib(omp).orc_grad_multipass(_p(_mf(phi)), comp, _p(_mf(out)), ocomp)
+
+
+class MFPool:
+    """Scratch-multifab factory for repeated pipeline passes (the timed CPU baseline): the n-th request of a pass returns the
+    buffer the n-th request of the first pass allocated, zero-filled (the reference's setVal(0), curvature.cpp:505-506).
+    Call start_pass() before each pass."""
+
+    def __init__(self, MF):
+        self.MF, self.bufs, self.i = MF, [], 0
+
+    def start_pass(self):
+        self.i = 0
+
+    def __call__(self, level, ncomp, ng):
+        if self.i == len(self.bufs):
+            self.bufs.append(self.MF(level, ncomp, ng))
+        m = self.bufs[self.i]
+        assert m.level is level and m.ncomp == ncomp and m.ng == ng
+        self.i += 1
+        m.data.fill(0.0)
+        return m
 
 
 def grad_fused(phi, comp, out, ocomp, with_mag=True, omp=False):
@@ -150,7 +171,7 @@ def grad_pipeline(levels, states, comp, bc, outs, ocomp, multipass=True, omp=Fal
     for l in range(len(levels)):
         apply_bc(states[l], comp, states[l - 1] if l > 0 else None, comp, bc, omp=omp)
         if multipass:
-            grad_multipass(states[l], comp, outs[l], ocomp)
+            grad_multipass(states[l], comp, outs[l], ocomp, omp)
         else:
             grad_fused(states[l], comp, outs[l], ocomp, True, omp)
 

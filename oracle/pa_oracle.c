@@ -245,6 +245,7 @@ void orc_grad_multipass(const orc_mf* phi, int comp, orc_mf* out, int ocomp) {
   const orc_level* L = phi->lev;
   double dxinv[3];
   orc_dxinv(L, dxinv);
+#pragma omp parallel for schedule(dynamic)
   for (int b = 0; b < L->nboxes; ++b) {
     bx_t B = get_box(L, b);
     const int nx = B.n[0], ny = B.n[1], nz = B.n[2];

@@ -80,6 +80,7 @@ extern "C" int pa_profile_read(pa_ctx* ctx, int tag, int64_t* nlaunch, double* t
   return 0;
 }
 
+extern "C" const char* pa_sweep_kernel_name(const pa_ctx* ctx) { return ctx ? ctx->sweep_kernel.c_str() : ""; }
 extern "C" const char* pa_last_error(const pa_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 extern "C" void* pa_ctx_stream(pa_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 

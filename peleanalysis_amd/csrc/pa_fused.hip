@@ -379,8 +379,9 @@ static int fused_order() {
 }
 // pair_ok: every tile of every box is 64 columns wide and starts on an even column of an even-length
 // output row (16-byte stores, see PAIR in pa_fused_march3.h)
+// kname: receives the variant that was launched (what bench.py matches the committed PMC traffic figure against)
 template <typename BP>
-static void march_launch(hipStream_t st, const BP& bp, int nx, int ny, int nz, unsigned nboxes, const MarchArgs& A0, bool pair_ok = false) {
+static void march_launch(hipStream_t st, const BP& bp, int nx, int ny, int nz, unsigned nboxes, const MarchArgs& A0, bool pair_ok = false, std::string* kname = nullptr) {
   MarchArgs A = A0;
   // Small levels: a 256^3 level of 64^3 boxes is 320 workgroups at 64 planes each -- 1.25 rounds on 256 CUs -- and
   // ran at 50 % of the HBM figure; shorter z segments give the chip enough workgroups to balance (PA_KSEG 64 / 32 /
@@ -409,6 +410,7 @@ static void march_launch(hipStream_t st, const BP& bp, int nx, int ny, int nz, u
     const dim3 g = A.order == 2 ? dim3(tiles * 8u * ((nboxes + 7u) / 8u), 1) : dim3(tiles, nboxes);
     if (A.thr >= 0.0) hipLaunchKernelGGL((k_gradcurv_march3n<BP, NRW, true>), g, dim3(64 * (NRW + 2)), 0, st, bp, A);
     else hipLaunchKernelGGL((k_gradcurv_march3n<BP, NRW, false>), g, dim3(64 * (NRW + 2)), 0, st, bp, A);
+    if (kname) *kname = std::string("k_gradcurv_march3n<NRW=8,CLIP=") + (A.thr >= 0.0 ? "1>" : "0>");
     return;
   }
   if (march_ver == 3) {
@@ -435,6 +437,7 @@ static void march_launch(hipStream_t st, const BP& bp, int nx, int ny, int nz, u
     A.tiles_max = (int)g.x;                                                                                            \
     if (A.order == 2) g = dim3(g.x * 8u * ((nboxes + 7u) / 8u), 1);                                                    \
     else if (A.order) g = dim3(g.x * g.y, 1);                                                                          \
+    if (kname) *kname = "k_gradcurv_march3<MTY=" #M ",CLIP=" + std::to_string((int)clip) + ",PAIR=" + std::to_string((int)(pair && !(A.cg && !clip))) + ",CG=" + std::to_string((int)(A.cg && !clip)) + ">"; \
     if (A.cg && !clip) hipLaunchKernelGGL((k_gradcurv_march3<BP, M, false, false, 0, true>), g, dim3(64 * (M + 3)), 0, st, bp, A); \
     else if (pair && clip) hipLaunchKernelGGL((k_gradcurv_march3<BP, M, true, true>), g, dim3(64 * (M + 3)), 0, st, bp, A); \
     else if (pair) hipLaunchKernelGGL((k_gradcurv_march3<BP, M, false, true>), g, dim3(64 * (M + 3)), 0, st, bp, A);   \
@@ -479,7 +482,7 @@ extern "C" int pa_gradcurv_level(pa_ctx* ctx, const pa_mf* phi, int pcomp, doubl
     pair_ok = pair_ok && (nxb % 64 == 0) && pa_cstride((nxb + 2 * out->ng) * nyb * nzb, out->ncomp) * 8 < (1ll << 31);
   }
   ProfScope prof(ctx, PA_TAG_GRADCURV);
-  march_launch(ctx->stream, bp, L->maxn[0], L->maxn[1], L->maxn[2], (unsigned)L->boxes.size(), A, pair_ok);
+  march_launch(ctx->stream, bp, L->maxn[0], L->maxn[1], L->maxn[2], (unsigned)L->boxes.size(), A, pair_ok, &ctx->sweep_kernel);
   PA_HIP(hipGetLastError());
   return 0;
 }
@@ -764,7 +767,7 @@ int pa_gradcurv_level_cg(pa_ctx* ctx, const pa_mf* phi, int pcomp, double pmin, 
   MarchArgs A{pcomp, ocomp, fused_kseg(), pmin, 1.0 / (pmax - pmin), -1.0, 0, 1, 1, 1};
   A.cg = 1;
   ProfScope prof(ctx, PA_TAG_GRADCURV);
-  march_launch(ctx->stream, bp, L->maxn[0], L->maxn[1], L->maxn[2], (unsigned)L->boxes.size(), A, false);
+  march_launch(ctx->stream, bp, L->maxn[0], L->maxn[1], L->maxn[2], (unsigned)L->boxes.size(), A, false, &ctx->sweep_kernel);
   PA_HIP(hipGetLastError());
   return 0;
 }

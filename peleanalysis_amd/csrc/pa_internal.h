@@ -82,6 +82,7 @@ struct pa_ctx {
   std::vector<hipEvent_t> sync_evs;
   // transport between the ranks that share a sharded hierarchy (pa_dist.hip): caller-supplied (pa_ctx_set_comm)
   // or the built-in RCCL one (pa_ctx_init_rccl)
+  std::string sweep_kernel;  // variant of the fused sweep launched last (pa_sweep_kernel_name)
   pa_comm comm = {nullptr, 0, 1, nullptr, nullptr};
   struct RcclState* rccl = nullptr;
 };
