@@ -204,6 +204,132 @@ def main():
             assert np.array_equal(dk.to_numpy(np.int32, (nv.value, 6)), k) and np.array_equal(dt.to_numpy(np.int32, (nt.value, 3)), t)
             checked += 1
     assert checked == 3
+    del t5, st5, tmk, mk5, frags
+    torch.cuda.empty_cache()
+
+    # ---- 7. BASELINE config 2: ONE 512^3 level, 10 components through the fused pipeline into recycled outputs: every
+    # component's result equals the pass-by-pass kernels' and a second run of the fused pipeline, bit for bit
+    lv1 = Level(chop_box((0, 0, 0), (n - 1,) * 3, 128), (0, 0, 0), (n - 1,) * 3, (1, 1, 0), (0, 0, 0), (1, 1, 1))
+    dl1 = capi.DevLevel(ctx, lv1)
+    nc2 = 10
+    off, cs, tot = mf_layout(lv1.boxes, nc2, 2)
+    tin2 = torch.zeros(tot, dtype=torch.float64, device=dev)
+    bench.fill_level_on_device(torch, lv1, tin2, nc2, 2, off, cs, dev, 777)
+    st2 = [capi.DevMF(ctx, dl1, nc2, 2, tin2.data_ptr())]
+    _, _, tw = mf_layout(lv1.boxes, 1, 2)
+    _, _, to8 = mf_layout(lv1.boxes, 8, 0)
+    tw2 = torch.zeros(tw, dtype=torch.float64, device=dev)
+    wk2 = [capi.DevMF(ctx, dl1, 1, 2, tw2.data_ptr())]
+    touts2 = [torch.zeros(to8, dtype=torch.float64, device=dev) for _ in range(3)]
+    outs2 = [[capi.DevMF(ctx, dl1, 8, 0, t.data_ptr())] for t in touts2]
+    torch.cuda.synchronize()
+    bc2 = capi.bc_from_flags((1, 1, 0))
+    for c in range(nc2):
+        pm = capi.curv_params(prog_min=200.0, prog_max=4000.0, fused=True)
+        capi.gradcurv_run(ctx, st2, c, bc2, pm, wk2, outs2[0], 0)
+        capi.gradcurv_run(ctx, st2, c, bc2, pm, wk2, outs2[1], 0)
+        capi.gradcurv_run(ctx, st2, c, bc2, capi.curv_params(prog_min=200.0, prog_max=4000.0, fused=False), wk2, outs2[2], 0)
+        ctx.sync()
+        assert same_bits(touts2[0], touts2[1]), f"config 2, component {c}: not deterministic"
+        assert same_bits(touts2[0], touts2[2]), f"config 2, component {c}: fused pipeline differs from the pass-by-pass kernels"
+    assert ctx.bc_errors() == 0
+    del tin2, tw2, touts2, outs2, st2, wk2
+    torch.cuda.empty_cache()
+
+    # ---- 8. BASELINE config 3: filterPlt's ghost fill + box filter, then grad, on the 3-level base-256^3 hierarchy (64^3 boxes,
+    # periodic x/y, wall z; fgr 2 / 4 / 8): a constant and (away from walls) a linear field are reproduced across both
+    # coarse-fine interfaces, the filter is exactly homogeneous under phi -> 2 phi, two runs agree bit for bit, and the
+    # gradient of the filtered linear field is the exact constant
+    H3 = nested_hierarchy(256, 3, 64, is_per=(1, 1, 0))
+    dl3 = [capi.DevLevel(ctx, lv) for lv in H3.levels]
+    ngs = [1, 2, 4]
+    ws = []
+    for f in (2, 4, 8):
+        w_ = (C.c_double * (f + 2))()
+        assert ctx.lib.pa_box_filter_weights(f, w_) == f // 2
+        ws.append(w_)
+
+    def lin(lv_, b, g_):
+        lo = lv_.boxes[b, :3] - g_
+        nz_, ny_, nx_ = lv_.box_shape(b, g_)
+        dx = lv_.dx
+        z = (torch.arange(int(lo[2]), int(lo[2]) + nz_, device=dev, dtype=torch.float64) + 0.5) * dx[2]
+        return (1.0 + 3.0 * z)[:, None, None].expand(nz_, ny_, nx_)  # linear in the wall direction only (x / y are periodic)
+
+    def filt(fill):
+        tin_, tout_, fi, fo = [], [], [], []
+        for l, (lv_, dl_) in enumerate(zip(H3.levels, dl3)):
+            off_, cs_, tot_ = mf_layout(lv_.boxes, 1, ngs[l])
+            t = torch.full((tot_,), float("nan"), dtype=torch.float64, device=dev)
+            for b in range(lv_.nboxes):
+                nz_, ny_, nx_ = lv_.box_shape(b, ngs[l])
+                g_ = ngs[l]
+                v = t[off_[b]: off_[b] + nz_ * ny_ * nx_].view(nz_, ny_, nx_)
+                v[g_:-g_, g_:-g_, g_:-g_] = fill(lv_, b)
+            _, _, to_ = mf_layout(lv_.boxes, 1, 1)
+            o = torch.zeros(to_, dtype=torch.float64, device=dev)
+            tin_.append(t); tout_.append(o)
+            fi.append(capi.DevMF(ctx, dl_, 1, ngs[l], t.data_ptr())); fo.append(capi.DevMF(ctx, dl_, 1, 1, o.data_ptr()))
+        torch.cuda.synchronize()
+        for l in range(3):
+            ctx.check(ctx.lib.pa_fill_boundary(ctx.h, fi[l].h, 0, 1, ngs[l]))
+            if l > 0:
+                ctx.check(ctx.lib.pa_fillpatch_two_levels(ctx.h, fi[l].h, fi[l - 1].h, 0, 1, ngs[l], 2, 1))
+            ctx.check(ctx.lib.pa_foextrap(ctx.h, fi[l].h, 0, 1, ngs[l]))
+            ctx.check(ctx.lib.pa_boxfilter_level(ctx.h, fi[l].h, fo[l].h, 0, 1, ngs[l], ws[l]))
+        ctx.sync()
+        assert ctx.bc_errors() == 0
+        return tin_, tout_, fo
+
+    def valid(lv_, t, b, g_):
+        off_, cs_, _ = mf_layout(lv_.boxes, 1, g_)
+        nz_, ny_, nx_ = lv_.box_shape(b, g_)
+        v = t[off_[b]: off_[b] + nz_ * ny_ * nx_].view(nz_, ny_, nx_)
+        return v[g_:nz_ - g_, g_:ny_ - g_, g_:nx_ - g_] if g_ else v
+
+    _, oc, _ = filt(lambda lv_, b: 3.0)
+    for l, lv_ in enumerate(H3.levels):
+        for b in range(lv_.nboxes):
+            assert bool((valid(lv_, oc[l], b, 1) == 3.0).all()), f"config 3: constant not reproduced on level {l} box {b}"
+    rnd = [300.0 + 1700.0 * torch.rand((lv_.nboxes, 64, 64, 64), dtype=torch.float64, device=dev) for lv_ in H3.levels]
+    lvid = {id(lv_): i for i, lv_ in enumerate(H3.levels)}
+    _, o1, _ = filt(lambda lv_, b: rnd[lvid[id(lv_)]][b])
+    _, o1b, _ = filt(lambda lv_, b: rnd[lvid[id(lv_)]][b])
+    _, o2, _ = filt(lambda lv_, b: 2.0 * rnd[lvid[id(lv_)]][b])
+    for l in range(3):
+        assert same_bits(o1[l], o1b[l]), f"config 3: filter not deterministic on level {l}"
+        assert same_bits(o1[l] * 2.0, o2[l]), f"config 3: filter not exactly homogeneous on level {l}"
+    _, ol, fo_l = filt(lambda lv_, b: lin(lv_, b, 0))
+    for l, lv_ in enumerate(H3.levels):
+        for b in range(lv_.nboxes):
+            zlo, zhi = int(lv_.boxes[b, 2]), int(lv_.boxes[b, 5])
+            nzd = int(lv_.domhi[2]) + 1
+            k0, k1 = max(zlo, ngs[l]), min(zhi, nzd - 1 - ngs[l])  # a filter width away from the walls
+            if k0 > k1:
+                continue
+            got = valid(lv_, ol[l], b, 1)[k0 - zlo: k1 - zlo + 1]
+            want = lin(lv_, b, 0)[k0 - zlo: k1 - zlo + 1]
+            assert float((got - want).abs().max()) < 1e-13, f"config 3: linear field not reproduced on level {l} box {b}"
+    # grad of the filtered linear field (filterPlt + grad of BASELINE config 3): dz = 3 away from the walls, dx = dy = 0
+    gts, gos = [], []
+    for l, (lv_, dl_) in enumerate(zip(H3.levels, dl3)):
+        _, _, tg_ = mf_layout(lv_.boxes, 4, 0)
+        t = torch.zeros(tg_, dtype=torch.float64, device=dev)
+        gts.append(t); gos.append(capi.DevMF(ctx, dl_, 4, 0, t.data_ptr()))
+    torch.cuda.synchronize()
+    capi.grad_run(ctx, fo_l, 0, capi.bc_from_flags((1, 1, 0)), gos, 0)
+    ctx.sync()
+    assert ctx.bc_errors() == 0
+    for l, lv_ in enumerate(H3.levels):
+        off4, cs4, _ = mf_layout(lv_.boxes, 4, 0)
+        for b in range(lv_.nboxes):
+            zlo, zhi = int(lv_.boxes[b, 2]), int(lv_.boxes[b, 5])
+            nzd = int(lv_.domhi[2]) + 1
+            k0, k1 = max(zlo, ngs[l] + 1), min(zhi, nzd - 2 - ngs[l])
+            if k0 > k1:
+                continue
+            g3 = [gts[l][off4[b] + c * cs4[b]: off4[b] + c * cs4[b] + 64 ** 3].view(64, 64, 64)[k0 - zlo: k1 - zlo + 1] for c in range(3)]
+            assert float(g3[0].abs().max()) < 1e-9 and float(g3[1].abs().max()) < 1e-9 and float((g3[2] - 3.0).abs().max()) < 1e-9, (l, b)
     print("fullsize properties OK")
 
 

@@ -344,6 +344,33 @@ int main(int argc, char** argv) {
     std::snprintf(buf, sizeof buf, "%g", isoVal);
     std::string outfile_base = infile + "_" + isoCompName + "_" + std::string(buf);
     pp.query("outfile_base", outfile_base);
+    // surface_is_large (isosurface.cpp:1919-1999): the reference stages the node data through a file of FABs of at most
+    // chunk_size nodes to release its node set before it allocates the final FAB; the MEF is the same either way.  Nothing
+    // needs releasing here (nodes are already one array), but the staging file is an observable product of the run (it is
+    // never removed), so it is written the same way: Box (0..N-1,0,0) chopped by BoxArray::maxSize(chunk_size), each
+    // piece a FAB of nodeSize components whose memory is node-major (:1943-1950).
+    int surface_is_large = 0, chunk_size = 32768;
+    pp.query("surface_is_large", surface_is_large);
+    pp.query("chunk_size", chunk_size);
+    if (surface_is_large) {
+      if (chunk_size < 1) pa::Abort("chunk_size must be positive");
+      std::string tmpFile = "isoTEMPFILE";
+      pp.query("tmpFile", tmpFile);
+      std::ofstream ost(tmpFile, std::ios::binary);
+      if (!ost) pa::Abort("Unable to create " + tmpFile);
+      const long long N = merger.num_nodes();
+      const long long nparts = (N + chunk_size - 1) / chunk_size, base = nparts ? N / nparts : 0, rem = nparts ? N % nparts : 0;
+      if (verbose) std::cout << "  staging vertex data to disk in " << nparts << " chunks..." << std::endl;
+      long long lo = 0;
+      for (long long q = 0; q < nparts; ++q) {  // BoxArray::maxSize: an even split, the first `rem` pieces one longer
+        const long long n = base + (q < rem ? 1 : 0);
+        pa::Box3 b{{(int)lo, 0, 0}, {(int)(lo + n - 1), 0, 0}};
+        ost << "FAB ((8, (64 11 52 0 1 12 0 1023)),(8, (8 7 6 5 4 3 2 1)))" << pa::box_str(b) << ' ' << nc << "\n";
+        ost.write((const char*)(merger.nodes().data() + lo * nc), sizeof(double) * (size_t)(n * nc));
+        lo += n;
+      }
+      if (verbose) std::cout << "  ... data staged." << std::endl;
+    }
     std::cout << "  Writing the file..." << std::endl;
     pa::write_mef(outfile_base + ".mef", H.time, vars, merger.nodes(), elts);
     std::cout << "            ...done" << std::endl;
