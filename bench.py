@@ -246,8 +246,9 @@ def main():
     params = capi.curv_params(prog_min=300.0, prog_max=2000.0, threshold=None, fused=bool(args.fused))
 
     def step():
-        for c in range(args.ncomp):  # output buffers are recycled per component (SURVEY 8d memory budget)
-            capi.gradcurv_run(ctx, states, c, bc, params, works, outs, 0)  # cross-rank ghost fills happen inside
+        # every component through the pipeline into recycled output buffers (SURVEY 8d memory budget); cross-rank ghost fills
+        # happen inside; result-independent ghost fills are done once for all components
+        capi.gradcurv_run_comps(ctx, states, 0, args.ncomp, bc, params, works, outs, 0)
 
     def barrier():
         if world > 1:

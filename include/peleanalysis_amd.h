@@ -357,6 +357,15 @@ int pa_smooth_solve(pa_ctx*, int nlev, pa_mf* const* rhs, int rcomp, pa_mf* cons
 int pa_gradcurv_run(pa_ctx*, int nlev, pa_mf* const* state, int comp, const int32_t bc[3],
                     const pa_curv_params*, pa_mf* const* work, pa_mf* const* out, int ocomp);
 
+/* Components comp0 .. comp0+ncomps-1 of state, one after the other into the SAME output buffers (what a tool does with the
+ * variables of a plotfile).  done(user, comp) is called when a component's results are complete in `out` -- stream-ordered:
+ * pa_sync before reading them on the host -- and before the next component overwrites them (NULL: no callback).  Ghost
+ * fills that do not depend on results are done once for all components: FillBoundary of every component in one launch
+ * and, on a sharded hierarchy, the first cross-rank exchange. */
+int pa_gradcurv_run_comps(pa_ctx*, int nlev, pa_mf* const* state, int comp0, int ncomps, const int32_t bc[3],
+                          const pa_curv_params*, pa_mf* const* work, pa_mf* const* out, int ocomp,
+                          int (*done)(void* user, int comp), void* user);
+
 #ifdef __cplusplus
 }
 #endif

@@ -43,6 +43,9 @@ EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int32, C.c_int32)
 
 
+DONE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)
+
+
 class PaComm(C.Structure):
     _fields_ = [("user", C.c_void_p), ("rank", C.c_int32), ("nranks", C.c_int32), ("exchange", EXCHANGE_FN), ("allreduce", ALLREDUCE_FN)]
 
@@ -151,6 +154,8 @@ def load_library() -> C.CDLL:
         "pa_curvature_run": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.c_int, pi32, C.POINTER(PaCurvParams), C.POINTER(vp), C.c_int]),
         "pa_gradcurv_run": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.c_int, pi32, C.POINTER(PaCurvParams), C.POINTER(vp), C.POINTER(vp),
                                       C.c_int]),
+        "pa_gradcurv_run_comps": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.c_int, C.c_int, pi32, C.POINTER(PaCurvParams), C.POINTER(vp), C.POINTER(vp),
+                                            C.c_int, DONE_FN, vp]),
     }
     missing = []
     for name, (res, args) in sig.items():
@@ -389,6 +394,25 @@ def curvature_run(ctx, states, comp, bc, params: PaCurvParams, outs, ocomp):
 def gradcurv_run(ctx, states, comp, bc, params: PaCurvParams, works, outs, ocomp):
     ctx.check(ctx.lib.pa_gradcurv_run(ctx.h, len(states), _handles(states), comp, _i3(bc), C.byref(params), _handles(works),
                                       _handles(outs), ocomp))
+
+
+def gradcurv_run_comps(ctx, states, comp0, ncomps, bc, params: PaCurvParams, works, outs, ocomp, done=None):
+    """pa_gradcurv_run_comps; done(comp) is called when a component's results are complete in outs (sync before reading)"""
+    err = []
+
+    def _cb(user, comp):
+        try:
+            done(comp)
+            return 0
+        except Exception as e:  # never let an exception cross the C boundary
+            err.append(e)
+            return 1
+    cb = DONE_FN(_cb) if done is not None else C.cast(None, DONE_FN)
+    rc = ctx.lib.pa_gradcurv_run_comps(ctx.h, len(states), _handles(states), int(comp0), int(ncomps), _i3(bc), C.byref(params), _handles(works),
+                                       _handles(outs), int(ocomp), cb, None)
+    if err:
+        raise err[0]
+    ctx.check(rc)
 
 
 def sdf_level_set(ctx: Context, meshes, exact_band: int = 1):

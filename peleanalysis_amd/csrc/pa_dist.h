@@ -31,8 +31,8 @@ struct XPlan {
 struct CsPlan {
   XPlan x;                       // coarse level (sharded) -> cs level
   pa_level* cs = nullptr;        // disjoint pieces of the coarse level (null: this rank needs none)
-  std::map<int, pa_mf*> mfs;     // multifabs on cs by component count, ng = 0
-  pa_mf* mf(pa_ctx* ctx, int ncomp);
+  std::map<int, pa_mf*> mfs;     // multifabs on cs by (component count, slot), ng = 0
+  pa_mf* mf(pa_ctx* ctx, int ncomp, int slot = 0);  // slot: distinct buffers of equal component count (phi / normals)
   ~CsPlan();
 };
 

@@ -417,12 +417,13 @@ CsPlan* pa_cs_plan(pa_ctx* ctx, const pa_level* F, const pa_level* C, int mode, 
   return raw;
 }
 
-pa_mf* CsPlan::mf(pa_ctx* ctx, int ncomp) {
+pa_mf* CsPlan::mf(pa_ctx* ctx, int ncomp, int slot) {
   if (!cs) return nullptr;
-  auto it = mfs.find(ncomp);
+  const int key = ncomp * 4 + slot;
+  auto it = mfs.find(key);
   if (it != mfs.end()) return it->second;
   pa_mf* m = pa_mf_create(ctx, cs, ncomp, 0, nullptr);
-  if (m) mfs[ncomp] = m;
+  if (m) mfs[key] = m;
   return m;
 }
 

@@ -197,7 +197,7 @@ static int fused_passes_dist(pa_ctx* ctx, int nlev, pa_mf* const* state, int com
     cs[l] = pa_cs_plan(ctx, state[l]->lev, state[l - 1]->lev, 0, 0, 0);
     if (!cs[l]) return 1;
     csphi[l] = cs[l]->mf(ctx, 1);
-    csn[l] = cs[l]->mf(ctx, 3);
+    csn[l] = cs[l]->mf(ctx, 3, 1);
     if (cs[l]->cs && (!csphi[l] || !csn[l])) return 1;
     jobs.push_back({&cs[l]->x, state[l - 1], comp, csphi[l], 0, 1});
   }
@@ -443,4 +443,75 @@ extern "C" int pa_gradcurv_run(pa_ctx* ctx, int nlev, pa_mf* const* state, int c
   // general AMR (concave coarse-fine corners, very thin boxes) or fused=0: pass by pass
   PA_TRY(pa_grad_run(ctx, nlev, state, comp, bc, out, ocomp));
   return curvature_passes(ctx, nlev, state, comp, bc, pmin, pmax, thr, out, -1, ocomp + 7, ocomp + 4, nullptr, -1, P->spacedim == 2 ? 1.0 : 0.5);
+}
+
+// Components comp0 .. comp0+ncomps-1 through the fused pipeline, one after the other into the SAME output buffers (the
+// reference's tools push one variable through at a time too; SURVEY 8d memory budget).  What does not depend on results
+// is done ONCE for all components: the local FillBoundary of every component is one launch, and on a sharded hierarchy
+// exchange A (ghost cells of phi + coarse phi under the coarse-fine faces) carries all components, so a component costs
+// one exchange (B, the coarse normals) instead of two.  Exact-normal pipeline only; anything else runs component by
+// component through pa_gradcurv_run.
+extern "C" int pa_gradcurv_run_comps(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp0, int ncomps, const int32_t bc[3], const pa_curv_params* P,
+                                     pa_mf* const* work, pa_mf* const* out, int ocomp, int (*done)(void* user, int comp), void* user) {
+  PaBind bind_(ctx);
+  PA_TRY(check_levels(ctx, nlev, state, "pa_gradcurv_run_comps"));
+  PA_TRY(check_levels(ctx, nlev, out, "pa_gradcurv_run_comps"));
+  if (!P) return pa_fail(ctx, "pa_gradcurv_run_comps: null params");
+  if (ncomps < 1 || comp0 < 0) return pa_fail(ctx, "pa_gradcurv_run_comps: component range");
+  for (int l = 0; l < nlev; ++l)
+    if (comp0 + ncomps > state[l]->ncomp) return pa_fail(ctx, "pa_gradcurv_run_comps: component range");
+  bool exact = P->fused && P->spacedim != 2 && !P->do_threshold && all_fusable(nlev, state);
+  for (int l = 0; l < nlev; ++l) exact = exact && pa_fused2_level_ok(state[l]->lev) && state[l]->ng >= 2;
+  if (!exact || ncomps == 1) {
+    for (int c = comp0; c < comp0 + ncomps; ++c) {
+      PA_TRY(pa_gradcurv_run(ctx, nlev, state, c, bc, P, work, out, ocomp));
+      if (done && done(user, c) != 0) return pa_fail(ctx, "pa_gradcurv_run_comps: the caller's callback failed");
+    }
+    return 0;
+  }
+  const bool dist = state[0]->lev->nranks > 1;
+  std::vector<CsPlan*> cs(nlev, nullptr);
+  std::vector<pa_mf*> csn(nlev, nullptr);
+  std::vector<const pa_mf*> crse(nlev, nullptr), crse_n(nlev, nullptr);
+  if (dist) {
+    std::vector<XJob> jobs;
+    for (int l = 0; l < nlev; ++l) {
+      XPlan* Pl = pa_fb_plan(ctx, state[l]->lev, 2);
+      if (!Pl) return 1;
+      jobs.push_back({Pl, state[l], comp0, state[l], comp0, ncomps});
+    }
+    for (int l = 1; l < nlev; ++l) {
+      cs[l] = pa_cs_plan(ctx, state[l]->lev, state[l - 1]->lev, 0, 0, 0);
+      if (!cs[l]) return 1;
+      pa_mf* m = cs[l]->mf(ctx, ncomps);
+      csn[l] = cs[l]->mf(ctx, 3, 1);
+      if (cs[l]->cs && (!m || !csn[l])) return 1;
+      crse[l] = m;
+      crse_n[l] = csn[l];
+      jobs.push_back({&cs[l]->x, state[l - 1], comp0, m, 0, ncomps});
+    }
+    ProfScope prof(ctx, PA_TAG_XCHG);
+    PA_TRY(pa_xexchange(ctx, (int)jobs.size(), jobs.data()));
+  } else {
+    for (int l = 1; l < nlev; ++l) { crse[l] = state[l - 1]; crse_n[l] = out[l - 1]; }
+  }
+  {
+    ProfScope prof(ctx, PA_TAG_FILL);
+    PA_TRY(pa_fill_boundary_local_batch(ctx, nlev, state, comp0, ncomps, 2));
+  }
+  for (int c = comp0; c < comp0 + ncomps; ++c) {
+    double pmin, pmax;
+    PA_TRY(prog_minmax(ctx, nlev, state, c, P, pmin, pmax));
+    PA_TRY(pa_gradcurv_prep_levels(ctx, nlev, state, c, crse.data(), dist ? c - comp0 : c, bc, pmin, pmax));
+    for (int l = 0; l < nlev; ++l) PA_TRY(pa_gradcurv_level_cg(ctx, state[l], c, pmin, pmax, out[l], ocomp));
+    if (dist) {
+      std::vector<XJob> jobs;
+      for (int l = 1; l < nlev; ++l) jobs.push_back({&cs[l]->x, out[l - 1], ocomp + 4, csn[l], 0, 3});
+      ProfScope prof(ctx, PA_TAG_XCHG);
+      PA_TRY(pa_xexchange(ctx, (int)jobs.size(), jobs.data()));
+    }
+    PA_TRY(pa_gradcurv_fix_levels(ctx, nlev, state, c, crse_n.data(), dist ? 0 : ocomp + 4, bc, pmin, pmax, out, ocomp + 4, ocomp + 7));
+    if (done && done(user, c) != 0) return pa_fail(ctx, "pa_gradcurv_run_comps: the caller's callback failed");
+  }
+  return 0;
 }

@@ -92,6 +92,24 @@ def _worker(rank, world, port, case):
             if fused:
                 assert comm.nexchange - n0 == 2, "the fused pipeline batches its cross-rank traffic into two exchanges"
             check(out, {0: (og, 0), 1: (og, 1), 2: (og, 2), 3: (og, 3), 4: (oc, 2), 5: (oc, 3), 6: (oc, 4), 7: (oc, 1)}, f"gradcurv fused={fused}")
+        # several components at once: exchange A carries all of them, one exchange (B) per component
+        out = [capi.DevMF(ctx, dl, 8, 0) for dl in dls]
+        seen = {}
+
+        def done(c):
+            ctx.sync()
+            seen[c] = [o.download() for o in out]
+        n0 = comm.nexchange
+        capi.gradcurv_run_comps(ctx, lst, 0, 2, bc, capi.curv_params(prog_min=pm[0], prog_max=pm[1], threshold=thr, fused=True), work, out, 0, done)
+        ctx.sync()
+        assert sorted(seen) == [0, 1]
+        if case == "wide" and thr is None:
+            assert comm.nexchange - n0 == 3, "exact-normal pipeline, 2 components: one exchange A + one exchange B per component"
+        for l, dl in enumerate(dls):
+            for i, g in enumerate(dl.gids):
+                v = seen[0][l].valid(i)
+                assert _same(v[0:4], og[l].valid(int(g))) and _same(v[4:7], oc[l].valid(int(g))[2:5]) and _same(v[7], oc[l].valid(int(g))[1]), \
+                    f"rank {rank}/{world} run_comps: level {l} box {g} differs from the undistributed oracle"
         # the curvature tool's pipeline with every option (Hessian rows and velocity need their own coarse data)
         out = [capi.DevMF(ctx, dl, 17, 0) for dl in dls]
         capi.curvature_run(ctx, lst, 0, bc, capi.curv_params(threshold=thr, fused=False, do_gauss=True, do_strain=True, strain_tensor=True, do_velnormal=True,

@@ -307,3 +307,34 @@ def test_curvature_options_match_oracle(ctx, oracle, name):
     small = [capi.DevMF(ctx, dl, 6, 0) for dl in dls]
     with pytest.raises(capi.PaError):
         capi.curvature_run(ctx, dst, 0, bc, P, small, 0)
+
+
+def test_gradcurv_run_comps_equals_component_by_component(ctx, oracle):
+    """pa_gradcurv_run_comps (FillBoundary of all components hoisted into one launch, results delivered through the callback
+    before the next component overwrites them) == pa_gradcurv_run per component, bit for bit; wide boxes (exact-normal
+    pipeline) and narrow boxes (falls back to the per-component path)"""
+    from peleanalysis_amd.hierarchy import nested_hierarchy, field_flame
+    for base, box in ((80, 40), (16, 8)):
+        H = nested_hierarchy(base, 3, box, is_per=(1, 1, 0))
+        states = make_states(H, 4, 2, field_flame, seed=31)
+        bc = capi.bc_from_flags((1, 1, 0))
+        dls, dst = _dev(ctx, H, states)
+        work = [capi.DevMF(ctx, dl, 1, 2) for dl in dls]
+        dout = [capi.DevMF(ctx, dl, 8, 0) for dl in dls]
+        want = {}
+        for c in (1, 2, 3):
+            capi.gradcurv_run(ctx, dst, c, bc, capi.curv_params(fused=True), work, dout, 0)
+            ctx.sync()
+            want[c] = [d.download().data.copy() for d in dout]
+        dst2 = [capi.DevMF.from_host(ctx, dl, st) for dl, st in zip(dls, states)]  # fresh ghost cells, same levels
+        got = {}
+
+        def done(c):
+            ctx.sync()
+            got[c] = [d.download().data.copy() for d in dout]
+        capi.gradcurv_run_comps(ctx, dst2, 1, 3, bc, capi.curv_params(fused=True), work, dout, 0, done)
+        ctx.sync()
+        assert ctx.bc_errors() == 0 and sorted(got) == [1, 2, 3]
+        for c in (1, 2, 3):
+            for l in range(H.nlev):
+                assert np.array_equal(got[c][l].view(np.int64), want[c][l].view(np.int64)), (base, c, l)
