@@ -718,6 +718,8 @@ def _tree_bytes(path):
                         "do_strain=1", "do_velnormal=1"], "_K"),
     ("filterPlt3d.ex", ["max_grid_size=8", "is_per=1 1 0"], "_filtered"),
     ("filterPlt3d.ex", ["max_grid_size=8", "interp_type=0", "base_fgr=4", "same_fgr_all_levels=1"], "_filtered"),
+    ("isosurface3d.ex", ["isoCompName=temp", "isoVal=1150", "comps=0 4", "outfile_base=surf"], "surf.mef"),
+    ("isosurface3d.ex", ["isoCompName=temp", "isoVal=1150", "comps=0 1", "outfile_base=surf", "is_per=1 1 0", "nGrow=2", "surfFormat=XDMF"], "surf.mesh"),
 ])
 def test_tools_multi_gpu_outputs_are_byte_identical(tmp_path, tool, args, suffix):
     """ngpus=<n>: the boxes of every level dealt to n ranks (host threads, one HIP context each; here they share the one GPU
@@ -731,8 +733,12 @@ def test_tools_multi_gpu_outputs_are_byte_identical(tmp_path, tool, args, suffix
         out = _run(tool, ["infile=" + p] + args + [f"ngpus={n}", "gpu_share=1"], d)
         if n > 1:
             assert f"distributed over {n} GPUs" in out.stdout
-        got = _tree_bytes(str(d / ("plt00005" + suffix)))
-        assert len(got) >= 5
+        if suffix.startswith("surf"):  # isosurface: the surface file(s) in the run directory
+            got = {f: open(d / f, "rb").read() for f in os.listdir(d) if f.startswith("surf")}
+            assert suffix in got and len(got[suffix]) > 10000
+        else:
+            got = _tree_bytes(str(d / ("plt00005" + suffix)))
+            assert len(got) >= 5
         if ref is None:
             ref = got
         else:

@@ -10,10 +10,16 @@
 // triangles of the box grown by nGrow[lev] = int(dmax*1.0000001/dx_lev) feed the GPU distance function
 // (pa_sdf_level_set3 = Tools/SDFGen make_level_set3, batched over all FABs of a level), signed with
 // the iso component and clipped at dmax; written as a one-component plotfile "distance".
-//       [surfFormat=MEF|XDMF]
+//       [surfFormat=MEF|XDMF] [surface_is_large=0 [chunk_size=32768] [tmpFile=isoTEMPFILE]] [ngpus=<n> [gpu_share=0|1]]
+// ngpus=<n> (pa_team.h): the FABs of every level are dealt to n ranks as the reference's MPI ranks own them
+// (isosurface.cpp:1441); every rank polygonises its FABs and the fragments are merged in BoxArray order -- the 1-rank
+// ordering against which connectivity is defined (the reference gathers per-rank node / element lists to the
+// I/O rank and re-uniquifies there, :932-1037, :1838-1878, so ITS node numbering depends on the rank layout) -- so the
+// surface file is byte-identical for every n.  collate is accepted and has no effect: the merged surface is always
+// written by the one process.  build_distance_function needs ngpus=1.
 // Periodic directions behave as in the reference: ghost cells behind a periodic face keep the coordinates of the
 // cells they image (isosurface.cpp:1469 "bad data in periodic directions"; the shift back at :1483-1507 never fires).
-#include "../common/pa_device.h"
+#include "../common/pa_team.h"
 #include "../common/pa_isomerge.h"
 #include <chrono>
 #include <future>
@@ -84,7 +90,7 @@ int main(int argc, char** argv) {
   double io_time = 0.0;  // plotfile reads (isosurface.cpp:1388-1415); everything else up to the merge is "Compute Surface"
   // the HIP context comes up on a second thread (~0.25 s) while this one reads the plotfile
   double tq = now();
-  pa::AsyncCtx actx;
+  pa::AsyncTeam ateam(pp);
   std::vector<pa::HostMF> host(Nlev);
   std::vector<std::vector<int64_t>> soff(Nlev), scs(Nlev);
   for (int lev = 0; lev < Nlev; ++lev) {
@@ -98,48 +104,94 @@ int main(int argc, char** argv) {
     io_time += now() - t_io;
   }
   tq = now();
-  pa::Ctx& ctx = actx.get();
+  pa::Team& team = ateam.get();
   t_ctx = now() - tq;  // what was not hidden behind the reads
+  if (team.n > 1) std::cout << "Boxes distributed over " << team.n << " GPUs, transport: " << team.transport << std::endl;
+  if (team.n > 1 && build_distance_function) pa::Abort("build_distance_function runs on one GPU: use ngpus=1");
+  const std::vector<std::vector<int32_t>> owner = pa::shard_levels(H, Nlev, team.n);
+  pa::IsoMerger merger(nc);
+  std::vector<pa::HostMF> hdist(build_distance_function ? Nlev : 0);
+  // one FAB's fragment into the global node / element sets: elements with a vertex whose edge is not inside the valid box
+  // grown by 1 are dropped, with those vertices (isosurface.cpp:1657-1682; a no-op when nGrow = 1), then isosurface.cpp:1687-1726
+  std::vector<double> hv;
+  std::vector<int32_t> ht, hk;
+  auto merge_box = [&](const pa::Box3& B, int ng, int64_t nv, int64_t nt, const double* pv, const int32_t* pk, const int32_t* pt) {
+    hv.assign(pv, pv + nv * nc);
+    ht.assign(pt, pt + nt * 3);
+    hk.assign(pk, pk + nv * 6);
+    long long nvk = nv, ntk = nt;
+    if (rm_external_elements && ng > 1) {
+      std::vector<int32_t> remap((size_t)nv);
+      nvk = 0;
+      for (int64_t q = 0; q < nv; ++q) {
+        bool in = true;
+        for (int d = 0; d < 3; ++d) {
+          const int a = hk[(size_t)q * 6 + d], c = hk[(size_t)q * 6 + 3 + d];
+          in = in && a >= B.lo[d] - 1 && a <= B.hi[d] + 1 && c >= B.lo[d] - 1 && c <= B.hi[d] + 1;
+        }
+        remap[(size_t)q] = in ? (int32_t)nvk : -1;
+        if (in) {
+          if (nvk != q) std::copy(hv.begin() + q * nc, hv.begin() + (q + 1) * nc, hv.begin() + nvk * nc);
+          ++nvk;
+        }
+      }
+      ntk = 0;
+      for (int64_t t = 0; t < nt; ++t) {
+        const int32_t a = remap[(size_t)ht[(size_t)t * 3]], c = remap[(size_t)ht[(size_t)t * 3 + 1]], e = remap[(size_t)ht[(size_t)t * 3 + 2]];
+        if (a < 0 || c < 0 || e < 0) continue;
+        ht[(size_t)ntk * 3] = a; ht[(size_t)ntk * 3 + 1] = c; ht[(size_t)ntk * 3 + 2] = e;
+        ++ntk;
+      }
+    }
+    merger.add(hv.data(), nvk, ht.data(), ntk);
+  };
+  // per rank and level: the fragments of its FABs as they came off the device (ngpus > 1: merged afterwards in BoxArray order)
+  struct LevFrag { std::vector<int> gids; std::vector<int64_t> nvb, ntb; std::vector<double> hva; std::vector<int32_t> hta, hka; };
+  std::vector<std::vector<LevFrag>> frags(team.n, std::vector<LevFrag>(Nlev));
+  team.run([&](int r) {
+  pa::Ctx& ctx = *team.ctx[r];
+  const bool lead = r == 0;  // the phase timers are rank 0's
   std::vector<std::unique_ptr<pa::DevLevel>> dl;
   std::vector<std::unique_ptr<pa::DevMF>> dst;
+  std::vector<pa::Share> shares;
+  std::vector<pa::HostMF> hloc(Nlev);
+  double tq = now();
   for (int lev = 0; lev < Nlev; ++lev) {
     const auto& L = H.lev[lev];
     const int ng = nGrow[lev];
     tq = now();
-    dl.emplace_back(new pa::DevLevel(ctx, L.boxes, L.domain, is_per.data(), H.prob_lo, H.prob_hi));
+    shares.emplace_back(L.boxes, owner[lev], r);
+    dl.emplace_back(new pa::DevLevel(ctx, L.boxes, L.domain, is_per.data(), H.prob_lo, H.prob_hi, &owner[lev], r, team.n));
     dst.emplace_back(new pa::DevMF(ctx, *dl.back(), nc, ng));
+    if (team.n > 1) shares.back().gather(host[lev], hloc[lev]);
     {
       pa::DevMF dfield(ctx, *dl.back(), nComp, ng);
-      ctx.check(pa_mf_upload(ctx.h, dfield.h, host[lev].data.data()));
+      ctx.check(pa_mf_upload(ctx.h, dfield.h, (team.n > 1 ? hloc[lev] : host[lev]).data.data()));
       ctx.check(pa_iso_coords_level(ctx.h, dst.back()->h, 0));
       ctx.check(pa_mf_copy(ctx.h, dfield.h, 0, dst.back()->h, 3, nComp, ng));
       ctx.check(pa_sync(ctx.h));
     }
-    {  // offsets of the nc-component device multifab
+    if (team.n == 1) {  // offsets of the nc-component device multifab (distance function)
       const std::vector<int32_t> b6 = host[lev].boxes6();
       soff[lev].resize(L.boxes.size());
       scs[lev].resize(L.boxes.size());
       pa_mf_layout((int)L.boxes.size(), b6.data(), nc, ng, soff[lev].data(), scs[lev].data());
     }
-    t_up += now() - tq;
+    if (lead) t_up += now() - tq;
     tq = now();
-    std::cout << "FillPatching the grown structures at level " << lev << "..." << std::endl;
+    if (lead) std::cout << "FillPatching the grown structures at level " << lev << "..." << std::endl;
     ctx.check(pa_fill_boundary(ctx.h, dst[lev]->h, 0, nc, ng));
     if (lev > 0) ctx.check(pa_fillpatch_two_levels(ctx.h, dst[lev]->h, dst[lev - 1]->h, 0, nc, ng, 2, 0));  // PCInterp
-    std::cout << "...done FillPatching the grown structures at level " << lev << "..." << std::endl;
+    if (lead) std::cout << "...done FillPatching the grown structures at level " << lev << "..." << std::endl;
     ctx.check(pa_sync(ctx.h));
-    t_fill += now() - tq;
+    if (lead) t_fill += now() - tq;
   }
   ctx.check(pa_sync(ctx.h));
   if (pa_bc_errors(ctx.h) != 0) pa::Abort("FillPatchTwoLevels: fine grids are not properly nested in the coarse level");
 
-  pa::IsoMerger merger(nc);
-  std::vector<double> hv;
-  std::vector<int32_t> ht, hk;
-  std::vector<pa::HostMF> hdist(build_distance_function ? Nlev : 0);
   for (int lev = 0; lev < Nlev; ++lev) {
-    const auto& L = H.lev[lev];
     const int ng = nGrow[lev];
+    struct { const std::vector<pa::Box3>& boxes; const pa::Box3& domain; } L{shares[lev].boxes, H.lev[lev].domain};  // this rank's FABs
     double* base = pa_mf_data(dst[lev]->h);
     // distance function: one grid per FAB that holds triangles, run as one batch per level
     std::unique_ptr<pa::DevMF> ddist;
@@ -170,20 +222,24 @@ int main(int argc, char** argv) {
     double* dv = nullptr;
     int32_t *dk = nullptr, *dt = nullptr;
     tq = now();
-    ctx.check(pa_mc_level_fine(ctx.h, dst[lev]->h, fine_mask ? dl[lev + 1]->h : nullptr, 2, loops.data(), 3 + isoComp, isoVal, nvb.data(), ntb.data(), &dv, &dk,
-                               &dt));
-    t_mc += now() - tq;
+    if (nb > 0)  // a rank may own no FAB of a level
+      ctx.check(pa_mc_level_fine(ctx.h, dst[lev]->h, fine_mask ? dl[lev + 1]->h : nullptr, 2, loops.data(), 3 + isoComp, isoVal, nvb.data(), ntb.data(), &dv, &dk,
+                                 &dt));
+    if (lead) t_mc += now() - tq;
     tq = now();
     int64_t nvt = 0, ntt = 0;
     for (size_t b = 0; b < nb; ++b) { nvt += nvb[b]; ntt += ntb[b]; }
-    std::vector<double> hva((size_t)(nvt * nc));
-    std::vector<int32_t> hta((size_t)(ntt * 3)), hka((size_t)(nvt * 6));
+    LevFrag& F = frags[r][lev];
+    F.gids = shares[lev].gids; F.nvb = nvb; F.ntb = ntb;
+    std::vector<double>& hva = F.hva;
+    std::vector<int32_t>&hta = F.hta, &hka = F.hka;
+    hva.resize((size_t)(nvt * nc)); hta.resize((size_t)(ntt * 3)); hka.resize((size_t)(nvt * 6));
     if (nvt > 0) {
       ctx.check(pa_memcpy_d2h(ctx.h, hva.data(), dv, nvt * nc * 8));
       ctx.check(pa_memcpy_d2h(ctx.h, hka.data(), dk, nvt * 6 * 4));
     }
     if (ntt > 0) ctx.check(pa_memcpy_d2h(ctx.h, hta.data(), dt, ntt * 3 * 4));
-    t_d2h += now() - tq;
+    if (lead) t_d2h += now() - tq;
     tq = now();
     void* dx3 = nullptr;
     if (build_distance_function && nvt > 0) {  // vertList: Vec3f(loc) rounds to float (isosurface.cpp:1598-1611)
@@ -201,9 +257,6 @@ int main(int argc, char** argv) {
       const int64_t nv = nvb[b], nt = ntb[b];
       if (nt <= 0) continue;
       has_elts[b] = 1;
-      hv.assign(hva.begin() + vo * nc, hva.begin() + (vo + nv) * nc);
-      ht.assign(hta.begin() + to * 3, hta.begin() + (to + nt) * 3);
-      hk.assign(hka.begin() + vo * 6, hka.begin() + (vo + nv) * 6);
       if (build_distance_function) {
         // vertList / faceList of this FAB BEFORE trimming (isosurface.cpp:1598-1626)
         pa::Box3 g{{B.lo[0] - ng, B.lo[1] - ng, B.lo[2] - ng}, {B.hi[0] + ng, B.hi[1] + ng, B.hi[2] + ng}};
@@ -223,35 +276,9 @@ int main(int argc, char** argv) {
         grid_box.push_back(b);
         grid_bufs.push_back(dphi);
       }
-      // elements with a vertex whose edge is not inside the valid box grown by 1 are dropped, with those
-      // vertices (isosurface.cpp:1657-1682); a no-op when nGrow = 1
-      long long nvk = nv, ntk = nt;
-      if (rm_external_elements && ng > 1) {
-        std::vector<int32_t> remap((size_t)nv);
-        nvk = 0;
-        for (int64_t q = 0; q < nv; ++q) {
-          bool in = true;
-          for (int d = 0; d < 3; ++d) {
-            const int a = hk[(size_t)q * 6 + d], c = hk[(size_t)q * 6 + 3 + d];
-            in = in && a >= B.lo[d] - 1 && a <= B.hi[d] + 1 && c >= B.lo[d] - 1 && c <= B.hi[d] + 1;
-          }
-          remap[(size_t)q] = in ? (int32_t)nvk : -1;
-          if (in) {
-            if (nvk != q) std::copy(hv.begin() + q * nc, hv.begin() + (q + 1) * nc, hv.begin() + nvk * nc);
-            ++nvk;
-          }
-        }
-        ntk = 0;
-        for (int64_t t = 0; t < nt; ++t) {
-          const int32_t a = remap[(size_t)ht[(size_t)t * 3]], c = remap[(size_t)ht[(size_t)t * 3 + 1]], e = remap[(size_t)ht[(size_t)t * 3 + 2]];
-          if (a < 0 || c < 0 || e < 0) continue;
-          ht[(size_t)ntk * 3] = a; ht[(size_t)ntk * 3 + 1] = c; ht[(size_t)ntk * 3 + 2] = e;
-          ++ntk;
-        }
-      }
-      merger.add(hv.data(), nvk, ht.data(), ntk);
+      if (team.n == 1) merge_box(B, ng, nv, nt, hva.data() + vo * nc, hka.data() + vo * 6, hta.data() + to * 3);
     }
-    t_merge += now() - tq;
+    if (lead) t_merge += now() - tq;
     // dv, dk, dt are one allocation (base dv); the distance function still reads the triangles
     if (build_distance_function) grid_bufs.push_back(dv); else pa_device_free(ctx.h, dv);
     if (build_distance_function) {
@@ -278,6 +305,26 @@ int main(int argc, char** argv) {
             for (int i = B.lo[0] - ng; i <= B.hi[0] + ng; ++i) *hdist[lev].ptr((int)b, 0, i, j, k) = v;
       }
     }
+  }
+  });
+  if (team.n > 1) {  // BoxArray order = the 1-rank ordering (isosurface.cpp:1531: MFIter over the level's FABs)
+    tq = now();
+    for (int lev = 0; lev < Nlev; ++lev) {
+      std::vector<std::pair<int, int>> where(H.lev[lev].boxes.size());  // global box -> (rank, local index)
+      std::vector<std::vector<int64_t>> vo(team.n), to(team.n);
+      for (int r = 0; r < team.n; ++r) {
+        const LevFrag& F = frags[r][lev];
+        vo[r].assign(F.gids.size() + 1, 0); to[r].assign(F.gids.size() + 1, 0);
+        for (size_t i = 0; i < F.gids.size(); ++i) { where[F.gids[i]] = {r, (int)i}; vo[r][i + 1] = vo[r][i] + F.nvb[i]; to[r][i + 1] = to[r][i] + F.ntb[i]; }
+      }
+      for (size_t g = 0; g < where.size(); ++g) {
+        const int r = where[g].first, i = where[g].second;
+        const LevFrag& F = frags[r][lev];
+        if (F.ntb[i] <= 0) continue;
+        merge_box(H.lev[lev].boxes[g], nGrow[lev], F.nvb[i], F.ntb[i], F.hva.data() + vo[r][i] * nc, F.hka.data() + vo[r][i] * 6, F.hta.data() + to[r][i] * 3);
+      }
+    }
+    t_merge += now() - tq;
   }
   if (build_distance_function) {  // isosurface.cpp:1731-1748
     std::string outfile("distance");
