@@ -757,3 +757,71 @@ def isosurface2d_pipeline(levels, fields, comps, isocomp_index, isoval, MF, ngro
             if len(verts):
                 frags.append((verts, segs))
     return iso2d_merge(frags, nc)
+
+
+# ---------------------------------------------------------------- isoMEF.cpp (contour lines on a MEF surface)
+def iso_mef(nodes, elts0, iso_comp, iso_val, eps=1.0e-8):
+    """Plain-Python restatement of isoMEF.cpp:121-341, 382-482 (test infrastructure; PARITY UNPINNED -- the reference holds
+    no MEF data): returns (number of segments, lines) with lines = list of lists of vertex tuples as out.dat lists them
+    (first point of every segment, then the last point of the last one)."""
+    nodes = np.asarray(nodes, dtype=np.float64)
+    cache = {}  # (min node, max node) -> point (interpolated with the endpoint order of the first request)
+
+    def vertex(a, b):
+        key = (min(a, b), max(a, b))
+        if key not in cache:
+            va, vb = nodes[a, iso_comp], nodes[b, iso_comp]
+            if abs(iso_val - va) < eps:
+                p = nodes[a].copy()
+            elif abs(iso_val - vb) < eps:
+                p = nodes[b].copy()
+            elif abs(va - vb) < eps:
+                p = nodes[a].copy()
+            else:
+                mu = (iso_val - va) / (vb - va)
+                p = nodes[a] + mu * (nodes[b] - nodes[a])
+            cache[key] = p
+        return key
+    raw = []
+    for e in np.asarray(elts0):
+        n = [int(v) for v in e]
+        lo = [nodes[q, iso_comp] < iso_val for q in n]
+        cut = [vertex(n[i], n[(i + 1) % 3]) for i in range(3) if lo[i] != lo[(i + 1) % 3]]
+        if len(cut) == 2:
+            raw.append(cut)
+    ids = {k: i for i, k in enumerate(sorted(cache))}  # std::map order of the unordered pairs
+    pts = [cache[k] for k in sorted(cache)]
+    segs = [(ids[a], ids[b]) for a, b in raw]
+    rest = list(range(len(segs)))
+    lines = []
+    if segs:
+        idx = segs[rest[0]][0]
+        lines.append([])
+        while rest:
+            hit = next((i for i in rest if idx in segs[i]), None)
+            if hit is None:
+                lines.append([])
+                idx = segs[rest[0]][0]
+                continue
+            l, r = segs[hit]
+            lines[-1].append((l, r) if l == idx else (r, l))
+            idx = r if l == idx else l
+            rest.remove(hit)
+        changed = True
+        while changed:
+            changed = False
+            for a in lines:
+                if not a:
+                    continue
+                idx_l, idx_r = a[0][0], a[-1][1]  # read once per outer fragment, stale after a splice (as in the reference)
+                for b in lines:
+                    if not b or a[0] == b[0]:
+                        continue
+                    if idx_r == b[0][0]:
+                        a.extend(b); del b[:]; changed = True
+                    elif idx_r == b[-1][1]:
+                        a.extend([(r, l) for l, r in reversed(b)]); del b[:]; changed = True
+                    elif idx_l == b[0][0]:
+                        a[0:0] = [(r, l) for l, r in reversed(b)]; del b[:]; changed = True
+    lines = [ln for ln in lines if ln]
+    return len(segs), [[pts[s[0]] for s in ln] + [pts[ln[-1][1]]] for ln in lines]

@@ -89,6 +89,65 @@ def _write_mef(path, nodes, faces1, names=b"X Y Z"):
         fh.write(np.ascontiguousarray(faces1, "<i4").tobytes())
 
 
+def _icosphere(nsub=2):
+    """closed, consistently oriented triangulation of the unit sphere (subdivided octahedron)"""
+    v = [(1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1)]
+    f = [(0, 2, 4), (2, 1, 4), (1, 3, 4), (3, 0, 4), (2, 0, 5), (1, 2, 5), (3, 1, 5), (0, 3, 5)]
+    v = [np.array(p, float) for p in v]
+    for _ in range(nsub):
+        mid, nf = {}, []
+
+        def m(a, b):
+            k = (min(a, b), max(a, b))
+            if k not in mid:
+                p = v[a] + v[b]
+                v.append(p / np.linalg.norm(p))
+                mid[k] = len(v) - 1
+            return mid[k]
+        for a, b, c in f:
+            ab, bc, ca = m(a, b), m(b, c), m(c, a)
+            nf += [(a, ab, ca), (ab, b, bc), (ca, bc, c), (ab, bc, ca)]
+        f = nf
+    return np.array(v), np.array(f, dtype=np.int32)
+
+
+def test_cpp_iso_mef_tool(tmp_path, oracle):
+    """isoMEF3d.ex (host only; isoMEF.cpp): contour lines of a node variable on a MEF surface -> Tecplot line zones in
+    ./out.dat.  Known answers on a sphere: the contour of z is ONE closed line on the plane z = isoVal whose points lie
+    between the sphere and the chords of its facets; the contour of x*y at 0.2 is two closed lines; out.dat equals the
+    Python restatement (oracle.iso_mef) line for line."""
+    _build_tools()
+    xyz, faces = _icosphere(3)
+    nodes = np.column_stack([xyz, xyz[:, 2] + 0.013, xyz[:, 0] * xyz[:, 1]])
+    f = str(tmp_path / "sphere.mef")
+    _write_mef(f, nodes, faces + 1, names=b"X Y Z height xy")
+    for comp, val, nlines in ((3, 0.35, 1), (4, 0.2, 2), (3, 5.0, 0)):
+        out = subprocess.run([os.path.join(BIN, "isoMEF3d.ex"), "infile=" + f, f"isoComp={comp}", f"isoVal={val}"], cwd=tmp_path, capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr
+        nseg, lines = oracle.iso_mef(nodes, faces, comp, val)
+        assert f"Found {nseg} segments" in out.stdout and f"number of contours {nlines}" in out.stderr and len(lines) == nlines
+        txt = open(tmp_path / "out.dat").read().split("\n")
+        assert txt[0] == "VARIABLES = X Y Z height xy"
+        want = []
+        for ln in lines:
+            want.append(f"ZONE ZONETYPE=FELINESEG DATAPACKING=POINT N={len(ln)} E={len(ln) - 1}")
+            want += [" ".join("%g" % v for v in p) + " " for p in ln]
+            want += [f"{c} {c + 1}" for c in range(1, len(ln))]
+        assert txt[1:-1] == want and txt[-1] == ""
+        for ln in lines:
+            P = np.array(ln)
+            assert np.allclose(P[0], P[-1], atol=0)                                  # closed
+            assert np.abs(P[:, comp] - val).max() < 1e-12                            # on the iso value
+            r = np.linalg.norm(P[:, :3], axis=1)
+            assert r.max() <= 1.0 + 1e-12 and r.min() > 0.98                         # on the facets' edges, just inside the sphere
+        if comp == 3 and nlines == 1:
+            P = np.array(lines[0])
+            length = np.linalg.norm(np.diff(P[:, :3], axis=0), axis=1).sum()
+            assert abs(length / (2 * np.pi * np.sqrt(1 - (0.35 - 0.013) ** 2)) - 1) < 0.01
+    bad = subprocess.run([os.path.join(BIN, "isoMEF3d.ex"), "infile=" + f, "isoComp=9", "isoVal=0"], cwd=tmp_path, capture_output=True, text=True)
+    assert bad.returncode != 0 and "isoComp" in bad.stderr
+
+
 def test_cpp_check_iso_tool(tmp_path):
     """checkIso3d.ex (host only; checkIso.cpp:127-149): a consistently oriented tetrahedron passes; with one face
     flipped the reference's assertion still cannot fire (direction-blind comparator: quirk kept), strict=1 reports it"""
