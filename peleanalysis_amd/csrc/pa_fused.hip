@@ -387,9 +387,22 @@ static void march_launch(hipStream_t st, const BP& bp, int nx, int ny, int nz, u
   // ran at 50 % of the HBM figure; shorter z segments give the chip enough workgroups to balance (PA_KSEG 64 / 32 /
   // 16 / 8 on that level: 0.305 / 0.280 / 0.267 / 0.269 ms per launch; on the 512^3 headline level 64 stays best).
   // An explicit PA_KSEG is taken as given.
+  // Round 2: the segment length is chosen from a small model instead of halved -- one workgroup per CU (LDS), so a launch
+  // takes about ceil(workgroups / 256) rounds of (planes per segment + ~4 planes of pipeline fill); measured on rank 0's
+  // share of the headline (8 boxes of 128^3 per level = 160 tiles): 16 / 22 / 32 / 43 / 64 planes -> 0.266 / 0.272 / 0.280 /
+  // 0.254 / 0.309 ms per launch (model: 100 / 104 / 108 / 94 / 136), 16 boxes: 32 planes best (model and measurement).
   if (!getenv("PA_KSEG")) {
     const long long per_seg = (long long)((nx + 63) / 64) * ((ny + 12) / 13) * nboxes;
-    while (A.kseg > 16 && per_seg * ((nz + A.kseg - 1) / A.kseg) < 2048) A.kseg /= 2;
+    if (per_seg * ((nz + A.kseg - 1) / A.kseg) < 2048) {
+      long long best = -1;
+      int best_k = A.kseg;
+      for (int tz = 1; tz <= std::max(1, nz / 8); ++tz) {
+        const int k = (nz + tz - 1) / tz;
+        const long long rounds = (per_seg * ((nz + k - 1) / k) + 255) / 256, cost = rounds * (k + 4);
+        if (best < 0 || cost < best) { best = cost; best_k = k; }
+      }
+      A.kseg = std::max(best_k, 4);
+    }
   }
   // PA_PAIR=1 selects the 16-byte paired stores (read per launch so that a test can switch it).
   // Off by default: measured 2.36 vs 2.31 ms per launch on the headline level.

@@ -181,8 +181,9 @@ static int fused_pre(pa_ctx* ctx, int l, pa_mf* const* state, int comp, const in
 // only, so the cross-rank traffic of a whole pass collapses into TWO grouped exchanges:
 //   A  ghost cells of phi on every level (FillBoundary, 2 layers) + the coarse phi under every fine level's coarse-fine
 //      faces (what setCoarseFineBC / the MLMG boundary registers copy, curvature.cpp:443-445, grad.cpp:212)
-//   B  the coarse flame normal under those faces, once the layer-1 normals of every level are final (curvature.cpp:514-518)
-// with the ghost preparation + sweeps + layer-1 normals of all levels between them and the face curvature after B.
+//   B  the coarse flame normal under those faces, once the normals of the coarser level are final (curvature.cpp:514-518)
+// with the ghost preparation + sweeps (+ layer-1 normals in the first pipeline) between them and the face curvature after
+// B.  In the exact-normal pipeline B is split per level and overlapped with the sweeps (nlev exchanges, two exposed).
 static int fused_passes_dist(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, const int32_t bc[3], double pmin, double pmax, double thr,
                              pa_mf* const* work, pa_mf* const* out, int ocomp, bool exact) {
   std::vector<XJob> jobs;
@@ -201,26 +202,62 @@ static int fused_passes_dist(pa_ctx* ctx, int nlev, pa_mf* const* state, int com
     if (cs[l]->cs && (!csphi[l] || !csn[l])) return 1;
     jobs.push_back({&cs[l]->x, state[l - 1], comp, csphi[l], 0, 1});
   }
-  {
-    ProfScope prof(ctx, PA_TAG_XCHG);
-    PA_TRY(pa_xexchange(ctx, (int)jobs.size(), jobs.data()));
-  }
-  if (exact) {  // exact-normal pipeline: normals are final after the sweeps, one fix-up launch pair for all levels after exchange B
+  if (exact) {
+    // Exact-normal pipeline with the exchanges on a side stream (PA_XOVERLAP, default on): exchange A runs next to the
+    // local half of FillBoundary; the coarse normals of level l+1 (exchange B, split per level) leave as soon as sweep(l)
+    // is done and travel under the sweeps of the finer levels -- only the last piece and exchange A are exposed.
+    //   stream A: [FillBoundary local] wait(A) prep sweep(0) sweep(1)        sweep(2) wait(B) fix
+    //   stream C: [exchange A        ]                  B(1) ...      B(2) ...
+    static const int xov = [] { const char* e = getenv("PA_XOVERLAP"); return e ? atoi(e) : 1; }();
     std::vector<const pa_mf*> crse(csphi.begin(), csphi.end()), crse_n(csn.begin(), csn.end());
+    hipStream_t A = ctx->stream, C = A;
+    const size_t nev = 3 + (size_t)nlev;
+    if (xov) {
+      if (!ctx->stream2) PA_HIP(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+      C = ctx->stream2;
+      while (ctx->sync_evs.size() < nev) {
+        hipEvent_t e;
+        PA_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->sync_evs.push_back(e);
+      }
+      PA_HIP(hipEventRecord(ctx->sync_evs[0], A));  // the side stream starts after everything already queued (inputs, the previous pass)
+      PA_HIP(hipStreamWaitEvent(C, ctx->sync_evs[0], 0));
+    }
+    {
+      StreamSwap sw(ctx, C);
+      ProfScope prof(ctx, PA_TAG_XCHG);
+      PA_TRY(pa_xexchange(ctx, (int)jobs.size(), jobs.data()));
+    }
+    if (xov) PA_HIP(hipEventRecord(ctx->sync_evs[1], C));
     {
       ProfScope prof(ctx, PA_TAG_FILL);
       PA_TRY(pa_fill_boundary_local_batch(ctx, nlev, state, comp, 1, 2));
     }
+    if (xov) PA_HIP(hipStreamWaitEvent(A, ctx->sync_evs[1], 0));
     PA_TRY(pa_gradcurv_prep_levels(ctx, nlev, state, comp, crse.data(), 0, bc, pmin, pmax));
-    for (int l = 0; l < nlev; ++l) PA_TRY(pa_gradcurv_level_cg(ctx, state[l], comp, pmin, pmax, out[l], ocomp));
-    jobs.clear();
-    for (int l = 1; l < nlev; ++l) jobs.push_back({&cs[l]->x, out[l - 1], ocomp + 4, csn[l], 0, 3});
-    {
-      ProfScope prof(ctx, PA_TAG_XCHG);
-      PA_TRY(pa_xexchange(ctx, (int)jobs.size(), jobs.data()));
+    for (int l = 0; l < nlev; ++l) {
+      PA_TRY(pa_gradcurv_level_cg(ctx, state[l], comp, pmin, pmax, out[l], ocomp));
+      if (l + 1 < nlev) {  // the coarse normals level l+1 needs: every rank takes part, whatever it owns
+        if (xov) {
+          PA_HIP(hipEventRecord(ctx->sync_evs[3 + l], A));
+          PA_HIP(hipStreamWaitEvent(C, ctx->sync_evs[3 + l], 0));
+        }
+        XJob J = {&cs[l + 1]->x, out[l], ocomp + 4, csn[l + 1], 0, 3};
+        StreamSwap sw(ctx, C);
+        ProfScope prof(ctx, PA_TAG_XCHG);
+        PA_TRY(pa_xexchange(ctx, 1, &J));
+      }
+    }
+    if (xov) {
+      PA_HIP(hipEventRecord(ctx->sync_evs[2], C));
+      PA_HIP(hipStreamWaitEvent(A, ctx->sync_evs[2], 0));
     }
     PA_TRY(pa_gradcurv_fix_levels(ctx, nlev, state, comp, crse_n.data(), 0, bc, pmin, pmax, out, ocomp + 4, ocomp + 7));
     return 0;
+  }
+  {
+    ProfScope prof(ctx, PA_TAG_XCHG);
+    PA_TRY(pa_xexchange(ctx, (int)jobs.size(), jobs.data()));
   }
   for (int l = 0; l < nlev; ++l) PA_TRY(fused_pre(ctx, l, state, comp, bc, pmin, pmax, work, csphi[l], true));
   for (int l = 0; l < nlev; ++l) {
