@@ -156,13 +156,17 @@ __global__ __launch_bounds__(64 * (PA_MTY + 3), 1) void k_gradcurv_march3(BP bp,
   const int rtop = min(PA_MROWS - 1, V.hi[1] + 1 - j0 + 1);  // row slot of the last live row
   // compact resolved-ghost arrays of the special faces this tile touches (null: ordinary face / tile not at that face)
   const double *cgxl = nullptr, *cgxh = nullptr, *cgyl = nullptr, *cgyh = nullptr, *cgzl = nullptr, *cgzh = nullptr;
+  // On the HIGH sides a tile / segment may also end one short of the box (widths 64 t + 1, MTY t + 1 rows, a last
+  // segment of one plane): its outermost neighbour row / column / plane is then the last VALID one and the "row beyond"
+  // it is the ghost row -- which must come from the array as well (mode 2 below; mode 1 = the neighbour itself is the ghost).
+  int xhmode = 0, yhmode = 0;
   if (CG) {
     if (bx == 0) cgxl = bp.cg_face(box, 0);
-    if (iR == V.hi[0] + 1) cgxh = bp.cg_face(box, 1);
+    if (iR >= V.hi[0]) { cgxh = bp.cg_face(box, 1); xhmode = cgxh ? (iR == V.hi[0] + 1 ? 1 : 2) : 0; }
     if (by == 0) cgyl = bp.cg_face(box, 2);
-    if (j0 + rtop - 1 == V.hi[1] + 1) cgyh = bp.cg_face(box, 3);
+    if (j0 + rtop - 1 >= V.hi[1]) { cgyh = bp.cg_face(box, 3); yhmode = cgyh ? (j0 + rtop - 1 == V.hi[1] + 1 ? 1 : 2) : 0; }
     if (k0 == V.lo[2]) cgzl = bp.cg_face(box, 4);
-    if (k1 == V.hi[2]) cgzh = bp.cg_face(box, 5);
+    if (k1 >= V.hi[2] - 1) cgzh = bp.cg_face(box, 5);
   }
 
   __shared__ MarchLds<PA_MTY> S;
@@ -214,17 +218,22 @@ __global__ __launch_bounds__(64 * (PA_MTY + 3), 1) void k_gradcurv_march3(BP bp,
       // CG: this row is the ghost row behind a special y face: the second stream reads the face's compact array
       // [plane][x], one plane AHEAD (it supplies c of plane p+2 at step p instead of c_out of plane p+1)
       const double* cgy = CG ? ((rr == 0) ? cgyl : cgyh) : nullptr;
-      const bool ysp = CG && cgy != nullptr;
-      const long long pso = ysp ? (long long)(nx + 2) * 8 : pps;  // plane stride of the second stream
+      const int ymode = (CG && cgy) ? ((rr == 0) ? 1 : yhmode) : 0;  // 1: this row is the ghost row; 2: the row beyond it is
+      const bool ysp = ymode == 1;
+      const long long pso = ymode ? (long long)(nx + 2) * 8 : pps;  // plane stride of the second stream
       const int sh = ysp ? 1 : 0;
-      if (ysp) {
+      if (ymode) {
         const char* cb = (const char*)(cgy + (long long)(k0 - 1 - V.lo[2] + 1) * (nx + 2) + (i0 - V.lo[0] + 1));
-        cc = PA_LDG(cb, lo8);  // c of plane k0-1
-        go = cb + pso;         // plane k0
+        if (ysp) {
+          cc = PA_LDG(cb, lo8);  // c of plane k0-1
+          go = cb + pso;         // plane k0
+        } else {
+          go = cb;               // c of the row beyond, same planes as the phi stream it replaces
+        }
       }
       double co = PA_LDG(go, lo8);
       if (ysp) cp = co;        // c of plane k0
-      else co = PA_PROG(co);
+      else if (ymode == 0) co = PA_PROG(co);
       double fo[3];
       __builtin_amdgcn_sched_barrier(0);
       f[0] = PA_LDG(gp + 3 * pps, lo8);
@@ -273,7 +282,7 @@ __global__ __launch_bounds__(64 * (PA_MTY + 3), 1) void k_gradcurv_march3(BP bp,
           f[SP] = PA_LDG(gp, lo8);
           fo[SP] = PA_LDG(go, lo8);
         }
-        cm = cc; cc = cp; cp = ysp ? xo : PA_PROG(x); co = PA_PROG(xo);
+        cm = cc; cc = cp; cp = ysp ? xo : PA_PROG(x); co = (ymode == 2) ? xo : PA_PROG(xo);
         fzc = fzh;
         p0 = p1; p1 = x;
       };
@@ -299,7 +308,7 @@ __global__ __launch_bounds__(64 * (PA_MTY + 3), 1) void k_gradcurv_march3(BP bp,
     }
     if (CG && cgzh) {
       cgzv = PA_LDG((const char*)(cgzh + (long long)(j - V.lo[1] + 1) * (nx + 2) + (i0 - V.lo[0] + 1)), lo8);
-      pzh = k1 - 1;
+      pzh = V.hi[2] - 1;  // step p requests phi of plane p + 2; plane hi_z + 1 is read when k1 >= hi_z - 1
     }
     S.c[0][rr][xs] = cc;
     __syncthreads();
@@ -457,17 +466,22 @@ __global__ __launch_bounds__(64 * (PA_MTY + 3), 1) void k_gradcurv_march3(BP bp,
     double p0 = PA_LDG(gp + pps, og), p1 = PA_LDG(gp + 2 * pps, og);
     double cm = PA_PROG(PA_LDG(gp, og)), cc = PA_PROG(p0), cp = PA_PROG(p1);
     const double* cgx = CG ? (side ? cgxh : cgxl) : nullptr;
-    const bool xsp = CG && cgx != nullptr;
-    if (xsp) {
+    const int xmode = (CG && cgx) ? (side ? xhmode : 1) : 0;  // 1: this column is the ghost column; 2: the column beyond it is
+    const bool xsp = xmode == 1;
+    if (xmode) {
       const char* cb = (const char*)(cgx + (long long)(k0 - 1 - V.lo[2] + 1) * (ny + 2) + (j - V.lo[1] + 1));
       pso = (long long)(ny + 2) * 8;
-      sh = 1;
-      cc = PA_LDG(cb, 0);  // c of plane k0-1
-      gol = cb + pso;      // plane k0
+      if (xsp) {
+        sh = 1;
+        cc = PA_LDG(cb, 0);  // c of plane k0-1
+        gol = cb + pso;      // plane k0
+      } else {
+        gol = cb;            // c of the column beyond, same planes as the phi stream it replaces
+      }
     }
     double co = PA_LDO(0);
     if (xsp) cp = co;
-    else co = PA_PROG(co);
+    else if (xmode == 0) co = PA_PROG(co);
     double f[3], fo[3];
     __builtin_amdgcn_sched_barrier(0);
     f[0] = PA_LDG(gp + 3 * pps, og);
@@ -523,7 +537,7 @@ __global__ __launch_bounds__(64 * (PA_MTY + 3), 1) void k_gradcurv_march3(BP bp,
         f[SP] = PA_LDG(gp, og);
         fo[SP] = PA_LDO(0);
       }
-      cm = cc; cc = cp; cp = xsp ? xo : PA_PROG(x); co = PA_PROG(xo);
+      cm = cc; cc = cp; cp = xsp ? xo : PA_PROG(x); co = (xmode == 2) ? xo : PA_PROG(xo);
       fzc = fzh;
       p0 = p1; p1 = x;
     };

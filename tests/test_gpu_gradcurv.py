@@ -134,10 +134,40 @@ def test_gradcurv_exact_normal_pipeline(ctx, oracle, per, sym):
         capi.gradcurv_run(ctx, dst, 0, bc, capi.curv_params(fused=True), work, dout, 0)
         ctx.sync()
         assert ctx.bc_errors() == 0
+        assert ctx.lib.pa_sweep_kernel_name(ctx.h).decode().endswith("CG=1>")  # the exact-normal pipeline did run
         for l in range(H.nlev):
             got = dout[l].download()
             assert_valid_bits_equal(got, og[l], [(c, c) for c in range(4)], f"exact grad level {l}")
             assert_valid_bits_equal(got, oc[l], [(4, 2), (5, 3), (6, 4), (7, 1)], f"exact curv level {l}")
+
+
+@pytest.mark.parametrize("per", [(0, 0, 0), (1, 0, 1)])
+def test_gradcurv_exact_normal_pipeline_one_short_tiles(ctx, oracle, per):
+    """fine boxes of 65 x 13 x 21 cells: the sweep's last full tile ends ONE column / row short of the box (64 t + 1 columns,
+    4 t + 1 rows), so its outermost neighbour column / row is the last valid one and the ghost c behind the special face is
+    the cell BEYOND it (mode 2 of the CG variant, pa_fused_march3.h) -- the case a randomly drawn hierarchy exposed"""
+    from peleanalysis_amd.hierarchy import Hierarchy, Level, field_flame
+    l0 = Level(np.array([[0, 0, 0, 79, 23, 31]]), (0, 0, 0), (79, 23, 31), per, (0, 0, 0), (1, 1, 1))
+    fb = [[16 + 65 * a, 10 + 13 * b, 12 + 21 * c, 16 + 65 * a + 64, 10 + 13 * b + 12, 12 + 21 * c + 20] for c in range(2) for b in range(2) for a in range(2)]
+    l1 = Level(np.array(fb), (0, 0, 0), (159, 47, 63), per, (0, 0, 0), (1, 1, 1))
+    H = Hierarchy([l0, l1], 2)
+    states = make_states(H, 1, 2, field_flame, seed=37)
+    bc = capi.bc_from_flags(per, (0, 0, 0))
+    og = [MultiFab(lv, 4, 0) for lv in H.levels]
+    oracle.grad_pipeline(H.levels, [s.copy() for s in states], 0, bc, og, 0, multipass=False)
+    oc = [MultiFab(lv, 5, 0) for lv in H.levels]
+    oracle.curvature_pipeline(H.levels, [s.copy() for s in states], 0, bc, oc, 0, MultiFab)
+    dls, dst = _dev(ctx, H, states)
+    work = [capi.DevMF(ctx, dl, 1, 2) for dl in dls]
+    dout = [capi.DevMF(ctx, dl, 8, 0) for dl in dls]
+    capi.gradcurv_run(ctx, dst, 0, bc, capi.curv_params(fused=True), work, dout, 0)
+    ctx.sync()
+    assert ctx.bc_errors() == 0
+    assert ctx.lib.pa_sweep_kernel_name(ctx.h).decode().endswith("CG=1>")  # the exact-normal pipeline did run
+    for l in range(H.nlev):
+        got = dout[l].download()
+        assert_valid_bits_equal(got, og[l], [(c, c) for c in range(4)], f"one-short grad level {l}")
+        assert_valid_bits_equal(got, oc[l], [(4, 2), (5, 3), (6, 4), (7, 1)], f"one-short curv level {l}")
 
 
 def test_gradcurv_four_levels_many_components(ctx, oracle):

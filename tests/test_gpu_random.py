@@ -176,3 +176,53 @@ def test_random_hierarchy_curvature_options(ctx, oracle, seed):
     assert ctx.bc_errors() == 0
     for l in range(H.nlev):
         assert_valid_bits_equal(dout[l].download(), oout[l], [(c, c) for c in range(17)], f"seed {seed} options level {l}")
+
+
+def _draw_wide(seed):
+    """hierarchies whose boxes are wider than 32 cells (odd widths from uneven chops): the exact-normal pipeline where every
+    special face is pure, the first pipeline where a chop leaves a face half covered"""
+    rng = np.random.default_rng(5000 + seed)
+    n = np.array([int(rng.integers(9, 14)) * 8, int(rng.integers(5, 9)) * 8, int(rng.integers(4, 8)) * 8])
+    per = rng.integers(0, 2, size=3)
+    sym = np.where(per == 1, 0, rng.integers(0, 2, size=3))
+    dom_hi = n - 1
+    levels = [Level(chop_box((0, 0, 0), dom_hi, int(rng.integers(36, 60))), (0, 0, 0), dom_hi, per, np.zeros(3), np.ones(3))]
+    lo, hi = np.zeros(3, dtype=np.int64), dom_hi.astype(np.int64)
+    for l in range(1, 3):
+        ext = hi - lo + 1
+        clo = lo + rng.integers(2, np.maximum(3, ext // 4))
+        chi = hi - rng.integers(2, np.maximum(3, ext // 4))
+        clo[0] = min(clo[0], chi[0] - 20)  # at least 42 fine cells in x
+        if l == 1 and per[1] and rng.random() < 0.5:
+            clo[1] = lo[1]
+        if np.any(chi - clo < 6) or clo[0] < lo[0] + 2:
+            break
+        flo, fhi = 2 * clo, 2 * chi + 1
+        domhi_f = 2 * (np.asarray(levels[-1].domhi) + 1) - 1
+        levels.append(Level(chop_box(flo, fhi, int(rng.integers(40, 72))), (0, 0, 0), domhi_f, per, np.zeros(3), np.ones(3)))
+        lo, hi = flo, fhi
+    return Hierarchy(levels, 2), tuple(int(x) for x in per), tuple(int(x) for x in sym), (field_flame if seed % 2 else field_trig)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PA_RANDOM_WIDE_SEEDS", "6"))))
+def test_random_wide_box_hierarchy_matches_oracle(ctx, oracle, seed):
+    H, per, sym, fn = _draw_wide(seed)
+    assert H.nlev >= 2 and min(int((lv.boxes[:, 3] - lv.boxes[:, 0]).min()) + 1 for lv in H.levels) > 16
+    states = make_states(H, 1, 2, fn, seed=seed)
+    bc = capi.bc_from_flags(per, sym)
+    og = [MultiFab(lv, 4, 0) for lv in H.levels]
+    oracle.grad_pipeline(H.levels, [s.copy() for s in states], 0, bc, og, 0, multipass=False)
+    oc = [MultiFab(lv, 5, 0) for lv in H.levels]
+    oracle.curvature_pipeline(H.levels, [s.copy() for s in states], 0, bc, oc, 0, MultiFab)
+    tag = f"wide seed {seed}: {[tuple(lv.domhi + 1) for lv in H.levels]} per {per} sym {sym} boxes {[(lv.nboxes, int((lv.boxes[:, 3] - lv.boxes[:, 0]).max()) + 1) for lv in H.levels]}"
+    dls = [capi.DevLevel(ctx, lv) for lv in H.levels]
+    dst = [capi.DevMF.from_host(ctx, dl, s) for dl, s in zip(dls, states)]
+    work = [capi.DevMF(ctx, dl, 1, 2) for dl in dls]
+    dout = [capi.DevMF(ctx, dl, 8, 0) for dl in dls]
+    capi.gradcurv_run(ctx, dst, 0, bc, capi.curv_params(fused=True), work, dout, 0)
+    ctx.sync()
+    assert ctx.bc_errors() == 0, tag
+    for l in range(H.nlev):
+        got = dout[l].download()
+        assert_valid_bits_equal(got, og[l], [(c, c) for c in range(4)], f"{tag} grad level {l}")
+        assert_valid_bits_equal(got, oc[l], [(4, 2), (5, 3), (6, 4), (7, 1)], f"{tag} curv level {l}")
