@@ -42,7 +42,11 @@ def _worker(rank, world, port, case):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         per, sym = ((1, 1, 0), (0, 0, 0)) if case != "sym" else ((0, 1, 1), (1, 0, 0))
-        H = nested_hierarchy(16, 3, 8, is_per=per) if case != "wide" else nested_hierarchy(80, 3, 40, is_per=per)  # wide: the exact-normal pipeline
+        if case.startswith("rand"):  # randomly drawn hierarchies (tests/test_gpu_random.py): odd extents, uneven chops, levels with
+            import test_gpu_random as R  # fewer boxes than ranks (some ranks own nothing there), every boundary-condition mix
+            H, per, sym, _fn = (R._draw_wide if case[4] == "w" else R._draw)(int(case[5:] if case[4] == "w" else case[4:]))
+        else:
+            H = nested_hierarchy(16, 3, 8, is_per=per) if case != "wide" else nested_hierarchy(80, 3, 40, is_per=per)  # wide: the exact-normal pipeline
         owners = [scattered_owner(lv.nboxes, world, 31 + l) if case != "sfc" else padist.distribution_map(lv.boxes, world) for l, lv in enumerate(H.levels)]
         rng = np.random.default_rng(99)
         ncomp = 4
@@ -89,10 +93,15 @@ def _worker(rank, world, port, case):
             capi.gradcurv_run(ctx, lst, 0, bc, capi.curv_params(threshold=thr, fused=fused), work, out, 0)
             ctx.sync()
             assert ctx.bc_errors() == 0
-            if fused:  # exchange A for every level at once; B at once (first pipeline) or per fine level under the sweeps (exact-normal)
+            if fused and not case.startswith("rand"):  # exchange A for every level at once; B at once (first pipeline) or per fine level (exact-normal)
                 assert comm.nexchange - n0 == (3 if case == "wide" else 2), "the fused pipeline batches its cross-rank traffic"
             check(out, {0: (og, 0), 1: (og, 1), 2: (og, 2), 3: (og, 3), 4: (oc, 2), 5: (oc, 3), 6: (oc, 4), 7: (oc, 1)}, f"gradcurv fused={fused}")
         # several components at once: exchange A carries all of them, one exchange (B) per component
+        if case.startswith("rand"):
+            H.levels  # the option / multi-component runs below assume the fixed hierarchies' component layout: skip for random draws
+            dist.barrier()
+            ctx.close()
+            return
         out = [capi.DevMF(ctx, dl, 8, 0) for dl in dls]
         seen = {}
 
@@ -129,7 +138,8 @@ def _worker(rank, world, port, case):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,case", [(2, "scatter"), (4, "scatter"), (4, "thr"), (2, "sym"), (4, "sfc"), (4, "wide"), (2, "wide")])
+@pytest.mark.parametrize("world,case", [(2, "scatter"), (4, "scatter"), (4, "thr"), (2, "sym"), (4, "sfc"), (4, "wide"), (2, "wide"), (3, "rand2"), (4, "rand5"),
+                                        (3, "rand11"), (3, "randw1"), (4, "randw4")])
 def test_sharded_hierarchy_on_shared_gpu_matches_undistributed_oracle(world, case):
     import torch.multiprocessing as mp
     mp.spawn(_worker, args=(world, _free_port(), case), nprocs=world, join=True)
