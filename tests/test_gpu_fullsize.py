@@ -25,3 +25,10 @@ def test_headline_size_properties():
     """child process: torch (device-side synthetic data) has to initialise HIP before the library does"""
     r = subprocess.run([sys.executable, os.path.join(HERE, "fullsize_props.py")], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "fullsize properties OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_config5_sharded_equals_undistributed():
+    """BASELINE config 5 (4 levels of 256^3, 64^3 boxes, 55 components) sharded over 4 ranks that share the GPU == undistributed,
+    checksum per box and component (tests/c5_dist_props.py)"""
+    r = subprocess.run([sys.executable, os.path.join(HERE, "c5_dist_props.py")], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0 and "c5 dist properties OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
