@@ -62,6 +62,9 @@ static int sfind(const orc_level* L, const int p[3], int hint) {
   return -1;
 }
 static int sfloor_div(int i, int r) { return (i < 0) ? -((-i + r - 1) / r) : i / r; }
+/* refinement ratio of direction d: the AMREX_SPACEDIM == 2 build is a hierarchy of one-cell-thick planes (k = 0 on every
+ * level), which is not refined in z */
+static int rdir(const orc_level* fine, int d, int ratio) { return (d == 2 && fine->domlo[2] == fine->domhi[2]) ? 1 : ratio; }
 
 /* mask[l] = 1 on valid cells not covered by level l+1, 0 on covered ones (same layout as the vectors) */
 void orc_smooth_mask(const orc_mf* mask, const orc_level* fine /* NULL on the finest level */, int ratio) {
@@ -75,7 +78,7 @@ void orc_smooth_mask(const orc_mf* mask, const orc_level* fine /* NULL on the fi
         for (int i = B.lo[0]; i <= B.hi[0]; ++i) {
           double m = 1.0;
           if (fine) {
-            int p[3] = {i * ratio, j * ratio, k * ratio};
+            int p[3] = {i * ratio, j * ratio, k * rdir(fine, 2, ratio)};
             const int fb = sfind(fine, p, hint);
             if (fb >= 0) { hint = fb; m = 0.0; }
           }
@@ -87,18 +90,19 @@ void orc_smooth_mask(const orc_mf* mask, const orc_level* fine /* NULL on the fi
 /* average_down: coarse cells under a fine box = mean of their ratio^3 children (sum in k,j,i order) */
 void orc_smooth_avgdown(const orc_mf* fine, int fcomp, orc_mf* crse, int ccomp, int ratio) {
   const orc_level *LF = fine->lev, *LC = crse->lev;
-  const double fac = 1.0 / (double)(ratio * ratio * ratio);
+  const int rz = rdir(LF, 2, ratio);
+  const double fac = 1.0 / (double)(ratio * ratio * rz);
 #pragma omp parallel for schedule(dynamic)
   for (int b = 0; b < LF->nboxes; ++b) {
     sbx_t B = sbox(LF, b);
     int hint = -1;
-    for (int kc = sfloor_div(B.lo[2], ratio); kc <= sfloor_div(B.hi[2], ratio); ++kc)
+    for (int kc = sfloor_div(B.lo[2], rz); kc <= sfloor_div(B.hi[2], rz); ++kc)
       for (int jc = sfloor_div(B.lo[1], ratio); jc <= sfloor_div(B.hi[1], ratio); ++jc)
         for (int ic = sfloor_div(B.lo[0], ratio); ic <= sfloor_div(B.hi[0], ratio); ++ic) {
           double c = 0.0;
-          for (int kk = 0; kk < ratio; ++kk)
+          for (int kk = 0; kk < rz; ++kk)
             for (int jj = 0; jj < ratio; ++jj)
-              for (int ii = 0; ii < ratio; ++ii) c += SAT(fine, &B, b, fcomp, ic * ratio + ii, jc * ratio + jj, kc * ratio + kk);
+              for (int ii = 0; ii < ratio; ++ii) c += SAT(fine, &B, b, fcomp, ic * ratio + ii, jc * ratio + jj, kc * rz + kk);
           c *= fac;
           int p[3] = {ic, jc, kc};
           const int cb = sfind(LC, p, hint);
@@ -138,28 +142,29 @@ void orc_smooth_reflux(const orc_mf* xf, int xfc, const orc_mf* xc, int xcc, orc
   double dxf[3], dxc[3];
   orc_dxinv(LF, dxf);
   orc_dxinv(LC, dxc);
-  const double fac = 1.0 / (double)(ratio * ratio);
 #pragma omp parallel for schedule(dynamic)
   for (int b = 0; b < LF->nboxes; ++b) {
     sbx_t B = sbox(LF, b);
     int fh = b, ch = -1;
     for (int dir = 0; dir < 3; ++dir) {
       const int t0 = (dir == 0) ? 1 : 0, t1 = (dir == 2) ? 1 : 2;
+      const int r0 = rdir(LF, t0, ratio), r1 = rdir(LF, t1, ratio), rn = rdir(LF, dir, ratio);
+      const double fac = 1.0 / (double)(r0 * r1);
       for (int side = 0; side < 2; ++side) {
         const int gq = side ? B.hi[dir] + 1 : B.lo[dir] - 1;  /* fine ghost plane */
         const int inq = side ? B.hi[dir] : B.lo[dir];        /* fine cells next to the face */
-        for (int b1 = sfloor_div(B.lo[t1], ratio); b1 <= sfloor_div(B.hi[t1], ratio); ++b1)
-          for (int a0 = sfloor_div(B.lo[t0], ratio); a0 <= sfloor_div(B.hi[t0], ratio); ++a0) {
+        for (int b1 = sfloor_div(B.lo[t1], r1); b1 <= sfloor_div(B.hi[t1], r1); ++b1)
+          for (int a0 = sfloor_div(B.lo[t0], r0); a0 <= sfloor_div(B.hi[t0], r0); ++a0) {
             int q[3];
-            q[dir] = gq; q[t0] = a0 * ratio; q[t1] = b1 * ratio;
+            q[dir] = gq; q[t0] = a0 * r0; q[t1] = b1 * r1;
             int p[3] = {q[0], q[1], q[2]};
             if (!swrap(LF, p)) continue;                 /* physical boundary: no coarse-fine face */
             const int nb = sfind(LF, p, fh);
             if (nb >= 0) continue;                       /* another fine box: interior face */
             /* outside coarse cell (uncovered) and inside coarse cell (covered, holds the average) */
             int oc[3], ic[3];
-            oc[dir] = sfloor_div(gq, ratio); oc[t0] = a0; oc[t1] = b1;
-            ic[dir] = sfloor_div(inq, ratio); ic[t0] = a0; ic[t1] = b1;
+            oc[dir] = sfloor_div(gq, rn); oc[t0] = a0; oc[t1] = b1;
+            ic[dir] = sfloor_div(inq, rn); ic[t0] = a0; ic[t1] = b1;
             int ow[3] = {oc[0], oc[1], oc[2]}, iw[3] = {ic[0], ic[1], ic[2]};
             if (!swrap(LC, ow) || !swrap(LC, iw)) continue;
             const int ob = sfind(LC, ow, ch);
@@ -169,10 +174,10 @@ void orc_smooth_reflux(const orc_mf* xf, int xfc, const orc_mf* xc, int xcc, orc
             if (ib < 0) continue;
             sbx_t OB = sbox(LC, ob), IB = sbox(LC, ib);
             double favg = 0.0;
-            for (int v = 0; v < ratio; ++v)
-              for (int u = 0; u < ratio; ++u) {
+            for (int v = 0; v < r1; ++v)
+              for (int u = 0; u < r0; ++u) {
                 int g[3], in[3];
-                g[dir] = gq; g[t0] = a0 * ratio + u; g[t1] = b1 * ratio + v;
+                g[dir] = gq; g[t0] = a0 * r0 + u; g[t1] = b1 * r1 + v;
                 in[dir] = inq; in[t0] = g[t0]; in[t1] = g[t1];
                 const double xg = SAT(xf, &B, b, xfc, g[0], g[1], g[2]), xi = SAT(xf, &B, b, xfc, in[0], in[1], in[2]);
                 favg += side ? dxf[dir] * (xg - xi) : dxf[dir] * (xi - xg);  /* flux in +dir */

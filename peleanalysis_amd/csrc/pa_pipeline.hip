@@ -459,8 +459,8 @@ extern "C" int pa_curvature_run(pa_ctx* ctx, int nlev, pa_mf* const* state, int 
   const double thr = P->do_threshold ? P->threshold : -1.0;
   // 2-D levels: the strain / normal-velocity options work as they are when the caller supplies a zero third velocity
   // component (their z terms are then exact zeros); Gaussian curvature is 3-D only in the reference (curvature.cpp:208-216)
-  if (P->spacedim == 2 && (P->do_gauss_curv || P->do_smooth))
-    return pa_fail(ctx, "pa_curvature_run: do_gauss_curv / do_smooth are not available for 2-D levels (spacedim = 2)");
+  if (P->spacedim == 2 && P->do_gauss_curv)
+    return pa_fail(ctx, "pa_curvature_run: do_gauss_curv is not available for 2-D levels (spacedim = 2)");
   return curvature_passes(ctx, nlev, state, comp, bc, pmin, pmax, thr, out, ocomp, ocomp + 1, ocomp + 2, P, ocomp, P->spacedim == 2 ? 1.0 : 0.5);
 }
 

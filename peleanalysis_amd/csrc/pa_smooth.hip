@@ -32,6 +32,8 @@ struct BoxIt {  // thread -> cell of box blockIdx.y (grid-stride over the box's 
     k = B.lo[2] + (int)(r / (unsigned)ny);
   }
 };
+// refinement ratio of direction d: a 2-D hierarchy is stored as one plane of cells per level (k = 0), not refined in z
+__device__ __forceinline__ int rdir(const DLevelView& LF, int d, int ratio) { return (d == 2 && LF.domlo[2] == LF.domhi[2]) ? 1 : ratio; }
 #define PA_BOX_LOOP(L)                                                                                                \
   const int b = blockIdx.y;                                                                                            \
   const BoxIt it(L, b);                                                                                                \
@@ -44,7 +46,7 @@ __global__ __launch_bounds__(256) void k_smooth_mask(DLevelView L, DMFView M, DL
     it.cell(t, i, j, k);
     double m = 1.0;
     if (has_fine) {
-      int p[3] = {i * ratio, j * ratio, k * ratio};
+      int p[3] = {i * ratio, j * ratio, k * rdir(LF, 2, ratio)};
       if (owner_of(LF, p) != -1) m = 0.0;
     }
     M.data[M.off[b] + fab_index(it.B, M.ng, M.ncomp, 0, i, j, k)] = m;
@@ -55,17 +57,18 @@ __global__ __launch_bounds__(256) void k_smooth_mask(DLevelView L, DMFView M, DL
 __global__ __launch_bounds__(256) void k_smooth_avgdown(DLevelView LF, DMFView F, DLevelView LC, DMFView Cm, int ratio) {
   const int b = blockIdx.y;
   const DBox B = LF.boxes[b];
-  const int cx = (B.hi[0] - B.lo[0] + 1) / ratio, cy = (B.hi[1] - B.lo[1] + 1) / ratio, cz = (B.hi[2] - B.lo[2] + 1) / ratio;
+  const int rz = rdir(LF, 2, ratio);
+  const int cx = (B.hi[0] - B.lo[0] + 1) / ratio, cy = (B.hi[1] - B.lo[1] + 1) / ratio, cz = (B.hi[2] - B.lo[2] + 1) / rz;
   const long long n = (long long)cx * cy * cz;
-  const double fac = 1.0 / (double)(ratio * ratio * ratio);
+  const double fac = 1.0 / (double)(ratio * ratio * rz);
   const double* f = F.data + F.off[b];
   for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
     const unsigned u = (unsigned)t, r = u / (unsigned)cx;
-    const int ic = coarsen_idx(B.lo[0], ratio) + (int)(u - r * cx), jc = coarsen_idx(B.lo[1], ratio) + (int)(r % cy), kc = coarsen_idx(B.lo[2], ratio) + (int)(r / cy);
+    const int ic = coarsen_idx(B.lo[0], ratio) + (int)(u - r * cx), jc = coarsen_idx(B.lo[1], ratio) + (int)(r % cy), kc = coarsen_idx(B.lo[2], rz) + (int)(r / cy);
     double c = 0.0;
-    for (int kk = 0; kk < ratio; ++kk)
+    for (int kk = 0; kk < rz; ++kk)
       for (int jj = 0; jj < ratio; ++jj)
-        for (int ii = 0; ii < ratio; ++ii) c += f[fab_index(B, F.ng, F.ncomp, 0, ic * ratio + ii, jc * ratio + jj, kc * ratio + kk)];
+        for (int ii = 0; ii < ratio; ++ii) c += f[fab_index(B, F.ng, F.ncomp, 0, ic * ratio + ii, jc * ratio + jj, kc * rz + kk)];
     c *= fac;
     const int p[3] = {ic, jc, kc};
     const int cb = owner_of(LC, p);
@@ -98,18 +101,19 @@ __global__ __launch_bounds__(256) void k_smooth_reflux(DLevelView LF, DMFView XF
   const DBox B = LF.boxes[b];
   const int t0 = (dir == 0) ? 1 : 0, t1 = (dir == 2) ? 1 : 2;
   const int n0 = B.hi[t0] - B.lo[t0] + 1, n1 = B.hi[t1] - B.lo[t1] + 1;
-  const unsigned c0 = n0 / ratio, c1 = n1 / ratio;
+  const int r0 = rdir(LF, t0, ratio), r1 = rdir(LF, t1, ratio), rn = rdir(LF, dir, ratio);
+  const unsigned c0 = n0 / r0, c1 = n1 / r1;
   const long long tt = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (tt >= (long long)c0 * c1) return;
   const unsigned u = (unsigned)tt, r = u / c0;
   const int a0 = (int)(u - r * c0), b1 = (int)r;  // coarse offsets inside the face
   // class of the first child ghost cell: 1 = coarse-fine (a coarse cell is covered entirely or not at all)
-  if ((LF.sfcode[LF.sfoff[blockIdx.y] + (long long)(a0 * ratio) + (long long)n0 * (b1 * ratio)] & 3u) != 1u) return;
+  if ((LF.sfcode[LF.sfoff[blockIdx.y] + (long long)(a0 * r0) + (long long)n0 * (b1 * r1)] & 3u) != 1u) return;
   const int gq = side ? B.hi[dir] + 1 : B.lo[dir] - 1, inq = side ? B.hi[dir] : B.lo[dir];
   int oc[3], ic[3];
-  oc[dir] = coarsen_idx(gq, ratio); ic[dir] = coarsen_idx(inq, ratio);
-  oc[t0] = ic[t0] = coarsen_idx(B.lo[t0], ratio) + a0;
-  oc[t1] = ic[t1] = coarsen_idx(B.lo[t1], ratio) + b1;
+  oc[dir] = coarsen_idx(gq, rn); ic[dir] = coarsen_idx(inq, rn);
+  oc[t0] = ic[t0] = coarsen_idx(B.lo[t0], r0) + a0;
+  oc[t1] = ic[t1] = coarsen_idx(B.lo[t1], r1) + b1;
   int ow[3] = {oc[0], oc[1], oc[2]}, iw[3] = {ic[0], ic[1], ic[2]};
   if (!wrap_cell(LC, ow) || !wrap_cell(LC, iw)) return;
   const int ob = owner_of(LC, ow), ib = owner_of(LC, iw);
@@ -117,16 +121,16 @@ __global__ __launch_bounds__(256) void k_smooth_reflux(DLevelView LF, DMFView XF
   const double* xf = XF.data + XF.off[b];
   const double dxf = LF.dxinv[dir], dxc = LC.dxinv[dir];
   double favg = 0.0;
-  for (int v = 0; v < ratio; ++v)
-    for (int uu = 0; uu < ratio; ++uu) {
+  for (int v = 0; v < r1; ++v)
+    for (int uu = 0; uu < r0; ++uu) {
       int g[3], in[3];
       g[dir] = gq; in[dir] = inq;
-      g[t0] = in[t0] = B.lo[t0] + a0 * ratio + uu;
-      g[t1] = in[t1] = B.lo[t1] + b1 * ratio + v;
+      g[t0] = in[t0] = B.lo[t0] + a0 * r0 + uu;
+      g[t1] = in[t1] = B.lo[t1] + b1 * r1 + v;
       const double xg = xf[fab_index(B, XF.ng, XF.ncomp, 0, g[0], g[1], g[2])], xi = xf[fab_index(B, XF.ng, XF.ncomp, 0, in[0], in[1], in[2])];
       favg += side ? dxf * (xg - xi) : dxf * (xi - xg);
     }
-  favg *= 1.0 / (double)(ratio * ratio);
+  favg *= 1.0 / (double)(r0 * r1);
   const double xo = XC.data[XC.off[ob] + fab_index(LC.boxes[ob], XC.ng, XC.ncomp, 0, ow[0], ow[1], ow[2])];
   const double xin = XC.data[XC.off[ib] + fab_index(LC.boxes[ib], XC.ng, XC.ncomp, 0, iw[0], iw[1], iw[2])];
   const double fc = side ? dxc * (xo - xin) : dxc * (xin - xo);
@@ -235,7 +239,7 @@ struct SmoothSolver {
     for (int l = nlev - 1; l > 0; --l) {
       const pa_level* LF = lev[l];
       if (LF->sfaces.empty()) continue;
-      const long long nf = std::max((long long)LF->maxn[1] * LF->maxn[2], std::max((long long)LF->maxn[0] * LF->maxn[2], (long long)LF->maxn[0] * LF->maxn[1])) / (ratio * ratio);
+      const long long nf = std::max((long long)LF->maxn[1] * LF->maxn[2], std::max((long long)LF->maxn[0] * LF->maxn[2], (long long)LF->maxn[0] * LF->maxn[1])) / ratio;  // >= coarse faces per fine face (2-D planes: not refined in z)
       hipLaunchKernelGGL(k_smooth_reflux, dim3((unsigned)((nf + 255) / 256), (unsigned)LF->sfaces.size()), dim3(256), 0, ctx->stream, LF->view, X.v[l]->view,
                          lev[l - 1]->view, X.v[l - 1]->view, Y.v[l - 1]->view, dt, ratio);
     }
@@ -286,8 +290,10 @@ extern "C" int pa_smooth_solve(pa_ctx* ctx, int nlev, pa_mf* const* rhs, int rco
     S.lev.push_back(rhs[l]->lev);
     if (l > 0)
       for (const DBox& B : S.lev[l]->boxes)
-        for (int d = 0; d < 3; ++d)
+        for (int d = 0; d < 3; ++d) {
+          if (d == 2 && S.lev[l]->domlo[2] == S.lev[l]->domhi[2]) continue;  // 2-D hierarchy: one plane per level, not refined in z
           if ((B.lo[d] & 1) || !((B.hi[d] - B.lo[d]) & 1)) return pa_fail(ctx, "pa_smooth_solve: fine boxes must be aligned to the refinement ratio 2");
+        }
   }
   if (S.alloc(S.r) || S.alloc(S.rh) || S.alloc(S.p) || S.alloc(S.v) || S.alloc(S.s) || S.alloc(S.t) || S.alloc(S.mask)) return 1;
   Vecs x;  // the solution as a 1-comp vector (sol may have other components / ghost widths)

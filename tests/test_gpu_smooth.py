@@ -91,6 +91,55 @@ def test_curvature_run_with_smoothing(ctx, oracle, per, sym):
                 assert np.abs((gv[c] - wv[c]) * strong).max() <= 1e-5 * scale, (l, b, c)
 
 
+def _hier2d(per):
+    from peleanalysis_amd.hierarchy import Hierarchy
+    per3 = np.array([per[0], per[1], 0])
+    l0 = Level(chop_box((0, 0, 0), (31, 31, 0), 16), (0, 0, 0), (31, 31, 0), per3, np.zeros(3), np.ones(3))
+    l1 = Level(chop_box((16, 16, 0), (47, 47, 0), 16), (0, 0, 0), (63, 63, 0), per3, np.zeros(3), np.ones(3))
+    return Hierarchy([l0, l1], 2)
+
+
+@pytest.mark.parametrize("per", [(1, 0), (0, 0)])
+def test_smooth_2d_composite_matches_oracle(ctx, oracle, per):
+    """the AMREX_SPACEDIM == 2 build of do_smooth: one plane of cells per level, refined in x and y only (covered blocks
+    of 2 x 2, two fine faces per coarse face in the reflux), z a Neumann wall"""
+    H = _hier2d(per)
+    rhs = []
+    for lv in H.levels:
+        m = MultiFab(lv, 1, 0)
+        fill_analytic(m, 0, lambda x, y, z: 0.5 * (1.0 + np.tanh((np.hypot(x - 0.5, (y - 0.5) / 0.8) - 0.27) / 0.06)) + 0 * z)
+        rhs.append(m)
+    bc = capi.bc_from_flags((per[0], per[1], 0))
+    dt = 4e-4
+    want, oit, ores = oracle.smooth_solve(H.levels, rhs, 0, dt, bc, MultiFab, tol=1e-14)
+    got, it, res = _solve_gpu(ctx, H.levels, rhs, dt, bc, 1e-14)
+    assert 0 < it < 100 and res <= 1e-14 and abs(it - oit) <= 3
+    for l, lv in enumerate(H.levels):
+        for b in range(lv.nboxes):
+            assert np.abs(got[l].valid(b)[0] - want[l].valid(b)[0]).max() <= 1e-12, (l, b)
+    x = [MultiFab(lv, 1, 1) for lv in H.levels]
+    for l, lv in enumerate(H.levels):
+        for b in range(lv.nboxes):
+            x[l].valid(b)[0] = got[l].valid(b)[0]
+    y, mask = oracle.smooth_apply(H.levels, x, dt, bc, MultiFab)
+    r = max(float(np.abs((y[l].valid(b)[0] - rhs[l].valid(b)[0]) * mask[l].valid(b)[0]).max()) for l, lv in enumerate(H.levels) for b in range(lv.nboxes))
+    assert r <= 1e-12
+
+
+def test_smooth_2d_single_level_eigenmode(ctx):
+    n = 64
+    lv = Level(chop_box((0, 0, 0), (n - 1, n - 1, 0), 32), (0, 0, 0), (n - 1, n - 1, 0), (1, 1, 0), (0, 0, 0), (1, 1, 1))
+    rhs = MultiFab(lv, 1, 0)
+    kx, ky = 3, 5
+    fill_analytic(rhs, 0, lambda x, y, z: 0.5 + 0.25 * np.sin(2 * np.pi * kx * x + 0.1) * np.cos(2 * np.pi * ky * y) + 0 * z)
+    dt, h = 5e-4, 1.0 / n
+    sol, it, res = _solve_gpu(ctx, [lv], [rhs], dt, capi.bc_from_flags((1, 1, 0)), 1e-14)
+    assert 0 < it < 60 and res <= 1e-14
+    lam = sum((2 - 2 * np.cos(2 * np.pi * k * h)) / h ** 2 for k in (kx, ky))
+    for b in range(lv.nboxes):
+        assert np.abs(sol[0].valid(b)[0] - (0.5 + (rhs.valid(b)[0] - 0.5) / (1 + dt * lam))).max() < 1e-13
+
+
 def test_smooth_and_stream_reject_bad_input(ctx):
     """host-side shape checks before any kernel runs: misaligned fine boxes, component ranges, ghost widths"""
     import ctypes as C

@@ -90,3 +90,72 @@ def test_composite_solve_reaches_tolerance(oracle):
                 FB = H.levels[1].boxes[fb]
                 blk = sol[1].valid(fb)[0][f[2] - FB[2]:f[2] - FB[2] + 2, f[1] - FB[1]:f[1] - FB[1] + 2, f[0] - FB[0]:f[0] - FB[0] + 2]
                 assert abs(v[k - B[2], j - B[1], i - B[0]] - blk.mean()) < 1e-15
+
+
+def _hier2d(per):
+    from peleanalysis_amd.hierarchy import Hierarchy
+    per3 = np.array([per[0], per[1], 0])
+    l0 = Level(chop_box((0, 0, 0), (31, 31, 0), 16), (0, 0, 0), (31, 31, 0), per3, np.zeros(3), np.ones(3))
+    l1 = Level(chop_box((16, 16, 0), (47, 47, 0), 16), (0, 0, 0), (63, 63, 0), per3, np.zeros(3), np.ones(3))
+    return Hierarchy([l0, l1], 2)
+
+
+def test_2d_single_level_periodic_eigenmode(oracle):
+    """the AMREX_SPACEDIM == 2 build: one plane of cells, z a Neumann wall -> the operator is the 5-point one and a 2-D
+    Fourier mode is its eigenfunction with the 2-D eigenvalue (no z term)"""
+    n = 32
+    lv = Level(chop_box((0, 0, 0), (n - 1, n - 1, 0), 16), (0, 0, 0), (n - 1, n - 1, 0), (1, 1, 0), (0, 0, 0), (1, 1, 1))
+    rhs = MultiFab(lv, 1, 0)
+    kx, ky = 3, 2
+    fill_analytic(rhs, 0, lambda x, y, z: 0.5 + 0.25 * np.sin(2 * np.pi * kx * x + 0.1) * np.cos(2 * np.pi * ky * y) + 0 * z)
+    dt, h = 1e-3, 1.0 / n
+    sol, it, res = oracle.smooth_solve([lv], [rhs], 0, dt, oracle.bc_from_flags((1, 1, 0)), MultiFab, tol=1e-14)
+    assert 0 < it < 60 and res <= 1e-14
+    lam = sum((2 - 2 * np.cos(2 * np.pi * k * h)) / h ** 2 for k in (kx, ky))
+    for b in range(lv.nboxes):
+        want = 0.5 + (rhs.valid(b)[0] - 0.5) / (1 + dt * lam)
+        assert np.abs(sol[0].valid(b)[0] - want).max() < 1e-13
+
+
+def test_2d_composite_conserves_and_averages(oracle):
+    """2-D hierarchy (refined in x and y only): covered cells are the 2 x 2 child blocks, the refluxed operator conserves
+    the integral for any x, and after the solve the covered coarse cells hold the mean of their FOUR children"""
+    for per in ((1, 0), (0, 0)):
+        H = _hier2d(per)
+        rng = np.random.default_rng(5)
+        x = []
+        for lv in H.levels:
+            m = MultiFab(lv, 1, 1)
+            for b in range(lv.nboxes):
+                m.valid(b)[0] = rng.random(m.valid(b)[0].shape)
+            x.append(m)
+        bc = oracle.bc_from_flags((per[0], per[1], 0))
+        dt = 4e-4
+        y, mask = oracle.smooth_apply(H.levels, x, dt, bc, MultiFab)
+        ncov = 32 * 32 - sum(float(mask[0].valid(b)[0].sum()) for b in range(H.levels[0].nboxes))
+        assert abs(ncov - 16 * 16) < 0.5  # 32 x 32 fine cells cover 16 x 16 coarse ones (ratio 1 in z)
+        sx, sy = _composite_sum(H.levels, x, mask), _composite_sum(H.levels, y, mask)
+        assert abs(sx) > 0.1 and abs(sy - sx) < 1e-13 * abs(sx)
+        rhs = []
+        for lv in H.levels:
+            m = MultiFab(lv, 1, 0)
+            fill_analytic(m, 0, lambda x, y, z: 0.5 * (1.0 + np.tanh((np.hypot(x - 0.5, (y - 0.5) / 0.8) - 0.27) / 0.06)) + 0 * z)
+            rhs.append(m)
+        sol, it, res = oracle.smooth_solve(H.levels, rhs, 0, dt, bc, MultiFab, tol=1e-13)
+        assert 0 < it < 100 and res <= 1e-13
+        assert abs(_composite_sum(H.levels, sol, mask) - _composite_sum(H.levels, rhs, mask)) < 1e-12
+        xs = [MultiFab(lv, 1, 1, s.data.copy()) for lv, s in zip(H.levels, sol)]
+        ys, _ = oracle.smooth_apply(H.levels, xs, dt, bc, MultiFab)
+        r = max(float(np.abs((ys[l].valid(b)[0] - rhs[l].valid(b)[0]) * mask[l].valid(b)[0]).max()) for l, lv in enumerate(H.levels) for b in range(lv.nboxes))
+        assert r <= 2e-12
+        fine = np.zeros((64, 64))
+        for b in range(H.levels[1].nboxes):
+            B = H.levels[1].boxes[b]
+            fine[B[1]:B[4] + 1, B[0]:B[3] + 1] = sol[1].valid(b)[0][0]
+        for b in range(H.levels[0].nboxes):
+            B = H.levels[0].boxes[b]
+            v, k = sol[0].valid(b)[0][0], mask[0].valid(b)[0][0]
+            for j in range(B[1], B[4] + 1):
+                for i in range(B[0], B[3] + 1):
+                    if k[j - B[1], i - B[0]] == 0.0:
+                        assert abs(v[j - B[1], i - B[0]] - fine[2 * j:2 * j + 2, 2 * i:2 * i + 2].mean()) < 1e-15

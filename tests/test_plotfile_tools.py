@@ -609,7 +609,21 @@ def test_grad2d_and_curvature2d_tools(tmp_path, oracle, per):
                 assert np.array_equal(np.ascontiguousarray(got[gc]).view(np.int64), np.ascontiguousarray(want[wc]).view(np.int64)), (l, b, gc)
             nz += int((got[4] != 0).sum())
     assert nz > 200
-    bad = subprocess.run([os.path.join(BIN, "curvature2d.ex"), "infile=" + p, "progressName=temp", "do_smooth=1"], cwd=tmp_path, capture_output=True, text=True)
+    # do_smooth in the 2-D build: SmoothedProgress from the composite solve on the planes, curvature from the smoothed field
+    _run("curvature2d.ex", ["infile=" + p, "progressName=temp", "is_per=%d %d" % per, "do_smooth=1", "smoothing_time=4e-4", "outfile=" + str(tmp_path / "plt2_KS")], tmp_path)
+    ks = read_plotfile(str(tmp_path / "plt2_KS"))
+    assert ks.names == ["temp", "Progress", "SmoothedProgress", "MeanCurvature_temp", "FlameNormalX_temp", "FlameNormalY_temp"]
+    ocs = [MultiFab(lv, 18, 0) for lv in H.levels]  # comp 17 = SmoothedProgress
+    oracle.curvature_pipeline(H.levels, [o.copy() for o in ost], 0, bc, ocs, 0, MultiFab, do_smooth=True, smoothing_time=4e-4, smooth_tol=1e-14, spacedim=2)
+    for l, lv in enumerate(H.levels):
+        for b in range(lv.nboxes):
+            got, want = ks.mfs[l].valid(b), ocs[l].valid(b)
+            assert np.array_equal(np.ascontiguousarray(got[1]).view(np.int64), np.ascontiguousarray(want[0]).view(np.int64))
+            assert np.abs(got[2] - want[17]).max() <= 1e-12 and not np.array_equal(got[2], got[1])
+            strong = np.abs(want[17] - 0.5) < 0.45
+            for gc, wc in ((3, 1), (4, 2), (5, 3)):
+                assert np.abs((got[gc] - want[wc]) * strong).max() <= 1e-5 * max(np.abs(want[wc]).max(), 1.0), (l, b, gc)
+    bad = subprocess.run([os.path.join(BIN, "curvature2d.ex"), "infile=" + p, "progressName=temp", "do_gaussCurv=1"], cwd=tmp_path, capture_output=True, text=True)
     assert bad.returncode != 0 and "2-D build" in bad.stderr
 
 

@@ -17,7 +17,7 @@
 // FlameNormalX/Y_<v>] (no Gaussian curvature in 2-D, curvature.cpp:208-226), MeanCurvature = d(nx)/dx + d(ny)/dy without
 // the 0.5 of the 3-D build (:542-546).  The level is one plane of cells with z a homogeneous-Neumann wall
 // (pa_curv_params.spacedim = 2); do_strain / getStrainTensor (2 x 2) / do_velnormal work through a zero third velocity
-// component on the device; do_gaussCurv (3-D only in the reference) and do_smooth are not available in this build.
+// component on the device; do_gaussCurv (3-D only in the reference) is not available in this build; do_smooth solves on the planes (not refined in z).
 #include "../common/pa_team.h"
 #ifndef PA_SPACEDIM
 #define PA_SPACEDIM 3
@@ -59,7 +59,7 @@ int main(int argc, char** argv) {
   pa::PhaseTimer tm(pp, PA_SPACEDIM == 2 ? "curvature2d" : "curvature3d");
   pa::PlotfileHeader H = pa::read_header(infile, PA_SPACEDIM);
 #if PA_SPACEDIM == 2
-  if (do_gaussCurv || do_smooth) pa::Abort("do_gaussCurv / do_smooth are not available in the 2-D build");
+  if (do_gaussCurv) pa::Abort("do_gaussCurv is not available in the 2-D build");  // 3-D only in the reference too (curvature.cpp:208-216)
 #endif
   finestLevel = std::min(finestLevel, H.nlev - 1);
   const int Nlev = finestLevel + 1;
