@@ -42,6 +42,7 @@ extern "C" void pa_ctx_destroy(pa_ctx* ctx) {
   if (ctx->d_red) (void)hipFree(ctx->d_red);
   if (ctx->d_flags) (void)hipFree(ctx->d_flags);
   if (ctx->d_scr) (void)hipFree(ctx->d_scr);
+  for (auto& c : ctx->surf_cache) (void)hipFree(c.first);
   for (auto& e : ctx->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (auto& e : ctx->sync_evs) (void)hipEventDestroy(e);
   if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
@@ -930,8 +931,16 @@ extern "C" void* pa_device_malloc(pa_ctx* ctx, int64_t bytes) {
 }
 extern "C" void pa_device_free(pa_ctx* ctx, void* p) {
   PaBind bind_(ctx);
-  (void)ctx;
-  if (p) (void)hipFree(p);
+  if (!p) return;
+  if (ctx) {
+    auto it = ctx->surf_live.find(p);
+    if (it != ctx->surf_live.end()) {  // a surface of pa_mc_level*: keep the block for the next one
+      const size_t bytes = it->second;
+      ctx->surf_live.erase(it);
+      if (ctx->surf_cache.size() < 4) { ctx->surf_cache.emplace_back(p, bytes); return; }
+    }
+  }
+  (void)hipFree(p);
 }
 extern "C" int pa_memcpy_h2d(pa_ctx* ctx, void* dst, const void* src, int64_t bytes) {
   PaBind bind_(ctx);

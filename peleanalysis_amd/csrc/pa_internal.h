@@ -71,6 +71,10 @@ struct pa_ctx {
   int* d_flags = nullptr;   // [0] = coarse-fine ghost cells whose coarse data was missing
   void* d_scr = nullptr;    // grow-only scratch (marching cubes)
   size_t scr_cap = 0;
+  // surface blocks handed out by pa_mc_level* / taken back by pa_device_free: a freed block is kept (up to 4 of them) for
+  // the next level's surface instead of a hipFree + hipMalloc pair per level (~0.1 ms, as long as the whole GPU pass)
+  std::map<void*, size_t> surf_live;
+  std::vector<std::pair<void*, size_t>> surf_cache;
   // optional per-launch timing of tagged kernels with HIP events on ctx->stream (bench.py roofline)
   unsigned profile = 0;  // bit t set: launches under tag t are timed (pa_profile_enable)
   struct Ev { hipEvent_t a, b; int tag; };

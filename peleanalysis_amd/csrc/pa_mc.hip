@@ -380,6 +380,7 @@ struct MclArgs {
   DLevelView L;
   DMFView S, M;
   int mcomp, isocomp, ncomp, kseg;
+  int rows, nslab, tiles, ldsw;  // k_mcl_cells4: rows of a slab (multiple of 4), slabs / tiles of the largest FAB, LDS dwords per parity
   int nomask, has_fine, ratio;  // nomask: no mask multifab -- a cell is masked iff the next finer level LF covers it
   DLevelView LF;
   int dim2;                // marching squares on the plane k = loops[b].lo[2] (isosurface.cpp:303-406), see below
@@ -557,6 +558,187 @@ __global__ __launch_bounds__(64 * TY) void k_mcl_cells(MclArgs A) {
   if (k1 + 1 >= nz) emit(k1, 0, false);  // top plane of the FAB: no cube, no z edge
 }
 
+// Cell pass, second form (the default).  What the first form above pays for (PMC: 3.64 GB fetched for 2.25 GB of cells):
+// its 63-column tiles cut every 130-cell row into three pieces on 8-byte offsets, so most 128-byte lines are fetched by
+// two workgroups that sit on different XCDs (different L2s), one row in eight is read twice, and 45 % of the lanes
+// idle.  A plane of a FAB is CONTIGUOUS in memory, so here a workgroup owns a slab of whole rows [j0, j0 + rows) and
+// walks it as a flat array: lane-contiguous 32-byte loads (4 consecutive cells per thread), one halo row per slab, the
+// only partial lines are the two ends of the slab.  The 4 cells of a thread are handled as 4 bytes of one register
+// (flags, cube nibbles, candidate bits, cube index: all byte-parallel), neighbours come through LDS as dwords (the
+// row above by a funnel shift, its offset q + nx has any alignment), and both result bytes of 4 cells leave as one dword
+// each when the FAB's scratch offsets are 4-aligned (nx ny and j0 nx multiples of 4; else byte stores).  Slabs that
+// share a halo row, and z segments that share a plane, are neighbours in a numbering that keeps them on one XCD.
+// The values of cells whose right / upper neighbour does not exist are never used: such cells are outside every loop
+// box (mc_level_impl checks loop hi + 1 <= FAB hi), so their cube index is forced to 0 and their x / y bits are masked.
+template <int NT, int GPT, int MM>  // MM: 0 mask multifab, 1 no mask and no finer level, 2 mask = covered by the finer level LF
+__global__ __launch_bounds__(NT) void k_mcl_cells4(MclArgs A) {
+  extern __shared__ unsigned s_fl[];  // [2][A.ldsw]: one flag byte per cell of the slab + halo row, by plane parity
+  const unsigned total = (unsigned)A.L.nboxes * (unsigned)A.tiles, chunk = (total + 7u) / 8u;
+  const unsigned wg = (blockIdx.x & 7u) * chunk + (blockIdx.x >> 3);  // XCD x of 8 works through one contiguous run of tiles
+  if (wg >= total) return;
+  const int b = (int)(wg / (unsigned)A.tiles), tile = (int)(wg - (unsigned)b * (unsigned)A.tiles);
+  MclGeo G;
+  if (!mcl_geo(A, b, G)) return;
+  const int nx = G.n[0], ny = G.n[1], nz = G.n[2];
+  const int slab = tile % A.nslab, tz = tile / A.nslab;
+  const int j0 = slab * A.rows, k0 = tz * A.kseg;
+  if (j0 >= ny || k0 >= nz) return;  // uniform
+  const int own = min(A.rows, ny - j0), halo = j0 + own < ny ? 1 : 0;
+  const int len_own = own * nx, len_all = (own + halo) * nx;
+  const int k1 = min(k0 + A.kseg, nz) - 1, klast = min(k1 + 1, nz - 1);
+  const long long nxy = (long long)nx * ny;
+  const long long cs = pa_cstride((long long)G.ncell, A.S.ncomp), cm = MM ? 0 : pa_cstride((long long)G.ncell, A.M.ncomp);
+  const double* sp = A.S.data + A.S.off[b] + (long long)A.isocomp * cs + (long long)j0 * nx;
+  const double* mp = MM ? sp : A.M.data + A.M.off[b] + (long long)A.mcomp * cm + (long long)j0 * nx;
+  const double iso = A.iso;
+  const bool al4 = (nxy & 3) == 0 && (((long long)j0 * nx) & 3) == 0;
+  const long long g0 = A.coff[b] + (long long)j0 * nx;
+  const int t = threadIdx.x;
+  constexpr unsigned M1 = 0x01010101u;
+  // per group of 4 cells: byte masks (bit 0 of byte e = cell q + e)
+  unsigned XM[GPT], YM[GPT], OKM[GPT], OWN[GPT];
+#pragma unroll
+  for (int g = 0; g < GPT; ++g) {
+    const int q = 4 * (t + NT * g);
+    int r = q / nx, c = q - r * nx;
+    unsigned xm = 0, ym = 0, okm = 0, ow = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (q + e < len_own) {
+        const int i = c, j = j0 + r;
+        const bool xin = i + 1 < nx, yin = j + 1 < ny;
+        const bool okxy = xin && yin && i + G.slo[0] >= G.llo[0] && i + G.slo[0] <= G.lhi[0] && j + G.slo[1] >= G.llo[1] && j + G.slo[1] <= G.lhi[1];
+        ow |= 1u << (8 * e);
+        xm |= (xin ? 1u : 0u) << (8 * e);
+        ym |= (yin ? 1u : 0u) << (8 * e);
+        okm |= (okxy ? 1u : 0u) << (8 * e);
+      }
+      if (++c == nx) { c = 0; ++r; }
+    }
+    XM[g] = xm; YM[g] = ym; OKM[g] = okm; OWN[g] = ow;
+  }
+  // ONE set of value registers: the loads of plane kp + 1 are issued when plane kp's values have been turned into flag
+  // bytes, and fly while plane kp goes through LDS and plane kp - 1 is stored
+  double vs[GPT][4], vm[GPT][4];
+  auto load_plane = [&](int kp) {
+    const long long o = (long long)min(kp, nz - 1) * nxy;
+#pragma unroll
+    for (int g = 0; g < GPT; ++g) {
+      const int q = 4 * (t + NT * g);
+      if (q + 4 <= len_all) {
+        typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+        const d2u a = *(const d2u*)(sp + o + q), c = *(const d2u*)(sp + o + q + 2);
+        vs[g][0] = a.x; vs[g][1] = a.y; vs[g][2] = c.x; vs[g][3] = c.y;
+        if (MM == 0) {
+          const d2u ma = *(const d2u*)(mp + o + q), mc = *(const d2u*)(mp + o + q + 2);
+          vm[g][0] = ma.x; vm[g][1] = ma.y; vm[g][2] = mc.x; vm[g][3] = mc.y;
+        }
+      } else {  // the slab's last, partial group; groups past the slab re-read its last cell
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int qe = min(q + e, len_all - 1);
+          vs[g][e] = sp[o + qe];
+          if (MM == 0) vm[g][e] = mp[o + qe];
+        }
+      }
+    }
+  };
+  auto flags_of = [&](int kp, unsigned (&F)[GPT]) {
+#pragma unroll
+    for (int g = 0; g < GPT; ++g) {
+      unsigned f = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) f |= ((vs[g][e] < iso ? 1u : 0u) | ((MM == 0 && vm[g][e] < 0.0) ? 2u : 0u)) << (8 * e);
+      if (MM == 2) {  // isosurface.cpp:1540-1563 evaluated in place: masked where the refined cell has an owner on the finer level
+        const int q = 4 * (t + NT * g), kc = min(kp, nz - 1);
+        int r = q / nx, c = q - r * nx;
+#pragma unroll 1
+        for (int e = 0; e < 4; ++e) {
+          if (q + e < len_all) {
+            int p[3] = {(G.slo[0] + c) * A.ratio, (G.slo[1] + j0 + r) * A.ratio, (G.slo[2] + kc) * A.ratio};
+            if (wrap_cell(A.LF, p) && owner_of(A.LF, p) != -1) f |= 2u << (8 * e);
+          }
+          if (++c == nx) { c = 0; ++r; }
+        }
+      }
+      F[g] = f;
+    }
+  };
+  unsigned cur[GPT], F[GPT];
+#pragma unroll
+  for (int g = 0; g < GPT; ++g) cur[g] = 0;
+  int par = 0;
+  const unsigned actmask = A.dim2 ? 0x07070707u : 0x7F7F7F7Fu;
+  auto emit = [&](int k, int g, unsigned cu, unsigned up, bool up_in) {  // cells of group g on plane k: cu = their plane, up = the plane above
+    if (OWN[g] == 0) return;
+    const int kk = k + G.slo[2];
+    const bool kz = kk >= G.llo[2] && kk <= G.lhi[2];
+    unsigned X = (cu ^ (cu >> 1)) & XM[g], Y = (cu ^ (cu >> 3)) & YM[g], Z, bad, ci;
+    if (A.dim2) {  // squares of the plane k = llo[2] only; no z edges, no upper corners; Segmentise bails if a corner is masked (:326-327)
+      if (kk != G.llo[2]) X = Y = 0;
+      Z = 0;
+      bad = cu & 0xF0F0F0F0u;
+      ci = cu & 0x0F0F0F0Fu;
+    } else {  // Polygonise bails if any corner is masked (:436-438)
+      Z = up_in ? ((cu ^ up) & M1) : 0u;
+      bad = (cu | up) & 0xF0F0F0F0u;
+      ci = (cu & 0x0F0F0F0Fu) | ((up & 0x0F0F0F0Fu) << 4);
+    }
+    unsigned tt = bad >> 4;
+    tt |= tt >> 1;
+    tt |= tt >> 2;
+    const unsigned okm = kz ? (~tt & OKM[g]) : 0u;
+    ci &= okm * 0xFFu;
+    const unsigned lc = okm | (X << 1) | (Y << 2) | (Z << 3);
+    const unsigned act = (((X | Y | Z) * 0xFFu) | ((ci ^ (ci >> 1)) & actmask)) & (OWN[g] * 0xFFu);
+    const long long gi = g0 + (unsigned long long)k * (unsigned long long)nxy + 4 * (t + NT * g);
+    if (al4 && OWN[g] == M1) {
+      *(unsigned*)(A.lc + gi) = lc;
+      *(unsigned*)(A.cidx + gi) = ci;
+      if (act) A.bact[gi >> 8] = 1;  // same value from every writer
+    } else {
+#pragma unroll 1
+      for (int e = 0; e < 4; ++e)
+        if ((OWN[g] >> (8 * e)) & 1u) {
+          A.lc[gi + e] = (unsigned char)(lc >> (8 * e));
+          A.cidx[gi + e] = (unsigned char)(ci >> (8 * e));
+          if ((act >> (8 * e)) & 0xFFu) A.bact[(gi + e) >> 8] = 1;
+        }
+    }
+  };
+  load_plane(k0);
+  for (int kp = k0; kp <= klast; ++kp) {
+    flags_of(kp, F);  // waits for plane kp
+    if (kp < klast) load_plane(kp + 1);
+    unsigned* sf = s_fl + par * A.ldsw;
+#pragma unroll
+    for (int g = 0; g < GPT; ++g)
+      if (4 * (t + NT * g) < len_all) sf[t + NT * g] = F[g];
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < GPT; ++g) {
+      if (OWN[g] == 0) continue;
+      const int qa = 4 * (t + NT * g) + nx;
+      const unsigned nxt = sf[t + NT * g + 1];
+      const unsigned F1 = (F[g] >> 8) | (nxt << 24);
+      const unsigned lo = sf[qa >> 2], hi = sf[(qa >> 2) + 1];
+      const int sh = (qa & 3) * 8;
+      const unsigned long long W = (unsigned long long)lo | ((unsigned long long)hi << 32);
+      const unsigned F3 = (unsigned)(W >> sh);
+      const unsigned F2 = (unsigned)(W >> (sh + 8));  // bytes qa + 1 .. qa + 4 (sh + 8 <= 32)
+      const unsigned N = (F[g] & M1) | ((F1 & M1) << 1) | ((F2 & M1) << 2) | ((F3 & M1) << 3) | ((F[g] & (M1 << 1)) << 3) | ((F1 & (M1 << 1)) << 4) |
+                         ((F2 & (M1 << 1)) << 5) | ((F3 & (M1 << 1)) << 6);
+      if (kp > k0) emit(kp - 1, g, cur[g], N, true);
+      cur[g] = N;
+    }
+    par ^= 1;
+  }
+  if (k1 + 1 >= nz) {
+#pragma unroll
+    for (int g = 0; g < GPT; ++g) emit(k1, g, cur[g], 0u, false);  // top plane of the FAB: no cube, no z edge
+  }
+}
+
 // FAB of a scratch block: last b with coff[b] <= first cell of the block
 __device__ __forceinline__ int mcl_box_of(const MclArgs& A, long long cell0) {
   int lo = 0, hi = A.L.nboxes - 1;
@@ -566,44 +748,77 @@ __device__ __forceinline__ int mcl_box_of(const MclArgs& A, long long cell0) {
   }
   return lo;
 }
-// list of the marked blocks as (block, FAB) pairs (order irrelevant: every block is processed on its own)
+// list of the marked blocks as (block, FAB) pairs (order irrelevant: every block is processed on its own); one atomic per wave
 __global__ __launch_bounds__(256) void k_mcl_active(MclArgs A, int nblk) {
   const int q = blockIdx.x * 256 + threadIdx.x;
-  if (q < nblk && A.bact[q]) {
-    const int slot = atomicAdd(A.nact, 1);
+  const bool on = q < nblk && A.bact[q];
+  const unsigned long long m = __ballot(on);
+  if (!m) return;
+  int base = 0;
+  const int lane = threadIdx.x & 63;
+  if (lane == 0) base = atomicAdd(A.nact, __popcll(m));
+  base = __shfl(base, 0);
+  if (on) {
+    const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
     A.alist[2 * slot] = q;
     A.alist[2 * slot + 1] = mcl_box_of(A, 256LL * q);
   }
 }
 
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ int wave_excl(int v, int lane) {  // exclusive prefix over the lanes of a wave
+  int x = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int y = __shfl_up(x, o);
+    if (lane >= o) x += y;
+  }
+  return x - v;
+}
+
+// A marked 256-cell block is one WAVE's work: lane l holds cells 4 l .. 4 l + 3 (their lc / cidx bytes are one dword each),
+// sums and prefixes are wave shuffles -- no LDS, no barrier.  (As one workgroup per block, with two barriers per block,
+// these two kernels took 0.145 + 0.131 ms on ~1.3e5 marked blocks.)
 __global__ __launch_bounds__(256) void k_mcl_count(MclArgs A) {
-  const int nact = *A.nact;
-  for (int q = blockIdx.x; q < nact; q += gridDim.x) {  // marked blocks only (bsum of the others was zeroed)
+  const int nact = *A.nact, lane = threadIdx.x & 63;
+  const int nwave = gridDim.x * 4;
+  for (int q = blockIdx.x * 4 + (threadIdx.x >> 6); q < nact; q += nwave) {  // marked blocks only (bsum of the others was zeroed)
     const long long blk = A.alist[2 * q];
     const int b = A.alist[2 * q + 1];
     MclGeo G;
     mcl_geo(A, b, G);
     const long long g0 = A.coff[b];
-    const unsigned lin = (unsigned)(blk * 256 - g0) + threadIdx.x;
-    const long long g = g0 + lin;
-    int bits = 0, nt = 0;
-    if (lin < G.ncell) {
-      const int lcv = A.lc[g], cand = lcv >> 1;
+    const unsigned lin0 = (unsigned)(blk * 256 - g0) + 4u * lane;
+    const long long g = g0 + lin0;
+    unsigned lcw = *(const unsigned*)(A.lc + g), cw = *(const unsigned*)(A.cidx + g);
+    unsigned vf = 0;
+    int nv = 0, nt = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (lin0 + e >= G.ncell) break;  // the FAB's last block is padded
+      const int lcv = (lcw >> (8 * e)) & 0xFF, cand = lcv >> 1;
+      int bits = 0;
       if (cand) {
         int i, j, k;
-        mcl_cell(G, lin, i, j, k);
+        mcl_cell(G, lin0 + e, i, j, k);
         for (int d = 0; d < 3; ++d) {
           if (!((cand >> d) & 1)) continue;  // edgeTable flags an edge iff its endpoints are on different sides
           bool rev;
           if ((A.dim2 ? first_toucher2(G, A.lc + g0, i, j, k, d, rev) : first_toucher(G, A.lc + g0, i, j, k, d, rev)) >= 0) bits |= (1 << d);
         }
       }
-      nt = (lcv & 1) ? (A.dim2 ? d_nseg[A.cidx[g]] : c_ntri[A.cidx[g]]) : 0;
-      A.vflag[g] = (unsigned char)bits;
+      const int ci = (cw >> (8 * e)) & 0xFF;
+      nt += (lcv & 1) ? (A.dim2 ? d_nseg[ci] : c_ntri[ci]) : 0;
+      nv += __popc(bits);
+      vf |= (unsigned)bits << (8 * e);
     }
-    int pv, pt, tv, tt;
-    block_prefix(__popc(bits), nt, pv, pt, tv, tt);
-    if (threadIdx.x == 0) {
+    *(unsigned*)(A.vflag + g) = vf;  // (padding cells of the last block: zeros, never read as cells)
+    const int tv = wave_sum(nv), tt = wave_sum(nt);
+    if (lane == 0) {
       A.bsum[2 * blk] = tv;
       A.bsum[2 * blk + 1] = tt;
     }
@@ -645,30 +860,44 @@ __global__ __launch_bounds__(1024) void k_mcl_scan(MclArgs A) {
 // a marked block holds ~3 vertices per 256 cells, so per-block emission left 99 % of the lanes idle behind chains of
 // dependent loads (measured 0.64 + 0.33 ms for 0.46 M vertices + 0.91 M triangles).
 __global__ __launch_bounds__(256) void k_mcl_lists(MclArgs A, int* vkeys, int* tris) {
-  const int nact = *A.nact;
-  for (int q = blockIdx.x; q < nact; q += gridDim.x) {
+  const int nact = *A.nact, lane = threadIdx.x & 63;
+  const int nwave = gridDim.x * 4;
+  for (int q = blockIdx.x * 4 + (threadIdx.x >> 6); q < nact; q += nwave) {  // one wave per marked block, as k_mcl_count
     const long long blk = A.alist[2 * q];
     const int b = A.alist[2 * q + 1];
-    const long long g = blk * 256 + threadIdx.x;
     MclGeo G;
     mcl_geo(A, b, G);
-    const bool cell = (unsigned long long)(g - A.coff[b]) < G.ncell;  // the FAB's last block is padded
-    const int bits = cell ? A.vflag[g] : 0;
-    const int nt = (cell && (A.lc[g] & 1)) ? (A.dim2 ? d_nseg[A.cidx[g]] : c_ntri[A.cidx[g]]) : 0;
-    int pv, pt, tv, tt;
-    block_prefix(__popc(bits), nt, pv, pt, tv, tt);
-    if (!cell) continue;
-    int vid = A.bsum[2 * blk] + pv;
-    A.voff[g] = vid;
-    const int glo = (int)(unsigned)(g & 0xffffffffLL), ghi = (int)(g >> 32);
-    for (int d = 0; d < 3; ++d) {
-      if (!(bits & (1 << d))) continue;
-      int* e = vkeys + 6LL * (A.base[2 * b] + vid);
-      e[0] = glo; e[1] = ghi; e[2] = b | (d << 28);
-      ++vid;
+    const long long g = blk * 256 + 4 * lane;
+    const unsigned lin0 = (unsigned)(g - A.coff[b]);
+    const unsigned vf = *(const unsigned*)(A.vflag + g), lcw = *(const unsigned*)(A.lc + g), cw = *(const unsigned*)(A.cidx + g);
+    int nvc[4], ntc[4], nv = 0, nt = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const bool cell = lin0 + e < G.ncell;  // the FAB's last block is padded
+      const int ci = (cw >> (8 * e)) & 0xFF;
+      nvc[e] = cell ? __popc((vf >> (8 * e)) & 7) : 0;
+      ntc[e] = (cell && ((lcw >> (8 * e)) & 1)) ? (A.dim2 ? d_nseg[ci] : c_ntri[ci]) : 0;
+      nv += nvc[e];
+      nt += ntc[e];
     }
-    int* t = tris + 3LL * (A.base[2 * b + 1] + A.bsum[2 * blk + 1] + pt);
-    for (int r = 0; r < nt; ++r) { t[3 * r] = glo; t[3 * r + 1] = ghi; t[3 * r + 2] = b | (r << 28); }
+    int vid = A.bsum[2 * blk] + wave_excl(nv, lane);
+    int* t = tris + 3LL * (A.base[2 * b + 1] + A.bsum[2 * blk + 1] + wave_excl(nt, lane));
+    int* const kb = vkeys + 6LL * A.base[2 * b];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (lin0 + e >= G.ncell) break;
+      A.voff[g + e] = vid;
+      const long long ge = g + e;
+      const int glo = (int)(unsigned)(ge & 0xffffffffLL), ghi = (int)(ge >> 32);
+      const int bits = (vf >> (8 * e)) & 7;
+      for (int d = 0; d < 3; ++d) {
+        if (!(bits & (1 << d))) continue;
+        int* k = kb + 6LL * vid;
+        k[0] = glo; k[1] = ghi; k[2] = b | (d << 28);
+        ++vid;
+      }
+      for (int r = 0; r < ntc[e]; ++r) { t[0] = glo; t[1] = ghi; t[2] = b | (r << 28); t += 3; }
+    }
   }
 }
 
@@ -871,6 +1100,7 @@ static int mc_level_impl(pa_ctx* ctx, const pa_mf* state, const pa_mf* mask, int
   A.L = L->view; A.S = state->view; A.M = mask->view;
   A.mcomp = mcomp; A.isocomp = isocomp; A.ncomp = state->ncomp; A.iso = isoval;
   A.kseg = 32;
+  A.rows = A.nslab = A.tiles = A.ldsw = 0;
   A.dim2 = dim2;
   A.nomask = nomask;
   A.has_fine = (nomask && fine) ? 1 : 0;
@@ -894,8 +1124,9 @@ static int mc_level_impl(pa_ctx* ctx, const pa_mf* state, const pa_mf* mask, int
   PA_HIP(hipMemcpyAsync(d_coff, coff.data(), 8 * ((size_t)nb + 1), hipMemcpyHostToDevice, ctx->stream));
   PA_HIP(hipMemcpyAsync(d_loops, dl.data(), sizeof(DBox) * (size_t)nb, hipMemcpyHostToDevice, ctx->stream));
   {
-    const char* te = getenv("PA_MC_TY");  // tile rows / planes per workgroup of the cell pass (tuning, read per call)
+    const char* te = getenv("PA_MC_TY");  // first form only: tile rows / planes per workgroup of the cell pass (tuning, read per call)
     const char* ke = getenv("PA_MC_KSEG");
+    const char* fe = getenv("PA_MC_CELLS");  // "tiles": the first form of the cell pass (kept for A/B measurements)
     const int TY = te ? atoi(te) : 8;
     if (ke && atoi(ke) > 0) A.kseg = atoi(ke);
     const int mx = L->maxn[0] + 2 * ng, my = L->maxn[1] + 2 * ng, mz = L->maxn[2] + 2 * ng;
@@ -903,7 +1134,28 @@ static int mc_level_impl(pa_ctx* ctx, const pa_mf* state, const pa_mf* mask, int
     PA_HIP(hipMemsetAsync(A.bact, 0, nblk, ctx->stream));
     PA_HIP(hipMemsetAsync(A.bsum, 0, 8 * nblk, ctx->stream));
     PA_HIP(hipMemsetAsync(A.nact, 0, 4, ctx->stream));
-    if (TY == 16) hipLaunchKernelGGL((k_mcl_cells<16>), dim3(tiles(16), (unsigned)nb), dim3(64 * 16), 0, ctx->stream, A);
+    constexpr int NT4 = 512, GPT4 = 2;  // 4096 cells of a plane per workgroup
+    if (!(fe && std::string(fe) == "tiles") && (long long)mx * 5 <= 4LL * NT4 * GPT4) {
+      // slab = as many whole rows as fit next to their halo row, evened out over the slabs of the largest FAB, multiple of 4
+      const int rmax = std::max(4, ((4 * NT4 * GPT4) / mx - 1) / 4 * 4);
+      const int ns0 = (my + rmax - 1) / rmax;
+      A.rows = std::min(rmax, ((my + ns0 - 1) / ns0 + 3) / 4 * 4);
+      A.nslab = (my + A.rows - 1) / A.rows;
+      if (!ke) {  // enough workgroups for 8 per CU in flight, planes re-read at the segment ends <= 1 in 16
+        const long long want = 6144;
+        const int nseg = (int)std::min<long long>(std::max<long long>(1, mz / 16), std::max<long long>(1, (want + (long long)nb * A.nslab - 1) / ((long long)nb * A.nslab)));
+        A.kseg = (mz + nseg - 1) / nseg;
+      }
+      A.tiles = A.nslab * ((mz + A.kseg - 1) / A.kseg);
+      A.ldsw = NT4 * GPT4 + (mx >> 2) + 4;
+      const long long total = (long long)nb * A.tiles;
+      if (total > 0x7ffffff0LL) return pa_fail(ctx, "pa_mc_level: level too large for one pass");
+      const dim3 g4((unsigned)((total + 7) / 8 * 8));
+      const size_t lds4 = 2 * (size_t)A.ldsw * 4;
+      if (!nomask) hipLaunchKernelGGL((k_mcl_cells4<NT4, GPT4, 0>), g4, dim3(NT4), lds4, ctx->stream, A);
+      else if (!A.has_fine) hipLaunchKernelGGL((k_mcl_cells4<NT4, GPT4, 1>), g4, dim3(NT4), lds4, ctx->stream, A);
+      else hipLaunchKernelGGL((k_mcl_cells4<NT4, GPT4, 2>), g4, dim3(NT4), lds4, ctx->stream, A);
+    } else if (TY == 16) hipLaunchKernelGGL((k_mcl_cells<16>), dim3(tiles(16), (unsigned)nb), dim3(64 * 16), 0, ctx->stream, A);
     else if (TY == 4) hipLaunchKernelGGL((k_mcl_cells<4>), dim3(tiles(4), (unsigned)nb), dim3(64 * 4), 0, ctx->stream, A);
     else hipLaunchKernelGGL((k_mcl_cells<8>), dim3(tiles(8), (unsigned)nb), dim3(64 * 8), 0, ctx->stream, A);
     hipLaunchKernelGGL(k_mcl_active, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, ctx->stream, A, (int)nblk);
@@ -928,8 +1180,28 @@ static int mc_level_impl(pa_ctx* ctx, const pa_mf* state, const pa_mf* mask, int
   // one allocation: vertices | keys | triangles (each part 256-byte aligned)
   const size_t bv = ((size_t)nv * state->ncomp * 8 + 255) / 256 * 256, bk = ((size_t)nv * 24 + 255) / 256 * 256, bt = std::max<size_t>(8, (size_t)nt * 12);
   unsigned char* blockp = nullptr;
-  auto bail = [&](const std::string& m) { if (blockp) (void)hipFree(blockp); return pa_fail(ctx, m); };
-  if (hipMalloc(&blockp, bv + bk + bt) != hipSuccess) return bail("pa_mc_level: out of device memory for the surface");
+  auto bail = [&](const std::string& m) { if (blockp) { ctx->surf_live.erase(blockp); (void)hipFree(blockp); } return pa_fail(ctx, m); };
+  {  // a cached block that fits without wasting more than half of itself, else a new one (freed by pa_device_free)
+    const size_t need = bv + bk + bt;
+    size_t got = 0;
+    int best = -1;
+    for (int c = 0; c < (int)ctx->surf_cache.size(); ++c)
+      if (ctx->surf_cache[c].second >= need && ctx->surf_cache[c].second <= 2 * need + (1u << 20) && (best < 0 || ctx->surf_cache[c].second < ctx->surf_cache[best].second)) best = c;
+    if (best >= 0) {
+      blockp = (unsigned char*)ctx->surf_cache[best].first;
+      got = ctx->surf_cache[best].second;
+      ctx->surf_cache.erase(ctx->surf_cache.begin() + best);
+    } else {
+      if (hipMalloc(&blockp, need) != hipSuccess) {  // make room: drop the cache and try once more
+        blockp = nullptr;
+        for (auto& c : ctx->surf_cache) (void)hipFree(c.first);
+        ctx->surf_cache.clear();
+        if (hipMalloc(&blockp, need) != hipSuccess) { blockp = nullptr; return bail("pa_mc_level: out of device memory for the surface"); }
+      }
+      got = need;
+    }
+    ctx->surf_live[blockp] = got;
+  }
   double* dv = (double*)blockp;
   int32_t *dk = (int32_t*)(blockp + bv), *dt = (int32_t*)(blockp + bv + bk);
   if (hipMemcpyAsync(d_base, base.data(), 16 * (size_t)nb, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return bail("pa_mc_level: upload failed");
