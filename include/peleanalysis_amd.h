@@ -276,6 +276,19 @@ int pa_mc_level_fine(pa_ctx*, const pa_mf* state, const pa_level* fine, int rati
 int pa_msq_level_fine(pa_ctx*, const pa_mf* state, const pa_level* fine, int ratio, const pa_box* loops, int isocomp,
                       double isoval, int64_t* nvert, int64_t* nseg, double** dev_verts, int32_t** dev_vkeys,
                       int32_t** dev_segs);
+/* isosurface.cpp:1687-1726 + 1751-1812 on the device: the global node / element sets from the per-FAB fragments, in
+ * insertion order (level by level, FAB by FAB: exactly the fragments whose ntri > 0, as the reference skips the others).
+ * A vertex within 1e-15 (Euclidean) of an earlier node IS that node (Node::operator<, :834-873), otherwise a new node
+ * numbered by insertion rank; elements = node-id triples rotated so the smallest id leads, degenerate ones dropped,
+ * unique, sorted (std::set<Element>, :877-927).  verts / tris are DEVICE pointers ([nvert][ncomp] with the position in
+ * the first three components; [ntri][3] fragment-local vertex ids) -- e.g. slices of what pa_mc_level* returned.
+ * Outputs: two device allocations ([nnodes][ncomp], [nelts][3]; release each with pa_device_free; NULL when empty).
+ * Returns 0, or 1 on error, or 2 when some cluster of nearby vertices is not transitive under the tolerance (a ~ b,
+ * b ~ c, a !~ c): the reference's answer then depends on the insertion chain, nothing is returned, and the caller runs
+ * the sequential merge (tools/common/pa_isomerge.h).  Synchronous. */
+typedef struct { const double* verts; int64_t nvert; const int32_t* tris; int64_t ntri; } pa_iso_frag;
+int pa_iso_merge(pa_ctx*, int nfrag, const pa_iso_frag* frags /* host array */, int ncomp, int64_t* nnodes,
+                 double** dev_nodes, int64_t* nelts, int32_t** dev_elts);
 const uint16_t* pa_mc_edge_table(void); /* [256] host */
 const int8_t*   pa_mc_tri_table(void);  /* [256][16] host */
 

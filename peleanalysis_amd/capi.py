@@ -50,6 +50,10 @@ class PaComm(C.Structure):
     _fields_ = [("user", C.c_void_p), ("rank", C.c_int32), ("nranks", C.c_int32), ("exchange", EXCHANGE_FN), ("allreduce", ALLREDUCE_FN)]
 
 
+class PaIsoFrag(C.Structure):
+    _fields_ = [("verts", C.c_void_p), ("nvert", C.c_int64), ("tris", C.c_void_p), ("ntri", C.c_int64)]
+
+
 class PaSdfGrid(C.Structure):
     _fields_ = [("ntri", C.c_int64), ("tri", C.c_void_p), ("nvert", C.c_int64), ("x", C.c_void_p), ("origin", C.c_float * 3), ("dx", C.c_float),
                 ("n", C.c_int32 * 3), ("phi", C.c_void_p)]
@@ -144,6 +148,7 @@ def load_library() -> C.CDLL:
                                    C.POINTER(vp)]),
         "pa_mc_level": (C.c_int, [vp, vp, vp, C.c_int, C.POINTER(PaBox), C.c_int, dbl, C.POINTER(i64), C.POINTER(i64), C.POINTER(vp), C.POINTER(vp),
                                   C.POINTER(vp)]),
+        "pa_iso_merge": (C.c_int, [vp, C.c_int, C.POINTER(PaIsoFrag), C.c_int, C.POINTER(i64), C.POINTER(vp), C.POINTER(i64), C.POINTER(vp)]),
         "pa_mc_edge_table": (C.POINTER(C.c_uint16), []),
         "pa_mc_tri_table": (C.POINTER(C.c_int8), []),
         "pa_sdf_level_set3": (C.c_int, [vp, C.c_int, C.POINTER(PaSdfGrid), C.c_int]),
@@ -457,6 +462,35 @@ def stream_trace(ctx, vfield, vcomp, seeds, nsteps, dt):
     ctx.check(ctx.lib.pa_stream_trace(ctx.h, len(vfield), _handles(vfield), int(vcomp), n, seeds.ctypes.data_as(C.POINTER(C.c_double)), int(nsteps),
                                       float(dt), C.c_void_p(buf.ptr), C.byref(nred)))
     return buf.to_numpy(np.float64, (2 * n, nsteps, 3)), nred.value
+
+
+def iso_merge(ctx: Context, fragments, ncomp: int):
+    """pa_iso_merge on host fragments [(verts [nv][ncomp], tris [nt][3])] (uploaded here).  Returns (nodes [n][ncomp],
+    elts [m][3] int32), or None when the library reports clusters that are not transitive under the tolerance (code 2)."""
+    bufs, arr = [], (PaIsoFrag * max(len(fragments), 1))()
+    for f, (v, t) in enumerate(fragments):
+        v = np.ascontiguousarray(v, dtype=np.float64).reshape(-1, ncomp)
+        t = np.ascontiguousarray(t, dtype=np.int32).reshape(-1, 3)
+        bv = DevBuf.from_numpy(ctx, v) if len(v) else None
+        bt = DevBuf.from_numpy(ctx, t) if len(t) else None
+        bufs += [bv, bt]
+        arr[f].verts, arr[f].nvert, arr[f].tris, arr[f].ntri = (bv.ptr if bv else None), len(v), (bt.ptr if bt else None), len(t)
+    nn, ne, pn, pe = C.c_int64(0), C.c_int64(0), C.c_void_p(), C.c_void_p()
+    rc = ctx.lib.pa_iso_merge(ctx.h, len(fragments), arr, int(ncomp), C.byref(nn), C.byref(pn), C.byref(ne), C.byref(pe))
+    if rc == 2:
+        return None
+    ctx.check(rc)
+    try:
+        nodes, elts = np.empty((nn.value, ncomp)), np.empty((ne.value, 3), np.int32)
+        if nn.value:
+            ctx.check(ctx.lib.pa_memcpy_d2h(ctx.h, nodes.ctypes.data_as(C.c_void_p), pn, nodes.nbytes))
+        if ne.value:
+            ctx.check(ctx.lib.pa_memcpy_d2h(ctx.h, elts.ctypes.data_as(C.c_void_p), pe, elts.nbytes))
+    finally:
+        for q in (pn, pe):
+            if q.value:
+                ctx.lib.pa_device_free(ctx.h, q)
+    return nodes, elts
 
 
 def mc_level(ctx: Context, state: "DevMF", mask: "DevMF", loops, isocomp: int, isoval: float, mcomp: int = 0, squares: bool = False):

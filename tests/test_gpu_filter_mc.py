@@ -171,6 +171,7 @@ def test_marching_cubes_level_batched_matches_oracle(ctx, oracle, name, ng):
     iso = float(np.median(allv))
     dls = [capi.DevLevel(ctx, lv) for lv in H.levels]
     ntri_total = 0
+    frags = []
     for l, lv in enumerate(H.levels):
         dst = capi.DevMF.from_host(ctx, dls[l], states[l])
         dco = capi.DevMF(ctx, dls[l], 4, ng)  # pa_iso_coords_level: the analytic coordinates of every grown FAB, bit for bit
@@ -210,7 +211,15 @@ def test_marching_cubes_level_batched_matches_oracle(ctx, oracle, name, ng):
             assert np.array_equal(gk, k) and np.array_equal(gt, t), f"{name} level {l} box {b}: keys / connectivity differ"
             assert np.array_equal(gv.view(np.int64), np.ascontiguousarray(v).view(np.int64)), f"{name} level {l} box {b}: vertex data not bit-identical"
             ntri_total += len(t)
+            if len(gt):
+                frags.append((gv, gt))
     assert ntri_total > 100
+    # the global node / element sets on the device (pa_iso_merge) against the oracle's sequential insertion
+    wn, we = oracle.iso_merge(frags, nc)
+    gn, ge = capi.iso_merge(ctx, frags, nc)
+    assert len(wn) < sum(len(v) for v, _ in frags), "the case has no vertex shared between FABs"
+    assert gn.shape == wn.shape and np.array_equal(gn.view(np.int64), np.ascontiguousarray(wn).view(np.int64)), f"{name}: merged nodes differ"
+    assert np.array_equal(ge, we), f"{name}: merged elements differ"
 
 
 @pytest.mark.parametrize("per", [(0, 0, 0), (1, 0, 0)])
@@ -276,6 +285,57 @@ def test_marching_squares_level_matches_oracle(ctx, oracle, per):
             assert np.array_equal(gv.view(np.int64), np.ascontiguousarray(v).view(np.int64)), f"level {l} box {b}: vertex data not bit-identical"
             nseg_total += len(sg)
     assert nseg_total > 60
+
+
+def test_iso_merge_synthetic_clusters(ctx, oracle):
+    """pa_iso_merge on hand-made fragments: exact copies and copies 1-3 ulp away in later fragments (in either direction),
+    nodes on and next to the faces of the 1e-14 hash cells (the neighbour probes), an element that collapses once its nodes
+    merge, the same element arriving from two fragments in two rotations; then a chain a ~ b ~ c with a !~ c, which the
+    device path must hand back (code 2) instead of guessing"""
+    rng = np.random.default_rng(17)
+    nc = 5
+    base = np.concatenate([rng.random((400, 3)), 0.25 + 1.0e-14 * rng.integers(0, 50, (60, 3)), 0.5 + 1.0e-14 * rng.integers(0, 4, (60, 3)) + rng.choice([0.0, 1e-16, -1e-16], (60, 3))])
+    base = np.unique(base, axis=0)
+    rng.shuffle(base)
+
+    def data(p):  # node data is carried along from the FIRST copy: make the copies distinguishable
+        return np.concatenate([p, rng.random((len(p), nc - 3))], axis=1)
+
+    frags = []
+    n0 = len(base)
+    t0 = rng.integers(0, n0, (900, 3)).astype(np.int32)
+    frags.append((data(base), t0))
+    for rep in range(3):
+        pick = rng.choice(n0, 150, replace=False)
+        p = base[pick].copy()
+        ulps = rng.integers(-3, 4, p.shape)
+        for _ in range(3):
+            p = np.where(ulps > 0, np.nextafter(p, 2.0), np.where(ulps < 0, np.nextafter(p, -1.0), p))
+            ulps = ulps - np.sign(ulps)
+        extra = rng.random((40, 3))
+        pts = np.concatenate([p, extra])
+        rng.shuffle(pts)
+        t = rng.integers(0, len(pts), (500, 3)).astype(np.int32)
+        frags.append((data(pts), t))
+    # the first fragment's elements again, rotated, through a fragment that holds exact copies of its nodes
+    frags.append((data(base), np.roll(t0[:200], 1, axis=1)))
+    frags.append((np.zeros((0, nc)), np.zeros((0, 3), np.int32)))
+    wn, we = oracle.iso_merge(frags, nc)
+    got = capi.iso_merge(ctx, frags, nc)
+    assert got is not None
+    gn, ge = got
+    assert len(wn) < sum(len(v) for v, _ in frags) - 300
+    assert gn.shape == wn.shape and np.array_equal(gn.view(np.int64), np.ascontiguousarray(wn).view(np.int64))
+    assert np.array_equal(ge, we) and len(ge) > 1500
+    # not transitive: b is within 1e-15 of a and of c, a and c are 1.4e-15 apart
+    a = np.array([0.3, 0.3, 0.3])
+    chain = np.stack([a, a + [7e-16, 0, 0], a + [14e-16, 0, 0]])
+    assert np.linalg.norm(chain[1] - chain[0]) < 1e-15 and np.linalg.norm(chain[2] - chain[1]) < 1e-15 and np.linalg.norm(chain[2] - chain[0]) > 1e-15
+    f2 = [(data(chain), np.array([[0, 1, 2]], np.int32))]
+    assert capi.iso_merge(ctx, f2, nc) is None
+    wn2, _ = oracle.iso_merge(f2, nc)
+    assert len(wn2) == 2  # the sequential rule: c is compared with the kept node a only
+    assert capi.iso_merge(ctx, [], nc)[0].shape == (0, nc)
 
 
 def test_level_entry_points_reject_bad_arguments(ctx):

@@ -301,6 +301,11 @@ def test_isosurface_tool_end_to_end(tmp_path, oracle):
     assert len(oelts) > 200
     assert np.array_equal(faces, oelts + 1), "connectivity (1-based) differs"
     assert np.array_equal(nodes.view(np.int64), onodes.view(np.int64)), "node data not bit-identical"
+    # the run above built the node / element sets on the device (pa_iso_merge); the sequential host merge writes the same bytes
+    host = subprocess.run([os.path.join(BIN, "isosurface3d.ex"), "infile=" + p, "isoCompName=temp", "isoVal=1150", "comps=0 2", "outfile_base=" + str(tmp_path / "hostmerge")],
+                          cwd=tmp_path, capture_output=True, text=True, env=dict(os.environ, PA_ISO_HOST_MERGE="1"))
+    assert host.returncode == 0, host.stderr
+    assert open(tmp_path / "hostmerge.mef", "rb").read() == open(p + "_temp_1150.mef", "rb").read()
     # single-level surface: closed and consistently oriented (the invariant checkIso.cpp is after, checked for real)
     (tmp_path / "one").mkdir()
     p1, H1, _ = _synth(tmp_path / "one", nlev=1, base=32, box=16, per=(0, 0, 0))
@@ -854,6 +859,10 @@ def test_isosurface_tool_full_size_config4_closed_manifold(tmp_path):
     assert V - E + F == 2, (V, E, F)
     assert np.abs(nodes[:, 3] - 1150.0).max() < 1e-9
     assert np.abs(nodes[:, 4] - (nodes[:, 0] + 2.0 * nodes[:, 1] + 3.0 * nodes[:, 2])).max() < 1e-12
+    host = subprocess.run([os.path.join(BIN, "isosurface3d.ex"), "infile=" + p, "isoCompName=temp", "isoVal=1150", "comps=0 1", "outfile_base=" + str(tmp_path / "surf_host")],
+                          cwd=tmp_path, capture_output=True, text=True, env=dict(os.environ, PA_ISO_HOST_MERGE="1"))
+    assert host.returncode == 0, host.stderr
+    assert open(tmp_path / "surf_host.mef", "rb").read() == open(tmp_path / "surf.mef", "rb").read(), "device merge and sequential host merge differ"
     chk = _run("checkIso3d.ex", ["isoFile=" + str(tmp_path / "surf.mef"), "strict=1"], tmp_path)  # exit 2 on an edge traversed twice the same way
     assert "All shared edges are consistently numbered." in chk.stdout
     # the staging file: FABs of <= chunk_size nodes, node-major, in order

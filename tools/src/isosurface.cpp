@@ -146,8 +146,12 @@ int main(int argc, char** argv) {
     merger.add(hv.data(), nvk, ht.data(), ntk);
   };
   // per rank and level: the fragments of its FABs as they came off the device (ngpus > 1: merged afterwards in BoxArray order)
-  struct LevFrag { std::vector<int> gids; std::vector<int64_t> nvb, ntb; std::vector<double> hva; std::vector<int32_t> hta, hka; };
+  struct LevFrag { std::vector<int> gids; std::vector<int64_t> nvb, ntb; std::vector<double> hva; std::vector<int32_t> hta, hka; double* dv = nullptr; int32_t *dk = nullptr, *dt = nullptr; };
   std::vector<std::vector<LevFrag>> frags(team.n, std::vector<LevFrag>(Nlev));
+  // one GPU, no per-FAB trimming, no distance function: the node / element sets are built on the device from the fragments
+  // where they lie (pa_iso_merge); the fragments are only downloaded if the library hands the merge back (PA_ISO_HOST_MERGE=1 forces that path)
+  bool dev_merge = team.n == 1 && !build_distance_function && !std::getenv("PA_ISO_HOST_MERGE");
+  for (int lev = 0; lev < Nlev; ++lev) dev_merge = dev_merge && !(rm_external_elements && nGrow[lev] > 1);
   team.run([&](int r) {
   pa::Ctx& ctx = *team.ctx[r];
   const bool lead = r == 0;  // the phase timers are rank 0's
@@ -233,6 +237,8 @@ int main(int argc, char** argv) {
     F.gids = shares[lev].gids; F.nvb = nvb; F.ntb = ntb;
     std::vector<double>& hva = F.hva;
     std::vector<int32_t>&hta = F.hta, &hka = F.hka;
+    F.dv = dv; F.dk = dk; F.dt = dt;
+    if (dev_merge) continue;  // the level's surface stays on the device until pa_iso_merge
     hva.resize((size_t)(nvt * nc)); hta.resize((size_t)(ntt * 3)); hka.resize((size_t)(nvt * 6));
     if (nvt > 0) {
       ctx.check(pa_memcpy_d2h(ctx.h, hva.data(), dv, nvt * nc * 8));
@@ -326,6 +332,52 @@ int main(int argc, char** argv) {
     }
     t_merge += now() - tq;
   }
+  std::vector<double> dnodes;   // the device merge's results (dev_merge)
+  std::vector<int32_t> delts;
+  if (dev_merge) {
+    tq = now();
+    pa::Ctx& ctx = *team.ctx[0];
+    std::vector<pa_iso_frag> fr;
+    for (int lev = 0; lev < Nlev; ++lev) {  // insertion order of isosurface.cpp:1531-1726: level by level, FAB by FAB, FABs without elements skipped (:1595)
+      const LevFrag& F = frags[0][lev];
+      int64_t vo = 0, to = 0;
+      for (size_t b = 0; b < F.nvb.size(); vo += F.nvb[b], to += F.ntb[b], ++b)
+        if (F.ntb[b] > 0) fr.push_back(pa_iso_frag{F.dv + vo * nc, F.nvb[b], F.dt + 3 * to, F.ntb[b]});
+    }
+    int64_t nn = 0, ne = 0;
+    double* dn = nullptr;
+    int32_t* de = nullptr;
+    const int rc = pa_iso_merge(ctx.h, (int)fr.size(), fr.data(), nc, &nn, &dn, &ne, &de);
+    if (rc == 0) {
+      dnodes.resize((size_t)(nn * nc));
+      delts.resize((size_t)(ne * 3));
+      if (nn > 0) ctx.check(pa_memcpy_d2h(ctx.h, dnodes.data(), dn, nn * nc * 8));
+      if (ne > 0) ctx.check(pa_memcpy_d2h(ctx.h, delts.data(), de, ne * 12));
+      pa_device_free(ctx.h, dn);
+      pa_device_free(ctx.h, de);
+    } else if (rc == 2) {  // clusters that are not transitive under the tolerance: the sequential rule decides (host)
+      if (verbose) std::cout << "  " << pa_last_error(ctx.h) << std::endl;
+      dev_merge = false;
+      for (int lev = 0; lev < Nlev; ++lev) {
+        LevFrag& F = frags[0][lev];
+        int64_t nvt = 0, ntt = 0;
+        for (size_t b = 0; b < F.nvb.size(); ++b) { nvt += F.nvb[b]; ntt += F.ntb[b]; }
+        F.hva.resize((size_t)(nvt * nc)); F.hta.resize((size_t)(ntt * 3)); F.hka.resize((size_t)(nvt * 6));
+        if (nvt > 0) {
+          ctx.check(pa_memcpy_d2h(ctx.h, F.hva.data(), F.dv, nvt * nc * 8));
+          ctx.check(pa_memcpy_d2h(ctx.h, F.hka.data(), F.dk, nvt * 6 * 4));
+        }
+        if (ntt > 0) ctx.check(pa_memcpy_d2h(ctx.h, F.hta.data(), F.dt, ntt * 3 * 4));
+        int64_t vo = 0, to = 0;
+        for (size_t b = 0; b < F.nvb.size(); vo += F.nvb[b], to += F.ntb[b], ++b)
+          if (F.ntb[b] > 0) merge_box(H.lev[lev].boxes[b], nGrow[lev], F.nvb[b], F.ntb[b], F.hva.data() + vo * nc, F.hka.data() + vo * 6, F.hta.data() + to * 3);
+      }
+    } else {
+      pa::Abort(pa_last_error(ctx.h));
+    }
+    for (int lev = 0; lev < Nlev; ++lev) pa_device_free(ctx.h, frags[0][lev].dv);
+    t_merge += now() - tq;
+  }
   if (build_distance_function) {  // isosurface.cpp:1731-1748
     std::string outfile("distance");
     pp.query("outfile", outfile);
@@ -353,8 +405,10 @@ int main(int argc, char** argv) {
                 << ", marching cubes " << t_mc << ", download " << t_d2h << ", per-FAB trimming + node/element insertion " << t_merge << '\n';
   }
   const double strt_time_uniq = now();
-  merger.finish();
-  const std::vector<int32_t> elts = merger.elements();
+  if (!dev_merge) merger.finish();
+  const std::vector<int32_t> elts = dev_merge ? std::move(delts) : merger.elements();
+  const std::vector<double>& nodes = dev_merge ? dnodes : merger.nodes();
+  const long long num_nodes = (long long)nodes.size() / nc;
   std::cout << "Uniquify time: " << now() - strt_time_uniq << '\n';  // :1888-1890
   const double strt_time_sout = now();
   int writeSurf = 1, computeArea = 0;
@@ -364,7 +418,7 @@ int main(int argc, char** argv) {
   pp.query("surfFormat", surfFormat);
   if (surfFormat != "MEF" && surfFormat != "XDMF") pa::Abort("surfFormat must be MEF or XDMF");
   if (computeArea) {  // computed before the element list is released (the reference prints 0 here: quirk Q7)
-    const auto& nd = merger.nodes();
+    const auto& nd = nodes;
     double area = 0;
     for (size_t e = 0; e + 2 < elts.size(); e += 3) {
       const double *a = &nd[(size_t)elts[e] * nc], *b = &nd[(size_t)elts[e + 1] * nc], *c = &nd[(size_t)elts[e + 2] * nc];
@@ -381,10 +435,10 @@ int main(int argc, char** argv) {
     pp.query("outfile_base", outfile_base);
     std::vector<std::string> vn;
     for (int n = 0; n < nComp; ++n) vn.push_back(H.names[pltComps[n]]);
-    pa::write_xdmf(outfile_base, H.time, isoCompName, isoVal, vn, merger.nodes(), elts);
+    pa::write_xdmf(outfile_base, H.time, isoCompName, isoVal, vn, nodes, elts);
   } else if (writeSurf) {
     std::cout << "...write surface in mef format (mef = Marcs element format)" << std::endl;
-    std::cout << "      (Nelts,Nnodes):(" << elts.size() / 3 << ", " << merger.num_nodes() << ")" << std::endl;
+    std::cout << "      (Nelts,Nnodes):(" << elts.size() / 3 << ", " << num_nodes << ")" << std::endl;
     std::vector<std::string> vars{"X", "Y", "Z"};
     for (int n = 0; n < nComp; ++n) vars.push_back(H.names[pltComps[n]]);
     char buf[72];
@@ -405,7 +459,7 @@ int main(int argc, char** argv) {
       pp.query("tmpFile", tmpFile);
       std::ofstream ost(tmpFile, std::ios::binary);
       if (!ost) pa::Abort("Unable to create " + tmpFile);
-      const long long N = merger.num_nodes();
+      const long long N = num_nodes;
       const long long nparts = (N + chunk_size - 1) / chunk_size, base = nparts ? N / nparts : 0, rem = nparts ? N % nparts : 0;
       if (verbose) std::cout << "  staging vertex data to disk in " << nparts << " chunks..." << std::endl;
       long long lo = 0;
@@ -413,13 +467,13 @@ int main(int argc, char** argv) {
         const long long n = base + (q < rem ? 1 : 0);
         pa::Box3 b{{(int)lo, 0, 0}, {(int)(lo + n - 1), 0, 0}};
         ost << "FAB ((8, (64 11 52 0 1 12 0 1023)),(8, (8 7 6 5 4 3 2 1)))" << pa::box_str(b) << ' ' << nc << "\n";
-        ost.write((const char*)(merger.nodes().data() + lo * nc), sizeof(double) * (size_t)(n * nc));
+        ost.write((const char*)(nodes.data() + lo * nc), sizeof(double) * (size_t)(n * nc));
         lo += n;
       }
       if (verbose) std::cout << "  ... data staged." << std::endl;
     }
     std::cout << "  Writing the file..." << std::endl;
-    pa::write_mef(outfile_base + ".mef", H.time, vars, merger.nodes(), elts);
+    pa::write_mef(outfile_base + ".mef", H.time, vars, nodes, elts);
     std::cout << "            ...done" << std::endl;
   }
   std::cout << "Surface output time: " << now() - strt_time_sout << '\n';  // :2232-2234
