@@ -305,7 +305,8 @@ def main():
                    "parallelism": par, "exchange": xch},
     }
     if nk:
-        # one launch of the fused kernel = this rank's boxes of one level; achieved = algorithmic bytes of all timed launches / their time
+        # one launch of the fused kernel = this rank's boxes of every level (k_gradcurv_march3_levels) or of one level;
+        # achieved = algorithmic bytes of all timed launches / their time
         avg_ms = ms_k / nk
         ach = cells_local * args.ncomp * args.steps * BYTES_PER_CELL / (ms_k * 1e-3) / 1e9
         # HBM bytes per launch from this round's rocprofv3 PMC passes of the same workload (profiles/, tools/r2_pmc.sh): only
@@ -318,7 +319,7 @@ def main():
                 traffic = rec.get("traffic_bytes_per_launch")
         res["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                            "traffic": traffic, "kernel": kern + " (fused grad->curvature sweep)", "avg_launch_ms": avg_ms,
-                           "launches": nk, "bytes_per_cell": BYTES_PER_CELL, "cells_per_launch": cells_local / args.nlev}
+                           "launches": nk, "bytes_per_cell": BYTES_PER_CELL, "cells_per_launch": cells_local * args.ncomp * args.steps / nk}
         res["breakdown_ms_per_step"] = bd  # from the untimed steps after the timed region (rank 0)
         res["step_frac_of_hbm_roofline"] = (cells_local * args.ncomp * BYTES_PER_CELL / (dt / args.steps) / 1e9) / HBM_PEAK_GBS
     if rank == 0 and world == 1 and not args.no_cpu and not args.sim_of:

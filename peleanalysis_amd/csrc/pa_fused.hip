@@ -785,6 +785,82 @@ int pa_gradcurv_level_cg(pa_ctx* ctx, const pa_mf* phi, int pcomp, double pmin, 
   return 0;
 }
 
+// the CG sweeps of all levels: one launch (k_gradcurv_march3_levels) when every level takes the same tile variant and the
+// XCD-aware order is on, else level by level.  PA_SWEEP_BATCH=0: always level by level (A/B).
+int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, double pmin, double pmax, pa_mf* const* out, int ocomp) {
+  static const int batch_env = [] { const char* e = getenv("PA_SWEEP_BATCH"); return e ? atoi(e) : 1; }();
+  static const bool knobs = getenv("PA_MARCH") || getenv("PA_DBG") || getenv("PA_MTY") || getenv("PA_PAIR");
+  std::vector<int> lv;
+  for (int l = 0; l < nlev; ++l)
+    if (!phi[l]->lev->boxes.empty()) lv.push_back(l);
+  int mty = 0;
+  bool ok = batch_env && !knobs && fused_order() == 2 && lv.size() >= 2 && (int)lv.size() <= PA_MAXB;
+  for (int l : lv) {
+    const pa_level* L = phi[l]->lev;
+    const int m = L->maxn[1] >= 52 ? 13 : (L->maxn[1] >= 16 ? 8 : 4);  // as march_launch
+    ok = ok && L->maxn[0] > 32 && (mty == 0 || m == mty);
+    mty = m;
+  }
+  if (!ok) {
+    for (int l = 0; l < nlev; ++l)
+      if (pa_gradcurv_level_cg(ctx, phi[l], pcomp, pmin, pmax, out[l], ocomp)) return 1;
+    return 0;
+  }
+  SweepBatch S;
+  S.n = (int)lv.size();
+  S.wg0[0] = 0;
+  // planes per workgroup: the model of march_launch on the whole launch (workgroups of all levels share the rounds)
+  std::vector<long long> per_seg(lv.size());
+  long long wgs = 0;
+  int kdef = fused_kseg();
+  for (size_t q = 0; q < lv.size(); ++q) {
+    const pa_level* L = phi[lv[q]]->lev;
+    per_seg[q] = (long long)((L->maxn[0] + 63) / 64) * ((L->maxn[1] + mty - 1) / mty) * (long long)L->boxes.size();
+    wgs += per_seg[q] * ((L->maxn[2] + kdef - 1) / kdef);
+  }
+  int tz_best = 0;
+  if (!getenv("PA_KSEG") && wgs < 2048) {
+    long long best = -1;
+    int nzmax = 0;
+    for (int l : lv) nzmax = std::max(nzmax, phi[l]->lev->maxn[2]);
+    for (int tz = 1; tz <= std::max(1, nzmax / 8); ++tz) {
+      long long w = 0;
+      int kmax = 0;
+      for (size_t q = 0; q < lv.size(); ++q) {
+        const int nz = phi[lv[q]]->lev->maxn[2], k = std::max(4, (nz + tz - 1) / tz);
+        w += per_seg[q] * ((nz + k - 1) / k);
+        kmax = std::max(kmax, k);
+      }
+      const long long cost = ((w + 255) / 256) * (kmax + 4);
+      if (best < 0 || cost < best) { best = cost; tz_best = tz; }
+    }
+  }
+  for (size_t q = 0; q < lv.size(); ++q) {
+    const int l = lv[q];
+    const pa_level* L = phi[l]->lev;
+    if (level_cg(ctx, L)) return 1;
+    S.bp[q] = LevelBP2{L->view, phi[l]->view, out[l]->view};
+    MarchArgs A{pcomp, ocomp, kdef, pmin, 1.0 / (pmax - pmin), -1.0, 2, 1, 1, 1};
+    A.cg = 1;
+    if (tz_best) A.kseg = std::max(4, (L->maxn[2] + tz_best - 1) / tz_best);
+    const unsigned nb = (unsigned)L->boxes.size();
+    const dim3 g = march_grid(L->maxn[0], L->maxn[1], L->maxn[2], A.kseg, mty, nb);
+    A.nboxes = (int)nb;
+    A.txy_max = ((L->maxn[0] + 63) / 64) * ((L->maxn[1] + mty - 1) / mty);
+    A.tiles_max = (int)g.x;
+    S.A[q] = A;
+    S.wg0[q + 1] = S.wg0[q] + g.x * 8u * ((nb + 7u) / 8u);
+  }
+  ProfScope prof(ctx, PA_TAG_GRADCURV);
+  const dim3 grid(S.wg0[S.n]);
+  if (mty == 13) hipLaunchKernelGGL(k_gradcurv_march3_levels<13>, grid, dim3(64 * 16), 0, ctx->stream, S);
+  else if (mty == 8) hipLaunchKernelGGL(k_gradcurv_march3_levels<8>, grid, dim3(64 * 11), 0, ctx->stream, S);
+  else hipLaunchKernelGGL(k_gradcurv_march3_levels<4>, grid, dim3(64 * 7), 0, ctx->stream, S);
+  ctx->sweep_kernel = "k_gradcurv_march3_levels<MTY=" + std::to_string(mty) + "> (" + std::to_string(S.n) + " levels per launch)";
+  PA_HIP(hipGetLastError());
+  return 0;
+}
+
 // after the sweeps of ALL levels: curvature of the first layer behind every special face, several levels per launch pair.
 // crse_n[l]: the coarser level's output (normal components from cncomp0) or this rank's coarse-source copy of them.
 int pa_gradcurv_fix_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, const pa_mf* const* crse_n, int cncomp0, const int32_t bc[3], double pmin, double pmax,

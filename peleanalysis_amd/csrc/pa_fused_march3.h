@@ -119,14 +119,14 @@ __device__ __forceinline__ void store_pair(char* base, unsigned off, bool odd, d
 //            which is irrelevant there) is re-aimed at the array, one plane ahead;
 //   x faces  the edge wave's lanes of that side: likewise its stream of the column beyond.
 // Values that only feed ghost normals behind special faces (edge ghosts, second ghost layer) may be anything.
-template <typename BP, int PA_MTY, bool CLIP, bool PAIR = false, int DBG = 0, bool CG = false>
-__global__ __launch_bounds__(64 * (PA_MTY + 3), 1) void k_gradcurv_march3(BP bp, MarchArgs A) {
+template <typename BP, int PA_MTY, bool CLIP, bool PAIR, int DBG, bool CG>
+__device__ __forceinline__ void gradcurv_march3_body(const BP& bp, const MarchArgs& A, const unsigned bid_x, const unsigned bid_y) {
   FabView P, O;
   DBox V;
   double dxinv[3];
   constexpr int PA_MROWS = PA_MTY + 2;
   constexpr bool OLD_SCHED = (DBG & 256) != 0;  // requests at the top of a step + stores spread over it (first v3 schedule)
-  unsigned bid = blockIdx.x;
+  unsigned bid = bid_x;
   int box;
   if (A.order == 2) {
     const unsigned per8 = 8u * (unsigned)A.tiles_max, g = bid / per8, r = bid % per8;
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(64 * (PA_MTY + 3), 1) void k_gradcurv_march3(BP bp,
     bid = r >> 3;
     if (box >= A.nboxes) return;
   } else {
-    box = A.order ? (int)((blockIdx.x / (unsigned)A.txy_max) % (unsigned)A.nboxes) : (int)blockIdx.y;
+    box = A.order ? (int)((bid_x / (unsigned)A.txy_max) % (unsigned)A.nboxes) : (int)bid_y;
   }
   if (!bp.get(box, P, O, V, dxinv)) return;
   const int pcomp = A.pcomp, kseg = A.kseg;
@@ -546,4 +546,27 @@ __global__ __launch_bounds__(64 * (PA_MTY + 3), 1) void k_gradcurv_march3(BP bp,
 #undef PA_LDO
 #undef PA_PROG
 #undef PA_RUN3
+}
+
+template <typename BP, int PA_MTY, bool CLIP, bool PAIR = false, int DBG = 0, bool CG = false>
+__global__ __launch_bounds__(64 * (PA_MTY + 3), 1) void k_gradcurv_march3(BP bp, MarchArgs A) {
+  gradcurv_march3_body<BP, PA_MTY, CLIP, PAIR, DBG, CG>(bp, A, blockIdx.x, blockIdx.y);
+}
+
+// The CG sweeps of several levels in ONE launch (exact-normal pipeline: the sweeps of different levels do not depend on
+// each other -- only the fix-up afterwards needs the coarser level's normals).  A level of a few boxes is 1-2 rounds of
+// workgroups on 256 CUs, each launch ends in a tail of idle CUs, and the next one ramps up again: levels back to back
+// in one grid fill those tails (BASELINE config 5's shape, and every rank's share of a sharded hierarchy).  Level l
+// owns workgroups wg0[l] .. wg0[l+1]-1, each range a multiple of 8 so that the XCD-aware numbering (order 2) is kept.
+struct SweepBatch {
+  int n;
+  unsigned wg0[PA_MAXB + 1];
+  LevelBP2 bp[PA_MAXB];
+  MarchArgs A[PA_MAXB];
+};
+template <int PA_MTY>
+__global__ __launch_bounds__(64 * (PA_MTY + 3), 1) void k_gradcurv_march3_levels(SweepBatch S) {
+  int l = 0;
+  while (l + 1 < S.n && blockIdx.x >= S.wg0[l + 1]) ++l;
+  gradcurv_march3_body<LevelBP2, PA_MTY, false, false, 0, true>(S.bp[l], S.A[l], blockIdx.x - S.wg0[l], 0u);
 }

@@ -16,6 +16,7 @@ bool pa_fused2_level_ok(const pa_level* L);
 int pa_fill_boundary_local_batch(pa_ctx* ctx, int n, pa_mf* const* Ms, int comp, int ncomp, int ng);
 int pa_gradcurv_prep_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int comp, const pa_mf* const* crse, int ccomp, const int32_t bc[3], double pmin, double pmax);
 int pa_gradcurv_level_cg(pa_ctx* ctx, const pa_mf* phi, int pcomp, double pmin, double pmax, pa_mf* out, int ocomp);
+int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, double pmin, double pmax, pa_mf* const* out, int ocomp);
 int pa_gradcurv_fix_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, const pa_mf* const* crse_n, int cncomp0, const int32_t bc[3], double pmin, double pmax,
                            pa_mf* const* out, int ncomp0, int kcomp);
 int pa_gauss_curv_level(pa_ctx* ctx, const pa_mf* G, int gcomp, const pa_mf* normgrad, int ngcomp, const pa_mf* c, int ccomp, double thr, pa_mf* out,
@@ -235,7 +236,18 @@ static int fused_passes_dist(pa_ctx* ctx, int nlev, pa_mf* const* state, int com
     }
     if (xov) PA_HIP(hipStreamWaitEvent(A, ctx->sync_evs[1], 0));
     PA_TRY(pa_gradcurv_prep_levels(ctx, nlev, state, comp, crse.data(), 0, bc, pmin, pmax));
-    for (int l = 0; l < nlev; ++l) {
+    // PA_DIST_SWEEP_BATCH=1 (default): the sweeps of all levels in one launch (a rank's share of a level is 1-2 rounds of
+    // workgroups: per-level launches end in idle tails), then ONE grouped exchange of the coarse normals of all levels;
+    // 0: level by level, each level's exchange on the side stream next to the following sweep
+    static const int dsb = [] { const char* e = getenv("PA_DIST_SWEEP_BATCH"); return e ? atoi(e) : 1; }();
+    if (dsb) {
+      PA_TRY(pa_gradcurv_levels_cg(ctx, nlev, state, comp, pmin, pmax, out, ocomp));
+      std::vector<XJob> nj;
+      for (int l = 1; l < nlev; ++l) nj.push_back({&cs[l]->x, out[l - 1], ocomp + 4, csn[l], 0, 3});
+      ProfScope prof(ctx, PA_TAG_XCHG);
+      PA_TRY(pa_xexchange(ctx, (int)nj.size(), nj.data()));
+    }
+    for (int l = 0; l < nlev && !dsb; ++l) {
       PA_TRY(pa_gradcurv_level_cg(ctx, state[l], comp, pmin, pmax, out[l], ocomp));
       if (l + 1 < nlev) {  // the coarse normals level l+1 needs: every rank takes part, whatever it owns
         if (xov) {
@@ -390,7 +402,7 @@ static int fused_passes(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, co
       PA_TRY(pa_fill_boundary_local_batch(ctx, nlev, state, comp, 1, 2));
     }
     PA_TRY(pa_gradcurv_prep_levels(ctx, nlev, state, comp, crse.data(), comp, bc, pmin, pmax));
-    for (int l = 0; l < nlev; ++l) PA_TRY(pa_gradcurv_level_cg(ctx, state[l], comp, pmin, pmax, out[l], ocomp));
+    PA_TRY(pa_gradcurv_levels_cg(ctx, nlev, state, comp, pmin, pmax, out, ocomp));
     PA_TRY(pa_gradcurv_fix_levels(ctx, nlev, state, comp, crse_n.data(), ocomp + 4, bc, pmin, pmax, out, ocomp + 4, ocomp + 7));
     return 0;
   }
@@ -540,7 +552,7 @@ extern "C" int pa_gradcurv_run_comps(pa_ctx* ctx, int nlev, pa_mf* const* state,
     double pmin, pmax;
     PA_TRY(prog_minmax(ctx, nlev, state, c, P, pmin, pmax));
     PA_TRY(pa_gradcurv_prep_levels(ctx, nlev, state, c, crse.data(), dist ? c - comp0 : c, bc, pmin, pmax));
-    for (int l = 0; l < nlev; ++l) PA_TRY(pa_gradcurv_level_cg(ctx, state[l], c, pmin, pmax, out[l], ocomp));
+    PA_TRY(pa_gradcurv_levels_cg(ctx, nlev, state, c, pmin, pmax, out, ocomp));
     if (dist) {
       std::vector<XJob> jobs;
       for (int l = 1; l < nlev; ++l) jobs.push_back({&cs[l]->x, out[l - 1], ocomp + 4, csn[l], 0, 3});

@@ -93,8 +93,8 @@ def _worker(rank, world, port, case):
             capi.gradcurv_run(ctx, lst, 0, bc, capi.curv_params(threshold=thr, fused=fused), work, out, 0)
             ctx.sync()
             assert ctx.bc_errors() == 0
-            if fused and not case.startswith("rand"):  # exchange A for every level at once; B at once (first pipeline) or per fine level (exact-normal)
-                assert comm.nexchange - n0 == (3 if case == "wide" else 2), "the fused pipeline batches its cross-rank traffic"
+            if fused and not case.startswith("rand"):  # exchange A for every level at once; B (the coarse normals) for every level at once
+                assert comm.nexchange - n0 == 2, "the fused pipeline batches its cross-rank traffic"
             check(out, {0: (og, 0), 1: (og, 1), 2: (og, 2), 3: (og, 3), 4: (oc, 2), 5: (oc, 3), 6: (oc, 4), 7: (oc, 1)}, f"gradcurv fused={fused}")
         # several components at once: exchange A carries all of them, one exchange (B) per component
         if case.startswith("rand"):
