@@ -856,7 +856,7 @@ int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, d
   if (mty == 13) hipLaunchKernelGGL(k_gradcurv_march3_levels<13>, grid, dim3(64 * 16), 0, ctx->stream, S);
   else if (mty == 8) hipLaunchKernelGGL(k_gradcurv_march3_levels<8>, grid, dim3(64 * 11), 0, ctx->stream, S);
   else hipLaunchKernelGGL(k_gradcurv_march3_levels<4>, grid, dim3(64 * 7), 0, ctx->stream, S);
-  ctx->sweep_kernel = "k_gradcurv_march3_levels<MTY=" + std::to_string(mty) + "> (" + std::to_string(S.n) + " levels per launch)";
+  ctx->sweep_kernel = "k_gradcurv_march3_levels<MTY=" + std::to_string(mty) + ">[" + std::to_string(S.n) + " levels per launch]";
   PA_HIP(hipGetLastError());
   return 0;
 }
