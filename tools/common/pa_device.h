@@ -52,8 +52,10 @@ struct PhaseTimer {
     ph.emplace_back(phase, t - tl);
     tl = t;
   }
-  ~PhaseTimer() {
+  ~PhaseTimer() { report(); }
+  void report() {  // once: at the end of main (before pa::Finish, which does not unwind) or from the destructor
     if (!on) return;
+    on = false;
     std::cout << "{\"tool\": \"" << tool << "\", \"cells\": " << cells << ", \"total_s\": " << now() - t0 << ", \"phases_s\": {";
     for (size_t i = 0; i < ph.size(); ++i) std::cout << (i ? ", " : "") << "\"" << ph[i].first << "\": " << ph[i].second;
     std::cout << "}}" << std::endl;

@@ -24,6 +24,15 @@ namespace pa {
   std::_Exit(134);
 }
 
+// Normal end of a tool: everything it writes has been written and closed.  Leaves without unwinding: tearing down the HIP
+// runtime, the device allocations and GBs of host buffers costs 0.1-0.3 s that produce nothing (the OS reclaims all of it).
+[[noreturn]] inline void Finish() {
+  std::cout.flush();
+  std::cerr.flush();
+  std::fflush(nullptr);
+  std::_Exit(0);
+}
+
 class ParmParse {
  public:
   ParmParse(int argc, char** argv) {

@@ -139,5 +139,6 @@ int main(int argc, char** argv) {
   pa::write_plotfile(pa::getFileRoot(infile) + "_filtered", names, doms, H.prob_lo, H.prob_hi, out, H.time, steps, 2, PA_SPACEDIM);
   tm.mark("write");
   std::cout << "Done!" << std::endl;
-  return 0;
+  tm.report();
+  pa::Finish();
 }

@@ -127,5 +127,6 @@ int main(int argc, char** argv) {
   std::vector<int> isteps(Nlev, 0);
   pa::write_plotfile(outfile, nnames, doms, H.prob_lo, H.prob_hi, state, 0.0, isteps, 2, PA_SPACEDIM, &ocomps);
   tm.mark("write");
-  return 0;
+  tm.report();
+  pa::Finish();
 }

@@ -477,5 +477,5 @@ int main(int argc, char** argv) {
     std::cout << "            ...done" << std::endl;
   }
   std::cout << "Surface output time: " << now() - strt_time_sout << '\n';  // :2232-2234
-  return 0;
+  pa::Finish();
 }
