@@ -16,7 +16,9 @@
 // The predicate sqrt(a*a + b*b + c*c) < 1e-15 of the host merge (tools/common/pa_isomerge.h) is evaluated as
 // (a*a + b*b + c*c) <= smax, smax = the largest double whose HOST square root is below 1e-15 (found once by the caller
 // side of this file with std::sqrt / std::nextafter), so no device sqrt rounding enters.
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 #include <cmath>
 #include "pa_internal.h"
 
@@ -182,13 +184,13 @@ extern "C" int pa_iso_merge(pa_ctx* ctx, int nfrag, const pa_iso_frag* frags, in
     return s;
   }();
   hipStream_t st = ctx->stream;
-  // cub temp sizes
+  // rocPRIM temporary storage
   size_t t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
-  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, t1, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (int*)nullptr, (int*)nullptr, (int)N, 0, 64, st);
-  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, t2, (int*)nullptr, (int*)nullptr, (int)std::max(N, M), st);
+  (void)rocprim::radix_sort_pairs(nullptr, t1, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (int*)nullptr, (int*)nullptr, (size_t)N, 0, 64, st);
+  (void)rocprim::exclusive_scan(nullptr, t2, (int*)nullptr, (int*)nullptr, 0, (size_t)std::max(N, M), rocprim::plus<int>(), st);
   if (M > 0) {
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, t3, (unsigned*)nullptr, (unsigned*)nullptr, (int*)nullptr, (int*)nullptr, (int)M, 0, 32, st);
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, t4, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (int*)nullptr, (int*)nullptr, (int)M, 0, 64, st);
+    (void)rocprim::radix_sort_pairs(nullptr, t3, (unsigned*)nullptr, (unsigned*)nullptr, (int*)nullptr, (int*)nullptr, (size_t)M, 0, 32, st);
+    (void)rocprim::radix_sort_pairs(nullptr, t4, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (int*)nullptr, (int*)nullptr, (size_t)M, 0, 64, st);
   }
   t5 = std::max(std::max(t1, t2), std::max(t3, t4));
   const size_t NN = (size_t)N, MM = (size_t)std::max<long long>(M, 1);
@@ -219,11 +221,11 @@ extern "C" int pa_iso_merge(pa_ctx* ctx, int nfrag, const pa_iso_frag* frags, in
   const dim3 gn((unsigned)((N + 255) / 256)), gm((unsigned)((std::max<long long>(M, 1) + 255) / 256)), blk(256);
   hipLaunchKernelGGL(k_im_keys, gn, blk, 0, st, T, N, P, hash, idx);
   size_t tb1 = t5;
-  IM_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tb1, hash, shash, idx, sidx, (int)N, 0, 64, st));  // stable: equal hashes stay in raw order
+  IM_HIP(rocprim::radix_sort_pairs(tmp, tb1, hash, shash, idx, sidx, (size_t)N, 0, 64, st));  // stable: equal hashes stay in raw order
   hipLaunchKernelGGL(k_im_probe, gn, blk, 0, st, N, P, shash, sidx, smax, dup);
   hipLaunchKernelGGL(k_im_flags, gn, blk, 0, st, N, dup, isnew, d_flag);
   tb1 = t5;
-  IM_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tb1, isnew, newid, (int)N, st));
+  IM_HIP(rocprim::exclusive_scan(tmp, tb1, isnew, newid, 0, (size_t)N, rocprim::plus<int>(), st));
   int h_flag = 0, h_lastid = 0, h_lastnew = 0;
   IM_HIP(hipMemcpyAsync(&h_flag, d_flag, 4, hipMemcpyDeviceToHost, st));
   IM_HIP(hipMemcpyAsync(&h_lastid, newid + (N - 1), 4, hipMemcpyDeviceToHost, st));
@@ -243,7 +245,7 @@ extern "C" int pa_iso_merge(pa_ctx* ctx, int nfrag, const pa_iso_frag* frags, in
   if (M > 0) {
     hipLaunchKernelGGL(k_im_elts, gm, blk, 0, st, T, M, nid, k01, k2, keep);
     tb1 = t5;
-    IM_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tb1, keep, pos, (int)M, st));
+    IM_HIP(rocprim::exclusive_scan(tmp, tb1, keep, pos, 0, (size_t)M, rocprim::plus<int>(), st));
     int lp = 0, lk = 0;
     IM_HIP(hipMemcpyAsync(&lp, pos + (M - 1), 4, hipMemcpyDeviceToHost, st));
     IM_HIP(hipMemcpyAsync(&lk, keep + (M - 1), 4, hipMemcpyDeviceToHost, st));
@@ -254,14 +256,14 @@ extern "C" int pa_iso_merge(pa_ctx* ctx, int nfrag, const pa_iso_frag* frags, in
       const dim3 g2((unsigned)((M2 + 255) / 256));
       // lexicographic order of (a, b, c): stable sort by c, then stable sort by (a, b)
       tb1 = t5;
-      IM_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tb1, c2, s2, cidx, perm1, (int)M2, 0, 32, st));
+      IM_HIP(rocprim::radix_sort_pairs(tmp, tb1, c2, s2, cidx, perm1, (size_t)M2, 0, 32, st));
       hipLaunchKernelGGL(k_im_gather01, g2, blk, 0, st, M2, perm1, c01, k01);  // k01 reused: (a, b) in c-order
       tb1 = t5;
       int* perm2 = cidx;  // reused
-      IM_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tb1, k01, s01, perm1, perm2, (int)M2, 0, 64, st));
+      IM_HIP(rocprim::radix_sort_pairs(tmp, tb1, k01, s01, perm1, perm2, (size_t)M2, 0, 64, st));
       hipLaunchKernelGGL(k_im_uniqflag, g2, blk, 0, st, M2, perm2, s01, c2, keep);
       tb1 = t5;
-      IM_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tb1, keep, pos, (int)M2, st));
+      IM_HIP(rocprim::exclusive_scan(tmp, tb1, keep, pos, 0, (size_t)M2, rocprim::plus<int>(), st));
       IM_HIP(hipMemcpyAsync(&lp, pos + (M2 - 1), 4, hipMemcpyDeviceToHost, st));
       IM_HIP(hipMemcpyAsync(&lk, keep + (M2 - 1), 4, hipMemcpyDeviceToHost, st));
       IM_HIP(hipStreamSynchronize(st));
