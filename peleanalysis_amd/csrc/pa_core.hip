@@ -598,6 +598,30 @@ __global__ void k_fill_boundary(LevBatch<FillArgs> Bt) {
     M.data[M.off[b] + fab_index(B, M.ng, M.ncomp, c, i, j, k)] = M.data[M.off[s] + fab_index(S, M.ng, M.ncomp, c, p[0], p[1], p[2])];
 }
 
+// the same copies from the level's region plan (pa_dist.h: FbLocal): blockIdx.y = level of the batch, blockIdx.x = its workgroup table
+struct FbrArgs { DLevelView L; DMFView M; const int* regs; const int* wgs; int nwg, comp, ncomp; };
+__global__ __launch_bounds__(256) void k_fill_boundary_regions(LevBatch<FbrArgs> Bt) {
+  const FbrArgs& Fa = Bt.a[blockIdx.y];
+  if ((int)blockIdx.x >= Fa.nwg) return;
+  const int* R = Fa.regs + 16 * Fa.wgs[2 * blockIdx.x];
+  const unsigned t = (unsigned)Fa.wgs[2 * blockIdx.x + 1] * 256u + threadIdx.x;
+  if (t >= (unsigned)R[11]) return;
+  const DMFView& M = Fa.M;
+  const DBox D = Fa.L.boxes[R[0]], S = Fa.L.boxes[R[1]];
+  const int ng = M.ng;
+  const unsigned r = R[5] == 1 ? t : __umulhi(t, (unsigned)R[12]), i = t - r * (unsigned)R[5];  // (ceil(2^32 / 1) does not fit)
+  const unsigned k = R[6] == 1 ? r : __umulhi(r, (unsigned)R[13]), j = r - k * (unsigned)R[6];
+  const int nxd = D.hi[0] - D.lo[0] + 1 + 2 * ng, nyd = D.hi[1] - D.lo[1] + 1 + 2 * ng, nzd = D.hi[2] - D.lo[2] + 1 + 2 * ng;
+  const int nxs = S.hi[0] - S.lo[0] + 1 + 2 * ng, nys = S.hi[1] - S.lo[1] + 1 + 2 * ng, nzs = S.hi[2] - S.lo[2] + 1 + 2 * ng;
+  const long long csd = pa_cstride((long long)nxd * nyd * nzd, M.ncomp), css = pa_cstride((long long)nxs * nys * nzs, M.ncomp);
+  // region origin inside the two FABs (wave-uniform), then the cell
+  const int dk = R[4] - D.lo[2] + ng, dj = R[3] - D.lo[1] + ng, di = R[2] - D.lo[0] + ng;
+  const int sk = R[4] - R[10] - S.lo[2] + ng, sj = R[3] - R[9] - S.lo[1] + ng, si = R[2] - R[8] - S.lo[0] + ng;
+  double* dst = M.data + M.off[R[0]] + (long long)Fa.comp * csd + ((long long)(dk + (int)k) * nyd + (dj + (int)j)) * nxd + (di + (int)i);
+  const double* src = M.data + M.off[R[1]] + (long long)Fa.comp * css + ((long long)(sk + (int)k) * nys + (sj + (int)j)) * nxs + (si + (int)i);
+  for (int c = 0; c < Fa.ncomp; ++c) dst[c * csd] = src[c * css];
+}
+
 int pa_fill_boundary_local_batch(pa_ctx* ctx, int n, pa_mf* const* Ms, int comp, int ncomp, int ng);
 static long long max_shell(const pa_level* L, int ng) {
   long long m = 0;
@@ -610,6 +634,31 @@ static long long max_shell(const pa_level* L, int ng) {
 
 // the local half of FillBoundary on several levels (same component range and ghost width) in as few launches as possible
 int pa_fill_boundary_local_batch(pa_ctx* ctx, int n, pa_mf* const* Ms, int comp, int ncomp, int ng) {
+  {  // copy regions when every level of the batch has a plan (pa_dist.hip)
+    bool regions = true;
+    std::vector<FbLocal*> plans(n, nullptr);
+    for (int i = 0; i < n && regions; ++i) {
+      if (Ms[i]->lev->boxes.empty()) continue;
+      plans[i] = pa_fb_local_plan(ctx, Ms[i]->lev, ng);
+      regions = plans[i] && plans[i]->ok;
+    }
+    if (regions) {
+      for (int i0 = 0; i0 < n; i0 += PA_MAXB) {
+        LevBatch<FbrArgs> Bt;
+        int mw = 0;
+        for (int i = i0; i < n && i < i0 + PA_MAXB; ++i) {
+          if (!plans[i] || plans[i]->nwg == 0) continue;
+          Bt.a[Bt.n] = FbrArgs{Ms[i]->lev->view, Ms[i]->view, plans[i]->d_regs, plans[i]->d_wgs, plans[i]->nwg, comp, ncomp};
+          ++Bt.n;
+          mw = std::max(mw, plans[i]->nwg);
+        }
+        if (!Bt.n) continue;
+        hipLaunchKernelGGL(k_fill_boundary_regions, dim3((unsigned)mw, (unsigned)Bt.n), dim3(256), 0, ctx->stream, Bt);
+      }
+      PA_HIP(hipGetLastError());
+      return 0;
+    }
+  }
   for (int i0 = 0; i0 < n; i0 += PA_MAXB) {
     LevBatch<FillArgs> Bt;
     long long ms = 0;

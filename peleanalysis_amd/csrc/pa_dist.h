@@ -36,6 +36,22 @@ struct CsPlan {
   ~CsPlan();
 };
 
+// The LOCAL half of FillBoundary as a list of copy regions (dst box, src box, region, shift), found once per level and
+// ghost width on the host, + one (region, chunk of 256 cells) entry per workgroup.  The per-cell form (k_fill_boundary:
+// shell index -> cell -> wrap -> owner map -> source box -> two 64-bit FAB indices) spent 150 vector + 170 scalar
+// instructions and three dependent loads on every 8 bytes it moved (SQ counters: 0.17 ms of its 0.33 ms on the headline were
+// VALU issue alone).  Here the geometry of a region is wave-uniform (scalar registers) and a cell costs two magic-number
+// divisions and two address sums.  ok = false (too many boxes for the host search, or a region too large for the 32-bit
+// magic division): the caller keeps the per-cell kernel.
+struct FbLocal {
+  bool ok = false;
+  int nreg = 0, nwg = 0;
+  int* d_regs = nullptr;   // [nreg][16]: dbox, sbox, lo[3] (dst index space), n[3], shift[3] (src cell = dst cell - shift), ncell, m0, m1, 0, 0
+  int* d_wgs = nullptr;    // [nwg][2]: region, chunk
+  ~FbLocal();
+};
+FbLocal* pa_fb_local_plan(pa_ctx* ctx, const pa_level* L, int ng);
+
 struct XJob { XPlan* plan; const pa_mf* src; int scomp; pa_mf* dst; int dcomp; int ncomp; };
 
 XPlan* pa_fb_plan(pa_ctx* ctx, const pa_level* L, int ng);

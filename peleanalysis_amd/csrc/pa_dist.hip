@@ -354,6 +354,49 @@ static int side_finish(pa_ctx* ctx, XSide& S, std::vector<std::pair<int, std::ar
 }
 static std::array<int32_t, 7> reg7(int box, const DBox& r) { return {box, r.lo[0], r.lo[1], r.lo[2], r.hi[0], r.hi[1], r.hi[2]}; }
 
+FbLocal::~FbLocal() {
+  if (d_regs) (void)hipFree(d_regs);
+  if (d_wgs) (void)hipFree(d_wgs);
+}
+FbLocal* pa_fb_local_plan(pa_ctx* ctx, const pa_level* L, int ng) {
+  auto it = L->fb_local.find(ng);
+  if (it != L->fb_local.end()) return it->second.get();
+  std::unique_ptr<FbLocal> P(new FbLocal());
+  FbLocal* raw = P.get();
+  L->fb_local[ng] = std::move(P);
+  const int n = (int)L->boxes.size();
+  static const int on = [] { const char* e = getenv("PA_FB_REGIONS"); return e ? atoi(e) : 1; }();
+  if (!on || n == 0 || n > 1024) return raw;  // the pair search below is O(n^2 x shifts)
+  const auto shifts = domain_shifts(L->domlo, L->domhi, L->is_per);
+  std::vector<int> regs, wgs;
+  for (int d = 0; d < n; ++d) {
+    const DBox G = bx_grow(L->boxes[d], ng);
+    for (int s = 0; s < n; ++s)
+      for (const auto& sh : shifts) {
+        if (s == d && sh[0] == 0 && sh[1] == 0 && sh[2] == 0) continue;
+        DBox I;
+        if (!bx_isect(G, bx_shift(L->boxes[s], sh.data()), I)) continue;
+        const long long n0 = I.hi[0] - I.lo[0] + 1, n1 = I.hi[1] - I.lo[1] + 1, n2 = I.hi[2] - I.lo[2] + 1, nc = n0 * n1 * n2;
+        if (nc >= (1LL << 21) || n0 >= 2048 || n1 >= 2048) return raw;  // q = umulhi(t, ceil(2^32 / d)) is exact for t d < 2^32
+        const int r = (int)(regs.size() / 16);
+        const unsigned m0 = (unsigned)(((1ULL << 32) + n0 - 1) / n0), m1 = (unsigned)(((1ULL << 32) + n1 - 1) / n1);
+        const int row[16] = {d, s, I.lo[0], I.lo[1], I.lo[2], (int)n0, (int)n1, (int)n2, sh[0], sh[1], sh[2], (int)nc, (int)m0, (int)m1, 0, 0};
+        regs.insert(regs.end(), row, row + 16);
+        for (int c = 0; c < (int)((nc + 255) / 256); ++c) { wgs.push_back(r); wgs.push_back(c); }
+      }
+  }
+  raw->nreg = (int)(regs.size() / 16);
+  raw->nwg = (int)(wgs.size() / 2);
+  if (raw->nreg > 0) {
+    if (hipMalloc(&raw->d_regs, sizeof(int) * regs.size()) != hipSuccess || hipMalloc(&raw->d_wgs, sizeof(int) * wgs.size()) != hipSuccess) return raw;
+    if (hipMemcpy(raw->d_regs, regs.data(), sizeof(int) * regs.size(), hipMemcpyHostToDevice) != hipSuccess) return raw;
+    if (hipMemcpy(raw->d_wgs, wgs.data(), sizeof(int) * wgs.size(), hipMemcpyHostToDevice) != hipSuccess) return raw;
+  }
+  (void)ctx;
+  raw->ok = true;
+  return raw;
+}
+
 XPlan* pa_fb_plan(pa_ctx* ctx, const pa_level* L, int ng) {
   auto it = L->fb_plans.find(ng);
   if (it != L->fb_plans.end()) return it->second.get();

@@ -145,6 +145,7 @@ struct pa_level {
   std::vector<int> glocal;         // local index of global box g, or -1
   bool source_only = false;        // coarse-source level (pa_dist.hip): no special faces, never swept
   mutable std::map<int, std::unique_ptr<struct XPlan>> fb_plans;                       // FillBoundary plans by ghost width
+  mutable std::map<int, std::unique_ptr<struct FbLocal>> fb_local;                     // local FillBoundary as copy regions, by ghost width (pa_dist.hip)
   mutable std::map<std::pair<long long, int>, std::unique_ptr<struct CsPlan>> cs_plans; // coarse-source plans by (coarse level serial, mode)
   ~pa_level();
 };

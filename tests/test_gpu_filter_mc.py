@@ -144,11 +144,13 @@ def test_marching_cubes_empty_and_all_masked(ctx, oracle):
         ctx.check(ctx.lib.pa_mc_emit_fab(ctx.h, bx, fs, fm, 3, iso, None, None, None, 0, 0))
 
 
-@pytest.mark.parametrize("name,ng", [("amr3_wall_z", 1), ("amr2_allwalls_ragged", 2), ("amr3_sym_x", 1)])
-def test_marching_cubes_level_batched_matches_oracle(ctx, oracle, name, ng):
+@pytest.mark.parametrize("name,ng,cells", [("amr3_wall_z", 1, "slab"), ("amr2_allwalls_ragged", 2, "slab"), ("amr3_sym_x", 1, "slab"), ("amr2_allwalls_ragged", 2, "tiles")])
+def test_marching_cubes_level_batched_matches_oracle(ctx, oracle, name, ng, cells, monkeypatch):
     """pa_iso_mask_level + pa_mc_level over every FAB of every level at once: the fine-covered mask, and per FAB
     the same vertices (bit for bit), edge keys and connectivity as the oracle's per-FAB Polygonise loop"""
     from util import build_config, make_states
+    if cells == "tiles":  # the first form of the cell pass (k_mcl_cells<8>): still what FABs wider than 819 cells take
+        monkeypatch.setenv("PA_MC_CELLS", "tiles")
     H, per, sym, fn = build_config(name)
     fields = make_states(H, 2, 0, fn, seed=11)
     nc = 5
