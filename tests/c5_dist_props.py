@@ -80,7 +80,8 @@ def run(rank, world, port, ncomp, outdir):
     capi.gradcurv_run_comps(ctx, states, 0, ncomp, capi.bc_from_flags((1, 1, 0)), params, works, [o[0] for o in outs], 0, done)
     ctx.sync()
     assert ctx.bc_errors() == 0
-    assert ctx.lib.pa_sweep_kernel_name(ctx.h).decode().endswith("CG=1>")
+    kn = ctx.lib.pa_sweep_kernel_name(ctx.h).decode()
+    assert kn.endswith("CG=1>") or kn.startswith("k_gradcurv_march3_levels<"), kn  # the exact-normal sweep, level by level or all levels in one launch
     if comm is not None:
         assert comm.nexchange == 1 + ncomp, (comm.nexchange, ncomp)  # exchange A once for all components + one exchange B per component
     keys = np.array(sorted(sums), dtype=np.int64).reshape(-1, 3)
