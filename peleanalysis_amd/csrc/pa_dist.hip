@@ -366,13 +366,39 @@ FbLocal* pa_fb_local_plan(pa_ctx* ctx, const pa_level* L, int ng) {
   L->fb_local[ng] = std::move(P);
   const int n = (int)L->boxes.size();
   static const int on = [] { const char* e = getenv("PA_FB_REGIONS"); return e ? atoi(e) : 1; }();
-  if (!on || n == 0 || n > 1024) return raw;  // the pair search below is O(n^2 x shifts)
+  if (!on || n == 0) return raw;
   const auto shifts = domain_shifts(L->domlo, L->domhi, L->is_per);
-  std::vector<int> regs, wgs;
+  std::vector<int> regs, wgs, cand;
+  // source boxes that can reach (G - shift): from the level's owner grid (cells of g^3), or all boxes when that grid is
+  // too fine to walk (ragged BoxArrays) and the level is small enough for the O(n^2) search
+  const DBox M = {{L->mlo[0], L->mlo[1], L->mlo[2]}, {L->mlo[0] + L->mn[0] * L->g - 1, L->mlo[1] + L->mn[1] * L->g - 1, L->mlo[2] + L->mn[2] * L->g - 1}};
+  auto candidates = [&](const DBox& Q) -> bool {
+    cand.clear();
+    DBox I;
+    if (!bx_isect(Q, M, I)) return true;
+    int c0[3], c1[3];
+    long long cells = 1;
+    for (int d = 0; d < 3; ++d) { c0[d] = (I.lo[d] - L->mlo[d]) / L->g; c1[d] = (I.hi[d] - L->mlo[d]) / L->g; cells *= c1[d] - c0[d] + 1; }
+    if (cells > 4096) return false;
+    for (int kz = c0[2]; kz <= c1[2]; ++kz)
+      for (int ky = c0[1]; ky <= c1[1]; ++ky)
+        for (int kx = c0[0]; kx <= c1[0]; ++kx) {
+          const int o = L->owner[((size_t)kz * L->mn[1] + ky) * L->mn[0] + kx];
+          if (o >= 0 && std::find(cand.begin(), cand.end(), o) == cand.end()) cand.push_back(o);
+        }
+    std::sort(cand.begin(), cand.end());  // (dst box, src box, shift) order, whatever the search
+    return true;
+  };
   for (int d = 0; d < n; ++d) {
     const DBox G = bx_grow(L->boxes[d], ng);
-    for (int s = 0; s < n; ++s)
-      for (const auto& sh : shifts) {
+    for (const auto& sh : shifts) {
+      const int neg[3] = {-sh[0], -sh[1], -sh[2]};
+      if (!candidates(bx_shift(G, neg))) {
+        if (n > 1024) return raw;
+        cand.resize(n);
+        std::iota(cand.begin(), cand.end(), 0);
+      }
+      for (int s : cand) {
         if (s == d && sh[0] == 0 && sh[1] == 0 && sh[2] == 0) continue;
         DBox I;
         if (!bx_isect(G, bx_shift(L->boxes[s], sh.data()), I)) continue;
@@ -384,6 +410,7 @@ FbLocal* pa_fb_local_plan(pa_ctx* ctx, const pa_level* L, int ng) {
         regs.insert(regs.end(), row, row + 16);
         for (int c = 0; c < (int)((nc + 255) / 256); ++c) { wgs.push_back(r); wgs.push_back(c); }
       }
+    }
   }
   raw->nreg = (int)(regs.size() / 16);
   raw->nwg = (int)(wgs.size() / 2);
