@@ -370,3 +370,17 @@ def test_gradcurv_run_comps_equals_component_by_component(ctx, oracle):
         for c in (1, 2, 3):
             for l in range(H.nlev):
                 assert np.array_equal(got[c][l].view(np.int64), want[c][l].view(np.int64)), (base, c, l)
+
+
+def test_switched_off_paths_still_match(ctx):
+    """the kernels the defaults no longer reach -- FillBoundary per ghost cell (PA_FB_REGIONS=0: still what a level takes
+    whose regions do not fit the plan) and the sweep level by level (PA_SWEEP_BATCH=0: levels of unequal tile variants) --
+    through the same oracle comparisons, in a child process (both switches are read once per process)"""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, PA_FB_REGIONS="0", PA_SWEEP_BATCH="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider",
+                        "-k", "ghost_fill_matches_oracle or exact_normal_pipeline or fused_matches_oracle"], env=env, capture_output=True, text=True,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
