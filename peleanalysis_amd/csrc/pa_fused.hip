@@ -739,7 +739,9 @@ bool pa_fused2_level_ok(const pa_level* L) {
 // before the sweeps: face ghosts of phi + resolved ghost c (faces and ring) of several levels, one launch pair for up to
 // PA_MAXB levels.  crse[l]: the coarser level's phi (component ccomp) or this rank's coarse-source copy of it, null on
 // level 0 / where this rank has no coarse-fine face; the local half of FillBoundary(2) must have run.
-int pa_gradcurv_prep_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int comp, const pa_mf* const* crse, int ccomp, const int32_t bc[3], double pmin, double pmax) {
+// phase: 1 = the faces (k_prep_faces: reads valid cells and coarse data only, so it may run NEXT TO FillBoundary), 2 = the
+// ring (k_prep_ring: reads ghost cells FillBoundary fills), 3 = both
+int pa_gradcurv_prep_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int comp, const pa_mf* const* crse, int ccomp, const int32_t bc[3], double pmin, double pmax, int phase) {
   for (int l0 = 0; l0 < nlev; l0 += PA_MAXB) {
     LevBatch<PrepLev> Bf, Br;
     long long ntf = 0, ntr = 0;
@@ -764,8 +766,8 @@ int pa_gradcurv_prep_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int comp, 
     }
     if (!Bf.n) continue;
     ProfScope prof(ctx, PA_TAG_BC);
-    hipLaunchKernelGGL(k_prep_faces, dim3((unsigned)((ntf + 255) / 256), (unsigned)Bf.ycum[Bf.n]), dim3(256), 0, ctx->stream, Bf, ctx->d_flags);
-    hipLaunchKernelGGL(k_prep_ring, dim3((unsigned)((ntr + 255) / 256), (unsigned)Br.ycum[Br.n]), dim3(256), 0, ctx->stream, Br, ctx->d_flags);
+    if (phase & 1) hipLaunchKernelGGL(k_prep_faces, dim3((unsigned)((ntf + 255) / 256), (unsigned)Bf.ycum[Bf.n]), dim3(256), 0, ctx->stream, Bf, ctx->d_flags);
+    if (phase & 2) hipLaunchKernelGGL(k_prep_ring, dim3((unsigned)((ntr + 255) / 256), (unsigned)Br.ycum[Br.n]), dim3(256), 0, ctx->stream, Br, ctx->d_flags);
   }
   PA_HIP(hipGetLastError());
   return 0;

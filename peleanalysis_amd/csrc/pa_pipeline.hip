@@ -14,7 +14,7 @@ int pa_fill_boundary_impl(pa_ctx* ctx, pa_mf* M, int comp, int ncomp, int ng, in
 // exact-normal pipeline (pa_fused.hip)
 bool pa_fused2_level_ok(const pa_level* L);
 int pa_fill_boundary_local_batch(pa_ctx* ctx, int n, pa_mf* const* Ms, int comp, int ncomp, int ng);
-int pa_gradcurv_prep_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int comp, const pa_mf* const* crse, int ccomp, const int32_t bc[3], double pmin, double pmax);
+int pa_gradcurv_prep_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int comp, const pa_mf* const* crse, int ccomp, const int32_t bc[3], double pmin, double pmax, int phase = 3);
 int pa_gradcurv_level_cg(pa_ctx* ctx, const pa_mf* phi, int pcomp, double pmin, double pmax, pa_mf* out, int ocomp);
 int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, double pmin, double pmax, pa_mf* const* out, int ocomp);
 int pa_gradcurv_fix_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, const pa_mf* const* crse_n, int cncomp0, const int32_t bc[3], double pmin, double pmax,
@@ -397,11 +397,36 @@ static int fused_passes(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, co
     // sweeps slowing from 1.94 to 2.15 ms -- they share the memory path -- so everything stays on one stream.)
     std::vector<const pa_mf*> crse(nlev, nullptr), crse_n(nlev, nullptr);
     for (int l = 1; l < nlev; ++l) { crse[l] = state[l - 1]; crse_n[l] = out[l - 1]; }
+    // k_prep_faces (latency bound: dependent lookups, 1.8 TB/s) runs on the side stream NEXT TO FillBoundary (bandwidth
+    // bound): it reads valid cells and coarse data and writes the ghost cells of special faces + the compact arrays, FillBoundary
+    // writes the ghost cells that are valid cells elsewhere -- disjoint on pure faces, which this pipeline requires.
+    // PA_PREP_OVERLAP=0: one stream.  Measured with tools/ab_driver.py (alternating blocks in one process): 6.588 against
+    // 6.642 ms per pass.  The same tool on the two other overlaps that look plausible: the perimeter fix-up kernel next to
+    // the interior one +0.009 ms (nothing), the fix-up of level l under the sweep of level l + 1 -0.21 ms (the sweep pays
+    // more than the fix-up hides) -- neither is kept.
+    const char* pove = getenv("PA_PREP_OVERLAP");  // read per pass: tools/ab_driver.py alternates it inside one process
+    const int pov = pove ? atoi(pove) : 1;
+    if (pov) {
+      if (!ctx->stream2) PA_HIP(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+      while (ctx->sync_evs.size() < 2) {
+        hipEvent_t e;
+        PA_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->sync_evs.push_back(e);
+      }
+      PA_HIP(hipEventRecord(ctx->sync_evs[0], ctx->stream));  // after everything already queued (the inputs, the previous pass)
+      PA_HIP(hipStreamWaitEvent(ctx->stream2, ctx->sync_evs[0], 0));
+      {
+        StreamSwap sw(ctx, ctx->stream2);
+        PA_TRY(pa_gradcurv_prep_levels(ctx, nlev, state, comp, crse.data(), comp, bc, pmin, pmax, 1));
+      }
+      PA_HIP(hipEventRecord(ctx->sync_evs[1], ctx->stream2));
+    }
     {
       ProfScope prof(ctx, PA_TAG_FILL);
       PA_TRY(pa_fill_boundary_local_batch(ctx, nlev, state, comp, 1, 2));
     }
-    PA_TRY(pa_gradcurv_prep_levels(ctx, nlev, state, comp, crse.data(), comp, bc, pmin, pmax));
+    if (pov) PA_HIP(hipStreamWaitEvent(ctx->stream, ctx->sync_evs[1], 0));
+    PA_TRY(pa_gradcurv_prep_levels(ctx, nlev, state, comp, crse.data(), comp, bc, pmin, pmax, pov ? 2 : 3));
     PA_TRY(pa_gradcurv_levels_cg(ctx, nlev, state, comp, pmin, pmax, out, ocomp));
     PA_TRY(pa_gradcurv_fix_levels(ctx, nlev, state, comp, crse_n.data(), ocomp + 4, bc, pmin, pmax, out, ocomp + 4, ocomp + 7));
     return 0;

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""A/B of an environment switch the library reads per pass, inside ONE process (the clock a box holds drifts by more than
+the effects worth measuring: alternate short blocks and compare medians).
+usage: ab_driver.py VAR [base=512] [box=128] [blocks=8] [steps=15]"""
+import os
+import statistics
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from peleanalysis_amd import capi  # noqa: E402
+from peleanalysis_amd.hierarchy import MultiFab, nested_hierarchy  # noqa: E402
+
+var = sys.argv[1]
+base = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+box = int(sys.argv[3]) if len(sys.argv) > 3 else 128
+blocks = int(sys.argv[4]) if len(sys.argv) > 4 else 8
+steps = int(sys.argv[5]) if len(sys.argv) > 5 else 15
+H = nested_hierarchy(base, 3, box, is_per=(1, 1, 0))
+bc = capi.bc_from_flags((1, 1, 0))
+ctx = capi.Context(0)
+dls = [capi.DevLevel(ctx, lv) for lv in H.levels]
+rng = np.random.default_rng(1)
+states, works, outs = [], [], []
+for lv, dl in zip(H.levels, dls):
+    s = MultiFab(lv, 1, 2)
+    s.data[:] = np.resize(300.0 + 1700.0 * rng.random(1 << 22), s.total)
+    states.append(capi.DevMF.from_host(ctx, dl, s))
+    works.append(capi.DevMF(ctx, dl, 1, 2))
+    outs.append(capi.DevMF(ctx, dl, 8, 0))
+params = capi.curv_params(prog_min=300.0, prog_max=2000.0, fused=True)
+
+
+def block(val):
+    os.environ[var] = val  # "1" vs "0": for a switch that is off by default, 0 is the current behaviour
+    capi.gradcurv_run(ctx, states, 0, bc, params, works, outs, 0)
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        capi.gradcurv_run(ctx, states, 0, bc, params, works, outs, 0)
+    ctx.sync()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+res = {"1": [], "0": []}
+for b in range(blocks):
+    for v in ("1", "0") if b % 2 == 0 else ("0", "1"):
+        res[v].append(block(v))
+for v in ("1", "0"):
+    print(f"{var}={v}: median {statistics.median(res[v]):.3f} ms/step  (min {min(res[v]):.3f}, max {max(res[v]):.3f}, {len(res[v])} blocks of {steps})")
+print(f"difference of medians (0 - 1): {statistics.median(res['0']) - statistics.median(res['1']):+.3f} ms")
