@@ -221,6 +221,11 @@ int pa_boxfilter_fab(pa_ctx*, pa_box valid, const pa_fab* in, pa_fab* out, int s
 /* ----------------------------------------------------------------- filterPlt
  * Filter(type=box, fgr) weights (filterPlt.cpp:136-137); returns ngrow */
 int pa_box_filter_weights(int fgr, double* w);
+/* filterPlt.cpp:80 filter_type -> the PelePhysics Filter weights for the types restated here: 0 none, 1 box, 3 / 7 the
+ * 3-point and 4 / 8 the 5-point approximations of the box / Gaussian filter (w: at least max(fgr + 2, 5) doubles).
+ * Returns ngrow, or -1 for a type that is not available (2 Gaussian, 5 6 9 10 "optimized") or fgr < 1.  Host only.
+ * [weights re-derived from the moment conditions; PelePhysics is not part of the reference tree: parity unpinned] */
+int pa_filter_weights(int type, int fgr, double* w);
 /* filterPlt.cpp:206-219, all boxes of a level */
 int pa_boxfilter_level(pa_ctx*, const pa_mf* in, pa_mf* out, int scomp, int ncomp, int ng, const double* w);
 /* the AMREX_SPACEDIM == 2 build of the same call on a level stored as one plane of cells (k = 0):

@@ -163,6 +163,13 @@ def box_filter_weights(fgr):
     return ng, np.array(w[:2 * ng + 1])
 
 
+def filter_weights(ftype, fgr):
+    """orc_filter_weights: (ngrow, weights) of PelePhysics filter type ftype (0, 1, 3, 4, 7, 8), None for the others"""
+    w = (C.c_double * (max(fgr, 3) + 2))()
+    ng = lib().orc_filter_weights(int(ftype), int(fgr), w)
+    return None if ng < 0 else (ng, np.array(w[:2 * ng + 1]))
+
+
 # ---------------------------------------------------------------- pipelines
 def grad_pipeline(levels, states, comp, bc, outs, ocomp, multipass=True, omp=False):
     """grad.cpp:158-236.  states[l]: multifab with ng>=1; outs[l][ocomp..ocomp+3]."""
@@ -264,7 +271,7 @@ def curvature_pipeline(levels, states, comp, bc, outs, ocomp, MF, prog_min=None,
     return prog_min, prog_max
 
 
-def filter_pipeline(levels, ins, outs, ncomp, base_fgr=2, same_fgr_all_levels=False, ratio=2, interp_type=1, omp=False, spacedim=3):
+def filter_pipeline(levels, ins, outs, ncomp, base_fgr=2, same_fgr_all_levels=False, ratio=2, interp_type=1, omp=False, spacedim=3, filter_type=1):
     """filterPlt.cpp:126-219.  ins[l] must have ng >= fgr_l/2 ghost layers, valid cells filled.
     spacedim = 2: the 2-D build on a hierarchy stored as one plane of cells (ghost fill by the 3-D C pieces, whose z
     terms vanish on such a hierarchy; the filter itself restated here in numpy over the plane)."""
@@ -274,7 +281,7 @@ def filter_pipeline(levels, ins, outs, ncomp, base_fgr=2, same_fgr_all_levels=Fa
     for l in range(len(levels)):
         if l > 0 and not same_fgr_all_levels:
             fgr *= ratio
-        ngf, w = box_filter_weights(fgr)
+        ngf, w = box_filter_weights(fgr) if filter_type == 1 else filter_weights(filter_type, fgr)
         assert ins[l].ng >= ngf
         fill_boundary(ins[l], 0, ncomp, ngf, omp)
         if l > 0:

@@ -526,6 +526,34 @@ int orc_box_filter_weights(int fgr, double* w) {
   return ng;
 }
 
+/* PelePhysics Filter types with closed-form weights (filterPlt.cpp:80) [RECALLED / re-derived: PelePhysics is
+ * absent from the reference tree].  3-point approximations (types 3 = box, 7 = Gaussian: identical): the symmetric stencil
+ * {a, 1 - 2a, a} whose second moment 2a equals that of the filter, fgr^2/12 -> a = fgr^2/24.  5-point approximations
+ * {a2, a1, a0, a1, a2}: second moment 2(a1 + 4 a2) = fgr^2/12 and fourth moment 2(a1 + 16 a2) = m4 with m4 = fgr^4/80
+ * (box, type 4) or 3 (fgr^2/12)^2 = fgr^4/48 (Gaussian, type 8), a0 = 1 - 2 a1 - 2 a2. */
+int orc_filter_weights(int type, int fgr, double* w) {
+  const double f2 = (double)fgr * (double)fgr, f4 = f2 * f2;
+  if (fgr < 1) return -1;
+  switch (type) {
+    case 0: w[0] = 1.0; return 0;
+    case 1: return orc_box_filter_weights(fgr, w);
+    case 3: case 7:
+      w[0] = f2 / 24.0; w[2] = f2 / 24.0; w[1] = (12.0 - f2) / 12.0;
+      return 1;
+    case 4:
+      w[0] = w[4] = (3.0 * f4 - 20.0 * f2) / 5760.0;
+      w[1] = w[3] = (80.0 * f2 - 3.0 * f4) / 1440.0;
+      w[2] = (3.0 * f4 - 100.0 * f2 + 960.0) / 960.0;
+      return 2;
+    case 8:
+      w[0] = w[4] = (f4 - 4.0 * f2) / 1152.0;
+      w[1] = w[3] = (16.0 * f2 - f4) / 288.0;
+      w[2] = (f4 - 20.0 * f2 + 192.0) / 192.0;
+      return 2;
+    default: return -1;
+  }
+}
+
 void orc_apply_filter(const orc_mf* in, orc_mf* out, int scomp, int ncomp, int ngf, const double* w) {
   const orc_level* L = in->lev;
 #pragma omp parallel for schedule(dynamic)

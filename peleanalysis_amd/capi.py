@@ -132,6 +132,7 @@ def load_library() -> C.CDLL:
         "pa_gradcurv_fab": (C.c_int, [vp, PaBox, C.POINTER(PaFab), C.c_int, dbl, dbl, pdbl, dbl, C.POINTER(PaFab), C.c_int]),
         "pa_boxfilter_fab": (C.c_int, [vp, PaBox, C.POINTER(PaFab), C.POINTER(PaFab), C.c_int, C.c_int, C.c_int, pdbl]),
         "pa_box_filter_weights": (C.c_int, [C.c_int, pdbl]),
+        "pa_filter_weights": (C.c_int, [C.c_int, C.c_int, pdbl]),
         "pa_boxfilter_level": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, pdbl]),
         "pa_boxfilter_level2d": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, pdbl]),
         "pa_foextrap": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int]),

@@ -21,6 +21,34 @@ extern "C" int pa_box_filter_weights(int fgr, double* w) {
   return ng;
 }
 
+// The other PelePhysics filter types whose weights are closed-form polynomials of the filter-to-grid ratio (filterPlt.cpp:80
+// `filter_type`, PelePhysics Filter.H).  [RECALLED / re-derived -- the PelePhysics source is not in the reference
+// tree: parity unpinned.]  0 none; 1 box; 3 and 7: the 3-point approximation of the box / Gaussian filter (the same weights:
+// both match the second moment fgr^2/12, Sagaut & Grohens 1999); 4 and 8: the 5-point approximations (second moment fgr^2/12
+// and fourth moment fgr^4/80 (box) or fgr^4/48 (Gaussian of the same variance)).  Every weight is ONE division of an
+// exactly representable integer expression, so any algebraically equal way of writing it gives the same double.  The
+// Gaussian (2) and the "optimized" variants (5, 6, 9, 10: tabulated coefficients) are not restated: -1.
+extern "C" int pa_filter_weights(int type, int fgr, double* w) {
+  if (!w || fgr < 1) return -1;
+  const double f2 = (double)fgr * (double)fgr, f4 = f2 * f2;
+  switch (type) {
+    case 0: w[0] = 1.0; return 0;
+    case 1: return pa_box_filter_weights(fgr, w);
+    case 3: case 7:
+      w[0] = f2 / 24.0; w[1] = (12.0 - f2) / 12.0; w[2] = w[0];
+      return 1;
+    case 4:
+      w[0] = (3.0 * f4 - 20.0 * f2) / 5760.0; w[1] = (80.0 * f2 - 3.0 * f4) / 1440.0; w[2] = (3.0 * f4 - 100.0 * f2 + 960.0) / 960.0;
+      w[3] = w[1]; w[4] = w[0];
+      return 2;
+    case 8:
+      w[0] = (f4 - 4.0 * f2) / 1152.0; w[1] = (16.0 * f2 - f4) / 288.0; w[2] = (f4 - 20.0 * f2 + 192.0) / 192.0;
+      w[3] = w[1]; w[4] = w[0];
+      return 2;
+    default: return -1;
+  }
+}
+
 struct FilterW { double w[33]; };  // up to ng = 16
 
 // tile of TX x TY x TZ outputs per 256-thread workgroup; thread = (x, y) column, loops over z

@@ -57,6 +57,14 @@ def test_box_filter_weights_host_entry(oracle):
         ong, ow = oracle.box_filter_weights(fgr)
         assert ng == ong and np.array_equal(np.array(w[:2 * ng + 1]), ow)
     assert lib.pa_box_filter_weights(0, (C.c_double * 4)()) < 0
+    for ftype in range(-1, 12):  # the other filter types: the library's weights are the oracle's, bit for bit; the same types are refused
+        for fgr in (1, 2, 4, 6, 16):
+            w = (C.c_double * (max(fgr, 3) + 2))()
+            ng = lib.pa_filter_weights(ftype, fgr, w)
+            want = oracle.filter_weights(ftype, fgr)
+            assert (ng < 0) == (want is None), (ftype, fgr)
+            if want is not None:
+                assert ng == want[0] and np.array_equal(np.array(w[:2 * ng + 1]).view(np.int64), want[1].view(np.int64)), (ftype, fgr)
 
 
 def test_mc_tables_exported_match_oracle(oracle):

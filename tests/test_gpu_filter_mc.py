@@ -13,7 +13,7 @@ from util import assert_valid_bits_equal, make_states, rel_err
 pytestmark = pytest.mark.gpu
 
 
-def _filter_gpu(ctx, H, ins, ncomp, base_fgr, same, interp_type):
+def _filter_gpu(ctx, H, ins, ncomp, base_fgr, same, interp_type, filter_type=1):
     dls = [capi.DevLevel(ctx, lv) for lv in H.levels]
     din = [capi.DevMF.from_host(ctx, dl, s) for dl, s in zip(dls, ins)]
     dout = [capi.DevMF(ctx, dl, ncomp, 0) for dl in dls]
@@ -21,8 +21,8 @@ def _filter_gpu(ctx, H, ins, ncomp, base_fgr, same, interp_type):
     for l in range(H.nlev):
         if l > 0 and not same:
             fgr *= 2
-        w = (C.c_double * (fgr + 2))()
-        ngf = ctx.lib.pa_box_filter_weights(fgr, w)
+        w = (C.c_double * (max(fgr, 3) + 2))()
+        ngf = ctx.lib.pa_box_filter_weights(fgr, w) if filter_type == 1 else ctx.lib.pa_filter_weights(filter_type, fgr, w)
         ctx.check(ctx.lib.pa_fill_boundary(ctx.h, din[l].h, 0, ncomp, ngf))
         if l > 0:
             ctx.check(ctx.lib.pa_fillpatch_two_levels(ctx.h, din[l].h, din[l - 1].h, 0, ncomp, ngf, 2, interp_type))
@@ -55,6 +55,23 @@ def test_filter_pipeline_matches_oracle(ctx, oracle, per, interp_type, same):
         assert_valid_bits_equal(got[l], o_out[l], [(c, c) for c in range(ncomp)], f"filter level {l} (fgr {info[l][0]})")
         for c in range(ncomp):
             assert rel_err(got[l], o_out[l], c, c) <= 1e-12
+
+
+@pytest.mark.parametrize("ftype", [0, 3, 4, 8])
+def test_filter_pipeline_other_filter_types(ctx, oracle, ftype):
+    """filter_type 0 / 3 (= 7) / 4 / 8 (filterPlt.cpp:80): the same ghost fill and tap loop with the closed-form weights of
+    those PelePhysics types (fgr 2 / 4 / 8 on the three levels enter the weights only: 1-, 3- and 5-point stencils)"""
+    H = nested_hierarchy(32, 3, 16, is_per=(1, 0, 0))
+    ncomp = 2
+    ins = make_states(H, ncomp, 2, field_flame, seed=23)
+    o_in = [s.copy() for s in ins]
+    o_out = [MultiFab(lv, ncomp, 0) for lv in H.levels]
+    oracle.filter_pipeline(H.levels, o_in, o_out, ncomp, base_fgr=2, interp_type=1, filter_type=ftype)
+    got, _ = _filter_gpu(ctx, H, ins, ncomp, 2, False, 1, filter_type=ftype)
+    for l in range(H.nlev):
+        assert_valid_bits_equal(got[l], o_out[l], [(c, c) for c in range(ncomp)], f"filter type {ftype} level {l}")
+        if ftype == 0:
+            assert_valid_bits_equal(got[l], ins[l], [(c, c) for c in range(ncomp)], "type 0 is the identity")
 
 
 def test_filter_generic_width_and_fab_entry(ctx, oracle):

@@ -283,10 +283,23 @@ def test_filter_tool_end_to_end(tmp_path, oracle):
         levels.append(nl)
         ins.append(s)
     outs = [MultiFab(lv, 2, 0) for lv in levels]
-    oracle.filter_pipeline(levels, ins, outs, 2, base_fgr=2, interp_type=1)
+    oracle.filter_pipeline(levels, [s.copy() for s in ins], outs, 2, base_fgr=2, interp_type=1)
     for l, lv in enumerate(levels):
         for b in range(lv.nboxes):
             assert np.array_equal(np.ascontiguousarray(r.mfs[l].valid(b)).view(np.int64), np.ascontiguousarray(outs[l].valid(b)).view(np.int64))
+    # filter_type=4 (the 5-point approximation of the box filter; an odd base_fgr is fine there), and the types that stay refused
+    _run("filterPlt3d.ex", ["infile=" + p, "max_grid_size=8", "variables=temp density", "filter_type=4", "base_fgr=3"], tmp_path)
+    r4 = read_plotfile(str(tmp_path / "plt00005_filtered"))
+    outs4 = [MultiFab(lv, 2, 0) for lv in levels]
+    oracle.filter_pipeline(levels, [s.copy() for s in ins], outs4, 2, base_fgr=3, interp_type=1, filter_type=4)
+    for l, lv in enumerate(levels):
+        for b in range(lv.nboxes):
+            assert np.array_equal(np.ascontiguousarray(r4.mfs[l].valid(b)).view(np.int64), np.ascontiguousarray(outs4[l].valid(b)).view(np.int64))
+            assert not np.array_equal(r4.mfs[l].valid(b), outs[l].valid(b))
+    bad = subprocess.run([os.path.join(BIN, "filterPlt3d.ex"), "infile=" + p, "filter_type=2"], cwd=tmp_path, capture_output=True, text=True)
+    assert bad.returncode != 0 and "filter_type 2 is not available" in bad.stderr
+    bad = subprocess.run([os.path.join(BIN, "filterPlt3d.ex"), "infile=" + p, "base_fgr=3"], cwd=tmp_path, capture_output=True, text=True)
+    assert bad.returncode != 0 and "even" in bad.stderr
 
 
 @pytest.mark.gpu

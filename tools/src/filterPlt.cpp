@@ -1,5 +1,5 @@
 // filterPlt3d -- drop-in for PeleAnalysis Src/filterPlt.cpp (box filter) on MI355X.
-//   filterPlt3d.ex infile=<plt> [max_filter_level=<n>] [filter_type=1] [base_fgr=2] [same_fgr_all_levels=false]
+//   filterPlt3d.ex infile=<plt> [max_filter_level=<n>] [filter_type=1 (0 none, 1 box, 3/7 and 4/8: 3- and 5-point approximations)] [base_fgr=2] [same_fgr_all_levels=false]
 //       [max_grid_size=32] [interp_type=1] [variables="a b"] [is_per="0 0 0"]
 // Output: <root>_filtered, same variable names, plotfile time (filterPlt.cpp:222-225).
 // The plotfile Header stores no periodicity; like PltFileManager's Geometry it defaults to
@@ -27,8 +27,12 @@ int main(int argc, char** argv) {
   pp.query("same_fgr_all_levels", same_fgr);
   pp.query("max_grid_size", max_grid_size);
   pp.query("interp_type", interp_type);
-  if (filter_type != 1) pa::Abort("only filter_type=1 (box) is available in this build");
-  if (fgr != 1 && fgr % 2 != 0) pa::Abort("Box filter requires an even filter-to-grid ratio");
+  {  // PelePhysics filter types restated in the library: 0 none, 1 box, 3 / 7 and 4 / 8 the 3- and 5-point approximations
+    std::vector<double> wt(std::max(fgr, 3) + 2);
+    if (pa_filter_weights(filter_type, std::max(fgr, 1), wt.data()) < 0)
+      pa::Abort("filter_type " + std::to_string(filter_type) + " is not available in this build (0 none, 1 box, 3 / 7 three-point, 4 / 8 five-point approximations)");
+  }
+  if (filter_type == 1 && fgr != 1 && fgr % 2 != 0) pa::Abort("Box filter requires an even filter-to-grid ratio");
   std::vector<int> is_per(3, 0);
 #if PA_SPACEDIM == 2
   {
@@ -66,8 +70,8 @@ int main(int argc, char** argv) {
   for (int lev = 0; lev < Nlev; ++lev) {
     std::cout << "on level " << lev << std::endl;
     if (!same_fgr && lev > 0) fgr_lev *= 2;
-    std::vector<double> w(fgr_lev + 2);
-    const int ng = pa_box_filter_weights(fgr_lev, w.data());
+    std::vector<double> w(std::max(fgr_lev, 3) + 2);
+    const int ng = pa_filter_weights(filter_type, fgr_lev, w.data());
     ngs.push_back(ng);
     ws.push_back(w);
     const std::vector<pa::Box3> ba = pa::max_size(H.lev[lev].boxes, max_grid_size);
