@@ -148,9 +148,10 @@ int main(int argc, char** argv) {
   // per rank and level: the fragments of its FABs as they came off the device (ngpus > 1: merged afterwards in BoxArray order)
   struct LevFrag { std::vector<int> gids; std::vector<int64_t> nvb, ntb; std::vector<double> hva; std::vector<int32_t> hta, hka; double* dv = nullptr; int32_t *dk = nullptr, *dt = nullptr; };
   std::vector<std::vector<LevFrag>> frags(team.n, std::vector<LevFrag>(Nlev));
-  // one GPU, no per-FAB trimming, no distance function: the node / element sets are built on the device from the fragments
-  // where they lie (pa_iso_merge); the fragments are only downloaded if the library hands the merge back (PA_ISO_HOST_MERGE=1 forces that path)
-  bool dev_merge = team.n == 1 && !build_distance_function && !std::getenv("PA_ISO_HOST_MERGE");
+  // no per-FAB trimming, no distance function: the node / element sets are built on the device (pa_iso_merge) from the
+  // fragments where pa_mc_level_fine left them (ngpus > 1: the other ranks' fragments are first copied to GPU 0); they are
+  // only downloaded if the library hands the merge back (PA_ISO_HOST_MERGE=1 forces the host path)
+  bool dev_merge = !build_distance_function && !std::getenv("PA_ISO_HOST_MERGE");
   for (int lev = 0; lev < Nlev; ++lev) dev_merge = dev_merge && !(rm_external_elements && nGrow[lev] > 1);
   team.run([&](int r) {
   pa::Ctx& ctx = *team.ctx[r];
@@ -313,7 +314,7 @@ int main(int argc, char** argv) {
     }
   }
   });
-  if (team.n > 1) {  // BoxArray order = the 1-rank ordering (isosurface.cpp:1531: MFIter over the level's FABs)
+  if (team.n > 1 && !dev_merge) {  // BoxArray order = the 1-rank ordering (isosurface.cpp:1531: MFIter over the level's FABs)
     tq = now();
     for (int lev = 0; lev < Nlev; ++lev) {
       std::vector<std::pair<int, int>> where(H.lev[lev].boxes.size());  // global box -> (rank, local index)
@@ -337,12 +338,41 @@ int main(int argc, char** argv) {
   if (dev_merge) {
     tq = now();
     pa::Ctx& ctx = *team.ctx[0];
+    // every rank's level blocks on GPU 0 (rank 0's are there already): vertices and triangles, keys are not needed
+    std::vector<std::vector<const double*>> bv(team.n, std::vector<const double*>(Nlev, nullptr));
+    std::vector<std::vector<const int32_t*>> bt(team.n, std::vector<const int32_t*>(Nlev, nullptr));
+    std::vector<void*> copies;
+    for (int r = 0; r < team.n; ++r)
+      for (int lev = 0; lev < Nlev; ++lev) {
+        const LevFrag& F = frags[r][lev];
+        int64_t nvt = 0, ntt = 0;
+        for (size_t b = 0; b < F.nvb.size(); ++b) { nvt += F.nvb[b]; ntt += F.ntb[b]; }
+        if (r == 0 || nvt == 0) { bv[r][lev] = F.dv; bt[r][lev] = F.dt; continue; }
+        const int64_t vbytes = (nvt * nc * 8 + 255) / 256 * 256, tbytes = std::max<int64_t>(ntt * 12, 8);
+        char* c = (char*)pa_device_malloc(ctx.h, vbytes + tbytes);
+        if (!c) pa::Abort(pa_last_error(ctx.h));
+        ctx.check(pa_memcpy_d2d(ctx.h, c, F.dv, nvt * nc * 8));
+        if (ntt > 0) ctx.check(pa_memcpy_d2d(ctx.h, c + vbytes, F.dt, ntt * 12));
+        bv[r][lev] = (const double*)c; bt[r][lev] = (const int32_t*)(c + vbytes);
+        copies.push_back(c);
+      }
+    // insertion order of isosurface.cpp:1531-1726: level by level, FAB by FAB in BoxArray order (= the 1-rank ordering), FABs without elements skipped (:1595)
+    struct FragAt { int lev, r; size_t i; int64_t vo, to; };
+    std::vector<FragAt> order;
+    for (int lev = 0; lev < Nlev; ++lev) {
+      std::vector<FragAt> at(H.lev[lev].boxes.size(), FragAt{lev, -1, 0, 0, 0});
+      for (int r = 0; r < team.n; ++r) {
+        const LevFrag& F = frags[r][lev];
+        int64_t vo = 0, to = 0;
+        for (size_t i = 0; i < F.gids.size(); vo += F.nvb[i], to += F.ntb[i], ++i) at[F.gids[i]] = FragAt{lev, r, i, vo, to};
+      }
+      for (const FragAt& a : at)
+        if (a.r >= 0 && frags[a.r][lev].ntb[a.i] > 0) order.push_back(a);
+    }
     std::vector<pa_iso_frag> fr;
-    for (int lev = 0; lev < Nlev; ++lev) {  // insertion order of isosurface.cpp:1531-1726: level by level, FAB by FAB, FABs without elements skipped (:1595)
-      const LevFrag& F = frags[0][lev];
-      int64_t vo = 0, to = 0;
-      for (size_t b = 0; b < F.nvb.size(); vo += F.nvb[b], to += F.ntb[b], ++b)
-        if (F.ntb[b] > 0) fr.push_back(pa_iso_frag{F.dv + vo * nc, F.nvb[b], F.dt + 3 * to, F.ntb[b]});
+    for (const FragAt& a : order) {
+      const LevFrag& F = frags[a.r][a.lev];
+      fr.push_back(pa_iso_frag{bv[a.r][a.lev] + a.vo * nc, F.nvb[a.i], bt[a.r][a.lev] + 3 * a.to, F.ntb[a.i]});
     }
     int64_t nn = 0, ne = 0;
     double* dn = nullptr;
@@ -358,24 +388,22 @@ int main(int argc, char** argv) {
     } else if (rc == 2) {  // clusters that are not transitive under the tolerance: the sequential rule decides (host)
       if (verbose) std::cout << "  " << pa_last_error(ctx.h) << std::endl;
       dev_merge = false;
-      for (int lev = 0; lev < Nlev; ++lev) {
-        LevFrag& F = frags[0][lev];
-        int64_t nvt = 0, ntt = 0;
-        for (size_t b = 0; b < F.nvb.size(); ++b) { nvt += F.nvb[b]; ntt += F.ntb[b]; }
-        F.hva.resize((size_t)(nvt * nc)); F.hta.resize((size_t)(ntt * 3)); F.hka.resize((size_t)(nvt * 6));
-        if (nvt > 0) {
-          ctx.check(pa_memcpy_d2h(ctx.h, F.hva.data(), F.dv, nvt * nc * 8));
-          ctx.check(pa_memcpy_d2h(ctx.h, F.hka.data(), F.dk, nvt * 6 * 4));
-        }
-        if (ntt > 0) ctx.check(pa_memcpy_d2h(ctx.h, F.hta.data(), F.dt, ntt * 3 * 4));
-        int64_t vo = 0, to = 0;
-        for (size_t b = 0; b < F.nvb.size(); vo += F.nvb[b], to += F.ntb[b], ++b)
-          if (F.ntb[b] > 0) merge_box(H.lev[lev].boxes[b], nGrow[lev], F.nvb[b], F.ntb[b], F.hva.data() + vo * nc, F.hka.data() + vo * 6, F.hta.data() + to * 3);
+      std::vector<double> fv;
+      std::vector<int32_t> ft, fk;
+      for (const FragAt& a : order) {
+        const LevFrag& F = frags[a.r][a.lev];
+        const int64_t nv = F.nvb[a.i], nt = F.ntb[a.i];
+        fv.resize((size_t)(nv * nc)); ft.resize((size_t)(nt * 3)); fk.assign((size_t)(nv * 6), 0);  // keys: only read by the trimming, which this path excludes
+        ctx.check(pa_memcpy_d2h(ctx.h, fv.data(), bv[a.r][a.lev] + a.vo * nc, nv * nc * 8));
+        ctx.check(pa_memcpy_d2h(ctx.h, ft.data(), bt[a.r][a.lev] + 3 * a.to, nt * 12));
+        merge_box(H.lev[a.lev].boxes[F.gids[a.i]], 1, nv, nt, fv.data(), fk.data(), ft.data());
       }
     } else {
       pa::Abort(pa_last_error(ctx.h));
     }
-    for (int lev = 0; lev < Nlev; ++lev) pa_device_free(ctx.h, frags[0][lev].dv);
+    for (void* c : copies) pa_device_free(ctx.h, c);
+    for (int r = 0; r < team.n; ++r)
+      for (int lev = 0; lev < Nlev; ++lev) pa_device_free(team.ctx[r]->h, frags[r][lev].dv);
     t_merge += now() - tq;
   }
   if (build_distance_function) {  // isosurface.cpp:1731-1748
