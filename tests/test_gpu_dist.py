@@ -138,8 +138,11 @@ def _worker(rank, world, port, case):
         dist.destroy_process_group()
 
 
+_HUNT = int(os.environ.get("PA_DIST_RANDOM_SEEDS", "0"))  # PA_DIST_RANDOM_SEEDS=30: that many more random draws (a longer hunt)
+
+
 @pytest.mark.parametrize("world,case", [(2, "scatter"), (4, "scatter"), (4, "thr"), (2, "sym"), (4, "sfc"), (4, "wide"), (2, "wide"), (3, "rand2"), (4, "rand5"),
-                                        (3, "rand11"), (3, "randw1"), (4, "randw4")])
+                                        (3, "rand11"), (3, "randw1"), (4, "randw4")] + [(2 + s % 3, ("randw" if s % 4 == 3 else "rand") + str(20 + s)) for s in range(_HUNT)])
 def test_sharded_hierarchy_on_shared_gpu_matches_undistributed_oracle(world, case):
     import torch.multiprocessing as mp
     mp.spawn(_worker, args=(world, _free_port(), case), nprocs=world, join=True)
