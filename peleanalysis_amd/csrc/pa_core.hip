@@ -325,10 +325,21 @@ pa_level* pa_level_create_spec(pa_ctx* ctx, const LevelSpec& S, const int32_t do
   long long ncode = 0;
   L->cgoff.assign(nsf_alloc, 0);
   L->cg_total = 0;
+  std::vector<long long> cpoff(nsf_alloc, -1);  // coarse patches (DLevelView::cp): faces inside the domain or behind a periodic side
+  L->cp_total = 0;
   for (size_t e = 0; e < L->sfaces.size(); ++e) {
     const int f = L->sfaces[e];
     const DBox& B = L->boxes[f / 6];
     const int d = (f % 6) >> 1, t0 = (d == 0) ? 1 : 0, t1 = (d == 2) ? 1 : 2;
+    {
+      const int side = f & 1, qd = side ? B.hi[d] + 1 : B.lo[d] - 1;
+      if (L->is_per[d] || (qd >= L->domlo[d] && qd <= L->domhi[d])) {
+        int plane, u0, v0, pw, ph;
+        cpatch_geom(B, d, side, plane, u0, v0, pw, ph);
+        cpoff[e] = L->cp_total;
+        L->cp_total += ((long long)pw * ph + 7) / 8 * 8;
+      }
+    }
     sfindex[f] = (int)e;
     sfoff[e] = ncode;
     ncode += (long long)(B.hi[t0] - B.lo[t0] + 1) * (B.hi[t1] - B.lo[t1] + 1);
@@ -340,6 +351,8 @@ pa_level* pa_level_create_spec(pa_ctx* ctx, const LevelSpec& S, const int32_t do
       (!L->sfaces.empty() && hipMemcpy(L->d_sfaces, L->sfaces.data(), sizeof(int) * L->sfaces.size(), hipMemcpyHostToDevice) != hipSuccess) ||
       hipMalloc(&L->d_sfindex, sizeof(int) * std::max<size_t>(sfindex.size(), 1)) != hipSuccess ||
       (!sfindex.empty() && hipMemcpy(L->d_sfindex, sfindex.data(), sizeof(int) * sfindex.size(), hipMemcpyHostToDevice) != hipSuccess) ||
+      hipMalloc(&L->d_cpoff, sizeof(long long) * nsf_alloc) != hipSuccess ||
+      hipMemcpy(L->d_cpoff, cpoff.data(), sizeof(long long) * nsf_alloc, hipMemcpyHostToDevice) != hipSuccess ||
       hipMalloc(&L->d_cgoff, sizeof(long long) * nsf_alloc) != hipSuccess ||
       hipMemcpy(L->d_cgoff, L->cgoff.data(), sizeof(long long) * nsf_alloc, hipMemcpyHostToDevice) != hipSuccess ||
       hipMalloc(&L->d_sfoff, sizeof(long long) * nsf_alloc) != hipSuccess ||
@@ -355,6 +368,7 @@ pa_level* pa_level_create_spec(pa_ctx* ctx, const LevelSpec& S, const int32_t do
     if (L->d_sfindex) (void)hipFree(L->d_sfindex);
     if (L->d_sfoff) (void)hipFree(L->d_sfoff);
     if (L->d_cgoff) (void)hipFree(L->d_cgoff);
+    if (L->d_cpoff) (void)hipFree(L->d_cpoff);
     if (L->d_sfcode) (void)hipFree(L->d_sfcode);
     delete L;
     return nullptr;
@@ -362,6 +376,8 @@ pa_level* pa_level_create_spec(pa_ctx* ctx, const LevelSpec& S, const int32_t do
   DLevelView& V = L->view;
   V.cgoff = L->d_cgoff;
   V.cg = nullptr;
+  V.cpoff = L->d_cpoff;
+  V.cp = nullptr;
   V.sfindex = L->d_sfindex;
   V.sfoff = L->d_sfoff;
   V.sfcode = L->d_sfcode;
@@ -396,6 +412,8 @@ extern "C" void pa_level_destroy(pa_level* L) {
   if (L->d_sfoff) (void)hipFree(L->d_sfoff);
   if (L->d_cgoff) (void)hipFree(L->d_cgoff);
   if (L->d_cg) (void)hipFree(L->d_cg);
+  if (L->d_cpoff) (void)hipFree(L->d_cpoff);
+  if (L->d_cp) (void)hipFree(L->d_cp);
   if (L->d_sfcode) (void)hipFree(L->d_sfcode);
   if (L->d_boxes) (void)hipFree(L->d_boxes);
   if (L->d_owner) (void)hipFree(L->d_owner);

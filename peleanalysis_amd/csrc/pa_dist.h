@@ -52,6 +52,19 @@ struct FbLocal {
 };
 FbLocal* pa_fb_local_plan(pa_ctx* ctx, const pa_level* L, int ng);
 
+// The gather of a fine level's coarse patches (DLevelView::cp) from one coarse level as copy regions: (special face, coarse
+// box, rectangle) found once on the host, + one (region, chunk of 256 cells) entry per workgroup.  Patch cells no coarse box
+// covers keep the "missing" pattern the patch buffer is filled with when it is allocated.  ok = false: k_cpatch (owner map
+// per cell) does the gather.
+struct CpPlan {
+  bool ok = false;
+  int nreg = 0, nwg = 0;
+  int* d_regs = nullptr;   // [nreg][12]: face entry, coarse box, patch-local origin (pu, pv), coarse cell of that origin [3], nu, nv, dir, m (magic of nu), 0
+  int* d_wgs = nullptr;    // [nwg][2]: region, chunk
+  ~CpPlan();
+};
+CpPlan* pa_cp_plan(pa_ctx* ctx, const pa_level* F, const pa_level* C);
+
 struct XJob { XPlan* plan; const pa_mf* src; int scomp; pa_mf* dst; int dcomp; int ncomp; };
 
 XPlan* pa_fb_plan(pa_ctx* ctx, const pa_level* L, int ng);

@@ -424,6 +424,75 @@ FbLocal* pa_fb_local_plan(pa_ctx* ctx, const pa_level* L, int ng) {
   return raw;
 }
 
+CpPlan::~CpPlan() {
+  if (d_regs) (void)hipFree(d_regs);
+  if (d_wgs) (void)hipFree(d_wgs);
+}
+CpPlan* pa_cp_plan(pa_ctx* ctx, const pa_level* F, const pa_level* C) {
+  auto it = F->cp_plans.find(C->serial);
+  if (it != F->cp_plans.end()) return it->second.get();
+  std::unique_ptr<CpPlan> P(new CpPlan());
+  CpPlan* raw = P.get();
+  F->cp_plans[C->serial] = std::move(P);
+  static const int on = [] { const char* e = getenv("PA_CP_REGIONS"); return e ? atoi(e) : 1; }();
+  const int nc = (int)C->boxes.size();
+  if (!on || nc == 0 || F->sfaces.empty()) return raw;
+  const auto shifts = domain_shifts(C->domlo, C->domhi, C->is_per);
+  const DBox M = {{C->mlo[0], C->mlo[1], C->mlo[2]}, {C->mlo[0] + C->mn[0] * C->g - 1, C->mlo[1] + C->mn[1] * C->g - 1, C->mlo[2] + C->mn[2] * C->g - 1}};
+  std::vector<int> regs, wgs, cand;
+  for (size_t e = 0; e < F->sfaces.size(); ++e) {
+    const int f = F->sfaces[e], dir = (f % 6) >> 1, side = f & 1;
+    const DBox& B = F->boxes[f / 6];
+    const int qd = side ? B.hi[dir] + 1 : B.lo[dir] - 1;
+    if (!(F->is_per[dir] || (qd >= F->domlo[dir] && qd <= F->domhi[dir]))) continue;  // a wall face: no patch (pa_level_create)
+    const int t0 = dir == 0 ? 1 : 0, t1 = dir == 2 ? 1 : 2;
+    int plane, u0, v0, pw, ph;
+    cpatch_geom(B, dir, side, plane, u0, v0, pw, ph);
+    DBox R;  // the patch in the coarse index space (unwrapped)
+    R.lo[dir] = R.hi[dir] = plane;
+    R.lo[t0] = u0; R.hi[t0] = u0 + pw - 1;
+    R.lo[t1] = v0; R.hi[t1] = v0 + ph - 1;
+    for (const auto& sh : shifts) {  // coarse box s shifted by sh covers part of R  <=>  s covers part of R - sh
+      const int neg[3] = {-sh[0], -sh[1], -sh[2]};
+      const DBox Q = bx_shift(R, neg);
+      DBox I;
+      cand.clear();
+      if (bx_isect(Q, M, I)) {
+        long long cells = 1;
+        int c0[3], c1[3];
+        for (int d = 0; d < 3; ++d) { c0[d] = (I.lo[d] - C->mlo[d]) / C->g; c1[d] = (I.hi[d] - C->mlo[d]) / C->g; cells *= c1[d] - c0[d] + 1; }
+        if (cells > 65536) return raw;
+        for (int kz = c0[2]; kz <= c1[2]; ++kz)
+          for (int ky = c0[1]; ky <= c1[1]; ++ky)
+            for (int kx = c0[0]; kx <= c1[0]; ++kx) {
+              const int o = C->owner[((size_t)kz * C->mn[1] + ky) * C->mn[0] + kx];
+              if (o >= 0 && std::find(cand.begin(), cand.end(), o) == cand.end()) cand.push_back(o);
+            }
+      }
+      for (int sbox : cand) {
+        if (!bx_isect(Q, C->boxes[sbox], I)) continue;  // I: coarse cells of box sbox (its own coordinates)
+        const long long nu = I.hi[t0] - I.lo[t0] + 1, nv = I.hi[t1] - I.lo[t1] + 1;
+        if (nu * nv >= (1LL << 21) || nu >= 2048) return raw;
+        const int r = (int)(regs.size() / 12);
+        const unsigned m = (unsigned)(((1ULL << 32) + nu - 1) / nu);
+        const int row[12] = {(int)e, sbox, I.lo[t0] + sh[t0] - u0, I.lo[t1] + sh[t1] - v0, I.lo[0], I.lo[1], I.lo[2], (int)nu, (int)nv, dir, (int)m, 0};
+        regs.insert(regs.end(), row, row + 12);
+        for (int c = 0; c < (int)((nu * nv + 255) / 256); ++c) { wgs.push_back(r); wgs.push_back(c); }
+      }
+    }
+  }
+  raw->nreg = (int)(regs.size() / 12);
+  raw->nwg = (int)(wgs.size() / 2);
+  if (raw->nreg > 0) {
+    if (hipMalloc(&raw->d_regs, sizeof(int) * regs.size()) != hipSuccess || hipMalloc(&raw->d_wgs, sizeof(int) * wgs.size()) != hipSuccess) return raw;
+    if (hipMemcpy(raw->d_regs, regs.data(), sizeof(int) * regs.size(), hipMemcpyHostToDevice) != hipSuccess) return raw;
+    if (hipMemcpy(raw->d_wgs, wgs.data(), sizeof(int) * wgs.size(), hipMemcpyHostToDevice) != hipSuccess) return raw;
+  }
+  (void)ctx;
+  raw->ok = true;
+  return raw;
+}
+
 XPlan* pa_fb_plan(pa_ctx* ctx, const pa_level* L, int ng) {
   auto it = L->fb_plans.find(ng);
   if (it != L->fb_plans.end()) return it->second.get();

@@ -97,6 +97,7 @@ struct FixArgs {
   DMFView MO;
   int ncomp0, kcomp;
   FaceArgs A;
+  int use_cp = 0;  // the level's coarse patches hold the coarse normal component of each face's direction (k_cpatch ran)
 };
 
 __device__ __forceinline__ double comp_of(const Vec3& v, int d) { return d == 0 ? v.x : (d == 1 ? v.y : v.z); }
@@ -253,7 +254,7 @@ __global__ __launch_bounds__(256, PA_FC_WAVES) void k_faces_curv(LevBatch<FixArg
 template <int FD, int NL>
 __device__ __forceinline__ void faces_curv_fast_body(const DLevelView& L, const DLevelView& LCr, const DMFView& MN, int cncomp0, const DMFView& MO,
                                                      int ncomp0, int kcomp, const FaceArgs& A, int* nbad, int b, const DBox& B, int side,
-                                                     const int q0[3], unsigned code) {
+                                                     const int q0[3], unsigned code, const double* patch) {
   constexpr int T0 = (FD == 0) ? 1 : 0, T1 = (FD == 2) ? 1 : 2;
   const int cls = (int)(code & 3u);
   if (cls == 0) return;
@@ -290,7 +291,8 @@ __device__ __forceinline__ void faces_curv_fast_body(const DLevelView& L, const 
       const int NX = cf_normal_coef(n[FD], A.ratio, coef);
       const int xf[1] = {0};
       double bv1[1];
-      cf_interp<1>(code, LCr, MN, cncomp0 + FD, q0, FD, A.ratio, xf, ok, bv1);
+      if (patch) cf_interp_patch<1>(code, patch, B, side, MN, q0, FD, xf, ok, bv1);  // the face's coarse patch holds component cncomp0 + FD
+      else cf_interp<1>(code, LCr, MN, cncomp0 + FD, q0, FD, A.ratio, xf, ok, bv1);
       double tmp = 0.0;
       for (int m = 1; m < NX; ++m) {
         const double v = (m == 1) ? nfd1 : (m == 2 ? nfd2 : nfd3);
@@ -340,10 +342,12 @@ __global__ __launch_bounds__(256) void k_faces_curv_fast(LevBatch<FixArgs> Bt, i
   const int t0 = (fdir == 0) ? 1 : 0, t1 = (fdir == 2) ? 1 : 2;
   if (!(q0[t0] > B.lo[t0] && q0[t0] < B.hi[t0] && q0[t1] > B.lo[t1] && q0[t1] < B.hi[t1])) return;  // perimeter: k_faces_curv
   const unsigned code = L.sfcode[L.sfoff[fy] + t];
+  const long long cpo = (Fx.use_cp && L.cp) ? L.cpoff[fy] : -1;  // wave-uniform
+  const double* patch = cpo >= 0 ? L.cp + cpo : nullptr;
   switch (fdir) {  // uniform per workgroup
-    case 0: faces_curv_fast_body<0, NL>(L, LCr, MN, cncomp0, MO, ncomp0, kcomp, A, nbad, b, B, side, q0, code); break;
-    case 1: faces_curv_fast_body<1, NL>(L, LCr, MN, cncomp0, MO, ncomp0, kcomp, A, nbad, b, B, side, q0, code); break;
-    default: faces_curv_fast_body<2, NL>(L, LCr, MN, cncomp0, MO, ncomp0, kcomp, A, nbad, b, B, side, q0, code); break;
+    case 0: faces_curv_fast_body<0, NL>(L, LCr, MN, cncomp0, MO, ncomp0, kcomp, A, nbad, b, B, side, q0, code, patch); break;
+    case 1: faces_curv_fast_body<1, NL>(L, LCr, MN, cncomp0, MO, ncomp0, kcomp, A, nbad, b, B, side, q0, code, patch); break;
+    default: faces_curv_fast_body<2, NL>(L, LCr, MN, cncomp0, MO, ncomp0, kcomp, A, nbad, b, B, side, q0, code, patch); break;
   }
 }
 
@@ -586,7 +590,7 @@ struct PrepArgs {
 // Thread per ghost cell of a special face: the face ghost of phi (MLMG applyBC, as k_apply_bc_sfaces) and the resolved
 // ghost value of c = the same boundary condition applied to c, whose interior values are (phi - pmin) * invd formed on the
 // fly and whose coarse values are the affine view of the coarse phi -- the operations of k_apply_bc_sfaces<2> on a stored c.
-struct PrepLev { DLevelView L; DMFView M; int comp; DLevelView LC; DMFView MC; int ccomp; PrepArgs A; };
+struct PrepLev { DLevelView L; DMFView M; int comp; DLevelView LC; DMFView MC; int ccomp; PrepArgs A; int use_cp; };
 __global__ __launch_bounds__(256) void k_prep_faces(LevBatch<PrepLev> Bt, int* nbad) {
   unsigned fy;
   const PrepLev& Pl = Bt.a[Bt.find(blockIdx.y, fy)];
@@ -625,7 +629,9 @@ __global__ __launch_bounds__(256) void k_prep_faces(LevBatch<PrepLev> Bt, int* n
   double coef[4], bv[2];
   const int NX = cf_normal_coef(B.hi[dir] - B.lo[dir] + 1, A.ratio, coef);
   const int xf[2] = {0, 1};
-  cf_interp<2>(code, LC, MC, ccomp, q, dir, A.ratio, xf, ok, bv);
+  const long long cpo = (Pl.use_cp && L.cp) ? L.cpoff[fy] : -1;  // wave-uniform
+  if (cpo >= 0) cf_interp_patch<2>(code, L.cp + cpo, B, side, MC, q, dir, xf, ok, bv);
+  else cf_interp<2>(code, LC, MC, ccomp, q, dir, A.ratio, xf, ok, bv);
   if (!ok) atomicAdd(nbad, 1);
   double tp = 0.0, tc = 0.0;
   for (int m = 1; m < NX; ++m) {
@@ -720,6 +726,108 @@ static int level_cg(pa_ctx* ctx, const pa_level* Lc) {
   return 0;
 }
 
+// ---- coarse patches (DLevelView::cp, pa_internal.h): one thread per patch cell fetches the coarse value through the owner
+// map of the coarse level (or of this rank's coarse-source copy) -- 1/4 of the fine face cells, once, instead of every
+// fine ghost cell walking owner map -> box -> offset before its 5-11 coarse loads.  by_dir: the patch of a face of
+// direction d holds component ccomp + d (the coarse normal the fix-up needs), else component ccomp for every face.
+struct CpLev { DLevelView L; DLevelView LC; DMFView MC; int ccomp, by_dir; };
+__global__ __launch_bounds__(256) void k_cpatch(LevBatch<CpLev> Bt) {
+  unsigned fy;
+  const CpLev& P = Bt.a[Bt.find(blockIdx.y, fy)];
+  const DLevelView& L = P.L;
+  const long long off = L.cpoff[fy];
+  if (off < 0) return;  // a wall face
+  const int e = L.sfaces[fy], dir = (e % 6) >> 1, side = e & 1;
+  const DBox B = L.boxes[e / 6];
+  int plane, u0, v0, pw, ph;
+  cpatch_geom(B, dir, side, plane, u0, v0, pw, ph);
+  const unsigned t = blockIdx.x * 256u + threadIdx.x;
+  if (t >= (unsigned)(pw * ph)) return;
+  const int t0 = dir == 0 ? 1 : 0, t1 = dir == 2 ? 1 : 2;
+  const unsigned r = t / (unsigned)pw;
+  int p[3];
+  p[dir] = plane; p[t0] = u0 + (int)(t - r * (unsigned)pw); p[t1] = v0 + (int)r;
+  double v = __longlong_as_double(PA_CP_MISSING);
+  if (wrap_cell(P.LC, p)) {
+    const int cb = owner_of(P.LC, p);
+    if (cb >= 0) v = P.MC.data[P.MC.off[cb] + fab_index(P.LC.boxes[cb], P.MC.ng, P.MC.ncomp, P.ccomp + (P.by_dir ? dir : 0), p[0], p[1], p[2])];
+  }
+  L.cp[off + t] = v;
+}
+// the same gather from the plan of copy regions (pa_dist.h: CpPlan): no owner-map lookups at all
+struct CprLev { DLevelView L; DLevelView LC; DMFView MC; const int* regs; const int* wgs; int nwg, ccomp, by_dir; };
+__global__ __launch_bounds__(256) void k_cpatch_regions(LevBatch<CprLev> Bt) {
+  const CprLev& P = Bt.a[blockIdx.y];
+  if ((int)blockIdx.x >= P.nwg) return;
+  const int* R = P.regs + 12 * P.wgs[2 * blockIdx.x];
+  const unsigned t = (unsigned)P.wgs[2 * blockIdx.x + 1] * 256u + threadIdx.x, nu = (unsigned)R[7];
+  if (t >= nu * (unsigned)R[8]) return;
+  const unsigned b = nu == 1 ? t : __umulhi(t, (unsigned)R[10]), a = t - b * nu;
+  const int dir = R[9], t0 = dir == 0 ? 1 : 0, t1 = dir == 2 ? 1 : 2;
+  const DLevelView& L = P.L;
+  const int e = L.sfaces[R[0]], side = e & 1;
+  int plane, u0, v0, pw, ph;
+  cpatch_geom(L.boxes[e / 6], dir, side, plane, u0, v0, pw, ph);
+  int p[3] = {R[4], R[5], R[6]};
+  p[t0] += (int)a; p[t1] += (int)b;
+  L.cp[L.cpoff[R[0]] + (long long)(R[3] + (int)b) * pw + (R[2] + (int)a)] =
+      P.MC.data[P.MC.off[R[1]] + fab_index(P.LC.boxes[R[1]], P.MC.ng, P.MC.ncomp, P.ccomp + (P.by_dir ? dir : 0), p[0], p[1], p[2])];
+}
+__global__ __launch_bounds__(256) void k_cpatch_clear(double* cp, long long n) {
+  const long long t = blockIdx.x * 256LL + threadIdx.x;
+  if (t < n) cp[t] = __longlong_as_double(PA_CP_MISSING);
+}
+static int level_cp(pa_ctx* ctx, const pa_level* Lc) {
+  pa_level* L = const_cast<pa_level*>(Lc);
+  if (L->d_cp) return 0;
+  const long long n = std::max<long long>(L->cp_total, 8);
+  PA_HIP(hipMalloc(&L->d_cp, sizeof(double) * (size_t)n));
+  hipLaunchKernelGGL(k_cpatch_clear, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, L->d_cp, n);  // cells without a coarse owner stay "missing"
+  L->view.cp = L->d_cp;
+  return 0;
+}
+static bool cpatch_on() {
+  const char* e = getenv("PA_CPATCH");  // read per pass (tools/ab_driver.py)
+  return e ? atoi(e) != 0 : true;
+}
+// gather the patches of levels [l0, l1) (those that have a coarse source): one launch
+static int cpatch_launch(pa_ctx* ctx, int l0, int l1, pa_mf* const* fine, const pa_mf* const* crse, int ccomp, int by_dir) {
+  {  // copy regions when every level of the batch has a plan
+    LevBatch<CprLev> Br;
+    bool regions = true;
+    int mw = 0;
+    for (int l = l0; l < l1 && regions; ++l) {
+      const pa_level* L = fine[l]->lev;
+      if (!crse[l] || L->boxes.empty() || L->sfaces.empty() || L->cp_total == 0) continue;
+      if (level_cp(ctx, L)) return 1;
+      const CpPlan* P = pa_cp_plan(ctx, L, crse[l]->lev);
+      regions = P && P->ok;
+      if (!regions || P->nwg == 0) continue;
+      Br.a[Br.n] = CprLev{L->view, crse[l]->lev->view, crse[l]->view, P->d_regs, P->d_wgs, P->nwg, ccomp, by_dir};
+      ++Br.n;
+      mw = std::max(mw, P->nwg);
+    }
+    if (regions) {
+      if (Br.n) hipLaunchKernelGGL(k_cpatch_regions, dim3((unsigned)mw, (unsigned)Br.n), dim3(256), 0, ctx->stream, Br);
+      return 0;
+    }
+  }
+  LevBatch<CpLev> Bt;
+  long long mp = 0;
+  for (int l = l0; l < l1; ++l) {
+    const pa_level* L = fine[l]->lev;
+    if (!crse[l] || L->boxes.empty() || L->sfaces.empty() || L->cp_total == 0) continue;
+    if (level_cp(ctx, L)) return 1;
+    Bt.a[Bt.n] = CpLev{L->view, crse[l]->lev->view, crse[l]->view, ccomp, by_dir};
+    Bt.ycum[Bt.n + 1] = Bt.ycum[Bt.n] + (int)L->sfaces.size();
+    ++Bt.n;
+    const long long n0 = L->maxn[0] / 2 + 8, n1 = L->maxn[1] / 2 + 8, n2 = L->maxn[2] / 2 + 8;
+    mp = std::max(mp, std::max(n1 * n2, std::max(n0 * n2, n0 * n1)));
+  }
+  if (Bt.n) hipLaunchKernelGGL(k_cpatch, dim3((unsigned)((mp + 255) / 256), (unsigned)Bt.ycum[Bt.n]), dim3(256), 0, ctx->stream, Bt);
+  return 0;
+}
+
 // can the exact-normal pipeline run on this level (same answer on every rank of a sharded level)?
 bool pa_fused2_level_ok(const pa_level* L) {
   static const int env = [] { const char* e = getenv("PA_FUSED2"); return e ? atoi(e) : 1; }();
@@ -742,7 +850,9 @@ bool pa_fused2_level_ok(const pa_level* L) {
 // phase: 1 = the faces (k_prep_faces: reads valid cells and coarse data only, so it may run NEXT TO FillBoundary), 2 = the
 // ring (k_prep_ring: reads ghost cells FillBoundary fills), 3 = both
 int pa_gradcurv_prep_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int comp, const pa_mf* const* crse, int ccomp, const int32_t bc[3], double pmin, double pmax, int phase) {
+  const bool use_cp = cpatch_on() && (phase & 1);
   for (int l0 = 0; l0 < nlev; l0 += PA_MAXB) {
+    if (use_cp && cpatch_launch(ctx, l0, std::min(nlev, l0 + PA_MAXB), phi, crse, ccomp, 0)) return 1;  // before P.L = L->view picks up cp
     LevBatch<PrepLev> Bf, Br;
     long long ntf = 0, ntr = 0;
     for (int l = l0; l < nlev && l < l0 + PA_MAXB; ++l) {
@@ -758,6 +868,7 @@ int pa_gradcurv_prep_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int comp, 
       P.MC = crse[l] ? crse[l]->view : phi[l]->view;
       P.MC.xform = 1; P.MC.xa = pmin; P.MC.xb = P.A.invd;
       P.ccomp = ccomp;
+      P.use_cp = (use_cp && crse[l] && L->cp_total > 0) ? 1 : 0;
       const long long n0 = L->maxn[0], n1 = L->maxn[1], n2 = L->maxn[2];
       ntf = std::max(ntf, std::max(n1 * n2, std::max(n0 * n2, n0 * n1)));
       ntr = std::max(ntr, 4 * (n0 + n1 + n2));
@@ -867,7 +978,9 @@ int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, d
 // crse_n[l]: the coarser level's output (normal components from cncomp0) or this rank's coarse-source copy of them.
 int pa_gradcurv_fix_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, const pa_mf* const* crse_n, int cncomp0, const int32_t bc[3], double pmin, double pmax,
                            pa_mf* const* out, int ncomp0, int kcomp) {
+  const bool use_cp = cpatch_on();
   for (int l0 = 0; l0 < nlev; l0 += PA_MAXB) {
+    if (use_cp && cpatch_launch(ctx, l0, std::min(nlev, l0 + PA_MAXB), phi, crse_n, cncomp0, 1)) return 1;
     LevBatch<FixArgs> Bt;
     long long nf = 0, nper = 0;
     for (int l = l0; l < nlev && l < l0 + PA_MAXB; ++l) {
@@ -877,7 +990,7 @@ int pa_gradcurv_fix_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, 
       for (int d = 0; d < 3; ++d) A.bc[d] = bc[d];
       A.ratio = 2; A.has_crse = crse_n[l] ? 1 : 0; A.thr = -1.0; A.layers = 1; A.perim_only = 1; A.pmin = pmin; A.invd = 1.0 / (pmax - pmin);
       Bt.a[Bt.n] = FixArgs{L->view, phi[l]->view, pcomp, crse_n[l] ? crse_n[l]->lev->view : L->view, crse_n[l] ? crse_n[l]->view : phi[l]->view, cncomp0,
-                           out[l]->view, ncomp0, kcomp, A};
+                           out[l]->view, ncomp0, kcomp, A, (use_cp && crse_n[l] && L->cp_total > 0) ? 1 : 0};
       Bt.ycum[Bt.n + 1] = Bt.ycum[Bt.n] + (int)L->sfaces.size();
       ++Bt.n;
       const long long n0 = L->maxn[0], n1 = L->maxn[1], n2 = L->maxn[2];

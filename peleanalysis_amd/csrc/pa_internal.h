@@ -32,6 +32,12 @@ struct DLevelView {
   // coordinate - box lo + 1 (a ring of one cell for the edge ghosts), + 2 rows of slack.  Null: not allocated.
   const long long* cgoff;
   double* cg;
+  // Coarse patches (pa_fused.hip, k_cpatch): for every special coarse-fine face the coarse values its boundary
+  // interpolation can touch -- the coarse plane behind the face, tangentially coarsen(lo - 1) - 2 .. coarsen(hi + 1) + 2 --
+  // as one dense 2-D array at cp + cpoff[e] (cpoff < 0: a wall face).  Filled by a gather pass so that the face kernels
+  // read coarse data without owner-map lookups.  Null: not allocated.
+  const long long* cpoff;
+  double* cp;
 };
 
 struct DMFView {
@@ -129,6 +135,9 @@ struct pa_level {
   long long ncells = 0;
   bool fusable = true;      // no concave coarse-fine corner (see pa_level_create)
   bool pure_faces = true;   // every special face of the WHOLE BoxArray has no ghost cell that is a valid cell (pa_fused2.hip)
+  long long* d_cpoff = nullptr;
+  double* d_cp = nullptr;   // allocated on first use (level_cp)
+  long long cp_total = 0;
   long long* d_cgoff = nullptr;
   double* d_cg = nullptr;   // allocated on first use (pa_level_cg)
   long long cg_total = 0;
@@ -145,6 +154,7 @@ struct pa_level {
   std::vector<int> glocal;         // local index of global box g, or -1
   bool source_only = false;        // coarse-source level (pa_dist.hip): no special faces, never swept
   mutable std::map<int, std::unique_ptr<struct XPlan>> fb_plans;                       // FillBoundary plans by ghost width
+  mutable std::map<long long, std::unique_ptr<struct CpPlan>> cp_plans;               // coarse-patch gather as copy regions, by coarse level serial (pa_dist.hip)
   mutable std::map<int, std::unique_ptr<struct FbLocal>> fb_local;                     // local FillBoundary as copy regions, by ghost width (pa_dist.hip)
   mutable std::map<std::pair<long long, int>, std::unique_ptr<struct CsPlan>> cs_plans; // coarse-source plans by (coarse level serial, mode)
   ~pa_level();
@@ -249,7 +259,7 @@ __device__ __forceinline__ int classify(const DLevelView& L, int i, int j, int k
   return classify(L, i, j, k, b, p);
 }
 
-__device__ __forceinline__ int coarsen_idx(int i, int r) { return r == 2 ? (i >> 1) : ((i < 0) ? -((-i + r - 1) / r) : i / r); }  // floor
+__host__ __device__ __forceinline__ int coarsen_idx(int i, int r) { return r == 2 ? (i >> 1) : ((i < 0) ? -((-i + r - 1) / r) : i / r); }  // floor
 
 // amrex::poly_interp_coeff restated (Lagrange weights evaluated in fp64)
 __device__ __forceinline__ void poly_interp_coeff(double xInt, const double* x, int N, double* c) {
@@ -371,31 +381,12 @@ __device__ inline unsigned cf_masks(const DLevelView& LF, const int q[3], int di
 // (v - MC.xa) * MC.xb when xf[f] != 0 (the progress variable as an affine view of the coarse phi).
 // Per field the operation order is the reference's.  Coarse neighbours inside the FAB that holds
 // the coarse cell of q are addressed relative to it (one owner-map lookup instead of eleven).
-template <int NF>
-__device__ inline void cf_interp(unsigned code, const DLevelView& LC, const DMFView& MC, int ccomp, const int q[3], int dir, int r,
-                                 const int xf[NF], bool& ok, double b[NF]) {
-  const int qc[3] = {coarsen_idx(q[0], r), coarsen_idx(q[1], r), coarsen_idx(q[2], r)};
+// the arithmetic of InterpBndryData on raw coarse values craw(a0, a1) = coarse(qc + a0 e_t0 + a1 e_t1): shared by the two
+// ways of fetching them (owner map / coarse patch), so that both are the same operations in the same order
+template <int NF, typename CRAW>
+__device__ __forceinline__ void cf_interp_core(unsigned code, CRAW craw, const DMFView& MC, const int q[3], const int qc[3], int dir, int r,
+                                               const int xf[NF], double b[NF]) {
   const int t0 = dir == 0 ? 1 : 0, t1 = dir == 2 ? 1 : 2;
-  int pq[3] = {qc[0], qc[1], qc[2]};
-  const int cb = wrap_cell(LC, pq) ? owner_of(LC, pq) : -1;
-  DBox Bc = {{0, 0, 0}, {-1, -1, -1}};
-  const double* base = MC.data;
-  long long st0 = 0, st1 = 0;
-  if (cb >= 0) {
-    Bc = LC.boxes[cb];
-    const long long nxg = Bc.hi[0] - Bc.lo[0] + 1 + 2 * MC.ng, nyg = Bc.hi[1] - Bc.lo[1] + 1 + 2 * MC.ng;
-    base = MC.data + MC.off[cb] + fab_index(Bc, MC.ng, MC.ncomp, ccomp, pq[0], pq[1], pq[2]);
-    st0 = t0 == 0 ? 1 : nxg;          // t0 is x or y
-    st1 = t1 == 1 ? nxg : nxg * nyg;  // t1 is y or z
-  }
-  // raw coarse value at qc + a0 e_t0 + a1 e_t1
-  auto craw = [&](int a0, int a1) -> double {
-    const int u = pq[t0] + a0, v = pq[t1] + a1;
-    if (u >= Bc.lo[t0] && u <= Bc.hi[t0] && v >= Bc.lo[t1] && v <= Bc.hi[t1]) return base[a0 * st0 + a1 * st1];
-    int cc[3] = {qc[0], qc[1], qc[2]};
-    cc[t0] += a0; cc[t1] += a1;
-    return crse_raw(LC, MC, ccomp, cc[0], cc[1], cc[2], ok);
-  };
 #pragma unroll
   for (int f = 0; f < NF; ++f) b[f] = 0.0;
   double xi[2];
@@ -437,6 +428,61 @@ __device__ inline void cf_interp(unsigned code, const DLevelView& LC, const DMFV
     }
   }
 }
+
+template <int NF>
+__device__ inline void cf_interp(unsigned code, const DLevelView& LC, const DMFView& MC, int ccomp, const int q[3], int dir, int r,
+                                 const int xf[NF], bool& ok, double b[NF]) {
+  const int qc[3] = {coarsen_idx(q[0], r), coarsen_idx(q[1], r), coarsen_idx(q[2], r)};
+  const int t0 = dir == 0 ? 1 : 0, t1 = dir == 2 ? 1 : 2;
+  int pq[3] = {qc[0], qc[1], qc[2]};
+  const int cb = wrap_cell(LC, pq) ? owner_of(LC, pq) : -1;
+  DBox Bc = {{0, 0, 0}, {-1, -1, -1}};
+  const double* base = MC.data;
+  long long st0 = 0, st1 = 0;
+  if (cb >= 0) {
+    Bc = LC.boxes[cb];
+    const long long nxg = Bc.hi[0] - Bc.lo[0] + 1 + 2 * MC.ng, nyg = Bc.hi[1] - Bc.lo[1] + 1 + 2 * MC.ng;
+    base = MC.data + MC.off[cb] + fab_index(Bc, MC.ng, MC.ncomp, ccomp, pq[0], pq[1], pq[2]);
+    st0 = t0 == 0 ? 1 : nxg;          // t0 is x or y
+    st1 = t1 == 1 ? nxg : nxg * nyg;  // t1 is y or z
+  }
+  // raw coarse value at qc + a0 e_t0 + a1 e_t1
+  auto craw = [&](int a0, int a1) -> double {
+    const int u = pq[t0] + a0, v = pq[t1] + a1;
+    if (u >= Bc.lo[t0] && u <= Bc.hi[t0] && v >= Bc.lo[t1] && v <= Bc.hi[t1]) return base[a0 * st0 + a1 * st1];
+    int cc[3] = {qc[0], qc[1], qc[2]};
+    cc[t0] += a0; cc[t1] += a1;
+    return crse_raw(LC, MC, ccomp, cc[0], cc[1], cc[2], ok);
+  };
+  cf_interp_core<NF>(code, craw, MC, q, qc, dir, r, xf, b);
+}
+
+// ---- coarse patches (DLevelView::cp): geometry of the patch of a special face of box B, and the same interpolation from it
+#define PA_CP_MISSING 0x7FF8C0A45EC0FFEEll /* bit pattern of a patch cell that has no coarse owner (a NaN payload no data carries) */
+__host__ __device__ __forceinline__ void cpatch_geom(const DBox& B, int dir, int side, int& plane, int& u0, int& v0, int& pw, int& ph) {
+  const int t0 = dir == 0 ? 1 : 0, t1 = dir == 2 ? 1 : 2;
+  plane = coarsen_idx(side ? B.hi[dir] + 1 : B.lo[dir] - 1, 2);
+  u0 = coarsen_idx(B.lo[t0] - 1, 2) - 2;
+  v0 = coarsen_idx(B.lo[t1] - 1, 2) - 2;
+  pw = coarsen_idx(B.hi[t0] + 1, 2) + 2 - u0 + 1;
+  ph = coarsen_idx(B.hi[t1] + 1, 2) + 2 - v0 + 1;
+}
+template <int NF>
+__device__ inline void cf_interp_patch(unsigned code, const double* patch, const DBox& B, int side, const DMFView& MC, const int q[3], int dir,
+                                       const int xf[NF], bool& ok, double b[NF]) {
+  const int qc[3] = {coarsen_idx(q[0], 2), coarsen_idx(q[1], 2), coarsen_idx(q[2], 2)};
+  const int t0 = dir == 0 ? 1 : 0, t1 = dir == 2 ? 1 : 2;
+  int plane, u0, v0, pw, ph;
+  cpatch_geom(B, dir, side, plane, u0, v0, pw, ph);
+  const double* base = patch + (long long)(qc[t1] - v0) * pw + (qc[t0] - u0);
+  auto craw = [&](int a0, int a1) -> double {
+    const double v = base[a1 * pw + a0];
+    if (__double_as_longlong(v) == PA_CP_MISSING) { ok = false; return 0.0; }
+    return v;
+  };
+  cf_interp_core<NF>(code, craw, MC, q, qc, dir, 2, xf, b);
+}
+
 template <int NF>
 __device__ inline void cf_bndry_values(const DLevelView& LF, const DLevelView& LC, const DMFView& MC, int ccomp,
                                        const int q[3], int dir, int r, const int xf[NF], bool& ok, double b[NF]) {
