@@ -384,3 +384,39 @@ def test_switched_off_paths_still_match(ctx):
                         "-k", "ghost_fill_matches_oracle or exact_normal_pipeline or fused_matches_oracle"], env=env, capture_output=True, text=True,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_not_properly_nested_fine_level_is_counted_on_every_path(ctx, monkeypatch):
+    """a level-2 region that touches the edge of level 1 (no buffer cells): its ghost cells beyond that edge have no coarse
+    parent.  The library never aborts -- it counts those ghost cells (pa_bc_errors; the tools turn a non-zero count into the
+    reference's abort) -- and the count is the same whether the coarse values come through the owner map or from the
+    coarse patches, where a cell without an owner is a reserved bit pattern"""
+    from peleanalysis_amd.hierarchy import Hierarchy, Level
+    z, o = np.zeros(3), np.ones(3)
+    l0 = Level(np.array([[0, 0, 0, 63, 63, 63]], np.int32), (0, 0, 0), (63, 63, 63), (0, 0, 0), z, o)
+    l1 = Level(np.array([[16, 16, 16, 79, 79, 79]], np.int32), (0, 0, 0), (127, 127, 127), (0, 0, 0), z, o)
+    l2 = Level(np.array([[32, 32, 32, 95, 95, 95]], np.int32), (0, 0, 0), (255, 255, 255), (0, 0, 0), z, o)  # level-1 cells 16..47: flush with level 1's low sides
+    H = Hierarchy([l0, l1, l2], 2)
+    rng = np.random.default_rng(5)
+    states = []
+    for lv in H.levels:
+        m = MultiFab(lv, 1, 2)
+        m.data[:] = 300.0 + 1700.0 * rng.random(m.total)
+        states.append(m)
+    bc = capi.bc_from_flags((0, 0, 0))
+    dls, dst = _dev(ctx, H, states)
+    work = [capi.DevMF(ctx, dl, 1, 2) for dl in dls]
+    dout = [capi.DevMF(ctx, dl, 8, 0) for dl in dls]
+    counts = {}
+    for sw in ("1", "0"):
+        monkeypatch.setenv("PA_CPATCH", sw)
+        capi.gradcurv_run(ctx, dst, 0, bc, capi.curv_params(prog_min=200.0, prog_max=2100.0, fused=True), work, dout, 0)
+        ctx.sync()
+        kn = ctx.lib.pa_sweep_kernel_name(ctx.h).decode()
+        assert kn.endswith("CG=1>") or kn.startswith("k_gradcurv_march3_levels<"), kn
+        counts[sw] = ctx.bc_errors()
+    capi.gradcurv_run(ctx, dst, 0, bc, capi.curv_params(prog_min=200.0, prog_max=2100.0, fused=False), work, dout, 0)
+    ctx.sync()
+    assert ctx.bc_errors() > 0  # pass by pass: counted as well (its own number of passes over those cells)
+    # three faces of 64 x 64 ghost cells sit beyond level 1, counted once by the prep and once by the fix-up of phi's and n's ghosts
+    assert counts["1"] == counts["0"] and counts["1"] >= 3 * 64 * 64, counts
