@@ -205,8 +205,8 @@ __global__ __launch_bounds__(256, PA_FC_WAVES) void k_faces_curv(LevBatch<FixArg
       if (in_box(B, q)) { nb[s2] = nrm(q, d); continue; }
       // q is a ghost cell of face (d, s2) of this box: its masks are stored unless the face is ordinary
       unsigned code = 0;
+      const int e2 = L.sfindex[b * 6 + d * 2 + s2];
       {
-        const int e2 = L.sfindex[b * 6 + d * 2 + s2];
         const int u0 = (d == 0) ? 1 : 0, u1 = (d == 2) ? 1 : 2;
         if (e2 >= 0) code = L.sfcode[L.sfoff[e2] + (q[u0] - B.lo[u0]) + (long long)n[u0] * (q[u1] - B.lo[u1])];
       }
@@ -221,7 +221,9 @@ __global__ __launch_bounds__(256, PA_FC_WAVES) void k_faces_curv(LevBatch<FixArg
         const int NX = cf_normal_coef(n[d], A.ratio, coef);
         const int xf[1] = {0};
         double bv1[1];
-        cf_interp<1>(code, LCr, MN, cncomp0 + d, q, d, A.ratio, xf, ok, bv1);
+        const long long cpo = (Fx.use_cp && L.cp) ? L.cpoff[e2] : -1;  // that face's coarse patch holds component cncomp0 + d
+        if (cpo >= 0) cf_interp_patch<1>(code, L.cp + cpo, B, s2, MN, q, d, xf, ok, bv1);
+        else cf_interp<1>(code, LCr, MN, cncomp0 + d, q, d, A.ratio, xf, ok, bv1);
         const double bv = bv1[0];
         double tmp = 0.0;
         for (int m = 1; m < NX; ++m) {
