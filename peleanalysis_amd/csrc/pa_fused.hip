@@ -703,7 +703,16 @@ __global__ void k_prep_ring(LevBatch<PrepLev> Bt, int* nbad) {
     bool ok = true;
     double coef[4];
     const int NX = cf_normal_coef(n[dir], A.ratio, coef);
-    const double bv = cf_bndry_value(L, LC, MC, ccomp, q, dir, A.ratio, ok);  // MC carries the affine view
+    double bv;
+    const long long cpo = (Pl.use_cp && L.cp) ? L.cpoff[ef] : -1;
+    if (cpo >= 0) {  // the same masks, the coarse values from the face's patch (its ring of two coarse cells covers the edge ghosts)
+      const int xf[1] = {MC.xform};
+      double b1[1];
+      cf_interp_patch<1>(cf_masks(L, q, dir, A.ratio) | 1u, L.cp + cpo, B, sd, MC, q, dir, xf, ok, b1);
+      bv = b1[0];
+    } else {
+      bv = cf_bndry_value(L, LC, MC, ccomp, q, dir, A.ratio, ok);  // MC carries the affine view
+    }
     if (!ok) atomicAdd(nbad, 1);
     double tmp = 0.0;
     for (int m = 1; m < NX; ++m) {
@@ -852,9 +861,9 @@ bool pa_fused2_level_ok(const pa_level* L) {
 // phase: 1 = the faces (k_prep_faces: reads valid cells and coarse data only, so it may run NEXT TO FillBoundary), 2 = the
 // ring (k_prep_ring: reads ghost cells FillBoundary fills), 3 = both
 int pa_gradcurv_prep_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int comp, const pa_mf* const* crse, int ccomp, const int32_t bc[3], double pmin, double pmax, int phase) {
-  const bool use_cp = cpatch_on() && (phase & 1);
+  const bool use_cp = cpatch_on();  // the patches are gathered with the faces (phase 1) and still hold the coarse phi when the ring runs (phase 2)
   for (int l0 = 0; l0 < nlev; l0 += PA_MAXB) {
-    if (use_cp && cpatch_launch(ctx, l0, std::min(nlev, l0 + PA_MAXB), phi, crse, ccomp, 0)) return 1;  // before P.L = L->view picks up cp
+    if (use_cp && (phase & 1) && cpatch_launch(ctx, l0, std::min(nlev, l0 + PA_MAXB), phi, crse, ccomp, 0)) return 1;  // before P.L = L->view picks up cp
     LevBatch<PrepLev> Bf, Br;
     long long ntf = 0, ntr = 0;
     for (int l = l0; l < nlev && l < l0 + PA_MAXB; ++l) {
