@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void k_faces_normal(DLevelView L, DMFView MC_,
 // back from the output (exact after phase A) unless the threshold clip zeroed them there; normals
 // of valid cells of neighbouring boxes are recomputed from the local ghost c.
 // CG = false: c from the stored shell copy MC_[ccomp]; CG = true: MC_[ccomp] is PHI and c comes through CgAcc.
-template <bool CG>
+template <bool CG, bool PATCH = false>
 __global__ __launch_bounds__(256, PA_FC_WAVES) void k_faces_curv(LevBatch<FixArgs> Bt, int* nbad) {
   unsigned fy;
   const FixArgs& Fx = Bt.a[Bt.find(blockIdx.y, fy)];
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256, PA_FC_WAVES) void k_faces_curv(LevBatch<FixArg
         const int xf[1] = {0};
         double bv1[1];
         const long long cpo = (Fx.use_cp && L.cp) ? L.cpoff[e2] : -1;  // that face's coarse patch holds component cncomp0 + d
-        if (cpo >= 0) cf_interp_patch<1>(code, L.cp + cpo, B, s2, MN, q, d, xf, ok, bv1);
+        if (PATCH || cpo >= 0) cf_interp_patch<1>(code, L.cp + cpo, B, s2, MN, q, d, xf, ok, bv1);
         else cf_interp<1>(code, LCr, MN, cncomp0 + d, q, d, A.ratio, xf, ok, bv1);
         const double bv = bv1[0];
         double tmp = 0.0;
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256, PA_FC_WAVES) void k_faces_curv(LevBatch<FixArg
 // normals it needs are plain loads from the output (exact after phase A), shared between the two
 // layers, and only the ghost normal beyond the face needs the boundary condition.  Same operations in
 // the same order as k_faces_curv (d = 0,1,2; cdiff; *0.5), which still handles the perimeter cells.
-template <int FD, int NL>
+template <int FD, int NL, bool PATCH>
 __device__ __forceinline__ void faces_curv_fast_body(const DLevelView& L, const DLevelView& LCr, const DMFView& MN, int cncomp0, const DMFView& MO,
                                                      int ncomp0, int kcomp, const FaceArgs& A, int* nbad, int b, const DBox& B, int side,
                                                      const int q0[3], unsigned code, const double* patch) {
@@ -293,7 +293,7 @@ __device__ __forceinline__ void faces_curv_fast_body(const DLevelView& L, const 
       const int NX = cf_normal_coef(n[FD], A.ratio, coef);
       const int xf[1] = {0};
       double bv1[1];
-      if (patch) cf_interp_patch<1>(code, patch, B, side, MN, q0, FD, xf, ok, bv1);  // the face's coarse patch holds component cncomp0 + FD
+      if (PATCH || patch) cf_interp_patch<1>(code, patch, B, side, MN, q0, FD, xf, ok, bv1);  // the face's coarse patch holds component cncomp0 + FD
       else cf_interp<1>(code, LCr, MN, cncomp0 + FD, q0, FD, A.ratio, xf, ok, bv1);
       double tmp = 0.0;
       for (int m = 1; m < NX; ++m) {
@@ -327,7 +327,8 @@ __device__ __forceinline__ void faces_curv_fast_body(const DLevelView& L, const 
   if (NL > 1) ko[in] = k2;
 }
 
-template <int NL>
+// PATCH: every coarse-fine face of every level of the batch has its coarse patch (the owner-map interpolation is not compiled in)
+template <int NL, bool PATCH = false>
 __global__ __launch_bounds__(256) void k_faces_curv_fast(LevBatch<FixArgs> Bt, int* nbad) {
   unsigned fy;
   const FixArgs& Fx = Bt.a[Bt.find(blockIdx.y, fy)];
@@ -347,9 +348,9 @@ __global__ __launch_bounds__(256) void k_faces_curv_fast(LevBatch<FixArgs> Bt, i
   const long long cpo = (Fx.use_cp && L.cp) ? L.cpoff[fy] : -1;  // wave-uniform
   const double* patch = cpo >= 0 ? L.cp + cpo : nullptr;
   switch (fdir) {  // uniform per workgroup
-    case 0: faces_curv_fast_body<0, NL>(L, LCr, MN, cncomp0, MO, ncomp0, kcomp, A, nbad, b, B, side, q0, code, patch); break;
-    case 1: faces_curv_fast_body<1, NL>(L, LCr, MN, cncomp0, MO, ncomp0, kcomp, A, nbad, b, B, side, q0, code, patch); break;
-    default: faces_curv_fast_body<2, NL>(L, LCr, MN, cncomp0, MO, ncomp0, kcomp, A, nbad, b, B, side, q0, code, patch); break;
+    case 0: faces_curv_fast_body<0, NL, PATCH>(L, LCr, MN, cncomp0, MO, ncomp0, kcomp, A, nbad, b, B, side, q0, code, patch); break;
+    case 1: faces_curv_fast_body<1, NL, PATCH>(L, LCr, MN, cncomp0, MO, ncomp0, kcomp, A, nbad, b, B, side, q0, code, patch); break;
+    default: faces_curv_fast_body<2, NL, PATCH>(L, LCr, MN, cncomp0, MO, ncomp0, kcomp, A, nbad, b, B, side, q0, code, patch); break;
   }
 }
 
@@ -593,6 +594,7 @@ struct PrepArgs {
 // ghost value of c = the same boundary condition applied to c, whose interior values are (phi - pmin) * invd formed on the
 // fly and whose coarse values are the affine view of the coarse phi -- the operations of k_apply_bc_sfaces<2> on a stored c.
 struct PrepLev { DLevelView L; DMFView M; int comp; DLevelView LC; DMFView MC; int ccomp; PrepArgs A; int use_cp; };
+template <bool PATCH>
 __global__ __launch_bounds__(256) void k_prep_faces(LevBatch<PrepLev> Bt, int* nbad) {
   unsigned fy;
   const PrepLev& Pl = Bt.a[Bt.find(blockIdx.y, fy)];
@@ -632,7 +634,7 @@ __global__ __launch_bounds__(256) void k_prep_faces(LevBatch<PrepLev> Bt, int* n
   const int NX = cf_normal_coef(B.hi[dir] - B.lo[dir] + 1, A.ratio, coef);
   const int xf[2] = {0, 1};
   const long long cpo = (Pl.use_cp && L.cp) ? L.cpoff[fy] : -1;  // wave-uniform
-  if (cpo >= 0) cf_interp_patch<2>(code, L.cp + cpo, B, side, MC, q, dir, xf, ok, bv);
+  if (PATCH || cpo >= 0) cf_interp_patch<2>(code, L.cp + cpo, B, side, MC, q, dir, xf, ok, bv);
   else cf_interp<2>(code, LC, MC, ccomp, q, dir, A.ratio, xf, ok, bv);
   if (!ok) atomicAdd(nbad, 1);
   double tp = 0.0, tc = 0.0;
@@ -653,6 +655,7 @@ __global__ __launch_bounds__(256) void k_prep_faces(LevBatch<PrepLev> Bt, int* n
 // The edge ghost cells of c (outside the box in two directions a < c) that are the boundary ghost of a valid cell of a
 // NEIGHBOURING box (k_apply_bc_edges): stored in the ring of the special face they continue.  Needs the ghost cells of phi
 // that are valid cells of the level (FillBoundary) filled.
+template <bool PATCH>
 __global__ void k_prep_ring(LevBatch<PrepLev> Bt, int* nbad) {
   unsigned fy;
   const PrepLev& Pl = Bt.a[Bt.find(blockIdx.y, fy)];
@@ -705,7 +708,7 @@ __global__ void k_prep_ring(LevBatch<PrepLev> Bt, int* nbad) {
     const int NX = cf_normal_coef(n[dir], A.ratio, coef);
     double bv;
     const long long cpo = (Pl.use_cp && L.cp) ? L.cpoff[ef] : -1;
-    if (cpo >= 0) {  // the same masks, the coarse values from the face's patch (its ring of two coarse cells covers the edge ghosts)
+    if (PATCH || cpo >= 0) {  // the same masks, the coarse values from the face's patch (its ring of two coarse cells covers the edge ghosts)
       const int xf[1] = {MC.xform};
       double b1[1];
       cf_interp_patch<1>(cf_masks(L, q, dir, A.ratio) | 1u, L.cp + cpo, B, sd, MC, q, dir, xf, ok, b1);
@@ -888,8 +891,17 @@ int pa_gradcurv_prep_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int comp, 
     }
     if (!Bf.n) continue;
     ProfScope prof(ctx, PA_TAG_BC);
-    if (phase & 1) hipLaunchKernelGGL(k_prep_faces, dim3((unsigned)((ntf + 255) / 256), (unsigned)Bf.ycum[Bf.n]), dim3(256), 0, ctx->stream, Bf, ctx->d_flags);
-    if (phase & 2) hipLaunchKernelGGL(k_prep_ring, dim3((unsigned)((ntr + 255) / 256), (unsigned)Br.ycum[Br.n]), dim3(256), 0, ctx->stream, Br, ctx->d_flags);
+    bool all_patch = true;  // every level of the batch that has a coarser level interpolates from patches: the owner-map path is not compiled in
+    for (int q = 0; q < Bf.n; ++q) all_patch = all_patch && (Bf.a[q].use_cp || !Bf.a[q].A.has_crse);
+    const dim3 gf((unsigned)((ntf + 255) / 256), (unsigned)Bf.ycum[Bf.n]), gr((unsigned)((ntr + 255) / 256), (unsigned)Br.ycum[Br.n]);
+    if (phase & 1) {
+      if (all_patch) hipLaunchKernelGGL(k_prep_faces<true>, gf, dim3(256), 0, ctx->stream, Bf, ctx->d_flags);
+      else hipLaunchKernelGGL(k_prep_faces<false>, gf, dim3(256), 0, ctx->stream, Bf, ctx->d_flags);
+    }
+    if (phase & 2) {
+      if (all_patch) hipLaunchKernelGGL(k_prep_ring<true>, gr, dim3(256), 0, ctx->stream, Br, ctx->d_flags);
+      else hipLaunchKernelGGL(k_prep_ring<false>, gr, dim3(256), 0, ctx->stream, Br, ctx->d_flags);
+    }
   }
   PA_HIP(hipGetLastError());
   return 0;
@@ -1010,8 +1022,12 @@ int pa_gradcurv_fix_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, 
     }
     if (!Bt.n) continue;
     ProfScope prof(ctx, PA_TAG_GRADCURV_FACES);
-    hipLaunchKernelGGL(k_faces_curv_fast<1>, dim3((unsigned)((nf + 255) / 256), (unsigned)Bt.ycum[Bt.n]), dim3(256), 0, ctx->stream, Bt, ctx->d_flags);
-    hipLaunchKernelGGL(k_faces_curv<true>, dim3((unsigned)((nper + 255) / 256), (unsigned)Bt.ycum[Bt.n]), dim3(256), 0, ctx->stream, Bt, ctx->d_flags);
+    bool all_patch = true;  // every level of the batch that interpolates from a coarser level does so from patches
+    for (int q = 0; q < Bt.n; ++q) all_patch = all_patch && (Bt.a[q].use_cp || !Bt.a[q].A.has_crse);
+    if (all_patch) hipLaunchKernelGGL((k_faces_curv_fast<1, true>), dim3((unsigned)((nf + 255) / 256), (unsigned)Bt.ycum[Bt.n]), dim3(256), 0, ctx->stream, Bt, ctx->d_flags);
+    else hipLaunchKernelGGL((k_faces_curv_fast<1, false>), dim3((unsigned)((nf + 255) / 256), (unsigned)Bt.ycum[Bt.n]), dim3(256), 0, ctx->stream, Bt, ctx->d_flags);
+    if (all_patch) hipLaunchKernelGGL((k_faces_curv<true, true>), dim3((unsigned)((nper + 255) / 256), (unsigned)Bt.ycum[Bt.n]), dim3(256), 0, ctx->stream, Bt, ctx->d_flags);
+    else hipLaunchKernelGGL((k_faces_curv<true, false>), dim3((unsigned)((nper + 255) / 256), (unsigned)Bt.ycum[Bt.n]), dim3(256), 0, ctx->stream, Bt, ctx->d_flags);
   }
   PA_HIP(hipGetLastError());
   return 0;
