@@ -949,6 +949,7 @@ int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, d
   std::vector<long long> per_seg(lv.size());
   long long wgs = 0;
   int kdef = fused_kseg();
+  if (const char* kb = getenv("PA_KSEG_B")) kdef = std::max(4, atoi(kb));  // per pass (tools/ab_driver.py): planes per workgroup of the batched launch
   for (size_t q = 0; q < lv.size(); ++q) {
     const pa_level* L = phi[lv[q]]->lev;
     per_seg[q] = (long long)((L->maxn[0] + 63) / 64) * ((L->maxn[1] + mty - 1) / mty) * (long long)L->boxes.size();

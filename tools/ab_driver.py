@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B of an environment switch the library reads per pass, inside ONE process (the clock a box holds drifts by more than
 the effects worth measuring: alternate short blocks and compare medians).
-usage: ab_driver.py VAR [base=512] [box=128] [blocks=8] [steps=15]"""
+usage: ab_driver.py VAR [base=512] [box=128] [blocks=8] [steps=15] [valA=1] [valB=0]"""
 import os
 import statistics
 import sys
@@ -18,6 +18,8 @@ base = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 box = int(sys.argv[3]) if len(sys.argv) > 3 else 128
 blocks = int(sys.argv[4]) if len(sys.argv) > 4 else 8
 steps = int(sys.argv[5]) if len(sys.argv) > 5 else 15
+VA = sys.argv[6] if len(sys.argv) > 6 else "1"
+VB = sys.argv[7] if len(sys.argv) > 7 else "0"
 H = nested_hierarchy(base, 3, box, is_per=(1, 1, 0))
 bc = capi.bc_from_flags((1, 1, 0))
 ctx = capi.Context(0)
@@ -44,10 +46,10 @@ def block(val):
     return (time.perf_counter() - t0) / steps * 1e3
 
 
-res = {"1": [], "0": []}
+res = {VA: [], VB: []}
 for b in range(blocks):
-    for v in ("1", "0") if b % 2 == 0 else ("0", "1"):
+    for v in (VA, VB) if b % 2 == 0 else (VB, VA):
         res[v].append(block(v))
-for v in ("1", "0"):
+for v in (VA, VB):
     print(f"{var}={v}: median {statistics.median(res[v]):.3f} ms/step  (min {min(res[v]):.3f}, max {max(res[v]):.3f}, {len(res[v])} blocks of {steps})")
-print(f"difference of medians (0 - 1): {statistics.median(res['0']) - statistics.median(res['1']):+.3f} ms")
+print(f"difference of medians ({VB} - {VA}): {statistics.median(res[VB]) - statistics.median(res[VA]):+.3f} ms")
