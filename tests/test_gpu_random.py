@@ -110,6 +110,7 @@ def test_random_hierarchy_isosurface_and_filter(ctx, oracle, seed):
     iso = float(np.quantile(allv, 0.4))
     dls = [capi.DevLevel(ctx, lv) for lv in H.levels]
     ntri = 0
+    frags = []
     for l, lv in enumerate(H.levels):
         dst = capi.DevMF.from_host(ctx, dls[l], states[l])
         loops, want = np.zeros((lv.nboxes, 6), np.int64), []
@@ -124,7 +125,17 @@ def test_random_hierarchy_isosurface_and_filter(ctx, oracle, seed):
             assert np.array_equal(gk, k) and np.array_equal(gt, t), f"seed {seed} level {l} box {b}: keys / connectivity differ"
             assert np.array_equal(gv.view(np.int64), np.ascontiguousarray(v).view(np.int64)), f"seed {seed} level {l} box {b}: vertex data differ"
             ntri += len(t)
+            if len(gt):
+                frags.append((gv, gt))
     assert ntri > 0
+    # the global node / element sets (pa_iso_merge) against the oracle's sequential insertion (ng = 1: no per-FAB trimming);
+    # a surface whose nearby vertices do not form transitive clusters is handed back by the device path (None): not seen so far
+    if ng == 1 and sum(len(v) for v, _ in frags) < 6000:
+        wn, we = oracle.iso_merge(frags, nc)
+        got = capi.iso_merge(ctx, frags, nc)
+        if got is not None:
+            assert got[0].shape == wn.shape and np.array_equal(got[0].view(np.int64), np.ascontiguousarray(wn).view(np.int64)), f"seed {seed}: merged nodes differ"
+            assert np.array_equal(got[1], we), f"seed {seed}: merged elements differ"
     # box filter, the same width on every level (fgr 2 or 4: 1 or 2 ghost layers -- the random fine regions keep 2 coarse
     # cells to their level's edge, which is what 2 fine ghost layers + the interpolation stencil need)
     interp = int(rng.integers(0, 2))
