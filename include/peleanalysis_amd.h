@@ -90,7 +90,11 @@ typedef struct {
   /* One grouped exchange: for every i send nsend doubles from sendbuf to rank peer and receive nrecv doubles from it
    * into recvbuf (device pointers; either count may be 0).  Several entries may name the same peer: they are matched
    * in list order on both sides.  Stream-ordered: the call consumes data produced by work already enqueued on
-   * hip_stream, and work enqueued on it afterwards sees the received data. */
+   * hip_stream, and work enqueued on it afterwards sees the received data.
+   * POINT-TO-POINT contract (like MPI_Isend/Irecv inside FillBoundary): the library calls exchange on a rank only when
+   * that rank has at least one entry, so a rank without a box of the level, or without a neighbour on another rank,
+   * does not call it -- an implementation must pair sends with receives per (sender, receiver) in FIFO order and must
+   * never wait for ranks that are not named in x. */
   int (*exchange)(void* user, void* hip_stream, int32_t n, const pa_xfer* x);
   /* vals[i] = reduction over the ranks of vals[i] (host memory); op: 0 min, 1 max, 2 sum */
   int (*allreduce)(void* user, double* vals, int32_t n, int32_t op);

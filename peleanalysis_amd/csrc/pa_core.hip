@@ -481,6 +481,7 @@ extern "C" int64_t pa_mf_size(const pa_mf* M) { return M ? M->total : 0; }
 
 extern "C" int pa_mf_upload(pa_ctx* ctx, pa_mf* M, const double* host) {
   PaBind bind_(ctx);
+  if (ctx && M && M->total == 0) return 0;  // a rank that owns no box of the level: nothing to move (host may be null)
   if (!ctx || !M || !host) return pa_fail(ctx, "pa_mf_upload: null argument");
   PA_HIP(hipMemcpyAsync(M->data, host, sizeof(double) * (size_t)M->total, hipMemcpyHostToDevice, ctx->stream));
   PA_HIP(hipStreamSynchronize(ctx->stream));
@@ -488,6 +489,7 @@ extern "C" int pa_mf_upload(pa_ctx* ctx, pa_mf* M, const double* host) {
 }
 extern "C" int pa_mf_download(pa_ctx* ctx, const pa_mf* M, double* host) {
   PaBind bind_(ctx);
+  if (ctx && M && M->total == 0) return 0;
   if (!ctx || !M || !host) return pa_fail(ctx, "pa_mf_download: null argument");
   PA_HIP(hipMemcpyAsync(host, M->data, sizeof(double) * (size_t)M->total, hipMemcpyDeviceToHost, ctx->stream));
   PA_HIP(hipStreamSynchronize(ctx->stream));

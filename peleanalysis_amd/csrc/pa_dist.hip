@@ -571,9 +571,10 @@ pa_mf* CsPlan::mf(pa_ctx* ctx, int ncomp, int slot) {
 // direction); 32-bit index arithmetic.  One launch covers the region lists of several plans (LevBatch rows = regions).
 #define PA_XB 8
 struct XRegArgs { DLevelView L; DMFView M; int comp, ncomp; const int* regs; const long long* coff; double* buf; };
-__global__ __launch_bounds__(256) void k_xregions(LevBatch<XRegArgs, PA_XB> Bt, int unpack) {
+#define PA_YMAX 65535
+__global__ __launch_bounds__(256) void k_xregions(LevBatch<XRegArgs, PA_XB> Bt, int unpack, int y0) {
   unsigned ry;
-  const XRegArgs& X = Bt.a[Bt.find(blockIdx.y, ry)];
+  const XRegArgs& X = Bt.a[Bt.find(blockIdx.y + (unsigned)y0, ry)];
   const DLevelView& L = X.L;
   const DMFView& M = X.M;
   const int comp = X.comp, ncomp = X.ncomp;
@@ -598,9 +599,9 @@ __global__ __launch_bounds__(256) void k_xregions(LevBatch<XRegArgs, PA_XB> Bt, 
 
 // same-rank part of a coarse-source refill: region pairs of equal shape, coarse level -> coarse-source level
 struct XCopyArgs { DLevelView LS; DMFView MS; int scomp; DLevelView LD; DMFView MD; int dcomp, ncomp; const int* sregs; const int* dregs; };
-__global__ __launch_bounds__(256) void k_xcopy(LevBatch<XCopyArgs, PA_XB> Bt) {
+__global__ __launch_bounds__(256) void k_xcopy(LevBatch<XCopyArgs, PA_XB> Bt, int y0) {
   unsigned ry;
-  const XCopyArgs& X = Bt.a[Bt.find(blockIdx.y, ry)];
+  const XCopyArgs& X = Bt.a[Bt.find(blockIdx.y + (unsigned)y0, ry)];
   const int* R = X.sregs + 7 * ry;
   const int* D = X.dregs + 7 * ry;
   const unsigned nx = R[4] - R[1] + 1, ny = R[5] - R[2] + 1, nz = R[6] - R[3] + 1, n = nx * ny * nz;
@@ -642,7 +643,9 @@ static void launch_regions(pa_ctx* ctx, int njobs, const XJob* jobs, int unpack)
       maxcells = std::max(maxcells, S.maxcells);
     }
     if (!Bt.n) continue;
-    hipLaunchKernelGGL(k_xregions, dim3((unsigned)std::min<long long>((maxcells + 255) / 256, 64), (unsigned)Bt.ycum[Bt.n]), dim3(256), 0, ctx->stream, Bt, unpack);
+    const unsigned gx = (unsigned)std::min<long long>((maxcells + 255) / 256, 64);
+    for (int y0 = 0; y0 < Bt.ycum[Bt.n]; y0 += PA_YMAX)  // gridDim.y is limited to 65535 rows
+      hipLaunchKernelGGL(k_xregions, dim3(gx, (unsigned)std::min(PA_YMAX, Bt.ycum[Bt.n] - y0)), dim3(256), 0, ctx->stream, Bt, unpack, y0);
   }
 }
 
@@ -651,6 +654,9 @@ int pa_xexchange(pa_ctx* ctx, int njobs, const XJob* jobs) {
   for (int q = 0; q < njobs; ++q) {
     const XJob& J = jobs[q];
     XPlan& P = *J.plan;
+    // a plan owns ONE pair of packed buffers: two jobs of one call on the same plan would pack over each other
+    for (int p = 0; p < q; ++p)
+      if (jobs[p].plan == J.plan) return pa_fail(ctx, "ghost exchange: the same plan appears twice in one exchange (one packed buffer per plan)");
     if (J.ncomp < 1 || J.scomp < 0 || J.scomp + J.ncomp > J.src->ncomp || J.dcomp < 0 || (J.dst && J.dcomp + J.ncomp > J.dst->ncomp))
       return pa_fail(ctx, "ghost exchange: component range");
     PA_TRY(ensure_buf(ctx, P.sbuf, P.scap, P.send.coff.back() * J.ncomp));
@@ -686,7 +692,9 @@ int pa_xexchange(pa_ctx* ctx, int njobs, const XJob* jobs) {
       ++Bt.n;
       lmax = std::max(lmax, J.plan->lmax);
     }
-    if (Bt.n) hipLaunchKernelGGL(k_xcopy, dim3((unsigned)std::min<long long>((lmax + 255) / 256, 64), (unsigned)Bt.ycum[Bt.n]), dim3(256), 0, ctx->stream, Bt);
+    if (Bt.n)
+      for (int y0 = 0; y0 < Bt.ycum[Bt.n]; y0 += PA_YMAX)
+        hipLaunchKernelGGL(k_xcopy, dim3((unsigned)std::min<long long>((lmax + 255) / 256, 64), (unsigned)std::min(PA_YMAX, Bt.ycum[Bt.n] - y0)), dim3(256), 0, ctx->stream, Bt, y0);
   }
   PA_HIP(hipGetLastError());
   if (!xf.empty()) {

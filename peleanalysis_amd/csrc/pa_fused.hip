@@ -444,7 +444,7 @@ static void march_launch(hipStream_t st, const BP& bp, int nx, int ny, int nz, u
       else if (A.order) g = dim3(g.x * g.y, 1);
       switch (dbg) {
 #define PA_DBGCASE(D) case D: hipLaunchKernelGGL((k_gradcurv_march3<BP, 13, false, false, D>), g, dim3(64 * 16), 0, st, bp, A); return;
-        PA_DBGCASE(1) PA_DBGCASE(7) PA_DBGCASE(256) PA_DBGCASE(512) PA_DBGCASE(1024) PA_DBGCASE(2048)
+        PA_DBGCASE(1) PA_DBGCASE(2) PA_DBGCASE(4) PA_DBGCASE(6) PA_DBGCASE(7) PA_DBGCASE(256) PA_DBGCASE(512) PA_DBGCASE(1024) PA_DBGCASE(2048)
 #undef PA_DBGCASE
         default: break;
       }

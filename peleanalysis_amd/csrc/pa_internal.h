@@ -203,14 +203,20 @@ struct PaBind {
 };
 
 // ---------------------------------------------------------------- device helpers
-// Component stride of a FAB inside a pa_mf (in doubles): the cell count rounded up to 512 B and
-// kept off multiples of 16 KiB.  With the plain AMReX stride (nx*ny*nz) a 128^3 box puts all
-// components of one cell 16 MiB apart = on the same HBM channel, which costs ~20 % of the write
-// bandwidth of an 8-output kernel (tools/bench/membench2.hip); amrex::Array4 carries an explicit
-// nstride too, so this stays within the reference's data model.
+// Component stride of a FAB inside a pa_mf (in doubles): the cell count rounded up to 512 B and placed at
+// 2 KiB past a multiple of 16 KiB (boxes of >= 32^3 cells; smaller ones are only kept off multiples of 16 KiB).
+// With the plain AMReX stride (nx*ny*nz) a 128^3 box puts all components of one cell 16 MiB apart = on the same
+// HBM channel, which costs ~20 % of the write bandwidth of an 8-output kernel (tools/bench/membench2.hip).  The
+// address interleave repeats every 16 KiB (tools/bench/membench5.hip "stride", profiles/r03_membench5_stride.txt:
+// 8 output streams + 1 input stream, 1-D streaming, stride = 16 MiB + pad: pad 0 2.49 ms, 4 KiB 2.11, 512 B 1.81,
+// 1 KiB 1.69, 2 KiB 1.65 = the rate of streams 1 GiB apart): 2 KiB spreads the 8 results of the fused sweep evenly
+// over the period.  amrex::Array4 carries an explicit nstride too, so this stays within the reference's data model.
 __host__ __device__ __forceinline__ long long pa_cstride(long long ncells, int ncomp) {
   long long cs = (ncells + 63) / 64 * 64;
-  if (ncomp > 1 && (cs % 2048) == 0) cs += 64;
+  if (ncomp > 1) {
+    if (ncells >= 32768) cs += (256 + 2048 - cs % 2048) % 2048;
+    else if ((cs % 2048) == 0) cs += 64;
+  }
   return cs;
 }
 

@@ -286,7 +286,7 @@ extern "C" int pa_smooth_solve(pa_ctx* ctx, int nlev, pa_mf* const* rhs, int rco
   for (int l = 0; l < nlev; ++l) {
     if (!rhs[l] || !sol[l] || rhs[l]->lev != sol[l]->lev) return pa_fail(ctx, "pa_smooth_solve: rhs/sol on different levels");
     if (rcomp < 0 || rcomp >= rhs[l]->ncomp || scomp < 0 || scomp >= sol[l]->ncomp) return pa_fail(ctx, "pa_smooth_solve: component range");
-    if (rhs[l]->lev->nremote > 0) return pa_fail(ctx, "pa_smooth_solve: levels sharded across ranks are not supported (composite solve on one rank)");
+    if (rhs[l]->lev->nranks > 1) return pa_fail(ctx, "pa_smooth_solve: do_smooth is not supported on a sharded hierarchy (composite solve on one rank)");
     S.lev.push_back(rhs[l]->lev);
     if (l > 0)
       for (const DBox& B : S.lev[l]->boxes)

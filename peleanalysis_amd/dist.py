@@ -126,12 +126,21 @@ def host_exchange(rows: np.ndarray, glocal: Dict[int, int], src: MultiFab, dst: 
 
 # ------------------------------------------------------------------------------- transports
 def init_rccl(ctx: "capi.Context", group=None) -> None:
-    """built-in RCCL transport: rank 0 creates the communicator id, torch.distributed (any backend) broadcasts it"""
+    """built-in RCCL transport: rank 0 creates the communicator id, torch.distributed (any backend) broadcasts it.
+    Every rank always takes part in the broadcast -- rank 0 sends an error marker when it could not make the id -- so that a
+    failure on rank 0 raises on ALL ranks and their next collective (bench.py's fallback to the gloo transport) still lines up."""
     import torch.distributed as dist
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    ids = [ctx.rccl_unique_id() if rank == 0 else None]
-    dist.broadcast_object_list(ids, src=0, group=group)
-    ctx.init_rccl(world, rank, ids[0])
+    msg = [None, None]
+    if rank == 0:
+        try:
+            msg[0] = ctx.rccl_unique_id()
+        except Exception as e:  # librccl missing, ncclGetUniqueId failed
+            msg[1] = repr(e)[:300]
+    dist.broadcast_object_list(msg, src=0, group=group)
+    if msg[1] is not None or msg[0] is None:
+        raise RuntimeError("RCCL unique id not available on rank 0: " + str(msg[1]))
+    ctx.init_rccl(world, rank, msg[0])
 
 
 class GlooComm:

@@ -50,11 +50,15 @@ class Level:
 
 
 def comp_stride(ncells, ncomp: int):
-    """Same rule as pa_cstride: cells rounded up to 64 doubles (512 B), never a multiple of 16 KiB
-    when there is more than one component (HBM channel conflicts, see csrc/pa_internal.h)."""
-    cs = (np.asarray(ncells, dtype=np.int64) + 63) // 64 * 64
+    """Same rule as pa_cstride: cells rounded up to 64 doubles (512 B); with more than one component, boxes of >= 32^3
+    cells sit 2 KiB past a multiple of 16 KiB and smaller ones are kept off multiples of 16 KiB (HBM address interleave,
+    see csrc/pa_internal.h)."""
+    n = np.asarray(ncells, dtype=np.int64)
+    cs = (n + 63) // 64 * 64
     if ncomp > 1:
-        cs = np.where(cs % 2048 == 0, cs + 64, cs)
+        big = cs + (256 + 2048 - cs % 2048) % 2048
+        small = np.where(cs % 2048 == 0, cs + 64, cs)
+        cs = np.where(n >= 32768, big, small)
     return cs
 
 

@@ -138,6 +138,7 @@ def main():
 
     tin, fin = one(1, ng, lambda tot: 300.0 + 1700.0 * torch.rand(tot, dtype=torch.float64, device=dev))
     outs_f = []
+    os.environ["PA_FILTER_EXACT"] = "1"  # the two tap-order kernels against each other, bit for bit
     for env in ("1", "0"):
         os.environ["PA_FILTER_STREAM"] = env
         to, fo = one(1, 0, lambda tot: torch.zeros(tot, dtype=torch.float64, device=dev))
@@ -147,7 +148,16 @@ def main():
         ctx.sync()
         outs_f.append((to, fo))
     os.environ.pop("PA_FILTER_STREAM")
+    os.environ.pop("PA_FILTER_EXACT")
     assert same_bits(outs_f[0][0], outs_f[1][0]), "box filter: streaming kernel and tile kernel differ"
+    # the separable default against the tap-order sum: SURVEY 8(d) metric, <= 1e-12 * Linf
+    ts, fs = one(1, 0, lambda tot: torch.zeros(tot, dtype=torch.float64, device=dev))
+    torch.cuda.synchronize()
+    ctx.check(ctx.lib.pa_boxfilter_level(ctx.h, fin.h, fs.h, 0, 1, ng, w))
+    ctx.sync()
+    dsep = float((ts - outs_f[0][0]).abs().max()) / float(outs_f[0][0].abs().max())
+    assert 0.0 < dsep <= 1e-12, f"separable box filter differs from the tap-order sum by {dsep:.3e} of Linf (0 would mean the exact kernel ran)"
+    del ts, fs
     tin.fill_(1.0)
     to, fo = outs_f[0]
     torch.cuda.synchronize()

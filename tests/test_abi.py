@@ -46,7 +46,10 @@ def test_mf_layout_matches_python_mirror():
         assert np.all(cs >= n)
         if ncomp > 1:
             assert np.all(cs % 2048 != 0)  # never a multiple of 16 KiB (HBM channel aliasing)
-    assert int(comp_stride(128 ** 3, 8)) == 128 ** 3 + 64 and int(comp_stride(128 ** 3, 1)) == 128 ** 3
+            assert np.all((cs % 2048 == 256) | (n < 32768))  # boxes of >= 32^3 cells: 2 KiB past a multiple of 16 KiB
+            assert np.all(cs - n < 2048 + 64)  # at most 16.5 KiB of padding per component
+    assert int(comp_stride(128 ** 3, 8)) == 128 ** 3 + 256 and int(comp_stride(128 ** 3, 1)) == 128 ** 3
+    assert int(comp_stride(16 ** 3, 8)) == 16 ** 3 + 64 and int(comp_stride(20 ** 3, 8)) == 8000
 
 
 def test_box_filter_weights_host_entry(oracle):

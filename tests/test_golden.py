@@ -94,7 +94,7 @@ def test_hip_reproduces_gradcurv_fixture(ctx, fused):
 
 
 @pytest.mark.gpu
-def test_hip_reproduces_filter_fixture(ctx):
+def test_hip_reproduces_filter_fixture(ctx, filter_mode):
     import ctypes as C
     from peleanalysis_amd import capi
     d, H = _load("filter_amr2.npz")
@@ -116,5 +116,9 @@ def test_hip_reproduces_filter_fixture(ctx):
     ctx.sync()
     for l, lv in enumerate(H.levels):
         got = dout[l].download()
+        scale = max(float(np.abs(d[f"out{l}"][b]).max()) for b in range(lv.nboxes))
         for b in range(lv.nboxes):
-            assert _same(got.valid(b)[0], d[f"out{l}"][b])
+            if filter_mode == "exact":
+                assert _same(got.valid(b)[0], d[f"out{l}"][b])
+            else:  # separable default: SURVEY 8(d) metric
+                assert float(np.abs(got.valid(b)[0] - d[f"out{l}"][b]).max()) <= 1e-12 * scale

@@ -8,7 +8,7 @@ import pytest
 
 from peleanalysis_amd import capi
 from peleanalysis_amd.hierarchy import MultiFab, cell_centers, chop_box, field_flame, nested_hierarchy
-from util import assert_valid_bits_equal, make_states, rel_err
+from util import assert_filter_parity, assert_valid_bits_equal, make_states, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -34,7 +34,7 @@ def _filter_gpu(ctx, H, ins, ncomp, base_fgr, same, interp_type, filter_type=1):
 
 
 @pytest.mark.parametrize("per,interp_type,same", [((1, 1, 0), 1, False), ((0, 0, 0), 0, False), ((1, 0, 1), 1, True)])
-def test_filter_pipeline_matches_oracle(ctx, oracle, per, interp_type, same):
+def test_filter_pipeline_matches_oracle(ctx, oracle, filter_mode, per, interp_type, same):
     """filterPlt.cpp:126-219 on a 3-level hierarchy: fgr 2/4/8 (27-, 125-, 729-point box filters),
     FillPatchTwoLevels (cell-conservative linear / piecewise constant) and wall extrapolation"""
     H = nested_hierarchy(32, 3, 16, is_per=per)
@@ -52,13 +52,13 @@ def test_filter_pipeline_matches_oracle(ctx, oracle, per, interp_type, same):
             s = 4 - ngf
             sl = (slice(None), slice(s, g.shape[1] - s), slice(s, g.shape[2] - s), slice(s, g.shape[3] - s))
             assert np.array_equal(g[sl].view(np.int64), w[sl].view(np.int64)), f"ghost fill differs: level {l} box {b}"
-        assert_valid_bits_equal(got[l], o_out[l], [(c, c) for c in range(ncomp)], f"filter level {l} (fgr {info[l][0]})")
+        assert_filter_parity(got[l], o_out[l], [(c, c) for c in range(ncomp)], f"filter level {l} (fgr {info[l][0]})", filter_mode)
         for c in range(ncomp):
             assert rel_err(got[l], o_out[l], c, c) <= 1e-12
 
 
 @pytest.mark.parametrize("ftype", [0, 3, 4, 8])
-def test_filter_pipeline_other_filter_types(ctx, oracle, ftype):
+def test_filter_pipeline_other_filter_types(ctx, oracle, filter_mode, ftype):
     """filter_type 0 / 3 (= 7) / 4 / 8 (filterPlt.cpp:80): the same ghost fill and tap loop with the closed-form weights of
     those PelePhysics types (fgr 2 / 4 / 8 on the three levels enter the weights only: 1-, 3- and 5-point stencils)"""
     H = nested_hierarchy(32, 3, 16, is_per=(1, 0, 0))
@@ -69,12 +69,12 @@ def test_filter_pipeline_other_filter_types(ctx, oracle, ftype):
     oracle.filter_pipeline(H.levels, o_in, o_out, ncomp, base_fgr=2, interp_type=1, filter_type=ftype)
     got, _ = _filter_gpu(ctx, H, ins, ncomp, 2, False, 1, filter_type=ftype)
     for l in range(H.nlev):
-        assert_valid_bits_equal(got[l], o_out[l], [(c, c) for c in range(ncomp)], f"filter type {ftype} level {l}")
+        assert_filter_parity(got[l], o_out[l], [(c, c) for c in range(ncomp)], f"filter type {ftype} level {l}", filter_mode)
         if ftype == 0:
             assert_valid_bits_equal(got[l], ins[l], [(c, c) for c in range(ncomp)], "type 0 is the identity")
 
 
-def test_filter_generic_width_and_fab_entry(ctx, oracle):
+def test_filter_generic_width_and_fab_entry(ctx, oracle, filter_mode):
     """fgr = 6 (ng = 3, no LDS specialisation) through pa_boxfilter_fab on ragged boxes"""
     from peleanalysis_amd.hierarchy import Level
     lv = Level(chop_box((0, 0, 0), (19, 13, 10), 9), (0, 0, 0), (19, 13, 10), (1, 1, 1), (0, 0, 0), (1, 1, 1))
@@ -93,7 +93,7 @@ def test_filter_generic_width_and_fab_entry(ctx, oracle):
     for b in range(lv.nboxes):
         ctx.check(ctx.lib.pa_boxfilter_fab(ctx.h, capi.box_of(lv, b), di.fab(b), do.fab(b), 0, 1, 3, wc))
     ctx.sync()
-    assert_valid_bits_equal(do.download(), oo, [(0, 0)], "pa_boxfilter_fab ng=3")
+    assert_filter_parity(do.download(), oo, [(0, 0)], "pa_boxfilter_fab ng=3", filter_mode)
 
 
 # ------------------------------------------------------------------------------- marching cubes

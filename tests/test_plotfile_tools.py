@@ -227,10 +227,10 @@ def test_grad_tool_end_to_end(tmp_path, oracle):
     assert bad.returncode != 0 and "Cannot find nope" in bad.stderr
 
 
-def _run(tool, args, cwd):
+def _run(tool, args, cwd, timeout=None):
     if not os.path.exists(os.path.join(BIN, tool)):
         _build_tools()
-    out = subprocess.run([os.path.join(BIN, tool)] + args, cwd=cwd, capture_output=True, text=True)
+    out = subprocess.run([os.path.join(BIN, tool)] + args, cwd=cwd, capture_output=True, text=True, timeout=timeout)
     assert out.returncode == 0, out.stderr + out.stdout
     return out
 
@@ -264,6 +264,8 @@ def test_curvature_tool_end_to_end(tmp_path, oracle, fused):
 def test_filter_tool_end_to_end(tmp_path, oracle):
     p, H, mfs = _synth(tmp_path, nlev=2, base=16, box=16, per=(0, 0, 0))
     _run("filterPlt3d.ex", ["infile=" + p, "max_grid_size=8", "variables=temp density"], tmp_path)
+    rsep = read_plotfile(str(tmp_path / "plt00005_filtered"))  # the separable default, compared below to 1e-12 * Linf
+    _run("filterPlt3d.ex", ["infile=" + p, "max_grid_size=8", "variables=temp density", "exact_filter=1"], tmp_path)
     r = read_plotfile(str(tmp_path / "plt00005_filtered"))
     assert r.names == ["temp", "density"] and r.time == 0.125
     # oracle on the re-chopped BoxArray (BoxArray::maxSize(8))
@@ -287,8 +289,12 @@ def test_filter_tool_end_to_end(tmp_path, oracle):
     for l, lv in enumerate(levels):
         for b in range(lv.nboxes):
             assert np.array_equal(np.ascontiguousarray(r.mfs[l].valid(b)).view(np.int64), np.ascontiguousarray(outs[l].valid(b)).view(np.int64))
+        for c in range(2):
+            scale = max(float(np.abs(outs[l].valid(b)[c]).max()) for b in range(lv.nboxes))
+            for b in range(lv.nboxes):
+                assert float(np.abs(rsep.mfs[l].valid(b)[c] - outs[l].valid(b)[c]).max()) <= 1e-12 * scale
     # filter_type=4 (the 5-point approximation of the box filter; an odd base_fgr is fine there), and the types that stay refused
-    _run("filterPlt3d.ex", ["infile=" + p, "max_grid_size=8", "variables=temp density", "filter_type=4", "base_fgr=3"], tmp_path)
+    _run("filterPlt3d.ex", ["infile=" + p, "max_grid_size=8", "variables=temp density", "filter_type=4", "base_fgr=3", "exact_filter=1"], tmp_path)
     r4 = read_plotfile(str(tmp_path / "plt00005_filtered"))
     outs4 = [MultiFab(lv, 2, 0) for lv in levels]
     oracle.filter_pipeline(levels, [s.copy() for s in ins], outs4, 2, base_fgr=3, interp_type=1, filter_type=4)
@@ -762,7 +768,7 @@ def test_tool_options_level_limits_ranges_inputs_file(tmp_path, oracle):
                 assert np.array_equal(np.ascontiguousarray(got[gc]).view(np.int64), np.ascontiguousarray(want[wc]).view(np.int64)), (l, b, gc)
     # filterPlt: two of three levels, the same 125-tap filter on both, piecewise-constant interpolation
     _run("filterPlt3d.ex", ["infile=" + p, "max_filter_level=1", "same_fgr_all_levels=1", "base_fgr=4", "interp_type=0", "max_grid_size=8", "is_per=1 1 0",
-                            "variables=temp"], tmp_path)
+                            "variables=temp", "exact_filter=1"], tmp_path)
     f = read_plotfile(str(tmp_path / "plt00005_filtered"))
     assert f.hier.nlev == 2 and f.names == ["temp"]
     ins = [MultiFab(lv, 1, 2, fill=0.0) for lv in H2.levels]
@@ -830,6 +836,48 @@ def test_tools_multi_gpu_outputs_are_byte_identical(tmp_path, tool, args, suffix
         else:
             got = _tree_bytes(str(d / ("plt00005" + suffix)))
             assert len(got) >= 5
+        if ref is None:
+            ref = got
+        else:
+            assert got.keys() == ref.keys()
+            for k in ref:
+                assert got[k] == ref[k], f"{tool} ngpus={n}: {k} differs from the single-GPU output"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tool,args,suffix", [
+    ("grad3d.ex", ["gradVar=temp", "is_per=1 1 0"], "_gt"),
+    ("curvature3d.ex", ["progressName=temp", "is_per=1 1 0", "fused=0"], "_K"),
+    ("curvature3d.ex", ["progressName=temp", "is_per=1 1 0"], "_K"),
+    ("filterPlt3d.ex", ["max_grid_size=8", "is_per=1 1 0"], "_filtered"),
+    ("isosurface3d.ex", ["isoCompName=temp", "isoVal=1150", "comps=0 1", "outfile_base=surf"], "surf.mef"),
+])
+def test_tools_multi_gpu_sparse_levels(tmp_path, tool, args, suffix):
+    """More ranks than boxes: every level is TWO adjacent 8^3 boxes, dealt to 3 and 4 ranks, so some ranks own nothing and
+    never enter a level's ghost exchange (the library calls a transport only on ranks that send or receive).  A
+    transport that waits for all ranks hangs here or pairs the lists of two different exchanges (round-2 advisor finding
+    on the in-process transport); run under a timeout, outputs byte-identical to the single-GPU run."""
+    from peleanalysis_amd.hierarchy import Hierarchy, Level, chop_box
+    per = np.asarray((1, 1, 0))
+    plo, phi = np.zeros(3), np.asarray((1.0, 0.5, 0.5))
+    l0 = Level(chop_box((0, 0, 0), (15, 7, 7), 8), np.zeros(3, dtype=np.int64), np.asarray((15, 7, 7)), per, plo, phi)
+    l1 = Level(chop_box((8, 4, 4), (23, 11, 11), 8), np.zeros(3, dtype=np.int64), np.asarray((31, 15, 15)), per, plo, phi)
+    H = Hierarchy([l0, l1], 2)
+    assert l0.nboxes == 2 and l1.nboxes == 2
+    mfs = make_states(H, 3, 0, field_flame, seed=5)
+    p = str(tmp_path / "plt00005")
+    write_plotfile(p, H, mfs, ["temp", "x_velocity", "density"], time=0.125, level_steps=[5, 5])
+    ref = None
+    for n in (1, 3, 4):
+        d = tmp_path / f"n{n}"
+        d.mkdir()
+        _run(tool, ["infile=" + p] + args + [f"ngpus={n}", "gpu_share=1"], d, timeout=120)
+        if suffix.startswith("surf"):
+            got = {f: open(d / f, "rb").read() for f in os.listdir(d) if f.startswith("surf")}
+            assert suffix in got
+        else:
+            got = _tree_bytes(str(d / ("plt00005" + suffix)))
+            assert len(got) >= 4
         if ref is None:
             ref = got
         else:

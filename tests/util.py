@@ -28,6 +28,16 @@ def rel_err(got: MultiFab, want: MultiFab, gc, wc):
     return float((d / np.maximum(np.abs(w_all), scale if scale > 0 else 1.0)).max())
 
 
+def assert_filter_parity(got: MultiFab, want: MultiFab, comps, what, mode):
+    """exact mode: bit for bit; separable mode: SURVEY 8(d)'s metric <= 1e-12 (the separable sum differs by a few ulp)"""
+    if mode == "exact":
+        assert_valid_bits_equal(got, want, comps, what)
+    else:
+        for gc, wc in comps:
+            e = rel_err(got, want, gc, wc)
+            assert e <= 1e-12, f"{what}: separable filter differs from the oracle by {e:.3e} (comp {gc})"
+
+
 def make_states(H, ncomp, ng, fn, seed=None):
     out = []
     for lev in H.levels:

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void k_stream(const double* __restrict__ in, d
 
 static double *g_in, *g_out;
 static const int nb = 64;
-static const long long boxsz = 128LL * 128 * 128 + 64;
+static long long boxsz = 128LL * 128 * 128 + 64;  // MB_PAD=<doubles> overrides the + 64
 
 template <typename F>
 int timeit(const char* name, F launch) {
@@ -120,10 +120,12 @@ int runs() {
 }
 
 int main() {
+  if (getenv("MB_PAD")) { boxsz = 128LL * 128 * 128 + atoll(getenv("MB_PAD")); printf("component stride pad %lld doubles\n", boxsz - 128LL * 128 * 128); }
   CK(hipMalloc(&g_in, 8 * boxsz * nb));
   CK(hipMalloc(&g_out, 8 * boxsz * nb * 8));
   CK(hipMemset(g_in, 0, 8 * boxsz * nb));
   CK(hipMemset(g_out, 0, 8 * boxsz * nb * 8));
+  if (getenv("MB_QUICK")) { runs<1, 0>(); return 0; }
   for (int rep = 0; rep < 2; ++rep) {
     runs<1, 0>(); runs<2, 0>(); runs<2, 1>(); runs<2, 2>();
     run<1, 16, 0, 90000>(128, 0);

@@ -5,6 +5,7 @@
 // last partial).  No arithmetic.  Reported GB/s = algorithmic 72 B/cell.  Not part of the product.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
 // FEAT bits: 1 ghosted phi layout, 2 halo row waves, 4 edge wave, 8 warm-up: 3 extra planes of stores
@@ -109,7 +110,7 @@ __global__ void k_fill(double* p, long long n, int mode) {
 }
 static double *g_in, *g_out;
 static const int nb = 64;
-static const long long boxsz = 128LL * 128 * 128 + 64, inbox = 132LL * 132 * 132 + 64;
+static long long boxsz = 128LL * 128 * 128 + 64, inbox = 132LL * 132 * 132 + 64;  // MB_PAD=<doubles> overrides the + 64 of boxsz
 
 template <int TY, int FEAT, int NFMA = 0, int NLDS = 0, int NBURN = 0, int NWORK = 0>
 int run() {
@@ -134,6 +135,7 @@ int run() {
 }
 
 int main(int argc, char**) {
+  if (getenv("MB_PAD")) { boxsz = 128LL * 128 * 128 + atoll(getenv("MB_PAD")); printf("component stride pad %lld doubles\n", boxsz - 128LL * 128 * 128); }
   CK(hipMalloc(&g_in, 8 * inbox * nb));
   CK(hipMalloc(&g_out, 8 * boxsz * nb * 8));
   CK(hipMemset(g_in, 0, 8 * inbox * nb));

@@ -5,11 +5,12 @@
 // are dealt to the ranks by pa_distribution_map, every rank creates its share with pa_level_create_sharded and runs the
 // SAME library pipeline as a 1-GPU run -- the library does the cross-rank ghost fills through the rank's transport:
 //   * RCCL over xGMI (pa_ctx_init_rccl: one communicator rank per thread) when every rank has its own GPU;
-//   * an in-process transport (peer copies between the contexts' buffers around two barriers) when ranks share a GPU
+//   * an in-process transport (pairwise peer copies between the contexts' buffers through FIFO mailboxes) when ranks share a GPU
 //     (gpu_share=1 / fewer GPUs than ranks: how the tests run n > 1 on a one-GPU box) or RCCL is unavailable.
 // Results are bit-identical for every n, so the output files are byte-identical.
 #pragma once
 #include <condition_variable>
+#include <deque>
 #include <mutex>
 #include <thread>
 
@@ -42,8 +43,6 @@ struct Team {
   std::vector<User> users;
   std::vector<pa_comm> comms;
   std::unique_ptr<Barrier> bar;
-  std::vector<const pa_xfer*> xlist;
-  std::vector<int> xn;
   std::vector<std::vector<double>> red;
 
   explicit Team(const ParmParse& pp) {
@@ -58,8 +57,7 @@ struct Team {
     ctx.resize(n);
     users.resize(n);
     comms.resize(n);
-    xlist.assign(n, nullptr);
-    xn.assign(n, 0);
+    box.resize((size_t)n * n);
     red.resize(n);
     bar.reset(new Barrier(n));
     for (int r = 0; r < n; ++r) users[r] = User{this, r};
@@ -97,27 +95,60 @@ struct Team {
   void run(F body) { run_threads(body); }
 
   // ---- in-process transport (pa_comm callbacks; errors abort the process like the tools' other failures)
+  // PAIRWISE, like RCCL's grouped send / receive and the gloo transport: the library calls a rank's exchange only when
+  // that rank has something to send or receive (pa_xexchange), so a rank that owns no box of a level -- or has no
+  // neighbour on another rank -- never shows up and nothing here may wait for "all ranks".  Every ordered pair
+  // (sender, receiver) has a FIFO mailbox; the k-th send of a to b meets the k-th receive of b from a (both sides derive
+  // their lists from the same plans in the same order).  A rank posts all its sends first (never blocks), then serves
+  // its receives (waits for the peer's post, copies device to device), then waits until its own posts were consumed,
+  // so its packed buffers may be overwritten when the call returns.
+  struct Post { const double* buf; long long n; bool done; };
+  std::mutex xm;
+  std::condition_variable xcv;
+  std::vector<std::deque<Post*>> box;  // [sender * n + receiver]
   static int exchange(void* user, void*, int32_t cnt, const pa_xfer* x) {
     User* u = (User*)user;
     Team* T = u->t;
     const int me = u->r;
     T->ctx[me]->check(pa_sync(T->ctx[me]->h));  // my packed buffers are complete
-    T->xlist[me] = x;
-    T->xn[me] = cnt;
-    T->bar->wait();
+    std::vector<Post> mine;
+    mine.reserve(cnt);
+    for (int i = 0; i < cnt; ++i)
+      if (x[i].nsend > 0) mine.push_back(Post{x[i].sendbuf, x[i].nsend, false});
+    {
+      std::lock_guard<std::mutex> lk(T->xm);
+      size_t k = 0;
+      for (int i = 0; i < cnt; ++i)
+        if (x[i].nsend > 0) {
+          if (x[i].peer < 0 || x[i].peer >= T->n || x[i].peer == me) Abort("in-process transport: bad peer");
+          T->box[(size_t)me * T->n + x[i].peer].push_back(&mine[k++]);
+        }
+    }
+    T->xcv.notify_all();
     for (int i = 0; i < cnt; ++i) {
       if (x[i].nrecv <= 0) continue;
       const int p = x[i].peer;
-      int k = 0;  // which of my receives from p this is: matched with p's k-th send to me
-      for (int j = 0; j < i; ++j) k += x[j].peer == p && x[j].nrecv > 0;
-      const pa_xfer* y = T->xlist[p];
-      int m = -1;
-      for (int j = 0; j < T->xn[p]; ++j)
-        if (y[j].peer == me && y[j].nsend > 0 && k-- == 0) { m = j; break; }
-      if (m < 0 || y[m].nsend != x[i].nrecv) Abort("in-process transport: send / receive lists of two ranks do not match");
-      T->ctx[me]->check(pa_memcpy_d2d(T->ctx[me]->h, x[i].recvbuf, y[m].sendbuf, 8 * x[i].nrecv));
+      if (p < 0 || p >= T->n || p == me) Abort("in-process transport: bad peer");
+      Post* q;
+      {
+        std::unique_lock<std::mutex> lk(T->xm);
+        auto& mb = T->box[(size_t)p * T->n + me];
+        T->xcv.wait(lk, [&] { return !mb.empty(); });
+        q = mb.front();
+        mb.pop_front();
+      }
+      if (q->n != x[i].nrecv) Abort("in-process transport: send / receive lists of two ranks do not match");
+      T->ctx[me]->check(pa_memcpy_d2d(T->ctx[me]->h, x[i].recvbuf, q->buf, 8 * x[i].nrecv));  // synchronous
+      {
+        std::lock_guard<std::mutex> lk(T->xm);
+        q->done = true;
+      }
+      T->xcv.notify_all();
     }
-    T->bar->wait();  // nobody packs again before everyone has copied
+    {
+      std::unique_lock<std::mutex> lk(T->xm);
+      T->xcv.wait(lk, [&] { for (const Post& q : mine) if (!q.done) return false; return true; });
+    }
     return 0;
   }
   static int allreduce(void* user, double* vals, int32_t cnt, int32_t op) {

@@ -62,18 +62,26 @@ if len(sys.argv) > 3 and sys.argv[3] == "gradonly":
     sys.exit(0)
 
 MCONLY = len(sys.argv) > 3 and sys.argv[3] == "mconly"
-# ---- box filter (filterPlt.cpp:217): 16 B/cell, fgr 2 / 4 / 8 -> 27 / 125 / 729 taps
+# ---- box filter (filterPlt.cpp:217): 16 B/cell, fgr 2 / 4 / 8 -> 27 / 125 / 729 taps; the separable default and the tap-order form
+FILTERONLY = len(sys.argv) > 3 and sys.argv[3] == "filteronly"
 for fgr in (() if MCONLY else (2, 4, 8)):
     w = (C.c_double * (fgr + 2))()
     ng = ctx.lib.pa_box_filter_weights(fgr, w)
     tin, fin = dev_mf(1, ng)
     tfo, fo = dev_mf(1, 0, False)
     ctx.check(ctx.lib.pa_fill_boundary(ctx.h, fin.h, 0, 1, ng))
-    ms = timed(7, lambda: ctx.check(ctx.lib.pa_boxfilter_level(ctx.h, fin.h, fo.h, 0, 1, ng, w)))
     taps = (2 * ng + 1) ** 3
-    out["kernels"][f"k_boxfilter fgr={fgr} ({taps} taps)"] = {"ms": ms, "bytes_per_cell": 16, "GBs": cells * 16 / ms / 1e6, "frac_hbm": cells * 16 / ms / 1e6 / HBM,
-                                                             "Mcells_s": cells / ms / 1e3, "Gflop_s": cells * 2 * taps / ms / 1e6}
+    for mode in ("separable", "exact"):
+        if mode == "exact":
+            os.environ["PA_FILTER_EXACT"] = "1"
+        ms = timed(7, lambda: ctx.check(ctx.lib.pa_boxfilter_level(ctx.h, fin.h, fo.h, 0, 1, ng, w)))
+        os.environ.pop("PA_FILTER_EXACT", None)
+        key = f"k_filter_sep fgr={fgr} (3 x {2 * ng + 1} taps)" if mode == "separable" else f"k_boxfilter fgr={fgr} ({taps} taps, PA_FILTER_EXACT=1)"
+        out["kernels"][key] = {"ms": ms, "bytes_per_cell": 16, "GBs": cells * 16 / ms / 1e6, "frac_hbm": cells * 16 / ms / 1e6 / HBM, "Mcells_s": cells / ms / 1e3}
     del fin, fo, tin, tfo
+if FILTERONLY:
+    print(json.dumps(out))
+    sys.exit(0)
 
 # ---- marching cubes on one FAB (isosurface.cpp:1566-1592): scan 8 B/cell (+ mask 8 B/cell as the reference stores it)
 g = box + 2

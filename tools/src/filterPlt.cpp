@@ -1,11 +1,15 @@
 // filterPlt3d -- drop-in for PeleAnalysis Src/filterPlt.cpp (box filter) on MI355X.
 //   filterPlt3d.ex infile=<plt> [max_filter_level=<n>] [filter_type=1 (0 none, 1 box, 3/7 and 4/8: 3- and 5-point approximations)] [base_fgr=2] [same_fgr_all_levels=false]
-//       [max_grid_size=32] [interp_type=1] [variables="a b"] [is_per="0 0 0"]
+//       [max_grid_size=32] [interp_type=1] [variables="a b"] [is_per="0 0 0"] [exact_filter=0]
+// exact_filter=0 (default): the filter as three 1-D passes (tensor-product weights; within 1e-12 * Linf of the reference's
+// tap-order sum, HBM-bound); exact_filter=1 (or PA_FILTER_EXACT=1): Filter::apply_filter's (2ng+1)^3 taps in the
+// reference's accumulation order, bit for bit with the CPU restatement (3-D build; the 2-D build always sums tap by tap).
 // Output: <root>_filtered, same variable names, plotfile time (filterPlt.cpp:222-225).
 // The plotfile Header stores no periodicity; like PltFileManager's Geometry it defaults to
 // non-periodic unless is_per / geometry.is_periodic is given.
 // Built twice: filterPlt3d.ex, and with -DPA_SPACEDIM=2 filterPlt2d.ex = the AMREX_SPACEDIM == 2 build (2-D plotfile in and
 // out, is_per of two entries, (2 ng + 1)^2 taps; the level is one plane of cells with z a wall direction).
+#include <cstdlib>
 #include "../common/pa_team.h"
 #ifndef PA_SPACEDIM
 #define PA_SPACEDIM 3
@@ -27,6 +31,9 @@ int main(int argc, char** argv) {
   pp.query("same_fgr_all_levels", same_fgr);
   pp.query("max_grid_size", max_grid_size);
   pp.query("interp_type", interp_type);
+  int exact_filter = 0;
+  pp.query("exact_filter", exact_filter);
+  if (exact_filter) setenv("PA_FILTER_EXACT", "1", 1);  // read by the library at every launch
   {  // PelePhysics filter types restated in the library: 0 none, 1 box, 3 / 7 and 4 / 8 the 3- and 5-point approximations
     std::vector<double> wt(std::max(fgr, 3) + 2);
     if (pa_filter_weights(filter_type, std::max(fgr, 1), wt.data()) < 0)
