@@ -124,6 +124,170 @@ def cpu_baseline(base, nlev, box):
                       f"{box}^3 boxes{' (the GPU line box size)' if box == 128 else ''}, {cells} cells = {cells / (3 * 512 ** 3):.3f} of the headline hierarchy, 1 comp"}
 
 
+def secondary(ctx, torch, stream, dev):
+    """The other kernel families of the path in front of the driver (N = 1 only, after the timed headline region; a few
+    seconds in all): BASELINE configs 2, 3 and 4, the gradient alone, and the headline hierarchy in 64^3 and 32^3 boxes.
+    Each entry: wall-clock ms per pass on the library's stream (launches + stream sync, second and third pass), the
+    algorithmic bytes per cell of SURVEY 8(d) and the fraction of the 8 TB/s HBM figure they amount to."""
+    import ctypes as C
+    from peleanalysis_amd import capi
+    from peleanalysis_amd.hierarchy import mf_layout, nested_hierarchy
+
+    def alloc(lv, dl, ncomp, ng, fill=None, seed=1):
+        off, cs, tot = mf_layout(lv.boxes, ncomp, ng)
+        with torch.cuda.stream(stream):
+            t = torch.zeros(max(tot, 1), dtype=torch.float64, device=dev)
+            if fill == "flame":  # component 0 the flame field + noise, the others cheap affine images of it
+                fill_level_on_device(torch, lv, t, 1, ng, off, cs, dev, seed)
+                for b in range(lv.nboxes):
+                    nz, ny, nx = lv.box_shape(b, ng)
+                    n = nz * ny * nx
+                    for c in range(1, ncomp):
+                        t[off[b] + c * cs[b]: off[b] + c * cs[b] + n] = (1.0 + 0.1 * c) * t[off[b]: off[b] + n] + 3.0 * c
+        return t, capi.DevMF(ctx, dl, ncomp, ng, t.data_ptr())
+
+    def timed(fn, reps=2):
+        fn()
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        ctx.sync()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    def entry(ms, cells, bpc, **kw):
+        e = {"ms": ms, "cells": cells, "bytes_per_cell": bpc, "Mcells_s": cells / ms / 1e3}
+        if bpc:
+            e["frac_hbm"] = cells * bpc / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        e.update(kw)
+        return e
+
+    out = {}
+
+    def gradcurv_case(name, base, nlev, box, ncomp, per):
+        H = nested_hierarchy(base, nlev, box, is_per=per)
+        dls = [capi.DevLevel(ctx, lv) for lv in H.levels]
+        keep, st, wk, ou = [], [], [], []
+        for li, (lv, dl) in enumerate(zip(H.levels, dls)):
+            a, b_, c_ = alloc(lv, dl, ncomp, 2, "flame", 77 + li), alloc(lv, dl, 1, 2), alloc(lv, dl, 8, 0)
+            keep += [a[0], b_[0], c_[0]]
+            st.append(a[1]); wk.append(b_[1]); ou.append(c_[1])
+        stream.synchronize()
+        bc = capi.bc_from_flags(per)
+        params = capi.curv_params(prog_min=300.0, prog_max=2000.0 * (1.0 + 0.1 * ncomp) + 3.0 * ncomp, threshold=None, fused=True)
+        cells = sum(lv.ncells for lv in H.levels) * ncomp
+        ms = timed(lambda: capi.gradcurv_run_comps(ctx, st, 0, ncomp, bc, params, wk, ou, 0))
+        assert ctx.bc_errors() == 0
+        out[name] = entry(ms, cells, 72, workload=f"fused grad->curvature, {nlev}-level base {base}^3, {box}^3 boxes, {ncomp} comp(s), is_per {per}")
+        return H, dls, keep, st
+
+    # BASELINE config 2: single level 512^3, 10 components
+    h = gradcurv_case("c2_1lev_512_10comp", 512, 1, 128, 10, (1, 1, 1))
+    del h
+    torch.cuda.empty_cache()
+    # the headline hierarchy in smaller boxes (SURVEY 7.4(3))
+    for box in (64, 32):
+        h = gradcurv_case(f"headline_box{box}", 512, 3, box, 1, (1, 1, 0))
+        del h
+        torch.cuda.empty_cache()
+    # the gradient alone on the headline hierarchy (grad.cpp:211-236; 40 B/cell)
+    H = nested_hierarchy(512, 3, 128, is_per=(1, 1, 0))
+    dls = [capi.DevLevel(ctx, lv) for lv in H.levels]
+    ins = [alloc(lv, dl, 1, 1, "flame", 5 + li) for li, (lv, dl) in enumerate(zip(H.levels, dls))]
+    gos = [alloc(lv, dl, 4, 0) for lv, dl in zip(H.levels, dls)]
+    stream.synchronize()
+    bc = capi.bc_from_flags((1, 1, 0))
+    ms = timed(lambda: capi.grad_run(ctx, [a[1] for a in ins], 0, bc, [g[1] for g in gos], 0))
+    out["grad_only_headline"] = entry(ms, sum(lv.ncells for lv in H.levels), 40, workload="grad (ghost fills + k_grad_march), 3-level base 512^3, 128^3 boxes, 1 comp")
+    del ins, gos, dls, H
+    torch.cuda.empty_cache()
+
+    # BASELINE config 3: filterPlt's ghost fill + box filter (fgr 2 / 4 / 8 on levels 0 / 1 / 2) + grad of the filtered field
+    H = nested_hierarchy(256, 3, 64, is_per=(1, 1, 0))
+    dls = [capi.DevLevel(ctx, lv) for lv in H.levels]
+    ngs, ws = [1, 2, 4], []
+    for f in (2, 4, 8):
+        w = (C.c_double * (f + 2))()
+        assert ctx.lib.pa_box_filter_weights(f, w) == f // 2
+        ws.append(w)
+    fin = [alloc(lv, dl, 1, ngs[l], "flame", 31 + l) for l, (lv, dl) in enumerate(zip(H.levels, dls))]
+    fout = [alloc(lv, dl, 1, 1) for lv, dl in zip(H.levels, dls)]
+    gout = [alloc(lv, dl, 4, 0) for lv, dl in zip(H.levels, dls)]
+    stream.synchronize()
+
+    def ghosts():
+        for l in range(3):
+            ctx.check(ctx.lib.pa_fill_boundary(ctx.h, fin[l][1].h, 0, 1, ngs[l]))
+            if l > 0:
+                ctx.check(ctx.lib.pa_fillpatch_two_levels(ctx.h, fin[l][1].h, fin[l - 1][1].h, 0, 1, ngs[l], 2, 1))
+            ctx.check(ctx.lib.pa_foextrap(ctx.h, fin[l][1].h, 0, 1, ngs[l]))
+
+    def filt(l):
+        ctx.check(ctx.lib.pa_boxfilter_level(ctx.h, fin[l][1].h, fout[l][1].h, 0, 1, ngs[l], ws[l]))
+
+    def c3_all():
+        ghosts()
+        for l in range(3):
+            filt(l)
+        capi.grad_run(ctx, [f[1] for f in fout], 0, bc, [g[1] for g in gout], 0)
+
+    c3cells = sum(lv.ncells for lv in H.levels)
+    c3 = {"ghost_fill_ms": timed(ghosts)}
+    for l in range(3):
+        m = timed(lambda l=l: filt(l))
+        c3[f"filter_fgr{2 << l}_level{l}"] = entry(m, H.levels[l].ncells, 16)
+    c3["grad_ms"] = timed(lambda: capi.grad_run(ctx, [f[1] for f in fout], 0, bc, [g[1] for g in gout], 0))
+    c3.update(entry(timed(c3_all), c3cells, None, workload="filterPlt ghost fill + separable box filter fgr 2/4/8 + grad, 3-level base 256^3, 64^3 boxes, 1 comp"))
+    assert ctx.bc_errors() == 0
+    out["c3_filter_grad_base256"] = c3
+    del fin, fout, gout
+    torch.cuda.empty_cache()
+
+    # BASELINE config 4: isosurface (isosurface.cpp:1434-1592) -- state build (coordinates, ghost fill) + level-batched marching cubes
+    Hn = nested_hierarchy(256, 3, 64, is_per=(0, 0, 0))
+    dln = [capi.DevLevel(ctx, lv) for lv in Hn.levels]
+    fld = [alloc(lv, dl, 1, 1, "flame", 91 + l) for l, (lv, dl) in enumerate(zip(Hn.levels, dln))]
+    sts = [alloc(lv, dl, 4, 1) for lv, dl in zip(Hn.levels, dln)]
+    loops = []
+    for lv in Hn.levels:
+        arr = (capi.PaBox * lv.nboxes)()
+        for b in range(lv.nboxes):
+            for d in range(3):
+                arr[b].lo[d] = max(int(lv.boxes[b, d]) - 1, int(lv.domlo[d]))
+                arr[b].hi[d] = min(int(lv.boxes[b, 3 + d]) + 1, int(lv.domhi[d])) - 1
+        loops.append(arr)
+    stream.synchronize()
+    tri = [0]
+
+    def iso_state():
+        for l in range(3):
+            ctx.check(ctx.lib.pa_iso_coords_level(ctx.h, sts[l][1].h, 0))
+            ctx.check(ctx.lib.pa_mf_copy(ctx.h, fld[l][1].h, 0, sts[l][1].h, 3, 1, 1))
+            ctx.check(ctx.lib.pa_fill_boundary(ctx.h, sts[l][1].h, 0, 4, 1))
+            if l > 0:
+                ctx.check(ctx.lib.pa_fillpatch_two_levels(ctx.h, sts[l][1].h, sts[l - 1][1].h, 0, 4, 1, 2, 0))
+
+    def iso_mc():
+        tri[0] = 0
+        for l in range(3):
+            nb = Hn.levels[l].nboxes
+            nv, nt = (C.c_int64 * nb)(), (C.c_int64 * nb)()
+            pv, pk, pt = C.c_void_p(), C.c_void_p(), C.c_void_p()
+            ctx.check(ctx.lib.pa_mc_level_fine(ctx.h, sts[l][1].h, dln[l + 1].h if l < 2 else None, 2, loops[l], 3, 1150.0, nv, nt, C.byref(pv), C.byref(pk), C.byref(pt)))
+            tri[0] += int(sum(nt[:nb]))
+            if pv.value:
+                ctx.lib.pa_device_free(ctx.h, pv)
+
+    iso_state()
+    c4cells = sum(lv.ncells for lv in Hn.levels)
+    ms_state, ms_mc = timed(iso_state), timed(iso_mc)
+    assert ctx.bc_errors() == 0
+    out["c4_isosurface_base256"] = entry(ms_mc, c4cells, 8, state_build_ms=ms_state, triangles=tri[0], Mtriangles_s=tri[0] / ms_mc / 1e3,
+                                         workload="coordinates + ghost fill (state_build_ms), then pa_mc_level_fine on 3 levels (finer level as mask), base 256^3, 64^3 boxes, "
+                                                  "T = 1150 isotherm; ms includes the per-level count read-back and output allocation")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -136,6 +300,7 @@ def main():
     ap.add_argument("--fused", type=int, default=1)
     ap.add_argument("--per", type=str, default="1 1 0", help="periodicity flags x y z (headline: periodic x/y, wall z); single GPU only")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads (configs 2-4, grad only, small boxes)")
     ap.add_argument("--no-profile", action="store_true", help="diagnostic: no HIP events in the timed region (no roofline object)")
     ap.add_argument("--cpu-base", type=int, default=0, help="base size of the cpu_baseline sample (0: from the core count)")
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong", help="N > 1: shard ONE hierarchy (strong) or one hierarchy per GPU (weak)")
@@ -349,6 +514,15 @@ def main():
                            "launches": nk, "bytes_per_cell": BYTES_PER_CELL, "cells_per_launch": cells_local * args.ncomp * args.steps / nk}
         res["breakdown_ms_per_step"] = bd  # from the untimed steps after the timed region (rank 0)
         res["step_frac_of_hbm_roofline"] = (cells_local * args.ncomp * BYTES_PER_CELL / (dt / args.steps) / 1e9) / HBM_PEAK_GBS
+    if rank == 0 and world == 1 and not args.sim_of and not args.no_secondary:
+        try:
+            del hold, states, works, outs  # the headline buffers (33 GB) make room for the secondary workloads
+            torch.cuda.empty_cache()
+            t0s = time.perf_counter()
+            res["secondary"] = secondary(ctx, torch, stream, dev)
+            res["secondary"]["wall_s_incl_data_generation"] = round(time.perf_counter() - t0s, 2)
+        except Exception as e:  # the headline line must survive a failure here
+            res["secondary"] = {"error": repr(e)[:300]}
     if rank == 0 and world == 1 and not args.no_cpu and not args.sim_of:
         try:
             # bounded sample (~10-30 s of CPU work): a 3-level hierarchy sized from the host core count
