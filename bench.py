@@ -299,6 +299,7 @@ def main():
     ap.add_argument("--ncomp", type=int, default=1, help="components pushed through grad->curvature per step")
     ap.add_argument("--fused", type=int, default=1)
     ap.add_argument("--per", type=str, default="1 1 0", help="periodicity flags x y z (headline: periodic x/y, wall z); single GPU only")
+    ap.add_argument("--threshold", type=float, default=-1.0, help="diagnostic: threshold_prog / threshold_value of curvature.cpp:549-570 (< 0: off, the headline)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads (configs 2-4, grad only, small boxes)")
     ap.add_argument("--no-profile", action="store_true", help="diagnostic: no HIP events in the timed region (no roofline object)")
@@ -427,7 +428,7 @@ def main():
             works.append(capi.DevMF(ctx, dl, 1, 2, twk.data_ptr()))
             outs.append(capi.DevMF(ctx, dl, 8, 0, tout.data_ptr()))
     stream.synchronize()
-    params = capi.curv_params(prog_min=300.0, prog_max=2000.0, threshold=None, fused=bool(args.fused))
+    params = capi.curv_params(prog_min=300.0, prog_max=2000.0, threshold=(args.threshold if args.threshold >= 0 else None), fused=bool(args.fused))
 
     def step():
         # every component through the pipeline into recycled output buffers (SURVEY 8d memory budget); cross-rank ghost fills

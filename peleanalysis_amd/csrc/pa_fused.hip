@@ -134,10 +134,13 @@ __global__ __launch_bounds__(256) void k_faces_normal(DLevelView L, DMFView MC_,
 // back from the output (exact after phase A) unless the threshold clip zeroed them there; normals
 // of valid cells of neighbouring boxes are recomputed from the local ghost c.
 // CG = false: c from the stored shell copy MC_[ccomp]; CG = true: MC_[ccomp] is PHI and c comes through CgAcc.
-template <bool CG, bool PATCH = false>
-__global__ __launch_bounds__(256, PA_FC_WAVES) void k_faces_curv(LevBatch<FixArgs> Bt, int* nbad) {
+// cells the clip-aware fast path hands to the general one (exact-normal pipeline with the threshold clip): {batch row, face cell}
+struct SlowList { int* count; int2* items; int cap; };
+// CGCLIP: the threshold clip in the exact-normal pipeline (compiled in only where it is used: 116 against 168 VGPRs)
+template <bool CG, bool PATCH, bool CGCLIP = false>
+__device__ __forceinline__ void faces_curv_cell(const LevBatch<FixArgs>& Bt, unsigned y, long long t, int perim_only, int* nbad) {
   unsigned fy;
-  const FixArgs& Fx = Bt.a[Bt.find(blockIdx.y, fy)];
+  const FixArgs& Fx = Bt.a[Bt.find(y, fy)];
   const DLevelView& L = Fx.L;
   const DMFView& MC_ = Fx.MC_;
   const DLevelView& LCr = Fx.LCr;
@@ -147,8 +150,7 @@ __global__ __launch_bounds__(256, PA_FC_WAVES) void k_faces_curv(LevBatch<FixArg
   const int ccomp = Fx.ccomp, cncomp0 = Fx.cncomp0, ncomp0 = Fx.ncomp0, kcomp = Fx.kcomp;
   int b, fdir, side, layer, q0[3];
   DBox B;
-  const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  if (A.perim_only) {
+  if (perim_only) {
     // compact enumeration of the perimeter cells of the face (the interior belongs to k_faces_curv_fast):
     // two full rows in t0, then the two end columns of the rows in between; layers slowest
     const int e = L.sfaces[fy];
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(256, PA_FC_WAVES) void k_faces_curv(LevBatch<FixArg
   auto C = [&](int i, int j, int k) -> double { return CG ? Cg(i, j, k) : Cs(i, j, k); };
   // component d of the (unclipped) normal at a valid cell p of this box
   auto nrm = [&](const int p[3], int d) -> double {
-    if (!CG && A.thr >= 0.0) {
+    if ((!CG || CGCLIP) && A.thr >= 0.0) {  // the sweep zeroed clipped normals in the output: the divergence needs the unclipped ones
       const double cp = C(p[0], p[1], p[2]);
       if (cp < A.thr || cp > 1.0 - A.thr) return comp_of(normal_at(C, p[0], p[1], p[2], dxinv), d);
     }
@@ -240,12 +242,27 @@ __global__ __launch_bounds__(256, PA_FC_WAVES) void k_faces_curv(LevBatch<FixArg
     curv += cdiff(dxinv[d], nb[0], n0d, nb[1]);
   }
   curv = curv * 0.5;
-  if (!CG && A.thr >= 0.0) {
+  if ((!CG || CGCLIP) && A.thr >= 0.0) {
     const double c0 = C(X[0], X[1], X[2]);
     if (c0 < A.thr || c0 > 1.0 - A.thr) curv = 0.0;
   }
   if (!ok) atomicAdd(nbad, 1);
   MO.data[MO.off[b] + fab_index(B, MO.ng, MO.ncomp, kcomp, X[0], X[1], X[2])] = curv;
+}
+template <bool CG, bool PATCH = false, bool CGCLIP = false>
+__global__ __launch_bounds__(256, PA_FC_WAVES) void k_faces_curv(LevBatch<FixArgs> Bt, int* nbad) {
+  unsigned fy;
+  const int perim = Bt.a[Bt.find(blockIdx.y, fy)].A.perim_only;
+  faces_curv_cell<CG, PATCH, CGCLIP>(Bt, blockIdx.y, blockIdx.x * (long long)blockDim.x + threadIdx.x, perim, nbad);
+}
+// the cells of SlowList through the general path (any cell of a face, one layer)
+template <bool PATCH>
+__global__ __launch_bounds__(256, PA_FC_WAVES) void k_faces_curv_list(LevBatch<FixArgs> Bt, int* nbad, SlowList sl) {
+  const int n = min(*sl.count, sl.cap);
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const int2 it = sl.items[i];
+    faces_curv_cell<true, PATCH, true>(Bt, (unsigned)it.x, it.y, 0, nbad);
+  }
 }
 
 // Phase B, fast path: the interior cells of a special face (all four tangential neighbours inside the
@@ -253,10 +270,18 @@ __global__ __launch_bounds__(256, PA_FC_WAVES) void k_faces_curv(LevBatch<FixArg
 // normals it needs are plain loads from the output (exact after phase A), shared between the two
 // layers, and only the ghost normal beyond the face needs the boundary condition.  Same operations in
 // the same order as k_faces_curv (d = 0,1,2; cdiff; *0.5), which still handles the perimeter cells.
-template <int FD, int NL, bool PATCH>
+// CLIP (exact-normal pipeline with the threshold clip, curvature.cpp:549-570): the sweep wrote N = 0, K = 0 where the
+// progress variable is outside [thr, 1 - thr].  A clipped cell keeps its K = 0; an unclipped one needs the UNCLIPPED normals
+// of its neighbours: a stored component that is exactly 0.0 may be a clipped one -- then (and only then) the neighbour's
+// progress variable is formed from phi and, if it is clipped, the cell is appended to SlowList and k_faces_curv_list
+// recomputes it through the general path (normals from c: CgAcc, the same operations as the sweep's); inlining that
+// recomputation here cost 2.4 KB of scratch per lane.  The coarse normal under a coarse-fine face is taken as stored =
+// clipped (quirk Q2).
+template <int FD, int NL, bool PATCH, bool CLIP = false>
 __device__ __forceinline__ void faces_curv_fast_body(const DLevelView& L, const DLevelView& LCr, const DMFView& MN, int cncomp0, const DMFView& MO,
                                                      int ncomp0, int kcomp, const FaceArgs& A, int* nbad, int b, const DBox& B, int side,
-                                                     const int q0[3], unsigned code, const double* patch) {
+                                                     const int q0[3], unsigned code, const double* patch, const DMFView& MP = DMFView(), int pcomp = 0, SlowList sl = SlowList(),
+                                                     unsigned row = 0, long long tcell = 0) {
   constexpr int T0 = (FD == 0) ? 1 : 0, T1 = (FD == 2) ? 1 : 2;
   const int cls = (int)(code & 3u);
   if (cls == 0) return;
@@ -276,6 +301,29 @@ __device__ __forceinline__ void faces_curv_fast_body(const DLevelView& L, const 
   const double nfd1 = nf[0], nfd2 = nf[in], nfd3 = nf[2 * in];
   const double a0m = n0p[-st[T0]], a0c = n0p[0], a0p = n0p[st[T0]];
   const double a1m = n1p[-st[T1]], a1c = n1p[0], a1p = n1p[st[T1]];
+  if (CLIP) {
+    static_assert(!CLIP || NL == 1, "the clip-aware fast path fixes one layer");
+    const FabView P = mf_view(MP, B, b);
+    auto clipped = [&](int i, int j, int k) {
+      const double c = (P(i, j, k, pcomp) - A.pmin) * A.invd;
+      return c < A.thr || c > 1.0 - A.thr;
+    };
+    if (clipped(X1[0], X1[1], X1[2])) return;  // K = 0 from the sweep
+    const int iv = -sg;  // one cell into the box along FD
+    bool slow = false;   // a needed neighbour component that the sweep clipped: this cell goes through the general path
+    slow = slow || (nfd2 == 0.0 && clipped(X1[0] + (FD == 0 ? iv : 0), X1[1] + (FD == 1 ? iv : 0), X1[2] + (FD == 2 ? iv : 0)));
+    slow = slow || (nfd3 == 0.0 && clipped(X1[0] + (FD == 0 ? 2 * iv : 0), X1[1] + (FD == 1 ? 2 * iv : 0), X1[2] + (FD == 2 ? 2 * iv : 0)));
+    slow = slow || (a0m == 0.0 && clipped(X1[0] - (T0 == 0), X1[1] - (T0 == 1), X1[2]));
+    slow = slow || (a0p == 0.0 && clipped(X1[0] + (T0 == 0), X1[1] + (T0 == 1), X1[2]));
+    slow = slow || (a1m == 0.0 && clipped(X1[0], X1[1] - (T1 == 1), X1[2] - (T1 == 2)));
+    slow = slow || (a1p == 0.0 && clipped(X1[0], X1[1] + (T1 == 1), X1[2] + (T1 == 2)));
+    if (slow) {
+      const int i = atomicAdd(sl.count, 1);
+      if (i < sl.cap) sl.items[i] = make_int2((int)row, (int)tcell);
+      else atomicAdd(nbad, 1);
+      return;
+    }
+  }
   double b0m = 0, b0c = 0, b0p = 0, b1m = 0, b1c = 0, b1p = 0;
   if (NL > 1) {
     b0m = n0p[in - st[T0]]; b0c = n0p[in]; b0p = n0p[in + st[T0]];
@@ -328,8 +376,8 @@ __device__ __forceinline__ void faces_curv_fast_body(const DLevelView& L, const 
 }
 
 // PATCH: every coarse-fine face of every level of the batch has its coarse patch (the owner-map interpolation is not compiled in)
-template <int NL, bool PATCH = false>
-__global__ __launch_bounds__(256) void k_faces_curv_fast(LevBatch<FixArgs> Bt, int* nbad) {
+template <int NL, bool PATCH = false, bool CLIP = false>
+__global__ __launch_bounds__(256) void k_faces_curv_fast(LevBatch<FixArgs> Bt, int* nbad, SlowList sl = SlowList()) {
   unsigned fy;
   const FixArgs& Fx = Bt.a[Bt.find(blockIdx.y, fy)];
   const DLevelView& L = Fx.L;
@@ -348,9 +396,9 @@ __global__ __launch_bounds__(256) void k_faces_curv_fast(LevBatch<FixArgs> Bt, i
   const long long cpo = (Fx.use_cp && L.cp) ? L.cpoff[fy] : -1;  // wave-uniform
   const double* patch = cpo >= 0 ? L.cp + cpo : nullptr;
   switch (fdir) {  // uniform per workgroup
-    case 0: faces_curv_fast_body<0, NL, PATCH>(L, LCr, MN, cncomp0, MO, ncomp0, kcomp, A, nbad, b, B, side, q0, code, patch); break;
-    case 1: faces_curv_fast_body<1, NL, PATCH>(L, LCr, MN, cncomp0, MO, ncomp0, kcomp, A, nbad, b, B, side, q0, code, patch); break;
-    default: faces_curv_fast_body<2, NL, PATCH>(L, LCr, MN, cncomp0, MO, ncomp0, kcomp, A, nbad, b, B, side, q0, code, patch); break;
+    case 0: faces_curv_fast_body<0, NL, PATCH, CLIP>(L, LCr, MN, cncomp0, MO, ncomp0, kcomp, A, nbad, b, B, side, q0, code, patch, Fx.MC_, Fx.ccomp, sl, blockIdx.y, t); break;
+    case 1: faces_curv_fast_body<1, NL, PATCH, CLIP>(L, LCr, MN, cncomp0, MO, ncomp0, kcomp, A, nbad, b, B, side, q0, code, patch, Fx.MC_, Fx.ccomp, sl, blockIdx.y, t); break;
+    default: faces_curv_fast_body<2, NL, PATCH, CLIP>(L, LCr, MN, cncomp0, MO, ncomp0, kcomp, A, nbad, b, B, side, q0, code, patch, Fx.MC_, Fx.ccomp, sl, blockIdx.y, t); break;
   }
 }
 
@@ -457,8 +505,9 @@ static void march_launch(hipStream_t st, const BP& bp, int nx, int ny, int nz, u
     A.tiles_max = (int)g.x;                                                                                            \
     if (A.order == 2) g = dim3(g.x * 8u * ((nboxes + 7u) / 8u), 1);                                                    \
     else if (A.order) g = dim3(g.x * g.y, 1);                                                                          \
-    if (kname) *kname = "k_gradcurv_march3<MTY=" #M ",CLIP=" + std::to_string((int)clip) + ",PAIR=" + std::to_string((int)(pair && !(A.cg && !clip))) + ",CG=" + std::to_string((int)(A.cg && !clip)) + ">"; \
+    if (kname) *kname = "k_gradcurv_march3<MTY=" #M ",CLIP=" + std::to_string((int)clip) + ",PAIR=" + std::to_string((int)(pair && !A.cg)) + ",CG=" + std::to_string((int)(A.cg != 0)) + ">"; \
     if (A.cg && !clip) hipLaunchKernelGGL((k_gradcurv_march3<BP, M, false, false, 0, true>), g, dim3(64 * (M + 3)), 0, st, bp, A); \
+    else if (A.cg) hipLaunchKernelGGL((k_gradcurv_march3<BP, M, true, false, 0, true>), g, dim3(64 * (M + 3)), 0, st, bp, A); \
     else if (pair && clip) hipLaunchKernelGGL((k_gradcurv_march3<BP, M, true, true>), g, dim3(64 * (M + 3)), 0, st, bp, A); \
     else if (pair) hipLaunchKernelGGL((k_gradcurv_march3<BP, M, false, true>), g, dim3(64 * (M + 3)), 0, st, bp, A);   \
     else if (clip) hipLaunchKernelGGL((k_gradcurv_march3<BP, M, true>), g, dim3(64 * (M + 3)), 0, st, bp, A);          \
@@ -842,6 +891,18 @@ static int cpatch_launch(pa_ctx* ctx, int l0, int l1, pa_mf* const* fine, const 
   return 0;
 }
 
+// the context's list of cells for k_faces_curv_list (grow-never: 1 M entries)
+static int pa_slow_list(pa_ctx* ctx, int** count, int2** items, int* cap) {
+  constexpr int CAP = 1 << 20;
+  if (!ctx->d_slow) {
+    PA_HIP(hipMalloc(&ctx->d_slow, sizeof(int2) * (size_t)CAP + 16));
+  }
+  *count = (int*)ctx->d_slow;
+  *items = (int2*)((char*)ctx->d_slow + 16);
+  *cap = CAP;
+  return 0;
+}
+
 // can the exact-normal pipeline run on this level (same answer on every rank of a sharded level)?
 bool pa_fused2_level_ok(const pa_level* L) {
   static const int env = [] { const char* e = getenv("PA_FUSED2"); return e ? atoi(e) : 1; }();
@@ -908,12 +969,12 @@ int pa_gradcurv_prep_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int comp, 
 }
 
 // the sweep with exact normals (the level's compact ghost arrays must be current: pa_gradcurv_prep_level)
-int pa_gradcurv_level_cg(pa_ctx* ctx, const pa_mf* phi, int pcomp, double pmin, double pmax, pa_mf* out, int ocomp) {
+int pa_gradcurv_level_cg(pa_ctx* ctx, const pa_mf* phi, int pcomp, double pmin, double pmax, pa_mf* out, int ocomp, double thr) {
   const pa_level* L = phi->lev;
   if (L->boxes.empty()) return 0;
   if (level_cg(ctx, L)) return 1;
   LevelBP2 bp{L->view, phi->view, out->view};
-  MarchArgs A{pcomp, ocomp, fused_kseg(), pmin, 1.0 / (pmax - pmin), -1.0, 0, 1, 1, 1};
+  MarchArgs A{pcomp, ocomp, fused_kseg(), pmin, 1.0 / (pmax - pmin), thr >= 0.0 ? thr : -1.0, 0, 1, 1, 1};
   A.cg = 1;
   ProfScope prof(ctx, PA_TAG_GRADCURV);
   march_launch(ctx->stream, bp, L->maxn[0], L->maxn[1], L->maxn[2], (unsigned)L->boxes.size(), A, false, &ctx->sweep_kernel);
@@ -923,7 +984,8 @@ int pa_gradcurv_level_cg(pa_ctx* ctx, const pa_mf* phi, int pcomp, double pmin, 
 
 // the CG sweeps of all levels: one launch (k_gradcurv_march3_levels) when every level takes the same tile variant and the
 // XCD-aware order is on, else level by level.  PA_SWEEP_BATCH=0: always level by level (A/B).
-int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, double pmin, double pmax, pa_mf* const* out, int ocomp) {
+int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, double pmin, double pmax, pa_mf* const* out, int ocomp, double thr) {
+  const bool clip = thr >= 0.0;
   static const int batch_env = [] { const char* e = getenv("PA_SWEEP_BATCH"); return e ? atoi(e) : 1; }();
   static const bool knobs = getenv("PA_MARCH") || getenv("PA_DBG") || getenv("PA_MTY") || getenv("PA_PAIR");
   std::vector<int> lv;
@@ -939,7 +1001,7 @@ int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, d
   }
   if (!ok) {
     for (int l = 0; l < nlev; ++l)
-      if (pa_gradcurv_level_cg(ctx, phi[l], pcomp, pmin, pmax, out[l], ocomp)) return 1;
+      if (pa_gradcurv_level_cg(ctx, phi[l], pcomp, pmin, pmax, out[l], ocomp, thr)) return 1;
     return 0;
   }
   SweepBatch S;
@@ -977,7 +1039,7 @@ int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, d
     const pa_level* L = phi[l]->lev;
     if (level_cg(ctx, L)) return 1;
     S.bp[q] = LevelBP2{L->view, phi[l]->view, out[l]->view};
-    MarchArgs A{pcomp, ocomp, kdef, pmin, 1.0 / (pmax - pmin), -1.0, 2, 1, 1, 1};
+    MarchArgs A{pcomp, ocomp, kdef, pmin, 1.0 / (pmax - pmin), clip ? thr : -1.0, 2, 1, 1, 1};
     A.cg = 1;
     if (tz_best) A.kseg = std::max(4, (L->maxn[2] + tz_best - 1) / tz_best);
     const unsigned nb = (unsigned)L->boxes.size();
@@ -990,10 +1052,16 @@ int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, d
   }
   ProfScope prof(ctx, PA_TAG_GRADCURV);
   const dim3 grid(S.wg0[S.n]);
-  if (mty == 13) hipLaunchKernelGGL(k_gradcurv_march3_levels<13>, grid, dim3(64 * 16), 0, ctx->stream, S);
-  else if (mty == 8) hipLaunchKernelGGL(k_gradcurv_march3_levels<8>, grid, dim3(64 * 11), 0, ctx->stream, S);
-  else hipLaunchKernelGGL(k_gradcurv_march3_levels<4>, grid, dim3(64 * 7), 0, ctx->stream, S);
-  ctx->sweep_kernel = "k_gradcurv_march3_levels<MTY=" + std::to_string(mty) + ">[" + std::to_string(S.n) + " levels per launch]";
+  if (clip) {
+    if (mty == 13) hipLaunchKernelGGL((k_gradcurv_march3_levels<13, true>), grid, dim3(64 * 16), 0, ctx->stream, S);
+    else if (mty == 8) hipLaunchKernelGGL((k_gradcurv_march3_levels<8, true>), grid, dim3(64 * 11), 0, ctx->stream, S);
+    else hipLaunchKernelGGL((k_gradcurv_march3_levels<4, true>), grid, dim3(64 * 7), 0, ctx->stream, S);
+  } else {
+    if (mty == 13) hipLaunchKernelGGL(k_gradcurv_march3_levels<13>, grid, dim3(64 * 16), 0, ctx->stream, S);
+    else if (mty == 8) hipLaunchKernelGGL(k_gradcurv_march3_levels<8>, grid, dim3(64 * 11), 0, ctx->stream, S);
+    else hipLaunchKernelGGL(k_gradcurv_march3_levels<4>, grid, dim3(64 * 7), 0, ctx->stream, S);
+  }
+  ctx->sweep_kernel = "k_gradcurv_march3_levels<MTY=" + std::to_string(mty) + (clip ? ",CLIP" : "") + ">[" + std::to_string(S.n) + " levels per launch]";
   PA_HIP(hipGetLastError());
   return 0;
 }
@@ -1001,8 +1069,9 @@ int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, d
 // after the sweeps of ALL levels: curvature of the first layer behind every special face, several levels per launch pair.
 // crse_n[l]: the coarser level's output (normal components from cncomp0) or this rank's coarse-source copy of them.
 int pa_gradcurv_fix_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, const pa_mf* const* crse_n, int cncomp0, const int32_t bc[3], double pmin, double pmax,
-                           pa_mf* const* out, int ncomp0, int kcomp) {
+                           pa_mf* const* out, int ncomp0, int kcomp, double thr) {
   const bool use_cp = cpatch_on();
+  const bool clip = thr >= 0.0;
   for (int l0 = 0; l0 < nlev; l0 += PA_MAXB) {
     if (use_cp && cpatch_launch(ctx, l0, std::min(nlev, l0 + PA_MAXB), phi, crse_n, cncomp0, 1)) return 1;
     LevBatch<FixArgs> Bt;
@@ -1012,7 +1081,7 @@ int pa_gradcurv_fix_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, 
       if (L->boxes.empty() || L->sfaces.empty()) continue;
       FaceArgs A;
       for (int d = 0; d < 3; ++d) A.bc[d] = bc[d];
-      A.ratio = 2; A.has_crse = crse_n[l] ? 1 : 0; A.thr = -1.0; A.layers = 1; A.perim_only = 1; A.pmin = pmin; A.invd = 1.0 / (pmax - pmin);
+      A.ratio = 2; A.has_crse = crse_n[l] ? 1 : 0; A.thr = clip ? thr : -1.0; A.layers = 1; A.perim_only = 1; A.pmin = pmin; A.invd = 1.0 / (pmax - pmin);
       Bt.a[Bt.n] = FixArgs{L->view, phi[l]->view, pcomp, crse_n[l] ? crse_n[l]->lev->view : L->view, crse_n[l] ? crse_n[l]->view : phi[l]->view, cncomp0,
                            out[l]->view, ncomp0, kcomp, A, (use_cp && crse_n[l] && L->cp_total > 0) ? 1 : 0};
       Bt.ycum[Bt.n + 1] = Bt.ycum[Bt.n] + (int)L->sfaces.size();
@@ -1025,10 +1094,23 @@ int pa_gradcurv_fix_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, 
     ProfScope prof(ctx, PA_TAG_GRADCURV_FACES);
     bool all_patch = true;  // every level of the batch that interpolates from a coarser level does so from patches
     for (int q = 0; q < Bt.n; ++q) all_patch = all_patch && (Bt.a[q].use_cp || !Bt.a[q].A.has_crse);
-    if (all_patch) hipLaunchKernelGGL((k_faces_curv_fast<1, true>), dim3((unsigned)((nf + 255) / 256), (unsigned)Bt.ycum[Bt.n]), dim3(256), 0, ctx->stream, Bt, ctx->d_flags);
-    else hipLaunchKernelGGL((k_faces_curv_fast<1, false>), dim3((unsigned)((nf + 255) / 256), (unsigned)Bt.ycum[Bt.n]), dim3(256), 0, ctx->stream, Bt, ctx->d_flags);
-    if (all_patch) hipLaunchKernelGGL((k_faces_curv<true, true>), dim3((unsigned)((nper + 255) / 256), (unsigned)Bt.ycum[Bt.n]), dim3(256), 0, ctx->stream, Bt, ctx->d_flags);
-    else hipLaunchKernelGGL((k_faces_curv<true, false>), dim3((unsigned)((nper + 255) / 256), (unsigned)Bt.ycum[Bt.n]), dim3(256), 0, ctx->stream, Bt, ctx->d_flags);
+    const dim3 gfast((unsigned)((nf + 255) / 256), (unsigned)Bt.ycum[Bt.n]);
+    if (clip) {
+      SlowList sl;
+      if (pa_slow_list(ctx, &sl.count, &sl.items, &sl.cap)) return 1;
+      PA_HIP(hipMemsetAsync(sl.count, 0, sizeof(int), ctx->stream));
+      if (all_patch) hipLaunchKernelGGL((k_faces_curv_fast<1, true, true>), gfast, dim3(256), 0, ctx->stream, Bt, ctx->d_flags, sl);
+      else hipLaunchKernelGGL((k_faces_curv_fast<1, false, true>), gfast, dim3(256), 0, ctx->stream, Bt, ctx->d_flags, sl);
+      if (all_patch) hipLaunchKernelGGL((k_faces_curv_list<true>), dim3(128), dim3(256), 0, ctx->stream, Bt, ctx->d_flags, sl);
+      else hipLaunchKernelGGL((k_faces_curv_list<false>), dim3(128), dim3(256), 0, ctx->stream, Bt, ctx->d_flags, sl);
+    } else if (all_patch) hipLaunchKernelGGL((k_faces_curv_fast<1, true>), gfast, dim3(256), 0, ctx->stream, Bt, ctx->d_flags);
+    else hipLaunchKernelGGL((k_faces_curv_fast<1, false>), gfast, dim3(256), 0, ctx->stream, Bt, ctx->d_flags);
+    const dim3 gper((unsigned)((nper + 255) / 256), (unsigned)Bt.ycum[Bt.n]);
+    if (clip) {
+      if (all_patch) hipLaunchKernelGGL((k_faces_curv<true, true, true>), gper, dim3(256), 0, ctx->stream, Bt, ctx->d_flags);
+      else hipLaunchKernelGGL((k_faces_curv<true, false, true>), gper, dim3(256), 0, ctx->stream, Bt, ctx->d_flags);
+    } else if (all_patch) hipLaunchKernelGGL((k_faces_curv<true, true>), gper, dim3(256), 0, ctx->stream, Bt, ctx->d_flags);
+    else hipLaunchKernelGGL((k_faces_curv<true, false>), gper, dim3(256), 0, ctx->stream, Bt, ctx->d_flags);
   }
   PA_HIP(hipGetLastError());
   return 0;

@@ -564,9 +564,9 @@ struct SweepBatch {
   LevelBP2 bp[PA_MAXB];
   MarchArgs A[PA_MAXB];
 };
-template <int PA_MTY>
+template <int PA_MTY, bool CLIP = false>
 __global__ __launch_bounds__(64 * (PA_MTY + 3), 1) void k_gradcurv_march3_levels(SweepBatch S) {
   int l = 0;
   while (l + 1 < S.n && blockIdx.x >= S.wg0[l + 1]) ++l;
-  gradcurv_march3_body<LevelBP2, PA_MTY, false, false, 0, true>(S.bp[l], S.A[l], blockIdx.x - S.wg0[l], 0u);
+  gradcurv_march3_body<LevelBP2, PA_MTY, CLIP, false, 0, true>(S.bp[l], S.A[l], blockIdx.x - S.wg0[l], 0u);
 }

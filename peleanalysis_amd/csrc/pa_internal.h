@@ -75,6 +75,7 @@ struct pa_ctx {
   double* d_red = nullptr;  // reduction scratch
   size_t red_cap = 0;
   int* d_flags = nullptr;   // [0] = coarse-fine ghost cells whose coarse data was missing
+  void* d_slow = nullptr;   // cells the clip-aware curvature fix-up hands to its general path (pa_fused.hip: SlowList)
   void* d_scr = nullptr;    // grow-only scratch (marching cubes)
   size_t scr_cap = 0;
   // surface blocks handed out by pa_mc_level* / taken back by pa_device_free: a freed block is kept (up to 4 of them) for

@@ -15,10 +15,10 @@ int pa_fill_boundary_impl(pa_ctx* ctx, pa_mf* M, int comp, int ncomp, int ng, in
 bool pa_fused2_level_ok(const pa_level* L);
 int pa_fill_boundary_local_batch(pa_ctx* ctx, int n, pa_mf* const* Ms, int comp, int ncomp, int ng);
 int pa_gradcurv_prep_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int comp, const pa_mf* const* crse, int ccomp, const int32_t bc[3], double pmin, double pmax, int phase = 3);
-int pa_gradcurv_level_cg(pa_ctx* ctx, const pa_mf* phi, int pcomp, double pmin, double pmax, pa_mf* out, int ocomp);
-int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, double pmin, double pmax, pa_mf* const* out, int ocomp);
+int pa_gradcurv_level_cg(pa_ctx* ctx, const pa_mf* phi, int pcomp, double pmin, double pmax, pa_mf* out, int ocomp, double thr = -1.0);
+int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, double pmin, double pmax, pa_mf* const* out, int ocomp, double thr = -1.0);
 int pa_gradcurv_fix_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, const pa_mf* const* crse_n, int cncomp0, const int32_t bc[3], double pmin, double pmax,
-                           pa_mf* const* out, int ncomp0, int kcomp);
+                           pa_mf* const* out, int ncomp0, int kcomp, double thr = -1.0);
 int pa_gauss_curv_level(pa_ctx* ctx, const pa_mf* G, int gcomp, const pa_mf* normgrad, int ngcomp, const pa_mf* c, int ccomp, double thr, pa_mf* out,
                         int kcomp);
 int pa_strain_level(pa_ctx* ctx, const pa_mf* u, int ucomp, pa_mf* out, int srcomp, int rostcomp);
@@ -241,14 +241,14 @@ static int fused_passes_dist(pa_ctx* ctx, int nlev, pa_mf* const* state, int com
     // 0: level by level, each level's exchange on the side stream next to the following sweep
     static const int dsb = [] { const char* e = getenv("PA_DIST_SWEEP_BATCH"); return e ? atoi(e) : 1; }();
     if (dsb) {
-      PA_TRY(pa_gradcurv_levels_cg(ctx, nlev, state, comp, pmin, pmax, out, ocomp));
+      PA_TRY(pa_gradcurv_levels_cg(ctx, nlev, state, comp, pmin, pmax, out, ocomp, thr));
       std::vector<XJob> nj;
       for (int l = 1; l < nlev; ++l) nj.push_back({&cs[l]->x, out[l - 1], ocomp + 4, csn[l], 0, 3});
       ProfScope prof(ctx, PA_TAG_XCHG);
       PA_TRY(pa_xexchange(ctx, (int)nj.size(), nj.data()));
     }
     for (int l = 0; l < nlev && !dsb; ++l) {
-      PA_TRY(pa_gradcurv_level_cg(ctx, state[l], comp, pmin, pmax, out[l], ocomp));
+      PA_TRY(pa_gradcurv_level_cg(ctx, state[l], comp, pmin, pmax, out[l], ocomp, thr));
       if (l + 1 < nlev) {  // the coarse normals level l+1 needs: every rank takes part, whatever it owns
         if (xov) {
           PA_HIP(hipEventRecord(ctx->sync_evs[3 + l], A));
@@ -264,7 +264,7 @@ static int fused_passes_dist(pa_ctx* ctx, int nlev, pa_mf* const* state, int com
       PA_HIP(hipEventRecord(ctx->sync_evs[2], C));
       PA_HIP(hipStreamWaitEvent(A, ctx->sync_evs[2], 0));
     }
-    PA_TRY(pa_gradcurv_fix_levels(ctx, nlev, state, comp, crse_n.data(), 0, bc, pmin, pmax, out, ocomp + 4, ocomp + 7));
+    PA_TRY(pa_gradcurv_fix_levels(ctx, nlev, state, comp, crse_n.data(), 0, bc, pmin, pmax, out, ocomp + 4, ocomp + 7, thr));
     return 0;
   }
   {
@@ -386,8 +386,11 @@ static int fused_passes(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, co
                         pa_mf* const* work, pa_mf* const* out, int ocomp) {
   for (int l = 0; l < nlev; ++l)
     if (state[l]->ng < 2 || work[l]->ng < 2) return pa_fail(ctx, "fused grad->curvature needs 2 ghost layers on state and work");
-  // exact-normal pipeline (pa_fused.hip): no threshold clip, pure special faces, boxes wider than 32 cells
-  bool exact = !(thr >= 0.0);
+  // exact-normal pipeline (pa_fused.hip): pure special faces, boxes wider than 32 cells; with the threshold clip the sweep
+  // zeroes N and K itself and the one-layer fix-up recomputes the (few) clipped normals it needs (PA_FUSED2_CLIP=0: first pipeline)
+  const char* c2e = getenv("PA_FUSED2_CLIP");  // read per pass (tests, tools/ab_driver.py)
+  const int clip2 = c2e ? atoi(c2e) : 1;
+  bool exact = !(thr >= 0.0) || clip2;
   for (int l = 0; l < nlev; ++l) exact = exact && pa_fused2_level_ok(state[l]->lev);
   if (state[0]->lev->nranks > 1) return fused_passes_dist(ctx, nlev, state, comp, bc, pmin, pmax, thr, work, out, ocomp, exact);
   if (exact) {
@@ -427,8 +430,8 @@ static int fused_passes(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, co
     }
     if (pov) PA_HIP(hipStreamWaitEvent(ctx->stream, ctx->sync_evs[1], 0));
     PA_TRY(pa_gradcurv_prep_levels(ctx, nlev, state, comp, crse.data(), comp, bc, pmin, pmax, pov ? 2 : 3));
-    PA_TRY(pa_gradcurv_levels_cg(ctx, nlev, state, comp, pmin, pmax, out, ocomp));
-    PA_TRY(pa_gradcurv_fix_levels(ctx, nlev, state, comp, crse_n.data(), ocomp + 4, bc, pmin, pmax, out, ocomp + 4, ocomp + 7));
+    PA_TRY(pa_gradcurv_levels_cg(ctx, nlev, state, comp, pmin, pmax, out, ocomp, thr));
+    PA_TRY(pa_gradcurv_fix_levels(ctx, nlev, state, comp, crse_n.data(), ocomp + 4, bc, pmin, pmax, out, ocomp + 4, ocomp + 7, thr));
     return 0;
   }
   if (nlev >= 2 && !overlap_on() && conc_on(nlev, state)) return fused_passes_conc(ctx, nlev, state, comp, bc, pmin, pmax, thr, work, out, ocomp);
@@ -534,7 +537,9 @@ extern "C" int pa_gradcurv_run_comps(pa_ctx* ctx, int nlev, pa_mf* const* state,
   if (ncomps < 1 || comp0 < 0) return pa_fail(ctx, "pa_gradcurv_run_comps: component range");
   for (int l = 0; l < nlev; ++l)
     if (comp0 + ncomps > state[l]->ncomp) return pa_fail(ctx, "pa_gradcurv_run_comps: component range");
-  bool exact = P->fused && P->spacedim != 2 && !P->do_threshold && all_fusable(nlev, state);
+  const double thr = P->do_threshold ? P->threshold : -1.0;
+  const char* c2e = getenv("PA_FUSED2_CLIP");
+  bool exact = P->fused && P->spacedim != 2 && all_fusable(nlev, state) && (!(thr >= 0.0) || !c2e || atoi(c2e));
   for (int l = 0; l < nlev; ++l) exact = exact && pa_fused2_level_ok(state[l]->lev) && state[l]->ng >= 2;
   if (!exact || ncomps == 1) {
     for (int c = comp0; c < comp0 + ncomps; ++c) {
@@ -577,14 +582,14 @@ extern "C" int pa_gradcurv_run_comps(pa_ctx* ctx, int nlev, pa_mf* const* state,
     double pmin, pmax;
     PA_TRY(prog_minmax(ctx, nlev, state, c, P, pmin, pmax));
     PA_TRY(pa_gradcurv_prep_levels(ctx, nlev, state, c, crse.data(), dist ? c - comp0 : c, bc, pmin, pmax));
-    PA_TRY(pa_gradcurv_levels_cg(ctx, nlev, state, c, pmin, pmax, out, ocomp));
+    PA_TRY(pa_gradcurv_levels_cg(ctx, nlev, state, c, pmin, pmax, out, ocomp, thr));
     if (dist) {
       std::vector<XJob> jobs;
       for (int l = 1; l < nlev; ++l) jobs.push_back({&cs[l]->x, out[l - 1], ocomp + 4, csn[l], 0, 3});
       ProfScope prof(ctx, PA_TAG_XCHG);
       PA_TRY(pa_xexchange(ctx, (int)jobs.size(), jobs.data()));
     }
-    PA_TRY(pa_gradcurv_fix_levels(ctx, nlev, state, c, crse_n.data(), dist ? 0 : ocomp + 4, bc, pmin, pmax, out, ocomp + 4, ocomp + 7));
+    PA_TRY(pa_gradcurv_fix_levels(ctx, nlev, state, c, crse_n.data(), dist ? 0 : ocomp + 4, bc, pmin, pmax, out, ocomp + 4, ocomp + 7, thr));
     if (done && done(user, c) != 0) return pa_fail(ctx, "pa_gradcurv_run_comps: the caller's callback failed");
   }
   return 0;

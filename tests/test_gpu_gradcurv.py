@@ -91,6 +91,8 @@ def test_gradcurv_fused_wide_boxes(ctx, oracle, threshold, pair, monkeypatch):
     partial last row tile (48 = 3*13 + 9 rows), anisotropic dx, 2 levels, periodic x/y + wall z"""
     from peleanalysis_amd.hierarchy import Hierarchy, Level, chop_box, field_flame
     monkeypatch.setenv("PA_PAIR", str(pair))  # read by the library at every launch
+    if pair:
+        monkeypatch.setenv("PA_FUSED2_CLIP", "0")  # the paired stores live in the first pipeline's sweep: keep the clip there
     l0 = Level(chop_box((0, 0, 0), (127, 47, 19), 64), (0, 0, 0), (127, 47, 19), (1, 1, 0), (0, 0, 0), (1, 1, 1))
     l1 = Level(chop_box((64, 24, 10), (191, 71, 29), 64), (0, 0, 0), (255, 95, 39), (1, 1, 0), (0, 0, 0), (1, 1, 1))
     H = Hierarchy([l0, l1], 2)
@@ -113,8 +115,9 @@ def test_gradcurv_fused_wide_boxes(ctx, oracle, threshold, pair, monkeypatch):
         assert_valid_bits_equal(got, oc[l], [(4, 2), (5, 3), (6, 4), (7, 1)], f"wide curv level {l}")
 
 
+@pytest.mark.parametrize("threshold", [None, 0.05, 0.3])
 @pytest.mark.parametrize("per,sym", [((1, 1, 0), (0, 0, 0)), ((0, 0, 0), (1, 0, 1)), ((0, 1, 1), (0, 0, 0))])
-def test_gradcurv_exact_normal_pipeline(ctx, oracle, per, sym):
+def test_gradcurv_exact_normal_pipeline(ctx, oracle, per, sym, threshold):
     """boxes wider than 32 cells, no threshold, pure special faces: the exact-normal pipeline (pa_fused.hip: the sweep reads
     the resolved ghost c behind coarse-fine / wall faces from compact face-major arrays; only the curvature of the first
     layer behind such a face is fixed up).  3 levels of 48^3 boxes: 4 row tiles per box (3 x 13 + 9 rows), 3 z segments of
@@ -126,16 +129,23 @@ def test_gradcurv_exact_normal_pipeline(ctx, oracle, per, sym):
     og = [MultiFab(lv, 4, 0) for lv in H.levels]
     oracle.grad_pipeline(H.levels, [s.copy() for s in states], 0, bc, og, 0, multipass=False)
     oc = [MultiFab(lv, 5, 0) for lv in H.levels]
-    oracle.curvature_pipeline(H.levels, [s.copy() for s in states], 0, bc, oc, 0, MultiFab)
+    oracle.curvature_pipeline(H.levels, [s.copy() for s in states], 0, bc, oc, 0, MultiFab, threshold=threshold)
     dls, dst = _dev(ctx, H, states)
     work = [capi.DevMF(ctx, dl, 1, 2) for dl in dls]
     dout = [capi.DevMF(ctx, dl, 8, 0) for dl in dls]
     for rep in range(2):  # the second pass reuses the level's compact arrays
-        capi.gradcurv_run(ctx, dst, 0, bc, capi.curv_params(fused=True), work, dout, 0)
+        # with a threshold the sweep clips N and K itself and the one-layer fix-up recomputes the clipped normals it needs
+        # (curvature.cpp:549-570; the coarse normals under coarse-fine faces stay clipped: quirk Q2)
+        capi.gradcurv_run(ctx, dst, 0, bc, capi.curv_params(threshold=threshold, fused=True), work, dout, 0)
         ctx.sync()
         assert ctx.bc_errors() == 0
         kn = ctx.lib.pa_sweep_kernel_name(ctx.h).decode()
         assert kn.endswith("CG=1>") or kn.startswith("k_gradcurv_march3_levels<"), kn  # the exact-normal pipeline did run (level by level or all levels in one launch)
+        if threshold is not None:
+            assert "CLIP" in kn
+            nclip = sum(int((np.abs(oc[l].valid_concat(2)) == 0).sum()) for l in range(H.nlev))
+            ncell = sum(lv.ncells for lv in H.levels)
+            assert 0.05 * ncell < nclip < 0.98 * ncell  # clipped and unclipped cells both present
         for l in range(H.nlev):
             got = dout[l].download()
             assert_valid_bits_equal(got, og[l], [(c, c) for c in range(4)], f"exact grad level {l}")
