@@ -476,9 +476,11 @@ static void march_launch(hipStream_t st, const BP& bp, int nx, int ny, int nz, u
     A.tiles_max = (int)tiles;
     if (A.order == 1) A.order = 0;
     const dim3 g = A.order == 2 ? dim3(tiles * 8u * ((nboxes + 7u) / 8u), 1) : dim3(tiles, nboxes);
-    if (A.thr >= 0.0) hipLaunchKernelGGL((k_gradcurv_march3n<BP, NRW, true>), g, dim3(64 * (NRW + 2)), 0, st, bp, A);
+    if (A.cg && A.thr >= 0.0) hipLaunchKernelGGL((k_gradcurv_march3n<BP, NRW, true, true>), g, dim3(64 * (NRW + 2)), 0, st, bp, A);
+    else if (A.cg) hipLaunchKernelGGL((k_gradcurv_march3n<BP, NRW, false, true>), g, dim3(64 * (NRW + 2)), 0, st, bp, A);
+    else if (A.thr >= 0.0) hipLaunchKernelGGL((k_gradcurv_march3n<BP, NRW, true>), g, dim3(64 * (NRW + 2)), 0, st, bp, A);
     else hipLaunchKernelGGL((k_gradcurv_march3n<BP, NRW, false>), g, dim3(64 * (NRW + 2)), 0, st, bp, A);
-    if (kname) *kname = std::string("k_gradcurv_march3n<NRW=8,CLIP=") + (A.thr >= 0.0 ? "1>" : "0>");
+    if (kname) *kname = std::string("k_gradcurv_march3n<NRW=8,CLIP=") + (A.thr >= 0.0 ? "1" : "0") + ",CG=" + (A.cg ? "1>" : "0>");
     return;
   }
   if (march_ver == 3) {
@@ -916,7 +918,9 @@ bool pa_fused2_level_ok(const pa_level* L) {
     for (int d = 0; d < 3; ++d)
       if (B.hi[d] - B.lo[d] + 1 < 3) return false;
   }
-  return maxnx > 32;  // narrower boxes run k_gradcurv_march3n, which has no CG variant
+  static const int narrow_cg = [] { const char* e = getenv("PA_NARROW_CG"); return e ? atoi(e) : 1; }();  // 0: boxes <= 32 wide keep the first pipeline (A/B)
+  static const int narrow_on = [] { const char* e = getenv("PA_NARROW"); return e ? atoi(e) : 1; }();
+  return maxnx > 32 || narrow_cg || !narrow_on;  // narrower boxes run k_gradcurv_march3n (its CG variant; PA_NARROW=0: the wide kernel)
 }
 
 // before the sweeps: face ghosts of phi + resolved ghost c (faces and ring) of several levels, one launch pair for up to

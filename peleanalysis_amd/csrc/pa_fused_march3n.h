@@ -23,7 +23,13 @@ struct MarchLdsN {
   double ny[3][ROWS][32];
 };
 
-template <typename BP, int NRW, bool CLIP>
+// CG (exact-normal pipeline, see pa_fused_march3.h): the progress variable in the ghost cells behind SPECIAL faces comes from
+// the level's compact face-major arrays.  z faces: the output rows take plane lo_z - 1 in the prologue and plane hi_z + 1
+// through one select per step; y faces: the halo wave's lanes of that side read the array [plane][x] with their second
+// stream (mode 1: the halo row IS the ghost row, the stream runs one plane ahead and supplies its c; mode 2: the tile ends
+// one row short of the box, the row BEYOND the halo row is the ghost row); x faces: the edge wave's lanes likewise with the
+// array [plane][y].  Both waves address the second stream through per-lane pointers when CG is on.
+template <typename BP, int NRW, bool CLIP, bool CG = false>
 __global__ __launch_bounds__(64 * (NRW + 2), 1) void k_gradcurv_march3n(BP bp, MarchArgs A) {
   FabView P, O;
   DBox V;
@@ -54,6 +60,16 @@ __global__ __launch_bounds__(64 * (NRW + 2), 1) void k_gradcurv_march3n(BP bp, M
   const int rtop = nrows + 1;                     // row slot of the upper halo row
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int rsub = lane >> 5, col = lane & 31;
+  const double *cgxl = nullptr, *cgxh = nullptr, *cgyl = nullptr, *cgyh = nullptr, *cgzl = nullptr, *cgzh = nullptr;
+  int xhmode = 0, yhmode = 0;
+  if (CG) {
+    if (bx == 0) cgxl = bp.cg_face(box, 0);
+    if (iR >= V.hi[0]) { cgxh = bp.cg_face(box, 1); xhmode = cgxh ? (iR == V.hi[0] + 1 ? 1 : 2) : 0; }
+    if (by == 0) cgyl = bp.cg_face(box, 2);
+    if (j0 + nrows >= V.hi[1]) { cgyh = bp.cg_face(box, 3); yhmode = cgyh ? (j0 + nrows == V.hi[1] + 1 ? 1 : 2) : 0; }
+    if (k0 == V.lo[2]) cgzl = bp.cg_face(box, 4);
+    if (k1 >= V.hi[2] - 1) cgzh = bp.cg_face(box, 5);
+  }
 
   __shared__ MarchLdsN<NRW> S;
   const long long pps = (long long)P.nx * P.ny * 8;  // plane stride of phi, bytes
@@ -96,6 +112,16 @@ __global__ __launch_bounds__(64 * (NRW + 2), 1) void k_gradcurv_march3n(BP bp, M
     gp += (k0 + 3 <= kfmax) ? pps : 0;
     f[2] = PA_LDG(gp, lo8);
     asm volatile("" ::"v"(f[0]), "v"(f[1]), "v"(f[2]));  // enter the loop with nothing in flight (see pa_fused_march3.h)
+    double cgzv = 0.0;
+    int pzh = -0x40000000;  // the step whose request becomes c of plane hi_z + 1
+    if (CG && cgzl) {
+      cc = cgzl[(long long)(j0 + rr - 1 - V.lo[1] + 1) * (nx + 2) + (i0 + le - V.lo[0] + 1)];
+      fzc = zflux(dxinv[2], cm, cc);
+    }
+    if (CG && cgzh) {
+      cgzv = cgzh[(long long)(j0 + rr - 1 - V.lo[1] + 1) * (nx + 2) + (i0 + le - V.lo[0] + 1)];
+      pzh = V.hi[2] - 1;
+    }
     S.c[0][rr][xs] = cc;
     __syncthreads();
     double nxq = 0, nyq = 0, nzq = 0, fzn = 0, fzp = 0;
@@ -157,6 +183,7 @@ __global__ __launch_bounds__(64 * (NRW + 2), 1) void k_gradcurv_march3n(BP bp, M
         o4 = nxq; o5 = nyq; o6 = nzq; o7 = curv;
       }
       cm = cc; cc = cp; cp = PA_PROG(x);
+      if (CG) cp = (p == pzh) ? cgzv : cp;  // x was phi of plane hi_z + 1
       fzc = fzh; fzn = fznh; fzp = fzph;
       pc = p0; p0 = p1; p1 = x;
       nxq = nxp; nyq = nyp; nzq = nzp;
@@ -180,24 +207,47 @@ __global__ __launch_bounds__(64 * (NRW + 2), 1) void k_gradcurv_march3n(BP bp, M
     unsigned oo8 = (unsigned)((jout - P.lo[1]) * P.nx + le) * 8u;
     const char* gp = gb;
     const char* go = gb + pps;
+    // CG: the second stream through a per-lane pointer (the two halves of the wave may sit on different kinds of face)
+    const char* gol = gb + pps + oo8;
+    long long pso = pps;
+    int sh = 0;
+#define PA_LDO(d) (CG ? PA_LDG(gol + (d) * pso, 0) : PA_LDG(go + (d) * pps, oo8))
     double p0 = PA_LDG(gp + pps, lo8), p1 = PA_LDG(gp + 2 * pps, lo8);
     double cm = PA_PROG(PA_LDG(gp, lo8)), cc = PA_PROG(p0), cp = PA_PROG(p1);
-    double co = PA_PROG(PA_LDG(go, oo8));
+    const double* cgy = CG ? (rsub ? cgyh : cgyl) : nullptr;
+    const int ymode = (CG && cgy) ? (rsub ? yhmode : 1) : 0;  // 1: this row is the ghost row; 2: the row beyond it is
+    const bool ysp = ymode == 1;
+    if (ymode) {
+      const char* cb = (const char*)(cgy + (long long)(k0 - 1 - V.lo[2] + 1) * (nx + 2) + (i0 + le - V.lo[0] + 1));
+      pso = (long long)(nx + 2) * 8;
+      if (ysp) {
+        sh = 1;
+        cc = PA_LDG(cb, 0);  // c of plane k0-1
+        gol = cb + pso;      // plane k0
+      } else {
+        gol = cb;            // c of the row beyond, same planes as the phi stream it replaces
+      }
+    }
+    double co = PA_LDO(0);
+    if (ysp) cp = co;
+    else if (ymode == 0) co = PA_PROG(co);
     double fzc = zflux(dxinv[2], cm, cc);
     double f[3], fo[3];
     __builtin_amdgcn_sched_barrier(0);
     f[0] = PA_LDG(gp + 3 * pps, lo8);
-    fo[0] = PA_LDG(go + pps, oo8);
+    fo[0] = PA_LDO(1);
     __builtin_amdgcn_sched_barrier(0);
     f[1] = PA_LDG(gp + 4 * pps, lo8);
-    fo[1] = PA_LDG(go + 2 * pps, oo8);
+    fo[1] = PA_LDO(2);
     __builtin_amdgcn_sched_barrier(0);
     gp += 4 * pps;
     gp += (k0 + 3 <= kfmax) ? pps : 0;
     go += 2 * pps;
     go += (k0 + 2 <= pend) ? pps : 0;
+    gol += 2 * pso;
+    gol += (k0 + 2 + sh <= pend) ? pso : 0;
     f[2] = PA_LDG(gp, lo8);
-    fo[2] = PA_LDG(go, oo8);
+    fo[2] = PA_LDO(0);
     __builtin_amdgcn_sched_barrier(0);
     S.c[0][rr][xs] = cc;
     __syncthreads();
@@ -209,6 +259,7 @@ __global__ __launch_bounds__(64 * (NRW + 2), 1) void k_gradcurv_march3n(BP bp, M
       __builtin_amdgcn_sched_barrier(0);
       gp += (p + 5 <= kfmax) ? pps : 0;
       go += (p + 4 <= pend) ? pps : 0;
+      if (CG) gol += (p + 4 + sh <= pend) ? pso : 0;
       const double cl = S.c[SP][rr][xs - 1], cr = S.c[SP][rr][xs + 1];
       const double cin = S.c[SP][rin][xs];
       const double cs = rsub ? cin : co, cn = rsub ? co : cin;
@@ -223,14 +274,15 @@ __global__ __launch_bounds__(64 * (NRW + 2), 1) void k_gradcurv_march3n(BP bp, M
       S.p[SP][rr][xs] = p0;
       __syncthreads();
       PA_OPAQUE(lo8);
-      PA_OPAQUE(oo8);
+      if (!CG) PA_OPAQUE(oo8);
       f[SP] = PA_LDG(gp, lo8);
-      fo[SP] = PA_LDG(go, oo8);
-      cm = cc; cc = cp; cp = PA_PROG(x); co = PA_PROG(xo);
+      fo[SP] = PA_LDO(0);
+      cm = cc; cc = cp; cp = ysp ? xo : PA_PROG(x); co = (ymode == 2) ? xo : PA_PROG(xo);
       fzc = fzh;
       p0 = p1; p1 = x;
     };
     PA_RUN3(step)
+#undef PA_LDO
     return;
   }
 
@@ -250,23 +302,45 @@ __global__ __launch_bounds__(64 * (NRW + 2), 1) void k_gradcurv_march3n(BP bp, M
     unsigned oo = (unsigned)((j - P.lo[1]) * P.nx + ((side ? i + 1 : i - 1) - P.lo[0])) * 8u;
     const char* gp = gb;
     const char* go = gb + pps;
+    const char* gol = gb + pps + oo;  // CG: per-lane pointer of the second stream (see the halo wave)
+    long long pso = pps;
+    int sh = 0;
+#define PA_LDO(d) (CG ? PA_LDG(gol + (d) * pso, 0) : PA_LDG(go + (d) * pps, oo))
     double p0 = PA_LDG(gp + pps, og), p1 = PA_LDG(gp + 2 * pps, og);
     double cm = PA_PROG(PA_LDG(gp, og)), cc = PA_PROG(p0), cp = PA_PROG(p1);
-    double co = PA_PROG(PA_LDG(go, oo));
+    const double* cgx = CG ? (side ? cgxh : cgxl) : nullptr;
+    const int xmode = (CG && cgx) ? (side ? xhmode : 1) : 0;  // 1: this column is the ghost column; 2: the column beyond it is
+    const bool xsp = xmode == 1;
+    if (xmode) {
+      const char* cb = (const char*)(cgx + (long long)(k0 - 1 - V.lo[2] + 1) * (ny + 2) + (j - V.lo[1] + 1));
+      pso = (long long)(ny + 2) * 8;
+      if (xsp) {
+        sh = 1;
+        cc = PA_LDG(cb, 0);  // c of plane k0-1
+        gol = cb + pso;      // plane k0
+      } else {
+        gol = cb;
+      }
+    }
+    double co = PA_LDO(0);
+    if (xsp) cp = co;
+    else if (xmode == 0) co = PA_PROG(co);
     double f[3], fo[3];
     __builtin_amdgcn_sched_barrier(0);
     f[0] = PA_LDG(gp + 3 * pps, og);
-    fo[0] = PA_LDG(go + pps, oo);
+    fo[0] = PA_LDO(1);
     __builtin_amdgcn_sched_barrier(0);
     f[1] = PA_LDG(gp + 4 * pps, og);
-    fo[1] = PA_LDG(go + 2 * pps, oo);
+    fo[1] = PA_LDO(2);
     __builtin_amdgcn_sched_barrier(0);
     gp += 4 * pps;
     gp += (k0 + 3 <= kfmax) ? pps : 0;
     go += 2 * pps;
     go += (k0 + 2 <= pend) ? pps : 0;
+    gol += 2 * pso;
+    gol += (k0 + 2 + sh <= pend) ? pso : 0;
     f[2] = PA_LDG(gp, og);
-    fo[2] = PA_LDG(go, oo);
+    fo[2] = PA_LDO(0);
     __builtin_amdgcn_sched_barrier(0);
     double fzc = zflux(dxinv[2], cm, cc);
     S.c[0][rr][xs] = cc;
@@ -279,6 +353,7 @@ __global__ __launch_bounds__(64 * (NRW + 2), 1) void k_gradcurv_march3n(BP bp, M
       __builtin_amdgcn_sched_barrier(0);
       gp += (p + 5 <= kfmax) ? pps : 0;
       go += (p + 4 <= pend) ? pps : 0;
+      if (CG) gol += (p + 4 + sh <= pend) ? pso : 0;
       const double inner = S.c[SP][rr][xin];
       const double cl = side ? inner : co, cr = side ? co : inner;
       const double cs = S.c[SP][rlo][xs], cn = S.c[SP][rhi][xs];
@@ -294,14 +369,15 @@ __global__ __launch_bounds__(64 * (NRW + 2), 1) void k_gradcurv_march3n(BP bp, M
       S.p[SP][rr][xs] = p0;
       __syncthreads();
       PA_OPAQUE(og);
-      PA_OPAQUE(oo);
+      if (!CG) PA_OPAQUE(oo);
       f[SP] = PA_LDG(gp, og);
-      fo[SP] = PA_LDG(go, oo);
-      cm = cc; cc = cp; cp = PA_PROG(x); co = PA_PROG(xo);
+      fo[SP] = PA_LDO(0);
+      cm = cc; cc = cp; cp = xsp ? xo : PA_PROG(x); co = (xmode == 2) ? xo : PA_PROG(xo);
       fzc = fzh;
       p0 = p1; p1 = x;
     };
     PA_RUN3(step)
+#undef PA_LDO
   }
 #undef PA_PROG
 #undef PA_RUN3
