@@ -208,6 +208,24 @@ __global__ __launch_bounds__(1024) void k_sdf_sweeps(const SdfGrid* grids) {
     }
 }
 
+// The same sweeps with the points of a hyperplane spread over the whole chip: ONE LAUNCH PER HYPERPLANE (all grids of the
+// batch side by side, blockIdx.y = grid), the kernel boundary is the barrier between hyperplanes and makes one step's
+// results visible to every CU of the next (per-XCD L2s are not coherent inside a launch).  Same points, same neighbour
+// order, same arithmetic as k_sdf_sweeps: bit-identical.  16 x (ni + nj + nk - 5) launches of a few microseconds each
+// instead of one workgroup walking ~6000 barriers with up to 12 points per thread behind each.
+__global__ __launch_bounds__(256) void k_sdf_sweep_plane(const SdfGrid* grids, int di, int dj, int dk, int s) {
+  const SdfGrid G = grids[blockIdx.y];
+  const int nu = G.ni - 1, nv = G.nj - 1, nw = G.nk - 1;
+  if (nu <= 0 || nv <= 0 || nw <= 0 || s >= nu + nv + nw - 2) return;
+  const int wlo = max(0, s - (nu - 1) - (nv - 1)), whi = min(nw - 1, s);
+  const int idx = wlo * nv + (int)(blockIdx.x * 256u + threadIdx.x);
+  if (idx >= (whi + 1) * nv) return;
+  const int v = idx % nv, w = idx / nv, u = s - v - w;
+  if (u < 0 || u >= nu) return;
+  const int i = di > 0 ? 1 + u : G.ni - 2 - u, j = dj > 0 ? 1 + v : G.nj - 2 - v, k = dk > 0 ? 1 + w : G.nk - 2 - w;
+  relax_point(G, i, j, k, di, dj, dk);
+}
+
 static int ensure_scr_sdf(pa_ctx* ctx, size_t bytes) {
   if (ctx->scr_cap >= bytes) return 0;
   if (ctx->d_scr) (void)hipFree(ctx->d_scr);
@@ -278,7 +296,24 @@ extern "C" int pa_sdf_level_set3(pa_ctx* ctx, int ngrids, const pa_sdf_grid* gri
     hipLaunchKernelGGL(k_sdf_band, dim3(gx_tri, (unsigned)ngrids), dim3(256), 0, ctx->stream, dg, exact_band);
   }
   hipLaunchKernelGGL(k_sdf_unpack, dim3(gx_cells, (unsigned)ngrids), dim3(256), 0, ctx->stream, dg);
-  if (max_tri > 0) hipLaunchKernelGGL(k_sdf_sweeps, dim3((unsigned)ngrids), dim3(1024), 0, ctx->stream, dg);
+  static const int onewg = [] { const char* e = getenv("PA_SDF_ONEWG"); return e ? atoi(e) : 0; }();  // 1: one workgroup per grid (A/B)
+  if (max_tri > 0 && onewg) hipLaunchKernelGGL(k_sdf_sweeps, dim3((unsigned)ngrids), dim3(1024), 0, ctx->stream, dg);
+  if (max_tri > 0 && !onewg) {
+    static const int dirs[8][3] = {{1, 1, 1}, {-1, -1, -1}, {1, 1, -1}, {-1, -1, 1}, {1, -1, 1}, {-1, 1, -1}, {1, -1, -1}, {-1, 1, 1}};
+    int nplanes = 0;
+    long long vw = 0;
+    for (int g = 0; g < ngrids; ++g) {
+      const pa_sdf_grid& S = grids[g];
+      if (S.ntri <= 0 || S.n[0] < 2 || S.n[1] < 2 || S.n[2] < 2) continue;  // a grid without triangles stays at its upper bound either way
+      nplanes = std::max(nplanes, S.n[0] + S.n[1] + S.n[2] - 5);
+      vw = std::max(vw, (long long)(S.n[1] - 1) * (S.n[2] - 1));
+    }
+    const dim3 gs((unsigned)((vw + 255) / 256), (unsigned)ngrids);
+    for (int pass = 0; pass < 2 && nplanes > 0; ++pass)
+      for (int s8 = 0; s8 < 8; ++s8)
+        for (int sp = 0; sp < nplanes; ++sp)
+          hipLaunchKernelGGL(k_sdf_sweep_plane, gs, dim3(256), 0, ctx->stream, dg, dirs[s8][0], dirs[s8][1], dirs[s8][2], sp);
+  }
   PA_HIP(hipGetLastError());
   // the scratch (descriptors) must outlive the kernels; it is only re-used by later calls on this stream
   return 0;

@@ -166,7 +166,7 @@ out["kernels"]["pa_mc_level_fine (same level, mask evaluated in the cell pass: 8
     "ms": ms_fine, "cells": lc, "Mcells_s": lc / ms_fine / 1e3, "bytes_per_cell": 8, "GBs": lc * 8 / ms_fine / 1e6, "frac_hbm": lc * 8 / ms_fine / 1e6 / HBM,
     "triangles": int(sum(ntb)), "Mtriangles_s": sum(ntb) / ms_fine / 1e3}
 del st5, mk5, t5, tmk
-if MCONLY:
+if MCONLY and not (len(sys.argv) > 4 and sys.argv[4] == "sdf"):
     print(json.dumps(out))
     sys.exit(0)
 
@@ -189,4 +189,4 @@ for nb in (1, 64):
     ctx.sync()
     dt = (time.perf_counter() - t0) * 1e3
     out["kernels"][f"sdf make_level_set3, {nb} grid(s) of {g}^3, {nt.value} triangles each"] = {"ms": dt, "Mpoints_s": nb * g ** 3 / dt / 1e3}
-print(json.dumps(out, indent=1))
+print(json.dumps(out) if MCONLY else json.dumps(out, indent=1))
