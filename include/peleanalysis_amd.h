@@ -332,6 +332,12 @@ int pa_sdf_signed_fab(pa_ctx*, pa_box vbox, const float* dev_phi, const pa_fab* 
  * [2*nseed][nsteps][3].  Returns non-zero where the reference aborts with "bad RK".  Synchronous. */
 int pa_stream_trace(pa_ctx*, int nlev, pa_mf* const* vfield, int vcomp, int64_t nseed, const double* seeds, int nsteps,
                     double dt, double* dev_pos, int32_t* nredist /* may be NULL */);
+/* The same with the lines dealt to the ranks of the context's transport (partStream.cpp under MPI: the particles live on
+ * the ranks, StreamPC.cpp:88-141 Redistribute is collective): every rank holds the WHOLE vector field (levels created
+ * unsharded) and traces its own seeds; with share_flags != 0 the per-step "a line has left its grid" flag is max-reduced
+ * over the ranks, so every line equals the one-rank run's.  Every rank must call it, also with nseed = 0. */
+int pa_stream_trace_ranks(pa_ctx*, int nlev, pa_mf* const* vfield, int vcomp, int64_t nseed, const double* seeds, int nsteps,
+                          double dt, double* dev_pos, int32_t* nredist /* may be NULL */, int share_flags);
 
 /* ------------------------------------------------------------ tool pipelines
  * The level loops of the tool mains, operating on device-resident MultiFabs.

@@ -150,11 +150,30 @@ __global__ __launch_bounds__(256) void k_stream_step(StreamLevels S, long long n
 
 extern "C" int pa_stream_trace(pa_ctx* ctx, int nlev, pa_mf* const* vfield, int vcomp, int64_t nseed, const double* seeds, int nsteps, double dt,
                                double* dev_pos, int32_t* nredist) {
+  return pa_stream_trace_ranks(ctx, nlev, vfield, vcomp, nseed, seeds, nsteps, dt, dev_pos, nredist, 0);
+}
+
+// share_flags: the lines are dealt to the ranks of the context's transport (every rank holds the WHOLE vector field and
+// traces its own seeds); "some line has left its grid" is then a property of all ranks' lines, as it is of all MPI ranks'
+// particles in the reference (StreamPC.cpp:88-141 Redistribute), so the step's flag is max-reduced over the ranks before
+// the step uses it -- every rank makes nsteps - 1 reductions, also one without seeds.  Results equal the one-rank run.
+extern "C" int pa_stream_trace_ranks(pa_ctx* ctx, int nlev, pa_mf* const* vfield, int vcomp, int64_t nseed, const double* seeds, int nsteps, double dt,
+                                     double* dev_pos, int32_t* nredist, int share_flags) {
   PaBind bind_(ctx);
   if (!ctx || !vfield || nlev <= 0 || nlev > PA_STREAM_MAXLEV || (nseed > 0 && (!seeds || !dev_pos))) return pa_fail(ctx, "pa_stream_trace: bad argument");
   if (nsteps < 1) return pa_fail(ctx, "pa_stream_trace: Nsteps must be at least 1");
   if (nredist) *nredist = 0;
-  if (nseed == 0) return 0;
+  const bool share = share_flags && ctx->comm.nranks > 1;
+  if (nseed == 0) {
+    int nr = 0;
+    for (int step = 0; share && step + 1 < nsteps; ++step) {  // keep the other ranks' reductions company
+      double f = 0.0;
+      if (pa_allreduce(ctx, &f, 1, 1)) return 1;
+      nr += f != 0.0;
+    }
+    if (nredist) *nredist = nr;
+    return 0;
+  }
   StreamLevels S;
   S.nlev = nlev; S.vcomp = vcomp; S.ng = vfield[0] ? vfield[0]->ng : 0;
   for (int l = 0; l < nlev; ++l) {
@@ -186,10 +205,20 @@ extern "C" int pa_stream_trace(pa_ctx* ctx, int nlev, pa_mf* const* vfield, int 
         hipMemcpyAsync(dbad, &big, sizeof(int), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { rc = pa_fail(ctx, "pa_stream_trace: copy failed"); break; }
     const unsigned g = (unsigned)((np + 255) / 256);
     hipLaunchKernelGGL(k_stream_init, dim3(g), dim3(256), 0, ctx->stream, S, np, dseeds, nsteps, dev_pos, dlev, dgrd);
-    for (int step = 0; step + 1 < nsteps; ++step) {
+    bool xfail = false;
+    for (int step = 0; step + 1 < nsteps && !xfail; ++step) {
       hipLaunchKernelGGL(k_stream_check, dim3(g), dim3(256), 0, ctx->stream, S, np, nsteps, step, dev_pos, dlev, dgrd, dflags);
+      if (share) {  // the flag of ALL ranks' lines
+        int hf1 = 0;
+        xfail = hipMemcpyAsync(&hf1, dflags + step, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess;
+        double f = hf1 ? 1.0 : 0.0;
+        xfail = xfail || pa_allreduce(ctx, &f, 1, 1) != 0;
+        hf1 = f != 0.0;
+        xfail = xfail || hipMemcpyAsync(dflags + step, &hf1, sizeof(int), hipMemcpyHostToDevice, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess;
+      }
       hipLaunchKernelGGL(k_stream_step, dim3(g), dim3(256), 0, ctx->stream, S, np, nsteps, step, dt, dev_pos, dlev, dgrd, dflags, dbad);
     }
+    if (xfail) { rc = pa_fail(ctx, "pa_stream_trace: sharing the redistribution flag between the ranks failed"); break; }
     if (hipGetLastError() != hipSuccess) { rc = pa_fail(ctx, "pa_stream_trace: launch failed"); break; }
     std::vector<int> hf((size_t)nsteps + 1);
     if (hipMemcpyAsync(hf.data(), dflags, sizeof(int) * hf.size(), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||

@@ -481,8 +481,59 @@ def test_partstream_tool_end_to_end(tmp_path, oracle):
         want, _ = oracle.stream_trace(H.levels, v, seeds, 30, dt)
         assert z.shape == want.shape and len(seeds) >= 5
         assert np.abs(z - want).max() <= 5e-6 * max(1.0, np.abs(want).max())  # ostream default precision: 6 significant digits
+        # ngpus=<n>: the lines dealt to n ranks (here sharing the GPU), the redistribution flag of every step reduced over the
+        # ranks: the file is byte-identical (3 ranks: uneven shares; 7 ranks > 5 rake seeds: ranks without a line)
+        ref_bytes = open(tmp_path / "tec.dat" / "str_00000.dat", "rb").read()
+        for n in (3, 7):
+            out = _run("partStream3d.ex", ["infile=" + p, "Nsteps=30", "hRK=0.2", f"ngpus={n}", "gpu_share=1"] + args, tmp_path, timeout=300)
+            assert f"Lines dealt to {n} GPUs" in out.stdout
+            assert open(tmp_path / "tec.dat" / "str_00000.dat", "rb").read() == ref_bytes, f"partStream ngpus={n} differs from the single-GPU file"
     bad = subprocess.run([os.path.join(BIN, "partStream3d.ex"), "infile=" + p], cwd=tmp_path, capture_output=True, text=True)
     assert bad.returncode != 0 and "Assertion" in bad.stderr
+
+
+@pytest.mark.gpu
+def test_partstream_one_seed_per_cell(tmp_path, oracle):
+    """oneSeedPerCell (partStream.cpp:21-61): a seed at the centre of every cell, not covered by the finer level, of the grids
+    that contain cell (0, 50, 107) of their level -- here one 8 x 32 x 32 grid of level 0 (a finer level covers part of
+    it) and one grid of level 1.  Lines equal the oracle's for the seeds generated here by the same rule."""
+    from peleanalysis_amd.hierarchy import Hierarchy, Level, chop_box, fill_analytic
+    plo, phi = np.zeros(3), np.asarray((0.125, 1.0, 2.0))
+    l0 = Level(chop_box((0, 0, 0), (7, 63, 127), 32), np.zeros(3, dtype=np.int64), np.asarray((7, 63, 127)), np.zeros(3, dtype=np.int64), plo, phi)
+    # level 1 refines coarse cells [0..7] x [40..55] x [100..111]  ->  fine [0..15] x [80..111] x [200..223] (contains (0, 50, 107)? no: j = 50 < 80)
+    l1 = Level(chop_box((0, 80, 200), (15, 111, 223), 16), np.zeros(3, dtype=np.int64), np.asarray((15, 127, 255)), np.zeros(3, dtype=np.int64), plo, phi)
+    H = Hierarchy([l0, l1], 2)
+    mfs = []
+    for lv in H.levels:
+        m = MultiFab(lv, 3, 0)
+        fill_analytic(m, 0, lambda x, y, z: 0.3 + 0.0 * x + 0.2 * np.sin(3 * y))
+        fill_analytic(m, 1, lambda x, y, z: 0.1 * np.cos(2 * z) + 0.0 * x)
+        fill_analytic(m, 2, lambda x, y, z: -0.2 + 0.1 * x + 0.05 * y)
+        mfs.append(m)
+    p = str(tmp_path / "pltv")
+    write_plotfile(p, H, mfs, ["x_velocity", "y_velocity", "z_velocity"], time=0.0, level_steps=[0, 0])
+    seeds = []
+    for l, lv in enumerate(H.levels):
+        dx = lv.dx
+        for b in range(lv.nboxes):
+            lo, hi = lv.boxes[b, :3], lv.boxes[b, 3:]
+            if not (lo[0] <= 0 <= hi[0] and lo[1] <= 50 <= hi[1] and lo[2] <= 107 <= hi[2]):
+                continue
+            for k in range(lo[2], hi[2] + 1):
+                for j in range(lo[1], hi[1] + 1):
+                    for i in range(lo[0], hi[0] + 1):
+                        if l == 0 and 0 <= i <= 7 and 40 <= j <= 55 and 100 <= k <= 111:
+                            continue  # covered by level 1
+                        seeds.append([(i + 0.5) * dx[0], (j + 0.5) * dx[1], (k + 0.5) * dx[2]])
+    seeds = np.asarray(seeds)
+    assert len(seeds) == 8 * 32 * 32 - 8 * 16 * 12  # only the level-0 grid [0..7] x [32..63] x [96..127] holds the tagged cell
+    _run("partStream3d.ex", ["infile=" + p, "oneSeedPerCell=1", "Nsteps=4", "hRK=0.25", "nGrow=2"], tmp_path)
+    txt = open(tmp_path / "tec.dat" / "str_00000.dat").read().split("\n")
+    z = np.array([[float(t) for t in ln.split()] for ln in txt[1:] if ln.strip() and not ln.startswith("ZONE")]).reshape(-1, 4, 3)
+    v = oracle.stream_field(H.levels, [MultiFab(lv, 3, 0, m.data.copy()) for lv, m in zip(H.levels, mfs)], (0, 1, 2), MultiFab, ngrow=2)
+    want, _ = oracle.stream_trace(H.levels, v, seeds, 4, 0.25 * float(H.levels[-1].dx[0]))
+    assert z.shape == want.shape
+    assert np.abs(z - want).max() <= 5e-6 * max(1.0, np.abs(want).max())
 
 
 @pytest.mark.gpu
@@ -817,6 +868,7 @@ def _tree_bytes(path):
     ("filterPlt3d.ex", ["max_grid_size=8", "interp_type=0", "base_fgr=4", "same_fgr_all_levels=1"], "_filtered"),
     ("isosurface3d.ex", ["isoCompName=temp", "isoVal=1150", "comps=0 4", "outfile_base=surf"], "surf.mef"),
     ("isosurface3d.ex", ["isoCompName=temp", "isoVal=1150", "comps=0 1", "outfile_base=surf", "is_per=1 1 0", "nGrow=2", "surfFormat=XDMF"], "surf.mesh"),
+    ("isosurface3d.ex", ["isoCompName=temp", "isoVal=1150", "comps=0", "outfile_base=surf", "build_distance_function=1", "outfile=dist", "nGrow=2"], "DIST"),
 ])
 def test_tools_multi_gpu_outputs_are_byte_identical(tmp_path, tool, args, suffix):
     """ngpus=<n>: the boxes of every level dealt to n ranks (host threads, one HIP context each; here they share the one GPU
@@ -833,6 +885,10 @@ def test_tools_multi_gpu_outputs_are_byte_identical(tmp_path, tool, args, suffix
         if suffix.startswith("surf"):  # isosurface: the surface file(s) in the run directory
             got = {f: open(d / f, "rb").read() for f in os.listdir(d) if f.startswith("surf")}
             assert suffix in got and len(got[suffix]) > 10000
+        elif suffix == "DIST":  # the distance plotfile (every rank computes the grids of its own FABs) + the surface
+            got = _tree_bytes(str(d / "dist"))
+            got.update({f: open(d / f, "rb").read() for f in os.listdir(d) if f.startswith("surf")})
+            assert len(got) >= 6 and "surf.mef" in got
         else:
             got = _tree_bytes(str(d / ("plt00005" + suffix)))
             assert len(got) >= 5

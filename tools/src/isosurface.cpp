@@ -16,7 +16,8 @@
 // ordering against which connectivity is defined (the reference gathers per-rank node / element lists to the
 // I/O rank and re-uniquifies there, :932-1037, :1838-1878, so ITS node numbering depends on the rank layout) -- so the
 // surface file is byte-identical for every n.  collate is accepted and has no effect: the merged surface is always
-// written by the one process.  build_distance_function needs ngpus=1.
+// written by the one process.  build_distance_function: every rank computes the grids of its own FABs (one make_level_set3 per FAB on the
+// FAB's own triangles: no cross-rank data), the distance plotfile is assembled on the host.
 // Periodic directions behave as in the reference: ghost cells behind a periodic face keep the coordinates of the
 // cells they image (isosurface.cpp:1469 "bad data in periodic directions"; the shift back at :1483-1507 never fires).
 #include "../common/pa_team.h"
@@ -92,7 +93,6 @@ int main(int argc, char** argv) {
   double tq = now();
   pa::AsyncTeam ateam(pp);
   std::vector<pa::HostMF> host(Nlev);
-  std::vector<std::vector<int64_t>> soff(Nlev), scs(Nlev);
   for (int lev = 0; lev < Nlev; ++lev) {
     // host side: the mapped plotfile components only (ghost cells -666: gstate.setVal(-666), isosurface.cpp:1512);
     // the three coordinate components are written on the device (isosurface.cpp:1458-1465)
@@ -107,10 +107,11 @@ int main(int argc, char** argv) {
   pa::Team& team = ateam.get();
   t_ctx = now() - tq;  // what was not hidden behind the reads
   if (team.n > 1) std::cout << "Boxes distributed over " << team.n << " GPUs, transport: " << team.transport << std::endl;
-  if (team.n > 1 && build_distance_function) pa::Abort("build_distance_function runs on one GPU: use ngpus=1");
   const std::vector<std::vector<int32_t>> owner = pa::shard_levels(H, Nlev, team.n);
   pa::IsoMerger merger(nc);
   std::vector<pa::HostMF> hdist(build_distance_function ? Nlev : 0);
+  if (build_distance_function)  // the whole level's distance multifab; every rank fills the FABs it owns (one grid per FAB: no cross-rank data)
+    for (int lev = 0; lev < Nlev; ++lev) hdist[lev].define(H.lev[lev].boxes, 1, nGrow[lev]);
   // one FAB's fragment into the global node / element sets: elements with a vertex whose edge is not inside the valid box
   // grown by 1 are dropped, with those vertices (isosurface.cpp:1657-1682; a no-op when nGrow = 1), then isosurface.cpp:1687-1726
   std::vector<double> hv;
@@ -176,12 +177,6 @@ int main(int argc, char** argv) {
       ctx.check(pa_mf_copy(ctx.h, dfield.h, 0, dst.back()->h, 3, nComp, ng));
       ctx.check(pa_sync(ctx.h));
     }
-    if (team.n == 1) {  // offsets of the nc-component device multifab (distance function)
-      const std::vector<int32_t> b6 = host[lev].boxes6();
-      soff[lev].resize(L.boxes.size());
-      scs[lev].resize(L.boxes.size());
-      pa_mf_layout((int)L.boxes.size(), b6.data(), nc, ng, soff[lev].data(), scs[lev].data());
-    }
     if (lead) t_up += now() - tq;
     tq = now();
     if (lead) std::cout << "FillPatching the grown structures at level " << lev << "..." << std::endl;
@@ -206,10 +201,20 @@ int main(int argc, char** argv) {
     std::vector<char> has_elts(L.boxes.size(), 0);
     double dxf[3];
     for (int d = 0; d < 3; ++d) dxf[d] = (H.prob_hi[d] - H.prob_lo[d]) / (double)(L.domain.hi[d] - L.domain.lo[d] + 1);
+    pa::HostMF hd_loc;  // this rank's FABs of the distance multifab (ngpus = 1: the level's multifab itself)
+    std::vector<int64_t> lsoff, lscs;  // offsets of this rank's nc-component device multifab
     if (build_distance_function) {
-      hdist[lev].define(L.boxes, 1, ng);
+      if (team.n > 1) hd_loc.define(L.boxes, 1, ng);
       ddist.reset(new pa::DevMF(ctx, *dl[lev], 1, ng));
+      std::vector<int32_t> b6(6 * L.boxes.size());
+      for (size_t i = 0; i < L.boxes.size(); ++i)
+        for (int d = 0; d < 3; ++d) { b6[6 * i + d] = L.boxes[i].lo[d]; b6[6 * i + 3 + d] = L.boxes[i].hi[d]; }
+      lsoff.resize(L.boxes.size());
+      lscs.resize(L.boxes.size());
+      pa_mf_layout((int)L.boxes.size(), b6.data(), nc, ng, lsoff.data(), lscs.data());
     }
+    pa::HostMF& hd = team.n > 1 ? hd_loc : (build_distance_function ? hdist[lev] : hd_loc);
+    pa::HostMF& hsrc = team.n > 1 ? hloc[lev] : host[lev];  // the plotfile components of this rank's FABs
     // fine-covered mask (isosurface.cpp:1540-1563; all 1 when building the distance function, :1542) and the whole
     // MFIter loop of :1531-1592 as one batch per level
     const bool fine_mask = lev < finestLevel && !build_distance_function;
@@ -296,21 +301,22 @@ int main(int argc, char** argv) {
         const pa::Box3& B = L.boxes[b];
         pa_box vb;
         pa_fab fs, fd;
-        fs.p = base + soff[lev][b]; fs.ncomp = nc; fs.nstride = scs[lev][b];
-        fd.p = dbase + hdist[lev].off[b]; fd.ncomp = 1; fd.nstride = hdist[lev].cs[b];
+        fs.p = base + lsoff[b]; fs.ncomp = nc; fs.nstride = lscs[b];
+        fd.p = dbase + hd.off[b]; fd.ncomp = 1; fd.nstride = hd.cs[b];
         for (int d = 0; d < 3; ++d) { vb.lo[d] = fs.lo[d] = fd.lo[d] = B.lo[d] - ng; vb.hi[d] = fs.hi[d] = fd.hi[d] = B.hi[d] + ng; }
         ctx.check(pa_sdf_signed_fab(ctx.h, vb, grids[q].phi, &fs, 3 + isoComp, isoVal, dmax, &fd, 0));
       }
-      ctx.check(pa_mf_download(ctx.h, ddist->h, hdist[lev].data.data()));
+      ctx.check(pa_mf_download(ctx.h, ddist->h, hd.data.data()));
       for (void* p : grid_bufs) pa_device_free(ctx.h, p);
       for (size_t b = 0; b < L.boxes.size(); ++b) {  // FABs without triangles: +-dmax from the first valid cell (isosurface.cpp:1651-1654)
         if (has_elts[b]) continue;
         const pa::Box3& B = L.boxes[b];
-        const double v = *host[lev].ptr((int)b, isoComp, B.lo[0], B.lo[1], B.lo[2]) < isoVal ? -dmax : dmax;
+        const double v = *hsrc.ptr((int)b, isoComp, B.lo[0], B.lo[1], B.lo[2]) < isoVal ? -dmax : dmax;
         for (int k = B.lo[2] - ng; k <= B.hi[2] + ng; ++k)
           for (int j = B.lo[1] - ng; j <= B.hi[1] + ng; ++j)
-            for (int i = B.lo[0] - ng; i <= B.hi[0] + ng; ++i) *hdist[lev].ptr((int)b, 0, i, j, k) = v;
+            for (int i = B.lo[0] - ng; i <= B.hi[0] + ng; ++i) *hd.ptr((int)b, 0, i, j, k) = v;
       }
+      if (team.n > 1) shares[lev].scatter(hd_loc, hdist[lev]);  // disjoint FABs: every rank writes its own
     }
   }
   });
