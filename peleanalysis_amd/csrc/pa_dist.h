@@ -65,6 +65,17 @@ struct CpPlan {
 };
 CpPlan* pa_cp_plan(pa_ctx* ctx, const pa_level* F, const pa_level* C);
 
+// A sharded level replicated on every rank (the implicit smoothing solve, pa_smooth.hip: a global iterative solve whose
+// dot products, average-down and reflux would otherwise each be a collective): `rep` holds the whole BoxArray unsharded;
+// gather = all ranks' valid cells into a multifab on rep (every rank sends its boxes to every other rank; its own by a
+// local copy), back = this rank's boxes of a multifab on rep into one on the sharded level (local copies only).
+struct RepPlan {
+  XPlan gather, back;
+  pa_level* rep = nullptr;
+  ~RepPlan();
+};
+RepPlan* pa_rep_plan(pa_ctx* ctx, const pa_level* L);
+
 struct XJob { XPlan* plan; const pa_mf* src; int scomp; pa_mf* dst; int dcomp; int ncomp; };
 
 XPlan* pa_fb_plan(pa_ctx* ctx, const pa_level* L, int ng);

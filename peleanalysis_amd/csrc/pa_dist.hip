@@ -508,6 +508,47 @@ XPlan* pa_fb_plan(pa_ctx* ctx, const pa_level* L, int ng) {
   return raw;
 }
 
+RepPlan::~RepPlan() {
+  if (rep) pa_level_destroy(rep);
+}
+RepPlan* pa_rep_plan(pa_ctx* ctx, const pa_level* L) {
+  if (L->rep_plan) return L->rep_plan.get();
+  if (L->nranks <= 1 || L->gboxes.empty()) { pa_fail(ctx, "pa_rep_plan: the level is not sharded"); return nullptr; }
+  std::unique_ptr<RepPlan> P(new RepPlan());
+  LevelSpec S;
+  S.local = L->gboxes;  // the whole BoxArray, unsharded: box index = global index
+  P->rep = pa_level_create_spec(ctx, S, L->domlo, L->domhi, L->is_per, L->prob_lo, L->prob_hi);
+  if (!P->rep) return nullptr;
+  std::vector<std::pair<int, std::array<int32_t, 7>>> s, r, none;
+  std::vector<int32_t> own_s, own_g;  // this rank's boxes: (local index, box) and (global index, box)
+  for (size_t b = 0; b < L->boxes.size(); ++b) {
+    for (int q = 0; q < L->nranks; ++q)
+      if (q != L->rank) s.push_back({q, reg7((int)b, L->boxes[b])});  // side_finish groups by peer and keeps the box order
+    const auto a = reg7((int)b, L->boxes[b]), g = reg7(L->gid[b], L->boxes[b]);
+    own_s.insert(own_s.end(), a.begin(), a.end());
+    own_g.insert(own_g.end(), g.begin(), g.end());
+    P->gather.lmax = std::max(P->gather.lmax, bx_cells(L->boxes[b]));
+  }
+  for (size_t g = 0; g < L->gboxes.size(); ++g)
+    if (L->gowner[g] != L->rank) r.push_back({L->gowner[g], reg7((int)g, L->gboxes[g])});  // ascending global index = the sender's box order
+  if (side_finish(ctx, P->gather.send, s) || side_finish(ctx, P->gather.recv, r)) return nullptr;
+  if (side_finish(ctx, P->back.send, none) || side_finish(ctx, P->back.recv, none)) return nullptr;
+  P->back.lmax = P->gather.lmax;
+  P->gather.nlocal = P->back.nlocal = (int)L->boxes.size();
+  if (!L->boxes.empty()) {
+    const size_t bytes = sizeof(int) * own_s.size();
+    if (hipMalloc(&P->gather.d_lsrc, bytes) != hipSuccess || hipMalloc(&P->gather.d_ldst, bytes) != hipSuccess || hipMalloc(&P->back.d_lsrc, bytes) != hipSuccess ||
+        hipMalloc(&P->back.d_ldst, bytes) != hipSuccess || hipMemcpy(P->gather.d_lsrc, own_s.data(), bytes, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(P->gather.d_ldst, own_g.data(), bytes, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(P->back.d_lsrc, own_g.data(), bytes, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(P->back.d_ldst, own_s.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) {
+      pa_fail(ctx, "pa_rep_plan: device allocation failed");
+      return nullptr;
+    }
+  }
+  L->rep_plan = std::move(P);
+  return L->rep_plan.get();
+}
+
 CsPlan* pa_cs_plan(pa_ctx* ctx, const pa_level* F, const pa_level* C, int mode, int ng, int halo) {
   const auto key = std::make_pair(C->serial, mode == 0 ? 0 : 1 + ng * 16 + halo);
   auto it = F->cs_plans.find(key);

@@ -158,6 +158,7 @@ struct pa_level {
   mutable std::map<long long, std::unique_ptr<struct CpPlan>> cp_plans;               // coarse-patch gather as copy regions, by coarse level serial (pa_dist.hip)
   mutable std::map<int, std::unique_ptr<struct FbLocal>> fb_local;                     // local FillBoundary as copy regions, by ghost width (pa_dist.hip)
   mutable std::map<std::pair<long long, int>, std::unique_ptr<struct CsPlan>> cs_plans; // coarse-source plans by (coarse level serial, mode)
+  mutable std::unique_ptr<struct RepPlan> rep_plan;                                     // the level replicated on every rank (pa_dist.hip)
   ~pa_level();
 };
 

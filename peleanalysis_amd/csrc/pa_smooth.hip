@@ -10,6 +10,7 @@
 // writes y once (16 B/cell), reductions are two-stage with a fixed summation order per launch shape.
 #include "pa_internal.h"
 #include "pa_fabview.h"
+#include "pa_dist.h"
 #include <cmath>
 #include <memory>
 #include <vector>
@@ -276,10 +277,46 @@ struct SmoothSolver {
   }
 };
 
+// A hierarchy sharded over ranks: the solve is REPLICATED.  Every rank gathers the right-hand side of the whole hierarchy
+// (one grouped exchange, RepPlan in pa_dist.hip), runs the same composite solve on its own GPU -- same input, same kernels,
+// same fixed summation order, so every rank gets the same field and the result equals the one-rank run -- and keeps the
+// boxes it owns.  The reference's MLMG distributes this solve; here it is an optional pre-pass (do_smooth, curvature.cpp:
+// 328-406) on one component, and a distributed Krylov solve would make every dot product, average-down and reflux a
+// collective.  Stated cost: no speed-up of this phase with the number of GPUs, (nranks - 1) x this rank's cells of send buffer.
+static int smooth_solve_replicated(pa_ctx* ctx, int nlev, pa_mf* const* rhs, int rcomp, pa_mf* const* sol, int scomp, double dt, const int32_t bc[3], double tol,
+                                   int maxiter, int* iters, double* res) {
+  std::vector<RepPlan*> P((size_t)nlev, nullptr);
+  Vecs R, X;
+  std::vector<XJob> gj, bj;
+  for (int l = 0; l < nlev; ++l) {
+    if (!rhs[l] || !sol[l] || rhs[l]->lev != sol[l]->lev) return pa_fail(ctx, "pa_smooth_solve: rhs/sol on different levels");
+    if (rcomp < 0 || rcomp >= rhs[l]->ncomp || scomp < 0 || scomp >= sol[l]->ncomp) return pa_fail(ctx, "pa_smooth_solve: component range");
+    if (rhs[l]->lev->nranks != ctx->comm.nranks) return pa_fail(ctx, "pa_smooth_solve: the context's transport has a different number of ranks than the levels");
+    P[(size_t)l] = pa_rep_plan(ctx, rhs[l]->lev);
+    if (!P[(size_t)l]) return 1;
+    pa_mf* r = pa_mf_create(ctx, P[(size_t)l]->rep, 1, 0, nullptr);
+    pa_mf* x = pa_mf_create(ctx, P[(size_t)l]->rep, 1, 0, nullptr);
+    if (r) R.v.push_back(r);
+    if (x) X.v.push_back(x);
+    if (!r || !x) return 1;
+    gj.push_back({&P[(size_t)l]->gather, rhs[l], rcomp, r, 0, 1});
+    bj.push_back({&P[(size_t)l]->back, x, 0, sol[l], scomp, 1});
+  }
+  if (pa_xexchange(ctx, nlev, gj.data())) return 1;
+  // a solve that stopped short of `tol` still hands its last iterate back (the caller decides: pa_pipeline.hip accepts 1e-12)
+  const int rc = pa_smooth_solve(ctx, nlev, R.v.data(), 0, X.v.data(), 0, dt, bc, tol, maxiter, iters, res);
+  const std::string why = ctx->err;
+  if (pa_xexchange(ctx, nlev, bj.data())) return 1;  // local copies only: no transport call
+  PA_HIP(hipStreamSynchronize(ctx->stream));   // R, X are freed on return
+  if (rc) ctx->err = why;
+  return rc;
+}
+
 extern "C" int pa_smooth_solve(pa_ctx* ctx, int nlev, pa_mf* const* rhs, int rcomp, pa_mf* const* sol, int scomp, double dt, const int32_t bc[3], double tol,
                                int maxiter, int* iters, double* res) {
   PaBind bind_(ctx);
   if (!ctx || nlev <= 0 || !rhs || !sol || !bc) return pa_fail(ctx, "pa_smooth_solve: null argument");
+  if (rhs[0] && rhs[0]->lev->nranks > 1) return smooth_solve_replicated(ctx, nlev, rhs, rcomp, sol, scomp, dt, bc, tol, maxiter, iters, res);
   SmoothSolver S;
   S.ctx = ctx; S.nlev = nlev; S.ratio = 2; S.dt = dt;
   for (int d = 0; d < 3; ++d) S.bc[d] = bc[d];
