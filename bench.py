@@ -502,10 +502,10 @@ def main():
         # achieved = algorithmic bytes of all timed launches / their time
         avg_ms = ms_k / nk
         ach = cells_local * args.ncomp * args.steps * BYTES_PER_CELL / (ms_k * 1e-3) / 1e9
-        # HBM bytes per launch from this round's rocprofv3 PMC passes of the same workload (profiles/, tools/r2_pmc.sh): only
+        # HBM bytes per launch from this round's rocprofv3 PMC passes of the same workload (profiles/, tools/prof.sh bench): only
         # valid for the kernel variant it was measured on -- null when the library launched another one
         traffic, kern = None, ctx.lib.pa_sweep_kernel_name(ctx.h).decode()
-        tj = os.path.join(ROOT, "profiles", "r02_headline_traffic.json")
+        tj = os.path.join(ROOT, "profiles", "r03_headline_traffic.json")
         if os.path.exists(tj) and (args.base, args.nlev, args.box, args.ncomp, world, args.sim_of) == (512, 3, 128, 1, 1, 0):
             rec = json.load(open(tj))
             if rec.get("kernel") == kern:

@@ -1,41 +1,158 @@
 #!/bin/bash
-# Profile the fused grad->curvature path on the GPU box: kernel trace + stats, then PMC passes in
-# separate runs (as the MI355X guide prescribes).  Every run is bounded by `timeout`.
-# Usage: tools/prof.sh <tag> [base] [box]   -> gpurun_out/prof_<tag>/summary.txt (small files only)
+# tools/prof.sh -- the ONE profiling entry point (run on the GPU box through gpurun; every step bounded by `timeout`,
+# rocprofv3 --kernel-trace --stats first, PMC counters in their own passes as MI355X_MICROARCH.md prescribes).
+# Results: small text / JSON files under gpurun_out/ named <tag>_*; copy what is to be judged into profiles/.
+#
+#   tools/prof.sh bench    <tag> [bench.py args]   bench.py under the kernel trace (+ kernel stats of the library's kernels),
+#                                                  then FETCH_SIZE / WRITE_SIZE passes of the same hierarchy on the torch-free
+#                                                  driver -> <tag>_bench.json, <tag>_kstats.txt, <tag>_traffic.json
+#   tools/prof.sh kernels  <tag> [base box]        time + HBM traffic of EVERY kernel of the headline pass -> <tag>_all_kernels_traffic.txt
+#   tools/prof.sh sq       <tag> [base box]        SQ cycle / instruction counters per kernel -> <tag>_sq_counters.txt
+#   tools/prof.sh filter   <tag> [box]             separable + tap-order box filter: time + traffic -> <tag>_filter_traffic.txt
+#   tools/prof.sh membench <tag>                   store-ceiling experiments (tools/bench/membench5: matrix, stride, fronts +
+#                                                  memory-side counters per cell) -> <tag>_membench5*.txt
+#   tools/prof.sh ab       <tag> VAR [A=1 B=0]       tools/ab_driver.py: one environment switch, alternating blocks of passes inside one process
 set -u
-TAG=$1; BASE=${2:-256}; BOX=${3:-128}
-OUT=$PWD/gpurun_out/prof_$TAG
-SCR=/tmp/prof_$TAG
-rm -rf "$SCR"; mkdir -p "$OUT" "$SCR"
+WHAT=${1:?what}; TAG=${2:?tag}; shift 2
 export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$SCR/trace" -- python3 tools/prof_driver.py $BASE $BOX 3 > "$OUT/driver.txt" 2> "$SCR/trace.err" || echo "trace run failed/timeout" >> "$OUT/driver.txt"
-i=0
-for P in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \
-         "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VMEM" \
-         "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE"; do
-  i=$((i+1))
-  timeout 300 rocprofv3 --pmc $P --output-format csv -d "$SCR/pmc_$i" -- python3 tools/prof_driver.py $BASE $BOX 1 > /dev/null 2> "$SCR/pmc_$i.err" || echo "pmc pass $i ($P) failed/timeout" >> "$OUT/driver.txt"
-done
-python3 - "$SCR" "$OUT" <<'PY'
-import csv, glob, sys, collections, os
-scr, out = sys.argv[1], sys.argv[2]
-with open(os.path.join(out, "summary.txt"), "w") as f:
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
+mkdir -p gpurun_out
+S=/tmp/prof_$TAG; rm -rf "$S"; mkdir -p "$S"
+
+pmc_pass() {  # pmc_pass <dir> "<counters>" <program...>
+  local d=$1 c=$2; shift 2
+  timeout 300 rocprofv3 --pmc $c --output-format csv -d "$d" -- "$@" > "$d.out" 2>&1 || echo "pmc pass ($c) failed: $(tail -2 "$d.out")" >> gpurun_out/${TAG}_errors.txt
+}
+
+case $WHAT in
+bench)
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $S/trace -- python3 bench.py --steps 20 --warmup 5 "$@" > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
+  for C in FETCH_SIZE WRITE_SIZE; do pmc_pass $S/pmc_$C $C python3 tools/prof_driver.py 512 128 2; done
+  python3 - $S $TAG <<'PY'
+import csv, glob, json, sys, collections
+scr, tag = sys.argv[1], sys.argv[2]
+sym = avg = calls = None
+with open(f"gpurun_out/{tag}_kstats.txt", "w") as f:
+    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5 [args] (kernels of the library; torch's data-generation kernels omitted)\n")
     for p in glob.glob(scr + "/trace/**/*kernel_stats.csv", recursive=True):
-        f.write("== kernel stats (%s)\n" % os.path.basename(p))
         for row in csv.DictReader(open(p)):
-            f.write("%-64s calls %6s total_ns %14s avg_ns %12s pct %s\n" % (row.get("Name", "")[:64], row.get("Calls"), row.get("TotalDurationNs"), row.get("AverageNs"), row.get("Percentage")))
-    agg = collections.defaultdict(lambda: collections.defaultdict(float))
-    nd = collections.defaultdict(set)
-    for p in glob.glob(scr + "/pmc_*/**/*counter_collection.csv", recursive=True):
-        for row in csv.DictReader(open(p)):
-            k = row["Kernel_Name"][:64]
-            agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
-            nd[(k, row["Counter_Name"])].add(row["Dispatch_Id"])
-    f.write("== PMC: sum over dispatches / number of dispatches (per kernel)\n")
-    for k, cs in agg.items():
-        f.write(k + "\n")
-        for c, v in sorted(cs.items()):
-            n = len(nd[(k, c)])
-            f.write("    %-28s sum %.6g  dispatches %d  per-dispatch %.6g\n" % (c, v, n, v / max(n, 1)))
-print(open(os.path.join(out, "summary.txt")).read())
+            n = row.get("Name", "")
+            if "at::native" in n or "rocclr" in n or "elementwise" in n:
+                continue
+            f.write("%-100s calls %6s total_ns %12s avg_ns %12s pct %s\n" % (n[:100], row.get("Calls"), row.get("TotalDurationNs"), row.get("AverageNs"), row.get("Percentage")))
+            if "k_gradcurv_march3" in n and (avg is None or float(row["TotalDurationNs"]) > avg * calls):
+                sym, avg, calls = n, float(row["AverageNs"]), int(row["Calls"])
+agg, nd = collections.defaultdict(float), collections.defaultdict(set)
+for p in glob.glob(scr + "/pmc_*/**/*counter_collection.csv", recursive=True):
+    for row in csv.DictReader(open(p)):
+        if "k_gradcurv_march3" in row["Kernel_Name"]:
+            agg[row["Counter_Name"]] += float(row["Counter_Value"]); nd[row["Counter_Name"]].add(row["Dispatch_Id"])
+line = json.loads(open(f"gpurun_out/{tag}_bench.json").read().strip().splitlines()[-1])
+rec = {"command": "tools/prof.sh bench: rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5 ; rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE -- python3 tools/prof_driver.py 512 128 2 (separate passes, the same hierarchy and library calls without torch)",
+       "workload": line["config"]["workload"], "kernel": line["roofline"]["kernel"].split(" (")[0], "symbol": sym,
+       "avg_launch_ns_trace": avg, "launches_in_trace": calls, "avg_launch_ms_bench_events": line["roofline"]["avg_launch_ms"]}
+if "FETCH_SIZE" in agg and "WRITE_SIZE" in agg:
+    fetch, write = agg["FETCH_SIZE"] / len(nd["FETCH_SIZE"]), agg["WRITE_SIZE"] / len(nd["WRITE_SIZE"])
+    rec.update({"FETCH_SIZE_KiB_per_launch": fetch, "WRITE_SIZE_KiB_per_launch": write,
+                "note": "gfx950 correction per MI355X_MICROARCH.md (HBM section): FETCH_SIZE counts 64 B per 128-B request -> doubled; WRITE_SIZE exact",
+                "traffic_bytes_per_launch": int(2 * fetch * 1024 + write * 1024), "algorithmic_bytes_per_launch": int(line["roofline"]["cells_per_launch"] * 72)})
+json.dump(rec, open(f"gpurun_out/{tag}_traffic.json", "w"), indent=1)
+print(open(f"gpurun_out/{tag}_kstats.txt").read()); print(json.dumps(rec, indent=1)); print(json.dumps({k: v for k, v in line.items() if k != "secondary"})[:1800])
 PY
+  ;;
+kernels|sq)
+  BASE=${1:-512}; BOX=${2:-128}
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $S/trace -- python3 tools/prof_driver.py $BASE $BOX 4 > $S/trace.out 2>&1
+  if [ $WHAT = kernels ]; then GROUPS_=("FETCH_SIZE" "WRITE_SIZE"); else
+    GROUPS_=("SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE"); fi
+  i=0; for C in "${GROUPS_[@]}"; do i=$((i+1)); pmc_pass $S/pmc_$i "$C" python3 tools/prof_driver.py $BASE $BOX 2; done
+  python3 - $S $TAG $WHAT $BASE $BOX <<'PY'
+import csv, glob, sys, collections
+scr, tag, what, base, box = sys.argv[1:6]
+avg = {}
+for p in glob.glob(scr + "/trace/**/*kernel_stats.csv", recursive=True):
+    for row in csv.DictReader(open(p)):
+        avg[row["Name"]] = (float(row["AverageNs"]), int(row["Calls"]))
+agg, nd = collections.defaultdict(float), collections.defaultdict(set)
+for p in glob.glob(scr + "/pmc_*/**/*counter_collection.csv", recursive=True):
+    for row in csv.DictReader(open(p)):
+        key = (row["Kernel_Name"], row["Counter_Name"])
+        agg[key] += float(row["Counter_Value"]); nd[key].add(row["Dispatch_Id"])
+out = f"gpurun_out/{tag}_" + ("all_kernels_traffic.txt" if what == "kernels" else "sq_counters.txt")
+with open(out, "w") as o:
+    o.write(f"# tools/prof.sh {what}: rocprofv3 --kernel-trace --stats, then --pmc passes (separate) -- python3 tools/prof_driver.py {base} {box}\n")
+    if what == "kernels":
+        o.write("# traffic = 2 x FETCH_SIZE (gfx950: 64 B counted per 128-B request) + WRITE_SIZE, per launch\n")
+        for name in sorted(avg, key=lambda n: -avg[n][0] * avg[n][1]):
+            f = agg.get((name, "FETCH_SIZE"), 0) / max(1, len(nd.get((name, "FETCH_SIZE"), [1])))
+            w = agg.get((name, "WRITE_SIZE"), 0) / max(1, len(nd.get((name, "WRITE_SIZE"), [1])))
+            t = avg[name][0]
+            gb = (2 * f + w) * 1024 / 1e9
+            o.write("%-62s %9.1f us  fetch x2 %8.3f GB  write %8.3f GB  -> %6.2f TB/s\n" % (name[:62], t / 1e3, 2 * f * 1024 / 1e9, w * 1024 / 1e9, gb / (t * 1e-9) / 1e3 if t else 0))
+    else:
+        for n in sorted({k[0] for k in agg}):
+            if "rocclr" in n: continue
+            o.write(n[:60] + "\n")
+            for c in sorted({k[1] for k in agg if k[0] == n}):
+                o.write("    %-22s %16.0f per launch\n" % (c, agg[(n, c)] / len(nd[(n, c)])))
+print(open(out).read())
+PY
+  ;;
+filter)
+  BOX=${1:-128}
+  for C in FETCH_SIZE WRITE_SIZE; do pmc_pass $S/$C $C python3 tools/kernel_bench.py 512 $BOX filteronly; done
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $S/trace -- python3 tools/kernel_bench.py 512 $BOX filteronly > $S/trace.out 2>&1
+  python3 - $S $TAG $BOX <<'PY'
+import csv, glob, sys, collections
+scr, tag, box = sys.argv[1:4]
+agg, nd = collections.defaultdict(float), collections.defaultdict(set)
+for p in glob.glob(scr + "/*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(p)):
+        n = r["Kernel_Name"]
+        if "filter" not in n: continue
+        k = (n[:60], r["Counter_Name"]); agg[k] += float(r["Counter_Value"]); nd[k].add(r["Dispatch_Id"])
+dur = {}
+for p in glob.glob(scr + "/trace/**/*kernel_stats.csv", recursive=True):
+    for r in csv.DictReader(open(p)):
+        if "filter" in r["Name"]: dur[r["Name"][:60]] = float(r["AverageNs"])
+with open(f"gpurun_out/{tag}_filter_traffic.txt", "w") as o:
+    o.write(f"# tools/prof.sh filter: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) + --kernel-trace --stats -- python3 tools/kernel_bench.py 512 {box} filteronly\n")
+    o.write("# traffic = 2 x FETCH_SIZE (gfx950: 64 B counted per 128-B request) + WRITE_SIZE per launch; algorithmic = 2.147 GB (16 B x 512^3)\n")
+    for n in sorted({k[0] for k in agg}):
+        f = agg[(n, "FETCH_SIZE")] / max(1, len(nd[(n, "FETCH_SIZE")])) * 1024 * 2 / 1e9
+        w = agg[(n, "WRITE_SIZE")] / max(1, len(nd[(n, "WRITE_SIZE")])) * 1024 / 1e9
+        o.write("%-62s avg %8.1f us  fetch x2 %6.3f GB  write %6.3f GB  total %6.3f GB = %.2f x algorithmic\n" % (n, dur.get(n, 0) / 1e3, f, w, f + w, (f + w) / 2.147))
+print(open(f"gpurun_out/{tag}_filter_traffic.txt").read())
+PY
+  ;;
+membench)
+  B=tools/bench/membench5
+  for SET in matrix stride fronts; do timeout 300 $B 6 $SET > gpurun_out/${TAG}_membench5_$SET.txt 2>&1; done
+  i=0
+  for C in "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_WRREQ_STALL_sum" "TCC_EA0_WRREQ_DRAM_CREDIT_STALL_sum TCC_TAG_STALL_sum TCC_TOO_MANY_EA_WRREQS_STALL_sum" "TCC_EA0_WRREQ_LEVEL_sum TCC_EA0_RDREQ_sum GRBM_GUI_ACTIVE"; do
+    i=$((i+1)); pmc_pass $S/m$i "$C" $B 1 matrix; pmc_pass $S/f$i "$C" $B 1 fronts
+  done
+  python3 - $S $TAG <<'PY'
+import csv, glob, sys, collections
+scr, tag = sys.argv[1], sys.argv[2]
+for pre, name in (("m", "matrix"), ("f", "fronts")):
+    cells = [l.split("|")[0].strip() for l in open(f"{scr}/{pre}1.out") if " rd " in l and "|" in l]
+    tab = collections.defaultdict(dict)
+    for p in sorted(glob.glob(f"{scr}/{pre}*/**/*counter_collection.csv", recursive=True)):
+        rows = [r for r in csv.DictReader(open(p)) if "k_mix" in r["Kernel_Name"]]
+        pos = {d: n for n, d in enumerate(sorted({int(r["Dispatch_Id"]) for r in rows}))}
+        for r in rows:
+            tab[pos[int(r["Dispatch_Id"])]][r["Counter_Name"]] = float(r["Counter_Value"])
+    with open(f"gpurun_out/{tag}_membench5_{name}_pmc.txt", "w") as o:
+        o.write(f"# rocprofv3 --pmc <group> -- tools/bench/membench5 1 {name} : one dispatch per cell, counters per dispatch\n")
+        for n in sorted(tab):
+            o.write((cells[n] if n < len(cells) else "cell %d" % n) + "  " + "  ".join("%s=%.3g" % (k.replace("TCC_", "").replace("_sum", ""), v) for k, v in sorted(tab[n].items())) + "\n")
+PY
+  cat gpurun_out/${TAG}_membench5_fronts.txt
+  ;;
+ab)
+  VAR=$1; A=${2:-1}; B=${3:-0}
+  timeout 900 python3 tools/ab_driver.py $VAR 512 128 8 15 $A $B | tee gpurun_out/${TAG}_ab_${VAR}.txt
+  ;;
+*) echo "unknown: $WHAT"; exit 2;;
+esac
