@@ -96,6 +96,31 @@ def test_filter_generic_width_and_fab_entry(ctx, oracle, filter_mode):
     assert_filter_parity(do.download(), oo, [(0, 0)], "pa_boxfilter_fab ng=3", filter_mode)
 
 
+@pytest.mark.parametrize("fgr", [12, 16])
+def test_filter_wide_windows(ctx, oracle, filter_mode, fgr):
+    """fgr = 12 / 16 (ng = 6 / 8: 13^3 / 17^3 taps, the widths a 3- or 4-level run with base_fgr = 2 .. 6 reaches on its finest
+    level, filterPlt.cpp:132-134): the separable kernel's one-pair-per-thread instantiations (512 and 1024 threads) and the
+    generic tap-order kernel, on a level of mixed box widths (40 and 20 cells: both thread counts) through pa_boxfilter_level"""
+    from peleanalysis_amd.hierarchy import Level
+    ng = fgr // 2
+    boxes = np.vstack([chop_box((0, 0, 0), (39, 19, 19), 40), chop_box((40, 0, 0), (59, 19, 19), 20)])
+    lv = Level(boxes, (0, 0, 0), (59, 19, 19), (1, 1, 1), (0, 0, 0), (3, 1, 1))
+    rng = np.random.default_rng(fgr)
+    s = MultiFab(lv, 2, ng)
+    s.data[:] = 300.0 + 1700.0 * rng.random(s.total)
+    ngf, w = oracle.box_filter_weights(fgr)
+    assert ngf == ng
+    oracle.fill_boundary(s, 0, 2, ng)
+    oo = MultiFab(lv, 2, 0)
+    oracle.lib().orc_apply_filter(C.byref(oracle._mf(s)), C.byref(oracle._mf(oo)), 0, 2, ng, (C.c_double * (2 * ng + 1))(*w))
+    dl = capi.DevLevel(ctx, lv)
+    di = capi.DevMF.from_host(ctx, dl, s)
+    do = capi.DevMF(ctx, dl, 2, 0)
+    ctx.check(ctx.lib.pa_boxfilter_level(ctx.h, di.h, do.h, 0, 2, ng, (C.c_double * (2 * ng + 1))(*w)))
+    ctx.sync()
+    assert_filter_parity(do.download(), oo, [(0, 0), (1, 1)], f"fgr {fgr}", filter_mode)
+
+
 # ------------------------------------------------------------------------------- marching cubes
 def _mc_case(n, seed, masked):
     """state FAB over box (-1..n)^3 with 3 coordinate comps + 2 fields; iso field = wrinkled sphere"""
