@@ -684,6 +684,85 @@ __global__ void k_fillpatch2(DLevelView L, DMFView M, DLevelView LC, DMFView MC,
   }
 }
 
+// The same for interp_type 1 with one thread per COARSE parent cell of the ghost shell: the 8 children of a parent share
+// its limited slopes and common factor (27 coarse values through the owner map, min / max, two divisions), which the
+// per-ghost-cell kernel recomputed for each of them.  Same operations on the same operands per child, so the ghost cells
+// are bit-identical (the filter tests compare the shell with the oracle).  Parents whose children are all valid cells of
+// the box leave at once.
+__global__ __launch_bounds__(256) void k_fillpatch2p(DLevelView L, DMFView M, DLevelView LC, DMFView MC, int comp, int cshift, int ncomp, int ngf, int* nbad) {
+  const int b = blockIdx.y, r = 2;
+  const DBox B = L.boxes[b];
+  int clo[3], cn[3];
+  for (int d = 0; d < 3; ++d) {
+    clo[d] = coarsen_idx(B.lo[d] - ngf, r);
+    cn[d] = coarsen_idx(B.hi[d] + ngf, r) - clo[d] + 1;
+  }
+  const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (t >= (long long)cn[0] * cn[1] * cn[2]) return;
+  const unsigned u = (unsigned)t, rr = u / (unsigned)cn[0];
+  const int qc[3] = {clo[0] + (int)(u - rr * (unsigned)cn[0]), clo[1] + (int)(rr % (unsigned)cn[1]), clo[2] + (int)(rr / (unsigned)cn[1])};
+  bool interior = true;
+  for (int d = 0; d < 3; ++d) interior = interior && (r * qc[d] >= B.lo[d] && r * qc[d] + r - 1 <= B.hi[d]);
+  if (interior) return;
+  unsigned mask = 0;  // children that are coarse-fine ghost cells of this FAB
+  for (int c8 = 0; c8 < 8; ++c8) {
+    const int q[3] = {r * qc[0] + (c8 & 1), r * qc[1] + ((c8 >> 1) & 1), r * qc[2] + (c8 >> 2)};
+    bool in = true, valid = true;
+    for (int d = 0; d < 3; ++d) {
+      in = in && q[d] >= B.lo[d] - ngf && q[d] <= B.hi[d] + ngf;
+      valid = valid && q[d] >= B.lo[d] && q[d] <= B.hi[d];
+    }
+    if (in && !valid && classify(L, q[0], q[1], q[2]) == 1) mask |= 1u << c8;
+  }
+  if (!mask) return;
+  double* f = M.data + M.off[b];
+  for (int c = comp; c < comp + ncomp; ++c) {
+    bool ok = true;
+    const double u0 = crse_val(LC, MC, c + cshift, qc[0], qc[1], qc[2], ok);
+    auto cu = [&](int dx, int dy, int dz) -> double {
+      int p[3] = {qc[0] + dx, qc[1] + dy, qc[2] + dz};
+      for (int d = 0; d < 3; ++d)
+        if (!LC.is_per[d]) { p[d] = max(p[d], LC.domlo[d]); p[d] = min(p[d], LC.domhi[d]); }
+      return crse_val(LC, MC, c + cshift, p[0], p[1], p[2], ok);
+    };
+    double sl[3];
+    for (int d = 0; d < 3; ++d) {
+      const double um = cu(-(d == 0), -(d == 1), -(d == 2)), up = cu(d == 0, d == 1, d == 2);
+      const double dc = 0.5 * (up - um);
+      const double df = 2.0 * (up - u0), db = 2.0 * (u0 - um);
+      double sx = (df * db >= 0.0) ? fmin(fabs(df), fabs(db)) : 0.0;
+      sx = copysign(1.0, dc) * fmin(sx, fabs(dc));
+      sl[d] = sx;
+    }
+    double alpha = 1.0;
+    if (sl[0] != 0.0 || sl[1] != 0.0 || sl[2] != 0.0) {
+      const double dumax = fabs(sl[0]) * (double)(r - 1) / (double)(2 * r) + fabs(sl[1]) * (double)(r - 1) / (double)(2 * r) +
+                           fabs(sl[2]) * (double)(r - 1) / (double)(2 * r);
+      double umax = u0, umin = u0;
+      for (int dz = -1; dz <= 1; ++dz)
+        for (int dy = -1; dy <= 1; ++dy)
+          for (int dx = -1; dx <= 1; ++dx) {
+            const double v = cu(dx, dy, dz);
+            umin = v < umin ? v : umin;
+            umax = v > umax ? v : umax;
+          }
+      if (dumax * alpha > (umax - u0)) alpha = (umax - u0) / dumax;
+      if (dumax * alpha > (u0 - umin)) alpha = (u0 - umin) / dumax;
+    }
+    if (!ok) atomicAdd(nbad, __popc(mask));
+    for (int c8 = 0; c8 < 8; ++c8) {
+      if (!((mask >> c8) & 1u)) continue;
+      const int q[3] = {r * qc[0] + (c8 & 1), r * qc[1] + ((c8 >> 1) & 1), r * qc[2] + (c8 >> 2)};
+      double acc = u0;
+      for (int d = 0; d < 3; ++d) {
+        const double xoff = ((double)(q[d] - qc[d] * r) + 0.5) / (double)r - 0.5;
+        acc += xoff * (sl[d] * alpha);
+      }
+      f[fab_index(B, M.ng, M.ncomp, c, q[0], q[1], q[2])] = acc;
+    }
+  }
+}
+
 extern "C" int pa_fillpatch_two_levels(pa_ctx* ctx, pa_mf* fine, const pa_mf* crse, int comp, int ncomp, int ng, int ratio, int interp_type) {
   PaBind bind_(ctx);
   if (!ctx || !fine || !crse) return pa_fail(ctx, "pa_fillpatch_two_levels: null argument");
@@ -695,6 +774,19 @@ extern "C" int pa_fillpatch_two_levels(pa_ctx* ctx, pa_mf* fine, const pa_mf* cr
   int ccomp = comp;
   if (pa_coarse_source(ctx, fine->lev, crse, comp, ncomp, 1, ng, 1, &crse, &ccomp)) return 1;
   if (fine->lev->boxes.empty() || !crse) return 0;
+  static const int parent_env = [] { const char* e = getenv("PA_FILLPATCH_PARENT"); return e ? atoi(e) : 1; }();  // 0: thread per ghost cell (A/B)
+  if (interp_type == 1 && parent_env) {
+    long long mp = 0;
+    for (const DBox& B : fine->lev->boxes) {
+      long long n = 1;
+      for (int d = 0; d < 3; ++d) n *= coarsen_idx(B.hi[d] + ng, 2) - coarsen_idx(B.lo[d] - ng, 2) + 1;
+      mp = std::max(mp, n);
+    }
+    hipLaunchKernelGGL(k_fillpatch2p, dim3((unsigned)((mp + 255) / 256), (unsigned)fine->lev->boxes.size()), dim3(256), 0, ctx->stream, fine->lev->view, fine->view,
+                       crse->lev->view, crse->view, comp, ccomp - comp, ncomp, ng, ctx->d_flags);
+    PA_HIP(hipGetLastError());
+    return 0;
+  }
   dim3 grid((unsigned)((max_shell2(fine->lev, ng) + 255) / 256), (unsigned)fine->lev->boxes.size());
   hipLaunchKernelGGL(k_fillpatch2, grid, dim3(256), 0, ctx->stream, fine->lev->view, fine->view, crse->lev->view, crse->view, comp, ccomp - comp, ncomp, ng, ratio,
                      interp_type, ctx->d_flags);
