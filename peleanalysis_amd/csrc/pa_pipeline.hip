@@ -48,7 +48,14 @@ extern "C" int pa_grad_run(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp,
   PA_TRY(check_levels(ctx, nlev, state, "pa_grad_run"));
   PA_TRY(check_levels(ctx, nlev, out, "pa_grad_run"));
   // grad.cpp:169 FillBoundary on every level, then MLMG getFluxes level by level (applyBC + flux)
-  for (int l = 0; l < nlev; ++l) PA_TRY(pa_fill_boundary(ctx, state[l], comp, 1, 1));
+  if (state[0]->lev->nranks > 1) {
+    for (int l = 0; l < nlev; ++l) PA_TRY(pa_fill_boundary(ctx, state[l], comp, 1, 1));  // + the cross-rank half, level by level
+  } else {
+    for (int l = 0; l < nlev; ++l)
+      if (state[l]->ng < 1 || comp < 0 || comp >= state[l]->ncomp) return pa_fail(ctx, "pa_grad_run: state needs >= 1 ghost layer and the component");
+    ProfScope prof(ctx, PA_TAG_FILL);
+    PA_TRY(pa_fill_boundary_local_batch(ctx, nlev, state, comp, 1, 1));  // every level in one launch
+  }
   for (int l = 0; l < nlev; ++l) {
     PA_TRY(pa_apply_bc(ctx, state[l], comp, l > 0 ? state[l - 1] : nullptr, comp, bc, 2, -1));
     PA_TRY(pa_grad_level(ctx, state[l], comp, out[l], ocomp));
