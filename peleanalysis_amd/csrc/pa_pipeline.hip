@@ -233,8 +233,14 @@ static int fused_passes_dist(pa_ctx* ctx, int nlev, pa_mf* const* state, int com
     }
     {
       StreamSwap sw(ctx, C);
-      ProfScope prof(ctx, PA_TAG_XCHG);
-      PA_TRY(pa_xexchange(ctx, (int)jobs.size(), jobs.data()));
+      {
+        ProfScope prof(ctx, PA_TAG_XCHG);
+        PA_TRY(pa_xexchange(ctx, (int)jobs.size(), jobs.data()));
+      }
+      // the faces' half of the ghost preparation (patch gather + k_prep_faces) reads valid cells and the coarse data that
+      // just arrived, and writes only ghost cells behind special faces: it stays on the side stream, next to the local
+      // FillBoundary (as in the single-GPU pass; rank 0 of 8: k_prep_faces 45 us against FillBoundary 39 us)
+      if (xov) PA_TRY(pa_gradcurv_prep_levels(ctx, nlev, state, comp, crse.data(), 0, bc, pmin, pmax, 1));
     }
     if (xov) PA_HIP(hipEventRecord(ctx->sync_evs[1], C));
     {
@@ -242,7 +248,7 @@ static int fused_passes_dist(pa_ctx* ctx, int nlev, pa_mf* const* state, int com
       PA_TRY(pa_fill_boundary_local_batch(ctx, nlev, state, comp, 1, 2));
     }
     if (xov) PA_HIP(hipStreamWaitEvent(A, ctx->sync_evs[1], 0));
-    PA_TRY(pa_gradcurv_prep_levels(ctx, nlev, state, comp, crse.data(), 0, bc, pmin, pmax));
+    PA_TRY(pa_gradcurv_prep_levels(ctx, nlev, state, comp, crse.data(), 0, bc, pmin, pmax, xov ? 2 : 3));
     // PA_DIST_SWEEP_BATCH=1 (default): the sweeps of all levels in one launch (a rank's share of a level is 1-2 rounds of
     // workgroups: per-level launches end in idle tails), then ONE grouped exchange of the coarse normals of all levels;
     // 0: level by level, each level's exchange on the side stream next to the following sweep
