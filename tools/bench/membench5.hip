@@ -154,5 +154,12 @@ int main(int argc, char** argv) {
         if (run(c, nit)) return 1;
       }
   }
+  if (!strcmp(set, "fronts3")) {  // three cells for the wide counter pass (tools/prof.sh membench)
+    for (int F : {1, 64, 4096}) {
+      Cfg c{8, 1, 8, 1, 3, 2048, 0};
+      c.fronts = F;
+      if (run(c, nit)) return 1;
+    }
+  }
   return 0;
 }
