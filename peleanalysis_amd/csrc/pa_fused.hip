@@ -905,6 +905,16 @@ static int pa_slow_list(pa_ctx* ctx, int** count, int2** items, int* cap) {
   return 0;
 }
 
+// diagnostic (tests): how many cells the clip-aware fix-up of the LAST pass handed to its general path; -1: never used
+extern "C" int pa_last_slow_cells(pa_ctx* ctx) {
+  PaBind bind_(ctx);
+  if (!ctx) return -1;
+  if (!ctx->d_slow) return -1;
+  int n = -1;
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipMemcpy(&n, ctx->d_slow, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return n;
+}
+
 // can the exact-normal pipeline run on this level (same answer on every rank of a sharded level)?
 bool pa_fused2_level_ok(const pa_level* L) {
   static const int env = [] { const char* e = getenv("PA_FUSED2"); return e ? atoi(e) : 1; }();

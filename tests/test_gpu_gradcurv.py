@@ -133,6 +133,7 @@ def test_gradcurv_exact_normal_pipeline(ctx, oracle, per, sym, threshold):
     dls, dst = _dev(ctx, H, states)
     work = [capi.DevMF(ctx, dl, 1, 2) for dl in dls]
     dout = [capi.DevMF(ctx, dl, 8, 0) for dl in dls]
+    slow_seen = []
     for rep in range(2):  # the second pass reuses the level's compact arrays
         # with a threshold the sweep clips N and K itself and the one-layer fix-up recomputes the clipped normals it needs
         # (curvature.cpp:549-570; the coarse normals under coarse-fine faces stay clipped: quirk Q2)
@@ -143,6 +144,9 @@ def test_gradcurv_exact_normal_pipeline(ctx, oracle, per, sym, threshold):
         assert kn.endswith("CG=1>") or kn.startswith("k_gradcurv_march3_levels<"), kn  # the exact-normal pipeline did run (level by level or all levels in one launch)
         if threshold is not None:
             assert "CLIP" in kn
+            nslow = ctx.lib.pa_last_slow_cells(ctx.h)
+            assert nslow >= 0
+            slow_seen.append(nslow)
             nclip = sum(int((np.abs(oc[l].valid_concat(2)) == 0).sum()) for l in range(H.nlev))
             ncell = sum(lv.ncells for lv in H.levels)
             assert 0.05 * ncell < nclip < 0.98 * ncell  # clipped and unclipped cells both present
@@ -150,6 +154,30 @@ def test_gradcurv_exact_normal_pipeline(ctx, oracle, per, sym, threshold):
             got = dout[l].download()
             assert_valid_bits_equal(got, og[l], [(c, c) for c in range(4)], f"exact grad level {l}")
             assert_valid_bits_equal(got, oc[l], [(4, 2), (5, 3), (6, 4), (7, 1)], f"exact curv level {l}")
+
+
+def test_clip_fixup_general_path_is_exercised(ctx, oracle):
+    """the clip-aware fix-up's hand-over list (pa_fused.hip: SlowList): a threshold whose iso-surfaces cross the coarse-fine
+    faces puts layer-1 cells next to clipped neighbours, which must go through the general path -- and still match the oracle"""
+    from peleanalysis_amd.hierarchy import nested_hierarchy, field_flame
+    H = nested_hierarchy(96, 3, 48, is_per=(1, 1, 0))
+    states = make_states(H, 1, 2, field_flame, seed=31)
+    bc = capi.bc_from_flags((1, 1, 0), (0, 0, 0))
+    dls, dst = _dev(ctx, H, states)
+    work = [capi.DevMF(ctx, dl, 1, 2) for dl in dls]
+    dout = [capi.DevMF(ctx, dl, 8, 0) for dl in dls]
+    total = 0
+    for thr in (0.02, 0.1, 0.25, 0.4):
+        oc = [MultiFab(lv, 5, 0) for lv in H.levels]
+        oracle.curvature_pipeline(H.levels, [s.copy() for s in states], 0, bc, oc, 0, MultiFab, threshold=thr)
+        capi.gradcurv_run(ctx, dst, 0, bc, capi.curv_params(threshold=thr, fused=True), work, dout, 0)
+        ctx.sync()
+        n = ctx.lib.pa_last_slow_cells(ctx.h)
+        assert n >= 0
+        total += n
+        for l in range(H.nlev):
+            assert_valid_bits_equal(dout[l].download(), oc[l], [(4, 2), (5, 3), (6, 4), (7, 1)], f"thr {thr} level {l}")
+    assert total > 0, "no cell ever took the general path: the case does not exercise it"
 
 
 @pytest.mark.parametrize("per", [(0, 0, 0), (1, 0, 1)])
