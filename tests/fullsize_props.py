@@ -14,6 +14,8 @@ would take minutes: size-independent properties of the path instead, every compa
      reproduced exactly (the box weights are dyadic and sum to one without rounding);
   6. marching cubes on a 512^3 level (64 FABs of 130^3): the level-batched pass reproduces the per-FAB entry points
      bit for bit on FABs that hold surface, per-FAB counts add up, connectivity stays inside each FAB's vertex range.
+  9. 32^3 boxes (512 per level, base 256^3): the narrow exact-normal sweep + one-layer fix-up == the pass-by-pass kernels ==
+     the first fused pipeline, with and without the threshold clip.
 """
 import os
 import sys
@@ -340,6 +342,56 @@ def main():
                 continue
             g3 = [gts[l][off4[b] + c * cs4[b]: off4[b] + c * cs4[b] + 64 ** 3].view(64, 64, 64)[k0 - zlo: k1 - zlo + 1] for c in range(3)]
             assert float(g3[0].abs().max()) < 1e-9 and float(g3[1].abs().max()) < 1e-9 and float((g3[2] - 3.0).abs().max()) < 1e-9, (l, b)
+    # ---- 9. small boxes (AMReX's default max_grid_size = 32): the headline hierarchy's shape at base 256^3 in 32^3 boxes
+    # (512 boxes per level) -- the narrow sweep's exact-normal variant + one-layer fix-up against the pass-by-pass kernels
+    # and against the first pipeline (PA_NARROW_CG is read once per process, so the first pipeline is reached through the
+    # threshold switch PA_FUSED2_CLIP=0), with and without the threshold clip, bit for bit
+    del gts, gos
+    torch.cuda.empty_cache()
+    Hs = nested_hierarchy(256, 3, 32, is_per=(1, 1, 0))
+    dls_s = [capi.DevLevel(ctx, lv_) for lv_ in Hs.levels]
+
+    def mfs_s(ncomp, ng):
+        ts, ms = [], []
+        for lv_, dl_ in zip(Hs.levels, dls_s):
+            _, _, tot_ = mf_layout(lv_.boxes, ncomp, ng)
+            t = torch.zeros(tot_, dtype=torch.float64, device=dev)
+            ts.append(t); ms.append(capi.DevMF(ctx, dl_, ncomp, ng, t.data_ptr()))
+        return ts, ms
+
+    tin_s, st_s = mfs_s(1, 2)
+    for li, lv_ in enumerate(Hs.levels):
+        off_, cs_, _ = mf_layout(lv_.boxes, 1, 2)
+        bench.fill_level_on_device(torch, lv_, tin_s[li], 1, 2, off_, cs_, dev, 777 + li)
+    prist_s = [t.clone() for t in tin_s]
+    _tw, wk_s = mfs_s(1, 2)
+
+    def run_s(fused, thr):
+        for t, p_ in zip(tin_s, prist_s):
+            t.copy_(p_)
+        to_, o_ = mfs_s(8, 0)
+        torch.cuda.synchronize()
+        capi.gradcurv_run(ctx, st_s, 0, bc, capi.curv_params(prog_min=300.0, prog_max=2000.0, threshold=thr, fused=fused), wk_s, o_, 0)
+        ctx.sync()
+        assert ctx.bc_errors() == 0
+        return to_, o_, ctx.lib.pa_sweep_kernel_name(ctx.h).decode()
+
+    for thr in (None, 0.05):
+        a, _ka, kn = run_s(True, thr)
+        assert "march3n" in kn and "CG=1" in kn, kn  # the narrow exact-normal sweep did run
+        b_, _kb, _ = run_s(False, thr)
+        for l in range(3):
+            assert same_bits(a[l], b_[l]), f"32^3 boxes, level {l}, threshold {thr}: narrow exact-normal pipeline differs from the pass-by-pass kernels"
+        del b_, _kb
+        if thr is not None:
+            os.environ["PA_FUSED2_CLIP"] = "0"
+            c_, _kc, kn1 = run_s(True, thr)
+            os.environ.pop("PA_FUSED2_CLIP")
+            assert "CG=0" in kn1, kn1
+            for l in range(3):
+                assert same_bits(a[l], c_[l]), f"32^3 boxes, level {l}: the two fused pipelines differ under the threshold clip"
+            del c_, _kc
+        del a, _ka
     print("fullsize properties OK")
 
 
