@@ -184,3 +184,187 @@ __global__ __launch_bounds__(64 * (TY + 3)) void k_grad_march(BP bp, GradMarchAr
   }
 #undef PA_GRUN3
 }
+
+// Boxes at most 32 cells wide (AMReX's default max_grid_size in 3-D): the same sweep with TWO rows of 32 columns per
+// wavefront, so that a wave's loads and stores stay 512 contiguous bytes (two adjacent 256-byte rows of a 32-wide output
+// FAB) -- as pa_fused_march3n.h does for the fused sweep.  Waves 0..NRW-1: output rows 2w, 2w+1 (lanes 0-31 / 32-63); wave
+// NRW: the two halo rows; wave NRW+1: the edge columns.  Rows past a partial tile repeat the last valid row (same LDS slot,
+// same addresses, same values).  Same arithmetic as k_grad_march: bit-identical.
+template <int NRW>
+struct GradLdsN {
+  double p[3][2 * NRW + 2][34];  // x index 0 = left edge column, 1..32 = columns, llast+2 = right edge column
+};
+
+template <typename BP, int NRW>
+__global__ __launch_bounds__(64 * (NRW + 2)) void k_grad_marchn(BP bp, GradMarchArgs A) {
+  FabView P, O;
+  DBox V;
+  double dxinv[3];
+  constexpr int MTY2 = 2 * NRW, ROWS = MTY2 + 2;
+  static_assert(2 * ROWS <= 64, "the edge wavefront serves two columns of every row");
+  unsigned bid = blockIdx.x;
+  const unsigned per8 = 8u * (unsigned)A.tiles_max, grp = bid / per8, rem = bid % per8;
+  const int box = (int)(grp * 8u + (rem & 7u));
+  bid = rem >> 3;
+  if (box >= A.nboxes) return;
+  if (!bp.get(box, P, O, V, dxinv)) return;
+  const int comp = A.comp, kseg = A.kseg;
+  const int nx = V.hi[0] - V.lo[0] + 1, ny = V.hi[1] - V.lo[1] + 1, nz = V.hi[2] - V.lo[2] + 1;
+  const int tx = (nx + 31) / 32, ty = (ny + MTY2 - 1) / MTY2, tz = (nz + kseg - 1) / kseg;
+  if (bid >= (unsigned)tx * ty * tz) return;
+  const int bx = bid % tx, by = (bid / tx) % ty, bz = bid / (tx * ty);
+  const int i0 = V.lo[0] + bx * 32, j0 = V.lo[1] + by * MTY2;
+  const int k0 = V.lo[2] + bz * kseg, k1 = min(k0 + kseg - 1, V.hi[2]);
+  const int iR = min(i0 + 32, V.hi[0] + 1);
+  const int llast = iR - 1 - i0;
+  const int nrows = min(MTY2, V.hi[1] - j0 + 1);
+  const int rtop = nrows + 1;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int rsub = lane >> 5, col = lane & 31;
+  const int kf = k1 + 1;
+
+  __shared__ GradLdsN<NRW> S;
+  const long long pps = (long long)P.nx * P.ny * 8;
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+#define PA_GRUN3(step)                                                                                                 \
+  {                                                                                                                    \
+    int p = k0;                                                                                                        \
+    _Pragma("unroll 1") for (; p + 2 <= k1; p += 3) {                                                                  \
+      step(I0{}, p);                                                                                                   \
+      step(I1{}, p + 1);                                                                                               \
+      step(I2{}, p + 2);                                                                                               \
+    }                                                                                                                  \
+    if (p <= k1) {                                                                                                     \
+      step(I0{}, p);                                                                                                   \
+      if (p + 1 <= k1) step(I1{}, p + 1);                                                                              \
+    }                                                                                                                  \
+  }
+
+  if (w < NRW) {
+    // ------------------------------------------------------------------------- output rows
+    const int rr = min(1 + 2 * w + rsub, nrows);
+    const int le = min(col, llast);
+    const int xs = le + 1;
+    unsigned lo8 = (unsigned)((rr - 1) * P.nx + le) * 8u;
+    unsigned so8 = (unsigned)((rr - 1) * O.nx + le) * 8u;
+    const char* gp = (const char*)(P.p + P.idx(i0, j0, k0 - 1, comp));  // wave-uniform: the tile's first row
+    const double pm = PA_LDG(gp, lo8);
+    double pc = PA_LDG(gp + pps, lo8);
+    double f[3];
+    f[0] = PA_LDG(gp + 2 * pps, lo8);
+    gp += 2 * pps;
+    gp += (k0 + 2 <= kf) ? pps : 0;
+    f[1] = PA_LDG(gp, lo8);
+    gp += (k0 + 3 <= kf) ? pps : 0;
+    f[2] = PA_LDG(gp, lo8);
+    asm volatile("" ::"v"(f[0]), "v"(f[1]), "v"(f[2]));  // enter the loop with nothing in flight (pa_fused_march3.h)
+    S.p[0][rr][xs] = pc;
+    __syncthreads();
+    double fz = zflux(dxinv[2], pm, pc);
+    char* ob = (char*)(O.p + O.idx(i0, j0, k0, A.ocomp));
+    const long long ops = (long long)O.nx * O.ny * 8, osc = O.sc * 8;
+    double o0 = 0, o1 = 0, o2 = 0, o3 = 0;
+    auto step = [&](auto spc, int p) __attribute__((always_inline)) {
+      constexpr int SP = decltype(spc)::value, SP1 = (SP + 1) % 3;
+      double x;
+      PA_TAKE(x, f[SP]);
+      PA_OPAQUE(so8);
+      __builtin_amdgcn_sched_barrier(0);
+      gp += (p + 4 <= kf) ? pps : 0;
+      PA_STG(ob, so8, o0); PA_STG(ob + osc, so8, o1); PA_STG(ob + 2 * osc, so8, o2); PA_STG(ob + 3 * osc, so8, o3);
+      __builtin_amdgcn_sched_barrier(0);
+      const double pl = S.p[SP][rr][xs - 1], pr = S.p[SP][rr][xs + 1];
+      const double ps = S.p[SP][rr - 1][xs], pn = S.p[SP][rr + 1][xs];
+      S.p[SP1][rr][xs] = x;
+      const double gx = cdiff(dxinv[0], pl, pc, pr);
+      const double gy = cdiff(dxinv[1], ps, pc, pn);
+      const double fzh = zflux(dxinv[2], pc, x);
+      const double gz = favg(fz, fzh);
+      const double gm = sqrt(gx * gx + gy * gy + gz * gz);
+      __syncthreads();
+      PA_OPAQUE(lo8);
+      f[SP] = PA_LDG(gp, lo8);
+      ob += (p >= k0 + 1) ? ops : 0;
+      o0 = gx; o1 = gy; o2 = gz; o3 = gm;
+      fz = fzh;
+      pc = x;
+    };
+    PA_GRUN3(step)
+    PA_STG(ob, so8, o0);
+    PA_STG(ob + osc, so8, o1);
+    PA_STG(ob + 2 * osc, so8, o2);
+    PA_STG(ob + 3 * osc, so8, o3);
+    return;
+  }
+
+  if (w == NRW) {
+    // ------------------------------------------------------------------------- the two halo rows (neighbours only)
+    const int rr = rsub ? rtop : 0;
+    const int j = rsub ? j0 + nrows : j0 - 1;
+    const int le = min(col, llast);
+    const int xs = le + 1;
+    const char* gp = (const char*)(P.p + P.idx(i0, P.lo[1], k0, comp));  // wave-uniform: first row of the FAB, plane k0
+    unsigned lo8 = (unsigned)((j - P.lo[1]) * P.nx + le) * 8u;
+    const double pc = PA_LDG(gp, lo8);
+    double f[3];
+    f[0] = PA_LDG(gp + pps, lo8);
+    gp += pps;
+    gp += (k0 + 2 <= kf) ? pps : 0;
+    f[1] = PA_LDG(gp, lo8);
+    gp += (k0 + 3 <= kf) ? pps : 0;
+    f[2] = PA_LDG(gp, lo8);
+    S.p[0][rr][xs] = pc;
+    __syncthreads();
+    auto step = [&](auto spc, int p) __attribute__((always_inline)) {
+      constexpr int SP = decltype(spc)::value, SP1 = (SP + 1) % 3;
+      double x;
+      PA_TAKE(x, f[SP]);
+      __builtin_amdgcn_sched_barrier(0);
+      gp += (p + 4 <= kf) ? pps : 0;
+      S.p[SP1][rr][xs] = x;
+      __syncthreads();
+      PA_OPAQUE(lo8);
+      f[SP] = PA_LDG(gp, lo8);
+    };
+    PA_GRUN3(step)
+    return;
+  }
+
+  // ----------------------------------------------------------------------------- edge wave
+  {
+    const int l2 = lane % (2 * ROWS);
+    const int rr = min(l2 >> 1, rtop);
+    const int side = l2 & 1;
+    const int j = j0 + rr - 1;
+    const int i = side ? iR : i0 - 1;
+    const int xs = side ? llast + 2 : 0;
+    const char* gp = (const char*)(P.p + P.idx(P.lo[0], P.lo[1], k0, comp));
+    unsigned og = (unsigned)((j - P.lo[1]) * P.nx + (i - P.lo[0])) * 8u;
+    const double pc = PA_LDG(gp, og);
+    double f[3];
+    f[0] = PA_LDG(gp + pps, og);
+    gp += pps;
+    gp += (k0 + 2 <= kf) ? pps : 0;
+    f[1] = PA_LDG(gp, og);
+    gp += (k0 + 3 <= kf) ? pps : 0;
+    f[2] = PA_LDG(gp, og);
+    S.p[0][rr][xs] = pc;
+    __syncthreads();
+    auto step = [&](auto spc, int p) __attribute__((always_inline)) {
+      constexpr int SP = decltype(spc)::value, SP1 = (SP + 1) % 3;
+      double x;
+      PA_TAKE(x, f[SP]);
+      __builtin_amdgcn_sched_barrier(0);
+      gp += (p + 4 <= kf) ? pps : 0;
+      S.p[SP1][rr][xs] = x;
+      __syncthreads();
+      PA_OPAQUE(og);
+      f[SP] = PA_LDG(gp, og);
+    };
+    PA_GRUN3(step)
+  }
+#undef PA_GRUN3
+}
+

@@ -70,6 +70,15 @@ static void grad_launch(hipStream_t st, const BP& bp, int nx, int ny, int nz, un
     }
     return;
   }
+  static const int narrow_env = [] { const char* e = getenv("PA_GRAD_NARROW"); return e ? atoi(e) : 1; }();  // 0: the tiled k_grad (A/B)
+  if (march_env && narrow_env) {  // boxes at most 32 cells wide: two rows per wavefront (k_grad_marchn)
+    constexpr int NRW = 8;
+    GradMarchArgs A{comp, ocomp, std::max(1, std::min(kseg_env, nz)), (int)nboxes, 0};
+    A.tiles_max = ((nx + 31) / 32) * ((ny + 2 * NRW - 1) / (2 * NRW)) * ((nz + A.kseg - 1) / A.kseg);
+    const dim3 g((unsigned)A.tiles_max * 8u * ((nboxes + 7u) / 8u));
+    hipLaunchKernelGGL((k_grad_marchn<BP, NRW>), g, dim3(64 * (NRW + 2)), 0, st, bp, A);
+    return;
+  }
   const int tz = std::max(1, std::min(tz_env, nz));
   auto grid = [&](int TY) { return dim3((unsigned)(((nx + 63) / 64) * ((ny + TY - 1) / TY) * ((nz + tz - 1) / tz)), nboxes); };
   switch (ny >= 16 ? ty_env : 4) {
