@@ -122,21 +122,28 @@ struct FabBP4 {
 #define PA_TY 4
 #define PA_TZ 16
 
+// Boxes at most 32 cells wide (AMReX's default max_grid_size): 32 (x) x 8 (y) tiles, two rows per wavefront, so that no
+// lane idles and a wave still touches 512 contiguous bytes of a 32-wide FAB row pair (the pass-by-pass kernels ran such
+// boxes with half of every wavefront masked off).  The rule is per BOX; the launch grid is sized for the larger count.
 __device__ __forceinline__ bool tile_cell(const DBox& V, int& i, int& j, int& k0, int& k1) {
   const int nx = V.hi[0] - V.lo[0] + 1, ny = V.hi[1] - V.lo[1] + 1, nz = V.hi[2] - V.lo[2] + 1;
-  const int tx = (nx + PA_TX - 1) / PA_TX, ty = (ny + PA_TY - 1) / PA_TY, tz = (nz + PA_TZ - 1) / PA_TZ;
+  const bool narrow = nx <= 32;
+  const int TX = narrow ? 32 : PA_TX, TY = narrow ? 8 : PA_TY;
+  const int tx = (nx + TX - 1) / TX, ty = (ny + TY - 1) / TY, tz = (nz + PA_TZ - 1) / PA_TZ;
   const unsigned bid = blockIdx.x;
   if (bid >= (unsigned)tx * ty * tz) return false;
   const int bx = bid % tx, by = (bid / tx) % ty, bz = bid / (tx * ty);
-  i = V.lo[0] + bx * PA_TX + (threadIdx.x & 63);
-  j = V.lo[1] + by * PA_TY + (threadIdx.x >> 6);
+  i = V.lo[0] + bx * TX + (narrow ? (threadIdx.x & 31) : (threadIdx.x & 63));
+  j = V.lo[1] + by * TY + (narrow ? (threadIdx.x >> 5) : (threadIdx.x >> 6));
   k0 = V.lo[2] + bz * PA_TZ;
   k1 = min(k0 + PA_TZ - 1, V.hi[2]);
   return i <= V.hi[0] && j <= V.hi[1];
 }
 
 inline dim3 tile_grid_dims(int nx, int ny, int nz, unsigned nboxes) {
-  const unsigned tx = (nx + PA_TX - 1) / PA_TX, ty = (ny + PA_TY - 1) / PA_TY, tz = (nz + PA_TZ - 1) / PA_TZ;
+  // the level's widest box decides: a wide tiling (64 x 4) never has fewer tiles than the narrow one (32 x 8) of a narrower box
+  const bool narrow = nx <= 32;
+  const unsigned tx = narrow ? 1u : (nx + PA_TX - 1) / PA_TX, ty = narrow ? (ny + 7) / 8 : (ny + PA_TY - 1) / PA_TY, tz = (nz + PA_TZ - 1) / PA_TZ;
   return dim3(tx * ty * tz, nboxes);
 }
 inline dim3 tile_grid(const pa_level* L, int grow = 0) {
