@@ -396,6 +396,15 @@ int pa_gradcurv_run(pa_ctx*, int nlev, pa_mf* const* state, int comp, const int3
 int pa_gradcurv_run_comps(pa_ctx*, int nlev, pa_mf* const* state, int comp0, int ncomps, const int32_t bc[3],
                           const pa_curv_params*, pa_mf* const* work, pa_mf* const* out, int ocomp,
                           int (*done)(void* user, int comp), void* user);
+/* The same in batches of nbatch components (1 .. 16): out[lev] holds nbatch SLOTS of 8 components from ocomp, component
+ * comp0 + i of a batch goes to slot i % nbatch, and done(user, comp, ocomp_of_its_slot) is called for every component of a
+ * batch once the batch is complete (stream-ordered, as above).  The boundary kernels of the exact-normal pipeline -- resolved
+ * ghost values, coarse-patch gathers, curvature fix-up, and on a sharded hierarchy the exchange of the coarse normals --
+ * then run once per BATCH instead of once per component; the sweeps stay component by component.  nbatch = 1 is
+ * pa_gradcurv_run_comps.  (curvature.cpp:126-330 applied to each variable of a plotfile in turn.) */
+int pa_gradcurv_run_comps2(pa_ctx*, int nlev, pa_mf* const* state, int comp0, int ncomps, const int32_t bc[3],
+                           const pa_curv_params*, pa_mf* const* work, pa_mf* const* out, int ocomp, int nbatch,
+                           int (*done)(void* user, int comp, int ocomp), void* user);
 
 #ifdef __cplusplus
 }

@@ -44,6 +44,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int32
 
 
 DONE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)
+DONE2_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int)
 
 
 class PaComm(C.Structure):
@@ -164,6 +165,8 @@ def load_library() -> C.CDLL:
                                       C.c_int]),
         "pa_gradcurv_run_comps": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.c_int, C.c_int, pi32, C.POINTER(PaCurvParams), C.POINTER(vp), C.POINTER(vp),
                                             C.c_int, DONE_FN, vp]),
+        "pa_gradcurv_run_comps2": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.c_int, C.c_int, pi32, C.POINTER(PaCurvParams), C.POINTER(vp), C.POINTER(vp),
+                                             C.c_int, C.c_int, DONE2_FN, vp]),
     }
     missing = []
     for name, (res, args) in sig.items():
@@ -418,6 +421,26 @@ def gradcurv_run_comps(ctx, states, comp0, ncomps, bc, params: PaCurvParams, wor
     cb = DONE_FN(_cb) if done is not None else C.cast(None, DONE_FN)
     rc = ctx.lib.pa_gradcurv_run_comps(ctx.h, len(states), _handles(states), int(comp0), int(ncomps), _i3(bc), C.byref(params), _handles(works),
                                        _handles(outs), int(ocomp), cb, None)
+    if err:
+        raise err[0]
+    ctx.check(rc)
+
+
+def gradcurv_run_comps2(ctx, states, comp0, ncomps, bc, params: PaCurvParams, works, outs, ocomp, nbatch, done=None):
+    """pa_gradcurv_run_comps2: batches of nbatch components, outs hold nbatch slots of 8 components from ocomp;
+    done(comp, ocomp_of_its_slot) is called for every component of a batch once the batch is complete (sync before reading)"""
+    err = []
+
+    def _cb(user, comp, oc):
+        try:
+            done(comp, oc)
+            return 0
+        except Exception as e:  # never let an exception cross the C boundary
+            err.append(e)
+            return 1
+    cb = DONE2_FN(_cb) if done is not None else C.cast(None, DONE2_FN)
+    rc = ctx.lib.pa_gradcurv_run_comps2(ctx.h, len(states), _handles(states), int(comp0), int(ncomps), _i3(bc), C.byref(params), _handles(works),
+                                        _handles(outs), int(ocomp), int(nbatch), cb, None)
     if err:
         raise err[0]
     ctx.check(rc)

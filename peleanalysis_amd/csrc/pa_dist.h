@@ -76,7 +76,9 @@ struct RepPlan {
 };
 RepPlan* pa_rep_plan(pa_ctx* ctx, const pa_level* L);
 
-struct XJob { XPlan* plan; const pa_mf* src; int scomp; pa_mf* dst; int dcomp; int ncomp; };
+// group > 0: the ncomp components are groups of `group` consecutive ones, group g starting at scomp + g * sgstride in src and at
+// dcomp + g * dgstride in dst (the normals of several component slots: 3 of every 8 output components)
+struct XJob { XPlan* plan; const pa_mf* src; int scomp; pa_mf* dst; int dcomp; int ncomp; int group = 0, sgstride = 0, dgstride = 0; };
 
 XPlan* pa_fb_plan(pa_ctx* ctx, const pa_level* L, int ng);
 CsPlan* pa_cs_plan(pa_ctx* ctx, const pa_level* F, const pa_level* C, int mode, int ng, int halo);

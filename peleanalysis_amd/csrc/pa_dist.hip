@@ -611,7 +611,7 @@ pa_mf* CsPlan::mf(pa_ctx* ctx, int ncomp, int slot) {
 // Thread t of block row r handles cell t of region r for all components.  Regions are thin (1-2 cells along one
 // direction); 32-bit index arithmetic.  One launch covers the region lists of several plans (LevBatch rows = regions).
 #define PA_XB 8
-struct XRegArgs { DLevelView L; DMFView M; int comp, ncomp; const int* regs; const long long* coff; double* buf; };
+struct XRegArgs { DLevelView L; DMFView M; int comp, ncomp; const int* regs; const long long* coff; double* buf; int group = 0, gstride = 0; };
 #define PA_YMAX 65535
 __global__ __launch_bounds__(256) void k_xregions(LevBatch<XRegArgs, PA_XB> Bt, int unpack, int y0) {
   unsigned ry;
@@ -632,14 +632,15 @@ __global__ __launch_bounds__(256) void k_xregions(LevBatch<XRegArgs, PA_XB> Bt, 
     const unsigned r = t / nx, i = t - r * nx, k = r / ny, j = r - k * ny;
     const long long idx = ((long long)(k + ok) * gny + (j + oj)) * gnx + (i + oi);
     for (int c = 0; c < ncomp; ++c) {
-      if (unpack) f[c * cs + idx] = q[(long long)c * n + t];
-      else q[(long long)c * n + t] = f[c * cs + idx];
+      const int fc = X.group ? (c / X.group) * X.gstride + c % X.group : c;  // component groups (XJob)
+      if (unpack) f[fc * cs + idx] = q[(long long)c * n + t];
+      else q[(long long)c * n + t] = f[fc * cs + idx];
     }
   }
 }
 
 // same-rank part of a coarse-source refill: region pairs of equal shape, coarse level -> coarse-source level
-struct XCopyArgs { DLevelView LS; DMFView MS; int scomp; DLevelView LD; DMFView MD; int dcomp, ncomp; const int* sregs; const int* dregs; };
+struct XCopyArgs { DLevelView LS; DMFView MS; int scomp; DLevelView LD; DMFView MD; int dcomp, ncomp; const int* sregs; const int* dregs; int group = 0, sgstride = 0, dgstride = 0; };
 __global__ __launch_bounds__(256) void k_xcopy(LevBatch<XCopyArgs, PA_XB> Bt, int y0) {
   unsigned ry;
   const XCopyArgs& X = Bt.a[Bt.find(blockIdx.y + (unsigned)y0, ry)];
@@ -649,9 +650,11 @@ __global__ __launch_bounds__(256) void k_xcopy(LevBatch<XCopyArgs, PA_XB> Bt, in
   const DBox BS = X.LS.boxes[R[0]], BD = X.LD.boxes[D[0]];
   for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
     const unsigned r = t / nx, i = t - r * nx, k = r / ny, j = r - k * ny;
-    for (int c = 0; c < X.ncomp; ++c)
-      X.MD.data[X.MD.off[D[0]] + fab_index(BD, X.MD.ng, X.MD.ncomp, X.dcomp + c, D[1] + (int)i, D[2] + (int)j, D[3] + (int)k)] =
-          X.MS.data[X.MS.off[R[0]] + fab_index(BS, X.MS.ng, X.MS.ncomp, X.scomp + c, R[1] + (int)i, R[2] + (int)j, R[3] + (int)k)];
+    for (int c = 0; c < X.ncomp; ++c) {
+      const int sc = X.group ? (c / X.group) * X.sgstride + c % X.group : c, dc = X.group ? (c / X.group) * X.dgstride + c % X.group : c;
+      X.MD.data[X.MD.off[D[0]] + fab_index(BD, X.MD.ng, X.MD.ncomp, X.dcomp + dc, D[1] + (int)i, D[2] + (int)j, D[3] + (int)k)] =
+          X.MS.data[X.MS.off[R[0]] + fab_index(BS, X.MS.ng, X.MS.ncomp, X.scomp + sc, R[1] + (int)i, R[2] + (int)j, R[3] + (int)k)];
+    }
   }
 }
 
@@ -678,7 +681,7 @@ static void launch_regions(pa_ctx* ctx, int njobs, const XJob* jobs, int unpack)
       const int nreg = (int)(S.regs7.size() / 7);
       if (!nreg) continue;
       const pa_mf* M = unpack ? J.dst : J.src;
-      Bt.a[Bt.n] = XRegArgs{M->lev->view, M->view, unpack ? J.dcomp : J.scomp, J.ncomp, S.d_regs, S.d_coff, unpack ? J.plan->rbuf : J.plan->sbuf};
+      Bt.a[Bt.n] = XRegArgs{M->lev->view, M->view, unpack ? J.dcomp : J.scomp, J.ncomp, S.d_regs, S.d_coff, unpack ? J.plan->rbuf : J.plan->sbuf, J.group, unpack ? J.dgstride : J.sgstride};
       Bt.ycum[Bt.n + 1] = Bt.ycum[Bt.n] + nreg;
       ++Bt.n;
       maxcells = std::max(maxcells, S.maxcells);
@@ -728,7 +731,7 @@ int pa_xexchange(pa_ctx* ctx, int njobs, const XJob* jobs) {
     for (int q = q0; q < njobs && q < q0 + PA_XB; ++q) {
       const XJob& J = jobs[q];
       if (!J.plan->nlocal) continue;
-      Bt.a[Bt.n] = XCopyArgs{J.src->lev->view, J.src->view, J.scomp, J.dst->lev->view, J.dst->view, J.dcomp, J.ncomp, J.plan->d_lsrc, J.plan->d_ldst};
+      Bt.a[Bt.n] = XCopyArgs{J.src->lev->view, J.src->view, J.scomp, J.dst->lev->view, J.dst->view, J.dcomp, J.ncomp, J.plan->d_lsrc, J.plan->d_ldst, J.group, J.sgstride, J.dgstride};
       Bt.ycum[Bt.n + 1] = Bt.ycum[Bt.n] + J.plan->nlocal;
       ++Bt.n;
       lmax = std::max(lmax, J.plan->lmax);

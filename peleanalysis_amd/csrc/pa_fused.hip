@@ -41,6 +41,7 @@ struct CgAcc {
   DBox B;
   int b, pcomp;
   double pmin, invd;
+  const double* cg;  // the component slot's set of compact arrays (L->cg + slot * stride)
   __device__ __forceinline__ double operator()(int i, int j, int k) const {
     const int p[3] = {i, j, k};
     int nout = 0, fd[2] = {0, 0}, fs[2] = {0, 0};
@@ -64,7 +65,7 @@ struct CgAcc {
     }
     if (e < 0) return (P(i, j, k, pcomp) - pmin) * invd;
     const int t0 = (d == 0) ? 1 : 0, t1 = (d == 2) ? 1 : 2;
-    return L->cg[L->cgoff[e] + (long long)(p[t1] - B.lo[t1] + 1) * (B.hi[t0] - B.lo[t0] + 3) + (p[t0] - B.lo[t0] + 1)];
+    return cg[L->cgoff[e] + (long long)(p[t1] - B.lo[t1] + 1) * (B.hi[t0] - B.lo[t0] + 3) + (p[t0] - B.lo[t0] + 1)];
   }
 };
 
@@ -98,7 +99,14 @@ struct FixArgs {
   int ncomp0, kcomp;
   FaceArgs A;
   int use_cp = 0;  // the level's coarse patches hold the coarse normal component of each face's direction (k_cpatch ran)
+  long long cg_stride = 0, cp_stride = 0;  // component slots (blockIdx.z): doubles between the slots' sets of compact arrays / coarse patches
 };
+// Component slots: the boundary kernels of the exact-normal pipeline run for several components in ONE launch, blockIdx.z =
+// slot z: phi component + z, output components + 8 z, coarse-normal components + cn_z z, the slot's own set of compact ghost
+// arrays and coarse patches, its own progress-variable range prog[2 z], prog[2 z + 1] = (pmin, 1 / (pmax - pmin)) (null: the
+// one in the level arguments).  One launch over 16 components costs little more than over one: at the size of a level's
+// special faces these kernels are latency bound (pa_gradcurv_run_comps2).
+struct SlotK { const double* prog = nullptr; int cn_z = 8; };
 
 __device__ __forceinline__ double comp_of(const Vec3& v, int d) { return d == 0 ? v.x : (d == 1 ? v.y : v.z); }
 
@@ -138,7 +146,7 @@ __global__ __launch_bounds__(256) void k_faces_normal(DLevelView L, DMFView MC_,
 struct SlowList { int* count; int2* items; int cap; };
 // CGCLIP: the threshold clip in the exact-normal pipeline (compiled in only where it is used: 116 against 168 VGPRs)
 template <bool CG, bool PATCH, bool CGCLIP = false>
-__device__ __forceinline__ void faces_curv_cell(const LevBatch<FixArgs>& Bt, unsigned y, long long t, int perim_only, int* nbad) {
+__device__ __forceinline__ void faces_curv_cell(const LevBatch<FixArgs>& Bt, unsigned y, long long t, int perim_only, int* nbad, const SlotK& sk, int z) {
   unsigned fy;
   const FixArgs& Fx = Bt.a[Bt.find(y, fy)];
   const DLevelView& L = Fx.L;
@@ -146,8 +154,11 @@ __device__ __forceinline__ void faces_curv_cell(const LevBatch<FixArgs>& Bt, uns
   const DLevelView& LCr = Fx.LCr;
   const DMFView& MN = Fx.MN;
   const DMFView& MO = Fx.MO;
-  const FaceArgs& A = Fx.A;
-  const int ccomp = Fx.ccomp, cncomp0 = Fx.cncomp0, ncomp0 = Fx.ncomp0, kcomp = Fx.kcomp;
+  FaceArgs A = Fx.A;
+  if (sk.prog) { A.pmin = sk.prog[2 * z]; A.invd = sk.prog[2 * z + 1]; }
+  const int ccomp = Fx.ccomp + z, cncomp0 = Fx.cncomp0 + sk.cn_z * z, ncomp0 = Fx.ncomp0 + 8 * z, kcomp = Fx.kcomp + 8 * z;
+  const double* cgz = L.cg + z * Fx.cg_stride;
+  const double* cpz = L.cp ? L.cp + z * Fx.cp_stride : nullptr;
   int b, fdir, side, layer, q0[3];
   DBox B;
   if (perim_only) {
@@ -183,7 +194,7 @@ __device__ __forceinline__ void faces_curv_cell(const LevBatch<FixArgs>& Bt, uns
   int X[3] = {q0[0], q0[1], q0[2]};
   X[fdir] += side ? -(1 + layer) : (1 + layer);
   const ShellAcc Cs = {mf_view(MC_, B, b), ccomp};
-  const CgAcc Cg = {&L, mf_view(MC_, B, b), B, b, ccomp, A.pmin, A.invd};
+  const CgAcc Cg = {&L, mf_view(MC_, B, b), B, b, ccomp, A.pmin, A.invd, cgz};
   const double dxinv[3] = {L.dxinv[0], L.dxinv[1], L.dxinv[2]};
   const double* o = MO.data + MO.off[b];
   auto C = [&](int i, int j, int k) -> double { return CG ? Cg(i, j, k) : Cs(i, j, k); };
@@ -224,7 +235,7 @@ __device__ __forceinline__ void faces_curv_cell(const LevBatch<FixArgs>& Bt, uns
         const int xf[1] = {0};
         double bv1[1];
         const long long cpo = (Fx.use_cp && L.cp) ? L.cpoff[e2] : -1;  // that face's coarse patch holds component cncomp0 + d
-        if (PATCH || cpo >= 0) cf_interp_patch<1>(code, L.cp + cpo, B, s2, MN, q, d, xf, ok, bv1);
+        if (PATCH || cpo >= 0) cf_interp_patch<1>(code, cpz + cpo, B, s2, MN, q, d, xf, ok, bv1);
         else cf_interp<1>(code, LCr, MN, cncomp0 + d, q, d, A.ratio, xf, ok, bv1);
         const double bv = bv1[0];
         double tmp = 0.0;
@@ -250,18 +261,18 @@ __device__ __forceinline__ void faces_curv_cell(const LevBatch<FixArgs>& Bt, uns
   MO.data[MO.off[b] + fab_index(B, MO.ng, MO.ncomp, kcomp, X[0], X[1], X[2])] = curv;
 }
 template <bool CG, bool PATCH = false, bool CGCLIP = false>
-__global__ __launch_bounds__(256, PA_FC_WAVES) void k_faces_curv(LevBatch<FixArgs> Bt, int* nbad) {
+__global__ __launch_bounds__(256, PA_FC_WAVES) void k_faces_curv(LevBatch<FixArgs> Bt, int* nbad, SlotK sk = SlotK()) {
   unsigned fy;
   const int perim = Bt.a[Bt.find(blockIdx.y, fy)].A.perim_only;
-  faces_curv_cell<CG, PATCH, CGCLIP>(Bt, blockIdx.y, blockIdx.x * (long long)blockDim.x + threadIdx.x, perim, nbad);
+  faces_curv_cell<CG, PATCH, CGCLIP>(Bt, blockIdx.y, blockIdx.x * (long long)blockDim.x + threadIdx.x, perim, nbad, sk, (int)blockIdx.z);
 }
 // the cells of SlowList through the general path (any cell of a face, one layer)
 template <bool PATCH>
-__global__ __launch_bounds__(256, PA_FC_WAVES) void k_faces_curv_list(LevBatch<FixArgs> Bt, int* nbad, SlowList sl) {
+__global__ __launch_bounds__(256, PA_FC_WAVES) void k_faces_curv_list(LevBatch<FixArgs> Bt, int* nbad, SlowList sl, SlotK sk = SlotK()) {
   const int n = min(*sl.count, sl.cap);
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-    const int2 it = sl.items[i];
-    faces_curv_cell<true, PATCH, true>(Bt, (unsigned)it.x, it.y, 0, nbad);
+    const int2 it = sl.items[i];  // x = batch row | slot << 24
+    faces_curv_cell<true, PATCH, true>(Bt, (unsigned)it.x & 0xffffffu, it.y, 0, nbad, sk, (int)((unsigned)it.x >> 24));
   }
 }
 
@@ -377,15 +388,17 @@ __device__ __forceinline__ void faces_curv_fast_body(const DLevelView& L, const 
 
 // PATCH: every coarse-fine face of every level of the batch has its coarse patch (the owner-map interpolation is not compiled in)
 template <int NL, bool PATCH = false, bool CLIP = false>
-__global__ __launch_bounds__(256) void k_faces_curv_fast(LevBatch<FixArgs> Bt, int* nbad, SlowList sl = SlowList()) {
+__global__ __launch_bounds__(256) void k_faces_curv_fast(LevBatch<FixArgs> Bt, int* nbad, SlowList sl = SlowList(), SlotK sk = SlotK()) {
   unsigned fy;
   const FixArgs& Fx = Bt.a[Bt.find(blockIdx.y, fy)];
   const DLevelView& L = Fx.L;
   const DLevelView& LCr = Fx.LCr;
   const DMFView& MN = Fx.MN;
   const DMFView& MO = Fx.MO;
-  const FaceArgs& A = Fx.A;
-  const int cncomp0 = Fx.cncomp0, ncomp0 = Fx.ncomp0, kcomp = Fx.kcomp;
+  const int z = (int)blockIdx.z;
+  FaceArgs A = Fx.A;
+  if (sk.prog) { A.pmin = sk.prog[2 * z]; A.invd = sk.prog[2 * z + 1]; }
+  const int cncomp0 = Fx.cncomp0 + sk.cn_z * z, ncomp0 = Fx.ncomp0 + 8 * z, kcomp = Fx.kcomp + 8 * z;
   int b, fdir, side, layer, q0[3];
   DBox B;
   const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
@@ -394,11 +407,12 @@ __global__ __launch_bounds__(256) void k_faces_curv_fast(LevBatch<FixArgs> Bt, i
   if (!(q0[t0] > B.lo[t0] && q0[t0] < B.hi[t0] && q0[t1] > B.lo[t1] && q0[t1] < B.hi[t1])) return;  // perimeter: k_faces_curv
   const unsigned code = L.sfcode[L.sfoff[fy] + t];
   const long long cpo = (Fx.use_cp && L.cp) ? L.cpoff[fy] : -1;  // wave-uniform
-  const double* patch = cpo >= 0 ? L.cp + cpo : nullptr;
+  const double* patch = cpo >= 0 ? L.cp + z * Fx.cp_stride + cpo : nullptr;
+  const unsigned row = blockIdx.y | ((unsigned)z << 24);  // SlowList entries carry the slot
   switch (fdir) {  // uniform per workgroup
-    case 0: faces_curv_fast_body<0, NL, PATCH, CLIP>(L, LCr, MN, cncomp0, MO, ncomp0, kcomp, A, nbad, b, B, side, q0, code, patch, Fx.MC_, Fx.ccomp, sl, blockIdx.y, t); break;
-    case 1: faces_curv_fast_body<1, NL, PATCH, CLIP>(L, LCr, MN, cncomp0, MO, ncomp0, kcomp, A, nbad, b, B, side, q0, code, patch, Fx.MC_, Fx.ccomp, sl, blockIdx.y, t); break;
-    default: faces_curv_fast_body<2, NL, PATCH, CLIP>(L, LCr, MN, cncomp0, MO, ncomp0, kcomp, A, nbad, b, B, side, q0, code, patch, Fx.MC_, Fx.ccomp, sl, blockIdx.y, t); break;
+    case 0: faces_curv_fast_body<0, NL, PATCH, CLIP>(L, LCr, MN, cncomp0, MO, ncomp0, kcomp, A, nbad, b, B, side, q0, code, patch, Fx.MC_, Fx.ccomp + z, sl, row, t); break;
+    case 1: faces_curv_fast_body<1, NL, PATCH, CLIP>(L, LCr, MN, cncomp0, MO, ncomp0, kcomp, A, nbad, b, B, side, q0, code, patch, Fx.MC_, Fx.ccomp + z, sl, row, t); break;
+    default: faces_curv_fast_body<2, NL, PATCH, CLIP>(L, LCr, MN, cncomp0, MO, ncomp0, kcomp, A, nbad, b, B, side, q0, code, patch, Fx.MC_, Fx.ccomp + z, sl, row, t); break;
   }
 }
 
@@ -644,17 +658,21 @@ struct PrepArgs {
 // Thread per ghost cell of a special face: the face ghost of phi (MLMG applyBC, as k_apply_bc_sfaces) and the resolved
 // ghost value of c = the same boundary condition applied to c, whose interior values are (phi - pmin) * invd formed on the
 // fly and whose coarse values are the affine view of the coarse phi -- the operations of k_apply_bc_sfaces<2> on a stored c.
-struct PrepLev { DLevelView L; DMFView M; int comp; DLevelView LC; DMFView MC; int ccomp; PrepArgs A; int use_cp; };
+struct PrepLev { DLevelView L; DMFView M; int comp; DLevelView LC; DMFView MC; int ccomp; PrepArgs A; int use_cp; long long cg_stride = 0, cp_stride = 0; };
 template <bool PATCH>
-__global__ __launch_bounds__(256) void k_prep_faces(LevBatch<PrepLev> Bt, int* nbad) {
+__global__ __launch_bounds__(256) void k_prep_faces(LevBatch<PrepLev> Bt, int* nbad, SlotK sk = SlotK()) {
   unsigned fy;
   const PrepLev& Pl = Bt.a[Bt.find(blockIdx.y, fy)];
   const DLevelView& L = Pl.L;
   const DMFView& M = Pl.M;
   const DLevelView& LC = Pl.LC;
-  const DMFView& MC = Pl.MC;
-  const PrepArgs& A = Pl.A;
-  const int comp = Pl.comp, ccomp = Pl.ccomp;
+  const int z = (int)blockIdx.z;  // component slot
+  DMFView MC = Pl.MC;
+  PrepArgs A = Pl.A;
+  if (sk.prog) { A.pmin = MC.xa = sk.prog[2 * z]; A.invd = MC.xb = sk.prog[2 * z + 1]; }
+  const int comp = Pl.comp + z, ccomp = Pl.ccomp + z;
+  double* const cgz = L.cg + z * Pl.cg_stride;
+  const double* const cpz = L.cp ? L.cp + z * Pl.cp_stride : nullptr;
   int b, dir, side, layer, q[3];
   DBox B;
   const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
@@ -662,7 +680,7 @@ __global__ __launch_bounds__(256) void k_prep_faces(LevBatch<PrepLev> Bt, int* n
   const unsigned code = L.sfcode[L.sfoff[fy] + t];
   const int cls = (int)(code & 3u);
   const int t0 = (dir == 0) ? 1 : 0, t1 = (dir == 2) ? 1 : 2;
-  double* cgp = L.cg + L.cgoff[fy] + (long long)(q[t1] - B.lo[t1] + 1) * (B.hi[t0] - B.lo[t0] + 3) + (q[t0] - B.lo[t0] + 1);
+  double* cgp = cgz + L.cgoff[fy] + (long long)(q[t1] - B.lo[t1] + 1) * (B.hi[t0] - B.lo[t0] + 3) + (q[t0] - B.lo[t0] + 1);
   double* p = M.data + M.off[b];
   if (cls == 0) {  // a valid cell of the level (mixed face): FillBoundary has filled phi there
     *cgp = (p[fab_index(B, M.ng, M.ncomp, comp, q[0], q[1], q[2])] - A.pmin) * A.invd;
@@ -685,7 +703,7 @@ __global__ __launch_bounds__(256) void k_prep_faces(LevBatch<PrepLev> Bt, int* n
   const int NX = cf_normal_coef(B.hi[dir] - B.lo[dir] + 1, A.ratio, coef);
   const int xf[2] = {0, 1};
   const long long cpo = (Pl.use_cp && L.cp) ? L.cpoff[fy] : -1;  // wave-uniform
-  if (PATCH || cpo >= 0) cf_interp_patch<2>(code, L.cp + cpo, B, side, MC, q, dir, xf, ok, bv);
+  if (PATCH || cpo >= 0) cf_interp_patch<2>(code, cpz + cpo, B, side, MC, q, dir, xf, ok, bv);
   else cf_interp<2>(code, LC, MC, ccomp, q, dir, A.ratio, xf, ok, bv);
   if (!ok) atomicAdd(nbad, 1);
   double tp = 0.0, tc = 0.0;
@@ -707,15 +725,19 @@ __global__ __launch_bounds__(256) void k_prep_faces(LevBatch<PrepLev> Bt, int* n
 // NEIGHBOURING box (k_apply_bc_edges): stored in the ring of the special face they continue.  Needs the ghost cells of phi
 // that are valid cells of the level (FillBoundary) filled.
 template <bool PATCH>
-__global__ void k_prep_ring(LevBatch<PrepLev> Bt, int* nbad) {
+__global__ void k_prep_ring(LevBatch<PrepLev> Bt, int* nbad, SlotK sk = SlotK()) {
   unsigned fy;
   const PrepLev& Pl = Bt.a[Bt.find(blockIdx.y, fy)];
   const DLevelView& L = Pl.L;
   const DMFView& M = Pl.M;
   const DLevelView& LC = Pl.LC;
-  const DMFView& MC = Pl.MC;
-  const PrepArgs& A = Pl.A;
-  const int comp = Pl.comp, ccomp = Pl.ccomp;
+  const int z = (int)blockIdx.z;  // component slot
+  DMFView MC = Pl.MC;
+  PrepArgs A = Pl.A;
+  if (sk.prog) { A.pmin = MC.xa = sk.prog[2 * z]; A.invd = MC.xb = sk.prog[2 * z + 1]; }
+  const int comp = Pl.comp + z, ccomp = Pl.ccomp + z;
+  double* const cgz = L.cg + z * Pl.cg_stride;
+  const double* const cpz = L.cp ? L.cp + z * Pl.cp_stride : nullptr;
   const int b = (int)fy;
   const DBox B = L.boxes[b];
   const int n[3] = {B.hi[0] - B.lo[0] + 1, B.hi[1] - B.lo[1] + 1, B.hi[2] - B.lo[2] + 1};
@@ -762,7 +784,7 @@ __global__ void k_prep_ring(LevBatch<PrepLev> Bt, int* nbad) {
     if (PATCH || cpo >= 0) {  // the same masks, the coarse values from the face's patch (its ring of two coarse cells covers the edge ghosts)
       const int xf[1] = {MC.xform};
       double b1[1];
-      cf_interp_patch<1>(cf_masks(L, q, dir, A.ratio) | 1u, L.cp + cpo, B, sd, MC, q, dir, xf, ok, b1);
+      cf_interp_patch<1>(cf_masks(L, q, dir, A.ratio) | 1u, cpz + cpo, B, sd, MC, q, dir, xf, ok, b1);
       bv = b1[0];
     } else {
       bv = cf_bndry_value(L, LC, MC, ccomp, q, dir, A.ratio, ok);  // MC carries the affine view
@@ -778,24 +800,34 @@ __global__ void k_prep_ring(LevBatch<PrepLev> Bt, int* nbad) {
     g += bv * coef[0];
   }
   const int t0 = (dir == 0) ? 1 : 0, t1 = (dir == 2) ? 1 : 2;
-  L.cg[L.cgoff[ef] + (long long)(q[t1] - B.lo[t1] + 1) * (B.hi[t0] - B.lo[t0] + 3) + (q[t0] - B.lo[t0] + 1)] = g;
+  cgz[L.cgoff[ef] + (long long)(q[t1] - B.lo[t1] + 1) * (B.hi[t0] - B.lo[t0] + 3) + (q[t0] - B.lo[t0] + 1)] = g;
 }
 
 // the level's compact ghost arrays, allocated on first use (a cache of the level object)
-static int level_cg(pa_ctx* ctx, const pa_level* Lc) {
+static int level_cg(pa_ctx* ctx, const pa_level* Lc, int nsets = 1) {
   pa_level* L = const_cast<pa_level*>(Lc);
-  if (L->d_cg) return 0;
-  PA_HIP(hipMalloc(&L->d_cg, sizeof(double) * (size_t)std::max<long long>(L->cg_total, 8)));
-  PA_HIP(hipMemsetAsync(L->d_cg, 0, sizeof(double) * (size_t)std::max<long long>(L->cg_total, 8), ctx->stream));
+  if (L->d_cg && L->cg_sets >= nsets) return 0;
+  if (L->d_cg) {  // more component slots than before: a larger buffer (every pass rewrites what it reads)
+    PA_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->stream2) PA_HIP(hipStreamSynchronize(ctx->stream2));
+    (void)hipFree(L->d_cg);
+    L->d_cg = nullptr;
+  }
+  const size_t n = (size_t)std::max<long long>(L->cg_total, 8) * (size_t)nsets;
+  PA_HIP(hipMalloc(&L->d_cg, sizeof(double) * n));
+  PA_HIP(hipMemsetAsync(L->d_cg, 0, sizeof(double) * n, ctx->stream));
+  L->cg_sets = nsets;
   L->view.cg = L->d_cg;
   return 0;
 }
+static long long cg_stride(const pa_level* L) { return std::max<long long>(L->cg_total, 8); }
+static long long cp_stride(const pa_level* L) { return std::max<long long>(L->cp_total, 8); }
 
 // ---- coarse patches (DLevelView::cp, pa_internal.h): one thread per patch cell fetches the coarse value through the owner
 // map of the coarse level (or of this rank's coarse-source copy) -- 1/4 of the fine face cells, once, instead of every
 // fine ghost cell walking owner map -> box -> offset before its 5-11 coarse loads.  by_dir: the patch of a face of
 // direction d holds component ccomp + d (the coarse normal the fix-up needs), else component ccomp for every face.
-struct CpLev { DLevelView L; DLevelView LC; DMFView MC; int ccomp, by_dir; };
+struct CpLev { DLevelView L; DLevelView LC; DMFView MC; int ccomp, by_dir; long long cp_stride = 0; int zstride = 1; };  // slot z: component ccomp + zstride z, patches + cp_stride z
 __global__ __launch_bounds__(256) void k_cpatch(LevBatch<CpLev> Bt) {
   unsigned fy;
   const CpLev& P = Bt.a[Bt.find(blockIdx.y, fy)];
@@ -813,14 +845,15 @@ __global__ __launch_bounds__(256) void k_cpatch(LevBatch<CpLev> Bt) {
   int p[3];
   p[dir] = plane; p[t0] = u0 + (int)(t - r * (unsigned)pw); p[t1] = v0 + (int)r;
   double v = __longlong_as_double(PA_CP_MISSING);
+  const int z = (int)blockIdx.z;
   if (wrap_cell(P.LC, p)) {
     const int cb = owner_of(P.LC, p);
-    if (cb >= 0) v = P.MC.data[P.MC.off[cb] + fab_index(P.LC.boxes[cb], P.MC.ng, P.MC.ncomp, P.ccomp + (P.by_dir ? dir : 0), p[0], p[1], p[2])];
+    if (cb >= 0) v = P.MC.data[P.MC.off[cb] + fab_index(P.LC.boxes[cb], P.MC.ng, P.MC.ncomp, P.ccomp + P.zstride * z + (P.by_dir ? dir : 0), p[0], p[1], p[2])];
   }
-  L.cp[off + t] = v;
+  L.cp[z * P.cp_stride + off + t] = v;
 }
 // the same gather from the plan of copy regions (pa_dist.h: CpPlan): no owner-map lookups at all
-struct CprLev { DLevelView L; DLevelView LC; DMFView MC; const int* regs; const int* wgs; int nwg, ccomp, by_dir; };
+struct CprLev { DLevelView L; DLevelView LC; DMFView MC; const int* regs; const int* wgs; int nwg, ccomp, by_dir; long long cp_stride = 0; int zstride = 1; };
 __global__ __launch_bounds__(256) void k_cpatch_regions(LevBatch<CprLev> Bt) {
   const CprLev& P = Bt.a[blockIdx.y];
   if ((int)blockIdx.x >= P.nwg) return;
@@ -835,19 +868,27 @@ __global__ __launch_bounds__(256) void k_cpatch_regions(LevBatch<CprLev> Bt) {
   cpatch_geom(L.boxes[e / 6], dir, side, plane, u0, v0, pw, ph);
   int p[3] = {R[4], R[5], R[6]};
   p[t0] += (int)a; p[t1] += (int)b;
-  L.cp[L.cpoff[R[0]] + (long long)(R[3] + (int)b) * pw + (R[2] + (int)a)] =
-      P.MC.data[P.MC.off[R[1]] + fab_index(P.LC.boxes[R[1]], P.MC.ng, P.MC.ncomp, P.ccomp + (P.by_dir ? dir : 0), p[0], p[1], p[2])];
+  const int z = (int)blockIdx.z;
+  L.cp[z * P.cp_stride + L.cpoff[R[0]] + (long long)(R[3] + (int)b) * pw + (R[2] + (int)a)] =
+      P.MC.data[P.MC.off[R[1]] + fab_index(P.LC.boxes[R[1]], P.MC.ng, P.MC.ncomp, P.ccomp + P.zstride * z + (P.by_dir ? dir : 0), p[0], p[1], p[2])];
 }
 __global__ __launch_bounds__(256) void k_cpatch_clear(double* cp, long long n) {
   const long long t = blockIdx.x * 256LL + threadIdx.x;
   if (t < n) cp[t] = __longlong_as_double(PA_CP_MISSING);
 }
-static int level_cp(pa_ctx* ctx, const pa_level* Lc) {
+static int level_cp(pa_ctx* ctx, const pa_level* Lc, int nsets = 1) {
   pa_level* L = const_cast<pa_level*>(Lc);
-  if (L->d_cp) return 0;
-  const long long n = std::max<long long>(L->cp_total, 8);
+  if (L->d_cp && L->cp_sets >= nsets) return 0;
+  if (L->d_cp) {
+    PA_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->stream2) PA_HIP(hipStreamSynchronize(ctx->stream2));
+    (void)hipFree(L->d_cp);
+    L->d_cp = nullptr;
+  }
+  const long long n = cp_stride(L) * nsets;
   PA_HIP(hipMalloc(&L->d_cp, sizeof(double) * (size_t)n));
   hipLaunchKernelGGL(k_cpatch_clear, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, L->d_cp, n);  // cells without a coarse owner stay "missing"
+  L->cp_sets = nsets;
   L->view.cp = L->d_cp;
   return 0;
 }
@@ -856,7 +897,7 @@ static bool cpatch_on() {
   return e ? atoi(e) != 0 : true;
 }
 // gather the patches of levels [l0, l1) (those that have a coarse source): one launch
-static int cpatch_launch(pa_ctx* ctx, int l0, int l1, pa_mf* const* fine, const pa_mf* const* crse, int ccomp, int by_dir) {
+static int cpatch_launch(pa_ctx* ctx, int l0, int l1, pa_mf* const* fine, const pa_mf* const* crse, int ccomp, int by_dir, int nslots = 1, int zstride = 1) {
   {  // copy regions when every level of the batch has a plan
     LevBatch<CprLev> Br;
     bool regions = true;
@@ -864,16 +905,16 @@ static int cpatch_launch(pa_ctx* ctx, int l0, int l1, pa_mf* const* fine, const 
     for (int l = l0; l < l1 && regions; ++l) {
       const pa_level* L = fine[l]->lev;
       if (!crse[l] || L->boxes.empty() || L->sfaces.empty() || L->cp_total == 0) continue;
-      if (level_cp(ctx, L)) return 1;
+      if (level_cp(ctx, L, nslots)) return 1;
       const CpPlan* P = pa_cp_plan(ctx, L, crse[l]->lev);
       regions = P && P->ok;
       if (!regions || P->nwg == 0) continue;
-      Br.a[Br.n] = CprLev{L->view, crse[l]->lev->view, crse[l]->view, P->d_regs, P->d_wgs, P->nwg, ccomp, by_dir};
+      Br.a[Br.n] = CprLev{L->view, crse[l]->lev->view, crse[l]->view, P->d_regs, P->d_wgs, P->nwg, ccomp, by_dir, cp_stride(L), zstride};
       ++Br.n;
       mw = std::max(mw, P->nwg);
     }
     if (regions) {
-      if (Br.n) hipLaunchKernelGGL(k_cpatch_regions, dim3((unsigned)mw, (unsigned)Br.n), dim3(256), 0, ctx->stream, Br);
+      if (Br.n) hipLaunchKernelGGL(k_cpatch_regions, dim3((unsigned)mw, (unsigned)Br.n, (unsigned)nslots), dim3(256), 0, ctx->stream, Br);
       return 0;
     }
   }
@@ -882,14 +923,14 @@ static int cpatch_launch(pa_ctx* ctx, int l0, int l1, pa_mf* const* fine, const 
   for (int l = l0; l < l1; ++l) {
     const pa_level* L = fine[l]->lev;
     if (!crse[l] || L->boxes.empty() || L->sfaces.empty() || L->cp_total == 0) continue;
-    if (level_cp(ctx, L)) return 1;
-    Bt.a[Bt.n] = CpLev{L->view, crse[l]->lev->view, crse[l]->view, ccomp, by_dir};
+    if (level_cp(ctx, L, nslots)) return 1;
+    Bt.a[Bt.n] = CpLev{L->view, crse[l]->lev->view, crse[l]->view, ccomp, by_dir, cp_stride(L), zstride};
     Bt.ycum[Bt.n + 1] = Bt.ycum[Bt.n] + (int)L->sfaces.size();
     ++Bt.n;
     const long long n0 = L->maxn[0] / 2 + 8, n1 = L->maxn[1] / 2 + 8, n2 = L->maxn[2] / 2 + 8;
     mp = std::max(mp, std::max(n1 * n2, std::max(n0 * n2, n0 * n1)));
   }
-  if (Bt.n) hipLaunchKernelGGL(k_cpatch, dim3((unsigned)((mp + 255) / 256), (unsigned)Bt.ycum[Bt.n]), dim3(256), 0, ctx->stream, Bt);
+  if (Bt.n) hipLaunchKernelGGL(k_cpatch, dim3((unsigned)((mp + 255) / 256), (unsigned)Bt.ycum[Bt.n], (unsigned)nslots), dim3(256), 0, ctx->stream, Bt);
   return 0;
 }
 
@@ -938,18 +979,24 @@ bool pa_fused2_level_ok(const pa_level* L) {
 // level 0 / where this rank has no coarse-fine face; the local half of FillBoundary(2) must have run.
 // phase: 1 = the faces (k_prep_faces: reads valid cells and coarse data only, so it may run NEXT TO FillBoundary), 2 = the
 // ring (k_prep_ring: reads ghost cells FillBoundary fills), 3 = both
-int pa_gradcurv_prep_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int comp, const pa_mf* const* crse, int ccomp, const int32_t bc[3], double pmin, double pmax, int phase) {
+// nslots > 1: components comp .. comp + nslots - 1 (coarse components ccomp ..) in one launch each, slot z with the progress
+// range prog[2 z], prog[2 z + 1] (device) and its own set of compact arrays / coarse patches (SlotK)
+int pa_gradcurv_prep_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int comp, const pa_mf* const* crse, int ccomp, const int32_t bc[3], double pmin, double pmax, int phase,
+                            int nslots, const double* prog) {
+  SlotK sk;
+  sk.prog = prog;
   const bool use_cp = cpatch_on();  // the patches are gathered with the faces (phase 1) and still hold the coarse phi when the ring runs (phase 2)
   for (int l0 = 0; l0 < nlev; l0 += PA_MAXB) {
-    if (use_cp && (phase & 1) && cpatch_launch(ctx, l0, std::min(nlev, l0 + PA_MAXB), phi, crse, ccomp, 0)) return 1;  // before P.L = L->view picks up cp
+    if (use_cp && (phase & 1) && cpatch_launch(ctx, l0, std::min(nlev, l0 + PA_MAXB), phi, crse, ccomp, 0, nslots, 1)) return 1;  // before P.L = L->view picks up cp
     LevBatch<PrepLev> Bf, Br;
     long long ntf = 0, ntr = 0;
     for (int l = l0; l < nlev && l < l0 + PA_MAXB; ++l) {
       const pa_level* L = phi[l]->lev;
       if (L->boxes.empty()) continue;
-      if (level_cg(ctx, L)) return 1;
+      if (level_cg(ctx, L, nslots)) return 1;
       if (L->sfaces.empty()) continue;
       PrepLev P;
+      P.cg_stride = cg_stride(L); P.cp_stride = cp_stride(L);
       for (int d = 0; d < 3; ++d) P.A.bc[d] = bc[d];
       P.A.ratio = 2; P.A.has_crse = crse[l] ? 1 : 0; P.A.pmin = pmin; P.A.invd = 1.0 / (pmax - pmin);
       P.L = L->view; P.M = phi[l]->view; P.comp = comp;
@@ -968,14 +1015,14 @@ int pa_gradcurv_prep_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int comp, 
     ProfScope prof(ctx, PA_TAG_BC);
     bool all_patch = true;  // every level of the batch that has a coarser level interpolates from patches: the owner-map path is not compiled in
     for (int q = 0; q < Bf.n; ++q) all_patch = all_patch && (Bf.a[q].use_cp || !Bf.a[q].A.has_crse);
-    const dim3 gf((unsigned)((ntf + 255) / 256), (unsigned)Bf.ycum[Bf.n]), gr((unsigned)((ntr + 255) / 256), (unsigned)Br.ycum[Br.n]);
+    const dim3 gf((unsigned)((ntf + 255) / 256), (unsigned)Bf.ycum[Bf.n], (unsigned)nslots), gr((unsigned)((ntr + 255) / 256), (unsigned)Br.ycum[Br.n], (unsigned)nslots);
     if (phase & 1) {
-      if (all_patch) hipLaunchKernelGGL(k_prep_faces<true>, gf, dim3(256), 0, ctx->stream, Bf, ctx->d_flags);
-      else hipLaunchKernelGGL(k_prep_faces<false>, gf, dim3(256), 0, ctx->stream, Bf, ctx->d_flags);
+      if (all_patch) hipLaunchKernelGGL(k_prep_faces<true>, gf, dim3(256), 0, ctx->stream, Bf, ctx->d_flags, sk);
+      else hipLaunchKernelGGL(k_prep_faces<false>, gf, dim3(256), 0, ctx->stream, Bf, ctx->d_flags, sk);
     }
     if (phase & 2) {
-      if (all_patch) hipLaunchKernelGGL(k_prep_ring<true>, gr, dim3(256), 0, ctx->stream, Br, ctx->d_flags);
-      else hipLaunchKernelGGL(k_prep_ring<false>, gr, dim3(256), 0, ctx->stream, Br, ctx->d_flags);
+      if (all_patch) hipLaunchKernelGGL(k_prep_ring<true>, gr, dim3(256), 0, ctx->stream, Br, ctx->d_flags, sk);
+      else hipLaunchKernelGGL(k_prep_ring<false>, gr, dim3(256), 0, ctx->stream, Br, ctx->d_flags, sk);
     }
   }
   PA_HIP(hipGetLastError());
@@ -983,11 +1030,12 @@ int pa_gradcurv_prep_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int comp, 
 }
 
 // the sweep with exact normals (the level's compact ghost arrays must be current: pa_gradcurv_prep_level)
-int pa_gradcurv_level_cg(pa_ctx* ctx, const pa_mf* phi, int pcomp, double pmin, double pmax, pa_mf* out, int ocomp, double thr) {
+int pa_gradcurv_level_cg(pa_ctx* ctx, const pa_mf* phi, int pcomp, double pmin, double pmax, pa_mf* out, int ocomp, double thr, int slot) {
   const pa_level* L = phi->lev;
   if (L->boxes.empty()) return 0;
-  if (level_cg(ctx, L)) return 1;
+  if (level_cg(ctx, L, slot + 1)) return 1;
   LevelBP2 bp{L->view, phi->view, out->view};
+  bp.L.cg += slot * cg_stride(L);  // the component slot's set of compact arrays
   MarchArgs A{pcomp, ocomp, fused_kseg(), pmin, 1.0 / (pmax - pmin), thr >= 0.0 ? thr : -1.0, 0, 1, 1, 1};
   A.cg = 1;
   ProfScope prof(ctx, PA_TAG_GRADCURV);
@@ -998,7 +1046,7 @@ int pa_gradcurv_level_cg(pa_ctx* ctx, const pa_mf* phi, int pcomp, double pmin, 
 
 // the CG sweeps of all levels: one launch (k_gradcurv_march3_levels) when every level takes the same tile variant and the
 // XCD-aware order is on, else level by level.  PA_SWEEP_BATCH=0: always level by level (A/B).
-int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, double pmin, double pmax, pa_mf* const* out, int ocomp, double thr) {
+int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, double pmin, double pmax, pa_mf* const* out, int ocomp, double thr, int slot) {
   const bool clip = thr >= 0.0;
   static const int batch_env = [] { const char* e = getenv("PA_SWEEP_BATCH"); return e ? atoi(e) : 1; }();
   static const bool knobs = getenv("PA_MARCH") || getenv("PA_DBG") || getenv("PA_MTY") || getenv("PA_PAIR");
@@ -1015,7 +1063,7 @@ int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, d
   }
   if (!ok) {
     for (int l = 0; l < nlev; ++l)
-      if (pa_gradcurv_level_cg(ctx, phi[l], pcomp, pmin, pmax, out[l], ocomp, thr)) return 1;
+      if (pa_gradcurv_level_cg(ctx, phi[l], pcomp, pmin, pmax, out[l], ocomp, thr, slot)) return 1;
     return 0;
   }
   SweepBatch S;
@@ -1051,8 +1099,9 @@ int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, d
   for (size_t q = 0; q < lv.size(); ++q) {
     const int l = lv[q];
     const pa_level* L = phi[l]->lev;
-    if (level_cg(ctx, L)) return 1;
+    if (level_cg(ctx, L, slot + 1)) return 1;
     S.bp[q] = LevelBP2{L->view, phi[l]->view, out[l]->view};
+    S.bp[q].L.cg += slot * cg_stride(L);
     MarchArgs A{pcomp, ocomp, kdef, pmin, 1.0 / (pmax - pmin), clip ? thr : -1.0, 2, 1, 1, 1};
     A.cg = 1;
     if (tz_best) A.kseg = std::max(4, (L->maxn[2] + tz_best - 1) / tz_best);
@@ -1082,12 +1131,17 @@ int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, d
 
 // after the sweeps of ALL levels: curvature of the first layer behind every special face, several levels per launch pair.
 // crse_n[l]: the coarser level's output (normal components from cncomp0) or this rank's coarse-source copy of them.
+// nslots > 1: components pcomp .. pcomp + nslots - 1, slot z with outputs at ncomp0 + 8 z / kcomp + 8 z, coarse normals at
+// cncomp0 + cn_z z, progress range prog[2 z], prog[2 z + 1] (device): one launch each (SlotK)
 int pa_gradcurv_fix_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, const pa_mf* const* crse_n, int cncomp0, const int32_t bc[3], double pmin, double pmax,
-                           pa_mf* const* out, int ncomp0, int kcomp, double thr) {
+                           pa_mf* const* out, int ncomp0, int kcomp, double thr, int nslots, const double* prog, int cn_z) {
+  SlotK sk;
+  sk.prog = prog;
+  sk.cn_z = cn_z;
   const bool use_cp = cpatch_on();
   const bool clip = thr >= 0.0;
   for (int l0 = 0; l0 < nlev; l0 += PA_MAXB) {
-    if (use_cp && cpatch_launch(ctx, l0, std::min(nlev, l0 + PA_MAXB), phi, crse_n, cncomp0, 1)) return 1;
+    if (use_cp && cpatch_launch(ctx, l0, std::min(nlev, l0 + PA_MAXB), phi, crse_n, cncomp0, 1, nslots, cn_z)) return 1;
     LevBatch<FixArgs> Bt;
     long long nf = 0, nper = 0;
     for (int l = l0; l < nlev && l < l0 + PA_MAXB; ++l) {
@@ -1097,7 +1151,7 @@ int pa_gradcurv_fix_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, 
       for (int d = 0; d < 3; ++d) A.bc[d] = bc[d];
       A.ratio = 2; A.has_crse = crse_n[l] ? 1 : 0; A.thr = clip ? thr : -1.0; A.layers = 1; A.perim_only = 1; A.pmin = pmin; A.invd = 1.0 / (pmax - pmin);
       Bt.a[Bt.n] = FixArgs{L->view, phi[l]->view, pcomp, crse_n[l] ? crse_n[l]->lev->view : L->view, crse_n[l] ? crse_n[l]->view : phi[l]->view, cncomp0,
-                           out[l]->view, ncomp0, kcomp, A, (use_cp && crse_n[l] && L->cp_total > 0) ? 1 : 0};
+                           out[l]->view, ncomp0, kcomp, A, (use_cp && crse_n[l] && L->cp_total > 0) ? 1 : 0, cg_stride(L), cp_stride(L)};
       Bt.ycum[Bt.n + 1] = Bt.ycum[Bt.n] + (int)L->sfaces.size();
       ++Bt.n;
       const long long n0 = L->maxn[0], n1 = L->maxn[1], n2 = L->maxn[2];
@@ -1108,23 +1162,24 @@ int pa_gradcurv_fix_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, 
     ProfScope prof(ctx, PA_TAG_GRADCURV_FACES);
     bool all_patch = true;  // every level of the batch that interpolates from a coarser level does so from patches
     for (int q = 0; q < Bt.n; ++q) all_patch = all_patch && (Bt.a[q].use_cp || !Bt.a[q].A.has_crse);
-    const dim3 gfast((unsigned)((nf + 255) / 256), (unsigned)Bt.ycum[Bt.n]);
+    if (Bt.ycum[Bt.n] >= (1 << 24)) return pa_fail(ctx, "pa_gradcurv_fix_levels: too many special faces in one batch");
+    const dim3 gfast((unsigned)((nf + 255) / 256), (unsigned)Bt.ycum[Bt.n], (unsigned)nslots);
     if (clip) {
       SlowList sl;
       if (pa_slow_list(ctx, &sl.count, &sl.items, &sl.cap)) return 1;
       PA_HIP(hipMemsetAsync(sl.count, 0, sizeof(int), ctx->stream));
-      if (all_patch) hipLaunchKernelGGL((k_faces_curv_fast<1, true, true>), gfast, dim3(256), 0, ctx->stream, Bt, ctx->d_flags, sl);
-      else hipLaunchKernelGGL((k_faces_curv_fast<1, false, true>), gfast, dim3(256), 0, ctx->stream, Bt, ctx->d_flags, sl);
-      if (all_patch) hipLaunchKernelGGL((k_faces_curv_list<true>), dim3(128), dim3(256), 0, ctx->stream, Bt, ctx->d_flags, sl);
-      else hipLaunchKernelGGL((k_faces_curv_list<false>), dim3(128), dim3(256), 0, ctx->stream, Bt, ctx->d_flags, sl);
-    } else if (all_patch) hipLaunchKernelGGL((k_faces_curv_fast<1, true>), gfast, dim3(256), 0, ctx->stream, Bt, ctx->d_flags);
-    else hipLaunchKernelGGL((k_faces_curv_fast<1, false>), gfast, dim3(256), 0, ctx->stream, Bt, ctx->d_flags);
-    const dim3 gper((unsigned)((nper + 255) / 256), (unsigned)Bt.ycum[Bt.n]);
+      if (all_patch) hipLaunchKernelGGL((k_faces_curv_fast<1, true, true>), gfast, dim3(256), 0, ctx->stream, Bt, ctx->d_flags, sl, sk);
+      else hipLaunchKernelGGL((k_faces_curv_fast<1, false, true>), gfast, dim3(256), 0, ctx->stream, Bt, ctx->d_flags, sl, sk);
+      if (all_patch) hipLaunchKernelGGL((k_faces_curv_list<true>), dim3(128), dim3(256), 0, ctx->stream, Bt, ctx->d_flags, sl, sk);
+      else hipLaunchKernelGGL((k_faces_curv_list<false>), dim3(128), dim3(256), 0, ctx->stream, Bt, ctx->d_flags, sl, sk);
+    } else if (all_patch) hipLaunchKernelGGL((k_faces_curv_fast<1, true>), gfast, dim3(256), 0, ctx->stream, Bt, ctx->d_flags, SlowList(), sk);
+    else hipLaunchKernelGGL((k_faces_curv_fast<1, false>), gfast, dim3(256), 0, ctx->stream, Bt, ctx->d_flags, SlowList(), sk);
+    const dim3 gper((unsigned)((nper + 255) / 256), (unsigned)Bt.ycum[Bt.n], (unsigned)nslots);
     if (clip) {
-      if (all_patch) hipLaunchKernelGGL((k_faces_curv<true, true, true>), gper, dim3(256), 0, ctx->stream, Bt, ctx->d_flags);
-      else hipLaunchKernelGGL((k_faces_curv<true, false, true>), gper, dim3(256), 0, ctx->stream, Bt, ctx->d_flags);
-    } else if (all_patch) hipLaunchKernelGGL((k_faces_curv<true, true>), gper, dim3(256), 0, ctx->stream, Bt, ctx->d_flags);
-    else hipLaunchKernelGGL((k_faces_curv<true, false>), gper, dim3(256), 0, ctx->stream, Bt, ctx->d_flags);
+      if (all_patch) hipLaunchKernelGGL((k_faces_curv<true, true, true>), gper, dim3(256), 0, ctx->stream, Bt, ctx->d_flags, sk);
+      else hipLaunchKernelGGL((k_faces_curv<true, false, true>), gper, dim3(256), 0, ctx->stream, Bt, ctx->d_flags, sk);
+    } else if (all_patch) hipLaunchKernelGGL((k_faces_curv<true, true>), gper, dim3(256), 0, ctx->stream, Bt, ctx->d_flags, sk);
+    else hipLaunchKernelGGL((k_faces_curv<true, false>), gper, dim3(256), 0, ctx->stream, Bt, ctx->d_flags, sk);
   }
   PA_HIP(hipGetLastError());
   return 0;

@@ -54,6 +54,7 @@ struct DMFView {
 // level and kernel costs more than the work): blockIdx.y runs over the concatenated rows (boxes / special faces) of up to
 // PA_MAXB levels; level l owns rows ycum[l] .. ycum[l+1]-1.  Passed by value (kernel arguments, < 4 KB).
 #define PA_MAXB 4
+#define PA_MAXSLOTS 16  // component slots per batch of the boundary kernels (pa_fused.hip: SlotK)
 template <typename A, int CAP = PA_MAXB>
 struct LevBatch {
   int n = 0;
@@ -76,6 +77,7 @@ struct pa_ctx {
   size_t red_cap = 0;
   int* d_flags = nullptr;   // [0] = coarse-fine ghost cells whose coarse data was missing
   void* d_slow = nullptr;   // cells the clip-aware curvature fix-up hands to its general path (pa_fused.hip: SlowList)
+  double* d_prog = nullptr; // (pmin, 1 / (pmax - pmin)) of the component slots of a batch (pa_gradcurv_run_comps2)
   void* d_scr = nullptr;    // grow-only scratch (marching cubes)
   size_t scr_cap = 0;
   // surface blocks handed out by pa_mc_level* / taken back by pa_device_free: a freed block is kept (up to 4 of them) for
@@ -138,6 +140,7 @@ struct pa_level {
   bool pure_faces = true;   // every special face of the WHOLE BoxArray has no ghost cell that is a valid cell (pa_fused2.hip)
   long long* d_cpoff = nullptr;
   double* d_cp = nullptr;   // allocated on first use (level_cp)
+  int cp_sets = 0, cg_sets = 0;  // component slots the buffers hold (pa_fused.hip: SlotK)
   long long cp_total = 0;
   long long* d_cgoff = nullptr;
   double* d_cg = nullptr;   // allocated on first use (pa_level_cg)

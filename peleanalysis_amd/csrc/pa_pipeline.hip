@@ -14,11 +14,12 @@ int pa_fill_boundary_impl(pa_ctx* ctx, pa_mf* M, int comp, int ncomp, int ng, in
 // exact-normal pipeline (pa_fused.hip)
 bool pa_fused2_level_ok(const pa_level* L);
 int pa_fill_boundary_local_batch(pa_ctx* ctx, int n, pa_mf* const* Ms, int comp, int ncomp, int ng);
-int pa_gradcurv_prep_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int comp, const pa_mf* const* crse, int ccomp, const int32_t bc[3], double pmin, double pmax, int phase = 3);
-int pa_gradcurv_level_cg(pa_ctx* ctx, const pa_mf* phi, int pcomp, double pmin, double pmax, pa_mf* out, int ocomp, double thr = -1.0);
-int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, double pmin, double pmax, pa_mf* const* out, int ocomp, double thr = -1.0);
+int pa_gradcurv_prep_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int comp, const pa_mf* const* crse, int ccomp, const int32_t bc[3], double pmin, double pmax, int phase = 3,
+                            int nslots = 1, const double* prog = nullptr);
+int pa_gradcurv_level_cg(pa_ctx* ctx, const pa_mf* phi, int pcomp, double pmin, double pmax, pa_mf* out, int ocomp, double thr = -1.0, int slot = 0);
+int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, double pmin, double pmax, pa_mf* const* out, int ocomp, double thr = -1.0, int slot = 0);
 int pa_gradcurv_fix_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, const pa_mf* const* crse_n, int cncomp0, const int32_t bc[3], double pmin, double pmax,
-                           pa_mf* const* out, int ncomp0, int kcomp, double thr = -1.0);
+                           pa_mf* const* out, int ncomp0, int kcomp, double thr = -1.0, int nslots = 1, const double* prog = nullptr, int cn_z = 8);
 int pa_gauss_curv_level(pa_ctx* ctx, const pa_mf* G, int gcomp, const pa_mf* normgrad, int ngcomp, const pa_mf* c, int ccomp, double thr, pa_mf* out,
                         int kcomp);
 int pa_strain_level(pa_ctx* ctx, const pa_mf* u, int ucomp, pa_mf* out, int srcomp, int rostcomp);
@@ -535,14 +536,17 @@ extern "C" int pa_gradcurv_run(pa_ctx* ctx, int nlev, pa_mf* const* state, int c
   return curvature_passes(ctx, nlev, state, comp, bc, pmin, pmax, thr, out, -1, ocomp + 7, ocomp + 4, nullptr, -1, P->spacedim == 2 ? 1.0 : 0.5);
 }
 
-// Components comp0 .. comp0+ncomps-1 through the fused pipeline, one after the other into the SAME output buffers (the
-// reference's tools push one variable through at a time too; SURVEY 8d memory budget).  What does not depend on results
-// is done ONCE for all components: the local FillBoundary of every component is one launch, and on a sharded hierarchy
-// exchange A (ghost cells of phi + coarse phi under the coarse-fine faces) carries all components, so a component costs
-// one exchange (B, the coarse normals) instead of two.  Exact-normal pipeline only; anything else runs component by
-// component through pa_gradcurv_run.
-extern "C" int pa_gradcurv_run_comps(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp0, int ncomps, const int32_t bc[3], const pa_curv_params* P,
-                                     pa_mf* const* work, pa_mf* const* out, int ocomp, int (*done)(void* user, int comp), void* user) {
+// Components comp0 .. comp0+ncomps-1 through the fused pipeline (the reference's tools push one variable through at a time
+// too; SURVEY 8d memory budget).  What does not depend on results is done ONCE for all components: the local FillBoundary
+// of every component is one launch, and on a sharded hierarchy exchange A (ghost cells of phi + coarse phi under the
+// coarse-fine faces) carries all components.  The components go through in BATCHES of nbatch: `out` holds nbatch slots of 8
+// components from ocomp, the boundary kernels (resolved ghost values before the sweeps, curvature fix-up after them, the
+// coarse-patch gathers, on a sharded hierarchy exchange B of the coarse normals) run ONCE per batch with the slot as a
+// grid dimension (pa_fused.hip: SlotK) -- at the size of a level's special faces they are latency bound, so a batch costs
+// little more than one component did -- and the sweeps component by component in between.  Exact-normal pipeline only;
+// anything else runs component by component through pa_gradcurv_run into slot 0.
+extern "C" int pa_gradcurv_run_comps2(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp0, int ncomps, const int32_t bc[3], const pa_curv_params* P,
+                                      pa_mf* const* work, pa_mf* const* out, int ocomp, int nbatch, int (*done)(void* user, int comp, int ocomp), void* user) {
   PaBind bind_(ctx);
   PA_TRY(check_levels(ctx, nlev, state, "pa_gradcurv_run_comps"));
   PA_TRY(check_levels(ctx, nlev, out, "pa_gradcurv_run_comps"));
@@ -550,6 +554,9 @@ extern "C" int pa_gradcurv_run_comps(pa_ctx* ctx, int nlev, pa_mf* const* state,
   if (ncomps < 1 || comp0 < 0) return pa_fail(ctx, "pa_gradcurv_run_comps: component range");
   for (int l = 0; l < nlev; ++l)
     if (comp0 + ncomps > state[l]->ncomp) return pa_fail(ctx, "pa_gradcurv_run_comps: component range");
+  nbatch = std::max(1, std::min(std::min(nbatch, ncomps), PA_MAXSLOTS));
+  for (int l = 0; l < nlev; ++l)
+    if (ocomp < 0 || ocomp + 8 * nbatch > out[l]->ncomp) return pa_fail(ctx, "pa_gradcurv_run_comps: out needs 8 components per slot of the batch");
   const double thr = P->do_threshold ? P->threshold : -1.0;
   const char* c2e = getenv("PA_FUSED2_CLIP");
   bool exact = P->fused && P->spacedim != 2 && all_fusable(nlev, state) && (!(thr >= 0.0) || !c2e || atoi(c2e));
@@ -557,7 +564,7 @@ extern "C" int pa_gradcurv_run_comps(pa_ctx* ctx, int nlev, pa_mf* const* state,
   if (!exact || ncomps == 1) {
     for (int c = comp0; c < comp0 + ncomps; ++c) {
       PA_TRY(pa_gradcurv_run(ctx, nlev, state, c, bc, P, work, out, ocomp));
-      if (done && done(user, c) != 0) return pa_fail(ctx, "pa_gradcurv_run_comps: the caller's callback failed");
+      if (done && done(user, c, ocomp) != 0) return pa_fail(ctx, "pa_gradcurv_run_comps: the caller's callback failed");
     }
     return 0;
   }
@@ -576,7 +583,7 @@ extern "C" int pa_gradcurv_run_comps(pa_ctx* ctx, int nlev, pa_mf* const* state,
       cs[l] = pa_cs_plan(ctx, state[l]->lev, state[l - 1]->lev, 0, 0, 0);
       if (!cs[l]) return 1;
       pa_mf* m = cs[l]->mf(ctx, ncomps);
-      csn[l] = cs[l]->mf(ctx, 3, 1);
+      csn[l] = cs[l]->mf(ctx, 3 * nbatch, 1);
       if (cs[l]->cs && (!m || !csn[l])) return 1;
       crse[l] = m;
       crse_n[l] = csn[l];
@@ -591,19 +598,47 @@ extern "C" int pa_gradcurv_run_comps(pa_ctx* ctx, int nlev, pa_mf* const* state,
     ProfScope prof(ctx, PA_TAG_FILL);
     PA_TRY(pa_fill_boundary_local_batch(ctx, nlev, state, comp0, ncomps, 2));
   }
-  for (int c = comp0; c < comp0 + ncomps; ++c) {
-    double pmin, pmax;
-    PA_TRY(prog_minmax(ctx, nlev, state, c, P, pmin, pmax));
-    PA_TRY(pa_gradcurv_prep_levels(ctx, nlev, state, c, crse.data(), dist ? c - comp0 : c, bc, pmin, pmax));
-    PA_TRY(pa_gradcurv_levels_cg(ctx, nlev, state, c, pmin, pmax, out, ocomp, thr));
+  if (!ctx->d_prog) PA_HIP(hipMalloc(&ctx->d_prog, sizeof(double) * 2 * PA_MAXSLOTS));
+  std::vector<double> prog(2 * (size_t)nbatch), pmins(nbatch), pmaxs(nbatch);
+  for (int g0 = comp0; g0 < comp0 + ncomps; g0 += nbatch) {
+    const int ns = std::min(nbatch, comp0 + ncomps - g0);
+    for (int z = 0; z < ns; ++z) {
+      PA_TRY(prog_minmax(ctx, nlev, state, g0 + z, P, pmins[z], pmaxs[z]));
+      prog[2 * z] = pmins[z];
+      prog[2 * z + 1] = 1.0 / (pmaxs[z] - pmins[z]);
+    }
+    // (pageable source: the copy is staged before the call returns, so the host vector may be rewritten for the next batch)
+    PA_HIP(hipMemcpyAsync(ctx->d_prog, prog.data(), sizeof(double) * 2 * ns, hipMemcpyHostToDevice, ctx->stream));
+    PA_TRY(pa_gradcurv_prep_levels(ctx, nlev, state, g0, crse.data(), dist ? g0 - comp0 : g0, bc, pmins[0], pmaxs[0], 3, ns, ctx->d_prog));
+    for (int z = 0; z < ns; ++z) PA_TRY(pa_gradcurv_levels_cg(ctx, nlev, state, g0 + z, pmins[z], pmaxs[z], out, ocomp + 8 * z, thr, z));
     if (dist) {
       std::vector<XJob> jobs;
-      for (int l = 1; l < nlev; ++l) jobs.push_back({&cs[l]->x, out[l - 1], ocomp + 4, csn[l], 0, 3});
+      for (int l = 1; l < nlev; ++l) {
+        XJob J = {&cs[l]->x, out[l - 1], ocomp + 4, csn[l], 0, 3 * ns};
+        J.group = 3; J.sgstride = 8; J.dgstride = 3;
+        jobs.push_back(J);
+      }
       ProfScope prof(ctx, PA_TAG_XCHG);
       PA_TRY(pa_xexchange(ctx, (int)jobs.size(), jobs.data()));
     }
-    PA_TRY(pa_gradcurv_fix_levels(ctx, nlev, state, c, crse_n.data(), dist ? 0 : ocomp + 4, bc, pmin, pmax, out, ocomp + 4, ocomp + 7, thr));
-    if (done && done(user, c) != 0) return pa_fail(ctx, "pa_gradcurv_run_comps: the caller's callback failed");
+    PA_TRY(pa_gradcurv_fix_levels(ctx, nlev, state, g0, crse_n.data(), dist ? 0 : ocomp + 4, bc, pmins[0], pmaxs[0], out, ocomp + 4, ocomp + 7, thr, ns, ctx->d_prog,
+                                  dist ? 3 : 8));
+    for (int z = 0; z < ns; ++z)
+      if (done && done(user, g0 + z, ocomp + 8 * z) != 0) return pa_fail(ctx, "pa_gradcurv_run_comps: the caller's callback failed");
   }
   return 0;
+}
+
+// one slot: every component into out components ocomp .. ocomp + 7 (the round-2 entry point)
+namespace {
+struct Done1 { int (*done)(void*, int); void* user; };
+int done1_thunk(void* u, int comp, int) {
+  const Done1* d = static_cast<const Done1*>(u);
+  return d->done ? d->done(d->user, comp) : 0;
+}
+}  // namespace
+extern "C" int pa_gradcurv_run_comps(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp0, int ncomps, const int32_t bc[3], const pa_curv_params* P,
+                                     pa_mf* const* work, pa_mf* const* out, int ocomp, int (*done)(void* user, int comp), void* user) {
+  Done1 d{done, user};
+  return pa_gradcurv_run_comps2(ctx, nlev, state, comp0, ncomps, bc, P, work, out, ocomp, 1, done1_thunk, &d);
 }

@@ -119,6 +119,25 @@ def _worker(rank, world, port, case):
                 v = seen[0][l].valid(i)
                 assert _same(v[0:4], og[l].valid(int(g))) and _same(v[4:7], oc[l].valid(int(g))[2:5]) and _same(v[7], oc[l].valid(int(g))[1]), \
                     f"rank {rank}/{world} run_comps: level {l} box {g} differs from the undistributed oracle"
+        # the same two components as ONE batch (pa_gradcurv_run_comps2): exchange B carries the normals of both slots
+        out2 = [capi.DevMF(ctx, dl, 16, 0) for dl in dls]
+        seen2 = {}
+
+        def done2(c, oc):
+            ctx.sync()
+            seen2[c] = (oc, [o.download() for o in out2])
+        n0 = comm.nexchange
+        capi.gradcurv_run_comps2(ctx, lst, 0, 2, bc, capi.curv_params(prog_min=pm[0], prog_max=pm[1], threshold=thr, fused=True), work, out2, 0, 2, done2)
+        ctx.sync()
+        assert sorted(seen2) == [0, 1]
+        if case == "wide" and thr is None:
+            assert comm.nexchange - n0 == 2, "one batch of 2 components: one exchange A + ONE exchange B"
+        for c in (0, 1):
+            oc_, mfs = seen2[c]
+            assert oc_ == 8 * c
+            for l, dl in enumerate(dls):
+                for i in range(len(dl.gids)):
+                    assert _same(mfs[l].valid(i)[oc_:oc_ + 8], seen[c][l].valid(i)[0:8]), f"rank {rank}/{world} run_comps2: component {c} level {l} box {i}"
         # the curvature tool's pipeline with every option (Hessian rows and velocity need their own coarse data)
         out = [capi.DevMF(ctx, dl, 17, 0) for dl in dls]
         capi.curvature_run(ctx, lst, 0, bc, capi.curv_params(threshold=thr, fused=False, do_gauss=True, do_strain=True, strain_tensor=True, do_velnormal=True,

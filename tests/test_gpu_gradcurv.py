@@ -410,6 +410,53 @@ def test_gradcurv_run_comps_equals_component_by_component(ctx, oracle):
                 assert np.array_equal(got[c][l].view(np.int64), want[c][l].view(np.int64)), (base, c, l)
 
 
+@pytest.mark.parametrize("threshold", [None, 0.1])
+@pytest.mark.parametrize("nbatch", [2, 5, 16])
+def test_gradcurv_run_comps_batched_equals_component_by_component(ctx, oracle, nbatch, threshold):
+    """pa_gradcurv_run_comps2: the boundary kernels of the exact-normal pipeline once per BATCH of components (slot = grid
+    dimension: own compact ghost arrays, coarse patches, progress range and 8 output components per slot), the sweeps
+    component by component -- every component bit-equal to pa_gradcurv_run on it alone.  5 components with different
+    progress ranges (the per-slot range matters), batches that do not divide the count, with and without the threshold clip
+    (its hand-over list carries the slot)."""
+    from peleanalysis_amd.hierarchy import nested_hierarchy, field_flame
+    H = nested_hierarchy(80, 3, 40, is_per=(1, 1, 0))
+    ncomp = 5
+    states = make_states(H, ncomp, 2, field_flame, seed=43)
+    for st in states:  # different ranges per component
+        for b in range(st.level.nboxes):
+            for c in range(ncomp):
+                st.fab(b)[c] = st.fab(b)[c] * (1.0 + 0.37 * c) + 11.0 * c
+    bc = capi.bc_from_flags((1, 1, 0))
+    dls, dst = _dev(ctx, H, states)
+    work = [capi.DevMF(ctx, dl, 1, 2) for dl in dls]
+    dout = [capi.DevMF(ctx, dl, 8, 0) for dl in dls]
+    params = capi.curv_params(threshold=threshold, fused=True)
+    want = {}
+    for c in range(ncomp):
+        capi.gradcurv_run(ctx, dst, c, bc, params, work, dout, 0)
+        ctx.sync()
+        want[c] = [d.download() for d in dout]
+    dst2 = [capi.DevMF.from_host(ctx, dl, st) for dl, st in zip(dls, states)]  # fresh ghost cells, same levels
+    nslot = min(nbatch, ncomp)
+    dout2 = [capi.DevMF(ctx, dl, 3 + 8 * nslot, 0) for dl in dls]
+    got = {}
+
+    def done(c, oc):
+        ctx.sync()
+        got[c] = (oc, [d.download() for d in dout2])
+    capi.gradcurv_run_comps2(ctx, dst2, 0, ncomp, bc, params, work, dout2, 3, nbatch, done)
+    ctx.sync()
+    assert ctx.bc_errors() == 0 and sorted(got) == list(range(ncomp))
+    kn = ctx.lib.pa_sweep_kernel_name(ctx.h).decode()
+    assert kn.endswith("CG=1>") or kn.startswith("k_gradcurv_march3_levels<"), kn
+    for c in range(ncomp):
+        oc, mfs = got[c]
+        assert oc == 3 + 8 * (c % nslot)
+        for l in range(H.nlev):
+            for b in range(H.levels[l].nboxes):
+                assert np.array_equal(mfs[l].fab(b)[oc:oc + 8].view(np.int64), want[c][l].fab(b)[0:8].view(np.int64)), (nbatch, c, l, b)
+
+
 def test_switched_off_paths_still_match(ctx):
     """the kernels the defaults no longer reach -- FillBoundary per ghost cell (PA_FB_REGIONS=0: still what a level takes
     whose regions do not fit the plan) and the sweep level by level (PA_SWEEP_BATCH=0: levels of unequal tile variants) --
