@@ -332,6 +332,7 @@ def main():
     ap.add_argument("--nlev", type=int, default=3)
     ap.add_argument("--box", type=int, default=128)
     ap.add_argument("--ncomp", type=int, default=1, help="components pushed through grad->curvature per step")
+    ap.add_argument("--nbatch", type=int, default=8, help="components per batch of the boundary kernels (pa_gradcurv_run_comps2; 8 output components per slot)")
     ap.add_argument("--fused", type=int, default=1)
     ap.add_argument("--per", type=str, default="1 1 0", help="periodicity flags x y z (headline: periodic x/y, wall z); single GPU only")
     ap.add_argument("--threshold", type=float, default=-1.0, help="diagnostic: threshold_prog / threshold_value of curvature.cpp:549-570 (< 0: off, the headline)")
@@ -450,6 +451,7 @@ def main():
     cells = sum(lv.ncells for lv in H.levels)                # the whole job
     cells_local = sum(dl.level.ncells for dl in dls)         # this rank's share
     hold, states, works, outs = [], [], [], []
+    nslot = max(1, min(args.nbatch, args.ncomp, 16))  # output slots: the boundary kernels run once per batch of nslot components
     with torch.cuda.stream(stream):
         for li, dl in enumerate(dls):
             lv = dl.level
@@ -457,20 +459,20 @@ def main():
             tin = torch.zeros(max(tot, 1), dtype=torch.float64, device=dev)
             fill_level_on_device(torch, lv, tin, args.ncomp, 2, off, cs, dev, 1234 + 100 * rank + li)
             _, _, tw = mf_layout(lv.boxes, 1, 2)
-            _, _, to = mf_layout(lv.boxes, 8, 0)
+            _, _, to = mf_layout(lv.boxes, 8 * nslot, 0)
             twk = torch.zeros(max(tw, 1), dtype=torch.float64, device=dev)
             tout = torch.zeros(max(to, 1), dtype=torch.float64, device=dev)
             hold += [tin, twk, tout]
             states.append(capi.DevMF(ctx, dl, args.ncomp, 2, tin.data_ptr()))
             works.append(capi.DevMF(ctx, dl, 1, 2, twk.data_ptr()))
-            outs.append(capi.DevMF(ctx, dl, 8, 0, tout.data_ptr()))
+            outs.append(capi.DevMF(ctx, dl, 8 * nslot, 0, tout.data_ptr()))
     stream.synchronize()
     params = capi.curv_params(prog_min=300.0, prog_max=2000.0, threshold=(args.threshold if args.threshold >= 0 else None), fused=bool(args.fused))
 
     def step():
         # every component through the pipeline into recycled output buffers (SURVEY 8d memory budget); cross-rank ghost fills
         # happen inside; result-independent ghost fills are done once for all components
-        capi.gradcurv_run_comps(ctx, states, 0, args.ncomp, bc, params, works, outs, 0)
+        capi.gradcurv_run_comps2(ctx, states, 0, args.ncomp, bc, params, works, outs, 0, nslot)
 
     def barrier():
         if world > 1:
@@ -525,7 +527,7 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"fused grad->curvature, {args.nlev}-level AMR, base {args.base}^3{' per GPU' if weak else ''}, ref_ratio 2, {args.box}^3 boxes "
                                f"({nb0} per level), {args.ncomp} comp(s), {per_txt}, {cells} cells in the job",
-                   "cells": cells, "cells_this_rank": cells_local, "ncomp": args.ncomp, "fused": bool(args.fused),
+                   "cells": cells, "cells_this_rank": cells_local, "ncomp": args.ncomp, "components_per_batch": nslot, "fused": bool(args.fused),
                    "parallelism": par, "exchange": xch},
     }
     if args.sim_of:
