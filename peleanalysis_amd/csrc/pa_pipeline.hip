@@ -253,13 +253,28 @@ static int fused_passes_dist(pa_ctx* ctx, int nlev, pa_mf* const* state, int com
     // PA_DIST_SWEEP_BATCH=1 (default): the sweeps of all levels in one launch (a rank's share of a level is 1-2 rounds of
     // workgroups: per-level launches end in idle tails), then ONE grouped exchange of the coarse normals of all levels;
     // 0: level by level, each level's exchange on the side stream next to the following sweep
-    static const int dsb = [] { const char* e = getenv("PA_DIST_SWEEP_BATCH"); return e ? atoi(e) : 1; }();
+    const char* dsbe = getenv("PA_DIST_SWEEP_BATCH");  // read per pass (A/B)
+    const int dsb = dsbe ? atoi(dsbe) : 1;
     if (dsb) {
-      PA_TRY(pa_gradcurv_levels_cg(ctx, nlev, state, comp, pmin, pmax, out, ocomp, thr));
+      // 1 (default): one launch for all levels, exchange B exposed after it.  2: the finest level's sweep is a launch of its
+      // own and exchange B -- which needs the normals of every level BUT the finest -- travels under it on the side stream
+      // (pack, grouped send / recv, unpack).  Rank 0's share of an 8-way shard of the headline, exchanges as no-ops: 1.04 /
+      // 0.97 ms per pass against 1.08 / 1.05 with the split (two launches' tails + the pack / unpack kernels next to the
+      // sweep): it pays only where exchange B takes longer than ~0.05-0.09 ms on the fabric, which one GPU cannot tell.
+      const bool split = dsb >= 2 && xov && nlev >= 2;
+      PA_TRY(pa_gradcurv_levels_cg(ctx, split ? nlev - 1 : nlev, state, comp, pmin, pmax, out, ocomp, thr));
       std::vector<XJob> nj;
       for (int l = 1; l < nlev; ++l) nj.push_back({&cs[l]->x, out[l - 1], ocomp + 4, csn[l], 0, 3});
-      ProfScope prof(ctx, PA_TAG_XCHG);
-      PA_TRY(pa_xexchange(ctx, (int)nj.size(), nj.data()));
+      if (split) {
+        PA_HIP(hipEventRecord(ctx->sync_evs[3], A));
+        PA_HIP(hipStreamWaitEvent(C, ctx->sync_evs[3], 0));
+      }
+      {
+        StreamSwap sw(ctx, split ? C : A);
+        ProfScope prof(ctx, PA_TAG_XCHG);
+        PA_TRY(pa_xexchange(ctx, (int)nj.size(), nj.data()));
+      }
+      if (split) PA_TRY(pa_gradcurv_levels_cg(ctx, 1, state + (nlev - 1), comp, pmin, pmax, out + (nlev - 1), ocomp, thr));
     }
     for (int l = 0; l < nlev && !dsb; ++l) {
       PA_TRY(pa_gradcurv_level_cg(ctx, state[l], comp, pmin, pmax, out[l], ocomp, thr));
