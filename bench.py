@@ -199,25 +199,30 @@ def secondary(ctx, torch, stream, dev):
 
     out = {}
 
-    def gradcurv_case(name, base, nlev, box, ncomp, per):
+    def gradcurv_case(name, base, nlev, box, ncomp, per, nbatch=1):
         H = nested_hierarchy(base, nlev, box, is_per=per)
         dls = [capi.DevLevel(ctx, lv) for lv in H.levels]
         keep, st, wk, ou = [], [], [], []
         for li, (lv, dl) in enumerate(zip(H.levels, dls)):
-            a, b_, c_ = alloc(lv, dl, ncomp, 2, "flame", 77 + li), alloc(lv, dl, 1, 2), alloc(lv, dl, 8, 0)
+            a, b_, c_ = alloc(lv, dl, ncomp, 2, "flame", 77 + li), alloc(lv, dl, 1, 2), alloc(lv, dl, 8 * nbatch, 0)
             keep += [a[0], b_[0], c_[0]]
             st.append(a[1]); wk.append(b_[1]); ou.append(c_[1])
         stream.synchronize()
         bc = capi.bc_from_flags(per)
         params = capi.curv_params(prog_min=300.0, prog_max=2000.0 * (1.0 + 0.1 * ncomp) + 3.0 * ncomp, threshold=None, fused=True)
         cells = sum(lv.ncells for lv in H.levels) * ncomp
-        ms = timed(lambda: capi.gradcurv_run_comps(ctx, st, 0, ncomp, bc, params, wk, ou, 0))
+        ms = timed(lambda: capi.gradcurv_run_comps2(ctx, st, 0, ncomp, bc, params, wk, ou, 0, nbatch))
         assert ctx.bc_errors() == 0
-        out[name] = entry(ms, cells, 72, workload=f"fused grad->curvature, {nlev}-level base {base}^3, {box}^3 boxes, {ncomp} comp(s), is_per {per}")
+        out[name] = entry(ms, cells, 72, workload=f"fused grad->curvature, {nlev}-level base {base}^3, {box}^3 boxes, {ncomp} comp(s)" +
+                          (f" in batches of {nbatch} (pa_gradcurv_run_comps2)" if nbatch > 1 else "") + f", is_per {per}")
         return H, dls, keep, st
 
     # BASELINE config 2: single level 512^3, 10 components
     h = gradcurv_case("c2_1lev_512_10comp", 512, 1, 128, 10, (1, 1, 1))
+    del h
+    torch.cuda.empty_cache()
+    # BASELINE config 5's shape on one GPU, 8 of its 55 components: 4 levels of 256^3 cells in 64^3 boxes, components in one batch
+    h = gradcurv_case("c5_shape_4lev_256_8comp", 256, 4, 64, 8, (1, 1, 0), nbatch=8)
     del h
     torch.cuda.empty_cache()
     # the headline hierarchy in smaller boxes

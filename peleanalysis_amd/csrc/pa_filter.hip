@@ -689,7 +689,16 @@ __global__ void k_fillpatch2(DLevelView L, DMFView M, DLevelView LC, DMFView MC,
 // per-ghost-cell kernel recomputed for each of them.  Same operations on the same operands per child, so the ghost cells
 // are bit-identical (the filter tests compare the shell with the oracle).  Parents whose children are all valid cells of
 // the box leave at once.
-__global__ __launch_bounds__(256) void k_fillpatch2p(DLevelView L, DMFView M, DLevelView LC, DMFView MC, int comp, int cshift, int ncomp, int ngf, int* nbad) {
+// interp_type 1 in two steps.  (1) k_fp_find, ONCE per (fine level, coarse level, ghost width): thread per coarse parent of
+// every box's ghost shell; the parents with at least one child that is a coarse-fine ghost cell go to a list {box, children
+// mask, parent cell} kept with the fine level (FpPlan) -- the geometry of a hierarchy does not change between calls, and of
+// the 3 M parents of config 3's finest level pair only a few hundred thousand qualify.  (2) k_fp_do, every call: thread per
+// list entry, dense wavefronts: the 8 children of a parent share its limited slopes and common factor (27 coarse values, min /
+// max, two divisions), which the per-ghost-cell kernel recomputed for each of them.  Same operations on the same operands
+// per child, so the ghost cells are bit-identical (the filter tests compare the shell with the oracle).
+// uniform: every coarse parent's 8 children share one owner-grid cell and one side of every wall (even owner-grid cells and
+// domain bounds: checked on the host), so ONE classification per parent stands for all of them.
+__global__ __launch_bounds__(256) void k_fp_find(DLevelView L, int ngf, int uniform, int4* items, int* count, int cap) {
   const int b = blockIdx.y, r = 2;
   const DBox B = L.boxes[b];
   int clo[3], cn[3];
@@ -704,7 +713,7 @@ __global__ __launch_bounds__(256) void k_fillpatch2p(DLevelView L, DMFView M, DL
   bool interior = true;
   for (int d = 0; d < 3; ++d) interior = interior && (r * qc[d] >= B.lo[d] && r * qc[d] + r - 1 <= B.hi[d]);
   if (interior) return;
-  unsigned mask = 0;  // children that are coarse-fine ghost cells of this FAB
+  unsigned geo = 0;  // children inside the grown box and outside the valid box
   for (int c8 = 0; c8 < 8; ++c8) {
     const int q[3] = {r * qc[0] + (c8 & 1), r * qc[1] + ((c8 >> 1) & 1), r * qc[2] + (c8 >> 2)};
     bool in = true, valid = true;
@@ -712,22 +721,75 @@ __global__ __launch_bounds__(256) void k_fillpatch2p(DLevelView L, DMFView M, DL
       in = in && q[d] >= B.lo[d] - ngf && q[d] <= B.hi[d] + ngf;
       valid = valid && q[d] >= B.lo[d] && q[d] <= B.hi[d];
     }
-    if (in && !valid && classify(L, q[0], q[1], q[2]) == 1) mask |= 1u << c8;
+    if (in && !valid) geo |= 1u << c8;
+  }
+  if (!geo) return;
+  unsigned mask = 0;  // children that are coarse-fine ghost cells of this FAB
+  if (uniform) {
+    if (classify(L, r * qc[0], r * qc[1], r * qc[2]) == 1) mask = geo;
+  } else {
+    for (int c8 = 0; c8 < 8; ++c8)
+      if (((geo >> c8) & 1u) && classify(L, r * qc[0] + (c8 & 1), r * qc[1] + ((c8 >> 1) & 1), r * qc[2] + (c8 >> 2)) == 1) mask |= 1u << c8;
   }
   if (!mask) return;
+  const int i = atomicAdd(count, 1);
+  if (i < cap) items[i] = make_int4(b | (int)(mask << 24), qc[0], qc[1], qc[2]);
+}
+
+__global__ __launch_bounds__(256) void k_fp_do(DLevelView L, DMFView M, DLevelView LC, DMFView MC, int comp, int cshift, int ncomp, const int4* items, int n, int* nbad) {
+  const int t = blockIdx.x * 256 + threadIdx.x, r = 2;
+  if (t >= n) return;
+  const int4 it = items[t];
+  const int b = it.x & 0xffffff;
+  const unsigned mask = (unsigned)it.x >> 24;
+  const int qc[3] = {it.y, it.z, it.w};
+  const DBox B = L.boxes[b];
   double* f = M.data + M.off[b];
+  // the coarse box that holds the parent (through a periodic image if need be): its neighbours inside the same box are plain
+  // loads at fixed offsets, issued together; only the ones beyond it (a parent on the box's surface) walk the owner map
+  int pw[3] = {qc[0], qc[1], qc[2]};
+  const int cb = wrap_cell(LC, pw) ? owner_of(LC, pw) : -1;
+  const DBox CB = LC.boxes[cb >= 0 ? cb : 0];
+  const long long sy = CB.hi[0] - CB.lo[0] + 1 + 2 * MC.ng, sz = sy * (CB.hi[1] - CB.lo[1] + 1 + 2 * MC.ng);
   for (int c = comp; c < comp + ncomp; ++c) {
     bool ok = true;
-    const double u0 = crse_val(LC, MC, c + cshift, qc[0], qc[1], qc[2], ok);
-    auto cu = [&](int dx, int dy, int dz) -> double {
-      int p[3] = {qc[0] + dx, qc[1] + dy, qc[2] + dz};
-      for (int d = 0; d < 3; ++d)
+    double v[27];  // coarse values, index (dz + 1) * 9 + (dy + 1) * 3 + (dx + 1)
+    const double* p0 = MC.data + MC.off[cb >= 0 ? cb : 0] + fab_index(CB, MC.ng, MC.ncomp, c + cshift, pw[0], pw[1], pw[2]);
+    unsigned far = 0;  // neighbours that are not cells of CB
+#pragma unroll
+    for (int n = 0; n < 27; ++n) {
+      // coarse neighbours beyond a non-periodic wall are the nearest cell inside the domain (filterPlt.cpp:164-173)
+      int p[3] = {qc[0] + n % 3 - 1, qc[1] + (n / 3) % 3 - 1, qc[2] + n / 9 - 1};
+      bool in = cb >= 0;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
         if (!LC.is_per[d]) { p[d] = max(p[d], LC.domlo[d]); p[d] = min(p[d], LC.domhi[d]); }
-      return crse_val(LC, MC, c + cshift, p[0], p[1], p[2], ok);
-    };
+        const int len = LC.domhi[d] - LC.domlo[d] + 1;
+        if (p[d] < LC.domlo[d]) p[d] += len;  // one period is enough where it matters: further out the cell is not in CB either
+        if (p[d] > LC.domhi[d]) p[d] -= len;
+        in = in && p[d] >= CB.lo[d] && p[d] <= CB.hi[d];
+      }
+      const long long o = in ? (p[2] - pw[2]) * sz + (p[1] - pw[1]) * sy + (p[0] - pw[0]) : 0;
+      double x = p0[o];
+      if (MC.xform) x = (x - MC.xa) * MC.xb;
+      v[n] = x;
+      far |= in ? 0u : 1u << n;
+    }
+    if (far) {
+#pragma unroll
+      for (int n = 0; n < 27; ++n) {
+        if (!((far >> n) & 1u)) continue;
+        int p[3] = {qc[0] + n % 3 - 1, qc[1] + (n / 3) % 3 - 1, qc[2] + n / 9 - 1};
+        for (int d = 0; d < 3; ++d)
+          if (!LC.is_per[d]) { p[d] = max(p[d], LC.domlo[d]); p[d] = min(p[d], LC.domhi[d]); }
+        v[n] = crse_val(LC, MC, c + cshift, p[0], p[1], p[2], ok);
+      }
+    }
+    const double u0 = v[13];
     double sl[3];
     for (int d = 0; d < 3; ++d) {
-      const double um = cu(-(d == 0), -(d == 1), -(d == 2)), up = cu(d == 0, d == 1, d == 2);
+      const int st = d == 0 ? 1 : (d == 1 ? 3 : 9);
+      const double um = v[13 - st], up = v[13 + st];
       const double dc = 0.5 * (up - um);
       const double df = 2.0 * (up - u0), db = 2.0 * (u0 - um);
       double sx = (df * db >= 0.0) ? fmin(fabs(df), fabs(db)) : 0.0;
@@ -739,13 +801,11 @@ __global__ __launch_bounds__(256) void k_fillpatch2p(DLevelView L, DMFView M, DL
       const double dumax = fabs(sl[0]) * (double)(r - 1) / (double)(2 * r) + fabs(sl[1]) * (double)(r - 1) / (double)(2 * r) +
                            fabs(sl[2]) * (double)(r - 1) / (double)(2 * r);
       double umax = u0, umin = u0;
-      for (int dz = -1; dz <= 1; ++dz)
-        for (int dy = -1; dy <= 1; ++dy)
-          for (int dx = -1; dx <= 1; ++dx) {
-            const double v = cu(dx, dy, dz);
-            umin = v < umin ? v : umin;
-            umax = v > umax ? v : umax;
-          }
+#pragma unroll
+      for (int n = 0; n < 27; ++n) {  // dz, dy, dx ascending, dx fastest: the order of the per-cell kernel
+        umin = v[n] < umin ? v[n] : umin;
+        umax = v[n] > umax ? v[n] : umax;
+      }
       if (dumax * alpha > (umax - u0)) alpha = (umax - u0) / dumax;
       if (dumax * alpha > (u0 - umin)) alpha = (u0 - umin) / dumax;
     }
@@ -761,6 +821,10 @@ __global__ __launch_bounds__(256) void k_fillpatch2p(DLevelView L, DMFView M, DL
       f[fab_index(B, M.ng, M.ncomp, c, q[0], q[1], q[2])] = acc;
     }
   }
+}
+
+FpPlan::~FpPlan() {
+  if (d_items) (void)hipFree(d_items);
 }
 
 extern "C" int pa_fillpatch_two_levels(pa_ctx* ctx, pa_mf* fine, const pa_mf* crse, int comp, int ncomp, int ng, int ratio, int interp_type) {
@@ -782,8 +846,42 @@ extern "C" int pa_fillpatch_two_levels(pa_ctx* ctx, pa_mf* fine, const pa_mf* cr
       for (int d = 0; d < 3; ++d) n *= coarsen_idx(B.hi[d] + ng, 2) - coarsen_idx(B.lo[d] - ng, 2) + 1;
       mp = std::max(mp, n);
     }
-    hipLaunchKernelGGL(k_fillpatch2p, dim3((unsigned)((mp + 255) / 256), (unsigned)fine->lev->boxes.size()), dim3(256), 0, ctx->stream, fine->lev->view, fine->view,
-                       crse->lev->view, crse->view, comp, ccomp - comp, ncomp, ng, ctx->d_flags);
+    const pa_level* F = fine->lev;
+    const auto key = std::make_pair(crse->lev->serial, ng);
+    auto itp = F->fp_plans.find(key);
+    if (itp == F->fp_plans.end()) {  // the list of parents, once
+      if (F->boxes.size() >= (1u << 24)) return pa_fail(ctx, "pa_fillpatch_two_levels: too many boxes");
+      bool uniform = F->g % 2 == 0;  // one classification per parent (see k_fp_find)
+      for (int d = 0; d < 3; ++d) uniform = uniform && F->mlo[d] % 2 == 0 && F->domlo[d] % 2 == 0 && (F->domhi[d] + 1) % 2 == 0;
+      long long cap = 0;  // parents of the shells
+      for (const DBox& B : F->boxes) {
+        long long all = 1, in = 1;
+        for (int d = 0; d < 3; ++d) {
+          all *= coarsen_idx(B.hi[d] + ng, 2) - coarsen_idx(B.lo[d] - ng, 2) + 1;
+          in *= std::max(0, coarsen_idx(B.hi[d] - 1, 2) - coarsen_idx(B.lo[d] + 1, 2) + 1);  // parents whose 2 cells per direction are all valid (>=: a lower bound)
+        }
+        cap += all - in;
+      }
+      if (cap >= (1LL << 31)) return pa_fail(ctx, "pa_fillpatch_two_levels: ghost shell too large");
+      std::unique_ptr<FpPlan> P(new FpPlan());
+      PA_HIP(hipMalloc(&P->d_items, sizeof(int4) * (size_t)std::max<long long>(cap, 1)));
+      int* d_count = nullptr;
+      PA_HIP(hipMalloc(&d_count, sizeof(int)));
+      PA_HIP(hipMemsetAsync(d_count, 0, sizeof(int), ctx->stream));
+      hipLaunchKernelGGL(k_fp_find, dim3((unsigned)((mp + 255) / 256), (unsigned)F->boxes.size()), dim3(256), 0, ctx->stream, F->view, ng, uniform ? 1 : 0,
+                         (int4*)P->d_items, d_count, (int)cap);
+      int n = 0;
+      PA_HIP(hipMemcpyAsync(&n, d_count, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+      PA_HIP(hipStreamSynchronize(ctx->stream));
+      (void)hipFree(d_count);
+      if (n > cap) return pa_fail(ctx, "pa_fillpatch_two_levels: parent list overflow");
+      P->n = n;
+      itp = F->fp_plans.emplace(key, std::move(P)).first;
+    }
+    const FpPlan& P = *itp->second;
+    if (P.n > 0)
+      hipLaunchKernelGGL(k_fp_do, dim3((unsigned)((P.n + 255) / 256)), dim3(256), 0, ctx->stream, F->view, fine->view, crse->lev->view, crse->view, comp, ccomp - comp,
+                         ncomp, (const int4*)P.d_items, P.n, ctx->d_flags);
     PA_HIP(hipGetLastError());
     return 0;
   }

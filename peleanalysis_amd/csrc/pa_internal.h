@@ -162,7 +162,15 @@ struct pa_level {
   mutable std::map<int, std::unique_ptr<struct FbLocal>> fb_local;                     // local FillBoundary as copy regions, by ghost width (pa_dist.hip)
   mutable std::map<std::pair<long long, int>, std::unique_ptr<struct CsPlan>> cs_plans; // coarse-source plans by (coarse level serial, mode)
   mutable std::unique_ptr<struct RepPlan> rep_plan;                                     // the level replicated on every rank (pa_dist.hip)
+  mutable std::map<std::pair<long long, int>, std::unique_ptr<struct FpPlan>> fp_plans; // FillPatchTwoLevels parent lists by (coarse level serial, ghost width) (pa_filter.hip)
   ~pa_level();
+};
+
+// coarse parents of a fine level's ghost shell that have coarse-fine children (pa_filter.hip: k_fp_find / k_fp_do)
+struct FpPlan {
+  int n = 0;
+  void* d_items = nullptr;  // int4 {box | children mask << 24, parent cell}
+  ~FpPlan();
 };
 
 struct LevelSpec {
