@@ -43,6 +43,8 @@ extern "C" void pa_ctx_destroy(pa_ctx* ctx) {
   if (ctx->d_flags) (void)hipFree(ctx->d_flags);
   if (ctx->d_slow) (void)hipFree(ctx->d_slow);
   if (ctx->d_prog) (void)hipFree(ctx->d_prog);
+  for (hipEvent_t e : ctx->fix_evs)
+    if (e) (void)hipEventDestroy(e);
   if (ctx->d_scr) (void)hipFree(ctx->d_scr);
   for (auto& c : ctx->surf_cache) (void)hipFree(c.first);
   for (auto& e : ctx->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }

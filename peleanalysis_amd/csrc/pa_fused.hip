@@ -1164,22 +1164,38 @@ int pa_gradcurv_fix_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, 
     for (int q = 0; q < Bt.n; ++q) all_patch = all_patch && (Bt.a[q].use_cp || !Bt.a[q].A.has_crse);
     if (Bt.ycum[Bt.n] >= (1 << 24)) return pa_fail(ctx, "pa_gradcurv_fix_levels: too many special faces in one batch");
     const dim3 gfast((unsigned)((nf + 255) / 256), (unsigned)Bt.ycum[Bt.n], (unsigned)nslots);
+    hipStream_t pst = ctx->stream;  // the perimeter kernel's stream
     if (clip) {
       SlowList sl;
       if (pa_slow_list(ctx, &sl.count, &sl.items, &sl.cap)) return 1;
       PA_HIP(hipMemsetAsync(sl.count, 0, sizeof(int), ctx->stream));
       if (all_patch) hipLaunchKernelGGL((k_faces_curv_fast<1, true, true>), gfast, dim3(256), 0, ctx->stream, Bt, ctx->d_flags, sl, sk);
       else hipLaunchKernelGGL((k_faces_curv_fast<1, false, true>), gfast, dim3(256), 0, ctx->stream, Bt, ctx->d_flags, sl, sk);
-      if (all_patch) hipLaunchKernelGGL((k_faces_curv_list<true>), dim3(128), dim3(256), 0, ctx->stream, Bt, ctx->d_flags, sl, sk);
-      else hipLaunchKernelGGL((k_faces_curv_list<false>), dim3(128), dim3(256), 0, ctx->stream, Bt, ctx->d_flags, sl, sk);
+      // the hand-over list is a few thousand cells through a long chain of dependent loads (~0.12 ms whatever its length): the
+      // perimeter kernel (other cells, as latency bound) runs next to it on the side stream.  PA_FIX_OVERLAP=0: one stream
+      const char* foe = getenv("PA_FIX_OVERLAP");  // read per pass (tools/ab_driver.py)
+      if ((!foe || atoi(foe)) && ctx->stream2 != ctx->stream) {
+        if (!ctx->stream2) PA_HIP(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+        for (int e = 0; e < 2; ++e)
+          if (!ctx->fix_evs[e]) PA_HIP(hipEventCreateWithFlags(&ctx->fix_evs[e], hipEventDisableTiming));
+        pst = ctx->stream2;
+        PA_HIP(hipEventRecord(ctx->fix_evs[0], ctx->stream));
+        PA_HIP(hipStreamWaitEvent(pst, ctx->fix_evs[0], 0));
+      }
+      if (all_patch) hipLaunchKernelGGL((k_faces_curv_list<true>), dim3(1024), dim3(256), 0, ctx->stream, Bt, ctx->d_flags, sl, sk);
+      else hipLaunchKernelGGL((k_faces_curv_list<false>), dim3(1024), dim3(256), 0, ctx->stream, Bt, ctx->d_flags, sl, sk);
     } else if (all_patch) hipLaunchKernelGGL((k_faces_curv_fast<1, true>), gfast, dim3(256), 0, ctx->stream, Bt, ctx->d_flags, SlowList(), sk);
     else hipLaunchKernelGGL((k_faces_curv_fast<1, false>), gfast, dim3(256), 0, ctx->stream, Bt, ctx->d_flags, SlowList(), sk);
     const dim3 gper((unsigned)((nper + 255) / 256), (unsigned)Bt.ycum[Bt.n], (unsigned)nslots);
     if (clip) {
-      if (all_patch) hipLaunchKernelGGL((k_faces_curv<true, true, true>), gper, dim3(256), 0, ctx->stream, Bt, ctx->d_flags, sk);
-      else hipLaunchKernelGGL((k_faces_curv<true, false, true>), gper, dim3(256), 0, ctx->stream, Bt, ctx->d_flags, sk);
-    } else if (all_patch) hipLaunchKernelGGL((k_faces_curv<true, true>), gper, dim3(256), 0, ctx->stream, Bt, ctx->d_flags, sk);
-    else hipLaunchKernelGGL((k_faces_curv<true, false>), gper, dim3(256), 0, ctx->stream, Bt, ctx->d_flags, sk);
+      if (all_patch) hipLaunchKernelGGL((k_faces_curv<true, true, true>), gper, dim3(256), 0, pst, Bt, ctx->d_flags, sk);
+      else hipLaunchKernelGGL((k_faces_curv<true, false, true>), gper, dim3(256), 0, pst, Bt, ctx->d_flags, sk);
+    } else if (all_patch) hipLaunchKernelGGL((k_faces_curv<true, true>), gper, dim3(256), 0, pst, Bt, ctx->d_flags, sk);
+    else hipLaunchKernelGGL((k_faces_curv<true, false>), gper, dim3(256), 0, pst, Bt, ctx->d_flags, sk);
+    if (pst != ctx->stream) {
+      PA_HIP(hipEventRecord(ctx->fix_evs[1], pst));
+      PA_HIP(hipStreamWaitEvent(ctx->stream, ctx->fix_evs[1], 0));
+    }
   }
   PA_HIP(hipGetLastError());
   return 0;

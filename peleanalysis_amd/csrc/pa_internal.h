@@ -77,6 +77,7 @@ struct pa_ctx {
   size_t red_cap = 0;
   int* d_flags = nullptr;   // [0] = coarse-fine ghost cells whose coarse data was missing
   void* d_slow = nullptr;   // cells the clip-aware curvature fix-up hands to its general path (pa_fused.hip: SlowList)
+  hipEvent_t fix_evs[2] = {nullptr, nullptr};  // fix-up: perimeter kernel on the side stream (pa_fused.hip)
   double* d_prog = nullptr; // (pmin, 1 / (pmax - pmin)) of the component slots of a batch (pa_gradcurv_run_comps2)
   void* d_scr = nullptr;    // grow-only scratch (marching cubes)
   size_t scr_cap = 0;

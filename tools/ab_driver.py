@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B of an environment switch the library reads per pass, inside ONE process (the clock a box holds drifts by more than
 the effects worth measuring: alternate short blocks and compare medians).
-usage: ab_driver.py VAR [base=512] [box=128] [blocks=8] [steps=15] [valA=1] [valB=0]"""
+usage: ab_driver.py VAR [base=512] [box=128] [blocks=8] [steps=15] [valA=1] [valB=0] [threshold=-1]"""
 import os
 import statistics
 import sys
@@ -20,6 +20,7 @@ blocks = int(sys.argv[4]) if len(sys.argv) > 4 else 8
 steps = int(sys.argv[5]) if len(sys.argv) > 5 else 15
 VA = sys.argv[6] if len(sys.argv) > 6 else "1"
 VB = sys.argv[7] if len(sys.argv) > 7 else "0"
+THR = float(sys.argv[8]) if len(sys.argv) > 8 else -1.0
 H = nested_hierarchy(base, 3, box, is_per=(1, 1, 0))
 bc = capi.bc_from_flags((1, 1, 0))
 ctx = capi.Context(0)
@@ -32,7 +33,7 @@ for lv, dl in zip(H.levels, dls):
     states.append(capi.DevMF.from_host(ctx, dl, s))
     works.append(capi.DevMF(ctx, dl, 1, 2))
     outs.append(capi.DevMF(ctx, dl, 8, 0))
-params = capi.curv_params(prog_min=300.0, prog_max=2000.0, fused=True)
+params = capi.curv_params(prog_min=300.0, prog_max=2000.0, threshold=(THR if THR >= 0 else None), fused=True)
 
 
 def block(val):
