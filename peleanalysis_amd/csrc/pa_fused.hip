@@ -722,9 +722,10 @@ __global__ __launch_bounds__(256) void k_prep_faces(LevBatch<PrepLev> Bt, int* n
 }
 
 // The edge ghost cells of c (outside the box in two directions a < c) that are the boundary ghost of a valid cell of a
-// NEIGHBOURING box (k_apply_bc_edges): stored in the ring of the special face they continue.  Needs the ghost cells of phi
-// that are valid cells of the level (FillBoundary) filled.
-template <bool PATCH>
+// NEIGHBOURING box (k_apply_bc_edges): stored in the ring of the special face they continue.  Reads ghost cells of phi that
+// are valid cells of the level: from this box's FAB once FillBoundary has filled them (DIRECT = false), or -- DIRECT, an
+// unsharded level -- in the box that owns them, so that the kernel does not wait for FillBoundary and runs next to it.
+template <bool PATCH, bool DIRECT = false>
 __global__ void k_prep_ring(LevBatch<PrepLev> Bt, int* nbad, SlotK sk = SlotK()) {
   unsigned fy;
   const PrepLev& Pl = Bt.a[Bt.find(blockIdx.y, fy)];
@@ -769,11 +770,18 @@ __global__ void k_prep_ring(LevBatch<PrepLev> Bt, int* nbad, SlotK sk = SlotK())
   if (ef < 0) return;
   if (cls == 1 && !A.has_crse) { atomicAdd(nbad, 1); return; }
   const double* p = M.data + M.off[b];
+  auto phi_at = [&](const int x[3]) -> double {  // a cell one row / plane outside this box that is a valid cell of the level
+    if (DIRECT) {
+      int sb, xw[3];
+      if (classify(L, x[0], x[1], x[2], sb, xw) == 0 && sb >= 0) return M.data[M.off[sb] + fab_index(L.boxes[sb], M.ng, M.ncomp, comp, xw[0], xw[1], xw[2])];
+    }
+    return p[fab_index(B, M.ng, M.ncomp, comp, x[0], x[1], x[2])];
+  };
   double g;
   if (cls == 2) {
     int in[3] = {q[0], q[1], q[2]};
     in[dir] += s;
-    const double v = (p[fab_index(B, M.ng, M.ncomp, comp, in[0], in[1], in[2])] - A.pmin) * A.invd;
+    const double v = (phi_at(in) - A.pmin) * A.invd;
     g = (A.bc[dir] == PA_BC_REFLECT_ODD) ? -v : v;
   } else {
     bool ok = true;
@@ -794,7 +802,7 @@ __global__ void k_prep_ring(LevBatch<PrepLev> Bt, int* nbad, SlotK sk = SlotK())
     for (int m = 1; m < NX; ++m) {
       int pc[3] = {q[0], q[1], q[2]};
       pc[dir] += s * m;
-      tmp += ((p[fab_index(B, M.ng, M.ncomp, comp, pc[0], pc[1], pc[2])] - A.pmin) * A.invd) * coef[m];
+      tmp += ((phi_at(pc) - A.pmin) * A.invd) * coef[m];
     }
     g = tmp;
     g += bv * coef[0];
@@ -981,8 +989,11 @@ bool pa_fused2_level_ok(const pa_level* L) {
 // ring (k_prep_ring: reads ghost cells FillBoundary fills), 3 = both
 // nslots > 1: components comp .. comp + nslots - 1 (coarse components ccomp ..) in one launch each, slot z with the progress
 // range prog[2 z], prog[2 z + 1] (device) and its own set of compact arrays / coarse patches (SlotK)
+// phase & 4: the ring reads its neighbours' cells in the boxes that own them (unsharded levels only), not the ghost cells
 int pa_gradcurv_prep_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int comp, const pa_mf* const* crse, int ccomp, const int32_t bc[3], double pmin, double pmax, int phase,
                             int nslots, const double* prog) {
+  bool direct = (phase & 4) != 0;
+  for (int l = 0; l < nlev; ++l) direct = direct && phi[l]->lev->nranks == 1;
   SlotK sk;
   sk.prog = prog;
   const bool use_cp = cpatch_on();  // the patches are gathered with the faces (phase 1) and still hold the coarse phi when the ring runs (phase 2)
@@ -1021,7 +1032,9 @@ int pa_gradcurv_prep_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int comp, 
       else hipLaunchKernelGGL(k_prep_faces<false>, gf, dim3(256), 0, ctx->stream, Bf, ctx->d_flags, sk);
     }
     if (phase & 2) {
-      if (all_patch) hipLaunchKernelGGL(k_prep_ring<true>, gr, dim3(256), 0, ctx->stream, Br, ctx->d_flags, sk);
+      if (all_patch && direct) hipLaunchKernelGGL((k_prep_ring<true, true>), gr, dim3(256), 0, ctx->stream, Br, ctx->d_flags, sk);
+      else if (direct) hipLaunchKernelGGL((k_prep_ring<false, true>), gr, dim3(256), 0, ctx->stream, Br, ctx->d_flags, sk);
+      else if (all_patch) hipLaunchKernelGGL(k_prep_ring<true>, gr, dim3(256), 0, ctx->stream, Br, ctx->d_flags, sk);
       else hipLaunchKernelGGL(k_prep_ring<false>, gr, dim3(256), 0, ctx->stream, Br, ctx->d_flags, sk);
     }
   }

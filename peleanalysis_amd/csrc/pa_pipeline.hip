@@ -438,6 +438,8 @@ static int fused_passes(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, co
     // more than the fix-up hides) -- neither is kept.
     const char* pove = getenv("PA_PREP_OVERLAP");  // read per pass: tools/ab_driver.py alternates it inside one process
     const int pov = pove ? atoi(pove) : 1;
+    const char* rse = getenv("PA_RING_SIDE");  // 0: k_prep_ring after FillBoundary on the main stream (A/B)
+    const bool ring_side = !rse || atoi(rse);
     if (pov) {
       if (!ctx->stream2) PA_HIP(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
       while (ctx->sync_evs.size() < 2) {
@@ -449,7 +451,8 @@ static int fused_passes(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, co
       PA_HIP(hipStreamWaitEvent(ctx->stream2, ctx->sync_evs[0], 0));
       {
         StreamSwap sw(ctx, ctx->stream2);
-        PA_TRY(pa_gradcurv_prep_levels(ctx, nlev, state, comp, crse.data(), comp, bc, pmin, pmax, 1));
+        // faces AND ring: the ring reads the neighbouring boxes' valid cells in place (phase 4), so it does not wait for FillBoundary
+        PA_TRY(pa_gradcurv_prep_levels(ctx, nlev, state, comp, crse.data(), comp, bc, pmin, pmax, ring_side ? 7 : 1));
       }
       PA_HIP(hipEventRecord(ctx->sync_evs[1], ctx->stream2));
     }
@@ -458,7 +461,7 @@ static int fused_passes(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, co
       PA_TRY(pa_fill_boundary_local_batch(ctx, nlev, state, comp, 1, 2));
     }
     if (pov) PA_HIP(hipStreamWaitEvent(ctx->stream, ctx->sync_evs[1], 0));
-    PA_TRY(pa_gradcurv_prep_levels(ctx, nlev, state, comp, crse.data(), comp, bc, pmin, pmax, pov ? 2 : 3));
+    if (!(pov && ring_side)) PA_TRY(pa_gradcurv_prep_levels(ctx, nlev, state, comp, crse.data(), comp, bc, pmin, pmax, pov ? 2 : 3));
     PA_TRY(pa_gradcurv_levels_cg(ctx, nlev, state, comp, pmin, pmax, out, ocomp, thr));
     PA_TRY(pa_gradcurv_fix_levels(ctx, nlev, state, comp, crse_n.data(), ocomp + 4, bc, pmin, pmax, out, ocomp + 4, ocomp + 7, thr));
     return 0;

@@ -8,6 +8,8 @@
 #                                                  driver -> <tag>_bench.json, <tag>_kstats.txt, <tag>_traffic.json
 #   tools/prof.sh kernels  <tag> [base box]        time + HBM traffic of EVERY kernel of the headline pass -> <tag>_all_kernels_traffic.txt
 #   tools/prof.sh sq       <tag> [base box]        SQ cycle / instruction counters per kernel -> <tag>_sq_counters.txt
+#   tools/prof.sh families <tag> [n box]           the same time + traffic table for the NON-headline kernel families (grad, pass-by-pass
+#                                                  curvature, filter, marching cubes, distance function: tools/kernel_bench.py) -> <tag>_families_traffic.txt
 #   tools/prof.sh filter   <tag> [box]             separable + tap-order box filter: time + traffic -> <tag>_filter_traffic.txt
 #   tools/prof.sh membench <tag>                   store-ceiling experiments (tools/bench/membench5: matrix, stride, fronts +
 #                                                  memory-side counters per cell) -> <tag>_membench5*.txt
@@ -60,15 +62,17 @@ json.dump(rec, open(f"gpurun_out/{tag}_traffic.json", "w"), indent=1)
 print(open(f"gpurun_out/{tag}_kstats.txt").read()); print(json.dumps(rec, indent=1)); print(json.dumps({k: v for k, v in line.items() if k != "secondary"})[:1800])
 PY
   ;;
-kernels|sq)
+kernels|sq|families)
   BASE=${1:-512}; BOX=${2:-128}
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $S/trace -- python3 tools/prof_driver.py $BASE $BOX 4 > $S/trace.out 2>&1
-  if [ $WHAT = kernels ]; then GROUPS_=("FETCH_SIZE" "WRITE_SIZE"); else
+  PROG=tools/prof_driver.py; A1=4; A2=2
+  if [ $WHAT = families ]; then PROG=tools/kernel_bench.py; A1=mconly; A2=mconly; fi  # grad + marching cubes (filters: the filter mode; the distance function is 6192 launches per grid, too slow under counters)
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $S/trace -- python3 $PROG $BASE $BOX $A1 > $S/trace.out 2>&1
+  if [ $WHAT != sq ]; then GROUPS_=("FETCH_SIZE" "WRITE_SIZE"); else
     GROUPS_=("SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE"); fi
-  i=0; for C in "${GROUPS_[@]}"; do i=$((i+1)); pmc_pass $S/pmc_$i "$C" python3 tools/prof_driver.py $BASE $BOX 2; done
-  python3 - $S $TAG $WHAT $BASE $BOX <<'PY'
+  i=0; for C in "${GROUPS_[@]}"; do i=$((i+1)); pmc_pass $S/pmc_$i "$C" python3 $PROG $BASE $BOX $A2; done
+  python3 - $S $TAG $WHAT $BASE $BOX $PROG <<'PY'
 import csv, glob, sys, collections
-scr, tag, what, base, box = sys.argv[1:6]
+scr, tag, what, base, box, prog = sys.argv[1:7]
 avg = {}
 for p in glob.glob(scr + "/trace/**/*kernel_stats.csv", recursive=True):
     for row in csv.DictReader(open(p)):
@@ -78,12 +82,13 @@ for p in glob.glob(scr + "/pmc_*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(p)):
         key = (row["Kernel_Name"], row["Counter_Name"])
         agg[key] += float(row["Counter_Value"]); nd[key].add(row["Dispatch_Id"])
-out = f"gpurun_out/{tag}_" + ("all_kernels_traffic.txt" if what == "kernels" else "sq_counters.txt")
+out = f"gpurun_out/{tag}_" + ({"kernels": "all_kernels_traffic.txt", "families": "families_traffic.txt"}.get(what, "sq_counters.txt"))
 with open(out, "w") as o:
-    o.write(f"# tools/prof.sh {what}: rocprofv3 --kernel-trace --stats, then --pmc passes (separate) -- python3 tools/prof_driver.py {base} {box}\n")
-    if what == "kernels":
+    o.write(f"# tools/prof.sh {what}: rocprofv3 --kernel-trace --stats, then --pmc passes (separate) -- python3 {prog} {base} {box}\n")
+    if what != "sq":
         o.write("# traffic = 2 x FETCH_SIZE (gfx950: 64 B counted per 128-B request) + WRITE_SIZE, per launch\n")
         for name in sorted(avg, key=lambda n: -avg[n][0] * avg[n][1]):
+            if "at::native" in name or "rocclr" in name or "elementwise" in name: continue
             f = agg.get((name, "FETCH_SIZE"), 0) / max(1, len(nd.get((name, "FETCH_SIZE"), [1])))
             w = agg.get((name, "WRITE_SIZE"), 0) / max(1, len(nd.get((name, "WRITE_SIZE"), [1])))
             t = avg[name][0]
