@@ -2,7 +2,7 @@
 boxes, 55 components = 53 species + T + rho) through the fused grad->curvature pipeline, (a) undistributed and (b) with
 the BoxArray of every level sharded over 4 ranks (Morton order + equal-volume cuts) that SHARE the GPU -- the library's
 plans, pack / unpack kernels, coarse-source copies and the multi-component entry point (exchange A once for all 55
-components, one exchange B per component) are exactly what 8 GPUs run; only the transport is the gloo callback instead
+components, one exchange B per batch of 8 components: pa_gradcurv_run_comps2) are exactly what 8 GPUs run; only the transport is the gloo callback instead
 of RCCL.  Property: for every box and component the checksum (wrap-around sum of the bit patterns of its 8 result
 fields) of the sharded run equals the undistributed one -- bit-identical results, 1.5e10 values.
 
@@ -46,6 +46,7 @@ def run(rank, world, port, ncomp, outdir):
         os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
         dist.init_process_group("gloo", rank=rank, world_size=world)
     ctx = capi.Context(0)
+    nbatch = 8 if world > 1 else 1
     comm = padist.GlooComm(ctx) if world > 1 else None
     H = nested_hierarchy(256, 4, 64, is_per=(1, 1, 0))
     owners = padist.shard(H, world) if world > 1 else [None] * 4
@@ -60,30 +61,32 @@ def run(rank, world, port, ncomp, outdir):
             for c in range(ncomp):
                 t[off[i] + c * cs[i]: off[i] + c * cs[i] + nz * ny * nx] = field(torch, H.levels[l], int(g), 2, c, dev).reshape(-1)
         _, _, tw = mf_layout(lv.boxes, 1, 2)
-        _, _, to = mf_layout(lv.boxes, 8, 0)
+        _, _, to = mf_layout(lv.boxes, 8 * nbatch, 0)
         w, o = torch.zeros(max(tw, 1), dtype=torch.float64, device=dev), torch.zeros(max(to, 1), dtype=torch.float64, device=dev)
         hold += [t, w, o]
         states.append(capi.DevMF(ctx, dl, ncomp, 2, t.data_ptr()))
         works.append(capi.DevMF(ctx, dl, 1, 2, w.data_ptr()))
-        outs.append((capi.DevMF(ctx, dl, 8, 0, o.data_ptr()), o))
+        outs.append((capi.DevMF(ctx, dl, 8 * nbatch, 0, o.data_ptr()), o))
     torch.cuda.synchronize()
     sums = {}
 
-    def done(c):
+    def done(c, oc):
         ctx.sync()
         for l, dl in enumerate(dls):
-            off8, cs8, _ = mf_layout(dl.level.boxes, 8, 0)
+            off8, cs8, _ = mf_layout(dl.level.boxes, 8 * nbatch, 0)
             o = outs[l][1]
             for i, g in enumerate(dl.gids):
-                sums[(l, int(g), c)] = int(o[off8[i]: off8[i] + 8 * cs8[i]].view(torch.int64).sum().item())
+                sums[(l, int(g), c)] = int(o[off8[i] + oc * cs8[i]: off8[i] + (oc + 8) * cs8[i]].view(torch.int64).sum().item())
     params = capi.curv_params(prog_min=200.0, prog_max=5000.0, fused=True)
-    capi.gradcurv_run_comps(ctx, states, 0, ncomp, capi.bc_from_flags((1, 1, 0)), params, works, [o[0] for o in outs], 0, done)
+    # the undistributed reference one component at a time, the sharded run in batches of 8 (pa_gradcurv_run_comps2: boundary
+    # kernels and exchange B once per batch)
+    capi.gradcurv_run_comps2(ctx, states, 0, ncomp, capi.bc_from_flags((1, 1, 0)), params, works, [o[0] for o in outs], 0, nbatch, done)
     ctx.sync()
     assert ctx.bc_errors() == 0
     kn = ctx.lib.pa_sweep_kernel_name(ctx.h).decode()
     assert kn.endswith("CG=1>") or kn.startswith("k_gradcurv_march3_levels<"), kn  # the exact-normal sweep, level by level or all levels in one launch
     if comm is not None:
-        assert comm.nexchange == 1 + ncomp, (comm.nexchange, ncomp)  # exchange A once for all components + one exchange B per component
+        assert comm.nexchange == 1 + (ncomp + nbatch - 1) // nbatch, (comm.nexchange, ncomp)  # exchange A once for all components + one exchange B per batch
     keys = np.array(sorted(sums), dtype=np.int64).reshape(-1, 3)
     np.savez(os.path.join(outdir, f"sums_w{world}_r{rank}.npz"), keys=keys, vals=np.array([sums[tuple(k)] for k in keys], dtype=np.int64))
     if world > 1:
