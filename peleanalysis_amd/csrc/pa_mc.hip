@@ -748,18 +748,24 @@ __device__ __forceinline__ int mcl_box_of(const MclArgs& A, long long cell0) {
   }
   return lo;
 }
-// list of the marked blocks as (block, FAB) pairs (order irrelevant: every block is processed on its own); one atomic per wave
-__global__ __launch_bounds__(256) void k_mcl_active(MclArgs A, int nblk) {
-  const int q = blockIdx.x * 256 + threadIdx.x;
+// list of the marked blocks as (block, FAB) pairs (order irrelevant: every block is processed on its own); one atomic per
+// WORKGROUP of 1024 blocks (per wave of 64 it was 8192 serialised atomics on one address for a 512^3 level: 35 us)
+__global__ __launch_bounds__(1024) void k_mcl_active(MclArgs A, int nblk) {
+  __shared__ int s_cnt[16], s_base;
+  const int q = blockIdx.x * 1024 + threadIdx.x;
   const bool on = q < nblk && A.bact[q];
   const unsigned long long m = __ballot(on);
-  if (!m) return;
-  int base = 0;
-  const int lane = threadIdx.x & 63;
-  if (lane == 0) base = atomicAdd(A.nact, __popcll(m));
-  base = __shfl(base, 0);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) s_cnt[w] = __popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int tot = 0;
+    for (int i = 0; i < 16; ++i) { const int c = s_cnt[i]; s_cnt[i] = tot; tot += c; }
+    s_base = tot ? atomicAdd(A.nact, tot) : 0;
+  }
+  __syncthreads();
   if (on) {
-    const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+    const int slot = s_base + s_cnt[w] + __popcll(m & ((1ull << lane) - 1ull));
     A.alist[2 * slot] = q;
     A.alist[2 * slot + 1] = mcl_box_of(A, 256LL * q);
   }
@@ -1158,7 +1164,7 @@ static int mc_level_impl(pa_ctx* ctx, const pa_mf* state, const pa_mf* mask, int
     } else if (TY == 16) hipLaunchKernelGGL((k_mcl_cells<16>), dim3(tiles(16), (unsigned)nb), dim3(64 * 16), 0, ctx->stream, A);
     else if (TY == 4) hipLaunchKernelGGL((k_mcl_cells<4>), dim3(tiles(4), (unsigned)nb), dim3(64 * 4), 0, ctx->stream, A);
     else hipLaunchKernelGGL((k_mcl_cells<8>), dim3(tiles(8), (unsigned)nb), dim3(64 * 8), 0, ctx->stream, A);
-    hipLaunchKernelGGL(k_mcl_active, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, ctx->stream, A, (int)nblk);
+    hipLaunchKernelGGL(k_mcl_active, dim3((unsigned)((nblk + 1023) / 1024)), dim3(1024), 0, ctx->stream, A, (int)nblk);
   }
   const dim3 grid(4096);  // persistent over the marked blocks
   hipLaunchKernelGGL(k_mcl_count, grid, dim3(256), 0, ctx->stream, A);
