@@ -44,8 +44,16 @@ static int check_levels(pa_ctx* ctx, int nlev, pa_mf* const* a, const char* who)
   return 0;
 }
 
+struct StreamSwap {  // the level entry points launch on ctx->stream
+  pa_ctx* c;
+  hipStream_t keep;
+  StreamSwap(pa_ctx* ctx, hipStream_t s) : c(ctx), keep(ctx->stream) { ctx->stream = s; }
+  ~StreamSwap() { c->stream = keep; }
+};
+
 extern "C" int pa_grad_run(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, const int32_t bc[3], pa_mf* const* out, int ocomp) {
   PaBind bind_(ctx);
+  bool bc_done = false;
   PA_TRY(check_levels(ctx, nlev, state, "pa_grad_run"));
   PA_TRY(check_levels(ctx, nlev, out, "pa_grad_run"));
   // grad.cpp:169 FillBoundary on every level, then MLMG getFluxes level by level (applyBC + flux)
@@ -54,22 +62,38 @@ extern "C" int pa_grad_run(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp,
   } else {
     for (int l = 0; l < nlev; ++l)
       if (state[l]->ng < 1 || comp < 0 || comp >= state[l]->ncomp) return pa_fail(ctx, "pa_grad_run: state needs >= 1 ghost layer and the component");
-    ProfScope prof(ctx, PA_TAG_FILL);
-    PA_TRY(pa_fill_boundary_local_batch(ctx, nlev, state, comp, 1, 1));  // every level in one launch
+    // applyBC of every level on the side stream NEXT TO FillBoundary: it reads valid cells and coarse valid cells and writes
+    // the ghost cells behind special faces that are NOT valid cells of the level, FillBoundary writes those that are -- disjoint
+    // (as k_prep_faces in the fused pass).  PA_GRAD_BC_SIDE=0 (read per call): one stream
+    const char* se = getenv("PA_GRAD_BC_SIDE");
+    if (!se || atoi(se)) {
+      if (!ctx->stream2) PA_HIP(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+      while (ctx->sync_evs.size() < 2) {
+        hipEvent_t e;
+        PA_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->sync_evs.push_back(e);
+      }
+      PA_HIP(hipEventRecord(ctx->sync_evs[0], ctx->stream));  // after the inputs / the previous call
+      PA_HIP(hipStreamWaitEvent(ctx->stream2, ctx->sync_evs[0], 0));
+      {
+        StreamSwap sw(ctx, ctx->stream2);
+        for (int l = 0; l < nlev; ++l) PA_TRY(pa_apply_bc(ctx, state[l], comp, l > 0 ? state[l - 1] : nullptr, comp, bc, 2, -1));
+      }
+      PA_HIP(hipEventRecord(ctx->sync_evs[1], ctx->stream2));
+      bc_done = true;
+    }
+    {
+      ProfScope prof(ctx, PA_TAG_FILL);
+      PA_TRY(pa_fill_boundary_local_batch(ctx, nlev, state, comp, 1, 1));  // every level in one launch
+    }
+    if (bc_done) PA_HIP(hipStreamWaitEvent(ctx->stream, ctx->sync_evs[1], 0));
   }
   for (int l = 0; l < nlev; ++l) {
-    PA_TRY(pa_apply_bc(ctx, state[l], comp, l > 0 ? state[l - 1] : nullptr, comp, bc, 2, -1));
+    if (!bc_done) PA_TRY(pa_apply_bc(ctx, state[l], comp, l > 0 ? state[l - 1] : nullptr, comp, bc, 2, -1));
     PA_TRY(pa_grad_level(ctx, state[l], comp, out[l], ocomp));
   }
   return 0;
 }
-
-struct StreamSwap {  // the level entry points launch on ctx->stream
-  pa_ctx* c;
-  hipStream_t keep;
-  StreamSwap(pa_ctx* ctx, hipStream_t s) : c(ctx), keep(ctx->stream) { ctx->stream = s; }
-  ~StreamSwap() { c->stream = keep; }
-};
 
 struct MFDel { void operator()(pa_mf* m) const { pa_mf_destroy(m); } };
 using MFPtr = std::unique_ptr<pa_mf, MFDel>;
