@@ -457,6 +457,30 @@ def test_gradcurv_run_comps_batched_equals_component_by_component(ctx, oracle, n
                 assert np.array_equal(mfs[l].fab(b)[oc:oc + 8].view(np.int64), want[c][l].fab(b)[0:8].view(np.int64)), (nbatch, c, l, b)
 
 
+def test_gradcurv_run_comps2_arguments(ctx):
+    """pa_gradcurv_run_comps2: `out` must hold 8 components per slot of the batch (a batch larger than the component count is
+    cut to it, 0 is taken as 1); a bad component range or a short `out` is refused with a message, nothing is launched"""
+    from peleanalysis_amd.hierarchy import nested_hierarchy, field_flame
+    H = nested_hierarchy(80, 2, 40, is_per=(1, 1, 0))
+    states = make_states(H, 3, 2, field_flame, seed=47)
+    bc = capi.bc_from_flags((1, 1, 0))
+    dls, dst = _dev(ctx, H, states)
+    work = [capi.DevMF(ctx, dl, 1, 2) for dl in dls]
+    params = capi.curv_params(fused=True)
+    out16 = [capi.DevMF(ctx, dl, 16, 0) for dl in dls]
+    seen = []
+    capi.gradcurv_run_comps2(ctx, dst, 0, 2, bc, params, work, out16, 0, 99, lambda c, oc: seen.append((c, oc)))  # 99 -> 2 slots
+    capi.gradcurv_run_comps2(ctx, dst, 2, 1, bc, params, work, out16, 8, 0, lambda c, oc: seen.append((c, oc)))   # 0 -> 1 slot, at ocomp 8
+    ctx.sync()
+    assert seen == [(0, 0), (1, 8), (2, 8)]
+    for bad in (lambda: capi.gradcurv_run_comps2(ctx, dst, 0, 3, bc, params, work, out16, 0, 3),    # 3 slots need 24 components
+                lambda: capi.gradcurv_run_comps2(ctx, dst, 0, 3, bc, params, work, out16, 9, 1),    # 9 + 8 > 16
+                lambda: capi.gradcurv_run_comps2(ctx, dst, 2, 2, bc, params, work, out16, 0, 1),    # components 2, 3 of 3
+                lambda: capi.gradcurv_run_comps2(ctx, dst, 0, 0, bc, params, work, out16, 0, 1)):   # no component
+        with pytest.raises(capi.PaError):
+            bad()
+
+
 def test_switched_off_paths_still_match(ctx):
     """the kernels the defaults no longer reach -- FillBoundary per ghost cell (PA_FB_REGIONS=0: still what a level takes
     whose regions do not fit the plan) and the sweep level by level (PA_SWEEP_BATCH=0: levels of unequal tile variants) --
