@@ -256,22 +256,30 @@ static int fused_passes_dist(pa_ctx* ctx, int nlev, pa_mf* const* state, int com
       PA_HIP(hipEventRecord(ctx->sync_evs[0], A));  // the side stream starts after everything already queued (inputs, the previous pass)
       PA_HIP(hipStreamWaitEvent(C, ctx->sync_evs[0], 0));
     }
+    // PA_DIST_FB_SIDE (default 1, read per pass): the LOCAL FillBoundary goes to the side stream and the chain the sweep waits
+    // for -- exchange A, patch gather + k_prep_faces, k_prep_ring -- stays on the main stream: the wait for the side stream then
+    // hits an event that completed long ago.  0 (round 2): the exchange + faces on the side stream, whose hand-over back to the
+    // main stream sat on the critical path (rank 0 of 8, kernel trace: 26 us between k_prep_faces' end and k_prep_ring's start)
+    const char* fse = getenv("PA_DIST_FB_SIDE");
+    const bool fb_side = xov && (!fse || atoi(fse));
     {
-      StreamSwap sw(ctx, C);
+      StreamSwap sw(ctx, fb_side ? A : C);
       {
         ProfScope prof(ctx, PA_TAG_XCHG);
         PA_TRY(pa_xexchange(ctx, (int)jobs.size(), jobs.data()));
       }
       // the faces' half of the ghost preparation (patch gather + k_prep_faces) reads valid cells and the coarse data that
-      // just arrived, and writes only ghost cells behind special faces: it stays on the side stream, next to the local
-      // FillBoundary (as in the single-GPU pass; rank 0 of 8: k_prep_faces 45 us against FillBoundary 39 us)
+      // just arrived, and writes only ghost cells behind special faces: it runs next to the local FillBoundary
+      // (as in the single-GPU pass; rank 0 of 8: k_prep_faces 45 us against FillBoundary 39 us)
       if (xov) PA_TRY(pa_gradcurv_prep_levels(ctx, nlev, state, comp, crse.data(), 0, bc, pmin, pmax, 1));
     }
-    if (xov) PA_HIP(hipEventRecord(ctx->sync_evs[1], C));
+    if (xov && !fb_side) PA_HIP(hipEventRecord(ctx->sync_evs[1], C));
     {
+      StreamSwap sw(ctx, fb_side ? C : A);
       ProfScope prof(ctx, PA_TAG_FILL);
       PA_TRY(pa_fill_boundary_local_batch(ctx, nlev, state, comp, 1, 2));
     }
+    if (fb_side) PA_HIP(hipEventRecord(ctx->sync_evs[1], C));
     if (xov) PA_HIP(hipStreamWaitEvent(A, ctx->sync_evs[1], 0));
     PA_TRY(pa_gradcurv_prep_levels(ctx, nlev, state, comp, crse.data(), 0, bc, pmin, pmax, xov ? 2 : 3));
     // PA_DIST_SWEEP_BATCH=1 (default): the sweeps of all levels in one launch (a rank's share of a level is 1-2 rounds of
