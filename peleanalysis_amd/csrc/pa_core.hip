@@ -643,6 +643,10 @@ __global__ __launch_bounds__(256) void k_fill_boundary_regions(LevBatch<FbrArgs>
   const int sk = R[4] - R[10] - S.lo[2] + ng, sj = R[3] - R[9] - S.lo[1] + ng, si = R[2] - R[8] - S.lo[0] + ng;
   double* dst = M.data + M.off[R[0]] + (long long)Fa.comp * csd + ((long long)(dk + (int)k) * nyd + (dj + (int)j)) * nxd + (di + (int)i);
   const double* src = M.data + M.off[R[1]] + (long long)Fa.comp * css + ((long long)(sk + (int)k) * nys + (sj + (int)j)) * nxs + (si + (int)i);
+  if (gridDim.z > 1) {  // components as a grid dimension: a wave stays inside one component's pages
+    dst[blockIdx.z * csd] = src[blockIdx.z * css];
+    return;
+  }
   for (int c = 0; c < Fa.ncomp; ++c) dst[c * csd] = src[c * css];
 }
 
@@ -677,7 +681,11 @@ int pa_fill_boundary_local_batch(pa_ctx* ctx, int n, pa_mf* const* Ms, int comp,
           mw = std::max(mw, plans[i]->nwg);
         }
         if (!Bt.n) continue;
-        hipLaunchKernelGGL(k_fill_boundary_regions, dim3((unsigned)mw, (unsigned)Bt.n), dim3(256), 0, ctx->stream, Bt);
+        // several components: the component is a grid dimension, not a loop inside the thread -- a wave then stays inside one
+        // component's pages (config 2's 10 components: 1.27 -> 1.03-1.10 ms, config 5's shape 1.58 -> 1.34-1.38).  PA_FB_COMP_Z=0: the loop
+        const char* ze = getenv("PA_FB_COMP_Z");
+        const unsigned gz = (ncomp > 1 && ncomp <= 65535 && (!ze || atoi(ze))) ? (unsigned)ncomp : 1u;
+        hipLaunchKernelGGL(k_fill_boundary_regions, dim3((unsigned)mw, (unsigned)Bt.n, gz), dim3(256), 0, ctx->stream, Bt);
       }
       PA_HIP(hipGetLastError());
       return 0;
