@@ -736,7 +736,7 @@ __global__ __launch_bounds__(256) void k_fp_find(DLevelView L, int ngf, int unif
   if (i < cap) items[i] = make_int4(b | (int)(mask << 24), qc[0], qc[1], qc[2]);
 }
 
-__global__ __launch_bounds__(256) void k_fp_do(DLevelView L, DMFView M, DLevelView LC, DMFView MC, int comp, int cshift, int ncomp, const int4* items, int n, int* nbad) {
+__global__ __launch_bounds__(256, 4) void k_fp_do(DLevelView L, DMFView M, DLevelView LC, DMFView MC, int comp, int cshift, int ncomp, const int4* items, int n, int* nbad) {
   const int t = blockIdx.x * 256 + threadIdx.x, r = 2;
   if (t >= n) return;
   const int4 it = items[t];
@@ -750,7 +750,7 @@ __global__ __launch_bounds__(256) void k_fp_do(DLevelView L, DMFView M, DLevelVi
   int pw[3] = {qc[0], qc[1], qc[2]};
   const int cb = wrap_cell(LC, pw) ? owner_of(LC, pw) : -1;
   const DBox CB = LC.boxes[cb >= 0 ? cb : 0];
-  const long long sy = CB.hi[0] - CB.lo[0] + 1 + 2 * MC.ng, sz = sy * (CB.hi[1] - CB.lo[1] + 1 + 2 * MC.ng);
+  const int sy = CB.hi[0] - CB.lo[0] + 1 + 2 * MC.ng, sz = sy * (CB.hi[1] - CB.lo[1] + 1 + 2 * MC.ng);  // a coarse FAB is far below 2^31 cells
   for (int c = comp; c < comp + ncomp; ++c) {
     bool ok = true;
     double v[27];  // coarse values, index (dz + 1) * 9 + (dy + 1) * 3 + (dx + 1)
@@ -769,7 +769,7 @@ __global__ __launch_bounds__(256) void k_fp_do(DLevelView L, DMFView M, DLevelVi
         if (p[d] > LC.domhi[d]) p[d] -= len;
         in = in && p[d] >= CB.lo[d] && p[d] <= CB.hi[d];
       }
-      const long long o = in ? (p[2] - pw[2]) * sz + (p[1] - pw[1]) * sy + (p[0] - pw[0]) : 0;
+      const int o = in ? (p[2] - pw[2]) * sz + (p[1] - pw[1]) * sy + (p[0] - pw[0]) : 0;
       double x = p0[o];
       if (MC.xform) x = (x - MC.xa) * MC.xb;
       v[n] = x;
