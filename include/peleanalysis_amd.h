@@ -68,6 +68,12 @@ const char* pa_sweep_kernel_name(const pa_ctx*);
 /* diagnostic: cells that the clip-aware curvature fix-up of the last fused pass (threshold_prog, curvature.cpp:549-570) had to
  * recompute through its general path because a neighbour's normal was clipped; -1 if that path has never run.  Synchronous. */
 int pa_last_slow_cells(pa_ctx*);
+/* diagnostic: number of IRREGULAR cells of a level -- boundary cells of its local boxes next to a concave coarse-fine corner or to
+ * the line where a box face changes from covered-by-a-neighbour to coarse-fine (general BoxArrays; the reference's MLPoisson /
+ * FillBoundary code has no such distinction, curvature.cpp:426-546) -- whose curvature the fused grad->curvature pass recomputes
+ * cell by cell after its sweep.  0 for the nested, convex hierarchies of the SURVEY's configs.  Builds the list on first use;
+ * synchronous; -1 on error. */
+int64_t pa_level_irregular_cells(pa_ctx*, const pa_level*);
 int pa_profile_read(pa_ctx*, int tag, int64_t* nlaunch, double* total_ms, int reset);
 
 /* ---------------------------------------------------- level = BoxArray+Geometry

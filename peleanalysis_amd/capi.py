@@ -158,6 +158,7 @@ def load_library() -> C.CDLL:
         "pa_smooth_solve": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.c_int, C.POINTER(vp), C.c_int, dbl, pi32, dbl, C.c_int, C.POINTER(C.c_int), pdbl]),
         "pa_stream_trace": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.c_int, i64, pdbl, C.c_int, dbl, vp, pi32]),
         "pa_last_slow_cells": (C.c_int, [vp]),
+        "pa_level_irregular_cells": (i64, [vp, vp]),
         "pa_stream_trace_ranks": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.c_int, i64, pdbl, C.c_int, dbl, vp, pi32, C.c_int]),
         "pa_grad_run": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.c_int, pi32, C.POINTER(vp), C.c_int]),
         "pa_curvature_run": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.c_int, pi32, C.POINTER(PaCurvParams), C.POINTER(vp), C.c_int]),

@@ -421,6 +421,7 @@ extern "C" void pa_level_destroy(pa_level* L) {
   if (L->d_sfcode) (void)hipFree(L->d_sfcode);
   if (L->d_boxes) (void)hipFree(L->d_boxes);
   if (L->d_owner) (void)hipFree(L->d_owner);
+  if (L->d_irr) (void)hipFree(L->d_irr);
   delete L;
 }
 extern "C" int pa_level_nboxes(const pa_level* L) { return L ? (int)L->boxes.size() : 0; }

@@ -198,9 +198,68 @@ static void plan_fill_boundary(const std::vector<DBox>& boxes, const std::vector
 
 struct CsPiece { int cbox; DBox box; };
 
+// Can box B have IRREGULAR cells (pa_fused.hip: k_find_irregular)?  A test at the granularity of the owner grid, true for every
+// box with such a cell (and for a few without): a face that is partly covered by a neighbouring box and partly not, or an
+// edge ghost line that is a concave corner of the level (not a valid cell while both its face-ring neighbours are) or a
+// valid cell next to a special face.  Pure geometry of the whole BoxArray: every rank gives the same answer for every box.
+static bool box_suspect(const HostGeom& FG, const DBox& B) {
+  bool special[6];
+  for (int d = 0; d < 3; ++d)
+    for (int side = 0; side < 2; ++side) {
+      const int t0 = (d == 0) ? 1 : 0, t1 = (d == 2) ? 1 : 2;
+      int q[3], nval = 0, nnot = 0;
+      q[d] = side ? B.hi[d] + 1 : B.lo[d] - 1;
+      for (int v = B.lo[t1]; v <= B.hi[t1]; v += FG.g)
+        for (int u = B.lo[t0]; u <= B.hi[t0]; u += FG.g) {
+          q[t0] = u; q[t1] = v;
+          (FG.classify(q[0], q[1], q[2]) == 0 ? nval : nnot)++;
+        }
+      if (nval && nnot) return true;
+      special[d * 2 + side] = nnot > 0;
+    }
+  for (int a = 0; a < 3; ++a)
+    for (int c = a + 1; c < 3; ++c) {
+      const int e = 3 - a - c;
+      for (int sa = 0; sa < 2; ++sa)
+        for (int sc = 0; sc < 2; ++sc)
+          for (int t = B.lo[e]; t <= B.hi[e]; t += FG.g) {
+            int q[3];
+            q[e] = t;
+            q[a] = sa ? B.hi[a] + 1 : B.lo[a] - 1;
+            q[c] = sc ? B.hi[c] + 1 : B.lo[c] - 1;
+            if (FG.classify(q[0], q[1], q[2]) == 0) {
+              if (special[a * 2 + sa] || special[c * 2 + sc]) return true;
+              continue;
+            }
+            int qa[3] = {q[0], q[1], q[2]}, qc[3] = {q[0], q[1], q[2]};
+            qa[a] += sa ? -1 : 1;
+            qc[c] += sc ? -1 : 1;
+            if (FG.classify(qa[0], qa[1], qa[2]) == 0 && FG.classify(qc[0], qc[1], qc[2]) == 0) return true;
+          }
+    }
+  return false;
+}
+
 // coarse cells the coarse-fine stencils of fine box B touch (coarse index space, may reach outside the domain)
 static void cs_rects_of_box(const HostGeom& FG, const DBox& B, int mode, int ng, int halo, std::vector<DBox>& rects) {
   if (mode == 0) {
+    // A box that may hold irregular cells rebuilds ghost normals as the NEIGHBOURING box sees them (k_curv_general: boundary
+    // values of the tangential directions at cells one layer outside the box): the coarse parents of the box grown by one
+    // cell, +-2 coarse cells in every direction, minus the coarse cells deep under the box
+    if (box_suspect(FG, B)) {
+      DBox outer, inner;
+      bool has_inner = true;
+      for (int t = 0; t < 3; ++t) {
+        outer.lo[t] = fl2(B.lo[t] - 1) - 2;
+        outer.hi[t] = fl2(B.hi[t] + 1) + 2;
+        inner.lo[t] = fl2(B.lo[t] + 1) + 3;
+        inner.hi[t] = fl2(B.hi[t] + 1) - 1 - 3;
+        has_inner = has_inner && inner.lo[t] <= inner.hi[t];
+      }
+      if (has_inner) bx_diff(outer, inner, rects);
+      else rects.push_back(outer);
+      return;
+    }
     // pa_apply_bc family (InterpBndryData order 3 behind MLMG applyBC): for a ghost cell q behind face
     // (d, side) the stencil sits in the coarse plane coarsen(q[d]) and spans +-2 coarse cells tangentially around
     // coarsen(q); the edge ghost cells the fused path resolves lie one fine cell beyond the face's tangential extent.

@@ -754,7 +754,9 @@ __global__ __launch_bounds__(256, 4) void k_fp_do(DLevelView L, DMFView M, DLeve
   for (int c = comp; c < comp + ncomp; ++c) {
     bool ok = true;
     double v[27];  // coarse values, index (dz + 1) * 9 + (dy + 1) * 3 + (dx + 1)
-    const double* p0 = MC.data + MC.off[cb >= 0 ? cb : 0] + fab_index(CB, MC.ng, MC.ncomp, c + cshift, pw[0], pw[1], pw[2]);
+    // a parent without an owning coarse box (fine level not properly nested): every neighbour is `far`, the 27 predicated
+    // loads below read element 0 of the coarse multifab (in bounds) and crse_val counts the ghost cells in nbad
+    const double* p0 = cb >= 0 ? MC.data + MC.off[cb] + fab_index(CB, MC.ng, MC.ncomp, c + cshift, pw[0], pw[1], pw[2]) : MC.data;
     unsigned far = 0;  // neighbours that are not cells of CB
 #pragma unroll
     for (int n = 0; n < 27; ++n) {

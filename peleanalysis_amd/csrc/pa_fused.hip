@@ -682,8 +682,16 @@ __global__ __launch_bounds__(256) void k_prep_faces(LevBatch<PrepLev> Bt, int* n
   const int t0 = (dir == 0) ? 1 : 0, t1 = (dir == 2) ? 1 : 2;
   double* cgp = cgz + L.cgoff[fy] + (long long)(q[t1] - B.lo[t1] + 1) * (B.hi[t0] - B.lo[t0] + 3) + (q[t0] - B.lo[t0] + 1);
   double* p = M.data + M.off[b];
-  if (cls == 0) {  // a valid cell of the level (mixed face): FillBoundary has filled phi there
-    *cgp = (p[fab_index(B, M.ng, M.ncomp, comp, q[0], q[1], q[2])] - A.pmin) * A.invd;
+  if (cls == 0) {
+    // a valid cell of the level (a face that is partly coarse-fine, partly covered by a neighbouring box): the progress variable
+    // of the cell itself.  Read in the box that OWNS the cell when that box is local -- this kernel runs next to the local
+    // FillBoundary, which is what fills the ghost cell -- and in the ghost cell when the owner is another rank's box (the
+    // cross-rank exchange has completed on this stream before this launch)
+    int sb, xw[3];
+    double v;
+    if (classify(L, q[0], q[1], q[2], sb, xw) == 0 && sb >= 0) v = M.data[M.off[sb] + fab_index(L.boxes[sb], M.ng, M.ncomp, comp, xw[0], xw[1], xw[2])];
+    else v = p[fab_index(B, M.ng, M.ncomp, comp, q[0], q[1], q[2])];
+    *cgp = (v - A.pmin) * A.invd;
     return;
   }
   const int s = side ? -1 : 1;
@@ -964,12 +972,258 @@ extern "C" int pa_last_slow_cells(pa_ctx* ctx) {
   return n;
 }
 
+// ===================================================================================== irregular cells (general BoxArrays)
+// The exact-normal pipeline leaves the flame normal exact in EVERY valid cell whatever the BoxArray looks like: a cell's normal
+// needs the progress variable in the six face neighbours only, and a face ghost cell holds one well-defined value (a valid
+// cell's, or the reference's boundary condition of the face's direction).  The CURVATURE of a boundary cell X of box B needs
+// the normal of the ghost cell Y behind the face; where Y is a valid cell of a neighbouring box N, the sweep forms that
+// normal from the progress variable around Y as B's FAB holds it, and that is N's view of it only if every tangential
+// neighbour Z of Y is a valid cell too -- or the ghost cell of exactly one reader.  On general BoxArrays it is not:
+//   * a face that is partly covered by a neighbour and partly coarse-fine: at the line where it changes, Z is a face ghost of
+//     B (boundary condition normal to B's face) AND N's ghost cell in the tangential direction (another boundary value);
+//   * a concave coarse-fine corner: the edge ghost Z has two valid neighbours in two boxes, each with its own boundary value.
+// k_find_irregular lists those cells X (a property of the BoxArray, found once per level): a boundary cell with a valid ghost
+// neighbour Y = X + s e_d is REGULAR if, for both tangential directions t and both signs, Z = Y +- e_t is
+//   - a valid cell, reached through a FAB slot the sweep / the fix-up read as such: Z inside the face's extent, or an edge
+//     ghost whose two faces (d and t) are both ordinary -- the ring of a special face holds no valid cells' values;
+//   - or an edge ghost that is not a valid cell while W = X +- e_t is not one either and face d is ordinary: the convex corner
+//     the face fix-up handles (X lies in the first layer behind the special face t, the ring of that face's compact array holds
+//     N's boundary value: k_prep_ring);
+// and the second ghost layer Y + s e_d is a valid cell (N at least two cells thick).  Everything else is irregular.  The
+// rule is deliberately conservative: an irregular cell costs a few hundred dependent loads once per pass, a missed one a
+// wrong curvature.  k_curv_general then recomputes K of the listed cells from the FINAL normals of the box and from normals
+// of ghost cells rebuilt as their owner sees them (gen_c: valid cell -> phi of B's FAB, which FillBoundary(2) filled
+// everywhere; otherwise the boundary condition of the direction Z - Y, MLMG applyBC / InterpBndryData as k_prep_faces) --
+// nothing in it depends on compact arrays, rings or stored masks.
+__global__ __launch_bounds__(256) void k_find_irregular(DLevelView L, int y0, int4* items, int* count, int cap) {
+  const int row = (int)blockIdx.y + y0, b = row / 6, f = row % 6;
+  if (b >= L.nboxes) return;
+  const DBox B = L.boxes[b];
+  const int fdir = f >> 1, fside = f & 1;
+  const int t0 = fdir == 0 ? 1 : 0, t1 = fdir == 2 ? 1 : 2;
+  const unsigned n0 = B.hi[t0] - B.lo[t0] + 1, n1 = B.hi[t1] - B.lo[t1] + 1;
+  const unsigned t = blockIdx.x * 256u + threadIdx.x;
+  if (t >= n0 * n1) return;
+  int X[3];
+  X[fdir] = fside ? B.hi[fdir] : B.lo[fdir];
+  X[t0] = B.lo[t0] + (int)(t % n0);
+  X[t1] = B.lo[t1] + (int)(t / n0);
+  for (int g = 0; g < f; ++g)  // a cell on an edge / corner of the box belongs to the lowest-numbered face it touches
+    if (X[g >> 1] == ((g & 1) ? B.hi[g >> 1] : B.lo[g >> 1])) return;
+  bool irr = false;
+  for (int g = 0; g < 6 && !irr; ++g) {
+    const int d = g >> 1, sg = (g & 1) ? 1 : -1;
+    if (X[d] != ((g & 1) ? B.hi[d] : B.lo[d])) continue;
+    int Y[3] = {X[0], X[1], X[2]};
+    Y[d] += sg;
+    if (classify(L, Y[0], Y[1], Y[2]) != 0) continue;  // boundary condition on n itself: exact from the box's own normals
+    const bool fd_special = L.sfindex[b * 6 + g] >= 0;
+    // a valid ghost cell behind a SPECIAL face (one that is coarse-fine elsewhere): the sweep's ghost row / column / plane of
+    // such a face comes from the compact array and its second stream -- the row beyond, which the ghost normal needs -- is
+    // re-aimed at that array (pa_fused_march3.h), so no ghost normal behind a special face is usable
+    if (fd_special) { irr = true; break; }
+    {
+      int Y2[3] = {Y[0], Y[1], Y[2]};
+      Y2[d] += sg;
+      if (classify(L, Y2[0], Y2[1], Y2[2]) != 0) irr = true;
+    }
+    for (int tt = 0; tt < 3 && !irr; ++tt) {
+      if (tt == d) continue;
+      for (int s2 = 0; s2 < 2 && !irr; ++s2) {
+        const int sg2 = s2 ? 1 : -1;
+        int Z[3] = {Y[0], Y[1], Y[2]};
+        Z[tt] += sg2;
+        const bool zvalid = classify(L, Z[0], Z[1], Z[2]) == 0;
+        if (Z[tt] >= B.lo[tt] && Z[tt] <= B.hi[tt]) { irr = !zvalid; continue; }
+        int W[3] = {X[0], X[1], X[2]};
+        W[tt] += sg2;
+        const bool ft_special = L.sfindex[b * 6 + tt * 2 + s2] >= 0;
+        if (!zvalid) irr = !(classify(L, W[0], W[1], W[2]) != 0 && !fd_special);
+        else irr = fd_special || ft_special;
+      }
+    }
+  }
+  if (!irr) return;
+  const int i = atomicAdd(count, 1);
+  if (items && i < cap) items[i] = make_int4(b, X[0], X[1], X[2]);
+}
+
+// the level's list of irregular cells, built on first use (a cache of the level object, like level_cg)
+static int level_irregular(pa_ctx* ctx, const pa_level* Lc) {
+  pa_level* L = const_cast<pa_level*>(Lc);
+  if (L->nirr >= 0) return 0;
+  const int nb = (int)L->boxes.size();
+  if (nb == 0) { L->nirr = 0; return 0; }
+  const long long n0 = L->maxn[0], n1 = L->maxn[1], n2 = L->maxn[2];
+  const long long nf = std::max(n1 * n2, std::max(n0 * n2, n0 * n1));
+  int* d_count = nullptr;
+  PA_HIP(hipMalloc(&d_count, sizeof(int)));
+  int n = 0;
+  for (int pass = 0; pass < 2; ++pass) {  // count, then fill
+    if (pass == 1) {
+      if (n == 0) break;
+      PA_HIP(hipMalloc(&L->d_irr, sizeof(int4) * (size_t)n));
+    }
+    PA_HIP(hipMemsetAsync(d_count, 0, sizeof(int), ctx->stream));
+    for (int y0 = 0; y0 < nb * 6; y0 += 65535 / 6 * 6)
+      hipLaunchKernelGGL(k_find_irregular, dim3((unsigned)((nf + 255) / 256), (unsigned)std::min(65535 / 6 * 6, nb * 6 - y0)), dim3(256), 0, ctx->stream, L->view, y0,
+                         pass ? (int4*)L->d_irr : nullptr, d_count, n);
+    int m = 0;
+    PA_HIP(hipMemcpyAsync(&m, d_count, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    PA_HIP(hipStreamSynchronize(ctx->stream));
+    if (pass == 1 && m != n) { (void)hipFree(d_count); return pa_fail(ctx, "irregular-cell list: the two passes disagree"); }
+    n = m;
+  }
+  (void)hipFree(d_count);
+  L->nirr = n;
+  return 0;
+}
+extern "C" int64_t pa_level_irregular_cells(pa_ctx* ctx, const pa_level* L) {
+  PaBind bind_(ctx);
+  if (!ctx || !L) return -1;
+  if (level_irregular(ctx, L)) return -1;
+  return L->nirr;
+}
+
+struct GenLev {
+  DLevelView L; DMFView MP; int pcomp;          // the level and its phi (2 ghost layers, FillBoundary done)
+  DLevelView LCp; DMFView MCp; int cpcomp;      // coarse phi (or this rank's coarse-source copy of it)
+  DLevelView LCn; DMFView MCn; int cncomp0;     // coarse flame normal (likewise)
+  DMFView MO; int ncomp0, kcomp;
+  FaceArgs A;
+  const int4* items; int n;
+};
+struct GenBox {
+  const DLevelView* L; const DLevelView* LCp; DMFView MCp; int cpcomp;
+  DBox B; FabView P; int pcomp, has_crse, bc[3]; double pmin, invd;
+  __device__ __forceinline__ double c_in(const int p[3]) const { return (P(p[0], p[1], p[2], pcomp) - pmin) * invd; }
+};
+// the progress variable at Z = Y + sg e_dir as the owner of the valid cell Y sees it (Y: a cell of the box or in the first ghost layer)
+__device__ double gen_c(const GenBox& g, const int Y[3], int dir, int sg, bool& ok) {
+  int Z[3] = {Y[0], Y[1], Y[2]};
+  Z[dir] += sg;
+  if (in_box(g.B, Z)) return g.c_in(Z);
+  const int cls = classify(*g.L, Z[0], Z[1], Z[2]);
+  if (cls == 0) return g.c_in(Z);
+  if (cls == 2) {
+    const double v = g.c_in(Y);
+    return (g.bc[dir] == PA_BC_REFLECT_ODD) ? -v : v;
+  }
+  if (!g.has_crse) { ok = false; return 0.0; }
+  int blen = 3;  // thickness of Y's box along dir (levels with boxes thinner than 3 cells do not take this pipeline)
+  if (in_box(g.B, Y)) blen = g.B.hi[dir] - g.B.lo[dir] + 1;
+  else {
+    int sb, yw[3];
+    if (classify(*g.L, Y[0], Y[1], Y[2], sb, yw) == 0 && sb >= 0) blen = g.L->boxes[sb].hi[dir] - g.L->boxes[sb].lo[dir] + 1;
+  }
+  double coef[4];
+  const int NX = cf_normal_coef(blen, 2, coef);
+  const double bv = cf_bndry_value(*g.L, *g.LCp, g.MCp, g.cpcomp, Z, dir, 2, ok);  // MCp carries the affine view of the coarse phi
+  double tmp = 0.0;
+  for (int m = 1; m < NX; ++m) {
+    int pc[3] = {Z[0], Z[1], Z[2]};
+    pc[dir] -= sg * m;
+    tmp += g.c_in(pc) * coef[m];
+  }
+  double r = tmp;
+  r += bv * coef[0];
+  return r;
+}
+__device__ Vec3 gen_normal(const GenBox& g, const int Y[3], const double dxinv[3], bool& ok) {
+  Vec3 n;
+  const double cxm = gen_c(g, Y, 0, -1, ok), cxp = gen_c(g, Y, 0, 1, ok), cym = gen_c(g, Y, 1, -1, ok), cyp = gen_c(g, Y, 1, 1, ok);
+  const double czm = gen_c(g, Y, 2, -1, ok), czp = gen_c(g, Y, 2, 1, ok);
+  normal_from(cxm, cxp, cym, cyp, czm, g.c_in(Y), czp, dxinv, n.x, n.y, n.z);
+  return n;
+}
+
+template <bool CLIP>
+__global__ __launch_bounds__(64) void k_curv_general(GenLev G, int* nbad, SlotK sk) {
+  const int z = (int)blockIdx.z;
+  FaceArgs A = G.A;
+  if (sk.prog) { A.pmin = sk.prog[2 * z]; A.invd = sk.prog[2 * z + 1]; }
+  const int cncomp0 = G.cncomp0 + sk.cn_z * z, ncomp0 = G.ncomp0 + 8 * z, kcomp = G.kcomp + 8 * z;
+  const DLevelView& L = G.L;
+  const double dxinv[3] = {L.dxinv[0], L.dxinv[1], L.dxinv[2]};
+  for (int i = blockIdx.x * 64 + threadIdx.x; i < G.n; i += gridDim.x * 64) {
+    const int4 it = G.items[i];
+    const int b = it.x, X[3] = {it.y, it.z, it.w};
+    GenBox g;
+    g.L = &G.L; g.LCp = &G.LCp; g.MCp = G.MCp; g.cpcomp = G.cpcomp + z;
+    g.MCp.xform = 1; g.MCp.xa = A.pmin; g.MCp.xb = A.invd;
+    g.B = L.boxes[b];
+    g.P = mf_view(G.MP, g.B, b);
+    g.pcomp = G.pcomp + z; g.has_crse = A.has_crse; g.pmin = A.pmin; g.invd = A.invd;
+    for (int d = 0; d < 3; ++d) g.bc[d] = A.bc[d];
+    const DBox& B = g.B;
+    const int n[3] = {B.hi[0] - B.lo[0] + 1, B.hi[1] - B.lo[1] + 1, B.hi[2] - B.lo[2] + 1};
+    double* o = G.MO.data + G.MO.off[b];
+    bool ok = true;
+    auto clipped = [&](const int p[3]) { const double c = g.c_in(p); return c < A.thr || c > 1.0 - A.thr; };
+    double* kout = o + fab_index(B, G.MO.ng, G.MO.ncomp, kcomp, X[0], X[1], X[2]);
+    if (CLIP && clipped(X)) { *kout = 0.0; continue; }
+    // component d of the UNCLIPPED normal of cell p of this box (the sweep zeroed the clipped ones in the output)
+    auto nrm = [&](const int p[3], int d) -> double {
+      if (CLIP && clipped(p)) return comp_of(gen_normal(g, p, dxinv, ok), d);
+      return o[fab_index(B, G.MO.ng, G.MO.ncomp, ncomp0 + d, p[0], p[1], p[2])];
+    };
+    double curv = 0.0;
+    for (int d = 0; d < 3; ++d) {
+      const double n0d = nrm(X, d);
+      double nb[2];
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int sg = s2 ? 1 : -1;
+        int q[3] = {X[0], X[1], X[2]};
+        q[d] += sg;
+        if (in_box(B, q)) { nb[s2] = nrm(q, d); continue; }
+        int sb, qw[3];
+        const int cls = classify(L, q[0], q[1], q[2], sb, qw);
+        if (cls == 0) {
+          // a valid cell of a neighbouring box: its FINAL normal from that box's output when the box is local (the sweeps of
+          // the level are done), rebuilt from the progress variable as its owner sees it when it is another rank's
+          if (sb >= 0) {
+            const double v = G.MO.data[G.MO.off[sb] + fab_index(L.boxes[sb], G.MO.ng, G.MO.ncomp, ncomp0 + d, qw[0], qw[1], qw[2])];
+            nb[s2] = (CLIP && v == 0.0 && clipped(q)) ? comp_of(gen_normal(g, q, dxinv, ok), d) : v;
+          } else {
+            nb[s2] = comp_of(gen_normal(g, q, dxinv, ok), d);
+          }
+        } else if (cls == 2) {
+          nb[s2] = (A.bc[d] == PA_BC_REFLECT_ODD) ? -n0d : n0d;
+        } else {
+          if (!A.has_crse) { ok = false; nb[s2] = 0.0; continue; }
+          double coef[4];
+          const int NX = cf_normal_coef(n[d], A.ratio, coef);
+          const double bv = cf_bndry_value(L, G.LCn, G.MCn, cncomp0 + d, q, d, A.ratio, ok);
+          double tmp = 0.0;
+          for (int m = 1; m < NX; ++m) {
+            int pc[3] = {q[0], q[1], q[2]};
+            pc[d] -= sg * m;  // into the box
+            const double v = (m == 1) ? n0d : nrm(pc, d);
+            tmp += v * coef[m];
+          }
+          double gv = tmp;
+          gv += bv * coef[0];
+          nb[s2] = gv;
+        }
+      }
+      curv += cdiff(dxinv[d], nb[0], n0d, nb[1]);
+    }
+    curv = curv * 0.5;
+    if (!ok) atomicAdd(nbad, 1);
+    *kout = curv;
+  }
+}
+
 // can the exact-normal pipeline run on this level (same answer on every rank of a sharded level)?
 bool pa_fused2_level_ok(const pa_level* L) {
   static const int env = [] { const char* e = getenv("PA_FUSED2"); return e ? atoi(e) : 1; }();
   static const int march = [] { const char* e = getenv("PA_MARCH"); return e ? atoi(e) : 3; }();
   if (!env || march != 3 || getenv("PA_DBG") || getenv("PA_MTY")) return false;
-  if (!L->fusable || !L->pure_faces) return false;
+  // general BoxArrays (concave coarse-fine corners, faces partly covered by a neighbour) take this pipeline too: their
+  // irregular cells are listed per level and recomputed after the fix-up (k_curv_general).  PA_FUSED2_GENERAL=0: only levels of
+  // pure special faces without concave corners, as before round 4 (A/B; everything else then goes pass by pass)
+  static const int general = [] { const char* e = getenv("PA_FUSED2_GENERAL"); return e ? atoi(e) : 1; }();
+  if (!general && (!L->fusable || !L->pure_faces)) return false;
   const std::vector<DBox>& all = L->gboxes.empty() ? L->boxes : L->gboxes;
   int maxnx = 0;
   for (const DBox& B : all) {
@@ -1146,8 +1400,10 @@ int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, d
 // crse_n[l]: the coarser level's output (normal components from cncomp0) or this rank's coarse-source copy of them.
 // nslots > 1: components pcomp .. pcomp + nslots - 1, slot z with outputs at ncomp0 + 8 z / kcomp + 8 z, coarse normals at
 // cncomp0 + cn_z z, progress range prog[2 z], prog[2 z + 1] (device): one launch each (SlotK)
+// crse_phi[l] (component cpcomp + slot): the coarse progress source behind level l's coarse-fine faces, as handed to
+// pa_gradcurv_prep_levels -- the irregular cells of general BoxArrays rebuild ghost normals from it (k_curv_general)
 int pa_gradcurv_fix_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, const pa_mf* const* crse_n, int cncomp0, const int32_t bc[3], double pmin, double pmax,
-                           pa_mf* const* out, int ncomp0, int kcomp, double thr, int nslots, const double* prog, int cn_z) {
+                           pa_mf* const* out, int ncomp0, int kcomp, double thr, int nslots, const double* prog, int cn_z, const pa_mf* const* crse_phi, int cpcomp) {
   SlotK sk;
   sk.prog = prog;
   sk.cn_z = cn_z;
@@ -1209,6 +1465,26 @@ int pa_gradcurv_fix_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, 
       PA_HIP(hipEventRecord(ctx->fix_evs[1], pst));
       PA_HIP(hipStreamWaitEvent(ctx->stream, ctx->fix_evs[1], 0));
     }
+  }
+  // general BoxArrays: the listed irregular cells, after (and over) whatever the kernels above wrote there
+  for (int l = 0; l < nlev; ++l) {
+    const pa_level* L = phi[l]->lev;
+    if (L->boxes.empty()) continue;
+    if (level_irregular(ctx, L)) return 1;
+    if (L->nirr == 0) continue;
+    GenLev G;
+    G.L = L->view; G.MP = phi[l]->view; G.pcomp = pcomp;
+    const pa_mf* cp = crse_phi ? crse_phi[l] : nullptr;
+    G.LCp = cp ? cp->lev->view : L->view; G.MCp = cp ? cp->view : phi[l]->view; G.cpcomp = cpcomp;
+    G.LCn = crse_n[l] ? crse_n[l]->lev->view : L->view; G.MCn = crse_n[l] ? crse_n[l]->view : phi[l]->view; G.cncomp0 = cncomp0;
+    G.MO = out[l]->view; G.ncomp0 = ncomp0; G.kcomp = kcomp;
+    for (int d = 0; d < 3; ++d) G.A.bc[d] = bc[d];
+    G.A.ratio = 2; G.A.has_crse = (crse_n[l] && cp) ? 1 : 0; G.A.thr = clip ? thr : -1.0; G.A.layers = 1; G.A.perim_only = 0; G.A.pmin = pmin; G.A.invd = 1.0 / (pmax - pmin);
+    G.items = (const int4*)L->d_irr; G.n = L->nirr;
+    ProfScope prof(ctx, PA_TAG_GRADCURV_FACES);
+    const dim3 gg((unsigned)std::min((L->nirr + 63) / 64, 65535), 1, (unsigned)nslots);
+    if (clip) hipLaunchKernelGGL(k_curv_general<true>, gg, dim3(64), 0, ctx->stream, G, ctx->d_flags, sk);
+    else hipLaunchKernelGGL(k_curv_general<false>, gg, dim3(64), 0, ctx->stream, G, ctx->d_flags, sk);
   }
   PA_HIP(hipGetLastError());
   return 0;

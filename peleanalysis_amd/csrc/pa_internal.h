@@ -147,6 +147,11 @@ struct pa_level {
   double* d_cg = nullptr;   // allocated on first use (pa_level_cg)
   long long cg_total = 0;
   std::vector<long long> cgoff;
+  // Irregular cells (pa_fused.hip: k_find_irregular / k_curv_general): boundary cells of local boxes next to a concave
+  // coarse-fine corner or to the line where a box face changes from covered to coarse-fine, whose curvature neither the
+  // sweep nor the face fix-up gets right; recomputed one by one through a geometry-independent path.  Built on first use.
+  void* d_irr = nullptr;    // int4 {box, i, j, k}
+  int nirr = -1;            // -1: not built yet
   int nremote = 0;          // boxes of this level owned by other ranks (pa_level_create_sharded)
   DLevelView view;
   // ---- sharding (pa_level_create_sharded): the level's whole BoxArray and its DistributionMapping; `boxes` are the

@@ -19,7 +19,8 @@ int pa_gradcurv_prep_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int comp, 
 int pa_gradcurv_level_cg(pa_ctx* ctx, const pa_mf* phi, int pcomp, double pmin, double pmax, pa_mf* out, int ocomp, double thr = -1.0, int slot = 0);
 int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, double pmin, double pmax, pa_mf* const* out, int ocomp, double thr = -1.0, int slot = 0);
 int pa_gradcurv_fix_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, const pa_mf* const* crse_n, int cncomp0, const int32_t bc[3], double pmin, double pmax,
-                           pa_mf* const* out, int ncomp0, int kcomp, double thr = -1.0, int nslots = 1, const double* prog = nullptr, int cn_z = 8);
+                           pa_mf* const* out, int ncomp0, int kcomp, double thr = -1.0, int nslots = 1, const double* prog = nullptr, int cn_z = 8,
+                           const pa_mf* const* crse_phi = nullptr, int cpcomp = 0);
 int pa_gauss_curv_level(pa_ctx* ctx, const pa_mf* G, int gcomp, const pa_mf* normgrad, int ngcomp, const pa_mf* c, int ccomp, double thr, pa_mf* out,
                         int kcomp);
 int pa_strain_level(pa_ctx* ctx, const pa_mf* u, int ucomp, pa_mf* out, int srcomp, int rostcomp);
@@ -325,7 +326,7 @@ static int fused_passes_dist(pa_ctx* ctx, int nlev, pa_mf* const* state, int com
       PA_HIP(hipEventRecord(ctx->sync_evs[2], C));
       PA_HIP(hipStreamWaitEvent(A, ctx->sync_evs[2], 0));
     }
-    PA_TRY(pa_gradcurv_fix_levels(ctx, nlev, state, comp, crse_n.data(), 0, bc, pmin, pmax, out, ocomp + 4, ocomp + 7, thr));
+    PA_TRY(pa_gradcurv_fix_levels(ctx, nlev, state, comp, crse_n.data(), 0, bc, pmin, pmax, out, ocomp + 4, ocomp + 7, thr, 1, nullptr, 8, crse.data(), 0));
     return 0;
   }
   {
@@ -443,16 +444,14 @@ static int fused_passes_conc(pa_ctx* ctx, int nlev, pa_mf* const* state, int com
   return 0;
 }
 
+static bool exact_ok(int nlev, pa_mf* const* state, double thr);
 static int fused_passes(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, const int32_t bc[3], double pmin, double pmax, double thr,
                         pa_mf* const* work, pa_mf* const* out, int ocomp) {
   for (int l = 0; l < nlev; ++l)
     if (state[l]->ng < 2 || work[l]->ng < 2) return pa_fail(ctx, "fused grad->curvature needs 2 ghost layers on state and work");
   // exact-normal pipeline (pa_fused.hip): pure special faces, boxes wider than 32 cells; with the threshold clip the sweep
   // zeroes N and K itself and the one-layer fix-up recomputes the (few) clipped normals it needs (PA_FUSED2_CLIP=0: first pipeline)
-  const char* c2e = getenv("PA_FUSED2_CLIP");  // read per pass (tests, tools/ab_driver.py)
-  const int clip2 = c2e ? atoi(c2e) : 1;
-  bool exact = !(thr >= 0.0) || clip2;
-  for (int l = 0; l < nlev; ++l) exact = exact && pa_fused2_level_ok(state[l]->lev);
+  const bool exact = exact_ok(nlev, state, thr);
   if (state[0]->lev->nranks > 1) return fused_passes_dist(ctx, nlev, state, comp, bc, pmin, pmax, thr, work, out, ocomp, exact);
   if (exact) {
     // 3 + nlev launches per pass: ghost cells of every level (one launch), resolved ghost c (two), the sweeps, the curvature
@@ -495,7 +494,7 @@ static int fused_passes(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, co
     if (pov) PA_HIP(hipStreamWaitEvent(ctx->stream, ctx->sync_evs[1], 0));
     if (!(pov && ring_side)) PA_TRY(pa_gradcurv_prep_levels(ctx, nlev, state, comp, crse.data(), comp, bc, pmin, pmax, pov ? 2 : 3));
     PA_TRY(pa_gradcurv_levels_cg(ctx, nlev, state, comp, pmin, pmax, out, ocomp, thr));
-    PA_TRY(pa_gradcurv_fix_levels(ctx, nlev, state, comp, crse_n.data(), ocomp + 4, bc, pmin, pmax, out, ocomp + 4, ocomp + 7, thr));
+    PA_TRY(pa_gradcurv_fix_levels(ctx, nlev, state, comp, crse_n.data(), ocomp + 4, bc, pmin, pmax, out, ocomp + 4, ocomp + 7, thr, 1, nullptr, 8, crse.data(), comp));
     return 0;
   }
   if (nlev >= 2 && !overlap_on() && conc_on(nlev, state)) return fused_passes_conc(ctx, nlev, state, comp, bc, pmin, pmax, thr, work, out, ocomp);
@@ -552,6 +551,14 @@ static bool all_fusable(int nlev, pa_mf* const* state) {
   return true;
 }
 
+// can the exact-normal pipeline take this hierarchy (the same answer on every rank)?
+static bool exact_ok(int nlev, pa_mf* const* state, double thr) {
+  const char* c2e = getenv("PA_FUSED2_CLIP");  // read per pass (tests, tools/ab_driver.py)
+  bool exact = !(thr >= 0.0) || !c2e || atoi(c2e);
+  for (int l = 0; l < nlev; ++l) exact = exact && state[l]->ng >= 2 && pa_fused2_level_ok(state[l]->lev);
+  return exact;
+}
+
 extern "C" int pa_curvature_run(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, const int32_t bc[3], const pa_curv_params* P,
                                 pa_mf* const* out, int ocomp) {
   PaBind bind_(ctx);
@@ -577,11 +584,13 @@ extern "C" int pa_gradcurv_run(pa_ctx* ctx, int nlev, pa_mf* const* state, int c
   double pmin, pmax;
   PA_TRY(prog_minmax(ctx, nlev, state, comp, P, pmin, pmax));
   const double thr = P->do_threshold ? P->threshold : -1.0;
-  if (P->fused && P->spacedim != 2 && all_fusable(nlev, state)) {
+  // exact-normal pipeline: any BoxArray of boxes >= 3 cells thick (irregular cells are listed and recomputed, pa_fused.hip);
+  // first pipeline (A/B switches only): hierarchies without concave coarse-fine corners
+  if (P->fused && P->spacedim != 2 && (exact_ok(nlev, state, thr) || all_fusable(nlev, state))) {
     PA_TRY(check_levels(ctx, nlev, work, "pa_gradcurv_run"));
     return fused_passes(ctx, nlev, state, comp, bc, pmin, pmax, thr, work, out, ocomp);
   }
-  // general AMR (concave coarse-fine corners, very thin boxes) or fused=0: pass by pass
+  // boxes thinner than 3 cells, 2-D levels or fused=0: pass by pass
   PA_TRY(pa_grad_run(ctx, nlev, state, comp, bc, out, ocomp));
   return curvature_passes(ctx, nlev, state, comp, bc, pmin, pmax, thr, out, -1, ocomp + 7, ocomp + 4, nullptr, -1, P->spacedim == 2 ? 1.0 : 0.5);
 }
@@ -608,9 +617,7 @@ extern "C" int pa_gradcurv_run_comps2(pa_ctx* ctx, int nlev, pa_mf* const* state
   for (int l = 0; l < nlev; ++l)
     if (ocomp < 0 || ocomp + 8 * nbatch > out[l]->ncomp) return pa_fail(ctx, "pa_gradcurv_run_comps: out needs 8 components per slot of the batch");
   const double thr = P->do_threshold ? P->threshold : -1.0;
-  const char* c2e = getenv("PA_FUSED2_CLIP");
-  bool exact = P->fused && P->spacedim != 2 && all_fusable(nlev, state) && (!(thr >= 0.0) || !c2e || atoi(c2e));
-  for (int l = 0; l < nlev; ++l) exact = exact && pa_fused2_level_ok(state[l]->lev) && state[l]->ng >= 2;
+  const bool exact = P->fused && P->spacedim != 2 && exact_ok(nlev, state, thr);
   if (!exact || ncomps == 1) {
     for (int c = comp0; c < comp0 + ncomps; ++c) {
       PA_TRY(pa_gradcurv_run(ctx, nlev, state, c, bc, P, work, out, ocomp));
@@ -672,7 +679,7 @@ extern "C" int pa_gradcurv_run_comps2(pa_ctx* ctx, int nlev, pa_mf* const* state
       PA_TRY(pa_xexchange(ctx, (int)jobs.size(), jobs.data()));
     }
     PA_TRY(pa_gradcurv_fix_levels(ctx, nlev, state, g0, crse_n.data(), dist ? 0 : ocomp + 4, bc, pmins[0], pmaxs[0], out, ocomp + 4, ocomp + 7, thr, ns, ctx->d_prog,
-                                  dist ? 3 : 8));
+                                  dist ? 3 : 8, crse.data(), dist ? g0 - comp0 : g0));
     for (int z = 0; z < ns; ++z)
       if (done && done(user, g0 + z, ocomp + 8 * z) != 0) return pa_fail(ctx, "pa_gradcurv_run_comps: the caller's callback failed");
   }

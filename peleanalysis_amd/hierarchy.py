@@ -197,3 +197,133 @@ def field_flame(x, y, z, m: int = 0):
     phi = np.arccos(np.clip(zc / rho, -1.0, 1.0))
     s = r - 0.03 * np.sin(6 * theta) * np.sin(5 * phi)
     return (1.0 + 0.1 * m) * (300.0 + 850.0 * (1.0 + np.tanh((s - 1.0) / 0.08))) + 3.0 * m * np.sin(2 * np.pi * (x + 0.37 * m))
+
+
+# ----------------------------------------------------------------------------- general (non-convex) BoxArrays
+# What a Pele plotfile's fine levels look like: unions of rectangles -- L / T shapes, disjoint patches, box faces that are
+# partly covered by a neighbour and partly coarse-fine, concave coarse-fine corners (the reference runs the same MLPoisson /
+# FillBoundary code on whatever BoxArray the file holds, grad.cpp:173-213, curvature.cpp:426-457).
+def _occupancy(level: Level) -> np.ndarray:
+    """bool[nz, ny, nx] over the level's domain: valid cells"""
+    n = level.domhi - level.domlo + 1
+    occ = np.zeros((int(n[2]), int(n[1]), int(n[0])), dtype=bool)
+    for lo0, lo1, lo2, hi0, hi1, hi2 in level.boxes - np.concatenate([level.domlo, level.domlo]):
+        occ[lo2:hi2 + 1, lo1:hi1 + 1, lo0:hi0 + 1] = True
+    return occ
+
+
+def _nested_blocks(U: np.ndarray, s: int, occ: np.ndarray, is_per, buf: int = 2) -> np.ndarray:
+    """drop the blocks (s coarse cells per side, bool[bz, by, bx]) whose `buf`-cell halo is not valid coarse data: proper
+    nesting -- the fine ghost cells (2 layers = 1 coarse cell) and the +-1 (one-sided: 2) coarse cells of the coarse-fine
+    interpolation stencils must find coarse values.  Cells beyond a wall do not count, periodic directions wrap."""
+    nz, ny, nx = occ.shape
+    out = U.copy()
+    for bk, bj, bi in np.argwhere(U):
+        idx = []
+        ok = True
+        for d, (b, n) in enumerate(((bi, nx), (bj, ny), (bk, nz))):
+            r = np.arange(b * s - buf, (b + 1) * s + buf)
+            if is_per[d]:
+                r = r % n
+            else:
+                r = r[(r >= 0) & (r < n)]
+            idx.append(r)
+        if not occ[np.ix_(idx[2], idx[1], idx[0])].all():
+            ok = False
+        out[bk, bj, bi] = ok
+    return out
+
+
+def blocks_to_boxes(U: np.ndarray, s: int, max_blocks, rng=None) -> np.ndarray:
+    """greedy merge of a block mask (bool[bz, by, bx], s cells per block side) into boxes of at most max_blocks blocks per
+    direction: grow in x, then y, then z while every block is set and unassigned (what a grid generator's chop + merge gives)"""
+    U = U.copy()
+    bz, by, bx = U.shape
+    mb = np.broadcast_to(np.asarray(max_blocks), (3,))
+    boxes = []
+    for k in range(bz):
+        for j in range(by):
+            for i in range(bx):
+                if not U[k, j, i]:
+                    continue
+                lim = [int(rng.integers(1, m + 1)) if rng is not None else int(m) for m in mb]
+                i1 = i
+                while i1 + 1 < bx and i1 + 1 - i < lim[0] and U[k, j, i1 + 1]:
+                    i1 += 1
+                j1 = j
+                while j1 + 1 < by and j1 + 1 - j < lim[1] and U[k, j1 + 1, i:i1 + 1].all():
+                    j1 += 1
+                k1 = k
+                while k1 + 1 < bz and k1 + 1 - k < lim[2] and U[k1 + 1, j:j1 + 1, i:i1 + 1].all():
+                    k1 += 1
+                U[k:k1 + 1, j:j1 + 1, i:i1 + 1] = False
+                boxes.append([i * s, j * s, k * s, (i1 + 1) * s - 1, (j1 + 1) * s - 1, (k1 + 1) * s - 1])
+    return np.asarray(boxes, dtype=np.int32).reshape(-1, 6)
+
+
+def union_hierarchy(seed: int, nlev: int = 3, n0=None, is_per=None, nrect=(2, 5), block=(2, 5), max_blocks=3, base_box=None) -> Hierarchy:
+    """random hierarchy whose fine levels are UNIONS of 2-4 rectangles of blocks (ratio 2): L / T shapes, disjoint patches,
+    partly covered faces, concave coarse-fine corners; properly nested (2 coarse cells of buffer, or flush with the domain)"""
+    rng = np.random.default_rng(seed)
+    n = np.asarray(n0 if n0 is not None else rng.integers(12, 33, size=3), dtype=np.int64)
+    per = np.asarray(is_per if is_per is not None else rng.integers(0, 2, size=3))
+    dom_hi = n - 1
+    size0 = int(base_box if base_box is not None else rng.integers(6, 20))
+    levels = [Level(chop_box((0, 0, 0), dom_hi, size0), (0, 0, 0), dom_hi, per, np.zeros(3), np.ones(3))]
+    for l in range(1, nlev):
+        crse = levels[-1]
+        occ = _occupancy(crse)
+        cn = crse.domhi - crse.domlo + 1
+        s = int(rng.integers(block[0], block[1]))  # coarse cells per block side
+        nb = cn // s
+        if np.any(nb < 3):
+            break
+        U = np.zeros((int(nb[2]), int(nb[1]), int(nb[0])), dtype=bool)
+        # rectangles around where the coarse level has data
+        where = np.argwhere(occ)
+        clo, chi = where.min(axis=0)[::-1] // s, where.max(axis=0)[::-1] // s
+        for _ in range(int(rng.integers(nrect[0], nrect[1]))):
+            a = np.array([rng.integers(clo[d], chi[d] + 1) for d in range(3)])
+            e = np.array([rng.integers(1, max(2, (chi[d] - clo[d] + 1) // 2 + 1)) for d in range(3)])
+            b = np.minimum(a + e, nb) - 1
+            U[a[2]:b[2] + 1, a[1]:b[1] + 1, a[0]:b[0] + 1] = True
+        U = _nested_blocks(U, s, occ, per)
+        if not U.any():
+            break
+        boxes = blocks_to_boxes(U, 2 * s, max_blocks, rng)
+        domhi_f = 2 * (crse.domhi + 1) - 1
+        levels.append(Level(boxes, (0, 0, 0), domhi_f, per, np.zeros(3), np.ones(3)))
+    return Hierarchy(levels, 2)
+
+
+def tagged_hierarchy(base_n: int, nlev: int, fn, bf: int = 16, max_box: int = 128, frac=(0.30, 0.30), base_box: int = 128, is_per=(1, 1, 0),
+                     seed: int = 0) -> Hierarchy:
+    """an irregular hierarchy the way a Pele run makes one: level l + 1 covers the blocks of bf coarse cells (blocking factor
+    2 bf on the fine level) where |grad fn| at the block centre is among the largest `frac[l-1]` of the level's blocks,
+    properly nested, merged into boxes of 2 bf .. max_box cells per side (random sizes: the mix a grid generator's
+    efficiency-driven chopping leaves)."""
+    rng = np.random.default_rng(seed)
+    per = np.asarray(is_per)
+    n = np.full(3, base_n, dtype=np.int64)
+    levels = [Level(chop_box((0, 0, 0), n - 1, base_box), (0, 0, 0), n - 1, per, np.zeros(3), np.ones(3))]
+    for l in range(1, nlev):
+        crse = levels[-1]
+        occ = _occupancy(crse)
+        cn = crse.domhi - crse.domlo + 1
+        nb = (cn // bf).astype(int)
+        h = 1.0 / float(cn[0])
+        c = (np.arange(nb[0]) + 0.5) * bf * h
+        X, Y, Z = c[None, None, :], c[None, :, None], c[:, None, None]
+        e = 0.5 * h
+        g = np.sqrt((fn(X + e, Y, Z) - fn(X - e, Y, Z)) ** 2 + (fn(X, Y + e, Z) - fn(X, Y - e, Z)) ** 2 + (fn(X, Y, Z + e) - fn(X, Y, Z - e)) ** 2)
+        g = np.broadcast_to(g, (nb[2], nb[1], nb[0])).copy()
+        covered = occ[bf // 2::bf, bf // 2::bf, bf // 2::bf][:nb[2], :nb[1], :nb[0]]
+        g[~covered] = -1.0
+        k = max(1, int(frac[min(l - 1, len(frac) - 1)] * covered.sum()))
+        thr = np.sort(g.ravel())[-k]
+        U = _nested_blocks((g >= thr) & covered, bf, occ, per)
+        if not U.any():
+            break
+        boxes = blocks_to_boxes(U, 2 * bf, max(1, max_box // (2 * bf)), rng)
+        levels.append(Level(boxes, (0, 0, 0), 2 * (crse.domhi + 1) - 1, per, np.zeros(3), np.ones(3)))
+    return Hierarchy(levels, 2)

@@ -44,7 +44,8 @@ def _worker(rank, world, port, case):
         per, sym = ((1, 1, 0), (0, 0, 0)) if case != "sym" else ((0, 1, 1), (1, 0, 0))
         if case.startswith("rand"):  # randomly drawn hierarchies (tests/test_gpu_random.py): odd extents, uneven chops, levels with
             import test_gpu_random as R  # fewer boxes than ranks (some ranks own nothing there), every boundary-condition mix
-            H, per, sym, _fn = (R._draw_wide if case[4] == "w" else R._draw)(int(case[5:] if case[4] == "w" else case[4:]))
+            draw = {"w": R._draw_wide, "u": R._union_case, "U": R._union_wide_case}.get(case[4])  # u / U: general BoxArrays (unions of rectangles)
+            H, per, sym, _fn = draw(int(case[5:])) if draw else R._draw(int(case[4:]))
         else:
             H = nested_hierarchy(16, 3, 8, is_per=per) if case != "wide" else nested_hierarchy(80, 3, 40, is_per=per)  # wide: the exact-normal pipeline
         owners = [scattered_owner(lv.nboxes, world, 31 + l) if case != "sfc" else padist.distribution_map(lv.boxes, world) for l, lv in enumerate(H.levels)]
@@ -161,7 +162,7 @@ _HUNT = int(os.environ.get("PA_DIST_RANDOM_SEEDS", "0"))  # PA_DIST_RANDOM_SEEDS
 
 
 @pytest.mark.parametrize("world,case", [(2, "scatter"), (4, "scatter"), (4, "thr"), (2, "sym"), (4, "sfc"), (4, "wide"), (2, "wide"), (3, "rand2"), (4, "rand5"),
-                                        (3, "rand11"), (3, "randw1"), (4, "randw4")] + [(2 + s % 3, ("randw" if s % 4 == 3 else "rand") + str(20 + s)) for s in range(_HUNT)])
+                                        (3, "rand11"), (3, "randw1"), (4, "randw4"), (3, "randu0"), (4, "randu13"), (2, "randu21"), (3, "randU0"), (4, "randU4")] + [(2 + s % 3, ("randw" if s % 4 == 3 else "rand") + str(20 + s)) for s in range(_HUNT)])
 def test_sharded_hierarchy_on_shared_gpu_matches_undistributed_oracle(world, case):
     import torch.multiprocessing as mp
     mp.spawn(_worker, args=(world, _free_port(), case), nprocs=world, join=True)

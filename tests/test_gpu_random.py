@@ -237,3 +237,127 @@ def test_random_wide_box_hierarchy_matches_oracle(ctx, oracle, seed):
         got = dout[l].download()
         assert_valid_bits_equal(got, og[l], [(c, c) for c in range(4)], f"{tag} grad level {l}")
         assert_valid_bits_equal(got, oc[l], [(4, 2), (5, 3), (6, 4), (7, 1)], f"{tag} curv level {l}")
+
+
+# ------------------------------------------------------------------------------------------- general BoxArrays
+from peleanalysis_amd.hierarchy import union_hierarchy  # noqa: E402
+
+NUNION = int(os.environ.get("PA_RANDOM_UNION_SEEDS", "24"))
+
+
+def _union_case(seed):
+    H = union_hierarchy(7000 + seed)
+    rng = np.random.default_rng(9000 + seed)
+    per = tuple(int(x) for x in H.levels[0].is_per)
+    sym = tuple(int(x) for x in np.where(np.asarray(per) == 1, 0, rng.integers(0, 2, size=3)))
+    return H, per, sym, (field_flame if seed % 2 else field_trig)
+
+
+@pytest.mark.parametrize("seed", range(NUNION))
+def test_random_union_hierarchy_matches_oracle(ctx, oracle, seed):
+    """fine levels that are UNIONS of rectangles (L / T shapes, disjoint patches, faces partly covered by a neighbour,
+    concave coarse-fine corners -- what a Pele plotfile holds): the exact-normal pipeline with its irregular-cell list, the
+    pass-by-pass kernels and the gradient tool's pipeline against the oracle, bit for bit, with and without the threshold"""
+    H, per, sym, fn = _union_case(seed)
+    thr = None if seed % 3 else 0.03
+    states = make_states(H, 1, 2, fn, seed=seed)
+    bc = capi.bc_from_flags(per, sym)
+    og = [MultiFab(lv, 4, 0) for lv in H.levels]
+    oracle.grad_pipeline(H.levels, [s.copy() for s in states], 0, bc, og, 0, multipass=True)
+    oc = [MultiFab(lv, 5, 0) for lv in H.levels]
+    oracle.curvature_pipeline(H.levels, [s.copy() for s in states], 0, bc, oc, 0, MultiFab, threshold=thr)
+    tag = f"union seed {seed}: {[tuple(lv.domhi + 1) for lv in H.levels]} per {per} sym {sym} boxes {[lv.nboxes for lv in H.levels]}"
+    for fused in (True, False):
+        dls = [capi.DevLevel(ctx, lv) for lv in H.levels]
+        dst = [capi.DevMF.from_host(ctx, dl, s) for dl, s in zip(dls, states)]
+        work = [capi.DevMF(ctx, dl, 1, 2) for dl in dls]
+        dout = [capi.DevMF(ctx, dl, 8, 0) for dl in dls]
+        capi.gradcurv_run(ctx, dst, 0, bc, capi.curv_params(threshold=thr, fused=fused), work, dout, 0)
+        ctx.sync()
+        assert ctx.bc_errors() == 0, tag
+        if fused:  # the exact-normal pipeline took it, whatever the shape
+            kn = ctx.lib.pa_sweep_kernel_name(ctx.h).decode()
+            assert "CG=1" in kn or kn.startswith("k_gradcurv_march3_levels<"), (tag, kn)
+        for l in range(H.nlev):
+            got = dout[l].download()
+            assert_valid_bits_equal(got, og[l], [(c, c) for c in range(4)], f"{tag} fused {fused} grad level {l}")
+            assert_valid_bits_equal(got, oc[l], [(4, 2), (5, 3), (6, 4), (7, 1)], f"{tag} fused {fused} curv level {l}")
+    dgr = [capi.DevMF(ctx, dl, 4, 0) for dl in dls]
+    capi.grad_run(ctx, dst, 0, bc, dgr, 0)
+    ctx.sync()
+    for l in range(H.nlev):
+        assert_valid_bits_equal(dgr[l].download(), og[l], [(c, c) for c in range(4)], f"{tag} grad_run level {l}")
+
+
+def test_union_hierarchies_have_irregular_cells(ctx):
+    """the draws above do contain what they are for: cells the sweep + face fix-up cannot get right (and the nested, convex
+    hierarchies of the contract configs contain none)"""
+    from peleanalysis_amd.hierarchy import nested_hierarchy
+    tot = 0
+    for seed in range(NUNION):
+        H, _, _, _ = _union_case(seed)
+        for lv in H.levels[1:]:
+            dl = capi.DevLevel(ctx, lv)
+            n = ctx.lib.pa_level_irregular_cells(ctx.h, dl.h)
+            assert n >= 0
+            tot += n
+    assert tot > 500, tot
+    H = nested_hierarchy(32, 3, 16, is_per=(1, 1, 0))
+    for lv in H.levels:
+        assert ctx.lib.pa_level_irregular_cells(ctx.h, capi.DevLevel(ctx, lv).h) == 0
+
+
+def _union_wide_case(seed):
+    """unions of rectangles with boxes wider than 32 cells (the wide sweep kernel, several levels per launch): blocks of
+    6-12 coarse cells, boxes of 1-4 blocks along x"""
+    for attempt in range(50):
+        rng = np.random.default_rng(11000 + seed + 1000 * attempt)
+        n0 = np.array([int(rng.integers(9, 13)) * 8, int(rng.integers(4, 7)) * 8, int(rng.integers(4, 6)) * 8])
+        per = rng.integers(0, 2, size=3)
+        H = union_hierarchy(12000 + seed + 1000 * attempt, nlev=3, n0=n0, is_per=per, nrect=(2, 5), block=(8, 13) if seed % 2 else (6, 9), max_blocks=(4, 2, 2),
+                            base_box=int(rng.integers(40, 60)))
+        if H.nlev >= 2 and all(int((lv.boxes[:, 3] - lv.boxes[:, 0]).max()) + 1 > 32 for lv in H.levels):
+            break
+    sym = tuple(int(x) for x in np.where(per == 1, 0, rng.integers(0, 2, size=3)))
+    return H, tuple(int(x) for x in per), sym, (field_flame if seed % 2 else field_trig)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PA_RANDOM_UNION_WIDE_SEEDS", "8"))))
+def test_random_union_wide_box_hierarchy_matches_oracle(ctx, oracle, seed):
+    """general BoxArrays with boxes up to 4 blocks wide: the wide sweep kernel (one launch for all levels where the levels
+    agree on the tile shape) + irregular-cell list; single component, then two components as one batch (component slots of
+    the boundary kernels and of k_curv_general)"""
+    H, per, sym, fn = _union_wide_case(seed)
+    assert H.nlev >= 2
+    thr = None if seed % 2 else 0.04
+    states = make_states(H, 2, 2, fn, seed=seed)
+    bc = capi.bc_from_flags(per, sym)
+    tag = f"union-wide seed {seed}: {[tuple(lv.domhi + 1) for lv in H.levels]} per {per} sym {sym} boxes {[(lv.nboxes, int((lv.boxes[:, 3] - lv.boxes[:, 0]).max()) + 1) for lv in H.levels]}"
+    og, oc = [], []
+    for c in range(2):
+        og.append([MultiFab(lv, 4, 0) for lv in H.levels])
+        oc.append([MultiFab(lv, 5, 0) for lv in H.levels])
+        oracle.grad_pipeline(H.levels, [s.copy() for s in states], c, bc, og[c], 0, multipass=False)
+        oracle.curvature_pipeline(H.levels, [s.copy() for s in states], c, bc, oc[c], 0, MultiFab, threshold=thr)
+    dls = [capi.DevLevel(ctx, lv) for lv in H.levels]
+    dst = [capi.DevMF.from_host(ctx, dl, s) for dl, s in zip(dls, states)]
+    work = [capi.DevMF(ctx, dl, 1, 2) for dl in dls]
+    dout = [capi.DevMF(ctx, dl, 16, 0) for dl in dls]
+    nirr = sum(ctx.lib.pa_level_irregular_cells(ctx.h, dl.h) for dl in dls)
+    capi.gradcurv_run(ctx, dst, 0, bc, capi.curv_params(threshold=thr, fused=True), work, dout, 0)
+    ctx.sync()
+    assert ctx.bc_errors() == 0, tag
+    kn = ctx.lib.pa_sweep_kernel_name(ctx.h).decode()
+    assert "CG=1" in kn or kn.startswith("k_gradcurv_march3_levels<"), (tag, kn)
+    for l in range(H.nlev):
+        got = dout[l].download()
+        assert_valid_bits_equal(got, og[0][l], [(c, c) for c in range(4)], f"{tag} ({nirr} irregular cells) grad level {l}")
+        assert_valid_bits_equal(got, oc[0][l], [(4, 2), (5, 3), (6, 4), (7, 1)], f"{tag} ({nirr} irregular cells) curv level {l}")
+    capi.gradcurv_run_comps2(ctx, dst, 0, 2, bc, capi.curv_params(threshold=thr, fused=True), work, dout, 0, 2)
+    ctx.sync()
+    assert ctx.bc_errors() == 0, tag
+    for l in range(H.nlev):
+        got = dout[l].download()
+        for c in range(2):
+            assert_valid_bits_equal(got, og[c][l], [(8 * c + q, q) for q in range(4)], f"{tag} batch comp {c} grad level {l}")
+            assert_valid_bits_equal(got, oc[c][l], [(8 * c + 4, 2), (8 * c + 5, 3), (8 * c + 6, 4), (8 * c + 7, 1)], f"{tag} batch comp {c} curv level {l}")
