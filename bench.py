@@ -141,7 +141,7 @@ def live_traffic(timeout_s=150):
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="pa_pmc_", dir="/tmp")
         try:
-            subprocess.run(["rocprofv3", "--pmc", ctr, "--output-format", "csv", "-d", d, "--", "python3", os.path.join(ROOT, "tools", "prof_driver.py"), "512", "128", "2"],
+            subprocess.run(["rocprofv3", "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.join(ROOT, "tools", "prof_driver.py"), "512", "128", "2"],
                            stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, env=env, cwd=ROOT, check=True)
             tot, ids = 0.0, set()
             for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
@@ -159,7 +159,7 @@ def live_traffic(timeout_s=150):
     return int(2.0 * per["FETCH_SIZE"] + per["WRITE_SIZE"]), "measured in this run: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE -- python3 tools/prof_driver.py 512 128 2 (FETCH x2)"
 
 
-def secondary(ctx, torch, stream, dev):
+def secondary(ctx, torch, stream, dev, only=None):
     """The other kernel families of the path in front of the driver (N = 1 only, after the timed headline region; a few
     seconds in all): BASELINE configs 2, 3 and 4, the gradient alone, and the headline hierarchy in 64^3 and 32^3 boxes.
     Each entry: wall-clock ms per pass on the library's stream (launches + stream sync, second and third pass), the
@@ -199,6 +199,9 @@ def secondary(ctx, torch, stream, dev):
 
     out = {}
 
+    def want(name):  # --secondary-only <name>: one entry (kernel work on one family without the rest of the bench)
+        return only is None or only == name
+
     def gradcurv_case(name, base, nlev, box, ncomp, per, nbatch=1):
         H = nested_hierarchy(base, nlev, box, is_per=per)
         dls = [capi.DevLevel(ctx, lv) for lv in H.levels]
@@ -218,113 +221,161 @@ def secondary(ctx, torch, stream, dev):
         return H, dls, keep, st
 
     # BASELINE config 2: single level 512^3, 10 components
-    h = gradcurv_case("c2_1lev_512_10comp", 512, 1, 128, 10, (1, 1, 1))
-    del h
-    torch.cuda.empty_cache()
+    if want("c2_1lev_512_10comp"):
+        h = gradcurv_case("c2_1lev_512_10comp", 512, 1, 128, 10, (1, 1, 1))
+        del h
+        torch.cuda.empty_cache()
     # BASELINE config 5's shape on one GPU, 8 of its 55 components: 4 levels of 256^3 cells in 64^3 boxes, components in one batch
-    h = gradcurv_case("c5_shape_4lev_256_8comp", 256, 4, 64, 8, (1, 1, 0), nbatch=8)
-    del h
-    torch.cuda.empty_cache()
+    if want("c5_shape_4lev_256_8comp"):
+        h = gradcurv_case("c5_shape_4lev_256_8comp", 256, 4, 64, 8, (1, 1, 0), nbatch=8)
+        del h
+        torch.cuda.empty_cache()
     # the headline hierarchy in smaller boxes
     for box in (64, 32):
+        if not want(f"headline_box{box}"):
+            continue
         h = gradcurv_case(f"headline_box{box}", 512, 3, box, 1, (1, 1, 0))
         del h
         torch.cuda.empty_cache()
-    # the gradient alone on the headline hierarchy (grad.cpp:211-236; 40 B/cell)
-    H = nested_hierarchy(512, 3, 128, is_per=(1, 1, 0))
-    dls = [capi.DevLevel(ctx, lv) for lv in H.levels]
-    ins = [alloc(lv, dl, 1, 1, "flame", 5 + li) for li, (lv, dl) in enumerate(zip(H.levels, dls))]
-    gos = [alloc(lv, dl, 4, 0) for lv, dl in zip(H.levels, dls)]
-    stream.synchronize()
-    bc = capi.bc_from_flags((1, 1, 0))
-    ms = timed(lambda: capi.grad_run(ctx, [a[1] for a in ins], 0, bc, [g[1] for g in gos], 0))
-    out["grad_only_headline"] = entry(ms, sum(lv.ncells for lv in H.levels), 40, workload="grad (ghost fills + k_grad_march), 3-level base 512^3, 128^3 boxes, 1 comp")
-    del ins, gos, dls, H
-    torch.cuda.empty_cache()
+    def irregular_case():
+        # An IRREGULAR hierarchy, what a Pele plotfile holds (grad.cpp:173-213 / curvature.cpp:426-457 run on whatever BoxArray the
+        # file has): the headline field on a 512^3 base, finer levels tagged where |grad T| is largest -- the wrinkled flame sheet --
+        # in blocks of 32 fine cells, merged into boxes of 32 .. 128 cells per side.  L-shaped regions, faces that are partly
+        # covered by a neighbour and partly coarse-fine, concave coarse-fine corners; the irregular cells go through k_curv_general.
+        from peleanalysis_amd.hierarchy import tagged_hierarchy, field_flame
+        Hi = tagged_hierarchy(512, 3, lambda x, y, z: field_flame(x, y, z, 0), bf=16, max_box=128, base_box=128, frac=(0.08, 0.16), is_per=(1, 1, 0))
+        dli = [capi.DevLevel(ctx, lv) for lv in Hi.levels]
+        keep, st, wk, ou = [], [], [], []
+        for li, (lv, dl) in enumerate(zip(Hi.levels, dli)):
+            a, b_, c_ = alloc(lv, dl, 1, 2, "flame", 177 + li), alloc(lv, dl, 1, 2), alloc(lv, dl, 8, 0)
+            keep += [a[0], b_[0], c_[0]]
+            st.append(a[1]); wk.append(b_[1]); ou.append(c_[1])
+        stream.synchronize()
+        bci = capi.bc_from_flags((1, 1, 0))
+        pari = capi.curv_params(prog_min=300.0, prog_max=2003.0, threshold=None, fused=True)
+        nirr = [int(ctx.lib.pa_level_irregular_cells(ctx.h, dl.h)) for dl in dli]
+        ms = timed(lambda: capi.gradcurv_run(ctx, st, 0, bci, pari, wk, ou, 0))
+        assert ctx.bc_errors() == 0
+        kn = ctx.lib.pa_sweep_kernel_name(ctx.h).decode()
+        ms_pp = timed(lambda: capi.gradcurv_run(ctx, st, 0, bci, capi.curv_params(prog_min=300.0, prog_max=2003.0, threshold=None, fused=False), wk, ou, 0), reps=1)
+        ci = sum(lv.ncells for lv in Hi.levels)
+        widths = [np.bincount(((lv.boxes[:, 3] - lv.boxes[:, 0] + 1) // 32).astype(int), minlength=5)[1:5].tolist() for lv in Hi.levels]
+        out["irregular_amr"] = entry(ms, ci, 72, boxes_per_level=[lv.nboxes for lv in Hi.levels], cells_per_level=[lv.ncells for lv in Hi.levels],
+                                     boxes_32_64_96_128_wide_per_level=widths, irregular_cells_per_level=nirr, irregular_cell_share=sum(nirr) / ci,
+                                     share_of_boxes_on_fused_pipeline=1.0 if ("CG=1" in kn or "march3_levels" in kn) else 0.0, sweep_kernel=kn,
+                                     pass_by_pass_ms=ms_pp, pass_by_pass_frac_hbm=ci * 72 / (ms_pp * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                     workload="fused grad->curvature, 3-level AMR, base 512^3, levels 1-2 = the blocks of 32 fine cells with the largest |grad T| (8 % / 16 % of "
+                                              "the coarser level's blocks: the wrinkled flame sheet), boxes of 32..128 cells per side, 1 comp, periodic x/y + wall z; "
+                                              "pass_by_pass_ms = the same hierarchy with fused=0 (the pre-round-4 path for such BoxArrays)")
+        del keep, st, wk, ou, dli, Hi
+        torch.cuda.empty_cache()
+    if want("irregular_amr"):
+        irregular_case()
+    def grad_only_case():
+        # the gradient alone on the headline hierarchy (grad.cpp:211-236; 40 B/cell)
+        H = nested_hierarchy(512, 3, 128, is_per=(1, 1, 0))
+        dls = [capi.DevLevel(ctx, lv) for lv in H.levels]
+        ins = [alloc(lv, dl, 1, 1, "flame", 5 + li) for li, (lv, dl) in enumerate(zip(H.levels, dls))]
+        gos = [alloc(lv, dl, 4, 0) for lv, dl in zip(H.levels, dls)]
+        stream.synchronize()
+        bc = capi.bc_from_flags((1, 1, 0))
+        ms = timed(lambda: capi.grad_run(ctx, [a[1] for a in ins], 0, bc, [g[1] for g in gos], 0))
+        out["grad_only_headline"] = entry(ms, sum(lv.ncells for lv in H.levels), 40, workload="grad (ghost fills + k_grad_march), 3-level base 512^3, 128^3 boxes, 1 comp")
+        del ins, gos, dls, H
+        torch.cuda.empty_cache()
 
-    # BASELINE config 3: filterPlt's ghost fill + box filter (fgr 2 / 4 / 8 on levels 0 / 1 / 2) + grad of the filtered field
-    H = nested_hierarchy(256, 3, 64, is_per=(1, 1, 0))
-    dls = [capi.DevLevel(ctx, lv) for lv in H.levels]
-    ngs, ws = [1, 2, 4], []
-    for f in (2, 4, 8):
-        w = (C.c_double * (f + 2))()
-        assert ctx.lib.pa_box_filter_weights(f, w) == f // 2
-        ws.append(w)
-    fin = [alloc(lv, dl, 1, ngs[l], "flame", 31 + l) for l, (lv, dl) in enumerate(zip(H.levels, dls))]
-    fout = [alloc(lv, dl, 1, 1) for lv, dl in zip(H.levels, dls)]
-    gout = [alloc(lv, dl, 4, 0) for lv, dl in zip(H.levels, dls)]
-    stream.synchronize()
+    if want("grad_only_headline"):
+        grad_only_case()
+    def c3_case():
+        # BASELINE config 3: filterPlt's ghost fill + box filter (fgr 2 / 4 / 8 on levels 0 / 1 / 2) + grad of the filtered field
+        H = nested_hierarchy(256, 3, 64, is_per=(1, 1, 0))
+        bc = capi.bc_from_flags((1, 1, 0))
+        dls = [capi.DevLevel(ctx, lv) for lv in H.levels]
+        ngs, ws = [1, 2, 4], []
+        for f in (2, 4, 8):
+            w = (C.c_double * (f + 2))()
+            assert ctx.lib.pa_box_filter_weights(f, w) == f // 2
+            ws.append(w)
+        fin = [alloc(lv, dl, 1, ngs[l], "flame", 31 + l) for l, (lv, dl) in enumerate(zip(H.levels, dls))]
+        fout = [alloc(lv, dl, 1, 1) for lv, dl in zip(H.levels, dls)]
+        gout = [alloc(lv, dl, 4, 0) for lv, dl in zip(H.levels, dls)]
+        stream.synchronize()
 
-    def ghosts():
+        def ghosts():
+            for l in range(3):
+                ctx.check(ctx.lib.pa_fill_boundary(ctx.h, fin[l][1].h, 0, 1, ngs[l]))
+                if l > 0:
+                    ctx.check(ctx.lib.pa_fillpatch_two_levels(ctx.h, fin[l][1].h, fin[l - 1][1].h, 0, 1, ngs[l], 2, 1))
+                ctx.check(ctx.lib.pa_foextrap(ctx.h, fin[l][1].h, 0, 1, ngs[l]))
+
+        def filt(l):
+            ctx.check(ctx.lib.pa_boxfilter_level(ctx.h, fin[l][1].h, fout[l][1].h, 0, 1, ngs[l], ws[l]))
+
+        def c3_all():
+            ghosts()
+            for l in range(3):
+                filt(l)
+            capi.grad_run(ctx, [f[1] for f in fout], 0, bc, [g[1] for g in gout], 0)
+
+        c3cells = sum(lv.ncells for lv in H.levels)
+        c3 = {"ghost_fill_ms": timed(ghosts)}
         for l in range(3):
-            ctx.check(ctx.lib.pa_fill_boundary(ctx.h, fin[l][1].h, 0, 1, ngs[l]))
-            if l > 0:
-                ctx.check(ctx.lib.pa_fillpatch_two_levels(ctx.h, fin[l][1].h, fin[l - 1][1].h, 0, 1, ngs[l], 2, 1))
-            ctx.check(ctx.lib.pa_foextrap(ctx.h, fin[l][1].h, 0, 1, ngs[l]))
+            m = timed(lambda l=l: filt(l))
+            c3[f"filter_fgr{2 << l}_level{l}"] = entry(m, H.levels[l].ncells, 16)
+        c3["grad_ms"] = timed(lambda: capi.grad_run(ctx, [f[1] for f in fout], 0, bc, [g[1] for g in gout], 0))
+        c3.update(entry(timed(c3_all), c3cells, None, workload="filterPlt ghost fill + separable box filter fgr 2/4/8 + grad, 3-level base 256^3, 64^3 boxes, 1 comp"))
+        assert ctx.bc_errors() == 0
+        out["c3_filter_grad_base256"] = c3
+        del fin, fout, gout
+        torch.cuda.empty_cache()
 
-    def filt(l):
-        ctx.check(ctx.lib.pa_boxfilter_level(ctx.h, fin[l][1].h, fout[l][1].h, 0, 1, ngs[l], ws[l]))
+    if want("c3_filter_grad_base256"):
+        c3_case()
+    def c4_case():
+        # BASELINE config 4: isosurface (isosurface.cpp:1434-1592) -- state build (coordinates, ghost fill) + level-batched marching cubes
+        Hn = nested_hierarchy(256, 3, 64, is_per=(0, 0, 0))
+        dln = [capi.DevLevel(ctx, lv) for lv in Hn.levels]
+        fld = [alloc(lv, dl, 1, 1, "flame", 91 + l) for l, (lv, dl) in enumerate(zip(Hn.levels, dln))]
+        sts = [alloc(lv, dl, 4, 1) for lv, dl in zip(Hn.levels, dln)]
+        loops = []
+        for lv in Hn.levels:
+            arr = (capi.PaBox * lv.nboxes)()
+            for b in range(lv.nboxes):
+                for d in range(3):
+                    arr[b].lo[d] = max(int(lv.boxes[b, d]) - 1, int(lv.domlo[d]))
+                    arr[b].hi[d] = min(int(lv.boxes[b, 3 + d]) + 1, int(lv.domhi[d])) - 1
+            loops.append(arr)
+        stream.synchronize()
+        tri = [0]
 
-    def c3_all():
-        ghosts()
-        for l in range(3):
-            filt(l)
-        capi.grad_run(ctx, [f[1] for f in fout], 0, bc, [g[1] for g in gout], 0)
+        def iso_state():
+            for l in range(3):
+                ctx.check(ctx.lib.pa_iso_coords_level(ctx.h, sts[l][1].h, 0))
+                ctx.check(ctx.lib.pa_mf_copy(ctx.h, fld[l][1].h, 0, sts[l][1].h, 3, 1, 1))
+                ctx.check(ctx.lib.pa_fill_boundary(ctx.h, sts[l][1].h, 0, 4, 1))
+                if l > 0:
+                    ctx.check(ctx.lib.pa_fillpatch_two_levels(ctx.h, sts[l][1].h, sts[l - 1][1].h, 0, 4, 1, 2, 0))
 
-    c3cells = sum(lv.ncells for lv in H.levels)
-    c3 = {"ghost_fill_ms": timed(ghosts)}
-    for l in range(3):
-        m = timed(lambda l=l: filt(l))
-        c3[f"filter_fgr{2 << l}_level{l}"] = entry(m, H.levels[l].ncells, 16)
-    c3["grad_ms"] = timed(lambda: capi.grad_run(ctx, [f[1] for f in fout], 0, bc, [g[1] for g in gout], 0))
-    c3.update(entry(timed(c3_all), c3cells, None, workload="filterPlt ghost fill + separable box filter fgr 2/4/8 + grad, 3-level base 256^3, 64^3 boxes, 1 comp"))
-    assert ctx.bc_errors() == 0
-    out["c3_filter_grad_base256"] = c3
-    del fin, fout, gout
-    torch.cuda.empty_cache()
+        def iso_mc():
+            tri[0] = 0
+            for l in range(3):
+                nb = Hn.levels[l].nboxes
+                nv, nt = (C.c_int64 * nb)(), (C.c_int64 * nb)()
+                pv, pk, pt = C.c_void_p(), C.c_void_p(), C.c_void_p()
+                ctx.check(ctx.lib.pa_mc_level_fine(ctx.h, sts[l][1].h, dln[l + 1].h if l < 2 else None, 2, loops[l], 3, 1150.0, nv, nt, C.byref(pv), C.byref(pk), C.byref(pt)))
+                tri[0] += int(sum(nt[:nb]))
+                if pv.value:
+                    ctx.lib.pa_device_free(ctx.h, pv)
 
-    # BASELINE config 4: isosurface (isosurface.cpp:1434-1592) -- state build (coordinates, ghost fill) + level-batched marching cubes
-    Hn = nested_hierarchy(256, 3, 64, is_per=(0, 0, 0))
-    dln = [capi.DevLevel(ctx, lv) for lv in Hn.levels]
-    fld = [alloc(lv, dl, 1, 1, "flame", 91 + l) for l, (lv, dl) in enumerate(zip(Hn.levels, dln))]
-    sts = [alloc(lv, dl, 4, 1) for lv, dl in zip(Hn.levels, dln)]
-    loops = []
-    for lv in Hn.levels:
-        arr = (capi.PaBox * lv.nboxes)()
-        for b in range(lv.nboxes):
-            for d in range(3):
-                arr[b].lo[d] = max(int(lv.boxes[b, d]) - 1, int(lv.domlo[d]))
-                arr[b].hi[d] = min(int(lv.boxes[b, 3 + d]) + 1, int(lv.domhi[d])) - 1
-        loops.append(arr)
-    stream.synchronize()
-    tri = [0]
-
-    def iso_state():
-        for l in range(3):
-            ctx.check(ctx.lib.pa_iso_coords_level(ctx.h, sts[l][1].h, 0))
-            ctx.check(ctx.lib.pa_mf_copy(ctx.h, fld[l][1].h, 0, sts[l][1].h, 3, 1, 1))
-            ctx.check(ctx.lib.pa_fill_boundary(ctx.h, sts[l][1].h, 0, 4, 1))
-            if l > 0:
-                ctx.check(ctx.lib.pa_fillpatch_two_levels(ctx.h, sts[l][1].h, sts[l - 1][1].h, 0, 4, 1, 2, 0))
-
-    def iso_mc():
-        tri[0] = 0
-        for l in range(3):
-            nb = Hn.levels[l].nboxes
-            nv, nt = (C.c_int64 * nb)(), (C.c_int64 * nb)()
-            pv, pk, pt = C.c_void_p(), C.c_void_p(), C.c_void_p()
-            ctx.check(ctx.lib.pa_mc_level_fine(ctx.h, sts[l][1].h, dln[l + 1].h if l < 2 else None, 2, loops[l], 3, 1150.0, nv, nt, C.byref(pv), C.byref(pk), C.byref(pt)))
-            tri[0] += int(sum(nt[:nb]))
-            if pv.value:
-                ctx.lib.pa_device_free(ctx.h, pv)
-
-    iso_state()
-    c4cells = sum(lv.ncells for lv in Hn.levels)
-    ms_state, ms_mc = timed(iso_state), timed(iso_mc)
-    assert ctx.bc_errors() == 0
-    out["c4_isosurface_base256"] = entry(ms_mc, c4cells, 8, state_build_ms=ms_state, triangles=tri[0], Mtriangles_s=tri[0] / ms_mc / 1e3,
-                                         workload="coordinates + ghost fill (state_build_ms), then pa_mc_level_fine on 3 levels (finer level as mask), base 256^3, 64^3 boxes, "
-                                                  "T = 1150 isotherm; ms includes the per-level count read-back and output allocation")
+        iso_state()
+        c4cells = sum(lv.ncells for lv in Hn.levels)
+        ms_state, ms_mc = timed(iso_state), timed(iso_mc)
+        assert ctx.bc_errors() == 0
+        out["c4_isosurface_base256"] = entry(ms_mc, c4cells, 8, state_build_ms=ms_state, triangles=tri[0], Mtriangles_s=tri[0] / ms_mc / 1e3,
+                                             workload="coordinates + ghost fill (state_build_ms), then pa_mc_level_fine on 3 levels (finer level as mask), base 256^3, 64^3 boxes, "
+                                                      "T = 1150 isotherm; ms includes the per-level count read-back and output allocation")
+    if want("c4_isosurface_base256"):
+        c4_case()
     return out
 
 
@@ -345,6 +396,7 @@ def main():
                     help="roofline.traffic: measured now by two rocprofv3 --pmc child passes (falls back to the committed figure), the committed figure, or null")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads (configs 2-4, grad only, small boxes)")
+    ap.add_argument("--secondary-only", type=str, default="", help="diagnostic: skip the headline region and the CPU leg, run ONE secondary entry (e.g. irregular_amr)")
     ap.add_argument("--no-profile", action="store_true", help="diagnostic: no HIP events in the timed region (no roofline object)")
     ap.add_argument("--cpu-base", type=int, default=0, help="base size of the cpu_baseline sample (0: from the core count)")
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong", help="N > 1: shard ONE hierarchy (strong) or one hierarchy per GPU (weak)")
@@ -390,6 +442,12 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     ctx = capi.Context(local, stream.cuda_stream)
 
+    if args.secondary_only:
+        t0s = time.perf_counter()
+        res = {"secondary_only": args.secondary_only, "secondary": secondary(ctx, torch, stream, dev, only=args.secondary_only)}
+        res["wall_s"] = round(time.perf_counter() - t0s, 2)
+        print(json.dumps(res))
+        return
     per = tuple(int(v) for v in args.per.split())
     if world > 1 and per != (1, 1, 0):
         raise SystemExit("--per is a single-GPU diagnostic option")
@@ -451,7 +509,7 @@ def main():
             ctx.comm_selftest(1 << 12)
             xch["mode"] = "host-staged gloo point-to-point (pa_comm callbacks)" + ("" if rehearse else " -- RCCL transport failed: " + next(e for e in ok if e))
         else:
-            xch["mode"] = "RCCL point-to-point (grouped ncclSend/ncclRecv issued by the library on its stream), 2 exchanges per component per step"
+            xch["mode"] = "RCCL point-to-point (grouped ncclSend/ncclRecv issued by the library on its stream): exchange A (ghost cells of phi + coarse phi, all components) once per step, exchange B (coarse normals) once per batch of components"
     dls = [capi.DevLevel(ctx, lv, owners[l], myrank, nshard) if nshard > 1 else capi.DevLevel(ctx, lv) for l, lv in enumerate(H.levels)]
     cells = sum(lv.ncells for lv in H.levels)                # the whole job
     cells_local = sum(dl.level.ncells for dl in dls)         # this rank's share

@@ -143,7 +143,11 @@ __global__ __launch_bounds__(256) void k_faces_normal(DLevelView L, DMFView MC_,
 // of valid cells of neighbouring boxes are recomputed from the local ghost c.
 // CG = false: c from the stored shell copy MC_[ccomp]; CG = true: MC_[ccomp] is PHI and c comes through CgAcc.
 // cells the clip-aware fast path hands to the general one (exact-normal pipeline with the threshold clip): {batch row, face cell}
-struct SlowList { int* count; int2* items; int cap; };
+struct SlowList {
+  int* count; int2* items; int cap;
+  // cells with a VALID ghost cell (general BoxArrays) that need the neighbouring box's unclipped normal: a list for k_curv_general
+  int* gcount = nullptr; int4* gitems = nullptr; int gcap = 0; unsigned glev = 0;
+};
 // CGCLIP: the threshold clip in the exact-normal pipeline (compiled in only where it is used: 116 against 168 VGPRs)
 template <bool CG, bool PATCH, bool CGCLIP = false>
 __device__ __forceinline__ void faces_curv_cell(const LevBatch<FixArgs>& Bt, unsigned y, long long t, int perim_only, int* nbad, const SlotK& sk, int z) {
@@ -295,7 +299,16 @@ __device__ __forceinline__ void faces_curv_fast_body(const DLevelView& L, const 
                                                      unsigned row = 0, long long tcell = 0) {
   constexpr int T0 = (FD == 0) ? 1 : 0, T1 = (FD == 2) ? 1 : 2;
   const int cls = (int)(code & 3u);
-  if (cls == 0) return;
+  // cls == 0: a VALID ghost cell behind a special face (a face that is coarse-fine elsewhere; general BoxArrays).  The sweep's
+  // ghost normals behind a special face are unusable (pa_fused_march3.h re-aims the stream they need at the compact array), so
+  // the cell's curvature is formed here too, with the neighbour's FINAL normal read from the box that owns the ghost cell.
+  // Exact-normal pipeline only (NL == 1: the normals are final once the sweeps are done); a ghost cell owned by another rank's
+  // box is on the level's irregular list instead (k_find_irregular, k_curv_general rebuilds its normal).
+  int sbn = -1, qw[3] = {0, 0, 0};
+  if (cls == 0) {
+    if (NL > 1) return;
+    if (classify(L, q0[0], q0[1], q0[2], sbn, qw) != 0 || sbn < 0) return;
+  }
   const int n[3] = {B.hi[0] - B.lo[0] + 1, B.hi[1] - B.lo[1] + 1, B.hi[2] - B.lo[2] + 1};
   const int sg = side ? 1 : -1;  // the ghost cell sits at X1 + sg e_FD
   int X1[3] = {q0[0], q0[1], q0[2]};
@@ -322,12 +335,22 @@ __device__ __forceinline__ void faces_curv_fast_body(const DLevelView& L, const 
     if (clipped(X1[0], X1[1], X1[2])) return;  // K = 0 from the sweep
     const int iv = -sg;  // one cell into the box along FD
     bool slow = false;   // a needed neighbour component that the sweep clipped: this cell goes through the general path
+    if (cls == 0) {  // the neighbouring box's normal: clipped there if its progress variable (this FAB's ghost cell holds its phi) is
+      const double gn = MO.data[MO.off[sbn] + fab_index(L.boxes[sbn], MO.ng, MO.ncomp, ncomp0 + FD, qw[0], qw[1], qw[2])];
+      slow = gn == 0.0 && clipped(q0[0], q0[1], q0[2]);
+    }
     slow = slow || (nfd2 == 0.0 && clipped(X1[0] + (FD == 0 ? iv : 0), X1[1] + (FD == 1 ? iv : 0), X1[2] + (FD == 2 ? iv : 0)));
     slow = slow || (nfd3 == 0.0 && clipped(X1[0] + (FD == 0 ? 2 * iv : 0), X1[1] + (FD == 1 ? 2 * iv : 0), X1[2] + (FD == 2 ? 2 * iv : 0)));
     slow = slow || (a0m == 0.0 && clipped(X1[0] - (T0 == 0), X1[1] - (T0 == 1), X1[2]));
     slow = slow || (a0p == 0.0 && clipped(X1[0] + (T0 == 0), X1[1] + (T0 == 1), X1[2]));
     slow = slow || (a1m == 0.0 && clipped(X1[0], X1[1] - (T1 == 1), X1[2] - (T1 == 2)));
     slow = slow || (a1p == 0.0 && clipped(X1[0], X1[1] + (T1 == 1), X1[2] + (T1 == 2)));
+    if (slow && cls == 0) {  // k_curv_general<true> over the context's dynamic list: {box | batch level << 24 | slot << 27, cell}
+      const int i = atomicAdd(sl.gcount, 1);
+      if (i < sl.gcap) sl.gitems[i] = make_int4(b | (int)(sl.glev << 24) | (int)((row >> 24) << 27), X1[0], X1[1], X1[2]);
+      else atomicAdd(nbad, 1);
+      return;
+    }
     if (slow) {
       const int i = atomicAdd(sl.count, 1);
       if (i < sl.cap) sl.items[i] = make_int2((int)row, (int)tcell);
@@ -343,7 +366,9 @@ __device__ __forceinline__ void faces_curv_fast_body(const DLevelView& L, const 
   // ghost normal: MLMG applyBC on n_FD (curvature.cpp:510-531)
   double g;
   bool ok = true;
-  if (cls == 2) {
+  if (cls == 0) {
+    g = MO.data[MO.off[sbn] + fab_index(L.boxes[sbn], MO.ng, MO.ncomp, ncomp0 + FD, qw[0], qw[1], qw[2])];
+  } else if (cls == 2) {
     g = (A.bc[FD] == PA_BC_REFLECT_ODD) ? -nfd1 : nfd1;
   } else {
     if (!A.has_crse) { ok = false; g = 0.0; }
@@ -390,7 +415,9 @@ __device__ __forceinline__ void faces_curv_fast_body(const DLevelView& L, const 
 template <int NL, bool PATCH = false, bool CLIP = false>
 __global__ __launch_bounds__(256) void k_faces_curv_fast(LevBatch<FixArgs> Bt, int* nbad, SlowList sl = SlowList(), SlotK sk = SlotK()) {
   unsigned fy;
-  const FixArgs& Fx = Bt.a[Bt.find(blockIdx.y, fy)];
+  const int blev = Bt.find(blockIdx.y, fy);
+  const FixArgs& Fx = Bt.a[blev];
+  sl.glev = (unsigned)blev;
   const DLevelView& L = Fx.L;
   const DLevelView& LCr = Fx.LCr;
   const DMFView& MN = Fx.MN;
@@ -950,15 +977,19 @@ static int cpatch_launch(pa_ctx* ctx, int l0, int l1, pa_mf* const* fine, const 
   return 0;
 }
 
-// the context's list of cells for k_faces_curv_list (grow-never: 1 M entries)
-static int pa_slow_list(pa_ctx* ctx, int** count, int2** items, int* cap) {
+// the context's lists of cells for k_faces_curv_list and (general BoxArrays) k_curv_general (grow-never: 1 M entries each);
+// layout: [count, gcount, pad, pad][int2 x CAP][int4 x CAP]
+static int pa_slow_list(pa_ctx* ctx, SlowList* sl) {
   constexpr int CAP = 1 << 20;
   if (!ctx->d_slow) {
-    PA_HIP(hipMalloc(&ctx->d_slow, sizeof(int2) * (size_t)CAP + 16));
+    PA_HIP(hipMalloc(&ctx->d_slow, (sizeof(int2) + sizeof(int4)) * (size_t)CAP + 16));
   }
-  *count = (int*)ctx->d_slow;
-  *items = (int2*)((char*)ctx->d_slow + 16);
-  *cap = CAP;
+  sl->count = (int*)ctx->d_slow;
+  sl->items = (int2*)((char*)ctx->d_slow + 16);
+  sl->cap = CAP;
+  sl->gcount = sl->count + 1;
+  sl->gitems = (int4*)((char*)ctx->d_slow + 16 + sizeof(int2) * (size_t)CAP);
+  sl->gcap = CAP;
   return 0;
 }
 
@@ -1020,8 +1051,17 @@ __global__ __launch_bounds__(256) void k_find_irregular(DLevelView L, int y0, in
     const bool fd_special = L.sfindex[b * 6 + g] >= 0;
     // a valid ghost cell behind a SPECIAL face (one that is coarse-fine elsewhere): the sweep's ghost row / column / plane of
     // such a face comes from the compact array and its second stream -- the row beyond, which the ghost normal needs -- is
-    // re-aimed at that array (pa_fused_march3.h), so no ghost normal behind a special face is usable
-    if (fd_special) { irr = true; break; }
+    // re-aimed at that array (pa_fused_march3.h), so no ghost normal behind a special face is usable.  In the interior of
+    // the face k_faces_curv_fast forms the curvature with the neighbouring box's final normal (when that box is local);
+    // cells on the face's perimeter and ghost cells owned by another rank's box are listed
+    if (fd_special) {
+      bool other = false;
+      for (int tt = 0; tt < 3; ++tt) other = other || (tt != d && (X[tt] == B.lo[tt] || X[tt] == B.hi[tt]));
+      int sb, yw[3];
+      (void)classify(L, Y[0], Y[1], Y[2], sb, yw);
+      if (other || sb < 0) irr = true;
+      continue;
+    }
     {
       int Y2[3] = {Y[0], Y[1], Y[2]};
       Y2[d] += sg;
@@ -1092,6 +1132,9 @@ struct GenLev {
   DMFView MO; int ncomp0, kcomp;
   FaceArgs A;
   const int4* items; int n;
+  // dynamic list (filled by k_faces_curv_fast<CLIP> in this pass): the count lives on the device, an item's first word carries
+  // box | batch level << 24 | slot << 27 and only the items of batch level `lev` are this launch's
+  const int* ncount = nullptr; int lev = -1;
 };
 struct GenBox {
   const DLevelView* L; const DLevelView* LCp; DMFView MCp; int cpcomp;
@@ -1139,15 +1182,21 @@ __device__ Vec3 gen_normal(const GenBox& g, const int Y[3], const double dxinv[3
 
 template <bool CLIP>
 __global__ __launch_bounds__(64) void k_curv_general(GenLev G, int* nbad, SlotK sk) {
-  const int z = (int)blockIdx.z;
-  FaceArgs A = G.A;
-  if (sk.prog) { A.pmin = sk.prog[2 * z]; A.invd = sk.prog[2 * z + 1]; }
-  const int cncomp0 = G.cncomp0 + sk.cn_z * z, ncomp0 = G.ncomp0 + 8 * z, kcomp = G.kcomp + 8 * z;
   const DLevelView& L = G.L;
   const double dxinv[3] = {L.dxinv[0], L.dxinv[1], L.dxinv[2]};
-  for (int i = blockIdx.x * 64 + threadIdx.x; i < G.n; i += gridDim.x * 64) {
+  const int ntot = G.ncount ? min(*G.ncount, G.n) : G.n;
+  for (int i = blockIdx.x * 64 + threadIdx.x; i < ntot; i += gridDim.x * 64) {
     const int4 it = G.items[i];
-    const int b = it.x, X[3] = {it.y, it.z, it.w};
+    int z = (int)blockIdx.z, b = it.x;
+    if (G.lev >= 0) {
+      if (((it.x >> 24) & 7) != G.lev) continue;
+      z = (int)((unsigned)it.x >> 27);
+      b = it.x & 0xffffff;
+    }
+    FaceArgs A = G.A;
+    if (sk.prog) { A.pmin = sk.prog[2 * z]; A.invd = sk.prog[2 * z + 1]; }
+    const int cncomp0 = G.cncomp0 + sk.cn_z * z, ncomp0 = G.ncomp0 + 8 * z, kcomp = G.kcomp + 8 * z;
+    const int X[3] = {it.y, it.z, it.w};
     GenBox g;
     g.L = &G.L; g.LCp = &G.LCp; g.MCp = G.MCp; g.cpcomp = G.cpcomp + z;
     g.MCp.xform = 1; g.MCp.xa = A.pmin; g.MCp.xb = A.invd;
@@ -1409,13 +1458,28 @@ int pa_gradcurv_fix_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, 
   sk.cn_z = cn_z;
   const bool use_cp = cpatch_on();
   const bool clip = thr >= 0.0;
+  auto gen_lev = [&](int l) {  // level l's arguments of k_curv_general
+    const pa_level* L = phi[l]->lev;
+    GenLev G;
+    G.L = L->view; G.MP = phi[l]->view; G.pcomp = pcomp;
+    const pa_mf* cp = crse_phi ? crse_phi[l] : nullptr;
+    G.LCp = cp ? cp->lev->view : L->view; G.MCp = cp ? cp->view : phi[l]->view; G.cpcomp = cpcomp;
+    G.LCn = crse_n[l] ? crse_n[l]->lev->view : L->view; G.MCn = crse_n[l] ? crse_n[l]->view : phi[l]->view; G.cncomp0 = cncomp0;
+    G.MO = out[l]->view; G.ncomp0 = ncomp0; G.kcomp = kcomp;
+    for (int d = 0; d < 3; ++d) G.A.bc[d] = bc[d];
+    G.A.ratio = 2; G.A.has_crse = (crse_n[l] && cp) ? 1 : 0; G.A.thr = clip ? thr : -1.0; G.A.layers = 1; G.A.perim_only = 0; G.A.pmin = pmin; G.A.invd = 1.0 / (pmax - pmin);
+    G.items = nullptr; G.n = 0;
+    return G;
+  };
   for (int l0 = 0; l0 < nlev; l0 += PA_MAXB) {
     if (use_cp && cpatch_launch(ctx, l0, std::min(nlev, l0 + PA_MAXB), phi, crse_n, cncomp0, 1, nslots, cn_z)) return 1;
     LevBatch<FixArgs> Bt;
+    int blev[PA_MAXB];  // hierarchy level of every batch row
     long long nf = 0, nper = 0;
     for (int l = l0; l < nlev && l < l0 + PA_MAXB; ++l) {
       const pa_level* L = phi[l]->lev;
       if (L->boxes.empty() || L->sfaces.empty()) continue;
+      blev[Bt.n] = l;
       FaceArgs A;
       for (int d = 0; d < 3; ++d) A.bc[d] = bc[d];
       A.ratio = 2; A.has_crse = crse_n[l] ? 1 : 0; A.thr = clip ? thr : -1.0; A.layers = 1; A.perim_only = 1; A.pmin = pmin; A.invd = 1.0 / (pmax - pmin);
@@ -1436,8 +1500,8 @@ int pa_gradcurv_fix_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, 
     hipStream_t pst = ctx->stream;  // the perimeter kernel's stream
     if (clip) {
       SlowList sl;
-      if (pa_slow_list(ctx, &sl.count, &sl.items, &sl.cap)) return 1;
-      PA_HIP(hipMemsetAsync(sl.count, 0, sizeof(int), ctx->stream));
+      if (pa_slow_list(ctx, &sl)) return 1;
+      PA_HIP(hipMemsetAsync(sl.count, 0, 2 * sizeof(int), ctx->stream));
       if (all_patch) hipLaunchKernelGGL((k_faces_curv_fast<1, true, true>), gfast, dim3(256), 0, ctx->stream, Bt, ctx->d_flags, sl, sk);
       else hipLaunchKernelGGL((k_faces_curv_fast<1, false, true>), gfast, dim3(256), 0, ctx->stream, Bt, ctx->d_flags, sl, sk);
       // the hand-over list is a few thousand cells through a long chain of dependent loads (~0.12 ms whatever its length): the
@@ -1453,6 +1517,13 @@ int pa_gradcurv_fix_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, 
       }
       if (all_patch) hipLaunchKernelGGL((k_faces_curv_list<true>), dim3(1024), dim3(256), 0, ctx->stream, Bt, ctx->d_flags, sl, sk);
       else hipLaunchKernelGGL((k_faces_curv_list<false>), dim3(1024), dim3(256), 0, ctx->stream, Bt, ctx->d_flags, sl, sk);
+      // general BoxArrays: cells with a valid ghost cell behind a special face whose neighbour's normal the sweep clipped
+      for (int q = 0; q < Bt.n; ++q) {
+        if (phi[blev[q]]->lev->pure_faces) continue;  // no such cells on this level
+        GenLev G = gen_lev(blev[q]);
+        G.items = sl.gitems; G.n = sl.gcap; G.ncount = sl.gcount; G.lev = q;
+        hipLaunchKernelGGL(k_curv_general<true>, dim3(256), dim3(64), 0, ctx->stream, G, ctx->d_flags, sk);
+      }
     } else if (all_patch) hipLaunchKernelGGL((k_faces_curv_fast<1, true>), gfast, dim3(256), 0, ctx->stream, Bt, ctx->d_flags, SlowList(), sk);
     else hipLaunchKernelGGL((k_faces_curv_fast<1, false>), gfast, dim3(256), 0, ctx->stream, Bt, ctx->d_flags, SlowList(), sk);
     const dim3 gper((unsigned)((nper + 255) / 256), (unsigned)Bt.ycum[Bt.n], (unsigned)nslots);
@@ -1472,14 +1543,7 @@ int pa_gradcurv_fix_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, 
     if (L->boxes.empty()) continue;
     if (level_irregular(ctx, L)) return 1;
     if (L->nirr == 0) continue;
-    GenLev G;
-    G.L = L->view; G.MP = phi[l]->view; G.pcomp = pcomp;
-    const pa_mf* cp = crse_phi ? crse_phi[l] : nullptr;
-    G.LCp = cp ? cp->lev->view : L->view; G.MCp = cp ? cp->view : phi[l]->view; G.cpcomp = cpcomp;
-    G.LCn = crse_n[l] ? crse_n[l]->lev->view : L->view; G.MCn = crse_n[l] ? crse_n[l]->view : phi[l]->view; G.cncomp0 = cncomp0;
-    G.MO = out[l]->view; G.ncomp0 = ncomp0; G.kcomp = kcomp;
-    for (int d = 0; d < 3; ++d) G.A.bc[d] = bc[d];
-    G.A.ratio = 2; G.A.has_crse = (crse_n[l] && cp) ? 1 : 0; G.A.thr = clip ? thr : -1.0; G.A.layers = 1; G.A.perim_only = 0; G.A.pmin = pmin; G.A.invd = 1.0 / (pmax - pmin);
+    GenLev G = gen_lev(l);
     G.items = (const int4*)L->d_irr; G.n = L->nirr;
     ProfScope prof(ctx, PA_TAG_GRADCURV_FACES);
     const dim3 gg((unsigned)std::min((L->nirr + 63) / 64, 65535), 1, (unsigned)nslots);

@@ -296,34 +296,58 @@ def union_hierarchy(seed: int, nlev: int = 3, n0=None, is_per=None, nrect=(2, 5)
     return Hierarchy(levels, 2)
 
 
+def _erode_blocks(occ: np.ndarray, is_per) -> np.ndarray:
+    """blocks whose 26 neighbour blocks are all occupied (beyond a wall counts as occupied, periodic directions wrap)"""
+    out = occ.copy()
+    for dz in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            for dx in (-1, 0, 1):
+                if dx == dy == dz == 0:
+                    continue
+                sh = occ
+                for ax, (d, pd) in enumerate(((dz, is_per[2]), (dy, is_per[1]), (dx, is_per[0]))):
+                    if d == 0:
+                        continue
+                    sh = np.roll(sh, d, axis=ax)
+                    if not pd:  # the slice that wrapped around came from beyond a wall
+                        idx = [slice(None)] * 3
+                        idx[ax] = slice(0, 1) if d == 1 else slice(-1, None)
+                        sh = sh.copy()
+                        sh[tuple(idx)] = True
+                out &= sh
+    return out
+
+
 def tagged_hierarchy(base_n: int, nlev: int, fn, bf: int = 16, max_box: int = 128, frac=(0.30, 0.30), base_box: int = 128, is_per=(1, 1, 0),
-                     seed: int = 0) -> Hierarchy:
+                     seed: int = 0, random_sizes: bool = False) -> Hierarchy:
     """an irregular hierarchy the way a Pele run makes one: level l + 1 covers the blocks of bf coarse cells (blocking factor
     2 bf on the fine level) where |grad fn| at the block centre is among the largest `frac[l-1]` of the level's blocks,
-    properly nested, merged into boxes of 2 bf .. max_box cells per side (random sizes: the mix a grid generator's
-    efficiency-driven chopping leaves)."""
+    properly nested (one block of buffer to the edge of the coarse level), merged into boxes of 2 bf .. max_box cells per
+    side (greedy, as large as the tagged region allows; random_sizes: random limits per box instead).  Works at block
+    granularity, so a 512^3 base with three levels takes a fraction of a second."""
     rng = np.random.default_rng(seed)
     per = np.asarray(is_per)
     n = np.full(3, base_n, dtype=np.int64)
     levels = [Level(chop_box((0, 0, 0), n - 1, base_box), (0, 0, 0), n - 1, per, np.zeros(3), np.ones(3))]
+    nb = base_n // bf
+    occ = np.ones((nb, nb, nb), dtype=bool)  # valid region of the current level in blocks of bf of ITS cells
+    cn = base_n
     for l in range(1, nlev):
-        crse = levels[-1]
-        occ = _occupancy(crse)
-        cn = crse.domhi - crse.domlo + 1
-        nb = (cn // bf).astype(int)
-        h = 1.0 / float(cn[0])
-        c = (np.arange(nb[0]) + 0.5) * bf * h
+        h = 1.0 / float(cn)
+        c = (np.arange(nb) + 0.5) * bf * h
         X, Y, Z = c[None, None, :], c[None, :, None], c[:, None, None]
         e = 0.5 * h
         g = np.sqrt((fn(X + e, Y, Z) - fn(X - e, Y, Z)) ** 2 + (fn(X, Y + e, Z) - fn(X, Y - e, Z)) ** 2 + (fn(X, Y, Z + e) - fn(X, Y, Z - e)) ** 2)
-        g = np.broadcast_to(g, (nb[2], nb[1], nb[0])).copy()
-        covered = occ[bf // 2::bf, bf // 2::bf, bf // 2::bf][:nb[2], :nb[1], :nb[0]]
-        g[~covered] = -1.0
-        k = max(1, int(frac[min(l - 1, len(frac) - 1)] * covered.sum()))
+        g = np.broadcast_to(g, (nb, nb, nb)).copy()
+        g[~occ] = -1.0
+        k = max(1, int(frac[min(l - 1, len(frac) - 1)] * occ.sum()))
         thr = np.sort(g.ravel())[-k]
-        U = _nested_blocks((g >= thr) & covered, bf, occ, per)
+        U = (g >= thr) & _erode_blocks(occ, per)
         if not U.any():
             break
-        boxes = blocks_to_boxes(U, 2 * bf, max(1, max_box // (2 * bf)), rng)
-        levels.append(Level(boxes, (0, 0, 0), 2 * (crse.domhi + 1) - 1, per, np.zeros(3), np.ones(3)))
+        boxes = blocks_to_boxes(U, 2 * bf, max(1, max_box // (2 * bf)), rng if random_sizes else None)
+        cn *= 2
+        levels.append(Level(boxes, (0, 0, 0), (cn - 1,) * 3, per, np.zeros(3), np.ones(3)))
+        occ = np.repeat(np.repeat(np.repeat(U, 2, axis=0), 2, axis=1), 2, axis=2)
+        nb *= 2
     return Hierarchy(levels, 2)
