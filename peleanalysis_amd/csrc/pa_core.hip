@@ -350,6 +350,47 @@ pa_level* pa_level_create_spec(pa_ctx* ctx, const LevelSpec& S, const int32_t do
     L->cgoff[e] = L->cg_total;  // (n0+2) x (n1+2) + two rows of slack, starts on a 64-byte boundary
     L->cg_total += ((long long)(B.hi[t0] - B.lo[t0] + 3) * (B.hi[t1] - B.lo[t1] + 5) + 7) / 8 * 8;
   }
+  {  // sweep groups by box width
+    std::vector<int> wide, narrow;
+    for (int b = 0; b < nboxes; ++b) {
+      const DBox& B = L->boxes[b];
+      const bool nar = B.hi[0] - B.lo[0] + 1 <= 32;
+      (nar ? narrow : wide).push_back(b);
+      for (int d = 0; d < 3; ++d) {
+        int& m = nar ? L->nmax[d] : L->wmax[d];
+        m = std::max(m, B.hi[d] - B.lo[d] + 1);
+      }
+    }
+    L->nwide = (int)wide.size();
+    L->nnarrow = (int)narrow.size();
+    if (L->nwide && L->nnarrow) {
+      wide.insert(wide.end(), narrow.begin(), narrow.end());
+      if (hipMalloc(&L->d_blist, sizeof(int) * wide.size()) != hipSuccess ||
+          hipMemcpy(L->d_blist, wide.data(), sizeof(int) * wide.size(), hipMemcpyHostToDevice) != hipSuccess) {
+        pa_fail(ctx, "pa_level_create: device allocation failed");
+        delete L;
+        return nullptr;
+      }
+    }
+  }
+  {  // work table of the kernels that run one thread per ghost cell of a special face: faces differ in size by 16x on general
+     // BoxArrays (32^2 .. 128^2 cells), a grid of (largest face / 256) x faces would be mostly empty workgroups
+    std::vector<int> wg;
+    for (size_t e = 0; e < L->sfaces.size(); ++e) {
+      const int f = L->sfaces[e];
+      const DBox& B = L->boxes[f / 6];
+      const int d = (f % 6) >> 1, t0 = (d == 0) ? 1 : 0, t1 = (d == 2) ? 1 : 2;
+      const long long nc = (long long)(B.hi[t0] - B.lo[t0] + 1) * (B.hi[t1] - B.lo[t1] + 1);
+      for (int c = 0; c < (int)((nc + 255) / 256); ++c) { wg.push_back((int)e); wg.push_back(c); }
+    }
+    L->nsfwg = (int)(wg.size() / 2);
+    if (L->nsfwg > 0 && (hipMalloc(&L->d_sfwg, sizeof(int) * wg.size()) != hipSuccess ||
+                         hipMemcpy(L->d_sfwg, wg.data(), sizeof(int) * wg.size(), hipMemcpyHostToDevice) != hipSuccess)) {
+      pa_fail(ctx, "pa_level_create: device allocation failed");
+      delete L;
+      return nullptr;
+    }
+  }
   if (hipMalloc(&L->d_boxes, sizeof(DBox) * std::max(nboxes, 1)) != hipSuccess ||
       hipMalloc(&L->d_sfaces, sizeof(int) * nsf_alloc) != hipSuccess ||
       (!L->sfaces.empty() && hipMemcpy(L->d_sfaces, L->sfaces.data(), sizeof(int) * L->sfaces.size(), hipMemcpyHostToDevice) != hipSuccess) ||
@@ -422,6 +463,8 @@ extern "C" void pa_level_destroy(pa_level* L) {
   if (L->d_boxes) (void)hipFree(L->d_boxes);
   if (L->d_owner) (void)hipFree(L->d_owner);
   if (L->d_irr) (void)hipFree(L->d_irr);
+  if (L->d_sfwg) (void)hipFree(L->d_sfwg);
+  if (L->d_blist) (void)hipFree(L->d_blist);
   delete L;
 }
 extern "C" int pa_level_nboxes(const pa_level* L) { return L ? (int)L->boxes.size() : 0; }

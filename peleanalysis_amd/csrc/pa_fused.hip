@@ -100,7 +100,20 @@ struct FixArgs {
   FaceArgs A;
   int use_cp = 0;  // the level's coarse patches hold the coarse normal component of each face's direction (k_cpatch ran)
   long long cg_stride = 0, cp_stride = 0;  // component slots (blockIdx.z): doubles between the slots' sets of compact arrays / coarse patches
+  const int2* wg = nullptr; int nwg = 0;   // the level's work table {special face, chunk of 256 face cells} (pa_level::d_sfwg)
 };
+// workgroup -> (batch level, special face, first face cell) through the levels' work tables
+template <typename BT>
+__device__ __forceinline__ bool wg_decode(const BT& Bt, int& blev, unsigned& fy, long long& t) {
+  unsigned w = blockIdx.x;
+  blev = 0;
+  while (blev + 1 < Bt.n && w >= (unsigned)Bt.a[blev].nwg) { w -= (unsigned)Bt.a[blev].nwg; ++blev; }
+  if (w >= (unsigned)Bt.a[blev].nwg) return false;
+  const int2 c = Bt.a[blev].wg[w];
+  fy = (unsigned)c.x;
+  t = (long long)c.y * 256 + threadIdx.x;
+  return true;
+}
 // Component slots: the boundary kernels of the exact-normal pipeline run for several components in ONE launch, blockIdx.z =
 // slot z: phi component + z, output components + 8 z, coarse-normal components + cn_z z, the slot's own set of compact ghost
 // arrays and coarse patches, its own progress-variable range prog[2 z], prog[2 z + 1] = (pmin, 1 / (pmax - pmin)) (null: the
@@ -415,7 +428,9 @@ __device__ __forceinline__ void faces_curv_fast_body(const DLevelView& L, const 
 template <int NL, bool PATCH = false, bool CLIP = false>
 __global__ __launch_bounds__(256) void k_faces_curv_fast(LevBatch<FixArgs> Bt, int* nbad, SlowList sl = SlowList(), SlotK sk = SlotK()) {
   unsigned fy;
-  const int blev = Bt.find(blockIdx.y, fy);
+  int blev;
+  long long t;
+  if (!wg_decode(Bt, blev, fy, t)) return;
   const FixArgs& Fx = Bt.a[blev];
   sl.glev = (unsigned)blev;
   const DLevelView& L = Fx.L;
@@ -428,14 +443,13 @@ __global__ __launch_bounds__(256) void k_faces_curv_fast(LevBatch<FixArgs> Bt, i
   const int cncomp0 = Fx.cncomp0 + sk.cn_z * z, ncomp0 = Fx.ncomp0 + 8 * z, kcomp = Fx.kcomp + 8 * z;
   int b, fdir, side, layer, q0[3];
   DBox B;
-  const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (!sface_decode(L, fy, t, 1, b, B, fdir, side, q0, layer)) return;
   const int t0 = (fdir == 0) ? 1 : 0, t1 = (fdir == 2) ? 1 : 2;
   if (!(q0[t0] > B.lo[t0] && q0[t0] < B.hi[t0] && q0[t1] > B.lo[t1] && q0[t1] < B.hi[t1])) return;  // perimeter: k_faces_curv
   const unsigned code = L.sfcode[L.sfoff[fy] + t];
   const long long cpo = (Fx.use_cp && L.cp) ? L.cpoff[fy] : -1;  // wave-uniform
   const double* patch = cpo >= 0 ? L.cp + z * Fx.cp_stride + cpo : nullptr;
-  const unsigned row = blockIdx.y | ((unsigned)z << 24);  // SlowList entries carry the slot
+  const unsigned row = ((unsigned)Bt.ycum[blev] + fy) | ((unsigned)z << 24);  // batch row of the face; SlowList entries carry the slot
   switch (fdir) {  // uniform per workgroup
     case 0: faces_curv_fast_body<0, NL, PATCH, CLIP>(L, LCr, MN, cncomp0, MO, ncomp0, kcomp, A, nbad, b, B, side, q0, code, patch, Fx.MC_, Fx.ccomp + z, sl, row, t); break;
     case 1: faces_curv_fast_body<1, NL, PATCH, CLIP>(L, LCr, MN, cncomp0, MO, ncomp0, kcomp, A, nbad, b, B, side, q0, code, patch, Fx.MC_, Fx.ccomp + z, sl, row, t); break;
@@ -645,8 +659,10 @@ int pa_gradcurv_faces_phase(pa_ctx* ctx, const pa_mf* c, int ccomp, const pa_mf*
   Bt.n = 1;
   Bt.ycum[1] = (int)nsf;
   Bt.a[0] = FixArgs{L->view, c->view, ccomp, crse_n ? crse_n->lev->view : L->view, crse_n ? crse_n->view : c->view, cncomp0, out->view, ncomp0, kcomp, A};
+  Bt.a[0].wg = (const int2*)L->d_sfwg;
+  Bt.a[0].nwg = L->nsfwg;
   if (fast) {
-    hipLaunchKernelGGL(k_faces_curv_fast<2>, dim3((unsigned)((nf + 255) / 256), nsf), dim3(256), 0, ctx->stream, Bt, ctx->d_flags);
+    hipLaunchKernelGGL(k_faces_curv_fast<2>, dim3((unsigned)L->nsfwg), dim3(256), 0, ctx->stream, Bt, ctx->d_flags);
     Bt.a[0].A.perim_only = 1;
   }
   const long long ncell = fast ? 2 * (std::max(n0, std::max(n1, n2)) + std::max(n0, std::max(n1, n2))) : nf;  // perimeter <= 4 * longest edge
@@ -685,11 +701,14 @@ struct PrepArgs {
 // Thread per ghost cell of a special face: the face ghost of phi (MLMG applyBC, as k_apply_bc_sfaces) and the resolved
 // ghost value of c = the same boundary condition applied to c, whose interior values are (phi - pmin) * invd formed on the
 // fly and whose coarse values are the affine view of the coarse phi -- the operations of k_apply_bc_sfaces<2> on a stored c.
-struct PrepLev { DLevelView L; DMFView M; int comp; DLevelView LC; DMFView MC; int ccomp; PrepArgs A; int use_cp; long long cg_stride = 0, cp_stride = 0; };
+struct PrepLev { DLevelView L; DMFView M; int comp; DLevelView LC; DMFView MC; int ccomp; PrepArgs A; int use_cp; long long cg_stride = 0, cp_stride = 0; const int2* wg = nullptr; int nwg = 0; };
 template <bool PATCH>
 __global__ __launch_bounds__(256) void k_prep_faces(LevBatch<PrepLev> Bt, int* nbad, SlotK sk = SlotK()) {
   unsigned fy;
-  const PrepLev& Pl = Bt.a[Bt.find(blockIdx.y, fy)];
+  int blev;
+  long long t;
+  if (!wg_decode(Bt, blev, fy, t)) return;
+  const PrepLev& Pl = Bt.a[blev];
   const DLevelView& L = Pl.L;
   const DMFView& M = Pl.M;
   const DLevelView& LC = Pl.LC;
@@ -702,7 +721,6 @@ __global__ __launch_bounds__(256) void k_prep_faces(LevBatch<PrepLev> Bt, int* n
   const double* const cpz = L.cp ? L.cp + z * Pl.cp_stride : nullptr;
   int b, dir, side, layer, q[3];
   DBox B;
-  const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (!sface_decode(L, fy, t, 1, b, B, dir, side, q, layer)) return;
   const unsigned code = L.sfcode[L.sfoff[fy] + t];
   const int cls = (int)(code & 3u);
@@ -1319,6 +1337,7 @@ int pa_gradcurv_prep_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int comp, 
       P.MC.xform = 1; P.MC.xa = pmin; P.MC.xb = P.A.invd;
       P.ccomp = ccomp;
       P.use_cp = (use_cp && crse[l] && L->cp_total > 0) ? 1 : 0;
+      P.wg = (const int2*)L->d_sfwg; P.nwg = L->nsfwg;
       const long long n0 = L->maxn[0], n1 = L->maxn[1], n2 = L->maxn[2];
       ntf = std::max(ntf, std::max(n1 * n2, std::max(n0 * n2, n0 * n1)));
       ntr = std::max(ntr, 4 * (n0 + n1 + n2));
@@ -1329,7 +1348,9 @@ int pa_gradcurv_prep_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int comp, 
     ProfScope prof(ctx, PA_TAG_BC);
     bool all_patch = true;  // every level of the batch that has a coarser level interpolates from patches: the owner-map path is not compiled in
     for (int q = 0; q < Bf.n; ++q) all_patch = all_patch && (Bf.a[q].use_cp || !Bf.a[q].A.has_crse);
-    const dim3 gf((unsigned)((ntf + 255) / 256), (unsigned)Bf.ycum[Bf.n], (unsigned)nslots), gr((unsigned)((ntr + 255) / 256), (unsigned)Br.ycum[Br.n], (unsigned)nslots);
+    unsigned nwgf = 0;
+    for (int q = 0; q < Bf.n; ++q) nwgf += (unsigned)Bf.a[q].nwg;
+    const dim3 gf(nwgf, 1, (unsigned)nslots), gr((unsigned)((ntr + 255) / 256), (unsigned)Br.ycum[Br.n], (unsigned)nslots);
     if (phase & 1) {
       if (all_patch) hipLaunchKernelGGL(k_prep_faces<true>, gf, dim3(256), 0, ctx->stream, Bf, ctx->d_flags, sk);
       else hipLaunchKernelGGL(k_prep_faces<false>, gf, dim3(256), 0, ctx->stream, Bf, ctx->d_flags, sk);
@@ -1345,103 +1366,128 @@ int pa_gradcurv_prep_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int comp, 
   return 0;
 }
 
+// A sweep group: the boxes of one level that one kernel variant covers (all of them, or -- a level with boxes both wider and
+// not wider than 32 cells -- its wide or its narrow ones through an index list)
+struct SweepGroup { int lev; const int* list; int n; int dims[3]; };
+static void sweep_groups(int l, const pa_level* L, std::vector<SweepGroup>& out) {
+  static const int split = [] { const char* e = getenv("PA_SWEEP_SPLIT"); return e ? atoi(e) : 1; }();  // 0: one group per level (A/B)
+  if (L->boxes.empty()) return;
+  if (!L->d_blist || !split) { out.push_back({l, nullptr, (int)L->boxes.size(), {L->maxn[0], L->maxn[1], L->maxn[2]}}); return; }
+  out.push_back({l, L->d_blist, L->nwide, {L->wmax[0], L->wmax[1], L->wmax[2]}});
+  out.push_back({l, L->d_blist + L->nwide, L->nnarrow, {L->nmax[0], L->nmax[1], L->nmax[2]}});
+}
+
 // the sweep with exact normals (the level's compact ghost arrays must be current: pa_gradcurv_prep_level)
-int pa_gradcurv_level_cg(pa_ctx* ctx, const pa_mf* phi, int pcomp, double pmin, double pmax, pa_mf* out, int ocomp, double thr, int slot) {
+static int sweep_group_cg(pa_ctx* ctx, const SweepGroup& g, const pa_mf* phi, int pcomp, double pmin, double pmax, pa_mf* out, int ocomp, double thr, int slot) {
   const pa_level* L = phi->lev;
-  if (L->boxes.empty()) return 0;
   if (level_cg(ctx, L, slot + 1)) return 1;
   LevelBP2 bp{L->view, phi->view, out->view};
   bp.L.cg += slot * cg_stride(L);  // the component slot's set of compact arrays
   MarchArgs A{pcomp, ocomp, fused_kseg(), pmin, 1.0 / (pmax - pmin), thr >= 0.0 ? thr : -1.0, 0, 1, 1, 1};
   A.cg = 1;
+  A.boxlist = g.list;
   ProfScope prof(ctx, PA_TAG_GRADCURV);
-  march_launch(ctx->stream, bp, L->maxn[0], L->maxn[1], L->maxn[2], (unsigned)L->boxes.size(), A, false, &ctx->sweep_kernel);
+  march_launch(ctx->stream, bp, g.dims[0], g.dims[1], g.dims[2], (unsigned)g.n, A, false, &ctx->sweep_kernel);
   PA_HIP(hipGetLastError());
   return 0;
 }
+int pa_gradcurv_level_cg(pa_ctx* ctx, const pa_mf* phi, int pcomp, double pmin, double pmax, pa_mf* out, int ocomp, double thr, int slot) {
+  std::vector<SweepGroup> gs;
+  sweep_groups(0, phi->lev, gs);
+  for (const SweepGroup& g : gs)
+    if (sweep_group_cg(ctx, g, phi, pcomp, pmin, pmax, out, ocomp, thr, slot)) return 1;
+  return 0;
+}
 
-// the CG sweeps of all levels: one launch (k_gradcurv_march3_levels) when every level takes the same tile variant and the
-// XCD-aware order is on, else level by level.  PA_SWEEP_BATCH=0: always level by level (A/B).
+// the CG sweeps of all levels: the groups of boxes wider than 32 cells in one launch (k_gradcurv_march3_levels) when they agree
+// on the tile variant and the XCD-aware order is on, else group by group; narrow groups one launch each.
+// PA_SWEEP_BATCH=0: always group by group (A/B).
 int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, double pmin, double pmax, pa_mf* const* out, int ocomp, double thr, int slot) {
   const bool clip = thr >= 0.0;
   static const int batch_env = [] { const char* e = getenv("PA_SWEEP_BATCH"); return e ? atoi(e) : 1; }();
   static const bool knobs = getenv("PA_MARCH") || getenv("PA_DBG") || getenv("PA_MTY") || getenv("PA_PAIR");
-  std::vector<int> lv;
-  for (int l = 0; l < nlev; ++l)
-    if (!phi[l]->lev->boxes.empty()) lv.push_back(l);
+  std::vector<SweepGroup> all, lv, rest;
+  for (int l = 0; l < nlev; ++l) sweep_groups(l, phi[l]->lev, all);
   int mty = 0;
-  bool ok = batch_env && !knobs && fused_order() == 2 && lv.size() >= 2 && (int)lv.size() <= PA_MAXB;
-  for (int l : lv) {
-    const pa_level* L = phi[l]->lev;
-    const int m = L->maxn[1] >= 52 ? 13 : (L->maxn[1] >= 16 ? 8 : 4);  // as march_launch (tools/ab_driver.py, 13 against 12 / 11 / 10 / 9 rows: +0.058 / +0.041 / +0.31 / +0.97 ms per pass)
-    ok = ok && L->maxn[0] > 32 && (mty == 0 || m == mty);
+  bool same = true;
+  for (const SweepGroup& g : all) {
+    if (g.dims[0] <= 32) { rest.push_back(g); continue; }
+    const int m = g.dims[1] >= 52 ? 13 : (g.dims[1] >= 16 ? 8 : 4);  // as march_launch (tools/ab_driver.py, 13 against 12 / 11 / 10 / 9 rows: +0.058 / +0.041 / +0.31 / +0.97 ms per pass)
+    same = same && (mty == 0 || m == mty);
     mty = m;
+    lv.push_back(g);
   }
+  const bool ok = batch_env && !knobs && fused_order() == 2 && lv.size() >= 2 && (int)lv.size() <= PA_MAXB && same;
   if (!ok) {
-    for (int l = 0; l < nlev; ++l)
-      if (pa_gradcurv_level_cg(ctx, phi[l], pcomp, pmin, pmax, out[l], ocomp, thr, slot)) return 1;
-    return 0;
+    rest.insert(rest.begin(), lv.begin(), lv.end());
+    lv.clear();
   }
-  SweepBatch S;
-  S.n = (int)lv.size();
-  S.wg0[0] = 0;
-  // planes per workgroup: the model of march_launch on the whole launch (workgroups of all levels share the rounds)
-  std::vector<long long> per_seg(lv.size());
-  long long wgs = 0;
-  int kdef = fused_kseg();
-  if (const char* kb = getenv("PA_KSEG_B")) kdef = std::max(4, atoi(kb));  // per pass (tools/ab_driver.py): planes per workgroup of the batched launch
-  for (size_t q = 0; q < lv.size(); ++q) {
-    const pa_level* L = phi[lv[q]]->lev;
-    per_seg[q] = (long long)((L->maxn[0] + 63) / 64) * ((L->maxn[1] + mty - 1) / mty) * (long long)L->boxes.size();
-    wgs += per_seg[q] * ((L->maxn[2] + kdef - 1) / kdef);
-  }
-  int tz_best = 0;
-  if (!getenv("PA_KSEG") && wgs < 2048) {
-    long long best = -1;
-    int nzmax = 0;
-    for (int l : lv) nzmax = std::max(nzmax, phi[l]->lev->maxn[2]);
-    for (int tz = 1; tz <= std::max(1, nzmax / 8); ++tz) {
-      long long w = 0;
-      int kmax = 0;
-      for (size_t q = 0; q < lv.size(); ++q) {
-        const int nz = phi[lv[q]]->lev->maxn[2], k = std::max(4, (nz + tz - 1) / tz);
-        w += per_seg[q] * ((nz + k - 1) / k);
-        kmax = std::max(kmax, k);
-      }
-      const long long cost = ((w + 255) / 256) * (kmax + 4);
-      if (best < 0 || cost < best) { best = cost; tz_best = tz; }
+  if (!lv.empty()) {
+    SweepBatch S;
+    S.n = (int)lv.size();
+    S.wg0[0] = 0;
+    // planes per workgroup: the model of march_launch on the whole launch (workgroups of all levels share the rounds)
+    std::vector<long long> per_seg(lv.size());
+    long long wgs = 0;
+    int kdef = fused_kseg();
+    if (const char* kb = getenv("PA_KSEG_B")) kdef = std::max(4, atoi(kb));  // per pass (tools/ab_driver.py): planes per workgroup of the batched launch
+    for (size_t q = 0; q < lv.size(); ++q) {
+      per_seg[q] = (long long)((lv[q].dims[0] + 63) / 64) * ((lv[q].dims[1] + mty - 1) / mty) * (long long)lv[q].n;
+      wgs += per_seg[q] * ((lv[q].dims[2] + kdef - 1) / kdef);
     }
+    int tz_best = 0;
+    if (!getenv("PA_KSEG") && wgs < 2048) {
+      long long best = -1;
+      int nzmax = 0;
+      for (const SweepGroup& g : lv) nzmax = std::max(nzmax, g.dims[2]);
+      for (int tz = 1; tz <= std::max(1, nzmax / 8); ++tz) {
+        long long w = 0;
+        int kmax = 0;
+        for (size_t q = 0; q < lv.size(); ++q) {
+          const int nz = lv[q].dims[2], k = std::max(4, (nz + tz - 1) / tz);
+          w += per_seg[q] * ((nz + k - 1) / k);
+          kmax = std::max(kmax, k);
+        }
+        const long long cost = ((w + 255) / 256) * (kmax + 4);
+        if (best < 0 || cost < best) { best = cost; tz_best = tz; }
+      }
+    }
+    for (size_t q = 0; q < lv.size(); ++q) {
+      const int l = lv[q].lev;
+      const pa_level* L = phi[l]->lev;
+      if (level_cg(ctx, L, slot + 1)) return 1;
+      S.bp[q] = LevelBP2{L->view, phi[l]->view, out[l]->view};
+      S.bp[q].L.cg += slot * cg_stride(L);
+      MarchArgs A{pcomp, ocomp, kdef, pmin, 1.0 / (pmax - pmin), clip ? thr : -1.0, 2, 1, 1, 1};
+      A.cg = 1;
+      A.boxlist = lv[q].list;
+      if (tz_best) A.kseg = std::max(4, (lv[q].dims[2] + tz_best - 1) / tz_best);
+      const unsigned nb = (unsigned)lv[q].n;
+      const dim3 g = march_grid(lv[q].dims[0], lv[q].dims[1], lv[q].dims[2], A.kseg, mty, nb);
+      A.nboxes = (int)nb;
+      A.txy_max = ((lv[q].dims[0] + 63) / 64) * ((lv[q].dims[1] + mty - 1) / mty);
+      A.tiles_max = (int)g.x;
+      S.A[q] = A;
+      S.wg0[q + 1] = S.wg0[q] + g.x * 8u * ((nb + 7u) / 8u);
+    }
+    ProfScope prof(ctx, PA_TAG_GRADCURV);
+    const dim3 grid(S.wg0[S.n]);
+    if (clip) {
+      if (mty == 13) hipLaunchKernelGGL((k_gradcurv_march3_levels<13, true>), grid, dim3(64 * 16), 0, ctx->stream, S);
+      else if (mty == 8) hipLaunchKernelGGL((k_gradcurv_march3_levels<8, true>), grid, dim3(64 * 11), 0, ctx->stream, S);
+      else hipLaunchKernelGGL((k_gradcurv_march3_levels<4, true>), grid, dim3(64 * 7), 0, ctx->stream, S);
+    } else {
+      if (mty == 13) hipLaunchKernelGGL(k_gradcurv_march3_levels<13>, grid, dim3(64 * 16), 0, ctx->stream, S);
+      else if (mty == 8) hipLaunchKernelGGL(k_gradcurv_march3_levels<8>, grid, dim3(64 * 11), 0, ctx->stream, S);
+      else hipLaunchKernelGGL(k_gradcurv_march3_levels<4>, grid, dim3(64 * 7), 0, ctx->stream, S);
+    }
+    PA_HIP(hipGetLastError());
   }
-  for (size_t q = 0; q < lv.size(); ++q) {
-    const int l = lv[q];
-    const pa_level* L = phi[l]->lev;
-    if (level_cg(ctx, L, slot + 1)) return 1;
-    S.bp[q] = LevelBP2{L->view, phi[l]->view, out[l]->view};
-    S.bp[q].L.cg += slot * cg_stride(L);
-    MarchArgs A{pcomp, ocomp, kdef, pmin, 1.0 / (pmax - pmin), clip ? thr : -1.0, 2, 1, 1, 1};
-    A.cg = 1;
-    if (tz_best) A.kseg = std::max(4, (L->maxn[2] + tz_best - 1) / tz_best);
-    const unsigned nb = (unsigned)L->boxes.size();
-    const dim3 g = march_grid(L->maxn[0], L->maxn[1], L->maxn[2], A.kseg, mty, nb);
-    A.nboxes = (int)nb;
-    A.txy_max = ((L->maxn[0] + 63) / 64) * ((L->maxn[1] + mty - 1) / mty);
-    A.tiles_max = (int)g.x;
-    S.A[q] = A;
-    S.wg0[q + 1] = S.wg0[q] + g.x * 8u * ((nb + 7u) / 8u);
-  }
-  ProfScope prof(ctx, PA_TAG_GRADCURV);
-  const dim3 grid(S.wg0[S.n]);
-  if (clip) {
-    if (mty == 13) hipLaunchKernelGGL((k_gradcurv_march3_levels<13, true>), grid, dim3(64 * 16), 0, ctx->stream, S);
-    else if (mty == 8) hipLaunchKernelGGL((k_gradcurv_march3_levels<8, true>), grid, dim3(64 * 11), 0, ctx->stream, S);
-    else hipLaunchKernelGGL((k_gradcurv_march3_levels<4, true>), grid, dim3(64 * 7), 0, ctx->stream, S);
-  } else {
-    if (mty == 13) hipLaunchKernelGGL(k_gradcurv_march3_levels<13>, grid, dim3(64 * 16), 0, ctx->stream, S);
-    else if (mty == 8) hipLaunchKernelGGL(k_gradcurv_march3_levels<8>, grid, dim3(64 * 11), 0, ctx->stream, S);
-    else hipLaunchKernelGGL(k_gradcurv_march3_levels<4>, grid, dim3(64 * 7), 0, ctx->stream, S);
-  }
-  ctx->sweep_kernel = "k_gradcurv_march3_levels<MTY=" + std::to_string(mty) + (clip ? ",CLIP" : "") + ">[" + std::to_string(S.n) + " levels per launch]";
-  PA_HIP(hipGetLastError());
+  for (const SweepGroup& g : rest)
+    if (sweep_group_cg(ctx, g, phi[g.lev], pcomp, pmin, pmax, out[g.lev], ocomp, thr, slot)) return 1;
+  if (!lv.empty())
+    ctx->sweep_kernel = "k_gradcurv_march3_levels<MTY=" + std::to_string(mty) + (clip ? ",CLIP" : "") + ">[" + std::to_string(lv.size()) + " levels per launch]" +
+                        (rest.empty() ? "" : " + " + std::to_string(rest.size()) + " narrow-box launch(es)");
   return 0;
 }
 
@@ -1484,7 +1530,7 @@ int pa_gradcurv_fix_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, 
       for (int d = 0; d < 3; ++d) A.bc[d] = bc[d];
       A.ratio = 2; A.has_crse = crse_n[l] ? 1 : 0; A.thr = clip ? thr : -1.0; A.layers = 1; A.perim_only = 1; A.pmin = pmin; A.invd = 1.0 / (pmax - pmin);
       Bt.a[Bt.n] = FixArgs{L->view, phi[l]->view, pcomp, crse_n[l] ? crse_n[l]->lev->view : L->view, crse_n[l] ? crse_n[l]->view : phi[l]->view, cncomp0,
-                           out[l]->view, ncomp0, kcomp, A, (use_cp && crse_n[l] && L->cp_total > 0) ? 1 : 0, cg_stride(L), cp_stride(L)};
+                           out[l]->view, ncomp0, kcomp, A, (use_cp && crse_n[l] && L->cp_total > 0) ? 1 : 0, cg_stride(L), cp_stride(L), (const int2*)L->d_sfwg, L->nsfwg};
       Bt.ycum[Bt.n + 1] = Bt.ycum[Bt.n] + (int)L->sfaces.size();
       ++Bt.n;
       const long long n0 = L->maxn[0], n1 = L->maxn[1], n2 = L->maxn[2];
@@ -1496,7 +1542,9 @@ int pa_gradcurv_fix_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, 
     bool all_patch = true;  // every level of the batch that interpolates from a coarser level does so from patches
     for (int q = 0; q < Bt.n; ++q) all_patch = all_patch && (Bt.a[q].use_cp || !Bt.a[q].A.has_crse);
     if (Bt.ycum[Bt.n] >= (1 << 24)) return pa_fail(ctx, "pa_gradcurv_fix_levels: too many special faces in one batch");
-    const dim3 gfast((unsigned)((nf + 255) / 256), (unsigned)Bt.ycum[Bt.n], (unsigned)nslots);
+    unsigned nwgf = 0;
+    for (int q = 0; q < Bt.n; ++q) nwgf += (unsigned)Bt.a[q].nwg;
+    const dim3 gfast(nwgf, 1, (unsigned)nslots);
     hipStream_t pst = ctx->stream;  // the perimeter kernel's stream
     if (clip) {
       SlowList sl;

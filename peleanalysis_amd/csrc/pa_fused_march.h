@@ -61,6 +61,7 @@ struct MarchArgs {
   // neighbouring tiles both read are served by that XCD's L2 instead of being fetched once per XCD.
   int order, nboxes, txy_max, tiles_max;
   int cg = 0;  // host side: launch the CG variant of k_gradcurv_march3 (pa_fused_march3.h)
+  const int* boxlist = nullptr;  // k_gradcurv_march3 / march3n: the launch covers boxes boxlist[0 .. nboxes-1] of the level (null: all of them)
 };
 
 template <typename BP, int PA_MTY, int MINW>

@@ -136,6 +136,10 @@ __device__ __forceinline__ void gradcurv_march3_body(const BP& bp, const MarchAr
   } else {
     box = A.order ? (int)((bid_x / (unsigned)A.txy_max) % (unsigned)A.nboxes) : (int)bid_y;
   }
+  if (A.boxlist) {
+    if (box >= A.nboxes) return;
+    box = A.boxlist[box];
+  }
   if (!bp.get(box, P, O, V, dxinv)) return;
   const int pcomp = A.pcomp, kseg = A.kseg;
   const double pmin = A.pmin, invd = A.invdenom;

@@ -45,6 +45,10 @@ __global__ __launch_bounds__(64 * (NRW + 2), 1) void k_gradcurv_march3n(BP bp, M
   } else {
     box = (int)blockIdx.y;
   }
+  if (A.boxlist) {
+    if (box >= A.nboxes) return;
+    box = A.boxlist[box];
+  }
   if (!bp.get(box, P, O, V, dxinv)) return;
   const int pcomp = A.pcomp, kseg = A.kseg;
   const double pmin = A.pmin, invd = A.invdenom;

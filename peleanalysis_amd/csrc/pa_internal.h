@@ -150,6 +150,13 @@ struct pa_level {
   // Irregular cells (pa_fused.hip: k_find_irregular / k_curv_general): boundary cells of local boxes next to a concave
   // coarse-fine corner or to the line where a box face changes from covered to coarse-fine, whose curvature neither the
   // sweep nor the face fix-up gets right; recomputed one by one through a geometry-independent path.  Built on first use.
+  // Sweep groups (pa_fused.hip): boxes wider than 32 cells take the wide sweep kernel (64-column tiles), the others the narrow
+  // one (two 32-column rows per wavefront); a level that has both kinds keeps two index lists (wide first) for the two launches
+  int* d_blist = nullptr;
+  int nwide = 0, nnarrow = 0;
+  int wmax[3] = {0, 0, 0}, nmax[3] = {0, 0, 0};  // largest extents among the wide / the narrow boxes
+  void* d_sfwg = nullptr;   // int2 {special face, chunk of 256 of its ghost cells}: the work table of the per-face-cell kernels
+  int nsfwg = 0;
   void* d_irr = nullptr;    // int4 {box, i, j, k}
   int nirr = -1;            // -1: not built yet
   int nremote = 0;          // boxes of this level owned by other ranks (pa_level_create_sharded)
