@@ -119,9 +119,41 @@ def cpu_baseline(base, nlev, box):
                 break
         variants[name] = {"Mcells/s": cells * reps / dt / 1e6, "passes": reps, "seconds": round(dt, 2)}
     best = max(variants, key=lambda k: variants[k]["Mcells/s"])
-    return {"value": variants[best]["Mcells/s"], "unit": "Mcells/s", "cores": cores, "kind": "port", "variant": best, "variants": variants,
-            "sample": f"oracle grad+curvature pipelines (C restatement, OpenMP over boxes, scratch preallocated), {nlev}-level base {base}^3, "
-                      f"{box}^3 boxes{' (the GPU line box size)' if box == 128 else ''}, {cells} cells = {cells / (3 * 512 ** 3):.3f} of the headline hierarchy, 1 comp"}
+    res = {"value": variants[best]["Mcells/s"], "unit": "Mcells/s", "cores": cores, "kind": "port", "variant": best, "variants": variants,
+           "sample": f"oracle grad+curvature pipelines (C restatement, OpenMP over boxes, scratch preallocated), {nlev}-level base {base}^3, "
+                     f"{box}^3 boxes{' (the GPU line box size)' if box == 128 else ''}, {cells} cells = {cells / (3 * 512 ** 3):.3f} of the headline hierarchy, 1 comp"}
+    return res, (H, states, og, oc)
+
+
+def parity_check(ctx, sample):
+    """The oracle's outputs of the cpu_baseline sample (production geometry: 128^3 boxes, two x tiles x ten row tiles x two z
+    segments per box, all levels in one sweep launch) against the HIP path on the SAME inputs, bit for bit: the checker's work
+    is already paid for by the baseline leg, the GPU pass and the download add a few seconds."""
+    from peleanalysis_amd import capi
+    H, states, og, oc = sample
+    t0 = time.perf_counter()
+    bc = capi.bc_from_flags((1, 1, 0))
+    dls = [capi.DevLevel(ctx, lv) for lv in H.levels]
+    dst = [capi.DevMF.from_host(ctx, dl, s) for dl, s in zip(dls, states)]
+    work = [capi.DevMF(ctx, dl, 1, 2) for dl in dls]
+    dout = [capi.DevMF(ctx, dl, 8, 0) for dl in dls]
+    capi.gradcurv_run(ctx, dst, 0, bc, capi.curv_params(prog_min=300.0, prog_max=2000.0, threshold=None, fused=True), work, dout, 0)
+    ctx.sync()
+    kn = ctx.lib.pa_sweep_kernel_name(ctx.h).decode()
+    nbad, ncmp = 0, 0
+    pairs = [(0, og, 0), (1, og, 1), (2, og, 2), (3, og, 3), (4, oc, 2), (5, oc, 3), (6, oc, 4), (7, oc, 1)]
+    for l, lv in enumerate(H.levels):
+        got = dout[l].download()
+        for b in range(lv.nboxes):
+            g = got.valid(b)
+            for gc, ref, rc in pairs:
+                w = ref[l].valid(b)[rc]
+                nbad += int(np.count_nonzero(np.ascontiguousarray(g[gc]).view(np.int64) != np.ascontiguousarray(w).view(np.int64)))
+                ncmp += w.size
+        del got
+    return {"cells": sum(lv.ncells for lv in H.levels), "values_compared": ncmp, "values_differing": nbad, "bits_equal": nbad == 0 and ctx.bc_errors() == 0,
+            "kernel": kn, "outputs": "gx gy gz |g| Nx Ny Nz K of every valid cell of every level, oracle (cpu_baseline sample) vs HIP path, int64 view",
+            "seconds": round(time.perf_counter() - t0, 2)}
 
 
 def live_traffic(timeout_s=150):
@@ -636,9 +668,15 @@ def main():
             # bounded sample (~10-30 s of CPU work): a 3-level hierarchy sized from the host core count
             cores = usable_cpus()
             base = args.cpu_base or (384 if cores >= 16 else (256 if cores >= 8 else 128))
-            res["cpu_baseline"] = cpu_baseline(base, args.nlev, min(args.box, base // 2))
+            res["cpu_baseline"], sample = cpu_baseline(base, args.nlev, min(args.box, base // 2))
         except Exception as e:  # the baseline is reported, never required for the GPU number
-            res["cpu_baseline"] = {"error": repr(e)}
+            res["cpu_baseline"], sample = {"error": repr(e)}, None
+        if sample is not None:
+            try:
+                torch.cuda.empty_cache()
+                res["parity_check"] = parity_check(ctx, sample)
+            except Exception as e:
+                res["parity_check"] = {"error": repr(e)[:300]}
     if rank == 0:
         print(json.dumps(res))
     if world > 1:
