@@ -388,7 +388,7 @@ def secondary(ctx, torch, stream, dev, only=None):
                 if l > 0:
                     ctx.check(ctx.lib.pa_fillpatch_two_levels(ctx.h, sts[l][1].h, sts[l - 1][1].h, 0, 4, 1, 2, 0))
 
-        def iso_mc():
+        def iso_mc_levels():  # one call per level (rounds 1-3): two host round trips and an allocation per level
             tri[0] = 0
             for l in range(3):
                 nb = Hn.levels[l].nboxes
@@ -399,13 +399,30 @@ def secondary(ctx, torch, stream, dev, only=None):
                 if pv.value:
                     ctx.lib.pa_device_free(ctx.h, pv)
 
+        nvs = [(C.c_int64 * lv.nboxes)() for lv in Hn.levels]
+        nts = [(C.c_int64 * lv.nboxes)() for lv in Hn.levels]
+        parr = (C.POINTER(capi.PaBox) * 3)(*[C.cast(a, C.POINTER(capi.PaBox)) for a in loops])
+        pnv = (C.POINTER(C.c_int64) * 3)(*[C.cast(a, C.POINTER(C.c_int64)) for a in nvs])
+        pnt = (C.POINTER(C.c_int64) * 3)(*[C.cast(a, C.POINTER(C.c_int64)) for a in nts])
+        fm = (C.c_int32 * 3)(1, 1, 0)
+        hst = (C.c_void_p * 3)(*[s_[1].h for s_ in sts])
+
+        def iso_mc():  # the whole hierarchy in one call: one count read-back, one pooled allocation, one final sync
+            pv, pk, pt = (C.c_void_p * 3)(), (C.c_void_p * 3)(), (C.c_void_p * 3)()
+            block = C.c_void_p()
+            ctx.check(ctx.lib.pa_mc_hierarchy_fine(ctx.h, 3, hst, fm, 2, parr, 3, 1150.0, pnv, pnt, pv, pk, pt, C.byref(block)))
+            tri[0] = sum(int(sum(nts[l][:Hn.levels[l].nboxes])) for l in range(3))
+            if block.value:
+                ctx.lib.pa_device_free(ctx.h, block)
+
         iso_state()
         c4cells = sum(lv.ncells for lv in Hn.levels)
-        ms_state, ms_mc = timed(iso_state), timed(iso_mc)
+        ms_state, ms_lev, ms_mc = timed(iso_state), timed(iso_mc_levels, reps=4), timed(iso_mc, reps=4)
         assert ctx.bc_errors() == 0
-        out["c4_isosurface_base256"] = entry(ms_mc, c4cells, 8, state_build_ms=ms_state, triangles=tri[0], Mtriangles_s=tri[0] / ms_mc / 1e3,
-                                             workload="coordinates + ghost fill (state_build_ms), then pa_mc_level_fine on 3 levels (finer level as mask), base 256^3, 64^3 boxes, "
-                                                      "T = 1150 isotherm; ms includes the per-level count read-back and output allocation")
+        out["c4_isosurface_base256"] = entry(ms_mc, c4cells, 8, state_build_ms=ms_state, level_by_level_ms=ms_lev, triangles=tri[0], Mtriangles_s=tri[0] / ms_mc / 1e3,
+                                             workload="coordinates + ghost fill (state_build_ms), then pa_mc_hierarchy_fine: marching cubes on 3 levels in one call (finer level as "
+                                                      "mask), base 256^3, 64^3 boxes, T = 1150 isotherm; ms includes the count read-back, the pooled output block and the final "
+                                                      "sync; level_by_level_ms = one pa_mc_level_fine call per level")
     if want("c4_isosurface_base256"):
         c4_case()
     return out

@@ -294,6 +294,16 @@ int pa_mc_level_fine(pa_ctx*, const pa_mf* state, const pa_level* fine, int rati
 int pa_msq_level_fine(pa_ctx*, const pa_mf* state, const pa_level* fine, int ratio, const pa_box* loops, int isocomp,
                       double isoval, int64_t* nvert, int64_t* nseg, double** dev_verts, int32_t** dev_vkeys,
                       int32_t** dev_segs);
+/* The level loop of isosurface.cpp:1434-1728 as ONE call: pa_mc_level_fine on every level of the hierarchy, with the cell
+ * passes and counts of all levels enqueued back to back, ONE read-back of the per-FAB counts, ONE pooled allocation for the
+ * surfaces of all levels and ONE final synchronisation (per level the reference pays an MFIter loop; here a level costs no
+ * host round trip of its own).  states[l] lives on level l; fine_mask[l] != 0: cells covered by level l + 1 are masked
+ * (isosurface.cpp:1540-1563; null: nothing is masked); loops[l] / nvert[l] / ntri[l]: host arrays over the FABs of level l.
+ * dev_verts[l] / dev_vkeys[l] / dev_tris[l] (host arrays of nlev pointers) point into *block (null for a level without
+ * surface); free *block with pa_device_free.  Per-level results are identical to pa_mc_level_fine's. */
+int pa_mc_hierarchy_fine(pa_ctx*, int nlev, const pa_mf* const* states, const int32_t* fine_mask, int ratio,
+                         const pa_box* const* loops, int isocomp, double isoval, int64_t* const* nvert, int64_t* const* ntri,
+                         double** dev_verts, int32_t** dev_vkeys, int32_t** dev_tris, void** block);
 /* isosurface.cpp:1687-1726 + 1751-1812 on the device: the global node / element sets from the per-FAB fragments, in
  * insertion order (level by level, FAB by FAB: exactly the fragments whose ntri > 0, as the reference skips the others).
  * A vertex within 1e-15 (Euclidean) of an earlier node IS that node (Node::operator<, :834-873), otherwise a new node

@@ -146,6 +146,8 @@ def load_library() -> C.CDLL:
                                        C.POINTER(vp)]),
         "pa_msq_level_fine": (C.c_int, [vp, vp, vp, C.c_int, C.POINTER(PaBox), C.c_int, dbl, C.POINTER(i64), C.POINTER(i64), C.POINTER(vp), C.POINTER(vp),
                                         C.POINTER(vp)]),
+        "pa_mc_hierarchy_fine": (C.c_int, [vp, C.c_int, C.POINTER(vp), pi32, C.c_int, C.POINTER(C.POINTER(PaBox)), C.c_int, dbl, C.POINTER(C.POINTER(i64)),
+                                           C.POINTER(C.POINTER(i64)), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
         "pa_msq_level": (C.c_int, [vp, vp, vp, C.c_int, C.POINTER(PaBox), C.c_int, dbl, C.POINTER(i64), C.POINTER(i64), C.POINTER(vp), C.POINTER(vp),
                                    C.POINTER(vp)]),
         "pa_mc_level": (C.c_int, [vp, vp, vp, C.c_int, C.POINTER(PaBox), C.c_int, dbl, C.POINTER(i64), C.POINTER(i64), C.POINTER(vp), C.POINTER(vp),
@@ -445,6 +447,56 @@ def gradcurv_run_comps2(ctx, states, comp0, ncomps, bc, params: PaCurvParams, wo
     if err:
         raise err[0]
     ctx.check(rc)
+
+
+def mc_hierarchy(ctx: Context, states, fine_mask, loops_per_level, isocomp: int, isoval: float, download: bool = True):
+    """pa_mc_hierarchy_fine: marching cubes on every level in one call.  states: DevMF per level; fine_mask: flag per level
+    (mask by the next finer level); loops_per_level: (nboxes, 6) arrays.  Returns per level the per-box list
+    [(verts, vkeys, tris)] (download=False: only the per-box counts [(nv, nt)])"""
+    nlev = len(states)
+    arrs, nvs, nts = [], [], []
+    for l in range(nlev):
+        lp = np.asarray(loops_per_level[l], dtype=np.int64).reshape(-1, 6)
+        nb = len(lp)
+        arr = (PaBox * max(nb, 1))()
+        for b in range(nb):
+            for d in range(3):
+                arr[b].lo[d], arr[b].hi[d] = int(lp[b, d]), int(lp[b, 3 + d])
+        arrs.append(arr)
+        nvs.append((C.c_int64 * max(nb, 1))())
+        nts.append((C.c_int64 * max(nb, 1))())
+    parr = (C.POINTER(PaBox) * nlev)(*[C.cast(a, C.POINTER(PaBox)) for a in arrs])
+    pnv = (C.POINTER(C.c_int64) * nlev)(*[C.cast(a, C.POINTER(C.c_int64)) for a in nvs])
+    pnt = (C.POINTER(C.c_int64) * nlev)(*[C.cast(a, C.POINTER(C.c_int64)) for a in nts])
+    fm = (C.c_int32 * nlev)(*[int(bool(f)) for f in fine_mask])
+    pv, pk, pt = (C.c_void_p * nlev)(), (C.c_void_p * nlev)(), (C.c_void_p * nlev)()
+    block = C.c_void_p()
+    ctx.check(ctx.lib.pa_mc_hierarchy_fine(ctx.h, nlev, _handles(states), fm, 2, parr, int(isocomp), float(isoval), pnv, pnt, pv, pk, pt, C.byref(block)))
+    out = []
+    try:
+        for l in range(nlev):
+            nb = len(np.asarray(loops_per_level[l]).reshape(-1, 6))
+            nv, nt = nvs[l], nts[l]
+            if not download:
+                out.append([(int(nv[b]), int(nt[b])) for b in range(nb)])
+                continue
+            nc = states[l].ncomp
+            tv, tt = int(sum(nv[:nb])), int(sum(nt[:nb]))
+            V = np.empty((tv, nc)); K = np.empty((tv, 6), np.int32); T = np.empty((tt, 3), np.int32)
+            if tv:
+                ctx.check(ctx.lib.pa_memcpy_d2h(ctx.h, V.ctypes.data_as(C.c_void_p), pv[l], V.nbytes))
+                ctx.check(ctx.lib.pa_memcpy_d2h(ctx.h, K.ctypes.data_as(C.c_void_p), pk[l], K.nbytes))
+            if tt:
+                ctx.check(ctx.lib.pa_memcpy_d2h(ctx.h, T.ctypes.data_as(C.c_void_p), pt[l], T.nbytes))
+            lev, ov, ot = [], 0, 0
+            for b in range(nb):
+                lev.append((V[ov:ov + nv[b]], K[ov:ov + nv[b]], T[ot:ot + nt[b]]))
+                ov += nv[b]; ot += nt[b]
+            out.append(lev)
+    finally:
+        if block.value:
+            ctx.lib.pa_device_free(ctx.h, block)
+    return out
 
 
 def sdf_level_set(ctx: Context, meshes, exact_band: int = 1):

@@ -46,6 +46,8 @@ extern "C" void pa_ctx_destroy(pa_ctx* ctx) {
   for (hipEvent_t e : ctx->fix_evs)
     if (e) (void)hipEventDestroy(e);
   if (ctx->d_scr) (void)hipFree(ctx->d_scr);
+  if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
+  if (ctx->d_mcz) (void)hipFree(ctx->d_mcz);
   for (auto& c : ctx->surf_cache) (void)hipFree(c.first);
   for (auto& e : ctx->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (auto& e : ctx->sync_evs) (void)hipEventDestroy(e);

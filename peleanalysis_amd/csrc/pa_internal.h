@@ -81,6 +81,11 @@ struct pa_ctx {
   double* d_prog = nullptr; // (pmin, 1 / (pmax - pmin)) of the component slots of a batch (pa_gradcurv_run_comps2)
   void* d_scr = nullptr;    // grow-only scratch (marching cubes)
   size_t scr_cap = 0;
+  void* h_pin = nullptr;    // grow-only pinned host buffer (count read-backs of marching cubes)
+  size_t h_pin_cap = 0;
+  void* d_mcz = nullptr;    // per-cell code bytes of the level-batched marching cubes: all zeros between calls (pa_mc.hip)
+  size_t mcz_cap = 0;
+  bool mcz_dirty = true;
   // surface blocks handed out by pa_mc_level* / taken back by pa_device_free: a freed block is kept (up to 4 of them) for
   // the next level's surface instead of a hipFree + hipMalloc pair per level (~0.1 ms, as long as the whole GPU pass)
   std::map<void*, size_t> surf_live;

@@ -12,6 +12,7 @@
 //   k_mc_tris      triangle connectivity (local vertex ids)
 // Each edge vertex is interpolated with the endpoint order of the FIRST live cube that touches the
 // edge in traversal order, like the reference's vertCache does.
+#include <cstring>
 #include "pa_internal.h"
 #include "pa_fabview.h"
 #include "mc_tables.h"
@@ -571,10 +572,10 @@ __global__ __launch_bounds__(64 * TY) void k_mcl_cells(MclArgs A) {
 // The values of cells whose right / upper neighbour does not exist are never used: such cells are outside every loop
 // box (mc_level_impl checks loop hi + 1 <= FAB hi), so their cube index is forced to 0 and their x / y bits are masked.
 template <int NT, int GPT, int MM>  // MM: 0 mask multifab, 1 no mask and no finer level, 2 mask = covered by the finer level LF
-__global__ __launch_bounds__(NT) void k_mcl_cells4(MclArgs A) {
-  extern __shared__ unsigned s_fl[];  // [2][A.ldsw]: one flag byte per cell of the slab + halo row, by plane parity
+__device__ __forceinline__ void mcl_cells4_body(const MclArgs& A, const unsigned bidx, unsigned* s_fl) {
+  // s_fl: [2][A.ldsw]: one flag byte per cell of the slab + halo row, by plane parity
   const unsigned total = (unsigned)A.L.nboxes * (unsigned)A.tiles, chunk = (total + 7u) / 8u;
-  const unsigned wg = (blockIdx.x & 7u) * chunk + (blockIdx.x >> 3);  // XCD x of 8 works through one contiguous run of tiles
+  const unsigned wg = (bidx & 7u) * chunk + (bidx >> 3);  // XCD x of 8 works through one contiguous run of tiles
   if (wg >= total) return;
   const int b = (int)(wg / (unsigned)A.tiles), tile = (int)(wg - (unsigned)b * (unsigned)A.tiles);
   MclGeo G;
@@ -692,17 +693,23 @@ __global__ __launch_bounds__(NT) void k_mcl_cells4(MclArgs A) {
     const unsigned lc = okm | (X << 1) | (Y << 2) | (Z << 3);
     const unsigned act = (((X | Y | Z) * 0xFFu) | ((ci ^ (ci >> 1)) & actmask)) & (OWN[g] * 0xFFu);
     const long long gi = g0 + (unsigned long long)k * (unsigned long long)nxy + 4 * (t + NT * g);
+    // The two code bytes of a cell are stored only where there is something: a cell that owns a crossing edge or whose live
+    // cube is cut by the surface.  Every later kernel reads codes of such cells only, or the live bit of a cube that touches
+    // a crossing edge -- which is cut if it is live -- so a zero byte stands for the rest.  The scratch that holds the codes
+    // is all zeros between calls (pa_ctx::d_mcz, k_mcl_clean); the pass then writes a few per cent of the level's cells
+    // instead of 2 B for every cell (measured before: 0.28 GB of the pass's 1.47 GB on a 512^3 level).
+    if (!act) return;
     if (al4 && OWN[g] == M1) {
       *(unsigned*)(A.lc + gi) = lc;
       *(unsigned*)(A.cidx + gi) = ci;
-      if (act) A.bact[gi >> 8] = 1;  // same value from every writer
+      A.bact[gi >> 8] = 1;  // same value from every writer
     } else {
 #pragma unroll 1
       for (int e = 0; e < 4; ++e)
-        if ((OWN[g] >> (8 * e)) & 1u) {
+        if (((OWN[g] >> (8 * e)) & 1u) && ((act >> (8 * e)) & 0xFFu)) {
           A.lc[gi + e] = (unsigned char)(lc >> (8 * e));
           A.cidx[gi + e] = (unsigned char)(ci >> (8 * e));
-          if ((act >> (8 * e)) & 0xFFu) A.bact[(gi + e) >> 8] = 1;
+          A.bact[(gi + e) >> 8] = 1;
         }
     }
   };
@@ -739,6 +746,35 @@ __global__ __launch_bounds__(NT) void k_mcl_cells4(MclArgs A) {
   }
 }
 
+template <int NT, int GPT, int MM>
+__global__ __launch_bounds__(NT) void k_mcl_cells4(MclArgs A) {
+  extern __shared__ unsigned s_fl[];
+  mcl_cells4_body<NT, GPT, MM>(A, blockIdx.x, s_fl);
+}
+
+// ---- several levels per launch (pa_mc_hierarchy_fine): level l owns workgroups wg0[l] .. wg0[l+1]-1 of a launch (the host
+// fills wg0 per kernel: tiles, 1024-block chunks, FABs, vertices / 256, triangles / 256); the persistent kernels walk the
+// levels' marked-block lists one after the other
+struct MclBatch {
+  int n;
+  unsigned wg0[PA_MAXB + 1];
+  MclArgs a[PA_MAXB];
+  __device__ __forceinline__ int find(unsigned w, unsigned& local) const {
+    int l = 0;
+    while (l + 1 < n && w >= wg0[l + 1]) ++l;
+    local = w - wg0[l];
+    return l;
+  }
+};
+template <int NT, int GPT>
+__global__ __launch_bounds__(NT) void k_mclb_cells4(MclBatch Bt) {
+  extern __shared__ unsigned s_fl[];
+  unsigned w;
+  const MclArgs& A = Bt.a[Bt.find(blockIdx.x, w)];
+  if (A.has_fine) mcl_cells4_body<NT, GPT, 2>(A, w, s_fl);
+  else mcl_cells4_body<NT, GPT, 1>(A, w, s_fl);
+}
+
 // FAB of a scratch block: last b with coff[b] <= first cell of the block
 __device__ __forceinline__ int mcl_box_of(const MclArgs& A, long long cell0) {
   int lo = 0, hi = A.L.nboxes - 1;
@@ -750,9 +786,9 @@ __device__ __forceinline__ int mcl_box_of(const MclArgs& A, long long cell0) {
 }
 // list of the marked blocks as (block, FAB) pairs (order irrelevant: every block is processed on its own); one atomic per
 // WORKGROUP of 1024 blocks (per wave of 64 it was 8192 serialised atomics on one address for a 512^3 level: 35 us)
-__global__ __launch_bounds__(1024) void k_mcl_active(MclArgs A, int nblk) {
+__device__ __forceinline__ void mcl_active_body(const MclArgs& A, int nblk, unsigned bidx) {
   __shared__ int s_cnt[16], s_base;
-  const int q = blockIdx.x * 1024 + threadIdx.x;
+  const int q = (int)bidx * 1024 + threadIdx.x;
   const bool on = q < nblk && A.bact[q];
   const unsigned long long m = __ballot(on);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -769,6 +805,13 @@ __global__ __launch_bounds__(1024) void k_mcl_active(MclArgs A, int nblk) {
     A.alist[2 * slot] = q;
     A.alist[2 * slot + 1] = mcl_box_of(A, 256LL * q);
   }
+}
+
+__global__ __launch_bounds__(1024) void k_mcl_active(MclArgs A, int nblk) { mcl_active_body(A, nblk, blockIdx.x); }
+__global__ __launch_bounds__(1024) void k_mclb_active(MclBatch Bt) {
+  unsigned w;
+  const int l = Bt.find(blockIdx.x, w);
+  mcl_active_body(Bt.a[l], (int)(Bt.a[l].coff[Bt.a[l].L.nboxes] / 256), w);
 }
 
 __device__ __forceinline__ int wave_sum(int v) {
@@ -789,7 +832,7 @@ __device__ __forceinline__ int wave_excl(int v, int lane) {  // exclusive prefix
 // A marked 256-cell block is one WAVE's work: lane l holds cells 4 l .. 4 l + 3 (their lc / cidx bytes are one dword each),
 // sums and prefixes are wave shuffles -- no LDS, no barrier.  (As one workgroup per block, with two barriers per block,
 // these two kernels took 0.145 + 0.131 ms on ~1.3e5 marked blocks.)
-__global__ __launch_bounds__(256) void k_mcl_count(MclArgs A) {
+__device__ __forceinline__ void mcl_count_body(const MclArgs& A) {
   const int nact = *A.nact, lane = threadIdx.x & 63;
   const int nwave = gridDim.x * 4;
   for (int q = blockIdx.x * 4 + (threadIdx.x >> 6); q < nact; q += nwave) {  // marked blocks only (bsum of the others was zeroed)
@@ -831,10 +874,15 @@ __global__ __launch_bounds__(256) void k_mcl_count(MclArgs A) {
   }
 }
 
+__global__ __launch_bounds__(256) void k_mcl_count(MclArgs A) { mcl_count_body(A); }
+__global__ __launch_bounds__(256) void k_mclb_count(MclBatch Bt) {
+  for (int l = 0; l < Bt.n; ++l) mcl_count_body(Bt.a[l]);
+}
+
 // one workgroup per FAB: exclusive scan of the FAB's block sums in place (FAB-local offsets), totals to tot[b]
-__global__ __launch_bounds__(1024) void k_mcl_scan(MclArgs A) {
+__device__ __forceinline__ void mcl_scan_body(const MclArgs& A, const int b) {
   __shared__ long long s_a[1024], s_b[1024];
-  const int b = blockIdx.x, t = threadIdx.x;
+  const int t = threadIdx.x;
   MclGeo G;
   const bool on = mcl_geo(A, b, G);
   const int nblocks = on ? (int)((G.ncell + 255u) / 256u) : 0;
@@ -860,12 +908,47 @@ __global__ __launch_bounds__(1024) void k_mcl_scan(MclArgs A) {
   if (t == 1023) { A.tot[2 * b] = s_a[1023]; A.tot[2 * b + 1] = s_b[1023]; }
 }
 
+__global__ __launch_bounds__(1024) void k_mcl_scan(MclArgs A) { mcl_scan_body(A, blockIdx.x); }
+__global__ __launch_bounds__(1024) void k_mclb_scan(MclBatch Bt) {
+  unsigned w;
+  const int l = Bt.find(blockIdx.x, w);
+  mcl_scan_body(Bt.a[l], (int)w);
+}
+// first vertex / triangle of every FAB inside its level's part of the output (exclusive prefix of the FAB totals; one
+// workgroup per level, a level has at most a few thousand FABs): the host only needs the totals
+__global__ __launch_bounds__(256) void k_mclb_base(MclBatch Bt) {
+  const MclArgs& A = Bt.a[blockIdx.x];
+  long long* base = const_cast<long long*>(A.base);
+  __shared__ long long s_v[256], s_t[256];
+  const int nb = A.L.nboxes, t = threadIdx.x, per = (nb + 255) / 256;
+  const int lo = min(t * per, nb), hi = min(lo + per, nb);
+  long long v = 0, c = 0;
+  for (int b = lo; b < hi; ++b) {
+    const bool on = A.coff[b + 1] > A.coff[b];
+    v += on ? A.tot[2 * b] : 0; c += on ? A.tot[2 * b + 1] : 0;
+  }
+  s_v[t] = v; s_t[t] = c;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {
+    const long long xv = t >= o ? s_v[t - o] : 0, xt = t >= o ? s_t[t - o] : 0;
+    __syncthreads();
+    s_v[t] += xv; s_t[t] += xt;
+    __syncthreads();
+  }
+  long long ev = s_v[t] - v, et = s_t[t] - c;
+  for (int b = lo; b < hi; ++b) {
+    const bool on = A.coff[b + 1] > A.coff[b];
+    base[2 * b] = ev; base[2 * b + 1] = et;
+    ev += on ? A.tot[2 * b] : 0; et += on ? A.tot[2 * b + 1] : 0;
+  }
+}
+
 // Emission.  k_mcl_lists (marked blocks): vertex offset of every cell (kept for the triangles) and one work item per
 // vertex / per triangle, parked in the output slot of that vertex (its 24-byte key) / triangle (its 12-byte id triple):
 // (scratch cell, FAB, edge direction or triangle number).  k_mcl_verts / k_mcl_tris then run one thread per item --
 // a marked block holds ~3 vertices per 256 cells, so per-block emission left 99 % of the lanes idle behind chains of
 // dependent loads (measured 0.64 + 0.33 ms for 0.46 M vertices + 0.91 M triangles).
-__global__ __launch_bounds__(256) void k_mcl_lists(MclArgs A, int* vkeys, int* tris) {
+__device__ __forceinline__ void mcl_lists_body(const MclArgs& A, int* vkeys, int* tris) {
   const int nact = *A.nact, lane = threadIdx.x & 63;
   const int nwave = gridDim.x * 4;
   for (int q = blockIdx.x * 4 + (threadIdx.x >> 6); q < nact; q += nwave) {  // one wave per marked block, as k_mcl_count
@@ -907,8 +990,14 @@ __global__ __launch_bounds__(256) void k_mcl_lists(MclArgs A, int* vkeys, int* t
   }
 }
 
-__global__ __launch_bounds__(256) void k_mcl_verts(MclArgs A, double* verts, int* vkeys, long long nv) {
-  const long long vo = blockIdx.x * 256LL + threadIdx.x;
+__global__ __launch_bounds__(256) void k_mcl_lists(MclArgs A, int* vkeys, int* tris) { mcl_lists_body(A, vkeys, tris); }
+struct MclOut { double* dv[PA_MAXB]; int* dk[PA_MAXB]; int* dt[PA_MAXB]; long long nv[PA_MAXB], nt[PA_MAXB]; };
+__global__ __launch_bounds__(256) void k_mclb_lists(MclBatch Bt, MclOut O) {
+  for (int l = 0; l < Bt.n; ++l)
+    if (O.dk[l]) mcl_lists_body(Bt.a[l], O.dk[l], O.dt[l]);
+}
+
+__device__ __forceinline__ void mcl_verts_body(const MclArgs& A, double* verts, int* vkeys, long long nv, const long long vo) {
   if (vo >= nv) return;
   int* key = vkeys + 6LL * vo;
   const long long g = (long long)(unsigned)key[0] | ((long long)key[1] << 32);
@@ -940,8 +1029,16 @@ __global__ __launch_bounds__(256) void k_mcl_verts(MclArgs A, double* verts, int
   key[0] = i; key[1] = j; key[2] = k; key[3] = hi_i; key[4] = hi_j; key[5] = hi_k;
 }
 
-__global__ __launch_bounds__(256) void k_mcl_tris(MclArgs A, int* tris, long long nt) {
-  const long long to = blockIdx.x * 256LL + threadIdx.x;
+__global__ __launch_bounds__(256) void k_mcl_verts(MclArgs A, double* verts, int* vkeys, long long nv) {
+  mcl_verts_body(A, verts, vkeys, nv, blockIdx.x * 256LL + threadIdx.x);
+}
+__global__ __launch_bounds__(256) void k_mclb_verts(MclBatch Bt, MclOut O) {
+  unsigned w;
+  const int l = Bt.find(blockIdx.x, w);
+  mcl_verts_body(Bt.a[l], O.dv[l], O.dk[l], O.nv[l], w * 256LL + threadIdx.x);
+}
+
+__device__ __forceinline__ void mcl_tris_body(const MclArgs& A, int* tris, long long nt, const long long to) {
   if (to >= nt) return;
   int* o = tris + 3LL * to;
   const long long g = (long long)(unsigned)o[0] | ((long long)o[1] << 32);
@@ -970,6 +1067,29 @@ __global__ __launch_bounds__(256) void k_mcl_tris(MclArgs A, int* tris, long lon
     }
   }
   o[0] = out[0]; o[1] = out[1]; o[2] = out[2];
+}
+
+__global__ __launch_bounds__(256) void k_mcl_tris(MclArgs A, int* tris, long long nt) { mcl_tris_body(A, tris, nt, blockIdx.x * 256LL + threadIdx.x); }
+__global__ __launch_bounds__(256) void k_mclb_tris(MclBatch Bt, MclOut O) {
+  unsigned w;
+  const int l = Bt.find(blockIdx.x, w);
+  mcl_tris_body(Bt.a[l], O.dt[l], O.nt[l], w * 256LL + threadIdx.x);
+}
+
+// the code bytes of the marked blocks back to zero: the invariant of pa_ctx::d_mcz (one wave per block, 4 bytes per lane and array)
+__device__ __forceinline__ void mcl_clean_body(const MclArgs& A) {
+  const int nact = *A.nact, lane = threadIdx.x & 63;
+  const int nwave = gridDim.x * 4;
+  for (int q = blockIdx.x * 4 + (threadIdx.x >> 6); q < nact; q += nwave) {
+    const long long g = (long long)A.alist[2 * q] * 256 + 4 * lane;
+    *(unsigned*)(A.lc + g) = 0u;
+    *(unsigned*)(A.cidx + g) = 0u;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_mcl_clean(MclArgs A) { mcl_clean_body(A); }
+__global__ __launch_bounds__(256) void k_mclb_clean(MclBatch Bt) {
+  for (int l = 0; l < Bt.n; ++l) mcl_clean_body(Bt.a[l]);
 }
 
 // mask of isosurface.cpp:1540-1563: 1, and -1 on cells (ghost cells included) covered by the next finer level
@@ -1062,26 +1182,46 @@ extern "C" int pa_msq_level(pa_ctx* ctx, const pa_mf* state, const pa_mf* mask, 
   PaBind bind_(ctx);
   return mc_level_impl(ctx, state, mask, mcomp, loops, isocomp, isoval, nvert, nseg, dev_verts, dev_vkeys, dev_segs, 1);
 }
-static int mc_level_impl(pa_ctx* ctx, const pa_mf* state, const pa_mf* mask, int mcomp, const pa_box* loops, int isocomp, double isoval, int64_t* nvert,
-                         int64_t* ntri, double** dev_verts, int32_t** dev_vkeys, int32_t** dev_tris, int dim2, int nomask, const pa_level* fine, int ratio) {
-  if (!ctx || !state || !mask || !loops || !nvert || !ntri || !dev_verts || !dev_vkeys || !dev_tris) return pa_fail(ctx, "pa_mc_level: null argument");
-  *dev_verts = nullptr; *dev_vkeys = nullptr; *dev_tris = nullptr;
+// ---- one level's pass in two phases, so that several levels share ONE count read-back, ONE output allocation and ONE final
+// synchronisation (pa_mc_hierarchy_fine); the single-level entry points run the same two phases back to back.
+//   phase 1  cell pass, marked-block list, counts, per-FAB scan; the FAB totals are copied to pinned host memory (async)
+//   -- the caller synchronises once, sums the totals of every level and carves the output block --
+//   phase 2  work lists, vertices, triangles into the level's part of the block
+struct MclWork {
+  MclArgs A;
+  const pa_mf* state = nullptr;
+  int nb = 0, dim2 = 0;
+  std::vector<long long> coff, base;
+  std::vector<DBox> dl;
+  size_t ncell = 0, nblk = 0, hdr = 0, bytes = 0;  // scratch of this level
+  long long maxcell = 0, nv = 0, nt = 0;
+  int64_t *nvert = nullptr, *ntri = nullptr;
+  long long* h_tot = nullptr;                      // [nb][2] in the context's pinned buffer
+  long long* d_base = nullptr;
+  double* dv = nullptr; int32_t *dk = nullptr, *dt = nullptr;
+  bool full_codes = false;
+};
+
+static int mc_prepare(pa_ctx* ctx, const pa_mf* state, const pa_mf* mask, int mcomp, const pa_box* loops, int isocomp, double isoval, int64_t* nvert, int64_t* ntri,
+                      int dim2, int nomask, const pa_level* fine, int ratio, MclWork& W) {
+  if (!ctx || !state || !mask || !loops || !nvert || !ntri) return pa_fail(ctx, "pa_mc_level: null argument");
   if (state->lev != mask->lev || state->ng != mask->ng) return pa_fail(ctx, "pa_mc_level: state and mask must share the level and the ghost width");
   if (state->ncomp < (dim2 ? 3 : 4)) return pa_fail(ctx, "pa_mc_level: state needs the coordinate components + at least one field");
   if (isocomp < 0 || isocomp >= state->ncomp || mcomp < 0 || mcomp >= mask->ncomp) return pa_fail(ctx, "pa_mc_level: component range");
   const pa_level* L = state->lev;
   const int nb = (int)L->boxes.size(), ng = state->ng;
-  std::vector<long long> coff((size_t)nb + 1, 0);
-  std::vector<DBox> dl((size_t)nb);
-  long long maxcell = 0;
+  W.state = state; W.nb = nb; W.dim2 = dim2; W.nvert = nvert; W.ntri = ntri;
+  W.coff.assign((size_t)nb + 1, 0);
+  W.dl.resize((size_t)nb);
+  W.maxcell = 0;
   for (int b = 0; b < nb; ++b) {
     const DBox& B = L->boxes[b];
     long long nc = 1;
     bool on = true;
     for (int d = 0; d < 3; ++d) {
       nc *= B.hi[d] - B.lo[d] + 1 + 2 * ng;
-      dl[b].lo[d] = loops[b].lo[d];
-      dl[b].hi[d] = loops[b].hi[d];
+      W.dl[b].lo[d] = loops[b].lo[d];
+      W.dl[b].hi[d] = loops[b].hi[d];
       on = on && loops[b].lo[d] <= loops[b].hi[d];
     }
     if (on)
@@ -1091,18 +1231,19 @@ static int mc_level_impl(pa_ctx* ctx, const pa_mf* state, const pa_mf* mask, int
         if (dim2 && d == 2 && loops[b].lo[d] != loops[b].hi[d]) return pa_fail(ctx, "pa_msq_level: the loop box must be one plane of cells");
       }
     if (nc >= (1LL << 31)) return pa_fail(ctx, "pa_mc_level: FAB too large");
-    maxcell = std::max(maxcell, on ? nc : 0);
-    coff[b + 1] = coff[b] + (on ? (nc + 255) / 256 * 256 : 0);
+    W.maxcell = std::max(W.maxcell, on ? nc : 0);
+    W.coff[b + 1] = W.coff[b] + (on ? (nc + 255) / 256 * 256 : 0);
     nvert[b] = ntri[b] = 0;
   }
-  if (nb == 0 || maxcell == 0) return 0;
-  PA_TRY_RET(upload_tables(ctx));
-  const size_t ncell = (size_t)coff[nb], nblk = ncell / 256;
-  if (nblk > 0x7fffffffull) return pa_fail(ctx, "pa_mc_level: level too large for one pass");
-  const size_t hdr = ((size_t)nb * (16 + 16 + 24) + ((size_t)nb + 1) * 8 + 255) / 256 * 256;
-  if (ensure_scr(ctx, hdr + 7 * ncell + 17 * nblk + 512)) return 1;
-  unsigned char* p = (unsigned char*)ctx->d_scr;
-  MclArgs A;
+  W.ncell = W.nblk = W.hdr = W.bytes = 0;
+  if (nb == 0 || W.maxcell == 0) return 0;
+  if (nb > 0x0fffffff) return pa_fail(ctx, "pa_mc_level: too many FABs");
+  W.ncell = (size_t)W.coff[nb];
+  W.nblk = W.ncell / 256;
+  if (W.nblk > 0x7fffffffull) return pa_fail(ctx, "pa_mc_level: level too large for one pass");
+  W.hdr = ((size_t)nb * (16 + 16 + 24) + ((size_t)nb + 1) * 8 + 255) / 256 * 256;
+  W.bytes = (W.hdr + 5 * W.ncell + 17 * W.nblk + 512 + 255) / 256 * 256;  // + 2 B per cell in the context's zeroed code buffer
+  MclArgs& A = W.A;
   A.L = L->view; A.S = state->view; A.M = mask->view;
   A.mcomp = mcomp; A.isocomp = isocomp; A.ncomp = state->ncomp; A.iso = isoval;
   A.kseg = 32;
@@ -1112,23 +1253,44 @@ static int mc_level_impl(pa_ctx* ctx, const pa_mf* state, const pa_mf* mask, int
   A.has_fine = (nomask && fine) ? 1 : 0;
   A.ratio = ratio;
   A.LF = fine ? fine->view : L->view;
+  return 0;
+}
+
+// pinned host memory for the FAB totals of a pass (grow-only)
+static long long* mc_pinned(pa_ctx* ctx, size_t n) {
+  if (ctx->h_pin_cap < n * sizeof(long long)) {
+    if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
+    ctx->h_pin = nullptr; ctx->h_pin_cap = 0;
+    const size_t want = std::max<size_t>(n * sizeof(long long), 1 << 16);
+    if (hipHostMalloc(&ctx->h_pin, want, hipHostMallocDefault) != hipSuccess) { pa_fail(ctx, "pa_mc_level: pinned host allocation failed"); return nullptr; }
+    ctx->h_pin_cap = want;
+  }
+  return (long long*)ctx->h_pin;
+}
+
+static int mc_phase1(pa_ctx* ctx, MclWork& W, unsigned char* scr, unsigned char* codes) {
+  if (W.nb == 0 || W.maxcell == 0) return 0;
+  const pa_level* L = W.state->lev;
+  const int nb = W.nb, ng = W.state->ng;
+  const size_t ncell = W.ncell, nblk = W.nblk;
+  MclArgs& A = W.A;
+  unsigned char* p = scr;
   A.tot = (long long*)p; p += 16 * (size_t)nb;
-  long long* d_base = (long long*)p; p += 16 * (size_t)nb;
+  W.d_base = (long long*)p; p += 16 * (size_t)nb;
   long long* d_coff = (long long*)p; p += 8 * ((size_t)nb + 1);
   DBox* d_loops = (DBox*)p;
-  p = (unsigned char*)ctx->d_scr + hdr;
+  p = scr + W.hdr;
   A.voff = (int*)p; p += 4 * ncell;
   A.bsum = (int*)p; p += 8 * nblk;
-  A.lc = p; p += ncell;
-  A.cidx = p; p += ncell;
+  A.lc = codes;
+  A.cidx = codes + ncell;
   A.vflag = p; p += ncell;
   A.bact = p; p += (nblk + 255) / 256 * 256;
   A.alist = (int*)p; p += 8 * nblk;
   A.nact = (int*)p;
-  A.base = d_base; A.coff = d_coff; A.loops = d_loops;
-  ProfScope prof(ctx, PA_TAG_MC);
-  PA_HIP(hipMemcpyAsync(d_coff, coff.data(), 8 * ((size_t)nb + 1), hipMemcpyHostToDevice, ctx->stream));
-  PA_HIP(hipMemcpyAsync(d_loops, dl.data(), sizeof(DBox) * (size_t)nb, hipMemcpyHostToDevice, ctx->stream));
+  A.base = W.d_base; A.coff = d_coff; A.loops = d_loops;
+  PA_HIP(hipMemcpyAsync(d_coff, W.coff.data(), 8 * ((size_t)nb + 1), hipMemcpyHostToDevice, ctx->stream));
+  PA_HIP(hipMemcpyAsync(d_loops, W.dl.data(), sizeof(DBox) * (size_t)nb, hipMemcpyHostToDevice, ctx->stream));
   {
     const char* te = getenv("PA_MC_TY");  // first form only: tile rows / planes per workgroup of the cell pass (tuning, read per call)
     const char* ke = getenv("PA_MC_KSEG");
@@ -1137,9 +1299,9 @@ static int mc_level_impl(pa_ctx* ctx, const pa_mf* state, const pa_mf* mask, int
     if (ke && atoi(ke) > 0) A.kseg = atoi(ke);
     const int mx = L->maxn[0] + 2 * ng, my = L->maxn[1] + 2 * ng, mz = L->maxn[2] + 2 * ng;
     auto tiles = [&](int ty) { return (unsigned)(std::max(1, (mx - 1 + 62) / 63) * std::max(1, (my - 1 + ty - 2) / (ty - 1)) * ((mz + A.kseg - 1) / A.kseg)); };
-    PA_HIP(hipMemsetAsync(A.bact, 0, nblk, ctx->stream));
+    // bact | alist | nact are adjacent and bsum precedes lc: two clears (bsum; bact .. nact)
     PA_HIP(hipMemsetAsync(A.bsum, 0, 8 * nblk, ctx->stream));
-    PA_HIP(hipMemsetAsync(A.nact, 0, 4, ctx->stream));
+    PA_HIP(hipMemsetAsync(A.bact, 0, (size_t)((unsigned char*)A.nact - A.bact) + 4, ctx->stream));
     constexpr int NT4 = 512, GPT4 = 2;  // 4096 cells of a plane per workgroup
     if (!(fe && std::string(fe) == "tiles") && (long long)mx * 5 <= 4LL * NT4 * GPT4) {
       // slab = as many whole rows as fit next to their halo row, evened out over the slabs of the largest FAB, multiple of 4
@@ -1158,64 +1320,314 @@ static int mc_level_impl(pa_ctx* ctx, const pa_mf* state, const pa_mf* mask, int
       if (total > 0x7ffffff0LL) return pa_fail(ctx, "pa_mc_level: level too large for one pass");
       const dim3 g4((unsigned)((total + 7) / 8 * 8));
       const size_t lds4 = 2 * (size_t)A.ldsw * 4;
-      if (!nomask) hipLaunchKernelGGL((k_mcl_cells4<NT4, GPT4, 0>), g4, dim3(NT4), lds4, ctx->stream, A);
+      if (!A.nomask) hipLaunchKernelGGL((k_mcl_cells4<NT4, GPT4, 0>), g4, dim3(NT4), lds4, ctx->stream, A);
       else if (!A.has_fine) hipLaunchKernelGGL((k_mcl_cells4<NT4, GPT4, 1>), g4, dim3(NT4), lds4, ctx->stream, A);
       else hipLaunchKernelGGL((k_mcl_cells4<NT4, GPT4, 2>), g4, dim3(NT4), lds4, ctx->stream, A);
-    } else if (TY == 16) hipLaunchKernelGGL((k_mcl_cells<16>), dim3(tiles(16), (unsigned)nb), dim3(64 * 16), 0, ctx->stream, A);
-    else if (TY == 4) hipLaunchKernelGGL((k_mcl_cells<4>), dim3(tiles(4), (unsigned)nb), dim3(64 * 4), 0, ctx->stream, A);
-    else hipLaunchKernelGGL((k_mcl_cells<8>), dim3(tiles(8), (unsigned)nb), dim3(64 * 8), 0, ctx->stream, A);
+    } else {
+      W.full_codes = true;  // the first form writes the codes of every cell: the code buffer is cleared as a whole afterwards
+      if (TY == 16) hipLaunchKernelGGL((k_mcl_cells<16>), dim3(tiles(16), (unsigned)nb), dim3(64 * 16), 0, ctx->stream, A);
+      else if (TY == 4) hipLaunchKernelGGL((k_mcl_cells<4>), dim3(tiles(4), (unsigned)nb), dim3(64 * 4), 0, ctx->stream, A);
+      else hipLaunchKernelGGL((k_mcl_cells<8>), dim3(tiles(8), (unsigned)nb), dim3(64 * 8), 0, ctx->stream, A);
+    }
     hipLaunchKernelGGL(k_mcl_active, dim3((unsigned)((nblk + 1023) / 1024)), dim3(1024), 0, ctx->stream, A, (int)nblk);
   }
   const dim3 grid(4096);  // persistent over the marked blocks
   hipLaunchKernelGGL(k_mcl_count, grid, dim3(256), 0, ctx->stream, A);
   hipLaunchKernelGGL(k_mcl_scan, dim3((unsigned)nb), dim3(1024), 0, ctx->stream, A);
   PA_HIP(hipGetLastError());
-  std::vector<long long> tot(2 * (size_t)nb), base(2 * (size_t)nb);
-  PA_HIP(hipMemcpyAsync(tot.data(), A.tot, 16 * (size_t)nb, hipMemcpyDeviceToHost, ctx->stream));
-  PA_HIP(hipStreamSynchronize(ctx->stream));  // coff / dl / tot are host vectors of this call
-  long long nv = 0, nt = 0;
-  for (int b = 0; b < nb; ++b) {
-    const bool on = coff[b + 1] > coff[b];
-    nvert[b] = on ? tot[2 * b] : 0;
-    ntri[b] = on ? tot[2 * b + 1] : 0;
-    if (nvert[b] > 0x7fffffffLL || ntri[b] > 0x7fffffffLL / 3) return pa_fail(ctx, "pa_mc_level: surface of one FAB too large for 32-bit ids");
-    base[2 * b] = nv; base[2 * b + 1] = nt;
-    nv += nvert[b]; nt += ntri[b];
+  PA_HIP(hipMemcpyAsync(W.h_tot, A.tot, 16 * (size_t)nb, hipMemcpyDeviceToHost, ctx->stream));
+  return 0;
+}
+
+// after the synchronisation: per-FAB counts of this level, its bases inside its part of the output
+static int mc_counts(pa_ctx* ctx, MclWork& W) {
+  W.nv = W.nt = 0;
+  if (W.nb == 0 || W.maxcell == 0) return 0;
+  W.base.assign(2 * (size_t)W.nb, 0);
+  for (int b = 0; b < W.nb; ++b) {
+    const bool on = W.coff[b + 1] > W.coff[b];
+    W.nvert[b] = on ? W.h_tot[2 * b] : 0;
+    W.ntri[b] = on ? W.h_tot[2 * b + 1] : 0;
+    if (W.nvert[b] > 0x7fffffffLL || W.ntri[b] > 0x7fffffffLL / 3) return pa_fail(ctx, "pa_mc_level: surface of one FAB too large for 32-bit ids");
+    W.base[2 * b] = W.nv; W.base[2 * b + 1] = W.nt;
+    W.nv += W.nvert[b]; W.nt += W.ntri[b];
   }
-  if (nv == 0 && nt == 0) return 0;
-  // one allocation: vertices | keys | triangles (each part 256-byte aligned)
-  const size_t bv = ((size_t)nv * state->ncomp * 8 + 255) / 256 * 256, bk = ((size_t)nv * 24 + 255) / 256 * 256, bt = std::max<size_t>(8, (size_t)nt * 12);
+  return 0;
+}
+// bytes of a level's part of the output block: vertices | keys | triangles, each 256-byte aligned
+static void mc_parts(const MclWork& W, size_t& bv, size_t& bk, size_t& bt) {
+  bv = ((size_t)W.nv * W.state->ncomp * 8 + 255) / 256 * 256;
+  bk = ((size_t)W.nv * 24 + 255) / 256 * 256;
+  bt = (std::max<size_t>(8, (size_t)W.nt * 12) + 255) / 256 * 256;
+}
+
+static int mc_phase2(pa_ctx* ctx, MclWork& W, unsigned char* part) {
+  if (W.nv == 0 && W.nt == 0) return 0;
+  size_t bv, bk, bt;
+  mc_parts(W, bv, bk, bt);
+  W.dv = (double*)part;
+  W.dk = (int32_t*)(part + bv);
+  W.dt = (int32_t*)(part + bv + bk);
+  PA_HIP(hipMemcpyAsync(W.d_base, W.base.data(), 16 * (size_t)W.nb, hipMemcpyHostToDevice, ctx->stream));
+  const dim3 grid(4096);
+  hipLaunchKernelGGL(k_mcl_lists, grid, dim3(256), 0, ctx->stream, W.A, W.dk, W.dt);
+  if (W.nv > 0) hipLaunchKernelGGL(k_mcl_verts, dim3((unsigned)((W.nv + 255) / 256)), dim3(256), 0, ctx->stream, W.A, W.dv, W.dk, W.nv);
+  if (W.nt > 0) hipLaunchKernelGGL(k_mcl_tris, dim3((unsigned)((W.nt + 255) / 256)), dim3(256), 0, ctx->stream, W.A, W.dt, W.nt);
+  PA_HIP(hipGetLastError());
+  return 0;
+}
+
+// the output block: a cached one that fits without wasting more than half of itself, else a new one (freed by pa_device_free)
+static unsigned char* mc_block(pa_ctx* ctx, size_t need) {
   unsigned char* blockp = nullptr;
-  auto bail = [&](const std::string& m) { if (blockp) { ctx->surf_live.erase(blockp); (void)hipFree(blockp); } return pa_fail(ctx, m); };
-  {  // a cached block that fits without wasting more than half of itself, else a new one (freed by pa_device_free)
-    const size_t need = bv + bk + bt;
-    size_t got = 0;
-    int best = -1;
-    for (int c = 0; c < (int)ctx->surf_cache.size(); ++c)
-      if (ctx->surf_cache[c].second >= need && ctx->surf_cache[c].second <= 2 * need + (1u << 20) && (best < 0 || ctx->surf_cache[c].second < ctx->surf_cache[best].second)) best = c;
-    if (best >= 0) {
-      blockp = (unsigned char*)ctx->surf_cache[best].first;
-      got = ctx->surf_cache[best].second;
-      ctx->surf_cache.erase(ctx->surf_cache.begin() + best);
-    } else {
-      if (hipMalloc(&blockp, need) != hipSuccess) {  // make room: drop the cache and try once more
-        blockp = nullptr;
-        for (auto& c : ctx->surf_cache) (void)hipFree(c.first);
-        ctx->surf_cache.clear();
-        if (hipMalloc(&blockp, need) != hipSuccess) { blockp = nullptr; return bail("pa_mc_level: out of device memory for the surface"); }
-      }
-      got = need;
+  size_t got = 0;
+  int best = -1;
+  for (int c = 0; c < (int)ctx->surf_cache.size(); ++c)
+    if (ctx->surf_cache[c].second >= need && ctx->surf_cache[c].second <= 2 * need + (1u << 20) && (best < 0 || ctx->surf_cache[c].second < ctx->surf_cache[best].second)) best = c;
+  if (best >= 0) {
+    blockp = (unsigned char*)ctx->surf_cache[best].first;
+    got = ctx->surf_cache[best].second;
+    ctx->surf_cache.erase(ctx->surf_cache.begin() + best);
+  } else {
+    if (hipMalloc(&blockp, need) != hipSuccess) {  // make room: drop the cache and try once more
+      blockp = nullptr;
+      for (auto& c : ctx->surf_cache) (void)hipFree(c.first);
+      ctx->surf_cache.clear();
+      if (hipMalloc(&blockp, need) != hipSuccess) { pa_fail(ctx, "pa_mc_level: out of device memory for the surface"); return nullptr; }
     }
-    ctx->surf_live[blockp] = got;
+    got = need;
   }
-  double* dv = (double*)blockp;
-  int32_t *dk = (int32_t*)(blockp + bv), *dt = (int32_t*)(blockp + bv + bk);
-  if (hipMemcpyAsync(d_base, base.data(), 16 * (size_t)nb, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return bail("pa_mc_level: upload failed");
-  if (nb > 0x0fffffff) return bail("pa_mc_level: too many FABs");
-  hipLaunchKernelGGL(k_mcl_lists, grid, dim3(256), 0, ctx->stream, A, dk, dt);
-  if (nv > 0) hipLaunchKernelGGL(k_mcl_verts, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, ctx->stream, A, dv, dk, nv);
-  if (nt > 0) hipLaunchKernelGGL(k_mcl_tris, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, ctx->stream, A, dt, nt);
-  if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return bail("pa_mc_level: emit kernels failed");
-  *dev_verts = dv; *dev_vkeys = dk; *dev_tris = dt;
+  ctx->surf_live[blockp] = got;
+  return blockp;
+}
+
+static_assert(sizeof(MclBatch) + sizeof(MclOut) <= 4000, "kernel arguments of the batched marching-cubes kernels");
+
+// The levels of a hierarchy through ONE set of launches (k_mclb_*): one upload of the levels' tables, one clear, one launch per
+// stage for all levels, one read-back of the FAB totals, the FAB bases computed on the device, no final synchronisation (the
+// results are complete in stream order: pa_memcpy_d2h and every later call on the context wait for them).
+// Scratch: [C: per level coff | loops][T: per level tot][B: per level base][Z: per level bsum | bact | alist | nact][R: per level voff | vflag]
+static int mc_run_batched(pa_ctx* ctx, int nlev, MclWork* W) {
+  constexpr int NT4 = 512, GPT4 = 2;
+  auto al = [](size_t v) { return (v + 255) / 256 * 256; };
+  size_t cb = 0, tb = 0, zb = 0, rb = 0, ncodes = 0;
+  for (int l = 0; l < nlev; ++l) {
+    const size_t nb = (size_t)W[l].nb;
+    cb += al(8 * (nb + 1) + sizeof(DBox) * nb);
+    tb += 16 * nb;
+    zb += al(8 * W[l].nblk) + al(W[l].nblk) + al(8 * W[l].nblk) + 256;
+    rb += al(4 * W[l].ncell) + al(W[l].ncell);
+    ncodes += 2 * W[l].ncell;
+  }
+  tb = al(tb);
+  const size_t bb = tb;
+  if (ensure_scr(ctx, cb + tb + bb + zb + rb)) return 1;
+  PA_TRY_RET(upload_tables(ctx));
+  unsigned char* pin = (unsigned char*)mc_pinned(ctx, (cb + tb) / sizeof(long long) + 8);
+  if (!pin) return 1;
+  if (ctx->mcz_cap < ncodes) {
+    if (ctx->d_mcz) (void)hipFree(ctx->d_mcz);
+    ctx->d_mcz = nullptr; ctx->mcz_cap = 0;
+    PA_HIP(hipMalloc(&ctx->d_mcz, ncodes));
+    ctx->mcz_cap = ncodes;
+    ctx->mcz_dirty = true;
+  }
+  if (ctx->mcz_dirty) PA_HIP(hipMemsetAsync(ctx->d_mcz, 0, ctx->mcz_cap, ctx->stream));
+  ctx->mcz_dirty = true;
+  unsigned char* const S = (unsigned char*)ctx->d_scr;
+  unsigned char *pc = S, *pt = S + cb, *pb = S + cb + tb, *pz = S + cb + tb + bb, *pr = S + cb + tb + bb + zb, *pcode = (unsigned char*)ctx->d_mcz;
+  unsigned char* hc = pin;  // host image of region C
+  MclBatch Bt;
+  Bt.n = nlev;
+  size_t ldsw = 0;
+  for (int l = 0; l < nlev; ++l) {
+    MclWork& w = W[l];
+    MclArgs& A = w.A;
+    const size_t nb = (size_t)w.nb;
+    const pa_level* L = w.state->lev;
+    const int ng = w.state->ng;
+    std::memcpy(hc, w.coff.data(), 8 * (nb + 1));
+    std::memcpy(hc + 8 * (nb + 1), w.dl.data(), sizeof(DBox) * nb);
+    A.coff = (const long long*)pc;
+    A.loops = (const DBox*)(pc + 8 * (nb + 1));
+    pc += al(8 * (nb + 1) + sizeof(DBox) * nb); hc += al(8 * (nb + 1) + sizeof(DBox) * nb);
+    A.tot = (long long*)pt; w.h_tot = (long long*)(pin + cb + (pt - (S + cb))); pt += 16 * nb;
+    w.d_base = (long long*)pb; A.base = w.d_base; pb += 16 * nb;
+    A.bsum = (int*)pz; pz += al(8 * w.nblk);
+    A.bact = pz; pz += al(w.nblk);
+    A.alist = (int*)pz; pz += al(8 * w.nblk);
+    A.nact = (int*)pz; pz += 256;
+    A.voff = (int*)pr; pr += al(4 * w.ncell);
+    A.vflag = pr; pr += al(w.ncell);
+    A.lc = pcode; A.cidx = pcode + w.ncell; pcode += 2 * w.ncell;
+    // slab form of the cell pass (as mc_phase1)
+    const int mx = L->maxn[0] + 2 * ng, my = L->maxn[1] + 2 * ng, mz = L->maxn[2] + 2 * ng;
+    const int rmax = std::max(4, ((4 * NT4 * GPT4) / mx - 1) / 4 * 4);
+    const int ns0 = (my + rmax - 1) / rmax;
+    A.rows = std::min(rmax, ((my + ns0 - 1) / ns0 + 3) / 4 * 4);
+    A.nslab = (my + A.rows - 1) / A.rows;
+    {
+      const long long want = 6144;
+      const int nseg = (int)std::min<long long>(std::max<long long>(1, mz / 16), std::max<long long>(1, (want + (long long)nb * A.nslab - 1) / ((long long)nb * A.nslab)));
+      A.kseg = (mz + nseg - 1) / nseg;
+    }
+    A.tiles = A.nslab * ((mz + A.kseg - 1) / A.kseg);
+    A.ldsw = NT4 * GPT4 + (mx >> 2) + 4;
+    ldsw = std::max(ldsw, (size_t)A.ldsw);
+    Bt.a[l] = A;
+  }
+  ProfScope prof(ctx, PA_TAG_MC);
+  PA_HIP(hipMemcpyAsync(S, pin, cb, hipMemcpyHostToDevice, ctx->stream));
+  PA_HIP(hipMemsetAsync(S + cb + tb + bb, 0, zb, ctx->stream));
+  auto ranges = [&](auto count) {  // wg0 of a launch from the levels' workgroup counts
+    Bt.wg0[0] = 0;
+    for (int l = 0; l < nlev; ++l) Bt.wg0[l + 1] = Bt.wg0[l] + (unsigned)count(l);
+    return Bt.wg0[nlev];
+  };
+  unsigned g = ranges([&](int l) { return ((long long)W[l].nb * W[l].A.tiles + 7) / 8 * 8; });
+  hipLaunchKernelGGL((k_mclb_cells4<NT4, GPT4>), dim3(g), dim3(NT4), 2 * ldsw * 4, ctx->stream, Bt);
+  g = ranges([&](int l) { return (W[l].nblk + 1023) / 1024; });
+  hipLaunchKernelGGL(k_mclb_active, dim3(g), dim3(1024), 0, ctx->stream, Bt);
+  hipLaunchKernelGGL(k_mclb_count, dim3(4096), dim3(256), 0, ctx->stream, Bt);
+  g = ranges([&](int l) { return W[l].nb; });
+  hipLaunchKernelGGL(k_mclb_scan, dim3(g), dim3(1024), 0, ctx->stream, Bt);
+  hipLaunchKernelGGL(k_mclb_base, dim3((unsigned)nlev), dim3(256), 0, ctx->stream, Bt);
+  PA_HIP(hipGetLastError());
+  PA_HIP(hipMemcpyAsync(pin + cb, S + cb, tb, hipMemcpyDeviceToHost, ctx->stream));
+  PA_HIP(hipStreamSynchronize(ctx->stream));  // the ONE read-back: FAB totals of every level
+  size_t need = 0;
+  for (int l = 0; l < nlev; ++l) {
+    if (mc_counts(ctx, W[l])) return 1;
+    if (W[l].nv || W[l].nt) { size_t bv, bk, bt; mc_parts(W[l], bv, bk, bt); need += bv + bk + bt; }
+  }
+  MclOut O;
+  if (need > 0) {
+    unsigned char* blockp = mc_block(ctx, need);
+    if (!blockp) return 1;
+    size_t off = 0;
+    for (int l = 0; l < nlev; ++l) {
+      O.dv[l] = nullptr; O.dk[l] = nullptr; O.dt[l] = nullptr; O.nv[l] = W[l].nv; O.nt[l] = W[l].nt;
+      if (!(W[l].nv || W[l].nt)) continue;
+      size_t bv, bk, bt;
+      mc_parts(W[l], bv, bk, bt);
+      W[l].dv = (double*)(blockp + off); W[l].dk = (int32_t*)(blockp + off + bv); W[l].dt = (int32_t*)(blockp + off + bv + bk);
+      O.dv[l] = W[l].dv; O.dk[l] = W[l].dk; O.dt[l] = W[l].dt;
+      off += bv + bk + bt;
+    }
+    hipLaunchKernelGGL(k_mclb_lists, dim3(4096), dim3(256), 0, ctx->stream, Bt, O);
+    g = ranges([&](int l) { return (W[l].nv + 255) / 256; });
+    if (g) hipLaunchKernelGGL(k_mclb_verts, dim3(g), dim3(256), 0, ctx->stream, Bt, O);
+    g = ranges([&](int l) { return (W[l].nt + 255) / 256; });
+    if (g) hipLaunchKernelGGL(k_mclb_tris, dim3(g), dim3(256), 0, ctx->stream, Bt, O);
+  }
+  hipLaunchKernelGGL(k_mclb_clean, dim3(1024), dim3(256), 0, ctx->stream, Bt);
+  if (hipGetLastError() != hipSuccess) return pa_fail(ctx, "pa_mc_hierarchy_fine: emit kernels failed");
+  ctx->mcz_dirty = false;
+  return 0;
+}
+
+// nlev levels (one for the single-level entry points): see MclWork
+static int mc_run(pa_ctx* ctx, int nlev, MclWork* W) {
+  {  // all levels in one set of launches when each of them takes the slab form of the cell pass with the mask evaluated in place
+    const char* be = getenv("PA_MC_BATCH");  // 0: level by level (A/B), read per call
+    bool batched = nlev > 1 && nlev <= PA_MAXB && (!be || atoi(be)) && !getenv("PA_MC_CELLS") && !getenv("PA_MC_KSEG");
+    for (int l = 0; l < nlev && batched; ++l) {
+      const int mx = W[l].state->lev->maxn[0] + 2 * W[l].state->ng;
+      batched = W[l].nb > 0 && W[l].maxcell > 0 && W[l].A.nomask && !W[l].dim2 && (long long)mx * 5 <= 4LL * 512 * 2;
+    }
+    if (batched) return mc_run_batched(ctx, nlev, W);
+  }
+  size_t scr = 0, npin = 0;
+  for (int l = 0; l < nlev; ++l) { scr += W[l].bytes; npin += 2 * (size_t)W[l].nb; }
+  if (scr == 0) return 0;
+  PA_TRY_RET(upload_tables(ctx));
+  if (ensure_scr(ctx, scr)) return 1;
+  long long* pin = mc_pinned(ctx, npin);
+  if (!pin) return 1;
+  // the code bytes (2 per cell) live in a buffer that is all zeros between calls: cleared when it is (re)allocated or when a
+  // call left it dirty (an error between the cell pass and the clean-up), otherwise only the marked blocks are reset
+  size_t ncodes = 0;
+  for (int l = 0; l < nlev; ++l) ncodes += 2 * W[l].ncell;
+  if (ctx->mcz_cap < ncodes) {
+    if (ctx->d_mcz) (void)hipFree(ctx->d_mcz);
+    ctx->d_mcz = nullptr; ctx->mcz_cap = 0;
+    PA_HIP(hipMalloc(&ctx->d_mcz, ncodes));
+    ctx->mcz_cap = ncodes;
+    ctx->mcz_dirty = true;
+  }
+  if (ctx->mcz_dirty) PA_HIP(hipMemsetAsync(ctx->d_mcz, 0, ctx->mcz_cap, ctx->stream));
+  ctx->mcz_dirty = true;  // until the clean-up of this call is enqueued
+  ProfScope prof(ctx, PA_TAG_MC);
+  size_t so = 0, po = 0, co = 0;
+  for (int l = 0; l < nlev; ++l) {
+    W[l].h_tot = pin + po;
+    if (mc_phase1(ctx, W[l], (unsigned char*)ctx->d_scr + so, (unsigned char*)ctx->d_mcz + co)) return 1;
+    so += W[l].bytes; po += 2 * (size_t)W[l].nb; co += 2 * W[l].ncell;
+  }
+  auto clean = [&]() {  // enqueue the reset of the code buffer (after the last reader)
+    bool full = false;
+    for (int l = 0; l < nlev; ++l) full = full || W[l].full_codes;
+    if (full) return;  // stays dirty: the next call clears everything
+    for (int l = 0; l < nlev; ++l)
+      if (W[l].nb && W[l].maxcell) hipLaunchKernelGGL(k_mcl_clean, dim3(1024), dim3(256), 0, ctx->stream, W[l].A);
+    if (hipGetLastError() == hipSuccess) ctx->mcz_dirty = false;
+  };
+  PA_HIP(hipStreamSynchronize(ctx->stream));  // the ONE count read-back (coff / dl are host vectors of this call)
+  size_t need = 0;
+  for (int l = 0; l < nlev; ++l) {
+    if (mc_counts(ctx, W[l])) return 1;
+    if (W[l].nv || W[l].nt) { size_t bv, bk, bt; mc_parts(W[l], bv, bk, bt); need += bv + bk + bt; }
+  }
+  if (need == 0) { clean(); return 0; }
+  unsigned char* blockp = mc_block(ctx, need);
+  if (!blockp) return 1;
+  auto bail = [&](const std::string& m) { ctx->surf_live.erase(blockp); (void)hipFree(blockp); for (int l = 0; l < nlev; ++l) { W[l].dv = nullptr; W[l].dk = W[l].dt = nullptr; } return pa_fail(ctx, m); };
+  size_t off = 0;
+  for (int l = 0; l < nlev; ++l) {
+    if (!(W[l].nv || W[l].nt)) continue;
+    if (mc_phase2(ctx, W[l], blockp + off)) return bail("pa_mc_level: emit kernels failed: " + ctx->err);
+    size_t bv, bk, bt;
+    mc_parts(W[l], bv, bk, bt);
+    off += bv + bk + bt;
+  }
+  clean();
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess) return bail("pa_mc_level: emit kernels failed");  // base vectors are host memory of this call
+  return 0;
+}
+
+static int mc_level_impl(pa_ctx* ctx, const pa_mf* state, const pa_mf* mask, int mcomp, const pa_box* loops, int isocomp, double isoval, int64_t* nvert,
+                         int64_t* ntri, double** dev_verts, int32_t** dev_vkeys, int32_t** dev_tris, int dim2, int nomask, const pa_level* fine, int ratio) {
+  if (!ctx || !dev_verts || !dev_vkeys || !dev_tris) return pa_fail(ctx, "pa_mc_level: null argument");
+  *dev_verts = nullptr; *dev_vkeys = nullptr; *dev_tris = nullptr;
+  MclWork W;
+  if (mc_prepare(ctx, state, mask, mcomp, loops, isocomp, isoval, nvert, ntri, dim2, nomask, fine, ratio, W)) return 1;
+  if (mc_run(ctx, 1, &W)) return 1;
+  *dev_verts = W.dv; *dev_vkeys = W.dk; *dev_tris = W.dt;  // one allocation, base = the vertex array
+  return 0;
+}
+
+// isosurface.cpp:1434-1728 for ALL levels in one call: every level's cell pass / counts are enqueued back to back, the counts
+// of the whole hierarchy are read back ONCE, every level's surface goes into ONE pooled allocation (*block, freed with
+// pa_device_free; dev_verts[l] / dev_vkeys[l] / dev_tris[l] point into it, null for a level without surface) and the host
+// waits once at the end.  states[l] on level l, masked by level l + 1 (fine_mask[l] != 0, isosurface.cpp:1540-1563) or not
+// at all; loops / nvert / ntri: per level, as pa_mc_level_fine.
+extern "C" int pa_mc_hierarchy_fine(pa_ctx* ctx, int nlev, const pa_mf* const* states, const int32_t* fine_mask, int ratio, const pa_box* const* loops, int isocomp,
+                                    double isoval, int64_t* const* nvert, int64_t* const* ntri, double** dev_verts, int32_t** dev_vkeys, int32_t** dev_tris, void** block) {
+  PaBind bind_(ctx);
+  if (!ctx || nlev <= 0 || !states || !loops || !nvert || !ntri || !dev_verts || !dev_vkeys || !dev_tris || !block) return pa_fail(ctx, "pa_mc_hierarchy_fine: null argument");
+  if (ratio < 1) return pa_fail(ctx, "pa_mc_hierarchy_fine: bad refinement ratio");
+  *block = nullptr;
+  std::vector<MclWork> W((size_t)nlev);
+  for (int l = 0; l < nlev; ++l) {
+    dev_verts[l] = nullptr; dev_vkeys[l] = nullptr; dev_tris[l] = nullptr;
+    if (!states[l]) return pa_fail(ctx, "pa_mc_hierarchy_fine: null state");
+    const pa_level* fine = (fine_mask && fine_mask[l] && l + 1 < nlev) ? states[l + 1]->lev : nullptr;
+    if (mc_prepare(ctx, states[l], states[l], 0, loops[l], isocomp, isoval, nvert[l], ntri[l], 0, 1, fine, ratio, W[l])) return 1;
+  }
+  if (mc_run(ctx, nlev, W.data())) return 1;
+  for (int l = 0; l < nlev; ++l) {
+    dev_verts[l] = W[l].dv; dev_vkeys[l] = W[l].dk; dev_tris[l] = W[l].dt;
+    if (W[l].dv && !*block) *block = W[l].dv;  // the first level with a surface starts the block
+  }
   return 0;
 }

@@ -429,3 +429,62 @@ def test_level_entry_points_reject_bad_arguments(ctx):
     assert rc == 0
     if pv.value:
         ctx.lib.pa_device_free(ctx.h, pv)
+
+
+@pytest.mark.parametrize("name,ng", [("amr3_wall_z", 1), ("amr2_allwalls_ragged", 2), ("amr3_sym_x", 1)])
+def test_marching_cubes_hierarchy_call_matches_oracle_and_level_calls(ctx, oracle, name, ng):
+    """pa_mc_hierarchy_fine (all levels in one call: one count read-back, one pooled output block) against the oracle's per-FAB
+    Polygonise loop and against pa_mc_level_fine level by level -- vertices bit for bit, keys and connectivity identical; a
+    level whose loop boxes are all empty, and a second call that reuses the cached block"""
+    from util import build_config, make_states
+    H, per, sym, fn = build_config(name)
+    fields = make_states(H, 2, 0, fn, seed=12)
+    nc = 5
+    states = []
+    for l, lv in enumerate(H.levels):
+        st = MultiFab(lv, nc, ng, fill=-666.0)
+        for b in range(lv.nboxes):
+            f = st.fab(b)
+            lo = lv.boxes[b, :3] - ng
+            nz, ny, nx = f.shape[1:]
+            f[0] = ((np.arange(lo[0], lo[0] + nx) + 0.5) * lv.dx[0] + lv.prob_lo[0])[None, None, :]
+            f[1] = ((np.arange(lo[1], lo[1] + ny) + 0.5) * lv.dx[1] + lv.prob_lo[1])[None, :, None]
+            f[2] = ((np.arange(lo[2], lo[2] + nz) + 0.5) * lv.dx[2] + lv.prob_lo[2])[:, None, None]
+            st.valid(b)[3:5] = fields[l].valid(b)[0:2]
+        oracle.fill_boundary(st, 0, nc, ng)
+        if l > 0:
+            assert oracle.lib().orc_fillpatch_two_levels(C.byref(oracle._mf(st)), C.byref(oracle._mf(states[l - 1])), 0, nc, ng, 2, 0) == 0
+        states.append(st)
+    iso = float(np.median(np.concatenate([s.valid(b)[3].ravel() for s in states for b in range(s.level.nboxes)])))
+    dls = [capi.DevLevel(ctx, lv) for lv in H.levels]
+    dst = [capi.DevMF.from_host(ctx, dl, s) for dl, s in zip(dls, states)]
+    loops, want = [], []
+    for l, lv in enumerate(H.levels):
+        lp, wl = np.zeros((lv.nboxes, 6), np.int64), []
+        for b in range(lv.nboxes):
+            lo, hi, mask, llo, lhi = oracle.iso_fab_inputs(H.levels, states, l, b, ng)
+            lp[b, :3], lp[b, 3:] = llo, lhi
+            wl.append(oracle.mc_fab(np.ascontiguousarray(states[l].fab(b)), mask, lo, hi, 3, iso, llo, lhi))
+        loops.append(lp)
+        want.append(wl)
+    fm = [1] * (H.nlev - 1) + [0]
+    for rep in range(2):  # the second call takes the output block from the context's cache
+        got = capi.mc_hierarchy(ctx, dst, fm, loops, 3, iso)
+        ntri = 0
+        for l, lv in enumerate(H.levels):
+            lev = capi.mc_level(ctx, dst[l], dls[l + 1] if l + 1 < H.nlev else None, loops[l], 3, iso)
+            for b in range(lv.nboxes):
+                (v, k, t), (gv, gk, gt), (lv_, lk, lt) = want[l][b], got[l][b], lev[b]
+                assert (len(gv), len(gt)) == (len(v), len(t)), f"{name} level {l} box {b}: counts differ"
+                assert np.array_equal(gk, k) and np.array_equal(gt, t), f"{name} level {l} box {b}: keys / connectivity differ"
+                assert np.array_equal(gv.view(np.int64), np.ascontiguousarray(v).view(np.int64)), f"{name} level {l} box {b}: vertex data not bit-identical"
+                assert np.array_equal(gv.view(np.int64), lv_.view(np.int64)) and np.array_equal(gk, lk) and np.array_equal(gt, lt), "hierarchy call != level call"
+                ntri += len(t)
+        assert ntri > 100
+    # the finest level switched off (every loop box empty) and an iso value nothing crosses: null parts, no block
+    off = [lp.copy() for lp in loops]
+    off[-1][:, 3] = off[-1][:, 0] - 1
+    got = capi.mc_hierarchy(ctx, dst, fm, off, 3, iso)
+    assert all(len(t) == 0 for (_, _, t) in got[-1]) and sum(len(t) for (_, _, t) in got[0]) > 0
+    got = capi.mc_hierarchy(ctx, dst, fm, loops, 3, 1.0e30)
+    assert all(len(t) == 0 and len(v) == 0 for lev in got for (v, _, t) in lev)
