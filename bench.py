@@ -450,6 +450,9 @@ def main():
     ap.add_argument("--cpu-base", type=int, default=0, help="base size of the cpu_baseline sample (0: from the core count)")
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong", help="N > 1: shard ONE hierarchy (strong) or one hierarchy per GPU (weak)")
     ap.add_argument("--sim-of", type=int, default=0, help="diagnostic, 1 GPU: time rank 0's share of an N-rank strong-scaling run with no-op exchanges")
+    ap.add_argument("--xdelay-us", type=float, default=-1.0, help="--sim-of: every exchange costs this many microseconds (+ bytes / --xlink-GBs) on the stream it is issued on "
+                                                                  "(pa_ctx_set_delay_comm) instead of nothing: how much of an exchange the schedule hides")
+    ap.add_argument("--xlink-GBs", type=float, default=0.0, help="--sim-of with --xdelay-us: per-peer link bandwidth of the delay model (xGMI: ~153 GB/s nominal); 0: fixed delay only")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.sim_of:
@@ -519,11 +522,16 @@ def main():
     xch = {"mode": "none"}
     gcomm = None
     if args.sim_of:  # one rank's share of an N-rank run on this GPU, exchanges replaced by no-ops: compute time per rank
-        nullx = capi.EXCHANGE_FN(lambda user, st, n, x: 0)
-        nullr = capi.ALLREDUCE_FN(lambda user, v, n, op: 0)
-        simc = capi.PaComm(None, 0, nshard, nullx, nullr)
-        ctx.set_comm(simc)
-        xch["mode"] = f"SIMULATION of rank 0 of {nshard}: exchanges are no-ops (results wrong in ghost cells, timing = compute only)"
+        if args.xdelay_us >= 0:
+            ctx.check(ctx.lib.pa_ctx_set_delay_comm(ctx.h, nshard, 0, float(args.xdelay_us), float(args.xlink_GBs)))
+            xch["mode"] = (f"SIMULATION of rank 0 of {nshard}: every exchange is a spin of {args.xdelay_us:g} us" +
+                           (f" + bytes to the busiest peer / {args.xlink_GBs:g} GB/s" if args.xlink_GBs > 0 else "") + " on its stream (delay-model transport; results wrong in ghost cells)")
+        else:
+            nullx = capi.EXCHANGE_FN(lambda user, st, n, x: 0)
+            nullr = capi.ALLREDUCE_FN(lambda user, v, n, op: 0)
+            simc = capi.PaComm(None, 0, nshard, nullx, nullr)
+            ctx.set_comm(simc)
+            xch["mode"] = f"SIMULATION of rank 0 of {nshard}: exchanges are no-ops (results wrong in ghost cells, timing = compute only)"
     elif world > 1:
         err = ""
         if not rehearse:
@@ -642,6 +650,12 @@ def main():
                    "cells": cells, "cells_this_rank": cells_local, "ncomp": args.ncomp, "components_per_batch": nslot, "fused": bool(args.fused),
                    "parallelism": par, "exchange": xch},
     }
+    if args.sim_of and args.xdelay_us >= 0:
+        import ctypes as C_
+        nc_, us_ = C_.c_int64(), C_.c_double()
+        if ctx.lib.pa_delay_comm_stats(ctx.h, C_.byref(nc_), C_.byref(us_)) == 0 and nc_.value:
+            res["delay_model"] = {"exchanges": nc_.value, "modelled_us_per_exchange": us_.value / nc_.value,
+                                  "modelled_us_per_step": us_.value / max(1, args.steps + args.warmup + 2)}
     if args.sim_of:
         res["simulated"] = True
         res["sim_of"] = nshard

@@ -112,6 +112,12 @@ typedef struct {
 int pa_ctx_set_comm(pa_ctx*, const pa_comm*);
 /* built-in transport: RCCL over xGMI (grouped ncclSend / ncclRecv on the context's stream, ncclAllReduce).
  * pa_rccl_unique_id fills 128 bytes on one rank; the caller broadcasts them; every rank then calls pa_ctx_init_rccl. */
+/* diagnostic transport for PROJECTIONS of an N-rank run on one GPU (bench.py --sim-of N --xdelay-us / --xlink-GBs): moves no
+ * data; every exchange enqueues on its stream a kernel that spins for fixed_us + (most bytes to or from one peer) / link_GBs,
+ * the cost model of a grouped point-to-point exchange over per-peer xGMI links -- the schedule hides or exposes that time as it
+ * would a real exchange.  Ghost-cell results are wrong by construction.  pa_delay_comm_stats: exchanges issued / modelled time. */
+int pa_ctx_set_delay_comm(pa_ctx*, int nranks, int rank, double fixed_us, double link_GBs);
+int pa_delay_comm_stats(const pa_ctx*, int64_t* calls, double* total_us);
 int pa_rccl_unique_id(pa_ctx*, void* id128);
 int pa_ctx_init_rccl(pa_ctx*, int nranks, int rank, const void* id128);
 int pa_ctx_nranks(const pa_ctx*);

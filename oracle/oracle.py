@@ -164,8 +164,8 @@ def box_filter_weights(fgr):
 
 
 def filter_weights(ftype, fgr):
-    """orc_filter_weights: (ngrow, weights) of PelePhysics filter type ftype (0, 1, 3, 4, 7, 8), None for the others"""
-    w = (C.c_double * (max(fgr, 3) + 2))()
+    """orc_filter_weights: (ngrow, weights) of PelePhysics filter type ftype (0, 1, 2 [unverified], 3, 4, 7, 8), None for the others"""
+    w = (C.c_double * 40)()
     ng = lib().orc_filter_weights(int(ftype), int(fgr), w)
     return None if ng < 0 else (ng, np.array(w[:2 * ng + 1]))
 
@@ -496,7 +496,7 @@ def iso_merge(fragments, ncomp):
     return nodes, elts
 
 
-def iso_fab_inputs(levels, states, lev, b, ng=1, fine_mask=True):
+def iso_fab_inputs(levels, states, lev, b, ng=1, fine_mask=True, ratio=2):
     """mask (isosurface.cpp:1540-1563, with the periodic images of the coarsened fine boxes, :1550-1560; all 1 when
     building the distance function, :1542) and loop box (:1566-1569: grown box & domain grown by ng in the periodic
     directions, high side - 1) of box b grown by ng"""
@@ -511,7 +511,7 @@ def iso_fab_inputs(levels, states, lev, b, ng=1, fine_mask=True):
                   for sz in ((-1, 0, 1) if per[2] else (0,))]
         for fb in levels[lev + 1].boxes:
             for sh in shifts:
-                clo, chi = fb[:3] // 2 + sh, fb[3:] // 2 + sh  # coarsen (floor), periodic image
+                clo, chi = fb[:3] // ratio + sh, fb[3:] // ratio + sh  # coarsen (floor), periodic image
                 ilo, ihi = np.maximum(lo, clo), np.minimum(hi, chi)
                 if np.all(ilo <= ihi):
                     mask[ilo[2] - lo[2]:ihi[2] - lo[2] + 1, ilo[1] - lo[1]:ihi[1] - lo[1] + 1, ilo[0] - lo[0]:ihi[0] - lo[0] + 1] = -1.0

@@ -537,6 +537,15 @@ int orc_filter_weights(int type, int fgr, double* w) {
   switch (type) {
     case 0: w[0] = 1.0; return 0;
     case 1: return orc_box_filter_weights(fgr, w);
+    case 2: { /* Gaussian, UNVERIFIED against PelePhysics: exp(-6 i^2 / fgr^2), i = -ng..ng, ng = ceil(4 fgr / sqrt 12) >= 1, sum 1 */
+      int ng = (int)ceil(4.0 * (double)fgr / sqrt(12.0));
+      double sum = 0.0;
+      if (ng < 1) ng = 1;
+      if (ng > 16) return -1;
+      for (int i = -ng; i <= ng; ++i) { w[i + ng] = exp(-6.0 * (double)(i * i) / f2); sum += w[i + ng]; }
+      for (int i = 0; i <= 2 * ng; ++i) w[i] = w[i] / sum;
+      return ng;
+    }
     case 3: case 7:
       w[0] = f2 / 24.0; w[2] = f2 / 24.0; w[1] = (12.0 - f2) / 12.0;
       return 1;

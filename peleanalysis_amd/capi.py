@@ -94,6 +94,8 @@ def load_library() -> C.CDLL:
         "pa_level_create_sharded": (vp, [vp, C.c_int, pi32, pi32, C.c_int, C.c_int, pi32, pi32, pi32, pdbl, pdbl]),
         "pa_level_global_ids": (C.c_int, [vp, pi32]),
         "pa_ctx_set_comm": (C.c_int, [vp, C.POINTER(PaComm)]),
+        "pa_ctx_set_delay_comm": (C.c_int, [vp, C.c_int, C.c_int, dbl, dbl]),
+        "pa_delay_comm_stats": (C.c_int, [vp, C.POINTER(i64), pdbl]),
         "pa_rccl_unique_id": (C.c_int, [vp, vp]),
         "pa_ctx_init_rccl": (C.c_int, [vp, C.c_int, C.c_int, vp]),
         "pa_ctx_nranks": (C.c_int, [vp]),

@@ -81,8 +81,8 @@ RepPlan* pa_rep_plan(pa_ctx* ctx, const pa_level* L);
 struct XJob { XPlan* plan; const pa_mf* src; int scomp; pa_mf* dst; int dcomp; int ncomp; int group = 0, sgstride = 0, dgstride = 0; };
 
 XPlan* pa_fb_plan(pa_ctx* ctx, const pa_level* L, int ng);
-CsPlan* pa_cs_plan(pa_ctx* ctx, const pa_level* F, const pa_level* C, int mode, int ng, int halo);
+CsPlan* pa_cs_plan(pa_ctx* ctx, const pa_level* F, const pa_level* C, int mode, int ng, int halo, int ratio = 2);
 // pack -> ONE grouped point-to-point call over all jobs and peers -> unpack; stream-ordered, no host synchronisation
 int pa_xexchange(pa_ctx* ctx, int njobs, const XJob* jobs);
-int pa_coarse_source(pa_ctx* ctx, const pa_level* fine, const pa_mf* crse, int ccomp, int ncomp, int mode, int ng, int halo, const pa_mf** src, int* scomp);
+int pa_coarse_source(pa_ctx* ctx, const pa_level* fine, const pa_mf* crse, int ccomp, int ncomp, int mode, int ng, int halo, const pa_mf** src, int* scomp, int ratio = 2);
 void pa_rccl_destroy(pa_ctx* ctx);

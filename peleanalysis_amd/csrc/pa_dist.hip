@@ -241,7 +241,7 @@ static bool box_suspect(const HostGeom& FG, const DBox& B) {
 }
 
 // coarse cells the coarse-fine stencils of fine box B touch (coarse index space, may reach outside the domain)
-static void cs_rects_of_box(const HostGeom& FG, const DBox& B, int mode, int ng, int halo, std::vector<DBox>& rects) {
+static void cs_rects_of_box(const HostGeom& FG, const DBox& B, int mode, int ng, int halo, std::vector<DBox>& rects, int ratio = 2) {
   if (mode == 0) {
     // A box that may hold irregular cells rebuilds ghost normals as the NEIGHBOURING box sees them (k_curv_general: boundary
     // values of the tangential directions at cells one layer outside the box): the coarse parents of the box grown by one
@@ -278,10 +278,10 @@ static void cs_rects_of_box(const HostGeom& FG, const DBox& B, int mode, int ng,
     // mf_cell_cons_interp: 1), minus the coarse cells well inside the box
     DBox outer, inner;
     for (int t = 0; t < 3; ++t) {
-      outer.lo[t] = fl2(B.lo[t] - ng) - halo;
-      outer.hi[t] = fl2(B.hi[t] + ng) + halo;
-      inner.lo[t] = fl2(B.lo[t] + 1) + halo;       // first coarse cell with all children inside, moved in by halo
-      inner.hi[t] = fl2(B.hi[t] + 1) - 1 - halo;
+      outer.lo[t] = coarsen_idx(B.lo[t] - ng, ratio) - halo;
+      outer.hi[t] = coarsen_idx(B.hi[t] + ng, ratio) + halo;
+      inner.lo[t] = coarsen_idx(B.lo[t] + ratio - 1, ratio) + halo;   // first coarse cell with all children inside, moved in by halo
+      inner.hi[t] = coarsen_idx(B.hi[t] + 1, ratio) - 1 - halo;
     }
     bool has_inner = true;
     for (int t = 0; t < 3; ++t) has_inner = has_inner && inner.lo[t] <= inner.hi[t];
@@ -292,10 +292,10 @@ static void cs_rects_of_box(const HostGeom& FG, const DBox& B, int mode, int ng,
 
 // the disjoint pieces of the coarse level that rank r keeps a copy of, in the order of r's coarse-source BoxArray
 static std::vector<CsPiece> cs_pieces(const HostGeom& FG, const std::vector<DBox>& fboxes, const std::vector<int>& fowner, const std::vector<DBox>& cboxes,
-                                      const int cdomlo[3], const int cdomhi[3], const int is_per[3], int r, int mode, int ng, int halo) {
+                                      const int cdomlo[3], const int cdomhi[3], const int is_per[3], int r, int mode, int ng, int halo, int ratio = 2) {
   std::vector<DBox> rects;
   for (size_t b = 0; b < fboxes.size(); ++b)
-    if (fowner[b] == r) cs_rects_of_box(FG, fboxes[b], mode, ng, halo, rects);
+    if (fowner[b] == r) cs_rects_of_box(FG, fboxes[b], mode, ng, halo, rects, ratio);
   std::vector<CsPiece> out;
   if (rects.empty()) return out;
   DBox hull = rects[0];
@@ -608,14 +608,15 @@ RepPlan* pa_rep_plan(pa_ctx* ctx, const pa_level* L) {
   return L->rep_plan.get();
 }
 
-CsPlan* pa_cs_plan(pa_ctx* ctx, const pa_level* F, const pa_level* C, int mode, int ng, int halo) {
-  const auto key = std::make_pair(C->serial, mode == 0 ? 0 : 1 + ng * 16 + halo);
+CsPlan* pa_cs_plan(pa_ctx* ctx, const pa_level* F, const pa_level* C, int mode, int ng, int halo, int ratio) {
+  if (mode == 0 && ratio != 2) { pa_fail(ctx, "coarse-source plan of the MLMG boundary: refinement ratio 2 only"); return nullptr; }
+  const auto key = std::make_pair(C->serial, mode == 0 ? 0 : 1 + ng * 16 + halo + 4096 * ratio);
   auto it = F->cs_plans.find(key);
   if (it != F->cs_plans.end()) return it->second.get();
   if (F->nranks != C->nranks || F->rank != C->rank) { pa_fail(ctx, "coarse and fine level are sharded over different rank sets"); return nullptr; }
   const HostGeom FG(F->gboxes, F->domlo, F->domhi, F->is_per);
   std::unique_ptr<CsPlan> P(new CsPlan());
-  const std::vector<CsPiece> mine = cs_pieces(FG, F->gboxes, F->gowner, C->gboxes, C->domlo, C->domhi, C->is_per, F->rank, mode, ng, halo);
+  const std::vector<CsPiece> mine = cs_pieces(FG, F->gboxes, F->gowner, C->gboxes, C->domlo, C->domhi, C->is_per, F->rank, mode, ng, halo, ratio);
   LevelSpec S;
   S.source_only = true;
   std::vector<std::pair<int, std::array<int32_t, 7>>> s, r;
@@ -634,7 +635,7 @@ CsPlan* pa_cs_plan(pa_ctx* ctx, const pa_level* F, const pa_level* C, int mode, 
   }
   for (int q = 0; q < F->nranks; ++q) {
     if (q == F->rank) continue;
-    for (const CsPiece& p : cs_pieces(FG, F->gboxes, F->gowner, C->gboxes, C->domlo, C->domhi, C->is_per, q, mode, ng, halo))
+    for (const CsPiece& p : cs_pieces(FG, F->gboxes, F->gowner, C->gboxes, C->domlo, C->domhi, C->is_per, q, mode, ng, halo, ratio))
       if (C->gowner[p.cbox] == C->rank) s.push_back({q, reg7(C->glocal[p.cbox], p.box)});
   }
   if (side_finish(ctx, P->x.send, s) || side_finish(ctx, P->x.recv, r)) return nullptr;
@@ -813,12 +814,12 @@ int pa_xexchange(pa_ctx* ctx, int njobs, const XJob* jobs) {
 // The multifab to read coarse data from when filling ghost cells of `fine` from crse[ccomp .. ccomp+ncomp): crse itself
 // on one rank, else this rank's freshly refilled coarse-source copy (component 0 = ccomp).  *src = nullptr when this
 // rank has nothing to fill (no box, or no coarse-fine face) -- the exchange still runs: other ranks may need our data.
-int pa_coarse_source(pa_ctx* ctx, const pa_level* fine, const pa_mf* crse, int ccomp, int ncomp, int mode, int ng, int halo, const pa_mf** src, int* scomp) {
+int pa_coarse_source(pa_ctx* ctx, const pa_level* fine, const pa_mf* crse, int ccomp, int ncomp, int mode, int ng, int halo, const pa_mf** src, int* scomp, int ratio) {
   *src = crse;
   *scomp = ccomp;
   if (!crse || crse->lev->nranks <= 1) return 0;
   if (fine->nranks != crse->lev->nranks) return pa_fail(ctx, "coarse and fine level are sharded over different rank sets");
-  CsPlan* P = pa_cs_plan(ctx, fine, crse->lev, mode, ng, halo);
+  CsPlan* P = pa_cs_plan(ctx, fine, crse->lev, mode, ng, halo, ratio);
   if (!P) return 1;
   pa_mf* m = P->mf(ctx, ncomp);
   if (P->cs && !m) return 1;
@@ -971,6 +972,44 @@ extern "C" int pa_ctx_init_rccl(pa_ctx* ctx, int nranks, int rank, const void* i
   if (hipMalloc(&S->d_red, 64 * sizeof(double)) != hipSuccess) { (void)api->CommDestroy(S->comm); delete S; return pa_fail(ctx, "pa_ctx_init_rccl: device allocation failed"); }
   ctx->rccl = S;
   ctx->comm = pa_comm{S, rank, nranks, rccl_exchange, rccl_allreduce};
+  return 0;
+}
+
+// ---- a transport that moves NOTHING and costs what a link would: for projections of an N-rank run on one GPU (bench.py
+// --sim-of N --xdelay ...).  Every exchange enqueues, on the stream it is issued on, a kernel that spins for
+//   fixed_us + (largest number of bytes this rank sends to or receives from ONE peer) / link_GBs
+// -- xGMI is point to point, every peer has its own link, so a grouped exchange is bound by the busiest link --
+// so the schedule's overlaps hide or expose that time exactly as they would a real exchange.  Results are wrong in ghost cells.
+struct DelayState { double fixed_us, link_GBs; double total_us = 0; long long calls = 0; };
+__global__ void k_spin_us(long long ticks) {  // 100 MHz constant clock; bounded: exits after `ticks` (host caps them at 20 ms)
+  const long long t0 = (long long)wall_clock64();
+  while ((long long)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+static int delay_exchange(void* user, void* stream, int32_t n, const pa_xfer* x) {
+  DelayState* S = (DelayState*)user;
+  std::map<int, long long> bs, br;
+  for (int i = 0; i < n; ++i) { bs[x[i].peer] += 8 * x[i].nsend; br[x[i].peer] += 8 * x[i].nrecv; }
+  long long mx = 0;
+  for (auto& kv : bs) mx = std::max(mx, kv.second);
+  for (auto& kv : br) mx = std::max(mx, kv.second);
+  double us = S->fixed_us + (S->link_GBs > 0 ? (double)mx / (S->link_GBs * 1e3) : 0.0);
+  us = std::min(us, 20000.0);
+  S->total_us += us; ++S->calls;
+  if (us > 0) hipLaunchKernelGGL(k_spin_us, dim3(1), dim3(1), 0, (hipStream_t)stream, (long long)(us * 100.0));
+  return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+static int delay_allreduce(void*, double*, int32_t, int32_t) { return 0; }
+extern "C" int pa_ctx_set_delay_comm(pa_ctx* ctx, int nranks, int rank, double fixed_us, double link_GBs) {
+  if (!ctx || nranks < 1 || rank < 0 || rank >= nranks || fixed_us < 0) return pa_fail(ctx, "pa_ctx_set_delay_comm: bad argument");
+  DelayState* S = new DelayState{fixed_us, link_GBs};  // lives as long as the process (a diagnostic transport)
+  ctx->comm = pa_comm{S, rank, nranks, delay_exchange, delay_allreduce};
+  return 0;
+}
+// (calls, modelled microseconds) of the delay transport since it was set
+extern "C" int pa_delay_comm_stats(const pa_ctx* ctx, int64_t* calls, double* total_us) {
+  if (!ctx || ctx->comm.exchange != delay_exchange || !calls || !total_us) return 1;
+  const DelayState* S = (const DelayState*)ctx->comm.user;
+  *calls = S->calls; *total_us = S->total_us;
   return 0;
 }
 

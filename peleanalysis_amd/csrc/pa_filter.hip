@@ -9,6 +9,7 @@
 #include "pa_dist.h"
 #include "pa_fabview.h"
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <type_traits>
 
@@ -26,14 +27,26 @@ extern "C" int pa_box_filter_weights(int fgr, double* w) {
 // tree: parity unpinned.]  0 none; 1 box; 3 and 7: the 3-point approximation of the box / Gaussian filter (the same weights:
 // both match the second moment fgr^2/12, Sagaut & Grohens 1999); 4 and 8: the 5-point approximations (second moment fgr^2/12
 // and fourth moment fgr^4/80 (box) or fgr^4/48 (Gaussian of the same variance)).  Every weight is ONE division of an
-// exactly representable integer expression, so any algebraically equal way of writing it gives the same double.  The
-// Gaussian (2) and the "optimized" variants (5, 6, 9, 10: tabulated coefficients) are not restated: -1.
+// exactly representable integer expression, so any algebraically equal way of writing it gives the same double.  2: the
+// Gaussian from its textbook kernel (unverified, see below).  The "optimized" variants (5, 6, 9, 10: tabulated coefficients)
+// are not restated: -1.  w must hold 2 * ngrow + 1 doubles: up to 33 (Gaussian, ngrow = ceil(4 fgr / sqrt 12) <= 16).
 extern "C" int pa_filter_weights(int type, int fgr, double* w) {
   if (!w || fgr < 1) return -1;
   const double f2 = (double)fgr * (double)fgr, f4 = f2 * f2;
   switch (type) {
     case 0: w[0] = 1.0; return 0;
     case 1: return pa_box_filter_weights(fgr, w);
+    case 2: {
+      // Gaussian (PelePhysics filter_type 2) [UNVERIFIED against PelePhysics: its source is not in the reference tree].  The textbook
+      // LES Gaussian of width Delta = fgr dx, G(r) = sqrt(6 / (pi Delta^2)) exp(-6 r^2 / Delta^2) (variance Delta^2 / 12, the box
+      // filter's), sampled at the cell centres, cut at 4 standard deviations and normalised so that the weights sum to one
+      const int ng = std::max(1, (int)std::ceil(4.0 * (double)fgr / std::sqrt(12.0)));
+      if (ng > 16) return -1;
+      double sum = 0.0;
+      for (int i = -ng; i <= ng; ++i) { w[i + ng] = std::exp(-6.0 * (double)(i * i) / f2); sum += w[i + ng]; }
+      for (int i = 0; i <= 2 * ng; ++i) w[i] = w[i] / sum;
+      return ng;
+    }
     case 3: case 7:
       w[0] = f2 / 24.0; w[1] = (12.0 - f2) / 12.0; w[2] = w[0];
       return 1;
@@ -833,15 +846,17 @@ extern "C" int pa_fillpatch_two_levels(pa_ctx* ctx, pa_mf* fine, const pa_mf* cr
   PaBind bind_(ctx);
   if (!ctx || !fine || !crse) return pa_fail(ctx, "pa_fillpatch_two_levels: null argument");
   if (ng > fine->ng || ng < 0 || comp < 0 || comp + ncomp > fine->ncomp || comp + ncomp > crse->ncomp) return pa_fail(ctx, "pa_fillpatch_two_levels: ng/component range");
-  if (ratio != 2) return pa_fail(ctx, "pa_fillpatch_two_levels: only refinement ratio 2 is supported (quirk Q11)");
+  // any integer refinement ratio (isosurface.cpp:1472,1518 and filterPlt.cpp:133,200 take the plotfile's); the cached parent
+  // lists of interp_type 1 (k_fp_find / k_fp_do) are the ratio-2 form, other ratios take the per-ghost-cell kernel
+  if (ratio < 2 || ratio > 16) return pa_fail(ctx, "pa_fillpatch_two_levels: refinement ratio must be 2 .. 16");
   if (interp_type != 0 && interp_type != 1) return pa_fail(ctx, "pa_fillpatch_two_levels: interp_type must be 0 (pc) or 1 (cell-conservative linear)");
   if (ng == 0) return 0;
   // sharded coarse level: the parents of the ghost layers (+ 1 coarse cell for slopes / min-max) from this rank's coarse-source copy
   int ccomp = comp;
-  if (pa_coarse_source(ctx, fine->lev, crse, comp, ncomp, 1, ng, 1, &crse, &ccomp)) return 1;
+  if (pa_coarse_source(ctx, fine->lev, crse, comp, ncomp, 1, ng, 1, &crse, &ccomp, ratio)) return 1;
   if (fine->lev->boxes.empty() || !crse) return 0;
   static const int parent_env = [] { const char* e = getenv("PA_FILLPATCH_PARENT"); return e ? atoi(e) : 1; }();  // 0: thread per ghost cell (A/B)
-  if (interp_type == 1 && parent_env) {
+  if (interp_type == 1 && parent_env && ratio == 2) {
     long long mp = 0;
     for (const DBox& B : fine->lev->boxes) {
       long long n = 1;

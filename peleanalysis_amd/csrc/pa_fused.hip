@@ -1572,8 +1572,23 @@ int pa_gradcurv_fix_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, 
         G.items = sl.gitems; G.n = sl.gcap; G.ncount = sl.gcount; G.lev = q;
         hipLaunchKernelGGL(k_curv_general<true>, dim3(256), dim3(64), 0, ctx->stream, G, ctx->d_flags, sk);
       }
-    } else if (all_patch) hipLaunchKernelGGL((k_faces_curv_fast<1, true>), gfast, dim3(256), 0, ctx->stream, Bt, ctx->d_flags, SlowList(), sk);
-    else hipLaunchKernelGGL((k_faces_curv_fast<1, false>), gfast, dim3(256), 0, ctx->stream, Bt, ctx->d_flags, SlowList(), sk);
+    } else {
+      // no clip: PA_FIX_OVERLAP=1 (read per pass) puts the perimeter kernel next to the interior one on the side stream.  OFF by
+      // default: measured twice and it buys nothing -- 1-GPU headline +0.009 ms (round 2); rank 0's share of an 8-way shard, where
+      // both launches are short chains of dependent loads, 1.060 against 1.040 ms per pass (round 4, profiles/r04_sim8_delay.txt)
+      const char* foe = getenv("PA_FIX_OVERLAP");
+      const bool side = foe && atoi(foe) != 0;
+      if (side && ctx->stream2 != ctx->stream) {
+        if (!ctx->stream2) PA_HIP(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+        for (int e = 0; e < 2; ++e)
+          if (!ctx->fix_evs[e]) PA_HIP(hipEventCreateWithFlags(&ctx->fix_evs[e], hipEventDisableTiming));
+        pst = ctx->stream2;
+        PA_HIP(hipEventRecord(ctx->fix_evs[0], ctx->stream));
+        PA_HIP(hipStreamWaitEvent(pst, ctx->fix_evs[0], 0));
+      }
+      if (all_patch) hipLaunchKernelGGL((k_faces_curv_fast<1, true>), gfast, dim3(256), 0, ctx->stream, Bt, ctx->d_flags, SlowList(), sk);
+      else hipLaunchKernelGGL((k_faces_curv_fast<1, false>), gfast, dim3(256), 0, ctx->stream, Bt, ctx->d_flags, SlowList(), sk);
+    }
     const dim3 gper((unsigned)((nper + 255) / 256), (unsigned)Bt.ycum[Bt.n], (unsigned)nslots);
     if (clip) {
       if (all_patch) hipLaunchKernelGGL((k_faces_curv<true, true, true>), gper, dim3(256), 0, pst, Bt, ctx->d_flags, sk);

@@ -26,7 +26,7 @@ def _same(a, b):
     return np.array_equal(np.ascontiguousarray(a).view(np.int64), np.ascontiguousarray(b).view(np.int64))
 
 
-def _worker(rank, world, port, case):
+def _worker(rank, world, port, case, transport="gloo"):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import torch
@@ -68,8 +68,14 @@ def _worker(rank, world, port, case):
         pm = O.curvature_pipeline(H.levels, [s.copy() for s in gst], 0, bc, oc, 0, MultiFab, threshold=thr, do_gauss=True, do_strain=True, strain_tensor=True,
                                   do_velnormal=True, vel_comp=1)
 
-        ctx = capi.Context(0)
-        comm = padist.GlooComm(ctx)
+        if transport == "rccl":  # one GPU per rank, the library's own communicator: grouped ncclSend / ncclRecv over xGMI
+            torch.cuda.set_device(rank)
+            ctx = capi.Context(rank)
+            padist.init_rccl(ctx)
+            comm = None
+        else:
+            ctx = capi.Context(0)
+            comm = padist.GlooComm(ctx)
         ctx.comm_selftest(1000)  # the transport itself: ring exchange + reduction with known answers
         dls = [capi.DevLevel(ctx, lv, owners[l], rank, world) for l, lv in enumerate(H.levels)]
         lst = []
@@ -90,11 +96,11 @@ def _worker(rank, world, port, case):
         # fused and pass-by-pass grad -> curvature; the progress range comes from the min / max reduction over the ranks
         for fused in (True, False):
             out = [capi.DevMF(ctx, dl, 8, 0) for dl in dls]
-            n0 = comm.nexchange
+            n0 = comm.nexchange if comm else 0
             capi.gradcurv_run(ctx, lst, 0, bc, capi.curv_params(threshold=thr, fused=fused), work, out, 0)
             ctx.sync()
             assert ctx.bc_errors() == 0
-            if fused and not case.startswith("rand"):  # exchange A for every level at once; B (the coarse normals) for every level at once
+            if comm and fused and not case.startswith("rand"):  # exchange A for every level at once; B (the coarse normals) for every level at once
                 assert comm.nexchange - n0 == 2, "the fused pipeline batches its cross-rank traffic"
             check(out, {0: (og, 0), 1: (og, 1), 2: (og, 2), 3: (og, 3), 4: (oc, 2), 5: (oc, 3), 6: (oc, 4), 7: (oc, 1)}, f"gradcurv fused={fused}")
         # several components at once: exchange A carries all of them, one exchange (B) per component
@@ -109,11 +115,11 @@ def _worker(rank, world, port, case):
         def done(c):
             ctx.sync()
             seen[c] = [o.download() for o in out]
-        n0 = comm.nexchange
+        n0 = comm.nexchange if comm else 0
         capi.gradcurv_run_comps(ctx, lst, 0, 2, bc, capi.curv_params(prog_min=pm[0], prog_max=pm[1], threshold=thr, fused=True), work, out, 0, done)
         ctx.sync()
         assert sorted(seen) == [0, 1]
-        if case == "wide" and thr is None:
+        if comm and case == "wide" and thr is None:
             assert comm.nexchange - n0 == 3, "exact-normal pipeline, 2 components: one exchange A for both + one exchange B per component"
         for l, dl in enumerate(dls):
             for i, g in enumerate(dl.gids):
@@ -127,11 +133,11 @@ def _worker(rank, world, port, case):
         def done2(c, oc):
             ctx.sync()
             seen2[c] = (oc, [o.download() for o in out2])
-        n0 = comm.nexchange
+        n0 = comm.nexchange if comm else 0
         capi.gradcurv_run_comps2(ctx, lst, 0, 2, bc, capi.curv_params(prog_min=pm[0], prog_max=pm[1], threshold=thr, fused=True), work, out2, 0, 2, done2)
         ctx.sync()
         assert sorted(seen2) == [0, 1]
-        if case == "wide" and thr is None:
+        if comm and case == "wide" and thr is None:
             assert comm.nexchange - n0 == 2, "one batch of 2 components: one exchange A + ONE exchange B"
         for c in (0, 1):
             oc_, mfs = seen2[c]
@@ -151,7 +157,7 @@ def _worker(rank, world, port, case):
         capi.grad_run(ctx, lst, 0, bc, out, 0)
         ctx.sync()
         check(out, {c: (og, c) for c in range(4)}, "grad_run")
-        assert comm.bytes_sent > 0
+        assert comm is None or comm.bytes_sent > 0
         dist.barrier()
         ctx.close()
     finally:
@@ -166,6 +172,22 @@ _HUNT = int(os.environ.get("PA_DIST_RANDOM_SEEDS", "0"))  # PA_DIST_RANDOM_SEEDS
 def test_sharded_hierarchy_on_shared_gpu_matches_undistributed_oracle(world, case):
     import torch.multiprocessing as mp
     mp.spawn(_worker, args=(world, _free_port(), case), nprocs=world, join=True)
+
+
+def _ngpus():
+    import torch
+    return torch.cuda.device_count()  # (counting devices does not initialise the GPU)
+
+
+@pytest.mark.skipif(_ngpus() < 2, reason="needs two GPUs: RCCL refuses two ranks on one device (a 1-GPU box runs the single-rank RCCL test below)")
+@pytest.mark.parametrize("case", ["wide", "thr", "randU0"])
+def test_sharded_hierarchy_over_rccl_two_gpus(case):
+    """the same sharded-hierarchy checks with the library's built-in transport and REAL peers: two ranks, one GPU each, the
+    cross-rank FillBoundary / coarse-source / coarse-normal exchanges as ncclGroupStart .. ncclSend / ncclRecv .. ncclGroupEnd on
+    the library's stream, the progress range through ncclAllReduce; results against the undistributed oracle, bit for bit.
+    The first multi-GPU box that runs the GPU tier exercises it."""
+    import torch.multiprocessing as mp
+    mp.spawn(_worker, args=(2, _free_port(), case, "rccl"), nprocs=2, join=True)
 
 
 _RCCL_SELF = """

@@ -146,7 +146,7 @@ inline bool parse_box(const std::string& s, size_t& pos, Box3& b, int dim = 3) {
 }
 
 // dim_wanted = 3: the 3-D tools (a 2-D plotfile aborts); 2: the 2-D build of isosurface (boxes become the plane k = 0)
-inline PlotfileHeader read_header(const std::string& path, int dim_wanted = 3) {
+inline PlotfileHeader read_header(const std::string& path, int dim_wanted = 3, bool any_ratio = false) {
   PlotfileHeader H;
   H.path = path;
   std::ifstream f(path + "/Header");
@@ -221,8 +221,12 @@ inline PlotfileHeader read_header(const std::string& path, int dim_wanted = 3) {
     }
     if ((int)H.lev[l].fab_file.size() != ngrids) Abort("Cell_H FabOnDisk count does not match the Header");
   }
-  for (int r : H.ref_ratio)
-    if (r != 2 && H.nlev > 1) Abort("only refinement ratio 2 is supported (the reference tools write ratio 2 as well)");
+  // grad / curvature hard-code ratio 2 in the reference too (curvature.cpp:445, grad.cpp:255); isosurface and filterPlt take
+  // the file's ratio (isosurface.cpp:1472,1518,1543; filterPlt.cpp:133,200) and pass any_ratio
+  for (int r : H.ref_ratio) {
+    if (r != 2 && H.nlev > 1 && !any_ratio) Abort("only refinement ratio 2 is supported (the reference tools write ratio 2 as well)");
+    if (r < 2 && H.nlev > 1) Abort("bad refinement ratio in the plotfile Header");
+  }
   return H;
 }
 

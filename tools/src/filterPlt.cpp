@@ -34,10 +34,12 @@ int main(int argc, char** argv) {
   int exact_filter = 0;
   pp.query("exact_filter", exact_filter);
   if (exact_filter) setenv("PA_FILTER_EXACT", "1", 1);  // read by the library at every launch
-  {  // PelePhysics filter types restated in the library: 0 none, 1 box, 3 / 7 and 4 / 8 the 3- and 5-point approximations
-    std::vector<double> wt(std::max(fgr, 3) + 2);
+  {  // PelePhysics filter types restated in the library: 0 none, 1 box, 2 Gaussian, 3 / 7 and 4 / 8 the 3- and 5-point approximations
+    std::vector<double> wt(40);
     if (pa_filter_weights(filter_type, std::max(fgr, 1), wt.data()) < 0)
-      pa::Abort("filter_type " + std::to_string(filter_type) + " is not available in this build (0 none, 1 box, 3 / 7 three-point, 4 / 8 five-point approximations)");
+      pa::Abort("filter_type " + std::to_string(filter_type) + " is not available in this build (0 none, 1 box, 2 Gaussian, 3 / 7 three-point, 4 / 8 five-point approximations)");
+    if (filter_type == 2)
+      std::cout << "filter_type 2: Gaussian weights from the textbook kernel exp(-6 r^2 / Delta^2), cut at 4 standard deviations -- UNVERIFIED against PelePhysics' Filter" << std::endl;
   }
   if (filter_type == 1 && fgr != 1 && fgr % 2 != 0) pa::Abort("Box filter requires an even filter-to-grid ratio");
   std::vector<int> is_per(3, 0);
@@ -52,7 +54,7 @@ int main(int argc, char** argv) {
   if (!pp.queryarr("is_per", is_per, 0, 3)) pp.queryarr("geometry.is_periodic", is_per, 0, 3);
 #endif
   pa::PhaseTimer tm(pp, PA_SPACEDIM == 2 ? "filterPlt2d" : "filterPlt3d");
-  pa::PlotfileHeader H = pa::read_header(infile, PA_SPACEDIM);
+  pa::PlotfileHeader H = pa::read_header(infile, PA_SPACEDIM, /* any_ratio: filterPlt.cpp:133,200 take the file's */ true);
   const int Nlev = std::min(finestLevel + 1, H.nlev);
   std::vector<std::string> names;
   std::vector<int> comps;
@@ -76,9 +78,10 @@ int main(int argc, char** argv) {
   int fgr_lev = fgr;
   for (int lev = 0; lev < Nlev; ++lev) {
     std::cout << "on level " << lev << std::endl;
-    if (!same_fgr && lev > 0) fgr_lev *= 2;
-    std::vector<double> w(std::max(fgr_lev, 3) + 2);
+    if (!same_fgr && lev > 0) fgr_lev *= H.ref_ratio[lev - 1];  // filterPlt.cpp:132-134
+    std::vector<double> w(std::max(fgr_lev + 2, 40));
     const int ng = pa_filter_weights(filter_type, fgr_lev, w.data());
+    if (ng < 0 || ng > 16) pa::Abort("filter width on level " + std::to_string(lev) + " (filter-to-grid ratio " + std::to_string(fgr_lev) + ") exceeds 16 ghost cells");
     ngs.push_back(ng);
     ws.push_back(w);
     const std::vector<pa::Box3> ba = pa::max_size(H.lev[lev].boxes, max_grid_size);
@@ -118,7 +121,7 @@ int main(int argc, char** argv) {
     for (int lev = 0; lev < Nlev; ++lev) {
       if (r == 0) std::cout << "on level " << lev << std::endl;
       ctx.check(pa_fill_boundary(ctx.h, din[lev]->h, 0, ncomp, ngs[lev]));
-      if (lev > 0) ctx.check(pa_fillpatch_two_levels(ctx.h, din[lev]->h, din[lev - 1]->h, 0, ncomp, ngs[lev], 2, interp_type == 1 ? 1 : 0));
+      if (lev > 0) ctx.check(pa_fillpatch_two_levels(ctx.h, din[lev]->h, din[lev - 1]->h, 0, ncomp, ngs[lev], H.ref_ratio[lev - 1], interp_type == 1 ? 1 : 0));
       ctx.check(pa_foextrap(ctx.h, din[lev]->h, 0, ncomp, ngs[lev]));
     }
     if (r == 0) std::cout << "Done!" << std::endl << "Filtering data..." << std::endl;

@@ -36,7 +36,7 @@ int main(int argc, char** argv) {
   std::string infile;
   pp.get("infile", infile);
   if (infile.empty()) pa::Abort("Plotfile not specified, Use infile=");
-  pa::PlotfileHeader H = pa::read_header(infile);
+  pa::PlotfileHeader H = pa::read_header(infile, 3, /* any_ratio: isosurface.cpp:1472,1518,1543 take the file's */ true);
   double isoVal = 1090;
   pp.query("isoVal", isoVal);
   std::string isoCompName = "temp";
@@ -181,7 +181,7 @@ int main(int argc, char** argv) {
     tq = now();
     if (lead) std::cout << "FillPatching the grown structures at level " << lev << "..." << std::endl;
     ctx.check(pa_fill_boundary(ctx.h, dst[lev]->h, 0, nc, ng));
-    if (lev > 0) ctx.check(pa_fillpatch_two_levels(ctx.h, dst[lev]->h, dst[lev - 1]->h, 0, nc, ng, 2, 0));  // PCInterp
+    if (lev > 0) ctx.check(pa_fillpatch_two_levels(ctx.h, dst[lev]->h, dst[lev - 1]->h, 0, nc, ng, H.ref_ratio[lev - 1], 0));  // PCInterp, the file's ratio (isosurface.cpp:1472,1518)
     if (lead) std::cout << "...done FillPatching the grown structures at level " << lev << "..." << std::endl;
     ctx.check(pa_sync(ctx.h));
     if (lead) t_fill += now() - tq;
@@ -233,7 +233,7 @@ int main(int argc, char** argv) {
     int32_t *dk = nullptr, *dt = nullptr;
     tq = now();
     if (nb > 0)  // a rank may own no FAB of a level
-      ctx.check(pa_mc_level_fine(ctx.h, dst[lev]->h, fine_mask ? dl[lev + 1]->h : nullptr, 2, loops.data(), 3 + isoComp, isoVal, nvb.data(), ntb.data(), &dv, &dk,
+      ctx.check(pa_mc_level_fine(ctx.h, dst[lev]->h, fine_mask ? dl[lev + 1]->h : nullptr, fine_mask ? H.ref_ratio[lev] : 2, loops.data(), 3 + isoComp, isoVal, nvb.data(), ntb.data(), &dv, &dk,
                                  &dt));
     if (lead) t_mc += now() - tq;
     tq = now();
