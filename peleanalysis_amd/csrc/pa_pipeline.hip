@@ -287,7 +287,10 @@ static int fused_passes_dist(pa_ctx* ctx, int nlev, pa_mf* const* state, int com
     // workgroups: per-level launches end in idle tails), then ONE grouped exchange of the coarse normals of all levels;
     // 0: level by level, each level's exchange on the side stream next to the following sweep
     const char* dsbe = getenv("PA_DIST_SWEEP_BATCH");  // read per pass (A/B)
-    const int dsb = dsbe ? atoi(dsbe) : 1;
+    // default 2 (round 4): with the delay-model transport (68 us per exchange: 50 us + 2.2 MB to the busiest peer at 120 GB/s) rank
+    // 0 of 8 takes 1.140 ms per pass against 1.170 with one launch, with no-op exchanges 1.046 against 1.022: the split pays as soon
+    // as an exchange costs more than ~25 us, which a grouped RCCL send / receive always does (profiles/r04_sim8_delay.txt)
+    const int dsb = dsbe ? atoi(dsbe) : 2;
     if (dsb) {
       // 1 (default): one launch for all levels, exchange B exposed after it.  2: the finest level's sweep is a launch of its
       // own and exchange B -- which needs the normals of every level BUT the finest -- travels under it on the side stream
