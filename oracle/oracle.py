@@ -537,7 +537,7 @@ def iso_ngrow(levels, build_distance, dmax=None, ngrow=1):
     return out, dmax
 
 
-def isosurface_pipeline(levels, fields, comps, isocomp_index, isoval, MF, ngrow=1, rm_external=True, build_distance=False, dmax=None):
+def isosurface_pipeline(levels, fields, comps, isocomp_index, isoval, MF, ngrow=1, rm_external=True, build_distance=False, dmax=None, ratio=2):
     """isosurface.cpp:1434-1728.  Periodic directions as the reference leaves them (:1469 "bad data in periodic
     directions": the ghost cells behind a periodic face carry the coordinates of the cells they image -- the shift back
     at :1483-1507 intersects VALID boxes with the domain shifted by a period and so never fires).  fields[l]: multifab holding the plotfile components;
@@ -563,14 +563,14 @@ def isosurface_pipeline(levels, fields, comps, isocomp_index, isoval, MF, ngrow=
                 st.valid(b)[3 + n] = fields[l].valid(b)[c]
         fill_boundary(st, 0, nc, ng)
         if l > 0:
-            nbad = L.orc_fillpatch_two_levels(_p(_mf(st)), _p(_mf(states[l - 1])), 0, nc, ng, 2, 0)
+            nbad = L.orc_fillpatch_two_levels(_p(_mf(st)), _p(_mf(states[l - 1])), 0, nc, ng, ratio, 0)
             assert nbad == 0
         states.append(st)
     for l, lv in enumerate(levels):
         ng = ngs[l]
         dist = MF(lv, 1, ng) if build_distance else None
         for b in range(lv.nboxes):
-            lo, hi, mask, llo, lhi = iso_fab_inputs(levels, states, l, b, ng, fine_mask=not build_distance)
+            lo, hi, mask, llo, lhi = iso_fab_inputs(levels, states, l, b, ng, fine_mask=not build_distance, ratio=ratio)
             sfab = np.ascontiguousarray(states[l].fab(b))
             verts = np.zeros((0, nc))
             vkeys = np.zeros((0, 6), np.int32)

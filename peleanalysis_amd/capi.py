@@ -451,7 +451,7 @@ def gradcurv_run_comps2(ctx, states, comp0, ncomps, bc, params: PaCurvParams, wo
     ctx.check(rc)
 
 
-def mc_hierarchy(ctx: Context, states, fine_mask, loops_per_level, isocomp: int, isoval: float, download: bool = True):
+def mc_hierarchy(ctx: Context, states, fine_mask, loops_per_level, isocomp: int, isoval: float, download: bool = True, ratio: int = 2):
     """pa_mc_hierarchy_fine: marching cubes on every level in one call.  states: DevMF per level; fine_mask: flag per level
     (mask by the next finer level); loops_per_level: (nboxes, 6) arrays.  Returns per level the per-box list
     [(verts, vkeys, tris)] (download=False: only the per-box counts [(nv, nt)])"""
@@ -473,7 +473,7 @@ def mc_hierarchy(ctx: Context, states, fine_mask, loops_per_level, isocomp: int,
     fm = (C.c_int32 * nlev)(*[int(bool(f)) for f in fine_mask])
     pv, pk, pt = (C.c_void_p * nlev)(), (C.c_void_p * nlev)(), (C.c_void_p * nlev)()
     block = C.c_void_p()
-    ctx.check(ctx.lib.pa_mc_hierarchy_fine(ctx.h, nlev, _handles(states), fm, 2, parr, int(isocomp), float(isoval), pnv, pnt, pv, pk, pt, C.byref(block)))
+    ctx.check(ctx.lib.pa_mc_hierarchy_fine(ctx.h, nlev, _handles(states), fm, int(ratio), parr, int(isocomp), float(isoval), pnv, pnt, pv, pk, pt, C.byref(block)))
     out = []
     try:
         for l in range(nlev):

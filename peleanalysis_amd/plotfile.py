@@ -119,8 +119,9 @@ def read_plotfile(path: str, is_per=(0, 0, 0)) -> PlotfileData:
     prob_lo = np.array([float(x) for x in next(it).split()] + ([0.0] if dim == 2 else []))
     prob_hi = np.array([float(x) for x in next(it).split()] + ([1.0] if dim == 2 else []))
     rr = [int(x) for x in re.findall(r"-?\d+", next(it))]
-    if any(r != 2 for r in rr[:nlev - 1]):
-        raise ValueError("only refinement ratio 2 is supported (quirk Q11)")
+    if len(set(rr[:nlev - 1])) > 1:
+        raise ValueError("levels with different refinement ratios are not supported by this reader")
+    ratio = rr[0] if nlev > 1 and rr else 2
     doms = box_re.findall(next(it))
     steps = [int(x) for x in next(it).split()]
     for _ in range(nlev):
@@ -167,7 +168,7 @@ def read_plotfile(path: str, is_per=(0, 0, 0)) -> PlotfileData:
             mf.valid(b)[:] = data[:ncomp, g[2]:g[2] + nz, g[1]:g[1] + ny, g[0]:g[0] + nx]
         levels.append(lv)
         mfs.append(mf)
-    return PlotfileData(names, time, Hierarchy(levels, 2), mfs, steps)
+    return PlotfileData(names, time, Hierarchy(levels, ratio), mfs, steps)
 
 
 def read_mef(path: str):

@@ -62,7 +62,7 @@ def test_box_filter_weights_host_entry(oracle):
     assert lib.pa_box_filter_weights(0, (C.c_double * 4)()) < 0
     for ftype in range(-1, 12):  # the other filter types: the library's weights are the oracle's, bit for bit; the same types are refused
         for fgr in (1, 2, 4, 6, 16):
-            w = (C.c_double * (max(fgr, 3) + 2))()
+            w = (C.c_double * 40)()  # up to 2 * 16 + 1 weights (the Gaussian, type 2, is the widest)
             ng = lib.pa_filter_weights(ftype, fgr, w)
             want = oracle.filter_weights(ftype, fgr)
             assert (ng < 0) == (want is None), (ftype, fgr)

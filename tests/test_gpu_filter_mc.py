@@ -488,3 +488,130 @@ def test_marching_cubes_hierarchy_call_matches_oracle_and_level_calls(ctx, oracl
     assert all(len(t) == 0 for (_, _, t) in got[-1]) and sum(len(t) for (_, _, t) in got[0]) > 0
     got = capi.mc_hierarchy(ctx, dst, fm, loops, 3, 1.0e30)
     assert all(len(t) == 0 and len(v) == 0 for lev in got for (v, _, t) in lev)
+
+
+def _ratio4_hierarchy(per):
+    """2 levels, refinement ratio 4: base 24^3 in 12^3 boxes; level 1 = coarse cells [6, 15] x [6, 17] x [8, 15] refined (x4) in boxes <= 24"""
+    from peleanalysis_amd.hierarchy import Hierarchy, Level, chop_box
+    l0 = Level(chop_box((0, 0, 0), (23, 23, 23), 12), (0, 0, 0), (23, 23, 23), per, np.zeros(3), np.ones(3))
+    l1 = Level(chop_box((24, 24, 32), (63, 71, 63), 24), (0, 0, 0), (95, 95, 95), per, np.zeros(3), np.ones(3))
+    return Hierarchy([l0, l1], 4)
+
+
+@pytest.mark.parametrize("interp,ng", [(0, 1), (1, 2), (1, 4), (0, 3)])
+def test_fillpatch_two_levels_refinement_ratio_4(ctx, oracle, interp, ng):
+    """FillPatchTwoLevels with the plotfile's refinement ratio (filterPlt.cpp:193-200, isosurface.cpp:1474-1478,1515-1524), here 4:
+    piecewise constant (the parent of 4^3 children) and cell-conservative linear (offsets +-1/8, +-3/8; the limiter's common
+    factor with (r - 1) / (2 r) = 3/8) against the oracle, every ghost cell bit for bit"""
+    from util import make_states, field_flame
+    H = _ratio4_hierarchy((1, 0, 1))
+    src = make_states(H, 2, 0, field_flame, seed=9)
+    mfs = []
+    for l, lv in enumerate(H.levels):
+        m = MultiFab(lv, 2, ng, fill=-666.0)
+        for b in range(lv.nboxes):
+            m.valid(b)[:] = src[l].valid(b)
+        mfs.append(m)
+    om = [m.copy() for m in mfs]
+    for l in range(2):
+        oracle.fill_boundary(om[l], 0, 2, ng)
+        if l > 0:
+            assert oracle.lib().orc_fillpatch_two_levels(C.byref(oracle._mf(om[l])), C.byref(oracle._mf(om[l - 1])), 0, 2, ng, 4, interp) == 0
+        oracle.foextrap(om[l], 0, 2, ng)
+    dls = [capi.DevLevel(ctx, lv) for lv in H.levels]
+    dm = [capi.DevMF.from_host(ctx, dl, m) for dl, m in zip(dls, mfs)]
+    for l in range(2):
+        ctx.check(ctx.lib.pa_fill_boundary(ctx.h, dm[l].h, 0, 2, ng))
+        if l > 0:
+            ctx.check(ctx.lib.pa_fillpatch_two_levels(ctx.h, dm[l].h, dm[l - 1].h, 0, 2, ng, 4, interp))
+        ctx.check(ctx.lib.pa_foextrap(ctx.h, dm[l].h, 0, 2, ng))
+    ctx.sync()
+    assert ctx.bc_errors() == 0
+    for l, lv in enumerate(H.levels):
+        got = dm[l].download()
+        for b in range(lv.nboxes):
+            assert np.array_equal(got.fab(b).view(np.int64), om[l].fab(b).view(np.int64)), f"ratio 4 interp {interp} ng {ng}: level {l} box {b} (ghost cells included)"
+    assert ctx.lib.pa_fillpatch_two_levels(ctx.h, dm[1].h, dm[0].h, 0, 2, ng, 1, interp) != 0  # ratio 1 is refused
+    ctx.lib.pa_last_error(ctx.h)
+
+
+def test_marching_cubes_refinement_ratio_4(ctx, oracle):
+    """the fine-covered mask with the finer level coarsened by 4 (isosurface.cpp:1543) evaluated in the cell pass -- level by
+    level and through pa_mc_hierarchy_fine -- and the mask multifab form, against the oracle's per-FAB loop"""
+    from util import make_states, field_flame
+    H = _ratio4_hierarchy((0, 0, 0))
+    fields = make_states(H, 1, 0, field_flame, seed=5)
+    ng, nc = 1, 4
+    states = []
+    for l, lv in enumerate(H.levels):
+        st = MultiFab(lv, nc, ng, fill=-666.0)
+        for b in range(lv.nboxes):
+            f = st.fab(b)
+            lo = lv.boxes[b, :3] - ng
+            nz, ny, nx = f.shape[1:]
+            f[0] = ((np.arange(lo[0], lo[0] + nx) + 0.5) * lv.dx[0] + lv.prob_lo[0])[None, None, :]
+            f[1] = ((np.arange(lo[1], lo[1] + ny) + 0.5) * lv.dx[1] + lv.prob_lo[1])[None, :, None]
+            f[2] = ((np.arange(lo[2], lo[2] + nz) + 0.5) * lv.dx[2] + lv.prob_lo[2])[:, None, None]
+            st.valid(b)[3] = fields[l].valid(b)[0]
+        oracle.fill_boundary(st, 0, nc, ng)
+        if l > 0:
+            assert oracle.lib().orc_fillpatch_two_levels(C.byref(oracle._mf(st)), C.byref(oracle._mf(states[l - 1])), 0, nc, ng, 4, 0) == 0
+        states.append(st)
+    iso = 1150.0
+    dls = [capi.DevLevel(ctx, lv) for lv in H.levels]
+    dst = [capi.DevMF.from_host(ctx, dl, s) for dl, s in zip(dls, states)]
+    loops, want = [], []
+    for l, lv in enumerate(H.levels):
+        lp, wl = np.zeros((lv.nboxes, 6), np.int64), []
+        for b in range(lv.nboxes):
+            lo, hi, mask, llo, lhi = oracle.iso_fab_inputs(H.levels, states, l, b, ng, ratio=4)
+            lp[b, :3], lp[b, 3:] = llo, lhi
+            wl.append(oracle.mc_fab(np.ascontiguousarray(states[l].fab(b)), mask, lo, hi, 3, iso, llo, lhi))
+            if l == 0:  # the mask multifab of pa_iso_mask_level with ratio 4
+                pass
+        loops.append(lp)
+        want.append(wl)
+    dmask = capi.DevMF(ctx, dls[0], 1, ng)
+    ctx.check(ctx.lib.pa_iso_mask_level(ctx.h, dmask.h, 0, dls[1].h, 4))
+    ctx.sync()
+    gm = dmask.download()
+    for b in range(H.levels[0].nboxes):
+        assert np.array_equal(gm.fab(b)[0], oracle.iso_fab_inputs(H.levels, states, 0, b, ng, ratio=4)[2]), f"ratio 4 mask box {b}"
+
+    def check(got, what):
+        nt = 0
+        for l, lv in enumerate(H.levels):
+            for b in range(lv.nboxes):
+                (v, k, t), (gv, gk, gt) = want[l][b], got[l][b]
+                assert (len(gv), len(gt)) == (len(v), len(t)), f"{what} level {l} box {b}: counts differ"
+                assert np.array_equal(gk, k) and np.array_equal(gt, t) and np.array_equal(gv.view(np.int64), np.ascontiguousarray(v).view(np.int64)), f"{what} level {l} box {b}"
+                nt += len(t)
+        assert nt > 200
+
+    # level by level with ratio 4 (capi.mc_level passes 2: call the C entry directly)
+    got = []
+    for l, lv in enumerate(H.levels):
+        nb = lv.nboxes
+        arr = (capi.PaBox * nb)()
+        for b in range(nb):
+            for d in range(3):
+                arr[b].lo[d], arr[b].hi[d] = int(loops[l][b, d]), int(loops[l][b, 3 + d])
+        nv, nt = (C.c_int64 * nb)(), (C.c_int64 * nb)()
+        pv, pk, pt = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        ctx.check(ctx.lib.pa_mc_level_fine(ctx.h, dst[l].h, dls[1].h if l == 0 else None, 4, arr, 3, iso, nv, nt, C.byref(pv), C.byref(pk), C.byref(pt)))
+        tv, tt = int(sum(nv[:nb])), int(sum(nt[:nb]))
+        V = np.empty((tv, nc)); K = np.empty((tv, 6), np.int32); T = np.empty((tt, 3), np.int32)
+        if tv:
+            ctx.check(ctx.lib.pa_memcpy_d2h(ctx.h, V.ctypes.data_as(C.c_void_p), pv, V.nbytes))
+            ctx.check(ctx.lib.pa_memcpy_d2h(ctx.h, K.ctypes.data_as(C.c_void_p), pk, K.nbytes))
+        if tt:
+            ctx.check(ctx.lib.pa_memcpy_d2h(ctx.h, T.ctypes.data_as(C.c_void_p), pt, T.nbytes))
+        if pv.value:
+            ctx.lib.pa_device_free(ctx.h, pv)
+        lev, ov, ot = [], 0, 0
+        for b in range(nb):
+            lev.append((V[ov:ov + nv[b]], K[ov:ov + nv[b]], T[ot:ot + nt[b]]))
+            ov += nv[b]; ot += nt[b]
+        got.append(lev)
+    check(got, "pa_mc_level_fine ratio 4")
+    check(capi.mc_hierarchy(ctx, dst, [1, 0], loops, 3, iso, ratio=4), "pa_mc_hierarchy_fine ratio 4")

@@ -451,7 +451,7 @@ def test_filter_type_weights_match_their_moment_conditions(oracle):
         if fgr % 2 == 0:
             ng, w = oracle.filter_weights(1, fgr)
             assert np.array_equal(w, oracle.box_filter_weights(fgr)[1])
-    for t in (2, 5, 6, 9, 10, 11, -1):
+    for t in (5, 6, 9, 10, 11, -1):  # (2, the Gaussian: test_filter_weights_moment_conditions)
         assert oracle.filter_weights(t, 2) is None
     # through the pipeline: one periodic level, f = x^2-like polynomial in index space is reproduced + fgr^2/12 per direction
     from peleanalysis_amd.hierarchy import Level, MultiFab, chop_box
@@ -472,3 +472,36 @@ def test_filter_type_weights_match_their_moment_conditions(oracle):
             z, y, x = np.meshgrid(np.arange(B[2], B[5] + 1), np.arange(B[1], B[4] + 1), np.arange(B[0], B[3] + 1), indexing="ij")
             want = tf(1) * tf(0) * tf(0) * np.cos(2 * np.pi * x / n) + 0.5 * tf(0) * tf(1) * tf(2) * np.sin(2 * np.pi * (y + 2 * z) / n)
             assert np.abs(out.valid(b)[0] - want).max() < 1e-14
+
+
+def test_filter_weights_moment_conditions(oracle):
+    """Known answers for the PelePhysics filter types whose weights are restated from their defining conditions (the source is
+    not in the reference tree): every type sums to one and is symmetric (constants and linear fields pass unchanged); the 3-point
+    types carry the box filter's second moment fgr^2 / 12; the 5-point types also the fourth moment fgr^4 / 80 (box, type 4) or
+    3 (fgr^2 / 12)^2 (Gaussian, type 8); the sampled Gaussian (type 2, flagged unverified) is positive, decreasing from the
+    centre, cut at 4 standard deviations and within 4 % of the continuous kernel's second moment."""
+    import numpy as np
+    for fgr in (2, 3, 4, 6, 8):
+        for ftype in (1, 2, 3, 4, 7, 8):
+            if ftype == 1 and fgr % 2:
+                continue
+            got = oracle.filter_weights(ftype, fgr)
+            assert got is not None, (ftype, fgr)
+            ng, w = got
+            i = np.arange(-ng, ng + 1, dtype=np.float64)
+            assert len(w) == 2 * ng + 1 and abs(w.sum() - 1.0) < 1e-14 and np.array_equal(w, w[::-1]), (ftype, fgr)
+            m2, m4 = float((w * i ** 2).sum()), float((w * i ** 4).sum())
+            if ftype in (3, 7, 4, 8):
+                assert abs(m2 - fgr ** 2 / 12.0) < 1e-13 * max(1.0, fgr ** 2), (ftype, fgr, m2)
+            if ftype == 4:
+                assert abs(m4 - fgr ** 4 / 80.0) < 1e-12 * fgr ** 4, (fgr, m4)
+            if ftype == 8:
+                assert abs(m4 - fgr ** 4 / 48.0) < 1e-12 * fgr ** 4, (fgr, m4)
+            if ftype == 1:  # trapezoid over [-fgr/2, fgr/2]: second moment fgr^2 / 12 + 1 / 6 (end-point rule)
+                assert abs(m2 - (fgr ** 2 / 12.0 + 1.0 / 6.0)) < 1e-13 * fgr ** 2, (fgr, m2)
+            if ftype == 2:
+                assert ng == max(1, int(np.ceil(4.0 * fgr / np.sqrt(12.0)))) and np.all(w > 0) and np.all(np.diff(w[ng:]) < 0)
+                assert abs(m2 - fgr ** 2 / 12.0) < 0.04 * fgr ** 2 / 12.0, (fgr, m2)
+                ref = np.exp(-6.0 * i ** 2 / fgr ** 2)
+                assert np.allclose(w, ref / ref.sum(), rtol=1e-15, atol=0)
+    assert oracle.filter_weights(5, 2) is None and oracle.filter_weights(2, 16) is None  # tabulated types / wider than 16 ghost cells: refused

@@ -302,8 +302,24 @@ def test_filter_tool_end_to_end(tmp_path, oracle):
         for b in range(lv.nboxes):
             assert np.array_equal(np.ascontiguousarray(r4.mfs[l].valid(b)).view(np.int64), np.ascontiguousarray(outs4[l].valid(b)).view(np.int64))
             assert not np.array_equal(r4.mfs[l].valid(b), outs[l].valid(b))
-    bad = subprocess.run([os.path.join(BIN, "filterPlt3d.ex"), "infile=" + p, "filter_type=2"], cwd=tmp_path, capture_output=True, text=True)
-    assert bad.returncode != 0 and "filter_type 2 is not available" in bad.stderr
+    bad = subprocess.run([os.path.join(BIN, "filterPlt3d.ex"), "infile=" + p, "filter_type=5"], cwd=tmp_path, capture_output=True, text=True)
+    assert bad.returncode != 0 and "filter_type 5 is not available" in bad.stderr
+    # filter_type=2: the Gaussian from its textbook kernel (flagged unverified in the tool's output), against the oracle's restatement
+    g = _run("filterPlt3d.ex", ["infile=" + p, "max_grid_size=8", "variables=temp density", "filter_type=2", "exact_filter=1"], tmp_path)
+    assert "UNVERIFIED against PelePhysics" in g.stdout
+    rg = read_plotfile(str(tmp_path / "plt00005_filtered"))
+    insg = []
+    for s_, lv in zip(ins, levels):  # ngrow 3 on level 0 (fgr 2), 5 on level 1 (fgr 4)
+        m = MultiFab(lv, 2, 5)
+        for b in range(lv.nboxes):
+            m.valid(b)[:] = s_.valid(b)
+        insg.append(m)
+    outsg = [MultiFab(lv, 2, 0) for lv in levels]
+    info = oracle.filter_pipeline(levels, insg, outsg, 2, base_fgr=2, interp_type=1, filter_type=2)
+    assert info == [(2, 3), (4, 5)]
+    for l, lv in enumerate(levels):
+        for b in range(lv.nboxes):
+            assert np.array_equal(np.ascontiguousarray(rg.mfs[l].valid(b)).view(np.int64), np.ascontiguousarray(outsg[l].valid(b)).view(np.int64)), f"gaussian level {l} box {b}"
     bad = subprocess.run([os.path.join(BIN, "filterPlt3d.ex"), "infile=" + p, "base_fgr=3"], cwd=tmp_path, capture_output=True, text=True)
     assert bad.returncode != 0 and "even" in bad.stderr
 
@@ -998,3 +1014,51 @@ def test_isosurface_tool_full_size_config4_closed_manifold(tmp_path):
         pos = eol + 1 + 8 * n * nc
     assert np.array_equal(np.vstack(got).view(np.int64), np.ascontiguousarray(nodes).view(np.int64))
     assert "staging vertex data to disk in %d chunks" % len(got) in out.stdout
+
+
+def _synth_ratio4(tmp_path, per=(0, 0, 0)):
+    """2-level plotfile with refinement ratio 4: base 16^3 in 8^3 boxes, level 1 = coarse cells [4, 11]^3 refined to [16, 47]^3 in 16^3 boxes"""
+    from peleanalysis_amd.hierarchy import Hierarchy, Level, chop_box
+    l0 = Level(chop_box((0, 0, 0), (15, 15, 15), 8), (0, 0, 0), (15, 15, 15), per, np.zeros(3), np.ones(3))
+    l1 = Level(chop_box((16, 16, 16), (47, 47, 47), 16), (0, 0, 0), (63, 63, 63), per, np.zeros(3), np.ones(3))
+    H = Hierarchy([l0, l1], 4)
+    from util import make_states, field_flame
+    mfs = make_states(H, 3, 0, field_flame, seed=3)
+    p = str(tmp_path / "plt00004")
+    write_plotfile(p, H, mfs, ["temp", "x_velocity", "density"], time=0.25)
+    return p, H, mfs
+
+
+@pytest.mark.gpu
+def test_filter_and_isosurface_tools_refinement_ratio_4(tmp_path, oracle):
+    """the two tools whose reference takes the plotfile's refinement ratio (filterPlt.cpp:133,200; isosurface.cpp:1472,1518,1543)
+    on a ratio-4 plotfile: filterPlt's filter-to-grid ratio grows by 4 (fgr 2 -> 8: 729 taps on level 1) and its ghost fill
+    interpolates with ratio-4 offsets; isosurface masks by the finer level coarsened by 4 and fills coarse-fine ghosts from the
+    parent of 4^3 children.  Both against the oracle run with ratio = 4; grad keeps refusing such a file like the reference's
+    hard-coded 2 would mis-handle it"""
+    p, H, mfs = _synth_ratio4(tmp_path)
+    assert read_plotfile(p).hier.ref_ratio == 4
+    _run("filterPlt3d.ex", ["infile=" + p, "max_grid_size=16", "variables=temp", "exact_filter=1"], tmp_path)
+    r = read_plotfile(str(tmp_path / "plt00004_filtered"))
+    ins = []
+    for l, lv in enumerate(H.levels):
+        s = MultiFab(lv, 1, 4)
+        for b in range(lv.nboxes):
+            s.valid(b)[0] = mfs[l].valid(b)[0]
+        ins.append(s)
+    outs = [MultiFab(lv, 1, 0) for lv in H.levels]
+    info = oracle.filter_pipeline(H.levels, ins, outs, 1, base_fgr=2, ratio=4, interp_type=1)
+    assert info == [(2, 1), (8, 4)]
+    for l, lv in enumerate(H.levels):
+        assert np.array_equal(r.hier.levels[l].boxes, lv.boxes)
+        for b in range(lv.nboxes):
+            assert np.array_equal(np.ascontiguousarray(r.mfs[l].valid(b)).view(np.int64), np.ascontiguousarray(outs[l].valid(b)).view(np.int64)), f"ratio 4 filter level {l} box {b}"
+    _run("isosurface3d.ex", ["infile=" + p, "isoCompName=temp", "isoVal=1150", "comps=0 2"], tmp_path)
+    label, names, nodes, faces = read_mef(p + "_temp_1150.mef")
+    fields = [MultiFab(lv, 3, 0, mfs[l].data.copy()) for l, lv in enumerate(H.levels)]
+    onodes, oelts = oracle.isosurface_pipeline(H.levels, fields, [0, 2], 0, 1150.0, MultiFab, ratio=4)
+    assert len(oelts) > 100
+    assert np.array_equal(faces, oelts + 1), "connectivity (1-based) differs"
+    assert np.array_equal(nodes.view(np.int64), onodes.view(np.int64)), "node data not bit-identical"
+    bad = subprocess.run([os.path.join(BIN, "grad3d.ex"), "infile=" + p], cwd=tmp_path, capture_output=True, text=True)
+    assert bad.returncode != 0 and "refinement ratio 2" in bad.stderr
