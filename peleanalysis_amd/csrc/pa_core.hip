@@ -385,6 +385,16 @@ pa_level* pa_level_create_spec(pa_ctx* ctx, const LevelSpec& S, const int32_t do
       const long long nc = (long long)(B.hi[t0] - B.lo[t0] + 1) * (B.hi[t1] - B.lo[t1] + 1);
       for (int c = 0; c < (int)((nc + 255) / 256); ++c) { wg.push_back((int)e); wg.push_back(c); }
     }
+    std::vector<int> sfb;
+    for (int f : L->sfaces)
+      if (sfb.empty() || sfb.back() != f / 6) sfb.push_back(f / 6);  // sfaces is sorted by box
+    L->nsfboxes = (int)sfb.size();
+    if (L->nsfboxes > 0 && (hipMalloc(&L->d_sfboxes, sizeof(int) * sfb.size()) != hipSuccess ||
+                            hipMemcpy(L->d_sfboxes, sfb.data(), sizeof(int) * sfb.size(), hipMemcpyHostToDevice) != hipSuccess)) {
+      pa_fail(ctx, "pa_level_create: device allocation failed");
+      delete L;
+      return nullptr;
+    }
     L->nsfwg = (int)(wg.size() / 2);
     if (L->nsfwg > 0 && (hipMalloc(&L->d_sfwg, sizeof(int) * wg.size()) != hipSuccess ||
                          hipMemcpy(L->d_sfwg, wg.data(), sizeof(int) * wg.size(), hipMemcpyHostToDevice) != hipSuccess)) {
@@ -467,6 +477,7 @@ extern "C" void pa_level_destroy(pa_level* L) {
   if (L->d_irr) (void)hipFree(L->d_irr);
   if (L->d_sfwg) (void)hipFree(L->d_sfwg);
   if (L->d_blist) (void)hipFree(L->d_blist);
+  if (L->d_sfboxes) (void)hipFree(L->d_sfboxes);
   delete L;
 }
 extern "C" int pa_level_nboxes(const pa_level* L) { return L ? (int)L->boxes.size() : 0; }

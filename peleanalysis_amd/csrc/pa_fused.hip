@@ -701,7 +701,7 @@ struct PrepArgs {
 // Thread per ghost cell of a special face: the face ghost of phi (MLMG applyBC, as k_apply_bc_sfaces) and the resolved
 // ghost value of c = the same boundary condition applied to c, whose interior values are (phi - pmin) * invd formed on the
 // fly and whose coarse values are the affine view of the coarse phi -- the operations of k_apply_bc_sfaces<2> on a stored c.
-struct PrepLev { DLevelView L; DMFView M; int comp; DLevelView LC; DMFView MC; int ccomp; PrepArgs A; int use_cp; long long cg_stride = 0, cp_stride = 0; const int2* wg = nullptr; int nwg = 0; };
+struct PrepLev { DLevelView L; DMFView M; int comp; DLevelView LC; DMFView MC; int ccomp; PrepArgs A; int use_cp; long long cg_stride = 0, cp_stride = 0; const int2* wg = nullptr; int nwg = 0; const int* sfboxes = nullptr; };
 template <bool PATCH>
 __global__ __launch_bounds__(256) void k_prep_faces(LevBatch<PrepLev> Bt, int* nbad, SlotK sk = SlotK()) {
   unsigned fy;
@@ -792,7 +792,7 @@ __global__ void k_prep_ring(LevBatch<PrepLev> Bt, int* nbad, SlotK sk = SlotK())
   const int comp = Pl.comp + z, ccomp = Pl.ccomp + z;
   double* const cgz = L.cg + z * Pl.cg_stride;
   const double* const cpz = L.cp ? L.cp + z * Pl.cp_stride : nullptr;
-  const int b = (int)fy;
+  const int b = Pl.sfboxes[fy];  // the launch runs over the boxes that have a special face: the others have no ring to fill
   const DBox B = L.boxes[b];
   const int n[3] = {B.hi[0] - B.lo[0] + 1, B.hi[1] - B.lo[1] + 1, B.hi[2] - B.lo[2] + 1};
   long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
@@ -1337,12 +1337,12 @@ int pa_gradcurv_prep_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int comp, 
       P.MC.xform = 1; P.MC.xa = pmin; P.MC.xb = P.A.invd;
       P.ccomp = ccomp;
       P.use_cp = (use_cp && crse[l] && L->cp_total > 0) ? 1 : 0;
-      P.wg = (const int2*)L->d_sfwg; P.nwg = L->nsfwg;
+      P.wg = (const int2*)L->d_sfwg; P.nwg = L->nsfwg; P.sfboxes = L->d_sfboxes;
       const long long n0 = L->maxn[0], n1 = L->maxn[1], n2 = L->maxn[2];
       ntf = std::max(ntf, std::max(n1 * n2, std::max(n0 * n2, n0 * n1)));
       ntr = std::max(ntr, 4 * (n0 + n1 + n2));
       Bf.a[Bf.n] = P; Bf.ycum[Bf.n + 1] = Bf.ycum[Bf.n] + (int)L->sfaces.size(); ++Bf.n;
-      Br.a[Br.n] = P; Br.ycum[Br.n + 1] = Br.ycum[Br.n] + (int)L->boxes.size(); ++Br.n;
+      Br.a[Br.n] = P; Br.ycum[Br.n + 1] = Br.ycum[Br.n] + L->nsfboxes; ++Br.n;
     }
     if (!Bf.n) continue;
     ProfScope prof(ctx, PA_TAG_BC);
@@ -1483,11 +1483,61 @@ int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, d
     }
     PA_HIP(hipGetLastError());
   }
+  // the narrow groups (boxes at most 32 cells wide) of all levels in one launch too
+  std::vector<SweepGroup> nar;
+  {
+    static const int narrow_env = [] { const char* e = getenv("PA_NARROW"); return e ? atoi(e) : 1; }();
+    std::vector<SweepGroup> keep;
+    for (const SweepGroup& g : rest) ((g.dims[0] <= 32 && narrow_env) ? nar : keep).push_back(g);
+    if (batch_env && !knobs && fused_order() == 2 && nar.size() >= 2 && (int)nar.size() <= PA_MAXB) rest.swap(keep);
+    else nar.clear();
+  }
+  if (!nar.empty()) {
+    constexpr int NRW = 8;
+    SweepBatch S;
+    S.n = (int)nar.size();
+    S.wg0[0] = 0;
+    for (size_t q = 0; q < nar.size(); ++q) {
+      const int l = nar[q].lev;
+      const pa_level* L = phi[l]->lev;
+      if (level_cg(ctx, L, slot + 1)) return 1;
+      S.bp[q] = LevelBP2{L->view, phi[l]->view, out[l]->view};
+      S.bp[q].L.cg += slot * cg_stride(L);
+      MarchArgs A{pcomp, ocomp, fused_kseg(), pmin, 1.0 / (pmax - pmin), clip ? thr : -1.0, 2, 1, 1, 1};
+      A.cg = 1;
+      A.boxlist = nar[q].list;
+      A.nboxes = nar[q].n;
+      // planes per workgroup as march_launch chooses them for one level
+      const int nx = nar[q].dims[0], ny = nar[q].dims[1], nz = nar[q].dims[2];
+      if (!getenv("PA_KSEG")) {
+        const long long per_seg = (long long)((nx + 63) / 64) * ((ny + 12) / 13) * nar[q].n;
+        if (per_seg * ((nz + A.kseg - 1) / A.kseg) < 2048) {
+          long long best = -1;
+          int best_k = A.kseg;
+          for (int tz = 1; tz <= std::max(1, nz / 8); ++tz) {
+            const int k = (nz + tz - 1) / tz;
+            const long long rounds = (per_seg * ((nz + k - 1) / k) + 255) / 256, cost = rounds * (k + 4);
+            if (best < 0 || cost < best) { best = cost; best_k = k; }
+          }
+          A.kseg = std::max(best_k, 4);
+        }
+      }
+      const unsigned tiles = (unsigned)(((nx + 31) / 32) * ((ny + 2 * NRW - 1) / (2 * NRW)) * ((nz + A.kseg - 1) / A.kseg));
+      A.tiles_max = (int)tiles;
+      S.A[q] = A;
+      S.wg0[q + 1] = S.wg0[q] + tiles * 8u * (((unsigned)nar[q].n + 7u) / 8u);
+    }
+    ProfScope prof(ctx, PA_TAG_GRADCURV);
+    if (clip) hipLaunchKernelGGL((k_gradcurv_march3n_levels<NRW, true>), dim3(S.wg0[S.n]), dim3(64 * (NRW + 2)), 0, ctx->stream, S);
+    else hipLaunchKernelGGL((k_gradcurv_march3n_levels<NRW, false>), dim3(S.wg0[S.n]), dim3(64 * (NRW + 2)), 0, ctx->stream, S);
+    PA_HIP(hipGetLastError());
+    if (lv.empty()) ctx->sweep_kernel = "k_gradcurv_march3n_levels<NRW=8" + std::string(clip ? ",CLIP" : "") + ">[" + std::to_string(S.n) + " levels per launch]";
+  }
   for (const SweepGroup& g : rest)
     if (sweep_group_cg(ctx, g, phi[g.lev], pcomp, pmin, pmax, out[g.lev], ocomp, thr, slot)) return 1;
   if (!lv.empty())
     ctx->sweep_kernel = "k_gradcurv_march3_levels<MTY=" + std::to_string(mty) + (clip ? ",CLIP" : "") + ">[" + std::to_string(lv.size()) + " levels per launch]" +
-                        (rest.empty() ? "" : " + " + std::to_string(rest.size()) + " narrow-box launch(es)");
+                        ((rest.empty() && nar.empty()) ? "" : " + narrow-box launch(es)");
   return 0;
 }
 

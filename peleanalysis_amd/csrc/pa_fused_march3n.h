@@ -30,12 +30,12 @@ struct MarchLdsN {
 // one row short of the box, the row BEYOND the halo row is the ghost row); x faces: the edge wave's lanes likewise with the
 // array [plane][y].  Both waves address the second stream through per-lane pointers when CG is on.
 template <typename BP, int NRW, bool CLIP, bool CG = false>
-__global__ __launch_bounds__(64 * (NRW + 2), 1) void k_gradcurv_march3n(BP bp, MarchArgs A) {
+__device__ __forceinline__ void gradcurv_march3n_body(const BP& bp, const MarchArgs& A, const unsigned bid_x, const unsigned bid_y) {
   FabView P, O;
   DBox V;
   double dxinv[3];
   constexpr int MTY2 = 2 * NRW, MROWS = MTY2 + 2;
-  unsigned bid = blockIdx.x;
+  unsigned bid = bid_x;
   int box;
   if (A.order == 2) {
     const unsigned per8 = 8u * (unsigned)A.tiles_max, g = bid / per8, r = bid % per8;
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(64 * (NRW + 2), 1) void k_gradcurv_march3n(BP bp, M
     bid = r >> 3;
     if (box >= A.nboxes) return;
   } else {
-    box = (int)blockIdx.y;
+    box = (int)bid_y;
   }
   if (A.boxlist) {
     if (box >= A.nboxes) return;
@@ -385,4 +385,18 @@ __global__ __launch_bounds__(64 * (NRW + 2), 1) void k_gradcurv_march3n(BP bp, M
   }
 #undef PA_PROG
 #undef PA_RUN3
+}
+
+template <typename BP, int NRW, bool CLIP, bool CG = false>
+__global__ __launch_bounds__(64 * (NRW + 2), 1) void k_gradcurv_march3n(BP bp, MarchArgs A) {
+  gradcurv_march3n_body<BP, NRW, CLIP, CG>(bp, A, blockIdx.x, blockIdx.y);
+}
+
+// the CG sweeps of the narrow-box groups of several levels in ONE launch (as k_gradcurv_march3_levels for the wide boxes: no idle
+// tail and ramp-up between the levels)
+template <int NRW, bool CLIP = false>
+__global__ __launch_bounds__(64 * (NRW + 2), 1) void k_gradcurv_march3n_levels(SweepBatch S) {
+  int l = 0;
+  while (l + 1 < S.n && blockIdx.x >= S.wg0[l + 1]) ++l;
+  gradcurv_march3n_body<LevelBP2, NRW, CLIP, true>(S.bp[l], S.A[l], blockIdx.x - S.wg0[l], 0u);
 }

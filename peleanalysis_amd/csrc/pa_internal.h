@@ -160,6 +160,8 @@ struct pa_level {
   int* d_blist = nullptr;
   int nwide = 0, nnarrow = 0;
   int wmax[3] = {0, 0, 0}, nmax[3] = {0, 0, 0};  // largest extents among the wide / the narrow boxes
+  int* d_sfboxes = nullptr; // local boxes with at least one special face (k_prep_ring runs over these only)
+  int nsfboxes = 0;
   void* d_sfwg = nullptr;   // int2 {special face, chunk of 256 of its ghost cells}: the work table of the per-face-cell kernels
   int nsfwg = 0;
   void* d_irr = nullptr;    // int4 {box, i, j, k}

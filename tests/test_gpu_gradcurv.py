@@ -141,7 +141,7 @@ def test_gradcurv_exact_normal_pipeline(ctx, oracle, per, sym, threshold):
         ctx.sync()
         assert ctx.bc_errors() == 0
         kn = ctx.lib.pa_sweep_kernel_name(ctx.h).decode()
-        assert kn.endswith("CG=1>") or kn.startswith("k_gradcurv_march3_levels<"), kn  # the exact-normal pipeline did run (level by level or all levels in one launch)
+        assert kn.endswith("CG=1>") or "_levels<" in kn, kn  # the exact-normal pipeline did run (level by level or all levels in one launch)
         if threshold is not None:
             assert "CLIP" in kn
             nslow = ctx.lib.pa_last_slow_cells(ctx.h)
@@ -203,7 +203,7 @@ def test_gradcurv_exact_normal_pipeline_one_short_tiles(ctx, oracle, per):
     ctx.sync()
     assert ctx.bc_errors() == 0
     kn = ctx.lib.pa_sweep_kernel_name(ctx.h).decode()
-    assert kn.endswith("CG=1>") or kn.startswith("k_gradcurv_march3_levels<"), kn  # the exact-normal pipeline did run (level by level or all levels in one launch)
+    assert kn.endswith("CG=1>") or "_levels<" in kn, kn  # the exact-normal pipeline did run (level by level or all levels in one launch)
     for l in range(H.nlev):
         got = dout[l].download()
         assert_valid_bits_equal(got, og[l], [(c, c) for c in range(4)], f"one-short grad level {l}")
@@ -448,7 +448,7 @@ def test_gradcurv_run_comps_batched_equals_component_by_component(ctx, oracle, n
     ctx.sync()
     assert ctx.bc_errors() == 0 and sorted(got) == list(range(ncomp))
     kn = ctx.lib.pa_sweep_kernel_name(ctx.h).decode()
-    assert kn.endswith("CG=1>") or kn.startswith("k_gradcurv_march3_levels<"), kn
+    assert kn.endswith("CG=1>") or "_levels<" in kn, kn
     for c in range(ncomp):
         oc, mfs = got[c]
         assert oc == 3 + 8 * (c % nslot)
@@ -522,7 +522,7 @@ def test_not_properly_nested_fine_level_is_counted_on_every_path(ctx, monkeypatc
         capi.gradcurv_run(ctx, dst, 0, bc, capi.curv_params(prog_min=200.0, prog_max=2100.0, fused=True), work, dout, 0)
         ctx.sync()
         kn = ctx.lib.pa_sweep_kernel_name(ctx.h).decode()
-        assert kn.endswith("CG=1>") or kn.startswith("k_gradcurv_march3_levels<"), kn
+        assert kn.endswith("CG=1>") or "_levels<" in kn, kn
         counts[sw] = ctx.bc_errors()
     capi.gradcurv_run(ctx, dst, 0, bc, capi.curv_params(prog_min=200.0, prog_max=2100.0, fused=False), work, dout, 0)
     ctx.sync()

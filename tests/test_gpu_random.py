@@ -277,7 +277,7 @@ def test_random_union_hierarchy_matches_oracle(ctx, oracle, seed):
         assert ctx.bc_errors() == 0, tag
         if fused:  # the exact-normal pipeline took it, whatever the shape
             kn = ctx.lib.pa_sweep_kernel_name(ctx.h).decode()
-            assert "CG=1" in kn or kn.startswith("k_gradcurv_march3_levels<"), (tag, kn)
+            assert "CG=1" in kn or "_levels<" in kn, (tag, kn)
         for l in range(H.nlev):
             got = dout[l].download()
             assert_valid_bits_equal(got, og[l], [(c, c) for c in range(4)], f"{tag} fused {fused} grad level {l}")
@@ -348,7 +348,7 @@ def test_random_union_wide_box_hierarchy_matches_oracle(ctx, oracle, seed):
     ctx.sync()
     assert ctx.bc_errors() == 0, tag
     kn = ctx.lib.pa_sweep_kernel_name(ctx.h).decode()
-    assert "CG=1" in kn or kn.startswith("k_gradcurv_march3_levels<"), (tag, kn)
+    assert "CG=1" in kn or "_levels<" in kn, (tag, kn)
     for l in range(H.nlev):
         got = dout[l].download()
         assert_valid_bits_equal(got, og[0][l], [(c, c) for c in range(4)], f"{tag} ({nirr} irregular cells) grad level {l}")
