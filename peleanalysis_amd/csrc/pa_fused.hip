@@ -18,6 +18,7 @@
 #include "pa_fused_march.h"
 #include "pa_fused_march3.h"
 #include "pa_fused_march3n.h"
+#include <algorithm>
 #include <cstdlib>
 
 #ifndef PA_FC_WAVES
@@ -1133,6 +1134,17 @@ static int level_irregular(pa_ctx* ctx, const pa_level* Lc) {
     n = m;
   }
   (void)hipFree(d_count);
+  if (n > 1) {  // the kernel appended the cells in any order: sort by (box, k, j, i) so that neighbouring threads touch neighbouring cells
+    std::vector<int4> h((size_t)n);
+    PA_HIP(hipMemcpy(h.data(), L->d_irr, sizeof(int4) * (size_t)n, hipMemcpyDeviceToHost));
+    std::sort(h.begin(), h.end(), [](const int4& a, const int4& b) {
+      if (a.x != b.x) return a.x < b.x;
+      if (a.w != b.w) return a.w < b.w;
+      if (a.z != b.z) return a.z < b.z;
+      return a.y < b.y;
+    });
+    PA_HIP(hipMemcpy(L->d_irr, h.data(), sizeof(int4) * (size_t)n, hipMemcpyHostToDevice));
+  }
   L->nirr = n;
   return 0;
 }
@@ -1153,6 +1165,7 @@ struct GenLev {
   // dynamic list (filled by k_faces_curv_fast<CLIP> in this pass): the count lives on the device, an item's first word carries
   // box | batch level << 24 | slot << 27 and only the items of batch level `lev` are this launch's
   const int* ncount = nullptr; int lev = -1;
+  int use_cp = 0; long long cp_stride = 0;  // the level's coarse patches hold the coarse normal component of each face's direction
 };
 struct GenBox {
   const DLevelView* L; const DLevelView* LCp; DMFView MCp; int cpcomp;
@@ -1160,7 +1173,7 @@ struct GenBox {
   __device__ __forceinline__ double c_in(const int p[3]) const { return (P(p[0], p[1], p[2], pcomp) - pmin) * invd; }
 };
 // the progress variable at Z = Y + sg e_dir as the owner of the valid cell Y sees it (Y: a cell of the box or in the first ghost layer)
-__device__ double gen_c(const GenBox& g, const int Y[3], int dir, int sg, bool& ok) {
+__device__ __noinline__ double gen_c(const GenBox& g, const int Y[3], int dir, int sg, bool& ok) {
   int Z[3] = {Y[0], Y[1], Y[2]};
   Z[dir] += sg;
   if (in_box(g.B, Z)) return g.c_in(Z);
@@ -1190,7 +1203,7 @@ __device__ double gen_c(const GenBox& g, const int Y[3], int dir, int sg, bool& 
   r += bv * coef[0];
   return r;
 }
-__device__ Vec3 gen_normal(const GenBox& g, const int Y[3], const double dxinv[3], bool& ok) {
+__device__ __noinline__ Vec3 gen_normal(const GenBox& g, const int Y[3], const double dxinv[3], bool& ok) {
   Vec3 n;
   const double cxm = gen_c(g, Y, 0, -1, ok), cxp = gen_c(g, Y, 0, 1, ok), cym = gen_c(g, Y, 1, -1, ok), cyp = gen_c(g, Y, 1, 1, ok);
   const double czm = gen_c(g, Y, 2, -1, ok), czp = gen_c(g, Y, 2, 1, ok);
@@ -1198,12 +1211,20 @@ __device__ Vec3 gen_normal(const GenBox& g, const int Y[3], const double dxinv[3
   return n;
 }
 
-template <bool CLIP>
-__global__ __launch_bounds__(64) void k_curv_general(GenLev G, int* nbad, SlotK sk) {
+// the coarse-normal boundary value of the cell's own coarse-fine face (out of line: the common irregular cell has none)
+__device__ __noinline__ double gen_crse_normal(const DLevelView& L, const DLevelView& LCn, const DMFView& MCn, int comp, const int q[3], int d, int ratio, bool& ok) {
+  return cf_bndry_value(L, LCn, MCn, comp, q, d, ratio, ok);
+}
+// GEN: the code that rebuilds a ghost normal from the progress variable is compiled in (needed where the ghost cell's owner is
+// another rank's box, or -- CLIP -- where the sweep zeroed a stored normal); PATCH: the coarse-fine boundary value of the
+// cell's own face comes from the face's coarse patch (the owner-map interpolation is not compiled in).  The common case --
+// one rank, no clip, patches on -- is <false, false, true>: a handful of loads per cell, no calls.
+template <bool CLIP, bool GEN, bool PATCH>
+__device__ __forceinline__ void curv_general_body(const GenLev& G, int* nbad, const SlotK& sk, const long long i0, const long long stride) {
   const DLevelView& L = G.L;
   const double dxinv[3] = {L.dxinv[0], L.dxinv[1], L.dxinv[2]};
-  const int ntot = G.ncount ? min(*G.ncount, G.n) : G.n;
-  for (int i = blockIdx.x * 64 + threadIdx.x; i < ntot; i += gridDim.x * 64) {
+  const long long ntot = G.ncount ? min(*G.ncount, G.n) : G.n;
+  for (long long i = i0; i < ntot; i += stride) {  // (64-bit: i0 + stride must not wrap)
     const int4 it = G.items[i];
     int z = (int)blockIdx.z, b = it.x;
     if (G.lev >= 0) {
@@ -1231,7 +1252,7 @@ __global__ __launch_bounds__(64) void k_curv_general(GenLev G, int* nbad, SlotK 
     if (CLIP && clipped(X)) { *kout = 0.0; continue; }
     // component d of the UNCLIPPED normal of cell p of this box (the sweep zeroed the clipped ones in the output)
     auto nrm = [&](const int p[3], int d) -> double {
-      if (CLIP && clipped(p)) return comp_of(gen_normal(g, p, dxinv, ok), d);
+      if (CLIP && GEN && clipped(p)) return comp_of(gen_normal(g, p, dxinv, ok), d);
       return o[fab_index(B, G.MO.ng, G.MO.ncomp, ncomp0 + d, p[0], p[1], p[2])];
     };
     double curv = 0.0;
@@ -1250,9 +1271,11 @@ __global__ __launch_bounds__(64) void k_curv_general(GenLev G, int* nbad, SlotK 
           // the level are done), rebuilt from the progress variable as its owner sees it when it is another rank's
           if (sb >= 0) {
             const double v = G.MO.data[G.MO.off[sb] + fab_index(L.boxes[sb], G.MO.ng, G.MO.ncomp, ncomp0 + d, qw[0], qw[1], qw[2])];
-            nb[s2] = (CLIP && v == 0.0 && clipped(q)) ? comp_of(gen_normal(g, q, dxinv, ok), d) : v;
-          } else {
+            nb[s2] = (CLIP && GEN && v == 0.0 && clipped(q)) ? comp_of(gen_normal(g, q, dxinv, ok), d) : v;
+          } else if (GEN) {
             nb[s2] = comp_of(gen_normal(g, q, dxinv, ok), d);
+          } else {  // (cannot happen: the host compiles GEN in for sharded levels)
+            ok = false; nb[s2] = 0.0;
           }
         } else if (cls == 2) {
           nb[s2] = (A.bc[d] == PA_BC_REFLECT_ODD) ? -n0d : n0d;
@@ -1260,7 +1283,22 @@ __global__ __launch_bounds__(64) void k_curv_general(GenLev G, int* nbad, SlotK 
           if (!A.has_crse) { ok = false; nb[s2] = 0.0; continue; }
           double coef[4];
           const int NX = cf_normal_coef(n[d], A.ratio, coef);
-          const double bv = cf_bndry_value(L, G.LCn, G.MCn, cncomp0 + d, q, d, A.ratio, ok);
+          // q is a ghost cell of face (d, s2) of this box, which is special: its masks are stored, its coarse patch holds component d
+          double bv;
+          const int e2 = L.sfindex[b * 6 + d * 2 + s2];
+          const long long cpo = (G.use_cp && L.cp && e2 >= 0) ? L.cpoff[e2] : -1;
+          if (e2 < 0 || ((PATCH || cpo >= 0) && (!L.cp || L.cpoff[e2] < 0))) {  // (cannot happen: a coarse-fine ghost cell makes its face special, with a patch)
+            ok = false; bv = 0.0;
+          } else if (PATCH || cpo >= 0) {
+            const int u0 = (d == 0) ? 1 : 0, u1 = (d == 2) ? 1 : 2;
+            const unsigned code = L.sfcode[L.sfoff[e2] + (q[u0] - B.lo[u0]) + (long long)n[u0] * (q[u1] - B.lo[u1])];
+            const int xf[1] = {0};
+            double bv1[1];
+            cf_interp_patch<1>(code, L.cp + z * G.cp_stride + L.cpoff[e2], B, s2, G.MCn, q, d, xf, ok, bv1);
+            bv = bv1[0];
+          } else {
+            bv = gen_crse_normal(L, G.LCn, G.MCn, cncomp0 + d, q, d, A.ratio, ok);
+          }
           double tmp = 0.0;
           for (int m = 1; m < NX; ++m) {
             int pc[3] = {q[0], q[1], q[2]};
@@ -1279,6 +1317,20 @@ __global__ __launch_bounds__(64) void k_curv_general(GenLev G, int* nbad, SlotK 
     if (!ok) atomicAdd(nbad, 1);
     *kout = curv;
   }
+}
+template <bool CLIP, bool GEN = true, bool PATCH = false>
+__global__ __launch_bounds__(256) void k_curv_general(GenLev G, int* nbad, SlotK sk) {
+  curv_general_body<CLIP, GEN, PATCH>(G, nbad, sk, blockIdx.x * 256LL + threadIdx.x, gridDim.x * 256LL);
+}
+// the static lists of several levels in one launch: level l owns workgroups wg0[l] .. wg0[l+1]-1, 256 list items each
+struct GenBatch { int n; unsigned wg0[PA_MAXB + 1]; GenLev a[PA_MAXB]; };
+static_assert(sizeof(GenBatch) + sizeof(SlotK) + 16 <= 4000, "kernel arguments of k_curv_general_levels");
+template <bool CLIP, bool GEN, bool PATCH>
+__global__ __launch_bounds__(256) void k_curv_general_levels(GenBatch Bt, int* nbad, SlotK sk) {
+  int l = 0;
+  while (l + 1 < Bt.n && blockIdx.x >= Bt.wg0[l + 1]) ++l;
+  const GenLev G = Bt.a[l];
+  curv_general_body<CLIP, GEN, PATCH>(G, nbad, sk, (long long)(blockIdx.x - Bt.wg0[l]) * 256 + threadIdx.x, 1LL << 40);
 }
 
 // can the exact-normal pipeline run on this level (same answer on every rank of a sharded level)?
@@ -1565,6 +1617,8 @@ int pa_gradcurv_fix_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, 
     for (int d = 0; d < 3; ++d) G.A.bc[d] = bc[d];
     G.A.ratio = 2; G.A.has_crse = (crse_n[l] && cp) ? 1 : 0; G.A.thr = clip ? thr : -1.0; G.A.layers = 1; G.A.perim_only = 0; G.A.pmin = pmin; G.A.invd = 1.0 / (pmax - pmin);
     G.items = nullptr; G.n = 0;
+    G.use_cp = (use_cp && crse_n[l] && L->cp_total > 0) ? 1 : 0;
+    G.cp_stride = cp_stride(L);
     return G;
   };
   for (int l0 = 0; l0 < nlev; l0 += PA_MAXB) {
@@ -1620,7 +1674,7 @@ int pa_gradcurv_fix_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, 
         if (phi[blev[q]]->lev->pure_faces) continue;  // no such cells on this level
         GenLev G = gen_lev(blev[q]);
         G.items = sl.gitems; G.n = sl.gcap; G.ncount = sl.gcount; G.lev = q;
-        hipLaunchKernelGGL(k_curv_general<true>, dim3(256), dim3(64), 0, ctx->stream, G, ctx->d_flags, sk);
+        hipLaunchKernelGGL(k_curv_general<true>, dim3(256), dim3(256), 0, ctx->stream, G, ctx->d_flags, sk);
       }
     } else {
       // no clip: PA_FIX_OVERLAP=1 (read per pass) puts the perimeter kernel next to the interior one on the side stream.  OFF by
@@ -1650,18 +1704,39 @@ int pa_gradcurv_fix_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, 
       PA_HIP(hipStreamWaitEvent(ctx->stream, ctx->fix_evs[1], 0));
     }
   }
-  // general BoxArrays: the listed irregular cells, after (and over) whatever the kernels above wrote there
-  for (int l = 0; l < nlev; ++l) {
-    const pa_level* L = phi[l]->lev;
-    if (L->boxes.empty()) continue;
-    if (level_irregular(ctx, L)) return 1;
-    if (L->nirr == 0) continue;
-    GenLev G = gen_lev(l);
-    G.items = (const int4*)L->d_irr; G.n = L->nirr;
-    ProfScope prof(ctx, PA_TAG_GRADCURV_FACES);
-    const dim3 gg((unsigned)std::min((L->nirr + 63) / 64, 65535), 1, (unsigned)nslots);
-    if (clip) hipLaunchKernelGGL(k_curv_general<true>, gg, dim3(64), 0, ctx->stream, G, ctx->d_flags, sk);
-    else hipLaunchKernelGGL(k_curv_general<false>, gg, dim3(64), 0, ctx->stream, G, ctx->d_flags, sk);
+  // general BoxArrays: the listed irregular cells, after (and over) whatever the kernels above wrote there; the lists of up to
+  // PA_MAXB levels in one launch
+  {
+    const int phi_nranks = nlev > 0 ? phi[0]->lev->nranks : 1;
+    GenBatch Gb;
+    Gb.n = 0;
+    Gb.wg0[0] = 0;
+    auto flush = [&]() {
+      if (!Gb.n) return;
+      ProfScope prof(ctx, PA_TAG_GRADCURV_FACES);
+      const dim3 gg(Gb.wg0[Gb.n], 1, (unsigned)nslots);
+      bool light = !clip, patch = true;  // one rank, no clip, every coarse-fine face has its patch: the small variant
+      for (int q = 0; q < Gb.n; ++q) {
+        light = light && Gb.a[q].L.nboxes > 0 && phi_nranks == 1;
+        patch = patch && (Gb.a[q].use_cp || !Gb.a[q].A.has_crse);
+      }
+      if (light && patch) hipLaunchKernelGGL((k_curv_general_levels<false, false, true>), gg, dim3(256), 0, ctx->stream, Gb, ctx->d_flags, sk);
+      else if (clip) hipLaunchKernelGGL((k_curv_general_levels<true, true, false>), gg, dim3(256), 0, ctx->stream, Gb, ctx->d_flags, sk);
+      else hipLaunchKernelGGL((k_curv_general_levels<false, true, false>), gg, dim3(256), 0, ctx->stream, Gb, ctx->d_flags, sk);
+      Gb.n = 0;
+    };
+    for (int l = 0; l < nlev; ++l) {
+      const pa_level* L = phi[l]->lev;
+      if (L->boxes.empty()) continue;
+      if (level_irregular(ctx, L)) return 1;
+      if (L->nirr == 0) continue;
+      GenLev G = gen_lev(l);
+      G.items = (const int4*)L->d_irr; G.n = L->nirr;
+      Gb.a[Gb.n] = G;
+      Gb.wg0[Gb.n + 1] = Gb.wg0[Gb.n] + (unsigned)((L->nirr + 255) / 256);
+      if (++Gb.n == PA_MAXB) flush();
+    }
+    flush();
   }
   PA_HIP(hipGetLastError());
   return 0;
