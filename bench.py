@@ -540,10 +540,18 @@ def main():
             # forms (ncclCommInitRank blocks until every rank has joined) must degrade to the gloo transport, not eat the run.
             import threading
             box = {}
+            # the id broadcast is a torch.distributed collective: it runs HERE, on the thread that issues all the others, so that
+            # the order of collectives is the same on every rank whatever the helper thread does (advisor finding, round 3)
+            try:
+                uid = padist.broadcast_rccl_id(ctx)
+            except Exception as e:
+                uid, box["err"] = None, repr(e)[:300]
 
             def bring_up():
+                if uid is None:
+                    return
                 try:
-                    padist.init_rccl(ctx)
+                    ctx.init_rccl(world, rank, uid)  # ncclCommInitRank: blocks until every rank has joined
                     ctx.comm_selftest(1 << 16)
                     box["ok"] = True
                 except Exception as e:

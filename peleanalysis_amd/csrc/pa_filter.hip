@@ -9,6 +9,7 @@
 #include "pa_dist.h"
 #include "pa_fabview.h"
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <type_traits>
@@ -410,11 +411,18 @@ static bool sep_shape(int nx, int ny, int nz, int ng, unsigned nboxes, int ncomp
 }
 template <typename BP, int NG, int NT, int NIT>
 static void sep_launch(hipStream_t st, const BP& bp, const SepShape& S, unsigned nboxes, int scomp, int ncomp, const FilterW& W) {
-  static bool attr = [] {
-    (void)hipFuncSetAttribute((const void*)k_filter_sep<BP, NG, NT, NIT>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    return true;
-  }();
-  (void)attr;
+  // more than 64 KiB of dynamic LDS needs the attribute, and function attributes are per DEVICE: one flag per device and
+  // instantiation (ngpus > 1 in one process: pa::Team runs one host thread per GPU; advisor finding, round 3)
+  static std::atomic<unsigned long long> done{0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (!(done.load(std::memory_order_acquire) & bit)) {
+    if (hipFuncSetAttribute((const void*)k_filter_sep<BP, NG, NT, NIT>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess)
+      done.fetch_or(bit, std::memory_order_release);
+    else
+      (void)hipGetLastError();  // the launch below then fails on its own if the LDS request is refused; pa_boxfilter_level reports it
+  }
   const dim3 g(8u * (unsigned)S.T * ((nboxes + 7u) / 8u), (unsigned)ncomp);
   hipLaunchKernelGGL((k_filter_sep<BP, NG, NT, NIT>), g, dim3(NT), S.lds, st, bp, scomp, W, S.TY, S.kseg, S.nys, S.T, (int)nboxes, S.ld_max);
 }

@@ -164,16 +164,10 @@ extern "C" int pa_stream_trace_ranks(pa_ctx* ctx, int nlev, pa_mf* const* vfield
   if (nsteps < 1) return pa_fail(ctx, "pa_stream_trace: Nsteps must be at least 1");
   if (nredist) *nredist = 0;
   const bool share = share_flags && ctx->comm.nranks > 1;
-  if (nseed == 0) {
-    int nr = 0;
-    for (int step = 0; share && step + 1 < nsteps; ++step) {  // keep the other ranks' reductions company
-      double f = 0.0;
-      if (pa_allreduce(ctx, &f, 1, 1)) return 1;
-      nr += f != 0.0;
-    }
-    if (nredist) *nredist = nr;
-    return 0;
-  }
+  // Every rank checks the SAME things about the field before the first collective (a rank without seeds too), so that an
+  // argument error makes all ranks return together; failures that only one rank can have (allocation, copies, a line leaving
+  // its ghost cells) travel with the per-step reduction as a second, max-reduced value: every rank sees it at the same step
+  // and all of them stop there -- no rank is left waiting in a collective (advisor finding, round 3).
   StreamLevels S;
   S.nlev = nlev; S.vcomp = vcomp; S.ng = vfield[0] ? vfield[0]->ng : 0;
   for (int l = 0; l < nlev; ++l) {
@@ -187,47 +181,74 @@ extern "C" int pa_stream_trace_ranks(pa_ctx* ctx, int nlev, pa_mf* const* vfield
     for (int d = 0; d < 3; ++d) S.dx[l][d] = (m->lev->prob_hi[d] - m->lev->prob_lo[d]) / (double)(m->lev->domhi[d] - m->lev->domlo[d] + 1);
   }
   for (int d = 0; d < 3; ++d) { S.plo[d] = vfield[0]->lev->prob_lo[d]; S.phi[d] = vfield[0]->lev->prob_hi[d]; }
+  // one reduction of (flag, error) per step; returns false when the transport itself failed
+  auto reduce2 = [&](int& flag, bool& err) {
+    double fe[2] = {flag ? 1.0 : 0.0, err ? 1.0 : 0.0};
+    if (pa_allreduce(ctx, fe, 2, 1) != 0) return false;
+    flag = fe[0] != 0.0;
+    err = fe[1] != 0.0;
+    return true;
+  };
   const long long np = 2 * nseed;
   double* dseeds = nullptr;
   int *dlev = nullptr, *dflags = nullptr;
-  PA_HIP(hipMalloc(&dseeds, sizeof(double) * 3 * (size_t)nseed));
-  if (hipMalloc(&dlev, sizeof(int) * 2 * (size_t)np) != hipSuccess || hipMalloc(&dflags, sizeof(int) * ((size_t)nsteps + 1)) != hipSuccess) {
-    (void)hipFree(dseeds); (void)hipFree(dlev);
-    return pa_fail(ctx, "pa_stream_trace: device allocation failed");
+  bool lerr = false;       // this rank cannot go on
+  std::string lmsg;
+  if (nseed > 0) {
+    if (hipMalloc(&dseeds, sizeof(double) * 3 * (size_t)nseed) != hipSuccess || hipMalloc(&dlev, sizeof(int) * 2 * (size_t)np) != hipSuccess ||
+        hipMalloc(&dflags, sizeof(int) * ((size_t)nsteps + 1)) != hipSuccess) {
+      lerr = true; lmsg = "pa_stream_trace: device allocation failed";
+    }
   }
-  int* dgrd = dlev + np;
-  int* dbad = dflags + nsteps;
+  int* dgrd = dlev ? dlev + np : nullptr;
+  int* dbad = dflags ? dflags + nsteps : nullptr;
   const int big = 0x7fffffff;
-  int rc = 0;
-  do {
+  int rc = 0, nr_shared = 0;
+  const unsigned g = (unsigned)((np + 255) / 256);
+  if (nseed > 0 && !lerr) {
     if (hipMemcpyAsync(dseeds, seeds, sizeof(double) * 3 * (size_t)nseed, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
         hipMemsetAsync(dflags, 0, sizeof(int) * (size_t)nsteps, ctx->stream) != hipSuccess ||
-        hipMemcpyAsync(dbad, &big, sizeof(int), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { rc = pa_fail(ctx, "pa_stream_trace: copy failed"); break; }
-    const unsigned g = (unsigned)((np + 255) / 256);
-    hipLaunchKernelGGL(k_stream_init, dim3(g), dim3(256), 0, ctx->stream, S, np, dseeds, nsteps, dev_pos, dlev, dgrd);
-    bool xfail = false;
-    for (int step = 0; step + 1 < nsteps && !xfail; ++step) {
-      hipLaunchKernelGGL(k_stream_check, dim3(g), dim3(256), 0, ctx->stream, S, np, nsteps, step, dev_pos, dlev, dgrd, dflags);
-      if (share) {  // the flag of ALL ranks' lines
-        int hf1 = 0;
-        xfail = hipMemcpyAsync(&hf1, dflags + step, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess;
-        double f = hf1 ? 1.0 : 0.0;
-        xfail = xfail || pa_allreduce(ctx, &f, 1, 1) != 0;
-        hf1 = f != 0.0;
-        xfail = xfail || hipMemcpyAsync(dflags + step, &hf1, sizeof(int), hipMemcpyHostToDevice, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess;
+        hipMemcpyAsync(dbad, &big, sizeof(int), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { lerr = true; lmsg = "pa_stream_trace: copy failed"; }
+    else hipLaunchKernelGGL(k_stream_init, dim3(g), dim3(256), 0, ctx->stream, S, np, dseeds, nsteps, dev_pos, dlev, dgrd);
+  }
+  bool gerr = false;  // some rank cannot go on (after a reduction: the same on every rank)
+  for (int step = 0; step + 1 < nsteps; ++step) {
+    const bool work = nseed > 0 && !lerr;
+    if (work) hipLaunchKernelGGL(k_stream_check, dim3(g), dim3(256), 0, ctx->stream, S, np, nsteps, step, dev_pos, dlev, dgrd, dflags);
+    if (share) {  // the flag of ALL ranks' lines (every rank takes part in every step's reduction, whatever happened to it)
+      int hf1 = 0;
+      if (work && (hipMemcpyAsync(&hf1, dflags + step, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)) {
+        lerr = true; lmsg = "pa_stream_trace: reading the redistribution flag failed";
       }
-      hipLaunchKernelGGL(k_stream_step, dim3(g), dim3(256), 0, ctx->stream, S, np, nsteps, step, dt, dev_pos, dlev, dgrd, dflags, dbad);
+      gerr = lerr;
+      if (!reduce2(hf1, gerr)) { rc = pa_fail(ctx, "pa_stream_trace: sharing the redistribution flag between the ranks failed"); gerr = true; break; }
+      if (gerr) break;  // every rank leaves at this step
+      nr_shared += hf1;
+      if (work && (hipMemcpyAsync(dflags + step, &hf1, sizeof(int), hipMemcpyHostToDevice, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)) {
+        lerr = true; lmsg = "pa_stream_trace: writing the redistribution flag failed";  // reported with the next step's reduction
+      }
+    } else if (lerr) {
+      break;
     }
-    if (xfail) { rc = pa_fail(ctx, "pa_stream_trace: sharing the redistribution flag between the ranks failed"); break; }
-    if (hipGetLastError() != hipSuccess) { rc = pa_fail(ctx, "pa_stream_trace: launch failed"); break; }
-    std::vector<int> hf((size_t)nsteps + 1);
-    if (hipMemcpyAsync(hf.data(), dflags, sizeof(int) * hf.size(), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-        hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = pa_fail(ctx, "pa_stream_trace: synchronisation failed"); break; }
-    int nr = 0;
-    for (int s = 0; s < nsteps; ++s) nr += hf[(size_t)s] != 0;
-    if (nredist) *nredist = nr;
-    if (hf[(size_t)nsteps] != big) rc = pa_fail(ctx, "pa_stream_trace: bad RK (line " + std::to_string(hf[(size_t)nsteps]) + " left the ghost cells of its grid; increase nGrow or lower hRK)");
-  } while (0);
-  (void)hipFree(dseeds); (void)hipFree(dlev); (void)hipFree(dflags);
+    if (nseed > 0 && !lerr) hipLaunchKernelGGL(k_stream_step, dim3(g), dim3(256), 0, ctx->stream, S, np, nsteps, step, dt, dev_pos, dlev, dgrd, dflags, dbad);
+  }
+  if (rc == 0 && (lerr || gerr)) rc = pa_fail(ctx, lerr ? lmsg : std::string("pa_stream_trace: another rank failed"));
+  if (rc == 0 && nseed > 0) {
+    do {
+      if (hipGetLastError() != hipSuccess) { rc = pa_fail(ctx, "pa_stream_trace: launch failed"); break; }
+      std::vector<int> hf((size_t)nsteps + 1);
+      if (hipMemcpyAsync(hf.data(), dflags, sizeof(int) * hf.size(), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+          hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = pa_fail(ctx, "pa_stream_trace: synchronisation failed"); break; }
+      int nr = 0;
+      for (int s2 = 0; s2 < nsteps; ++s2) nr += hf[(size_t)s2] != 0;
+      if (nredist) *nredist = nr;
+      if (hf[(size_t)nsteps] != big) rc = pa_fail(ctx, "pa_stream_trace: bad RK (line " + std::to_string(hf[(size_t)nsteps]) + " left the ghost cells of its grid; increase nGrow or lower hRK)");
+    } while (0);
+  } else if (rc == 0 && nredist) {
+    *nredist = nr_shared;  // a rank without seeds: the shared flags it saw
+  }
+  if (dseeds) (void)hipFree(dseeds);
+  if (dlev) (void)hipFree(dlev);
+  if (dflags) (void)hipFree(dflags);
   return rc;
 }

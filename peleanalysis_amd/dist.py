@@ -125,12 +125,13 @@ def host_exchange(rows: np.ndarray, glocal: Dict[int, int], src: MultiFab, dst: 
 
 
 # ------------------------------------------------------------------------------- transports
-def init_rccl(ctx: "capi.Context", group=None) -> None:
-    """built-in RCCL transport: rank 0 creates the communicator id, torch.distributed (any backend) broadcasts it.
-    Every rank always takes part in the broadcast -- rank 0 sends an error marker when it could not make the id -- so that a
-    failure on rank 0 raises on ALL ranks and their next collective (bench.py's fallback to the gloo transport) still lines up."""
+def broadcast_rccl_id(ctx: "capi.Context", group=None) -> bytes:
+    """rank 0 creates the RCCL communicator id, torch.distributed (any backend) broadcasts it.  Every rank always takes part in
+    the broadcast -- rank 0 sends an error marker when it could not make the id -- so that a failure on rank 0 raises on ALL
+    ranks and their next collective still lines up.  A torch.distributed collective: call it from the thread that issues the
+    process group's other collectives."""
     import torch.distributed as dist
-    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    rank = dist.get_rank(group)
     msg = [None, None]
     if rank == 0:
         try:
@@ -140,7 +141,14 @@ def init_rccl(ctx: "capi.Context", group=None) -> None:
     dist.broadcast_object_list(msg, src=0, group=group)
     if msg[1] is not None or msg[0] is None:
         raise RuntimeError("RCCL unique id not available on rank 0: " + str(msg[1]))
-    ctx.init_rccl(world, rank, msg[0])
+    return msg[0]
+
+
+def init_rccl(ctx: "capi.Context", group=None) -> None:
+    """built-in RCCL transport: broadcast_rccl_id + pa_ctx_init_rccl (ncclCommInitRank blocks until every rank has joined)"""
+    import torch.distributed as dist
+    uid = broadcast_rccl_id(ctx, group)
+    ctx.init_rccl(dist.get_world_size(group), dist.get_rank(group), uid)
 
 
 class GlooComm:

@@ -124,7 +124,12 @@ int main(int argc, char** argv) {
       if (lev > 0) ctx.check(pa_fillpatch_two_levels(ctx.h, din[lev]->h, din[lev - 1]->h, 0, ncomp, ngs[lev], H.ref_ratio[lev - 1], interp_type == 1 ? 1 : 0));
       ctx.check(pa_foextrap(ctx.h, din[lev]->h, 0, ncomp, ngs[lev]));
     }
-    if (r == 0) std::cout << "Done!" << std::endl << "Filtering data..." << std::endl;
+    if (r == 0) {
+      // which summation the library takes (ADVICE: say so in the output): the separable three-pass form differs from the
+      // reference's tap order by a few ulp (<= 1e-12 of the field's scale); exact_filter=1 / PA_FILTER_EXACT=1 keeps the tap order
+      const char* fe = getenv("PA_FILTER_EXACT");
+      std::cout << "Done!" << std::endl << "Filtering data... (" << ((fe && atoi(fe)) ? "tap order of Filter::apply_filter, bit-identical" : "separable form, within 1e-12 of the tap-order sum; exact_filter=1 for the tap order") << ")" << std::endl;
+    }
     for (int lev = 0; lev < Nlev; ++lev) {
       if (r == 0) std::cout << "on level " << lev << std::endl;
 #if PA_SPACEDIM == 2
