@@ -2,6 +2,7 @@
 oracle.  Derived fields bit-exact (stated tolerance 1e-12 relative); vertex order, edge keys and
 triangle connectivity identical."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -615,3 +616,39 @@ def test_marching_cubes_refinement_ratio_4(ctx, oracle):
         got.append(lev)
     check(got, "pa_mc_level_fine ratio 4")
     check(capi.mc_hierarchy(ctx, dst, [1, 0], loops, 3, iso, ratio=4), "pa_mc_hierarchy_fine ratio 4")
+
+
+@pytest.mark.parametrize("parent", ["1", "0"])
+def test_fillpatch_not_properly_nested_counts_errors_without_faulting(parent):
+    """a fine box whose ghost parents lie outside the coarse level (not properly nested): FillPatchTwoLevels with the
+    cell-conservative interpolation must COUNT those ghost cells (pa_bc_errors > 0; the tools turn that into the reference's
+    abort) on both forms -- the cached parent list (k_fp_do: advisor finding of round 3, it used to index the coarse multifab
+    with an unrelated cell) and the per-ghost-cell kernel -- and never read out of bounds.  Own process: the switch is read once."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+from peleanalysis_amd import capi
+from peleanalysis_amd.hierarchy import Hierarchy, Level, MultiFab
+z, o = np.zeros(3), np.ones(3)
+l0 = Level(np.array([[8, 8, 8, 23, 23, 23]], np.int32), (0, 0, 0), (31, 31, 31), (0, 0, 0), z, o)       # the coarse level covers the middle only
+l1 = Level(np.array([[16, 16, 16, 47, 47, 47]], np.int32), (0, 0, 0), (63, 63, 63), (0, 0, 0), z, o)   # fine box flush with the coarse level: ghost parents at coarse 7 do not exist
+ctx = capi.Context(0)
+rng = np.random.default_rng(1)
+ms = []
+for lv in (l0, l1):
+    m = MultiFab(lv, 1, 2)
+    m.data[:] = rng.random(m.total)
+    ms.append(m)
+dls = [capi.DevLevel(ctx, lv) for lv in (l0, l1)]
+dm = [capi.DevMF.from_host(ctx, dl, m) for dl, m in zip(dls, ms)]
+for it in (1, 0):
+    ctx.check(ctx.lib.pa_fillpatch_two_levels(ctx.h, dm[1].h, dm[0].h, 0, 1, 2, 2, it))
+    ctx.sync()
+    n = ctx.bc_errors()
+    assert n > 0, (it, n)
+print("NESTED_ERRORS_COUNTED")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, PA_FILLPATCH_PARENT=parent))
+    assert r.returncode == 0 and "NESTED_ERRORS_COUNTED" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
