@@ -682,12 +682,12 @@ def main():
         headline_cfg = (args.base, args.nlev, args.box, args.ncomp, world, args.sim_of) == (512, 3, 128, 1, 1, 0) and per == (1, 1, 0) and args.threshold < 0
         if headline_cfg and args.traffic == "live" and rank == 0:
             traffic, traffic_src = live_traffic()
-        tj = os.path.join(ROOT, "profiles", "r03_headline_traffic.json")
+        tj = os.path.join(ROOT, "profiles", "r04_headline_traffic.json")
         if traffic is None and args.traffic != "none" and os.path.exists(tj) and headline_cfg:
             rec = json.load(open(tj))
             if rec.get("kernel") == kern:
                 traffic = rec.get("traffic_bytes_per_launch")
-                traffic_src = "profiles/r03_headline_traffic.json (PMC passes of the same workload and kernel variant, tools/prof.sh bench)" + (f"; live pass: {traffic_src}" if traffic_src else "")
+                traffic_src = "profiles/r04_headline_traffic.json (PMC passes of the same workload and kernel variant, tools/prof.sh bench)" + (f"; live pass: {traffic_src}" if traffic_src else "")
         res["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                            "traffic": traffic, "traffic_source": traffic_src, "kernel": kern + " (fused grad->curvature sweep)", "avg_launch_ms": avg_ms,
                            "launches": nk, "bytes_per_cell": BYTES_PER_CELL, "cells_per_launch": cells_local * args.ncomp * args.steps / nk}

@@ -1454,8 +1454,13 @@ int pa_gradcurv_level_cg(pa_ctx* ctx, const pa_mf* phi, int pcomp, double pmin, 
 // the CG sweeps of all levels: the groups of boxes wider than 32 cells in one launch (k_gradcurv_march3_levels) when they agree
 // on the tile variant and the XCD-aware order is on, else group by group; narrow groups one launch each.
 // PA_SWEEP_BATCH=0: always group by group (A/B).
-int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, double pmin, double pmax, pa_mf* const* out, int ocomp, double thr, int slot) {
+// nslots > 1 (slot must be 0): components pcomp .. pcomp + nslots - 1 in ONE launch per kernel variant (blockIdx.y = slot: outputs at
+// ocomp + 8 z, compact arrays of slot z, progress range prog[2 z], prog[2 z + 1] on the device); groups that do not take a batched
+// launch run slot by slot with the host's ranges pmins / pmaxs
+int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, double pmin, double pmax, pa_mf* const* out, int ocomp, double thr, int slot,
+                          int nslots, const double* prog, const double* pmins, const double* pmaxs) {
   const bool clip = thr >= 0.0;
+  if (nslots > 1 && (slot != 0 || !prog || !pmins || !pmaxs)) return pa_fail(ctx, "pa_gradcurv_levels_cg: component slots need slot 0 and the progress ranges");
   static const int batch_env = [] { const char* e = getenv("PA_SWEEP_BATCH"); return e ? atoi(e) : 1; }();
   static const bool knobs = getenv("PA_MARCH") || getenv("PA_DBG") || getenv("PA_MTY") || getenv("PA_PAIR");
   std::vector<SweepGroup> all, lv, rest;
@@ -1469,7 +1474,7 @@ int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, d
     mty = m;
     lv.push_back(g);
   }
-  const bool ok = batch_env && !knobs && fused_order() == 2 && lv.size() >= 2 && (int)lv.size() <= PA_MAXB && same;
+  const bool ok = batch_env && !knobs && fused_order() == 2 && (lv.size() >= 2 || (nslots > 1 && lv.size() == 1)) && (int)lv.size() <= PA_MAXB && same;
   if (!ok) {
     rest.insert(rest.begin(), lv.begin(), lv.end());
     lv.clear();
@@ -1507,9 +1512,10 @@ int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, d
     for (size_t q = 0; q < lv.size(); ++q) {
       const int l = lv[q].lev;
       const pa_level* L = phi[l]->lev;
-      if (level_cg(ctx, L, slot + 1)) return 1;
+      if (level_cg(ctx, L, slot + nslots)) return 1;
       S.bp[q] = LevelBP2{L->view, phi[l]->view, out[l]->view};
       S.bp[q].L.cg += slot * cg_stride(L);
+      S.cgs[q] = cg_stride(L);
       MarchArgs A{pcomp, ocomp, kdef, pmin, 1.0 / (pmax - pmin), clip ? thr : -1.0, 2, 1, 1, 1};
       A.cg = 1;
       A.boxlist = lv[q].list;
@@ -1523,7 +1529,8 @@ int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, d
       S.wg0[q + 1] = S.wg0[q] + g.x * 8u * ((nb + 7u) / 8u);
     }
     ProfScope prof(ctx, PA_TAG_GRADCURV);
-    const dim3 grid(S.wg0[S.n]);
+    S.prog = nslots > 1 ? prog : nullptr;
+    const dim3 grid(S.wg0[S.n], (unsigned)nslots);
     if (clip) {
       if (mty == 13) hipLaunchKernelGGL((k_gradcurv_march3_levels<13, true>), grid, dim3(64 * 16), 0, ctx->stream, S);
       else if (mty == 8) hipLaunchKernelGGL((k_gradcurv_march3_levels<8, true>), grid, dim3(64 * 11), 0, ctx->stream, S);
@@ -1541,7 +1548,7 @@ int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, d
     static const int narrow_env = [] { const char* e = getenv("PA_NARROW"); return e ? atoi(e) : 1; }();
     std::vector<SweepGroup> keep;
     for (const SweepGroup& g : rest) ((g.dims[0] <= 32 && narrow_env) ? nar : keep).push_back(g);
-    if (batch_env && !knobs && fused_order() == 2 && nar.size() >= 2 && (int)nar.size() <= PA_MAXB) rest.swap(keep);
+    if (batch_env && !knobs && fused_order() == 2 && (nar.size() >= 2 || (nslots > 1 && nar.size() == 1)) && (int)nar.size() <= PA_MAXB) rest.swap(keep);
     else nar.clear();
   }
   if (!nar.empty()) {
@@ -1552,9 +1559,10 @@ int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, d
     for (size_t q = 0; q < nar.size(); ++q) {
       const int l = nar[q].lev;
       const pa_level* L = phi[l]->lev;
-      if (level_cg(ctx, L, slot + 1)) return 1;
+      if (level_cg(ctx, L, slot + nslots)) return 1;
       S.bp[q] = LevelBP2{L->view, phi[l]->view, out[l]->view};
       S.bp[q].L.cg += slot * cg_stride(L);
+      S.cgs[q] = cg_stride(L);
       MarchArgs A{pcomp, ocomp, fused_kseg(), pmin, 1.0 / (pmax - pmin), clip ? thr : -1.0, 2, 1, 1, 1};
       A.cg = 1;
       A.boxlist = nar[q].list;
@@ -1580,13 +1588,15 @@ int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, d
       S.wg0[q + 1] = S.wg0[q] + tiles * 8u * (((unsigned)nar[q].n + 7u) / 8u);
     }
     ProfScope prof(ctx, PA_TAG_GRADCURV);
-    if (clip) hipLaunchKernelGGL((k_gradcurv_march3n_levels<NRW, true>), dim3(S.wg0[S.n]), dim3(64 * (NRW + 2)), 0, ctx->stream, S);
-    else hipLaunchKernelGGL((k_gradcurv_march3n_levels<NRW, false>), dim3(S.wg0[S.n]), dim3(64 * (NRW + 2)), 0, ctx->stream, S);
+    S.prog = nslots > 1 ? prog : nullptr;
+    if (clip) hipLaunchKernelGGL((k_gradcurv_march3n_levels<NRW, true>), dim3(S.wg0[S.n], (unsigned)nslots), dim3(64 * (NRW + 2)), 0, ctx->stream, S);
+    else hipLaunchKernelGGL((k_gradcurv_march3n_levels<NRW, false>), dim3(S.wg0[S.n], (unsigned)nslots), dim3(64 * (NRW + 2)), 0, ctx->stream, S);
     PA_HIP(hipGetLastError());
     if (lv.empty()) ctx->sweep_kernel = "k_gradcurv_march3n_levels<NRW=8" + std::string(clip ? ",CLIP" : "") + ">[" + std::to_string(S.n) + " levels per launch]";
   }
   for (const SweepGroup& g : rest)
-    if (sweep_group_cg(ctx, g, phi[g.lev], pcomp, pmin, pmax, out[g.lev], ocomp, thr, slot)) return 1;
+    for (int z = 0; z < nslots; ++z)
+      if (sweep_group_cg(ctx, g, phi[g.lev], pcomp + z, nslots > 1 ? pmins[z] : pmin, nslots > 1 ? pmaxs[z] : pmax, out[g.lev], ocomp + 8 * z, thr, slot + z)) return 1;
   if (!lv.empty())
     ctx->sweep_kernel = "k_gradcurv_march3_levels<MTY=" + std::to_string(mty) + (clip ? ",CLIP" : "") + ">[" + std::to_string(lv.size()) + " levels per launch]" +
                         ((rest.empty() && nar.empty()) ? "" : " + narrow-box launch(es)");

@@ -562,15 +562,39 @@ __global__ __launch_bounds__(64 * (PA_MTY + 3), 1) void k_gradcurv_march3(BP bp,
 // workgroups on 256 CUs, each launch ends in a tail of idle CUs, and the next one ramps up again: levels back to back
 // in one grid fill those tails (BASELINE config 5's shape, and every rank's share of a sharded hierarchy).  Level l
 // owns workgroups wg0[l] .. wg0[l+1]-1, each range a multiple of 8 so that the XCD-aware numbering (order 2) is kept.
+// Component slots (blockIdx.y = slot z of a batch of components, pa_gradcurv_run_comps2): phi component + z, outputs + 8 z, the
+// slot's set of compact ghost arrays (cg + z cgs[l]) and its progress range prog[2 z], prog[2 z + 1] (device table, null: one slot).
+// The sweeps of a batch's components are then ONE launch: on small levels (config 5's shape: 4 x 256^3 per component, a rank's
+// share of a sharded hierarchy) a launch per component ended in an idle tail each time.
 struct SweepBatch {
   int n;
   unsigned wg0[PA_MAXB + 1];
   LevelBP2 bp[PA_MAXB];
   MarchArgs A[PA_MAXB];
+  long long cgs[PA_MAXB] = {};
+  const double* prog = nullptr;
 };
+__device__ __forceinline__ void sweep_slot(const SweepBatch& S, int l, LevelBP2& bp, MarchArgs& A) {
+  bp = S.bp[l];
+  A = S.A[l];
+  const int z = (int)blockIdx.y;
+  if (z) {
+    A.pcomp += z;
+    A.ocomp += 8 * z;
+    bp.L.cg += z * S.cgs[l];
+  }
+  if (S.prog) { A.pmin = S.prog[2 * z]; A.invdenom = S.prog[2 * z + 1]; }
+}
 template <int PA_MTY, bool CLIP = false>
 __global__ __launch_bounds__(64 * (PA_MTY + 3), 1) void k_gradcurv_march3_levels(SweepBatch S) {
   int l = 0;
   while (l + 1 < S.n && blockIdx.x >= S.wg0[l + 1]) ++l;
-  gradcurv_march3_body<LevelBP2, PA_MTY, CLIP, false, 0, true>(S.bp[l], S.A[l], blockIdx.x - S.wg0[l], 0u);
+  if (gridDim.y == 1 && !S.prog) {  // one component: the arguments straight from the argument segment
+    gradcurv_march3_body<LevelBP2, PA_MTY, CLIP, false, 0, true>(S.bp[l], S.A[l], blockIdx.x - S.wg0[l], 0u);
+    return;
+  }
+  LevelBP2 bp;
+  MarchArgs A;
+  sweep_slot(S, l, bp, A);
+  gradcurv_march3_body<LevelBP2, PA_MTY, CLIP, false, 0, true>(bp, A, blockIdx.x - S.wg0[l], 0u);
 }

@@ -398,5 +398,12 @@ template <int NRW, bool CLIP = false>
 __global__ __launch_bounds__(64 * (NRW + 2), 1) void k_gradcurv_march3n_levels(SweepBatch S) {
   int l = 0;
   while (l + 1 < S.n && blockIdx.x >= S.wg0[l + 1]) ++l;
-  gradcurv_march3n_body<LevelBP2, NRW, CLIP, true>(S.bp[l], S.A[l], blockIdx.x - S.wg0[l], 0u);
+  if (gridDim.y == 1 && !S.prog) {
+    gradcurv_march3n_body<LevelBP2, NRW, CLIP, true>(S.bp[l], S.A[l], blockIdx.x - S.wg0[l], 0u);
+    return;
+  }
+  LevelBP2 bp;
+  MarchArgs A;
+  sweep_slot(S, l, bp, A);
+  gradcurv_march3n_body<LevelBP2, NRW, CLIP, true>(bp, A, blockIdx.x - S.wg0[l], 0u);
 }

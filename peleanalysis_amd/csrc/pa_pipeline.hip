@@ -17,7 +17,8 @@ int pa_fill_boundary_local_batch(pa_ctx* ctx, int n, pa_mf* const* Ms, int comp,
 int pa_gradcurv_prep_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int comp, const pa_mf* const* crse, int ccomp, const int32_t bc[3], double pmin, double pmax, int phase = 3,
                             int nslots = 1, const double* prog = nullptr);
 int pa_gradcurv_level_cg(pa_ctx* ctx, const pa_mf* phi, int pcomp, double pmin, double pmax, pa_mf* out, int ocomp, double thr = -1.0, int slot = 0);
-int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, double pmin, double pmax, pa_mf* const* out, int ocomp, double thr = -1.0, int slot = 0);
+int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, double pmin, double pmax, pa_mf* const* out, int ocomp, double thr = -1.0, int slot = 0,
+                          int nslots = 1, const double* prog = nullptr, const double* pmins = nullptr, const double* pmaxs = nullptr);
 int pa_gradcurv_fix_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, const pa_mf* const* crse_n, int cncomp0, const int32_t bc[3], double pmin, double pmax,
                            pa_mf* const* out, int ncomp0, int kcomp, double thr = -1.0, int nslots = 1, const double* prog = nullptr, int cn_z = 8,
                            const pa_mf* const* crse_phi = nullptr, int cpcomp = 0);
@@ -670,7 +671,13 @@ extern "C" int pa_gradcurv_run_comps2(pa_ctx* ctx, int nlev, pa_mf* const* state
     // (pageable source: the copy is staged before the call returns, so the host vector may be rewritten for the next batch)
     PA_HIP(hipMemcpyAsync(ctx->d_prog, prog.data(), sizeof(double) * 2 * ns, hipMemcpyHostToDevice, ctx->stream));
     PA_TRY(pa_gradcurv_prep_levels(ctx, nlev, state, g0, crse.data(), dist ? g0 - comp0 : g0, bc, pmins[0], pmaxs[0], 3, ns, ctx->d_prog));
-    for (int z = 0; z < ns; ++z) PA_TRY(pa_gradcurv_levels_cg(ctx, nlev, state, g0 + z, pmins[z], pmaxs[z], out, ocomp + 8 * z, thr, z));
+    {
+      // the sweeps of the batch's components: ONE launch with the slot as a grid dimension (PA_SWEEP_SLOTS=0, read per pass:
+      // a launch per component, rounds 2-3)
+      const char* sse = getenv("PA_SWEEP_SLOTS");
+      if (ns > 1 && (!sse || atoi(sse))) PA_TRY(pa_gradcurv_levels_cg(ctx, nlev, state, g0, pmins[0], pmaxs[0], out, ocomp, thr, 0, ns, ctx->d_prog, pmins.data(), pmaxs.data()));
+      else for (int z = 0; z < ns; ++z) PA_TRY(pa_gradcurv_levels_cg(ctx, nlev, state, g0 + z, pmins[z], pmaxs[z], out, ocomp + 8 * z, thr, z));
+    }
     if (dist) {
       std::vector<XJob> jobs;
       for (int l = 1; l < nlev; ++l) {
