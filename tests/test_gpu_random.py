@@ -81,13 +81,28 @@ def test_random_hierarchy_matches_oracle(ctx, oracle, seed):
         assert_valid_bits_equal(dgr[l].download(), og[l], [(c, c) for c in range(4)], f"{tag} grad_run level {l}")
 
 
-@pytest.mark.parametrize("seed", range(NSEEDS))
+def _draw_any(seed):
+    """seeds 0 .. NSEEDS-1: one rectangular refined region per level (_draw); NSEEDS ..: unions of rectangles (general BoxArrays)"""
+    if seed < NSEEDS:
+        return _draw(seed)
+    from peleanalysis_amd.hierarchy import union_hierarchy
+    H = union_hierarchy(7000 + seed - NSEEDS)
+    rng = np.random.default_rng(9000 + seed)
+    per = tuple(int(x) for x in H.levels[0].is_per)
+    sym = tuple(int(x) for x in np.where(np.asarray(per) == 1, 0, rng.integers(0, 2, size=3)))
+    return H, per, sym, (field_flame if seed % 2 else field_trig)
+
+
+NUNION_TOOLS = int(os.environ.get("PA_RANDOM_UNION_TOOL_SEEDS", "8"))
+
+
+@pytest.mark.parametrize("seed", range(NSEEDS + NUNION_TOOLS))
 def test_random_hierarchy_isosurface_and_filter(ctx, oracle, filter_mode, seed):
     """the same random hierarchies through the level-batched marching cubes (mask evaluated from the finer level, periodic
     images included; 1 or 2 ghost layers) and through the box filter with its ghost fill (conservative-linear or
     piecewise-constant; 27 or 125 taps), against the oracle per FAB"""
     import ctypes as C
-    H, per, sym, fn = _draw(seed)
+    H, per, sym, fn = _draw_any(seed)
     rng = np.random.default_rng(77 + seed)
     ng, nc = int(rng.integers(1, 3)), 5
     fields = make_states(H, 2, 0, fn, seed=seed + 1)
@@ -167,11 +182,11 @@ def test_random_hierarchy_isosurface_and_filter(ctx, oracle, filter_mode, seed):
         dprev = din
 
 
-@pytest.mark.parametrize("seed", range(NSEEDS))
+@pytest.mark.parametrize("seed", range(NSEEDS + NUNION_TOOLS))
 def test_random_hierarchy_curvature_options(ctx, oracle, seed):
-    """the same hierarchies through pa_curvature_run with every option on (Gaussian curvature, strain rate + tensor,
-    flame-normal velocity; curvature.cpp:575-789) against the oracle, all 17 output components bit for bit"""
-    H, per, sym, fn = _draw(seed)
+    """the same hierarchies (and unions of rectangles) through pa_curvature_run with every option on (Gaussian curvature, strain
+    rate + tensor, flame-normal velocity; curvature.cpp:575-789) against the oracle, all 17 output components bit for bit"""
+    H, per, sym, fn = _draw_any(seed)
     thr = None if seed % 2 else 0.04
     states = make_states(H, 4, 2, fn, seed=seed + 5)  # comp 0 = progress source, 1..3 = velocity
     bc = capi.bc_from_flags(per, sym)
