@@ -247,6 +247,11 @@ int pa_box_filter_weights(int fgr, double* w);
 int pa_filter_weights(int type, int fgr, double* w);
 /* filterPlt.cpp:206-219, all boxes of a level */
 int pa_boxfilter_level(pa_ctx*, const pa_mf* in, pa_mf* out, int scomp, int ncomp, int ng, const double* w);
+/* Filter::apply_filter on every level of a hierarchy in one call (the level loop of filterPlt.cpp:206-219): in[l] / out[l] / ngs[l] /
+ * ws[l] as pa_boxfilter_level's arguments for level l.  (PA_FILTER_LEVEL_STREAMS=1: the levels side by side on streams of their
+ * own -- measured slower than one after the other on config 3, so off by default.) */
+int pa_boxfilter_hierarchy(pa_ctx*, int nlev, const pa_mf* const* in, pa_mf* const* out, int scomp, int ncomp, const int32_t* ngs,
+                           const double* const* ws);
 /* the AMREX_SPACEDIM == 2 build of the same call on a level stored as one plane of cells (k = 0):
  * out(i,j,c) = sum_m sum_l (w_l w_m) in(i+l, j+m, c) */
 int pa_boxfilter_level2d(pa_ctx*, const pa_mf* in, pa_mf* out, int scomp, int ncomp, int ng, const double* w);

@@ -137,6 +137,7 @@ def load_library() -> C.CDLL:
         "pa_box_filter_weights": (C.c_int, [C.c_int, pdbl]),
         "pa_filter_weights": (C.c_int, [C.c_int, C.c_int, pdbl]),
         "pa_boxfilter_level": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, pdbl]),
+        "pa_boxfilter_hierarchy": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int, pi32, C.POINTER(pdbl)]),
         "pa_boxfilter_level2d": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, pdbl]),
         "pa_foextrap": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int]),
         "pa_fillpatch_two_levels": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -510,6 +510,47 @@ extern "C" int pa_boxfilter_level(pa_ctx* ctx, const pa_mf* in, pa_mf* out, int 
   return 0;
 }
 
+// Filter::apply_filter on EVERY level of a hierarchy (the level loop of filterPlt.cpp:206-219).  The levels do not depend on each
+// other and a level of a few 10^7 cells does not fill the chip (config 3: 16.8 M cells per level at 0.37-0.49 of HBM), so
+// PA_FILTER_LEVEL_STREAMS=1 (read per call) puts each level's launch on a stream of its own between a fork and a join.  OFF by
+// default: MEASURED slower -- config 3's three levels 0.304 ms side by side against 0.248 ms one after the other (the fork /
+// join events cost more than the tails they fill; profiles/r04_small_experiments.txt).
+extern "C" int pa_boxfilter_hierarchy(pa_ctx* ctx, int nlev, const pa_mf* const* in, pa_mf* const* out, int scomp, int ncomp, const int32_t* ngs,
+                                      const double* const* ws) {
+  PaBind bind_(ctx);
+  if (!ctx || nlev <= 0 || !in || !out || !ngs || !ws) return pa_fail(ctx, "pa_boxfilter_hierarchy: null argument");
+  const char* se = getenv("PA_FILTER_LEVEL_STREAMS");
+  const bool streams = nlev > 1 && se && atoi(se);
+  if (!streams) {
+    for (int l = 0; l < nlev; ++l)
+      if (pa_boxfilter_level(ctx, in[l], out[l], scomp, ncomp, ngs[l], ws[l])) return 1;
+    return 0;
+  }
+  while ((int)ctx->lev_streams.size() < nlev) {
+    hipStream_t st;
+    PA_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    ctx->lev_streams.push_back(st);
+  }
+  while (ctx->sync_evs.size() < 1 + (size_t)nlev) {
+    hipEvent_t e;
+    PA_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    ctx->sync_evs.push_back(e);
+  }
+  hipStream_t keep = ctx->stream;
+  PA_HIP(hipEventRecord(ctx->sync_evs[0], keep));  // after the ghost fills queued so far
+  int rc = 0;
+  for (int l = 0; l < nlev && !rc; ++l) {
+    hipStream_t T = ctx->lev_streams[l];
+    if (hipStreamWaitEvent(T, ctx->sync_evs[0], 0) != hipSuccess) { rc = pa_fail(ctx, "pa_boxfilter_hierarchy: stream wait failed"); break; }
+    ctx->stream = T;
+    rc = pa_boxfilter_level(ctx, in[l], out[l], scomp, ncomp, ngs[l], ws[l]);
+    ctx->stream = keep;
+    if (!rc && (hipEventRecord(ctx->sync_evs[1 + l], T) != hipSuccess || hipStreamWaitEvent(keep, ctx->sync_evs[1 + l], 0) != hipSuccess))
+      rc = pa_fail(ctx, "pa_boxfilter_hierarchy: stream join failed");
+  }
+  return rc;
+}
+
 // 2-D build of Filter::apply_filter: out(i,j,c) = sum_m sum_l (w_l w_m) in(i+l, j+m, c) on a level stored as one plane
 // of cells (the z index is carried along untouched); thread per cell -- 2-D data is small next to the 3-D levels
 template <typename BP>

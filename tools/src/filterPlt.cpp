@@ -130,14 +130,24 @@ int main(int argc, char** argv) {
       const char* fe = getenv("PA_FILTER_EXACT");
       std::cout << "Done!" << std::endl << "Filtering data... (" << ((fe && atoi(fe)) ? "tap order of Filter::apply_filter, bit-identical" : "separable form, within 1e-12 of the tap-order sum; exact_filter=1 for the tap order") << ")" << std::endl;
     }
+#if PA_SPACEDIM == 2
     for (int lev = 0; lev < Nlev; ++lev) {
       if (r == 0) std::cout << "on level " << lev << std::endl;
-#if PA_SPACEDIM == 2
       ctx.check(pa_boxfilter_level2d(ctx.h, din[lev]->h, dout[lev]->h, 0, ncomp, ngs[lev], ws[lev].data()));
-#else
-      ctx.check(pa_boxfilter_level(ctx.h, din[lev]->h, dout[lev]->h, 0, ncomp, ngs[lev], ws[lev].data()));
-#endif
     }
+#else
+    {  // every level in one call: the levels are independent and run side by side (pa_boxfilter_hierarchy)
+      std::vector<const pa_mf*> hin;
+      std::vector<pa_mf*> hout;
+      std::vector<int32_t> hng;
+      std::vector<const double*> hw;
+      for (int lev = 0; lev < Nlev; ++lev) {
+        if (r == 0) std::cout << "on level " << lev << std::endl;
+        hin.push_back(din[lev]->h); hout.push_back(dout[lev]->h); hng.push_back(ngs[lev]); hw.push_back(ws[lev].data());
+      }
+      ctx.check(pa_boxfilter_hierarchy(ctx.h, Nlev, hin.data(), hout.data(), 0, ncomp, hng.data(), hw.data()));
+    }
+#endif
     ctx.check(pa_sync(ctx.h));
     if (pa_bc_errors(ctx.h) != 0) pa::Abort("FillPatchTwoLevels: fine grids are not properly nested in the coarse level");
     if (r == 0) tm.mark("compute");
