@@ -149,6 +149,7 @@ int main(int argc, char** argv) {
   // per rank and level: the fragments of its FABs as they came off the device (ngpus > 1: merged afterwards in BoxArray order)
   struct LevFrag { std::vector<int> gids; std::vector<int64_t> nvb, ntb; std::vector<double> hva; std::vector<int32_t> hta, hka; double* dv = nullptr; int32_t *dk = nullptr, *dt = nullptr; };
   std::vector<std::vector<LevFrag>> frags(team.n, std::vector<LevFrag>(Nlev));
+  std::vector<void*> mc_blocks(team.n, nullptr);  // per rank: the ONE device block that holds the surfaces of all its levels (pa_mc_hierarchy_fine)
   // no per-FAB trimming, no distance function: the node / element sets are built on the device (pa_iso_merge) from the
   // fragments where pa_mc_level_fine left them (ngpus > 1: the other ranks' fragments are first copied to GPU 0); they are
   // only downloaded if the library hands the merge back (PA_ISO_HOST_MERGE=1 forces the host path)
@@ -189,6 +190,51 @@ int main(int argc, char** argv) {
   ctx.check(pa_sync(ctx.h));
   if (pa_bc_errors(ctx.h) != 0) pa::Abort("FillPatchTwoLevels: fine grids are not properly nested in the coarse level");
 
+  // The MFIter loops of isosurface.cpp:1531-1592 for ALL levels in one call: the cell passes and counts of every level back to
+  // back, one read-back of the per-FAB counts, one pooled allocation for the surfaces, no host round trip per level.
+  std::vector<std::vector<pa_box>> loops_all(Nlev);
+  std::vector<std::vector<int64_t>> nvb_all(Nlev), ntb_all(Nlev);
+  std::vector<double*> dv_all(Nlev, nullptr);
+  std::vector<int32_t*> dk_all(Nlev, nullptr), dt_all(Nlev, nullptr);
+  {
+    tq = now();
+    std::vector<const pa_mf*> sts(Nlev);
+    std::vector<int32_t> fmask(Nlev, 0);
+    std::vector<const pa_box*> lp(Nlev);
+    std::vector<int64_t*> pnv(Nlev), pnt(Nlev);
+    int ratio = 2;
+    for (int lev = 0; lev < Nlev; ++lev) {
+      const int ng = nGrow[lev];
+      const std::vector<pa::Box3>& bxs = shares[lev].boxes;
+      const pa::Box3& dom = H.lev[lev].domain;
+      // fine-covered mask (isosurface.cpp:1540-1563; all 1 when building the distance function, :1542)
+      fmask[lev] = (lev < finestLevel && !build_distance_function) ? 1 : 0;
+      if (fmask[lev]) ratio = H.ref_ratio[lev];
+      loops_all[lev].resize(std::max<size_t>(bxs.size(), 1));
+      for (size_t b = 0; b < bxs.size(); ++b)  // base points: (grown box & domain grown in the periodic directions), high side - 1 (isosurface.cpp:1566-1569)
+        for (int d = 0; d < 3; ++d) {
+          const int pg = is_per[d] ? ng : 0;  // growPeriodicDomain (isosurface.cpp:1437)
+          loops_all[lev][b].lo[d] = std::max(bxs[b].lo[d] - ng, dom.lo[d] - pg);
+          loops_all[lev][b].hi[d] = std::min(bxs[b].hi[d] + ng, dom.hi[d] + pg) - 1;
+        }
+      nvb_all[lev].assign(std::max<size_t>(bxs.size(), 1), 0);
+      ntb_all[lev].assign(std::max<size_t>(bxs.size(), 1), 0);
+      sts[lev] = dst[lev]->h; lp[lev] = loops_all[lev].data(); pnv[lev] = nvb_all[lev].data(); pnt[lev] = ntb_all[lev].data();
+    }
+    bool uniform = true;  // one ratio argument: levels with different ratios fall back to a call per level
+    for (int lev = 0; lev + 1 < Nlev; ++lev) uniform = uniform && (!fmask[lev] || H.ref_ratio[lev] == ratio);
+    if (uniform) {
+      ctx.check(pa_mc_hierarchy_fine(ctx.h, Nlev, sts.data(), fmask.data(), ratio, lp.data(), 3 + isoComp, isoVal, pnv.data(), pnt.data(), dv_all.data(), dk_all.data(),
+                                     dt_all.data(), &mc_blocks[r]));
+    } else {
+      for (int lev = 0; lev < Nlev; ++lev)
+        if (!shares[lev].boxes.empty())
+          ctx.check(pa_mc_level_fine(ctx.h, dst[lev]->h, fmask[lev] ? dl[lev + 1]->h : nullptr, fmask[lev] ? H.ref_ratio[lev] : 2, lp[lev], 3 + isoComp, isoVal, pnv[lev], pnt[lev],
+                                     &dv_all[lev], &dk_all[lev], &dt_all[lev]));
+    }
+    ctx.check(pa_sync(ctx.h));
+    if (lead) t_mc += now() - tq;
+  }
   for (int lev = 0; lev < Nlev; ++lev) {
     const int ng = nGrow[lev];
     struct { const std::vector<pa::Box3>& boxes; const pa::Box3& domain; } L{shares[lev].boxes, H.lev[lev].domain};  // this rank's FABs
@@ -215,27 +261,11 @@ int main(int argc, char** argv) {
     }
     pa::HostMF& hd = team.n > 1 ? hd_loc : (build_distance_function ? hdist[lev] : hd_loc);
     pa::HostMF& hsrc = team.n > 1 ? hloc[lev] : host[lev];  // the plotfile components of this rank's FABs
-    // fine-covered mask (isosurface.cpp:1540-1563; all 1 when building the distance function, :1542) and the whole
-    // MFIter loop of :1531-1592 as one batch per level
-    const bool fine_mask = lev < finestLevel && !build_distance_function;
+    // (marching cubes of every level ran above: pa_mc_hierarchy_fine)
     const size_t nb = L.boxes.size();
-    std::vector<pa_box> loops(nb);
-    for (size_t b = 0; b < nb; ++b) {  // base points: (grown box & domain grown in the periodic directions), high side - 1 (isosurface.cpp:1566-1569)
-      const pa::Box3& B = L.boxes[b];
-      for (int d = 0; d < 3; ++d) {
-        const int pg = is_per[d] ? ng : 0;  // growPeriodicDomain (isosurface.cpp:1437)
-        loops[b].lo[d] = std::max(B.lo[d] - ng, L.domain.lo[d] - pg);
-        loops[b].hi[d] = std::min(B.hi[d] + ng, L.domain.hi[d] + pg) - 1;
-      }
-    }
-    std::vector<int64_t> nvb(nb, 0), ntb(nb, 0);
-    double* dv = nullptr;
-    int32_t *dk = nullptr, *dt = nullptr;
-    tq = now();
-    if (nb > 0)  // a rank may own no FAB of a level
-      ctx.check(pa_mc_level_fine(ctx.h, dst[lev]->h, fine_mask ? dl[lev + 1]->h : nullptr, fine_mask ? H.ref_ratio[lev] : 2, loops.data(), 3 + isoComp, isoVal, nvb.data(), ntb.data(), &dv, &dk,
-                                 &dt));
-    if (lead) t_mc += now() - tq;
+    std::vector<int64_t> nvb(nvb_all[lev].begin(), nvb_all[lev].begin() + nb), ntb(ntb_all[lev].begin(), ntb_all[lev].begin() + nb);
+    double* dv = dv_all[lev];
+    int32_t *dk = dk_all[lev], *dt = dt_all[lev];
     tq = now();
     int64_t nvt = 0, ntt = 0;
     for (size_t b = 0; b < nb; ++b) { nvt += nvb[b]; ntt += ntb[b]; }
@@ -291,8 +321,7 @@ int main(int argc, char** argv) {
       if (team.n == 1) merge_box(B, ng, nv, nt, hva.data() + vo * nc, hka.data() + vo * 6, hta.data() + to * 3);
     }
     if (lead) t_merge += now() - tq;
-    // dv, dk, dt are one allocation (base dv); the distance function still reads the triangles
-    if (build_distance_function) grid_bufs.push_back(dv); else pa_device_free(ctx.h, dv);
+    // (dv, dk, dt live in the rank's pooled block -- or, levels of different ratios, in a block per level -- freed after the loop / the merge)
     if (build_distance_function) {
       ctx.check(pa_sdf_level_set3(ctx.h, (int)grids.size(), grids.data(), 1));
       double* dbase = pa_mf_data(ddist->h);
@@ -318,6 +347,13 @@ int main(int argc, char** argv) {
       }
       if (team.n > 1) shares[lev].scatter(hd_loc, hdist[lev]);  // disjoint FABs: every rank writes its own
     }
+  }
+  if (!dev_merge) {  // the surfaces are on the host now
+    if (mc_blocks[r]) pa_device_free(ctx.h, mc_blocks[r]);
+    else
+      for (int lev = 0; lev < Nlev; ++lev) pa_device_free(ctx.h, dv_all[lev]);
+    mc_blocks[r] = nullptr;
+    for (int lev = 0; lev < Nlev; ++lev) frags[r][lev].dv = nullptr;
   }
   });
   if (team.n > 1 && !dev_merge) {  // BoxArray order = the 1-rank ordering (isosurface.cpp:1531: MFIter over the level's FABs)
@@ -408,8 +444,11 @@ int main(int argc, char** argv) {
       pa::Abort(pa_last_error(ctx.h));
     }
     for (void* c : copies) pa_device_free(ctx.h, c);
-    for (int r = 0; r < team.n; ++r)
-      for (int lev = 0; lev < Nlev; ++lev) pa_device_free(team.ctx[r]->h, frags[r][lev].dv);
+    for (int r = 0; r < team.n; ++r) {
+      if (mc_blocks[r]) pa_device_free(team.ctx[r]->h, mc_blocks[r]);
+      else
+        for (int lev = 0; lev < Nlev; ++lev) pa_device_free(team.ctx[r]->h, frags[r][lev].dv);  // (a block per level: levels of different ratios)
+    }
     t_merge += now() - tq;
   }
   if (build_distance_function) {  // isosurface.cpp:1731-1748
