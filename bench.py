@@ -289,13 +289,24 @@ def secondary(ctx, torch, stream, dev, only=None):
         ms = timed(lambda: capi.gradcurv_run(ctx, st, 0, bci, pari, wk, ou, 0))
         assert ctx.bc_errors() == 0
         kn = ctx.lib.pa_sweep_kernel_name(ctx.h).decode()
+        # the two independent kernel sets on the same irregular hierarchy, bit for bit on the device: the exact-normal pipeline with
+        # its irregular-cell list against the pass-by-pass kernels (each parity-tested against the oracle at small sizes)
+        capi.gradcurv_run(ctx, st, 0, bci, pari, wk, ou, 0)
+        ctx.sync()
+        keep_f = [k.clone() for k in keep[2::3]]  # the output multifabs of the three levels
         ms_pp = timed(lambda: capi.gradcurv_run(ctx, st, 0, bci, capi.curv_params(prog_min=300.0, prog_max=2003.0, threshold=None, fused=False), wk, ou, 0), reps=1)
+        ctx.sync()
+        ndiff = 0
+        for a, b_ in zip(keep_f, keep[2::3]):
+            ndiff += int((a.view(torch.int64) != b_.view(torch.int64)).sum().item())
+        del keep_f
         ci = sum(lv.ncells for lv in Hi.levels)
         widths = [np.bincount(((lv.boxes[:, 3] - lv.boxes[:, 0] + 1) // 32).astype(int), minlength=5)[1:5].tolist() for lv in Hi.levels]
         out["irregular_amr"] = entry(ms, ci, 72, boxes_per_level=[lv.nboxes for lv in Hi.levels], cells_per_level=[lv.ncells for lv in Hi.levels],
                                      boxes_32_64_96_128_wide_per_level=widths, irregular_cells_per_level=nirr, irregular_cell_share=sum(nirr) / ci,
                                      share_of_boxes_on_fused_pipeline=1.0 if ("CG=1" in kn or "march3_levels" in kn) else 0.0, sweep_kernel=kn,
                                      pass_by_pass_ms=ms_pp, pass_by_pass_frac_hbm=ci * 72 / (ms_pp * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                     fused_vs_pass_by_pass_values_differing=ndiff,
                                      workload="fused grad->curvature, 3-level AMR, base 512^3, levels 1-2 = the blocks of 32 fine cells with the largest |grad T| (8 % / 16 % of "
                                               "the coarser level's blocks: the wrinkled flame sheet), boxes of 32..128 cells per side, 1 comp, periodic x/y + wall z; "
                                               "pass_by_pass_ms = the same hierarchy with fused=0 (the pre-round-4 path for such BoxArrays)")

@@ -131,3 +131,48 @@ def test_box_filter_128_boxes_matches_oracle(ctx, oracle, filter_mode, fgr):
     ctx.check(ctx.lib.pa_boxfilter_level(ctx.h, din.h, dout.h, 0, 1, ngf, w))
     ctx.sync()
     assert_filter_parity(dout.download(), oout, [(0, 0)], f"128^3 boxes fgr {fgr}", filter_mode)
+
+
+def test_gradcurv_tagged_irregular_hierarchy_matches_oracle(ctx, oracle):
+    """an irregular hierarchy built the way the bench's `irregular_amr` is (levels 1-2 = the blocks with the largest |grad T|,
+    greedy boxes of 1-4 blocks per side: L-shaped regions, mixed faces, concave corners, boxes of 16..64 cells next to each other,
+    wide and narrow sweep groups on one level) at a size the OpenMP oracle does in seconds: every output of every cell bit for
+    bit, with the threshold clip, fused and pass by pass"""
+    _omp()
+    from peleanalysis_amd.hierarchy import tagged_hierarchy
+    H = tagged_hierarchy(128, 3, lambda x, y, z: field_flame(x, y, z, 0), bf=8, max_box=64, base_box=64, frac=(0.10, 0.18), is_per=(1, 1, 0))
+    assert H.nlev == 3
+    widths = [set(int(w) for w in (lv.boxes[:, 3] - lv.boxes[:, 0] + 1)) for lv in H.levels]
+    assert any(w <= 32 for w in widths[2]) and any(w > 32 for w in widths[2])  # both sweep groups on the finest level
+    bc = capi.bc_from_flags((1, 1, 0))
+    rng = np.random.default_rng(8)
+    states = []
+    for lv in H.levels:
+        s = MultiFab(lv, 1, 2)
+        fill_analytic(s, 0, lambda x, y, z: field_flame(x, y, z, 0))
+        for b in range(lv.nboxes):
+            v = s.valid(b)
+            v += 1e-3 * rng.uniform(-1, 1, size=v.shape)
+        states.append(s)
+    thr = 0.04
+    og = [MultiFab(lv, 4, 0) for lv in H.levels]
+    oc = [MultiFab(lv, 5, 0) for lv in H.levels]
+    oracle.grad_pipeline(H.levels, [s.copy() for s in states], 0, bc, og, 0, multipass=False, omp=True)
+    oracle.curvature_pipeline(H.levels, [s.copy() for s in states], 0, bc, oc, 0, MultiFab, prog_min=300.0, prog_max=2000.0, threshold=thr, omp=True)
+    dls = [capi.DevLevel(ctx, lv) for lv in H.levels]
+    nirr = [int(ctx.lib.pa_level_irregular_cells(ctx.h, dl.h)) for dl in dls]
+    assert nirr[0] == 0 and nirr[1] > 0 and nirr[2] > 0, nirr
+    dst = [capi.DevMF.from_host(ctx, dl, s) for dl, s in zip(dls, states)]
+    work = [capi.DevMF(ctx, dl, 1, 2) for dl in dls]
+    for fused in (True, False):
+        dout = [capi.DevMF(ctx, dl, 8, 0) for dl in dls]
+        capi.gradcurv_run(ctx, dst, 0, bc, capi.curv_params(prog_min=300.0, prog_max=2000.0, threshold=thr, fused=fused), work, dout, 0)
+        ctx.sync()
+        assert ctx.bc_errors() == 0
+        if fused:
+            kn = ctx.lib.pa_sweep_kernel_name(ctx.h).decode()
+            assert "_levels<" in kn or "CG=1" in kn, kn  # the exact-normal pipeline (wide + narrow sweep groups), not the pass-by-pass fallback
+        for l in range(H.nlev):
+            got = dout[l].download()
+            assert_valid_bits_equal(got, og[l], [(c, c) for c in range(4)], f"tagged irregular fused {fused} grad level {l}")
+            assert_valid_bits_equal(got, oc[l], [(4, 2), (5, 3), (6, 4), (7, 1)], f"tagged irregular fused {fused} curv level {l} ({nirr} irregular cells)")
