@@ -76,6 +76,20 @@ struct RepPlan {
 };
 RepPlan* pa_rep_plan(pa_ctx* ctx, const pa_level* L);
 
+// Restriction of a sharded fine level onto its sharded coarse level (the distributed smoothing solve, pa_smooth.hip; what
+// amrex::average_down and the MLMG flux register move between ranks): `cf` is the fine BoxArray coarsened by the ratio with
+// the FINE level's owners, so a rank restricts its own fine boxes without communication; `down` then copies cf's valid cells
+// into the coarse level's valid cells (the coarse owner may be another rank), and flux[2 * dir + side] copies the one-cell
+// ghost slab behind every special face (dir, side) of cf's boxes -- where the fine rank leaves the average fine flux of each
+// coarse face -- onto the coarse cells next to the fine level, through the periodic images of the coarse domain.
+struct RsPlan {
+  pa_level* cf = nullptr;
+  XPlan down;
+  XPlan flux[6];
+  ~RsPlan();
+};
+RsPlan* pa_rs_plan(pa_ctx* ctx, const pa_level* F, const pa_level* C, int ratio);
+
 // group > 0: the ncomp components are groups of `group` consecutive ones, group g starting at scomp + g * sgstride in src and at
 // dcomp + g * dgstride in dst (the normals of several component slots: 3 of every 8 output components)
 struct XJob { XPlan* plan; const pa_mf* src; int scomp; pa_mf* dst; int dcomp; int ncomp; int group = 0, sgstride = 0, dgstride = 0; };

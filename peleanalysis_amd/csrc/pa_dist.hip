@@ -608,6 +608,117 @@ RepPlan* pa_rep_plan(pa_ctx* ctx, const pa_level* L) {
   return L->rep_plan.get();
 }
 
+// ------------------------------------------------------------------ restriction onto a sharded coarse level
+RsPlan::~RsPlan() {
+  if (cf) pa_level_destroy(cf);
+}
+// global boxes of `G`'s BoxArray that may intersect Q, ascending (from the owner grid; all boxes when Q spans too much of it)
+static void boxes_near(const HostGeom& G, int nboxes, const DBox& Q, std::vector<int>& out) {
+  out.clear();
+  int c0[3], c1[3];
+  long long cells = 1;
+  for (int d = 0; d < 3; ++d) {
+    const int lo = std::max(Q.lo[d], G.mlo[d]), hi = std::min(Q.hi[d], G.mlo[d] + G.mn[d] * G.g - 1);
+    if (lo > hi) return;
+    c0[d] = (lo - G.mlo[d]) / G.g; c1[d] = (hi - G.mlo[d]) / G.g;
+    cells *= c1[d] - c0[d] + 1;
+  }
+  if (cells > 4096) {
+    for (int b = 0; b < nboxes; ++b) out.push_back(b);
+    return;
+  }
+  for (int kz = c0[2]; kz <= c1[2]; ++kz)
+    for (int ky = c0[1]; ky <= c1[1]; ++ky)
+      for (int kx = c0[0]; kx <= c1[0]; ++kx) {
+        const int o = G.owner[((size_t)kz * G.mn[1] + ky) * G.mn[0] + kx];
+        if (o >= 0) out.push_back(o);
+      }
+  std::sort(out.begin(), out.end());
+  out.erase(std::unique(out.begin(), out.end()), out.end());
+}
+static int xplan_locals(pa_ctx* ctx, XPlan& X, const std::vector<int32_t>& lsrc, const std::vector<int32_t>& ldst) {
+  X.nlocal = (int)(lsrc.size() / 7);
+  if (!X.nlocal) return 0;
+  PA_HIP(hipMalloc(&X.d_lsrc, sizeof(int) * lsrc.size()));
+  PA_HIP(hipMalloc(&X.d_ldst, sizeof(int) * ldst.size()));
+  PA_HIP(hipMemcpy(X.d_lsrc, lsrc.data(), sizeof(int) * lsrc.size(), hipMemcpyHostToDevice));
+  PA_HIP(hipMemcpy(X.d_ldst, ldst.data(), sizeof(int) * ldst.size(), hipMemcpyHostToDevice));
+  return 0;
+}
+RsPlan* pa_rs_plan(pa_ctx* ctx, const pa_level* F, const pa_level* C, int ratio) {
+  auto it = F->rs_plans.find(C->serial);
+  if (it != F->rs_plans.end()) return it->second.get();
+  if (F->nranks <= 1 || F->gboxes.empty() || C->gboxes.empty()) { pa_fail(ctx, "pa_rs_plan: the levels are not sharded"); return nullptr; }
+  if (F->nranks != C->nranks || F->rank != C->rank) { pa_fail(ctx, "coarse and fine level are sharded over different rank sets"); return nullptr; }
+  const int r3[3] = {ratio, ratio, F->domlo[2] == F->domhi[2] ? 1 : ratio};  // a 2-D hierarchy is one plane of cells per level
+  auto fdiv = [](int a, int r) { return a >= 0 ? a / r : -((-a + r - 1) / r); };
+  auto crs = [&](const DBox& B) {
+    DBox c;
+    for (int d = 0; d < 3; ++d) { c.lo[d] = fdiv(B.lo[d], r3[d]); c.hi[d] = fdiv(B.hi[d], r3[d]); }
+    return c;
+  };
+  std::unique_ptr<RsPlan> P(new RsPlan());
+  LevelSpec S;
+  S.source_only = true;
+  S.rank = F->rank; S.nranks = F->nranks;
+  S.gid = F->gid; S.gowner = F->gowner;
+  for (const DBox& B : F->boxes) S.local.push_back(crs(B));
+  for (const DBox& B : F->gboxes) S.gboxes.push_back(crs(B));
+  P->cf = pa_level_create_spec(ctx, S, C->domlo, C->domhi, C->is_per, C->prob_lo, C->prob_hi);
+  if (!P->cf) return nullptr;
+  const HostGeom CG(C->gboxes, C->domlo, C->domhi, C->is_per);
+  const int nF = (int)F->gboxes.size(), nC = (int)C->gboxes.size(), me = F->rank;
+  const auto shifts = domain_shifts(C->domlo, C->domhi, C->is_per);
+  std::vector<int> cand;
+  // one plan from a list of (fine global box, source region in cf's index space, shift): destination region = source - shift
+  auto build = [&](XPlan& X, auto&& each_source) -> int {
+    std::vector<std::pair<int, std::array<int32_t, 7>>> s, r;
+    std::vector<int32_t> lsrc, ldst;
+    each_source([&](int gf, const DBox& Q, const std::array<int, 3>& sh) {
+      const int neg[3] = {-sh[0], -sh[1], -sh[2]};
+      const DBox Qc = bx_shift(Q, neg);  // in the coarse level's index space
+      boxes_near(CG, nC, Qc, cand);
+      for (int gc : cand) {
+        DBox I;
+        if (!bx_isect(Qc, C->gboxes[gc], I)) continue;
+        const int pos[3] = {sh[0], sh[1], sh[2]};
+        const DBox Is = bx_shift(I, pos);
+        const int fo = F->gowner[gf], co = C->gowner[gc];
+        if (fo == me && co == me) {
+          const auto a = reg7(F->glocal[gf], Is), b = reg7(C->glocal[gc], I);
+          lsrc.insert(lsrc.end(), a.begin(), a.end());
+          ldst.insert(ldst.end(), b.begin(), b.end());
+          X.lmax = std::max(X.lmax, bx_cells(I));
+        } else if (fo == me) {
+          s.push_back({co, reg7(F->glocal[gf], Is)});
+        } else if (co == me) {
+          r.push_back({fo, reg7(C->glocal[gc], I)});
+        }
+      }
+    });
+    if (side_finish(ctx, X.send, s) || side_finish(ctx, X.recv, r)) return 1;
+    return xplan_locals(ctx, X, lsrc, ldst);
+  };
+  const std::array<int, 3> zero = {0, 0, 0};
+  if (build(P->down, [&](auto&& emit) {
+        for (int gf = 0; gf < nF; ++gf) emit(gf, S.gboxes[gf], zero);  // fine boxes lie inside the domain: no periodic image
+      })) return nullptr;
+  for (int o = 0; o < 6; ++o) {
+    const int dir = o >> 1, side = o & 1;
+    if (build(P->flux[o], [&](auto&& emit) {
+          for (int gf = 0; gf < nF; ++gf) {
+            if (!pa_face_is_special(F, F->gboxes[gf], dir, side)) continue;
+            DBox Q = S.gboxes[gf];
+            Q.lo[dir] = Q.hi[dir] = side ? Q.hi[dir] + 1 : Q.lo[dir] - 1;
+            for (const auto& sh : shifts) emit(gf, Q, sh);
+          }
+        })) return nullptr;
+  }
+  RsPlan* raw = P.get();
+  F->rs_plans[C->serial] = std::move(P);
+  return raw;
+}
+
 CsPlan* pa_cs_plan(pa_ctx* ctx, const pa_level* F, const pa_level* C, int mode, int ng, int halo, int ratio) {
   if (mode == 0 && ratio != 2) { pa_fail(ctx, "coarse-source plan of the MLMG boundary: refinement ratio 2 only"); return nullptr; }
   const auto key = std::make_pair(C->serial, mode == 0 ? 0 : 1 + ng * 16 + halo + 4096 * ratio);
@@ -761,7 +872,7 @@ int pa_xexchange(pa_ctx* ctx, int njobs, const XJob* jobs) {
     // a plan owns ONE pair of packed buffers: two jobs of one call on the same plan would pack over each other
     for (int p = 0; p < q; ++p)
       if (jobs[p].plan == J.plan) return pa_fail(ctx, "ghost exchange: the same plan appears twice in one exchange (one packed buffer per plan)");
-    if (J.ncomp < 1 || J.scomp < 0 || J.scomp + J.ncomp > J.src->ncomp || J.dcomp < 0 || (J.dst && J.dcomp + J.ncomp > J.dst->ncomp))
+    if (J.ncomp < 1 || J.scomp < 0 || !J.src || J.scomp + J.ncomp > J.src->ncomp || J.dcomp < 0 || (J.dst && J.dcomp + J.ncomp > J.dst->ncomp))
       return pa_fail(ctx, "ghost exchange: component range");
     PA_TRY(ensure_buf(ctx, P.sbuf, P.scap, P.send.coff.back() * J.ncomp));
     PA_TRY(ensure_buf(ctx, P.rbuf, P.rcap, P.recv.coff.back() * J.ncomp));

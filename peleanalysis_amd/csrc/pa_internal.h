@@ -182,6 +182,7 @@ struct pa_level {
   mutable std::map<int, std::unique_ptr<struct FbLocal>> fb_local;                     // local FillBoundary as copy regions, by ghost width (pa_dist.hip)
   mutable std::map<std::pair<long long, int>, std::unique_ptr<struct CsPlan>> cs_plans; // coarse-source plans by (coarse level serial, mode)
   mutable std::unique_ptr<struct RepPlan> rep_plan;                                     // the level replicated on every rank (pa_dist.hip)
+  mutable std::map<long long, std::unique_ptr<struct RsPlan>> rs_plans;                 // restriction onto a sharded coarse level, by coarse level serial (pa_dist.hip)
   mutable std::map<std::pair<long long, int>, std::unique_ptr<struct FpPlan>> fp_plans; // FillPatchTwoLevels parent lists by (coarse level serial, ghost width) (pa_filter.hip)
   ~pa_level();
 };

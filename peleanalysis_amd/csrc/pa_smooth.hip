@@ -16,6 +16,8 @@
 #include <vector>
 
 int pa_ensure_red(pa_ctx* ctx, size_t n);
+int pa_fill_boundary_impl(pa_ctx* ctx, pa_mf* M, int comp, int ncomp, int ng, int no_exchange);
+int pa_apply_bc_impl(pa_ctx* ctx, pa_mf* F, int comp, const pa_mf* C, int ccomp, const int32_t bc[3], int ratio, int only_dir, int edges, const double* crse_xform);
 
 struct BoxIt {  // thread -> cell of box blockIdx.y (grid-stride over the box's valid cells)
   DBox B;
@@ -148,6 +150,106 @@ __global__ __launch_bounds__(256) void k_smooth_zero_covered(DLevelView L, DMFVi
   }
 }
 
+// ---- the same operator on a hierarchy SHARDED over ranks: the fine rank restricts its own boxes into the coarsened level
+// (pa_dist.h: RsPlan), an exchange moves the result to the coarse owners
+__global__ __launch_bounds__(256) void k_smooth_avgdown_cf(DLevelView LF, DMFView F, DLevelView LCF, DMFView CF, int ratio) {
+  const int b = blockIdx.y;
+  const DBox B = LF.boxes[b];
+  const int rz = rdir(LF, 2, ratio);
+  const int cx = (B.hi[0] - B.lo[0] + 1) / ratio, cy = (B.hi[1] - B.lo[1] + 1) / ratio, cz = (B.hi[2] - B.lo[2] + 1) / rz;
+  const long long n = (long long)cx * cy * cz;
+  const double fac = 1.0 / (double)(ratio * ratio * rz);
+  const double* f = F.data + F.off[b];
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+    const unsigned u = (unsigned)t, r = u / (unsigned)cx;
+    const int ic = coarsen_idx(B.lo[0], ratio) + (int)(u - r * cx), jc = coarsen_idx(B.lo[1], ratio) + (int)(r % cy), kc = coarsen_idx(B.lo[2], rz) + (int)(r / cy);
+    double c = 0.0;
+    for (int kk = 0; kk < rz; ++kk)
+      for (int jj = 0; jj < ratio; ++jj)
+        for (int ii = 0; ii < ratio; ++ii) c += f[fab_index(B, F.ng, F.ncomp, 0, ic * ratio + ii, jc * ratio + jj, kc * rz + kk)];
+    CF.data[CF.off[b] + fab_index(LCF.boxes[b], CF.ng, CF.ncomp, 0, ic, jc, kc)] = c * fac;
+  }
+}
+
+// flux register, fine side: thread per coarse face of a special fine face; the average fine flux across it (0 where the face
+// is not coarse-fine) goes to the ghost cell of the coarsened box behind that face.  mask_mode: 1.0 on coarse-fine faces instead.
+__global__ __launch_bounds__(256) void k_smooth_fluxreg(DLevelView LF, DMFView XF, DLevelView LCF, DMFView CF, int ratio, int mask_mode) {
+  const int e = LF.sfaces[blockIdx.y];
+  const int b = e / 6, dir = (e % 6) >> 1, side = e & 1;
+  const DBox B = LF.boxes[b];
+  const int t0 = (dir == 0) ? 1 : 0, t1 = (dir == 2) ? 1 : 2;
+  const int n0 = B.hi[t0] - B.lo[t0] + 1, n1 = B.hi[t1] - B.lo[t1] + 1;
+  const int r0 = rdir(LF, t0, ratio), r1 = rdir(LF, t1, ratio), rn = rdir(LF, dir, ratio);
+  const unsigned c0 = n0 / r0, c1 = n1 / r1;
+  const long long tt = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (tt >= (long long)c0 * c1) return;
+  const unsigned u = (unsigned)tt, r = u / c0;
+  const int a0 = (int)(u - r * c0), b1 = (int)r;
+  const bool cf = (LF.sfcode[LF.sfoff[blockIdx.y] + (long long)(a0 * r0) + (long long)n0 * (b1 * r1)] & 3u) == 1u;
+  const int gq = side ? B.hi[dir] + 1 : B.lo[dir] - 1, inq = side ? B.hi[dir] : B.lo[dir];
+  int oc[3];
+  oc[dir] = coarsen_idx(gq, rn);
+  oc[t0] = coarsen_idx(B.lo[t0], r0) + a0;
+  oc[t1] = coarsen_idx(B.lo[t1], r1) + b1;
+  double favg = 0.0;
+  if (cf && mask_mode) favg = 1.0;
+  if (cf && !mask_mode) {
+    const double* xf = XF.data + XF.off[b];
+    const double dxf = LF.dxinv[dir];
+    for (int v = 0; v < r1; ++v)
+      for (int uu = 0; uu < r0; ++uu) {
+        int g[3], in[3];
+        g[dir] = gq; in[dir] = inq;
+        g[t0] = in[t0] = B.lo[t0] + a0 * r0 + uu;
+        g[t1] = in[t1] = B.lo[t1] + b1 * r1 + v;
+        const double xg = xf[fab_index(B, XF.ng, XF.ncomp, 0, g[0], g[1], g[2])], xi = xf[fab_index(B, XF.ng, XF.ncomp, 0, in[0], in[1], in[2])];
+        favg += side ? dxf * (xg - xi) : dxf * (xi - xg);
+      }
+    favg *= 1.0 / (double)(r0 * r1);
+  }
+  CF.data[CF.off[b] + fab_index(LCF.boxes[b], CF.ng, CF.ncomp, 0, oc[0], oc[1], oc[2])] = favg;
+}
+
+// the six 0/1 components of the received mask register -> one bit set per coarse cell, kept in component 0
+__global__ __launch_bounds__(256) void k_smooth_fluxmask(DLevelView L, DMFView FM) {
+  PA_BOX_LOOP(L) {
+    int i, j, k;
+    it.cell(t, i, j, k);
+    int m = 0;
+    for (int o = 0; o < 6; ++o)
+      if (FM.data[FM.off[b] + fab_index(it.B, FM.ng, FM.ncomp, o, i, j, k)] != 0.0) m |= 1 << o;
+    FM.data[FM.off[b] + fab_index(it.B, FM.ng, FM.ncomp, 0, i, j, k)] = (double)m;
+  }
+}
+
+// flux register, coarse side: the coarse flux the 7-point apply used across a coarse-fine face is replaced by the average fine
+// flux (component 2 * dir + side of FR: the fine box lies on the low side of the cell for side = 1); fixed order, no atomics
+__global__ __launch_bounds__(256) void k_smooth_reflux_apply(DLevelView L, DMFView X, DMFView Y, DMFView FR, DMFView FM, double dt) {
+  PA_BOX_LOOP(L) {
+    int i, j, k;
+    it.cell(t, i, j, k);
+    const int m = (int)FM.data[FM.off[b] + fab_index(it.B, FM.ng, FM.ncomp, 0, i, j, k)];
+    if (!m) continue;
+    const double* x = X.data + X.off[b];
+    const long long nxg = it.nx + 2 * X.ng, nyg = it.ny + 2 * X.ng;
+    const long long q = fab_index(it.B, X.ng, X.ncomp, 0, i, j, k);
+    const long long st[3] = {1, nxg, nxg * nyg};
+    const double xo = x[q];
+    double y = Y.data[Y.off[b] + fab_index(it.B, Y.ng, Y.ncomp, 0, i, j, k)];
+    for (int o = 0; o < 6; ++o) {
+      if (!((m >> o) & 1)) continue;
+      const int dir = o >> 1, side = o & 1;
+      const double favg = FR.data[FR.off[b] + fab_index(it.B, FR.ng, FR.ncomp, o, i, j, k)];
+      const double xin = x[q + (side ? -st[dir] : st[dir])];
+      const double dxc = L.dxinv[dir];
+      const double fc = side ? dxc * (xo - xin) : dxc * (xin - xo);
+      const double corr = dt * (dxc * (favg - fc));
+      y += side ? corr : -corr;
+    }
+    Y.data[Y.off[b] + fab_index(it.B, Y.ng, Y.ncomp, 0, i, j, k)] = y;
+  }
+}
+
 // z = a x + bc y + c z on valid cells (x, y may be null)
 __global__ __launch_bounds__(256) void k_smooth_axpbypcz(DLevelView L, double a, DMFView X, int hx, double bc, DMFView Y, int hy, double c, DMFView Z) {
   PA_BOX_LOOP(L) {
@@ -220,6 +322,51 @@ struct SmoothSolver {
   int32_t bc[3];
   std::vector<const pa_level*> lev;
   Vecs r, rh, p, v, s, t, mask;
+  // sharded hierarchy (dist): rs[l] restricts level l onto level l - 1; cfw[l] lives on rs[l]->cf (valid cells: child averages,
+  // face ghosts: fine fluxes); fr[l] / fm[l] on level l: the received fluxes of level l + 1 (6 components) and where they apply
+  bool dist = false;
+  std::vector<RsPlan*> rs;
+  Vecs cfw, fr, fm;
+  long long nallreduce = 0, nexchange = 0;
+
+  template <class K, class... A>
+  void on_boxes(K kern, const pa_level* L, dim3 g, A... a) {  // a rank may own no box of a level
+    if (g.y) hipLaunchKernelGGL(kern, g, dim3(256), 0, ctx->stream, a...);
+  }
+  static long long face_cells(const pa_level* LF, int ratio) {
+    return std::max((long long)LF->maxn[1] * LF->maxn[2], std::max((long long)LF->maxn[0] * LF->maxn[2], (long long)LF->maxn[0] * LF->maxn[1])) / ratio;
+  }
+  int setup_dist() {
+    rs.assign((size_t)nlev, nullptr);
+    cfw.v.assign((size_t)nlev, nullptr); fr.v.assign((size_t)nlev, nullptr); fm.v.assign((size_t)nlev, nullptr);
+    for (int l = 1; l < nlev; ++l) {
+      rs[l] = pa_rs_plan(ctx, lev[l], lev[l - 1], ratio);
+      if (!rs[l]) return 1;
+      cfw.v[l] = pa_mf_create(ctx, rs[l]->cf, 1, 1, nullptr);
+      fr.v[l - 1] = pa_mf_create(ctx, lev[l - 1], 6, 0, nullptr);
+      fm.v[l - 1] = pa_mf_create(ctx, lev[l - 1], 6, 0, nullptr);
+      if (!cfw.v[l] || !fr.v[l - 1] || !fm.v[l - 1]) return 1;
+    }
+    // where the fluxes of the finer level apply: the same exchange once with 1.0 on every coarse-fine face
+    if (flux_exchange(nullptr, fm, 1)) return 1;
+    for (int l = 0; l + 1 < nlev; ++l) on_boxes(k_smooth_fluxmask, lev[l], box_grid(lev[l]), lev[l]->view, fm.v[l]->view);
+    PA_HIP(hipGetLastError());
+    return 0;
+  }
+  // fine fluxes (or the mask) of every level into the registers of the level below: one grouped exchange for the hierarchy
+  int flux_exchange(Vecs* X, Vecs& R, int mask_mode) {
+    std::vector<XJob> jobs;
+    for (int l = nlev - 1; l > 0; --l) {
+      const pa_level* LF = lev[l];
+      if (!LF->sfaces.empty())
+        hipLaunchKernelGGL(k_smooth_fluxreg, dim3((unsigned)((face_cells(LF, ratio) + 255) / 256), (unsigned)LF->sfaces.size()), dim3(256), 0, ctx->stream, LF->view,
+                           X ? X->v[l]->view : cfw.v[l]->view, rs[l]->cf->view, cfw.v[l]->view, ratio, mask_mode);
+      for (int o = 0; o < 6; ++o) jobs.push_back({&rs[l]->flux[o], cfw.v[l], 0, R.v[l - 1], o, 1});
+    }
+    PA_HIP(hipGetLastError());
+    ++nexchange;
+    return pa_xexchange(ctx, (int)jobs.size(), jobs.data());
+  }
 
   int alloc(Vecs& V) {
     for (int l = 0; l < nlev; ++l) {
@@ -230,30 +377,73 @@ struct SmoothSolver {
     return 0;
   }
   int apply(Vecs& X, Vecs& Y) {  // y = A x (x: covered cells and ghosts are overwritten)
-    for (int l = nlev - 1; l > 0; --l)
-      hipLaunchKernelGGL(k_smooth_avgdown, box_grid(lev[l]), dim3(256), 0, ctx->stream, lev[l]->view, X.v[l]->view, lev[l - 1]->view, X.v[l - 1]->view, ratio);
-    for (int l = 0; l < nlev; ++l) {
-      if (pa_fill_boundary(ctx, X.v[l], 0, 1, 1)) return 1;
-      if (pa_apply_bc(ctx, X.v[l], 0, l ? X.v[l - 1] : nullptr, 0, bc, ratio, -1)) return 1;
-      hipLaunchKernelGGL(k_smooth_apply, box_grid(lev[l]), dim3(256), 0, ctx->stream, lev[l]->view, X.v[l]->view, Y.v[l]->view, dt);
-    }
     for (int l = nlev - 1; l > 0; --l) {
-      const pa_level* LF = lev[l];
-      if (LF->sfaces.empty()) continue;
-      const long long nf = std::max((long long)LF->maxn[1] * LF->maxn[2], std::max((long long)LF->maxn[0] * LF->maxn[2], (long long)LF->maxn[0] * LF->maxn[1])) / ratio;  // >= coarse faces per fine face (2-D planes: not refined in z)
-      hipLaunchKernelGGL(k_smooth_reflux, dim3((unsigned)((nf + 255) / 256), (unsigned)LF->sfaces.size()), dim3(256), 0, ctx->stream, LF->view, X.v[l]->view,
-                         lev[l - 1]->view, X.v[l - 1]->view, Y.v[l - 1]->view, dt, ratio);
+      if (!dist) {
+        hipLaunchKernelGGL(k_smooth_avgdown, box_grid(lev[l]), dim3(256), 0, ctx->stream, lev[l]->view, X.v[l]->view, lev[l - 1]->view, X.v[l - 1]->view, ratio);
+        continue;
+      }
+      on_boxes(k_smooth_avgdown_cf, lev[l], box_grid(lev[l]), lev[l]->view, X.v[l]->view, rs[l]->cf->view, cfw.v[l]->view, ratio);
+      const XJob J = {&rs[l]->down, cfw.v[l], 0, X.v[l - 1], 0, 1};  // level l - 1 must be complete before it is restricted in turn
+      ++nexchange;
+      if (pa_xexchange(ctx, 1, &J)) return 1;
     }
-    for (int l = 0; l + 1 < nlev; ++l)
-      hipLaunchKernelGGL(k_smooth_zero_covered, box_grid(lev[l]), dim3(256), 0, ctx->stream, lev[l]->view, Y.v[l]->view, mask.v[l]->view);
+    std::vector<const pa_mf*> crse((size_t)nlev, nullptr);
+    if (dist) {
+      // every ghost fill of the operator reads VALID cells only (same-level neighbours; the coarse cells under the coarse-fine
+      // faces), and those are final once the restriction is done: the cross-rank half of all of them is ONE grouped exchange
+      std::vector<XJob> jobs;
+      for (int l = 0; l < nlev; ++l) {
+        XPlan* P = pa_fb_plan(ctx, lev[l], 1);
+        if (!P) return 1;
+        jobs.push_back({P, X.v[l], 0, X.v[l], 0, 1});
+      }
+      for (int l = 1; l < nlev; ++l) {
+        CsPlan* cs = pa_cs_plan(ctx, lev[l], lev[l - 1], 0, 0, 0);
+        if (!cs) return 1;
+        pa_mf* m = cs->mf(ctx, 1);
+        if (cs->cs && !m) return 1;
+        crse[(size_t)l] = m;  // null: no coarse-fine ghost cell on this rank
+        jobs.push_back({&cs->x, X.v[l - 1], 0, m, 0, 1});
+      }
+      ++nexchange;
+      if (pa_xexchange(ctx, (int)jobs.size(), jobs.data())) return 1;
+    }
+    for (int l = 0; l < nlev; ++l) {
+      if (dist) {
+        if (pa_fill_boundary_impl(ctx, X.v[l], 0, 1, 1, 1)) return 1;
+        if (pa_apply_bc_impl(ctx, X.v[l], 0, crse[(size_t)l], 0, bc, ratio, -1, 0, nullptr)) return 1;
+      } else {
+        if (pa_fill_boundary(ctx, X.v[l], 0, 1, 1)) return 1;
+        if (pa_apply_bc(ctx, X.v[l], 0, l ? X.v[l - 1] : nullptr, 0, bc, ratio, -1)) return 1;
+      }
+      on_boxes(k_smooth_apply, lev[l], box_grid(lev[l]), lev[l]->view, X.v[l]->view, Y.v[l]->view, dt);
+    }
+    if (dist) {
+      if (nlev > 1) {
+        if (flux_exchange(&X, fr, 0)) return 1;
+        for (int l = 0; l + 1 < nlev; ++l)
+          on_boxes(k_smooth_reflux_apply, lev[l], box_grid(lev[l]), lev[l]->view, X.v[l]->view, Y.v[l]->view, fr.v[l]->view, fm.v[l]->view, dt);
+      }
+    } else {
+      for (int l = nlev - 1; l > 0; --l) {
+        const pa_level* LF = lev[l];
+        if (LF->sfaces.empty()) continue;
+        const long long nf = face_cells(LF, ratio);  // >= coarse faces per fine face (2-D planes: not refined in z)
+        hipLaunchKernelGGL(k_smooth_reflux, dim3((unsigned)((nf + 255) / 256), (unsigned)LF->sfaces.size()), dim3(256), 0, ctx->stream, LF->view, X.v[l]->view,
+                           lev[l - 1]->view, X.v[l - 1]->view, Y.v[l - 1]->view, dt, ratio);
+      }
+    }
+    for (int l = 0; l + 1 < nlev; ++l) on_boxes(k_smooth_zero_covered, lev[l], box_grid(lev[l]), lev[l]->view, Y.v[l]->view, mask.v[l]->view);
     PA_HIP(hipGetLastError());
     return 0;
   }
-  int dot(Vecs& A, Vecs& B, double* d, double* amax) {
+  // this rank's part of a . b and of max |a| over the uncovered cells
+  int ldot(Vecs& A, Vecs& B, double* d, double* amax) {
     double sd = 0.0, sm = 0.0;
     for (int l = 0; l < nlev; ++l) {
       const dim3 g = box_grid(lev[l], 64);
       const size_t np = (size_t)g.x * g.y;
+      if (!np) continue;
       if (pa_ensure_red(ctx, 2 * np)) return 1;
       hipLaunchKernelGGL(k_smooth_dot, g, dim3(256), 0, ctx->stream, lev[l]->view, A.v[l]->view, B.v[l]->view, mask.v[l]->view, ctx->d_red);
       PA_HIP(hipGetLastError());
@@ -266,23 +456,40 @@ struct SmoothSolver {
     *amax = sm;
     return 0;
   }
+  // what: 1 = the dot product, 2 = max |a|, 3 = both (each is one reduction over the ranks of a sharded hierarchy; every rank
+  // gets the same bits back, so every rank takes the same branches of the iteration)
+  int dot(Vecs& A, Vecs& B, double* d, double* amax, int what = 3) {
+    if (ldot(A, B, d, amax)) return 1;
+    if (dist) {
+      if ((what & 1) && (++nallreduce, pa_allreduce(ctx, d, 1, 2))) return 1;
+      if ((what & 2) && (++nallreduce, pa_allreduce(ctx, amax, 1, 1))) return 1;
+    }
+    return 0;
+  }
+  int dot2(Vecs& A, Vecs& B, Vecs& C, Vecs& D, double* ab, double* cd) {  // two dot products, one reduction
+    double v[2], dummy;
+    if (ldot(A, B, &v[0], &dummy) || ldot(C, D, &v[1], &dummy)) return 1;
+    if (dist && (++nallreduce, pa_allreduce(ctx, v, 2, 2))) return 1;
+    *ab = v[0];
+    *cd = v[1];
+    return 0;
+  }
   void axpbypcz(double a, Vecs* X, double b, Vecs* Y, double c, Vecs& Z) {
     for (int l = 0; l < nlev; ++l)
-      hipLaunchKernelGGL(k_smooth_axpbypcz, box_grid(lev[l]), dim3(256), 0, ctx->stream, lev[l]->view, a, X ? X->v[l]->view : Z.v[l]->view, X ? 1 : 0, b,
-                         Y ? Y->v[l]->view : Z.v[l]->view, Y ? 1 : 0, c, Z.v[l]->view);
+      on_boxes(k_smooth_axpbypcz, lev[l], box_grid(lev[l]), lev[l]->view, a, X ? X->v[l]->view : Z.v[l]->view, X ? 1 : 0, b, Y ? Y->v[l]->view : Z.v[l]->view,
+               Y ? 1 : 0, c, Z.v[l]->view);
   }
   void copy(Vecs& S, Vecs& D) {
-    for (int l = 0; l < nlev; ++l)
-      hipLaunchKernelGGL(k_smooth_copy, box_grid(lev[l]), dim3(256), 0, ctx->stream, lev[l]->view, S.v[l]->view, 0, D.v[l]->view, 0);
+    for (int l = 0; l < nlev; ++l) on_boxes(k_smooth_copy, lev[l], box_grid(lev[l]), lev[l]->view, S.v[l]->view, 0, D.v[l]->view, 0);
   }
 };
 
-// A hierarchy sharded over ranks: the solve is REPLICATED.  Every rank gathers the right-hand side of the whole hierarchy
-// (one grouped exchange, RepPlan in pa_dist.hip), runs the same composite solve on its own GPU -- same input, same kernels,
-// same fixed summation order, so every rank gets the same field and the result equals the one-rank run -- and keeps the
-// boxes it owns.  The reference's MLMG distributes this solve; here it is an optional pre-pass (do_smooth, curvature.cpp:
-// 328-406) on one component, and a distributed Krylov solve would make every dot product, average-down and reflux a
-// collective.  Stated cost: no speed-up of this phase with the number of GPUs, (nranks - 1) x this rank's cells of send buffer.
+// A hierarchy sharded over ranks, REPLICATED form (PA_SMOOTH_REPLICATED=1): every rank gathers the right-hand side of the whole
+// hierarchy (one grouped exchange, RepPlan in pa_dist.hip), runs the same composite solve on its own GPU -- same input, same
+// kernels, same fixed summation order, so every rank gets the same field and the result equals the one-rank run BIT FOR BIT --
+// and keeps the boxes it owns.  No speed-up with the number of GPUs and (nranks - 1) x this rank's cells of send buffer: the
+// default is the distributed solve below (the reference's MLMG distributes this solve too); this form stays for runs that
+// must reproduce the one-GPU bits.
 static int smooth_solve_replicated(pa_ctx* ctx, int nlev, pa_mf* const* rhs, int rcomp, pa_mf* const* sol, int scomp, double dt, const int32_t bc[3], double tol,
                                    int maxiter, int* iters, double* res) {
   std::vector<RepPlan*> P((size_t)nlev, nullptr);
@@ -316,14 +523,22 @@ extern "C" int pa_smooth_solve(pa_ctx* ctx, int nlev, pa_mf* const* rhs, int rco
                                int maxiter, int* iters, double* res) {
   PaBind bind_(ctx);
   if (!ctx || nlev <= 0 || !rhs || !sol || !bc) return pa_fail(ctx, "pa_smooth_solve: null argument");
-  if (rhs[0] && rhs[0]->lev->nranks > 1) return smooth_solve_replicated(ctx, nlev, rhs, rcomp, sol, scomp, dt, bc, tol, maxiter, iters, res);
+  // A hierarchy sharded over ranks: DISTRIBUTED solve.  Every rank keeps the vectors of its own boxes; the operator's
+  // average_down and reflux go through the restriction plans (pa_dist.h: RsPlan -- the fine rank restricts / sums the fluxes of
+  // its own boxes, one exchange hands them to the coarse owners), its ghost fills are the sharded pa_fill_boundary /
+  // pa_apply_bc, and each dot product / norm is one pa_allreduce.  The iteration is the one-rank iteration with the sums taken
+  // in another order: the field agrees with the one-rank (and the oracle's) to the solve's tolerance, not bit for bit.
+  const bool sharded = rhs[0] && rhs[0]->lev->nranks > 1;
+  static const int replicated = [] { const char* e = getenv("PA_SMOOTH_REPLICATED"); return e ? atoi(e) : 0; }();
+  if (sharded && replicated) return smooth_solve_replicated(ctx, nlev, rhs, rcomp, sol, scomp, dt, bc, tol, maxiter, iters, res);
   SmoothSolver S;
-  S.ctx = ctx; S.nlev = nlev; S.ratio = 2; S.dt = dt;
+  S.ctx = ctx; S.nlev = nlev; S.ratio = 2; S.dt = dt; S.dist = sharded;
   for (int d = 0; d < 3; ++d) S.bc[d] = bc[d];
   for (int l = 0; l < nlev; ++l) {
     if (!rhs[l] || !sol[l] || rhs[l]->lev != sol[l]->lev) return pa_fail(ctx, "pa_smooth_solve: rhs/sol on different levels");
     if (rcomp < 0 || rcomp >= rhs[l]->ncomp || scomp < 0 || scomp >= sol[l]->ncomp) return pa_fail(ctx, "pa_smooth_solve: component range");
-    if (rhs[l]->lev->nranks > 1) return pa_fail(ctx, "pa_smooth_solve: do_smooth is not supported on a sharded hierarchy (composite solve on one rank)");
+    if ((rhs[l]->lev->nranks > 1) != sharded) return pa_fail(ctx, "pa_smooth_solve: sharded and unsharded levels in one hierarchy");
+    if (sharded && rhs[l]->lev->nranks != ctx->comm.nranks) return pa_fail(ctx, "pa_smooth_solve: the context's transport has a different number of ranks than the levels");
     S.lev.push_back(rhs[l]->lev);
     if (l > 0)
       for (const DBox& B : S.lev[l]->boxes)
@@ -335,35 +550,36 @@ extern "C" int pa_smooth_solve(pa_ctx* ctx, int nlev, pa_mf* const* rhs, int rco
   if (S.alloc(S.r) || S.alloc(S.rh) || S.alloc(S.p) || S.alloc(S.v) || S.alloc(S.s) || S.alloc(S.t) || S.alloc(S.mask)) return 1;
   Vecs x;  // the solution as a 1-comp vector (sol may have other components / ghost widths)
   if (S.alloc(x)) return 1;
+  if (S.dist && S.setup_dist()) return 1;
   for (int l = 0; l < nlev; ++l) {
     const pa_level* L = S.lev[l];
-    hipLaunchKernelGGL(k_smooth_mask, box_grid(L), dim3(256), 0, ctx->stream, L->view, S.mask.v[l]->view, l + 1 < nlev ? S.lev[l + 1]->view : L->view, l + 1 < nlev ? 1 : 0, 2);
-    hipLaunchKernelGGL(k_smooth_copy, box_grid(L), dim3(256), 0, ctx->stream, L->view, rhs[l]->view, rcomp, S.r.v[l]->view, 0);
-    hipLaunchKernelGGL(k_smooth_copy, box_grid(L), dim3(256), 0, ctx->stream, L->view, rhs[l]->view, rcomp, S.rh.v[l]->view, 0);
+    S.on_boxes(k_smooth_mask, L, box_grid(L), L->view, S.mask.v[l]->view, l + 1 < nlev ? S.lev[l + 1]->view : L->view, l + 1 < nlev ? 1 : 0, 2);
+    S.on_boxes(k_smooth_copy, L, box_grid(L), L->view, rhs[l]->view, rcomp, S.r.v[l]->view, 0);
+    S.on_boxes(k_smooth_copy, L, box_grid(L), L->view, rhs[l]->view, rcomp, S.rh.v[l]->view, 0);
   }
   PA_HIP(hipGetLastError());
   double bnorm, dummy, rho = 1.0, alpha = 1.0, omega = 1.0;
-  if (S.dot(S.r, S.r, &dummy, &bnorm)) return 1;
+  if (S.dot(S.r, S.r, &dummy, &bnorm, 2)) return 1;
   int it = 0, status = -1;
   double rnorm = bnorm;
   if (bnorm == 0.0) status = 0;
   while (status != 0 && it < maxiter) {
     ++it;
     double rho1;
-    if (S.dot(S.rh, S.r, &rho1, &dummy)) return 1;
+    if (S.dot(S.rh, S.r, &rho1, &dummy, 1)) return 1;
     if (rho1 == 0.0) { status = -2; break; }
     const double beta = (rho1 / rho) * (alpha / omega);
     S.axpbypcz(-omega * beta, &S.v, 0.0, nullptr, beta, S.p);  // p = r + beta (p - omega v)
     S.axpbypcz(1.0, &S.r, 0.0, nullptr, 1.0, S.p);
     if (S.apply(S.p, S.v)) return 1;
     double rhv;
-    if (S.dot(S.rh, S.v, &rhv, &dummy)) return 1;
+    if (S.dot(S.rh, S.v, &rhv, &dummy, 1)) return 1;
     if (rhv == 0.0) { status = -3; break; }
     alpha = rho1 / rhv;
     S.copy(S.r, S.s);  // s = r - alpha v
     S.axpbypcz(-alpha, &S.v, 0.0, nullptr, 1.0, S.s);
     double snorm;
-    if (S.dot(S.s, S.s, &dummy, &snorm)) return 1;
+    if (S.dot(S.s, S.s, &dummy, &snorm, 2)) return 1;
     if (snorm <= tol * bnorm) {
       S.axpbypcz(alpha, &S.p, 0.0, nullptr, 1.0, x);
       rnorm = snorm;
@@ -372,22 +588,27 @@ extern "C" int pa_smooth_solve(pa_ctx* ctx, int nlev, pa_mf* const* rhs, int rco
     }
     if (S.apply(S.s, S.t)) return 1;
     double ts, tt;
-    if (S.dot(S.t, S.s, &ts, &dummy)) return 1;
-    if (S.dot(S.t, S.t, &tt, &dummy)) return 1;
+    if (S.dot2(S.t, S.s, S.t, S.t, &ts, &tt)) return 1;
     if (tt == 0.0) { status = -4; break; }
     omega = ts / tt;
     S.axpbypcz(alpha, &S.p, omega, &S.s, 1.0, x);  // x += alpha p + omega s
     S.copy(S.s, S.r);                               // r = s - omega t
     S.axpbypcz(-omega, &S.t, 0.0, nullptr, 1.0, S.r);
-    if (S.dot(S.r, S.r, &dummy, &rnorm)) return 1;
+    if (S.dot(S.r, S.r, &dummy, &rnorm, 2)) return 1;
     rho = rho1;
     if (rnorm <= tol * bnorm) { status = 0; break; }
     if (omega == 0.0) { status = -5; break; }
   }
-  for (int l = nlev - 1; l > 0; --l)
-    hipLaunchKernelGGL(k_smooth_avgdown, box_grid(S.lev[l]), dim3(256), 0, ctx->stream, S.lev[l]->view, x.v[l]->view, S.lev[l - 1]->view, x.v[l - 1]->view, 2);
-  for (int l = 0; l < nlev; ++l)
-    hipLaunchKernelGGL(k_smooth_copy, box_grid(S.lev[l]), dim3(256), 0, ctx->stream, S.lev[l]->view, x.v[l]->view, 0, sol[l]->view, scomp);
+  for (int l = nlev - 1; l > 0; --l) {
+    if (!S.dist) {
+      hipLaunchKernelGGL(k_smooth_avgdown, box_grid(S.lev[l]), dim3(256), 0, ctx->stream, S.lev[l]->view, x.v[l]->view, S.lev[l - 1]->view, x.v[l - 1]->view, 2);
+      continue;
+    }
+    S.on_boxes(k_smooth_avgdown_cf, S.lev[l], box_grid(S.lev[l]), S.lev[l]->view, x.v[l]->view, S.rs[l]->cf->view, S.cfw.v[l]->view, 2);
+    const XJob J = {&S.rs[l]->down, S.cfw.v[l], 0, x.v[l - 1], 0, 1};
+    if (pa_xexchange(ctx, 1, &J)) return 1;
+  }
+  for (int l = 0; l < nlev; ++l) S.on_boxes(k_smooth_copy, S.lev[l], box_grid(S.lev[l]), S.lev[l]->view, x.v[l]->view, 0, sol[l]->view, scomp);
   PA_HIP(hipGetLastError());
   PA_HIP(hipStreamSynchronize(ctx->stream));  // the work vectors are freed on return
   if (iters) *iters = it;

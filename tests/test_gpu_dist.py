@@ -174,6 +174,99 @@ def test_sharded_hierarchy_on_shared_gpu_matches_undistributed_oracle(world, cas
     mp.spawn(_worker, args=(world, _free_port(), case), nprocs=world, join=True)
 
 
+def _smooth_worker(rank, world, port, case, transport="gloo"):
+    """do_smooth (curvature.cpp:328-406) on a sharded hierarchy: the DISTRIBUTED composite solve against the undistributed oracle"""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    replicated = case.endswith("+rep")
+    case = case.replace("+rep", "")
+    if replicated:
+        os.environ["PA_SMOOTH_REPLICATED"] = "1"  # read once, when the library first solves
+    import torch
+    import torch.distributed as dist
+    torch.cuda.init()
+    from oracle import oracle as O
+    from peleanalysis_amd import capi
+    from peleanalysis_amd import dist as padist
+    from peleanalysis_amd.hierarchy import MultiFab, cell_centers, nested_hierarchy
+    from test_dist_gloo import scattered_owner
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        per = (1, 1, 0)
+        if case.startswith("rand"):
+            import test_gpu_random as R
+            draw = {"u": R._union_case, "U": R._union_wide_case}.get(case[4])
+            H, per, _sym, _fn = draw(int(case[5:])) if draw else R._draw(int(case[4:]))
+        elif case == "walls":
+            per = (0, 0, 0)
+            H = nested_hierarchy(16, 3, 8, is_per=per)
+        else:
+            H = nested_hierarchy(16, 3, 8, is_per=per)
+        for lv in H.levels[1:]:  # the composite operator needs fine boxes aligned to the ratio (pa_smooth_solve checks it)
+            for b in lv.boxes:
+                assert not any(b[d] % 2 or (b[3 + d] + 1) % 2 for d in range(3)), "pick a draw whose fine boxes are aligned to the ratio"
+        owners = [scattered_owner(lv.nboxes, world, 57 + l) for l, lv in enumerate(H.levels)]
+        bc = capi.bc_from_flags(per)
+        rng = np.random.default_rng(5)
+        rhs = []
+        for lv in H.levels:
+            m = MultiFab(lv, 1, 0)
+            for b in range(lv.nboxes):
+                x, y, z = cell_centers(lv, b, 0)
+                m.valid(b)[0] = 0.5 + 0.5 * np.tanh((np.sqrt((x - 0.5) ** 2 + (y - 0.45) ** 2 + (z - 0.5) ** 2) - 0.3) / 0.08) + 1e-2 * rng.uniform(-1, 1, size=m.valid(b)[0].shape)
+            rhs.append(m)
+        dt = 5e-4
+        want, oit, ores = O.smooth_solve(H.levels, rhs, 0, dt, bc, MultiFab, tol=1e-14)
+
+        if transport == "rccl":
+            torch.cuda.set_device(rank)
+            ctx = capi.Context(rank)
+            padist.init_rccl(ctx)
+            comm = None
+        else:
+            ctx = capi.Context(0)
+            comm = padist.GlooComm(ctx)
+        dls = [capi.DevLevel(ctx, lv, owners[l], rank, world) for l, lv in enumerate(H.levels)]
+        drhs, dsol = [], []
+        for l, dl in enumerate(dls):
+            s = MultiFab(dl.level, 1, 0)
+            for i, g in enumerate(dl.gids):
+                s.valid(i)[...] = rhs[l].valid(int(g))
+            drhs.append(capi.DevMF.from_host(ctx, dl, s))
+            dsol.append(capi.DevMF(ctx, dl, 1, 0))
+        n0 = comm.nexchange if comm else 0
+        it, res = capi.smooth_solve(ctx, drhs, 0, dsol, 0, dt, bc, tol=1e-14, maxiter=200)
+        assert 0 < it < 100 and res <= 1e-14 and abs(it - oit) <= 12, (it, oit, res)  # at 1e-14 the last steps sit on the rounding floor: the count wanders with the summation order
+        if comm:
+            nx = comm.nexchange - n0
+            if replicated:
+                assert nx == 1, "replicated solve: one gather of the right-hand side"
+            else:
+                assert nx > 4 * it, "distributed solve: ghost fills, restriction and flux registers cross ranks in every operator application"
+        worst = 0.0
+        for l, dl in enumerate(dls):
+            got = dsol[l].download()
+            for i, g in enumerate(dl.gids):
+                worst = max(worst, float(np.abs(got.valid(i)[0] - want[l].valid(int(g))[0]).max()))
+        assert worst <= 1e-12, f"rank {rank}/{world}: smoothed field differs from the undistributed oracle by {worst}"
+        dist.barrier()
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,case", [(2, "nested"), (4, "nested"), (3, "walls"), (4, "nested+rep"), (3, "randu0"), (4, "randu13"), (2, "randu2"), (3, "randU0"), (4, "rand7")])
+def test_sharded_smoothing_solve_matches_undistributed_oracle(world, case):
+    """do_smooth with the hierarchy dealt to `world` ranks (scattered owners: fine boxes, their coarse parents and their
+    neighbours mostly on different ranks): average_down and the flux register through the restriction plans, dot products
+    through the transport's allreduce; the field equals the oracle's one-process composite solve to 1e-12 (both iterated to
+    1e-14), with the one-rank iteration count.  `+rep`: the replicated form (PA_SMOOTH_REPLICATED=1)."""
+    import torch.multiprocessing as mp
+    mp.spawn(_smooth_worker, args=(world, _free_port(), case), nprocs=world, join=True)
+
+
 def _ngpus():
     import torch
     return torch.cuda.device_count()  # (counting devices does not initialise the GPU)
@@ -188,6 +281,8 @@ def test_sharded_hierarchy_over_rccl_two_gpus(case):
     The first multi-GPU box that runs the GPU tier exercises it."""
     import torch.multiprocessing as mp
     mp.spawn(_worker, args=(2, _free_port(), case, "rccl"), nprocs=2, join=True)
+    if case == "wide":  # + the distributed smoothing solve: its restriction / flux-register exchanges and ncclAllReduce dot products
+        mp.spawn(_smooth_worker, args=(2, _free_port(), "nested", "rccl"), nprocs=2, join=True)
 
 
 _RCCL_SELF = """

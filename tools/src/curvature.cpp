@@ -145,8 +145,9 @@ int main(int argc, char** argv) {
   const std::vector<std::vector<int32_t>> owner = pa::shard_levels(H, Nlev, team.n);
   // ngpus > 1: the reference's MPI ranks own the FABs DistributionMapping gives them (curvature.cpp:289); here every rank
   // (host thread + GPU) runs the same pipeline on its share and the library fills ghost cells across ranks.  do_smooth: the
-  // composite solve is REPLICATED (every rank gathers the progress variable of the whole hierarchy, solves, keeps its boxes:
-  // pa_smooth.hip) -- same result as one rank, no speed-up of that phase.  Downstream of the solve, curvature / normals are an
+  // composite solve is DISTRIBUTED like the reference's MLMG (every rank iterates on its own boxes; restriction, ghost fills,
+  // flux register and dot products cross ranks: pa_smooth.hip) -- the one-rank field to the solver tolerance, not its bits
+  // (PA_SMOOTH_REPLICATED=1: every rank solves the whole hierarchy, bit-identical).  Downstream of the solve, curvature / normals are an
   // ill-conditioned function (n = G / |G|) of a field that is itself only fixed to ~1e-12 by the solver tolerance: the GPU
   // tests compare them with the oracle to 1e-5 of their scale, the smoothed field itself to 1e-12 (tests/test_gpu_smooth.py).
   team.run([&](int r) {
