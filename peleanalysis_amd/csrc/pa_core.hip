@@ -32,6 +32,10 @@ extern "C" pa_ctx* pa_ctx_create(int device, void* hip_stream) {
     delete ctx;
     return nullptr;
   }
+  // the side stream of the pipelines (boundary kernels next to a sweep, exchanges next to the local ghost fill): creating a
+  // stream costs ~10 ms the first time, so it is made here -- the tools bring the context up while they read the plotfile --
+  // and not inside the first pass.  A failure leaves it to the first use.
+  if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess) { ctx->stream2 = nullptr; (void)hipGetLastError(); }
   return ctx;
 }
 
