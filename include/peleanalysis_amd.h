@@ -148,6 +148,17 @@ int64_t pa_plan_coarse_source(int nfine, const int32_t* fboxes6, const int32_t* 
                               const int32_t fdomhi[3], int ncrse, const int32_t* cboxes6, const int32_t* cowner,
                               const int32_t cdomlo[3], const int32_t cdomhi[3], const int32_t is_per[3], int rank,
                               int mode, int ng, int halo, int32_t* rows9, int64_t cap);
+/* pa_plan_restriction: what moves between ranks in the distributed smoothing solve (pa_smooth_solve on sharded levels; what
+ * amrex::average_down and MLMG's flux register move, curvature.cpp:328-406).  which = 0: the child averages -- kind 0 = send
+ * (box = global FINE box this rank owns, region = part of that box coarsened by `ratio`), kind 1 = receive (box = global COARSE
+ * box, the same region: its valid cells), kinds 3 / 4 = source / destination of a same-rank copy, in pairs.  which = 1 + 2 * dir
+ * + side: the flux register of that face orientation -- the source regions lie in the one-cell ghost slab behind face (dir, side)
+ * of the coarsened fine box (special faces only), the destination regions are those cells folded into the coarse domain through
+ * its periodic images.  Both sides of a pair of ranks list their regions in the same order. */
+int64_t pa_plan_restriction(int nfine, const int32_t* fboxes6, const int32_t* fowner, const int32_t fdomlo[3],
+                            const int32_t fdomhi[3], int ncrse, const int32_t* cboxes6, const int32_t* cowner,
+                            const int32_t cdomlo[3], const int32_t cdomhi[3], const int32_t is_per[3], int rank, int ratio,
+                            int which, int32_t* rows9, int64_t cap);
 void      pa_level_destroy(pa_level*);
 int       pa_level_nboxes(const pa_level*);
 

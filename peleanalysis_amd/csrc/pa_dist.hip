@@ -636,6 +636,77 @@ static void boxes_near(const HostGeom& G, int nboxes, const DBox& Q, std::vector
   std::sort(out.begin(), out.end());
   out.erase(std::unique(out.begin(), out.end()), out.end());
 }
+// The region lists of one restriction plan as host arithmetic (which = 0: `down`, 1 + 2 * dir + side: that flux plan), for rank
+// `me`: what it sends (fine global box, region in the coarsened fine level's index space), what it receives (coarse global box,
+// region in the coarse level's index space = the sender's region minus the periodic shift) and its same-rank pairs.  Every rank
+// walks (fine box, shift, coarse box) in the same order, so a sender's list to a peer and that peer's list from it pair up.
+struct RsRegions {
+  std::vector<std::pair<int, std::array<int32_t, 7>>> send, recv;  // (peer, {global box, lo, hi})
+  std::vector<std::array<int32_t, 7>> lsrc, ldst;
+};
+static std::vector<DBox> rs_coarsen(const std::vector<DBox>& fb, const int fdomlo[3], const int fdomhi[3], int ratio) {
+  const int r3[3] = {ratio, ratio, fdomlo[2] == fdomhi[2] ? 1 : ratio};  // a 2-D hierarchy is one plane of cells per level
+  auto fdiv = [](int a, int r) { return a >= 0 ? a / r : -((-a + r - 1) / r); };
+  std::vector<DBox> out;
+  for (const DBox& B : fb) {
+    DBox c;
+    for (int d = 0; d < 3; ++d) { c.lo[d] = fdiv(B.lo[d], r3[d]); c.hi[d] = fdiv(B.hi[d], r3[d]); }
+    out.push_back(c);
+  }
+  return out;
+}
+static RsRegions rs_regions(const HostGeom& FG, const std::vector<DBox>& fb, const std::vector<int>& fowner, const std::vector<DBox>& cfb, const HostGeom& CG,
+                            const std::vector<DBox>& cb, const std::vector<int>& cowner, int me, int which) {
+  RsRegions R;
+  const int nF = (int)fb.size(), nC = (int)cb.size();
+  std::vector<int> cand;
+  auto emit = [&](int gf, const DBox& Q, const std::array<int, 3>& sh) {
+    const int neg[3] = {-sh[0], -sh[1], -sh[2]}, pos[3] = {sh[0], sh[1], sh[2]};
+    const DBox Qc = bx_shift(Q, neg);  // in the coarse level's index space
+    boxes_near(CG, nC, Qc, cand);
+    for (int gc : cand) {
+      DBox I;
+      if (!bx_isect(Qc, cb[gc], I)) continue;
+      const DBox Is = bx_shift(I, pos);
+      const int fo = fowner[gf], co = cowner[gc];
+      if (fo == me && co == me) { R.lsrc.push_back(reg7(gf, Is)); R.ldst.push_back(reg7(gc, I)); }
+      else if (fo == me) R.send.push_back({co, reg7(gf, Is)});
+      else if (co == me) R.recv.push_back({fo, reg7(gc, I)});
+    }
+  };
+  if (which == 0) {
+    const std::array<int, 3> zero = {0, 0, 0};
+    for (int gf = 0; gf < nF; ++gf) emit(gf, cfb[gf], zero);  // fine boxes lie inside the domain: no periodic image
+  } else {
+    const int dir = (which - 1) >> 1, side = (which - 1) & 1;
+    const auto shifts = domain_shifts(CG.domlo, CG.domhi, CG.is_per);
+    for (int gf = 0; gf < nF; ++gf) {
+      if (!FG.face_is_special(fb[gf], dir, side)) continue;
+      DBox Q = cfb[gf];
+      Q.lo[dir] = Q.hi[dir] = side ? Q.hi[dir] + 1 : Q.lo[dir] - 1;
+      for (const auto& sh : shifts) emit(gf, Q, sh);
+    }
+  }
+  return R;
+}
+extern "C" int64_t pa_plan_restriction(int nfine, const int32_t* fb6, const int32_t* fowner, const int32_t fdomlo[3], const int32_t fdomhi[3], int ncrse,
+                                       const int32_t* cb6, const int32_t* cowner, const int32_t cdomlo[3], const int32_t cdomhi[3], const int32_t is_per[3],
+                                       int rank, int ratio, int which, int32_t* rows9, int64_t cap) {
+  if (nfine <= 0 || ncrse <= 0 || !fb6 || !fowner || !cb6 || !cowner || which < 0 || which > 6 || ratio < 2) return -1;
+  const std::vector<DBox> fb = boxes_from6(nfine, fb6), cb = boxes_from6(ncrse, cb6);
+  const HostGeom FG(fb, fdomlo, fdomhi, is_per), CG(cb, cdomlo, cdomhi, is_per);
+  const RsRegions R = rs_regions(FG, fb, std::vector<int>(fowner, fowner + nfine), rs_coarsen(fb, fdomlo, fdomhi, ratio), CG, cb, std::vector<int>(cowner, cowner + ncrse), rank, which);
+  auto box_of = [](const std::array<int32_t, 7>& a) { DBox b; for (int d = 0; d < 3; ++d) { b.lo[d] = a[1 + d]; b.hi[d] = a[4 + d]; } return b; };
+  int64_t n = 0;
+  for (const auto& s : R.send) put_row(rows9, cap, n, 0, s.first, s.second[0], box_of(s.second));
+  for (const auto& r : R.recv) put_row(rows9, cap, n, 1, r.first, r.second[0], box_of(r.second));
+  for (size_t i = 0; i < R.lsrc.size(); ++i) {
+    put_row(rows9, cap, n, 3, rank, R.lsrc[i][0], box_of(R.lsrc[i]));
+    put_row(rows9, cap, n, 4, rank, R.ldst[i][0], box_of(R.ldst[i]));
+  }
+  return n;
+}
+
 static int xplan_locals(pa_ctx* ctx, XPlan& X, const std::vector<int32_t>& lsrc, const std::vector<int32_t>& ldst) {
   X.nlocal = (int)(lsrc.size() / 7);
   if (!X.nlocal) return 0;
@@ -650,69 +721,31 @@ RsPlan* pa_rs_plan(pa_ctx* ctx, const pa_level* F, const pa_level* C, int ratio)
   if (it != F->rs_plans.end()) return it->second.get();
   if (F->nranks <= 1 || F->gboxes.empty() || C->gboxes.empty()) { pa_fail(ctx, "pa_rs_plan: the levels are not sharded"); return nullptr; }
   if (F->nranks != C->nranks || F->rank != C->rank) { pa_fail(ctx, "coarse and fine level are sharded over different rank sets"); return nullptr; }
-  const int r3[3] = {ratio, ratio, F->domlo[2] == F->domhi[2] ? 1 : ratio};  // a 2-D hierarchy is one plane of cells per level
-  auto fdiv = [](int a, int r) { return a >= 0 ? a / r : -((-a + r - 1) / r); };
-  auto crs = [&](const DBox& B) {
-    DBox c;
-    for (int d = 0; d < 3; ++d) { c.lo[d] = fdiv(B.lo[d], r3[d]); c.hi[d] = fdiv(B.hi[d], r3[d]); }
-    return c;
-  };
   std::unique_ptr<RsPlan> P(new RsPlan());
+  const std::vector<DBox> cfb = rs_coarsen(F->gboxes, F->domlo, F->domhi, ratio);
   LevelSpec S;
   S.source_only = true;
   S.rank = F->rank; S.nranks = F->nranks;
   S.gid = F->gid; S.gowner = F->gowner;
-  for (const DBox& B : F->boxes) S.local.push_back(crs(B));
-  for (const DBox& B : F->gboxes) S.gboxes.push_back(crs(B));
+  S.gboxes = cfb;
+  for (int g : F->gid) S.local.push_back(cfb[g]);
   P->cf = pa_level_create_spec(ctx, S, C->domlo, C->domhi, C->is_per, C->prob_lo, C->prob_hi);
   if (!P->cf) return nullptr;
-  const HostGeom CG(C->gboxes, C->domlo, C->domhi, C->is_per);
-  const int nF = (int)F->gboxes.size(), nC = (int)C->gboxes.size(), me = F->rank;
-  const auto shifts = domain_shifts(C->domlo, C->domhi, C->is_per);
-  std::vector<int> cand;
-  // one plan from a list of (fine global box, source region in cf's index space, shift): destination region = source - shift
-  auto build = [&](XPlan& X, auto&& each_source) -> int {
-    std::vector<std::pair<int, std::array<int32_t, 7>>> s, r;
+  const HostGeom FG(F->gboxes, F->domlo, F->domhi, F->is_per), CG(C->gboxes, C->domlo, C->domhi, C->is_per);
+  for (int which = 0; which <= 6; ++which) {
+    XPlan& X = which ? P->flux[which - 1] : P->down;
+    RsRegions R = rs_regions(FG, F->gboxes, F->gowner, cfb, CG, C->gboxes, C->gowner, F->rank, which);
     std::vector<int32_t> lsrc, ldst;
-    each_source([&](int gf, const DBox& Q, const std::array<int, 3>& sh) {
-      const int neg[3] = {-sh[0], -sh[1], -sh[2]};
-      const DBox Qc = bx_shift(Q, neg);  // in the coarse level's index space
-      boxes_near(CG, nC, Qc, cand);
-      for (int gc : cand) {
-        DBox I;
-        if (!bx_isect(Qc, C->gboxes[gc], I)) continue;
-        const int pos[3] = {sh[0], sh[1], sh[2]};
-        const DBox Is = bx_shift(I, pos);
-        const int fo = F->gowner[gf], co = C->gowner[gc];
-        if (fo == me && co == me) {
-          const auto a = reg7(F->glocal[gf], Is), b = reg7(C->glocal[gc], I);
-          lsrc.insert(lsrc.end(), a.begin(), a.end());
-          ldst.insert(ldst.end(), b.begin(), b.end());
-          X.lmax = std::max(X.lmax, bx_cells(I));
-        } else if (fo == me) {
-          s.push_back({co, reg7(F->glocal[gf], Is)});
-        } else if (co == me) {
-          r.push_back({fo, reg7(C->glocal[gc], I)});
-        }
-      }
-    });
-    if (side_finish(ctx, X.send, s) || side_finish(ctx, X.recv, r)) return 1;
-    return xplan_locals(ctx, X, lsrc, ldst);
-  };
-  const std::array<int, 3> zero = {0, 0, 0};
-  if (build(P->down, [&](auto&& emit) {
-        for (int gf = 0; gf < nF; ++gf) emit(gf, S.gboxes[gf], zero);  // fine boxes lie inside the domain: no periodic image
-      })) return nullptr;
-  for (int o = 0; o < 6; ++o) {
-    const int dir = o >> 1, side = o & 1;
-    if (build(P->flux[o], [&](auto&& emit) {
-          for (int gf = 0; gf < nF; ++gf) {
-            if (!pa_face_is_special(F, F->gboxes[gf], dir, side)) continue;
-            DBox Q = S.gboxes[gf];
-            Q.lo[dir] = Q.hi[dir] = side ? Q.hi[dir] + 1 : Q.lo[dir] - 1;
-            for (const auto& sh : shifts) emit(gf, Q, sh);
-          }
-        })) return nullptr;
+    for (auto& s : R.send) s.second[0] = F->glocal[s.second[0]];  // global -> this rank's box indices
+    for (auto& r : R.recv) r.second[0] = C->glocal[r.second[0]];
+    for (size_t i = 0; i < R.lsrc.size(); ++i) {
+      R.lsrc[i][0] = F->glocal[R.lsrc[i][0]];
+      R.ldst[i][0] = C->glocal[R.ldst[i][0]];
+      lsrc.insert(lsrc.end(), R.lsrc[i].begin(), R.lsrc[i].end());
+      ldst.insert(ldst.end(), R.ldst[i].begin(), R.ldst[i].end());
+      X.lmax = std::max(X.lmax, (long long)(R.ldst[i][4] - R.ldst[i][1] + 1) * (R.ldst[i][5] - R.ldst[i][2] + 1) * (R.ldst[i][6] - R.ldst[i][3] + 1));
+    }
+    if (side_finish(ctx, X.send, R.send) || side_finish(ctx, X.recv, R.recv) || xplan_locals(ctx, X, lsrc, ldst)) return nullptr;
   }
   RsPlan* raw = P.get();
   F->rs_plans[C->serial] = std::move(P);

@@ -62,6 +62,11 @@ struct MarchArgs {
   int order, nboxes, txy_max, tiles_max;
   int cg = 0;  // host side: launch the CG variant of k_gradcurv_march3 (pa_fused_march3.h)
   const int* boxlist = nullptr;  // k_gradcurv_march3 / march3n: the launch covers boxes boxlist[0 .. nboxes-1] of the level (null: all of them)
+  // k_gradcurv_march3 / march3n on boxes of different sizes: workgroup i works on tile wgtab[2 i + 1] of box wgtab[2 i] (< 0: none).
+  // With order 2 every box gets the tile count of the LARGEST box of the launch and the others exit at once -- on a Pele BoxArray
+  // (boxes of 32 .. 128 cells per side) 2 of 3 workgroups; the table has none of those and keeps order 2's property (workgroups
+  // i and i + 8, one XCD, work on the same box).
+  const int* wgtab = nullptr;
 };
 
 template <typename BP, int PA_MTY, int MINW>

@@ -128,7 +128,11 @@ __device__ __forceinline__ void gradcurv_march3_body(const BP& bp, const MarchAr
   constexpr bool OLD_SCHED = (DBG & 256) != 0;  // requests at the top of a step + stores spread over it (first v3 schedule)
   unsigned bid = bid_x;
   int box;
-  if (A.order == 2) {
+  if (A.wgtab) {
+    box = A.wgtab[2 * bid_x];
+    if (box < 0) return;
+    bid = (unsigned)A.wgtab[2 * bid_x + 1];
+  } else if (A.order == 2) {
     const unsigned per8 = 8u * (unsigned)A.tiles_max, g = bid / per8, r = bid % per8;
     box = (int)(g * 8u + (r & 7u));
     bid = r >> 3;
@@ -136,7 +140,7 @@ __device__ __forceinline__ void gradcurv_march3_body(const BP& bp, const MarchAr
   } else {
     box = A.order ? (int)((bid_x / (unsigned)A.txy_max) % (unsigned)A.nboxes) : (int)bid_y;
   }
-  if (A.boxlist) {
+  if (A.boxlist && !A.wgtab) {
     if (box >= A.nboxes) return;
     box = A.boxlist[box];
   }

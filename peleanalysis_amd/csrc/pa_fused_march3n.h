@@ -37,7 +37,11 @@ __device__ __forceinline__ void gradcurv_march3n_body(const BP& bp, const MarchA
   constexpr int MTY2 = 2 * NRW, MROWS = MTY2 + 2;
   unsigned bid = bid_x;
   int box;
-  if (A.order == 2) {
+  if (A.wgtab) {
+    box = A.wgtab[2 * bid_x];
+    if (box < 0) return;
+    bid = (unsigned)A.wgtab[2 * bid_x + 1];
+  } else if (A.order == 2) {
     const unsigned per8 = 8u * (unsigned)A.tiles_max, g = bid / per8, r = bid % per8;
     box = (int)(g * 8u + (r & 7u));
     bid = r >> 3;
@@ -45,7 +49,7 @@ __device__ __forceinline__ void gradcurv_march3n_body(const BP& bp, const MarchA
   } else {
     box = (int)bid_y;
   }
-  if (A.boxlist) {
+  if (A.boxlist && !A.wgtab) {
     if (box >= A.nboxes) return;
     box = A.boxlist[box];
   }

@@ -126,6 +126,14 @@ struct ProfScope {
 enum { PA_TAG_GRADCURV = 1, PA_TAG_GRADCURV_FACES = 2, PA_TAG_FILL = 3, PA_TAG_BC = 4, PA_TAG_GRAD = 5, PA_TAG_PROGRESS = 6,
        PA_TAG_FILTER = 7, PA_TAG_MC = 8, PA_TAG_XCHG = 9 };
 
+// Workgroup table of a sweep over boxes of DIFFERENT sizes (pa_fused.hip: sweep_wgtab): entry i = {box, tile of that box} or
+// {-1, 0}; groups of 8 boxes with similar tile counts are interleaved so that entry i and i + 8 (same XCD) belong to one box
+struct WgTab {
+  int* d = nullptr;
+  unsigned n = 0;
+  ~WgTab() { if (d) (void)hipFree(d); }
+};
+
 struct pa_level {
   pa_ctx* ctx = nullptr;
   std::vector<DBox> boxes;
@@ -182,6 +190,7 @@ struct pa_level {
   mutable std::map<int, std::unique_ptr<struct FbLocal>> fb_local;                     // local FillBoundary as copy regions, by ghost width (pa_dist.hip)
   mutable std::map<std::pair<long long, int>, std::unique_ptr<struct CsPlan>> cs_plans; // coarse-source plans by (coarse level serial, mode)
   mutable std::unique_ptr<struct RepPlan> rep_plan;                                     // the level replicated on every rank (pa_dist.hip)
+  mutable std::map<long long, std::unique_ptr<WgTab>> wgtabs;                           // sweep workgroup tables by (group, tile shape) (pa_fused.hip)
   mutable std::map<long long, std::unique_ptr<struct RsPlan>> rs_plans;                 // restriction onto a sharded coarse level, by coarse level serial (pa_dist.hip)
   mutable std::map<std::pair<long long, int>, std::unique_ptr<struct FpPlan>> fp_plans; // FillPatchTwoLevels parent lists by (coarse level serial, ghost width) (pa_filter.hip)
   ~pa_level();

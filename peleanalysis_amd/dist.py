@@ -77,6 +77,17 @@ def plan_coarse_source(fine: Level, fowner, crse: Level, cowner, rank: int, mode
                  _i3(crse.domlo), _i3(crse.domhi), _i3(fine.is_per), int(rank), int(mode), int(ng), int(halo))
 
 
+def plan_restriction(fine: Level, fowner, crse: Level, cowner, rank: int, which: int, ratio: int = 2) -> np.ndarray:
+    """rows {kind, peer, global box, lo[3], hi[3]} of one restriction plan of the distributed smoothing solve (which = 0: child
+    averages, 1 + 2 * dir + side: the flux register of that face orientation); kind 0 send (fine box), 1 receive (coarse box),
+    3 / 4 source / destination of a same-rank copy"""
+    lib = capi.load_library()
+    fb, cb = np.ascontiguousarray(fine.boxes, dtype=np.int32), np.ascontiguousarray(crse.boxes, dtype=np.int32)
+    fo, co = np.ascontiguousarray(fowner, dtype=np.int32), np.ascontiguousarray(cowner, dtype=np.int32)
+    return _rows(lib.pa_plan_restriction, fine.nboxes, _pi32(fb), _pi32(fo), _i3(fine.domlo), _i3(fine.domhi), crse.nboxes, _pi32(cb), _pi32(co),
+                 _i3(crse.domlo), _i3(crse.domhi), _i3(fine.is_per), int(rank), int(ratio), int(which))
+
+
 # ------------------------------------------------------------------------------- numpy pack / unpack (CPU-tier tests)
 def host_region(mf: MultiFab, b: int, lo, hi, comp: int, ncomp: int) -> np.ndarray:
     """view of components comp..comp+ncomp of box b (local index) over the index-space region lo..hi (ghost cells allowed)"""

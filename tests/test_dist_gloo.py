@@ -298,3 +298,89 @@ def test_coarse_source_plan_on_general_boxarrays_covers_the_neighbours_view(seed
                 assert np.array_equal(s[:, 2:], want[:, 2:])
         if l == 1 and seed == 0:
             assert nchecked > 0, (seed, l)  # this draw does contain boxes with mixed faces on level 1
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_restriction_plans_of_the_distributed_smoothing_solve(seed):
+    """pa_plan_restriction (host arithmetic behind pa_smooth_solve on sharded levels): on general BoxArrays dealt to 3 ranks
+    with scattered owners, (a) what a rank sends to a peer and what that peer expects from it pair up region by region, the
+    destination being the source folded into the coarse domain; (b) the child averages reach every covered coarse cell exactly
+    once; (c) per face orientation, every coarse cell across a coarse-fine face of the fine level receives exactly one flux
+    from the ghost slab behind that face -- and no coarse cell receives two of one orientation."""
+    from peleanalysis_amd.hierarchy import union_hierarchy, _occupancy
+    H = union_hierarchy(7100 + seed)
+    nranks = 3
+    for l in range(1, H.nlev):
+        fine, crse = H.levels[l], H.levels[l - 1]
+        assert not fine.domlo.any() and not crse.domlo.any()
+        fown, cown = scattered_owner(fine.nboxes, nranks, 41 + l), scattered_owner(crse.nboxes, nranks, 43 + l)
+        ncr = (crse.domhi - crse.domlo + 1).astype(np.int64)
+        cocc, focc = _occupancy(crse), _occupancy(fine)
+        covered = focc[::2, ::2, ::2]
+        cfb = fine.boxes.copy()
+        cfb[:, :3] //= 2
+        cfb[:, 3:] //= 2
+        for which in range(7):
+            rows = [padist.plan_restriction(fine, fown, crse, cown, r, which) for r in range(nranks)]
+            got = np.zeros(cocc.shape, np.int32)
+
+            def dst_mark(row, r):
+                cb = crse.boxes[row[2]]
+                assert cown[row[2]] == r and np.all(row[3:6] >= cb[:3]) and np.all(row[6:9] <= cb[3:]), "destination inside a coarse box of the receiver"
+                got[row[5]:row[8] + 1, row[4]:row[7] + 1, row[3]:row[6] + 1] += 1
+
+            def src_check(row, r):
+                b = cfb[row[2]]
+                assert fown[row[2]] == r
+                if which == 0:
+                    assert np.all(row[3:6] >= b[:3]) and np.all(row[6:9] <= b[3:]), "source inside the coarsened fine box"
+                else:
+                    d, side = (which - 1) >> 1, (which - 1) & 1
+                    for t in range(3):
+                        if t == d:
+                            assert row[3 + t] == row[6 + t] == (b[3 + t] + 1 if side else b[t] - 1), "source in the ghost slab behind the face"
+                        else:
+                            assert row[3 + t] >= b[t] and row[6 + t] <= b[3 + t]
+
+            def pair_check(src, dst):
+                assert np.array_equal(src[6:9] - src[3:6], dst[6:9] - dst[3:6]), "same shape on both sides"
+                sh = src[3:6] - dst[3:6]
+                for t in range(3):
+                    assert sh[t] == 0 or (which > 0 and crse.is_per[t] and abs(sh[t]) == ncr[t]), "destination = source folded through a periodic image"
+
+            for r in range(nranks):
+                R = rows[r]
+                for row in R[R[:, 0] == 0]:
+                    src_check(row, r)
+                for row in R[R[:, 0] == 1]:
+                    dst_mark(row, r)
+                loc_s, loc_d = R[R[:, 0] == 3], R[R[:, 0] == 4]
+                assert len(loc_s) == len(loc_d)
+                for a, b in zip(loc_s, loc_d):
+                    src_check(a, r)
+                    dst_mark(b, r)
+                    pair_check(a, b)
+                for q in range(nranks):
+                    if q == r:
+                        continue
+                    snd = R[(R[:, 0] == 0) & (R[:, 1] == q)]
+                    rcv = rows[q][(rows[q][:, 0] == 1) & (rows[q][:, 1] == r)]
+                    assert len(snd) == len(rcv), f"rank {r} -> {q}: {len(snd)} regions sent, {len(rcv)} expected"
+                    for a, b in zip(snd, rcv):
+                        pair_check(a, b)
+            if which == 0:
+                assert np.array_equal(got, (covered & cocc).astype(np.int32)), "every covered coarse cell gets its child average exactly once"
+            else:
+                d, side = (which - 1) >> 1, (which - 1) & 1
+                want = np.zeros(cocc.shape, np.int32)
+                for b in cfb:
+                    lo, hi = b[:3].copy(), b[3:].copy()
+                    lo[d] = hi[d] = b[3 + d] + 1 if side else b[d] - 1
+                    if lo[d] < 0 or lo[d] >= ncr[d]:
+                        if not crse.is_per[d]:
+                            continue
+                        lo[d] = hi[d] = lo[d] % ncr[d]
+                    sl = (slice(lo[2], hi[2] + 1), slice(lo[1], hi[1] + 1), slice(lo[0], hi[0] + 1))
+                    want[sl] += (cocc[sl] & ~covered[sl]).astype(np.int32)
+                assert want.max() <= 1 and got.max() <= 1, "one flux per coarse cell and face orientation"
+                assert np.all(got[want == 1] == 1), "every coarse cell across a coarse-fine face receives its flux"

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """A/B of an environment switch the library reads per pass, inside ONE process (the clock a box holds drifts by more than
 the effects worth measuring: alternate short blocks and compare medians).
-usage: ab_driver.py VAR [base=512] [box=128] [blocks=8] [steps=15] [valA=1] [valB=0] [threshold=-1]"""
+usage: ab_driver.py VAR [base=512] [box=128] [blocks=8] [steps=15] [valA=1] [valB=0] [threshold=-1]
+(box = 0: the irregular hierarchy of bench.py's secondary.irregular_amr instead of the nested one)"""
 import os
 import statistics
 import sys
@@ -11,7 +12,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from peleanalysis_amd import capi  # noqa: E402
-from peleanalysis_amd.hierarchy import MultiFab, nested_hierarchy  # noqa: E402
+from peleanalysis_amd.hierarchy import MultiFab, field_flame, nested_hierarchy, tagged_hierarchy  # noqa: E402
 
 var = sys.argv[1]
 base = int(sys.argv[2]) if len(sys.argv) > 2 else 512
@@ -21,7 +22,10 @@ steps = int(sys.argv[5]) if len(sys.argv) > 5 else 15
 VA = sys.argv[6] if len(sys.argv) > 6 else "1"
 VB = sys.argv[7] if len(sys.argv) > 7 else "0"
 THR = float(sys.argv[8]) if len(sys.argv) > 8 else -1.0
-H = nested_hierarchy(base, 3, box, is_per=(1, 1, 0))
+if box:
+    H = nested_hierarchy(base, 3, box, is_per=(1, 1, 0))
+else:
+    H = tagged_hierarchy(base, 3, lambda x, y, z: field_flame(x, y, z, 0), bf=16, max_box=128, base_box=128, frac=(0.08, 0.16), is_per=(1, 1, 0))
 bc = capi.bc_from_flags((1, 1, 0))
 ctx = capi.Context(0)
 dls = [capi.DevLevel(ctx, lv) for lv in H.levels]
