@@ -296,6 +296,10 @@ def secondary(ctx, torch, stream, dev, only=None):
         keep_f = [k.clone() for k in keep[2::3]]  # the output multifabs of the three levels
         ms_pp = timed(lambda: capi.gradcurv_run(ctx, st, 0, bci, capi.curv_params(prog_min=300.0, prog_max=2003.0, threshold=None, fused=False), wk, ou, 0), reps=1)
         ctx.sync()
+        gou = [alloc(lv, dl, 4, 0) for lv, dl in zip(Hi.levels, dli)]  # the gradient tool's pass on the same BoxArrays (40 B/cell)
+        stream.synchronize()
+        ms_grad = timed(lambda: capi.grad_run(ctx, st, 0, bci, [g[1] for g in gou], 0))
+        del gou
         ndiff = 0
         for a, b_ in zip(keep_f, keep[2::3]):
             ndiff += int((a.view(torch.int64) != b_.view(torch.int64)).sum().item())
@@ -306,6 +310,7 @@ def secondary(ctx, torch, stream, dev, only=None):
                                      boxes_32_64_96_128_wide_per_level=widths, irregular_cells_per_level=nirr, irregular_cell_share=sum(nirr) / ci,
                                      share_of_boxes_on_fused_pipeline=1.0 if ("CG=1" in kn or "march3_levels" in kn) else 0.0, sweep_kernel=kn,
                                      pass_by_pass_ms=ms_pp, pass_by_pass_frac_hbm=ci * 72 / (ms_pp * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                     grad_only_ms=ms_grad, grad_only_frac_hbm=ci * 40 / (ms_grad * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                      fused_vs_pass_by_pass_values_differing=ndiff,
                                      workload="fused grad->curvature, 3-level AMR, base 512^3, levels 1-2 = the blocks of 32 fine cells with the largest |grad T| (8 % / 16 % of "
                                               "the coarser level's blocks: the wrinkled flame sheet), boxes of 32..128 cells per side, 1 comp, periodic x/y + wall z; "

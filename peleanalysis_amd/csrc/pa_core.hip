@@ -15,6 +15,51 @@ int pa_fail(pa_ctx* ctx, const std::string& msg) {
 
 extern "C" int pa_version(void) { return 100; }
 
+// Workgroup table of a sweep over boxes that differ in size (MarchArgs::wgtab, GradMarchArgs::wgtab), cached on the level per
+// box class (0: wider than 32 cells, 1: at most 32, 2: all) and tile shape.  Null when the order-2 arithmetic (every box takes
+// the tile count of the largest) wastes less than a tenth of the launch and the caller does not insist -- the regular tilings
+// keep the launch they were tuned on.
+const WgTab* pa_sweep_wgtab(const pa_level* L, int cls, int tw, int mty, int kseg, bool force) {
+  const long long key = ((long long)cls << 56) | ((long long)(force ? 1 : 0) << 52) | ((long long)tw << 40) | ((long long)mty << 24) | (long long)kseg;
+  auto it = L->wgtabs.find(key);
+  if (it != L->wgtabs.end()) return it->second->d ? it->second.get() : nullptr;
+  std::unique_ptr<WgTab> T(new WgTab());
+  std::vector<std::pair<int, int>> bt;  // (tiles, box)
+  long long real = 0;
+  int tmax = 0;
+  for (int b = 0; b < (int)L->boxes.size(); ++b) {
+    const DBox& B = L->boxes[b];
+    const int nx = B.hi[0] - B.lo[0] + 1, ny = B.hi[1] - B.lo[1] + 1, nz = B.hi[2] - B.lo[2] + 1;
+    if (cls != 2 && (nx <= 32) != (cls == 1)) continue;
+    const int t = ((nx + tw - 1) / tw) * ((ny + mty - 1) / mty) * ((nz + kseg - 1) / kseg);
+    bt.push_back({t, b});
+    real += t;
+    tmax = std::max(tmax, t);
+  }
+  const long long launched = (long long)tmax * 8 * (((long long)bt.size() + 7) / 8);
+  if (!bt.empty() && (force || launched * 10 > real * 11)) {
+    std::stable_sort(bt.begin(), bt.end(), [](const auto& a, const auto& b) { return a.first > b.first; });  // large boxes first; 8 neighbours in this order share a chunk
+    std::vector<int> tab;
+    for (size_t c = 0; c < bt.size(); c += 8)
+      for (int t = 0; t < bt[c].first; ++t)
+        for (size_t j = c; j < c + 8; ++j) {
+          const bool has = j < bt.size() && t < bt[j].first;
+          tab.push_back(has ? bt[j].second : -1);
+          tab.push_back(has ? t : 0);
+        }
+    if (hipMalloc(&T->d, sizeof(int) * tab.size()) == hipSuccess && hipMemcpy(T->d, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice) == hipSuccess) {
+      T->n = (unsigned)(tab.size() / 2);
+    } else {
+      if (T->d) (void)hipFree(T->d);
+      T->d = nullptr;
+      (void)hipGetLastError();  // no table: the order-2 launch does the same work
+    }
+  }
+  const WgTab* raw = T.get();
+  L->wgtabs[key] = std::move(T);
+  return raw->d ? raw : nullptr;
+}
+
 extern "C" pa_ctx* pa_ctx_create(int device, void* hip_stream) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device >= ndev) return nullptr;

@@ -1429,51 +1429,10 @@ static void sweep_groups(int l, const pa_level* L, std::vector<SweepGroup>& out)
   out.push_back({l, L->d_blist + L->nwide, L->nnarrow, {L->nmax[0], L->nmax[1], L->nmax[2]}});
 }
 
-// Workgroup table of a sweep group whose boxes differ in size (MarchArgs::wgtab), cached on the level per tile shape; null when
-// the order-2 arithmetic (every box takes the tile count of the largest) wastes less than a tenth of the launch -- the regular
-// tilings keep the launch they were tuned on.  PA_SWEEP_WGTAB=0: never (A/B).
 static const WgTab* sweep_wgtab(const pa_level* L, const SweepGroup& g, int tw, int mty, int kseg) {
   const char* e = getenv("PA_SWEEP_WGTAB");  // read per pass (tools/ab_driver.py)
   if ((e && !atoi(e)) || g.n <= 0) return nullptr;
-  const int cls = !g.list ? 2 : (g.list == L->d_blist ? 0 : 1);  // whole level / the wide boxes / the narrow boxes
-  const long long key = ((long long)cls << 56) | ((long long)tw << 40) | ((long long)mty << 24) | (long long)kseg;
-  auto it = L->wgtabs.find(key);
-  if (it != L->wgtabs.end()) return it->second->d ? it->second.get() : nullptr;
-  std::unique_ptr<WgTab> T(new WgTab());
-  std::vector<std::pair<int, int>> bt;  // (tiles, box)
-  long long real = 0;
-  int tmax = 0;
-  for (int b = 0; b < (int)L->boxes.size(); ++b) {
-    const DBox& B = L->boxes[b];
-    const int nx = B.hi[0] - B.lo[0] + 1, ny = B.hi[1] - B.lo[1] + 1, nz = B.hi[2] - B.lo[2] + 1;
-    if (cls != 2 && (nx <= 32) != (cls == 1)) continue;
-    const int t = ((nx + tw - 1) / tw) * ((ny + mty - 1) / mty) * ((nz + kseg - 1) / kseg);
-    bt.push_back({t, b});
-    real += t;
-    tmax = std::max(tmax, t);
-  }
-  const long long launched = (long long)tmax * 8 * (((long long)bt.size() + 7) / 8);
-  if ((int)bt.size() == g.n && launched * 10 > real * 11) {
-    std::stable_sort(bt.begin(), bt.end(), [](const auto& a, const auto& b) { return a.first > b.first; });  // large boxes first; 8 neighbours in this order share a chunk
-    std::vector<int> tab;
-    for (size_t c = 0; c < bt.size(); c += 8)
-      for (int t = 0; t < bt[c].first; ++t)
-        for (size_t j = c; j < c + 8; ++j) {
-          const bool has = j < bt.size() && t < bt[j].first;
-          tab.push_back(has ? bt[j].second : -1);
-          tab.push_back(has ? t : 0);
-        }
-    if (hipMalloc(&T->d, sizeof(int) * tab.size()) == hipSuccess && hipMemcpy(T->d, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice) == hipSuccess) {
-      T->n = (unsigned)(tab.size() / 2);
-    } else {
-      if (T->d) (void)hipFree(T->d);
-      T->d = nullptr;
-      (void)hipGetLastError();  // no table: the order-2 launch does the same work
-    }
-  }
-  const WgTab* raw = T.get();
-  L->wgtabs[key] = std::move(T);
-  return raw->d ? raw : nullptr;
+  return pa_sweep_wgtab(L, !g.list ? 2 : (g.list == L->d_blist ? 0 : 1), tw, mty, kseg, false);
 }
 
 // the sweep with exact normals (the level's compact ghost arrays must be current: pa_gradcurv_prep_level)

@@ -21,6 +21,7 @@ struct GradLds {
 
 struct GradMarchArgs {
   int comp, ocomp, kseg, nboxes, tiles_max;
+  const int* wgtab = nullptr;  // boxes of different sizes: workgroup i = tile wgtab[2 i + 1] of box wgtab[2 i] (< 0: none); see MarchArgs::wgtab
 };
 
 template <typename BP, int TY>
@@ -32,10 +33,17 @@ __global__ __launch_bounds__(64 * (TY + 3)) void k_grad_march(BP bp, GradMarchAr
   static_assert(2 * ROWS <= 64, "the edge wavefront serves two columns of every row");
   // XCD-aware order (MarchArgs order 2): block 8*T*g + 8*t + q works on tile t of box 8*g + q
   unsigned bid = blockIdx.x;
-  const unsigned per8 = 8u * (unsigned)A.tiles_max, grp = bid / per8, rem = bid % per8;
-  const int box = (int)(grp * 8u + (rem & 7u));
-  bid = rem >> 3;
-  if (box >= A.nboxes) return;
+  int box;
+  if (A.wgtab) {
+    box = A.wgtab[2 * bid];
+    if (box < 0) return;
+    bid = (unsigned)A.wgtab[2 * bid + 1];
+  } else {
+    const unsigned per8 = 8u * (unsigned)A.tiles_max, grp = bid / per8, rem = bid % per8;
+    box = (int)(grp * 8u + (rem & 7u));
+    bid = rem >> 3;
+    if (box >= A.nboxes) return;
+  }
   if (!bp.get(box, P, O, V, dxinv)) return;
   const int comp = A.comp, kseg = A.kseg;
   const int nx = V.hi[0] - V.lo[0] + 1, ny = V.hi[1] - V.lo[1] + 1, nz = V.hi[2] - V.lo[2] + 1;
@@ -203,10 +211,17 @@ __global__ __launch_bounds__(64 * (NRW + 2)) void k_grad_marchn(BP bp, GradMarch
   constexpr int MTY2 = 2 * NRW, ROWS = MTY2 + 2;
   static_assert(2 * ROWS <= 64, "the edge wavefront serves two columns of every row");
   unsigned bid = blockIdx.x;
-  const unsigned per8 = 8u * (unsigned)A.tiles_max, grp = bid / per8, rem = bid % per8;
-  const int box = (int)(grp * 8u + (rem & 7u));
-  bid = rem >> 3;
-  if (box >= A.nboxes) return;
+  int box;
+  if (A.wgtab) {
+    box = A.wgtab[2 * bid];
+    if (box < 0) return;
+    bid = (unsigned)A.wgtab[2 * bid + 1];
+  } else {
+    const unsigned per8 = 8u * (unsigned)A.tiles_max, grp = bid / per8, rem = bid % per8;
+    box = (int)(grp * 8u + (rem & 7u));
+    bid = rem >> 3;
+    if (box >= A.nboxes) return;
+  }
   if (!bp.get(box, P, O, V, dxinv)) return;
   const int comp = A.comp, kseg = A.kseg;
   const int nx = V.hi[0] - V.lo[0] + 1, ny = V.hi[1] - V.lo[1] + 1, nz = V.hi[2] - V.lo[2] + 1;

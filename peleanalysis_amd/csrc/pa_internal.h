@@ -214,6 +214,7 @@ struct LevelSpec {
 pa_level* pa_level_create_spec(pa_ctx* ctx, const LevelSpec& S, const int32_t domlo[3], const int32_t domhi[3], const int32_t is_per[3],
                                const double prob_lo[3], const double prob_hi[3]);
 bool pa_face_is_special(const pa_level* L, const DBox& B, int d, int side);
+const WgTab* pa_sweep_wgtab(const pa_level* L, int cls, int tw, int mty, int kseg, bool force);
 int pa_host_classify(const pa_level* L, int i, int j, int k);
 
 struct pa_mf {

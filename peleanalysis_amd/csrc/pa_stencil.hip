@@ -43,7 +43,7 @@ __global__ __launch_bounds__(64 * TY) void k_grad(BP bp, int comp, int ocomp, in
 }
 
 template <typename BP>
-static void grad_launch(hipStream_t st, const BP& bp, int nx, int ny, int nz, unsigned nboxes, int comp, int ocomp) {
+static void grad_launch(hipStream_t st, const BP& bp, int nx, int ny, int nz, unsigned nboxes, int comp, int ocomp, const pa_level* L = nullptr) {
   static const int ty_env = [] { const char* e = getenv("PA_GRAD_TY"); return e ? atoi(e) : 4; }();  // sweep (tools/grad_sweep.py): 1.34-1.51 ms, best 4 x 32
   static const int tz_env = [] { const char* e = getenv("PA_GRAD_TZ"); return e ? atoi(e) : 32; }();
   // PA_GRAD_MARCH (default 1): the k-marching kernel of pa_grad_march.h for boxes wider than half a wavefront.
@@ -53,13 +53,21 @@ static void grad_launch(hipStream_t st, const BP& bp, int nx, int ny, int nz, un
   const char* ke = getenv("PA_GRAD_KSEG");  // read per launch: the tests switch them
   const char* me = getenv("PA_GRAD_MTY");
   const int kseg_env = ke ? atoi(ke) : 16, mty_env = me ? atoi(me) : 0;
-  if (march_env && nx > 32) {
-    GradMarchArgs A{comp, ocomp, std::max(1, std::min(kseg_env, nz)), (int)nboxes, 0};
-    const int mty = mty_env ? mty_env : (ny >= 52 ? 13 : (ny >= 16 ? 8 : 4));
+  // boxes wider than 32 cells: a row per wavefront; at most 32: two rows per wavefront (k_grad_marchn).  A level that holds both
+  // kinds, or boxes of different sizes, takes a workgroup table per kind (pa_sweep_wgtab): no box is swept by the wrong kernel
+  // and no workgroup is launched for a tile its box does not have.
+  const char* te = getenv("PA_SWEEP_WGTAB");  // read per launch (tools/ab_driver.py)
+  const bool tables = L && !(te && !atoi(te));
+  auto table = [&](int cls, int tw, int mty, int kseg, bool force) -> const WgTab* { return tables ? pa_sweep_wgtab(L, cls, tw, mty, kseg, force) : nullptr; };
+  auto wide = [&](int wx, int wy, int wz, int cls, bool force) {
+    GradMarchArgs A{comp, ocomp, std::max(1, std::min(kseg_env, wz)), (int)nboxes, 0};
+    const int mty = mty_env ? mty_env : (wy >= 52 ? 13 : (wy >= 16 ? 8 : 4));
     auto go = [&](auto tyc) {
       constexpr int M = decltype(tyc)::value;
-      A.tiles_max = ((nx + 63) / 64) * ((ny + M - 1) / M) * ((nz + A.kseg - 1) / A.kseg);
-      const dim3 g((unsigned)A.tiles_max * 8u * ((nboxes + 7u) / 8u));
+      A.tiles_max = ((wx + 63) / 64) * ((wy + M - 1) / M) * ((wz + A.kseg - 1) / A.kseg);
+      const WgTab* wt = table(cls, 64, M, A.kseg, force);
+      if (wt) A.wgtab = wt->d;
+      const dim3 g(wt ? wt->n : (unsigned)A.tiles_max * 8u * ((nboxes + 7u) / 8u));
       hipLaunchKernelGGL((k_grad_march<BP, M>), g, dim3(64 * (M + 3)), 0, st, bp, A);
     };
     switch (mty) {
@@ -68,15 +76,28 @@ static void grad_launch(hipStream_t st, const BP& bp, int nx, int ny, int nz, un
       case 5: go(std::integral_constant<int, 5>{}); break;
       default: go(std::integral_constant<int, 4>{}); break;
     }
+  };
+  static const int narrow_env = [] { const char* e = getenv("PA_GRAD_NARROW"); return e ? atoi(e) : 1; }();  // 0: the tiled k_grad (A/B)
+  auto narrow = [&](int wx, int wy, int wz, int cls, bool force) {
+    constexpr int NRW = 8;
+    GradMarchArgs A{comp, ocomp, std::max(1, std::min(kseg_env, wz)), (int)nboxes, 0};
+    A.tiles_max = ((wx + 31) / 32) * ((wy + 2 * NRW - 1) / (2 * NRW)) * ((wz + A.kseg - 1) / A.kseg);
+    const WgTab* wt = table(cls, 32, 2 * NRW, A.kseg, force);
+    if (wt) A.wgtab = wt->d;
+    const dim3 g(wt ? wt->n : (unsigned)A.tiles_max * 8u * ((nboxes + 7u) / 8u));
+    hipLaunchKernelGGL((k_grad_marchn<BP, NRW>), g, dim3(64 * (NRW + 2)), 0, st, bp, A);
+  };
+  if (march_env && narrow_env && tables && L->nwide && L->nnarrow) {  // both kinds: two launches, each over its own boxes (the tables carry the
+    wide(L->wmax[0], L->wmax[1], L->wmax[2], 0, true);               // box lists; without one a launch covers every box, which either kernel can)
+    narrow(L->nmax[0], L->nmax[1], L->nmax[2], 1, true);
     return;
   }
-  static const int narrow_env = [] { const char* e = getenv("PA_GRAD_NARROW"); return e ? atoi(e) : 1; }();  // 0: the tiled k_grad (A/B)
-  if (march_env && narrow_env) {  // boxes at most 32 cells wide: two rows per wavefront (k_grad_marchn)
-    constexpr int NRW = 8;
-    GradMarchArgs A{comp, ocomp, std::max(1, std::min(kseg_env, nz)), (int)nboxes, 0};
-    A.tiles_max = ((nx + 31) / 32) * ((ny + 2 * NRW - 1) / (2 * NRW)) * ((nz + A.kseg - 1) / A.kseg);
-    const dim3 g((unsigned)A.tiles_max * 8u * ((nboxes + 7u) / 8u));
-    hipLaunchKernelGGL((k_grad_marchn<BP, NRW>), g, dim3(64 * (NRW + 2)), 0, st, bp, A);
+  if (march_env && nx > 32) {
+    wide(nx, ny, nz, 2, false);
+    return;
+  }
+  if (march_env && narrow_env) {
+    narrow(nx, ny, nz, 2, false);
     return;
   }
   const int tz = std::max(1, std::min(tz_env, nz));
@@ -98,7 +119,7 @@ extern "C" int pa_grad_level(pa_ctx* ctx, const pa_mf* phi, int comp, pa_mf* out
   const pa_level* L = phi->lev;
   if (phi->lev->boxes.empty()) return 0;  // a rank that owns no box of this level
   ProfScope prof(ctx, PA_TAG_GRAD);
-  grad_launch(ctx->stream, bp, L->maxn[0], L->maxn[1], L->maxn[2], (unsigned)L->boxes.size(), comp, ocomp);
+  grad_launch(ctx->stream, bp, L->maxn[0], L->maxn[1], L->maxn[2], (unsigned)L->boxes.size(), comp, ocomp, L);
   PA_HIP(hipGetLastError());
   return 0;
 }

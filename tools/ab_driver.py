@@ -40,13 +40,25 @@ for lv, dl in zip(H.levels, dls):
 params = capi.curv_params(prog_min=300.0, prog_max=2000.0, threshold=(THR if THR >= 0 else None), fused=True)
 
 
+GRAD = os.environ.get("PA_AB_GRAD", "0") == "1"  # time the gradient tool's pass (pa_grad_run) instead of grad->curvature
+if GRAD:
+    gouts = [capi.DevMF(ctx, dl, 4, 0) for dl in dls]
+
+
+def one():
+    if GRAD:
+        capi.grad_run(ctx, states, 0, bc, gouts, 0)
+    else:
+        capi.gradcurv_run(ctx, states, 0, bc, params, works, outs, 0)
+
+
 def block(val):
     os.environ[var] = val  # "1" vs "0": for a switch that is off by default, 0 is the current behaviour
-    capi.gradcurv_run(ctx, states, 0, bc, params, works, outs, 0)
+    one()
     ctx.sync()
     t0 = time.perf_counter()
     for _ in range(steps):
-        capi.gradcurv_run(ctx, states, 0, bc, params, works, outs, 0)
+        one()
     ctx.sync()
     return (time.perf_counter() - t0) / steps * 1e3
 
