@@ -418,7 +418,12 @@ int pa_curvature_run(pa_ctx*, int nlev, pa_mf* const* state, int comp, const int
 /* curvature.cpp:328-406: (I - dt Lap) sol = rhs[rcomp] as a composite solve over the levels (periodic /
  * homogeneous Neumann walls from bc, fine ghosts by applyBC, refluxed coarse-fine fluxes, covered coarse
  * cells = child averages), BiCGStab to ||b - A x||_inf <= tol ||b||_inf (the reference: 1e-12).  sol[lev]
- * comp scomp receives the solution on valid cells.  Refinement ratio 2, single rank.  Synchronous. */
+ * comp scomp receives the solution on valid cells.  Refinement ratio 2.  Synchronous.
+ * Levels from pa_level_create_sharded: the solve is DISTRIBUTED over the context's ranks -- every rank iterates on its own boxes,
+ * the restriction / ghost fills / flux register of one operator application cross ranks in nlev + 1 grouped exchanges
+ * (pa_plan_restriction lists two of them), every dot product is one allreduce of the transport -- and returns the one-rank field
+ * to the tolerance, not bit for bit; all ranks must call it together.  PA_SMOOTH_REPLICATED=1 in the environment: every rank
+ * gathers the right-hand side of the whole hierarchy and runs the one-rank solve (its bits; no speed-up). */
 int pa_smooth_solve(pa_ctx*, int nlev, pa_mf* const* rhs, int rcomp, pa_mf* const* sol, int scomp, double dt,
                     const int32_t bc[3], double tol, int maxiter, int* iters, double* rel_residual);
 /* fused grad+curvature of one variable: out[lev] comps ocomp+0..3 = gx,gy,gz,|g|,
