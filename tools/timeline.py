@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Timeline of one bench step from a rocprofv3 --kernel-trace csv: per kernel start (us from the step's first
+"""usage: timeline.py <trace dir> [launches of the marker kernel per step = 3] [marker kernel = k_gradcurv_march3]
+Timeline of one bench step from a rocprofv3 --kernel-trace csv: per kernel start (us from the step's first
 kernel), duration, stream/queue; and sum-of-durations against the busy union (how much ran concurrently)."""
 import csv, sys, glob
 path = sys.argv[1]
@@ -7,7 +8,8 @@ f = glob.glob(path + '/**/*kernel_trace.csv', recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 # last step: find the last 3 k_gradcurv_march3 launches and the window around them
-idx = [i for i, r in enumerate(rows) if 'k_gradcurv_march3' in r['Kernel_Name']]
+pat = sys.argv[3] if len(sys.argv) > 3 else 'k_gradcurv_march3'  # the kernel that ends a step, launched nlev times per step
+idx = [i for i, r in enumerate(rows) if pat in r['Kernel_Name']]
 nlev = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 first_sweep = idx[-nlev]
 prev_sweep = idx[-nlev - 1]
