@@ -65,6 +65,9 @@ int pa_profile_enable(pa_ctx*, int on);
 /* which variant of the fused grad->curvature sweep the last pa_gradcurv_* call launched, e.g.
  * "k_gradcurv_march3<MTY=13,CLIP=0,PAIR=0,CG=1>" (bench.py keys the committed PMC traffic figure on it) */
 const char* pa_sweep_kernel_name(const pa_ctx*);
+/* diagnostic: workgroups of the all-levels sweep kernel the runtime keeps resident per CU (which = 0: boxes wider than 32 cells,
+ * 1: the narrow-box kernel); < 0: the query failed */
+int pa_sweep_occupancy(pa_ctx*, int which);
 /* diagnostic: cells that the clip-aware curvature fix-up of the last fused pass (threshold_prog, curvature.cpp:549-570) had to
  * recompute through its general path because a neighbour's normal was clipped; -1 if that path has never run.  Synchronous. */
 int pa_last_slow_cells(pa_ctx*);

@@ -89,6 +89,7 @@ def load_library() -> C.CDLL:
         "pa_device_count": (C.c_int, []),
         "pa_profile_enable": (C.c_int, [vp, C.c_int]),
         "pa_sweep_kernel_name": (C.c_char_p, [vp]),
+        "pa_sweep_occupancy": (C.c_int, [vp, C.c_int]),
         "pa_profile_read": (C.c_int, [vp, C.c_int, C.POINTER(i64), pdbl, C.c_int]),
         "pa_level_create": (vp, [vp, C.c_int, pi32, pi32, pi32, pi32, pdbl, pdbl]),
         "pa_level_create_sharded": (vp, [vp, C.c_int, pi32, pi32, C.c_int, C.c_int, pi32, pi32, pi32, pdbl, pdbl]),

@@ -592,6 +592,20 @@ static void march_launch(hipStream_t st, const BP& bp, int nx, int ny, int nz, u
   }
 }
 
+// diagnostic: workgroups of a sweep kernel the runtime's occupancy query admits per CU (which = 0: the wide all-levels sweep, 13 rows;
+// 1: the narrow all-levels sweep, 2 x 8 rows).  < 0: the query failed.  NOTE (profiles/r04_wg_residency.txt): the query says 2 for the
+// narrow kernel (640 threads, 56 KB of LDS, 80 VGPRs) but per-workgroup clocks show exactly ONE resident per CU; 512-thread variants
+// of the same kernel are admitted two per CU.
+extern "C" int pa_sweep_occupancy(pa_ctx* ctx, int which) {
+  PaBind bind_(ctx);
+  if (!ctx) return -1;
+  int nb = -1;
+  hipError_t e = which == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_gradcurv_march3_levels<13, false>, 64 * 16, 0)
+                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_gradcurv_march3n_levels<8, false>, 64 * 10, 0);
+  if (e != hipSuccess) { (void)hipGetLastError(); return -1; }
+  return nb;
+}
+
 extern "C" int pa_gradcurv_level(pa_ctx* ctx, const pa_mf* phi, int pcomp, double pmin, double pmax, double thr, pa_mf* out, int ocomp) {
   PaBind bind_(ctx);
   if (!ctx || !phi || !out) return pa_fail(ctx, "pa_gradcurv_level: null argument");
