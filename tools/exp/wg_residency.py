@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Experiment: residency of the narrow sweep's workgroups from the per-workgroup {start, end, HW_ID, XCC_ID} records that
-PA_SWEEP_DBG=<file> makes the library dump (level 0 of the hierarchy).  usage: wg_residency.py <file>"""
+PA_SWEEP_DBG=<file> made an INSTRUMENTED build of the library dump (level 0 of the hierarchy; the instrumentation -- wall_clock64 and
+HW_ID / XCC_ID of lane 0 at the start and end of a workgroup of gradcurv_march3n_body -- was removed after the measurement, see
+profiles/r04_small_experiments.txt).  usage: wg_residency.py <file>"""
 import sys
 import numpy as np
 a = np.fromfile(sys.argv[1], dtype=np.int64).reshape(-1, 4)
