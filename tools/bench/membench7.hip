@@ -13,14 +13,14 @@
 #include <vector>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
-struct Cfg { const char* name; int nx, ny, nz, wcols, waves, ipw, xsplit, kseg; };
+struct Cfg { const char* name; int nx, ny, nz, wcols, waves, ipw, xsplit, kseg; int idle = 0; };  // idle: extra waves that only take part in the barrier (halo / edge waves: the workgroup's size decides how many are resident per CU)
 
 __global__ __launch_bounds__(1024) void k_tiles(const double* __restrict__ in, double* __restrict__ out, int nx, int ny, int nz, int wcols, int ipw, int xsplit, int kseg,
-                                                 long long cs, int nboxes, int tiles) {
+                                                 long long cs, int nboxes, int tiles, int idle) {
   const unsigned per8 = 8u * (unsigned)tiles, g = blockIdx.x / per8, r = blockIdx.x % per8;
   const int box = (int)(g * 8u + (r & 7u)), tile = (int)(r >> 3);
   if (box >= nboxes) return;
-  const int waves = blockDim.x >> 6, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int waves = (blockDim.x >> 6) - idle, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int rpw = 64 / wcols;                       // rows per wave instruction
   const int R = waves * rpw * (xsplit ? 1 : ipw);   // rows per tile
   const int tcols = xsplit ? wcols * ipw : wcols;   // columns per tile
@@ -31,7 +31,7 @@ __global__ __launch_bounds__(1024) void k_tiles(const double* __restrict__ in, d
   const double* ib = in + box * boxcells;
   double* ob = out + box * 8 * cs;
   for (int k = k0; k < k1; ++k) {
-    for (int q = 0; q < ipw; ++q) {
+    for (int q = 0; q < ipw && w < waves; ++q) {
       const int col = bx * tcols + (xsplit ? q * wcols : 0) + lane % wcols;
       int row = by * R + (xsplit ? w * rpw : (w * ipw + q) * rpw) + lane / wcols;
       row = min(row, ny - 1);  // rows past a partial tile repeat the last one (as the sweeps do)
@@ -62,6 +62,11 @@ int main(int argc, char** argv) {
       {"32^3 boxes, 32 x 32 tile: the whole plane of a box per workgroup", 32, 32, 32, 32, 8, 2, 0, 32},
       {"32^3 boxes, 32 x 32 tile, 16 waves", 32, 32, 32, 32, 16, 1, 0, 32},
       {"128^3 boxes, 64 x 16 tile (16 row waves, no halo / edge wave)", 128, 128, 128, 64, 16, 1, 0, 64},
+      {"32^3 boxes, 32 x 16 tile + 2 idle waves = 640 threads (the narrow sweep's workgroup)", 32, 32, 32, 32, 8, 1, 0, 32, 2},
+      {"32^3 boxes, 32 x 32 tile, two row pairs per lane + 2 idle waves = 640 threads", 32, 32, 32, 32, 8, 2, 0, 32, 2},
+      {"32^3 boxes, 32 x 12 tile + 2 idle waves = 512 threads", 32, 32, 32, 32, 6, 1, 0, 32, 2},
+      {"128^3 boxes, 64 x 13 tile + 3 idle waves = 1024 threads (the wide sweep's workgroup)", 128, 128, 128, 64, 13, 1, 0, 64, 3},
+      {"64^3 boxes, 64 x 13 tile + 3 idle waves = 1024 threads", 64, 64, 64, 64, 13, 1, 0, 64, 3},
   };
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -76,7 +81,7 @@ int main(int argc, char** argv) {
       float best = 1e9f;
       for (int it = 0; it < 4; ++it) {
         CK(hipEventRecord(e0, 0));
-        hipLaunchKernelGGL(k_tiles, dim3(grid), dim3(64 * c.waves), 0, 0, in, out, c.nx, c.ny, c.nz, c.wcols, c.ipw, c.xsplit, c.kseg, cs, nboxes, tiles);
+        hipLaunchKernelGGL(k_tiles, dim3(grid), dim3(64 * (c.waves + c.idle)), 0, 0, in, out, c.nx, c.ny, c.nz, c.wcols, c.ipw, c.xsplit, c.kseg, cs, nboxes, tiles, c.idle);
         CK(hipEventRecord(e1, 0));
         CK(hipEventSynchronize(e1));
         float ms;
@@ -84,7 +89,7 @@ int main(int argc, char** argv) {
         if (it) best = ms < best ? ms : best;
       }
       if (rep) printf("%-72s rows/tile %2d  contiguous run %5.1f KiB  workgroups %6u x %4d threads: %.3f ms = %.2f TB/s (72 B/cell)\n", c.name, R,
-                      (c.nx == tcols ? R : 1) * tcols * 8 / 1024.0, grid, 64 * c.waves, best, cells * 72.0 / (best * 1e-3) / 1e12);
+                      (c.nx == tcols ? R : 1) * tcols * 8 / 1024.0, grid, 64 * (c.waves + c.idle), best, cells * 72.0 / (best * 1e-3) / 1e12);
     }
   return 0;
 }
