@@ -16,7 +16,7 @@
 struct Cfg { const char* name; int nx, ny, nz, wcols, waves, ipw, xsplit, kseg; int idle = 0; };  // idle: extra waves that only take part in the barrier (halo / edge waves: the workgroup's size decides how many are resident per CU)
 
 __global__ __launch_bounds__(1024) void k_tiles(const double* __restrict__ in, double* __restrict__ out, int nx, int ny, int nz, int wcols, int ipw, int xsplit, int kseg,
-                                                 long long cs, int nboxes, int tiles, int idle) {
+                                                 long long cs, int nboxes, int tiles, int idle, int nsleep) {
   const unsigned per8 = 8u * (unsigned)tiles, g = blockIdx.x / per8, r = blockIdx.x % per8;
   const int box = (int)(g * 8u + (r & 7u)), tile = (int)(r >> 3);
   if (box >= nboxes) return;
@@ -41,11 +41,13 @@ __global__ __launch_bounds__(1024) void k_tiles(const double* __restrict__ in, d
       for (int c = 0; c < 8; ++c) ob[c * cs + o] = v + c;
     }
     __syncthreads();
+    for (int z = 0; z < nsleep; ++z) __builtin_amdgcn_s_sleep(16);  // ~1024 cycles each: the compute / LDS phase of a real step (argv[1])
   }
 }
 
 int main(int argc, char** argv) {
   const int N = 512;
+  const int nsleep = argc > 1 ? atoi(argv[1]) : 0;
   const long long cells = (long long)N * N * N;
   double *in, *out;
   CK(hipMalloc(&in, cells * 8));
@@ -81,7 +83,7 @@ int main(int argc, char** argv) {
       float best = 1e9f;
       for (int it = 0; it < 4; ++it) {
         CK(hipEventRecord(e0, 0));
-        hipLaunchKernelGGL(k_tiles, dim3(grid), dim3(64 * (c.waves + c.idle)), 0, 0, in, out, c.nx, c.ny, c.nz, c.wcols, c.ipw, c.xsplit, c.kseg, cs, nboxes, tiles, c.idle);
+        hipLaunchKernelGGL(k_tiles, dim3(grid), dim3(64 * (c.waves + c.idle)), 0, 0, in, out, c.nx, c.ny, c.nz, c.wcols, c.ipw, c.xsplit, c.kseg, cs, nboxes, tiles, c.idle, nsleep);
         CK(hipEventRecord(e1, 0));
         CK(hipEventSynchronize(e1));
         float ms;
