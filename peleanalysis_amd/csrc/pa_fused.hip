@@ -717,7 +717,10 @@ struct PrepArgs {
 // ghost value of c = the same boundary condition applied to c, whose interior values are (phi - pmin) * invd formed on the
 // fly and whose coarse values are the affine view of the coarse phi -- the operations of k_apply_bc_sfaces<2> on a stored c.
 struct PrepLev { DLevelView L; DMFView M; int comp; DLevelView LC; DMFView MC; int ccomp; PrepArgs A; int use_cp; long long cg_stride = 0, cp_stride = 0; const int2* wg = nullptr; int nwg = 0; const int* sfboxes = nullptr; };
-template <bool PATCH>
+// PHIONLY (the gradient tool's pass): only the face ghost of phi -- MLMG applyBC as k_apply_bc_sfaces does it, but on the per-face
+// work tables and from the coarse PATCHES instead of owner-map lookups into the coarse FABs (the three applyBC launches of a
+// 3-level hierarchy took 0.43 ms, this kernel 0.19 ms with the progress variable on top)
+template <bool PATCH, bool PHIONLY = false>
 __global__ __launch_bounds__(256) void k_prep_faces(LevBatch<PrepLev> Bt, int* nbad, SlotK sk = SlotK()) {
   unsigned fy;
   int blev;
@@ -740,8 +743,9 @@ __global__ __launch_bounds__(256) void k_prep_faces(LevBatch<PrepLev> Bt, int* n
   const unsigned code = L.sfcode[L.sfoff[fy] + t];
   const int cls = (int)(code & 3u);
   const int t0 = (dir == 0) ? 1 : 0, t1 = (dir == 2) ? 1 : 2;
-  double* cgp = cgz + L.cgoff[fy] + (long long)(q[t1] - B.lo[t1] + 1) * (B.hi[t0] - B.lo[t0] + 3) + (q[t0] - B.lo[t0] + 1);
+  double* cgp = PHIONLY ? nullptr : cgz + L.cgoff[fy] + (long long)(q[t1] - B.lo[t1] + 1) * (B.hi[t0] - B.lo[t0] + 3) + (q[t0] - B.lo[t0] + 1);
   double* p = M.data + M.off[b];
+  if (PHIONLY && cls == 0) return;  // a valid cell of the level: FillBoundary's
   if (cls == 0) {
     // a valid cell of the level (a face that is partly coarse-fine, partly covered by a neighbouring box): the progress variable
     // of the cell itself.  Read in the box that OWNS the cell when that box is local -- this kernel runs next to the local
@@ -762,7 +766,7 @@ __global__ __launch_bounds__(256) void k_prep_faces(LevBatch<PrepLev> Bt, int* n
     const double vc = (v - A.pmin) * A.invd;
     const bool odd = A.bc[dir] == PA_BC_REFLECT_ODD;
     p[fab_index(B, M.ng, M.ncomp, comp, q[0], q[1], q[2])] = odd ? -v : v;
-    *cgp = odd ? -vc : vc;
+    if (!PHIONLY) *cgp = odd ? -vc : vc;
     return;
   }
   if (!A.has_crse) { atomicAdd(nbad, 1); return; }
@@ -786,7 +790,7 @@ __global__ __launch_bounds__(256) void k_prep_faces(LevBatch<PrepLev> Bt, int* n
   gp += bv[0] * coef[0];
   gc += bv[1] * coef[0];
   p[fab_index(B, M.ng, M.ncomp, comp, q[0], q[1], q[2])] = gp;
-  *cgp = gc;
+  if (!PHIONLY) *cgp = gc;
 }
 
 // The edge ghost cells of c (outside the box in two directions a < c) that are the boundary ghost of a valid cell of a
@@ -1377,6 +1381,7 @@ bool pa_fused2_level_ok(const pa_level* L) {
 // nslots > 1: components comp .. comp + nslots - 1 (coarse components ccomp ..) in one launch each, slot z with the progress
 // range prog[2 z], prog[2 z + 1] (device) and its own set of compact arrays / coarse patches (SlotK)
 // phase & 4: the ring reads its neighbours' cells in the boxes that own them (unsharded levels only), not the ghost cells
+// phase & 8 (with 1): only the face ghosts of phi (k_prep_faces<.., PHIONLY>): pa_grad_run's applyBC of every level in one launch
 int pa_gradcurv_prep_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int comp, const pa_mf* const* crse, int ccomp, const int32_t bc[3], double pmin, double pmax, int phase,
                             int nslots, const double* prog) {
   bool direct = (phase & 4) != 0;
@@ -1391,7 +1396,7 @@ int pa_gradcurv_prep_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int comp, 
     for (int l = l0; l < nlev && l < l0 + PA_MAXB; ++l) {
       const pa_level* L = phi[l]->lev;
       if (L->boxes.empty()) continue;
-      if (level_cg(ctx, L, nslots)) return 1;
+      if (!(phase & 8) && level_cg(ctx, L, nslots)) return 1;  // phase & 8: phi only (the gradient tool), no compact arrays
       if (L->sfaces.empty()) continue;
       PrepLev P;
       P.cg_stride = cg_stride(L); P.cp_stride = cp_stride(L);
@@ -1417,7 +1422,10 @@ int pa_gradcurv_prep_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int comp, 
     unsigned nwgf = 0;
     for (int q = 0; q < Bf.n; ++q) nwgf += (unsigned)Bf.a[q].nwg;
     const dim3 gf(nwgf, 1, (unsigned)nslots), gr((unsigned)((ntr + 255) / 256), (unsigned)Br.ycum[Br.n], (unsigned)nslots);
-    if (phase & 1) {
+    if ((phase & 1) && (phase & 8)) {
+      if (all_patch) hipLaunchKernelGGL((k_prep_faces<true, true>), gf, dim3(256), 0, ctx->stream, Bf, ctx->d_flags, sk);
+      else hipLaunchKernelGGL((k_prep_faces<false, true>), gf, dim3(256), 0, ctx->stream, Bf, ctx->d_flags, sk);
+    } else if (phase & 1) {
       if (all_patch) hipLaunchKernelGGL(k_prep_faces<true>, gf, dim3(256), 0, ctx->stream, Bf, ctx->d_flags, sk);
       else hipLaunchKernelGGL(k_prep_faces<false>, gf, dim3(256), 0, ctx->stream, Bf, ctx->d_flags, sk);
     }

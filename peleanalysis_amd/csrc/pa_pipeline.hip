@@ -79,7 +79,19 @@ extern "C" int pa_grad_run(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp,
       PA_HIP(hipStreamWaitEvent(ctx->stream2, ctx->sync_evs[0], 0));
       {
         StreamSwap sw(ctx, ctx->stream2);
-        for (int l = 0; l < nlev; ++l) PA_TRY(pa_apply_bc(ctx, state[l], comp, l > 0 ? state[l - 1] : nullptr, comp, bc, 2, -1));
+        // the face ghosts of every level in ONE launch on the per-face work tables, coarse values from the gathered coarse patches
+        // (k_prep_faces<.., PHIONLY>, pa_fused.hip: 0.43 -> ~0.2 ms on the headline hierarchy); PA_GRAD_BC_PATCH=0 (read per call),
+        // 2-D hierarchies (one plane of cells: the patches are a 3-D layout): applyBC level by level
+        const char* pe = getenv("PA_GRAD_BC_PATCH");
+        bool patch = !pe || atoi(pe);
+        for (int l = 0; l < nlev; ++l) patch = patch && state[l]->lev->domhi[2] > state[l]->lev->domlo[2];
+        if (patch) {
+          std::vector<const pa_mf*> crse((size_t)nlev, nullptr);
+          for (int l = 1; l < nlev; ++l) crse[(size_t)l] = state[l - 1];
+          PA_TRY(pa_gradcurv_prep_levels(ctx, nlev, state, comp, crse.data(), comp, bc, 0.0, 1.0, 1 | 8, 1, nullptr));
+        } else {
+          for (int l = 0; l < nlev; ++l) PA_TRY(pa_apply_bc(ctx, state[l], comp, l > 0 ? state[l - 1] : nullptr, comp, bc, 2, -1));
+        }
       }
       PA_HIP(hipEventRecord(ctx->sync_evs[1], ctx->stream2));
       bc_done = true;
