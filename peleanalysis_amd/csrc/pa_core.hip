@@ -885,14 +885,18 @@ struct BCFields {
   int comp[NF];
   int xf[NF];
 };
+// wg != null: workgroup w works on chunk wg[w].y (256 ghost cells) of special face wg[w].x (the level's work table, pa_level::d_sfwg:
+// faces differ 16x in size on general BoxArrays, a grid of (largest face / 256) x faces is mostly empty workgroups there); else
+// blockIdx.y = special face, blockIdx.x = chunk
 template <int NF>
-__global__ __launch_bounds__(256) void k_apply_bc_sfaces(DLevelView L, BCFields<NF> F, DLevelView LC, DMFView MC, int ccomp, BCArgs A, int* nbad) {
+__global__ __launch_bounds__(256) void k_apply_bc_sfaces(DLevelView L, BCFields<NF> F, DLevelView LC, DMFView MC, int ccomp, BCArgs A, int* nbad, const int2* wg = nullptr) {
   int b, dir, side, layer, q[3];
   DBox B;
-  const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  if (!sface_decode(L, blockIdx.y, t, 1, b, B, dir, side, q, layer)) return;
+  const unsigned fy = wg ? (unsigned)wg[blockIdx.x].x : blockIdx.y;
+  const long long t = (wg ? (long long)wg[blockIdx.x].y : (long long)blockIdx.x) * (long long)blockDim.x + threadIdx.x;
+  if (!sface_decode(L, fy, t, 1, b, B, dir, side, q, layer)) return;
   if (A.only_dir >= 0 && dir != A.only_dir) return;
-  const unsigned code = L.sfcode[L.sfoff[blockIdx.y] + t];
+  const unsigned code = L.sfcode[L.sfoff[fy] + t];
   const int cls = (int)(code & 3u);
   if (cls == 0) return;
   if (cls == 1 && !A.has_crse) { atomicAdd(nbad, 1); return; }
@@ -1020,9 +1024,10 @@ int pa_apply_bc_impl(pa_ctx* ctx, pa_mf* F, int comp, const pa_mf* C, int ccomp,
     if (L->sfaces.empty()) return 0;  // every ghost cell is a valid cell of the level
     const long long nt = std::max(n1 * n2, std::max(n0 * n2, n0 * n1));
     dim3 grid((unsigned)((nt + 255) / 256), (unsigned)L->sfaces.size());
+    if (L->d_sfwg) grid = dim3((unsigned)L->nsfwg);
     BCFields<1> Fs;
     Fs.M[0] = F->view; Fs.comp[0] = comp; Fs.xf[0] = MC.xform;
-    hipLaunchKernelGGL(k_apply_bc_sfaces<1>, grid, dim3(256), 0, ctx->stream, L->view, Fs, LC, MC, ccomp, A, nbad);
+    hipLaunchKernelGGL(k_apply_bc_sfaces<1>, grid, dim3(256), 0, ctx->stream, L->view, Fs, LC, MC, ccomp, A, nbad, (const int2*)L->d_sfwg);
   } else {
     const long long nt = 4 * (n0 + n1 + n2);
     dim3 grid((unsigned)((nt + 255) / 256), (unsigned)L->boxes.size());
@@ -1057,8 +1062,9 @@ int pa_apply_bc_dual(pa_ctx* ctx, pa_mf* F0, int comp0, pa_mf* F1, int comp1, co
   const long long n0 = L->maxn[0], n1 = L->maxn[1], n2 = L->maxn[2];
   const long long nt = std::max(n1 * n2, std::max(n0 * n2, n0 * n1));
   dim3 grid((unsigned)((nt + 255) / 256), (unsigned)L->sfaces.size());
+  if (L->d_sfwg) grid = dim3((unsigned)L->nsfwg);
   ProfScope prof(ctx, PA_TAG_BC);
-  hipLaunchKernelGGL(k_apply_bc_sfaces<2>, grid, dim3(256), 0, ctx->stream, L->view, Fs, LC, MC, ccomp, A, ctx->d_flags);
+  hipLaunchKernelGGL(k_apply_bc_sfaces<2>, grid, dim3(256), 0, ctx->stream, L->view, Fs, LC, MC, ccomp, A, ctx->d_flags, (const int2*)L->d_sfwg);
   PA_HIP(hipGetLastError());
   return 0;
 }
