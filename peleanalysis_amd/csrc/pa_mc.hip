@@ -382,6 +382,8 @@ struct MclArgs {
   DMFView S, M;
   int mcomp, isocomp, ncomp, kseg;
   int rows, nslab, tiles, ldsw;  // k_mcl_cells4: rows of a slab (multiple of 4), slabs / tiles of the largest FAB, LDS dwords per parity
+  const int* tiletab = nullptr;  // FABs of different sizes (mcl_tiletab): workgroup w = {FAB, first row, rows, first plane} = tiletab[4 w .. 4 w + 3]; `tiles` = entries
+  unsigned ntab = 0;
   int nomask, has_fine, ratio;  // nomask: no mask multifab -- a cell is masked iff the next finer level LF covers it
   DLevelView LF;
   int dim2;                // marching squares on the plane k = loops[b].lo[2] (isosurface.cpp:303-406), see below
@@ -574,17 +576,23 @@ __global__ __launch_bounds__(64 * TY) void k_mcl_cells(MclArgs A) {
 template <int NT, int GPT, int MM>  // MM: 0 mask multifab, 1 no mask and no finer level, 2 mask = covered by the finer level LF
 __device__ __forceinline__ void mcl_cells4_body(const MclArgs& A, const unsigned bidx, unsigned* s_fl) {
   // s_fl: [2][A.ldsw]: one flag byte per cell of the slab + halo row, by plane parity
-  const unsigned total = (unsigned)A.L.nboxes * (unsigned)A.tiles, chunk = (total + 7u) / 8u;
+  const unsigned total = A.tiletab ? A.ntab : (unsigned)A.L.nboxes * (unsigned)A.tiles, chunk = (total + 7u) / 8u;
   const unsigned wg = (bidx & 7u) * chunk + (bidx >> 3);  // XCD x of 8 works through one contiguous run of tiles
   if (wg >= total) return;
-  const int b = (int)(wg / (unsigned)A.tiles), tile = (int)(wg - (unsigned)b * (unsigned)A.tiles);
+  int b, j0, k0, rows = A.rows;
+  if (A.tiletab) {  // FABs of different sizes: every FAB has its own slab height (as many rows of ITS width as the workgroup holds) and only the tiles it has
+    b = A.tiletab[4 * wg]; j0 = A.tiletab[4 * wg + 1]; rows = A.tiletab[4 * wg + 2]; k0 = A.tiletab[4 * wg + 3];
+  } else {
+    b = (int)(wg / (unsigned)A.tiles);
+    const int tile = (int)(wg - (unsigned)b * (unsigned)A.tiles);
+    const int slab = tile % A.nslab, tz = tile / A.nslab;
+    j0 = slab * A.rows; k0 = tz * A.kseg;
+  }
   MclGeo G;
   if (!mcl_geo(A, b, G)) return;
   const int nx = G.n[0], ny = G.n[1], nz = G.n[2];
-  const int slab = tile % A.nslab, tz = tile / A.nslab;
-  const int j0 = slab * A.rows, k0 = tz * A.kseg;
   if (j0 >= ny || k0 >= nz) return;  // uniform
-  const int own = min(A.rows, ny - j0), halo = j0 + own < ny ? 1 : 0;
+  const int own = min(rows, ny - j0), halo = j0 + own < ny ? 1 : 0;
   const int len_own = own * nx, len_all = (own + halo) * nx;
   const int k1 = min(k0 + A.kseg, nz) - 1, klast = min(k1 + 1, nz - 1);
   const long long nxy = (long long)nx * ny;
@@ -1133,18 +1141,19 @@ __global__ __launch_bounds__(256) void k_iso_mask(DLevelView L, DMFView M, int c
   const int b = blockIdx.y;
   const DBox B = L.boxes[b];
   const unsigned nx = B.hi[0] - B.lo[0] + 1 + 2 * M.ng, ny = B.hi[1] - B.lo[1] + 1 + 2 * M.ng, nz = B.hi[2] - B.lo[2] + 1 + 2 * M.ng;
-  const unsigned lin = blockIdx.x * 256u + threadIdx.x;
-  if (lin >= nx * ny * nz) return;
-  const unsigned r = lin / nx, kk = r / ny;
-  double v = 1.0;
-  if (has_fine) {
-    int p[3] = {(B.lo[0] - M.ng + (int)(lin - r * nx)) * ratio, (B.lo[1] - M.ng + (int)(r - kk * ny)) * ratio, (B.lo[2] - M.ng + (int)kk) * ratio};
-    if (wrap_cell(LF, p)) {  // periodic images of the coarsened fine boxes mask too (isosurface.cpp:1550-1560)
-      const int o = owner_of(LF, p);
-      if (o != -1) v = -1.0;
+  // grid-stride over the FAB's cells: gridDim.x is sized by the SMALLEST FAB of the level (iso_grid_x), larger ones take more trips
+  for (unsigned lin = blockIdx.x * 256u + threadIdx.x; lin < nx * ny * nz; lin += gridDim.x * 256u) {
+    const unsigned r = lin / nx, kk = r / ny;
+    double v = 1.0;
+    if (has_fine) {
+      int p[3] = {(B.lo[0] - M.ng + (int)(lin - r * nx)) * ratio, (B.lo[1] - M.ng + (int)(r - kk * ny)) * ratio, (B.lo[2] - M.ng + (int)kk) * ratio};
+      if (wrap_cell(LF, p)) {  // periodic images of the coarsened fine boxes mask too (isosurface.cpp:1550-1560)
+        const int o = owner_of(LF, p);
+        if (o != -1) v = -1.0;
+      }
     }
+    M.data[M.off[b] + (long long)comp * pa_cstride((long long)nx * ny * nz, M.ncomp) + lin] = v;
   }
-  M.data[M.off[b] + (long long)comp * pa_cstride((long long)nx * ny * nz, M.ncomp) + lin] = v;
 }
 
 // cell-centre coordinates of every cell of every grown FAB (isosurface.cpp:1458-1465): (i + 0.5) * dx + plo
@@ -1153,14 +1162,23 @@ __global__ __launch_bounds__(256) void k_iso_coords(DLevelView L, DMFView M, int
   const int b = blockIdx.y;
   const DBox B = L.boxes[b];
   const unsigned nx = B.hi[0] - B.lo[0] + 1 + 2 * M.ng, ny = B.hi[1] - B.lo[1] + 1 + 2 * M.ng, nz = B.hi[2] - B.lo[2] + 1 + 2 * M.ng;
-  const unsigned lin = blockIdx.x * 256u + threadIdx.x;
-  if (lin >= nx * ny * nz) return;
-  const unsigned r = lin / nx, kk = r / ny;
-  const int p[3] = {B.lo[0] - M.ng + (int)(lin - r * nx), B.lo[1] - M.ng + (int)(r - kk * ny), B.lo[2] - M.ng + (int)kk};
   const long long cs = pa_cstride((long long)nx * ny * nz, M.ncomp);
-  double* o = M.data + M.off[b] + (long long)comp0 * cs + lin;
+  for (unsigned lin = blockIdx.x * 256u + threadIdx.x; lin < nx * ny * nz; lin += gridDim.x * 256u) {  // grid-stride, as k_iso_mask
+    const unsigned r = lin / nx, kk = r / ny;
+    const int p[3] = {B.lo[0] - M.ng + (int)(lin - r * nx), B.lo[1] - M.ng + (int)(r - kk * ny), B.lo[2] - M.ng + (int)kk};
+    double* o = M.data + M.off[b] + (long long)comp0 * cs + lin;
 #pragma unroll
-  for (int d = 0; d < 3; ++d) o[d * cs] = (p[d] + 0.5) * Q.dx[d] + Q.plo[d];
+    for (int d = 0; d < 3; ++d) o[d * cs] = (p[d] + 0.5) * Q.dx[d] + Q.plo[d];
+  }
+}
+
+// workgroups per FAB of the per-cell kernels above: enough for the SMALLEST grown FAB of the level (the others loop), so that a
+// level of boxes of 32 .. 128 cells per side does not launch the largest FAB's count for every box (2 of 3 workgroups empty on
+// the bench's irregular hierarchy); equal boxes: one trip each, as before
+static unsigned iso_grid_x(const pa_level* L, int ng) {
+  long long nmin = 1LL << 40;
+  for (const DBox& B : L->boxes) nmin = std::min(nmin, (long long)(B.hi[0] - B.lo[0] + 1 + 2 * ng) * (B.hi[1] - B.lo[1] + 1 + 2 * ng) * (B.hi[2] - B.lo[2] + 1 + 2 * ng));
+  return (unsigned)std::max<long long>(1, (nmin + 255) / 256);
 }
 
 extern "C" int pa_iso_coords_level(pa_ctx* ctx, pa_mf* state, int comp0) {
@@ -1173,7 +1191,7 @@ extern "C" int pa_iso_coords_level(pa_ctx* ctx, pa_mf* state, int comp0) {
   if (L->boxes.empty()) return 0;
   IsoGeom Q;
   for (int d = 0; d < 3; ++d) { Q.dx[d] = L->dx[d]; Q.plo[d] = L->prob_lo[d]; }
-  hipLaunchKernelGGL(k_iso_coords, dim3((unsigned)((nmax + 255) / 256), (unsigned)L->boxes.size()), dim3(256), 0, ctx->stream, L->view, state->view, comp0, Q);
+  hipLaunchKernelGGL(k_iso_coords, dim3(iso_grid_x(L, state->ng), (unsigned)L->boxes.size()), dim3(256), 0, ctx->stream, L->view, state->view, comp0, Q);
   PA_HIP(hipGetLastError());
   return 0;
 }
@@ -1186,7 +1204,8 @@ extern "C" int pa_iso_mask_level(pa_ctx* ctx, pa_mf* mask, int comp, const pa_le
   const pa_level* L = mask->lev;
   const long long nmax = (long long)(L->maxn[0] + 2 * mask->ng) * (L->maxn[1] + 2 * mask->ng) * (L->maxn[2] + 2 * mask->ng);
   if (nmax >= (1LL << 31)) return pa_fail(ctx, "pa_iso_mask_level: FAB too large");
-  hipLaunchKernelGGL(k_iso_mask, dim3((unsigned)((nmax + 255) / 256), (unsigned)L->boxes.size()), dim3(256), 0, ctx->stream, L->view, mask->view, comp,
+  if (L->boxes.empty()) return 0;
+  hipLaunchKernelGGL(k_iso_mask, dim3(iso_grid_x(L, mask->ng), (unsigned)L->boxes.size()), dim3(256), 0, ctx->stream, L->view, mask->view, comp,
                      fine ? fine->view : L->view, fine ? 1 : 0, ratio);
   PA_HIP(hipGetLastError());
   return 0;
@@ -1304,6 +1323,45 @@ static long long* mc_pinned(pa_ctx* ctx, size_t n) {
   return (long long*)ctx->h_pin;
 }
 
+// Tile table of the slab cell pass for a level whose FABs differ in size (MclArgs::tiletab): {FAB, first row, rows, first plane} per
+// workgroup.  The level-wide form cuts every FAB like the LARGEST one -- a 34-wide FAB of a level whose widest is 130 got
+// 28-row slabs (a quarter of the 4096 cells a workgroup holds per plane) and the workgroups of the largest FAB's tile count, most of
+// which left at once: on the bench's irregular hierarchy the pass ran at 1.8 TB/s against 4.4 on 128^3 boxes.  Here every FAB gets
+// as many rows of ITS width as fit and only the tiles it has.  Null for levels of equal boxes (the tuned path).  Cached per level,
+// ghost width and planes per workgroup; PA_MC_TILETAB=0: never (A/B, read per call).
+static const WgTab* mcl_tiletab(const pa_level* L, int ng, int kseg, int cap_cells) {
+  const char* e = getenv("PA_MC_TILETAB");
+  if (e && !atoi(e)) return nullptr;
+  bool same = true;
+  for (const DBox& B : L->boxes)
+    for (int d = 0; d < 3; ++d) same = same && (B.hi[d] - B.lo[d] + 1 == L->maxn[d]);
+  if (same || L->boxes.empty()) return nullptr;
+  const long long key = (3LL << 56) | ((long long)ng << 40) | (long long)kseg;
+  auto it = L->wgtabs.find(key);
+  if (it != L->wgtabs.end()) return it->second->d ? it->second.get() : nullptr;
+  std::unique_ptr<WgTab> T(new WgTab());
+  std::vector<int> tab;
+  for (int b = 0; b < (int)L->boxes.size(); ++b) {
+    const DBox& B = L->boxes[b];
+    const int nx = B.hi[0] - B.lo[0] + 1 + 2 * ng, ny = B.hi[1] - B.lo[1] + 1 + 2 * ng, nz = B.hi[2] - B.lo[2] + 1 + 2 * ng;
+    const int rmax = std::max(4, (cap_cells / nx - 1) / 4 * 4);  // whole rows next to their halo row, multiple of 4 (as the level-wide form)
+    const int ns0 = (ny + rmax - 1) / rmax;
+    const int rows = std::min(rmax, ((ny + ns0 - 1) / ns0 + 3) / 4 * 4);
+    for (int k0 = 0; k0 < nz; k0 += kseg)
+      for (int j0 = 0; j0 < ny; j0 += rows) { tab.push_back(b); tab.push_back(j0); tab.push_back(rows); tab.push_back(k0); }
+  }
+  if (hipMalloc(&T->d, sizeof(int) * tab.size()) == hipSuccess && hipMemcpy(T->d, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice) == hipSuccess) {
+    T->n = (unsigned)(tab.size() / 4);
+  } else {
+    if (T->d) (void)hipFree(T->d);
+    T->d = nullptr;
+    (void)hipGetLastError();
+  }
+  const WgTab* raw = T.get();
+  L->wgtabs[key] = std::move(T);
+  return raw->d ? raw : nullptr;
+}
+
 static int mc_phase1(pa_ctx* ctx, MclWork& W, unsigned char* scr, unsigned char* codes) {
   if (W.nb == 0 || W.maxcell == 0) return 0;
   const pa_level* L = W.state->lev;
@@ -1352,7 +1410,8 @@ static int mc_phase1(pa_ctx* ctx, MclWork& W, unsigned char* scr, unsigned char*
       }
       A.tiles = A.nslab * ((mz + A.kseg - 1) / A.kseg);
       A.ldsw = NT4 * GPT4 + (mx >> 2) + 4;
-      const long long total = (long long)nb * A.tiles;
+      if (const WgTab* tt = mcl_tiletab(L, ng, A.kseg, 4 * NT4 * GPT4)) { A.tiletab = tt->d; A.ntab = tt->n; }
+      const long long total = A.tiletab ? (long long)A.ntab : (long long)nb * A.tiles;
       if (total > 0x7ffffff0LL) return pa_fail(ctx, "pa_mc_level: level too large for one pass");
       const dim3 g4((unsigned)((total + 7) / 8 * 8));
       const size_t lds4 = 2 * (size_t)A.ldsw * 4;
@@ -1509,6 +1568,7 @@ static int mc_run_batched(pa_ctx* ctx, int nlev, MclWork* W) {
     }
     A.tiles = A.nslab * ((mz + A.kseg - 1) / A.kseg);
     A.ldsw = NT4 * GPT4 + (mx >> 2) + 4;
+    if (const WgTab* tt = mcl_tiletab(L, ng, A.kseg, 4 * NT4 * GPT4)) { A.tiletab = tt->d; A.ntab = tt->n; }
     ldsw = std::max(ldsw, (size_t)A.ldsw);
     Bt.a[l] = A;
   }
@@ -1520,7 +1580,7 @@ static int mc_run_batched(pa_ctx* ctx, int nlev, MclWork* W) {
     for (int l = 0; l < nlev; ++l) Bt.wg0[l + 1] = Bt.wg0[l] + (unsigned)count(l);
     return Bt.wg0[nlev];
   };
-  unsigned g = ranges([&](int l) { return ((long long)W[l].nb * W[l].A.tiles + 7) / 8 * 8; });
+  unsigned g = ranges([&](int l) { return ((W[l].A.tiletab ? (long long)W[l].A.ntab : (long long)W[l].nb * W[l].A.tiles) + 7) / 8 * 8; });
   hipLaunchKernelGGL((k_mclb_cells4<NT4, GPT4>), dim3(g), dim3(NT4), 2 * ldsw * 4, ctx->stream, Bt);
   g = ranges([&](int l) { return (W[l].nblk + 1023) / 1024; });
   hipLaunchKernelGGL(k_mclb_active, dim3(g), dim3(1024), 0, ctx->stream, Bt);
