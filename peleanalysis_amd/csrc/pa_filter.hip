@@ -641,33 +641,35 @@ __device__ __forceinline__ bool shell_cell2(const DBox& B, int ng, long long t, 
   return false;
 }
 
-static long long max_shell2(const pa_level* L, int ng) {
-  long long m = 0;
+static long long min_shell2(const pa_level* L, int ng) {  // workgroups per box of the grid-stride shell kernels: enough for the smallest box
+  long long m = 1LL << 50;
   for (const DBox& B : L->boxes) {
     const long long nx = B.hi[0] - B.lo[0] + 1, ny = B.hi[1] - B.lo[1] + 1, nz = B.hi[2] - B.lo[2] + 1;
-    m = std::max(m, (nx + 2 * ng) * (ny + 2 * ng) * (nz + 2 * ng) - nx * ny * nz);
+    m = std::min(m, (nx + 2 * ng) * (ny + 2 * ng) * (nz + 2 * ng) - nx * ny * nz);
   }
-  return m;
+  return std::max<long long>(m, 1);
 }
-
 // first-order extrapolation: a ghost cell outside a non-periodic wall takes the value of the
 // nearest cell inside the domain (which lies in the same grown FAB and is already filled)
 __global__ void k_foextrap(DLevelView L, DMFView M, int comp, int ncomp, int ngf) {
   const int b = blockIdx.y;
   const DBox B = L.boxes[b];
-  const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  int q[3];
-  if (!shell_cell2(B, ngf, t, q[0], q[1], q[2])) return;
-  int p[3] = {q[0], q[1], q[2]};
-  bool out = false;
-  for (int d = 0; d < 3; ++d)
-    if (!L.is_per[d]) {
-      if (p[d] < L.domlo[d]) { p[d] = L.domlo[d]; out = true; }
-      if (p[d] > L.domhi[d]) { p[d] = L.domhi[d]; out = true; }
-    }
-  if (!out) return;
+  const long long nx = B.hi[0] - B.lo[0] + 1, ny = B.hi[1] - B.lo[1] + 1, nz = B.hi[2] - B.lo[2] + 1;
+  const long long nsh = (nx + 2 * ngf) * (ny + 2 * ngf) * (nz + 2 * ngf) - nx * ny * nz;
   double* f = M.data + M.off[b];
-  for (int c = comp; c < comp + ncomp; ++c) f[fab_index(B, M.ng, M.ncomp, c, q[0], q[1], q[2])] = f[fab_index(B, M.ng, M.ncomp, c, p[0], p[1], p[2])];
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < nsh; t += (long long)gridDim.x * blockDim.x) {  // grid-stride (min_shell2)
+    int q[3];
+    if (!shell_cell2(B, ngf, t, q[0], q[1], q[2])) continue;
+    int p[3] = {q[0], q[1], q[2]};
+    bool out = false;
+    for (int d = 0; d < 3; ++d)
+      if (!L.is_per[d]) {
+        if (p[d] < L.domlo[d]) { p[d] = L.domlo[d]; out = true; }
+        if (p[d] > L.domhi[d]) { p[d] = L.domhi[d]; out = true; }
+      }
+    if (!out) continue;
+    for (int c = comp; c < comp + ncomp; ++c) f[fab_index(B, M.ng, M.ncomp, c, q[0], q[1], q[2])] = f[fab_index(B, M.ng, M.ncomp, c, p[0], p[1], p[2])];
+  }
 }
 
 extern "C" int pa_foextrap(pa_ctx* ctx, pa_mf* M, int comp, int ncomp, int ng) {
@@ -676,7 +678,7 @@ extern "C" int pa_foextrap(pa_ctx* ctx, pa_mf* M, int comp, int ncomp, int ng) {
   if (ng > M->ng || ng < 0 || comp < 0 || comp + ncomp > M->ncomp) return pa_fail(ctx, "pa_foextrap: ng/component range");
   if (ng == 0) return 0;
   if (M->lev->boxes.empty()) return 0;  // a rank that owns no box of this level
-  dim3 grid((unsigned)((max_shell2(M->lev, ng) + 255) / 256), (unsigned)M->lev->boxes.size());
+  dim3 grid((unsigned)((min_shell2(M->lev, ng) + 255) / 256), (unsigned)M->lev->boxes.size());
   hipLaunchKernelGGL(k_foextrap, grid, dim3(256), 0, ctx->stream, M->lev->view, M->view, comp, ncomp, ng);
   PA_HIP(hipGetLastError());
   return 0;
@@ -685,11 +687,8 @@ extern "C" int pa_foextrap(pa_ctx* ctx, pa_mf* M, int comp, int ncomp, int ng) {
 // FillPatchTwoLevels for the ghost cells that no fine box covers: piecewise constant or
 // cell-conservative linear interpolation of the coarse level (see oracle/pa_oracle.c
 // orc_fillpatch_two_levels for the restated limiter)
-__global__ void k_fillpatch2(DLevelView L, DMFView M, DLevelView LC, DMFView MC, int comp, int cshift /* coarse component = fine component + cshift */, int ncomp, int ngf, int r,
-                             int interp, int* nbad) {
-  const int b = blockIdx.y;
-  const DBox B = L.boxes[b];
-  const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+__device__ __forceinline__ void fillpatch2_cell(const DLevelView& L, const DMFView& M, const DLevelView& LC, const DMFView& MC, int comp, int cshift, int ncomp, int ngf, int r,
+                                                int interp, int* nbad, int b, const DBox& B, long long t) {
   int q[3];
   if (!shell_cell2(B, ngf, t, q[0], q[1], q[2])) return;
   if (classify(L, q[0], q[1], q[2]) != 1) return;  // covered: FillBoundary; outside a wall: foextrap afterwards
@@ -744,6 +743,16 @@ __global__ void k_fillpatch2(DLevelView L, DMFView M, DLevelView LC, DMFView MC,
     if (!ok) atomicAdd(nbad, 1);
     f[fab_index(B, M.ng, M.ncomp, c, q[0], q[1], q[2])] = val;
   }
+}
+// thread per ghost-shell cell, grid-stride: gridDim.x is sized by the SMALLEST shell of the level (min_shell2), larger boxes take more trips
+__global__ void k_fillpatch2(DLevelView L, DMFView M, DLevelView LC, DMFView MC, int comp, int cshift /* coarse component = fine component + cshift */, int ncomp, int ngf, int r,
+                             int interp, int* nbad) {
+  const int b = blockIdx.y;
+  const DBox B = L.boxes[b];
+  const long long nx = B.hi[0] - B.lo[0] + 1, ny = B.hi[1] - B.lo[1] + 1, nz = B.hi[2] - B.lo[2] + 1;
+  const long long nsh = (nx + 2 * ngf) * (ny + 2 * ngf) * (nz + 2 * ngf) - nx * ny * nz;
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < nsh; t += (long long)gridDim.x * blockDim.x)
+    fillpatch2_cell(L, M, LC, MC, comp, cshift, ncomp, ngf, r, interp, nbad, b, B, t);
 }
 
 // The same for interp_type 1 with one thread per COARSE parent cell of the ghost shell: the 8 children of a parent share
@@ -951,7 +960,7 @@ extern "C" int pa_fillpatch_two_levels(pa_ctx* ctx, pa_mf* fine, const pa_mf* cr
     PA_HIP(hipGetLastError());
     return 0;
   }
-  dim3 grid((unsigned)((max_shell2(fine->lev, ng) + 255) / 256), (unsigned)fine->lev->boxes.size());
+  dim3 grid((unsigned)((min_shell2(fine->lev, ng) + 255) / 256), (unsigned)fine->lev->boxes.size());
   hipLaunchKernelGGL(k_fillpatch2, grid, dim3(256), 0, ctx->stream, fine->lev->view, fine->view, crse->lev->view, crse->view, comp, ccomp - comp, ncomp, ng, ratio,
                      interp_type, ctx->d_flags);
   PA_HIP(hipGetLastError());
