@@ -10,6 +10,8 @@ import torch
 from peleanalysis_amd import capi
 from peleanalysis_amd.hierarchy import Level, mf_layout
 import bench
+if os.environ.get("PA_LIB"):  # a diagnostic build of the library (tools/exp/_dbg/*.so)
+    capi.LIB_PATH = os.environ["PA_LIB"]
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 shapes = [tuple(int(v) for v in a.split("x")) for a in sys.argv[2:]] or [(32, 32, 32), (32, 32, 64), (64, 64, 64), (128, 128, 128)]
