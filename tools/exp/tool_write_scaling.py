@@ -18,7 +18,7 @@ p = os.path.join(d, "plt00000")
 write_plotfile(p, H, mfs, ["temp"], time=0.0, level_steps=[0, 0, 0])
 print(f"plotfile: base {base}^3, 3 levels, {sum(l.ncells for l in H.levels)} cells x 1 comp", flush=True)
 exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bin", "grad3d.ex")
-for nt, nf in ((16, 0), (16, 1), (16, 0), (16, 1), (4, 0), (4, 1), (1, 0)):
+for nt, nf in ((16, 0), (16, 0), (16, 0), (4, 0), (1, 0)):
     env = dict(os.environ, PA_IO_THREADS=str(nt))
     if nf:
         env["PA_PLT_NFILES"] = str(nf)
