@@ -254,7 +254,7 @@ def secondary(ctx, torch, stream, dev, only=None):
 
     # BASELINE config 2: single level 512^3, 10 components
     if want("c2_1lev_512_10comp"):
-        h = gradcurv_case("c2_1lev_512_10comp", 512, 1, 128, 10, (1, 1, 1))
+        h = gradcurv_case("c2_1lev_512_10comp", 512, 1, 128, 10, (1, 1, 1), nbatch=int(os.environ.get("PA_C2_NBATCH", "10")))  # all 10 components in one batch: one FillBoundary launch and one sweep launch (slots) for all of them, 86 GB of outputs; 1: component by component (20.8 against 19.0 ms)
         del h
         torch.cuda.empty_cache()
     # BASELINE config 5's shape on one GPU, 8 of its 55 components: 4 levels of 256^3 cells in 64^3 boxes, components in one batch
