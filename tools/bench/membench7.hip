@@ -45,14 +45,60 @@ __global__ __launch_bounds__(1024) void k_tiles(const double* __restrict__ in, d
   }
 }
 
+// the same tiles with the real sweeps' step order: three planes of loads in flight (requested right AFTER the barrier, three steps ahead), the 8 stores of a
+// plane issued in one burst at the top of the NEXT step (argv[2] = 1)
+__global__ __launch_bounds__(1024) void k_tiles_pref(const double* __restrict__ in, double* __restrict__ out, int nx, int ny, int nz, int wcols, int kseg, long long cs, int nboxes,
+                                                      int tiles, int idle, long long pitch_x, long long pitch_xy, int ghost) {
+  const unsigned per8 = 8u * (unsigned)tiles, g = blockIdx.x / per8, r = blockIdx.x % per8;
+  const int box = (int)(g * 8u + (r & 7u)), tile = (int)(r >> 3);
+  if (box >= nboxes) return;
+  const int waves = (blockDim.x >> 6) - idle, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int rpw = 64 / wcols, R = waves * rpw;
+  const int tx = nx / wcols, ty = (ny + R - 1) / R;
+  const int bx = tile % tx, by = (tile / tx) % ty, bz = tile / (tx * ty);
+  const int k0 = bz * kseg, k1 = min(k0 + kseg, nz);
+  const long long boxcells = (long long)nx * ny * nz;
+  // input: a FAB with `ghost` ghost layers (pitch_x = nx + 2 ghost, pitch_xy = pitch_x (ny + 2 ghost)), box b at b * pitch_xy * (nz + 2 ghost)
+  const double* ib = in + box * pitch_xy * (nz + 2 * ghost) + ((long long)ghost * pitch_xy + ghost * pitch_x + ghost);
+  double* ob = out + box * 8 * cs;
+  const bool act = w < waves;
+  const int col = bx * wcols + lane % wcols;
+  const int row = min(by * R + w * rpw + lane / wcols, ny - 1);
+  const long long oin = (long long)row * pitch_x + col, oout = (long long)row * nx + col;
+  double f0 = 0, f1 = 0, f2 = 0, x = 0;
+  if (act) { f0 = ib[(long long)k0 * pitch_xy + oin]; f1 = ib[(long long)min(k0 + 1, nz - 1) * pitch_xy + oin]; f2 = ib[(long long)min(k0 + 2, nz - 1) * pitch_xy + oin]; }
+  bool have = false;
+  long long kprev = 0;
+#define STEP(F, K)                                                                                                           \
+  {                                                                                                                          \
+    if (act && have) {                                                                                                       \
+      _Pragma("unroll") for (int c = 0; c < 8; ++c) ob[c * cs + kprev * nx * ny + oout] = x + c;                             \
+    }                                                                                                                        \
+    if (act) { asm volatile("v_mov_b64 %0, %1" : "=v"(x) : "v"(F)); }                                                        \
+    __syncthreads();                                                                                                         \
+    if (act) F = ib[(long long)min((K) + 3, nz - 1) * pitch_xy + oin];                                                       \
+    have = true;                                                                                                             \
+    kprev = (K);                                                                                                             \
+  }
+  int k = k0;
+  for (; k + 2 < k1; k += 3) { STEP(f0, k) STEP(f1, k + 1) STEP(f2, k + 2) }
+  if (k < k1) { STEP(f0, k) if (k + 1 < k1) STEP(f1, k + 1) }
+#undef STEP
+  if (act && have) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) ob[c * cs + kprev * nx * ny + oout] = x + c;
+  }
+}
+
 int main(int argc, char** argv) {
   const int N = 512;
   const int nsleep = argc > 1 ? atoi(argv[1]) : 0;
+  const int pref = argc > 2 ? atoi(argv[2]) : 0;  // 1: k_tiles_pref from plain input, 2: from FABs with 2 ghost layers
   const long long cells = (long long)N * N * N;
   double *in, *out;
-  CK(hipMalloc(&in, cells * 8));
+  CK(hipMalloc(&in, cells * 8 * 3 / 2 + (1 << 20)));
   CK(hipMalloc(&out, cells * 64 + (1ll << 30)));
-  CK(hipMemset(in, 0, cells * 8));
+  CK(hipMemset(in, 0, cells * 8 * 3 / 2));
   const Cfg cfgs[] = {
       {"64^3 boxes, 64 x 13 tile (the wide sweep on 64^3)", 64, 64, 64, 64, 13, 1, 0, 64},
       {"128^3 boxes, 64 x 13 tile (the headline)", 128, 128, 128, 64, 13, 1, 0, 64},
@@ -83,6 +129,11 @@ int main(int argc, char** argv) {
       float best = 1e9f;
       for (int it = 0; it < 4; ++it) {
         CK(hipEventRecord(e0, 0));
+        if (pref && c.ipw == 1 && !c.xsplit) {
+          const int gh = pref == 2 ? 2 : 0;
+          hipLaunchKernelGGL(k_tiles_pref, dim3(grid), dim3(64 * (c.waves + c.idle)), 0, 0, in, out, c.nx, c.ny, c.nz, c.wcols, c.kseg, cs, nboxes, tiles, c.idle, (long long)(c.nx + 2 * gh),
+                             (long long)(c.nx + 2 * gh) * (c.ny + 2 * gh), gh);
+        } else
         hipLaunchKernelGGL(k_tiles, dim3(grid), dim3(64 * (c.waves + c.idle)), 0, 0, in, out, c.nx, c.ny, c.nz, c.wcols, c.ipw, c.xsplit, c.kseg, cs, nboxes, tiles, c.idle, nsleep);
         CK(hipEventRecord(e1, 0));
         CK(hipEventSynchronize(e1));
