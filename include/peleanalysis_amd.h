@@ -162,6 +162,24 @@ int64_t pa_plan_restriction(int nfine, const int32_t* fboxes6, const int32_t* fo
                             const int32_t fdomhi[3], int ncrse, const int32_t* cboxes6, const int32_t* cowner,
                             const int32_t cdomlo[3], const int32_t cdomhi[3], const int32_t is_per[3], int rank, int ratio,
                             int which, int32_t* rows9, int64_t cap);
+/* Internal re-tiling (host arithmetic only): another BoxArray with exactly the cells of boxes6 -- boxes at least min_thick cells
+ * thick in every direction merged into the largest rectangles the cell set allows (maximal x-runs, stacked in y, then z; at
+ * most max_size[d] cells per direction, cut as evenly as the input edges allow; an input box larger than that is not split),
+ * thinner boxes passed through unchanged at the end of the list.  grad.cpp:158-236, curvature.cpp:283-570 and
+ * Filter::apply_filter (filterPlt.cpp:206-219) are point-wise functions of the level's cell set except for the coarse-fine
+ * interpolant of a box fewer than 3 cells thick (MLCellLinOp::applyBC, order min(n + 1, 4)), so with min_thick >= 3 a level
+ * created on the returned boxes gives the same value in every cell -- bit for bit -- as one created on boxes6
+ * (tests/test_retile.py; filterPlt.cpp:141 re-chops the file's BoxArray itself: the tiling is not part of the tools'
+ * contract).  Marching cubes numbers nodes in box order and must keep the file's boxes.  The caller moves FAB data between
+ * the two tilings by box intersection (tools/common/pa_plotfile.h read_comp / write_plotfile, hierarchy.regrid_copy).
+ * out_boxes6: room for cap >= nboxes boxes (an L-shaped union of two boxes may come back as three rectangles); returns the
+ * number of boxes written (the input itself when nothing can be merged, a piece would come out thinner than min_thick or cap
+ * is too small for the result), -1 on bad arguments.  max_size NULL: 128 per direction. */
+int pa_level_retile(int nboxes, const int32_t* boxes6, const int32_t max_size[3], int min_thick, int32_t* out_boxes6, int cap);
+/* The max_size the tools and bench.py pass to pa_level_retile for the levels of one hierarchy (boxes6[l]: the nboxes[l] boxes of
+ * level l): 256 cells per direction where every level then consists of blocks at least 128 cells thick, else 128 (measured:
+ * profiles/r05_retile.txt); PA_RETILE_MAX="x y z" in the environment overrides.  Host arithmetic only; 0 = OK. */
+int pa_hierarchy_retile_limits(int nlev, const int32_t* nboxes, const int32_t* const* boxes6, int min_thick, int32_t max_size[3]);
 void      pa_level_destroy(pa_level*);
 int       pa_level_nboxes(const pa_level*);
 

@@ -15,15 +15,21 @@ int pa_fail(pa_ctx* ctx, const std::string& msg) {
 
 extern "C" int pa_version(void) { return 100; }
 
-// Workgroup table of a sweep over boxes that differ in size (MarchArgs::wgtab, GradMarchArgs::wgtab), cached on the level per
-// box class (0: wider than 32 cells, 1: at most 32, 2: all) and tile shape.  Null when the order-2 arithmetic (every box takes
-// the tile count of the largest) wastes less than a tenth of the launch and the caller does not insist -- the regular tilings
-// keep the launch they were tuned on.
+// Workgroup table of a sweep (MarchArgs::wgtab, GradMarchArgs::wgtab), cached on the level per box class (0: wider than 32
+// cells, 1: at most 32, 2: all) and tile shape.  Workgroup i runs on XCD i % 8, so the table is eight QUEUES: a box's tiles are
+// cut into chunks of consecutive tiles (neighbouring tiles share halo rows / planes through that XCD's L2), the chunks are
+// dealt largest first to the queue with the least work, and entry 8 s + q is the s-th tile of queue q ({-1, 0}: the queue has
+// run out).  Round 5: chunks instead of whole boxes -- a level of a few large boxes (what pa_level_retile makes of a Pele
+// BoxArray) or of a box count that is not a multiple of eight keeps all eight XCDs busy: 27 boxes of 128^3 ran at 0.54 of HBM
+// against 0.61 for 64 of them, four boxes of 256 x 128 x 128 on four XCDs.  Null when the order-2 arithmetic (every box takes
+// the tile count of the largest, boxes in groups of eight) launches at most 3 % more workgroups than the queues are long and
+// the caller does not insist -- the regular tilings keep the launch they were tuned on.
 const WgTab* pa_sweep_wgtab(const pa_level* L, int cls, int tw, int mty, int kseg, bool force) {
   const long long key = ((long long)cls << 56) | ((long long)(force ? 1 : 0) << 52) | ((long long)tw << 40) | ((long long)mty << 24) | (long long)kseg;
   auto it = L->wgtabs.find(key);
   if (it != L->wgtabs.end()) return it->second->d ? it->second.get() : nullptr;
   std::unique_ptr<WgTab> T(new WgTab());
+  struct Chunk { int n, box, t0; };
   std::vector<std::pair<int, int>> bt;  // (tiles, box)
   long long real = 0;
   int tmax = 0;
@@ -37,22 +43,43 @@ const WgTab* pa_sweep_wgtab(const pa_level* L, int cls, int tw, int mty, int kse
     tmax = std::max(tmax, t);
   }
   const long long launched = (long long)tmax * 8 * (((long long)bt.size() + 7) / 8);
-  if (!bt.empty() && (force || launched * 10 > real * 11)) {
-    std::stable_sort(bt.begin(), bt.end(), [](const auto& a, const auto& b) { return a.first > b.first; });  // large boxes first; 8 neighbours in this order share a chunk
-    std::vector<int> tab;
-    for (size_t c = 0; c < bt.size(); c += 8)
-      for (int t = 0; t < bt[c].first; ++t)
-        for (size_t j = c; j < c + 8; ++j) {
-          const bool has = j < bt.size() && t < bt[j].first;
-          tab.push_back(has ? bt[j].second : -1);
-          tab.push_back(has ? t : 0);
-        }
-    if (hipMalloc(&T->d, sizeof(int) * tab.size()) == hipSuccess && hipMemcpy(T->d, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice) == hipSuccess) {
-      T->n = (unsigned)(tab.size() / 2);
-    } else {
-      if (T->d) (void)hipFree(T->d);
-      T->d = nullptr;
-      (void)hipGetLastError();  // no table: the order-2 launch does the same work
+  if (!bt.empty()) {
+    static const int chunk_env = [] { const char* e = getenv("PA_SWEEP_CHUNK"); return e ? atoi(e) : 0; }();  // tiles per chunk (0: from the level's size)
+    const int cap = chunk_env > 0 ? chunk_env : (int)std::max<long long>(8, std::min<long long>(64, real / 32));
+    std::vector<Chunk> ch;
+    for (const auto& p : bt) {
+      const int parts = (p.first + cap - 1) / cap;
+      for (int q = 0; q < parts; ++q) {
+        const int a = (int)((long long)p.first * q / parts), e = (int)((long long)p.first * (q + 1) / parts);
+        ch.push_back({e - a, p.second, a});
+      }
+    }
+    std::stable_sort(ch.begin(), ch.end(), [](const Chunk& a, const Chunk& b) { return a.n > b.n; });
+    std::vector<Chunk> queue[8];
+    long long load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (const Chunk& c : ch) {
+      int q = 0;
+      for (int x = 1; x < 8; ++x)
+        if (load[x] < load[q]) q = x;
+      queue[q].push_back(c);
+      load[q] += c.n;
+    }
+    const long long qlen = *std::max_element(load, load + 8);
+    if (force || launched * 100 > qlen * 8 * 103) {
+      std::vector<int> tab((size_t)(qlen * 8 * 2), 0);
+      for (int q = 0; q < 8; ++q) {
+        long long s = 0;
+        for (const Chunk& c : queue[q])
+          for (int t = 0; t < c.n; ++t, ++s) { tab[(size_t)(2 * (8 * s + q))] = c.box; tab[(size_t)(2 * (8 * s + q) + 1)] = c.t0 + t; }
+        for (; s < qlen; ++s) tab[(size_t)(2 * (8 * s + q))] = -1;
+      }
+      if (hipMalloc(&T->d, sizeof(int) * tab.size()) == hipSuccess && hipMemcpy(T->d, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice) == hipSuccess) {
+        T->n = (unsigned)(tab.size() / 2);
+      } else {
+        if (T->d) (void)hipFree(T->d);
+        T->d = nullptr;
+        (void)hipGetLastError();  // no table: the order-2 launch does the same work
+      }
     }
   }
   const WgTab* raw = T.get();

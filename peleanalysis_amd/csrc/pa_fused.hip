@@ -1502,7 +1502,10 @@ int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, d
     mty = m;
     lv.push_back(g);
   }
-  const bool ok = batch_env && !knobs && fused_order() == 2 && (lv.size() >= 2 || (nslots > 1 && lv.size() == 1)) && (int)lv.size() <= PA_MAXB && same;
+  // (Round 5, measured and not kept: tiles of 11 or 12 rows on BoxArrays whose boxes are 32 or 96 rows tall -- 13 + 13 + 6 rows
+  // leave a fifth of the row slots idle -- took 7.52 against 7.41 ms per pass on the re-tiled irregular hierarchy: idle ROWS cost
+  // nothing, a partly filled 64-cell tile in x does; profiles/r05_retile.txt.)
+  const bool ok = batch_env && !knobs && fused_order() == 2 && !lv.empty() && (int)lv.size() <= PA_MAXB && same;
   if (!ok) {
     rest.insert(rest.begin(), lv.begin(), lv.end());
     lv.clear();
@@ -1578,7 +1581,7 @@ int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, d
     static const int narrow_env = [] { const char* e = getenv("PA_NARROW"); return e ? atoi(e) : 1; }();
     std::vector<SweepGroup> keep;
     for (const SweepGroup& g : rest) ((g.dims[0] <= 32 && narrow_env) ? nar : keep).push_back(g);
-    if (batch_env && !knobs && fused_order() == 2 && (nar.size() >= 2 || (nslots > 1 && nar.size() == 1)) && (int)nar.size() <= PA_MAXB) rest.swap(keep);
+    if (batch_env && !knobs && fused_order() == 2 && !nar.empty() && (int)nar.size() <= PA_MAXB) rest.swap(keep);
     else nar.clear();
   }
   if (!nar.empty()) {

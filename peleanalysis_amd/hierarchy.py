@@ -351,3 +351,56 @@ def tagged_hierarchy(base_n: int, nlev: int, fn, bf: int = 16, max_box: int = 12
         occ = np.repeat(np.repeat(np.repeat(U, 2, axis=0), 2, axis=1), 2, axis=2)
         nb *= 2
     return Hierarchy(levels, 2)
+
+
+# ----------------------------------------------------------------------------- internal re-tiling (pa_level_retile)
+def retile_level(level: Level, max_size=(128, 128, 128), min_thick: int = 3) -> Level:
+    """The level on the BoxArray pa_level_retile returns for it: the same cells in fewer, larger boxes (host arithmetic
+    in the library, no GPU).  max_size: cells per direction (x, y, z)."""
+    import ctypes as C
+    from . import capi
+    lib = capi.load_library()
+    b = np.ascontiguousarray(level.boxes, dtype=np.int32)
+    cap = 4 * level.nboxes + 16
+    out = np.zeros((cap, 6), dtype=np.int32)
+    mx = (C.c_int32 * 3)(*[int(v) for v in np.broadcast_to(np.asarray(max_size), (3,))])
+    n = lib.pa_level_retile(level.nboxes, b.ctypes.data_as(C.POINTER(C.c_int32)), mx, int(min_thick), out.ctypes.data_as(C.POINTER(C.c_int32)), cap)
+    if n < 0:
+        raise ValueError("pa_level_retile: bad arguments")
+    return Level(out[:n].copy(), level.domlo, level.domhi, level.is_per, level.prob_lo, level.prob_hi)
+
+
+def regrid_copy(src: MultiFab, dst: MultiFab, scomp: int = 0, dcomp: int = 0, ncomp: int | None = None) -> None:
+    """valid cells of src -> valid cells of dst wherever their boxes intersect (two tilings of one cell set: what the tools'
+    read_comp / write_plotfile do between the file's BoxArray and the re-tiled one)."""
+    nc = src.ncomp - scomp if ncomp is None else ncomp
+    sb, db = src.level.boxes.astype(np.int64), dst.level.boxes.astype(np.int64)
+    for a in range(len(db)):
+        lo = np.maximum(db[a, :3], sb[:, :3])
+        hi = np.minimum(db[a, 3:], sb[:, 3:])
+        dv = None
+        for b in np.nonzero((lo <= hi).all(axis=1))[0]:
+            if dv is None:
+                dv = dst.valid(a)
+            sv = src.valid(int(b))
+            l, h = lo[b], hi[b]
+            ds = tuple(slice(int(l[d] - db[a, d]), int(h[d] - db[a, d]) + 1) for d in (2, 1, 0))
+            ss = tuple(slice(int(l[d] - sb[b, d]), int(h[d] - sb[b, d]) + 1) for d in (2, 1, 0))
+            dv[(slice(dcomp, dcomp + nc),) + ds] = sv[(slice(scomp, scomp + nc),) + ss]
+
+
+def retile_hierarchy(H: Hierarchy, max_size=None, min_thick: int = 3) -> Hierarchy:
+    """every level re-tiled with the limits the tools use (pa_hierarchy_retile_limits) or with max_size"""
+    import ctypes as C
+    from . import capi
+    if max_size is None:
+        lib = capi.load_library()
+        pi32 = C.POINTER(C.c_int32)
+        bs = [np.ascontiguousarray(lv.boxes, dtype=np.int32) for lv in H.levels]
+        nb = (C.c_int32 * H.nlev)(*[lv.nboxes for lv in H.levels])
+        ptrs = (pi32 * H.nlev)(*[b.ctypes.data_as(pi32) for b in bs])
+        mx = (C.c_int32 * 3)()
+        if lib.pa_hierarchy_retile_limits(H.nlev, nb, ptrs, int(min_thick), mx) != 0:
+            raise ValueError("pa_hierarchy_retile_limits: bad arguments")
+        max_size = tuple(mx)
+    return Hierarchy([retile_level(lv, max_size, min_thick) for lv in H.levels], H.ref_ratio)
