@@ -900,7 +900,8 @@ def test_tools_multi_gpu_outputs_are_byte_identical(tmp_path, tool, args, suffix
     for n in (1, 2, 4):
         d = tmp_path / f"n{n}"
         d.mkdir()
-        out = _run(tool, ["infile=" + p] + args + [f"ngpus={n}", "gpu_share=1"], d, env={"PA_SMOOTH_REPLICATED": "1"} if smooth else None)
+        # retile=0: the boxes of the FILE are dealt to the ranks (with the internal re-tiling these 16^3 .. 64^3 levels are one box each)
+        out = _run(tool, ["infile=" + p] + args + [f"ngpus={n}", "gpu_share=1", "retile=0"], d, env={"PA_SMOOTH_REPLICATED": "1"} if smooth else None)
         if n > 1:
             assert f"distributed over {n} GPUs" in out.stdout
         if suffix.startswith("surf"):  # isosurface: the surface file(s) in the run directory
@@ -924,7 +925,7 @@ def test_tools_multi_gpu_outputs_are_byte_identical(tmp_path, tool, args, suffix
         for n in (2, 4):
             d = tmp_path / f"dist{n}"
             d.mkdir()
-            _run(tool, ["infile=" + p] + args + [f"ngpus={n}", "gpu_share=1"], d)
+            _run(tool, ["infile=" + p] + args + [f"ngpus={n}", "gpu_share=1", "retile=0"], d)
             r = read_plotfile(str(d / ("plt00005" + suffix)))
             assert r.names == one.names
             isp, ipr = r.names.index("SmoothedProgress"), r.names.index("Progress")
@@ -933,6 +934,37 @@ def test_tools_multi_gpu_outputs_are_byte_identical(tmp_path, tool, args, suffix
                     assert np.array_equal(r.mfs[l].valid(b)[ipr], one.mfs[l].valid(b)[ipr])
                     assert np.abs(r.mfs[l].valid(b)[isp] - one.mfs[l].valid(b)[isp]).max() <= 1e-12, f"distributed smoothing solve on {n} ranks, level {l} box {b}"
                     assert np.isfinite(r.mfs[l].valid(b)).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tool,args,suffix", [
+    ("grad3d.ex", ["gradVar=temp", "is_per=1 1 0", "Aux_Variables=density"], "_gt"),
+    ("curvature3d.ex", ["progressName=temp", "is_per=1 1 0", "Aux_Variables=density"], "_K"),
+    ("curvature3d.ex", ["progressName=temp", "is_per=0 1 1", "sym_dir=1 0 0", "threshold_prog=1", "threshold_value=0.02", "do_gaussCurv=1", "do_strain=1",
+                        "do_velnormal=1"], "_K"),
+    ("filterPlt3d.ex", ["max_grid_size=8", "is_per=1 1 0", "exact_filter=1"], "_filtered"),
+    ("filterPlt3d.ex", ["max_grid_size=16", "interp_type=0", "base_fgr=4", "same_fgr_all_levels=1", "exact_filter=1"], "_filtered"),
+])
+def test_tools_retiled_outputs_are_byte_identical(tmp_path, tool, args, suffix):
+    """retile=1 (the default): the tool holds and sweeps the level on merged boxes (pa_level_retile) and writes the file's
+    BoxArray back -- every byte of the output, the per-FAB minima / maxima of Cell_H included, must equal the run on the
+    file's own boxes (retile=0).  Default limits (one box per level here), small limits (PA_RETILE_MAX: several merged boxes
+    per level, chains cut), and the small limits sharded over two ranks."""
+    p, H, mfs = _synth(tmp_path, nlev=3, base=32, box=8, ncomp=5, names=("temp", "x_velocity", "y_velocity", "z_velocity", "density"))
+    ref = None
+    for name, extra, env in (("file", ["retile=0"], None), ("default", [], None), ("small", ["retile=1"], {"PA_RETILE_MAX": "16 24 16"}),
+                             ("small2", ["ngpus=2", "gpu_share=1"], {"PA_RETILE_MAX": "16 24 16"})):
+        d = tmp_path / name
+        d.mkdir()
+        _run(tool, ["infile=" + p] + args + extra, d, env=env)
+        got = _tree_bytes(str(d / ("plt00005" + suffix)))
+        assert len(got) >= 5
+        if ref is None:
+            ref = got
+            continue
+        assert got.keys() == ref.keys()
+        for k in ref:
+            assert got[k] == ref[k], f"{tool} {name}: {k} differs from the run on the file's boxes"
 
 
 @pytest.mark.gpu

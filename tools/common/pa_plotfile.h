@@ -319,10 +319,14 @@ inline std::string g17(double v) {
 // WriteMultiLevelPlotfile restated: valid cells of comps [0, names.size()) of each level's HostMF
 inline void write_plotfile(const std::string& path, const std::vector<std::string>& names, const std::vector<Box3>& domains,
                            const double prob_lo[3], const double prob_hi[3], std::vector<HostMF>& mf, double time,
-                           const std::vector<int>& level_steps, int ref_ratio = 2, int dim = 3, const std::vector<int>* comps = nullptr) {
+                           const std::vector<int>& level_steps, int ref_ratio = 2, int dim = 3, const std::vector<int>* comps = nullptr,
+                           const std::vector<std::vector<Box3>>* file_boxes = nullptr) {
   // dim = 2: the levels are one plane of cells (k = 0) and the file is what a 2-D AMReX code writes; comps: the HostMF
-  // component behind each name (default: 0, 1, 2, ...)
+  // component behind each name (default: 0, 1, 2, ...); file_boxes: the BoxArray the file gets on each level when the
+  // multifabs live on ANOTHER tiling of the same cells (retile_levels below: the tools compute on merged boxes and write
+  // the input's BoxArray, as grad.cpp:256 does) -- every FAB is then gathered from the multifab boxes it intersects
   const int nlev = (int)mf.size(), ncomp = (int)names.size();
+  auto wboxes = [&](int l) -> const std::vector<Box3>& { return file_boxes ? (*file_boxes)[l] : mf[l].boxes; };
   auto bstr = [dim](const Box3& b) {
     if (dim == 3) return box_str(b);
     char s[160];
@@ -353,8 +357,8 @@ inline void write_plotfile(const std::string& path, const std::vector<std::strin
     }
     f << "0\n0\n";
     for (int l = 0; l < nlev; ++l) {
-      f << l << ' ' << mf[l].boxes.size() << ' ' << g17(time) << "\n" << level_steps[l] << "\n";
-      for (auto& B : mf[l].boxes)
+      f << l << ' ' << wboxes(l).size() << ' ' << g17(time) << "\n" << level_steps[l] << "\n";
+      for (auto& B : wboxes(l))
         for (int d = 0; d < dim; ++d) {
           const double dx = (prob_hi[d] - prob_lo[d]) / (double)(domains[l].hi[d] - domains[l].lo[d] + 1);
           f << g17(prob_lo[d] + B.lo[d] * dx) << ' ' << g17(prob_lo[d] + (B.hi[d] + 1) * dx) << "\n";
@@ -366,7 +370,8 @@ inline void write_plotfile(const std::string& path, const std::vector<std::strin
     const std::string dir = path + "/Level_" + std::to_string(l);
     ::mkdir(dir.c_str(), 0755);
     HostMF& M = mf[l];
-    const size_t nb = M.boxes.size();
+    const std::vector<Box3>& WB = wboxes(l);
+    const size_t nb = WB.size();
     std::vector<long long> offs(nb);
     std::vector<std::vector<double>> mins(nb), maxs(nb);
     {
@@ -375,9 +380,9 @@ inline void write_plotfile(const std::string& path, const std::vector<std::strin
       std::vector<std::string> hdr(nb);
       long long pos = 0;
       for (size_t b = 0; b < nb; ++b) {
-        hdr[b] = "FAB ((8, (64 11 52 0 1 12 0 1023)),(8, (8 7 6 5 4 3 2 1)))" + bstr(M.boxes[b]) + ' ' + std::to_string(ncomp) + "\n";
+        hdr[b] = "FAB ((8, (64 11 52 0 1 12 0 1023)),(8, (8 7 6 5 4 3 2 1)))" + bstr(WB[b]) + ' ' + std::to_string(ncomp) + "\n";
         offs[b] = pos;
-        pos += (long long)hdr[b].size() + (long long)ncomp * M.boxes[b].numPts() * 8;
+        pos += (long long)hdr[b].size() + (long long)ncomp * WB[b].numPts() * 8;
       }
       const std::string fname = dir + "/Cell_D_00000";
       const int fd = ::open(fname.c_str(), O_CREAT | O_TRUNC | O_WRONLY, 0644);
@@ -392,9 +397,44 @@ inline void write_plotfile(const std::string& path, const std::vector<std::strin
         }
       };
       parallel_for(nb, [&](size_t b) {
-        const Box3& B = M.boxes[b];
+        const Box3& B = WB[b];
         const int nx = B.hi[0] - B.lo[0] + 1;
         const long long npts = B.numPts();
+        if (file_boxes) {  // the FAB's cells lie in one or more boxes of the multifab's tiling: gathered run by run
+          std::vector<char> buf(hdr[b].size() + (size_t)ncomp * (size_t)npts * 8);
+          std::memcpy(buf.data(), hdr[b].data(), hdr[b].size());
+          char* base = buf.data() + hdr[b].size();
+          const long long ny = B.hi[1] - B.lo[1] + 1;
+          long long got = 0;
+          for (size_t t = 0; t < M.boxes.size(); ++t) {
+            const Box3& T = M.boxes[t];
+            int lo[3], hi[3];
+            bool in = true;
+            for (int d = 0; d < 3; ++d) { lo[d] = std::max(B.lo[d], T.lo[d]); hi[d] = std::min(B.hi[d], T.hi[d]); in = in && lo[d] <= hi[d]; }
+            if (!in) continue;
+            const size_t run = sizeof(double) * (size_t)(hi[0] - lo[0] + 1);
+            for (int c = 0; c < ncomp; ++c)
+              for (int k = lo[2]; k <= hi[2]; ++k)
+                for (int j = lo[1]; j <= hi[1]; ++j)
+                  std::memcpy(base + 8 * ((long long)c * npts + ((long long)(k - B.lo[2]) * ny + (j - B.lo[1])) * nx + (lo[0] - B.lo[0])), M.ptr((int)t, src(c), lo[0], j, k), run);
+            got += (long long)(hi[0] - lo[0] + 1) * (hi[1] - lo[1] + 1) * (hi[2] - lo[2] + 1);
+          }
+          if (got != npts) { bad[b] = 1; return; }  // the two tilings do not hold the same cells
+          std::vector<double> mn(ncomp, 1e300), mx(ncomp, -1e300);
+          std::vector<double> tmp;
+          for (int c = 0; c < ncomp; ++c) {
+            const char* p = base + 8 * (long long)c * npts;
+            if (((uintptr_t)p & 7u) == 0) minmax_run((const double*)p, npts, mn[c], mx[c]);
+            else {  // the header's length leaves the data unaligned: through an aligned copy
+              tmp.resize((size_t)npts);
+              std::memcpy(tmp.data(), p, (size_t)npts * 8);
+              minmax_run(tmp.data(), npts, mn[c], mx[c]);
+            }
+          }
+          mins[b] = mn; maxs[b] = mx;
+          put(b, buf.data(), buf.size(), offs[b]);
+          return;
+        }
         if (M.ng == 0) {  // a component of a ghost-free FAB is one contiguous run: written straight from the multifab
           std::vector<double> mn(ncomp, 1e300), mx(ncomp, -1e300);
           put(b, hdr[b].data(), hdr[b].size(), offs[b]);
@@ -423,16 +463,16 @@ inline void write_plotfile(const std::string& path, const std::vector<std::strin
         put(b, buf.data(), buf.size(), offs[b]);
       });
       ::close(fd);
-      for (int x : bad) if (x) Abort("short write to " + fname);
+      for (int x : bad) if (x) Abort("short write to " + fname + (file_boxes ? " (or the output BoxArray does not match the computed tiling)" : ""));
     }
     std::ofstream h(dir + "/Cell_H");
-    h << "1\n1\n" << ncomp << "\n0\n(" << M.boxes.size() << " 0\n";
-    for (auto& B : M.boxes) h << bstr(B) << "\n";
-    h << ")\n" << M.boxes.size() << "\n";
-    for (size_t b = 0; b < M.boxes.size(); ++b) h << "FabOnDisk: Cell_D_00000 " << offs[b] << "\n";
-    h << "\n" << M.boxes.size() << "," << ncomp << "\n";
+    h << "1\n1\n" << ncomp << "\n0\n(" << nb << " 0\n";
+    for (auto& B : WB) h << bstr(B) << "\n";
+    h << ")\n" << nb << "\n";
+    for (size_t b = 0; b < nb; ++b) h << "FabOnDisk: Cell_D_00000 " << offs[b] << "\n";
+    h << "\n" << nb << "," << ncomp << "\n";
     for (auto& m : mins) { for (double v : m) h << g17(v) << ","; h << "\n"; }
-    h << "\n" << M.boxes.size() << "," << ncomp << "\n";
+    h << "\n" << nb << "," << ncomp << "\n";
     for (auto& m : maxs) { for (double v : m) h << g17(v) << ","; h << "\n"; }
   }
 }
@@ -552,6 +592,53 @@ inline std::vector<Box3> max_size(const std::vector<Box3>& in, int n) {
         for (auto& x : cut[0]) out.push_back(Box3{{x.first, y.first, z.first}, {x.second, y.second, z.second}});
   }
   return out;
+}
+
+// Internal re-tiling (pa_level_retile, include/peleanalysis_amd.h): the boxes the tools COMPUTE on for each level -- the file's
+// cells merged into the largest rectangles -- while their output keeps the file's BoxArray (write_plotfile's file_boxes).
+// retile=0 on the command line: the file's boxes as they are.  read_comp fills such boxes from every file FAB they intersect.
+inline std::vector<std::vector<Box3>> retile_levels(const std::vector<std::vector<Box3>>& file_boxes, const ParmParse& pp) {
+  int on = 1;
+  pp.query("retile", on);
+  if (!on) return file_boxes;
+  const int nlev = (int)file_boxes.size();
+  std::vector<std::vector<int32_t>> b6(nlev);
+  std::vector<int32_t> nb(nlev);
+  std::vector<const int32_t*> ptr(nlev);
+  for (int l = 0; l < nlev; ++l) {
+    nb[l] = (int32_t)file_boxes[l].size();
+    for (const Box3& B : file_boxes[l]) {
+      for (int d = 0; d < 3; ++d) b6[l].push_back(B.lo[d]);
+      for (int d = 0; d < 3; ++d) b6[l].push_back(B.hi[d]);
+    }
+    ptr[l] = b6[l].data();
+  }
+  int32_t mx[3];
+  if (pa_hierarchy_retile_limits(nlev, nb.data(), ptr.data(), 3, mx) != 0) return file_boxes;
+  std::vector<std::vector<Box3>> out(nlev);
+  for (int l = 0; l < nlev; ++l) {
+    const int cap = 4 * nb[l] + 16;
+    std::vector<int32_t> o6((size_t)cap * 6);
+    const int n = nb[l] > 0 ? pa_level_retile(nb[l], b6[l].data(), mx, 3, o6.data(), cap) : 0;
+    if (n <= 0) { out[l] = file_boxes[l]; continue; }
+    for (int b = 0; b < n; ++b) out[l].push_back(Box3{{o6[6 * b], o6[6 * b + 1], o6[6 * b + 2]}, {o6[6 * b + 3], o6[6 * b + 4], o6[6 * b + 5]}});
+  }
+  return out;
+}
+// write_plotfile's file_boxes argument: null when the computed tiling IS the file's (the writer then streams ghost-free FABs
+// straight from the multifab)
+inline const std::vector<std::vector<Box3>>* boxes_if_retiled(const std::vector<std::vector<Box3>>& file_boxes, const std::vector<std::vector<Box3>>& tile) {
+  bool same = file_boxes.size() == tile.size();
+  for (size_t l = 0; same && l < tile.size(); ++l) {
+    same = file_boxes[l].size() == tile[l].size();
+    for (size_t b = 0; same && b < tile[l].size(); ++b) same = std::memcmp(&file_boxes[l][b], &tile[l][b], sizeof(Box3)) == 0;
+  }
+  return same ? nullptr : &file_boxes;
+}
+inline std::vector<std::vector<Box3>> level_boxes(const PlotfileHeader& H, int nlev) {
+  std::vector<std::vector<Box3>> b;
+  for (int l = 0; l < nlev; ++l) b.push_back(H.lev[l].boxes);
+  return b;
 }
 
 }  // namespace pa

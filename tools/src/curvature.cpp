@@ -130,19 +130,23 @@ int main(int argc, char** argv) {
   pa::AsyncTeam ateam(pp);  // the HIP contexts (ngpus of them, pa_team.h) come up behind the reads
   std::vector<pa::HostMF> in(Nlev), ostate(Nlev);
   std::vector<pa::Box3> doms;
+  // retile=1 (default): data held and swept on the file's cells merged into large boxes (pa_level_retile; identical results in
+  // every cell), written back on the file's BoxArray
+  const std::vector<std::vector<pa::Box3>> fileBoxes = pa::level_boxes(H, Nlev), tile = pa::retile_levels(fileBoxes, pp);
   for (int lev = 0; lev < Nlev; ++lev) {
     if (verbose) std::cout << "Reading data for level " << lev << "\n";
-    in[lev].define(H.lev[lev].boxes, nCompDev, 2);
+    in[lev].define(tile[lev], nCompDev, 2);
     for (int c = 0; c < nCompIn; ++c) pa::read_comp(H, lev, inComps[c], in[lev], devOf(c));
     for (auto& B : H.lev[lev].boxes) tm.cells += B.numPts();
     doms.push_back(H.lev[lev].domain);
-    ostate[lev].define(H.lev[lev].boxes, nCompOut, 0);
+    ostate[lev].define(tile[lev], nCompOut, 0);
   }
   tm.mark("read");
   pa::Team& team = ateam.get();
   tm.mark("hip_context_wait");
   if (team.n > 1) std::cout << "Boxes distributed over " << team.n << " GPUs, transport: " << team.transport << std::endl;
-  const std::vector<std::vector<int32_t>> owner = pa::shard_levels(H, Nlev, team.n);
+  std::vector<std::vector<int32_t>> owner(Nlev);
+  for (int lev = 0; lev < Nlev; ++lev) owner[lev] = pa::shard_boxes(tile[lev], team.n);  // DistributionMapping(ba), curvature.cpp:289
   // ngpus > 1: the reference's MPI ranks own the FABs DistributionMapping gives them (curvature.cpp:289); here every rank
   // (host thread + GPU) runs the same pipeline on its share and the library fills ghost cells across ranks.  do_smooth: the
   // composite solve is DISTRIBUTED like the reference's MLMG (every rank iterates on its own boxes; restriction, ghost fills,
@@ -157,8 +161,8 @@ int main(int argc, char** argv) {
     std::vector<pa::Share> sh;
     std::vector<pa::HostMF> loc(Nlev);
     for (int lev = 0; lev < Nlev; ++lev) {
-      sh.emplace_back(H.lev[lev].boxes, owner[lev], r);
-      dl.emplace_back(new pa::DevLevel(ctx, H.lev[lev].boxes, H.lev[lev].domain, is_per.data(), H.prob_lo, H.prob_hi, &owner[lev], r, team.n));
+      sh.emplace_back(tile[lev], owner[lev], r);
+      dl.emplace_back(new pa::DevLevel(ctx, tile[lev], H.lev[lev].domain, is_per.data(), H.prob_lo, H.prob_hi, &owner[lev], r, team.n));
       dst.emplace_back(new pa::DevMF(ctx, *dl.back(), nCompDev, 2));
       dwork.emplace_back(new pa::DevMF(ctx, *dl.back(), 1, 2));
       dout.emplace_back(new pa::DevMF(ctx, *dl.back(), nres, 0));
@@ -254,7 +258,7 @@ int main(int argc, char** argv) {
   if (do_velnormal) nnames[idVelNormal] = "VelFlameNormal";
   std::cout << "Writing new data to " << outfile << "\n";
   std::vector<int> isteps(Nlev, 0);
-  pa::write_plotfile(outfile, nnames, doms, H.prob_lo, H.prob_hi, ostate, 0.0, isteps, 2, PA_SPACEDIM);
+  pa::write_plotfile(outfile, nnames, doms, H.prob_lo, H.prob_hi, ostate, 0.0, isteps, 2, PA_SPACEDIM, nullptr, pa::boxes_if_retiled(fileBoxes, tile));
   tm.mark("write");
   tm.report();
   pa::Finish();

@@ -74,6 +74,12 @@ int main(int argc, char** argv) {
   std::vector<pa::Box3> doms;
   std::vector<int> ngs;
   std::vector<std::vector<double>> ws;
+  // The output BoxArray is the file's re-chopped to max_grid_size (filterPlt.cpp:141); the data are held and filtered on the
+  // same cells merged into large boxes (retile=1, the default; pa_level_retile) -- Filter::apply_filter and the ghost fill are
+  // point-wise functions of the level's cells, tests/test_retile.py -- and written back on that BoxArray.
+  std::vector<std::vector<pa::Box3>> chopped(Nlev);
+  for (int lev = 0; lev < Nlev; ++lev) chopped[lev] = pa::max_size(H.lev[lev].boxes, max_grid_size);
+  const std::vector<std::vector<pa::Box3>> tile = pa::retile_levels(chopped, pp);
   std::cout << "Reading data..." << std::endl;
   int fgr_lev = fgr;
   for (int lev = 0; lev < Nlev; ++lev) {
@@ -84,7 +90,7 @@ int main(int argc, char** argv) {
     if (ng < 0 || ng > 16) pa::Abort("filter width on level " + std::to_string(lev) + " (filter-to-grid ratio " + std::to_string(fgr_lev) + ") exceeds 16 ghost cells");
     ngs.push_back(ng);
     ws.push_back(w);
-    const std::vector<pa::Box3> ba = pa::max_size(H.lev[lev].boxes, max_grid_size);
+    const std::vector<pa::Box3>& ba = tile[lev];
     host[lev].define(ba, ncomp, ng);
     for (int c = 0; c < ncomp; ++c) pa::read_comp(H, lev, comps[c], host[lev], c);
     for (auto& B : ba) tm.cells += B.numPts();
@@ -165,7 +171,7 @@ int main(int argc, char** argv) {
   std::cout << "Done!" << std::endl << "Saving filtered data..." << std::endl;
   tm.mark("download");
   std::vector<int> steps(Nlev, 0);
-  pa::write_plotfile(pa::getFileRoot(infile) + "_filtered", names, doms, H.prob_lo, H.prob_hi, out, H.time, steps, 2, PA_SPACEDIM);
+  pa::write_plotfile(pa::getFileRoot(infile) + "_filtered", names, doms, H.prob_lo, H.prob_hi, out, H.time, steps, 2, PA_SPACEDIM, nullptr, pa::boxes_if_retiled(chopped, tile));
   tm.mark("write");
   std::cout << "Done!" << std::endl;
   tm.report();

@@ -1,6 +1,8 @@
 // grad3d -- drop-in for PeleAnalysis Src/grad.cpp on MI355X.
 //   grad3d.ex infile=<plt> [gradVar=temp] [finestLevel=<n>] [Aux_Variables="a b"] [sym_dir="0 0 0"]
-//             [is_per="1 1 1"] [outfile=<root>_gt] [ngpus=<n>] [gpu_share=0|1]
+//             [is_per="1 1 1"] [outfile=<root>_gt] [ngpus=<n>] [gpu_share=0|1] [retile=1|0]
+// retile=1 (default): the level data are held and swept on an internal tiling -- the file's cells merged into large boxes
+// (pa_level_retile; results identical in every cell, tests/test_retile.py) -- and written back on the file's BoxArray.
 // ngpus=<n>: the boxes of every level are dealt to n GPUs (one host thread each, pa_team.h) the way the reference's MPI ranks
 // own them (DistributionMapping, grad.cpp:162); the output is byte-identical for every n.
 // Output plotfile components: [gradVar, aux..., <v>_gx, <v>_gy, <v>_gz, ||grad<v>||], time 0, steps 0,
@@ -69,9 +71,10 @@ int main(int argc, char** argv) {
   pa::AsyncTeam ateam(pp);  // the HIP contexts (ngpus of them) come up behind the reads
   std::vector<pa::HostMF> state(Nlev);
   std::vector<pa::Box3> doms;
+  const std::vector<std::vector<pa::Box3>> fileBoxes = pa::level_boxes(H, Nlev), tile = pa::retile_levels(fileBoxes, pp);
   for (int lev = 0; lev < Nlev; ++lev) {
     std::cout << "Reading data for level: " << lev << std::endl;
-    state[lev].define(H.lev[lev].boxes, nCompOut, 1);
+    state[lev].define(tile[lev], nCompOut, 1);
     for (int c = 0; c < nCompIn; ++c) pa::read_comp(H, lev, inComps[c], state[lev], c);
     for (auto& B : H.lev[lev].boxes) tm.cells += B.numPts();
     doms.push_back(H.lev[lev].domain);
@@ -80,7 +83,8 @@ int main(int argc, char** argv) {
   pa::Team& team = ateam.get();
   tm.mark("hip_context_wait");
   if (team.n > 1) std::cout << "Boxes distributed over " << team.n << " GPUs, transport: " << team.transport << std::endl;
-  const std::vector<std::vector<int32_t>> owner = pa::shard_levels(H, Nlev, team.n);
+  std::vector<std::vector<int32_t>> owner(Nlev);
+  for (int lev = 0; lev < Nlev; ++lev) owner[lev] = pa::shard_boxes(tile[lev], team.n);  // DistributionMapping(ba), grad.cpp:162
   team.run([&](int r) {  // one rank: its boxes of every level through the library's pipeline (cross-rank ghost fills inside)
     pa::Ctx& ctx = *team.ctx[r];
     std::vector<std::unique_ptr<pa::DevLevel>> dl;
@@ -88,8 +92,8 @@ int main(int argc, char** argv) {
     std::vector<pa::Share> sh;
     std::vector<pa::HostMF> loc(Nlev);
     for (int lev = 0; lev < Nlev; ++lev) {
-      sh.emplace_back(H.lev[lev].boxes, owner[lev], r);
-      dl.emplace_back(new pa::DevLevel(ctx, H.lev[lev].boxes, H.lev[lev].domain, is_per.data(), H.prob_lo, H.prob_hi, &owner[lev], r, team.n));
+      sh.emplace_back(tile[lev], owner[lev], r);
+      dl.emplace_back(new pa::DevLevel(ctx, tile[lev], H.lev[lev].domain, is_per.data(), H.prob_lo, H.prob_hi, &owner[lev], r, team.n));
       dmf.emplace_back(new pa::DevMF(ctx, *dl.back(), nCompOut, 1));
       pa::HostMF& src = team.n > 1 ? loc[lev] : state[lev];
       if (team.n > 1) sh.back().gather(state[lev], loc[lev]);
@@ -125,7 +129,7 @@ int main(int argc, char** argv) {
   pp.query("outfile", outfile);
   std::cout << "Writing new data to " << outfile << std::endl;
   std::vector<int> isteps(Nlev, 0);
-  pa::write_plotfile(outfile, nnames, doms, H.prob_lo, H.prob_hi, state, 0.0, isteps, 2, PA_SPACEDIM, &ocomps);
+  pa::write_plotfile(outfile, nnames, doms, H.prob_lo, H.prob_hi, state, 0.0, isteps, 2, PA_SPACEDIM, &ocomps, pa::boxes_if_retiled(fileBoxes, tile));
   tm.mark("write");
   tm.report();
   pa::Finish();
