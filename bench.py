@@ -125,16 +125,28 @@ def cpu_baseline(base, nlev, box):
     return res, (H, states, og, oc)
 
 
-def parity_check(ctx, sample):
+def parity_check(ctx, sample, retile=1):
     """The oracle's outputs of the cpu_baseline sample (production geometry: 128^3 boxes, two x tiles x ten row tiles x two z
     segments per box, all levels in one sweep launch) against the HIP path on the SAME inputs, bit for bit: the checker's work
     is already paid for by the baseline leg, the GPU pass and the download add a few seconds."""
     from peleanalysis_amd import capi
+    from peleanalysis_amd.hierarchy import MultiFab, regrid_copy, retile_hierarchy
     H, states, og, oc = sample
     t0 = time.perf_counter()
     bc = capi.bc_from_flags((1, 1, 0))
-    dls = [capi.DevLevel(ctx, lv) for lv in H.levels]
-    dst = [capi.DevMF.from_host(ctx, dl, s) for dl, s in zip(dls, states)]
+    # as the tools: the file's FABs into the internal tiling, the HIP path there, the results back per FILE box -- against the oracle
+    # run on the file's boxes
+    T = retile_hierarchy(H) if retile else H
+    if retile:
+        tst = []
+        for s, tv in zip(states, T.levels):
+            m = MultiFab(tv, s.ncomp, s.ng)
+            regrid_copy(s, m)
+            tst.append(m)
+    else:
+        tst = states
+    dls = [capi.DevLevel(ctx, lv) for lv in T.levels]
+    dst = [capi.DevMF.from_host(ctx, dl, s) for dl, s in zip(dls, tst)]
     work = [capi.DevMF(ctx, dl, 1, 2) for dl in dls]
     dout = [capi.DevMF(ctx, dl, 8, 0) for dl in dls]
     capi.gradcurv_run(ctx, dst, 0, bc, capi.curv_params(prog_min=300.0, prog_max=2000.0, threshold=None, fused=True), work, dout, 0)
@@ -144,6 +156,10 @@ def parity_check(ctx, sample):
     pairs = [(0, og, 0), (1, og, 1), (2, og, 2), (3, og, 3), (4, oc, 2), (5, oc, 3), (6, oc, 4), (7, oc, 1)]
     for l, lv in enumerate(H.levels):
         got = dout[l].download()
+        if retile:
+            back = MultiFab(lv, 8, 0)
+            regrid_copy(got, back)
+            got = back
         for b in range(lv.nboxes):
             g = got.valid(b)
             for gc, ref, rc in pairs:
@@ -152,11 +168,11 @@ def parity_check(ctx, sample):
                 ncmp += w.size
         del got
     return {"cells": sum(lv.ncells for lv in H.levels), "values_compared": ncmp, "values_differing": nbad, "bits_equal": nbad == 0 and ctx.bc_errors() == 0,
-            "kernel": kn, "outputs": "gx gy gz |g| Nx Ny Nz K of every valid cell of every level, oracle (cpu_baseline sample) vs HIP path, int64 view",
+            "kernel": kn, "tiling": {"file_boxes_per_level": [lv.nboxes for lv in H.levels], "swept_boxes_per_level": [lv.nboxes for lv in T.levels]}, "outputs": "gx gy gz |g| Nx Ny Nz K of every valid cell of every level, oracle (cpu_baseline sample) vs HIP path, int64 view",
             "seconds": round(time.perf_counter() - t0, 2)}
 
 
-def live_traffic(timeout_s=150):
+def live_traffic(timeout_s=150, retile=1):
     """HBM bytes per launch of the fused sweep, measured NOW on this box: two child runs of the torch-free driver on the
     headline hierarchy under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes; FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for gfx950: 64 B counted per 128-B request).  Returns (bytes or None, note)."""
@@ -173,7 +189,7 @@ def live_traffic(timeout_s=150):
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="pa_pmc_", dir="/tmp")
         try:
-            subprocess.run(["rocprofv3", "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.join(ROOT, "tools", "prof_driver.py"), "512", "128", "2"],
+            subprocess.run(["rocprofv3", "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.join(ROOT, "tools", "prof_driver.py"), "512", "128", "2", str(int(retile))],
                            stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, env=env, cwd=ROOT, check=True)
             tot, ids = 0.0, set()
             for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
@@ -188,10 +204,10 @@ def live_traffic(timeout_s=150):
             return None, f"{ctr} pass failed: {repr(e)[:120]}"
         finally:
             shutil.rmtree(d, ignore_errors=True)
-    return int(2.0 * per["FETCH_SIZE"] + per["WRITE_SIZE"]), "measured in this run: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE -- python3 tools/prof_driver.py 512 128 2 (FETCH x2)"
+    return int(2.0 * per["FETCH_SIZE"] + per["WRITE_SIZE"]), "measured in this run: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE -- python3 tools/prof_driver.py 512 128 2 " + str(int(retile)) + " (FETCH x2)"
 
 
-def secondary(ctx, torch, stream, dev, only=None):
+def secondary(ctx, torch, stream, dev, only=None, retile=1):
     """The other kernel families of the path in front of the driver (N = 1 only, after the timed headline region; a few
     seconds in all): BASELINE configs 2, 3 and 4, the gradient alone, and the headline hierarchy in 64^3 and 32^3 boxes.
     Each entry: wall-clock ms per pass on the library's stream (launches + stream sync, second and third pass), the
@@ -234,48 +250,72 @@ def secondary(ctx, torch, stream, dev, only=None):
     def want(name):  # --secondary-only <name>: one entry (kernel work on one family without the rest of the bench)
         return only is None or only == name
 
-    def gradcurv_case(name, base, nlev, box, ncomp, per, nbatch=1):
-        H = nested_hierarchy(base, nlev, box, is_per=per)
-        dls = [capi.DevLevel(ctx, lv) for lv in H.levels]
+    def tiling_txt(Hf, T):
+        return (f"file tiling {[lv.nboxes for lv in Hf.levels]} boxes per level, swept on the internal tiling pa_level_retile makes of it: "
+                f"{[lv.nboxes for lv in T.levels]} boxes per level") if T is not Hf else f"swept on the file's tiling ({[lv.nboxes for lv in Hf.levels]} boxes per level)"
+
+    def gradcurv_on(T, ncomp, per, nbatch, seed0=77):
+        """ms per pass of pa_gradcurv_run_comps2 on the tiling T (allocated, run, released)"""
+        dls = [capi.DevLevel(ctx, lv) for lv in T.levels]
         keep, st, wk, ou = [], [], [], []
-        for li, (lv, dl) in enumerate(zip(H.levels, dls)):
-            a, b_, c_ = alloc(lv, dl, ncomp, 2, "flame", 77 + li), alloc(lv, dl, 1, 2), alloc(lv, dl, 8 * nbatch, 0)
+        for li, (lv, dl) in enumerate(zip(T.levels, dls)):
+            a, b_, c_ = alloc(lv, dl, ncomp, 2, "flame", seed0 + li), alloc(lv, dl, 1, 2), alloc(lv, dl, 8 * nbatch, 0)
             keep += [a[0], b_[0], c_[0]]
             st.append(a[1]); wk.append(b_[1]); ou.append(c_[1])
         stream.synchronize()
         bc = capi.bc_from_flags(per)
         params = capi.curv_params(prog_min=300.0, prog_max=2000.0 * (1.0 + 0.1 * ncomp) + 3.0 * ncomp, threshold=None, fused=True)
-        cells = sum(lv.ncells for lv in H.levels) * ncomp
         ms = timed(lambda: capi.gradcurv_run_comps2(ctx, st, 0, ncomp, bc, params, wk, ou, 0, nbatch))
         assert ctx.bc_errors() == 0
-        out[name] = entry(ms, cells, 72, workload=f"fused grad->curvature, {nlev}-level base {base}^3, {box}^3 boxes, {ncomp} comp(s)" +
-                          (f" in batches of {nbatch} (pa_gradcurv_run_comps2)" if nbatch > 1 else "") + f", is_per {per}")
-        return H, dls, keep, st
+        kn = ctx.lib.pa_sweep_kernel_name(ctx.h).decode()
+        for x in st + wk + ou:
+            x.close()
+        for d in dls:
+            d.close()
+        del keep
+        torch.cuda.empty_cache()
+        return ms, kn
+
+    def gradcurv_case(name, base, nlev, box, ncomp, per, nbatch=1, also_file=False):
+        # as the tools run a plotfile: the file's boxes (box^3) merged by pa_level_retile, the sweep on the merged boxes; also_file:
+        # the same pass on the file's own boxes beside it (retile=0)
+        from peleanalysis_amd.hierarchy import retile_hierarchy
+        H = nested_hierarchy(base, nlev, box, is_per=per)
+        T = retile_hierarchy(H) if retile else H
+        cells = sum(lv.ncells for lv in H.levels) * ncomp
+        ms, kn = gradcurv_on(T, ncomp, per, nbatch)
+        extra = {}
+        if also_file and T is not H:
+            ms_f, kn_f = gradcurv_on(H, ncomp, per, nbatch)
+            extra = {"file_tiling_ms": ms_f, "file_tiling_frac_hbm": cells * 72 / (ms_f * 1e-3) / 1e9 / HBM_PEAK_GBS, "file_tiling_sweep_kernel": kn_f}
+        out[name] = entry(ms, cells, 72, sweep_kernel=kn, workload=f"fused grad->curvature, {nlev}-level base {base}^3, {box}^3 boxes in the file, {ncomp} comp(s)" +
+                          (f" in batches of {nbatch} (pa_gradcurv_run_comps2)" if nbatch > 1 else "") + f", is_per {per}; " + tiling_txt(H, T), **extra)
 
     # BASELINE config 2: single level 512^3, 10 components
     if want("c2_1lev_512_10comp"):
-        h = gradcurv_case("c2_1lev_512_10comp", 512, 1, 128, 10, (1, 1, 1), nbatch=int(os.environ.get("PA_C2_NBATCH", "10")))  # all 10 components in one batch: one FillBoundary launch and one sweep launch (slots) for all of them, 86 GB of outputs; 1: component by component (20.8 against 19.0 ms)
-        del h
-        torch.cuda.empty_cache()
+        gradcurv_case("c2_1lev_512_10comp", 512, 1, 128, 10, (1, 1, 1), nbatch=int(os.environ.get("PA_C2_NBATCH", "10")))  # all 10 components in one batch: one FillBoundary launch and one sweep launch (slots) for all of them, 86 GB of outputs; 1: component by component (20.8 against 19.0 ms)
     # BASELINE config 5's shape on one GPU, 8 of its 55 components: 4 levels of 256^3 cells in 64^3 boxes, components in one batch
     if want("c5_shape_4lev_256_8comp"):
-        h = gradcurv_case("c5_shape_4lev_256_8comp", 256, 4, 64, 8, (1, 1, 0), nbatch=8)
-        del h
-        torch.cuda.empty_cache()
+        gradcurv_case("c5_shape_4lev_256_8comp", 256, 4, 64, 8, (1, 1, 0), nbatch=8, also_file=True)
     # the headline hierarchy in smaller boxes (SURVEY 7.4(3))
     for box in (64, 32):
         if not want(f"headline_box{box}"):
             continue
-        h = gradcurv_case(f"headline_box{box}", 512, 3, box, 1, (1, 1, 0))
-        del h
-        torch.cuda.empty_cache()
+        gradcurv_case(f"headline_box{box}", 512, 3, box, 1, (1, 1, 0), also_file=True)
     def irregular_case():
         # An IRREGULAR hierarchy, what a Pele plotfile holds (grad.cpp:173-213 / curvature.cpp:426-457 run on whatever BoxArray the
         # file has): the headline field on a 512^3 base, finer levels tagged where |grad T| is largest -- the wrinkled flame sheet --
         # in blocks of 32 fine cells, merged into boxes of 32 .. 128 cells per side.  L-shaped regions, faces that are partly
         # covered by a neighbour and partly coarse-fine, concave coarse-fine corners; the irregular cells go through k_curv_general.
-        from peleanalysis_amd.hierarchy import tagged_hierarchy, field_flame
-        Hi = tagged_hierarchy(512, 3, lambda x, y, z: field_flame(x, y, z, 0), bf=16, max_box=128, base_box=128, frac=(0.08, 0.16), is_per=(1, 1, 0))
+        # As the tools do, the pass runs on the internal tiling pa_level_retile makes of those boxes; the file's own tiling beside it.
+        from peleanalysis_amd.hierarchy import tagged_hierarchy, field_flame, retile_hierarchy
+        Hf = tagged_hierarchy(512, 3, lambda x, y, z: field_flame(x, y, z, 0), bf=16, max_box=128, base_box=128, frac=(0.08, 0.16), is_per=(1, 1, 0))
+        Hi = retile_hierarchy(Hf) if retile else Hf
+        ci = sum(lv.ncells for lv in Hf.levels)
+        extra = {}
+        if Hi is not Hf:
+            ms_f, kn_f = gradcurv_on(Hf, 1, (1, 1, 0), 1, seed0=177)
+            extra = {"file_tiling_ms": ms_f, "file_tiling_frac_hbm": ci * 72 / (ms_f * 1e-3) / 1e9 / HBM_PEAK_GBS, "file_tiling_sweep_kernel": kn_f}
         dli = [capi.DevLevel(ctx, lv) for lv in Hi.levels]
         keep, st, wk, ou = [], [], [], []
         for li, (lv, dl) in enumerate(zip(Hi.levels, dli)):
@@ -307,31 +347,34 @@ def secondary(ctx, torch, stream, dev, only=None):
         for a, b_ in zip(keep_f, keep[2::3]):
             ndiff += int((a.view(torch.int64) != b_.view(torch.int64)).sum().item())
         del keep_f
-        ci = sum(lv.ncells for lv in Hi.levels)
-        widths = [np.bincount(((lv.boxes[:, 3] - lv.boxes[:, 0] + 1) // 32).astype(int), minlength=5)[1:5].tolist() for lv in Hi.levels]
+        wid = lambda H_: [np.bincount(np.minimum((lv.boxes[:, 3] - lv.boxes[:, 0] + 1 + 31) // 32, 9).astype(int), minlength=10)[1:].tolist() for lv in H_.levels]
         out["irregular_amr"] = entry(ms, ci, 72, boxes_per_level=[lv.nboxes for lv in Hi.levels], cells_per_level=[lv.ncells for lv in Hi.levels],
-                                     boxes_32_64_96_128_wide_per_level=widths, irregular_cells_per_level=nirr, irregular_cell_share=sum(nirr) / ci,
+                                     file_boxes_per_level=[lv.nboxes for lv in Hf.levels],
+                                     boxes_by_width_in_32s_per_level=wid(Hi), file_boxes_by_width_in_32s_per_level=wid(Hf),
+                                     irregular_cells_per_level=nirr, irregular_cell_share=sum(nirr) / ci,
                                      share_of_boxes_on_fused_pipeline=1.0 if ("CG=1" in kn or "march3_levels" in kn) else 0.0, sweep_kernel=kn,
                                      pass_by_pass_ms=ms_pp, pass_by_pass_frac_hbm=ci * 72 / (ms_pp * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                      grad_only_ms=ms_grad, grad_only_frac_hbm=ci * 40 / (ms_grad * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                      fused_vs_pass_by_pass_values_differing=ndiff,
                                      workload="fused grad->curvature, 3-level AMR, base 512^3, levels 1-2 = the blocks of 32 fine cells with the largest |grad T| (8 % / 16 % of "
-                                              "the coarser level's blocks: the wrinkled flame sheet), boxes of 32..128 cells per side, 1 comp, periodic x/y + wall z; "
-                                              "pass_by_pass_ms = the same hierarchy with fused=0 (the pre-round-4 path for such BoxArrays)")
+                                              "the coarser level's blocks: the wrinkled flame sheet), boxes of 32..128 cells per side in the file, 1 comp, periodic x/y + wall z; " +
+                                              tiling_txt(Hf, Hi) + "; pass_by_pass_ms = the same tiling with fused=0 (the pre-round-4 path for such BoxArrays)", **extra)
         del keep, st, wk, ou, dli, Hi
         torch.cuda.empty_cache()
     if want("irregular_amr"):
         irregular_case()
     def grad_only_case():
         # the gradient alone on the headline hierarchy (grad.cpp:211-236; 40 B/cell)
-        H = nested_hierarchy(512, 3, 128, is_per=(1, 1, 0))
+        from peleanalysis_amd.hierarchy import retile_hierarchy
+        Hf = nested_hierarchy(512, 3, 128, is_per=(1, 1, 0))
+        H = retile_hierarchy(Hf) if retile else Hf
         dls = [capi.DevLevel(ctx, lv) for lv in H.levels]
         ins = [alloc(lv, dl, 1, 1, "flame", 5 + li) for li, (lv, dl) in enumerate(zip(H.levels, dls))]
         gos = [alloc(lv, dl, 4, 0) for lv, dl in zip(H.levels, dls)]
         stream.synchronize()
         bc = capi.bc_from_flags((1, 1, 0))
         ms = timed(lambda: capi.grad_run(ctx, [a[1] for a in ins], 0, bc, [g[1] for g in gos], 0))
-        out["grad_only_headline"] = entry(ms, sum(lv.ncells for lv in H.levels), 40, workload="grad (ghost fills + k_grad_march), 3-level base 512^3, 128^3 boxes, 1 comp")
+        out["grad_only_headline"] = entry(ms, sum(lv.ncells for lv in H.levels), 40, workload="grad (ghost fills + k_grad_march), 3-level base 512^3, 128^3 boxes in the file, 1 comp; " + tiling_txt(Hf, H))
         del ins, gos, dls, H
         torch.cuda.empty_cache()
 
@@ -339,7 +382,9 @@ def secondary(ctx, torch, stream, dev, only=None):
         grad_only_case()
     def c3_case():
         # BASELINE config 3: filterPlt's ghost fill + box filter (fgr 2 / 4 / 8 on levels 0 / 1 / 2) + grad of the filtered field
-        H = nested_hierarchy(256, 3, 64, is_per=(1, 1, 0))
+        from peleanalysis_amd.hierarchy import retile_hierarchy
+        Hf = nested_hierarchy(256, 3, 64, is_per=(1, 1, 0))
+        H = retile_hierarchy(Hf, (128, 128, 128)) if retile else Hf  # as filterPlt3d: the re-chopped file boxes merged (at most 128^3: k_filter_sep deals boxes to the XCDs), written back per file box
         bc = capi.bc_from_flags((1, 1, 0))
         dls = [capi.DevLevel(ctx, lv) for lv in H.levels]
         ngs, ws = [1, 2, 4], []
@@ -382,7 +427,7 @@ def secondary(ctx, torch, stream, dev, only=None):
             c3[f"filter_fgr{2 << l}_level{l}"] = entry(m, H.levels[l].ncells, 16)
         c3["filter_all_levels_ms"] = timed(filt_all, reps=4)
         c3["grad_ms"] = timed(lambda: capi.grad_run(ctx, [f[1] for f in fout], 0, bc, [g[1] for g in gout], 0))
-        c3.update(entry(timed(c3_all), c3cells, None, workload="filterPlt ghost fill + separable box filter fgr 2/4/8 + grad, 3-level base 256^3, 64^3 boxes, 1 comp"))
+        c3.update(entry(timed(c3_all), c3cells, None, workload="filterPlt ghost fill + separable box filter fgr 2/4/8 + grad, 3-level base 256^3, 64^3 boxes in the file, 1 comp; " + tiling_txt(Hf, H)))
         assert ctx.bc_errors() == 0
         out["c3_filter_grad_base256"] = c3
         del fin, fout, gout
@@ -466,6 +511,8 @@ def main():
     ap.add_argument("--ncomp", type=int, default=1, help="components pushed through grad->curvature per step")
     ap.add_argument("--nbatch", type=int, default=8, help="components per batch of the boundary kernels (pa_gradcurv_run_comps2; 8 output components per slot)")
     ap.add_argument("--fused", type=int, default=1)
+    ap.add_argument("--retile", type=int, default=1, help="1 (default, as the tools): the levels are held and swept on the internal tiling pa_level_retile makes of the "
+                                                           "file's boxes (--box); 0: on the file's boxes themselves")
     ap.add_argument("--per", type=str, default="1 1 0", help="periodicity flags x y z (headline: periodic x/y, wall z); single GPU only")
     ap.add_argument("--threshold", type=float, default=-1.0, help="diagnostic: threshold_prog / threshold_value of curvature.cpp:549-570 (< 0: off, the headline)")
     ap.add_argument("--traffic", choices=("live", "file", "none"), default="live",
@@ -523,7 +570,7 @@ def main():
 
     if args.secondary_only:
         t0s = time.perf_counter()
-        res = {"secondary_only": args.secondary_only, "secondary": secondary(ctx, torch, stream, dev, only=args.secondary_only)}
+        res = {"secondary_only": args.secondary_only, "secondary": secondary(ctx, torch, stream, dev, only=args.secondary_only, retile=args.retile)}
         res["wall_s"] = round(time.perf_counter() - t0s, 2)
         print(json.dumps(res))
         return
@@ -544,6 +591,14 @@ def main():
         H = Hierarchy(levels, 2)
     else:
         H = nested_hierarchy(args.base, args.nlev, args.box, is_per=per)
+        owners = padist.shard(H, nshard) if nshard > 1 else [None] * args.nlev
+    # internal re-tiling (what grad3d / curvature3d do with a plotfile's BoxArray): same cells, merged boxes -- results identical in
+    # every cell (tests/test_retile.py).  One GPU: the tools' limits (pa_hierarchy_retile_limits); sharded: 128^3 so that every
+    # rank keeps several boxes per level.  Weak-scaling copies stay as built (a copy per rank).
+    Hfile = H
+    if args.retile and not (args.scaling == "weak" and nshard > 1):
+        from peleanalysis_amd.hierarchy import retile_hierarchy
+        H = retile_hierarchy(Hfile, None if nshard == 1 else (128, 128, 128))
         owners = padist.shard(H, nshard) if nshard > 1 else [None] * args.nlev
     bc = capi.bc_from_flags(per)
     xch = {"mode": "none"}
@@ -663,7 +718,6 @@ def main():
         dt = float(t.item())
 
     weak = args.scaling == "weak" and nshard > 1
-    nb0 = H.levels[0].nboxes
     value = cells * args.ncomp * args.steps / dt / 1e6  # whole job: every cell of every level and rank
     if args.sim_of:  # a simulation is not a measurement of the whole job: report what this GPU really processed
         value = cells_local * args.ncomp * args.steps / dt / 1e6
@@ -681,7 +735,11 @@ def main():
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"fused grad->curvature, {args.nlev}-level AMR, base {args.base}^3{' per GPU' if weak else ''}, ref_ratio 2, {args.box}^3 boxes "
-                               f"({nb0} per level), {args.ncomp} comp(s), {per_txt}, {cells} cells in the job",
+                               f"({Hfile.levels[0].nboxes} per level) in the file" +
+                               (f", swept on the internal tiling pa_level_retile makes of them ({', '.join(str(lv.nboxes) for lv in H.levels)} boxes per level, "
+                                f"largest {'x'.join(str(int(v)) for v in (H.levels[0].boxes[:, 3:] - H.levels[0].boxes[:, :3] + 1).max(axis=0))})" if H is not Hfile else ", swept as they are (--retile 0)") +
+                               f", {args.ncomp} comp(s), {per_txt}, {cells} cells in the job",
+                   "tiling": {"file_boxes_per_level": [lv.nboxes for lv in Hfile.levels], "swept_boxes_per_level": [lv.nboxes for lv in H.levels], "retile": bool(H is not Hfile)},
                    "cells": cells, "cells_this_rank": cells_local, "ncomp": args.ncomp, "components_per_batch": nslot, "fused": bool(args.fused),
                    "parallelism": par, "exchange": xch},
     }
@@ -708,13 +766,13 @@ def main():
         traffic_src = None
         headline_cfg = (args.base, args.nlev, args.box, args.ncomp, world, args.sim_of) == (512, 3, 128, 1, 1, 0) and per == (1, 1, 0) and args.threshold < 0
         if headline_cfg and args.traffic == "live" and rank == 0:
-            traffic, traffic_src = live_traffic()
-        tj = os.path.join(ROOT, "profiles", "r04_headline_traffic.json")
+            traffic, traffic_src = live_traffic(retile=args.retile)
+        tj = os.path.join(ROOT, "profiles", "r05_headline_traffic.json" if args.retile else "r04_headline_traffic.json")
         if traffic is None and args.traffic != "none" and os.path.exists(tj) and headline_cfg:
             rec = json.load(open(tj))
             if rec.get("kernel") == kern:
                 traffic = rec.get("traffic_bytes_per_launch")
-                traffic_src = "profiles/r04_headline_traffic.json (PMC passes of the same workload and kernel variant, tools/prof.sh bench)" + (f"; live pass: {traffic_src}" if traffic_src else "")
+                traffic_src = "profiles/" + os.path.basename(tj) + " (PMC passes of the same workload and kernel variant, tools/prof.sh bench)" + (f"; live pass: {traffic_src}" if traffic_src else "")
         res["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                            "traffic": traffic, "traffic_source": traffic_src, "kernel": kern + " (fused grad->curvature sweep)", "avg_launch_ms": avg_ms,
                            "launches": nk, "bytes_per_cell": BYTES_PER_CELL, "cells_per_launch": cells_local * args.ncomp * args.steps / nk}
@@ -725,7 +783,7 @@ def main():
             del hold, states, works, outs  # the headline buffers (33 GB) make room for the secondary workloads
             torch.cuda.empty_cache()
             t0s = time.perf_counter()
-            res["secondary"] = secondary(ctx, torch, stream, dev)
+            res["secondary"] = secondary(ctx, torch, stream, dev, retile=args.retile)
             res["secondary"]["wall_s_incl_data_generation"] = round(time.perf_counter() - t0s, 2)
         except Exception as e:  # the headline line must survive a failure here
             res["secondary"] = {"error": repr(e)[:300]}
@@ -740,7 +798,7 @@ def main():
         if sample is not None:
             try:
                 torch.cuda.empty_cache()
-                res["parity_check"] = parity_check(ctx, sample)
+                res["parity_check"] = parity_check(ctx, sample, retile=args.retile)
             except Exception as e:
                 res["parity_check"] = {"error": repr(e)[:300]}
     if rank == 0:

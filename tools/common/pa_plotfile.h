@@ -597,7 +597,9 @@ inline std::vector<Box3> max_size(const std::vector<Box3>& in, int n) {
 // Internal re-tiling (pa_level_retile, include/peleanalysis_amd.h): the boxes the tools COMPUTE on for each level -- the file's
 // cells merged into the largest rectangles -- while their output keeps the file's BoxArray (write_plotfile's file_boxes).
 // retile=0 on the command line: the file's boxes as they are.  read_comp fills such boxes from every file FAB they intersect.
-inline std::vector<std::vector<Box3>> retile_levels(const std::vector<std::vector<Box3>>& file_boxes, const ParmParse& pp) {
+// max_cells > 0: that limit per direction instead of pa_hierarchy_retile_limits' choice (filterPlt: 128 -- k_filter_sep stages whole
+// rows of a box in LDS and deals boxes, not tiles, to the XCDs: one 256^3 box per level ran 1.25 ms against 0.25 for eight of 128^3)
+inline std::vector<std::vector<Box3>> retile_levels(const std::vector<std::vector<Box3>>& file_boxes, const ParmParse& pp, int max_cells = 0) {
   int on = 1;
   pp.query("retile", on);
   if (!on) return file_boxes;
@@ -613,8 +615,8 @@ inline std::vector<std::vector<Box3>> retile_levels(const std::vector<std::vecto
     }
     ptr[l] = b6[l].data();
   }
-  int32_t mx[3];
-  if (pa_hierarchy_retile_limits(nlev, nb.data(), ptr.data(), 3, mx) != 0) return file_boxes;
+  int32_t mx[3] = {max_cells, max_cells, max_cells};
+  if (max_cells <= 0 && pa_hierarchy_retile_limits(nlev, nb.data(), ptr.data(), 3, mx) != 0) return file_boxes;
   std::vector<std::vector<Box3>> out(nlev);
   for (int l = 0; l < nlev; ++l) {
     const int cap = 4 * nb[l] + 16;

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Lean driver for rocprofv3 runs: fused grad->curvature over a 3-level hierarchy through the
-C ABI only (no torch, few dispatches).  usage: prof_driver.py [base=256] [box=128] [steps=3]"""
+C ABI only (no torch, few dispatches).  usage: prof_driver.py [base=256] [box=128] [steps=3] [retile=1]
+retile = 1: swept on the internal tiling the tools and bench.py use (pa_level_retile of the box^3 tiling), 0: on the box^3 tiling itself"""
 import os
 import sys
 import time
@@ -15,6 +16,9 @@ base = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 box = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 H = nested_hierarchy(base, 3, box, is_per=(1, 1, 0))
+if (int(sys.argv[4]) if len(sys.argv) > 4 else 1):
+    from peleanalysis_amd.hierarchy import retile_hierarchy  # noqa: E402
+    H = retile_hierarchy(H)
 bc = capi.bc_from_flags((1, 1, 0))
 ctx = capi.Context(0)
 dls = [capi.DevLevel(ctx, lv) for lv in H.levels]

@@ -79,7 +79,7 @@ int main(int argc, char** argv) {
   // point-wise functions of the level's cells, tests/test_retile.py -- and written back on that BoxArray.
   std::vector<std::vector<pa::Box3>> chopped(Nlev);
   for (int lev = 0; lev < Nlev; ++lev) chopped[lev] = pa::max_size(H.lev[lev].boxes, max_grid_size);
-  const std::vector<std::vector<pa::Box3>> tile = pa::retile_levels(chopped, pp);
+  const std::vector<std::vector<pa::Box3>> tile = pa::retile_levels(chopped, pp, 128);
   std::cout << "Reading data..." << std::endl;
   int fgr_lev = fgr;
   for (int lev = 0; lev < Nlev; ++lev) {
