@@ -497,6 +497,138 @@ def secondary(ctx, torch, stream, dev, only=None, retile=1):
                                                       "sync; level_by_level_ms = one pa_mc_level_fine call per level")
     if want("c4_isosurface_base256"):
         c4_case()
+
+    # ------------------------------------------------------------------ options, smoothing, distance function, streamlines
+    def curv_options_case():
+        # curvature.cpp:575-789 on the headline hierarchy: pa_curvature_run with do_gaussCurv + do_strain + do_velnormal (pass-by-pass
+        # kernels; quirk Q3 kept).  Algorithmic bytes: read the progress source + 3 velocity components (32 B), write Progress,
+        # MeanCurvature, FlameNormal x3, GaussianCurvature, StrainRate, VelFlameNormal (64 B) = 96 B/cell
+        from peleanalysis_amd.hierarchy import retile_hierarchy
+        Hf = nested_hierarchy(512, 3, 128, is_per=(1, 1, 0))
+        H = retile_hierarchy(Hf) if retile else Hf
+        dls = [capi.DevLevel(ctx, lv) for lv in H.levels]
+        ins = [alloc(lv, dl, 4, 2, "flame", 401 + l) for l, (lv, dl) in enumerate(zip(H.levels, dls))]
+        ous = [alloc(lv, dl, 18, 0) for lv, dl in zip(H.levels, dls)]
+        stream.synchronize()
+        bc = capi.bc_from_flags((1, 1, 0))
+        cells = sum(lv.ncells for lv in H.levels)
+        P = capi.curv_params(prog_min=300.0, prog_max=2600.0, threshold=None, fused=False, do_gauss=True, do_strain=True, do_velnormal=True, vel_comp=1)
+        ms = min(timed(lambda: capi.curvature_run(ctx, [a[1] for a in ins], 0, bc, P, [o[1] for o in ous], 0), reps=1) for _ in range(2))
+        assert ctx.bc_errors() == 0
+        out["f1_curvature_options_headline"] = entry(ms, cells, 96, workload="pa_curvature_run (curvature.cpp:283-789) with do_gaussCurv + do_strain + do_velnormal, 3-level base 512^3, "
+                                                     "128^3 boxes in the file, progress source + 3 velocity components in, 8 fields out; " + tiling_txt(Hf, H) +
+                                                     "; the smaller of two single passes (the pass-by-pass path allocates its work multifabs per call)")
+        # curvature.cpp:328-406: the implicit smoothing solve alone (BiCGStab on the composite operator), same hierarchy, one rank
+        c = [alloc(lv, dl, 1, 1) for lv, dl in zip(H.levels, dls)]
+        sol = [alloc(lv, dl, 1, 1) for lv, dl in zip(H.levels, dls)]
+        for a, ci in zip(ins, c):  # progress variable in [0, 1] as the right-hand side
+            ctx.check(ctx.lib.pa_progress_level(ctx.h, a[1].h, 0, 300.0, 2003.0, ci[1].h, 0, 0))
+        ctx.sync()
+        sm = {}
+        hr = (C.c_void_p * 3)(*[x[1].h for x in c])
+        hs = (C.c_void_p * 3)(*[x[1].h for x in sol])
+        for dt_s in (1e-7, 1e-5):  # the reference's default smoothing_time and one that makes the solver work
+            it_, rs_ = C.c_int(0), C.c_double(0.0)
+            for _ in range(2 if dt_s < 1e-6 else 1):
+                t0 = time.perf_counter()
+                rc_ = ctx.lib.pa_smooth_solve(ctx.h, 3, hr, 0, hs, 0, dt_s, (C.c_int32 * 3)(*bc), 1e-12, 600, C.byref(it_), C.byref(rs_))
+                msq = (time.perf_counter() - t0) * 1e3
+            sm[f"smoothing_time_{dt_s:g}"] = {"iterations": it_.value, "rel_residual": rs_.value, "converged_to_1e-12": rc_ == 0, "ms": msq, "ms_per_iteration": msq / max(it_.value, 1)}
+        out["f1_do_smooth_headline"] = dict(sm, cells=cells, workload="pa_smooth_solve (curvature.cpp:328-406: (I - dt Lap) c~ = c, composite over the levels, tol 1e-12), 3-level base "
+                                            "512^3, 1 rank; ms = one whole solve incl. its allocations; per iteration 2 operator applications + 5 dot products; " + tiling_txt(Hf, H))
+        del ins, ous, c, sol, dls
+        torch.cuda.empty_cache()
+
+    if want("f1_curvature_options_headline") or want("f1_do_smooth_headline"):
+        curv_options_case()
+
+    def sdf_case():
+        # isosurface.cpp:1595-1655 (build_distance_function): make_level_set3 on 130^3 grids (a 128^3 FAB + 1 ghost layer), a sphere of
+        # 32768 triangles through the grid; 1 grid and a batch of 16
+        v = [np.array(p_, float) for p_ in ((1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1))]
+        f = [(0, 2, 4), (2, 1, 4), (1, 3, 4), (3, 0, 4), (2, 0, 5), (1, 2, 5), (3, 1, 5), (0, 3, 5)]
+        for _ in range(6):
+            mid, nf = {}, []
+
+            def m(a, b):
+                k = (min(a, b), max(a, b))
+                if k not in mid:
+                    q = v[a] + v[b]
+                    v.append(q / np.linalg.norm(q))
+                    mid[k] = len(v) - 1
+                return mid[k]
+            for a, b, c_ in f:
+                ab, bc_, ca = m(a, b), m(b, c_), m(c_, a)
+                nf += [(a, ab, ca), (ab, b, bc_), (ca, bc_, c_), (ab, bc_, ca)]
+            f = nf
+        verts = (0.5 + 0.31 * np.array(v)).astype(np.float32)
+        tris = np.array(f, dtype=np.uint32)
+        g = 130
+        tt = torch.from_numpy(tris.astype(np.int32)).to(dev)
+        tx = torch.from_numpy(verts).to(dev)
+        nb = 16
+        phis = [torch.empty(g ** 3, dtype=torch.float32, device=dev) for _ in range(nb)]
+        grids = (capi.PaSdfGrid * nb)()
+        for q, gr in enumerate(grids):
+            gr.ntri, gr.tri, gr.nvert, gr.x = len(tris), tt.data_ptr(), len(verts), tx.data_ptr()
+            for d in range(3):
+                gr.origin[d] = np.float32(0.0)
+                gr.n[d] = g
+            gr.dx = np.float32(1.0 / g)
+            gr.phi = phis[q].data_ptr()
+        torch.cuda.synchronize()
+        res = {}
+        for n_ in (1, nb):
+            ctx.check(ctx.lib.pa_sdf_level_set3(ctx.h, n_, grids, 1))
+            ctx.sync()
+            t0 = time.perf_counter()
+            ctx.check(ctx.lib.pa_sdf_level_set3(ctx.h, n_, grids, 1))
+            ctx.sync()
+            ms_ = (time.perf_counter() - t0) * 1e3
+            res[f"grids_per_call_{n_}"] = {"ms": ms_, "ms_per_grid": ms_ / n_, "Mpoints_s": n_ * g ** 3 / ms_ / 1e3}
+        out["f2_distance_function"] = dict(res, triangles=int(len(tris)), grid=f"{g}^3", workload="pa_sdf_level_set3 = make_level_set3 (isosurface.cpp:1625, Tools/SDFGen/makelevelset3.cpp:118-185), "
+                                           f"exact band 1, float32, a sphere of {len(tris)} triangles through 130^3 grids; a chain of ~6000 dependent hyperplane launches: no roofline")
+        del phis, tt, tx
+        torch.cuda.empty_cache()
+
+    if want("f2_distance_function"):
+        sdf_case()
+
+    def stream_case():
+        # partStream.cpp:121-207 / StreamPC.cpp: RK4 lines through the trilinear interpolant of a velocity field on a 3-level hierarchy
+        # (base 128^3, nGrow 3, PCInterp ghost fill), two lines per seed
+        H = nested_hierarchy(128, 3, 64, is_per=(0, 0, 0))
+        dls = [capi.DevLevel(ctx, lv) for lv in H.levels]
+        vf = [alloc(lv, dl, 3, 3, "flame", 611 + l) for l, (lv, dl) in enumerate(zip(H.levels, dls))]
+        for l in range(3):
+            with torch.cuda.stream(stream):
+                vf[l][0].mul_(1.0e-3)  # O(1) velocities
+            ctx.check(ctx.lib.pa_fill_boundary(ctx.h, vf[l][1].h, 0, 3, 3))
+            if l > 0:
+                ctx.check(ctx.lib.pa_fillpatch_two_levels(ctx.h, vf[l][1].h, vf[l - 1][1].h, 0, 3, 3, 2, 0))
+        ctx.sync()
+        rng = np.random.default_rng(5)
+        nseed, nsteps = 50000, 50
+        seeds = 0.3 + 0.4 * rng.random((nseed, 3))
+        dts = 0.1 / 512.0  # hRK * finest dx
+        buf = torch.empty(2 * nseed * nsteps * 3, dtype=torch.float64, device=dev)
+        nred = C.c_int32(0)
+        hv = (C.c_void_p * 3)(*[x[1].h for x in vf])
+
+        def go():
+            ctx.check(ctx.lib.pa_stream_trace(ctx.h, 3, hv, 0, nseed, seeds.ctypes.data_as(C.POINTER(C.c_double)), nsteps, dts, C.c_void_p(buf.data_ptr()), C.byref(nred)))
+        go()
+        t0 = time.perf_counter()
+        go()
+        ms_ = (time.perf_counter() - t0) * 1e3
+        out["f4_partstream"] = {"ms": ms_, "seeds": nseed, "lines": 2 * nseed, "steps_per_line": nsteps - 1, "Mline_steps_s": 2 * nseed * (nsteps - 1) / ms_ / 1e3, "redistributions": int(nred.value),
+                                "workload": "pa_stream_trace (partStream.cpp:121-207, StreamPC.cpp:88-260): RK4 through the trilinear interpolant, 3-level base 128^3, 64^3 boxes, nGrow 3, "
+                                            "50000 random seeds x 2 lines x 49 steps, hRK 0.1; synchronous call incl. seed upload and flag read-back"}
+        del vf, buf, dls
+        torch.cuda.empty_cache()
+
+    if want("f4_partstream"):
+        stream_case()
     return out
 
 

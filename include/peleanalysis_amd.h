@@ -274,7 +274,9 @@ int pa_boxfilter_fab(pa_ctx*, pa_box valid, const pa_fab* in, pa_fab* out, int s
 int pa_box_filter_weights(int fgr, double* w);
 /* filterPlt.cpp:80 filter_type -> the PelePhysics Filter weights for the types restated here: 0 none, 1 box, 3 / 7 the
  * 3-point and 4 / 8 the 5-point approximations of the box / Gaussian filter (w: at least max(fgr + 2, 5) doubles).
- * Returns ngrow, or -1 for a type that is not available (2 Gaussian, 5 6 9 10 "optimized") or fgr < 1.  Host only.
+ * Returns ngrow, or -1 for a type that is not available (5 6 9 10 "optimized"; 2 Gaussian unless PA_ALLOW_UNVERIFIED_GAUSSIAN=1 is
+ * in the environment: its weights -- the textbook kernel sampled at cell centres, cut at 4 standard deviations -- could not be
+ * checked against PelePhysics, whose source is not in the reference tree) or fgr < 1.  Host only.
  * [weights re-derived from the moment conditions; PelePhysics is not part of the reference tree: parity unpinned] */
 int pa_filter_weights(int type, int fgr, double* w);
 /* filterPlt.cpp:206-219, all boxes of a level */
@@ -447,6 +449,10 @@ int pa_curvature_run(pa_ctx*, int nlev, pa_mf* const* state, int comp, const int
  * gathers the right-hand side of the whole hierarchy and runs the one-rank solve (its bits; no speed-up). */
 int pa_smooth_solve(pa_ctx*, int nlev, pa_mf* const* rhs, int rcomp, pa_mf* const* sol, int scomp, double dt,
                     const int32_t bc[3], double tol, int maxiter, int* iters, double* rel_residual);
+/* what the do_smooth solve of the last pa_curvature_run took: iterations and ||b - A x||_inf / ||b||_inf (the reference runs MLMG
+ * with setVerbose(1), curvature.cpp:396-399, which prints its iteration count and residuals; the tool prints these).  Non-zero
+ * when no such solve has run on the context. */
+int pa_smooth_last(const pa_ctx*, int* iters, double* rel_residual);
 /* fused grad+curvature of one variable: out[lev] comps ocomp+0..3 = gx,gy,gz,|g|,
  * +4..6 FlameNormal, +7 MeanCurvature.  work[lev]: scratch mf, 1 comp, ng=2. */
 int pa_gradcurv_run(pa_ctx*, int nlev, pa_mf* const* state, int comp, const int32_t bc[3],

@@ -38,6 +38,13 @@ extern "C" int pa_filter_weights(int type, int fgr, double* w) {
     case 0: w[0] = 1.0; return 0;
     case 1: return pa_box_filter_weights(fgr, w);
     case 2: {
+      // REFUSED unless the caller opts in (PA_ALLOW_UNVERIFIED_GAUSSIAN=1 in the environment, read per call; filterPlt:
+      // allow_unverified_gaussian=1): these weights are a guess at PelePhysics' and a plotfile filtered with them may differ from
+      // the reference's at 1e-6 .. 1e-5 without any other sign (advisor finding, round 4).
+      {
+        const char* e = getenv("PA_ALLOW_UNVERIFIED_GAUSSIAN");
+        if (!e || !atoi(e)) return -1;
+      }
       // Gaussian (PelePhysics filter_type 2) [UNVERIFIED against PelePhysics: its source is not in the reference tree].  The textbook
       // LES Gaussian of width Delta = fgr dx, G(r) = sqrt(6 / (pi Delta^2)) exp(-6 r^2 / Delta^2) (variance Delta^2 / 12, the box
       // filter's), sampled at the cell centres, cut at 4 standard deviations and normalised so that the weights sum to one

@@ -1134,34 +1134,42 @@ static int level_irregular(pa_ctx* ctx, const pa_level* Lc) {
   const long long n0 = L->maxn[0], n1 = L->maxn[1], n2 = L->maxn[2];
   const long long nf = std::max(n1 * n2, std::max(n0 * n2, n0 * n1));
   int* d_count = nullptr;
-  PA_HIP(hipMalloc(&d_count, sizeof(int)));
+  // every error path releases the counter and the half-built list: nirr stays -1, so the next call starts over (advisor, round 4)
+  auto fail = [&](const char* what) {
+    if (d_count) (void)hipFree(d_count);
+    if (L->d_irr) { (void)hipFree(L->d_irr); L->d_irr = nullptr; }
+    (void)hipGetLastError();
+    return pa_fail(ctx, std::string("irregular-cell list: ") + what);
+  };
+  if (L->d_irr) { (void)hipFree(L->d_irr); L->d_irr = nullptr; }  // left by a call that failed before this guard existed
+  if (hipMalloc(&d_count, sizeof(int)) != hipSuccess) return fail("device allocation failed");
   int n = 0;
   for (int pass = 0; pass < 2; ++pass) {  // count, then fill
     if (pass == 1) {
       if (n == 0) break;
-      PA_HIP(hipMalloc(&L->d_irr, sizeof(int4) * (size_t)n));
+      if (hipMalloc(&L->d_irr, sizeof(int4) * (size_t)n) != hipSuccess) { L->d_irr = nullptr; return fail("device allocation failed"); }
     }
-    PA_HIP(hipMemsetAsync(d_count, 0, sizeof(int), ctx->stream));
+    if (hipMemsetAsync(d_count, 0, sizeof(int), ctx->stream) != hipSuccess) return fail("memset failed");
     for (int y0 = 0; y0 < nb * 6; y0 += 65535 / 6 * 6)
       hipLaunchKernelGGL(k_find_irregular, dim3((unsigned)((nf + 255) / 256), (unsigned)std::min(65535 / 6 * 6, nb * 6 - y0)), dim3(256), 0, ctx->stream, L->view, y0,
                          pass ? (int4*)L->d_irr : nullptr, d_count, n);
     int m = 0;
-    PA_HIP(hipMemcpyAsync(&m, d_count, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    PA_HIP(hipStreamSynchronize(ctx->stream));
-    if (pass == 1 && m != n) { (void)hipFree(d_count); return pa_fail(ctx, "irregular-cell list: the two passes disagree"); }
+    if (hipMemcpyAsync(&m, d_count, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return fail("reading the count failed");
+    if (pass == 1 && m != n) return fail("the two passes disagree");
     n = m;
   }
   (void)hipFree(d_count);
+  d_count = nullptr;
   if (n > 1) {  // the kernel appended the cells in any order: sort by (box, k, j, i) so that neighbouring threads touch neighbouring cells
     std::vector<int4> h((size_t)n);
-    PA_HIP(hipMemcpy(h.data(), L->d_irr, sizeof(int4) * (size_t)n, hipMemcpyDeviceToHost));
+    if (hipMemcpy(h.data(), L->d_irr, sizeof(int4) * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) return fail("download failed");
     std::sort(h.begin(), h.end(), [](const int4& a, const int4& b) {
       if (a.x != b.x) return a.x < b.x;
       if (a.w != b.w) return a.w < b.w;
       if (a.z != b.z) return a.z < b.z;
       return a.y < b.y;
     });
-    PA_HIP(hipMemcpy(L->d_irr, h.data(), sizeof(int4) * (size_t)n, hipMemcpyHostToDevice));
+    if (hipMemcpy(L->d_irr, h.data(), sizeof(int4) * (size_t)n, hipMemcpyHostToDevice) != hipSuccess) return fail("upload failed");
   }
   L->nirr = n;
   return 0;

@@ -102,6 +102,8 @@ struct pa_ctx {
   // transport between the ranks that share a sharded hierarchy (pa_dist.hip): caller-supplied (pa_ctx_set_comm)
   // or the built-in RCCL one (pa_ctx_init_rccl)
   std::string sweep_kernel;  // variant of the fused sweep launched last (pa_sweep_kernel_name)
+  int smooth_iters = -1;     // the last do_smooth solve of pa_curvature_run (pa_smooth_last): iterations, relative residual
+  double smooth_res = 0.0;
   pa_comm comm = {nullptr, 0, 1, nullptr, nullptr};
   struct RcclState* rccl = nullptr;
 };

@@ -1597,8 +1597,9 @@ static int mc_run_batched(pa_ctx* ctx, int nlev, MclWork* W) {
     if (W[l].nv || W[l].nt) { size_t bv, bk, bt; mc_parts(W[l], bv, bk, bt); need += bv + bk + bt; }
   }
   MclOut O;
+  unsigned char* blockp = nullptr;
   if (need > 0) {
-    unsigned char* blockp = mc_block(ctx, need);
+    blockp = mc_block(ctx, need);
     if (!blockp) return 1;
     size_t off = 0;
     for (int l = 0; l < nlev; ++l) {
@@ -1617,7 +1618,11 @@ static int mc_run_batched(pa_ctx* ctx, int nlev, MclWork* W) {
     if (g) hipLaunchKernelGGL(k_mclb_tris, dim3(g), dim3(256), 0, ctx->stream, Bt, O);
   }
   hipLaunchKernelGGL(k_mclb_clean, dim3(1024), dim3(256), 0, ctx->stream, Bt);
-  if (hipGetLastError() != hipSuccess) return pa_fail(ctx, "pa_mc_hierarchy_fine: emit kernels failed");
+  if (hipGetLastError() != hipSuccess) {  // as mc_run's bail: the pooled block goes back, the levels' pointers are cleared
+    if (blockp) { ctx->surf_live.erase(blockp); (void)hipFree(blockp); }
+    for (int l = 0; l < nlev; ++l) { W[l].dv = nullptr; W[l].dk = W[l].dt = nullptr; }
+    return pa_fail(ctx, "pa_mc_hierarchy_fine: emit kernels failed");
+  }
   ctx->mcz_dirty = false;
   return 0;
 }

@@ -328,6 +328,12 @@ struct SmoothSolver {
   std::vector<RsPlan*> rs;
   Vecs cfw, fr, fm;
   long long nallreduce = 0, nexchange = 0;
+  // A failure on THIS rank inside an operator application or a local dot product (a launch error, a failed copy) does not return
+  // at once on a sharded hierarchy: the rank keeps making the same exchanges as its peers and the flag travels with the next
+  // reduction, where every rank sees it and leaves together -- a rank that returned alone would leave the others blocked in
+  // pa_xexchange / pa_allreduce.
+  bool lerr = false;
+  int fail_local() { lerr = true; return dist ? 0 : 1; }
 
   template <class K, class... A>
   void on_boxes(K kern, const pa_level* L, dim3 g, A... a) {  // a rank may own no box of a level
@@ -347,6 +353,17 @@ struct SmoothSolver {
       fm.v[l - 1] = pa_mf_create(ctx, lev[l - 1], 6, 0, nullptr);
       if (!cfw.v[l] || !fr.v[l - 1] || !fm.v[l - 1]) return 1;
     }
+    // the plans (and their buffers) every operator application will ask for: built here, before the first collective, so that a
+    // rank that cannot allocate them fails BEFORE its peers enter an exchange (advisor finding, round 4)
+    for (int l = 0; l < nlev; ++l)
+      if (!pa_fb_plan(ctx, lev[l], 1)) return 1;
+    for (int l = 1; l < nlev; ++l) {
+      CsPlan* cs = pa_cs_plan(ctx, lev[l], lev[l - 1], 0, 0, 0);
+      if (!cs || (cs->cs && !cs->mf(ctx, 1))) return 1;
+    }
+    return 0;
+  }
+  int setup_dist_mask() {
     // where the fluxes of the finer level apply: the same exchange once with 1.0 on every coarse-fine face
     if (flux_exchange(nullptr, fm, 1)) return 1;
     for (int l = 0; l + 1 < nlev; ++l) on_boxes(k_smooth_fluxmask, lev[l], box_grid(lev[l]), lev[l]->view, fm.v[l]->view);
@@ -385,7 +402,7 @@ struct SmoothSolver {
       on_boxes(k_smooth_avgdown_cf, lev[l], box_grid(lev[l]), lev[l]->view, X.v[l]->view, rs[l]->cf->view, cfw.v[l]->view, ratio);
       const XJob J = {&rs[l]->down, cfw.v[l], 0, X.v[l - 1], 0, 1};  // level l - 1 must be complete before it is restricted in turn
       ++nexchange;
-      if (pa_xexchange(ctx, 1, &J)) return 1;
+      if (pa_xexchange(ctx, 1, &J) && fail_local()) return 1;
     }
     std::vector<const pa_mf*> crse((size_t)nlev, nullptr);
     if (dist) {
@@ -393,7 +410,7 @@ struct SmoothSolver {
       // faces), and those are final once the restriction is done: the cross-rank half of all of them is ONE grouped exchange
       std::vector<XJob> jobs;
       for (int l = 0; l < nlev; ++l) {
-        XPlan* P = pa_fb_plan(ctx, lev[l], 1);
+        XPlan* P = pa_fb_plan(ctx, lev[l], 1);  // built in setup_dist
         if (!P) return 1;
         jobs.push_back({P, X.v[l], 0, X.v[l], 0, 1});
       }
@@ -406,12 +423,12 @@ struct SmoothSolver {
         jobs.push_back({&cs->x, X.v[l - 1], 0, m, 0, 1});
       }
       ++nexchange;
-      if (pa_xexchange(ctx, (int)jobs.size(), jobs.data())) return 1;
+      if (pa_xexchange(ctx, (int)jobs.size(), jobs.data()) && fail_local()) return 1;
     }
     for (int l = 0; l < nlev; ++l) {
       if (dist) {
-        if (pa_fill_boundary_impl(ctx, X.v[l], 0, 1, 1, 1)) return 1;
-        if (pa_apply_bc_impl(ctx, X.v[l], 0, crse[(size_t)l], 0, bc, ratio, -1, 0, nullptr)) return 1;
+        if (pa_fill_boundary_impl(ctx, X.v[l], 0, 1, 1, 1) && fail_local()) return 1;
+        if (pa_apply_bc_impl(ctx, X.v[l], 0, crse[(size_t)l], 0, bc, ratio, -1, 0, nullptr) && fail_local()) return 1;
       } else {
         if (pa_fill_boundary(ctx, X.v[l], 0, 1, 1)) return 1;
         if (pa_apply_bc(ctx, X.v[l], 0, l ? X.v[l - 1] : nullptr, 0, bc, ratio, -1)) return 1;
@@ -420,7 +437,7 @@ struct SmoothSolver {
     }
     if (dist) {
       if (nlev > 1) {
-        if (flux_exchange(&X, fr, 0)) return 1;
+        if (flux_exchange(&X, fr, 0) && fail_local()) return 1;
         for (int l = 0; l + 1 < nlev; ++l)
           on_boxes(k_smooth_reflux_apply, lev[l], box_grid(lev[l]), lev[l]->view, X.v[l]->view, Y.v[l]->view, fr.v[l]->view, fm.v[l]->view, dt);
       }
@@ -434,7 +451,7 @@ struct SmoothSolver {
       }
     }
     for (int l = 0; l + 1 < nlev; ++l) on_boxes(k_smooth_zero_covered, lev[l], box_grid(lev[l]), lev[l]->view, Y.v[l]->view, mask.v[l]->view);
-    PA_HIP(hipGetLastError());
+    if (hipGetLastError() != hipSuccess) { pa_fail(ctx, "pa_smooth_solve: a kernel launch of the operator failed"); if (fail_local()) return 1; }
     return 0;
   }
   // this rank's part of a . b and of max |a| over the uncovered cells
@@ -458,18 +475,37 @@ struct SmoothSolver {
   }
   // what: 1 = the dot product, 2 = max |a|, 3 = both (each is one reduction over the ranks of a sharded hierarchy; every rank
   // gets the same bits back, so every rank takes the same branches of the iteration)
+  // (the local error flag rides along as a second / third element: a sum or a maximum of non-negative flags is non-zero iff some
+  // rank failed, and every rank receives the same value)
   int dot(Vecs& A, Vecs& B, double* d, double* amax, int what = 3) {
-    if (ldot(A, B, d, amax)) return 1;
+    if (ldot(A, B, d, amax) && fail_local()) return 1;
     if (dist) {
-      if ((what & 1) && (++nallreduce, pa_allreduce(ctx, d, 1, 2))) return 1;
-      if ((what & 2) && (++nallreduce, pa_allreduce(ctx, amax, 1, 1))) return 1;
+      double e = 0.0;
+      if (what & 1) {
+        double v[2] = {lerr ? 0.0 : *d, lerr ? 1.0 : 0.0};
+        ++nallreduce;
+        if (pa_allreduce(ctx, v, 2, 2)) return 1;
+        *d = v[0]; e += v[1];
+      }
+      if (what & 2) {
+        double v[2] = {lerr ? 0.0 : *amax, lerr ? 1.0 : 0.0};
+        ++nallreduce;
+        if (pa_allreduce(ctx, v, 2, 1)) return 1;
+        *amax = v[0]; e += v[1];
+      }
+      if (e != 0.0) return lerr ? 1 : pa_fail(ctx, "pa_smooth_solve: another rank failed");
     }
     return 0;
   }
   int dot2(Vecs& A, Vecs& B, Vecs& C, Vecs& D, double* ab, double* cd) {  // two dot products, one reduction
-    double v[2], dummy;
-    if (ldot(A, B, &v[0], &dummy) || ldot(C, D, &v[1], &dummy)) return 1;
-    if (dist && (++nallreduce, pa_allreduce(ctx, v, 2, 2))) return 1;
+    double v[3] = {0.0, 0.0, 0.0}, dummy;
+    if ((ldot(A, B, &v[0], &dummy) || ldot(C, D, &v[1], &dummy)) && fail_local()) return 1;
+    if (dist) {
+      if (lerr) { v[0] = v[1] = 0.0; v[2] = 1.0; }
+      ++nallreduce;
+      if (pa_allreduce(ctx, v, 3, 2)) return 1;
+      if (v[2] != 0.0) return lerr ? 1 : pa_fail(ctx, "pa_smooth_solve: another rank failed");
+    }
     *ab = v[0];
     *cd = v[1];
     return 0;
@@ -547,10 +583,21 @@ extern "C" int pa_smooth_solve(pa_ctx* ctx, int nlev, pa_mf* const* rhs, int rco
           if ((B.lo[d] & 1) || !((B.hi[d] - B.lo[d]) & 1)) return pa_fail(ctx, "pa_smooth_solve: fine boxes must be aligned to the refinement ratio 2");
         }
   }
-  if (S.alloc(S.r) || S.alloc(S.rh) || S.alloc(S.p) || S.alloc(S.v) || S.alloc(S.s) || S.alloc(S.t) || S.alloc(S.mask)) return 1;
   Vecs x;  // the solution as a 1-comp vector (sol may have other components / ghost widths)
-  if (S.alloc(x)) return 1;
-  if (S.dist && S.setup_dist()) return 1;
+  {
+    // every allocation of the solve -- Krylov vectors, restriction / flux-register plans, ghost-fill plans and their buffers --
+    // happens here, before the first collective; the ranks of a sharded hierarchy then agree on success with ONE reduction
+    int bad = (S.alloc(S.r) || S.alloc(S.rh) || S.alloc(S.p) || S.alloc(S.v) || S.alloc(S.s) || S.alloc(S.t) || S.alloc(S.mask) || S.alloc(x)) ? 1 : 0;
+    if (!bad && S.dist && S.setup_dist()) bad = 1;
+    if (S.dist) {
+      double e = bad ? 1.0 : 0.0;
+      if (pa_allreduce(ctx, &e, 1, 1)) return 1;
+      if (e != 0.0) return bad ? 1 : pa_fail(ctx, "pa_smooth_solve: another rank could not set the solve up");
+    } else if (bad) {
+      return 1;
+    }
+    if (S.dist && S.setup_dist_mask()) return 1;
+  }
   for (int l = 0; l < nlev; ++l) {
     const pa_level* L = S.lev[l];
     S.on_boxes(k_smooth_mask, L, box_grid(L), L->view, S.mask.v[l]->view, l + 1 < nlev ? S.lev[l + 1]->view : L->view, l + 1 < nlev ? 1 : 0, 2);

@@ -250,5 +250,14 @@ extern "C" int pa_stream_trace_ranks(pa_ctx* ctx, int nlev, pa_mf* const* vfield
   if (dseeds) (void)hipFree(dseeds);
   if (dlev) (void)hipFree(dlev);
   if (dflags) (void)hipFree(dflags);
+  // One last reduction when the ranks share flags: an error found only after the step loop (a "bad RK" line, the write-back of the
+  // last step's flag, the final read-back) must come back from EVERY rank, or the caller's next collective pairs a rank that
+  // returned an error with ranks that went on (advisor finding, round 4).  Skipped when the transport itself failed / a shared
+  // error already ended the loop on every rank together (gerr).
+  if (share && !gerr) {
+    double e = rc ? 1.0 : 0.0;
+    if (pa_allreduce(ctx, &e, 1, 1) != 0) return rc ? rc : pa_fail(ctx, "pa_stream_trace: sharing the final status between the ranks failed");
+    if (e != 0.0 && rc == 0) rc = pa_fail(ctx, "pa_stream_trace: another rank failed (bad RK or a device error after its last step)");
+  }
   return rc;
 }

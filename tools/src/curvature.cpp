@@ -199,7 +199,15 @@ int main(int argc, char** argv) {
     int rK, rN, rKg = -1, rSR = -1, rVn = -1, rROST = -1;
     if (options) {
       ctx.check(pa_curvature_run(ctx.h, Nlev, s.data(), 0, bc, &P, o.data(), 0));
-      if (r == 0 && do_smooth && verbose) std::cout << "Progress variable smoothed successfully \n";
+      if (r == 0 && do_smooth) {
+        // the reference's MLMG runs with setVerbose(1) whatever `verbose` says (curvature.cpp:397) and prints its iterations and
+        // residuals; this solver is BiCGStab on the same composite operator, so the line names it
+        int its = 0;
+        double res = 0.0;
+        if (pa_smooth_last(ctx.h, &its, &res) == 0)
+          std::cout << "Smoothing solve (BiCGStab on the composite operator): " << its << " iterations, resid/bnorm = " << res << "\n";
+        if (verbose) std::cout << "Progress variable smoothed successfully \n";
+      }
       rK = 1; rN = 2; rKg = 5; rSR = 6; rVn = 7; rROST = 8;
     } else {
       ctx.check(pa_gradcurv_run(ctx.h, Nlev, s.data(), 0, bc, &P, w.data(), o.data(), 0));

@@ -1,6 +1,6 @@
 // filterPlt3d -- drop-in for PeleAnalysis Src/filterPlt.cpp (box filter) on MI355X.
 //   filterPlt3d.ex infile=<plt> [max_filter_level=<n>] [filter_type=1 (0 none, 1 box, 3/7 and 4/8: 3- and 5-point approximations)] [base_fgr=2] [same_fgr_all_levels=false]
-//       [max_grid_size=32] [interp_type=1] [variables="a b"] [is_per="0 0 0"] [exact_filter=0]
+//       [max_grid_size=32] [interp_type=1] [variables="a b"] [is_per="0 0 0"] [exact_filter=0] [retile=1] [allow_unverified_gaussian=0]
 // exact_filter=0 (default): the filter as three 1-D passes (tensor-product weights; within 1e-12 * Linf of the reference's
 // tap-order sum, HBM-bound); exact_filter=1 (or PA_FILTER_EXACT=1): Filter::apply_filter's (2ng+1)^3 taps in the
 // reference's accumulation order, bit for bit with the CPU restatement (3-D build; the 2-D build always sums tap by tap).
@@ -34,10 +34,17 @@ int main(int argc, char** argv) {
   int exact_filter = 0;
   pp.query("exact_filter", exact_filter);
   if (exact_filter) setenv("PA_FILTER_EXACT", "1", 1);  // read by the library at every launch
-  {  // PelePhysics filter types restated in the library: 0 none, 1 box, 2 Gaussian, 3 / 7 and 4 / 8 the 3- and 5-point approximations
+  {  // PelePhysics filter types restated in the library: 0 none, 1 box, 3 / 7 and 4 / 8 the 3- and 5-point approximations; 2 (Gaussian) only on request
+    int allow_gauss = 0;
+    pp.query("allow_unverified_gaussian", allow_gauss);
+    if (filter_type == 2 && !allow_gauss)
+      pa::Abort("filter_type 2 (Gaussian) is refused by default: PelePhysics' Filter source is not available to this build, so its weights (ngrow rule, "
+                "normalisation) could not be checked and the output could differ from the reference's at 1e-6 .. 1e-5; allow_unverified_gaussian=1 uses "
+                "the textbook kernel exp(-6 r^2 / Delta^2) cut at 4 standard deviations");
+    if (allow_gauss) setenv("PA_ALLOW_UNVERIFIED_GAUSSIAN", "1", 1);  // read by the library per call
     std::vector<double> wt(40);
     if (pa_filter_weights(filter_type, std::max(fgr, 1), wt.data()) < 0)
-      pa::Abort("filter_type " + std::to_string(filter_type) + " is not available in this build (0 none, 1 box, 2 Gaussian, 3 / 7 three-point, 4 / 8 five-point approximations)");
+      pa::Abort("filter_type " + std::to_string(filter_type) + " is not available in this build (0 none, 1 box, 3 / 7 three-point, 4 / 8 five-point approximations; 2 Gaussian with allow_unverified_gaussian=1)");
     if (filter_type == 2)
       std::cout << "filter_type 2: Gaussian weights from the textbook kernel exp(-6 r^2 / Delta^2), cut at 4 standard deviations -- UNVERIFIED against PelePhysics' Filter" << std::endl;
   }

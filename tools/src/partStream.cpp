@@ -167,6 +167,10 @@ int main(int argc, char** argv) {
       pa_device_free(ctx.h, dpos);
     }
   });
+  // partStream.cpp:197-199 writes the lines a second time as an AMReX particle plotfile ("Writing paticles to junkPlt",
+  // ParticleContainer::WritePlotFile).  That binary format lives in AMReX, which is not part of the reference tree, and cannot
+  // be restated from a source here -- said on stdout where the reference announces the file, instead of writing a guess.
+  std::cout << "Not writing particles to junkPlt (AMReX particle-plotfile format: not available in this build; the line points are all in tec.dat)" << std::endl;
   const std::string tecfile = "tec.dat";
   std::cout << "Writing streamlines in Tecplot ascii format to " << tecfile << std::endl;
   ::mkdir(tecfile.c_str(), 0755);
