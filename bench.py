@@ -83,8 +83,10 @@ def cpu_baseline(base, nlev, box):
     shape and BOX SIZE with a smaller base (the sample).  Both variants of BASELINE.md section 3 that the oracle has:
       multipass  the gradient as the reference computes it (face-gradient arrays -> 1/bscalar -> average_face_to_cellcenter
                  -> mult(-1) -> magnitude, grad.cpp:211-236), the curvature pass by pass (curvature.cpp:310-570);
-      stencil    the gradient as one central-difference sweep per level; the curvature pass by pass as above (the oracle has
-                 no single-sweep CPU curvature: the boundary conditions on n sit between its passes).
+      stencil    the gradient as one central-difference sweep per level; the curvature pass by pass as above;
+      fused      BASELINE.md section 3 (ii): gradient, normal and curvature of a level in ONE sweep over its cells (every cell rebuilds
+                 its six neighbours' normals from c), then the first layer of every box from the stored normals with the reference's
+                 boundary conditions on n (oracle.gradcurv_fused_pipeline); its outputs are compared bit for bit with multipass's.
     Scratch multifabs are allocated in an untimed first pass (MFPool); timed: whole passes until ~10 s per variant."""
     cores = usable_cpus()
     os.environ["OMP_NUM_THREADS"] = str(cores)  # before the OpenMP build of the oracle is loaded
@@ -102,11 +104,17 @@ def cpu_baseline(base, nlev, box):
     oc = [MultiFab(lv, 5, 0) for lv in H.levels]
     cells = sum(lv.ncells for lv in H.levels)
     variants = {}
-    for name, multipass in (("stencil", False), ("multipass", True)):
+    g2 = [MultiFab(lv, 4, 0) for lv in H.levels]
+    n2 = [MultiFab(lv, 3, 1) for lv in H.levels]
+    k2 = [MultiFab(lv, 1, 0) for lv in H.levels]
+    for name, multipass in (("fused", None), ("stencil", False), ("multipass", True)):  # multipass last: og / oc then hold the reference-shaped results
         pool = O.MFPool(MultiFab)
 
         def one_pass():
             pool.start_pass()
+            if multipass is None:  # one sweep per level + the first layer of every box (orc_gradcurv_fused)
+                O.gradcurv_fused_pipeline(H.levels, states, 0, bc, g2, n2, k2, pool, 300.0, 2000.0, omp=True)
+                return
             O.grad_pipeline(H.levels, states, 0, bc, og, 0, multipass=multipass, omp=True)
             O.curvature_pipeline(H.levels, states, 0, bc, oc, 0, pool, prog_min=300.0, prog_max=2000.0, omp=True)
         one_pass()  # untimed: allocates the scratch multifabs, pages everything in
@@ -118,6 +126,16 @@ def cpu_baseline(base, nlev, box):
             if dt >= 10.0 or reps >= 8:
                 break
         variants[name] = {"Mcells/s": cells * reps / dt / 1e6, "passes": reps, "seconds": round(dt, 2)}
+    # the fused variant's outputs against the reference-shaped multipass ones, bit for bit (a variant that computed something else would
+    # not be a baseline of this path)
+    same = True
+    for l, lv in enumerate(H.levels):
+        for b in range(lv.nboxes):
+            same = same and np.array_equal(g2[l].valid(b).view(np.int64), og[l].valid(b).view(np.int64))
+            same = same and np.array_equal(np.ascontiguousarray(n2[l].valid(b)).view(np.int64), np.ascontiguousarray(oc[l].valid(b)[2:5]).view(np.int64))
+            same = same and np.array_equal(k2[l].valid(b)[0].view(np.int64), np.ascontiguousarray(oc[l].valid(b)[1]).view(np.int64))
+    variants["fused"]["bits_equal_to_multipass"] = bool(same)
+    del g2, n2, k2
     best = max(variants, key=lambda k: variants[k]["Mcells/s"])
     res = {"value": variants[best]["Mcells/s"], "unit": "Mcells/s", "cores": cores, "kind": "port", "variant": best, "variants": variants,
            "sample": f"oracle grad+curvature pipelines (C restatement, OpenMP over boxes, scratch preallocated), {nlev}-level base {base}^3, "

@@ -271,6 +271,31 @@ def curvature_pipeline(levels, states, comp, bc, outs, ocomp, MF, prog_min=None,
     return prog_min, prog_max
 
 
+def gradcurv_fused_pipeline(levels, states, comp, bc, gouts, nouts, kouts, MF, prog_min, prog_max, omp=False):
+    """grad (grad.cpp:158-236) + curvature core (curvature.cpp:283-326, 408-546, no threshold) with ONE
+    sweep per level (orc_gradcurv_fused) + the first layer of every box from the stored normals once their ghost cells carry the
+    reference's boundary conditions.  gouts[l]: 4 comps (gx gy gz |g|); nouts[l]: 3 comps, ng 1 (FlameNormal, ghosts filled as a
+    side effect); kouts[l]: 1 comp (MeanCurvature).  Bit-identical to grad_pipeline + curvature_pipeline (tests/test_oracle_known_answers.py)."""
+    L = lib(omp)
+    nlev = len(levels)
+    cmf = []
+    for l in range(nlev):
+        fill_boundary(states[l], comp, 1, 1, omp)
+    for l in range(nlev):
+        apply_bc(states[l], comp, states[l - 1] if l > 0 else None, comp, bc, omp=omp)
+        c = MF(levels[l], 1, 2)
+        L.orc_progress(_p(_mf(states[l])), comp, C.c_double(prog_min), C.c_double(prog_max), _p(_mf(c)), 0)
+        fill_boundary(c, 0, 1, 2, omp)
+        cmf.append(c)
+    for l in range(nlev):
+        apply_bc(cmf[l], 0, cmf[l - 1] if l > 0 else None, 0, bc, omp=omp)
+        L.orc_gradcurv_fused(_p(_mf(states[l])), comp, _p(_mf(cmf[l])), 0, _p(_mf(gouts[l])), 0, _p(_mf(nouts[l])), 0, _p(_mf(kouts[l])), 0)
+        fill_boundary(nouts[l], 0, 3, 1, omp)
+        for d in range(3):
+            apply_bc(nouts[l], d, nouts[l - 1] if l > 0 else None, d, bc, only_dir=d, omp=omp)
+        L.orc_curv_first_layer(_p(_mf(nouts[l])), 0, _p(_mf(kouts[l])), 0)
+
+
 def filter_pipeline(levels, ins, outs, ncomp, base_fgr=2, same_fgr_all_levels=False, ratio=2, interp_type=1, omp=False, spacedim=3, filter_type=1):
     """filterPlt.cpp:126-219.  ins[l] must have ng >= fgr_l/2 ghost layers, valid cells filled.
     spacedim = 2: the 2-D build on a hierarchy stored as one plane of cells (ghost fill by the 3-D C pieces, whose z

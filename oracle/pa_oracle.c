@@ -387,6 +387,91 @@ void orc_div_accum(const orc_mf* nd, int comp, int dir, orc_mf* curv, int kcomp)
   }
 }
 
+/* -------------------------------------------------- fused single-sweep CPU variant (BASELINE.md section 3 ii)
+ * The grad -> curvature path of grad.cpp:211-236 + curvature.cpp:457-546 as ONE sweep per level instead of one pass per AMReX
+ * call: every valid cell forms gx, gy, gz, |g| from phi, its normal from c, and its curvature from the normals of its six
+ * face neighbours, which it rebuilds from c (radius 2) with the very operations orc_grad_fused / orc_normal / orc_div_accum
+ * use -- so the bits equal the pass-by-pass result wherever the neighbour's normal IS a function of c: every neighbour that
+ * is a valid cell of the level.  Behind a coarse-fine or physical face the reference's ghost normal is the boundary
+ * condition applied to n itself; orc_curv_first_layer recomputes the first layer of cells of every box from the
+ * stored normals once their ghost cells are filled (FillBoundary + applyBC on n, surface work).  phi: >= 1 resolved ghost
+ * layer; c: FillBoundary(2) + applyBC; nmf: 3 components, >= 1 ghost layer, valid cells written here.
+ * Used by bench.py's cpu_baseline ("fused" variant, results compared bit for bit with the multipass variant's). */
+static inline void grad3_at(const orc_mf* c, const bx_t* B, int b, int comp, const double dxinv[3], int i, int j, int k, double g[3]) {
+  const double v = AT(c, B, b, comp, i, j, k);
+  g[0] = cdiff(dxinv[0], AT(c, B, b, comp, i - 1, j, k), v, AT(c, B, b, comp, i + 1, j, k));
+  g[1] = cdiff(dxinv[1], AT(c, B, b, comp, i, j - 1, k), v, AT(c, B, b, comp, i, j + 1, k));
+  g[2] = cdiff(dxinv[2], AT(c, B, b, comp, i, j, k - 1), v, AT(c, B, b, comp, i, j, k + 1));
+}
+static inline double normgrad_of(const double g[3]) {
+  const double sn = sqrt(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
+  const double ng = (1e-14 < sn) ? sn : 1e-14;
+  return -ng;
+}
+void orc_gradcurv_fused(const orc_mf* phi, int pcomp, const orc_mf* c, int ccomp, orc_mf* gout, int gcomp, orc_mf* nmf, int ncomp0, orc_mf* K,
+                        int kcomp) {
+  const orc_level* L = phi->lev;
+  double dxinv[3];
+  orc_dxinv(L, dxinv);
+#pragma omp parallel
+  for (int b = 0; b < L->nboxes; ++b) {
+    bx_t B = get_box(L, b);
+#pragma omp for schedule(dynamic, 1) nowait
+    for (int k = B.lo[2]; k <= B.hi[2]; ++k)
+      for (int j = B.lo[1]; j <= B.hi[1]; ++j)
+        for (int i = B.lo[0]; i <= B.hi[0]; ++i) {
+          double g[3], G[3], Gn[3];
+          grad3_at(phi, &B, b, pcomp, dxinv, i, j, k, g);
+          AT(gout, &B, b, gcomp, i, j, k) = g[0];
+          AT(gout, &B, b, gcomp + 1, i, j, k) = g[1];
+          AT(gout, &B, b, gcomp + 2, i, j, k) = g[2];
+          AT(gout, &B, b, gcomp + 3, i, j, k) = sqrt(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
+          grad3_at(c, &B, b, ccomp, dxinv, i, j, k, G);
+          const double ng = normgrad_of(G);
+          const double n0 = G[0] / ng, n1 = G[1] / ng, n2 = G[2] / ng;
+          AT(nmf, &B, b, ncomp0, i, j, k) = n0;
+          AT(nmf, &B, b, ncomp0 + 1, i, j, k) = n1;
+          AT(nmf, &B, b, ncomp0 + 2, i, j, k) = n2;
+          /* n_d of the two neighbours in direction d, each from its own gradient of c */
+          double nm[3], np[3];
+          for (int d = 0; d < 3; ++d) {
+            const int e0 = d == 0, e1 = d == 1, e2 = d == 2;
+            grad3_at(c, &B, b, ccomp, dxinv, i - e0, j - e1, k - e2, Gn);
+            nm[d] = Gn[d] / normgrad_of(Gn);
+            grad3_at(c, &B, b, ccomp, dxinv, i + e0, j + e1, k + e2, Gn);
+            np[d] = Gn[d] / normgrad_of(Gn);
+          }
+          double acc = 0.0;
+          acc += cdiff(dxinv[0], nm[0], n0, np[0]);
+          acc += cdiff(dxinv[1], nm[1], n1, np[1]);
+          acc += cdiff(dxinv[2], nm[2], n2, np[2]);
+          AT(K, &B, b, kcomp, i, j, k) = acc * 0.5;
+        }
+  }
+}
+/* K of the first layer of cells behind every face of every box from the STORED normals (ghost cells filled by the caller:
+ * FillBoundary, then applyBC on component d in direction d), the sums of orc_div_accum + orc_mult(0.5) */
+void orc_curv_first_layer(const orc_mf* nmf, int ncomp0, orc_mf* K, int kcomp) {
+  const orc_level* L = nmf->lev;
+  double dxinv[3];
+  orc_dxinv(L, dxinv);
+#pragma omp parallel for schedule(dynamic)
+  for (int b = 0; b < L->nboxes; ++b) {
+    bx_t B = get_box(L, b);
+    for (int k = B.lo[2]; k <= B.hi[2]; ++k)
+      for (int j = B.lo[1]; j <= B.hi[1]; ++j) {
+        const int edge_row = (k == B.lo[2] || k == B.hi[2] || j == B.lo[1] || j == B.hi[1]);
+        for (int i = B.lo[0]; i <= B.hi[0]; i += (edge_row || i == B.hi[0] || B.hi[0] == B.lo[0]) ? 1 : (B.hi[0] - B.lo[0])) {
+          double acc = 0.0;
+          acc += cdiff(dxinv[0], AT(nmf, &B, b, ncomp0, i - 1, j, k), AT(nmf, &B, b, ncomp0, i, j, k), AT(nmf, &B, b, ncomp0, i + 1, j, k));
+          acc += cdiff(dxinv[1], AT(nmf, &B, b, ncomp0 + 1, i, j - 1, k), AT(nmf, &B, b, ncomp0 + 1, i, j, k), AT(nmf, &B, b, ncomp0 + 1, i, j + 1, k));
+          acc += cdiff(dxinv[2], AT(nmf, &B, b, ncomp0 + 2, i, j, k - 1), AT(nmf, &B, b, ncomp0 + 2, i, j, k), AT(nmf, &B, b, ncomp0 + 2, i, j, k + 1));
+          AT(K, &B, b, kcomp, i, j, k) = acc * 0.5;
+        }
+      }
+  }
+}
+
 void orc_setval(orc_mf* mf, int comp, double v) {
   const orc_level* L = mf->lev;
 #pragma omp parallel for schedule(dynamic)

@@ -82,6 +82,9 @@ void orc_normal(const orc_mf* G, int gcomp, orc_mf* normgrad, int ngcomp, orc_mf
 /* curvature.cpp:508-540 one direction: Curv += d n_d / d x_d (central, via
  * face fluxes).  nd has resolved ring-1 face ghosts in direction dir. */
 void orc_div_accum(const orc_mf* nd, int comp, int dir, orc_mf* curv, int kcomp);
+/* fused single-sweep CPU variant of grad.cpp:211-236 + curvature.cpp:457-546 (bench.py cpu_baseline "fused"; see pa_oracle.c) */
+void orc_gradcurv_fused(const orc_mf* phi, int pcomp, const orc_mf* c, int ccomp, orc_mf* gout, int gcomp, orc_mf* nmf, int ncomp0, orc_mf* K, int kcomp);
+void orc_curv_first_layer(const orc_mf* nmf, int ncomp0, orc_mf* K, int kcomp);
 /* mf[comp] = v on valid cells / mf *= v on valid cells */
 void orc_setval(orc_mf* mf, int comp, double v);
 void orc_mult(orc_mf* mf, int comp, double v);

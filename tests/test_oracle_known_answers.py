@@ -505,3 +505,27 @@ def test_filter_weights_moment_conditions(oracle):
                 ref = np.exp(-6.0 * i ** 2 / fgr ** 2)
                 assert np.allclose(w, ref / ref.sum(), rtol=1e-15, atol=0)
     assert oracle.filter_weights(5, 2) is None and oracle.filter_weights(2, 16) is None  # tabulated types / wider than 16 ghost cells: refused
+
+
+def test_fused_single_sweep_cpu_variant_equals_the_pass_by_pass_pipelines(oracle):
+    """bench.py's cpu_baseline "fused" variant (oracle.gradcurv_fused_pipeline: one sweep per level + the first layer of every
+    box) against grad_pipeline + curvature_pipeline on random hierarchies incl. unions of rectangles, bit for bit"""
+    import numpy as np
+    from peleanalysis_amd.hierarchy import MultiFab
+    from test_retile import _draw_h
+    from util import bits_equal, make_states
+    for seed in range(6):
+        H, per, sym, fn = _draw_h(seed)
+        states = make_states(H, 1, 2, fn, seed=seed)
+        bc = oracle.bc_from_flags(per, sym)
+        og = [MultiFab(lv, 4, 0) for lv in H.levels]
+        oracle.grad_pipeline(H.levels, [s.copy() for s in states], 0, bc, og, 0, multipass=True)
+        oc = [MultiFab(lv, 5, 0) for lv in H.levels]
+        pmin, pmax = oracle.curvature_pipeline(H.levels, [s.copy() for s in states], 0, bc, oc, 0, MultiFab)
+        g2, n2, k2 = [MultiFab(lv, 4, 0) for lv in H.levels], [MultiFab(lv, 3, 1) for lv in H.levels], [MultiFab(lv, 1, 0) for lv in H.levels]
+        oracle.gradcurv_fused_pipeline(H.levels, [s.copy() for s in states], 0, bc, g2, n2, k2, MultiFab, pmin, pmax)
+        for l, lv in enumerate(H.levels):
+            for b in range(lv.nboxes):
+                assert bits_equal(g2[l].valid(b), og[l].valid(b)), (seed, l, b, "gradient")
+                assert bits_equal(n2[l].valid(b), oc[l].valid(b)[2:5]), (seed, l, b, "normal")
+                assert bits_equal(k2[l].valid(b)[0], oc[l].valid(b)[1]), (seed, l, b, "curvature")
