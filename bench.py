@@ -415,12 +415,18 @@ def secondary(ctx, torch, stream, dev, only=None, retile=1):
         gout = [alloc(lv, dl, 4, 0) for lv, dl in zip(H.levels, dls)]
         stream.synchronize()
 
-        def ghosts():
+        def ghosts_levels():  # rounds 1-4: three calls per level
             for l in range(3):
                 ctx.check(ctx.lib.pa_fill_boundary(ctx.h, fin[l][1].h, 0, 1, ngs[l]))
                 if l > 0:
                     ctx.check(ctx.lib.pa_fillpatch_two_levels(ctx.h, fin[l][1].h, fin[l - 1][1].h, 0, 1, ngs[l], 2, 1))
                 ctx.check(ctx.lib.pa_foextrap(ctx.h, fin[l][1].h, 0, 1, ngs[l]))
+
+        hfin = (C.c_void_p * 3)(*[f[1].h for f in fin])
+        hngs = (C.c_int32 * 3)(*ngs)
+
+        def ghosts():  # filterPlt.cpp:159-203 for the whole hierarchy: FillBoundary / FillPatchTwoLevels / foextrap, one launch each
+            ctx.check(ctx.lib.pa_fill_ghosts_hierarchy(ctx.h, 3, hfin, 0, 1, hngs, 2, 1, 1))
 
         def filt(l):
             ctx.check(ctx.lib.pa_boxfilter_level(ctx.h, fin[l][1].h, fout[l][1].h, 0, 1, ngs[l], ws[l]))
@@ -439,7 +445,7 @@ def secondary(ctx, torch, stream, dev, only=None, retile=1):
             capi.grad_run(ctx, [f[1] for f in fout], 0, bc, [g[1] for g in gout], 0)
 
         c3cells = sum(lv.ncells for lv in H.levels)
-        c3 = {"ghost_fill_ms": timed(ghosts)}
+        c3 = {"ghost_fill_ms": timed(ghosts, reps=4), "ghost_fill_level_by_level_ms": timed(ghosts_levels, reps=4)}
         for l in range(3):
             m = timed(lambda l=l: filt(l))
             c3[f"filter_fgr{2 << l}_level{l}"] = entry(m, H.levels[l].ncells, 16)
@@ -505,14 +511,38 @@ def secondary(ctx, torch, stream, dev, only=None, retile=1):
             if block.value:
                 ctx.lib.pa_device_free(ctx.h, block)
 
+        # round 5: the state is the field alone -- its ghost cells of all levels in two launches, vertex coordinates from cell indices
+        hfld = (C.c_void_p * 3)(*[f_[1].h for f_ in fld])
+        hng1 = (C.c_int32 * 3)(1, 1, 1)
+
+        def iso_state_xyz():
+            ctx.check(ctx.lib.pa_fill_ghosts_hierarchy(ctx.h, 3, hfld, 0, 1, hng1, 2, 0, 0))
+
+        def iso_mc_xyz():
+            pv, pk, pt = (C.c_void_p * 3)(), (C.c_void_p * 3)(), (C.c_void_p * 3)()
+            block = C.c_void_p()
+            ctx.check(ctx.lib.pa_mc_hierarchy_xyz(ctx.h, 3, hfld, fm, 2, parr, 0, 1150.0, pnv, pnt, pv, pk, pt, C.byref(block)))
+            tri[0] = sum(int(sum(nts[l][:Hn.levels[l].nboxes])) for l in range(3))
+            if block.value:
+                ctx.lib.pa_device_free(ctx.h, block)
+
+        def iso_all():  # isosurface.cpp:1434-1592 as the tool runs it: ghost fill of the state + marching cubes of the hierarchy
+            iso_state_xyz()
+            iso_mc_xyz()
+
         iso_state()
         c4cells = sum(lv.ncells for lv in Hn.levels)
         ms_state, ms_lev, ms_mc = timed(iso_state), timed(iso_mc_levels, reps=4), timed(iso_mc, reps=4)
-        assert ctx.bc_errors() == 0
-        out["c4_isosurface_base256"] = entry(ms_mc, c4cells, 8, state_build_ms=ms_state, level_by_level_ms=ms_lev, triangles=tri[0], Mtriangles_s=tri[0] / ms_mc / 1e3,
-                                             workload="coordinates + ghost fill (state_build_ms), then pa_mc_hierarchy_fine: marching cubes on 3 levels in one call (finer level as "
-                                                      "mask), base 256^3, 64^3 boxes, T = 1150 isotherm; ms includes the count read-back, the pooled output block and the final "
-                                                      "sync; level_by_level_ms = one pa_mc_level_fine call per level")
+        tri_stored = tri[0]
+        ms_state_xyz, ms_mc_xyz, ms_all = timed(iso_state_xyz, reps=4), timed(iso_mc_xyz, reps=4), timed(iso_all, reps=4)
+        assert ctx.bc_errors() == 0 and tri[0] == tri_stored
+        out["c4_isosurface_base256"] = entry(ms_all, c4cells, 8, state_build_ms=ms_state_xyz, marching_cubes_ms=ms_mc_xyz, triangles=tri[0], Mtriangles_s=tri[0] / ms_all / 1e3,
+                                             stored_coordinates={"state_build_ms": ms_state, "marching_cubes_ms": ms_mc, "level_by_level_ms": ms_lev},
+                                             workload="isosurface.cpp:1434-1592 for the hierarchy: ghost fill of the state (pa_fill_ghosts_hierarchy: FillBoundary + FillPatchTwoLevels "
+                                                      "with PCInterp, one launch each) + pa_mc_hierarchy_xyz (marching cubes on 3 levels in one call, finer level as mask, vertex coordinates "
+                                                      "from cell indices), base 256^3, 64^3 boxes, T = 1150 isotherm; ms = BOTH, incl. the count read-back, the pooled output block and the "
+                                                      "final sync; stored_coordinates = the round-4 path (3 coordinate components per cell written, FillBoundaried and FillPatched: 12 "
+                                                      "launches; pa_mc_hierarchy_fine; level_by_level_ms = one pa_mc_level_fine call per level)")
     if want("c4_isosurface_base256"):
         c4_case()
 

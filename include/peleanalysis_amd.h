@@ -294,6 +294,12 @@ int pa_foextrap(pa_ctx*, pa_mf*, int comp, int ncomp, int ng);
 int pa_fillpatch_two_levels(pa_ctx*, pa_mf* fine, const pa_mf* crse, int comp, int ncomp, int ng, int ratio,
                             int interp_type);
 
+/* The ghost fill of a whole hierarchy in three launches: pa_fill_boundary of every level, pa_fillpatch_two_levels of every level
+ * pair, and (foextrap != 0) pa_foextrap of every level -- filterPlt.cpp:159-203 with foextrap, isosurface.cpp:1468-1524 (PCInterp,
+ * interp_type 0) without.  mfs[l] on level l (coarse first), ngs[l] ghost layers on level l.  Results identical to the per-level
+ * calls (no step of a level reads what another level's step writes); sharded levels take the per-level calls. */
+int pa_fill_ghosts_hierarchy(pa_ctx*, int nlev, pa_mf* const* mfs, int comp, int ncomp, const int32_t* ngs, int ratio, int interp_type, int foextrap);
+
 /* ---------------------------------------------------------------- isosurface
  * isosurface.cpp:1531-1592 for one FAB: state = 3 coordinate comps + fields,
  * mask (<0 = covered by a finer level), loop = box of cube base points.
@@ -349,6 +355,16 @@ int pa_msq_level_fine(pa_ctx*, const pa_mf* state, const pa_level* fine, int rat
 int pa_mc_hierarchy_fine(pa_ctx*, int nlev, const pa_mf* const* states, const int32_t* fine_mask, int ratio,
                          const pa_box* const* loops, int isocomp, double isoval, int64_t* const* nvert, int64_t* const* ntri,
                          double** dev_verts, int32_t** dev_vkeys, int32_t** dev_tris, void** block);
+/* pa_mc_hierarchy_fine WITHOUT the three coordinate components: fields[l] holds only the plotfile components (the iso field at
+ * isocomp + the mapped ones, ghost cells filled by pa_fill_ghosts_hierarchy with PCInterp).  The coordinates isosurface.cpp:1458-1465
+ * stores per cell and :1468-1478 FillBoundaries / FillPatches in ghost cells are a function of the cell index and of which level
+ * covers the cell -- (i + 0.5) dx + plo where the level itself covers it (through periodic images too), the coarse parent's centre
+ * in every other ghost cell -- so the vertex kernels form them in registers, with the operations of pa_iso_coords_level: vertices
+ * ([nvert][3 + ncomp]), keys and triangles are bit-identical to pa_mc_hierarchy_fine's on the reference-shaped state, and 24 B
+ * per cell (+ their ghost fills) are never written.  3-D levels; level l must be the `ratio` refinement of level l - 1. */
+int pa_mc_hierarchy_xyz(pa_ctx*, int nlev, const pa_mf* const* fields, const int32_t* fine_mask, int ratio, const pa_box* const* loops,
+                        int isocomp, double isoval, int64_t* const* nvert, int64_t* const* ntri, double** dev_verts, int32_t** dev_vkeys,
+                        int32_t** dev_tris, void** block);
 /* isosurface.cpp:1687-1726 + 1751-1812 on the device: the global node / element sets from the per-FAB fragments, in
  * insertion order (level by level, FAB by FAB: exactly the fragments whose ntri > 0, as the reference skips the others).
  * A vertex within 1e-15 (Euclidean) of an earlier node IS that node (Node::operator<, :834-873), otherwise a new node

@@ -145,6 +145,7 @@ def load_library() -> C.CDLL:
         "pa_boxfilter_level2d": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, pdbl]),
         "pa_foextrap": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int]),
         "pa_fillpatch_two_levels": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+        "pa_fill_ghosts_hierarchy": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.c_int, C.c_int, pi32, C.c_int, C.c_int, C.c_int]),
         "pa_mc_count_fab": (C.c_int, [vp, PaBox, C.POINTER(PaFab), C.POINTER(PaFab), C.c_int, dbl, C.POINTER(i64), C.POINTER(i64)]),
         "pa_mc_emit_fab": (C.c_int, [vp, PaBox, C.POINTER(PaFab), C.POINTER(PaFab), C.c_int, dbl, vp, vp, vp, i64, i64]),
         "pa_iso_mask_level": (C.c_int, [vp, vp, C.c_int, vp, C.c_int]),
@@ -155,6 +156,8 @@ def load_library() -> C.CDLL:
                                         C.POINTER(vp)]),
         "pa_mc_hierarchy_fine": (C.c_int, [vp, C.c_int, C.POINTER(vp), pi32, C.c_int, C.POINTER(C.POINTER(PaBox)), C.c_int, dbl, C.POINTER(C.POINTER(i64)),
                                            C.POINTER(C.POINTER(i64)), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
+        "pa_mc_hierarchy_xyz": (C.c_int, [vp, C.c_int, C.POINTER(vp), pi32, C.c_int, C.POINTER(C.POINTER(PaBox)), C.c_int, dbl, C.POINTER(C.POINTER(i64)),
+                                          C.POINTER(C.POINTER(i64)), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
         "pa_msq_level": (C.c_int, [vp, vp, vp, C.c_int, C.POINTER(PaBox), C.c_int, dbl, C.POINTER(i64), C.POINTER(i64), C.POINTER(vp), C.POINTER(vp),
                                    C.POINTER(vp)]),
         "pa_mc_level": (C.c_int, [vp, vp, vp, C.c_int, C.POINTER(PaBox), C.c_int, dbl, C.POINTER(i64), C.POINTER(i64), C.POINTER(vp), C.POINTER(vp),
@@ -457,10 +460,11 @@ def gradcurv_run_comps2(ctx, states, comp0, ncomps, bc, params: PaCurvParams, wo
     ctx.check(rc)
 
 
-def mc_hierarchy(ctx: Context, states, fine_mask, loops_per_level, isocomp: int, isoval: float, download: bool = True, ratio: int = 2):
+def mc_hierarchy(ctx: Context, states, fine_mask, loops_per_level, isocomp: int, isoval: float, download: bool = True, ratio: int = 2, xyz: bool = False):
     """pa_mc_hierarchy_fine: marching cubes on every level in one call.  states: DevMF per level; fine_mask: flag per level
     (mask by the next finer level); loops_per_level: (nboxes, 6) arrays.  Returns per level the per-box list
-    [(verts, vkeys, tris)] (download=False: only the per-box counts [(nv, nt)])"""
+    [(verts, vkeys, tris)] (download=False: only the per-box counts [(nv, nt)]).
+    xyz=True: pa_mc_hierarchy_xyz -- the states hold the fields only (isocomp among them), vertex coordinates come from cell indices"""
     nlev = len(states)
     arrs, nvs, nts = [], [], []
     for l in range(nlev):
@@ -479,7 +483,8 @@ def mc_hierarchy(ctx: Context, states, fine_mask, loops_per_level, isocomp: int,
     fm = (C.c_int32 * nlev)(*[int(bool(f)) for f in fine_mask])
     pv, pk, pt = (C.c_void_p * nlev)(), (C.c_void_p * nlev)(), (C.c_void_p * nlev)()
     block = C.c_void_p()
-    ctx.check(ctx.lib.pa_mc_hierarchy_fine(ctx.h, nlev, _handles(states), fm, int(ratio), parr, int(isocomp), float(isoval), pnv, pnt, pv, pk, pt, C.byref(block)))
+    fn = ctx.lib.pa_mc_hierarchy_xyz if xyz else ctx.lib.pa_mc_hierarchy_fine
+    ctx.check(fn(ctx.h, nlev, _handles(states), fm, int(ratio), parr, int(isocomp), float(isoval), pnv, pnt, pv, pk, pt, C.byref(block)))
     out = []
     try:
         for l in range(nlev):
@@ -488,7 +493,7 @@ def mc_hierarchy(ctx: Context, states, fine_mask, loops_per_level, isocomp: int,
             if not download:
                 out.append([(int(nv[b]), int(nt[b])) for b in range(nb)])
                 continue
-            nc = states[l].ncomp
+            nc = states[l].ncomp + (3 if xyz else 0)
             tv, tt = int(sum(nv[:nb])), int(sum(nt[:nb]))
             V = np.empty((tv, nc)); K = np.empty((tv, 6), np.int32); T = np.empty((tt, 3), np.int32)
             if tv:

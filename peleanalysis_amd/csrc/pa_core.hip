@@ -784,6 +784,7 @@ __global__ __launch_bounds__(256) void k_fill_boundary_regions(LevBatch<FbrArgs>
 }
 
 int pa_fill_boundary_local_batch(pa_ctx* ctx, int n, pa_mf* const* Ms, int comp, int ncomp, int ng);
+int pa_fill_boundary_local_batch_ngs(pa_ctx* ctx, int n, pa_mf* const* Ms, int comp, int ncomp, const int* ngs);
 static long long max_shell(const pa_level* L, int ng) {
   long long m = 0;
   for (const DBox& B : L->boxes) {
@@ -795,12 +796,17 @@ static long long max_shell(const pa_level* L, int ng) {
 
 // the local half of FillBoundary on several levels (same component range and ghost width) in as few launches as possible
 int pa_fill_boundary_local_batch(pa_ctx* ctx, int n, pa_mf* const* Ms, int comp, int ncomp, int ng) {
+  std::vector<int> ngs((size_t)std::max(n, 1), ng);
+  return pa_fill_boundary_local_batch_ngs(ctx, n, Ms, comp, ncomp, ngs.data());
+}
+// ... with a ghost width per level (filterPlt's levels: ngrow 1 / 2 / 4; pa_fill_ghosts_hierarchy); ngs[i] = 0: level i is skipped
+int pa_fill_boundary_local_batch_ngs(pa_ctx* ctx, int n, pa_mf* const* Ms, int comp, int ncomp, const int* ngs) {
   {  // copy regions when every level of the batch has a plan (pa_dist.hip)
     bool regions = true;
     std::vector<FbLocal*> plans(n, nullptr);
     for (int i = 0; i < n && regions; ++i) {
-      if (Ms[i]->lev->boxes.empty()) continue;
-      plans[i] = pa_fb_local_plan(ctx, Ms[i]->lev, ng);
+      if (Ms[i]->lev->boxes.empty() || ngs[i] <= 0) continue;
+      plans[i] = pa_fb_local_plan(ctx, Ms[i]->lev, ngs[i]);
       regions = plans[i] && plans[i]->ok;
     }
     if (regions) {
@@ -828,11 +834,11 @@ int pa_fill_boundary_local_batch(pa_ctx* ctx, int n, pa_mf* const* Ms, int comp,
     LevBatch<FillArgs> Bt;
     long long ms = 0;
     for (int i = i0; i < n && i < i0 + PA_MAXB; ++i) {
-      if (Ms[i]->lev->boxes.empty()) continue;
-      Bt.a[Bt.n] = FillArgs{Ms[i]->lev->view, Ms[i]->view, comp, ncomp, ng};
+      if (Ms[i]->lev->boxes.empty() || ngs[i] <= 0) continue;
+      Bt.a[Bt.n] = FillArgs{Ms[i]->lev->view, Ms[i]->view, comp, ncomp, ngs[i]};
       Bt.ycum[Bt.n + 1] = Bt.ycum[Bt.n] + (int)Ms[i]->lev->boxes.size();
       ++Bt.n;
-      ms = std::max(ms, max_shell(Ms[i]->lev, ng));
+      ms = std::max(ms, max_shell(Ms[i]->lev, ngs[i]));
     }
     if (!Bt.n) continue;
     hipLaunchKernelGGL(k_fill_boundary, dim3((unsigned)((ms + 255) / 256), (unsigned)Bt.ycum[Bt.n]), dim3(256), 0, ctx->stream, Bt);

@@ -814,8 +814,9 @@ __global__ __launch_bounds__(256) void k_fp_find(DLevelView L, int ngf, int unif
   if (i < cap) items[i] = make_int4(b | (int)(mask << 24), qc[0], qc[1], qc[2]);
 }
 
-__global__ __launch_bounds__(256, 4) void k_fp_do(DLevelView L, DMFView M, DLevelView LC, DMFView MC, int comp, int cshift, int ncomp, const int4* items, int n, int* nbad) {
-  const int t = blockIdx.x * 256 + threadIdx.x, r = 2;
+__device__ __forceinline__ void fp_do_item(const DLevelView& L, const DMFView& M, const DLevelView& LC, const DMFView& MC, int comp, int cshift, int ncomp, const int4* items, int n,
+                                           int* nbad, const int t) {
+  const int r = 2;
   if (t >= n) return;
   const int4 it = items[t];
   const int b = it.x & 0xffffff;
@@ -903,8 +904,113 @@ __global__ __launch_bounds__(256, 4) void k_fp_do(DLevelView L, DMFView M, DLeve
   }
 }
 
+__global__ __launch_bounds__(256, 4) void k_fp_do(DLevelView L, DMFView M, DLevelView LC, DMFView MC, int comp, int cshift, int ncomp, const int4* items, int n, int* nbad) {
+  fp_do_item(L, M, LC, MC, comp, cshift, ncomp, items, n, nbad, blockIdx.x * 256 + threadIdx.x);
+}
+// the level pairs of a hierarchy in ONE launch (pa_fill_ghosts_hierarchy): FillPatchTwoLevels reads VALID coarse cells only (through
+// the owner map; beyond a wall the nearest cell inside), so the pairs do not depend on each other
+struct FpdLev { DLevelView L; DMFView M; DLevelView LC; DMFView MC; int comp, cshift, ncomp; const int4* items; int n; };
+struct FpdBatch { int n; unsigned wg0[PA_MAXB + 1]; FpdLev a[PA_MAXB]; };
+__global__ __launch_bounds__(256, 4) void k_fp_do_levels(FpdBatch Bt, int* nbad) {
+  int l = 0;
+  while (l + 1 < Bt.n && blockIdx.x >= Bt.wg0[l + 1]) ++l;
+  const int t = (int)(blockIdx.x - Bt.wg0[l]) * 256 + (int)threadIdx.x;
+  // a constant index per case: the level's arguments stay in the kernel-argument segment (a run-time index into the by-value
+  // array sends the whole batch through scratch memory: 191 us for two level pairs against 2 x 70 us for two k_fp_do launches)
+  static_assert(PA_MAXB == 4, "one case per batch row");
+  switch (l) {
+    case 0: fp_do_item(Bt.a[0].L, Bt.a[0].M, Bt.a[0].LC, Bt.a[0].MC, Bt.a[0].comp, Bt.a[0].cshift, Bt.a[0].ncomp, Bt.a[0].items, Bt.a[0].n, nbad, t); break;
+    case 1: fp_do_item(Bt.a[1].L, Bt.a[1].M, Bt.a[1].LC, Bt.a[1].MC, Bt.a[1].comp, Bt.a[1].cshift, Bt.a[1].ncomp, Bt.a[1].items, Bt.a[1].n, nbad, t); break;
+    case 2: fp_do_item(Bt.a[2].L, Bt.a[2].M, Bt.a[2].LC, Bt.a[2].MC, Bt.a[2].comp, Bt.a[2].cshift, Bt.a[2].ncomp, Bt.a[2].items, Bt.a[2].n, nbad, t); break;
+    default: fp_do_item(Bt.a[3].L, Bt.a[3].M, Bt.a[3].LC, Bt.a[3].MC, Bt.a[3].comp, Bt.a[3].cshift, Bt.a[3].ncomp, Bt.a[3].items, Bt.a[3].n, nbad, t); break;
+  }
+}
+struct Fp2Args { DLevelView L; DMFView M; DLevelView LC; DMFView MC; int comp, cshift, ncomp, ngf, r, interp; };
+__global__ void k_fillpatch2_levels(LevBatch<Fp2Args> Bt, int* nbad) {
+  unsigned b;
+  const Fp2Args& A = Bt.a[Bt.find(blockIdx.y, b)];
+  const DBox B = A.L.boxes[b];
+  const long long nx = B.hi[0] - B.lo[0] + 1, ny = B.hi[1] - B.lo[1] + 1, nz = B.hi[2] - B.lo[2] + 1;
+  const long long nsh = (nx + 2 * A.ngf) * (ny + 2 * A.ngf) * (nz + 2 * A.ngf) - nx * ny * nz;
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < nsh; t += (long long)gridDim.x * blockDim.x)
+    fillpatch2_cell(A.L, A.M, A.LC, A.MC, A.comp, A.cshift, A.ncomp, A.ngf, A.r, A.interp, nbad, (int)b, B, t);
+}
+struct FoArgs { DLevelView L; DMFView M; int comp, ncomp, ngf; };
+__global__ void k_foextrap_levels(LevBatch<FoArgs> Bt) {
+  unsigned b;
+  const FoArgs& A = Bt.a[Bt.find(blockIdx.y, b)];
+  const DBox B = A.L.boxes[b];
+  const long long nx = B.hi[0] - B.lo[0] + 1, ny = B.hi[1] - B.lo[1] + 1, nz = B.hi[2] - B.lo[2] + 1;
+  const long long nsh = (nx + 2 * A.ngf) * (ny + 2 * A.ngf) * (nz + 2 * A.ngf) - nx * ny * nz;
+  double* f = A.M.data + A.M.off[b];
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < nsh; t += (long long)gridDim.x * blockDim.x) {
+    int q[3];
+    if (!shell_cell2(B, A.ngf, t, q[0], q[1], q[2])) continue;
+    int p[3] = {q[0], q[1], q[2]};
+    bool out = false;
+    for (int d = 0; d < 3; ++d)
+      if (!A.L.is_per[d]) {
+        if (p[d] < A.L.domlo[d]) { p[d] = A.L.domlo[d]; out = true; }
+        if (p[d] > A.L.domhi[d]) { p[d] = A.L.domhi[d]; out = true; }
+      }
+    if (!out) continue;
+    for (int c = A.comp; c < A.comp + A.ncomp; ++c) f[fab_index(B, A.M.ng, A.M.ncomp, c, q[0], q[1], q[2])] = f[fab_index(B, A.M.ng, A.M.ncomp, c, p[0], p[1], p[2])];
+  }
+}
+
 FpPlan::~FpPlan() {
   if (d_items) (void)hipFree(d_items);
+}
+
+#define PA_HIPN(call)                                                                     \
+  do {                                                                                    \
+    hipError_t e_ = (call);                                                               \
+    if (e_ != hipSuccess) {                                                               \
+      ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                       \
+      return nullptr;                                                                     \
+    }                                                                                     \
+  } while (0)
+// the parent list of a (fine level, coarse level, ghost width) triple, built on first use (k_fp_find) and kept with the fine level
+static const FpPlan* fp_parent_plan(pa_ctx* ctx, const pa_level* F, const pa_level* C, int ng) {
+  long long mp = 0;
+  for (const DBox& B : F->boxes) {
+    long long n = 1;
+    for (int d = 0; d < 3; ++d) n *= coarsen_idx(B.hi[d] + ng, 2) - coarsen_idx(B.lo[d] - ng, 2) + 1;
+    mp = std::max(mp, n);
+  }
+  auto fail = [&](const char* m) -> const FpPlan* { pa_fail(ctx, m); return nullptr; };
+  const auto key = std::make_pair(C->serial, ng);
+  auto itp = F->fp_plans.find(key);
+    if (itp == F->fp_plans.end()) {  // the list of parents, once
+      if (F->boxes.size() >= (1u << 24)) return fail("pa_fillpatch_two_levels: too many boxes");
+      bool uniform = F->g % 2 == 0;  // one classification per parent (see k_fp_find)
+      for (int d = 0; d < 3; ++d) uniform = uniform && F->mlo[d] % 2 == 0 && F->domlo[d] % 2 == 0 && (F->domhi[d] + 1) % 2 == 0;
+      long long cap = 0;  // parents of the shells
+      for (const DBox& B : F->boxes) {
+        long long all = 1, in = 1;
+        for (int d = 0; d < 3; ++d) {
+          all *= coarsen_idx(B.hi[d] + ng, 2) - coarsen_idx(B.lo[d] - ng, 2) + 1;
+          in *= std::max(0, coarsen_idx(B.hi[d] - 1, 2) - coarsen_idx(B.lo[d] + 1, 2) + 1);  // parents whose 2 cells per direction are all valid (>=: a lower bound)
+        }
+        cap += all - in;
+      }
+      if (cap >= (1LL << 31)) return fail("pa_fillpatch_two_levels: ghost shell too large");
+      std::unique_ptr<FpPlan> P(new FpPlan());
+      PA_HIPN(hipMalloc(&P->d_items, sizeof(int4) * (size_t)std::max<long long>(cap, 1)));
+      int* d_count = nullptr;
+      PA_HIPN(hipMalloc(&d_count, sizeof(int)));
+      PA_HIPN(hipMemsetAsync(d_count, 0, sizeof(int), ctx->stream));
+      hipLaunchKernelGGL(k_fp_find, dim3((unsigned)((mp + 255) / 256), (unsigned)F->boxes.size()), dim3(256), 0, ctx->stream, F->view, ng, uniform ? 1 : 0,
+                         (int4*)P->d_items, d_count, (int)cap);
+      int n = 0;
+      PA_HIPN(hipMemcpyAsync(&n, d_count, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+      PA_HIPN(hipStreamSynchronize(ctx->stream));
+      (void)hipFree(d_count);
+      if (n > cap) return fail("pa_fillpatch_two_levels: parent list overflow");
+      P->n = n;
+      itp = F->fp_plans.emplace(key, std::move(P)).first;
+    }
+  return itp->second.get();
 }
 
 extern "C" int pa_fillpatch_two_levels(pa_ctx* ctx, pa_mf* fine, const pa_mf* crse, int comp, int ncomp, int ng, int ratio, int interp_type) {
@@ -922,45 +1028,10 @@ extern "C" int pa_fillpatch_two_levels(pa_ctx* ctx, pa_mf* fine, const pa_mf* cr
   if (fine->lev->boxes.empty() || !crse) return 0;
   static const int parent_env = [] { const char* e = getenv("PA_FILLPATCH_PARENT"); return e ? atoi(e) : 1; }();  // 0: thread per ghost cell (A/B)
   if (interp_type == 1 && parent_env && ratio == 2) {
-    long long mp = 0;
-    for (const DBox& B : fine->lev->boxes) {
-      long long n = 1;
-      for (int d = 0; d < 3; ++d) n *= coarsen_idx(B.hi[d] + ng, 2) - coarsen_idx(B.lo[d] - ng, 2) + 1;
-      mp = std::max(mp, n);
-    }
+    const FpPlan* Pp = fp_parent_plan(ctx, fine->lev, crse->lev, ng);
+    if (!Pp) return 1;
+    const FpPlan& P = *Pp;
     const pa_level* F = fine->lev;
-    const auto key = std::make_pair(crse->lev->serial, ng);
-    auto itp = F->fp_plans.find(key);
-    if (itp == F->fp_plans.end()) {  // the list of parents, once
-      if (F->boxes.size() >= (1u << 24)) return pa_fail(ctx, "pa_fillpatch_two_levels: too many boxes");
-      bool uniform = F->g % 2 == 0;  // one classification per parent (see k_fp_find)
-      for (int d = 0; d < 3; ++d) uniform = uniform && F->mlo[d] % 2 == 0 && F->domlo[d] % 2 == 0 && (F->domhi[d] + 1) % 2 == 0;
-      long long cap = 0;  // parents of the shells
-      for (const DBox& B : F->boxes) {
-        long long all = 1, in = 1;
-        for (int d = 0; d < 3; ++d) {
-          all *= coarsen_idx(B.hi[d] + ng, 2) - coarsen_idx(B.lo[d] - ng, 2) + 1;
-          in *= std::max(0, coarsen_idx(B.hi[d] - 1, 2) - coarsen_idx(B.lo[d] + 1, 2) + 1);  // parents whose 2 cells per direction are all valid (>=: a lower bound)
-        }
-        cap += all - in;
-      }
-      if (cap >= (1LL << 31)) return pa_fail(ctx, "pa_fillpatch_two_levels: ghost shell too large");
-      std::unique_ptr<FpPlan> P(new FpPlan());
-      PA_HIP(hipMalloc(&P->d_items, sizeof(int4) * (size_t)std::max<long long>(cap, 1)));
-      int* d_count = nullptr;
-      PA_HIP(hipMalloc(&d_count, sizeof(int)));
-      PA_HIP(hipMemsetAsync(d_count, 0, sizeof(int), ctx->stream));
-      hipLaunchKernelGGL(k_fp_find, dim3((unsigned)((mp + 255) / 256), (unsigned)F->boxes.size()), dim3(256), 0, ctx->stream, F->view, ng, uniform ? 1 : 0,
-                         (int4*)P->d_items, d_count, (int)cap);
-      int n = 0;
-      PA_HIP(hipMemcpyAsync(&n, d_count, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-      PA_HIP(hipStreamSynchronize(ctx->stream));
-      (void)hipFree(d_count);
-      if (n > cap) return pa_fail(ctx, "pa_fillpatch_two_levels: parent list overflow");
-      P->n = n;
-      itp = F->fp_plans.emplace(key, std::move(P)).first;
-    }
-    const FpPlan& P = *itp->second;
     if (P.n > 0)
       hipLaunchKernelGGL(k_fp_do, dim3((unsigned)((P.n + 255) / 256)), dim3(256), 0, ctx->stream, F->view, fine->view, crse->lev->view, crse->view, comp, ccomp - comp,
                          ncomp, (const int4*)P.d_items, P.n, ctx->d_flags);
@@ -973,3 +1044,93 @@ extern "C" int pa_fillpatch_two_levels(pa_ctx* ctx, pa_mf* fine, const pa_mf* cr
   PA_HIP(hipGetLastError());
   return 0;
 }
+
+int pa_fill_boundary_local_batch_ngs(pa_ctx* ctx, int n, pa_mf* const* Ms, int comp, int ncomp, const int* ngs);
+// The ghost fill of a whole hierarchy -- filterPlt.cpp:159-203 (FillBoundary, FillPatchTwoLevels, foextrap per level) and
+// isosurface.cpp:1468-1524 (FillBoundary + FillPatchTwoLevels with PCInterp) -- in THREE launches instead of three per level:
+// FillBoundary of every level, FillPatchTwoLevels of every level pair, foextrap of every level.  Legal because no step of a
+// level reads what another level's step writes: FillBoundary and FillPatchTwoLevels read VALID cells only (the coarse values
+// through the owner map, the nearest cell inside the domain beyond a wall) and write disjoint ghost cells; foextrap reads the
+// ghost cells of its own FAB that the two earlier launches filled.  Results identical to the per-level calls.  Levels sharded
+// over ranks take the per-level calls (their cross-rank halves are exchanges of their own).
+extern "C" int pa_fill_ghosts_hierarchy(pa_ctx* ctx, int nlev, pa_mf* const* mfs, int comp, int ncomp, const int32_t* ngs, int ratio, int interp_type, int foextrap) {
+  PaBind bind_(ctx);
+  if (!ctx || nlev <= 0 || !mfs || !ngs) return pa_fail(ctx, "pa_fill_ghosts_hierarchy: null argument");
+  if (ratio < 2 || ratio > 16) return pa_fail(ctx, "pa_fill_ghosts_hierarchy: refinement ratio must be 2 .. 16");
+  if (interp_type != 0 && interp_type != 1) return pa_fail(ctx, "pa_fill_ghosts_hierarchy: interp_type must be 0 (pc) or 1 (cell-conservative linear)");
+  bool sharded = false;
+  for (int l = 0; l < nlev; ++l) {
+    if (!mfs[l]) return pa_fail(ctx, "pa_fill_ghosts_hierarchy: null multifab");
+    if (ngs[l] > mfs[l]->ng || ngs[l] < 0 || comp < 0 || comp + ncomp > mfs[l]->ncomp) return pa_fail(ctx, "pa_fill_ghosts_hierarchy: ng/component range");
+    for (int d = 0; d < 3; ++d)
+      if (mfs[l]->lev->is_per[d] && ngs[l] > mfs[l]->lev->domhi[d] - mfs[l]->lev->domlo[d] + 1) return pa_fail(ctx, "pa_fill_ghosts_hierarchy: ng larger than the periodic domain");
+    sharded = sharded || mfs[l]->lev->nranks > 1;
+  }
+  static const int batch_env = [] { const char* e = getenv("PA_GHOSTS_BATCH"); return e ? atoi(e) : 1; }();  // 0: level by level (A/B)
+  if (sharded || !batch_env) {
+    for (int l = 0; l < nlev; ++l) {
+      if (pa_fill_boundary(ctx, mfs[l], comp, ncomp, ngs[l])) return 1;
+      if (l > 0 && pa_fillpatch_two_levels(ctx, mfs[l], mfs[l - 1], comp, ncomp, ngs[l], ratio, interp_type)) return 1;
+      if (foextrap && pa_foextrap(ctx, mfs[l], comp, ncomp, ngs[l])) return 1;
+    }
+    return 0;
+  }
+  {
+    ProfScope prof(ctx, PA_TAG_FILL);
+    std::vector<int> g(ngs, ngs + nlev);
+    if (pa_fill_boundary_local_batch_ngs(ctx, nlev, mfs, comp, ncomp, g.data())) return 1;
+  }
+  static const int parent_env = [] { const char* e = getenv("PA_FILLPATCH_PARENT"); return e ? atoi(e) : 1; }();
+  if (interp_type == 1 && parent_env && ratio == 2) {
+    for (int l0 = 1; l0 < nlev; l0 += PA_MAXB) {
+      FpdBatch Bt;
+      Bt.n = 0;
+      Bt.wg0[0] = 0;
+      for (int l = l0; l < nlev && l < l0 + PA_MAXB; ++l) {
+        if (ngs[l] == 0 || mfs[l]->lev->boxes.empty()) continue;
+        const FpPlan* P = fp_parent_plan(ctx, mfs[l]->lev, mfs[l - 1]->lev, ngs[l]);
+        if (!P) return 1;
+        if (P->n <= 0) continue;
+        Bt.a[Bt.n] = FpdLev{mfs[l]->lev->view, mfs[l]->view, mfs[l - 1]->lev->view, mfs[l - 1]->view, comp, 0, ncomp, (const int4*)P->d_items, P->n};
+        Bt.wg0[Bt.n + 1] = Bt.wg0[Bt.n] + (unsigned)((P->n + 255) / 256);
+        ++Bt.n;
+      }
+      if (Bt.n) hipLaunchKernelGGL(k_fp_do_levels, dim3(Bt.wg0[Bt.n]), dim3(256), 0, ctx->stream, Bt, ctx->d_flags);
+    }
+  } else {
+    for (int l0 = 1; l0 < nlev; l0 += PA_MAXB) {
+      LevBatch<Fp2Args> Bt;
+      long long ms = 0;
+      for (int l = l0; l < nlev && l < l0 + PA_MAXB; ++l) {
+        if (ngs[l] == 0 || mfs[l]->lev->boxes.empty()) continue;
+        Bt.a[Bt.n] = Fp2Args{mfs[l]->lev->view, mfs[l]->view, mfs[l - 1]->lev->view, mfs[l - 1]->view, comp, 0, ncomp, ngs[l], ratio, interp_type};
+        Bt.ycum[Bt.n + 1] = Bt.ycum[Bt.n] + (int)mfs[l]->lev->boxes.size();
+        ++Bt.n;
+        ms = std::max(ms, min_shell2(mfs[l]->lev, ngs[l]));
+      }
+      if (Bt.n) hipLaunchKernelGGL(k_fillpatch2_levels, dim3((unsigned)((ms + 255) / 256), (unsigned)Bt.ycum[Bt.n]), dim3(256), 0, ctx->stream, Bt, ctx->d_flags);
+    }
+  }
+  PA_HIP(hipGetLastError());
+  if (foextrap) {
+    for (int l0 = 0; l0 < nlev; l0 += PA_MAXB) {
+      LevBatch<FoArgs> Bt;
+      long long ms = 0;
+      for (int l = l0; l < nlev && l < l0 + PA_MAXB; ++l) {
+        if (ngs[l] == 0 || mfs[l]->lev->boxes.empty()) continue;
+        bool wall = false;  // a level without a non-periodic direction has nothing to extrapolate
+        for (int d = 0; d < 3; ++d) wall = wall || !mfs[l]->lev->is_per[d];
+        if (!wall) continue;
+        Bt.a[Bt.n] = FoArgs{mfs[l]->lev->view, mfs[l]->view, comp, ncomp, ngs[l]};
+        Bt.ycum[Bt.n + 1] = Bt.ycum[Bt.n] + (int)mfs[l]->lev->boxes.size();
+        ++Bt.n;
+        ms = std::max(ms, min_shell2(mfs[l]->lev, ngs[l]));
+      }
+      if (Bt.n) hipLaunchKernelGGL(k_foextrap_levels, dim3((unsigned)((ms + 255) / 256), (unsigned)Bt.ycum[Bt.n]), dim3(256), 0, ctx->stream, Bt);
+    }
+    PA_HIP(hipGetLastError());
+  }
+  return 0;
+}
+
+

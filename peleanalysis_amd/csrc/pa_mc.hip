@@ -397,7 +397,27 @@ struct MclArgs {
   int* bsum;               // [coff[nboxes] / 256][2]
   long long* tot;          // [nboxes][2]
   const long long* base;   // [nboxes][2] first vertex / triangle of a FAB in the output
+  // xyz != 0 (pa_mc_hierarchy_xyz): the state holds the FIELDS only and a vertex's first three components are formed from cell
+  // indices -- the cell-centre coordinates isosurface.cpp:1458-1465 stores per cell and :1468-1478 overwrites in ghost cells
+  // are a function of (i, j, k) and of which level covers the cell (mcl_xyz) -- instead of read from three stored components;
+  // ncomp stays the number of values per vertex, 3 + the state's components
+  int xyz = 0, cratio = 0;
+  double gdx[3] = {0, 0, 0}, gplo[3] = {0, 0, 0}, gdxc[3] = {0, 0, 0};
 };
+// Component d of what the reference's state holds in its coordinate components at cell p of a grown FAB of level A.L:
+//   a cell covered by the level itself (valid, or a ghost cell inside a neighbouring box / a periodic image of one: FillBoundary
+//   copies the owner's value, isosurface.cpp:1468)          -> (i_w + 0.5) * dx + plo with i_w the index folded into the domain;
+//   any other ghost cell inside the (periodically extended) domain: FillPatchTwoLevels with PCInterp hands it its coarse
+//   parent's value (:1474-1478)                              -> (coarsen(i_w) + 0.5) * dx_coarse + plo.
+// Same operations in the same order as k_iso_coords, so the doubles are the ones the stored components would hold.
+__device__ __forceinline__ void mcl_xyz(const MclArgs& A, const int p[3], double x[3]) {
+  int pw[3] = {p[0], p[1], p[2]};
+  const bool inside = wrap_cell(A.L, pw);
+  const bool covered = !inside || A.cratio <= 0 || owner_of(A.L, pw) != -1;  // (cells beyond a wall are never corners of a visited cube)
+#pragma unroll
+  for (int d = 0; d < 3; ++d)
+    x[d] = covered ? (pw[d] + 0.5) * A.gdx[d] + A.gplo[d] : (coarsen_idx(pw[d], A.cratio) + 0.5) * A.gdxc[d] + A.gplo[d];
+}
 
 __device__ __forceinline__ bool mcl_geo(const MclArgs& A, int b, MclGeo& G) {
   const DBox B = A.L.boxes[b], Lp = A.loops[b];
@@ -1064,9 +1084,17 @@ __device__ __forceinline__ void mcl_verts_body(const MclArgs& A, double* verts, 
   else if (fabs(v1 - v2) < PA_EPS_DEF) mode = 0;
   else mode = 2;
   const double mu = mode == 2 ? (A.iso - v1) / (v2 - v1) : 0.0;
-  for (int c = 0; c < A.ncomp; ++c) {
+  int c0 = 0;
+  if (A.xyz) {  // the three coordinate components from the cell indices; the state's components follow
+    double x1[3], x2[3];
+    mcl_xyz(A, a, x1);
+    mcl_xyz(A, e, x2);
+    for (int d = 0; d < 3; ++d) o[d] = mode == 0 ? x1[d] : (mode == 1 ? x2[d] : x1[d] + mu * (x2[d] - x1[d]));
+    c0 = 3;
+  }
+  for (int c = 0; c + c0 < A.ncomp; ++c) {
     const double a1 = S(a[0], a[1], a[2], c), a2 = S(e[0], e[1], e[2], c);
-    o[c] = mode == 0 ? a1 : (mode == 1 ? a2 : a1 + mu * (a2 - a1));
+    o[c + c0] = mode == 0 ? a1 : (mode == 1 ? a2 : a1 + mu * (a2 - a1));
   }
   key[0] = i; key[1] = j; key[2] = k; key[3] = hi_i; key[4] = hi_j; key[5] = hi_k;
 }
@@ -1258,10 +1286,10 @@ struct MclWork {
 };
 
 static int mc_prepare(pa_ctx* ctx, const pa_mf* state, const pa_mf* mask, int mcomp, const pa_box* loops, int isocomp, double isoval, int64_t* nvert, int64_t* ntri,
-                      int dim2, int nomask, const pa_level* fine, int ratio, MclWork& W) {
+                      int dim2, int nomask, const pa_level* fine, int ratio, MclWork& W, const pa_level* xyz_crse = nullptr, int xyz = 0, int cratio = 0) {
   if (!ctx || !state || !mask || !loops || !nvert || !ntri) return pa_fail(ctx, "pa_mc_level: null argument");
   if (state->lev != mask->lev || state->ng != mask->ng) return pa_fail(ctx, "pa_mc_level: state and mask must share the level and the ghost width");
-  if (state->ncomp < (dim2 ? 3 : 4)) return pa_fail(ctx, "pa_mc_level: state needs the coordinate components + at least one field");
+  if (!xyz && state->ncomp < (dim2 ? 3 : 4)) return pa_fail(ctx, "pa_mc_level: state needs the coordinate components + at least one field");
   if (isocomp < 0 || isocomp >= state->ncomp || mcomp < 0 || mcomp >= mask->ncomp) return pa_fail(ctx, "pa_mc_level: component range");
   const pa_level* L = state->lev;
   const int nb = (int)L->boxes.size(), ng = state->ng;
@@ -1308,6 +1336,17 @@ static int mc_prepare(pa_ctx* ctx, const pa_mf* state, const pa_mf* mask, int mc
   A.has_fine = (nomask && fine) ? 1 : 0;
   A.ratio = ratio;
   A.LF = fine ? fine->view : L->view;
+  A.xyz = xyz;
+  A.cratio = 0;
+  if (xyz) {
+    A.ncomp = 3 + state->ncomp;
+    for (int d = 0; d < 3; ++d) {
+      A.gdx[d] = L->dx[d];
+      A.gplo[d] = L->prob_lo[d];
+      A.gdxc[d] = xyz_crse ? xyz_crse->dx[d] : L->dx[d];
+    }
+    A.cratio = xyz_crse ? cratio : 0;
+  }
   return 0;
 }
 
@@ -1451,7 +1490,7 @@ static int mc_counts(pa_ctx* ctx, MclWork& W) {
 }
 // bytes of a level's part of the output block: vertices | keys | triangles, each 256-byte aligned
 static void mc_parts(const MclWork& W, size_t& bv, size_t& bk, size_t& bt) {
-  bv = ((size_t)W.nv * W.state->ncomp * 8 + 255) / 256 * 256;
+  bv = ((size_t)W.nv * W.A.ncomp * 8 + 255) / 256 * 256;
   bk = ((size_t)W.nv * 24 + 255) / 256 * 256;
   bt = (std::max<size_t>(8, (size_t)W.nt * 12) + 255) / 256 * 256;
 }
@@ -1712,6 +1751,34 @@ static int mc_level_impl(pa_ctx* ctx, const pa_mf* state, const pa_mf* mask, int
 // pa_device_free; dev_verts[l] / dev_vkeys[l] / dev_tris[l] point into it, null for a level without surface) and the host
 // waits once at the end.  states[l] on level l, masked by level l + 1 (fine_mask[l] != 0, isosurface.cpp:1540-1563) or not
 // at all; loops / nvert / ntri: per level, as pa_mc_level_fine.
+// pa_mc_hierarchy_fine on states WITHOUT coordinate components (see MclArgs::xyz)
+extern "C" int pa_mc_hierarchy_xyz(pa_ctx* ctx, int nlev, const pa_mf* const* fields, const int32_t* fine_mask, int ratio, const pa_box* const* loops, int isocomp,
+                                   double isoval, int64_t* const* nvert, int64_t* const* ntri, double** dev_verts, int32_t** dev_vkeys, int32_t** dev_tris, void** block) {
+  PaBind bind_(ctx);
+  if (!ctx || nlev <= 0 || !fields || !loops || !nvert || !ntri || !dev_verts || !dev_vkeys || !dev_tris || !block) return pa_fail(ctx, "pa_mc_hierarchy_xyz: null argument");
+  if (ratio < 2) return pa_fail(ctx, "pa_mc_hierarchy_xyz: bad refinement ratio");
+  *block = nullptr;
+  std::vector<MclWork> W((size_t)nlev);
+  for (int l = 0; l < nlev; ++l) {
+    dev_verts[l] = nullptr; dev_vkeys[l] = nullptr; dev_tris[l] = nullptr;
+    if (!fields[l]) return pa_fail(ctx, "pa_mc_hierarchy_xyz: null state");
+    if (fields[l]->lev->domhi[2] == fields[l]->lev->domlo[2]) return pa_fail(ctx, "pa_mc_hierarchy_xyz: 3-D levels only (marching squares keep their coordinate components)");
+    if (l > 0)  // the coarse cell centre needs the coarse level's geometry: level l must be the `ratio` refinement of level l - 1
+      for (int d = 0; d < 3; ++d)
+        if ((long long)(fields[l]->lev->domhi[d] - fields[l]->lev->domlo[d] + 1) != (long long)ratio * (fields[l - 1]->lev->domhi[d] - fields[l - 1]->lev->domlo[d] + 1) ||
+            fields[l]->lev->domlo[d] != ratio * fields[l - 1]->lev->domlo[d])
+          return pa_fail(ctx, "pa_mc_hierarchy_xyz: level " + std::to_string(l) + " is not the ratio-" + std::to_string(ratio) + " refinement of level " + std::to_string(l - 1));
+    const pa_level* fine = (fine_mask && fine_mask[l] && l + 1 < nlev) ? fields[l + 1]->lev : nullptr;
+    if (mc_prepare(ctx, fields[l], fields[l], 0, loops[l], isocomp, isoval, nvert[l], ntri[l], 0, 1, fine, ratio, W[l], l > 0 ? fields[l - 1]->lev : nullptr, 1, ratio)) return 1;
+  }
+  if (mc_run(ctx, nlev, W.data())) return 1;
+  for (int l = 0; l < nlev; ++l) {
+    dev_verts[l] = W[l].dv; dev_vkeys[l] = W[l].dk; dev_tris[l] = W[l].dt;
+    if (W[l].dv && !*block) *block = W[l].dv;
+  }
+  return 0;
+}
+
 extern "C" int pa_mc_hierarchy_fine(pa_ctx* ctx, int nlev, const pa_mf* const* states, const int32_t* fine_mask, int ratio, const pa_box* const* loops, int isocomp,
                                     double isoval, int64_t* const* nvert, int64_t* const* ntri, double** dev_verts, int32_t** dev_vkeys, int32_t** dev_tris, void** block) {
   PaBind bind_(ctx);

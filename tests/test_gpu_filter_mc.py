@@ -652,3 +652,91 @@ print("NESTED_ERRORS_COUNTED")
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, PA_FILLPATCH_PARENT=parent))
     assert r.returncode == 0 and "NESTED_ERRORS_COUNTED" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+def _iso_loops(H, ng, per):
+    """cube base points per FAB as isosurface.cpp:1566-1569: (grown box & domain grown in the periodic directions), high side - 1"""
+    loops = []
+    for lv in H.levels:
+        lp = np.zeros((lv.nboxes, 6), np.int64)
+        for b in range(lv.nboxes):
+            for d in range(3):
+                pg = ng if per[d] else 0
+                lp[b, d] = max(int(lv.boxes[b, d]) - ng, int(lv.domlo[d]) - pg)
+                lp[b, 3 + d] = min(int(lv.boxes[b, 3 + d]) + ng, int(lv.domhi[d]) + pg) - 1
+        loops.append(lp)
+    return loops
+
+
+@pytest.mark.parametrize("case", ["amr3_wall_z", "amr3_sym_x", "periodic", "union0", "union1", "union2", "ratio4"])
+@pytest.mark.parametrize("ng", [1, 2])
+def test_marching_cubes_with_analytic_coordinates_equals_the_stored_coordinate_state(ctx, oracle, case, ng):
+    """pa_mc_hierarchy_xyz (states = fields only, ghost cells by pa_fill_ghosts_hierarchy, vertex coordinates formed from cell
+    indices) against pa_mc_hierarchy_fine on the reference-shaped state (three stored coordinate components, FillBoundary +
+    FillPatchTwoLevels on them as isosurface.cpp:1458-1478; that path is compared with the oracle's Polygonise above): vertices
+    bit for bit, keys and connectivity identical -- nested and non-convex hierarchies, periodic images (quirk Q5: wrapped
+    coordinates), coarse-fine ghost cells (coarse cell centres), one or two ghost layers, refinement ratio 2 and 4."""
+    from util import build_config, make_states
+    from peleanalysis_amd.hierarchy import field_flame, field_trig, union_hierarchy
+    ratio = 2
+    if case in ("amr3_wall_z", "amr3_sym_x"):
+        H, per, _, fn = build_config(case)
+    elif case == "periodic":
+        from peleanalysis_amd.hierarchy import nested_hierarchy
+        H, per, fn = nested_hierarchy(32, 3, 8, is_per=(1, 1, 1)), (1, 1, 1), field_trig
+    elif case == "ratio4":
+        H, per, fn, ratio = _ratio4_hierarchy((1, 0, 0)), (1, 0, 0), field_flame, 4
+    else:
+        H = union_hierarchy(7100 + int(case[-1]))
+        per, fn = tuple(int(v) for v in H.levels[0].is_per), field_flame
+    nf = 2
+    fields = make_states(H, nf, 0, fn, seed=3)
+    dls = [capi.DevLevel(ctx, lv) for lv in H.levels]
+    # reference-shaped state on the device, the way tools/src/isosurface.cpp built it up to round 4
+    ref, fld = [], []
+    for l, (lv, dl) in enumerate(zip(H.levels, dls)):
+        hf = MultiFab(lv, nf, ng, fill=-666.0)
+        for b in range(lv.nboxes):
+            hf.valid(b)[:] = fields[l].valid(b)
+        df = capi.DevMF.from_host(ctx, dl, hf)
+        st = capi.DevMF(ctx, dl, 3 + nf, ng)
+        ctx.check(ctx.lib.pa_iso_coords_level(ctx.h, st.h, 0))
+        ctx.check(ctx.lib.pa_mf_copy(ctx.h, df.h, 0, st.h, 3, nf, ng))
+        ctx.check(ctx.lib.pa_fill_boundary(ctx.h, st.h, 0, 3 + nf, ng))
+        if l > 0:
+            ctx.check(ctx.lib.pa_fillpatch_two_levels(ctx.h, st.h, ref[l - 1].h, 0, 3 + nf, ng, ratio, 0))
+        ref.append(st)
+        fld.append(capi.DevMF.from_host(ctx, dl, hf))
+    hm = (C.c_void_p * H.nlev)(*[f.h for f in fld])
+    hg = (C.c_int32 * H.nlev)(*([ng] * H.nlev))
+    ctx.check(ctx.lib.pa_fill_ghosts_hierarchy(ctx.h, H.nlev, hm, 0, nf, hg, ratio, 0, 0))
+    ctx.sync()
+    assert ctx.bc_errors() == 0
+    # the ghost fill of the hierarchy in three launches == the per-level calls (the field components of the reference-shaped state)
+    for l, lv in enumerate(H.levels):
+        a, b_ = fld[l].download(), ref[l].download()
+        for b in range(lv.nboxes):
+            fa, fb = a.fab(b), b_.fab(b)[3:]
+            inside = np.ones(fa.shape[1:], bool)  # ghost cells beyond a non-periodic wall are never read: compare the others
+            for d, ax in ((0, 2), (1, 1), (2, 0)):
+                if not per[d]:
+                    idx = np.arange(fa.shape[1 + ax]) + int(lv.boxes[b, d]) - ng
+                    m = (idx >= lv.domlo[d]) & (idx <= lv.domhi[d])
+                    sh = [1, 1, 1]
+                    sh[ax] = -1
+                    inside &= m.reshape(sh)
+            assert np.array_equal(fa[:, inside].view(np.int64), fb[:, inside].view(np.int64)), f"{case} ng {ng}: ghost fill of level {l} box {b} differs"
+    iso = float(np.median(np.concatenate([f.valid(b)[0].ravel() for f in fields for b in range(f.level.nboxes)])))
+    loops = _iso_loops(H, ng, per)
+    fm = [1] * (H.nlev - 1) + [0]
+    want = capi.mc_hierarchy(ctx, ref, fm, loops, 3, iso, ratio=ratio)
+    got = capi.mc_hierarchy(ctx, fld, fm, loops, 0, iso, ratio=ratio, xyz=True)
+    ntri = 0
+    for l, lv in enumerate(H.levels):
+        for b in range(lv.nboxes):
+            (v, k, t), (gv, gk, gt) = want[l][b], got[l][b]
+            assert (len(gv), len(gt)) == (len(v), len(t)), f"{case} ng {ng} level {l} box {b}: counts differ"
+            assert np.array_equal(gk, k) and np.array_equal(gt, t), f"{case} ng {ng} level {l} box {b}: keys / connectivity differ"
+            assert np.array_equal(gv.view(np.int64), v.view(np.int64)), f"{case} ng {ng} level {l} box {b}: vertex data (coordinates from indices) not bit-identical"
+            ntri += len(t)
+    assert ntri > 50

@@ -131,11 +131,24 @@ int main(int argc, char** argv) {
       }
     }
     if (r == 0) tm.mark("upload");
-    for (int lev = 0; lev < Nlev; ++lev) {
-      if (r == 0) std::cout << "on level " << lev << std::endl;
-      ctx.check(pa_fill_boundary(ctx.h, din[lev]->h, 0, ncomp, ngs[lev]));
-      if (lev > 0) ctx.check(pa_fillpatch_two_levels(ctx.h, din[lev]->h, din[lev - 1]->h, 0, ncomp, ngs[lev], H.ref_ratio[lev - 1], interp_type == 1 ? 1 : 0));
-      ctx.check(pa_foextrap(ctx.h, din[lev]->h, 0, ncomp, ngs[lev]));
+    bool one_ratio = true;  // one ratio argument: hierarchies whose levels differ in ratio take the per-level calls
+    for (int lev = 1; lev < Nlev; ++lev) one_ratio = one_ratio && H.ref_ratio[lev - 1] == H.ref_ratio[0];
+    if (one_ratio) {  // filterPlt.cpp:159-203 for ALL levels: FillBoundary, FillPatchTwoLevels and foextrap, one launch each
+      std::vector<pa_mf*> hm;
+      std::vector<int32_t> hg;
+      for (int lev = 0; lev < Nlev; ++lev) {
+        if (r == 0) std::cout << "on level " << lev << std::endl;
+        hm.push_back(din[lev]->h);
+        hg.push_back(ngs[lev]);
+      }
+      ctx.check(pa_fill_ghosts_hierarchy(ctx.h, Nlev, hm.data(), 0, ncomp, hg.data(), Nlev > 1 ? H.ref_ratio[0] : 2, interp_type == 1 ? 1 : 0, 1));
+    } else {
+      for (int lev = 0; lev < Nlev; ++lev) {
+        if (r == 0) std::cout << "on level " << lev << std::endl;
+        ctx.check(pa_fill_boundary(ctx.h, din[lev]->h, 0, ncomp, ngs[lev]));
+        if (lev > 0) ctx.check(pa_fillpatch_two_levels(ctx.h, din[lev]->h, din[lev - 1]->h, 0, ncomp, ngs[lev], H.ref_ratio[lev - 1], interp_type == 1 ? 1 : 0));
+        ctx.check(pa_foextrap(ctx.h, din[lev]->h, 0, ncomp, ngs[lev]));
+      }
     }
     if (r == 0) {
       // which summation the library takes (ADVICE: say so in the output): the separable three-pass form differs from the

@@ -163,15 +163,25 @@ int main(int argc, char** argv) {
   std::vector<pa::Share> shares;
   std::vector<pa::HostMF> hloc(Nlev);
   double tq = now();
+  // Round 5: the state holds the plotfile components only.  The three coordinate components isosurface.cpp:1458-1478 stores,
+  // FillBoundaries and FillPatches are a function of the cell index and of which level covers the cell, so the vertex kernels form
+  // them in registers (pa_mc_hierarchy_xyz; same doubles), and the ghost cells of all levels are filled in two launches
+  // (pa_fill_ghosts_hierarchy).  Hierarchies whose levels differ in refinement ratio keep the stored-coordinate state and a call
+  // per level (xyz_state = false; PA_ISO_XYZ=0 forces it for A/B).
+  bool xyz_state = !(std::getenv("PA_ISO_XYZ") && !std::atoi(std::getenv("PA_ISO_XYZ")));
+  for (int lev = 1; lev + 1 < Nlev; ++lev) xyz_state = xyz_state && H.ref_ratio[lev] == H.ref_ratio[0];
+  const int nst = xyz_state ? nComp : nc, iso_st = xyz_state ? isoComp : 3 + isoComp;  // components of the state, index of the iso field in it
   for (int lev = 0; lev < Nlev; ++lev) {
     const auto& L = H.lev[lev];
     const int ng = nGrow[lev];
     tq = now();
     shares.emplace_back(L.boxes, owner[lev], r);
     dl.emplace_back(new pa::DevLevel(ctx, L.boxes, L.domain, is_per.data(), H.prob_lo, H.prob_hi, &owner[lev], r, team.n));
-    dst.emplace_back(new pa::DevMF(ctx, *dl.back(), nc, ng));
+    dst.emplace_back(new pa::DevMF(ctx, *dl.back(), nst, ng));
     if (team.n > 1) shares.back().gather(host[lev], hloc[lev]);
-    {
+    if (xyz_state) {
+      ctx.check(pa_mf_upload(ctx.h, dst.back()->h, (team.n > 1 ? hloc[lev] : host[lev]).data.data()));
+    } else {
       pa::DevMF dfield(ctx, *dl.back(), nComp, ng);
       ctx.check(pa_mf_upload(ctx.h, dfield.h, (team.n > 1 ? hloc[lev] : host[lev]).data.data()));
       ctx.check(pa_iso_coords_level(ctx.h, dst.back()->h, 0));
@@ -179,11 +189,27 @@ int main(int argc, char** argv) {
       ctx.check(pa_sync(ctx.h));
     }
     if (lead) t_up += now() - tq;
+    if (xyz_state) continue;
     tq = now();
     if (lead) std::cout << "FillPatching the grown structures at level " << lev << "..." << std::endl;
     ctx.check(pa_fill_boundary(ctx.h, dst[lev]->h, 0, nc, ng));
     if (lev > 0) ctx.check(pa_fillpatch_two_levels(ctx.h, dst[lev]->h, dst[lev - 1]->h, 0, nc, ng, H.ref_ratio[lev - 1], 0));  // PCInterp, the file's ratio (isosurface.cpp:1472,1518)
     if (lead) std::cout << "...done FillPatching the grown structures at level " << lev << "..." << std::endl;
+    ctx.check(pa_sync(ctx.h));
+    if (lead) t_fill += now() - tq;
+  }
+  if (xyz_state) {  // isosurface.cpp:1468-1524 for ALL levels: FillBoundary, then FillPatchTwoLevels with PCInterp, one launch each
+    tq = now();
+    std::vector<pa_mf*> hm;
+    std::vector<int32_t> hg;
+    for (int lev = 0; lev < Nlev; ++lev) {
+      if (lead) std::cout << "FillPatching the grown structures at level " << lev << "..." << std::endl;
+      hm.push_back(dst[lev]->h);
+      hg.push_back(nGrow[lev]);
+    }
+    ctx.check(pa_fill_ghosts_hierarchy(ctx.h, Nlev, hm.data(), 0, nComp, hg.data(), Nlev > 1 ? H.ref_ratio[0] : 2, 0, 0));
+    for (int lev = 0; lev < Nlev; ++lev)
+      if (lead) std::cout << "...done FillPatching the grown structures at level " << lev << "..." << std::endl;
     ctx.check(pa_sync(ctx.h));
     if (lead) t_fill += now() - tq;
   }
@@ -223,7 +249,10 @@ int main(int argc, char** argv) {
     }
     bool uniform = true;  // one ratio argument: levels with different ratios fall back to a call per level
     for (int lev = 0; lev + 1 < Nlev; ++lev) uniform = uniform && (!fmask[lev] || H.ref_ratio[lev] == ratio);
-    if (uniform) {
+    if (xyz_state) {
+      ctx.check(pa_mc_hierarchy_xyz(ctx.h, Nlev, sts.data(), fmask.data(), Nlev > 1 ? H.ref_ratio[0] : 2, lp.data(), iso_st, isoVal, pnv.data(), pnt.data(), dv_all.data(),
+                                    dk_all.data(), dt_all.data(), &mc_blocks[r]));
+    } else if (uniform) {
       ctx.check(pa_mc_hierarchy_fine(ctx.h, Nlev, sts.data(), fmask.data(), ratio, lp.data(), 3 + isoComp, isoVal, pnv.data(), pnt.data(), dv_all.data(), dk_all.data(),
                                      dt_all.data(), &mc_blocks[r]));
     } else {
@@ -257,7 +286,7 @@ int main(int argc, char** argv) {
         for (int d = 0; d < 3; ++d) { b6[6 * i + d] = L.boxes[i].lo[d]; b6[6 * i + 3 + d] = L.boxes[i].hi[d]; }
       lsoff.resize(L.boxes.size());
       lscs.resize(L.boxes.size());
-      pa_mf_layout((int)L.boxes.size(), b6.data(), nc, ng, lsoff.data(), lscs.data());
+      pa_mf_layout((int)L.boxes.size(), b6.data(), nst, ng, lsoff.data(), lscs.data());
     }
     pa::HostMF& hd = team.n > 1 ? hd_loc : (build_distance_function ? hdist[lev] : hd_loc);
     pa::HostMF& hsrc = team.n > 1 ? hloc[lev] : host[lev];  // the plotfile components of this rank's FABs
@@ -330,10 +359,10 @@ int main(int argc, char** argv) {
         const pa::Box3& B = L.boxes[b];
         pa_box vb;
         pa_fab fs, fd;
-        fs.p = base + lsoff[b]; fs.ncomp = nc; fs.nstride = lscs[b];
+        fs.p = base + lsoff[b]; fs.ncomp = nst; fs.nstride = lscs[b];
         fd.p = dbase + hd.off[b]; fd.ncomp = 1; fd.nstride = hd.cs[b];
         for (int d = 0; d < 3; ++d) { vb.lo[d] = fs.lo[d] = fd.lo[d] = B.lo[d] - ng; vb.hi[d] = fs.hi[d] = fd.hi[d] = B.hi[d] + ng; }
-        ctx.check(pa_sdf_signed_fab(ctx.h, vb, grids[q].phi, &fs, 3 + isoComp, isoVal, dmax, &fd, 0));
+        ctx.check(pa_sdf_signed_fab(ctx.h, vb, grids[q].phi, &fs, iso_st, isoVal, dmax, &fd, 0));
       }
       ctx.check(pa_mf_download(ctx.h, ddist->h, hd.data.data()));
       for (void* p : grid_bufs) pa_device_free(ctx.h, p);
