@@ -706,6 +706,8 @@ def main():
     ap.add_argument("--sim-of", type=int, default=0, help="diagnostic, 1 GPU: time rank 0's share of an N-rank strong-scaling run with no-op exchanges")
     ap.add_argument("--xdelay-us", type=float, default=-1.0, help="--sim-of: every exchange costs this many microseconds (+ bytes / --xlink-GBs) on the stream it is issued on "
                                                                   "(pa_ctx_set_delay_comm) instead of nothing: how much of an exchange the schedule hides")
+    ap.add_argument("--ab", type=str, default="", help="diagnostic: VAR=A,B -- alternate an environment switch the library reads per pass in blocks of --steps passes inside this "
+                                                        "process (8 blocks each), print the two medians and exit (works with --sim-of)")
     ap.add_argument("--xlink-GBs", type=float, default=0.0, help="--sim-of with --xdelay-us: per-peer link bandwidth of the delay model (xGMI: ~153 GB/s nominal); 0: fixed delay only")
     args = ap.parse_args()
 
@@ -773,12 +775,12 @@ def main():
         H = nested_hierarchy(args.base, args.nlev, args.box, is_per=per)
         owners = padist.shard(H, nshard) if nshard > 1 else [None] * args.nlev
     # internal re-tiling (what grad3d / curvature3d do with a plotfile's BoxArray): same cells, merged boxes -- results identical in
-    # every cell (tests/test_retile.py).  One GPU: the tools' limits (pa_hierarchy_retile_limits); sharded: 128^3 so that every
-    # rank keeps several boxes per level.  Weak-scaling copies stay as built (a copy per rank).
+    # every cell (tests/test_retile.py), with the tools' limits: pa_hierarchy_retile_limits on one GPU, ..._ranks when sharded (every
+    # rank keeps at least four boxes per level).  Weak-scaling copies stay as built (a copy per rank).
     Hfile = H
     if args.retile and not (args.scaling == "weak" and nshard > 1):
         from peleanalysis_amd.hierarchy import retile_hierarchy
-        H = retile_hierarchy(Hfile, None if nshard == 1 else (128, 128, 128))
+        H = retile_hierarchy(Hfile, nranks=nshard)
         owners = padist.shard(H, nshard) if nshard > 1 else [None] * args.nlev
     bc = capi.bc_from_flags(per)
     xch = {"mode": "none"}
@@ -872,6 +874,25 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    if args.ab:
+        import statistics
+        var, vals = args.ab.split("=")
+        va, vb = vals.split(",")
+        tm = {va: [], vb: []}
+        for blk in range(16):
+            v = (va, vb)[blk & 1]
+            os.environ[var] = v
+            step()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            barrier()
+            tm[v].append((time.perf_counter() - t0) / args.steps * 1e3)
+        if rank == 0:
+            print(json.dumps({"ab": var, "median_ms": {k: statistics.median(v) for k, v in tm.items()}, "blocks_ms": {k: [round(x, 4) for x in v] for k, v in tm.items()},
+                              "delta_ms_B_minus_A": statistics.median(tm[vb]) - statistics.median(tm[va])}))
+        return
     ctx.profile_read(1, reset=True)
     ctx.profile_enable(0 if args.no_profile else (1 << 1))  # timed region: HIP events around the dominant kernel only
     t0 = time.perf_counter()

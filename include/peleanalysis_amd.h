@@ -180,6 +180,9 @@ int pa_level_retile(int nboxes, const int32_t* boxes6, const int32_t max_size[3]
  * level l): 256 cells per direction where every level then consists of blocks at least 128 cells thick, else 128 (measured:
  * profiles/r05_retile.txt); PA_RETILE_MAX="x y z" in the environment overrides.  Host arithmetic only; 0 = OK. */
 int pa_hierarchy_retile_limits(int nlev, const int32_t* nboxes, const int32_t* const* boxes6, int min_thick, int32_t max_size[3]);
+/* the same for a hierarchy sharded over nranks ranks: the largest of 256^3 / 256 x 256 x 128 / 128^3 that leaves every level at least
+ * 4 nranks boxes (nranks <= 1: pa_hierarchy_retile_limits) */
+int pa_hierarchy_retile_limits_ranks(int nlev, const int32_t* nboxes, const int32_t* const* boxes6, int min_thick, int nranks, int32_t max_size[3]);
 void      pa_level_destroy(pa_level*);
 int       pa_level_nboxes(const pa_level*);
 

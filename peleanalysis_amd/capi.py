@@ -109,6 +109,7 @@ def load_library() -> C.CDLL:
         "pa_plan_restriction": (i64, [C.c_int, pi32, pi32, pi32, pi32, C.c_int, pi32, pi32, pi32, pi32, pi32, C.c_int, C.c_int, C.c_int, pi32, i64]),
         "pa_level_retile": (C.c_int, [C.c_int, pi32, pi32, C.c_int, pi32, C.c_int]),
         "pa_hierarchy_retile_limits": (C.c_int, [C.c_int, pi32, C.POINTER(pi32), C.c_int, pi32]),
+        "pa_hierarchy_retile_limits_ranks": (C.c_int, [C.c_int, pi32, C.POINTER(pi32), C.c_int, C.c_int, pi32]),
         "pa_level_destroy": (None, [vp]),
         "pa_level_nboxes": (C.c_int, [vp]),
         "pa_mf_layout": (i64, [C.c_int, pi32, C.c_int, C.c_int, C.POINTER(i64), C.POINTER(i64)]),

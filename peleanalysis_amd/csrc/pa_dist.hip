@@ -817,9 +817,7 @@ pa_mf* CsPlan::mf(pa_ctx* ctx, int ncomp, int slot) {
 #define PA_XB 8
 struct XRegArgs { DLevelView L; DMFView M; int comp, ncomp; const int* regs; const long long* coff; double* buf; int group = 0, gstride = 0; };
 #define PA_YMAX 65535
-__global__ __launch_bounds__(256) void k_xregions(LevBatch<XRegArgs, PA_XB> Bt, int unpack, int y0) {
-  unsigned ry;
-  const XRegArgs& X = Bt.a[Bt.find(blockIdx.y + (unsigned)y0, ry)];
+__device__ __forceinline__ void xregions_row(const XRegArgs& X, const unsigned ry, const int unpack) {
   const DLevelView& L = X.L;
   const DMFView& M = X.M;
   const int comp = X.comp, ncomp = X.ncomp;
@@ -842,12 +840,15 @@ __global__ __launch_bounds__(256) void k_xregions(LevBatch<XRegArgs, PA_XB> Bt, 
     }
   }
 }
+__global__ __launch_bounds__(256) void k_xregions(LevBatch<XRegArgs, PA_XB> Bt, int unpack, int y0) {
+  unsigned ry;
+  const XRegArgs& X = Bt.a[Bt.find(blockIdx.y + (unsigned)y0, ry)];
+  xregions_row(X, ry, unpack);
+}
 
 // same-rank part of a coarse-source refill: region pairs of equal shape, coarse level -> coarse-source level
 struct XCopyArgs { DLevelView LS; DMFView MS; int scomp; DLevelView LD; DMFView MD; int dcomp, ncomp; const int* sregs; const int* dregs; int group = 0, sgstride = 0, dgstride = 0; };
-__global__ __launch_bounds__(256) void k_xcopy(LevBatch<XCopyArgs, PA_XB> Bt, int y0) {
-  unsigned ry;
-  const XCopyArgs& X = Bt.a[Bt.find(blockIdx.y + (unsigned)y0, ry)];
+__device__ __forceinline__ void xcopy_row(const XCopyArgs& X, const unsigned ry) {
   const int* R = X.sregs + 7 * ry;
   const int* D = X.dregs + 7 * ry;
   const unsigned nx = R[4] - R[1] + 1, ny = R[5] - R[2] + 1, nz = R[6] - R[3] + 1, n = nx * ny * nz;
@@ -859,6 +860,29 @@ __global__ __launch_bounds__(256) void k_xcopy(LevBatch<XCopyArgs, PA_XB> Bt, in
       X.MD.data[X.MD.off[D[0]] + fab_index(BD, X.MD.ng, X.MD.ncomp, X.dcomp + dc, D[1] + (int)i, D[2] + (int)j, D[3] + (int)k)] =
           X.MS.data[X.MS.off[R[0]] + fab_index(BS, X.MS.ng, X.MS.ncomp, X.scomp + sc, R[1] + (int)i, R[2] + (int)j, R[3] + (int)k)];
     }
+  }
+}
+__global__ __launch_bounds__(256) void k_xcopy(LevBatch<XCopyArgs, PA_XB> Bt, int y0) {
+  unsigned ry;
+  const XCopyArgs& X = Bt.a[Bt.find(blockIdx.y + (unsigned)y0, ry)];
+  xcopy_row(X, ry);
+}
+// The producer side of an exchange in ONE launch (round 5): the pack of every send list AND the same-rank pieces of the
+// coarse-source refills -- both read valid cells of the source multifabs, one writes the send buffers, the other the
+// coarse-source multifab, nothing depends on anything.  Rows [0, npack) pack, the rest copy.  On a rank's share of an 8-way shard
+// the two launches were 27 + 24 us of a ~1 ms pass, twice per pass.
+#define PA_XC 3
+struct XProd { LevBatch<XRegArgs, PA_XB> pk; LevBatch<XCopyArgs, PA_XC> cp; };
+static_assert(sizeof(XProd) <= 4000, "kernel arguments are limited to 4 KB");
+__global__ __launch_bounds__(256) void k_xproduce(XProd P) {
+  const unsigned npack = (unsigned)P.pk.ycum[P.pk.n];
+  unsigned ry;
+  if (blockIdx.y < npack) {
+    const XRegArgs& X = P.pk.a[P.pk.find(blockIdx.y, ry)];
+    xregions_row(X, ry, 0);
+  } else {
+    const XCopyArgs& X = P.cp.a[P.cp.find(blockIdx.y - npack, ry)];
+    xcopy_row(X, ry);
   }
 }
 
@@ -928,8 +952,41 @@ int pa_xexchange(pa_ctx* ctx, int njobs, const XJob* jobs) {
       xf.push_back(x);
     }
   }
-  launch_regions(ctx, njobs, jobs, 0);
-  for (int q0 = 0; q0 < njobs; q0 += PA_XB) {  // same-rank pieces of coarse-source refills
+  bool produced = false;
+  {  // pack + same-rank copies in one launch when everything fits one batch (PA_XFUSE=0, read per call: two launches, A/B)
+    const char* fe = getenv("PA_XFUSE");
+    XProd P;
+    long long maxcells = 0;
+    int ncopyjobs = 0, npackjobs = 0;
+    bool fits = njobs <= PA_XB && !(fe && !atoi(fe));
+    for (int q = 0; q < njobs && fits; ++q) {
+      const XJob& J = jobs[q];
+      const XSide& S = J.plan->send;
+      const int nreg = (int)(S.regs7.size() / 7);
+      if (nreg) {
+        P.pk.a[P.pk.n] = XRegArgs{J.src->lev->view, J.src->view, J.scomp, J.ncomp, S.d_regs, S.d_coff, J.plan->sbuf, J.group, J.sgstride};
+        P.pk.ycum[P.pk.n + 1] = P.pk.ycum[P.pk.n] + nreg;
+        ++P.pk.n;
+        ++npackjobs;
+        maxcells = std::max(maxcells, S.maxcells);
+      }
+      if (J.plan->nlocal) {
+        if (P.cp.n >= PA_XC) { fits = false; break; }
+        P.cp.a[P.cp.n] = XCopyArgs{J.src->lev->view, J.src->view, J.scomp, J.dst->lev->view, J.dst->view, J.dcomp, J.ncomp, J.plan->d_lsrc, J.plan->d_ldst, J.group, J.sgstride, J.dgstride};
+        P.cp.ycum[P.cp.n + 1] = P.cp.ycum[P.cp.n] + J.plan->nlocal;
+        ++P.cp.n;
+        ++ncopyjobs;
+        maxcells = std::max(maxcells, J.plan->lmax);
+      }
+    }
+    const long long rows = fits ? (long long)P.pk.ycum[P.pk.n] + P.cp.ycum[P.cp.n] : 0;
+    if (fits && npackjobs && ncopyjobs && rows <= PA_YMAX) {
+      hipLaunchKernelGGL(k_xproduce, dim3((unsigned)std::min<long long>((maxcells + 255) / 256, 64), (unsigned)rows), dim3(256), 0, ctx->stream, P);
+      produced = true;
+    }
+  }
+  if (!produced) launch_regions(ctx, njobs, jobs, 0);
+  for (int q0 = 0; q0 < njobs && !produced; q0 += PA_XB) {  // same-rank pieces of coarse-source refills
     LevBatch<XCopyArgs, PA_XB> Bt;
     long long lmax = 0;
     for (int q = q0; q < njobs && q < q0 + PA_XB; ++q) {

@@ -861,6 +861,7 @@ __device__ __forceinline__ void fp_do_item(const DLevelView& L, const DMFView& M
       for (int n = 0; n < 27; ++n) {
         if (!((far >> n) & 1u)) continue;
         int p[3] = {qc[0] + n % 3 - 1, qc[1] + (n / 3) % 3 - 1, qc[2] + n / 9 - 1};
+#pragma unroll
         for (int d = 0; d < 3; ++d)
           if (!LC.is_per[d]) { p[d] = max(p[d], LC.domlo[d]); p[d] = min(p[d], LC.domhi[d]); }
         v[n] = crse_val(LC, MC, c + cshift, p[0], p[1], p[2], ok);
@@ -868,7 +869,8 @@ __device__ __forceinline__ void fp_do_item(const DLevelView& L, const DMFView& M
     }
     const double u0 = v[13];
     double sl[3];
-    for (int d = 0; d < 3; ++d) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {  // (unrolled: v[13 +- st] with a run-time st sends the 27 values through scratch memory)
       const int st = d == 0 ? 1 : (d == 1 ? 3 : 9);
       const double um = v[13 - st], up = v[13 + st];
       const double dc = 0.5 * (up - um);
@@ -895,6 +897,7 @@ __device__ __forceinline__ void fp_do_item(const DLevelView& L, const DMFView& M
       if (!((mask >> c8) & 1u)) continue;
       const int q[3] = {r * qc[0] + (c8 & 1), r * qc[1] + ((c8 >> 1) & 1), r * qc[2] + (c8 >> 2)};
       double acc = u0;
+#pragma unroll
       for (int d = 0; d < 3; ++d) {
         const double xoff = ((double)(q[d] - qc[d] * r) + 0.5) / (double)r - 0.5;
         acc += xoff * (sl[d] * alpha);
@@ -904,14 +907,14 @@ __device__ __forceinline__ void fp_do_item(const DLevelView& L, const DMFView& M
   }
 }
 
-__global__ __launch_bounds__(256, 4) void k_fp_do(DLevelView L, DMFView M, DLevelView LC, DMFView MC, int comp, int cshift, int ncomp, const int4* items, int n, int* nbad) {
+__global__ __launch_bounds__(256, 2) void k_fp_do(DLevelView L, DMFView M, DLevelView LC, DMFView MC, int comp, int cshift, int ncomp, const int4* items, int n, int* nbad) {
   fp_do_item(L, M, LC, MC, comp, cshift, ncomp, items, n, nbad, blockIdx.x * 256 + threadIdx.x);
 }
 // the level pairs of a hierarchy in ONE launch (pa_fill_ghosts_hierarchy): FillPatchTwoLevels reads VALID coarse cells only (through
 // the owner map; beyond a wall the nearest cell inside), so the pairs do not depend on each other
 struct FpdLev { DLevelView L; DMFView M; DLevelView LC; DMFView MC; int comp, cshift, ncomp; const int4* items; int n; };
 struct FpdBatch { int n; unsigned wg0[PA_MAXB + 1]; FpdLev a[PA_MAXB]; };
-__global__ __launch_bounds__(256, 4) void k_fp_do_levels(FpdBatch Bt, int* nbad) {
+__global__ __launch_bounds__(256, 2) void k_fp_do_levels(FpdBatch Bt, int* nbad) {
   int l = 0;
   while (l + 1 < Bt.n && blockIdx.x >= Bt.wg0[l + 1]) ++l;
   const int t = (int)(blockIdx.x - Bt.wg0[l]) * 256 + (int)threadIdx.x;

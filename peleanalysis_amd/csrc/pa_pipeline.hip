@@ -319,7 +319,11 @@ static int fused_passes_dist(pa_ctx* ctx, int nlev, pa_mf* const* state, int com
     // default 2 (round 4): with the delay-model transport (68 us per exchange: 50 us + 2.2 MB to the busiest peer at 120 GB/s) rank
     // 0 of 8 takes 1.140 ms per pass against 1.170 with one launch, with no-op exchanges 1.046 against 1.022: the split pays as soon
     // as an exchange costs more than ~25 us, which a grouped RCCL send / receive always does (profiles/r04_sim8_delay.txt)
-    const int dsb = dsbe ? atoi(dsbe) : 2;
+    // round 5: back to 1.  With the sweep's workgroup tables as per-XCD queues of tile chunks the ONE launch over all levels is
+    // balanced, and two launches pay two tails: alternating blocks inside one process (bench.py --sim-of 8 --ab
+    // PA_DIST_SWEEP_BATCH=2,1): 1.062 against 1.079 ms with 32-us exchanges, 0.997 against 1.030 with no-op exchanges
+    // (profiles/r05_sim8_delay.txt)
+    const int dsb = dsbe ? atoi(dsbe) : 1;
     if (dsb) {
       // 1 (default): one launch for all levels, exchange B exposed after it.  2: the finest level's sweep is a launch of its
       // own and exchange B -- which needs the normals of every level BUT the finest -- travels under it on the side stream

@@ -260,3 +260,29 @@ extern "C" int pa_hierarchy_retile_limits(int nlev, const int32_t* nboxes, const
   for (int d = 0; d < 3; ++d) max_size[d] = ok ? 256 : 128;
   return 0;
 }
+
+// ... for a hierarchy that is sharded over nranks ranks: every rank should keep at least four boxes per level (fewer, larger boxes
+// balance worse over the ranks and leave the sweep's per-XCD queues short: rank 0's share of the headline hierarchy, ms per pass
+// with 32-us exchanges, 256^3 / 256 x 256 x 128 / 128^3 boxes: 2 ranks 3.38 / 3.56 / 3.59, 4 ranks 2.21 / 1.94 / 2.00, 8 ranks
+// 1.31 / 1.16 / 1.06; profiles/r05_sim8_delay.txt).  The largest of those three tilings that leaves >= 4 nranks boxes on every
+// level, and 128^3 wherever the one-rank choice is 128^3.
+extern "C" int pa_hierarchy_retile_limits_ranks(int nlev, const int32_t* nboxes, const int32_t* const* boxes6, int min_thick, int nranks, int32_t max_size[3]) {
+  if (pa_hierarchy_retile_limits(nlev, nboxes, boxes6, min_thick, max_size) != 0) return -1;
+  if (nranks <= 1 || getenv("PA_RETILE_MAX") || max_size[0] <= 128) return 0;
+  const int32_t cand[3][3] = {{256, 256, 256}, {256, 256, 128}, {128, 128, 128}};
+  for (int c = 0; c < 3; ++c) {
+    bool ok = true;
+    for (int l = 0; l < nlev && ok; ++l) {
+      if (nboxes[l] <= 0) continue;
+      const int cap = 4 * nboxes[l] + 16;
+      std::vector<int32_t> out((size_t)cap * 6);
+      const int n = pa_level_retile(nboxes[l], boxes6[l], cand[c], min_thick, out.data(), cap);
+      ok = n >= 4 * nranks || c == 2;
+    }
+    if (ok) {
+      for (int d = 0; d < 3; ++d) max_size[d] = cand[c][d];
+      return 0;
+    }
+  }
+  return 0;
+}

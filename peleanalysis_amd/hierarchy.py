@@ -389,8 +389,8 @@ def regrid_copy(src: MultiFab, dst: MultiFab, scomp: int = 0, dcomp: int = 0, nc
             dv[(slice(dcomp, dcomp + nc),) + ds] = sv[(slice(scomp, scomp + nc),) + ss]
 
 
-def retile_hierarchy(H: Hierarchy, max_size=None, min_thick: int = 3) -> Hierarchy:
-    """every level re-tiled with the limits the tools use (pa_hierarchy_retile_limits) or with max_size"""
+def retile_hierarchy(H: Hierarchy, max_size=None, min_thick: int = 3, nranks: int = 1) -> Hierarchy:
+    """every level re-tiled with the limits the tools use (pa_hierarchy_retile_limits[_ranks]) or with max_size"""
     import ctypes as C
     from . import capi
     if max_size is None:
@@ -400,7 +400,7 @@ def retile_hierarchy(H: Hierarchy, max_size=None, min_thick: int = 3) -> Hierarc
         nb = (C.c_int32 * H.nlev)(*[lv.nboxes for lv in H.levels])
         ptrs = (pi32 * H.nlev)(*[b.ctypes.data_as(pi32) for b in bs])
         mx = (C.c_int32 * 3)()
-        if lib.pa_hierarchy_retile_limits(H.nlev, nb, ptrs, int(min_thick), mx) != 0:
+        if lib.pa_hierarchy_retile_limits_ranks(H.nlev, nb, ptrs, int(min_thick), int(nranks), mx) != 0:
             raise ValueError("pa_hierarchy_retile_limits: bad arguments")
         max_size = tuple(mx)
     return Hierarchy([retile_level(lv, max_size, min_thick) for lv in H.levels], H.ref_ratio)

@@ -616,7 +616,9 @@ inline std::vector<std::vector<Box3>> retile_levels(const std::vector<std::vecto
     ptr[l] = b6[l].data();
   }
   int32_t mx[3] = {max_cells, max_cells, max_cells};
-  if (max_cells <= 0 && pa_hierarchy_retile_limits(nlev, nb.data(), ptr.data(), 3, mx) != 0) return file_boxes;
+  int ngpus = 1;
+  pp.query("ngpus", ngpus);  // a hierarchy dealt to several GPUs keeps at least four boxes per level and rank
+  if (max_cells <= 0 && pa_hierarchy_retile_limits_ranks(nlev, nb.data(), ptr.data(), 3, std::max(ngpus, 1), mx) != 0) return file_boxes;
   std::vector<std::vector<Box3>> out(nlev);
   for (int l = 0; l < nlev; ++l) {
     const int cap = 4 * nb[l] + 16;
