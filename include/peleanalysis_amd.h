@@ -199,6 +199,10 @@ double* pa_mf_data(pa_mf*);
 int64_t pa_mf_size(const pa_mf*);
 int     pa_mf_upload(pa_ctx*, pa_mf*, const double* host);  /* synchronous */
 int     pa_mf_download(pa_ctx*, const pa_mf*, double* host); /* synchronous */
+/* components comp .. comp + ncomp - 1 only; host is laid out like the whole multifab (pa_mf_layout), its other components are not
+ * read / written (a tool's multifab that holds inputs AND outputs, grad.cpp:164: only the inputs go up, only the outputs come back) */
+int     pa_mf_upload_comps(pa_ctx*, pa_mf*, const double* host, int comp, int ncomp);   /* synchronous */
+int     pa_mf_download_comps(pa_ctx*, const pa_mf*, double* host, int comp, int ncomp); /* synchronous */
 int     pa_mf_setval(pa_ctx*, pa_mf*, int comp, int ncomp, double v); /* whole fabs incl. ghosts */
 /* MultiFab::Copy(dst, src, scomp, dcomp, ncomp, ng) -- same BoxArray */
 int     pa_mf_copy(pa_ctx*, const pa_mf* src, int scomp, pa_mf* dst, int dcomp, int ncomp, int ng);

@@ -119,6 +119,8 @@ def load_library() -> C.CDLL:
         "pa_mf_size": (i64, [vp]),
         "pa_mf_upload": (C.c_int, [vp, vp, vp]),
         "pa_mf_download": (C.c_int, [vp, vp, vp]),
+        "pa_mf_upload_comps": (C.c_int, [vp, vp, vp, C.c_int, C.c_int]),
+        "pa_mf_download_comps": (C.c_int, [vp, vp, vp, C.c_int, C.c_int]),
         "pa_mf_setval": (C.c_int, [vp, vp, C.c_int, C.c_int, dbl]),
         "pa_mf_copy": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int]),
         "pa_fill_boundary": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int]),

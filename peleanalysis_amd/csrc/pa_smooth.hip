@@ -304,6 +304,64 @@ __global__ __launch_bounds__(256) void k_smooth_dot(DLevelView L, DMFView A, DMF
   }
 }
 
+// Round 5: the Krylov vector passes fused with their reductions.  Every vector of the iteration is exactly 0.0 on the coarse cells
+// a finer level covers (the right-hand side is zeroed there once, k_smooth_zero_covered ends every operator application, and linear
+// combinations of zeros are zeros), so a product or a maximum over ALL valid cells equals the one over the uncovered cells bit for
+// bit (x + 0.0 = x) and the mask multifab need not be read.  Block partials: {sum0, sum1, max}.
+__device__ __forceinline__ void smooth_block_reduce(double s0, double s1, double m, double* part) {
+  for (int o = 32; o > 0; o >>= 1) {
+    s0 += __shfl_xor(s0, o);
+    s1 += __shfl_xor(s1, o);
+    const double m2 = __shfl_xor(m, o);
+    m = m2 > m ? m2 : m;
+  }
+  __shared__ double ss0[4], ss1[4], sm[4];
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { ss0[w] = s0; ss1[w] = s1; sm[w] = m; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int q = 1; q < 4; ++q) { s0 += ss0[q]; s1 += ss1[q]; m = sm[q] > m ? sm[q] : m; }
+    const long long slot = (long long)blockIdx.y * gridDim.x + blockIdx.x;
+    part[3 * slot] = s0;
+    part[3 * slot + 1] = s1;
+    part[3 * slot + 2] = m;
+  }
+}
+// sum0 = a . b, sum1 = c . d (hc = 0: not formed), max = max |a|
+__global__ __launch_bounds__(256) void k_smooth_dot2(DLevelView L, DMFView A, DMFView Bv, DMFView Cv, DMFView Dv, int hc, double* part) {
+  double s0 = 0.0, s1 = 0.0, m = 0.0;
+  {
+    PA_BOX_LOOP(L) {
+      int i, j, k;
+      it.cell(t, i, j, k);
+      const long long q = fab_index(it.B, A.ng, A.ncomp, 0, i, j, k);
+      const double va = A.data[A.off[b] + q];
+      s0 += va * Bv.data[Bv.off[b] + q];
+      if (hc) s1 += Cv.data[Cv.off[b] + q] * Dv.data[Dv.off[b] + q];
+      m = fabs(va) > m ? fabs(va) : m;
+    }
+  }
+  smooth_block_reduce(s0, s1, m, part);
+}
+// z = a x + bc y + c z (hz = 0: z is only written) and, of the NEW z: sum0 = z . w (hw = 0: not formed), max = max |z|
+__global__ __launch_bounds__(256) void k_smooth_lincomb_red(DLevelView L, double a, DMFView X, double bc, DMFView Y, double c, DMFView Z, int hz, DMFView W, int hw, double* part) {
+  double s0 = 0.0, m = 0.0;
+  {
+    PA_BOX_LOOP(L) {
+      int i, j, k;
+      it.cell(t, i, j, k);
+      const long long q = fab_index(it.B, Z.ng, Z.ncomp, 0, i, j, k);
+      double v = hz ? c * Z.data[Z.off[b] + q] : 0.0;
+      v += a * X.data[X.off[b] + q];
+      v += bc * Y.data[Y.off[b] + q];
+      Z.data[Z.off[b] + q] = v;
+      if (hw) s0 += v * W.data[W.off[b] + q];
+      m = fabs(v) > m ? fabs(v) : m;
+    }
+  }
+  smooth_block_reduce(s0, 0.0, m, part);
+}
+
 namespace {
 struct Vecs {  // one 1-comp ng-1 vector per level, owned
   std::vector<pa_mf*> v;
@@ -453,6 +511,76 @@ struct SmoothSolver {
     for (int l = 0; l + 1 < nlev; ++l) on_boxes(k_smooth_zero_covered, lev[l], box_grid(lev[l]), lev[l]->view, Y.v[l]->view, mask.v[l]->view);
     if (hipGetLastError() != hipSuccess) { pa_fail(ctx, "pa_smooth_solve: a kernel launch of the operator failed"); if (fail_local()) return 1; }
     return 0;
+  }
+  // ---- fused passes (round 5): one launch per level writes its block partials behind the previous level's, ONE read-back and one
+  // host sum in a fixed order for the hierarchy; red[0..1] sums, red[2] maximum of this rank
+  dim3 red_grid(const pa_level* L) const {
+    const long long cells = (long long)L->maxn[0] * L->maxn[1] * L->maxn[2];
+    return dim3((unsigned)std::min<long long>(std::max<long long>(cells / (256 * 32), 64), 1024), (unsigned)L->boxes.size());
+  }
+  template <class F>
+  int reduce_levels(F launch, double red[3]) {
+    size_t tot = 0;
+    std::vector<size_t> off((size_t)nlev, 0);
+    for (int l = 0; l < nlev; ++l) {
+      const dim3 g = red_grid(lev[l]);
+      off[(size_t)l] = tot;
+      tot += 3 * (size_t)g.x * g.y;
+    }
+    red[0] = red[1] = red[2] = 0.0;
+    if (!tot) return 0;
+    if (pa_ensure_red(ctx, tot)) return 1;
+    for (int l = 0; l < nlev; ++l) {
+      const dim3 g = red_grid(lev[l]);
+      if (g.y) launch(l, g, ctx->d_red + off[(size_t)l]);
+    }
+    PA_HIP(hipGetLastError());
+    hred.resize(tot);
+    PA_HIP(hipMemcpyAsync(hred.data(), ctx->d_red, tot * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    PA_HIP(hipStreamSynchronize(ctx->stream));
+    for (size_t q = 0; q + 2 < tot + 1 && q < tot; q += 3) { red[0] += hred[q]; red[1] += hred[q + 1]; red[2] = std::max(red[2], hred[q + 2]); }  // fixed order
+    return 0;
+  }
+  std::vector<double> hred;
+  // the ranks' parts of a reduction: nsum sums (red[0 .. nsum-1]) and, with_max, the maximum red[2]; the local error flag rides along
+  int share(double red[3], int nsum, bool with_max) {
+    if (!dist) return 0;
+    double e = 0.0;
+    if (nsum > 0) {
+      double v[3] = {lerr ? 0.0 : red[0], lerr ? 0.0 : red[1], lerr ? 1.0 : 0.0};
+      if (nsum == 1) v[1] = v[2];
+      ++nallreduce;
+      if (pa_allreduce(ctx, v, nsum + 1, 2)) return 1;
+      red[0] = v[0];
+      if (nsum == 2) red[1] = v[1];
+      e += v[nsum];
+    }
+    if (with_max) {
+      double v[2] = {lerr ? 0.0 : red[2], lerr ? 1.0 : 0.0};
+      ++nallreduce;
+      if (pa_allreduce(ctx, v, 2, 1)) return 1;
+      red[2] = v[0];
+      e += v[1];
+    }
+    if (e != 0.0) return lerr ? 1 : pa_fail(ctx, "pa_smooth_solve: another rank failed");
+    return 0;
+  }
+  // a . b (+ c . d) and max |a| in one pass
+  int fdot(Vecs& A, Vecs& B, Vecs* Cc, Vecs* Dd, double red[3], int nsum, bool with_max) {
+    if (reduce_levels([&](int l, dim3 g, double* part) {
+          hipLaunchKernelGGL(k_smooth_dot2, g, dim3(256), 0, ctx->stream, lev[l]->view, A.v[l]->view, B.v[l]->view, (Cc ? Cc : &A)->v[l]->view, (Dd ? Dd : &B)->v[l]->view, Cc ? 1 : 0, part);
+        }, red) && fail_local()) return 1;
+    return share(red, nsum, with_max);
+  }
+  // z = a x + b y + c z (c == 0: z is only written) with z . w (W non-null) and max |z| of the new z in the same pass
+  int flin(double a, Vecs& X, double b, Vecs& Y, double c, Vecs& Z, Vecs* W, double red[3], bool with_max) {
+    if (reduce_levels([&](int l, dim3 g, double* part) {
+          hipLaunchKernelGGL(k_smooth_lincomb_red, g, dim3(256), 0, ctx->stream, lev[l]->view, a, X.v[l]->view, b, Y.v[l]->view, c, Z.v[l]->view, c != 0.0 ? 1 : 0, (W ? W : &Z)->v[l]->view, W ? 1 : 0, part);
+        }, red) && fail_local()) return 1;
+    return share(red, W ? 1 : 0, with_max);
+  }
+  void zero_covered(Vecs& Y) {
+    for (int l = 0; l + 1 < nlev; ++l) on_boxes(k_smooth_zero_covered, lev[l], box_grid(lev[l]), lev[l]->view, Y.v[l]->view, mask.v[l]->view);
   }
   // this rank's part of a . b and of max |a| over the uncovered cells
   int ldot(Vecs& A, Vecs& B, double* d, double* amax) {
@@ -605,28 +733,51 @@ extern "C" int pa_smooth_solve(pa_ctx* ctx, int nlev, pa_mf* const* rhs, int rco
     S.on_boxes(k_smooth_copy, L, box_grid(L), L->view, rhs[l]->view, rcomp, S.rh.v[l]->view, 0);
   }
   PA_HIP(hipGetLastError());
-  double bnorm, dummy, rho = 1.0, alpha = 1.0, omega = 1.0;
-  if (S.dot(S.r, S.r, &dummy, &bnorm, 2)) return 1;
+  // r and r^ are zeroed on the covered coarse cells once: every vector of the iteration then stays exactly zero there (see the
+  // fused kernels above) and the reductions run over all valid cells without reading the mask
+  S.zero_covered(S.r);
+  S.zero_covered(S.rh);
+  PA_HIP(hipGetLastError());
+  double red[3], rho = 1.0, alpha = 1.0, omega = 1.0;
+  if (S.fdot(S.r, S.rh, nullptr, nullptr, red, 1, true)) return 1;  // rho_1 = r^ . r and ||b||_inf in one pass
+  const double bnorm = red[2];
+  double rho1 = red[0];
   int it = 0, status = -1;
   double rnorm = bnorm;
   if (bnorm == 0.0) status = 0;
+  // PA_SMOOTH_FUSED=0 (read per solve): round 4's form of the iteration -- one pass per vector operation and per reduction
+  // (6 reductions with a read-back per LEVEL each, 6 vector passes, 2 copies: 42.5 ms per iteration on the headline hierarchy)
+  const char* fe = getenv("PA_SMOOTH_FUSED");
+  const bool fused = !(fe && !atoi(fe));
+  double dummy;
   while (status != 0 && it < maxiter) {
     ++it;
-    double rho1;
-    if (S.dot(S.rh, S.r, &rho1, &dummy, 1)) return 1;
+    if (!fused && S.dot(S.rh, S.r, &rho1, &dummy, 1)) return 1;
     if (rho1 == 0.0) { status = -2; break; }
     const double beta = (rho1 / rho) * (alpha / omega);
-    S.axpbypcz(-omega * beta, &S.v, 0.0, nullptr, beta, S.p);  // p = r + beta (p - omega v)
-    S.axpbypcz(1.0, &S.r, 0.0, nullptr, 1.0, S.p);
+    if (fused) {
+      S.axpbypcz(1.0, &S.r, -omega * beta, &S.v, beta, S.p);  // p = r + beta (p - omega v), one pass
+    } else {
+      S.axpbypcz(-omega * beta, &S.v, 0.0, nullptr, beta, S.p);
+      S.axpbypcz(1.0, &S.r, 0.0, nullptr, 1.0, S.p);
+    }
     if (S.apply(S.p, S.v)) return 1;
     double rhv;
-    if (S.dot(S.rh, S.v, &rhv, &dummy, 1)) return 1;
+    if (fused) {
+      if (S.fdot(S.rh, S.v, nullptr, nullptr, red, 1, false)) return 1;
+      rhv = red[0];
+    } else if (S.dot(S.rh, S.v, &rhv, &dummy, 1)) return 1;
     if (rhv == 0.0) { status = -3; break; }
     alpha = rho1 / rhv;
-    S.copy(S.r, S.s);  // s = r - alpha v
-    S.axpbypcz(-alpha, &S.v, 0.0, nullptr, 1.0, S.s);
     double snorm;
-    if (S.dot(S.s, S.s, &dummy, &snorm, 2)) return 1;
+    if (fused) {
+      if (S.flin(1.0, S.r, -alpha, S.v, 0.0, S.s, nullptr, red, true)) return 1;  // s = r - alpha v and ||s||_inf
+      snorm = red[2];
+    } else {
+      S.copy(S.r, S.s);
+      S.axpbypcz(-alpha, &S.v, 0.0, nullptr, 1.0, S.s);
+      if (S.dot(S.s, S.s, &dummy, &snorm, 2)) return 1;
+    }
     if (snorm <= tol * bnorm) {
       S.axpbypcz(alpha, &S.p, 0.0, nullptr, 1.0, x);
       rnorm = snorm;
@@ -635,14 +786,24 @@ extern "C" int pa_smooth_solve(pa_ctx* ctx, int nlev, pa_mf* const* rhs, int rco
     }
     if (S.apply(S.s, S.t)) return 1;
     double ts, tt;
-    if (S.dot2(S.t, S.s, S.t, S.t, &ts, &tt)) return 1;
+    if (fused) {
+      if (S.fdot(S.t, S.s, &S.t, &S.t, red, 2, false)) return 1;  // t . s and t . t in one pass
+      ts = red[0]; tt = red[1];
+    } else if (S.dot2(S.t, S.s, S.t, S.t, &ts, &tt)) return 1;
     if (tt == 0.0) { status = -4; break; }
     omega = ts / tt;
     S.axpbypcz(alpha, &S.p, omega, &S.s, 1.0, x);  // x += alpha p + omega s
-    S.copy(S.s, S.r);                               // r = s - omega t
-    S.axpbypcz(-omega, &S.t, 0.0, nullptr, 1.0, S.r);
-    if (S.dot(S.r, S.r, &dummy, &rnorm, 2)) return 1;
-    rho = rho1;
+    if (fused) {
+      if (S.flin(1.0, S.s, -omega, S.t, 0.0, S.r, &S.rh, red, true)) return 1;  // r = s - omega t, ||r||_inf and the NEXT rho_1 = r^ . r
+      rnorm = red[2];
+      rho = rho1;
+      rho1 = red[0];
+    } else {
+      S.copy(S.s, S.r);
+      S.axpbypcz(-omega, &S.t, 0.0, nullptr, 1.0, S.r);
+      if (S.dot(S.r, S.r, &dummy, &rnorm, 2)) return 1;
+      rho = rho1;
+    }
     if (rnorm <= tol * bnorm) { status = 0; break; }
     if (omega == 0.0) { status = -5; break; }
   }

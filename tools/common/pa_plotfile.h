@@ -16,6 +16,9 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <functional>
+#include <condition_variable>
+#include <mutex>
 #include <memory>
 #include <regex>
 #include <sstream>
@@ -320,7 +323,7 @@ inline std::string g17(double v) {
 inline void write_plotfile(const std::string& path, const std::vector<std::string>& names, const std::vector<Box3>& domains,
                            const double prob_lo[3], const double prob_hi[3], std::vector<HostMF>& mf, double time,
                            const std::vector<int>& level_steps, int ref_ratio = 2, int dim = 3, const std::vector<int>* comps = nullptr,
-                           const std::vector<std::vector<Box3>>* file_boxes = nullptr) {
+                           const std::vector<std::vector<Box3>>* file_boxes = nullptr, const std::function<void(int)>* wait_level = nullptr) {
   // dim = 2: the levels are one plane of cells (k = 0) and the file is what a 2-D AMReX code writes; comps: the HostMF
   // component behind each name (default: 0, 1, 2, ...); file_boxes: the BoxArray the file gets on each level when the
   // multifabs live on ANOTHER tiling of the same cells (retile_levels below: the tools compute on merged boxes and write
@@ -369,6 +372,7 @@ inline void write_plotfile(const std::string& path, const std::vector<std::strin
   for (int l = 0; l < nlev; ++l) {
     const std::string dir = path + "/Level_" + std::to_string(l);
     ::mkdir(dir.c_str(), 0755);
+    if (wait_level) (*wait_level)(l);  // the level's data may still be on its way from the device (LevelGate below)
     HostMF& M = mf[l];
     const std::vector<Box3>& WB = wboxes(l);
     const size_t nb = WB.size();
@@ -593,6 +597,23 @@ inline std::vector<Box3> max_size(const std::vector<Box3>& in, int n) {
   }
   return out;
 }
+
+// Levels handed from the thread that downloads them to the thread that writes them: the writer starts on level l as soon as it is
+// on the host while the levels after it are still coming down (the plotfile write is 60-70 % of a tool's wall time and the
+// downloads 5-15 %: tools/tool_e2e.py).  done(l): level l (and every level before it) is complete; wait(l) blocks until then.
+struct LevelGate {
+  std::mutex m;
+  std::condition_variable cv;
+  int ready = 0;  // levels 0 .. ready-1 are complete
+  void done(int l) {
+    { std::lock_guard<std::mutex> g(m); ready = std::max(ready, l + 1); }
+    cv.notify_all();
+  }
+  void wait(int l) {
+    std::unique_lock<std::mutex> g(m);
+    cv.wait(g, [&] { return ready > l; });
+  }
+};
 
 // Internal re-tiling (pa_level_retile, include/peleanalysis_amd.h): the boxes the tools COMPUTE on for each level -- the file's
 // cells merged into the largest rectangles -- while their output keeps the file's BoxArray (write_plotfile's file_boxes).

@@ -154,6 +154,35 @@ int main(int argc, char** argv) {
   // (PA_SMOOTH_REPLICATED=1: every rank solves the whole hierarchy, bit-identical).  Downstream of the solve, curvature / normals are an
   // ill-conditioned function (n = G / |G|) of a field that is itself only fixed to ~1e-12 by the solver tolerance: the GPU
   // tests compare them with the oracle to 1e-5 of their scale, the smoothed field itself to 1e-12 (tests/test_gpu_smooth.py).
+  std::vector<std::string> nnames(inNames);
+  nnames.resize(nCompOut);
+  nnames[idProg] = "Progress";
+  nnames[idSmProg] = "SmoothedProgress";
+  nnames[idKm] = "MeanCurvature_" + progressName;
+  nnames[idN] = "FlameNormalX_" + progressName;
+  nnames[idN + 1] = "FlameNormalY_" + progressName;
+#if PA_SPACEDIM == 3
+  nnames[idN + 2] = "FlameNormalZ_" + progressName;
+  nnames[idKg] = "GaussianCurvature_" + progressName;
+#endif
+  if (do_strain) nnames[idSR] = "StrainRate_" + progressName;
+  if (getStrainTensor) {
+    const std::string dirChar[3] = {"x", "y", "z"};
+    for (int i = 0; i < PA_SPACEDIM * PA_SPACEDIM; ++i)
+      nnames[idROST + i] = "ROST_dU" + dirChar[i / PA_SPACEDIM] + "d" + dirChar[i % PA_SPACEDIM];  // curvature.cpp:815-823
+  }
+  if (do_velnormal) nnames[idVelNormal] = "VelFlameNormal";
+  // one GPU: the writer thread starts now and takes every level as soon as it is assembled and downloaded (pa::LevelGate); the later
+  // levels come down while the earlier ones are written
+  std::vector<int> isteps(Nlev, 0);
+  pa::LevelGate gate;
+  const std::function<void(int)> wait_level = [&](int l) { gate.wait(l); };
+  const bool overlap_write = team.n == 1;
+  std::thread writer;
+  if (overlap_write) {
+    std::cout << "Writing new data to " << outfile << "\n";
+    writer = std::thread([&] { pa::write_plotfile(outfile, nnames, doms, H.prob_lo, H.prob_hi, ostate, 0.0, isteps, 2, PA_SPACEDIM, nullptr, pa::boxes_if_retiled(fileBoxes, tile), &wait_level); });
+  }
   team.run([&](int r) {
     pa::Ctx& ctx = *team.ctx[r];
     std::vector<std::unique_ptr<pa::DevLevel>> dl;
@@ -243,29 +272,17 @@ int main(int argc, char** argv) {
         ctx.check(pa_mf_download(ctx.h, dfin.h, ostate[lev].data.data()));
       }
       if (r == 0 && verbose) std::cout << "Mean curvature has been computed on level " << lev << "\n";
+      if (overlap_write) gate.done(lev);
     }
   });
   tm.mark("assemble_download");
-  std::vector<std::string> nnames(inNames);
-  nnames.resize(nCompOut);
-  nnames[idProg] = "Progress";
-  nnames[idSmProg] = "SmoothedProgress";
-  nnames[idKm] = "MeanCurvature_" + progressName;
-  nnames[idN] = "FlameNormalX_" + progressName;
-  nnames[idN + 1] = "FlameNormalY_" + progressName;
-#if PA_SPACEDIM == 3
-  nnames[idN + 2] = "FlameNormalZ_" + progressName;
-  nnames[idKg] = "GaussianCurvature_" + progressName;
-#endif
-  if (do_strain) nnames[idSR] = "StrainRate_" + progressName;
-  if (getStrainTensor) {
-    const std::string dirChar[3] = {"x", "y", "z"};
-    for (int i = 0; i < PA_SPACEDIM * PA_SPACEDIM; ++i)
-      nnames[idROST + i] = "ROST_dU" + dirChar[i / PA_SPACEDIM] + "d" + dirChar[i % PA_SPACEDIM];  // curvature.cpp:815-823
+  if (overlap_write) {
+    writer.join();
+    tm.mark("write");
+    tm.report();
+    pa::Finish();
   }
-  if (do_velnormal) nnames[idVelNormal] = "VelFlameNormal";
   std::cout << "Writing new data to " << outfile << "\n";
-  std::vector<int> isteps(Nlev, 0);
   pa::write_plotfile(outfile, nnames, doms, H.prob_lo, H.prob_hi, ostate, 0.0, isteps, 2, PA_SPACEDIM, nullptr, pa::boxes_if_retiled(fileBoxes, tile));
   tm.mark("write");
   tm.report();

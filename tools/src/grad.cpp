@@ -85,35 +85,8 @@ int main(int argc, char** argv) {
   if (team.n > 1) std::cout << "Boxes distributed over " << team.n << " GPUs, transport: " << team.transport << std::endl;
   std::vector<std::vector<int32_t>> owner(Nlev);
   for (int lev = 0; lev < Nlev; ++lev) owner[lev] = pa::shard_boxes(tile[lev], team.n);  // DistributionMapping(ba), grad.cpp:162
-  team.run([&](int r) {  // one rank: its boxes of every level through the library's pipeline (cross-rank ghost fills inside)
-    pa::Ctx& ctx = *team.ctx[r];
-    std::vector<std::unique_ptr<pa::DevLevel>> dl;
-    std::vector<std::unique_ptr<pa::DevMF>> dmf;
-    std::vector<pa::Share> sh;
-    std::vector<pa::HostMF> loc(Nlev);
-    for (int lev = 0; lev < Nlev; ++lev) {
-      sh.emplace_back(tile[lev], owner[lev], r);
-      dl.emplace_back(new pa::DevLevel(ctx, tile[lev], H.lev[lev].domain, is_per.data(), H.prob_lo, H.prob_hi, &owner[lev], r, team.n));
-      dmf.emplace_back(new pa::DevMF(ctx, *dl.back(), nCompOut, 1));
-      pa::HostMF& src = team.n > 1 ? loc[lev] : state[lev];
-      if (team.n > 1) sh.back().gather(state[lev], loc[lev]);
-      ctx.check(pa_mf_upload(ctx.h, dmf.back()->h, src.data.data()));
-    }
-    if (r == 0) tm.mark("upload");
-    std::vector<pa_mf*> mfs;
-    for (auto& m : dmf) mfs.push_back(m->h);
-    ctx.check(pa_grad_run(ctx.h, Nlev, mfs.data(), 0, bc, mfs.data(), idGr));  // outputs into the same MultiFab, like grad.cpp
-    ctx.check(pa_sync(ctx.h));
-    if (pa_bc_errors(ctx.h) != 0) pa::Abort("coarse-fine boundary: fine grids are not properly nested in the coarse level");
-    if (r == 0) tm.mark("compute");
-    for (int lev = 0; lev < Nlev; ++lev) {
-      pa::HostMF& dst = team.n > 1 ? loc[lev] : state[lev];
-      ctx.check(pa_mf_download(ctx.h, dmf[lev]->h, dst.data.data()));
-      if (team.n > 1) sh[lev].scatter(loc[lev], state[lev]);
-    }
-  });
-  tm.mark("download");
-
+  // output names / components are known before the data: with one GPU the writer thread starts now and takes every level as soon
+  // as its download is done (pa::LevelGate), the later levels come down while the earlier ones are written
   std::vector<std::string> nnames(inNames);
   nnames.push_back(gradVar + "_gx");
   nnames.push_back(gradVar + "_gy");
@@ -127,8 +100,52 @@ int main(int argc, char** argv) {
   ocomps.push_back(idGr + 3);
   std::string outfile = pa::getFileRoot(infile) + "_gt";
   pp.query("outfile", outfile);
-  std::cout << "Writing new data to " << outfile << std::endl;
   std::vector<int> isteps(Nlev, 0);
+  pa::LevelGate gate;
+  const std::function<void(int)> wait_level = [&](int l) { gate.wait(l); };
+  const bool overlap_write = team.n == 1;
+  std::thread writer;
+  if (overlap_write) {
+    std::cout << "Writing new data to " << outfile << std::endl;
+    writer = std::thread([&] { pa::write_plotfile(outfile, nnames, doms, H.prob_lo, H.prob_hi, state, 0.0, isteps, 2, PA_SPACEDIM, &ocomps, pa::boxes_if_retiled(fileBoxes, tile), &wait_level); });
+  }
+  team.run([&](int r) {  // one rank: its boxes of every level through the library's pipeline (cross-rank ghost fills inside)
+    pa::Ctx& ctx = *team.ctx[r];
+    std::vector<std::unique_ptr<pa::DevLevel>> dl;
+    std::vector<std::unique_ptr<pa::DevMF>> dmf;
+    std::vector<pa::Share> sh;
+    std::vector<pa::HostMF> loc(Nlev);
+    for (int lev = 0; lev < Nlev; ++lev) {
+      sh.emplace_back(tile[lev], owner[lev], r);
+      dl.emplace_back(new pa::DevLevel(ctx, tile[lev], H.lev[lev].domain, is_per.data(), H.prob_lo, H.prob_hi, &owner[lev], r, team.n));
+      dmf.emplace_back(new pa::DevMF(ctx, *dl.back(), nCompOut, 1));
+      pa::HostMF& src = team.n > 1 ? loc[lev] : state[lev];
+      if (team.n > 1) sh.back().gather(state[lev], loc[lev]);
+      ctx.check(pa_mf_upload_comps(ctx.h, dmf.back()->h, src.data.data(), 0, nCompIn));  // the inputs only: the 4 output components are written on the device
+    }
+    if (r == 0) tm.mark("upload");
+    std::vector<pa_mf*> mfs;
+    for (auto& m : dmf) mfs.push_back(m->h);
+    ctx.check(pa_grad_run(ctx.h, Nlev, mfs.data(), 0, bc, mfs.data(), idGr));  // outputs into the same MultiFab, like grad.cpp
+    ctx.check(pa_sync(ctx.h));
+    if (pa_bc_errors(ctx.h) != 0) pa::Abort("coarse-fine boundary: fine grids are not properly nested in the coarse level");
+    if (r == 0) tm.mark("compute");
+    for (int lev = 0; lev < Nlev; ++lev) {
+      pa::HostMF& dst = team.n > 1 ? loc[lev] : state[lev];
+      ctx.check(pa_mf_download_comps(ctx.h, dmf[lev]->h, dst.data.data(), idGr, 4));  // the outputs only: the inputs are still on the host
+      if (team.n > 1) sh[lev].scatter(loc[lev], state[lev]);
+      if (overlap_write) gate.done(lev);
+    }
+  });
+  tm.mark("download");
+  if (overlap_write) {
+    writer.join();
+    tm.mark("write");
+    tm.report();
+    pa::Finish();
+  }
+
+  std::cout << "Writing new data to " << outfile << std::endl;
   pa::write_plotfile(outfile, nnames, doms, H.prob_lo, H.prob_hi, state, 0.0, isteps, 2, PA_SPACEDIM, &ocomps, pa::boxes_if_retiled(fileBoxes, tile));
   tm.mark("write");
   tm.report();
