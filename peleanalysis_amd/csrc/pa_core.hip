@@ -453,13 +453,23 @@ pa_level* pa_level_create_spec(pa_ctx* ctx, const LevelSpec& S, const int32_t do
   }
   {  // work table of the kernels that run one thread per ghost cell of a special face: faces differ in size by 16x on general
      // BoxArrays (32^2 .. 128^2 cells), a grid of (largest face / 256) x faces would be mostly empty workgroups
-    std::vector<int> wg;
+    std::vector<int> wg, pwg;
     for (size_t e = 0; e < L->sfaces.size(); ++e) {
       const int f = L->sfaces[e];
       const DBox& B = L->boxes[f / 6];
       const int d = (f % 6) >> 1, t0 = (d == 0) ? 1 : 0, t1 = (d == 2) ? 1 : 2;
       const long long nc = (long long)(B.hi[t0] - B.lo[t0] + 1) * (B.hi[t1] - B.lo[t1] + 1);
       for (int c = 0; c < (int)((nc + 255) / 256); ++c) { wg.push_back((int)e); wg.push_back(c); }
+      // perimeter cells of the face as faces_curv_cell enumerates them: two full rows, then the end columns of the rows between
+      const long long n0 = B.hi[t0] - B.lo[t0] + 1, n1 = B.hi[t1] - B.lo[t1] + 1, P = n1 >= 2 ? 2 * n0 + 2 * (n1 - 2) : n0;
+      for (int c = 0; c < (int)((P + 255) / 256); ++c) { pwg.push_back((int)e); pwg.push_back(c); }
+    }
+    L->npfwg = (int)(pwg.size() / 2);
+    if (L->npfwg > 0 && (hipMalloc(&L->d_pfwg, sizeof(int) * pwg.size()) != hipSuccess ||
+                         hipMemcpy(L->d_pfwg, pwg.data(), sizeof(int) * pwg.size(), hipMemcpyHostToDevice) != hipSuccess)) {
+      pa_fail(ctx, "pa_level_create: device allocation failed");
+      delete L;
+      return nullptr;
     }
     std::vector<int> sfb;
     for (int f : L->sfaces)
@@ -552,6 +562,7 @@ extern "C" void pa_level_destroy(pa_level* L) {
   if (L->d_owner) (void)hipFree(L->d_owner);
   if (L->d_irr) (void)hipFree(L->d_irr);
   if (L->d_sfwg) (void)hipFree(L->d_sfwg);
+  if (L->d_pfwg) (void)hipFree(L->d_pfwg);
   if (L->d_blist) (void)hipFree(L->d_blist);
   if (L->d_sfboxes) (void)hipFree(L->d_sfboxes);
   delete L;

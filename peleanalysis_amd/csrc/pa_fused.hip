@@ -102,6 +102,7 @@ struct FixArgs {
   int use_cp = 0;  // the level's coarse patches hold the coarse normal component of each face's direction (k_cpatch ran)
   long long cg_stride = 0, cp_stride = 0;  // component slots (blockIdx.z): doubles between the slots' sets of compact arrays / coarse patches
   const int2* wg = nullptr; int nwg = 0;   // the level's work table {special face, chunk of 256 face cells} (pa_level::d_sfwg)
+  const int2* pwg = nullptr; int npwg = 0; // ... {special face, chunk of 256 perimeter cells} (pa_level::d_pfwg)
 };
 // workgroup -> (batch level, special face, first face cell) through the levels' work tables
 template <typename BT>
@@ -283,6 +284,18 @@ __global__ __launch_bounds__(256, PA_FC_WAVES) void k_faces_curv(LevBatch<FixArg
   unsigned fy;
   const int perim = Bt.a[Bt.find(blockIdx.y, fy)].A.perim_only;
   faces_curv_cell<CG, PATCH, CGCLIP>(Bt, blockIdx.y, blockIdx.x * (long long)blockDim.x + threadIdx.x, perim, nbad, sk, (int)blockIdx.z);
+}
+// The perimeter cells through the levels' perimeter work tables (round 5): the grid of k_faces_curv is (longest perimeter of the
+// batch / 256) x faces -- on a hierarchy whose faces differ in size (a 256^2 wall face next to the 32^2 .. 128^2 faces of a flame
+// sheet) most workgroups find nothing to do: 333 -> 595 us when level 0 was re-tiled to 256^3 boxes.  One layer only.
+template <bool CG, bool PATCH = false, bool CGCLIP = false>
+__global__ __launch_bounds__(256, PA_FC_WAVES) void k_faces_curv_tab(LevBatch<FixArgs> Bt, int* nbad, SlotK sk = SlotK()) {
+  unsigned w = blockIdx.x;
+  int blev = 0;
+  while (blev + 1 < Bt.n && w >= (unsigned)Bt.a[blev].npwg) { w -= (unsigned)Bt.a[blev].npwg; ++blev; }
+  if (w >= (unsigned)Bt.a[blev].npwg) return;
+  const int2 it = Bt.a[blev].pwg[w];
+  faces_curv_cell<CG, PATCH, CGCLIP>(Bt, (unsigned)Bt.ycum[blev] + (unsigned)it.x, (long long)it.y * 256 + threadIdx.x, 1, nbad, sk, (int)blockIdx.z);
 }
 // the cells of SlowList through the general path (any cell of a face, one layer)
 template <bool PATCH>
@@ -1687,7 +1700,7 @@ int pa_gradcurv_fix_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, 
       for (int d = 0; d < 3; ++d) A.bc[d] = bc[d];
       A.ratio = 2; A.has_crse = crse_n[l] ? 1 : 0; A.thr = clip ? thr : -1.0; A.layers = 1; A.perim_only = 1; A.pmin = pmin; A.invd = 1.0 / (pmax - pmin);
       Bt.a[Bt.n] = FixArgs{L->view, phi[l]->view, pcomp, crse_n[l] ? crse_n[l]->lev->view : L->view, crse_n[l] ? crse_n[l]->view : phi[l]->view, cncomp0,
-                           out[l]->view, ncomp0, kcomp, A, (use_cp && crse_n[l] && L->cp_total > 0) ? 1 : 0, cg_stride(L), cp_stride(L), (const int2*)L->d_sfwg, L->nsfwg};
+                           out[l]->view, ncomp0, kcomp, A, (use_cp && crse_n[l] && L->cp_total > 0) ? 1 : 0, cg_stride(L), cp_stride(L), (const int2*)L->d_sfwg, L->nsfwg, (const int2*)L->d_pfwg, L->npfwg};
       Bt.ycum[Bt.n + 1] = Bt.ycum[Bt.n] + (int)L->sfaces.size();
       ++Bt.n;
       const long long n0 = L->maxn[0], n1 = L->maxn[1], n2 = L->maxn[2];
@@ -1747,7 +1760,17 @@ int pa_gradcurv_fix_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, 
       else hipLaunchKernelGGL((k_faces_curv_fast<1, false>), gfast, dim3(256), 0, ctx->stream, Bt, ctx->d_flags, SlowList(), sk);
     }
     const dim3 gper((unsigned)((nper + 255) / 256), (unsigned)Bt.ycum[Bt.n], (unsigned)nslots);
-    if (clip) {
+    unsigned nptab = 0;  // perimeter work tables of every level of the batch (PA_FIX_PTAB=0, read per pass: the (perimeter, face) grid)
+    bool ptab = !(getenv("PA_FIX_PTAB") && !atoi(getenv("PA_FIX_PTAB")));
+    for (int q = 0; q < Bt.n; ++q) { ptab = ptab && Bt.a[q].pwg && Bt.a[q].npwg > 0; nptab += (unsigned)Bt.a[q].npwg; }
+    const dim3 gtab(nptab, 1, (unsigned)nslots);
+    if (ptab) {
+      if (clip) {
+        if (all_patch) hipLaunchKernelGGL((k_faces_curv_tab<true, true, true>), gtab, dim3(256), 0, pst, Bt, ctx->d_flags, sk);
+        else hipLaunchKernelGGL((k_faces_curv_tab<true, false, true>), gtab, dim3(256), 0, pst, Bt, ctx->d_flags, sk);
+      } else if (all_patch) hipLaunchKernelGGL((k_faces_curv_tab<true, true>), gtab, dim3(256), 0, pst, Bt, ctx->d_flags, sk);
+      else hipLaunchKernelGGL((k_faces_curv_tab<true, false>), gtab, dim3(256), 0, pst, Bt, ctx->d_flags, sk);
+    } else if (clip) {
       if (all_patch) hipLaunchKernelGGL((k_faces_curv<true, true, true>), gper, dim3(256), 0, pst, Bt, ctx->d_flags, sk);
       else hipLaunchKernelGGL((k_faces_curv<true, false, true>), gper, dim3(256), 0, pst, Bt, ctx->d_flags, sk);
     } else if (all_patch) hipLaunchKernelGGL((k_faces_curv<true, true>), gper, dim3(256), 0, pst, Bt, ctx->d_flags, sk);

@@ -174,6 +174,8 @@ struct pa_level {
   int nsfboxes = 0;
   void* d_sfwg = nullptr;   // int2 {special face, chunk of 256 of its ghost cells}: the work table of the per-face-cell kernels
   int nsfwg = 0;
+  void* d_pfwg = nullptr;   // int2 {special face, chunk of 256 of its PERIMETER cells}: the work table of k_faces_curv_tab (round 5)
+  int npfwg = 0;
   void* d_irr = nullptr;    // int4 {box, i, j, k}
   int nirr = -1;            // -1: not built yet
   int nremote = 0;          // boxes of this level owned by other ranks (pa_level_create_sharded)
