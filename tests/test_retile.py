@@ -238,3 +238,84 @@ def test_thin_boxes_pass_through_and_are_the_reason_for_min_thick(oracle):
     assert W.levels[1].nboxes == 1
     g2, _ = _oracle_all(oracle, W, _on_tiling(states, W, 2), per, sym, None)
     assert not bits_equal(g0[1], g2[1])
+
+
+def test_retile_limits_policy():
+    """pa_hierarchy_retile_limits[_ranks]: 256^3 where every level is made of blocks >= 128 cells thick, else 128^3; sharded: the
+    largest of 256^3 / 256 x 256 x 128 / 128^3 that leaves every level at least four boxes per rank"""
+    from peleanalysis_amd.hierarchy import nested_hierarchy, retile_hierarchy, tagged_hierarchy
+    H = nested_hierarchy(512, 3, 64)
+    assert [lv.nboxes for lv in retile_hierarchy(H).levels] == [8, 8, 8]
+    assert [lv.nboxes for lv in retile_hierarchy(H, nranks=2).levels] == [8, 8, 8]
+    assert [lv.nboxes for lv in retile_hierarchy(H, nranks=4).levels] == [16, 16, 16]
+    assert [lv.nboxes for lv in retile_hierarchy(H, nranks=8).levels] == [64, 64, 64]
+    for n in (1, 2, 4, 8):
+        for lv, tv in zip(H.levels, retile_hierarchy(H, nranks=n).levels):
+            assert tv.ncells == lv.ncells and (n == 1 or tv.nboxes >= 4 * n)
+    Hi = tagged_hierarchy(256, 3, lambda x, y, z: field_flame(x, y, z, 0), bf=16, max_box=128, base_box=128, frac=(0.08, 0.16), is_per=(1, 1, 0))
+    T = retile_hierarchy(Hi)  # a flame sheet of 32-cell blocks: 128^3 limits on every level
+    for lv, tv in zip(Hi.levels, T.levels):
+        n = tv.boxes[:, 3:] - tv.boxes[:, :3] + 1
+        assert tv.ncells == lv.ncells and n.max() <= 128
+        # x-runs are cut into whole 64-cell tiles + at most one remainder box of <= 32 cells
+        assert set(np.unique(n[:, 0] % 64)) <= {0, 32} and ((n[:, 0] % 64 == 0) | (n[:, 0] == 32)).all()
+
+
+@pytest.mark.gpu
+def test_upload_and_download_of_component_ranges(ctx):
+    """pa_mf_upload_comps / pa_mf_download_comps move the named components only (grad3d: inputs up, outputs down)"""
+    import ctypes as C
+    from peleanalysis_amd import capi
+    from peleanalysis_amd.hierarchy import nested_hierarchy
+    lv = nested_hierarchy(16, 1, 8).levels[0]
+    rng = np.random.default_rng(3)
+    host = MultiFab(lv, 5, 1)
+    host.data[:] = rng.random(host.total)
+    dl = capi.DevLevel(ctx, lv)
+    d = capi.DevMF(ctx, dl, 5, 1)
+    ctx.check(ctx.lib.pa_mf_setval(ctx.h, d.h, 0, 5, -7.0))
+    ctx.check(ctx.lib.pa_mf_upload_comps(ctx.h, d.h, host.data.ctypes.data_as(C.c_void_p), 1, 2))
+    got = d.download()
+    for b in range(lv.nboxes):
+        assert np.array_equal(got.fab(b)[1:3], host.fab(b)[1:3]) and (got.fab(b)[0] == -7.0).all() and (got.fab(b)[3:] == -7.0).all()
+    back = MultiFab(lv, 5, 1, fill=9.0)
+    ctx.check(ctx.lib.pa_mf_download_comps(ctx.h, d.h, back.data.ctypes.data_as(C.c_void_p), 2, 3))
+    for b in range(lv.nboxes):
+        assert np.array_equal(back.fab(b)[2], host.fab(b)[2]) and (back.fab(b)[3:] == -7.0).all() and (back.fab(b)[:2] == 9.0).all()
+    assert ctx.lib.pa_mf_upload_comps(ctx.h, d.h, host.data.ctypes.data_as(C.c_void_p), 4, 2) != 0  # component range
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("interp", [0, 1])
+def test_ghost_fill_of_a_hierarchy_equals_the_per_level_calls(ctx, seed, interp):
+    """pa_fill_ghosts_hierarchy (FillBoundary / FillPatchTwoLevels / foextrap of all levels, one launch each) against the sequence
+    filterPlt.cpp:159-203 makes per level, every ghost cell bit for bit; ghost widths 1 / 2 / 4 as filterPlt's levels"""
+    import ctypes as C
+    from peleanalysis_amd import capi
+    H, per, sym, fn = _draw_h(seed)
+    fields = make_states(H, 2, 0, fn, seed=seed + 9)
+    ngs = [1, 2, 4][:H.nlev]
+    dls = [capi.DevLevel(ctx, lv) for lv in H.levels]
+
+    def upload():
+        out = []
+        for l, (lv, dl) in enumerate(zip(H.levels, dls)):
+            m = MultiFab(lv, 2, ngs[l], fill=-666.0)
+            for b in range(lv.nboxes):
+                m.valid(b)[:] = fields[l].valid(b)
+            out.append(capi.DevMF.from_host(ctx, dl, m))
+        return out
+    a, b_ = upload(), upload()
+    for l in range(H.nlev):
+        ctx.check(ctx.lib.pa_fill_boundary(ctx.h, a[l].h, 0, 2, ngs[l]))
+        if l > 0:
+            ctx.check(ctx.lib.pa_fillpatch_two_levels(ctx.h, a[l].h, a[l - 1].h, 0, 2, ngs[l], 2, interp))
+        ctx.check(ctx.lib.pa_foextrap(ctx.h, a[l].h, 0, 2, ngs[l]))
+    hm = (C.c_void_p * H.nlev)(*[x.h for x in b_])
+    hg = (C.c_int32 * H.nlev)(*ngs)
+    ctx.check(ctx.lib.pa_fill_ghosts_hierarchy(ctx.h, H.nlev, hm, 0, 2, hg, 2, interp, 1))
+    ctx.sync()
+    nbad = ctx.bc_errors()  # improperly nested ghost shells (wide stencils on small random hierarchies) are counted by both paths alike
+    for l in range(H.nlev):
+        assert np.array_equal(a[l].download().data.view(np.int64), b_[l].download().data.view(np.int64)), f"seed {seed} interp {interp} level {l} (bad cells {nbad})"
