@@ -346,6 +346,12 @@ def test_isosurface_tool_end_to_end(tmp_path, oracle):
                           cwd=tmp_path, capture_output=True, text=True, env=dict(os.environ, PA_ISO_HOST_MERGE="1"))
     assert host.returncode == 0, host.stderr
     assert open(tmp_path / "hostmerge.mef", "rb").read() == open(p + "_temp_1150.mef", "rb").read()
+    # ... and so does the round-4 form of the state (three stored coordinate components, FillBoundary + FillPatch on them, a ghost fill
+    # per level: PA_ISO_XYZ=0); the default forms the coordinates from cell indices (pa_mc_hierarchy_xyz)
+    stored = subprocess.run([os.path.join(BIN, "isosurface3d.ex"), "infile=" + p, "isoCompName=temp", "isoVal=1150", "comps=0 2", "outfile_base=" + str(tmp_path / "stored")],
+                            cwd=tmp_path, capture_output=True, text=True, env=dict(os.environ, PA_ISO_XYZ="0"))
+    assert stored.returncode == 0, stored.stderr
+    assert open(tmp_path / "stored.mef", "rb").read() == open(p + "_temp_1150.mef", "rb").read()
     # single-level surface: closed and consistently oriented (the invariant checkIso.cpp is after, checked for real)
     (tmp_path / "one").mkdir()
     p1, H1, _ = _synth(tmp_path / "one", nlev=1, base=32, box=16, per=(0, 0, 0))
