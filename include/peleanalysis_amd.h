@@ -177,10 +177,10 @@ int64_t pa_plan_restriction(int nfine, const int32_t* fboxes6, const int32_t* fo
  * is too small for the result), -1 on bad arguments.  max_size NULL: 128 per direction. */
 int pa_level_retile(int nboxes, const int32_t* boxes6, const int32_t max_size[3], int min_thick, int32_t* out_boxes6, int cap);
 /* The max_size the tools and bench.py pass to pa_level_retile for the levels of one hierarchy (boxes6[l]: the nboxes[l] boxes of
- * level l): 256 cells per direction where every level then consists of blocks at least 128 cells thick, else 128 (measured:
+ * level l): 512 x 256 x 256 cells where every level then consists of blocks at least 128 cells thick, else 128^3 (measured:
  * profiles/r05_retile.txt); PA_RETILE_MAX="x y z" in the environment overrides.  Host arithmetic only; 0 = OK. */
 int pa_hierarchy_retile_limits(int nlev, const int32_t* nboxes, const int32_t* const* boxes6, int min_thick, int32_t max_size[3]);
-/* the same for a hierarchy sharded over nranks ranks: the largest of 256^3 / 256 x 256 x 128 / 128^3 that leaves every level at least
+/* the same for a hierarchy sharded over nranks ranks: the largest of 512 x 256 x 256 / 256^3 / 256 x 256 x 128 / 128^3 that leaves every level at least
  * 4 nranks boxes (nranks <= 1: pa_hierarchy_retile_limits) */
 int pa_hierarchy_retile_limits_ranks(int nlev, const int32_t* nboxes, const int32_t* const* boxes6, int min_thick, int nranks, int32_t max_size[3]);
 void      pa_level_destroy(pa_level*);

@@ -227,9 +227,11 @@ extern "C" int pa_level_retile(int nboxes, const int32_t* b6, const int32_t max_
 }
 
 // The limits the tools and bench.py hand to pa_level_retile for a whole hierarchy (measured, profiles/r05_retile.txt): boxes of
-// 256^3 where EVERY level then consists of blocks at least 128 cells thick (the nested, regular hierarchies: fewer ghost
-// shells and special faces, headline pass 6.4 -> 6.1 ms), otherwise 128^3 on all levels -- on a Pele-like BoxArray the large
-// faces of a few 256^3 boxes set the grid of the per-face kernels for all the small ones (7.1 against 7.3 ms).
+// 512 x 256 x 256 where EVERY level then consists of blocks at least 128 cells thick (the nested, regular hierarchies: fewer
+// ghost shells and special faces, and no box-box faces in x -- the direction whose ghost strips cost a 128-B line per 16 bytes --
+// across a 512-wide level: headline pass 6.4-6.5 ms on the file's 128^3 boxes, 6.14-6.34 on 256^3, 6.05-6.12 on 512 x 256 x 256,
+// 6.3 on one 512^3 box per level), otherwise 128^3 on all levels -- on a Pele-like BoxArray larger limits lose (6.93-7.0 ms
+// against 7.0-7.1 for 256^3 on the regular level only and 7.05-7.2 for 256^3 / 256 x 128 x 128 everywhere).
 // PA_RETILE_MAX="x y z" in the environment overrides.
 extern "C" int pa_hierarchy_retile_limits(int nlev, const int32_t* nboxes, const int32_t* const* boxes6, int min_thick, int32_t max_size[3]) {
   if (nlev <= 0 || !nboxes || !boxes6 || !max_size) return -1;
@@ -240,7 +242,7 @@ extern "C" int pa_hierarchy_retile_limits(int nlev, const int32_t* nboxes, const
       return 0;
     }
   }
-  const int32_t big[3] = {256, 256, 256};
+  const int32_t big[3] = {512, 256, 256};
   bool ok = true;
   for (int l = 0; l < nlev && ok; ++l) {
     if (nboxes[l] <= 0) continue;
@@ -257,27 +259,27 @@ extern "C" int pa_hierarchy_retile_limits(int nlev, const int32_t* nboxes, const
         if (!flat && ext < 128) ok = false;
       }
   }
-  for (int d = 0; d < 3; ++d) max_size[d] = ok ? 256 : 128;
+  for (int d = 0; d < 3; ++d) max_size[d] = ok ? big[d] : 128;
   return 0;
 }
 
 // ... for a hierarchy that is sharded over nranks ranks: every rank should keep at least four boxes per level (fewer, larger boxes
 // balance worse over the ranks and leave the sweep's per-XCD queues short: rank 0's share of the headline hierarchy, ms per pass
 // with 32-us exchanges, 256^3 / 256 x 256 x 128 / 128^3 boxes: 2 ranks 3.38 / 3.56 / 3.59, 4 ranks 2.21 / 1.94 / 2.00, 8 ranks
-// 1.31 / 1.16 / 1.06; profiles/r05_sim8_delay.txt).  The largest of those three tilings that leaves >= 4 nranks boxes on every
-// level, and 128^3 wherever the one-rank choice is 128^3.
+// 1.31 / 1.16 / 1.06; profiles/r05_sim8_delay.txt).  The largest of 512 x 256 x 256 and those three tilings that leaves >= 4 nranks
+// boxes on every level, and 128^3 wherever the one-rank choice is 128^3.
 extern "C" int pa_hierarchy_retile_limits_ranks(int nlev, const int32_t* nboxes, const int32_t* const* boxes6, int min_thick, int nranks, int32_t max_size[3]) {
   if (pa_hierarchy_retile_limits(nlev, nboxes, boxes6, min_thick, max_size) != 0) return -1;
   if (nranks <= 1 || getenv("PA_RETILE_MAX") || max_size[0] <= 128) return 0;
-  const int32_t cand[3][3] = {{256, 256, 256}, {256, 256, 128}, {128, 128, 128}};
-  for (int c = 0; c < 3; ++c) {
+  const int32_t cand[4][3] = {{512, 256, 256}, {256, 256, 256}, {256, 256, 128}, {128, 128, 128}};
+  for (int c = 0; c < 4; ++c) {
     bool ok = true;
     for (int l = 0; l < nlev && ok; ++l) {
       if (nboxes[l] <= 0) continue;
       const int cap = 4 * nboxes[l] + 16;
       std::vector<int32_t> out((size_t)cap * 6);
       const int n = pa_level_retile(nboxes[l], boxes6[l], cand[c], min_thick, out.data(), cap);
-      ok = n >= 4 * nranks || c == 2;
+      ok = n >= 4 * nranks || c == 3;
     }
     if (ok) {
       for (int d = 0; d < 3; ++d) max_size[d] = cand[c][d];

@@ -241,11 +241,11 @@ def test_thin_boxes_pass_through_and_are_the_reason_for_min_thick(oracle):
 
 
 def test_retile_limits_policy():
-    """pa_hierarchy_retile_limits[_ranks]: 256^3 where every level is made of blocks >= 128 cells thick, else 128^3; sharded: the
-    largest of 256^3 / 256 x 256 x 128 / 128^3 that leaves every level at least four boxes per rank"""
+    """pa_hierarchy_retile_limits[_ranks]: 512 x 256 x 256 where every level is made of blocks >= 128 cells thick, else 128^3;
+    sharded: the largest of 512 x 256 x 256 / 256^3 / 256 x 256 x 128 / 128^3 that leaves every level at least four boxes per rank"""
     from peleanalysis_amd.hierarchy import nested_hierarchy, retile_hierarchy, tagged_hierarchy
     H = nested_hierarchy(512, 3, 64)
-    assert [lv.nboxes for lv in retile_hierarchy(H).levels] == [8, 8, 8]
+    assert [lv.nboxes for lv in retile_hierarchy(H).levels] == [4, 4, 4]  # 512 x 256 x 256
     assert [lv.nboxes for lv in retile_hierarchy(H, nranks=2).levels] == [8, 8, 8]
     assert [lv.nboxes for lv in retile_hierarchy(H, nranks=4).levels] == [16, 16, 16]
     assert [lv.nboxes for lv in retile_hierarchy(H, nranks=8).levels] == [64, 64, 64]
