@@ -59,6 +59,33 @@ def test_cpp_template_tool_roundtrip(tmp_path):
     assert out.returncode != 0 and "infile" in out.stderr
 
 
+def test_cpp_template_tool_retiled_io_is_byte_identical(tmp_path):
+    """the host half of the tools' internal re-tiling without a GPU: template3d.ex retile=1 reads the file's FABs into merged boxes
+    (pa_level_retile; small limits through PA_RETILE_MAX so that merged boxes span several file boxes AND file boxes span several
+    merged ones) and writes the file's BoxArray back -- every byte, the per-FAB minima / maxima of Cell_H included, as retile=0"""
+    _build_tools()
+    p, H, mfs = _synth(tmp_path, nlev=3, base=32, box=8)
+    ref = None
+    for name, args, env in (("file", [], None), ("default", ["retile=1"], None), ("small", ["retile=1"], {"PA_RETILE_MAX": "24 12 16"}),
+                            ("tiny", ["retile=1"], {"PA_RETILE_MAX": "5 7 3"})):
+        d = tmp_path / name
+        d.mkdir()
+        out = subprocess.run([os.path.join(BIN, "template3d.ex"), "infile=" + p, "is_per=1 1 0"] + args, cwd=d, capture_output=True, text=True,
+                             env=None if env is None else dict(os.environ, **env))
+        assert out.returncode == 0, out.stderr
+        got = {}
+        for root, _, files in os.walk(d / "plt00005_temp"):
+            for f in files:
+                got[os.path.relpath(os.path.join(root, f), d)] = open(os.path.join(root, f), "rb").read()
+        assert len(got) >= 7
+        if ref is None:
+            ref = got
+        else:
+            assert got.keys() == ref.keys()
+            for k in ref:
+                assert got[k] == ref[k], f"template3d {name}: {k} differs"
+
+
 def test_cpp_mef_to_dat_tool(tmp_path):
     """surfMEFtoDAT3d.ex (host only): the MEF layout written by the python writer is what the consumer parses"""
     _build_tools()
