@@ -25,14 +25,14 @@ struct GradMarchArgs {
 };
 
 template <typename BP, int TY>
-__global__ __launch_bounds__(64 * (TY + 3)) void k_grad_march(BP bp, GradMarchArgs A) {
+__device__ __forceinline__ void grad_march_body(const BP& bp, const GradMarchArgs& A, const unsigned bid_in) {
   FabView P, O;
   DBox V;
   double dxinv[3];
   constexpr int ROWS = TY + 2;
   static_assert(2 * ROWS <= 64, "the edge wavefront serves two columns of every row");
   // XCD-aware order (MarchArgs order 2): block 8*T*g + 8*t + q works on tile t of box 8*g + q
-  unsigned bid = blockIdx.x;
+  unsigned bid = bid_in;
   int box;
   if (A.wgtab) {
     box = A.wgtab[2 * bid];
@@ -191,6 +191,25 @@ __global__ __launch_bounds__(64 * (TY + 3)) void k_grad_march(BP bp, GradMarchAr
     PA_GRUN3(step)
   }
 #undef PA_GRUN3
+}
+template <typename BP, int TY>
+__global__ __launch_bounds__(64 * (TY + 3)) void k_grad_march(BP bp, GradMarchArgs A) {
+  grad_march_body<BP, TY>(bp, A, blockIdx.x);
+}
+// the gradient sweeps of several levels in ONE launch (round 5; as k_gradcurv_march3_levels: the levels of grad.cpp:215-236 do not
+// depend on each other once their ghost cells are filled, and a level of a few boxes is 1-2 rounds of workgroups whose launch ends in
+// an idle tail): level l owns workgroups wg0[l] .. wg0[l+1]-1, each range a multiple of 8 (XCD numbering)
+struct GradBatch {
+  int n;
+  unsigned wg0[PA_MAXB + 1];
+  LevelBP2 bp[PA_MAXB];
+  GradMarchArgs A[PA_MAXB];
+};
+template <int TY>
+__global__ __launch_bounds__(64 * (TY + 3)) void k_grad_march_levels(GradBatch S) {
+  int l = 0;
+  while (l + 1 < S.n && blockIdx.x >= S.wg0[l + 1]) ++l;
+  grad_march_body<LevelBP2, TY>(S.bp[l], S.A[l], blockIdx.x - S.wg0[l]);
 }
 
 // Boxes at most 32 cells wide (AMReX's default max_grid_size in 3-D): the same sweep with TWO rows of 32 columns per

@@ -14,6 +14,7 @@ int pa_fill_boundary_impl(pa_ctx* ctx, pa_mf* M, int comp, int ncomp, int ng, in
 // exact-normal pipeline (pa_fused.hip)
 bool pa_fused2_level_ok(const pa_level* L);
 int pa_fill_boundary_local_batch(pa_ctx* ctx, int n, pa_mf* const* Ms, int comp, int ncomp, int ng);
+int pa_grad_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int comp, pa_mf* const* out, int ocomp);
 int pa_gradcurv_prep_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int comp, const pa_mf* const* crse, int ccomp, const int32_t bc[3], double pmin, double pmax, int phase = 3,
                             int nslots = 1, const double* prog = nullptr);
 int pa_gradcurv_level_cg(pa_ctx* ctx, const pa_mf* phi, int pcomp, double pmin, double pmax, pa_mf* out, int ocomp, double thr = -1.0, int slot = 0);
@@ -110,6 +111,14 @@ extern "C" int pa_grad_run(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp,
       PA_TRY(pa_fill_boundary_local_batch(ctx, nlev, state, comp, 1, 1));  // every level in one launch
     }
     if (bc_done) PA_HIP(hipStreamWaitEvent(ctx->stream, ctx->sync_evs[1], 0));
+  }
+  if (bc_done) {  // every level's ghost cells are final: the sweeps of all levels in one launch where the levels allow it
+    for (int l = 0; l < nlev; ++l) {
+      if (state[l]->lev != out[l]->lev) return pa_fail(ctx, "pa_grad_run: state and out live on different levels");
+      if (ocomp < 0 || ocomp + 4 > out[l]->ncomp) return pa_fail(ctx, "pa_grad_run: component range");
+    }
+    const int rc = pa_grad_levels(ctx, nlev, state, comp, out, ocomp);
+    if (rc >= 0) return rc;
   }
   for (int l = 0; l < nlev; ++l) {
     if (!bc_done) PA_TRY(pa_apply_bc(ctx, state[l], comp, l > 0 ? state[l - 1] : nullptr, comp, bc, 2, -1));
