@@ -27,6 +27,9 @@ for name in ("amr3_wall_z", "amr2_allwalls_ragged", "amr3_sym_x"):
     oc = [MultiFab(lv, 18, 0) for lv in H.levels]
     oracle.curvature_pipeline(H.levels, [s.copy() for s in states], 0, bc, oc, 0, MultiFab, threshold=0.05, do_gauss=True, vel_comp=1, do_strain=True,
                               do_velnormal=True, strain_tensor=True)
+    # the fused single-sweep CPU variant (bench.py cpu_baseline "fused": orc_gradcurv_fused + orc_curv_first_layer)
+    oracle.gradcurv_fused_pipeline(H.levels, [s.copy() for s in states], 0, bc, [MultiFab(lv, 4, 0) for lv in H.levels], [MultiFab(lv, 3, 1) for lv in H.levels],
+                                   [MultiFab(lv, 1, 0) for lv in H.levels], MultiFab, 300.0, 2003.0)
     ins = [MultiFab(lv, 2, 4, fill=0.0) for lv in H.levels]
     for l, lv in enumerate(H.levels):
         for b in range(lv.nboxes):
@@ -84,6 +87,16 @@ def test_tool_host_paths_under_sanitizers(tmp_path):
     back = read_plotfile(str(tmp_path / "plt00001_temp"))
     for l in range(3):
         assert np.array_equal(back.mfs[l].data.view(np.int64), mfs[l].data.view(np.int64))
+    # the re-tiled form of the same round trip: file FABs into merged boxes (read_comp), file boxes gathered back (write_plotfile),
+    # with limits that make merged boxes span file boxes and file boxes span merged ones (the re-tiler itself runs in the GPU
+    # library's host code, outside the sanitized objects; its index arithmetic is exercised through what the tool does with its answer)
+    for mx in ("24 12 16", "5 7 3"):
+        out = subprocess.run([os.path.join(bin_asan, "template3d.ex"), "infile=" + p, "is_per=1 1 0", "retile=1"], cwd=tmp_path, capture_output=True, text=True,
+                             env=dict(env, PA_RETILE_MAX=mx))
+        assert out.returncode == 0, out.stderr[-3000:]
+        back = read_plotfile(str(tmp_path / "plt00001_temp"))
+        for l in range(3):
+            assert np.array_equal(back.mfs[l].data.view(np.int64), mfs[l].data.view(np.int64))
     nodes = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]], float)
     faces = np.array([[1, 3, 2], [1, 2, 4], [2, 3, 4], [3, 1, 4]], np.int32)
     f = str(tmp_path / "tet.mef")
