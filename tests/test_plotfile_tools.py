@@ -1007,6 +1007,29 @@ def test_tools_retiled_outputs_are_byte_identical(tmp_path, tool, args, suffix):
 @pytest.mark.gpu
 @pytest.mark.parametrize("tool,args,suffix", [
     ("grad3d.ex", ["gradVar=temp", "is_per=1 1 0"], "_gt"),
+    ("curvature3d.ex", ["progressName=temp", "is_per=1 1 0"], "_K"),
+    ("filterPlt3d.ex", ["max_grid_size=8", "is_per=1 1 0"], "_filtered"),
+])
+def test_tools_run_again_over_their_own_output(tmp_path, tool, args, suffix):
+    """A tool run a second time in the same directory (AMReX: UtilCreateCleanDirectory moves the old plotfile away): the old
+    output directory is renamed and removed on a helper thread (pa::OldOutput) -- the second run's files must be the first
+    run's bytes, stale files of the old directory must be gone and no '.old.<pid>' directory may survive the process."""
+    p, H, mfs = _synth(tmp_path, nlev=3, base=16, box=8, ncomp=3)
+    d = tmp_path / "run"
+    d.mkdir()
+    _run(tool, ["infile=" + p] + args, d)
+    outdir = d / ("plt00005" + suffix)
+    first = _tree_bytes(str(outdir))
+    assert len(first) >= 5
+    (outdir / "stale_file_of_the_first_run").write_bytes(b"x" * 100)
+    _run(tool, ["infile=" + p] + args, d)
+    assert _tree_bytes(str(outdir)) == first
+    assert not [f for f in os.listdir(outdir.parent) if ".old." in f]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tool,args,suffix", [
+    ("grad3d.ex", ["gradVar=temp", "is_per=1 1 0"], "_gt"),
     ("curvature3d.ex", ["progressName=temp", "is_per=1 1 0", "fused=0"], "_K"),
     ("curvature3d.ex", ["progressName=temp", "is_per=1 1 0"], "_K"),
     ("filterPlt3d.ex", ["max_grid_size=8", "is_per=1 1 0"], "_filtered"),

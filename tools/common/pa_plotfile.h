@@ -6,6 +6,7 @@
 // a whole level goes to / from HBM with one pa_mf_upload / pa_mf_download.
 #pragma once
 #include <fcntl.h>
+#include <ftw.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -597,6 +598,25 @@ inline std::vector<Box3> max_size(const std::vector<Box3>& in, int n) {
   }
   return out;
 }
+
+// An output plotfile that already exists (a tool run again on the same input): AMReX's UtilCreateCleanDirectory moves the old
+// directory out of the way before WriteMultiLevelPlotfile creates the new one.  Here the old directory is renamed at once and
+// REMOVED on a helper thread while the tool reads and computes: writing over the old files made the kernel drop their cached pages
+// inside the timed write (16 GB at 3.7 GB/s against ~7 GB/s into a fresh directory, profiles/r04_small_experiments.txt) -- the
+// user-visible cost of re-running a tool.  finish() before the process exits.
+struct OldOutput {
+  std::thread th;
+  static int rm_entry(const char* p, const struct stat*, int, struct FTW*) { return ::remove(p); }
+  void move_away(const std::string& path) {
+    struct stat st;
+    if (::stat(path.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) return;
+    const std::string old = path + ".old." + std::to_string((long)::getpid());
+    if (::rename(path.c_str(), old.c_str()) != 0) return;  // left in place: the writer truncates the files as before
+    th = std::thread([old] { ::nftw(old.c_str(), rm_entry, 64, FTW_DEPTH | FTW_PHYS); });
+  }
+  void finish() { if (th.joinable()) th.join(); }
+  ~OldOutput() { finish(); }
+};
 
 // Levels handed from the thread that downloads them to the thread that writes them: the writer starts on level l as soon as it is
 // on the host while the levels after it are still coming down (the plotfile write is 60-70 % of a tool's wall time and the

@@ -38,6 +38,8 @@ int main(int argc, char** argv) {
   pp.get("infile", infile);
   std::string outfile = pa::getFileRoot(infile) + "_K";
   pp.query("outfile", outfile);
+  pa::OldOutput old_out;
+  old_out.move_away(outfile);  // an earlier run's output goes away while this one reads and computes
   pp.query("finestLevel", finestLevel);
   pp.query("do_gaussCurv", do_gaussCurv);
   pp.query("progressName", progressName);
@@ -279,12 +281,14 @@ int main(int argc, char** argv) {
   if (overlap_write) {
     writer.join();
     tm.mark("write");
+    old_out.finish();
     tm.report();
     pa::Finish();
   }
   std::cout << "Writing new data to " << outfile << "\n";
   pa::write_plotfile(outfile, nnames, doms, H.prob_lo, H.prob_hi, ostate, 0.0, isteps, 2, PA_SPACEDIM, nullptr, pa::boxes_if_retiled(fileBoxes, tile));
   tm.mark("write");
+  old_out.finish();
   tm.report();
   pa::Finish();
 }

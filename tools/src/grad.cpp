@@ -31,6 +31,10 @@ int main(int argc, char** argv) {
   pp.query("gradVar", gradVar);
   pp.query("finestLevel", finestLevel);
   pa::PhaseTimer tm(pp, PA_SPACEDIM == 2 ? "grad2d" : "grad3d");
+  std::string outfile = pa::getFileRoot(infile) + "_gt";
+  pp.query("outfile", outfile);
+  pa::OldOutput old_out;
+  old_out.move_away(outfile);  // an earlier run's output goes away while this one reads and computes
   pa::PlotfileHeader H = pa::read_header(infile, PA_SPACEDIM);
   finestLevel = std::min(finestLevel, H.nlev - 1);
   const int Nlev = finestLevel + 1;
@@ -98,8 +102,6 @@ int main(int argc, char** argv) {
 #endif
   nnames.push_back("||grad" + gradVar + "||");
   ocomps.push_back(idGr + 3);
-  std::string outfile = pa::getFileRoot(infile) + "_gt";
-  pp.query("outfile", outfile);
   std::vector<int> isteps(Nlev, 0);
   pa::LevelGate gate;
   const std::function<void(int)> wait_level = [&](int l) { gate.wait(l); };
@@ -141,6 +143,7 @@ int main(int argc, char** argv) {
   if (overlap_write) {
     writer.join();
     tm.mark("write");
+    old_out.finish();
     tm.report();
     pa::Finish();
   }
@@ -148,6 +151,7 @@ int main(int argc, char** argv) {
   std::cout << "Writing new data to " << outfile << std::endl;
   pa::write_plotfile(outfile, nnames, doms, H.prob_lo, H.prob_hi, state, 0.0, isteps, 2, PA_SPACEDIM, &ocomps, pa::boxes_if_retiled(fileBoxes, tile));
   tm.mark("write");
+  old_out.finish();
   tm.report();
   pa::Finish();
 }
