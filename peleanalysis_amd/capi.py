@@ -361,6 +361,10 @@ class DevMF:
         self.ctx.check(self.ctx.lib.pa_mf_download(self.ctx.h, self.h, mf.data.ctypes.data_as(C.c_void_p)))
         return mf
 
+    def setval(self, v: float, comp: int = 0, ncomp: Optional[int] = None):
+        """pa_mf_setval: components comp .. comp + ncomp - 1 (default: all) of every FAB, ghost cells included"""
+        self.ctx.check(self.ctx.lib.pa_mf_setval(self.ctx.h, self.h, int(comp), self.ncomp - int(comp) if ncomp is None else int(ncomp), float(v)))
+
     def fab(self, b: int) -> PaFab:
         """pa_fab for box b (device pointer into this multifab)."""
         lv = self.dlev.level

@@ -110,6 +110,136 @@ __global__ __launch_bounds__(256) void k_velnormal(BP3 bp, int ucomp, int ncomp0
   }
 }
 
+// The three options in ONE z-marching pass (pa_curvature_run's fast path): per cell the Hessian of c from G (ghost cells
+// resolved by the caller), grad u from the velocity (likewise), u . n from the stored normal; z-neighbours of the six
+// differentiated components ride in registers (one new plane per step), x / y neighbours come from the cache.  Same
+// operations in the same order as k_gauss_curv / k_strain / k_velnormal above (normgrad is formed again from G's centre value
+// with the expression of pa_normal_level: its sign drops out of normgrad^4).  c for the threshold = the Progress component of out.
+struct OptArgs {
+  DLevelView L;
+  DMFView G, U, O;
+  int ucomp, pc, nc, kgc, src, vnc, rostc;
+  double thr;
+};
+template <bool GAUSS, bool STRAIN, bool VELN>
+__global__ __launch_bounds__(256) void k_curvopts(OptArgs A) {
+  const int b = blockIdx.y;
+  if (b >= A.L.nboxes) return;
+  const DBox V = A.L.boxes[b];
+  int i, j, k0, k1;
+  if (!tile_cell(V, i, j, k0, k1)) return;
+  const FabView G = mf_view(A.G, V, b), U = mf_view(A.U, V, b), O = mf_view(A.O, V, b);
+  const double dx0 = A.L.dxinv[0], dx1 = A.L.dxinv[1], dx2 = A.L.dxinv[2];
+  const double thr = A.thr;
+  double gm[3] = {0, 0, 0}, gc[3] = {0, 0, 0}, um[3] = {0, 0, 0}, uc[3] = {0, 0, 0};
+  const long long gps = (long long)G.nx * G.ny, ups = (long long)U.nx * U.ny, ops = (long long)O.nx * O.ny;
+  const double* gp = GAUSS ? G.p + G.idx(i, j, k0, 0) : nullptr;
+  const double* up = (STRAIN || VELN) ? U.p + U.idx(i, j, k0, A.ucomp) : nullptr;
+  double* op = O.p + O.idx(i, j, k0, 0);
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    if (GAUSS) { gm[d] = gp[d * G.sc - gps]; gc[d] = gp[d * G.sc]; }
+    if (STRAIN) um[d] = up[d * U.sc - ups];
+    if (STRAIN || VELN) uc[d] = up[d * U.sc];
+  }
+  for (int k = k0; k <= k1; ++k) {
+    bool clip = false;
+    if (thr >= 0.0 && (GAUSS || VELN)) {
+      const double p = op[A.pc * O.sc];
+      clip = p < thr || p > 1.0 - thr;
+    }
+    if (GAUSS) {
+      double H[3][3];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        const double* q = gp + d * G.sc;
+        const double nxt = q[gps];
+        H[d][0] = cdiff(dx0, q[-1], gc[d], q[1]);
+        H[d][1] = cdiff(dx1, q[-G.nx], gc[d], q[G.nx]);
+        H[d][2] = cdiff(dx2, gm[d], gc[d], nxt);
+        gm[d] = nxt;  // holds plane k + 1 until the swap below
+      }
+#define HX(n) H[0][n]
+#define HY(n) H[1][n]
+#define HZ(n) H[2][n]
+      const double ax0 = HY(1) * HZ(2) - HZ(1) * HY(2);
+      const double ay0 = HY(2) * HZ(0) - HZ(2) * HY(0);
+      const double az0 = HY(0) * HZ(1) - HZ(0) * HY(1);
+      const double ax1 = HX(2) * HZ(1) - HZ(2) * HX(1);
+      const double ay1 = HX(0) * HZ(2) - HZ(0) * HX(2);
+      const double az1 = HX(1) * HZ(0) - HZ(1) * HX(0);
+      const double ax2 = HX(1) * HY(2) - HY(1) * HX(2);
+      const double ay2 = HX(2) * HY(0) - HY(2) * HX(0);
+      const double az2 = HX(0) * HY(1) - HY(0) * HX(1);
+#undef HX
+#undef HY
+#undef HZ
+      const double cx = gc[0], cy = gc[1], cz = gc[2];
+      const double sn = sqrt(cx * cx + cy * cy + cz * cz);
+      const double gn = (1e-14 < sn) ? sn : 1e-14;
+      double kg = (cx * (ax0 * cx + ax1 * cy + ax2 * cz) + cy * (ay0 * cx + ay1 * cy + ay2 * cz) + cz * (az0 * cx + az1 * cy + az2 * cz)) /
+                  ((gn * gn) * (gn * gn));
+      if (clip) kg = 0.0;
+      op[A.kgc * O.sc] = kg;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { const double t = gm[d]; gm[d] = gc[d]; gc[d] = t; }
+      gp += gps;
+    }
+    if (VELN) {
+      const double* n = op + A.nc * O.sc;
+      double v = +uc[0] * n[0] + uc[1] * n[O.sc] + uc[2] * n[2 * O.sc];
+      if (clip) v = 0.0;
+      op[A.vnc * O.sc] = v;
+    }
+    if (STRAIN) {
+      double gu[9];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        const double* q = up + d * U.sc;
+        const double nxt = q[ups];
+        gu[3 * d + 0] = cdiff(dx0, q[-1], uc[d], q[1]);
+        gu[3 * d + 1] = cdiff(dx1, q[-U.nx], uc[d], q[U.nx]);
+        gu[3 * d + 2] = cdiff(dx2, um[d], uc[d], nxt);
+        um[d] = uc[d];
+        uc[d] = nxt;
+      }
+      op[A.src * O.sc] = +gu[0] + gu[4] + gu[8];
+      if (A.rostc >= 0)
+#pragma unroll
+        for (int q = 0; q < 9; ++q) op[(A.rostc + q) * O.sc] = gu[q];
+      up += ups;
+    } else if (VELN) {
+      up += ups;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) uc[d] = (k < k1) ? up[d * U.sc] : 0.0;
+    }
+    op += ops;
+  }
+}
+
+// which: bit 0 Gaussian curvature (G: 3 components from 0, >= 1 resolved ghost layer), bit 1 strain (u: >= 1 resolved ghost layer),
+// bit 2 normal velocity; out components pc (Progress, read), nc (normal, read), kgc / src / vnc / rostc (written; rostc < 0: no tensor)
+int pa_curvopts_level(pa_ctx* ctx, int which, const pa_mf* G, const pa_mf* u, int ucomp, pa_mf* out, int pc, int nc, int kgc, int src, int vnc, int rostc, double thr) {
+  if (!ctx || !out || ((which & 1) && !G) || ((which & 6) && !u)) return pa_fail(ctx, "pa_curvopts_level: null argument");
+  const pa_level* L = out->lev;
+  if (((which & 1) && (G->lev != L || G->ng < 1 || G->ncomp < 3)) || ((which & 6) && u->lev != L) || ((which & 2) && u->ng < 1))
+    return pa_fail(ctx, "pa_curvopts_level: G and the velocity need >= 1 ghost layer on the level of out");
+  if ((which & 6) && (ucomp < 0 || ucomp + 3 > u->ncomp)) return pa_fail(ctx, "pa_curvopts_level: velocity component range");
+  const int hi = std::max(std::max(pc, nc + 2), std::max(std::max((which & 1) ? kgc : 0, (which & 2) ? (rostc >= 0 ? rostc + 8 : src) : 0), (which & 4) ? vnc : 0));
+  if (pc < 0 || nc < 0 || hi >= out->ncomp) return pa_fail(ctx, "pa_curvopts_level: out component range");
+  if (L->boxes.empty() || !(which & 7)) return 0;
+  OptArgs A{L->view, (which & 1) ? G->view : out->view, (which & 6) ? u->view : out->view, out->view, ucomp, pc, nc, kgc, src, vnc, (which & 2) ? rostc : -1, thr};
+  const dim3 g = tile_grid(L);
+  switch (which & 7) {
+#define PA_OPT(W) case W: hipLaunchKernelGGL((k_curvopts<(W & 1) != 0, (W & 2) != 0, (W & 4) != 0>), g, dim3(256), 0, ctx->stream, A); break;
+    PA_OPT(1) PA_OPT(2) PA_OPT(3) PA_OPT(4) PA_OPT(5) PA_OPT(6) PA_OPT(7)
+#undef PA_OPT
+    default: break;
+  }
+  PA_HIP(hipGetLastError());
+  return 0;
+}
+
 int pa_gauss_curv_level(pa_ctx* ctx, const pa_mf* G, int gcomp, const pa_mf* normgrad, int ngcomp, const pa_mf* c, int ccomp, double thr, pa_mf* out,
                         int kcomp) {
   if (!ctx || !G || !normgrad || !out || (thr >= 0.0 && !c)) return pa_fail(ctx, "pa_gauss_curv_level: null argument");

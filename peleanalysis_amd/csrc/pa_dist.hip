@@ -388,7 +388,16 @@ CsPlan::~CsPlan() {
   for (auto& kv : mfs) pa_mf_destroy(kv.second);
   if (cs) pa_level_destroy(cs);
 }
-pa_level::~pa_level() {}
+pa_level::~pa_level() {
+  for (auto& kv : scratch) pa_mf_destroy(kv.second);
+}
+pa_mf* pa_level_scratch(pa_ctx* ctx, const pa_level* L, int ncomp, int ng) {
+  auto it = L->scratch.find({ncomp, ng});
+  if (it != L->scratch.end()) return it->second;
+  pa_mf* m = pa_mf_create(ctx, L, ncomp, ng, nullptr);
+  if (m) L->scratch[{ncomp, ng}] = m;
+  return m;
+}
 
 // regions (already sorted by peer, stable) -> host + device tables
 static int side_finish(pa_ctx* ctx, XSide& S, std::vector<std::pair<int, std::array<int32_t, 7>>>& regs) {

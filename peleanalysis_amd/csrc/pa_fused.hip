@@ -1506,10 +1506,32 @@ int pa_gradcurv_level_cg(pa_ctx* ctx, const pa_mf* phi, int pcomp, double pmin, 
 // nslots > 1 (slot must be 0): components pcomp .. pcomp + nslots - 1 in ONE launch per kernel variant (blockIdx.y = slot: outputs at
 // ocomp + 8 z, compact arrays of slot z, progress range prog[2 z], prog[2 z + 1] on the device); groups that do not take a batched
 // launch run slot by slot with the host's ranges pmins / pmaxs
+// gout (pa_curvature_run with options): the GOUT variants of the sweeps -- Progress, K, N at out components ocomp .. ocomp + 4, the
+// cell-centred gradient of c at components 0 .. 2 of gout[l] (any ghost width).  Only as all-levels launches:
+// pa_gradcurv_gout_ok says whether this hierarchy takes them (else the caller runs pass by pass).
+bool pa_gradcurv_gout_ok(int nlev, pa_mf* const* phi) {
+  static const int batch_env = [] { const char* e = getenv("PA_SWEEP_BATCH"); return e ? atoi(e) : 1; }();
+  static const bool knobs = getenv("PA_MARCH") || getenv("PA_DBG") || getenv("PA_MTY") || getenv("PA_PAIR") || getenv("PA_KSEG");
+  static const int narrow_env = [] { const char* e = getenv("PA_NARROW"); return e ? atoi(e) : 1; }();
+  if (!batch_env || knobs || !narrow_env || fused_order() != 2) return false;
+  std::vector<SweepGroup> all;
+  for (int l = 0; l < nlev; ++l) sweep_groups(l, phi[l]->lev, all);
+  int nw = 0, nn = 0, mty = 0;
+  for (const SweepGroup& g : all) {
+    if (g.dims[0] <= 32) { ++nn; continue; }
+    const int m = g.dims[1] >= 52 ? 13 : (g.dims[1] >= 16 ? 8 : 4);
+    if (mty && m != mty) return false;
+    mty = m;
+    ++nw;
+  }
+  return nw <= PA_MAXB && nn <= PA_MAXB;
+}
+
 int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, double pmin, double pmax, pa_mf* const* out, int ocomp, double thr, int slot,
-                          int nslots, const double* prog, const double* pmins, const double* pmaxs) {
+                          int nslots, const double* prog, const double* pmins, const double* pmaxs, pa_mf* const* gout) {
   const bool clip = thr >= 0.0;
   if (nslots > 1 && (slot != 0 || !prog || !pmins || !pmaxs)) return pa_fail(ctx, "pa_gradcurv_levels_cg: component slots need slot 0 and the progress ranges");
+  if (gout && (nslots != 1 || slot != 0 || !pa_gradcurv_gout_ok(nlev, phi))) return pa_fail(ctx, "pa_gradcurv_levels_cg: the G-output sweeps take one component of a hierarchy pa_gradcurv_gout_ok accepts");
   static const int batch_env = [] { const char* e = getenv("PA_SWEEP_BATCH"); return e ? atoi(e) : 1; }();
   static const bool knobs = getenv("PA_MARCH") || getenv("PA_DBG") || getenv("PA_MTY") || getenv("PA_PAIR");
   std::vector<SweepGroup> all, lv, rest;
@@ -1579,13 +1601,24 @@ int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, d
       A.tiles_max = (int)g.x;
       const WgTab* wt = sweep_wgtab(L, lv[q], 64, mty, A.kseg);
       if (wt) A.wgtab = wt->d;
+      if (gout) { A.gdata = gout[l]->data; A.goff = gout[l]->d_off; A.gng = gout[l]->ng; }
       S.A[q] = A;
       S.wg0[q + 1] = S.wg0[q] + (wt ? wt->n : g.x * 8u * ((nb + 7u) / 8u));
     }
     ProfScope prof(ctx, PA_TAG_GRADCURV);
     S.prog = nslots > 1 ? prog : nullptr;
     const dim3 grid(S.wg0[S.n], (unsigned)nslots);
-    if (clip) {
+    if (gout) {
+      if (clip) {
+        if (mty == 13) hipLaunchKernelGGL((k_gradcurv_march3_levels<13, true, true>), grid, dim3(64 * 16), 0, ctx->stream, S);
+        else if (mty == 8) hipLaunchKernelGGL((k_gradcurv_march3_levels<8, true, true>), grid, dim3(64 * 11), 0, ctx->stream, S);
+        else hipLaunchKernelGGL((k_gradcurv_march3_levels<4, true, true>), grid, dim3(64 * 7), 0, ctx->stream, S);
+      } else {
+        if (mty == 13) hipLaunchKernelGGL((k_gradcurv_march3_levels<13, false, true>), grid, dim3(64 * 16), 0, ctx->stream, S);
+        else if (mty == 8) hipLaunchKernelGGL((k_gradcurv_march3_levels<8, false, true>), grid, dim3(64 * 11), 0, ctx->stream, S);
+        else hipLaunchKernelGGL((k_gradcurv_march3_levels<4, false, true>), grid, dim3(64 * 7), 0, ctx->stream, S);
+      }
+    } else if (clip) {
       if (mty == 13) hipLaunchKernelGGL((k_gradcurv_march3_levels<13, true>), grid, dim3(64 * 16), 0, ctx->stream, S);
       else if (mty == 8) hipLaunchKernelGGL((k_gradcurv_march3_levels<8, true>), grid, dim3(64 * 11), 0, ctx->stream, S);
       else hipLaunchKernelGGL((k_gradcurv_march3_levels<4, true>), grid, dim3(64 * 7), 0, ctx->stream, S);
@@ -1640,16 +1673,20 @@ int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, d
       A.tiles_max = (int)tiles;
       const WgTab* wt = sweep_wgtab(L, nar[q], 32, 2 * NRW, A.kseg);
       if (wt) A.wgtab = wt->d;
+      if (gout) { A.gdata = gout[l]->data; A.goff = gout[l]->d_off; A.gng = gout[l]->ng; }
       S.A[q] = A;
       S.wg0[q + 1] = S.wg0[q] + (wt ? wt->n : tiles * 8u * (((unsigned)nar[q].n + 7u) / 8u));
     }
     ProfScope prof(ctx, PA_TAG_GRADCURV);
     S.prog = nslots > 1 ? prog : nullptr;
-    if (clip) hipLaunchKernelGGL((k_gradcurv_march3n_levels<NRW, true>), dim3(S.wg0[S.n], (unsigned)nslots), dim3(64 * (NRW + 2)), 0, ctx->stream, S);
+    if (gout && clip) hipLaunchKernelGGL((k_gradcurv_march3n_levels<NRW, true, true>), dim3(S.wg0[S.n], 1u), dim3(64 * (NRW + 2)), 0, ctx->stream, S);
+    else if (gout) hipLaunchKernelGGL((k_gradcurv_march3n_levels<NRW, false, true>), dim3(S.wg0[S.n], 1u), dim3(64 * (NRW + 2)), 0, ctx->stream, S);
+    else if (clip) hipLaunchKernelGGL((k_gradcurv_march3n_levels<NRW, true>), dim3(S.wg0[S.n], (unsigned)nslots), dim3(64 * (NRW + 2)), 0, ctx->stream, S);
     else hipLaunchKernelGGL((k_gradcurv_march3n_levels<NRW, false>), dim3(S.wg0[S.n], (unsigned)nslots), dim3(64 * (NRW + 2)), 0, ctx->stream, S);
     PA_HIP(hipGetLastError());
     if (lv.empty()) ctx->sweep_kernel = "k_gradcurv_march3n_levels<NRW=8" + std::string(clip ? ",CLIP" : "") + ">[" + std::to_string(S.n) + " levels per launch]";
   }
+  if (gout && !rest.empty()) return pa_fail(ctx, "pa_gradcurv_levels_cg: a sweep group outside the all-levels launches (G-output variant)");
   for (const SweepGroup& g : rest)
     for (int z = 0; z < nslots; ++z)
       if (sweep_group_cg(ctx, g, phi[g.lev], pcomp + z, nslots > 1 ? pmins[z] : pmin, nslots > 1 ? pmaxs[z] : pmax, out[g.lev], ocomp + 8 * z, thr, slot + z)) return 1;

@@ -67,6 +67,12 @@ struct MarchArgs {
   // (boxes of 32 .. 128 cells per side) 2 of 3 workgroups; the table has none of those and keeps order 2's property (workgroups
   // i and i + 8, one XCD, work on the same box).
   const int* wgtab = nullptr;
+  // GOUT variants (curvature.cpp with options: pa_curvature_run): the sweep stores Progress, K, N at out components
+  // ocomp .. ocomp + 4 and the cell-centred gradient of c (curvature.cpp:457-490, "cell_normal" before its normalisation:
+  // the field do_gaussCurv differentiates again) at components 0 .. 2 of this second multifab instead of grad phi
+  double* gdata = nullptr;
+  const long long* goff = nullptr;
+  int gng = 0;
 };
 
 template <typename BP, int PA_MTY, int MINW>

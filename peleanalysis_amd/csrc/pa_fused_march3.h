@@ -119,8 +119,12 @@ __device__ __forceinline__ void store_pair(char* base, unsigned off, bool odd, d
 //            which is irrelevant there) is re-aimed at the array, one plane ahead;
 //   x faces  the edge wave's lanes of that side: likewise its stream of the column beyond.
 // Values that only feed ghost normals behind special faces (edge ghosts, second ghost layer) may be anything.
-template <typename BP, int PA_MTY, bool CLIP, bool PAIR, int DBG, bool CG>
+// GOUT (pa_curvature_run with options; CG only): no gradient of phi -- the 8 stores of a plane are Progress, K, N (out components
+// ocomp .. ocomp + 4) and G = the cell-centred gradient of c, the normal before its normalisation (curvature.cpp:457-490),
+// into components 0 .. 2 of a second multifab (MarchArgs::gdata) that do_gaussCurv differentiates again.
+template <typename BP, int PA_MTY, bool CLIP, bool PAIR, int DBG, bool CG, bool GOUT = false>
 __device__ __forceinline__ void gradcurv_march3_body(const BP& bp, const MarchArgs& A, const unsigned bid_x, const unsigned bid_y) {
+  static_assert(!GOUT || (CG && !PAIR && DBG == 0), "GOUT: exact-normal sweep, 8-byte stores");
   FabView P, O;
   DBox V;
   double dxinv[3];
@@ -283,7 +287,7 @@ __device__ __forceinline__ void gradcurv_march3_body(const BP& bp, const MarchAr
         const double ng = -((1e-14 < sn) ? sn : 1e-14);
         S.ny[SP][rr][lane] = ggy / ng;
         S.c[SP1][rr][xs] = cp;
-        S.p[SP][rr][xs] = p0;
+        if (!GOUT) S.p[SP][rr][xs] = p0;
         __syncthreads();
         if (!OLD_SCHED) {
           PA_OPAQUE(lo8);
@@ -323,6 +327,15 @@ __device__ __forceinline__ void gradcurv_march3_body(const BP& bp, const MarchAr
     double nxq = 0, nyq = 0, nzq = 0, fzn = 0, fzp = 0;
     char* ob = (char*)(O.p + O.idx(i0, j, k0, A.ocomp));  // wave-uniform
     const long long ops = (long long)O.nx * O.ny * 8, osc = O.sc * 8;
+    char* ob2 = nullptr;  // GOUT: the row of G's FAB (same lane offset, its own plane / component strides)
+    long long ops2 = 0, osc2 = 0;
+    if (GOUT) {
+      const FabView G2 = mf_view(DMFView{A.gdata, A.goff, 3, A.gng, 0, 0.0, 0.0}, V, box);
+      ob2 = (char*)(G2.p + G2.idx(i0, j, k0, 0));
+      ops2 = (long long)G2.nx * G2.ny * 8;
+      osc2 = G2.sc * 8;
+    }
+    double gxq = 0, gyq = 0, gzq = 0;  // GOUT: G of plane q
     const double thr = A.thr;
     const bool odd = lane & 1;
     unsigned lo16 = odd ? (unsigned)(le - 1) * 8u + (unsigned)osc : (unsigned)le * 8u;
@@ -343,6 +356,9 @@ __device__ __forceinline__ void gradcurv_march3_body(const BP& bp, const MarchAr
           PA_OPAQUE(lo16);
           store_pair(ob, lo16, odd, o0, o1); store_pair(ob + 2 * osc, lo16, odd, o2, o3);
           store_pair(ob + 4 * osc, lo16, odd, o4, o5); store_pair(ob + 6 * osc, lo16, odd, o6, o7);
+        } else if (GOUT) {
+          PA_STL(ob, lo8, o0); PA_STL(ob + osc, lo8, o1); PA_STL(ob + 2 * osc, lo8, o2); PA_STL(ob + 3 * osc, lo8, o3);
+          PA_STL(ob + 4 * osc, lo8, o4); PA_STL(ob2, lo8, o5); PA_STL(ob2 + osc2, lo8, o6); PA_STL(ob2 + 2 * osc2, lo8, o7);
         } else {
           PA_STL(ob, lo8, o0); PA_STL(ob + osc, lo8, o1); PA_STL(ob + 2 * osc, lo8, o2); PA_STL(ob + 3 * osc, lo8, o3);
           PA_STL(ob + 4 * osc, lo8, o4); PA_STL(ob + 5 * osc, lo8, o5); PA_STL(ob + 6 * osc, lo8, o6); PA_STL(ob + 7 * osc, lo8, o7);
@@ -375,7 +391,7 @@ __device__ __forceinline__ void gradcurv_march3_body(const BP& bp, const MarchAr
       S.ny[SP][rr][lane] = nyp;
       S.nx[SP][rr - 1][xs] = nxp;
       S.c[SP1][rr][xs] = cp;
-      S.p[SP][rr][xs] = p0;
+      if (!GOUT) S.p[SP][rr][xs] = p0;
       if (OLD_SCHED) __builtin_amdgcn_sched_barrier(0);
       if (OLD_SCHED && !PAIR) PA_STL(ob + 4 * osc, lo8, o4);
       if (DBG & 512) {  // experiment: the burst just before the barrier
@@ -397,20 +413,34 @@ __device__ __forceinline__ void gradcurv_march3_body(const BP& bp, const MarchAr
       if (OLD_SCHED) { if (PAIR) { PA_OPAQUE(lo16); store_pair(ob + 4 * osc, lo16, odd, o4, o5); } else PA_STL(ob + 5 * osc, lo8, o5); }
       if (OLD_SCHED) __builtin_amdgcn_sched_barrier(0);
       // phi gradient at plane q (pc = phi(q), p0 = phi(q+1); fzp = low z-face flux at plane q)
-      const double pl = (DBG & 4) ? p1 : S.p[SQ][rr][xs - 1], pr = (DBG & 4) ? p0 : S.p[SQ][rr][xs + 1];
-      const double ps = (DBG & 4) ? p1 : S.p[SQ][rr - 1][xs], pnn = (DBG & 4) ? p0 : S.p[SQ][rr + 1][xs];
-      const double gx = cdiff(dxinv[0], pl, pc, pr);
-      const double gy = cdiff(dxinv[1], ps, pc, pnn);
-      const double fzph = zflux(dxinv[2], pc, p0);
-      const double gz = favg(fzp, fzph);
+      double gx = 0, gy = 0, gz = 0, gm = 0, fzph = 0;
+      if (!GOUT) {
+        const double pl = (DBG & 4) ? p1 : S.p[SQ][rr][xs - 1], pr = (DBG & 4) ? p0 : S.p[SQ][rr][xs + 1];
+        const double ps = (DBG & 4) ? p1 : S.p[SQ][rr - 1][xs], pnn = (DBG & 4) ? p0 : S.p[SQ][rr + 1][xs];
+        gx = cdiff(dxinv[0], pl, pc, pr);
+        gy = cdiff(dxinv[1], ps, pc, pnn);
+        fzph = zflux(dxinv[2], pc, p0);
+        gz = favg(fzp, fzph);
+      }
       if (OLD_SCHED) __builtin_amdgcn_sched_barrier(0);
       if (OLD_SCHED && !PAIR) PA_STL(ob + 6 * osc, lo8, o6);
       if (OLD_SCHED) __builtin_amdgcn_sched_barrier(0);
-      const double gm = (DBG & 2) ? (gx * gx + gy * gy + gz * gz) : sqrt(gx * gx + gy * gy + gz * gz);
+      if (!GOUT) gm = (DBG & 2) ? (gx * gx + gy * gy + gz * gz) : sqrt(gx * gx + gy * gy + gz * gz);
       if (OLD_SCHED) __builtin_amdgcn_sched_barrier(0);
       if (OLD_SCHED) { if (PAIR) { PA_OPAQUE(lo16); store_pair(ob + 6 * osc, lo16, odd, o6, o7); } else PA_STL(ob + 7 * osc, lo8, o7); }
       if (DBG & 1024) { PA_OPAQUE(lo8); f[SP] = PA_LDG(gp, lo8); }  // experiment: the request at the end of the step
       ob += (p >= k0 + 2) ? ops : 0;
+      if (GOUT) {  // [Progress K Nx Ny Nz] + G; cm = c at plane q; Progress and G are not clipped (curvature.cpp:557-566 clips K and N)
+        ob2 += (p >= k0 + 2) ? ops2 : 0;
+        const bool clip = CLIP && ((cm < thr) || (cm > 1.0 - thr));
+        o0 = cm;
+        o1 = clip ? 0.0 : curv;
+        o2 = clip ? 0.0 : nxq;
+        o3 = clip ? 0.0 : nyq;
+        o4 = clip ? 0.0 : nzq;
+        o5 = gxq; o6 = gyq; o7 = gzq;
+        gxq = ggx; gyq = ggy; gzq = ggz;
+      } else {
       o0 = gx; o1 = gy; o2 = gz; o3 = gm;
       if (CLIP) {  // threshold clip (curvature.cpp:557-566); cm = c at plane q
         const bool clip = (cm < thr) || (cm > 1.0 - thr);
@@ -420,6 +450,7 @@ __device__ __forceinline__ void gradcurv_march3_body(const BP& bp, const MarchAr
         o7 = clip ? 0.0 : curv;
       } else {
         o4 = nxq; o5 = nyq; o6 = nzq; o7 = curv;
+      }
       }
       cm = cc; cc = cp; cp = PA_PROG(x);
       if (CG) cp = (p == pzh) ? cgzv : cp;  // x was phi of plane hi_z + 1
@@ -434,6 +465,15 @@ __device__ __forceinline__ void gradcurv_march3_body(const BP& bp, const MarchAr
       store_pair(ob + 2 * osc, lo16, odd, o2, o3);
       store_pair(ob + 4 * osc, lo16, odd, o4, o5);
       store_pair(ob + 6 * osc, lo16, odd, o6, o7);
+    } else if (GOUT) {
+      PA_STG(ob, lo8, o0);
+      PA_STG(ob + osc, lo8, o1);
+      PA_STG(ob + 2 * osc, lo8, o2);
+      PA_STG(ob + 3 * osc, lo8, o3);
+      PA_STG(ob + 4 * osc, lo8, o4);
+      PA_STG(ob2, lo8, o5);
+      PA_STG(ob2 + osc2, lo8, o6);
+      PA_STG(ob2 + 2 * osc2, lo8, o7);
     } else {
       PA_STG(ob, lo8, o0);
       PA_STG(ob + osc, lo8, o1);
@@ -537,7 +577,7 @@ __device__ __forceinline__ void gradcurv_march3_body(const BP& bp, const MarchAr
       const double nxp = ggx / ng;
       if (has_n) S.nx[SP][rr - 1][xs] = nxp;
       S.c[SP1][rr][xs] = cp;
-      S.p[SP][rr][xs] = p0;
+      if (!GOUT) S.p[SP][rr][xs] = p0;
       __syncthreads();
       if (!OLD_SCHED) {
         PA_OPAQUE(og);
@@ -589,16 +629,16 @@ __device__ __forceinline__ void sweep_slot(const SweepBatch& S, int l, LevelBP2&
   }
   if (S.prog) { A.pmin = S.prog[2 * z]; A.invdenom = S.prog[2 * z + 1]; }
 }
-template <int PA_MTY, bool CLIP = false>
+template <int PA_MTY, bool CLIP = false, bool GOUT = false>
 __global__ __launch_bounds__(64 * (PA_MTY + 3), 1) void k_gradcurv_march3_levels(SweepBatch S) {
   int l = 0;
   while (l + 1 < S.n && blockIdx.x >= S.wg0[l + 1]) ++l;
-  if (gridDim.y == 1 && !S.prog) {  // one component: the arguments straight from the argument segment
-    gradcurv_march3_body<LevelBP2, PA_MTY, CLIP, false, 0, true>(S.bp[l], S.A[l], blockIdx.x - S.wg0[l], 0u);
+  if (GOUT || (gridDim.y == 1 && !S.prog)) {  // one component: the arguments straight from the argument segment
+    gradcurv_march3_body<LevelBP2, PA_MTY, CLIP, false, 0, true, GOUT>(S.bp[l], S.A[l], blockIdx.x - S.wg0[l], 0u);
     return;
   }
   LevelBP2 bp;
   MarchArgs A;
   sweep_slot(S, l, bp, A);
-  gradcurv_march3_body<LevelBP2, PA_MTY, CLIP, false, 0, true>(bp, A, blockIdx.x - S.wg0[l], 0u);
+  gradcurv_march3_body<LevelBP2, PA_MTY, CLIP, false, 0, true, GOUT>(bp, A, blockIdx.x - S.wg0[l], 0u);
 }

@@ -29,7 +29,8 @@ struct MarchLdsN {
 // stream (mode 1: the halo row IS the ghost row, the stream runs one plane ahead and supplies its c; mode 2: the tile ends
 // one row short of the box, the row BEYOND the halo row is the ghost row); x faces: the edge wave's lanes likewise with the
 // array [plane][y].  Both waves address the second stream through per-lane pointers when CG is on.
-template <typename BP, int NRW, bool CLIP, bool CG = false>
+// GOUT: as in pa_fused_march3.h -- Progress, K, N at out components ocomp .. ocomp + 4 and G into a second multifab.
+template <typename BP, int NRW, bool CLIP, bool CG = false, bool GOUT = false>
 __device__ __forceinline__ void gradcurv_march3n_body(const BP& bp, const MarchArgs& A, const unsigned bid_x, const unsigned bid_y) {
   FabView P, O;
   DBox V;
@@ -135,6 +136,18 @@ __device__ __forceinline__ void gradcurv_march3n_body(const BP& bp, const MarchA
     double nxq = 0, nyq = 0, nzq = 0, fzn = 0, fzp = 0;
     char* ob = (char*)(O.p + O.idx(i0, j0, k0, A.ocomp));
     const long long ops = (long long)O.nx * O.ny * 8, osc = O.sc * 8;
+    char* ob2 = nullptr;  // GOUT: G's FAB (its own row length, plane and component strides)
+    long long ops2 = 0, osc2 = 0;
+    unsigned sg8 = 0;
+    if (GOUT) {
+      static_assert(!GOUT || CG, "GOUT: exact-normal sweep");
+      const FabView G2 = mf_view(DMFView{A.gdata, A.goff, 3, A.gng, 0, 0.0, 0.0}, V, box);
+      ob2 = (char*)(G2.p + G2.idx(i0, j0, k0, 0));
+      ops2 = (long long)G2.nx * G2.ny * 8;
+      osc2 = G2.sc * 8;
+      sg8 = (unsigned)((rr - 1) * G2.nx + le) * 8u;
+    }
+    double gxq = 0, gyq = 0, gzq = 0;  // GOUT: G of plane q
     const double thr = A.thr;
     double o0 = 0, o1 = 0, o2 = 0, o3 = 0, o4 = 0, o5 = 0, o6 = 0, o7 = 0;
     auto step = [&](auto spc, int p) __attribute__((always_inline)) {
@@ -145,7 +158,13 @@ __device__ __forceinline__ void gradcurv_march3n_body(const BP& bp, const MarchA
       __builtin_amdgcn_sched_barrier(0);
       gp += (p + 5 <= kfmax) ? pps : 0;
       PA_STG(ob, so8, o0); PA_STG(ob + osc, so8, o1); PA_STG(ob + 2 * osc, so8, o2); PA_STG(ob + 3 * osc, so8, o3);
-      PA_STG(ob + 4 * osc, so8, o4); PA_STG(ob + 5 * osc, so8, o5); PA_STG(ob + 6 * osc, so8, o6); PA_STG(ob + 7 * osc, so8, o7);
+      PA_STG(ob + 4 * osc, so8, o4);
+      if (GOUT) {
+        PA_OPAQUE(sg8);
+        PA_STG(ob2, sg8, o5); PA_STG(ob2 + osc2, sg8, o6); PA_STG(ob2 + 2 * osc2, sg8, o7);
+      } else {
+        PA_STG(ob + 5 * osc, so8, o5); PA_STG(ob + 6 * osc, so8, o6); PA_STG(ob + 7 * osc, so8, o7);
+      }
       __builtin_amdgcn_sched_barrier(0);
       const double cl = S.c[SP][rr][xs - 1], cr = S.c[SP][rr][xs + 1];
       const double cs = S.c[SP][rr - 1][xs], cn = S.c[SP][rr + 1][xs];
@@ -160,7 +179,7 @@ __device__ __forceinline__ void gradcurv_march3n_body(const BP& bp, const MarchA
       S.ny[SP][rr][col] = nyp;
       S.nx[SP][rr - 1][xs] = nxp;
       S.c[SP1][rr][xs] = cp;
-      S.p[SP][rr][xs] = p0;
+      if (!GOUT) S.p[SP][rr][xs] = p0;
       __syncthreads();
       PA_OPAQUE(lo8);
       f[SP] = PA_LDG(gp, lo8);  // request for plane p+5, after the barrier
@@ -172,14 +191,28 @@ __device__ __forceinline__ void gradcurv_march3n_body(const BP& bp, const MarchA
       curv += cdiff(dxinv[1], nys, nyq, nyn);
       curv += favg(fzn, fznh);
       curv = curv * 0.5;
-      const double pl = S.p[SQ][rr][xs - 1], pr = S.p[SQ][rr][xs + 1];
-      const double ps = S.p[SQ][rr - 1][xs], pnn = S.p[SQ][rr + 1][xs];
-      const double gx = cdiff(dxinv[0], pl, pc, pr);
-      const double gy = cdiff(dxinv[1], ps, pc, pnn);
-      const double fzph = zflux(dxinv[2], pc, p0);
-      const double gz = favg(fzp, fzph);
-      const double gm = sqrt(gx * gx + gy * gy + gz * gz);
+      double gx = 0, gy = 0, gz = 0, gm = 0, fzph = 0;
+      if (!GOUT) {
+        const double pl = S.p[SQ][rr][xs - 1], pr = S.p[SQ][rr][xs + 1];
+        const double ps = S.p[SQ][rr - 1][xs], pnn = S.p[SQ][rr + 1][xs];
+        gx = cdiff(dxinv[0], pl, pc, pr);
+        gy = cdiff(dxinv[1], ps, pc, pnn);
+        fzph = zflux(dxinv[2], pc, p0);
+        gz = favg(fzp, fzph);
+        gm = sqrt(gx * gx + gy * gy + gz * gz);
+      }
       ob += (p >= k0 + 2) ? ops : 0;
+      if (GOUT) {  // [Progress K Nx Ny Nz] + G; cm = c at plane q; Progress and G are not clipped
+        ob2 += (p >= k0 + 2) ? ops2 : 0;
+        const bool clip = CLIP && ((cm < thr) || (cm > 1.0 - thr));
+        o0 = cm;
+        o1 = clip ? 0.0 : curv;
+        o2 = clip ? 0.0 : nxq;
+        o3 = clip ? 0.0 : nyq;
+        o4 = clip ? 0.0 : nzq;
+        o5 = gxq; o6 = gyq; o7 = gzq;
+        gxq = ggx; gyq = ggy; gzq = ggz;
+      } else {
       o0 = gx; o1 = gy; o2 = gz; o3 = gm;
       if (CLIP) {  // threshold clip (curvature.cpp:557-566); cm = c at plane q
         const bool clip = (cm < thr) || (cm > 1.0 - thr);
@@ -190,6 +223,7 @@ __device__ __forceinline__ void gradcurv_march3n_body(const BP& bp, const MarchA
       } else {
         o4 = nxq; o5 = nyq; o6 = nzq; o7 = curv;
       }
+      }
       cm = cc; cc = cp; cp = PA_PROG(x);
       if (CG) cp = (p == pzh) ? cgzv : cp;  // x was phi of plane hi_z + 1
       fzc = fzh; fzn = fznh; fzp = fzph;
@@ -198,7 +232,12 @@ __device__ __forceinline__ void gradcurv_march3n_body(const BP& bp, const MarchA
     };
     PA_RUN3(step)
     PA_STG(ob, so8, o0); PA_STG(ob + osc, so8, o1); PA_STG(ob + 2 * osc, so8, o2); PA_STG(ob + 3 * osc, so8, o3);
-    PA_STG(ob + 4 * osc, so8, o4); PA_STG(ob + 5 * osc, so8, o5); PA_STG(ob + 6 * osc, so8, o6); PA_STG(ob + 7 * osc, so8, o7);
+    PA_STG(ob + 4 * osc, so8, o4);
+    if (GOUT) {
+      PA_STG(ob2, sg8, o5); PA_STG(ob2 + osc2, sg8, o6); PA_STG(ob2 + 2 * osc2, sg8, o7);
+    } else {
+      PA_STG(ob + 5 * osc, so8, o5); PA_STG(ob + 6 * osc, so8, o6); PA_STG(ob + 7 * osc, so8, o7);
+    }
     return;
   }
 
@@ -279,7 +318,7 @@ __device__ __forceinline__ void gradcurv_march3n_body(const BP& bp, const MarchA
       const double ng = -((1e-14 < sn) ? sn : 1e-14);
       S.ny[SP][rr][col] = ggy / ng;
       S.c[SP1][rr][xs] = cp;
-      S.p[SP][rr][xs] = p0;
+      if (!GOUT) S.p[SP][rr][xs] = p0;
       __syncthreads();
       PA_OPAQUE(lo8);
       if (!CG) PA_OPAQUE(oo8);
@@ -374,7 +413,7 @@ __device__ __forceinline__ void gradcurv_march3n_body(const BP& bp, const MarchA
       const double nxp = ggx / ng;
       if (has_n) S.nx[SP][rr - 1][xs] = nxp;
       S.c[SP1][rr][xs] = cp;
-      S.p[SP][rr][xs] = p0;
+      if (!GOUT) S.p[SP][rr][xs] = p0;
       __syncthreads();
       PA_OPAQUE(og);
       if (!CG) PA_OPAQUE(oo);
@@ -398,16 +437,16 @@ __global__ __launch_bounds__(64 * (NRW + 2), 1) void k_gradcurv_march3n(BP bp, M
 
 // the CG sweeps of the narrow-box groups of several levels in ONE launch (as k_gradcurv_march3_levels for the wide boxes: no idle
 // tail and ramp-up between the levels)
-template <int NRW, bool CLIP = false>
+template <int NRW, bool CLIP = false, bool GOUT = false>
 __global__ __launch_bounds__(64 * (NRW + 2), 1) void k_gradcurv_march3n_levels(SweepBatch S) {
   int l = 0;
   while (l + 1 < S.n && blockIdx.x >= S.wg0[l + 1]) ++l;
-  if (gridDim.y == 1 && !S.prog) {
-    gradcurv_march3n_body<LevelBP2, NRW, CLIP, true>(S.bp[l], S.A[l], blockIdx.x - S.wg0[l], 0u);
+  if (GOUT || (gridDim.y == 1 && !S.prog)) {
+    gradcurv_march3n_body<LevelBP2, NRW, CLIP, true, GOUT>(S.bp[l], S.A[l], blockIdx.x - S.wg0[l], 0u);
     return;
   }
   LevelBP2 bp;
   MarchArgs A;
   sweep_slot(S, l, bp, A);
-  gradcurv_march3n_body<LevelBP2, NRW, CLIP, true>(bp, A, blockIdx.x - S.wg0[l], 0u);
+  gradcurv_march3n_body<LevelBP2, NRW, CLIP, true, GOUT>(bp, A, blockIdx.x - S.wg0[l], 0u);
 }

@@ -197,6 +197,7 @@ struct pa_level {
   mutable std::map<long long, std::unique_ptr<WgTab>> wgtabs;                           // sweep workgroup tables by (group, tile shape) (pa_fused.hip)
   mutable std::map<long long, std::unique_ptr<struct RsPlan>> rs_plans;                 // restriction onto a sharded coarse level, by coarse level serial (pa_dist.hip)
   mutable std::map<std::pair<long long, int>, std::unique_ptr<struct FpPlan>> fp_plans; // FillPatchTwoLevels parent lists by (coarse level serial, ghost width) (pa_filter.hip)
+  mutable std::map<std::pair<int, int>, struct pa_mf*> scratch;                         // work multifabs by (components, ghost width), kept for the level's lifetime (pa_level_scratch)
   ~pa_level();
 };
 
@@ -218,6 +219,9 @@ struct LevelSpec {
 pa_level* pa_level_create_spec(pa_ctx* ctx, const LevelSpec& S, const int32_t domlo[3], const int32_t domhi[3], const int32_t is_per[3],
                                const double prob_lo[3], const double prob_hi[3]);
 bool pa_face_is_special(const pa_level* L, const DBox& B, int d, int side);
+// a work multifab of the level that lives as long as the level does (contents undefined between calls): a 10-GB hipMalloc +
+// hipFree per call of pa_curvature_run cost more than the kernels it served
+struct pa_mf* pa_level_scratch(pa_ctx* ctx, const pa_level* L, int ncomp, int ng);
 const WgTab* pa_sweep_wgtab(const pa_level* L, int cls, int tw, int mty, int kseg, bool force);
 int pa_host_classify(const pa_level* L, int i, int j, int k);
 

@@ -18,8 +18,9 @@ int pa_grad_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int comp, pa_mf* co
 int pa_gradcurv_prep_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int comp, const pa_mf* const* crse, int ccomp, const int32_t bc[3], double pmin, double pmax, int phase = 3,
                             int nslots = 1, const double* prog = nullptr);
 int pa_gradcurv_level_cg(pa_ctx* ctx, const pa_mf* phi, int pcomp, double pmin, double pmax, pa_mf* out, int ocomp, double thr = -1.0, int slot = 0);
+bool pa_gradcurv_gout_ok(int nlev, pa_mf* const* phi);
 int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, double pmin, double pmax, pa_mf* const* out, int ocomp, double thr = -1.0, int slot = 0,
-                          int nslots = 1, const double* prog = nullptr, const double* pmins = nullptr, const double* pmaxs = nullptr);
+                          int nslots = 1, const double* prog = nullptr, const double* pmins = nullptr, const double* pmaxs = nullptr, pa_mf* const* gout = nullptr);
 int pa_gradcurv_fix_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, const pa_mf* const* crse_n, int cncomp0, const int32_t bc[3], double pmin, double pmax,
                            pa_mf* const* out, int ncomp0, int kcomp, double thr = -1.0, int nslots = 1, const double* prog = nullptr, int cn_z = 8,
                            const pa_mf* const* crse_phi = nullptr, int cpcomp = 0);
@@ -27,6 +28,7 @@ int pa_gauss_curv_level(pa_ctx* ctx, const pa_mf* G, int gcomp, const pa_mf* nor
                         int kcomp);
 int pa_strain_level(pa_ctx* ctx, const pa_mf* u, int ucomp, pa_mf* out, int srcomp, int rostcomp);
 int pa_velnormal_level(pa_ctx* ctx, const pa_mf* u, int ucomp, const pa_mf* n, int ncomp0, const pa_mf* c, int ccomp, double thr, pa_mf* out, int ocomp);
+int pa_curvopts_level(pa_ctx* ctx, int which, const pa_mf* G, const pa_mf* u, int ucomp, pa_mf* out, int pc, int nc, int kgc, int src, int vnc, int rostc, double thr);
 
 int pa_gradcurv_faces_phase(pa_ctx* ctx, const pa_mf* c, int ccomp, const pa_mf* crse_n, int cncomp0, const int32_t bc[3], int ratio, double thr,
                             pa_mf* out, int ncomp0, int kcomp, int phase);
@@ -490,15 +492,13 @@ static int fused_passes_conc(pa_ctx* ctx, int nlev, pa_mf* const* state, int com
 }
 
 static bool exact_ok(int nlev, pa_mf* const* state, double thr);
-static int fused_passes(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, const int32_t bc[3], double pmin, double pmax, double thr,
-                        pa_mf* const* work, pa_mf* const* out, int ocomp) {
-  for (int l = 0; l < nlev; ++l)
-    if (state[l]->ng < 2 || work[l]->ng < 2) return pa_fail(ctx, "fused grad->curvature needs 2 ghost layers on state and work");
-  // exact-normal pipeline (pa_fused.hip): pure special faces, boxes wider than 32 cells; with the threshold clip the sweep
-  // zeroes N and K itself and the one-layer fix-up recomputes the (few) clipped normals it needs (PA_FUSED2_CLIP=0: first pipeline)
-  const bool exact = exact_ok(nlev, state, thr);
-  if (state[0]->lev->nranks > 1) return fused_passes_dist(ctx, nlev, state, comp, bc, pmin, pmax, thr, work, out, ocomp, exact);
-  if (exact) {
+// The exact-normal pipeline on one rank.  gout == null: [gx gy gz |g| Nx Ny Nz K] at out components ocomp .. ocomp + 7;
+// gout != null (pa_curvature_run with options): [Progress K Nx Ny Nz] at ocomp .. ocomp + 4 and G, the cell-centred gradient of c,
+// at components 0 .. 2 of gout[l] (the GOUT sweeps, pa_fused_march3.h)
+static int exact_passes(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, const int32_t bc[3], double pmin, double pmax, double thr,
+                        pa_mf* const* out, int ocomp, pa_mf* const* gout = nullptr) {
+  const int ncomp0 = gout ? ocomp + 2 : ocomp + 4, kcomp = gout ? ocomp + 1 : ocomp + 7;
+  {
     // 3 + nlev launches per pass: ghost cells of every level (one launch), resolved ghost c (two), the sweeps, the curvature
     // of the first layer behind the special faces of every level (two).  (Running the boundary launches on a side stream
     // next to the sweeps was measured again with this lighter pipeline: 7.04-7.09 against 6.93-7.03 ms per step, the
@@ -538,10 +538,21 @@ static int fused_passes(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, co
     }
     if (pov) PA_HIP(hipStreamWaitEvent(ctx->stream, ctx->sync_evs[1], 0));
     if (!(pov && ring_side)) PA_TRY(pa_gradcurv_prep_levels(ctx, nlev, state, comp, crse.data(), comp, bc, pmin, pmax, pov ? 2 : 3));
-    PA_TRY(pa_gradcurv_levels_cg(ctx, nlev, state, comp, pmin, pmax, out, ocomp, thr));
-    PA_TRY(pa_gradcurv_fix_levels(ctx, nlev, state, comp, crse_n.data(), ocomp + 4, bc, pmin, pmax, out, ocomp + 4, ocomp + 7, thr, 1, nullptr, 8, crse.data(), comp));
+    PA_TRY(pa_gradcurv_levels_cg(ctx, nlev, state, comp, pmin, pmax, out, ocomp, thr, 0, 1, nullptr, nullptr, nullptr, gout));
+    PA_TRY(pa_gradcurv_fix_levels(ctx, nlev, state, comp, crse_n.data(), ncomp0, bc, pmin, pmax, out, ncomp0, kcomp, thr, 1, nullptr, 8, crse.data(), comp));
     return 0;
   }
+}
+
+static int fused_passes(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, const int32_t bc[3], double pmin, double pmax, double thr,
+                        pa_mf* const* work, pa_mf* const* out, int ocomp) {
+  for (int l = 0; l < nlev; ++l)
+    if (state[l]->ng < 2 || work[l]->ng < 2) return pa_fail(ctx, "fused grad->curvature needs 2 ghost layers on state and work");
+  // exact-normal pipeline (pa_fused.hip): pure special faces, boxes wider than 32 cells; with the threshold clip the sweep
+  // zeroes N and K itself and the one-layer fix-up recomputes the (few) clipped normals it needs (PA_FUSED2_CLIP=0: first pipeline)
+  const bool exact = exact_ok(nlev, state, thr);
+  if (state[0]->lev->nranks > 1) return fused_passes_dist(ctx, nlev, state, comp, bc, pmin, pmax, thr, work, out, ocomp, exact);
+  if (exact) return exact_passes(ctx, nlev, state, comp, bc, pmin, pmax, thr, out, ocomp);
   if (nlev >= 2 && !overlap_on() && conc_on(nlev, state)) return fused_passes_conc(ctx, nlev, state, comp, bc, pmin, pmax, thr, work, out, ocomp);
   if (!overlap_on() || nlev < 2) {
     for (int l = 0; l < nlev; ++l) PA_TRY(fused_pre(ctx, l, state, comp, bc, pmin, pmax, work));
@@ -585,6 +596,37 @@ static int fused_passes(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, co
   return 0;
 }
 
+// pa_curvature_run on the exact-normal pipeline (see there).  out components as curvature_passes writes them.
+static int curvature_fast(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, const int32_t bc[3], double pmin, double pmax, double thr,
+                          pa_mf* const* out, int opt, const pa_curv_params* P) {
+  const bool gauss = P->do_gauss_curv, strain = P->do_strain, veln = P->do_velnormal;
+  for (int l = 0; l < nlev; ++l) {
+    const int need = opt + (strain && P->get_strain_tensor ? 17 : (veln ? 8 : (strain ? 7 : (gauss ? 6 : 5))));
+    if (out[l]->ncomp < need) return pa_fail(ctx, "pa_curvature_run: out needs " + std::to_string(need) + " components for the requested options");
+    if ((strain || veln) && (P->vel_comp < 0 || P->vel_comp + 3 > state[l]->ncomp)) return pa_fail(ctx, "pa_curvature_run: vel_comp out of range");
+  }
+  std::vector<pa_mf*> G(nlev);
+  for (int l = 0; l < nlev; ++l) {
+    G[l] = pa_level_scratch(ctx, state[l]->lev, 3, 1);
+    if (!G[l]) return 1;
+  }
+  PA_TRY(exact_passes(ctx, nlev, state, comp, bc, pmin, pmax, thr, out, opt, G.data()));  // :316-322, 426-570
+  if (gauss) {  // :575-613: ghost cells of G = cell_normal before its normalisation; coarse-fine values from the coarser level's G
+    PA_TRY(pa_fill_boundary_local_batch(ctx, nlev, G.data(), 0, 3, 1));
+    for (int l = 0; l < nlev; ++l)
+      for (int d = 0; d < 3; ++d) PA_TRY(pa_apply_bc(ctx, G[l], d, l > 0 ? G[l - 1] : nullptr, d, bc, 2, -1));
+  }
+  if (strain) {  // :679-757
+    PA_TRY(pa_fill_boundary_local_batch(ctx, nlev, state, P->vel_comp, 3, 1));
+    for (int l = 0; l < nlev; ++l)
+      for (int d = 0; d < 3; ++d) PA_TRY(pa_apply_bc(ctx, state[l], P->vel_comp + d, l > 0 ? state[l - 1] : nullptr, P->vel_comp + d, bc, 2, -1));
+  }
+  const int which = (gauss ? 1 : 0) | (strain ? 2 : 0) | (veln ? 4 : 0);
+  for (int l = 0; l < nlev && which; ++l)
+    PA_TRY(pa_curvopts_level(ctx, which, G[l], state[l], P->vel_comp, out[l], opt, opt + 2, opt + 5, opt + 6, opt + 7, P->get_strain_tensor ? opt + 8 : -1, thr));
+  return 0;
+}
+
 static bool all_fusable(int nlev, pa_mf* const* state) {
   for (int l = 0; l < nlev; ++l) {
     if (!state[l]->lev->fusable) return false;
@@ -624,6 +666,16 @@ extern "C" int pa_curvature_run(pa_ctx* ctx, int nlev, pa_mf* const* state, int 
   // component (their z terms are then exact zeros); Gaussian curvature is 3-D only in the reference (curvature.cpp:208-216)
   if (P->spacedim == 2 && P->do_gauss_curv)
     return pa_fail(ctx, "pa_curvature_run: do_gauss_curv is not available for 2-D levels (spacedim = 2)");
+  // Fast path (round 5): Progress, K and N from the exact-normal pipeline -- its G-output sweeps leave the cell-centred gradient
+  // of c in a work multifab of the level instead of grad phi -- then ONE pass per level for the options.  One rank, 3-D, no
+  // smoothing solve, a hierarchy the all-levels sweeps take; PA_CURV_FAST=0 (read per call) or fused = 0: pass by pass.
+  {
+    const char* cfe = getenv("PA_CURV_FAST");
+    bool fast = P->fused && P->spacedim != 2 && !P->do_smooth && (!cfe || atoi(cfe)) && state[0]->lev->nranks == 1;
+    for (int l = 0; l < nlev && fast; ++l) fast = state[l]->ng >= 2 && !state[l]->lev->boxes.empty();
+    fast = fast && exact_ok(nlev, state, thr) && pa_gradcurv_gout_ok(nlev, state);
+    if (fast) return curvature_fast(ctx, nlev, state, comp, bc, pmin, pmax, thr, out, ocomp, P);
+  }
   return curvature_passes(ctx, nlev, state, comp, bc, pmin, pmax, thr, out, ocomp, ocomp + 1, ocomp + 2, P, ocomp, P->spacedim == 2 ? 1.0 : 0.5);
 }
 

@@ -367,12 +367,16 @@ def test_curvature_options_match_oracle(ctx, oracle, name):
                               do_strain=True, do_velnormal=True, strain_tensor=True)
     dls, dst = _dev(ctx, H, states)
     dout = [capi.DevMF(ctx, dl, 17, 0) for dl in dls]
-    P = capi.curv_params(threshold=0.05, fused=False, do_gauss=True, do_strain=True, strain_tensor=True, do_velnormal=True, vel_comp=1)
-    capi.curvature_run(ctx, dst, 0, bc, P, dout, 0)
-    ctx.sync()
-    assert ctx.bc_errors() == 0
-    for l in range(H.nlev):
-        assert_valid_bits_equal(dout[l].download(), oout[l], [(c, c) for c in range(17)], f"{name} options level {l}")
+    # fused=False: pass by pass; fused=True: Progress / K / N from the exact-normal pipeline's G-output sweeps + one options pass per level
+    for fused in (False, True):
+        for m in dout:
+            m.setval(-7.0)
+        P = capi.curv_params(threshold=0.05, fused=fused, do_gauss=True, do_strain=True, strain_tensor=True, do_velnormal=True, vel_comp=1)
+        capi.curvature_run(ctx, dst, 0, bc, P, dout, 0)
+        ctx.sync()
+        assert ctx.bc_errors() == 0
+        for l in range(H.nlev):
+            assert_valid_bits_equal(dout[l].download(), oout[l], [(c, c) for c in range(17)], f"{name} options fused {fused} level {l}")
     # too few output components are rejected before any launch
     small = [capi.DevMF(ctx, dl, 6, 0) for dl in dls]
     with pytest.raises(capi.PaError):

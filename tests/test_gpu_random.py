@@ -196,12 +196,49 @@ def test_random_hierarchy_curvature_options(ctx, oracle, seed):
     dls = [capi.DevLevel(ctx, lv) for lv in H.levels]
     dst = [capi.DevMF.from_host(ctx, dl, s) for dl, s in zip(dls, states)]
     dout = [capi.DevMF(ctx, dl, 17, 0) for dl in dls]
-    P = capi.curv_params(threshold=thr, fused=False, do_gauss=True, do_strain=True, strain_tensor=True, do_velnormal=True, vel_comp=1)
-    capi.curvature_run(ctx, dst, 0, bc, P, dout, 0)
+    for fused in (False, True):  # pass by pass / the exact-normal pipeline's G-output sweeps + one options pass per level
+        for m in dout:
+            m.setval(-7.0)
+        P = capi.curv_params(threshold=thr, fused=fused, do_gauss=True, do_strain=True, strain_tensor=True, do_velnormal=True, vel_comp=1)
+        capi.curvature_run(ctx, dst, 0, bc, P, dout, 0)
+        ctx.sync()
+        assert ctx.bc_errors() == 0
+        for l in range(H.nlev):
+            assert_valid_bits_equal(dout[l].download(), oout[l], [(c, c) for c in range(17)], f"seed {seed} options fused {fused} level {l}")
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PA_RANDOM_WIDE_SEEDS", "6"))))
+@pytest.mark.parametrize("which", ["all", "gauss", "strain_veln", "veln"])
+def test_random_wide_box_curvature_options_fast_path(ctx, oracle, seed, which):
+    """pa_curvature_run's fast path on boxes wider than 32 cells (the wide G-output sweep, all levels in one launch; uneven
+    chops also leave narrow boxes: both kernels in one pass): every subset of the options the fused options kernel is
+    instantiated for, with and without the threshold clip, all written components against the oracle bit for bit; components
+    of options that are off stay untouched"""
+    H, per, sym, fn = _draw_wide(seed)
+    thr = None if seed % 2 else 0.04
+    opts = dict(all=dict(do_gauss=True, do_strain=True, strain_tensor=True, do_velnormal=True), gauss=dict(do_gauss=True),
+                strain_veln=dict(do_strain=True, do_velnormal=True), veln=dict(do_velnormal=True))[which]
+    comps = dict(all=list(range(17)), gauss=[0, 1, 2, 3, 4, 5], strain_veln=[0, 1, 2, 3, 4, 6, 7], veln=[0, 1, 2, 3, 4, 7])[which]
+    states = make_states(H, 4, 2, fn, seed=seed + 5)
+    bc = capi.bc_from_flags(per, sym)
+    oout = [MultiFab(lv, 17, 0) for lv in H.levels]
+    oracle.curvature_pipeline(H.levels, [s.copy() for s in states], 0, bc, oout, 0, MultiFab, threshold=thr, vel_comp=1, **opts)
+    dls = [capi.DevLevel(ctx, lv) for lv in H.levels]
+    dst = [capi.DevMF.from_host(ctx, dl, s) for dl, s in zip(dls, states)]
+    dout = [capi.DevMF(ctx, dl, 17, 0) for dl in dls]
+    for m in dout:
+        m.setval(-7.0)
+    capi.curvature_run(ctx, dst, 0, bc, capi.curv_params(threshold=thr, fused=True, vel_comp=1, **opts), dout, 0)
     ctx.sync()
     assert ctx.bc_errors() == 0
+    kn = ctx.lib.pa_sweep_kernel_name(ctx.h).decode()
+    assert "_levels<" in kn, kn
     for l in range(H.nlev):
-        assert_valid_bits_equal(dout[l].download(), oout[l], [(c, c) for c in range(17)], f"seed {seed} options level {l}")
+        got = dout[l].download()
+        assert_valid_bits_equal(got, oout[l], [(c, c) for c in comps], f"wide seed {seed} options {which} level {l}")
+        for c in set(range(17)) - set(comps):
+            for b in range(H.levels[l].nboxes):
+                assert np.all(got.valid(b)[c] == -7.0), f"wide seed {seed} options {which}: component {c} was written"
 
 
 def _draw_wide(seed):
