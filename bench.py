@@ -587,6 +587,10 @@ def secondary(ctx, torch, stream, dev, only=None, retile=1):
                                                      "128^3 boxes in the file, progress source + 3 velocity components in, 8 fields out; " + tiling_txt(Hf, H) +
                                                      "; ms = the fast path (G-output sweeps + one options pass per level), pass_by_pass_ms = fused=0, the smaller of two "
                                                      "single passes (that path allocates its work multifabs per call)")
+        if not want("f1_do_smooth_headline"):
+            del ins, ous, dls
+            torch.cuda.empty_cache()
+            return
         # curvature.cpp:328-406: the implicit smoothing solve alone (BiCGStab on the composite operator), same hierarchy, one rank
         c = [alloc(lv, dl, 1, 1) for lv, dl in zip(H.levels, dls)]
         sol = [alloc(lv, dl, 1, 1) for lv, dl in zip(H.levels, dls)]

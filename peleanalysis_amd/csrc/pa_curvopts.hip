@@ -121,13 +121,32 @@ struct OptArgs {
   int ucomp, pc, nc, kgc, src, vnc, rostc;
   double thr;
 };
-template <bool GAUSS, bool STRAIN, bool VELN>
-__global__ __launch_bounds__(256) void k_curvopts(OptArgs A) {
+// Tiles: TY wavefronts per workgroup, one row of 64 cells each (boxes at most 32 wide: two rows of 32), marching kz planes.  A
+// tile re-reads one row above and below and one plane before and after its own: 64 x 4 x 16 tiles fetched 117 B per cell where
+// 80 are needed (rocprofv3 FETCH_SIZE, nothing of the halo came from the L2), which is what the time followed -- so the tiles
+// are tall, and the tiles of one (x, z) column are consecutive workgroups of ONE XCD (workgroup i runs on XCD i mod 8): the rows
+// two neighbours share are fetched by both at about the same time.
+template <bool GAUSS, bool STRAIN, bool VELN, int TY>
+__global__ __launch_bounds__(64 * TY, TY <= 8 ? 2 : 1) void k_curvopts(OptArgs A, int kz) {
   const int b = blockIdx.y;
   if (b >= A.L.nboxes) return;
   const DBox V = A.L.boxes[b];
   int i, j, k0, k1;
-  if (!tile_cell(V, i, j, k0, k1)) return;
+  {
+    const int nx = V.hi[0] - V.lo[0] + 1, ny = V.hi[1] - V.lo[1] + 1, nz = V.hi[2] - V.lo[2] + 1;
+    const bool narrow = nx <= 32;
+    const int TX = narrow ? 32 : 64, rows = narrow ? 2 * TY : TY;
+    const int tx = (nx + TX - 1) / TX, ty = (ny + rows - 1) / rows, tz = (nz + kz - 1) / kz;
+    const unsigned q = blockIdx.x & 7u, m = blockIdx.x >> 3;
+    const int col = (int)(q + 8u * (m / (unsigned)ty)), by = (int)(m % (unsigned)ty);
+    if (col >= tx * tz) return;
+    const int bx = col % tx, bz = col / tx;
+    i = V.lo[0] + bx * TX + (narrow ? (threadIdx.x & 31) : (threadIdx.x & 63));
+    j = V.lo[1] + by * rows + (narrow ? (threadIdx.x >> 5) : (threadIdx.x >> 6));
+    k0 = V.lo[2] + bz * kz;
+    k1 = min(k0 + kz - 1, V.hi[2]);
+    if (i > V.hi[0] || j > V.hi[1]) return;
+  }
   const FabView G = mf_view(A.G, V, b), U = mf_view(A.U, V, b), O = mf_view(A.O, V, b);
   const double dx0 = A.L.dxinv[0], dx1 = A.L.dxinv[1], dx2 = A.L.dxinv[2];
   const double thr = A.thr;
@@ -229,13 +248,25 @@ int pa_curvopts_level(pa_ctx* ctx, int which, const pa_mf* G, const pa_mf* u, in
   if (pc < 0 || nc < 0 || hi >= out->ncomp) return pa_fail(ctx, "pa_curvopts_level: out component range");
   if (L->boxes.empty() || !(which & 7)) return 0;
   OptArgs A{L->view, (which & 1) ? G->view : out->view, (which & 6) ? u->view : out->view, out->view, ucomp, pc, nc, kgc, src, vnc, (which & 2) ? rostc : -1, thr};
-  const dim3 g = tile_grid(L);
+  const char* tye = getenv("PA_OPT_TY");  // read per call (A/B): rows of 64 cells per workgroup
+  const char* kze = getenv("PA_OPT_KZ");
+  const int TY = tye ? atoi(tye) : 4, kz = std::max(1, kze ? atoi(kze) : 64);  // measured: 4 x 64 17.65 ms per headline pass, 8 x 64 18.0 (spills under 128 VGPRs), 16 x 64 25.3
+  unsigned gx = 8;
+  for (const DBox& B : L->boxes) {
+    const int nx = B.hi[0] - B.lo[0] + 1, ny = B.hi[1] - B.lo[1] + 1, nz = B.hi[2] - B.lo[2] + 1;
+    const int TX = nx <= 32 ? 32 : 64, rows = nx <= 32 ? 2 * TY : TY;
+    const unsigned ncol = (unsigned)(((nx + TX - 1) / TX) * ((nz + kz - 1) / kz)), ty = (unsigned)((ny + rows - 1) / rows);
+    gx = std::max(gx, 8u * ((ncol + 7u) / 8u) * ty);
+  }
+  const dim3 g(gx, (unsigned)L->boxes.size());
+#define PA_OPT(W, T) hipLaunchKernelGGL((k_curvopts<(W & 1) != 0, (W & 2) != 0, (W & 4) != 0, T>), g, dim3(64 * T), 0, ctx->stream, A, kz)
+#define PA_OPTW(W) case W: if (TY == 4) PA_OPT(W, 4); else if (TY == 16) PA_OPT(W, 16); else PA_OPT(W, 8); break;
   switch (which & 7) {
-#define PA_OPT(W) case W: hipLaunchKernelGGL((k_curvopts<(W & 1) != 0, (W & 2) != 0, (W & 4) != 0>), g, dim3(256), 0, ctx->stream, A); break;
-    PA_OPT(1) PA_OPT(2) PA_OPT(3) PA_OPT(4) PA_OPT(5) PA_OPT(6) PA_OPT(7)
-#undef PA_OPT
+    PA_OPTW(1) PA_OPTW(2) PA_OPTW(3) PA_OPTW(4) PA_OPTW(5) PA_OPTW(6) PA_OPTW(7)
     default: break;
   }
+#undef PA_OPTW
+#undef PA_OPT
   PA_HIP(hipGetLastError());
   return 0;
 }

@@ -28,6 +28,7 @@ int pa_gauss_curv_level(pa_ctx* ctx, const pa_mf* G, int gcomp, const pa_mf* nor
                         int kcomp);
 int pa_strain_level(pa_ctx* ctx, const pa_mf* u, int ucomp, pa_mf* out, int srcomp, int rostcomp);
 int pa_velnormal_level(pa_ctx* ctx, const pa_mf* u, int ucomp, const pa_mf* n, int ncomp0, const pa_mf* c, int ccomp, double thr, pa_mf* out, int ocomp);
+int pa_apply_bc_multi(pa_ctx* ctx, int nlev, pa_mf* const* F1, int comp1, int ncomp1, pa_mf* const* F2, int comp2, int ncomp2, const int32_t bc[3]);
 int pa_curvopts_level(pa_ctx* ctx, int which, const pa_mf* G, const pa_mf* u, int ucomp, pa_mf* out, int pc, int nc, int kgc, int src, int vnc, int rostc, double thr);
 
 int pa_gradcurv_faces_phase(pa_ctx* ctx, const pa_mf* c, int ccomp, const pa_mf* crse_n, int cncomp0, const int32_t bc[3], int ratio, double thr,
@@ -611,15 +612,22 @@ static int curvature_fast(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, 
     if (!G[l]) return 1;
   }
   PA_TRY(exact_passes(ctx, nlev, state, comp, bc, pmin, pmax, thr, out, opt, G.data()));  // :316-322, 426-570
-  if (gauss) {  // :575-613: ghost cells of G = cell_normal before its normalisation; coarse-fine values from the coarser level's G
-    PA_TRY(pa_fill_boundary_local_batch(ctx, nlev, G.data(), 0, 3, 1));
-    for (int l = 0; l < nlev; ++l)
-      for (int d = 0; d < 3; ++d) PA_TRY(pa_apply_bc(ctx, G[l], d, l > 0 ? G[l - 1] : nullptr, d, bc, 2, -1));
-  }
-  if (strain) {  // :679-757
-    PA_TRY(pa_fill_boundary_local_batch(ctx, nlev, state, P->vel_comp, 3, 1));
-    for (int l = 0; l < nlev; ++l)
-      for (int d = 0; d < 3; ++d) PA_TRY(pa_apply_bc(ctx, state[l], P->vel_comp + d, l > 0 ? state[l - 1] : nullptr, P->vel_comp + d, bc, 2, -1));
+  // :575-613 ghost cells of G = cell_normal before its normalisation, coarse-fine values from the coarser level's G; :679-757 the
+  // velocity's likewise: FillBoundary of all levels in one launch each, applyBC of both fields on all levels in ONE launch
+  if (gauss) PA_TRY(pa_fill_boundary_local_batch(ctx, nlev, G.data(), 0, 3, 1));
+  if (strain) PA_TRY(pa_fill_boundary_local_batch(ctx, nlev, state, P->vel_comp, 3, 1));
+  if (gauss || strain) {
+    pa_mf* const* F1 = gauss ? G.data() : state;
+    const int c1 = gauss ? 0 : P->vel_comp;
+    const char* bme = getenv("PA_BC_MULTI");  // 0 (read per call): a launch per level and component
+    int rc = (nlev <= PA_MAXB && !(bme && !atoi(bme))) ? pa_apply_bc_multi(ctx, nlev, F1, c1, 3, (gauss && strain) ? state : nullptr, P->vel_comp, 3, bc) : 2;
+    if (rc == 1) return 1;
+    if (rc == 2) {
+      for (int l = 0; l < nlev && gauss; ++l)
+        for (int d = 0; d < 3; ++d) PA_TRY(pa_apply_bc(ctx, G[l], d, l > 0 ? G[l - 1] : nullptr, d, bc, 2, -1));
+      for (int l = 0; l < nlev && strain; ++l)
+        for (int d = 0; d < 3; ++d) PA_TRY(pa_apply_bc(ctx, state[l], P->vel_comp + d, l > 0 ? state[l - 1] : nullptr, P->vel_comp + d, bc, 2, -1));
+    }
   }
   const int which = (gauss ? 1 : 0) | (strain ? 2 : 0) | (veln ? 4 : 0);
   for (int l = 0; l < nlev && which; ++l)
