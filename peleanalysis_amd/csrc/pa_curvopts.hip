@@ -115,23 +115,36 @@ __global__ __launch_bounds__(256) void k_velnormal(BP3 bp, int ucomp, int ncomp0
 // differentiated components ride in registers (one new plane per step), x / y neighbours come from the cache.  Same
 // operations in the same order as k_gauss_curv / k_strain / k_velnormal above (normgrad is formed again from G's centre value
 // with the expression of pa_normal_level: its sign drops out of normgrad^4).  c for the threshold = the Progress component of out.
+// x-neighbours from the neighbouring LANES (the centre values of a plane are in registers anyway): DPP wavefront shifts instead
+// of two more loads per component -- the three stencil kernels above run at 3-4 TB/s of real traffic, bound by their 21 load
+// instructions per cell, not by HBM.  Only the first / last lane of a row still loads (a neighbouring tile's or a ghost cell).
+__device__ __forceinline__ double lane_from_left(double v) {  // lane n <- lane n - 1
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xF, 0xF, false);  // wave_shr:1
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_from_right(double v) {  // lane n <- lane n + 1
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xF, 0xF, false);  // wave_shl:1
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
 struct OptArgs {
   DLevelView L;
   DMFView G, U, O;
   int ucomp, pc, nc, kgc, src, vnc, rostc;
   double thr;
 };
-// Tiles: TY wavefronts per workgroup, one row of 64 cells each (boxes at most 32 wide: two rows of 32), marching kz planes.  A
-// tile re-reads one row above and below and one plane before and after its own: 64 x 4 x 16 tiles fetched 117 B per cell where
-// 80 are needed (rocprofv3 FETCH_SIZE, nothing of the halo came from the L2), which is what the time followed -- so the tiles
-// are tall, and the tiles of one (x, z) column are consecutive workgroups of ONE XCD (workgroup i runs on XCD i mod 8): the rows
-// two neighbours share are fetched by both at about the same time.
+// Tiles: TY wavefronts per workgroup, one row of 64 cells each (boxes at most 32 wide: two rows of 32), marching kz planes; the
+// tiles of one (x, z) column are consecutive workgroups of ONE XCD (workgroup i runs on XCD i mod 8).  Default 4 rows x 64 planes.
 template <bool GAUSS, bool STRAIN, bool VELN, int TY>
-__global__ __launch_bounds__(64 * TY, TY <= 8 ? 2 : 1) void k_curvopts(OptArgs A, int kz) {
+__global__ __launch_bounds__(64 * TY, TY >= 8 ? 4 : 1) void k_curvopts(OptArgs A, int kz) {
   const int b = blockIdx.y;
   if (b >= A.L.nboxes) return;
   const DBox V = A.L.boxes[b];
   int i, j, k0, k1;
+  bool ledge, redge;  // this lane's x-neighbour is not held by the lane next to it
   {
     const int nx = V.hi[0] - V.lo[0] + 1, ny = V.hi[1] - V.lo[1] + 1, nz = V.hi[2] - V.lo[2] + 1;
     const bool narrow = nx <= 32;
@@ -146,7 +159,14 @@ __global__ __launch_bounds__(64 * TY, TY <= 8 ? 2 : 1) void k_curvopts(OptArgs A
     k0 = V.lo[2] + bz * kz;
     k1 = min(k0 + kz - 1, V.hi[2]);
     if (i > V.hi[0] || j > V.hi[1]) return;
+    const int lw = (int)threadIdx.x & (TX - 1);
+    ledge = lw == 0;
+    redge = lw == TX - 1 || i == V.hi[0];
   }
+  // (Measured and not kept, profiles/r05_curvopts.txt: rows of 8 / 16 per workgroup, and the y-neighbours handed from wave to wave
+  // through LDS with one barrier per plane instead of loaded again -- FETCH_SIZE is 1.5-1.9 x the bytes needed because a row's
+  // values of plane k, loaded one step earlier as centre values, have left the L2 by the time the rows next to it want them --
+  // both correct, both slower: 18.8 against 17.6 ms per headline pass for the LDS form.)
   const FabView G = mf_view(A.G, V, b), U = mf_view(A.U, V, b), O = mf_view(A.O, V, b);
   const double dx0 = A.L.dxinv[0], dx1 = A.L.dxinv[1], dx2 = A.L.dxinv[2];
   const double thr = A.thr;
@@ -173,7 +193,10 @@ __global__ __launch_bounds__(64 * TY, TY <= 8 ? 2 : 1) void k_curvopts(OptArgs A
       for (int d = 0; d < 3; ++d) {
         const double* q = gp + d * G.sc;
         const double nxt = q[gps];
-        H[d][0] = cdiff(dx0, q[-1], gc[d], q[1]);
+        double xl = lane_from_left(gc[d]), xr = lane_from_right(gc[d]);
+        if (ledge) xl = q[-1];
+        if (redge) xr = q[1];
+        H[d][0] = cdiff(dx0, xl, gc[d], xr);
         H[d][1] = cdiff(dx1, q[-G.nx], gc[d], q[G.nx]);
         H[d][2] = cdiff(dx2, gm[d], gc[d], nxt);
         gm[d] = nxt;  // holds plane k + 1 until the swap below
@@ -216,7 +239,10 @@ __global__ __launch_bounds__(64 * TY, TY <= 8 ? 2 : 1) void k_curvopts(OptArgs A
       for (int d = 0; d < 3; ++d) {
         const double* q = up + d * U.sc;
         const double nxt = q[ups];
-        gu[3 * d + 0] = cdiff(dx0, q[-1], uc[d], q[1]);
+        double xl = lane_from_left(uc[d]), xr = lane_from_right(uc[d]);
+        if (ledge) xl = q[-1];
+        if (redge) xr = q[1];
+        gu[3 * d + 0] = cdiff(dx0, xl, uc[d], xr);
         gu[3 * d + 1] = cdiff(dx1, q[-U.nx], uc[d], q[U.nx]);
         gu[3 * d + 2] = cdiff(dx2, um[d], uc[d], nxt);
         um[d] = uc[d];

@@ -630,8 +630,18 @@ static int curvature_fast(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, 
     }
   }
   const int which = (gauss ? 1 : 0) | (strain ? 2 : 0) | (veln ? 4 : 0);
-  for (int l = 0; l < nlev && which; ++l)
-    PA_TRY(pa_curvopts_level(ctx, which, G[l], state[l], P->vel_comp, out[l], opt, opt + 2, opt + 5, opt + 6, opt + 7, P->get_strain_tensor ? opt + 8 : -1, thr));
+  // the Gaussian curvature apart from strain + normal velocity: 80 and 118 VGPRs against 158 for all three in one kernel, c read twice;
+  // 17.1 against 17.6 ms per headline pass (PA_OPT_SPLIT=0, read per call: one kernel)
+  const char* spe = getenv("PA_OPT_SPLIT");
+  const bool split = !(spe && !atoi(spe)) && (which & 1) && (which & 6);
+  for (int l = 0; l < nlev && which; ++l) {
+    if (split) {
+      PA_TRY(pa_curvopts_level(ctx, 1, G[l], state[l], P->vel_comp, out[l], opt, opt + 2, opt + 5, opt + 6, opt + 7, -1, thr));
+      PA_TRY(pa_curvopts_level(ctx, which & 6, G[l], state[l], P->vel_comp, out[l], opt, opt + 2, opt + 5, opt + 6, opt + 7, P->get_strain_tensor ? opt + 8 : -1, thr));
+    } else {
+      PA_TRY(pa_curvopts_level(ctx, which, G[l], state[l], P->vel_comp, out[l], opt, opt + 2, opt + 5, opt + 6, opt + 7, P->get_strain_tensor ? opt + 8 : -1, thr));
+    }
+  }
   return 0;
 }
 
