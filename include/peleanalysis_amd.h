@@ -458,7 +458,12 @@ typedef struct {
  * (ng>=2; with do_strain the velocity components get their ghost cells filled in place).
  * out[lev] comps: ocomp+0 Progress, +1 MeanCurvature, +2..4 FlameNormal, and when requested
  * +5 GaussianCurvature, +6 StrainRate, +7 VelFlameNormal, +8..16 ROST_dU?d? (row-major grad u), and with
- * do_smooth +17 SmoothedProgress. */
+ * do_smooth +17 SmoothedProgress.
+ * Two implementations with identical results (bit for bit; both tested against the oracle): fused != 0 on one rank, 3-D, without
+ * do_smooth, boxes >= 3 cells thick: Progress / MeanCurvature / FlameNormal from the exact-normal pipeline of pa_gradcurv_run, whose
+ * sweeps leave the cell-centred gradient of c (curvature.cpp:457-490, what do_gaussCurv differentiates again at :582-613) in a work
+ * multifab of the level (3 components + 1 ghost layer, kept for the level's lifetime) instead of grad phi, then one pass per level
+ * for the options; otherwise (or PA_CURV_FAST=0 in the environment) one pass per AMReX call of the reference. */
 int pa_curvature_run(pa_ctx*, int nlev, pa_mf* const* state, int comp, const int32_t bc[3],
                      const pa_curv_params*, pa_mf* const* out, int ocomp);
 /* curvature.cpp:328-406: (I - dt Lap) sol = rhs[rcomp] as a composite solve over the levels (periodic /
