@@ -481,6 +481,10 @@ int pa_smooth_solve(pa_ctx*, int nlev, pa_mf* const* rhs, int rcomp, pa_mf* cons
  * with setVerbose(1), curvature.cpp:396-399, which prints its iteration count and residuals; the tool prints these).  Non-zero
  * when no such solve has run on the context. */
 int pa_smooth_last(const pa_ctx*, int* iters, double* rel_residual);
+/* which implementation the last pa_curvature_run on the context took: 1 = the exact-normal pipeline's G-output sweeps + one options
+ * pass per level, 0 = one kernel per AMReX call (fused = 0, do_smooth, 2-D levels, boxes thinner than 3 cells, or a hierarchy the
+ * all-levels sweeps do not take; on a sharded hierarchy the ranks agree on one answer), -1 = none yet.  Diagnostic (tests, bench.py). */
+int pa_curvature_last_path(const pa_ctx*);
 /* fused grad+curvature of one variable: out[lev] comps ocomp+0..3 = gx,gy,gz,|g|,
  * +4..6 FlameNormal, +7 MeanCurvature.  work[lev]: scratch mf, 1 comp, ng=2. */
 int pa_gradcurv_run(pa_ctx*, int nlev, pa_mf* const* state, int comp, const int32_t bc[3],

@@ -1516,14 +1516,8 @@ bool pa_gradcurv_gout_ok(int nlev, pa_mf* const* phi) {
   if (!batch_env || knobs || !narrow_env || fused_order() != 2) return false;
   std::vector<SweepGroup> all;
   for (int l = 0; l < nlev; ++l) sweep_groups(l, phi[l]->lev, all);
-  int nw = 0, nn = 0, mty = 0;
-  for (const SweepGroup& g : all) {
-    if (g.dims[0] <= 32) { ++nn; continue; }
-    const int m = g.dims[1] >= 52 ? 13 : (g.dims[1] >= 16 ? 8 : 4);
-    if (mty && m != mty) return false;
-    mty = m;
-    ++nw;
-  }
+  int nw = 0, nn = 0;
+  for (const SweepGroup& g : all) ++(g.dims[0] <= 32 ? nn : nw);
   return nw <= PA_MAXB && nn <= PA_MAXB;
 }
 
@@ -1548,12 +1542,21 @@ int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, d
   // (Round 5, measured and not kept: tiles of 11 or 12 rows on BoxArrays whose boxes are 32 or 96 rows tall -- 13 + 13 + 6 rows
   // leave a fifth of the row slots idle -- took 7.52 against 7.41 ms per pass on the re-tiled irregular hierarchy: idle ROWS cost
   // nothing, a partly filled 64-cell tile in x does; profiles/r05_retile.txt.)
-  const bool ok = batch_env && !knobs && fused_order() == 2 && !lv.empty() && (int)lv.size() <= PA_MAXB && same;
+  // groups of different tile heights (a level of flat boxes next to one of tall ones): one launch per tile height (until round 5's
+  // second session such a hierarchy went group by group, a launch each)
+  (void)same;
+  const bool ok = batch_env && !knobs && fused_order() == 2 && !lv.empty() && (int)lv.size() <= PA_MAXB;
   if (!ok) {
     rest.insert(rest.begin(), lv.begin(), lv.end());
     lv.clear();
   }
-  if (!lv.empty()) {
+  const std::vector<SweepGroup> lv_all = lv;
+  for (const int mty_pass : {13, 8, 4}) {
+    std::vector<SweepGroup> lv;
+    for (const SweepGroup& g : lv_all)
+      if ((g.dims[1] >= 52 ? 13 : (g.dims[1] >= 16 ? 8 : 4)) == mty_pass) lv.push_back(g);
+    if (lv.empty()) continue;
+    const int mty = mty_pass;
     SweepBatch S;
     S.n = (int)lv.size();
     S.wg0[0] = 0;

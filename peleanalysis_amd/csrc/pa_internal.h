@@ -104,6 +104,7 @@ struct pa_ctx {
   std::string sweep_kernel;  // variant of the fused sweep launched last (pa_sweep_kernel_name)
   int smooth_iters = -1;     // the last do_smooth solve of pa_curvature_run (pa_smooth_last): iterations, relative residual
   double smooth_res = 0.0;
+  int curv_path = -1;        // implementation of the last pa_curvature_run (pa_curvature_last_path)
   pa_comm comm = {nullptr, 0, 1, nullptr, nullptr};
   struct RcclState* rccl = nullptr;
 };

@@ -259,8 +259,11 @@ static int fused_pre(pa_ctx* ctx, int l, pa_mf* const* state, int comp, const in
 //   B  the coarse flame normal under those faces, once the normals of the coarser level are final (curvature.cpp:514-518)
 // with the ghost preparation + sweeps (+ layer-1 normals in the first pipeline) between them and the face curvature after
 // B.  In the exact-normal pipeline B is split per level and overlapped with the sweeps (nlev exchanges, two exposed).
+// gout (exact only; pa_curvature_run's fast path): the G-output sweeps -- [Progress K Nx Ny Nz] at ocomp .. ocomp + 4, G in gout[l]
 static int fused_passes_dist(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, const int32_t bc[3], double pmin, double pmax, double thr,
-                             pa_mf* const* work, pa_mf* const* out, int ocomp, bool exact) {
+                             pa_mf* const* work, pa_mf* const* out, int ocomp, bool exact, pa_mf* const* gout = nullptr) {
+  const int ncomp0 = gout ? ocomp + 2 : ocomp + 4, kcomp = gout ? ocomp + 1 : ocomp + 7;
+  if (gout && !exact) return pa_fail(ctx, "fused_passes_dist: the G-output sweeps belong to the exact-normal pipeline");
   std::vector<XJob> jobs;
   std::vector<CsPlan*> cs(nlev, nullptr);
   std::vector<pa_mf*> csphi(nlev, nullptr), csn(nlev, nullptr);
@@ -343,9 +346,9 @@ static int fused_passes_dist(pa_ctx* ctx, int nlev, pa_mf* const* state, int com
       // 0.97 ms per pass against 1.08 / 1.05 with the split (two launches' tails + the pack / unpack kernels next to the
       // sweep): it pays only where exchange B takes longer than ~0.05-0.09 ms on the fabric, which one GPU cannot tell.
       const bool split = dsb >= 2 && xov && nlev >= 2;
-      PA_TRY(pa_gradcurv_levels_cg(ctx, split ? nlev - 1 : nlev, state, comp, pmin, pmax, out, ocomp, thr));
+      PA_TRY(pa_gradcurv_levels_cg(ctx, split ? nlev - 1 : nlev, state, comp, pmin, pmax, out, ocomp, thr, 0, 1, nullptr, nullptr, nullptr, gout));
       std::vector<XJob> nj;
-      for (int l = 1; l < nlev; ++l) nj.push_back({&cs[l]->x, out[l - 1], ocomp + 4, csn[l], 0, 3});
+      for (int l = 1; l < nlev; ++l) nj.push_back({&cs[l]->x, out[l - 1], ncomp0, csn[l], 0, 3});
       if (split) {
         PA_HIP(hipEventRecord(ctx->sync_evs[3], A));
         PA_HIP(hipStreamWaitEvent(C, ctx->sync_evs[3], 0));
@@ -355,8 +358,9 @@ static int fused_passes_dist(pa_ctx* ctx, int nlev, pa_mf* const* state, int com
         ProfScope prof(ctx, PA_TAG_XCHG);
         PA_TRY(pa_xexchange(ctx, (int)nj.size(), nj.data()));
       }
-      if (split) PA_TRY(pa_gradcurv_levels_cg(ctx, 1, state + (nlev - 1), comp, pmin, pmax, out + (nlev - 1), ocomp, thr));
+      if (split) PA_TRY(pa_gradcurv_levels_cg(ctx, 1, state + (nlev - 1), comp, pmin, pmax, out + (nlev - 1), ocomp, thr, 0, 1, nullptr, nullptr, nullptr, gout ? gout + (nlev - 1) : nullptr));
     }
+    if (gout && !dsb) return pa_fail(ctx, "fused_passes_dist: the G-output sweeps need the all-levels launch (PA_DIST_SWEEP_BATCH != 0)");
     for (int l = 0; l < nlev && !dsb; ++l) {
       PA_TRY(pa_gradcurv_level_cg(ctx, state[l], comp, pmin, pmax, out[l], ocomp, thr));
       if (l + 1 < nlev) {  // the coarse normals level l+1 needs: every rank takes part, whatever it owns
@@ -374,7 +378,7 @@ static int fused_passes_dist(pa_ctx* ctx, int nlev, pa_mf* const* state, int com
       PA_HIP(hipEventRecord(ctx->sync_evs[2], C));
       PA_HIP(hipStreamWaitEvent(A, ctx->sync_evs[2], 0));
     }
-    PA_TRY(pa_gradcurv_fix_levels(ctx, nlev, state, comp, crse_n.data(), 0, bc, pmin, pmax, out, ocomp + 4, ocomp + 7, thr, 1, nullptr, 8, crse.data(), 0));
+    PA_TRY(pa_gradcurv_fix_levels(ctx, nlev, state, comp, crse_n.data(), 0, bc, pmin, pmax, out, ncomp0, kcomp, thr, 1, nullptr, 8, crse.data(), 0));
     return 0;
   }
   {
@@ -611,16 +615,23 @@ static int curvature_fast(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, 
     G[l] = pa_level_scratch(ctx, state[l]->lev, 3, 1);
     if (!G[l]) return 1;
   }
-  PA_TRY(exact_passes(ctx, nlev, state, comp, bc, pmin, pmax, thr, out, opt, G.data()));  // :316-322, 426-570
+  const bool dist = state[0]->lev->nranks > 1;  // sharded hierarchy: the same pipeline with its two exchanges, ghost fills below across ranks
+  if (dist) PA_TRY(fused_passes_dist(ctx, nlev, state, comp, bc, pmin, pmax, thr, state, out, opt, true, G.data()));
+  else PA_TRY(exact_passes(ctx, nlev, state, comp, bc, pmin, pmax, thr, out, opt, G.data()));  // :316-322, 426-570
   // :575-613 ghost cells of G = cell_normal before its normalisation, coarse-fine values from the coarser level's G; :679-757 the
   // velocity's likewise: FillBoundary of all levels in one launch each, applyBC of both fields on all levels in ONE launch
-  if (gauss) PA_TRY(pa_fill_boundary_local_batch(ctx, nlev, G.data(), 0, 3, 1));
-  if (strain) PA_TRY(pa_fill_boundary_local_batch(ctx, nlev, state, P->vel_comp, 3, 1));
+  if (dist) {  // every rank makes the same calls in the same order (pa_fill_boundary / pa_apply_bc exchange inside)
+    for (int l = 0; l < nlev && gauss; ++l) PA_TRY(pa_fill_boundary(ctx, G[l], 0, 3, 1));
+    for (int l = 0; l < nlev && strain; ++l) PA_TRY(pa_fill_boundary(ctx, state[l], P->vel_comp, 3, 1));
+  } else {
+    if (gauss) PA_TRY(pa_fill_boundary_local_batch(ctx, nlev, G.data(), 0, 3, 1));
+    if (strain) PA_TRY(pa_fill_boundary_local_batch(ctx, nlev, state, P->vel_comp, 3, 1));
+  }
   if (gauss || strain) {
     pa_mf* const* F1 = gauss ? G.data() : state;
     const int c1 = gauss ? 0 : P->vel_comp;
     const char* bme = getenv("PA_BC_MULTI");  // 0 (read per call): a launch per level and component
-    int rc = (nlev <= PA_MAXB && !(bme && !atoi(bme))) ? pa_apply_bc_multi(ctx, nlev, F1, c1, 3, (gauss && strain) ? state : nullptr, P->vel_comp, 3, bc) : 2;
+    int rc = (!dist && nlev <= PA_MAXB && !(bme && !atoi(bme))) ? pa_apply_bc_multi(ctx, nlev, F1, c1, 3, (gauss && strain) ? state : nullptr, P->vel_comp, 3, bc) : 2;
     if (rc == 1) return 1;
     if (rc == 2) {
       for (int l = 0; l < nlev && gauss; ++l)
@@ -664,6 +675,8 @@ static bool exact_ok(int nlev, pa_mf* const* state, double thr) {
   return exact;
 }
 
+extern "C" int pa_curvature_last_path(const pa_ctx* ctx) { return ctx ? ctx->curv_path : -1; }
+
 extern "C" int pa_smooth_last(const pa_ctx* ctx, int* iters, double* rel_residual) {
   if (!ctx || ctx->smooth_iters < 0) return 1;
   if (iters) *iters = ctx->smooth_iters;
@@ -689,9 +702,16 @@ extern "C" int pa_curvature_run(pa_ctx* ctx, int nlev, pa_mf* const* state, int 
   // smoothing solve, a hierarchy the all-levels sweeps take; PA_CURV_FAST=0 (read per call) or fused = 0: pass by pass.
   {
     const char* cfe = getenv("PA_CURV_FAST");
-    bool fast = P->fused && P->spacedim != 2 && !P->do_smooth && (!cfe || atoi(cfe)) && state[0]->lev->nranks == 1;
-    for (int l = 0; l < nlev && fast; ++l) fast = state[l]->ng >= 2 && !state[l]->lev->boxes.empty();
+    const bool dist = state[0]->lev->nranks > 1;
+    bool fast = P->fused && P->spacedim != 2 && !P->do_smooth && (!cfe || atoi(cfe));
+    for (int l = 0; l < nlev && fast; ++l) fast = state[l]->ng >= 2 && (dist || !state[l]->lev->boxes.empty());
     fast = fast && exact_ok(nlev, state, thr) && pa_gradcurv_gout_ok(nlev, state);
+    if (dist) {  // the answer depends on the boxes a rank owns: all ranks take the path every one of them can take
+      double v = fast ? 1.0 : 0.0;
+      PA_TRY(pa_allreduce(ctx, &v, 1, 0));
+      fast = v > 0.5;
+    }
+    ctx->curv_path = fast ? 1 : 0;
     if (fast) return curvature_fast(ctx, nlev, state, comp, bc, pmin, pmax, thr, out, ocomp, P);
   }
   return curvature_passes(ctx, nlev, state, comp, bc, pmin, pmax, thr, out, ocomp, ocomp + 1, ocomp + 2, P, ocomp, P->spacedim == 2 ? 1.0 : 0.5);

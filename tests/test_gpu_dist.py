@@ -146,12 +146,19 @@ def _worker(rank, world, port, case, transport="gloo"):
                 for i in range(len(dl.gids)):
                     assert _same(mfs[l].valid(i)[oc_:oc_ + 8], seen[c][l].valid(i)[0:8]), f"rank {rank}/{world} run_comps2: component {c} level {l} box {i}"
         # the curvature tool's pipeline with every option (Hessian rows and velocity need their own coarse data)
-        out = [capi.DevMF(ctx, dl, 17, 0) for dl in dls]
-        capi.curvature_run(ctx, lst, 0, bc, capi.curv_params(threshold=thr, fused=False, do_gauss=True, do_strain=True, strain_tensor=True, do_velnormal=True,
-                                                            vel_comp=1), out, 0)
-        ctx.sync()
-        assert ctx.bc_errors() == 0
-        check(out, {c: (oc, c) for c in range(17)}, "curvature_run with options")
+        # (fused=False: pass by pass; fused=True: the sharded exact-normal pipeline's G-output sweeps + one options pass per level where
+        # every rank's share takes it -- the ranks agree on the path through one reduction)
+        for fused in (False, True):
+            out = [capi.DevMF(ctx, dl, 17, 0) for dl in dls]
+            capi.curvature_run(ctx, lst, 0, bc, capi.curv_params(threshold=thr, fused=fused, do_gauss=True, do_strain=True, strain_tensor=True, do_velnormal=True,
+                                                                vel_comp=1), out, 0)
+            ctx.sync()
+            assert ctx.bc_errors() == 0
+            check(out, {c: (oc, c) for c in range(17)}, f"curvature_run with options, fused {fused}")
+            path = ctx.lib.pa_curvature_last_path(ctx.h)
+            assert path == 0 if not fused else path in (0, 1)
+            if fused and case in ("wide", "thr", "sym", "sfc", "scatter"):  # nested hierarchies: every rank's share takes the all-levels sweeps
+                assert path == 1, f"rank {rank}/{world} case {case}: the sharded options pass fell back to the pass-by-pass kernels"
         # the gradient tool's pipeline
         out = [capi.DevMF(ctx, dl, 4, 0) for dl in dls]
         capi.grad_run(ctx, lst, 0, bc, out, 0)

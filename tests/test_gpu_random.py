@@ -232,7 +232,7 @@ def test_random_wide_box_curvature_options_fast_path(ctx, oracle, seed, which):
     ctx.sync()
     assert ctx.bc_errors() == 0
     kn = ctx.lib.pa_sweep_kernel_name(ctx.h).decode()
-    assert "_levels<" in kn, kn
+    assert "_levels<" in kn and ctx.lib.pa_curvature_last_path(ctx.h) == 1, kn
     for l in range(H.nlev):
         got = dout[l].download()
         assert_valid_bits_equal(got, oout[l], [(c, c) for c in comps], f"wide seed {seed} options {which} level {l}")

@@ -918,6 +918,8 @@ def _tree_bytes(path):
     ("curvature3d.ex", ["progressName=temp", "is_per=1 1 0", "Aux_Variables=density"], "_K"),
     ("curvature3d.ex", ["progressName=temp", "is_per=0 1 1", "sym_dir=1 0 0", "fused=0", "threshold_prog=1", "threshold_value=0.02", "do_gaussCurv=1",
                         "do_strain=1", "do_velnormal=1"], "_K"),
+    ("curvature3d.ex", ["progressName=temp", "is_per=0 1 1", "sym_dir=1 0 0", "threshold_prog=1", "threshold_value=0.02", "do_gaussCurv=1",
+                        "do_strain=1", "do_velnormal=1"], "_K"),
     ("curvature3d.ex", ["progressName=temp", "is_per=1 1 0", "do_smooth=1", "smoothing_time=1e-3"], "_K"),
     ("filterPlt3d.ex", ["max_grid_size=8", "is_per=1 1 0"], "_filtered"),
     ("filterPlt3d.ex", ["max_grid_size=8", "interp_type=0", "base_fgr=4", "same_fgr_all_levels=1"], "_filtered"),
