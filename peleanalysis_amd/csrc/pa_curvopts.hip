@@ -138,7 +138,7 @@ struct OptArgs {
 };
 // Tiles: TY wavefronts per workgroup, one row of 64 cells each (boxes at most 32 wide: two rows of 32), marching kz planes; the
 // tiles of one (x, z) column are consecutive workgroups of ONE XCD (workgroup i runs on XCD i mod 8).  Default 4 rows x 64 planes.
-template <bool GAUSS, bool STRAIN, bool VELN, int TY>
+template <bool GAUSS, bool STRAIN, bool VELN, int TY, bool YQ = true>
 __global__ __launch_bounds__(64 * TY, TY >= 8 ? 4 : 1) void k_curvopts(OptArgs A, int kz) {
   const int b = blockIdx.y;
   if (b >= A.L.nboxes) return;
@@ -171,6 +171,10 @@ __global__ __launch_bounds__(64 * TY, TY >= 8 ? 4 : 1) void k_curvopts(OptArgs A
   const double dx0 = A.L.dxinv[0], dx1 = A.L.dxinv[1], dx2 = A.L.dxinv[2];
   const double thr = A.thr;
   double gm[3] = {0, 0, 0}, gc[3] = {0, 0, 0}, um[3] = {0, 0, 0}, uc[3] = {0, 0, 0};
+  // y-neighbours of the CURRENT plane, requested one step earlier together with the centre value of that plane (YQ): the rows next
+  // door ask for the same lines as THEIR centre values in the same step, so the request meets them in the cache -- asked for a step
+  // later, as the neighbours of the plane being computed, they had left the L2 (FETCH_SIZE 1.5-1.9 x the bytes needed)
+  double gyl[3] = {0, 0, 0}, gyr[3] = {0, 0, 0}, uyl[3] = {0, 0, 0}, uyr[3] = {0, 0, 0};
   const long long gps = (long long)G.nx * G.ny, ups = (long long)U.nx * U.ny, ops = (long long)O.nx * O.ny;
   const double* gp = GAUSS ? G.p + G.idx(i, j, k0, 0) : nullptr;
   const double* up = (STRAIN || VELN) ? U.p + U.idx(i, j, k0, A.ucomp) : nullptr;
@@ -178,7 +182,9 @@ __global__ __launch_bounds__(64 * TY, TY >= 8 ? 4 : 1) void k_curvopts(OptArgs A
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
     if (GAUSS) { gm[d] = gp[d * G.sc - gps]; gc[d] = gp[d * G.sc]; }
+    if (GAUSS && YQ) { gyl[d] = gp[d * G.sc - G.nx]; gyr[d] = gp[d * G.sc + G.nx]; }
     if (STRAIN) um[d] = up[d * U.sc - ups];
+    if (STRAIN && YQ) { uyl[d] = up[d * U.sc - U.nx]; uyr[d] = up[d * U.sc + U.nx]; }
     if (STRAIN || VELN) uc[d] = up[d * U.sc];
   }
   for (int k = k0; k <= k1; ++k) {
@@ -197,7 +203,13 @@ __global__ __launch_bounds__(64 * TY, TY >= 8 ? 4 : 1) void k_curvopts(OptArgs A
         if (ledge) xl = q[-1];
         if (redge) xr = q[1];
         H[d][0] = cdiff(dx0, xl, gc[d], xr);
-        H[d][1] = cdiff(dx1, q[-G.nx], gc[d], q[G.nx]);
+        if (YQ) {
+          H[d][1] = cdiff(dx1, gyl[d], gc[d], gyr[d]);
+          gyl[d] = q[gps - G.nx];
+          gyr[d] = q[gps + G.nx];
+        } else {
+          H[d][1] = cdiff(dx1, q[-G.nx], gc[d], q[G.nx]);
+        }
         H[d][2] = cdiff(dx2, gm[d], gc[d], nxt);
         gm[d] = nxt;  // holds plane k + 1 until the swap below
       }
@@ -243,7 +255,13 @@ __global__ __launch_bounds__(64 * TY, TY >= 8 ? 4 : 1) void k_curvopts(OptArgs A
         if (ledge) xl = q[-1];
         if (redge) xr = q[1];
         gu[3 * d + 0] = cdiff(dx0, xl, uc[d], xr);
-        gu[3 * d + 1] = cdiff(dx1, q[-U.nx], uc[d], q[U.nx]);
+        if (YQ) {
+          gu[3 * d + 1] = cdiff(dx1, uyl[d], uc[d], uyr[d]);
+          uyl[d] = q[ups - U.nx];
+          uyr[d] = q[ups + U.nx];
+        } else {
+          gu[3 * d + 1] = cdiff(dx1, q[-U.nx], uc[d], q[U.nx]);
+        }
         gu[3 * d + 2] = cdiff(dx2, um[d], uc[d], nxt);
         um[d] = uc[d];
         uc[d] = nxt;
@@ -285,8 +303,10 @@ int pa_curvopts_level(pa_ctx* ctx, int which, const pa_mf* G, const pa_mf* u, in
     gx = std::max(gx, 8u * ((ncol + 7u) / 8u) * ty);
   }
   const dim3 g(gx, (unsigned)L->boxes.size());
-#define PA_OPT(W, T) hipLaunchKernelGGL((k_curvopts<(W & 1) != 0, (W & 2) != 0, (W & 4) != 0, T>), g, dim3(64 * T), 0, ctx->stream, A, kz)
-#define PA_OPTW(W) case W: if (TY == 4) PA_OPT(W, 4); else if (TY == 16) PA_OPT(W, 16); else PA_OPT(W, 8); break;
+  const char* yqe = getenv("PA_OPT_YQ");  // 0 (read per call, A/B): y-neighbours loaded with the plane they belong to
+  const bool yq = !(yqe && !atoi(yqe));
+#define PA_OPT(W, T, Y) hipLaunchKernelGGL((k_curvopts<(W & 1) != 0, (W & 2) != 0, (W & 4) != 0, T, Y>), g, dim3(64 * T), 0, ctx->stream, A, kz)
+#define PA_OPTW(W) case W: if (!yq) PA_OPT(W, 4, false); else if (TY == 4) PA_OPT(W, 4, true); else if (TY == 16) PA_OPT(W, 16, true); else PA_OPT(W, 8, true); break;
   switch (which & 7) {
     PA_OPTW(1) PA_OPTW(2) PA_OPTW(3) PA_OPTW(4) PA_OPTW(5) PA_OPTW(6) PA_OPTW(7)
     default: break;

@@ -1,7 +1,8 @@
+# FETCH_SIZE / WRITE_SIZE of the options kernels (k_curvopts) for a list of "YQ TY KZ" settings; bench.py's options entry under rocprofv3 --pmc
 export TMPDIR=/tmp
-for cfg in "0 4 64" "1 16 64" "0 4 16"; do set -- $cfg
+for cfg in "${@:-1 4 64}"; do set -- $cfg
   for C in FETCH_SIZE WRITE_SIZE; do
-    rm -rf /tmp/pp; PA_OPT_SPLIT=$1 PA_OPT_TY=$2 PA_OPT_KZ=$3 timeout -k 10 200 rocprofv3 --pmc $C --output-format csv -d /tmp/pp -- python3 bench.py --secondary-only f1_curvature_options_headline > /tmp/pp.log 2>&1
+    rm -rf /tmp/pp; PA_OPT_YQ=$1 PA_OPT_TY=$2 PA_OPT_KZ=$3 timeout -k 10 200 rocprofv3 --pmc $C --output-format csv -d /tmp/pp -- python3 bench.py --secondary-only f1_curvature_options_headline > /tmp/pp.log 2>&1
     python3 - "$cfg" $C <<'PY'
 import csv, glob, collections, sys
 agg = collections.defaultdict(list)
