@@ -586,7 +586,7 @@ def secondary(ctx, torch, stream, dev, only=None, retile=1):
                                                      workload="pa_curvature_run (curvature.cpp:283-789) with do_gaussCurv + do_strain + do_velnormal, 3-level base 512^3, "
                                                      "128^3 boxes in the file, progress source + 3 velocity components in, 8 fields out; " + tiling_txt(Hf, H) +
                                                      "; ms = the fast path (G-output sweeps + one options pass per level), pass_by_pass_ms = fused=0, the smaller of two "
-                                                     "single passes (that path allocates its work multifabs per call)")
+                                                     "single passes (one kernel per AMReX call of the reference)")
         if not want("f1_do_smooth_headline"):
             del ins, ous, dls
             torch.cuda.empty_cache()

@@ -391,11 +391,12 @@ CsPlan::~CsPlan() {
 pa_level::~pa_level() {
   for (auto& kv : scratch) pa_mf_destroy(kv.second);
 }
-pa_mf* pa_level_scratch(pa_ctx* ctx, const pa_level* L, int ncomp, int ng) {
-  auto it = L->scratch.find({ncomp, ng});
+pa_mf* pa_level_scratch(pa_ctx* ctx, const pa_level* L, int ncomp, int ng, int role) {
+  const std::array<int, 3> key{ncomp, ng, role};
+  auto it = L->scratch.find(key);
   if (it != L->scratch.end()) return it->second;
   pa_mf* m = pa_mf_create(ctx, L, ncomp, ng, nullptr);
-  if (m) L->scratch[{ncomp, ng}] = m;
+  if (m) L->scratch[key] = m;
   return m;
 }
 

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <array>
 #include <map>
 #include <memory>
 #include <string>
@@ -198,7 +199,7 @@ struct pa_level {
   mutable std::map<long long, std::unique_ptr<WgTab>> wgtabs;                           // sweep workgroup tables by (group, tile shape) (pa_fused.hip)
   mutable std::map<long long, std::unique_ptr<struct RsPlan>> rs_plans;                 // restriction onto a sharded coarse level, by coarse level serial (pa_dist.hip)
   mutable std::map<std::pair<long long, int>, std::unique_ptr<struct FpPlan>> fp_plans; // FillPatchTwoLevels parent lists by (coarse level serial, ghost width) (pa_filter.hip)
-  mutable std::map<std::pair<int, int>, struct pa_mf*> scratch;                         // work multifabs by (components, ghost width), kept for the level's lifetime (pa_level_scratch)
+  mutable std::map<std::array<int, 3>, struct pa_mf*> scratch;                          // work multifabs by (components, ghost width, role), kept for the level's lifetime (pa_level_scratch)
   ~pa_level();
 };
 
@@ -222,7 +223,8 @@ pa_level* pa_level_create_spec(pa_ctx* ctx, const LevelSpec& S, const int32_t do
 bool pa_face_is_special(const pa_level* L, const DBox& B, int d, int side);
 // a work multifab of the level that lives as long as the level does (contents undefined between calls): a 10-GB hipMalloc +
 // hipFree per call of pa_curvature_run cost more than the kernels it served
-struct pa_mf* pa_level_scratch(pa_ctx* ctx, const pa_level* L, int ncomp, int ng);
+// role: two work multifabs of the same shape that are alive at the same time take different roles
+struct pa_mf* pa_level_scratch(pa_ctx* ctx, const pa_level* L, int ncomp, int ng, int role = 0);
 const WgTab* pa_sweep_wgtab(const pa_level* L, int cls, int tw, int mty, int kseg, bool force);
 int pa_host_classify(const pa_level* L, int i, int j, int k);
 

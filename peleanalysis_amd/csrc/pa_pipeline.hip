@@ -157,7 +157,10 @@ static int prog_minmax(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, con
 static int curvature_passes(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, const int32_t bc[3], double pmin, double pmax,
                             double thr, pa_mf* const* out, int pc, int kc, int nc, const pa_curv_params* P = nullptr, int opt = -1,
                             double kscale = 0.5 /* curvature.cpp:542-546: 0.5 in the 3-D build, none (1.0, exact) in the 2-D build */) {
-  std::vector<MFPtr> cmf(nlev), nmf(nlev), gmf(nlev), ngmf(nlev);
+  // work multifabs of the level, kept for its lifetime (pa_level_scratch; until round 5 a hipMalloc + hipFree of up to 8 components
+  // per level and call -- a call that did not get the previous call's blocks back took 0.8 s instead of 50 ms at the headline size);
+  // every cell that is read is written first in each call
+  std::vector<pa_mf*> cmf(nlev, nullptr), nmf(nlev, nullptr), gmf(nlev, nullptr), ngmf(nlev, nullptr);
   const bool gauss = opt >= 0 && P && P->do_gauss_curv;
   const bool strain = opt >= 0 && P && P->do_strain;
   const bool veln = opt >= 0 && P && P->do_velnormal;
@@ -167,17 +170,17 @@ static int curvature_passes(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp
     if ((strain || veln) && (P->vel_comp < 0 || P->vel_comp + 3 > state[l]->ncomp)) return pa_fail(ctx, "pa_curvature_run: vel_comp out of range");
   }
   for (int l = 0; l < nlev; ++l) {
-    cmf[l].reset(pa_mf_create(ctx, state[l]->lev, 1, 1, nullptr));
-    nmf[l].reset(pa_mf_create(ctx, state[l]->lev, 3, 1, nullptr));
+    cmf[l] = pa_level_scratch(ctx, state[l]->lev, 1, 1);
+    nmf[l] = pa_level_scratch(ctx, state[l]->lev, 3, 1, 1);
     if (!cmf[l] || !nmf[l]) return 1;
-    PA_TRY(pa_progress_level(ctx, state[l], comp, pmin, pmax, cmf[l].get(), 0, 0));  // curvature.cpp:316-320
-    if (pc >= 0) PA_TRY(pa_mf_copy(ctx, cmf[l].get(), 0, out[l], pc, 1, 0));         // Progress is the unsmoothed field
-    PA_TRY(pa_fill_boundary(ctx, cmf[l].get(), 0, 1, 1));                            // :322
+    PA_TRY(pa_progress_level(ctx, state[l], comp, pmin, pmax, cmf[l], 0, 0));  // curvature.cpp:316-320
+    if (pc >= 0) PA_TRY(pa_mf_copy(ctx, cmf[l], 0, out[l], pc, 1, 0));         // Progress is the unsmoothed field
+    PA_TRY(pa_fill_boundary(ctx, cmf[l], 0, 1, 1));                            // :322
   }
   if (opt >= 0 && P && P->do_smooth) {  // :328-406; idprogvar = idSmProg from here on (:408)
     std::vector<pa_mf*> cs(nlev);
     for (int l = 0; l < nlev; ++l) {
-      cs[l] = cmf[l].get();
+      cs[l] = cmf[l];
       if (out[l]->ncomp < opt + 18) return pa_fail(ctx, "pa_curvature_run: out needs " + std::to_string(opt + 18) + " components with do_smooth");
     }
     int iters = 0;
@@ -197,30 +200,30 @@ static int curvature_passes(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp
     ctx->smooth_res = res;
     if (src != 0 && !(iters > 0 && res <= 1e-12)) return 1;
     for (int l = 0; l < nlev; ++l) {
-      PA_TRY(pa_mf_copy(ctx, cmf[l].get(), 0, out[l], opt + 17, 1, 0));
-      PA_TRY(pa_fill_boundary(ctx, cmf[l].get(), 0, 1, 1));  // :403
+      PA_TRY(pa_mf_copy(ctx, cmf[l], 0, out[l], opt + 17, 1, 0));
+      PA_TRY(pa_fill_boundary(ctx, cmf[l], 0, 1, 1));  // :403
     }
   }
   for (int l = 0; l < nlev; ++l) {
-    pa_mf* c = cmf[l].get();
-    pa_mf* n = nmf[l].get();
-    PA_TRY(pa_apply_bc(ctx, c, 0, l > 0 ? cmf[l - 1].get() : nullptr, 0, bc, 2, -1));  // :426-457 (inside getFluxes)
+    pa_mf* c = cmf[l];
+    pa_mf* n = nmf[l];
+    PA_TRY(pa_apply_bc(ctx, c, 0, l > 0 ? cmf[l - 1] : nullptr, 0, bc, 2, -1));  // :426-457 (inside getFluxes)
     if (gauss) {
-      gmf[l].reset(pa_mf_create(ctx, state[l]->lev, 3, 1, nullptr));
-      ngmf[l].reset(pa_mf_create(ctx, state[l]->lev, 1, 0, nullptr));
+      gmf[l] = pa_level_scratch(ctx, state[l]->lev, 3, 1);  // the role the fast path's G plays
+      ngmf[l] = pa_level_scratch(ctx, state[l]->lev, 1, 0);
       if (!gmf[l] || !ngmf[l]) return 1;
     }
-    PA_TRY(pa_normal_level(ctx, c, 0, gmf[l].get(), 0, ngmf[l].get(), 0, n, 0));         // :457-500
+    PA_TRY(pa_normal_level(ctx, c, 0, gmf[l], 0, ngmf[l], 0, n, 0));         // :457-500
     PA_TRY(pa_fill_boundary(ctx, n, 0, 3, 1));                                          // :502
     for (int d = 0; d < 3; ++d)                                                         // :508-531
       PA_TRY(pa_apply_bc(ctx, n, d, l > 0 ? out[l - 1] : nullptr, nc + d, bc, 2, d));
     PA_TRY(pa_div_level(ctx, n, 0, kscale, c, 0, thr, out[l], kc));                        // :533-567
     PA_TRY(pa_mf_copy(ctx, n, 0, out[l], nc, 3, 0));                                    // :569-570
     if (gauss) {  // :575-677: Hessian of c from cell_normal (= G), coarse-fine BC from cell_normal[lev-1]
-      pa_mf* G = gmf[l].get();
+      pa_mf* G = gmf[l];
       PA_TRY(pa_fill_boundary(ctx, G, 0, 3, 1));                                        // :488
-      for (int d = 0; d < 3; ++d) PA_TRY(pa_apply_bc(ctx, G, d, l > 0 ? gmf[l - 1].get() : nullptr, d, bc, 2, -1));
-      PA_TRY(pa_gauss_curv_level(ctx, G, 0, ngmf[l].get(), 0, c, 0, thr, out[l], opt + 5));
+      for (int d = 0; d < 3; ++d) PA_TRY(pa_apply_bc(ctx, G, d, l > 0 ? gmf[l - 1] : nullptr, d, bc, 2, -1));
+      PA_TRY(pa_gauss_curv_level(ctx, G, 0, ngmf[l], 0, c, 0, thr, out[l], opt + 5));
     }
     if (strain) {  // :679-757: grad u through the same ghost-resolved central differences
       PA_TRY(pa_fill_boundary(ctx, state[l], P->vel_comp, 3, 1));
@@ -229,7 +232,6 @@ static int curvature_passes(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp
     }
     if (veln) PA_TRY(pa_velnormal_level(ctx, state[l], P->vel_comp, n, 0, c, 0, thr, out[l], opt + 7));  // :765-787
   }
-  PA_TRY(pa_sync(ctx));  // scratch multifabs are freed on return
   return 0;
 }
 

@@ -367,8 +367,16 @@ def test_curvature_options_match_oracle(ctx, oracle, name):
                               do_strain=True, do_velnormal=True, strain_tensor=True)
     dls, dst = _dev(ctx, H, states)
     dout = [capi.DevMF(ctx, dl, 17, 0) for dl in dls]
-    # fused=False: pass by pass; fused=True: Progress / K / N from the exact-normal pipeline's G-output sweeps + one options pass per level
+    # the work multifabs of both paths live as long as the level does: a first call on OTHER data leaves them full of stale values
+    other = make_states(H, 4, 2, fn, seed=77)
+    for m in other:
+        m.data[:] = 3.0 * m.data + 11.0
+    dst_other = [capi.DevMF.from_host(ctx, dl, s) for dl, s in zip(dls, other)]
     for fused in (False, True):
+        capi.curvature_run(ctx, dst_other, 0, bc, capi.curv_params(fused=fused, do_gauss=True, do_strain=True, strain_tensor=True, do_velnormal=True, vel_comp=1), dout, 0)
+    ctx.sync()
+    # fused=False: pass by pass; fused=True: Progress / K / N from the exact-normal pipeline's G-output sweeps + one options pass per level
+    for fused in (False, True, False):
         for m in dout:
             m.setval(-7.0)
         P = capi.curv_params(threshold=0.05, fused=fused, do_gauss=True, do_strain=True, strain_tensor=True, do_velnormal=True, vel_comp=1)
