@@ -106,8 +106,7 @@ struct FixArgs {
 };
 // workgroup -> (batch level, special face, first face cell) through the levels' work tables
 template <typename BT>
-__device__ __forceinline__ bool wg_decode(const BT& Bt, int& blev, unsigned& fy, long long& t) {
-  unsigned w = blockIdx.x;
+__device__ __forceinline__ bool wg_decode(const BT& Bt, int& blev, unsigned& fy, long long& t, unsigned w = blockIdx.x) {
   blev = 0;
   while (blev + 1 < Bt.n && w >= (unsigned)Bt.a[blev].nwg) { w -= (unsigned)Bt.a[blev].nwg; ++blev; }
   if (w >= (unsigned)Bt.a[blev].nwg) return false;
@@ -288,14 +287,17 @@ __global__ __launch_bounds__(256, PA_FC_WAVES) void k_faces_curv(LevBatch<FixArg
 // The perimeter cells through the levels' perimeter work tables (round 5): the grid of k_faces_curv is (longest perimeter of the
 // batch / 256) x faces -- on a hierarchy whose faces differ in size (a 256^2 wall face next to the 32^2 .. 128^2 faces of a flame
 // sheet) most workgroups find nothing to do: 333 -> 595 us when level 0 was re-tiled to 256^3 boxes.  One layer only.
-template <bool CG, bool PATCH = false, bool CGCLIP = false>
-__global__ __launch_bounds__(256, PA_FC_WAVES) void k_faces_curv_tab(LevBatch<FixArgs> Bt, int* nbad, SlotK sk = SlotK()) {
-  unsigned w = blockIdx.x;
+template <bool CG, bool PATCH, bool CGCLIP>
+__device__ __forceinline__ void faces_tab_wg(const LevBatch<FixArgs>& Bt, int* nbad, const SlotK& sk, unsigned w) {
   int blev = 0;
   while (blev + 1 < Bt.n && w >= (unsigned)Bt.a[blev].npwg) { w -= (unsigned)Bt.a[blev].npwg; ++blev; }
   if (w >= (unsigned)Bt.a[blev].npwg) return;
   const int2 it = Bt.a[blev].pwg[w];
   faces_curv_cell<CG, PATCH, CGCLIP>(Bt, (unsigned)Bt.ycum[blev] + (unsigned)it.x, (long long)it.y * 256 + threadIdx.x, 1, nbad, sk, (int)blockIdx.z);
+}
+template <bool CG, bool PATCH = false, bool CGCLIP = false>
+__global__ __launch_bounds__(256, PA_FC_WAVES) void k_faces_curv_tab(LevBatch<FixArgs> Bt, int* nbad, SlotK sk = SlotK()) {
+  faces_tab_wg<CG, PATCH, CGCLIP>(Bt, nbad, sk, blockIdx.x);
 }
 // the cells of SlowList through the general path (any cell of a face, one layer)
 template <bool PATCH>
@@ -439,12 +441,12 @@ __device__ __forceinline__ void faces_curv_fast_body(const DLevelView& L, const 
 }
 
 // PATCH: every coarse-fine face of every level of the batch has its coarse patch (the owner-map interpolation is not compiled in)
-template <int NL, bool PATCH = false, bool CLIP = false>
-__global__ __launch_bounds__(256) void k_faces_curv_fast(LevBatch<FixArgs> Bt, int* nbad, SlowList sl = SlowList(), SlotK sk = SlotK()) {
+template <int NL, bool PATCH, bool CLIP>
+__device__ __forceinline__ void faces_fast_wg(const LevBatch<FixArgs>& Bt, int* nbad, SlowList sl, const SlotK& sk, unsigned w) {
   unsigned fy;
   int blev;
   long long t;
-  if (!wg_decode(Bt, blev, fy, t)) return;
+  if (!wg_decode(Bt, blev, fy, t, w)) return;
   const FixArgs& Fx = Bt.a[blev];
   sl.glev = (unsigned)blev;
   const DLevelView& L = Fx.L;
@@ -469,6 +471,18 @@ __global__ __launch_bounds__(256) void k_faces_curv_fast(LevBatch<FixArgs> Bt, i
     case 1: faces_curv_fast_body<1, NL, PATCH, CLIP>(L, LCr, MN, cncomp0, MO, ncomp0, kcomp, A, nbad, b, B, side, q0, code, patch, Fx.MC_, Fx.ccomp + z, sl, row, t); break;
     default: faces_curv_fast_body<2, NL, PATCH, CLIP>(L, LCr, MN, cncomp0, MO, ncomp0, kcomp, A, nbad, b, B, side, q0, code, patch, Fx.MC_, Fx.ccomp + z, sl, row, t); break;
   }
+}
+template <int NL, bool PATCH = false, bool CLIP = false>
+__global__ __launch_bounds__(256) void k_faces_curv_fast(LevBatch<FixArgs> Bt, int* nbad, SlowList sl = SlowList(), SlotK sk = SlotK()) {
+  faces_fast_wg<NL, PATCH, CLIP>(Bt, nbad, sl, sk, blockIdx.x);
+}
+// Face interiors and face perimeters of all levels in ONE launch (no clip): the two kernels above write different cells from the
+// same final normals, and at the size of a level's special faces each is a chain of dependent loads -- back to back they cost
+// their sum.  Workgroups 0 .. nfast - 1 take the interiors' work tables, the rest the perimeters'.
+template <bool PATCH>
+__global__ __launch_bounds__(256, PA_FC_WAVES) void k_faces_curv_both(LevBatch<FixArgs> Bt, int* nbad, SlotK sk, unsigned nfast) {
+  if (blockIdx.x < nfast) faces_fast_wg<1, PATCH, false>(Bt, nbad, SlowList(), sk, blockIdx.x);
+  else faces_tab_wg<true, PATCH, false>(Bt, nbad, sk, blockIdx.x - nfast);
 }
 
 // tuning knobs (environment, read once): PA_KSEG=<planes per workgroup>, PA_MTY=<rows*10 + min waves/SIMD>
@@ -1756,6 +1770,7 @@ int pa_gradcurv_fix_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, 
     for (int q = 0; q < Bt.n; ++q) nwgf += (unsigned)Bt.a[q].nwg;
     const dim3 gfast(nwgf, 1, (unsigned)nslots);
     hipStream_t pst = ctx->stream;  // the perimeter kernel's stream
+    bool both_done = false;         // the perimeters went with the interiors (k_faces_curv_both)
     if (clip) {
       SlowList sl;
       if (pa_slow_list(ctx, &sl)) return 1;
@@ -1796,7 +1811,21 @@ int pa_gradcurv_fix_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, 
         PA_HIP(hipEventRecord(ctx->fix_evs[0], ctx->stream));
         PA_HIP(hipStreamWaitEvent(pst, ctx->fix_evs[0], 0));
       }
-      if (all_patch) hipLaunchKernelGGL((k_faces_curv_fast<1, true>), gfast, dim3(256), 0, ctx->stream, Bt, ctx->d_flags, SlowList(), sk);
+      // PA_FIX_BOTH (read per pass): interiors and perimeters in one launch (k_faces_curv_both) when the perimeters have their work tables.
+      // Default: on a sharded hierarchy only.  In-process A/B (bench.py --ab PA_FIX_BOTH=0,1): rank 0 of 8 0.900 -> 0.885 ms per pass (two
+      // 35-60-us latency chains side by side), but the headline on one GPU 6.002 -> 6.026 and the irregular hierarchy 6.75-6.95 -> 7.2:
+      // the merged kernel carries the perimeter path's 128 VGPRs, and the interiors' bandwidth-bound part runs at 4 instead of 6 waves per SIMD
+      const char* fbe = getenv("PA_FIX_BOTH");
+      const bool both_on = fbe ? atoi(fbe) != 0 : (nlev > 0 && phi[0]->lev->nranks > 1);
+      bool ptab_ok = !side && !(getenv("PA_FIX_PTAB") && !atoi(getenv("PA_FIX_PTAB")));
+      unsigned npt = 0;
+      for (int q = 0; q < Bt.n; ++q) { ptab_ok = ptab_ok && Bt.a[q].pwg && Bt.a[q].npwg > 0; npt += (unsigned)Bt.a[q].npwg; }
+      if (ptab_ok && both_on) {
+        const dim3 gboth(nwgf + npt, 1, (unsigned)nslots);
+        if (all_patch) hipLaunchKernelGGL((k_faces_curv_both<true>), gboth, dim3(256), 0, ctx->stream, Bt, ctx->d_flags, sk, nwgf);
+        else hipLaunchKernelGGL((k_faces_curv_both<false>), gboth, dim3(256), 0, ctx->stream, Bt, ctx->d_flags, sk, nwgf);
+        both_done = true;
+      } else if (all_patch) hipLaunchKernelGGL((k_faces_curv_fast<1, true>), gfast, dim3(256), 0, ctx->stream, Bt, ctx->d_flags, SlowList(), sk);
       else hipLaunchKernelGGL((k_faces_curv_fast<1, false>), gfast, dim3(256), 0, ctx->stream, Bt, ctx->d_flags, SlowList(), sk);
     }
     const dim3 gper((unsigned)((nper + 255) / 256), (unsigned)Bt.ycum[Bt.n], (unsigned)nslots);
@@ -1804,7 +1833,8 @@ int pa_gradcurv_fix_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, 
     bool ptab = !(getenv("PA_FIX_PTAB") && !atoi(getenv("PA_FIX_PTAB")));
     for (int q = 0; q < Bt.n; ++q) { ptab = ptab && Bt.a[q].pwg && Bt.a[q].npwg > 0; nptab += (unsigned)Bt.a[q].npwg; }
     const dim3 gtab(nptab, 1, (unsigned)nslots);
-    if (ptab) {
+    if (both_done) {
+    } else if (ptab) {
       if (clip) {
         if (all_patch) hipLaunchKernelGGL((k_faces_curv_tab<true, true, true>), gtab, dim3(256), 0, pst, Bt, ctx->d_flags, sk);
         else hipLaunchKernelGGL((k_faces_curv_tab<true, false, true>), gtab, dim3(256), 0, pst, Bt, ctx->d_flags, sk);
