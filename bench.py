@@ -600,15 +600,23 @@ def secondary(ctx, torch, stream, dev, only=None, retile=1):
         sm = {}
         hr = (C.c_void_p * 3)(*[x[1].h for x in c])
         hs = (C.c_void_p * 3)(*[x[1].h for x in sol])
-        for dt_s in (1e-7, 1e-5):  # the reference's default smoothing_time and one that makes the solver work
+        # the reference's default smoothing_time on this unit-cube test domain (dt / dx^2 = 0.42 on the finest level: plain BiCGStab), 1e-5
+        # (dt / dx^2 = 42) with and without the V-cycle preconditioner, and 6e-5 (dt / dx^2 = 250: what 1e-7 is for a plotfile in physical units)
+        for dt_s, mg_env in ((1e-7, None), (1e-5, None), (1e-5, "0"), (6e-5, None)):
             it_, rs_ = C.c_int(0), C.c_double(0.0)
+            if mg_env is not None:
+                os.environ["PA_SMOOTH_MG"] = mg_env
             for _ in range(2 if dt_s < 1e-6 else 1):
                 t0 = time.perf_counter()
                 rc_ = ctx.lib.pa_smooth_solve(ctx.h, 3, hr, 0, hs, 0, dt_s, (C.c_int32 * 3)(*bc), 1e-12, 600, C.byref(it_), C.byref(rs_))
                 msq = (time.perf_counter() - t0) * 1e3
-            sm[f"smoothing_time_{dt_s:g}"] = {"iterations": it_.value, "rel_residual": rs_.value, "converged_to_1e-12": rc_ == 0, "ms": msq, "ms_per_iteration": msq / max(it_.value, 1)}
+            os.environ.pop("PA_SMOOTH_MG", None)
+            sm[f"smoothing_time_{dt_s:g}" + ("_unpreconditioned" if mg_env == "0" else "")] = {
+                "iterations": it_.value, "rel_residual": rs_.value, "converged_to_1e-12": rc_ == 0, "ms": msq, "ms_per_iteration": msq / max(it_.value, 1),
+                "solver": "BiCGStab" if (mg_env == "0" or dt_s < 4e-6) else "BiCGStab + V(2,2) multigrid preconditioner (damped Jacobi, AMR levels + coarsened copies of level 0)"}
         out["f1_do_smooth_headline"] = dict(sm, cells=cells, workload="pa_smooth_solve (curvature.cpp:328-406: (I - dt Lap) c~ = c, composite over the levels, tol 1e-12), 3-level base "
-                                            "512^3, 1 rank; ms = one whole solve incl. its allocations; per iteration 2 operator applications + 5 dot products; " + tiling_txt(Hf, H))
+                                            "512^3, 1 rank; ms = one whole solve incl. its allocations; per iteration 2 operator applications + 5 dot products (+ 2 V-cycles where the finest "
+                                            "level's dt / dx^2 > 8); " + tiling_txt(Hf, H))
         del ins, ous, c, sol, dls
         torch.cuda.empty_cache()
 

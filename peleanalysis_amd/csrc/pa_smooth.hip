@@ -11,7 +11,9 @@
 #include "pa_internal.h"
 #include "pa_fabview.h"
 #include "pa_dist.h"
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <memory>
 #include <vector>
 
@@ -272,6 +274,18 @@ __global__ __launch_bounds__(256) void k_smooth_copy(DLevelView L, DMFView S, in
   }
 }
 
+// multigrid preconditioner: e_fine += e_coarse(parent cell) (piecewise-constant prolongation, ratio 2)
+__global__ __launch_bounds__(256) void k_smooth_prolong_add(DLevelView LF, DMFView EF, DLevelView LC, DMFView EC, int ratio) {
+  PA_BOX_LOOP(LF) {
+    int i, j, k;
+    it.cell(t, i, j, k);
+    const int p[3] = {coarsen_idx(i, ratio), coarsen_idx(j, ratio), coarsen_idx(k, rdir(LF, 2, ratio))};
+    const int cb = owner_of(LC, p);
+    if (cb < 0) continue;
+    EF.data[EF.off[b] + fab_index(it.B, EF.ng, EF.ncomp, 0, i, j, k)] += EC.data[EC.off[cb] + fab_index(LC.boxes[cb], EC.ng, EC.ncomp, 0, p[0], p[1], p[2])];
+  }
+}
+
 // per-block partial sums of a*b and max|a| over uncovered cells
 __global__ __launch_bounds__(256) void k_smooth_dot(DLevelView L, DMFView A, DMFView Bv, DMFView M, double* part) {
   double s = 0.0, m = 0.0;
@@ -363,9 +377,10 @@ __global__ __launch_bounds__(256) void k_smooth_lincomb_red(DLevelView L, double
 }
 
 namespace {
-struct Vecs {  // one 1-comp ng-1 vector per level, owned
+struct Vecs {  // one 1-comp ng-1 vector per level; owned, or work multifabs kept with the levels (pa_level_scratch)
   std::vector<pa_mf*> v;
-  ~Vecs() { for (pa_mf* m : v) pa_mf_destroy(m); }
+  bool owned = true;
+  ~Vecs() { if (owned) for (pa_mf* m : v) pa_mf_destroy(m); }
 };
 dim3 box_grid(const pa_level* L, unsigned gx = 0) {
   if (!gx) gx = (unsigned)std::min<long long>(((long long)L->maxn[0] * L->maxn[1] * L->maxn[2] + 255) / 256, 1024);
@@ -379,7 +394,7 @@ struct SmoothSolver {
   double dt;
   int32_t bc[3];
   std::vector<const pa_level*> lev;
-  Vecs r, rh, p, v, s, t, mask;
+  Vecs r, rh, p, v, s, t, mask, ph, sh;
   // sharded hierarchy (dist): rs[l] restricts level l onto level l - 1; cfw[l] lives on rs[l]->cf (valid cells: child averages,
   // face ghosts: fine fluxes); fr[l] / fm[l] on level l: the received fluxes of level l + 1 (6 components) and where they apply
   bool dist = false;
@@ -443,11 +458,18 @@ struct SmoothSolver {
     return pa_xexchange(ctx, (int)jobs.size(), jobs.data());
   }
 
-  int alloc(Vecs& V) {
+  // One rank: the vectors are work multifabs kept with the levels (role > 0; zeroed here, as a fresh allocation would be) -- 30-50 GB
+  // of hipMalloc + hipFree per solve at the headline size took 0.8-1.2 s, more than the preconditioned iteration itself.
+  // Sharded hierarchy: allocated and freed per solve as before.
+  int alloc(Vecs& V, int role = 0) {
     for (int l = 0; l < nlev; ++l) {
-      pa_mf* m = pa_mf_create(ctx, lev[l], 1, 1, nullptr);
+      pa_mf* m = (role > 0 && !dist) ? pa_level_scratch(ctx, lev[l], 1, 1, role) : pa_mf_create(ctx, lev[l], 1, 1, nullptr);
       if (!m) return 1;
       V.v.push_back(m);
+      if (role > 0 && !dist) {
+        V.owned = false;
+        if (m->total > 0 && hipMemsetAsync(m->data, 0, sizeof(double) * (size_t)m->total, ctx->stream) != hipSuccess) return 1;
+      }
     }
     return 0;
   }
@@ -638,6 +660,110 @@ struct SmoothSolver {
     *cd = v[1];
     return 0;
   }
+  // ---- multigrid preconditioner (one rank, 3-D): z = M^-1 r by one V(2,2) cycle of damped Jacobi over the AMR levels and, below
+  // level 0, coarsened copies of it (until dt / dx^2 is small or the boxes stop halving).  curvature.cpp:381-399 solves with MLMG;
+  // unpreconditioned BiCGStab needs ~sqrt(cond) iterations (165 at dt / dx^2 = 42 on the finest level, hundreds for a plotfile in
+  // physical units), a V-cycle per application keeps the count at a handful whatever dt.  Level-local problems: the finer level's
+  // residual is averaged down onto the cells it covers, a level's coarse-fine ghost cells come from the coarser level's correction by
+  // the operator's own applyBC (zero on the way down), the flux mismatch at coarse-fine faces is left to the Krylov iteration.  M is a
+  // fixed linear operator, so BiCGStab's recurrences hold; the solution it converges to is the unpreconditioned one.
+  struct MgLev { const pa_level* L = nullptr; pa_level* owned = nullptr; pa_mf *e = nullptr, *r = nullptr, *w = nullptr; };  // owned: a coarsened copy of level 0 (its vectors too)
+  std::vector<MgLev> mg;
+  int mg_sub = 0;  // coarsened copies of level 0: mg[0 .. mg_sub - 1]; AMR level l = mg[mg_sub + l]
+  ~SmoothSolver() {
+    for (MgLev& g : mg) {
+      if (!g.owned) continue;  // the AMR levels' vectors are kept with the levels
+      pa_mf_destroy(g.e); pa_mf_destroy(g.r); pa_mf_destroy(g.w);
+      pa_level_destroy(g.owned);
+    }
+  }
+  int mg_setup() {
+    std::vector<MgLev> sub;
+    const pa_level* Lc = lev[0];
+    // coarsen level 0 while every box halves evenly, stays >= 4 cells thick and dt / dx^2 of the CURRENT coarsest level is not small yet
+    for (int n = 0; n < 8; ++n) {
+      double q = 0.0;
+      for (int d = 0; d < 3; ++d) q = std::max(q, dt * Lc->dxinv[d] * Lc->dxinv[d]);
+      if (q < 0.25) break;
+      bool ok = true;
+      std::vector<int32_t> b6;
+      for (const DBox& B : Lc->boxes)
+        for (int d = 0; d < 3; ++d) ok = ok && !(B.lo[d] & 1) && ((B.hi[d] - B.lo[d] + 1) % 2 == 0) && (B.hi[d] - B.lo[d] + 1) >= 8;
+      for (int d = 0; d < 3; ++d) ok = ok && !(Lc->domlo[d] & 1) && ((Lc->domhi[d] - Lc->domlo[d] + 1) % 2 == 0);
+      if (!ok) break;
+      for (const DBox& B : Lc->boxes) {
+        for (int d = 0; d < 3; ++d) b6.push_back(B.lo[d] / 2);
+        for (int d = 0; d < 3; ++d) b6.push_back((B.hi[d] + 1) / 2 - 1);
+      }
+      int32_t dlo[3], dhi[3], per[3];
+      for (int d = 0; d < 3; ++d) { dlo[d] = Lc->domlo[d] / 2; dhi[d] = (Lc->domhi[d] + 1) / 2 - 1; per[d] = Lc->is_per[d]; }
+      pa_level* Ln = pa_level_create(ctx, (int)Lc->boxes.size(), b6.data(), dlo, dhi, per, Lc->prob_lo, Lc->prob_hi);
+      if (!Ln) return 1;
+      MgLev g;
+      g.L = g.owned = Ln;
+      sub.push_back(g);
+      Lc = Ln;
+    }
+    mg_sub = (int)sub.size();
+    for (int q = mg_sub - 1; q >= 0; --q) mg.push_back(sub[(size_t)q]);  // coarsest first
+    for (int l = 0; l < nlev; ++l) { MgLev g; g.L = lev[l]; mg.push_back(g); }
+    for (MgLev& g : mg) {
+      g.e = g.owned ? pa_mf_create(ctx, g.L, 1, 1, nullptr) : pa_level_scratch(ctx, g.L, 1, 1, 20);
+      g.r = g.owned ? pa_mf_create(ctx, g.L, 1, 1, nullptr) : pa_level_scratch(ctx, g.L, 1, 1, 21);
+      g.w = g.owned ? pa_mf_create(ctx, g.L, 1, 1, nullptr) : pa_level_scratch(ctx, g.L, 1, 1, 22);
+      if (!g.e || !g.r || !g.w) return 1;
+    }
+    return 0;
+  }
+  // w = A_g e on MG level g (level-local: same-level + wall ghost cells, coarse-fine ghost cells from the coarser level's e)
+  int mg_apply(int g) {
+    MgLev& X = mg[(size_t)g];
+    if (pa_fill_boundary(ctx, X.e, 0, 1, 1)) return 1;
+    if (pa_apply_bc(ctx, X.e, 0, g > mg_sub ? mg[(size_t)g - 1].e : nullptr, 0, bc, ratio, -1)) return 1;
+    on_boxes(k_smooth_apply, X.L, box_grid(X.L), X.L->view, X.e->view, X.w->view, dt);
+    return 0;
+  }
+  // nu damped-Jacobi steps on A_g e = r_g; zero_start: e is 0 (the first step needs no operator application)
+  int mg_smooth(int g, int nu, bool zero_start) {
+    MgLev& X = mg[(size_t)g];
+    double D = 1.0;
+    for (int d = 0; d < 3; ++d)
+      if (!(d == 2 && X.L->domlo[2] == X.L->domhi[2])) D += 2.0 * dt * X.L->dxinv[d] * X.L->dxinv[d];
+    const double om = 0.85 / D;
+    for (int it = 0; it < nu; ++it) {
+      if (it == 0 && zero_start) {
+        on_boxes(k_smooth_axpbypcz, X.L, box_grid(X.L), X.L->view, om, X.r->view, 1, 0.0, X.r->view, 0, 0.0, X.e->view);  // e = om r
+        continue;
+      }
+      if (mg_apply(g)) return 1;
+      on_boxes(k_smooth_axpbypcz, X.L, box_grid(X.L), X.L->view, om, X.r->view, 1, -om, X.w->view, 1, 1.0, X.e->view);  // e += om (r - A e)
+    }
+    return 0;
+  }
+  int vcycle(Vecs& R, Vecs& Z) {
+    const int G = (int)mg.size();
+    for (int l = 0; l < nlev; ++l) on_boxes(k_smooth_copy, lev[l], box_grid(lev[l]), lev[l]->view, R.v[l]->view, 0, mg[(size_t)(mg_sub + l)].r->view, 0);
+    for (int g = 0; g < G; ++g) PA_HIP(hipMemsetAsync(mg[(size_t)g].e->data, 0, sizeof(double) * (size_t)mg[(size_t)g].e->total, ctx->stream));
+    for (int g = G - 1; g > 0; --g) {
+      if (mg_smooth(g, 2, true)) return 1;
+      if (mg_apply(g)) return 1;
+      MgLev& X = mg[(size_t)g];
+      on_boxes(k_smooth_axpbypcz, X.L, box_grid(X.L), X.L->view, 1.0, X.r->view, 1, 0.0, X.r->view, 0, -1.0, X.w->view);  // w = r - A e
+      MgLev& C = mg[(size_t)g - 1];
+      hipLaunchKernelGGL(k_smooth_avgdown, box_grid(X.L), dim3(256), 0, ctx->stream, X.L->view, X.w->view, C.L->view, C.r->view, ratio);
+    }
+    if (mg_smooth(0, G > 1 ? 8 : 4, true)) return 1;
+    for (int g = 1; g < G; ++g) {
+      MgLev& X = mg[(size_t)g];
+      MgLev& C = mg[(size_t)g - 1];
+      on_boxes(k_smooth_prolong_add, X.L, box_grid(X.L), X.L->view, X.e->view, C.L->view, C.e->view, ratio);
+      if (mg_smooth(g, 2, false)) return 1;
+    }
+    for (int l = 0; l < nlev; ++l) on_boxes(k_smooth_copy, lev[l], box_grid(lev[l]), lev[l]->view, mg[(size_t)(mg_sub + l)].e->view, 0, Z.v[l]->view, 0);
+    zero_covered(Z);
+    PA_HIP(hipGetLastError());
+    return 0;
+  }
   void axpbypcz(double a, Vecs* X, double b, Vecs* Y, double c, Vecs& Z) {
     for (int l = 0; l < nlev; ++l)
       on_boxes(k_smooth_axpbypcz, lev[l], box_grid(lev[l]), lev[l]->view, a, X ? X->v[l]->view : Z.v[l]->view, X ? 1 : 0, b, Y ? Y->v[l]->view : Z.v[l]->view,
@@ -695,6 +821,9 @@ extern "C" int pa_smooth_solve(pa_ctx* ctx, int nlev, pa_mf* const* rhs, int rco
   const bool sharded = rhs[0] && rhs[0]->lev->nranks > 1;
   static const int replicated = [] { const char* e = getenv("PA_SMOOTH_REPLICATED"); return e ? atoi(e) : 0; }();
   if (sharded && replicated) return smooth_solve_replicated(ctx, nlev, rhs, rcomp, sol, scomp, dt, bc, tol, maxiter, iters, res);
+  const bool timing = getenv("PA_SMOOTH_TIMING") != nullptr;  // diagnostic: setup / iteration / total wall time on stderr
+  const auto tm0 = std::chrono::steady_clock::now();
+  auto since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
   SmoothSolver S;
   S.ctx = ctx; S.nlev = nlev; S.ratio = 2; S.dt = dt; S.dist = sharded;
   for (int d = 0; d < 3; ++d) S.bc[d] = bc[d];
@@ -715,7 +844,7 @@ extern "C" int pa_smooth_solve(pa_ctx* ctx, int nlev, pa_mf* const* rhs, int rco
   {
     // every allocation of the solve -- Krylov vectors, restriction / flux-register plans, ghost-fill plans and their buffers --
     // happens here, before the first collective; the ranks of a sharded hierarchy then agree on success with ONE reduction
-    int bad = (S.alloc(S.r) || S.alloc(S.rh) || S.alloc(S.p) || S.alloc(S.v) || S.alloc(S.s) || S.alloc(S.t) || S.alloc(S.mask) || S.alloc(x)) ? 1 : 0;
+    int bad = (S.alloc(S.r, 10) || S.alloc(S.rh, 11) || S.alloc(S.p, 12) || S.alloc(S.v, 13) || S.alloc(S.s, 14) || S.alloc(S.t, 15) || S.alloc(S.mask, 16) || S.alloc(x, 17)) ? 1 : 0;
     if (!bad && S.dist && S.setup_dist()) bad = 1;
     if (S.dist) {
       double e = bad ? 1.0 : 0.0;
@@ -725,6 +854,18 @@ extern "C" int pa_smooth_solve(pa_ctx* ctx, int nlev, pa_mf* const* rhs, int rco
       return 1;
     }
     if (S.dist && S.setup_dist_mask()) return 1;
+  }
+  // PA_SMOOTH_MG (read per solve): 1 / 0 = the multigrid preconditioner on / off; default: on where the finest level's dt / dx^2
+  // exceeds 8 (below that the unpreconditioned iteration needs < ~45 iterations and two V-cycles per iteration cost more than they
+  // save); one rank, 3-D
+  bool use_mg = false;
+  {
+    const pa_level* Lf = S.lev[(size_t)nlev - 1];
+    double q = 0.0;
+    for (int d = 0; d < 3; ++d) q = std::max(q, dt * Lf->dxinv[d] * Lf->dxinv[d]);
+    const char* me = getenv("PA_SMOOTH_MG");
+    use_mg = !S.dist && S.lev[0]->domlo[2] != S.lev[0]->domhi[2] && (me ? atoi(me) != 0 : q > 8.0);
+    if (use_mg && (S.mg_setup() || S.alloc(S.ph, 18) || S.alloc(S.sh, 19))) return 1;
   }
   for (int l = 0; l < nlev; ++l) {
     const pa_level* L = S.lev[l];
@@ -740,6 +881,8 @@ extern "C" int pa_smooth_solve(pa_ctx* ctx, int nlev, pa_mf* const* rhs, int rco
   PA_HIP(hipGetLastError());
   double red[3], rho = 1.0, alpha = 1.0, omega = 1.0;
   if (S.fdot(S.r, S.rh, nullptr, nullptr, red, 1, true)) return 1;  // rho_1 = r^ . r and ||b||_inf in one pass
+  const double setup_ms = since(tm0);
+  const auto tm1 = std::chrono::steady_clock::now();
   const double bnorm = red[2];
   double rho1 = red[0];
   int it = 0, status = -1;
@@ -761,7 +904,9 @@ extern "C" int pa_smooth_solve(pa_ctx* ctx, int nlev, pa_mf* const* rhs, int rco
       S.axpbypcz(-omega * beta, &S.v, 0.0, nullptr, beta, S.p);
       S.axpbypcz(1.0, &S.r, 0.0, nullptr, 1.0, S.p);
     }
-    if (S.apply(S.p, S.v)) return 1;
+    if (use_mg) {  // right preconditioning: v = A M^-1 p
+      if (S.vcycle(S.p, S.ph) || S.apply(S.ph, S.v)) return 1;
+    } else if (S.apply(S.p, S.v)) return 1;
     double rhv;
     if (fused) {
       if (S.fdot(S.rh, S.v, nullptr, nullptr, red, 1, false)) return 1;
@@ -779,12 +924,14 @@ extern "C" int pa_smooth_solve(pa_ctx* ctx, int nlev, pa_mf* const* rhs, int rco
       if (S.dot(S.s, S.s, &dummy, &snorm, 2)) return 1;
     }
     if (snorm <= tol * bnorm) {
-      S.axpbypcz(alpha, &S.p, 0.0, nullptr, 1.0, x);
+      S.axpbypcz(alpha, use_mg ? &S.ph : &S.p, 0.0, nullptr, 1.0, x);
       rnorm = snorm;
       status = 0;
       break;
     }
-    if (S.apply(S.s, S.t)) return 1;
+    if (use_mg) {
+      if (S.vcycle(S.s, S.sh) || S.apply(S.sh, S.t)) return 1;
+    } else if (S.apply(S.s, S.t)) return 1;
     double ts, tt;
     if (fused) {
       if (S.fdot(S.t, S.s, &S.t, &S.t, red, 2, false)) return 1;  // t . s and t . t in one pass
@@ -792,7 +939,7 @@ extern "C" int pa_smooth_solve(pa_ctx* ctx, int nlev, pa_mf* const* rhs, int rco
     } else if (S.dot2(S.t, S.s, S.t, S.t, &ts, &tt)) return 1;
     if (tt == 0.0) { status = -4; break; }
     omega = ts / tt;
-    S.axpbypcz(alpha, &S.p, omega, &S.s, 1.0, x);  // x += alpha p + omega s
+    S.axpbypcz(alpha, use_mg ? &S.ph : &S.p, omega, use_mg ? &S.sh : &S.s, 1.0, x);  // x += alpha p + omega s (preconditioned: M^-1 p, M^-1 s)
     if (fused) {
       if (S.flin(1.0, S.s, -omega, S.t, 0.0, S.r, &S.rh, red, true)) return 1;  // r = s - omega t, ||r||_inf and the NEXT rho_1 = r^ . r
       rnorm = red[2];
@@ -819,6 +966,7 @@ extern "C" int pa_smooth_solve(pa_ctx* ctx, int nlev, pa_mf* const* rhs, int rco
   for (int l = 0; l < nlev; ++l) S.on_boxes(k_smooth_copy, S.lev[l], box_grid(S.lev[l]), S.lev[l]->view, x.v[l]->view, 0, sol[l]->view, scomp);
   PA_HIP(hipGetLastError());
   PA_HIP(hipStreamSynchronize(ctx->stream));  // the work vectors are freed on return
+  if (timing) fprintf(stderr, "pa_smooth_solve: setup %.1f ms, %d iterations %.1f ms (%s)\n", setup_ms, it, since(tm1), use_mg ? "multigrid-preconditioned" : "plain");
   if (iters) *iters = it;
   if (res) *res = bnorm > 0.0 ? rnorm / bnorm : 0.0;
   if (status != 0) return pa_fail(ctx, "pa_smooth_solve: BiCGStab did not reach the tolerance (status " + std::to_string(status) + " after " + std::to_string(it) + " iterations)");
