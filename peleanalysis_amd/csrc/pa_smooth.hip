@@ -729,7 +729,7 @@ struct SmoothSolver {
     double D = 1.0;
     for (int d = 0; d < 3; ++d)
       if (!(d == 2 && X.L->domlo[2] == X.L->domhi[2])) D += 2.0 * dt * X.L->dxinv[d] * X.L->dxinv[d];
-    const double om = 0.85 / D;
+    const double om = jac_omega / D;
     for (int it = 0; it < nu; ++it) {
       if (it == 0 && zero_start) {
         on_boxes(k_smooth_axpbypcz, X.L, box_grid(X.L), X.L->view, om, X.r->view, 1, 0.0, X.r->view, 0, 0.0, X.e->view);  // e = om r
@@ -740,24 +740,26 @@ struct SmoothSolver {
     }
     return 0;
   }
+  int nu1 = 2, nu2 = 2, nub = 8;  // pre- / post-smoothing steps, steps on the coarsest level (PA_MG_NU="nu1 nu2 nub", read per solve)
+  double jac_omega = 0.85;
   int vcycle(Vecs& R, Vecs& Z) {
     const int G = (int)mg.size();
     for (int l = 0; l < nlev; ++l) on_boxes(k_smooth_copy, lev[l], box_grid(lev[l]), lev[l]->view, R.v[l]->view, 0, mg[(size_t)(mg_sub + l)].r->view, 0);
     for (int g = 0; g < G; ++g) PA_HIP(hipMemsetAsync(mg[(size_t)g].e->data, 0, sizeof(double) * (size_t)mg[(size_t)g].e->total, ctx->stream));
     for (int g = G - 1; g > 0; --g) {
-      if (mg_smooth(g, 2, true)) return 1;
+      if (mg_smooth(g, nu1, true)) return 1;
       if (mg_apply(g)) return 1;
       MgLev& X = mg[(size_t)g];
       on_boxes(k_smooth_axpbypcz, X.L, box_grid(X.L), X.L->view, 1.0, X.r->view, 1, 0.0, X.r->view, 0, -1.0, X.w->view);  // w = r - A e
       MgLev& C = mg[(size_t)g - 1];
       hipLaunchKernelGGL(k_smooth_avgdown, box_grid(X.L), dim3(256), 0, ctx->stream, X.L->view, X.w->view, C.L->view, C.r->view, ratio);
     }
-    if (mg_smooth(0, G > 1 ? 8 : 4, true)) return 1;
+    if (mg_smooth(0, G > 1 ? nub : std::max(nu1 + nu2, 2), true)) return 1;
     for (int g = 1; g < G; ++g) {
       MgLev& X = mg[(size_t)g];
       MgLev& C = mg[(size_t)g - 1];
       on_boxes(k_smooth_prolong_add, X.L, box_grid(X.L), X.L->view, X.e->view, C.L->view, C.e->view, ratio);
-      if (mg_smooth(g, 2, false)) return 1;
+      if (mg_smooth(g, nu2, false)) return 1;
     }
     for (int l = 0; l < nlev; ++l) on_boxes(k_smooth_copy, lev[l], box_grid(lev[l]), lev[l]->view, mg[(size_t)(mg_sub + l)].e->view, 0, Z.v[l]->view, 0);
     zero_covered(Z);
@@ -866,6 +868,11 @@ extern "C" int pa_smooth_solve(pa_ctx* ctx, int nlev, pa_mf* const* rhs, int rco
     const char* me = getenv("PA_SMOOTH_MG");
     use_mg = !S.dist && S.lev[0]->domlo[2] != S.lev[0]->domhi[2] && (me ? atoi(me) != 0 : q > 8.0);
     if (use_mg && (S.mg_setup() || S.alloc(S.ph, 18) || S.alloc(S.sh, 19))) return 1;
+    if (const char* ne = getenv("PA_MG_NU")) {
+      int a = 2, b = 2, c = 8;
+      double w = 0.85;
+      if (sscanf(ne, "%d %d %d %lf", &a, &b, &c, &w) >= 2) { S.nu1 = std::max(a, 1); S.nu2 = std::max(b, 0); S.nub = std::max(c, 1); S.jac_omega = w; }
+    }
   }
   for (int l = 0; l < nlev; ++l) {
     const pa_level* L = S.lev[l];

@@ -236,7 +236,7 @@ int main(int argc, char** argv) {
         int its = 0;
         double res = 0.0;
         if (pa_smooth_last(ctx.h, &its, &res) == 0)
-          std::cout << "Smoothing solve (BiCGStab on the composite operator): " << its << " iterations, resid/bnorm = " << res << "\n";
+          std::cout << "Smoothing solve (BiCGStab on the composite operator, multigrid-preconditioned where the step is stiff): " << its << " iterations, resid/bnorm = " << res << "\n";
         if (verbose) std::cout << "Progress variable smoothed successfully \n";
       }
       rK = 1; rN = 2; rKg = 5; rSR = 6; rVn = 7; rROST = 8;
