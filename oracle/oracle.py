@@ -185,7 +185,7 @@ def grad_pipeline(levels, states, comp, bc, outs, ocomp, multipass=True, omp=Fal
 
 def curvature_pipeline(levels, states, comp, bc, outs, ocomp, MF, prog_min=None, prog_max=None, threshold=None,
                        do_gauss=False, vel_comp=None, do_strain=False, do_velnormal=False, strain_tensor=False, omp=False,
-                       do_smooth=False, smoothing_time=1e-7, smooth_tol=1e-12, spacedim=3):
+                       do_smooth=False, smoothing_time=1e-7, smooth_tol=1e-12, spacedim=3, smooth_maxiter=100):
     """curvature.cpp:283-326 + 408-570 (core), 575-789 (options).
     spacedim = 2: the AMREX_SPACEDIM == 2 build on a hierarchy stored as one plane of cells (k = 0, z a wall): the
     divergence runs over x and y only and is NOT halved (:542-546 multiplies by 0.5 in 3-D only); the gradient pieces
@@ -208,7 +208,7 @@ def curvature_pipeline(levels, states, comp, bc, outs, ocomp, MF, prog_min=None,
     progress = [c.copy() for c in cmf] if do_smooth else None
     if do_smooth:  # :328-406; everything below uses the smoothed field (idprogvar = idSmProg, :408)
         bc_s = [BC_PERIODIC if v == BC_PERIODIC else BC_NEUMANN for v in bc]  # curvature.cpp:348-357: Periodic / Neumann only, sym_dir ignored
-        sol, it, res = smooth_solve(levels, cmf, 0, smoothing_time, bc_s, MF, tol=smooth_tol, maxiter=100, omp=omp)
+        sol, it, res = smooth_solve(levels, cmf, 0, smoothing_time, bc_s, MF, tol=smooth_tol, maxiter=smooth_maxiter, omp=omp)
         assert it > 0, f"composite smoothing solve failed ({it}, residual {res})"
         for l in range(nlev):
             L.orc_copy(_p(_mf(sol[l])), 0, _p(_mf(cmf[l])), 0, 1, 0)

@@ -481,11 +481,16 @@ def test_curvature_tool_options(tmp_path, oracle):
 
 
 @pytest.mark.gpu
-def test_curvature_tool_do_smooth(tmp_path, oracle):
+@pytest.mark.parametrize("dt", [1e-3, 2.5e-2])
+def test_curvature_tool_do_smooth(tmp_path, oracle, dt):
     """do_smooth=1 smoothing_time=<dt> (curvature.cpp:328-406): SmoothedProgress from the composite implicit solve
-    (to the oracle's solve within 1e-10), Progress untouched, curvature computed from the smoothed field"""
+    (to the oracle's solve within 1e-10), Progress untouched, curvature computed from the smoothed field.  dt = 2.5e-2 is
+    dt / dx^2 = 100 on the finest level: the tool's solve then runs with the multigrid preconditioner (pa_smooth.hip), the
+    oracle's stays the plain iteration"""
     p, H, mfs = _synth(tmp_path, nlev=3, ncomp=1, names=("temp",))
-    _run("curvature3d.ex", ["infile=" + p, "is_per=1 1 0", "do_smooth=1", "smoothing_time=1e-3"], tmp_path)
+    out = _run("curvature3d.ex", ["infile=" + p, "is_per=1 1 0", "do_smooth=1", f"smoothing_time={dt}"], tmp_path)
+    its = int(out.stdout.split("Smoothing solve")[1].split(":")[1].split("iterations")[0])
+    assert 0 < its < (40 if dt > 1e-2 else 100), out.stdout
     r = read_plotfile(str(tmp_path / "plt00005_K"))
     assert r.names == ["temp", "Progress", "SmoothedProgress", "MeanCurvature_temp", "FlameNormalX_temp", "FlameNormalY_temp", "FlameNormalZ_temp",
                        "GaussianCurvature_temp"]
@@ -494,7 +499,7 @@ def test_curvature_tool_do_smooth(tmp_path, oracle):
         for b in range(lv.nboxes):
             st[l].valid(b)[:] = mfs[l].valid(b)
     oc = [MultiFab(lv, 18, 0) for lv in H.levels]
-    oracle.curvature_pipeline(H.levels, st, 0, oracle.bc_from_flags((1, 1, 0)), oc, 0, MultiFab, do_smooth=True, smoothing_time=1e-3, smooth_tol=1e-13)
+    oracle.curvature_pipeline(H.levels, st, 0, oracle.bc_from_flags((1, 1, 0)), oc, 0, MultiFab, do_smooth=True, smoothing_time=dt, smooth_tol=1e-13, smooth_maxiter=3000)
     for l, lv in enumerate(H.levels):
         for b in range(lv.nboxes):
             v, w = r.mfs[l].valid(b), oc[l].valid(b)
