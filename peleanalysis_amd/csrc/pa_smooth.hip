@@ -99,6 +99,27 @@ __global__ __launch_bounds__(256) void k_smooth_apply(DLevelView L, DMFView X, D
   }
 }
 
+// multigrid smoother / residual in one pass over a level (x with resolved ring-1 face ghosts):
+//   MODE 0: y = x + om (r - A x)   (a damped-Jacobi step into a SECOND buffer)      MODE 1: y = r - A x
+template <int MODE>
+__global__ __launch_bounds__(256) void k_smooth_jacobi(DLevelView L, DMFView X, DMFView R, DMFView Y, double dt, double om) {
+  PA_BOX_LOOP(L) {
+    int i, j, k;
+    it.cell(t, i, j, k);
+    const double* x = X.data + X.off[b];
+    const long long nxg = it.nx + 2 * X.ng, nyg = it.ny + 2 * X.ng;
+    const long long q = fab_index(it.B, X.ng, X.ncomp, 0, i, j, k);
+    const double c = x[q];
+    const double d0 = L.dxinv[0], d1 = L.dxinv[1], d2 = L.dxinv[2];
+    double div = 0.0;
+    div += d0 * (d0 * (x[q + 1] - c) - d0 * (c - x[q - 1]));
+    div += d1 * (d1 * (x[q + nxg] - c) - d1 * (c - x[q - nxg]));
+    div += d2 * (d2 * (x[q + nxg * nyg] - c) - d2 * (c - x[q - nxg * nyg]));
+    const double res = R.data[R.off[b] + fab_index(it.B, R.ng, R.ncomp, 0, i, j, k)] - (c - dt * div);
+    Y.data[Y.off[b] + fab_index(it.B, Y.ng, Y.ncomp, 0, i, j, k)] = MODE == 0 ? c + om * res : res;
+  }
+}
+
 // reflux from the fine side: thread per coarse face of a special fine face (coarse-fine cells only)
 __global__ __launch_bounds__(256) void k_smooth_reflux(DLevelView LF, DMFView XF, DLevelView LC, DMFView XC, DMFView YC, double dt, int ratio) {
   const int e = LF.sfaces[blockIdx.y];
@@ -715,15 +736,15 @@ struct SmoothSolver {
     }
     return 0;
   }
-  // w = A_g e on MG level g (level-local: same-level + wall ghost cells, coarse-fine ghost cells from the coarser level's e)
-  int mg_apply(int g) {
+  // ghost cells of the CURRENT correction of MG level g (level-local: same-level neighbours, walls, and at coarse-fine faces the coarser
+  // level's current correction through the operator's own applyBC)
+  int mg_ghosts(int g) {
     MgLev& X = mg[(size_t)g];
     if (pa_fill_boundary(ctx, X.e, 0, 1, 1)) return 1;
-    if (pa_apply_bc(ctx, X.e, 0, g > mg_sub ? mg[(size_t)g - 1].e : nullptr, 0, bc, ratio, -1)) return 1;
-    on_boxes(k_smooth_apply, X.L, box_grid(X.L), X.L->view, X.e->view, X.w->view, dt);
-    return 0;
+    return pa_apply_bc(ctx, X.e, 0, g > mg_sub ? mg[(size_t)g - 1].e : nullptr, 0, bc, ratio, -1);
   }
-  // nu damped-Jacobi steps on A_g e = r_g; zero_start: e is 0 (the first step needs no operator application)
+  // nu damped-Jacobi steps on A_g e = r_g, each ONE pass (k_smooth_jacobi<0>: reads e and r, writes the new e into the level's second
+  // buffer; the two are swapped: X.e is always the current one); zero_start: e is 0 (the first step needs no operator application)
   int mg_smooth(int g, int nu, bool zero_start) {
     MgLev& X = mg[(size_t)g];
     double D = 1.0;
@@ -735,12 +756,13 @@ struct SmoothSolver {
         on_boxes(k_smooth_axpbypcz, X.L, box_grid(X.L), X.L->view, om, X.r->view, 1, 0.0, X.r->view, 0, 0.0, X.e->view);  // e = om r
         continue;
       }
-      if (mg_apply(g)) return 1;
-      on_boxes(k_smooth_axpbypcz, X.L, box_grid(X.L), X.L->view, om, X.r->view, 1, -om, X.w->view, 1, 1.0, X.e->view);  // e += om (r - A e)
+      if (mg_ghosts(g)) return 1;
+      on_boxes(k_smooth_jacobi<0>, X.L, box_grid(X.L), X.L->view, X.e->view, X.r->view, X.w->view, dt, om);
+      std::swap(X.e, X.w);
     }
     return 0;
   }
-  int nu1 = 2, nu2 = 2, nub = 8;  // pre- / post-smoothing steps, steps on the coarsest level (PA_MG_NU="nu1 nu2 nub", read per solve)
+  int nu1 = 2, nu2 = 2, nub = 8;  // pre- / post-smoothing steps, steps on the coarsest level (PA_MG_NU="nu1 nu2 nub omega", read per solve)
   double jac_omega = 0.85;
   int vcycle(Vecs& R, Vecs& Z) {
     const int G = (int)mg.size();
@@ -748,9 +770,9 @@ struct SmoothSolver {
     for (int g = 0; g < G; ++g) PA_HIP(hipMemsetAsync(mg[(size_t)g].e->data, 0, sizeof(double) * (size_t)mg[(size_t)g].e->total, ctx->stream));
     for (int g = G - 1; g > 0; --g) {
       if (mg_smooth(g, nu1, true)) return 1;
-      if (mg_apply(g)) return 1;
+      if (mg_ghosts(g)) return 1;
       MgLev& X = mg[(size_t)g];
-      on_boxes(k_smooth_axpbypcz, X.L, box_grid(X.L), X.L->view, 1.0, X.r->view, 1, 0.0, X.r->view, 0, -1.0, X.w->view);  // w = r - A e
+      on_boxes(k_smooth_jacobi<1>, X.L, box_grid(X.L), X.L->view, X.e->view, X.r->view, X.w->view, dt, 0.0);  // w = r - A e
       MgLev& C = mg[(size_t)g - 1];
       hipLaunchKernelGGL(k_smooth_avgdown, box_grid(X.L), dim3(256), 0, ctx->stream, X.L->view, X.w->view, C.L->view, C.r->view, ratio);
     }
