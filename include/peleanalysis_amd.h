@@ -489,6 +489,11 @@ int pa_smooth_last(const pa_ctx*, int* iters, double* rel_residual);
  * pass per level, 0 = one kernel per AMReX call (fused = 0, do_smooth, 2-D levels, boxes thinner than 3 cells, or a hierarchy the
  * all-levels sweeps do not take; on a sharded hierarchy the ranks agree on one answer), -1 = none yet.  Diagnostic (tests, bench.py). */
 int pa_curvature_last_path(const pa_ctx*);
+/* Work multifabs the library keeps with a level between calls (pa_curvature_run: the gradient of c, 3 components, or the pass-by-pass
+ * path's 8; pa_smooth_solve: its 8-13 vectors) -- kept because a multi-GB hipMalloc + hipFree per call cost more than the kernels they
+ * served.  pa_level_destroy frees them; this frees them now (after a synchronisation of the context's stream) and returns the bytes
+ * released.  The next call that needs them allocates again. */
+int64_t pa_level_free_scratch(pa_level*);
 /* fused grad+curvature of one variable: out[lev] comps ocomp+0..3 = gx,gy,gz,|g|,
  * +4..6 FlameNormal, +7 MeanCurvature.  work[lev]: scratch mf, 1 comp, ng=2. */
 int pa_gradcurv_run(pa_ctx*, int nlev, pa_mf* const* state, int comp, const int32_t bc[3],

@@ -177,6 +177,7 @@ def load_library() -> C.CDLL:
         "pa_stream_trace_ranks": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.c_int, i64, pdbl, C.c_int, dbl, vp, pi32, C.c_int]),
         "pa_smooth_last": (C.c_int, [vp, C.POINTER(C.c_int), pdbl]),
         "pa_curvature_last_path": (C.c_int, [vp]),
+        "pa_level_free_scratch": (i64, [vp]),
         "pa_grad_run": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.c_int, pi32, C.POINTER(vp), C.c_int]),
         "pa_curvature_run": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.c_int, pi32, C.POINTER(PaCurvParams), C.POINTER(vp), C.c_int]),
         "pa_gradcurv_run": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.c_int, pi32, C.POINTER(PaCurvParams), C.POINTER(vp), C.POINTER(vp),

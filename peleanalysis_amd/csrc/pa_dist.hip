@@ -391,6 +391,18 @@ CsPlan::~CsPlan() {
 pa_level::~pa_level() {
   for (auto& kv : scratch) pa_mf_destroy(kv.second);
 }
+extern "C" int64_t pa_level_free_scratch(pa_level* L) {
+  if (!L) return 0;
+  PaBind bind_(L->ctx);
+  if (L->ctx && L->ctx->stream) (void)hipStreamSynchronize(L->ctx->stream);  // a kernel still in flight may be using them
+  int64_t bytes = 0;
+  for (auto& kv : L->scratch) {
+    bytes += kv.second ? 8 * (int64_t)kv.second->total : 0;
+    pa_mf_destroy(kv.second);
+  }
+  L->scratch.clear();
+  return bytes;
+}
 pa_mf* pa_level_scratch(pa_ctx* ctx, const pa_level* L, int ncomp, int ng, int role) {
   const std::array<int, 3> key{ncomp, ng, role};
   auto it = L->scratch.find(key);

@@ -385,6 +385,15 @@ def test_curvature_options_match_oracle(ctx, oracle, name):
         assert ctx.bc_errors() == 0
         for l in range(H.nlev):
             assert_valid_bits_equal(dout[l].download(), oout[l], [(c, c) for c in range(17)], f"{name} options fused {fused} level {l}")
+    # the work multifabs kept with the levels can be released (and come back on the next call)
+    freed = sum(int(ctx.lib.pa_level_free_scratch(dl.h)) for dl in dls)
+    assert freed > 0 and sum(int(ctx.lib.pa_level_free_scratch(dl.h)) for dl in dls) == 0
+    for m in dout:
+        m.setval(-7.0)
+    capi.curvature_run(ctx, dst, 0, bc, capi.curv_params(threshold=0.05, fused=True, do_gauss=True, do_strain=True, strain_tensor=True, do_velnormal=True, vel_comp=1), dout, 0)
+    ctx.sync()
+    for l in range(H.nlev):
+        assert_valid_bits_equal(dout[l].download(), oout[l], [(c, c) for c in range(17)], f"{name} options after pa_level_free_scratch, level {l}")
     # too few output components are rejected before any launch
     small = [capi.DevMF(ctx, dl, 6, 0) for dl in dls]
     with pytest.raises(capi.PaError):

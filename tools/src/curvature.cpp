@@ -246,6 +246,9 @@ int main(int argc, char** argv) {
     }
     ctx.check(pa_sync(ctx.h));
     if (pa_bc_errors(ctx.h) != 0) pa::Abort("coarse-fine boundary: fine grids are not properly nested in the coarse level");
+    // the library's work multifabs of these levels (gradient of c, solver vectors) are not needed again: their memory goes to the
+    // assembly buffers below
+    for (int l = 0; l < Nlev; ++l) (void)pa_level_free_scratch(dl[l]->h);
     if (r == 0) tm.mark("compute");
     // the ghost-free output state (curvature.cpp:833-839) is put together on the device and comes down in one piece:
     // input components (valid cells of the state: the passes only write ghost cells), Progress (curvature.cpp:319, the
