@@ -18,6 +18,7 @@
 // Float rules: no contraction (Makefile), correctly rounded `/` and sqrtf (hipcc default),
 // denormals kept; the two double-precision steps of the reference (:9, :131-133) are kept in double.
 #include "pa_internal.h"
+#include <cstdio>
 #include "pa_fabview.h"
 #include <cmath>
 #include <cstring>
@@ -151,30 +152,53 @@ __global__ __launch_bounds__(256) void k_sdf_unpack(const SdfGrid* grids) {
 }
 
 // :46-58 for one point, the 7 upwind neighbours in the reference's order
+// COH (experiments only): phi / ct read with agent-scope relaxed atomic loads (they bypass the CU's vector cache and hit the XCD's L2)
+template <bool COH = false>
 __device__ __forceinline__ void relax_point(const SdfGrid& G, int i, int j, int k, int di, int dj, int dk) {
   const long long sj = G.ni, sk = (long long)G.ni * G.nj, q = (long long)k * sk + j * sj + i;
   const V3 gx = grid_point(G, i, j, k);
-  float phi = G.phi[q];
-  int ct = G.ct[q];
+  float phi = COH ? __hip_atomic_load(&G.phi[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : G.phi[q];
+  int ct = COH ? __hip_atomic_load(&G.ct[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : G.ct[q];
   const long long nb[7] = {q - di, q - dj * sj, q - di - dj * sj, q - dk * sk, q - di - dk * sk, q - dj * sj - dk * sk, q - di - dj * sj - dk * sk};
   // A triangle whose distance to this point is already known to be >= phi cannot pass the strict
   // `d < phi` test: the point's own closest triangle (d == phi when phi came from it -- phi always is
   // the distance to triangle ct once ct >= 0) and a triangle already tried in this call.  Skipping
   // those evaluations changes nothing in the result; after the first sweeps most neighbours share
   // the point's triangle.
+  // The loads of all candidates are issued together -- the 7 neighbours' triangles, then the vertex indices of those that will be
+  // evaluated, then their vertices -- and only the comparisons run in the reference's order: a chain of three memory latencies per
+  // point instead of up to 1 + 2 x 7 (the distances do not depend on phi; the skip rules only on the triangles).
   int tried[7];
+  bool ev[7];
   const int ct0 = ct;
   bool changed = false;
 #pragma unroll
+  for (int m = 0; m < 7; ++m) tried[m] = COH ? __hip_atomic_load(&G.ct[nb[m]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : G.ct[nb[m]];
+#pragma unroll
   for (int m = 0; m < 7; ++m) {
-    const int t = G.ct[nb[m]];
-    tried[m] = t;
+    const int t = tried[m];
     bool skip = (t < 0) || (t == ct0);
 #pragma unroll
     for (int r = 0; r < m; ++r) skip = skip || (tried[r] == t);
-    if (!skip) {
-      const float d = dist_to_tri(G, gx, t);
-      if (d < phi) { phi = d; ct = t; changed = true; }
+    ev[m] = !skip;
+  }
+  unsigned vi[7][3];
+#pragma unroll
+  for (int m = 0; m < 7; ++m) {
+    const long long t = ev[m] ? (long long)tried[m] : 0;  // triangle 0 exists (the sweeps run only where ntri > 0): a harmless load
+#pragma unroll
+    for (int c = 0; c < 3; ++c) vi[m][c] = G.tri[3 * t + c];
+  }
+  V3 vx[7][3];
+#pragma unroll
+  for (int m = 0; m < 7; ++m)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) vx[m][c] = G.x[vi[m][c]];
+#pragma unroll
+  for (int m = 0; m < 7; ++m) {
+    if (ev[m]) {
+      const float d = point_triangle_distance(gx, vx[m][0], vx[m][1], vx[m][2]);
+      if (d < phi) { phi = d; ct = tried[m]; changed = true; }
     }
   }
   if (changed) {
@@ -226,6 +250,12 @@ __global__ __launch_bounds__(256) void k_sdf_sweep_plane(const SdfGrid* grids, i
   relax_point(G, i, j, k, di, dj, dk);
 }
 
+// (Round 5, second session, measured and not kept: ALL sweeps of a batch in one launch with a barrier per XCD -- the 32 CUs of an XCD share
+// one L2, a step's plain stores are written through to it and agent-scope relaxed loads find them there without any cache flush
+// (tools/bench/xcdsync.hip: 1-2 us per barrier + step, 0 wrong values in 2000 dependent steps; buffer_inv sc0 does not drop the vector
+// cache, sc1 costs 9-30 us).  Bit-identical, but 125-143 ms per 130^3 grid against 76 ms and 15.5 ms per grid in a batch of 16
+// against 8.0: a hyperplane of ~10^4 points is throughput work -- ~18 us on the 32 CUs of one XCD, ~3 on the chip -- so the launch
+// per hyperplane, whose kernel uses all eight XCDs, stays.)
 static int ensure_scr_sdf(pa_ctx* ctx, size_t bytes) {
   if (ctx->scr_cap >= bytes) return 0;
   if (ctx->d_scr) (void)hipFree(ctx->d_scr);
