@@ -155,6 +155,7 @@ __global__ __launch_bounds__(256) void k_sdf_unpack(const SdfGrid* grids) {
 // COH (experiments only): phi / ct read with agent-scope relaxed atomic loads (they bypass the CU's vector cache and hit the XCD's L2)
 template <bool COH = false>
 __device__ __forceinline__ void relax_point(const SdfGrid& G, int i, int j, int k, int di, int dj, int dk) {
+  if (G.ntri <= 0) return;  // a grid of the batch without triangles: every point keeps its upper bound (and there is no triangle 0 to load below)
   const long long sj = G.ni, sk = (long long)G.ni * G.nj, q = (long long)k * sk + j * sj + i;
   const V3 gx = grid_point(G, i, j, k);
   float phi = COH ? __hip_atomic_load(&G.phi[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : G.phi[q];
