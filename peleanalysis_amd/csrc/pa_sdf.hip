@@ -18,7 +18,6 @@
 // Float rules: no contraction (Makefile), correctly rounded `/` and sqrtf (hipcc default),
 // denormals kept; the two double-precision steps of the reference (:9, :131-133) are kept in double.
 #include "pa_internal.h"
-#include <cstdio>
 #include "pa_fabview.h"
 #include <cmath>
 #include <cstring>
@@ -152,14 +151,12 @@ __global__ __launch_bounds__(256) void k_sdf_unpack(const SdfGrid* grids) {
 }
 
 // :46-58 for one point, the 7 upwind neighbours in the reference's order
-// COH (experiments only): phi / ct read with agent-scope relaxed atomic loads (they bypass the CU's vector cache and hit the XCD's L2)
-template <bool COH = false>
 __device__ __forceinline__ void relax_point(const SdfGrid& G, int i, int j, int k, int di, int dj, int dk) {
   if (G.ntri <= 0) return;  // a grid of the batch without triangles: every point keeps its upper bound (and there is no triangle 0 to load below)
   const long long sj = G.ni, sk = (long long)G.ni * G.nj, q = (long long)k * sk + j * sj + i;
   const V3 gx = grid_point(G, i, j, k);
-  float phi = COH ? __hip_atomic_load(&G.phi[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : G.phi[q];
-  int ct = COH ? __hip_atomic_load(&G.ct[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : G.ct[q];
+  float phi = G.phi[q];
+  int ct = G.ct[q];
   const long long nb[7] = {q - di, q - dj * sj, q - di - dj * sj, q - dk * sk, q - di - dk * sk, q - dj * sj - dk * sk, q - di - dj * sj - dk * sk};
   // A triangle whose distance to this point is already known to be >= phi cannot pass the strict
   // `d < phi` test: the point's own closest triangle (d == phi when phi came from it -- phi always is
@@ -174,7 +171,7 @@ __device__ __forceinline__ void relax_point(const SdfGrid& G, int i, int j, int 
   const int ct0 = ct;
   bool changed = false;
 #pragma unroll
-  for (int m = 0; m < 7; ++m) tried[m] = COH ? __hip_atomic_load(&G.ct[nb[m]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : G.ct[nb[m]];
+  for (int m = 0; m < 7; ++m) tried[m] = G.ct[nb[m]];
 #pragma unroll
   for (int m = 0; m < 7; ++m) {
     const int t = tried[m];
