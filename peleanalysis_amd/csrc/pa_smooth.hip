@@ -11,6 +11,7 @@
 #include "pa_internal.h"
 #include "pa_fabview.h"
 #include "pa_dist.h"
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -699,8 +700,7 @@ struct SmoothSolver {
     }
   }
   int mg_setup() {
-    std::vector<MgLev> sub;
-    const pa_level* Lc = lev[0];
+    const pa_level* Lc = lev[0];  // (every coarsened level goes into `mg` at once: the destructor frees it whatever happens later)
     // coarsen level 0 while every box halves evenly, stays >= 4 cells thick and dt / dx^2 of the CURRENT coarsest level is not small yet
     for (int n = 0; n < 8; ++n) {
       double q = 0.0;
@@ -722,11 +722,11 @@ struct SmoothSolver {
       if (!Ln) return 1;
       MgLev g;
       g.L = g.owned = Ln;
-      sub.push_back(g);
+      mg.push_back(g);
       Lc = Ln;
     }
-    mg_sub = (int)sub.size();
-    for (int q = mg_sub - 1; q >= 0; --q) mg.push_back(sub[(size_t)q]);  // coarsest first
+    mg_sub = (int)mg.size();
+    std::reverse(mg.begin(), mg.end());  // coarsest first
     for (int l = 0; l < nlev; ++l) { MgLev g; g.L = lev[l]; mg.push_back(g); }
     for (MgLev& g : mg) {
       g.e = g.owned ? pa_mf_create(ctx, g.L, 1, 1, nullptr) : pa_level_scratch(ctx, g.L, 1, 1, 20);
