@@ -55,6 +55,10 @@ def test_cpp_template_tool_roundtrip(tmp_path):
     # finestLevel clamps; a missing required key aborts with the ParmParse message
     out = subprocess.run([os.path.join(BIN, "template3d.ex"), "infile=" + p, "finestLevel=0"], cwd=tmp_path, capture_output=True, text=True)
     assert out.returncode == 0 and read_plotfile(str(tmp_path / "plt00005_temp")).hier.nlev == 1
+    # the second run over the first one's output: the old directory was moved away and removed (pa::OldOutput, as AMReX's
+    # UtilCreateCleanDirectory does) -- no levels of the three-level run survive, no '.old.<pid>' directory is left behind
+    assert sorted(os.listdir(tmp_path / "plt00005_temp")) == ["Header", "Level_0"]
+    assert not [f for f in os.listdir(tmp_path) if ".old." in f]
     out = subprocess.run([os.path.join(BIN, "template3d.ex"), "finestLevel=0"], cwd=tmp_path, capture_output=True, text=True)
     assert out.returncode != 0 and "infile" in out.stderr
 
