@@ -607,9 +607,11 @@ inline std::vector<Box3> max_size(const std::vector<Box3>& in, int n) {
 struct OldOutput {
   std::thread th;
   static int rm_entry(const char* p, const struct stat*, int, struct FTW*) { return ::remove(p); }
-  void move_away(const std::string& path) {
-    struct stat st;
+  // input: the plotfile the tool is about to read -- an output path that IS the input (outfile=<infile>) is left alone
+  void move_away(const std::string& path, const std::string& input = std::string()) {
+    struct stat st, si;
     if (::stat(path.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) return;
+    if (!input.empty() && ::stat(input.c_str(), &si) == 0 && si.st_dev == st.st_dev && si.st_ino == st.st_ino) return;
     const std::string old = path + ".old." + std::to_string((long)::getpid());
     if (::rename(path.c_str(), old.c_str()) != 0) return;  // left in place: the writer truncates the files as before
     th = std::thread([old] { ::nftw(old.c_str(), rm_entry, 64, FTW_DEPTH | FTW_PHYS); });

@@ -39,7 +39,7 @@ int main(int argc, char** argv) {
   std::string outfile = pa::getFileRoot(infile) + "_K";
   pp.query("outfile", outfile);
   pa::OldOutput old_out;
-  old_out.move_away(outfile);  // an earlier run's output goes away while this one reads and computes
+  old_out.move_away(outfile, infile);  // an earlier run's output goes away while this one reads and computes
   pp.query("finestLevel", finestLevel);
   pp.query("do_gaussCurv", do_gaussCurv);
   pp.query("progressName", progressName);

@@ -62,7 +62,7 @@ int main(int argc, char** argv) {
 #endif
   pa::PhaseTimer tm(pp, PA_SPACEDIM == 2 ? "filterPlt2d" : "filterPlt3d");
   pa::OldOutput old_out;
-  old_out.move_away(pa::getFileRoot(infile) + "_filtered");  // an earlier run's output goes away while this one reads and computes
+  old_out.move_away(pa::getFileRoot(infile) + "_filtered", infile);  // an earlier run's output goes away while this one reads and computes
   pa::PlotfileHeader H = pa::read_header(infile, PA_SPACEDIM, /* any_ratio: filterPlt.cpp:133,200 take the file's */ true);
   const int Nlev = std::min(finestLevel + 1, H.nlev);
   std::vector<std::string> names;

@@ -34,7 +34,7 @@ int main(int argc, char** argv) {
   std::string outfile = pa::getFileRoot(infile) + "_gt";
   pp.query("outfile", outfile);
   pa::OldOutput old_out;
-  old_out.move_away(outfile);  // an earlier run's output goes away while this one reads and computes
+  old_out.move_away(outfile, infile);  // an earlier run's output goes away while this one reads and computes
   pa::PlotfileHeader H = pa::read_header(infile, PA_SPACEDIM);
   finestLevel = std::min(finestLevel, H.nlev - 1);
   const int Nlev = finestLevel + 1;
