@@ -459,8 +459,8 @@ typedef struct {
  * out[lev] comps: ocomp+0 Progress, +1 MeanCurvature, +2..4 FlameNormal, and when requested
  * +5 GaussianCurvature, +6 StrainRate, +7 VelFlameNormal, +8..16 ROST_dU?d? (row-major grad u), and with
  * do_smooth +17 SmoothedProgress.
- * Two implementations with identical results (bit for bit; both tested against the oracle): fused != 0 on one rank, 3-D, without
- * do_smooth, boxes >= 3 cells thick: Progress / MeanCurvature / FlameNormal from the exact-normal pipeline of pa_gradcurv_run, whose
+ * Two implementations with identical results (bit for bit; both tested against the oracle): fused != 0, 3-D, boxes >= 3 cells thick
+ * (one rank or a sharded hierarchy; with do_smooth the smoothed field is the pipeline's progress source with range [0, 1]): Progress / MeanCurvature / FlameNormal from the exact-normal pipeline of pa_gradcurv_run, whose
  * sweeps leave the cell-centred gradient of c (curvature.cpp:457-490, what do_gaussCurv differentiates again at :582-613) in a work
  * multifab of the level (3 components + 1 ghost layer, kept for the level's lifetime) instead of grad phi, then one pass per level
  * for the options; otherwise (or PA_CURV_FAST=0 in the environment) one pass per AMReX call of the reference. */

@@ -606,20 +606,41 @@ static int fused_passes(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, co
 // pa_curvature_run on the exact-normal pipeline (see there).  out components as curvature_passes writes them.
 static int curvature_fast(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, const int32_t bc[3], double pmin, double pmax, double thr,
                           pa_mf* const* out, int opt, const pa_curv_params* P) {
-  const bool gauss = P->do_gauss_curv, strain = P->do_strain, veln = P->do_velnormal;
+  const bool gauss = P->do_gauss_curv, strain = P->do_strain, veln = P->do_velnormal, smooth = P->do_smooth != 0;
   for (int l = 0; l < nlev; ++l) {
-    const int need = opt + (strain && P->get_strain_tensor ? 17 : (veln ? 8 : (strain ? 7 : (gauss ? 6 : 5))));
+    const int need = opt + (smooth ? 18 : (strain && P->get_strain_tensor ? 17 : (veln ? 8 : (strain ? 7 : (gauss ? 6 : 5)))));
     if (out[l]->ncomp < need) return pa_fail(ctx, "pa_curvature_run: out needs " + std::to_string(need) + " components for the requested options");
     if ((strain || veln) && (P->vel_comp < 0 || P->vel_comp + 3 > state[l]->ncomp)) return pa_fail(ctx, "pa_curvature_run: vel_comp out of range");
   }
-  std::vector<pa_mf*> G(nlev);
+  std::vector<pa_mf*> G(nlev), src(state, state + nlev);
   for (int l = 0; l < nlev; ++l) {
     G[l] = pa_level_scratch(ctx, state[l]->lev, 3, 1);
     if (!G[l]) return 1;
   }
+  int scomp = comp;
+  double smin = pmin, smax = pmax;
+  if (smooth) {
+    // :328-406: c~ solves (I - dt Lap) c~ = c; everything below works on c~ (idprogvar = idSmProg, :408).  The sweeps form the progress
+    // variable as (x - pmin) * (1 / (pmax - pmin)): with x = c~, pmin = 0, pmax = 1 that is (c~ - 0.0) * 1.0 = c~ bit for bit, so the
+    // smoothed field goes through the same pipeline as a source with range [0, 1] (2 ghost layers: a work multifab of the level).
+    for (int l = 0; l < nlev; ++l) {
+      src[l] = pa_level_scratch(ctx, state[l]->lev, 1, 2, 30);
+      if (!src[l]) return 1;
+      PA_TRY(pa_progress_level(ctx, state[l], comp, pmin, pmax, src[l], 0, 0));  // :316-320
+    }
+    int iters = 0;
+    double res = 0.0;
+    const int32_t bc_s[3] = {bc[0] == PA_BC_PERIODIC ? PA_BC_PERIODIC : PA_BC_NEUMANN, bc[1] == PA_BC_PERIODIC ? PA_BC_PERIODIC : PA_BC_NEUMANN,
+                             bc[2] == PA_BC_PERIODIC ? PA_BC_PERIODIC : PA_BC_NEUMANN};  // :348-357, as in curvature_passes
+    const int rc = pa_smooth_solve(ctx, nlev, src.data(), 0, src.data(), 0, P->smoothing_time, bc_s, 1e-14, 2000, &iters, &res);
+    ctx->smooth_iters = iters;
+    ctx->smooth_res = res;
+    if (rc != 0 && !(iters > 0 && res <= 1e-12)) return 1;
+    scomp = 0; smin = 0.0; smax = 1.0;
+  }
   const bool dist = state[0]->lev->nranks > 1;  // sharded hierarchy: the same pipeline with its two exchanges, ghost fills below across ranks
-  if (dist) PA_TRY(fused_passes_dist(ctx, nlev, state, comp, bc, pmin, pmax, thr, state, out, opt, true, G.data()));
-  else PA_TRY(exact_passes(ctx, nlev, state, comp, bc, pmin, pmax, thr, out, opt, G.data()));  // :316-322, 426-570
+  if (dist) PA_TRY(fused_passes_dist(ctx, nlev, src.data(), scomp, bc, smin, smax, thr, src.data(), out, opt, true, G.data()));
+  else PA_TRY(exact_passes(ctx, nlev, src.data(), scomp, bc, smin, smax, thr, out, opt, G.data()));  // :316-322, 426-570
   // :575-613 ghost cells of G = cell_normal before its normalisation, coarse-fine values from the coarser level's G; :679-757 the
   // velocity's likewise: FillBoundary of all levels in one launch each, applyBC of both fields on all levels in ONE launch
   if (dist) {  // every rank makes the same calls in the same order (pa_fill_boundary / pa_apply_bc exchange inside)
@@ -655,6 +676,11 @@ static int curvature_fast(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, 
       PA_TRY(pa_curvopts_level(ctx, which, G[l], state[l], P->vel_comp, out[l], opt, opt + 2, opt + 5, opt + 6, opt + 7, P->get_strain_tensor ? opt + 8 : -1, thr));
     }
   }
+  if (smooth)  // the sweeps left c~ in the Progress slot (the options' threshold read it there): SmoothedProgress = c~, Progress = the unsmoothed field
+    for (int l = 0; l < nlev; ++l) {
+      PA_TRY(pa_mf_copy(ctx, out[l], opt, out[l], opt + 17, 1, 0));
+      PA_TRY(pa_progress_level(ctx, state[l], comp, pmin, pmax, out[l], opt, 0));
+    }
   return 0;
 }
 
@@ -705,7 +731,7 @@ extern "C" int pa_curvature_run(pa_ctx* ctx, int nlev, pa_mf* const* state, int 
   {
     const char* cfe = getenv("PA_CURV_FAST");
     const bool dist = state[0]->lev->nranks > 1;
-    bool fast = P->fused && P->spacedim != 2 && !P->do_smooth && (!cfe || atoi(cfe));
+    bool fast = P->fused && P->spacedim != 2 && (!cfe || atoi(cfe));
     for (int l = 0; l < nlev && fast; ++l) fast = state[l]->ng >= 2 && (dist || !state[l]->lev->boxes.empty());
     fast = fast && exact_ok(nlev, state, thr) && pa_gradcurv_gout_ok(nlev, state);
     if (dist) {  // the answer depends on the boxes a rank owns: all ranks take the path every one of them can take

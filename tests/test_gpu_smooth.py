@@ -77,6 +77,24 @@ def test_curvature_run_with_smoothing(ctx, oracle, per, sym):
     dout = [capi.DevMF(ctx, dl, 18, 0) for dl in dls]
     capi.curvature_run(ctx, dst, 0, bc, capi.curv_params(fused=False, do_smooth=True, smoothing_time=dt), dout, 0)
     ctx.sync()
+    assert ctx.lib.pa_curvature_last_path(ctx.h) == 0
+    # the same solve feeding the exact-normal pipeline (fused=True: the smoothed field as a progress source of range [0, 1], which the
+    # sweeps' (x - pmin) * invdenom leaves bit for bit): every output, options included, equals the pass-by-pass path's bits
+    st4 = make_states(H, 4, 2, field_flame, seed=41)
+    dst4 = [capi.DevMF.from_host(ctx, dl, s) for dl, s in zip(dls, st4)]
+    both = []
+    for fused in (False, True):
+        o = [capi.DevMF(ctx, dl, 18, 0) for dl in dls]
+        for m in o:
+            m.setval(-7.0)
+        capi.curvature_run(ctx, dst4, 0, bc, capi.curv_params(threshold=0.04, fused=fused, do_smooth=True, smoothing_time=dt, do_gauss=True, do_strain=True,
+                                                             strain_tensor=True, do_velnormal=True, vel_comp=1), o, 0)
+        ctx.sync()
+        assert ctx.lib.pa_curvature_last_path(ctx.h) == (1 if fused else 0)
+        both.append([m.download() for m in o])
+    for l, lv in enumerate(H.levels):
+        for b in range(lv.nboxes):
+            assert np.array_equal(both[0][l].valid(b).view(np.int64), both[1][l].valid(b).view(np.int64)), f"do_smooth + options: fast path != pass by pass, level {l} box {b}"
     for l, lv in enumerate(H.levels):
         g = dout[l].download()
         for b in range(lv.nboxes):
