@@ -1532,7 +1532,8 @@ bool pa_gradcurv_gout_ok(int nlev, pa_mf* const* phi) {
   for (int l = 0; l < nlev; ++l) sweep_groups(l, phi[l]->lev, all);
   int nw = 0, nn = 0;
   for (const SweepGroup& g : all) ++(g.dims[0] <= 32 ? nn : nw);
-  return nw <= PA_MAXB && nn <= PA_MAXB;
+  (void)nw; (void)nn;
+  return all.size() <= 8 * PA_MAXB;  // (the launches come in chunks of PA_MAXB groups)
 }
 
 int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, double pmin, double pmax, pa_mf* const* out, int ocomp, double thr, int slot,
@@ -1559,16 +1560,18 @@ int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, d
   // groups of different tile heights (a level of flat boxes next to one of tall ones): one launch per tile height (until round 5's
   // second session such a hierarchy went group by group, a launch each)
   (void)same;
-  const bool ok = batch_env && !knobs && fused_order() == 2 && !lv.empty() && (int)lv.size() <= PA_MAXB;
+  const bool ok = batch_env && !knobs && fused_order() == 2 && !lv.empty() && lv.size() <= 8u * PA_MAXB;  // more than PA_MAXB groups (a hierarchy of 5+ levels): several launches
   if (!ok) {
     rest.insert(rest.begin(), lv.begin(), lv.end());
     lv.clear();
   }
   const std::vector<SweepGroup> lv_all = lv;
-  for (const int mty_pass : {13, 8, 4}) {
-    std::vector<SweepGroup> lv;
+  for (int pass_i = 0; pass_i < 3 * 8; ++pass_i) {  // (tile height) x (chunk of PA_MAXB groups)
+    const int mty_pass = pass_i / 8 == 0 ? 13 : (pass_i / 8 == 1 ? 8 : 4), chunk = pass_i % 8;
+    std::vector<SweepGroup> lvm, lv;
     for (const SweepGroup& g : lv_all)
-      if ((g.dims[1] >= 52 ? 13 : (g.dims[1] >= 16 ? 8 : 4)) == mty_pass) lv.push_back(g);
+      if ((g.dims[1] >= 52 ? 13 : (g.dims[1] >= 16 ? 8 : 4)) == mty_pass) lvm.push_back(g);
+    for (size_t q = (size_t)chunk * PA_MAXB; q < lvm.size() && q < (size_t)(chunk + 1) * PA_MAXB; ++q) lv.push_back(lvm[q]);
     if (lv.empty()) continue;
     const int mty = mty_pass;
     SweepBatch S;
@@ -1652,10 +1655,12 @@ int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, d
     static const int narrow_env = [] { const char* e = getenv("PA_NARROW"); return e ? atoi(e) : 1; }();
     std::vector<SweepGroup> keep;
     for (const SweepGroup& g : rest) ((g.dims[0] <= 32 && narrow_env) ? nar : keep).push_back(g);
-    if (batch_env && !knobs && fused_order() == 2 && !nar.empty() && (int)nar.size() <= PA_MAXB) rest.swap(keep);
+    if (batch_env && !knobs && fused_order() == 2 && !nar.empty()) rest.swap(keep);
     else nar.clear();
   }
-  if (!nar.empty()) {
+  const std::vector<SweepGroup> nar_all = nar;
+  for (size_t n0 = 0; n0 < nar_all.size(); n0 += PA_MAXB) {  // chunks of PA_MAXB groups
+    const std::vector<SweepGroup> nar(nar_all.begin() + (long)n0, nar_all.begin() + (long)std::min(nar_all.size(), n0 + PA_MAXB));
     constexpr int NRW = 8;
     SweepBatch S;
     S.n = (int)nar.size();

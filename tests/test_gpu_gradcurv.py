@@ -400,6 +400,44 @@ def test_curvature_options_match_oracle(ctx, oracle, name):
         capi.curvature_run(ctx, dst, 0, bc, P, small, 0)
 
 
+@pytest.mark.parametrize("nlev,base,box", [(5, 8, 8), (6, 8, 4), (5, 40, 40)])
+def test_deep_hierarchies_take_the_fused_pipelines(ctx, oracle, nlev, base, box):
+    """five and six levels (what a Pele plotfile often holds): the all-levels launches come in chunks of four groups -- until round 5 a
+    hierarchy of more than four levels went group by group, and its curvature options pass by pass.  The fused grad -> curvature pass
+    and pa_curvature_run with every option (fast path asserted) against the oracle, bit for bit; narrow and wide boxes."""
+    from peleanalysis_amd.hierarchy import nested_hierarchy, field_flame
+    per = (1, 1, 0)
+    H = nested_hierarchy(base, nlev, box, is_per=per)
+    assert H.nlev == nlev
+    states = make_states(H, 4, 2, field_flame, seed=3)
+    bc = capi.bc_from_flags(per)
+    og = [MultiFab(lv, 4, 0) for lv in H.levels]
+    oracle.grad_pipeline(H.levels, [s.copy() for s in states], 0, bc, og, 0, multipass=False)
+    oo = [MultiFab(lv, 17, 0) for lv in H.levels]
+    oracle.curvature_pipeline(H.levels, [s.copy() for s in states], 0, bc, oo, 0, MultiFab, threshold=0.03, do_gauss=True, vel_comp=1, do_strain=True,
+                              do_velnormal=True, strain_tensor=True)
+    ou = [MultiFab(lv, 5, 0) for lv in H.levels]
+    oracle.curvature_pipeline(H.levels, [s.copy() for s in states], 0, bc, ou, 0, MultiFab)
+    dls, dst = _dev(ctx, H, states)
+    work = [capi.DevMF(ctx, dl, 1, 2) for dl in dls]
+    d8 = [capi.DevMF(ctx, dl, 8, 0) for dl in dls]
+    capi.gradcurv_run(ctx, dst, 0, bc, capi.curv_params(fused=True), work, d8, 0)
+    ctx.sync()
+    assert ctx.bc_errors() == 0
+    kn = ctx.lib.pa_sweep_kernel_name(ctx.h).decode()
+    assert "_levels<" in kn, kn
+    for l in range(nlev):
+        got = d8[l].download()
+        assert_valid_bits_equal(got, og[l], [(c, c) for c in range(4)], f"{nlev} levels: grad level {l}")
+        assert_valid_bits_equal(got, ou[l], [(4, 2), (5, 3), (6, 4), (7, 1)], f"{nlev} levels: curvature level {l}")
+    d17 = [capi.DevMF(ctx, dl, 17, 0) for dl in dls]
+    capi.curvature_run(ctx, dst, 0, bc, capi.curv_params(threshold=0.03, fused=True, do_gauss=True, do_strain=True, strain_tensor=True, do_velnormal=True, vel_comp=1), d17, 0)
+    ctx.sync()
+    assert ctx.bc_errors() == 0 and ctx.lib.pa_curvature_last_path(ctx.h) == 1
+    for l in range(nlev):
+        assert_valid_bits_equal(d17[l].download(), oo[l], [(c, c) for c in range(17)], f"{nlev} levels: options level {l}")
+
+
 def test_gradcurv_run_comps_equals_component_by_component(ctx, oracle):
     """pa_gradcurv_run_comps (FillBoundary of all components hoisted into one launch, results delivered through the callback
     before the next component overwrites them) == pa_gradcurv_run per component, bit for bit; wide boxes (exact-normal
