@@ -1074,11 +1074,14 @@ __global__ __launch_bounds__(256) void k_apply_bc_multi(BcMulti S, int* nbad) {
 // applyBC (all directions) on up to two groups of components per level, all levels in one launch; one rank, levels with work tables
 // (every level pa_level_create makes has one).  F2 may be null.  Returns 2 when a level has no work table (the caller falls back).
 int pa_apply_bc_multi(pa_ctx* ctx, int nlev, pa_mf* const* F1, int comp1, int ncomp1, pa_mf* const* F2, int comp2, int ncomp2, const int32_t bc[3]) {
-  if (!ctx || !F1 || nlev < 1 || nlev > PA_MAXB) return pa_fail(ctx, "pa_apply_bc_multi: null argument or too many levels");
+  if (!ctx || !F1 || nlev < 1) return pa_fail(ctx, "pa_apply_bc_multi: null argument");
+  for (int l = 0; l < nlev; ++l)
+    if (F1[l]->lev->nranks > 1 || (!F1[l]->lev->boxes.empty() && !F1[l]->lev->sfaces.empty() && (!F1[l]->lev->d_sfwg || F1[l]->lev->nsfwg <= 0))) return 2;
+  for (int l0 = 0; l0 < nlev; l0 += PA_MAXB) {  // up to PA_MAXB levels per launch
   BcMulti S;
   S.n = 0;
   S.wg0[0] = 0;
-  for (int l = 0; l < nlev; ++l) {
+  for (int l = l0; l < nlev && l < l0 + PA_MAXB; ++l) {
     const pa_level* L = F1[l]->lev;
     if (L->nranks > 1) return 2;
     if (F1[l]->ng < 1 || comp1 < 0 || comp1 + ncomp1 > F1[l]->ncomp) return pa_fail(ctx, "pa_apply_bc_multi: ghost cells / component range");
@@ -1099,10 +1102,11 @@ int pa_apply_bc_multi(pa_ctx* ctx, int nlev, pa_mf* const* F1, int comp1, int nc
     S.wg0[S.n + 1] = S.wg0[S.n] + (unsigned)L->nsfwg;
     ++S.n;
   }
-  if (!S.n) return 0;
+  if (!S.n) continue;
   ProfScope prof(ctx, PA_TAG_BC);
   hipLaunchKernelGGL(k_apply_bc_multi, dim3(S.wg0[S.n], (unsigned)(ncomp1 + (F2 ? ncomp2 : 0))), dim3(256), 0, ctx->stream, S, ctx->d_flags);
   PA_HIP(hipGetLastError());
+  }
   return 0;
 }
 

@@ -654,7 +654,7 @@ static int curvature_fast(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, 
     pa_mf* const* F1 = gauss ? G.data() : state;
     const int c1 = gauss ? 0 : P->vel_comp;
     const char* bme = getenv("PA_BC_MULTI");  // 0 (read per call): a launch per level and component
-    int rc = (!dist && nlev <= PA_MAXB && !(bme && !atoi(bme))) ? pa_apply_bc_multi(ctx, nlev, F1, c1, 3, (gauss && strain) ? state : nullptr, P->vel_comp, 3, bc) : 2;
+    int rc = (!dist && !(bme && !atoi(bme))) ? pa_apply_bc_multi(ctx, nlev, F1, c1, 3, (gauss && strain) ? state : nullptr, P->vel_comp, 3, bc) : 2;
     if (rc == 1) return 1;
     if (rc == 2) {
       for (int l = 0; l < nlev && gauss; ++l)
