@@ -273,6 +273,11 @@ static void cs_rects_of_box(const HostGeom& FG, const DBox& B, int mode, int ng,
         }
         rects.push_back(r);
       }
+  } else if (mode == 2) {
+    // the parents of the box's valid cells, all of them (prolongation of the smoothing solve's multigrid preconditioner)
+    DBox r;
+    for (int t = 0; t < 3; ++t) { r.lo[t] = coarsen_idx(B.lo[t], ratio); r.hi[t] = coarsen_idx(B.hi[t], ratio); }
+    rects.push_back(r);
   } else {
     // pa_fillpatch_two_levels: parents of the ng ghost layers, grown by `halo` coarse cells (slopes / min-max of
     // mf_cell_cons_interp: 1), minus the coarse cells well inside the box
@@ -776,7 +781,7 @@ RsPlan* pa_rs_plan(pa_ctx* ctx, const pa_level* F, const pa_level* C, int ratio)
 
 CsPlan* pa_cs_plan(pa_ctx* ctx, const pa_level* F, const pa_level* C, int mode, int ng, int halo, int ratio) {
   if (mode == 0 && ratio != 2) { pa_fail(ctx, "coarse-source plan of the MLMG boundary: refinement ratio 2 only"); return nullptr; }
-  const auto key = std::make_pair(C->serial, mode == 0 ? 0 : 1 + ng * 16 + halo + 4096 * ratio);
+  const auto key = std::make_pair(C->serial, mode == 0 ? 0 : 1 + ng * 16 + halo + 4096 * ratio + (mode == 2 ? (1 << 20) : 0));
   auto it = F->cs_plans.find(key);
   if (it != F->cs_plans.end()) return it->second.get();
   if (F->nranks != C->nranks || F->rank != C->rank) { pa_fail(ctx, "coarse and fine level are sharded over different rank sets"); return nullptr; }

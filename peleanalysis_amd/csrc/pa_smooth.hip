@@ -689,15 +689,21 @@ struct SmoothSolver {
   // residual is averaged down onto the cells it covers, a level's coarse-fine ghost cells come from the coarser level's correction by
   // the operator's own applyBC (zero on the way down), the flux mismatch at coarse-fine faces is left to the Krylov iteration.  M is a
   // fixed linear operator, so BiCGStab's recurrences hold; the solution it converges to is the unpreconditioned one.
-  struct MgLev { const pa_level* L = nullptr; pa_level* owned = nullptr; pa_mf *e = nullptr, *r = nullptr, *w = nullptr; };  // owned: a coarsened copy of level 0 (its vectors too)
+  // owned: a coarsened copy of level 0 (its vectors too).  Sharded hierarchy: rsd restricts this level onto the one below (cfd lives on
+  // rsd->cf: the fine rank's child averages), csp brings the parents of this rank's cells of this level from their owners (pmf on csp->cs)
+  struct MgLev {
+    const pa_level* L = nullptr; pa_level* owned = nullptr; pa_mf *e = nullptr, *r = nullptr, *w = nullptr;
+    RsPlan* rsd = nullptr; pa_mf* cfd = nullptr; CsPlan* csp = nullptr; pa_mf* pmf = nullptr; bool own_cfd = false, own_vec = false;
+  };
   std::vector<MgLev> mg;
   int mg_sub = 0;  // coarsened copies of level 0: mg[0 .. mg_sub - 1]; AMR level l = mg[mg_sub + l]
   ~SmoothSolver() {
     for (MgLev& g : mg) {
-      if (!g.owned) continue;  // the AMR levels' vectors are kept with the levels
-      pa_mf_destroy(g.e); pa_mf_destroy(g.r); pa_mf_destroy(g.w);
-      pa_level_destroy(g.owned);
+      if (g.own_cfd) pa_mf_destroy(g.cfd);
+      if (g.own_vec) { pa_mf_destroy(g.e); pa_mf_destroy(g.r); pa_mf_destroy(g.w); }  // (one rank: the AMR levels' vectors are kept with the levels)
     }
+    for (MgLev& g : mg)
+      if (g.owned) pa_level_destroy(g.owned);  // after every multifab on it (and on the plans it owns) is gone
   }
   int mg_setup() {
     const pa_level* Lc = lev[0];  // (every coarsened level goes into `mg` at once: the destructor frees it whatever happens later)
@@ -708,17 +714,19 @@ struct SmoothSolver {
       if (q < 0.25) break;
       bool ok = true;
       std::vector<int32_t> b6;
-      for (const DBox& B : Lc->boxes)
+      const std::vector<DBox>& all = dist ? Lc->gboxes : Lc->boxes;  // the WHOLE BoxArray: every rank of a sharded hierarchy decides alike
+      for (const DBox& B : all)
         for (int d = 0; d < 3; ++d) ok = ok && !(B.lo[d] & 1) && ((B.hi[d] - B.lo[d] + 1) % 2 == 0) && (B.hi[d] - B.lo[d] + 1) >= 8;
       for (int d = 0; d < 3; ++d) ok = ok && !(Lc->domlo[d] & 1) && ((Lc->domhi[d] - Lc->domlo[d] + 1) % 2 == 0);
       if (!ok) break;
-      for (const DBox& B : Lc->boxes) {
+      for (const DBox& B : all) {
         for (int d = 0; d < 3; ++d) b6.push_back(B.lo[d] / 2);
         for (int d = 0; d < 3; ++d) b6.push_back((B.hi[d] + 1) / 2 - 1);
       }
       int32_t dlo[3], dhi[3], per[3];
       for (int d = 0; d < 3; ++d) { dlo[d] = Lc->domlo[d] / 2; dhi[d] = (Lc->domhi[d] + 1) / 2 - 1; per[d] = Lc->is_per[d]; }
-      pa_level* Ln = pa_level_create(ctx, (int)Lc->boxes.size(), b6.data(), dlo, dhi, per, Lc->prob_lo, Lc->prob_hi);
+      pa_level* Ln = dist ? pa_level_create_sharded(ctx, (int)all.size(), b6.data(), Lc->gowner.data(), Lc->rank, Lc->nranks, dlo, dhi, per, Lc->prob_lo, Lc->prob_hi)
+                          : pa_level_create(ctx, (int)all.size(), b6.data(), dlo, dhi, per, Lc->prob_lo, Lc->prob_hi);
       if (!Ln) return 1;
       MgLev g;
       g.L = g.owned = Ln;
@@ -729,19 +737,46 @@ struct SmoothSolver {
     std::reverse(mg.begin(), mg.end());  // coarsest first
     for (int l = 0; l < nlev; ++l) { MgLev g; g.L = lev[l]; mg.push_back(g); }
     for (MgLev& g : mg) {
-      g.e = g.owned ? pa_mf_create(ctx, g.L, 1, 1, nullptr) : pa_level_scratch(ctx, g.L, 1, 1, 20);
-      g.r = g.owned ? pa_mf_create(ctx, g.L, 1, 1, nullptr) : pa_level_scratch(ctx, g.L, 1, 1, 21);
-      g.w = g.owned ? pa_mf_create(ctx, g.L, 1, 1, nullptr) : pa_level_scratch(ctx, g.L, 1, 1, 22);
+      g.own_vec = g.owned || dist;
+      g.e = g.own_vec ? pa_mf_create(ctx, g.L, 1, 1, nullptr) : pa_level_scratch(ctx, g.L, 1, 1, 20);
+      g.r = g.own_vec ? pa_mf_create(ctx, g.L, 1, 1, nullptr) : pa_level_scratch(ctx, g.L, 1, 1, 21);
+      g.w = g.own_vec ? pa_mf_create(ctx, g.L, 1, 1, nullptr) : pa_level_scratch(ctx, g.L, 1, 1, 22);
       if (!g.e || !g.r || !g.w) return 1;
+    }
+    if (dist) {  // every plan and buffer the V-cycle will ask for, before the first collective (see setup_dist)
+      for (size_t g = 0; g < mg.size(); ++g) {
+        MgLev& X = mg[g];
+        if (!pa_fb_plan(ctx, X.L, 1)) return 1;
+        if (g == 0) continue;
+        const int l = (int)g - mg_sub;  // AMR level (> 0: its restriction plan and buffer exist already)
+        if (l >= 1) { X.rsd = rs[(size_t)l]; X.cfd = cfw.v[(size_t)l]; }
+        else {
+          X.rsd = pa_rs_plan(ctx, X.L, mg[g - 1].L, ratio);
+          if (!X.rsd) return 1;
+          X.cfd = pa_mf_create(ctx, X.rsd->cf, 1, 1, nullptr);
+          X.own_cfd = true;
+          if (!X.cfd) return 1;
+        }
+        X.csp = pa_cs_plan(ctx, X.L, mg[g - 1].L, 2, 0, 0, ratio);  // the coarse cells under this rank's boxes of level g: the parents
+        if (!X.csp) return 1;
+        X.pmf = X.csp->mf(ctx, 1, 2);
+        if (X.csp->cs && !X.pmf) return 1;
+        if ((int)g > mg_sub) {  // coarse-fine ghost cells of the correction: the operator's coarse-source plan (and its buffer)
+          CsPlan* c0 = pa_cs_plan(ctx, X.L, mg[g - 1].L, 0, 0, 0);
+          if (!c0 || (c0->cs && !c0->mf(ctx, 1))) return 1;
+        }
+      }
     }
     return 0;
   }
   // ghost cells of the CURRENT correction of MG level g (level-local: same-level neighbours, walls, and at coarse-fine faces the coarser
   // level's current correction through the operator's own applyBC)
+  // (sharded: pa_fill_boundary / pa_apply_bc exchange inside; every rank makes the same calls)
   int mg_ghosts(int g) {
     MgLev& X = mg[(size_t)g];
-    if (pa_fill_boundary(ctx, X.e, 0, 1, 1)) return 1;
-    return pa_apply_bc(ctx, X.e, 0, g > mg_sub ? mg[(size_t)g - 1].e : nullptr, 0, bc, ratio, -1);
+    if (pa_fill_boundary(ctx, X.e, 0, 1, 1) && fail_local()) return 1;
+    if (pa_apply_bc(ctx, X.e, 0, g > mg_sub ? mg[(size_t)g - 1].e : nullptr, 0, bc, ratio, -1) && fail_local()) return 1;
+    return 0;
   }
   // nu damped-Jacobi steps on A_g e = r_g, each ONE pass (k_smooth_jacobi<0>: reads e and r, writes the new e into the level's second
   // buffer; the two are swapped: X.e is always the current one); zero_start: e is 0 (the first step needs no operator application)
@@ -774,13 +809,27 @@ struct SmoothSolver {
       MgLev& X = mg[(size_t)g];
       on_boxes(k_smooth_jacobi<1>, X.L, box_grid(X.L), X.L->view, X.e->view, X.r->view, X.w->view, dt, 0.0);  // w = r - A e
       MgLev& C = mg[(size_t)g - 1];
-      hipLaunchKernelGGL(k_smooth_avgdown, box_grid(X.L), dim3(256), 0, ctx->stream, X.L->view, X.w->view, C.L->view, C.r->view, ratio);
+      if (!dist) {
+        hipLaunchKernelGGL(k_smooth_avgdown, box_grid(X.L), dim3(256), 0, ctx->stream, X.L->view, X.w->view, C.L->view, C.r->view, ratio);
+      } else {  // the fine rank averages its own boxes, one exchange hands the averages to the coarse owners
+        on_boxes(k_smooth_avgdown_cf, X.L, box_grid(X.L), X.L->view, X.w->view, X.rsd->cf->view, X.cfd->view, ratio);
+        const XJob J = {&X.rsd->down, X.cfd, 0, C.r, 0, 1};
+        ++nexchange;
+        if (pa_xexchange(ctx, 1, &J) && fail_local()) return 1;
+      }
     }
     if (mg_smooth(0, G > 1 ? nub : std::max(nu1 + nu2, 2), true)) return 1;
     for (int g = 1; g < G; ++g) {
       MgLev& X = mg[(size_t)g];
       MgLev& C = mg[(size_t)g - 1];
-      on_boxes(k_smooth_prolong_add, X.L, box_grid(X.L), X.L->view, X.e->view, C.L->view, C.e->view, ratio);
+      if (!dist) {
+        on_boxes(k_smooth_prolong_add, X.L, box_grid(X.L), X.L->view, X.e->view, C.L->view, C.e->view, ratio);
+      } else {  // the parents of this rank's cells come from their owners (coarse-source plan of the coarsened boxes)
+        const XJob J = {&X.csp->x, C.e, 0, X.pmf, 0, 1};
+        ++nexchange;
+        if (pa_xexchange(ctx, 1, &J) && fail_local()) return 1;
+        if (X.csp->cs && X.pmf) on_boxes(k_smooth_prolong_add, X.L, box_grid(X.L), X.L->view, X.e->view, X.csp->cs->view, X.pmf->view, ratio);
+      }
       if (mg_smooth(g, nu2, false)) return 1;
     }
     for (int l = 0; l < nlev; ++l) on_boxes(k_smooth_copy, lev[l], box_grid(lev[l]), lev[l]->view, mg[(size_t)(mg_sub + l)].e->view, 0, Z.v[l]->view, 0);
@@ -888,8 +937,17 @@ extern "C" int pa_smooth_solve(pa_ctx* ctx, int nlev, pa_mf* const* rhs, int rco
     double q = 0.0;
     for (int d = 0; d < 3; ++d) q = std::max(q, dt * Lf->dxinv[d] * Lf->dxinv[d]);
     const char* me = getenv("PA_SMOOTH_MG");
-    use_mg = !S.dist && S.lev[0]->domlo[2] != S.lev[0]->domhi[2] && (me ? atoi(me) != 0 : q > 8.0);
-    if (use_mg && (S.mg_setup() || S.alloc(S.ph, 18) || S.alloc(S.sh, 19))) return 1;
+    use_mg = S.lev[0]->domlo[2] != S.lev[0]->domhi[2] && (me ? atoi(me) != 0 : q > 8.0);
+    if (use_mg) {
+      int bad = (S.mg_setup() || S.alloc(S.ph, 18) || S.alloc(S.sh, 19)) ? 1 : 0;
+      if (S.dist) {  // the ranks agree on the preconditioner's setup before its first exchange
+        double e = bad ? 1.0 : 0.0;
+        if (pa_allreduce(ctx, &e, 1, 1)) return 1;
+        if (e != 0.0) return bad ? 1 : pa_fail(ctx, "pa_smooth_solve: another rank could not set the multigrid preconditioner up");
+      } else if (bad) {
+        return 1;
+      }
+    }
     if (const char* ne = getenv("PA_MG_NU")) {
       int a = 2, b = 2, c = 8;
       double w = 0.85;

@@ -206,7 +206,7 @@ def _smooth_worker(rank, world, port, case, transport="gloo"):
             import test_gpu_random as R
             draw = {"u": R._union_case, "U": R._union_wide_case}.get(case[4])
             H, per, _sym, _fn = draw(int(case[5:])) if draw else R._draw(int(case[4:]))
-        elif case == "walls":
+        elif case.startswith("walls"):
             per = (0, 0, 0)
             H = nested_hierarchy(16, 3, 8, is_per=per)
         elif case == "2d":  # the AMREX_SPACEDIM == 2 build: one plane of cells per level, refined in x and y only
@@ -231,7 +231,13 @@ def _smooth_worker(rank, world, port, case, transport="gloo"):
                 m.valid(b)[0] = 0.5 + 0.5 * np.tanh((np.sqrt((x - 0.5) ** 2 + (y - 0.45) ** 2 + (z - 0.5) ** 2) - 0.3) / 0.08) + 1e-2 * rng.uniform(-1, 1, size=m.valid(b)[0].shape)
             rhs.append(m)
         dt = 5e-4
-        want, oit, ores = O.smooth_solve(H.levels, rhs, 0, dt, bc, MultiFab, tol=1e-14)
+        stiff = case.endswith("+mg")  # dt / dx^2 = 100 on the finest level: the multigrid-preconditioned solve (restriction, prolongation and ghost fills across ranks)
+        if stiff:
+            dt = 100.0 / float(H.levels[-1].domhi[0] + 1) ** 2
+            want, oit, ores = O.smooth_solve(H.levels, rhs, 0, dt, bc, MultiFab, tol=1e-13, maxiter=3000)
+            assert ores <= 1e-13
+        else:
+            want, oit, ores = O.smooth_solve(H.levels, rhs, 0, dt, bc, MultiFab, tol=1e-14)
 
         if transport == "rccl":
             torch.cuda.set_device(rank)
@@ -250,8 +256,14 @@ def _smooth_worker(rank, world, port, case, transport="gloo"):
             drhs.append(capi.DevMF.from_host(ctx, dl, s))
             dsol.append(capi.DevMF(ctx, dl, 1, 0))
         n0 = comm.nexchange if comm else 0
-        it, res = capi.smooth_solve(ctx, drhs, 0, dsol, 0, dt, bc, tol=1e-14, maxiter=200)
-        assert 0 < it < 100 and res <= 1e-14 and abs(it - oit) <= 12, (it, oit, res)  # at 1e-14 the last steps sit on the rounding floor: the count wanders with the summation order
+        it, res = capi.smooth_solve(ctx, drhs, 0, dsol, 0, dt, bc, tol=1e-13 if stiff else 1e-14, maxiter=200)
+        if stiff:
+            assert 0 < it <= 40 and res <= 1e-13 and it * 3 <= oit, (it, oit, res)  # the unpreconditioned oracle needs several times as many
+        else:
+            # at 1e-14 the last steps sit on the rounding floor: the count wanders with the summation order; where dt / dx^2 > 8 on the finest
+            # level (the wide random draws) the library preconditions with a V-cycle and needs FEWER iterations than the plain oracle
+            qf = dt * float(H.levels[-1].domhi[0] + 1) ** 2
+            assert 0 < it < 100 and res <= 1e-14 and (it <= oit if qf > 8.0 else abs(it - oit) <= 12), (it, oit, res, qf)
         if comm:
             nx = comm.nexchange - n0
             if replicated:
@@ -263,14 +275,15 @@ def _smooth_worker(rank, world, port, case, transport="gloo"):
             got = dsol[l].download()
             for i, g in enumerate(dl.gids):
                 worst = max(worst, float(np.abs(got.valid(i)[0] - want[l].valid(int(g))[0]).max()))
-        assert worst <= 1e-12, f"rank {rank}/{world}: smoothed field differs from the undistributed oracle by {worst}"
+        assert worst <= (1e-10 if stiff else 1e-12), f"rank {rank}/{world}: smoothed field differs from the undistributed oracle by {worst}"
         dist.barrier()
         ctx.close()
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,case", [(2, "nested"), (4, "nested"), (3, "walls"), (4, "nested+rep"), (3, "randu0"), (4, "randu13"), (2, "randu2"), (3, "randU0"), (4, "rand7"), (3, "2d")])
+@pytest.mark.parametrize("world,case", [(2, "nested"), (4, "nested"), (3, "walls"), (4, "nested+rep"), (3, "randu0"), (4, "randu13"), (2, "randu2"), (3, "randU0"), (4, "rand7"), (3, "2d"),
+                                        (2, "nested+mg"), (4, "nested+mg"), (3, "walls+mg")])
 def test_sharded_smoothing_solve_matches_undistributed_oracle(world, case):
     """do_smooth with the hierarchy dealt to `world` ranks (scattered owners: fine boxes, their coarse parents and their
     neighbours mostly on different ranks): average_down and the flux register through the restriction plans, dot products
