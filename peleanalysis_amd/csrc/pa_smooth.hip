@@ -735,6 +735,12 @@ struct SmoothSolver {
     }
     mg_sub = (int)mg.size();
     std::reverse(mg.begin(), mg.end());  // coarsest first
+    {  // Jacobi steps on the coarsest level: 8 where the coarsening went on until dt / dx^2 < 0.25; where it had to stop earlier (boxes that
+       // do not halve: odd corners, fewer than 8 cells) the coarsest problem is still stiff and gets ~3 sqrt(cond) steps (at most 64)
+      double q = 0.0;
+      for (int d = 0; d < 3; ++d) q = std::max(q, dt * Lc->dxinv[d] * Lc->dxinv[d]);
+      nub = std::max(8, std::min(64, (int)(3.0 * std::sqrt(1.0 + 12.0 * q))));
+    }
     for (int l = 0; l < nlev; ++l) { MgLev g; g.L = lev[l]; mg.push_back(g); }
     for (MgLev& g : mg) {
       g.own_vec = g.owned || dist;

@@ -209,7 +209,7 @@ def test_smooth_and_stream_reject_bad_input(ctx):
     assert pos.shape == (0, 5, 3) and nred == 0
 
 
-@pytest.mark.parametrize("per,base,box", [((1, 1, 0), 16, 8), ((0, 0, 0), 32, 16)])
+@pytest.mark.parametrize("per,base,box", [((1, 1, 0), 16, 8), ((0, 0, 0), 32, 16), ((1, 1, 0), 12, 6)])  # 6-cell boxes: level 0 cannot be coarsened, more steps on it
 def test_smooth_multigrid_preconditioner(ctx, oracle, per, base, box, monkeypatch):
     """a STIFF smoothing step (dt / dx^2 = 100 on the finest level: what smoothing_time = 1e-7 is for a plotfile in physical units):
     BiCGStab with the V-cycle preconditioner (default there; PA_SMOOTH_MG=1) reaches the tolerance in a fraction of the iterations of the
