@@ -708,23 +708,24 @@ struct SmoothSolver {
   int mg_setup() {
     const pa_level* Lc = lev[0];  // (every coarsened level goes into `mg` at once: the destructor frees it whatever happens later)
     // coarsen level 0 while every box halves evenly, stays >= 4 cells thick and dt / dx^2 of the CURRENT coarsest level is not small yet
+    const int nd = lev[0]->domlo[2] == lev[0]->domhi[2] ? 2 : 3;  // a 2-D hierarchy is one plane of cells per level: not coarsened in z
     for (int n = 0; n < 8; ++n) {
       double q = 0.0;
-      for (int d = 0; d < 3; ++d) q = std::max(q, dt * Lc->dxinv[d] * Lc->dxinv[d]);
+      for (int d = 0; d < nd; ++d) q = std::max(q, dt * Lc->dxinv[d] * Lc->dxinv[d]);
       if (q < 0.25) break;
       bool ok = true;
       std::vector<int32_t> b6;
       const std::vector<DBox>& all = dist ? Lc->gboxes : Lc->boxes;  // the WHOLE BoxArray: every rank of a sharded hierarchy decides alike
       for (const DBox& B : all)
-        for (int d = 0; d < 3; ++d) ok = ok && !(B.lo[d] & 1) && ((B.hi[d] - B.lo[d] + 1) % 2 == 0) && (B.hi[d] - B.lo[d] + 1) >= 8;
-      for (int d = 0; d < 3; ++d) ok = ok && !(Lc->domlo[d] & 1) && ((Lc->domhi[d] - Lc->domlo[d] + 1) % 2 == 0);
+        for (int d = 0; d < nd; ++d) ok = ok && !(B.lo[d] & 1) && ((B.hi[d] - B.lo[d] + 1) % 2 == 0) && (B.hi[d] - B.lo[d] + 1) >= 8;
+      for (int d = 0; d < nd; ++d) ok = ok && !(Lc->domlo[d] & 1) && ((Lc->domhi[d] - Lc->domlo[d] + 1) % 2 == 0);
       if (!ok) break;
       for (const DBox& B : all) {
-        for (int d = 0; d < 3; ++d) b6.push_back(B.lo[d] / 2);
-        for (int d = 0; d < 3; ++d) b6.push_back((B.hi[d] + 1) / 2 - 1);
+        for (int d = 0; d < 3; ++d) b6.push_back(d < nd ? B.lo[d] / 2 : B.lo[d]);
+        for (int d = 0; d < 3; ++d) b6.push_back(d < nd ? (B.hi[d] + 1) / 2 - 1 : B.hi[d]);
       }
       int32_t dlo[3], dhi[3], per[3];
-      for (int d = 0; d < 3; ++d) { dlo[d] = Lc->domlo[d] / 2; dhi[d] = (Lc->domhi[d] + 1) / 2 - 1; per[d] = Lc->is_per[d]; }
+      for (int d = 0; d < 3; ++d) { dlo[d] = d < nd ? Lc->domlo[d] / 2 : Lc->domlo[d]; dhi[d] = d < nd ? (Lc->domhi[d] + 1) / 2 - 1 : Lc->domhi[d]; per[d] = Lc->is_per[d]; }
       pa_level* Ln = dist ? pa_level_create_sharded(ctx, (int)all.size(), b6.data(), Lc->gowner.data(), Lc->rank, Lc->nranks, dlo, dhi, per, Lc->prob_lo, Lc->prob_hi)
                           : pa_level_create(ctx, (int)all.size(), b6.data(), dlo, dhi, per, Lc->prob_lo, Lc->prob_hi);
       if (!Ln) return 1;
@@ -738,7 +739,7 @@ struct SmoothSolver {
     {  // Jacobi steps on the coarsest level: 8 where the coarsening went on until dt / dx^2 < 0.25; where it had to stop earlier (boxes that
        // do not halve: odd corners, fewer than 8 cells) the coarsest problem is still stiff and gets ~3 sqrt(cond) steps (at most 64)
       double q = 0.0;
-      for (int d = 0; d < 3; ++d) q = std::max(q, dt * Lc->dxinv[d] * Lc->dxinv[d]);
+      for (int d = 0; d < nd; ++d) q = std::max(q, dt * Lc->dxinv[d] * Lc->dxinv[d]);
       nub = std::max(8, std::min(64, (int)(3.0 * std::sqrt(1.0 + 12.0 * q))));
     }
     for (int l = 0; l < nlev; ++l) { MgLev g; g.L = lev[l]; mg.push_back(g); }
@@ -936,14 +937,14 @@ extern "C" int pa_smooth_solve(pa_ctx* ctx, int nlev, pa_mf* const* rhs, int rco
   }
   // PA_SMOOTH_MG (read per solve): 1 / 0 = the multigrid preconditioner on / off; default: on where the finest level's dt / dx^2
   // exceeds 8 (below that the unpreconditioned iteration needs < ~45 iterations and two V-cycles per iteration cost more than they
-  // save); one rank, 3-D
+  // save); 3-D and 2-D hierarchies, one rank or sharded
   bool use_mg = false;
   {
     const pa_level* Lf = S.lev[(size_t)nlev - 1];
     double q = 0.0;
-    for (int d = 0; d < 3; ++d) q = std::max(q, dt * Lf->dxinv[d] * Lf->dxinv[d]);
+    for (int d = 0; d < (Lf->domlo[2] == Lf->domhi[2] ? 2 : 3); ++d) q = std::max(q, dt * Lf->dxinv[d] * Lf->dxinv[d]);
     const char* me = getenv("PA_SMOOTH_MG");
-    use_mg = S.lev[0]->domlo[2] != S.lev[0]->domhi[2] && (me ? atoi(me) != 0 : q > 8.0);
+    use_mg = me ? atoi(me) != 0 : q > 8.0;
     if (use_mg) {
       int bad = (S.mg_setup() || S.alloc(S.ph, 18) || S.alloc(S.sh, 19)) ? 1 : 0;
       if (S.dist) {  // the ranks agree on the preconditioner's setup before its first exchange

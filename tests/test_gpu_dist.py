@@ -209,7 +209,7 @@ def _smooth_worker(rank, world, port, case, transport="gloo"):
         elif case.startswith("walls"):
             per = (0, 0, 0)
             H = nested_hierarchy(16, 3, 8, is_per=per)
-        elif case == "2d":  # the AMREX_SPACEDIM == 2 build: one plane of cells per level, refined in x and y only
+        elif case.startswith("2d"):  # the AMREX_SPACEDIM == 2 build: one plane of cells per level, refined in x and y only
             from peleanalysis_amd.hierarchy import Hierarchy, Level, chop_box
             per = (1, 0, 0)
             l0 = Level(chop_box((0, 0, 0), (31, 31, 0), 8), (0, 0, 0), (31, 31, 0), np.array(per), np.zeros(3), np.ones(3))
@@ -219,7 +219,7 @@ def _smooth_worker(rank, world, port, case, transport="gloo"):
             H = nested_hierarchy(16, 3, 8, is_per=per)
         for lv in H.levels[1:]:  # the composite operator needs fine boxes aligned to the ratio (pa_smooth_solve checks it)
             for b in lv.boxes:
-                assert not any(b[d] % 2 or (b[3 + d] + 1) % 2 for d in range(2 if case == "2d" else 3)), "pick a draw whose fine boxes are aligned to the ratio"
+                assert not any(b[d] % 2 or (b[3 + d] + 1) % 2 for d in range(2 if case.startswith("2d") else 3)), "pick a draw whose fine boxes are aligned to the ratio"
         owners = [scattered_owner(lv.nboxes, world, 57 + l) for l, lv in enumerate(H.levels)]
         bc = capi.bc_from_flags(per)
         rng = np.random.default_rng(5)
@@ -283,7 +283,7 @@ def _smooth_worker(rank, world, port, case, transport="gloo"):
 
 
 @pytest.mark.parametrize("world,case", [(2, "nested"), (4, "nested"), (3, "walls"), (4, "nested+rep"), (3, "randu0"), (4, "randu13"), (2, "randu2"), (3, "randU0"), (4, "rand7"), (3, "2d"),
-                                        (2, "nested+mg"), (4, "nested+mg"), (3, "walls+mg")])
+                                        (2, "nested+mg"), (4, "nested+mg"), (3, "walls+mg"), (3, "2d+mg")])
 def test_sharded_smoothing_solve_matches_undistributed_oracle(world, case):
     """do_smooth with the hierarchy dealt to `world` ranks (scattered owners: fine boxes, their coarse parents and their
     neighbours mostly on different ranks): average_down and the flux register through the restriction plans, dot products
