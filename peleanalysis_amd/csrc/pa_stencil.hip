@@ -128,18 +128,23 @@ extern "C" int pa_grad_level(pa_ctx* ctx, const pa_mf* phi, int comp, pa_mf* out
 // Applicable: every level's boxes are wider than 32 cells and at least 52 rows tall (the 13-row tiles), PA_GRAD_LEVELS != 0.
 int pa_grad_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int comp, pa_mf* const* out, int ocomp) {
   const char* le = getenv("PA_GRAD_LEVELS");  // read per call (tools/ab_driver.py)
-  if ((le && !atoi(le)) || nlev < 2 || nlev > PA_MAXB || getenv("PA_GRAD_MARCH") || getenv("PA_GRAD_MTY") || getenv("PA_GRAD_KSEG")) return -1;
+  if ((le && !atoi(le)) || nlev < 2 || getenv("PA_GRAD_MARCH") || getenv("PA_GRAD_MTY") || getenv("PA_GRAD_KSEG")) return -1;
   const char* te = getenv("PA_SWEEP_WGTAB");
   if (te && !atoi(te)) return -1;
-  GradBatch S;
-  S.n = 0;
-  S.wg0[0] = 0;
-  for (int l = 0; l < nlev; ++l) {
+  for (int l = 0; l < nlev; ++l) {  // applicable to every level, or to none (nothing is launched before this is known)
     const pa_level* L = phi[l]->lev;
     if (L->boxes.empty()) continue;
     if (L->nnarrow > 0 || L->maxn[1] < 52) return -1;
     for (const DBox& B : L->boxes)
       if (B.hi[0] - B.lo[0] + 1 <= 32) return -1;
+  }
+  for (int l0 = 0; l0 < nlev; l0 += PA_MAXB) {  // up to PA_MAXB levels per launch
+  GradBatch S;
+  S.n = 0;
+  S.wg0[0] = 0;
+  for (int l = l0; l < nlev && l < l0 + PA_MAXB; ++l) {
+    const pa_level* L = phi[l]->lev;
+    if (L->boxes.empty()) continue;
     GradMarchArgs A{comp, ocomp, std::max(1, std::min(16, L->maxn[2])), (int)L->boxes.size(), 0};
     A.tiles_max = ((L->maxn[0] + 63) / 64) * ((L->maxn[1] + 12) / 13) * ((L->maxn[2] + A.kseg - 1) / A.kseg);
     const WgTab* wt = pa_sweep_wgtab(L, 2, 64, 13, A.kseg, false);
@@ -149,10 +154,11 @@ int pa_grad_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int comp, pa_mf* co
     S.wg0[S.n + 1] = S.wg0[S.n] + (wt ? wt->n : (unsigned)A.tiles_max * 8u * (((unsigned)L->boxes.size() + 7u) / 8u));
     ++S.n;
   }
-  if (!S.n) return 0;
+  if (!S.n) continue;
   ProfScope prof(ctx, PA_TAG_GRAD);
   hipLaunchKernelGGL(k_grad_march_levels<13>, dim3(S.wg0[S.n]), dim3(64 * 16), 0, ctx->stream, S);
   PA_HIP(hipGetLastError());
+  }
   return 0;
 }
 

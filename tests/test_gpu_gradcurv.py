@@ -400,7 +400,7 @@ def test_curvature_options_match_oracle(ctx, oracle, name):
         capi.curvature_run(ctx, dst, 0, bc, P, small, 0)
 
 
-@pytest.mark.parametrize("nlev,base,box", [(5, 8, 8), (6, 8, 4), (5, 40, 40)])
+@pytest.mark.parametrize("nlev,base,box", [(5, 8, 8), (6, 8, 4), (5, 40, 40), (5, 64, 64)])
 def test_deep_hierarchies_take_the_fused_pipelines(ctx, oracle, nlev, base, box):
     """five and six levels (what a Pele plotfile often holds): the all-levels launches come in chunks of four groups -- until round 5 a
     hierarchy of more than four levels went group by group, and its curvature options pass by pass.  The fused grad -> curvature pass
@@ -430,6 +430,11 @@ def test_deep_hierarchies_take_the_fused_pipelines(ctx, oracle, nlev, base, box)
         got = d8[l].download()
         assert_valid_bits_equal(got, og[l], [(c, c) for c in range(4)], f"{nlev} levels: grad level {l}")
         assert_valid_bits_equal(got, ou[l], [(4, 2), (5, 3), (6, 4), (7, 1)], f"{nlev} levels: curvature level {l}")
+    d4 = [capi.DevMF(ctx, dl, 4, 0) for dl in dls]  # the gradient tool's pass (64-row boxes: the all-levels gradient launch, in chunks too)
+    capi.grad_run(ctx, dst, 0, bc, d4, 0)
+    ctx.sync()
+    for l in range(nlev):
+        assert_valid_bits_equal(d4[l].download(), og[l], [(c, c) for c in range(4)], f"{nlev} levels: grad_run level {l}")
     d17 = [capi.DevMF(ctx, dl, 17, 0) for dl in dls]
     capi.curvature_run(ctx, dst, 0, bc, capi.curv_params(threshold=0.03, fused=True, do_gauss=True, do_strain=True, strain_tensor=True, do_velnormal=True, vel_comp=1), d17, 0)
     ctx.sync()
