@@ -6,6 +6,7 @@
 // applyBC done by the caller, pa_pipeline.hip) in the reference's operation order (cdiff).
 #include "pa_internal.h"
 #include "pa_fabview.h"
+#include "pa_dpp.h"
 
 struct BP3 {
   DLevelView L;
@@ -118,18 +119,6 @@ __global__ __launch_bounds__(256) void k_velnormal(BP3 bp, int ucomp, int ncomp0
 // x-neighbours from the neighbouring LANES (the centre values of a plane are in registers anyway): DPP wavefront shifts instead
 // of two more loads per component -- the three stencil kernels above run at 3-4 TB/s of real traffic, bound by their 21 load
 // instructions per cell, not by HBM.  Only the first / last lane of a row still loads (a neighbouring tile's or a ghost cell).
-__device__ __forceinline__ double lane_from_left(double v) {  // lane n <- lane n - 1
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xF, 0xF, false);  // wave_shr:1
-  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xF, 0xF, false);
-  return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double lane_from_right(double v) {  // lane n <- lane n + 1
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xF, 0xF, false);  // wave_shl:1
-  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xF, 0xF, false);
-  return __hiloint2double(hi, lo);
-}
 struct OptArgs {
   DLevelView L;
   DMFView G, U, O;

@@ -10,11 +10,13 @@
 // writes y once (16 B/cell), reductions are two-stage with a fixed summation order per launch shape.
 #include "pa_internal.h"
 #include "pa_fabview.h"
+#include "pa_dpp.h"
 #include "pa_dist.h"
 #include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <map>
 #include <memory>
 #include <vector>
 
@@ -118,6 +120,73 @@ __global__ __launch_bounds__(256) void k_smooth_jacobi(DLevelView L, DMFView X, 
     div += d2 * (d2 * (x[q + nxg * nyg] - c) - d2 * (c - x[q - nxg * nyg]));
     const double res = R.data[R.off[b] + fab_index(it.B, R.ng, R.ncomp, 0, i, j, k)] - (c - dt * div);
     Y.data[Y.off[b] + fab_index(it.B, Y.ng, Y.ncomp, 0, i, j, k)] = MODE == 0 ? c + om * res : res;
+  }
+}
+
+// The same three passes as z-MARCHING kernels (round 5, third session): a wavefront holds a row of 64 cells (boxes at most 32
+// wide: two rows of 32), TY wavefronts a tile of TY rows, and the tile marches kz planes -- the z-neighbours ride in registers (one
+// new plane per step), the x-neighbours come from the neighbouring LANES (pa_dpp.h; the first / last lane of a row loads a
+// neighbouring tile's or a ghost cell), the y-neighbours of a plane are requested one step early together with its centre value
+// (the rows next door ask for the same lines as THEIR centre values in that step).  3 load instructions per cell instead of 7, no
+// integer division per cell; same operations in the same order as k_smooth_apply / k_smooth_jacobi, so the same bits.
+//   MODE 0: y = A x    1: y = x + om (r - A x)    2: y = r - A x;   MASKED: y = 0 where M == 0 (the cells under the finer level)
+// Tiles of one (x, z) column are consecutive workgroups of ONE XCD (workgroup i runs on XCD i mod 8); gridDim.x is a multiple of 8.
+struct SmArgs {
+  DLevelView L;
+  DMFView X, R, Y, M;
+  double dt, om;
+  int kz;
+};
+template <int MODE, bool MASKED, int TY>
+__global__ __launch_bounds__(64 * TY) void k_smooth_march(SmArgs A) {
+  const int b = blockIdx.y;
+  const DBox V = A.L.boxes[b];
+  const int nx = V.hi[0] - V.lo[0] + 1, ny = V.hi[1] - V.lo[1] + 1, nz = V.hi[2] - V.lo[2] + 1;
+  const bool narrow = nx <= 32;
+  const int TX = narrow ? 32 : 64, rows = narrow ? 2 * TY : TY;
+  const int tx = (nx + TX - 1) / TX, tz = (nz + A.kz - 1) / A.kz;
+  const unsigned ty = (unsigned)((ny + rows - 1) / rows);
+  const int lw = (int)threadIdx.x & (TX - 1), jr = narrow ? (int)(threadIdx.x >> 5) : (int)(threadIdx.x >> 6);
+  const FabView X = mf_view(A.X, V, b), Y = mf_view(A.Y, V, b), R = mf_view(MODE ? A.R : A.X, V, b), M = mf_view(MASKED ? A.M : A.X, V, b);
+  const long long xs = (long long)X.nx * X.ny, ys = (long long)Y.nx * Y.ny, rs = (long long)R.nx * R.ny, ms = (long long)M.nx * M.ny;
+  const double d0 = A.L.dxinv[0], d1 = A.L.dxinv[1], d2 = A.L.dxinv[2], dt = A.dt, om = A.om;
+  for (unsigned w = blockIdx.x;; w += gridDim.x) {
+    const unsigned q = w & 7u, m = w >> 3;
+    const int col = (int)(q + 8u * (m / ty)), by = (int)(m % ty);
+    if (col >= tx * tz) break;  // (col grows with w: gridDim.x is a multiple of 8)
+    const int bx = col % tx, bz = col / tx;
+    const int i = V.lo[0] + bx * TX + lw, j = V.lo[1] + by * rows + jr, k0 = V.lo[2] + bz * A.kz, k1 = min(k0 + A.kz - 1, V.hi[2]);
+    if (i > V.hi[0] || j > V.hi[1]) continue;
+    const bool ledge = lw == 0, redge = lw == TX - 1 || i == V.hi[0];  // this lane's x-neighbour is not held by the lane next to it
+    const double* xp = X.p + X.idx(i, j, k0, 0);
+    double* yp = Y.p + Y.idx(i, j, k0, 0);
+    const double* rp = R.p + R.idx(i, j, k0, 0);
+    const double* mp = M.p + M.idx(i, j, k0, 0);
+    double zm = xp[-xs], c = xp[0], yl = xp[-X.nx], yr = xp[X.nx];
+    for (int k = k0; k <= k1; ++k) {
+      const double nxt = xp[xs], nyl = xp[xs - X.nx], nyr = xp[xs + X.nx];  // plane k + 1 (k1 + 1: a ghost plane at most)
+      double xl = lane_from_left(c), xr = lane_from_right(c);
+      if (ledge) xl = xp[-1];
+      if (redge) xr = xp[1];
+      double div = 0.0;
+      div += d0 * (d0 * (xr - c) - d0 * (c - xl));
+      div += d1 * (d1 * (yr - c) - d1 * (c - yl));
+      div += d2 * (d2 * (nxt - c) - d2 * (c - zm));
+      double out = c - dt * div;
+      if (MODE) {
+        const double res = rp[0] - out;
+        out = MODE == 1 ? c + om * res : res;
+        rp += rs;
+      }
+      if (MASKED) {
+        if (mp[0] == 0.0) out = 0.0;
+        mp += ms;
+      }
+      yp[0] = out;
+      zm = c; c = nxt; yl = nyl; yr = nyr;
+      xp += xs;
+      yp += ys;
+    }
   }
 }
 
@@ -495,6 +564,40 @@ struct SmoothSolver {
     }
     return 0;
   }
+  // one stencil pass over a level as a z-marching launch (k_smooth_march): mode 0 y = A x, 1 a damped-Jacobi step, 2 the residual;
+  // M non-null: y = 0 on the cells the finer level covers.  PA_SMOOTH_MARCH=0 (read per solve): the cell-per-thread kernels
+  bool use_march = true;
+  int march_kz = 64;
+  std::map<const pa_level*, unsigned> march_gx;
+  void stencil(int mode, const pa_level* L, pa_mf* X, pa_mf* R, pa_mf* Y, pa_mf* M, double om) {
+    if (L->boxes.empty()) return;
+    if (!use_march) {
+      if (mode == 0) hipLaunchKernelGGL(k_smooth_apply, box_grid(L), dim3(256), 0, ctx->stream, L->view, X->view, Y->view, dt);
+      else if (mode == 1) hipLaunchKernelGGL(k_smooth_jacobi<0>, box_grid(L), dim3(256), 0, ctx->stream, L->view, X->view, R->view, Y->view, dt, om);
+      else hipLaunchKernelGGL(k_smooth_jacobi<1>, box_grid(L), dim3(256), 0, ctx->stream, L->view, X->view, R->view, Y->view, dt, 0.0);
+      if (M) hipLaunchKernelGGL(k_smooth_zero_covered, box_grid(L), dim3(256), 0, ctx->stream, L->view, Y->view, M->view);
+      return;
+    }
+    constexpr int TY = 4;
+    unsigned& gx = march_gx[L];
+    if (!gx) {
+      gx = 8;
+      for (const DBox& B : L->boxes) {
+        const int nx = B.hi[0] - B.lo[0] + 1, ny = B.hi[1] - B.lo[1] + 1, nz = B.hi[2] - B.lo[2] + 1;
+        const int TX = nx <= 32 ? 32 : 64, rows = nx <= 32 ? 2 * TY : TY;
+        const unsigned ncol = (unsigned)(((nx + TX - 1) / TX) * ((nz + march_kz - 1) / march_kz)), ty = (unsigned)((ny + rows - 1) / rows);
+        gx = std::max(gx, 8u * ((ncol + 7u) / 8u) * ty);
+      }
+      gx = std::min(gx, 4096u);  // a multiple of 8 either way: the kernel strides over the rest
+    }
+    const dim3 g(gx, (unsigned)L->boxes.size());
+    SmArgs A{L->view, X->view, R ? R->view : X->view, Y->view, M ? M->view : X->view, dt, om, march_kz};
+#define PA_SM(MD, MK) hipLaunchKernelGGL((k_smooth_march<MD, MK, TY>), g, dim3(64 * TY), 0, ctx->stream, A)
+    if (mode == 0) { if (M) PA_SM(0, true); else PA_SM(0, false); }
+    else if (mode == 1) { if (M) PA_SM(1, true); else PA_SM(1, false); }
+    else { if (M) PA_SM(2, true); else PA_SM(2, false); }
+#undef PA_SM
+  }
   int apply(Vecs& X, Vecs& Y) {  // y = A x (x: covered cells and ghosts are overwritten)
     for (int l = nlev - 1; l > 0; --l) {
       if (!dist) {
@@ -535,7 +638,8 @@ struct SmoothSolver {
         if (pa_fill_boundary(ctx, X.v[l], 0, 1, 1)) return 1;
         if (pa_apply_bc(ctx, X.v[l], 0, l ? X.v[l - 1] : nullptr, 0, bc, ratio, -1)) return 1;
       }
-      on_boxes(k_smooth_apply, lev[l], box_grid(lev[l]), lev[l]->view, X.v[l]->view, Y.v[l]->view, dt);
+      // (the cells under level l + 1 are zeroed in the same pass: reflux touches uncovered cells only)
+      stencil(0, lev[l], X.v[l], nullptr, Y.v[l], (use_march && l + 1 < nlev) ? mask.v[l] : nullptr, 0.0);
     }
     if (dist) {
       if (nlev > 1) {
@@ -552,7 +656,8 @@ struct SmoothSolver {
                            lev[l - 1]->view, X.v[l - 1]->view, Y.v[l - 1]->view, dt, ratio);
       }
     }
-    for (int l = 0; l + 1 < nlev; ++l) on_boxes(k_smooth_zero_covered, lev[l], box_grid(lev[l]), lev[l]->view, Y.v[l]->view, mask.v[l]->view);
+    if (!use_march)
+      for (int l = 0; l + 1 < nlev; ++l) on_boxes(k_smooth_zero_covered, lev[l], box_grid(lev[l]), lev[l]->view, Y.v[l]->view, mask.v[l]->view);
     if (hipGetLastError() != hipSuccess) { pa_fail(ctx, "pa_smooth_solve: a kernel launch of the operator failed"); if (fail_local()) return 1; }
     return 0;
   }
@@ -799,7 +904,7 @@ struct SmoothSolver {
         continue;
       }
       if (mg_ghosts(g)) return 1;
-      on_boxes(k_smooth_jacobi<0>, X.L, box_grid(X.L), X.L->view, X.e->view, X.r->view, X.w->view, dt, om);
+      stencil(1, X.L, X.e, X.r, X.w, nullptr, om);
       std::swap(X.e, X.w);
     }
     return 0;
@@ -808,13 +913,17 @@ struct SmoothSolver {
   double jac_omega = 0.85;
   int vcycle(Vecs& R, Vecs& Z) {
     const int G = (int)mg.size();
-    for (int l = 0; l < nlev; ++l) on_boxes(k_smooth_copy, lev[l], box_grid(lev[l]), lev[l]->view, R.v[l]->view, 0, mg[(size_t)(mg_sub + l)].r->view, 0);
-    for (int g = 0; g < G; ++g) PA_HIP(hipMemsetAsync(mg[(size_t)g].e->data, 0, sizeof(double) * (size_t)mg[(size_t)g].e->total, ctx->stream));
+    // the right-hand side of the FINEST level is only read (nothing is averaged down onto it): R itself, no copy; its correction starts
+    // as om r on every valid cell (no memset); the coarser levels' corrections must read 0 as the finer levels' coarse-fine ghost source
+    struct Borrow { pa_mf*& slot; pa_mf* mine; ~Borrow() { slot = mine; } } borrow{mg[(size_t)G - 1].r, mg[(size_t)G - 1].r};
+    mg[(size_t)G - 1].r = R.v[(size_t)nlev - 1];
+    for (int l = 0; l + 1 < nlev; ++l) on_boxes(k_smooth_copy, lev[l], box_grid(lev[l]), lev[l]->view, R.v[l]->view, 0, mg[(size_t)(mg_sub + l)].r->view, 0);
+    for (int g = 0; g + 1 < G; ++g) PA_HIP(hipMemsetAsync(mg[(size_t)g].e->data, 0, sizeof(double) * (size_t)mg[(size_t)g].e->total, ctx->stream));
     for (int g = G - 1; g > 0; --g) {
       if (mg_smooth(g, nu1, true)) return 1;
       if (mg_ghosts(g)) return 1;
       MgLev& X = mg[(size_t)g];
-      on_boxes(k_smooth_jacobi<1>, X.L, box_grid(X.L), X.L->view, X.e->view, X.r->view, X.w->view, dt, 0.0);  // w = r - A e
+      stencil(2, X.L, X.e, X.r, X.w, nullptr, 0.0);  // w = r - A e
       MgLev& C = mg[(size_t)g - 1];
       if (!dist) {
         hipLaunchKernelGGL(k_smooth_avgdown, box_grid(X.L), dim3(256), 0, ctx->stream, X.L->view, X.w->view, C.L->view, C.r->view, ratio);
@@ -839,8 +948,10 @@ struct SmoothSolver {
       }
       if (mg_smooth(g, nu2, false)) return 1;
     }
-    for (int l = 0; l < nlev; ++l) on_boxes(k_smooth_copy, lev[l], box_grid(lev[l]), lev[l]->view, mg[(size_t)(mg_sub + l)].e->view, 0, Z.v[l]->view, 0);
-    zero_covered(Z);
+    // z = the corrections: the vectors change hands (same level, same shape) instead of being copied.  z keeps the coarse levels'
+    // corrections on the cells a finer level covers: its only readers are the operator (which averages the finer level down onto
+    // them first) and the update of x (whose covered cells are averaged down at the end of the solve)
+    for (int l = 0; l < nlev; ++l) std::swap(Z.v[(size_t)l], mg[(size_t)(mg_sub + l)].e);
     PA_HIP(hipGetLastError());
     return 0;
   }
@@ -935,6 +1046,8 @@ extern "C" int pa_smooth_solve(pa_ctx* ctx, int nlev, pa_mf* const* rhs, int rco
     }
     if (S.dist && S.setup_dist_mask()) return 1;
   }
+  if (const char* me = getenv("PA_SMOOTH_MARCH")) S.use_march = atoi(me) != 0;  // 0 (read per solve, A/B): the cell-per-thread stencil kernels
+  if (const char* ke = getenv("PA_SMOOTH_KZ")) S.march_kz = std::max(1, atoi(ke));
   // PA_SMOOTH_MG (read per solve): 1 / 0 = the multigrid preconditioner on / off; default: on where the finest level's dt / dx^2
   // exceeds 8 (below that the unpreconditioned iteration needs < ~45 iterations and two V-cycles per iteration cost more than they
   // save); 3-D and 2-D hierarchies, one rank or sharded

@@ -7,6 +7,7 @@
 #pragma once
 #include <fcntl.h>
 #include <ftw.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -15,6 +16,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <functional>
@@ -115,9 +117,24 @@ struct PlotfileHeader {
 // level data in pa_mf_layout order
 // std::vector that leaves new doubles uninitialised: the multi-GB host multifabs are then first touched (page-faulted)
 // by the filling threads instead of by one thread inside resize()
+// Blocks of >= 4 MiB are 2-MiB aligned and marked MADV_HUGEPAGE (PA_HOST_THP=0: off): a level's data are tens of GB that are
+// touched once by the reader, pinned once by the copy to the device and torn down at exit -- per 4-KiB page each time otherwise
 template <typename T>
 struct DefaultInitAlloc : std::allocator<T> {
   template <typename U> struct rebind { using other = DefaultInitAlloc<U>; };
+  static bool thp() { static const bool on = [] { const char* e = getenv("PA_HOST_THP"); return !(e && !atoi(e)); }(); return on; }
+  T* allocate(size_t n) {
+    const size_t bytes = n * sizeof(T), huge = (size_t)2 << 20;
+    if (bytes < 2 * huge || !thp()) return std::allocator<T>::allocate(n);
+    void* p = nullptr;
+    if (posix_memalign(&p, huge, (bytes + huge - 1) / huge * huge) != 0 || !p) throw std::bad_alloc();
+    madvise(p, (bytes + huge - 1) / huge * huge, MADV_HUGEPAGE);
+    return static_cast<T*>(p);
+  }
+  void deallocate(T* p, size_t n) noexcept {
+    if (n * sizeof(T) < ((size_t)4 << 20) || !thp()) std::allocator<T>::deallocate(p, n);
+    else free(p);
+  }
   template <typename U> void construct(U* p) noexcept { ::new ((void*)p) U; }
   template <typename U, typename... A> void construct(U* p, A&&... a) { ::new ((void*)p) U(std::forward<A>(a)...); }
 };
