@@ -303,12 +303,12 @@ inline void read_comp(const PlotfileHeader& H, int lev, int comp, HostMF& dst, i
       const bool le8 = hdr.find("(8, (8 7 6 5 4 3 2 1))") != std::string::npos, le4 = hdr.find("(4, (4 3 2 1))") != std::string::npos;
       if (!((nbytes == 8 && le8) || (nbytes == 4 && le4))) Abort("unsupported FAB RealDescriptor in " + L.fab_file[fb] + ": " + hdr.substr(0, 80));
     }
-    std::vector<double> buf((size_t)n);
+    std::vector<double, DefaultInitAlloc<double>> buf((size_t)n);  // (not zero-filled; huge pages)
     f.seekg((long long)f.tellg() + (long long)comp * n * nbytes);
     if (nbytes == 8) {
       f.read((char*)buf.data(), n * 8);
     } else {
-      std::vector<float> b4((size_t)n);
+      std::vector<float, DefaultInitAlloc<float>> b4((size_t)n);
       f.read((char*)b4.data(), n * 4);
       for (long long i = 0; i < n; ++i) buf[(size_t)i] = (double)b4[(size_t)i];
     }
@@ -423,7 +423,7 @@ inline void write_plotfile(const std::string& path, const std::vector<std::strin
         const int nx = B.hi[0] - B.lo[0] + 1;
         const long long npts = B.numPts();
         if (file_boxes) {  // the FAB's cells lie in one or more boxes of the multifab's tiling: gathered run by run
-          std::vector<char> buf(hdr[b].size() + (size_t)ncomp * (size_t)npts * 8);
+          std::vector<char, DefaultInitAlloc<char>> buf(hdr[b].size() + (size_t)ncomp * (size_t)npts * 8);  // (not zero-filled; huge pages)
           std::memcpy(buf.data(), hdr[b].data(), hdr[b].size());
           char* base = buf.data() + hdr[b].size();
           const long long ny = B.hi[1] - B.lo[1] + 1;
@@ -468,7 +468,7 @@ inline void write_plotfile(const std::string& path, const std::vector<std::strin
           mins[b] = mn; maxs[b] = mx;
           return;
         }
-        std::vector<char> buf(hdr[b].size() + (size_t)ncomp * (size_t)npts * 8);
+        std::vector<char, DefaultInitAlloc<char>> buf(hdr[b].size() + (size_t)ncomp * (size_t)npts * 8);  // (not zero-filled; huge pages)
         std::memcpy(buf.data(), hdr[b].data(), hdr[b].size());
         double* out = (double*)(buf.data() + hdr[b].size());  // may be unaligned: filled with memcpy
         char* w = (char*)out;
