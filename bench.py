@@ -613,7 +613,7 @@ def secondary(ctx, torch, stream, dev, only=None, retile=1):
             os.environ.pop("PA_SMOOTH_MG", None)
             sm[f"smoothing_time_{dt_s:g}" + ("_unpreconditioned" if mg_env == "0" else "")] = {
                 "iterations": it_.value, "rel_residual": rs_.value, "converged_to_1e-12": rc_ == 0, "ms": msq, "ms_per_iteration": msq / max(it_.value, 1),
-                "solver": "BiCGStab" if (mg_env == "0" or dt_s < 4e-6) else "BiCGStab + V(2,2) multigrid preconditioner (damped Jacobi, AMR levels + coarsened copies of level 0)"}
+                "solver": "BiCGStab" if (mg_env == "0" or dt_s < 4e-6) else "BiCGStab + V(2,4) multigrid preconditioner (damped Jacobi, AMR levels + coarsened copies of level 0)"}
         out["f1_do_smooth_headline"] = dict(sm, cells=cells, workload="pa_smooth_solve (curvature.cpp:328-406: (I - dt Lap) c~ = c, composite over the levels, tol 1e-12), 3-level base "
                                             "512^3, 1 rank; ms = one whole solve incl. its allocations; per iteration 2 operator applications + 5 dot products (+ 2 V-cycles where the finest "
                                             "level's dt / dx^2 > 8); " + tiling_txt(Hf, H))

@@ -471,7 +471,7 @@ int pa_curvature_run(pa_ctx*, int nlev, pa_mf* const* state, int comp, const int
  * cells = child averages), BiCGStab to ||b - A x||_inf <= tol ||b||_inf (the reference: 1e-12).  sol[lev]
  * comp scomp receives the solution on valid cells.  Refinement ratio 2.  Synchronous.
  * dt / dx^2 > 8 on the finest level (PA_SMOOTH_MG=1 / 0 in the environment: always / never; one rank or sharded): right-preconditioned with
- * one multigrid V(2,2) cycle per application (damped Jacobi on the AMR levels and on coarsened copies of level 0) -- the reference
+ * one multigrid V(2,4) cycle per application (damped Jacobi on the AMR levels and on coarsened copies of level 0) -- the reference
  * solves with MLMG, whose iteration count does not grow with dt either; same solution to the tolerance.  The work vectors stay with
  * the levels (pa_level_destroy frees them).
  * Levels from pa_level_create_sharded: the solve is DISTRIBUTED over the context's ranks -- every rank iterates on its own boxes,
