@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """End-to-end wall time of the plotfile tools on a synthetic C3-shaped plotfile (3 levels, base N^3, flame field, 3
 components).  usage: python tools/tool_e2e.py [base=256] [box=64] [options]
-"options": a 5-component file (temp, 3 velocity components, density) and curvature3d with do_gaussCurv + do_strain + do_velnormal only."""
+"options": a 5-component file (temp, 3 velocity components, density) and curvature3d with do_gaussCurv + do_strain + do_velnormal only.
+"smooth": curvature3d with do_smooth=1, smoothing_time 1e-7 (dt / dx^2 = 0.42 on the finest level at base 512: plain BiCGStab) and 1e-5 (42: preconditioned)."""
 import os, subprocess, sys, tempfile, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from peleanalysis_amd.hierarchy import MultiFab, field_flame, fill_analytic, nested_hierarchy
@@ -9,6 +10,7 @@ from peleanalysis_amd.plotfile import write_plotfile
 base = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 box = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 options = len(sys.argv) > 3 and sys.argv[3] == "options"
+smooth = len(sys.argv) > 3 and sys.argv[3] == "smooth"
 names = ["temp", "x_velocity", "y_velocity", "z_velocity", "density"] if options else ["temp", "x_velocity", "density"]
 H = nested_hierarchy(base, 3, box, is_per=(1, 1, 0))
 mfs = []
@@ -27,6 +29,9 @@ runs = (("grad3d.ex", ["gradVar=temp", "is_per=1 1 0"]), ("curvature3d.ex", ["pr
 if options:
     runs = (("curvature3d.ex", ["progressName=temp", "is_per=1 1 0", "do_gaussCurv=1", "do_strain=1", "do_velnormal=1"]),
             ("curvature3d.ex", ["progressName=temp", "is_per=1 1 0", "do_gaussCurv=1", "do_strain=1", "do_velnormal=1", "fused=0"]))
+if smooth:
+    runs = (("curvature3d.ex", ["progressName=temp", "is_per=1 1 0", "do_smooth=1", "smoothing_time=1e-7"]),
+            ("curvature3d.ex", ["progressName=temp", "is_per=1 1 0", "do_smooth=1", "smoothing_time=1e-5"]))
 for tool, args in runs:
     for rep in range(2):
         t0 = time.perf_counter()
@@ -34,4 +39,6 @@ for tool, args in runs:
         dt = time.perf_counter() - t0
         assert out.returncode == 0, out.stderr[-500:]
     js = [ln for ln in out.stdout.splitlines() if ln.startswith('{"tool"')]
+    if smooth:
+        print("   ", "; ".join(ln for ln in (out.stdout + out.stderr).splitlines() if "mooth" in ln or "iteration" in ln), flush=True)
     print(f"{tool:18s} wall {dt:.2f} s (second run)  {js[-1] if js else ''}", flush=True)
