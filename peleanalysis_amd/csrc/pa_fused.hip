@@ -747,12 +747,12 @@ struct PrepLev { DLevelView L; DMFView M; int comp; DLevelView LC; DMFView MC; i
 // PHIONLY (the gradient tool's pass): only the face ghost of phi -- MLMG applyBC as k_apply_bc_sfaces does it, but on the per-face
 // work tables and from the coarse PATCHES instead of owner-map lookups into the coarse FABs (the three applyBC launches of a
 // 3-level hierarchy took 0.43 ms, this kernel 0.19 ms with the progress variable on top)
-template <bool PATCH, bool PHIONLY>
-__device__ __forceinline__ void prep_faces_wg(const LevBatch<PrepLev>& Bt, int* nbad, const SlotK& sk, unsigned w) {
+template <bool PATCH, bool PHIONLY = false>
+__global__ __launch_bounds__(256) void k_prep_faces(LevBatch<PrepLev> Bt, int* nbad, SlotK sk = SlotK()) {
   unsigned fy;
   int blev;
   long long t;
-  if (!wg_decode(Bt, blev, fy, t, w)) return;
+  if (!wg_decode(Bt, blev, fy, t)) return;
   const PrepLev& Pl = Bt.a[blev];
   const DLevelView& L = Pl.L;
   const DMFView& M = Pl.M;
@@ -819,18 +819,15 @@ __device__ __forceinline__ void prep_faces_wg(const LevBatch<PrepLev>& Bt, int* 
   p[fab_index(B, M.ng, M.ncomp, comp, q[0], q[1], q[2])] = gp;
   if (!PHIONLY) *cgp = gc;
 }
-template <bool PATCH, bool PHIONLY = false>
-__global__ __launch_bounds__(256) void k_prep_faces(LevBatch<PrepLev> Bt, int* nbad, SlotK sk = SlotK()) {
-  prep_faces_wg<PATCH, PHIONLY>(Bt, nbad, sk, blockIdx.x);
-}
 
 // The edge ghost cells of c (outside the box in two directions a < c) that are the boundary ghost of a valid cell of a
 // NEIGHBOURING box (k_apply_bc_edges): stored in the ring of the special face they continue.  Reads ghost cells of phi that
 // are valid cells of the level: from this box's FAB once FillBoundary has filled them (DIRECT = false), or -- DIRECT, an
 // unsharded level -- in the box that owns them, so that the kernel does not wait for FillBoundary and runs next to it.
-template <bool PATCH, bool DIRECT>
-__device__ __forceinline__ void prep_ring_wg(const LevBatch<PrepLev>& Bt, int* nbad, const SlotK& sk, unsigned bx, int blev, unsigned fy) {
-  const PrepLev& Pl = Bt.a[blev];
+template <bool PATCH, bool DIRECT = false>
+__global__ void k_prep_ring(LevBatch<PrepLev> Bt, int* nbad, SlotK sk = SlotK()) {
+  unsigned fy;
+  const PrepLev& Pl = Bt.a[Bt.find(blockIdx.y, fy)];
   const DLevelView& L = Pl.L;
   const DMFView& M = Pl.M;
   const DLevelView& LC = Pl.LC;
@@ -844,7 +841,7 @@ __device__ __forceinline__ void prep_ring_wg(const LevBatch<PrepLev>& Bt, int* n
   const int b = Pl.sfboxes[fy];  // the launch runs over the boxes that have a special face: the others have no ring to fill
   const DBox B = L.boxes[b];
   const int n[3] = {B.hi[0] - B.lo[0] + 1, B.hi[1] - B.lo[1] + 1, B.hi[2] - B.lo[2] + 1};
-  long long t = bx * (long long)blockDim.x + threadIdx.x;
+  long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   int e = -1, which = 0, pos = 0;
   for (int d = 0; d < 3; ++d) {
     if (t < 4LL * n[d]) { e = d; which = (int)((unsigned)t / (unsigned)n[d]); pos = (int)((unsigned)t % (unsigned)n[d]); break; }
@@ -911,24 +908,6 @@ __device__ __forceinline__ void prep_ring_wg(const LevBatch<PrepLev>& Bt, int* n
   }
   const int t0 = (dir == 0) ? 1 : 0, t1 = (dir == 2) ? 1 : 2;
   cgz[L.cgoff[ef] + (long long)(q[t1] - B.lo[t1] + 1) * (B.hi[t0] - B.lo[t0] + 3) + (q[t0] - B.lo[t0] + 1)] = g;
-}
-template <bool PATCH, bool DIRECT = false>
-__global__ void k_prep_ring(LevBatch<PrepLev> Bt, int* nbad, SlotK sk = SlotK()) {
-  unsigned fy;
-  const int blev = Bt.find(blockIdx.y, fy);
-  prep_ring_wg<PATCH, DIRECT>(Bt, nbad, sk, blockIdx.x, blev, fy);
-}
-// Faces and ring in ONE launch (an unsharded hierarchy: the ring reads its neighbours' cells in the boxes that own them, so neither
-// half waits for the other or for FillBoundary): workgroups 0 .. nfw - 1 take the faces' work tables, the rest the rings of the boxes
-// with a special face -- rb.ycum[] = those boxes per level of the batch, grx workgroups per box.  PA_PREP_MERGE=0: two launches
-struct RingRows { int n; int ycum[PA_MAXB + 1]; };
-template <bool PATCH>
-__global__ __launch_bounds__(256) void k_prep_faces_ring(LevBatch<PrepLev> Bt, int* nbad, SlotK sk, unsigned nfw, unsigned grx, RingRows rb) {
-  if (blockIdx.x < nfw) { prep_faces_wg<PATCH, false>(Bt, nbad, sk, blockIdx.x); return; }
-  const unsigned r = blockIdx.x - nfw, y = r / grx, bx = r - y * grx;
-  int blev = 0;
-  while (blev + 1 < rb.n && (int)y >= rb.ycum[blev + 1]) ++blev;
-  prep_ring_wg<PATCH, true>(Bt, nbad, sk, bx, blev, y - (unsigned)rb.ycum[blev]);
 }
 
 // the level's compact ghost arrays, allocated on first use (a cache of the level object)
@@ -1478,16 +1457,6 @@ int pa_gradcurv_prep_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int comp, 
     unsigned nwgf = 0;
     for (int q = 0; q < Bf.n; ++q) nwgf += (unsigned)Bf.a[q].nwg;
     const dim3 gf(nwgf, 1, (unsigned)nslots), gr((unsigned)((ntr + 255) / 256), (unsigned)Br.ycum[Br.n], (unsigned)nslots);
-    const char* pme = getenv("PA_PREP_MERGE");  // read per pass (tools/ab_driver.py)
-    if ((phase & 3) == 3 && !(phase & 8) && direct && !(pme && !atoi(pme)) && (unsigned long long)nwgf + (unsigned long long)gr.x * gr.y < 0x7fffffffull) {
-      RingRows rb;
-      rb.n = Br.n;
-      for (int q = 0; q <= Br.n; ++q) rb.ycum[q] = Br.ycum[q];
-      const dim3 gm(nwgf + gr.x * gr.y, 1, (unsigned)nslots);
-      if (all_patch) hipLaunchKernelGGL(k_prep_faces_ring<true>, gm, dim3(256), 0, ctx->stream, Bf, ctx->d_flags, sk, nwgf, gr.x, rb);
-      else hipLaunchKernelGGL(k_prep_faces_ring<false>, gm, dim3(256), 0, ctx->stream, Bf, ctx->d_flags, sk, nwgf, gr.x, rb);
-      continue;
-    }
     if ((phase & 1) && (phase & 8)) {
       if (all_patch) hipLaunchKernelGGL((k_prep_faces<true, true>), gf, dim3(256), 0, ctx->stream, Bf, ctx->d_flags, sk);
       else hipLaunchKernelGGL((k_prep_faces<false, true>), gf, dim3(256), 0, ctx->stream, Bf, ctx->d_flags, sk);
