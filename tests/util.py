@@ -66,6 +66,7 @@ CONFIGS = {
     "amr3_wall_z": (32, 3, 16, (1, 1, 0), (0, 0, 0), field_flame),
     "amr3_sym_x": (32, 3, 8, (0, 1, 1), (1, 0, 0), field_flame),
     "amr2_allwalls_ragged": (24, 2, 8, (0, 0, 0), (0, 1, 0), field_flame),
+    "amr5_wall_z": (16, 5, 8, (1, 1, 0), (0, 0, 0), field_flame),  # more levels than one batched launch takes (PA_MAXB = 4)
 }
 
 
