@@ -392,6 +392,43 @@ def test_isosurface_tool_end_to_end(tmp_path, oracle):
 
 
 @pytest.mark.gpu
+def test_tools_on_a_five_level_plotfile(tmp_path, oracle):
+    """more levels than one batched launch of the library takes (PA_MAXB = 4: the all-levels launches go in chunks, marching cubes level
+    by level): grad3d, curvature3d and isosurface3d against the oracle, bit for bit"""
+    p, H, mfs = _synth(tmp_path, nlev=5, base=16, box=8, per=(1, 1, 0))
+    same = lambda a, c: np.array_equal(np.ascontiguousarray(a).view(np.int64), np.ascontiguousarray(c).view(np.int64))
+    _run("grad3d.ex", ["infile=" + p, "gradVar=temp", "is_per=1 1 0"], tmp_path)
+    r = read_plotfile(str(tmp_path / "plt00005_gt"))
+    assert r.hier.nlev == 5
+    st1, st2 = [], []
+    for l, lv in enumerate(H.levels):
+        for ng, dst in ((1, st1), (2, st2)):
+            s = MultiFab(lv, 1, ng)
+            for b in range(lv.nboxes):
+                s.valid(b)[0] = mfs[l].valid(b)[0]
+            dst.append(s)
+    og = [MultiFab(lv, 4, 0) for lv in H.levels]
+    oracle.grad_pipeline(H.levels, st1, 0, oracle.bc_from_flags((1, 1, 0)), og, 0)
+    for l, lv in enumerate(H.levels):
+        for b in range(lv.nboxes):
+            assert same(r.mfs[l].valid(b)[1:5], og[l].valid(b)), ("grad", l, b)
+    _run("curvature3d.ex", ["infile=" + p, "progressName=temp", "is_per=1 1 0"], tmp_path)
+    r = read_plotfile(str(tmp_path / "plt00005_K"))
+    oc = [MultiFab(lv, 5, 0) for lv in H.levels]
+    oracle.curvature_pipeline(H.levels, st2, 0, oracle.bc_from_flags((1, 1, 0)), oc, 0, MultiFab)
+    i0 = r.names.index("Progress")
+    for l, lv in enumerate(H.levels):
+        for b in range(lv.nboxes):
+            v, w = r.mfs[l].valid(b), oc[l].valid(b)
+            assert same(v[i0], w[0]) and same(v[i0 + 2], w[1]) and same(v[i0 + 3:i0 + 6], w[2:5]), ("curvature", l, b)
+    _run("isosurface3d.ex", ["infile=" + p, "isoCompName=temp", "isoVal=1150", "comps=0 2", "is_per=1 1 0"], tmp_path)
+    label, names, nodes, faces = read_mef(p + "_temp_1150.mef")
+    fields = [MultiFab(lv, 3, 0, mfs[l].data.copy()) for l, lv in enumerate(H.levels)]
+    onodes, oelts = oracle.isosurface_pipeline(H.levels, fields, [0, 2], 0, 1150.0, MultiFab)
+    assert len(oelts) > 100 and np.array_equal(faces, oelts + 1) and np.array_equal(nodes.view(np.int64), onodes.view(np.int64))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("per", [(1, 1, 0), (1, 1, 1)])
 def test_isosurface_tool_periodic(tmp_path, oracle, per):
     """is_per != 0 (isosurface.cpp:1395, 1437, 1469, 1550-1560): periodic ghost fill of coordinates and fields, periodic
