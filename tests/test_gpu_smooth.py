@@ -257,37 +257,41 @@ def test_smooth_multigrid_preconditioner(ctx, oracle, per, base, box, monkeypatc
     assert r <= 1e-11
 
 
+@pytest.mark.parametrize("base", [80, 46])
 @pytest.mark.parametrize("dtq", [2.0, 20.0])  # dt / dx^2 on the finest level: the plain iteration / the multigrid-preconditioned one
-def test_smooth_wide_boxes_marching_kernels(ctx, oracle, dtq, monkeypatch):
+def test_smooth_wide_boxes_marching_kernels(ctx, oracle, dtq, base, monkeypatch):
     """boxes wider than a wavefront row and taller than a z chunk (every other smoothing test has boxes of <= 16 cells: two rows of 32
-    lanes, one chunk): 80-cell boxes = a full 64-cell tile + a partly filled one, two chunks of planes (three with PA_SMOOTH_KZ=24).
+    lanes, one chunk): 80-cell boxes = a full 64-cell tile + a partly filled one, two chunks of planes (three with PA_SMOOTH_KZ=24);
+    46-cell boxes = one partly filled tile in x and a last tile of rows that is partly outside the box.
     The z-marching stencil kernels (k_smooth_march) give the SAME BITS as the cell-per-thread kernels (PA_SMOOTH_MARCH=0) whatever
     the chunk length, and the field agrees with the oracle's solve"""
-    H = nested_hierarchy(80, 2, 80, is_per=(1, 0, 0))
+    H = nested_hierarchy(base, 2, base, is_per=(1, 0, 0))
     rhs = []
     for lv in H.levels:
         m = MultiFab(lv, 1, 0)
         fill_analytic(m, 0, lambda x, y, z: (field_flame(x, y, z, 0) - 300.0) / 1700.0)
         rhs.append(m)
     bc = capi.bc_from_flags((1, 0, 0))
-    dt = dtq / 160.0 ** 2
+    dt = dtq / (2.0 * base) ** 2
     dls = [capi.DevLevel(ctx, lv) for lv in H.levels]
     drhs = [capi.DevMF.from_host(ctx, dl, r) for dl, r in zip(dls, rhs)]
     out = {}
-    for march, kz in (("0", ""), ("1", ""), ("1", "24")):
+    variants = (("0", "64"), ("1", "64"), ("1", "24"))
+    for march, kz in variants:
         monkeypatch.setenv("PA_SMOOTH_MARCH", march)
-        if kz:
-            monkeypatch.setenv("PA_SMOOTH_KZ", kz)
+        monkeypatch.setenv("PA_SMOOTH_KZ", kz)
         dsol = [capi.DevMF(ctx, dl, 1, 0) for dl in dls]
         it, res = capi.smooth_solve(ctx, drhs, 0, dsol, 0, dt, bc, tol=1e-13, maxiter=500)
         assert res <= 1e-13
         out[(march, kz)] = ([d.download() for d in dsol], it, res)
-    ref = out[("0", "")]
-    for key in (("1", ""), ("1", "24")):
+    ref = out[variants[0]]
+    for key in variants[1:]:
         assert out[key][1] == ref[1] and out[key][2] == ref[2], (key, out[key][1:], ref[1:])
         for l, lv in enumerate(H.levels):
             for b in range(lv.nboxes):
                 assert np.array_equal(out[key][0][l].valid(b)[0], ref[0][l].valid(b)[0]), (key, l, b)
+    if base > 64 and dtq > 8:
+        return  # (the oracle's unpreconditioned solve of the stiff case takes half a minute at this size: compared on the smaller hierarchy)
     want, oit, ores = oracle.smooth_solve(H.levels, rhs, 0, dt, bc, MultiFab, tol=1e-13, maxiter=2000)
     assert ores <= 1e-13
     for l, lv in enumerate(H.levels):
