@@ -1,0 +1,95 @@
+"""GPU tier: device memory comes back.  A context with its levels, multifabs, cached plans, work multifabs (pa_level_scratch), compact
+ghost arrays, marching-cubes blocks and solver vectors is built, driven through the pipelines of the four tools and destroyed, several
+times over; the free memory of the device after the last cycle must be what it was after the second (the first two pay for the runtime's
+own one-time allocations: code objects, queues, scratch)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from peleanalysis_amd import capi
+from peleanalysis_amd.hierarchy import MultiFab, field_flame, nested_hierarchy
+
+pytestmark = pytest.mark.gpu
+
+
+def _cycle(per=(1, 1, 0), stages="abcdefgh"):
+    from util import make_states
+    ctx = capi.Context(0)
+    H = nested_hierarchy(32, 3, 16, is_per=per)
+    bc = capi.bc_from_flags(per)
+    st = make_states(H, 4, 2, field_flame, seed=3)
+    dls = [capi.DevLevel(ctx, lv) for lv in H.levels]
+    own = []
+
+    def mf(dl, nc, ng):
+        m = capi.DevMF(ctx, dl, nc, ng)
+        own.append(m)
+        return m
+
+    dst = [capi.DevMF.from_host(ctx, dl, s) for dl, s in zip(dls, st)]
+    own += dst
+    works = [mf(dl, 1, 2) for dl in dls]
+    outs = [mf(dl, 8, 0) for dl in dls]
+    if "a" in stages:
+        capi.gradcurv_run(ctx, dst, 0, bc, capi.curv_params(prog_min=300.0, prog_max=2000.0, fused=True), works, outs, 0)  # fused sweeps, compact ghost arrays, patches
+    if "b" in stages:
+        capi.gradcurv_run(ctx, dst, 0, bc, capi.curv_params(prog_min=300.0, prog_max=2000.0, fused=True, threshold=0.05), works, outs, 0)  # clip: slow lists
+    g4 = [mf(dl, 4, 0) for dl in dls]
+    if "c" in stages:
+        capi.grad_run(ctx, dst, 0, bc, g4, 0)
+    o18 = [mf(dl, 18, 0) for dl in dls]
+    for fused in (True, False):  # options (work multifabs kept with the levels) + the smoothing solve, plain and multigrid-preconditioned
+        for dt in (1e-4, 2e-2):
+            if ("d" if dt < 1e-3 else "e") in stages:
+                capi.curvature_run(ctx, dst, 0, bc, capi.curv_params(fused=fused, do_smooth=True, smoothing_time=dt, do_gauss=True, do_strain=True,
+                                                                     strain_tensor=True, do_velnormal=True, vel_comp=1), o18, 0)
+    # filterPlt: ghost fill of the hierarchy + box filter
+    ngs = [1, 2, 4]
+    fin = [mf(dl, 1, ngs[l]) for l, dl in enumerate(dls)]
+    fout = [mf(dl, 1, 0) for dl in dls]
+    for m in fin:
+        m.setval(1.0)
+    hfin = (C.c_void_p * 3)(*[m.h for m in fin])
+    if "f" in stages:
+        ctx.check(ctx.lib.pa_fill_ghosts_hierarchy(ctx.h, 3, hfin, 0, 1, (C.c_int32 * 3)(*ngs), 2, 1, 1))
+        for l, f in enumerate((2, 4, 8)):
+            w = (C.c_double * (f + 2))()
+            assert ctx.lib.pa_box_filter_weights(f, w) == f // 2
+            ctx.check(ctx.lib.pa_boxfilter_level(ctx.h, fin[l].h, fout[l].h, 0, 1, ngs[l], w))
+    # isosurface: marching cubes of the hierarchy (pooled output block), coordinates from the cell indices
+    loops = []
+    for lv in H.levels:
+        lp = np.zeros((lv.nboxes, 6), np.int64)
+        lp[:, :3], lp[:, 3:] = lv.boxes[:, :3], lv.boxes[:, 3:] - 1
+        loops.append(lp)
+    for _ in range(2 if "g" in stages else 0):
+        capi.mc_hierarchy(ctx, dst, [1, 1, 0], loops, 0, 1150.0)
+    # streamlines through the hierarchy
+    v3 = [mf(dl, 3, 2) for dl in dls]
+    for m in v3:
+        m.setval(0.25)
+    if "h" in stages:
+        capi.stream_trace(ctx, v3, 0, np.array([[0.5, 0.5, 0.5], [0.3, 0.6, 0.4]]), 8, 0.005)
+    ctx.sync()
+    assert ctx.bc_errors() == 0
+    for m in own:
+        m.close()
+    for dl in dls:
+        dl.close()
+    ctx.close()
+
+
+def test_device_memory_comes_back_after_contexts_are_destroyed():
+    """(two warm-up cycles: the runtime keeps 356 MiB after the first context of a process and another 88 MiB after the second -- code
+    objects, queues and their scratch -- and nothing after that: tools/exp/leak_seq.py, ten cycles)"""
+    torch = pytest.importorskip("torch")
+    for _ in range(2):
+        _cycle()
+    torch.cuda.synchronize()
+    free2, _ = torch.cuda.mem_get_info(0)
+    for _ in range(3):
+        _cycle()
+    torch.cuda.synchronize()
+    free5, _ = torch.cuda.mem_get_info(0)
+    assert free2 - free5 <= 4 << 20, f"{(free2 - free5) / 2**20:.1f} MiB of device memory did not come back over three create / run / destroy cycles"
