@@ -13,9 +13,11 @@ from peleanalysis_amd.hierarchy import MultiFab, field_flame, nested_hierarchy
 pytestmark = pytest.mark.gpu
 
 
-def _cycle(per=(1, 1, 0), stages="abcdefgh"):
+def _cycle(per=(1, 1, 0), stages="abcdefgh", ctx=None):
     from util import make_states
-    ctx = capi.Context(0)
+    own_ctx = ctx is None
+    if own_ctx:
+        ctx = capi.Context(0)
     H = nested_hierarchy(32, 3, 16, is_per=per)
     bc = capi.bc_from_flags(per)
     st = make_states(H, 4, 2, field_flame, seed=3)
@@ -77,7 +79,8 @@ def _cycle(per=(1, 1, 0), stages="abcdefgh"):
         m.close()
     for dl in dls:
         dl.close()
-    ctx.close()
+    if own_ctx:
+        ctx.close()
 
 
 def test_device_memory_comes_back_after_contexts_are_destroyed():
@@ -93,3 +96,20 @@ def test_device_memory_comes_back_after_contexts_are_destroyed():
     torch.cuda.synchronize()
     free5, _ = torch.cuda.mem_get_info(0)
     assert free2 - free5 <= 4 << 20, f"{(free2 - free5) / 2**20:.1f} MiB of device memory did not come back over three create / run / destroy cycles"
+
+
+def test_device_memory_comes_back_when_levels_are_rebuilt_under_one_context():
+    """what a regridding AMR code does: ONE long-lived context, the levels (BoxArrays) and their multifabs created and destroyed again and
+    again -- plans, tables and work multifabs cached for a level must go with the level"""
+    torch = pytest.importorskip("torch")
+    ctx = capi.Context(0)
+    for _ in range(2):
+        _cycle(ctx=ctx)
+    torch.cuda.synchronize()
+    free2, _ = torch.cuda.mem_get_info(0)
+    for _ in range(4):
+        _cycle(ctx=ctx)
+    torch.cuda.synchronize()
+    free6, _ = torch.cuda.mem_get_info(0)
+    ctx.close()
+    assert free2 - free6 <= 4 << 20, f"{(free2 - free6) / 2**20:.1f} MiB of device memory did not come back over four rebuilds of the levels under one context"
