@@ -555,6 +555,7 @@ extern "C" void pa_level_destroy(pa_level* L) {
   if (L->d_sfoff) (void)hipFree(L->d_sfoff);
   if (L->d_cgoff) (void)hipFree(L->d_cgoff);
   if (L->d_cg) (void)hipFree(L->d_cg);
+  if (L->d_ncg) (void)hipFree(L->d_ncg);
   if (L->d_cpoff) (void)hipFree(L->d_cpoff);
   if (L->d_cp) (void)hipFree(L->d_cp);
   if (L->d_sfcode) (void)hipFree(L->d_sfcode);

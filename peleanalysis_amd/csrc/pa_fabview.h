@@ -77,6 +77,7 @@ struct LevelBP2 {
     const int e = L.sfindex[b * 6 + f];
     return e < 0 ? nullptr : L.cg + L.cgoff[e];
   }
+  __device__ __forceinline__ const double* cg_base() const { return L.cg; }
 };
 struct LevelBP4 {
   DLevelView L;
@@ -103,6 +104,7 @@ struct FabBP2 {
     return true;
   }
   __device__ __forceinline__ const double* cg_face(int, int) const { return nullptr; }
+  __device__ __forceinline__ const double* cg_base() const { return nullptr; }
 };
 struct FabBP4 {
   FabView A, B, C, D;

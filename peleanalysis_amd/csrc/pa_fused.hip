@@ -103,7 +103,15 @@ struct FixArgs {
   long long cg_stride = 0, cp_stride = 0;  // component slots (blockIdx.z): doubles between the slots' sets of compact arrays / coarse patches
   const int2* wg = nullptr; int nwg = 0;   // the level's work table {special face, chunk of 256 face cells} (pa_level::d_sfwg)
   const int2* pwg = nullptr; int npwg = 0; // ... {special face, chunk of 256 perimeter cells} (pa_level::d_pfwg)
+  // NCG: this pass's sweep mirrored the first-layer data of the special x faces of boxes at least ncg_minw wide (pa_fused_march.h)
+  const double* ncg = nullptr; long long ncgs = 0; int ncg_minw = 0;
 };
+typedef double pa_fix_d2 __attribute__((ext_vector_type(2)));
+// the x faces the wide CG sweep mirrors (the tile that holds the face must hold the first three columns behind it: pa_fused_march3.h ncgl / ncgh)
+__device__ __forceinline__ bool ncg_face_ok(const DBox& B, int side, int minw) {
+  const int nx = B.hi[0] - B.lo[0] + 1;
+  return nx >= minw && (side ? ((nx - 1) & 63) + 1 : min(nx, 64)) >= 3;
+}
 // workgroup -> (batch level, special face, first face cell) through the levels' work tables
 template <typename BT>
 __device__ __forceinline__ bool wg_decode(const BT& Bt, int& blev, unsigned& fy, long long& t, unsigned w = blockIdx.x) {
@@ -325,7 +333,7 @@ template <int FD, int NL, bool PATCH, bool CLIP = false>
 __device__ __forceinline__ void faces_curv_fast_body(const DLevelView& L, const DLevelView& LCr, const DMFView& MN, int cncomp0, const DMFView& MO,
                                                      int ncomp0, int kcomp, const FaceArgs& A, int* nbad, int b, const DBox& B, int side,
                                                      const int q0[3], unsigned code, const double* patch, const DMFView& MP = DMFView(), int pcomp = 0, SlowList sl = SlowList(),
-                                                     unsigned row = 0, long long tcell = 0) {
+                                                     unsigned row = 0, long long tcell = 0, const double* ncgp = nullptr, long long ncgs = 0) {
   constexpr int T0 = (FD == 0) ? 1 : 0, T1 = (FD == 2) ? 1 : 2;
   const int cls = (int)(code & 3u);
   // cls == 0: a VALID ghost cell behind a special face (a face that is coarse-fine elsewhere; general BoxArrays).  The sweep's
@@ -351,9 +359,19 @@ __device__ __forceinline__ void faces_curv_fast_body(const DLevelView& L, const 
   const double* nf = o + (long long)(ncomp0 + FD) * cso + idx1;
   const double* n0p = o + (long long)(ncomp0 + T0) * cso + idx1;
   const double* n1p = o + (long long)(ncomp0 + T1) * cso + idx1;
-  const double nfd1 = nf[0], nfd2 = nf[in], nfd3 = nf[2 * in];
-  const double a0m = n0p[-st[T0]], a0c = n0p[0], a0p = n0p[st[T0]];
-  const double a1m = n1p[-st[T1]], a1c = n1p[0], a1p = n1p[st[T1]];
+  // NCG (x faces, one layer, no clip): N_x of the first three cells and the two tangential terms of K as the sweep formed them, from the
+  // level's face-major arrays -- five contiguous streams instead of 8 bytes of five different lines
+  const bool pre = FD == 0 && NL == 1 && !CLIP && ncgp != nullptr;
+  double nfd1, nfd2, nfd3, a0m = 0, a0c = 0, a0p = 0, a1m = 0, a1c = 0, a1p = 0, t01n = 0, t11n = 0;
+  if (pre) {  // three arrays of pairs: (N_x of the first, second cell), (N_x of the third cell, y term of K), (z term of K, -)
+    const pa_fix_d2* np = (const pa_fix_d2*)ncgp;
+    const pa_fix_d2 v0 = np[0], v1 = np[ncgs], v2 = np[2 * ncgs];
+    nfd1 = v0.x; nfd2 = v0.y; nfd3 = v1.x; t01n = v1.y; t11n = v2.x;
+  } else {
+    nfd1 = nf[0]; nfd2 = nf[in]; nfd3 = nf[2 * in];
+    a0m = n0p[-st[T0]]; a0c = n0p[0]; a0p = n0p[st[T0]];
+    a1m = n1p[-st[T1]]; a1c = n1p[0]; a1p = n1p[st[T1]];
+  }
   if (CLIP) {
     static_assert(!CLIP || NL == 1, "the clip-aware fast path fixes one layer");
     const FabView P = mf_view(MP, B, b);
@@ -421,7 +439,7 @@ __device__ __forceinline__ void faces_curv_fast_body(const DLevelView& L, const 
   // face-normal terms: (minus neighbour, centre, plus neighbour)
   const double f1 = side ? cdiff(L.dxinv[FD], nfd2, nfd1, g) : cdiff(L.dxinv[FD], g, nfd1, nfd2);
   const double f2 = side ? cdiff(L.dxinv[FD], nfd3, nfd2, nfd1) : cdiff(L.dxinv[FD], nfd1, nfd2, nfd3);
-  const double t01 = cdiff(L.dxinv[T0], a0m, a0c, a0p), t11 = cdiff(L.dxinv[T1], a1m, a1c, a1p);
+  const double t01 = pre ? t01n : cdiff(L.dxinv[T0], a0m, a0c, a0p), t11 = pre ? t11n : cdiff(L.dxinv[T1], a1m, a1c, a1p);
   const double t02 = cdiff(L.dxinv[T0], b0m, b0c, b0p), t12 = cdiff(L.dxinv[T1], b1m, b1c, b1p);
   (void)dx0; (void)dx1; (void)dx2;
   double k1 = 0.0, k2 = 0.0;
@@ -466,8 +484,11 @@ __device__ __forceinline__ void faces_fast_wg(const LevBatch<FixArgs>& Bt, int* 
   const long long cpo = (Fx.use_cp && L.cp) ? L.cpoff[fy] : -1;  // wave-uniform
   const double* patch = cpo >= 0 ? L.cp + z * Fx.cp_stride + cpo : nullptr;
   const unsigned row = ((unsigned)Bt.ycum[blev] + fy) | ((unsigned)z << 24);  // batch row of the face; SlowList entries carry the slot
+  const double* ncgp = nullptr;
+  if (NL == 1 && !CLIP && fdir == 0 && Fx.ncg && z == 0 && ncg_face_ok(B, side, Fx.ncg_minw))
+    ncgp = Fx.ncg + 2 * (L.cgoff[fy] + (long long)(q0[2] - B.lo[2] + 1) * (B.hi[1] - B.lo[1] + 3) + (q0[1] - B.lo[1] + 1));
   switch (fdir) {  // uniform per workgroup
-    case 0: faces_curv_fast_body<0, NL, PATCH, CLIP>(L, LCr, MN, cncomp0, MO, ncomp0, kcomp, A, nbad, b, B, side, q0, code, patch, Fx.MC_, Fx.ccomp + z, sl, row, t); break;
+    case 0: faces_curv_fast_body<0, NL, PATCH, CLIP>(L, LCr, MN, cncomp0, MO, ncomp0, kcomp, A, nbad, b, B, side, q0, code, patch, Fx.MC_, Fx.ccomp + z, sl, row, t, ncgp, Fx.ncgs); break;
     case 1: faces_curv_fast_body<1, NL, PATCH, CLIP>(L, LCr, MN, cncomp0, MO, ncomp0, kcomp, A, nbad, b, B, side, q0, code, patch, Fx.MC_, Fx.ccomp + z, sl, row, t); break;
     default: faces_curv_fast_body<2, NL, PATCH, CLIP>(L, LCr, MN, cncomp0, MO, ncomp0, kcomp, A, nbad, b, B, side, q0, code, patch, Fx.MC_, Fx.ccomp + z, sl, row, t); break;
   }
@@ -928,6 +949,15 @@ static int level_cg(pa_ctx* ctx, const pa_level* Lc, int nsets = 1) {
   return 0;
 }
 static long long cg_stride(const pa_level* L) { return std::max<long long>(L->cg_total, 8); }
+// NCG arrays of a level (MarchArgs::ncg): three arrays of pairs, each shaped like one set of the compact ghost arrays, allocated on first use
+static int level_ncg(pa_ctx* ctx, const pa_level* Lc) {
+  pa_level* L = const_cast<pa_level*>(Lc);
+  if (L->d_ncg) return 0;
+  const size_t n = 6 * (size_t)std::max<long long>(L->cg_total, 8);  // three arrays of pairs
+  if (hipMalloc(&L->d_ncg, sizeof(double) * n) != hipSuccess) { L->d_ncg = nullptr; return pa_fail(ctx, "compact first-layer arrays: device allocation failed"); }
+  PA_HIP(hipMemsetAsync(L->d_ncg, 0, sizeof(double) * n, ctx->stream));
+  return 0;
+}
 static long long cp_stride(const pa_level* L) { return std::max<long long>(L->cp_total, 8); }
 
 // ---- coarse patches (DLevelView::cp, pa_internal.h): one thread per patch cell fetches the coarse value through the owner
@@ -1545,6 +1575,8 @@ int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, d
   static const bool knobs = getenv("PA_MARCH") || getenv("PA_DBG") || getenv("PA_MTY") || getenv("PA_PAIR");
   std::vector<SweepGroup> all, lv, rest;
   for (int l = 0; l < nlev; ++l) sweep_groups(l, phi[l]->lev, all);
+  for (int l = 0; l < nlev; ++l) const_cast<pa_level*>(phi[l]->lev)->ncg_live = false;  // (set again below by the launches that mirror the x faces' first layer)
+  bool any_ncg = false;
   int mty = 0;
   bool same = true;
   for (const SweepGroup& g : all) {
@@ -1612,6 +1644,17 @@ int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, d
       S.cgs[q] = cg_stride(L);
       MarchArgs A{pcomp, ocomp, kdef, pmin, 1.0 / (pmax - pmin), clip ? thr : -1.0, 2, 1, 1, 1};
       A.cg = 1;
+      {  // NCG: the first-layer data of the special x faces for the fix-up (PA_NCG=0, read per pass: off)
+        const char* ne = getenv("PA_NCG");
+        if (!(ne && !atoi(ne)) && !clip && nslots == 1 && slot == 0 && !L->sfaces.empty()) {
+          if (level_ncg(ctx, L)) return 1;
+          pa_level* Lm = const_cast<pa_level*>(L);
+          A.ncg = L->d_ncg; A.ncgs = cg_stride(L);
+          Lm->ncg_live = true;
+          any_ncg = true;
+          Lm->ncg_minw = lv[q].list ? 33 : 1;  // a list: the level's boxes wider than 32 cells; none: every box of the level is in this group
+        }
+      }
       A.boxlist = lv[q].list;
       if (tz_best) A.kseg = std::max(4, (lv[q].dims[2] + tz_best - 1) / tz_best);
       const unsigned nb = (unsigned)lv[q].n;
@@ -1713,7 +1756,7 @@ int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, d
     for (int z = 0; z < nslots; ++z)
       if (sweep_group_cg(ctx, g, phi[g.lev], pcomp + z, nslots > 1 ? pmins[z] : pmin, nslots > 1 ? pmaxs[z] : pmax, out[g.lev], ocomp + 8 * z, thr, slot + z)) return 1;
   if (!lv.empty())
-    ctx->sweep_kernel = "k_gradcurv_march3_levels<MTY=" + std::to_string(mty) + (clip ? ",CLIP" : "") + ">[" + std::to_string(lv.size()) + " levels per launch]" +
+    ctx->sweep_kernel = "k_gradcurv_march3_levels<MTY=" + std::to_string(mty) + (clip ? ",CLIP" : "") + ">[" + std::to_string(lv.size()) + " levels per launch" + (any_ncg ? "; x faces mirrored" : "") + "]" +
                         ((rest.empty() && nar.empty()) ? "" : " + narrow-box launch(es)");
   return 0;
 }
@@ -1760,6 +1803,10 @@ int pa_gradcurv_fix_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, 
       A.ratio = 2; A.has_crse = crse_n[l] ? 1 : 0; A.thr = clip ? thr : -1.0; A.layers = 1; A.perim_only = 1; A.pmin = pmin; A.invd = 1.0 / (pmax - pmin);
       Bt.a[Bt.n] = FixArgs{L->view, phi[l]->view, pcomp, crse_n[l] ? crse_n[l]->lev->view : L->view, crse_n[l] ? crse_n[l]->view : phi[l]->view, cncomp0,
                            out[l]->view, ncomp0, kcomp, A, (use_cp && crse_n[l] && L->cp_total > 0) ? 1 : 0, cg_stride(L), cp_stride(L), (const int2*)L->d_sfwg, L->nsfwg, (const int2*)L->d_pfwg, L->npfwg};
+      if (L->ncg_live) {  // this pass's sweep mirrored the first layer behind the special x faces
+        if (!clip && nslots == 1) { Bt.a[Bt.n].ncg = L->d_ncg; Bt.a[Bt.n].ncgs = cg_stride(L); Bt.a[Bt.n].ncg_minw = L->ncg_minw; }
+        const_cast<pa_level*>(L)->ncg_live = false;
+      }
       Bt.ycum[Bt.n + 1] = Bt.ycum[Bt.n] + (int)L->sfaces.size();
       ++Bt.n;
       const long long n0 = L->maxn[0], n1 = L->maxn[1], n2 = L->maxn[2];

@@ -48,6 +48,7 @@ struct MarchLds {
   double p[3][MTY + 2][PA_MLW];   // phi
   double nx[3][MTY][PA_MLW];      // n_x of rows 1..MTY (+ edge columns)
   double ny[3][MTY + 2][64];      // n_y
+  alignas(16) double h[2][MTY + 2][2][6];  // NCG hand-over (pa_fused_march3.h): per plane parity, row and side (N_x of the first three cells, y term, z term of K, -)
 };
 
 struct MarchArgs {
@@ -61,6 +62,12 @@ struct MarchArgs {
   // neighbouring tiles both read are served by that XCD's L2 instead of being fetched once per XCD.
   int order, nboxes, txy_max, tiles_max;
   int cg = 0;  // host side: launch the CG variant of k_gradcurv_march3 (pa_fused_march3.h)
+  // NCG (pa_fused_march3.h, wide CG sweep without the clip): for the first cell behind a special X face the sweep writes N_x of the
+  // first three cells and the y and z terms of K into the level's face-major arrays of PAIRS ((double2*)ncg)[pair * ncgs + cgoff + ...],
+  // pair = 0 .. 2, so that the fix-up of those cells (k_faces_curv_fast) reads three contiguous streams instead of 8 bytes of five
+  // different lines per cell
+  double* ncg = nullptr;
+  long long ncgs = 0;
   const int* boxlist = nullptr;  // k_gradcurv_march3 / march3n: the launch covers boxes boxlist[0 .. nboxes-1] of the level (null: all of them)
   // k_gradcurv_march3 / march3n on boxes of different sizes: workgroup i works on tile wgtab[2 i + 1] of box wgtab[2 i] (< 0: none).
   // With order 2 every box gets the tile count of the LARGEST box of the launch and the others exit at once -- on a Pele BoxArray

@@ -180,6 +180,11 @@ __device__ __forceinline__ void gradcurv_march3_body(const BP& bp, const MarchAr
     if (k0 == V.lo[2]) cgzl = bp.cg_face(box, 4);
     if (k1 >= V.hi[2] - 1) cgzh = bp.cg_face(box, 5);
   }
+  // NCG (MarchArgs::ncg): the special x faces of this tile whose first-layer data the sweep mirrors -- the tile must hold the first three
+  // columns behind the face (the same rule in k_faces_curv_fast: ncg_face_ok)
+  const bool ncgl = CG && !CLIP && A.ncg && cgxl && llast >= 2;
+  const bool ncgh = CG && !CLIP && A.ncg && cgxh && xhmode == 1 && llast >= 2;
+  const bool ncg_tile = ncgl || ncgh;
 
   __shared__ MarchLds<PA_MTY> S;
   const long long pps = (long long)P.nx * P.ny * 8;  // plane stride of phi, bytes
@@ -206,6 +211,7 @@ __device__ __forceinline__ void gradcurv_march3_body(const BP& bp, const MarchAr
   if (w < PA_MROWS && w > rtop) {
     // ---------------------------------------------------------------- dead row (partial tile)
     for (int it = 0; it <= pend - (k0 - 1) + 1; ++it) __syncthreads();
+    if (ncg_tile) __syncthreads();
     return;
   }
 
@@ -299,6 +305,7 @@ __device__ __forceinline__ void gradcurv_march3_body(const BP& bp, const MarchAr
         p0 = p1; p1 = x;
       };
       PA_RUN3(step)
+      if (ncg_tile) __syncthreads();
       return;
     }
     // output rows
@@ -406,9 +413,23 @@ __device__ __forceinline__ void gradcurv_march3_body(const BP& bp, const MarchAr
       const double fznh = zflux(dxinv[2], nzq, nzp);
       double curv = 0.0;
       curv += cdiff(dxinv[0], nxl, nxq, nxr);
-      curv += cdiff(dxinv[1], nys, nyq, nyn);
-      curv += favg(fzn, fznh);
+      const double cty = cdiff(dxinv[1], nys, nyq, nyn), ctz = favg(fzn, fznh);
+      curv += cty;
+      curv += ctz;
       curv = curv * 0.5;
+      if (CG && !CLIP && ncg_tile) {  // (uniform) NCG: what the fix-up of the first cell behind a special x face needs, handed to the edge wave
+        double* hl = &S.h[p & 1][rr][0][0];
+        double* hh = &S.h[p & 1][rr][1][0];
+        const int xh = llast + 1 - xs;  // 0, 1, 2: the last three columns of the tile (lanes past the box edge mirror the last one)
+        if (ncgl) {  // (uniform)
+          if (xs <= 3) hl[xs - 1] = nxq;
+          if (xs == 1) { hl[3] = cty; hl[4] = ctz; }
+        }
+        if (ncgh) {
+          if (xh <= 2) hh[xh] = nxq;
+          if (xh == 0) { hh[3] = cty; hh[4] = ctz; }
+        }
+      }
       if (OLD_SCHED) __builtin_amdgcn_sched_barrier(0);
       if (OLD_SCHED) { if (PAIR) { PA_OPAQUE(lo16); store_pair(ob + 4 * osc, lo16, odd, o4, o5); } else PA_STL(ob + 5 * osc, lo8, o5); }
       if (OLD_SCHED) __builtin_amdgcn_sched_barrier(0);
@@ -484,6 +505,7 @@ __device__ __forceinline__ void gradcurv_march3_body(const BP& bp, const MarchAr
       PA_STG(ob + 6 * osc, lo8, o6);
       PA_STG(ob + 7 * osc, lo8, o7);
     }
+    if (ncg_tile) __syncthreads();
     return;
   }
 
@@ -550,8 +572,33 @@ __device__ __forceinline__ void gradcurv_march3_body(const BP& bp, const MarchAr
     double fzc = zflux(dxinv[2], cm, cc);
     S.c[0][rr][xs] = cc;
     __syncthreads();
-    auto step = [&](auto spc, int p) __attribute__((always_inline)) {
+    // NCG: ONE 16-byte store per step and face (the sweep is bound by the store instructions a CU can issue, not by their bytes): lane
+    // (pair, row) of the edge wave writes a pair of values of row `row` of the tile -- pair 0 = (N_x of the first, second cell), 1 = (N_x
+    // of the third cell, y term of K), 2 = (z term of K, unused) -- into the face's arrays of pairs; a lane without a live cell writes to
+    // an element of the arrays' ring that nobody reads, so that the store is unconditional
+    const int npair = lane / PA_MTY, nrow = lane % PA_MTY + 1, njr = j0 + nrow - 1;
+    pa_d2* nbase[2] = {nullptr, nullptr};
+    pa_d2* ndum = nullptr;
+    const bool nrow_ok = npair < 3 && njr <= V.hi[1];
+    if (CG && ncg_tile) {
+      pa_d2* const n2 = (pa_d2*)A.ncg;
+      if (ncgl) nbase[0] = n2 + (cgxl - bp.cg_base());
+      if (ncgh) nbase[1] = n2 + (cgxh - bp.cg_base());
+      ndum = ncgl ? nbase[0] : nbase[1];
+    }
+    const long long npl = (long long)(ny + 2), ncgs = A.ncgs;
+    auto ncg_store = [&](int q2, int par) __attribute__((always_inline)) {
+#pragma unroll
+      for (int sd = 0; sd < 2; ++sd) {
+        if (!nbase[sd]) continue;  // (uniform)
+        const pa_d2 v = *(const pa_d2*)&S.h[par][nrow][sd][2 * min(npair, 2)];
+        pa_d2* dst = (nrow_ok && q2 >= k0) ? nbase[sd] + (long long)min(npair, 2) * ncgs + (long long)(q2 - V.lo[2] + 1) * npl + (njr - V.lo[1] + 1) : ndum;
+        *dst = v;
+      }
+    };
+    auto step_impl = [&](auto spc, int p, auto ncgf) __attribute__((always_inline)) {
       constexpr int SP = decltype(spc)::value, SP1 = (SP + 1) % 3;
+      constexpr bool NCGF = decltype(ncgf)::value;
       double x, xo;
       PA_TAKE(x, f[SP]);
       PA_TAKE(xo, fo[SP]);
@@ -585,11 +632,20 @@ __device__ __forceinline__ void gradcurv_march3_body(const BP& bp, const MarchAr
         f[SP] = PA_LDG(gp, og);
         fo[SP] = PA_LDO(0);
       }
+      if (NCGF) ncg_store(p - 2, (p - 1) & 1);  // the row waves handed plane p - 2 over after the PREVIOUS barrier
       cm = cc; cc = cp; cp = xsp ? xo : PA_PROG(x); co = (xmode == 2) ? xo : PA_PROG(xo);
       fzc = fzh;
       p0 = p1; p1 = x;
     };
-    PA_RUN3(step)
+    auto step = [&](auto spc, int p) __attribute__((always_inline)) { step_impl(spc, p, std::false_type{}); };
+    auto stepn = [&](auto spc, int p) __attribute__((always_inline)) { step_impl(spc, p, std::true_type{}); };
+    if (CG && ncg_tile) {
+      PA_RUN3(stepn)
+      __syncthreads();  // (every wave of an NCG tile ends with this barrier) the last plane's hand-over
+      ncg_store(k1, pend & 1);
+    } else {
+      PA_RUN3(step)
+    }
   }
 #undef PA_LDO
 #undef PA_PROG

@@ -163,6 +163,9 @@ struct pa_level {
   long long* d_cgoff = nullptr;
   double* d_cg = nullptr;   // allocated on first use (pa_level_cg)
   long long cg_total = 0;
+  double* d_ncg = nullptr;  // NCG (pa_fused_march.h MarchArgs::ncg): 5 arrays of cg_stride doubles, allocated on first use (level_ncg)
+  bool ncg_live = false;    // this pass's sweep wrote them (set by pa_gradcurv_levels_cg, consumed by pa_gradcurv_fix_levels)
+  int ncg_minw = 0;         // ... for the boxes at least this wide
   std::vector<long long> cgoff;
   // Irregular cells (pa_fused.hip: k_find_irregular / k_curv_general): boundary cells of local boxes next to a concave
   // coarse-fine corner or to the line where a box face changes from covered to coarse-fine, whose curvature neither the

@@ -176,3 +176,62 @@ def test_gradcurv_tagged_irregular_hierarchy_matches_oracle(ctx, oracle):
             got = dout[l].download()
             assert_valid_bits_equal(got, og[l], [(c, c) for c in range(4)], f"tagged irregular fused {fused} grad level {l}")
             assert_valid_bits_equal(got, oc[l], [(4, 2), (5, 3), (6, 4), (7, 1)], f"tagged irregular fused {fused} curv level {l} ({nirr} irregular cells)")
+
+
+@pytest.mark.parametrize("shape", ["nested128", "widths"])
+def test_x_face_mirror_of_the_sweep_gives_the_same_bits(ctx, oracle, shape, monkeypatch):
+    """round 5, third session: the wide exact-normal sweep hands the fix-up what the first cell behind a special X face needs (N_x of the
+    first three cells, the y and z terms of K) through face-major arrays (MarchArgs::ncg; PA_NCG=0: the fix-up reads the normals' FABs as
+    before).  Both ways bit for bit, with the path asserted -- the parity tests against the oracle run with the default (on).
+    "widths": separate fine boxes 36, 66, 68 and 130 cells wide -- high faces whose last tile is 36, 2, 4 and 2 columns wide: the mirror
+    takes only tiles that hold three columns, the others keep the old path (the same rule on both sides: ncg_face_ok)"""
+    from peleanalysis_amd.hierarchy import Hierarchy, Level, chop_box
+    per = (0, 1, 0)
+    if shape == "nested128":
+        H = nested_hierarchy(128, 3, 64, is_per=(1, 1, 0))
+        per = (1, 1, 0)
+    else:
+        # level 0: 192 x 32 x 32 in one row of boxes; level 1: boxes of the widths under test side by side in y (each its own x extent)
+        l0 = Level(chop_box((0, 0, 0), (191, 31, 31), 64), (0, 0, 0), (191, 31, 31), per, np.zeros(3), np.array([6.0, 1.0, 1.0]))
+        widths, boxes, y = [36, 66, 68, 130], [], 2
+        for w in widths:  # fine boxes: x from 20, 12 rows each with 4 rows of coarse cells between them, z 8 .. 55 (even corners: ratio 2)
+            boxes.append([20, y, 8, 20 + w - 1, y + 11, 55])
+            y += 16
+        l1 = Level(np.array(boxes, np.int32), (0, 0, 0), (383, 63, 63), per, np.zeros(3), np.array([6.0, 1.0, 1.0]))
+        H = Hierarchy([l0, l1], 2)
+    bc = capi.bc_from_flags(per)
+    rng = np.random.default_rng(9)
+    states = []
+    for lv in H.levels:
+        s = MultiFab(lv, 1, 2)
+        fill_analytic(s, 0, lambda x, y, z: field_flame(x / (6.0 if shape == "widths" else 1.0), y, z, 0))
+        for b in range(lv.nboxes):
+            v = s.valid(b)
+            v += 1e-3 * rng.uniform(-1, 1, size=v.shape)
+        states.append(s)
+    dls = [capi.DevLevel(ctx, lv) for lv in H.levels]
+    dst = [capi.DevMF.from_host(ctx, dl, s) for dl, s in zip(dls, states)]
+    work = [capi.DevMF(ctx, dl, 1, 2) for dl in dls]
+    outs = {}
+    for v in ("0", "1"):
+        monkeypatch.setenv("PA_NCG", v)
+        dout = [capi.DevMF(ctx, dl, 8, 0) for dl in dls]
+        for m in dout:
+            m.setval(-3.0)
+        capi.gradcurv_run(ctx, dst, 0, bc, capi.curv_params(prog_min=300.0, prog_max=2000.0, fused=True), work, dout, 0)
+        ctx.sync()
+        assert ctx.bc_errors() == 0
+        kn = ctx.lib.pa_sweep_kernel_name(ctx.h).decode()
+        assert ("x faces mirrored" in kn) == (v == "1"), kn
+        outs[v] = [m.download() for m in dout]
+    for l, lv in enumerate(H.levels):
+        for b in range(lv.nboxes):
+            assert np.array_equal(outs["0"][l].valid(b).view(np.int64), outs["1"][l].valid(b).view(np.int64)), (shape, l, b)
+    _omp()
+    og = [MultiFab(lv, 4, 0) for lv in H.levels]
+    oc = [MultiFab(lv, 5, 0) for lv in H.levels]
+    oracle.grad_pipeline(H.levels, [s.copy() for s in states], 0, bc, og, 0, multipass=False, omp=True)
+    oracle.curvature_pipeline(H.levels, [s.copy() for s in states], 0, bc, oc, 0, MultiFab, prog_min=300.0, prog_max=2000.0, omp=True)
+    for l in range(H.nlev):
+        assert_valid_bits_equal(outs["1"][l], og[l], [(c, c) for c in range(4)], f"{shape} grad level {l}")
+        assert_valid_bits_equal(outs["1"][l], oc[l], [(4, 2), (5, 3), (6, 4), (7, 1)], f"{shape} curv level {l}")

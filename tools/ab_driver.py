@@ -26,6 +26,9 @@ if box:
     H = nested_hierarchy(base, 3, box, is_per=(1, 1, 0))
 else:
     H = tagged_hierarchy(base, 3, lambda x, y, z: field_flame(x, y, z, 0), bf=16, max_box=128, base_box=128, frac=(0.08, 0.16), is_per=(1, 1, 0))
+if os.environ.get("PA_AB_RETILE", "0") == "1":  # swept on the internal tiling of the tools and bench.py
+    from peleanalysis_amd.hierarchy import retile_hierarchy  # noqa: E402
+    H = retile_hierarchy(H)
 bc = capi.bc_from_flags((1, 1, 0))
 ctx = capi.Context(0)
 dls = [capi.DevLevel(ctx, lv) for lv in H.levels]
