@@ -45,6 +45,29 @@ def _draw(seed):
 
 import os
 
+@pytest.fixture(autouse=True)
+def _free_device_objects(monkeypatch):
+    """every DevMF / DevLevel a test of this file makes is destroyed after it (the python wrappers have no finaliser): a hunt of a
+    thousand cases (PA_RANDOM_*_SEEDS) otherwise ends in `out of device memory` for a 3-MB multifab -- not the card's 288 GB, the
+    process's limit on separate allocations (profiles/r05_random_hunt.txt)"""
+    made = []
+    for cls in (capi.DevMF, capi.DevLevel):
+        orig = cls.__init__
+
+        def init(self, *a, _orig=orig, **k):
+            _orig(self, *a, **k)
+            made.append(self)
+
+        monkeypatch.setattr(cls, "__init__", init)
+    yield
+    for o in reversed(made):
+        if isinstance(o, capi.DevMF):
+            o.close()
+    for o in reversed(made):
+        if isinstance(o, capi.DevLevel):
+            o.close()
+
+
 NSEEDS = int(os.environ.get("PA_RANDOM_SEEDS", "16"))  # PA_RANDOM_SEEDS=200 for a longer hunt
 
 
