@@ -113,3 +113,80 @@ def test_device_memory_comes_back_when_levels_are_rebuilt_under_one_context():
     free6, _ = torch.cuda.mem_get_info(0)
     ctx.close()
     assert free2 - free6 <= 4 << 20, f"{(free2 - free6) / 2**20:.1f} MiB of device memory did not come back over four rebuilds of the levels under one context"
+
+
+def _sharded_worker(rank, world, port):
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import torch
+    import torch.distributed as dist
+    torch.cuda.init()  # torch first: one HIP runtime per process
+    from peleanalysis_amd import capi as cp
+    from peleanalysis_amd import dist as padist
+    from peleanalysis_amd.hierarchy import MultiFab as MF, field_flame as ff, nested_hierarchy as nh
+    from test_dist_gloo import scattered_owner
+    from util import make_states
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ctx = cp.Context(0)
+        comm = padist.GlooComm(ctx)
+        per = (1, 1, 0)
+        bc = cp.bc_from_flags(per)
+        used = []
+        for cycle in range(6):
+            H = nh(40, 3, 20, is_per=per)
+            owners = [scattered_owner(lv.nboxes, world, 31 + l + cycle) for l, lv in enumerate(H.levels)]  # another owner map every time: new plans
+            gst = make_states(H, 4, 2, ff, seed=5)
+            dls = [cp.DevLevel(ctx, lv, owners[l], rank, world) for l, lv in enumerate(H.levels)]
+            own = []
+            lst = []
+            for l, dl in enumerate(dls):
+                s = MF(dl.level, 4, 2, fill=0.0)
+                for i, g in enumerate(dl.gids):
+                    s.valid(i)[...] = gst[l].valid(int(g))
+                lst.append(cp.DevMF.from_host(ctx, dl, s))
+            own += lst
+            work = [cp.DevMF(ctx, dl, 1, 2) for dl in dls]
+            out8 = [cp.DevMF(ctx, dl, 8, 0) for dl in dls]
+            out18 = [cp.DevMF(ctx, dl, 18, 0) for dl in dls]
+            own += work + out8 + out18
+            cp.gradcurv_run(ctx, lst, 0, bc, cp.curv_params(fused=True), work, out8, 0)
+            cp.gradcurv_run(ctx, lst, 0, bc, cp.curv_params(fused=False), work, out8, 0)
+            for dt in (1e-4, 2e-2):  # the distributed smoothing solve, plain and multigrid-preconditioned, feeding the options
+                cp.curvature_run(ctx, lst, 0, bc, cp.curv_params(fused=True, do_smooth=True, smoothing_time=dt, do_gauss=True, do_strain=True, strain_tensor=True,
+                                                                do_velnormal=True, vel_comp=1), out18, 0)
+            ctx.sync()
+            assert ctx.bc_errors() == 0
+            for m in own:
+                m.close()
+            for dl in dls:
+                dl.close()
+            dist.barrier()
+            torch.cuda.synchronize()
+            dist.barrier()
+            free, total = torch.cuda.mem_get_info(0)
+            used.append((total - free) / 2**20)
+            dist.barrier()
+        if rank == 0:
+            assert used[-1] - used[2] <= 8.0, f"device memory in use after each rebuild of the sharded levels (MiB): {[round(u) for u in used]}"
+        dist.barrier()
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_device_memory_comes_back_when_sharded_levels_are_rebuilt():
+    """the same for a hierarchy sharded over two ranks that share the card (the transport's plans, coarse-source copies, restriction
+    plans and flux registers of the distributed smoothing solve live with the levels): six rebuilds with a different owner map each"""
+    import socket
+    torch = pytest.importorskip("torch")
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_sharded_worker, args=(2, port), nprocs=2, join=True)
