@@ -28,6 +28,7 @@
 //   * the threshold clip is a template parameter.
 // Results are bit-identical to k_gradcurv_march and to the CPU oracle.
 #pragma once
+#include "pa_dpp.h"
 #include <type_traits>
 #include "pa_fused_march.h"
 
@@ -421,14 +422,23 @@ __device__ __forceinline__ void gradcurv_march3_body(const BP& bp, const MarchAr
         double* hl = &S.h[p & 1][rr][0][0];
         double* hh = &S.h[p & 1][rr][1][0];
         const int xh = llast + 1 - xs;  // 0, 1, 2: the last three columns of the tile (lanes past the box edge mirror the last one)
-        if (ncgl) {  // (uniform)
-          if (xs <= 3) hl[xs - 1] = nxq;
-          if (xs == 1) { hl[3] = cty; hl[4] = ctz; }
+        // ONE 16-byte LDS store per side: the three lanes next to the face each write a pair, the values of the other lanes by DPP shifts
+        if (ncgl) {  // (uniform) lanes 0, 1, 2 = the first, second, third cell behind the low face
+          const double n2 = lane_from_right(nxq), tz1 = lane_from_left(ctz), ty2 = lane_from_left(lane_from_left(cty));
+          pa_d2 v;
+          v.x = lane == 1 ? tz1 : nxq;
+          v.y = lane == 0 ? n2 : (lane == 1 ? 0.0 : ty2);
+          if (lane <= 2) *(pa_d2*)&hl[lane == 0 ? 0 : (lane == 1 ? 4 : 2)] = v;
         }
-        if (ncgh) {
-          if (xh <= 2) hh[xh] = nxq;
-          if (xh == 0) { hh[3] = cty; hh[4] = ctz; }
+        if (ncgh) {  // lanes llast, llast - 1, llast - 2 = the first, second, third cell behind the high face
+          const double n2 = lane_from_left(nxq), tz1 = lane_from_right(ctz), ty2 = lane_from_right(lane_from_right(cty));
+          const int hk = llast - lane;  // 0, 1, 2
+          pa_d2 v;
+          v.x = hk == 1 ? tz1 : nxq;
+          v.y = hk == 0 ? n2 : (hk == 1 ? 0.0 : ty2);
+          if (hk >= 0 && hk <= 2) *(pa_d2*)&hh[hk == 0 ? 0 : (hk == 1 ? 4 : 2)] = v;
         }
+        (void)xh;
       }
       if (OLD_SCHED) __builtin_amdgcn_sched_barrier(0);
       if (OLD_SCHED) { if (PAIR) { PA_OPAQUE(lo16); store_pair(ob + 4 * osc, lo16, odd, o4, o5); } else PA_STL(ob + 5 * osc, lo8, o5); }
