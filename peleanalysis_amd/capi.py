@@ -277,6 +277,12 @@ class Context:
             self.lib.pa_ctx_destroy(self.h)
             self.h = None
 
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
 
 class DevBuf:
     """raw HBM buffer from pa_device_malloc (freed with the object)"""
@@ -331,9 +337,18 @@ class DevLevel:
             raise PaError(ctx.lib.pa_last_error(ctx.h).decode())
 
     def close(self):
+        """pa_level_destroy: the level's device arrays, cached plans and work multifabs.  There is NO finaliser: a level (and a multifab)
+        lives until close() -- or the end of a `with` block -- is reached; destroy the multifabs on a level before the level, the levels
+        before their context"""
         if self.h:
             self.ctx.lib.pa_level_destroy(self.h)
             self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
 
 class DevMF:
@@ -384,6 +399,12 @@ class DevMF:
         if self.h:
             self.ctx.lib.pa_mf_destroy(self.h)
             self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
 
 def box_of(level: Level, b: int, grow: int = 0) -> PaBox:
