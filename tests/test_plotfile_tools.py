@@ -63,6 +63,29 @@ def test_cpp_template_tool_roundtrip(tmp_path):
     assert out.returncode != 0 and "infile" in out.stderr
 
 
+def test_cpp_template_tool_large_level_with_and_without_huge_pages(tmp_path):
+    """a level big enough (80^3 x 3 components = 12 MB per multifab, 4 MB per FAB buffer) for the tools' host copies to take the 2-MiB-aligned,
+    MADV_HUGEPAGE blocks (tools/common/pa_plotfile.h DefaultInitAlloc; the other CPU-tier cases stay below its 4-MiB threshold):
+    template3d writes the same bytes with PA_HOST_THP=1 (default) and 0, re-tiled or not"""
+    _build_tools()
+    p, H, mfs = _synth(tmp_path, nlev=2, base=80, box=80)
+    outs = {}
+    for thp in ("1", "0"):
+        for retile in ("0", "1"):
+            out = subprocess.run([os.path.join(BIN, "template3d.ex"), "infile=" + p, "is_per=1 1 0", "retile=" + retile], cwd=tmp_path, capture_output=True,
+                                 text=True, env=dict(os.environ, PA_HOST_THP=thp))
+            assert out.returncode == 0, out.stderr
+            d = tmp_path / "plt00005_temp"
+            outs[(thp, retile)] = {os.path.relpath(os.path.join(r, f), d): open(os.path.join(r, f), "rb").read() for r, _, fs in os.walk(d) for f in fs}
+    ref = outs[("1", "0")]
+    assert len(ref) >= 5 and sum(len(v) for v in ref.values()) > 20_000_000
+    for k, v in outs.items():
+        assert v == ref, k
+    r = read_plotfile(str(tmp_path / "plt00005_temp"))
+    for l in range(2):
+        assert np.array_equal(r.mfs[l].data.view(np.int64), mfs[l].data.view(np.int64))
+
+
 def test_cpp_template_tool_retiled_io_is_byte_identical(tmp_path):
     """the host half of the tools' internal re-tiling without a GPU: template3d.ex retile=1 reads the file's FABs into merged boxes
     (pa_level_retile; small limits through PA_RETILE_MAX so that merged boxes span several file boxes AND file boxes span several
