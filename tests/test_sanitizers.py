@@ -97,6 +97,20 @@ def test_tool_host_paths_under_sanitizers(tmp_path):
         back = read_plotfile(str(tmp_path / "plt00001_temp"))
         for l in range(3):
             assert np.array_equal(back.mfs[l].data.view(np.int64), mfs[l].data.view(np.int64))
+    # a level large enough for the 2-MiB-aligned, MADV_HUGEPAGE blocks of the host copies (DefaultInitAlloc: posix_memalign / free) and the
+    # reader's / writer's FAB buffers on them
+    (tmp_path / "big").mkdir()
+    Hb = nested_hierarchy(72, 2, 72, is_per=(1, 1, 0))
+    mb = make_states(Hb, 3, 0, field_flame, seed=4)
+    pb = str(tmp_path / "big" / "plt00002")
+    write_plotfile(pb, Hb, mb, ["temp", "x_velocity", "density"], time=0.5, level_steps=[2, 2])
+    for retile in ("0", "1"):
+        out = subprocess.run([os.path.join(bin_asan, "template3d.ex"), "infile=" + pb, "is_per=1 1 0", "retile=" + retile], cwd=tmp_path / "big", capture_output=True,
+                             text=True, env=env)
+        assert out.returncode == 0, out.stderr[-3000:]
+        back = read_plotfile(str(tmp_path / "big" / "plt00002_temp"))
+        for l in range(2):
+            assert np.array_equal(back.mfs[l].data.view(np.int64), mb[l].data.view(np.int64))
     nodes = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]], float)
     faces = np.array([[1, 3, 2], [1, 2, 4], [2, 3, 4], [3, 1, 4]], np.int32)
     f = str(tmp_path / "tet.mef")
