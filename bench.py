@@ -710,6 +710,54 @@ def secondary(ctx, torch, stream, dev, only=None, retile=1):
 
     if want("f4_partstream"):
         stream_case()
+
+    def tools_case():
+        # the drop-in binaries end to end on a plotfile of config 3 / 4's size (3 levels, base 256^3, 64^3 boxes, 3 components: 1.2 GB), SECOND run of
+        # each in the same directory (tools/tool_e2e.py does this at the headline size: profiles/r05_tool_e2e_512.txt).  Bounded and guarded: whatever
+        # goes wrong here (no room in the scratch directory, a missing binary) is reported in the entry, the bench line itself is not at risk
+        import shutil
+        import tempfile
+        ent = {"workload": "grad3d / curvature3d / filterPlt3d / isosurface3d (tools/bin/*.ex) on a synthetic plotfile, 3 levels, base 256^3, 64^3 boxes, 3 components "
+                           "(temp, x_velocity, density), periodic x/y: wall seconds of the SECOND run of each tool (process start to exit) and the phases the tool reports"}
+        d = None
+        try:
+            from peleanalysis_amd.hierarchy import MultiFab, field_flame, fill_analytic
+            from peleanalysis_amd.plotfile import write_plotfile
+            bindir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "bin")
+            Ht = nested_hierarchy(256, 3, 64, is_per=(1, 1, 0))
+            names = ["temp", "x_velocity", "density"]
+            mfs = []
+            for lv in Ht.levels:
+                m = MultiFab(lv, 3, 0, fill=0.0)
+                for c in range(3):
+                    fill_analytic(m, c, (lambda x, y, z, c=c: field_flame(x, y, z, c)))
+                mfs.append(m)
+            d = tempfile.mkdtemp(dir=os.environ.get("TMPDIR", "/tmp"))
+            pth = os.path.join(d, "plt00000")
+            write_plotfile(pth, Ht, mfs, names, time=0.0, level_steps=[0, 0, 0])
+            del mfs
+            ent["cells"] = sum(lv.ncells for lv in Ht.levels)
+            runs = (("grad3d.ex", ["gradVar=temp", "is_per=1 1 0"]), ("curvature3d.ex", ["progressName=temp", "is_per=1 1 0"]),
+                    ("filterPlt3d.ex", ["is_per=1 1 0"]), ("isosurface3d.ex", ["isoCompName=temp", "isoVal=1150", "comps=0 1 2"]))
+            for tool, targs in runs:
+                wall, js = None, None
+                for rep in range(2):
+                    t0 = time.perf_counter()
+                    r = subprocess.run([os.path.join(bindir, tool), "infile=" + pth, "bench_json=1"] + targs, cwd=d, capture_output=True, text=True, timeout=120)
+                    wall = time.perf_counter() - t0
+                    if r.returncode != 0:
+                        raise RuntimeError(tool + ": " + r.stderr[-300:])
+                    js = [ln for ln in r.stdout.splitlines() if ln.startswith('{"tool"')]
+                ent[tool] = {"wall_s": round(wall, 3), "phases_s": (json.loads(js[-1]).get("phases_s") if js else None)}
+        except Exception as e:  # noqa: BLE001 -- reported, never fatal for the bench line
+            ent["error"] = repr(e)[:400]
+        finally:
+            if d:
+                shutil.rmtree(d, ignore_errors=True)
+        out["tools_end_to_end_base256"] = ent
+
+    if want("tools_end_to_end_base256"):
+        tools_case()
     return out
 
 
