@@ -55,12 +55,60 @@ def test_cpp_template_tool_roundtrip(tmp_path):
     # finestLevel clamps; a missing required key aborts with the ParmParse message
     out = subprocess.run([os.path.join(BIN, "template3d.ex"), "infile=" + p, "finestLevel=0"], cwd=tmp_path, capture_output=True, text=True)
     assert out.returncode == 0 and read_plotfile(str(tmp_path / "plt00005_temp")).hier.nlev == 1
-    # the second run over the first one's output: the old directory was moved away and removed (pa::OldOutput, as AMReX's
-    # UtilCreateCleanDirectory does) -- no levels of the three-level run survive, no '.old.<pid>' directory is left behind
+    # the second run over the first one's output: the old plotfile was renamed at WRITE time and kept, as AMReX's
+    # UtilCreateCleanDirectory does -- no level of the three-level run survives in the new one, the old one is whole
     assert sorted(os.listdir(tmp_path / "plt00005_temp")) == ["Header", "Level_0"]
-    assert not [f for f in os.listdir(tmp_path) if ".old." in f]
+    olds = [f for f in os.listdir(tmp_path) if ".old." in f]
+    assert len(olds) == 1 and sorted(os.listdir(tmp_path / olds[0])) == ["Header", "Level_0", "Level_1", "Level_2"]
+    # remove_old_output=1: the renamed directory goes away once the new plotfile is complete
+    out = subprocess.run([os.path.join(BIN, "template3d.ex"), "infile=" + p, "remove_old_output=1"], cwd=tmp_path, capture_output=True, text=True)
+    assert out.returncode == 0 and [f for f in os.listdir(tmp_path) if ".old." in f] == olds
+    assert read_plotfile(str(tmp_path / "plt00005_temp")).hier.nlev == 3
     out = subprocess.run([os.path.join(BIN, "template3d.ex"), "finestLevel=0"], cwd=tmp_path, capture_output=True, text=True)
     assert out.returncode != 0 and "infile" in out.stderr
+
+
+def test_old_output_is_only_touched_after_validation(tmp_path):
+    """Round-5 advisor finding on pa::OldOutput: (1) a run that aborts on its inputs (missing plotfile, bad Header) must leave an
+    earlier output exactly as it was; (2) an existing directory at the output path that is NOT a plotfile (no Header + Level_0)
+    is never renamed -- the tool writes into it."""
+    _build_tools()
+    p, H, mfs = _synth(tmp_path)
+    exe = os.path.join(BIN, "template3d.ex")
+    assert subprocess.run([exe, "infile=" + p], cwd=tmp_path, capture_output=True, text=True).returncode == 0
+    first = _tree_bytes(str(tmp_path / "plt00005_temp"))
+    # (1) same output name, input gone: abort, nothing renamed, nothing removed
+    bad = tmp_path / "elsewhere"
+    bad.mkdir()
+    os.symlink(tmp_path / "plt00005_temp", bad / "plt00005_temp")
+    out = subprocess.run([exe, "infile=" + str(bad / "plt00005")], cwd=bad, capture_output=True, text=True)
+    assert out.returncode != 0 and "Unable to open plotfile Header" in out.stderr
+    assert _tree_bytes(str(tmp_path / "plt00005_temp")) == first
+    assert not [f for f in os.listdir(tmp_path) + os.listdir(bad) if ".old." in f]
+    # a Header that does not parse (2-D file handed to the 3-D build)
+    hdr = open(os.path.join(p, "Header")).read().split("\n")
+    p2 = tmp_path / "plt2d"
+    os.makedirs(p2)
+    hdr[2 + 3] = "2"  # HyperCLaw-V1.1, ncomp, 3 names, then the dimension
+    (p2 / "Header").write_text("\n".join(hdr))
+    (tmp_path / "plt2d_temp").mkdir()
+    (tmp_path / "plt2d_temp" / "Header").write_text("an earlier output")
+    (tmp_path / "plt2d_temp" / "Level_0").mkdir()
+    out = subprocess.run([exe, "infile=" + str(p2)], cwd=tmp_path, capture_output=True, text=True)
+    assert out.returncode != 0
+    assert (tmp_path / "plt2d_temp" / "Header").read_text() == "an earlier output" and not [f for f in os.listdir(tmp_path) if ".old." in f]
+    # (2) a directory that is not a plotfile: written into, never renamed
+    d = tmp_path / "notplt"
+    d.mkdir()
+    os.symlink(p, d / "plt00005")
+    (d / "plt00005_temp").mkdir()
+    (d / "plt00005_temp" / "my_notes.txt").write_text("keep me")
+    out = subprocess.run([exe, "infile=plt00005"], cwd=d, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert (d / "plt00005_temp" / "my_notes.txt").read_text() == "keep me" and not [f for f in os.listdir(d) if ".old." in f]
+    got = _tree_bytes(str(d / "plt00005_temp"))
+    got.pop("my_notes.txt")
+    assert got == first
 
 
 def test_cpp_template_tool_large_level_with_and_without_huge_pages(tmp_path):
@@ -1082,9 +1130,11 @@ def test_tools_retiled_outputs_are_byte_identical(tmp_path, tool, args, suffix):
     ("filterPlt3d.ex", ["max_grid_size=8", "is_per=1 1 0"], "_filtered"),
 ])
 def test_tools_run_again_over_their_own_output(tmp_path, tool, args, suffix):
-    """A tool run a second time in the same directory (AMReX: UtilCreateCleanDirectory moves the old plotfile away): the old
-    output directory is renamed and removed on a helper thread (pa::OldOutput) -- the second run's files must be the first
-    run's bytes, stale files of the old directory must be gone and no '.old.<pid>' directory may survive the process."""
+    """A tool run a second time in the same directory: as AMReX's UtilCreateCleanDirectory does inside WriteMultiLevelPlotfile
+    (grad.cpp:256, curvature.cpp:843, filterPlt.cpp:52), the old plotfile is renamed to <name>.old.<unique> at write time and
+    KEPT (pa::OldOutput) -- the second run's files are the first run's bytes, stale files of the old directory are not in the new
+    one, the renamed directory is whole; remove_old_output=1 removes it once the new plotfile is complete; a run that aborts on its
+    inputs touches nothing; an output path that contains the input aborts before anything is renamed."""
     p, H, mfs = _synth(tmp_path, nlev=3, base=16, box=8, ncomp=3)
     d = tmp_path / "run"
     d.mkdir()
@@ -1095,7 +1145,20 @@ def test_tools_run_again_over_their_own_output(tmp_path, tool, args, suffix):
     (outdir / "stale_file_of_the_first_run").write_bytes(b"x" * 100)
     _run(tool, ["infile=" + p] + args, d)
     assert _tree_bytes(str(outdir)) == first
-    assert not [f for f in os.listdir(outdir.parent) if ".old." in f]
+    olds = [f for f in os.listdir(d) if ".old." in f]
+    kept = _tree_bytes(str(d / olds[0]))
+    assert len(olds) == 1 and kept.pop("stale_file_of_the_first_run") == b"x" * 100 and kept == first
+    _run(tool, ["infile=" + p] + args + ["remove_old_output=1"], d)
+    assert _tree_bytes(str(outdir)) == first and [f for f in os.listdir(d) if ".old." in f] == olds
+    # an unknown variable aborts after the Header is read: the output of the earlier run stays as it is
+    bad = {"grad3d.ex": "gradVar=nope", "curvature3d.ex": "progressName=nope", "filterPlt3d.ex": "variables=nope"}[tool]
+    out = subprocess.run([os.path.join(BIN, tool), "infile=" + p] + args + [bad], cwd=d, capture_output=True, text=True)
+    assert out.returncode != 0
+    assert _tree_bytes(str(outdir)) == first and [f for f in os.listdir(d) if ".old." in f] == olds
+    if tool != "filterPlt3d.ex":  # outfile= is a key of grad / curvature only
+        out = subprocess.run([os.path.join(BIN, tool), "infile=" + p] + args + ["outfile=" + str(tmp_path)], cwd=d, capture_output=True, text=True)
+        assert out.returncode != 0 and "contains the input plotfile" in out.stderr
+        assert os.path.isdir(p) and _tree_bytes(str(outdir)) == first and not [f for f in os.listdir(tmp_path.parent) if ".old." in f]
 
 
 @pytest.mark.gpu

@@ -7,6 +7,7 @@
 #pragma once
 #include <fcntl.h>
 #include <ftw.h>
+#include <limits.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -616,25 +617,47 @@ inline std::vector<Box3> max_size(const std::vector<Box3>& in, int n) {
   return out;
 }
 
-// An output plotfile that already exists (a tool run again on the same input): AMReX's UtilCreateCleanDirectory moves the old
-// directory out of the way before WriteMultiLevelPlotfile creates the new one.  Here the old directory is renamed at once and
-// REMOVED on a helper thread while the tool reads and computes: writing over the old files made the kernel drop their cached pages
-// inside the timed write (16 GB at 3.7 GB/s against ~7 GB/s into a fresh directory, profiles/r04_small_experiments.txt) -- the
-// user-visible cost of re-running a tool.  finish() before the process exits.
+// An output plotfile that already exists (a tool run again on the same input): AMReX's UtilCreateCleanDirectory -- called by
+// WriteMultiLevelPlotfile at WRITE time (grad.cpp:256, curvature.cpp:843, filterPlt.cpp:52) -- renames the old directory to
+// <path>.old.<unique> and KEEPS it.  Same here: move_away() is called once the header, the variables and the parameters are
+// validated, immediately before the first byte is written; the old directory is renamed (writing over the old files made the
+// kernel drop their cached pages inside the timed write: 16 GB at 3.7 GB/s against ~12 GB/s into a fresh directory,
+// profiles/r05_tool_e2e_512.txt) and kept.  remove_old_output=1 removes it -- in finish(), i.e. only after the new plotfile is
+// completely written, so a run that aborts in between leaves the old output intact under its .old name.
+// Guards (round-5 advisor): only a PLOTFILE directory (Header + Level_0) is ever renamed -- any other existing directory is
+// written into as it is -- and an output path that is the input or contains it aborts before anything is touched.
 struct OldOutput {
-  std::thread th;
+  std::string old;
+  bool remove_after = false;
   static int rm_entry(const char* p, const struct stat*, int, struct FTW*) { return ::remove(p); }
-  // input: the plotfile the tool is about to read -- an output path that IS the input (outfile=<infile>) is left alone
-  void move_away(const std::string& path, const std::string& input = std::string()) {
-    struct stat st, si;
-    if (::stat(path.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) return;
-    if (!input.empty() && ::stat(input.c_str(), &si) == 0 && si.st_dev == st.st_dev && si.st_ino == st.st_ino) return;
-    const std::string old = path + ".old." + std::to_string((long)::getpid());
-    if (::rename(path.c_str(), old.c_str()) != 0) return;  // left in place: the writer truncates the files as before
-    th = std::thread([old] { ::nftw(old.c_str(), rm_entry, 64, FTW_DEPTH | FTW_PHYS); });
+  static bool is_plotfile_dir(const std::string& path) {
+    struct stat st;
+    if (::stat((path + "/Header").c_str(), &st) != 0 || !S_ISREG(st.st_mode)) return false;
+    return ::stat((path + "/Level_0").c_str(), &st) == 0 && S_ISDIR(st.st_mode);
   }
-  void finish() { if (th.joinable()) th.join(); }
-  ~OldOutput() { finish(); }
+  // input: the plotfile the tool has read its header from
+  void move_away(const std::string& path, const std::string& input, const ParmParse& pp) {
+    int rm = 0;
+    pp.query("remove_old_output", rm);
+    remove_after = rm != 0;
+    struct stat st;
+    if (::stat(path.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) return;
+    char rp[PATH_MAX], ri[PATH_MAX];
+    if (!input.empty() && ::realpath(path.c_str(), rp) && ::realpath(input.c_str(), ri)) {
+      const std::string P(rp), I(ri);
+      if (I == P) return;  // outfile=<infile>: written over in place, the data are in memory by then
+      if (I.size() > P.size() && I.compare(0, P.size(), P) == 0 && I[P.size()] == '/')
+        Abort("the output path " + path + " contains the input plotfile " + input);
+    }
+    if (!is_plotfile_dir(path)) return;  // not something this tool (or the reference) wrote: left alone
+    old = path + ".old." + std::to_string((long)::getpid());
+    if (::rename(path.c_str(), old.c_str()) != 0) old.clear();  // left in place: the writer truncates the files
+  }
+  // the new plotfile is complete
+  void finish() {
+    if (remove_after && !old.empty()) ::nftw(old.c_str(), rm_entry, 64, FTW_DEPTH | FTW_PHYS);
+    old.clear();
+  }
 };
 
 // Levels handed from the thread that downloads them to the thread that writes them: the writer starts on level l as soon as it is

@@ -38,8 +38,6 @@ int main(int argc, char** argv) {
   pp.get("infile", infile);
   std::string outfile = pa::getFileRoot(infile) + "_K";
   pp.query("outfile", outfile);
-  pa::OldOutput old_out;
-  old_out.move_away(outfile, infile);  // an earlier run's output goes away while this one reads and computes
   pp.query("finestLevel", finestLevel);
   pp.query("do_gaussCurv", do_gaussCurv);
   pp.query("progressName", progressName);
@@ -180,6 +178,8 @@ int main(int argc, char** argv) {
   pa::LevelGate gate;
   const std::function<void(int)> wait_level = [&](int l) { gate.wait(l); };
   const bool overlap_write = team.n == 1;
+  pa::OldOutput old_out;
+  old_out.move_away(outfile, infile, pp);  // UtilCreateCleanDirectory: header, variables and parameters are validated, the data are read
   std::thread writer;
   if (overlap_write) {
     std::cout << "Writing new data to " << outfile << "\n";

@@ -61,8 +61,6 @@ int main(int argc, char** argv) {
   if (!pp.queryarr("is_per", is_per, 0, 3)) pp.queryarr("geometry.is_periodic", is_per, 0, 3);
 #endif
   pa::PhaseTimer tm(pp, PA_SPACEDIM == 2 ? "filterPlt2d" : "filterPlt3d");
-  pa::OldOutput old_out;
-  old_out.move_away(pa::getFileRoot(infile) + "_filtered", infile);  // an earlier run's output goes away while this one reads and computes
   pa::PlotfileHeader H = pa::read_header(infile, PA_SPACEDIM, /* any_ratio: filterPlt.cpp:133,200 take the file's */ true);
   const int Nlev = std::min(finestLevel + 1, H.nlev);
   std::vector<std::string> names;
@@ -193,6 +191,8 @@ int main(int argc, char** argv) {
   std::cout << "Done!" << std::endl << "Saving filtered data..." << std::endl;
   tm.mark("download");
   std::vector<int> steps(Nlev, 0);
+  pa::OldOutput old_out;
+  old_out.move_away(pa::getFileRoot(infile) + "_filtered", infile, pp);  // UtilCreateCleanDirectory at write time (filterPlt.cpp:52)
   pa::write_plotfile(pa::getFileRoot(infile) + "_filtered", names, doms, H.prob_lo, H.prob_hi, out, H.time, steps, 2, PA_SPACEDIM, nullptr, pa::boxes_if_retiled(chopped, tile));
   tm.mark("write");
   old_out.finish();

@@ -33,8 +33,6 @@ int main(int argc, char** argv) {
   pa::PhaseTimer tm(pp, PA_SPACEDIM == 2 ? "grad2d" : "grad3d");
   std::string outfile = pa::getFileRoot(infile) + "_gt";
   pp.query("outfile", outfile);
-  pa::OldOutput old_out;
-  old_out.move_away(outfile, infile);  // an earlier run's output goes away while this one reads and computes
   pa::PlotfileHeader H = pa::read_header(infile, PA_SPACEDIM);
   finestLevel = std::min(finestLevel, H.nlev - 1);
   const int Nlev = finestLevel + 1;
@@ -106,6 +104,8 @@ int main(int argc, char** argv) {
   pa::LevelGate gate;
   const std::function<void(int)> wait_level = [&](int l) { gate.wait(l); };
   const bool overlap_write = team.n == 1;
+  pa::OldOutput old_out;
+  old_out.move_away(outfile, infile, pp);  // UtilCreateCleanDirectory: header, variables and parameters are validated, the data are read
   std::thread writer;
   if (overlap_write) {
     std::cout << "Writing new data to " << outfile << std::endl;

@@ -40,7 +40,7 @@ int main(int argc, char** argv) {
   }
   const std::string outfile = pa::getFileRoot(infile) + "_temp";
   pa::OldOutput old_out;
-  old_out.move_away(outfile, infile);  // UtilCreateCleanDirectory: an earlier run's plotfile (levels this run does not write included) goes away
+  old_out.move_away(outfile, infile, pp);  // UtilCreateCleanDirectory: an earlier run's plotfile (levels this run does not write included) is renamed
   std::cout << "Writing new data to " << outfile << std::endl;
   pa::write_plotfile(outfile, H.names, doms, H.prob_lo, H.prob_hi, out, 0.0, steps, 2, 3, nullptr, pa::boxes_if_retiled(fileBoxes, tile));
   old_out.finish();

@@ -38,6 +38,9 @@ for tool, args in runs:
         out = subprocess.run([os.path.join(bindir, tool), "infile=" + p, "bench_json=1"] + args, cwd=d, capture_output=True, text=True)
         dt = time.perf_counter() - t0
         assert out.returncode == 0, out.stderr[-500:]
+    for f in os.listdir(d):  # the first run's output, renamed and kept by the second one as UtilCreateCleanDirectory does: tidy up outside the timing
+        if ".old." in f:
+            subprocess.run(["rm", "-rf", os.path.join(d, f)])
     js = [ln for ln in out.stdout.splitlines() if ln.startswith('{"tool"')]
     if smooth:
         print("   ", "; ".join(ln for ln in (out.stdout + out.stderr).splitlines() if "mooth" in ln or "iteration" in ln), flush=True)
