@@ -761,6 +761,46 @@ def secondary(ctx, torch, stream, dev, only=None, retile=1):
     return out
 
 
+def dry_run(args, rank, world):
+    """PA_BENCH_REHEARSE=dry (see main): what the driver's multi-GPU command does before any rank touches its card -- the
+    launcher's environment, the gloo rendezvous, the hierarchy, the internal tiling per rank count and the shard every rank
+    would build, one collective of each kind the control plane uses -- without a GPU.  Not a measurement."""
+    import torch.distributed as dist
+    from peleanalysis_amd import dist as padist
+    from peleanalysis_amd.hierarchy import nested_hierarchy, retile_hierarchy
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    per = tuple(int(v) for v in args.per.split())
+    Hfile = nested_hierarchy(args.base, args.nlev, args.box, is_per=per)
+    H = retile_hierarchy(Hfile, nranks=world) if args.retile else Hfile
+    owners = padist.shard(H, world) if world > 1 else [np.zeros(lv.nboxes, dtype=np.int32) for lv in H.levels]
+    mine = [int((np.asarray(o) == rank).sum()) for o in owners]
+    cells_mine = 0
+    for lv, o in zip(H.levels, owners):
+        bx = lv.boxes[np.asarray(o) == rank].astype(np.int64)
+        cells_mine += int((bx[:, 3:] - bx[:, :3] + 1).prod(axis=1).sum())
+    got = [None] * world
+    if world > 1:
+        import torch
+        dist.all_gather_object(got, {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "boxes": mine, "cells": cells_mine})
+        t = torch.tensor([float(rank)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        assert int(t.item()) == world - 1
+        dist.barrier()
+    else:
+        got = [{"rank": 0, "local_rank": 0, "boxes": mine, "cells": cells_mine}]
+    if rank == 0:
+        cells = sum(lv.ncells for lv in H.levels)
+        assert sorted(g["rank"] for g in got) == list(range(world)) and sum(g["cells"] for g in got) == cells
+        print(json.dumps({"dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "cells": cells,
+                          "swept_boxes_per_level": [lv.nboxes for lv in H.levels], "boxes_per_level_by_rank": [g["boxes"] for g in sorted(got, key=lambda g: g["rank"])],
+                          "cells_by_rank": [g["cells"] for g in sorted(got, key=lambda g: g["rank"])],
+                          "note": "PA_BENCH_REHEARSE=dry: launcher / rendezvous / sharding plumbing only, no GPU, not a measurement"}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -812,12 +852,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (the product path has no CPU fallback)")
     # PA_BENCH_REHEARSE=1: rehearsal of the N > 1 code path on a box with FEWER GPUs than ranks -- ranks share the cards,
     # transport is the pa_comm callback over gloo through host memory (RCCL wants one GPU per rank).  Same sharding, same
     # region plans, same pack / unpack kernels, same reductions; the number it prints is not a scaling measurement.
-    rehearse = os.environ.get("PA_BENCH_REHEARSE", "0") == "1"
+    # PA_BENCH_REHEARSE=rccl: the same, but the RCCL bring-up is ATTEMPTED first (it cannot succeed with two ranks on one card):
+    # rehearses the degradation to the gloo transport -- by error or, with a small PA_RCCL_TIMEOUT, by time limit.
+    # PA_BENCH_REHEARSE=dry: no GPU at all -- launcher, rendezvous, argument plumbing, the hierarchy / re-tiling / sharding every
+    # rank would build and the collectives of the control plane, for any N (the CPU tier runs it with N = 8); prints a
+    # {"dry_run": true, ...} line that is not a measurement of anything.
+    rehearse_mode = os.environ.get("PA_BENCH_REHEARSE", "0")
+    if rehearse_mode == "dry":
+        return dry_run(args, rank, world)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (the product path has no CPU fallback)")
+    rehearse = rehearse_mode in ("1", "rccl")
+    try_rccl = rehearse_mode in ("0", "rccl")
     if rehearse:
         local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
@@ -866,6 +915,7 @@ def main():
     bc = capi.bc_from_flags(per)
     xch = {"mode": "none"}
     gcomm = None
+    helper = None
     if args.sim_of:  # one rank's share of an N-rank run on this GPU, exchanges replaced by no-ops: compute time per rank
         if args.xdelay_us >= 0:
             ctx.check(ctx.lib.pa_ctx_set_delay_comm(ctx.h, nshard, 0, float(args.xdelay_us), float(args.xlink_GBs)))
@@ -879,7 +929,10 @@ def main():
             xch["mode"] = f"SIMULATION of rank 0 of {nshard}: exchanges are no-ops (results wrong in ghost cells, timing = compute only)"
     elif world > 1:
         err = ""
-        if not rehearse:
+        helper = None
+        if not try_rccl:
+            err = "PA_BENCH_REHEARSE=1: ranks share the cards, RCCL not attempted"
+        else:
             # built-in transport: grouped ncclSend / ncclRecv on the library's stream; a ring exchange + a reduction with known
             # answers before it is trusted.  Bring-up runs on a helper thread under a time limit: a communicator that never
             # forms (ncclCommInitRank blocks until every rank has joined) must degrade to the gloo transport, not eat the run.
@@ -906,6 +959,7 @@ def main():
             th = threading.Thread(target=bring_up, daemon=True)
             th.start()
             th.join(limit)
+            helper = th
             if th.is_alive():
                 err = f"RCCL bring-up did not finish within {limit:.0f} s (ncclCommInitRank / self-test)"
                 # the helper may still be inside the library with this context: leave it behind, continue on a fresh one
@@ -914,10 +968,10 @@ def main():
                 err = box.get("err", "")
         ok = [None] * world
         dist.all_gather_object(ok, err)
-        if rehearse or any(ok):
+        if any(ok):
             gcomm = padist.GlooComm(ctx)    # pa_comm callbacks: packed buffers staged through host memory + gloo
             ctx.comm_selftest(1 << 12)
-            xch["mode"] = "host-staged gloo point-to-point (pa_comm callbacks)" + ("" if rehearse else " -- RCCL transport failed: " + next(e for e in ok if e))
+            xch["mode"] = "host-staged gloo point-to-point (pa_comm callbacks)" + ("" if not try_rccl else " -- RCCL transport failed: " + next(e for e in ok if e))
         else:
             xch["mode"] = "RCCL point-to-point (grouped ncclSend/ncclRecv issued by the library on its stream): exchange A (ghost cells of phi + coarse phi, all components) once per step, exchange B (coarse normals) once per batch of components"
     dls = [capi.DevLevel(ctx, lv, owners[l], myrank, nshard) if nshard > 1 else capi.DevLevel(ctx, lv) for l, lv in enumerate(H.levels)]
@@ -1085,10 +1139,16 @@ def main():
             except Exception as e:
                 res["parity_check"] = {"error": repr(e)[:300]}
     if rank == 0:
-        print(json.dumps(res))
+        print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+        if helper is not None and helper.is_alive():
+            # an RCCL bring-up that never returned is still inside the library on its abandoned context: no interpreter / runtime
+            # teardown under it -- the line is out, leave at once
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(0)
 
 
 if __name__ == "__main__":

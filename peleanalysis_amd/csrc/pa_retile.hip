@@ -267,19 +267,21 @@ extern "C" int pa_hierarchy_retile_limits(int nlev, const int32_t* nboxes, const
 // balance worse over the ranks and leave the sweep's per-XCD queues short: rank 0's share of the headline hierarchy, ms per pass
 // with 32-us exchanges, 256^3 / 256 x 256 x 128 / 128^3 boxes: 2 ranks 3.38 / 3.56 / 3.59, 4 ranks 2.21 / 1.94 / 2.00, 8 ranks
 // 1.31 / 1.16 / 1.06; profiles/r05_sim8_delay.txt).  The largest of 512 x 256 x 256 and those three tilings that leaves >= 4 nranks
-// boxes on every level, and 128^3 wherever the one-rank choice is 128^3.
+// boxes on every level (or as many as the file has), starting at 128^3 wherever the one-rank choice is 128^3.
 extern "C" int pa_hierarchy_retile_limits_ranks(int nlev, const int32_t* nboxes, const int32_t* const* boxes6, int min_thick, int nranks, int32_t max_size[3]) {
   if (pa_hierarchy_retile_limits(nlev, nboxes, boxes6, min_thick, max_size) != 0) return -1;
-  if (nranks <= 1 || getenv("PA_RETILE_MAX") || max_size[0] <= 128) return 0;
-  const int32_t cand[4][3] = {{512, 256, 256}, {256, 256, 256}, {256, 256, 128}, {128, 128, 128}};
-  for (int c = 0; c < 4; ++c) {
+  if (nranks <= 1 || getenv("PA_RETILE_MAX")) return 0;
+  // round 6: 64^3 and 32^3 after 128^3 -- a small hierarchy on many ranks (base 64 on 8: one merged box per level, seven ranks
+  // idle) keeps boxes for every rank; a level never needs more boxes than the file gave it
+  const int32_t cand[6][3] = {{512, 256, 256}, {256, 256, 256}, {256, 256, 128}, {128, 128, 128}, {64, 64, 64}, {32, 32, 32}};
+  for (int c = max_size[0] <= 128 ? 3 : 0; c < 6; ++c) {
     bool ok = true;
     for (int l = 0; l < nlev && ok; ++l) {
       if (nboxes[l] <= 0) continue;
       const int cap = 4 * nboxes[l] + 16;
       std::vector<int32_t> out((size_t)cap * 6);
       const int n = pa_level_retile(nboxes[l], boxes6[l], cand[c], min_thick, out.data(), cap);
-      ok = n >= 4 * nranks || c == 3;
+      ok = n >= std::min(4 * nranks, (int)nboxes[l]) || c == 5;
     }
     if (ok) {
       for (int d = 0; d < 3; ++d) max_size[d] = cand[c][d];
