@@ -122,3 +122,26 @@ def test_hip_reproduces_filter_fixture(ctx, filter_mode):
                 assert _same(got.valid(b)[0], d[f"out{l}"][b])
             else:  # separable default: SURVEY 8(d) metric
                 assert float(np.abs(got.valid(b)[0] - d[f"out{l}"][b]).max()) <= 1e-12 * scale
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("merge", ["device", "host"])
+def test_hip_reproduces_iso_fixture(tmp_path, merge):
+    """isosurface.cpp:1434-1728 + 1657-1726 on the HIP path against the committed fixture, no live oracle: the fixture's two
+    components go into a plotfile, the drop-in binary (state build, pa_mc_hierarchy_*, node / element sets on the device or --
+    PA_ISO_HOST_MERGE=1 -- the sequential host merge) writes its MEF; nodes bit for bit, elements identical (1-based in the file)."""
+    import subprocess
+    from peleanalysis_amd.plotfile import read_mef, write_plotfile
+    d, H = _load("iso_amr2.npz")
+    mfs = [_mf_from(lv, d[f"in{l}"], 0) for l, lv in enumerate(H.levels)]
+    p = str(tmp_path / "plt00007")
+    write_plotfile(p, H, mfs, ["temp", "x_velocity"], time=0.5, level_steps=[7] * H.nlev)
+    exe = os.path.join(os.path.dirname(GOLD), "..", "tools", "bin", "isosurface3d.ex")
+    env = dict(os.environ, PA_ISO_HOST_MERGE="1") if merge == "host" else None
+    out = subprocess.run([exe, "infile=" + p, "isoCompName=temp", "isoVal=%r" % float(d["isoval"]), "comps=0 1", "outfile_base=" + str(tmp_path / "surf")],
+                         cwd=tmp_path, capture_output=True, text=True, env=env)
+    assert out.returncode == 0, out.stderr
+    _, names, nodes, faces = read_mef(str(tmp_path / "surf.mef"))
+    assert names == ["X", "Y", "Z", "temp", "x_velocity"]
+    assert _same(nodes, d["nodes"]), "node data not bit-identical to the fixture"
+    assert np.array_equal(faces, d["elts"] + 1), "connectivity differs from the fixture"
