@@ -130,11 +130,29 @@ def test_curvature_run_with_smoothing(ctx, oracle, per, sym):
             dk = np.abs(gv[1] - wv[1])
             kb = 0.5 * S1 * nb + 1e-13 * max(1.0, float(np.abs(wv[1]).max()))
             assert np.all(dk[okk] <= kb[okk]), (l, b, float((dk[okk] / kb[okk]).max()))
-            # every other cell (box faces: ghost data with its own coarse-fine weights; nearly flat profile): the loose sanity bound
-            for c in (1, 2, 3, 4):
-                scale = max(np.abs(wv[c]).max(), 1.0)
-                strong = np.abs(wv[17] - 0.5) < 0.45
-                assert np.abs((gv[c] - wv[c]) * strong).max() <= 1e-5 * scale, (l, b, c)
+    # EVERY cell (box faces with their coarse-fine / wall ghost data, the flat parts of the profile), without a tolerance: the
+    # downstream fields are a function f of the smoothed field, and f on the HIP path is the reference's f BIT FOR BIT -- the ORACLE's
+    # smoothed field handed to the HIP pipeline as a progress variable of range [0, 1] ((c - 0.0) * 1.0 = c exactly) gives the
+    # oracle's normals and curvature in every cell.  What separates the two runs above is therefore the solve's eps alone
+    # (<= 1e-12, iterative on both sides -- MLMG's in the reference), amplified by the conditioning of f: the bounds above.
+    sm = []
+    for l, lv in enumerate(H.levels):
+        m = MultiFab(lv, 1, 2)
+        for b in range(lv.nboxes):
+            m.valid(b)[0] = oout[l].valid(b)[17]
+        sm.append(m)
+    dsm = [capi.DevMF.from_host(ctx, dl, m) for dl, m in zip(dls, sm)]
+    for fused in (False, True):
+        o = [capi.DevMF(ctx, dl, 18, 0) for dl in dls]
+        capi.curvature_run(ctx, dsm, 0, bc, capi.curv_params(prog_min=0.0, prog_max=1.0, fused=fused), o, 0)
+        ctx.sync()
+        for l, lv in enumerate(H.levels):
+            g = o[l].download()
+            for b in range(lv.nboxes):
+                gv, wv = g.valid(b), oout[l].valid(b)
+                assert np.array_equal(gv[0].view(np.int64), wv[17].view(np.int64))
+                for c in (1, 2, 3, 4):
+                    assert np.array_equal(gv[c].view(np.int64), wv[c].view(np.int64)), f"f(oracle's smoothed field), fused={fused}: level {l} box {b} comp {c}"
 
 
 def _hier2d(per):
