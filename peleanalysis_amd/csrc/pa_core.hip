@@ -221,6 +221,28 @@ __global__ __launch_bounds__(256) void k_build_sfcode(DLevelView L, unsigned sho
   code[L.sfoff[blockIdx.y] + t] = (unsigned short)cf_masks(L, q, dir, 2);
 }
 
+// flags of the chunk records (SfChunk): one workgroup per chunk, thread = 2 x 2 block as in the kernels that use them
+__global__ __launch_bounds__(256) void k_sfchunk_flags(DLevelView L, SfChunk* ck) {
+  SfChunk& D = ck[blockIdx.x];
+  const int dir = D.dir_side >> 1, t0 = dir == 0 ? 1 : 0, t1 = dir == 2 ? 1 : 2;
+  const int n0 = D.hi[t0] - D.lo[t0] + 1, n1 = D.hi[t1] - D.lo[t1] + 1;
+  const int hw = D.cw >> 1, bu = (int)threadIdx.x % hw, bv = (int)threadIdx.x / hw;
+  bool full = true, wall = true;
+  for (int dv = 0; dv < 2; ++dv)
+    for (int du = 0; du < 2; ++du) {
+      const int u = D.u0 + 2 * bu + du, v = D.v0 + 2 * bv + dv;
+      if (u >= n0 || v >= n1) continue;
+      const unsigned code = L.sfcode[D.sfoff + (long long)v * n0 + u];
+      full = full && code == PA_CODE_FULL;
+      wall = wall && (code & 3u) == 2u;
+    }
+  const int afull = __syncthreads_and(full ? 1 : 0), awall = __syncthreads_and(wall ? 1 : 0);
+  if (threadIdx.x == 0) {
+    const bool even = !((D.lo[t0] | D.lo[t1] | n0 | n1 | D.u0 | D.v0) & 1);
+    D.flags = (afull && even && D.cpoff >= 0 ? PA_SFC_FULL : 0) | (awall && even ? PA_SFC_WALL : 0);
+  }
+}
+
 // Everything a level is made from.  Unsharded: gboxes empty, every box local.  Sharded: `local` are the global boxes
 // owned by `rank` (global order, gid = their global indices), the other global boxes only mark their cells as valid
 // cells of the level (owner-map entry -2 - g).
@@ -481,6 +503,34 @@ pa_level* pa_level_create_spec(pa_ctx* ctx, const LevelSpec& S, const int32_t do
       delete L;
       return nullptr;
     }
+    {  // chunk records (SfChunk): rectangles of cw x ch = 1024 ghost cells, cw = the power of two that covers the face's rows (32 .. 512)
+      std::vector<SfChunk> ck;
+      for (size_t e = 0; e < L->sfaces.size(); ++e) {
+        const int f = L->sfaces[e];
+        const DBox& B = L->boxes[f / 6];
+        const int d = (f % 6) >> 1, t0 = (d == 0) ? 1 : 0, t1 = (d == 2) ? 1 : 2;
+        const int n0 = B.hi[t0] - B.lo[t0] + 1, n1 = B.hi[t1] - B.lo[t1] + 1;
+        int cw = 32;
+        while (cw < 512 && cw < n0) cw *= 2;
+        const int ch = 1024 / cw;
+        for (int v0 = 0; v0 < n1; v0 += ch)
+          for (int u0 = 0; u0 < n0; u0 += cw) {
+            SfChunk D;
+            D.face = (int)e; D.box = f / 6; D.dir_side = f % 6; D.flags = 0;
+            for (int q = 0; q < 3; ++q) { D.lo[q] = B.lo[q]; D.hi[q] = B.hi[q]; }
+            D.u0 = u0; D.v0 = v0; D.cw = cw; D.ch = ch;
+            D.sfoff = sfoff[e]; D.cgoff = L->cgoff[e]; D.cpoff = cpoff[e];
+            ck.push_back(D);
+          }
+      }
+      L->nsfchunk = (int)ck.size();
+      if (L->nsfchunk > 0 && (hipMalloc(&L->d_sfchunk, sizeof(SfChunk) * ck.size()) != hipSuccess ||
+                              hipMemcpy(L->d_sfchunk, ck.data(), sizeof(SfChunk) * ck.size(), hipMemcpyHostToDevice) != hipSuccess)) {
+        pa_fail(ctx, "pa_level_create: device allocation failed");
+        delete L;
+        return nullptr;
+      }
+    }
     L->nsfwg = (int)(wg.size() / 2);
     if (L->nsfwg > 0 && (hipMalloc(&L->d_sfwg, sizeof(int) * wg.size()) != hipSuccess ||
                          hipMemcpy(L->d_sfwg, wg.data(), sizeof(int) * wg.size(), hipMemcpyHostToDevice) != hipSuccess)) {
@@ -539,6 +589,7 @@ pa_level* pa_level_create_spec(pa_ctx* ctx, const LevelSpec& S, const int32_t do
     const long long n0 = L->maxn[0], n1 = L->maxn[1], n2 = L->maxn[2];
     const long long nt = std::max(n1 * n2, std::max(n0 * n2, n0 * n1));
     hipLaunchKernelGGL(k_build_sfcode, dim3((unsigned)((nt + 255) / 256), (unsigned)L->sfaces.size()), dim3(256), 0, ctx->stream, V, L->d_sfcode);
+    if (L->nsfchunk > 0) hipLaunchKernelGGL(k_sfchunk_flags, dim3((unsigned)L->nsfchunk), dim3(256), 0, ctx->stream, V, L->d_sfchunk);
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
       pa_fail(ctx, "pa_level_create: building the boundary masks failed");
       pa_level_destroy(L);
@@ -564,6 +615,7 @@ extern "C" void pa_level_destroy(pa_level* L) {
   if (L->d_irr) (void)hipFree(L->d_irr);
   if (L->d_sfwg) (void)hipFree(L->d_sfwg);
   if (L->d_pfwg) (void)hipFree(L->d_pfwg);
+  if (L->d_sfchunk) (void)hipFree(L->d_sfchunk);
   if (L->d_blist) (void)hipFree(L->d_blist);
   if (L->d_sfboxes) (void)hipFree(L->d_sfboxes);
   delete L;

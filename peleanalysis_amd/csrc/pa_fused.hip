@@ -460,11 +460,7 @@ __device__ __forceinline__ void faces_curv_fast_body(const DLevelView& L, const 
 
 // PATCH: every coarse-fine face of every level of the batch has its coarse patch (the owner-map interpolation is not compiled in)
 template <int NL, bool PATCH, bool CLIP>
-__device__ __forceinline__ void faces_fast_wg(const LevBatch<FixArgs>& Bt, int* nbad, SlowList sl, const SlotK& sk, unsigned w) {
-  unsigned fy;
-  int blev;
-  long long t;
-  if (!wg_decode(Bt, blev, fy, t, w)) return;
+__device__ __forceinline__ void faces_fast_cell(const LevBatch<FixArgs>& Bt, int* nbad, SlowList sl, const SlotK& sk, int blev, unsigned fy, long long t) {
   const FixArgs& Fx = Bt.a[blev];
   sl.glev = (unsigned)blev;
   const DLevelView& L = Fx.L;
@@ -493,6 +489,175 @@ __device__ __forceinline__ void faces_fast_wg(const LevBatch<FixArgs>& Bt, int* 
     default: faces_curv_fast_body<2, NL, PATCH, CLIP>(L, LCr, MN, cncomp0, MO, ncomp0, kcomp, A, nbad, b, B, side, q0, code, patch, Fx.MC_, Fx.ccomp + z, sl, row, t); break;
   }
 }
+template <int NL, bool PATCH, bool CLIP>
+__device__ __forceinline__ void faces_fast_wg(const LevBatch<FixArgs>& Bt, int* nbad, SlowList sl, const SlotK& sk, unsigned w) {
+  unsigned fy;
+  int blev;
+  long long t;
+  if (!wg_decode(Bt, blev, fy, t, w)) return;
+  faces_fast_cell<NL, PATCH, CLIP>(Bt, nbad, sl, sk, blev, fy, t);
+}
+
+// ---- round 6: the face interiors from the levels' chunk records (see k_prep_faces_chunks below for the scheme): a thread takes the
+// 2 x 2 block of first-layer cells whose ghost cells share one coarse parent.  Uniform chunks (all coarse-fine with the full
+// stencil / all behind a wall) run straight-line code -- the parent's 3 x 3 coarse normals loaded once for the four cells, the
+// tangential neighbours of a row or column of the block shared, interpolation weights as literals; per cell the operations and their
+// order are faces_curv_fast_body<FD, 1, PATCH>'s with code PA_CODE_FULL (same bits).  Mixed chunks: faces_fast_cell per cell.
+template <int FD>
+__device__ __forceinline__ void fix_chunk_uniform(const FixArgs& Fx, const SfChunk& D, int z, int* nbad) {
+  constexpr int T0 = (FD == 0) ? 1 : 0, T1 = (FD == 2) ? 1 : 2;
+  const int side = D.dir_side & 1;
+  const DMFView& MO = Fx.MO;
+  const DLevelView& L = Fx.L;
+  const int n[3] = {D.hi[0] - D.lo[0] + 1, D.hi[1] - D.lo[1] + 1, D.hi[2] - D.lo[2] + 1};
+  const int n0 = n[T0], n1 = n[T1];
+  const int hw = D.cw >> 1, sh = 31 - __builtin_clz((unsigned)hw);
+  const int u = D.u0 + 2 * ((int)threadIdx.x & (hw - 1)), v = D.v0 + 2 * ((int)threadIdx.x >> sh);
+  if (u >= n0 || v >= n1) return;
+  const int ng = MO.ng, ncomp0 = Fx.ncomp0 + 8 * z, kcomp = Fx.kcomp + 8 * z;
+  const long long nxo = n[0] + 2 * ng, nyo = n[1] + 2 * ng, nzo = n[2] + 2 * ng;
+  const long long cso = pa_cstride(nxo * nyo * nzo, MO.ncomp);
+  const long long st[3] = {1, nxo, nxo * nyo};
+  int X1[3];
+  X1[FD] = side ? D.hi[FD] : D.lo[FD];
+  X1[T0] = D.lo[T0] + u;
+  X1[T1] = D.lo[T1] + v;
+  const long long idx1 = ((long long)(X1[2] - D.lo[2] + ng) * nyo + (X1[1] - D.lo[1] + ng)) * nxo + (X1[0] - D.lo[0] + ng);
+  const long long in = side ? -st[FD] : st[FD], s0 = st[T0], s1 = st[T1];
+  double* const o = MO.data + MO.off[D.box];
+  const double* const nf = o + (long long)(ncomp0 + FD) * cso + idx1;
+  const double* const n0p = o + (long long)(ncomp0 + T0) * cso + idx1;
+  const double* const n1p = o + (long long)(ncomp0 + T1) * cso + idx1;
+  double* const ko = o + (long long)kcomp * cso + idx1;
+  DBox B;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) { B.lo[d] = D.lo[d]; B.hi[d] = D.hi[d]; }
+  const bool wall = (D.flags & PA_SFC_WALL) != 0;
+  // NCG: this pass's sweep mirrored the first layer behind this x face (N_x of the first three cells, the y and z terms of K)
+  const bool pre = FD == 0 && Fx.ncg && z == 0 && ncg_face_ok(B, side, Fx.ncg_minw);
+  double nfd[2][2][3], A0[2][4], A1[2][4], t01n[2][2], t11n[2][2];
+  // tangential neighbours: positions u - 1 .. u + 2 of each of the block's two rows (rows: v - 1 .. v + 2 of its two columns); a
+  // position outside the face belongs to a perimeter cell, which is not written here -- clamped onto the face
+  long long k0[4], k1o[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    k0[k] = (long long)(min(max(u + k - 1, 0), n0 - 1) - u) * s0;
+    k1o[k] = (long long)(min(max(v + k - 1, 0), n1 - 1) - v) * s1;
+  }
+  if (pre) {
+    const pa_fix_d2* np = (const pa_fix_d2*)(Fx.ncg + 2 * (D.cgoff + (long long)(v + 1) * (n0 + 2) + (u + 1)));
+#pragma unroll
+    for (int dv = 0; dv < 2; ++dv)
+#pragma unroll
+      for (int du = 0; du < 2; ++du) {
+        const pa_fix_d2 v0 = np[dv * (n0 + 2) + du], v1 = np[Fx.ncgs + dv * (n0 + 2) + du], v2 = np[2 * Fx.ncgs + dv * (n0 + 2) + du];
+        nfd[dv][du][0] = v0.x; nfd[dv][du][1] = v0.y; nfd[dv][du][2] = v1.x; t01n[dv][du] = v1.y; t11n[dv][du] = v2.x;
+      }
+  } else {
+#pragma unroll
+    for (int dv = 0; dv < 2; ++dv)
+#pragma unroll
+      for (int du = 0; du < 2; ++du)
+#pragma unroll
+        for (int m = 0; m < 3; ++m) nfd[dv][du][m] = nf[dv * s1 + du * s0 + m * in];
+#pragma unroll
+    for (int dv = 0; dv < 2; ++dv)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) A0[dv][k] = n0p[dv * s1 + k0[k]];
+#pragma unroll
+    for (int du = 0; du < 2; ++du)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) A1[du][k] = n1p[du * s0 + k1o[k]];
+  }
+  double r[3][3];
+  if (!wall) {
+    int plane, pu0, pv0, pw, ph;
+    cpatch_geom(B, FD, side, plane, pu0, pv0, pw, ph);
+    const double* const cb = L.cp + z * Fx.cp_stride + D.cpoff + (long long)((X1[T1] >> 1) - pv0) * pw + ((X1[T0] >> 1) - pu0);
+    bool ok = true;
+#pragma unroll
+    for (int a1 = 0; a1 < 3; ++a1)
+#pragma unroll
+      for (int a0 = 0; a0 < 3; ++a0) r[a1][a0] = cb[(a1 - 1) * pw + (a0 - 1)];
+#pragma unroll
+    for (int a1 = 0; a1 < 3; ++a1)
+#pragma unroll
+      for (int a0 = 0; a0 < 3; ++a0)
+        if (__double_as_longlong(r[a1][a0]) == PA_CP_MISSING) { ok = false; r[a1][a0] = 0.0; }
+    if (!ok) atomicAdd(nbad, ((int)(u > 0) + (int)(u + 1 < n0 - 1)) * ((int)(v > 0) + (int)(v + 1 < n1 - 1)));  // counted per face-interior cell of the block
+  }
+  const bool odd = Fx.A.bc[FD] == PA_BC_REFLECT_ODD;
+  constexpr double nc0 = k_cf_coef.nrm[4][0], nc1 = k_cf_coef.nrm[4][1], nc2 = k_cf_coef.nrm[4][2], nc3 = k_cf_coef.nrm[4][3];
+#pragma unroll
+  for (int dv = 0; dv < 2; ++dv)
+#pragma unroll
+    for (int du = 0; du < 2; ++du) {
+      const double nfd1 = nfd[dv][du][0], nfd2 = nfd[dv][du][1], nfd3 = nfd[dv][du][2];
+      double g;
+      if (wall) {
+        g = odd ? -nfd1 : nfd1;
+      } else {
+        const double c00 = du ? k_cf_coef.tan[1][1][1][0] : k_cf_coef.tan[0][1][1][0], c01 = du ? k_cf_coef.tan[1][1][1][1] : k_cf_coef.tan[0][1][1][1],
+                     c02 = du ? k_cf_coef.tan[1][1][1][2] : k_cf_coef.tan[0][1][1][2];
+        const double c10 = dv ? k_cf_coef.tan[1][1][1][0] : k_cf_coef.tan[0][1][1][0], c11 = dv ? k_cf_coef.tan[1][1][1][1] : k_cf_coef.tan[0][1][1][1],
+                     c12 = dv ? k_cf_coef.tan[1][1][1][2] : k_cf_coef.tan[0][1][1][2];
+        const double xi0 = du ? 0.25 : -0.25, xi1 = dv ? 0.25 : -0.25;
+        double b0 = 0.0;
+        b0 += c00 * r[1][0];
+        b0 += c01 * r[1][1];
+        b0 += c02 * r[1][2];
+        b0 += c10 * r[0][1];
+        b0 += c11 * r[1][1];
+        b0 += c12 * r[2][1];
+        b0 -= r[1][1];
+        b0 += ((xi0 * xi1) * 0.25) * (((r[2][2] - r[2][0]) + r[0][0]) - r[0][2]);
+        double tmp = 0.0;
+        tmp += nfd1 * nc1;
+        tmp += nfd2 * nc2;
+        tmp += nfd3 * nc3;
+        g = tmp;
+        g += b0 * nc0;
+      }
+      const double f1 = side ? cdiff(L.dxinv[FD], nfd2, nfd1, g) : cdiff(L.dxinv[FD], g, nfd1, nfd2);
+      const double t01 = pre ? t01n[dv][du] : cdiff(L.dxinv[T0], A0[dv][du], A0[dv][du + 1], A0[dv][du + 2]);
+      const double t11 = pre ? t11n[dv][du] : cdiff(L.dxinv[T1], A1[du][dv], A1[du][dv + 1], A1[du][dv + 2]);
+      double k1 = 0.0;
+      k1 += (FD == 0) ? f1 : t01;
+      k1 += (FD == 1) ? f1 : (FD == 0 ? t01 : t11);
+      k1 += (FD == 2) ? f1 : t11;
+      k1 = k1 * 0.5;
+      const int uu = u + du, vv = v + dv;
+      if (uu > 0 && uu < n0 - 1 && vv > 0 && vv < n1 - 1) ko[dv * s1 + du * s0] = k1;  // the perimeter is k_faces_curv_tab's
+    }
+}
+
+struct LevChunks { const SfChunk* ck[PA_MAXB]; unsigned w0[PA_MAXB + 1]; };  // level l of the batch owns workgroups w0[l] .. w0[l + 1] - 1
+template <bool PATCH>
+__global__ __launch_bounds__(256) void k_faces_fix_chunks(LevBatch<FixArgs> Bt, LevChunks Ck, int* nbad, SlotK sk) {
+  int blev = 0;
+  while (blev + 1 < Bt.n && blockIdx.x >= Ck.w0[blev + 1]) ++blev;
+  const FixArgs& Fx = Bt.a[blev];
+  const SfChunk D = Ck.ck[blev][blockIdx.x - Ck.w0[blev]];
+  const int dir = D.dir_side >> 1;
+  const int e0 = D.hi[0] - D.lo[0] + 1, e1 = D.hi[1] - D.lo[1] + 1, e2 = D.hi[2] - D.lo[2] + 1;
+  const int blen = dir == 0 ? e0 : (dir == 1 ? e1 : e2), n0 = dir == 0 ? e1 : e0, n1 = dir == 2 ? e1 : e2;
+  const bool straight = blen >= 3 && ((D.flags & PA_SFC_WALL) != 0 ||
+                                     ((D.flags & PA_SFC_FULL) != 0 && Fx.A.has_crse && Fx.A.ratio == 2 && Fx.use_cp && Fx.L.cp));
+  if (straight) {
+    switch (dir) {  // (uniform)
+      case 0: fix_chunk_uniform<0>(Fx, D, (int)blockIdx.z, nbad); break;
+      case 1: fix_chunk_uniform<1>(Fx, D, (int)blockIdx.z, nbad); break;
+      default: fix_chunk_uniform<2>(Fx, D, (int)blockIdx.z, nbad); break;
+    }
+    return;
+  }
+  const int hw = D.cw >> 1, sh = 31 - __builtin_clz((unsigned)hw);
+  const int u = D.u0 + 2 * ((int)threadIdx.x & (hw - 1)), v = D.v0 + 2 * ((int)threadIdx.x >> sh);
+  for (int dv = 0; dv < 2; ++dv)
+    for (int du = 0; du < 2; ++du)
+      if (u + du < n0 && v + dv < n1) faces_fast_cell<1, PATCH, false>(Bt, nbad, SlowList(), sk, blev, (unsigned)D.face, (long long)(v + dv) * n0 + (u + du));
+}
+
 template <int NL, bool PATCH = false, bool CLIP = false>
 __global__ __launch_bounds__(256) void k_faces_curv_fast(LevBatch<FixArgs> Bt, int* nbad, SlowList sl = SlowList(), SlotK sk = SlotK()) {
   faces_fast_wg<NL, PATCH, CLIP>(Bt, nbad, sl, sk, blockIdx.x);
@@ -768,13 +933,8 @@ struct PrepLev { DLevelView L; DMFView M; int comp; DLevelView LC; DMFView MC; i
 // PHIONLY (the gradient tool's pass): only the face ghost of phi -- MLMG applyBC as k_apply_bc_sfaces does it, but on the per-face
 // work tables and from the coarse PATCHES instead of owner-map lookups into the coarse FABs (the three applyBC launches of a
 // 3-level hierarchy took 0.43 ms, this kernel 0.19 ms with the progress variable on top)
-template <bool PATCH, bool PHIONLY = false>
-__global__ __launch_bounds__(256) void k_prep_faces(LevBatch<PrepLev> Bt, int* nbad, SlotK sk = SlotK()) {
-  unsigned fy;
-  int blev;
-  long long t;
-  if (!wg_decode(Bt, blev, fy, t)) return;
-  const PrepLev& Pl = Bt.a[blev];
+template <bool PATCH, bool PHIONLY>
+__device__ __forceinline__ void prep_faces_cell(const PrepLev& Pl, int* nbad, const SlotK& sk, unsigned fy, long long t) {
   const DLevelView& L = Pl.L;
   const DMFView& M = Pl.M;
   const DLevelView& LC = Pl.LC;
@@ -839,6 +999,155 @@ __global__ __launch_bounds__(256) void k_prep_faces(LevBatch<PrepLev> Bt, int* n
   gc += bv[1] * coef[0];
   p[fab_index(B, M.ng, M.ncomp, comp, q[0], q[1], q[2])] = gp;
   if (!PHIONLY) *cgp = gc;
+}
+template <bool PATCH, bool PHIONLY = false>
+__global__ __launch_bounds__(256) void k_prep_faces(LevBatch<PrepLev> Bt, int* nbad, SlotK sk = SlotK()) {
+  unsigned fy;
+  int blev;
+  long long t;
+  if (!wg_decode(Bt, blev, fy, t)) return;
+  prep_faces_cell<PATCH, PHIONLY>(Bt.a[blev], nbad, sk, fy, t);
+}
+
+// ---- round 6: the same work from the levels' CHUNK RECORDS (SfChunk, pa_internal.h).  A workgroup takes one record = a rectangle of
+// 1024 ghost cells of one face, a thread the 2 x 2 block of ghost cells that share ONE coarse parent.  Chunks of one kind run
+// straight-line code: no per-cell code, no code-dependent trip counts, the interpolation weights as literals -- so the 21 loads of
+// a thread's four cells (9 coarse values of the parent's 3 x 3 neighbourhood, loaded once instead of four times, + 3 interior cells
+// each) are issued together.  Before: one thread per cell behind the chain work table -> sfaces -> boxes -> offsets -> code ->
+// weights + patch -> data (a wave lived 13 us, 3/4 of it waiting).  Per cell the operations and their order are those of
+// prep_faces_cell / cf_interp_core with code PA_CODE_FULL, so the same bits; mixed chunks take prep_faces_cell itself.
+template <int dir, bool PHIONLY>
+__device__ __forceinline__ void prep_chunk_uniform(const PrepLev& Pl, const SfChunk& D, const PrepArgs& A, double xa, double xb, int comp, double* cgz, const double* cpz, int* nbad) {
+  const int side = D.dir_side & 1;
+  constexpr int t0 = dir == 0 ? 1 : 0, t1 = dir == 2 ? 1 : 2;
+  const DMFView& M = Pl.M;
+  const int n0 = D.hi[t0] - D.lo[t0] + 1, n1 = D.hi[t1] - D.lo[t1] + 1;
+  const int hw = D.cw >> 1, sh = 31 - __builtin_clz((unsigned)hw);
+  const int u = D.u0 + 2 * ((int)threadIdx.x & (hw - 1)), v = D.v0 + 2 * ((int)threadIdx.x >> sh);
+  if (u >= n0 || v >= n1) return;  // (even extents: a block is inside the face or outside it)
+  const int ng = M.ng;
+  const long long nxg = D.hi[0] - D.lo[0] + 1 + 2 * ng, nyg = D.hi[1] - D.lo[1] + 1 + 2 * ng, nzg = D.hi[2] - D.lo[2] + 1 + 2 * ng;
+  double* const p = M.data + M.off[D.box] + (long long)comp * pa_cstride(nxg * nyg * nzg, M.ncomp);
+  const long long st[3] = {1, nxg, nxg * nyg};
+  int q[3];
+  q[dir] = side ? D.hi[dir] + 1 : D.lo[dir] - 1;
+  q[t0] = D.lo[t0] + u;
+  q[t1] = D.lo[t1] + v;
+  const long long iq = ((long long)(q[2] - D.lo[2] + ng) * nyg + (q[1] - D.lo[1] + ng)) * nxg + (q[0] - D.lo[0] + ng);
+  const long long sn = side ? -st[dir] : st[dir], s0 = st[t0], s1 = st[t1];
+  double* const cgp = PHIONLY ? nullptr : cgz + D.cgoff + (long long)(v + 1) * (n0 + 2) + (u + 1);
+  const bool odd = A.bc[dir] == PA_BC_REFLECT_ODD;
+  if (D.flags & PA_SFC_WALL) {
+    double w[2][2];
+#pragma unroll
+    for (int dv = 0; dv < 2; ++dv)
+#pragma unroll
+      for (int du = 0; du < 2; ++du) w[dv][du] = p[iq + dv * s1 + du * s0 + sn];
+#pragma unroll
+    for (int dv = 0; dv < 2; ++dv)
+#pragma unroll
+      for (int du = 0; du < 2; ++du) {
+        const double x = w[dv][du], xc = (x - A.pmin) * A.invd;
+        p[iq + dv * s1 + du * s0] = odd ? -x : x;
+        if (!PHIONLY) cgp[dv * (n0 + 2) + du] = odd ? -xc : xc;
+      }
+    return;
+  }
+  // PA_SFC_FULL: the coarse parent of the block and its 3 x 3 neighbourhood in the face's coarse patch
+  DBox B;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) { B.lo[d] = D.lo[d]; B.hi[d] = D.hi[d]; }
+  int plane, pu0, pv0, pw, ph;
+  cpatch_geom(B, dir, side, plane, pu0, pv0, pw, ph);
+  const double* const cb = cpz + D.cpoff + (long long)((q[t1] >> 1) - pv0) * pw + ((q[t0] >> 1) - pu0);
+  double r[3][3];  // r[a1 + 1][a0 + 1] = coarse(qc + a0 e_t0 + a1 e_t1)
+#pragma unroll
+  for (int a1 = 0; a1 < 3; ++a1)
+#pragma unroll
+    for (int a0 = 0; a0 < 3; ++a0) r[a1][a0] = cb[(a1 - 1) * pw + (a0 - 1)];
+  double f[2][2][3];  // the three cells behind the face of every ghost cell of the block
+#pragma unroll
+  for (int dv = 0; dv < 2; ++dv)
+#pragma unroll
+    for (int du = 0; du < 2; ++du)
+#pragma unroll
+      for (int m = 0; m < 3; ++m) f[dv][du][m] = p[iq + dv * s1 + du * s0 + (m + 1) * sn];
+  bool ok = true;
+#pragma unroll
+  for (int a1 = 0; a1 < 3; ++a1)
+#pragma unroll
+    for (int a0 = 0; a0 < 3; ++a0)
+      if (__double_as_longlong(r[a1][a0]) == PA_CP_MISSING) { ok = false; r[a1][a0] = 0.0; }
+  if (!ok) atomicAdd(nbad, 4);  // counted per ghost cell: the four cells of the block use all nine values
+  double rc[3][3];  // the progress variable as the affine view of the coarse phi
+#pragma unroll
+  for (int a1 = 0; a1 < 3; ++a1)
+#pragma unroll
+    for (int a0 = 0; a0 < 3; ++a0) rc[a1][a0] = (r[a1][a0] - xa) * xb;
+  constexpr double nc0 = k_cf_coef.nrm[4][0], nc1 = k_cf_coef.nrm[4][1], nc2 = k_cf_coef.nrm[4][2], nc3 = k_cf_coef.nrm[4][3];
+#pragma unroll
+  for (int dv = 0; dv < 2; ++dv)
+#pragma unroll
+    for (int du = 0; du < 2; ++du) {
+      // InterpBndryData, cf_interp_core with lo = -1, hi = 1 in both directions and the cross term, child (du, dv) of the parent
+      const double c00 = du ? k_cf_coef.tan[1][1][1][0] : k_cf_coef.tan[0][1][1][0], c01 = du ? k_cf_coef.tan[1][1][1][1] : k_cf_coef.tan[0][1][1][1],
+                   c02 = du ? k_cf_coef.tan[1][1][1][2] : k_cf_coef.tan[0][1][1][2];
+      const double c10 = dv ? k_cf_coef.tan[1][1][1][0] : k_cf_coef.tan[0][1][1][0], c11 = dv ? k_cf_coef.tan[1][1][1][1] : k_cf_coef.tan[0][1][1][1],
+                   c12 = dv ? k_cf_coef.tan[1][1][1][2] : k_cf_coef.tan[0][1][1][2];
+      const double xi0 = du ? 0.25 : -0.25, xi1 = dv ? 0.25 : -0.25;
+      double b0 = 0.0, b1 = 0.0;
+      b0 += c00 * r[1][0];  b1 += c00 * rc[1][0];
+      b0 += c01 * r[1][1];  b1 += c01 * rc[1][1];
+      b0 += c02 * r[1][2];  b1 += c02 * rc[1][2];
+      b0 += c10 * r[0][1];  b1 += c10 * rc[0][1];
+      b0 += c11 * r[1][1];  b1 += c11 * rc[1][1];
+      b0 += c12 * r[2][1];  b1 += c12 * rc[2][1];
+      b0 -= r[1][1];        b1 -= rc[1][1];
+      b0 += ((xi0 * xi1) * 0.25) * (((r[2][2] - r[2][0]) + r[0][0]) - r[0][2]);
+      b1 += ((xi0 * xi1) * 0.25) * (((rc[2][2] - rc[2][0]) + rc[0][0]) - rc[0][2]);
+      // MLMG applyBC across the face: points {-1 (the interpolated value), 0.5, 1.5, 2.5} seen from -0.5
+      double tp = 0.0, tc = 0.0;
+      tp += f[dv][du][0] * nc1;  tc += ((f[dv][du][0] - A.pmin) * A.invd) * nc1;
+      tp += f[dv][du][1] * nc2;  tc += ((f[dv][du][1] - A.pmin) * A.invd) * nc2;
+      tp += f[dv][du][2] * nc3;  tc += ((f[dv][du][2] - A.pmin) * A.invd) * nc3;
+      double gp = tp, gc = tc;
+      gp += b0 * nc0;
+      gc += b1 * nc0;
+      p[iq + dv * s1 + du * s0] = gp;
+      if (!PHIONLY) cgp[dv * (n0 + 2) + du] = gc;
+    }
+}
+
+template <bool PATCH, bool PHIONLY = false>
+__global__ __launch_bounds__(256) void k_prep_faces_chunks(LevBatch<PrepLev> Bt, LevChunks Ck, int* nbad, SlotK sk = SlotK()) {
+  int blev = 0;
+  while (blev + 1 < Bt.n && blockIdx.x >= Ck.w0[blev + 1]) ++blev;
+  const PrepLev& Pl = Bt.a[blev];
+  const SfChunk D = Ck.ck[blev][blockIdx.x - Ck.w0[blev]];
+  const int dir = D.dir_side >> 1;
+  // (selects, not D.lo[dir]: a run-time index would send the record through scratch)
+  const int e0 = D.hi[0] - D.lo[0] + 1, e1 = D.hi[1] - D.lo[1] + 1, e2 = D.hi[2] - D.lo[2] + 1;
+  const int blen = dir == 0 ? e0 : (dir == 1 ? e1 : e2), n0 = dir == 0 ? e1 : e0, n1 = dir == 2 ? e1 : e2;
+  const bool straight = ((D.flags & PA_SFC_WALL) != 0 || ((D.flags & PA_SFC_FULL) != 0 && Pl.A.has_crse && Pl.A.ratio == 2 && Pl.use_cp && Pl.L.cp && blen >= 3));
+  if (straight) {
+    const int z = (int)blockIdx.z;  // component slot
+    PrepArgs A = Pl.A;
+    double xa = Pl.MC.xa, xb = Pl.MC.xb;
+    if (sk.prog) { A.pmin = xa = sk.prog[2 * z]; A.invd = xb = sk.prog[2 * z + 1]; }
+    double* const cgz = PHIONLY ? nullptr : Pl.L.cg + z * Pl.cg_stride;
+    const double* const cpz = Pl.L.cp ? Pl.L.cp + z * Pl.cp_stride : nullptr;
+    switch (dir) {  // (uniform) compile-time directions: every index into lo / hi / strides is a constant
+      case 0: prep_chunk_uniform<0, PHIONLY>(Pl, D, A, xa, xb, Pl.comp + z, cgz, cpz, nbad); break;
+      case 1: prep_chunk_uniform<1, PHIONLY>(Pl, D, A, xa, xb, Pl.comp + z, cgz, cpz, nbad); break;
+      default: prep_chunk_uniform<2, PHIONLY>(Pl, D, A, xa, xb, Pl.comp + z, cgz, cpz, nbad); break;
+    }
+    return;
+  }
+  const int hw = D.cw >> 1, sh = 31 - __builtin_clz((unsigned)hw);
+  const int u = D.u0 + 2 * ((int)threadIdx.x & (hw - 1)), v = D.v0 + 2 * ((int)threadIdx.x >> sh);
+  for (int dv = 0; dv < 2; ++dv)
+    for (int du = 0; du < 2; ++du)
+      if (u + du < n0 && v + dv < n1) prep_faces_cell<PATCH, PHIONLY>(Pl, nbad, sk, (unsigned)D.face, (long long)(v + dv) * n0 + (u + du));
 }
 
 // The edge ghost cells of c (outside the box in two directions a < c) that are the boundary ghost of a valid cell of a
@@ -1457,6 +1766,7 @@ int pa_gradcurv_prep_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int comp, 
   for (int l0 = 0; l0 < nlev; l0 += PA_MAXB) {
     if (use_cp && (phase & 1) && cpatch_launch(ctx, l0, std::min(nlev, l0 + PA_MAXB), phi, crse, ccomp, 0, nslots, 1)) return 1;  // before P.L = L->view picks up cp
     LevBatch<PrepLev> Bf, Br;
+    const pa_level* batch_lev[PA_MAXB] = {};
     long long ntf = 0, ntr = 0;
     for (int l = l0; l < nlev && l < l0 + PA_MAXB; ++l) {
       const pa_level* L = phi[l]->lev;
@@ -1477,6 +1787,7 @@ int pa_gradcurv_prep_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int comp, 
       const long long n0 = L->maxn[0], n1 = L->maxn[1], n2 = L->maxn[2];
       ntf = std::max(ntf, std::max(n1 * n2, std::max(n0 * n2, n0 * n1)));
       ntr = std::max(ntr, 4 * (n0 + n1 + n2));
+      batch_lev[Bf.n] = L;
       Bf.a[Bf.n] = P; Bf.ycum[Bf.n + 1] = Bf.ycum[Bf.n] + (int)L->sfaces.size(); ++Bf.n;
       Br.a[Br.n] = P; Br.ycum[Br.n + 1] = Br.ycum[Br.n] + L->nsfboxes; ++Br.n;
     }
@@ -1487,7 +1798,26 @@ int pa_gradcurv_prep_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int comp, 
     unsigned nwgf = 0;
     for (int q = 0; q < Bf.n; ++q) nwgf += (unsigned)Bf.a[q].nwg;
     const dim3 gf(nwgf, 1, (unsigned)nslots), gr((unsigned)((ntr + 255) / 256), (unsigned)Br.ycum[Br.n], (unsigned)nslots);
-    if ((phase & 1) && (phase & 8)) {
+    // round 6: the faces from the levels' chunk records (k_prep_faces_chunks).  PA_FACE_CHUNKS=0 (read per pass): the per-cell kernel
+    LevChunks Ck;
+    Ck.w0[0] = 0;
+    bool chunks = !(getenv("PA_FACE_CHUNKS") && !atoi(getenv("PA_FACE_CHUNKS")));
+    for (int q = 0; q < Bf.n; ++q) {
+      const pa_level* Lq = batch_lev[q];
+      chunks = chunks && Lq->d_sfchunk && Lq->nsfchunk > 0;
+      Ck.ck[q] = Lq->d_sfchunk;
+      Ck.w0[q + 1] = Ck.w0[q] + (unsigned)Lq->nsfchunk;
+    }
+    if ((phase & 1) && chunks) {
+      const dim3 gc(Ck.w0[Bf.n], 1, (unsigned)nslots);
+      if (phase & 8) {
+        if (all_patch) hipLaunchKernelGGL((k_prep_faces_chunks<true, true>), gc, dim3(256), 0, ctx->stream, Bf, Ck, ctx->d_flags, sk);
+        else hipLaunchKernelGGL((k_prep_faces_chunks<false, true>), gc, dim3(256), 0, ctx->stream, Bf, Ck, ctx->d_flags, sk);
+      } else {
+        if (all_patch) hipLaunchKernelGGL((k_prep_faces_chunks<true, false>), gc, dim3(256), 0, ctx->stream, Bf, Ck, ctx->d_flags, sk);
+        else hipLaunchKernelGGL((k_prep_faces_chunks<false, false>), gc, dim3(256), 0, ctx->stream, Bf, Ck, ctx->d_flags, sk);
+      }
+    } else if ((phase & 1) && (phase & 8)) {
       if (all_patch) hipLaunchKernelGGL((k_prep_faces<true, true>), gf, dim3(256), 0, ctx->stream, Bf, ctx->d_flags, sk);
       else hipLaunchKernelGGL((k_prep_faces<false, true>), gf, dim3(256), 0, ctx->stream, Bf, ctx->d_flags, sk);
     } else if (phase & 1) {
@@ -1821,6 +2151,15 @@ int pa_gradcurv_fix_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, 
     unsigned nwgf = 0;
     for (int q = 0; q < Bt.n; ++q) nwgf += (unsigned)Bt.a[q].nwg;
     const dim3 gfast(nwgf, 1, (unsigned)nslots);
+    LevChunks Ck;  // PA_FACE_CHUNKS=0 (read per pass): the per-cell kernel
+    Ck.w0[0] = 0;
+    bool chunks = !(getenv("PA_FACE_CHUNKS") && !atoi(getenv("PA_FACE_CHUNKS")));
+    for (int q = 0; q < Bt.n; ++q) {
+      const pa_level* Lq = phi[blev[q]]->lev;
+      chunks = chunks && Lq->d_sfchunk && Lq->nsfchunk > 0;
+      Ck.ck[q] = Lq->d_sfchunk;
+      Ck.w0[q + 1] = Ck.w0[q] + (unsigned)Lq->nsfchunk;
+    }
     hipStream_t pst = ctx->stream;  // the perimeter kernel's stream
     bool both_done = false;         // the perimeters went with the interiors (k_faces_curv_both)
     if (clip) {
@@ -1877,6 +2216,10 @@ int pa_gradcurv_fix_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, 
         if (all_patch) hipLaunchKernelGGL((k_faces_curv_both<true>), gboth, dim3(256), 0, ctx->stream, Bt, ctx->d_flags, sk, nwgf);
         else hipLaunchKernelGGL((k_faces_curv_both<false>), gboth, dim3(256), 0, ctx->stream, Bt, ctx->d_flags, sk, nwgf);
         both_done = true;
+      } else if (chunks) {  // round 6: the face interiors from the levels' chunk records
+        const dim3 gc(Ck.w0[Bt.n], 1, (unsigned)nslots);
+        if (all_patch) hipLaunchKernelGGL((k_faces_fix_chunks<true>), gc, dim3(256), 0, ctx->stream, Bt, Ck, ctx->d_flags, sk);
+        else hipLaunchKernelGGL((k_faces_fix_chunks<false>), gc, dim3(256), 0, ctx->stream, Bt, Ck, ctx->d_flags, sk);
       } else if (all_patch) hipLaunchKernelGGL((k_faces_curv_fast<1, true>), gfast, dim3(256), 0, ctx->stream, Bt, ctx->d_flags, SlowList(), sk);
       else hipLaunchKernelGGL((k_faces_curv_fast<1, false>), gfast, dim3(256), 0, ctx->stream, Bt, ctx->d_flags, SlowList(), sk);
     }

@@ -41,6 +41,27 @@ struct DLevelView {
   double* cp;
 };
 
+// One work item of the chunked special-face kernels (round 6, pa_fused.hip: k_prep_faces_chunks / k_faces_fix_chunks): a rectangle
+// (u0 .. u0 + cw - 1) x (v0 .. v0 + ch - 1) of the ghost cells of ONE special face in the face's tangential coordinates (t0 fastest),
+// cw * ch = 1024, one thread per 2 x 2 block.  Everything the kernels need to know about the face sits in the record -- one wide
+// scalar load instead of the chain work table -> sfaces -> boxes -> sfoff / cgoff / cpoff -- and `flags` says whether the whole
+// chunk is of ONE kind, so that the uniform kinds run straight-line code without reading a per-cell code first.
+enum { PA_SFC_FULL = 1,   // every cell is coarse-fine with the full centred stencil (code PA_CODE_FULL), the face starts on even tangential
+                          // indices and has even extents: a thread's 2 x 2 block shares ONE coarse parent
+       PA_SFC_WALL = 2 }; // every cell lies outside a wall
+struct alignas(16) SfChunk {
+  int face;      // entry of the face in DLevelView::sfaces
+  int box;
+  int dir_side;  // dir * 2 + side
+  int flags;
+  int lo[3], hi[3];
+  int u0, v0, cw, ch;
+  long long sfoff, cgoff, cpoff;
+};
+// cf_masks of a coarse-fine ghost cell whose 3 x 3 coarse neighbourhood in the ghost plane is coarse-fine throughout: class 1,
+// tangential stencils -1 .. 1 in both directions, cross term on
+#define PA_CODE_FULL 0x555u
+
 struct DMFView {
   double* data;
   const long long* off;  // per box, in doubles
@@ -181,6 +202,8 @@ struct pa_level {
   int nsfwg = 0;
   void* d_pfwg = nullptr;   // int2 {special face, chunk of 256 of its PERIMETER cells}: the work table of k_faces_curv_tab (round 5)
   int npfwg = 0;
+  SfChunk* d_sfchunk = nullptr;  // the chunk records of the level's special faces (round 6)
+  int nsfchunk = 0;
   void* d_irr = nullptr;    // int4 {box, i, j, k}
   int nirr = -1;            // -1: not built yet
   int nremote = 0;          // boxes of this level owned by other ranks (pa_level_create_sharded)
@@ -404,6 +427,9 @@ constexpr CfCoefTab make_cf_coef_tab() {
   return T;
 }
 static __device__ __constant__ const CfCoefTab g_cf_coef = make_cf_coef_tab();
+// the same table for uses with compile-time indices: literals in the instruction stream instead of loads (the straight-line paths of
+// the chunked face kernels); same constexpr evaluation, so the same bits as the table above
+static constexpr CfCoefTab k_cf_coef = make_cf_coef_tab();
 
 // Masks of InterpBndryData for ghost cell q of a face normal to `dir` (ratio r), packed:
 //   bits 0-1 class of q (0 valid cell, 1 coarse-fine, 2 outside a wall); for class 1 also
