@@ -227,19 +227,23 @@ __global__ __launch_bounds__(256) void k_sfchunk_flags(DLevelView L, SfChunk* ck
   const int dir = D.dir_side >> 1, t0 = dir == 0 ? 1 : 0, t1 = dir == 2 ? 1 : 2;
   const int n0 = D.hi[t0] - D.lo[t0] + 1, n1 = D.hi[t1] - D.lo[t1] + 1;
   const int hw = D.cw >> 1, bu = (int)threadIdx.x % hw, bv = (int)threadIdx.x / hw;
-  bool full = true, wall = true;
+  bool full = true, wall = true, cf = false, valid = false;
   for (int dv = 0; dv < 2; ++dv)
     for (int du = 0; du < 2; ++du) {
       const int u = D.u0 + 2 * bu + du, v = D.v0 + 2 * bv + dv;
-      if (u >= n0 || v >= n1) continue;
+      if (u < 0 || v < 0 || u >= n0 || v >= n1) continue;
       const unsigned code = L.sfcode[D.sfoff + (long long)v * n0 + u];
       full = full && code == PA_CODE_FULL;
       wall = wall && (code & 3u) == 2u;
+      cf = cf || (code & 3u) == 1u;
+      valid = valid || (code & 3u) == 0u;
     }
   const int afull = __syncthreads_and(full ? 1 : 0), awall = __syncthreads_and(wall ? 1 : 0);
+  const int acf = __syncthreads_or(cf ? 1 : 0), avalid = __syncthreads_or(valid ? 1 : 0);
   if (threadIdx.x == 0) {
+    // the straight-line kinds want whole blocks: even start, even extents
     const bool even = !((D.lo[t0] | D.lo[t1] | n0 | n1 | D.u0 | D.v0) & 1);
-    D.flags = (afull && even && D.cpoff >= 0 ? PA_SFC_FULL : 0) | (awall && even ? PA_SFC_WALL : 0);
+    D.flags = (afull && even && D.cpoff >= 0 ? PA_SFC_FULL : 0) | (awall && even ? PA_SFC_WALL : 0) | (acf ? PA_SFC_HAS_CF : 0) | (avalid ? PA_SFC_HAS_VALID : 0);
   }
 }
 
@@ -513,8 +517,8 @@ pa_level* pa_level_create_spec(pa_ctx* ctx, const LevelSpec& S, const int32_t do
         int cw = 32;
         while (cw < 512 && cw < n0) cw *= 2;
         const int ch = 1024 / cw;
-        for (int v0 = 0; v0 < n1; v0 += ch)
-          for (int u0 = 0; u0 < n0; u0 += cw) {
+        for (int v0 = -(B.lo[t1] & 1); v0 < n1; v0 += ch)  // blocks on even global indices
+          for (int u0 = -(B.lo[t0] & 1); u0 < n0; u0 += cw) {
             SfChunk D;
             D.face = (int)e; D.box = f / 6; D.dir_side = f % 6; D.flags = 0;
             for (int q = 0; q < 3; ++q) { D.lo[q] = B.lo[q]; D.hi[q] = B.hi[q]; }

@@ -498,6 +498,85 @@ __device__ __forceinline__ void faces_fast_wg(const LevBatch<FixArgs>& Bt, int* 
   faces_fast_cell<NL, PATCH, CLIP>(Bt, nbad, sl, sk, blev, fy, t);
 }
 
+
+// ---- round 6: the coarse-fine interpolation of the four ghost cells of a 2 x 2 block for ANY mix of codes, without branches.  The
+// block's cells share the coarse parent qc; InterpBndryData reaches at most two coarse cells along each tangential axis and the
+// four diagonal neighbours, so 13 values of the face's coarse patch are a superset of what the four cells read (always inside the
+// patch: it covers coarsen(lo - 1) - 2 .. coarsen(hi + 1) + 2).  Per cell: the stencil extents come out of its code, the weights
+// out of a copy of g_cf_coef.tan in LDS, the values out of the superset by selects, and a term outside the cell's stencil is
+// SKIPPED by a select (not multiplied by zero) -- the additions that happen are cf_interp_core's, in its order.
+struct CfBlock {
+  double ax0[5], ax1[5], dg[4];  // coarse(qc + a e_t0), coarse(qc + a e_t1) for a = -2 .. 2; diagonals (+,+) (-,+) (-,-) (+,-)
+  unsigned miss;                 // bit i: ax0[i]; bit 5 + i: ax1[i]; bit 10 + i: dg[i] has no coarse owner (zeroed here, as craw does)
+};
+__device__ __forceinline__ void cf_block_load(const double* cb, int pw, CfBlock& K) {
+#pragma unroll
+  for (int a = 0; a < 5; ++a) K.ax0[a] = cb[a - 2];
+#pragma unroll
+  for (int a = 0; a < 5; ++a) K.ax1[a] = (a == 2) ? 0.0 : cb[(long long)(a - 2) * pw];
+  K.dg[0] = cb[pw + 1]; K.dg[1] = cb[pw - 1]; K.dg[2] = cb[-pw - 1]; K.dg[3] = cb[-pw + 1];
+}
+__device__ __forceinline__ void cf_block_finish(CfBlock& K) {  // after the loads have been issued with everything else
+  K.ax1[2] = K.ax0[2];
+  K.miss = 0;
+#pragma unroll
+  for (int a = 0; a < 5; ++a) {
+    if (__double_as_longlong(K.ax0[a]) == PA_CP_MISSING) { K.miss |= 1u << a; K.ax0[a] = 0.0; }
+    if (__double_as_longlong(K.ax1[a]) == PA_CP_MISSING) { K.miss |= 1u << (5 + a); K.ax1[a] = 0.0; }
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+    if (__double_as_longlong(K.dg[a]) == PA_CP_MISSING) { K.miss |= 1u << (10 + a); K.dg[a] = 0.0; }
+}
+__device__ __forceinline__ void cf_tab_to_lds(double* tabs) {  // g_cf_coef.tan, flat: ((rem * 3 + lo + 2) * 3 + hi) * 3 + m
+  if (threadIdx.x < 54) tabs[threadIdx.x] = (&g_cf_coef.tan[0][0][0][0])[threadIdx.x];
+  __syncthreads();
+}
+// child (du, dv) of the parent, masks `code` (class 1); field 0 sees the raw coarse values, field 1 (NF == 2) (v - xa) * xb.
+// Returns true when the cell's stencil touches a coarse cell without an owner.
+// one tangential direction of cf_block_interp: the (up to three) stencil points lo .. hi out of the five axis values e0 .. e4 = coarse(qc + a e_t),
+// a = -2 .. 2 (by value: a pointer chosen by the direction would keep the block in memory and turn the selects into an indexed load)
+template <int NF>
+__device__ __forceinline__ unsigned cf_block_axis(unsigned fld, int rem, const double* tabs, double e0, double e1, double e2, double e3, double e4, double xa, double xb, double b[NF]) {
+  const int lo2 = (int)(fld & 3u), hi = (int)((fld >> 2) & 3u);  // lo2 = lo + 2
+  const int N = hi - (lo2 - 2) + 1;
+  const double* ct = tabs + ((rem * 3 + lo2) * 3 + hi) * 3;
+  const double c0 = ct[0], c1 = ct[1], c2 = ct[2];
+  const double v0 = lo2 == 0 ? e0 : (lo2 == 1 ? e1 : e2), v1 = lo2 == 0 ? e1 : (lo2 == 1 ? e2 : e3), v2 = lo2 == 0 ? e2 : (lo2 == 1 ? e3 : e4);
+#pragma unroll
+  for (int f = 0; f < NF; ++f) {
+    const double w0 = f ? (v0 - xa) * xb : v0, w1 = f ? (v1 - xa) * xb : v1, w2 = f ? (v2 - xa) * xb : v2;
+    b[f] += c0 * w0;
+    const double s1 = b[f] + c1 * w1;
+    b[f] = N > 1 ? s1 : b[f];
+    const double s2 = b[f] + c2 * w2;
+    b[f] = N > 2 ? s2 : b[f];
+  }
+  return ((1u << (hi + 3)) - 1u) & ~((1u << lo2) - 1u);  // the axis values the stencil uses
+}
+// child (du, dv) of the parent, masks `code` (class 1); field 0 sees the raw coarse values, field 1 (NF == 2) (v - xa) * xb.
+// Returns true when the cell's stencil touches a coarse cell without an owner.
+template <int NF>
+__device__ __forceinline__ bool cf_block_interp(const CfBlock& K, unsigned code, int du, int dv, const double* tabs, double xa, double xb, double b[NF]) {
+#pragma unroll
+  for (int f = 0; f < NF; ++f) b[f] = 0.0;
+  unsigned used = cf_block_axis<NF>((code >> 2) & 15u, du, tabs, K.ax0[0], K.ax0[1], K.ax0[2], K.ax0[3], K.ax0[4], xa, xb, b);
+  used |= cf_block_axis<NF>((code >> 6) & 15u, dv, tabs, K.ax1[0], K.ax1[1], K.ax1[2], K.ax1[3], K.ax1[4], xa, xb, b) << 5;
+  const bool cross = (code & (1u << 10)) != 0;
+  used |= cross ? (0xFu << 10) : 0u;
+  const double xi0 = du ? 0.25 : -0.25, xi1 = dv ? 0.25 : -0.25;
+#pragma unroll
+  for (int f = 0; f < NF; ++f) {
+    const double ce = f ? (K.ax0[2] - xa) * xb : K.ax0[2];
+    b[f] -= ce;
+    const double vpp = f ? (K.dg[0] - xa) * xb : K.dg[0], vmp = f ? (K.dg[1] - xa) * xb : K.dg[1];
+    const double vmm = f ? (K.dg[2] - xa) * xb : K.dg[2], vpm = f ? (K.dg[3] - xa) * xb : K.dg[3];
+    const double sc = b[f] + ((xi0 * xi1) * 0.25) * (((vpp - vmp) + vmm) - vpm);
+    b[f] = cross ? sc : b[f];
+  }
+  return (K.miss & used) != 0;
+}
+
 // ---- round 6: the face interiors from the levels' chunk records (see k_prep_faces_chunks below for the scheme): a thread takes the
 // 2 x 2 block of first-layer cells whose ghost cells share one coarse parent.  Uniform chunks (all coarse-fine with the full
 // stencil / all behind a wall) run straight-line code -- the parent's 3 x 3 coarse normals loaded once for the four cells, the
@@ -631,6 +710,138 @@ __device__ __forceinline__ void fix_chunk_uniform(const FixArgs& Fx, const SfChu
     }
 }
 
+
+// the face interiors of a chunk with any mix of cell kinds (see prep_chunk_mixed): the ghost normal of a first-layer cell is the
+// boundary condition on n across a coarse-fine face, the mirror image behind a wall, or -- a valid ghost cell behind a partly
+// covered face -- the neighbouring box's FINAL normal, read in the box that owns it (a branch, taken only by waves that have such
+// cells; a ghost cell owned by another rank's box is on the level's irregular list: not written here)
+template <int FD>
+__device__ __forceinline__ void fix_chunk_mixed(const FixArgs& Fx, const SfChunk& D, int z, int* nbad, const double* tabs) {
+  constexpr int T0 = (FD == 0) ? 1 : 0, T1 = (FD == 2) ? 1 : 2;
+  const int side = D.dir_side & 1;
+  const DMFView& MO = Fx.MO;
+  const DLevelView& L = Fx.L;
+  const int n[3] = {D.hi[0] - D.lo[0] + 1, D.hi[1] - D.lo[1] + 1, D.hi[2] - D.lo[2] + 1};
+  const int n0 = n[T0], n1 = n[T1];
+  const int hw = D.cw >> 1, sh = 31 - __builtin_clz((unsigned)hw);
+  const int u = D.u0 + 2 * ((int)threadIdx.x & (hw - 1)), v = D.v0 + 2 * ((int)threadIdx.x >> sh);
+  if (u >= n0 || v >= n1) return;
+  const int ng = MO.ng, ncomp0 = Fx.ncomp0 + 8 * z, kcomp = Fx.kcomp + 8 * z;
+  const long long nxo = n[0] + 2 * ng, nyo = n[1] + 2 * ng, nzo = n[2] + 2 * ng;
+  const long long cso = pa_cstride(nxo * nyo * nzo, MO.ncomp);
+  const long long st[3] = {1, nxo, nxo * nyo};
+  int X1[3];
+  X1[FD] = side ? D.hi[FD] : D.lo[FD];
+  X1[T0] = D.lo[T0] + u;
+  X1[T1] = D.lo[T1] + v;
+  const long long idx1 = ((long long)(X1[2] - D.lo[2] + ng) * nyo + (X1[1] - D.lo[1] + ng)) * nxo + (X1[0] - D.lo[0] + ng);
+  const long long in = side ? -st[FD] : st[FD], s0 = st[T0], s1 = st[T1];
+  double* const o = MO.data + MO.off[D.box];
+  const double* const nf = o + (long long)(ncomp0 + FD) * cso + idx1;
+  const double* const n0p = o + (long long)(ncomp0 + T0) * cso + idx1;
+  const double* const n1p = o + (long long)(ncomp0 + T1) * cso + idx1;
+  double* const ko = o + (long long)kcomp * cso + idx1;
+  DBox B;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) { B.lo[d] = D.lo[d]; B.hi[d] = D.hi[d]; }
+  const bool pre = FD == 0 && Fx.ncg && z == 0 && ncg_face_ok(B, side, Fx.ncg_minw);
+  // only face-interior cells are written (the perimeter is k_faces_curv_tab's): every other cell of the block is folded onto the
+  // nearest interior cell, so that all of its loads stay inside the FAB (faces at least three cells wide in both directions;
+  // narrower ones have no interior cell)
+  bool live[2][2];
+  long long off[2][2], cgo[2][2];
+  unsigned code[2][2];
+  const int ulo = min(1, n0 - 1), uhi = max(n0 - 2, 0), vlo = min(1, n1 - 1), vhi = max(n1 - 2, 0);
+#pragma unroll
+  for (int dv = 0; dv < 2; ++dv)
+#pragma unroll
+    for (int du = 0; du < 2; ++du) {
+      const int uu = u + du, vv = v + dv;
+      live[dv][du] = uu > 0 && uu < n0 - 1 && vv > 0 && vv < n1 - 1;
+      const int uc = min(max(uu, ulo), uhi), vc = min(max(vv, vlo), vhi);
+      off[dv][du] = (long long)(vc - v) * s1 + (long long)(uc - u) * s0;
+      cgo[dv][du] = (long long)(vc + 1) * (n0 + 2) + (uc + 1);
+      code[dv][du] = L.sfcode[D.sfoff + (long long)vc * n0 + uc];
+    }
+  if (n0 < 3 || n1 < 3) return;
+  const bool cf_here = (D.flags & PA_SFC_HAS_CF) != 0;
+  CfBlock K;
+  if (cf_here) {
+    int plane, pu0, pv0, pw, ph;
+    cpatch_geom(B, FD, side, plane, pu0, pv0, pw, ph);
+    cf_block_load(L.cp + z * Fx.cp_stride + D.cpoff + (long long)((X1[T1] >> 1) - pv0) * pw + ((X1[T0] >> 1) - pu0), pw, K);
+  }
+  double nfd[2][2][3], a0[2][2][3], a1[2][2][3], t01n[2][2], t11n[2][2];
+  if (pre) {
+    const pa_fix_d2* np = (const pa_fix_d2*)(Fx.ncg + 2 * D.cgoff);
+#pragma unroll
+    for (int dv = 0; dv < 2; ++dv)
+#pragma unroll
+      for (int du = 0; du < 2; ++du) {
+        const pa_fix_d2 v0 = np[cgo[dv][du]], v1 = np[Fx.ncgs + cgo[dv][du]], v2 = np[2 * Fx.ncgs + cgo[dv][du]];
+        nfd[dv][du][0] = v0.x; nfd[dv][du][1] = v0.y; nfd[dv][du][2] = v1.x; t01n[dv][du] = v1.y; t11n[dv][du] = v2.x;
+      }
+  } else {
+#pragma unroll
+    for (int dv = 0; dv < 2; ++dv)
+#pragma unroll
+      for (int du = 0; du < 2; ++du) {
+#pragma unroll
+        for (int m = 0; m < 3; ++m) nfd[dv][du][m] = nf[off[dv][du] + m * in];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          a0[dv][du][k] = n0p[off[dv][du] + (k - 1) * s0];
+          a1[dv][du][k] = n1p[off[dv][du] + (k - 1) * s1];
+        }
+      }
+  }
+  if (cf_here) cf_block_finish(K);
+  const bool odd = Fx.A.bc[FD] == PA_BC_REFLECT_ODD;
+  constexpr double nc0 = k_cf_coef.nrm[4][0], nc1 = k_cf_coef.nrm[4][1], nc2 = k_cf_coef.nrm[4][2], nc3 = k_cf_coef.nrm[4][3];
+  int nbad_here = 0;
+#pragma unroll
+  for (int dv = 0; dv < 2; ++dv)
+#pragma unroll
+    for (int du = 0; du < 2; ++du) {
+      const unsigned cd = live[dv][du] ? code[dv][du] : 2u;
+      const int cls = (int)(cd & 3u);
+      const double nfd1 = nfd[dv][du][0], nfd2 = nfd[dv][du][1], nfd3 = nfd[dv][du][2];
+      double g = odd ? -nfd1 : nfd1;  // wall
+      bool write = live[dv][du];
+      if (cf_here) {
+        double b[1];
+        const bool bad = cf_block_interp<1>(K, cd, du, dv, tabs, 0.0, 1.0, b);
+        double tmp = 0.0;
+        tmp += nfd1 * nc1;
+        tmp += nfd2 * nc2;
+        tmp += nfd3 * nc3;
+        double h = tmp;
+        h += b[0] * nc0;
+        g = cls == 1 ? h : g;
+        nbad_here += (cls == 1 && bad) ? 1 : 0;
+      }
+      if (cls == 0) {  // (rare) the ghost cell is a valid cell of a neighbouring box
+        int q0[3] = {X1[0], X1[1], X1[2]};
+        q0[FD] += side ? 1 : -1;
+        q0[T0] += du;
+        q0[T1] += dv;
+        int sbn = -1, qw[3];
+        if (classify(L, q0[0], q0[1], q0[2], sbn, qw) == 0 && sbn >= 0) g = MO.data[MO.off[sbn] + fab_index(L.boxes[sbn], MO.ng, MO.ncomp, ncomp0 + FD, qw[0], qw[1], qw[2])];
+        else write = false;
+      }
+      const double f1 = side ? cdiff(L.dxinv[FD], nfd2, nfd1, g) : cdiff(L.dxinv[FD], g, nfd1, nfd2);
+      const double t01 = pre ? t01n[dv][du] : cdiff(L.dxinv[T0], a0[dv][du][0], a0[dv][du][1], a0[dv][du][2]);
+      const double t11 = pre ? t11n[dv][du] : cdiff(L.dxinv[T1], a1[dv][du][0], a1[dv][du][1], a1[dv][du][2]);
+      double k1 = 0.0;
+      k1 += (FD == 0) ? f1 : t01;
+      k1 += (FD == 1) ? f1 : (FD == 0 ? t01 : t11);
+      k1 += (FD == 2) ? f1 : t11;
+      k1 = k1 * 0.5;
+      if (write) ko[off[dv][du]] = k1;
+    }
+  if (nbad_here) atomicAdd(nbad, nbad_here);
+}
+
 struct LevChunks { const SfChunk* ck[PA_MAXB]; unsigned w0[PA_MAXB + 1]; };  // level l of the batch owns workgroups w0[l] .. w0[l + 1] - 1
 template <bool PATCH>
 __global__ __launch_bounds__(256) void k_faces_fix_chunks(LevBatch<FixArgs> Bt, LevChunks Ck, int* nbad, SlotK sk) {
@@ -641,8 +852,9 @@ __global__ __launch_bounds__(256) void k_faces_fix_chunks(LevBatch<FixArgs> Bt, 
   const int dir = D.dir_side >> 1;
   const int e0 = D.hi[0] - D.lo[0] + 1, e1 = D.hi[1] - D.lo[1] + 1, e2 = D.hi[2] - D.lo[2] + 1;
   const int blen = dir == 0 ? e0 : (dir == 1 ? e1 : e2), n0 = dir == 0 ? e1 : e0, n1 = dir == 2 ? e1 : e2;
-  const bool straight = blen >= 3 && ((D.flags & PA_SFC_WALL) != 0 ||
-                                     ((D.flags & PA_SFC_FULL) != 0 && Fx.A.has_crse && Fx.A.ratio == 2 && Fx.use_cp && Fx.L.cp));
+  const bool cfok = Fx.A.has_crse && Fx.A.ratio == 2 && Fx.use_cp && Fx.L.cp && D.cpoff >= 0;
+  const bool straight = blen >= 3 && ((D.flags & PA_SFC_WALL) != 0 || ((D.flags & PA_SFC_FULL) != 0 && cfok));
+  const bool mixed = !straight && blen >= 3 && (cfok || !(D.flags & PA_SFC_HAS_CF));
   if (straight) {
     switch (dir) {  // (uniform)
       case 0: fix_chunk_uniform<0>(Fx, D, (int)blockIdx.z, nbad); break;
@@ -651,11 +863,21 @@ __global__ __launch_bounds__(256) void k_faces_fix_chunks(LevBatch<FixArgs> Bt, 
     }
     return;
   }
+  if (mixed) {
+    __shared__ double tabs[54];
+    cf_tab_to_lds(tabs);
+    switch (dir) {
+      case 0: fix_chunk_mixed<0>(Fx, D, (int)blockIdx.z, nbad, tabs); break;
+      case 1: fix_chunk_mixed<1>(Fx, D, (int)blockIdx.z, nbad, tabs); break;
+      default: fix_chunk_mixed<2>(Fx, D, (int)blockIdx.z, nbad, tabs); break;
+    }
+    return;
+  }
   const int hw = D.cw >> 1, sh = 31 - __builtin_clz((unsigned)hw);
   const int u = D.u0 + 2 * ((int)threadIdx.x & (hw - 1)), v = D.v0 + 2 * ((int)threadIdx.x >> sh);
   for (int dv = 0; dv < 2; ++dv)
     for (int du = 0; du < 2; ++du)
-      if (u + du < n0 && v + dv < n1) faces_fast_cell<1, PATCH, false>(Bt, nbad, SlowList(), sk, blev, (unsigned)D.face, (long long)(v + dv) * n0 + (u + du));
+      if (u + du >= 0 && v + dv >= 0 && u + du < n0 && v + dv < n1) faces_fast_cell<1, PATCH, false>(Bt, nbad, SlowList(), sk, blev, (unsigned)D.face, (long long)(v + dv) * n0 + (u + du));
 }
 
 template <int NL, bool PATCH = false, bool CLIP = false>
@@ -1118,6 +1340,121 @@ __device__ __forceinline__ void prep_chunk_uniform(const PrepLev& Pl, const SfCh
     }
 }
 
+
+// Any mix of cell kinds in the chunk (coarse-fine with any stencil, wall, valid cells of the level behind a partly covered face),
+// block origins on even GLOBAL indices (u0 / v0 may be -1: cells outside the face are predicated off).  Everything a block may need
+// is requested up front -- four codes, the 13 coarse values, three interior cells per ghost cell -- then each cell's value is chosen
+// by selects; only a valid ghost cell (its value lives in the box that owns it: an owner-map lookup) takes a branch.
+template <int dir, bool PHIONLY>
+__device__ __forceinline__ void prep_chunk_mixed(const PrepLev& Pl, const SfChunk& D, const PrepArgs& A, double xa, double xb, int comp, double* cgz, const double* cpz,
+                                                 int* nbad, const double* tabs) {
+  const int side = D.dir_side & 1;
+  constexpr int t0 = dir == 0 ? 1 : 0, t1 = dir == 2 ? 1 : 2;
+  const DMFView& M = Pl.M;
+  const DLevelView& L = Pl.L;
+  const int n0 = D.hi[t0] - D.lo[t0] + 1, n1 = D.hi[t1] - D.lo[t1] + 1;
+  const int hw = D.cw >> 1, sh = 31 - __builtin_clz((unsigned)hw);
+  const int u = D.u0 + 2 * ((int)threadIdx.x & (hw - 1)), v = D.v0 + 2 * ((int)threadIdx.x >> sh);
+  if (u >= n0 || v >= n1) return;
+  const int ng = M.ng;
+  const long long nxg = D.hi[0] - D.lo[0] + 1 + 2 * ng, nyg = D.hi[1] - D.lo[1] + 1 + 2 * ng, nzg = D.hi[2] - D.lo[2] + 1 + 2 * ng;
+  double* const p = M.data + M.off[D.box] + (long long)comp * pa_cstride(nxg * nyg * nzg, M.ncomp);
+  const long long st[3] = {1, nxg, nxg * nyg};
+  int q[3];
+  q[dir] = side ? D.hi[dir] + 1 : D.lo[dir] - 1;
+  q[t0] = D.lo[t0] + u;
+  q[t1] = D.lo[t1] + v;
+  const long long iq = ((long long)(q[2] - D.lo[2] + ng) * nyg + (q[1] - D.lo[1] + ng)) * nxg + (q[0] - D.lo[0] + ng);
+  const long long sn = side ? -st[dir] : st[dir], s0 = st[t0], s1 = st[t1];
+  double* const cgp = PHIONLY ? nullptr : cgz + D.cgoff + (long long)(v + 1) * (n0 + 2) + (u + 1);
+  const bool odd = A.bc[dir] == PA_BC_REFLECT_ODD;
+  bool in[2][2];
+  long long off[2][2];
+  unsigned code[2][2];
+#pragma unroll
+  for (int dv = 0; dv < 2; ++dv)
+#pragma unroll
+    for (int du = 0; du < 2; ++du) {
+      const int uu = u + du, vv = v + dv;
+      in[dv][du] = uu >= 0 && uu < n0 && vv >= 0 && vv < n1;
+      const int uc = min(max(uu, 0), n0 - 1), vc = min(max(vv, 0), n1 - 1);
+      off[dv][du] = (long long)(vc - v) * s1 + (long long)(uc - u) * s0;
+      code[dv][du] = L.sfcode[D.sfoff + (long long)vc * n0 + uc];
+    }
+  const bool cf_here = (D.flags & PA_SFC_HAS_CF) != 0;  // (uniform) a chunk without coarse-fine cells may belong to a face without a patch
+  CfBlock K;
+  if (cf_here) {
+    DBox B;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { B.lo[d] = D.lo[d]; B.hi[d] = D.hi[d]; }
+    int plane, pu0, pv0, pw, ph;
+    cpatch_geom(B, dir, side, plane, pu0, pv0, pw, ph);
+    cf_block_load(cpz + D.cpoff + (long long)((q[t1] >> 1) - pv0) * pw + ((q[t0] >> 1) - pu0), pw, K);
+  }
+  double f[2][2][3];
+#pragma unroll
+  for (int dv = 0; dv < 2; ++dv)
+#pragma unroll
+    for (int du = 0; du < 2; ++du)
+#pragma unroll
+      for (int m = 0; m < 3; ++m) f[dv][du][m] = p[iq + off[dv][du] + (m + 1) * sn];
+  if (cf_here) cf_block_finish(K);
+  constexpr double nc0 = k_cf_coef.nrm[4][0], nc1 = k_cf_coef.nrm[4][1], nc2 = k_cf_coef.nrm[4][2], nc3 = k_cf_coef.nrm[4][3];
+  int nbad_here = 0;
+  bool any_valid = false;
+#pragma unroll
+  for (int dv = 0; dv < 2; ++dv)
+#pragma unroll
+    for (int du = 0; du < 2; ++du) {
+      const unsigned cd = in[dv][du] ? code[dv][du] : 0u;
+      const int cls = (int)(cd & 3u);
+      any_valid = any_valid || (in[dv][du] && cls == 0);
+      double gp, gc;
+      {  // wall: the mirror image of the first cell
+        const double x = f[dv][du][0], xc = (x - A.pmin) * A.invd;
+        gp = odd ? -x : x;
+        gc = odd ? -xc : xc;
+      }
+      if (cf_here) {  // coarse-fine: InterpBndryData + MLMG applyBC across the face (both formed, chosen by the class)
+        double b[2];
+        const bool bad = cf_block_interp<2>(K, cd, du, dv, tabs, xa, xb, b);
+        double tp = 0.0, tc = 0.0;
+        tp += f[dv][du][0] * nc1;  tc += ((f[dv][du][0] - A.pmin) * A.invd) * nc1;
+        tp += f[dv][du][1] * nc2;  tc += ((f[dv][du][1] - A.pmin) * A.invd) * nc2;
+        tp += f[dv][du][2] * nc3;  tc += ((f[dv][du][2] - A.pmin) * A.invd) * nc3;
+        double hp = tp, hc = tc;
+        hp += b[0] * nc0;
+        hc += b[1] * nc0;
+        gp = cls == 1 ? hp : gp;
+        gc = cls == 1 ? hc : gc;
+        nbad_here += (cls == 1 && bad) ? 1 : 0;
+      }
+      if (in[dv][du] && cls != 0) {
+        p[iq + off[dv][du]] = gp;
+        if (!PHIONLY) cgp[dv * (n0 + 2) + du] = gc;
+      }
+    }
+  if (nbad_here) atomicAdd(nbad, nbad_here);
+  if (!PHIONLY && any_valid) {
+    // a valid cell of the level behind a partly covered face: the progress variable of the cell itself, read in the box that OWNS it
+    // when that box is local (this kernel runs next to the local FillBoundary), in the ghost cell when another rank owns it
+#pragma unroll
+    for (int dv = 0; dv < 2; ++dv)
+#pragma unroll
+      for (int du = 0; du < 2; ++du) {
+        if (!(in[dv][du] && (code[dv][du] & 3u) == 0u)) continue;
+        int qq[3] = {q[0], q[1], q[2]};
+        qq[t0] += du;
+        qq[t1] += dv;
+        int sb, xw[3];
+        double x;
+        if (classify(L, qq[0], qq[1], qq[2], sb, xw) == 0 && sb >= 0) x = M.data[M.off[sb] + fab_index(L.boxes[sb], M.ng, M.ncomp, comp, xw[0], xw[1], xw[2])];
+        else x = p[iq + off[dv][du]];
+        cgp[dv * (n0 + 2) + du] = (x - A.pmin) * A.invd;
+      }
+  }
+}
+
 template <bool PATCH, bool PHIONLY = false>
 __global__ __launch_bounds__(256) void k_prep_faces_chunks(LevBatch<PrepLev> Bt, LevChunks Ck, int* nbad, SlotK sk = SlotK()) {
   int blev = 0;
@@ -1128,26 +1465,40 @@ __global__ __launch_bounds__(256) void k_prep_faces_chunks(LevBatch<PrepLev> Bt,
   // (selects, not D.lo[dir]: a run-time index would send the record through scratch)
   const int e0 = D.hi[0] - D.lo[0] + 1, e1 = D.hi[1] - D.lo[1] + 1, e2 = D.hi[2] - D.lo[2] + 1;
   const int blen = dir == 0 ? e0 : (dir == 1 ? e1 : e2), n0 = dir == 0 ? e1 : e0, n1 = dir == 2 ? e1 : e2;
-  const bool straight = ((D.flags & PA_SFC_WALL) != 0 || ((D.flags & PA_SFC_FULL) != 0 && Pl.A.has_crse && Pl.A.ratio == 2 && Pl.use_cp && Pl.L.cp && blen >= 3));
-  if (straight) {
+  const bool cfok = Pl.A.has_crse && Pl.A.ratio == 2 && Pl.use_cp && Pl.L.cp && D.cpoff >= 0 && blen >= 3;  // coarse-fine cells: from the face's coarse patch, four points across the face
+  const bool straight = (D.flags & PA_SFC_WALL) != 0 || ((D.flags & PA_SFC_FULL) != 0 && cfok);
+  const bool mixed = !straight && blen >= 3 && (cfok || !(D.flags & PA_SFC_HAS_CF));
+  if (straight || mixed) {
+    __shared__ double tabs[54];
+    if (mixed) cf_tab_to_lds(tabs);  // (uniform per workgroup; before any thread leaves)
     const int z = (int)blockIdx.z;  // component slot
     PrepArgs A = Pl.A;
     double xa = Pl.MC.xa, xb = Pl.MC.xb;
     if (sk.prog) { A.pmin = xa = sk.prog[2 * z]; A.invd = xb = sk.prog[2 * z + 1]; }
     double* const cgz = PHIONLY ? nullptr : Pl.L.cg + z * Pl.cg_stride;
     const double* const cpz = Pl.L.cp ? Pl.L.cp + z * Pl.cp_stride : nullptr;
-    switch (dir) {  // (uniform) compile-time directions: every index into lo / hi / strides is a constant
-      case 0: prep_chunk_uniform<0, PHIONLY>(Pl, D, A, xa, xb, Pl.comp + z, cgz, cpz, nbad); break;
-      case 1: prep_chunk_uniform<1, PHIONLY>(Pl, D, A, xa, xb, Pl.comp + z, cgz, cpz, nbad); break;
-      default: prep_chunk_uniform<2, PHIONLY>(Pl, D, A, xa, xb, Pl.comp + z, cgz, cpz, nbad); break;
+    if (straight) {
+      switch (dir) {  // (uniform) compile-time directions: every index into lo / hi / strides is a constant
+        case 0: prep_chunk_uniform<0, PHIONLY>(Pl, D, A, xa, xb, Pl.comp + z, cgz, cpz, nbad); break;
+        case 1: prep_chunk_uniform<1, PHIONLY>(Pl, D, A, xa, xb, Pl.comp + z, cgz, cpz, nbad); break;
+        default: prep_chunk_uniform<2, PHIONLY>(Pl, D, A, xa, xb, Pl.comp + z, cgz, cpz, nbad); break;
+      }
+    } else {
+      switch (dir) {
+        case 0: prep_chunk_mixed<0, PHIONLY>(Pl, D, A, xa, xb, Pl.comp + z, cgz, cpz, nbad, tabs); break;
+        case 1: prep_chunk_mixed<1, PHIONLY>(Pl, D, A, xa, xb, Pl.comp + z, cgz, cpz, nbad, tabs); break;
+        default: prep_chunk_mixed<2, PHIONLY>(Pl, D, A, xa, xb, Pl.comp + z, cgz, cpz, nbad, tabs); break;
+      }
     }
     return;
   }
+  // what is left: a level that interpolates through the owner map (no coarse patches), boxes thinner than three cells, a level
+  // without a coarser one that has coarse-fine cells (counted as errors): cell by cell
   const int hw = D.cw >> 1, sh = 31 - __builtin_clz((unsigned)hw);
   const int u = D.u0 + 2 * ((int)threadIdx.x & (hw - 1)), v = D.v0 + 2 * ((int)threadIdx.x >> sh);
   for (int dv = 0; dv < 2; ++dv)
     for (int du = 0; du < 2; ++du)
-      if (u + du < n0 && v + dv < n1) prep_faces_cell<PATCH, PHIONLY>(Pl, nbad, sk, (unsigned)D.face, (long long)(v + dv) * n0 + (u + du));
+      if (u + du >= 0 && v + dv >= 0 && u + du < n0 && v + dv < n1) prep_faces_cell<PATCH, PHIONLY>(Pl, nbad, sk, (unsigned)D.face, (long long)(v + dv) * n0 + (u + du));
 }
 
 // The edge ghost cells of c (outside the box in two directions a < c) that are the boundary ghost of a valid cell of a

@@ -43,12 +43,15 @@ struct DLevelView {
 
 // One work item of the chunked special-face kernels (round 6, pa_fused.hip: k_prep_faces_chunks / k_faces_fix_chunks): a rectangle
 // (u0 .. u0 + cw - 1) x (v0 .. v0 + ch - 1) of the ghost cells of ONE special face in the face's tangential coordinates (t0 fastest),
-// cw * ch = 1024, one thread per 2 x 2 block.  Everything the kernels need to know about the face sits in the record -- one wide
+// cw * ch = 1024, one thread per 2 x 2 block; blocks start on even GLOBAL indices (the four ghost cells of a block share one coarse
+// parent), so u0 / v0 are -1 where the face starts on an odd index: cells outside the face are predicated off.  Everything the kernels need to know about the face sits in the record -- one wide
 // scalar load instead of the chain work table -> sfaces -> boxes -> sfoff / cgoff / cpoff -- and `flags` says whether the whole
 // chunk is of ONE kind, so that the uniform kinds run straight-line code without reading a per-cell code first.
 enum { PA_SFC_FULL = 1,   // every cell is coarse-fine with the full centred stencil (code PA_CODE_FULL), the face starts on even tangential
                           // indices and has even extents: a thread's 2 x 2 block shares ONE coarse parent
-       PA_SFC_WALL = 2 }; // every cell lies outside a wall
+       PA_SFC_WALL = 2,   // every cell lies outside a wall
+       PA_SFC_HAS_CF = 4, // some cell is coarse-fine
+       PA_SFC_HAS_VALID = 8 };  // some cell is a valid cell of the level (a face that is partly covered by a neighbouring box)
 struct alignas(16) SfChunk {
   int face;      // entry of the face in DLevelView::sfaces
   int box;
