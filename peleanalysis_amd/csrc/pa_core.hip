@@ -620,6 +620,7 @@ extern "C" void pa_level_destroy(pa_level* L) {
   if (L->d_sfwg) (void)hipFree(L->d_sfwg);
   if (L->d_pfwg) (void)hipFree(L->d_pfwg);
   if (L->d_sfchunk) (void)hipFree(L->d_sfchunk);
+  if (L->d_ring) (void)hipFree(L->d_ring);
   if (L->d_blist) (void)hipFree(L->d_blist);
   if (L->d_sfboxes) (void)hipFree(L->d_sfboxes);
   delete L;

@@ -843,12 +843,16 @@ __device__ __forceinline__ void fix_chunk_mixed(const FixArgs& Fx, const SfChunk
 }
 
 struct LevChunks { const SfChunk* ck[PA_MAXB]; unsigned w0[PA_MAXB + 1]; };  // level l of the batch owns workgroups w0[l] .. w0[l + 1] - 1
+// nperim > 0: the first nperim workgroups take the face PERIMETERS' work tables (faces_tab_wg: other cells, the same final normals, long
+// chains of dependent loads -- in front, so that they run under the interiors instead of after them)
 template <bool PATCH>
-__global__ __launch_bounds__(256) void k_faces_fix_chunks(LevBatch<FixArgs> Bt, LevChunks Ck, int* nbad, SlotK sk) {
+__global__ __launch_bounds__(256) void k_faces_fix_chunks(LevBatch<FixArgs> Bt, LevChunks Ck, int* nbad, SlotK sk, unsigned nperim) {
+  if (blockIdx.x < nperim) { faces_tab_wg<true, PATCH, false>(Bt, nbad, sk, blockIdx.x); return; }
+  const unsigned wx = blockIdx.x - nperim;
   int blev = 0;
-  while (blev + 1 < Bt.n && blockIdx.x >= Ck.w0[blev + 1]) ++blev;
+  while (blev + 1 < Bt.n && wx >= Ck.w0[blev + 1]) ++blev;
   const FixArgs& Fx = Bt.a[blev];
-  const SfChunk D = Ck.ck[blev][blockIdx.x - Ck.w0[blev]];
+  const SfChunk D = Ck.ck[blev][wx - Ck.w0[blev]];
   const int dir = D.dir_side >> 1;
   const int e0 = D.hi[0] - D.lo[0] + 1, e1 = D.hi[1] - D.lo[1] + 1, e2 = D.hi[2] - D.lo[2] + 1;
   const int blen = dir == 0 ? e0 : (dir == 1 ? e1 : e2), n0 = dir == 0 ? e1 : e0, n1 = dir == 2 ? e1 : e2;
@@ -1455,12 +1459,140 @@ __device__ __forceinline__ void prep_chunk_mixed(const PrepLev& Pl, const SfChun
   }
 }
 
-template <bool PATCH, bool PHIONLY = false>
-__global__ __launch_bounds__(256) void k_prep_faces_chunks(LevBatch<PrepLev> Bt, LevChunks Ck, int* nbad, SlotK sk = SlotK()) {
+// The edge ghost cells of c (outside the box in two directions a < c) that are the boundary ghost of a valid cell of a
+// NEIGHBOURING box (k_apply_bc_edges): stored in the ring of the special face they continue.  WHICH edge ghost cells those are, the
+// face they continue and their interpolation masks depend on the level's geometry only: a list built once per level
+// (k_find_ring; until round 6 every pass re-derived it from three owner-map classifications per edge ghost cell of every box with a
+// special face, a 40-us chain of dependent lookups for a few thousand values).  The values read ghost cells of phi that are valid
+// cells of the level: from this box's FAB once FillBoundary has filled them (DIRECT = false), or -- DIRECT, an unsharded level -- in
+// the box that owns them, so that the work does not wait for FillBoundary and runs next to it.
+struct RingItem { int b, q[3], w /* dir | side << 2 | class << 3 */, ef, code, pad; };
+__global__ __launch_bounds__(256) void k_find_ring(DLevelView L, const int* sfboxes, int nsfboxes, RingItem* items, int* count, int cap) {
+  const int b = sfboxes[blockIdx.y];
+  const DBox B = L.boxes[b];
+  const int n[3] = {B.hi[0] - B.lo[0] + 1, B.hi[1] - B.lo[1] + 1, B.hi[2] - B.lo[2] + 1};
+  long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  int e = -1, which = 0, pos = 0;
+  for (int d = 0; d < 3; ++d) {
+    if (t < 4LL * n[d]) { e = d; which = (int)((unsigned)t / (unsigned)n[d]); pos = (int)((unsigned)t % (unsigned)n[d]); break; }
+    t -= 4LL * n[d];
+  }
+  if (e < 0) return;
+  const int a = (e == 0) ? 1 : 0, c = (e == 2) ? 1 : 2;
+  const int sa = which & 1, sc = which >> 1;
+  int q[3];
+  q[e] = B.lo[e] + pos;
+  q[a] = sa ? B.hi[a] + 1 : B.lo[a] - 1;
+  q[c] = sc ? B.hi[c] + 1 : B.lo[c] - 1;
+  const int cls = classify(L, q[0], q[1], q[2]);
+  if (cls == 0) return;
+  int qa[3] = {q[0], q[1], q[2]}, qc[3] = {q[0], q[1], q[2]};
+  qa[a] += sa ? -1 : 1;
+  qc[c] += sc ? -1 : 1;
+  const bool va = classify(L, qa[0], qa[1], qa[2]) == 0;
+  const bool vc = classify(L, qc[0], qc[1], qc[2]) == 0;
+  if (va == vc) return;
+  const int dir = va ? a : c, sd = va ? sa : sc;
+  if (cls == 2 && !((q[dir] < L.domlo[dir] || q[dir] > L.domhi[dir]) && !L.is_per[dir])) return;
+  const int ef = L.sfindex[b * 6 + dir * 2 + sd];
+  if (ef < 0) return;
+  const int i = atomicAdd(count, 1);
+  if (items && i < cap) {
+    RingItem R;
+    R.b = b; R.q[0] = q[0]; R.q[1] = q[1]; R.q[2] = q[2]; R.w = dir | (sd << 2) | (cls << 3); R.ef = ef;
+    R.code = cls == 1 ? (int)(cf_masks(L, q, dir, 2) | 1u) : 0;
+    R.pad = 0;
+    items[i] = R;
+  }
+}
+
+template <bool PATCH, bool DIRECT>
+__device__ __forceinline__ void prep_ring_item(const PrepLev& Pl, const RingItem& R, int* nbad, const SlotK& sk) {
+  const DLevelView& L = Pl.L;
+  const DMFView& M = Pl.M;
+  const DLevelView& LC = Pl.LC;
+  const int z = (int)blockIdx.z;  // component slot
+  DMFView MC = Pl.MC;
+  PrepArgs A = Pl.A;
+  if (sk.prog) { A.pmin = MC.xa = sk.prog[2 * z]; A.invd = MC.xb = sk.prog[2 * z + 1]; }
+  const int comp = Pl.comp + z, ccomp = Pl.ccomp + z;
+  double* const cgz = L.cg + z * Pl.cg_stride;
+  const double* const cpz = L.cp ? L.cp + z * Pl.cp_stride : nullptr;
+  const int b = R.b, dir = R.w & 3, sd = (R.w >> 2) & 1, cls = R.w >> 3, ef = R.ef;
+  const int q[3] = {R.q[0], R.q[1], R.q[2]};
+  const DBox B = L.boxes[b];
+  const int n[3] = {B.hi[0] - B.lo[0] + 1, B.hi[1] - B.lo[1] + 1, B.hi[2] - B.lo[2] + 1};
+  const int s = sd ? -1 : 1;
+  if (cls == 1 && !A.has_crse) { atomicAdd(nbad, 1); return; }
+  const double* p = M.data + M.off[b];
+  auto phi_at = [&](const int x[3]) -> double {  // a cell one row / plane outside this box that is a valid cell of the level
+    if (DIRECT) {
+      int sb, xw[3];
+      if (classify(L, x[0], x[1], x[2], sb, xw) == 0 && sb >= 0) return M.data[M.off[sb] + fab_index(L.boxes[sb], M.ng, M.ncomp, comp, xw[0], xw[1], xw[2])];
+    }
+    return p[fab_index(B, M.ng, M.ncomp, comp, x[0], x[1], x[2])];
+  };
+  double g;
+  if (cls == 2) {
+    int in[3] = {q[0], q[1], q[2]};
+    in[dir] += s;
+    const double v = (phi_at(in) - A.pmin) * A.invd;
+    g = (A.bc[dir] == PA_BC_REFLECT_ODD) ? -v : v;
+  } else {
+    bool ok = true;
+    double coef[4];
+    const int NX = cf_normal_coef(n[dir], A.ratio, coef);
+    double bv;
+    const long long cpo = (Pl.use_cp && L.cp) ? L.cpoff[ef] : -1;
+    if (PATCH || cpo >= 0) {  // the coarse values from the face's patch (its ring of two coarse cells covers the edge ghosts)
+      const int xf[1] = {MC.xform};
+      double b1[1];
+      cf_interp_patch<1>((unsigned)R.code, cpz + cpo, B, sd, MC, q, dir, xf, ok, b1);
+      bv = b1[0];
+    } else {
+      const int xf[1] = {MC.xform};
+      double b1[1];
+      cf_interp<1>((unsigned)R.code, LC, MC, ccomp, q, dir, A.ratio, xf, ok, b1);  // MC carries the affine view
+      bv = b1[0];
+    }
+    if (!ok) atomicAdd(nbad, 1);
+    double tmp = 0.0;
+    for (int m = 1; m < NX; ++m) {
+      int pc[3] = {q[0], q[1], q[2]};
+      pc[dir] += s * m;
+      tmp += ((phi_at(pc) - A.pmin) * A.invd) * coef[m];
+    }
+    g = tmp;
+    g += bv * coef[0];
+  }
+  const int t0 = (dir == 0) ? 1 : 0, t1 = (dir == 2) ? 1 : 2;
+  cgz[L.cgoff[ef] + (long long)(q[t1] - B.lo[t1] + 1) * (B.hi[t0] - B.lo[t0] + 3) + (q[t0] - B.lo[t0] + 1)] = g;
+}
+struct LevRings { const RingItem* it[PA_MAXB]; unsigned n[PA_MAXB]; unsigned w0[PA_MAXB + 1]; };  // level l of the batch owns workgroups w0[l] .. w0[l + 1] - 1
+template <bool PATCH, bool DIRECT>
+__device__ __forceinline__ void prep_ring_wg(const LevBatch<PrepLev>& Bt, const LevRings& Rg, int* nbad, const SlotK& sk, unsigned w) {
   int blev = 0;
-  while (blev + 1 < Bt.n && blockIdx.x >= Ck.w0[blev + 1]) ++blev;
+  while (blev + 1 < Bt.n && w >= Rg.w0[blev + 1]) ++blev;
+  const unsigned i = (w - Rg.w0[blev]) * 256u + threadIdx.x;
+  if (i >= Rg.n[blev]) return;
+  prep_ring_item<PATCH, DIRECT>(Bt.a[blev], Rg.it[blev][i], nbad, sk);
+}
+template <bool PATCH, bool DIRECT = false>
+__global__ __launch_bounds__(256) void k_prep_ring(LevBatch<PrepLev> Bt, LevRings Rg, int* nbad, SlotK sk = SlotK()) {
+  prep_ring_wg<PATCH, DIRECT>(Bt, Rg, nbad, sk, blockIdx.x);
+}
+
+template <bool PATCH, bool PHIONLY = false>
+__global__ __launch_bounds__(256) void k_prep_faces_chunks(LevBatch<PrepLev> Bt, LevChunks Ck, LevRings Rg, int* nbad, SlotK sk = SlotK()) {
+  // the levels' ring items in front (Rg.w0[Bt.n] workgroups, none when the ring has its own launch): independent of the faces -- they
+  // read valid cells in the boxes that own them -- and a longer chain of dependent loads, so they run under the faces' workgroups
+  const unsigned nrw = Rg.w0[Bt.n];
+  if (blockIdx.x < nrw) { if (!PHIONLY) prep_ring_wg<PATCH, true>(Bt, Rg, nbad, sk, blockIdx.x); return; }
+  const unsigned wx = blockIdx.x - nrw;
+  int blev = 0;
+  while (blev + 1 < Bt.n && wx >= Ck.w0[blev + 1]) ++blev;
   const PrepLev& Pl = Bt.a[blev];
-  const SfChunk D = Ck.ck[blev][blockIdx.x - Ck.w0[blev]];
+  const SfChunk D = Ck.ck[blev][wx - Ck.w0[blev]];
   const int dir = D.dir_side >> 1;
   // (selects, not D.lo[dir]: a run-time index would send the record through scratch)
   const int e0 = D.hi[0] - D.lo[0] + 1, e1 = D.hi[1] - D.lo[1] + 1, e2 = D.hi[2] - D.lo[2] + 1;
@@ -1501,96 +1633,6 @@ __global__ __launch_bounds__(256) void k_prep_faces_chunks(LevBatch<PrepLev> Bt,
       if (u + du >= 0 && v + dv >= 0 && u + du < n0 && v + dv < n1) prep_faces_cell<PATCH, PHIONLY>(Pl, nbad, sk, (unsigned)D.face, (long long)(v + dv) * n0 + (u + du));
 }
 
-// The edge ghost cells of c (outside the box in two directions a < c) that are the boundary ghost of a valid cell of a
-// NEIGHBOURING box (k_apply_bc_edges): stored in the ring of the special face they continue.  Reads ghost cells of phi that
-// are valid cells of the level: from this box's FAB once FillBoundary has filled them (DIRECT = false), or -- DIRECT, an
-// unsharded level -- in the box that owns them, so that the kernel does not wait for FillBoundary and runs next to it.
-template <bool PATCH, bool DIRECT = false>
-__global__ void k_prep_ring(LevBatch<PrepLev> Bt, int* nbad, SlotK sk = SlotK()) {
-  unsigned fy;
-  const PrepLev& Pl = Bt.a[Bt.find(blockIdx.y, fy)];
-  const DLevelView& L = Pl.L;
-  const DMFView& M = Pl.M;
-  const DLevelView& LC = Pl.LC;
-  const int z = (int)blockIdx.z;  // component slot
-  DMFView MC = Pl.MC;
-  PrepArgs A = Pl.A;
-  if (sk.prog) { A.pmin = MC.xa = sk.prog[2 * z]; A.invd = MC.xb = sk.prog[2 * z + 1]; }
-  const int comp = Pl.comp + z, ccomp = Pl.ccomp + z;
-  double* const cgz = L.cg + z * Pl.cg_stride;
-  const double* const cpz = L.cp ? L.cp + z * Pl.cp_stride : nullptr;
-  const int b = Pl.sfboxes[fy];  // the launch runs over the boxes that have a special face: the others have no ring to fill
-  const DBox B = L.boxes[b];
-  const int n[3] = {B.hi[0] - B.lo[0] + 1, B.hi[1] - B.lo[1] + 1, B.hi[2] - B.lo[2] + 1};
-  long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  int e = -1, which = 0, pos = 0;
-  for (int d = 0; d < 3; ++d) {
-    if (t < 4LL * n[d]) { e = d; which = (int)((unsigned)t / (unsigned)n[d]); pos = (int)((unsigned)t % (unsigned)n[d]); break; }
-    t -= 4LL * n[d];
-  }
-  if (e < 0) return;
-  const int a = (e == 0) ? 1 : 0, c = (e == 2) ? 1 : 2;
-  const int sa = which & 1, sc = which >> 1;
-  int q[3];
-  q[e] = B.lo[e] + pos;
-  q[a] = sa ? B.hi[a] + 1 : B.lo[a] - 1;
-  q[c] = sc ? B.hi[c] + 1 : B.lo[c] - 1;
-  const int cls = classify(L, q[0], q[1], q[2]);
-  if (cls == 0) return;
-  int qa[3] = {q[0], q[1], q[2]}, qc[3] = {q[0], q[1], q[2]};
-  qa[a] += sa ? -1 : 1;
-  qc[c] += sc ? -1 : 1;
-  const bool va = classify(L, qa[0], qa[1], qa[2]) == 0;
-  const bool vc = classify(L, qc[0], qc[1], qc[2]) == 0;
-  if (va == vc) return;
-  const int dir = va ? a : c, sd = va ? sa : sc;
-  const int s = sd ? -1 : 1;
-  if (cls == 2 && !((q[dir] < L.domlo[dir] || q[dir] > L.domhi[dir]) && !L.is_per[dir])) return;
-  const int ef = L.sfindex[b * 6 + dir * 2 + sd];
-  if (ef < 0) return;
-  if (cls == 1 && !A.has_crse) { atomicAdd(nbad, 1); return; }
-  const double* p = M.data + M.off[b];
-  auto phi_at = [&](const int x[3]) -> double {  // a cell one row / plane outside this box that is a valid cell of the level
-    if (DIRECT) {
-      int sb, xw[3];
-      if (classify(L, x[0], x[1], x[2], sb, xw) == 0 && sb >= 0) return M.data[M.off[sb] + fab_index(L.boxes[sb], M.ng, M.ncomp, comp, xw[0], xw[1], xw[2])];
-    }
-    return p[fab_index(B, M.ng, M.ncomp, comp, x[0], x[1], x[2])];
-  };
-  double g;
-  if (cls == 2) {
-    int in[3] = {q[0], q[1], q[2]};
-    in[dir] += s;
-    const double v = (phi_at(in) - A.pmin) * A.invd;
-    g = (A.bc[dir] == PA_BC_REFLECT_ODD) ? -v : v;
-  } else {
-    bool ok = true;
-    double coef[4];
-    const int NX = cf_normal_coef(n[dir], A.ratio, coef);
-    double bv;
-    const long long cpo = (Pl.use_cp && L.cp) ? L.cpoff[ef] : -1;
-    if (PATCH || cpo >= 0) {  // the same masks, the coarse values from the face's patch (its ring of two coarse cells covers the edge ghosts)
-      const int xf[1] = {MC.xform};
-      double b1[1];
-      cf_interp_patch<1>(cf_masks(L, q, dir, A.ratio) | 1u, cpz + cpo, B, sd, MC, q, dir, xf, ok, b1);
-      bv = b1[0];
-    } else {
-      bv = cf_bndry_value(L, LC, MC, ccomp, q, dir, A.ratio, ok);  // MC carries the affine view
-    }
-    if (!ok) atomicAdd(nbad, 1);
-    double tmp = 0.0;
-    for (int m = 1; m < NX; ++m) {
-      int pc[3] = {q[0], q[1], q[2]};
-      pc[dir] += s * m;
-      tmp += ((phi_at(pc) - A.pmin) * A.invd) * coef[m];
-    }
-    g = tmp;
-    g += bv * coef[0];
-  }
-  const int t0 = (dir == 0) ? 1 : 0, t1 = (dir == 2) ? 1 : 2;
-  cgz[L.cgoff[ef] + (long long)(q[t1] - B.lo[t1] + 1) * (B.hi[t0] - B.lo[t0] + 3) + (q[t0] - B.lo[t0] + 1)] = g;
-}
-
 // the level's compact ghost arrays, allocated on first use (a cache of the level object)
 static int level_cg(pa_ctx* ctx, const pa_level* Lc, int nsets = 1) {
   pa_level* L = const_cast<pa_level*>(Lc);
@@ -1619,6 +1661,53 @@ static int level_ncg(pa_ctx* ctx, const pa_level* Lc) {
   return 0;
 }
 static long long cp_stride(const pa_level* L) { return std::max<long long>(L->cp_total, 8); }
+// the level's ring items (k_find_ring), built on first use: count, then fill; sorted by (face, position) so that neighbouring threads
+// touch neighbouring cells
+static int level_ring(pa_ctx* ctx, const pa_level* Lc) {
+  pa_level* L = const_cast<pa_level*>(Lc);
+  if (L->nring >= 0) return 0;
+  if (L->nsfboxes == 0 || L->sfaces.empty()) { L->nring = 0; return 0; }
+  int* d_count = nullptr;
+  auto fail = [&](const char* what) {
+    if (d_count) (void)hipFree(d_count);
+    if (L->d_ring) { (void)hipFree(L->d_ring); L->d_ring = nullptr; }
+    (void)hipGetLastError();
+    return pa_fail(ctx, std::string("ring list: ") + what);
+  };
+  if (hipMalloc(&d_count, sizeof(int)) != hipSuccess) return fail("device allocation failed");
+  const long long nt = 4LL * (L->maxn[0] + L->maxn[1] + L->maxn[2]);
+  int n = 0;
+  for (int pass = 0; pass < 2; ++pass) {
+    if (pass == 1) {
+      if (n == 0) break;
+      if (hipMalloc(&L->d_ring, sizeof(RingItem) * (size_t)n) != hipSuccess) { L->d_ring = nullptr; return fail("device allocation failed"); }
+    }
+    if (hipMemsetAsync(d_count, 0, sizeof(int), ctx->stream) != hipSuccess) return fail("memset failed");
+    for (int y0 = 0; y0 < L->nsfboxes; y0 += 65535)
+      hipLaunchKernelGGL(k_find_ring, dim3((unsigned)((nt + 255) / 256), (unsigned)std::min(65535, L->nsfboxes - y0)), dim3(256), 0, ctx->stream, L->view, L->d_sfboxes + y0,
+                         L->nsfboxes - y0, pass ? (RingItem*)L->d_ring : nullptr, d_count, n);
+    int m = 0;
+    if (hipMemcpyAsync(&m, d_count, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return fail("reading the count failed");
+    if (pass == 1 && m != n) return fail("the two passes disagree");
+    n = m;
+  }
+  (void)hipFree(d_count);
+  d_count = nullptr;
+  if (n > 1) {
+    std::vector<RingItem> h((size_t)n);
+    if (hipMemcpy(h.data(), L->d_ring, sizeof(RingItem) * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) return fail("download failed");
+    std::sort(h.begin(), h.end(), [](const RingItem& a, const RingItem& b) {
+      if (a.ef != b.ef) return a.ef < b.ef;
+      if (a.q[2] != b.q[2]) return a.q[2] < b.q[2];
+      if (a.q[1] != b.q[1]) return a.q[1] < b.q[1];
+      return a.q[0] < b.q[0];
+    });
+    if (hipMemcpy(L->d_ring, h.data(), sizeof(RingItem) * (size_t)n, hipMemcpyHostToDevice) != hipSuccess) return fail("upload failed");
+  }
+  L->nring = n;
+  return 0;
+}
+
 
 // ---- coarse patches (DLevelView::cp, pa_internal.h): one thread per patch cell fetches the coarse value through the owner
 // map of the coarse level (or of this rank's coarse-source copy) -- 1/4 of the fine face cells, once, instead of every
@@ -2116,9 +2205,9 @@ int pa_gradcurv_prep_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int comp, 
   const bool use_cp = cpatch_on();  // the patches are gathered with the faces (phase 1) and still hold the coarse phi when the ring runs (phase 2)
   for (int l0 = 0; l0 < nlev; l0 += PA_MAXB) {
     if (use_cp && (phase & 1) && cpatch_launch(ctx, l0, std::min(nlev, l0 + PA_MAXB), phi, crse, ccomp, 0, nslots, 1)) return 1;  // before P.L = L->view picks up cp
-    LevBatch<PrepLev> Bf, Br;
+    LevBatch<PrepLev> Bf;
     const pa_level* batch_lev[PA_MAXB] = {};
-    long long ntf = 0, ntr = 0;
+    long long ntf = 0;
     for (int l = l0; l < nlev && l < l0 + PA_MAXB; ++l) {
       const pa_level* L = phi[l]->lev;
       if (L->boxes.empty()) continue;
@@ -2137,10 +2226,8 @@ int pa_gradcurv_prep_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int comp, 
       P.wg = (const int2*)L->d_sfwg; P.nwg = L->nsfwg; P.sfboxes = L->d_sfboxes;
       const long long n0 = L->maxn[0], n1 = L->maxn[1], n2 = L->maxn[2];
       ntf = std::max(ntf, std::max(n1 * n2, std::max(n0 * n2, n0 * n1)));
-      ntr = std::max(ntr, 4 * (n0 + n1 + n2));
       batch_lev[Bf.n] = L;
       Bf.a[Bf.n] = P; Bf.ycum[Bf.n + 1] = Bf.ycum[Bf.n] + (int)L->sfaces.size(); ++Bf.n;
-      Br.a[Br.n] = P; Br.ycum[Br.n + 1] = Br.ycum[Br.n] + L->nsfboxes; ++Br.n;
     }
     if (!Bf.n) continue;
     ProfScope prof(ctx, PA_TAG_BC);
@@ -2148,7 +2235,7 @@ int pa_gradcurv_prep_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int comp, 
     for (int q = 0; q < Bf.n; ++q) all_patch = all_patch && (Bf.a[q].use_cp || !Bf.a[q].A.has_crse);
     unsigned nwgf = 0;
     for (int q = 0; q < Bf.n; ++q) nwgf += (unsigned)Bf.a[q].nwg;
-    const dim3 gf(nwgf, 1, (unsigned)nslots), gr((unsigned)((ntr + 255) / 256), (unsigned)Br.ycum[Br.n], (unsigned)nslots);
+    const dim3 gf(nwgf, 1, (unsigned)nslots);
     // round 6: the faces from the levels' chunk records (k_prep_faces_chunks).  PA_FACE_CHUNKS=0 (read per pass): the per-cell kernel
     LevChunks Ck;
     Ck.w0[0] = 0;
@@ -2159,14 +2246,33 @@ int pa_gradcurv_prep_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int comp, 
       Ck.ck[q] = Lq->d_sfchunk;
       Ck.w0[q + 1] = Ck.w0[q] + (unsigned)Lq->nsfchunk;
     }
+    // the ring items of the batch's levels (level_ring): with the faces' launch when both are asked for and the ring reads its
+    // neighbours in place (one rank), else a launch of their own.  PA_RING_APART=1 (read per pass): always their own launch
+    LevRings Rg, Rnone;
+    Rg.w0[0] = 0;
+    for (int q = 0; q <= PA_MAXB; ++q) Rnone.w0[q] = 0;
+    for (int q = 0; q < PA_MAXB; ++q) { Rnone.it[q] = nullptr; Rnone.n[q] = 0; }
+    if (phase & 2)
+      for (int q = 0; q < Bf.n; ++q) {
+        const pa_level* Lq = batch_lev[q];
+        if (level_ring(ctx, Lq)) return 1;
+        Rg.it[q] = (const RingItem*)Lq->d_ring;
+        Rg.n[q] = (unsigned)Lq->nring;
+        Rg.w0[q + 1] = Rg.w0[q] + (unsigned)((Lq->nring + 255) / 256);
+      }
+    // (few items -- large faces -- hide under the faces: headline 5.913 -> 5.895 ms per pass; the long lists of a BoxArray of many small boxes
+    // are latency-bound work that wants its own launch at its own occupancy: irregular hierarchy 6.39 against 6.48 ms merged)
+    const char* rae = getenv("PA_RING_APART");
+    const bool ring_with_faces = (phase & 1) && (phase & 2) && !(phase & 8) && chunks && direct && (rae ? !atoi(rae) : Rg.w0[Bf.n] * 8u <= Ck.w0[Bf.n]);
     if ((phase & 1) && chunks) {
-      const dim3 gc(Ck.w0[Bf.n], 1, (unsigned)nslots);
+      const LevRings& Rk = ring_with_faces ? Rg : Rnone;
+      const dim3 gc(Rk.w0[Bf.n] + Ck.w0[Bf.n], 1, (unsigned)nslots);
       if (phase & 8) {
-        if (all_patch) hipLaunchKernelGGL((k_prep_faces_chunks<true, true>), gc, dim3(256), 0, ctx->stream, Bf, Ck, ctx->d_flags, sk);
-        else hipLaunchKernelGGL((k_prep_faces_chunks<false, true>), gc, dim3(256), 0, ctx->stream, Bf, Ck, ctx->d_flags, sk);
+        if (all_patch) hipLaunchKernelGGL((k_prep_faces_chunks<true, true>), gc, dim3(256), 0, ctx->stream, Bf, Ck, Rk, ctx->d_flags, sk);
+        else hipLaunchKernelGGL((k_prep_faces_chunks<false, true>), gc, dim3(256), 0, ctx->stream, Bf, Ck, Rk, ctx->d_flags, sk);
       } else {
-        if (all_patch) hipLaunchKernelGGL((k_prep_faces_chunks<true, false>), gc, dim3(256), 0, ctx->stream, Bf, Ck, ctx->d_flags, sk);
-        else hipLaunchKernelGGL((k_prep_faces_chunks<false, false>), gc, dim3(256), 0, ctx->stream, Bf, Ck, ctx->d_flags, sk);
+        if (all_patch) hipLaunchKernelGGL((k_prep_faces_chunks<true, false>), gc, dim3(256), 0, ctx->stream, Bf, Ck, Rk, ctx->d_flags, sk);
+        else hipLaunchKernelGGL((k_prep_faces_chunks<false, false>), gc, dim3(256), 0, ctx->stream, Bf, Ck, Rk, ctx->d_flags, sk);
       }
     } else if ((phase & 1) && (phase & 8)) {
       if (all_patch) hipLaunchKernelGGL((k_prep_faces<true, true>), gf, dim3(256), 0, ctx->stream, Bf, ctx->d_flags, sk);
@@ -2175,11 +2281,12 @@ int pa_gradcurv_prep_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int comp, 
       if (all_patch) hipLaunchKernelGGL(k_prep_faces<true>, gf, dim3(256), 0, ctx->stream, Bf, ctx->d_flags, sk);
       else hipLaunchKernelGGL(k_prep_faces<false>, gf, dim3(256), 0, ctx->stream, Bf, ctx->d_flags, sk);
     }
-    if (phase & 2) {
-      if (all_patch && direct) hipLaunchKernelGGL((k_prep_ring<true, true>), gr, dim3(256), 0, ctx->stream, Br, ctx->d_flags, sk);
-      else if (direct) hipLaunchKernelGGL((k_prep_ring<false, true>), gr, dim3(256), 0, ctx->stream, Br, ctx->d_flags, sk);
-      else if (all_patch) hipLaunchKernelGGL(k_prep_ring<true>, gr, dim3(256), 0, ctx->stream, Br, ctx->d_flags, sk);
-      else hipLaunchKernelGGL(k_prep_ring<false>, gr, dim3(256), 0, ctx->stream, Br, ctx->d_flags, sk);
+    if ((phase & 2) && !ring_with_faces && Rg.w0[Bf.n] > 0) {
+      const dim3 gr(Rg.w0[Bf.n], 1, (unsigned)nslots);
+      if (all_patch && direct) hipLaunchKernelGGL((k_prep_ring<true, true>), gr, dim3(256), 0, ctx->stream, Bf, Rg, ctx->d_flags, sk);
+      else if (direct) hipLaunchKernelGGL((k_prep_ring<false, true>), gr, dim3(256), 0, ctx->stream, Bf, Rg, ctx->d_flags, sk);
+      else if (all_patch) hipLaunchKernelGGL(k_prep_ring<true>, gr, dim3(256), 0, ctx->stream, Bf, Rg, ctx->d_flags, sk);
+      else hipLaunchKernelGGL(k_prep_ring<false>, gr, dim3(256), 0, ctx->stream, Bf, Rg, ctx->d_flags, sk);
     }
   }
   PA_HIP(hipGetLastError());
@@ -2567,10 +2674,17 @@ int pa_gradcurv_fix_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, 
         if (all_patch) hipLaunchKernelGGL((k_faces_curv_both<true>), gboth, dim3(256), 0, ctx->stream, Bt, ctx->d_flags, sk, nwgf);
         else hipLaunchKernelGGL((k_faces_curv_both<false>), gboth, dim3(256), 0, ctx->stream, Bt, ctx->d_flags, sk, nwgf);
         both_done = true;
-      } else if (chunks) {  // round 6: the face interiors from the levels' chunk records
-        const dim3 gc(Ck.w0[Bt.n], 1, (unsigned)nslots);
-        if (all_patch) hipLaunchKernelGGL((k_faces_fix_chunks<true>), gc, dim3(256), 0, ctx->stream, Bt, Ck, ctx->d_flags, sk);
-        else hipLaunchKernelGGL((k_faces_fix_chunks<false>), gc, dim3(256), 0, ctx->stream, Bt, Ck, ctx->d_flags, sk);
+      } else if (chunks) {  // round 6: the face interiors from the levels' chunk records, the perimeters' work tables in front of them
+        // ... when they are few next to the interiors (large faces: headline 5.906 -> 5.870 ms per pass); the many short perimeters of small
+        // faces run better as their own launch with their own register budget (irregular hierarchy: 6.50 against 6.60 ms merged).
+        // PA_FIX_PERIM_APART=1 / 0 (read per pass): never / always merged
+        const char* pae = getenv("PA_FIX_PERIM_APART");
+        const bool with_perim = ptab_ok && (pae ? !atoi(pae) : npt * 8u <= Ck.w0[Bt.n]);
+        const unsigned np = with_perim ? npt : 0u;
+        const dim3 gc(np + Ck.w0[Bt.n], 1, (unsigned)nslots);
+        if (all_patch) hipLaunchKernelGGL((k_faces_fix_chunks<true>), gc, dim3(256), 0, ctx->stream, Bt, Ck, ctx->d_flags, sk, np);
+        else hipLaunchKernelGGL((k_faces_fix_chunks<false>), gc, dim3(256), 0, ctx->stream, Bt, Ck, ctx->d_flags, sk, np);
+        both_done = with_perim;
       } else if (all_patch) hipLaunchKernelGGL((k_faces_curv_fast<1, true>), gfast, dim3(256), 0, ctx->stream, Bt, ctx->d_flags, SlowList(), sk);
       else hipLaunchKernelGGL((k_faces_curv_fast<1, false>), gfast, dim3(256), 0, ctx->stream, Bt, ctx->d_flags, SlowList(), sk);
     }

@@ -207,6 +207,8 @@ struct pa_level {
   int npfwg = 0;
   SfChunk* d_sfchunk = nullptr;  // the chunk records of the level's special faces (round 6)
   int nsfchunk = 0;
+  void* d_ring = nullptr;   // RingItem (pa_fused.hip): the edge ghost cells whose resolved progress variable goes into a face's ring, built on first use
+  int nring = -1;           // -1: not built yet
   void* d_irr = nullptr;    // int4 {box, i, j, k}
   int nirr = -1;            // -1: not built yet
   int nremote = 0;          // boxes of this level owned by other ranks (pa_level_create_sharded)
