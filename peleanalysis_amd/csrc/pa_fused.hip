@@ -2669,7 +2669,7 @@ int pa_gradcurv_fix_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, 
       bool ptab_ok = !side && !(getenv("PA_FIX_PTAB") && !atoi(getenv("PA_FIX_PTAB")));
       unsigned npt = 0;
       for (int q = 0; q < Bt.n; ++q) { ptab_ok = ptab_ok && Bt.a[q].pwg && Bt.a[q].npwg > 0; npt += (unsigned)Bt.a[q].npwg; }
-      if (ptab_ok && both_on) {
+      if (ptab_ok && both_on && !chunks) {
         const dim3 gboth(nwgf + npt, 1, (unsigned)nslots);
         if (all_patch) hipLaunchKernelGGL((k_faces_curv_both<true>), gboth, dim3(256), 0, ctx->stream, Bt, ctx->d_flags, sk, nwgf);
         else hipLaunchKernelGGL((k_faces_curv_both<false>), gboth, dim3(256), 0, ctx->stream, Bt, ctx->d_flags, sk, nwgf);
@@ -2679,7 +2679,7 @@ int pa_gradcurv_fix_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, 
         // faces run better as their own launch with their own register budget (irregular hierarchy: 6.50 against 6.60 ms merged).
         // PA_FIX_PERIM_APART=1 / 0 (read per pass): never / always merged
         const char* pae = getenv("PA_FIX_PERIM_APART");
-        const bool with_perim = ptab_ok && (pae ? !atoi(pae) : npt * 8u <= Ck.w0[Bt.n]);
+        const bool with_perim = ptab_ok && (pae ? !atoi(pae) : (both_on || npt * 8u <= Ck.w0[Bt.n]));  // (a rank's share of a sharded hierarchy: two short chains, always together)
         const unsigned np = with_perim ? npt : 0u;
         const dim3 gc(np + Ck.w0[Bt.n], 1, (unsigned)nslots);
         if (all_patch) hipLaunchKernelGGL((k_faces_fix_chunks<true>), gc, dim3(256), 0, ctx->stream, Bt, Ck, ctx->d_flags, sk, np);
