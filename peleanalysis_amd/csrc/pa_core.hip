@@ -24,20 +24,53 @@ extern "C" int pa_version(void) { return 100; }
 // against 0.61 for 64 of them, four boxes of 256 x 128 x 128 on four XCDs.  Null when the order-2 arithmetic (every box takes
 // the tile count of the largest, boxes in groups of eight) launches at most 3 % more workgroups than the queues are long and
 // the caller does not insist -- the regular tilings keep the launch they were tuned on.
-const WgTab* pa_sweep_wgtab(const pa_level* L, int cls, int tw, int mty, int kseg, bool force) {
-  const long long key = ((long long)cls << 56) | ((long long)(force ? 1 : 0) << 52) | ((long long)tw << 40) | ((long long)mty << 24) | (long long)kseg;
+static int host_owner(const pa_level* L, int i, int j, int k);
+// part (round 6, sharded levels): 0 = every tile; 1 = the EARLY tiles, 2 = the rest.  A tile is early when every cell it reads
+// outside its own box -- two cells around the tile, clipped to the FAB -- is a valid cell of a box THIS RANK owns: the local
+// FillBoundary alone completes its input, so its sweep can start while the cross-rank exchange and the ghost preparation that
+// follows it (coarse patches, special faces, ring) are still under way.  Tables of a part list tiles one by one (always built).
+const WgTab* pa_sweep_wgtab(const pa_level* L, int cls, int tw, int mty, int kseg, bool force, int part) {
+  if (part) force = true;
+  const long long key = ((long long)cls << 56) | ((long long)part << 54) | ((long long)(force ? 1 : 0) << 52) | ((long long)tw << 40) | ((long long)mty << 24) | (long long)kseg;
   auto it = L->wgtabs.find(key);
-  if (it != L->wgtabs.end()) return it->second->d ? it->second.get() : nullptr;
+  if (it != L->wgtabs.end()) return (it->second->d || part) ? it->second.get() : nullptr;
   std::unique_ptr<WgTab> T(new WgTab());
   struct Chunk { int n, box, t0; };
   std::vector<std::pair<int, int>> bt;  // (tiles, box)
+  std::vector<std::vector<int>> sel;    // part != 0: the tiles of bt[i] that belong to the part
   long long real = 0;
   int tmax = 0;
   for (int b = 0; b < (int)L->boxes.size(); ++b) {
     const DBox& B = L->boxes[b];
     const int nx = B.hi[0] - B.lo[0] + 1, ny = B.hi[1] - B.lo[1] + 1, nz = B.hi[2] - B.lo[2] + 1;
     if (cls != 2 && (nx <= 32) != (cls == 1)) continue;
-    const int t = ((nx + tw - 1) / tw) * ((ny + mty - 1) / mty) * ((nz + kseg - 1) / kseg);
+    const int tx = (nx + tw - 1) / tw, ty = (ny + mty - 1) / mty, tz = (nz + kseg - 1) / kseg;
+    int t = tx * ty * tz;
+    if (part) {
+      std::vector<int> mine;
+      for (int id = 0; id < t; ++id) {
+        const int bx = id % tx, by = (id / tx) % ty, bz = id / (tx * ty);
+        int lo[3] = {B.lo[0] + bx * tw, B.lo[1] + by * mty, B.lo[2] + bz * kseg}, hi[3];
+        hi[0] = std::min(lo[0] + tw - 1, B.hi[0]); hi[1] = std::min(lo[1] + mty - 1, B.hi[1]); hi[2] = std::min(lo[2] + kseg - 1, B.hi[2]);
+        bool early = true;
+        for (int d = 0; d < 3 && early; ++d)
+          for (int side = 0; side < 2 && early; ++side) {
+            // the slab of the read region beyond face (d, side) of the box (empty when the tile does not come within two cells of it)
+            int slo[3], shi[3];
+            for (int q = 0; q < 3; ++q) { slo[q] = std::max(lo[q] - 2, B.lo[q] - 2); shi[q] = std::min(hi[q] + 2, B.hi[q] + 2); }
+            if (side == 0) shi[d] = std::min(shi[d], B.lo[d] - 1); else slo[d] = std::max(slo[d], B.hi[d] + 1);
+            if (slo[d] > shi[d]) continue;
+            for (int k = slo[2]; k <= shi[2] && early; ++k)
+              for (int j = slo[1]; j <= shi[1] && early; ++j)
+                for (int i = slo[0]; i <= shi[0]; ++i)
+                  if (host_owner(L, i, j, k) < 0) { early = false; break; }
+          }
+        if (early == (part == 1)) mine.push_back(id);
+      }
+      t = (int)mine.size();
+      if (t == 0) continue;
+      sel.push_back(std::move(mine));
+    }
     bt.push_back({t, b});
     real += t;
     tmax = std::max(tmax, t);
@@ -47,11 +80,12 @@ const WgTab* pa_sweep_wgtab(const pa_level* L, int cls, int tw, int mty, int kse
     static const int chunk_env = [] { const char* e = getenv("PA_SWEEP_CHUNK"); return e ? atoi(e) : 0; }();  // tiles per chunk (0: from the level's size)
     const int cap = chunk_env > 0 ? chunk_env : (int)std::max<long long>(8, std::min<long long>(64, real / 32));
     std::vector<Chunk> ch;
-    for (const auto& p : bt) {
+    for (size_t bi = 0; bi < bt.size(); ++bi) {
+      const auto& p = bt[bi];
       const int parts = (p.first + cap - 1) / cap;
       for (int q = 0; q < parts; ++q) {
         const int a = (int)((long long)p.first * q / parts), e = (int)((long long)p.first * (q + 1) / parts);
-        ch.push_back({e - a, p.second, a});
+        ch.push_back({e - a, part ? (int)bi : p.second, a});  // part: box = index into bt / sel, t0 = position in its tile list
       }
     }
     std::stable_sort(ch.begin(), ch.end(), [](const Chunk& a, const Chunk& b) { return a.n > b.n; });
@@ -70,7 +104,10 @@ const WgTab* pa_sweep_wgtab(const pa_level* L, int cls, int tw, int mty, int kse
       for (int q = 0; q < 8; ++q) {
         long long s = 0;
         for (const Chunk& c : queue[q])
-          for (int t = 0; t < c.n; ++t, ++s) { tab[(size_t)(2 * (8 * s + q))] = c.box; tab[(size_t)(2 * (8 * s + q) + 1)] = c.t0 + t; }
+          for (int t = 0; t < c.n; ++t, ++s) {
+            tab[(size_t)(2 * (8 * s + q))] = part ? bt[(size_t)c.box].second : c.box;
+            tab[(size_t)(2 * (8 * s + q) + 1)] = part ? sel[(size_t)c.box][(size_t)(c.t0 + t)] : c.t0 + t;
+          }
         for (; s < qlen; ++s) tab[(size_t)(2 * (8 * s + q))] = -1;
       }
       if (hipMalloc(&T->d, sizeof(int) * tab.size()) == hipSuccess && hipMemcpy(T->d, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice) == hipSuccess) {
@@ -84,7 +121,7 @@ const WgTab* pa_sweep_wgtab(const pa_level* L, int cls, int tw, int mty, int kse
   }
   const WgTab* raw = T.get();
   L->wgtabs[key] = std::move(T);
-  return raw->d ? raw : nullptr;
+  return (raw->d || part) ? raw : nullptr;  // a part's table may be empty (n == 0): the caller launches nothing for it
 }
 
 extern "C" pa_ctx* pa_ctx_create(int device, void* hip_stream) {
@@ -194,6 +231,27 @@ static int host_classify(const pa_level* L, int i, int j, int k) {
   }
   const int o = L->owner[((size_t)m[2] * L->mn[1] + m[1]) * L->mn[0] + m[0]];
   return (o != -1) ? 0 : 1;  // <= -2: valid cell of a box owned by another rank
+}
+
+// the owner-map entry of a cell (through periodic images): >= 0 a box of this rank, <= -2 a box of another rank, -1 none / outside a wall
+static int host_owner(const pa_level* L, int i, int j, int k) {
+  int p[3] = {i, j, k};
+  for (int d = 0; d < 3; ++d) {
+    const int len = L->domhi[d] - L->domlo[d] + 1;
+    if (p[d] < L->domlo[d] || p[d] > L->domhi[d]) {
+      if (!L->is_per[d]) return -1;
+      while (p[d] < L->domlo[d]) p[d] += len;
+      while (p[d] > L->domhi[d]) p[d] -= len;
+    }
+  }
+  int m[3];
+  for (int d = 0; d < 3; ++d) {
+    const int r = p[d] - L->mlo[d];
+    if (r < 0) return -1;
+    m[d] = r / L->g;
+    if (m[d] >= L->mn[d]) return -1;
+  }
+  return L->owner[((size_t)m[2] * L->mn[1] + m[1]) * L->mn[0] + m[0]];
 }
 
 // true if face (d, side) of box B (any box of the level, local or not) has a ghost cell that is not a valid cell of the

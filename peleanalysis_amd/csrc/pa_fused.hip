@@ -2304,10 +2304,10 @@ static void sweep_groups(int l, const pa_level* L, std::vector<SweepGroup>& out)
   out.push_back({l, L->d_blist + L->nwide, L->nnarrow, {L->nmax[0], L->nmax[1], L->nmax[2]}});
 }
 
-static const WgTab* sweep_wgtab(const pa_level* L, const SweepGroup& g, int tw, int mty, int kseg) {
+static const WgTab* sweep_wgtab(const pa_level* L, const SweepGroup& g, int tw, int mty, int kseg, int part = 0) {
   const char* e = getenv("PA_SWEEP_WGTAB");  // read per pass (tools/ab_driver.py)
-  if ((e && !atoi(e)) || g.n <= 0) return nullptr;
-  return pa_sweep_wgtab(L, !g.list ? 2 : (g.list == L->d_blist ? 0 : 1), tw, mty, kseg, false);
+  if (!part && ((e && !atoi(e)) || g.n <= 0)) return nullptr;
+  return pa_sweep_wgtab(L, !g.list ? 2 : (g.list == L->d_blist ? 0 : 1), tw, mty, kseg, false, part);
 }
 
 // the sweep with exact normals (the level's compact ghost arrays must be current: pa_gradcurv_prep_level)
@@ -2341,6 +2341,9 @@ int pa_gradcurv_level_cg(pa_ctx* ctx, const pa_mf* phi, int pcomp, double pmin, 
 // gout (pa_curvature_run with options): the GOUT variants of the sweeps -- Progress, K, N at out components ocomp .. ocomp + 4, the
 // cell-centred gradient of c at components 0 .. 2 of gout[l] (any ghost width).  Only as all-levels launches:
 // pa_gradcurv_gout_ok says whether this hierarchy takes them (else the caller runs pass by pass).
+// the sweeps of this hierarchy can be split into early and late tiles: every group of wide boxes goes through the all-levels launches
+bool pa_gradcurv_gout_ok(int nlev, pa_mf* const* phi);
+bool pa_gradcurv_parts_ok(int nlev, pa_mf* const* phi) { return pa_gradcurv_gout_ok(nlev, phi); }
 bool pa_gradcurv_gout_ok(int nlev, pa_mf* const* phi) {
   static const int batch_env = [] { const char* e = getenv("PA_SWEEP_BATCH"); return e ? atoi(e) : 1; }();
   static const bool knobs = getenv("PA_MARCH") || getenv("PA_DBG") || getenv("PA_MTY") || getenv("PA_PAIR") || getenv("PA_KSEG");
@@ -2354,9 +2357,12 @@ bool pa_gradcurv_gout_ok(int nlev, pa_mf* const* phi) {
   return all.size() <= 8 * PA_MAXB;  // (the launches come in chunks of PA_MAXB groups)
 }
 
+// part (a sharded hierarchy's pass, pa_pipeline.hip): 1 = only the EARLY tiles of the wide boxes (pa_sweep_wgtab: their input is
+// complete after the local FillBoundary), 2 = the other tiles and every narrow box; 0 = everything
 int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, double pmin, double pmax, pa_mf* const* out, int ocomp, double thr, int slot,
-                          int nslots, const double* prog, const double* pmins, const double* pmaxs, pa_mf* const* gout) {
+                          int nslots, const double* prog, const double* pmins, const double* pmaxs, pa_mf* const* gout, int part) {
   const bool clip = thr >= 0.0;
+  if (part && !pa_gradcurv_parts_ok(nlev, phi)) return pa_fail(ctx, "pa_gradcurv_levels_cg: this hierarchy's sweeps cannot be split into early and late tiles");
   if (nslots > 1 && (slot != 0 || !prog || !pmins || !pmaxs)) return pa_fail(ctx, "pa_gradcurv_levels_cg: component slots need slot 0 and the progress ranges");
   if (gout && (nslots != 1 || slot != 0 || !pa_gradcurv_gout_ok(nlev, phi))) return pa_fail(ctx, "pa_gradcurv_levels_cg: the G-output sweeps take one component of a hierarchy pa_gradcurv_gout_ok accepts");
   static const int batch_env = [] { const char* e = getenv("PA_SWEEP_BATCH"); return e ? atoi(e) : 1; }();
@@ -2450,12 +2456,13 @@ int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, d
       A.nboxes = (int)nb;
       A.txy_max = ((lv[q].dims[0] + 63) / 64) * ((lv[q].dims[1] + mty - 1) / mty);
       A.tiles_max = (int)g.x;
-      const WgTab* wt = sweep_wgtab(L, lv[q], 64, mty, A.kseg);
+      const WgTab* wt = sweep_wgtab(L, lv[q], 64, mty, A.kseg, part);
       if (wt) A.wgtab = wt->d;
       if (gout) { A.gdata = gout[l]->data; A.goff = gout[l]->d_off; A.gng = gout[l]->ng; }
       S.A[q] = A;
-      S.wg0[q + 1] = S.wg0[q] + (wt ? wt->n : g.x * 8u * ((nb + 7u) / 8u));
+      S.wg0[q + 1] = S.wg0[q] + (wt ? wt->n : (part ? 0u : g.x * 8u * ((nb + 7u) / 8u)));  // (a part's table may be empty)
     }
+    if (S.wg0[S.n] == 0) continue;
     ProfScope prof(ctx, PA_TAG_GRADCURV);
     S.prog = nslots > 1 ? prog : nullptr;
     const dim3 grid(S.wg0[S.n], (unsigned)nslots);
@@ -2480,6 +2487,7 @@ int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, d
     }
     PA_HIP(hipGetLastError());
   }
+  if (part == 1) return 0;  // the narrow boxes and the groups outside the all-levels launches go with the late tiles
   // the narrow groups (boxes at most 32 cells wide) of all levels in one launch too
   std::vector<SweepGroup> nar;
   {

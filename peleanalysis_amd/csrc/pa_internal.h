@@ -256,7 +256,7 @@ bool pa_face_is_special(const pa_level* L, const DBox& B, int d, int side);
 // hipFree per call of pa_curvature_run cost more than the kernels it served
 // role: two work multifabs of the same shape that are alive at the same time take different roles
 struct pa_mf* pa_level_scratch(pa_ctx* ctx, const pa_level* L, int ncomp, int ng, int role = 0);
-const WgTab* pa_sweep_wgtab(const pa_level* L, int cls, int tw, int mty, int kseg, bool force);
+const WgTab* pa_sweep_wgtab(const pa_level* L, int cls, int tw, int mty, int kseg, bool force, int part = 0);
 int pa_host_classify(const pa_level* L, int i, int j, int k);
 
 struct pa_mf {

@@ -20,7 +20,8 @@ int pa_gradcurv_prep_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int comp, 
 int pa_gradcurv_level_cg(pa_ctx* ctx, const pa_mf* phi, int pcomp, double pmin, double pmax, pa_mf* out, int ocomp, double thr = -1.0, int slot = 0);
 bool pa_gradcurv_gout_ok(int nlev, pa_mf* const* phi);
 int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, double pmin, double pmax, pa_mf* const* out, int ocomp, double thr = -1.0, int slot = 0,
-                          int nslots = 1, const double* prog = nullptr, const double* pmins = nullptr, const double* pmaxs = nullptr, pa_mf* const* gout = nullptr);
+                          int nslots = 1, const double* prog = nullptr, const double* pmins = nullptr, const double* pmaxs = nullptr, pa_mf* const* gout = nullptr, int part = 0);
+bool pa_gradcurv_parts_ok(int nlev, pa_mf* const* phi);
 int pa_gradcurv_fix_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, const pa_mf* const* crse_n, int cncomp0, const int32_t bc[3], double pmin, double pmax,
                            pa_mf* const* out, int ncomp0, int kcomp, double thr = -1.0, int nslots = 1, const double* prog = nullptr, int cn_z = 8,
                            const pa_mf* const* crse_phi = nullptr, int cpcomp = 0);
@@ -327,6 +328,25 @@ static int fused_passes_dist(pa_ctx* ctx, int nlev, pa_mf* const* state, int com
       PA_TRY(pa_fill_boundary_local_batch(ctx, nlev, state, comp, 1, 2));
     }
     if (fb_side) PA_HIP(hipEventRecord(ctx->sync_evs[1], C));
+    // round 6: EARLY TILES (PA_DIST_EARLY=1, read per pass; OFF by default).  A tile of the sweep whose read region touches only valid
+    // cells of this rank's own boxes has its input complete once the LOCAL FillBoundary is done; those tiles (pa_sweep_wgtab part 1:
+    // 30 % of an 8-way share of the headline) are swept on the side stream right behind it -- under exchange A, the patch gather, the
+    // face and ring preparation -- and only the tiles next to another rank's box or to a special face wait for that chain.
+    // Bit-identical (tests/test_gpu_dist.py runs both), and measured with the delay-model transport on rank 0's share of 8
+    // (profiles/r06_sim8_delay.txt): 1.108 -> 1.100 ms per pass with 68-us exchanges, 1.024 -> 1.033 with 18 us + bytes / 153 GB/s,
+    // 0.955 -> 0.965 with no-op exchanges.  Why it hides so little: an eighth of the headline is 480 tiles on 256 CUs, one workgroup
+    // per CU -- two rounds of ~350 us as ONE launch, but 150 early + 330 late tiles are one round + two rounds.  It pays only where
+    // an exchange costs more than a round is long; on a hierarchy with more work per rank the rounds stop mattering.
+    const char* ete = getenv("PA_DIST_EARLY");
+    const char* dsb0 = getenv("PA_DIST_SWEEP_BATCH");
+    const bool early = fb_side && ete && atoi(ete) && (!dsb0 || atoi(dsb0) == 1) && pa_gradcurv_parts_ok(nlev, state);
+    if (early) {
+      {
+        StreamSwap sw(ctx, C);
+        PA_TRY(pa_gradcurv_levels_cg(ctx, nlev, state, comp, pmin, pmax, out, ocomp, thr, 0, 1, nullptr, nullptr, nullptr, gout, 1));
+      }
+      PA_HIP(hipEventRecord(ctx->sync_evs[2], C));
+    }
     if (xov) PA_HIP(hipStreamWaitEvent(A, ctx->sync_evs[1], 0));
     PA_TRY(pa_gradcurv_prep_levels(ctx, nlev, state, comp, crse.data(), 0, bc, pmin, pmax, xov ? 2 : 3));
     // PA_DIST_SWEEP_BATCH=1 (default): the sweeps of all levels in one launch (a rank's share of a level is 1-2 rounds of
@@ -348,7 +368,8 @@ static int fused_passes_dist(pa_ctx* ctx, int nlev, pa_mf* const* state, int com
       // 0.97 ms per pass against 1.08 / 1.05 with the split (two launches' tails + the pack / unpack kernels next to the
       // sweep): it pays only where exchange B takes longer than ~0.05-0.09 ms on the fabric, which one GPU cannot tell.
       const bool split = dsb >= 2 && xov && nlev >= 2;
-      PA_TRY(pa_gradcurv_levels_cg(ctx, split ? nlev - 1 : nlev, state, comp, pmin, pmax, out, ocomp, thr, 0, 1, nullptr, nullptr, nullptr, gout));
+      PA_TRY(pa_gradcurv_levels_cg(ctx, split ? nlev - 1 : nlev, state, comp, pmin, pmax, out, ocomp, thr, 0, 1, nullptr, nullptr, nullptr, gout, early ? 2 : 0));
+      if (early) PA_HIP(hipStreamWaitEvent(A, ctx->sync_evs[2], 0));  // the early tiles' normals go into exchange B and the fix-up too
       std::vector<XJob> nj;
       for (int l = 1; l < nlev; ++l) nj.push_back({&cs[l]->x, out[l - 1], ncomp0, csn[l], 0, 3});
       if (split) {
