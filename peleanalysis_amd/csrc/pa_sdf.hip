@@ -87,6 +87,8 @@ struct SdfGrid {  // device-side descriptor of one make_level_set3 call
   float* phi;
   unsigned long long* key;  // scratch: (float bits of phi << 32) | closest triangle
   int* ct;                  // scratch: closest triangle (-1: none)
+  V3* tv;                   // scratch: the three vertices of every triangle, gathered once per call (k_sdf_gather_tv): the sweeps' chain of
+                            // dependent loads is then neighbour's triangle -> its vertices, without the vertex indices in between
 };
 
 __device__ __forceinline__ V3 grid_point(const SdfGrid& G, int i, int j, int k) {
@@ -163,9 +165,9 @@ __device__ __forceinline__ void relax_point(const SdfGrid& G, int i, int j, int 
   // the distance to triangle ct once ct >= 0) and a triangle already tried in this call.  Skipping
   // those evaluations changes nothing in the result; after the first sweeps most neighbours share
   // the point's triangle.
-  // The loads of all candidates are issued together -- the 7 neighbours' triangles, then the vertex indices of those that will be
-  // evaluated, then their vertices -- and only the comparisons run in the reference's order: a chain of three memory latencies per
-  // point instead of up to 1 + 2 x 7 (the distances do not depend on phi; the skip rules only on the triangles).
+  // The loads of all candidates are issued together -- the 7 neighbours' triangles, then the vertices of those that will be evaluated
+  // (from the per-call gather tv: the same floats as x[tri[..]]) -- and only the comparisons run in the reference's order: a chain of
+  // two memory latencies per point instead of up to 1 + 2 x 7 (the distances do not depend on phi; the skip rules only on the triangles).
   int tried[7];
   bool ev[7];
   const int ct0 = ct;
@@ -180,18 +182,13 @@ __device__ __forceinline__ void relax_point(const SdfGrid& G, int i, int j, int 
     for (int r = 0; r < m; ++r) skip = skip || (tried[r] == t);
     ev[m] = !skip;
   }
-  unsigned vi[7][3];
+  V3 vx[7][3];
 #pragma unroll
   for (int m = 0; m < 7; ++m) {
     const long long t = ev[m] ? (long long)tried[m] : 0;  // triangle 0 exists (the sweeps run only where ntri > 0): a harmless load
 #pragma unroll
-    for (int c = 0; c < 3; ++c) vi[m][c] = G.tri[3 * t + c];
+    for (int c = 0; c < 3; ++c) vx[m][c] = G.tv[3 * t + c];
   }
-  V3 vx[7][3];
-#pragma unroll
-  for (int m = 0; m < 7; ++m)
-#pragma unroll
-    for (int c = 0; c < 3; ++c) vx[m][c] = G.x[vi[m][c]];
 #pragma unroll
   for (int m = 0; m < 7; ++m) {
     if (ev[m]) {
@@ -203,6 +200,12 @@ __device__ __forceinline__ void relax_point(const SdfGrid& G, int i, int j, int 
     G.phi[q] = phi;
     G.ct[q] = ct;
   }
+}
+
+// tv[3 t + c] = x[tri[3 t + c]] (round 6: one of the three dependent memory levels behind every point of every hyperplane, paid once)
+__global__ __launch_bounds__(256) void k_sdf_gather_tv(const SdfGrid* grids) {
+  const SdfGrid G = grids[blockIdx.y];
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < 3 * G.ntri; i += (long long)gridDim.x * 256ll) G.tv[i] = G.x[G.tri[i]];
 }
 
 // :60-85 + :169-178: one workgroup per grid, hyperplane by hyperplane
@@ -283,12 +286,17 @@ extern "C" int pa_sdf_level_set3(pa_ctx* ctx, int ngrids, const pa_sdf_grid* gri
     max_cells = std::max(max_cells, n);
     max_tri = std::max(max_tri, (long long)S.ntri);
   }
-  // scratch: descriptors + vertex counts | keys (8 B per point) | closest triangle (4 B per point)
+  // scratch: descriptors + vertex counts | keys (8 B per point) | closest triangle (4 B per point) | gathered triangle vertices (36 B per triangle)
   const size_t desc_bytes = ((size_t)ngrids * (sizeof(SdfGrid) + sizeof(long long)) + 255) / 256 * 256;
-  if (ensure_scr_sdf(ctx, desc_bytes + cells * 12 + 256)) return 1;
+  size_t tris = 0;
+  for (int g = 0; g < ngrids; ++g) tris += (size_t)grids[g].ntri;
+  const size_t tv_at = (desc_bytes + cells * 12 + 255) / 256 * 256;
+  if (ensure_scr_sdf(ctx, tv_at + tris * 3 * sizeof(V3) + 256)) return 1;
   unsigned char* base = (unsigned char*)ctx->d_scr;
   unsigned long long* keys = (unsigned long long*)(base + desc_bytes);
   int* cts = (int*)(base + desc_bytes + cells * 8);
+  V3* tvs = (V3*)(base + tv_at);
+  size_t tat = 0;
   std::vector<SdfGrid> h((size_t)ngrids);
   size_t at = 0;
   for (int g = 0; g < ngrids; ++g) {
@@ -298,6 +306,8 @@ extern "C" int pa_sdf_level_set3(pa_ctx* ctx, int ngrids, const pa_sdf_grid* gri
     for (int d = 0; d < 3; ++d) D.origin[d] = S.origin[d];
     D.dx = S.dx; D.ni = S.n[0]; D.nj = S.n[1]; D.nk = S.n[2];
     D.phi = S.phi; D.key = keys + at; D.ct = cts + at;
+    D.tv = tvs + tat;
+    tat += 3 * (size_t)S.ntri;
     at += (size_t)S.n[0] * S.n[1] * S.n[2];
   }
   std::vector<long long> hnv((size_t)ngrids);
@@ -324,6 +334,7 @@ extern "C" int pa_sdf_level_set3(pa_ctx* ctx, int ngrids, const pa_sdf_grid* gri
     hipLaunchKernelGGL(k_sdf_band, dim3(gx_tri, (unsigned)ngrids), dim3(256), 0, ctx->stream, dg, exact_band);
   }
   hipLaunchKernelGGL(k_sdf_unpack, dim3(gx_cells, (unsigned)ngrids), dim3(256), 0, ctx->stream, dg);
+  if (max_tri > 0) hipLaunchKernelGGL(k_sdf_gather_tv, dim3((unsigned)std::min<long long>((3 * max_tri + 255) / 256, 4096), (unsigned)ngrids), dim3(256), 0, ctx->stream, dg);
   static const int onewg = [] { const char* e = getenv("PA_SDF_ONEWG"); return e ? atoi(e) : 0; }();  // 1: one workgroup per grid (A/B)
   if (max_tri > 0 && onewg) hipLaunchKernelGGL(k_sdf_sweeps, dim3((unsigned)ngrids), dim3(1024), 0, ctx->stream, dg);
   if (max_tri > 0 && !onewg) {
