@@ -606,11 +606,13 @@ def secondary(ctx, torch, stream, dev, only=None, retile=1):
             it_, rs_ = C.c_int(0), C.c_double(0.0)
             if mg_env is not None:
                 os.environ["PA_SMOOTH_MG"] = mg_env
+                ctx.lib.pa_options_reload()
             for _ in range(2 if dt_s < 1e-6 else 1):
                 t0 = time.perf_counter()
                 rc_ = ctx.lib.pa_smooth_solve(ctx.h, 3, hr, 0, hs, 0, dt_s, (C.c_int32 * 3)(*bc), 1e-12, 600, C.byref(it_), C.byref(rs_))
                 msq = (time.perf_counter() - t0) * 1e3
             os.environ.pop("PA_SMOOTH_MG", None)
+            ctx.lib.pa_options_reload()
             sm[f"smoothing_time_{dt_s:g}" + ("_unpreconditioned" if mg_env == "0" else "")] = {
                 "iterations": it_.value, "rel_residual": rs_.value, "converged_to_1e-12": rc_ == 0, "ms": msq, "ms_per_iteration": msq / max(it_.value, 1),
                 "solver": "BiCGStab" if (mg_env == "0" or dt_s < 4e-6) else "BiCGStab + V(2,4) multigrid preconditioner (damped Jacobi, AMR levels + coarsened copies of level 0)"}
@@ -1017,6 +1019,7 @@ def main():
         for blk in range(16):
             v = (va, vb)[blk & 1]
             os.environ[var] = v
+            ctx.lib.pa_options_reload()  # the library reads its switches once: re-read after the flip
             step()
             barrier()
             t0 = time.perf_counter()

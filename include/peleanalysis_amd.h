@@ -44,6 +44,10 @@ void        pa_ctx_destroy(pa_ctx*);
 const char* pa_last_error(const pa_ctx*);
 int         pa_sync(pa_ctx*);
 void*       pa_ctx_stream(pa_ctx*);
+/* The library's environment switches (the PA_* table in peleanalysis_amd/csrc/pa_internal.h: pa_options) are read ONCE, when the
+ * first context is created.  A caller that changes one afterwards -- a test, an A/B measurement inside one process -- asks for a
+ * re-read with this call.  No reference counterpart (AMReX's ParmParse is read at amrex::Initialize, grad.cpp:31). */
+void        pa_options_reload(void);
 
 /* raw HBM buffers for callers without their own device allocator (vertex / triangle buffers of
  * the marching-cubes entry points, caller-owned FABs).  Copies are synchronous. */

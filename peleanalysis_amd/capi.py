@@ -76,6 +76,7 @@ def load_library() -> C.CDLL:
     pi32, pdbl = C.POINTER(C.c_int32), C.POINTER(C.c_double)
     sig = {
         "pa_version": (C.c_int, []),
+        "pa_options_reload": (None, []),
         "pa_ctx_create": (vp, [C.c_int, vp]),
         "pa_ctx_destroy": (None, [vp]),
         "pa_last_error": (C.c_char_p, [vp]),
@@ -208,6 +209,12 @@ def declared_symbols(header: Optional[str] = None) -> List[str]:
     header = header or os.path.join(os.path.dirname(_HERE), "include", "peleanalysis_amd.h")
     txt = re.sub(r"/\*.*?\*/", "", open(header).read(), flags=re.S)
     return sorted(set(re.findall(r"\b(pa_[a-z0-9_]+)\s*\(", txt)))
+
+
+def reload_options() -> None:
+    """pa_options_reload: the library reads its PA_* environment switches once (first context); a caller that changes one
+    afterwards -- a test, bench.py --ab -- asks for a re-read."""
+    load_library().pa_options_reload()
 
 
 class PaError(RuntimeError):

@@ -77,7 +77,7 @@ const WgTab* pa_sweep_wgtab(const pa_level* L, int cls, int tw, int mty, int kse
   }
   const long long launched = (long long)tmax * 8 * (((long long)bt.size() + 7) / 8);
   if (!bt.empty()) {
-    static const int chunk_env = [] { const char* e = getenv("PA_SWEEP_CHUNK"); return e ? atoi(e) : 0; }();  // tiles per chunk (0: from the level's size)
+    constexpr int chunk_env = 0;  // tiles per chunk (0: from the level's size)
     const int cap = chunk_env > 0 ? chunk_env : (int)std::max<long long>(8, std::min<long long>(64, real / 32));
     std::vector<Chunk> ch;
     for (size_t bi = 0; bi < bt.size(); ++bi) {
@@ -122,6 +122,34 @@ const WgTab* pa_sweep_wgtab(const pa_level* L, int cls, int tw, int mty, int kse
   const WgTab* raw = T.get();
   L->wgtabs[key] = std::move(T);
   return (raw->d || part) ? raw : nullptr;  // a part's table may be empty (n == 0): the caller launches nothing for it
+}
+
+static pa_options g_opt;
+static bool g_opt_read = false;
+extern "C" void pa_options_reload(void) {
+  pa_options o;
+  auto geti = [](const char* n, int def) { const char* e = getenv(n); return e ? atoi(e) : def; };
+  o.filter_exact = geti("PA_FILTER_EXACT", 0) != 0;
+  o.allow_unverified_gaussian = geti("PA_ALLOW_UNVERIFIED_GAUSSIAN", 0) != 0;
+  if (const char* e = getenv("PA_RETILE_MAX")) {
+    int v[3] = {0, 0, 0};
+    if (sscanf(e, "%d %d %d", &v[0], &v[1], &v[2]) == 3 && v[0] > 0 && v[1] > 0 && v[2] > 0)
+      for (int d = 0; d < 3; ++d) o.retile_max[d] = v[d];
+  }
+  o.fused2 = geti("PA_FUSED2", 1) != 0;
+  o.ncg = geti("PA_NCG", 1) != 0;
+  o.dist_early = geti("PA_DIST_EARLY", 0) != 0;
+  o.smooth_replicated = geti("PA_SMOOTH_REPLICATED", 0) != 0;
+  o.smooth_mg = geti("PA_SMOOTH_MG", -1);
+  o.smooth_march = geti("PA_SMOOTH_MARCH", 1) != 0;
+  o.smooth_timing = geti("PA_SMOOTH_TIMING", 0) != 0;
+  o.force_fallbacks = geti("PA_FORCE_FALLBACKS", 0) != 0;
+  g_opt = o;
+  g_opt_read = true;
+}
+const pa_options& pa_opt() {
+  if (!g_opt_read) pa_options_reload();
+  return g_opt;
 }
 
 extern "C" pa_ctx* pa_ctx_create(int device, void* hip_stream) {
@@ -976,8 +1004,7 @@ int pa_fill_boundary_local_batch_ngs(pa_ctx* ctx, int n, pa_mf* const* Ms, int c
         if (!Bt.n) continue;
         // several components: the component is a grid dimension, not a loop inside the thread -- a wave then stays inside one
         // component's pages (config 2's 10 components: 1.27 -> 1.03-1.10 ms, config 5's shape 1.58 -> 1.34-1.38).  PA_FB_COMP_Z=0: the loop
-        const char* ze = getenv("PA_FB_COMP_Z");
-        const unsigned gz = (ncomp > 1 && ncomp <= 65535 && (!ze || atoi(ze))) ? (unsigned)ncomp : 1u;
+        const unsigned gz = (ncomp > 1 && ncomp <= 65535) ? (unsigned)ncomp : 1u;
         hipLaunchKernelGGL(k_fill_boundary_regions, dim3((unsigned)mw, (unsigned)Bt.n, gz), dim3(256), 0, ctx->stream, Bt);
       }
       PA_HIP(hipGetLastError());

@@ -281,9 +281,7 @@ int pa_curvopts_level(pa_ctx* ctx, int which, const pa_mf* G, const pa_mf* u, in
   if (pc < 0 || nc < 0 || hi >= out->ncomp) return pa_fail(ctx, "pa_curvopts_level: out component range");
   if (L->boxes.empty() || !(which & 7)) return 0;
   OptArgs A{L->view, (which & 1) ? G->view : out->view, (which & 6) ? u->view : out->view, out->view, ucomp, pc, nc, kgc, src, vnc, (which & 2) ? rostc : -1, thr};
-  const char* tye = getenv("PA_OPT_TY");  // read per call (A/B): rows of 64 cells per workgroup
-  const char* kze = getenv("PA_OPT_KZ");
-  const int TY = tye ? atoi(tye) : 4, kz = std::max(1, kze ? atoi(kze) : 64);  // measured: 4 x 64 17.65 ms per headline pass, 8 x 64 18.0 (spills under 128 VGPRs), 16 x 64 25.3
+  constexpr int TY = 4, kz = 64;  // rows of 64 cells per workgroup x planes per segment; measured: 4 x 64 17.65 ms per headline pass, 8 x 64 18.0 (spills under 128 VGPRs), 16 x 64 25.3
   unsigned gx = 8;
   for (const DBox& B : L->boxes) {
     const int nx = B.hi[0] - B.lo[0] + 1, ny = B.hi[1] - B.lo[1] + 1, nz = B.hi[2] - B.lo[2] + 1;
@@ -292,10 +290,9 @@ int pa_curvopts_level(pa_ctx* ctx, int which, const pa_mf* G, const pa_mf* u, in
     gx = std::max(gx, 8u * ((ncol + 7u) / 8u) * ty);
   }
   const dim3 g(gx, (unsigned)L->boxes.size());
-  const char* yqe = getenv("PA_OPT_YQ");  // 0 (read per call, A/B): y-neighbours loaded with the plane they belong to
-  const bool yq = !(yqe && !atoi(yqe));
+  // (the y-neighbours of a plane are requested one step early, with that plane's centre value: profiles/r05_curvopts.txt)
 #define PA_OPT(W, T, Y) hipLaunchKernelGGL((k_curvopts<(W & 1) != 0, (W & 2) != 0, (W & 4) != 0, T, Y>), g, dim3(64 * T), 0, ctx->stream, A, kz)
-#define PA_OPTW(W) case W: if (!yq) PA_OPT(W, 4, false); else if (TY == 4) PA_OPT(W, 4, true); else if (TY == 16) PA_OPT(W, 16, true); else PA_OPT(W, 8, true); break;
+#define PA_OPTW(W) case W: PA_OPT(W, 4, true); break;
   switch (which & 7) {
     PA_OPTW(1) PA_OPTW(2) PA_OPTW(3) PA_OPTW(4) PA_OPTW(5) PA_OPTW(6) PA_OPTW(7)
     default: break;

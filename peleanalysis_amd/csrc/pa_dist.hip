@@ -451,7 +451,7 @@ FbLocal* pa_fb_local_plan(pa_ctx* ctx, const pa_level* L, int ng) {
   FbLocal* raw = P.get();
   L->fb_local[ng] = std::move(P);
   const int n = (int)L->boxes.size();
-  static const int on = [] { const char* e = getenv("PA_FB_REGIONS"); return e ? atoi(e) : 1; }();
+  const int on = !pa_opt().force_fallbacks;
   if (!on || n == 0) return raw;
   const auto shifts = domain_shifts(L->domlo, L->domhi, L->is_per);
   std::vector<int> regs, wgs, cand;
@@ -520,7 +520,7 @@ CpPlan* pa_cp_plan(pa_ctx* ctx, const pa_level* F, const pa_level* C) {
   std::unique_ptr<CpPlan> P(new CpPlan());
   CpPlan* raw = P.get();
   F->cp_plans[C->serial] = std::move(P);
-  static const int on = [] { const char* e = getenv("PA_CP_REGIONS"); return e ? atoi(e) : 1; }();
+  const int on = !pa_opt().force_fallbacks;
   const int nc = (int)C->boxes.size();
   if (!on || nc == 0 || F->sfaces.empty()) return raw;
   const auto shifts = domain_shifts(C->domlo, C->domhi, C->is_per);
@@ -980,12 +980,11 @@ int pa_xexchange(pa_ctx* ctx, int njobs, const XJob* jobs) {
     }
   }
   bool produced = false;
-  {  // pack + same-rank copies in one launch when everything fits one batch (PA_XFUSE=0, read per call: two launches, A/B)
-    const char* fe = getenv("PA_XFUSE");
+  {  // pack + same-rank copies in one launch when everything fits one batch
     XProd P;
     long long maxcells = 0;
     int ncopyjobs = 0, npackjobs = 0;
-    bool fits = njobs <= PA_XB && !(fe && !atoi(fe));
+    bool fits = njobs <= PA_XB;
     for (int q = 0; q < njobs && fits; ++q) {
       const XJob& J = jobs[q];
       const XSide& S = J.plan->send;

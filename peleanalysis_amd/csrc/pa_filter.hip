@@ -42,8 +42,7 @@ extern "C" int pa_filter_weights(int type, int fgr, double* w) {
       // allow_unverified_gaussian=1): these weights are a guess at PelePhysics' and a plotfile filtered with them may differ from
       // the reference's at 1e-6 .. 1e-5 without any other sign (advisor finding, round 4).
       {
-        const char* e = getenv("PA_ALLOW_UNVERIFIED_GAUSSIAN");
-        if (!e || !atoi(e)) return -1;
+        if (!pa_opt().allow_unverified_gaussian) return -1;
       }
       // Gaussian (PelePhysics filter_type 2) [UNVERIFIED against PelePhysics: its source is not in the reference tree].  The textbook
       // LES Gaussian of width Delta = fgr dx, G(r) = sqrt(6 / (pi Delta^2)) exp(-6 r^2 / Delta^2) (variance Delta^2 / 12, the box
@@ -404,12 +403,10 @@ static bool sep_shape(int nx, int ny, int nz, int ng, unsigned nboxes, int ncomp
   // planes per workgroup: a segment re-reads 2 ng planes, so wide windows take long segments (measured on a 512^3 level of
   // 128^3 boxes, fgr 8: 32 / 64 / 128 planes 0.595 / 0.531 / 0.500 ms; fgr 2 and 4 are flat); shorter while a launch would
   // leave CUs without a workgroup
-  static const int kseg_env = [] { const char* e = getenv("PA_FILTER_SEP_KSEG"); return e ? atoi(e) : 0; }();
   S.TY = TY;
   S.nys = (ny + TY - 1) / TY;
-  int kseg = std::min(kseg_env > 0 ? kseg_env : (ng > 2 ? 128 : 64), nz);
-  if (kseg_env <= 0)
-    while (kseg > 8 * ng && kseg > 16 && (long long)nboxes * ncomp * S.nys * ((nz + kseg - 1) / kseg) < 512) kseg = (kseg + 1) / 2;
+  int kseg = std::min(ng > 2 ? 128 : 64, nz);
+  while (kseg > 8 * ng && kseg > 16 && (long long)nboxes * ncomp * S.nys * ((nz + kseg - 1) / kseg) < 512) kseg = (kseg + 1) / 2;
   S.kseg = std::max(1, kseg);
   S.T = S.nys * ((nz + S.kseg - 1) / S.kseg);
   S.ld_max = ld;
@@ -464,11 +461,11 @@ template <typename BP>
 static void filter_launch(hipStream_t st, const BP& bp, int nx, int ny, int nz, unsigned nboxes, int scomp, int ncomp, int ng, const FilterW& W) {
   auto grid = [&](int TX, int TY, int TZ) { return dim3(((nx + TX - 1) / TX) * ((ny + TY - 1) / TY) * ((nz + TZ - 1) / TZ), nboxes); };
   // default: the separable form (1e-12 relative); PA_FILTER_EXACT=1: the reference's tap order, bit for bit (read per launch)
-  const char* ee = getenv("PA_FILTER_EXACT");
+  const bool exact = pa_opt().filter_exact != 0;
   SepShape S;
   bool sym = true;  // the separable kernel pairs the taps w_m (a[m] + a[2ng - m]); every filter type of the library is symmetric
   for (int q = 0; q < ng; ++q) sym = sym && W.w[q] == W.w[2 * ng - q];
-  if (!(ee && atoi(ee)) && ng >= 1 && sym && sep_shape(nx, ny, nz, ng, nboxes, ncomp, S)) {
+  if (!exact && ng >= 1 && sym && sep_shape(nx, ny, nz, ng, nboxes, ncomp, S)) {
     switch (ng) {
       case 1: sep_dispatch<BP, 1>(st, bp, S, nboxes, scomp, ncomp, W); return;
       case 2: sep_dispatch<BP, 2>(st, bp, S, nboxes, scomp, ncomp, W); return;
@@ -479,15 +476,12 @@ static void filter_launch(hipStream_t st, const BP& bp, int nx, int ny, int nz, 
       default: break;
     }
   }
-  // box weights (w0/2, w0, ..., w0, w0/2): the streaming kernel (PA_FILTER_STREAM=0 forces the tile kernel)
-  const char* se = getenv("PA_FILTER_STREAM");  // read per launch: the full-size test runs both kernels
-  const int stream_env = se ? atoi(se) : 1;
+  // box weights (w0/2, w0, ..., w0, w0/2): the streaming kernel
   const int nw = 2 * ng + 1;
-  bool box = stream_env && ng >= 1 && W.w[0] == 0.5 * W.w[1] && W.w[nw - 1] == W.w[0];
+  bool box = ng >= 1 && W.w[0] == 0.5 * W.w[1] && W.w[nw - 1] == W.w[0];
   for (int q = 2; q < nw - 1 && box; ++q) box = W.w[q] == W.w[1];
   if (box && (ng == 1 || ng == 2 || ng == 4)) {
-    static const int kseg_env = [] { const char* e = getenv("PA_FILTER_KSEG"); return e ? atoi(e) : 32; }();
-    const int kseg = std::max(1, std::min(kseg_env, nz));
+    const int kseg = std::max(1, std::min(32, nz));
     const dim3 g = grid(32, 8, kseg);
     if (ng == 1) hipLaunchKernelGGL((k_boxfilter_stream<BP, 1>), g, dim3(256), 0, st, bp, scomp, ncomp, W.w[1], kseg);
     else if (ng == 2) hipLaunchKernelGGL((k_boxfilter_stream<BP, 2>), g, dim3(256), 0, st, bp, scomp, ncomp, W.w[1], kseg);
@@ -526,36 +520,10 @@ extern "C" int pa_boxfilter_hierarchy(pa_ctx* ctx, int nlev, const pa_mf* const*
                                       const double* const* ws) {
   PaBind bind_(ctx);
   if (!ctx || nlev <= 0 || !in || !out || !ngs || !ws) return pa_fail(ctx, "pa_boxfilter_hierarchy: null argument");
-  const char* se = getenv("PA_FILTER_LEVEL_STREAMS");
-  const bool streams = nlev > 1 && se && atoi(se);
-  if (!streams) {
-    for (int l = 0; l < nlev; ++l)
-      if (pa_boxfilter_level(ctx, in[l], out[l], scomp, ncomp, ngs[l], ws[l])) return 1;
-    return 0;
-  }
-  while ((int)ctx->lev_streams.size() < nlev) {
-    hipStream_t st;
-    PA_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    ctx->lev_streams.push_back(st);
-  }
-  while (ctx->sync_evs.size() < 1 + (size_t)nlev) {
-    hipEvent_t e;
-    PA_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    ctx->sync_evs.push_back(e);
-  }
-  hipStream_t keep = ctx->stream;
-  PA_HIP(hipEventRecord(ctx->sync_evs[0], keep));  // after the ghost fills queued so far
-  int rc = 0;
-  for (int l = 0; l < nlev && !rc; ++l) {
-    hipStream_t T = ctx->lev_streams[l];
-    if (hipStreamWaitEvent(T, ctx->sync_evs[0], 0) != hipSuccess) { rc = pa_fail(ctx, "pa_boxfilter_hierarchy: stream wait failed"); break; }
-    ctx->stream = T;
-    rc = pa_boxfilter_level(ctx, in[l], out[l], scomp, ncomp, ngs[l], ws[l]);
-    ctx->stream = keep;
-    if (!rc && (hipEventRecord(ctx->sync_evs[1 + l], T) != hipSuccess || hipStreamWaitEvent(keep, ctx->sync_evs[1 + l], 0) != hipSuccess))
-      rc = pa_fail(ctx, "pa_boxfilter_hierarchy: stream join failed");
-  }
-  return rc;
+  // (the levels on one stream each was measured slower than one after the other on one stream: DESIGN_HISTORY.md R4)
+  for (int l = 0; l < nlev; ++l)
+    if (pa_boxfilter_level(ctx, in[l], out[l], scomp, ncomp, ngs[l], ws[l])) return 1;
+  return 0;
 }
 
 // 2-D build of Filter::apply_filter: out(i,j,c) = sum_m sum_l (w_l w_m) in(i+l, j+m, c) on a level stored as one plane
@@ -1029,8 +997,7 @@ extern "C" int pa_fillpatch_two_levels(pa_ctx* ctx, pa_mf* fine, const pa_mf* cr
   int ccomp = comp;
   if (pa_coarse_source(ctx, fine->lev, crse, comp, ncomp, 1, ng, 1, &crse, &ccomp, ratio)) return 1;
   if (fine->lev->boxes.empty() || !crse) return 0;
-  static const int parent_env = [] { const char* e = getenv("PA_FILLPATCH_PARENT"); return e ? atoi(e) : 1; }();  // 0: thread per ghost cell (A/B)
-  if (interp_type == 1 && parent_env && ratio == 2) {
+  if (interp_type == 1 && ratio == 2 && !pa_opt().force_fallbacks) {
     const FpPlan* Pp = fp_parent_plan(ctx, fine->lev, crse->lev, ng);
     if (!Pp) return 1;
     const FpPlan& P = *Pp;
@@ -1069,8 +1036,7 @@ extern "C" int pa_fill_ghosts_hierarchy(pa_ctx* ctx, int nlev, pa_mf* const* mfs
       if (mfs[l]->lev->is_per[d] && ngs[l] > mfs[l]->lev->domhi[d] - mfs[l]->lev->domlo[d] + 1) return pa_fail(ctx, "pa_fill_ghosts_hierarchy: ng larger than the periodic domain");
     sharded = sharded || mfs[l]->lev->nranks > 1;
   }
-  static const int batch_env = [] { const char* e = getenv("PA_GHOSTS_BATCH"); return e ? atoi(e) : 1; }();  // 0: level by level (A/B)
-  if (sharded || !batch_env) {
+  if (sharded || pa_opt().force_fallbacks) {
     for (int l = 0; l < nlev; ++l) {
       if (pa_fill_boundary(ctx, mfs[l], comp, ncomp, ngs[l])) return 1;
       if (l > 0 && pa_fillpatch_two_levels(ctx, mfs[l], mfs[l - 1], comp, ncomp, ngs[l], ratio, interp_type)) return 1;
@@ -1083,8 +1049,7 @@ extern "C" int pa_fill_ghosts_hierarchy(pa_ctx* ctx, int nlev, pa_mf* const* mfs
     std::vector<int> g(ngs, ngs + nlev);
     if (pa_fill_boundary_local_batch_ngs(ctx, nlev, mfs, comp, ncomp, g.data())) return 1;
   }
-  static const int parent_env = [] { const char* e = getenv("PA_FILLPATCH_PARENT"); return e ? atoi(e) : 1; }();
-  if (interp_type == 1 && parent_env && ratio == 2) {
+  if (interp_type == 1 && ratio == 2 && !pa_opt().force_fallbacks) {
     for (int l0 = 1; l0 < nlev; l0 += PA_MAXB) {
       FpdBatch Bt;
       Bt.n = 0;

@@ -888,60 +888,28 @@ template <int NL, bool PATCH = false, bool CLIP = false>
 __global__ __launch_bounds__(256) void k_faces_curv_fast(LevBatch<FixArgs> Bt, int* nbad, SlowList sl = SlowList(), SlotK sk = SlotK()) {
   faces_fast_wg<NL, PATCH, CLIP>(Bt, nbad, sl, sk, blockIdx.x);
 }
-// Face interiors and face perimeters of all levels in ONE launch (no clip): the two kernels above write different cells from the
-// same final normals, and at the size of a level's special faces each is a chain of dependent loads -- back to back they cost
-// their sum.  Workgroups 0 .. nfast - 1 take the interiors' work tables, the rest the perimeters'.
-template <bool PATCH>
-__global__ __launch_bounds__(256, PA_FC_WAVES) void k_faces_curv_both(LevBatch<FixArgs> Bt, int* nbad, SlotK sk, unsigned nfast) {
-  if (blockIdx.x < nfast) faces_fast_wg<1, PATCH, false>(Bt, nbad, SlowList(), sk, blockIdx.x);
-  else faces_tab_wg<true, PATCH, false>(Bt, nbad, sk, blockIdx.x - nfast);
-}
-
-// tuning knobs (environment, read once): PA_KSEG=<planes per workgroup>, PA_MTY=<rows*10 + min waves/SIMD>
-static int fused_kseg() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("PA_KSEG");
-    v = e ? atoi(e) : 64;  // planes per workgroup: 64 vs 128 measured 1.91 vs 1.94 ms with the burst schedule (within noise; more, shorter workgroups)
-    if (v < 4) v = 4;
-  }
-  return v;
-}
-static int fused_mty() {
-  static int v = -2;
-  if (v == -2) {
-    const char* e = getenv("PA_MTY");
-    v = e ? atoi(e) : -1;
-  }
-  return v;
-}
+// planes per workgroup: 64 vs 128 measured 1.91 vs 1.94 ms with the burst schedule (within noise; more, shorter workgroups).  The tile
+// heights (13 / 8 / 4 rows by the boxes' height), the XCD-aware workgroup order (2) and 8-byte stores are what the measurements of
+// rounds 1-5 left standing; the 16-byte paired stores, the first marching kernel, tiles of 9-12 rows and the diagnostic builds of the
+// sweep went with their switches in round 6 (DESIGN_HISTORY.md lists what each measured).
+static int fused_kseg() { return 64; }
 static dim3 march_grid(int nx, int ny, int nz, int kseg, int mty, unsigned nboxes) {
   const unsigned tx = (nx + 63) / 64, ty = (ny + mty - 1) / mty, tz = (nz + kseg - 1) / kseg;
   return dim3(tx * ty * tz, nboxes);
 }
-static int fused_order() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("PA_ORDER");
-    v = e ? atoi(e) : 2;
-  }
-  return v;
-}
-// pair_ok: every tile of every box is 64 columns wide and starts on an even column of an even-length
-// output row (16-byte stores, see PAIR in pa_fused_march3.h)
+static int fused_order() { return 2; }
 // kname: receives the variant that was launched (what bench.py matches the committed PMC traffic figure against)
 template <typename BP>
-static void march_launch(hipStream_t st, const BP& bp, int nx, int ny, int nz, unsigned nboxes, const MarchArgs& A0, bool pair_ok = false, std::string* kname = nullptr) {
+static void march_launch(hipStream_t st, const BP& bp, int nx, int ny, int nz, unsigned nboxes, const MarchArgs& A0, bool /*pair_ok*/ = false, std::string* kname = nullptr) {
   MarchArgs A = A0;
   // Small levels: a 256^3 level of 64^3 boxes is 320 workgroups at 64 planes each -- 1.25 rounds on 256 CUs -- and
-  // ran at 50 % of the HBM figure; shorter z segments give the chip enough workgroups to balance (PA_KSEG 64 / 32 /
-  // 16 / 8 on that level: 0.305 / 0.280 / 0.267 / 0.269 ms per launch; on the 512^3 headline level 64 stays best).
-  // An explicit PA_KSEG is taken as given.
+  // ran at 50 % of the HBM figure; shorter z segments give the chip enough workgroups to balance (64 / 32 /
+  // 16 / 8 planes on that level: 0.305 / 0.280 / 0.267 / 0.269 ms per launch; on the 512^3 headline level 64 stays best).
   // Round 2: the segment length is chosen from a small model instead of halved -- one workgroup per CU (LDS), so a launch
   // takes about ceil(workgroups / 256) rounds of (planes per segment + ~4 planes of pipeline fill); measured on rank 0's
   // share of the headline (8 boxes of 128^3 per level = 160 tiles): 16 / 22 / 32 / 43 / 64 planes -> 0.266 / 0.272 / 0.280 /
   // 0.254 / 0.309 ms per launch (model: 100 / 104 / 108 / 94 / 136), 16 boxes: 32 planes best (model and measurement).
-  if (!getenv("PA_KSEG")) {
+  {
     const long long per_seg = (long long)((nx + 63) / 64) * ((ny + 12) / 13) * nboxes;
     if (per_seg * ((nz + A.kseg - 1) / A.kseg) < 2048) {
       long long best = -1;
@@ -954,81 +922,36 @@ static void march_launch(hipStream_t st, const BP& bp, int nx, int ny, int nz, u
       A.kseg = std::max(best_k, 4);
     }
   }
-  // PA_PAIR=1 selects the 16-byte paired stores (read per launch so that a test can switch it).
-  // Off by default: measured 2.36 vs 2.31 ms per launch on the headline level.
-  const char* pe = getenv("PA_PAIR");
-  const int pair_env = pe ? atoi(pe) : 0;
-  const bool pair = pair_ok && pair_env;
   A.order = fused_order();
   A.nboxes = (int)nboxes;
-  int sel = fused_mty();
-  if (sel < 0) sel = (ny >= 52) ? 131 : (ny >= 16 ? 81 : 41);  // short boxes do not fill a 13-row tile
-  static const int march_ver = [] { const char* e = getenv("PA_MARCH"); return e ? atoi(e) : 3; }();  // 1: k_gradcurv_march (A/B)
-  static const int narrow_env = [] { const char* e = getenv("PA_NARROW"); return e ? atoi(e) : 1; }();
-  if (march_ver == 3 && narrow_env && nx <= 32) {  // boxes at most 32 cells wide: two rows per wavefront (pa_fused_march3n.h)
+  const bool clip = A.thr >= 0.0;
+  if (nx <= 32) {  // boxes at most 32 cells wide: two rows per wavefront (pa_fused_march3n.h)
     constexpr int NRW = 8;
     const unsigned tiles = (unsigned)(((nx + 31) / 32) * ((ny + 2 * NRW - 1) / (2 * NRW)) * ((nz + A.kseg - 1) / A.kseg));
     A.tiles_max = (int)tiles;
-    if (A.order == 1) A.order = 0;
-    const dim3 g = A.order == 2 ? dim3(tiles * 8u * ((nboxes + 7u) / 8u), 1) : dim3(tiles, nboxes);
-    if (A.cg && A.thr >= 0.0) hipLaunchKernelGGL((k_gradcurv_march3n<BP, NRW, true, true>), g, dim3(64 * (NRW + 2)), 0, st, bp, A);
+    const dim3 g(tiles * 8u * ((nboxes + 7u) / 8u), 1);
+    if (A.cg && clip) hipLaunchKernelGGL((k_gradcurv_march3n<BP, NRW, true, true>), g, dim3(64 * (NRW + 2)), 0, st, bp, A);
     else if (A.cg) hipLaunchKernelGGL((k_gradcurv_march3n<BP, NRW, false, true>), g, dim3(64 * (NRW + 2)), 0, st, bp, A);
-    else if (A.thr >= 0.0) hipLaunchKernelGGL((k_gradcurv_march3n<BP, NRW, true>), g, dim3(64 * (NRW + 2)), 0, st, bp, A);
+    else if (clip) hipLaunchKernelGGL((k_gradcurv_march3n<BP, NRW, true>), g, dim3(64 * (NRW + 2)), 0, st, bp, A);
     else hipLaunchKernelGGL((k_gradcurv_march3n<BP, NRW, false>), g, dim3(64 * (NRW + 2)), 0, st, bp, A);
-    if (kname) *kname = std::string("k_gradcurv_march3n<NRW=8,CLIP=") + (A.thr >= 0.0 ? "1" : "0") + ",CG=" + (A.cg ? "1>" : "0>");
+    if (kname) *kname = std::string("k_gradcurv_march3n<NRW=8,CLIP=") + (clip ? "1" : "0") + ",CG=" + (A.cg ? "1>" : "0>");
     return;
   }
-  if (march_ver == 3) {
-    const bool clip = A.thr >= 0.0;
-    static const int dbg = [] { const char* e = getenv("PA_DBG"); return e ? atoi(e) : 0; }();  // diagnostic variants (wrong results)
-    if (dbg && !clip && sel / 10 == 13) {
-      dim3 g = march_grid(nx, ny, nz, A.kseg, 13, nboxes);
-      A.txy_max = ((nx + 63) / 64) * ((ny + 12) / 13);
-      A.tiles_max = (int)g.x;
-      if (A.order == 2) g = dim3(g.x * 8u * ((nboxes + 7u) / 8u), 1);
-      else if (A.order) g = dim3(g.x * g.y, 1);
-      switch (dbg) {
-#define PA_DBGCASE(D) case D: hipLaunchKernelGGL((k_gradcurv_march3<BP, 13, false, false, D>), g, dim3(64 * 16), 0, st, bp, A); return;
-        PA_DBGCASE(1) PA_DBGCASE(2) PA_DBGCASE(4) PA_DBGCASE(6) PA_DBGCASE(7) PA_DBGCASE(256) PA_DBGCASE(512) PA_DBGCASE(1024) PA_DBGCASE(2048)
-#undef PA_DBGCASE
-        default: break;
-      }
-    }
-    switch (sel / 10) {
-#define PA_CASE3(M)                                                                                                    \
-  case M: {                                                                                                            \
-    dim3 g = march_grid(nx, ny, nz, A.kseg, M, nboxes);                                                                \
-    A.txy_max = ((nx + 63) / 64) * ((ny + M - 1) / M);                                                                 \
-    A.tiles_max = (int)g.x;                                                                                            \
-    if (A.order == 2) g = dim3(g.x * 8u * ((nboxes + 7u) / 8u), 1);                                                    \
-    else if (A.order) g = dim3(g.x * g.y, 1);                                                                          \
-    if (kname) *kname = "k_gradcurv_march3<MTY=" #M ",CLIP=" + std::to_string((int)clip) + ",PAIR=" + std::to_string((int)(pair && !A.cg)) + ",CG=" + std::to_string((int)(A.cg != 0)) + ">"; \
-    if (A.cg && !clip) hipLaunchKernelGGL((k_gradcurv_march3<BP, M, false, false, 0, true>), g, dim3(64 * (M + 3)), 0, st, bp, A); \
-    else if (A.cg) hipLaunchKernelGGL((k_gradcurv_march3<BP, M, true, false, 0, true>), g, dim3(64 * (M + 3)), 0, st, bp, A); \
-    else if (pair && clip) hipLaunchKernelGGL((k_gradcurv_march3<BP, M, true, true>), g, dim3(64 * (M + 3)), 0, st, bp, A); \
-    else if (pair) hipLaunchKernelGGL((k_gradcurv_march3<BP, M, false, true>), g, dim3(64 * (M + 3)), 0, st, bp, A);   \
-    else if (clip) hipLaunchKernelGGL((k_gradcurv_march3<BP, M, true>), g, dim3(64 * (M + 3)), 0, st, bp, A);          \
-    else hipLaunchKernelGGL((k_gradcurv_march3<BP, M, false>), g, dim3(64 * (M + 3)), 0, st, bp, A);                   \
-  } return;
-      PA_CASE3(4) PA_CASE3(8) PA_CASE3(9) PA_CASE3(10) PA_CASE3(11) PA_CASE3(12) PA_CASE3(13)
-#undef PA_CASE3
-      default: break;
-    }
-  }
-  switch (sel) {
-#define PA_CASE(M, W)                                                                                                  \
-  case M * 10 + W: {                                                                                                   \
-    dim3 g = march_grid(nx, ny, nz, A.kseg, M, nboxes);                                                                \
-    A.txy_max = ((nx + 63) / 64) * ((ny + M - 1) / M);                                                                 \
-    if (A.order) g = dim3(g.x * g.y, 1);                                                                               \
-    hipLaunchKernelGGL((k_gradcurv_march<BP, M, W>), g, dim3(64 * (M + 3)), 0, st, bp, A);                             \
-  } break;
-    PA_CASE(4, 1) PA_CASE(5, 1) PA_CASE(5, 4) PA_CASE(8, 1) PA_CASE(8, 6) PA_CASE(12, 1) PA_CASE(13, 1)
-#undef PA_CASE
-    default:
-      A.order = 0;
-      hipLaunchKernelGGL((k_gradcurv_march<BP, 8, 1>), march_grid(nx, ny, nz, A.kseg, 8, nboxes), dim3(64 * 11), 0, st, bp, A);
-  }
+  auto go = [&](auto mc) {  // short boxes do not fill a 13-row tile
+    constexpr int M = decltype(mc)::value;
+    dim3 g = march_grid(nx, ny, nz, A.kseg, M, nboxes);
+    A.txy_max = ((nx + 63) / 64) * ((ny + M - 1) / M);
+    A.tiles_max = (int)g.x;
+    g = dim3(g.x * 8u * ((nboxes + 7u) / 8u), 1);
+    if (kname) *kname = "k_gradcurv_march3<MTY=" + std::to_string(M) + ",CLIP=" + std::to_string((int)clip) + ",PAIR=0,CG=" + std::to_string((int)(A.cg != 0)) + ">";
+    if (A.cg && !clip) hipLaunchKernelGGL((k_gradcurv_march3<BP, M, false, false, 0, true>), g, dim3(64 * (M + 3)), 0, st, bp, A);
+    else if (A.cg) hipLaunchKernelGGL((k_gradcurv_march3<BP, M, true, false, 0, true>), g, dim3(64 * (M + 3)), 0, st, bp, A);
+    else if (clip) hipLaunchKernelGGL((k_gradcurv_march3<BP, M, true>), g, dim3(64 * (M + 3)), 0, st, bp, A);
+    else hipLaunchKernelGGL((k_gradcurv_march3<BP, M, false>), g, dim3(64 * (M + 3)), 0, st, bp, A);
+  };
+  if (ny >= 52) go(std::integral_constant<int, 13>{});
+  else if (ny >= 16) go(std::integral_constant<int, 8>{});
+  else go(std::integral_constant<int, 4>{});
 }
 
 // diagnostic: workgroups of a sweep kernel the runtime's occupancy query admits per CU (which = 0: the wide all-levels sweep, 13 rows;
@@ -1056,13 +979,8 @@ extern "C" int pa_gradcurv_level(pa_ctx* ctx, const pa_mf* phi, int pcomp, doubl
   if (phi->lev->boxes.empty()) return 0;  // a rank that owns no box of this level
   LevelBP2 bp{L->view, phi->view, out->view};
   MarchArgs A{pcomp, ocomp, fused_kseg(), pmin, 1.0 / (pmax - pmin), thr, 0, 1, 1, 1};
-  bool pair_ok = (out->ng % 2 == 0);
-  for (const DBox& B : L->boxes) {
-    const long long nxb = B.hi[0] - B.lo[0] + 1, nyb = B.hi[1] - B.lo[1] + 1 + 2 * out->ng, nzb = B.hi[2] - B.lo[2] + 1 + 2 * out->ng;
-    pair_ok = pair_ok && (nxb % 64 == 0) && pa_cstride((nxb + 2 * out->ng) * nyb * nzb, out->ncomp) * 8 < (1ll << 31);
-  }
   ProfScope prof(ctx, PA_TAG_GRADCURV);
-  march_launch(ctx->stream, bp, L->maxn[0], L->maxn[1], L->maxn[2], (unsigned)L->boxes.size(), A, pair_ok, &ctx->sweep_kernel);
+  march_launch(ctx->stream, bp, L->maxn[0], L->maxn[1], L->maxn[2], (unsigned)L->boxes.size(), A, false, &ctx->sweep_kernel);
   PA_HIP(hipGetLastError());
   return 0;
 }
@@ -1097,7 +1015,7 @@ int pa_gradcurv_faces_phase(pa_ctx* ctx, const pa_mf* c, int ccomp, const pa_mf*
   bool fast = !(thr >= 0.0);
   for (const DBox& B : c->lev->boxes)
     for (int d = 0; d < 3; ++d) fast = fast && (B.hi[d] - B.lo[d] + 1 >= 3);
-  static const int fast_env = [] { const char* e = getenv("PA_FACES_FAST"); return e ? atoi(e) : 1; }();
+  constexpr int fast_env = 1;
   fast = fast && fast_env;
   if (L->sfaces.empty()) return 0;
   const long long n0 = L->maxn[0], n1 = L->maxn[1], n2 = L->maxn[2];
@@ -1225,14 +1143,6 @@ __device__ __forceinline__ void prep_faces_cell(const PrepLev& Pl, int* nbad, co
   gc += bv[1] * coef[0];
   p[fab_index(B, M.ng, M.ncomp, comp, q[0], q[1], q[2])] = gp;
   if (!PHIONLY) *cgp = gc;
-}
-template <bool PATCH, bool PHIONLY = false>
-__global__ __launch_bounds__(256) void k_prep_faces(LevBatch<PrepLev> Bt, int* nbad, SlotK sk = SlotK()) {
-  unsigned fy;
-  int blev;
-  long long t;
-  if (!wg_decode(Bt, blev, fy, t)) return;
-  prep_faces_cell<PATCH, PHIONLY>(Bt.a[blev], nbad, sk, fy, t);
 }
 
 // ---- round 6: the same work from the levels' CHUNK RECORDS (SfChunk, pa_internal.h).  A workgroup takes one record = a rectangle of
@@ -1778,10 +1688,7 @@ static int level_cp(pa_ctx* ctx, const pa_level* Lc, int nsets = 1) {
   L->view.cp = L->d_cp;
   return 0;
 }
-static bool cpatch_on() {
-  const char* e = getenv("PA_CPATCH");  // read per pass (tools/ab_driver.py)
-  return e ? atoi(e) != 0 : true;
-}
+static bool cpatch_on() { return true; }  // (the face kernels' owner-map interpolation is what levels without patches -- none today -- would take)
 // gather the patches of levels [l0, l1) (those that have a coarse source): one launch
 static int cpatch_launch(pa_ctx* ctx, int l0, int l1, pa_mf* const* fine, const pa_mf* const* crse, int ccomp, int by_dir, int nslots = 1, int zstride = 1) {
   {  // copy regions when every level of the batch has a plan
@@ -2167,24 +2074,14 @@ __global__ __launch_bounds__(256) void k_curv_general_levels(GenBatch Bt, int* n
 
 // can the exact-normal pipeline run on this level (same answer on every rank of a sharded level)?
 bool pa_fused2_level_ok(const pa_level* L) {
-  static const int env = [] { const char* e = getenv("PA_FUSED2"); return e ? atoi(e) : 1; }();
-  static const int march = [] { const char* e = getenv("PA_MARCH"); return e ? atoi(e) : 3; }();
-  if (!env || march != 3 || getenv("PA_DBG") || getenv("PA_MTY")) return false;
-  // general BoxArrays (concave coarse-fine corners, faces partly covered by a neighbour) take this pipeline too: their
-  // irregular cells are listed per level and recomputed after the fix-up (k_curv_general).  PA_FUSED2_GENERAL=0: only levels of
-  // pure special faces without concave corners, as before round 4 (A/B; everything else then goes pass by pass)
-  static const int general = [] { const char* e = getenv("PA_FUSED2_GENERAL"); return e ? atoi(e) : 1; }();
-  if (!general && (!L->fusable || !L->pure_faces)) return false;
+  // ANY BoxArray whose boxes are at least three cells thick: general BoxArrays (concave coarse-fine corners, faces partly covered by a
+  // neighbour) have their irregular cells listed per level and recomputed after the fix-up (k_curv_general); boxes at most 32 cells
+  // wide run k_gradcurv_march3n's CG variant
   const std::vector<DBox>& all = L->gboxes.empty() ? L->boxes : L->gboxes;
-  int maxnx = 0;
-  for (const DBox& B : all) {
-    maxnx = std::max(maxnx, B.hi[0] - B.lo[0] + 1);
+  for (const DBox& B : all)
     for (int d = 0; d < 3; ++d)
       if (B.hi[d] - B.lo[d] + 1 < 3) return false;
-  }
-  static const int narrow_cg = [] { const char* e = getenv("PA_NARROW_CG"); return e ? atoi(e) : 1; }();  // 0: boxes <= 32 wide keep the first pipeline (A/B)
-  static const int narrow_on = [] { const char* e = getenv("PA_NARROW"); return e ? atoi(e) : 1; }();
-  return maxnx > 32 || narrow_cg || !narrow_on;  // narrower boxes run k_gradcurv_march3n (its CG variant; PA_NARROW=0: the wide kernel)
+  return true;
 }
 
 // before the sweeps: face ghosts of phi + resolved ghost c (faces and ring) of several levels, one launch pair for up to
@@ -2233,21 +2130,17 @@ int pa_gradcurv_prep_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int comp, 
     ProfScope prof(ctx, PA_TAG_BC);
     bool all_patch = true;  // every level of the batch that has a coarser level interpolates from patches: the owner-map path is not compiled in
     for (int q = 0; q < Bf.n; ++q) all_patch = all_patch && (Bf.a[q].use_cp || !Bf.a[q].A.has_crse);
-    unsigned nwgf = 0;
-    for (int q = 0; q < Bf.n; ++q) nwgf += (unsigned)Bf.a[q].nwg;
-    const dim3 gf(nwgf, 1, (unsigned)nslots);
-    // round 6: the faces from the levels' chunk records (k_prep_faces_chunks).  PA_FACE_CHUNKS=0 (read per pass): the per-cell kernel
+    // the faces from the levels' chunk records (k_prep_faces_chunks; every level with special faces has them)
     LevChunks Ck;
     Ck.w0[0] = 0;
-    bool chunks = !(getenv("PA_FACE_CHUNKS") && !atoi(getenv("PA_FACE_CHUNKS")));
     for (int q = 0; q < Bf.n; ++q) {
       const pa_level* Lq = batch_lev[q];
-      chunks = chunks && Lq->d_sfchunk && Lq->nsfchunk > 0;
+      if (!Lq->d_sfchunk || Lq->nsfchunk <= 0) return pa_fail(ctx, "pa_gradcurv_prep_levels: a level without chunk records");
       Ck.ck[q] = Lq->d_sfchunk;
       Ck.w0[q + 1] = Ck.w0[q] + (unsigned)Lq->nsfchunk;
     }
     // the ring items of the batch's levels (level_ring): with the faces' launch when both are asked for and the ring reads its
-    // neighbours in place (one rank), else a launch of their own.  PA_RING_APART=1 (read per pass): always their own launch
+    // neighbours in place (one rank), else a launch of their own
     LevRings Rg, Rnone;
     Rg.w0[0] = 0;
     for (int q = 0; q <= PA_MAXB; ++q) Rnone.w0[q] = 0;
@@ -2262,9 +2155,8 @@ int pa_gradcurv_prep_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int comp, 
       }
     // (few items -- large faces -- hide under the faces: headline 5.913 -> 5.895 ms per pass; the long lists of a BoxArray of many small boxes
     // are latency-bound work that wants its own launch at its own occupancy: irregular hierarchy 6.39 against 6.48 ms merged)
-    const char* rae = getenv("PA_RING_APART");
-    const bool ring_with_faces = (phase & 1) && (phase & 2) && !(phase & 8) && chunks && direct && (rae ? !atoi(rae) : Rg.w0[Bf.n] * 8u <= Ck.w0[Bf.n]);
-    if ((phase & 1) && chunks) {
+    const bool ring_with_faces = (phase & 1) && (phase & 2) && !(phase & 8) && direct && Rg.w0[Bf.n] * 8u <= Ck.w0[Bf.n];
+    if (phase & 1) {
       const LevRings& Rk = ring_with_faces ? Rg : Rnone;
       const dim3 gc(Rk.w0[Bf.n] + Ck.w0[Bf.n], 1, (unsigned)nslots);
       if (phase & 8) {
@@ -2274,12 +2166,6 @@ int pa_gradcurv_prep_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int comp, 
         if (all_patch) hipLaunchKernelGGL((k_prep_faces_chunks<true, false>), gc, dim3(256), 0, ctx->stream, Bf, Ck, Rk, ctx->d_flags, sk);
         else hipLaunchKernelGGL((k_prep_faces_chunks<false, false>), gc, dim3(256), 0, ctx->stream, Bf, Ck, Rk, ctx->d_flags, sk);
       }
-    } else if ((phase & 1) && (phase & 8)) {
-      if (all_patch) hipLaunchKernelGGL((k_prep_faces<true, true>), gf, dim3(256), 0, ctx->stream, Bf, ctx->d_flags, sk);
-      else hipLaunchKernelGGL((k_prep_faces<false, true>), gf, dim3(256), 0, ctx->stream, Bf, ctx->d_flags, sk);
-    } else if (phase & 1) {
-      if (all_patch) hipLaunchKernelGGL(k_prep_faces<true>, gf, dim3(256), 0, ctx->stream, Bf, ctx->d_flags, sk);
-      else hipLaunchKernelGGL(k_prep_faces<false>, gf, dim3(256), 0, ctx->stream, Bf, ctx->d_flags, sk);
     }
     if ((phase & 2) && !ring_with_faces && Rg.w0[Bf.n] > 0) {
       const dim3 gr(Rg.w0[Bf.n], 1, (unsigned)nslots);
@@ -2297,16 +2183,14 @@ int pa_gradcurv_prep_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int comp, 
 // not wider than 32 cells -- its wide or its narrow ones through an index list)
 struct SweepGroup { int lev; const int* list; int n; int dims[3]; };
 static void sweep_groups(int l, const pa_level* L, std::vector<SweepGroup>& out) {
-  static const int split = [] { const char* e = getenv("PA_SWEEP_SPLIT"); return e ? atoi(e) : 1; }();  // 0: one group per level (A/B)
   if (L->boxes.empty()) return;
-  if (!L->d_blist || !split) { out.push_back({l, nullptr, (int)L->boxes.size(), {L->maxn[0], L->maxn[1], L->maxn[2]}}); return; }
+  if (!L->d_blist) { out.push_back({l, nullptr, (int)L->boxes.size(), {L->maxn[0], L->maxn[1], L->maxn[2]}}); return; }
   out.push_back({l, L->d_blist, L->nwide, {L->wmax[0], L->wmax[1], L->wmax[2]}});
   out.push_back({l, L->d_blist + L->nwide, L->nnarrow, {L->nmax[0], L->nmax[1], L->nmax[2]}});
 }
 
 static const WgTab* sweep_wgtab(const pa_level* L, const SweepGroup& g, int tw, int mty, int kseg, int part = 0) {
-  const char* e = getenv("PA_SWEEP_WGTAB");  // read per pass (tools/ab_driver.py)
-  if (!part && ((e && !atoi(e)) || g.n <= 0)) return nullptr;
+  if (!part && g.n <= 0) return nullptr;
   return pa_sweep_wgtab(L, !g.list ? 2 : (g.list == L->d_blist ? 0 : 1), tw, mty, kseg, false, part);
 }
 
@@ -2345,15 +2229,9 @@ int pa_gradcurv_level_cg(pa_ctx* ctx, const pa_mf* phi, int pcomp, double pmin, 
 bool pa_gradcurv_gout_ok(int nlev, pa_mf* const* phi);
 bool pa_gradcurv_parts_ok(int nlev, pa_mf* const* phi) { return pa_gradcurv_gout_ok(nlev, phi); }
 bool pa_gradcurv_gout_ok(int nlev, pa_mf* const* phi) {
-  static const int batch_env = [] { const char* e = getenv("PA_SWEEP_BATCH"); return e ? atoi(e) : 1; }();
-  static const bool knobs = getenv("PA_MARCH") || getenv("PA_DBG") || getenv("PA_MTY") || getenv("PA_PAIR") || getenv("PA_KSEG");
-  static const int narrow_env = [] { const char* e = getenv("PA_NARROW"); return e ? atoi(e) : 1; }();
-  if (!batch_env || knobs || !narrow_env || fused_order() != 2) return false;
+  if (pa_opt().force_fallbacks) return false;
   std::vector<SweepGroup> all;
   for (int l = 0; l < nlev; ++l) sweep_groups(l, phi[l]->lev, all);
-  int nw = 0, nn = 0;
-  for (const SweepGroup& g : all) ++(g.dims[0] <= 32 ? nn : nw);
-  (void)nw; (void)nn;
   return all.size() <= 8 * PA_MAXB;  // (the launches come in chunks of PA_MAXB groups)
 }
 
@@ -2365,8 +2243,6 @@ int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, d
   if (part && !pa_gradcurv_parts_ok(nlev, phi)) return pa_fail(ctx, "pa_gradcurv_levels_cg: this hierarchy's sweeps cannot be split into early and late tiles");
   if (nslots > 1 && (slot != 0 || !prog || !pmins || !pmaxs)) return pa_fail(ctx, "pa_gradcurv_levels_cg: component slots need slot 0 and the progress ranges");
   if (gout && (nslots != 1 || slot != 0 || !pa_gradcurv_gout_ok(nlev, phi))) return pa_fail(ctx, "pa_gradcurv_levels_cg: the G-output sweeps take one component of a hierarchy pa_gradcurv_gout_ok accepts");
-  static const int batch_env = [] { const char* e = getenv("PA_SWEEP_BATCH"); return e ? atoi(e) : 1; }();
-  static const bool knobs = getenv("PA_MARCH") || getenv("PA_DBG") || getenv("PA_MTY") || getenv("PA_PAIR");
   std::vector<SweepGroup> all, lv, rest;
   for (int l = 0; l < nlev; ++l) sweep_groups(l, phi[l]->lev, all);
   for (int l = 0; l < nlev; ++l) const_cast<pa_level*>(phi[l]->lev)->ncg_live = false;  // (set again below by the launches that mirror the x faces' first layer)
@@ -2386,7 +2262,7 @@ int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, d
   // groups of different tile heights (a level of flat boxes next to one of tall ones): one launch per tile height (until round 5's
   // second session such a hierarchy went group by group, a launch each)
   (void)same;
-  const bool ok = batch_env && !knobs && fused_order() == 2 && !lv.empty() && lv.size() <= 8u * PA_MAXB;  // more than PA_MAXB groups (a hierarchy of 5+ levels): several launches
+  const bool ok = !lv.empty() && lv.size() <= 8u * PA_MAXB && !pa_opt().force_fallbacks;  // more than PA_MAXB groups (a hierarchy of 5+ levels): several launches
   if (!ok) {
     rest.insert(rest.begin(), lv.begin(), lv.end());
     lv.clear();
@@ -2406,14 +2282,13 @@ int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, d
     // planes per workgroup: the model of march_launch on the whole launch (workgroups of all levels share the rounds)
     std::vector<long long> per_seg(lv.size());
     long long wgs = 0;
-    int kdef = fused_kseg();
-    if (const char* kb = getenv("PA_KSEG_B")) kdef = std::max(4, atoi(kb));  // per pass (tools/ab_driver.py): planes per workgroup of the batched launch
+    const int kdef = fused_kseg();
     for (size_t q = 0; q < lv.size(); ++q) {
       per_seg[q] = (long long)((lv[q].dims[0] + 63) / 64) * ((lv[q].dims[1] + mty - 1) / mty) * (long long)lv[q].n;
       wgs += per_seg[q] * ((lv[q].dims[2] + kdef - 1) / kdef);
     }
     int tz_best = 0;
-    if (!getenv("PA_KSEG") && wgs < 2048) {
+    if (wgs < 2048) {
       long long best = -1;
       int nzmax = 0;
       for (const SweepGroup& g : lv) nzmax = std::max(nzmax, g.dims[2]);
@@ -2438,9 +2313,8 @@ int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, d
       S.cgs[q] = cg_stride(L);
       MarchArgs A{pcomp, ocomp, kdef, pmin, 1.0 / (pmax - pmin), clip ? thr : -1.0, 2, 1, 1, 1};
       A.cg = 1;
-      {  // NCG: the first-layer data of the special x faces for the fix-up (PA_NCG=0, read per pass: off)
-        const char* ne = getenv("PA_NCG");
-        if (!(ne && !atoi(ne)) && !clip && nslots == 1 && slot == 0 && !L->sfaces.empty()) {
+      {  // NCG: the first-layer data of the special x faces for the fix-up (PA_NCG=0: off)
+        if (pa_opt().ncg && !clip && nslots == 1 && slot == 0 && !L->sfaces.empty()) {
           if (level_ncg(ctx, L)) return 1;
           pa_level* Lm = const_cast<pa_level*>(L);
           A.ncg = L->d_ncg; A.ncgs = cg_stride(L);
@@ -2491,10 +2365,9 @@ int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, d
   // the narrow groups (boxes at most 32 cells wide) of all levels in one launch too
   std::vector<SweepGroup> nar;
   {
-    static const int narrow_env = [] { const char* e = getenv("PA_NARROW"); return e ? atoi(e) : 1; }();
     std::vector<SweepGroup> keep;
-    for (const SweepGroup& g : rest) ((g.dims[0] <= 32 && narrow_env) ? nar : keep).push_back(g);
-    if (batch_env && !knobs && fused_order() == 2 && !nar.empty()) rest.swap(keep);
+    for (const SweepGroup& g : rest) (g.dims[0] <= 32 ? nar : keep).push_back(g);
+    if (!nar.empty() && !pa_opt().force_fallbacks) rest.swap(keep);
     else nar.clear();
   }
   const std::vector<SweepGroup> nar_all = nar;
@@ -2517,7 +2390,7 @@ int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, d
       A.nboxes = nar[q].n;
       // planes per workgroup as march_launch chooses them for one level
       const int nx = nar[q].dims[0], ny = nar[q].dims[1], nz = nar[q].dims[2];
-      if (!getenv("PA_KSEG")) {
+      {
         const long long per_seg = (long long)((nx + 63) / 64) * ((ny + 12) / 13) * nar[q].n;
         if (per_seg * ((nz + A.kseg - 1) / A.kseg) < 2048) {
           long long best = -1;
@@ -2589,7 +2462,6 @@ int pa_gradcurv_fix_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, 
     if (use_cp && cpatch_launch(ctx, l0, std::min(nlev, l0 + PA_MAXB), phi, crse_n, cncomp0, 1, nslots, cn_z)) return 1;
     LevBatch<FixArgs> Bt;
     int blev[PA_MAXB];  // hierarchy level of every batch row
-    long long nf = 0, nper = 0;
     for (int l = l0; l < nlev && l < l0 + PA_MAXB; ++l) {
       const pa_level* L = phi[l]->lev;
       if (L->boxes.empty() || L->sfaces.empty()) continue;
@@ -2605,9 +2477,6 @@ int pa_gradcurv_fix_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, 
       }
       Bt.ycum[Bt.n + 1] = Bt.ycum[Bt.n] + (int)L->sfaces.size();
       ++Bt.n;
-      const long long n0 = L->maxn[0], n1 = L->maxn[1], n2 = L->maxn[2];
-      nf = std::max(nf, std::max(n1 * n2, std::max(n0 * n2, n0 * n1)));
-      nper = std::max(nper, 4 * std::max(n0, std::max(n1, n2)));  // perimeter of a face <= 4 * the longest edge
     }
     if (!Bt.n) continue;
     ProfScope prof(ctx, PA_TAG_GRADCURV_FACES);
@@ -2617,17 +2486,17 @@ int pa_gradcurv_fix_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, 
     unsigned nwgf = 0;
     for (int q = 0; q < Bt.n; ++q) nwgf += (unsigned)Bt.a[q].nwg;
     const dim3 gfast(nwgf, 1, (unsigned)nslots);
-    LevChunks Ck;  // PA_FACE_CHUNKS=0 (read per pass): the per-cell kernel
+    LevChunks Ck;  // the levels' chunk records (the face interiors without the clip: k_faces_fix_chunks)
     Ck.w0[0] = 0;
-    bool chunks = !(getenv("PA_FACE_CHUNKS") && !atoi(getenv("PA_FACE_CHUNKS")));
+    unsigned npt = 0;  // the perimeters' work tables
     for (int q = 0; q < Bt.n; ++q) {
       const pa_level* Lq = phi[blev[q]]->lev;
-      chunks = chunks && Lq->d_sfchunk && Lq->nsfchunk > 0;
+      if (!Lq->d_sfchunk || Lq->nsfchunk <= 0 || !Bt.a[q].pwg || Bt.a[q].npwg <= 0) return pa_fail(ctx, "pa_gradcurv_fix_levels: a level without chunk records / perimeter tables");
       Ck.ck[q] = Lq->d_sfchunk;
       Ck.w0[q + 1] = Ck.w0[q] + (unsigned)Lq->nsfchunk;
+      npt += (unsigned)Bt.a[q].npwg;
     }
-    hipStream_t pst = ctx->stream;  // the perimeter kernel's stream
-    bool both_done = false;         // the perimeters went with the interiors (k_faces_curv_both)
+    const dim3 gtab(npt, 1, (unsigned)nslots);
     if (clip) {
       SlowList sl;
       if (pa_slow_list(ctx, &sl)) return 1;
@@ -2635,9 +2504,9 @@ int pa_gradcurv_fix_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, 
       if (all_patch) hipLaunchKernelGGL((k_faces_curv_fast<1, true, true>), gfast, dim3(256), 0, ctx->stream, Bt, ctx->d_flags, sl, sk);
       else hipLaunchKernelGGL((k_faces_curv_fast<1, false, true>), gfast, dim3(256), 0, ctx->stream, Bt, ctx->d_flags, sl, sk);
       // the hand-over list is a few thousand cells through a long chain of dependent loads (~0.12 ms whatever its length): the
-      // perimeter kernel (other cells, as latency bound) runs next to it on the side stream.  PA_FIX_OVERLAP=0: one stream
-      const char* foe = getenv("PA_FIX_OVERLAP");  // read per pass (tools/ab_driver.py)
-      if ((!foe || atoi(foe)) && ctx->stream2 != ctx->stream) {
+      // perimeter kernel (other cells, as latency bound) runs next to it on the side stream
+      hipStream_t pst = ctx->stream;
+      if (ctx->stream2 != ctx->stream) {
         if (!ctx->stream2) PA_HIP(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
         for (int e = 0; e < 2; ++e)
           if (!ctx->fix_evs[e]) PA_HIP(hipEventCreateWithFlags(&ctx->fix_evs[e], hipEventDisableTiming));
@@ -2654,68 +2523,28 @@ int pa_gradcurv_fix_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, 
         G.items = sl.gitems; G.n = sl.gcap; G.ncount = sl.gcount; G.lev = q;
         hipLaunchKernelGGL(k_curv_general<true>, dim3(256), dim3(256), 0, ctx->stream, G, ctx->d_flags, sk);
       }
-    } else {
-      // no clip: PA_FIX_OVERLAP=1 (read per pass) puts the perimeter kernel next to the interior one on the side stream.  OFF by
-      // default: measured twice and it buys nothing -- 1-GPU headline +0.009 ms (round 2); rank 0's share of an 8-way shard, where
-      // both launches are short chains of dependent loads, 1.060 against 1.040 ms per pass (round 4, profiles/r04_sim8_delay.txt)
-      const char* foe = getenv("PA_FIX_OVERLAP");
-      const bool side = foe && atoi(foe) != 0;
-      if (side && ctx->stream2 != ctx->stream) {
-        if (!ctx->stream2) PA_HIP(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
-        for (int e = 0; e < 2; ++e)
-          if (!ctx->fix_evs[e]) PA_HIP(hipEventCreateWithFlags(&ctx->fix_evs[e], hipEventDisableTiming));
-        pst = ctx->stream2;
-        PA_HIP(hipEventRecord(ctx->fix_evs[0], ctx->stream));
-        PA_HIP(hipStreamWaitEvent(pst, ctx->fix_evs[0], 0));
+      if (all_patch) hipLaunchKernelGGL((k_faces_curv_tab<true, true, true>), gtab, dim3(256), 0, pst, Bt, ctx->d_flags, sk);
+      else hipLaunchKernelGGL((k_faces_curv_tab<true, false, true>), gtab, dim3(256), 0, pst, Bt, ctx->d_flags, sk);
+      if (pst != ctx->stream) {
+        PA_HIP(hipEventRecord(ctx->fix_evs[1], pst));
+        PA_HIP(hipStreamWaitEvent(ctx->stream, ctx->fix_evs[1], 0));
       }
-      // PA_FIX_BOTH (read per pass): interiors and perimeters in one launch (k_faces_curv_both) when the perimeters have their work tables.
-      // Default: on a sharded hierarchy only.  In-process A/B (bench.py --ab PA_FIX_BOTH=0,1): rank 0 of 8 0.900 -> 0.885 ms per pass (two
-      // 35-60-us latency chains side by side), but the headline on one GPU 6.002 -> 6.026 and the irregular hierarchy 6.75-6.95 -> 7.2:
-      // the merged kernel carries the perimeter path's 128 VGPRs, and the interiors' bandwidth-bound part runs at 4 instead of 6 waves per SIMD
-      const char* fbe = getenv("PA_FIX_BOTH");
-      const bool both_on = fbe ? atoi(fbe) != 0 : (nlev > 0 && phi[0]->lev->nranks > 1);
-      bool ptab_ok = !side && !(getenv("PA_FIX_PTAB") && !atoi(getenv("PA_FIX_PTAB")));
-      unsigned npt = 0;
-      for (int q = 0; q < Bt.n; ++q) { ptab_ok = ptab_ok && Bt.a[q].pwg && Bt.a[q].npwg > 0; npt += (unsigned)Bt.a[q].npwg; }
-      if (ptab_ok && both_on && !chunks) {
-        const dim3 gboth(nwgf + npt, 1, (unsigned)nslots);
-        if (all_patch) hipLaunchKernelGGL((k_faces_curv_both<true>), gboth, dim3(256), 0, ctx->stream, Bt, ctx->d_flags, sk, nwgf);
-        else hipLaunchKernelGGL((k_faces_curv_both<false>), gboth, dim3(256), 0, ctx->stream, Bt, ctx->d_flags, sk, nwgf);
-        both_done = true;
-      } else if (chunks) {  // round 6: the face interiors from the levels' chunk records, the perimeters' work tables in front of them
-        // ... when they are few next to the interiors (large faces: headline 5.906 -> 5.870 ms per pass); the many short perimeters of small
-        // faces run better as their own launch with their own register budget (irregular hierarchy: 6.50 against 6.60 ms merged).
-        // PA_FIX_PERIM_APART=1 / 0 (read per pass): never / always merged
-        const char* pae = getenv("PA_FIX_PERIM_APART");
-        const bool with_perim = ptab_ok && (pae ? !atoi(pae) : (both_on || npt * 8u <= Ck.w0[Bt.n]));  // (a rank's share of a sharded hierarchy: two short chains, always together)
-        const unsigned np = with_perim ? npt : 0u;
-        const dim3 gc(np + Ck.w0[Bt.n], 1, (unsigned)nslots);
-        if (all_patch) hipLaunchKernelGGL((k_faces_fix_chunks<true>), gc, dim3(256), 0, ctx->stream, Bt, Ck, ctx->d_flags, sk, np);
-        else hipLaunchKernelGGL((k_faces_fix_chunks<false>), gc, dim3(256), 0, ctx->stream, Bt, Ck, ctx->d_flags, sk, np);
-        both_done = with_perim;
-      } else if (all_patch) hipLaunchKernelGGL((k_faces_curv_fast<1, true>), gfast, dim3(256), 0, ctx->stream, Bt, ctx->d_flags, SlowList(), sk);
-      else hipLaunchKernelGGL((k_faces_curv_fast<1, false>), gfast, dim3(256), 0, ctx->stream, Bt, ctx->d_flags, SlowList(), sk);
-    }
-    const dim3 gper((unsigned)((nper + 255) / 256), (unsigned)Bt.ycum[Bt.n], (unsigned)nslots);
-    unsigned nptab = 0;  // perimeter work tables of every level of the batch (PA_FIX_PTAB=0, read per pass: the (perimeter, face) grid)
-    bool ptab = !(getenv("PA_FIX_PTAB") && !atoi(getenv("PA_FIX_PTAB")));
-    for (int q = 0; q < Bt.n; ++q) { ptab = ptab && Bt.a[q].pwg && Bt.a[q].npwg > 0; nptab += (unsigned)Bt.a[q].npwg; }
-    const dim3 gtab(nptab, 1, (unsigned)nslots);
-    if (both_done) {
-    } else if (ptab) {
-      if (clip) {
-        if (all_patch) hipLaunchKernelGGL((k_faces_curv_tab<true, true, true>), gtab, dim3(256), 0, pst, Bt, ctx->d_flags, sk);
-        else hipLaunchKernelGGL((k_faces_curv_tab<true, false, true>), gtab, dim3(256), 0, pst, Bt, ctx->d_flags, sk);
-      } else if (all_patch) hipLaunchKernelGGL((k_faces_curv_tab<true, true>), gtab, dim3(256), 0, pst, Bt, ctx->d_flags, sk);
-      else hipLaunchKernelGGL((k_faces_curv_tab<true, false>), gtab, dim3(256), 0, pst, Bt, ctx->d_flags, sk);
-    } else if (clip) {
-      if (all_patch) hipLaunchKernelGGL((k_faces_curv<true, true, true>), gper, dim3(256), 0, pst, Bt, ctx->d_flags, sk);
-      else hipLaunchKernelGGL((k_faces_curv<true, false, true>), gper, dim3(256), 0, pst, Bt, ctx->d_flags, sk);
-    } else if (all_patch) hipLaunchKernelGGL((k_faces_curv<true, true>), gper, dim3(256), 0, pst, Bt, ctx->d_flags, sk);
-    else hipLaunchKernelGGL((k_faces_curv<true, false>), gper, dim3(256), 0, pst, Bt, ctx->d_flags, sk);
-    if (pst != ctx->stream) {
-      PA_HIP(hipEventRecord(ctx->fix_evs[1], pst));
-      PA_HIP(hipStreamWaitEvent(ctx->stream, ctx->fix_evs[1], 0));
+    } else {
+      // The face interiors from the chunk records, the perimeters' work tables IN FRONT of them in the same launch when they are few next
+      // to the interiors (large faces: headline 5.906 -> 5.870 ms per pass) or on a rank's share of a sharded hierarchy (two short
+      // chains, always together); the many short perimeters of small faces run better as their own launch with their own register
+      // budget (irregular hierarchy: 6.50 against 6.60 ms merged).  (The perimeter kernel on a side stream next to the interiors was
+      // measured twice and bought nothing: DESIGN_HISTORY.md R2, R4.)
+      const bool sharded = nlev > 0 && phi[0]->lev->nranks > 1;
+      const bool with_perim = sharded || npt * 8u <= Ck.w0[Bt.n];
+      const unsigned np = with_perim ? npt : 0u;
+      const dim3 gc(np + Ck.w0[Bt.n], 1, (unsigned)nslots);
+      if (all_patch) hipLaunchKernelGGL((k_faces_fix_chunks<true>), gc, dim3(256), 0, ctx->stream, Bt, Ck, ctx->d_flags, sk, np);
+      else hipLaunchKernelGGL((k_faces_fix_chunks<false>), gc, dim3(256), 0, ctx->stream, Bt, Ck, ctx->d_flags, sk, np);
+      if (!with_perim) {
+        if (all_patch) hipLaunchKernelGGL((k_faces_curv_tab<true, true>), gtab, dim3(256), 0, ctx->stream, Bt, ctx->d_flags, sk);
+        else hipLaunchKernelGGL((k_faces_curv_tab<true, false>), gtab, dim3(256), 0, ctx->stream, Bt, ctx->d_flags, sk);
+      }
     }
   }
   // general BoxArrays: the listed irregular cells, after (and over) whatever the kernels above wrote there; the lists of up to

@@ -12,6 +12,29 @@
 
 struct DBox { int lo[3]; int hi[3]; };
 
+// ---- pa_options: EVERY environment switch of the library (round 6: 76 ad-hoc getenv sites before).  Read once -- when the first
+// context is created -- and again only when the caller asks (pa_options_reload: tests and bench.py --ab flip a switch between two
+// passes of one process).  Each one selects between code paths that both exist for a reason (a class of inputs needs the other
+// path, or a result is only verifiable one way); the A/B switches of measured-and-lost experiments are gone with their losing sides
+// (DESIGN_HISTORY.md lists them).  tests/test_options.py flips every one.  The tools' own switches: tools/common/pa_parmparse.h.
+struct pa_options {
+  int filter_exact = 0;               // PA_FILTER_EXACT=1: Filter::apply_filter in the reference's tap order (bit-exact) instead of the separable form (<= 1e-12 Linf)
+  int allow_unverified_gaussian = 0;  // PA_ALLOW_UNVERIFIED_GAUSSIAN=1: filter_type 2 with the textbook weights (unverified against PelePhysics)
+  int retile_max[3] = {0, 0, 0};      // PA_RETILE_MAX="x y z": limits of the internal tiling instead of pa_hierarchy_retile_limits' choice
+  int fused2 = 1;                     // PA_FUSED2=0: the first fused pipeline (two-layer fix-up from a resolved shell of c) wherever it is legal
+  int ncg = 1;                        // PA_NCG=0: the sweep does not mirror the first layer behind special x faces for the fix-up
+  int dist_early = 0;                 // PA_DIST_EARLY=1: sharded pass, early tiles of the sweep on the side stream under exchange A
+  int smooth_replicated = 0;          // PA_SMOOTH_REPLICATED=1: do_smooth on a sharded hierarchy as N replicated solves (the one-rank bits)
+  int smooth_mg = -1;                 // PA_SMOOTH_MG=1 / 0: the multigrid preconditioner always / never (default: where dt / dx^2 > 8)
+  int smooth_march = 1;               // PA_SMOOTH_MARCH=0: the cell-per-thread stencil kernels of the solve
+  int smooth_timing = 0;              // PA_SMOOTH_TIMING=1: setup / iteration times of a solve on stderr
+  int force_fallbacks = 0;            // PA_FORCE_FALLBACKS=1 (tests): every path that exists for inputs the tuned one does not take -- FillBoundary /
+                                      // patch gather per ghost cell (regions that do not fit a plan), the sweeps group by group (more groups than a
+                                      // launch holds), the first form of the marching-cubes cell pass (FABs wider than 819 cells) and its
+                                      // level-by-level loop, FillPatchTwoLevels per ghost cell (ratio != 2), ghost fills level by level -- on ANY input
+};
+const pa_options& pa_opt();
+
 // Device view of one AMR level: the BoxArray plus an "owner map" -- a coarse
 // 3-D table at granularity g (gcd of all box origins/extents) that answers
 // "which box owns cell (i,j,k)" with one load.  Replaces AMReX's BoxArray hash.

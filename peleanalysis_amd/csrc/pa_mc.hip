@@ -1367,10 +1367,8 @@ static long long* mc_pinned(pa_ctx* ctx, size_t n) {
 // 28-row slabs (a quarter of the 4096 cells a workgroup holds per plane) and the workgroups of the largest FAB's tile count, most of
 // which left at once: on the bench's irregular hierarchy the pass ran at 1.8 TB/s against 4.4 on 128^3 boxes.  Here every FAB gets
 // as many rows of ITS width as fit and only the tiles it has.  Null for levels of equal boxes (the tuned path).  Cached per level,
-// ghost width and planes per workgroup; PA_MC_TILETAB=0: never (A/B, read per call).
+// ghost width and planes per workgroup.
 static const WgTab* mcl_tiletab(const pa_level* L, int ng, int kseg, int cap_cells) {
-  const char* e = getenv("PA_MC_TILETAB");
-  if (e && !atoi(e)) return nullptr;
   bool same = true;
   for (const DBox& B : L->boxes)
     for (int d = 0; d < 3; ++d) same = same && (B.hi[d] - B.lo[d] + 1 == L->maxn[d]);
@@ -1425,24 +1423,20 @@ static int mc_phase1(pa_ctx* ctx, MclWork& W, unsigned char* scr, unsigned char*
   PA_HIP(hipMemcpyAsync(d_coff, W.coff.data(), 8 * ((size_t)nb + 1), hipMemcpyHostToDevice, ctx->stream));
   PA_HIP(hipMemcpyAsync(d_loops, W.dl.data(), sizeof(DBox) * (size_t)nb, hipMemcpyHostToDevice, ctx->stream));
   {
-    const char* te = getenv("PA_MC_TY");  // first form only: tile rows / planes per workgroup of the cell pass (tuning, read per call)
-    const char* ke = getenv("PA_MC_KSEG");
-    const char* fe = getenv("PA_MC_CELLS");  // "tiles": the first form of the cell pass (kept for A/B measurements)
-    const int TY = te ? atoi(te) : 8;
-    if (ke && atoi(ke) > 0) A.kseg = atoi(ke);
+    constexpr int TY = 8;  // tile rows of the first form of the cell pass (FABs too wide for the slab form)
     const int mx = L->maxn[0] + 2 * ng, my = L->maxn[1] + 2 * ng, mz = L->maxn[2] + 2 * ng;
     auto tiles = [&](int ty) { return (unsigned)(std::max(1, (mx - 1 + 62) / 63) * std::max(1, (my - 1 + ty - 2) / (ty - 1)) * ((mz + A.kseg - 1) / A.kseg)); };
     // bact | alist | nact are adjacent and bsum precedes lc: two clears (bsum; bact .. nact)
     PA_HIP(hipMemsetAsync(A.bsum, 0, 8 * nblk, ctx->stream));
     PA_HIP(hipMemsetAsync(A.bact, 0, (size_t)((unsigned char*)A.nact - A.bact) + 4, ctx->stream));
     constexpr int NT4 = 512, GPT4 = 2;  // 4096 cells of a plane per workgroup
-    if (!(fe && std::string(fe) == "tiles") && (long long)mx * 5 <= 4LL * NT4 * GPT4) {
+    if ((long long)mx * 5 <= 4LL * NT4 * GPT4 && !pa_opt().force_fallbacks) {
       // slab = as many whole rows as fit next to their halo row, evened out over the slabs of the largest FAB, multiple of 4
       const int rmax = std::max(4, ((4 * NT4 * GPT4) / mx - 1) / 4 * 4);
       const int ns0 = (my + rmax - 1) / rmax;
       A.rows = std::min(rmax, ((my + ns0 - 1) / ns0 + 3) / 4 * 4);
       A.nslab = (my + A.rows - 1) / A.rows;
-      if (!ke) {  // enough workgroups for 8 per CU in flight, planes re-read at the segment ends <= 1 in 16
+      {  // enough workgroups for 8 per CU in flight, planes re-read at the segment ends <= 1 in 16
         const long long want = 6144;
         const int nseg = (int)std::min<long long>(std::max<long long>(1, mz / 16), std::max<long long>(1, (want + (long long)nb * A.nslab - 1) / ((long long)nb * A.nslab)));
         A.kseg = (mz + nseg - 1) / nseg;
@@ -1459,9 +1453,7 @@ static int mc_phase1(pa_ctx* ctx, MclWork& W, unsigned char* scr, unsigned char*
       else hipLaunchKernelGGL((k_mcl_cells4<NT4, GPT4, 2>), g4, dim3(NT4), lds4, ctx->stream, A);
     } else {
       W.full_codes = true;  // the first form writes the codes of every cell: the code buffer is cleared as a whole afterwards
-      if (TY == 16) hipLaunchKernelGGL((k_mcl_cells<16>), dim3(tiles(16), (unsigned)nb), dim3(64 * 16), 0, ctx->stream, A);
-      else if (TY == 4) hipLaunchKernelGGL((k_mcl_cells<4>), dim3(tiles(4), (unsigned)nb), dim3(64 * 4), 0, ctx->stream, A);
-      else hipLaunchKernelGGL((k_mcl_cells<8>), dim3(tiles(8), (unsigned)nb), dim3(64 * 8), 0, ctx->stream, A);
+      hipLaunchKernelGGL((k_mcl_cells<TY>), dim3(tiles(TY), (unsigned)nb), dim3(64 * TY), 0, ctx->stream, A);
     }
     hipLaunchKernelGGL(k_mcl_active, dim3((unsigned)((nblk + 1023) / 1024)), dim3(1024), 0, ctx->stream, A, (int)nblk);
   }
@@ -1669,8 +1661,7 @@ static int mc_run_batched(pa_ctx* ctx, int nlev, MclWork* W) {
 // nlev levels (one for the single-level entry points): see MclWork
 static int mc_run(pa_ctx* ctx, int nlev, MclWork* W) {
   {  // all levels in one set of launches when each of them takes the slab form of the cell pass with the mask evaluated in place
-    const char* be = getenv("PA_MC_BATCH");  // 0: level by level (A/B), read per call
-    bool batched = nlev > 1 && nlev <= PA_MAXB && (!be || atoi(be)) && !getenv("PA_MC_CELLS") && !getenv("PA_MC_KSEG");
+    bool batched = nlev > 1 && nlev <= PA_MAXB && !pa_opt().force_fallbacks;
     for (int l = 0; l < nlev && batched; ++l) {
       const int mx = W[l].state->lev->maxn[0] + 2 * W[l].state->ng;
       batched = W[l].nb > 0 && W[l].maxcell > 0 && W[l].A.nomask && !W[l].dim2 && (long long)mx * 5 <= 4LL * 512 * 2;

@@ -80,9 +80,8 @@ extern "C" int pa_grad_run(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp,
       if (state[l]->ng < 1 || comp < 0 || comp >= state[l]->ncomp) return pa_fail(ctx, "pa_grad_run: state needs >= 1 ghost layer and the component");
     // applyBC of every level on the side stream NEXT TO FillBoundary: it reads valid cells and coarse valid cells and writes
     // the ghost cells behind special faces that are NOT valid cells of the level, FillBoundary writes those that are -- disjoint
-    // (as k_prep_faces in the fused pass).  PA_GRAD_BC_SIDE=0 (read per call): one stream
-    const char* se = getenv("PA_GRAD_BC_SIDE");
-    if (!se || atoi(se)) {
+    // (as k_prep_faces in the fused pass)
+    {
       if (!ctx->stream2) PA_HIP(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
       while (ctx->sync_evs.size() < 2) {
         hipEvent_t e;
@@ -94,10 +93,9 @@ extern "C" int pa_grad_run(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp,
       {
         StreamSwap sw(ctx, ctx->stream2);
         // the face ghosts of every level in ONE launch on the per-face work tables, coarse values from the gathered coarse patches
-        // (k_prep_faces<.., PHIONLY>, pa_fused.hip: 0.43 -> ~0.2 ms on the headline hierarchy); PA_GRAD_BC_PATCH=0 (read per call),
+        // (k_prep_faces_chunks<.., PHIONLY>, pa_fused.hip: 0.43 -> ~0.2 ms on the headline hierarchy);
         // 2-D hierarchies (one plane of cells: the patches are a 3-D layout): applyBC level by level
-        const char* pe = getenv("PA_GRAD_BC_PATCH");
-        bool patch = !pe || atoi(pe);
+        bool patch = true;
         for (int l = 0; l < nlev; ++l) patch = patch && state[l]->lev->domhi[2] > state[l]->lev->domlo[2];
         if (patch) {
           std::vector<const pa_mf*> crse((size_t)nlev, nullptr);
@@ -284,62 +282,49 @@ static int fused_passes_dist(pa_ctx* ctx, int nlev, pa_mf* const* state, int com
     jobs.push_back({&cs[l]->x, state[l - 1], comp, csphi[l], 0, 1});
   }
   if (exact) {
-    // Exact-normal pipeline with the exchanges on a side stream (PA_XOVERLAP, default on): exchange A runs next to the
-    // local half of FillBoundary; the coarse normals of level l+1 (exchange B, split per level) leave as soon as sweep(l)
-    // is done and travel under the sweeps of the finer levels -- only the last piece and exchange A are exposed.
-    //   stream A: [FillBoundary local] wait(A) prep sweep(0) sweep(1)        sweep(2) wait(B) fix
-    //   stream C: [exchange A        ]                  B(1) ...      B(2) ...
-    static const int xov = [] { const char* e = getenv("PA_XOVERLAP"); return e ? atoi(e) : 1; }();
+    // Exact-normal pipeline of a sharded hierarchy.  Two grouped exchanges: A (ghost cells of phi + coarse phi under coarse-fine faces)
+    // and B (the coarse normals, after the sweeps).  The chain the sweep waits for -- exchange A, patch gather + faces, ring -- is on
+    // the main stream, the LOCAL FillBoundary next to it on the side stream (the other way round cost a stream hand-over of ~26 us on
+    // the critical path, round 3); the sweeps of all levels are ONE launch (per-XCD queues of tile chunks keep it balanced: two
+    // launches pay two tails, round 5), exchange B after it.
+    //   stream A: [exchange A][patches + faces]  wait(C) [ring][sweep: late tiles / all] wait(C) [exchange B][fix-up]
+    //   stream C: [FillBoundary local][sweep: early tiles (PA_DIST_EARLY=1)]
+    // The variants this replaced (exchange on the side stream, a launch per level with its exchange under the next sweep, the finest
+    // level's sweep apart) and their measurements: DESIGN_HISTORY.md R2-R5, profiles/r04_sim8_delay.txt, r05_sim8_delay.txt.
     std::vector<const pa_mf*> crse(csphi.begin(), csphi.end()), crse_n(csn.begin(), csn.end());
-    hipStream_t A = ctx->stream, C = A;
-    const size_t nev = 3 + (size_t)nlev;
-    if (xov) {
-      if (!ctx->stream2) PA_HIP(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
-      C = ctx->stream2;
-      while (ctx->sync_evs.size() < nev) {
-        hipEvent_t e;
-        PA_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        ctx->sync_evs.push_back(e);
-      }
-      PA_HIP(hipEventRecord(ctx->sync_evs[0], A));  // the side stream starts after everything already queued (inputs, the previous pass)
-      PA_HIP(hipStreamWaitEvent(C, ctx->sync_evs[0], 0));
+    hipStream_t A = ctx->stream;
+    if (!ctx->stream2) PA_HIP(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+    hipStream_t C = ctx->stream2;
+    while (ctx->sync_evs.size() < 3) {
+      hipEvent_t e;
+      PA_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      ctx->sync_evs.push_back(e);
     }
-    // PA_DIST_FB_SIDE (default 1, read per pass): the LOCAL FillBoundary goes to the side stream and the chain the sweep waits
-    // for -- exchange A, patch gather + k_prep_faces, k_prep_ring -- stays on the main stream: the wait for the side stream then
-    // hits an event that completed long ago.  0 (round 2): the exchange + faces on the side stream, whose hand-over back to the
-    // main stream sat on the critical path (rank 0 of 8, kernel trace: 26 us between k_prep_faces' end and k_prep_ring's start)
-    const char* fse = getenv("PA_DIST_FB_SIDE");
-    const bool fb_side = xov && (!fse || atoi(fse));
+    PA_HIP(hipEventRecord(ctx->sync_evs[0], A));  // the side stream starts after everything already queued (inputs, the previous pass)
+    PA_HIP(hipStreamWaitEvent(C, ctx->sync_evs[0], 0));
     {
-      StreamSwap sw(ctx, fb_side ? A : C);
-      {
-        ProfScope prof(ctx, PA_TAG_XCHG);
-        PA_TRY(pa_xexchange(ctx, (int)jobs.size(), jobs.data()));
-      }
-      // the faces' half of the ghost preparation (patch gather + k_prep_faces) reads valid cells and the coarse data that
-      // just arrived, and writes only ghost cells behind special faces: it runs next to the local FillBoundary
-      // (as in the single-GPU pass; rank 0 of 8: k_prep_faces 45 us against FillBoundary 39 us)
-      if (xov) PA_TRY(pa_gradcurv_prep_levels(ctx, nlev, state, comp, crse.data(), 0, bc, pmin, pmax, 1));
+      ProfScope prof(ctx, PA_TAG_XCHG);
+      PA_TRY(pa_xexchange(ctx, (int)jobs.size(), jobs.data()));
     }
-    if (xov && !fb_side) PA_HIP(hipEventRecord(ctx->sync_evs[1], C));
+    // the faces' half of the ghost preparation (patch gather + faces) reads valid cells and the coarse data that just arrived, and
+    // writes only ghost cells behind special faces: it runs next to the local FillBoundary
+    PA_TRY(pa_gradcurv_prep_levels(ctx, nlev, state, comp, crse.data(), 0, bc, pmin, pmax, 1));
     {
-      StreamSwap sw(ctx, fb_side ? C : A);
+      StreamSwap sw(ctx, C);
       ProfScope prof(ctx, PA_TAG_FILL);
       PA_TRY(pa_fill_boundary_local_batch(ctx, nlev, state, comp, 1, 2));
     }
-    if (fb_side) PA_HIP(hipEventRecord(ctx->sync_evs[1], C));
-    // round 6: EARLY TILES (PA_DIST_EARLY=1, read per pass; OFF by default).  A tile of the sweep whose read region touches only valid
-    // cells of this rank's own boxes has its input complete once the LOCAL FillBoundary is done; those tiles (pa_sweep_wgtab part 1:
-    // 30 % of an 8-way share of the headline) are swept on the side stream right behind it -- under exchange A, the patch gather, the
-    // face and ring preparation -- and only the tiles next to another rank's box or to a special face wait for that chain.
-    // Bit-identical (tests/test_gpu_dist.py runs both), and measured with the delay-model transport on rank 0's share of 8
+    PA_HIP(hipEventRecord(ctx->sync_evs[1], C));
+    // EARLY TILES (PA_DIST_EARLY=1; OFF by default).  A tile of the sweep whose read region touches only valid cells of this rank's
+    // own boxes has its input complete once the LOCAL FillBoundary is done; those tiles (pa_sweep_wgtab part 1: 30 % of an 8-way share
+    // of the headline) are swept on the side stream right behind it -- under exchange A, the patch gather, the face and ring
+    // preparation -- and only the tiles next to another rank's box or to a special face wait for that chain.  Bit-identical
+    // (tests/test_gpu_dist.py runs both), and measured with the delay-model transport on rank 0's share of 8
     // (profiles/r06_sim8_delay.txt): 1.108 -> 1.100 ms per pass with 68-us exchanges, 1.024 -> 1.033 with 18 us + bytes / 153 GB/s,
     // 0.955 -> 0.965 with no-op exchanges.  Why it hides so little: an eighth of the headline is 480 tiles on 256 CUs, one workgroup
     // per CU -- two rounds of ~350 us as ONE launch, but 150 early + 330 late tiles are one round + two rounds.  It pays only where
     // an exchange costs more than a round is long; on a hierarchy with more work per rank the rounds stop mattering.
-    const char* ete = getenv("PA_DIST_EARLY");
-    const char* dsb0 = getenv("PA_DIST_SWEEP_BATCH");
-    const bool early = fb_side && ete && atoi(ete) && (!dsb0 || atoi(dsb0) == 1) && pa_gradcurv_parts_ok(nlev, state);
+    const bool early = pa_opt().dist_early && pa_gradcurv_parts_ok(nlev, state);
     if (early) {
       {
         StreamSwap sw(ctx, C);
@@ -347,59 +332,15 @@ static int fused_passes_dist(pa_ctx* ctx, int nlev, pa_mf* const* state, int com
       }
       PA_HIP(hipEventRecord(ctx->sync_evs[2], C));
     }
-    if (xov) PA_HIP(hipStreamWaitEvent(A, ctx->sync_evs[1], 0));
-    PA_TRY(pa_gradcurv_prep_levels(ctx, nlev, state, comp, crse.data(), 0, bc, pmin, pmax, xov ? 2 : 3));
-    // PA_DIST_SWEEP_BATCH=1 (default): the sweeps of all levels in one launch (a rank's share of a level is 1-2 rounds of
-    // workgroups: per-level launches end in idle tails), then ONE grouped exchange of the coarse normals of all levels;
-    // 0: level by level, each level's exchange on the side stream next to the following sweep
-    const char* dsbe = getenv("PA_DIST_SWEEP_BATCH");  // read per pass (A/B)
-    // default 2 (round 4): with the delay-model transport (68 us per exchange: 50 us + 2.2 MB to the busiest peer at 120 GB/s) rank
-    // 0 of 8 takes 1.140 ms per pass against 1.170 with one launch, with no-op exchanges 1.046 against 1.022: the split pays as soon
-    // as an exchange costs more than ~25 us, which a grouped RCCL send / receive always does (profiles/r04_sim8_delay.txt)
-    // round 5: back to 1.  With the sweep's workgroup tables as per-XCD queues of tile chunks the ONE launch over all levels is
-    // balanced, and two launches pay two tails: alternating blocks inside one process (bench.py --sim-of 8 --ab
-    // PA_DIST_SWEEP_BATCH=2,1): 1.062 against 1.079 ms with 32-us exchanges, 0.997 against 1.030 with no-op exchanges
-    // (profiles/r05_sim8_delay.txt)
-    const int dsb = dsbe ? atoi(dsbe) : 1;
-    if (dsb) {
-      // 1 (default): one launch for all levels, exchange B exposed after it.  2: the finest level's sweep is a launch of its
-      // own and exchange B -- which needs the normals of every level BUT the finest -- travels under it on the side stream
-      // (pack, grouped send / recv, unpack).  Rank 0's share of an 8-way shard of the headline, exchanges as no-ops: 1.04 /
-      // 0.97 ms per pass against 1.08 / 1.05 with the split (two launches' tails + the pack / unpack kernels next to the
-      // sweep): it pays only where exchange B takes longer than ~0.05-0.09 ms on the fabric, which one GPU cannot tell.
-      const bool split = dsb >= 2 && xov && nlev >= 2;
-      PA_TRY(pa_gradcurv_levels_cg(ctx, split ? nlev - 1 : nlev, state, comp, pmin, pmax, out, ocomp, thr, 0, 1, nullptr, nullptr, nullptr, gout, early ? 2 : 0));
-      if (early) PA_HIP(hipStreamWaitEvent(A, ctx->sync_evs[2], 0));  // the early tiles' normals go into exchange B and the fix-up too
+    PA_HIP(hipStreamWaitEvent(A, ctx->sync_evs[1], 0));
+    PA_TRY(pa_gradcurv_prep_levels(ctx, nlev, state, comp, crse.data(), 0, bc, pmin, pmax, 2));
+    PA_TRY(pa_gradcurv_levels_cg(ctx, nlev, state, comp, pmin, pmax, out, ocomp, thr, 0, 1, nullptr, nullptr, nullptr, gout, early ? 2 : 0));
+    if (early) PA_HIP(hipStreamWaitEvent(A, ctx->sync_evs[2], 0));  // the early tiles' normals go into exchange B and the fix-up too
+    {
       std::vector<XJob> nj;
       for (int l = 1; l < nlev; ++l) nj.push_back({&cs[l]->x, out[l - 1], ncomp0, csn[l], 0, 3});
-      if (split) {
-        PA_HIP(hipEventRecord(ctx->sync_evs[3], A));
-        PA_HIP(hipStreamWaitEvent(C, ctx->sync_evs[3], 0));
-      }
-      {
-        StreamSwap sw(ctx, split ? C : A);
-        ProfScope prof(ctx, PA_TAG_XCHG);
-        PA_TRY(pa_xexchange(ctx, (int)nj.size(), nj.data()));
-      }
-      if (split) PA_TRY(pa_gradcurv_levels_cg(ctx, 1, state + (nlev - 1), comp, pmin, pmax, out + (nlev - 1), ocomp, thr, 0, 1, nullptr, nullptr, nullptr, gout ? gout + (nlev - 1) : nullptr));
-    }
-    if (gout && !dsb) return pa_fail(ctx, "fused_passes_dist: the G-output sweeps need the all-levels launch (PA_DIST_SWEEP_BATCH != 0)");
-    for (int l = 0; l < nlev && !dsb; ++l) {
-      PA_TRY(pa_gradcurv_level_cg(ctx, state[l], comp, pmin, pmax, out[l], ocomp, thr));
-      if (l + 1 < nlev) {  // the coarse normals level l+1 needs: every rank takes part, whatever it owns
-        if (xov) {
-          PA_HIP(hipEventRecord(ctx->sync_evs[3 + l], A));
-          PA_HIP(hipStreamWaitEvent(C, ctx->sync_evs[3 + l], 0));
-        }
-        XJob J = {&cs[l + 1]->x, out[l], ocomp + 4, csn[l + 1], 0, 3};
-        StreamSwap sw(ctx, C);
-        ProfScope prof(ctx, PA_TAG_XCHG);
-        PA_TRY(pa_xexchange(ctx, 1, &J));
-      }
-    }
-    if (xov) {
-      PA_HIP(hipEventRecord(ctx->sync_evs[2], C));
-      PA_HIP(hipStreamWaitEvent(A, ctx->sync_evs[2], 0));
+      ProfScope prof(ctx, PA_TAG_XCHG);
+      PA_TRY(pa_xexchange(ctx, (int)nj.size(), nj.data()));
     }
     PA_TRY(pa_gradcurv_fix_levels(ctx, nlev, state, comp, crse_n.data(), 0, bc, pmin, pmax, out, ncomp0, kcomp, thr, 1, nullptr, 8, crse.data(), 0));
     return 0;
@@ -439,7 +380,7 @@ static int fused_passes_dist(pa_ctx* ctx, int nlev, pa_mf* const* state, int com
 // without -- the sweep slows from 2.23-2.31 to 2.57-2.60 ms per launch and gives back everything the second
 // stream hides: both sides wait on the same memory path.  Kept for A/B (PA_OVERLAP=1), OFF by default.
 static int overlap_on() {
-  static const int v = [] { const char* e = getenv("PA_OVERLAP"); return e ? atoi(e) : 0; }();
+  constexpr int v = 0;
   return v;
 }
 
@@ -462,7 +403,7 @@ static int fused_faces(pa_ctx* ctx, int l, const int32_t bc[3], double thr, pa_m
 // the memory system and running the levels side by side does pay: 4 levels of 256^3 in 64^3 boxes 16.6-17.0 -> 16.2 ms
 // per 8-component step; on the 512^3 headline levels it costs 1 % (above).
 static int conc_on(int nlev, pa_mf* const* state) {
-  static const int v = [] { const char* e = getenv("PA_CONC"); return e ? atoi(e) : -1; }();
+  constexpr int v = -1;
   if (v >= 0) return v;
   long long big = 0;
   for (int l = 0; l < nlev; ++l) {
@@ -536,14 +477,11 @@ static int exact_passes(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, co
     // k_prep_faces (latency bound: dependent lookups, 1.8 TB/s) runs on the side stream NEXT TO FillBoundary (bandwidth
     // bound): it reads valid cells and coarse data and writes the ghost cells of special faces + the compact arrays, FillBoundary
     // writes the ghost cells that are valid cells elsewhere -- disjoint on pure faces, which this pipeline requires.
-    // PA_PREP_OVERLAP=0: one stream.  Measured with tools/ab_driver.py (alternating blocks in one process): 6.588 against
-    // 6.642 ms per pass.  The same tool on the two other overlaps that look plausible: the perimeter fix-up kernel next to
+    // Measured with tools/ab_driver.py (alternating blocks in one process): 6.588 against 6.642 ms per pass on one stream.  The same tool on the two other overlaps that look plausible: the perimeter fix-up kernel next to
     // the interior one +0.009 ms (nothing), the fix-up of level l under the sweep of level l + 1 -0.21 ms (the sweep pays
     // more than the fix-up hides) -- neither is kept.
-    const char* pove = getenv("PA_PREP_OVERLAP");  // read per pass: tools/ab_driver.py alternates it inside one process
-    const int pov = pove ? atoi(pove) : 1;
-    const char* rse = getenv("PA_RING_SIDE");  // 0: k_prep_ring after FillBoundary on the main stream (A/B)
-    const bool ring_side = !rse || atoi(rse);
+    constexpr int pov = 1;
+    constexpr bool ring_side = true;  // the ring with the faces: it reads its neighbours' valid cells in place
     if (pov) {
       if (!ctx->stream2) PA_HIP(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
       while (ctx->sync_evs.size() < 2) {
@@ -674,8 +612,7 @@ static int curvature_fast(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, 
   if (gauss || strain) {
     pa_mf* const* F1 = gauss ? G.data() : state;
     const int c1 = gauss ? 0 : P->vel_comp;
-    const char* bme = getenv("PA_BC_MULTI");  // 0 (read per call): a launch per level and component
-    int rc = (!dist && !(bme && !atoi(bme))) ? pa_apply_bc_multi(ctx, nlev, F1, c1, 3, (gauss && strain) ? state : nullptr, P->vel_comp, 3, bc) : 2;
+    int rc = !dist ? pa_apply_bc_multi(ctx, nlev, F1, c1, 3, (gauss && strain) ? state : nullptr, P->vel_comp, 3, bc) : 2;
     if (rc == 1) return 1;
     if (rc == 2) {
       for (int l = 0; l < nlev && gauss; ++l)
@@ -686,9 +623,8 @@ static int curvature_fast(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, 
   }
   const int which = (gauss ? 1 : 0) | (strain ? 2 : 0) | (veln ? 4 : 0);
   // the Gaussian curvature apart from strain + normal velocity: 80 and 118 VGPRs against 158 for all three in one kernel, c read twice;
-  // 17.1 against 17.6 ms per headline pass (PA_OPT_SPLIT=0, read per call: one kernel)
-  const char* spe = getenv("PA_OPT_SPLIT");
-  const bool split = !(spe && !atoi(spe)) && (which & 1) && (which & 6);
+  // 17.1 against 17.6 ms per headline pass in one kernel
+  const bool split = (which & 1) && (which & 6);
   for (int l = 0; l < nlev && which; ++l) {
     if (split) {
       PA_TRY(pa_curvopts_level(ctx, 1, G[l], state[l], P->vel_comp, out[l], opt, opt + 2, opt + 5, opt + 6, opt + 7, -1, thr));
@@ -718,8 +654,8 @@ static bool all_fusable(int nlev, pa_mf* const* state) {
 
 // can the exact-normal pipeline take this hierarchy (the same answer on every rank)?
 static bool exact_ok(int nlev, pa_mf* const* state, double thr) {
-  const char* c2e = getenv("PA_FUSED2_CLIP");  // read per pass (tests, tools/ab_driver.py)
-  bool exact = !(thr >= 0.0) || !c2e || atoi(c2e);
+  (void)thr;  // (the threshold clip stays on this pipeline since round 3)
+  bool exact = pa_opt().fused2 != 0;  // PA_FUSED2=0: the first fused pipeline wherever it is legal
   for (int l = 0; l < nlev; ++l) exact = exact && state[l]->ng >= 2 && pa_fused2_level_ok(state[l]->lev);
   return exact;
 }
@@ -748,11 +684,10 @@ extern "C" int pa_curvature_run(pa_ctx* ctx, int nlev, pa_mf* const* state, int 
     return pa_fail(ctx, "pa_curvature_run: do_gauss_curv is not available for 2-D levels (spacedim = 2)");
   // Fast path (round 5): Progress, K and N from the exact-normal pipeline -- its G-output sweeps leave the cell-centred gradient
   // of c in a work multifab of the level instead of grad phi -- then ONE pass per level for the options.  One rank, 3-D, no
-  // smoothing solve, a hierarchy the all-levels sweeps take; PA_CURV_FAST=0 (read per call) or fused = 0: pass by pass.
+  // smoothing solve, a hierarchy the all-levels sweeps take; fused = 0: pass by pass.
   {
-    const char* cfe = getenv("PA_CURV_FAST");
     const bool dist = state[0]->lev->nranks > 1;
-    bool fast = P->fused && P->spacedim != 2 && (!cfe || atoi(cfe));
+    bool fast = P->fused && P->spacedim != 2;
     for (int l = 0; l < nlev && fast; ++l) fast = state[l]->ng >= 2 && (dist || !state[l]->lev->boxes.empty());
     fast = fast && exact_ok(nlev, state, thr) && pa_gradcurv_gout_ok(nlev, state);
     if (dist) {  // the answer depends on the boxes a rank owns: all ranks take the path every one of them can take
@@ -859,10 +794,8 @@ extern "C" int pa_gradcurv_run_comps2(pa_ctx* ctx, int nlev, pa_mf* const* state
     PA_HIP(hipMemcpyAsync(ctx->d_prog, prog.data(), sizeof(double) * 2 * ns, hipMemcpyHostToDevice, ctx->stream));
     PA_TRY(pa_gradcurv_prep_levels(ctx, nlev, state, g0, crse.data(), dist ? g0 - comp0 : g0, bc, pmins[0], pmaxs[0], 3, ns, ctx->d_prog));
     {
-      // the sweeps of the batch's components: ONE launch with the slot as a grid dimension (PA_SWEEP_SLOTS=0, read per pass:
-      // a launch per component, rounds 2-3)
-      const char* sse = getenv("PA_SWEEP_SLOTS");
-      if (ns > 1 && (!sse || atoi(sse))) PA_TRY(pa_gradcurv_levels_cg(ctx, nlev, state, g0, pmins[0], pmaxs[0], out, ocomp, thr, 0, ns, ctx->d_prog, pmins.data(), pmaxs.data()));
+      // the sweeps of the batch's components: ONE launch with the slot as a grid dimension
+      if (ns > 1) PA_TRY(pa_gradcurv_levels_cg(ctx, nlev, state, g0, pmins[0], pmaxs[0], out, ocomp, thr, 0, ns, ctx->d_prog, pmins.data(), pmaxs.data()));
       else for (int z = 0; z < ns; ++z) PA_TRY(pa_gradcurv_levels_cg(ctx, nlev, state, g0 + z, pmins[z], pmaxs[z], out, ocomp + 8 * z, thr, z));
     }
     if (dist) {

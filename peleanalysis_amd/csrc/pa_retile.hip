@@ -12,6 +12,7 @@
 // cubes numbers its nodes in box order (isosurface.cpp:1687-1726) and stays on the file's boxes.
 // tests/test_retile.py: the oracle is bitwise invariant under such re-tilings (the consistency pin of the recalled
 // applyBC / InterpBndryData restatement) and the HIP path on the re-tiled level equals the oracle on the ORIGINAL boxes.
+#include "pa_internal.h"
 #include <algorithm>
 #include <array>
 #include <cstdint>
@@ -235,12 +236,9 @@ extern "C" int pa_level_retile(int nboxes, const int32_t* b6, const int32_t max_
 // PA_RETILE_MAX="x y z" in the environment overrides.
 extern "C" int pa_hierarchy_retile_limits(int nlev, const int32_t* nboxes, const int32_t* const* boxes6, int min_thick, int32_t max_size[3]) {
   if (nlev <= 0 || !nboxes || !boxes6 || !max_size) return -1;
-  if (const char* e = getenv("PA_RETILE_MAX")) {
-    int v[3];
-    if (sscanf(e, "%d %d %d", &v[0], &v[1], &v[2]) == 3 && v[0] > 0 && v[1] > 0 && v[2] > 0) {
-      for (int d = 0; d < 3; ++d) max_size[d] = v[d];
-      return 0;
-    }
+  if (pa_opt().retile_max[0] > 0) {
+    for (int d = 0; d < 3; ++d) max_size[d] = pa_opt().retile_max[d];
+    return 0;
   }
   const int32_t big[3] = {512, 256, 256};
   bool ok = true;
@@ -270,7 +268,7 @@ extern "C" int pa_hierarchy_retile_limits(int nlev, const int32_t* nboxes, const
 // boxes on every level (or as many as the file has), starting at 128^3 wherever the one-rank choice is 128^3.
 extern "C" int pa_hierarchy_retile_limits_ranks(int nlev, const int32_t* nboxes, const int32_t* const* boxes6, int min_thick, int nranks, int32_t max_size[3]) {
   if (pa_hierarchy_retile_limits(nlev, nboxes, boxes6, min_thick, max_size) != 0) return -1;
-  if (nranks <= 1 || getenv("PA_RETILE_MAX")) return 0;
+  if (nranks <= 1 || pa_opt().retile_max[0] > 0) return 0;
   // round 6: 64^3 and 32^3 after 128^3 -- a small hierarchy on many ranks (base 64 on 8: one merged box per level, seven ranks
   // idle) keeps boxes for every rank; a level never needs more boxes than the file gave it
   const int32_t cand[6][3] = {{512, 256, 256}, {256, 256, 256}, {256, 256, 128}, {128, 128, 128}, {64, 64, 64}, {32, 32, 32}};

@@ -208,35 +208,10 @@ __global__ __launch_bounds__(256) void k_sdf_gather_tv(const SdfGrid* grids) {
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < 3 * G.ntri; i += (long long)gridDim.x * 256ll) G.tv[i] = G.x[G.tri[i]];
 }
 
-// :60-85 + :169-178: one workgroup per grid, hyperplane by hyperplane
-__global__ __launch_bounds__(1024) void k_sdf_sweeps(const SdfGrid* grids) {
-  const SdfGrid G = grids[blockIdx.x];
-  const int nu = G.ni - 1, nv = G.nj - 1, nw = G.nk - 1;  // points a sweep visits per direction
-  if (nu <= 0 || nv <= 0 || nw <= 0) return;              // an extent of 1: the reference's loops do not run
-  const int dirs[8][3] = {{1, 1, 1}, {-1, -1, -1}, {1, 1, -1}, {-1, -1, 1}, {1, -1, 1}, {-1, 1, -1}, {1, -1, -1}, {-1, 1, 1}};
-  const int nvw = nv * nw, nplanes = nu + nv + nw - 2;
-  for (int pass = 0; pass < 2; ++pass)
-    for (int s8 = 0; s8 < 8; ++s8) {
-      const int di = dirs[s8][0], dj = dirs[s8][1], dk = dirs[s8][2];
-      for (int s = 0; s < nplanes; ++s) {
-        // w in [max(0, s-(nu-1)-(nv-1)), min(nw-1, s)]: skip (v,w) pairs that cannot lie on plane s
-        const int wlo = max(0, s - (nu - 1) - (nv - 1)), whi = min(nw - 1, s);
-        for (int idx = wlo * nv + (int)threadIdx.x; idx < (whi + 1) * nv; idx += (int)blockDim.x) {
-          const int v = idx % nv, w = idx / nv, u = s - v - w;
-          if (u < 0 || u >= nu) continue;
-          const int i = di > 0 ? 1 + u : G.ni - 2 - u, j = dj > 0 ? 1 + v : G.nj - 2 - v, k = dk > 0 ? 1 + w : G.nk - 2 - w;
-          relax_point(G, i, j, k, di, dj, dk);
-        }
-        __syncthreads();  // workgroup-scope release/acquire: the next hyperplane reads what this one wrote
-      }
-      (void)nvw;
-    }
-}
-
-// The same sweeps with the points of a hyperplane spread over the whole chip: ONE LAUNCH PER HYPERPLANE (all grids of the
+// :60-85 + :169-178, the points of a hyperplane spread over the whole chip: ONE LAUNCH PER HYPERPLANE (all grids of the
 // batch side by side, blockIdx.y = grid), the kernel boundary is the barrier between hyperplanes and makes one step's
 // results visible to every CU of the next (per-XCD L2s are not coherent inside a launch).  Same points, same neighbour
-// order, same arithmetic as k_sdf_sweeps: bit-identical.  16 x (ni + nj + nk - 5) launches of a few microseconds each
+// order, same arithmetic as the reference's sequential loops: bit-identical to its output (tests/golden/sdf_ref.npz).  16 x (ni + nj + nk - 5) launches of a few microseconds each
 // instead of one workgroup walking ~6000 barriers with up to 12 points per thread behind each.
 __global__ __launch_bounds__(256) void k_sdf_sweep_plane(const SdfGrid* grids, int di, int dj, int dk, int s) {
   const SdfGrid G = grids[blockIdx.y];
@@ -335,9 +310,7 @@ extern "C" int pa_sdf_level_set3(pa_ctx* ctx, int ngrids, const pa_sdf_grid* gri
   }
   hipLaunchKernelGGL(k_sdf_unpack, dim3(gx_cells, (unsigned)ngrids), dim3(256), 0, ctx->stream, dg);
   if (max_tri > 0) hipLaunchKernelGGL(k_sdf_gather_tv, dim3((unsigned)std::min<long long>((3 * max_tri + 255) / 256, 4096), (unsigned)ngrids), dim3(256), 0, ctx->stream, dg);
-  static const int onewg = [] { const char* e = getenv("PA_SDF_ONEWG"); return e ? atoi(e) : 0; }();  // 1: one workgroup per grid (A/B)
-  if (max_tri > 0 && onewg) hipLaunchKernelGGL(k_sdf_sweeps, dim3((unsigned)ngrids), dim3(1024), 0, ctx->stream, dg);
-  if (max_tri > 0 && !onewg) {
+  if (max_tri > 0) {
     static const int dirs[8][3] = {{1, 1, 1}, {-1, -1, -1}, {1, 1, -1}, {-1, -1, 1}, {1, -1, 1}, {-1, 1, -1}, {1, -1, -1}, {-1, 1, 1}};
     int nplanes = 0;
     long long vw = 0;

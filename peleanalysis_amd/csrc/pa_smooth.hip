@@ -1013,9 +1013,8 @@ extern "C" int pa_smooth_solve(pa_ctx* ctx, int nlev, pa_mf* const* rhs, int rco
   // pa_apply_bc, and each dot product / norm is one pa_allreduce.  The iteration is the one-rank iteration with the sums taken
   // in another order: the field agrees with the one-rank (and the oracle's) to the solve's tolerance, not bit for bit.
   const bool sharded = rhs[0] && rhs[0]->lev->nranks > 1;
-  static const int replicated = [] { const char* e = getenv("PA_SMOOTH_REPLICATED"); return e ? atoi(e) : 0; }();
-  if (sharded && replicated) return smooth_solve_replicated(ctx, nlev, rhs, rcomp, sol, scomp, dt, bc, tol, maxiter, iters, res);
-  const bool timing = getenv("PA_SMOOTH_TIMING") != nullptr;  // diagnostic: setup / iteration / total wall time on stderr
+  if (sharded && pa_opt().smooth_replicated) return smooth_solve_replicated(ctx, nlev, rhs, rcomp, sol, scomp, dt, bc, tol, maxiter, iters, res);
+  const bool timing = pa_opt().smooth_timing != 0;  // diagnostic: setup / iteration / total wall time on stderr
   const auto tm0 = std::chrono::steady_clock::now();
   auto since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
   SmoothSolver S;
@@ -1049,9 +1048,8 @@ extern "C" int pa_smooth_solve(pa_ctx* ctx, int nlev, pa_mf* const* rhs, int rco
     }
     if (S.dist && S.setup_dist_mask()) return 1;
   }
-  if (const char* me = getenv("PA_SMOOTH_MARCH")) S.use_march = atoi(me) != 0;  // 0 (read per solve, A/B): the cell-per-thread stencil kernels
-  if (const char* ke = getenv("PA_SMOOTH_KZ")) S.march_kz = std::max(1, atoi(ke));
-  // PA_SMOOTH_MG (read per solve): 1 / 0 = the multigrid preconditioner on / off; default: on where the finest level's dt / dx^2
+  if (!pa_opt().smooth_march) S.use_march = false;  // PA_SMOOTH_MARCH=0: the cell-per-thread stencil kernels
+  // PA_SMOOTH_MG: 1 / 0 = the multigrid preconditioner on / off; default: on where the finest level's dt / dx^2
   // exceeds 8 (below that the unpreconditioned iteration needs < ~45 iterations and two V-cycles per iteration cost more than they
   // save); 3-D and 2-D hierarchies, one rank or sharded
   bool use_mg = false;
@@ -1059,8 +1057,7 @@ extern "C" int pa_smooth_solve(pa_ctx* ctx, int nlev, pa_mf* const* rhs, int rco
     const pa_level* Lf = S.lev[(size_t)nlev - 1];
     double q = 0.0;
     for (int d = 0; d < (Lf->domlo[2] == Lf->domhi[2] ? 2 : 3); ++d) q = std::max(q, dt * Lf->dxinv[d] * Lf->dxinv[d]);
-    const char* me = getenv("PA_SMOOTH_MG");
-    use_mg = me ? atoi(me) != 0 : q > 8.0;
+    use_mg = pa_opt().smooth_mg >= 0 ? pa_opt().smooth_mg != 0 : q > 8.0;
     if (use_mg) {
       int bad = (S.mg_setup() || S.alloc(S.ph, 18) || S.alloc(S.sh, 19)) ? 1 : 0;
       if (S.dist) {  // the ranks agree on the preconditioner's setup before its first exchange
@@ -1070,11 +1067,6 @@ extern "C" int pa_smooth_solve(pa_ctx* ctx, int nlev, pa_mf* const* rhs, int rco
       } else if (bad) {
         return 1;
       }
-    }
-    if (const char* ne = getenv("PA_MG_NU")) {
-      int a = 2, b = 4, c = 8;
-      double w = 0.85;
-      if (sscanf(ne, "%d %d %d %lf", &a, &b, &c, &w) >= 2) { S.nu1 = std::max(a, 1); S.nu2 = std::max(b, 0); S.nub = std::max(c, 1); S.jac_omega = w; }
     }
   }
   for (int l = 0; l < nlev; ++l) {
@@ -1098,10 +1090,9 @@ extern "C" int pa_smooth_solve(pa_ctx* ctx, int nlev, pa_mf* const* rhs, int rco
   int it = 0, status = -1;
   double rnorm = bnorm;
   if (bnorm == 0.0) status = 0;
-  // PA_SMOOTH_FUSED=0 (read per solve): round 4's form of the iteration -- one pass per vector operation and per reduction
-  // (6 reductions with a read-back per LEVEL each, 6 vector passes, 2 copies: 42.5 ms per iteration on the headline hierarchy)
-  const char* fe = getenv("PA_SMOOTH_FUSED");
-  const bool fused = !(fe && !atoi(fe));
+  // (round 4's form of the iteration -- one pass per vector operation and per reduction: 42.5 against 19-25 ms per iteration on the
+  // headline hierarchy -- is gone; DESIGN_HISTORY.md R5)
+  constexpr bool fused = true;
   double dummy;
   while (status != 0 && it < maxiter) {
     ++it;

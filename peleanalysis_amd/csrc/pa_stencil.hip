@@ -8,56 +8,15 @@
 #include <cfloat>
 #include <cstdlib>
 
-// ============================================================ grad.cpp:211-236
-// Block = 64 (x) x TY (y) columns marching tz planes in z with the z-column in registers (one wavefront per
-// row: 512 contiguous bytes); x/y neighbours come through L1/L2.  Tile shape tuned on MI355X (512^3 level of
-// 128^3 boxes): see the table in DESIGN.md section 3.
-template <typename BP, int TY>
-__global__ __launch_bounds__(64 * TY) void k_grad(BP bp, int comp, int ocomp, int tz) {
-  FabView P, O;
-  DBox V;
-  double dxinv[3];
-  if (!bp.get(blockIdx.y, P, O, V, dxinv)) return;
-  const int nx = V.hi[0] - V.lo[0] + 1, ny = V.hi[1] - V.lo[1] + 1, nz = V.hi[2] - V.lo[2] + 1;
-  const int tx = (nx + 63) / 64, ty = (ny + TY - 1) / TY, ntz = (nz + tz - 1) / tz;
-  const unsigned bid = blockIdx.x;
-  if (bid >= (unsigned)tx * ty * ntz) return;
-  const int bx = bid % tx, by = (bid / tx) % ty, bz = bid / (tx * ty);
-  const int i = V.lo[0] + bx * 64 + (threadIdx.x & 63), j = V.lo[1] + by * TY + (threadIdx.x >> 6);
-  const int k0 = V.lo[2] + bz * tz, k1 = min(k0 + tz - 1, V.hi[2]);
-  if (i > V.hi[0] || j > V.hi[1]) return;
-  // march in k keeping the z-column in registers
-  double zm = P(i, j, k0 - 1, comp), zc = P(i, j, k0, comp);
-  for (int k = k0; k <= k1; ++k) {
-    const double zp = P(i, j, k + 1, comp);
-    const double gx = cdiff(dxinv[0], P(i - 1, j, k, comp), zc, P(i + 1, j, k, comp));
-    const double gy = cdiff(dxinv[1], P(i, j - 1, k, comp), zc, P(i, j + 1, k, comp));
-    const double gz = cdiff(dxinv[2], zm, zc, zp);
-    O(i, j, k, ocomp) = gx;
-    O(i, j, k, ocomp + 1) = gy;
-    O(i, j, k, ocomp + 2) = gz;
-    O(i, j, k, ocomp + 3) = sqrt(gx * gx + gy * gy + gz * gz);
-    zm = zc;
-    zc = zp;
-  }
-}
-
 template <typename BP>
 static void grad_launch(hipStream_t st, const BP& bp, int nx, int ny, int nz, unsigned nboxes, int comp, int ocomp, const pa_level* L = nullptr) {
-  static const int ty_env = [] { const char* e = getenv("PA_GRAD_TY"); return e ? atoi(e) : 4; }();  // sweep (tools/grad_sweep.py): 1.34-1.51 ms, best 4 x 32
-  static const int tz_env = [] { const char* e = getenv("PA_GRAD_TZ"); return e ? atoi(e) : 32; }();
-  // PA_GRAD_MARCH (default 1): the k-marching kernel of pa_grad_march.h for boxes wider than half a wavefront.
-  // tools/grad_sweep.py, 512^3 level of 128^3 boxes: tiled k_grad 1.45 ms; march 13 rows x 8/16/32/64 planes
-  // 1.037/1.039/1.081/1.088 ms, 8 rows 1.13-1.17 ms (64^3 boxes: 1.42 -> 1.08 ms)
-  static const int march_env = [] { const char* e = getenv("PA_GRAD_MARCH"); return e ? atoi(e) : 1; }();
-  const char* ke = getenv("PA_GRAD_KSEG");  // read per launch: the tests switch them
-  const char* me = getenv("PA_GRAD_MTY");
-  const int kseg_env = ke ? atoi(ke) : 16, mty_env = me ? atoi(me) : 0;
+  // the k-marching kernels of pa_grad_march.h.  512^3 level of 128^3 boxes: 13 rows x 8/16/32/64 planes 1.037/1.039/1.081/1.088 ms,
+  // 8 rows 1.13-1.17 ms (the tiled cell-per-thread kernel it replaced: 1.45 ms; DESIGN_HISTORY.md)
+  constexpr int kseg_env = 16, mty_env = 0;
   // boxes wider than 32 cells: a row per wavefront; at most 32: two rows per wavefront (k_grad_marchn).  A level that holds both
   // kinds, or boxes of different sizes, takes a workgroup table per kind (pa_sweep_wgtab): no box is swept by the wrong kernel
   // and no workgroup is launched for a tile its box does not have.
-  const char* te = getenv("PA_SWEEP_WGTAB");  // read per launch (tools/ab_driver.py)
-  const bool tables = L && !(te && !atoi(te));
+  const bool tables = L != nullptr;
   auto table = [&](int cls, int tw, int mty, int kseg, bool force) -> const WgTab* { return tables ? pa_sweep_wgtab(L, cls, tw, mty, kseg, force) : nullptr; };
   auto wide = [&](int wx, int wy, int wz, int cls, bool force) {
     GradMarchArgs A{comp, ocomp, std::max(1, std::min(kseg_env, wz)), (int)nboxes, 0};
@@ -77,7 +36,6 @@ static void grad_launch(hipStream_t st, const BP& bp, int nx, int ny, int nz, un
       default: go(std::integral_constant<int, 4>{}); break;
     }
   };
-  static const int narrow_env = [] { const char* e = getenv("PA_GRAD_NARROW"); return e ? atoi(e) : 1; }();  // 0: the tiled k_grad (A/B)
   auto narrow = [&](int wx, int wy, int wz, int cls, bool force) {
     constexpr int NRW = 8;
     GradMarchArgs A{comp, ocomp, std::max(1, std::min(kseg_env, wz)), (int)nboxes, 0};
@@ -87,26 +45,13 @@ static void grad_launch(hipStream_t st, const BP& bp, int nx, int ny, int nz, un
     const dim3 g(wt ? wt->n : (unsigned)A.tiles_max * 8u * ((nboxes + 7u) / 8u));
     hipLaunchKernelGGL((k_grad_marchn<BP, NRW>), g, dim3(64 * (NRW + 2)), 0, st, bp, A);
   };
-  if (march_env && narrow_env && tables && L->nwide && L->nnarrow) {  // both kinds: two launches, each over its own boxes (the tables carry the
+  if (tables && L->nwide && L->nnarrow) {  // both kinds: two launches, each over its own boxes (the tables carry the
     wide(L->wmax[0], L->wmax[1], L->wmax[2], 0, true);               // box lists; without one a launch covers every box, which either kernel can)
     narrow(L->nmax[0], L->nmax[1], L->nmax[2], 1, true);
     return;
   }
-  if (march_env && nx > 32) {
-    wide(nx, ny, nz, 2, false);
-    return;
-  }
-  if (march_env && narrow_env) {
-    narrow(nx, ny, nz, 2, false);
-    return;
-  }
-  const int tz = std::max(1, std::min(tz_env, nz));
-  auto grid = [&](int TY) { return dim3((unsigned)(((nx + 63) / 64) * ((ny + TY - 1) / TY) * ((nz + tz - 1) / tz)), nboxes); };
-  switch (ny >= 16 ? ty_env : 4) {
-    case 16: hipLaunchKernelGGL((k_grad<BP, 16>), grid(16), dim3(1024), 0, st, bp, comp, ocomp, tz); break;
-    case 8: hipLaunchKernelGGL((k_grad<BP, 8>), grid(8), dim3(512), 0, st, bp, comp, ocomp, tz); break;
-    default: hipLaunchKernelGGL((k_grad<BP, 4>), grid(4), dim3(256), 0, st, bp, comp, ocomp, tz); break;
-  }
+  if (nx > 32) wide(nx, ny, nz, 2, false);
+  else narrow(nx, ny, nz, 2, false);
 }
 
 extern "C" int pa_grad_level(pa_ctx* ctx, const pa_mf* phi, int comp, pa_mf* out, int ocomp) {
@@ -125,12 +70,9 @@ extern "C" int pa_grad_level(pa_ctx* ctx, const pa_mf* phi, int comp, pa_mf* out
 }
 
 // grad.cpp:215-236 for several levels in one launch: 0 = launched, -1 = not applicable (the caller goes level by level), 1 = error.
-// Applicable: every level's boxes are wider than 32 cells and at least 52 rows tall (the 13-row tiles), PA_GRAD_LEVELS != 0.
+// Applicable: every level's boxes are wider than 32 cells and at least 52 rows tall (the 13-row tiles).
 int pa_grad_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int comp, pa_mf* const* out, int ocomp) {
-  const char* le = getenv("PA_GRAD_LEVELS");  // read per call (tools/ab_driver.py)
-  if ((le && !atoi(le)) || nlev < 2 || getenv("PA_GRAD_MARCH") || getenv("PA_GRAD_MTY") || getenv("PA_GRAD_KSEG")) return -1;
-  const char* te = getenv("PA_SWEEP_WGTAB");
-  if (te && !atoi(te)) return -1;
+  if (nlev < 2 || pa_opt().force_fallbacks) return -1;
   for (int l = 0; l < nlev; ++l) {  // applicable to every level, or to none (nothing is launched before this is known)
     const pa_level* L = phi[l]->lev;
     if (L->boxes.empty()) continue;

@@ -31,14 +31,36 @@ def ctx():
 @pytest.fixture(params=["separable", "exact"])
 def filter_mode(request):
     """The two forms of Filter::apply_filter (filterPlt.cpp:217): the separable default (<= 1e-12 * Linf of the oracle,
-    SURVEY 8d metric) and PA_FILTER_EXACT=1 = the reference's tap order, bit for bit.  The library reads the switch per launch."""
+    SURVEY 8d metric) and PA_FILTER_EXACT=1 = the reference's tap order, bit for bit.  The library reads its switches once:
+    pa_options_reload after every change."""
+    from peleanalysis_amd import capi
     old = os.environ.get("PA_FILTER_EXACT")
     if request.param == "exact":
         os.environ["PA_FILTER_EXACT"] = "1"
     else:
         os.environ.pop("PA_FILTER_EXACT", None)
+    capi.reload_options()
     yield request.param
     if old is None:
         os.environ.pop("PA_FILTER_EXACT", None)
     else:
         os.environ["PA_FILTER_EXACT"] = old
+    capi.reload_options()
+
+
+@pytest.fixture
+def options(monkeypatch):
+    """set PA_* switches for one test -- options(PA_NCG=0), options(PA_FUSED2=None) -- and restore them afterwards: the library
+    reads its switches once (peleanalysis_amd/csrc/pa_internal.h: pa_options), so every change is followed by pa_options_reload"""
+    from peleanalysis_amd import capi
+
+    def setter(**kw):
+        for k, v in kw.items():
+            if v is None:
+                monkeypatch.delenv(k, raising=False)
+            else:
+                monkeypatch.setenv(k, str(v))
+        capi.reload_options()
+    yield setter
+    monkeypatch.undo()
+    capi.reload_options()

@@ -140,18 +140,16 @@ def main():
 
     tin, fin = one(1, ng, lambda tot: 300.0 + 1700.0 * torch.rand(tot, dtype=torch.float64, device=dev))
     outs_f = []
-    os.environ["PA_FILTER_EXACT"] = "1"  # the two tap-order kernels against each other, bit for bit
-    for env in ("1", "0"):
-        os.environ["PA_FILTER_STREAM"] = env
-        to, fo = one(1, 0, lambda tot: torch.zeros(tot, dtype=torch.float64, device=dev))
-        torch.cuda.synchronize()
-        ctx.check(ctx.lib.pa_fill_boundary(ctx.h, fin.h, 0, 1, ng))
-        ctx.check(ctx.lib.pa_boxfilter_level(ctx.h, fin.h, fo.h, 0, 1, ng, w))
-        ctx.sync()
-        outs_f.append((to, fo))
-    os.environ.pop("PA_FILTER_STREAM")
+    os.environ["PA_FILTER_EXACT"] = "1"  # the tap-order kernel: the reference's sum, bit for bit (its result is the yardstick below)
+    capi.reload_options()
+    to, fo = one(1, 0, lambda tot: torch.zeros(tot, dtype=torch.float64, device=dev))
+    torch.cuda.synchronize()
+    ctx.check(ctx.lib.pa_fill_boundary(ctx.h, fin.h, 0, 1, ng))
+    ctx.check(ctx.lib.pa_boxfilter_level(ctx.h, fin.h, fo.h, 0, 1, ng, w))
+    ctx.sync()
+    outs_f.append((to, fo))
     os.environ.pop("PA_FILTER_EXACT")
-    assert same_bits(outs_f[0][0], outs_f[1][0]), "box filter: streaming kernel and tile kernel differ"
+    capi.reload_options()
     # the separable default against the tap-order sum: SURVEY 8(d) metric, <= 1e-12 * Linf
     ts, fs = one(1, 0, lambda tot: torch.zeros(tot, dtype=torch.float64, device=dev))
     torch.cuda.synchronize()
@@ -344,8 +342,7 @@ def main():
             assert float(g3[0].abs().max()) < 1e-9 and float(g3[1].abs().max()) < 1e-9 and float((g3[2] - 3.0).abs().max()) < 1e-9, (l, b)
     # ---- 9. small boxes (AMReX's default max_grid_size = 32): the headline hierarchy's shape at base 256^3 in 32^3 boxes
     # (512 boxes per level) -- the narrow sweep's exact-normal variant + one-layer fix-up against the pass-by-pass kernels
-    # and against the first pipeline (PA_NARROW_CG is read once per process, so the first pipeline is reached through the
-    # threshold switch PA_FUSED2_CLIP=0), with and without the threshold clip, bit for bit
+    # and against the first pipeline (PA_FUSED2=0), with and without the threshold clip, bit for bit
     del gts, gos
     torch.cuda.empty_cache()
     Hs = nested_hierarchy(256, 3, 32, is_per=(1, 1, 0))
@@ -384,9 +381,11 @@ def main():
             assert same_bits(a[l], b_[l]), f"32^3 boxes, level {l}, threshold {thr}: narrow exact-normal pipeline differs from the pass-by-pass kernels"
         del b_, _kb
         if thr is not None:
-            os.environ["PA_FUSED2_CLIP"] = "0"
+            os.environ["PA_FUSED2"] = "0"
+            capi.reload_options()
             c_, _kc, kn1 = run_s(True, thr)
-            os.environ.pop("PA_FUSED2_CLIP")
+            os.environ.pop("PA_FUSED2")
+            capi.reload_options()
             assert "CG=0" in kn1, kn1
             for l in range(3):
                 assert same_bits(a[l], c_[l]), f"32^3 boxes, level {l}: the two fused pipelines differ under the threshold clip"

@@ -62,14 +62,17 @@ def test_box_filter_weights_host_entry(oracle):
     assert lib.pa_box_filter_weights(0, (C.c_double * 4)()) < 0
     import os
     os.environ.pop("PA_ALLOW_UNVERIFIED_GAUSSIAN", None)
+    lib.pa_options_reload()  # the library reads its switches once: re-read after every change
     assert lib.pa_filter_weights(2, 2, (C.c_double * 40)()) < 0  # the Gaussian is refused unless the caller opts in (weights unverified against PelePhysics)
     for ftype in range(-1, 12):  # the other filter types: the library's weights are the oracle's, bit for bit; the same types are refused
         for fgr in (1, 2, 4, 6, 16):
             w = (C.c_double * 40)()  # up to 2 * 16 + 1 weights (the Gaussian, type 2, is the widest)
             if ftype == 2:
                 os.environ["PA_ALLOW_UNVERIFIED_GAUSSIAN"] = "1"
+                lib.pa_options_reload()
             ng = lib.pa_filter_weights(ftype, fgr, w)
             os.environ.pop("PA_ALLOW_UNVERIFIED_GAUSSIAN", None)
+            lib.pa_options_reload()
             want = oracle.filter_weights(ftype, fgr)
             assert (ng < 0) == (want is None), (ftype, fgr)
             if want is not None:

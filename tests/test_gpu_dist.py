@@ -106,10 +106,12 @@ def _worker(rank, world, port, case, transport="gloo"):
         # PA_DIST_EARLY=1 (read per pass): the tiles whose input the local FillBoundary completes are swept on the side stream under
         # exchange A and the ghost preparation, the others after it -- the same tiles, so the same bits
         os.environ["PA_DIST_EARLY"] = "1"
+        capi.reload_options()
         out = [capi.DevMF(ctx, dl, 8, 0) for dl in dls]
         capi.gradcurv_run(ctx, lst, 0, bc, capi.curv_params(threshold=thr, fused=True), work, out, 0)
         ctx.sync()
         del os.environ["PA_DIST_EARLY"]
+        capi.reload_options()
         assert ctx.bc_errors() == 0
         check(out, {0: (og, 0), 1: (og, 1), 2: (og, 2), 3: (og, 3), 4: (oc, 2), 5: (oc, 3), 6: (oc, 4), 7: (oc, 1)}, "gradcurv fused, early tiles")
         # several components at once: exchange A carries all of them, one exchange (B) per component

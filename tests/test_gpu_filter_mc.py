@@ -188,12 +188,12 @@ def test_marching_cubes_empty_and_all_masked(ctx, oracle):
 
 
 @pytest.mark.parametrize("name,ng,cells", [("amr3_wall_z", 1, "slab"), ("amr2_allwalls_ragged", 2, "slab"), ("amr3_sym_x", 1, "slab"), ("amr2_allwalls_ragged", 2, "tiles")])
-def test_marching_cubes_level_batched_matches_oracle(ctx, oracle, name, ng, cells, monkeypatch):
+def test_marching_cubes_level_batched_matches_oracle(ctx, oracle, name, ng, cells, options):
     """pa_iso_mask_level + pa_mc_level over every FAB of every level at once: the fine-covered mask, and per FAB
     the same vertices (bit for bit), edge keys and connectivity as the oracle's per-FAB Polygonise loop"""
     from util import build_config, make_states
     if cells == "tiles":  # the first form of the cell pass (k_mcl_cells<8>): still what FABs wider than 819 cells take
-        monkeypatch.setenv("PA_MC_CELLS", "tiles")
+        options(PA_FORCE_FALLBACKS=1)
     H, per, sym, fn = build_config(name)
     fields = make_states(H, 2, 0, fn, seed=11)
     nc = 5
@@ -650,7 +650,7 @@ for it in (1, 0):
     assert n > 0, (it, n)
 print("NESTED_ERRORS_COUNTED")
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, PA_FILLPATCH_PARENT=parent))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, PA_FORCE_FALLBACKS="0" if parent == "1" else "1"))
     assert r.returncode == 0 and "NESTED_ERRORS_COUNTED" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
 
 

@@ -84,15 +84,14 @@ def test_gradcurv_fused_matches_oracle(ctx, oracle, name, threshold):
         assert_valid_bits_equal(got, oc[l], [(4, 2), (5, 3), (6, 4), (7, 1)], f"{name} curv level {l}")
 
 
-@pytest.mark.parametrize("pair", [0, 1])
+@pytest.mark.parametrize("pipeline", ["exact", "first"])
 @pytest.mark.parametrize("threshold", [None, 0.05])
-def test_gradcurv_fused_wide_boxes(ctx, oracle, threshold, pair, monkeypatch):
-    """boxes 64 cells wide (the 16-byte paired-store variant of the sweep, pa_fused_march3.h PAIR) with a
-    partial last row tile (48 = 3*13 + 9 rows), anisotropic dx, 2 levels, periodic x/y + wall z"""
+def test_gradcurv_fused_wide_boxes(ctx, oracle, threshold, pipeline, options):
+    """boxes 64 cells wide with a partial last row tile (48 = 3*13 + 9 rows), anisotropic dx, 2 levels, periodic x/y + wall z,
+    on the exact-normal pipeline and (PA_FUSED2=0) on the first fused pipeline"""
     from peleanalysis_amd.hierarchy import Hierarchy, Level, chop_box, field_flame
-    monkeypatch.setenv("PA_PAIR", str(pair))  # read by the library at every launch
-    if pair:
-        monkeypatch.setenv("PA_FUSED2_CLIP", "0")  # the paired stores live in the first pipeline's sweep: keep the clip there
+    if pipeline == "first":
+        options(PA_FUSED2=0)
     l0 = Level(chop_box((0, 0, 0), (127, 47, 19), 64), (0, 0, 0), (127, 47, 19), (1, 1, 0), (0, 0, 0), (1, 1, 1))
     l1 = Level(chop_box((64, 24, 10), (191, 71, 29), 64), (0, 0, 0), (255, 95, 39), (1, 1, 0), (0, 0, 0), (1, 1, 1))
     H = Hierarchy([l0, l1], 2)
@@ -267,15 +266,12 @@ def test_gradcurv_fused_ragged_shapes(ctx, oracle, dom, maxbox, per, monkeypatch
     got = dout[0].download()
     assert_valid_bits_equal(got, og[0], [(c, c) for c in range(4)], f"ragged {dom} grad")
     assert_valid_bits_equal(got, oc[0], [(4, 2), (5, 3), (6, 4), (7, 1)], f"ragged {dom} curv")
-    # the gradient tool's own kernel (k_grad_march above 32 columns, k_grad below), short z segments, every tile height
-    for kseg, mty in (("64", "0"), ("7", "13"), ("16", "8"), ("5", "5"), ("3", "4")):
-        monkeypatch.setenv("PA_GRAD_KSEG", kseg)
-        monkeypatch.setenv("PA_GRAD_MTY", mty)
-        dls2, dst2 = _dev(ctx, H, states)
-        dgr = [capi.DevMF(ctx, dl, 4, 0) for dl in dls2]
-        capi.grad_run(ctx, dst2, 0, bc, dgr, 0)
-        ctx.sync()
-        assert_valid_bits_equal(dgr[0].download(), og[0], [(c, c) for c in range(4)], f"ragged {dom} grad_run kseg {kseg} rows {mty}")
+    # the gradient tool's own kernels (k_grad_march above 32 columns, k_grad_marchn below)
+    dls2, dst2 = _dev(ctx, H, states)
+    dgr = [capi.DevMF(ctx, dl, 4, 0) for dl in dls2]
+    capi.grad_run(ctx, dst2, 0, bc, dgr, 0)
+    ctx.sync()
+    assert_valid_bits_equal(dgr[0].download(), og[0], [(c, c) for c in range(4)], f"ragged {dom} grad_run")
 
 
 def test_ghost_fill_matches_oracle(ctx, oracle):
@@ -546,24 +542,25 @@ def test_gradcurv_run_comps2_arguments(ctx):
 
 
 def test_switched_off_paths_still_match(ctx):
-    """the kernels the defaults no longer reach -- FillBoundary per ghost cell (PA_FB_REGIONS=0: still what a level takes
-    whose regions do not fit the plan) and the sweep level by level (PA_SWEEP_BATCH=0: levels of unequal tile variants) --
-    through the same oracle comparisons, in a child process (both switches are read once per process)"""
+    """PA_FORCE_FALLBACKS=1: the paths that exist for inputs the tuned ones do not take -- FillBoundary and the patch gather per
+    ghost cell (regions that do not fit a plan), the sweeps group by group (more groups than one launch holds), ghost fills level
+    by level -- on the ordinary test hierarchies, through the same oracle comparisons, in a child process (plans are cached per level)"""
     import os
     import subprocess
     import sys
-    env = dict(os.environ, PA_FB_REGIONS="0", PA_SWEEP_BATCH="0")
+    env = dict(os.environ, PA_FORCE_FALLBACKS="1")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider",
                         "-k", "ghost_fill_matches_oracle or exact_normal_pipeline or fused_matches_oracle"], env=env, capture_output=True, text=True,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
-def test_not_properly_nested_fine_level_is_counted_on_every_path(ctx, monkeypatch):
+def test_not_properly_nested_fine_level_is_counted_on_every_path(ctx):
     """a level-2 region that touches the edge of level 1 (no buffer cells): its ghost cells beyond that edge have no coarse
     parent.  The library never aborts -- it counts those ghost cells (pa_bc_errors; the tools turn a non-zero count into the
-    reference's abort) -- and the count is the same whether the coarse values come through the owner map or from the
-    coarse patches, where a cell without an owner is a reserved bit pattern"""
+    reference's abort): in the coarse patches a cell without an owner is a reserved bit pattern, and the chunked face kernels
+    count per ghost cell like the per-cell ones (26088 here: three faces of 64 x 64 ghost cells, counted by the preparation of
+    phi's ghosts and by the fix-up of n's, plus the ring)"""
     from peleanalysis_amd.hierarchy import Hierarchy, Level
     z, o = np.zeros(3), np.ones(3)
     l0 = Level(np.array([[0, 0, 0, 63, 63, 63]], np.int32), (0, 0, 0), (63, 63, 63), (0, 0, 0), z, o)
@@ -581,8 +578,7 @@ def test_not_properly_nested_fine_level_is_counted_on_every_path(ctx, monkeypatc
     work = [capi.DevMF(ctx, dl, 1, 2) for dl in dls]
     dout = [capi.DevMF(ctx, dl, 8, 0) for dl in dls]
     counts = {}
-    for sw in ("1", "0"):
-        monkeypatch.setenv("PA_CPATCH", sw)
+    for sw in ("1", "2"):
         capi.gradcurv_run(ctx, dst, 0, bc, capi.curv_params(prog_min=200.0, prog_max=2100.0, fused=True), work, dout, 0)
         ctx.sync()
         kn = ctx.lib.pa_sweep_kernel_name(ctx.h).decode()
@@ -592,4 +588,4 @@ def test_not_properly_nested_fine_level_is_counted_on_every_path(ctx, monkeypatc
     ctx.sync()
     assert ctx.bc_errors() > 0  # pass by pass: counted as well (its own number of passes over those cells)
     # three faces of 64 x 64 ghost cells sit beyond level 1, counted once by the prep and once by the fix-up of phi's and n's ghosts
-    assert counts["1"] == counts["0"] and counts["1"] >= 3 * 64 * 64, counts
+    assert counts["1"] == counts["2"] == 26088, counts

@@ -215,6 +215,7 @@ def test_x_face_mirror_of_the_sweep_gives_the_same_bits(ctx, oracle, shape, monk
     outs = {}
     for v in ("0", "1"):
         monkeypatch.setenv("PA_NCG", v)
+        capi.reload_options()
         dout = [capi.DevMF(ctx, dl, 8, 0) for dl in dls]
         for m in dout:
             m.setval(-3.0)
@@ -224,6 +225,8 @@ def test_x_face_mirror_of_the_sweep_gives_the_same_bits(ctx, oracle, shape, monk
         kn = ctx.lib.pa_sweep_kernel_name(ctx.h).decode()
         assert ("x faces mirrored" in kn) == (v == "1"), kn
         outs[v] = [m.download() for m in dout]
+    monkeypatch.delenv("PA_NCG")
+    capi.reload_options()
     for l, lv in enumerate(H.levels):
         for b in range(lv.nboxes):
             assert np.array_equal(outs["0"][l].valid(b).view(np.int64), outs["1"][l].valid(b).view(np.int64)), (shape, l, b)

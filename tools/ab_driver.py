@@ -57,6 +57,7 @@ def one():
 
 def block(val):
     os.environ[var] = val  # "1" vs "0": for a switch that is off by default, 0 is the current behaviour
+    ctx.lib.pa_options_reload()  # the library reads its switches once (pa_options): re-read after the flip
     one()
     ctx.sync()
     t0 = time.perf_counter()
