@@ -144,6 +144,7 @@ extern "C" void pa_options_reload(void) {
   o.smooth_march = geti("PA_SMOOTH_MARCH", 1) != 0;
   o.smooth_timing = geti("PA_SMOOTH_TIMING", 0) != 0;
   o.force_fallbacks = geti("PA_FORCE_FALLBACKS", 0) != 0;
+  o.scratch_poison = geti("PA_SCRATCH_POISON", 0) != 0;
   g_opt = o;
   g_opt_read = true;
 }

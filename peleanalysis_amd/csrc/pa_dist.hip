@@ -411,9 +411,10 @@ extern "C" int64_t pa_level_free_scratch(pa_level* L) {
 pa_mf* pa_level_scratch(pa_ctx* ctx, const pa_level* L, int ncomp, int ng, int role) {
   const std::array<int, 3> key{ncomp, ng, role};
   auto it = L->scratch.find(key);
-  if (it != L->scratch.end()) return it->second;
-  pa_mf* m = pa_mf_create(ctx, L, ncomp, ng, nullptr);
-  if (m) L->scratch[key] = m;
+  pa_mf* m = it != L->scratch.end() ? it->second : pa_mf_create(ctx, L, ncomp, ng, nullptr);
+  if (m && it == L->scratch.end()) L->scratch[key] = m;
+  // the contents are undefined between calls (what the previous call left): PA_SCRATCH_POISON=1 makes that visible -- all bits set = NaN
+  if (m && pa_opt().scratch_poison && m->total > 0 && hipMemsetAsync(m->data, 0xFF, sizeof(double) * (size_t)m->total, ctx->stream) != hipSuccess) (void)hipGetLastError();
   return m;
 }
 

@@ -82,210 +82,5 @@ struct MarchArgs {
   int gng = 0;
 };
 
-template <typename BP, int PA_MTY, int MINW>
-__global__ __launch_bounds__(64 * (PA_MTY + 3), MINW) void k_gradcurv_march(BP bp, MarchArgs A) {
-  FabView P, O;
-  DBox V;
-  double dxinv[3];
-  constexpr int PA_MROWS = PA_MTY + 2;
-  const int box = A.order ? (int)((blockIdx.x / (unsigned)A.txy_max) % (unsigned)A.nboxes) : (int)blockIdx.y;
-  if (!bp.get(box, P, O, V, dxinv)) return;
-  const int pcomp = A.pcomp, kseg = A.kseg;
-  const double pmin = A.pmin, invd = A.invdenom, thr = A.thr;
-  const int nx = V.hi[0] - V.lo[0] + 1, ny = V.hi[1] - V.lo[1] + 1, nz = V.hi[2] - V.lo[2] + 1;
-  const int tx = (nx + 63) / 64, ty = (ny + PA_MTY - 1) / PA_MTY, tz = (nz + kseg - 1) / kseg;
-  unsigned bid = blockIdx.x;
-  if (A.order) {
-    const unsigned t = bid % (unsigned)A.txy_max, z = bid / ((unsigned)A.txy_max * (unsigned)A.nboxes);
-    if (t >= (unsigned)tx * ty || z >= (unsigned)tz) return;
-    bid = z * (unsigned)(tx * ty) + t;
-  }
-  if (bid >= (unsigned)tx * ty * tz) return;  // uniform for the whole workgroup
-  const int bx = bid % tx, by = (bid / tx) % ty, bz = bid / (tx * ty);
-  const int i0 = V.lo[0] + bx * 64, j0 = V.lo[1] + by * PA_MTY;
-  const int k0 = V.lo[2] + bz * kseg, k1 = min(k0 + kseg - 1, V.hi[2]);
-  const int iR = min(i0 + 64, V.hi[0] + 1);  // column right of the tile's last valid column
-  const int llast = iR - 1 - i0;
-  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int rtop = min(PA_MROWS - 1, V.hi[1] + 1 - j0 + 1);  // row slot of the last live row (j = min(j0+MTY, hi_y+1))
-
-  __shared__ MarchLds<PA_MTY> S;
-  const long long pps = (long long)P.nx * P.ny;  // plane stride
-  const int niter = k1 - k0 + 3;                 // planes k0-1 .. k1+1
-#define PA_PROG(x) (((x) - pmin) * invd)         /* curvature.cpp:319 */
-
-  if (w < PA_MROWS && w > rtop) {
-    // ---------------------------------------------------------------- dead row (partial tile)
-    for (int it = 0; it <= niter; ++it) __syncthreads();
-    return;
-  }
-
-  if (w < PA_MROWS) {
-    // ------------------------------------------------------------------------- row waves
-    const int rr = w;
-    const int j = j0 + rr - 1;
-    const int le = min(lane, llast);  // lanes past the box edge mirror the last valid lane
-    const int i = i0 + le;
-    const int xs = le + 1;
-    const bool halo = (rr == 0) || (rr == rtop);  // supplies neighbours only; one y-neighbour comes from global
-    const double* gp = P.p + P.idx(i, j, k0 - 2, pcomp);
-    // phi queue: pm = phi(p-2), pc = phi(p-1), p0 = phi(p), p1 = phi(p+1), p2 = (prefetched) phi(p+2)
-    double pm = 0, pc = gp[0], p0 = gp[pps], p1 = gp[2 * pps], p2;
-    gp += 2 * pps;  // -> phi(k0)
-    double cm = PA_PROG(pc), cc = PA_PROG(p0), cp = PA_PROG(p1);  // c at planes p-1, p, p+1  (p = k0-1)
-    S.c[0][rr][xs] = cc;
-    if (halo) {
-      const int jout = (rr == 0) ? j - 1 : j + 1;
-      const double* go = P.p + P.idx(i, jout, k0 - 1, pcomp);
-      double co = PA_PROG(go[0]), con;
-      __syncthreads();
-      int sp = 0;
-      for (int p = k0 - 1; p <= k1 + 1; ++p) {
-        const int sp1 = (sp == 2) ? 0 : sp + 1;
-        const long long pi = (p <= k1) ? pps : 0;  // clamp the prefetch on the last plane
-        gp += pi; go += pi;
-        p2 = gp[0]; con = go[0];
-        const double cl = S.c[sp][rr][xs - 1], cr = S.c[sp][rr][xs + 1];
-        const double cin = S.c[sp][(rr == 0) ? 1 : rr - 1][xs];
-        const double cs = (rr == 0) ? co : cin, cn = (rr == 0) ? cin : co;
-        double nxp, nyp, nzp;
-        normal_from(cl, cr, cs, cn, cm, cc, cp, dxinv, nxp, nyp, nzp);
-        S.ny[sp][rr][lane] = nyp;
-        S.c[sp1][rr][xs] = cp;
-        S.p[sp][rr][xs] = p0;
-        __syncthreads();
-        cm = cc; cc = cp; cp = PA_PROG(p2); co = PA_PROG(con);
-        p0 = p1; p1 = p2;
-        sp = sp1;
-      }
-      return;
-    }
-    // output rows
-    __syncthreads();
-    double nxq = 0, nyq = 0, nzq = 0, nzqm = 0;
-    double* op = O.p + O.idx(i, j, k0, A.ocomp);
-    const long long ops = (long long)O.nx * O.ny, osc = O.sc;
-    int sp = 0;
-    // normal at plane p, outputs at plane q = p-1.  The 8 results of a plane are kept in registers
-    // and stored DURING the next plane's normal computation, two at a time between its stages:
-    // a burst of 8 stores per wave right after the barrier fills the CU's memory pipe and blocks
-    // every wave (and the prefetch loads queued behind them) until it drains.  The first three
-    // iterations have nothing valid to store yet: they write to plane k0, which the same thread
-    // overwrites in program order at p = k0+2.  Keeps the loop free of branches around global
-    // memory operations (vmcnt(N) instead of vmcnt(0)).
-    double o0 = 0, o1 = 0, o2 = 0, o3 = 0, o4 = 0, o5 = 0, o6 = 0, o7 = 0;
-#pragma unroll 1
-    for (int p = k0 - 1; p <= k1 + 1; ++p) {
-      const int sp1 = (sp == 2) ? 0 : sp + 1;
-      const int sq = (sp == 0) ? 2 : sp - 1;
-      gp += (p <= k1) ? pps : 0;
-      p2 = gp[0];
-      const double cl = S.c[sp][rr][xs - 1], cr = S.c[sp][rr][xs + 1];
-      const double cs = S.c[sp][rr - 1][xs], cn = S.c[sp][rr + 1][xs];
-      op[0] = o0;
-      __builtin_amdgcn_sched_barrier(0);
-      const double ggx = cdiff(dxinv[0], cl, cc, cr);
-      const double ggy = cdiff(dxinv[1], cs, cc, cn);
-      const double ggz = cdiff(dxinv[2], cm, cc, cp);
-      __builtin_amdgcn_sched_barrier(0);
-      op[osc] = o1;
-      __builtin_amdgcn_sched_barrier(0);
-      const double sn = sqrt(ggx * ggx + ggy * ggy + ggz * ggz);
-      const double ng = -((1e-14 < sn) ? sn : 1e-14);
-      __builtin_amdgcn_sched_barrier(0);
-      op[2 * osc] = o2;
-      __builtin_amdgcn_sched_barrier(0);
-      const double nxp = ggx / ng, nyp = ggy / ng;
-      __builtin_amdgcn_sched_barrier(0);
-      op[3 * osc] = o3;
-      __builtin_amdgcn_sched_barrier(0);
-      const double nzp = ggz / ng;
-      S.ny[sp][rr][lane] = nyp;
-      S.nx[sp][rr - 1][xs] = nxp;
-      S.c[sp1][rr][xs] = cp;
-      S.p[sp][rr][xs] = p0;
-      __builtin_amdgcn_sched_barrier(0);
-      op[4 * osc] = o4;
-      __syncthreads();
-      const double nxl = S.nx[sq][rr - 1][xs - 1], nxr = S.nx[sq][rr - 1][xs + 1];
-      const double nys = S.ny[sq][rr - 1][lane], nyn = S.ny[sq][rr + 1][lane];
-      double curv = 0.0;
-      curv += cdiff(dxinv[0], nxl, nxq, nxr);
-      curv += cdiff(dxinv[1], nys, nyq, nyn);
-      curv += cdiff(dxinv[2], nzqm, nzq, nzp);
-      curv = curv * 0.5;
-      __builtin_amdgcn_sched_barrier(0);
-      op[5 * osc] = o5;
-      __builtin_amdgcn_sched_barrier(0);
-      // phi gradient at plane q (pc = phi(q), pm = phi(q-1), p0 = phi(q+1))
-      const double pl = S.p[sq][rr][xs - 1], pr = S.p[sq][rr][xs + 1];
-      const double ps = S.p[sq][rr - 1][xs], pnn = S.p[sq][rr + 1][xs];
-      const double gx = cdiff(dxinv[0], pl, pc, pr);
-      const double gy = cdiff(dxinv[1], ps, pc, pnn);
-      const double gz = cdiff(dxinv[2], pm, pc, p0);
-      __builtin_amdgcn_sched_barrier(0);
-      op[6 * osc] = o6;
-      __builtin_amdgcn_sched_barrier(0);
-      const double gm = sqrt(gx * gx + gy * gy + gz * gz);
-      // threshold clip (curvature.cpp:557-566); cm = c at plane q.  thr < 0 never clips.
-      const bool clip = (thr >= 0.0) && ((cm < thr) || (cm > 1.0 - thr));
-      __builtin_amdgcn_sched_barrier(0);
-      op[7 * osc] = o7;
-      op += (p >= k0 + 2) ? ops : 0;
-      o0 = gx; o1 = gy; o2 = gz; o3 = gm;
-      o4 = clip ? 0.0 : nxq;
-      o5 = clip ? 0.0 : nyq;
-      o6 = clip ? 0.0 : nzq;
-      o7 = clip ? 0.0 : curv;
-      cm = cc; cc = cp; cp = PA_PROG(p2);
-      pm = pc; pc = p0; p0 = p1; p1 = p2;
-      nzqm = nzq; nxq = nxp; nyq = nyp; nzq = nzp;
-      sp = sp1;
-    }
-    // results of the last plane (k1)
-    op[0] = o0; op[osc] = o1; op[2 * osc] = o2; op[3 * osc] = o3;
-    op[4 * osc] = o4; op[5 * osc] = o5; op[6 * osc] = o6; op[7 * osc] = o7;
-    return;
-  }
-
-  // ----------------------------------------------------------------------------- edge wave
-  {
-    const int l20 = lane % (2 * PA_MROWS);  // idle lanes mirror the active ones
-    const int rr = min(l20 >> 1, rtop);
-    const int side = l20 & 1;
-    const int j = j0 + rr - 1;
-    const int i = side ? iR : i0 - 1;
-    const int xs = side ? llast + 2 : 0;
-    const int xin = side ? llast + 1 : 1;  // the tile column next to this edge column
-    const int rlo = max(rr - 1, 0), rhi = min(rr + 1, PA_MROWS - 1);
-    const bool has_n = (rr >= 1 && rr <= PA_MTY);
-    const double* gp = P.p + P.idx(i, j, k0 - 2, pcomp);
-    const double* go = P.p + P.idx(side ? i + 1 : i - 1, j, k0 - 1, pcomp);
-    double pc = gp[0], p0 = gp[pps], p1 = gp[2 * pps], p2;
-    gp += 2 * pps;
-    double cm = PA_PROG(pc), cc = PA_PROG(p0), cp = PA_PROG(p1);
-    double co = PA_PROG(go[0]), con;
-    S.c[0][rr][xs] = cc;
-    __syncthreads();
-    int sp = 0;
-    for (int p = k0 - 1; p <= k1 + 1; ++p) {
-      const int sp1 = (sp == 2) ? 0 : sp + 1;
-      const long long pi = (p <= k1) ? pps : 0;
-      gp += pi; go += pi;
-      p2 = gp[0]; con = go[0];
-      const double inner = S.c[sp][rr][xin];
-      const double cl = side ? inner : co, cr = side ? co : inner;
-      const double cs = S.c[sp][rlo][xs], cn = S.c[sp][rhi][xs];
-      double nxp, nyp, nzp;
-      normal_from(cl, cr, cs, cn, cm, cc, cp, dxinv, nxp, nyp, nzp);
-      if (has_n) S.nx[sp][rr - 1][xs] = nxp;
-      S.c[sp1][rr][xs] = cp;
-      S.p[sp][rr][xs] = p0;
-      __syncthreads();
-      cm = cc; cc = cp; cp = PA_PROG(p2); co = PA_PROG(con);
-      p0 = p1; p1 = p2;
-      sp = sp1;
-    }
-  }
-#undef PA_PROG
-}
+// (The first marching kernel, k_gradcurv_march -- requests and stores interleaved, one plane in flight -- lived here until round 6;
+// pa_fused_march3.h is its restructured form, measured 2.27 -> 1.92 ms per launch, bit-identical.)

@@ -28,6 +28,8 @@ struct pa_options {
   int smooth_mg = -1;                 // PA_SMOOTH_MG=1 / 0: the multigrid preconditioner always / never (default: where dt / dx^2 > 8)
   int smooth_march = 1;               // PA_SMOOTH_MARCH=0: the cell-per-thread stencil kernels of the solve
   int smooth_timing = 0;              // PA_SMOOTH_TIMING=1: setup / iteration times of a solve on stderr
+  int scratch_poison = 0;             // PA_SCRATCH_POISON=1 (tests): a level's work multifabs (pa_level_scratch: kept between calls, contents undefined) are
+                                      // filled with NaN at every acquisition -- a kernel that reads a cell no step of THIS call wrote shows up in the result
   int force_fallbacks = 0;            // PA_FORCE_FALLBACKS=1 (tests): every path that exists for inputs the tuned one does not take -- FillBoundary /
                                       // patch gather per ghost cell (regions that do not fit a plan), the sweeps group by group (more groups than a
                                       // launch holds), the first form of the marching-cubes cell pass (FABs wider than 819 cells) and its

@@ -109,8 +109,17 @@ std::vector<std::pair<int, int>> x_pieces(int a, int b, int mx, int min_thick) {
   const int parts = (W + cap - 1) / cap;
   if (parts <= 1) {
     out.push_back({a, wend});
-  } else if (cap < PA_XTILE) {  // limits below a tile (tests): an even split in cells
-    for (int p = 0; p < parts; ++p) out.push_back({a + (int)((long long)W * p / parts), a + (int)((long long)W * (p + 1) / parts)});
+  } else if (cap < PA_XTILE) {  // limits below a tile (tests): pieces of at most the limit, the cuts on EVEN indices -- fine boxes stay aligned to the
+    // refinement ratio (the smoothing solve's restriction and the face kernels' 2 x 2 blocks want that; advisor, round 5: [40..52] came out of
+    // boxes aligned to 4)
+    int pos = a;
+    while (wend - pos > cap) {
+      int c = pos + cap;
+      if ((c & 1) && c - 1 > pos) --c;
+      out.push_back({pos, c});
+      pos = c;
+    }
+    out.push_back({pos, wend});
   } else {
     const int units = (W + PA_XTILE - 1) / PA_XTILE;  // tiles; the last one may be ragged
     int pos = a;

@@ -589,3 +589,19 @@ def test_not_properly_nested_fine_level_is_counted_on_every_path(ctx):
     assert ctx.bc_errors() > 0  # pass by pass: counted as well (its own number of passes over those cells)
     # three faces of 64 x 64 ghost cells sit beyond level 1, counted once by the prep and once by the fix-up of phi's and n's ghosts
     assert counts["1"] == counts["2"] == 26088, counts
+
+
+def test_work_multifabs_are_never_read_before_they_are_written():
+    """PA_SCRATCH_POISON=1 (round-5 advisor): the work multifabs a level keeps between calls (pa_level_scratch: G, c, n of the
+    curvature passes, the Krylov vectors of do_smooth, the smoothed progress source) are filled with NaN every time a call acquires
+    them; the curvature-option, smoothing and random-hierarchy tests -- oracle comparisons, bit for bit or to the solve's tolerance --
+    run under it in a child process.  A kernel that reads a ghost cell no step of the same call wrote would put a NaN in a result."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, PA_SCRATCH_POISON="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_gradcurv.py"), os.path.join(here, "test_gpu_smooth.py"), os.path.join(here, "test_gpu_random.py"),
+                        "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider", "-k", "curvature_run or options or curvature_options or smoothing or gauss or strain"],
+                       env=env, capture_output=True, text=True, cwd=os.path.dirname(here))
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]

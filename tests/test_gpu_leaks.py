@@ -85,7 +85,7 @@ def _cycle(per=(1, 1, 0), stages="abcdefgh", ctx=None):
 
 def test_device_memory_comes_back_after_contexts_are_destroyed():
     """(two warm-up cycles: the runtime keeps 356 MiB after the first context of a process and another 88 MiB after the second -- code
-    objects, queues and their scratch -- and nothing after that: tools/exp/leak_seq.py, ten cycles)"""
+    objects, queues and their scratch -- and nothing after that: ten cycles of the round-5 leak hunt)"""
     torch = pytest.importorskip("torch")
     for _ in range(2):
         _cycle()

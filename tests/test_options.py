@@ -25,6 +25,7 @@ FLIPPED_BY = {
     "PA_SMOOTH_MG": "tests/test_gpu_smooth.py::test_smooth_multigrid_preconditioner",
     "PA_SMOOTH_MARCH": "tests/test_gpu_smooth.py::test_smooth_wide_boxes_marching_kernels",
     "PA_SMOOTH_TIMING": "tests/test_options.py::test_smooth_timing_and_tool_exit",
+    "PA_SCRATCH_POISON": "tests/test_gpu_gradcurv.py::test_work_multifabs_are_never_read_before_they_are_written",
     "PA_FORCE_FALLBACKS": "tests/test_gpu_gradcurv.py::test_switched_off_paths_still_match, test_gpu_filter_mc.py (tiles, fillpatch)",
     # the tools' own (tools/common, tools/src)
     "PA_HOST_THP": "tests/test_plotfile_tools.py::test_cpp_template_tool_large_level_with_and_without_huge_pages",

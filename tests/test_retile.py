@@ -213,6 +213,30 @@ def test_retiled_device_path_matches_oracle_on_the_file_boxes(ctx, oracle, seed)
                         f"({lv.nboxes} file boxes -> {T.levels[l].nboxes})"
 
 
+@pytest.mark.parametrize("mx", [(5, 7, 3), (13, 8, 8), (24, 12, 16), (40, 16, 16)])
+def test_small_limits_keep_fine_boxes_aligned_to_the_refinement_ratio(mx):
+    """round-5 advisor finding: with an x limit below one 64-cell tile the even split in cells gave boxes like [40..52] out of
+    inputs aligned to 4 -- the smoothing solve refuses fine boxes that are not aligned to the refinement ratio, so
+    curvature3d do_smooth=1 failed on a re-tiled level that worked with retile=0.  Cuts now fall on even indices."""
+    from peleanalysis_amd.hierarchy import retile_level
+    rng = np.random.default_rng(mx[0])
+    cut = 0
+    for trial in range(20):
+        # a fine level: a few boxes on a grid of 4 cells (every lo even, every hi odd)
+        n = int(rng.integers(2, 5))
+        boxes = []
+        x0 = 4 * int(rng.integers(0, 8))
+        for b in range(n):
+            w = 4 * int(rng.integers(2, 30))
+            boxes.append([x0, 8 * b, 0, x0 + w - 1, 8 * b + 7, 7])
+        lv = Level(np.array(boxes, np.int32), (0, 0, 0), (1023, 255, 63), (0, 0, 0), np.zeros(3), np.ones(3))
+        out = retile_level(lv, mx, min_thick=1)
+        assert int(((out.boxes[:, 3:] - out.boxes[:, :3] + 1).prod(axis=1)).sum()) == lv.ncells
+        assert (out.boxes[:, 0] % 2 == 0).all() and (out.boxes[:, 3] % 2 == 1).all(), (mx, boxes, out.boxes.tolist())
+        cut += int(out.nboxes > lv.nboxes)  # (more pieces than the caller's capacity: the level is merged by whole boxes instead)
+    assert cut > 0 or mx[0] < 13, "no trial was cut in x"
+
+
 def _thin_slab_hierarchy():
     """level 1 = thick boxes plus slabs only 2 cells thick in x at the coarse-fine face: their normal interpolant is of
     lower order (orc_apply_bc: NX = min(n + 1, 4)), so they must not be merged"""
