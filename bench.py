@@ -315,6 +315,10 @@ def secondary(ctx, torch, stream, dev, only=None, retile=1):
     # BASELINE config 5's shape on one GPU, 8 of its 55 components: 4 levels of 256^3 cells in 64^3 boxes, components in one batch
     if want("c5_shape_4lev_256_8comp"):
         gradcurv_case("c5_shape_4lev_256_8comp", 256, 4, 64, 8, (1, 1, 0), nbatch=8, also_file=True)
+    # the headline itself on the FILE's own 128^3 boxes (--retile 0) beside the default, so that rounds before and after the
+    # internal tiling stay comparable (advisor, round 5): ms = the default (what the headline line measures), file_tiling_ms = retile 0
+    if want("headline_box128"):
+        gradcurv_case("headline_box128", 512, 3, 128, 1, (1, 1, 0), also_file=True)
     # the headline hierarchy in smaller boxes
     for box in (64, 32):
         if not want(f"headline_box{box}"):
