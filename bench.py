@@ -1111,7 +1111,7 @@ def main():
         headline_cfg = (args.base, args.nlev, args.box, args.ncomp, world, args.sim_of) == (512, 3, 128, 1, 1, 0) and per == (1, 1, 0) and args.threshold < 0
         if headline_cfg and args.traffic == "live" and rank == 0:
             traffic, traffic_src = live_traffic(retile=args.retile)
-        tj = os.path.join(ROOT, "profiles", "r05_headline_traffic.json" if args.retile else "r04_headline_traffic.json")
+        tj = os.path.join(ROOT, "profiles", "r06_headline_traffic.json" if args.retile else "r04_headline_traffic.json")
         if traffic is None and args.traffic != "none" and os.path.exists(tj) and headline_cfg:
             rec = json.load(open(tj))
             if rec.get("kernel") == kern:
