@@ -612,8 +612,18 @@ static int curvature_fast(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, 
   if (gauss || strain) {
     pa_mf* const* F1 = gauss ? G.data() : state;
     const int c1 = gauss ? 0 : P->vel_comp;
-    int rc = !dist ? pa_apply_bc_multi(ctx, nlev, F1, c1, 3, (gauss && strain) ? state : nullptr, P->vel_comp, 3, bc) : 2;
-    if (rc == 1) return 1;
+    // round 6: one rank -- MLMG applyBC of the three components of G and of the velocity through the chunked special-face kernel
+    // (k_prep_faces_chunks<.., PHIONLY>: the gradient tool's applyBC, component = slot, coarse values from the gathered patches):
+    // k_apply_bc_multi, a thread per ghost cell and component through the owner map, took 1.2 ms of a 17-ms headline pass
+    int rc = 2;
+    if (!dist) {
+      std::vector<const pa_mf*> crG((size_t)nlev, nullptr), crU((size_t)nlev, nullptr);
+      for (int l = 1; l < nlev; ++l) { crG[(size_t)l] = G[(size_t)l - 1]; crU[(size_t)l] = state[l - 1]; }
+      if (gauss) PA_TRY(pa_gradcurv_prep_levels(ctx, nlev, G.data(), 0, crG.data(), 0, bc, 0.0, 1.0, 1 | 8, 3, nullptr));
+      if (strain) PA_TRY(pa_gradcurv_prep_levels(ctx, nlev, state, P->vel_comp, crU.data(), P->vel_comp, bc, 0.0, 1.0, 1 | 8, 3, nullptr));
+      rc = 0;
+      (void)F1; (void)c1;
+    }
     if (rc == 2) {
       for (int l = 0; l < nlev && gauss; ++l)
         for (int d = 0; d < 3; ++d) PA_TRY(pa_apply_bc(ctx, G[l], d, l > 0 ? G[l - 1] : nullptr, d, bc, 2, -1));
