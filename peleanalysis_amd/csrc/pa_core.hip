@@ -1147,113 +1147,6 @@ __global__ __launch_bounds__(256) void k_apply_bc_sfaces(DLevelView L, BCFields<
   }
 }
 
-// MLMG applyBC on the face ghost cells of SEVERAL components of SEVERAL levels in one launch (pa_curvature_run's fast path: the three
-// components of G and of the velocity on every level were 6 x nlev launches of ~80 us each, chains of dependent loads at the size of a
-// level's special faces).  Component c of a group interpolates from coarse component ccomp0 + c; the operations per component are
-// k_apply_bc_sfaces<1>'s.  Level = a range of workgroups (its work table pa_level::d_sfwg).
-struct BcGroup { DMFView M, MC; int comp0, ccomp0, ncomp; };
-struct BcMultiLev {
-  DLevelView L, LC;
-  BCArgs A;
-  const int2* wg;
-  int ngroups;
-  BcGroup g[2];
-};
-struct BcMulti {
-  int n;
-  unsigned wg0[PA_MAXB + 1];
-  BcMultiLev lev[PA_MAXB];
-};
-__global__ __launch_bounds__(256) void k_apply_bc_multi(BcMulti S, int* nbad) {
-  int l = 0;
-  while (l + 1 < S.n && blockIdx.x >= S.wg0[l + 1]) ++l;
-  const BcMultiLev& X = S.lev[l];
-  const int2 w = X.wg[blockIdx.x - S.wg0[l]];
-  int b, dir, side, layer, q[3];
-  DBox B;
-  const unsigned fy = (unsigned)w.x;
-  const long long t = (long long)w.y * (long long)blockDim.x + threadIdx.x;
-  if (!sface_decode(X.L, fy, t, 1, b, B, dir, side, q, layer)) return;
-  const unsigned code = X.L.sfcode[X.L.sfoff[fy] + t];
-  const int cls = (int)(code & 3u);
-  if (cls == 0) return;
-  if (cls == 1 && !X.A.has_crse) { atomicAdd(nbad, 1); return; }
-  const int s = side ? -1 : 1;
-  double coef[4];
-  const int NX = cls == 1 ? cf_normal_coef(B.hi[dir] - B.lo[dir] + 1, X.A.ratio, coef) : 0;
-  bool ok = true;
-  // blockIdx.y = (group, component): one component per thread -- with all six in one thread the launch was a chain of six dependent
-  // interpolations per ghost cell (1.17 ms for the headline's 3.7e6 face cells)
-  {
-    const int gi = (int)blockIdx.y >= X.g[0].ncomp ? 1 : 0;
-    const BcGroup& Gr = X.g[gi];
-    double* p = Gr.M.data + Gr.M.off[b];
-    const int c = (int)blockIdx.y - (gi ? X.g[0].ncomp : 0);
-    if (gi < X.ngroups && c < Gr.ncomp) {
-      const long long iq = fab_index(B, Gr.M.ng, Gr.M.ncomp, Gr.comp0 + c, q[0], q[1], q[2]);
-      if (cls == 2) {
-        int in[3] = {q[0], q[1], q[2]};
-        in[dir] += s;
-        const double v = p[fab_index(B, Gr.M.ng, Gr.M.ncomp, Gr.comp0 + c, in[0], in[1], in[2])];
-        p[iq] = (X.A.bc[dir] == PA_BC_REFLECT_ODD) ? -v : v;
-        return;
-      }
-      const int xf[1] = {0};
-      double bv[1];
-      cf_interp<1>(code, X.LC, Gr.MC, Gr.ccomp0 + c, q, dir, X.A.ratio, xf, ok, bv);
-      double tmp = 0.0;
-      for (int m = 1; m < NX; ++m) {
-        int pc[3] = {q[0], q[1], q[2]};
-        pc[dir] += s * m;
-        tmp += p[fab_index(B, Gr.M.ng, Gr.M.ncomp, Gr.comp0 + c, pc[0], pc[1], pc[2])] * coef[m];
-      }
-      double g = tmp;
-      g += bv[0] * coef[0];
-      p[iq] = g;
-    }
-  }
-  if (!ok) atomicAdd(nbad, 1);
-}
-
-// applyBC (all directions) on up to two groups of components per level, all levels in one launch; one rank, levels with work tables
-// (every level pa_level_create makes has one).  F2 may be null.  Returns 2 when a level has no work table (the caller falls back).
-int pa_apply_bc_multi(pa_ctx* ctx, int nlev, pa_mf* const* F1, int comp1, int ncomp1, pa_mf* const* F2, int comp2, int ncomp2, const int32_t bc[3]) {
-  if (!ctx || !F1 || nlev < 1) return pa_fail(ctx, "pa_apply_bc_multi: null argument");
-  for (int l = 0; l < nlev; ++l)
-    if (F1[l]->lev->nranks > 1 || (!F1[l]->lev->boxes.empty() && !F1[l]->lev->sfaces.empty() && (!F1[l]->lev->d_sfwg || F1[l]->lev->nsfwg <= 0))) return 2;
-  for (int l0 = 0; l0 < nlev; l0 += PA_MAXB) {  // up to PA_MAXB levels per launch
-  BcMulti S;
-  S.n = 0;
-  S.wg0[0] = 0;
-  for (int l = l0; l < nlev && l < l0 + PA_MAXB; ++l) {
-    const pa_level* L = F1[l]->lev;
-    if (L->nranks > 1) return 2;
-    if (F1[l]->ng < 1 || comp1 < 0 || comp1 + ncomp1 > F1[l]->ncomp) return pa_fail(ctx, "pa_apply_bc_multi: ghost cells / component range");
-    if (F2 && (F2[l]->lev != L || F2[l]->ng < 1 || comp2 < 0 || comp2 + ncomp2 > F2[l]->ncomp)) return pa_fail(ctx, "pa_apply_bc_multi: second group");
-    if (L->boxes.empty() || L->sfaces.empty()) continue;
-    if (!L->d_sfwg || L->nsfwg <= 0) return 2;
-    BcMultiLev& X = S.lev[S.n];
-    X.L = L->view;
-    X.LC = l > 0 ? F1[l - 1]->lev->view : L->view;
-    for (int d = 0; d < 3; ++d) X.A.bc[d] = bc[d];
-    X.A.ratio = 2; X.A.only_dir = -1; X.A.has_crse = l > 0 ? 1 : 0; X.A.edges = 0;
-    X.wg = (const int2*)L->d_sfwg;
-    X.ngroups = F2 ? 2 : 1;
-    X.g[0] = BcGroup{F1[l]->view, l > 0 ? F1[l - 1]->view : F1[l]->view, comp1, comp1, ncomp1};
-    X.g[0].MC.xform = 0;
-    X.g[1] = X.g[0];
-    if (F2) { X.g[1] = BcGroup{F2[l]->view, l > 0 ? F2[l - 1]->view : F2[l]->view, comp2, comp2, ncomp2}; X.g[1].MC.xform = 0; }
-    S.wg0[S.n + 1] = S.wg0[S.n] + (unsigned)L->nsfwg;
-    ++S.n;
-  }
-  if (!S.n) continue;
-  ProfScope prof(ctx, PA_TAG_BC);
-  hipLaunchKernelGGL(k_apply_bc_multi, dim3(S.wg0[S.n], (unsigned)(ncomp1 + (F2 ? ncomp2 : 0))), dim3(256), 0, ctx->stream, S, ctx->d_flags);
-  PA_HIP(hipGetLastError());
-  }
-  return 0;
-}
-
 // Fused-path extension: edge ghost cells (outside the box in two directions a<c).  Such a cell
 // is needed as the boundary ghost of a valid cell of a NEIGHBOURING box (role = the direction
 // towards that valid cell); see DESIGN.md "resolved ghost ring".

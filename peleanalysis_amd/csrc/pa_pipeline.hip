@@ -29,7 +29,6 @@ int pa_gauss_curv_level(pa_ctx* ctx, const pa_mf* G, int gcomp, const pa_mf* nor
                         int kcomp);
 int pa_strain_level(pa_ctx* ctx, const pa_mf* u, int ucomp, pa_mf* out, int srcomp, int rostcomp);
 int pa_velnormal_level(pa_ctx* ctx, const pa_mf* u, int ucomp, const pa_mf* n, int ncomp0, const pa_mf* c, int ccomp, double thr, pa_mf* out, int ocomp);
-int pa_apply_bc_multi(pa_ctx* ctx, int nlev, pa_mf* const* F1, int comp1, int ncomp1, pa_mf* const* F2, int comp2, int ncomp2, const int32_t bc[3]);
 int pa_curvopts_level(pa_ctx* ctx, int which, const pa_mf* G, const pa_mf* u, int ucomp, pa_mf* out, int pc, int nc, int kgc, int src, int vnc, int rostc, double thr);
 
 int pa_gradcurv_faces_phase(pa_ctx* ctx, const pa_mf* c, int ccomp, const pa_mf* crse_n, int cncomp0, const int32_t bc[3], int ratio, double thr,
@@ -610,8 +609,6 @@ static int curvature_fast(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, 
     if (strain) PA_TRY(pa_fill_boundary_local_batch(ctx, nlev, state, P->vel_comp, 3, 1));
   }
   if (gauss || strain) {
-    pa_mf* const* F1 = gauss ? G.data() : state;
-    const int c1 = gauss ? 0 : P->vel_comp;
     // round 6: one rank -- MLMG applyBC of the three components of G and of the velocity through the chunked special-face kernel
     // (k_prep_faces_chunks<.., PHIONLY>: the gradient tool's applyBC, component = slot, coarse values from the gathered patches):
     // k_apply_bc_multi, a thread per ghost cell and component through the owner map, took 1.2 ms of a 17-ms headline pass
@@ -622,7 +619,6 @@ static int curvature_fast(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, 
       if (gauss) PA_TRY(pa_gradcurv_prep_levels(ctx, nlev, G.data(), 0, crG.data(), 0, bc, 0.0, 1.0, 1 | 8, 3, nullptr));
       if (strain) PA_TRY(pa_gradcurv_prep_levels(ctx, nlev, state, P->vel_comp, crU.data(), P->vel_comp, bc, 0.0, 1.0, 1 | 8, 3, nullptr));
       rc = 0;
-      (void)F1; (void)c1;
     }
     if (rc == 2) {
       for (int l = 0; l < nlev && gauss; ++l)
