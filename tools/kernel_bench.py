@@ -74,8 +74,10 @@ for fgr in (() if MCONLY else (2, 4, 8)):
     for mode in ("separable", "exact"):
         if mode == "exact":
             os.environ["PA_FILTER_EXACT"] = "1"
+        ctx.lib.pa_options_reload()  # the library reads its switches once
         ms = timed(7, lambda: ctx.check(ctx.lib.pa_boxfilter_level(ctx.h, fin.h, fo.h, 0, 1, ng, w)))
         os.environ.pop("PA_FILTER_EXACT", None)
+        ctx.lib.pa_options_reload()
         key = f"k_filter_sep fgr={fgr} (3 x {2 * ng + 1} taps)" if mode == "separable" else f"k_boxfilter fgr={fgr} ({taps} taps, PA_FILTER_EXACT=1)"
         out["kernels"][key] = {"ms": ms, "bytes_per_cell": 16, "GBs": cells * 16 / ms / 1e6, "frac_hbm": cells * 16 / ms / 1e6 / HBM, "Mcells_s": cells / ms / 1e3}
     del fin, fo, tin, tfo
