@@ -605,3 +605,73 @@ def test_work_multifabs_are_never_read_before_they_are_written():
                         "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider", "-k", "curvature_run or options or curvature_options or smoothing or gauss or strain"],
                        env=env, capture_output=True, text=True, cwd=os.path.dirname(here))
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("per,sym", [((0, 0, 0), (0, 0, 0)), ((0, 1, 0), (1, 0, 1)), ((1, 0, 1), (0, 0, 0))])
+def test_chunked_face_kernels_odd_origins_small_faces_and_slots(ctx, oracle, per, sym):
+    """The chunk records' corner cases (pa_fused.hip, round 6): level-0 boxes cut on ODD indices (block origins on even global
+    indices start at -1: cells outside the face are predicated off), extents that are not multiples of anything, faces 3 cells
+    wide, wall / reflect-odd / coarse-fine cells in one chunk, a fine level whose faces end in one-sided stencils next to the
+    walls -- bit for bit against the oracle, one component at a time and three components in one batch (slot = blockIdx.z)."""
+    from peleanalysis_amd.hierarchy import Hierarchy, Level, field_flame
+
+    def cut(lo, hi, cuts):
+        edges = [lo[d:d + 1] + [c for c in cuts[d]] + [hi[d] + 1] for d in range(3)]
+        out = []
+        for kz in range(len(edges[2]) - 1):
+            for ky in range(len(edges[1]) - 1):
+                for kx in range(len(edges[0]) - 1):
+                    out.append([edges[0][kx], edges[1][ky], edges[2][kz], edges[0][kx + 1] - 1, edges[1][ky + 1] - 1, edges[2][kz + 1] - 1])
+        return np.array(out, np.int32)
+    l0 = Level(cut([0, 0, 0], [45, 37, 29], ([13, 27], [19], [3, 15])), (0, 0, 0), (45, 37, 29), per, np.zeros(3), np.ones(3))  # a 3-plane slab in z, odd cuts in x and y
+    # level 1: coarse cells [2, 19] x [8, 17] x [0, 13] -- flush with the z-low wall, two coarse cells from the x-low wall
+    l1 = Level(cut([4, 16, 0], [39, 35, 27], ([22], [], [10])), (0, 0, 0), (91, 75, 59), per, np.zeros(3), np.ones(3))
+    H = Hierarchy([l0, l1], 2)
+    ncomp = 3
+    states = make_states(H, ncomp, 2, field_flame, seed=91)
+    for st in states:
+        for b in range(st.level.nboxes):
+            for c in range(ncomp):
+                st.fab(b)[c] = st.fab(b)[c] * (1.0 + 0.21 * c) + 7.0 * c
+    bc = capi.bc_from_flags(per, sym)
+    dls, dst = _dev(ctx, H, states)
+    work = [capi.DevMF(ctx, dl, 1, 2) for dl in dls]
+    want = {}
+    for c in range(ncomp):
+        og = [MultiFab(lv, 4, 0) for lv in H.levels]
+        oc = [MultiFab(lv, 5, 0) for lv in H.levels]
+        oracle.grad_pipeline(H.levels, [s.copy() for s in states], c, bc, og, 0, multipass=True)
+        oracle.curvature_pipeline(H.levels, [s.copy() for s in states], c, bc, oc, 0, MultiFab)
+        want[c] = (og, oc)
+        dout = [capi.DevMF(ctx, dl, 8, 0) for dl in dls]
+        capi.gradcurv_run(ctx, dst, c, bc, capi.curv_params(fused=True), work, dout, 0)
+        ctx.sync()
+        assert ctx.bc_errors() == 0
+        assert ctx.lib.pa_sweep_kernel_name(ctx.h).decode().find("march3") >= 0
+        for l in range(H.nlev):
+            got = dout[l].download()
+            assert_valid_bits_equal(got, og[l], [(k, k) for k in range(4)], f"comp {c} grad level {l}")
+            assert_valid_bits_equal(got, oc[l], [(4, 2), (5, 3), (6, 4), (7, 1)], f"comp {c} curv level {l}")
+    # the same three components as one batch
+    dst2 = [capi.DevMF.from_host(ctx, dl, st) for dl, st in zip(dls, states)]
+    dout2 = [capi.DevMF(ctx, dl, 8 * ncomp, 0) for dl in dls]
+    capi.gradcurv_run_comps2(ctx, dst2, 0, ncomp, bc, capi.curv_params(fused=True), work, dout2, 0, ncomp, None)
+    ctx.sync()
+    assert ctx.bc_errors() == 0
+    for c in range(ncomp):
+        og, oc = want[c]
+        for l in range(H.nlev):
+            got = dout2[l].download()
+            assert_valid_bits_equal(got, og[l], [(8 * c + k, k) for k in range(4)], f"batch comp {c} grad level {l}")
+            assert_valid_bits_equal(got, oc[l], [(8 * c + 4, 2), (8 * c + 5, 3), (8 * c + 6, 4), (8 * c + 7, 1)], f"batch comp {c} curv level {l}")
+    # the gradient tool's applyBC goes through the same kernel (PHIONLY) on a state with ONE ghost layer
+    st1 = make_states(H, 1, 1, field_flame, seed=91)
+    dst1 = [capi.DevMF.from_host(ctx, dl, s) for dl, s in zip(dls, st1)]
+    og1 = [MultiFab(lv, 4, 0) for lv in H.levels]
+    oracle.grad_pipeline(H.levels, [s.copy() for s in st1], 0, bc, og1, 0, multipass=True)
+    dgr = [capi.DevMF(ctx, dl, 4, 0) for dl in dls]
+    capi.grad_run(ctx, dst1, 0, bc, dgr, 0)
+    ctx.sync()
+    assert ctx.bc_errors() == 0
+    for l in range(H.nlev):
+        assert_valid_bits_equal(dgr[l].download(), og1[l], [(k, k) for k in range(4)], f"grad_run level {l}")
