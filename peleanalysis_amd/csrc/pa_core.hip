@@ -1004,7 +1004,7 @@ int pa_fill_boundary_local_batch_ngs(pa_ctx* ctx, int n, pa_mf* const* Ms, int c
         }
         if (!Bt.n) continue;
         // several components: the component is a grid dimension, not a loop inside the thread -- a wave then stays inside one
-        // component's pages (config 2's 10 components: 1.27 -> 1.03-1.10 ms, config 5's shape 1.58 -> 1.34-1.38).  PA_FB_COMP_Z=0: the loop
+        // component's pages (config 2's 10 components: 1.27 -> 1.03-1.10 ms, config 5's shape 1.58 -> 1.34-1.38) than a loop over the components
         const unsigned gz = (ncomp > 1 && ncomp <= 65535) ? (unsigned)ncomp : 1u;
         hipLaunchKernelGGL(k_fill_boundary_regions, dim3((unsigned)mw, (unsigned)Bt.n, gz), dim3(256), 0, ctx->stream, Bt);
       }

@@ -513,9 +513,9 @@ extern "C" int pa_boxfilter_level(pa_ctx* ctx, const pa_mf* in, pa_mf* out, int 
 
 // Filter::apply_filter on EVERY level of a hierarchy (the level loop of filterPlt.cpp:206-219).  The levels do not depend on each
 // other and a level of a few 10^7 cells does not fill the chip (config 3: 16.8 M cells per level at 0.37-0.49 of HBM), so
-// PA_FILTER_LEVEL_STREAMS=1 (read per call) puts each level's launch on a stream of its own between a fork and a join.  OFF by
-// default: MEASURED slower -- config 3's three levels 0.304 ms side by side against 0.248 ms one after the other (the fork /
-// join events cost more than the tails they fill; profiles/r04_small_experiments.txt).
+// (Each level's launch on a stream of its own between a fork and a join was MEASURED slower -- config 3's three levels 0.304 ms side
+// by side against 0.248 ms one after the other: the fork / join events cost more than the tails they fill,
+// profiles/r04_small_experiments.txt -- and went with its switch in round 6.)
 extern "C" int pa_boxfilter_hierarchy(pa_ctx* ctx, int nlev, const pa_mf* const* in, pa_mf* const* out, int scomp, int ncomp, const int32_t* ngs,
                                       const double* const* ws) {
   PaBind bind_(ctx);

@@ -2217,8 +2217,7 @@ int pa_gradcurv_level_cg(pa_ctx* ctx, const pa_mf* phi, int pcomp, double pmin, 
 }
 
 // the CG sweeps of all levels: the groups of boxes wider than 32 cells in one launch (k_gradcurv_march3_levels) when they agree
-// on the tile variant and the XCD-aware order is on, else group by group; narrow groups one launch each.
-// PA_SWEEP_BATCH=0: always group by group (A/B).
+// on the tile variant, else group by group (PA_FORCE_FALLBACKS=1: always); narrow groups one launch each.
 // nslots > 1 (slot must be 0): components pcomp .. pcomp + nslots - 1 in ONE launch per kernel variant (blockIdx.y = slot: outputs at
 // ocomp + 8 z, compact arrays of slot z, progress range prog[2 z], prog[2 z + 1] on the device); groups that do not take a batched
 // launch run slot by slot with the host's ranges pmins / pmaxs
