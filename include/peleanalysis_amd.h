@@ -293,8 +293,7 @@ int pa_filter_weights(int type, int fgr, double* w);
 /* filterPlt.cpp:206-219, all boxes of a level */
 int pa_boxfilter_level(pa_ctx*, const pa_mf* in, pa_mf* out, int scomp, int ncomp, int ng, const double* w);
 /* Filter::apply_filter on every level of a hierarchy in one call (the level loop of filterPlt.cpp:206-219): in[l] / out[l] / ngs[l] /
- * ws[l] as pa_boxfilter_level's arguments for level l.  (PA_FILTER_LEVEL_STREAMS=1: the levels side by side on streams of their
- * own -- measured slower than one after the other on config 3, so off by default.) */
+ * ws[l] as pa_boxfilter_level's arguments for level l (the levels one after the other on the context's stream). */
 int pa_boxfilter_hierarchy(pa_ctx*, int nlev, const pa_mf* const* in, pa_mf* const* out, int scomp, int ncomp, const int32_t* ngs,
                            const double* const* ws);
 /* the AMREX_SPACEDIM == 2 build of the same call on a level stored as one plane of cells (k = 0):
@@ -467,7 +466,7 @@ typedef struct {
  * (one rank or a sharded hierarchy; with do_smooth the smoothed field is the pipeline's progress source with range [0, 1]): Progress / MeanCurvature / FlameNormal from the exact-normal pipeline of pa_gradcurv_run, whose
  * sweeps leave the cell-centred gradient of c (curvature.cpp:457-490, what do_gaussCurv differentiates again at :582-613) in a work
  * multifab of the level (3 components + 1 ghost layer, kept for the level's lifetime) instead of grad phi, then one pass per level
- * for the options; otherwise (or PA_CURV_FAST=0 in the environment) one pass per AMReX call of the reference. */
+ * for the options; otherwise (or with params.fused = 0) one pass per AMReX call of the reference. */
 int pa_curvature_run(pa_ctx*, int nlev, pa_mf* const* state, int comp, const int32_t bc[3],
                      const pa_curv_params*, pa_mf* const* out, int ocomp);
 /* curvature.cpp:328-406: (I - dt Lap) sol = rhs[rcomp] as a composite solve over the levels (periodic /
