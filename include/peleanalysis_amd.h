@@ -489,7 +489,8 @@ int pa_smooth_solve(pa_ctx*, int nlev, pa_mf* const* rhs, int rcomp, pa_mf* cons
  * when no such solve has run on the context. */
 int pa_smooth_last(const pa_ctx*, int* iters, double* rel_residual);
 /* which implementation the last pa_curvature_run on the context took: 1 = the exact-normal pipeline's G-output sweeps + one options
- * pass per level, 0 = one kernel per AMReX call (fused = 0, 2-D levels, boxes thinner than 3 cells, or a hierarchy the
+ * pass per level, 2 = the same with the Gaussian curvature formed inside the sweeps (one rank, every box wider than 32 cells and at
+ * least 16 rows tall; only its first layer behind special faces is recomputed from the stored G), 0 = one kernel per AMReX call (fused = 0, 2-D levels, boxes thinner than 3 cells, or a hierarchy the
  * all-levels sweeps do not take; on a sharded hierarchy the ranks agree on one answer), -1 = none yet.  Diagnostic (tests, bench.py). */
 int pa_curvature_last_path(const pa_ctx*);
 /* Work multifabs the library keeps with a level between calls (pa_curvature_run: the gradient of c, 3 components, or the pass-by-pass

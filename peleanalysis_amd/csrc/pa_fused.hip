@@ -2084,6 +2084,94 @@ bool pa_fused2_level_ok(const pa_level* L) {
   return true;
 }
 
+// ---- round 6: the Gaussian curvature of the cells the KG sweep cannot get right (pa_fused_march3.h, GOUT == 2): the first layer behind
+// every special face -- its ghost G is the boundary condition on G (the caller has run FillBoundary + applyBC on the stored G), not what
+// the sweep forms from ghost c -- and the level's irregular cells.  k_gauss_curv's operations (pa_curvopts.hip) on the stored G, a thread
+// per 2 x 2 block of a chunk record / per listed cell; every other cell keeps the sweep's value, which is the same arithmetic on the
+// same values.
+struct GaussFixLev { DLevelView L; DMFView G, O; int pc, kgc; double thr; const SfChunk* ck; unsigned nck; const int4* irr; unsigned nirr; unsigned w0; };
+__device__ __forceinline__ void gauss_cell(const GaussFixLev& A, int b, int i, int j, int k) {
+  const DBox V = A.L.boxes[b];
+  const FabView G = mf_view(A.G, V, b), O = mf_view(A.O, V, b);
+  double H[3][3], g[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const double c0 = G(i, j, k, d);
+    g[d] = c0;
+    H[d][0] = cdiff(A.L.dxinv[0], G(i - 1, j, k, d), c0, G(i + 1, j, k, d));
+    H[d][1] = cdiff(A.L.dxinv[1], G(i, j - 1, k, d), c0, G(i, j + 1, k, d));
+    H[d][2] = cdiff(A.L.dxinv[2], G(i, j, k - 1, d), c0, G(i, j, k + 1, d));
+  }
+  const double ax0 = H[1][1] * H[2][2] - H[2][1] * H[1][2];
+  const double ay0 = H[1][2] * H[2][0] - H[2][2] * H[1][0];
+  const double az0 = H[1][0] * H[2][1] - H[2][0] * H[1][1];
+  const double ax1 = H[0][2] * H[2][1] - H[2][2] * H[0][1];
+  const double ay1 = H[0][0] * H[2][2] - H[2][0] * H[0][2];
+  const double az1 = H[0][1] * H[2][0] - H[2][1] * H[0][0];
+  const double ax2 = H[0][1] * H[1][2] - H[1][1] * H[0][2];
+  const double ay2 = H[0][2] * H[1][0] - H[1][2] * H[0][0];
+  const double az2 = H[0][0] * H[1][1] - H[1][0] * H[0][1];
+  const double cx = g[0], cy = g[1], cz = g[2];
+  const double sn = sqrt(cx * cx + cy * cy + cz * cz);
+  const double gn = (1e-14 < sn) ? sn : 1e-14;
+  double kg = (cx * (ax0 * cx + ax1 * cy + ax2 * cz) + cy * (ay0 * cx + ay1 * cy + ay2 * cz) + cz * (az0 * cx + az1 * cy + az2 * cz)) / ((gn * gn) * (gn * gn));
+  if (A.thr >= 0.0) {
+    const double p = O(i, j, k, A.pc);
+    if (p < A.thr || p > 1.0 - A.thr) kg = 0.0;
+  }
+  O(i, j, k, A.kgc) = kg;
+}
+__global__ __launch_bounds__(256) void k_gauss_cells(LevBatch<GaussFixLev> Bt) {
+  int l = 0;
+  while (l + 1 < Bt.n && blockIdx.x >= Bt.a[l + 1].w0) ++l;
+  const GaussFixLev& A = Bt.a[l];
+  const unsigned w = blockIdx.x - A.w0;
+  if (w < A.nck) {  // a chunk of a special face: the first-layer cells behind its ghost cells
+    const SfChunk D = A.ck[w];
+    const int dir = D.dir_side >> 1, side = D.dir_side & 1;
+    const int e0 = D.hi[0] - D.lo[0] + 1, e1 = D.hi[1] - D.lo[1] + 1, e2 = D.hi[2] - D.lo[2] + 1;
+    const int n0 = dir == 0 ? e1 : e0, n1 = dir == 2 ? e1 : e2;
+    const int hw = D.cw >> 1, sh = 31 - __builtin_clz((unsigned)hw);
+    const int u = D.u0 + 2 * ((int)threadIdx.x & (hw - 1)), v = D.v0 + 2 * ((int)threadIdx.x >> sh);
+    for (int dv = 0; dv < 2; ++dv)
+      for (int du = 0; du < 2; ++du) {
+        const int uu = u + du, vv = v + dv;
+        if (uu < 0 || vv < 0 || uu >= n0 || vv >= n1) continue;
+        int i, j, k;
+        if (dir == 0) { i = side ? D.hi[0] : D.lo[0]; j = D.lo[1] + uu; k = D.lo[2] + vv; }
+        else if (dir == 1) { i = D.lo[0] + uu; j = side ? D.hi[1] : D.lo[1]; k = D.lo[2] + vv; }
+        else { i = D.lo[0] + uu; j = D.lo[1] + vv; k = side ? D.hi[2] : D.lo[2]; }
+        gauss_cell(A, D.box, i, j, k);
+      }
+    return;
+  }
+  const unsigned q = (w - A.nck) * 256u + threadIdx.x;
+  if (q < A.nirr) {
+    const int4 it = A.irr[q];
+    gauss_cell(A, it.x, it.y, it.z, it.w);
+  }
+}
+// G[l]: components 0 .. 2, >= 1 ghost layer, FillBoundary + applyBC done; out[l]: Progress at pc (read for the clip), Kg written at kgc
+int pa_gauss_cells_levels(pa_ctx* ctx, int nlev, pa_mf* const* G, pa_mf* const* out, int pc, int kgc, double thr) {
+  for (int l0 = 0; l0 < nlev; l0 += PA_MAXB) {
+    LevBatch<GaussFixLev> Bt;
+    unsigned w = 0;
+    for (int l = l0; l < nlev && l < l0 + PA_MAXB; ++l) {
+      const pa_level* L = out[l]->lev;
+      if (L->boxes.empty()) continue;
+      if (G[l]->lev != L || G[l]->ng < 1 || G[l]->ncomp < 3) return pa_fail(ctx, "pa_gauss_cells_levels: G needs 3 components and a ghost layer on the level of out");
+      if (L->nirr < 0 && level_irregular(ctx, L)) return 1;
+      GaussFixLev A{L->view, G[l]->view, out[l]->view, pc, kgc, thr, L->d_sfchunk, (unsigned)L->nsfchunk, (const int4*)L->d_irr, (unsigned)std::max(L->nirr, 0), w};
+      w += A.nck + (A.nirr + 255u) / 256u;
+      Bt.a[Bt.n++] = A;
+    }
+    if (!Bt.n || w == 0) continue;
+    hipLaunchKernelGGL(k_gauss_cells, dim3(w), dim3(256), 0, ctx->stream, Bt);
+  }
+  PA_HIP(hipGetLastError());
+  return 0;
+}
+
 // before the sweeps: face ghosts of phi + resolved ghost c (faces and ring) of several levels, one launch pair for up to
 // PA_MAXB levels.  crse[l]: the coarser level's phi (component ccomp) or this rank's coarse-source copy of it, null on
 // level 0 / where this rank has no coarse-fine face; the local half of FillBoundary(2) must have run.
@@ -2227,6 +2315,19 @@ int pa_gradcurv_level_cg(pa_ctx* ctx, const pa_mf* phi, int pcomp, double pmin, 
 // the sweeps of this hierarchy can be split into early and late tiles: every group of wide boxes goes through the all-levels launches
 bool pa_gradcurv_gout_ok(int nlev, pa_mf* const* phi);
 bool pa_gradcurv_parts_ok(int nlev, pa_mf* const* phi) { return pa_gradcurv_gout_ok(nlev, phi); }
+// the G-output sweeps of this hierarchy can form the Gaussian curvature themselves (GOUT == 2, pa_fused_march3.h): every box wider
+// than 32 cells (the narrow sweep has no such variant) and at least 16 rows tall (tiles of 13 or 8 rows)
+bool pa_gradcurv_kg_ok(int nlev, pa_mf* const* phi) {
+  if (!pa_gradcurv_gout_ok(nlev, phi)) return false;
+  for (int l = 0; l < nlev; ++l) {
+    const pa_level* L = phi[l]->lev;
+    if (L->boxes.empty()) continue;
+    if (L->nnarrow > 0 || L->maxn[1] < 16) return false;
+    for (const DBox& B : L->boxes)
+      if (B.hi[0] - B.lo[0] + 1 <= 32) return false;
+  }
+  return true;
+}
 bool pa_gradcurv_gout_ok(int nlev, pa_mf* const* phi) {
   if (pa_opt().force_fallbacks) return false;
   std::vector<SweepGroup> all;
@@ -2237,8 +2338,9 @@ bool pa_gradcurv_gout_ok(int nlev, pa_mf* const* phi) {
 // part (a sharded hierarchy's pass, pa_pipeline.hip): 1 = only the EARLY tiles of the wide boxes (pa_sweep_wgtab: their input is
 // complete after the local FillBoundary), 2 = the other tiles and every narrow box; 0 = everything
 int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, double pmin, double pmax, pa_mf* const* out, int ocomp, double thr, int slot,
-                          int nslots, const double* prog, const double* pmins, const double* pmaxs, pa_mf* const* gout, int part) {
+                          int nslots, const double* prog, const double* pmins, const double* pmaxs, pa_mf* const* gout, int part, int kg) {
   const bool clip = thr >= 0.0;
+  if (kg && (!gout || !pa_gradcurv_kg_ok(nlev, phi))) return pa_fail(ctx, "pa_gradcurv_levels_cg: the Gaussian curvature inside the sweep needs the G-output sweeps of wide boxes");
   if (part && !pa_gradcurv_parts_ok(nlev, phi)) return pa_fail(ctx, "pa_gradcurv_levels_cg: this hierarchy's sweeps cannot be split into early and late tiles");
   if (nslots > 1 && (slot != 0 || !prog || !pmins || !pmaxs)) return pa_fail(ctx, "pa_gradcurv_levels_cg: component slots need slot 0 and the progress ranges");
   if (gout && (nslots != 1 || slot != 0 || !pa_gradcurv_gout_ok(nlev, phi))) return pa_fail(ctx, "pa_gradcurv_levels_cg: the G-output sweeps take one component of a hierarchy pa_gradcurv_gout_ok accepts");
@@ -2339,7 +2441,15 @@ int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, d
     ProfScope prof(ctx, PA_TAG_GRADCURV);
     S.prog = nslots > 1 ? prog : nullptr;
     const dim3 grid(S.wg0[S.n], (unsigned)nslots);
-    if (gout) {
+    if (gout && kg) {  // GOUT == 2: + the Gaussian curvature at out component ocomp + 5
+      if (clip) {
+        if (mty == 13) hipLaunchKernelGGL((k_gradcurv_march3_levels<13, true, 2>), grid, dim3(64 * 16), 0, ctx->stream, S);
+        else hipLaunchKernelGGL((k_gradcurv_march3_levels<8, true, 2>), grid, dim3(64 * 11), 0, ctx->stream, S);
+      } else {
+        if (mty == 13) hipLaunchKernelGGL((k_gradcurv_march3_levels<13, false, 2>), grid, dim3(64 * 16), 0, ctx->stream, S);
+        else hipLaunchKernelGGL((k_gradcurv_march3_levels<8, false, 2>), grid, dim3(64 * 11), 0, ctx->stream, S);
+      }
+    } else if (gout) {
       if (clip) {
         if (mty == 13) hipLaunchKernelGGL((k_gradcurv_march3_levels<13, true, true>), grid, dim3(64 * 16), 0, ctx->stream, S);
         else if (mty == 8) hipLaunchKernelGGL((k_gradcurv_march3_levels<8, true, true>), grid, dim3(64 * 11), 0, ctx->stream, S);

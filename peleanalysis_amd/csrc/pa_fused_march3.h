@@ -123,9 +123,22 @@ __device__ __forceinline__ void store_pair(char* base, unsigned off, bool odd, d
 // GOUT (pa_curvature_run with options; CG only): no gradient of phi -- the 8 stores of a plane are Progress, K, N (out components
 // ocomp .. ocomp + 4) and G = the cell-centred gradient of c, the normal before its normalisation (curvature.cpp:457-490),
 // into components 0 .. 2 of a second multifab (MarchArgs::gdata) that do_gaussCurv differentiates again.
-template <typename BP, int PA_MTY, bool CLIP, bool PAIR, int DBG, bool CG, bool GOUT = false>
+// GOUT == 2 (round 6, "KG"): the sweep ALSO forms the Gaussian curvature (curvature.cpp:575-677: Hessian rows = grad(G_d), adjugate,
+// Kg = G^T adj(H) G / normgrad^4) and stores it at out component ocomp + 5 -- G of a plane goes through three more LDS rings for its
+// x / y neighbours (rows, halo rows and edge columns all form G anyway), its z-neighbours are the planes before and after in
+// registers; the operations and their order are k_gauss_curv's (pa_curvopts.hip), the values the ones it would load, so the bits are
+// the same in every cell whose six neighbours' G this FAB sees as the level does: every cell but the first layer behind a special face
+// (ghost G = the boundary condition on G, not what this sweep forms from ghost c) and the level's irregular cells -- those are
+// recomputed from the stored G afterwards (k_gauss_cells).  The separate Gaussian-curvature pass over all cells (1.43 ms per 512^3 level)
+// is gone; the sweep stores nine values per cell and plane instead of eight.
+template <int MTY>
+struct MarchLdsG {
+  double gy[3][MTY + 2][PA_MLW], gz[3][MTY + 2][PA_MLW];  // (G_x rides in MarchLds::p, which a GOUT sweep does not use)
+};
+template <typename BP, int PA_MTY, bool CLIP, bool PAIR, int DBG, bool CG, int GOUT = 0>
 __device__ __forceinline__ void gradcurv_march3_body(const BP& bp, const MarchArgs& A, const unsigned bid_x, const unsigned bid_y) {
   static_assert(!GOUT || (CG && !PAIR && DBG == 0), "GOUT: exact-normal sweep, 8-byte stores");
+  constexpr bool KG = GOUT == 2;
   FabView P, O;
   DBox V;
   double dxinv[3];
@@ -188,6 +201,9 @@ __device__ __forceinline__ void gradcurv_march3_body(const BP& bp, const MarchAr
   const bool ncg_tile = ncgl || ncgh;
 
   __shared__ MarchLds<PA_MTY> S;
+  __shared__ typename std::conditional<KG, MarchLdsG<PA_MTY>, char>::type SG;
+  (void)SG;
+#define PA_SGX S.p
   const long long pps = (long long)P.nx * P.ny * 8;  // plane stride of phi, bytes
   const int pend = k1 + 1;                            // normals are formed on planes k0-1 .. k1+1
   const int kfmax = k1 + 2;                           // last plane of phi that exists for this segment
@@ -295,6 +311,7 @@ __device__ __forceinline__ void gradcurv_march3_body(const BP& bp, const MarchAr
         S.ny[SP][rr][lane] = ggy / ng;
         S.c[SP1][rr][xs] = cp;
         if (!GOUT) S.p[SP][rr][xs] = p0;
+        if constexpr (KG) { PA_SGX[SP][rr][xs] = ggx; SG.gy[SP][rr][xs] = ggy; SG.gz[SP][rr][xs] = ggz; }
         __syncthreads();
         if (!OLD_SCHED) {
           PA_OPAQUE(lo8);
@@ -344,6 +361,7 @@ __device__ __forceinline__ void gradcurv_march3_body(const BP& bp, const MarchAr
       osc2 = G2.sc * 8;
     }
     double gxq = 0, gyq = 0, gzq = 0;  // GOUT: G of plane q
+    double gxm = 0, gym = 0, gzm = 0, gnq = 1.0, o8 = 0;  // KG: G of plane q - 1, max(1e-14, |G|) of plane q, the Gaussian curvature of plane q
     const double thr = A.thr;
     const bool odd = lane & 1;
     unsigned lo16 = odd ? (unsigned)(le - 1) * 8u + (unsigned)osc : (unsigned)le * 8u;
@@ -367,6 +385,7 @@ __device__ __forceinline__ void gradcurv_march3_body(const BP& bp, const MarchAr
         } else if (GOUT) {
           PA_STL(ob, lo8, o0); PA_STL(ob + osc, lo8, o1); PA_STL(ob + 2 * osc, lo8, o2); PA_STL(ob + 3 * osc, lo8, o3);
           PA_STL(ob + 4 * osc, lo8, o4); PA_STL(ob2, lo8, o5); PA_STL(ob2 + osc2, lo8, o6); PA_STL(ob2 + 2 * osc2, lo8, o7);
+          if constexpr (KG) PA_STL(ob + 5 * osc, lo8, o8);
         } else {
           PA_STL(ob, lo8, o0); PA_STL(ob + osc, lo8, o1); PA_STL(ob + 2 * osc, lo8, o2); PA_STL(ob + 3 * osc, lo8, o3);
           PA_STL(ob + 4 * osc, lo8, o4); PA_STL(ob + 5 * osc, lo8, o5); PA_STL(ob + 6 * osc, lo8, o6); PA_STL(ob + 7 * osc, lo8, o7);
@@ -400,6 +419,7 @@ __device__ __forceinline__ void gradcurv_march3_body(const BP& bp, const MarchAr
       S.nx[SP][rr - 1][xs] = nxp;
       S.c[SP1][rr][xs] = cp;
       if (!GOUT) S.p[SP][rr][xs] = p0;
+      if constexpr (KG) { PA_SGX[SP][rr][xs] = ggx; SG.gy[SP][rr][xs] = ggy; SG.gz[SP][rr][xs] = ggz; }
       if (OLD_SCHED) __builtin_amdgcn_sched_barrier(0);
       if (OLD_SCHED && !PAIR) PA_STL(ob + 4 * osc, lo8, o4);
       if (DBG & 512) {  // experiment: the burst just before the barrier
@@ -464,6 +484,33 @@ __device__ __forceinline__ void gradcurv_march3_body(const BP& bp, const MarchAr
       if (GOUT) {  // [Progress K Nx Ny Nz] + G; cm = c at plane q; Progress and G are not clipped (curvature.cpp:557-566 clips K and N)
         ob2 += (p >= k0 + 2) ? ops2 : 0;
         const bool clip = CLIP && ((cm < thr) || (cm > 1.0 - thr));
+        if constexpr (KG) {  // k_gauss_curv (pa_curvopts.hip) on plane q: x / y neighbours of G from the rings, z-neighbours from the registers
+          double H[3][3];
+          H[0][0] = cdiff(dxinv[0], PA_SGX[SQ][rr][xs - 1], gxq, PA_SGX[SQ][rr][xs + 1]);
+          H[0][1] = cdiff(dxinv[1], PA_SGX[SQ][rr - 1][xs], gxq, PA_SGX[SQ][rr + 1][xs]);
+          H[0][2] = cdiff(dxinv[2], gxm, gxq, ggx);
+          H[1][0] = cdiff(dxinv[0], SG.gy[SQ][rr][xs - 1], gyq, SG.gy[SQ][rr][xs + 1]);
+          H[1][1] = cdiff(dxinv[1], SG.gy[SQ][rr - 1][xs], gyq, SG.gy[SQ][rr + 1][xs]);
+          H[1][2] = cdiff(dxinv[2], gym, gyq, ggy);
+          H[2][0] = cdiff(dxinv[0], SG.gz[SQ][rr][xs - 1], gzq, SG.gz[SQ][rr][xs + 1]);
+          H[2][1] = cdiff(dxinv[1], SG.gz[SQ][rr - 1][xs], gzq, SG.gz[SQ][rr + 1][xs]);
+          H[2][2] = cdiff(dxinv[2], gzm, gzq, ggz);
+          const double ax0 = H[1][1] * H[2][2] - H[2][1] * H[1][2];
+          const double ay0 = H[1][2] * H[2][0] - H[2][2] * H[1][0];
+          const double az0 = H[1][0] * H[2][1] - H[2][0] * H[1][1];
+          const double ax1 = H[0][2] * H[2][1] - H[2][2] * H[0][1];
+          const double ay1 = H[0][0] * H[2][2] - H[2][0] * H[0][2];
+          const double az1 = H[0][1] * H[2][0] - H[2][1] * H[0][0];
+          const double ax2 = H[0][1] * H[1][2] - H[1][1] * H[0][2];
+          const double ay2 = H[0][2] * H[1][0] - H[1][2] * H[0][0];
+          const double az2 = H[0][0] * H[1][1] - H[1][0] * H[0][1];
+          const double cx = gxq, cy = gyq, cz = gzq;
+          const double kg = (cx * (ax0 * cx + ax1 * cy + ax2 * cz) + cy * (ay0 * cx + ay1 * cy + ay2 * cz) + cz * (az0 * cx + az1 * cy + az2 * cz)) /
+                            ((gnq * gnq) * (gnq * gnq));
+          o8 = clip ? 0.0 : kg;
+          gxm = gxq; gym = gyq; gzm = gzq;
+          gnq = (1e-14 < sn) ? sn : 1e-14;  // of plane p = the next step's plane q
+        }
         o0 = cm;
         o1 = clip ? 0.0 : curv;
         o2 = clip ? 0.0 : nxq;
@@ -505,6 +552,7 @@ __device__ __forceinline__ void gradcurv_march3_body(const BP& bp, const MarchAr
       PA_STG(ob2, lo8, o5);
       PA_STG(ob2 + osc2, lo8, o6);
       PA_STG(ob2 + 2 * osc2, lo8, o7);
+      if constexpr (KG) PA_STG(ob + 5 * osc, lo8, o8);
     } else {
       PA_STG(ob, lo8, o0);
       PA_STG(ob + osc, lo8, o1);
@@ -635,6 +683,7 @@ __device__ __forceinline__ void gradcurv_march3_body(const BP& bp, const MarchAr
       if (has_n) S.nx[SP][rr - 1][xs] = nxp;
       S.c[SP1][rr][xs] = cp;
       if (!GOUT) S.p[SP][rr][xs] = p0;
+      if constexpr (KG) { PA_SGX[SP][rr][xs] = ggx; SG.gy[SP][rr][xs] = ggy; SG.gz[SP][rr][xs] = ggz; }
       __syncthreads();
       if (!OLD_SCHED) {
         PA_OPAQUE(og);
@@ -660,6 +709,7 @@ __device__ __forceinline__ void gradcurv_march3_body(const BP& bp, const MarchAr
 #undef PA_LDO
 #undef PA_PROG
 #undef PA_RUN3
+#undef PA_SGX
 }
 
 template <typename BP, int PA_MTY, bool CLIP, bool PAIR = false, int DBG = 0, bool CG = false>
@@ -695,7 +745,7 @@ __device__ __forceinline__ void sweep_slot(const SweepBatch& S, int l, LevelBP2&
   }
   if (S.prog) { A.pmin = S.prog[2 * z]; A.invdenom = S.prog[2 * z + 1]; }
 }
-template <int PA_MTY, bool CLIP = false, bool GOUT = false>
+template <int PA_MTY, bool CLIP = false, int GOUT = 0>
 __global__ __launch_bounds__(64 * (PA_MTY + 3), 1) void k_gradcurv_march3_levels(SweepBatch S) {
   int l = 0;
   while (l + 1 < S.n && blockIdx.x >= S.wg0[l + 1]) ++l;

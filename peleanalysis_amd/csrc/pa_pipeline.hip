@@ -20,8 +20,10 @@ int pa_gradcurv_prep_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int comp, 
 int pa_gradcurv_level_cg(pa_ctx* ctx, const pa_mf* phi, int pcomp, double pmin, double pmax, pa_mf* out, int ocomp, double thr = -1.0, int slot = 0);
 bool pa_gradcurv_gout_ok(int nlev, pa_mf* const* phi);
 int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, double pmin, double pmax, pa_mf* const* out, int ocomp, double thr = -1.0, int slot = 0,
-                          int nslots = 1, const double* prog = nullptr, const double* pmins = nullptr, const double* pmaxs = nullptr, pa_mf* const* gout = nullptr, int part = 0);
+                          int nslots = 1, const double* prog = nullptr, const double* pmins = nullptr, const double* pmaxs = nullptr, pa_mf* const* gout = nullptr, int part = 0, int kg = 0);
 bool pa_gradcurv_parts_ok(int nlev, pa_mf* const* phi);
+bool pa_gradcurv_kg_ok(int nlev, pa_mf* const* phi);
+int pa_gauss_cells_levels(pa_ctx* ctx, int nlev, pa_mf* const* G, pa_mf* const* out, int pc, int kgc, double thr);
 int pa_gradcurv_fix_levels(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, const pa_mf* const* crse_n, int cncomp0, const int32_t bc[3], double pmin, double pmax,
                            pa_mf* const* out, int ncomp0, int kcomp, double thr = -1.0, int nslots = 1, const double* prog = nullptr, int cn_z = 8,
                            const pa_mf* const* crse_phi = nullptr, int cpcomp = 0);
@@ -464,7 +466,7 @@ static bool exact_ok(int nlev, pa_mf* const* state, double thr);
 // gout != null (pa_curvature_run with options): [Progress K Nx Ny Nz] at ocomp .. ocomp + 4 and G, the cell-centred gradient of c,
 // at components 0 .. 2 of gout[l] (the GOUT sweeps, pa_fused_march3.h)
 static int exact_passes(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, const int32_t bc[3], double pmin, double pmax, double thr,
-                        pa_mf* const* out, int ocomp, pa_mf* const* gout = nullptr) {
+                        pa_mf* const* out, int ocomp, pa_mf* const* gout = nullptr, int kg = 0) {
   const int ncomp0 = gout ? ocomp + 2 : ocomp + 4, kcomp = gout ? ocomp + 1 : ocomp + 7;
   {
     // 3 + nlev launches per pass: ghost cells of every level (one launch), resolved ghost c (two), the sweeps, the curvature
@@ -503,7 +505,7 @@ static int exact_passes(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, co
     }
     if (pov) PA_HIP(hipStreamWaitEvent(ctx->stream, ctx->sync_evs[1], 0));
     if (!(pov && ring_side)) PA_TRY(pa_gradcurv_prep_levels(ctx, nlev, state, comp, crse.data(), comp, bc, pmin, pmax, pov ? 2 : 3));
-    PA_TRY(pa_gradcurv_levels_cg(ctx, nlev, state, comp, pmin, pmax, out, ocomp, thr, 0, 1, nullptr, nullptr, nullptr, gout));
+    PA_TRY(pa_gradcurv_levels_cg(ctx, nlev, state, comp, pmin, pmax, out, ocomp, thr, 0, 1, nullptr, nullptr, nullptr, gout, 0, kg));
     PA_TRY(pa_gradcurv_fix_levels(ctx, nlev, state, comp, crse_n.data(), ncomp0, bc, pmin, pmax, out, ncomp0, kcomp, thr, 1, nullptr, 8, crse.data(), comp));
     return 0;
   }
@@ -597,8 +599,13 @@ static int curvature_fast(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, 
     scomp = 0; smin = 0.0; smax = 1.0;
   }
   const bool dist = state[0]->lev->nranks > 1;  // sharded hierarchy: the same pipeline with its two exchanges, ghost fills below across ranks
+  // round 6: the sweeps form the Gaussian curvature themselves where they can (one rank, every box wider than 32 cells and at least 16
+  // rows tall: pa_fused_march3.h GOUT == 2) -- out component opt + 5, right everywhere but in the first layer behind special faces and in
+  // the level's irregular cells, which k_gauss_cells recomputes below from the stored G once its ghost cells are resolved
+  const bool kg = gauss && !dist && pa_gradcurv_kg_ok(nlev, src.data());
+  if (kg) ctx->curv_path = 2;
   if (dist) PA_TRY(fused_passes_dist(ctx, nlev, src.data(), scomp, bc, smin, smax, thr, src.data(), out, opt, true, G.data()));
-  else PA_TRY(exact_passes(ctx, nlev, src.data(), scomp, bc, smin, smax, thr, out, opt, G.data()));  // :316-322, 426-570
+  else PA_TRY(exact_passes(ctx, nlev, src.data(), scomp, bc, smin, smax, thr, out, opt, G.data(), kg ? 1 : 0));  // :316-322, 426-570
   // :575-613 ghost cells of G = cell_normal before its normalisation, coarse-fine values from the coarser level's G; :679-757 the
   // velocity's likewise: FillBoundary of all levels in one launch each, applyBC of both fields on all levels in ONE launch
   if (dist) {  // every rank makes the same calls in the same order (pa_fill_boundary / pa_apply_bc exchange inside)
@@ -627,7 +634,8 @@ static int curvature_fast(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, 
         for (int d = 0; d < 3; ++d) PA_TRY(pa_apply_bc(ctx, state[l], P->vel_comp + d, l > 0 ? state[l - 1] : nullptr, P->vel_comp + d, bc, 2, -1));
     }
   }
-  const int which = (gauss ? 1 : 0) | (strain ? 2 : 0) | (veln ? 4 : 0);
+  if (kg) PA_TRY(pa_gauss_cells_levels(ctx, nlev, G.data(), out, opt, opt + 5, thr));
+  const int which = ((gauss && !kg) ? 1 : 0) | (strain ? 2 : 0) | (veln ? 4 : 0);
   // the Gaussian curvature apart from strain + normal velocity: 80 and 118 VGPRs against 158 for all three in one kernel, c read twice;
   // 17.1 against 17.6 ms per headline pass in one kernel
   const bool split = (which & 1) && (which & 6);

@@ -434,7 +434,7 @@ def test_deep_hierarchies_take_the_fused_pipelines(ctx, oracle, nlev, base, box)
     d17 = [capi.DevMF(ctx, dl, 17, 0) for dl in dls]
     capi.curvature_run(ctx, dst, 0, bc, capi.curv_params(threshold=0.03, fused=True, do_gauss=True, do_strain=True, strain_tensor=True, do_velnormal=True, vel_comp=1), d17, 0)
     ctx.sync()
-    assert ctx.bc_errors() == 0 and ctx.lib.pa_curvature_last_path(ctx.h) == 1
+    assert ctx.bc_errors() == 0 and ctx.lib.pa_curvature_last_path(ctx.h) in (1, 2)
     for l in range(nlev):
         assert_valid_bits_equal(d17[l].download(), oo[l], [(c, c) for c in range(17)], f"{nlev} levels: options level {l}")
 
@@ -675,3 +675,39 @@ def test_chunked_face_kernels_odd_origins_small_faces_and_slots(ctx, oracle, per
     assert ctx.bc_errors() == 0
     for l in range(H.nlev):
         assert_valid_bits_equal(dgr[l].download(), og1[l], [(k, k) for k in range(4)], f"grad_run level {l}")
+
+
+@pytest.mark.parametrize("threshold", [None, 0.06])
+@pytest.mark.parametrize("per,sym,base,box", [((1, 1, 0), (0, 0, 0), 96, 48), ((0, 0, 0), (1, 0, 1), 80, 40), ((0, 1, 1), (0, 0, 0), 104, 52)])
+def test_gaussian_curvature_inside_the_sweep(ctx, oracle, per, sym, base, box, threshold):
+    """pa_curvature_run with do_gaussCurv on hierarchies whose boxes are all wider than 32 cells: the G-output sweeps form the
+    Gaussian curvature themselves (pa_fused_march3.h GOUT == 2: G's x / y neighbours through LDS rings, z-neighbours in registers,
+    k_gauss_curv's operations), k_gauss_cells recomputes the first layer behind the special faces from the stored G -- path 2, all 17
+    components bit for bit against the oracle (3 levels: coarse-fine faces in every direction, walls / reflect-odd / periodic,
+    tiles of 13 rows (52-row boxes) and of 8 (40 / 48 rows), with and without the threshold clip), and against the pass-by-pass path"""
+    from peleanalysis_amd.hierarchy import nested_hierarchy, field_flame
+    H = nested_hierarchy(base, 3, box, is_per=per)
+    states = make_states(H, 4, 2, field_flame, seed=29)
+    bc = capi.bc_from_flags(per, sym)
+    oo = [MultiFab(lv, 17, 0) for lv in H.levels]
+    opts = dict(do_gauss=True, do_strain=True, strain_tensor=True, do_velnormal=True)
+    oracle.curvature_pipeline(H.levels, [s.copy() for s in states], 0, bc, oo, 0, MultiFab, threshold=threshold, vel_comp=1, **opts)
+    dls, dst = _dev(ctx, H, states)
+    for fused, want_path in ((True, 2), (False, 0)):
+        d17 = [capi.DevMF(ctx, dl, 17, 0) for dl in dls]
+        for m in d17:
+            m.setval(-5.0)
+        capi.curvature_run(ctx, dst, 0, bc, capi.curv_params(threshold=threshold, fused=fused, vel_comp=1, **opts), d17, 0)
+        ctx.sync()
+        assert ctx.bc_errors() == 0 and ctx.lib.pa_curvature_last_path(ctx.h) == want_path
+        for l in range(H.nlev):
+            assert_valid_bits_equal(d17[l].download(), oo[l], [(c, c) for c in range(17)], f"fused={fused} level {l}")
+    # the Gaussian curvature alone (no strain / velocity pass at all)
+    og = [MultiFab(lv, 17, 0) for lv in H.levels]
+    oracle.curvature_pipeline(H.levels, [s.copy() for s in states], 0, bc, og, 0, MultiFab, threshold=threshold, vel_comp=1, do_gauss=True)
+    d17 = [capi.DevMF(ctx, dl, 17, 0) for dl in dls]
+    capi.curvature_run(ctx, dst, 0, bc, capi.curv_params(threshold=threshold, fused=True, vel_comp=1, do_gauss=True), d17, 0)
+    ctx.sync()
+    assert ctx.lib.pa_curvature_last_path(ctx.h) == 2
+    for l in range(H.nlev):
+        assert_valid_bits_equal(d17[l].download(), og[l], [(c, c) for c in range(6)], f"gauss only, level {l}")
