@@ -112,6 +112,7 @@ const WgTab* pa_sweep_wgtab(const pa_level* L, int cls, int tw, int mty, int kse
       }
       if (hipMalloc(&T->d, sizeof(int) * tab.size()) == hipSuccess && hipMemcpy(T->d, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice) == hipSuccess) {
         T->n = (unsigned)(tab.size() / 2);
+        T->h = std::move(tab);
       } else {
         if (T->d) (void)hipFree(T->d);
         T->d = nullptr;
@@ -122,6 +123,84 @@ const WgTab* pa_sweep_wgtab(const pa_level* L, int cls, int tw, int mty, int kse
   const WgTab* raw = T.get();
   L->wgtabs[key] = std::move(T);
   return (raw->d || part) ? raw : nullptr;  // a part's table may be empty (n == 0): the caller launches nothing for it
+}
+
+// (see pa_internal.h)  The three columns behind an x face of box B are read by: the boundary condition on G at that face and the
+// fix-up of its first layer when the face is special; the FillBoundary of G into a neighbouring box B' across the face where B' has
+// fix-up cells next to it -- B' has a special face on the same plane (the facing face, partly covered by B), or a special y / z face
+// whose plane meets B's face away from B's own first three rows / planes (those are stored in any case).
+const unsigned char* pa_sweep_gneed(const pa_level* L, const WgTab* T, int tw, int mty, int kseg, long long fine_serial, const std::vector<int>* cpregs) {
+  if (!T || !T->d || T->h.size() != 2 * (size_t)T->n) return nullptr;
+  auto it = T->gneed.find(fine_serial);
+  if (it != T->gneed.end()) return it->second;
+  const int nb = (int)L->boxes.size();
+  pa_level* Lm = const_cast<pa_level*>(L);
+  if ((int)Lm->xneed.size() != nb) {
+    std::vector<unsigned char> sp((size_t)nb, 0);  // special faces of box b: bit 2 * dir + side
+    for (int f : L->sfaces) sp[(size_t)(f / 6)] |= (unsigned char)(1u << (f % 6));
+    Lm->xneed.assign((size_t)nb, 0);
+    for (int b = 0; b < nb; ++b) {
+      const DBox& B = L->boxes[b];
+      for (int side = 0; side < 2; ++side) {
+        bool need = (sp[(size_t)b] >> side) & 1;
+        const int x = side ? B.hi[0] + 1 : B.lo[0] - 1;
+        int last = -1;
+        for (int k = B.lo[2]; k <= B.hi[2] && !need; k += L->g)
+          for (int j = B.lo[1]; j <= B.hi[1] && !need; j += L->g) {
+            const int o = host_owner(L, x, j, k);
+            if (o < 0 || o == last) continue;
+            last = o;
+            const DBox& N = L->boxes[o];
+            if ((sp[(size_t)o] >> (1 - side)) & 1) need = true;
+            for (int d = 1; d < 3 && !need; ++d)
+              for (int t = 0; t < 2; ++t) {
+                const int c = t ? N.hi[d] : N.lo[d];
+                if (((sp[(size_t)o] >> (2 * d + t)) & 1) && c >= B.lo[d] + 3 && c <= B.hi[d] - 3) need = true;
+              }
+          }
+        if (need) Lm->xneed[(size_t)b] |= (unsigned char)(2u << side);
+      }
+    }
+  }
+  std::vector<std::vector<unsigned char>> full((size_t)nb);
+  auto tiles = [&](const DBox& B, int& tx, int& ty, int& tz) {
+    tx = (B.hi[0] - B.lo[0] + tw) / tw; ty = (B.hi[1] - B.lo[1] + mty) / mty; tz = (B.hi[2] - B.lo[2] + kseg) / kseg;
+  };
+  if (cpregs)
+    for (size_t r = 0; r + 12 <= cpregs->size(); r += 12) {
+      const int* R = cpregs->data() + r;
+      const int sb = R[1], dir = R[9], t0 = dir == 0 ? 1 : 0, t1 = dir == 2 ? 1 : 2;
+      if (sb < 0 || sb >= nb) continue;
+      const DBox& B = L->boxes[sb];
+      int lo[3] = {R[4], R[5], R[6]}, hi[3] = {R[4], R[5], R[6]};
+      hi[t0] += R[7] - 1; hi[t1] += R[8] - 1;
+      int tx, ty, tz;
+      tiles(B, tx, ty, tz);
+      auto& F = full[(size_t)sb];
+      if (F.empty()) F.assign((size_t)tx * ty * tz, 0);
+      const int a0 = std::max(0, (lo[0] - B.lo[0]) / tw), a1 = std::min(tx - 1, (hi[0] - B.lo[0]) / tw);
+      const int b0 = std::max(0, (lo[1] - B.lo[1]) / mty), b1 = std::min(ty - 1, (hi[1] - B.lo[1]) / mty);
+      const int c0 = std::max(0, (lo[2] - B.lo[2]) / kseg), c1 = std::min(tz - 1, (hi[2] - B.lo[2]) / kseg);
+      for (int c = c0; c <= c1; ++c)
+        for (int bb = b0; bb <= b1; ++bb)
+          for (int a = a0; a <= a1; ++a) F[((size_t)c * ty + bb) * tx + a] = 1;
+    }
+  std::vector<unsigned char> need((size_t)T->n, 0);
+  for (unsigned e = 0; e < T->n; ++e) {
+    const int b = T->h[2 * (size_t)e], id = T->h[2 * (size_t)e + 1];
+    if (b < 0 || b >= nb) continue;
+    unsigned char v = Lm->xneed[(size_t)b];
+    if (!full[(size_t)b].empty() && id >= 0 && (size_t)id < full[(size_t)b].size() && full[(size_t)b][(size_t)id]) v |= 1;
+    need[(size_t)e] = v;
+  }
+  unsigned char* d = nullptr;
+  if (hipMalloc(&d, need.size()) != hipSuccess || hipMemcpy(d, need.data(), need.size(), hipMemcpyHostToDevice) != hipSuccess) {
+    if (d) (void)hipFree(d);
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  T->gneed[fine_serial] = d;
+  return d;
 }
 
 static pa_options g_opt;

@@ -61,6 +61,7 @@ struct CpPlan {
   int nreg = 0, nwg = 0;
   int* d_regs = nullptr;   // [nreg][12]: face entry, coarse box, patch-local origin (pu, pv), coarse cell of that origin [3], nu, nv, dir, m (magic of nu), 0
   int* d_wgs = nullptr;    // [nwg][2]: region, chunk
+  std::vector<int> hregs;  // host copy of the regions (pa_sweep_gneed: the coarse tiles whose G a GOUT == 2 sweep must store in full)
   ~CpPlan();
 };
 CpPlan* pa_cp_plan(pa_ctx* ctx, const pa_level* F, const pa_level* C);

@@ -576,6 +576,7 @@ CpPlan* pa_cp_plan(pa_ctx* ctx, const pa_level* F, const pa_level* C) {
     if (hipMemcpy(raw->d_wgs, wgs.data(), sizeof(int) * wgs.size(), hipMemcpyHostToDevice) != hipSuccess) return raw;
   }
   (void)ctx;
+  raw->hregs = std::move(regs);
   raw->ok = true;
   return raw;
 }

@@ -2277,9 +2277,9 @@ static void sweep_groups(int l, const pa_level* L, std::vector<SweepGroup>& out)
   out.push_back({l, L->d_blist + L->nwide, L->nnarrow, {L->nmax[0], L->nmax[1], L->nmax[2]}});
 }
 
-static const WgTab* sweep_wgtab(const pa_level* L, const SweepGroup& g, int tw, int mty, int kseg, int part = 0) {
+static const WgTab* sweep_wgtab(const pa_level* L, const SweepGroup& g, int tw, int mty, int kseg, int part = 0, bool force = false) {
   if (!part && g.n <= 0) return nullptr;
-  return pa_sweep_wgtab(L, !g.list ? 2 : (g.list == L->d_blist ? 0 : 1), tw, mty, kseg, false, part);
+  return pa_sweep_wgtab(L, !g.list ? 2 : (g.list == L->d_blist ? 0 : 1), tw, mty, kseg, force, part);
 }
 
 // the sweep with exact normals (the level's compact ghost arrays must be current: pa_gradcurv_prep_level)
@@ -2431,9 +2431,15 @@ int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, d
       A.nboxes = (int)nb;
       A.txy_max = ((lv[q].dims[0] + 63) / 64) * ((lv[q].dims[1] + mty - 1) / mty);
       A.tiles_max = (int)g.x;
-      const WgTab* wt = sweep_wgtab(L, lv[q], 64, mty, A.kseg, part);
+      const WgTab* wt = sweep_wgtab(L, lv[q], 64, mty, A.kseg, part, kg == 2);
       if (wt) A.wgtab = wt->d;
       if (gout) { A.gdata = gout[l]->data; A.goff = gout[l]->d_off; A.gng = gout[l]->ng; }
+      if (kg == 2 && wt && wt->d) {  // G only where something reads it (null: everywhere)
+        const pa_level* F = l + 1 < nlev ? phi[l + 1]->lev : nullptr;
+        const CpPlan* cp = (F && !F->boxes.empty()) ? pa_cp_plan(ctx, F, L) : nullptr;
+        const bool no_patches = F && !F->boxes.empty() && F->cp_total > 0 && !(cp && cp->ok);  // the finer level reads the coarse G through the owner map: anywhere
+        if (!no_patches) A.gneed = pa_sweep_gneed(L, wt, 64, mty, A.kseg, F ? F->serial : 0, cp && cp->ok ? &cp->hregs : nullptr);
+      }
       S.A[q] = A;
       S.wg0[q + 1] = S.wg0[q] + (wt ? wt->n : (part ? 0u : g.x * 8u * ((nb + 7u) / 8u)));  // (a part's table may be empty)
     }

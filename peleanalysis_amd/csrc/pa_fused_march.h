@@ -80,6 +80,8 @@ struct MarchArgs {
   double* gdata = nullptr;
   const long long* goff = nullptr;
   int gng = 0;
+  // GOUT == 2: one byte per wgtab entry, where the tile stores G (pa_sweep_gneed); null: in every cell
+  const unsigned char* gneed = nullptr;
 };
 
 // (The first marching kernel, k_gradcurv_march -- requests and stores interleaved, one plane in flight -- lived here until round 6;

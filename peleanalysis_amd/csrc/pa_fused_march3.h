@@ -163,6 +163,10 @@ __device__ __forceinline__ void gradcurv_march3_body(const BP& bp, const MarchAr
     box = A.boxlist[box];
   }
   if (!bp.get(box, P, O, V, dxinv)) return;
+  int gfl = 1;  // KG: where this tile stores G (pa_sweep_gneed; bit 0: everywhere)
+  if constexpr (KG) {
+    if (A.gneed && A.wgtab) gfl = A.gneed[bid_x];
+  }
   const int pcomp = A.pcomp, kseg = A.kseg;
   const double pmin = A.pmin, invd = A.invdenom;
   const int nx = V.hi[0] - V.lo[0] + 1, ny = V.hi[1] - V.lo[1] + 1, nz = V.hi[2] - V.lo[2] + 1;
@@ -362,6 +366,14 @@ __device__ __forceinline__ void gradcurv_march3_body(const BP& bp, const MarchAr
     }
     double gxq = 0, gyq = 0, gzq = 0;  // GOUT: G of plane q
     double gxm = 0, gym = 0, gzm = 0, gnq = 1.0, o8 = 0;  // KG: G of plane q - 1, max(1e-14, |G|) of plane q, the Gaussian curvature of plane q
+    // KG: G goes to memory only where something reads it afterwards -- the first three layers behind the box faces (the boundary
+    // condition on G, its FillBoundary, the fix-up of the first layer: k_gauss_cells; behind x faces only where pa_sweep_gneed says so:
+    // three lanes of a row are three partial lines) and the tiles a coarse patch of the finer level gathers from (bit 0)
+    bool gsb = true, gs = !KG;
+    if constexpr (KG) {
+      const int i = i0 + le;
+      gsb = (gfl & 1) || ((gfl & 2) && i - V.lo[0] < 3) || ((gfl & 4) && V.hi[0] - i < 3) || (j - V.lo[1] < 3) || (V.hi[1] - j < 3);
+    }
     const double thr = A.thr;
     const bool odd = lane & 1;
     unsigned lo16 = odd ? (unsigned)(le - 1) * 8u + (unsigned)osc : (unsigned)le * 8u;
@@ -384,8 +396,9 @@ __device__ __forceinline__ void gradcurv_march3_body(const BP& bp, const MarchAr
           store_pair(ob + 4 * osc, lo16, odd, o4, o5); store_pair(ob + 6 * osc, lo16, odd, o6, o7);
         } else if (GOUT) {
           PA_STL(ob, lo8, o0); PA_STL(ob + osc, lo8, o1); PA_STL(ob + 2 * osc, lo8, o2); PA_STL(ob + 3 * osc, lo8, o3);
-          PA_STL(ob + 4 * osc, lo8, o4); PA_STL(ob2, lo8, o5); PA_STL(ob2 + osc2, lo8, o6); PA_STL(ob2 + 2 * osc2, lo8, o7);
+          PA_STL(ob + 4 * osc, lo8, o4);
           if constexpr (KG) PA_STL(ob + 5 * osc, lo8, o8);
+          if (gs) { PA_STL(ob2, lo8, o5); PA_STL(ob2 + osc2, lo8, o6); PA_STL(ob2 + 2 * osc2, lo8, o7); }
         } else {
           PA_STL(ob, lo8, o0); PA_STL(ob + osc, lo8, o1); PA_STL(ob + 2 * osc, lo8, o2); PA_STL(ob + 3 * osc, lo8, o3);
           PA_STL(ob + 4 * osc, lo8, o4); PA_STL(ob + 5 * osc, lo8, o5); PA_STL(ob + 6 * osc, lo8, o6); PA_STL(ob + 7 * osc, lo8, o7);
@@ -510,6 +523,8 @@ __device__ __forceinline__ void gradcurv_march3_body(const BP& bp, const MarchAr
           o8 = clip ? 0.0 : kg;
           gxm = gxq; gym = gyq; gzm = gzq;
           gnq = (1e-14 < sn) ? sn : 1e-14;  // of plane p = the next step's plane q
+          const int q = p - 1;
+          gs = q >= k0 && (gsb || q - V.lo[2] < 3 || V.hi[2] - q < 3);
         }
         o0 = cm;
         o1 = clip ? 0.0 : curv;
@@ -549,10 +564,12 @@ __device__ __forceinline__ void gradcurv_march3_body(const BP& bp, const MarchAr
       PA_STG(ob + 2 * osc, lo8, o2);
       PA_STG(ob + 3 * osc, lo8, o3);
       PA_STG(ob + 4 * osc, lo8, o4);
-      PA_STG(ob2, lo8, o5);
-      PA_STG(ob2 + osc2, lo8, o6);
-      PA_STG(ob2 + 2 * osc2, lo8, o7);
       if constexpr (KG) PA_STG(ob + 5 * osc, lo8, o8);
+      if (gs) {
+        PA_STG(ob2, lo8, o5);
+        PA_STG(ob2 + osc2, lo8, o6);
+        PA_STG(ob2 + 2 * osc2, lo8, o7);
+      }
     } else {
       PA_STG(ob, lo8, o0);
       PA_STG(ob + osc, lo8, o1);

@@ -184,7 +184,14 @@ enum { PA_TAG_GRADCURV = 1, PA_TAG_GRADCURV_FACES = 2, PA_TAG_FILL = 3, PA_TAG_B
 struct WgTab {
   int* d = nullptr;
   unsigned n = 0;
-  ~WgTab() { if (d) (void)hipFree(d); }
+  std::vector<int> h;  // host copy of the table
+  // GOUT == 2 sweeps that store G only where something reads it (pa_sweep_gneed): one byte per table entry, by the serial of the finer level (0: none)
+  mutable std::map<long long, unsigned char*> gneed;
+  ~WgTab() {
+    if (d) (void)hipFree(d);
+    for (auto& kv : gneed)
+      if (kv.second) (void)hipFree(kv.second);
+  }
 };
 
 struct pa_level {
@@ -234,6 +241,7 @@ struct pa_level {
   int nsfchunk = 0;
   void* d_ring = nullptr;   // RingItem (pa_fused.hip): the edge ghost cells whose resolved progress variable goes into a face's ring, built on first use
   int nring = -1;           // -1: not built yet
+  std::vector<unsigned char> xneed;  // per box: bits 1 / 2 as pa_sweep_gneed (built on first use)
   void* d_irr = nullptr;    // int4 {box, i, j, k}
   int nirr = -1;            // -1: not built yet
   int nremote = 0;          // boxes of this level owned by other ranks (pa_level_create_sharded)
@@ -282,6 +290,10 @@ bool pa_face_is_special(const pa_level* L, const DBox& B, int d, int side);
 // role: two work multifabs of the same shape that are alive at the same time take different roles
 struct pa_mf* pa_level_scratch(pa_ctx* ctx, const pa_level* L, int ncomp, int ng, int role = 0);
 const WgTab* pa_sweep_wgtab(const pa_level* L, int cls, int tw, int mty, int kseg, bool force, int part = 0);
+// Where a GOUT == 2 sweep (pa_fused_march3.h) has to store G, one byte per entry of table T (tiles of tw x mty x kseg cells): bit 0 =
+// every cell of the tile (a coarse patch of the finer level reads some of them: cpregs = the host copy of that level's CpPlan regions,
+// null when there is no finer level), bits 1 / 2 = the three columns behind the low / high x face of the tile's box.  Null: no memory.
+const unsigned char* pa_sweep_gneed(const pa_level* L, const WgTab* T, int tw, int mty, int kseg, long long fine_serial, const std::vector<int>* cpregs);
 int pa_host_classify(const pa_level* L, int i, int j, int k);
 
 struct pa_mf {

@@ -605,7 +605,7 @@ static int curvature_fast(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, 
   const bool kg = gauss && !dist && pa_gradcurv_kg_ok(nlev, src.data());
   if (kg) ctx->curv_path = 2;
   if (dist) PA_TRY(fused_passes_dist(ctx, nlev, src.data(), scomp, bc, smin, smax, thr, src.data(), out, opt, true, G.data()));
-  else PA_TRY(exact_passes(ctx, nlev, src.data(), scomp, bc, smin, smax, thr, out, opt, G.data(), kg ? 1 : 0));  // :316-322, 426-570
+  else PA_TRY(exact_passes(ctx, nlev, src.data(), scomp, bc, smin, smax, thr, out, opt, G.data(), kg ? 2 : 0));  // :316-322, 426-570
   // :575-613 ghost cells of G = cell_normal before its normalisation, coarse-fine values from the coarser level's G; :679-757 the
   // velocity's likewise: FillBoundary of all levels in one launch each, applyBC of both fields on all levels in ONE launch
   if (dist) {  // every rank makes the same calls in the same order (pa_fill_boundary / pa_apply_bc exchange inside)
