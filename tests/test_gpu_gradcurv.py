@@ -711,3 +711,39 @@ def test_gaussian_curvature_inside_the_sweep(ctx, oracle, per, sym, base, box, t
     assert ctx.lib.pa_curvature_last_path(ctx.h) == 2
     for l in range(H.nlev):
         assert_valid_bits_equal(d17[l].download(), og[l], [(c, c) for c in range(6)], f"gauss only, level {l}")
+
+
+@pytest.mark.parametrize("per,layout", [((0, 0, 0), 0), ((1, 0, 0), 0), ((0, 0, 0), 1)])
+def test_gaussian_curvature_inside_the_sweep_staggered_boxes(ctx, oracle, per, layout):
+    """The GOUT == 2 sweeps store G only where something reads it afterwards (pa_sweep_gneed, pa_core.hip): three layers behind box
+    faces -- behind an x face only when the face is special or a neighbouring box across it has fix-up cells next to it -- and the coarse
+    tiles a patch of the finer level gathers from.  Fine boxes STAGGERED in y and z across their x faces (a face partly covered, partly
+    coarse-fine; a neighbour's special y / z plane meeting the face in its interior; the same through the periodic wrap), work multifabs
+    poisoned with NaN by the caller's child process (test_work_multifabs_are_never_read_before_they_are_written): all 17 components
+    bit for bit against the oracle, path 2."""
+    from peleanalysis_amd.hierarchy import Hierarchy, Level, field_flame
+    l0 = Level(np.array([[0, 0, 0, 95, 63, 31]], np.int32), (0, 0, 0), (95, 63, 31), per, np.zeros(3), np.ones(3))
+    if layout == 1:
+        # the x-low face of the first box is covered entirely (two boxes stacked in y), so it is not special, nor is the face of the lower
+        # box that looks at it; but the lower box's y-high face is (the upper box is narrower), and its first-layer cell next to the first
+        # box differentiates G across that x face, in the middle of the first box's rows
+        fine = [[80, 32, 16, 143, 95, 55], [16, 32, 16, 79, 63, 55], [40, 64, 16, 79, 95, 55]]
+    elif per[0]:
+        fine = [[0, 16, 8, 63, 63, 39], [128, 32, 16, 191, 95, 55], [64, 16, 8, 127, 63, 39]]
+    else:
+        fine = [[16, 16, 8, 79, 63, 39], [80, 32, 16, 143, 95, 55], [80, 96, 16, 143, 127, 55]]
+    l1 = Level(np.array(fine, np.int32), (0, 0, 0), (191, 127, 63), per, np.zeros(3), np.ones(3))
+    H = Hierarchy([l0, l1], 2)
+    states = make_states(H, 4, 2, field_flame, seed=57)
+    bc = capi.bc_from_flags(per, (0, 0, 0))
+    opts = dict(do_gauss=True, do_strain=True, strain_tensor=True, do_velnormal=True)
+    for threshold in (None, 0.05):
+        oo = [MultiFab(lv, 17, 0) for lv in H.levels]
+        oracle.curvature_pipeline(H.levels, [s.copy() for s in states], 0, bc, oo, 0, MultiFab, threshold=threshold, vel_comp=1, **opts)
+        dls, dst = _dev(ctx, H, states)
+        d17 = [capi.DevMF(ctx, dl, 17, 0) for dl in dls]
+        capi.curvature_run(ctx, dst, 0, bc, capi.curv_params(threshold=threshold, fused=True, vel_comp=1, **opts), d17, 0)
+        ctx.sync()
+        assert ctx.bc_errors() == 0 and ctx.lib.pa_curvature_last_path(ctx.h) == 2
+        for l in range(H.nlev):
+            assert_valid_bits_equal(d17[l].download(), oo[l], [(c, c) for c in range(17)], f"threshold={threshold} level {l}")
