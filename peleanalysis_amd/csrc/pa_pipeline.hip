@@ -483,6 +483,9 @@ static int exact_passes(pa_ctx* ctx, int nlev, pa_mf* const* state, int comp, co
     // more than the fix-up hides) -- neither is kept.
     constexpr int pov = 1;
     constexpr bool ring_side = true;  // the ring with the faces: it reads its neighbours' valid cells in place
+    // (Round 6, measured and not kept: level 0 swept on its own as soon as ITS ghost cells are ready, the ghost preparation of the finer
+    // levels on the side stream under it -- 6.27 against 6.11 ms per pass on the irregular hierarchy, 5.845 against 5.827 on the
+    // headline, tools/ab_driver.py: as in round 4, whatever runs beside a sweep costs the sweep more than it hides.)
     if (pov) {
       if (!ctx->stream2) PA_HIP(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
       while (ctx->sync_evs.size() < 2) {
