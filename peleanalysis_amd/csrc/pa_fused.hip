@@ -2369,6 +2369,22 @@ int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, d
     lv.clear();
   }
   const std::vector<SweepGroup> lv_all = lv;
+  // Round 6: a hierarchy with wide AND narrow boxes -- the narrow-box launch goes to the side stream and runs BESIDE the wide one (both
+  // are sweeps: its workgroups fill the CUs the wide launch's tail leaves idle; 6.213 -> 6.167 ms per pass on the irregular hierarchy,
+  // tools/ab_driver.py, profiles/r06_narrow_side_ab.txt).  One rank only: a sharded pass uses the side stream for its exchanges.
+  bool nar_side = false;
+  for (const SweepGroup& g : rest) nar_side = nar_side || g.dims[0] <= 32;
+  nar_side = nar_side && !lv_all.empty() && part == 0 && !pa_opt().force_fallbacks && phi[0]->lev->nranks == 1;
+  if (nar_side) {
+    if (!ctx->stream2) PA_HIP(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+    while (ctx->sync_evs.size() < 5) {
+      hipEvent_t e;
+      PA_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      ctx->sync_evs.push_back(e);
+    }
+    PA_HIP(hipEventRecord(ctx->sync_evs[3], ctx->stream));  // the ghost cells and compact arrays the sweeps read are complete
+    PA_HIP(hipStreamWaitEvent(ctx->stream2, ctx->sync_evs[3], 0));
+  }
   for (int pass_i = 0; pass_i < 3 * 8; ++pass_i) {  // (tile height) x (chunk of PA_MAXB groups)
     const int mty_pass = pass_i / 8 == 0 ? 13 : (pass_i / 8 == 1 ? 8 : 4), chunk = pass_i % 8;
     std::vector<SweepGroup> lvm, lv;
@@ -2528,12 +2544,17 @@ int pa_gradcurv_levels_cg(pa_ctx* ctx, int nlev, pa_mf* const* phi, int pcomp, d
     }
     ProfScope prof(ctx, PA_TAG_GRADCURV);
     S.prog = nslots > 1 ? prog : nullptr;
-    if (gout && clip) hipLaunchKernelGGL((k_gradcurv_march3n_levels<NRW, true, true>), dim3(S.wg0[S.n], 1u), dim3(64 * (NRW + 2)), 0, ctx->stream, S);
-    else if (gout) hipLaunchKernelGGL((k_gradcurv_march3n_levels<NRW, false, true>), dim3(S.wg0[S.n], 1u), dim3(64 * (NRW + 2)), 0, ctx->stream, S);
-    else if (clip) hipLaunchKernelGGL((k_gradcurv_march3n_levels<NRW, true>), dim3(S.wg0[S.n], (unsigned)nslots), dim3(64 * (NRW + 2)), 0, ctx->stream, S);
-    else hipLaunchKernelGGL((k_gradcurv_march3n_levels<NRW, false>), dim3(S.wg0[S.n], (unsigned)nslots), dim3(64 * (NRW + 2)), 0, ctx->stream, S);
+    hipStream_t ns = nar_side ? ctx->stream2 : ctx->stream;
+    if (gout && clip) hipLaunchKernelGGL((k_gradcurv_march3n_levels<NRW, true, true>), dim3(S.wg0[S.n], 1u), dim3(64 * (NRW + 2)), 0, ns, S);
+    else if (gout) hipLaunchKernelGGL((k_gradcurv_march3n_levels<NRW, false, true>), dim3(S.wg0[S.n], 1u), dim3(64 * (NRW + 2)), 0, ns, S);
+    else if (clip) hipLaunchKernelGGL((k_gradcurv_march3n_levels<NRW, true>), dim3(S.wg0[S.n], (unsigned)nslots), dim3(64 * (NRW + 2)), 0, ns, S);
+    else hipLaunchKernelGGL((k_gradcurv_march3n_levels<NRW, false>), dim3(S.wg0[S.n], (unsigned)nslots), dim3(64 * (NRW + 2)), 0, ns, S);
     PA_HIP(hipGetLastError());
     if (lv.empty()) ctx->sweep_kernel = "k_gradcurv_march3n_levels<NRW=8" + std::string(clip ? ",CLIP" : "") + ">[" + std::to_string(S.n) + " levels per launch]";
+  }
+  if (nar_side) {  // later work on the caller's stream sees the narrow boxes swept
+    PA_HIP(hipEventRecord(ctx->sync_evs[4], ctx->stream2));
+    PA_HIP(hipStreamWaitEvent(ctx->stream, ctx->sync_evs[4], 0));
   }
   if (gout && !rest.empty()) return pa_fail(ctx, "pa_gradcurv_levels_cg: a sweep group outside the all-levels launches (G-output variant)");
   for (const SweepGroup& g : rest)
