@@ -667,7 +667,7 @@ def secondary(ctx, torch, stream, dev, only=None, retile=1):
             gr.phi = phis[q].data_ptr()
         torch.cuda.synchronize()
         res = {}
-        for n_ in (1, nb):
+        for n_ in (1, 4, nb):
             ctx.check(ctx.lib.pa_sdf_level_set3(ctx.h, n_, grids, 1))
             ctx.sync()
             t0 = time.perf_counter()
@@ -676,7 +676,8 @@ def secondary(ctx, torch, stream, dev, only=None, retile=1):
             ms_ = (time.perf_counter() - t0) * 1e3
             res[f"grids_per_call_{n_}"] = {"ms": ms_, "ms_per_grid": ms_ / n_, "Mpoints_s": n_ * g ** 3 / ms_ / 1e3}
         out["f2_distance_function"] = dict(res, triangles=int(len(tris)), grid=f"{g}^3", workload="pa_sdf_level_set3 = make_level_set3 (isosurface.cpp:1625, Tools/SDFGen/makelevelset3.cpp:118-185), "
-                                           f"exact band 1, float32, a sphere of {len(tris)} triangles through 130^3 grids; a chain of ~6000 dependent hyperplane launches: no roofline")
+                                           f"exact band 1, float32, a sphere of {len(tris)} triangles through 130^3 grids; block wavefronts: 16 sweeps x (block planes) dependent launches, each a workgroup "
+                                           "per block walking its inner hyperplanes -- a latency chain, no roofline")
         del phis, tt, tx
         torch.cuda.empty_cache()
 

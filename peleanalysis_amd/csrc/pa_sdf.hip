@@ -10,9 +10,8 @@
 //   sweeps (:169-178, 60-85)  Gauss-Seidel: a point looks at the closest triangle of its 7 upwind
 //       neighbours, which the same sweep has already updated.  All 7 lie on earlier hyperplanes
 //       u+v+w = const of the sweep's own coordinates, and points of one hyperplane do not read
-//       each other, so marching hyperplane by hyperplane (one workgroup per grid, a barrier per
-//       hyperplane, every point handled by one thread in the reference's neighbour order) gives
-//       the sequential result exactly.  2 passes x 8 directions.
+//       each other, so any order that puts a point after its 7 upwind neighbours gives the
+//       sequential result exactly: block wavefronts (k_sdf_sweep_blocks).  2 passes x 8 directions.
 //   The intersection counts (:146-165) only feed the sign step that the reference compiles out
 //   (`#if 0`, :179-184) and are not computed.
 // Float rules: no contraction (Makefile), correctly rounded `/` and sqrtf (hipcc default),
@@ -152,78 +151,129 @@ __global__ __launch_bounds__(256) void k_sdf_unpack(const SdfGrid* grids) {
   }
 }
 
-// :46-58 for one point, the 7 upwind neighbours in the reference's order
-__device__ __forceinline__ void relax_point(const SdfGrid& G, int i, int j, int k, int di, int dj, int dk) {
-  if (G.ntri <= 0) return;  // a grid of the batch without triangles: every point keeps its upper bound (and there is no triangle 0 to load below)
-  const long long sj = G.ni, sk = (long long)G.ni * G.nj, q = (long long)k * sk + j * sj + i;
-  const V3 gx = grid_point(G, i, j, k);
-  float phi = G.phi[q];
-  int ct = G.ct[q];
-  const long long nb[7] = {q - di, q - dj * sj, q - di - dj * sj, q - dk * sk, q - di - dk * sk, q - dj * sj - dk * sk, q - di - dj * sj - dk * sk};
-  // A triangle whose distance to this point is already known to be >= phi cannot pass the strict
-  // `d < phi` test: the point's own closest triangle (d == phi when phi came from it -- phi always is
-  // the distance to triangle ct once ct >= 0) and a triangle already tried in this call.  Skipping
-  // those evaluations changes nothing in the result; after the first sweeps most neighbours share
-  // the point's triangle.
-  // The loads of all candidates are issued together -- the 7 neighbours' triangles, then the vertices of those that will be evaluated
-  // (from the per-call gather tv: the same floats as x[tri[..]]) -- and only the comparisons run in the reference's order: a chain of
-  // two memory latencies per point instead of up to 1 + 2 x 7 (the distances do not depend on phi; the skip rules only on the triangles).
-  int tried[7];
-  bool ev[7];
-  const int ct0 = ct;
-  bool changed = false;
-#pragma unroll
-  for (int m = 0; m < 7; ++m) tried[m] = G.ct[nb[m]];
-#pragma unroll
-  for (int m = 0; m < 7; ++m) {
-    const int t = tried[m];
-    bool skip = (t < 0) || (t == ct0);
-#pragma unroll
-    for (int r = 0; r < m; ++r) skip = skip || (tried[r] == t);
-    ev[m] = !skip;
-  }
-  V3 vx[7][3];
-#pragma unroll
-  for (int m = 0; m < 7; ++m) {
-    const long long t = ev[m] ? (long long)tried[m] : 0;  // triangle 0 exists (the sweeps run only where ntri > 0): a harmless load
-#pragma unroll
-    for (int c = 0; c < 3; ++c) vx[m][c] = G.tv[3 * t + c];
-  }
-#pragma unroll
-  for (int m = 0; m < 7; ++m) {
-    if (ev[m]) {
-      const float d = point_triangle_distance(gx, vx[m][0], vx[m][1], vx[m][2]);
-      if (d < phi) { phi = d; ct = tried[m]; changed = true; }
-    }
-  }
-  if (changed) {
-    G.phi[q] = phi;
-    G.ct[q] = ct;
-  }
-}
-
 // tv[3 t + c] = x[tri[3 t + c]] (round 6: one of the three dependent memory levels behind every point of every hyperplane, paid once)
 __global__ __launch_bounds__(256) void k_sdf_gather_tv(const SdfGrid* grids) {
   const SdfGrid G = grids[blockIdx.y];
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < 3 * G.ntri; i += (long long)gridDim.x * 256ll) G.tv[i] = G.x[G.tri[i]];
 }
 
-// :60-85 + :169-178, the points of a hyperplane spread over the whole chip: ONE LAUNCH PER HYPERPLANE (all grids of the
-// batch side by side, blockIdx.y = grid), the kernel boundary is the barrier between hyperplanes and makes one step's
-// results visible to every CU of the next (per-XCD L2s are not coherent inside a launch).  Same points, same neighbour
-// order, same arithmetic as the reference's sequential loops: bit-identical to its output (tests/golden/sdf_ref.npz).  16 x (ni + nj + nk - 5) launches of a few microseconds each
-// instead of one workgroup walking ~6000 barriers with up to 12 points per thread behind each.
-__global__ __launch_bounds__(256) void k_sdf_sweep_plane(const SdfGrid* grids, int di, int dj, int dk, int s) {
+// :60-85 + :169-178 + :46-58.  BLOCK WAVEFRONTS (round 6): the sweep's own coordinates (u, v, w) are cut into blocks of B^3 points; a launch
+// takes the blocks of one block hyperplane bu + bv + bw = S (blockIdx.y = grid of the batch) -- the kernel boundary makes one plane's
+// results visible to every CU of the next (per-XCD L2s are not coherent inside a launch) -- and ONE workgroup walks its block's 3 B - 2
+// inner hyperplanes with a barrier between them, the block's closest-triangle indices (with the layer of upwind neighbours) and distances
+// in LDS.  A point still comes after its 7 upwind neighbours -- inside the block by the inner hyperplanes, across blocks by the launches
+// -- and no point of a sweep is written after a later point of the same sweep read it, so the result is the sequential one, bit for bit
+// (tests/golden/sdf_ref.npz).  Until round 6: one launch per hyperplane of POINTS, a thread per point walking its seven candidate
+// triangles one after the other -- 16 x (ni + nj + nk - 5) = 6160 launches of 12 us for a 130^3 grid, of which ~6 us were that chain of
+// seven dependent evaluations at one wave per SIMD and ~5 the launch-to-launch gap (72.5-76 ms; 7.9 ms per grid in a batch of 16).
+// Now 16 x (nbu + nbv + nbw - 2) launches, an inner step = LDS round + ONE global latency + ONE evaluation (eight lanes per point,
+// below): 34-39 ms per grid, 7.5 per grid in a batch of 16 (profiles/r06_sdf_blocks.txt).
+template <int B>
+__global__ __launch_bounds__(B == 8 ? 384 : 128) void k_sdf_sweep_blocks(const SdfGrid* grids, int di, int dj, int dk, int S) {
   const SdfGrid G = grids[blockIdx.y];
+  if (G.ntri <= 0) return;
   const int nu = G.ni - 1, nv = G.nj - 1, nw = G.nk - 1;
-  if (nu <= 0 || nv <= 0 || nw <= 0 || s >= nu + nv + nw - 2) return;
-  const int wlo = max(0, s - (nu - 1) - (nv - 1)), whi = min(nw - 1, s);
-  const int idx = wlo * nv + (int)(blockIdx.x * 256u + threadIdx.x);
-  if (idx >= (whi + 1) * nv) return;
-  const int v = idx % nv, w = idx / nv, u = s - v - w;
-  if (u < 0 || u >= nu) return;
-  const int i = di > 0 ? 1 + u : G.ni - 2 - u, j = dj > 0 ? 1 + v : G.nj - 2 - v, k = dk > 0 ? 1 + w : G.nk - 2 - w;
-  relax_point(G, i, j, k, di, dj, dk);
+  if (nu <= 0 || nv <= 0 || nw <= 0) return;
+  const int nbu = (nu + B - 1) / B, nbv = (nv + B - 1) / B, nbw = (nw + B - 1) / B;
+  if (S > nbu + nbv + nbw - 3) return;
+  const int bw_lo = max(0, S - (nbu - 1) - (nbv - 1)), bw_hi = min(nbw - 1, S);
+  const int idx = bw_lo * nbv + (int)blockIdx.x;
+  if (idx >= (bw_hi + 1) * nbv) return;  // (uniform for the workgroup, as every exit above)
+  const int bv = idx % nbv, bw = idx / nbv, bu = S - bv - bw;
+  if (bu < 0 || bu >= nbu) return;
+  constexpr int B1 = B + 1;
+  const int NT = (int)blockDim.x;  // 8 lanes x the largest inner plane's points, rounded up to whole waves (B = 8: 384, B = 4: 128)
+  __shared__ int s_ct[B1 * B1 * B1];   // [lw + 1][lv + 1][lu + 1], lu = -1: the upwind neighbour layer (other blocks' points or the grid's rim)
+  __shared__ float s_phi[B * B * B];
+  const int u0 = bu * B, v0 = bv * B, w0 = bw * B;
+  const long long sj = G.ni, sk = (long long)G.ni * G.nj;
+  for (int t = threadIdx.x; t < B1 * B1 * B1; t += NT) {
+    const int lu = t % B1 - 1, lv = (t / B1) % B1 - 1, lw = t / (B1 * B1) - 1;
+    const int u = u0 + lu, v = v0 + lv, w = w0 + lw;  // u = -1: the rim point the first plane reads
+    int c = -1;
+    if (u < nu && v < nv && w < nw) {
+      const int i = di > 0 ? 1 + u : G.ni - 2 - u, j = dj > 0 ? 1 + v : G.nj - 2 - v, k = dk > 0 ? 1 + w : G.nk - 2 - w;
+      const long long q = (long long)k * sk + j * sj + i;
+      c = G.ct[q];
+      if (lu >= 0 && lv >= 0 && lw >= 0) s_phi[(lw * B + lv) * B + lu] = G.phi[q];
+    }
+    s_ct[t] = c;
+  }
+  __syncthreads();
+  // EIGHT LANES PER POINT: lane m < 7 of a point's group evaluates the distance to the closest triangle of upwind neighbour m (the
+  // distances do not depend on phi, the skip rules only on the triangles), then the group's first lane runs the reference's seven strict
+  // comparisons in its order on those values -- the same floats compared in the same order, one triangle evaluation deep instead of seven
+  // (a point's chain of seven evaluations, ~6 us at one wave per SIMD, was most of a hyperplane launch's 12 us)
+  // the points of inner plane s, compact: group g of 8 lanes takes the g-th point of the plane, so a wave whose groups are all past the
+  // plane's count skips the step (a fixed column -> group mapping had every wave run every step: 2-3 x the issue slots, which is what a
+  // batch of grids pays for)
+  constexpr int PMAX = (3 * B * B + 3) / 4 + 1;
+  __shared__ unsigned char s_pts[3 * B - 2][PMAX];
+  __shared__ int s_cnt[3 * B - 2];
+  if (threadIdx.x < 64) {  // the first wave: lane = column (v, w) of the block (B * B <= 64), a ballot per plane
+    const int c = (int)threadIdx.x, cv = c % B, cw = c / B;
+    const bool colin = c < B * B && v0 + cv < nv && w0 + cw < nw;
+    for (int sp = 0; sp < 3 * B - 2; ++sp) {
+      const int lu = sp - cv - cw;
+      const bool in = colin && lu >= 0 && lu < B && u0 + lu < nu;
+      const unsigned long long mk = __ballot(in);
+      if (in) s_pts[sp][__popcll(mk & ((1ull << c) - 1ull))] = (unsigned char)c;
+      if (c == 0) s_cnt[sp] = __popcll(mk);
+    }
+  }
+  __syncthreads();
+  const int grp = (int)threadIdx.x >> 3, m = (int)threadIdx.x & 7;
+  const int gslot = min(grp, PMAX - 1);
+  int cnt = s_cnt[0], colx = s_pts[0][gslot];
+  for (int s = 0; s < 3 * B - 2; ++s) {
+    // the next plane's count and point: requested now, they do not wait for this plane's barrier
+    const int sn = min(s + 1, 3 * B - 3);
+    const int cnt_n = s_cnt[sn], colx_n = s_pts[sn][gslot];
+    const int cnt_c = cnt, colx_c = colx;
+    cnt = cnt_n; colx = colx_n;
+    if ((((int)threadIdx.x >> 6) << 3) >= cnt_c) { __syncthreads(); continue; }  // (uniform for the wave: its first group is past the plane)
+    const bool on = grp < cnt_c;  // (the same for the 8 lanes of a group)
+    const int colq = on ? colx_c : (int)s_pts[s][0];
+    const int lv = colq % B, lw = colq / B, lus = s - lv - lw;
+    const int u = u0 + lus, v = v0 + lv, w = w0 + lw;
+    const int i = di > 0 ? 1 + u : G.ni - 2 - u, j = dj > 0 ? 1 + v : G.nj - 2 - v, k = dk > 0 ? 1 + w : G.nk - 2 - w;
+    const int o = ((lw + 1) * B1 + (lv + 1)) * B1 + (lus + 1);
+    const int ct0 = s_ct[o];
+    // neighbour m: one step back in u, v, u + v, w, u + w, v + w, u + v + w (makelevelset3.cpp:46-58's order = m + 1 in binary)
+    const int mo = (m + 1) & 7;
+    const int noff = (mo & 1) + ((mo >> 1) & 1) * B1 + ((mo >> 2) & 1) * B1 * B1;
+    const int mine = (on && m < 7) ? s_ct[o - noff] : -1;
+    bool skip = mine < 0 || mine == ct0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      const int other = __shfl(mine, r, 8);
+      skip = skip || (r < m && other == mine);
+    }
+    float d = 0.f;
+    if (!skip) {
+      const V3 gx = grid_point(G, i, j, k);
+      const V3 a = G.tv[3 * (long long)mine], b = G.tv[3 * (long long)mine + 1], c = G.tv[3 * (long long)mine + 2];
+      d = point_triangle_distance(gx, a, b, c);
+    }
+    float phi = on ? s_phi[(lw * B + lv) * B + lus] : 0.f;
+    int ct = ct0;
+    bool changed = false;
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+      const float dr = __shfl(d, r, 8);
+      const int tr = __shfl(mine, r, 8);
+      const int sr = __shfl((int)skip, r, 8);
+      if (!sr && dr < phi) { phi = dr; ct = tr; changed = true; }
+    }
+    if (on && m == 0 && changed) {
+      const long long q = (long long)k * sk + j * sj + i;
+      s_phi[(lw * B + lv) * B + lus] = phi;
+      s_ct[o] = ct;
+      G.phi[q] = phi;
+      G.ct[q] = ct;
+    }
+    __syncthreads();
+  }
 }
 
 // (Round 5, second session, measured and not kept: ALL sweeps of a batch in one launch with a barrier per XCD -- the 32 CUs of an XCD share
@@ -313,18 +363,29 @@ extern "C" int pa_sdf_level_set3(pa_ctx* ctx, int ngrids, const pa_sdf_grid* gri
   if (max_tri > 0) {
     static const int dirs[8][3] = {{1, 1, 1}, {-1, -1, -1}, {1, 1, -1}, {-1, -1, 1}, {1, -1, 1}, {-1, 1, -1}, {1, -1, -1}, {-1, 1, 1}};
     int nplanes = 0;
-    long long vw = 0;
+    long long vw_sum = 0;
     for (int g = 0; g < ngrids; ++g) {
       const pa_sdf_grid& S = grids[g];
       if (S.ntri <= 0 || S.n[0] < 2 || S.n[1] < 2 || S.n[2] < 2) continue;  // a grid without triangles stays at its upper bound either way
       nplanes = std::max(nplanes, S.n[0] + S.n[1] + S.n[2] - 5);
-      vw = std::max(vw, (long long)(S.n[1] - 1) * (S.n[2] - 1));
+      vw_sum += (long long)(S.n[1] - 1) * (S.n[2] - 1);
     }
-    const dim3 gs((unsigned)((vw + 255) / 256), (unsigned)ngrids);
+    // blocks of 8^3 points; 4^3 for a call whose hyperplanes are small (one 130^3 grid: 970 inner steps per sweep against 1078, shorter ones)
+    const int blk = vw_sum <= 20000 ? 4 : 8;
+    int mb[3] = {0, 0, 0};
+    for (int g = 0; g < ngrids; ++g) {
+      const pa_sdf_grid& S = grids[g];
+      if (S.ntri <= 0 || S.n[0] < 2 || S.n[1] < 2 || S.n[2] < 2) continue;
+      for (int d = 0; d < 3; ++d) mb[d] = std::max(mb[d], (S.n[d] - 1 + blk - 1) / blk);
+    }
+    const int nbp = mb[0] + mb[1] + mb[2] - 2;
+    const dim3 gb((unsigned)(mb[1] * mb[2]), (unsigned)ngrids);
     for (int pass = 0; pass < 2 && nplanes > 0; ++pass)
       for (int s8 = 0; s8 < 8; ++s8)
-        for (int sp = 0; sp < nplanes; ++sp)
-          hipLaunchKernelGGL(k_sdf_sweep_plane, gs, dim3(256), 0, ctx->stream, dg, dirs[s8][0], dirs[s8][1], dirs[s8][2], sp);
+        for (int sp = 0; sp < nbp; ++sp) {
+          if (blk == 8) hipLaunchKernelGGL(k_sdf_sweep_blocks<8>, gb, dim3(384), 0, ctx->stream, dg, dirs[s8][0], dirs[s8][1], dirs[s8][2], sp);
+          else hipLaunchKernelGGL(k_sdf_sweep_blocks<4>, gb, dim3(128), 0, ctx->stream, dg, dirs[s8][0], dirs[s8][1], dirs[s8][2], sp);
+        }
   }
   PA_HIP(hipGetLastError());
   // the scratch (descriptors) must outlive the kernels; it is only re-used by later calls on this stream

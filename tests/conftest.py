@@ -22,6 +22,10 @@ def oracle():
 @pytest.fixture(scope="session")
 def ctx():
     """HIP context on cuda:0 -- the product path; raises (no CPU fallback) without a GPU."""
+    try:  # torch ships its own HIP runtime: it must be the first one a process loads, or torch later finds "No HIP GPUs" (a test file
+        import torch  # noqa: F401  -- that uses torch after one that only used the library: test_gpu_leaks.py after test_gpu_sdf.py)
+    except ImportError:
+        pass
     from peleanalysis_amd import capi
     c = capi.Context(0)
     yield c

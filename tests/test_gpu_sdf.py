@@ -60,6 +60,17 @@ def test_sdf_fab_sized_grid(ctx, oracle):
     k, j, i = np.meshgrid(np.arange(44), np.arange(44), np.arange(44), indexing="ij")
     r = np.sqrt((-2 * dx + i * dx - 0.47) ** 2 + (-2 * dx + j * dx - 0.52) ** 2 + (-2 * dx + k * dx - 0.5) ** 2)
     assert np.abs(phi - np.abs(r - 0.33)).max() < 1.5 * dx
+    # The same grid 11 times in ONE call next to two grids of other shapes: a call whose hyperplanes hold more than 20000 points takes the
+    # sweeps in blocks of 8^3 points (the calls above: 4^3; pa_sdf.hip k_sdf_sweep_blocks) -- partial blocks on every high side (43 = 5 x 8 + 3),
+    # grids that run out of block planes before the largest one does
+    rng = np.random.default_rng(5)
+    small = dict(tris=t, verts=v, origin=(0.11, -0.05, 0.2), dx=1.0 / 25, n=(19, 27, 10))
+    flat = dict(tris=t, verts=v, origin=(0.0, 0.0, 0.3), dx=1.0 / 30, n=(33, 9, 17))
+    batch = [c] * 6 + [small] + [c] * 5 + [flat]
+    got = capi.sdf_level_set(ctx, [_mesh(b) for b in batch], 1)
+    for b, g in zip(batch, got):
+        w = want if b is c else oracle.sdf_level_set(b["tris"], b["verts"], b["origin"], b["dx"], b["n"], 1)
+        assert np.array_equal(bits(g), bits(w)), b["n"]
 
 
 def test_sdf_signed_fab(ctx):
