@@ -32,11 +32,24 @@ for lv, dl in zip(H.levels, dls):
     works.append(capi.DevMF(ctx, dl, 1, 2))
     outs.append(capi.DevMF(ctx, dl, 8, 0))
 params = capi.curv_params(prog_min=300.0, prog_max=2000.0, fused=True)
-capi.gradcurv_run(ctx, states, 0, bc, params, works, outs, 0)
+if os.environ.get("PA_PROF_MODE", "") == "options":
+    # pa_curvature_run with do_gaussCurv + do_strain + do_velnormal (bench.py's secondary.f1_curvature_options_headline): progress source + 3 velocity
+    # components in, 8 fields out -- `PA_PROF_MODE=options tools/prof.sh kernels <tag>` gives time + HBM traffic of every kernel of that pass
+    st4, out8 = [], []
+    for lv, dl in zip(H.levels, dls):
+        s = MultiFab(lv, 4, 2)
+        s.data[:] = np.resize(300.0 + 1700.0 * rng.random(1 << 22), s.total)
+        st4.append(capi.DevMF.from_host(ctx, dl, s))
+        out8.append(capi.DevMF(ctx, dl, 8, 0))
+    popt = capi.curv_params(prog_min=300.0, prog_max=2000.0, fused=True, vel_comp=1, do_gauss=True, do_strain=True, do_velnormal=True)
+    run = lambda: capi.curvature_run(ctx, st4, 0, bc, popt, out8, 0)
+else:
+    run = lambda: capi.gradcurv_run(ctx, states, 0, bc, params, works, outs, 0)
+run()
 ctx.sync()
 t0 = time.perf_counter()
 for _ in range(steps):
-    capi.gradcurv_run(ctx, states, 0, bc, params, works, outs, 0)
+    run()
 ctx.sync()
 dt = (time.perf_counter() - t0) / steps
 cells = sum(lv.ncells for lv in H.levels)
