@@ -2131,18 +2131,20 @@ __global__ __launch_bounds__(256) void k_gauss_cells(LevBatch<GaussFixLev> Bt) {
     const int dir = D.dir_side >> 1, side = D.dir_side & 1;
     const int e0 = D.hi[0] - D.lo[0] + 1, e1 = D.hi[1] - D.lo[1] + 1, e2 = D.hi[2] - D.lo[2] + 1;
     const int n0 = dir == 0 ? e1 : e0, n1 = dir == 2 ? e1 : e2;
-    const int hw = D.cw >> 1, sh = 31 - __builtin_clz((unsigned)hw);
-    const int u = D.u0 + 2 * ((int)threadIdx.x & (hw - 1)), v = D.v0 + 2 * ((int)threadIdx.x >> sh);
-    for (int dv = 0; dv < 2; ++dv)
-      for (int du = 0; du < 2; ++du) {
-        const int uu = u + du, vv = v + dv;
-        if (uu < 0 || vv < 0 || uu >= n0 || vv >= n1) continue;
-        int i, j, k;
-        if (dir == 0) { i = side ? D.hi[0] : D.lo[0]; j = D.lo[1] + uu; k = D.lo[2] + vv; }
-        else if (dir == 1) { i = D.lo[0] + uu; j = side ? D.hi[1] : D.lo[1]; k = D.lo[2] + vv; }
-        else { i = D.lo[0] + uu; j = D.lo[1] + vv; k = side ? D.hi[2] : D.lo[2]; }
-        gauss_cell(A, D.box, i, j, k);
-      }
+    // the chunk's cw x ch = 1024 cells, a cell per thread and pass with u fastest (consecutive lanes = consecutive cells along the row
+    // for y and z faces; the 2 x 2 blocks of the boundary-condition kernels would read every other cell per pass)
+    const int sh = 31 - __builtin_clz((unsigned)D.cw);
+#pragma unroll 2
+    for (int r = 0; r < 4; ++r) {
+      const int c = (int)threadIdx.x + 256 * r;
+      const int uu = D.u0 + (c & (D.cw - 1)), vv = D.v0 + (c >> sh);
+      if (uu < 0 || vv < 0 || uu >= n0 || vv >= n1) continue;
+      int i, j, k;
+      if (dir == 0) { i = side ? D.hi[0] : D.lo[0]; j = D.lo[1] + uu; k = D.lo[2] + vv; }
+      else if (dir == 1) { i = D.lo[0] + uu; j = side ? D.hi[1] : D.lo[1]; k = D.lo[2] + vv; }
+      else { i = D.lo[0] + uu; j = D.lo[1] + vv; k = side ? D.hi[2] : D.lo[2]; }
+      gauss_cell(A, D.box, i, j, k);
+    }
     return;
   }
   const unsigned q = (w - A.nck) * 256u + threadIdx.x;
