@@ -747,3 +747,24 @@ def test_gaussian_curvature_inside_the_sweep_staggered_boxes(ctx, oracle, per, l
         assert ctx.bc_errors() == 0 and ctx.lib.pa_curvature_last_path(ctx.h) == 2
         for l in range(H.nlev):
             assert_valid_bits_equal(d17[l].download(), oo[l], [(c, c) for c in range(17)], f"threshold={threshold} level {l}")
+
+
+@pytest.mark.parametrize("per,sym", [((1, 1, 1), (0, 0, 0)), ((1, 0, 0), (0, 1, 0)), ((0, 0, 0), (0, 0, 1))])
+def test_gaussian_curvature_inside_the_sweep_single_level(ctx, oracle, per, sym):
+    """GOUT == 2 on ONE level (no finer level: no coarse tile stores G in full, no coarser one: walls and periodic sides only) cut into
+    boxes of different shapes -- all 17 components bit for bit against the oracle, path 2"""
+    from peleanalysis_amd.hierarchy import Hierarchy, Level, field_flame
+    boxes = [[0, 0, 0, 47, 39, 23], [48, 0, 0, 95, 39, 23], [0, 40, 0, 95, 63, 23], [0, 0, 24, 39, 63, 47], [40, 0, 24, 95, 63, 47]]
+    l0 = Level(np.array(boxes, np.int32), (0, 0, 0), (95, 63, 47), per, np.zeros(3), np.ones(3))
+    H = Hierarchy([l0], 2)
+    states = make_states(H, 4, 2, field_flame, seed=3)
+    bc = capi.bc_from_flags(per, sym)
+    opts = dict(do_gauss=True, do_strain=True, strain_tensor=True, do_velnormal=True)
+    oo = [MultiFab(lv, 17, 0) for lv in H.levels]
+    oracle.curvature_pipeline(H.levels, [s.copy() for s in states], 0, bc, oo, 0, MultiFab, threshold=0.03, vel_comp=1, **opts)
+    dls, dst = _dev(ctx, H, states)
+    d17 = [capi.DevMF(ctx, dl, 17, 0) for dl in dls]
+    capi.curvature_run(ctx, dst, 0, bc, capi.curv_params(threshold=0.03, fused=True, vel_comp=1, **opts), d17, 0)
+    ctx.sync()
+    assert ctx.bc_errors() == 0 and ctx.lib.pa_curvature_last_path(ctx.h) == 2
+    assert_valid_bits_equal(d17[0].download(), oo[0], [(c, c) for c in range(17)], "single level")
