@@ -768,3 +768,23 @@ def test_gaussian_curvature_inside_the_sweep_single_level(ctx, oracle, per, sym)
     ctx.sync()
     assert ctx.bc_errors() == 0 and ctx.lib.pa_curvature_last_path(ctx.h) == 2
     assert_valid_bits_equal(d17[0].download(), oo[0], [(c, c) for c in range(17)], "single level")
+
+
+def test_gaussian_curvature_inside_the_sweep_five_levels(ctx, oracle):
+    """five levels of wide boxes: the G-output sweeps go in chunks of four sweep groups per launch, every level but the finest stores G
+    in full in the tiles under the next level's coarse patches -- path 2, bit for bit against the oracle"""
+    from peleanalysis_amd.hierarchy import nested_hierarchy, field_flame
+    H = nested_hierarchy(48, 5, 48, is_per=(0, 1, 0))
+    assert H.nlev == 5
+    states = make_states(H, 4, 2, field_flame, seed=77)
+    bc = capi.bc_from_flags((0, 1, 0), (1, 0, 0))
+    opts = dict(do_gauss=True, do_strain=True, do_velnormal=True)
+    oo = [MultiFab(lv, 17, 0) for lv in H.levels]
+    oracle.curvature_pipeline(H.levels, [s.copy() for s in states], 0, bc, oo, 0, MultiFab, threshold=None, vel_comp=1, **opts)
+    dls, dst = _dev(ctx, H, states)
+    d17 = [capi.DevMF(ctx, dl, 17, 0) for dl in dls]
+    capi.curvature_run(ctx, dst, 0, bc, capi.curv_params(threshold=None, fused=True, vel_comp=1, **opts), d17, 0)
+    ctx.sync()
+    assert ctx.bc_errors() == 0 and ctx.lib.pa_curvature_last_path(ctx.h) == 2
+    for l in range(H.nlev):
+        assert_valid_bits_equal(d17[l].download(), oo[l], [(c, c) for c in range(8)], f"level {l}")
