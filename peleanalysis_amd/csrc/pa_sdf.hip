@@ -167,9 +167,16 @@ __global__ __launch_bounds__(256) void k_sdf_gather_tv(const SdfGrid* grids) {
 // triangles one after the other -- 16 x (ni + nj + nk - 5) = 6160 launches of 12 us for a 130^3 grid, of which ~6 us were that chain of
 // seven dependent evaluations at one wave per SIMD and ~5 the launch-to-launch gap (72.5-76 ms; 7.9 ms per grid in a batch of 16).
 // Now 16 x (nbu + nbv + nbw - 2) launches, an inner step = LDS round + ONE global latency + ONE evaluation (eight lanes per point,
-// below): 34-39 ms per grid, 7.5 per grid in a batch of 16 (profiles/r06_sdf_blocks.txt).
+// below): 34-39 ms per grid, 7.5 per grid in a batch of 16; with consecutive sweeps overlapping 28.7 / 7.2 (profiles/r06_sdf_blocks.txt).
+// CONSECUTIVE SWEEPS OVERLAP: sweep m + 1 may take a block while sweep m is still under way elsewhere, as long as every point it reads or
+// writes (itself and its neighbours: one cell in every direction) has been left behind by sweep m.  In launches: block plane S of sweep
+// m + 1 goes with plane S + D of sweep m, D = sum over the axes on which the two directions differ of (blocks along that axis - 1), + 4
+// (pa_sdf_level_set3 has the derivation) -- a whole sweep when all three axes flip, a third of one when one does.  A launch then carries
+// up to three sweeps (blockIdx.z), each on its own block plane.
+struct SdfSweeps { int n; int dir[3][3]; int S[3]; };
 template <int B>
-__global__ __launch_bounds__(B == 8 ? 384 : 128) void k_sdf_sweep_blocks(const SdfGrid* grids, int di, int dj, int dk, int S) {
+__global__ __launch_bounds__(B == 8 ? 384 : 128) void k_sdf_sweep_blocks(const SdfGrid* grids, SdfSweeps P) {
+  const int di = P.dir[blockIdx.z][0], dj = P.dir[blockIdx.z][1], dk = P.dir[blockIdx.z][2], S = P.S[blockIdx.z];
   const SdfGrid G = grids[blockIdx.y];
   if (G.ntri <= 0) return;
   const int nu = G.ni - 1, nv = G.nj - 1, nw = G.nk - 1;
@@ -379,13 +386,37 @@ extern "C" int pa_sdf_level_set3(pa_ctx* ctx, int ngrids, const pa_sdf_grid* gri
       for (int d = 0; d < 3; ++d) mb[d] = std::max(mb[d], (S.n[d] - 1 + blk - 1) / blk);
     }
     const int nbp = mb[0] + mb[1] + mb[2] - 2;
-    const dim3 gb((unsigned)(mb[1] * mb[2]), (unsigned)ngrids);
-    for (int pass = 0; pass < 2 && nplanes > 0; ++pass)
-      for (int s8 = 0; s8 < 8; ++s8)
-        for (int sp = 0; sp < nbp; ++sp) {
-          if (blk == 8) hipLaunchKernelGGL(k_sdf_sweep_blocks<8>, gb, dim3(384), 0, ctx->stream, dg, dirs[s8][0], dirs[s8][1], dirs[s8][2], sp);
-          else hipLaunchKernelGGL(k_sdf_sweep_blocks<4>, gb, dim3(128), 0, ctx->stream, dg, dirs[s8][0], dirs[s8][1], dirs[s8][2], sp);
+    // Start of sweep m + 1 relative to sweep m, in block planes.  A point p of sweep m + 1 (block plane sum_a floor(u'_a / B), u' its
+    // coordinates in that sweep) conflicts with sweep m only at points q within one cell of p, which sweep m takes on a block plane
+    // <= sum_a floor(u_a(p) / B) + 3; on an axis both sweeps walk the same way u = u', on a flipped one u = nu - 2 - u', so the
+    // difference of the two plane indices is at most sum over flipped axes of (blocks - 1): with D = that + 4 every such q is behind
+    // sweep m when p is taken (strictly earlier launch).  Sweeps further apart are covered by the sums of their neighbours' offsets.
+    int T[16];
+    T[0] = 0;
+    for (int m = 0; m + 1 < 16 && nplanes > 0; ++m) {
+      int d = 4;
+      for (int a = 0; a < 3; ++a)
+        if (dirs[m % 8][a] != dirs[(m + 1) % 8][a]) d += std::max(mb[a] - 1, 0);
+      T[m + 1] = T[m] + std::min(nbp, d);
+    }
+    for (int m = 2; m + 1 < 16 && nplanes > 0; ++m)  // a launch carries three sweeps at most (the reference's order of directions never
+      if (T[m + 1] - T[m - 2] < nbp) {                // has more than two under way: every other transition flips all three axes)
+        for (int q = 0; q + 1 < 16; ++q) T[q + 1] = T[q] + nbp;
+        break;
+      }
+    for (int tau = 0; nplanes > 0 && nbp > 0 && tau < T[15] + nbp; ++tau) {
+      SdfSweeps P;
+      P.n = 0;
+      for (int m = 0; m < 16 && P.n < 3; ++m)
+        if (tau >= T[m] && tau - T[m] < nbp) {
+          for (int a = 0; a < 3; ++a) P.dir[P.n][a] = dirs[m % 8][a];
+          P.S[P.n++] = tau - T[m];
         }
+      if (!P.n) continue;
+      const dim3 gb((unsigned)(mb[1] * mb[2]), (unsigned)ngrids, (unsigned)P.n);
+      if (blk == 8) hipLaunchKernelGGL(k_sdf_sweep_blocks<8>, gb, dim3(384), 0, ctx->stream, dg, P);
+      else hipLaunchKernelGGL(k_sdf_sweep_blocks<4>, gb, dim3(128), 0, ctx->stream, dg, P);
+    }
   }
   PA_HIP(hipGetLastError());
   // the scratch (descriptors) must outlive the kernels; it is only re-used by later calls on this stream

@@ -102,3 +102,24 @@ def test_sdf_rejects_bad_triangle_indices(ctx):
     tris = np.array([[0, 1, 2], [0, 1, 7]], dtype=np.uint32)
     with pytest.raises(capi.PaError, match="out of range"):
         capi.sdf_level_set(ctx, [(tris, verts, (0.0, 0.0, 0.0), 0.1, (5, 5, 5))], 1)
+
+
+def test_sdf_overlapping_sweeps_on_uneven_grids(ctx, oracle):
+    """Consecutive sweeps overlap (pa_sdf.hip: block plane S of sweep m + 1 runs with plane S + D of sweep m): grids whose block counts
+    differ per axis (long in one direction, one block thin in another, partial last blocks), alone (blocks of 4^3) and in one call of 14
+    (blocks of 8^3), three times each -- an ordering mistake would show as a run-to-run difference or against the sequential oracle"""
+    from sdf_cases import _mc_mesh
+    sph = lambda X, Y, Z: np.sqrt((X - 0.45) ** 2 + (Y - 0.55) ** 2 + (Z - 0.5) ** 2)
+    t, v = _mc_mesh(oracle, 24, sph, 0.3)
+    rng = np.random.default_rng(23)
+    shapes = [(67, 45, 93), (130, 7, 21), (5, 88, 34), (33, 33, 2), (41, 3, 3), (9, 9, 120)]
+    cs = [dict(tris=t, verts=v, origin=tuple(rng.random(3) * 0.2 - 0.1), dx=float(1.1 / max(n)), n=n) for n in shapes]
+    want = [oracle.sdf_level_set(c["tris"], c["verts"], c["origin"], c["dx"], c["n"], 1) for c in cs]
+    for rep in range(3):
+        for c, w in zip(cs, want):
+            phi = capi.sdf_level_set(ctx, [_mesh(c)], 1)[0]
+            assert np.array_equal(bits(phi), bits(w)), (rep, c["n"])
+        batch = cs + cs + cs[:2]
+        got = capi.sdf_level_set(ctx, [_mesh(c) for c in batch], 1)
+        for c, g in zip(batch, got):
+            assert np.array_equal(bits(g), bits(want[shapes.index(c["n"])])), (rep, "batch", c["n"])
